@@ -1,0 +1,158 @@
+/*
+ * rgbdfe.h -- C ABI of the MI355X-native RGB-D SLAM visual front end.
+ *
+ * This is the drop-in boundary behind rgbdslam_v2's Node / GraphManager seam
+ * (the reference has no FFI of its own; the seams are the C++ signatures cited
+ * on each entry point, paths relative to the rgbdslam_v2 tree).  Plain pointers
+ * and sizes only; no exceptions cross this boundary; every function returns an
+ * rgbdfe_status (0 = ok, <0 = error) unless noted.  INTEGRATION.md shows the
+ * reference-side binding.
+ *
+ * Threading: a context owns one HIP stream and is internally locked; calls on
+ * one context serialise (this replaces QtConcurrent::blockingMapped's barrier,
+ * graph_manager.cpp:548, one call = one batch of pairs).
+ */
+#ifndef RGBDFE_H
+#define RGBDFE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBDFE_MAX_MATCHES 320   /* capacity for max_matches (reference default 300) */
+#define RGBDFE_MASK_WORDS 5      /* RGBDFE_MAX_MATCHES / 64 */
+#define RGBDFE_MAX_KEYPOINTS 65535
+
+typedef enum {
+  RGBDFE_OK = 0,
+  RGBDFE_ERR_INVALID_ARG = -1,
+  RGBDFE_ERR_NO_DEVICE = -2,    /* no HIP device / kernels cannot run: never falls back to CPU */
+  RGBDFE_ERR_HIP = -3,
+  RGBDFE_ERR_UNKNOWN_NODE = -4,
+  RGBDFE_ERR_CAPACITY = -5,
+  RGBDFE_ERR_OUT_OF_MEMORY = -6
+} rgbdfe_status;
+
+/* Snapshot of the ParameterServer values the pair path reads at call time
+ * (parameter_server.cpp:85,86,100,101,46 ). */
+typedef struct {
+  int32_t  max_matches;           /* "max_matches"           default 300 (<= RGBDFE_MAX_MATCHES) */
+  int32_t  min_matches;           /* "min_matches"           default 20  */
+  int32_t  ransac_iterations;     /* "ransac_iterations"     default 200 */
+  float    max_dist_for_inliers;  /* "max_dist_for_inliers"  default 3.0 */
+  double   depth_cov;             /* value depth_covariance() froze at its first call
+                                     (misc2.h:30-35): (sigma_depth * z0^2)^2, default z0 = 1 m -> 1e-4 */
+  uint32_t seed;                  /* replaces srand(clock()) (node.cpp:1102) */
+  uint32_t reserved;
+} rgbdfe_params;
+
+typedef struct {
+  int32_t device_id;              /* HIP device ordinal */
+  int32_t max_nodes;              /* resident node slots (each max_keypoints rows) */
+  int32_t max_keypoints;          /* rows per node slot, <= RGBDFE_MAX_KEYPOINTS */
+  int32_t max_pairs_per_batch;    /* pairs per kernel batch (results/keys staging) */
+  rgbdfe_params params;
+} rgbdfe_config;
+
+/* Per-pair result: the MatchingResult POD (matching_result.h:24-46, edge.h:24-32).
+ * This exact layout is what lives in HBM, what is all-gathered between ranks
+ * and what rgbdfe_match_* copies to the host. */
+typedef struct {
+  int32_t  id1, id2;              /* edge.id1 = older node, edge.id2 = newer node; -1,-1 = no edge
+                                     (node.cpp:1337-1338, 1419-1422) */
+  int32_t  n_all;                 /* |all_matches| after keepStrongestMatches (node.cpp:674) */
+  int32_t  n_inl;                 /* |inlier_matches| */
+  float    rmse;                  /* MatchingResult::rmse */
+  float    trafo[16];             /* ransac_trafo == final_trafo, Eigen::Matrix4f column-major,
+                                     maps the newer node's frame into the older node's frame */
+  uint32_t pad0;
+  double   info_scale;            /* edge.informationMatrix = I6 * info_scale (node.cpp:1335) */
+  int32_t  valid_iterations;      /* diagnostics (node.cpp:1216) */
+  int32_t  real_iterations;
+  uint16_t all_q[RGBDFE_MAX_MATCHES];  /* DMatch.queryIdx, sorted by (hd, queryIdx) */
+  uint16_t all_t[RGBDFE_MAX_MATCHES];  /* DMatch.trainIdx */
+  uint8_t  all_hd[RGBDFE_MAX_MATCHES]; /* Hamming distance; DMatch.distance = hd/256.0f */
+  uint64_t inlier_mask[RGBDFE_MASK_WORDS]; /* bit m set <=> all_*[m] is in inlier_matches */
+} rgbdfe_match_result;
+
+typedef struct rgbdfe_ctx rgbdfe_ctx;
+
+/* ---- lifetime ---------------------------------------------------------- */
+void rgbdfe_default_config(rgbdfe_config* cfg);
+int  rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out);
+void rgbdfe_destroy(rgbdfe_ctx* ctx);
+int  rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p);
+const char* rgbdfe_status_string(int status);
+const char* rgbdfe_last_error(rgbdfe_ctx* ctx);
+
+/* ---- node residency (replaces Node::feature_descriptors_ / feature_locations_3d_,
+ *      node.h:167-178; lifetime follows GraphManager::addNode / clearFeatureInformation,
+ *      graph_manager.h:156-161, node.cpp:1431-1443) ---------------------------- */
+/* desc: n x 32 bytes, row-major, continuous (cv::Mat CV_8U, node.cpp:567-568);
+ * xyz1: n x 4 float, (x,y,z,1) as Node::projectTo3D writes them (node.cpp:955). */
+int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc,
+                       const float* xyz1, int32_t n);
+/* same, sources already in device memory (device-to-device copy on `stream`, a hipStream_t) */
+int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_desc,
+                              const void* d_xyz1, int32_t n, void* stream);
+int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id);
+int rgbdfe_node_count(rgbdfe_ctx* ctx, int32_t node_id); /* rows of a resident node or <0 */
+
+/* ---- the pair op -------------------------------------------------------- */
+/* Batched Node::matchNodePair (node.h:85, node.cpp:1305-1429): for one new node and
+ * n candidates.  1:1 replacement of
+ *   QtConcurrent::blockingMapped(nodes_to_comp, bind(&Node::matchNodePair,new_node,_1))
+ * (graph_manager.cpp:548): synchronous, out[i] belongs to candidate_ids[i]. */
+int rgbdfe_match_node_pairs(rgbdfe_ctx* ctx, int32_t new_node_id, const int32_t* candidate_ids,
+                            int32_t n_pairs, rgbdfe_match_result* out);
+/* general pair list (query = newer node, train = older node) */
+int rgbdfe_match_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                           int32_t n_pairs, rgbdfe_match_result* out);
+/* asynchronous, results stay in device memory (d_out: n_pairs rgbdfe_match_result in HBM);
+ * enqueued on `stream` (hipStream_t; NULL = the context's stream).  n_pairs must be
+ * <= max_pairs_per_batch. */
+int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids,
+                                  const int32_t* train_ids, int32_t n_pairs, void* d_out,
+                                  void* stream);
+int rgbdfe_synchronize(rgbdfe_ctx* ctx);
+
+/* ---- pieces of the pair op, exposed for A/B and parity ------------------- */
+/* Batched bruteForceSearchORB (features.h:14, features.cpp:168-182) of every row of
+ * query node against train node: out_hd[i] in [0,257], out_idx[i] (or -1), including
+ * the reference's "last train row is never searched" behaviour. */
+int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
+                            int32_t* out_hd, int32_t* out_idx);
+/* Drop-in twin of bruteForceSearchORB for host buffers (uploads, runs the kernel,
+ * downloads; for A/B only -- the batched entry points are the product path). */
+int rgbdfe_hamming_nn_host(rgbdfe_ctx* ctx, const uint8_t* qdesc, int32_t nq,
+                           const uint8_t* tdesc, int32_t nt, int32_t* out_hd, int32_t* out_idx);
+
+/* ---- per-frame depth filter + back-projection (removeDepthless node.cpp:67-97,
+ *      projectTo3D node.cpp:900-965, backProject misc2.h:49-65) ---------------- */
+/* kp_xy: n_kp x 2 float (KeyPoint.pt), depth: rows x cols float32 metres (NaN = invalid),
+ * host buffers.  Writes kept_idx (indices into kp_xy, ascending) and xyz1 (n x 4) for the
+ * first max_keypoints survivors; *n_out = survivors. */
+int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* depth,
+                         int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                         double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
+                         float* xyz1, int32_t* n_out);
+
+/* ---- measurement --------------------------------------------------------- */
+/* When enabled, every launch of the dominant kernels is bracketed by HIP events on the
+ * stream it runs on; totals are read back with rgbdfe_get_kernel_time. */
+enum { RGBDFE_KERNEL_HAMMING = 0, RGBDFE_KERNEL_RANSAC = 1, RGBDFE_KERNEL_COUNT = 2 };
+int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable);
+int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t* launches,
+                           int64_t* pairs);
+int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx);
+
+/* ABI self-description (lets bindings verify struct layout) */
+int rgbdfe_sizeof_match_result(void);
+int rgbdfe_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBDFE_H */

@@ -1,0 +1,259 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) and of the executable
+reference pin (oracle/_ref/libref_bforb.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under rgbdslam_v2_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORC_MAX_MATCHES = 320
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("max_matches", C.c_int32),
+        ("min_matches", C.c_int32),
+        ("ransac_iterations", C.c_int32),
+        ("max_dist_for_inliers", C.c_float),
+        ("depth_cov", C.c_double),
+        ("seed", C.c_uint32),
+    ]
+
+
+class OrcResult(C.Structure):
+    _fields_ = [
+        ("id1", C.c_int32),
+        ("id2", C.c_int32),
+        ("n_all", C.c_int32),
+        ("n_inl", C.c_int32),
+        ("rmse", C.c_float),
+        ("T", C.c_float * 16),
+        ("info_scale", C.c_double),
+        ("valid_iterations", C.c_int32),
+        ("real_iterations", C.c_int32),
+        ("all_q", C.c_int32 * ORC_MAX_MATCHES),
+        ("all_t", C.c_int32 * ORC_MAX_MATCHES),
+        ("all_hd", C.c_int32 * ORC_MAX_MATCHES),
+        ("inl_idx", C.c_int32 * ORC_MAX_MATCHES),
+    ]
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "rgbd_oracle.c")
+    hdr = os.path.join(_HERE, "rgbd_oracle.h")
+    stale = (not os.path.exists(so)) or any(
+        os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(_HERE, "_ref", "libref_bforb.so")) or force:
+        subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        vp = C.c_void_p
+        L.orc_hamming_nn.restype = C.c_int
+        L.orc_hamming_nn.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_int)]
+        L.orc_hamming_nn_batch.restype = None
+        L.orc_hamming_nn_batch.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp]
+        L.orc_feature_matching_orb.restype = C.c_int
+        L.orc_feature_matching_orb.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_int, vp, vp, vp]
+        L.orc_rand31.restype = C.c_uint32
+        L.orc_rand31.argtypes = [C.c_uint32] * 4
+        L.orc_pair_uid.restype = C.c_uint32
+        L.orc_pair_uid.argtypes = [C.c_int32, C.c_int32]
+        L.orc_sample4.restype = C.c_int
+        L.orc_sample4.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.orc_fit_transform.restype = None
+        L.orc_fit_transform.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+        L.orc_svd3.restype = None
+        L.orc_svd3.argtypes = [vp, vp, vp, vp]
+        L.orc_error_function2.restype = C.c_double
+        L.orc_error_function2.argtypes = [vp, vp, vp, C.c_double]
+        L.orc_raster_cov.restype = None
+        L.orc_raster_cov.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_compute_inliers_and_error.restype = C.c_int
+        L.orc_compute_inliers_and_error.argtypes = [vp, vp, vp, vp, C.c_int, vp, C.c_double,
+                                                    C.c_double, vp, C.POINTER(C.c_double)]
+        L.orc_ransac.restype = C.c_int
+        L.orc_ransac.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(OrcParams), C.c_uint32, vp,
+                                 C.POINTER(C.c_float), vp, C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_match_node_pair.restype = None
+        L.orc_match_node_pair.argtypes = [vp, vp, C.c_uint32, C.c_int32, vp, vp, C.c_uint32,
+                                          C.c_int32, C.POINTER(OrcParams), C.POINTER(OrcResult)]
+        L.orc_match_pairs_mt.restype = None
+        L.orc_match_pairs_mt.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(OrcParams),
+                                         vp, C.c_int]
+        L.orc_project_to_3d.restype = C.c_int
+        L.orc_project_to_3d.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_double, C.c_double, C.c_double, C.c_int, vp, vp]
+        L.orc_num_cores.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The reference's own bruteForceSearchORB, compiled from /root/reference (or None)."""
+    global _ref
+    if _ref is None:
+        p = os.path.join(_HERE, "_ref", "libref_bforb.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_bruteForceSearchORB.restype = C.c_int
+        R.ref_bruteForceSearchORB.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
+        _ref = R
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = OrcParams(max_matches=300, min_matches=20, ransac_iterations=200,
+                  max_dist_for_inliers=3.0, depth_cov=1e-4, seed=20260923)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def hamming_nn_batch(qdesc, tdesc):
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    nq, nt = qdesc.shape[0], tdesc.shape[0]
+    hd = np.empty(nq, np.int32)
+    idx = np.empty(nq, np.int32)
+    lib().orc_hamming_nn_batch(_p(qdesc), nq, _p(tdesc), nt, _p(hd), _p(idx))
+    return hd, idx
+
+
+def ref_hamming_nn(q_row, tdesc):
+    """One query through the reference's own compiled function."""
+    R = ref_lib()
+    q = np.ascontiguousarray(q_row, dtype=np.uint8)
+    t = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    idx = C.c_int(-2)
+    d = R.ref_bruteForceSearchORB(_p(q), _p(t), t.shape[0], C.byref(idx))
+    return d, idx.value
+
+
+def feature_matching_orb(qdesc, tdesc, max_matches=300):
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    cap = max(max_matches, 1)
+    mq = np.empty(cap, np.int32)
+    mt = np.empty(cap, np.int32)
+    mhd = np.empty(cap, np.int32)
+    n = lib().orc_feature_matching_orb(_p(qdesc), qdesc.shape[0], _p(tdesc), tdesc.shape[0],
+                                       max_matches, _p(mq), _p(mt), _p(mhd))
+    return mq[:n].copy(), mt[:n].copy(), mhd[:n].copy()
+
+
+def svd3(Cm):
+    Cm = np.ascontiguousarray(Cm, dtype=np.float32)
+    U = np.empty((3, 3), np.float32)
+    S = np.empty(3, np.float32)
+    V = np.empty((3, 3), np.float32)
+    lib().orc_svd3(_p(Cm), _p(U), _p(S), _p(V))
+    return U, S, V
+
+
+def fit_transform(qxyz1, txyz1, mq, mt, sel):
+    qxyz1 = np.ascontiguousarray(qxyz1, np.float32)
+    txyz1 = np.ascontiguousarray(txyz1, np.float32)
+    mq = np.ascontiguousarray(mq, np.int32)
+    mt = np.ascontiguousarray(mt, np.int32)
+    sel = np.ascontiguousarray(sel, np.int32)
+    T = np.empty(16, np.float32)
+    lib().orc_fit_transform(_p(qxyz1), _p(txyz1), _p(mq), _p(mt), _p(sel), len(sel), _p(T))
+    return T.reshape(4, 4).T.copy()  # column-major -> numpy [row, col]
+
+
+def error_function2(x1, x2, T, depth_cov):
+    x1 = np.ascontiguousarray(x1, np.float32)
+    x2 = np.ascontiguousarray(x2, np.float32)
+    Tc = np.ascontiguousarray(np.asarray(T, np.float64).T)  # to column-major
+    return lib().orc_error_function2(_p(x1), _p(x2), _p(Tc), float(depth_cov))
+
+
+def raster_cov():
+    a, b = C.c_double(), C.c_double()
+    lib().orc_raster_cov(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def match_node_pair(qdesc, qxyz1, qid, tdesc, txyz1, tid, params=None):
+    params = params or default_params()
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, np.uint8)
+    qxyz1 = np.ascontiguousarray(qxyz1, np.float32)
+    txyz1 = np.ascontiguousarray(txyz1, np.float32)
+    out = OrcResult()
+    lib().orc_match_node_pair(_p(qdesc), _p(qxyz1), qdesc.shape[0], qid, _p(tdesc), _p(txyz1),
+                              tdesc.shape[0], tid, C.byref(params), C.byref(out))
+    return result_to_dict(out)
+
+
+def result_to_dict(r):
+    n_all, n_inl = r.n_all, r.n_inl
+    return dict(
+        id1=r.id1, id2=r.id2, n_all=n_all, n_inl=n_inl, rmse=np.float32(r.rmse),
+        T=np.array(r.T, np.float32).reshape(4, 4).T.copy(),
+        info_scale=r.info_scale, valid_iterations=r.valid_iterations,
+        real_iterations=r.real_iterations,
+        all_q=np.array(r.all_q[:n_all], np.int32), all_t=np.array(r.all_t[:n_all], np.int32),
+        all_hd=np.array(r.all_hd[:n_all], np.int32),
+        inl_idx=np.array(r.inl_idx[:n_inl], np.int32))
+
+
+def match_pairs_mt(descs, xyzs, node_ids, pair_q, pair_t, params=None, n_threads=0):
+    """Pair-parallel oracle run (the CPU baseline).  descs/xyzs: lists of per-node arrays;
+    pair_q/pair_t index into those lists."""
+    params = params or default_params()
+    n_nodes = len(descs)
+    descs = [np.ascontiguousarray(d, np.uint8) for d in descs]
+    xyzs = [np.ascontiguousarray(x, np.float32) for x in xyzs]
+    dptr = (C.c_void_p * n_nodes)(*[d.ctypes.data for d in descs])
+    xptr = (C.c_void_p * n_nodes)(*[x.ctypes.data for x in xyzs])
+    counts = np.array([d.shape[0] for d in descs], np.uint32)
+    ids = np.ascontiguousarray(node_ids, np.int32)
+    pq = np.ascontiguousarray(pair_q, np.int32)
+    pt = np.ascontiguousarray(pair_t, np.int32)
+    out = (OrcResult * len(pq))()
+    lib().orc_match_pairs_mt(dptr, xptr, _p(counts), _p(ids), _p(pq), _p(pt), len(pq),
+                             C.byref(params), out, n_threads)
+    return out
+
+
+def project_to_3d(kp_xy, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000):
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    n = kp_xy.shape[0]
+    kept = np.empty(max(n, 1), np.int32)
+    xyz1 = np.empty((max(n, 1), 4), np.float32)
+    k = lib().orc_project_to_3d(_p(kp_xy), n, _p(depth), depth.shape[0], depth.shape[1],
+                                fx, fy, cx, cy, depth_scaling, max_keypoints, _p(kept), _p(xyz1))
+    return kept[:k].copy(), xyz1[:k].copy()
+
+
+def num_cores():
+    return lib().orc_num_cores()

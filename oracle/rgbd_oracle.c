@@ -1,0 +1,644 @@
+/*
+ * oracle/rgbd_oracle.c -- TEST INFRASTRUCTURE ONLY (see rgbd_oracle.h).
+ *
+ * Plain-C restatement of the reference's pair path.  Every function cites the
+ * reference file:line (relative to the rgbdslam_v2 tree) it follows.  Build with
+ * -ffp-contract=off and without -ffast-math: the float/double operation ORDER
+ * written here is the specification the HIP kernels reproduce bit-for-bit.
+ *
+ * Deliberate, documented deviations from the reference (all "define away a race
+ * or UB"):
+ *   D1  rand()/srand(clock()) is replaced by a counter-based generator
+ *       orc_rand31(seed, pair_uid, iteration, k)              (node.cpp:1033-1034,1102)
+ *   D2  the distance jitter rand()/(1000*RAND_MAX) is dropped; ties in hd are
+ *       broken by queryIdx (stable)                            (node.cpp:573, 520-531, 1127)
+ *   D3  depth_covariance()'s function-local static is an explicit parameter
+ *       depth_cov                                              (misc2.h:30-35)
+ *   D4  size==0 in bruteForceSearchORB (unsigned wrap -> OOB walk) returns (257,-1)
+ *                                                              (features.cpp:174)
+ *   D5  a non-positive LLT pivot yields DBL_MAX (Eigen would continue with a
+ *       partially factored matrix)                             (misc.cpp:763)
+ */
+#include "rgbd_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* A.1 Hamming nearest neighbour -- src/features.cpp:163-182                   */
+/* ------------------------------------------------------------------------- */
+static inline int orc_hd256(const uint64_t* a, const uint64_t* b) {
+  /* features.cpp:163-166: four 64-bit xor+popcount, little-endian words of the 32 bytes */
+  return (__builtin_popcountll(a[0] ^ b[0]) + __builtin_popcountll(a[1] ^ b[1])) +
+         (__builtin_popcountll(a[2] ^ b[2]) + __builtin_popcountll(a[3] ^ b[3]));
+}
+
+int orc_hamming_nn(const uint64_t* v, const uint64_t* search_array, uint32_t size,
+                   int* result_index) {
+  int best = 1 + 256; /* features.cpp:173 */
+  *result_index = -1; /* features.cpp:172 */
+  if (size == 0) return best; /* D4 */
+  /* features.cpp:174: `i < size-1` -- the LAST train row is never visited */
+  for (uint32_t i = 0; i + 1 < size; ++i, search_array += 4) {
+    int d = orc_hd256(v, search_array);
+    if (d < best) { /* strict: first minimum wins, features.cpp:176 */
+      best = d;
+      *result_index = (int)i;
+    }
+  }
+  return best;
+}
+
+void orc_hamming_nn_batch(const uint8_t* qdesc, uint32_t nq, const uint8_t* tdesc,
+                          uint32_t nt, int32_t* out_hd, int32_t* out_idx) {
+  /* node.cpp:567-571: descriptors are reinterpreted as uint64_t rows of 4 words */
+  for (uint32_t i = 0; i < nq; ++i) {
+    uint64_t q[4];
+    memcpy(q, qdesc + 32u * i, 32);
+    int idx;
+    /* train rows are 32-byte aligned copies to keep the cast legal */
+    int best = 257;
+    idx = -1;
+    if (nt > 0) {
+      for (uint32_t t = 0; t + 1 < nt; ++t) {
+        uint64_t r[4];
+        memcpy(r, tdesc + 32u * t, 32);
+        int d = orc_hd256(q, r);
+        if (d < best) { best = d; idx = (int)t; }
+      }
+    }
+    out_hd[i] = best;
+    out_idx[i] = idx;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A.2 featureMatching, ORB branch -- src/node.cpp:561-576, 520-531, 674       */
+/* ------------------------------------------------------------------------- */
+int orc_feature_matching_orb(const uint8_t* qdesc, uint32_t nq, const uint8_t* tdesc,
+                             uint32_t nt, int max_matches,
+                             int32_t* mq, int32_t* mt, int32_t* mhd) {
+  int32_t* hd = (int32_t*)malloc(sizeof(int32_t) * (nq ? nq : 1));
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (nq ? nq : 1));
+  orc_hamming_nn_batch(qdesc, nq, tdesc, nt, hd, idx);
+  /* node.cpp:572: `if(hd >= 128) continue;` then keepStrongestMatches(max_matches)
+   * (node.cpp:674) and the later std::sort by distance (node.cpp:1127).  With D2 the
+   * order is (hd, queryIdx): a stable counting sort over hd in query order. */
+  int n = 0;
+  for (int h = 0; h < 128 && n < max_matches; ++h)
+    for (uint32_t i = 0; i < nq && n < max_matches; ++i)
+      if (hd[i] == h) {
+        mq[n] = (int32_t)i;
+        mt[n] = idx[i];
+        mhd[n] = h;
+        ++n;
+      }
+  free(hd);
+  free(idx);
+  return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* D1: counter-based replacement for rand() -- node.cpp:1033-1034               */
+/* ------------------------------------------------------------------------- */
+static inline uint32_t orc_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+uint32_t orc_rand31(uint32_t seed, uint32_t uid, uint32_t iter, uint32_t k) {
+  uint32_t h = orc_mix32(seed ^ 0x9E3779B9u);
+  h = orc_mix32(h + uid * 0x85EBCA6Bu);
+  h = orc_mix32(h ^ (iter * 0xC2B2AE35u + 0x165667B1u));
+  h = orc_mix32(h + k * 0x27D4EB2Fu);
+  return h >> 1; /* rand() range [0, RAND_MAX = 2^31-1] */
+}
+
+uint32_t orc_pair_uid(int32_t query_id, int32_t train_id) {
+  return orc_mix32((uint32_t)query_id * 0x9E3779B1u ^ ((uint32_t)train_id + 0x7F4A7C15u));
+}
+
+/* sample_matches_prefer_by_distance -- node.cpp:1024-1047.  Returns #ids (ascending). */
+int orc_sample4(uint32_t seed, uint32_t uid, uint32_t iter, uint32_t n, uint32_t ids[4]) {
+  int cnt = 0;
+  int safety_net = 0;
+  uint32_t k = 0;
+  while (cnt < 4 && n >= 4) { /* node.cpp:1031 */
+    uint32_t id1 = orc_rand31(seed, uid, iter, k) % n; /* :1033 */
+    uint32_t id2 = orc_rand31(seed, uid, iter, k + 1) % n; /* :1034 */
+    k += 2;
+    if (id1 > id2) id1 = id2; /* :1035 */
+    /* std::set insert: keep ascending, ignore duplicates (:1036) */
+    int pos = 0, dup = 0;
+    while (pos < cnt && ids[pos] < id1) ++pos;
+    if (pos < cnt && ids[pos] == id1) dup = 1;
+    if (!dup) {
+      for (int j = cnt; j > pos; --j) ids[j] = ids[j - 1];
+      ids[pos] = id1;
+      ++cnt;
+    }
+    if (++safety_net > 10000) break; /* :1037 */
+  }
+  return cnt;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 3x3 float SVD (two-sided Jacobi, Eigen::JacobiSVD<Matrix3f> as published)   */
+/* Matrices are ROW-major here: A[i*3+j].                                      */
+/* ------------------------------------------------------------------------- */
+void orc_svd3(const float C[9], float U[9], float S[3], float V[9]) {
+  float W[9];
+  float scale = 0.0f;
+  for (int i = 0; i < 9; ++i) {
+    float a = fabsf(C[i]);
+    if (a > scale) scale = a;
+  }
+  if (scale == 0.0f) scale = 1.0f;
+  for (int i = 0; i < 9; ++i) W[i] = C[i] / scale;
+  for (int i = 0; i < 9; ++i) U[i] = V[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+
+  const float precision = 2.0f * FLT_EPSILON;
+  const float consider_as_zero = FLT_MIN;
+  float max_diag = fabsf(W[0]);
+  if (fabsf(W[4]) > max_diag) max_diag = fabsf(W[4]);
+  if (fabsf(W[8]) > max_diag) max_diag = fabsf(W[8]);
+
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    int finished = 1;
+    for (int p = 1; p < 3; ++p) {
+      for (int q = 0; q < p; ++q) {
+        float threshold = precision * max_diag;
+        if (consider_as_zero > threshold) threshold = consider_as_zero;
+        if (!(fabsf(W[p * 3 + q]) > threshold || fabsf(W[q * 3 + p]) > threshold)) continue;
+        finished = 0;
+        /* real_2x2_jacobi_svd on m = [W(p,p) W(p,q); W(q,p) W(q,q)] */
+        float m00 = W[p * 3 + p], m01 = W[p * 3 + q], m10 = W[q * 3 + p], m11 = W[q * 3 + q];
+        float t = m00 + m11;
+        float d = m10 - m01;
+        float c1, s1;
+        if (fabsf(d) < FLT_MIN) {
+          c1 = 1.0f; s1 = 0.0f;
+        } else {
+          float u = t / d;
+          float tmp = sqrtf(1.0f + u * u);
+          s1 = 1.0f / tmp;
+          c1 = u / tmp;
+        }
+        /* m.applyOnTheLeft(0,1,rot1) */
+        float n00 = c1 * m00 + s1 * m10;
+        float n01 = c1 * m01 + s1 * m11;
+        float n11 = (-s1) * m01 + c1 * m11;
+        /* j_right.makeJacobi(n00, n01, n11) */
+        float cr, sr;
+        float deno = 2.0f * fabsf(n01);
+        if (deno < FLT_MIN) {
+          cr = 1.0f; sr = 0.0f;
+        } else {
+          float tau = (n00 - n11) / deno;
+          float w = sqrtf(tau * tau + 1.0f);
+          float tt = (tau > 0.0f) ? 1.0f / (tau + w) : 1.0f / (tau - w);
+          float sign_t = (tt > 0.0f) ? 1.0f : -1.0f;
+          float nn = 1.0f / sqrtf(tt * tt + 1.0f);
+          sr = -sign_t * (n01 / fabsf(n01)) * fabsf(tt) * nn;
+          cr = nn;
+        }
+        /* j_left = rot1 * j_right.transpose() */
+        float cl = c1 * cr + s1 * sr;
+        float sl = s1 * cr - c1 * sr;
+        /* W.applyOnTheLeft(p,q,j_left) ; U.applyOnTheRight(p,q,j_left^T) */
+        for (int k = 0; k < 3; ++k) {
+          float x = W[p * 3 + k], y = W[q * 3 + k];
+          W[p * 3 + k] = cl * x + sl * y;
+          W[q * 3 + k] = (-sl) * x + cl * y;
+        }
+        for (int k = 0; k < 3; ++k) {
+          float x = U[k * 3 + p], y = U[k * 3 + q];
+          U[k * 3 + p] = cl * x + sl * y;
+          U[k * 3 + q] = (-sl) * x + cl * y;
+        }
+        /* W.applyOnTheRight(p,q,j_right) ; V.applyOnTheRight(p,q,j_right) */
+        for (int k = 0; k < 3; ++k) {
+          float x = W[k * 3 + p], y = W[k * 3 + q];
+          W[k * 3 + p] = cr * x - sr * y;
+          W[k * 3 + q] = sr * x + cr * y;
+        }
+        for (int k = 0; k < 3; ++k) {
+          float x = V[k * 3 + p], y = V[k * 3 + q];
+          V[k * 3 + p] = cr * x - sr * y;
+          V[k * 3 + q] = sr * x + cr * y;
+        }
+        float a = fabsf(W[p * 3 + p]), b = fabsf(W[q * 3 + q]);
+        if (b > a) a = b;
+        if (a > max_diag) max_diag = a;
+      }
+    }
+    if (finished) break;
+  }
+  /* positive singular values, then sort descending (columns of U,V follow) */
+  for (int i = 0; i < 3; ++i) {
+    float w = W[i * 3 + i];
+    S[i] = fabsf(w);
+    if (w < 0.0f)
+      for (int k = 0; k < 3; ++k) U[k * 3 + i] = -U[k * 3 + i];
+    S[i] = S[i] * scale;
+  }
+  for (int i = 0; i < 3; ++i) {
+    int pos = i;
+    float best = S[i];
+    for (int j = i + 1; j < 3; ++j)
+      if (S[j] > best) { best = S[j]; pos = j; }
+    if (best == 0.0f) break;
+    if (pos != i) {
+      float ts = S[i]; S[i] = S[pos]; S[pos] = ts;
+      for (int k = 0; k < 3; ++k) {
+        float tu = U[k * 3 + i]; U[k * 3 + i] = U[k * 3 + pos]; U[k * 3 + pos] = tu;
+        float tv = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + pos]; V[k * 3 + pos] = tv;
+      }
+    }
+  }
+}
+
+static inline float orc_det3(const float* m) {
+  /* Eigen bruteforce_det3_helper */
+  float h0 = m[0] * (m[4] * m[8] - m[5] * m[7]);
+  float h1 = m[1] * (m[3] * m[8] - m[5] * m[6]);
+  float h2 = m[2] * (m[3] * m[7] - m[4] * m[6]);
+  return h0 - h1 + h2;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A.4 getTransformFromMatches -- transformation_estimation_euclidean.cpp:7-61 */
+/*     + pcl::TransformationFromCorrespondences (PCL 1.7, not in tree)          */
+/* T is column-major (Eigen::Matrix4f storage): T[c*4+r].                       */
+/* ------------------------------------------------------------------------- */
+void orc_fit_transform(const float* qxyz1, const float* txyz1, const int32_t* mq,
+                       const int32_t* mt, const int32_t* sel, int nsel, float T[16]) {
+  float W = 0.0f;
+  float mean1[3] = {0, 0, 0}, mean2[3] = {0, 0, 0};
+  float C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < nsel; ++s) {
+    const int m = sel[s];
+    const float* from = qxyz1 + 4 * mq[m]; /* newer node, queryIdx (:20) */
+    const float* to = txyz1 + 4 * mt[m];   /* earlier node, trainIdx (:21) */
+    if (isnan(from[2]) || isnan(to[2])) continue; /* :22-23 */
+    /* :25  weight = 1.0/(from(2)*to(2)) : float product, double divide, float store */
+    float w = (float)(1.0 / (double)(from[2] * to[2]));
+    /* tfc.add(from, to, w) */
+    if (w == 0.0f) continue;
+    W += w;
+    float alpha = w / W;
+    float d1[3], d2[3];
+    for (int j = 0; j < 3; ++j) d1[j] = from[j] - mean1[j];
+    for (int i = 0; i < 3; ++i) d2[i] = to[i] - mean2[i];
+    float oma = 1.0f - alpha;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        float outer = d2[i] * d1[j];
+        float scaled = alpha * outer;
+        float sum = C[i * 3 + j] + scaled;
+        C[i * 3 + j] = oma * sum;
+      }
+    for (int j = 0; j < 3; ++j) {
+      float a1 = alpha * d1[j];
+      mean1[j] = mean1[j] + a1;
+    }
+    for (int i = 0; i < 3; ++i) {
+      float a2 = alpha * d2[i];
+      mean2[i] = mean2[i] + a2;
+    }
+  }
+  /* tfc.getTransformation() */
+  float U[9], S[3], V[9];
+  orc_svd3(C, U, S, V);
+  float s22 = 1.0f;
+  if (orc_det3(U) * orc_det3(V) < 0.0f) s22 = -1.0f;
+  float R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float us2 = U[i * 3 + 2] * s22;
+      R[i * 3 + j] = (U[i * 3 + 0] * V[j * 3 + 0] + U[i * 3 + 1] * V[j * 3 + 1]) + us2 * V[j * 3 + 2];
+    }
+  float t[3];
+  for (int i = 0; i < 3; ++i) {
+    float rm = (R[i * 3 + 0] * mean1[0] + R[i * 3 + 1] * mean1[1]) + R[i * 3 + 2] * mean1[2];
+    t[i] = mean2[i] - rm;
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[j * 4 + i] = R[i * 3 + j];
+    T[12 + i] = t[i];
+    T[i * 4 + 3] = 0.0f;
+  }
+  T[15] = 1.0f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A.5 errorFunction2 -- src/misc.cpp:697-770 (all double)                      */
+/* ------------------------------------------------------------------------- */
+static double g_raster_cov_x, g_raster_cov_y;
+static int g_raster_init = 0;
+static void orc_raster_init(void) {
+  if (g_raster_init) return;
+  const double cam_angle_x = 58.0 / 180.0 * M_PI; /* misc.cpp:702 */
+  const double cam_angle_y = 45.0 / 180.0 * M_PI; /* :703 */
+  const double cam_resol_x = 640;                 /* :704 */
+  const double cam_resol_y = 480;                 /* :705 */
+  const double sx = 3 * tan(cam_angle_x / cam_resol_x); /* :706 */
+  const double sy = 3 * tan(cam_angle_y / cam_resol_y); /* :707 */
+  g_raster_cov_x = sx * sx; /* :708 */
+  g_raster_cov_y = sy * sy; /* :709 */
+  g_raster_init = 1;
+}
+void orc_raster_cov(double* cx, double* cy) {
+  orc_raster_init();
+  *cx = g_raster_cov_x;
+  *cy = g_raster_cov_y;
+}
+
+double orc_error_function2(const float x1[4], const float x2[4], const double T[16],
+                           double depth_cov) {
+  orc_raster_init();
+  const double rcx = g_raster_cov_x, rcy = g_raster_cov_y;
+  if (isnan(x1[2]) || isnan(x2[2])) return DBL_MAX; /* :712-717 */
+  double a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = (double)x1[i]; b[i] = (double)x2[i]; } /* :718-719 */
+  /* mu_1_in_frame_2 = (tf_12 * x_1).head<3>()  (:724), T column-major */
+  double m12[3];
+  for (int i = 0; i < 3; ++i)
+    m12[i] = ((T[0 * 4 + i] * a[0] + T[1 * 4 + i] * a[1]) + T[2 * 4 + i] * a[2]) + T[3 * 4 + i] * a[3];
+  double d[3];
+  for (int i = 0; i < 3; ++i) d[i] = m12[i] - b[i];
+  /* shortcut :726-735 */
+  {
+    double dsq = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+    double smax1 = rcx > depth_cov ? rcx : depth_cov;
+    double smax2 = rcx > depth_cov ? rcx : depth_cov;
+    if (dsq > 2.0 * (smax1 + smax2)) return DBL_MAX;
+  }
+  /* cov1, cov2 :740-749 */
+  double c1[3] = {rcx * a[2], rcy * a[2], depth_cov};
+  double c2[3] = {rcx * b[2], rcy * b[2], depth_cov};
+  /* cov1_in_frame_2 = R^T * cov1 * R (:751, sic).  R(k,i) = T[i*4+k]. */
+  double S[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a0 = T[i * 4 + 0] * c1[0]; /* (R^T cov1)(i,0) = R(0,i)*c1_0 */
+      double a1 = T[i * 4 + 1] * c1[1];
+      double a2 = T[i * 4 + 2] * c1[2];
+      S[i * 3 + j] = (a0 * T[j * 4 + 0] + a1 * T[j * 4 + 1]) + a2 * T[j * 4 + 2];
+    }
+  if (isnan(d[2])) return DBL_MAX; /* :755-758 */
+  S[0] += c2[0]; S[4] += c2[1]; S[8] += c2[2]; /* :760 */
+  /* d^T * S.llt().solve(d) (:763): unblocked Cholesky on the lower triangle */
+  double l00, l10, l20, l11, l21, l22, x;
+  x = S[0];
+  if (!(x > 0.0)) return DBL_MAX; /* D5 */
+  l00 = sqrt(x);
+  l10 = S[3] / l00;
+  l20 = S[6] / l00;
+  x = S[4] - l10 * l10;
+  if (!(x > 0.0)) return DBL_MAX;
+  l11 = sqrt(x);
+  l21 = (S[7] - l20 * l10) / l11;
+  x = S[8] - (l20 * l20 + l21 * l21);
+  if (!(x > 0.0)) return DBL_MAX;
+  l22 = sqrt(x);
+  /* forward: L y = d ; backward: L^T z = y */
+  double y0 = d[0] / l00;
+  double y1 = (d[1] - l10 * y0) / l11;
+  double y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
+  double z2 = y2 / l22;
+  double z1 = (y1 - l21 * z2) / l11;
+  double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
+  double e = (d[0] * z0 + d[1] * z1) + d[2] * z2;
+  if (!(e >= 0.0)) return DBL_MAX; /* :765-768 */
+  return e;
+}
+
+/* ------------------------------------------------------------------------- */
+/* computeInliersAndError -- src/node.cpp:968-1020                              */
+/* ------------------------------------------------------------------------- */
+int orc_compute_inliers_and_error(const float* qxyz1, const float* txyz1,
+                                  const int32_t* mq, const int32_t* mt, int n,
+                                  const float T[16], double sq_max_dist, double depth_cov,
+                                  int32_t* inl, double* mean_error_out) {
+  double Td[16];
+  for (int i = 0; i < 16; ++i) Td[i] = (double)T[i]; /* :984 */
+  double mean_error = 0.0;
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) { /* :988 */
+    const float* origin = qxyz1 + 4 * mq[i];
+    const float* target = txyz1 + 4 * mt[i];
+    if (origin[2] == 0.0f || target[2] == 0.0f) continue; /* :994 */
+    double e = orc_error_function2(origin, target, Td, depth_cov); /* :997 */
+    if (e > sq_max_dist) continue; /* :998 */
+    if (!(e >= 0.0)) continue;     /* :1001 */
+    mean_error += e;               /* :1006 */
+    inl[cnt++] = i;                /* :1008 */
+  }
+  if (cnt < 3) { /* :1012 */
+    *mean_error_out = 1e9;
+  } else {
+    mean_error /= cnt;              /* :1016 */
+    *mean_error_out = sqrt(mean_error); /* :1017 */
+  }
+  return cnt;
+}
+
+static int orc_has_nan16(const float* T) {
+  for (int i = 0; i < 16; ++i)
+    if (T[i] != T[i]) return 1;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A.3 getRelativeTransformationTo -- src/node.cpp:1074-1277                    */
+/* matches (mq,mt) must already be sorted ascending by distance (:1127, D2).    */
+/* ------------------------------------------------------------------------- */
+int orc_ransac(const float* qxyz1, const float* txyz1, const int32_t* mq,
+               const int32_t* mt, int n, const orc_params* prm, uint32_t uid,
+               float T[16], float* rmse_out, int32_t* matches, int* n_matches_out,
+               int* valid_iterations_out, int* real_iterations_out) {
+  static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memcpy(T, I16, sizeof(I16));
+  *n_matches_out = 0;
+  *valid_iterations_out = 0;
+  *real_iterations_out = 0;
+  if (n <= prm->min_matches) { /* :1087 -- rmse is left untouched by the reference */
+    return 0;
+  }
+  unsigned int min_inlier_threshold = (unsigned int)prm->min_matches; /* :1094 */
+  if ((double)min_inlier_threshold > 0.75 * (double)n)                 /* :1095 */
+    min_inlier_threshold = (unsigned int)(0.75 * (double)n);           /* :1098 */
+
+  double inlier_error;
+  const float max_dist_m = (float)(double)prm->max_dist_for_inliers; /* :1105 */
+  const double sq_max = (double)(max_dist_m * max_dist_m);           /* float product, :1152 */
+  const int ransac_iterations = prm->ransac_iterations;
+
+  float rmse = 1e6f; /* :1112 */
+  int n_matches = 0;
+  unsigned int valid_iterations = 0;
+  int real_iterations = 0;
+
+  int32_t inlier[ORC_MAX_MATCHES], refined[ORC_MAX_MATCHES];
+  for (int it = 0; (it < ransac_iterations && n >= 4); it++) { /* :1130 */
+    double refined_error = 1e6;  /* :1133 */
+    int n_refined = 0;           /* :1134 */
+    float refined_T[16];
+    memcpy(refined_T, I16, sizeof(I16)); /* :1137 */
+    uint32_t ids[4];
+    int n_inl = orc_sample4(prm->seed, uid, (uint32_t)real_iterations, (uint32_t)n, ids); /* :1135 */
+    for (int i = 0; i < n_inl; ++i) inlier[i] = (int32_t)ids[i];
+    real_iterations++; /* :1139 */
+    for (int refinements = 1; refinements < 20; refinements++) { /* :1140 */
+      float Tn[16];
+      orc_fit_transform(qxyz1, txyz1, mq, mt, inlier, n_inl, Tn); /* :1142 */
+      if (orc_has_nan16(Tn)) break;                                /* :1144 */
+      n_inl = orc_compute_inliers_and_error(qxyz1, txyz1, mq, mt, n, Tn, sq_max,
+                                            prm->depth_cov, inlier, &inlier_error); /* :1148 */
+      if ((unsigned int)n_inl < min_inlier_threshold || inlier_error > (double)max_dist_m) /* :1154 */
+        break;
+      if (n_inl >= n_refined && inlier_error <= refined_error) { /* :1160 */
+        int prev = n_refined;
+        memcpy(refined_T, Tn, sizeof(Tn));
+        memcpy(refined, inlier, sizeof(int32_t) * (size_t)n_inl);
+        n_refined = n_inl;
+        refined_error = inlier_error;
+        if (n_inl == prev) break; /* :1166 */
+      } else
+        break;
+    }
+    if (n_refined > 0) { /* :1171 */
+      valid_iterations++;
+      if (refined_error <= (double)rmse && n_refined >= n_matches &&
+          (unsigned int)n_refined >= min_inlier_threshold) { /* :1177-1179 */
+        rmse = (float)refined_error; /* :1182 double -> float */
+        memcpy(T, refined_T, sizeof(refined_T));
+        memcpy(matches, refined, sizeof(int32_t) * (size_t)n_refined);
+        n_matches = n_refined;
+        if ((double)n_refined > (double)n * 0.5) it += 10;  /* :1186 */
+        if ((double)n_refined > (double)n * 0.75) it += 10; /* :1187 */
+        if ((double)n_refined > (double)n * 0.8) break;     /* :1188 */
+      }
+    }
+  }
+  if (valid_iterations == 0) { /* :1192 identity hypothesis */
+    int n_inl = orc_compute_inliers_and_error(qxyz1, txyz1, mq, mt, n, I16, sq_max,
+                                              prm->depth_cov, inlier, &inlier_error);
+    if ((unsigned int)n_inl > min_inlier_threshold && inlier_error < (double)max_dist_m) { /* :1206 */
+      memcpy(T, I16, sizeof(I16));
+      memcpy(matches, inlier, sizeof(int32_t) * (size_t)n_inl);
+      n_matches = n_inl;
+      rmse = (float)inlier_error;
+      valid_iterations++;
+    }
+  }
+  /* g2o refinement (:1225-1268) is off by default (g2o_transformation_refinement = 0). */
+  *rmse_out = rmse;
+  *n_matches_out = n_matches;
+  *valid_iterations_out = (int)valid_iterations;
+  *real_iterations_out = real_iterations;
+  return (unsigned int)n_matches >= min_inlier_threshold; /* :1275 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* matchNodePair -- src/node.cpp:1305-1429 ; MatchingResult matching_result.h   */
+/* ------------------------------------------------------------------------- */
+void orc_match_node_pair(const uint8_t* qdesc, const float* qxyz1, uint32_t nq, int32_t qid,
+                         const uint8_t* tdesc, const float* txyz1, uint32_t nt, int32_t tid,
+                         const orc_params* prm, orc_result* out) {
+  static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memset(out, 0, sizeof(*out));
+  out->id1 = out->id2 = -1;       /* matching_result.h:33 */
+  out->rmse = 0.0f;               /* matching_result.h:27 */
+  memcpy(out->T, I16, sizeof(I16));
+  int maxm = prm->max_matches;
+  if (maxm > ORC_MAX_MATCHES) maxm = ORC_MAX_MATCHES;
+  out->n_all = orc_feature_matching_orb(qdesc, nq, tdesc, nt, maxm, out->all_q, out->all_t,
+                                        out->all_hd); /* :1315 */
+  int found = 0;
+  if (out->n_all < prm->min_matches) { /* :1319 */
+    found = 0;
+  } else {
+    found = orc_ransac(qxyz1, txyz1, out->all_q, out->all_t, out->n_all, prm,
+                       orc_pair_uid(qid, tid), out->T, &out->rmse, out->inl_idx, &out->n_inl,
+                       &out->valid_iterations, &out->real_iterations); /* :1324 */
+    if (out->n_all <= prm->min_matches) out->rmse = 0.0f; /* early return leaves mr.rmse */
+  }
+  if (found) {
+    /* :1335 informationMatrix = I * (inlier_matches.size()/(rmse*rmse)) : float arithmetic */
+    out->info_scale = (double)((float)out->n_inl / (out->rmse * out->rmse));
+    out->id1 = tid; /* older node, :1337 */
+    out->id2 = qid; /* this,       :1338 */
+  } else {
+    out->id1 = out->id2 = -1; /* :1419-1422 */
+    out->info_scale = 0.0;
+  }
+}
+
+void orc_match_pairs_mt(const uint8_t* const* desc, const float* const* xyz1,
+                        const uint32_t* counts, const int32_t* node_ids,
+                        const int32_t* pair_q, const int32_t* pair_t, int n_pairs,
+                        const orc_params* prm, orc_result* out, int n_threads) {
+  /* graph_manager.cpp:541-548: one task per (new, candidate) pair on a pool of
+   * one thread per core. */
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int p = 0; p < n_pairs; ++p) {
+    int q = pair_q[p], t = pair_t[p];
+    orc_match_node_pair(desc[q], xyz1[q], counts[q], node_ids[q], desc[t], xyz1[t], counts[t],
+                        node_ids[t], prm, &out[p]);
+  }
+}
+
+int orc_num_cores(void) {
+#ifdef _OPENMP
+  return omp_get_num_procs();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* A.7 removeDepthless + projectTo3D -- node.cpp:67-97, 900-965; misc2.h:49-65  */
+/* kp_xy: n_kp x 2 float (pt.x, pt.y).  depth: rows x cols float32 (metres).    */
+/* ------------------------------------------------------------------------- */
+int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
+                      double fx, double fy, double cx_d, double cy_d, double depth_scaling,
+                      int max_keypoints, int32_t* kept_idx, float* xyz1) {
+  const float fxinv = (float)(1. / fx); /* :913 */
+  const float fyinv = (float)(1. / fy); /* :914 */
+  const float cx = (float)cx_d;         /* :915 */
+  const float cy = (float)cy_d;         /* :916 */
+  int n = 0;
+  for (int i = 0; i < n_kp; ++i) {
+    float px = kp_xy[2 * i], py = kp_xy[2 * i + 1];
+    if (px >= (float)cols || px < 0 || py >= (float)rows || py < 0 || isnan(px) || isnan(py))
+      continue; /* :931-937 */
+    /* :942 depth.at<float>(round(y), round(x)) * depth_scaling : round = half away
+     * from zero; the product is float*double -> double -> float Z. */
+    int r = (int)roundf(py), c = (int)roundf(px);
+    if (r >= rows) r = rows - 1; /* reference reads out of bounds here; clamp */
+    if (c >= cols) c = cols - 1;
+    float Z = (float)((double)depth[(size_t)r * (size_t)cols + (size_t)c] * depth_scaling);
+    if (isnan(Z)) continue; /* :947 */
+    /* backProject, misc2.h:62-64 */
+    xyz1[4 * n + 0] = (px - cx) * Z * fxinv;
+    xyz1[4 * n + 1] = (py - cy) * Z * fyinv;
+    xyz1[4 * n + 2] = Z;
+    xyz1[4 * n + 3] = 1.0f; /* :955 */
+    kept_idx[n] = i;
+    ++n;
+    if (n >= max_keypoints) break; /* :957 */
+  }
+  return n;
+}

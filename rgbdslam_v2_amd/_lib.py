@@ -1,0 +1,152 @@
+"""ctypes binding of librgbdfe.so (the C ABI in include/rgbdfe.h).
+
+The library is built in-tree by ``rgbdslam_v2_amd.build.build()`` (hipcc, gfx950).
+There is no CPU fallback anywhere in this package: if the shared library is
+missing, or no HIP device is present, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgbdfe.so")
+
+RGBDFE_MAX_MATCHES = 320
+RGBDFE_MASK_WORDS = 5
+
+KERNEL_HAMMING = 0
+KERNEL_RANSAC = 1
+
+
+class RgbdfeParams(C.Structure):
+    _fields_ = [
+        ("max_matches", C.c_int32),
+        ("min_matches", C.c_int32),
+        ("ransac_iterations", C.c_int32),
+        ("max_dist_for_inliers", C.c_float),
+        ("depth_cov", C.c_double),
+        ("seed", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class RgbdfeConfig(C.Structure):
+    _fields_ = [
+        ("device_id", C.c_int32),
+        ("max_nodes", C.c_int32),
+        ("max_keypoints", C.c_int32),
+        ("max_pairs_per_batch", C.c_int32),
+        ("params", RgbdfeParams),
+    ]
+
+
+class RgbdfeMatchResult(C.Structure):
+    _fields_ = [
+        ("id1", C.c_int32),
+        ("id2", C.c_int32),
+        ("n_all", C.c_int32),
+        ("n_inl", C.c_int32),
+        ("rmse", C.c_float),
+        ("trafo", C.c_float * 16),
+        ("pad0", C.c_uint32),
+        ("info_scale", C.c_double),
+        ("valid_iterations", C.c_int32),
+        ("real_iterations", C.c_int32),
+        ("all_q", C.c_uint16 * RGBDFE_MAX_MATCHES),
+        ("all_t", C.c_uint16 * RGBDFE_MAX_MATCHES),
+        ("all_hd", C.c_uint8 * RGBDFE_MAX_MATCHES),
+        ("inlier_mask", C.c_uint64 * RGBDFE_MASK_WORDS),
+    ]
+
+
+# numpy view of the same POD (used for bulk result handling and the all-gather payload)
+RESULT_DTYPE = np.dtype([
+    ("id1", "<i4"), ("id2", "<i4"), ("n_all", "<i4"), ("n_inl", "<i4"), ("rmse", "<f4"),
+    ("trafo", "<f4", (16,)), ("pad0", "<u4"), ("info_scale", "<f8"),
+    ("valid_iterations", "<i4"), ("real_iterations", "<i4"),
+    ("all_q", "<u2", (RGBDFE_MAX_MATCHES,)), ("all_t", "<u2", (RGBDFE_MAX_MATCHES,)),
+    ("all_hd", "u1", (RGBDFE_MAX_MATCHES,)), ("inlier_mask", "<u8", (RGBDFE_MASK_WORDS,)),
+], align=True)
+
+_lib = None
+
+
+class RgbdfeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load librgbdfe.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RgbdfeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    i32 = C.c_int32
+    ctx = vp
+    L.rgbdfe_default_config.restype = None
+    L.rgbdfe_default_config.argtypes = [C.POINTER(RgbdfeConfig)]
+    L.rgbdfe_create.restype = C.c_int
+    L.rgbdfe_create.argtypes = [C.POINTER(RgbdfeConfig), C.POINTER(vp)]
+    L.rgbdfe_destroy.restype = None
+    L.rgbdfe_destroy.argtypes = [ctx]
+    L.rgbdfe_set_params.restype = C.c_int
+    L.rgbdfe_set_params.argtypes = [ctx, C.POINTER(RgbdfeParams)]
+    L.rgbdfe_status_string.restype = C.c_char_p
+    L.rgbdfe_status_string.argtypes = [C.c_int]
+    L.rgbdfe_last_error.restype = C.c_char_p
+    L.rgbdfe_last_error.argtypes = [ctx]
+    L.rgbdfe_upload_node.restype = C.c_int
+    L.rgbdfe_upload_node.argtypes = [ctx, i32, vp, vp, i32]
+    L.rgbdfe_upload_node_device.restype = C.c_int
+    L.rgbdfe_upload_node_device.argtypes = [ctx, i32, vp, vp, i32, vp]
+    L.rgbdfe_release_node.restype = C.c_int
+    L.rgbdfe_release_node.argtypes = [ctx, i32]
+    L.rgbdfe_node_count.restype = C.c_int
+    L.rgbdfe_node_count.argtypes = [ctx, i32]
+    L.rgbdfe_match_node_pairs.restype = C.c_int
+    L.rgbdfe_match_node_pairs.argtypes = [ctx, i32, vp, i32, vp]
+    L.rgbdfe_match_pair_list.restype = C.c_int
+    L.rgbdfe_match_pair_list.argtypes = [ctx, vp, vp, i32, vp]
+    L.rgbdfe_match_pair_list_device.restype = C.c_int
+    L.rgbdfe_match_pair_list_device.argtypes = [ctx, vp, vp, i32, vp, vp]
+    L.rgbdfe_synchronize.restype = C.c_int
+    L.rgbdfe_synchronize.argtypes = [ctx]
+    L.rgbdfe_hamming_nn_nodes.restype = C.c_int
+    L.rgbdfe_hamming_nn_nodes.argtypes = [ctx, i32, i32, vp, vp]
+    L.rgbdfe_hamming_nn_host.restype = C.c_int
+    L.rgbdfe_hamming_nn_host.argtypes = [ctx, vp, i32, vp, i32, vp, vp]
+    L.rgbdfe_project_to_3d.restype = C.c_int
+    L.rgbdfe_project_to_3d.argtypes = [ctx, vp, i32, vp, i32, i32, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, i32, vp, vp,
+                                       C.POINTER(i32)]
+    L.rgbdfe_set_profiling.restype = C.c_int
+    L.rgbdfe_set_profiling.argtypes = [ctx, C.c_int]
+    L.rgbdfe_get_kernel_time.restype = C.c_int
+    L.rgbdfe_get_kernel_time.argtypes = [ctx, C.c_int, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.rgbdfe_reset_kernel_time.restype = C.c_int
+    L.rgbdfe_reset_kernel_time.argtypes = [ctx]
+    L.rgbdfe_sizeof_match_result.restype = C.c_int
+    L.rgbdfe_abi_version.restype = C.c_int
+    if L.rgbdfe_sizeof_match_result() != C.sizeof(RgbdfeMatchResult) or \
+            RESULT_DTYPE.itemsize != C.sizeof(RgbdfeMatchResult):
+        raise RgbdfeError("rgbdfe_match_result layout mismatch between librgbdfe.so and the binding")
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "rgbdfe_default_config", "rgbdfe_create", "rgbdfe_destroy", "rgbdfe_set_params",
+    "rgbdfe_status_string", "rgbdfe_last_error", "rgbdfe_upload_node",
+    "rgbdfe_upload_node_device", "rgbdfe_release_node", "rgbdfe_node_count",
+    "rgbdfe_match_node_pairs", "rgbdfe_match_pair_list", "rgbdfe_match_pair_list_device",
+    "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
+    "rgbdfe_project_to_3d", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
+    "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
+]

@@ -1,0 +1,534 @@
+// rgbdfe_api.hip -- host side of the C ABI declared in include/rgbdfe.h.
+//
+// Owns the HBM-resident node slabs (descriptors + xyz1 of every node the graph keeps,
+// GraphManager ownership semantics, graph_manager.h:156-161), the per-batch staging
+// buffers and one HIP stream.  There is no CPU fallback: without a HIP device every
+// entry point reports RGBDFE_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "rgbdfe_internal.h"
+
+using namespace rgbdfe;
+
+namespace {
+
+struct NodeEntry {
+  uint32_t slot;
+  uint32_t n;
+};
+
+inline uint32_t mix32_host(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// RNG stream id of a pair: depends on the two node ids only, so a pair yields the same
+// result in any batch, on any rank.
+inline uint32_t pair_uid(int32_t qid, int32_t tid) {
+  return mix32_host((uint32_t)qid * 0x9E3779B1u ^ ((uint32_t)tid + 0x7F4A7C15u));
+}
+
+}  // namespace
+
+struct rgbdfe_ctx {
+  rgbdfe_config cfg{};
+  std::mutex mu;
+  std::string last_error;
+  hipStream_t stream = nullptr;
+  // slabs
+  uint32_t* d_desc = nullptr;  // max_nodes x max_kp x 8 dwords (+ pad rows)
+  float4* d_xyz = nullptr;     // max_nodes x max_kp
+  // per-batch staging
+  PairWork* d_work = nullptr;
+  PairWork* h_work = nullptr;  // pinned
+  uint32_t* d_keys = nullptr;  // max_pairs x max_kp
+  rgbdfe_match_result* d_results = nullptr;
+  // scratch for single-pair helpers / project_to_3d
+  void* d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+  std::unordered_map<int32_t, NodeEntry> nodes;
+  std::vector<uint32_t> free_slots;
+  RansacConst rc{};
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  double k_ms[RGBDFE_KERNEL_COUNT] = {0, 0};
+  int64_t k_launches[RGBDFE_KERNEL_COUNT] = {0, 0};
+  int64_t k_pairs[RGBDFE_KERNEL_COUNT] = {0, 0};
+  struct Pending { hipEvent_t a, b, c; int32_t pairs; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(rgbdfe_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                          \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess)                                                           \
+      return fail(ctx, RGBDFE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+void fill_ransac_const(rgbdfe_ctx* ctx) {
+  const rgbdfe_params& p = ctx->cfg.params;
+  RansacConst& rc = ctx->rc;
+  rc.max_matches = p.max_matches;
+  rc.min_matches = p.min_matches;
+  rc.ransac_iterations = p.ransac_iterations;
+  rc.max_dist_m = (float)(double)p.max_dist_for_inliers;       // node.cpp:1105
+  rc.sq_max_dist = (double)(rc.max_dist_m * rc.max_dist_m);    // node.cpp:1152 (float product)
+  rc.depth_cov = p.depth_cov;
+  // misc.cpp:702-709
+  const double cam_angle_x = 58.0 / 180.0 * M_PI;
+  const double cam_angle_y = 45.0 / 180.0 * M_PI;
+  const double cam_resol_x = 640;
+  const double cam_resol_y = 480;
+  const double sx = 3 * tan(cam_angle_x / cam_resol_x);
+  const double sy = 3 * tan(cam_angle_y / cam_resol_y);
+  rc.raster_cov_x = sx * sx;
+  rc.raster_cov_y = sy * sy;
+  rc.seed = p.seed;
+}
+
+int validate_params(rgbdfe_ctx* ctx, const rgbdfe_params& p) {
+  if (p.max_matches < 1 || p.max_matches > RGBDFE_MAX_MATCHES)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "max_matches must be in [1, RGBDFE_MAX_MATCHES]");
+  if (p.min_matches < 0 || p.ransac_iterations < 0)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "min_matches / ransac_iterations must be >= 0");
+  if (!(p.max_dist_for_inliers > 0.f))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "max_dist_for_inliers must be > 0");
+  return RGBDFE_OK;
+}
+
+int ensure_scratch(rgbdfe_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return RGBDFE_OK;
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  ctx->d_scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return RGBDFE_OK;
+}
+
+hipEvent_t get_event(rgbdfe_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+// fold finished timing records into the totals
+void drain_pending(rgbdfe_ctx* ctx) {
+  for (auto& p : ctx->pending) {
+    float ms_h = 0.f, ms_r = 0.f;
+    if (hipEventElapsedTime(&ms_h, p.a, p.b) == hipSuccess &&
+        hipEventElapsedTime(&ms_r, p.b, p.c) == hipSuccess) {
+      ctx->k_ms[RGBDFE_KERNEL_HAMMING] += ms_h;
+      ctx->k_ms[RGBDFE_KERNEL_RANSAC] += ms_r;
+      ctx->k_launches[RGBDFE_KERNEL_HAMMING]++;
+      ctx->k_launches[RGBDFE_KERNEL_RANSAC]++;
+      ctx->k_pairs[RGBDFE_KERNEL_HAMMING] += p.pairs;
+      ctx->k_pairs[RGBDFE_KERNEL_RANSAC] += p.pairs;
+    }
+    ctx->event_pool.push_back(p.a);
+    ctx->event_pool.push_back(p.b);
+    ctx->event_pool.push_back(p.c);
+  }
+  ctx->pending.clear();
+}
+
+// Build the PairWork list (host) and enqueue H2D + both kernels on `stream`.
+// Results land in d_out (device).  Caller holds the lock.
+int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int32_t n,
+                  rgbdfe_match_result* d_out, hipStream_t stream) {
+  if (n == 0) return RGBDFE_OK;
+  if (n > ctx->cfg.max_pairs_per_batch)
+    return fail(ctx, RGBDFE_ERR_CAPACITY, "n_pairs exceeds max_pairs_per_batch");
+  uint32_t max_nq = 0, max_nt = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    auto q = ctx->nodes.find(qids[i]);
+    auto t = ctx->nodes.find(tids[i]);
+    if (q == ctx->nodes.end() || t == ctx->nodes.end())
+      return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "pair references a node that is not resident");
+    PairWork& w = ctx->h_work[i];
+    w.q_slot = q->second.slot;
+    w.t_slot = t->second.slot;
+    w.nq = q->second.n;
+    w.nt = t->second.n;
+    w.uid = pair_uid(qids[i], tids[i]);
+    w.qid = qids[i];
+    w.tid = tids[i];
+    w.pad = 0;
+    if (w.nq > max_nq) max_nq = w.nq;
+    if (w.nt > max_nt) max_nt = w.nt;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_work, sizeof(PairWork) * (size_t)n,
+                              hipMemcpyHostToDevice, stream));
+  rgbdfe_ctx::Pending pend{};
+  if (ctx->profiling) {
+    pend.a = get_event(ctx);
+    pend.b = get_event(ctx);
+    pend.c = get_event(ctx);
+    pend.pairs = n;
+    (void)hipEventRecord(pend.a, stream);
+  }
+  launch_hamming_nn(ctx->d_desc, ctx->d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints,
+                    (uint32_t)n, max_nq, max_nt, stream);
+  if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
+  launch_select_ransac(ctx->d_xyz, ctx->d_work, ctx->d_keys, d_out,
+                       (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->rc, stream);
+  if (ctx->profiling) {
+    (void)hipEventRecord(pend.c, stream);
+    ctx->pending.push_back(pend);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return RGBDFE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rgbdfe_default_config(rgbdfe_config* cfg) {
+  if (!cfg) return;
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->device_id = 0;
+  cfg->max_nodes = 256;
+  cfg->max_keypoints = 1024;
+  cfg->max_pairs_per_batch = 4096;
+  cfg->params.max_matches = 300;           // parameter_server.cpp:86
+  cfg->params.min_matches = 20;            // parameter_server.cpp:85
+  cfg->params.ransac_iterations = 200;     // parameter_server.cpp:101
+  cfg->params.max_dist_for_inliers = 3.0f; // parameter_server.cpp:100
+  cfg->params.depth_cov = 1e-4;            // (sigma_depth=0.01 * (1 m)^2)^2, misc2.h:20-35
+  cfg->params.seed = 20260923u;
+}
+
+int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
+  if (!cfg || !out) return RGBDFE_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (cfg->max_nodes < 1 || cfg->max_keypoints < 1 || cfg->max_keypoints > RGBDFE_MAX_KEYPOINTS ||
+      cfg->max_pairs_per_batch < 1)
+    return RGBDFE_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RGBDFE_ERR_NO_DEVICE;
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return RGBDFE_ERR_NO_DEVICE;
+  rgbdfe_ctx* ctx = new rgbdfe_ctx();
+  ctx->cfg = *cfg;
+  int rc = validate_params(ctx, cfg->params);
+  if (rc != RGBDFE_OK) { delete ctx; return rc; }
+  fill_ransac_const(ctx);
+  auto bail = [&](int code) { rgbdfe_destroy(ctx); return code; };
+  if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(RGBDFE_ERR_HIP);
+  const size_t rows = (size_t)cfg->max_nodes * (size_t)cfg->max_keypoints + 16;  // +pad: prefetch overrun
+  if (hipMalloc((void**)&ctx->d_desc, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  if (hipMalloc((void**)&ctx->d_xyz, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  if (hipMemset(ctx->d_desc, 0, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  if (hipMemset(ctx->d_xyz, 0, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  const size_t np = (size_t)cfg->max_pairs_per_batch;
+  if (hipMalloc((void**)&ctx->d_work, np * sizeof(PairWork)) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  if (hipHostMalloc((void**)&ctx->h_work, np * sizeof(PairWork), hipHostMallocDefault) != hipSuccess)
+    return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  if (hipMalloc((void**)&ctx->d_keys, np * (size_t)cfg->max_keypoints * 4) != hipSuccess)
+    return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  if (hipMalloc((void**)&ctx->d_results, np * sizeof(rgbdfe_match_result)) != hipSuccess)
+    return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  ctx->free_slots.reserve(cfg->max_nodes);
+  for (int32_t s = cfg->max_nodes - 1; s >= 0; --s) ctx->free_slots.push_back((uint32_t)s);
+  *out = ctx;
+  return RGBDFE_OK;
+}
+
+void rgbdfe_destroy(rgbdfe_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  drain_pending(ctx);
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+  if (ctx->d_xyz) (void)hipFree(ctx->d_xyz);
+  if (ctx->d_work) (void)hipFree(ctx->d_work);
+  if (ctx->h_work) (void)hipHostFree(ctx->h_work);
+  if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+  if (ctx->d_results) (void)hipFree(ctx->d_results);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p) {
+  if (!ctx || !p) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  int rc = validate_params(ctx, *p);
+  if (rc != RGBDFE_OK) return rc;
+  ctx->cfg.params = *p;
+  fill_ransac_const(ctx);
+  return RGBDFE_OK;
+}
+
+const char* rgbdfe_status_string(int status) {
+  switch (status) {
+    case RGBDFE_OK: return "ok";
+    case RGBDFE_ERR_INVALID_ARG: return "invalid argument";
+    case RGBDFE_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case RGBDFE_ERR_HIP: return "HIP runtime error";
+    case RGBDFE_ERR_UNKNOWN_NODE: return "unknown node id";
+    case RGBDFE_ERR_CAPACITY: return "capacity exceeded";
+    case RGBDFE_ERR_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown status";
+  }
+}
+
+const char* rgbdfe_last_error(rgbdfe_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+static int upload_common(rgbdfe_ctx* ctx, int32_t node_id, const void* desc, const void* xyz1,
+                         int32_t n, hipMemcpyKind kind, hipStream_t stream, bool sync) {
+  if (!ctx || n < 0 || (n > 0 && (!desc || !xyz1))) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad upload arguments");
+  if (n > ctx->cfg.max_keypoints) return fail(ctx, RGBDFE_ERR_CAPACITY, "node has more rows than max_keypoints");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  uint32_t slot;
+  auto it = ctx->nodes.find(node_id);
+  if (it != ctx->nodes.end()) {
+    slot = it->second.slot;
+  } else {
+    if (ctx->free_slots.empty()) return fail(ctx, RGBDFE_ERR_CAPACITY, "no free node slot (max_nodes)");
+    slot = ctx->free_slots.back();
+    ctx->free_slots.pop_back();
+  }
+  const size_t row0 = (size_t)slot * (size_t)ctx->cfg.max_keypoints;
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc + row0 * 8, desc, (size_t)n * 32, kind, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, xyz1, (size_t)n * 16, kind, stream));
+  }
+  if (sync) HIP_TRY(ctx, hipStreamSynchronize(stream));
+  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n};
+  return RGBDFE_OK;
+}
+
+int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc, const float* xyz1,
+                       int32_t n) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return upload_common(ctx, node_id, desc, xyz1, n, hipMemcpyHostToDevice, ctx->stream, true);
+}
+
+int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_desc,
+                              const void* d_xyz1, int32_t n, void* stream) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return upload_common(ctx, node_id, d_desc, d_xyz1, n, hipMemcpyDeviceToDevice, s, stream == nullptr);
+}
+
+int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  auto it = ctx->nodes.find(node_id);
+  if (it == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "release of unknown node");
+  ctx->free_slots.push_back(it->second.slot);
+  ctx->nodes.erase(it);
+  return RGBDFE_OK;
+}
+
+int rgbdfe_node_count(rgbdfe_ctx* ctx, int32_t node_id) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  auto it = ctx->nodes.find(node_id);
+  if (it == ctx->nodes.end()) return RGBDFE_ERR_UNKNOWN_NODE;
+  return (int)it->second.n;
+}
+
+int rgbdfe_match_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                           int32_t n_pairs, rgbdfe_match_result* out) {
+  if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!query_ids || !train_ids || !out)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  const int32_t cap = ctx->cfg.max_pairs_per_batch;
+  for (int32_t off = 0; off < n_pairs; off += cap) {
+    const int32_t n = (n_pairs - off) < cap ? (n_pairs - off) : cap;
+    int rc = enqueue_pairs(ctx, query_ids + off, train_ids + off, n, ctx->d_results, ctx->stream);
+    if (rc != RGBDFE_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out + off, ctx->d_results, sizeof(rgbdfe_match_result) * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h_work / d_results are reused
+  }
+  if (ctx->profiling) drain_pending(ctx);
+  return RGBDFE_OK;
+}
+
+int rgbdfe_match_node_pairs(rgbdfe_ctx* ctx, int32_t new_node_id, const int32_t* candidate_ids,
+                            int32_t n_pairs, rgbdfe_match_result* out) {
+  if (!ctx || n_pairs < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
+  std::vector<int32_t> q((size_t)n_pairs, new_node_id);
+  return rgbdfe_match_pair_list(ctx, q.data(), candidate_ids, n_pairs, out);
+}
+
+int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids,
+                                  const int32_t* train_ids, int32_t n_pairs, void* d_out,
+                                  void* stream) {
+  if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!query_ids || !train_ids || !d_out)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  // the pinned PairWork staging buffer is reused by every call: wait until the previous
+  // batch's H2D copy (and kernels) on this stream have consumed it.
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (ctx->profiling) drain_pending(ctx);
+  return enqueue_pairs(ctx, query_ids, train_ids, n_pairs, (rgbdfe_match_result*)d_out, s);
+}
+
+int rgbdfe_synchronize(rgbdfe_ctx* ctx) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profiling) drain_pending(ctx);
+  return RGBDFE_OK;
+}
+
+static int hamming_keys_to_host(rgbdfe_ctx* ctx, uint32_t nq, int32_t* out_hd, int32_t* out_idx) {
+  std::vector<uint32_t> keys(nq);
+  HIP_TRY(ctx, hipMemcpyAsync(keys.data(), ctx->d_keys, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t i = 0; i < nq; ++i) {
+    const uint32_t hd = keys[i] >> 16;
+    if (hd > 256u) {  // nothing searched: (257, -1), features.cpp:172-173
+      out_hd[i] = 257;
+      out_idx[i] = -1;
+    } else {
+      out_hd[i] = (int32_t)hd;
+      out_idx[i] = (int32_t)(keys[i] & 0xFFFFu);
+    }
+  }
+  return RGBDFE_OK;
+}
+
+int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* out_hd,
+                            int32_t* out_idx) {
+  if (!ctx || !out_hd || !out_idx) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  auto q = ctx->nodes.find(query_id);
+  auto t = ctx->nodes.find(train_id);
+  if (q == ctx->nodes.end() || t == ctx->nodes.end())
+    return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "node not resident");
+  PairWork& w = ctx->h_work[0];
+  w.q_slot = q->second.slot; w.t_slot = t->second.slot;
+  w.nq = q->second.n; w.nt = t->second.n;
+  w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id; w.pad = 0;
+  if (w.nq == 0) return RGBDFE_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_work, sizeof(PairWork), hipMemcpyHostToDevice, ctx->stream));
+  launch_hamming_nn(ctx->d_desc, ctx->d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints, 1u,
+                    w.nq, w.nt, ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return hamming_keys_to_host(ctx, w.nq, out_hd, out_idx);
+}
+
+int rgbdfe_hamming_nn_host(rgbdfe_ctx* ctx, const uint8_t* qdesc, int32_t nq, const uint8_t* tdesc,
+                           int32_t nt, int32_t* out_hd, int32_t* out_idx) {
+  if (!ctx || nq < 0 || nt < 0 || !out_hd || !out_idx) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  // two temporary nodes with ids outside the int32 range a SLAM graph uses
+  const int32_t qid = INT32_MIN + 1, tid = INT32_MIN + 2;
+  std::vector<float> zq((size_t)(nq > 0 ? nq : 1) * 4, 0.f), zt((size_t)(nt > 0 ? nt : 1) * 4, 0.f);
+  int rc = rgbdfe_upload_node(ctx, qid, qdesc, zq.data(), nq);
+  if (rc != RGBDFE_OK) return rc;
+  rc = rgbdfe_upload_node(ctx, tid, tdesc, zt.data(), nt);
+  if (rc == RGBDFE_OK) rc = rgbdfe_hamming_nn_nodes(ctx, qid, tid, out_hd, out_idx);
+  (void)rgbdfe_release_node(ctx, qid);
+  (void)rgbdfe_release_node(ctx, tid);
+  return rc;
+}
+
+int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* depth,
+                         int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                         double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
+                         float* xyz1, int32_t* n_out) {
+  if (!ctx || n_kp < 0 || rows < 1 || cols < 1 || !depth || !kept_idx || !xyz1 || !n_out ||
+      max_keypoints < 0 || (n_kp > 0 && !kp_xy))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  *n_out = 0;
+  if (n_kp == 0 || max_keypoints == 0) return RGBDFE_OK;
+  const size_t b_kp = ((size_t)n_kp * 8 + 255) & ~(size_t)255;
+  const size_t b_depth = ((size_t)rows * cols * 4 + 255) & ~(size_t)255;
+  const size_t b_idx = ((size_t)n_kp * 4 + 255) & ~(size_t)255;
+  const size_t b_xyz = ((size_t)n_kp * 16 + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, b_kp + b_depth + b_idx + b_xyz + 256);
+  if (rc != RGBDFE_OK) return rc;
+  char* base = (char*)ctx->d_scratch;
+  float* d_kp = (float*)base;
+  float* d_depth = (float*)(base + b_kp);
+  int32_t* d_idx = (int32_t*)(base + b_kp + b_depth);
+  float4* d_xyz = (float4*)(base + b_kp + b_depth + b_idx);
+  int32_t* d_n = (int32_t*)(base + b_kp + b_depth + b_idx + b_xyz);
+  HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp_xy, (size_t)n_kp * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 4, hipMemcpyHostToDevice, ctx->stream));
+  // node.cpp:913-916: fxinv = float(1./fx) etc.
+  launch_project_to_3d(d_kp, n_kp, d_depth, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
+                       (float)cy, depth_scaling, max_keypoints, d_idx, d_xyz, d_n, ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(kept_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(xyz1, d_xyz, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *n_out = n;
+  return RGBDFE_OK;
+}
+
+int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->profiling = enable != 0;
+  return RGBDFE_OK;
+}
+
+int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t* launches,
+                           int64_t* pairs) {
+  if (!ctx || which < 0 || which >= RGBDFE_KERNEL_COUNT) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  // records are folded in at synchronisation points
+  if (total_ms) *total_ms = ctx->k_ms[which];
+  if (launches) *launches = ctx->k_launches[which];
+  if (pairs) *pairs = ctx->k_pairs[which];
+  return RGBDFE_OK;
+}
+
+int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  for (int i = 0; i < RGBDFE_KERNEL_COUNT; ++i) {
+    ctx->k_ms[i] = 0;
+    ctx->k_launches[i] = 0;
+    ctx->k_pairs[i] = 0;
+  }
+  return RGBDFE_OK;
+}
+
+int rgbdfe_sizeof_match_result(void) { return (int)sizeof(rgbdfe_match_result); }
+int rgbdfe_abi_version(void) { return 1; }
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// rgbdfe_internal.h -- shared between the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rgbdfe.h"
+
+namespace rgbdfe {
+
+// One (newer node, older node) pair as the kernels see it.  Node features live in
+// two slabs (descriptor slab: slot x max_kp x 32 B, xyz1 slab: slot x max_kp x 16 B);
+// a pair is a couple of slot indices plus the row counts.
+struct PairWork {
+  uint32_t q_slot, t_slot;  // slab slots of the newer (query) / older (train) node
+  uint32_t nq, nt;          // rows
+  uint32_t uid;             // RNG stream id of the pair (D1), from (qid, tid)
+  int32_t qid, tid;         // node ids (edge.id2 / edge.id1)
+  uint32_t pad;
+};
+static_assert(sizeof(PairWork) == 32, "PairWork layout");
+
+// "no neighbour": hd = 257, idx = 0xFFFF (features.cpp:172-173 -> (257,-1))
+constexpr uint32_t kNoMatchKey = (257u << 16) | 0xFFFFu;
+
+struct RansacConst {
+  int32_t max_matches, min_matches, ransac_iterations;
+  float max_dist_m;
+  double sq_max_dist;   // (double)(max_dist_m*max_dist_m)  node.cpp:1152
+  double depth_cov;     // D3
+  double raster_cov_x;  // misc.cpp:708
+  double raster_cov_y;  // misc.cpp:709
+  uint32_t seed;
+};
+
+// launchers (defined in the .hip files)
+void launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
+                       uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
+                       hipStream_t stream);
+void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
+                          rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
+                          const RansacConst& rc, hipStream_t stream);
+void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
+                          float fxinv, float fyinv, float cx, float cy, double depth_scaling,
+                          int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
+                          hipStream_t stream);
+
+}  // namespace rgbdfe

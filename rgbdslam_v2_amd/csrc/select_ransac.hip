@@ -1,0 +1,685 @@
+// select_ransac.hip -- per-pair match selection + RANSAC rigid-transform estimation (gfx950).
+//
+// Replaces, per (newer node, older node) pair:
+//   Node::featureMatching's `hd >= 128` gate + keepStrongestMatches     (node.cpp:572, 520-531, 674)
+//   Node::getRelativeTransformationTo (RANSAC driver)                   (node.cpp:1074-1277)
+//   sample_matches_prefer_by_distance                                   (node.cpp:1024-1047)
+//   getTransformFromMatches / pcl::TransformationFromCorrespondences    (transformation_estimation_euclidean.cpp:7-61)
+//   Node::computeInliersAndError + errorFunction2                       (node.cpp:968-1020, misc.cpp:697-770)
+//   Node::matchNodePair's result assembly                               (node.cpp:1305-1429)
+//
+// One wave64 per pair, no inter-wave synchronisation:
+//   * selection: counting sort of the (hd, queryIdx) keys in LDS -- histogram by hd,
+//     wave prefix scan, then a stable placement pass that ranks equal-hd lanes of a
+//     64-query chunk with __ballot bit-matching;
+//   * hypothesis generation: LANE = HYPOTHESIS.  64 RANSAC iterations' 4-point samples,
+//     weighted Kabsch fits and 3x3 Jacobi SVDs are computed at once, one per lane, for
+//     the instruction cost of one;
+//   * scoring: LANE = MATCH.  The 4x4 hypothesis is broadcast (v_readlane), every lane
+//     evaluates the double-precision Mahalanobis error of its <=5 matches, inlier sets
+//     are __ballot masks, the wave-uniform shortcut (misc.cpp:726-735) skips the
+//     Cholesky solve when no lane survives it;
+//   * the float/double operation order is the oracle's (oracle/rgbd_oracle.c), which
+//     restates the reference: sequential weighted-mean recurrence, sequential error
+//     sum.  Compiled with -ffp-contract=off the results are bit-identical to the CPU
+//     restatement, so every discrete RANSAC decision is too.
+#include <float.h>
+
+#include "rgbdfe_internal.h"
+
+namespace rgbdfe {
+
+constexpr int kWave = 64;
+constexpr int kRounds = RGBDFE_MAX_MATCHES / kWave;  // 5
+
+struct __attribute__((aligned(16))) RansacLds {
+  double e[RGBDFE_MAX_MATCHES];        // per-match squared Mahalanobis error (0 for non-inliers)
+  float P[RGBDFE_MAX_MATCHES * 3];     // newer node's points ("from"), match order
+  float Q[RGBDFE_MAX_MATCHES * 3];     // older node's points ("to")
+  uint32_t mqt[RGBDFE_MAX_MATCHES];    // queryIdx | trainIdx << 16
+  uint32_t mhd[RGBDFE_MAX_MATCHES];
+  uint32_t cnt[128];                   // hd histogram / running bin cursors
+};
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// D1: counter-based replacement of rand() (node.cpp:1033-1034); same integer function as
+// the oracle's orc_rand31.
+__device__ __forceinline__ uint32_t rand31(uint32_t seed_mixed_uid, uint32_t iter, uint32_t k) {
+  uint32_t h = mix32(seed_mixed_uid ^ (iter * 0xC2B2AE35u + 0x165667B1u));
+  h = mix32(h + k * 0x27D4EB2Fu);
+  return h >> 1;
+}
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {
+  // number of set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ float bcast_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---------------------------------------------------------------------------------
+// pcl::TransformationFromCorrespondences accumulator (float, sequential recurrence)
+// ---------------------------------------------------------------------------------
+struct Tfc {
+  float W;
+  float m1[3], m2[3];
+  float C[9];  // row-major C[i*3+j]
+  __device__ __forceinline__ void reset() {
+    W = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) m1[i] = m2[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) C[i] = 0.0f;
+  }
+  // transformation_estimation_euclidean.cpp:20-25,56 + tfc.add()
+  __device__ __forceinline__ void add(const float* __restrict__ P, const float* __restrict__ Q, int m) {
+    float f[3] = {P[m * 3 + 0], P[m * 3 + 1], P[m * 3 + 2]};
+    float t[3] = {Q[m * 3 + 0], Q[m * 3 + 1], Q[m * 3 + 2]};
+    if (__builtin_isnan(f[2]) || __builtin_isnan(t[2])) return;
+    // weight = 1.0/(from(2)*to(2)): double divide rounded to float == float divide
+    // (53 >= 2*24+2: double rounding is innocuous for division)
+    float w = 1.0f / (f[2] * t[2]);
+    if (w == 0.0f) return;
+    W += w;
+    float alpha = w / W;
+    float d1[3], d2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) d1[j] = f[j] - m1[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d2[i] = t[i] - m2[i];
+    float oma = 1.0f - alpha;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float outer = d2[i] * d1[j];
+        float scaled = alpha * outer;
+        float sum = C[i * 3 + j] + scaled;
+        C[i * 3 + j] = oma * sum;
+      }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m1[j] = m1[j] + alpha * d1[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) m2[i] = m2[i] + alpha * d2[i];
+  }
+};
+
+// ---------------------------------------------------------------------------------
+// 3x3 two-sided Jacobi SVD (Eigen::JacobiSVD<Matrix3f> as published), row-major.
+// Same operation order as the oracle's orc_svd3.
+// ---------------------------------------------------------------------------------
+template <int p, int q>
+__device__ __forceinline__ bool jacobi_pair(float* W, float* U, float* V, float& max_diag) {
+  const float precision = 2.0f * FLT_EPSILON;
+  float threshold = precision * max_diag;
+  if (FLT_MIN > threshold) threshold = FLT_MIN;
+  if (!(fabsf(W[p * 3 + q]) > threshold || fabsf(W[q * 3 + p]) > threshold)) return false;
+  float m00 = W[p * 3 + p], m01 = W[p * 3 + q], m10 = W[q * 3 + p], m11 = W[q * 3 + q];
+  float t = m00 + m11;
+  float d = m10 - m01;
+  float c1, s1;
+  if (fabsf(d) < FLT_MIN) {
+    c1 = 1.0f; s1 = 0.0f;
+  } else {
+    float u = t / d;
+    float tmp = sqrtf(1.0f + u * u);
+    s1 = 1.0f / tmp;
+    c1 = u / tmp;
+  }
+  float n00 = c1 * m00 + s1 * m10;
+  float n01 = c1 * m01 + s1 * m11;
+  float n11 = (-s1) * m01 + c1 * m11;
+  float cr, sr;
+  float deno = 2.0f * fabsf(n01);
+  if (deno < FLT_MIN) {
+    cr = 1.0f; sr = 0.0f;
+  } else {
+    float tau = (n00 - n11) / deno;
+    float w = sqrtf(tau * tau + 1.0f);
+    float tt = (tau > 0.0f) ? 1.0f / (tau + w) : 1.0f / (tau - w);
+    float sign_t = (tt > 0.0f) ? 1.0f : -1.0f;
+    float nn = 1.0f / sqrtf(tt * tt + 1.0f);
+    sr = -sign_t * (n01 / fabsf(n01)) * fabsf(tt) * nn;
+    cr = nn;
+  }
+  float cl = c1 * cr + s1 * sr;
+  float sl = s1 * cr - c1 * sr;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float x = W[p * 3 + k], y = W[q * 3 + k];
+    W[p * 3 + k] = cl * x + sl * y;
+    W[q * 3 + k] = (-sl) * x + cl * y;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float x = U[k * 3 + p], y = U[k * 3 + q];
+    U[k * 3 + p] = cl * x + sl * y;
+    U[k * 3 + q] = (-sl) * x + cl * y;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float x = W[k * 3 + p], y = W[k * 3 + q];
+    W[k * 3 + p] = cr * x - sr * y;
+    W[k * 3 + q] = sr * x + cr * y;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float x = V[k * 3 + p], y = V[k * 3 + q];
+    V[k * 3 + p] = cr * x - sr * y;
+    V[k * 3 + q] = sr * x + cr * y;
+  }
+  float a = fabsf(W[p * 3 + p]), b = fabsf(W[q * 3 + q]);
+  if (b > a) a = b;
+  if (a > max_diag) max_diag = a;
+  return true;
+}
+
+template <int a, int b>
+__device__ __forceinline__ void swap_cols(float* S, float* U, float* V) {
+  float ts = S[a]; S[a] = S[b]; S[b] = ts;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float tu = U[k * 3 + a]; U[k * 3 + a] = U[k * 3 + b]; U[k * 3 + b] = tu;
+    float tv = V[k * 3 + a]; V[k * 3 + a] = V[k * 3 + b]; V[k * 3 + b] = tv;
+  }
+}
+
+__device__ __forceinline__ float det3(const float* m) {
+  float h0 = m[0] * (m[4] * m[8] - m[5] * m[7]);
+  float h1 = m[1] * (m[3] * m[8] - m[5] * m[6]);
+  float h2 = m[2] * (m[3] * m[7] - m[4] * m[6]);
+  return h0 - h1 + h2;
+}
+
+// tfc.getTransformation(): R (row-major 9) and t (3)
+__device__ __forceinline__ void tfc_get_transformation(const Tfc& s, float* R, float* tr) {
+  float W[9], U[9], V[9], S[3];
+  float scale = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    float a = fabsf(s.C[i]);
+    if (a > scale) scale = a;
+  }
+  if (scale == 0.0f) scale = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) W[i] = s.C[i] / scale;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) U[i] = V[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+  float max_diag = fabsf(W[0]);
+  if (fabsf(W[4]) > max_diag) max_diag = fabsf(W[4]);
+  if (fabsf(W[8]) > max_diag) max_diag = fabsf(W[8]);
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    bool any = false;
+    any |= jacobi_pair<1, 0>(W, U, V, max_diag);
+    any |= jacobi_pair<2, 0>(W, U, V, max_diag);
+    any |= jacobi_pair<2, 1>(W, U, V, max_diag);
+    if (!any) break;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float w = W[i * 3 + i];
+    S[i] = fabsf(w);
+    if (w < 0.0f) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) U[k * 3 + i] = -U[k * 3 + i];
+    }
+    S[i] = S[i] * scale;
+  }
+  // selection sort, descending, first maximum wins; stop at an all-zero tail
+  {
+    int pos = 0;
+    float best = S[0];
+    if (S[1] > best) { best = S[1]; pos = 1; }
+    if (S[2] > best) { best = S[2]; pos = 2; }
+    if (best != 0.0f) {
+      if (pos == 1) swap_cols<0, 1>(S, U, V);
+      if (pos == 2) swap_cols<0, 2>(S, U, V);
+      if (S[2] > S[1]) {  // i = 1: best = S[2] != 0 here since S[2] > S[1] >= 0
+        swap_cols<1, 2>(S, U, V);
+      }
+    }
+  }
+  float s22 = 1.0f;
+  if (det3(U) * det3(V) < 0.0f) s22 = -1.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float us2 = U[i * 3 + 2] * s22;
+      R[i * 3 + j] = (U[i * 3 + 0] * V[j * 3 + 0] + U[i * 3 + 1] * V[j * 3 + 1]) + us2 * V[j * 3 + 2];
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float rm = (R[i * 3 + 0] * s.m1[0] + R[i * 3 + 1] * s.m1[1]) + R[i * 3 + 2] * s.m1[2];
+    tr[i] = s.m2[i] - rm;
+  }
+}
+
+__device__ __forceinline__ bool has_nan12(const float* R, const float* t) {
+  bool n = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) n |= (R[i] != R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) n |= (t[i] != t[i]);
+  return n;
+}
+
+// ---------------------------------------------------------------------------------
+// computeInliersAndError (node.cpp:968-1020) with errorFunction2 (misc.cpp:697-770).
+// LANE = MATCH.  R,t are wave-uniform.  Returns inlier masks, count and rms error.
+// ---------------------------------------------------------------------------------
+struct PointRegs {
+  float px[kRounds], py[kRounds], pz[kRounds];
+  float qx[kRounds], qy[kRounds], qz[kRounds];
+};
+
+__device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, const PointRegs& pts,
+                                                 int n_all, const RansacConst& rc, RansacLds& lds,
+                                                 uint64_t* mask, int& n_inl, double& err) {
+  const int lane = threadIdx.x;
+  double Rd[9], td[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rd[i] = (double)R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) td[i] = (double)tr[i];
+  const double rcx = rc.raster_cov_x, rcy = rc.raster_cov_y, dc = rc.depth_cov;
+  const double smax = rcx > dc ? rcx : dc;
+  const double shortcut = 2.0 * (smax + smax);
+  n_inl = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int m = r * kWave + lane;
+    const bool active = m < n_all;
+    const float pzf = pts.pz[r], qzf = pts.qz[r];
+    // node.cpp:994 (z == 0 skip) ; misc.cpp:712-717 (NaN -> DBL_MAX)
+    bool cand = active && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
+    const double a0 = (double)pts.px[r], a1 = (double)pts.py[r], a2 = (double)pzf;
+    const double b0 = (double)pts.qx[r], b1 = (double)pts.qy[r], b2 = (double)qzf;
+    // mu_1_in_frame_2 = (T * x1).head<3>() with x1.w == 1 (misc.cpp:724)
+    double d[3];
+    {
+      double m0 = ((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0];
+      double m1 = ((Rd[3] * a0 + Rd[4] * a1) + Rd[5] * a2) + td[1];
+      double m2 = ((Rd[6] * a0 + Rd[7] * a1) + Rd[8] * a2) + td[2];
+      d[0] = m0 - b0; d[1] = m1 - b1; d[2] = m2 - b2;
+    }
+    const double dsq = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+    cand = cand && !(dsq > shortcut) && !__builtin_isnan(d[2]);  // misc.cpp:731, 755
+    double e = DBL_MAX;
+    if (__ballot(cand) != 0ull) {  // wave-uniform: skip the solve when nobody survives
+      if (cand) {
+        const double c1[3] = {rcx * a2, rcy * a2, dc};
+        const double c2[3] = {rcx * b2, rcy * b2, dc};
+        // S = R^T * cov1 * R + cov2 (misc.cpp:751,760), lower triangle only.
+        // S(i,j) = (R(0,i)c1_0*R(0,j) + R(1,i)c1_1*R(1,j)) + R(2,i)c1_2*R(2,j)
+        double A[9];  // A[i*3+k] = R(k,i) * c1_k
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) A[i * 3 + k] = Rd[k * 3 + i] * c1[k];
+        double S00 = ((A[0] * Rd[0] + A[1] * Rd[3]) + A[2] * Rd[6]) + c2[0];
+        double S10 = (A[3] * Rd[0] + A[4] * Rd[3]) + A[5] * Rd[6];
+        double S11 = ((A[3] * Rd[1] + A[4] * Rd[4]) + A[5] * Rd[7]) + c2[1];
+        double S20 = (A[6] * Rd[0] + A[7] * Rd[3]) + A[8] * Rd[6];
+        double S21 = (A[6] * Rd[1] + A[7] * Rd[4]) + A[8] * Rd[7];
+        double S22 = ((A[6] * Rd[2] + A[7] * Rd[5]) + A[8] * Rd[8]) + c2[2];
+        // LLT (misc.cpp:763), D5: non-positive pivot -> DBL_MAX
+        bool ok = S00 > 0.0;
+        double l00 = sqrt(S00);
+        double l10 = S10 / l00;
+        double l20 = S20 / l00;
+        double x1 = S11 - l10 * l10;
+        ok = ok && (x1 > 0.0);
+        double l11 = sqrt(x1);
+        double l21 = (S21 - l20 * l10) / l11;
+        double x2 = S22 - (l20 * l20 + l21 * l21);
+        ok = ok && (x2 > 0.0);
+        double l22 = sqrt(x2);
+        double y0 = d[0] / l00;
+        double y1 = (d[1] - l10 * y0) / l11;
+        double y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
+        double z2 = y2 / l22;
+        double z1 = (y1 - l21 * z2) / l11;
+        double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
+        double ee = (d[0] * z0 + d[1] * z1) + d[2] * z2;
+        if (ok && (ee >= 0.0)) e = ee;  // misc.cpp:765-768
+      }
+    }
+    const bool inl = cand && !(e > rc.sq_max_dist) && (e >= 0.0);  // node.cpp:998,1001
+    mask[r] = __ballot(inl);
+    n_inl += __popcll(mask[r]);
+    lds.e[m] = inl ? e : 0.0;  // +0.0 terms leave the sequential sum bit-identical
+  }
+  __syncthreads();
+  // mean_error += mahal_dist in match order (node.cpp:1006): strictly sequential double sum
+  double sum = 0.0;
+  const int n4 = n_all & ~3;
+  int m = 0;
+  for (; m < n4; m += 4) {
+    double e0 = lds.e[m], e1 = lds.e[m + 1], e2 = lds.e[m + 2], e3 = lds.e[m + 3];
+    sum += e0; sum += e1; sum += e2; sum += e3;
+  }
+  for (; m < n_all; ++m) sum += lds.e[m];
+  __syncthreads();
+  if (n_inl < 3) {
+    err = 1e9;  // node.cpp:1012-1014
+  } else {
+    err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
+  }
+}
+
+__device__ __forceinline__ int mask_count(const uint64_t* m) {
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) n += __popcll(m[r]);
+  return n;
+}
+
+__global__ __launch_bounds__(kWave) void select_ransac_kernel(
+    const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
+    const uint32_t* __restrict__ keys, rgbdfe_match_result* __restrict__ results,
+    uint32_t max_kp, uint32_t n_pairs, const RansacConst rc) {
+  __shared__ RansacLds lds;
+  const uint32_t pair = blockIdx.x;
+  if (pair >= n_pairs) return;
+  const int lane = threadIdx.x;
+  const PairWork w = work[pair];
+  const uint32_t nq = w.nq;
+  const uint32_t* __restrict__ kin = keys + (size_t)pair * max_kp;
+  rgbdfe_match_result* __restrict__ out = results + pair;
+  const int max_matches = rc.max_matches;
+
+  // ------------------------------------------------------------------ selection
+  lds.cnt[lane] = 0;
+  lds.cnt[lane + 64] = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nq; base += kWave) {
+    const uint32_t i = base + lane;
+    if (i < nq) {
+      const uint32_t hd = kin[i] >> 16;
+      if (hd < 128u) atomicAdd(&lds.cnt[hd], 1u);  // node.cpp:572
+    }
+  }
+  __syncthreads();
+  uint32_t total;
+  uint32_t cut_hd;  // bins >= cut_hd start at or beyond max_matches: never selected
+  {
+    const uint32_t a = lds.cnt[2 * lane], b = lds.cnt[2 * lane + 1];
+    uint32_t incl = a + b;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      uint32_t v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    const uint32_t excl = incl - (a + b);
+    total = __builtin_amdgcn_readlane(incl, 63);
+    const uint32_t s0 = excl, s1 = excl + a;
+    uint32_t c = 128u;
+    if (s1 >= (uint32_t)max_matches) c = 2 * lane + 1;
+    if (s0 >= (uint32_t)max_matches) c = 2 * lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c = min(c, (uint32_t)__shfl_xor(c, off));
+    cut_hd = c;
+    __syncthreads();
+    lds.cnt[2 * lane] = s0;
+    lds.cnt[2 * lane + 1] = s1;
+  }
+  __syncthreads();
+  const int n_all = (int)min(total, (uint32_t)max_matches);
+  // stable placement: (hd, queryIdx) order == D2's deterministic tie-break
+  for (uint32_t base = 0; base < nq; base += kWave) {
+    const uint32_t i = base + lane;
+    uint32_t key = i < nq ? kin[i] : 0xFFFFFFFFu;
+    const uint32_t hd = key >> 16;
+    const bool valid = hd < cut_hd;
+    uint64_t same = __ballot(valid);
+    if (same == 0ull) continue;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      const bool bit = (hd >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const uint32_t rank = lane_rank(same);
+    const uint32_t cnt_same = __popcll(same);
+    uint32_t pos = 0;
+    if (valid) pos = lds.cnt[hd] + rank;
+    __syncthreads();
+    if (valid && rank == 0) lds.cnt[hd] = pos + cnt_same;
+    if (valid && pos < (uint32_t)max_matches) {
+      lds.mqt[pos] = i | ((key & 0xFFFFu) << 16);
+      lds.mhd[pos] = hd;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+
+  // ------------------------------------------------- matched 3-D points -> regs + LDS
+  PointRegs pts;
+  const float4* __restrict__ qxyz = xyz_pool + (size_t)w.q_slot * max_kp;
+  const float4* __restrict__ txyz = xyz_pool + (size_t)w.t_slot * max_kp;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int m = r * kWave + lane;
+    float4 p = make_float4(0.f, 0.f, 0.f, 1.f), q = make_float4(0.f, 0.f, 0.f, 1.f);
+    uint32_t qt = 0, hd = 0;
+    if (m < n_all) {
+      qt = lds.mqt[m];
+      hd = lds.mhd[m];
+      p = qxyz[qt & 0xFFFFu];
+      q = txyz[qt >> 16];
+    }
+    pts.px[r] = p.x; pts.py[r] = p.y; pts.pz[r] = p.z;
+    pts.qx[r] = q.x; pts.qy[r] = q.y; pts.qz[r] = q.z;
+    lds.P[m * 3 + 0] = p.x; lds.P[m * 3 + 1] = p.y; lds.P[m * 3 + 2] = p.z;
+    lds.Q[m * 3 + 0] = q.x; lds.Q[m * 3 + 1] = q.y; lds.Q[m * 3 + 2] = q.z;
+    out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
+    out->all_t[m] = (uint16_t)(qt >> 16);
+    out->all_hd[m] = (uint8_t)hd;
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ RANSAC
+  // results (wave-uniform)
+  float bestR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bestt[3] = {0, 0, 0};
+  uint64_t best_mask[kRounds] = {0, 0, 0, 0, 0};
+  int best_n = 0;
+  float rmse = 0.0f;  // MatchingResult() default (matching_result.h:27)
+  int valid_iterations = 0, real_iterations = 0;
+  bool found = false;
+
+  // matchNodePair: `all_matches.size() < min_matches` -> no RANSAC (node.cpp:1319);
+  // getRelativeTransformationTo: `size <= min_matches` -> false      (node.cpp:1087)
+  if (n_all >= rc.min_matches && n_all > rc.min_matches) {
+    uint32_t thr = (uint32_t)rc.min_matches;                                  // :1094
+    if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
+    const double max_dist_d = (double)rc.max_dist_m;
+    rmse = 1e6f;  // :1112
+    const uint32_t seed_uid = mix32(mix32(rc.seed ^ 0x9E3779B9u) + w.uid * 0x85EBCA6Bu);
+
+    float hypR[9], hypt[3];
+    bool hyp_nan = true;
+    int hyp_base = -kWave;  // iteration index of lane 0's hypothesis
+
+    for (int it = 0; it < rc.ransac_iterations && n_all >= 4; ++it) {  // :1130
+      const int k = real_iterations;
+      if (k - hyp_base >= kWave) {
+        // ---- LANE = HYPOTHESIS: sample + 4-point fit for iterations k .. k+63
+        hyp_base = k;
+        const uint32_t iter = (uint32_t)(k + lane);
+        uint32_t ids[4] = {0, 0, 0, 0};
+        int cnt = 0;
+        {
+          // sample_matches_prefer_by_distance (node.cpp:1024-1047): ascending std::set of 4 ids
+          int safety_net = 0;
+          uint32_t kk = 0;
+          const uint32_t n = (uint32_t)n_all;
+          while (cnt < 4) {
+            uint32_t id1 = rand31(seed_uid, iter, kk) % n;
+            uint32_t id2 = rand31(seed_uid, iter, kk + 1) % n;
+            kk += 2;
+            if (id1 > id2) id1 = id2;
+            const bool dup = (cnt > 0 && ids[0] == id1) || (cnt > 1 && ids[1] == id1) ||
+                             (cnt > 2 && ids[2] == id1);
+            if (!dup) {
+              // sorted insert
+              uint32_t v = id1;
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                if (s < cnt) {
+                  if (ids[s] > v) { uint32_t tmp = ids[s]; ids[s] = v; v = tmp; }
+                } else if (s == cnt) {
+                  ids[s] = v;
+                }
+              }
+              ++cnt;
+            }
+            if (++safety_net > 10000) break;
+          }
+        }
+        Tfc acc;
+        acc.reset();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (s < cnt) acc.add(lds.P, lds.Q, (int)ids[s]);
+        tfc_get_transformation(acc, hypR, hypt);
+        hyp_nan = has_nan12(hypR, hypt);
+      }
+      const int hl = k - hyp_base;
+      real_iterations++;  // :1139
+
+      double refined_error = 1e6;  // :1133
+      int refined_n = 0;
+      float refR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, reft[3] = {0, 0, 0};
+      uint64_t ref_mask[kRounds] = {0, 0, 0, 0, 0};
+      uint64_t inl_mask[kRounds];
+
+      float curR[9], curt[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) curR[i] = bcast_f(hypR[i], hl);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) curt[i] = bcast_f(hypt[i], hl);
+      bool cur_nan = (__builtin_amdgcn_readlane((int)hyp_nan, hl) != 0);
+
+      for (int refinements = 1; refinements < 20; ++refinements) {  // :1140
+        if (refinements > 1) {
+          // getTransformFromMatches over the current inlier set, in match order (:1142)
+          Tfc acc;
+          acc.reset();
+#pragma unroll
+          for (int r = 0; r < kRounds; ++r) {
+            uint64_t mm = inl_mask[r];
+            while (mm) {
+              const int b = __builtin_ctzll(mm);
+              mm &= mm - 1;
+              acc.add(lds.P, lds.Q, r * kWave + b);
+            }
+          }
+          tfc_get_transformation(acc, curR, curt);
+          cur_nan = has_nan12(curR, curt);
+        }
+        if (cur_nan) break;  // :1144
+        int n_inl;
+        double inlier_error;
+        score_hypothesis(curR, curt, pts, n_all, rc, lds, inl_mask, n_inl, inlier_error);  // :1148
+        if ((uint32_t)n_inl < thr || inlier_error > max_dist_d) break;              // :1154
+        if (n_inl >= refined_n && inlier_error <= refined_error) {                   // :1160
+          const int prev = refined_n;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) refR[i] = curR[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) reft[i] = curt[i];
+#pragma unroll
+          for (int r = 0; r < kRounds; ++r) ref_mask[r] = inl_mask[r];
+          refined_n = n_inl;
+          refined_error = inlier_error;
+          if (n_inl == prev) break;  // :1166
+        } else {
+          break;
+        }
+      }
+      if (refined_n > 0) {  // :1171
+        valid_iterations++;
+        if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
+          rmse = (float)refined_error;  // :1182
+#pragma unroll
+          for (int i = 0; i < 9; ++i) bestR[i] = refR[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) bestt[i] = reft[i];
+#pragma unroll
+          for (int r = 0; r < kRounds; ++r) best_mask[r] = ref_mask[r];
+          best_n = refined_n;
+          if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
+          if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
+          if ((double)refined_n > (double)n_all * 0.8) break;      // :1188
+        }
+      }
+    }
+    if (valid_iterations == 0) {  // :1192 identity hypothesis
+      const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, It[3] = {0, 0, 0};
+      uint64_t inl_mask[kRounds];
+      int n_inl;
+      double inlier_error;
+      score_hypothesis(IR, It, pts, n_all, rc, lds, inl_mask, n_inl, inlier_error);
+      if ((uint32_t)n_inl > thr && inlier_error < max_dist_d) {  // :1206
+#pragma unroll
+        for (int i = 0; i < 9; ++i) bestR[i] = IR[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bestt[i] = It[i];
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) best_mask[r] = inl_mask[r];
+        best_n = n_inl;
+        rmse = (float)inlier_error;
+        valid_iterations++;
+      }
+    }
+    found = (uint32_t)best_n >= thr;  // :1275
+  }
+
+  // ------------------------------------------------------------------ result POD
+  if (lane == 0) {
+    out->n_all = n_all;
+    out->n_inl = best_n;
+    out->rmse = rmse;
+    // Eigen::Matrix4f column-major
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) out->trafo[j * 4 + i] = bestR[i * 3 + j];
+      out->trafo[12 + i] = bestt[i];
+      out->trafo[i * 4 + 3] = 0.0f;
+    }
+    out->trafo[15] = 1.0f;
+    out->pad0 = 0;
+    out->valid_iterations = valid_iterations;
+    out->real_iterations = real_iterations;
+    if (found) {
+      out->id1 = w.tid;  // node.cpp:1337
+      out->id2 = w.qid;  // node.cpp:1338
+      out->info_scale = (double)((float)best_n / (rmse * rmse));  // node.cpp:1335
+    } else {
+      out->id1 = -1;  // node.cpp:1419-1422
+      out->id2 = -1;
+      out->info_scale = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) out->inlier_mask[r] = best_mask[r];
+  }
+}
+
+void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
+                          rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
+                          const RansacConst& rc, hipStream_t stream) {
+  if (n_pairs == 0) return;
+  hipLaunchKernelGGL(select_ransac_kernel, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work,
+                     keys, results, max_kp, n_pairs, rc);
+}
+
+}  // namespace rgbdfe

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's front-end interface over the C ABI.
+
+The reference's seam is a set of C++ methods (there is no FFI):
+``Node::matchNodePair`` (src/node.h:85), ``Node::featureMatching`` (:117),
+``Node::getRelativeTransformationTo`` (:102), ``bruteForceSearchORB``
+(src/features.h:14) and ``GraphManager::nodeComparisons``'s
+``QtConcurrent::blockingMapped`` fan-out (src/graph_manager.cpp:541-548).
+This module keeps those names and argument meanings so the parity tests read
+like tests of the reference; all arithmetic happens in librgbdfe.so on the GPU.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import RESULT_DTYPE, RgbdfeConfig, RgbdfeError, RgbdfeParams
+
+
+@dataclass
+class DMatch:
+    """cv::DMatch as the reference fills it (node.cpp:573): distance = hd/256 (jitter dropped)."""
+    queryIdx: int
+    trainIdx: int
+    distance: float
+
+
+@dataclass
+class LoadedEdge3D:
+    """src/edge.h:24-32"""
+    id1: int = -1
+    id2: int = -1
+    transform: np.ndarray = field(default_factory=lambda: np.eye(4))
+    informationMatrix: np.ndarray = field(default_factory=lambda: np.zeros((6, 6)))
+
+
+@dataclass
+class MatchingResult:
+    """src/matching_result.h:24-46"""
+    inlier_matches: List[DMatch] = field(default_factory=list)
+    all_matches: List[DMatch] = field(default_factory=list)
+    edge: LoadedEdge3D = field(default_factory=LoadedEdge3D)
+    rmse: float = 0.0
+    ransac_trafo: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    final_trafo: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    valid_iterations: int = 0
+    real_iterations: int = 0
+
+
+def inlier_indices(rec) -> np.ndarray:
+    """Positions (into all_*) of the inlier matches of one RESULT_DTYPE record."""
+    bits = np.unpackbits(np.asarray(rec["inlier_mask"]).view(np.uint8), bitorder="little")
+    return np.flatnonzero(bits[: int(rec["n_all"])]).astype(np.int32)
+
+
+def record_to_matching_result(rec) -> MatchingResult:
+    n_all = int(rec["n_all"])
+    q = rec["all_q"][:n_all].astype(np.int32)
+    t = rec["all_t"][:n_all].astype(np.int32)
+    d = rec["all_hd"][:n_all].astype(np.float32) / np.float32(256.0)
+    all_matches = [DMatch(int(a), int(b), float(c)) for a, b, c in zip(q, t, d)]
+    inl = inlier_indices(rec)
+    T = np.array(rec["trafo"], np.float32).reshape(4, 4).T.copy()  # column-major storage
+    mr = MatchingResult(all_matches=all_matches, inlier_matches=[all_matches[i] for i in inl],
+                        rmse=float(rec["rmse"]), ransac_trafo=T, final_trafo=T.copy(),
+                        valid_iterations=int(rec["valid_iterations"]),
+                        real_iterations=int(rec["real_iterations"]))
+    mr.edge.id1, mr.edge.id2 = int(rec["id1"]), int(rec["id2"])
+    if mr.edge.id1 >= 0:
+        mr.edge.transform = T.astype(np.float64)                        # node.cpp:1339
+        mr.edge.informationMatrix = np.eye(6) * float(rec["info_scale"])  # node.cpp:1335
+    return mr
+
+
+class FrontEnd:
+    """One rgbdfe context = one GPU: resident node features + the batched pair op."""
+
+    def __init__(self, device_id: int = 0, max_nodes: int = 256, max_keypoints: int = 1024,
+                 max_pairs_per_batch: int = 4096, **params):
+        self._L = _lib.load()
+        cfg = RgbdfeConfig()
+        self._L.rgbdfe_default_config(C.byref(cfg))
+        cfg.device_id = device_id
+        cfg.max_nodes = max_nodes
+        cfg.max_keypoints = max_keypoints
+        cfg.max_pairs_per_batch = max_pairs_per_batch
+        for k, v in params.items():
+            if not hasattr(cfg.params, k):
+                raise TypeError(f"unknown front-end parameter {k!r}")
+            setattr(cfg.params, k, v)
+        self.cfg = cfg
+        self._ctx = C.c_void_p()
+        st = self._L.rgbdfe_create(C.byref(cfg), C.byref(self._ctx))
+        if st != 0:
+            self._ctx = C.c_void_p()
+            raise RgbdfeError(f"rgbdfe_create failed: {self._L.rgbdfe_status_string(st).decode()}")
+
+    # -- plumbing --------------------------------------------------------------
+    def _check(self, st):
+        if st != 0:
+            msg = self._L.rgbdfe_last_error(self._ctx).decode()
+            raise RgbdfeError(f"{self._L.rgbdfe_status_string(st).decode()}: {msg}")
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.rgbdfe_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def params(self) -> RgbdfeParams:
+        return self.cfg.params
+
+    def set_params(self, **params):
+        for k, v in params.items():
+            setattr(self.cfg.params, k, v)
+        self._check(self._L.rgbdfe_set_params(self._ctx, C.byref(self.cfg.params)))
+
+    # -- node residency ----------------------------------------------------------
+    def upload_node(self, node_id: int, desc: np.ndarray, xyz1: np.ndarray):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        xyz1 = np.ascontiguousarray(xyz1, np.float32)
+        n = desc.shape[0]
+        if desc.ndim != 2 or desc.shape[1] != 32 or xyz1.shape != (n, 4):
+            raise ValueError("desc must be [n,32] uint8 and xyz1 [n,4] float32")
+        self._check(self._L.rgbdfe_upload_node(self._ctx, node_id, desc.ctypes.data,
+                                               xyz1.ctypes.data, n))
+
+    def upload_node_device(self, node_id: int, d_desc_ptr: int, d_xyz1_ptr: int, n: int,
+                           stream: Optional[int] = None):
+        self._check(self._L.rgbdfe_upload_node_device(self._ctx, node_id, d_desc_ptr, d_xyz1_ptr,
+                                                      n, stream))
+
+    def release_node(self, node_id: int):
+        self._check(self._L.rgbdfe_release_node(self._ctx, node_id))
+
+    def node_count(self, node_id: int) -> int:
+        return self._L.rgbdfe_node_count(self._ctx, node_id)
+
+    # -- the pair op ---------------------------------------------------------------
+    def match_pair_list(self, query_ids: Sequence[int], train_ids: Sequence[int]) -> np.ndarray:
+        """Batched Node::matchNodePair; returns a RESULT_DTYPE array (one record per pair)."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        if q.shape != t.shape or q.ndim != 1:
+            raise ValueError("query_ids / train_ids must be 1-D and of equal length")
+        out = np.zeros(q.shape[0], RESULT_DTYPE)
+        self._check(self._L.rgbdfe_match_pair_list(self._ctx, q.ctypes.data, t.ctypes.data,
+                                                   q.shape[0], out.ctypes.data))
+        return out
+
+    def match_node_pairs(self, new_node_id: int, candidate_ids: Sequence[int]) -> np.ndarray:
+        """1:1 replacement of blockingMapped(nodes_to_comp, matchNodePair) (graph_manager.cpp:548)."""
+        c = np.ascontiguousarray(candidate_ids, np.int32)
+        out = np.zeros(c.shape[0], RESULT_DTYPE)
+        self._check(self._L.rgbdfe_match_node_pairs(self._ctx, new_node_id, c.ctypes.data,
+                                                    c.shape[0], out.ctypes.data))
+        return out
+
+    def match_pair_list_device(self, query_ids: np.ndarray, train_ids: np.ndarray,
+                               d_out_ptr: int, stream: Optional[int] = None):
+        """Asynchronous variant: results stay in HBM at d_out_ptr (n x sizeof(result))."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        self._check(self._L.rgbdfe_match_pair_list_device(self._ctx, q.ctypes.data, t.ctypes.data,
+                                                          q.shape[0], d_out_ptr, stream))
+
+    def synchronize(self):
+        self._check(self._L.rgbdfe_synchronize(self._ctx))
+
+    # -- pieces -----------------------------------------------------------------------
+    def hamming_nn_nodes(self, query_id: int, train_id: int):
+        n = self.node_count(query_id)
+        if n < 0:
+            raise RgbdfeError("unknown node id")
+        hd = np.empty(n, np.int32)
+        idx = np.empty(n, np.int32)
+        self._check(self._L.rgbdfe_hamming_nn_nodes(self._ctx, query_id, train_id,
+                                                    hd.ctypes.data, idx.ctypes.data))
+        return hd, idx
+
+    def bruteForceSearchORB_batch(self, qdesc: np.ndarray, tdesc: np.ndarray):
+        """Every row of qdesc through bruteForceSearchORB(row, tdesc, len(tdesc)) (features.h:14)."""
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        tdesc = np.ascontiguousarray(tdesc, np.uint8)
+        hd = np.empty(qdesc.shape[0], np.int32)
+        idx = np.empty(qdesc.shape[0], np.int32)
+        self._check(self._L.rgbdfe_hamming_nn_host(self._ctx, qdesc.ctypes.data, qdesc.shape[0],
+                                                   tdesc.ctypes.data, tdesc.shape[0],
+                                                   hd.ctypes.data, idx.ctypes.data))
+        return hd, idx
+
+    def project_to_3d(self, kp_xy, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000):
+        """removeDepthless + projectTo3D (node.cpp:67-97, 900-965)."""
+        kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+        depth = np.ascontiguousarray(depth, np.float32)
+        n = kp_xy.shape[0]
+        kept = np.empty(max(n, 1), np.int32)
+        xyz1 = np.empty((max(n, 1), 4), np.float32)
+        n_out = C.c_int32(0)
+        self._check(self._L.rgbdfe_project_to_3d(
+            self._ctx, kp_xy.ctypes.data, n, depth.ctypes.data, depth.shape[0], depth.shape[1],
+            fx, fy, cx, cy, depth_scaling, max_keypoints, kept.ctypes.data, xyz1.ctypes.data,
+            C.byref(n_out)))
+        return kept[: n_out.value].copy(), xyz1[: n_out.value].copy()
+
+    # -- measurement ----------------------------------------------------------------------
+    def set_profiling(self, enable: bool):
+        self._check(self._L.rgbdfe_set_profiling(self._ctx, int(enable)))
+
+    def reset_kernel_time(self):
+        self._check(self._L.rgbdfe_reset_kernel_time(self._ctx))
+
+    def kernel_time(self, which: int):
+        ms, n, p = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._L.rgbdfe_get_kernel_time(self._ctx, which, C.byref(ms), C.byref(n),
+                                                   C.byref(p)))
+        return ms.value, n.value, p.value
+
+
+class Node:
+    """The slice of the reference's Node (src/node.h) that the pair path touches."""
+
+    def __init__(self, frontend: FrontEnd, node_id: int, feature_descriptors: np.ndarray,
+                 feature_locations_3d: np.ndarray):
+        self.frontend = frontend
+        self.id_ = node_id
+        self.feature_descriptors_ = np.ascontiguousarray(feature_descriptors, np.uint8)
+        self.feature_locations_3d_ = np.ascontiguousarray(feature_locations_3d, np.float32)
+        self.matchable_ = True
+        frontend.upload_node(node_id, self.feature_descriptors_, self.feature_locations_3d_)
+
+    def matchNodePair(self, older_node: "Node") -> MatchingResult:
+        """src/node.cpp:1305-1429"""
+        rec = self.frontend.match_node_pairs(self.id_, [older_node.id_])[0]
+        return record_to_matching_result(rec)
+
+    def featureMatching(self, other: "Node") -> List[DMatch]:
+        """ORB branch of src/node.cpp:535-690 (matches sorted by (hd, queryIdx))."""
+        rec = self.frontend.match_node_pairs(self.id_, [other.id_])[0]
+        return record_to_matching_result(rec).all_matches
+
+    def clearFeatureInformation(self):
+        """src/node.cpp:1431-1443"""
+        self.frontend.release_node(self.id_)
+        self.matchable_ = False
+
+
+class GraphManager:
+    """Only the fan-out of GraphManager::nodeComparisons (src/graph_manager.cpp:531-583)."""
+
+    def __init__(self, frontend: FrontEnd):
+        self.frontend = frontend
+
+    def nodeComparisons(self, new_node: Node, nodes_to_comp: Sequence[Node]) -> List[MatchingResult]:
+        recs = self.frontend.match_node_pairs(new_node.id_, [n.id_ for n in nodes_to_comp])
+        return [record_to_matching_result(r) for r in recs]

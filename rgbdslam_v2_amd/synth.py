@@ -1,0 +1,131 @@
+"""Seeded synthetic RGB-D front-end data ("Level A").
+
+A world of 3-D points with random 256-bit descriptors is observed from a smooth
+camera trajectory.  Every frame holds exactly ``n_kp`` keypoints: observed world
+points (descriptor bits flipped independently per observation, pixel + depth
+noise, back-projected exactly like Node::projectTo3D does, node.cpp:900-965)
+padded with outliers (random descriptors at random places).  Used by the tests
+(small sizes) and by bench.py (BASELINE.json configs[1]: 640x480, ORB 1000 kp,
+20 candidate pairs per frame).
+"""
+import numpy as np
+
+FX = FY = 525.0
+CX, CY = 319.5, 239.5
+WIDTH, HEIGHT = 640, 480
+
+
+def _rot(rx, ry, rz):
+    cx, sx = np.cos(rx), np.sin(rx)
+    cy, sy = np.cos(ry), np.sin(ry)
+    cz, sz = np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def make_sequence(n_frames=200, n_kp=1000, n_world=4000, seed=20260923, bitflip=0.08,
+                  true_fraction=0.75, depth_noise=0.002, pixel_noise=0.3, nan_fraction=0.0,
+                  width=WIDTH, height=HEIGHT, motion_scale=1.0):
+    """Returns dict(desc uint8 [F,N,32], xyz1 float32 [F,N,4], poses float64 [F,4,4]
+    (camera-to-world), world_id int32 [F,N] (-1 = outlier))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    fx, fy = FX * width / WIDTH, FY * height / HEIGHT
+    cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
+    world = np.empty((n_world, 3))
+    world[:, 0] = rng.uniform(-2.0, 2.0, n_world)
+    world[:, 1] = rng.uniform(-1.5, 1.5, n_world)
+    world[:, 2] = rng.uniform(0.8, 4.0, n_world)
+    wdesc = rng.integers(0, 256, size=(n_world, 32), dtype=np.uint8)
+    # detector repeatability: every world point has a fixed "response"; a frame keeps the
+    # strongest visible ones (cv::KeyPointsFilter::retainBest, node.cpp:187-191), with a
+    # little per-frame jitter.
+    response = rng.random(n_world)
+
+    # smooth bounded trajectory: <= ~5 cm and <= ~3 deg between consecutive frames
+    f = np.arange(n_frames)
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    w = 2 * np.pi / 140.0
+    tx = 0.55 * motion_scale * np.sin(w * f + ph[0])
+    ty = 0.30 * motion_scale * np.sin(0.7 * w * f + ph[1])
+    tz = 0.25 * motion_scale * np.sin(1.3 * w * f + ph[2])
+    rx = np.deg2rad(6.0) * motion_scale * np.sin(0.9 * w * f + ph[3])
+    ry = np.deg2rad(14.0) * motion_scale * np.sin(1.1 * w * f + ph[4])
+    rz = np.deg2rad(5.0) * motion_scale * np.sin(0.6 * w * f + ph[5])
+
+    desc = np.empty((n_frames, n_kp, 32), np.uint8)
+    xyz1 = np.empty((n_frames, n_kp, 4), np.float32)
+    poses = np.empty((n_frames, 4, 4))
+    world_id = np.full((n_frames, n_kp), -1, np.int32)
+    n_true_max = int(round(true_fraction * n_kp))
+    for k in range(n_frames):
+        R = _rot(rx[k], ry[k], rz[k])
+        t = np.array([tx[k], ty[k], tz[k]])
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = t
+        poses[k] = T
+        pc = (world - t) @ R  # R^T (p - t)
+        z = pc[:, 2]
+        u = fx * pc[:, 0] / np.maximum(z, 1e-6) + cx
+        v = fy * pc[:, 1] / np.maximum(z, 1e-6) + cy
+        vis = np.flatnonzero((z > 0.5) & (z < 5.0) & (u >= 1) & (u < width - 1) &
+                             (v >= 1) & (v < height - 1))
+        n_true = min(n_true_max, vis.size)
+        score = response[vis] + rng.normal(0, 0.08, vis.size)
+        pick = vis[np.argsort(-score, kind="stable")[:n_true]]
+        # observation model: pixel noise, depth noise, float32 back-projection
+        uu = (u[pick] + rng.normal(0, pixel_noise, n_true)).astype(np.float32)
+        vv = (v[pick] + rng.normal(0, pixel_noise, n_true)).astype(np.float32)
+        zz = (z[pick] + rng.normal(0, 1, n_true) * depth_noise * z[pick] ** 2).astype(np.float32)
+        flips = rng.random((n_true, 256)) < bitflip
+        d_true = wdesc[pick] ^ np.packbits(flips, axis=1, bitorder="little")
+        # outliers
+        n_out = n_kp - n_true
+        uo = rng.uniform(1, width - 1, n_out).astype(np.float32)
+        vo = rng.uniform(1, height - 1, n_out).astype(np.float32)
+        zo = rng.uniform(0.6, 4.5, n_out).astype(np.float32)
+        d_out = rng.integers(0, 256, size=(n_out, 32), dtype=np.uint8)
+        U = np.concatenate([uu, uo])
+        V = np.concatenate([vv, vo])
+        Z = np.concatenate([zz, zo])
+        D = np.concatenate([d_true, d_out])
+        wid = np.concatenate([pick.astype(np.int32), np.full(n_out, -1, np.int32)])
+        if nan_fraction > 0:
+            Z = Z.copy()
+            Z[rng.random(n_kp) < nan_fraction] = np.nan
+        perm = rng.permutation(n_kp)
+        U, V, Z, D, wid = U[perm], V[perm], Z[perm], D[perm], wid[perm]
+        fxinv = np.float32(1.0 / fx)
+        fyinv = np.float32(1.0 / fy)
+        X = (U - np.float32(cx)) * Z * fxinv  # misc2.h:62
+        Y = (V - np.float32(cy)) * Z * fyinv  # misc2.h:63
+        xyz1[k, :, 0] = X
+        xyz1[k, :, 1] = Y
+        xyz1[k, :, 2] = Z
+        xyz1[k, :, 3] = 1.0
+        desc[k] = D
+        world_id[k] = wid
+    return dict(desc=desc, xyz1=xyz1, poses=poses, world_id=world_id)
+
+
+def candidate_pairs(n_frames, per_frame=20, seed=20260923, predecessors=3):
+    """For every frame: `predecessors` sequential predecessors (wrapping) plus pseudo-random
+    other frames up to `per_frame` candidates (200 x 20 = 4000 pairs)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    per_frame = min(per_frame, n_frames - 1)
+    pq, pt = [], []
+    for f in range(n_frames):
+        cands = [(f - d) % n_frames for d in range(1, min(predecessors, per_frame) + 1)]
+        pool = np.array([c for c in range(n_frames) if c != f and c not in cands])
+        extra = rng.choice(pool, size=per_frame - len(cands), replace=False) if per_frame > len(cands) else []
+        for c in list(cands) + [int(e) for e in extra]:
+            pq.append(f)
+            pt.append(c)
+    return np.asarray(pq, np.int32), np.asarray(pt, np.int32)
+
+
+def relative_pose(poses, q, t):
+    """Ground-truth transform mapping frame q's camera coordinates into frame t's."""
+    return np.linalg.inv(poses[t]) @ poses[q]

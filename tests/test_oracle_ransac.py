@@ -1,0 +1,198 @@
+"""Checks the oracle's RANSAC building blocks (A.3-A.6) against independent numpy math.
+These parts lean on PCL/Eigen arithmetic that is not in the reference tree: "parity unpinned"."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rgbdslam_v2_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "pair_golden.npz")
+
+
+def test_double_rounding_of_weight_is_innocuous():
+    # weight = float(1.0 / double(fz*tz)) (transformation_estimation_euclidean.cpp:25) equals the
+    # float division the HIP kernel uses: 53 >= 2*24+2 makes double rounding innocuous.
+    rng = np.random.default_rng(1)
+    x = (rng.random(2_000_000) * 20 + 0.01).astype(np.float32)
+    a = (1.0 / x.astype(np.float64)).astype(np.float32)
+    b = np.float32(1.0) / x
+    assert np.array_equal(a, b)
+
+
+def test_svd3_properties():
+    rng = np.random.default_rng(2)
+    for i in range(500):
+        Cm = (rng.normal(size=(3, 3)) * 10.0 ** rng.integers(-4, 3)).astype(np.float32)
+        if i % 7 == 0:
+            Cm[:, 1] = 0
+        U, S, V = po.svd3(Cm)
+        scale = max(np.abs(Cm).max(), 1e-30)
+        assert np.abs((U * S) @ V.T - Cm).max() <= 4e-6 * scale
+        assert np.allclose(U @ U.T, np.eye(3), atol=2e-5)
+        assert np.allclose(V @ V.T, np.eye(3), atol=2e-5)
+        assert S[0] >= S[1] >= S[2] >= 0
+        sref = np.linalg.svd(Cm.astype(np.float64), compute_uv=False)
+        assert np.allclose(S, sref, atol=3e-6 * scale)
+
+
+def kabsch_numpy(P, Q, w):
+    w = w / w.sum()
+    mp, mq = (w[:, None] * P).sum(0), (w[:, None] * Q).sum(0)
+    H = ((Q - mq) * w[:, None]).T @ (P - mp)
+    U, _, Vt = np.linalg.svd(H)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = mq - R @ mp
+    return T
+
+
+def test_fit_transform_matches_weighted_kabsch():
+    rng = np.random.default_rng(3)
+    for n in (4, 10, 250):
+        P = rng.uniform(-1, 1, (n, 3))
+        P[:, 2] += 2.5
+        R = synth._rot(0.1, -0.2, 0.05)
+        t = np.array([0.1, -0.05, 0.2])
+        Q = P @ R.T + t + rng.normal(0, 1e-3, (n, 3))
+        q1 = np.concatenate([P, np.ones((n, 1))], 1).astype(np.float32)
+        t1 = np.concatenate([Q, np.ones((n, 1))], 1).astype(np.float32)
+        ids = np.arange(n, dtype=np.int32)
+        T = po.fit_transform(q1, t1, ids, ids, ids)
+        w = 1.0 / (q1[:, 2].astype(np.float64) * t1[:, 2])
+        Tn = kabsch_numpy(q1[:, :3].astype(np.float64), t1[:, :3].astype(np.float64), w)
+        assert np.abs(T - Tn).max() < 2e-5
+        assert abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1) < 1e-5
+
+
+def test_fit_skips_nan_depth_and_propagates_zero_depth_as_nan():
+    q1 = np.array([[0, 0, 1, 1], [1, 0, 2, 1], [0, 1, 1.5, 1], [1, 1, np.nan, 1], [0.5, 0.2, 1.2, 1]], np.float32)
+    t1 = q1.copy()
+    t1[:, 0] += 0.1
+    ids = np.arange(5, dtype=np.int32)
+    T = po.fit_transform(q1, t1, ids, ids, ids)
+    assert np.all(np.isfinite(T)) and abs(T[0, 3] - 0.1) < 1e-5
+    q1[0, 2] = 0.0  # w = inf -> alpha = NaN -> NaN transform (the RANSAC loop then breaks, node.cpp:1144)
+    T = po.fit_transform(q1, t1, ids, ids, ids)
+    assert np.isnan(T).any()
+
+
+def err2_numpy(x1, x2, T, dc):
+    rcx, rcy = po.raster_cov()
+    a, b = x1.astype(np.float64), x2.astype(np.float64)
+    m12 = (T @ a)[:3]
+    d = m12 - b[:3]
+    smax = max(rcx, dc)
+    if d @ d > 2 * (smax + smax):
+        return np.finfo(np.float64).max
+    R = T[:3, :3]
+    C1 = np.diag([rcx * a[2], rcy * a[2], dc])
+    C2 = np.diag([rcx * b[2], rcy * b[2], dc])
+    S = R.T @ C1 @ R + C2  # sic (misc.cpp:751)
+    return d @ np.linalg.solve(S, d)
+
+
+def test_error_function2_matches_numpy():
+    rng = np.random.default_rng(4)
+    dc = 1e-4
+    n_checked = 0
+    for _ in range(400):
+        T = np.eye(4)
+        T[:3, :3] = synth._rot(*rng.normal(0, 0.1, 3))
+        T[:3, 3] = rng.normal(0, 0.05, 3)
+        x1 = np.append(rng.uniform(-1, 1, 3) + [0, 0, 2], 1).astype(np.float32)
+        x2 = (T @ x1.astype(np.float64)).astype(np.float32)
+        x2[:3] += rng.normal(0, 0.004, 3).astype(np.float32)
+        x2[3] = 1
+        e = po.error_function2(x1, x2, T, dc)
+        en = err2_numpy(x1, x2, T, dc)
+        if en > 1e300:
+            assert e > 1e300
+        else:
+            assert abs(e - en) <= 1e-9 * max(1, abs(en))
+            n_checked += 1
+    assert n_checked > 100
+    x1 = np.array([0, 0, np.nan, 1], np.float32)
+    assert po.error_function2(x1, x1, np.eye(4), dc) > 1e300
+
+
+def test_sample4_sorted_distinct_prefers_low_ids():
+    L = po.lib()
+    ids = np.zeros(4, np.uint32)
+    firsts = []
+    for it in range(300):
+        c = L.orc_sample4(123, 77, it, 300, ids.ctypes.data)
+        assert c == 4 and np.all(np.diff(ids.astype(np.int64)) > 0) and ids.max() < 300
+        firsts.append(ids.mean())
+    assert np.mean(firsts) < 0.4 * 300  # min(r1,r2) biases to low ranks (mean of min = n/3)
+    assert L.orc_sample4(1, 2, 3, 3, ids.ctypes.data) == 0  # fewer than 4 matches: no sample
+
+
+def test_ransac_recovers_ground_truth_and_is_deterministic():
+    seq = synth.make_sequence(n_frames=6, n_kp=600, n_world=2500, seed=3)
+    prm = po.default_params()
+    for q, t in [(1, 0), (4, 2), (5, 0)]:
+        r = po.match_node_pair(seq["desc"][q], seq["xyz1"][q], q, seq["desc"][t], seq["xyz1"][t], t, prm)
+        assert r["id1"] == t and r["id2"] == q
+        assert r["n_inl"] >= 20 and r["rmse"] <= 3.0
+        assert np.abs(r["T"] - synth.relative_pose(seq["poses"], q, t)).max() < 0.02
+        assert abs(r["info_scale"] - r["n_inl"] / float(r["rmse"]) ** 2) <= 1e-3 * r["info_scale"]
+        r2 = po.match_node_pair(seq["desc"][q], seq["xyz1"][q], q, seq["desc"][t], seq["xyz1"][t], t, prm)
+        assert np.array_equal(r["T"], r2["T"]) and np.array_equal(r["inl_idx"], r2["inl_idx"])
+
+
+def test_no_edge_conventions():
+    rng = np.random.default_rng(9)
+    prm = po.default_params()
+    # unrelated frames: plenty of hd<128 matches but no consistent transform
+    d1 = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    x1 = np.concatenate([rng.uniform(-1, 1, (300, 2)), rng.uniform(1, 3, (300, 1)), np.ones((300, 1))], 1).astype(np.float32)
+    x2 = np.concatenate([rng.uniform(-1, 1, (300, 2)), rng.uniform(1, 3, (300, 1)), np.ones((300, 1))], 1).astype(np.float32)
+    r = po.match_node_pair(d1, x1, 5, d2, x2, 2, prm)
+    assert (r["id1"], r["id2"]) == (-1, -1) and r["n_inl"] == 0  # node.cpp:1419-1422
+    assert np.array_equal(r["T"], np.eye(4, dtype=np.float32)) and r["rmse"] == np.float32(1e6)
+    # fewer than min_matches candidate matches: RANSAC never runs (node.cpp:1319)
+    r = po.match_node_pair(d1[:10], x1[:10], 5, d2[:10], x2[:10], 2, prm)
+    assert (r["id1"], r["id2"]) == (-1, -1) and r["real_iterations"] == 0 and r["rmse"] == 0
+
+
+def test_oracle_frozen_pair_outputs():
+    g = np.load(GOLD)
+    prm = po.default_params(seed=int(g["seed"]), depth_cov=float(g["depth_cov"]))
+    for k, (q, t) in enumerate(g["pairs"]):
+        r = po.match_node_pair(g["desc"][q], g["xyz1"][q], int(q), g["desc"][t], g["xyz1"][t], int(t), prm)
+        for key in ("id1", "id2", "n_all", "n_inl", "valid_iterations", "real_iterations"):
+            assert r[key] == int(g[f"p{k}_{key}"]), key
+        for key in ("all_q", "all_t", "all_hd", "inl_idx", "T", "rmse"):
+            assert np.array_equal(np.asarray(r[key]), g[f"p{k}_{key}"]), key
+
+
+def test_project_to_3d_oracle():
+    rng = np.random.default_rng(10)
+    depth = rng.uniform(0.5, 4, (48, 64)).astype(np.float32)
+    depth[rng.random((48, 64)) < 0.2] = np.nan
+    kp = np.stack([rng.uniform(-2, 66, 200), rng.uniform(-2, 50, 200)], 1).astype(np.float32)
+    kp[5] = [np.nan, 3]
+    kept, xyz = po.project_to_3d(kp, depth, 52.5, 52.5, 31.5, 23.5, 1.0, 1000)
+    exp = []
+    for i, (x, y) in enumerate(kp):
+        if not (0 <= x < 64 and 0 <= y < 48):
+            continue
+        r, c = int(np.floor(y + 0.5)), int(np.floor(x + 0.5))
+        r, c = min(r, 47), min(c, 63)
+        if np.isnan(depth[r, c]):
+            continue
+        exp.append(i)
+    assert list(kept) == exp
+    i = kept[0]
+    z = depth[min(int(np.floor(kp[i, 1] + 0.5)), 47), min(int(np.floor(kp[i, 0] + 0.5)), 63)]
+    assert xyz[0, 2] == z and xyz[0, 3] == 1
+    assert abs(xyz[0, 0] - (kp[i, 0] - 31.5) * z / 52.5) < 1e-5
+    kept2, _ = po.project_to_3d(kp, depth, 52.5, 52.5, 31.5, 23.5, 1.0, 7)
+    assert list(kept2) == exp[:7]  # node.cpp:957
