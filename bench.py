@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs matched+RANSAC'd per second (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (Hamming match -> select -> RANSAC, the whole
+Node::matchNodePair pair op) over one batch of candidate pairs of the synthetic
+BASELINE configs[1] workload: 640x480 RGB-D, ORB 1000 keypoints/frame, 200 frames,
+20 candidate pairs per frame = 4000 pairs per GPU per step.  Node features are resident
+in HBM before the timed region starts.  With N > 1 (one rank per GPU, launched by
+torch.distributed.run) every rank holds all nodes, the global pair list (N x 4000 pairs)
+is sharded pair k -> rank k mod N, and each step ends with the RCCL all-gather of the
+MatchingResult PODs: weak scaling.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_KP = 1000
+N_FRAMES = 200
+PAIRS_PER_FRAME = 20
+MAX_MATCHES = 300
+SEED = 20260923
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (int32 VALU lanes/s)
+
+
+def algorithmic_bytes(n_kp, m):
+    """SURVEY.md 8(d).  Whole pair path: 104*N + 24*M + 64 (= 111264 B at N=1000, M=300).
+    Per kernel (DESIGN.md 'Kernels'): Hamming = both descriptor sets read once + packed
+    (hd,idx) key written per query; select+RANSAC = keys read + matched xyz1 gathered +
+    result POD written."""
+    pair = 104 * n_kp + 24 * m + 64
+    hamming = 2 * n_kp * 32 + 4 * n_kp
+    ransac = 4 * n_kp + 2 * m * 16 + 1744
+    return pair, hamming, ransac
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=N_FRAMES)
+    ap.add_argument("--kp", type=int, default=N_KP)
+    ap.add_argument("--pairs-per-frame", type=int, default=PAIRS_PER_FRAME)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd._lib import KERNEL_HAMMING, KERNEL_RANSAC, RESULT_DTYPE
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    from rgbdslam_v2_amd.dist import shard_pairs
+
+    F, N = args.frames, args.kp
+    seq = synth.make_sequence(n_frames=F, n_kp=N, seed=SEED)
+    # global pair list: per frame 20*world candidates (weak scaling), sharded round-robin
+    per_frame = min(args.pairs_per_frame * world, F - 1)
+    pq_all, pt_all = synth.candidate_pairs(F, per_frame=per_frame, seed=SEED)
+    pq, pt = shard_pairs(pq_all, pt_all, rank, world)
+    n_local = len(pq)
+    counts = [n_local]
+    if world > 1:
+        t_cnt = torch.tensor([n_local], device="cuda")
+        all_cnt = [torch.zeros_like(t_cnt) for _ in range(world)]
+        dist.all_gather(all_cnt, t_cnt)
+        counts = [int(c.item()) for c in all_cnt]
+    n_pad = max(counts)
+
+    fe = FrontEnd(device_id=local_rank, max_nodes=F, max_keypoints=((N + 63) // 64) * 64,
+                  max_pairs_per_batch=max(n_pad, 1), seed=SEED)
+    # node features -> HBM (resident before the timed region)
+    for f in range(F):
+        fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+
+    rec_bytes = RESULT_DTYPE.itemsize
+    d_local = torch.zeros(n_pad * rec_bytes, dtype=torch.uint8, device="cuda")
+    d_all = torch.zeros(world * n_pad * rec_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        fe.match_pair_list_device(pq, pt, d_local.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_local)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    fe.synchronize()
+    fe.set_profiling(True)
+    fe.reset_kernel_time()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    fe.set_profiling(False)
+    ham_ms, ham_launches, ham_pairs = fe.kernel_time(KERNEL_HAMMING)
+    rsc_ms, rsc_launches, rsc_pairs = fe.kernel_time(KERNEL_RANSAC)
+
+    total_pairs = sum(counts) * args.steps
+    value = total_pairs / elapsed
+
+    # sanity: results of the last step are real (edges found)
+    res = np.frombuffer(d_local.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[:n_local]
+    edge_frac = float((res["id1"] >= 0).mean()) if n_local else 0.0
+    mean_iters = float(res["real_iterations"].mean()) if n_local else 0.0
+
+    if rank == 0:
+        b_pair, b_ham, b_rsc = algorithmic_bytes(N, MAX_MATCHES)
+        dominant = "hamming_nn" if ham_ms >= rsc_ms else "select_ransac"
+        dom_ms, dom_launches, dom_bytes = ((ham_ms, ham_launches, b_ham) if dominant == "hamming_nn"
+                                           else (rsc_ms, rsc_launches, b_rsc))
+        avg_launch_ms = dom_ms / max(dom_launches, 1)
+        achieved = (dom_bytes * n_local) / (avg_launch_ms * 1e-3) / 1e9 if dom_launches else 0.0
+        ham_avg_ms = ham_ms / max(ham_launches, 1)
+        valu_achieved = (16.0 * N * (N - 1) * n_local) / (ham_avg_ms * 1e-3) if ham_launches else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "traffic": traffic,
+            "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
+            "avg_launch_ms": round(avg_launch_ms, 4),
+            "hamming_ms_per_launch": round(ham_avg_ms, 4),
+            "ransac_ms_per_launch": round(rsc_ms / max(rsc_launches, 1), 4),
+            "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
+            "valu_laneops_per_s": round(valu_achieved, 1), "valu_peak": VALU_PEAK_LANEOPS,
+            "valu_frac": round(valu_achieved / VALU_PEAK_LANEOPS, 4),
+            "note": "the ORB match is integer-VALU bound (xor+bcnt), not HBM bound: see DESIGN.md",
+        }
+        out = {
+            "metric": "frame-pairs matched+RANSAC/sec, 640x480 ORB-1000",
+            "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 popcount (match) + f32/f64 (RANSAC)", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 640x480 RGB-D, ORB %d kp, %d candidate pairs/frame, %d frames"
+                                   % (N, args.pairs_per_frame, F),
+                       "pairs_per_gpu_per_step": n_local, "max_matches": MAX_MATCHES,
+                       "ransac_iterations": 200, "parallelism": "pair-sharded x%d" % world,
+                       "edge_fraction": round(edge_frac, 4), "mean_ransac_iterations": round(mean_iters, 2)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seq, pq, pt, fe, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    fe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(seq, pq, pt, fe, budget_s):
+    """The oracle (CPU restatement of the reference pair path, kind='port') timed pair-parallel
+    on this host's cores over a bounded sample of the same pair list."""
+    from oracle import pyoracle as po
+    prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov)
+    cores = po.num_cores()
+    descs, xyzs = list(seq["desc"]), list(seq["xyz1"])
+    ids = np.arange(len(descs))
+    probe = min(len(pq), max(2 * cores, 16))
+    t0 = time.perf_counter()
+    po.match_pairs_mt(descs, xyzs, ids, pq[:probe], pt[:probe], prm, cores)
+    dt = time.perf_counter() - t0
+    n = int(min(len(pq), max(probe, budget_s / max(dt / probe, 1e-6))))
+    sel = np.linspace(0, len(pq) - 1, n).astype(np.int64)
+    t0 = time.perf_counter()
+    po.match_pairs_mt(descs, xyzs, ids, pq[sel], pt[sel], prm, cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d of the %d pairs of one step, oracle/liboracle.so, OpenMP pair-parallel, %d threads"
+                      % (n, len(pq), cores)}
+
+
+if __name__ == "__main__":
+    main()

@@ -47,9 +47,18 @@ struct rgbdfe_ctx {
   // slabs
   uint32_t* d_desc = nullptr;  // max_nodes x max_kp x 8 dwords (+ pad rows)
   float4* d_xyz = nullptr;     // max_nodes x max_kp
-  // per-batch staging
-  PairWork* d_work = nullptr;
-  PairWork* h_work = nullptr;  // pinned
+  // per-batch staging: a ring of pair-list buffers so that the host can prepare batch k+1
+  // while batch k runs (the keys/results buffers are ordered by the stream itself)
+  static constexpr int kRing = 4;
+  struct Slot {
+    PairWork* h_work = nullptr;  // pinned
+    PairWork* d_work = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+  };
+  Slot ring[kRing];
+  int ring_next = 0;
+  hipStream_t last_stream = nullptr;
   uint32_t* d_keys = nullptr;  // max_pairs x max_kp
   rgbdfe_match_result* d_results = nullptr;
   // scratch for single-pair helpers / project_to_3d
@@ -137,6 +146,7 @@ hipEvent_t get_event(rgbdfe_ctx* ctx) {
 
 // fold finished timing records into the totals
 void drain_pending(rgbdfe_ctx* ctx) {
+  if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
   for (auto& p : ctx->pending) {
     float ms_h = 0.f, ms_r = 0.f;
     if (hipEventElapsedTime(&ms_h, p.a, p.b) == hipSuccess &&
@@ -162,13 +172,22 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
   if (n == 0) return RGBDFE_OK;
   if (n > ctx->cfg.max_pairs_per_batch)
     return fail(ctx, RGBDFE_ERR_CAPACITY, "n_pairs exceeds max_pairs_per_batch");
+  // d_keys is shared by consecutive batches: they must be ordered on one stream
+  if (ctx->last_stream && ctx->last_stream != stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  ctx->last_stream = stream;
+  rgbdfe_ctx::Slot& slot = ctx->ring[ctx->ring_next];
+  ctx->ring_next = (ctx->ring_next + 1) % rgbdfe_ctx::kRing;
+  if (slot.pending) {
+    HIP_TRY(ctx, hipEventSynchronize(slot.done));
+    slot.pending = false;
+  }
   uint32_t max_nq = 0, max_nt = 0;
   for (int32_t i = 0; i < n; ++i) {
     auto q = ctx->nodes.find(qids[i]);
     auto t = ctx->nodes.find(tids[i]);
     if (q == ctx->nodes.end() || t == ctx->nodes.end())
       return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "pair references a node that is not resident");
-    PairWork& w = ctx->h_work[i];
+    PairWork& w = slot.h_work[i];
     w.q_slot = q->second.slot;
     w.t_slot = t->second.slot;
     w.nq = q->second.n;
@@ -180,7 +199,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     if (w.nq > max_nq) max_nq = w.nq;
     if (w.nt > max_nt) max_nt = w.nt;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_work, sizeof(PairWork) * (size_t)n,
+  HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n,
                               hipMemcpyHostToDevice, stream));
   rgbdfe_ctx::Pending pend{};
   if (ctx->profiling) {
@@ -190,16 +209,18 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     pend.pairs = n;
     (void)hipEventRecord(pend.a, stream);
   }
-  launch_hamming_nn(ctx->d_desc, ctx->d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints,
+  launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints,
                     (uint32_t)n, max_nq, max_nt, stream);
   if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-  launch_select_ransac(ctx->d_xyz, ctx->d_work, ctx->d_keys, d_out,
+  launch_select_ransac(ctx->d_xyz, slot.d_work, ctx->d_keys, d_out,
                        (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->rc, stream);
   if (ctx->profiling) {
     (void)hipEventRecord(pend.c, stream);
     ctx->pending.push_back(pend);
   }
   HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(slot.done, stream));
+  slot.pending = true;
   return RGBDFE_OK;
 }
 
@@ -246,9 +267,12 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   if (hipMemset(ctx->d_desc, 0, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_HIP);
   if (hipMemset(ctx->d_xyz, 0, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_HIP);
   const size_t np = (size_t)cfg->max_pairs_per_batch;
-  if (hipMalloc((void**)&ctx->d_work, np * sizeof(PairWork)) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
-  if (hipHostMalloc((void**)&ctx->h_work, np * sizeof(PairWork), hipHostMallocDefault) != hipSuccess)
-    return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  for (auto& sl : ctx->ring) {
+    if (hipMalloc((void**)&sl.d_work, np * sizeof(PairWork)) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+    if (hipHostMalloc((void**)&sl.h_work, np * sizeof(PairWork), hipHostMallocDefault) != hipSuccess)
+      return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+    if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  }
   if (hipMalloc((void**)&ctx->d_keys, np * (size_t)cfg->max_keypoints * 4) != hipSuccess)
     return bail(RGBDFE_ERR_OUT_OF_MEMORY);
   if (hipMalloc((void**)&ctx->d_results, np * sizeof(rgbdfe_match_result)) != hipSuccess)
@@ -262,12 +286,16 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
 void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   if (!ctx) return;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipDeviceSynchronize();
   drain_pending(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
   if (ctx->d_xyz) (void)hipFree(ctx->d_xyz);
-  if (ctx->d_work) (void)hipFree(ctx->d_work);
-  if (ctx->h_work) (void)hipHostFree(ctx->h_work);
+  for (auto& sl : ctx->ring) {
+    if (sl.d_work) (void)hipFree(sl.d_work);
+    if (sl.h_work) (void)hipHostFree(sl.h_work);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
   if (ctx->d_results) (void)hipFree(ctx->d_results);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -390,10 +418,6 @@ int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids,
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  // the pinned PairWork staging buffer is reused by every call: wait until the previous
-  // batch's H2D copy (and kernels) on this stream have consumed it.
-  HIP_TRY(ctx, hipStreamSynchronize(s));
-  if (ctx->profiling) drain_pending(ctx);
   return enqueue_pairs(ctx, query_ids, train_ids, n_pairs, (rgbdfe_match_result*)d_out, s);
 }
 
@@ -401,7 +425,8 @@ int rgbdfe_synchronize(rgbdfe_ctx* ctx) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->profiling) drain_pending(ctx);
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  drain_pending(ctx);
   return RGBDFE_OK;
 }
 
@@ -431,13 +456,17 @@ int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   auto t = ctx->nodes.find(train_id);
   if (q == ctx->nodes.end() || t == ctx->nodes.end())
     return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "node not resident");
-  PairWork& w = ctx->h_work[0];
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  rgbdfe_ctx::Slot& slot = ctx->ring[0];
+  if (slot.pending) { HIP_TRY(ctx, hipEventSynchronize(slot.done)); slot.pending = false; }
+  PairWork& w = slot.h_work[0];
   w.q_slot = q->second.slot; w.t_slot = t->second.slot;
   w.nq = q->second.n; w.nt = t->second.n;
   w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id; w.pad = 0;
   if (w.nq == 0) return RGBDFE_OK;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_work, ctx->h_work, sizeof(PairWork), hipMemcpyHostToDevice, ctx->stream));
-  launch_hamming_nn(ctx->d_desc, ctx->d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints, 1u,
+  HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, ctx->stream));
+  ctx->last_stream = ctx->stream;
+  launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints, 1u,
                     w.nq, w.nt, ctx->stream);
   HIP_TRY(ctx, hipGetLastError());
   return hamming_keys_to_host(ctx, w.nq, out_hd, out_idx);
@@ -510,7 +539,7 @@ int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t
                            int64_t* pairs) {
   if (!ctx || which < 0 || which >= RGBDFE_KERNEL_COUNT) return RGBDFE_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(ctx->mu);
-  // records are folded in at synchronisation points
+  drain_pending(ctx);  // synchronises the stream the kernels ran on
   if (total_ms) *total_ms = ctx->k_ms[which];
   if (launches) *launches = ctx->k_launches[which];
   if (pairs) *pairs = ctx->k_pairs[which];

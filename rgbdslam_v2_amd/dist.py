@@ -1,0 +1,56 @@
+"""Multi-GPU pair sharding: one process per GPU, every rank holds all node
+features (48 KB per 1000-keypoint node -- trivial against 288 GB of HBM), the candidate pair
+list is sharded round-robin and the fixed-size MatchingResult PODs are exchanged with ONE
+all-gather (RCCL over xGMI when the tensors live on the GPU, gloo on CPU in the tests).
+No other collective exists on this path: pairs are independent
+(QtConcurrent::blockingMapped has no cross-task dependency, graph_manager.cpp:548)."""
+import numpy as np
+
+from ._lib import RESULT_DTYPE
+
+
+def shard_pairs(pair_q, pair_t, rank: int, world: int):
+    """pair k -> rank k mod world."""
+    pair_q = np.asarray(pair_q, np.int32)
+    pair_t = np.asarray(pair_t, np.int32)
+    return np.ascontiguousarray(pair_q[rank::world]), np.ascontiguousarray(pair_t[rank::world])
+
+
+def shard_sizes(n_pairs: int, world: int):
+    return [len(range(r, n_pairs, world)) for r in range(world)]
+
+
+def unshard(gathered: np.ndarray, n_pairs: int, world: int) -> np.ndarray:
+    """gathered: [world, n_pad] records as all-gathered (rank-major, shards padded to n_pad).
+    Returns the records in global pair order."""
+    out = np.zeros(n_pairs, gathered.dtype)
+    for r in range(world):
+        k = len(range(r, n_pairs, world))
+        out[r::world] = gathered[r, :k]
+    return out
+
+
+def all_gather_results(local_records, n_pairs: int, group=None):
+    """All-gather of the per-rank result records.  local_records: numpy RESULT_DTYPE array (CPU,
+    gloo) or a uint8 torch tensor already in HBM (RCCL).  Returns all records in global order
+    (numpy)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(n_pairs, world)
+    n_pad = max(sizes) if sizes else 0
+    rec = RESULT_DTYPE.itemsize
+    if isinstance(local_records, np.ndarray):
+        buf = np.zeros(n_pad, RESULT_DTYPE)
+        buf[: len(local_records)] = local_records
+        local = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy())
+    else:
+        local = local_records.reshape(-1)
+        if local.numel() != n_pad * rec:
+            pad = torch.zeros(n_pad * rec, dtype=torch.uint8, device=local.device)
+            pad[: local.numel()] = local
+            local = pad
+    out = torch.empty(world * n_pad * rec, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    g = np.frombuffer(out.cpu().numpy().tobytes(), dtype=RESULT_DTYPE).reshape(world, n_pad)
+    return unshard(g, n_pairs, world)
