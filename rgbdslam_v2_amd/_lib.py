@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librgbdfe.so")
+LIB_PATH = os.environ.get("RGBDFE_LIB", os.path.join(_HERE, "librgbdfe.so"))  # RGBDFE_LIB: diagnostics builds
 
 RGBDFE_MAX_MATCHES = 320
 RGBDFE_MASK_WORDS = 5

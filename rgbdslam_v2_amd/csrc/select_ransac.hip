@@ -32,13 +32,45 @@ namespace rgbdfe {
 constexpr int kWave = 64;
 constexpr int kRounds = RGBDFE_MAX_MATCHES / kWave;  // 5
 
-struct __attribute__((aligned(16))) RansacLds {
-  double e[RGBDFE_MAX_MATCHES];        // per-match squared Mahalanobis error (0 for non-inliers)
-  float P[RGBDFE_MAX_MATCHES * 3];     // newer node's points ("from"), match order
-  float Q[RGBDFE_MAX_MATCHES * 3];     // older node's points ("to")
-  uint32_t mqt[RGBDFE_MAX_MATCHES];    // queryIdx | trainIdx << 16
+constexpr int kMemo = 8;
+
+// selection phase
+struct SelBuf {
+  uint32_t mqt[RGBDFE_MAX_MATCHES];  // queryIdx | trainIdx << 16
   uint32_t mhd[RGBDFE_MAX_MATCHES];
-  uint32_t cnt[128];                   // hd histogram / running bin cursors
+  uint32_t cnt[128];                 // hd histogram / running bin cursors
+};
+// refit phase: the inlier set compacted in match order
+struct FitBuf {
+  float wc[RGBDFE_MAX_MATCHES];   // weights w_k              -> (1 - alpha_k) in place
+  float Wk[RGBDFE_MAX_MATCHES];   // running weight sums W_k  -> alpha_k = w_k / W_k in place
+  uint16_t ord[RGBDFE_MAX_MATCHES];  // k-th participating match
+};
+union Scratch {  // the three phases never overlap
+  SelBuf sel;
+  double e[RGBDFE_MAX_MATCHES];  // per-match squared Mahalanobis error (0 for non-inliers)
+  FitBuf fit;
+};
+// a (transform, inlier set, error) triple kept in LDS (wave-uniform state)
+struct Hyp {
+  float R[9], t[3];
+  uint64_t mask[kRounds];
+  int n;
+  int nan;
+  double err;
+};
+// memo of the pure function  inlier set -> (refit transform, its inlier set, its error)
+struct MemoEntry {
+  uint64_t key[kRounds];
+  Hyp val;
+};
+struct __attribute__((aligned(16))) RansacLds {
+  Scratch u;
+  float P[RGBDFE_MAX_MATCHES * 3];  // newer node's points ("from"), match order
+  float Q[RGBDFE_MAX_MATCHES * 3];  // older node's points ("to")
+  float w[RGBDFE_MAX_MATCHES];      // 1/(from.z*to.z), transformation_estimation_euclidean.cpp:25
+  MemoEntry memo[kMemo];
+  Hyp refined, best;
 };
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -275,13 +307,8 @@ __device__ __forceinline__ bool has_nan12(const float* R, const float* t) {
 // computeInliersAndError (node.cpp:968-1020) with errorFunction2 (misc.cpp:697-770).
 // LANE = MATCH.  R,t are wave-uniform.  Returns inlier masks, count and rms error.
 // ---------------------------------------------------------------------------------
-struct PointRegs {
-  float px[kRounds], py[kRounds], pz[kRounds];
-  float qx[kRounds], qy[kRounds], qz[kRounds];
-};
-
-__device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, const PointRegs& pts,
-                                                 int n_all, const RansacConst& rc, RansacLds& lds,
+__device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, int n_all,
+                                                 const RansacConst& rc, RansacLds& lds,
                                                  uint64_t* mask, int& n_inl, double& err) {
   const int lane = threadIdx.x;
   double Rd[9], td[3];
@@ -297,11 +324,13 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
     const bool active = m < n_all;
-    const float pzf = pts.pz[r], qzf = pts.qz[r];
+    // stride-3 word addresses: conflict-free across the 32 LDS banks
+    const float pxf = lds.P[m * 3 + 0], pyf = lds.P[m * 3 + 1], pzf = lds.P[m * 3 + 2];
+    const float qxf = lds.Q[m * 3 + 0], qyf = lds.Q[m * 3 + 1], qzf = lds.Q[m * 3 + 2];
     // node.cpp:994 (z == 0 skip) ; misc.cpp:712-717 (NaN -> DBL_MAX)
     bool cand = active && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
-    const double a0 = (double)pts.px[r], a1 = (double)pts.py[r], a2 = (double)pzf;
-    const double b0 = (double)pts.qx[r], b1 = (double)pts.qy[r], b2 = (double)qzf;
+    const double a0 = (double)pxf, a1 = (double)pyf, a2 = (double)pzf;
+    const double b0 = (double)qxf, b1 = (double)qyf, b2 = (double)qzf;
     // mu_1_in_frame_2 = (T * x1).head<3>() with x1.w == 1 (misc.cpp:724)
     double d[3];
     {
@@ -355,7 +384,7 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
     const bool inl = cand && !(e > rc.sq_max_dist) && (e >= 0.0);  // node.cpp:998,1001
     mask[r] = __ballot(inl);
     n_inl += __popcll(mask[r]);
-    lds.e[m] = inl ? e : 0.0;  // +0.0 terms leave the sequential sum bit-identical
+    lds.u.e[m] = inl ? e : 0.0;  // +0.0 terms leave the sequential sum bit-identical
   }
   __syncthreads();
   // mean_error += mahal_dist in match order (node.cpp:1006): strictly sequential double sum
@@ -363,10 +392,10 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   const int n4 = n_all & ~3;
   int m = 0;
   for (; m < n4; m += 4) {
-    double e0 = lds.e[m], e1 = lds.e[m + 1], e2 = lds.e[m + 2], e3 = lds.e[m + 3];
+    double e0 = lds.u.e[m], e1 = lds.u.e[m + 1], e2 = lds.u.e[m + 2], e3 = lds.u.e[m + 3];
     sum += e0; sum += e1; sum += e2; sum += e3;
   }
-  for (; m < n_all; ++m) sum += lds.e[m];
+  for (; m < n_all; ++m) sum += lds.u.e[m];
   __syncthreads();
   if (n_inl < 3) {
     err = 1e9;  // node.cpp:1012-1014
@@ -375,11 +404,126 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   }
 }
 
-__device__ __forceinline__ int mask_count(const uint64_t* m) {
-  int n = 0;
+// ---------------------------------------------------------------------------------
+// getTransformFromMatches over an inlier set given as ballot masks (match order).
+// The PCL recurrence is strictly sequential in its state, but not in its coefficients:
+//   1. compaction (lane = match): k-th participating match, its weight          [parallel]
+//   2. W_k = W_{k-1} + w_k                                   [sequential: 1 add per step]
+//   3. alpha_k = w_k / W_k, 1 - alpha_k (lane = k)                              [parallel]
+//   4. the 15 state elements (C 3x3, mean1, mean2) advance one step at a time with one
+//      element pair per lane (lane l: C[i][j], mean2[i], mean1[j], i = l/3, j = l%3):
+//      sub, sub, mul, mul, add, mul, mul, add, mul, add per step instead of ~85 ops.
+// Every float operation is the one the sequential code performs, in the same order on
+// the same operands: bit-identical to Tfc::add over the same matches.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void fit_inliers(const uint64_t* mask, RansacLds& lds, float* R, float* tr) {
+  const int lane = threadIdx.x;
+  uint32_t base = 0;
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) n += __popcll(m[r]);
-  return n;
+  for (int r = 0; r < kRounds; ++r) {
+    const int m = r * kWave + lane;
+    const float w = lds.w[m];
+    // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
+    const bool part = ((mask[r] >> lane) & 1ull) && (w != 0.0f);
+    const uint64_t pm = __ballot(part);
+    const uint32_t k = base + lane_rank(pm);
+    if (part) {
+      lds.u.fit.wc[k] = w;
+      lds.u.fit.ord[k] = (uint16_t)m;
+    }
+    base += (uint32_t)__popcll(pm);
+  }
+  const int n = (int)base;
+  __syncthreads();
+  {
+    float W = 0.0f;
+    int k = 0;
+    const int n4 = n & ~3;
+    for (; k < n4; k += 4) {
+      const float w0 = lds.u.fit.wc[k], w1 = lds.u.fit.wc[k + 1], w2 = lds.u.fit.wc[k + 2],
+                  w3 = lds.u.fit.wc[k + 3];
+      W += w0; const float W0 = W;
+      W += w1; const float W1 = W;
+      W += w2; const float W2 = W;
+      W += w3;
+      if (lane == 0) {
+        lds.u.fit.Wk[k] = W0; lds.u.fit.Wk[k + 1] = W1; lds.u.fit.Wk[k + 2] = W2; lds.u.fit.Wk[k + 3] = W;
+      }
+    }
+    for (; k < n; ++k) {
+      W += lds.u.fit.wc[k];
+      if (lane == 0) lds.u.fit.Wk[k] = W;
+    }
+  }
+  __syncthreads();
+  for (int k = lane; k < n; k += kWave) {
+    const float alpha = lds.u.fit.wc[k] / lds.u.fit.Wk[k];
+    lds.u.fit.Wk[k] = alpha;
+    lds.u.fit.wc[k] = 1.0f - alpha;
+  }
+  __syncthreads();
+  const int l9 = lane % 9;
+  const int ci = l9 / 3, cj = l9 % 3;
+  float C = 0.0f, m1 = 0.0f, m2 = 0.0f;
+#pragma unroll 4
+  for (int k = 0; k < n; ++k) {
+    const int m = lds.u.fit.ord[k];
+    const float alpha = lds.u.fit.Wk[k];
+    const float oma = lds.u.fit.wc[k];
+    const float f = lds.P[m * 3 + cj];
+    const float t = lds.Q[m * 3 + ci];
+    const float d1 = f - m1;
+    const float d2 = t - m2;
+    const float outer = d2 * d1;
+    const float scaled = alpha * outer;
+    const float sum = C + scaled;
+    C = oma * sum;
+    m1 = m1 + alpha * d1;
+    m2 = m2 + alpha * d2;
+  }
+  __syncthreads();
+  Tfc s;
+  s.W = 0.0f;
+#pragma unroll
+  for (int x = 0; x < 9; ++x) s.C[x] = bcast_f(C, x);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) s.m1[j] = bcast_f(m1, j);       // lane j: (i=0, j)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s.m2[i] = bcast_f(m2, 3 * i);   // lane 3i: (i, j=0)
+  tfc_get_transformation(s, R, tr);
+}
+
+__device__ __forceinline__ void hyp_store(Hyp& h, const float* R, const float* t, const uint64_t* mask,
+                                          int n, int nan, double err) {
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h.R[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) h.t[i] = t[i];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) h.mask[r] = mask[r];
+    h.n = n;
+    h.nan = nan;
+    h.err = err;
+  }
+}
+
+// Optional phase timers (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase are
+// written over the head of all_q of each result.  Never enabled in the product build.
+#ifdef RGBDFE_PROFILE_PHASES
+#define PH_DECL uint64_t ph_t0 = __builtin_readcyclecounter(); uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) { uint64_t ph_t1 = __builtin_readcyclecounter(); ph[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
+#define PH_COUNT(i) { ph[i] += 1; }
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_COUNT(i)
+#endif
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
 }
 
 __global__ __launch_bounds__(kWave) void select_ransac_kernel(
@@ -395,23 +539,25 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
   const uint32_t* __restrict__ kin = keys + (size_t)pair * max_kp;
   rgbdfe_match_result* __restrict__ out = results + pair;
   const int max_matches = rc.max_matches;
+  SelBuf& sel = lds.u.sel;
+  PH_DECL
 
   // ------------------------------------------------------------------ selection
-  lds.cnt[lane] = 0;
-  lds.cnt[lane + 64] = 0;
+  sel.cnt[lane] = 0;
+  sel.cnt[lane + 64] = 0;
   __syncthreads();
   for (uint32_t base = 0; base < nq; base += kWave) {
     const uint32_t i = base + lane;
     if (i < nq) {
       const uint32_t hd = kin[i] >> 16;
-      if (hd < 128u) atomicAdd(&lds.cnt[hd], 1u);  // node.cpp:572
+      if (hd < 128u) atomicAdd(&sel.cnt[hd], 1u);  // node.cpp:572
     }
   }
   __syncthreads();
   uint32_t total;
   uint32_t cut_hd;  // bins >= cut_hd start at or beyond max_matches: never selected
   {
-    const uint32_t a = lds.cnt[2 * lane], b = lds.cnt[2 * lane + 1];
+    const uint32_t a = sel.cnt[2 * lane], b = sel.cnt[2 * lane + 1];
     uint32_t incl = a + b;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -428,8 +574,8 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     for (int off = 32; off >= 1; off >>= 1) c = min(c, (uint32_t)__shfl_xor(c, off));
     cut_hd = c;
     __syncthreads();
-    lds.cnt[2 * lane] = s0;
-    lds.cnt[2 * lane + 1] = s1;
+    sel.cnt[2 * lane] = s0;
+    sel.cnt[2 * lane + 1] = s1;
   }
   __syncthreads();
   const int n_all = (int)min(total, (uint32_t)max_matches);
@@ -450,19 +596,19 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     const uint32_t rank = lane_rank(same);
     const uint32_t cnt_same = __popcll(same);
     uint32_t pos = 0;
-    if (valid) pos = lds.cnt[hd] + rank;
+    if (valid) pos = sel.cnt[hd] + rank;
     __syncthreads();
-    if (valid && rank == 0) lds.cnt[hd] = pos + cnt_same;
+    if (valid && rank == 0) sel.cnt[hd] = pos + cnt_same;
     if (valid && pos < (uint32_t)max_matches) {
-      lds.mqt[pos] = i | ((key & 0xFFFFu) << 16);
-      lds.mhd[pos] = hd;
+      sel.mqt[pos] = i | ((key & 0xFFFFu) << 16);
+      sel.mhd[pos] = hd;
     }
     __syncthreads();
   }
   __syncthreads();
 
-  // ------------------------------------------------- matched 3-D points -> regs + LDS
-  PointRegs pts;
+  PH_MARK(0)
+  // ------------------------------------------------- matched 3-D points -> LDS
   const float4* __restrict__ qxyz = xyz_pool + (size_t)w.q_slot * max_kp;
   const float4* __restrict__ txyz = xyz_pool + (size_t)w.t_slot * max_kp;
 #pragma unroll
@@ -471,25 +617,27 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     float4 p = make_float4(0.f, 0.f, 0.f, 1.f), q = make_float4(0.f, 0.f, 0.f, 1.f);
     uint32_t qt = 0, hd = 0;
     if (m < n_all) {
-      qt = lds.mqt[m];
-      hd = lds.mhd[m];
+      qt = sel.mqt[m];
+      hd = sel.mhd[m];
       p = qxyz[qt & 0xFFFFu];
       q = txyz[qt >> 16];
     }
-    pts.px[r] = p.x; pts.py[r] = p.y; pts.pz[r] = p.z;
-    pts.qx[r] = q.x; pts.qy[r] = q.y; pts.qz[r] = q.z;
     lds.P[m * 3 + 0] = p.x; lds.P[m * 3 + 1] = p.y; lds.P[m * 3 + 2] = p.z;
     lds.Q[m * 3 + 0] = q.x; lds.Q[m * 3 + 1] = q.y; lds.Q[m * 3 + 2] = q.z;
+    // weight = 1.0/(from(2)*to(2)) (transformation_estimation_euclidean.cpp:25): the double
+    // divide rounded to float equals the float divide (53 >= 2*24+2)
+    lds.w[m] = 1.0f / (p.z * q.z);
     out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
     out->all_t[m] = (uint16_t)(qt >> 16);
     out->all_hd[m] = (uint8_t)hd;
   }
   __syncthreads();
 
+  PH_MARK(1)
   // ------------------------------------------------------------------ RANSAC
-  // results (wave-uniform)
-  float bestR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bestt[3] = {0, 0, 0};
-  uint64_t best_mask[kRounds] = {0, 0, 0, 0, 0};
+  const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, It[3] = {0, 0, 0};
+  const uint64_t zero_mask[kRounds] = {0, 0, 0, 0, 0};
+  hyp_store(lds.best, IR, It, zero_mask, 0, 0, 0.0);
   int best_n = 0;
   float rmse = 0.0f;  // MatchingResult() default (matching_result.h:27)
   int valid_iterations = 0, real_iterations = 0;
@@ -497,7 +645,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 
   // matchNodePair: `all_matches.size() < min_matches` -> no RANSAC (node.cpp:1319);
   // getRelativeTransformationTo: `size <= min_matches` -> false      (node.cpp:1087)
-  if (n_all >= rc.min_matches && n_all > rc.min_matches) {
+  if (n_all > rc.min_matches) {
     uint32_t thr = (uint32_t)rc.min_matches;                                  // :1094
     if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
     const double max_dist_d = (double)rc.max_dist_m;
@@ -507,6 +655,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     float hypR[9], hypt[3];
     bool hyp_nan = true;
     int hyp_base = -kWave;  // iteration index of lane 0's hypothesis
+    int memo_n = 0, memo_next = 0;
 
     for (int it = 0; it < rc.ransac_iterations && n_all >= 4; ++it) {  // :1130
       const int k = real_iterations;
@@ -529,8 +678,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
             const bool dup = (cnt > 0 && ids[0] == id1) || (cnt > 1 && ids[1] == id1) ||
                              (cnt > 2 && ids[2] == id1);
             if (!dup) {
-              // sorted insert
-              uint32_t v = id1;
+              uint32_t v = id1;  // sorted insert
 #pragma unroll
               for (int s = 0; s < 4; ++s) {
                 if (s < cnt) {
@@ -551,15 +699,14 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
           if (s < cnt) acc.add(lds.P, lds.Q, (int)ids[s]);
         tfc_get_transformation(acc, hypR, hypt);
         hyp_nan = has_nan12(hypR, hypt);
+        PH_MARK(2)
       }
       const int hl = k - hyp_base;
       real_iterations++;  // :1139
 
       double refined_error = 1e6;  // :1133
       int refined_n = 0;
-      float refR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, reft[3] = {0, 0, 0};
-      uint64_t ref_mask[kRounds] = {0, 0, 0, 0, 0};
-      uint64_t inl_mask[kRounds];
+      uint64_t inl_mask[kRounds] = {0, 0, 0, 0, 0};
 
       float curR[9], curt[3];
 #pragma unroll
@@ -569,35 +716,68 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       bool cur_nan = (__builtin_amdgcn_readlane((int)hyp_nan, hl) != 0);
 
       for (int refinements = 1; refinements < 20; ++refinements) {  // :1140
-        if (refinements > 1) {
-          // getTransformFromMatches over the current inlier set, in match order (:1142)
-          Tfc acc;
-          acc.reset();
-#pragma unroll
-          for (int r = 0; r < kRounds; ++r) {
-            uint64_t mm = inl_mask[r];
-            while (mm) {
-              const int b = __builtin_ctzll(mm);
-              mm &= mm - 1;
-              acc.add(lds.P, lds.Q, r * kWave + b);
-            }
-          }
-          tfc_get_transformation(acc, curR, curt);
-          cur_nan = has_nan12(curR, curt);
-        }
-        if (cur_nan) break;  // :1144
         int n_inl;
         double inlier_error;
-        score_hypothesis(curR, curt, pts, n_all, rc, lds, inl_mask, n_inl, inlier_error);  // :1148
-        if ((uint32_t)n_inl < thr || inlier_error > max_dist_d) break;              // :1154
-        if (n_inl >= refined_n && inlier_error <= refined_error) {                   // :1160
+        if (refinements == 1) {
+          if (cur_nan) break;  // :1144
+          PH_MARK(5)
+          score_hypothesis(curR, curt, n_all, rc, lds, inl_mask, n_inl, inlier_error);  // :1148
+          PH_MARK(3)
+          PH_COUNT(6)
+        } else {
+          // getTransformFromMatches over the current inlier set (:1142) + scoring (:1148):
+          // a pure function of the set -> memoised per pair.
+          int hit = -1;
+          {
+            bool eq = lane < memo_n;
+            if (eq) {
+#pragma unroll
+              for (int r = 0; r < kRounds; ++r) eq = eq && (lds.memo[lane].key[r] == inl_mask[r]);
+            }
+            const uint64_t hm = __ballot(eq);
+            if (hm) hit = __builtin_ctzll(hm);
+          }
+          if (hit >= 0) {
+            const Hyp& h = lds.memo[hit].val;
+            if (h.nan) break;  // :1144
+#pragma unroll
+            for (int i = 0; i < 9; ++i) curR[i] = h.R[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) curt[i] = h.t[i];
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) inl_mask[r] = uniform_u64(h.mask[r]);
+            n_inl = __builtin_amdgcn_readfirstlane(h.n);
+            inlier_error = h.err;
+          } else {
+            uint64_t key[kRounds];
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) key[r] = inl_mask[r];
+            PH_MARK(5)
+            fit_inliers(inl_mask, lds, curR, curt);
+            cur_nan = has_nan12(curR, curt);
+            PH_MARK(4)
+            PH_COUNT(7)
+            n_inl = 0;
+            inlier_error = 0.0;
+            if (!cur_nan) score_hypothesis(curR, curt, n_all, rc, lds, inl_mask, n_inl, inlier_error);
+            PH_MARK(3)
+            PH_COUNT(6)
+            MemoEntry& me = lds.memo[memo_next];
+            if (lane == 0) {
+#pragma unroll
+              for (int r = 0; r < kRounds; ++r) me.key[r] = key[r];
+            }
+            hyp_store(me.val, curR, curt, inl_mask, n_inl, cur_nan ? 1 : 0, inlier_error);
+            memo_next = (memo_next + 1) % kMemo;
+            if (memo_n < kMemo) memo_n++;
+            __syncthreads();
+            if (cur_nan) break;  // :1144
+          }
+        }
+        if ((uint32_t)n_inl < thr || inlier_error > max_dist_d) break;  // :1154
+        if (n_inl >= refined_n && inlier_error <= refined_error) {       // :1160
           const int prev = refined_n;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) refR[i] = curR[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) reft[i] = curt[i];
-#pragma unroll
-          for (int r = 0; r < kRounds; ++r) ref_mask[r] = inl_mask[r];
+          hyp_store(lds.refined, curR, curt, inl_mask, n_inl, 0, inlier_error);
           refined_n = n_inl;
           refined_error = inlier_error;
           if (n_inl == prev) break;  // :1166
@@ -609,12 +789,9 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         valid_iterations++;
         if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
           rmse = (float)refined_error;  // :1182
-#pragma unroll
-          for (int i = 0; i < 9; ++i) bestR[i] = refR[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) bestt[i] = reft[i];
-#pragma unroll
-          for (int r = 0; r < kRounds; ++r) best_mask[r] = ref_mask[r];
+          __syncthreads();
+          if (lane == 0) lds.best = lds.refined;
+          __syncthreads();
           best_n = refined_n;
           if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
           if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
@@ -623,18 +800,12 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       }
     }
     if (valid_iterations == 0) {  // :1192 identity hypothesis
-      const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, It[3] = {0, 0, 0};
       uint64_t inl_mask[kRounds];
       int n_inl;
       double inlier_error;
-      score_hypothesis(IR, It, pts, n_all, rc, lds, inl_mask, n_inl, inlier_error);
+      score_hypothesis(IR, It, n_all, rc, lds, inl_mask, n_inl, inlier_error);
       if ((uint32_t)n_inl > thr && inlier_error < max_dist_d) {  // :1206
-#pragma unroll
-        for (int i = 0; i < 9; ++i) bestR[i] = IR[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) bestt[i] = It[i];
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) best_mask[r] = inl_mask[r];
+        hyp_store(lds.best, IR, It, inl_mask, n_inl, 0, inlier_error);
         best_n = n_inl;
         rmse = (float)inlier_error;
         valid_iterations++;
@@ -642,9 +813,11 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     }
     found = (uint32_t)best_n >= thr;  // :1275
   }
+  __syncthreads();
 
   // ------------------------------------------------------------------ result POD
   if (lane == 0) {
+    const Hyp& b = lds.best;
     out->n_all = n_all;
     out->n_inl = best_n;
     out->rmse = rmse;
@@ -652,8 +825,8 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) out->trafo[j * 4 + i] = bestR[i * 3 + j];
-      out->trafo[12 + i] = bestt[i];
+      for (int j = 0; j < 3; ++j) out->trafo[j * 4 + i] = b.R[i * 3 + j];
+      out->trafo[12 + i] = b.t[i];
       out->trafo[i * 4 + 3] = 0.0f;
     }
     out->trafo[15] = 1.0f;
@@ -670,7 +843,12 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       out->info_scale = 0.0;
     }
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) out->inlier_mask[r] = best_mask[r];
+    for (int r = 0; r < kRounds; ++r) out->inlier_mask[r] = b.mask[r];
+#ifdef RGBDFE_PROFILE_PHASES
+    PH_MARK(5)
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(out->all_q);
+    for (int i = 0; i < 8; ++i) dbg[i] = ph[i];
+#endif
   }
 }
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes for bench.py.
+# Usage: tools/profile_gpu.sh <tag>     -> gpurun_out/prof_<tag>/...
+set -u
+TAG=${1:-r01}
+REPO=$PWD
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $BENCH > $OUT/bench_write.json 2> $OUT/write.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -o sq -- $BENCH > $OUT/bench_sq.json 2> $OUT/sq.err
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o sq2 -- $BENCH > $OUT/bench_sq2.json 2> $OUT/sq2.err
+cd $REPO
+python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
+# keep the merge-back small: drop the big per-dispatch CSVs, keep stats + summaries
+find $OUT -name "*.db" -delete
+find $OUT -name "*_agent_info.csv" -delete
+du -sh $OUT

@@ -1,0 +1,82 @@
+"""Summarise rocprofv3 outputs of tools/profile_gpu.sh: per-kernel average duration (kernel-trace
+stats) and per-launch HBM traffic from the FETCH_SIZE / WRITE_SIZE PMC passes.
+
+HBM bytes follow MI355X_MICROARCH.md section "HBM": FETCH_SIZE / WRITE_SIZE are reported in KiB
+units (x1024); on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of a wide coalesced read, so
+the read side is doubled ("corrected"); other access widths are uncalibrated -- both the raw and
+the corrected numbers are kept."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out_dir = sys.argv[1]
+summary = {}
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out_dir, pattern), recursive=True))
+
+
+def short(name):
+    for k in ("hamming_nn_kernel", "select_ransac_kernel", "project_to_3d_kernel"):
+        if k in name:
+            return k.replace("_kernel", "")
+    return None
+
+
+# kernel-trace stats
+for f in find("trace/**/*kernel_stats.csv"):
+    for row in csv.DictReader(open(f)):
+        k = short(row.get("Name", ""))
+        if k:
+            summary.setdefault(k, {})
+            summary[k]["calls"] = int(row["Calls"])
+            summary[k]["avg_ns"] = float(row["AverageNs"])
+            summary[k]["total_ns"] = float(row["TotalDurationNs"])
+            summary[k]["pct"] = float(row["Percentage"])
+    print("kernel stats:", f)
+
+# per-dispatch durations from the kernel trace (cross-check of the stats)
+for f in find("trace/**/*kernel_trace.csv"):
+    dur = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        k = short(row.get("Kernel_Name", ""))
+        if k:
+            dur[k].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for k, v in dur.items():
+        summary.setdefault(k, {})["trace_avg_ns"] = sum(v) / len(v)
+        summary[k]["trace_min_ns"] = min(v)
+        summary[k]["trace_max_ns"] = max(v)
+
+
+def pmc(pattern):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in find(pattern):
+        for row in csv.DictReader(open(f)):
+            k = short(row.get("Kernel_Name", ""))
+            if k:
+                acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+for name, pat in (("fetch", "pmc_fetch/**/*counter_collection.csv"),
+                  ("write", "pmc_write/**/*counter_collection.csv"),
+                  ("sq", "pmc_sq/**/*counter_collection.csv"),
+                  ("sq2", "pmc_sq2/**/*counter_collection.csv")):
+    for k, ctrs in pmc(pat).items():
+        for c, vals in ctrs.items():
+            summary.setdefault(k, {})[c + "_avg"] = sum(vals) / len(vals)
+            summary[k][c + "_n"] = len(vals)
+
+for k, s in summary.items():
+    if "FETCH_SIZE_avg" in s and "WRITE_SIZE_avg" in s:
+        s["hbm_read_bytes_raw"] = s["FETCH_SIZE_avg"] * 1024
+        s["hbm_write_bytes_raw"] = s["WRITE_SIZE_avg"] * 1024
+        s["hbm_bytes_per_launch"] = 2 * s["hbm_read_bytes_raw"] + s["hbm_write_bytes_raw"]
+        s["note"] = "hbm_bytes_per_launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction)"
+
+print(json.dumps(summary, indent=1, sort_keys=True))
+json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1, sort_keys=True)
