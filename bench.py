@@ -100,17 +100,31 @@ def main():
         fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 
     rec_bytes = RESULT_DTYPE.itemsize
-    d_local = torch.zeros(n_pad * rec_bytes, dtype=torch.uint8, device="cuda")
+    # Steps are pipelined: step k is submitted to one of the context's internal streams while
+    # step k-1 still runs (its RANSAC tail overlaps step k's Hamming kernel).  A ring of result
+    # buffers keeps every step's output alive until its all-gather has consumed it.
+    NBUF = 4
+    d_local = [torch.zeros(n_pad * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     d_all = torch.zeros(world * n_pad * rec_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    consumed = [None] * NBUF
     stream = torch.cuda.current_stream().cuda_stream
+    state = {"k": 0}
 
     def step():
-        fe.match_pair_list_device(pq, pt, d_local.data_ptr(), stream)
+        b = state["k"] % NBUF
+        state["k"] += 1
+        if consumed[b] is not None:
+            consumed[b].synchronize()  # the all-gather that read this buffer (4 steps ago) is done
+        ticket = fe.submit_pair_list(pq, pt, d_local[b].data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_local)
+            fe.wait_ticket(ticket, stream)  # torch's stream waits for this batch only
+            dist.all_gather_into_tensor(d_all, d_local[b])
+            consumed[b] = torch.cuda.Event()
+            consumed[b].record()
 
     for _ in range(args.warmup):
         step()
+    fe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -121,7 +135,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    fe.synchronize()            # every internal stream of the context
+    torch.cuda.synchronize()    # device-wide
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
@@ -138,7 +153,8 @@ def main():
     value = total_pairs / elapsed
 
     # sanity: results of the last step are real (edges found)
-    res = np.frombuffer(d_local.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[:n_local]
+    last = d_local[(state["k"] - 1) % NBUF]
+    res = np.frombuffer(last.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[:n_local]
     edge_frac = float((res["id1"] >= 0).mean()) if n_local else 0.0
     mean_iters = float(res["real_iterations"].mean()) if n_local else 0.0
 

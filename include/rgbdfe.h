@@ -116,6 +116,14 @@ int rgbdfe_match_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int3
 int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids,
                                   const int32_t* train_ids, int32_t n_pairs, void* d_out,
                                   void* stream);
+/* Fully asynchronous form for pipelined callers: the batch is enqueued on one of the
+ * context's internal streams (consecutive batches alternate streams, so batch k+1 overlaps the
+ * tail of batch k) and identified by *ticket.  rgbdfe_wait_ticket makes `stream` (a
+ * hipStream_t) wait for that batch, or blocks the host when stream == NULL.  d_out must stay
+ * valid and untouched until the ticket has been waited for. */
+int rgbdfe_submit_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                            int32_t n_pairs, void* d_out, int64_t* ticket);
+int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream);
 int rgbdfe_synchronize(rgbdfe_ctx* ctx);
 
 /* ---- pieces of the pair op, exposed for A/B and parity ------------------- */

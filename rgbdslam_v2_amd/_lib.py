@@ -115,6 +115,10 @@ def load():
     L.rgbdfe_match_pair_list.argtypes = [ctx, vp, vp, i32, vp]
     L.rgbdfe_match_pair_list_device.restype = C.c_int
     L.rgbdfe_match_pair_list_device.argtypes = [ctx, vp, vp, i32, vp, vp]
+    L.rgbdfe_submit_pair_list.restype = C.c_int
+    L.rgbdfe_submit_pair_list.argtypes = [ctx, vp, vp, i32, vp, C.POINTER(C.c_int64)]
+    L.rgbdfe_wait_ticket.restype = C.c_int
+    L.rgbdfe_wait_ticket.argtypes = [ctx, C.c_int64, vp]
     L.rgbdfe_synchronize.restype = C.c_int
     L.rgbdfe_synchronize.argtypes = [ctx]
     L.rgbdfe_hamming_nn_nodes.restype = C.c_int
@@ -146,6 +150,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_status_string", "rgbdfe_last_error", "rgbdfe_upload_node",
     "rgbdfe_upload_node_device", "rgbdfe_release_node", "rgbdfe_node_count",
     "rgbdfe_match_node_pairs", "rgbdfe_match_pair_list", "rgbdfe_match_pair_list_device",
+    "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket",
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
     "rgbdfe_project_to_3d", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
     "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",

@@ -47,20 +47,28 @@ struct rgbdfe_ctx {
   // slabs
   uint32_t* d_desc = nullptr;  // max_nodes x max_kp x 8 dwords (+ pad rows)
   float4* d_xyz = nullptr;     // max_nodes x max_kp
-  // per-batch staging: a ring of pair-list buffers so that the host can prepare batch k+1
-  // while batch k runs (the keys/results buffers are ordered by the stream itself)
+  // Batches run on kLanes internal HIP streams ("lanes"), each with its own keys / results
+  // staging, so that batch k+1's Hamming kernel fills the SIMDs that batch k's RANSAC tail
+  // leaves idle.  The pair lists go through a ring of pinned buffers so the host can prepare
+  // batch k+1 while batch k runs.
+  static constexpr int kLanes = 2;
   static constexpr int kRing = 4;
+  struct Lane {
+    hipStream_t stream = nullptr;
+    uint32_t* d_keys = nullptr;             // max_pairs x max_kp
+    rgbdfe_match_result* d_results = nullptr;  // staging for the host-output entry points
+  };
   struct Slot {
     PairWork* h_work = nullptr;  // pinned
     PairWork* d_work = nullptr;
     hipEvent_t done = nullptr;
     bool pending = false;
+    int64_t ticket = 0;
   };
+  Lane lanes[kLanes];
   Slot ring[kRing];
-  int ring_next = 0;
-  hipStream_t last_stream = nullptr;
-  uint32_t* d_keys = nullptr;  // max_pairs x max_kp
-  rgbdfe_match_result* d_results = nullptr;
+  int64_t next_ticket = 1;
+  hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   // scratch for single-pair helpers / project_to_3d
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -146,7 +154,8 @@ hipEvent_t get_event(rgbdfe_ctx* ctx) {
 
 // fold finished timing records into the totals
 void drain_pending(rgbdfe_ctx* ctx) {
-  if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
+  for (auto& ln : ctx->lanes)
+    if (ln.stream) (void)hipStreamSynchronize(ln.stream);
   for (auto& p : ctx->pending) {
     float ms_h = 0.f, ms_r = 0.f;
     if (hipEventElapsedTime(&ms_h, p.a, p.b) == hipSuccess &&
@@ -165,18 +174,19 @@ void drain_pending(rgbdfe_ctx* ctx) {
   ctx->pending.clear();
 }
 
-// Build the PairWork list (host) and enqueue H2D + both kernels on `stream`.
-// Results land in d_out (device).  Caller holds the lock.
+// Build the PairWork list (host) and enqueue H2D + both kernels on the next lane.
+// Results land in d_out (device memory; nullptr = the lane's own staging buffer).
+// Returns the batch's ticket.  Caller holds the lock.
 int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int32_t n,
-                  rgbdfe_match_result* d_out, hipStream_t stream) {
-  if (n == 0) return RGBDFE_OK;
+                  rgbdfe_match_result* d_out, hipEvent_t wait_for, int64_t* ticket_out,
+                  int* lane_out) {
   if (n > ctx->cfg.max_pairs_per_batch)
     return fail(ctx, RGBDFE_ERR_CAPACITY, "n_pairs exceeds max_pairs_per_batch");
-  // d_keys is shared by consecutive batches: they must be ordered on one stream
-  if (ctx->last_stream && ctx->last_stream != stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
-  ctx->last_stream = stream;
-  rgbdfe_ctx::Slot& slot = ctx->ring[ctx->ring_next];
-  ctx->ring_next = (ctx->ring_next + 1) % rgbdfe_ctx::kRing;
+  const int64_t ticket = ctx->next_ticket;
+  rgbdfe_ctx::Slot& slot = ctx->ring[ticket % rgbdfe_ctx::kRing];
+  const int li = (int)(ticket % rgbdfe_ctx::kLanes);
+  rgbdfe_ctx::Lane& lane = ctx->lanes[li];
+  hipStream_t stream = lane.stream;
   if (slot.pending) {
     HIP_TRY(ctx, hipEventSynchronize(slot.done));
     slot.pending = false;
@@ -199,28 +209,50 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     if (w.nq > max_nq) max_nq = w.nq;
     if (w.nt > max_nt) max_nt = w.nt;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n,
-                              hipMemcpyHostToDevice, stream));
-  rgbdfe_ctx::Pending pend{};
-  if (ctx->profiling) {
-    pend.a = get_event(ctx);
-    pend.b = get_event(ctx);
-    pend.c = get_event(ctx);
-    pend.pairs = n;
-    (void)hipEventRecord(pend.a, stream);
+  ctx->next_ticket++;
+  slot.ticket = ticket;
+  if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(stream, wait_for, 0));
+  if (n > 0) {
+    if (!d_out) d_out = lane.d_results;
+    HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n,
+                                hipMemcpyHostToDevice, stream));
+    rgbdfe_ctx::Pending pend{};
+    if (ctx->profiling) {
+      pend.a = get_event(ctx);
+      pend.b = get_event(ctx);
+      pend.c = get_event(ctx);
+      pend.pairs = n;
+      (void)hipEventRecord(pend.a, stream);
+    }
+    launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, (uint32_t)ctx->cfg.max_keypoints,
+                      (uint32_t)n, max_nq, max_nt, stream);
+    if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
+    launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, d_out,
+                         (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->rc, stream);
+    if (ctx->profiling) {
+      (void)hipEventRecord(pend.c, stream);
+      ctx->pending.push_back(pend);
+    }
+    HIP_TRY(ctx, hipGetLastError());
   }
-  launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints,
-                    (uint32_t)n, max_nq, max_nt, stream);
-  if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-  launch_select_ransac(ctx->d_xyz, slot.d_work, ctx->d_keys, d_out,
-                       (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->rc, stream);
-  if (ctx->profiling) {
-    (void)hipEventRecord(pend.c, stream);
-    ctx->pending.push_back(pend);
-  }
-  HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(slot.done, stream));
   slot.pending = true;
+  if (ticket_out) *ticket_out = ticket;
+  if (lane_out) *lane_out = li;
+  return RGBDFE_OK;
+}
+
+// Make `stream` (or the host when stream == nullptr) wait for the batch with this ticket.
+int wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, hipStream_t stream) {
+  if (ticket <= 0 || ticket >= ctx->next_ticket) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "unknown ticket");
+  rgbdfe_ctx::Slot& slot = ctx->ring[ticket % rgbdfe_ctx::kRing];
+  if (slot.ticket != ticket || !slot.pending) return RGBDFE_OK;  // slot reused => that batch has completed
+  if (stream) {
+    HIP_TRY(ctx, hipStreamWaitEvent(stream, slot.done, 0));
+  } else {
+    HIP_TRY(ctx, hipEventSynchronize(slot.done));
+    slot.pending = false;
+  }
   return RGBDFE_OK;
 }
 
@@ -261,6 +293,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(RGBDFE_ERR_HIP);
+  if (hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) return bail(RGBDFE_ERR_HIP);
   const size_t rows = (size_t)cfg->max_nodes * (size_t)cfg->max_keypoints + 16;  // +pad: prefetch overrun
   if (hipMalloc((void**)&ctx->d_desc, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
   if (hipMalloc((void**)&ctx->d_xyz, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
@@ -273,10 +306,13 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
       return bail(RGBDFE_ERR_OUT_OF_MEMORY);
     if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) return bail(RGBDFE_ERR_HIP);
   }
-  if (hipMalloc((void**)&ctx->d_keys, np * (size_t)cfg->max_keypoints * 4) != hipSuccess)
-    return bail(RGBDFE_ERR_OUT_OF_MEMORY);
-  if (hipMalloc((void**)&ctx->d_results, np * sizeof(rgbdfe_match_result)) != hipSuccess)
-    return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  for (auto& ln : ctx->lanes) {
+    if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+    if (hipMalloc((void**)&ln.d_keys, np * (size_t)cfg->max_keypoints * 4) != hipSuccess)
+      return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+    if (hipMalloc((void**)&ln.d_results, np * sizeof(rgbdfe_match_result)) != hipSuccess)
+      return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  }
   ctx->free_slots.reserve(cfg->max_nodes);
   for (int32_t s = cfg->max_nodes - 1; s >= 0; --s) ctx->free_slots.push_back((uint32_t)s);
   *out = ctx;
@@ -296,8 +332,12 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (sl.h_work) (void)hipHostFree(sl.h_work);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
-  if (ctx->d_keys) (void)hipFree(ctx->d_keys);
-  if (ctx->d_results) (void)hipFree(ctx->d_results);
+  for (auto& ln : ctx->lanes) {
+    if (ln.d_keys) (void)hipFree(ln.d_keys);
+    if (ln.d_results) (void)hipFree(ln.d_results);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+  }
+  if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -337,7 +377,8 @@ static int upload_common(rgbdfe_ctx* ctx, int32_t node_id, const void* desc, con
   uint32_t slot;
   auto it = ctx->nodes.find(node_id);
   if (it != ctx->nodes.end()) {
-    slot = it->second.slot;
+    slot = it->second.slot;  // overwrite in place: wait for batches that may still read it
+    for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   } else {
     if (ctx->free_slots.empty()) return fail(ctx, RGBDFE_ERR_CAPACITY, "no free node slot (max_nodes)");
     slot = ctx->free_slots.back();
@@ -371,6 +412,8 @@ int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id) {
   std::lock_guard<std::mutex> g(ctx->mu);
   auto it = ctx->nodes.find(node_id);
   if (it == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "release of unknown node");
+  // batches in flight may still read this slot
+  for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   ctx->free_slots.push_back(it->second.slot);
   ctx->nodes.erase(it);
   return RGBDFE_OK;
@@ -391,14 +434,20 @@ int rgbdfe_match_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int3
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   const int32_t cap = ctx->cfg.max_pairs_per_batch;
-  for (int32_t off = 0; off < n_pairs; off += cap) {
+  int chunk = 0;
+  for (int32_t off = 0; off < n_pairs; off += cap, ++chunk) {
     const int32_t n = (n_pairs - off) < cap ? (n_pairs - off) : cap;
-    int rc = enqueue_pairs(ctx, query_ids + off, train_ids + off, n, ctx->d_results, ctx->stream);
+    // a lane's result staging buffer is free again once its previous chunk was copied out
+    const int li_next = (int)(ctx->next_ticket % rgbdfe_ctx::kLanes);
+    if (chunk >= rgbdfe_ctx::kLanes) HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[li_next].stream));
+    int li = 0;
+    int rc = enqueue_pairs(ctx, query_ids + off, train_ids + off, n, nullptr, nullptr, nullptr, &li);
     if (rc != RGBDFE_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out + off, ctx->d_results, sizeof(rgbdfe_match_result) * (size_t)n,
-                                hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h_work / d_results are reused
+    HIP_TRY(ctx, hipMemcpyAsync(out + off, ctx->lanes[li].d_results,
+                                sizeof(rgbdfe_match_result) * (size_t)n, hipMemcpyDeviceToHost,
+                                ctx->lanes[li].stream));
   }
+  for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   if (ctx->profiling) drain_pending(ctx);
   return RGBDFE_OK;
 }
@@ -417,23 +466,48 @@ int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids,
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  // in-order semantics on the caller's stream: the batch starts after everything already
+  // enqueued on `stream`, and `stream` continues after the batch.
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  return enqueue_pairs(ctx, query_ids, train_ids, n_pairs, (rgbdfe_match_result*)d_out, s);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_in, s));
+  int64_t ticket = 0;
+  int rc = enqueue_pairs(ctx, query_ids, train_ids, n_pairs, (rgbdfe_match_result*)d_out, ctx->ev_in,
+                         &ticket, nullptr);
+  if (rc != RGBDFE_OK) return rc;
+  return wait_ticket(ctx, ticket, s);
+}
+
+int rgbdfe_submit_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                            int32_t n_pairs, void* d_out, int64_t* ticket) {
+  if (!ctx || n_pairs < 0 || !ticket || (n_pairs > 0 && (!query_ids || !train_ids || !d_out)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad submit arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  return enqueue_pairs(ctx, query_ids, train_ids, n_pairs, (rgbdfe_match_result*)d_out, nullptr, ticket,
+                       nullptr);
+}
+
+int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  return wait_ticket(ctx, ticket, (hipStream_t)stream);
 }
 
 int rgbdfe_synchronize(rgbdfe_ctx* ctx) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
-  drain_pending(ctx);
+  drain_pending(ctx);  // synchronises every lane
   return RGBDFE_OK;
 }
 
 static int hamming_keys_to_host(rgbdfe_ctx* ctx, uint32_t nq, int32_t* out_hd, int32_t* out_idx) {
   std::vector<uint32_t> keys(nq);
-  HIP_TRY(ctx, hipMemcpyAsync(keys.data(), ctx->d_keys, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  hipStream_t st = ctx->lanes[0].stream;
+  HIP_TRY(ctx, hipMemcpyAsync(keys.data(), ctx->lanes[0].d_keys, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
   for (uint32_t i = 0; i < nq; ++i) {
     const uint32_t hd = keys[i] >> 16;
     if (hd > 256u) {  // nothing searched: (257, -1), features.cpp:172-173
@@ -456,18 +530,18 @@ int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   auto t = ctx->nodes.find(train_id);
   if (q == ctx->nodes.end() || t == ctx->nodes.end())
     return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "node not resident");
-  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+  for (auto& sl : ctx->ring) sl.pending = false;  // every lane is idle now
   rgbdfe_ctx::Slot& slot = ctx->ring[0];
-  if (slot.pending) { HIP_TRY(ctx, hipEventSynchronize(slot.done)); slot.pending = false; }
+  hipStream_t st = ctx->lanes[0].stream;
   PairWork& w = slot.h_work[0];
   w.q_slot = q->second.slot; w.t_slot = t->second.slot;
   w.nq = q->second.n; w.nt = t->second.n;
   w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id; w.pad = 0;
   if (w.nq == 0) return RGBDFE_OK;
-  HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, ctx->stream));
-  ctx->last_stream = ctx->stream;
-  launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->d_keys, (uint32_t)ctx->cfg.max_keypoints, 1u,
-                    w.nq, w.nt, ctx->stream);
+  HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, st));
+  launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->lanes[0].d_keys, (uint32_t)ctx->cfg.max_keypoints, 1u,
+                    w.nq, w.nt, st);
   HIP_TRY(ctx, hipGetLastError());
   return hamming_keys_to_host(ctx, w.nq, out_hd, out_idx);
 }

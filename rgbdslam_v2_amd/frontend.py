@@ -171,6 +171,19 @@ class FrontEnd:
         self._check(self._L.rgbdfe_match_pair_list_device(self._ctx, q.ctypes.data, t.ctypes.data,
                                                           q.shape[0], d_out_ptr, stream))
 
+    def submit_pair_list(self, query_ids: np.ndarray, train_ids: np.ndarray, d_out_ptr: int) -> int:
+        """Pipelined variant: enqueue on an internal stream, return a ticket (see wait_ticket)."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        ticket = C.c_int64(0)
+        self._check(self._L.rgbdfe_submit_pair_list(self._ctx, q.ctypes.data, t.ctypes.data,
+                                                    q.shape[0], d_out_ptr, C.byref(ticket)))
+        return ticket.value
+
+    def wait_ticket(self, ticket: int, stream: Optional[int] = None):
+        """Make `stream` (hipStream_t as int) wait for the batch, or block the host if None."""
+        self._check(self._L.rgbdfe_wait_ticket(self._ctx, ticket, stream))
+
     def synchronize(self):
         self._check(self._L.rgbdfe_synchronize(self._ctx))
 
