@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--frames", type=int, default=N_FRAMES)
     ap.add_argument("--kp", type=int, default=N_KP)
     ap.add_argument("--pairs-per-frame", type=int, default=PAIRS_PER_FRAME)
+    ap.add_argument("--config", choices=["orb", "sift"], default="orb",
+                    help="orb = BASELINE configs[1] (the headline metric); sift = configs[3]: SIFT 128-d "
+                         "float descriptors, dot-product matrix on the bf16 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -74,7 +77,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from rgbdslam_v2_amd import synth
-    from rgbdslam_v2_amd._lib import KERNEL_HAMMING, KERNEL_RANSAC, RESULT_DTYPE
+    from rgbdslam_v2_amd._lib import (KERNEL_HAMMING, KERNEL_RANSAC, KERNEL_SIFT_DOT,
+                                      KERNEL_SIFT_FINISH, RESULT_DTYPE)
     from rgbdslam_v2_amd.frontend import FrontEnd
     from rgbdslam_v2_amd.dist import shard_pairs
 
@@ -96,8 +100,13 @@ def main():
     fe = FrontEnd(device_id=local_rank, max_nodes=F, max_keypoints=((N + 63) // 64) * 64,
                   max_pairs_per_batch=max(n_pad, 1), seed=SEED)
     # node features -> HBM (resident before the timed region)
+    sift = args.config == "sift"
+    sift_desc = synth.sift_descriptors_like(seq["desc"], seed=SEED) if sift else None
     for f in range(F):
-        fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+        if sift:
+            fe.upload_sift_node(f, sift_desc[f], seq["xyz1"][f])
+        else:
+            fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 
     rec_bytes = RESULT_DTYPE.itemsize
     # Steps are pipelined: step k is submitted to one of the context's internal streams while
@@ -115,7 +124,10 @@ def main():
         state["k"] += 1
         if consumed[b] is not None:
             consumed[b].synchronize()  # the all-gather that read this buffer (4 steps ago) is done
-        ticket = fe.submit_pair_list(pq, pt, d_local[b].data_ptr())
+        if sift:
+            ticket = fe.submit_sift_pair_list(pq, pt, d_local[b].data_ptr())
+        else:
+            ticket = fe.submit_pair_list(pq, pt, d_local[b].data_ptr())
         if world > 1:
             fe.wait_ticket(ticket, stream)  # torch's stream waits for this batch only
             dist.all_gather_into_tensor(d_all, d_local[b])
@@ -146,8 +158,9 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     fe.set_profiling(False)
-    ham_ms, ham_launches, ham_pairs = fe.kernel_time(KERNEL_HAMMING)
+    ham_ms, ham_launches, ham_pairs = fe.kernel_time(KERNEL_SIFT_DOT if sift else KERNEL_HAMMING)
     rsc_ms, rsc_launches, rsc_pairs = fe.kernel_time(KERNEL_RANSAC)
+    fin_ms, fin_launches, _ = fe.kernel_time(KERNEL_SIFT_FINISH)
 
     total_pairs = sum(counts) * args.steps
     value = total_pairs / elapsed
@@ -174,6 +187,34 @@ def main():
                 traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if sift:
+            # configs[3]: the dense contraction.  FLOP per pair = 2 * Nq * Nt * 128 on the bf16 MFMA
+            # (dense peak 2.5 PFLOP/s, MI355X_MICROARCH.md); reported for the MFMA kernel itself.
+            flop = 2.0 * N * N * 128 * n_local
+            tf = flop / (ham_avg_ms * 1e-3) / 1e12 if ham_launches else 0.0
+            out = {
+                "metric": "frame-pairs matched+RANSAC/sec, 640x480 SIFT-1000 (128-d float, bf16 MFMA)",
+                "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16 MFMA (exact u8 dot products) + f32/f64 (RANSAC)", "data": "synthetic",
+                "config": {"workload": "configs[3]: synthetic SIFT 128-d float descriptors, %d kp, %d candidate "
+                                       "pairs/frame, %d frames" % (N, args.pairs_per_frame, F),
+                           "pairs_per_gpu_per_step": n_local, "edge_fraction": round(edge_frac, 4),
+                           "mean_ransac_iterations": round(mean_iters, 2)},
+                "roofline": {"bound": "mfma", "kernel": "sift_dot_top2", "achieved": round(tf, 3),
+                             "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
+                             "traffic": None, "flop_per_pair": 2.0 * N * N * 128,
+                             "pairs_per_launch": n_local, "avg_launch_ms": round(ham_avg_ms, 4),
+                             "finish_ms_per_launch": round(fin_ms / max(fin_launches, 1), 4),
+                             "ransac_ms_per_launch": round(rsc_ms / max(rsc_launches, 1), 4)},
+            }
+            print(json.dumps(out), flush=True)
+            fe.close()
+            if world > 1:
+                dist.destroy_process_group()
+            return
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

@@ -126,6 +126,25 @@ int rgbdfe_submit_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int
 int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream);
 int rgbdfe_synchronize(rgbdfe_ctx* ctx);
 
+/* ---- SIFT (128-d float descriptor) nodes: matcher_type == "SIFTGPU" ------------------------
+ * Replaces SiftGPUWrapper::match (sift_gpu_wrapper.h:61, sift_gpu_wrapper.cpp:169-227) inside
+ * Node::featureMatching (node.cpp:553-557): u8-quantised dot products (exact on the bf16 MFMA),
+ * acos distance / ratio tests, mutual best, DMatch.distance = float L2 of the raw descriptors.
+ * desc128: n x 128 float, as Node::siftgpu_descriptors holds them (node.h:172). */
+int rgbdfe_upload_sift_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc128,
+                            const float* xyz1, int32_t n);
+/* Batched matchNodePair for SIFT nodes.  out_dist (may be NULL): n_pairs x RGBDFE_MAX_MATCHES
+ * floats, the DMatch.distance of out[i].all_q/all_t (all_hd is 0 on this path). */
+int rgbdfe_match_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                int32_t n_pairs, rgbdfe_match_result* out, float* out_dist);
+/* same, asynchronous with results in HBM (see rgbdfe_submit_pair_list); d_out_dist may be NULL */
+int rgbdfe_submit_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                 int32_t n_pairs, void* d_out, void* d_out_dist, int64_t* ticket);
+/* Twin of SiftGPUWrapper::match for two resident SIFT nodes: the mutual-best matches in ascending
+ * query order (before keepStrongestMatches).  Arrays sized >= rows of the query node. */
+int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* match_q,
+                            int32_t* match_t, float* match_dist, int32_t* n_matches);
+
 /* ---- pieces of the pair op, exposed for A/B and parity ------------------- */
 /* Batched bruteForceSearchORB (features.h:14, features.cpp:168-182) of every row of
  * query node against train node: out_hd[i] in [0,257], out_idx[i] (or -1), including
@@ -150,7 +169,8 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, every launch of the dominant kernels is bracketed by HIP events on the
  * stream it runs on; totals are read back with rgbdfe_get_kernel_time. */
-enum { RGBDFE_KERNEL_HAMMING = 0, RGBDFE_KERNEL_RANSAC = 1, RGBDFE_KERNEL_COUNT = 2 };
+enum { RGBDFE_KERNEL_HAMMING = 0, RGBDFE_KERNEL_RANSAC = 1, RGBDFE_KERNEL_SIFT_DOT = 2,
+       RGBDFE_KERNEL_SIFT_FINISH = 3, RGBDFE_KERNEL_COUNT = 4 };
 int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable);
 int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t* launches,
                            int64_t* pairs);

@@ -104,6 +104,11 @@ def lib():
         L.orc_project_to_3d.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_double,
                                         C.c_double, C.c_double, C.c_double, C.c_int, vp, vp]
         L.orc_num_cores.restype = C.c_int
+        L.orc_sift_match.restype = C.c_int
+        L.orc_sift_match.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+        L.orc_match_sift_node_pair.restype = None
+        L.orc_match_sift_node_pair.argtypes = [vp, vp, C.c_int, C.c_int32, vp, vp, C.c_int, C.c_int32,
+                                               C.POINTER(OrcParams), C.POINTER(OrcResult), vp]
         _lib = L
     return _lib
 
@@ -257,3 +262,30 @@ def project_to_3d(kp_xy, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints
 
 def num_cores():
     return lib().orc_num_cores()
+
+
+def sift_match(d1, d2):
+    """SiftGPUWrapper::match restatement: (queryIdx, trainIdx, L2 distance) in ascending query order."""
+    d1 = np.ascontiguousarray(d1, np.float32)
+    d2 = np.ascontiguousarray(d2, np.float32)
+    n1 = d1.shape[0]
+    mq = np.empty(max(n1, 1), np.int32)
+    mt = np.empty(max(n1, 1), np.int32)
+    md = np.empty(max(n1, 1), np.float32)
+    n = lib().orc_sift_match(_p(d1), n1, _p(d2), d2.shape[0], _p(mq), _p(mt), _p(md))
+    return mq[:n].copy(), mt[:n].copy(), md[:n].copy()
+
+
+def match_sift_node_pair(qdesc, qxyz1, qid, tdesc, txyz1, tid, params=None):
+    params = params or default_params()
+    qdesc = np.ascontiguousarray(qdesc, np.float32)
+    tdesc = np.ascontiguousarray(tdesc, np.float32)
+    qxyz1 = np.ascontiguousarray(qxyz1, np.float32)
+    txyz1 = np.ascontiguousarray(txyz1, np.float32)
+    out = OrcResult()
+    dist = np.zeros(ORC_MAX_MATCHES, np.float32)
+    lib().orc_match_sift_node_pair(_p(qdesc), _p(qxyz1), qdesc.shape[0], qid, _p(tdesc), _p(txyz1),
+                                   tdesc.shape[0], tid, C.byref(params), C.byref(out), _p(dist))
+    r = result_to_dict(out)
+    r["all_dist"] = dist[: r["n_all"]].copy()
+    return r

@@ -642,3 +642,176 @@ int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows
   }
   return n;
 }
+
+
+/* ========================================================================= */
+/* SIFT (128-d float descriptor) matcher: SiftGPUWrapper::match semantics      */
+/* src/sift_gpu_wrapper.cpp:169-227 over SiftMatchGPU (CUDA back end):          */
+/*   external/SiftGPU/src/SiftGPU/SiftMatchCU.cpp:87-100  (u8 quantisation)     */
+/*   ProgramCU.cu:1405-1482 MultiplyDescriptor_Kernel (u8 dot products + per-8- */
+/*     row column partials), :1689-1743 RowMatch_Kernel, :1764-1782             */
+/*     ColMatch_Kernel, SiftMatchCU.cpp:148-177 GetBestMatch (mutual best).     */
+/* ========================================================================= */
+#define ORC_SIFT_DIM 128
+#define ORC_SIFT_MAX 4096 /* sift_gpu_wrapper.cpp:231 CreateNewSiftMatchGPU(4096) */
+
+static void orc_sift_quantise(const float* d, int n, unsigned char* q) {
+  /* SiftMatchCU.cpp:96-99: pub[i] = int(512 * descriptors[i] + 0.5); */
+  for (int i = 0; i < n * ORC_SIFT_DIM; ++i) q[i] = (unsigned char)(int)(512 * d[i] + 0.5);
+}
+
+static float orc_sift_angle(int dot) {
+  /* ProgramCU.cu:1738: acos(min(dot * 0.000003814697265625f, 1.0)) : float product, double
+   * min / acos, float result */
+  float prod = (float)dot * 0.000003814697265625f;
+  double v = (double)prod < 1.0 ? (double)prod : 1.0;
+  return (float)acos(v);
+}
+
+/* Returns number of matches; mq/mt/dist sized >= n1. */
+int orc_sift_match(const float* d1, int n1, const float* d2, int n2, int32_t* mq, int32_t* mt,
+                   float* dist_out) {
+  if (n1 > ORC_SIFT_MAX) n1 = ORC_SIFT_MAX; /* SiftMatchCU.cpp:93 */
+  if (n2 > ORC_SIFT_MAX) n2 = ORC_SIFT_MAX;
+  if (n1 <= 0 || n2 <= 0) return 0; /* SiftMatchCU.cpp:141 */
+  const float distmax = 0.9f, ratiomax = 0.9f; /* sift_gpu_wrapper.cpp:185 */
+  unsigned char* q1 = (unsigned char*)malloc((size_t)n1 * ORC_SIFT_DIM);
+  unsigned char* q2 = (unsigned char*)malloc((size_t)n2 * ORC_SIFT_DIM);
+  orc_sift_quantise(d1, n1, q1);
+  orc_sift_quantise(d2, n2, q2);
+  int* dot = (int*)malloc(sizeof(int) * (size_t)n2);
+  int* row_match = (int*)malloc(sizeof(int) * (size_t)n1);
+  /* column state merged over 8-row blocks in block order (ColMatch_Kernel) */
+  int* cmax = (int*)calloc((size_t)n2, sizeof(int));
+  int* cidx = (int*)malloc(sizeof(int) * (size_t)n2);
+  int* cnxt = (int*)calloc((size_t)n2, sizeof(int));
+  int* bmax = (int*)malloc(sizeof(int) * (size_t)n2);
+  int* bidx = (int*)malloc(sizeof(int) * (size_t)n2);
+  int* bnxt = (int*)malloc(sizeof(int) * (size_t)n2);
+  for (int j = 0; j < n2; ++j) cidx[j] = -1;
+  int first_block = 1;
+  for (int i0 = 0; i0 < n1; i0 += 8) {
+    for (int j = 0; j < n2; ++j) { bmax[j] = 0; bidx[j] = -1; bnxt[j] = 0; } /* :1457 */
+    for (int i = i0; i < i0 + 8 && i < n1; ++i) {
+      const unsigned char* a = q1 + (size_t)i * ORC_SIFT_DIM;
+      for (int j = 0; j < n2; ++j) {
+        const unsigned char* b = q2 + (size_t)j * ORC_SIFT_DIM;
+        int s = 0;
+        for (int k = 0; k < ORC_SIFT_DIM; ++k) s += (int)a[k] * (int)b[k];
+        dot[j] = s;
+        /* :1464-1467 */
+        if (s > bmax[j]) { bnxt[j] = bmax[j]; bmax[j] = s; bidx[j] = i; }
+        else if (s > bnxt[j]) bnxt[j] = s;
+      }
+      /* RowMatch_Kernel: 32 threads scan columns t, t+32, ... then a tree reduction */
+      int tmax[32], tnxt[32], tidx[32];
+      for (int t = 0; t < 32; ++t) {
+        int m = 0, nx = 0, id = -1;
+        for (int j = t; j < n2; j += 32) {
+          int v = dot[j];
+          int test = v > m;
+          nx = test ? m : (nx > v ? nx : v);
+          id = test ? j : id;
+          m = test ? v : m;
+        }
+        tmax[t] = m; tnxt[t] = nx; tidx[t] = id;
+      }
+      for (int step = 16; step > 0; step /= 2)
+        for (int t = 0; t < step; ++t) {
+          int v1 = tmax[t], v2 = tmax[t + step];
+          int test = v2 > v1;
+          int a1 = v1 > tnxt[t + step] ? v1 : tnxt[t + step];
+          int a2 = tnxt[t] > v2 ? tnxt[t] : v2;
+          tnxt[t] = test ? a1 : a2;
+          tidx[t] = test ? tidx[t + step] : tidx[t];
+          tmax[t] = test ? v2 : v1;
+        }
+      float dist = orc_sift_angle(tmax[0]);
+      float distn = orc_sift_angle(tnxt[0]);
+      row_match[i] = (dist < distmax) && (dist < distn * ratiomax) ? tidx[0] : -1; /* :1742 */
+    }
+    /* ColMatch_Kernel :1769-1776 */
+    for (int j = 0; j < n2; ++j) {
+      if (first_block) { cmax[j] = bmax[j]; cidx[j] = bidx[j]; cnxt[j] = bnxt[j]; }
+      else if (cmax[j] < bmax[j]) { cnxt[j] = cmax[j] > bnxt[j] ? cmax[j] : bnxt[j]; cmax[j] = bmax[j]; cidx[j] = bidx[j]; }
+      else { cnxt[j] = cnxt[j] > bmax[j] ? cnxt[j] : bmax[j]; }
+    }
+    first_block = 0;
+  }
+  /* GetBestMatch (SiftMatchCU.cpp:161-171) + the wrapper loop (sift_gpu_wrapper.cpp:194-222) */
+  int number = 0;
+  for (int i = 0; i < n1 && number < n1; ++i) {
+    int j = row_match[i];
+    if (j < 0) continue;
+    float dist = orc_sift_angle(cmax[j]);
+    float distn = orc_sift_angle(cnxt[j]);
+    int col_match = (dist < distmax) && (dist < distn * ratiomax) ? cidx[j] : -1;
+    if (col_match == i) { mq[number] = i; mt[number] = j; ++number; }
+  }
+  int n_out = 0, counter = 0;
+  for (int m = 0; m < number; ++m) {
+    if (mq[m] == 0 || mt[m] == 0) counter++;            /* :199 */
+    if ((double)counter > 0.5 * (double)number) { n_out = 0; break; } /* :203 "context error" */
+    float sum = 0;
+    for (int k = 0; k < ORC_SIFT_DIM; ++k) {
+      float a = d1[(size_t)mq[m] * ORC_SIFT_DIM + k] - d2[(size_t)mt[m] * ORC_SIFT_DIM + k];
+      float sq = a * a;
+      sum += sq;
+    }
+    dist_out[n_out] = sqrtf(sum); /* :217 */
+    mq[n_out] = mq[m];
+    mt[n_out] = mt[m];
+    ++n_out;
+  }
+  free(q1); free(q2); free(dot); free(row_match); free(cmax); free(cidx); free(cnxt);
+  free(bmax); free(bidx); free(bnxt);
+  return n_out;
+}
+
+/* matchNodePair with matcher_type == SIFTGPU: SiftGPUWrapper::match, keepStrongestMatches by the
+ * L2 distance (node.cpp:553-557, 674), then the same RANSAC. */
+void orc_match_sift_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid,
+                              const float* tdesc, const float* txyz1, int nt, int32_t tid,
+                              const orc_params* prm, orc_result* out, float* all_dist) {
+  static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memset(out, 0, sizeof(*out));
+  out->id1 = out->id2 = -1;
+  memcpy(out->T, I16, sizeof(I16));
+  int cap = nq > 0 ? nq : 1;
+  int32_t* mq = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  int32_t* mt = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  float* md = (float*)malloc(sizeof(float) * (size_t)cap);
+  int n = orc_sift_match(qdesc, nq, tdesc, nt, mq, mt, md);
+  int maxm = prm->max_matches > ORC_MAX_MATCHES ? ORC_MAX_MATCHES : prm->max_matches;
+  /* keep the max_matches smallest by (distance, queryIdx) (D2), ascending */
+  char* used = (char*)calloc((size_t)cap, 1);
+  int n_all = 0;
+  while (n_all < maxm && n_all < n) {
+    int best = -1;
+    for (int m = 0; m < n; ++m) {
+      if (used[m]) continue;
+      if (best < 0 || md[m] < md[best] || (md[m] == md[best] && mq[m] < mq[best])) best = m;
+    }
+    used[best] = 1;
+    out->all_q[n_all] = mq[best];
+    out->all_t[n_all] = mt[best];
+    out->all_hd[n_all] = 0;
+    all_dist[n_all] = md[best];
+    ++n_all;
+  }
+  out->n_all = n_all;
+  free(mq); free(mt); free(md); free(used);
+  int found = 0;
+  if (out->n_all >= prm->min_matches)
+    found = orc_ransac(qxyz1, txyz1, out->all_q, out->all_t, out->n_all, prm, orc_pair_uid(qid, tid),
+                       out->T, &out->rmse, out->inl_idx, &out->n_inl, &out->valid_iterations,
+                       &out->real_iterations);
+  if (found) {
+    out->info_scale = (double)((float)out->n_inl / (out->rmse * out->rmse));
+    out->id1 = tid;
+    out->id2 = qid;
+  } else {
+    out->id1 = out->id2 = -1;
+    out->info_scale = 0.0;
+  }
+}

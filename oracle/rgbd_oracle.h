@@ -94,6 +94,12 @@ int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows
                       double fx, double fy, double cx, double cy, double depth_scaling,
                       int max_keypoints, int32_t* kept_idx, float* xyz1);
 int orc_num_cores(void);
+/* SiftGPUWrapper::match (sift_gpu_wrapper.cpp:169-227) over the CUDA SiftMatchGPU kernels */
+int orc_sift_match(const float* d1, int n1, const float* d2, int n2, int32_t* mq, int32_t* mt,
+                   float* dist_out);
+void orc_match_sift_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid,
+                              const float* tdesc, const float* txyz1, int nt, int32_t tid,
+                              const orc_params* prm, orc_result* out, float* all_dist);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,8 @@ RGBDFE_MASK_WORDS = 5
 
 KERNEL_HAMMING = 0
 KERNEL_RANSAC = 1
+KERNEL_SIFT_DOT = 2
+KERNEL_SIFT_FINISH = 3
 
 
 class RgbdfeParams(C.Structure):
@@ -119,6 +121,14 @@ def load():
     L.rgbdfe_submit_pair_list.argtypes = [ctx, vp, vp, i32, vp, C.POINTER(C.c_int64)]
     L.rgbdfe_wait_ticket.restype = C.c_int
     L.rgbdfe_wait_ticket.argtypes = [ctx, C.c_int64, vp]
+    L.rgbdfe_upload_sift_node.restype = C.c_int
+    L.rgbdfe_upload_sift_node.argtypes = [ctx, i32, vp, vp, i32]
+    L.rgbdfe_match_sift_pair_list.restype = C.c_int
+    L.rgbdfe_match_sift_pair_list.argtypes = [ctx, vp, vp, i32, vp, vp]
+    L.rgbdfe_submit_sift_pair_list.restype = C.c_int
+    L.rgbdfe_submit_sift_pair_list.argtypes = [ctx, vp, vp, i32, vp, vp, C.POINTER(C.c_int64)]
+    L.rgbdfe_sift_match_nodes.restype = C.c_int
+    L.rgbdfe_sift_match_nodes.argtypes = [ctx, i32, i32, vp, vp, vp, C.POINTER(i32)]
     L.rgbdfe_synchronize.restype = C.c_int
     L.rgbdfe_synchronize.argtypes = [ctx]
     L.rgbdfe_hamming_nn_nodes.restype = C.c_int
@@ -150,7 +160,8 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_status_string", "rgbdfe_last_error", "rgbdfe_upload_node",
     "rgbdfe_upload_node_device", "rgbdfe_release_node", "rgbdfe_node_count",
     "rgbdfe_match_node_pairs", "rgbdfe_match_pair_list", "rgbdfe_match_pair_list_device",
-    "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket",
+    "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket", "rgbdfe_upload_sift_node",
+    "rgbdfe_match_sift_pair_list", "rgbdfe_submit_sift_pair_list", "rgbdfe_sift_match_nodes",
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
     "rgbdfe_project_to_3d", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
     "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",

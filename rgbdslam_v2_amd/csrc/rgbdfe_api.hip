@@ -23,6 +23,7 @@ namespace {
 struct NodeEntry {
   uint32_t slot;
   uint32_t n;
+  uint32_t kind;  // 0 = ORB (32-byte binary descriptors), 1 = SIFT (128 floats)
 };
 
 inline uint32_t mix32_host(uint32_t x) {
@@ -57,7 +58,18 @@ struct rgbdfe_ctx {
     hipStream_t stream = nullptr;
     uint32_t* d_keys = nullptr;             // max_pairs x max_kp
     rgbdfe_match_result* d_results = nullptr;  // staging for the host-output entry points
+    // SIFT scratch (allocated with the first SIFT node)
+    uint32_t* d_row_part = nullptr;   // max_pairs x max_kp x 3
+    uint32_t* d_col_part = nullptr;   // max_pairs x max_kp x 3 (per train row)
+    uint16_t* d_sm_q = nullptr;       // max_pairs x max_kp
+    uint16_t* d_sm_t = nullptr;
+    float* d_sm_d = nullptr;
+    int32_t* d_sm_n = nullptr;        // max_pairs
+    float* d_all_dist = nullptr;      // max_pairs x RGBDFE_MAX_MATCHES
   };
+  uint16_t* d_sift_bf16 = nullptr;  // max_nodes x max_kp x 128 (u8-quantised values as bf16)
+  float* d_sift_f32 = nullptr;      // max_nodes x max_kp x 128 (raw descriptors)
+  bool sift_ready = false;
   struct Slot {
     PairWork* h_work = nullptr;  // pinned
     PairWork* d_work = nullptr;
@@ -78,10 +90,11 @@ struct rgbdfe_ctx {
   // profiling
   bool profiling = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  double k_ms[RGBDFE_KERNEL_COUNT] = {0, 0};
-  int64_t k_launches[RGBDFE_KERNEL_COUNT] = {0, 0};
-  int64_t k_pairs[RGBDFE_KERNEL_COUNT] = {0, 0};
-  struct Pending { hipEvent_t a, b, c; int32_t pairs; };
+  double k_ms[RGBDFE_KERNEL_COUNT] = {0, 0, 0, 0};
+  int64_t k_launches[RGBDFE_KERNEL_COUNT] = {0, 0, 0, 0};
+  int64_t k_pairs[RGBDFE_KERNEL_COUNT] = {0, 0, 0, 0};
+  // ORB batch: a -[hamming]- b -[ransac]- c ; SIFT batch: a -[dot]- b -[finish]- c -[ransac]- d
+  struct Pending { hipEvent_t a, b, c, d; int32_t pairs; bool sift; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
 };
@@ -157,15 +170,22 @@ void drain_pending(rgbdfe_ctx* ctx) {
   for (auto& ln : ctx->lanes)
     if (ln.stream) (void)hipStreamSynchronize(ln.stream);
   for (auto& p : ctx->pending) {
-    float ms_h = 0.f, ms_r = 0.f;
-    if (hipEventElapsedTime(&ms_h, p.a, p.b) == hipSuccess &&
-        hipEventElapsedTime(&ms_r, p.b, p.c) == hipSuccess) {
-      ctx->k_ms[RGBDFE_KERNEL_HAMMING] += ms_h;
-      ctx->k_ms[RGBDFE_KERNEL_RANSAC] += ms_r;
-      ctx->k_launches[RGBDFE_KERNEL_HAMMING]++;
-      ctx->k_launches[RGBDFE_KERNEL_RANSAC]++;
-      ctx->k_pairs[RGBDFE_KERNEL_HAMMING] += p.pairs;
-      ctx->k_pairs[RGBDFE_KERNEL_RANSAC] += p.pairs;
+    auto add = [&](int which, hipEvent_t e0, hipEvent_t e1) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+        ctx->k_ms[which] += ms;
+        ctx->k_launches[which]++;
+        ctx->k_pairs[which] += p.pairs;
+      }
+    };
+    if (p.sift) {
+      add(RGBDFE_KERNEL_SIFT_DOT, p.a, p.b);
+      add(RGBDFE_KERNEL_SIFT_FINISH, p.b, p.c);
+      add(RGBDFE_KERNEL_RANSAC, p.c, p.d);
+      ctx->event_pool.push_back(p.d);
+    } else {
+      add(RGBDFE_KERNEL_HAMMING, p.a, p.b);
+      add(RGBDFE_KERNEL_RANSAC, p.b, p.c);
     }
     ctx->event_pool.push_back(p.a);
     ctx->event_pool.push_back(p.b);
@@ -179,7 +199,7 @@ void drain_pending(rgbdfe_ctx* ctx) {
 // Returns the batch's ticket.  Caller holds the lock.
 int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int32_t n,
                   rgbdfe_match_result* d_out, hipEvent_t wait_for, int64_t* ticket_out,
-                  int* lane_out) {
+                  int* lane_out, bool sift = false, float* d_out_dist = nullptr) {
   if (n > ctx->cfg.max_pairs_per_batch)
     return fail(ctx, RGBDFE_ERR_CAPACITY, "n_pairs exceeds max_pairs_per_batch");
   const int64_t ticket = ctx->next_ticket;
@@ -197,6 +217,8 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     auto t = ctx->nodes.find(tids[i]);
     if (q == ctx->nodes.end() || t == ctx->nodes.end())
       return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "pair references a node that is not resident");
+    if (q->second.kind != (sift ? 1u : 0u) || t->second.kind != (sift ? 1u : 0u))
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG, "node descriptor kind does not fit this matcher");
     PairWork& w = slot.h_work[i];
     w.q_slot = q->second.slot;
     w.t_slot = t->second.slot;
@@ -217,22 +239,34 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n,
                                 hipMemcpyHostToDevice, stream));
     rgbdfe_ctx::Pending pend{};
+    pend.sift = sift;
     if (ctx->profiling) {
       pend.a = get_event(ctx);
       pend.b = get_event(ctx);
       pend.c = get_event(ctx);
+      if (sift) pend.d = get_event(ctx);
       pend.pairs = n;
       (void)hipEventRecord(pend.a, stream);
     }
-    launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, (uint32_t)ctx->cfg.max_keypoints,
-                      (uint32_t)n, max_nq, max_nt, stream);
-    if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-    launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, d_out,
-                         (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->rc, stream);
-    if (ctx->profiling) {
-      (void)hipEventRecord(pend.c, stream);
-      ctx->pending.push_back(pend);
+    const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
+    if (!sift) {
+      launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, mk, (uint32_t)n, max_nq, max_nt, stream);
+      if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
+      launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, d_out, mk, (uint32_t)n, ctx->rc, stream);
+      if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
+    } else {
+      launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
+                      lane.d_col_part, stream);
+      if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
+      launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part,
+                         lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+      if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
+      launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
+                                lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
+                                (uint32_t)n, ctx->rc, stream);
+      if (ctx->profiling) (void)hipEventRecord(pend.d, stream);
     }
+    if (ctx->profiling) ctx->pending.push_back(pend);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(slot.done, stream));
@@ -332,7 +366,16 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (sl.h_work) (void)hipHostFree(sl.h_work);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
+  if (ctx->d_sift_bf16) (void)hipFree(ctx->d_sift_bf16);
+  if (ctx->d_sift_f32) (void)hipFree(ctx->d_sift_f32);
   for (auto& ln : ctx->lanes) {
+    if (ln.d_row_part) (void)hipFree(ln.d_row_part);
+    if (ln.d_col_part) (void)hipFree(ln.d_col_part);
+    if (ln.d_sm_q) (void)hipFree(ln.d_sm_q);
+    if (ln.d_sm_t) (void)hipFree(ln.d_sm_t);
+    if (ln.d_sm_d) (void)hipFree(ln.d_sm_d);
+    if (ln.d_sm_n) (void)hipFree(ln.d_sm_n);
+    if (ln.d_all_dist) (void)hipFree(ln.d_all_dist);
     if (ln.d_keys) (void)hipFree(ln.d_keys);
     if (ln.d_results) (void)hipFree(ln.d_results);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
@@ -390,7 +433,7 @@ static int upload_common(rgbdfe_ctx* ctx, int32_t node_id, const void* desc, con
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, xyz1, (size_t)n * 16, kind, stream));
   }
   if (sync) HIP_TRY(ctx, hipStreamSynchronize(stream));
-  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n};
+  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 0u};
   return RGBDFE_OK;
 }
 
@@ -500,6 +543,139 @@ int rgbdfe_synchronize(rgbdfe_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   drain_pending(ctx);  // synchronises every lane
+  return RGBDFE_OK;
+}
+
+
+static int ensure_sift(rgbdfe_ctx* ctx) {
+  if (ctx->sift_ready) return RGBDFE_OK;
+  const size_t rows = (size_t)ctx->cfg.max_nodes * (size_t)ctx->cfg.max_keypoints + 16;
+  const size_t np = (size_t)ctx->cfg.max_pairs_per_batch, mk = (size_t)ctx->cfg.max_keypoints;
+  if (hipMalloc((void**)&ctx->d_sift_bf16, rows * 128 * 2) != hipSuccess ||
+      hipMalloc((void**)&ctx->d_sift_f32, rows * 128 * 4) != hipSuccess)
+    return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "SIFT node slabs");
+  HIP_TRY(ctx, hipMemset(ctx->d_sift_bf16, 0, rows * 128 * 2));
+  HIP_TRY(ctx, hipMemset(ctx->d_sift_f32, 0, rows * 128 * 4));
+  for (auto& ln : ctx->lanes) {
+    if (hipMalloc((void**)&ln.d_row_part, np * mk * 3 * 4) != hipSuccess ||
+        hipMalloc((void**)&ln.d_col_part, np * mk * 3 * 4) != hipSuccess ||
+        hipMalloc((void**)&ln.d_sm_q, np * mk * 2) != hipSuccess ||
+        hipMalloc((void**)&ln.d_sm_t, np * mk * 2) != hipSuccess ||
+        hipMalloc((void**)&ln.d_sm_d, np * mk * 4) != hipSuccess ||
+        hipMalloc((void**)&ln.d_sm_n, np * 4) != hipSuccess ||
+        hipMalloc((void**)&ln.d_all_dist, np * RGBDFE_MAX_MATCHES * 4) != hipSuccess)
+      return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "SIFT batch scratch");
+  }
+  ctx->sift_ready = true;
+  return RGBDFE_OK;
+}
+
+int rgbdfe_upload_sift_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc128,
+                            const float* xyz1, int32_t n) {
+  if (!ctx || n < 0 || (n > 0 && (!desc128 || !xyz1))) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad upload arguments");
+  if (n > ctx->cfg.max_keypoints) return fail(ctx, RGBDFE_ERR_CAPACITY, "node has more rows than max_keypoints");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  int rc = ensure_sift(ctx);
+  if (rc != RGBDFE_OK) return rc;
+  uint32_t slot;
+  auto it = ctx->nodes.find(node_id);
+  if (it != ctx->nodes.end()) {
+    slot = it->second.slot;
+    for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+  } else {
+    if (ctx->free_slots.empty()) return fail(ctx, RGBDFE_ERR_CAPACITY, "no free node slot (max_nodes)");
+    slot = ctx->free_slots.back();
+    ctx->free_slots.pop_back();
+  }
+  const size_t row0 = (size_t)slot * (size_t)ctx->cfg.max_keypoints;
+  if (n > 0) {
+    float* df = ctx->d_sift_f32 + row0 * 128;
+    HIP_TRY(ctx, hipMemcpyAsync(df, desc128, (size_t)n * 128 * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_sift_quantise(df, ctx->d_sift_bf16 + row0 * 128, (size_t)n * 128, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, xyz1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 1u};
+  return RGBDFE_OK;
+}
+
+int rgbdfe_match_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                int32_t n_pairs, rgbdfe_match_result* out, float* out_dist) {
+  if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!query_ids || !train_ids || !out)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  if (!ctx->sift_ready) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "no SIFT node has been uploaded");
+  const int32_t cap = ctx->cfg.max_pairs_per_batch;
+  int chunk = 0;
+  for (int32_t off = 0; off < n_pairs; off += cap, ++chunk) {
+    const int32_t n = (n_pairs - off) < cap ? (n_pairs - off) : cap;
+    const int li_next = (int)(ctx->next_ticket % rgbdfe_ctx::kLanes);
+    if (chunk >= rgbdfe_ctx::kLanes) HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[li_next].stream));
+    int li = 0;
+    int rc = enqueue_pairs(ctx, query_ids + off, train_ids + off, n, nullptr, nullptr, nullptr, &li, true);
+    if (rc != RGBDFE_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out + off, ctx->lanes[li].d_results, sizeof(rgbdfe_match_result) * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->lanes[li].stream));
+    if (out_dist)
+      HIP_TRY(ctx, hipMemcpyAsync(out_dist + (size_t)off * RGBDFE_MAX_MATCHES, ctx->lanes[li].d_all_dist,
+                                  sizeof(float) * RGBDFE_MAX_MATCHES * (size_t)n, hipMemcpyDeviceToHost,
+                                  ctx->lanes[li].stream));
+  }
+  for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+  if (ctx->profiling) drain_pending(ctx);
+  return RGBDFE_OK;
+}
+
+int rgbdfe_submit_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                 int32_t n_pairs, void* d_out, void* d_out_dist, int64_t* ticket) {
+  if (!ctx || n_pairs < 0 || !ticket || (n_pairs > 0 && (!query_ids || !train_ids || !d_out)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad submit arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  if (!ctx->sift_ready) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "no SIFT node has been uploaded");
+  return enqueue_pairs(ctx, query_ids, train_ids, n_pairs, (rgbdfe_match_result*)d_out, nullptr, ticket,
+                       nullptr, true, (float*)d_out_dist);
+}
+
+int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* match_q,
+                            int32_t* match_t, float* match_dist, int32_t* n_matches) {
+  if (!ctx || !match_q || !match_t || !match_dist || !n_matches) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  *n_matches = 0;
+  auto q = ctx->nodes.find(query_id);
+  auto t = ctx->nodes.find(train_id);
+  if (q == ctx->nodes.end() || t == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "node not resident");
+  if (q->second.kind != 1u || t->second.kind != 1u) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "not SIFT nodes");
+  for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+  for (auto& sl : ctx->ring) sl.pending = false;
+  rgbdfe_ctx::Slot& slot = ctx->ring[0];
+  rgbdfe_ctx::Lane& lane = ctx->lanes[0];
+  PairWork& w = slot.h_work[0];
+  w.q_slot = q->second.slot; w.t_slot = t->second.slot;
+  w.nq = q->second.n; w.nt = t->second.n;
+  w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id; w.pad = 0;
+  const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
+  HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, lane.stream));
+  launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, 1u, w.nq, w.nt, lane.d_row_part, lane.d_col_part, lane.stream);
+  launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, 1u, lane.d_row_part, lane.d_col_part, lane.d_sm_q,
+                     lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, lane.stream);
+  HIP_TRY(ctx, hipGetLastError());
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n, lane.d_sm_n, 4, hipMemcpyDeviceToHost, lane.stream));
+  HIP_TRY(ctx, hipStreamSynchronize(lane.stream));
+  if (n > 0) {
+    std::vector<uint16_t> hq(n), ht(n);
+    HIP_TRY(ctx, hipMemcpyAsync(hq.data(), lane.d_sm_q, (size_t)n * 2, hipMemcpyDeviceToHost, lane.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ht.data(), lane.d_sm_t, (size_t)n * 2, hipMemcpyDeviceToHost, lane.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(match_dist, lane.d_sm_d, (size_t)n * 4, hipMemcpyDeviceToHost, lane.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(lane.stream));
+    for (int i = 0; i < n; ++i) { match_q[i] = hq[i]; match_t[i] = ht[i]; }
+  }
+  *n_matches = n;
   return RGBDFE_OK;
 }
 

@@ -39,6 +39,20 @@ void launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
                           const RansacConst& rc, hipStream_t stream);
+void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
+                               const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
+                               float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
+                               uint32_t n_pairs, const RansacConst& rc, hipStream_t stream);
+// SIFT matcher (sift_match.hip): u8-quantised descriptors as bf16, exact integer dot products
+// on the bf16 MFMA, SiftMatchGPU row/column/mutual-best semantics.
+void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,
+                     uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t* row_part,
+                     uint32_t* col_part, hipStream_t stream);
+void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t max_kp,
+                        uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part,
+                        uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n,
+                        hipStream_t stream);
+void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipStream_t stream);
 void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                           int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,

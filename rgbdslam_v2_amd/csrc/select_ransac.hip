@@ -526,22 +526,36 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Match sources: ORB = packed (hd, train row) keys of hamming_nn_kernel; SIFT = the mutual-best
+// match list of sift_finish_kernel (queryIdx, trainIdx, L2 distance).
+struct SiftMatchList {
+  const uint16_t* q;   // [pair][max_kp]
+  const uint16_t* t;
+  const float* d;
+  const int32_t* n;    // [pair]
+  float* all_dist;     // [pair][RGBDFE_MAX_MATCHES] output: distances of the selected matches
+};
+
+template <bool SIFT>
 __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
-    const uint32_t* __restrict__ keys, rgbdfe_match_result* __restrict__ results,
-    uint32_t max_kp, uint32_t n_pairs, const RansacConst rc) {
+    const uint32_t* __restrict__ keys, const SiftMatchList sm,
+    rgbdfe_match_result* __restrict__ results, uint32_t max_kp, uint32_t n_pairs,
+    const RansacConst rc) {
   __shared__ RansacLds lds;
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x;
   const PairWork w = work[pair];
-  const uint32_t nq = w.nq;
-  const uint32_t* __restrict__ kin = keys + (size_t)pair * max_kp;
   rgbdfe_match_result* __restrict__ out = results + pair;
   const int max_matches = rc.max_matches;
   SelBuf& sel = lds.u.sel;
   PH_DECL
+  int n_all;
 
+  if (!SIFT) {
+  const uint32_t nq = w.nq;
+  const uint32_t* __restrict__ kin = keys + (size_t)pair * max_kp;
   // ------------------------------------------------------------------ selection
   sel.cnt[lane] = 0;
   sel.cnt[lane + 64] = 0;
@@ -578,7 +592,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     sel.cnt[2 * lane + 1] = s1;
   }
   __syncthreads();
-  const int n_all = (int)min(total, (uint32_t)max_matches);
+  n_all = (int)min(total, (uint32_t)max_matches);
   // stable placement: (hd, queryIdx) order == D2's deterministic tie-break
   for (uint32_t base = 0; base < nq; base += kWave) {
     const uint32_t i = base + lane;
@@ -606,8 +620,35 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     __syncthreads();
   }
   __syncthreads();
+  } else {
+    // ------------------------------------------------------------- selection (SIFT)
+    // keepStrongestMatches by the float L2 distance (node.cpp:674) with D2's tie-break: the
+    // rank of a match is the number of matches with a smaller (distance, queryIdx) key.
+    // Distances are non-negative floats: their bit patterns order like the values.
+    const uint16_t* __restrict__ sq = sm.q + (size_t)pair * max_kp;
+    const uint16_t* __restrict__ st = sm.t + (size_t)pair * max_kp;
+    const float* __restrict__ sd = sm.d + (size_t)pair * max_kp;
+    const int n = sm.n[pair];
+    n_all = min(n, max_matches);
+    for (int base = 0; base < n; base += kWave) {
+      const int i = base + lane;
+      const bool act = i < n;
+      const uint32_t di = act ? __float_as_uint(sd[i]) : 0u;
+      const uint32_t qi = act ? (uint32_t)sq[i] : 0u;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const uint32_t dj = __float_as_uint(sd[j]);
+        const uint32_t qj = (uint32_t)sq[j];
+        rank += (dj < di || (dj == di && qj < qi)) ? 1 : 0;
+      }
+      if (act && rank < max_matches) {
+        sel.mqt[rank] = qi | ((uint32_t)st[i] << 16);
+        sel.mhd[rank] = di;  // distance bits travel in the hd slot
+      }
+    }
+    __syncthreads();
+  }
 
-  PH_MARK(0)
   // ------------------------------------------------- matched 3-D points -> LDS
   const float4* __restrict__ qxyz = xyz_pool + (size_t)w.q_slot * max_kp;
   const float4* __restrict__ txyz = xyz_pool + (size_t)w.t_slot * max_kp;
@@ -629,7 +670,12 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     lds.w[m] = 1.0f / (p.z * q.z);
     out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
     out->all_t[m] = (uint16_t)(qt >> 16);
-    out->all_hd[m] = (uint8_t)hd;
+    if (SIFT) {
+      out->all_hd[m] = 0;
+      sm.all_dist[(size_t)pair * RGBDFE_MAX_MATCHES + m] = __uint_as_float(hd);
+    } else {
+      out->all_hd[m] = (uint8_t)hd;
+    }
   }
   __syncthreads();
 
@@ -856,8 +902,19 @@ void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const ui
                           rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
                           const RansacConst& rc, hipStream_t stream) {
   if (n_pairs == 0) return;
-  hipLaunchKernelGGL(select_ransac_kernel, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work,
-                     keys, results, max_kp, n_pairs, rc);
+  SiftMatchList none{};
+  hipLaunchKernelGGL(select_ransac_kernel<false>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
+                     work, keys, none, results, max_kp, n_pairs, rc);
+}
+
+void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
+                               const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
+                               float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
+                               uint32_t n_pairs, const RansacConst& rc, hipStream_t stream) {
+  if (n_pairs == 0) return;
+  SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
+  hipLaunchKernelGGL(select_ransac_kernel<true>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
+                     work, (const uint32_t*)nullptr, sm, results, max_kp, n_pairs, rc);
 }
 
 }  // namespace rgbdfe

@@ -1,0 +1,301 @@
+// sift_match.hip -- 128-d float-descriptor (SIFT) matcher on the bf16 matrix cores (gfx950).
+//
+// Replaces SiftGPUWrapper::match (src/sift_gpu_wrapper.cpp:169-227) over SiftMatchGPU, whose
+// CUDA back end is the behavioural reference:
+//   SiftMatchCU.cpp:87-100   u8 quantisation  pub[i] = int(512*f + 0.5)
+//   ProgramCU.cu:1405-1482   MultiplyDescriptor_Kernel: u8 dot-product matrix + per-8-row column
+//                            (max, argmax, second) partials
+//   ProgramCU.cu:1689-1743   RowMatch_Kernel: per query row best / second best / acos tests
+//   ProgramCU.cu:1764-1782   ColMatch_Kernel: per train column best row
+//   SiftMatchCU.cpp:148-177  GetBestMatch: mutual best
+//
+// The dot-product matrix is the one dense contraction of the front end, so it runs on MFMA:
+// the u8 values (0..255) are exactly representable in bf16 and a 128-term sum of u8*u8
+// products is < 2^24, so v_mfma_f32_32x32x16_bf16 computes the INTEGER dot products exactly
+// (fp32 accumulation never rounds).  The matrix is never written to memory: every 32x64
+// accumulator chunk is reduced in registers to running (best, second best) keys per row.
+// Keys pack (dot << 7 | 127 - sequence) so that "strict >, first wins" is one unsigned max;
+// the cross-lane merge reproduces RowMatch_Kernel's 32-thread butterfly (lower thread wins
+// ties).  The per-train-column result (ColMatch_Kernel, "lowest row wins") is a second pass of
+// the same kernel with the operands swapped: recomputing the products on the matrix cores is
+// cheaper than exchanging column partials through LDS and HBM.
+#include "rgbdfe_internal.h"
+
+namespace rgbdfe {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kSiftDim = 128;
+constexpr int kTile = 128;     // rows per block, columns per tile
+constexpr int kSiftThreads = 256;
+
+__device__ __forceinline__ void top2_insert(uint32_t& mx, uint32_t& nx, uint32_t key) {
+  nx = max(nx, min(mx, key));
+  mx = max(mx, key);
+}
+
+__device__ __forceinline__ int row_of_reg(int reg, int lane) {
+  // v_mfma_f32_32x32x16 C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+// u8 quantisation of float descriptors, stored as bf16 (exact) -- SiftMatchCU.cpp:96-99
+__global__ void sift_quantise_kernel(const float* __restrict__ f, uint16_t* __restrict__ q, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    // int(512 * d + 0.5): float product, double add, truncation, then the unsigned char store
+    const float prod = 512 * f[i];
+    const int v = (int)((double)prod + 0.5);
+    const unsigned char u = (unsigned char)v;
+    const float uf = (float)u;                       // 0..255: exact in bf16 (8 significant bits)
+    q[i] = (uint16_t)(__float_as_uint(uf) >> 16);
+  }
+}
+
+void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipStream_t stream) {
+  if (n_elems == 0) return;
+  int blocks = (int)((n_elems + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sift_quantise_kernel, dim3(blocks), dim3(256), 0, stream, f32, bf16, n_elems);
+}
+
+// Best / second-best dot product of every row of node X against all rows of node Y.
+//   SWAP = false: X = query (newer) node, Y = train node  -> RowMatch_Kernel's per-query result
+//   SWAP = true : X = train node, Y = query node          -> ColMatch_Kernel's per-train-column result
+// The second pass recomputes the (cheap, MFMA) dot products instead of exchanging per-tile column
+// partials between waves through LDS and HBM: no barrier, no LDS, no partial buffers.
+// part: [pair][max_kp][3] = (best dot, second dot, best index or 0xFFFFFFFF)
+template <bool SWAP>
+__global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
+    const uint16_t* __restrict__ bf16_pool, const PairWork* __restrict__ work, uint32_t max_kp,
+    uint32_t* __restrict__ part) {
+  const uint32_t pair = blockIdx.y;
+  const uint32_t rb = blockIdx.x;
+  const PairWork w = work[pair];
+  const int nq = (int)min(w.nq, 4096u), nt = (int)min(w.nt, 4096u);  // sift_gpu_wrapper.cpp:231
+  const int nx = SWAP ? nt : nq, ny = SWAP ? nq : nt;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r0 = rb * kTile + wv * 32;
+  if (r0 >= nx) return;  // wave-uniform (no barriers in this kernel)
+
+  const uint16_t* __restrict__ xpool = bf16_pool + (size_t)(SWAP ? w.t_slot : w.q_slot) * max_kp * kSiftDim;
+  const uint16_t* __restrict__ ypool = bf16_pool + (size_t)(SWAP ? w.q_slot : w.t_slot) * max_kp * kSiftDim;
+
+  // A fragments: this wave's 32 rows of X, all of K = 128 (8 k-steps x 8 bf16 per lane)
+  bf16x8 A[8];
+  {
+    int row = r0 + (lane & 31);
+    row = row < nx ? row : nx - 1;
+    const uint4* src = reinterpret_cast<const uint4*>(xpool + (size_t)row * kSiftDim + (lane >> 5) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) A[ks] = __builtin_bit_cast(bf16x8, src[ks * 2]);
+  }
+
+  // running (best, second) keys per owned row; key = dot << 7 | (127 - sequence): the sequence
+  // number of a column inside this lane (col >> 5) grows with the column, so "strict >, first
+  // wins" (ProgramCU.cu:1464-1467, :1715-1719) is a plain unsigned max.  dot < 2^23.
+  uint32_t rmx[16], rnx[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rmx[r] = rnx[r] = 0u;
+
+  const int n_full = ny / 64;  // 64-column chunks without a ragged edge
+  int chunk = 0;
+  for (; chunk * 64 < ny; ++chunk) {
+    const int c0 = chunk * 64;
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      int col = c0 + c * 32 + (lane & 31);
+      col = col < ny ? col : ny - 1;
+      const uint4* src = reinterpret_cast<const uint4*>(ypool + (size_t)col * kSiftDim + (lane >> 5) * 8);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 B = __builtin_bit_cast(bf16x8, src[ks * 2]);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], B, acc[c], 0, 0, 0);
+      }
+    }
+    if (chunk < n_full) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t lo = 127u - (uint32_t)(chunk * 2 + c);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t key = ((uint32_t)(int)acc[c][r] << 7) | lo;  // dot == 0 -> key < 128: inert
+          top2_insert(rmx[r], rnx[r], key);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t lo = 127u - (uint32_t)(chunk * 2 + c);
+        const bool ok = (c0 + c * 32 + (lane & 31)) < ny;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t key = ok ? (((uint32_t)(int)acc[c][r] << 7) | lo) : 0u;
+          top2_insert(rmx[r], rnx[r], key);
+        }
+      }
+    }
+  }
+
+  // ---- merge the 32 lanes that share a row.
+  // !SWAP: RowMatch_Kernel's 32-thread butterfly (:1726-1736): slot t absorbs slot t+step, the
+  //        lower slot wins ties on the dot value.
+  //  SWAP: ColMatch_Kernel / MultiplyDescriptor_Kernel: the lowest query row wins ties.
+  uint32_t* __restrict__ opart = part + (size_t)pair * max_kp * 3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    uint32_t dmx = rmx[r] >> 7, dnx = rnx[r] >> 7;
+    uint32_t idx = dmx ? (((127u - (rmx[r] & 127u)) << 5) | (uint32_t)(lane & 31)) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 1) {
+      const uint32_t pmx = __shfl_xor(dmx, step), pnx = __shfl_xor(dnx, step), pidx = __shfl_xor(idx, step);
+      const bool i_am_low = ((lane & step) == 0);
+      const uint32_t v1 = i_am_low ? dmx : pmx, n1 = i_am_low ? dnx : pnx, i1 = i_am_low ? idx : pidx;
+      const uint32_t v2 = i_am_low ? pmx : dmx, n2 = i_am_low ? pnx : dnx, i2 = i_am_low ? pidx : idx;
+      const bool test = SWAP ? (v2 > v1 || (v2 == v1 && i2 < i1)) : (v2 > v1);
+      dnx = test ? max(v1, n2) : max(n1, v2);
+      idx = test ? i2 : i1;
+      dmx = test ? v2 : v1;
+    }
+    const int row = r0 + row_of_reg(r, lane);
+    if ((lane & 31) == 0 && row < nx) {
+      opart[(size_t)row * 3 + 0] = dmx;
+      opart[(size_t)row * 3 + 1] = dnx;
+      opart[(size_t)row * 3 + 2] = idx;
+    }
+  }
+}
+
+__device__ __forceinline__ float sift_angle(uint32_t dot) {
+  // ProgramCU.cu:1738: acos(min(dot * 0.000003814697265625f, 1.0)): float product, double min/acos
+  const float prod = (float)(int)dot * 0.000003814697265625f;
+  const double v = (double)prod < 1.0 ? (double)prod : 1.0;
+  return (float)acos(v);
+}
+
+// One block per pair: row/column acceptance tests (RowMatch_Kernel :1738-1742, ColMatch_Kernel
+// :1778-1781), mutual-best list in ascending query order (GetBestMatch), L2 distances of the raw
+// descriptors (sift_gpu_wrapper.cpp:211-217).
+__global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
+    const float* __restrict__ f32_pool, const PairWork* __restrict__ work, uint32_t max_kp,
+    const uint32_t* __restrict__ row_part, uint32_t* __restrict__ col_part,
+    uint16_t* __restrict__ sm_q, uint16_t* __restrict__ sm_t, float* __restrict__ sm_d,
+    int32_t* __restrict__ sm_n) {
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ int s_total;
+  const uint32_t pair = blockIdx.x;
+  const PairWork w = work[pair];
+  const int nq = (int)min(w.nq, 4096u), nt = (int)min(w.nt, 4096u);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float distmax = 0.9f, ratiomax = 0.9f;  // sift_gpu_wrapper.cpp:185
+  uint16_t* __restrict__ oq = sm_q + (size_t)pair * max_kp;
+  uint16_t* __restrict__ ot = sm_t + (size_t)pair * max_kp;
+  float* __restrict__ od = sm_d + (size_t)pair * max_kp;
+  if (nq <= 0 || nt <= 0) {  // SiftMatchCU.cpp:141
+    if (tid == 0) sm_n[pair] = 0;
+    return;
+  }
+  uint32_t* __restrict__ cbase = col_part + (size_t)pair * max_kp * 3;
+  // ---- ColMatch_Kernel acceptance: col_match[j] replaces the best-dot slot
+  for (int j = tid; j < nt; j += kSiftThreads) {
+    const uint32_t dot = cbase[(size_t)j * 3], dotn = cbase[(size_t)j * 3 + 1];
+    const int row = (int)cbase[(size_t)j * 3 + 2];
+    const float dist = sift_angle(dot), distn = sift_angle(dotn);
+    const int cm = (dist < distmax) && (dist < distn * ratiomax) ? row : -1;  // :1781
+    cbase[(size_t)j * 3] = (uint32_t)cm;
+  }
+  __syncthreads();
+  // ---- RowMatch acceptance (:1738-1742) + mutual best in ascending query order
+  const uint32_t* __restrict__ rpart = row_part + (size_t)pair * max_kp * 3;
+  uint32_t base = 0;
+  for (int i0 = 0; i0 < nq; i0 += kSiftThreads) {
+    const int i = i0 + tid;
+    bool keep = false;
+    int j = -1;
+    if (i < nq) {
+      const uint32_t dot = rpart[(size_t)i * 3], dotn = rpart[(size_t)i * 3 + 1];
+      const int idx = (int)rpart[(size_t)i * 3 + 2];
+      const float dist = sift_angle(dot), distn = sift_angle(dotn);
+      j = (dist < distmax) && (dist < distn * ratiomax) ? idx : -1;
+      keep = j >= 0 && (int)cbase[(size_t)j * 3] == i;  // SiftMatchCU.cpp:165
+    }
+    const uint64_t m = __ballot(keep);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base;
+    for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+    if (keep) {
+      oq[off + rank] = (uint16_t)i;
+      ot[off + rank] = (uint16_t)j;
+    }
+    base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  int number = (int)base;
+  // ---- the wrapper's "context error" heuristic (sift_gpu_wrapper.cpp:199-209): more than half of
+  // the matches touching index 0 clears everything.  counter <= 2, so only number <= 3 can trigger.
+  if (tid == 0) {
+    int n_out = number;
+    if (number <= 3) {
+      int counter = 0;
+      for (int m = 0; m < number; ++m) {
+        if (oq[m] == 0 || ot[m] == 0) counter++;
+        if ((double)counter > 0.5 * (double)number) { n_out = 0; break; }
+      }
+    }
+    s_total = n_out;
+    sm_n[pair] = n_out;
+  }
+  __syncthreads();
+  number = s_total;
+  // ---- DMatch.distance: float L2 of the raw descriptors, sequential sum (:211-217)
+  const float* __restrict__ qf = f32_pool + (size_t)w.q_slot * max_kp * kSiftDim;
+  const float* __restrict__ tf = f32_pool + (size_t)w.t_slot * max_kp * kSiftDim;
+  for (int m = tid; m < number; m += kSiftThreads) {
+    const float4* a = reinterpret_cast<const float4*>(qf + (size_t)oq[m] * kSiftDim);
+    const float4* b = reinterpret_cast<const float4*>(tf + (size_t)ot[m] * kSiftDim);
+    float sum = 0.0f;
+    for (int k = 0; k < kSiftDim / 4; ++k) {
+      const float4 x = a[k], y = b[k];
+      float d;
+      d = x.x - y.x; sum += d * d;
+      d = x.y - y.y; sum += d * d;
+      d = x.z - y.z; sum += d * d;
+      d = x.w - y.w; sum += d * d;
+    }
+    od[m] = sqrtf(sum);
+  }
+}
+
+void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,
+                     uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t* row_part,
+                     uint32_t* col_part, hipStream_t stream) {
+  if (n_pairs == 0) return;
+  uint32_t rbq = (max_nq + kTile - 1) / kTile, rbt = (max_nt + kTile - 1) / kTile;
+  if (rbq < 1) rbq = 1;
+  if (rbt < 1) rbt = 1;
+  hipLaunchKernelGGL(sift_row_top2_kernel<false>, dim3(rbq, n_pairs), dim3(kSiftThreads), 0, stream,
+                     bf16_pool, work, max_kp, row_part);
+  hipLaunchKernelGGL(sift_row_top2_kernel<true>, dim3(rbt, n_pairs), dim3(kSiftThreads), 0, stream,
+                     bf16_pool, work, max_kp, col_part);
+}
+
+void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t max_kp,
+                        uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part,
+                        uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n,
+                        hipStream_t stream) {
+  if (n_pairs == 0) return;
+  hipLaunchKernelGGL(sift_finish_kernel, dim3(n_pairs), dim3(kSiftThreads), 0, stream, f32_pool, work,
+                     max_kp, row_part, col_part, sm_q, sm_t, sm_d, sm_n);
+}
+
+}  // namespace rgbdfe

@@ -187,6 +187,46 @@ class FrontEnd:
     def synchronize(self):
         self._check(self._L.rgbdfe_synchronize(self._ctx))
 
+    # -- SIFT (128-d float descriptors, matcher_type == SIFTGPU) ---------------------------
+    def upload_sift_node(self, node_id: int, desc128: np.ndarray, xyz1: np.ndarray):
+        desc128 = np.ascontiguousarray(desc128, np.float32)
+        xyz1 = np.ascontiguousarray(xyz1, np.float32)
+        n = desc128.shape[0]
+        if desc128.ndim != 2 or desc128.shape[1] != 128 or xyz1.shape != (n, 4):
+            raise ValueError("desc128 must be [n,128] float32 and xyz1 [n,4] float32")
+        self._check(self._L.rgbdfe_upload_sift_node(self._ctx, node_id, desc128.ctypes.data,
+                                                    xyz1.ctypes.data, n))
+
+    def match_sift_pair_list(self, query_ids, train_ids):
+        """Batched matchNodePair for SIFT nodes; returns (records, all_dist [n, 320] float32)."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        out = np.zeros(q.shape[0], RESULT_DTYPE)
+        dist = np.zeros((q.shape[0], _lib.RGBDFE_MAX_MATCHES), np.float32)
+        self._check(self._L.rgbdfe_match_sift_pair_list(self._ctx, q.ctypes.data, t.ctypes.data,
+                                                        q.shape[0], out.ctypes.data, dist.ctypes.data))
+        return out, dist
+
+    def submit_sift_pair_list(self, query_ids, train_ids, d_out_ptr: int, d_dist_ptr: Optional[int] = None) -> int:
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        ticket = C.c_int64(0)
+        self._check(self._L.rgbdfe_submit_sift_pair_list(self._ctx, q.ctypes.data, t.ctypes.data,
+                                                         q.shape[0], d_out_ptr, d_dist_ptr,
+                                                         C.byref(ticket)))
+        return ticket.value
+
+    def sift_match_nodes(self, query_id: int, train_id: int):
+        """SiftGPUWrapper::match twin (sift_gpu_wrapper.cpp:169-227): (queryIdx, trainIdx, L2)."""
+        n = max(self.node_count(query_id), 1)
+        mq = np.empty(n, np.int32)
+        mt = np.empty(n, np.int32)
+        md = np.empty(n, np.float32)
+        k = C.c_int32(0)
+        self._check(self._L.rgbdfe_sift_match_nodes(self._ctx, query_id, train_id, mq.ctypes.data,
+                                                    mt.ctypes.data, md.ctypes.data, C.byref(k)))
+        return mq[: k.value].copy(), mt[: k.value].copy(), md[: k.value].copy()
+
     # -- pieces -----------------------------------------------------------------------
     def hamming_nn_nodes(self, query_id: int, train_id: int):
         n = self.node_count(query_id)

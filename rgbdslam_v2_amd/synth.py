@@ -129,3 +129,19 @@ def candidate_pairs(n_frames, per_frame=20, seed=20260923, predecessors=3):
 def relative_pose(poses, q, t):
     """Ground-truth transform mapping frame q's camera coordinates into frame t's."""
     return np.linalg.inv(poses[t]) @ poses[q]
+
+
+def sift_descriptors_like(desc_bits: np.ndarray, seed: int = 0, noise: float = 0.04) -> np.ndarray:
+    """128-d float descriptors for BASELINE configs[3] derived from the binary ones of make_sequence:
+    every 256-bit descriptor is mapped to a fixed pseudo-random non-negative 128-vector (pairs of
+    bits -> magnitude), perturbed, clamped at 0.2 and L2-normalised like SIFT; observations of the
+    same world point (few flipped bits) stay close, unrelated ones are far apart."""
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    bits = np.unpackbits(desc_bits, axis=-1, bitorder="little").astype(np.float32)  # [..., 256]
+    v = bits[..., 0::2] * 2.0 + bits[..., 1::2] + 0.25                               # [..., 128]
+    v = v + rng.normal(0, noise, v.shape).astype(np.float32)
+    v = np.maximum(v, 0)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    v = np.minimum(v, 0.2)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    return v.astype(np.float32)

@@ -1,0 +1,117 @@
+"""-m gpu: the bf16-MFMA SIFT matcher (SiftGPUWrapper::match semantics) and the SIFT pair op vs
+the oracle.  The dot products are integers computed exactly on the matrix cores, so match lists
+are compared bit-exactly; distances and poses are float and asserted both within tolerance and
+bit-equal (same operation order)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rgbdslam_v2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    f = FrontEnd(device_id=0, max_nodes=24, max_keypoints=1280, max_pairs_per_batch=256)
+    yield f
+    f.close()
+
+
+def _xyz(rng, n):
+    return np.concatenate([rng.uniform(-1, 1, (n, 2)), rng.uniform(1, 3, (n, 1)), np.ones((n, 1))], 1).astype(np.float32)
+
+
+def _rand_sift(rng, n):
+    v = rng.gamma(0.6, 1.0, (n, 128)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v = np.minimum(v, 0.2)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return v.astype(np.float32)
+
+
+@pytest.mark.parametrize("n1,n2", [(1000, 1000), (300, 700), (129, 127), (128, 128), (257, 33), (1, 1), (40, 1), (1, 40)])
+def test_sift_match_nodes_vs_oracle(fe, n1, n2):
+    rng = np.random.default_rng(n1 * 31 + n2)
+    d2 = _rand_sift(rng, n2)
+    d1 = _rand_sift(rng, n1)
+    k = min(n1, n2) * 2 // 3
+    src = rng.permutation(n2)[:k]
+    d1[:k] = d2[src] + rng.normal(0, 0.01, (k, 128)).astype(np.float32)
+    d1 = np.abs(d1)
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    fe.upload_sift_node(1, d1, _xyz(rng, n1))
+    fe.upload_sift_node(2, d2, _xyz(rng, n2))
+    mq, mt, md = fe.sift_match_nodes(1, 2)
+    oq, ot, od = po.sift_match(d1, d2)
+    assert np.array_equal(mq, oq) and np.array_equal(mt, ot)
+    assert np.allclose(md, od, rtol=1e-6, atol=0)
+    assert np.array_equal(md, od)
+    if min(n1, n2) > 100:
+        assert len(mq) > k // 2
+    fe.release_node(1)
+    fe.release_node(2)
+
+
+def test_sift_tie_rules(fe):
+    """Exact duplicates force equal dot products: the row side must follow RowMatch_Kernel's
+    32-thread butterfly (ProgramCU.cu:1715-1736), the column side "lowest row wins" (:1464-1467,
+    :1773)."""
+    rng = np.random.default_rng(5)
+    base = _rand_sift(rng, 40)
+    d2 = base[rng.integers(0, 40, 500)]          # many duplicate train rows
+    d1 = base[rng.integers(0, 40, 300)]          # many duplicate query rows
+    fe.upload_sift_node(1, d1, _xyz(rng, 300))
+    fe.upload_sift_node(2, d2, _xyz(rng, 500))
+    mq, mt, md = fe.sift_match_nodes(1, 2)
+    oq, ot, od = po.sift_match(d1, d2)
+    assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od)
+    # distinct near-duplicates: ratio test passes, ties still decide the winners
+    d2b = d2 + rng.normal(0, 1e-4, d2.shape).astype(np.float32)
+    fe.upload_sift_node(2, d2b, _xyz(rng, 500))
+    mq, mt, md = fe.sift_match_nodes(1, 2)
+    oq, ot, od = po.sift_match(d1, d2b)
+    assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od)
+    fe.release_node(1)
+    fe.release_node(2)
+
+
+def test_sift_pair_op_vs_oracle(fe):
+    from rgbdslam_v2_amd.frontend import inlier_indices
+    F = 8
+    seq = synth.make_sequence(n_frames=F, n_kp=1000, seed=4)
+    sd = synth.sift_descriptors_like(seq["desc"], seed=4)
+    for f in range(F):
+        fe.upload_sift_node(f, sd[f], seq["xyz1"][f])
+    pq, pt = synth.candidate_pairs(F, per_frame=3, seed=4)
+    out, dist = fe.match_sift_pair_list(pq, pt)
+    prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov)
+    n_edges = 0
+    for rec, dd, q, t in zip(out, dist, pq, pt):
+        ref = po.match_sift_node_pair(sd[q], seq["xyz1"][q], int(q), sd[t], seq["xyz1"][t], int(t), prm)
+        n = ref["n_all"]
+        assert rec["n_all"] == n
+        assert np.array_equal(rec["all_q"][:n], ref["all_q"]) and np.array_equal(rec["all_t"][:n], ref["all_t"])
+        assert np.array_equal(dd[:n], ref["all_dist"])
+        assert np.all(np.diff(dd[:n]) >= 0)
+        assert (rec["id1"], rec["id2"]) == (ref["id1"], ref["id2"])
+        assert rec["n_inl"] == ref["n_inl"] and rec["real_iterations"] == ref["real_iterations"]
+        assert np.array_equal(inlier_indices(rec), ref["inl_idx"])
+        T = np.array(rec["trafo"], np.float32).reshape(4, 4).T
+        assert np.abs(T - ref["T"]).max() <= 1e-4
+        assert np.array_equal(T, ref["T"])
+        if ref["id1"] >= 0:
+            n_edges += 1
+            assert np.abs(T - synth.relative_pose(seq["poses"], q, t)).max() < 0.03
+    assert n_edges >= len(pq) * 3 // 4
+    # ORB and SIFT nodes cannot be mixed in one pair
+    fe.upload_node(100, seq["desc"][0], seq["xyz1"][0])
+    from rgbdslam_v2_amd._lib import RgbdfeError
+    with pytest.raises(RgbdfeError):
+        fe.match_sift_pair_list([0], [100])
+    with pytest.raises(RgbdfeError):
+        fe.match_pair_list([100], [0])
+    fe.release_node(100)
+    for f in range(F):
+        fe.release_node(f)
