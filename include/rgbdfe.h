@@ -166,6 +166,41 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
                          double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
                          float* xyz1, int32_t* n_out);
 
+/* ---- per-frame feature path: detect + describe (Node::Node, node.cpp:139-210) -----------------
+ * rgbdfe_detect_describe replaces, for one frame,
+ *   detector->detect(gray, kps, mask)   the 3x3 grid of threshold-adaptive ORB detectors built by
+ *                                       createDetector("ORB") (features.h:9, features.cpp:63-113,
+ *                                       feature_adjuster.cpp:85-317); its per-cell FAST thresholds
+ *                                       persist across frames inside the context, like the reference's
+ *                                       detector_ object (openni_listener.h:195)
+ *   removeDepthless + KeyPointsFilter::retainBest(max_keypoints)          (node.cpp:186-191)
+ *   extractor->compute(gray, kps, desc) cv::ORB::create() defaults        (features.cpp:117-119)
+ *   projectTo3D                                                           (node.cpp:900-965)
+ * gray: rows x cols u8; mask: rows x cols u8 (depth_mono8, non-zero = usable) or NULL;
+ * depth: rows x cols float32 metres (NaN = no measurement).  Outputs are sized by the caller for
+ * max_keypoints entries: keypoints, descriptors (32 bytes each), xyz1 (4 floats each). */
+typedef struct {
+  float x, y;       /* cv::KeyPoint::pt (level-0 pixel coordinates) */
+  float size;       /* 31 * scale of the octave */
+  float angle;      /* degrees (cv::fastAtan2 of the intensity centroid) */
+  float response;   /* Harris response */
+  int32_t octave;   /* pyramid level */
+} rgbdfe_keypoint;
+int rgbdfe_detector_configure(rgbdfe_ctx* ctx, int32_t max_keypoints, int32_t grid_resolution,
+                              int32_t adjuster_max_iterations); /* parameter_server.cpp:83,87,89; resets thresholds */
+int rgbdfe_detector_thresholds(rgbdfe_ctx* ctx, double* thresholds, int32_t* n_cells);
+int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
+                           int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                           double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
+                           float* xyz1, int32_t* n_out);
+/* pieces, for A/B against cv::ORB: detect() of one image with a fixed FAST threshold (no grid,
+ * feature_adjuster.cpp:94) and compute() for given keypoints (may drop border keypoints and
+ * regroups them by octave, like cv::ORB::compute). */
+int rgbdfe_orb_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,
+                      int32_t fast_threshold, rgbdfe_keypoint* keypoints, int32_t capacity, int32_t* n_out);
+int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32_t cols,
+                       rgbdfe_keypoint* keypoints, int32_t n, uint8_t* descriptors, int32_t* n_out);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, every launch of the dominant kernels is bracketed by HIP events on the
  * stream it runs on; totals are read back with rgbdfe_get_kernel_time. */

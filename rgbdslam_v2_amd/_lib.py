@@ -62,6 +62,9 @@ class RgbdfeMatchResult(C.Structure):
     ]
 
 
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4")])
+
 # numpy view of the same POD (used for bulk result handling and the all-gather payload)
 RESULT_DTYPE = np.dtype([
     ("id1", "<i4"), ("id2", "<i4"), ("n_all", "<i4"), ("n_inl", "<i4"), ("rmse", "<f4"),
@@ -129,6 +132,17 @@ def load():
     L.rgbdfe_submit_sift_pair_list.argtypes = [ctx, vp, vp, i32, vp, vp, C.POINTER(C.c_int64)]
     L.rgbdfe_sift_match_nodes.restype = C.c_int
     L.rgbdfe_sift_match_nodes.argtypes = [ctx, i32, i32, vp, vp, vp, C.POINTER(i32)]
+    L.rgbdfe_detector_configure.restype = C.c_int
+    L.rgbdfe_detector_configure.argtypes = [ctx, i32, i32, i32]
+    L.rgbdfe_detector_thresholds.restype = C.c_int
+    L.rgbdfe_detector_thresholds.argtypes = [ctx, vp, C.POINTER(i32)]
+    L.rgbdfe_detect_describe.restype = C.c_int
+    L.rgbdfe_detect_describe.argtypes = [ctx, vp, vp, vp, i32, i32, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, C.c_double, vp, vp, vp, C.POINTER(i32)]
+    L.rgbdfe_orb_detect.restype = C.c_int
+    L.rgbdfe_orb_detect.argtypes = [ctx, vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
+    L.rgbdfe_orb_compute.restype = C.c_int
+    L.rgbdfe_orb_compute.argtypes = [ctx, vp, i32, i32, vp, i32, vp, C.POINTER(i32)]
     L.rgbdfe_synchronize.restype = C.c_int
     L.rgbdfe_synchronize.argtypes = [ctx]
     L.rgbdfe_hamming_nn_nodes.restype = C.c_int
@@ -160,6 +174,8 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_status_string", "rgbdfe_last_error", "rgbdfe_upload_node",
     "rgbdfe_upload_node_device", "rgbdfe_release_node", "rgbdfe_node_count",
     "rgbdfe_match_node_pairs", "rgbdfe_match_pair_list", "rgbdfe_match_pair_list_device",
+    "rgbdfe_detector_configure", "rgbdfe_detector_thresholds", "rgbdfe_detect_describe",
+    "rgbdfe_orb_detect", "rgbdfe_orb_compute",
     "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket", "rgbdfe_upload_sift_node",
     "rgbdfe_match_sift_pair_list", "rgbdfe_submit_sift_pair_list", "rgbdfe_sift_match_nodes",
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",

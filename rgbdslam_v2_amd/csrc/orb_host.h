@@ -1,0 +1,51 @@
+// orb_host.h -- per-context ORB workspace (device buffers + the detector's persistent state)
+#pragma once
+#include <string>
+#include <vector>
+
+#include "orb_internal.h"
+
+namespace rgbdfe {
+
+struct KpOut {  // cv::KeyPoint fields in use
+  float x, y, size, angle, response;
+  int octave;
+};
+
+struct OrbWorkspace {
+  struct Cell { int x0, y0, w, h; };
+  ~OrbWorkspace();
+  void release();
+  void reset_detector(int max_keypoints, int grid_res, int max_iters);
+  int prepare(int cols, int rows, bool use_grid, std::string& err);
+  int upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err);
+  int detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
+                  std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err);
+  int grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::string& err);
+  int compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err);
+
+  // detector state (the reference's detector_ object, openni_listener.h:195)
+  int grid = 3, adjuster_iters = 5, cell_min = 0, cell_max = 0, max_total = 0;
+  double thresh[64];
+  std::vector<char> cell_mask_nonzero;
+  // geometry
+  int W = 0, H = 0, n_cells = 0, max_w = 0, max_h = 0, n_rows_total = 0, kp_cap = 0;
+  std::vector<Cell> cells;
+  std::vector<ImgDesc> cell_imgs, frame_imgs;
+  std::vector<ResizeJob> jobs;
+  std::vector<int> level_job_begin;
+  float scale[8];
+  int flw[8], flh[8];
+  size_t pool_bytes = 0;
+  bool pattern_uploaded = false;
+  // device
+  uint8_t* d_pool = nullptr; uint8_t* d_score = nullptr; uint8_t* d_blur = nullptr;
+  ImgDesc* d_cell_imgs = nullptr; ImgDesc* d_frame_imgs = nullptr; ResizeJob* d_jobs = nullptr;
+  int* d_thr = nullptr; int* d_active = nullptr; int* d_row_cnt = nullptr; int* d_img_total = nullptr;
+  int* d_img_base = nullptr;
+  RawKp* d_kps = nullptr; DescKp* d_desckp = nullptr; uint8_t* d_desc = nullptr;
+  float* d_depth = nullptr; float* d_kpxy = nullptr; int32_t* d_kept = nullptr; float4* d_xyz = nullptr;
+  int32_t* d_n = nullptr;
+};
+
+}  // namespace rgbdfe

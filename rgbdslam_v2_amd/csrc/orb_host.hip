@@ -1,0 +1,376 @@
+// orb_host.hip -- host side of the per-frame feature path (rows a1-a7 of SURVEY.md section 8):
+// the reference's detector object (3x3 grid of threshold-adaptive ORB detectors, features.cpp:42-60,
+// feature_adjuster.cpp:185-317) and the Node constructor's detect -> removeDepthless -> retainBest ->
+// compute -> projectTo3D sequence (node.cpp:139-210).  Pixel work runs in orb_kernels.hip; what stays
+// here is the data-dependent control loop (re-detection with a lower threshold, top-N selection),
+// which the reference also runs on the host.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "orb_host.h"
+#include "orb_pattern.inc"
+
+namespace rgbdfe {
+
+namespace {
+
+constexpr int kLevels = 8;           // ORB nlevels
+constexpr int kDetectEdge = 15;      // ORB::create(10000, 1.2, 8, 15, ...)   feature_adjuster.cpp:94
+constexpr int kComputeEdge = 31;     // ORB::create() default edgeThreshold    features.cpp:118
+constexpr int kDetectFeatures = 10000;
+
+inline int cv_round_f(float v) { return (int)lrintf(v); }
+
+void level_geometry(int cols, int rows, int nlevels, float* scale, int* lw, int* lh) {
+  const double scaleFactor = (double)1.2f;
+  for (int l = 0; l < nlevels; ++l) {
+    scale[l] = (float)std::pow(scaleFactor, (double)l);
+    lw[l] = cv_round_f((float)cols / scale[l]);
+    lh[l] = cv_round_f((float)rows / scale[l]);
+  }
+}
+
+#define ORB_HIP(expr)                                   \
+  do {                                                  \
+    hipError_t _e = (expr);                             \
+    if (_e != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(_e); return RGBDFE_ERR_HIP; } \
+  } while (0)
+
+struct KP {  // cv::KeyPoint fields in use
+  float x, y, size, angle, response;
+  int octave;
+  float score;  // FAST score (first retainBest)
+};
+
+// KeyPointsFilter::retainBest: keep everything >= the n-th largest response; survivors keep their order
+template <typename F>
+void retain_best(std::vector<KP>& v, int n_points, F key) {
+  if (n_points < 0 || (int)v.size() <= n_points) return;
+  if (n_points == 0) { v.clear(); return; }
+  std::vector<float> r(v.size());
+  for (size_t i = 0; i < v.size(); ++i) r[i] = key(v[i]);
+  std::nth_element(r.begin(), r.begin() + (n_points - 1), r.end(), [](float a, float b) { return a > b; });
+  const float ambiguous = r[n_points - 1];
+  size_t m = 0;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (key(v[i]) >= ambiguous) v[m++] = v[i];
+  v.resize(m);
+}
+
+// exactly N strongest by key (descending), ties by original order; survivors keep their order
+template <typename F>
+void keep_strongest(std::vector<KP>& v, int N, F key) {
+  if ((int)v.size() <= N) return;
+  std::vector<int> idx(v.size());
+  for (size_t i = 0; i < v.size(); ++i) idx[i] = (int)i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(v[a]) > key(v[b]); });
+  std::vector<char> keep(v.size(), 0);
+  for (int i = 0; i < N; ++i) keep[idx[i]] = 1;
+  size_t m = 0;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (keep[i]) v[m++] = v[i];
+  v.resize(m);
+}
+
+}  // namespace
+
+OrbWorkspace::~OrbWorkspace() { release(); }
+
+void OrbWorkspace::release() {
+  auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  fr(d_pool); fr(d_score); fr(d_blur); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr); fr(d_active);
+  fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_depth); fr(d_kpxy);
+  fr(d_kept); fr(d_xyz); fr(d_n);
+  W = H = 0;
+}
+
+void OrbWorkspace::reset_detector(int max_keypoints, int grid_res, int max_iters) {
+  grid = grid_res;
+  adjuster_iters = max_iters;
+  const int mn = max_keypoints;            // features.cpp:47
+  const int mx = (int)(mn * 1.5);          // :48
+  const int cells = grid * grid;
+  cell_min = (int)roundf(mn / (float)cells);  // :52
+  cell_max = (int)roundf(mx / (float)cells);  // :53
+  max_total = mx;
+  for (int i = 0; i < 64; ++i) thresh[i] = 20.0;  // DetectorAdjuster("ORB", 20), features.cpp:99
+  W = H = 0;  // geometry depends on the grid
+}
+
+// (re)build the geometry for a frame size / cell layout
+int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
+  const int want_cells = use_grid ? grid * grid : 1;
+  if (cols == W && rows == H && n_cells == want_cells && d_pool) return RGBDFE_OK;
+  release();
+  W = cols; H = rows;
+  n_cells = want_cells;
+  const int G = use_grid ? grid : 1;
+  const int edge = use_grid ? 31 : 0;  // VideoGridAdaptedFeatureDetector edgeThreshold (feature_adjuster.h)
+  cells.clear();
+  for (int i = 0; i < G; ++i) {
+    const int rowstart = std::max((i * rows) / G - edge, 0);
+    const int rowend = std::min(rows, ((i + 1) * rows) / G + edge);
+    for (int j = 0; j < G; ++j) {
+      const int colstart = std::max((j * cols) / G - edge, 0);
+      const int colend = std::min(cols, ((j + 1) * cols) / G + edge);
+      cells.push_back(Cell{colstart, rowstart, colend - colstart, rowend - rowstart});
+    }
+  }
+  // pool layout
+  size_t off = 0;
+  const uint32_t gray_off = 0; off += (size_t)W * H;
+  const uint32_t mask_off = (uint32_t)off; off += (size_t)W * H;
+  cell_imgs.assign((size_t)n_cells * kLevels, ImgDesc{});
+  frame_imgs.assign(kLevels, ImgDesc{});
+  jobs.clear();
+  level_job_begin.assign(kLevels + 1, 0);
+  size_t score_off = 0, row_off = 0;
+  max_w = max_h = 0;
+  // geometry first
+  std::vector<int> lw((size_t)n_cells * kLevels), lh((size_t)n_cells * kLevels);
+  for (int c = 0; c < n_cells; ++c) {
+    float sc[kLevels];
+    level_geometry(cells[c].w, cells[c].h, kLevels, sc, &lw[(size_t)c * kLevels], &lh[(size_t)c * kLevels]);
+  }
+  level_geometry(W, H, kLevels, scale, flw, flh);
+  for (int c = 0; c < n_cells; ++c)
+    for (int l = 0; l < kLevels; ++l) {
+      ImgDesc& d = cell_imgs[(size_t)c * kLevels + l];
+      d.w = lw[(size_t)c * kLevels + l]; d.h = lh[(size_t)c * kLevels + l];
+      d.cell = c; d.level = l; d.has_mask = 1;
+      if (l == 0) {
+        d.off = gray_off + (uint32_t)((size_t)cells[c].y0 * W + cells[c].x0); d.stride = W;
+        d.mask_off = mask_off + (uint32_t)((size_t)cells[c].y0 * W + cells[c].x0); d.mask_stride = W;
+      } else {
+        d.off = (uint32_t)off; off += (size_t)d.w * d.h; d.stride = d.w;
+        d.mask_off = (uint32_t)off; off += (size_t)d.w * d.h; d.mask_stride = d.w;
+      }
+      d.score_off = (uint32_t)score_off; score_off += (size_t)d.w * d.h;
+      d.row_off = (int32_t)row_off; row_off += (size_t)d.h;
+      max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
+    }
+  size_t blur_off = 0;
+  for (int l = 0; l < kLevels; ++l) {
+    ImgDesc& d = frame_imgs[l];
+    d.w = flw[l]; d.h = flh[l]; d.cell = 0; d.level = l; d.has_mask = 0;
+    if (l == 0) { d.off = gray_off; d.stride = W; }
+    else { d.off = (uint32_t)off; off += (size_t)d.w * d.h; d.stride = d.w; }
+    d.score_off = (uint32_t)blur_off; blur_off += (size_t)d.w * d.h;
+  }
+  pool_bytes = off + 256;
+  // resize jobs, level by level (level l reads level l-1)
+  for (int l = 1; l < kLevels; ++l) {
+    level_job_begin[l] = (int)jobs.size();
+    auto add = [&](const ImgDesc& s, const ImgDesc& d, bool is_mask) {
+      ResizeJob j{};
+      j.src_off = is_mask ? s.mask_off : s.off; j.dst_off = is_mask ? d.mask_off : d.off;
+      j.sw = s.w; j.sh = s.h; j.sstride = is_mask ? s.mask_stride : s.stride; j.dw = d.w; j.dh = d.h;
+      j.is_mask = is_mask ? 1 : 0;
+      j.scale_x = 1. / ((double)d.w / s.w);
+      j.scale_y = 1. / ((double)d.h / s.h);
+      jobs.push_back(j);
+    };
+    for (int c = 0; c < n_cells; ++c) {
+      add(cell_imgs[(size_t)c * kLevels + l - 1], cell_imgs[(size_t)c * kLevels + l], false);
+      add(cell_imgs[(size_t)c * kLevels + l - 1], cell_imgs[(size_t)c * kLevels + l], true);
+    }
+    add(frame_imgs[l - 1], frame_imgs[l], false);
+  }
+  level_job_begin[kLevels] = (int)jobs.size();
+  n_rows_total = (int)row_off;
+  kp_cap = (int)(score_off / 4) + 64 * n_cells * kLevels;
+  ORB_HIP(hipMalloc((void**)&d_pool, pool_bytes));
+  ORB_HIP(hipMemset(d_pool, 0, pool_bytes));
+  ORB_HIP(hipMalloc((void**)&d_score, score_off + 256));
+  ORB_HIP(hipMalloc((void**)&d_blur, blur_off + 256));
+  ORB_HIP(hipMalloc((void**)&d_cell_imgs, sizeof(ImgDesc) * cell_imgs.size()));
+  ORB_HIP(hipMalloc((void**)&d_frame_imgs, sizeof(ImgDesc) * frame_imgs.size()));
+  ORB_HIP(hipMalloc((void**)&d_jobs, sizeof(ResizeJob) * jobs.size()));
+  ORB_HIP(hipMalloc((void**)&d_thr, sizeof(int) * 64));
+  ORB_HIP(hipMalloc((void**)&d_active, sizeof(int) * 64));
+  ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
+  ORB_HIP(hipMalloc((void**)&d_img_total, sizeof(int) * cell_imgs.size()));
+  ORB_HIP(hipMalloc((void**)&d_img_base, sizeof(int) * cell_imgs.size()));
+  ORB_HIP(hipMalloc((void**)&d_kps, sizeof(RawKp) * (size_t)kp_cap));
+  ORB_HIP(hipMalloc((void**)&d_desckp, sizeof(DescKp) * (size_t)kp_cap));
+  ORB_HIP(hipMalloc((void**)&d_desc, (size_t)32 * kp_cap));
+  ORB_HIP(hipMalloc((void**)&d_depth, sizeof(float) * (size_t)W * H));
+  ORB_HIP(hipMalloc((void**)&d_kpxy, sizeof(float) * 2 * (size_t)kp_cap));
+  ORB_HIP(hipMalloc((void**)&d_kept, sizeof(int32_t) * (size_t)kp_cap));
+  ORB_HIP(hipMalloc((void**)&d_xyz, sizeof(float4) * (size_t)kp_cap));
+  ORB_HIP(hipMalloc((void**)&d_n, sizeof(int32_t)));
+  ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
+  ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
+  ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));
+  if (!pattern_uploaded) { orb_upload_pattern(kOrbBitPattern31); pattern_uploaded = true; }
+  return RGBDFE_OK;
+}
+
+// uploads the frame and builds every pyramid (cells + whole frame) and the blurred frame levels
+int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err) {
+  ORB_HIP(hipMemcpyAsync(d_pool, gray, (size_t)W * H, hipMemcpyHostToDevice, s));
+  if (mask) ORB_HIP(hipMemcpyAsync(d_pool + (size_t)W * H, mask, (size_t)W * H, hipMemcpyHostToDevice, s));
+  else ORB_HIP(hipMemsetAsync(d_pool + (size_t)W * H, 255, (size_t)W * H, s));
+  for (int l = 1; l < kLevels; ++l) {
+    const int b = level_job_begin[l], e = level_job_begin[l + 1];
+    int mw = 0, mh = 0;
+    for (int k = b; k < e; ++k) { mw = std::max(mw, jobs[k].dw); mh = std::max(mh, jobs[k].dh); }
+    launch_orb_resize(d_pool, d_jobs + b, e - b, mw, mh, s);
+  }
+  launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+  ORB_HIP(hipGetLastError());
+  return RGBDFE_OK;
+}
+
+// One detection pass over the active cells with their current thresholds.  out[c] receives the cell's
+// keypoints (level coordinates scaled to the cell image, cell-local) after orb.cpp computeKeyPoints'
+// per-level selection: retainBest(2*featuresNum) by FAST score, Harris responses, retainBest(featuresNum).
+int OrbWorkspace::detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
+                              std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err) {
+  int h_thr[64] = {0}, h_act[64] = {0};
+  for (int c = 0; c < n_cells; ++c) { h_thr[c] = thr[c]; h_act[c] = active[c]; }
+  ORB_HIP(hipMemcpyAsync(d_thr, h_thr, sizeof(h_thr), hipMemcpyHostToDevice, s));
+  ORB_HIP(hipMemcpyAsync(d_active, h_act, sizeof(h_act), hipMemcpyHostToDevice, s));
+  const int n_imgs = n_cells * kLevels;
+  launch_orb_fast_score(d_pool, d_cell_imgs, n_imgs, max_w, max_h, d_thr, d_active, d_score, s);
+  launch_orb_nms_count(d_pool, d_cell_imgs, n_imgs, max_h, d_active, d_score, kDetectEdge, d_row_cnt, d_img_total, s);
+  std::vector<int> totals(n_imgs), base(n_imgs);
+  ORB_HIP(hipMemcpyAsync(totals.data(), d_img_total, sizeof(int) * n_imgs, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipStreamSynchronize(s));
+  int n_total = 0;
+  for (int i = 0; i < n_imgs; ++i) { base[i] = n_total; n_total += totals[i]; }
+  if (n_total > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
+  ORB_HIP(hipMemcpyAsync(d_img_base, base.data(), sizeof(int) * n_imgs, hipMemcpyHostToDevice, s));
+  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, d_active, d_score, kDetectEdge, d_row_cnt, d_img_base, d_kps,
+                  n_total, s);
+  ORB_HIP(hipGetLastError());
+  std::vector<RawKp> raw((size_t)n_total);
+  if (n_total)
+    ORB_HIP(hipMemcpyAsync(raw.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipStreamSynchronize(s));
+
+  // nfeaturesPerLevel (orb.cpp computeKeyPoints)
+  int per_level[kLevels];
+  {
+    const float factor = (float)(1.0 / (double)1.2f);
+    float nd = kDetectFeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)kLevels));
+    int sum = 0;
+    for (int l = 0; l < kLevels - 1; ++l) { per_level[l] = cv_round_f(nd); sum += per_level[l]; nd *= factor; }
+    per_level[kLevels - 1] = std::max(kDetectFeatures - sum, 0);
+  }
+  for (int c = 0; c < n_cells; ++c) {
+    if (!active[c]) continue;
+    out[c].clear();
+    float sc[kLevels]; int lw[kLevels], lh[kLevels];
+    level_geometry(cells[c].w, cells[c].h, kLevels, sc, lw, lh);
+    for (int l = 0; l < kLevels; ++l) {
+      const int img = c * kLevels + l;
+      std::vector<KP> v((size_t)totals[img]);
+      for (int k = 0; k < totals[img]; ++k) {
+        const RawKp& r = raw[(size_t)base[img] + k];
+        v[k] = KP{(float)r.x, (float)r.y, 31 * sc[l], r.angle, r.harris, l, (float)r.score};
+      }
+      retain_best(v, 2 * per_level[l], [](const KP& k) { return k.score; });
+      retain_best(v, per_level[l], [](const KP& k) { return k.response; });
+      for (const KP& k : v) out[c].push_back(KpOut{k.x * sc[l], k.y * sc[l], k.size, k.angle, k.response, l});
+    }
+  }
+  return RGBDFE_OK;
+}
+
+// VideoGridAdaptedFeatureDetector::detect over the whole frame (feature_adjuster.cpp:286-317)
+int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::string& err) {
+  std::vector<std::vector<KpOut>> cellkp((size_t)n_cells);
+  std::vector<int> active((size_t)n_cells, 1), iter_left((size_t)n_cells, adjuster_iters), thr((size_t)n_cells);
+  std::vector<char> checked((size_t)n_cells, 0);
+  // host copy of the mask is needed only for hasNonZero(): done lazily by the caller through mask_nonzero
+  bool any = true;
+  while (any) {
+    for (int c = 0; c < n_cells; ++c) thr[c] = (int)thresh[c];  // static_cast<int>(thresh_)
+    int rc = detect_pass(active, thr, cellkp, s, err);
+    if (rc != RGBDFE_OK) return rc;
+    any = false;
+    for (int c = 0; c < n_cells; ++c) {
+      if (!active[c]) continue;
+      const int found = (int)cellkp[c].size();
+      bool again = false;
+      // VideoDynamicAdaptedFeatureDetector::detect (feature_adjuster.cpp:185-224)
+      if (found < cell_min) {
+        thresh[c] *= 0.7;                       // tooFew (:131-136)
+        if (thresh[c] < 2) thresh[c] = 2;
+        bool brk = false;
+        if (found == 0 && !checked[c]) {
+          checked[c] = 1;
+          if (!cell_mask_nonzero[c]) brk = true;  // hasNonZero(mask) (:205-209)
+        }
+        if (!brk) {
+          iter_left[c]--;
+          again = iter_left[c] > 0 && (thresh[c] > 2 && thresh[c] < 10000);  // good() (:147-150)
+        }
+      } else if (found > cell_max) {
+        thresh[c] *= 1.3;                       // tooMany (:138-143)
+        if (thresh[c] > 10000) thresh[c] = 10000;
+      }
+      active[c] = again ? 1 : 0;
+      any |= again;
+    }
+  }
+  const int maxPerCell = max_total / (n_cells);  // :292
+  kps.clear();
+  for (int c = 0; c < n_cells; ++c) {
+    std::vector<KP> v;
+    v.reserve(cellkp[c].size());
+    for (const KpOut& k : cellkp[c]) v.push_back(KP{k.x, k.y, k.size, k.angle, k.response, k.octave, 0.f});
+    keep_strongest(v, maxPerCell, [](const KP& k) { return std::fabs(k.response); });  // :247-255
+    for (const KP& k : v)  // aggregateKeypointsPerGridCell (:259-282)
+      kps.push_back(KpOut{k.x + cells[c].x0, k.y + cells[c].y0, k.size, k.angle, k.response, k.octave});
+  }
+  return RGBDFE_OK;
+}
+
+// cv::ORB::create()->compute (features.cpp:117-119): border filter, regroup by level, rBRIEF
+int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err) {
+  {  // KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31)
+    size_t m = 0;
+    for (const KpOut& k : kps)
+      if (k.x >= kComputeEdge && k.x < W - kComputeEdge && k.y >= kComputeEdge && k.y < H - kComputeEdge) kps[m++] = k;
+    kps.resize(m);
+  }
+  int nlevels = 1;
+  for (const KpOut& k : kps) nlevels = std::max(nlevels, std::max(k.octave, 0) + 1);
+  if (nlevels > kLevels) { err = "keypoint octave beyond the 8-level pyramid"; return RGBDFE_ERR_INVALID_ARG; }
+  {  // stable regroup by level (orb.cpp: !sortedByLevel branch)
+    std::vector<KpOut> t;
+    t.reserve(kps.size());
+    for (int l = 0; l < nlevels; ++l)
+      for (const KpOut& k : kps)
+        if (k.octave == l) t.push_back(k);
+    kps.swap(t);
+  }
+  const int n = (int)kps.size();
+  desc.assign((size_t)n * 32, 0);
+  if (n == 0) return RGBDFE_OK;
+  if (n > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
+  std::vector<DescKp> dk((size_t)n);
+  for (int j = 0; j < n; ++j) {
+    const KpOut& k = kps[j];
+    const float sc = 1.f / scale[k.octave];
+    float angle = k.angle;
+    angle *= (float)(M_PI / 180.f);
+    dk[j].cos_a = (float)std::cos((double)angle);
+    dk[j].sin_a = (float)std::sin((double)angle);
+    dk[j].cx = cv_round_f(k.x * sc);
+    dk[j].cy = cv_round_f(k.y * sc);
+    dk[j].level = k.octave;
+  }
+  ORB_HIP(hipMemcpyAsync(d_desckp, dk.data(), sizeof(DescKp) * (size_t)n, hipMemcpyHostToDevice, s));
+  launch_orb_brief(d_pool, d_blur, d_frame_imgs, d_desckp, n, d_desc, s);
+  ORB_HIP(hipGetLastError());
+  ORB_HIP(hipMemcpyAsync(desc.data(), d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipStreamSynchronize(s));
+  return RGBDFE_OK;
+}
+
+}  // namespace rgbdfe

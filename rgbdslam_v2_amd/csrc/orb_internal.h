@@ -1,0 +1,57 @@
+// orb_internal.h -- shared by orb_kernels.hip and orb_host.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rgbdfe_internal.h"
+
+namespace rgbdfe {
+
+// one 8-bit image of a step (a pyramid level of a grid cell or of the whole frame) inside the byte pool
+struct ImgDesc {
+  uint32_t off;        // first pixel in the image pool
+  int32_t w, h, stride;
+  uint32_t score_off;  // FAST score map (cell images) / blurred copy (frame images), tightly packed w*h
+  uint32_t mask_off;   // mask pixels in the image pool
+  int32_t mask_stride;
+  int32_t has_mask;
+  int32_t cell;        // grid cell (index into thresholds / active flags)
+  int32_t level;
+  int32_t row_off;     // first entry of this image in the row-count array
+};
+
+struct ResizeJob {
+  uint32_t src_off, dst_off;
+  int32_t sw, sh, sstride, dw, dh, is_mask;
+  double scale_x, scale_y;  // 1 / ((double)dw / sw), computed on the host exactly as cv::resize does
+};
+
+// a FAST keypoint as the device emits it (16 bytes)
+struct RawKp {
+  uint16_t x, y, img, score;
+  float harris, angle;
+};
+
+// a keypoint handed to the descriptor kernel
+struct DescKp {
+  int32_t cx, cy, level;
+  float cos_a, sin_a;
+};
+
+void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max_w, int max_h, hipStream_t s);
+void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h,
+                           const int* cell_thr, const int* active, uint8_t* score_pool, hipStream_t s);
+void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
+                          const uint8_t* score_pool, int edge, int* row_cnt, int* img_total, hipStream_t s);
+void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
+                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_base, RawKp* out,
+                     int n_total, hipStream_t s);
+void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
+                     hipStream_t s);
+void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,
+                      uint8_t* desc, hipStream_t s);
+void orb_upload_pattern(const int8_t* host_pattern);
+
+}  // namespace rgbdfe

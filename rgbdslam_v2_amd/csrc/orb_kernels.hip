@@ -1,0 +1,406 @@
+// orb_kernels.hip -- ORB detect / describe kernels for gfx950 (rows a1, a6 of SURVEY.md section 8).
+//
+// Device side of cv::ORB as the reference uses it:
+//   detect : ORB::create(10000, 1.2f, 8, 15, 0, 2, HARRIS_SCORE, 31, thr)->detect(sub_image, kps, sub_mask)
+//            per grid cell (src/feature_adjuster.cpp:94, 286-317)
+//   compute: ORB::create()->compute(gray, kps, desc)                    (src/features.cpp:117-119, node.cpp:202)
+// OpenCV is not part of the reference tree: the arithmetic restated here is the published OpenCV 3.3
+// algorithm (features2d/src/orb.cpp, fast.cpp, fast_score.cpp; imgproc/src/resize.cpp, smooth.cpp) and is
+// tested for exact equality against oracle/orb_oracle.c ("parity unpinned" against a real OpenCV).
+//
+// All images of one step (9 grid cells x 8 pyramid levels, plus the full-frame pyramid) are described by
+// ImgDesc records and processed by ONE launch per stage: a frame is ~1.7 M pixels, far too little to fill
+// 256 CUs unless every (cell, level) image rides in the same grid.  Pixel kernels are streaming stencils
+// (HBM/L2 bound): one byte per lane, rows contiguous across lanes.  Keypoint lists are compacted in raster
+// order with __ballot / mbcnt prefixes (row counts -> block scan -> emit), so the order of keypoints is
+// the one cv::FAST produces; per-keypoint measurements (Harris response, intensity-centroid angle, rBRIEF)
+// use one wave per keypoint with shuffle reductions.
+#include "orb_internal.h"
+
+namespace rgbdfe {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::resize(..., INTER_LINEAR) for 8-bit images (fixed point, INTER_RESIZE_COEF_BITS = 11), one
+// pyramid level for every job in the launch; the mask variant applies threshold(254, TOZERO).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs) {
+  const ResizeJob j = jobs[blockIdx.z];
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= j.dw || dy >= j.dh) return;
+  const uint8_t* __restrict__ src = pool + j.src_off;
+  float fx = (float)((dx + 0.5) * j.scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= sx;
+  if (sx < 0) { fx = 0; sx = 0; }
+  const bool edge = (sx + 1 >= j.sw);
+  if (sx >= j.sw - 1) { fx = 0; sx = j.sw - 1; }
+  const int a0 = max(min(__float2int_rn((1.f - fx) * 2048), 32767), -32768);
+  const int a1 = max(min(__float2int_rn(fx * 2048), 32767), -32768);
+  float fy = (float)((dy + 0.5) * j.scale_y - 0.5);
+  int sy = (int)floorf(fy);
+  fy -= sy;
+  const int b0 = max(min(__float2int_rn((1.f - fy) * 2048), 32767), -32768);
+  const int b1 = max(min(__float2int_rn(fy * 2048), 32767), -32768);
+  const int y0 = min(max(sy, 0), j.sh - 1), y1 = min(max(sy + 1, 0), j.sh - 1);
+  const uint8_t* r0 = src + (size_t)y0 * j.sstride;
+  const uint8_t* r1 = src + (size_t)y1 * j.sstride;
+  int h0, h1;
+  if (!edge) {
+    h0 = r0[sx] * a0 + r0[sx + 1] * a1;
+    h1 = r1[sx] * a0 + r1[sx + 1] * a1;
+  } else {
+    h0 = r0[sx] * 2048;
+    h1 = r1[sx] * 2048;
+  }
+  int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+  v = min(max(v, 0), 255);
+  if (j.is_mask && v <= 254) v = 0;
+  pool[j.dst_off + (size_t)dy * j.dw + dx] = (uint8_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::FAST TYPE_9_16 corner test + cornerScore<16> for every pixel of every image of the launch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ ptr, int stride, int threshold) {
+  const int v = ptr[0];
+  int d[25];
+  d[0] = v - ptr[3 * stride];       d[1] = v - ptr[1 + 3 * stride];   d[2] = v - ptr[2 + 2 * stride];
+  d[3] = v - ptr[3 + stride];       d[4] = v - ptr[3];                d[5] = v - ptr[3 - stride];
+  d[6] = v - ptr[2 - 2 * stride];   d[7] = v - ptr[1 - 3 * stride];   d[8] = v - ptr[-3 * stride];
+  d[9] = v - ptr[-1 - 3 * stride];  d[10] = v - ptr[-2 - 2 * stride]; d[11] = v - ptr[-3 - stride];
+  d[12] = v - ptr[-3];              d[13] = v - ptr[-3 + stride];     d[14] = v - ptr[-2 + 2 * stride];
+  d[15] = v - ptr[-1 + 3 * stride];
+#pragma unroll
+  for (int k = 16; k < 25; ++k) d[k] = d[k - 16];
+  bool corner = false;
+  int cd = 0, cb = 0;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) {
+    cd = d[k] > threshold ? cd + 1 : 0;
+    cb = d[k] < -threshold ? cb + 1 : 0;
+    corner |= (cd > 8) | (cb > 8);
+  }
+  if (!corner) return 0;
+  int a0 = threshold;
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    int a = min(min(d[k + 1], d[k + 2]), d[k + 3]);
+    if (a <= a0) continue;
+    a = min(a, min(min(d[k + 4], d[k + 5]), min(d[k + 6], min(d[k + 7], d[k + 8]))));
+    a0 = max(a0, min(a, d[k]));
+    a0 = max(a0, min(a, d[k + 9]));
+  }
+  int b0 = -a0;
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    int b = max(max(d[k + 1], d[k + 2]), max(d[k + 3], max(d[k + 4], d[k + 5])));
+    if (b >= b0) continue;
+    b = max(b, max(d[k + 6], max(d[k + 7], d[k + 8])));
+    b0 = min(b0, max(b, d[k]));
+    b0 = min(b0, max(b, d[k + 9]));
+  }
+  return -b0 - 1;
+}
+
+__global__ __launch_bounds__(256) void orb_fast_score_kernel(const uint8_t* __restrict__ pool,
+                                                             const ImgDesc* __restrict__ imgs,
+                                                             const int* __restrict__ cell_thr,
+                                                             const int* __restrict__ active,
+                                                             uint8_t* __restrict__ score_pool) {
+  const ImgDesc im = imgs[blockIdx.z];
+  if (!active[im.cell]) return;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= im.w || y >= im.h) return;
+  int s = 0;
+  if (x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3) {
+    int thr = cell_thr[im.cell];
+    thr = min(max(thr, 0), 255);
+    s = fast_score(pool + im.off + (size_t)y * im.stride + x, im.stride, thr);
+    s = min(max(s, 0), 255);
+  }
+  score_pool[im.score_off + (size_t)y * im.w + x] = (uint8_t)s;
+}
+
+// keep = 3x3 non-maximum suppression (strict >) && runByPixelsMask && runByImageBorder(edge)
+__device__ __forceinline__ bool nms_keep(const uint8_t* __restrict__ sc, const uint8_t* __restrict__ pool,
+                                         const ImgDesc& im, int x, int y, int edge, int& s_out) {
+  if (!(x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3)) return false;
+  const uint8_t* p = sc + (size_t)y * im.w + x;
+  const int s = p[0];
+  s_out = s;
+  if (!s) return false;
+  const int w = im.w;
+  if (!(s > p[1] && s > p[-1] && s > p[-w - 1] && s > p[-w] && s > p[-w + 1] && s > p[w - 1] && s > p[w] &&
+        s > p[w + 1]))
+    return false;
+  if (im.has_mask && pool[im.mask_off + (size_t)y * im.mask_stride + x] == 0) return false;
+  return x >= edge && x < im.w - edge && y >= edge && y < im.h - edge;
+}
+
+// one wave per image row: count the keypoints of the row
+__global__ __launch_bounds__(64) void orb_nms_count_kernel(const uint8_t* __restrict__ pool,
+                                                           const ImgDesc* __restrict__ imgs,
+                                                           const int* __restrict__ active,
+                                                           const uint8_t* __restrict__ score_pool, int edge,
+                                                           int* __restrict__ row_cnt) {
+  const ImgDesc im = imgs[blockIdx.y];
+  const int y = blockIdx.x;
+  if (y >= im.h || !active[im.cell]) return;
+  const uint8_t* sc = score_pool + im.score_off;
+  int cnt = 0;
+  for (int x0 = 0; x0 < im.w; x0 += 64) {
+    int s;
+    const bool keep = nms_keep(sc, pool, im, x0 + (int)threadIdx.x, y, edge, s);
+    cnt += __popcll(__ballot(keep));
+  }
+  if (threadIdx.x == 0) row_cnt[im.row_off + y] = cnt;
+}
+
+// one block per image: exclusive scan of the row counts, total per image
+__global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __restrict__ imgs,
+                                                           const int* __restrict__ active,
+                                                           int* __restrict__ row_cnt, int* __restrict__ img_total) {
+  __shared__ int part[256];
+  const ImgDesc im = imgs[blockIdx.x];
+  if (!active[im.cell]) { if (threadIdx.x == 0) img_total[blockIdx.x] = 0; return; }
+  const int per = (im.h + 255) / 256;
+  const int r0 = threadIdx.x * per;
+  int sum = 0;
+  for (int r = r0; r < min(r0 + per, im.h); ++r) sum += row_cnt[im.row_off + r];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int i = 0; i < 256; ++i) { const int t = part[i]; part[i] = acc; acc += t; }
+    img_total[blockIdx.x] = acc;
+  }
+  __syncthreads();
+  int acc = part[threadIdx.x];
+  for (int r = r0; r < min(r0 + per, im.h); ++r) {
+    const int t = row_cnt[im.row_off + r];
+    row_cnt[im.row_off + r] = acc;
+    acc += t;
+  }
+}
+
+// one wave per image row: write the keypoints of the row at img_base + row_offset + rank (raster order)
+__global__ __launch_bounds__(64) void orb_emit_kernel(const uint8_t* __restrict__ pool,
+                                                      const ImgDesc* __restrict__ imgs, const int* __restrict__ active,
+                                                      const uint8_t* __restrict__ score_pool, int edge,
+                                                      const int* __restrict__ row_off, const int* __restrict__ img_base,
+                                                      RawKp* __restrict__ out) {
+  const int img = blockIdx.y;
+  const ImgDesc im = imgs[img];
+  const int y = blockIdx.x;
+  if (y >= im.h || !active[im.cell]) return;
+  const uint8_t* sc = score_pool + im.score_off;
+  int base = img_base[img] + row_off[im.row_off + y];
+  for (int x0 = 0; x0 < im.w; x0 += 64) {
+    int s = 0;
+    const int x = x0 + (int)threadIdx.x;
+    const bool keep = nms_keep(sc, pool, im, x, y, edge, s);
+    const uint64_t m = __ballot(keep);
+    if (keep) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      RawKp k;
+      k.x = (uint16_t)x; k.y = (uint16_t)y; k.img = (uint16_t)img; k.score = (uint16_t)s;
+      k.harris = 0.f; k.angle = 0.f;
+      out[base + rank] = k;
+    }
+    base += __popcll(m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one wave per keypoint: HarrisResponses (7x7 block of Sobel products, k = 0.04) and ICAngles
+// (intensity centroid over the radius-15 disc, cv::fastAtan2) -- orb.cpp
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+  const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+  const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+  const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restrict__ pool,
+                                                          const ImgDesc* __restrict__ imgs,
+                                                          RawKp* __restrict__ kps, int n) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const int lane = threadIdx.x & 63;
+  RawKp kp = kps[k];
+  const ImgDesc im = imgs[kp.img];
+  const int stride = im.stride;
+  const uint8_t* __restrict__ center = pool + im.off + (size_t)kp.y * stride + kp.x;
+  // Harris: 49 positions, one per lane
+  int a = 0, b = 0, c = 0;
+  if (lane < 49) {
+    const uint8_t* ptr = center + (lane / 7 - 3) * stride + (lane % 7 - 3);
+    const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-stride + 1] - ptr[-stride - 1]) + (ptr[stride + 1] - ptr[stride - 1]);
+    const int Iy = (ptr[stride] - ptr[-stride]) * 2 + (ptr[stride - 1] - ptr[-stride - 1]) + (ptr[stride + 1] - ptr[-stride + 1]);
+    a = Ix * Ix; b = Iy * Iy; c = Ix * Iy;
+  }
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;
+  const float harris = ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+  // IC angle: integer moments are order-independent -> any lane assignment is exact
+  int m01 = 0, m10 = 0;
+  for (int r = lane; r < 31 * 31; r += 64) {
+    const int v = r / 31 - 15, u = r % 31 - 15;
+    const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+    if (au <= c_umax[av]) {
+      const int val = center[u + v * stride];
+      m10 += u * val;
+      m01 += v * val;
+    }
+  }
+  m01 = wave_sum(m01); m10 = wave_sum(m10);
+  if (lane == 0) {
+    kp.harris = harris;
+    kp.angle = fast_atan2_deg((float)m01, (float)m10);
+    kps[k] = kp;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GaussianBlur 7x7, sigma 2, BORDER_REFLECT_101, 8-bit fixed point (kernel x256, (v + 2^15) >> 16)
+// ------------------------------------------------------------------------------------------------
+__constant__ int c_gauss[7] = {18, 34, 49, 55, 49, 34, 18};
+
+__global__ __launch_bounds__(256) void orb_blur_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
+                                                       uint8_t* __restrict__ blur_pool) {
+  const ImgDesc im = imgs[blockIdx.z];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= im.w || y >= im.h) return;
+  const uint8_t* __restrict__ src = pool + im.off;
+  int xs[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) xs[i] = reflect101(x + i - 3, im.w);
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const uint8_t* row = src + (size_t)reflect101(y + j - 3, im.h) * im.stride;
+    int h = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) h += c_gauss[i] * row[xs[i]];
+    s += c_gauss[j] * h;
+  }
+  int v = (s + (1 << 15)) >> 16;
+  v = min(max(v, 0), 255);
+  blur_pool[im.score_off + (size_t)y * im.w + x] = (uint8_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rBRIEF (computeOrbDescriptors, WTA_K = 2): one wave per keypoint, lane = (byte, half): every lane
+// evaluates 4 of the 256 tests; bits are assembled with shuffles.
+// ------------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[1024];
+
+void orb_upload_pattern(const int8_t* host_pattern) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), host_pattern, 1024);
+}
+
+__global__ __launch_bounds__(256) void orb_brief_kernel(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ blur_pool,
+                                                        const ImgDesc* __restrict__ imgs, const DescKp* __restrict__ kps,
+                                                        int n, uint8_t* __restrict__ desc) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const int lane = threadIdx.x & 63;
+  const DescKp kp = kps[k];
+  const ImgDesc im = imgs[kp.level];
+  const uint8_t* __restrict__ raw = pool + im.off;
+  const uint8_t* __restrict__ blur = blur_pool + im.score_off;
+  const float a = kp.cos_a, b = kp.sin_a;
+  const int byte = lane >> 1, half = lane & 1;
+  int bits = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int test = byte * 8 + half * 4 + t;
+    int v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float px = (float)c_pattern[(test * 2 + e) * 2], py = (float)c_pattern[(test * 2 + e) * 2 + 1];
+      const float x = px * a - py * b;
+      const float y = px * b + py * a;
+      const int ix = kp.cx + __float2int_rn(x), iy = kp.cy + __float2int_rn(y);
+      if (ix >= 0 && ix < im.w && iy >= 0 && iy < im.h)
+        v[e] = blur[(size_t)iy * im.w + ix];
+      else  // the unblurred reflect-101 border copyMakeBorder wrote before the in-place blur
+        v[e] = raw[(size_t)reflect101(iy, im.h) * im.stride + reflect101(ix, im.w)];
+    }
+    bits |= (v[0] < v[1]) << (half * 4 + t);
+  }
+  bits |= __shfl_xor(bits, 1);
+  if (half == 0) desc[(size_t)k * 32 + byte] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max_w, int max_h, hipStream_t s) {
+  if (n_jobs == 0) return;
+  hipLaunchKernelGGL(orb_resize_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_jobs), dim3(256), 0, s, pool, jobs);
+}
+void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h,
+                           const int* cell_thr, const int* active, uint8_t* score_pool, hipStream_t s) {
+  hipLaunchKernelGGL(orb_fast_score_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_imgs), dim3(256), 0, s, pool,
+                     imgs, cell_thr, active, score_pool);
+}
+void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
+                          const uint8_t* score_pool, int edge, int* row_cnt, int* img_total, hipStream_t s) {
+  hipLaunchKernelGGL(orb_nms_count_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, active, score_pool, edge,
+                     row_cnt);
+  hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, active, row_cnt, img_total);
+}
+void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
+                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_base, RawKp* out,
+                     int n_total, hipStream_t s) {
+  hipLaunchKernelGGL(orb_emit_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, active, score_pool, edge,
+                     row_off, img_base, out);
+  if (n_total > 0)
+    hipLaunchKernelGGL(orb_measure_kernel, dim3((n_total + 3) / 4), dim3(256), 0, s, pool, imgs, out, n_total);
+}
+void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(orb_blur_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_imgs), dim3(256), 0, s, pool, imgs,
+                     blur_pool);
+}
+void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,
+                      uint8_t* desc, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(orb_brief_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pool, blur_pool, imgs, kps, n, desc);
+}
+
+}  // namespace rgbdfe

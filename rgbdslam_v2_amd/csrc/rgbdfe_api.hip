@@ -14,6 +14,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "orb_host.h"
 #include "rgbdfe_internal.h"
 
 using namespace rgbdfe;
@@ -84,6 +85,8 @@ struct rgbdfe_ctx {
   // scratch for single-pair helpers / project_to_3d
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
+  OrbWorkspace orb;
+  int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;
   std::vector<uint32_t> free_slots;
   RansacConst rc{};
@@ -676,6 +679,164 @@ int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
     for (int i = 0; i < n; ++i) { match_q[i] = hq[i]; match_t[i] = ht[i]; }
   }
   *n_matches = n;
+  return RGBDFE_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// per-frame feature path
+// ---------------------------------------------------------------------------------------------
+static void ensure_detector(rgbdfe_ctx* ctx) {
+  if (ctx->orb_max_keypoints == 0) {
+    ctx->orb_max_keypoints = 600;  // parameter_server.cpp:83
+    ctx->orb.reset_detector(600, 3, 5);  // detector_grid_resolution 3, adjuster_max_iterations 5 (:87,:89)
+  }
+}
+
+int rgbdfe_detector_configure(rgbdfe_ctx* ctx, int32_t max_keypoints, int32_t grid_resolution,
+                              int32_t adjuster_max_iterations) {
+  if (!ctx || max_keypoints < 1 || grid_resolution < 1 || grid_resolution > 8 || adjuster_max_iterations < 1)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad detector configuration");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->orb_max_keypoints = max_keypoints;
+  ctx->orb.reset_detector(max_keypoints, grid_resolution, adjuster_max_iterations);
+  return RGBDFE_OK;
+}
+
+int rgbdfe_detector_thresholds(rgbdfe_ctx* ctx, double* thresholds, int32_t* n_cells) {
+  if (!ctx || !thresholds || !n_cells) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ensure_detector(ctx);
+  *n_cells = ctx->orb.grid * ctx->orb.grid;
+  for (int i = 0; i < *n_cells; ++i) thresholds[i] = ctx->orb.thresh[i];
+  return RGBDFE_OK;
+}
+
+static void kp_to_abi(const std::vector<KpOut>& v, rgbdfe_keypoint* out) {
+  for (size_t i = 0; i < v.size(); ++i) {
+    out[i].x = v[i].x; out[i].y = v[i].y; out[i].size = v[i].size; out[i].angle = v[i].angle;
+    out[i].response = v[i].response; out[i].octave = v[i].octave;
+  }
+}
+
+int rgbdfe_orb_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,
+                      int32_t fast_threshold, rgbdfe_keypoint* keypoints, int32_t capacity, int32_t* n_out) {
+  if (!ctx || !gray || rows < 1 || cols < 1 || !keypoints || !n_out || capacity < 0)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  ensure_detector(ctx);
+  std::string err;
+  int rc = ctx->orb.prepare(cols, rows, false, err);
+  if (rc == RGBDFE_OK) rc = ctx->orb.upload_and_build(gray, mask, ctx->stream, err);
+  std::vector<std::vector<KpOut>> out(1);
+  if (rc == RGBDFE_OK) rc = ctx->orb.detect_pass({1}, {fast_threshold}, out, ctx->stream, err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  if ((int)out[0].size() > capacity) out[0].resize((size_t)capacity);
+  kp_to_abi(out[0], keypoints);
+  *n_out = (int32_t)out[0].size();
+  return RGBDFE_OK;
+}
+
+int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32_t cols,
+                       rgbdfe_keypoint* keypoints, int32_t n, uint8_t* descriptors, int32_t* n_out) {
+  if (!ctx || !gray || rows < 1 || cols < 1 || n < 0 || (n > 0 && (!keypoints || !descriptors)) || !n_out)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  ensure_detector(ctx);
+  std::string err;
+  int rc = ctx->orb.prepare(cols, rows, false, err);
+  if (rc == RGBDFE_OK) rc = ctx->orb.upload_and_build(gray, nullptr, ctx->stream, err);
+  std::vector<KpOut> kps((size_t)n);
+  for (int i = 0; i < n; ++i)
+    kps[i] = KpOut{keypoints[i].x, keypoints[i].y, keypoints[i].size, keypoints[i].angle, keypoints[i].response,
+                   keypoints[i].octave};
+  std::vector<uint8_t> desc;
+  if (rc == RGBDFE_OK) rc = ctx->orb.compute(kps, desc, ctx->stream, err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  kp_to_abi(kps, keypoints);
+  if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());
+  *n_out = (int32_t)kps.size();
+  return RGBDFE_OK;
+}
+
+int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
+                           int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                           double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
+                           float* xyz1, int32_t* n_out) {
+  if (!ctx || !gray || !depth || rows < 1 || cols < 1 || !keypoints || !descriptors || !xyz1 || !n_out)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  ensure_detector(ctx);
+  OrbWorkspace& orb = ctx->orb;
+  const int max_kp = ctx->orb_max_keypoints;
+  std::string err;
+  int rc = orb.prepare(cols, rows, true, err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  // hasNonZero(sub_mask) per cell (feature_adjuster.cpp:175-183)
+  orb.cell_mask_nonzero.assign((size_t)orb.n_cells, mask ? 0 : 1);
+  if (mask)
+    for (int c = 0; c < orb.n_cells; ++c) {
+      const OrbWorkspace::Cell& ce = orb.cells[c];
+      char nz = 0;
+      for (int y = 0; y < ce.h && !nz; ++y) {
+        const uint8_t* r = mask + (size_t)(ce.y0 + y) * cols + ce.x0;
+        for (int x = 0; x < ce.w; ++x)
+          if (r[x]) { nz = 1; break; }
+      }
+      orb.cell_mask_nonzero[c] = nz;
+    }
+  HIP_TRY(ctx, hipMemcpyAsync(orb.d_depth, depth, sizeof(float) * (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream));
+  rc = orb.upload_and_build(gray, mask, ctx->stream, err);
+  std::vector<KpOut> kps;
+  if (rc == RGBDFE_OK) rc = orb.grid_detect(kps, ctx->stream, err);  // node.cpp:160
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  {  // removeDepthless (node.cpp:67-97, :186)
+    size_t m = 0;
+    for (const KpOut& k : kps) {
+      if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
+      int r = (int)roundf(k.y), c = (int)roundf(k.x);
+      r = r >= rows ? rows - 1 : r;
+      c = c >= cols ? cols - 1 : c;
+      if (std::isnan(depth[(size_t)r * cols + c])) continue;
+      kps[m++] = k;
+    }
+    kps.resize(m);
+  }
+  if ((int)kps.size() > max_kp) {  // retainBest(max_keypoints) + resize (node.cpp:188-191)
+    std::vector<int> idx(kps.size());
+    for (size_t i = 0; i < kps.size(); ++i) idx[i] = (int)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return kps[a].response > kps[b].response; });
+    std::vector<char> keep(kps.size(), 0);
+    for (int i = 0; i < max_kp; ++i) keep[idx[i]] = 1;
+    size_t m = 0;
+    for (size_t i = 0; i < kps.size(); ++i)
+      if (keep[i]) kps[m++] = kps[i];
+    kps.resize(m);
+  }
+  std::vector<uint8_t> desc;
+  rc = orb.compute(kps, desc, ctx->stream, err);  // node.cpp:202
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  const int n = (int)kps.size();
+  *n_out = 0;
+  if (n > 0) {  // projectTo3D (node.cpp:210)
+    std::vector<float> xy((size_t)n * 2);
+    for (int i = 0; i < n; ++i) { xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y; }
+    HIP_TRY(ctx, hipMemcpyAsync(orb.d_kpxy, xy.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    launch_project_to_3d(orb.d_kpxy, n, orb.d_depth, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
+                         (float)cy, depth_scaling, max_kp, orb.d_kept, orb.d_xyz, orb.d_n, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    int32_t n3 = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n3, orb.d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(xyz1, orb.d_xyz, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n3 != n) return fail(ctx, RGBDFE_ERR_HIP, "projectTo3D dropped keypoints that removeDepthless kept");
+  }
+  kp_to_abi(kps, keypoints);
+  if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());
+  *n_out = n;
   return RGBDFE_OK;
 }
 

@@ -187,6 +187,57 @@ class FrontEnd:
     def synchronize(self):
         self._check(self._L.rgbdfe_synchronize(self._ctx))
 
+    # -- per-frame feature path (Node::Node, node.cpp:139-210) ------------------------------
+    def detector_configure(self, max_keypoints=600, grid_resolution=3, adjuster_max_iterations=5):
+        """createDetector("ORB") (features.cpp:63-113): resets the per-cell FAST thresholds."""
+        self._max_keypoints = max_keypoints
+        self._check(self._L.rgbdfe_detector_configure(self._ctx, max_keypoints, grid_resolution,
+                                                      adjuster_max_iterations))
+
+    def detector_thresholds(self):
+        t = np.zeros(64, np.float64)
+        n = C.c_int32(0)
+        self._check(self._L.rgbdfe_detector_thresholds(self._ctx, t.ctypes.data, C.byref(n)))
+        return t[: n.value].copy()
+
+    def detect_describe(self, gray, mask, depth, fx, fy, cx, cy, depth_scaling=1.0):
+        """detect -> removeDepthless -> retainBest -> compute -> projectTo3D for one frame.
+        Returns (keypoints KEYPOINT_DTYPE, descriptors [n,32] uint8, xyz1 [n,4] float32)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        cap = getattr(self, "_max_keypoints", 600)
+        kp = np.zeros(cap, _lib.KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        xyz = np.zeros((cap, 4), np.float32)
+        n = C.c_int32(0)
+        self._check(self._L.rgbdfe_detect_describe(
+            self._ctx, gray.ctypes.data, None if m is None else m.ctypes.data, depth.ctypes.data,
+            gray.shape[0], gray.shape[1], fx, fy, cx, cy, depth_scaling, kp.ctypes.data, desc.ctypes.data,
+            xyz.ctypes.data, C.byref(n)))
+        return kp[: n.value].copy(), desc[: n.value].copy(), xyz[: n.value].copy()
+
+    def orb_detect(self, gray, mask, fast_threshold, capacity=60000):
+        """cv::ORB::create(10000,1.2,8,15,0,2,HARRIS,31,thr)->detect(gray, kps, mask) (feature_adjuster.cpp:94)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        kp = np.zeros(capacity, _lib.KEYPOINT_DTYPE)
+        n = C.c_int32(0)
+        self._check(self._L.rgbdfe_orb_detect(self._ctx, gray.ctypes.data, None if m is None else m.ctypes.data,
+                                              gray.shape[0], gray.shape[1], fast_threshold, kp.ctypes.data,
+                                              capacity, C.byref(n)))
+        return kp[: n.value].copy()
+
+    def orb_compute(self, gray, keypoints):
+        """cv::ORB::create()->compute(gray, kps, desc) (features.cpp:117-119)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        kp = np.ascontiguousarray(keypoints.copy())
+        desc = np.zeros((max(len(kp), 1), 32), np.uint8)
+        n = C.c_int32(0)
+        self._check(self._L.rgbdfe_orb_compute(self._ctx, gray.ctypes.data, gray.shape[0], gray.shape[1],
+                                               kp.ctypes.data, len(kp), desc.ctypes.data, C.byref(n)))
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
     # -- SIFT (128-d float descriptors, matcher_type == SIFTGPU) ---------------------------
     def upload_sift_node(self, node_id: int, desc128: np.ndarray, xyz1: np.ndarray):
         desc128 = np.ascontiguousarray(desc128, np.float32)

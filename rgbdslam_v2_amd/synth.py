@@ -145,3 +145,47 @@ def sift_descriptors_like(desc_bits: np.ndarray, seed: int = 0, noise: float = 0
     v = np.minimum(v, 0.2)
     v /= np.linalg.norm(v, axis=-1, keepdims=True)
     return v.astype(np.float32)
+
+
+def make_image_sequence(n_frames=4, width=WIDTH, height=HEIGHT, seed=20260923, plane_depth=2.0,
+                        nan_fraction=0.03):
+    """SURVEY.md 8(d) "Level B": textured gray images of a fronto-parallel plane seen from a moving
+    camera (pure translation + in-plane rotation -> an exact similarity warp of a large random
+    blob texture), float depth = plane depth (with NaN holes), mono8 mask as the reference derives
+    it (depthToCV8UC1, misc.cpp:414-430: convertTo(CV_8UC1, 100) -> 0 where depth is NaN)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 5))
+    T = 2048
+    tex = np.zeros((T, T), np.float32)
+    # random blobs at several scales -> corners at several pyramid levels
+    for scale, count in ((3, 9000), (6, 3000), (12, 900), (25, 250)):
+        cx = rng.integers(0, T, count); cy = rng.integers(0, T, count)
+        amp = rng.uniform(-90, 90, count)
+        for x, y, a in zip(cx, cy, amp):
+            x0, x1 = max(x - scale, 0), min(x + scale, T)
+            y0, y1 = max(y - scale, 0), min(y + scale, T)
+            tex[y0:y1, x0:x1] += a
+    tex = np.clip(tex + 128, 0, 255)
+    imgs, depths, masks = [], [], []
+    f = FX * width / WIDTH
+    for k in range(n_frames):
+        ang = np.deg2rad(4.0) * np.sin(0.7 * k + 0.3)
+        s = 1.0 + 0.04 * np.sin(0.5 * k)
+        tx, ty = 600 + 25 * k, 700 + 12 * k
+        v, u = np.mgrid[0:height, 0:width].astype(np.float32)
+        uc, vc = u - (width - 1) / 2, v - (height - 1) / 2
+        xs = s * (np.cos(ang) * uc - np.sin(ang) * vc) + tx
+        ys = s * (np.sin(ang) * uc + np.cos(ang) * vc) + ty
+        x0 = np.clip(np.floor(xs).astype(np.int64), 0, T - 2); y0 = np.clip(np.floor(ys).astype(np.int64), 0, T - 2)
+        fx_, fy_ = xs - x0, ys - y0
+        img = (tex[y0, x0] * (1 - fx_) * (1 - fy_) + tex[y0, x0 + 1] * fx_ * (1 - fy_) +
+               tex[y0 + 1, x0] * (1 - fx_) * fy_ + tex[y0 + 1, x0 + 1] * fx_ * fy_)
+        img = img + rng.normal(0, 2.0, img.shape)
+        imgs.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+        d = np.full((height, width), plane_depth * s, np.float32)
+        holes = rng.random((height // 16 + 1, width // 16 + 1)) < nan_fraction
+        d[np.kron(holes, np.ones((16, 16), bool))[:height, :width]] = np.nan
+        depths.append(d)
+        m = np.where(np.isnan(d), 0, np.clip(np.rint(np.nan_to_num(d) * 100), 0, 255)).astype(np.uint8)
+        masks.append(m)
+    return dict(gray=np.stack(imgs), depth=np.stack(depths), mask=np.stack(masks), fx=f, fy=f,
+                cx=(width - 1) / 2.0, cy=(height - 1) / 2.0)
