@@ -65,20 +65,31 @@ void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipS
 //   SWAP = false: X = query (newer) node, Y = train node  -> RowMatch_Kernel's per-query result
 //   SWAP = true : X = train node, Y = query node          -> ColMatch_Kernel's per-train-column result
 // The second pass recomputes the (cheap, MFMA) dot products instead of exchanging per-tile column
-// partials between waves through LDS and HBM: no barrier, no LDS, no partial buffers.
+// partials between waves through HBM: no partial buffers, no cross-wave reduction.
+//
+// Block = 4 waves = 128 rows of X (each wave keeps its 32 rows x K=128 as A fragments in 32 VGPRs).
+// Y streams through LDS in 128-row tiles (32 KB), double buffered: the tile is fetched with fully
+// coalesced 16-byte loads (a wave reads 4 whole 256-byte rows per instruction), written with an XOR
+// swizzle on the 16-byte chunk index (chunk ^ (row & 15)) and read back as MFMA B fragments with
+// conflict-free ds_read_b128 (the 16 lanes of a read group hit 16 different slots of the 256-byte
+// bank row).  Per tile and wave: 32 x v_mfma_f32_32x32x16_bf16 and a 5-op running top-2 update per
+// accumulator element.
 // part: [pair][max_kp][3] = (best dot, second dot, best index or 0xFFFFFFFF)
+constexpr int kChunksPerRow = 16;  // 256 B / 16 B
+
 template <bool SWAP>
 __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
     const uint16_t* __restrict__ bf16_pool, const PairWork* __restrict__ work, uint32_t max_kp,
     uint32_t* __restrict__ part) {
+  __shared__ uint4 tileY[2][kTile * kChunksPerRow];
   const uint32_t pair = blockIdx.y;
   const uint32_t rb = blockIdx.x;
   const PairWork w = work[pair];
   const int nq = (int)min(w.nq, 4096u), nt = (int)min(w.nt, 4096u);  // sift_gpu_wrapper.cpp:231
   const int nx = SWAP ? nt : nq, ny = SWAP ? nq : nt;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if ((int)(rb * kTile) >= nx) return;  // block-uniform
   const int r0 = rb * kTile + wv * 32;
-  if (r0 >= nx) return;  // wave-uniform (no barriers in this kernel)
 
   const uint16_t* __restrict__ xpool = bf16_pool + (size_t)(SWAP ? w.t_slot : w.q_slot) * max_kp * kSiftDim;
   const uint16_t* __restrict__ ypool = bf16_pool + (size_t)(SWAP ? w.q_slot : w.t_slot) * max_kp * kSiftDim;
@@ -88,6 +99,7 @@ __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
   {
     int row = r0 + (lane & 31);
     row = row < nx ? row : nx - 1;
+    row = row < 0 ? 0 : row;
     const uint4* src = reinterpret_cast<const uint4*>(xpool + (size_t)row * kSiftDim + (lane >> 5) * 8);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) A[ks] = __builtin_bit_cast(bf16x8, src[ks * 2]);
@@ -100,49 +112,75 @@ __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) rmx[r] = rnx[r] = 0u;
 
-  const int n_full = ny / 64;  // 64-column chunks without a ragged edge
-  int chunk = 0;
-  for (; chunk * 64 < ny; ++chunk) {
-    const int c0 = chunk * 64;
-    f32x16 acc[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      int col = c0 + c * 32 + (lane & 31);
-      col = col < ny ? col : ny - 1;
-      const uint4* src = reinterpret_cast<const uint4*>(ypool + (size_t)col * kSiftDim + (lane >> 5) * 8);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 B = __builtin_bit_cast(bf16x8, src[ks * 2]);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], B, acc[c], 0, 0, 0);
-      }
+  const int n_tiles = (ny + kTile - 1) / kTile;
+  const uint4* __restrict__ ysrc = reinterpret_cast<const uint4*>(ypool);
+  // this thread's 8 chunks of a tile: global chunk g = i * 256 + tid -> (row g >> 4, chunk g & 15)
+#define SIFT_LOAD_TILE(TILE, REGS)                                      \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                       \
+    const int g = i * kSiftThreads + tid;                               \
+    int row = (TILE) * kTile + (g >> 4);                                \
+    row = row < ny ? row : ny - 1;                                      \
+    REGS[i] = ysrc[(size_t)row * kChunksPerRow + (g & 15)];             \
+  }
+#define SIFT_STORE_TILE(BUF, REGS)                                      \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                       \
+    const int g = i * kSiftThreads + tid;                               \
+    const int row = g >> 4, chunk = g & 15;                             \
+    tileY[BUF][row * kChunksPerRow + (chunk ^ (row & 15))] = REGS[i];   \
+  }
+  {
+    uint4 first[8];
+    SIFT_LOAD_TILE(0, first)
+    SIFT_STORE_TILE(0, first)
+  }
+  __syncthreads();
+
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int buf = tile & 1;
+    uint4 nxt[8];
+    const bool more = tile + 1 < n_tiles;
+    {
+      const int tn = more ? tile + 1 : tile;  // unconditional: keeps the staging registers out of scratch
+      SIFT_LOAD_TILE(tn, nxt)
     }
-    if (chunk < n_full) {
+    const int t0 = tile * kTile;
+    const bool full = t0 + kTile <= ny;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {  // two column tiles at a time keeps the accumulators at 32 registers
+      f32x16 acc[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const uint32_t lo = 127u - (uint32_t)(chunk * 2 + c);
+        const int row = (cp * 2 + c) * 32 + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t key = ((uint32_t)(int)acc[c][r] << 7) | lo;  // dot == 0 -> key < 128: inert
-          top2_insert(rmx[r], rnx[r], key);
+        for (int ks = 0; ks < 8; ++ks) {
+          const int chunk = ks * 2 + (lane >> 5);
+          const bf16x8 B = __builtin_bit_cast(bf16x8, tileY[buf][row * kChunksPerRow + (chunk ^ (row & 15))]);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], B, acc[c], 0, 0, 0);
         }
       }
-    } else {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const uint32_t lo = 127u - (uint32_t)(chunk * 2 + c);
-        const bool ok = (c0 + c * 32 + (lane & 31)) < ny;
+        const int ct = cp * 2 + c;
+        const uint32_t lo = 127u - (uint32_t)(tile * 4 + ct);
+        const bool ok = full || (t0 + ct * 32 + (lane & 31)) < ny;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          // dot == 0 -> key < 128: inert; out-of-range columns of the ragged last tile -> 0
           const uint32_t key = ok ? (((uint32_t)(int)acc[c][r] << 7) | lo) : 0u;
           top2_insert(rmx[r], rnx[r], key);
         }
       }
     }
+    if (more) {
+      SIFT_STORE_TILE(buf ^ 1, nxt)
+    }
+    __syncthreads();
   }
+  if (r0 >= nx) return;  // waves beyond the last row (after the last barrier)
 
   // ---- merge the 32 lanes that share a row.
   // !SWAP: RowMatch_Kernel's 32-thread butterfly (:1726-1736): slot t absorbs slot t+step, the
