@@ -1,0 +1,49 @@
+// match_demo.cpp -- C++ consumer of include/rgbdfe.hpp, written the way the reference's call site
+// (GraphManager::nodeComparisons, graph_manager.cpp:531-583) would use it.
+//   match_demo <nodes.bin>
+// nodes.bin: int32 n_nodes, then per node: int32 n, n*32 bytes descriptors, n*4 floats xyz1.
+// Prints one JSON line per (last node, earlier node) pair.
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "rgbdfe.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: match_demo nodes.bin\n"); return 2; }
+  std::FILE* f = std::fopen(argv[1], "rb");
+  if (!f) { std::perror("open"); return 2; }
+  int32_t n_nodes = 0;
+  if (std::fread(&n_nodes, 4, 1, f) != 1) return 2;
+  rgbdfe_config cfg = rgbdslam::FrontEnd::defaultConfig();
+  cfg.max_nodes = n_nodes + 2;
+  cfg.max_keypoints = 2048;
+  cfg.max_pairs_per_batch = 64;
+  rgbdslam::FrontEnd fe(cfg);
+  std::vector<std::unique_ptr<rgbdslam::Node>> graph;
+  for (int i = 0; i < n_nodes; ++i) {
+    int32_t n = 0;
+    if (std::fread(&n, 4, 1, f) != 1) return 2;
+    std::vector<uint8_t> desc((size_t)n * 32);
+    std::vector<float> xyz((size_t)n * 4);
+    if (n && (std::fread(desc.data(), 32, (size_t)n, f) != (size_t)n || std::fread(xyz.data(), 16, (size_t)n, f) != (size_t)n)) return 2;
+    graph.emplace_back(new rgbdslam::Node(fe, i, desc.data(), xyz.data(), n));
+  }
+  std::fclose(f);
+  rgbdslam::GraphManager gm(fe);
+  const rgbdslam::Node* new_node = graph.back().get();
+  std::vector<const rgbdslam::Node*> nodes_to_comp;
+  for (int i = 0; i + 1 < n_nodes; ++i) nodes_to_comp.push_back(graph[i].get());
+  const std::vector<rgbdslam::MatchingResult> results = gm.nodeComparisons(new_node, nodes_to_comp);
+  for (const rgbdslam::MatchingResult& mr : results) {
+    std::printf("{\"id1\": %d, \"id2\": %d, \"n_all\": %zu, \"n_inl\": %zu, \"rmse\": %.9g, \"info\": %.17g, \"T\": [",
+                mr.edge.id1, mr.edge.id2, mr.all_matches.size(), mr.inlier_matches.size(), mr.rmse, mr.edge.informationScale);
+    for (int i = 0; i < 16; ++i) std::printf("%s%.9g", i ? ", " : "", mr.final_trafo[i]);
+    std::printf("]}\n");
+  }
+  // the serial call site (graph_manager.cpp:466): one pair through Node::matchNodePair
+  const rgbdslam::MatchingResult one = new_node->matchNodePair(graph.front().get());
+  std::printf("{\"single_id1\": %d, \"single_n_inl\": %zu}\n", one.edge.id1, one.inlier_matches.size());
+  return 0;
+}

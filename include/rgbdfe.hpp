@@ -1,0 +1,148 @@
+// rgbdfe.hpp -- header-only C++ host side above the C ABI (include/rgbdfe.h), mirroring the slice of
+// rgbdslam_v2's interface that the pair path exposes: same names, argument meaning and error behaviour
+// as src/node.h, src/matching_result.h, src/edge.h and GraphManager::nodeComparisons' fan-out
+// (src/graph_manager.cpp:541-548), without the OpenCV / Eigen / Qt / ROS types.
+//
+//   reference                                   here
+//   cv::DMatch                                  rgbdslam::DMatch {queryIdx, trainIdx, distance}
+//   Eigen::Matrix4f (column-major)              std::array<float,16> (column-major)
+//   LoadedEdge3D / MatchingResult               rgbdslam::LoadedEdge3D / rgbdslam::MatchingResult
+//   Node::matchNodePair(const Node*)            rgbdslam::Node::matchNodePair(const Node*)
+//   QtConcurrent::blockingMapped(nodes, ...)    rgbdslam::GraphManager::nodeComparisons(new_node, nodes)
+// No exceptions are thrown on the pair path: like Node::matchNodePair (node.cpp:1424-1426) failures end
+// in a MatchingResult whose edge ids are -1.
+#ifndef RGBDFE_HPP
+#define RGBDFE_HPP
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rgbdfe.h"
+
+namespace rgbdslam {
+
+struct DMatch {  // cv::DMatch
+  int queryIdx = -1, trainIdx = -1, imgIdx = -1;
+  float distance = 0.f;
+};
+
+struct LoadedEdge3D {  // src/edge.h:24-32
+  int id1 = -1, id2 = -1;
+  std::array<double, 16> transform{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};  // Isometry3d, column-major
+  double informationScale = 0.0;  // informationMatrix = Identity(6,6) * informationScale (node.cpp:1335)
+};
+
+struct MatchingResult {  // src/matching_result.h:24-46
+  std::vector<DMatch> inlier_matches, all_matches;
+  LoadedEdge3D edge;
+  float rmse = 0.0f;
+  std::array<float, 16> ransac_trafo{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+  std::array<float, 16> final_trafo{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+};
+
+inline MatchingResult toMatchingResult(const rgbdfe_match_result& r) {
+  MatchingResult mr;
+  mr.all_matches.resize((size_t)r.n_all);
+  for (int m = 0; m < r.n_all; ++m) {
+    mr.all_matches[m].queryIdx = r.all_q[m];
+    mr.all_matches[m].trainIdx = r.all_t[m];
+    mr.all_matches[m].distance = r.all_hd[m] / 256.0f;  // node.cpp:573 without the random jitter
+  }
+  for (int m = 0; m < r.n_all; ++m)
+    if ((r.inlier_mask[m >> 6] >> (m & 63)) & 1ull) mr.inlier_matches.push_back(mr.all_matches[m]);
+  mr.rmse = r.rmse;
+  for (int i = 0; i < 16; ++i) mr.ransac_trafo[i] = mr.final_trafo[i] = r.trafo[i];  // node.cpp:1334
+  mr.edge.id1 = r.id1;
+  mr.edge.id2 = r.id2;
+  if (r.id1 >= 0) {
+    for (int i = 0; i < 16; ++i) mr.edge.transform[i] = (double)r.trafo[i];  // node.cpp:1339
+    mr.edge.informationScale = r.info_scale;
+  }
+  return mr;
+}
+
+// Owns the rgbdfe context (one GPU).  Construction throws (like the reference's fatal start-up errors);
+// the per-pair calls never do.
+class FrontEnd {
+ public:
+  explicit FrontEnd(const rgbdfe_config& cfg) {
+    rgbdfe_ctx* c = nullptr;
+    const int st = rgbdfe_create(&cfg, &c);
+    if (st != RGBDFE_OK) throw std::runtime_error(std::string("rgbdfe_create: ") + rgbdfe_status_string(st));
+    ctx_.reset(c, rgbdfe_destroy);
+  }
+  static rgbdfe_config defaultConfig() {
+    rgbdfe_config c;
+    rgbdfe_default_config(&c);
+    return c;
+  }
+  rgbdfe_ctx* get() const { return ctx_.get(); }
+
+ private:
+  std::shared_ptr<rgbdfe_ctx> ctx_;
+};
+
+class Node {  // the slice of src/node.h the pair path touches
+ public:
+  // feature_descriptors: n x 32 bytes (cv::Mat CV_8U, continuous); feature_locations_3d: n x (x,y,z,1)
+  Node(const FrontEnd& fe, int id, const uint8_t* feature_descriptors, const float* feature_locations_3d, int n)
+      : fe_(fe), id_(id), n_(n) {
+    matchable_ = rgbdfe_upload_node(fe_.get(), id_, feature_descriptors, feature_locations_3d, n) == RGBDFE_OK;
+  }
+  ~Node() { clearFeatureInformation(); }
+  Node(const Node&) = delete;
+  Node& operator=(const Node&) = delete;
+
+  // src/node.cpp:1305-1429.  Never throws; no edge <=> mr.edge.id1 == -1 && mr.edge.id2 == -1.
+  MatchingResult matchNodePair(const Node* older_node) const {
+    rgbdfe_match_result pod;
+    if (!matchable_ || !older_node || !older_node->matchable_ ||
+        rgbdfe_match_node_pairs(fe_.get(), id_, &older_node->id_, 1, &pod) != RGBDFE_OK)
+      return MatchingResult();
+    return toMatchingResult(pod);
+  }
+  // src/node.cpp:535-690 (ORB branch): matches sorted by (hd, queryIdx), at most max_matches
+  unsigned int featureMatching(const Node* other, std::vector<DMatch>* matches) const {
+    *matches = matchNodePair(other).all_matches;
+    return (unsigned int)matches->size();
+  }
+  void clearFeatureInformation() {  // src/node.cpp:1431-1443
+    if (matchable_) rgbdfe_release_node(fe_.get(), id_);
+    matchable_ = false;
+  }
+  int id_;
+  bool matchable_ = false;
+
+ private:
+  const FrontEnd& fe_;
+  int n_;
+  friend class GraphManager;
+};
+
+class GraphManager {  // only the fan-out of GraphManager::nodeComparisons (graph_manager.cpp:531-583)
+ public:
+  explicit GraphManager(const FrontEnd& fe) : fe_(fe) {}
+  // 1:1 replacement of QtConcurrent::blockingMapped(nodes_to_comp, bind(&Node::matchNodePair, new_node, _1))
+  std::vector<MatchingResult> nodeComparisons(const Node* new_node, const std::vector<const Node*>& nodes_to_comp) const {
+    std::vector<int32_t> ids;
+    ids.reserve(nodes_to_comp.size());
+    for (const Node* n : nodes_to_comp) ids.push_back(n->id_);
+    std::vector<rgbdfe_match_result> pods(ids.size());
+    std::vector<MatchingResult> out(ids.size());
+    if (ids.empty() ||
+        rgbdfe_match_node_pairs(fe_.get(), new_node->id_, ids.data(), (int32_t)ids.size(), pods.data()) != RGBDFE_OK)
+      return out;
+    for (size_t i = 0; i < pods.size(); ++i) out[i] = toMatchingResult(pods[i]);
+    return out;
+  }
+
+ private:
+  const FrontEnd& fe_;
+};
+
+}  // namespace rgbdslam
+#endif
