@@ -46,9 +46,15 @@ struct FitBuf {
   float Wk[RGBDFE_MAX_MATCHES];   // running weight sums W_k  -> alpha_k = w_k / W_k in place
   uint16_t ord[RGBDFE_MAX_MATCHES];  // k-th participating match
 };
+// scoring phase: candidates (matches that survive the cheap shortcut test) and inliers, compacted
+struct ScoreBuf {
+  double ec[RGBDFE_MAX_MATCHES];     // squared Mahalanobis error of the k-th inlier (match order)
+  uint16_t cand[RGBDFE_MAX_MATCHES]; // k-th candidate match
+  uint32_t mbits[2 * kRounds];       // inlier set as bits over matches
+};
 union Scratch {  // the three phases never overlap
   SelBuf sel;
-  double e[RGBDFE_MAX_MATCHES];  // per-match squared Mahalanobis error (0 for non-inliers)
+  ScoreBuf sc;
   FitBuf fit;
 };
 // a (transform, inlier set, error) triple kept in LDS (wave-uniform state)
@@ -305,9 +311,17 @@ __device__ __forceinline__ bool has_nan12(const float* R, const float* t) {
 
 // ---------------------------------------------------------------------------------
 // computeInliersAndError (node.cpp:968-1020) with errorFunction2 (misc.cpp:697-770).
-// LANE = MATCH.  R,t are wave-uniform.  Returns inlier masks, count and rms error.
+// R,t are wave-uniform.  Returns inlier masks, count and rms error.
+//   pass 1 (lane = match, 5 rounds): the hypothesis-dependent part that is cheap -- transform the point,
+//           squared distance, the reference's shortcut test (misc.cpp:726-735) -- and a ballot compaction
+//           of the surviving candidates;
+//   pass 2 (lane = candidate): the double-precision covariance + 3x3 Cholesky solve, only for the
+//           ceil(n_cand / 64) dense rounds that are needed; inliers are compacted again, in match order;
+//   sum   : the reference's strictly sequential error sum over the compacted inliers.
+// When fewer candidates than `need` survive pass 1 the caller will reject the hypothesis whatever
+// the exact numbers are (node.cpp:1154, :1206): the solve is skipped and (0, 1e9) is returned.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, int n_all,
+__device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, int n_all, uint32_t need,
                                                  const RansacConst& rc, RansacLds& lds,
                                                  uint64_t* mask, int& n_inl, double& err) {
   const int lane = threadIdx.x;
@@ -319,89 +333,114 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   const double rcx = rc.raster_cov_x, rcy = rc.raster_cov_y, dc = rc.depth_cov;
   const double smax = rcx > dc ? rcx : dc;
   const double shortcut = 2.0 * (smax + smax);
-  n_inl = 0;
+  ScoreBuf& sb = lds.u.sc;
+  // ---- pass 1
+  int n_cand = 0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
-    const bool active = m < n_all;
     // stride-3 word addresses: conflict-free across the 32 LDS banks
     const float pxf = lds.P[m * 3 + 0], pyf = lds.P[m * 3 + 1], pzf = lds.P[m * 3 + 2];
     const float qxf = lds.Q[m * 3 + 0], qyf = lds.Q[m * 3 + 1], qzf = lds.Q[m * 3 + 2];
     // node.cpp:994 (z == 0 skip) ; misc.cpp:712-717 (NaN -> DBL_MAX)
-    bool cand = active && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
+    bool cand = (m < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
     const double a0 = (double)pxf, a1 = (double)pyf, a2 = (double)pzf;
-    const double b0 = (double)qxf, b1 = (double)qyf, b2 = (double)qzf;
-    // mu_1_in_frame_2 = (T * x1).head<3>() with x1.w == 1 (misc.cpp:724)
+    const double d0 = (((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0]) - (double)qxf;
+    const double d1 = (((Rd[3] * a0 + Rd[4] * a1) + Rd[5] * a2) + td[1]) - (double)qyf;
+    const double d2 = (((Rd[6] * a0 + Rd[7] * a1) + Rd[8] * a2) + td[2]) - (double)qzf;
+    const double dsq = (d0 * d0 + d1 * d1) + d2 * d2;
+    cand = cand && !(dsq > shortcut) && !__builtin_isnan(d2);  // misc.cpp:731, 755
+    const uint64_t cm = __ballot(cand);
+    if (cand) sb.cand[n_cand + (int)lane_rank(cm)] = (uint16_t)m;
+    n_cand += __popcll(cm);
+  }
+  if (lane < 2 * kRounds) sb.mbits[lane] = 0u;
+  __syncthreads();
+  n_inl = 0;
+  err = 1e9;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) mask[r] = 0ull;
+  if ((uint32_t)n_cand < need) return;  // hopeless: nobody looks at the exact numbers
+  // ---- pass 2
+  for (int k0 = 0; k0 < n_cand; k0 += kWave) {
+    const int k = k0 + lane;
+    const bool act = k < n_cand;
+    const int m = act ? (int)sb.cand[k] : 0;
+    const double a0 = (double)lds.P[m * 3 + 0], a1 = (double)lds.P[m * 3 + 1], a2 = (double)lds.P[m * 3 + 2];
+    const double b0 = (double)lds.Q[m * 3 + 0], b1 = (double)lds.Q[m * 3 + 1], b2 = (double)lds.Q[m * 3 + 2];
     double d[3];
-    {
-      double m0 = ((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0];
-      double m1 = ((Rd[3] * a0 + Rd[4] * a1) + Rd[5] * a2) + td[1];
-      double m2 = ((Rd[6] * a0 + Rd[7] * a1) + Rd[8] * a2) + td[2];
-      d[0] = m0 - b0; d[1] = m1 - b1; d[2] = m2 - b2;
-    }
-    const double dsq = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
-    cand = cand && !(dsq > shortcut) && !__builtin_isnan(d[2]);  // misc.cpp:731, 755
+    // mu_1_in_frame_2 = (T * x1).head<3>() with x1.w == 1 (misc.cpp:724)
+    d[0] = (((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0]) - b0;
+    d[1] = (((Rd[3] * a0 + Rd[4] * a1) + Rd[5] * a2) + td[1]) - b1;
+    d[2] = (((Rd[6] * a0 + Rd[7] * a1) + Rd[8] * a2) + td[2]) - b2;
     double e = DBL_MAX;
-    if (__ballot(cand) != 0ull) {  // wave-uniform: skip the solve when nobody survives
-      if (cand) {
-        const double c1[3] = {rcx * a2, rcy * a2, dc};
-        const double c2[3] = {rcx * b2, rcy * b2, dc};
-        // S = R^T * cov1 * R + cov2 (misc.cpp:751,760), lower triangle only.
-        // S(i,j) = (R(0,i)c1_0*R(0,j) + R(1,i)c1_1*R(1,j)) + R(2,i)c1_2*R(2,j)
-        double A[9];  // A[i*3+k] = R(k,i) * c1_k
+    {
+      const double c1[3] = {rcx * a2, rcy * a2, dc};
+      const double c2[3] = {rcx * b2, rcy * b2, dc};
+      // S = R^T * cov1 * R + cov2 (misc.cpp:751,760), lower triangle only.
+      // S(i,j) = (R(0,i)c1_0*R(0,j) + R(1,i)c1_1*R(1,j)) + R(2,i)c1_2*R(2,j)
+      double A[9];  // A[i*3+k] = R(k,i) * c1_k
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) A[i * 3 + k] = Rd[k * 3 + i] * c1[k];
-        double S00 = ((A[0] * Rd[0] + A[1] * Rd[3]) + A[2] * Rd[6]) + c2[0];
-        double S10 = (A[3] * Rd[0] + A[4] * Rd[3]) + A[5] * Rd[6];
-        double S11 = ((A[3] * Rd[1] + A[4] * Rd[4]) + A[5] * Rd[7]) + c2[1];
-        double S20 = (A[6] * Rd[0] + A[7] * Rd[3]) + A[8] * Rd[6];
-        double S21 = (A[6] * Rd[1] + A[7] * Rd[4]) + A[8] * Rd[7];
-        double S22 = ((A[6] * Rd[2] + A[7] * Rd[5]) + A[8] * Rd[8]) + c2[2];
-        // LLT (misc.cpp:763), D5: non-positive pivot -> DBL_MAX
-        bool ok = S00 > 0.0;
-        double l00 = sqrt(S00);
-        double l10 = S10 / l00;
-        double l20 = S20 / l00;
-        double x1 = S11 - l10 * l10;
-        ok = ok && (x1 > 0.0);
-        double l11 = sqrt(x1);
-        double l21 = (S21 - l20 * l10) / l11;
-        double x2 = S22 - (l20 * l20 + l21 * l21);
-        ok = ok && (x2 > 0.0);
-        double l22 = sqrt(x2);
-        double y0 = d[0] / l00;
-        double y1 = (d[1] - l10 * y0) / l11;
-        double y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
-        double z2 = y2 / l22;
-        double z1 = (y1 - l21 * z2) / l11;
-        double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
-        double ee = (d[0] * z0 + d[1] * z1) + d[2] * z2;
-        if (ok && (ee >= 0.0)) e = ee;  // misc.cpp:765-768
-      }
+        for (int kk = 0; kk < 3; ++kk) A[i * 3 + kk] = Rd[kk * 3 + i] * c1[kk];
+      const double S00 = ((A[0] * Rd[0] + A[1] * Rd[3]) + A[2] * Rd[6]) + c2[0];
+      const double S10 = (A[3] * Rd[0] + A[4] * Rd[3]) + A[5] * Rd[6];
+      const double S11 = ((A[3] * Rd[1] + A[4] * Rd[4]) + A[5] * Rd[7]) + c2[1];
+      const double S20 = (A[6] * Rd[0] + A[7] * Rd[3]) + A[8] * Rd[6];
+      const double S21 = (A[6] * Rd[1] + A[7] * Rd[4]) + A[8] * Rd[7];
+      const double S22 = ((A[6] * Rd[2] + A[7] * Rd[5]) + A[8] * Rd[8]) + c2[2];
+      // LLT (misc.cpp:763), D5: non-positive pivot -> DBL_MAX
+      bool ok = S00 > 0.0;
+      const double l00 = sqrt(S00);
+      const double l10 = S10 / l00;
+      const double l20 = S20 / l00;
+      const double x1 = S11 - l10 * l10;
+      ok = ok && (x1 > 0.0);
+      const double l11 = sqrt(x1);
+      const double l21 = (S21 - l20 * l10) / l11;
+      const double x2 = S22 - (l20 * l20 + l21 * l21);
+      ok = ok && (x2 > 0.0);
+      const double l22 = sqrt(x2);
+      const double y0 = d[0] / l00;
+      const double y1 = (d[1] - l10 * y0) / l11;
+      const double y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
+      const double z2 = y2 / l22;
+      const double z1 = (y1 - l21 * z2) / l11;
+      const double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
+      const double ee = (d[0] * z0 + d[1] * z1) + d[2] * z2;
+      if (ok && (ee >= 0.0)) e = ee;  // misc.cpp:765-768
     }
-    const bool inl = cand && !(e > rc.sq_max_dist) && (e >= 0.0);  // node.cpp:998,1001
-    mask[r] = __ballot(inl);
-    n_inl += __popcll(mask[r]);
-    lds.u.e[m] = inl ? e : 0.0;  // +0.0 terms leave the sequential sum bit-identical
+    const bool inl = act && !(e > rc.sq_max_dist) && (e >= 0.0);  // node.cpp:998,1001
+    const uint64_t im = __ballot(inl);
+    if (inl) {
+      sb.ec[n_inl + (int)lane_rank(im)] = e;  // candidates ascend in match index: so do the inliers
+      atomicOr(&sb.mbits[m >> 5], 1u << (m & 31));
+    }
+    n_inl += __popcll(im);
   }
   __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(sb.mbits[2 * r]);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(sb.mbits[2 * r + 1]);
+    mask[r] = ((uint64_t)hi << 32) | lo;
+  }
+  if ((uint32_t)n_inl < need || n_inl < 3) {  // err stays 1e9 (node.cpp:1012-1014); rejected anyway when < need
+    __syncthreads();
+    return;
+  }
   // mean_error += mahal_dist in match order (node.cpp:1006): strictly sequential double sum
   double sum = 0.0;
-  const int n4 = n_all & ~3;
-  int m = 0;
-  for (; m < n4; m += 4) {
-    double e0 = lds.u.e[m], e1 = lds.u.e[m + 1], e2 = lds.u.e[m + 2], e3 = lds.u.e[m + 3];
+  const int n4 = n_inl & ~3;
+  int k = 0;
+  for (; k < n4; k += 4) {
+    const double e0 = sb.ec[k], e1 = sb.ec[k + 1], e2 = sb.ec[k + 2], e3 = sb.ec[k + 3];
     sum += e0; sum += e1; sum += e2; sum += e3;
   }
-  for (; m < n_all; ++m) sum += lds.u.e[m];
+  for (; k < n_inl; ++k) sum += sb.ec[k];
   __syncthreads();
-  if (n_inl < 3) {
-    err = 1e9;  // node.cpp:1012-1014
-  } else {
-    err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
-  }
+  err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
 }
 
 // ---------------------------------------------------------------------------------
@@ -767,7 +806,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         if (refinements == 1) {
           if (cur_nan) break;  // :1144
           PH_MARK(5)
-          score_hypothesis(curR, curt, n_all, rc, lds, inl_mask, n_inl, inlier_error);  // :1148
+          score_hypothesis(curR, curt, n_all, thr, rc, lds, inl_mask, n_inl, inlier_error);  // :1148
           PH_MARK(3)
           PH_COUNT(6)
         } else {
@@ -805,7 +844,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
             PH_COUNT(7)
             n_inl = 0;
             inlier_error = 0.0;
-            if (!cur_nan) score_hypothesis(curR, curt, n_all, rc, lds, inl_mask, n_inl, inlier_error);
+            if (!cur_nan) score_hypothesis(curR, curt, n_all, thr, rc, lds, inl_mask, n_inl, inlier_error);
             PH_MARK(3)
             PH_COUNT(6)
             MemoEntry& me = lds.memo[memo_next];
@@ -849,7 +888,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       uint64_t inl_mask[kRounds];
       int n_inl;
       double inlier_error;
-      score_hypothesis(IR, It, n_all, rc, lds, inl_mask, n_inl, inlier_error);
+      score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, inl_mask, n_inl, inlier_error);  // needs > thr (:1206)
       if ((uint32_t)n_inl > thr && inlier_error < max_dist_d) {  // :1206
         hyp_store(lds.best, IR, It, inl_mask, n_inl, 0, inlier_error);
         best_n = n_inl;
