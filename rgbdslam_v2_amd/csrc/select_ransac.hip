@@ -32,7 +32,7 @@ namespace rgbdfe {
 constexpr int kWave = 64;
 constexpr int kRounds = RGBDFE_MAX_MATCHES / kWave;  // 5
 
-constexpr int kMemo = 8;
+constexpr int kSlots = 8;  // RANSAC iterations refined side by side (one batched SVD per round)
 
 // selection phase
 struct SelBuf {
@@ -65,18 +65,25 @@ struct Hyp {
   int nan;
   double err;
 };
-// memo of the pure function  inlier set -> (refit transform, its inlier set, its error)
-struct MemoEntry {
-  uint64_t key[kRounds];
-  Hyp val;
+// One RANSAC iteration in flight.  The iterations of a window are independent (the sample of
+// iteration k is a pure function of k, D1), so their refinement loops run side by side: scoring is
+// per slot (lane = match), the refits' 3x3 SVDs are batched (lane = slot).
+struct Slot {
+  float R[9], t[3];          // transform to score next
+  uint64_t mask[kRounds];    // inlier set of the last scoring = input of the next refit
+  float rR[9], rt[3];        // refined_transformation (node.cpp:1137,1163)
+  uint64_t rmask[kRounds];   // refined_matches
+  double rerr;               // refined_error
+  int rn;                    // refined_matches.size()
+  int active;
 };
 struct __attribute__((aligned(16))) RansacLds {
   Scratch u;
   float P[RGBDFE_MAX_MATCHES * 3];  // newer node's points ("from"), match order
   float Q[RGBDFE_MAX_MATCHES * 3];  // older node's points ("to")
   float w[RGBDFE_MAX_MATCHES];      // 1/(from.z*to.z), transformation_estimation_euclidean.cpp:25
-  MemoEntry memo[kMemo];
-  Hyp refined, best;
+  Slot slot[kSlots];
+  Hyp best;
 };
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -455,7 +462,7 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
 // Every float operation is the one the sequential code performs, in the same order on
 // the same operands: bit-identical to Tfc::add over the same matches.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void fit_inliers(const uint64_t* mask, RansacLds& lds, float* R, float* tr) {
+__device__ __forceinline__ void fit_accumulate(const uint64_t* mask, RansacLds& lds, Tfc& s) {
   const int lane = threadIdx.x;
   uint32_t base = 0;
 #pragma unroll
@@ -521,7 +528,6 @@ __device__ __forceinline__ void fit_inliers(const uint64_t* mask, RansacLds& lds
     m2 = m2 + alpha * d2;
   }
   __syncthreads();
-  Tfc s;
   s.W = 0.0f;
 #pragma unroll
   for (int x = 0; x < 9; ++x) s.C[x] = bcast_f(C, x);
@@ -529,7 +535,6 @@ __device__ __forceinline__ void fit_inliers(const uint64_t* mask, RansacLds& lds
   for (int j = 0; j < 3; ++j) s.m1[j] = bcast_f(m1, j);       // lane j: (i=0, j)
 #pragma unroll
   for (int i = 0; i < 3; ++i) s.m2[i] = bcast_f(m2, 3 * i);   // lane 3i: (i, j=0)
-  tfc_get_transformation(s, R, tr);
 }
 
 __device__ __forceinline__ void hyp_store(Hyp& h, const float* R, const float* t, const uint64_t* mask,
@@ -739,15 +744,18 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 
     float hypR[9], hypt[3];
     bool hyp_nan = true;
-    int hyp_base = -kWave;  // iteration index of lane 0's hypothesis
-    int memo_n = 0, memo_next = 0;
+    int hyp_base = -kWave;  // iteration index of lane 0's hypothesis (none yet)
+    bool done = false;
 
-    for (int it = 0; it < rc.ransac_iterations && n_all >= 4; ++it) {  // :1130
-      const int k = real_iterations;
-      if (k - hyp_base >= kWave) {
-        // ---- LANE = HYPOTHESIS: sample + 4-point fit for iterations k .. k+63
-        hyp_base = k;
-        const uint32_t iter = (uint32_t)(k + lane);
+    for (int it = 0; !done && it < rc.ransac_iterations && n_all >= 4;) {  // :1130
+      const int k0 = real_iterations;
+      // The first iteration runs alone: an easy pair leaves the loop right after it (:1188) and must
+      // not pay for a speculative window.
+      const int G = (k0 == 0) ? 1 : kSlots;
+      if (hyp_base < 0 || k0 + G > hyp_base + kWave) {
+        // ---- LANE = HYPOTHESIS: sample + 4-point fit for iterations k0 .. k0+63
+        hyp_base = k0;
+        const uint32_t iter = (uint32_t)(k0 + lane);
         uint32_t ids[4] = {0, 0, 0, 0};
         int cnt = 0;
         {
@@ -765,11 +773,11 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
             if (!dup) {
               uint32_t v = id1;  // sorted insert
 #pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                if (s < cnt) {
-                  if (ids[s] > v) { uint32_t tmp = ids[s]; ids[s] = v; v = tmp; }
-                } else if (s == cnt) {
-                  ids[s] = v;
+              for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 < cnt) {
+                  if (ids[s4] > v) { uint32_t tmp = ids[s4]; ids[s4] = v; v = tmp; }
+                } else if (s4 == cnt) {
+                  ids[s4] = v;
                 }
               }
               ++cnt;
@@ -780,108 +788,147 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         Tfc acc;
         acc.reset();
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          if (s < cnt) acc.add(lds.P, lds.Q, (int)ids[s]);
+        for (int s4 = 0; s4 < 4; ++s4)
+          if (s4 < cnt) acc.add(lds.P, lds.Q, (int)ids[s4]);
         tfc_get_transformation(acc, hypR, hypt);
         hyp_nan = has_nan12(hypR, hypt);
         PH_MARK(2)
       }
-      const int hl = k - hyp_base;
-      real_iterations++;  // :1139
-
-      double refined_error = 1e6;  // :1133
-      int refined_n = 0;
-      uint64_t inl_mask[kRounds] = {0, 0, 0, 0, 0};
-
-      float curR[9], curt[3];
+      // ---- open the window: slot g <- iteration k0 + g, first transform = its 4-point hypothesis
 #pragma unroll
-      for (int i = 0; i < 9; ++i) curR[i] = bcast_f(hypR[i], hl);
+      for (int g = 0; g < kSlots; ++g) {
+        if (g < G) {
+          const int hl = k0 + g - hyp_base;
+          float R0[9], t0[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) curt[i] = bcast_f(hypt[i], hl);
-      bool cur_nan = (__builtin_amdgcn_readlane((int)hyp_nan, hl) != 0);
-
-      for (int refinements = 1; refinements < 20; ++refinements) {  // :1140
-        int n_inl;
-        double inlier_error;
-        if (refinements == 1) {
-          if (cur_nan) break;  // :1144
+          for (int i = 0; i < 9; ++i) R0[i] = bcast_f(hypR[i], hl);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) t0[i] = bcast_f(hypt[i], hl);
+          const bool nan0 = (__builtin_amdgcn_readlane((int)hyp_nan, hl) != 0);
+          if (lane == 0) {
+            Slot& sl = lds.slot[g];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { sl.R[i] = R0[i]; sl.rR[i] = IR[i]; }  // :1137 refined = Identity
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { sl.t[i] = t0[i]; sl.rt[i] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) { sl.mask[r] = 0ull; sl.rmask[r] = 0ull; }
+            sl.rerr = 1e6;          // :1133
+            sl.rn = 0;              // :1134
+            sl.active = nan0 ? 0 : 1;  // a NaN transform leaves the refinement loop (:1144)
+          }
+        }
+      }
+      __syncthreads();
+      // ---- refinement rounds (`for refinements = 1 .. 19`, :1140)
+      for (int round = 0; round < 19; ++round) {
+        bool any_active = false;
+        for (int g = 0; g < G; ++g) {
+          Slot& sl = lds.slot[g];
+          if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
+          float curR[9], curt[3];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) curR[i] = sl.R[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) curt[i] = sl.t[i];
+          uint64_t inl_mask[kRounds];
+          int n_inl;
+          double inlier_error;
           PH_MARK(5)
           score_hypothesis(curR, curt, n_all, thr, rc, lds, inl_mask, n_inl, inlier_error);  // :1148
           PH_MARK(3)
           PH_COUNT(6)
-        } else {
-          // getTransformFromMatches over the current inlier set (:1142) + scoring (:1148):
-          // a pure function of the set -> memoised per pair.
-          int hit = -1;
-          {
-            bool eq = lane < memo_n;
-            if (eq) {
+          const int rn = __builtin_amdgcn_readfirstlane(sl.rn);
+          const double rerr = sl.rerr;
+          bool still = false;
+          if (!((uint32_t)n_inl < thr || inlier_error > max_dist_d)) {   // :1154
+            if (n_inl >= rn && inlier_error <= rerr) {                   // :1160
+              still = (n_inl != rn);                                     // :1166
+              if (lane == 0) {
 #pragma unroll
-              for (int r = 0; r < kRounds; ++r) eq = eq && (lds.memo[lane].key[r] == inl_mask[r]);
+                for (int i = 0; i < 9; ++i) sl.rR[i] = curR[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sl.rt[i] = curt[i];
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) { sl.rmask[r] = inl_mask[r]; sl.mask[r] = inl_mask[r]; }
+                sl.rn = n_inl;
+                sl.rerr = inlier_error;
+              }
             }
-            const uint64_t hm = __ballot(eq);
-            if (hm) hit = __builtin_ctzll(hm);
           }
-          if (hit >= 0) {
-            const Hyp& h = lds.memo[hit].val;
-            if (h.nan) break;  // :1144
+          if (round == 18) still = false;  // the 19th pass was the last one
+          if (lane == 0) sl.active = still ? 1 : 0;
+          any_active |= still;
+          __syncthreads();
+        }
+        if (!any_active) break;
+        // ---- refits (:1142): per active slot the weighted-mean recurrence over its inlier set, then
+        // ONE batched 3x3 SVD with lane = slot
+        Tfc mine;
+        mine.reset();
+        for (int g = 0; g < G; ++g) {
+          Slot& sl = lds.slot[g];
+          if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
+          uint64_t m5[kRounds];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) curR[i] = h.R[i];
+          for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.mask[r]);
+          Tfc su;
+          PH_MARK(5)
+          fit_accumulate(m5, lds, su);
+          PH_MARK(4)
+          PH_COUNT(7)
+          if (lane == g) mine = su;
+        }
+        {
+          float fR[9], ft[3];
+          tfc_get_transformation(mine, fR, ft);
+          const bool fnan = has_nan12(fR, ft);
+          if (lane < G) {
+            Slot& sl = lds.slot[lane];
+            if (sl.active) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) curt[i] = h.t[i];
+              for (int i = 0; i < 9; ++i) sl.R[i] = fR[i];
 #pragma unroll
-            for (int r = 0; r < kRounds; ++r) inl_mask[r] = uniform_u64(h.mask[r]);
-            n_inl = __builtin_amdgcn_readfirstlane(h.n);
-            inlier_error = h.err;
-          } else {
-            uint64_t key[kRounds];
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) key[r] = inl_mask[r];
-            PH_MARK(5)
-            fit_inliers(inl_mask, lds, curR, curt);
-            cur_nan = has_nan12(curR, curt);
-            PH_MARK(4)
-            PH_COUNT(7)
-            n_inl = 0;
-            inlier_error = 0.0;
-            if (!cur_nan) score_hypothesis(curR, curt, n_all, thr, rc, lds, inl_mask, n_inl, inlier_error);
-            PH_MARK(3)
-            PH_COUNT(6)
-            MemoEntry& me = lds.memo[memo_next];
-            if (lane == 0) {
-#pragma unroll
-              for (int r = 0; r < kRounds; ++r) me.key[r] = key[r];
+              for (int i = 0; i < 3; ++i) sl.t[i] = ft[i];
+              if (fnan) sl.active = 0;  // :1144
             }
-            hyp_store(me.val, curR, curt, inl_mask, n_inl, cur_nan ? 1 : 0, inlier_error);
-            memo_next = (memo_next + 1) % kMemo;
-            if (memo_n < kMemo) memo_n++;
-            __syncthreads();
-            if (cur_nan) break;  // :1144
           }
+          PH_MARK(4)
         }
-        if ((uint32_t)n_inl < thr || inlier_error > max_dist_d) break;  // :1154
-        if (n_inl >= refined_n && inlier_error <= refined_error) {       // :1160
-          const int prev = refined_n;
-          hyp_store(lds.refined, curR, curt, inl_mask, n_inl, 0, inlier_error);
-          refined_n = n_inl;
-          refined_error = inlier_error;
-          if (n_inl == prev) break;  // :1166
-        } else {
-          break;
-        }
+        __syncthreads();
       }
-      if (refined_n > 0) {  // :1171
-        valid_iterations++;
-        if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
-          rmse = (float)refined_error;  // :1182
-          __syncthreads();
-          if (lane == 0) lds.best = lds.refined;
-          __syncthreads();
-          best_n = refined_n;
-          if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
-          if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
-          if ((double)refined_n > (double)n_all * 0.8) break;      // :1188
+      // ---- replay the window in iteration order (:1171-1190)
+      for (int g = 0; g < G; ++g) {
+        if (!(it < rc.ransac_iterations)) { done = true; break; }
+        real_iterations++;  // :1139
+        const Slot& sl = lds.slot[g];
+        const int refined_n = __builtin_amdgcn_readfirstlane(sl.rn);
+        const double refined_error = sl.rerr;
+        if (refined_n > 0) {  // :1171
+          valid_iterations++;
+          if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
+            rmse = (float)refined_error;  // :1182
+            __syncthreads();
+            if (lane == 0) {
+              Hyp& b = lds.best;
+#pragma unroll
+              for (int i = 0; i < 9; ++i) b.R[i] = sl.rR[i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) b.t[i] = sl.rt[i];
+#pragma unroll
+              for (int r = 0; r < kRounds; ++r) b.mask[r] = sl.rmask[r];
+              b.n = refined_n;
+              b.nan = 0;
+              b.err = refined_error;
+            }
+            __syncthreads();
+            best_n = refined_n;
+            if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
+            if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
+            if ((double)refined_n > (double)n_all * 0.8) { done = true; break; }  // :1188
+          }
         }
+        ++it;
       }
     }
     if (valid_iterations == 0) {  // :1192 identity hypothesis
