@@ -42,9 +42,9 @@ struct SelBuf {
 };
 // refit phase: the inlier set compacted in match order
 struct FitBuf {
-  float wc[RGBDFE_MAX_MATCHES];   // weights w_k              -> (1 - alpha_k) in place
-  float Wk[RGBDFE_MAX_MATCHES];   // running weight sums W_k  -> alpha_k = w_k / W_k in place
-  uint16_t ord[RGBDFE_MAX_MATCHES];  // k-th participating match
+  // per participating match k (match order): {w_k -> alpha_k, W_k -> 1 - alpha_k} and the match index
+  float2 ao[RGBDFE_MAX_MATCHES];
+  uint16_t ord[RGBDFE_MAX_MATCHES];
 };
 // scoring phase: candidates (matches that survive the cheap shortcut test) and inliers, compacted
 struct ScoreBuf {
@@ -450,6 +450,22 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
 }
 
+// Optional phase timers (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase are
+// written over the head of all_q of each result.  Never enabled in the product build.
+#ifdef RGBDFE_PROFILE_PHASES
+#define PH_DECL uint64_t ph_t0 = __builtin_readcyclecounter(); uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) { uint64_t ph_t1 = __builtin_readcyclecounter(); ph[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
+#define PH_COUNT(i) { ph[i] += 1; }
+#define PH_ARG , uint64_t* ph, uint64_t& ph_t0
+#define PH_PASS , ph, ph_t0
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_COUNT(i)
+#define PH_ARG
+#define PH_PASS
+#endif
+
 // ---------------------------------------------------------------------------------
 // getTransformFromMatches over an inlier set given as ballot masks (match order).
 // The PCL recurrence is strictly sequential in its state, but not in its coefficients:
@@ -462,7 +478,7 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
 // Every float operation is the one the sequential code performs, in the same order on
 // the same operands: bit-identical to Tfc::add over the same matches.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void fit_accumulate(const uint64_t* mask, RansacLds& lds, Tfc& s) {
+__device__ __forceinline__ void fit_accumulate(const uint64_t* mask, RansacLds& lds, Tfc& s PH_ARG) {
   const int lane = threadIdx.x;
   uint32_t base = 0;
 #pragma unroll
@@ -474,48 +490,53 @@ __device__ __forceinline__ void fit_accumulate(const uint64_t* mask, RansacLds& 
     const uint64_t pm = __ballot(part);
     const uint32_t k = base + lane_rank(pm);
     if (part) {
-      lds.u.fit.wc[k] = w;
+      lds.u.fit.ao[k] = make_float2(w, 0.0f);
       lds.u.fit.ord[k] = (uint16_t)m;
     }
     base += (uint32_t)__popcll(pm);
   }
   const int n = (int)base;
   __syncthreads();
+  PH_MARK(8)
   {
+    // W_k = W_{k-1} + w_k: strictly sequential, 8 steps per trip (loads first, one store burst last)
     float W = 0.0f;
     int k = 0;
-    const int n4 = n & ~3;
-    for (; k < n4; k += 4) {
-      const float w0 = lds.u.fit.wc[k], w1 = lds.u.fit.wc[k + 1], w2 = lds.u.fit.wc[k + 2],
-                  w3 = lds.u.fit.wc[k + 3];
-      W += w0; const float W0 = W;
-      W += w1; const float W1 = W;
-      W += w2; const float W2 = W;
-      W += w3;
+    for (; k + 8 <= n; k += 8) {
+      float wv[8], Wv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[i] = lds.u.fit.ao[k + i].x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { W += wv[i]; Wv[i] = W; }
       if (lane == 0) {
-        lds.u.fit.Wk[k] = W0; lds.u.fit.Wk[k + 1] = W1; lds.u.fit.Wk[k + 2] = W2; lds.u.fit.Wk[k + 3] = W;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds.u.fit.ao[k + i].y = Wv[i];
       }
     }
     for (; k < n; ++k) {
-      W += lds.u.fit.wc[k];
-      if (lane == 0) lds.u.fit.Wk[k] = W;
+      W += lds.u.fit.ao[k].x;
+      if (lane == 0) lds.u.fit.ao[k].y = W;
     }
   }
   __syncthreads();
+  PH_MARK(9)
   for (int k = lane; k < n; k += kWave) {
-    const float alpha = lds.u.fit.wc[k] / lds.u.fit.Wk[k];
-    lds.u.fit.Wk[k] = alpha;
-    lds.u.fit.wc[k] = 1.0f - alpha;
+    const float2 wW = lds.u.fit.ao[k];
+    const float alpha = wW.x / wW.y;
+    lds.u.fit.ao[k] = make_float2(alpha, 1.0f - alpha);
   }
   __syncthreads();
+  PH_MARK(10)
   const int l9 = lane % 9;
   const int ci = l9 / 3, cj = l9 % 3;
   float C = 0.0f, m1 = 0.0f, m2 = 0.0f;
-#pragma unroll 4
+  // (alpha, 1 - alpha) are one 8-byte LDS record per step; 8 steps of loads are in flight.
+#pragma unroll 8
   for (int k = 0; k < n; ++k) {
+    const float2 co = lds.u.fit.ao[k];
     const int m = lds.u.fit.ord[k];
-    const float alpha = lds.u.fit.Wk[k];
-    const float oma = lds.u.fit.wc[k];
+    const float alpha = co.x;
+    const float oma = co.y;
     const float f = lds.P[m * 3 + cj];
     const float t = lds.Q[m * 3 + ci];
     const float d1 = f - m1;
@@ -528,6 +549,7 @@ __device__ __forceinline__ void fit_accumulate(const uint64_t* mask, RansacLds& 
     m2 = m2 + alpha * d2;
   }
   __syncthreads();
+  PH_MARK(11)
   s.W = 0.0f;
 #pragma unroll
   for (int x = 0; x < 9; ++x) s.C[x] = bcast_f(C, x);
@@ -551,18 +573,6 @@ __device__ __forceinline__ void hyp_store(Hyp& h, const float* R, const float* t
     h.err = err;
   }
 }
-
-// Optional phase timers (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase are
-// written over the head of all_q of each result.  Never enabled in the product build.
-#ifdef RGBDFE_PROFILE_PHASES
-#define PH_DECL uint64_t ph_t0 = __builtin_readcyclecounter(); uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define PH_MARK(i) { uint64_t ph_t1 = __builtin_readcyclecounter(); ph[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
-#define PH_COUNT(i) { ph[i] += 1; }
-#else
-#define PH_DECL
-#define PH_MARK(i)
-#define PH_COUNT(i)
-#endif
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -874,7 +884,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
           for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.mask[r]);
           Tfc su;
           PH_MARK(5)
-          fit_accumulate(m5, lds, su);
+          fit_accumulate(m5, lds, su PH_PASS);
           PH_MARK(4)
           PH_COUNT(7)
           if (lane == g) mine = su;
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
               if (fnan) sl.active = 0;  // :1144
             }
           }
-          PH_MARK(4)
+          PH_MARK(12)
         }
         __syncthreads();
       }
@@ -979,7 +989,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 #ifdef RGBDFE_PROFILE_PHASES
     PH_MARK(5)
     uint64_t* dbg = reinterpret_cast<uint64_t*>(out->all_q);
-    for (int i = 0; i < 8; ++i) dbg[i] = ph[i];
+    for (int i = 0; i < 16; ++i) dbg[i] = ph[i];
 #endif
   }
 }

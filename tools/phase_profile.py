@@ -13,9 +13,9 @@ fe = FrontEnd(max_nodes=F, max_keypoints=1024, max_pairs_per_batch=4096)
 for f in range(F):
     fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 out = fe.match_pair_list(pq, pt)
-dbg = out["all_q"][:, :32].copy().view(np.uint64)
+dbg = out["all_q"][:, :64].copy().view(np.uint64)
 names = ["select", "load_pts", "hyp_gen", "score", "refit", "other", "n_score", "n_refit"]
-tot = dbg[:, :6].sum(axis=1).astype(np.float64)
+tot = (dbg[:, :6].sum(axis=1) + dbg[:, 8:13].sum(axis=1)).astype(np.float64)
 print("pairs", len(out), "mean wall cycles/pair %.3g" % tot.mean(), "max %.3g" % tot.max())
 for i, n in enumerate(names):
     if i < 6:
@@ -23,3 +23,6 @@ for i, n in enumerate(names):
     else:
         print("%-9s mean %.1f" % (n, dbg[:, i].mean()))
 print("cycles per score %.0f, per refit %.0f" % (dbg[:, 3].sum() / dbg[:, 6].sum(), dbg[:, 4].sum() / dbg[:, 7].sum()))
+
+for i, n in ((8, "fit:compact"), (9, "fit:Wprefix"), (10, "fit:alpha"), (11, "fit:recurrence"), (4, "fit:gather"), (12, "fit:batched SVD")):
+    print("%-16s %6.2f%%  mean cycles %.3g" % (n, 100 * dbg[:, i].sum() / tot.sum(), dbg[:, i].mean()))
