@@ -90,6 +90,13 @@ def load():
         raise RgbdfeError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both see the
+    # GPU.  Loading torch first makes its runtime the process-wide one (librgbdfe.so then binds to it
+    # through the soname), whatever order the caller imports things in.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     i32 = C.c_int32

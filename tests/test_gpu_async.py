@@ -1,0 +1,91 @@
+"""-m gpu: batching machinery of the C ABI -- chunking of long pair lists over the two internal
+streams, the staging ring, and the asynchronous submit / wait-ticket entry points -- must not change
+any result."""
+import numpy as np
+import pytest
+
+from rgbdslam_v2_amd import synth
+from rgbdslam_v2_amd._lib import RESULT_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data():
+    seq = synth.make_sequence(n_frames=12, n_kp=400, n_world=1600, seed=14)
+    pq, pt = synth.candidate_pairs(12, per_frame=6, seed=14)
+    return seq, pq, pt
+
+
+def _fe(cap, seq):
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    fe = FrontEnd(device_id=0, max_nodes=16, max_keypoints=512, max_pairs_per_batch=cap)
+    for f in range(seq["desc"].shape[0]):
+        fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+    return fe
+
+
+def test_chunked_list_equals_single_batch(data):
+    seq, pq, pt = data
+    big = _fe(256, seq)
+    ref = big.match_pair_list(pq, pt)
+    big.close()
+    small = _fe(7, seq)  # 72 pairs -> 11 chunks alternating over both lanes, ring reused
+    out = small.match_pair_list(pq, pt)
+    assert out.tobytes() == ref.tobytes()
+    out2 = small.match_pair_list(pq[::-1].copy(), pt[::-1].copy())
+    assert out2[::-1].tobytes() == ref.tobytes()
+    small.close()
+
+
+def test_submit_wait_tickets(data):
+    import torch
+    seq, pq, pt = data
+    fe = _fe(32, seq)
+    ref = fe.match_pair_list(pq, pt)
+    rec = RESULT_DTYPE.itemsize
+    chunks = [slice(i, min(i + 20, len(pq))) for i in range(0, len(pq), 20)]
+    bufs = [torch.zeros(20 * rec, dtype=torch.uint8, device="cuda") for _ in chunks]
+    tickets = [fe.submit_pair_list(pq[c], pt[c], b.data_ptr()) for c, b in zip(chunks, bufs)]
+    assert tickets == sorted(tickets) and len(set(tickets)) == len(tickets)
+    # wait out of order: once on a torch stream, once on the host
+    s = torch.cuda.Stream()
+    fe.wait_ticket(tickets[-1], s.cuda_stream)
+    for t in tickets[:-1][::-1]:
+        fe.wait_ticket(t, None)
+    s.synchronize()
+    for c, b in zip(chunks, bufs):
+        n = c.stop - c.start
+        got = np.frombuffer(b.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[:n]
+        assert got.tobytes() == ref[c].tobytes()
+    # in-order variant on a caller stream
+    b0 = torch.zeros(len(pq[:16]) * rec, dtype=torch.uint8, device="cuda")
+    fe.match_pair_list_device(pq[:16], pt[:16], b0.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = np.frombuffer(b0.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+    assert got.tobytes() == ref[:16].tobytes()
+    # releasing / re-uploading a node while nothing is in flight, then matching again
+    fe.release_node(3)
+    fe.upload_node(3, seq["desc"][3], seq["xyz1"][3])
+    again = fe.match_pair_list(pq, pt)
+    assert again.tobytes() == ref.tobytes()
+    fe.close()
+
+
+def test_errors_are_reported_not_crashed(data):
+    from rgbdslam_v2_amd._lib import RgbdfeError
+    seq, pq, pt = data
+    fe = _fe(8, seq)
+    with pytest.raises(RgbdfeError):
+        fe.match_pair_list([0], [99])            # unknown node
+    with pytest.raises(ValueError):
+        fe.upload_node(50, np.zeros((5, 32), np.uint8), np.zeros((6, 4), np.float32))  # shape mismatch
+    with pytest.raises(RgbdfeError):
+        fe.set_params(max_matches=1000)          # beyond RGBDFE_MAX_MATCHES
+    fe.set_params(max_matches=300)
+    big = np.zeros((600, 32), np.uint8)
+    with pytest.raises(RgbdfeError):
+        fe.upload_node(51, big, np.zeros((600, 4), np.float32))  # more rows than max_keypoints
+    out = fe.match_pair_list(pq[:3], pt[:3])    # the context still works
+    assert out["n_all"].min() >= 0
+    fe.close()
