@@ -89,3 +89,18 @@ def test_errors_are_reported_not_crashed(data):
     out = fe.match_pair_list(pq[:3], pt[:3])    # the context still works
     assert out["n_all"].min() >= 0
     fe.close()
+
+
+def test_small_batches_repeat_bytes(data):
+    """Small batches take the split-train (atomicMin) Hamming path; repeated runs through fresh
+    contexts must be byte-identical to the big-batch (plain store) path."""
+    seq, pq, pt = data
+    big = _fe(256, seq)
+    ref = big.match_pair_list(pq, pt)
+    big.close()
+    for rep in range(6):
+        fe = _fe(64, seq)
+        for j in range(0, 24, 4):
+            b = fe.match_pair_list(pq[j:j + 4], pt[j:j + 4])
+            assert b.tobytes() == ref[j:j + 4].tobytes()
+        fe.close()
