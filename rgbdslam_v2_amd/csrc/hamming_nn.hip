@@ -11,8 +11,10 @@
 //     (accumulating form) + v_lshl_or_b32 + v_min_u32 per 256-bit compare -- no LDS, no
 //     vector-memory traffic in the loop;
 //   * (hd << 16 | train_row) packed keys turn "strict <, first minimum wins"
-//     (features.cpp:176) into a single unsigned min, and make the cross-block combine
-//     (train rows split over blocks for small batches) a plain atomicMin;
+//     (features.cpp:176) into a single unsigned min; when the train rows of a SMALL batch
+//     are split over several blocks every split writes its own key plane
+//     (keys[pair][split][row]) and the consumer takes the min over the planes -- no
+//     atomics, no pre-initialised buffer;
 //   * the reference never visits the last train row (`i < size-1`, features.cpp:174):
 //     rows [0, nt-1) are searched;
 //   * blocks of one pair are placed on one XCD (block b runs on XCD b % 8) so the
@@ -50,9 +52,8 @@ __global__ __launch_bounds__(kHamThreads) void hamming_nn_kernel(
   uint32_t t0 = 0, t1 = nt_search;
   if (SPLIT) {
     uint32_t chunk = (nt_search + tsplit - 1u) / tsplit;
-    t0 = split * chunk;
-    t1 = min(t0 + chunk, nt_search);
-    if (t0 >= t1) return;
+    t0 = min(split * chunk, nt_search);
+    t1 = min(t0 + chunk, nt_search);  // may be empty: the plane is then filled with "no match"
   }
 
   const uint32_t qbase = tile * kQueriesPerBlock + threadIdx.x;
@@ -121,27 +122,21 @@ __global__ __launch_bounds__(kHamThreads) void hamming_nn_kernel(
     }
   }
 
-  uint32_t* kout = keys + (size_t)pair * max_kp;
+  uint32_t* kout = keys + ((size_t)pair * tsplit + split) * max_kp;
 #pragma unroll
   for (int k = 0; k < kQPL; ++k) {
     uint32_t qi = qbase + k * kHamThreads;
-    if (qi < nq) {
-      uint32_t v = best[k] == 0xFFFFFFFFu ? kNoMatchKey : best[k];
-      if (SPLIT)
-        atomicMin(&kout[qi], v);
-      else
-        kout[qi] = v;
-    }
+    if (qi < nq) kout[qi] = best[k] == 0xFFFFFFFFu ? kNoMatchKey : best[k];
   }
 }
 
-void launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
-                       uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
-                       hipStream_t stream) {
-  if (n_pairs == 0 || max_nq == 0) return;
+uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
+                           uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
+                           uint32_t key_planes_capacity, hipStream_t stream) {
+  if (n_pairs == 0 || max_nq == 0) return 1;
   const uint32_t tiles = (max_nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
   // Enough blocks to fill 256 CUs several times over; split the train rows when the
-  // batch is small (live SLAM: ~20 pairs per frame).
+  // batch is small (live SLAM: ~20 pairs per frame).  Every split owns a key plane.
   uint32_t tsplit = 1;
   const uint32_t blocks1 = n_pairs * tiles;
   if (blocks1 < 2048 && max_nt > 64) {
@@ -149,19 +144,19 @@ void launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t
     const uint32_t max_split = (max_nt + 63) / 64;  // at least 64 rows per block
     if (tsplit > max_split) tsplit = max_split;
     if (tsplit > 32) tsplit = 32;
+    const uint32_t fit = key_planes_capacity / n_pairs;  // planes the keys buffer can hold
+    if (tsplit > fit) tsplit = fit;
     if (tsplit < 1) tsplit = 1;
   }
   const uint32_t pairs8 = (n_pairs + 7u) / 8u * 8u;
   const uint32_t grid = pairs8 * tiles * tsplit;
-  if (tsplit > 1) {
-    // keys must start at +inf for atomicMin; kNoMatchKey is the canonical "none"
-    (void)hipMemsetAsync(keys, 0xFF, (size_t)n_pairs * max_kp * sizeof(uint32_t), stream);
+  if (tsplit > 1)
     hipLaunchKernelGGL(hamming_nn_kernel<true>, dim3(grid), dim3(kHamThreads), 0, stream,
                        desc_pool, work, keys, max_kp, n_pairs, tiles, tsplit);
-  } else {
+  else
     hipLaunchKernelGGL(hamming_nn_kernel<false>, dim3(grid), dim3(kHamThreads), 0, stream,
                        desc_pool, work, keys, max_kp, n_pairs, tiles, tsplit);
-  }
+  return tsplit;
 }
 
 }  // namespace rgbdfe

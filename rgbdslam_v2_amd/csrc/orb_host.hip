@@ -183,6 +183,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   kp_cap = (int)(score_off / 4) + 64 * n_cells * kLevels;
   ORB_HIP(hipMalloc((void**)&d_pool, pool_bytes));
   ORB_HIP(hipMemset(d_pool, 0, pool_bytes));
+  ORB_HIP(hipDeviceSynchronize());  // NULL-stream memset vs the context's non-blocking stream
   ORB_HIP(hipMalloc((void**)&d_score, score_off + 256));
   ORB_HIP(hipMalloc((void**)&d_blur, blur_off + 256));
   ORB_HIP(hipMalloc((void**)&d_cell_imgs, sizeof(ImgDesc) * cell_imgs.size()));
@@ -204,6 +205,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));
+  ORB_HIP(hipDeviceSynchronize());
   if (!pattern_uploaded) { orb_upload_pattern(kOrbBitPattern31); pattern_uploaded = true; }
   return RGBDFE_OK;
 }

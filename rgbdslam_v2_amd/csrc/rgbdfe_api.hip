@@ -6,6 +6,7 @@
 // entry point reports RGBDFE_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -253,9 +254,10 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     }
     const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
     if (!sift) {
-      launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, mk, (uint32_t)n, max_nq, max_nt, stream);
+      const uint32_t planes = launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, mk, (uint32_t)n, max_nq,
+                                                max_nt, (uint32_t)ctx->cfg.max_pairs_per_batch, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-      launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, d_out, mk, (uint32_t)n, ctx->rc, stream);
+      launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
     } else {
       launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
@@ -334,8 +336,12 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   const size_t rows = (size_t)cfg->max_nodes * (size_t)cfg->max_keypoints + 16;  // +pad: prefetch overrun
   if (hipMalloc((void**)&ctx->d_desc, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
   if (hipMalloc((void**)&ctx->d_xyz, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  // hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which the
+  // context's non-blocking streams do not wait for: a node upload issued right after create could be
+  // overwritten by a late memset.  Wait for the device before returning.
   if (hipMemset(ctx->d_desc, 0, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_HIP);
   if (hipMemset(ctx->d_xyz, 0, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  if (hipDeviceSynchronize() != hipSuccess) return bail(RGBDFE_ERR_HIP);
   const size_t np = (size_t)cfg->max_pairs_per_batch;
   for (auto& sl : ctx->ring) {
     if (hipMalloc((void**)&sl.d_work, np * sizeof(PairWork)) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
@@ -559,6 +565,7 @@ static int ensure_sift(rgbdfe_ctx* ctx) {
     return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "SIFT node slabs");
   HIP_TRY(ctx, hipMemset(ctx->d_sift_bf16, 0, rows * 128 * 2));
   HIP_TRY(ctx, hipMemset(ctx->d_sift_f32, 0, rows * 128 * 4));
+  HIP_TRY(ctx, hipDeviceSynchronize());  // see rgbdfe_create: NULL-stream memsets vs non-blocking streams
   for (auto& ln : ctx->lanes) {
     if (hipMalloc((void**)&ln.d_row_part, np * mk * 3 * 4) != hipSuccess ||
         hipMalloc((void**)&ln.d_col_part, np * mk * 3 * 4) != hipSuccess ||
@@ -840,11 +847,17 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   return RGBDFE_OK;
 }
 
-static int hamming_keys_to_host(rgbdfe_ctx* ctx, uint32_t nq, int32_t* out_hd, int32_t* out_idx) {
-  std::vector<uint32_t> keys(nq);
+static int hamming_keys_to_host(rgbdfe_ctx* ctx, uint32_t nq, uint32_t planes, int32_t* out_hd, int32_t* out_idx) {
+  const size_t mk = (size_t)ctx->cfg.max_keypoints;
+  std::vector<uint32_t> all((size_t)planes * mk), keys(nq);
   hipStream_t st = ctx->lanes[0].stream;
-  HIP_TRY(ctx, hipMemcpyAsync(keys.data(), ctx->lanes[0].d_keys, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(all.data(), ctx->lanes[0].d_keys, all.size() * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (uint32_t i = 0; i < nq; ++i) {
+    uint32_t k = all[i];
+    for (uint32_t pl = 1; pl < planes; ++pl) k = std::min(k, all[(size_t)pl * mk + i]);
+    keys[i] = k;
+  }
   for (uint32_t i = 0; i < nq; ++i) {
     const uint32_t hd = keys[i] >> 16;
     if (hd > 256u) {  // nothing searched: (257, -1), features.cpp:172-173
@@ -877,10 +890,11 @@ int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id; w.pad = 0;
   if (w.nq == 0) return RGBDFE_OK;
   HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, st));
-  launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->lanes[0].d_keys, (uint32_t)ctx->cfg.max_keypoints, 1u,
-                    w.nq, w.nt, st);
+  const uint32_t planes = launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->lanes[0].d_keys,
+                                            (uint32_t)ctx->cfg.max_keypoints, 1u, w.nq, w.nt,
+                                            (uint32_t)ctx->cfg.max_pairs_per_batch, st);
   HIP_TRY(ctx, hipGetLastError());
-  return hamming_keys_to_host(ctx, w.nq, out_hd, out_idx);
+  return hamming_keys_to_host(ctx, w.nq, planes, out_hd, out_idx);
 }
 
 int rgbdfe_hamming_nn_host(rgbdfe_ctx* ctx, const uint8_t* qdesc, int32_t nq, const uint8_t* tdesc,

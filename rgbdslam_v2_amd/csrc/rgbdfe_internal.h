@@ -33,12 +33,14 @@ struct RansacConst {
 };
 
 // launchers (defined in the .hip files)
-void launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
-                       uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
-                       hipStream_t stream);
+// returns the number of key planes written per pair (keys[pair][plane][row]); the consumer
+// takes the min over planes.  key_planes_capacity = planes the keys buffer can hold in total.
+uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
+                           uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
+                           uint32_t key_planes_capacity, hipStream_t stream);
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
-                          rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                          const RansacConst& rc, hipStream_t stream);
+                          uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
+                          uint32_t n_pairs, const RansacConst& rc, hipStream_t stream);
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,

@@ -593,7 +593,7 @@ struct SiftMatchList {
 template <bool SIFT>
 __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
-    const uint32_t* __restrict__ keys, const SiftMatchList sm,
+    const uint32_t* __restrict__ keys, uint32_t key_planes, const SiftMatchList sm,
     rgbdfe_match_result* __restrict__ results, uint32_t max_kp, uint32_t n_pairs,
     const RansacConst rc) {
   __shared__ RansacLds lds;
@@ -609,7 +609,13 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 
   if (!SIFT) {
   const uint32_t nq = w.nq;
-  const uint32_t* __restrict__ kin = keys + (size_t)pair * max_kp;
+  const uint32_t* __restrict__ kin = keys + (size_t)pair * key_planes * max_kp;
+  // the Hamming kernel may have split the train rows over `key_planes` blocks: min over the planes
+  auto load_key = [&](uint32_t i) {
+    uint32_t k = kin[i];
+    for (uint32_t pl = 1; pl < key_planes; ++pl) k = min(k, kin[(size_t)pl * max_kp + i]);
+    return k;
+  };
   // ------------------------------------------------------------------ selection
   sel.cnt[lane] = 0;
   sel.cnt[lane + 64] = 0;
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
   for (uint32_t base = 0; base < nq; base += kWave) {
     const uint32_t i = base + lane;
     if (i < nq) {
-      const uint32_t hd = kin[i] >> 16;
+      const uint32_t hd = load_key(i) >> 16;
       if (hd < 128u) atomicAdd(&sel.cnt[hd], 1u);  // node.cpp:572
     }
   }
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
   // stable placement: (hd, queryIdx) order == D2's deterministic tie-break
   for (uint32_t base = 0; base < nq; base += kWave) {
     const uint32_t i = base + lane;
-    uint32_t key = i < nq ? kin[i] : 0xFFFFFFFFu;
+    uint32_t key = i < nq ? load_key(i) : 0xFFFFFFFFu;
     const uint32_t hd = key >> 16;
     const bool valid = hd < cut_hd;
     uint64_t same = __ballot(valid);
@@ -995,12 +1001,12 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 }
 
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
-                          rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                          const RansacConst& rc, hipStream_t stream) {
+                          uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
+                          uint32_t n_pairs, const RansacConst& rc, hipStream_t stream) {
   if (n_pairs == 0) return;
   SiftMatchList none{};
   hipLaunchKernelGGL(select_ransac_kernel<false>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, keys, none, results, max_kp, n_pairs, rc);
+                     work, keys, key_planes, none, results, max_kp, n_pairs, rc);
 }
 
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
@@ -1010,7 +1016,7 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, con
   if (n_pairs == 0) return;
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
   hipLaunchKernelGGL(select_ransac_kernel<true>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, (const uint32_t*)nullptr, sm, results, max_kp, n_pairs, rc);
+                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc);
 }
 
 }  // namespace rgbdfe
