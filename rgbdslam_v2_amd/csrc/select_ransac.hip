@@ -32,7 +32,16 @@ namespace rgbdfe {
 constexpr int kWave = 64;
 constexpr int kRounds = RGBDFE_MAX_MATCHES / kWave;  // 5
 
-constexpr int kSlots = 8;  // RANSAC iterations refined side by side (one batched SVD per round)
+// RANSAC iterations refined side by side: the refits of a round share ONE recurrence loop (9 lanes per
+// slot, 7 x 9 = 63 lanes) and ONE batched SVD (lane = slot).
+constexpr int kSlots = 7;
+constexpr int kFitUnroll = 4;   // recurrence steps per trip; loads run two trips ahead
+// u16 entries per slot list: 320 + two trips of read-ahead, an odd number of words so that the
+// slots' k-th entries sit in different LDS banks
+constexpr int kOrdStride = RGBDFE_MAX_MATCHES + 2 * kFitUnroll + 2;
+// one match in LDS: from.xyz, to.xyz, weight (7 words: a lane = match access is bank-conflict free)
+constexpr int kRec = 7;
+constexpr uint32_t kRecBytes = kRec * 4;
 
 // selection phase
 struct SelBuf {
@@ -42,9 +51,7 @@ struct SelBuf {
 };
 // refit phase: the inlier set compacted in match order
 struct FitBuf {
-  // per participating match k (match order): {w_k -> alpha_k, W_k -> 1 - alpha_k} and the match index
-  float2 ao[RGBDFE_MAX_MATCHES];
-  uint16_t ord[RGBDFE_MAX_MATCHES];
+  uint16_t ord[kSlots][kOrdStride];  // per slot: byte offsets of its participating matches' records, match order
 };
 // scoring phase: candidates (matches that survive the cheap shortcut test) and inliers, compacted
 struct ScoreBuf {
@@ -79,9 +86,9 @@ struct Slot {
 };
 struct __attribute__((aligned(16))) RansacLds {
   Scratch u;
-  float P[RGBDFE_MAX_MATCHES * 3];  // newer node's points ("from"), match order
-  float Q[RGBDFE_MAX_MATCHES * 3];  // older node's points ("to")
-  float w[RGBDFE_MAX_MATCHES];      // 1/(from.z*to.z), transformation_estimation_euclidean.cpp:25
+  // match m: M[7m..7m+2] newer node's point ("from"), M[7m+3..7m+5] older node's point ("to"),
+  // M[7m+6] = 1/(from.z*to.z) (transformation_estimation_euclidean.cpp:25)
+  float M[RGBDFE_MAX_MATCHES * kRec];
   Slot slot[kSlots];
   Hyp best;
 };
@@ -124,9 +131,9 @@ struct Tfc {
     for (int i = 0; i < 9; ++i) C[i] = 0.0f;
   }
   // transformation_estimation_euclidean.cpp:20-25,56 + tfc.add()
-  __device__ __forceinline__ void add(const float* __restrict__ P, const float* __restrict__ Q, int m) {
-    float f[3] = {P[m * 3 + 0], P[m * 3 + 1], P[m * 3 + 2]};
-    float t[3] = {Q[m * 3 + 0], Q[m * 3 + 1], Q[m * 3 + 2]};
+  __device__ __forceinline__ void add(const float* __restrict__ M, int m) {
+    float f[3] = {M[m * kRec + 0], M[m * kRec + 1], M[m * kRec + 2]};
+    float t[3] = {M[m * kRec + 3], M[m * kRec + 4], M[m * kRec + 5]};
     if (__builtin_isnan(f[2]) || __builtin_isnan(t[2])) return;
     // weight = 1.0/(from(2)*to(2)): double divide rounded to float == float divide
     // (53 >= 2*24+2: double rounding is innocuous for division)
@@ -327,10 +334,140 @@ __device__ __forceinline__ bool has_nan12(const float* R, const float* t) {
 //   sum   : the reference's strictly sequential error sum over the compacted inliers.
 // When fewer candidates than `need` survive pass 1 the caller will reject the hypothesis whatever
 // the exact numbers are (node.cpp:1154, :1206): the solve is skipped and (0, 1e9) is returned.
+// Optional phase timers (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase are
+// written over the head of all_q of each result.  Never enabled in the product build.
+#ifdef RGBDFE_PROFILE_PHASES
+#define PH_DECL uint64_t ph_t0 = __builtin_readcyclecounter(); uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) { uint64_t ph_t1 = __builtin_readcyclecounter(); ph[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
+#define PH_COUNT(i) { ph[i] += 1; }
+#define PH_ADDX(i, v) { ph[i] += (uint64_t)(v); }
+#define PH_ARG , uint64_t* ph, uint64_t& ph_t0
+#define PH_PASS , ph, ph_t0
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_COUNT(i)
+#define PH_ADDX(i, v)
+#define PH_ARG
+#define PH_PASS
+#endif
+#define PH_ADD(i, v) PH_ADDX(i, v)
+
+// ---------------------------------------------------------------------------------
+// d^T S^-1 d through the unblocked Cholesky factorisation and the two triangular solves of
+// Eigen's llt().solve() (misc.cpp:763); S given by its lower triangle.  Same operation order as
+// the oracle's orc_error_function2; `ok` = all pivots positive.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double mahal_llt_ieee(double S00, double S10, double S11, double S20, double S21,
+                                                 double S22, const double* d, bool& ok) {
+  ok = S00 > 0.0;
+  const double l00 = sqrt(S00);
+  const double l10 = S10 / l00;
+  const double l20 = S20 / l00;
+  const double x1 = S11 - l10 * l10;
+  ok = ok && (x1 > 0.0);
+  const double l11 = sqrt(x1);
+  const double l21 = (S21 - l20 * l10) / l11;
+  const double x2 = S22 - (l20 * l20 + l21 * l21);
+  ok = ok && (x2 > 0.0);
+  const double l22 = sqrt(x2);
+  const double y0 = d[0] / l00;
+  const double y1 = (d[1] - l10 * y0) / l11;
+  const double y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
+  const double z2 = y2 / l22;
+  const double z1 = (y1 - l21 * z2) / l11;
+  const double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
+  return (d[0] * z0 + d[1] * z1) + d[2] * z2;
+}
+
+// The same arithmetic with the IEEE divisions and square roots spelled out as the gfx950 expansion of
+// `/` and `sqrt` WITHOUT its range scaling (v_div_scale / v_div_fmas / v_div_fixup, v_ldexp), and with
+// the refined reciprocal of a pivot shared by the 2-4 divisions that use it: 9 divisions cost
+// 3 x 5 + 9 x 3 instructions instead of 9 x 11.  Bit-identical to the expansion whenever the scaling
+// would have been the identity, i.e. every numerator and radicand is a normal number with a binary
+// exponent within +-200 (no zero, denormal, inf, NaN).  `unsafe` reports a lane outside that window;
+// the caller then recomputes with mahal_llt_ieee.
+struct ExpWindow {
+  uint32_t lo = 0x7FF00000u, hi = 0u;
+  __device__ __forceinline__ void see(double v) {
+    const uint32_t e = (uint32_t)__double2hiint(v) & 0x7FF00000u;
+    lo = min(lo, e);
+    hi = max(hi, e);
+  }
+  __device__ __forceinline__ bool outside() const {
+    return lo < ((1023u - 200u) << 20) || hi > ((1023u + 200u) << 20);
+  }
+};
+__device__ __forceinline__ double rcp_refined(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_by(double a, double b, double rb) {
+  const double q = a * rb;
+  const double res = __builtin_fma(-b, q, a);
+  return __builtin_fma(res, rb, q);
+}
+__device__ __forceinline__ double sqrt_unscaled(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double t = __builtin_fma(-g, g, x);
+  g = __builtin_fma(t, h, g);
+  t = __builtin_fma(-g, g, x);
+  g = __builtin_fma(t, h, g);
+  return g;
+}
+__device__ __forceinline__ double mahal_llt_fast(double S00, double S10, double S11, double S20, double S21,
+                                                 double S22, const double* d, bool& ok, bool& unsafe) {
+  ExpWindow win;
+  ok = S00 > 0.0;
+  win.see(S00);
+  const double l00 = sqrt_unscaled(S00);
+  const double r00 = rcp_refined(l00);
+  win.see(S10); win.see(S20); win.see(d[0]);
+  const double l10 = div_by(S10, l00, r00);
+  const double l20 = div_by(S20, l00, r00);
+  const double y0 = div_by(d[0], l00, r00);
+  const double x1 = S11 - l10 * l10;
+  ok = ok && (x1 > 0.0);
+  win.see(x1);
+  const double l11 = sqrt_unscaled(x1);
+  const double r11 = rcp_refined(l11);
+  const double n21 = S21 - l20 * l10;
+  const double ny1 = d[1] - l10 * y0;
+  win.see(n21); win.see(ny1);
+  const double l21 = div_by(n21, l11, r11);
+  const double y1 = div_by(ny1, l11, r11);
+  const double x2 = S22 - (l20 * l20 + l21 * l21);
+  ok = ok && (x2 > 0.0);
+  win.see(x2);
+  const double l22 = sqrt_unscaled(x2);
+  const double r22 = rcp_refined(l22);
+  const double ny2 = d[2] - (l20 * y0 + l21 * y1);
+  win.see(ny2);
+  const double y2 = div_by(ny2, l22, r22);
+  win.see(y2);
+  const double z2 = div_by(y2, l22, r22);
+  const double nz1 = y1 - l21 * z2;
+  win.see(nz1);
+  const double z1 = div_by(nz1, l11, r11);
+  const double nz0 = y0 - (l10 * z1 + l20 * z2);
+  win.see(nz0);
+  const double z0 = div_by(nz0, l00, r00);
+  unsafe = win.outside();
+  return (d[0] * z0 + d[1] * z1) + d[2] * z2;
+}
+
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, int n_all, uint32_t need,
                                                  const RansacConst& rc, RansacLds& lds,
-                                                 uint64_t* mask, int& n_inl, double& err) {
+                                                 uint64_t* mask, int& n_inl, double& err PH_ARG) {
   const int lane = threadIdx.x;
   double Rd[9], td[3];
 #pragma unroll
@@ -346,9 +483,9 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
-    // stride-3 word addresses: conflict-free across the 32 LDS banks
-    const float pxf = lds.P[m * 3 + 0], pyf = lds.P[m * 3 + 1], pzf = lds.P[m * 3 + 2];
-    const float qxf = lds.Q[m * 3 + 0], qyf = lds.Q[m * 3 + 1], qzf = lds.Q[m * 3 + 2];
+    // stride-7 word addresses: conflict-free across the LDS banks
+    const float pxf = lds.M[m * kRec + 0], pyf = lds.M[m * kRec + 1], pzf = lds.M[m * kRec + 2];
+    const float qxf = lds.M[m * kRec + 3], qyf = lds.M[m * kRec + 4], qzf = lds.M[m * kRec + 5];
     // node.cpp:994 (z == 0 skip) ; misc.cpp:712-717 (NaN -> DBL_MAX)
     bool cand = (m < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
     const double a0 = (double)pxf, a1 = (double)pyf, a2 = (double)pzf;
@@ -367,14 +504,15 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   err = 1e9;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) mask[r] = 0ull;
-  if ((uint32_t)n_cand < need) return;  // hopeless: nobody looks at the exact numbers
+  PH_ADD(13, n_cand)
+  if ((uint32_t)n_cand < need) { PH_COUNT(15) return; }  // hopeless: nobody looks at the exact numbers
   // ---- pass 2
   for (int k0 = 0; k0 < n_cand; k0 += kWave) {
     const int k = k0 + lane;
     const bool act = k < n_cand;
     const int m = act ? (int)sb.cand[k] : 0;
-    const double a0 = (double)lds.P[m * 3 + 0], a1 = (double)lds.P[m * 3 + 1], a2 = (double)lds.P[m * 3 + 2];
-    const double b0 = (double)lds.Q[m * 3 + 0], b1 = (double)lds.Q[m * 3 + 1], b2 = (double)lds.Q[m * 3 + 2];
+    const double a0 = (double)lds.M[m * kRec + 0], a1 = (double)lds.M[m * kRec + 1], a2 = (double)lds.M[m * kRec + 2];
+    const double b0 = (double)lds.M[m * kRec + 3], b1 = (double)lds.M[m * kRec + 4], b2 = (double)lds.M[m * kRec + 5];
     double d[3];
     // mu_1_in_frame_2 = (T * x1).head<3>() with x1.w == 1 (misc.cpp:724)
     d[0] = (((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0]) - b0;
@@ -397,25 +535,11 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
       const double S20 = (A[6] * Rd[0] + A[7] * Rd[3]) + A[8] * Rd[6];
       const double S21 = (A[6] * Rd[1] + A[7] * Rd[4]) + A[8] * Rd[7];
       const double S22 = ((A[6] * Rd[2] + A[7] * Rd[5]) + A[8] * Rd[8]) + c2[2];
-      // LLT (misc.cpp:763), D5: non-positive pivot -> DBL_MAX
-      bool ok = S00 > 0.0;
-      const double l00 = sqrt(S00);
-      const double l10 = S10 / l00;
-      const double l20 = S20 / l00;
-      const double x1 = S11 - l10 * l10;
-      ok = ok && (x1 > 0.0);
-      const double l11 = sqrt(x1);
-      const double l21 = (S21 - l20 * l10) / l11;
-      const double x2 = S22 - (l20 * l20 + l21 * l21);
-      ok = ok && (x2 > 0.0);
-      const double l22 = sqrt(x2);
-      const double y0 = d[0] / l00;
-      const double y1 = (d[1] - l10 * y0) / l11;
-      const double y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
-      const double z2 = y2 / l22;
-      const double z1 = (y1 - l21 * z2) / l11;
-      const double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
-      const double ee = (d[0] * z0 + d[1] * z1) + d[2] * z2;
+      // LLT + solve (misc.cpp:763), D5: non-positive pivot -> DBL_MAX
+      bool ok, unsafe;
+      double ee = mahal_llt_fast(S00, S10, S11, S20, S21, S22, d, ok, unsafe);
+      if (__ballot(act && unsafe) != 0ull)  // an operand outside the fast path's exponent window (or 0, NaN)
+        ee = mahal_llt_ieee(S00, S10, S11, S20, S21, S22, d, ok);
       if (ok && (ee >= 0.0)) e = ee;  // misc.cpp:765-768
     }
     const bool inl = act && !(e > rc.sq_max_dist) && (e >= 0.0);  // node.cpp:998,1001
@@ -433,6 +557,7 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
     const uint32_t hi = __builtin_amdgcn_readfirstlane(sb.mbits[2 * r + 1]);
     mask[r] = ((uint64_t)hi << 32) | lo;
   }
+  PH_ADD(14, n_inl)
   if ((uint32_t)n_inl < need || n_inl < 3) {  // err stays 1e9 (node.cpp:1012-1014); rejected anyway when < need
     __syncthreads();
     return;
@@ -450,113 +575,106 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
 }
 
-// Optional phase timers (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase are
-// written over the head of all_q of each result.  Never enabled in the product build.
-#ifdef RGBDFE_PROFILE_PHASES
-#define PH_DECL uint64_t ph_t0 = __builtin_readcyclecounter(); uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define PH_MARK(i) { uint64_t ph_t1 = __builtin_readcyclecounter(); ph[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
-#define PH_COUNT(i) { ph[i] += 1; }
-#define PH_ARG , uint64_t* ph, uint64_t& ph_t0
-#define PH_PASS , ph, ph_t0
-#else
-#define PH_DECL
-#define PH_MARK(i)
-#define PH_COUNT(i)
-#define PH_ARG
-#define PH_PASS
-#endif
 
 // ---------------------------------------------------------------------------------
-// getTransformFromMatches over an inlier set given as ballot masks (match order).
-// The PCL recurrence is strictly sequential in its state, but not in its coefficients:
-//   1. compaction (lane = match): k-th participating match, its weight          [parallel]
-//   2. W_k = W_{k-1} + w_k                                   [sequential: 1 add per step]
-//   3. alpha_k = w_k / W_k, 1 - alpha_k (lane = k)                              [parallel]
-//   4. the 15 state elements (C 3x3, mean1, mean2) advance one step at a time with one
-//      element pair per lane (lane l: C[i][j], mean2[i], mean1[j], i = l/3, j = l%3):
-//      sub, sub, mul, mul, add, mul, mul, add, mul, add per step instead of ~85 ops.
-// Every float operation is the one the sequential code performs, in the same order on
-// the same operands: bit-identical to Tfc::add over the same matches.
+// getTransformFromMatches for the active slots of a window round, all at once.
+// The PCL recurrence (Tfc::add) is strictly sequential in its state, so one refit can keep only
+// 9 lanes busy (lane l: C[i][j], mean2[i], mean1[j], i = l/3, j = l%3).  The refits of different
+// slots are independent: slot s runs on lanes 9s .. 9s+8, each walking its own compacted inlier list.
+//   fit_compact     (lane = match): k-th participating match of slot s -> ord[s][k]
+//   fit_recurrence  (lane = slot x element): W += w; alpha = w / W; the 15 state elements advance
+// Every float operation is the one the sequential code performs, in the same order on the same
+// operands: bit-identical to Tfc::add over the same matches.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void fit_accumulate(const uint64_t* mask, RansacLds& lds, Tfc& s PH_ARG) {
+__device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, RansacLds& lds) {
   const int lane = threadIdx.x;
   uint32_t base = 0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
-    const float w = lds.w[m];
+    const float w = lds.M[m * kRec + 6];
     // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
     const bool part = ((mask[r] >> lane) & 1ull) && (w != 0.0f);
     const uint64_t pm = __ballot(part);
-    const uint32_t k = base + lane_rank(pm);
-    if (part) {
-      lds.u.fit.ao[k] = make_float2(w, 0.0f);
-      lds.u.fit.ord[k] = (uint16_t)m;
-    }
+    if (part) lds.u.fit.ord[s][base + lane_rank(pm)] = (uint16_t)(m * kRecBytes);
     base += (uint32_t)__popcll(pm);
   }
-  const int n = (int)base;
-  __syncthreads();
-  PH_MARK(8)
-  {
-    // W_k = W_{k-1} + w_k: strictly sequential, 8 steps per trip (loads first, one store burst last)
-    float W = 0.0f;
-    int k = 0;
-    for (; k + 8 <= n; k += 8) {
-      float wv[8], Wv[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) wv[i] = lds.u.fit.ao[k + i].x;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { W += wv[i]; Wv[i] = W; }
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lds.u.fit.ao[k + i].y = Wv[i];
-      }
-    }
-    for (; k < n; ++k) {
-      W += lds.u.fit.ao[k].x;
-      if (lane == 0) lds.u.fit.ao[k].y = W;
-    }
-  }
-  __syncthreads();
-  PH_MARK(9)
-  for (int k = lane; k < n; k += kWave) {
-    const float2 wW = lds.u.fit.ao[k];
-    const float alpha = wW.x / wW.y;
-    lds.u.fit.ao[k] = make_float2(alpha, 1.0f - alpha);
-  }
-  __syncthreads();
-  PH_MARK(10)
+  return (int)base;
+}
+
+// Keeps v in a register at this point: the compiler may not sink the computation of v into a
+// conditionally executed block (which would serialise the LDS loads feeding it again).
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+
+// n_mine: list length of this lane's slot (0: nothing to do), n_max: the longest list of the round.
+// On return lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s.
+// Software pipeline per trip of kFitUnroll steps: list entries are read two trips ahead, the match
+// records one trip ahead; every load is unconditional (lists are read past their end, offsets are
+// clamped) and a finished slot keeps its state through selects.
+__device__ __forceinline__ void fit_recurrence(int n_mine, int n_max, const RansacLds& lds,
+                                               float& C, float& m1, float& m2) {
+  constexpr int U = kFitUnroll;
+  constexpr uint32_t kLastRec = (RGBDFE_MAX_MATCHES - 1) * kRecBytes;
+  const int lane = threadIdx.x;
+  const int sl = min(lane / 9, kSlots - 1);
   const int l9 = lane % 9;
   const int ci = l9 / 3, cj = l9 % 3;
-  float C = 0.0f, m1 = 0.0f, m2 = 0.0f;
-  // (alpha, 1 - alpha) are one 8-byte LDS record per step; 8 steps of loads are in flight.
-#pragma unroll 8
-  for (int k = 0; k < n; ++k) {
-    const float2 co = lds.u.fit.ao[k];
-    const int m = lds.u.fit.ord[k];
-    const float alpha = co.x;
-    const float oma = co.y;
-    const float f = lds.P[m * 3 + cj];
-    const float t = lds.Q[m * 3 + ci];
-    const float d1 = f - m1;
-    const float d2 = t - m2;
-    const float outer = d2 * d1;
-    const float scaled = alpha * outer;
-    const float sum = C + scaled;
-    C = oma * sum;
-    m1 = m1 + alpha * d1;
-    m2 = m2 + alpha * d2;
+  const uint16_t* __restrict__ ord = lds.u.fit.ord[sl];
+  const char* __restrict__ recs = reinterpret_cast<const char*>(lds.M);
+  const char* __restrict__ recP = recs + cj * 4;        // from[cj]
+  const char* __restrict__ recQ = recs + 12 + ci * 4;   // to[ci]
+  float W = 0.0f;
+  C = 0.0f; m1 = 0.0f; m2 = 0.0f;
+  uint32_t off[U];
+  float wv[U], fv[U], tv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) off[u] = min((uint32_t)ord[u], kLastRec);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    wv[u] = *reinterpret_cast<const float*>(recs + off[u] + 24);
+    fv[u] = *reinterpret_cast<const float*>(recP + off[u]);
+    tv[u] = *reinterpret_cast<const float*>(recQ + off[u]);
   }
-  __syncthreads();
-  PH_MARK(11)
-  s.W = 0.0f;
 #pragma unroll
-  for (int x = 0; x < 9; ++x) s.C[x] = bcast_f(C, x);
+  for (int u = 0; u < U; ++u) off[u] = min((uint32_t)ord[U + u], kLastRec);
+  for (int k0 = 0; k0 < n_max; k0 += U) {
+    float wc[U], fc[U], tc[U];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s.m1[j] = bcast_f(m1, j);       // lane j: (i=0, j)
+    for (int u = 0; u < U; ++u) { wc[u] = wv[u]; fc[u] = fv[u]; tc[u] = tv[u]; }
+    // records of the next trip, list entries of the trip after it
 #pragma unroll
-  for (int i = 0; i < 3; ++i) s.m2[i] = bcast_f(m2, 3 * i);   // lane 3i: (i, j=0)
+    for (int u = 0; u < U; ++u) {
+      wv[u] = *reinterpret_cast<const float*>(recs + off[u] + 24);
+      fv[u] = *reinterpret_cast<const float*>(recP + off[u]);
+      tv[u] = *reinterpret_cast<const float*>(recQ + off[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) off[u] = min((uint32_t)ord[k0 + 2 * U + u], kLastRec);
+    // W_k = W_{k-1} + w_k, alpha_k = w_k / W_k: off the state's dependence chain
+    float al[U], om[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      W = W + wc[u];
+      al[u] = wc[u] / W;
+      om[u] = 1.0f - al[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool act = (k0 + u) < n_mine;
+      const float d1 = fc[u] - m1;
+      const float d2 = tc[u] - m2;
+      const float outer = d2 * d1;
+      const float scaled = al[u] * outer;
+      const float sum = C + scaled;
+      float Cn = om[u] * sum;
+      float m1n = m1 + al[u] * d1;
+      float m2n = m2 + al[u] * d2;
+      pin(Cn); pin(m1n); pin(m2n);
+      C = act ? Cn : C;
+      m1 = act ? m1n : m1;
+      m2 = act ? m2n : m2;
+    }
+  }
 }
 
 __device__ __forceinline__ void hyp_store(Hyp& h, const float* R, const float* t, const uint64_t* mask,
@@ -723,11 +841,11 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       p = qxyz[qt & 0xFFFFu];
       q = txyz[qt >> 16];
     }
-    lds.P[m * 3 + 0] = p.x; lds.P[m * 3 + 1] = p.y; lds.P[m * 3 + 2] = p.z;
-    lds.Q[m * 3 + 0] = q.x; lds.Q[m * 3 + 1] = q.y; lds.Q[m * 3 + 2] = q.z;
+    lds.M[m * kRec + 0] = p.x; lds.M[m * kRec + 1] = p.y; lds.M[m * kRec + 2] = p.z;
+    lds.M[m * kRec + 3] = q.x; lds.M[m * kRec + 4] = q.y; lds.M[m * kRec + 5] = q.z;
     // weight = 1.0/(from(2)*to(2)) (transformation_estimation_euclidean.cpp:25): the double
     // divide rounded to float equals the float divide (53 >= 2*24+2)
-    lds.w[m] = 1.0f / (p.z * q.z);
+    lds.M[m * kRec + 6] = 1.0f / (p.z * q.z);
     out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
     out->all_t[m] = (uint16_t)(qt >> 16);
     if (SIFT) {
@@ -805,7 +923,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         acc.reset();
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
-          if (s4 < cnt) acc.add(lds.P, lds.Q, (int)ids[s4]);
+          if (s4 < cnt) acc.add(lds.M, (int)ids[s4]);
         tfc_get_transformation(acc, hypR, hypt);
         hyp_nan = has_nan12(hypR, hypt);
         PH_MARK(2)
@@ -851,10 +969,13 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
           int n_inl;
           double inlier_error;
           PH_MARK(5)
-          score_hypothesis(curR, curt, n_all, thr, rc, lds, inl_mask, n_inl, inlier_error);  // :1148
+          // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever
+          // its error is (:1154, :1160): the scorer may stop counting as soon as that is certain
+          const int rn = __builtin_amdgcn_readfirstlane(sl.rn);
+          score_hypothesis(curR, curt, n_all, max(thr, (uint32_t)rn), rc, lds, inl_mask, n_inl,
+                           inlier_error PH_PASS);  // :1148
           PH_MARK(3)
           PH_COUNT(6)
-          const int rn = __builtin_amdgcn_readfirstlane(sl.rn);
           const double rerr = sl.rerr;
           bool still = false;
           if (!((uint32_t)n_inl < thr || inlier_error > max_dist_d)) {   // :1154
@@ -878,23 +999,41 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
           __syncthreads();
         }
         if (!any_active) break;
-        // ---- refits (:1142): per active slot the weighted-mean recurrence over its inlier set, then
+        // ---- refits (:1142): the weighted-mean recurrences of all active slots side by side, then
         // ONE batched 3x3 SVD with lane = slot
-        Tfc mine;
-        mine.reset();
+        int n_mine = 0, n_max = 0;
+        PH_MARK(5)
         for (int g = 0; g < G; ++g) {
           Slot& sl = lds.slot[g];
           if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
           uint64_t m5[kRounds];
 #pragma unroll
           for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.mask[r]);
-          Tfc su;
-          PH_MARK(5)
-          fit_accumulate(m5, lds, su PH_PASS);
-          PH_MARK(4)
+          const int n_g = fit_compact(g, m5, lds);
+          if (lane / 9 == g) n_mine = n_g;
+          n_max = max(n_max, n_g);
           PH_COUNT(7)
-          if (lane == g) mine = su;
         }
+        __syncthreads();
+        PH_MARK(8)
+        PH_COUNT(9)
+        PH_ADD(10, n_max)
+        Tfc mine;
+        mine.reset();
+        {
+          float C, m1, m2;
+          fit_recurrence(n_mine, n_max, lds, C, m1, m2);
+          PH_MARK(4)
+          // lane s (< G) collects the state of slot s
+          const int src = min(lane, kSlots - 1) * 9;
+#pragma unroll
+          for (int x = 0; x < 9; ++x) mine.C[x] = __shfl(C, src + x);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) mine.m1[j] = __shfl(m1, src + j);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) mine.m2[i] = __shfl(m2, src + 3 * i);
+        }
+        __syncthreads();
         {
           float fR[9], ft[3];
           tfc_get_transformation(mine, fR, ft);
@@ -951,7 +1090,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       uint64_t inl_mask[kRounds];
       int n_inl;
       double inlier_error;
-      score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, inl_mask, n_inl, inlier_error);  // needs > thr (:1206)
+      score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, inl_mask, n_inl, inlier_error PH_PASS);  // needs > thr (:1206)
       if ((uint32_t)n_inl > thr && inlier_error < max_dist_d) {  // :1206
         hyp_store(lds.best, IR, It, inl_mask, n_inl, 0, inlier_error);
         best_n = n_inl;

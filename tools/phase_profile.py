@@ -15,7 +15,7 @@ for f in range(F):
 out = fe.match_pair_list(pq, pt)
 dbg = out["all_q"][:, :64].copy().view(np.uint64)
 names = ["select", "load_pts", "hyp_gen", "score", "refit", "other", "n_score", "n_refit"]
-tot = (dbg[:, :6].sum(axis=1) + dbg[:, 8:13].sum(axis=1)).astype(np.float64)
+tot = (dbg[:, :6].sum(axis=1) + dbg[:, 8] + dbg[:, 12]).astype(np.float64)
 print("pairs", len(out), "mean wall cycles/pair %.3g" % tot.mean(), "max %.3g" % tot.max())
 for i, n in enumerate(names):
     if i < 6:
@@ -24,5 +24,8 @@ for i, n in enumerate(names):
         print("%-9s mean %.1f" % (n, dbg[:, i].mean()))
 print("cycles per score %.0f, per refit %.0f" % (dbg[:, 3].sum() / dbg[:, 6].sum(), dbg[:, 4].sum() / dbg[:, 7].sum()))
 
-for i, n in ((8, "fit:compact"), (9, "fit:Wprefix"), (10, "fit:alpha"), (11, "fit:recurrence"), (4, "fit:gather"), (12, "fit:batched SVD")):
-    print("%-16s %6.2f%%  mean cycles %.3g" % (n, 100 * dbg[:, i].sum() / tot.sum(), dbg[:, i].mean()))
+for i, n in ((8, "fit:compact"), (4, "fit:recurrence (all slots)"), (12, "fit:gather + batched SVD")):
+    print("%-28s %6.2f%%  mean cycles %.3g" % (n, 100 * dbg[:, i].sum() / tot.sum(), dbg[:, i].mean()))
+print("batched refit rounds/pair %.1f, mean longest list %.1f" % (dbg[:, 9].mean(), dbg[:, 10].sum() / max(1, dbg[:, 9].sum())))
+print("per scoring: candidates %.1f, inliers (when pass 2 ran) %.1f, hopeless early-outs %.1f%%" % (
+    dbg[:, 13].sum() / dbg[:, 6].sum(), dbg[:, 14].sum() / max(1, (dbg[:, 6].sum() - dbg[:, 15].sum())), 100.0 * dbg[:, 15].sum() / dbg[:, 6].sum()))
