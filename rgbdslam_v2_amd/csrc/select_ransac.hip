@@ -611,6 +611,11 @@ __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 // Software pipeline per trip of kFitUnroll steps: list entries are read two trips ahead, the match
 // records one trip ahead; every load is unconditional (lists are read past their end, offsets are
 // clamped) and a finished slot keeps its state through selects.
+// FAST_DIV: alpha = w / W through the gfx950 expansion of the f32 division without its range scaling
+// (v_div_scale / v_div_fmas / v_div_fixup): bit-identical when the scaling is the identity, which the
+// caller guarantees by checking once per pair that every weight lies in [2^-40, 2^40] (W is a sum of at
+// most 320 of them).
+template <bool FAST_DIV>
 __device__ __forceinline__ void fit_recurrence(int n_mine, int n_max, const RansacLds& lds,
                                                float& C, float& m1, float& m2) {
   constexpr int U = kFitUnroll;
@@ -655,7 +660,18 @@ __device__ __forceinline__ void fit_recurrence(int n_mine, int n_max, const Rans
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       W = W + wc[u];
-      al[u] = wc[u] / W;
+      if (FAST_DIV) {
+        float r = __builtin_amdgcn_rcpf(W);
+        const float e = __builtin_fmaf(-W, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        float q = wc[u] * r;
+        float res = __builtin_fmaf(-W, q, wc[u]);
+        q = __builtin_fmaf(res, r, q);
+        res = __builtin_fmaf(-W, q, wc[u]);
+        al[u] = __builtin_fmaf(res, r, q);
+      } else {
+        al[u] = wc[u] / W;
+      }
       om[u] = 1.0f - al[u];
     }
 #pragma unroll
@@ -830,6 +846,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
   // ------------------------------------------------- matched 3-D points -> LDS
   const float4* __restrict__ qxyz = xyz_pool + (size_t)w.q_slot * max_kp;
   const float4* __restrict__ txyz = xyz_pool + (size_t)w.t_slot * max_kp;
+  bool w_plain = false;  // a weight outside the window of fit_recurrence<true>
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
@@ -845,7 +862,12 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     lds.M[m * kRec + 3] = q.x; lds.M[m * kRec + 4] = q.y; lds.M[m * kRec + 5] = q.z;
     // weight = 1.0/(from(2)*to(2)) (transformation_estimation_euclidean.cpp:25): the double
     // divide rounded to float equals the float divide (53 >= 2*24+2)
-    lds.M[m * kRec + 6] = 1.0f / (p.z * q.z);
+    const float wgt = 1.0f / (p.z * q.z);
+    lds.M[m * kRec + 6] = wgt;
+    {
+      const uint32_t ex = (__float_as_uint(wgt) >> 23) & 0xFFu;
+      w_plain |= (m < n_all) && (wgt != 0.0f) && (ex < 127u - 40u || ex > 127u + 40u);
+    }
     out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
     out->all_t[m] = (uint16_t)(qt >> 16);
     if (SIFT) {
@@ -856,6 +878,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     }
   }
   __syncthreads();
+  const bool fast_alpha = (__ballot(w_plain) == 0ull);
 
   PH_MARK(1)
   // ------------------------------------------------------------------ RANSAC
@@ -1022,7 +1045,8 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         mine.reset();
         {
           float C, m1, m2;
-          fit_recurrence(n_mine, n_max, lds, C, m1, m2);
+          if (fast_alpha) fit_recurrence<true>(n_mine, n_max, lds, C, m1, m2);
+          else fit_recurrence<false>(n_mine, n_max, lds, C, m1, m2);
           PH_MARK(4)
           // lane s (< G) collects the state of slot s
           const int src = min(lane, kSlots - 1) * 9;

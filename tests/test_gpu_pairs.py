@@ -147,6 +147,35 @@ def test_edge_cases_match_oracle(fe):
         fe.release_node(k)
 
 
+@pytest.mark.parametrize("scale,depth_cov,max_dist", [(1e-7, 1e-4, 3.0), (1e8, 1e18, 1e6), (1e-15, 1e-70, 3.0)])
+def test_numeric_range_fallbacks(fe, scale, depth_cov, max_dist):
+    """The kernel's shortcut arithmetic (unscaled division / square-root expansions) is only taken when
+    every operand lies in a safe exponent window; outside it the plain IEEE operations run.  Extreme
+    coordinate scales and covariances push the weights (1/z^2) and the Cholesky pivots out of the
+    window: results must still equal the oracle's bit for bit."""
+    F = 4
+    seq = synth.make_sequence(n_frames=F, n_kp=300, n_world=900, seed=31)
+    xyz = seq["xyz1"].copy()
+    xyz[:, :, :3] = (xyz[:, :, :3].astype(np.float64) * scale).astype(np.float32)
+    fe.set_params(depth_cov=depth_cov, max_dist_for_inliers=max_dist)
+    try:
+        for f in range(F):
+            fe.upload_node(f, seq["desc"][f], xyz[f])
+        pq, pt = synth.candidate_pairs(F, per_frame=3, seed=31)
+        out = fe.match_pair_list(pq, pt)
+        prm = po.default_params(seed=fe.params.seed, depth_cov=depth_cov, max_dist_for_inliers=max_dist)
+        n_ransac = 0
+        for rec, q, t in zip(out, pq, pt):
+            ref = po.match_node_pair(seq["desc"][q], xyz[q], int(q), seq["desc"][t], xyz[t], int(t), prm)
+            check_against_oracle(rec, ref)
+            n_ransac += ref["valid_iterations"] > 0
+        assert n_ransac > 0  # refits and scorings really ran on the out-of-window data
+    finally:
+        fe.set_params(depth_cov=1e-4, max_dist_for_inliers=3.0)
+        for f in range(F):
+            fe.release_node(f)
+
+
 def test_full_size_properties(fe):
     """BASELINE configs[1] size (1000 kp, 20 candidates/frame) through size-independent properties:
     determinism, self-match identity, ground-truth pose recovery, inlier-set consistency."""
