@@ -586,17 +586,15 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
 // Every float operation is the one the sequential code performs, in the same order on the same
 // operands: bit-identical to Tfc::add over the same matches.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, RansacLds& lds) {
+__device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, const uint64_t* w_nonzero, RansacLds& lds) {
   const int lane = threadIdx.x;
   uint32_t base = 0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
-    const int m = r * kWave + lane;
-    const float w = lds.M[m * kRec + 6];
     // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
-    const bool part = ((mask[r] >> lane) & 1ull) && (w != 0.0f);
-    const uint64_t pm = __ballot(part);
-    if (part) lds.u.fit.ord[s][base + lane_rank(pm)] = (uint16_t)(m * kRecBytes);
+    const uint64_t pm = mask[r] & w_nonzero[r];  // wave-uniform: scalar ALU
+    if ((pm >> lane) & 1ull)
+      lds.u.fit.ord[s][base + lane_rank(pm)] = (uint16_t)((r * kWave + lane) * kRecBytes);
     base += (uint32_t)__popcll(pm);
   }
   return (int)base;
@@ -847,6 +845,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
   const float4* __restrict__ qxyz = xyz_pool + (size_t)w.q_slot * max_kp;
   const float4* __restrict__ txyz = xyz_pool + (size_t)w.t_slot * max_kp;
   bool w_plain = false;  // a weight outside the window of fit_recurrence<true>
+  uint64_t w_nonzero[kRounds];
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
@@ -867,6 +866,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     {
       const uint32_t ex = (__float_as_uint(wgt) >> 23) & 0xFFu;
       w_plain |= (m < n_all) && (wgt != 0.0f) && (ex < 127u - 40u || ex > 127u + 40u);
+      w_nonzero[r] = __ballot(wgt != 0.0f);
     }
     out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
     out->all_t[m] = (uint16_t)(qt >> 16);
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
           uint64_t m5[kRounds];
 #pragma unroll
           for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.mask[r]);
-          const int n_g = fit_compact(g, m5, lds);
+          const int n_g = fit_compact(g, m5, w_nonzero, lds);
           if (lane / 9 == g) n_mine = n_g;
           n_max = max(n_max, n_g);
           PH_COUNT(7)
