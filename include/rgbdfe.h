@@ -166,6 +166,22 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
                          double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
                          float* xyz1, int32_t* n_out);
 
+/* a20, SIFTGPU feature path: Node::projectTo3DSiftGPU (node.cpp:695-769) -- depth lookup with the
+ * keypoint coordinates TRUNCATED to int (:733), no inside-the-image test (indices are clamped here
+ * where the reference would read out of bounds), NaN depth drops the keypoint, stop at max_keypoints
+ * (:748); the used descriptors are re-packed densely (:752-766) into
+ *   siftgpu_descriptors  [n_out x 128] raw copy  = Node::siftgpu_descriptors, what rgbdfe_upload_sift_node takes
+ *   feature_descriptors  [n_out x 128] (may be NULL) = Node::feature_descriptors_, RootSIFT-normalised by
+ *                        squareroot_descriptor_space (node.cpp:1557-1571) when use_root_sift != 0
+ *                        (parameter "use_root_sift", node.cpp:233-239).
+ * kp_xy: n_kp x 2 f32, desc_in: n_kp x 128 f32, depth: rows x cols f32; outputs sized for
+ * min(n_kp, max_keypoints) rows. */
+int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* desc_in,
+                              const float* depth, int32_t rows, int32_t cols, double fx, double fy,
+                              double cx, double cy, double depth_scaling, int32_t max_keypoints,
+                              int32_t use_root_sift, int32_t* kept_idx, float* xyz1,
+                              float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out);
+
 /* ---- per-frame feature path: detect + describe (Node::Node, node.cpp:139-210) -----------------
  * rgbdfe_detect_describe replaces, for one frame,
  *   detector->detect(gray, kps, mask)   the 3x3 grid of threshold-adaptive ORB detectors built by

@@ -100,6 +100,13 @@ def lib():
         L.orc_match_pairs_mt.restype = None
         L.orc_match_pairs_mt.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(OrcParams),
                                          vp, C.c_int]
+        L.orc_project_to_3d_sift.restype = C.c_int
+        L.orc_project_to_3d_sift.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                             C.c_double, C.c_double, C.c_double, C.c_int, vp, vp]
+        L.orc_gather_rows_f32.restype = None
+        L.orc_gather_rows_f32.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+        L.orc_root_sift.restype = None
+        L.orc_root_sift.argtypes = [vp, C.c_int, C.c_int]
         L.orc_project_to_3d.restype = C.c_int
         L.orc_project_to_3d.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_double,
                                         C.c_double, C.c_double, C.c_double, C.c_int, vp, vp]
@@ -258,6 +265,27 @@ def project_to_3d(kp_xy, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints
     k = lib().orc_project_to_3d(_p(kp_xy), n, _p(depth), depth.shape[0], depth.shape[1],
                                 fx, fy, cx, cy, depth_scaling, max_keypoints, _p(kept), _p(xyz1))
     return kept[:k].copy(), xyz1[:k].copy()
+
+
+def sift_node_features(kp_xy, desc, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000,
+                       use_root_sift=True):
+    """projectTo3DSiftGPU + squareroot_descriptor_space: (kept_idx, xyz1, siftgpu_descriptors,
+    feature_descriptors)."""
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+    desc = np.ascontiguousarray(desc, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    n = kp_xy.shape[0]
+    kept = np.empty(max(n, 1), np.int32)
+    xyz1 = np.empty((max(n, 1), 4), np.float32)
+    k = lib().orc_project_to_3d_sift(_p(kp_xy), n, _p(depth), depth.shape[0], depth.shape[1],
+                                     fx, fy, cx, cy, depth_scaling, max_keypoints, _p(kept), _p(xyz1))
+    raw = np.empty((max(k, 1), desc.shape[1]), np.float32)
+    lib().orc_gather_rows_f32(_p(desc), _p(kept), k, desc.shape[1], _p(raw))
+    raw = raw[:k].copy()
+    feat = raw.copy()
+    if use_root_sift and k > 0:
+        lib().orc_root_sift(_p(feat), k, desc.shape[1])
+    return kept[:k].copy(), xyz1[:k].copy(), raw, feat
 
 
 def num_cores():

@@ -643,6 +643,78 @@ int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows
   return n;
 }
 
+/* ------------------------------------------------------------------------- */
+/* a20  Node::projectTo3DSiftGPU -- node.cpp:695-769 (SIFTGPU feature path)     */
+/* Differences to orc_project_to_3d: the depth lookup is depth.at<float>(p2d.y,  */
+/* p2d.x), i.e. the float coordinates are converted to int by TRUNCATION (:733),  */
+/* and there is no inside-the-image test (SiftGPU keypoints lie inside; an index   */
+/* outside is undefined behaviour in the reference -- clamped to the image here).  */
+/* The used descriptors are then re-packed densely (:752-766).                     */
+/* ------------------------------------------------------------------------- */
+static int orc_trunc_clamp(float v, int hi) {
+  int i = isnan(v) ? 0 : (v <= -2147483648.0f ? INT32_MIN : (v >= 2147483648.0f ? INT32_MAX : (int)v));
+  if (i < 0) i = 0;
+  if (i > hi) i = hi;
+  return i;
+}
+int orc_project_to_3d_sift(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
+                           double fx, double fy, double cx_d, double cy_d, double depth_scaling,
+                           int max_keypoints, int32_t* kept_idx, float* xyz1) {
+  const float fxinv = (float)(1. / fx); /* :709 */
+  const float fyinv = (float)(1. / fy); /* :710 */
+  const float cx = (float)cx_d;         /* :711 */
+  const float cy = (float)cy_d;         /* :712 */
+  int n = 0;
+  for (int i = 0; i < n_kp && n < max_keypoints; ++i) { /* :748 break once max_keyp are kept */
+    const float px = kp_xy[2 * i], py = kp_xy[2 * i + 1];
+    const int r = orc_trunc_clamp(py, rows - 1), c = orc_trunc_clamp(px, cols - 1);
+    const float Z = (float)((double)depth[(size_t)r * (size_t)cols + (size_t)c] * depth_scaling); /* :733 */
+    if (isnan(Z)) continue; /* :736-740 */
+    xyz1[4 * n + 0] = (px - cx) * Z * fxinv; /* backProject, misc2.h:62-64 */
+    xyz1[4 * n + 1] = (py - cy) * Z * fyinv;
+    xyz1[4 * n + 2] = Z;
+    xyz1[4 * n + 3] = 1.0f; /* :745 */
+    kept_idx[n] = i;        /* featuresUsed, :746 */
+    ++n;
+  }
+  return n;
+}
+
+/* descriptors_out / siftgpu_descriptors (:752-766): row y <- descriptors_in[featuresUsed[y]] */
+void orc_gather_rows_f32(const float* in, const int32_t* kept_idx, int n, int dim, float* out) {
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < dim; ++x) out[(size_t)y * dim + x] = in[(size_t)kept_idx[y] * dim + x];
+}
+
+/* squareroot_descriptor_space -- node.cpp:1557-1571 (RootSIFT), in place.
+ * cv::abs, then cv::reduce(..., 1, CV_REDUCE_SUM, CV_32FC1): OpenCV 3.3 reduceC_<float,float,OpAdd>
+ * keeps two float accumulators, a0 over columns 0,2,4,... and a1 over 1,3,5,... in steps of four, adds the
+ * leftover columns to a0 and returns a0 + a1 (modules/core/src/matrix.cpp, "parity unpinned": OpenCV is
+ * not in the tree).  Rows whose sum is 0 stay as they are (:1565); else d <- sqrt(d / sum) (:1569). */
+void orc_root_sift(float* desc, int n_rows, int dim) {
+  for (int r = 0; r < n_rows; ++r) {
+    float* d = desc + (size_t)r * dim;
+    for (int c = 0; c < dim; ++c) d[c] = fabsf(d[c]);
+    float sum;
+    if (dim == 1) {
+      sum = d[0];
+    } else {
+      float a0 = d[0], a1 = d[1];
+      int i = 2;
+      for (; i <= dim - 4; i += 4) {
+        a0 = a0 + d[i];
+        a1 = a1 + d[i + 1];
+        a0 = a0 + d[i + 2];
+        a1 = a1 + d[i + 3];
+      }
+      for (; i < dim; ++i) a0 = a0 + d[i];
+      sum = a0 + a1;
+    }
+    if (sum == 0.0f) continue;
+    for (int c = 0; c < dim; ++c) d[c] = sqrtf(d[c] / sum);
+  }
+}
+
 
 /* ========================================================================= */
 /* SIFT (128-d float descriptor) matcher: SiftGPUWrapper::match semantics      */

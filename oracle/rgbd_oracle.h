@@ -95,6 +95,12 @@ int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows
                       int max_keypoints, int32_t* kept_idx, float* xyz1);
 int orc_num_cores(void);
 /* SiftGPUWrapper::match (sift_gpu_wrapper.cpp:169-227) over the CUDA SiftMatchGPU kernels */
+/* a20: projectTo3DSiftGPU (node.cpp:695-769) and squareroot_descriptor_space (node.cpp:1557-1571) */
+int orc_project_to_3d_sift(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
+                           double fx, double fy, double cx, double cy, double depth_scaling,
+                           int max_keypoints, int32_t* kept_idx, float* xyz1);
+void orc_gather_rows_f32(const float* in, const int32_t* kept_idx, int n, int dim, float* out);
+void orc_root_sift(float* desc, int n_rows, int dim);
 int orc_sift_match(const float* d1, int n1, const float* d2, int n2, int32_t* mq, int32_t* mt,
                    float* dist_out);
 void orc_match_sift_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid,

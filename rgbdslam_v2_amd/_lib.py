@@ -160,6 +160,10 @@ def load():
     L.rgbdfe_project_to_3d.argtypes = [ctx, vp, i32, vp, i32, i32, C.c_double, C.c_double,
                                        C.c_double, C.c_double, C.c_double, i32, vp, vp,
                                        C.POINTER(i32)]
+    L.rgbdfe_sift_node_features.restype = C.c_int
+    L.rgbdfe_sift_node_features.argtypes = [ctx, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
+                                            C.c_double, C.c_double, C.c_double, i32, i32, vp, vp, vp, vp,
+                                            C.POINTER(i32)]
     L.rgbdfe_set_profiling.restype = C.c_int
     L.rgbdfe_set_profiling.argtypes = [ctx, C.c_int]
     L.rgbdfe_get_kernel_time.restype = C.c_int
@@ -186,6 +190,6 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket", "rgbdfe_upload_sift_node",
     "rgbdfe_match_sift_pair_list", "rgbdfe_submit_sift_pair_list", "rgbdfe_sift_match_nodes",
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
-    "rgbdfe_project_to_3d", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
+    "rgbdfe_project_to_3d", "rgbdfe_sift_node_features", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
     "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
 ]

@@ -9,10 +9,17 @@
 // __ballot / mbcnt prefix inside each wave plus a 4-entry wave-offset exchange in LDS per
 // 256-keypoint chunk (a running base carries across chunks).  The depth gather is the only
 // HBM traffic (one 4-byte load per keypoint).
+//
+// TRUNC = true is Node::projectTo3DSiftGPU (src/node.cpp:695-769, the SIFTGPU feature path): the
+// lookup is depth.at<float>(p2d.y, p2d.x) -- float -> int by truncation (:733) -- and there is no
+// inside-the-image test (indices are clamped to the image instead of read out of bounds).
+// sift_pack_kernel re-packs the used descriptors densely (:752-766) and applies
+// squareroot_descriptor_space (src/node.cpp:1557-1571, RootSIFT) to the feature_descriptors_ copy.
 #include "rgbdfe_internal.h"
 
 namespace rgbdfe {
 
+template <bool TRUNC>
 __global__ __launch_bounds__(256) void project_to_3d_kernel(
     const float2* __restrict__ kp, int n_kp, const float* __restrict__ depth, int rows, int cols,
     float fxinv, float fyinv, float cx, float cy, double depth_scaling, int max_keypoints,
@@ -29,9 +36,16 @@ __global__ __launch_bounds__(256) void project_to_3d_kernel(
       const float2 p = kp[i];
       px = p.x; py = p.y;
       // node.cpp:931-937
-      const bool bad = px >= (float)cols || px < 0.f || py >= (float)rows || py < 0.f ||
-                       __builtin_isnan(px) || __builtin_isnan(py);
-      if (!bad) {
+      const bool bad = !TRUNC && (px >= (float)cols || px < 0.f || py >= (float)rows || py < 0.f ||
+                                  __builtin_isnan(px) || __builtin_isnan(py));
+      if (TRUNC) {
+        // v_cvt_i32_f32 truncates, saturates and maps NaN to 0
+        int r = (int)py, c = (int)px;
+        r = min(max(r, 0), rows - 1);
+        c = min(max(c, 0), cols - 1);
+        Z = (float)((double)depth[(size_t)r * (size_t)cols + (size_t)c] * depth_scaling);  // :733
+        keep = !__builtin_isnan(Z);  // :736
+      } else if (!bad) {
         // depth.at<float>(round(y), round(x)): std::round = half away from zero (node.cpp:942).
         // round(y) can reach `rows` for y in [rows-0.5, rows): the reference reads out of
         // bounds there; clamp to the last row/column instead.
@@ -68,13 +82,63 @@ __global__ __launch_bounds__(256) void project_to_3d_kernel(
   if (tid == 0) *n_out = (int32_t)min(base, (uint32_t)max_keypoints);
 }
 
+// One wave per kept keypoint: row y of `raw` (siftgpu_descriptors) and of `feat`
+// (feature_descriptors_) <- descriptors_in[kept_idx[y]]; `feat` is RootSIFT-normalised when asked.
+// Lane l holds columns 2l, 2l+1.  The L1 norm follows cv::reduce's float accumulation order
+// (a0 over columns 0,2,..,124,126,127; a1 over 1,3,..,125; a0 + a1): a strictly sequential chain, fed
+// by v_readlane so that the whole wave computes it uniformly.
+__global__ __launch_bounds__(256) void sift_pack_kernel(const float2* __restrict__ in,
+                                                       const int32_t* __restrict__ kept_idx,
+                                                       const int32_t* __restrict__ n_ptr, int root_sift,
+                                                       float2* __restrict__ raw, float2* __restrict__ feat) {
+  const int lane = threadIdx.x & 63;
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (y >= *n_ptr) return;
+  const float2 v = in[(size_t)kept_idx[y] * 64 + lane];
+  raw[(size_t)y * 64 + lane] = v;
+  if (!feat) return;
+  float2 o = v;
+  if (root_sift) {
+    o.x = fabsf(v.x);  // cv::abs (:1561)
+    o.y = fabsf(v.y);
+    auto lane_f = [](float f, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l)); };
+    float a0 = lane_f(o.x, 0), a1 = lane_f(o.y, 0);
+#pragma unroll
+    for (int l = 1; l < 63; ++l) {
+      a0 = a0 + lane_f(o.x, l);
+      a1 = a1 + lane_f(o.y, l);
+    }
+    a0 = a0 + lane_f(o.x, 63);
+    a0 = a0 + lane_f(o.y, 63);
+    const float sum = a0 + a1;
+    if (sum != 0.0f) {  // :1565
+      o.x = sqrtf(o.x / sum);  // :1569
+      o.y = sqrtf(o.y / sum);
+    }
+  }
+  feat[(size_t)y * 64 + lane] = o;
+}
+
 void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                           int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
-                          hipStream_t stream) {
-  hipLaunchKernelGGL(project_to_3d_kernel, dim3(1), dim3(256), 0, stream,
-                     reinterpret_cast<const float2*>(kp_xy), n_kp, depth, rows, cols, fxinv, fyinv,
-                     cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out);
+                          hipStream_t stream, bool truncate) {
+  if (truncate)
+    hipLaunchKernelGGL(project_to_3d_kernel<true>, dim3(1), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(kp_xy), n_kp, depth, rows, cols, fxinv, fyinv,
+                       cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out);
+  else
+    hipLaunchKernelGGL(project_to_3d_kernel<false>, dim3(1), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(kp_xy), n_kp, depth, rows, cols, fxinv, fyinv,
+                       cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out);
+}
+
+void launch_sift_pack(const float* desc_in, const int32_t* kept_idx, const int32_t* n_ptr, int max_rows,
+                      bool root_sift, float* raw, float* feat, hipStream_t stream) {
+  if (max_rows <= 0) return;
+  hipLaunchKernelGGL(sift_pack_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, stream,
+                     reinterpret_cast<const float2*>(desc_in), kept_idx, n_ptr, root_sift ? 1 : 0,
+                     reinterpret_cast<float2*>(raw), reinterpret_cast<float2*>(feat));
 }
 
 }  // namespace rgbdfe

@@ -953,6 +953,56 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
   return RGBDFE_OK;
 }
 
+int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* desc_in,
+                              const float* depth, int32_t rows, int32_t cols, double fx, double fy,
+                              double cx, double cy, double depth_scaling, int32_t max_keypoints,
+                              int32_t use_root_sift, int32_t* kept_idx, float* xyz1,
+                              float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out) {
+  if (!ctx || n_kp < 0 || rows < 1 || cols < 1 || !depth || !kept_idx || !xyz1 || !siftgpu_descriptors ||
+      !n_out || max_keypoints < 0 || (n_kp > 0 && (!kp_xy || !desc_in)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  *n_out = 0;
+  if (n_kp == 0 || max_keypoints == 0) return RGBDFE_OK;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const int cap = n_kp < max_keypoints ? n_kp : max_keypoints;
+  const size_t b_kp = up((size_t)n_kp * 8), b_depth = up((size_t)rows * cols * 4), b_idx = up((size_t)n_kp * 4);
+  const size_t b_xyz = up((size_t)n_kp * 16), b_in = up((size_t)n_kp * 512), b_out = up((size_t)cap * 512);
+  int rc = ensure_scratch(ctx, b_kp + b_depth + b_idx + b_xyz + b_in + 2 * b_out + 256);
+  if (rc != RGBDFE_OK) return rc;
+  char* p = (char*)ctx->d_scratch;
+  float* d_kp = (float*)p;          p += b_kp;
+  float* d_depth = (float*)p;       p += b_depth;
+  int32_t* d_idx = (int32_t*)p;     p += b_idx;
+  float4* d_xyz = (float4*)p;       p += b_xyz;
+  float* d_in = (float*)p;          p += b_in;
+  float* d_raw = (float*)p;         p += b_out;
+  float* d_feat = (float*)p;        p += b_out;
+  int32_t* d_n = (int32_t*)p;
+  HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp_xy, (size_t)n_kp * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, desc_in, (size_t)n_kp * 512, hipMemcpyHostToDevice, ctx->stream));
+  launch_project_to_3d(d_kp, n_kp, d_depth, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
+                       (float)cy, depth_scaling, max_keypoints, d_idx, d_xyz, d_n, ctx->stream, true);
+  launch_sift_pack(d_in, d_idx, d_n, cap, use_root_sift != 0, d_raw, feature_descriptors ? d_feat : nullptr,
+                   ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(kept_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(xyz1, d_xyz, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(siftgpu_descriptors, d_raw, (size_t)n * 512, hipMemcpyDeviceToHost, ctx->stream));
+    if (feature_descriptors)
+      HIP_TRY(ctx, hipMemcpyAsync(feature_descriptors, d_feat, (size_t)n * 512, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *n_out = n;
+  return RGBDFE_OK;
+}
+
 int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(ctx->mu);

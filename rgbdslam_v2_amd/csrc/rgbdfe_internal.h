@@ -58,6 +58,8 @@ void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipS
 void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                           int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
-                          hipStream_t stream);
+                          hipStream_t stream, bool truncate = false);
+void launch_sift_pack(const float* desc_in, const int32_t* kept_idx, const int32_t* n_ptr, int max_rows,
+                      bool root_sift, float* raw, float* feat, hipStream_t stream);
 
 }  // namespace rgbdfe

@@ -314,6 +314,29 @@ class FrontEnd:
             C.byref(n_out)))
         return kept[: n_out.value].copy(), xyz1[: n_out.value].copy()
 
+    def sift_node_features(self, kp_xy, desc, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000,
+                           use_root_sift=True):
+        """projectTo3DSiftGPU (node.cpp:695-769) + squareroot_descriptor_space (node.cpp:1557-1571):
+        returns (kept_idx, xyz1, siftgpu_descriptors, feature_descriptors)."""
+        kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+        desc = np.ascontiguousarray(desc, np.float32)
+        depth = np.ascontiguousarray(depth, np.float32)
+        n = kp_xy.shape[0]
+        if desc.shape != (n, 128):
+            raise ValueError("desc must be n_kp x 128 float32")
+        cap = max(min(n, max_keypoints), 1)
+        kept = np.empty(cap, np.int32)
+        xyz1 = np.empty((cap, 4), np.float32)
+        raw = np.empty((cap, 128), np.float32)
+        feat = np.empty((cap, 128), np.float32)
+        n_out = C.c_int32(0)
+        self._check(self._L.rgbdfe_sift_node_features(
+            self._ctx, kp_xy.ctypes.data, n, desc.ctypes.data, depth.ctypes.data, depth.shape[0],
+            depth.shape[1], fx, fy, cx, cy, depth_scaling, max_keypoints, int(bool(use_root_sift)),
+            kept.ctypes.data, xyz1.ctypes.data, raw.ctypes.data, feat.ctypes.data, C.byref(n_out)))
+        k = n_out.value
+        return kept[:k].copy(), xyz1[:k].copy(), raw[:k].copy(), feat[:k].copy()
+
     # -- measurement ----------------------------------------------------------------------
     def set_profiling(self, enable: bool):
         self._check(self._L.rgbdfe_set_profiling(self._ctx, int(enable)))

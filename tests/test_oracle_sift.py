@@ -90,3 +90,42 @@ def test_sift_match_tie_rules_and_context_heuristic():
     mq, mt, _ = po.sift_match(one, one)
     assert len(mq) == 0
     assert po.sift_match(one[:0], one)[0].size == 0
+
+
+def test_sift_node_features_oracle():
+    """a20: projectTo3DSiftGPU (truncating lookup, node.cpp:733) + descriptor re-pack + RootSIFT."""
+    rng = np.random.default_rng(12)
+    rows, cols, n = 48, 64, 300
+    depth = rng.uniform(0.5, 4, (rows, cols)).astype(np.float32)
+    depth[rng.random((rows, cols)) < 0.2] = np.nan
+    kp = np.stack([rng.uniform(0, cols - 0.01, n), rng.uniform(0, rows - 0.01, n)], 1).astype(np.float32)
+    kp[7] = [10.9999959, 20.5]  # the reference's own example: truncation reads column 10, round() would read 11
+    desc = rng.gamma(0.6, 1.0, (n, 128)).astype(np.float32)
+    desc[3] *= -1.0   # cv::abs
+    desc[5] = 0.0     # zero row: left alone (node.cpp:1565)
+    kept, xyz, raw, feat = po.sift_node_features(kp, desc, depth, 52.5, 52.5, 31.5, 23.5, 1.0, 1000)
+    exp = [i for i, (x, y) in enumerate(kp) if not np.isnan(depth[int(y), int(x)])]
+    assert list(kept) == exp
+    assert (7 in exp) == (not np.isnan(depth[20, 10]))  # column 10, not 11
+    assert np.array_equal(raw, desc[kept])
+    i = kept[0]
+    assert xyz[0, 2] == depth[int(kp[i, 1]), int(kp[i, 0])] and xyz[0, 3] == 1
+    # RootSIFT: unit L2 norm, sqrt of the L1-normalised magnitudes
+    a = np.abs(desc[kept]).astype(np.float64)
+    ref = np.sqrt(a / np.maximum(a.sum(1, keepdims=True), 1e-300))
+    nz = a.sum(1) > 0
+    assert np.allclose(feat[nz], ref[nz], rtol=2e-6, atol=0)
+    assert np.allclose((feat[nz].astype(np.float64) ** 2).sum(1), 1.0, atol=1e-5)
+    assert np.array_equal(feat[~nz], np.zeros_like(feat[~nz]))
+    # the L1 norm follows cv::reduce's two-accumulator order exactly
+    d = np.abs(desc[kept[1]])
+    a0, a1 = np.float32(d[0]), np.float32(d[1])
+    for j in range(2, 125, 4):
+        a0 = np.float32(a0 + d[j]); a1 = np.float32(a1 + d[j + 1])
+        a0 = np.float32(a0 + d[j + 2]); a1 = np.float32(a1 + d[j + 3])
+    a0 = np.float32(np.float32(a0 + d[126]) + d[127])
+    s = np.float32(a0 + a1)
+    assert np.array_equal(feat[1], np.sqrt((d / s).astype(np.float32)).astype(np.float32))
+    # max_keypoints cut (node.cpp:748) and use_root_sift = false
+    kept2, _, raw2, feat2 = po.sift_node_features(kp, desc, depth, 52.5, 52.5, 31.5, 23.5, 1.0, 9, use_root_sift=False)
+    assert list(kept2) == exp[:9] and np.array_equal(raw2, feat2)
