@@ -176,6 +176,29 @@ def test_numeric_range_fallbacks(fe, scale, depth_cov, max_dist):
             fe.release_node(f)
 
 
+def test_config5_4000_keypoints_all_pairs_match_oracle():
+    """BASELINE configs[4]: 4000 keypoints per node, all-pairs candidate list."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    F = 6
+    fe5 = FrontEnd(device_id=0, max_nodes=F, max_keypoints=4096, max_pairs_per_batch=64)
+    try:
+        seq = synth.make_sequence(n_frames=F, n_kp=4000, n_world=12000, seed=55)
+        for f in range(F):
+            fe5.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+        pq = np.array([q for q in range(F) for t in range(q)], np.int32)
+        pt = np.array([t for q in range(F) for t in range(q)], np.int32)
+        out = fe5.match_pair_list(pq, pt)
+        prm = po.default_params(seed=fe5.params.seed, depth_cov=fe5.params.depth_cov)
+        refs = po.match_pairs_mt(list(seq["desc"]), list(seq["xyz1"]), np.arange(F), pq, pt, prm)
+        for rec, r in zip(out, refs):
+            check_against_oracle(rec, po.result_to_dict(r))
+        # the live-SLAM shape: one new node against a few candidates (train rows split over blocks)
+        one = fe5.match_node_pairs(F - 1, np.arange(F - 1, dtype=np.int32))
+        assert one.tobytes() == out[pq == F - 1].tobytes()
+    finally:
+        fe5.close()
+
+
 def test_full_size_properties(fe):
     """BASELINE configs[1] size (1000 kp, 20 candidates/frame) through size-independent properties:
     determinism, self-match identity, ground-truth pose recovery, inlier-set consistency."""
