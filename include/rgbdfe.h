@@ -182,6 +182,41 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
                               int32_t use_root_sift, int32_t* kept_idx, float* xyz1,
                               float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out);
 
+/* ---- frame-level data either side of the pair path ----------------
+ * rgbdfe_depth_to_mono8: depthToCV8UC1 (misc.cpp:414-430), the detection mask the listener derives from
+ *   the depth image.  depth_is_u16 == 0: depth is rows x cols f32 (metres), mono8 = convertTo(CV_8UC1, 100)
+ *   (:418), depth_m is ignored.  depth_is_u16 != 0: depth is u16 millimetres, mono8 = convertTo(CV_8UC1,
+ *   0.05, -25) (:423) and depth_m (required) = the float image in metres (:424-425).
+ * rgbdfe_upload_node_cloud: createXYZRGBPointCloud (misc.cpp:467-556) on the device.  Builds the node's
+ *   structured cloud -- (rows/cloud_skip) x (cols/cloud_skip) points of 4 floats (x, y, z, rgb bits
+ *   0x00RRGGBB) -- from its depth image (f32, metres x depth_scaling; Z < min_depth or NaN -> z = NaN with
+ *   x, y at 1 m, :525-530) and keeps it resident under node_id (Node::pc_col) for the environment measurement
+ *   model; rgb (rows x cols x rgb_channels u8, channels 1 or 3, may be NULL) only colours the points.
+ *   cloud_skip = cloud_creation_skip_step must divide rows and cols (the reference crashes otherwise, :479).
+ *   cloud_out (may be NULL) receives a copy.  rgbdfe_release_node also drops the node's cloud.
+ * rgbdfe_observation_likelihood: observationLikelihood (misc.cpp:814-969) for a batch of directed edges:
+ *   job i projects the cloud of new_ids[i], transformed by transforms[i] (16 floats, column-major, new ->
+ *   old), into the raster of old_ids[i] and classifies every emm_skip_step-th point (parameter
+ *   "emm__skip_step", 8) against the old depth.  pairwiseObservationLikelihood (node.cpp:1520-1554) is two
+ *   jobs per edge, (newer, older, final_trafo) and (older, newer, final_trafo.inverse()), with the counts
+ *   summed; matchNodePair then keeps the edge iff rgbdfe_observation_criterion_met(inliers, outliers,
+ *   occluded + inliers + outliers, observability_threshold) (node.cpp:1341-1342, misc.cpp:1136-1148).
+ *   depth_covariance() is params.depth_cov (the reference's frozen static, misc2.h:30-35). */
+typedef struct rgbdfe_emm_counts {
+  uint32_t inliers, outliers, occluded, all;
+} rgbdfe_emm_counts;
+int rgbdfe_depth_to_mono8(rgbdfe_ctx* ctx, const void* depth, int32_t depth_is_u16, int32_t rows, int32_t cols,
+                          uint8_t* mono8, float* depth_m);
+int rgbdfe_upload_node_cloud(rgbdfe_ctx* ctx, int32_t node_id, const float* depth, int32_t rows, int32_t cols,
+                             const uint8_t* rgb, int32_t rgb_channels, int32_t encoding_bgr, double fx,
+                             double fy, double cx, double cy, double depth_scaling, double min_depth,
+                             int32_t cloud_skip, float* cloud_out);
+int rgbdfe_release_node_cloud(rgbdfe_ctx* ctx, int32_t node_id);
+int rgbdfe_observation_likelihood(rgbdfe_ctx* ctx, int32_t n, const int32_t* new_ids, const int32_t* old_ids,
+                                  const float* transforms, int32_t emm_skip_step, rgbdfe_emm_counts* out);
+int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32_t all,
+                                     double observability_threshold, double* quality);
+
 /* ---- per-frame feature path: detect + describe (Node::Node, node.cpp:139-210) -----------------
  * rgbdfe_detect_describe replaces, for one frame,
  *   detector->detect(gray, kps, mask)   the 3x3 grid of threshold-adaptive ORB detectors built by
@@ -221,7 +256,7 @@ int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32
 /* When enabled, every launch of the dominant kernels is bracketed by HIP events on the
  * stream it runs on; totals are read back with rgbdfe_get_kernel_time. */
 enum { RGBDFE_KERNEL_HAMMING = 0, RGBDFE_KERNEL_RANSAC = 1, RGBDFE_KERNEL_SIFT_DOT = 2,
-       RGBDFE_KERNEL_SIFT_FINISH = 3, RGBDFE_KERNEL_COUNT = 4 };
+       RGBDFE_KERNEL_SIFT_FINISH = 3, RGBDFE_KERNEL_EMM = 4, RGBDFE_KERNEL_COUNT = 5 };
 int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable);
 int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t* launches,
                            int64_t* pairs);

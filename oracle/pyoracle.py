@@ -107,6 +107,20 @@ def lib():
         L.orc_gather_rows_f32.argtypes = [vp, vp, C.c_int, C.c_int, vp]
         L.orc_root_sift.restype = None
         L.orc_root_sift.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_depth_to_mono8_f32.restype = None
+        L.orc_depth_to_mono8_f32.argtypes = [vp, C.c_size_t, vp]
+        L.orc_depth_u16_to_mono8_f32.restype = None
+        L.orc_depth_u16_to_mono8_f32.argtypes = [vp, C.c_size_t, vp, vp]
+        L.orc_create_point_cloud.restype = None
+        L.orc_create_point_cloud.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                             C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, vp]
+        L.orc_observation_likelihood.restype = None
+        L.orc_observation_likelihood.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_double,
+                                                 C.c_double, C.c_int, C.c_int, C.c_double, vp]
+        L.orc_emm_erf_boundaries.restype = None
+        L.orc_emm_erf_boundaries.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_observation_criterion_met.restype = C.c_int
+        L.orc_observation_criterion_met.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_double, C.POINTER(C.c_double)]
         L.orc_project_to_3d.restype = C.c_int
         L.orc_project_to_3d.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_double,
                                         C.c_double, C.c_double, C.c_double, C.c_int, vp, vp]
@@ -286,6 +300,56 @@ def sift_node_features(kp_xy, desc, depth, fx, fy, cx, cy, depth_scaling=1.0, ma
     if use_root_sift and k > 0:
         lib().orc_root_sift(_p(feat), k, desc.shape[1])
     return kept[:k].copy(), xyz1[:k].copy(), raw, feat
+
+
+def depth_to_mono8(depth):
+    depth = np.ascontiguousarray(depth)
+    mono8 = np.empty(depth.shape, np.uint8)
+    if depth.dtype == np.uint16:
+        dm = np.empty(depth.shape, np.float32)
+        lib().orc_depth_u16_to_mono8_f32(_p(depth), depth.size, _p(mono8), _p(dm))
+        return mono8, dm
+    depth = np.ascontiguousarray(depth, np.float32)
+    lib().orc_depth_to_mono8_f32(_p(depth), depth.size, _p(mono8))
+    return mono8
+
+
+def create_point_cloud(depth, fx, fy, cx, cy, rgb=None, encoding_bgr=False, depth_scaling=1.0, min_depth=0.1,
+                       cloud_skip=2):
+    depth = np.ascontiguousarray(depth, np.float32)
+    rows, cols = depth.shape
+    ch = 1
+    if rgb is not None:
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        ch = 1 if rgb.ndim == 2 else rgb.shape[2]
+    out = np.empty((-(-rows // cloud_skip), -(-cols // cloud_skip), 4), np.float32)
+    lib().orc_create_point_cloud(_p(depth), rows, cols, _p(rgb) if rgb is not None else None, ch,
+                                 int(bool(encoding_bgr)), fx, fy, cx, cy, depth_scaling, min_depth,
+                                 int(cloud_skip), _p(out))
+    return out
+
+
+def observation_likelihood(new_cloud, old_cloud, T, fx, fy, cx, cy, cloud_skip=2, skip_step=8, depth_cov=1e-4):
+    """T: 4x4 row-major new -> old.  Returns uint32[4] = (inliers, outliers, occluded, all)."""
+    new_cloud = np.ascontiguousarray(new_cloud, np.float32)
+    old_cloud = np.ascontiguousarray(old_cloud, np.float32)
+    T = np.ascontiguousarray(T, np.float32)
+    out = np.zeros(4, np.uint32)
+    lib().orc_observation_likelihood(_p(new_cloud), _p(old_cloud), old_cloud.shape[0], old_cloud.shape[1], _p(T),
+                                     fx, fy, cx, cy, int(cloud_skip), int(skip_step), depth_cov, _p(out))
+    return out
+
+
+def emm_erf_boundaries():
+    lo, hi = C.c_double(0), C.c_double(0)
+    lib().orc_emm_erf_boundaries(C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def observation_criterion_met(inliers, outliers, all_points, obs_thresh):
+    q = C.c_double(0)
+    return bool(lib().orc_observation_criterion_met(int(inliers), int(outliers), int(all_points), obs_thresh,
+                                                    C.byref(q))), q.value
 
 
 def num_cores():

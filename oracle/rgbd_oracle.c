@@ -715,6 +715,185 @@ void orc_root_sift(float* desc, int n_rows, int dim) {
   }
 }
 
+/* ========================================================================= */
+/* SURVEY 8(f) "next" rows 3 and 2: the data either side of the pair path        */
+/*   depthToCV8UC1            misc.cpp:414-430  (detection mask from depth)       */
+/*   createXYZRGBPointCloud   misc.cpp:467-556  (structured cloud of a frame)      */
+/*   observationLikelihood    misc.cpp:814-969  (environment measurement model,    */
+/*                            called from matchNodePair, node.cpp:1340-1343, when  */
+/*                            observability_threshold > 0)                          */
+/*   observation_criterion_met misc.cpp:1136-1148                                    */
+/* Third-party arithmetic (OpenCV convertTo, pcl::transformPointCloud) is restated   */
+/* from the published sources: "parity unpinned".                                    */
+/* ========================================================================= */
+
+/* cv::Mat::convertTo(CV_8UC1, alpha, beta) for a float source: saturate_cast<uchar>(cvRound(v*alpha + beta))
+ * with the product and sum in float (cvtScale_<float, uchar, float>) and cvRound = round-half-to-even
+ * (cvtss2si); NaN and out-of-int-range values convert to INT_MIN, which saturates to 0. */
+static uint8_t orc_sat_u8_from_float(float t) {
+  if (!(t > -2147483648.0f && t < 2147483648.0f)) return 0; /* cvtss2si "integer indefinite" -> saturates to 0 */
+  const int r = (int)lrintf(t); /* current rounding mode: nearest-even */
+  return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+/* depthToCV8UC1, CV_32FC1 branch (misc.cpp:417-418): mono8 = convertTo(CV_8UC1, 100, 0) */
+void orc_depth_to_mono8_f32(const float* depth, size_t n, uint8_t* mono8) {
+  for (size_t i = 0; i < n; ++i) mono8[i] = orc_sat_u8_from_float(depth[i] * 100.0f + 0.0f);
+}
+/* CV_16UC1 branch (misc.cpp:420-426): mono8 = convertTo(CV_8UC1, 0.05, -25), depth(float, metres) =
+ * convertTo(CV_32FC1, 0.001, 0) */
+void orc_depth_u16_to_mono8_f32(const uint16_t* depth_mm, size_t n, uint8_t* mono8, float* depth_m) {
+  for (size_t i = 0; i < n; ++i) {
+    const float v = (float)depth_mm[i];
+    mono8[i] = orc_sat_u8_from_float(v * 0.05f + -25.0f);
+    depth_m[i] = v * 0.001f + 0.0f;
+  }
+}
+
+/* createXYZRGBPointCloud (misc.cpp:467-556), depth and colour image of the same size, skip step s.
+ * cloud: ceil(rows/s) x ceil(cols/s) points of 4 floats (x, y, z, rgb bits).  rgb may be NULL (colour
+ * bits 0), channels 1 or 3, encoding_bgr swaps red and blue (:488).  Quirk kept: the colour of the very
+ * first pixel is never written (`color_idx > 0`, :536): its rgb stays 0. */
+void orc_create_point_cloud(const float* depth, int rows, int cols, const uint8_t* rgb, int channels,
+                            int encoding_bgr, double fx, double fy, double cx_d, double cy_d,
+                            double depth_scaling, double min_depth_d, int s, float* cloud) {
+  float fxinv = (float)fx, fyinv = (float)fy; /* getCameraIntrinsics assigns double -> float (:59-62) */
+  const float cx = (float)cx_d, cy = (float)cy_d;
+  fxinv = (float)(1. / fxinv); /* :67-68 */
+  fyinv = (float)(1. / fyinv);
+  const int ch = (int)ceil(rows / (float)s), cw = (int)ceil(cols / (float)s); /* :482-483 */
+  const float min_depth = (float)min_depth_d;                                   /* :506 */
+  const unsigned int pix = (unsigned int)channels;
+  const unsigned int color_pix_step = pix * (unsigned int)(cols / cw);                          /* :491 */
+  const unsigned int color_row_step = pix * (unsigned int)(rows / ch - 1) * (unsigned int)cols; /* :492 */
+  const unsigned int depth_pix_step = (unsigned int)(cols / cw);                                /* :493 */
+  const unsigned int depth_row_step = (unsigned int)(rows / ch - 1) * (unsigned int)cols;       /* :494 */
+  const int red_idx = (channels == 3 && encoding_bgr) ? 2 : 0, green_idx = 1;
+  const int blue_idx = (channels == 3 && encoding_bgr) ? 0 : 2;
+  const size_t color_total = (size_t)rows * (size_t)cols * color_pix_step; /* rgb_img.total()*color_pix_step */
+  unsigned int color_idx = 0, depth_idx = 0;
+  size_t k = 0;
+  const size_t n_pts = (size_t)ch * (size_t)cw;
+  for (size_t i = 0; i < n_pts; ++i) { cloud[4 * i] = cloud[4 * i + 1] = cloud[4 * i + 2] = 0.f; cloud[4 * i + 3] = 0.f; }
+  for (int v = 0; v < rows; v += s, color_idx += color_row_step, depth_idx += depth_row_step) {
+    for (int u = 0; u < cols; u += s, color_idx += color_pix_step, depth_idx += depth_pix_step, ++k) {
+      if (k == n_pts) break; /* :514 */
+      float* pt = cloud + 4 * k;
+      const float Z = (float)((double)depth[depth_idx] * depth_scaling); /* :522 */
+      if (!(Z >= min_depth)) { /* :525, also NaN */
+        pt[0] = (float)((double)((float)u - cx) * 1.0 * (double)fxinv); /* :527 */
+        pt[1] = (float)((double)((float)v - cy) * 1.0 * (double)fyinv);
+        pt[2] = NAN;
+      } else { /* backProject(fxinv, fyinv, cx, cy, u, v, Z, ...), misc2.h:62-64 with u, v as float */
+        pt[0] = ((float)u - cx) * Z * fxinv;
+        pt[1] = ((float)v - cy) * Z * fyinv;
+        pt[2] = Z;
+      }
+      if (rgb && color_idx > 0 && (size_t)color_idx < color_total) { /* :536 */
+        uint32_t r, g, b;
+        if (channels == 3) {
+          r = rgb[color_idx + red_idx]; g = rgb[color_idx + green_idx]; b = rgb[color_idx + blue_idx];
+        } else {
+          r = g = b = rgb[color_idx];
+        }
+        const uint32_t bits = b | (g << 8) | (r << 16); /* RGBValue: Blue, Green, Red, Alpha = 0 */
+        memcpy(pt + 3, &bits, 4);
+      }
+    }
+  }
+}
+
+/* observationLikelihood (misc.cpp:814-969): the new frame's cloud, transformed by T (new -> old, row-major
+ * 4x4 float), is projected into the old frame's raster; every emm__skip_step-th point is classified against
+ * the old cloud's depth in a 5x5 neighbourhood sampled with step 2.  Returns inliers / outliers / occluded /
+ * all.  fx..cy are the OLD camera's intrinsics (already assigned to float by getCameraIntrinsics) and are
+ * divided by cloud_skip (:866-871); depth_covariance() is the frozen value (a18) = depth_cov.
+ * pcl::transformPointCloud on a non-dense cloud (PCL 1.7 common/impl/transforms.hpp) leaves points with a
+ * non-finite coordinate untouched and computes the others as
+ *   x' = T00*x + T01*y + T02*z + T03   (float, left to right). */
+void orc_observation_likelihood(const float* new_cloud, const float* old_cloud, int ch, int cw,
+                                const float* T, double fx_d, double fy_d, double cx_d, double cy_d,
+                                int cloud_skip, int skip_step, double depth_cov, uint32_t counts[4]) {
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  if (skip_step <= 0 || ch <= 1 || cw <= 1) { counts[0] = counts[3] = 1; return; } /* :829-843 */
+  float fx = (float)fx_d, fy = (float)fy_d, cx = (float)cx_d, cy = (float)cy_d;
+  fx = fx / cloud_skip; fy = fy / cloud_skip; cx = cx / cloud_skip; cy = cy / cloud_skip; /* :868-871 */
+  unsigned int good_points = 0, bad_points = 0, occluded_points = 0, all = 0;
+  for (int new_ry = 0; new_ry < ch; new_ry += skip_step) {
+    for (int new_rx = 0; new_rx < cw; new_rx += skip_step, all++) {
+      const float* q = new_cloud + 4 * ((size_t)new_ry * cw + new_rx);
+      float px = q[0], py = q[1], pz = q[2];
+      if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+        const float x = px, y = py, z = pz;
+        px = T[0] * x + T[1] * y + T[2] * z + T[3];
+        py = T[4] * x + T[5] * y + T[6] * z + T[7];
+        pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+      }
+      if (pz != pz) continue;  /* :886 */
+      if (pz < 0) continue;    /* :887 */
+      /* round(float d) = (int)floor(d + 0.5) with the sum in double (:804-807); the reference's cast of a
+       * non-finite or huge value is undefined: such projections are treated as outside the raster */
+      const double dx = floor((double)((px / pz) * fx + cx) + 0.5);
+      const double dy = floor((double)((py / pz) * fy + cy) + 0.5);
+      if (!(dx >= 0.0 && dx < (double)cw && dy >= 0.0 && dy < (double)ch)) continue; /* :891-896 */
+      const int old_rx_center = (int)dx, old_ry_center = (int)dy;
+      const int nbhd = 2;
+      int good_point = 0, occluded_point = 0, bad_point = 0;
+      const int startx = old_rx_center - nbhd > 0 ? old_rx_center - nbhd : 0;
+      const int starty = old_ry_center - nbhd > 0 ? old_ry_center - nbhd : 0;
+      const int endx = cw < old_rx_center + nbhd + 1 ? cw : old_rx_center + nbhd + 1;
+      const int endy = ch < old_ry_center + nbhd + 1 ? ch : old_ry_center + nbhd + 1;
+      for (int old_ry = starty; old_ry < endy; old_ry += 2) {
+        for (int old_rx = startx; old_rx < endx; old_rx += 2) {
+          const float oz = old_cloud[4 * ((size_t)old_ry * cw + old_rx) + 2];
+          if (oz != oz) continue; /* :911 */
+          const double old_sigma = cloud_skip * depth_cov; /* :914 */
+          const double new_sigma = cloud_skip * depth_cov; /* :916 */
+          const double joint_sigma = old_sigma + new_sigma;
+          /* cdf(old_p.z, p.z, sqrt(joint_sigma)), :809-812 with SQRT_2 = 1.41421 (:801) */
+          const double sigma = sqrt(joint_sigma);
+          const double p_new_in_front = 0.5 * (1 + erf(((double)oz - (double)pz) / (sigma * 1.41421)));
+          if (p_new_in_front < 0.001) occluded_point = 1;
+          else if (p_new_in_front < 0.999) good_point = 1;
+          else bad_point = 1;
+        }
+      }
+      if (good_point) good_points++;
+      else if (occluded_point) occluded_points++;
+      else if (bad_point) bad_points++;
+    }
+  }
+  counts[0] = good_points; counts[1] = bad_points; counts[2] = occluded_points; counts[3] = all;
+}
+
+/* Boundaries of the two cdf tests as arguments of erf: the smallest doubles q with
+ * 0.5*(1+erf(q)) >= 0.001 resp. >= 0.999 under THIS libm (bisection).  For a monotone erf,
+ * p < 0.001 <=> q < q_lo and p < 0.999 <=> q < q_hi; the device compares against these constants instead of
+ * evaluating erf. */
+void orc_emm_erf_boundaries(double* q_lo, double* q_hi) {
+  const double target[2] = {0.001, 0.999};
+  double out[2];
+  for (int k = 0; k < 2; ++k) {
+    double lo = -8.0, hi = 8.0; /* f(lo) < target <= f(hi) */
+    for (;;) {
+      const double mid = lo + (hi - lo) * 0.5;
+      if (!(mid > lo && mid < hi)) break;
+      if (0.5 * (1 + erf(mid)) >= target[k]) hi = mid; else lo = mid;
+    }
+    out[k] = hi;
+  }
+  *q_lo = out[0];
+  *q_hi = out[1];
+}
+
+/* observation_criterion_met (misc.cpp:1136-1148) */
+int orc_observation_criterion_met(unsigned int inliers, unsigned int outliers, unsigned int all,
+                                  double obs_thresh, double* quality) {
+  if (obs_thresh < 0) return 1;
+  *quality = inliers / (double)(inliers + outliers);
+  const double certainty = inliers / (double)all;
+  return (*quality > obs_thresh) && (certainty > 0.25);
+}
+
 
 /* ========================================================================= */
 /* SIFT (128-d float descriptor) matcher: SiftGPUWrapper::match semantics      */

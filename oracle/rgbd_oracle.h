@@ -21,6 +21,7 @@
  */
 #ifndef RGBD_ORACLE_H
 #define RGBD_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -95,6 +96,18 @@ int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows
                       int max_keypoints, int32_t* kept_idx, float* xyz1);
 int orc_num_cores(void);
 /* SiftGPUWrapper::match (sift_gpu_wrapper.cpp:169-227) over the CUDA SiftMatchGPU kernels */
+/* SURVEY 8(f) rows 3 + 2: depthToCV8UC1, createXYZRGBPointCloud, observationLikelihood (misc.cpp) */
+void orc_depth_to_mono8_f32(const float* depth, size_t n, uint8_t* mono8);
+void orc_depth_u16_to_mono8_f32(const uint16_t* depth_mm, size_t n, uint8_t* mono8, float* depth_m);
+void orc_create_point_cloud(const float* depth, int rows, int cols, const uint8_t* rgb, int channels,
+                            int encoding_bgr, double fx, double fy, double cx, double cy,
+                            double depth_scaling, double min_depth, int skip_step, float* cloud);
+void orc_observation_likelihood(const float* new_cloud, const float* old_cloud, int ch, int cw,
+                                const float* T, double fx, double fy, double cx, double cy,
+                                int cloud_skip, int skip_step, double depth_cov, uint32_t counts[4]);
+void orc_emm_erf_boundaries(double* q_lo, double* q_hi);
+int orc_observation_criterion_met(unsigned int inliers, unsigned int outliers, unsigned int all,
+                                  double obs_thresh, double* quality);
 /* a20: projectTo3DSiftGPU (node.cpp:695-769) and squareroot_descriptor_space (node.cpp:1557-1571) */
 int orc_project_to_3d_sift(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                            double fx, double fy, double cx, double cy, double depth_scaling,

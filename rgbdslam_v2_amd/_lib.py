@@ -19,6 +19,7 @@ KERNEL_HAMMING = 0
 KERNEL_RANSAC = 1
 KERNEL_SIFT_DOT = 2
 KERNEL_SIFT_FINISH = 3
+KERNEL_EMM = 4
 
 
 class RgbdfeParams(C.Structure):
@@ -164,6 +165,18 @@ def load():
     L.rgbdfe_sift_node_features.argtypes = [ctx, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
                                             C.c_double, C.c_double, C.c_double, i32, i32, vp, vp, vp, vp,
                                             C.POINTER(i32)]
+    L.rgbdfe_depth_to_mono8.restype = C.c_int
+    L.rgbdfe_depth_to_mono8.argtypes = [ctx, vp, i32, i32, i32, vp, vp]
+    L.rgbdfe_upload_node_cloud.restype = C.c_int
+    L.rgbdfe_upload_node_cloud.argtypes = [ctx, i32, vp, i32, i32, vp, i32, i32, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_double, C.c_double, i32, vp]
+    L.rgbdfe_release_node_cloud.restype = C.c_int
+    L.rgbdfe_release_node_cloud.argtypes = [ctx, i32]
+    L.rgbdfe_observation_likelihood.restype = C.c_int
+    L.rgbdfe_observation_likelihood.argtypes = [ctx, i32, vp, vp, vp, i32, vp]
+    L.rgbdfe_observation_criterion_met.restype = C.c_int
+    L.rgbdfe_observation_criterion_met.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                                   C.POINTER(C.c_double)]
     L.rgbdfe_set_profiling.restype = C.c_int
     L.rgbdfe_set_profiling.argtypes = [ctx, C.c_int]
     L.rgbdfe_get_kernel_time.restype = C.c_int
@@ -190,6 +203,8 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket", "rgbdfe_upload_sift_node",
     "rgbdfe_match_sift_pair_list", "rgbdfe_submit_sift_pair_list", "rgbdfe_sift_match_nodes",
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
-    "rgbdfe_project_to_3d", "rgbdfe_sift_node_features", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
+    "rgbdfe_project_to_3d", "rgbdfe_sift_node_features", "rgbdfe_depth_to_mono8",
+    "rgbdfe_upload_node_cloud", "rgbdfe_release_node_cloud", "rgbdfe_observation_likelihood",
+    "rgbdfe_observation_criterion_met", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
     "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
 ]

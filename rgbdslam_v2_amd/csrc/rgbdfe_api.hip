@@ -22,6 +22,33 @@ using namespace rgbdfe;
 
 namespace {
 
+// a frame's structured point cloud, resident for the environment measurement model
+struct CloudEntry {
+  float4* d = nullptr;  // ch x cw points, followed by the ch x cw depth plane (z only) the EMM gathers from
+  int ch = 0, cw = 0;
+  float fx = 0, fy = 0, cx = 0, cy = 0;  // as getCameraIntrinsics assigns them (double -> float)
+  int cloud_skip = 1;                    // cloud_creation_skip_step the cloud was built with
+};
+
+// smallest double q with 0.5 * (1 + erf(q)) >= target under the host's libm (bisection)
+inline double erf_boundary(double target) {
+  double lo = -8.0, hi = 8.0;
+  for (;;) {
+    const double mid = lo + (hi - lo) * 0.5;
+    if (!(mid > lo && mid < hi)) break;
+    if (0.5 * (1 + std::erf(mid)) >= target) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
+// smallest double d with d / denom >= q (denom > 0): the exact pre-image of the test `d / denom < q`
+inline double division_boundary(double q, double denom) {
+  double c = q * denom;
+  while (c / denom >= q) c = std::nextafter(c, -INFINITY);
+  while (c / denom < q) c = std::nextafter(c, INFINITY);
+  return c;
+}
+
 struct NodeEntry {
   uint32_t slot;
   uint32_t n;
@@ -89,14 +116,16 @@ struct rgbdfe_ctx {
   OrbWorkspace orb;
   int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;
+  std::unordered_map<int32_t, CloudEntry> clouds;
+  double emm_q_lo = 0.0, emm_q_hi = 0.0;  // cdf boundaries 0.001 / 0.999 as arguments of erf
   std::vector<uint32_t> free_slots;
   RansacConst rc{};
   // profiling
   bool profiling = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  double k_ms[RGBDFE_KERNEL_COUNT] = {0, 0, 0, 0};
-  int64_t k_launches[RGBDFE_KERNEL_COUNT] = {0, 0, 0, 0};
-  int64_t k_pairs[RGBDFE_KERNEL_COUNT] = {0, 0, 0, 0};
+  double k_ms[RGBDFE_KERNEL_COUNT] = {};
+  int64_t k_launches[RGBDFE_KERNEL_COUNT] = {};
+  int64_t k_pairs[RGBDFE_KERNEL_COUNT] = {};
   // ORB batch: a -[hamming]- b -[ransac]- c ; SIFT batch: a -[dot]- b -[finish]- c -[ransac]- d
   struct Pending { hipEvent_t a, b, c, d; int32_t pairs; bool sift; };
   std::vector<Pending> pending;
@@ -356,6 +385,8 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
     if (hipMalloc((void**)&ln.d_results, np * sizeof(rgbdfe_match_result)) != hipSuccess)
       return bail(RGBDFE_ERR_OUT_OF_MEMORY);
   }
+  ctx->emm_q_lo = erf_boundary(0.001);
+  ctx->emm_q_hi = erf_boundary(0.999);
   ctx->free_slots.reserve(cfg->max_nodes);
   for (int32_t s = cfg->max_nodes - 1; s >= 0; --s) ctx->free_slots.push_back((uint32_t)s);
   *out = ctx;
@@ -375,6 +406,8 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (sl.h_work) (void)hipHostFree(sl.h_work);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
+  for (auto& kv : ctx->clouds)
+    if (kv.second.d) (void)hipFree(kv.second.d);
   if (ctx->d_sift_bf16) (void)hipFree(ctx->d_sift_bf16);
   if (ctx->d_sift_f32) (void)hipFree(ctx->d_sift_f32);
   for (auto& ln : ctx->lanes) {
@@ -468,6 +501,12 @@ int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id) {
   for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   ctx->free_slots.push_back(it->second.slot);
   ctx->nodes.erase(it);
+  auto ci = ctx->clouds.find(node_id);
+  if (ci != ctx->clouds.end()) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ci->second.d) (void)hipFree(ci->second.d);
+    ctx->clouds.erase(ci);
+  }
   return RGBDFE_OK;
 }
 
@@ -1001,6 +1040,171 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
   }
   *n_out = n;
   return RGBDFE_OK;
+}
+
+int rgbdfe_depth_to_mono8(rgbdfe_ctx* ctx, const void* depth, int32_t depth_is_u16, int32_t rows, int32_t cols,
+                          uint8_t* mono8, float* depth_m) {
+  if (!ctx || !depth || !mono8 || rows < 1 || cols < 1 || (depth_is_u16 && !depth_m))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  const size_t n = (size_t)rows * (size_t)cols;
+  const size_t b_in = ((n * (depth_is_u16 ? 2 : 4)) + 255) & ~(size_t)255;
+  const size_t b_m8 = (n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, b_in + b_m8 + n * 4 + 256);
+  if (rc != RGBDFE_OK) return rc;
+  char* p = (char*)ctx->d_scratch;
+  void* d_in = p;
+  uint8_t* d_m8 = (uint8_t*)(p + b_in);
+  float* d_f = (float*)(p + b_in + b_m8);
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, depth, n * (depth_is_u16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
+  if (depth_is_u16) launch_depth_u16((const uint16_t*)d_in, n, d_m8, d_f, ctx->stream);
+  else launch_depth_to_mono8_f32((const float*)d_in, n, d_m8, ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(mono8, d_m8, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (depth_is_u16) HIP_TRY(ctx, hipMemcpyAsync(depth_m, d_f, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RGBDFE_OK;
+}
+
+int rgbdfe_upload_node_cloud(rgbdfe_ctx* ctx, int32_t node_id, const float* depth, int32_t rows, int32_t cols,
+                             const uint8_t* rgb, int32_t rgb_channels, int32_t encoding_bgr, double fx,
+                             double fy, double cx, double cy, double depth_scaling, double min_depth,
+                             int32_t cloud_skip, float* cloud_out) {
+  if (!ctx || !depth || rows < 1 || cols < 1 || cloud_skip < 1 || (rgb && rgb_channels != 1 && rgb_channels != 3))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  if (rows % cloud_skip != 0 || cols % cloud_skip != 0)  // misc.cpp:479-481: "will most likely crash"
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "cloud_creation_skip_step must divide the image dimensions");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  const int ch = rows / cloud_skip, cw = cols / cloud_skip;
+  const size_t n = (size_t)rows * (size_t)cols;
+  const size_t b_depth = (n * 4 + 255) & ~(size_t)255;
+  const size_t b_rgb = rgb ? ((n * (size_t)rgb_channels + 255) & ~(size_t)255) : 0;
+  int rc = ensure_scratch(ctx, b_depth + b_rgb + 256);
+  if (rc != RGBDFE_OK) return rc;
+  float* d_depth = (float*)ctx->d_scratch;
+  uint8_t* d_rgb = rgb ? (uint8_t*)ctx->d_scratch + b_depth : nullptr;
+  CloudEntry& ce = ctx->clouds[node_id];
+  if (ce.d && (ce.ch != ch || ce.cw != cw)) {
+    for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+    (void)hipFree(ce.d);
+    ce.d = nullptr;
+  }
+  if (!ce.d) {
+    if (hipMalloc((void**)&ce.d, (size_t)ch * cw * (sizeof(float4) + sizeof(float))) != hipSuccess) {
+      ctx->clouds.erase(node_id);
+      return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "cloud allocation failed");
+    }
+  }
+  ce.ch = ch; ce.cw = cw; ce.cloud_skip = cloud_skip;
+  ce.fx = (float)fx; ce.fy = (float)fy; ce.cx = (float)cx; ce.cy = (float)cy;  // misc.cpp:59-62
+  HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (rgb) HIP_TRY(ctx, hipMemcpyAsync(d_rgb, rgb, n * (size_t)rgb_channels, hipMemcpyHostToDevice, ctx->stream));
+  // getCameraIntrinsicsInverseFocalLength (misc.cpp:64-69): 1./float(fx) assigned to float
+  const float fxinv = (float)(1. / ce.fx), fyinv = (float)(1. / ce.fy);
+  launch_create_cloud(d_depth, rows, cols, d_rgb, rgb ? rgb_channels : 1, encoding_bgr, fxinv, fyinv, ce.cx, ce.cy,
+                      depth_scaling, (float)min_depth, cloud_skip, ch, cw, ce.d,
+                      reinterpret_cast<float*>(ce.d + (size_t)ch * cw), ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  if (cloud_out)
+    HIP_TRY(ctx, hipMemcpyAsync(cloud_out, ce.d, (size_t)ch * cw * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RGBDFE_OK;
+}
+
+int rgbdfe_release_node_cloud(rgbdfe_ctx* ctx, int32_t node_id) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  auto it = ctx->clouds.find(node_id);
+  if (it == ctx->clouds.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "no cloud for this node");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (it->second.d) (void)hipFree(it->second.d);
+  ctx->clouds.erase(it);
+  return RGBDFE_OK;
+}
+
+int rgbdfe_observation_likelihood(rgbdfe_ctx* ctx, int32_t n, const int32_t* new_ids, const int32_t* old_ids,
+                                  const float* transforms, int32_t emm_skip_step, rgbdfe_emm_counts* out) {
+  if (!ctx || n < 0 || (n > 0 && (!new_ids || !old_ids || !transforms || !out)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  if (n == 0) return RGBDFE_OK;
+  if (emm_skip_step <= 0) {  // misc.cpp:829-832 (skip_step < 0; 0 would not terminate in the reference)
+    for (int32_t i = 0; i < n; ++i) { out[i].inliers = out[i].all = 1; out[i].outliers = out[i].occluded = 0; }
+    return RGBDFE_OK;
+  }
+  std::vector<EmmJob> jobs((size_t)n);
+  int ch = 0, cw = 0, cloud_skip = 1;
+  for (int32_t i = 0; i < n; ++i) {
+    auto a = ctx->clouds.find(new_ids[i]);
+    auto b = ctx->clouds.find(old_ids[i]);
+    if (a == ctx->clouds.end() || b == ctx->clouds.end())
+      return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "observation likelihood needs the clouds of both nodes");
+    const CloudEntry& cn = a->second;
+    const CloudEntry& co = b->second;
+    if (i == 0) { ch = co.ch; cw = co.cw; cloud_skip = co.cloud_skip; }
+    if (cn.ch != ch || cn.cw != cw || co.ch != ch || co.cw != cw || co.cloud_skip != cloud_skip)
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG, "clouds of one batch must share their dimensions");  // misc.cpp:845
+    EmmJob& jb = jobs[(size_t)i];
+    jb.new_cloud = cn.d;
+    jb.old_z = reinterpret_cast<const float*>(co.d + (size_t)co.ch * co.cw);
+    const float* T = transforms + (size_t)i * 16;  // column-major like rgbdfe_match_result.trafo
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) jb.T[r * 4 + c] = T[c * 4 + r];
+    jb.fx = co.fx / cloud_skip; jb.fy = co.fy / cloud_skip;  // misc.cpp:868-871
+    jb.cx = co.cx / cloud_skip; jb.cy = co.cy / cloud_skip;
+  }
+  if (ch <= 1 || cw <= 1) {  // misc.cpp:834-843: unstructured cloud
+    for (int32_t i = 0; i < n; ++i) { out[i].inliers = out[i].all = 1; out[i].outliers = out[i].occluded = 0; }
+    return RGBDFE_OK;
+  }
+  const size_t b_jobs = (sizeof(EmmJob) * (size_t)n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, b_jobs + (size_t)n * 16 + 256);
+  if (rc != RGBDFE_OK) return rc;
+  EmmJob* d_jobs = (EmmJob*)ctx->d_scratch;
+  uint32_t* d_counts = (uint32_t*)((char*)ctx->d_scratch + b_jobs);
+  HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(EmmJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  // cdf(x, mu, sigma) = 0.5 * (1 + erf((x - mu) / (sigma * SQRT_2))), sigma = sqrt(old_sigma + new_sigma),
+  // both = cloud_creation_skip_step * depth_covariance() (misc.cpp:809-812, 914-922; a18: frozen value)
+  const double s1 = cloud_skip * ctx->cfg.params.depth_cov;
+  const double denom = std::sqrt(s1 + s1) * 1.41421;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profiling) {
+    e0 = get_event(ctx); e1 = get_event(ctx);
+    (void)hipEventRecord(e0, ctx->stream);
+  }
+  if (!(denom > 0.0) || !std::isfinite(denom))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "depth_cov must be positive and finite for the measurement model");
+  const double d_lo = division_boundary(ctx->emm_q_lo, denom), d_hi = division_boundary(ctx->emm_q_hi, denom);
+  launch_emm(d_jobs, n, ch, cw, emm_skip_step, d_lo, d_hi, d_counts, ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(e1, ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_counts, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profiling) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+      ctx->k_ms[RGBDFE_KERNEL_EMM] += ms;
+      ctx->k_launches[RGBDFE_KERNEL_EMM]++;
+      ctx->k_pairs[RGBDFE_KERNEL_EMM] += n;
+    }
+    ctx->event_pool.push_back(e0);
+    ctx->event_pool.push_back(e1);
+  }
+  return RGBDFE_OK;
+}
+
+int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32_t all, double observability_threshold,
+                                     double* quality) {
+  // misc.cpp:1136-1148
+  if (observability_threshold < 0) return 1;
+  const double q = inliers / static_cast<double>(inliers + outliers);
+  if (quality) *quality = q;
+  const double certainty = inliers / static_cast<double>(all);
+  return (q > observability_threshold) && (certainty > 0.25) ? 1 : 0;
 }
 
 int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable) {

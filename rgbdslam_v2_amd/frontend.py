@@ -337,6 +337,73 @@ class FrontEnd:
         k = n_out.value
         return kept[:k].copy(), xyz1[:k].copy(), raw[:k].copy(), feat[:k].copy()
 
+    # -- frame-level data either side of the pair path ------
+    def depth_to_mono8(self, depth):
+        """depthToCV8UC1 (misc.cpp:414-430).  float32 metres -> mono8; uint16 millimetres -> (mono8, metres)."""
+        depth = np.ascontiguousarray(depth)
+        rows, cols = depth.shape
+        mono8 = np.empty((rows, cols), np.uint8)
+        if depth.dtype == np.uint16:
+            dm = np.empty((rows, cols), np.float32)
+            self._check(self._L.rgbdfe_depth_to_mono8(self._ctx, depth.ctypes.data, 1, rows, cols,
+                                                      mono8.ctypes.data, dm.ctypes.data))
+            return mono8, dm
+        depth = np.ascontiguousarray(depth, np.float32)
+        self._check(self._L.rgbdfe_depth_to_mono8(self._ctx, depth.ctypes.data, 0, rows, cols,
+                                                  mono8.ctypes.data, None))
+        return mono8
+
+    def upload_node_cloud(self, node_id, depth, fx, fy, cx, cy, rgb=None, encoding_bgr=False, depth_scaling=1.0,
+                          min_depth=0.1, cloud_skip=2, return_cloud=False):
+        """createXYZRGBPointCloud (misc.cpp:467-556): builds and keeps the node's structured cloud."""
+        depth = np.ascontiguousarray(depth, np.float32)
+        rows, cols = depth.shape
+        ch = 0
+        if rgb is not None:
+            rgb = np.ascontiguousarray(rgb, np.uint8)
+            ch = 1 if rgb.ndim == 2 else rgb.shape[2]
+            if rgb.shape[:2] != (rows, cols):
+                raise ValueError("rgb and depth must have the same size")
+        out = np.empty((rows // cloud_skip, cols // cloud_skip, 4), np.float32) if return_cloud else None
+        self._check(self._L.rgbdfe_upload_node_cloud(
+            self._ctx, int(node_id), depth.ctypes.data, rows, cols, rgb.ctypes.data if rgb is not None else None,
+            ch, int(bool(encoding_bgr)), fx, fy, cx, cy, depth_scaling, min_depth, int(cloud_skip),
+            out.ctypes.data if out is not None else None))
+        return out
+
+    def release_node_cloud(self, node_id):
+        self._check(self._L.rgbdfe_release_node_cloud(self._ctx, int(node_id)))
+
+    def observation_likelihood(self, new_ids, old_ids, transforms, emm_skip_step=8):
+        """observationLikelihood (misc.cpp:814-969) for a batch of directed edges; transforms: n x 4 x 4
+        (row-major numpy matrices, new -> old).  Returns an n x 4 uint32 array (inliers, outliers, occluded, all)."""
+        new_ids = np.ascontiguousarray(new_ids, np.int32)
+        old_ids = np.ascontiguousarray(old_ids, np.int32)
+        T = np.ascontiguousarray(np.asarray(transforms, np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))  # column-major
+        n = len(new_ids)
+        out = np.zeros((max(n, 1), 4), np.uint32)
+        self._check(self._L.rgbdfe_observation_likelihood(self._ctx, n, new_ids.ctypes.data, old_ids.ctypes.data,
+                                                          T.ctypes.data, int(emm_skip_step), out.ctypes.data))
+        return out[:n]
+
+    def pairwise_observation_likelihood(self, results, observability_threshold, emm_skip_step=8):
+        """pairwiseObservationLikelihood (node.cpp:1520-1554) + observation_criterion_met (misc.cpp:1136-1148)
+        for match results with an edge: returns (counts n x 4 summed over both directions, criterion_met)."""
+        results = np.asarray(results)
+        n = len(results)
+        T = np.array([np.array(r["trafo"], np.float32).reshape(4, 4).T for r in results], np.float32).reshape(-1, 4, 4)
+        Tinv = np.array([np.linalg.inv(t.astype(np.float64)).astype(np.float32) for t in T], np.float32).reshape(-1, 4, 4)
+        newer, older = results["id2"].astype(np.int32), results["id1"].astype(np.int32)
+        a = self.observation_likelihood(newer, older, T, emm_skip_step)
+        b = self.observation_likelihood(older, newer, Tinv, emm_skip_step)
+        c = a + b
+        met = np.zeros(n, bool)
+        q = C.c_double(0)
+        for i in range(n):
+            met[i] = bool(self._L.rgbdfe_observation_criterion_met(
+                int(c[i, 0]), int(c[i, 1]), int(c[i, 2] + c[i, 0] + c[i, 1]), observability_threshold, C.byref(q)))
+        return c, met
+
     # -- measurement ----------------------------------------------------------------------
     def set_profiling(self, enable: bool):
         self._check(self._L.rgbdfe_set_profiling(self._ctx, int(enable)))

@@ -189,3 +189,38 @@ def make_image_sequence(n_frames=4, width=WIDTH, height=HEIGHT, seed=20260923, p
         masks.append(m)
     return dict(gray=np.stack(imgs), depth=np.stack(depths), mask=np.stack(masks), fx=f, fy=f,
                 cx=(width - 1) / 2.0, cy=(height - 1) / 2.0)
+
+
+def make_depth_sequence(n_frames=4, width=WIDTH, height=HEIGHT, seed=20260923, nan_fraction=0.03, noise=0.002):
+    """Depth images of one static scene (a wavy wall at ~2 m with a box in front of it) seen from a
+    translating camera: geometrically consistent frames for the environment measurement model
+    (observationLikelihood, misc.cpp:814-969).  Returns depth [F, H, W] f32 (NaN holes), poses [F, 4, 4]
+    (camera-to-world), intrinsics.  relative_pose(poses, new, old) is the new -> old transform."""
+    rng = np.random.Generator(np.random.PCG64(seed + 9))
+    f = FX * width / WIDTH
+    cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
+    v, u = np.mgrid[0:height, 0:width].astype(np.float64)
+    rx, ry = (u - cx) / f, (v - cy) / f
+
+    def wall(x, y):
+        return 2.0 + 0.25 * np.sin(1.7 * x) * np.cos(1.3 * y)
+
+    depths, poses = [], []
+    for k in range(n_frames):
+        t = np.array([0.04 * k, 0.02 * np.sin(0.9 * k), 0.03 * np.cos(0.7 * k) - 0.03])
+        z = np.full((height, width), 2.0)
+        for _ in range(12):  # fixed point of z = wall(x_w, y_w) - t_z along each pixel ray
+            z = wall(rx * z + t[0], ry * z + t[1]) - t[2]
+        # a box 0.5 m in front of the wall, fixed in the world: |x_w - 0.1| < 0.25, |y_w + 0.05| < 0.2 at z_w = 1.4
+        zb = 1.4 - t[2]
+        inside = (np.abs(rx * zb + t[0] - 0.1) < 0.25) & (np.abs(ry * zb + t[1] + 0.05) < 0.2)
+        z = np.where(inside, zb, z)
+        z = z + rng.normal(0, 1.0, z.shape) * noise * z * z
+        d = z.astype(np.float32)
+        holes = rng.random((height // 16 + 1, width // 16 + 1)) < nan_fraction
+        d[np.kron(holes, np.ones((16, 16), bool))[:height, :width]] = np.nan
+        depths.append(d)
+        P = np.eye(4)
+        P[:3, 3] = t
+        poses.append(P)
+    return dict(depth=np.stack(depths), poses=np.stack(poses), fx=f, fy=f, cx=cx, cy=cy)
