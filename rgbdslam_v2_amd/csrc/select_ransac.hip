@@ -36,9 +36,11 @@ constexpr int kRounds = RGBDFE_MAX_MATCHES / kWave;  // 5
 // slot, 7 x 9 = 63 lanes) and ONE batched SVD (lane = slot).
 constexpr int kSlots = 7;
 constexpr int kFitUnroll = 4;   // recurrence steps per trip; loads run two trips ahead
-// u16 entries per slot list: 320 + two trips of read-ahead, an odd number of words so that the
+// bytes per slot list: 320 entries + two trips of read-ahead, an odd number of words so that the
 // slots' k-th entries sit in different LDS banks
-constexpr int kOrdStride = RGBDFE_MAX_MATCHES + 2 * kFitUnroll + 2;
+constexpr int kOrdStride = RGBDFE_MAX_MATCHES + 2 * kFitUnroll + 4;
+static_assert(kOrdStride % 4 == 0 && (kOrdStride / 4) % 2 == 1, "list rows: word aligned, odd word count");
+static_assert(RGBDFE_MAX_MATCHES <= 512, "list entries keep the low 8 bits of a match index + one threshold");
 // one match in LDS: from.xyz, to.xyz, weight (7 words: a lane = match access is bank-conflict free)
 constexpr int kRec = 7;
 constexpr uint32_t kRecBytes = kRec * 4;
@@ -51,7 +53,10 @@ struct SelBuf {
 };
 // refit phase: the inlier set compacted in match order
 struct FitBuf {
-  uint16_t ord[kSlots][kOrdStride];  // per slot: byte offsets of its participating matches' records, match order
+  // per slot: its participating matches in match order, low 8 bits of the match index (the lists ascend, so
+  // "index >= 256" is one threshold position per list, kept in a register): 1/2 of the u16 footprint, which
+  // is what lets 12 instead of 10 waves share a CU's LDS
+  uint8_t ord[kSlots][kOrdStride];
 };
 // scoring phase: candidates (matches that survive the cheap shortcut test) and inliers, compacted
 struct ScoreBuf {
@@ -77,9 +82,10 @@ struct Hyp {
 // per slot (lane = match), the refits' 3x3 SVDs are batched (lane = slot).
 struct Slot {
   float R[9], t[3];          // transform to score next
-  uint64_t mask[kRounds];    // inlier set of the last scoring = input of the next refit
   float rR[9], rt[3];        // refined_transformation (node.cpp:1137,1163)
-  uint64_t rmask[kRounds];   // refined_matches
+  // refined_matches; while the slot is active this is also the inlier set of the last scoring, i.e. the
+  // input of the next refit (a slot stays active only through an accepted scoring, :1160-1166)
+  uint64_t rmask[kRounds];
   double rerr;               // refined_error
   int rn;                    // refined_matches.size()
   int active;
@@ -586,17 +592,21 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
 // Every float operation is the one the sequential code performs, in the same order on the same
 // operands: bit-identical to Tfc::add over the same matches.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, const uint64_t* w_nonzero, RansacLds& lds) {
+__device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, const uint64_t* w_nonzero, RansacLds& lds,
+                                           int& n_below_256) {
   const int lane = threadIdx.x;
   uint32_t base = 0;
+  n_below_256 = 0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
     const uint64_t pm = mask[r] & w_nonzero[r];  // wave-uniform: scalar ALU
-    if ((pm >> lane) & 1ull)
-      lds.u.fit.ord[s][base + lane_rank(pm)] = (uint16_t)((r * kWave + lane) * kRecBytes);
+    if ((pm >> lane) & 1ull) lds.u.fit.ord[s][base + lane_rank(pm)] = (uint8_t)(r * kWave + lane);
     base += (uint32_t)__popcll(pm);
+    if (r == 256 / kWave - 1) n_below_256 = (int)base;
   }
+  // the recurrence reads two trips past the end of a list: keep those entries valid match indices
+  if (lane < 2 * kFitUnroll) lds.u.fit.ord[s][base + lane] = 0;
   return (int)base;
 }
 
@@ -607,22 +617,26 @@ __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 // n_mine: list length of this lane's slot (0: nothing to do), n_max: the longest list of the round.
 // On return lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s.
 // Software pipeline per trip of kFitUnroll steps: list entries are read two trips ahead, the match
-// records one trip ahead; every load is unconditional (lists are read past their end, offsets are
-// clamped) and a finished slot keeps its state through selects.
+// records one trip ahead; every load is unconditional (lists are padded two trips past their end with a
+// valid index) and a finished slot keeps its state through selects.
 // FAST_DIV: alpha = w / W through the gfx950 expansion of the f32 division without its range scaling
 // (v_div_scale / v_div_fmas / v_div_fixup): bit-identical when the scaling is the identity, which the
 // caller guarantees by checking once per pair that every weight lies in [2^-40, 2^40] (W is a sum of at
 // most 320 of them).
 template <bool FAST_DIV>
-__device__ __forceinline__ void fit_recurrence(int n_mine, int n_max, const RansacLds& lds,
+__device__ __forceinline__ void fit_recurrence(int n_mine, int k256_mine, int n_max, const RansacLds& lds,
                                                float& C, float& m1, float& m2) {
   constexpr int U = kFitUnroll;
-  constexpr uint32_t kLastRec = (RGBDFE_MAX_MATCHES - 1) * kRecBytes;
   const int lane = threadIdx.x;
   const int sl = min(lane / 9, kSlots - 1);
   const int l9 = lane % 9;
   const int ci = l9 / 3, cj = l9 % 3;
-  const uint16_t* __restrict__ ord = lds.u.fit.ord[sl];
+  const uint8_t* __restrict__ ord = lds.u.fit.ord[sl];
+  // byte offset of the k-th list entry's record: (low 8 bits + 256 from position k256 on) * 28
+  auto rec_off = [&](int k) {
+    const uint32_t hi = (k >= k256_mine) ? 256u * kRecBytes : 0u;
+    return (uint32_t)ord[k] * kRecBytes + hi;
+  };
   const char* __restrict__ recs = reinterpret_cast<const char*>(lds.M);
   const char* __restrict__ recP = recs + cj * 4;        // from[cj]
   const char* __restrict__ recQ = recs + 12 + ci * 4;   // to[ci]
@@ -631,7 +645,7 @@ __device__ __forceinline__ void fit_recurrence(int n_mine, int n_max, const Rans
   uint32_t off[U];
   float wv[U], fv[U], tv[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) off[u] = min((uint32_t)ord[u], kLastRec);
+  for (int u = 0; u < U; ++u) off[u] = rec_off(u);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     wv[u] = *reinterpret_cast<const float*>(recs + off[u] + 24);
@@ -639,7 +653,7 @@ __device__ __forceinline__ void fit_recurrence(int n_mine, int n_max, const Rans
     tv[u] = *reinterpret_cast<const float*>(recQ + off[u]);
   }
 #pragma unroll
-  for (int u = 0; u < U; ++u) off[u] = min((uint32_t)ord[U + u], kLastRec);
+  for (int u = 0; u < U; ++u) off[u] = rec_off(U + u);
   for (int k0 = 0; k0 < n_max; k0 += U) {
     float wc[U], fc[U], tc[U];
 #pragma unroll
@@ -652,7 +666,7 @@ __device__ __forceinline__ void fit_recurrence(int n_mine, int n_max, const Rans
       tv[u] = *reinterpret_cast<const float*>(recQ + off[u]);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) off[u] = min((uint32_t)ord[k0 + 2 * U + u], kLastRec);
+    for (int u = 0; u < U; ++u) off[u] = rec_off(k0 + 2 * U + u);
     // W_k = W_{k-1} + w_k, alpha_k = w_k / W_k: off the state's dependence chain
     float al[U], om[U];
 #pragma unroll
@@ -969,7 +983,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 #pragma unroll
             for (int i = 0; i < 3; ++i) { sl.t[i] = t0[i]; sl.rt[i] = 0.f; }
 #pragma unroll
-            for (int r = 0; r < kRounds; ++r) { sl.mask[r] = 0ull; sl.rmask[r] = 0ull; }
+            for (int r = 0; r < kRounds; ++r) sl.rmask[r] = 0ull;
             sl.rerr = 1e6;          // :1133
             sl.rn = 0;              // :1134
             sl.active = nan0 ? 0 : 1;  // a NaN transform leaves the refinement loop (:1144)
@@ -1010,7 +1024,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 #pragma unroll
                 for (int i = 0; i < 3; ++i) sl.rt[i] = curt[i];
 #pragma unroll
-                for (int r = 0; r < kRounds; ++r) { sl.rmask[r] = inl_mask[r]; sl.mask[r] = inl_mask[r]; }
+                for (int r = 0; r < kRounds; ++r) sl.rmask[r] = inl_mask[r];
                 sl.rn = n_inl;
                 sl.rerr = inlier_error;
               }
@@ -1024,16 +1038,17 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         if (!any_active) break;
         // ---- refits (:1142): the weighted-mean recurrences of all active slots side by side, then
         // ONE batched 3x3 SVD with lane = slot
-        int n_mine = 0, n_max = 0;
+        int n_mine = 0, k256_mine = 0, n_max = 0;
         PH_MARK(5)
         for (int g = 0; g < G; ++g) {
           Slot& sl = lds.slot[g];
           if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
           uint64_t m5[kRounds];
 #pragma unroll
-          for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.mask[r]);
-          const int n_g = fit_compact(g, m5, w_nonzero, lds);
-          if (lane / 9 == g) n_mine = n_g;
+          for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.rmask[r]);
+          int k256_g;
+          const int n_g = fit_compact(g, m5, w_nonzero, lds, k256_g);
+          if (lane / 9 == g) { n_mine = n_g; k256_mine = k256_g; }
           n_max = max(n_max, n_g);
           PH_COUNT(7)
         }
@@ -1045,8 +1060,8 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         mine.reset();
         {
           float C, m1, m2;
-          if (fast_alpha) fit_recurrence<true>(n_mine, n_max, lds, C, m1, m2);
-          else fit_recurrence<false>(n_mine, n_max, lds, C, m1, m2);
+          if (fast_alpha) fit_recurrence<true>(n_mine, k256_mine, n_max, lds, C, m1, m2);
+          else fit_recurrence<false>(n_mine, k256_mine, n_max, lds, C, m1, m2);
           PH_MARK(4)
           // lane s (< G) collects the state of slot s
           const int src = min(lane, kSlots - 1) * 9;
