@@ -52,7 +52,8 @@ def build(force=False):
         os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
-    if not os.path.exists(os.path.join(_HERE, "_ref", "libref_bforb.so")) or force:
+    if force or not all(os.path.exists(os.path.join(_HERE, "_ref", f))
+                        for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so")):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -148,6 +149,50 @@ def ref_lib():
         R.ref_bruteForceSearchORB.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
         _ref = R
     return _ref
+
+
+_ref_node = None
+
+
+def ref_node_lib():
+    """The reference's own sample_matches_prefer_by_distance and keepStrongestMatches
+    (node.cpp:1023-1047, 516-531), compiled from /root/reference (or None)."""
+    global _ref_node
+    if _ref_node is None:
+        p = os.path.join(_HERE, "_ref", "libref_node.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_sample_ids.restype = C.c_int
+        R.ref_sample_ids.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        R.ref_keep_strongest.restype = C.c_int
+        R.ref_keep_strongest.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        R.ref_set_sigma_depth.restype = None
+        R.ref_set_sigma_depth.argtypes = [C.c_double]
+        R.ref_depth_covariance.restype = C.c_double
+        R.ref_depth_covariance.argtypes = [C.c_double]
+        R.ref_back_project.restype = None
+        R.ref_back_project.argtypes = [C.c_float] * 7 + [C.c_void_p]
+        _ref_node = R
+    return _ref_node
+
+
+def ref_sample_ids(n_matches, stream, sample_size=4):
+    """Reference sampling with rand() replaced by `stream` (ints): returns (ids, draws consumed)."""
+    stream = np.ascontiguousarray(stream, np.int32)
+    ids = np.zeros(max(sample_size, 1), np.int32)
+    used = C.c_int(0)
+    n = ref_node_lib().ref_sample_ids(int(n_matches), int(sample_size), _p(stream), _p(ids), C.byref(used))
+    return ids[:n].copy(), used.value
+
+
+def ref_keep_strongest(n, dist):
+    dist = np.ascontiguousarray(dist, np.float32)
+    kept = np.zeros(max(len(dist), 1), np.int32)
+    k = ref_node_lib().ref_keep_strongest(int(n), _p(dist), len(dist), _p(kept))
+    return kept[:k].copy()
 
 
 def _p(a):

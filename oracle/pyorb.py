@@ -191,3 +191,38 @@ def node_features(st, gray, mask, depth, max_keypoints=1000, cap=60000):
 
 def pattern():
     return np.ctypeslib.as_array(lib().orb_pattern(), shape=(1024,)).copy()
+
+
+_ref_adj = None
+
+
+def ref_adjuster_lib():
+    """The reference's own detector grid + threshold adaptation (src/feature_adjuster.cpp, src/features.cpp:35-60)
+    compiled from /root/reference around the oracle's cv::ORB::detect restatement (or None)."""
+    global _ref_adj
+    if _ref_adj is None:
+        import os
+        from . import pyoracle
+        p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_adjuster.so")
+        if not os.path.exists(p):
+            pyoracle.build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_grid_detector_create.restype = C.c_void_p
+        R.ref_grid_detector_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        R.ref_grid_detector_destroy.restype = None
+        R.ref_grid_detector_destroy.argtypes = [C.c_void_p]
+        R.ref_grid_detector_detect.restype = C.c_int
+        R.ref_grid_detector_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _ref_adj = R
+    return _ref_adj
+
+
+def ref_grid_detect(handle, img, mask, cap=60000):
+    img = np.ascontiguousarray(img, np.uint8)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    kp = np.zeros(cap, KP_DTYPE)
+    n = ref_adjuster_lib().ref_grid_detector_detect(handle, _p(img), None if m is None else _p(m), img.shape[1],
+                                                    img.shape[0], _p(kp), cap)
+    return kp[:n].copy()

@@ -157,3 +157,41 @@ def test_grid_detector_state_and_repeatability():
     # the same plane is seen with a small similarity motion: most descriptors find a close partner
     D = np.unpackbits(d0[:, None, :] ^ d1[None, :, :], axis=2).sum(2)
     assert (D.min(1) < 50).mean() > 0.5
+
+
+@pytest.mark.skipif(pyorb.ref_adjuster_lib() is None, reason="reference pin (oracle/_ref/libref_adjuster.so) not built")
+def test_grid_and_threshold_adaptation_match_live_reference_code():
+    """Rows a1-a3: the reference's own createDetector("ORB") wiring (features.cpp:35-60) and
+    feature_adjuster.cpp -- DetectorAdjuster, VideoDynamicAdaptedFeatureDetector (re-detect with threshold x0.7,
+    x1.3 for the next frame, <= 5 iterations), VideoGridAdaptedFeatureDetector (3x3 cells with +-31 px overlap,
+    keepStrongest per cell, aggregation) -- compiled from /root/reference and run around the oracle's cv::ORB::detect
+    restatement, against the oracle's orb_grid_detect: same keypoints on every frame of a sequence (the per-cell
+    thresholds persist across frames on both sides)."""
+    R = pyorb.ref_adjuster_lib()
+    key = lambda k: sorted(zip(k["octave"].tolist(), k["y"].tolist(), k["x"].tolist(), k["response"].tolist(),
+                               k["angle"].tolist(), k["size"].tolist()))
+    rng = np.random.default_rng(13)
+    for max_kp, grid, iters, frames in ((1000, 3, 5, 4), (300, 2, 3, 3), (4000, 3, 5, 2)):
+        seq = synth.make_image_sequence(n_frames=frames, seed=21 + grid)
+        st = pyorb.grid_state(max_kp, grid, iters)
+        h = R.ref_grid_detector_create(max_kp, grid, iters)
+        try:
+            for f in range(frames):
+                img = seq["gray"][f].copy()
+                mask = np.where(seq["mask"][f] > 0, 255, 0).astype(np.uint8)
+                if f == 1:   # a texture-poor frame: the x0.7 re-detection loop runs
+                    img = (img.astype(np.float32) * 0.15 + 100).astype(np.uint8)
+                if f == 2:   # a frame whose right third has no depth: cells with an all-zero mask break out
+                    mask[:, 430:] = 0
+                a = pyorb.grid_detect(st, img, mask)
+                b = pyorb.ref_grid_detect(h, img, mask)
+                assert len(a) == len(b) and len(a) > 0
+                assert key(a) == key(b), (max_kp, grid, f)
+        finally:
+            R.ref_grid_detector_destroy(h)
+    # no mask at all
+    seq = synth.make_image_sequence(n_frames=1, seed=5)
+    st = pyorb.grid_state(600, 3, 5)
+    h = R.ref_grid_detector_create(600, 3, 5)
+    assert key(pyorb.grid_detect(st, seq["gray"][0], None)) == key(pyorb.ref_grid_detect(h, seq["gray"][0], None))
+    R.ref_grid_detector_destroy(h)

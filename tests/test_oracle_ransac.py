@@ -133,6 +133,74 @@ def test_sample4_sorted_distinct_prefers_low_ids():
     assert L.orc_sample4(1, 2, 3, 3, ids.ctypes.data) == 0  # fewer than 4 matches: no sample
 
 
+@pytest.mark.skipif(po.ref_node_lib() is None, reason="reference pin (oracle/_ref/libref_node.so) not built")
+def test_sampling_matches_live_reference_function():
+    """The reference's own sample_matches_prefer_by_distance (node.cpp:1023-1047), compiled from where it
+    lies, fed the oracle's counter-based draws in place of rand() (D1): same four ids, same number of draws."""
+    L = po.lib()
+    ids = np.zeros(4, np.uint32)
+    rng = np.random.default_rng(2)
+    for trial in range(400):
+        n = int(rng.integers(4, 320)) if trial % 7 else int(rng.integers(4, 9))  # small n: many duplicate draws
+        seed, uid, it = (int(x) for x in rng.integers(0, 2**31, 3))
+        stream = np.array([L.orc_rand31(seed, uid, it, k) for k in range(256)], np.int64)
+        assert stream.max() < 2**31
+        ref_ids, used = po.ref_sample_ids(n, stream.astype(np.int32))
+        c = L.orc_sample4(seed, uid, it, n, ids.ctypes.data)
+        assert c == 4 and list(ids) == list(ref_ids), (n, seed, uid, it)
+        assert used % 2 == 0 and used >= 8  # two draws per attempt (:1033-1034)
+    # fewer matches than the sample size: the reference returns nothing (:1031), so does the oracle
+    assert len(po.ref_sample_ids(3, np.arange(64, dtype=np.int32))[0]) == 0
+    assert L.orc_sample4(1, 2, 3, 3, ids.ctypes.data) == 0
+
+
+@pytest.mark.skipif(po.ref_node_lib() is None, reason="reference pin (oracle/_ref/libref_node.so) not built")
+def test_keep_strongest_matches_live_reference_function():
+    """keepStrongestMatches (node.cpp:516-531) keeps the M smallest distances in unspecified order; the oracle
+    keeps the same multiset, ordered, with ties at the cut resolved by queryIdx (D2)."""
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        nq, nt, M = 400, 380, int(rng.integers(20, 320))
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        q = t[rng.integers(0, nt, nq)].copy()
+        flips = rng.random((nq, 256)) < rng.uniform(0.02, 0.3)
+        q ^= np.packbits(flips, axis=1)
+        mq_all, _, hd_all = po.feature_matching_orb(q, t, max_matches=100000)  # every hd < 128 match, sorted
+        mq, _, hd = po.feature_matching_orb(q, t, max_matches=M)
+        dist = (hd_all / 256.0).astype(np.float32)  # node.cpp:573 without the jitter (D2)
+        order = np.argsort(mq_all, kind="stable")    # the reference sees the matches in query order
+        kept = po.ref_keep_strongest(M, dist[order])
+        assert len(kept) == len(mq) == min(M, len(mq_all))
+        assert sorted(dist[order][kept].tolist()) == sorted((hd / 256.0).astype(np.float32).tolist())
+        cut = hd.max()
+        strictly_inside = set(mq[hd < cut].tolist())
+        assert strictly_inside <= set(mq_all[order][kept].tolist())  # everything below the cut distance is kept by both
+
+
+@pytest.mark.skipif(po.ref_node_lib() is None, reason="reference pin (oracle/_ref/libref_node.so) not built")
+def test_depth_covariance_freeze_and_back_project_on_live_reference_functions():
+    """misc2.h:20-35: the function-local statics freeze depth_covariance() at the FIRST call's depth (a18) --
+    shown on the reference's own code; this is why the ABI takes an explicit depth_cov (D3).
+    misc2.h:49-65: backProject's float expression is the one project_to_3d uses."""
+    R = po.ref_node_lib()
+    R.ref_set_sigma_depth(0.01)
+    first = R.ref_depth_covariance(2.0)            # first call in this process
+    assert first == (0.01 * 2.0 * 2.0) ** 2
+    assert R.ref_depth_covariance(1.0) == first and R.ref_depth_covariance(5.0) == first  # frozen
+    assert po.default_params().depth_cov == (0.01 * 1.0 * 1.0) ** 2  # the ABI default: first depth = 1 m
+    rng = np.random.default_rng(6)
+    depth = rng.uniform(0.5, 4, (48, 64)).astype(np.float32)
+    kp = np.stack([rng.uniform(0, 63, 100), rng.uniform(0, 47, 100)], 1).astype(np.float32)
+    fx, fy, cx, cy = 52.5, 51.25, 31.5, 23.5
+    kept, xyz = po.project_to_3d(kp, depth, fx, fy, cx, cy, 1.0, 1000)
+    out = np.zeros(3, np.float32)
+    for i, p in zip(kept, xyz):
+        z = depth[int(np.floor(kp[i, 1] + 0.5)), int(np.floor(kp[i, 0] + 0.5))]
+        R.ref_back_project(np.float32(1.0 / fx), np.float32(1.0 / fy), np.float32(cx), np.float32(cy),
+                           kp[i, 0], kp[i, 1], z, out.ctypes.data)
+        assert np.array_equal(out, p[:3])
+
+
 def test_ransac_recovers_ground_truth_and_is_deterministic():
     seq = synth.make_sequence(n_frames=6, n_kp=600, n_world=2500, seed=3)
     prm = po.default_params()
