@@ -53,7 +53,7 @@ def build(force=False):
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if force or not all(os.path.exists(os.path.join(_HERE, "_ref", f))
-                        for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so")):
+                        for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so", "libref_ransac.so")):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -193,6 +193,50 @@ def ref_keep_strongest(n, dist):
     kept = np.zeros(max(len(dist), 1), np.int32)
     k = ref_node_lib().ref_keep_strongest(int(n), _p(dist), len(dist), _p(kept))
     return kept[:k].copy()
+
+
+_ref_ransac = None
+
+
+def ref_ransac_lib():
+    """The reference's own getRelativeTransformationTo / computeInliersAndError / errorFunction2 /
+    getTransformFromMatches, compiled from /root/reference with Eigen / PCL stand-ins (or None)."""
+    global _ref_ransac
+    if _ref_ransac is None:
+        p = os.path.join(_HERE, "_ref", "libref_ransac.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_get_relative_transformation.restype = C.c_int
+        R.ref_get_relative_transformation.argtypes = (
+            [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+             C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
+             C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        _ref_ransac = R
+    return _ref_ransac
+
+
+def ref_get_relative_transformation(qxyz1, txyz1, mq, mt, mdist, params, uid):
+    """Runs the reference's RANSAC on a match list (any order; it sorts by distance itself).  Returns a dict
+    shaped like result_to_dict's RANSAC part."""
+    qxyz1 = np.ascontiguousarray(qxyz1, np.float32)
+    txyz1 = np.ascontiguousarray(txyz1, np.float32)
+    mq = np.ascontiguousarray(mq, np.int32)
+    mt = np.ascontiguousarray(mt, np.int32)
+    mdist = np.ascontiguousarray(mdist, np.float32)
+    n = len(mq)
+    T = np.zeros(16, np.float32)
+    rmse, n_inl, iters = C.c_float(0), C.c_int(0), C.c_int(0)
+    iq = np.zeros(max(n, 1), np.int32)
+    it = np.zeros(max(n, 1), np.int32)
+    found = ref_ransac_lib().ref_get_relative_transformation(
+        _p(qxyz1), len(qxyz1), _p(txyz1), len(txyz1), _p(mq), _p(mt), _p(mdist), n, params.min_matches,
+        params.ransac_iterations, float(params.max_dist_for_inliers), params.depth_cov, params.seed, int(uid),
+        _p(T), C.byref(rmse), _p(iq), _p(it), C.byref(n_inl), C.byref(iters))
+    return dict(found=bool(found), T=T.reshape(4, 4).T.copy(), rmse=np.float32(rmse.value),
+                inl_q=iq[:n_inl.value].copy(), inl_t=it[:n_inl.value].copy(), real_iterations=iters.value)
 
 
 def _p(a):

@@ -1,0 +1,221 @@
+// oracle/ref_stubs/ransac_prelude.h -- TEST INFRASTRUCTURE ONLY.
+// Everything the reference's RANSAC functions need from ROS, OpenCV, Eigen, PCL and the parameter server, as
+// minimal stand-ins, so that these first-party functions compile FROM WHERE THEY LIE in /root/reference:
+//   Node::computeInliersAndError            src/node.cpp:968-1020
+//   sample_matches_prefer_by_distance       src/node.cpp:1023-1047
+//   Node::getRelativeTransformationTo       src/node.cpp:1074-1277
+//   getTransformFromMatches                 src/transformation_estimation_euclidean.cpp:7-61
+//   errorFunction2                          src/misc.cpp:697-770
+// The third-party arithmetic behind the stand-ins (Eigen's coefficient-wise fixed-size products, LLT::solve,
+// pcl::TransformationFromCorrespondences) is the oracle's restatement -- that part stays "parity unpinned";
+// what this pins on the reference's own code is all the first-party logic around it: gates, thresholds, the
+// refinement loop, the iteration-skipping hacks, the identity fallback, inlier bookkeeping and the error function.
+// Deviations D1 (counter-based draws instead of rand()) and D3 (explicit depth covariance) enter through
+// rand() -> ref_rand_draw() and depth_covariance() below.
+#ifndef REF_STUB_RANSAC_PRELUDE_H
+#define REF_STUB_RANSAC_PRELUDE_H
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <ctime>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#define ROS_INFO(...)
+#define ROS_WARN(...)
+#define ROS_ERROR(...)
+#define ROS_DEBUG(...)
+#define ROS_INFO_STREAM(x)
+#define ROS_WARN_STREAM(x)
+#define ROS_ERROR_STREAM(x)
+#define ROS_DEBUG_STREAM_NAMED(n, x)
+#define BOOST_FOREACH(decl, cont) for (decl : cont)
+struct ScopedTimer { explicit ScopedTimer(const char*) {} };
+
+extern "C" {
+uint32_t orc_rand31(uint32_t seed, uint32_t uid, uint32_t iter, uint32_t k);
+void orc_fit_transform(const float* qxyz1, const float* txyz1, const int32_t* mq, const int32_t* mt,
+                       const int32_t* sel, int nsel, float T[16]);
+}
+
+// ---- parameters ---------------------------------------------------------------------------------
+struct RefParams {
+  int min_matches = 20, ransac_iterations = 200, g2o_transformation_refinement = 0;
+  double max_dist_for_inliers = 3.0, depth_cov = 1e-4;
+  uint32_t seed = 0, uid = 0;
+  uint32_t iter = 0, k = 0;  // position in the counter-based draw stream (D1)
+  int sampler_calls = 0;
+};
+extern RefParams g_ref;
+struct ParameterServer {
+  static ParameterServer* instance() { static ParameterServer p; return &p; }
+  template <class T> T get(const std::string& n) {
+    if (n == "min_matches") return (T)g_ref.min_matches;
+    if (n == "ransac_iterations") return (T)g_ref.ransac_iterations;
+    if (n == "max_dist_for_inliers") return (T)g_ref.max_dist_for_inliers;
+    if (n == "g2o_transformation_refinement") return (T)g_ref.g2o_transformation_refinement;
+    if (n == "allow_features_without_depth") return (T)0;
+    return T();
+  }
+};
+inline int ref_rand_draw() { return (int)orc_rand31(g_ref.seed, g_ref.uid, g_ref.iter, g_ref.k++); }
+// D3: the frozen static of misc2.h:30-35 as an explicit value
+inline double depth_covariance(double) { return g_ref.depth_cov; }
+
+namespace cv {
+struct DMatch {
+  int queryIdx, trainIdx, imgIdx;
+  float distance;
+  bool operator<(const DMatch& m) const { return distance < m.distance; }  // opencv2/core/types.hpp
+};
+}  // namespace cv
+
+// ---- mini Eigen: fixed-size, coefficient-wise, left-to-right sums ----------------------------------
+namespace Eigen {
+template <class T> using aligned_allocator = std::allocator<T>;
+
+struct Vector3f {
+  float v[3];
+  float& operator()(int i) { return v[i]; }
+  float operator()(int i) const { return v[i]; }
+  Vector3f operator-(const Vector3f& o) const { return Vector3f{{v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}}; }
+  float squaredNorm() const { return (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; }
+};
+struct Vector3d;
+struct RowVector3d {
+  double v[3];
+  double operator*(const Vector3d& b) const;
+};
+struct Vector3d {
+  double v[3];
+  double& operator()(int i) { return v[i]; }
+  double operator()(int i) const { return v[i]; }
+  Vector3d operator-(const Vector3d& o) const { return Vector3d{{v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}}; }
+  double squaredNorm() const { return (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; }
+  RowVector3d transpose() const { return RowVector3d{{v[0], v[1], v[2]}}; }
+};
+inline double RowVector3d::operator*(const Vector3d& b) const { return (v[0] * b.v[0] + v[1] * b.v[1]) + v[2] * b.v[2]; }
+struct Vector4d {
+  double v[4];
+  template <int N> Vector3d head() const { static_assert(N == 3, "head<3>"); return Vector3d{{v[0], v[1], v[2]}}; }
+};
+struct Vector4f {
+  float v[4];
+  Vector4f() : v{0, 0, 0, 0} {}
+  Vector4f(float x, float y, float z, float w) : v{x, y, z, w} {}
+  float& operator()(int i) { return v[i]; }
+  float operator()(int i) const { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+  template <int N> Vector3f head() const { static_assert(N == 3, "head<3>"); return Vector3f{{v[0], v[1], v[2]}}; }
+  template <class T> Vector4d cast() const { return Vector4d{{(T)v[0], (T)v[1], (T)v[2], (T)v[3]}}; }
+};
+struct Matrix3d;
+struct LLT3 {
+  double S[3][3];
+  Vector3d solve(const Vector3d& d) const;  // unblocked Cholesky + forward / backward substitution
+};
+struct Matrix3d {
+  double m[3][3];
+  static Matrix3d Zero() { Matrix3d r; for (auto& row : r.m) for (double& x : row) x = 0.0; return r; }
+  double& operator()(int i, int j) { return m[i][j]; }
+  double operator()(int i, int j) const { return m[i][j]; }
+  Matrix3d transpose() const { Matrix3d r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[j][i]; return r; }
+  Matrix3d operator*(const Matrix3d& b) const {
+    Matrix3d r;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) r.m[i][j] = (m[i][0] * b.m[0][j] + m[i][1] * b.m[1][j]) + m[i][2] * b.m[2][j];
+    return r;
+  }
+  Matrix3d operator+(const Matrix3d& b) const { Matrix3d r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i][j] + b.m[i][j]; return r; }
+  LLT3 llt() const { LLT3 l; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) l.S[i][j] = m[i][j]; return l; }
+};
+inline Vector3d LLT3::solve(const Vector3d& d) const {
+  const double l00 = std::sqrt(S[0][0]);
+  const double l10 = S[1][0] / l00, l20 = S[2][0] / l00;
+  const double l11 = std::sqrt(S[1][1] - l10 * l10);
+  const double l21 = (S[2][1] - l20 * l10) / l11;
+  const double l22 = std::sqrt(S[2][2] - (l20 * l20 + l21 * l21));
+  const double y0 = d.v[0] / l00;
+  const double y1 = (d.v[1] - l10 * y0) / l11;
+  const double y2 = (d.v[2] - (l20 * y0 + l21 * y1)) / l22;
+  const double z2 = y2 / l22;
+  const double z1 = (y1 - l21 * z2) / l11;
+  const double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
+  return Vector3d{{z0, z1, z2}};
+}
+struct Matrix4d {
+  double m[4][4];
+  Vector4d operator*(const Vector4d& x) const {
+    Vector4d r;
+    for (int i = 0; i < 4; ++i) r.v[i] = ((m[i][0] * x.v[0] + m[i][1] * x.v[1]) + m[i][2] * x.v[2]) + m[i][3] * x.v[3];
+    return r;
+  }
+  Matrix3d block(int, int, int, int) const { Matrix3d r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i][j]; return r; }
+};
+struct Matrix4f {
+  float m[4][4];
+  Matrix4f() { for (auto& row : m) for (float& x : row) x = 0.f; }
+  static Matrix4f Identity() { Matrix4f r; for (int i = 0; i < 4; ++i) r.m[i][i] = 1.f; return r; }
+  bool operator!=(const Matrix4f& o) const { for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (m[i][j] != o.m[i][j]) return true; return false; }
+  template <class T> Matrix4d cast() const { Matrix4d r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = (T)m[i][j]; return r; }
+};
+struct Affine3f {
+  Matrix4f M;
+  Matrix4f matrix() const { return M; }
+};
+}  // namespace Eigen
+
+// ---- pcl::TransformationFromCorrespondences: the oracle's restated recurrence + SVD --------------------
+namespace pcl {
+class TransformationFromCorrespondences {
+  std::vector<float> from_, to_;  // x, y, z, 1 per correspondence
+ public:
+  int weight_mismatches = 0;
+  void add(const Eigen::Vector3f& from, const Eigen::Vector3f& to, float weight) {
+    // orc_fit_transform recomputes the weight from the z coordinates (transformation_estimation_euclidean.cpp:25)
+    if (weight != (float)(1.0 / (double)(from(2) * to(2)))) weight_mismatches++;
+    for (int i = 0; i < 3; ++i) { from_.push_back(from(i)); to_.push_back(to(i)); }
+    from_.push_back(1.f); to_.push_back(1.f);
+  }
+  Eigen::Affine3f getTransformation() const {
+    const int n = (int)from_.size() / 4;
+    std::vector<int32_t> idx((size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    float T[16];  // column-major
+    orc_fit_transform(from_.data(), to_.data(), idx.data(), idx.data(), idx.data(), n, T);
+    Eigen::Affine3f a;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) a.M.m[r][c] = T[c * 4 + r];
+    if (weight_mismatches) a.M.m[0][0] = std::numeric_limits<float>::quiet_NaN();  // make a mismatch visible
+    return a;
+  }
+};
+}  // namespace pcl
+
+// ---- Node skeleton --------------------------------------------------------------------------------
+class Node {
+ public:
+  int id_ = 0;
+  std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> > feature_locations_3d_;
+  void computeInliersAndError(const std::vector<cv::DMatch>& all_matches, const Eigen::Matrix4f& transformation4f,
+                              const std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> >& origins,
+                              const std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> >& earlier,
+                              size_t min_inliers, std::vector<cv::DMatch>& inliers, double& return_mean_error,
+                              double squaredMaxInlierDistInM) const;
+  bool getRelativeTransformationTo(const Node* earlier_node, std::vector<cv::DMatch>* initial_matches,
+                                   Eigen::Matrix4f& resulting_transformation, float& rmse,
+                                   std::vector<cv::DMatch>& matches) const;
+};
+double errorFunction2(const Eigen::Vector4f& x1, const Eigen::Vector4f& x2, const Eigen::Matrix4d& transformation);
+Eigen::Matrix4f getTransformFromMatches(const Node* newer_node, const Node* earlier_node,
+                                        const std::vector<cv::DMatch>& matches, bool& valid, const float max_dist_m);
+inline void getTransformFromMatchesG2O(const Node*, const Node*, const std::vector<cv::DMatch>&, Eigen::Matrix4f&, int) {}
+std::vector<cv::DMatch> sample_matches_prefer_by_distance(unsigned int sample_size, std::vector<cv::DMatch>& matches_with_depth);
+#endif

@@ -201,6 +201,55 @@ def test_depth_covariance_freeze_and_back_project_on_live_reference_functions():
         assert np.array_equal(out, p[:3])
 
 
+@pytest.mark.skipif(po.ref_ransac_lib() is None, reason="reference pin (oracle/_ref/libref_ransac.so) not built")
+def test_ransac_matches_live_reference_functions():
+    """Rows a13-a17: the reference's own Node::getRelativeTransformationTo, Node::computeInliersAndError,
+    sample_matches_prefer_by_distance, errorFunction2 and getTransformFromMatches -- compiled from /root/reference
+    against Eigen / PCL stand-ins whose arithmetic is the oracle's restatement -- give the same transform (bits),
+    rmse, inlier list, success flag and iteration count as orc_ransac on the same matches and draws.  Every gate,
+    threshold, the refinement loop, `n += 10/20`, the 80 % exit and the identity fallback are the reference's code."""
+    L = po.lib()
+    cases = []
+    seq = synth.make_sequence(n_frames=6, n_kp=500, n_world=1500, seed=17)
+    for q, t in ((1, 0), (3, 1), (5, 2), (4, 4)):
+        cases.append((seq["desc"][q], seq["xyz1"][q], q, seq["desc"][t], seq["xyz1"][t], t, {}))
+    hard = synth.make_sequence(n_frames=3, n_kp=400, n_world=1200, seed=18, nan_fraction=0.08)
+    x = hard["xyz1"].copy()
+    x[1, :30, 2] = 0.0  # zero depth: skipped by computeInliersAndError (:994), poisons a fit when sampled
+    cases.append((hard["desc"][1], x[1], 1, hard["desc"][0], x[0], 0, {}))
+    cases.append((hard["desc"][2], x[2], 2, hard["desc"][1], x[1], 1, dict(max_dist_for_inliers=2.0, ransac_iterations=100)))
+    rng = np.random.default_rng(19)  # unrelated descriptors: matches exist, no transform -> identity fallback path
+    cases.append((rng.integers(0, 256, (300, 32), dtype=np.uint8), x[0][:300], 7, hard["desc"][0], x[0], 0, {}))
+    cases.append((seq["desc"][1][:21], seq["xyz1"][1][:21], 8, seq["desc"][1], seq["xyz1"][1], 1, dict(min_matches=20)))
+    cases.append((seq["desc"][1][:15], seq["xyz1"][1][:15], 9, seq["desc"][1], seq["xyz1"][1], 1, {}))  # too few
+    # no RANSAC iteration at all on a frame matched with itself: the identity hypothesis is accepted (:1192-1214)
+    cases.append((seq["desc"][2], seq["xyz1"][2], 2, seq["desc"][2], seq["xyz1"][2], 2, dict(ransac_iterations=0)))
+    n_found = n_fallback = 0
+    for qd, qx, qid, td, tx, tid, kw in cases:
+        prm = po.default_params(**kw)
+        ref = po.match_node_pair(qd, qx, qid, td, tx, tid, prm)
+        mq, mt, hd = ref["all_q"], ref["all_t"], ref["all_hd"]
+        if len(mq) == 0:
+            continue
+        # D2 made explicit: a strictly increasing distance in the oracle's (hd, queryIdx) order, list scrambled
+        dist = np.arange(len(mq), dtype=np.float32)
+        perm = np.random.default_rng(qid).permutation(len(mq))
+        got = po.ref_get_relative_transformation(qx, tx, mq[perm], mt[perm], dist[perm], prm,
+                                                 L.orc_pair_uid(qid, tid))
+        gate = len(mq) >= prm.min_matches  # matchNodePair's own gate (node.cpp:1319) in front of the call
+        if not gate:
+            continue
+        assert got["found"] == (ref["id1"] >= 0), (qid, tid)
+        assert got["real_iterations"] == ref["real_iterations"]
+        assert np.array_equal(got["T"], ref["T"]), "transform bits differ from the reference code's"
+        if len(mq) > prm.min_matches:
+            assert got["rmse"] == ref["rmse"]
+        assert np.array_equal(got["inl_q"], mq[ref["inl_idx"]]) and np.array_equal(got["inl_t"], mt[ref["inl_idx"]])
+        n_found += got["found"]
+        n_fallback += got["found"] and ref["real_iterations"] == 0
+    assert n_found >= 4 and n_fallback == 1
+
+
 def test_ransac_recovers_ground_truth_and_is_deterministic():
     seq = synth.make_sequence(n_frames=6, n_kp=600, n_world=2500, seed=3)
     prm = po.default_params()
