@@ -214,8 +214,39 @@ def ref_ransac_lib():
             [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
              C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
              C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        R.ref_match_node_pair.restype = C.c_int
+        R.ref_match_node_pair.argtypes = (
+            [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+             C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+             C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int),
+             C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)])
         _ref_ransac = R
     return _ref_ransac
+
+
+def ref_match_node_pair(qdesc, qxyz1, qid, tdesc, txyz1, tid, params):
+    """The reference's own Node::matchNodePair (featureMatching -> keepStrongestMatches -> RANSAC -> edge),
+    compiled from /root/reference; the distance jitter grows with the query index (D2), draws are D1's."""
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, np.uint8)
+    qxyz1 = np.ascontiguousarray(qxyz1, np.float32)
+    txyz1 = np.ascontiguousarray(txyz1, np.float32)
+    nq, nt = len(qdesc), len(tdesc)
+    cap = max(nq, 1)
+    aq, at, iq, it = (np.zeros(cap, np.int32) for _ in range(4))
+    ad = np.zeros(cap, np.float32)
+    T = np.zeros(16, np.float32)
+    n_all, n_inl, id1, id2, iters = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    rmse, info = C.c_float(0), C.c_double(0)
+    accepted = ref_ransac_lib().ref_match_node_pair(
+        _p(qdesc), _p(qxyz1), nq, int(qid), _p(tdesc), _p(txyz1), nt, int(tid), params.max_matches, params.min_matches,
+        params.ransac_iterations, float(params.max_dist_for_inliers), params.depth_cov, params.seed,
+        lib().orc_pair_uid(int(qid), int(tid)), _p(aq), _p(at), _p(ad), C.byref(n_all), _p(iq), _p(it), C.byref(n_inl),
+        _p(T), C.byref(rmse), C.byref(id1), C.byref(id2), C.byref(info), C.byref(iters))
+    na, ni = n_all.value, n_inl.value
+    return dict(id1=id1.value, id2=id2.value, all_q=aq[:na].copy(), all_t=at[:na].copy(), all_dist=ad[:na].copy(),
+                inl_q=iq[:ni].copy(), inl_t=it[:ni].copy(), T=T.reshape(4, 4).T.copy(), rmse=np.float32(rmse.value),
+                info_scale=info.value, real_iterations=iters.value, accepted=accepted)
 
 
 def ref_get_relative_transformation(qxyz1, txyz1, mq, mt, mdist, params, uid):

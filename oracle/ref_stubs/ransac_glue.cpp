@@ -38,3 +38,45 @@ extern "C" int ref_get_relative_transformation(
   *real_iterations_out = g_ref.sampler_calls;
   return found ? 1 : 0;
 }
+
+// The whole pair op: Node::matchNodePair = featureMatching (bruteForceSearchORB, keepStrongestMatches) ->
+// getRelativeTransformationTo -> edge assembly (src/node.cpp:1305-1429).
+extern "C" int ref_match_node_pair(
+    const uint8_t* qdesc, const float* qxyz1, int nq, int qid, const uint8_t* tdesc, const float* txyz1, int nt, int tid,
+    int max_matches, int min_matches, int ransac_iterations, double max_dist_for_inliers, double depth_cov,
+    uint32_t seed, uint32_t uid, int32_t* all_q, int32_t* all_t, float* all_dist, int* n_all_out, int32_t* inl_q,
+    int32_t* inl_t, int* n_inl_out, float* T_colmajor, float* rmse_out, int* id1_out, int* id2_out,
+    double* info00_out, int* real_iterations_out) {
+  g_ref = RefParams();
+  g_ref.max_matches = max_matches;
+  g_ref.min_matches = min_matches;
+  g_ref.ransac_iterations = ransac_iterations;
+  g_ref.max_dist_for_inliers = max_dist_for_inliers;
+  g_ref.depth_cov = depth_cov;
+  g_ref.seed = seed;
+  g_ref.uid = uid;
+  Node newer, older;
+  newer.id_ = qid; older.id_ = tid;
+  newer.feature_descriptors_.rows = nq; newer.feature_descriptors_.cols = 32;
+  newer.feature_descriptors_.data = const_cast<uint8_t*>(qdesc);
+  older.feature_descriptors_.rows = nt; older.feature_descriptors_.cols = 32;
+  older.feature_descriptors_.data = const_cast<uint8_t*>(tdesc);
+  newer.feature_locations_2d_.resize((size_t)nq);
+  older.feature_locations_2d_.resize((size_t)nt);
+  for (int i = 0; i < nq; ++i) newer.feature_locations_3d_.push_back(Eigen::Vector4f(qxyz1[4 * i], qxyz1[4 * i + 1], qxyz1[4 * i + 2], qxyz1[4 * i + 3]));
+  for (int i = 0; i < nt; ++i) older.feature_locations_3d_.push_back(Eigen::Vector4f(txyz1[4 * i], txyz1[4 * i + 1], txyz1[4 * i + 2], txyz1[4 * i + 3]));
+  MatchingResult mr = newer.matchNodePair(&older);
+  *n_all_out = (int)mr.all_matches.size();
+  for (size_t i = 0; i < mr.all_matches.size(); ++i) {
+    all_q[i] = mr.all_matches[i].queryIdx; all_t[i] = mr.all_matches[i].trainIdx; all_dist[i] = mr.all_matches[i].distance;
+  }
+  *n_inl_out = (int)mr.inlier_matches.size();
+  for (size_t i = 0; i < mr.inlier_matches.size(); ++i) { inl_q[i] = mr.inlier_matches[i].queryIdx; inl_t[i] = mr.inlier_matches[i].trainIdx; }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T_colmajor[c * 4 + r] = mr.final_trafo.m[r][c];
+  *rmse_out = mr.rmse;
+  *id1_out = mr.edge.id1;
+  *id2_out = mr.edge.id2;
+  *info00_out = mr.edge.id1 >= 0 ? mr.edge.informationMatrix.m[0][0] : 0.0;
+  *real_iterations_out = g_ref.sampler_calls;
+  return (int)newer.initial_node_matches_;
+}

@@ -6,6 +6,11 @@
 //   Node::getRelativeTransformationTo       src/node.cpp:1074-1277
 //   getTransformFromMatches                 src/transformation_estimation_euclidean.cpp:7-61
 //   errorFunction2                          src/misc.cpp:697-770
+//   bruteForceSearchORB                     src/features.cpp:163-182
+//   keepStrongestMatches                    src/node.cpp:516-531
+//   Node::featureMatching (ORB branch)      src/node.cpp:534-611 + 668-692 (the FLANN else-if is cut out)
+//   Node::matchNodePair                     src/node.cpp:1305-1429
+//   MatchingResult, LoadedEdge3D            src/matching_result.h:24-46, src/edge.h:24-32
 // The third-party arithmetic behind the stand-ins (Eigen's coefficient-wise fixed-size products, LLT::solve,
 // pcl::TransformationFromCorrespondences) is the oracle's restatement -- that part stays "parity unpinned";
 // what this pins on the reference's own code is all the first-party logic around it: gates, thresholds, the
@@ -20,6 +25,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <ctime>
+#include <exception>
 #include <iomanip>
 #include <iostream>
 #include <limits>
@@ -37,8 +43,12 @@
 #define ROS_WARN_STREAM(x)
 #define ROS_ERROR_STREAM(x)
 #define ROS_DEBUG_STREAM_NAMED(n, x)
+#define ROS_DEBUG_NAMED(...)
+#define ROS_INFO_COND(c, ...)
+#define ROS_FATAL_STREAM(x)
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 #define BOOST_FOREACH(decl, cont) for (decl : cont)
-struct ScopedTimer { explicit ScopedTimer(const char*) {} };
+struct ScopedTimer { explicit ScopedTimer(const char*, bool = false, bool = false) {} };
 
 extern "C" {
 uint32_t orc_rand31(uint32_t seed, uint32_t uid, uint32_t iter, uint32_t k);
@@ -53,6 +63,9 @@ struct RefParams {
   uint32_t seed = 0, uid = 0;
   uint32_t iter = 0, k = 0;  // position in the counter-based draw stream (D1)
   int sampler_calls = 0;
+  int max_matches = 300, max_connections = -1;
+  double observability_threshold = -0.6;
+  int jitter_calls = 0;  // featureMatching's distance jitter: monotone in the query index (D2)
 };
 extern RefParams g_ref;
 struct ParameterServer {
@@ -63,9 +76,21 @@ struct ParameterServer {
     if (n == "max_dist_for_inliers") return (T)g_ref.max_dist_for_inliers;
     if (n == "g2o_transformation_refinement") return (T)g_ref.g2o_transformation_refinement;
     if (n == "allow_features_without_depth") return (T)0;
+    if (n == "max_matches") return (T)g_ref.max_matches;
+    if (n == "max_connections") return (T)g_ref.max_connections;
+    if (n == "observability_threshold") return (T)g_ref.observability_threshold;
+    if (n == "nn_distance_ratio") return (T)0.95;
     return T();
   }
 };
+template <> inline std::string ParameterServer::get<std::string>(const std::string& n) {
+  if (n == "feature_detector_type" || n == "feature_extractor_type") return "ORB";
+  if (n == "matcher_type") return "FLANN";  // the default: the ORB branch pre-empts it (node.cpp:561)
+  return std::string();
+}
+// D2: the reference adds (float)rand()/(1000.0*RAND_MAX) to hd/256 so that no two distances are equal
+// (node.cpp:573); the realisation used here grows with the query index, which is exactly the oracle's tie-break.
+inline int ref_jitter_draw() { return (int)((long long)(g_ref.jitter_calls++) * (RAND_MAX / 8192)); }
 inline int ref_rand_draw() { return (int)orc_rand31(g_ref.seed, g_ref.uid, g_ref.iter, g_ref.k++); }
 // D3: the frozen static of misc2.h:30-35 as an explicit value
 inline double depth_covariance(double) { return g_ref.depth_cov; }
@@ -74,7 +99,23 @@ namespace cv {
 struct DMatch {
   int queryIdx, trainIdx, imgIdx;
   float distance;
+  DMatch() : queryIdx(-1), trainIdx(-1), imgIdx(-1), distance(std::numeric_limits<float>::max()) {}
+  DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
   bool operator<(const DMatch& m) const { return distance < m.distance; }  // opencv2/core/types.hpp
+};
+struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
+struct Mat {
+  int rows = 0, cols = 0;
+  unsigned char* data = nullptr;
+};
+template <class T>
+struct Ptr : std::shared_ptr<T> {
+  Ptr() {}
+  Ptr(T* p) : std::shared_ptr<T>(p) {}
+};
+struct DescriptorMatcher {
+  static Ptr<DescriptorMatcher> create(const std::string&) { return Ptr<DescriptorMatcher>(new DescriptorMatcher()); }
+  void knnMatch(const Mat&, const Mat&, std::vector<std::vector<DMatch> >&, int) {}
 };
 }  // namespace cv
 
@@ -171,6 +212,16 @@ struct Affine3f {
   Matrix4f M;
   Matrix4f matrix() const { return M; }
 };
+struct Isometry3d {
+  Matrix4d M;
+  Isometry3d& operator=(const Matrix4d& m) { M = m; return *this; }
+};
+template <class T, int R, int C>
+struct Matrix {
+  T m[R][C];
+  static Matrix Identity() { Matrix r; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) r.m[i][j] = (i == j) ? T(1) : T(0); return r; }
+  Matrix operator*(T s) const { Matrix r; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) r.m[i][j] = m[i][j] * s; return r; }
+};
 }  // namespace Eigen
 
 // ---- pcl::TransformationFromCorrespondences: the oracle's restated recurrence + SVD --------------------
@@ -199,10 +250,14 @@ class TransformationFromCorrespondences {
 };
 }  // namespace pcl
 
-// ---- Node skeleton --------------------------------------------------------------------------------
+// ---- Node skeleton, MatchingResult -------------------------------------------------------------------
+#include "ransac_types.inc"  // src/edge.h:24-32 and src/matching_result.h:24-46, streamed in by oracle/Makefile
 class Node {
  public:
   int id_ = 0;
+  unsigned int initial_node_matches_ = 0;
+  cv::Mat feature_descriptors_;
+  std::vector<cv::KeyPoint> feature_locations_2d_;
   std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> > feature_locations_3d_;
   void computeInliersAndError(const std::vector<cv::DMatch>& all_matches, const Eigen::Matrix4f& transformation4f,
                               const std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> >& origins,
@@ -212,10 +267,14 @@ class Node {
   bool getRelativeTransformationTo(const Node* earlier_node, std::vector<cv::DMatch>* initial_matches,
                                    Eigen::Matrix4f& resulting_transformation, float& rmse,
                                    std::vector<cv::DMatch>& matches) const;
+  unsigned int featureMatching(const Node* other, std::vector<cv::DMatch>* matches) const;
+  MatchingResult matchNodePair(const Node* older_node);
 };
 double errorFunction2(const Eigen::Vector4f& x1, const Eigen::Vector4f& x2, const Eigen::Matrix4d& transformation);
 Eigen::Matrix4f getTransformFromMatches(const Node* newer_node, const Node* earlier_node,
                                         const std::vector<cv::DMatch>& matches, bool& valid, const float max_dist_m);
 inline void getTransformFromMatchesG2O(const Node*, const Node*, const std::vector<cv::DMatch>&, Eigen::Matrix4f&, int) {}
+inline void pairwiseObservationLikelihood(const Node*, const Node*, MatchingResult&) {}
+inline bool observation_criterion_met(unsigned int, unsigned int, unsigned int, double&) { return true; }
 std::vector<cv::DMatch> sample_matches_prefer_by_distance(unsigned int sample_size, std::vector<cv::DMatch>& matches_with_depth);
 #endif

@@ -250,6 +250,47 @@ def test_ransac_matches_live_reference_functions():
     assert n_found >= 4 and n_fallback == 1
 
 
+@pytest.mark.skipif(po.ref_ransac_lib() is None, reason="reference pin (oracle/_ref/libref_ransac.so) not built")
+def test_match_node_pair_matches_live_reference_function():
+    """Rows a9-a19 end to end: the reference's own Node::matchNodePair -- featureMatching's ORB branch over
+    bruteForceSearchORB, the hd >= 128 gate, keepStrongestMatches, the in-place sort, RANSAC, MatchingResult /
+    LoadedEdge3D assembly -- compiled from /root/reference, against orc_match_node_pair: same match list in the same
+    order, same inliers, transform bits, rmse, edge ids, information scale and iteration count."""
+    seq = synth.make_sequence(n_frames=5, n_kp=600, n_world=1800, seed=23)
+    hard = synth.make_sequence(n_frames=3, n_kp=400, n_world=1200, seed=24, nan_fraction=0.06)
+    rng = np.random.default_rng(25)
+    cases = [(seq["desc"][q], seq["xyz1"][q], q, seq["desc"][t], seq["xyz1"][t], t, {}) for q, t in ((1, 0), (4, 2), (3, 3))]
+    cases.append((hard["desc"][2], hard["xyz1"][2], 2, hard["desc"][0], hard["xyz1"][0], 0,
+                  dict(max_dist_for_inliers=2.0, ransac_iterations=100)))
+    cases.append((seq["desc"][1], seq["xyz1"][1], 1, seq["desc"][0], seq["xyz1"][0], 0, dict(max_matches=64, min_matches=10)))
+    cases.append((rng.integers(0, 256, (300, 32), dtype=np.uint8), hard["xyz1"][0][:300], 9, hard["desc"][0], hard["xyz1"][0], 0, {}))
+    cases.append((seq["desc"][1][:15], seq["xyz1"][1][:15], 5, seq["desc"][1], seq["xyz1"][1], 1, {}))   # < min_matches
+    cases.append((seq["desc"][1][:1], seq["xyz1"][1][:1], 6, seq["desc"][1], seq["xyz1"][1], 1, {}))     # single query row
+    cases.append((seq["desc"][1], seq["xyz1"][1], 1, seq["desc"][0][:1], seq["xyz1"][0][:1], 7, {}))     # one train row: never searched
+    n_edges = 0
+    for qd, qx, qid, td, tx, tid, kw in cases:
+        prm = po.default_params(**kw)
+        ref = po.match_node_pair(qd, qx, qid, td, tx, tid, prm)
+        got = po.ref_match_node_pair(qd, qx, qid, td, tx, tid, prm)
+        n = ref["n_all"]
+        assert len(got["all_q"]) == n
+        if n > prm.min_matches:  # the reference sorts all_matches in place only when RANSAC runs (:1087, :1127)
+            assert np.array_equal(got["all_q"], ref["all_q"]) and np.array_equal(got["all_t"], ref["all_t"])
+            assert np.array_equal(np.floor(got["all_dist"] * 256 + 1e-3).astype(np.int32), ref["all_hd"])
+        else:
+            assert sorted(zip(got["all_q"], got["all_t"])) == sorted(zip(ref["all_q"], ref["all_t"]))
+        assert (got["id1"], got["id2"]) == (ref["id1"], ref["id2"])
+        assert got["real_iterations"] == ref["real_iterations"]
+        assert np.array_equal(got["T"], ref["T"])
+        assert got["rmse"] == ref["rmse"]
+        assert np.array_equal(got["inl_q"], ref["all_q"][ref["inl_idx"]])
+        assert np.array_equal(got["inl_t"], ref["all_t"][ref["inl_idx"]])
+        if ref["id1"] >= 0:
+            assert got["info_scale"] == ref["info_scale"] and got["accepted"] == 1
+            n_edges += 1
+    assert n_edges >= 4
+
+
 def test_ransac_recovers_ground_truth_and_is_deterministic():
     seq = synth.make_sequence(n_frames=6, n_kp=600, n_world=2500, seed=3)
     prm = po.default_params()
