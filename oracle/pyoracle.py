@@ -53,7 +53,8 @@ def build(force=False):
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if force or not all(os.path.exists(os.path.join(_HERE, "_ref", f))
-                        for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so", "libref_ransac.so")):
+                        for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so", "libref_ransac.so",
+                                  "libref_frame.so")):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -268,6 +269,39 @@ def ref_get_relative_transformation(qxyz1, txyz1, mq, mt, mdist, params, uid):
         _p(T), C.byref(rmse), _p(iq), _p(it), C.byref(n_inl), C.byref(iters))
     return dict(found=bool(found), T=T.reshape(4, 4).T.copy(), rmse=np.float32(rmse.value),
                 inl_q=iq[:n_inl.value].copy(), inl_t=it[:n_inl.value].copy(), real_iterations=iters.value)
+
+
+_ref_frame = None
+
+
+def ref_frame_lib():
+    """The reference's own removeDepthless / projectTo3D / projectTo3DSiftGPU / squareroot_descriptor_space /
+    createXYZRGBPointCloud / observationLikelihood, compiled from /root/reference with stand-ins (or None)."""
+    global _ref_frame
+    if _ref_frame is None:
+        p = os.path.join(_HERE, "_ref", "libref_frame.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        d, i, vp = C.c_double, C.c_int, C.c_void_p
+        R.ref_remove_depthless.restype = i
+        R.ref_remove_depthless.argtypes = [vp, i, vp, i, i, vp]
+        R.ref_project_to_3d.restype = i
+        R.ref_project_to_3d.argtypes = [vp, i, vp, i, i, d, d, d, d, d, i, vp, vp]
+        R.ref_project_to_3d_sift.restype = i
+        R.ref_project_to_3d_sift.argtypes = [vp, i, vp, vp, i, i, d, d, d, d, d, i, vp, vp, vp, vp]
+        R.ref_root_sift.restype = None
+        R.ref_root_sift.argtypes = [vp, i, i]
+        R.ref_create_point_cloud.restype = None
+        R.ref_create_point_cloud.argtypes = [vp, i, i, vp, i, i, d, d, d, d, d, d, i, vp]
+        R.ref_observation_likelihood.restype = None
+        R.ref_observation_likelihood.argtypes = [vp, vp, i, i, vp, d, d, d, d, i, i, d, vp]
+        R.ref_observation_criterion_met.restype = i
+        R.ref_observation_criterion_met.argtypes = [C.c_uint, C.c_uint, C.c_uint, d, C.POINTER(d)]
+        _ref_frame = R
+    return _ref_frame
 
 
 def _p(a):
