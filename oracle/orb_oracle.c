@@ -18,6 +18,10 @@
  * orb.cpp, fast.cpp, fast_score.cpp, keypoint.cpp; modules/imgproc/src/resize.cpp, smooth.cpp,
  * filter.cpp) and anchored on the reference's call sites.  The HIP kernels are tested for exact
  * equality against THIS restatement; equality with a real OpenCV build could not be checked.
+ * What IS pinned: the detector grid and its threshold adaptation (the first five entries above) -- the
+ * reference's own feature_adjuster.cpp and features.cpp:35-60, compiled from where they lie into
+ * oracle/_ref/libref_adjuster.so around this file's orb_detect, return the keypoints of orb_grid_detect
+ * frame after frame (tests/test_oracle_orb.py).  Unpinned remains what happens inside cv::ORB itself.
  *
  * Deliberate deviation (same class as D2 in rgbd_oracle.c): wherever the reference's result
  * depends on std::nth_element's unspecified order (KeyPointsFilter::retainBest, keepStrongest),

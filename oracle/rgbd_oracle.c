@@ -18,6 +18,18 @@
  *                                                              (features.cpp:174)
  *   D5  a non-positive LLT pivot yields DBL_MAX (Eigen would continue with a
  *       partially factored matrix)                             (misc.cpp:763)
+ *
+ * PINNING.  oracle/Makefile compiles the reference's own first-party code from the sources where they lie
+ * (/root/reference) into oracle/_ref/*.so and the tests hold this file against it bit for bit:
+ *   libref_bforb.so   bruteForceSearchORB                                   tests/test_oracle_hamming.py
+ *   libref_node.so    sampling, keepStrongestMatches, depth_covariance, backProject   tests/test_oracle_ransac.py
+ *   libref_ransac.so  matchNodePair, featureMatching (ORB), getRelativeTransformationTo, computeInliersAndError,
+ *                     errorFunction2, getTransformFromMatches                tests/test_oracle_ransac.py
+ *   libref_frame.so   removeDepthless, projectTo3D, projectTo3DSiftGPU, squareroot_descriptor_space,
+ *                     createXYZRGBPointCloud, observationLikelihood          tests/test_oracle_reference_frame.py
+ * Third-party arithmetic those functions call (Eigen products / LLT / JacobiSVD, pcl::TransformationFromCorrespondences,
+ * pcl::transformPointCloud, cv::reduce / convertTo) is absent from the tree and enters the pins through stand-ins that
+ * carry THIS file's restatement: for that arithmetic alone the status remains "parity unpinned".
  */
 #include "rgbd_oracle.h"
 
