@@ -20,7 +20,7 @@
  *       partially factored matrix)                             (misc.cpp:763)
  *
  * PINNING.  oracle/Makefile compiles the reference's own first-party code from the sources where they lie
- * (/root/reference) into oracle/_ref/*.so and the tests hold this file against it bit for bit:
+ * (/root/reference) into oracle/_ref/ (.so files) and the tests hold this file against it bit for bit:
  *   libref_bforb.so   bruteForceSearchORB                                   tests/test_oracle_hamming.py
  *   libref_node.so    sampling, keepStrongestMatches, depth_covariance, backProject   tests/test_oracle_ransac.py
  *   libref_ransac.so  matchNodePair, featureMatching (ORB), getRelativeTransformationTo, computeInliersAndError,
