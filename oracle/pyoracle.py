@@ -54,7 +54,7 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if force or not all(os.path.exists(os.path.join(_HERE, "_ref", f))
                         for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so", "libref_ransac.so",
-                                  "libref_frame.so")):
+                                  "libref_frame.so", "libref_siftmatch.so")):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -302,6 +302,37 @@ def ref_frame_lib():
         R.ref_observation_criterion_met.argtypes = [C.c_uint, C.c_uint, C.c_uint, d, C.POINTER(d)]
         _ref_frame = R
     return _ref_frame
+
+
+_ref_sift = None
+
+
+def ref_sift_lib():
+    """The SiftGPU matcher shipped in the reference tree (CUDA kernels + SiftMatchCU host code) and
+    SiftGPUWrapper::match, compiled from /root/reference on a CUDA-on-CPU emulation (or None)."""
+    global _ref_sift
+    if _ref_sift is None:
+        p = os.path.join(_HERE, "_ref", "libref_siftmatch.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_sift_match.restype = C.c_int
+        R.ref_sift_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _ref_sift = R
+    return _ref_sift
+
+
+def ref_sift_match(d1, d2):
+    d1 = np.ascontiguousarray(d1, np.float32)
+    d2 = np.ascontiguousarray(d2, np.float32)
+    n1 = d1.shape[0]
+    mq = np.empty(max(n1, 1), np.int32)
+    mt = np.empty(max(n1, 1), np.int32)
+    md = np.empty(max(n1, 1), np.float32)
+    n = ref_sift_lib().ref_sift_match(_p(d1), n1, _p(d2), d2.shape[0], _p(mq), _p(mt), _p(md))
+    return mq[:n].copy(), mt[:n].copy(), md[:n].copy()
 
 
 def _p(a):

@@ -25,6 +25,7 @@
  *   libref_node.so    sampling, keepStrongestMatches, depth_covariance, backProject   tests/test_oracle_ransac.py
  *   libref_ransac.so  matchNodePair, featureMatching (ORB), getRelativeTransformationTo, computeInliersAndError,
  *                     errorFunction2, getTransformFromMatches                tests/test_oracle_ransac.py
+ *   libref_siftmatch.so  the SiftGPU matcher kernels + SiftMatchCU + SiftGPUWrapper::match   tests/test_oracle_sift.py
  *   libref_frame.so   removeDepthless, projectTo3D, projectTo3DSiftGPU, squareroot_descriptor_space,
  *                     createXYZRGBPointCloud, observationLikelihood          tests/test_oracle_reference_frame.py
  * Third-party arithmetic those functions call (Eigen products / LLT / JacobiSVD, pcl::TransformationFromCorrespondences,

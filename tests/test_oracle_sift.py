@@ -129,3 +129,39 @@ def test_sift_node_features_oracle():
     # max_keypoints cut (node.cpp:748) and use_root_sift = false
     kept2, _, raw2, feat2 = po.sift_node_features(kp, desc, depth, 52.5, 52.5, 31.5, 23.5, 1.0, 9, use_root_sift=False)
     assert list(kept2) == exp[:9] and np.array_equal(raw2, feat2)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.skipif(po.ref_sift_lib() is None, reason="reference pin (oracle/_ref/libref_siftmatch.so) not built")
+def test_sift_match_matches_the_reference_trees_own_matcher():
+    """configs[3]'s behavioural reference itself: the SiftGPU matcher vendored in the reference tree --
+    MultiplyDescriptor_Kernel, RowMatch_Kernel, ColMatch_Kernel (ProgramCU.cu), SiftMatchCU::SetDescriptors /
+    GetSiftMatch / GetBestMatch -- and SiftGPUWrapper::match (src/sift_gpu_wrapper.cpp:169-227), compiled from where
+    they lie on a CUDA-on-CPU emulation, against orc_sift_match: same (queryIdx, trainIdx) list and the same float L2
+    distances, including exact duplicates (the 32-thread butterfly's tie rule), ragged sizes (not multiples of the
+    8-row / 128-column / 32-column blocks) and the index-0 "context error" heuristic."""
+    rng = np.random.default_rng(41)
+    base = _rand_sift(rng, 24)
+    cases = []
+    for n1, n2 in ((200, 260), (33, 129), (130, 31), (8, 8), (1, 40), (40, 1)):
+        d2 = _rand_sift(rng, n2)
+        d1 = d2[rng.integers(0, n2, n1)] + rng.normal(0, 0.03, (n1, 128)).astype(np.float32)
+        cases.append((np.abs(d1).astype(np.float32), d2))
+    # heavy ties: both sides drawn from 24 prototypes, a few of them exact duplicates
+    d2 = base[rng.integers(0, 24, 170)].copy()
+    d1 = base[rng.integers(0, 24, 90)].copy()
+    d2[::3] += rng.normal(0, 1e-4, d2[::3].shape).astype(np.float32)
+    cases.append((d1, d2))
+    one = _rand_sift(rng, 1)
+    cases.append((one, one))                      # a single match touching index 0: discarded (:199-209)
+    cases.append((_rand_sift(rng, 50), _rand_sift(rng, 60)))  # unrelated: (almost) nothing passes the ratio test
+    n_total = 0
+    for d1, d2 in cases:
+        mq, mt, md = po.sift_match(d1, d2)
+        rq, rt, rd = po.ref_sift_match(d1, d2)
+        assert np.array_equal(mq, rq) and np.array_equal(mt, rt), (d1.shape, d2.shape)
+        assert np.array_equal(md, rd)
+        n_total += len(mq)
+    assert n_total > 100
