@@ -200,13 +200,15 @@ def main():
         achieved = (dom_bytes * n_local) / (avg_launch_ms * 1e-3) / 1e9 if dom_launches else 0.0
         ham_avg_ms = ham_ms / max(ham_launches, 1)
         valu_achieved = (16.0 * N * (N - 1) * n_local) / (ham_avg_ms * 1e-3) if ham_launches else 0.0
-        traffic = None
+        traffic = valu_busy = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path)).get(dominant, {})
+                traffic = pmc.get("hbm_bytes_per_launch")
+                valu_busy = pmc.get("valu_busy_frac")  # SQ_ACTIVE_INST_VALU over the SIMD time of the launch
             except Exception:
-                traffic = None
+                traffic = valu_busy = None
         if sift:
             # configs[3]: the dense contraction.  FLOP per pair = 2 * Nq * Nt * 128 on the bf16 MFMA
             # (dense peak 2.5 PFLOP/s, MI355X_MICROARCH.md); reported for the MFMA kernel itself.
@@ -239,6 +241,7 @@ def main():
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic,
+            "valu_busy_frac_pmc": None if valu_busy is None else round(valu_busy, 3),
             "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
             "avg_launch_ms": round(avg_launch_ms, 4),
             "hamming_ms_per_launch": round(ham_avg_ms, 4),
@@ -246,7 +249,9 @@ def main():
             "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
             "valu_laneops_per_s": round(valu_achieved, 1), "valu_peak": VALU_PEAK_LANEOPS,
             "valu_frac": round(valu_achieved / VALU_PEAK_LANEOPS, 4), **iso,
-            "note": "the ORB match is integer-VALU bound (xor+bcnt), not HBM bound: see DESIGN.md",
+            "note": "neither kernel of the ORB pair path is HBM bound: the match is integer-VALU bound (xor+bcnt), "
+                    "select+RANSAC is VALU-issue/latency bound (valu_busy_frac_pmc = fraction of SIMD time with a VALU "
+                    "instruction active, rocprofv3 PMC pass); see DESIGN.md 4.1-4.2",
         }
         out = {
             "metric": "frame-pairs matched+RANSAC/sec, 640x480 ORB-1000",

@@ -78,5 +78,10 @@ for k, s in summary.items():
         s["hbm_bytes_per_launch"] = 2 * s["hbm_read_bytes_raw"] + s["hbm_write_bytes_raw"]
         s["note"] = "hbm_bytes_per_launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction)"
 
+    if "SQ_ACTIVE_INST_VALU_avg" in s and "GRBM_GUI_ACTIVE_avg" in s:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs (MI355X_MICROARCH.md: SQ_* count
+        # quad-cycles), GRBM_GUI_ACTIVE is summed over the 8 XCDs: fraction of SIMD time with a VALU instruction active
+        s["valu_busy_frac"] = s["SQ_ACTIVE_INST_VALU_avg"] * 4.0 / (s["GRBM_GUI_ACTIVE_avg"] / 8.0 * 1024.0)
+
 print(json.dumps(summary, indent=1, sort_keys=True))
 json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1, sort_keys=True)
