@@ -269,6 +269,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq, pq, pt, fe, args.cpu_seconds)
+            ref = cpu_reference_code(seq, pq, pt, fe, 5.0)
+            if ref is not None:
+                out["cpu_baseline_reference_code"] = ref
         print(json.dumps(out), flush=True)
 
     fe.close()
@@ -296,6 +299,30 @@ def cpu_baseline(seq, pq, pt, fe, budget_s):
     return {"value": round(n / dt, 2), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
             "sample": "%d of the %d pairs of one step, oracle/liboracle.so, OpenMP pair-parallel, %d threads"
                       % (n, len(pq), cores)}
+
+
+def cpu_reference_code(seq, pq, pt, fe, budget_s):
+    """The reference's OWN pair op (Node::matchNodePair and everything below it, compiled from the reference
+    sources into oracle/_ref/libref_ransac.so with Eigen / PCL stand-ins) timed on one host
+    thread over a bounded sample.  Reported next to cpu_baseline; None when the prebuilt pin is absent."""
+    from oracle import pyoracle as po
+    if po.ref_ransac_lib() is None:
+        return None
+    prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov)
+    descs, xyzs = seq["desc"], seq["xyz1"]
+    sel = np.linspace(0, len(pq) - 1, min(len(pq), 400)).astype(np.int64)
+    n = 0
+    t0 = time.perf_counter()
+    for k in sel:
+        q, t = int(pq[k]), int(pt[k])
+        po.ref_match_node_pair(descs[q], xyzs[q], q, descs[t], xyzs[t], t, prm)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "frame-pairs/s", "cores": 1, "kind": "reference",
+            "sample": "%d pairs of one step, the reference's matchNodePair compiled from its sources "
+                      "(oracle/_ref/libref_ransac.so, third-party arithmetic from stand-ins), one thread" % n}
 
 
 if __name__ == "__main__":
