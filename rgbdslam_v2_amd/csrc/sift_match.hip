@@ -30,8 +30,12 @@ constexpr int kSiftDim = 128;
 constexpr int kTile = 128;     // rows per block, columns per tile
 constexpr int kSiftThreads = 256;
 
+// running (best, second) with mx >= nx: the new second is the median of {mx, nx, key} (v_med3_u32), the new
+// best their maximum -- two VALU operations per accumulator element
 __device__ __forceinline__ void top2_insert(uint32_t& mx, uint32_t& nx, uint32_t key) {
-  nx = max(nx, min(mx, key));
+  uint32_t med;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(mx), "v"(nx), "v"(key));
+  nx = med;
   mx = max(mx, key);
 }
 
@@ -72,8 +76,8 @@ void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipS
 // coalesced 16-byte loads (a wave reads 4 whole 256-byte rows per instruction), written with an XOR
 // swizzle on the 16-byte chunk index (chunk ^ (row & 15)) and read back as MFMA B fragments with
 // conflict-free ds_read_b128 (the 16 lanes of a read group hit 16 different slots of the 256-byte
-// bank row).  Per tile and wave: 32 x v_mfma_f32_32x32x16_bf16 and a 5-op running top-2 update per
-// accumulator element.
+// bank row).  Per tile and wave: 32 x v_mfma_f32_32x32x16_bf16 and a 4-op running top-2 update per
+// accumulator element (cvt, key pack, v_med3_u32, v_max_u32).
 // part: [pair][max_kp][3] = (best dot, second dot, best index or 0xFFFFFFFF)
 constexpr int kChunksPerRow = 16;  // 256 B / 16 B
 
@@ -166,12 +170,15 @@ __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
       for (int c = 0; c < 2; ++c) {
         const int ct = cp * 2 + c;
         const uint32_t lo = 127u - (uint32_t)(tile * 4 + ct);
-        const bool ok = full || (t0 + ct * 32 + (lane & 31)) < ny;
+        // dot == 0 -> key < 128: inert.  Only the ragged last tile has out-of-range columns (key 0): the full
+        // tiles take the path without the per-element select.
+        if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // dot == 0 -> key < 128: inert; out-of-range columns of the ragged last tile -> 0
-          const uint32_t key = ok ? (((uint32_t)(int)acc[c][r] << 7) | lo) : 0u;
-          top2_insert(rmx[r], rnx[r], key);
+          for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], ((uint32_t)(int)acc[c][r] << 7) | lo);
+        } else {
+          const bool ok = (t0 + ct * 32 + (lane & 31)) < ny;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], ok ? (((uint32_t)(int)acc[c][r] << 7) | lo) : 0u);
         }
       }
     }
