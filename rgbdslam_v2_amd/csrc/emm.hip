@@ -85,6 +85,17 @@ __global__ __launch_bounds__(256) void create_cloud_kernel(
   zplane[k] = pt.z;  // dense depth plane for the EMM's neighbourhood reads (4 B instead of 16 B per point)
 }
 
+// The points observationLikelihood visits (every skip-th row and column, misc.cpp:882-883) copied into a dense
+// array: the EMM then reads 16 contiguous bytes per lane instead of 16 bytes per 128-byte line.  Built once per
+// (node, skip step) and cached next to the cloud.
+__global__ __launch_bounds__(256) void decimate_cloud_kernel(const float4* __restrict__ cloud, int cw, int skip_step,
+                                                            int nsx, int total, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int sy = i / nsx, sx = i - sy * nsx;
+  out[i] = cloud[(size_t)(sy * skip_step) * cw + sx * skip_step];
+}
+
 // One 256-lane block per job (= one direction of one edge), lane = sampled point of the new cloud.
 __global__ __launch_bounds__(256) void emm_kernel(const EmmJob* __restrict__ jobs, int ch, int cw, int skip_step,
                                                  double d_lo, double d_hi, uint32_t* __restrict__ counts) {
@@ -93,14 +104,13 @@ __global__ __launch_bounds__(256) void emm_kernel(const EmmJob* __restrict__ job
   const int tid = threadIdx.x;
   if (tid < 3) acc[tid] = 0u;
   __syncthreads();
-  const float4* __restrict__ new_pc = jb.new_cloud;
+  const float4* __restrict__ new_pc = jb.new_samples;  // the sampled points, contiguous (decimate_cloud_kernel)
   const float* __restrict__ old_z = jb.old_z;
   const int nsx = (cw + skip_step - 1) / skip_step, nsy = (ch + skip_step - 1) / skip_step;
   const int total = nsx * nsy;
   uint32_t good = 0, bad = 0, occ = 0;
   for (int i = tid; i < total; i += 256) {
-    const int sy = i / nsx, sx = i - sy * nsx;
-    const float4 q = new_pc[(size_t)(sy * skip_step) * cw + sx * skip_step];
+    const float4 q = new_pc[i];
     float px = q.x, py = q.y, pz = q.z;
     if (isfinite(px) && isfinite(py) && isfinite(pz)) {  // pcl::transformPointCloud, non-dense cloud
       const float x = px, y = py, z = pz;
@@ -185,6 +195,13 @@ void launch_create_cloud(const float* depth, int rows, int cols, const uint8_t* 
   if (n <= 0) return;
   hipLaunchKernelGGL(create_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, depth, rows, cols, rgb,
                      channels, encoding_bgr, fxinv, fyinv, cx, cy, depth_scaling, min_depth, s, ch, cw, cloud, zplane);
+}
+void launch_decimate_cloud(const float4* cloud, int ch, int cw, int skip_step, float4* out, hipStream_t stream) {
+  const int nsx = (cw + skip_step - 1) / skip_step, nsy = (ch + skip_step - 1) / skip_step;
+  const int total = nsx * nsy;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(decimate_cloud_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, cloud, cw, skip_step, nsx,
+                     total, out);
 }
 void launch_emm(const EmmJob* jobs, int n_jobs, int ch, int cw, int skip_step, double d_lo, double d_hi,
                 uint32_t* counts, hipStream_t stream) {

@@ -28,6 +28,8 @@ struct CloudEntry {
   int ch = 0, cw = 0;
   float fx = 0, fy = 0, cx = 0, cy = 0;  // as getCameraIntrinsics assigns them (double -> float)
   int cloud_skip = 1;                    // cloud_creation_skip_step the cloud was built with
+  float4* d_samples = nullptr;           // the points the EMM visits for emm skip step `samples_skip`, dense
+  int samples_skip = 0;                  // 0: not built (invalidated by a re-upload)
 };
 
 // smallest double q with 0.5 * (1 + erf(q)) >= target under the host's libm (bisection)
@@ -406,8 +408,10 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (sl.h_work) (void)hipHostFree(sl.h_work);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
-  for (auto& kv : ctx->clouds)
+  for (auto& kv : ctx->clouds) {
     if (kv.second.d) (void)hipFree(kv.second.d);
+    if (kv.second.d_samples) (void)hipFree(kv.second.d_samples);
+  }
   if (ctx->d_sift_bf16) (void)hipFree(ctx->d_sift_bf16);
   if (ctx->d_sift_f32) (void)hipFree(ctx->d_sift_f32);
   for (auto& ln : ctx->lanes) {
@@ -505,6 +509,7 @@ int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id) {
   if (ci != ctx->clouds.end()) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ci->second.d) (void)hipFree(ci->second.d);
+    if (ci->second.d_samples) (void)hipFree(ci->second.d_samples);
     ctx->clouds.erase(ci);
   }
   return RGBDFE_OK;
@@ -1098,6 +1103,7 @@ int rgbdfe_upload_node_cloud(rgbdfe_ctx* ctx, int32_t node_id, const float* dept
     }
   }
   ce.ch = ch; ce.cw = cw; ce.cloud_skip = cloud_skip;
+  ce.samples_skip = 0;  // the cached sample array belongs to the previous depth image
   ce.fx = (float)fx; ce.fy = (float)fy; ce.cx = (float)cx; ce.cy = (float)cy;  // misc.cpp:59-62
   HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, n * 4, hipMemcpyHostToDevice, ctx->stream));
   if (rgb) HIP_TRY(ctx, hipMemcpyAsync(d_rgb, rgb, n * (size_t)rgb_channels, hipMemcpyHostToDevice, ctx->stream));
@@ -1121,6 +1127,7 @@ int rgbdfe_release_node_cloud(rgbdfe_ctx* ctx, int32_t node_id) {
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (it->second.d) (void)hipFree(it->second.d);
+  if (it->second.d_samples) (void)hipFree(it->second.d_samples);
   ctx->clouds.erase(it);
   return RGBDFE_OK;
 }
@@ -1148,8 +1155,17 @@ int rgbdfe_observation_likelihood(rgbdfe_ctx* ctx, int32_t n, const int32_t* new
     if (i == 0) { ch = co.ch; cw = co.cw; cloud_skip = co.cloud_skip; }
     if (cn.ch != ch || cn.cw != cw || co.ch != ch || co.cw != cw || co.cloud_skip != cloud_skip)
       return fail(ctx, RGBDFE_ERR_INVALID_ARG, "clouds of one batch must share their dimensions");  // misc.cpp:845
+    if (cn.samples_skip != emm_skip_step) {  // (re)build this node's dense sample array for this skip step
+      CloudEntry& w = a->second;
+      if (w.d_samples) { (void)hipFree(w.d_samples); w.d_samples = nullptr; }
+      const size_t ns = (size_t)((ch + emm_skip_step - 1) / emm_skip_step) * (size_t)((cw + emm_skip_step - 1) / emm_skip_step);
+      if (hipMalloc((void**)&w.d_samples, ns * sizeof(float4)) != hipSuccess)
+        return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "sample array allocation failed");
+      launch_decimate_cloud(w.d, ch, cw, emm_skip_step, w.d_samples, ctx->stream);
+      w.samples_skip = emm_skip_step;
+    }
     EmmJob& jb = jobs[(size_t)i];
-    jb.new_cloud = cn.d;
+    jb.new_samples = cn.d_samples;
     jb.old_z = reinterpret_cast<const float*>(co.d + (size_t)co.ch * co.cw);
     const float* T = transforms + (size_t)i * 16;  // column-major like rgbdfe_match_result.trafo
     for (int r = 0; r < 3; ++r)

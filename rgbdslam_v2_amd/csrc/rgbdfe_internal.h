@@ -61,7 +61,7 @@ void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int 
                           hipStream_t stream, bool truncate = false);
 // one direction of one edge for the environment measurement model (emm.hip)
 struct EmmJob {
-  const float4* new_cloud;  // ch x cw points (x, y, z, rgb bits) of the frame that is projected
+  const float4* new_samples;  // the sampled points (every skip-th row / column) of the frame that is projected
   const float* old_z;       // ... into this frame's raster: its depth plane (z of every cloud point)
   float T[12];              // rows 0..2 of the 4x4 new -> old transform, row-major
   float fx, fy, cx, cy;     // old camera intrinsics, already divided by cloud_creation_skip_step
@@ -71,6 +71,7 @@ void launch_depth_u16(const uint16_t* depth_mm, size_t n, uint8_t* mono8, float*
 void launch_create_cloud(const float* depth, int rows, int cols, const uint8_t* rgb, int channels,
                          int encoding_bgr, float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                          float min_depth, int s, int ch, int cw, float4* cloud, float* zplane, hipStream_t stream);
+void launch_decimate_cloud(const float4* cloud, int ch, int cw, int skip_step, float4* out, hipStream_t stream);
 void launch_emm(const EmmJob* jobs, int n_jobs, int ch, int cw, int skip_step, double d_lo, double d_hi,
                 uint32_t* counts, hipStream_t stream);
 void launch_sift_pack(const float* desc_in, const int32_t* kept_idx, const int32_t* n_ptr, int max_rows,
