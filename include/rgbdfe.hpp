@@ -15,6 +15,8 @@
 #define RGBDFE_HPP
 
 #include <array>
+#include <cmath>
+#include <utility>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -42,6 +44,7 @@ struct MatchingResult {  // src/matching_result.h:24-46
   float rmse = 0.0f;
   std::array<float, 16> ransac_trafo{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
   std::array<float, 16> final_trafo{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+  unsigned int inlier_points = 0, outlier_points = 0, occluded_points = 0, all_points = 0;  // environment measurement model
 };
 
 inline MatchingResult toMatchingResult(const rgbdfe_match_result& r) {
@@ -110,6 +113,14 @@ class Node {  // the slice of src/node.h the pair path touches
     *matches = matchNodePair(other).all_matches;
     return (unsigned int)matches->size();
   }
+  // Node::pc_col (createXYZRGBPointCloud, src/misc.cpp:467-556): built on the device from the depth image and kept
+  // resident for the environment measurement model; rgb may be null
+  bool setPointCloud(const float* depth, int rows, int cols, const uint8_t* rgb, int rgb_channels, bool encoding_bgr,
+                     double fx, double fy, double cx, double cy, double depth_scaling, double minimum_depth,
+                     int cloud_creation_skip_step) {
+    return rgbdfe_upload_node_cloud(fe_.get(), id_, depth, rows, cols, rgb, rgb_channels, encoding_bgr ? 1 : 0, fx, fy,
+                                    cx, cy, depth_scaling, minimum_depth, cloud_creation_skip_step, nullptr) == RGBDFE_OK;
+  }
   void clearFeatureInformation() {  // src/node.cpp:1431-1443
     if (matchable_) rgbdfe_release_node(fe_.get(), id_);
     matchable_ = false;
@@ -143,6 +154,63 @@ class GraphManager {  // only the fan-out of GraphManager::nodeComparisons (grap
  private:
   const FrontEnd& fe_;
 };
+
+// 4x4 inverse of a column-major float matrix (the reference calls Eigen's Matrix4f::inverse(), node.cpp:1536):
+// Gauss-Jordan with partial pivoting in double, rounded to float
+inline std::array<float, 16> inverse4(const std::array<float, 16>& T) {
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) { a[r][c] = T[c * 4 + r]; a[r][c + 4] = r == c ? 1.0 : 0.0; }
+  for (int i = 0; i < 4; ++i) {
+    int p = i;
+    for (int r = i + 1; r < 4; ++r) if (std::fabs(a[r][i]) > std::fabs(a[p][i])) p = r;
+    for (int c = 0; c < 8; ++c) std::swap(a[i][c], a[p][c]);
+    const double d = a[i][i];
+    for (int c = 0; c < 8; ++c) a[i][c] /= d;
+    for (int r = 0; r < 4; ++r)
+      if (r != i) { const double f = a[r][i]; for (int c = 0; c < 8; ++c) a[r][c] -= f * a[i][c]; }
+  }
+  std::array<float, 16> out;
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[c * 4 + r] = (float)a[r][c + 4];
+  return out;
+}
+
+// pairwiseObservationLikelihood (src/node.cpp:1520-1554) + observation_criterion_met (src/misc.cpp:1136-1148) for a
+// batch of results, as matchNodePair applies them when observability_threshold > 0 (node.cpp:1340-1343): an edge that
+// fails the criterion is withdrawn (edge ids -1).  Both nodes of every edge need setPointCloud().
+inline bool pairwiseObservationLikelihood(const FrontEnd& fe, std::vector<MatchingResult>& results, int emm_skip_step,
+                                          double observability_threshold) {
+  std::vector<int32_t> new_ids, old_ids;
+  std::vector<float> T;
+  std::vector<size_t> which;
+  for (size_t i = 0; i < results.size(); ++i) {
+    const MatchingResult& mr = results[i];
+    if (mr.edge.id1 < 0) continue;
+    const std::array<float, 16> inv = inverse4(mr.final_trafo);
+    new_ids.push_back(mr.edge.id2); old_ids.push_back(mr.edge.id1); T.insert(T.end(), mr.final_trafo.begin(), mr.final_trafo.end());
+    new_ids.push_back(mr.edge.id1); old_ids.push_back(mr.edge.id2); T.insert(T.end(), inv.begin(), inv.end());
+    which.push_back(i);
+  }
+  if (which.empty()) return true;
+  std::vector<rgbdfe_emm_counts> c(new_ids.size());
+  if (rgbdfe_observation_likelihood(fe.get(), (int32_t)new_ids.size(), new_ids.data(), old_ids.data(), T.data(),
+                                    emm_skip_step, c.data()) != RGBDFE_OK)
+    return false;
+  for (size_t k = 0; k < which.size(); ++k) {
+    MatchingResult& mr = results[which[k]];
+    const rgbdfe_emm_counts &a = c[2 * k], &b = c[2 * k + 1];
+    mr.inlier_points = a.inliers + b.inliers;     // node.cpp:1548-1551
+    mr.outlier_points = a.outliers + b.outliers;
+    mr.occluded_points = a.occluded + b.occluded;
+    mr.all_points = a.all + b.all;
+    double quality = 0.0;
+    if (!rgbdfe_observation_criterion_met(mr.inlier_points, mr.outlier_points,
+                                          mr.occluded_points + mr.inlier_points + mr.outlier_points,
+                                          observability_threshold, &quality))
+      mr.edge.id1 = mr.edge.id2 = -1;  // node.cpp:1419-1422
+  }
+  return true;
+}
 
 }  // namespace rgbdslam
 #endif
