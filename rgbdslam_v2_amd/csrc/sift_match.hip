@@ -32,11 +32,12 @@ constexpr int kSiftThreads = 256;
 
 // running (best, second) with mx >= nx: the new second is the median of {mx, nx, key} (v_med3_u32), the new
 // best their maximum -- two VALU operations per accumulator element
+// running (best, second) with mx >= nx: the new second is the median of {mx, nx, key} (v_med3_u32), the new
+// best their maximum -- two VALU operations per accumulator element
 __device__ __forceinline__ void top2_insert(uint32_t& mx, uint32_t& nx, uint32_t key) {
-  uint32_t med;
-  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(mx), "v"(nx), "v"(key));
-  nx = med;
+  const uint32_t med = max(min(mx, nx), min(max(mx, nx), key));  // the shape the back end matches to v_med3_u32
   mx = max(mx, key);
+  nx = med;
 }
 
 __device__ __forceinline__ int row_of_reg(int reg, int lane) {
@@ -77,7 +78,8 @@ void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipS
 // swizzle on the 16-byte chunk index (chunk ^ (row & 15)) and read back as MFMA B fragments with
 // conflict-free ds_read_b128 (the 16 lanes of a read group hit 16 different slots of the 256-byte
 // bank row).  Per tile and wave: 32 x v_mfma_f32_32x32x16_bf16 and a 4-op running top-2 update per
-// accumulator element (cvt, key pack, v_med3_u32, v_max_u32).
+// accumulator element (v_cvt_i32_f32, v_lshl_or_b32, v_med3_u32, v_max_u32); the MFMAs write VGPRs
+// (-mllvm -amdgpu-mfma-vgpr-form, see the Makefile), so there is no v_accvgpr_read.
 // part: [pair][max_kp][3] = (best dot, second dot, best index or 0xFFFFFFFF)
 constexpr int kChunksPerRow = 16;  // 256 B / 16 B
 
@@ -149,38 +151,62 @@ __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
     }
     const int t0 = tile * kTile;
     const bool full = t0 + kTile <= ny;
+    // The 4 column tiles of the Y tile, software pipelined: the 8 MFMAs of column tile ct+1 are issued before
+    // the top-2 epilogue of column tile ct, so the matrix pipe works on ct+1 while the VALU digests ct
+    // (two accumulators = 32 registers in flight).
+    auto dots = [&](int ct) {
+      f32x16 acc;
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {  // two column tiles at a time keeps the accumulators at 32 registers
-      f32x16 acc[2];
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      const int row = ct * 32 + (lane & 31);
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int row = (cp * 2 + c) * 32 + (lane & 31);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const int chunk = ks * 2 + (lane >> 5);
-          const bf16x8 B = __builtin_bit_cast(bf16x8, tileY[buf][row * kChunksPerRow + (chunk ^ (row & 15))]);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], B, acc[c], 0, 0, 0);
-        }
+      for (int ks = 0; ks < 8; ++ks) {
+        const int chunk = ks * 2 + (lane >> 5);
+        const bf16x8 B = __builtin_bit_cast(bf16x8, tileY[buf][row * kChunksPerRow + (chunk ^ (row & 15))]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], B, acc, 0, 0, 0);
       }
+      return acc;
+    };
+    // full tiles: no per-element select, one straight-line block so that the scheduler can interleave the
+    // MFMAs of ct+1 with the VALU work of ct; the ragged last tile zeroes the keys of out-of-range columns
+    auto digest_full = [&](const f32x16& acc, int ct) {
+      const uint32_t lo = 127u - (uint32_t)(tile * 4 + ct);  // dot == 0 -> key < 128: inert
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int ct = cp * 2 + c;
-        const uint32_t lo = 127u - (uint32_t)(tile * 4 + ct);
-        // dot == 0 -> key < 128: inert.  Only the ragged last tile has out-of-range columns (key 0): the full
-        // tiles take the path without the per-element select.
-        if (full) {
+      for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], ((uint32_t)(int)acc[r] << 7) | lo);
+    };
+    auto digest_ragged = [&](const f32x16& acc, int ct) {
+      const uint32_t lo = 127u - (uint32_t)(tile * 4 + ct);
+      const bool ok = (t0 + ct * 32 + (lane & 31)) < ny;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], ((uint32_t)(int)acc[c][r] << 7) | lo);
-        } else {
-          const bool ok = (t0 + ct * 32 + (lane & 31)) < ny;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], ok ? (((uint32_t)(int)acc[c][r] << 7) | lo) : 0u);
-        }
-      }
+      for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], ok ? (((uint32_t)(int)acc[r] << 7) | lo) : 0u);
+    };
+    // scheduling hint for one (dots(ct+1), digest(ct)) pair: 8 x { 1 MFMA, 10 VALU }
+#define SIFT_INTERLEAVE()                                             \
+  _Pragma("unroll") for (int g = 0; g < 8; ++g) {                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);                \
+  }
+    if (full) {
+      const f32x16 a0 = dots(0);
+      const f32x16 a1 = dots(1);
+      digest_full(a0, 0);
+      SIFT_INTERLEAVE()
+      const f32x16 a2 = dots(2);
+      digest_full(a1, 1);
+      SIFT_INTERLEAVE()
+      const f32x16 a3 = dots(3);
+      digest_full(a2, 2);
+      SIFT_INTERLEAVE()
+      digest_full(a3, 3);
+    } else {
+      const f32x16 a0 = dots(0);
+      const f32x16 a1 = dots(1);
+      digest_ragged(a0, 0);
+      const f32x16 a2 = dots(2);
+      digest_ragged(a1, 1);
+      const f32x16 a3 = dots(3);
+      digest_ragged(a2, 2);
+      digest_ragged(a3, 3);
     }
     if (more) {
       SIFT_STORE_TILE(buf ^ 1, nxt)
