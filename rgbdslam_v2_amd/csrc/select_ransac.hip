@@ -29,6 +29,8 @@
 //     CPU restatement, so every discrete RANSAC decision is too.
 #include <float.h>
 
+#include <type_traits>
+
 #include "rgbdfe_internal.h"
 
 namespace rgbdfe {
@@ -618,7 +620,8 @@ __device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, const ui
 // conditionally executed block (which would serialise the LDS loads feeding it again).
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 
-// n_mine: list length of this lane's slot (0: nothing to do), n_max: the longest list of the round.
+// n_mine: list length of this lane's slot (0: nothing to do), n_min / n_max: the shortest / longest list among the
+// slots that take part in the round.
 // On return lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s.
 // Software pipeline per trip of kFitUnroll steps: list entries are read two trips ahead, the match
 // records one trip ahead; every load is unconditional (lists are padded two trips past their end with a
@@ -628,7 +631,7 @@ __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 // caller guarantees by checking once per pair that every weight lies in [2^-40, 2^40] (W is a sum of at
 // most 320 of them).
 template <bool FAST_DIV>
-__device__ __forceinline__ void fit_recurrence(int n_mine, int k256_mine, int n_max, const RansacLds& lds,
+__device__ __forceinline__ void fit_recurrence(int n_mine, int k256_mine, int n_min, int n_max, const RansacLds& lds,
                                                float& C, float& m1, float& m2) {
   constexpr int U = kFitUnroll;
   const int lane = threadIdx.x;
@@ -658,7 +661,7 @@ __device__ __forceinline__ void fit_recurrence(int n_mine, int k256_mine, int n_
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) off[u] = rec_off(U + u);
-  for (int k0 = 0; k0 < n_max; k0 += U) {
+  auto trip = [&](int k0, auto with_select) {
     float wc[U], fc[U], tc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { wc[u] = wv[u]; fc[u] = fv[u]; tc[u] = tv[u]; }
@@ -701,13 +704,23 @@ __device__ __forceinline__ void fit_recurrence(int n_mine, int k256_mine, int n_
       float Cn = om[u] * sum;
       float m1n = m1 + al[u] * d1;
       float m2n = m2 + al[u] * d2;
-      pin(Cn); pin(m1n); pin(m2n);
-      C = act ? Cn : C;
-      m1 = act ? m1n : m1;
-      m2 = act ? m2n : m2;
+      if (decltype(with_select)::value) {  // a slot whose list has ended keeps its state
+        pin(Cn); pin(m1n); pin(m2n);
+        C = act ? Cn : C;
+        m1 = act ? m1n : m1;
+        m2 = act ? m2n : m2;
+      } else {
+        C = Cn; m1 = m1n; m2 = m2n;
+      }
     }
-  }
+  };
+  // While every participating slot still has entries (k < n_min) no lane needs the selects; lanes of slots that
+  // do not take part in this round (n_mine == 0) compute garbage that nobody reads.
+  int k0 = 0;
+  for (; k0 + U <= n_min; k0 += U) trip(k0, std::false_type());
+  for (; k0 < n_max; k0 += U) trip(k0, std::true_type());
 }
+
 
 __device__ __forceinline__ void hyp_store(Hyp& h, const float* R, const float* t, const uint64_t* mask,
                                           int n, int nan, double err) {
@@ -1042,7 +1055,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         if (!any_active) break;
         // ---- refits (:1142): the weighted-mean recurrences of all active slots side by side, then
         // ONE batched 3x3 SVD with lane = slot
-        int n_mine = 0, k256_mine = 0, n_max = 0;
+        int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
         PH_MARK(5)
         for (int g = 0; g < G; ++g) {
           Slot& sl = lds.slot[g];
@@ -1054,6 +1067,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
           const int n_g = fit_compact(g, m5, w_nonzero, lds, k256_g);
           if (lane / 9 == g) { n_mine = n_g; k256_mine = k256_g; }
           n_max = max(n_max, n_g);
+          n_min = min(n_min, n_g);
           PH_COUNT(7)
         }
         __syncthreads();
@@ -1064,8 +1078,8 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         mine.reset();
         {
           float C, m1, m2;
-          if (fast_alpha) fit_recurrence<true>(n_mine, k256_mine, n_max, lds, C, m1, m2);
-          else fit_recurrence<false>(n_mine, k256_mine, n_max, lds, C, m1, m2);
+          if (fast_alpha) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, lds, C, m1, m2);
+          else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, lds, C, m1, m2);
           PH_MARK(4)
           // lane s (< G) collects the state of slot s
           const int src = min(lane, kSlots - 1) * 9;

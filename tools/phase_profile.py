@@ -13,7 +13,7 @@ fe = FrontEnd(max_nodes=F, max_keypoints=1024, max_pairs_per_batch=4096)
 for f in range(F):
     fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 out = fe.match_pair_list(pq, pt)
-dbg = out["all_q"][:, :64].copy().view(np.uint64)
+dbg = out["all_q"][:, :64].copy().view(np.int64)  # signed: a reordered timer read shows up as a small negative delta
 names = ["select", "load_pts", "hyp_gen", "score", "refit", "other", "n_score", "n_refit"]
 tot = (dbg[:, :6].sum(axis=1) + dbg[:, 8] + dbg[:, 12]).astype(np.float64)
 print("pairs", len(out), "mean wall cycles/pair %.3g" % tot.mean(), "max %.3g" % tot.max())
