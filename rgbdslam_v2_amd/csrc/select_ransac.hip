@@ -607,7 +607,8 @@ __device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, const ui
   for (int r = 0; r < kRounds; ++r) {
     // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
     const uint64_t pm = mask[r] & w_nonzero[r];  // wave-uniform: scalar ALU
-    if ((pm >> lane) & 1ull) lds.u.fit.ord[s][base + lane_rank(pm)] = (uint8_t)(r * kWave + lane);
+    // lane's bit of the wave-uniform mask as the execution mask itself (s_and_saveexec), no per-lane shift
+    if (__builtin_amdgcn_inverse_ballot_w64(pm)) lds.u.fit.ord[s][base + lane_rank(pm)] = (uint8_t)(r * kWave + lane);
     base += (uint32_t)__popcll(pm);
     if (r == 256 / kWave - 1) n_below_256 = (int)base;
   }
