@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
     const int g = i * kSiftThreads + tid;                               \
     int row = (TILE) * kTile + (g >> 4);                                \
     row = row < ny ? row : ny - 1;                                      \
+    row = row < 0 ? 0 : row; /* ny == 0: nothing is used, but the load is unconditional */ \
     REGS[i] = ysrc[(size_t)row * kChunksPerRow + (g & 15)];             \
   }
 #define SIFT_STORE_TILE(BUF, REGS)                                      \

@@ -227,3 +227,47 @@ def test_full_size_properties(fe):
         assert np.all(np.diff(hd) >= 0) and hd.max() < 128
     for f in range(F):
         fe.release_node(f)
+
+
+def test_randomised_nodes_and_parameters_match_oracle():
+    """Seeded fuzz: node sizes from 0 to the capacity, NaN / zero depths, unrelated and duplicated descriptors,
+    random max_matches / min_matches / ransac_iterations / max_dist_for_inliers / depth_cov / seed -- every pair
+    must equal the oracle bit for bit (this is the test that visits max_matches not a multiple of 64, n_all in 1..4,
+    ransac_iterations = 0, thresholds above the match count, ...)."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    rng = np.random.default_rng(20260924)
+    fe2 = FrontEnd(device_id=0, max_nodes=12, max_keypoints=1536, max_pairs_per_batch=64)
+    try:
+        for trial in range(6):
+            F = 8
+            sizes = [int(rng.choice([0, 1, 3, 5, 21, 64, 300, 777, 1000, 1536])) for _ in range(F)]
+            seq = synth.make_sequence(n_frames=F, n_kp=1536, n_world=4000, seed=100 + trial,
+                                      nan_fraction=float(rng.choice([0.0, 0.05, 0.3])))
+            nodes = []
+            for f in range(F):
+                d, x = seq["desc"][f][: sizes[f]].copy(), seq["xyz1"][f][: sizes[f]].copy()
+                if sizes[f] > 10 and rng.random() < 0.3:
+                    x[rng.random(sizes[f]) < 0.1, 2] = 0.0          # zero depths
+                if sizes[f] > 10 and rng.random() < 0.2:
+                    d[:] = rng.integers(0, 256, d.shape, dtype=np.uint8)  # unrelated descriptors
+                if sizes[f] > 10 and rng.random() < 0.2:
+                    d[1::2] = d[0::2][: len(d[1::2])]                 # duplicated rows: ties in hd and in the train index
+                nodes.append((d, x))
+                fe2.upload_node(f, d, x)
+            kw = dict(max_matches=int(rng.choice([1, 4, 5, 63, 64, 65, 200, 300, 320])),
+                      min_matches=int(rng.choice([0, 1, 4, 20, 50])),
+                      ransac_iterations=int(rng.choice([0, 1, 7, 8, 50, 200, 300])),
+                      max_dist_for_inliers=float(rng.choice([0.5, 2.0, 3.0])),
+                      depth_cov=float(rng.choice([1e-4, 2.5e-5, 1e-3])), seed=int(rng.integers(0, 2**31)))
+            fe2.set_params(**kw)
+            pq = rng.integers(0, F, 24).astype(np.int32)
+            pt = rng.integers(0, F, 24).astype(np.int32)
+            out = fe2.match_pair_list(pq, pt)
+            prm = po.default_params(**kw)
+            for rec, q, t in zip(out, pq, pt):
+                ref = po.match_node_pair(nodes[q][0], nodes[q][1], int(q), nodes[t][0], nodes[t][1], int(t), prm)
+                check_against_oracle(rec, ref)
+            for f in range(F):
+                fe2.release_node(f)
+    finally:
+        fe2.close()

@@ -115,3 +115,37 @@ def test_sift_pair_op_vs_oracle(fe):
     fe.release_node(100)
     for f in range(F):
         fe.release_node(f)
+
+
+def test_sift_pair_op_ragged_and_empty_nodes(fe):
+    """Regression (found by tools/fuzz_sift.py): an empty train node made the tile preload read before the slab.
+    Ragged sizes around the 32-row / 128-column tiles, empty and single-row nodes, small max_matches."""
+    from rgbdslam_v2_amd.frontend import inlier_indices
+    rng = np.random.default_rng(13)
+    sizes = [1, 127, 1536, 129, 300, 0, 33, 2]
+    F = len(sizes)
+    seq = synth.make_sequence(n_frames=F, n_kp=1536, n_world=4000, seed=313)
+    sd = synth.sift_descriptors_like(seq["desc"], seed=13)
+    nodes = [(sd[f][: sizes[f]].copy(), seq["xyz1"][f][: sizes[f]].copy()) for f in range(F)]
+    nodes[3][0][1::2] = nodes[3][0][0::2][: len(nodes[3][0][1::2])]  # exact duplicates: tie rules
+    for f in range(F):
+        fe.upload_sift_node(f, *nodes[f])
+    kw = dict(max_matches=5, min_matches=0, ransac_iterations=200)
+    fe.set_params(**kw)
+    try:
+        pq = np.array([q for q in range(F) for t in range(F)], np.int32)
+        pt = np.array([t for q in range(F) for t in range(F)], np.int32)
+        out, dist = fe.match_sift_pair_list(pq, pt)
+        prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov, **kw)
+        for rec, dd, q, t in zip(out, dist, pq, pt):
+            ref = po.match_sift_node_pair(nodes[q][0], nodes[q][1], int(q), nodes[t][0], nodes[t][1], int(t), prm)
+            n = ref["n_all"]
+            assert rec["n_all"] == n and np.array_equal(rec["all_q"][:n], ref["all_q"])
+            assert np.array_equal(rec["all_t"][:n], ref["all_t"]) and np.array_equal(dd[:n], ref["all_dist"])
+            assert (rec["id1"], rec["id2"], rec["n_inl"]) == (ref["id1"], ref["id2"], ref["n_inl"])
+            assert np.array_equal(inlier_indices(rec), ref["inl_idx"])
+            assert np.array_equal(np.array(rec["trafo"], np.float32).reshape(4, 4).T, ref["T"])
+    finally:
+        fe.set_params(max_matches=300, min_matches=20, ransac_iterations=200)
+        for f in range(F):
+            fe.release_node(f)
