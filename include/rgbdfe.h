@@ -182,6 +182,15 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
                               int32_t use_root_sift, int32_t* kept_idx, float* xyz1,
                               float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out);
 
+/* Small batches (the live-SLAM call: one new node against ~20 candidates) are latency-bound: one wave per pair runs
+ * that pair's whole RANSAC loop (~4.6 ms at 167 iterations).  For ORB batches of at most max_pairs pairs the library
+ * therefore spreads every pair's iterations over ceil(ransac_iterations / chunk_iterations) waves that record each
+ * iteration's outcome, and replays the records in iteration order with the reference's bookkeeping (node.cpp:1171-1190)
+ * afterwards: results are identical to the one-wave path (an iteration's refinement depends only on its index),
+ * the price is that no iteration is skipped by the reference's early exits.  Defaults: max_pairs = 64,
+ * chunk_iterations = 7; max_pairs = 0 disables the path. */
+int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations);
+
 /* ---- frame-level data either side of the pair path ----------------
  * rgbdfe_depth_to_mono8: depthToCV8UC1 (misc.cpp:414-430), the detection mask the listener derives from
  *   the depth image.  depth_is_u16 == 0: depth is rows x cols f32 (metres), mono8 = convertTo(CV_8UC1, 100)

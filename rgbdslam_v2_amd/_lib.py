@@ -177,6 +177,8 @@ def load():
     L.rgbdfe_observation_criterion_met.restype = C.c_int
     L.rgbdfe_observation_criterion_met.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                                    C.POINTER(C.c_double)]
+    L.rgbdfe_set_latency_mode.restype = C.c_int
+    L.rgbdfe_set_latency_mode.argtypes = [ctx, i32, i32]
     L.rgbdfe_set_profiling.restype = C.c_int
     L.rgbdfe_set_profiling.argtypes = [ctx, C.c_int]
     L.rgbdfe_get_kernel_time.restype = C.c_int
@@ -205,6 +207,6 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
     "rgbdfe_project_to_3d", "rgbdfe_sift_node_features", "rgbdfe_depth_to_mono8",
     "rgbdfe_upload_node_cloud", "rgbdfe_release_node_cloud", "rgbdfe_observation_likelihood",
-    "rgbdfe_observation_criterion_met", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
+    "rgbdfe_observation_criterion_met", "rgbdfe_set_latency_mode", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
     "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
 ]

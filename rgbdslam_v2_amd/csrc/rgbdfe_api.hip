@@ -87,6 +87,8 @@ struct rgbdfe_ctx {
   static constexpr int kRing = 4;
   struct Lane {
     hipStream_t stream = nullptr;
+    IterRec* d_recs = nullptr;              // latency path: per pair x RANSAC iteration outcome records
+    size_t recs_capacity = 0;               // in records
     uint32_t* d_keys = nullptr;             // max_pairs x max_kp
     rgbdfe_match_result* d_results = nullptr;  // staging for the host-output entry points
     // SIFT scratch (allocated with the first SIFT node)
@@ -110,6 +112,10 @@ struct rgbdfe_ctx {
   };
   Lane lanes[kLanes];
   Slot ring[kRing];
+  // Batches of at most latency_pairs ORB pairs take the record / replay path (select_ransac.hip): the refinement
+  // work of one pair is spread over ceil(ransac_iterations / latency_chunk_iters) waves.  0 disables it.
+  int32_t latency_pairs = 64;
+  int32_t latency_chunk_iters = 7;
   int64_t next_ticket = 1;
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   rgbdfe_match_result* h_results = nullptr;  // pinned staging of the synchronous host-output entry points
@@ -289,7 +295,22 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       const uint32_t planes = launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, mk, (uint32_t)n, max_nq,
                                                 max_nt, (uint32_t)ctx->cfg.max_pairs_per_batch, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-      launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, stream);
+      const size_t need_recs = (size_t)n * (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0);
+      bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * ctx->latency_chunk_iters &&
+                     need_recs <= ((size_t)1 << 22);
+      if (latency && need_recs > lane.recs_capacity) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (lane.d_recs) (void)hipFree(lane.d_recs);
+        lane.d_recs = nullptr;
+        lane.recs_capacity = 0;
+        if (hipMalloc((void**)&lane.d_recs, need_recs * sizeof(IterRec)) == hipSuccess) lane.recs_capacity = need_recs;
+        else latency = false;  // fall back to the one-wave-per-pair kernel
+      }
+      if (latency)
+        launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
+                                     lane.d_recs, ctx->latency_chunk_iters, stream);
+      else
+        launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
     } else {
       launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
@@ -423,6 +444,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (ln.d_sm_d) (void)hipFree(ln.d_sm_d);
     if (ln.d_sm_n) (void)hipFree(ln.d_sm_n);
     if (ln.d_all_dist) (void)hipFree(ln.d_all_dist);
+    if (ln.d_recs) (void)hipFree(ln.d_recs);
     if (ln.d_keys) (void)hipFree(ln.d_keys);
     if (ln.d_results) (void)hipFree(ln.d_results);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
@@ -1237,6 +1259,14 @@ int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32
   if (quality) *quality = q;
   const double certainty = inliers / static_cast<double>(all);
   return (q > observability_threshold) && (certainty > 0.25) ? 1 : 0;
+}
+
+int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations) {
+  if (!ctx || max_pairs < 0 || chunk_iterations < 1) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->latency_pairs = max_pairs;
+  ctx->latency_chunk_iters = chunk_iterations;
+  return RGBDFE_OK;
 }
 
 int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable) {

@@ -41,6 +41,18 @@ uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
                           uint32_t n_pairs, const RansacConst& rc, hipStream_t stream);
+// outcome of one RANSAC iteration's refinement loop (node.cpp:1140-1169): refined transform, inlier set, error
+struct IterRec {
+  float rR[9], rt[3];
+  uint64_t rmask[5];
+  double rerr;
+  int32_t rn;
+  int32_t pad;
+};
+void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
+                                  uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int chunk_iters,
+                                  hipStream_t stream);
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,

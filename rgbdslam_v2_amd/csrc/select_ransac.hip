@@ -754,15 +754,28 @@ struct SiftMatchList {
   float* all_dist;     // [pair][RGBDFE_MAX_MATCHES] output: distances of the selected matches
 };
 
-template <bool SIFT>
+// MODE selects what a wave does with a pair's RANSAC iterations ("latency"):
+//   kWhole   the whole pair: windows of iterations refined side by side, replayed in order (throughput path)
+//   kRecord  only iterations [chunk * chunk_iters, (chunk + 1) * chunk_iters): refine them and write each iteration's
+//            outcome (IterRec) to memory -- several waves share one pair; no replay, no result
+//   kReplay  the whole pair again, but every iteration's outcome is read from the records instead of being
+//            computed: the in-order replay with the reference's bookkeeping, the identity fallback, the result
+// kRecord + kReplay give the same result as kWhole (an iteration's refinement is a pure function of its index, D1)
+// with the refinement work of one pair spread over many waves: the small-batch / low-latency path.
+constexpr int kWhole = 0, kRecord = 1, kReplay = 2;
+
+template <bool SIFT, int MODE>
 __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
     const uint32_t* __restrict__ keys, uint32_t key_planes, const SiftMatchList sm,
     rgbdfe_match_result* __restrict__ results, uint32_t max_kp, uint32_t n_pairs,
-    const RansacConst rc) {
+    const RansacConst rc, IterRec* __restrict__ recs, uint32_t n_chunks, int chunk_iters) {
   __shared__ RansacLds lds;
-  const uint32_t pair = blockIdx.x;
+  const uint32_t pair = MODE == kRecord ? blockIdx.x / n_chunks : blockIdx.x;
+  const int k_begin = MODE == kRecord ? (int)(blockIdx.x % n_chunks) * chunk_iters : 0;
+  const int k_end = MODE == kRecord ? min(k_begin + chunk_iters, rc.ransac_iterations) : 0;
   if (pair >= n_pairs) return;
+  IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : recs + (size_t)pair * (size_t)rc.ransac_iterations;
   const int lane = threadIdx.x;
   const PairWork w = work[pair];
   rgbdfe_match_result* __restrict__ out = results + pair;
@@ -900,13 +913,15 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       w_plain |= (m < n_all) && (wgt != 0.0f) && (ex < 127u - 40u || ex > 127u + 40u);
       w_nonzero[r] = __ballot(wgt != 0.0f);
     }
-    out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
-    out->all_t[m] = (uint16_t)(qt >> 16);
-    if (SIFT) {
-      out->all_hd[m] = 0;
-      sm.all_dist[(size_t)pair * RGBDFE_MAX_MATCHES + m] = __uint_as_float(hd);
-    } else {
-      out->all_hd[m] = (uint8_t)hd;
+    if (MODE != kRecord) {
+      out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
+      out->all_t[m] = (uint16_t)(qt >> 16);
+      if (SIFT) {
+        out->all_hd[m] = 0;
+        sm.all_dist[(size_t)pair * RGBDFE_MAX_MATCHES + m] = __uint_as_float(hd);
+      } else {
+        out->all_hd[m] = (uint8_t)hd;
+      }
     }
   }
   __syncthreads();
@@ -936,11 +951,29 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     int hyp_base = -kWave;  // iteration index of lane 0's hypothesis (none yet)
     bool done = false;
 
-    for (int it = 0; !done && it < rc.ransac_iterations && n_all >= 4;) {  // :1130
-      const int k0 = real_iterations;
+    int k_cur = k_begin;  // kRecord: next iteration of this wave's chunk
+    for (int it = 0; MODE == kRecord ? (k_cur < k_end && n_all >= 4)
+                                     : (!done && it < rc.ransac_iterations && n_all >= 4);) {  // :1130
+      const int k0 = MODE == kRecord ? k_cur : real_iterations;
       // The first iteration runs alone: an easy pair leaves the loop right after it (:1188) and must
       // not pay for a speculative window.
-      const int G = (k0 == 0) ? 1 : kSlots;
+      const int G = MODE == kRecord ? min(kSlots, k_end - k0) : ((k0 == 0) ? 1 : kSlots);
+      if (MODE == kReplay) {
+        // the outcomes of iterations k0 .. k0+G-1 come from the records written by the kRecord waves
+        if (lane < G) {
+          const IterRec& r = rec_pair[k0 + lane];
+          Slot& sl = lds.slot[lane];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) sl.rR[i] = r.rR[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) sl.rt[i] = r.rt[i];
+#pragma unroll
+          for (int q = 0; q < kRounds; ++q) sl.rmask[q] = r.rmask[q];
+          sl.rerr = r.rerr;
+          sl.rn = r.rn;
+        }
+        __syncthreads();
+      } else {
       if (hyp_base < 0 || k0 + G > hyp_base + kWave) {
         // ---- LANE = HYPOTHESIS: sample + 4-point fit for iterations k0 .. k0+63
         hyp_base = k0;
@@ -1110,6 +1143,25 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         }
         __syncthreads();
       }
+      }  // MODE != kReplay
+      if (MODE == kRecord) {
+        if (lane < G) {
+          const Slot& sl = lds.slot[lane];
+          IterRec& r = rec_pair[k0 + lane];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) r.rR[i] = sl.rR[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) r.rt[i] = sl.rt[i];
+#pragma unroll
+          for (int q = 0; q < kRounds; ++q) r.rmask[q] = sl.rmask[q];
+          r.rerr = sl.rerr;
+          r.rn = sl.rn;
+          r.pad = 0;
+        }
+        __syncthreads();
+        k_cur += G;
+        continue;
+      }
       // ---- replay the window in iteration order (:1171-1190)
       for (int g = 0; g < G; ++g) {
         if (!(it < rc.ransac_iterations)) { done = true; break; }
@@ -1144,7 +1196,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         ++it;
       }
     }
-    if (valid_iterations == 0) {  // :1192 identity hypothesis
+    if (MODE != kRecord && valid_iterations == 0) {  // :1192 identity hypothesis
       uint64_t inl_mask[kRounds];
       int n_inl;
       double inlier_error;
@@ -1161,7 +1213,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
   __syncthreads();
 
   // ------------------------------------------------------------------ result POD
-  if (lane == 0) {
+  if (MODE != kRecord && lane == 0) {
     const Hyp& b = lds.best;
     out->n_all = n_all;
     out->n_inl = best_n;
@@ -1202,8 +1254,24 @@ void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const ui
                           uint32_t n_pairs, const RansacConst& rc, hipStream_t stream) {
   if (n_pairs == 0) return;
   SiftMatchList none{};
-  hipLaunchKernelGGL(select_ransac_kernel<false>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, keys, key_planes, none, results, max_kp, n_pairs, rc);
+  hipLaunchKernelGGL((select_ransac_kernel<false, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
+                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, (IterRec*)nullptr, 1u, 0);
+}
+
+// Small batches: the refinement of every pair's iterations is spread over n_chunks waves (kRecord), then one wave
+// per pair replays the recorded outcomes in order (kReplay).  recs: n_pairs x rc.ransac_iterations records.
+void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
+                                  uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int chunk_iters,
+                                  hipStream_t stream) {
+  if (n_pairs == 0) return;
+  SiftMatchList none{};
+  const uint32_t n_chunks = (uint32_t)((rc.ransac_iterations + chunk_iters - 1) / chunk_iters);
+  if (n_chunks > 0)
+    hipLaunchKernelGGL((select_ransac_kernel<false, kRecord>), dim3(n_pairs * n_chunks), dim3(kWave), 0, stream,
+                       xyz_pool, work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, n_chunks, chunk_iters);
+  hipLaunchKernelGGL((select_ransac_kernel<false, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
+                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, 1u, 0);
 }
 
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
@@ -1212,8 +1280,8 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, con
                                uint32_t n_pairs, const RansacConst& rc, hipStream_t stream) {
   if (n_pairs == 0) return;
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
-  hipLaunchKernelGGL(select_ransac_kernel<true>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc);
+  hipLaunchKernelGGL((select_ransac_kernel<true, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
+                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, (IterRec*)nullptr, 1u, 0);
 }
 
 }  // namespace rgbdfe

@@ -16,10 +16,14 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "pair_golden.npz")
 POSE_TOL = 1e-4
 
 
-@pytest.fixture(scope="module")
-def fe():
+# Every test of this module runs twice: through the one-wave-per-pair kernel (the throughput path bench.py measures)
+# and with small batches on the record / replay latency path (rgbdfe_set_latency_mode, the library default).
+@pytest.fixture(scope="module", params=[0, 64], ids=["one_wave_per_pair", "latency_path"])
+def fe(request):
     from rgbdslam_v2_amd.frontend import FrontEnd
     f = FrontEnd(device_id=0, max_nodes=64, max_keypoints=1536, max_pairs_per_batch=2048)
+    f.latency_default = request.param
+    f.set_latency_mode(request.param, 7)
     yield f
     f.close()
 
@@ -271,3 +275,44 @@ def test_randomised_nodes_and_parameters_match_oracle():
                 fe2.release_node(f)
     finally:
         fe2.close()
+
+
+def test_latency_path_equals_one_wave_path(fe):
+    """Small ORB batches spread every pair's RANSAC iterations over several waves (record + replay,
+    rgbdfe_set_latency_mode); the result must be byte-identical to the one-wave-per-pair kernel for every chunking,
+    including iteration counts that are no multiple of the chunk or of the 7-iteration window, and edge-case nodes."""
+    rng = np.random.default_rng(77)
+    seq = synth.make_sequence(n_frames=6, n_kp=700, n_world=2200, seed=77, nan_fraction=0.05)
+    nodes = {f: (seq["desc"][f], seq["xyz1"][f]) for f in range(6)}
+    nodes[6] = (rng.integers(0, 256, (300, 32), dtype=np.uint8), seq["xyz1"][0][:300])  # unrelated: identity fallback
+    nodes[7] = (seq["desc"][0][:21], seq["xyz1"][0][:21])                                 # barely above min_matches
+    nodes[8] = (seq["desc"][0][:3], seq["xyz1"][0][:3])
+    nodes[9] = (seq["desc"][0][:0], seq["xyz1"][0][:0])
+    for k, (d, x) in nodes.items():
+        fe.upload_node(k, d, x)
+    pairs = [(1, 0), (2, 0), (5, 3), (4, 4), (6, 0), (0, 6), (7, 0), (0, 7), (8, 0), (9, 0), (0, 9), (3, 1)]
+    pq = np.array([p[0] for p in pairs], np.int32)
+    pt = np.array([p[1] for p in pairs], np.int32)
+    try:
+        for iters in (200, 100, 15, 14, 13, 1, 0):
+            fe.set_params(ransac_iterations=iters)
+            fe.set_latency_mode(0)                       # one wave per pair
+            ref = fe.match_pair_list(pq, pt)
+            prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov, ransac_iterations=iters)
+            if iters in (200, 15):
+                for rec, (q, t) in zip(ref, pairs):
+                    check_against_oracle(rec, po.match_node_pair(nodes[q][0], nodes[q][1], q, nodes[t][0], nodes[t][1], t, prm))
+            for chunk in (1, 5, 7, 8, 64, 1000):
+                fe.set_latency_mode(64, chunk)
+                got = fe.match_pair_list(pq, pt)
+                assert got.tobytes() == ref.tobytes(), (iters, chunk)
+        # batches above the limit keep the one-wave path; the limit is configurable
+        fe.set_params(ransac_iterations=200)
+        fe.set_latency_mode(4, 7)
+        parts = [fe.match_pair_list(pq[a:a + 4], pt[a:a + 4]).tobytes() for a in (0, 4, 8)]  # 4 pairs: latency path
+        assert fe.match_pair_list(pq, pt).tobytes() == b"".join(parts)                        # 12 pairs: one-wave path
+    finally:
+        fe.set_params(ransac_iterations=200)
+        fe.set_latency_mode(fe.latency_default, 7)
+        for k in nodes:
+            fe.release_node(k)

@@ -6,6 +6,8 @@ from rgbdslam_v2_amd import synth
 from rgbdslam_v2_amd.frontend import FrontEnd
 bad = 0
 fe2 = FrontEnd(device_id=0, max_nodes=12, max_keypoints=1536, max_pairs_per_batch=64)
+if len(sys.argv) > 1:  # `one_wave`: disable the record / replay latency path, i.e. fuzz the throughput kernel
+    fe2.set_latency_mode(0 if sys.argv[1] == "one_wave" else 64, 7)
 for master in range(40):
     rng = np.random.default_rng(9000 + master)
     F = 8
