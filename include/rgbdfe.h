@@ -183,7 +183,7 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
                               float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out);
 
 /* Small batches (the live-SLAM call: one new node against ~20 candidates) are latency-bound: one wave per pair runs
- * that pair's whole RANSAC loop (~4.6 ms at 167 iterations).  For ORB batches of at most max_pairs pairs the library
+ * that pair's whole RANSAC loop (~4.6 ms at 167 iterations).  For batches of at most max_pairs pairs (ORB and SIFT) the library
  * therefore spreads every pair's iterations over ceil(ransac_iterations / chunk_iterations) waves that record each
  * iteration's outcome, and replays the records in iteration order with the reference's bookkeeping (node.cpp:1171-1190)
  * afterwards: results are identical to the one-wave path (an iteration's refinement depends only on its index),

@@ -236,6 +236,24 @@ void drain_pending(rgbdfe_ctx* ctx) {
   ctx->pending.clear();
 }
 
+// Decides whether a batch of n pairs takes the record / replay latency path and makes sure the lane's record buffer
+// is large enough (falls back to the one-wave-per-pair kernel when it cannot be allocated).
+int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStream_t stream, bool* use) {
+  const size_t need_recs = (size_t)n * (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0);
+  bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * ctx->latency_chunk_iters &&
+                 need_recs <= ((size_t)1 << 22);
+  if (latency && need_recs > lane.recs_capacity) {
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (lane.d_recs) (void)hipFree(lane.d_recs);
+    lane.d_recs = nullptr;
+    lane.recs_capacity = 0;
+    if (hipMalloc((void**)&lane.d_recs, need_recs * sizeof(IterRec)) == hipSuccess) lane.recs_capacity = need_recs;
+    else latency = false;
+  }
+  *use = latency;
+  return RGBDFE_OK;
+}
+
 // Build the PairWork list (host) and enqueue H2D + both kernels on the next lane.
 // Results land in d_out (device memory; nullptr = the lane's own staging buffer).
 // Returns the batch's ticket.  Caller holds the lock.
@@ -295,17 +313,8 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       const uint32_t planes = launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, mk, (uint32_t)n, max_nq,
                                                 max_nt, (uint32_t)ctx->cfg.max_pairs_per_batch, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-      const size_t need_recs = (size_t)n * (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0);
-      bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * ctx->latency_chunk_iters &&
-                     need_recs <= ((size_t)1 << 22);
-      if (latency && need_recs > lane.recs_capacity) {
-        HIP_TRY(ctx, hipStreamSynchronize(stream));
-        if (lane.d_recs) (void)hipFree(lane.d_recs);
-        lane.d_recs = nullptr;
-        lane.recs_capacity = 0;
-        if (hipMalloc((void**)&lane.d_recs, need_recs * sizeof(IterRec)) == hipSuccess) lane.recs_capacity = need_recs;
-        else latency = false;  // fall back to the one-wave-per-pair kernel
-      }
+      bool latency = false;
+      { int rcl = want_latency_path(ctx, lane, n, stream, &latency); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
                                      lane.d_recs, ctx->latency_chunk_iters, stream);
@@ -319,9 +328,16 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part,
                          lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
-      launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
-                                lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
-                                (uint32_t)n, ctx->rc, stream);
+      bool latency = false;
+      { int rcl = want_latency_path(ctx, lane, n, stream, &latency); if (rcl != RGBDFE_OK) return rcl; }
+      if (latency)
+        launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
+                                          d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
+                                          lane.d_recs, ctx->latency_chunk_iters, stream);
+      else
+        launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
+                                  lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
+                                  (uint32_t)n, ctx->rc, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.d, stream);
     }
     if (ctx->profiling) ctx->pending.push_back(pend);

@@ -53,6 +53,10 @@ void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, 
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
                                   uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int chunk_iters,
                                   hipStream_t stream);
+void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
+                                       const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
+                                       rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
+                                       const RansacConst& rc, IterRec* recs, int chunk_iters, hipStream_t stream);
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,

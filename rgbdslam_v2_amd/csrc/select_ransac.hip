@@ -1284,4 +1284,18 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, con
                      work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, (IterRec*)nullptr, 1u, 0);
 }
 
+void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
+                                       const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
+                                       rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
+                                       const RansacConst& rc, IterRec* recs, int chunk_iters, hipStream_t stream) {
+  if (n_pairs == 0) return;
+  SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
+  const uint32_t n_chunks = (uint32_t)((rc.ransac_iterations + chunk_iters - 1) / chunk_iters);
+  if (n_chunks > 0)
+    hipLaunchKernelGGL((select_ransac_kernel<true, kRecord>), dim3(n_pairs * n_chunks), dim3(kWave), 0, stream, xyz_pool,
+                       work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, n_chunks, chunk_iters);
+  hipLaunchKernelGGL((select_ransac_kernel<true, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work,
+                     (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, 1u, 0);
+}
+
 }  // namespace rgbdfe
