@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--config", choices=["orb", "sift"], default="orb",
                     help="orb = BASELINE configs[1] (the headline metric); sift = configs[3]: SIFT 128-d "
                          "float descriptors, dot-product matrix on the bf16 MFMA")
+    ap.add_argument("--ransac-path", choices=["default", "one_wave", "record_replay"], default="default",
+                    help="which select+RANSAC schedule the library uses for the batches of this run: its default "
+                         "(record / replay up to the library's batch limit, one wave per pair above it), or forced")
+    ap.add_argument("--chunk-iterations", type=int, default=0, help="iterations per wave on the record / replay path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -99,6 +103,10 @@ def main():
 
     fe = FrontEnd(device_id=local_rank, max_nodes=F, max_keypoints=((N + 63) // 64) * 64,
                   max_pairs_per_batch=max(n_pad, 1), seed=SEED)
+    if args.ransac_path == "one_wave":
+        fe.set_latency_mode(0, 0)
+    elif args.ransac_path == "record_replay":
+        fe.set_latency_mode(1 << 20, args.chunk_iterations)
     # node features -> HBM (resident before the timed region)
     sift = args.config == "sift"
     sift_desc = synth.sift_descriptors_like(seq["desc"], seed=SEED) if sift else None

@@ -114,8 +114,11 @@ struct rgbdfe_ctx {
   Slot ring[kRing];
   // Batches of at most latency_pairs ORB pairs take the record / replay path (select_ransac.hip): the refinement
   // work of one pair is spread over ceil(ransac_iterations / latency_chunk_iters) waves.  0 disables it.
-  int32_t latency_pairs = 64;
-  int32_t latency_chunk_iters = 7;
+  // Measured (tools/bench_batch_sweep.py, bench.py --ransac-path): record / replay wins up to ~2000 pairs per batch
+  // (uniform short waves fill the chip and have no straggler tail), the one-wave kernel above (it skips the
+  // iterations the reference's early exits skip, and overlapped batches hide its tail).
+  int32_t latency_pairs = 2048;
+  int32_t latency_chunk_iters = 0;  // 0 = automatic: 7 iterations per wave up to 256 pairs (latency), 14 above
   int64_t next_ticket = 1;
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   rgbdfe_match_result* h_results = nullptr;  // pinned staging of the synchronous host-output entry points
@@ -238,10 +241,11 @@ void drain_pending(rgbdfe_ctx* ctx) {
 
 // Decides whether a batch of n pairs takes the record / replay latency path and makes sure the lane's record buffer
 // is large enough (falls back to the one-wave-per-pair kernel when it cannot be allocated).
-int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStream_t stream, bool* use) {
+int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStream_t stream, bool* use, int* chunk_out) {
   const size_t need_recs = (size_t)n * (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0);
-  bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * ctx->latency_chunk_iters &&
-                 need_recs <= ((size_t)1 << 22);
+  const int chunk = ctx->latency_chunk_iters > 0 ? ctx->latency_chunk_iters : (n <= 256 ? 7 : 14);
+  bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * chunk && need_recs <= ((size_t)1 << 22);
+  *chunk_out = chunk;
   if (latency && need_recs > lane.recs_capacity) {
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (lane.d_recs) (void)hipFree(lane.d_recs);
@@ -314,10 +318,11 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
                                                 max_nt, (uint32_t)ctx->cfg.max_pairs_per_batch, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
       bool latency = false;
-      { int rcl = want_latency_path(ctx, lane, n, stream, &latency); if (rcl != RGBDFE_OK) return rcl; }
+      int chunk = 7;
+      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
-                                     lane.d_recs, ctx->latency_chunk_iters, stream);
+                                     lane.d_recs, chunk, stream);
       else
         launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
@@ -329,11 +334,12 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
                          lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
       bool latency = false;
-      { int rcl = want_latency_path(ctx, lane, n, stream, &latency); if (rcl != RGBDFE_OK) return rcl; }
+      int chunk = 7;
+      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
                                           d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
-                                          lane.d_recs, ctx->latency_chunk_iters, stream);
+                                          lane.d_recs, chunk, stream);
       else
         launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
                                   lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
@@ -1278,7 +1284,7 @@ int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32
 }
 
 int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations) {
-  if (!ctx || max_pairs < 0 || chunk_iterations < 1) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  if (!ctx || max_pairs < 0 || chunk_iterations < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   ctx->latency_pairs = max_pairs;
   ctx->latency_chunk_iters = chunk_iterations;

@@ -18,12 +18,12 @@ POSE_TOL = 1e-4
 
 # Every test of this module runs twice: through the one-wave-per-pair kernel (the throughput path bench.py measures)
 # and with small batches on the record / replay latency path (rgbdfe_set_latency_mode, the library default).
-@pytest.fixture(scope="module", params=[0, 64], ids=["one_wave_per_pair", "latency_path"])
+@pytest.fixture(scope="module", params=[0, 1 << 20], ids=["one_wave_per_pair", "record_replay"])
 def fe(request):
     from rgbdslam_v2_amd.frontend import FrontEnd
     f = FrontEnd(device_id=0, max_nodes=64, max_keypoints=1536, max_pairs_per_batch=2048)
     f.latency_default = request.param
-    f.set_latency_mode(request.param, 7)
+    f.set_latency_mode(request.param, 0)
     yield f
     f.close()
 
@@ -313,6 +313,6 @@ def test_latency_path_equals_one_wave_path(fe):
         assert fe.match_pair_list(pq, pt).tobytes() == b"".join(parts)                        # 12 pairs: one-wave path
     finally:
         fe.set_params(ransac_iterations=200)
-        fe.set_latency_mode(fe.latency_default, 7)
+        fe.set_latency_mode(fe.latency_default, 0)
         for k in nodes:
             fe.release_node(k)

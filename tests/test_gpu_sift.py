@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 
 
 # both RANSAC paths: one wave per pair, and the record / replay latency path small batches take by default
-@pytest.fixture(scope="module", params=[0, 64], ids=["one_wave_per_pair", "latency_path"])
+@pytest.fixture(scope="module", params=[0, 1 << 20], ids=["one_wave_per_pair", "record_replay"])
 def fe(request):
     from rgbdslam_v2_amd.frontend import FrontEnd
     f = FrontEnd(device_id=0, max_nodes=24, max_keypoints=1280, max_pairs_per_batch=256)
-    f.set_latency_mode(request.param, 7)
+    f.set_latency_mode(request.param, 0)
     yield f
     f.close()
 
