@@ -183,16 +183,19 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
                               float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out);
 
 /* Two schedules of a batch's RANSAC work give byte-identical results:
- *   one wave per pair     a wave runs a pair's whole loop (windows of 7 iterations, replayed in order).  It skips the
- *                         iterations the reference's early exits skip, but a pair takes ~4.6 ms however idle the chip is
- *                         and a launch lasts as long as its slowest pair;
- *   record / replay       ceil(ransac_iterations / chunk_iterations) waves per pair each refine a few iterations and
- *                         record the outcomes, a second launch (one wave per pair) replays the records in iteration
- *                         order with the reference's bookkeeping (node.cpp:1171-1190).  No iteration is skipped, but
- *                         the work is spread over uniform short waves: one node against 20 candidates returns in
- *                         0.44 ms instead of 5.7 ms, and batches up to ~2000 pairs are faster as well.
- * Batches of at most max_pairs pairs (ORB and SIFT) take record / replay.  Defaults: max_pairs = 2048,
- * chunk_iterations = 0 (automatic: 7 up to 256 pairs, 14 above); max_pairs = 0 forces one wave per pair. */
+ *   record / replay       (default) recording waves each refine chunk_iterations iterations of a pair and write the
+ *                         outcomes, then one wave per pair replays the records in iteration order with the reference's
+ *                         bookkeeping (node.cpp:1171-1190).  Up to 256 pairs all iterations are recorded in one phase
+ *                         (full speculation: one node against 20 candidates returns in 0.44 ms instead of 5.7 ms);
+ *                         larger batches run four phases ([0,14), [14,70), [70,140), [140,200) for 200 iterations)
+ *                         and each replay tells the next phase which pairs are finished and how many iterations the
+ *                         others can still need, so recording stops where the reference stops iterating.  The work
+ *                         is spread over uniform short waves (no long tail of slow pairs);
+ *   one wave per pair     a wave runs a pair's whole loop (windows of 7 iterations, replayed in order): exactly the
+ *                         iterations the reference runs, but a pair takes ~4.6 ms however idle the chip is and a
+ *                         launch lasts as long as its slowest pair.
+ * Batches of at most max_pairs pairs (ORB and SIFT) take record / replay.  Defaults: max_pairs = INT32_MAX (every
+ * batch), chunk_iterations = 0 (automatic: 7 up to 256 pairs, 14 above); max_pairs = 0 forces one wave per pair. */
 int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations);
 
 /* ---- frame-level data either side of the pair path ----------------

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -87,8 +89,9 @@ struct rgbdfe_ctx {
   static constexpr int kRing = 4;
   struct Lane {
     hipStream_t stream = nullptr;
-    IterRec* d_recs = nullptr;              // latency path: per pair x RANSAC iteration outcome records
+    IterRec* d_recs = nullptr;              // record / replay: per pair x RANSAC iteration outcome records
     size_t recs_capacity = 0;               // in records
+    int32_t* d_state = nullptr;             // record / replay: per pair progress (max_pairs)
     uint32_t* d_keys = nullptr;             // max_pairs x max_kp
     rgbdfe_match_result* d_results = nullptr;  // staging for the host-output entry points
     // SIFT scratch (allocated with the first SIFT node)
@@ -117,7 +120,7 @@ struct rgbdfe_ctx {
   // Measured (tools/bench_batch_sweep.py, bench.py --ransac-path): record / replay wins up to ~2000 pairs per batch
   // (uniform short waves fill the chip and have no straggler tail), the one-wave kernel above (it skips the
   // iterations the reference's early exits skip, and overlapped batches hide its tail).
-  int32_t latency_pairs = 2048;
+  int32_t latency_pairs = INT32_MAX;  // record / replay for every batch size (rgbdfe_set_latency_mode)
   int32_t latency_chunk_iters = 0;  // 0 = automatic: 7 iterations per wave up to 256 pairs (latency), 14 above
   int64_t next_ticket = 1;
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
@@ -241,7 +244,9 @@ void drain_pending(rgbdfe_ctx* ctx) {
 
 // Decides whether a batch of n pairs takes the record / replay latency path and makes sure the lane's record buffer
 // is large enough (falls back to the one-wave-per-pair kernel when it cannot be allocated).
-int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStream_t stream, bool* use, int* chunk_out) {
+struct PhasePlan { int ends[4]; int n_phases; };
+int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStream_t stream, bool* use, int* chunk_out,
+                      PhasePlan* plan) {
   const size_t need_recs = (size_t)n * (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0);
   const int chunk = ctx->latency_chunk_iters > 0 ? ctx->latency_chunk_iters : (n <= 256 ? 7 : 14);
   bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * chunk && need_recs <= ((size_t)1 << 22);
@@ -253,6 +258,22 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     lane.recs_capacity = 0;
     if (hipMalloc((void**)&lane.d_recs, need_recs * sizeof(IterRec)) == hipSuccess) lane.recs_capacity = need_recs;
     else latency = false;
+  }
+  if (latency && !lane.d_state &&
+      hipMalloc((void**)&lane.d_state, sizeof(int32_t) * (size_t)ctx->cfg.max_pairs_per_batch) != hipSuccess) {
+    lane.d_state = nullptr;
+    latency = false;
+  }
+  // Up to 256 pairs one phase (full speculation, lowest latency); above, four phases so that recording stops
+  // where the reference's bookkeeping stops iterating.
+  const int I = ctx->rc.ransac_iterations;
+  if (n <= 256) { plan->n_phases = 1; plan->ends[0] = I; }
+  else {
+    const int cand[4] = {14, ((I * 7 / 20) / 7) * 7, ((I * 14 / 20) / 7) * 7, I};
+    int k = 0, last = 0;
+    for (int c : cand) { const int e = c > I ? I : c; if (e > last) { plan->ends[k++] = e; last = e; } }
+    if (k == 0) plan->ends[k++] = I;  // ransac_iterations == 0: the replay alone writes the results
+    plan->n_phases = k;
   }
   *use = latency;
   return RGBDFE_OK;
@@ -319,10 +340,11 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
       bool latency = false;
       int chunk = 7;
-      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk); if (rcl != RGBDFE_OK) return rcl; }
+      PhasePlan pp{};
+      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
-                                     lane.d_recs, chunk, stream);
+                                     lane.d_recs, lane.d_state, chunk, pp.ends, pp.n_phases, stream);
       else
         launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
@@ -335,11 +357,12 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
       bool latency = false;
       int chunk = 7;
-      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk); if (rcl != RGBDFE_OK) return rcl; }
+      PhasePlan pp{};
+      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
                                           d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
-                                          lane.d_recs, chunk, stream);
+                                          lane.d_recs, lane.d_state, chunk, pp.ends, pp.n_phases, stream);
       else
         launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
                                   lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
@@ -467,6 +490,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (ln.d_sm_n) (void)hipFree(ln.d_sm_n);
     if (ln.d_all_dist) (void)hipFree(ln.d_all_dist);
     if (ln.d_recs) (void)hipFree(ln.d_recs);
+    if (ln.d_state) (void)hipFree(ln.d_state);
     if (ln.d_keys) (void)hipFree(ln.d_keys);
     if (ln.d_results) (void)hipFree(ln.d_results);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);

@@ -49,14 +49,23 @@ struct IterRec {
   int32_t rn;
   int32_t pad;
 };
+// parameters of one record / replay phase (select_ransac.hip)
+struct RecordPlan {
+  IterRec* recs = nullptr;   // [pair][iteration]
+  int32_t* state = nullptr;  // [pair]: >= 0 upper bound of the iterations still needed, < 0 finished
+  uint32_t n_chunks = 1;     // recording waves per pair in this phase
+  int chunk_iters = 0;       // iterations per recording wave
+  int phase_begin = 0, phase_end = 0;
+};
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int chunk_iters,
-                                  hipStream_t stream);
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
+                                  const int* phase_ends, int n_phases, hipStream_t stream);
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                        const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, int chunk_iters, hipStream_t stream);
+                                       const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
+                                       const int* phase_ends, int n_phases, hipStream_t stream);
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,

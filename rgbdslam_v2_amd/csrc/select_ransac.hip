@@ -769,13 +769,19 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
     const uint32_t* __restrict__ keys, uint32_t key_planes, const SiftMatchList sm,
     rgbdfe_match_result* __restrict__ results, uint32_t max_kp, uint32_t n_pairs,
-    const RansacConst rc, IterRec* __restrict__ recs, uint32_t n_chunks, int chunk_iters) {
+    const RansacConst rc, const RecordPlan plan) {
   __shared__ RansacLds lds;
-  const uint32_t pair = MODE == kRecord ? blockIdx.x / n_chunks : blockIdx.x;
-  const int k_begin = MODE == kRecord ? (int)(blockIdx.x % n_chunks) * chunk_iters : 0;
-  const int k_end = MODE == kRecord ? min(k_begin + chunk_iters, rc.ransac_iterations) : 0;
+  const uint32_t pair = MODE == kRecord ? blockIdx.x / plan.n_chunks : blockIdx.x;
   if (pair >= n_pairs) return;
-  IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : recs + (size_t)pair * (size_t)rc.ransac_iterations;
+  // record / replay bookkeeping: state[pair] >= 0 is an upper bound of the iterations the pair still needs recorded,
+  // < 0 means its result has been written
+  const int pair_state = MODE == kWhole ? 0 : plan.state[pair];
+  if (MODE != kWhole && pair_state < 0) return;
+  const int recorded_end = MODE == kWhole ? 0 : min(plan.phase_end, pair_state);
+  const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(blockIdx.x % plan.n_chunks) * plan.chunk_iters : 0;
+  const int k_end = MODE == kRecord ? min(k_begin + plan.chunk_iters, recorded_end) : 0;
+  if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
+  IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : plan.recs + (size_t)pair * (size_t)rc.ransac_iterations;
   const int lane = threadIdx.x;
   const PairWork w = work[pair];
   rgbdfe_match_result* __restrict__ out = results + pair;
@@ -952,12 +958,15 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     bool done = false;
 
     int k_cur = k_begin;  // kRecord: next iteration of this wave's chunk
-    for (int it = 0; MODE == kRecord ? (k_cur < k_end && n_all >= 4)
-                                     : (!done && it < rc.ransac_iterations && n_all >= 4);) {  // :1130
+    int it = 0;
+    for (; MODE == kRecord ? (k_cur < k_end && n_all >= 4)
+                           : (!done && it < rc.ransac_iterations && n_all >= 4 &&
+                              (MODE != kReplay || real_iterations < recorded_end));) {  // :1130
       const int k0 = MODE == kRecord ? k_cur : real_iterations;
       // The first iteration runs alone: an easy pair leaves the loop right after it (:1188) and must
       // not pay for a speculative window.
-      const int G = MODE == kRecord ? min(kSlots, k_end - k0) : ((k0 == 0) ? 1 : kSlots);
+      const int G = MODE == kRecord ? min(kSlots, k_end - k0)
+                                    : (MODE == kReplay ? min(kSlots, recorded_end - k0) : ((k0 == 0) ? 1 : kSlots));
       if (MODE == kReplay) {
         // the outcomes of iterations k0 .. k0+G-1 come from the records written by the kRecord waves
         if (lane < G) {
@@ -1196,6 +1205,11 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
         ++it;
       }
     }
+    if (MODE == kReplay && !done && it < rc.ransac_iterations && n_all >= 4) {
+      // the records ran out before the loop ended: at most (ransac_iterations - it) more iterations can follow
+      if (lane == 0) plan.state[pair] = real_iterations + (rc.ransac_iterations - it);
+      return;
+    }
     if (MODE != kRecord && valid_iterations == 0) {  // :1192 identity hypothesis
       uint64_t inl_mask[kRounds];
       int n_inl;
@@ -1241,6 +1255,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
     }
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) out->inlier_mask[r] = b.mask[r];
+    if (MODE == kReplay) plan.state[pair] = -1;  // finished: later phases skip this pair
 #ifdef RGBDFE_PROFILE_PHASES
     PH_MARK(5)
     uint64_t* dbg = reinterpret_cast<uint64_t*>(out->all_q);
@@ -1255,23 +1270,7 @@ void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const ui
   if (n_pairs == 0) return;
   SiftMatchList none{};
   hipLaunchKernelGGL((select_ransac_kernel<false, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, (IterRec*)nullptr, 1u, 0);
-}
-
-// Small batches: the refinement of every pair's iterations is spread over n_chunks waves (kRecord), then one wave
-// per pair replays the recorded outcomes in order (kReplay).  recs: n_pairs x rc.ransac_iterations records.
-void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
-                                  uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int chunk_iters,
-                                  hipStream_t stream) {
-  if (n_pairs == 0) return;
-  SiftMatchList none{};
-  const uint32_t n_chunks = (uint32_t)((rc.ransac_iterations + chunk_iters - 1) / chunk_iters);
-  if (n_chunks > 0)
-    hipLaunchKernelGGL((select_ransac_kernel<false, kRecord>), dim3(n_pairs * n_chunks), dim3(kWave), 0, stream,
-                       xyz_pool, work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, n_chunks, chunk_iters);
-  hipLaunchKernelGGL((select_ransac_kernel<false, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, 1u, 0);
+                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, RecordPlan{});
 }
 
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
@@ -1281,21 +1280,53 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, con
   if (n_pairs == 0) return;
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
   hipLaunchKernelGGL((select_ransac_kernel<true, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, (IterRec*)nullptr, 1u, 0);
+                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, RecordPlan{});
+}
+
+// Record / replay schedule.  The iteration range is covered in `n_phases` phases ending at phase_ends[]: each phase
+// launches the recording waves (ceil(phase length / chunk_iters) per pair; waves of finished pairs and waves beyond
+// a pair's remaining need return at once) and then one replay wave per pair, which either finishes the pair (result
+// written, state < 0) or tightens the bound on the iterations it still needs.  One phase = full speculation (lowest
+// latency); several phases stop recording where the reference's bookkeeping stops iterating.
+// recs: n_pairs x rc.ransac_iterations records; state: n_pairs ints (set to rc.ransac_iterations here).
+template <bool SIFT>
+static void launch_record_replay(const float4* xyz_pool, const PairWork* work, const uint32_t* keys, uint32_t key_planes,
+                                 const SiftMatchList& sm, rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
+                                 const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
+                                 const int* phase_ends, int n_phases, hipStream_t stream) {
+  if (n_pairs == 0) return;
+  (void)hipMemsetD32Async((hipDeviceptr_t)state, rc.ransac_iterations, n_pairs, stream);
+  int begin = 0;
+  for (int p = 0; p < n_phases; ++p) {
+    const int end = phase_ends[p];
+    RecordPlan plan{recs, state, (uint32_t)((end - begin + chunk_iters - 1) / chunk_iters), chunk_iters, begin, end};
+    if (end > begin)
+      hipLaunchKernelGGL((select_ransac_kernel<SIFT, kRecord>), dim3(n_pairs * plan.n_chunks), dim3(kWave), 0, stream,
+                         xyz_pool, work, keys, key_planes, sm, results, max_kp, n_pairs, rc, plan);
+    plan.n_chunks = 1;
+    hipLaunchKernelGGL((select_ransac_kernel<SIFT, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys,
+                       key_planes, sm, results, max_kp, n_pairs, rc, plan);
+    begin = end;
+  }
+}
+
+void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
+                                  uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
+                                  const int* phase_ends, int n_phases, hipStream_t stream) {
+  SiftMatchList none{};
+  launch_record_replay<false>(xyz_pool, work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, state,
+                              chunk_iters, phase_ends, n_phases, stream);
 }
 
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                        const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, int chunk_iters, hipStream_t stream) {
-  if (n_pairs == 0) return;
+                                       const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
+                                       const int* phase_ends, int n_phases, hipStream_t stream) {
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
-  const uint32_t n_chunks = (uint32_t)((rc.ransac_iterations + chunk_iters - 1) / chunk_iters);
-  if (n_chunks > 0)
-    hipLaunchKernelGGL((select_ransac_kernel<true, kRecord>), dim3(n_pairs * n_chunks), dim3(kWave), 0, stream, xyz_pool,
-                       work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, n_chunks, chunk_iters);
-  hipLaunchKernelGGL((select_ransac_kernel<true, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work,
-                     (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, 1u, 0);
+  launch_record_replay<true>(xyz_pool, work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, state,
+                             chunk_iters, phase_ends, n_phases, stream);
 }
 
 }  // namespace rgbdfe

@@ -404,9 +404,10 @@ class FrontEnd:
                 int(c[i, 0]), int(c[i, 1]), int(c[i, 2] + c[i, 0] + c[i, 1]), observability_threshold, C.byref(q)))
         return c, met
 
-    def set_latency_mode(self, max_pairs=2048, chunk_iterations=0):
+    def set_latency_mode(self, max_pairs=(1 << 31) - 1, chunk_iterations=0):
         """Batches of at most max_pairs pairs spread each pair's RANSAC iterations over several waves (record /
-        replay, identical results); max_pairs = 0 forces one wave per pair, chunk_iterations = 0 is automatic."""
+        replay, identical results; the default for every batch size); max_pairs = 0 forces one wave per pair,
+        chunk_iterations = 0 is automatic."""
         self._check(self._L.rgbdfe_set_latency_mode(self._ctx, int(max_pairs), int(chunk_iterations)))
 
     # -- measurement ----------------------------------------------------------------------

@@ -306,6 +306,13 @@ def test_latency_path_equals_one_wave_path(fe):
                 fe.set_latency_mode(64, chunk)
                 got = fe.match_pair_list(pq, pt)
                 assert got.tobytes() == ref.tobytes(), (iters, chunk)
+            # more than 256 pairs: the iteration range is recorded in up to four phases, each replay telling the
+            # next phase which pairs still need iterations
+            big_q, big_t = np.tile(pq, 25), np.tile(pt, 25)
+            for chunk in (0, 3, 7, 14, 64):
+                fe.set_latency_mode(1 << 20, chunk)
+                got = fe.match_pair_list(big_q[:300], big_t[:300])
+                assert got.tobytes() == np.tile(ref, 25)[:300].tobytes(), ("phased", iters, chunk)
         # batches above the limit keep the one-wave path; the limit is configurable
         fe.set_params(ransac_iterations=200)
         fe.set_latency_mode(4, 7)

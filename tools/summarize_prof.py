@@ -9,6 +9,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -27,17 +28,28 @@ def short(name):
     return None
 
 
-# kernel-trace stats
+# kernel-trace stats.  select_ransac has several template instances (one wave per pair / record / replay): a batch's
+# RANSAC stage is the sequence of those launches, so their totals are summed and divided by the number of batches
+# (= hamming_nn launches) -> "per_batch_ns".
 for f in find("trace/**/*kernel_stats.csv"):
     for row in csv.DictReader(open(f)):
         k = short(row.get("Name", ""))
         if k:
-            summary.setdefault(k, {})
-            summary[k]["calls"] = int(row["Calls"])
-            summary[k]["avg_ns"] = float(row["AverageNs"])
-            summary[k]["total_ns"] = float(row["TotalDurationNs"])
-            summary[k]["pct"] = float(row["Percentage"])
+            e = summary.setdefault(k, {})
+            e["calls"] = e.get("calls", 0) + int(row["Calls"])
+            e["total_ns"] = e.get("total_ns", 0.0) + float(row["TotalDurationNs"])
+            e["pct"] = e.get("pct", 0.0) + float(row["Percentage"])
+            e.setdefault("instances", {})[re.sub(r"\(.*", "", row["Name"]).replace("void rgbdfe::", "")] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
     print("kernel stats:", f)
+for k, e in summary.items():
+    if "calls" in e:
+        e["avg_ns"] = e["total_ns"] / e["calls"]
+batches = summary.get("hamming_nn", {}).get("calls")
+if batches:
+    for k, e in summary.items():
+        if "total_ns" in e:
+            e["per_batch_ns"] = e["total_ns"] / batches
+            e["launches_per_batch"] = e["calls"] / batches
 
 # per-dispatch durations from the kernel trace (cross-check of the stats)
 for f in find("trace/**/*kernel_trace.csv"):
@@ -46,13 +58,17 @@ for f in find("trace/**/*kernel_trace.csv"):
         k = short(row.get("Kernel_Name", ""))
         if k:
             dur[k].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    nb = len(dur.get("hamming_nn", [])) or None
     for k, v in dur.items():
         summary.setdefault(k, {})["trace_avg_ns"] = sum(v) / len(v)
         summary[k]["trace_min_ns"] = min(v)
         summary[k]["trace_max_ns"] = max(v)
+        if nb:
+            summary[k]["trace_per_batch_ns"] = sum(v) / nb
 
 
 def pmc(pattern):
+    """counter -> per kernel: (sum over dispatches, dispatches, batches in the same pass)"""
     acc = defaultdict(lambda: defaultdict(list))
     for f in find(pattern):
         for row in csv.DictReader(open(f)):
@@ -66,9 +82,12 @@ for name, pat in (("fetch", "pmc_fetch/**/*counter_collection.csv"),
                   ("write", "pmc_write/**/*counter_collection.csv"),
                   ("sq", "pmc_sq/**/*counter_collection.csv"),
                   ("sq2", "pmc_sq2/**/*counter_collection.csv")):
-    for k, ctrs in pmc(pat).items():
+    acc = pmc(pat)
+    for k, ctrs in acc.items():
         for c, vals in ctrs.items():
-            summary.setdefault(k, {})[c + "_avg"] = sum(vals) / len(vals)
+            nb = len(acc.get("hamming_nn", {}).get(c, [])) or len(vals)
+            # per batch: a batch's RANSAC stage may be several dispatches
+            summary.setdefault(k, {})[c + "_avg"] = sum(vals) / nb
             summary[k][c + "_n"] = len(vals)
 
 for k, s in summary.items():
