@@ -92,6 +92,8 @@ struct rgbdfe_ctx {
     IterRec* d_recs = nullptr;              // record / replay: per pair x RANSAC iteration outcome records
     size_t recs_capacity = 0;               // in records
     int32_t* d_state = nullptr;             // record / replay: per pair progress (max_pairs)
+    double* d_ec = nullptr;                 // error pool of select+RANSAC: one region per launched wave
+    size_t ec_regions = 0;
     uint32_t* d_keys = nullptr;             // max_pairs x max_kp
     rgbdfe_match_result* d_results = nullptr;  // staging for the host-output entry points
     // SIFT scratch (allocated with the first SIFT node)
@@ -245,10 +247,25 @@ void drain_pending(rgbdfe_ctx* ctx) {
 // Decides whether a batch of n pairs takes the record / replay latency path and makes sure the lane's record buffer
 // is large enough (falls back to the one-wave-per-pair kernel when it cannot be allocated).
 struct PhasePlan { int ends[4]; int n_phases; };
+// the error pool of the select+RANSAC launches of a lane: one region per wave of the largest grid
+constexpr size_t kMaxEcRegions = (size_t)1 << 16;  // 1.2 GB
+int ensure_ec_pool(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, size_t regions, hipStream_t stream) {
+  if (regions <= lane.ec_regions) return RGBDFE_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  if (lane.d_ec) (void)hipFree(lane.d_ec);
+  lane.d_ec = nullptr;
+  lane.ec_regions = 0;
+  HIP_TRY(ctx, hipMalloc((void**)&lane.d_ec, regions * select_ransac_ec_region_bytes()));
+  lane.ec_regions = regions;
+  return RGBDFE_OK;
+}
 int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStream_t stream, bool* use, int* chunk_out,
                       PhasePlan* plan) {
   const size_t need_recs = (size_t)n * (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0);
-  const int chunk = ctx->latency_chunk_iters > 0 ? ctx->latency_chunk_iters : (n <= 256 ? 7 : 14);
+  int chunk = ctx->latency_chunk_iters > 0 ? ctx->latency_chunk_iters : (n <= 256 ? 7 : 14);
+  // every recording wave owns a region of the error pool: keep the largest grid (a phase is at most all iterations)
+  // within kMaxEcRegions by recording more iterations per wave
+  while ((size_t)n * (size_t)((ctx->rc.ransac_iterations + chunk - 1) / chunk) > kMaxEcRegions) ++chunk;
   bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * chunk && need_recs <= ((size_t)1 << 22);
   *chunk_out = chunk;
   if (latency && need_recs > lane.recs_capacity) {
@@ -276,7 +293,16 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     plan->n_phases = k;
   }
   *use = latency;
-  return RGBDFE_OK;
+  size_t regions = (size_t)n;
+  if (latency) {
+    int begin = 0;
+    for (int p = 0; p < plan->n_phases; ++p) {
+      const size_t chunks = (size_t)((plan->ends[p] - begin + chunk - 1) / chunk);
+      if ((size_t)n * chunks > regions) regions = (size_t)n * chunks;
+      begin = plan->ends[p];
+    }
+  }
+  return ensure_ec_pool(ctx, lane, regions, stream);
 }
 
 // Build the PairWork list (host) and enqueue H2D + both kernels on the next lane.
@@ -344,9 +370,10 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
-                                     lane.d_recs, lane.d_state, chunk, pp.ends, pp.n_phases, stream);
+                                     lane.d_recs, lane.d_state, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
       else
-        launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, stream);
+        launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, lane.d_ec,
+                             stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
     } else {
       launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
@@ -362,11 +389,11 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       if (latency)
         launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
                                           d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
-                                          lane.d_recs, lane.d_state, chunk, pp.ends, pp.n_phases, stream);
+                                          lane.d_recs, lane.d_state, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
       else
         launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
                                   lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
-                                  (uint32_t)n, ctx->rc, stream);
+                                  (uint32_t)n, ctx->rc, lane.d_ec, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.d, stream);
     }
     if (ctx->profiling) ctx->pending.push_back(pend);
@@ -491,6 +518,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (ln.d_all_dist) (void)hipFree(ln.d_all_dist);
     if (ln.d_recs) (void)hipFree(ln.d_recs);
     if (ln.d_state) (void)hipFree(ln.d_state);
+    if (ln.d_ec) (void)hipFree(ln.d_ec);
     if (ln.d_keys) (void)hipFree(ln.d_keys);
     if (ln.d_results) (void)hipFree(ln.d_results);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);

@@ -40,7 +40,7 @@ uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint
                            uint32_t key_planes_capacity, hipStream_t stream);
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                          uint32_t n_pairs, const RansacConst& rc, hipStream_t stream);
+                          uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream);
 // outcome of one RANSAC iteration's refinement loop (node.cpp:1140-1169): refined transform, inlier set, error
 struct IterRec {
   float rR[9], rt[3];
@@ -56,20 +56,23 @@ struct RecordPlan {
   uint32_t n_chunks = 1;     // recording waves per pair in this phase
   int chunk_iters = 0;       // iterations per recording wave
   int phase_begin = 0, phase_end = 0;
+  double* ec_pool = nullptr;  // every mode: select_ransac_ec_region_bytes() per launched wave (the inlier errors of
+                              // a refinement round's scorings, read back lane = slot by the sequential error sums)
 };
+size_t select_ransac_ec_region_bytes();
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
-                                  const int* phase_ends, int n_phases, hipStream_t stream);
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                  int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                        const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
-                                       const int* phase_ends, int n_phases, hipStream_t stream);
+                                       const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                       int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
-                               uint32_t n_pairs, const RansacConst& rc, hipStream_t stream);
+                               uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream);
 // SIFT matcher (sift_match.hip): u8-quantised descriptors as bf16, exact integer dot products
 // on the bf16 MFMA, SiftMatchGPU row/column/mutual-best semantics.
 void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,

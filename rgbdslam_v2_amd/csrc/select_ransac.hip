@@ -66,14 +66,20 @@ struct FitBuf {
 };
 // scoring phase: candidates (matches that survive the cheap shortcut test) and inliers, compacted
 struct ScoreBuf {
-  double ec[RGBDFE_MAX_MATCHES];     // squared Mahalanobis error of the k-th inlier (match order)
   uint16_t cand[RGBDFE_MAX_MATCHES]; // k-th candidate match
   uint32_t mbits[2 * kRounds];       // inlier set as bits over matches
 };
-union Scratch {  // the three phases never overlap
+// error sums: one block of every slot's error list on its way from the error pool (global) to lane = slot
+constexpr int kStageBlk = 32;                // list entries per row and block
+constexpr int kStageRow = kStageBlk + 2;     // doubles; the rows start 4 banks apart: conflict-free 16-byte reads
+struct SumStage {
+  double v[kSlots][kStageRow];
+};
+union Scratch {  // the phases never overlap
   SelBuf sel;
   ScoreBuf sc;
   FitBuf fit;
+  SumStage sum;
 };
 // a (transform, inlier set, error) triple kept in LDS (wave-uniform state)
 struct Hyp {
@@ -92,9 +98,12 @@ struct Slot {
   // refined_matches; while the slot is active this is also the inlier set of the last scoring, i.e. the
   // input of the next refit (a slot stays active only through an accepted scoring, :1160-1166)
   uint64_t rmask[kRounds];
+  uint64_t cmask[kRounds];   // inlier set of the slot's scoring in the current refinement round
   double rerr;               // refined_error
   int rn;                    // refined_matches.size()
+  int cn;                    // inliers of the current scoring
   int active;
+  int pad;
 };
 struct __attribute__((aligned(16))) RansacLds {
   Scratch u;
@@ -477,9 +486,19 @@ __device__ __forceinline__ double mahal_llt_fast(double S00, double S10, double 
 }
 
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, int n_all, uint32_t need,
-                                                 const RansacConst& rc, RansacLds& lds,
-                                                 uint64_t* mask, int& n_inl, double& err PH_ARG) {
+// The squared errors of a scoring's inliers go, in match order, to a row of the wave's region of the error pool
+// (global memory: 7 rows of kEcRow doubles, L2 resident while the wave lives) instead of LDS: the strictly
+// sequential error sums of the (up to 7) scorings of a refinement round then run side by side, lane = slot
+// (sum_rows), instead of one after the other with all 64 lanes repeating the same addition.
+constexpr int kEcRow = RGBDFE_MAX_MATCHES;      // one list (whole staging blocks)
+constexpr int kEcRegion = kSlots * kEcRow;      // doubles per wave
+
+// Passes 1 and 2 of computeInliersAndError: the inlier set (mask, n_inl) and the inliers' errors (ec_row).
+// n_inl == 0 when fewer than `need` candidates survive pass 1 (the caller rejects the hypothesis whatever the
+// exact numbers are).
+__device__ __forceinline__ void score_passes(const float* R, const float* tr, int n_all, uint32_t need,
+                                             const RansacConst& rc, RansacLds& lds, double* __restrict__ ec_row,
+                                             uint64_t* mask, int& n_inl PH_ARG) {
   const int lane = threadIdx.x;
   double Rd[9], td[3];
 #pragma unroll
@@ -513,7 +532,6 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   if (lane < 2 * kRounds) sb.mbits[lane] = 0u;
   __syncthreads();
   n_inl = 0;
-  err = 1e9;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) mask[r] = 0ull;
   PH_ADD(13, n_cand)
@@ -557,7 +575,7 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
     const bool inl = act && !(e > rc.sq_max_dist) && (e >= 0.0);  // node.cpp:998,1001
     const uint64_t im = __ballot(inl);
     if (inl) {
-      sb.ec[n_inl + (int)lane_rank(im)] = e;  // candidates ascend in match index: so do the inliers
+      ec_row[n_inl + (int)lane_rank(im)] = e;  // candidates ascend in match index: so do the inliers
       atomicOr(&sb.mbits[m >> 5], 1u << (m & 31));
     }
     n_inl += __popcll(im);
@@ -570,23 +588,78 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
     mask[r] = ((uint64_t)hi << 32) | lo;
   }
   PH_ADD(14, n_inl)
-  if ((uint32_t)n_inl < need || n_inl < 3) {  // err stays 1e9 (node.cpp:1012-1014); rejected anyway when < need
-    __syncthreads();
-    return;
-  }
-  // mean_error += mahal_dist in match order (node.cpp:1006): strictly sequential double sum
-  double sum = 0.0;
-  const int n4 = n_inl & ~3;
-  int k = 0;
-  for (; k < n4; k += 4) {
-    const double e0 = sb.ec[k], e1 = sb.ec[k + 1], e2 = sb.ec[k + 2], e3 = sb.ec[k + 3];
-    sum += e0; sum += e1; sum += e2; sum += e3;
-  }
-  for (; k < n_inl; ++k) sum += sb.ec[k];
   __syncthreads();
-  err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
 }
 
+// mean_error += mahal_dist in match order (node.cpp:1006): a strictly sequential double sum per list.  Lane s
+// (< kSlots) sums the first n_mine entries of row s of the wave's error-pool region; every lane walks n_max
+// entries.  The additions are one dependent chain per lane, so the cost of a round's (up to 7) sums is that of the
+// longest one.  Transport is 64 lanes wide: a block of 32 entries of all 7 rows is fetched with 4 coalesced loads
+// per lane (two blocks ahead of the chain: the rows sit in L2), entries behind a list's end are replaced by 0.0
+// (x + 0.0 == x for these non-negative sums), the block goes through LDS, and lane s reads row s back.
+__device__ __forceinline__ double sum_rows(const double* __restrict__ ec_region, RansacLds& lds, int lane, int n_mine,
+                                           int n_max) {
+  SumStage& st = lds.u.sum;
+  // transport role of this lane: entries q = j * 64 + lane of a block, row = q / 32, column = q % 32
+  const int col = lane & (kStageBlk - 1);
+  int row[4], n_row[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    row[j] = (j * kWave + lane) / kStageBlk;                  // 0 .. 7; row 7 does not exist
+    n_row[j] = __shfl(n_mine, min(row[j], kSlots - 1));
+    if (row[j] >= kSlots) n_row[j] = -1;                      // never stored
+  }
+  const int nb = (n_max + kStageBlk - 1) / kStageBlk;
+  auto fetch = [&](double* g, int b) {
+    const int idx = min(b, nb - 1) * kStageBlk + col;         // reading ahead of the last block re-reads it
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = ec_region[min(row[j], kSlots - 1) * kEcRow + idx];
+  };
+  const double* mine = st.v[min(lane, kSlots - 1)];
+  double sum = 0.0;
+  auto block = [&](double* g, int b) {
+    const int idx = b * kStageBlk + col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n_row[j] >= 0) st.v[row[j]][col] = idx < n_row[j] ? g[j] : 0.0;
+    __syncthreads();
+    asm volatile("" ::: "memory");  // g is dead: its registers take the block after next
+    fetch(g, b + 2);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < kStageBlk; i += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(mine + i);
+      sum += v.x;
+      sum += v.y;
+    }
+    asm volatile("" : "+v"(sum) :: "memory");
+    __syncthreads();
+  };
+  double g0[4], g1[4];
+  fetch(g0, 0);
+  fetch(g1, 1);
+  for (int b = 0; b < nb; b += 2) {
+    block(g0, b);
+    if (b + 1 < nb) block(g1, b + 1);
+  }
+  return sum;
+}
+
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// computeInliersAndError for ONE wave-uniform transform (the identity fallback): score_passes + lane 0's sum.
+__device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, int n_all, uint32_t need,
+                                                 const RansacConst& rc, RansacLds& lds, double* __restrict__ ec_region,
+                                                 uint64_t* mask, int& n_inl, double& err PH_ARG) {
+  score_passes(R, tr, n_all, need, rc, lds, ec_region, mask, n_inl PH_PASS);
+  err = 1e9;
+  if ((uint32_t)n_inl < need || n_inl < 3) return;  // err stays 1e9 (node.cpp:1012-1014); rejected anyway when < need
+  const double sum = uniform_f64(sum_rows(ec_region, lds, threadIdx.x, threadIdx.x == 0 ? n_inl : 0, n_inl));
+  err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
+}
 
 // ---------------------------------------------------------------------------------
 // getTransformFromMatches for the active slots of a window round, all at once.
@@ -765,7 +838,7 @@ struct SiftMatchList {
 constexpr int kWhole = 0, kRecord = 1, kReplay = 2;
 
 template <bool SIFT, int MODE>
-__global__ __launch_bounds__(kWave) void select_ransac_kernel(
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void select_ransac_kernel(
     const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
     const uint32_t* __restrict__ keys, uint32_t key_planes, const SiftMatchList sm,
     rgbdfe_match_result* __restrict__ results, uint32_t max_kp, uint32_t n_pairs,
@@ -785,6 +858,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
   const int lane = threadIdx.x;
   const PairWork w = work[pair];
   rgbdfe_match_result* __restrict__ out = results + pair;
+  double* __restrict__ ec_region = plan.ec_pool + (size_t)blockIdx.x * kEcRegion;  // this wave's rows of the error pool
   const int max_matches = rc.max_matches;
   SelBuf& sel = lds.u.sel;
   PH_DECL
@@ -1053,7 +1127,9 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       __syncthreads();
       // ---- refinement rounds (`for refinements = 1 .. 19`, :1140)
       for (int round = 0; round < 19; ++round) {
-        bool any_active = false;
+        // ---- scorings (:1148) of the active slots, one after the other (lane = match) ...
+        int cn_mine = 0;  // lane s: inliers of slot s's scoring when its error sum is looked at
+        int n_sum_max = 0;
         for (int g = 0; g < G; ++g) {
           Slot& sl = lds.slot[g];
           if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
@@ -1064,37 +1140,52 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
           for (int i = 0; i < 3; ++i) curt[i] = sl.t[i];
           uint64_t inl_mask[kRounds];
           int n_inl;
-          double inlier_error;
           PH_MARK(5)
           // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever
           // its error is (:1154, :1160): the scorer may stop counting as soon as that is certain
-          const int rn = __builtin_amdgcn_readfirstlane(sl.rn);
-          score_hypothesis(curR, curt, n_all, max(thr, (uint32_t)rn), rc, lds, inl_mask, n_inl,
-                           inlier_error PH_PASS);  // :1148
+          const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
+          score_passes(curR, curt, n_all, need, rc, lds, ec_region + g * kEcRow, inl_mask, n_inl PH_PASS);
           PH_MARK(3)
           PH_COUNT(6)
-          const double rerr = sl.rerr;
-          bool still = false;
-          if (!((uint32_t)n_inl < thr || inlier_error > max_dist_d)) {   // :1154
-            if (n_inl >= rn && inlier_error <= rerr) {                   // :1160
-              still = (n_inl != rn);                                     // :1166
-              if (lane == 0) {
+          if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) sl.rR[i] = curR[i];
+            for (int r = 0; r < kRounds; ++r) sl.cmask[r] = inl_mask[r];
+            sl.cn = n_inl;
+          }
+          if (!((uint32_t)n_inl < need || n_inl < 3)) {  // else mean_error = 1e9 (:1012-1014) / rejected anyway
+            if (lane == g) cn_mine = n_inl;
+            n_sum_max = max(n_sum_max, n_inl);
+          }
+        }
+        __syncthreads();
+        // ... then their sequential error sums side by side and the bookkeeping (:1154-1166), lane = slot
+        const double sum_mine = sum_rows(ec_region, lds, lane, cn_mine, n_sum_max);
+        const double err_mine = cn_mine > 0 ? sqrt(sum_mine / (double)cn_mine) : 1e9;  // :1016-1017
+        PH_MARK(11)
+        bool still = false;
+        if (lane < G) {
+          Slot& sl = lds.slot[lane];
+          if (sl.active) {
+            const int n_inl = sl.cn, rn = sl.rn;
+            if (!((uint32_t)n_inl < thr || err_mine > max_dist_d)) {   // :1154
+              if (n_inl >= rn && err_mine <= sl.rerr) {                 // :1160
+                still = (n_inl != rn);                                 // :1166
 #pragma unroll
-                for (int i = 0; i < 3; ++i) sl.rt[i] = curt[i];
+                for (int i = 0; i < 9; ++i) sl.rR[i] = sl.R[i];
 #pragma unroll
-                for (int r = 0; r < kRounds; ++r) sl.rmask[r] = inl_mask[r];
+                for (int i = 0; i < 3; ++i) sl.rt[i] = sl.t[i];
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) sl.rmask[r] = sl.cmask[r];
                 sl.rn = n_inl;
-                sl.rerr = inlier_error;
+                sl.rerr = err_mine;
               }
             }
+            if (round == 18) still = false;  // the 19th pass was the last one
+            sl.active = still ? 1 : 0;
           }
-          if (round == 18) still = false;  // the 19th pass was the last one
-          if (lane == 0) sl.active = still ? 1 : 0;
-          any_active |= still;
-          __syncthreads();
         }
+        const bool any_active = __ballot(still) != 0ull;
+        __syncthreads();
         if (!any_active) break;
         // ---- refits (:1142): the weighted-mean recurrences of all active slots side by side, then
         // ONE batched 3x3 SVD with lane = slot
@@ -1214,7 +1305,7 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
       uint64_t inl_mask[kRounds];
       int n_inl;
       double inlier_error;
-      score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, inl_mask, n_inl, inlier_error PH_PASS);  // needs > thr (:1206)
+      score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, ec_region, inl_mask, n_inl, inlier_error PH_PASS);  // needs > thr (:1206)
       if ((uint32_t)n_inl > thr && inlier_error < max_dist_d) {  // :1206
         hyp_store(lds.best, IR, It, inl_mask, n_inl, 0, inlier_error);
         best_n = n_inl;
@@ -1266,21 +1357,25 @@ __global__ __launch_bounds__(kWave) void select_ransac_kernel(
 
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                          uint32_t n_pairs, const RansacConst& rc, hipStream_t stream) {
+                          uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream) {
   if (n_pairs == 0) return;
   SiftMatchList none{};
+  RecordPlan plan{};
+  plan.ec_pool = ec_pool;
   hipLaunchKernelGGL((select_ransac_kernel<false, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, RecordPlan{});
+                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, plan);
 }
 
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
-                               uint32_t n_pairs, const RansacConst& rc, hipStream_t stream) {
+                               uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream) {
   if (n_pairs == 0) return;
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
+  RecordPlan plan{};
+  plan.ec_pool = ec_pool;
   hipLaunchKernelGGL((select_ransac_kernel<true, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, RecordPlan{});
+                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, plan);
 }
 
 // Record / replay schedule.  The iteration range is covered in `n_phases` phases ending at phase_ends[]: each phase
@@ -1292,14 +1387,14 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, con
 template <bool SIFT>
 static void launch_record_replay(const float4* xyz_pool, const PairWork* work, const uint32_t* keys, uint32_t key_planes,
                                  const SiftMatchList& sm, rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                 const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
+                                 const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool, int chunk_iters,
                                  const int* phase_ends, int n_phases, hipStream_t stream) {
   if (n_pairs == 0) return;
   (void)hipMemsetD32Async((hipDeviceptr_t)state, rc.ransac_iterations, n_pairs, stream);
   int begin = 0;
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
-    RecordPlan plan{recs, state, (uint32_t)((end - begin + chunk_iters - 1) / chunk_iters), chunk_iters, begin, end};
+    RecordPlan plan{recs, state, (uint32_t)((end - begin + chunk_iters - 1) / chunk_iters), chunk_iters, begin, end, ec_pool};
     if (end > begin)
       hipLaunchKernelGGL((select_ransac_kernel<SIFT, kRecord>), dim3(n_pairs * plan.n_chunks), dim3(kWave), 0, stream,
                          xyz_pool, work, keys, key_planes, sm, results, max_kp, n_pairs, rc, plan);
@@ -1312,21 +1407,23 @@ static void launch_record_replay(const float4* xyz_pool, const PairWork* work, c
 
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
-                                  const int* phase_ends, int n_phases, hipStream_t stream) {
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                  int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream) {
   SiftMatchList none{};
   launch_record_replay<false>(xyz_pool, work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, state,
-                              chunk_iters, phase_ends, n_phases, stream);
+                              ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                        const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, int32_t* state, int chunk_iters,
-                                       const int* phase_ends, int n_phases, hipStream_t stream) {
+                                       const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                       int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream) {
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
   launch_record_replay<true>(xyz_pool, work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, state,
-                             chunk_iters, phase_ends, n_phases, stream);
+                             ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
+
+size_t select_ransac_ec_region_bytes() { return sizeof(double) * (size_t)kEcRegion; }
 
 }  // namespace rgbdfe

@@ -14,7 +14,7 @@ out = {}
 for n in (1, 20, 64, 128, 256, 512, 768, 1024, 1536, 2048, 4000):
     row = {}
     for name, limit in (("one_wave", 0), ("record_replay", 1 << 20)):
-        fe.set_latency_mode(limit, 7)
+        fe.set_latency_mode(limit, 0)
         fe.match_pair_list(pq[:n], pt[:n])
         reps = 5 if n >= 512 else 20
         t0 = time.perf_counter()
