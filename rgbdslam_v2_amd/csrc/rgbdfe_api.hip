@@ -262,7 +262,9 @@ int ensure_ec_pool(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, size_t regions, hipS
 int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStream_t stream, bool* use, int* chunk_out,
                       PhasePlan* plan) {
   const size_t need_recs = (size_t)n * (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0);
-  int chunk = ctx->latency_chunk_iters > 0 ? ctx->latency_chunk_iters : (n <= 256 ? 7 : 14);
+  const bool force_phases = ctx->latency_chunk_iters < 0;  // testing aid: the phased schedule for any batch size
+  const int chunk_cfg = force_phases ? -ctx->latency_chunk_iters : ctx->latency_chunk_iters;
+  int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 256 ? 7 : 14);
   // every recording wave owns a region of the error pool: keep the largest grid (a phase is at most all iterations)
   // within kMaxEcRegions by recording more iterations per wave
   while ((size_t)n * (size_t)((ctx->rc.ransac_iterations + chunk - 1) / chunk) > kMaxEcRegions) ++chunk;
@@ -284,7 +286,7 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   // Up to 256 pairs one phase (full speculation, lowest latency); above, four phases so that recording stops
   // where the reference's bookkeeping stops iterating.
   const int I = ctx->rc.ransac_iterations;
-  if (n <= 256) { plan->n_phases = 1; plan->ends[0] = I; }
+  if (n <= 256 && !force_phases) { plan->n_phases = 1; plan->ends[0] = I; }
   else {
     const int cand[4] = {14, ((I * 7 / 20) / 7) * 7, ((I * 14 / 20) / 7) * 7, I};
     int k = 0, last = 0;
@@ -1336,7 +1338,7 @@ int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32
 }
 
 int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations) {
-  if (!ctx || max_pairs < 0 || chunk_iterations < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  if (!ctx || max_pairs < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   ctx->latency_pairs = max_pairs;
   ctx->latency_chunk_iters = chunk_iterations;

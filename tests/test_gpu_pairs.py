@@ -313,6 +313,8 @@ def test_latency_path_equals_one_wave_path(fe):
                 fe.set_latency_mode(1 << 20, chunk)
                 got = fe.match_pair_list(big_q[:300], big_t[:300])
                 assert got.tobytes() == np.tile(ref, 25)[:300].tobytes(), ("phased", iters, chunk)
+            fe.set_latency_mode(1 << 20, -4)             # the phased plan forced onto a small batch
+            assert fe.match_pair_list(pq, pt).tobytes() == ref.tobytes(), ("phased, small batch", iters)
         # batches above the limit keep the one-wave path; the limit is configurable
         fe.set_params(ransac_iterations=200)
         fe.set_latency_mode(4, 7)

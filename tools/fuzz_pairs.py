@@ -6,8 +6,9 @@ from rgbdslam_v2_amd import synth
 from rgbdslam_v2_amd.frontend import FrontEnd
 bad = 0
 fe2 = FrontEnd(device_id=0, max_nodes=12, max_keypoints=1536, max_pairs_per_batch=64)
-if len(sys.argv) > 1:  # `one_wave`: disable the record / replay latency path, i.e. fuzz the throughput kernel
-    fe2.set_latency_mode(0 if sys.argv[1] == "one_wave" else 64, 7)
+if len(sys.argv) > 1:  # one_wave | latency (single recording phase) | phased (four phases, forced for small batches)
+    {"one_wave": lambda: fe2.set_latency_mode(0, 0), "latency": lambda: fe2.set_latency_mode(64, 7),
+     "phased": lambda: fe2.set_latency_mode(64, -5)}[sys.argv[1]]()
 for master in range(40):
     rng = np.random.default_rng(9000 + master)
     F = 8
