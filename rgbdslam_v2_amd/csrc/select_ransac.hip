@@ -497,8 +497,8 @@ constexpr int kEcRegion = kSlots * kEcRow;      // doubles per wave
 // n_inl == 0 when fewer than `need` candidates survive pass 1 (the caller rejects the hypothesis whatever the
 // exact numbers are).
 __device__ __forceinline__ void score_passes(const float* R, const float* tr, int n_all, uint32_t need,
-                                             const RansacConst& rc, RansacLds& lds, double* __restrict__ ec_row,
-                                             uint64_t* mask, int& n_inl PH_ARG) {
+                                             const RansacConst& rc, RansacLds& lds, float pmax,
+                                             double* __restrict__ ec_row, uint64_t* mask, int& n_inl PH_ARG) {
   const int lane = threadIdx.x;
   double Rd[9], td[3];
 #pragma unroll
@@ -509,7 +509,25 @@ __device__ __forceinline__ void score_passes(const float* R, const float* tr, in
   const double smax = rcx > dc ? rcx : dc;
   const double shortcut = 2.0 * (smax + smax);
   ScoreBuf& sb = lds.u.sc;
-  // ---- pass 1
+  // ---- pass 1.  The shortcut test `dsq > shortcut` (misc.cpp:731) is decided from a float evaluation of dsq
+  // whenever that is safe: with u = 2^-24 and P = the largest |coordinate| of the matched points, the fma-evaluated
+  // d_i differs from the exact one by at most e_i = 4u ((|R_i0| + |R_i1| + |R_i2| + 1) P + |t_i|), hence the float
+  // dsq from the exact one by at most 2 sqrt(S) (e_0 + e_1 + e_2) + (e_0 + e_1 + e_2)^2 + 4u S near the threshold S
+  // (and a dsq far above S stays above S - E).  E is doubled for the roundings of the bound itself and of the
+  // reference's double evaluation.  Lanes inside [S - E, S + E] -- or with NaN / overflow, where every comparison
+  // fails -- make the wave redo the round in double, the reference's own arithmetic.
+  float lo_f, hi_f;
+  {
+    const float u4 = 4.0f * 5.9604645e-8f;
+    float es = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      es += u4 * (((fabsf(R[3 * i]) + fabsf(R[3 * i + 1])) + fabsf(R[3 * i + 2]) + 1.0f) * pmax + fabsf(tr[i]));
+    const float S = (float)shortcut;
+    const float E = 2.0f * ((2.0f * sqrtf(S) * 1.001f) * es + es * es + u4 * S) + 1e-30f;
+    lo_f = S * 0.999999f - E;
+    hi_f = S * 1.000001f + E;
+  }
   int n_cand = 0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
@@ -518,13 +536,21 @@ __device__ __forceinline__ void score_passes(const float* R, const float* tr, in
     const float pxf = lds.M[m * kRec + 0], pyf = lds.M[m * kRec + 1], pzf = lds.M[m * kRec + 2];
     const float qxf = lds.M[m * kRec + 3], qyf = lds.M[m * kRec + 4], qzf = lds.M[m * kRec + 5];
     // node.cpp:994 (z == 0 skip) ; misc.cpp:712-717 (NaN -> DBL_MAX)
-    bool cand = (m < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
-    const double a0 = (double)pxf, a1 = (double)pyf, a2 = (double)pzf;
-    const double d0 = (((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0]) - (double)qxf;
-    const double d1 = (((Rd[3] * a0 + Rd[4] * a1) + Rd[5] * a2) + td[1]) - (double)qyf;
-    const double d2 = (((Rd[6] * a0 + Rd[7] * a1) + Rd[8] * a2) + td[2]) - (double)qzf;
-    const double dsq = (d0 * d0 + d1 * d1) + d2 * d2;
-    cand = cand && !(dsq > shortcut) && !__builtin_isnan(d2);  // misc.cpp:731, 755
+    const bool pre = (m < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
+    const float f0 = __builtin_fmaf(R[0], pxf, __builtin_fmaf(R[1], pyf, __builtin_fmaf(R[2], pzf, tr[0]))) - qxf;
+    const float f1 = __builtin_fmaf(R[3], pxf, __builtin_fmaf(R[4], pyf, __builtin_fmaf(R[5], pzf, tr[1]))) - qyf;
+    const float f2 = __builtin_fmaf(R[6], pxf, __builtin_fmaf(R[7], pyf, __builtin_fmaf(R[8], pzf, tr[2]))) - qzf;
+    const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
+    const bool sure_in = dsq_f < lo_f, sure_out = dsq_f > hi_f;
+    bool cand = pre && sure_in;
+    if (__ballot(pre && !(sure_in || sure_out)) != 0ull) {  // a lane too close to call: the round in double
+      const double a0 = (double)pxf, a1 = (double)pyf, a2 = (double)pzf;
+      const double d0 = (((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0]) - (double)qxf;
+      const double d1 = (((Rd[3] * a0 + Rd[4] * a1) + Rd[5] * a2) + td[1]) - (double)qyf;
+      const double d2 = (((Rd[6] * a0 + Rd[7] * a1) + Rd[8] * a2) + td[2]) - (double)qzf;
+      const double dsq = (d0 * d0 + d1 * d1) + d2 * d2;
+      cand = pre && !(dsq > shortcut) && !__builtin_isnan(d2);  // misc.cpp:731, 755
+    }
     const uint64_t cm = __ballot(cand);
     if (cand) sb.cand[n_cand + (int)lane_rank(cm)] = (uint16_t)m;
     n_cand += __popcll(cm);
@@ -652,9 +678,10 @@ __device__ __forceinline__ double uniform_f64(double v) {
 
 // computeInliersAndError for ONE wave-uniform transform (the identity fallback): score_passes + lane 0's sum.
 __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr, int n_all, uint32_t need,
-                                                 const RansacConst& rc, RansacLds& lds, double* __restrict__ ec_region,
-                                                 uint64_t* mask, int& n_inl, double& err PH_ARG) {
-  score_passes(R, tr, n_all, need, rc, lds, ec_region, mask, n_inl PH_PASS);
+                                                 const RansacConst& rc, RansacLds& lds, float pmax,
+                                                 double* __restrict__ ec_region, uint64_t* mask, int& n_inl,
+                                                 double& err PH_ARG) {
+  score_passes(R, tr, n_all, need, rc, lds, pmax, ec_region, mask, n_inl PH_PASS);
   err = 1e9;
   if ((uint32_t)n_inl < need || n_inl < 3) return;  // err stays 1e9 (node.cpp:1012-1014); rejected anyway when < need
   const double sum = uniform_f64(sum_rows(ec_region, lds, threadIdx.x, threadIdx.x == 0 ? n_inl : 0, n_inl));
@@ -971,6 +998,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   const float4* __restrict__ txyz = xyz_pool + (size_t)w.t_slot * max_kp;
   bool w_plain = false;  // a weight outside the window of fit_recurrence<true>
   uint64_t w_nonzero[kRounds];
+  float pmax = 0.0f;     // largest finite |coordinate| of the matched points (bounds the float prefilter's error)
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
@@ -982,6 +1010,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       p = qxyz[qt & 0xFFFFu];
       q = txyz[qt >> 16];
     }
+    pmax = fmaxf(pmax, fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)),
+                             fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z))));  // fmaxf skips NaN
     lds.M[m * kRec + 0] = p.x; lds.M[m * kRec + 1] = p.y; lds.M[m * kRec + 2] = p.z;
     lds.M[m * kRec + 3] = q.x; lds.M[m * kRec + 4] = q.y; lds.M[m * kRec + 5] = q.z;
     // weight = 1.0/(from(2)*to(2)) (transformation_estimation_euclidean.cpp:25): the double
@@ -1006,6 +1036,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   }
   __syncthreads();
   const bool fast_alpha = (__ballot(w_plain) == 0ull);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, d));
+  pmax = bcast_f(pmax, 0);
 
   PH_MARK(1)
   // ------------------------------------------------------------------ RANSAC
@@ -1144,7 +1177,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever
           // its error is (:1154, :1160): the scorer may stop counting as soon as that is certain
           const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
-          score_passes(curR, curt, n_all, need, rc, lds, ec_region + g * kEcRow, inl_mask, n_inl PH_PASS);
+          score_passes(curR, curt, n_all, need, rc, lds, pmax, ec_region + g * kEcRow, inl_mask, n_inl PH_PASS);
           PH_MARK(3)
           PH_COUNT(6)
           if (lane == 0) {
@@ -1305,7 +1338,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       uint64_t inl_mask[kRounds];
       int n_inl;
       double inlier_error;
-      score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, ec_region, inl_mask, n_inl, inlier_error PH_PASS);  // needs > thr (:1206)
+      score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, pmax, ec_region, inl_mask, n_inl, inlier_error PH_PASS);  // needs > thr (:1206)
       if ((uint32_t)n_inl > thr && inlier_error < max_dist_d) {  // :1206
         hyp_store(lds.best, IR, It, inl_mask, n_inl, 0, inlier_error);
         best_n = n_inl;
