@@ -102,7 +102,9 @@ struct Slot {
   double rerr;               // refined_error
   int rn;                    // refined_matches.size()
   int cn;                    // inliers of the current scoring
-  int active;
+  int active;                // still inside the refinement loop (:1140-1169)
+  int round;                 // refinement passes done
+  int iter;                  // RANSAC iteration held by the slot, -1 = free
   int pad;
 };
 struct __attribute__((aligned(16))) RansacLds {
@@ -637,7 +639,7 @@ __device__ __forceinline__ double sum_rows(const double* __restrict__ ec_region,
   }
   const int nb = (n_max + kStageBlk - 1) / kStageBlk;
   auto fetch = [&](double* g, int b) {
-    const int idx = min(b, nb - 1) * kStageBlk + col;         // reading ahead of the last block re-reads it
+    const int idx = max(min(b, nb - 1), 0) * kStageBlk + col;  // reading ahead of the last block re-reads it
 #pragma unroll
     for (int j = 0; j < 4; ++j) g[j] = ec_region[min(row[j], kSlots - 1) * kEcRow + idx];
   };
@@ -1064,33 +1066,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     int hyp_base = -kWave;  // iteration index of lane 0's hypothesis (none yet)
     bool done = false;
 
-    int k_cur = k_begin;  // kRecord: next iteration of this wave's chunk
-    int it = 0;
-    for (; MODE == kRecord ? (k_cur < k_end && n_all >= 4)
-                           : (!done && it < rc.ransac_iterations && n_all >= 4 &&
-                              (MODE != kReplay || real_iterations < recorded_end));) {  // :1130
-      const int k0 = MODE == kRecord ? k_cur : real_iterations;
-      // The first iteration runs alone: an easy pair leaves the loop right after it (:1188) and must
-      // not pay for a speculative window.
-      const int G = MODE == kRecord ? min(kSlots, k_end - k0)
-                                    : (MODE == kReplay ? min(kSlots, recorded_end - k0) : ((k0 == 0) ? 1 : kSlots));
-      if (MODE == kReplay) {
-        // the outcomes of iterations k0 .. k0+G-1 come from the records written by the kRecord waves
-        if (lane < G) {
-          const IterRec& r = rec_pair[k0 + lane];
-          Slot& sl = lds.slot[lane];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) sl.rR[i] = r.rR[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) sl.rt[i] = r.rt[i];
-#pragma unroll
-          for (int q = 0; q < kRounds; ++q) sl.rmask[q] = r.rmask[q];
-          sl.rerr = r.rerr;
-          sl.rn = r.rn;
-        }
-        __syncthreads();
-      } else {
-      if (hyp_base < 0 || k0 + G > hyp_base + kWave) {
+    auto gen_hypotheses = [&](int k0) {
         // ---- LANE = HYPOTHESIS: sample + 4-point fit for iterations k0 .. k0+63
         hyp_base = k0;
         const uint32_t iter = (uint32_t)(k0 + lane);
@@ -1131,39 +1107,39 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         tfc_get_transformation(acc, hypR, hypt);
         hyp_nan = has_nan12(hypR, hypt);
         PH_MARK(2)
+    };
+    // slot g <- iteration k: first transform = its 4-point hypothesis
+    auto open_slot = [&](int g, int k) {
+      if (hyp_base < 0 || k < hyp_base || k >= hyp_base + kWave) gen_hypotheses(k);
+      const int hl = k - hyp_base;
+      float R0[9], t0[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R0[i] = bcast_f(hypR[i], hl);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t0[i] = bcast_f(hypt[i], hl);
+      const bool nan0 = (__builtin_amdgcn_readlane((int)hyp_nan, hl) != 0);
+      if (lane == 0) {
+        Slot& sl = lds.slot[g];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { sl.R[i] = R0[i]; sl.rR[i] = IR[i]; }  // :1137 refined = Identity
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { sl.t[i] = t0[i]; sl.rt[i] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) sl.rmask[r] = 0ull;
+        sl.rerr = 1e6;          // :1133
+        sl.rn = 0;              // :1134
+        sl.active = nan0 ? 0 : 1;  // a NaN transform leaves the refinement loop (:1144)
+        sl.round = 0;
+        sl.iter = k;
       }
-      // ---- open the window: slot g <- iteration k0 + g, first transform = its 4-point hypothesis
-#pragma unroll
-      for (int g = 0; g < kSlots; ++g) {
-        if (g < G) {
-          const int hl = k0 + g - hyp_base;
-          float R0[9], t0[3];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) R0[i] = bcast_f(hypR[i], hl);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) t0[i] = bcast_f(hypt[i], hl);
-          const bool nan0 = (__builtin_amdgcn_readlane((int)hyp_nan, hl) != 0);
-          if (lane == 0) {
-            Slot& sl = lds.slot[g];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) { sl.R[i] = R0[i]; sl.rR[i] = IR[i]; }  // :1137 refined = Identity
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { sl.t[i] = t0[i]; sl.rt[i] = 0.f; }
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) sl.rmask[r] = 0ull;
-            sl.rerr = 1e6;          // :1133
-            sl.rn = 0;              // :1134
-            sl.active = nan0 ? 0 : 1;  // a NaN transform leaves the refinement loop (:1144)
-          }
-        }
-      }
-      __syncthreads();
-      // ---- refinement rounds (`for refinements = 1 .. 19`, :1140)
-      for (int round = 0; round < 19; ++round) {
+    };
+    // One pass of the refinement loop (`for refinements = 1 .. 19`, :1140) for every active slot; false when no
+    // slot stays active.
+    auto refine_round = [&]() -> bool {
         // ---- scorings (:1148) of the active slots, one after the other (lane = match) ...
         int cn_mine = 0;  // lane s: inliers of slot s's scoring when its error sum is looked at
         int n_sum_max = 0;
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < kSlots; ++g) {
           Slot& sl = lds.slot[g];
           if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
           float curR[9], curt[3];
@@ -1196,7 +1172,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         const double err_mine = cn_mine > 0 ? sqrt(sum_mine / (double)cn_mine) : 1e9;  // :1016-1017
         PH_MARK(11)
         bool still = false;
-        if (lane < G) {
+        if (lane < kSlots) {
           Slot& sl = lds.slot[lane];
           if (sl.active) {
             const int n_inl = sl.cn, rn = sl.rn;
@@ -1213,18 +1189,19 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
                 sl.rerr = err_mine;
               }
             }
-            if (round == 18) still = false;  // the 19th pass was the last one
+            if (sl.round == 18) still = false;  // the 19th pass was the last one (:1140)
+            sl.round++;
             sl.active = still ? 1 : 0;
           }
         }
         const bool any_active = __ballot(still) != 0ull;
         __syncthreads();
-        if (!any_active) break;
+        if (!any_active) return false;
         // ---- refits (:1142): the weighted-mean recurrences of all active slots side by side, then
         // ONE batched 3x3 SVD with lane = slot
         int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
         PH_MARK(5)
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < kSlots; ++g) {
           Slot& sl = lds.slot[g];
           if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
           uint64_t m5[kRounds];
@@ -1262,7 +1239,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           float fR[9], ft[3];
           tfc_get_transformation(mine, fR, ft);
           const bool fnan = has_nan12(fR, ft);
-          if (lane < G) {
+          if (lane < kSlots) {
             Slot& sl = lds.slot[lane];
             if (sl.active) {
 #pragma unroll
@@ -1275,25 +1252,76 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           PH_MARK(12)
         }
         __syncthreads();
-      }
-      }  // MODE != kReplay
-      if (MODE == kRecord) {
-        if (lane < G) {
-          const Slot& sl = lds.slot[lane];
-          IterRec& r = rec_pair[k0 + lane];
+      return true;
+    };
+
+    if (lane < kSlots) { lds.slot[lane].active = 0; lds.slot[lane].iter = -1; }
+    __syncthreads();
+
+    int it = 0;
+    if (MODE == kRecord) {
+      // Recording: the iterations of the chunk are independent and their outcomes are addressed by iteration index,
+      // so a slot whose iteration has left its refinement loop is written out and refilled with the next
+      // iteration at once -- the batched rounds stay full instead of waiting for a window's slowest slot.
+      int k_next = k_begin;
+      while (n_all >= 4) {
+        if (lane < kSlots) {
+          Slot& sl = lds.slot[lane];
+          if (sl.iter >= 0 && !sl.active) {
+            IterRec& r = rec_pair[sl.iter];
 #pragma unroll
-          for (int i = 0; i < 9; ++i) r.rR[i] = sl.rR[i];
+            for (int i = 0; i < 9; ++i) r.rR[i] = sl.rR[i];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) r.rt[i] = sl.rt[i];
+            for (int i = 0; i < 3; ++i) r.rt[i] = sl.rt[i];
 #pragma unroll
-          for (int q = 0; q < kRounds; ++q) r.rmask[q] = sl.rmask[q];
-          r.rerr = sl.rerr;
-          r.rn = sl.rn;
-          r.pad = 0;
+            for (int q = 0; q < kRounds; ++q) r.rmask[q] = sl.rmask[q];
+            r.rerr = sl.rerr;
+            r.rn = sl.rn;
+            r.pad = 0;
+            sl.iter = -1;
+          }
         }
         __syncthreads();
-        k_cur += G;
-        continue;
+        bool occupied = false;
+        for (int g = 0; g < kSlots; ++g) {
+          int it_g = __builtin_amdgcn_readfirstlane(lds.slot[g].iter);
+          if (it_g < 0 && k_next < k_end) {
+            open_slot(g, k_next);
+            it_g = k_next++;
+          }
+          occupied |= it_g >= 0;
+        }
+        __syncthreads();
+        if (!occupied) break;
+        refine_round();
+      }
+    } else {
+    for (; !done && it < rc.ransac_iterations && n_all >= 4 &&
+           (MODE != kReplay || real_iterations < recorded_end);) {  // :1130
+      const int k0 = real_iterations;
+      // The first iteration runs alone: an easy pair leaves the loop right after it (:1188) and must
+      // not pay for a speculative window.
+      const int G = MODE == kReplay ? min(kSlots, recorded_end - k0) : ((k0 == 0) ? 1 : kSlots);
+      if (MODE == kReplay) {
+        // the outcomes of iterations k0 .. k0+G-1 come from the records written by the kRecord waves
+        if (lane < G) {
+          const IterRec& r = rec_pair[k0 + lane];
+          Slot& sl = lds.slot[lane];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) sl.rR[i] = r.rR[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) sl.rt[i] = r.rt[i];
+#pragma unroll
+          for (int q = 0; q < kRounds; ++q) sl.rmask[q] = r.rmask[q];
+          sl.rerr = r.rerr;
+          sl.rn = r.rn;
+        }
+        __syncthreads();
+      } else {
+        // ---- open the window: slot g <- iteration k0 + g; refine all of them to the end
+        for (int g = 0; g < G; ++g) open_slot(g, k0 + g);
+        __syncthreads();
+        while (refine_round()) {}
       }
       // ---- replay the window in iteration order (:1171-1190)
       for (int g = 0; g < G; ++g) {
@@ -1329,6 +1357,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         ++it;
       }
     }
+    }  // MODE != kRecord
     if (MODE == kReplay && !done && it < rc.ransac_iterations && n_all >= 4) {
       // the records ran out before the loop ended: at most (ransac_iterations - it) more iterations can follow
       if (lane == 0) plan.state[pair] = real_iterations + (rc.ransac_iterations - it);
@@ -1427,7 +1456,10 @@ static void launch_record_replay(const float4* xyz_pool, const PairWork* work, c
   int begin = 0;
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
-    RecordPlan plan{recs, state, (uint32_t)((end - begin + chunk_iters - 1) / chunk_iters), chunk_iters, begin, end, ec_pool};
+    // the phase in ceil(length / chunk_iters) equal shares (a short last wave would be the launch's straggler)
+    const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
+    const int share = n_chunks > 0 ? (end - begin + n_chunks - 1) / n_chunks : chunk_iters;
+    RecordPlan plan{recs, state, (uint32_t)n_chunks, share, begin, end, ec_pool};
     if (end > begin)
       hipLaunchKernelGGL((select_ransac_kernel<SIFT, kRecord>), dim3(n_pairs * plan.n_chunks), dim3(kWave), 0, stream,
                          xyz_pool, work, keys, key_planes, sm, results, max_kp, n_pairs, rc, plan);

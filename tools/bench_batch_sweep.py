@@ -13,8 +13,9 @@ for f in range(F):
 out = {}
 for n in (1, 20, 64, 128, 256, 512, 768, 1024, 1536, 2048, 4000):
     row = {}
-    for name, limit in (("one_wave", 0), ("record_replay", 1 << 20)):
-        fe.set_latency_mode(limit, 0)
+    for name, limit, chunk in (("one_wave", 0, 0), ("record_replay_auto", 1 << 30, 0), ("record_replay_7", 1 << 30, 7),
+                               ("record_replay_14", 1 << 30, 14), ("record_replay_28", 1 << 30, 28)):
+        fe.set_latency_mode(limit, chunk)
         fe.match_pair_list(pq[:n], pt[:n])
         reps = 5 if n >= 512 else 20
         t0 = time.perf_counter()
