@@ -91,7 +91,7 @@ struct rgbdfe_ctx {
     hipStream_t stream = nullptr;
     IterRec* d_recs = nullptr;              // record / replay: per pair x RANSAC iteration outcome records
     size_t recs_capacity = 0;               // in records
-    int32_t* d_state = nullptr;             // record / replay: per pair progress (max_pairs)
+    WalkState* d_walk = nullptr;            // record / replay: per pair progress (max_pairs)
     double* d_ec = nullptr;                 // error pool of select+RANSAC: one region per launched wave
     size_t ec_regions = 0;
     uint32_t* d_keys = nullptr;             // max_pairs x max_kp
@@ -280,9 +280,9 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     if (hipMalloc((void**)&lane.d_recs, need_recs * sizeof(IterRec)) == hipSuccess) lane.recs_capacity = need_recs;
     else latency = false;
   }
-  if (latency && !lane.d_state &&
-      hipMalloc((void**)&lane.d_state, sizeof(int32_t) * (size_t)ctx->cfg.max_pairs_per_batch) != hipSuccess) {
-    lane.d_state = nullptr;
+  if (latency && !lane.d_walk &&
+      hipMalloc((void**)&lane.d_walk, sizeof(WalkState) * (size_t)ctx->cfg.max_pairs_per_batch) != hipSuccess) {
+    lane.d_walk = nullptr;
     latency = false;
   }
   // Up to 256 pairs one phase (full speculation, lowest latency); above, four phases so that recording stops
@@ -374,7 +374,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
-                                     lane.d_recs, lane.d_state, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+                                     lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
       else
         launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, lane.d_ec,
                              stream);
@@ -393,7 +393,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       if (latency)
         launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
                                           d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
-                                          lane.d_recs, lane.d_state, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+                                          lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
       else
         launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
                                   lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
@@ -521,7 +521,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (ln.d_sm_n) (void)hipFree(ln.d_sm_n);
     if (ln.d_all_dist) (void)hipFree(ln.d_all_dist);
     if (ln.d_recs) (void)hipFree(ln.d_recs);
-    if (ln.d_state) (void)hipFree(ln.d_state);
+    if (ln.d_walk) (void)hipFree(ln.d_walk);
     if (ln.d_ec) (void)hipFree(ln.d_ec);
     if (ln.d_keys) (void)hipFree(ln.d_keys);
     if (ln.d_results) (void)hipFree(ln.d_results);

@@ -49,10 +49,20 @@ struct IterRec {
   int32_t rn;
   int32_t pad;
 };
+// per-pair progress of the record / replay schedule: the reference's in-order bookkeeping (node.cpp:1171-1190),
+// resumed phase by phase by replay_walk_kernel
+struct WalkState {
+  int32_t state;             // >= 0: upper bound of the iterations that may still be needed; < 0: the loop has ended
+  int32_t n_all;             // selected matches of the pair (written by its recording waves)
+  int32_t it, real_iterations, valid_iterations;
+  int32_t best_idx;          // iteration whose record is the best hypothesis so far, -1 = none
+  int32_t best_n;
+  float rmse;
+};
 // parameters of one record / replay phase (select_ransac.hip)
 struct RecordPlan {
   IterRec* recs = nullptr;   // [pair][iteration]
-  int32_t* state = nullptr;  // [pair]: >= 0 upper bound of the iterations still needed, < 0 finished
+  WalkState* walk = nullptr; // [pair]
   uint32_t n_chunks = 1;     // recording waves per pair in this phase
   int chunk_iters = 0;       // iterations per recording wave
   int phase_begin = 0, phase_end = 0;
@@ -62,12 +72,12 @@ struct RecordPlan {
 size_t select_ransac_ec_region_bytes();
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
                                   int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                        const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                       const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
                                        int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,

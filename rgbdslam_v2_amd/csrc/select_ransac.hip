@@ -856,14 +856,14 @@ struct SiftMatchList {
   float* all_dist;     // [pair][RGBDFE_MAX_MATCHES] output: distances of the selected matches
 };
 
-// MODE selects what a wave does with a pair's RANSAC iterations ("latency"):
-//   kWhole   the whole pair: windows of iterations refined side by side, replayed in order (throughput path)
-//   kRecord  only iterations [chunk * chunk_iters, (chunk + 1) * chunk_iters): refine them and write each iteration's
-//            outcome (IterRec) to memory -- several waves share one pair; no replay, no result
-//   kReplay  the whole pair again, but every iteration's outcome is read from the records instead of being
-//            computed: the in-order replay with the reference's bookkeeping, the identity fallback, the result
-// kRecord + kReplay give the same result as kWhole (an iteration's refinement is a pure function of its index, D1)
-// with the refinement work of one pair spread over many waves: the small-batch / low-latency path.
+// MODE selects what a wave does with a pair's RANSAC iterations ("record / replay"):
+//   kWhole   the whole pair: windows of iterations refined side by side, replayed in order (one wave per pair)
+//   kRecord  a share of the iterations of a phase: refine them (7 slots, refilled as iterations finish) and write each
+//            iteration's outcome (IterRec) to memory -- several waves share one pair; no bookkeeping, no result
+//   kReplay  the result of a pair whose in-order bookkeeping replay_walk_kernel has run over the records: adopt the best
+//            record, the identity fallback, the result POD
+// kRecord + replay_walk_kernel + kReplay give the same result as kWhole (an iteration's refinement is a pure function of
+// its index, D1) with the refinement work of one pair spread over many waves.
 constexpr int kWhole = 0, kRecord = 1, kReplay = 2;
 
 template <bool SIFT, int MODE>
@@ -877,9 +877,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   if (pair >= n_pairs) return;
   // record / replay bookkeeping: state[pair] >= 0 is an upper bound of the iterations the pair still needs recorded,
   // < 0 means its result has been written
-  const int pair_state = MODE == kWhole ? 0 : plan.state[pair];
-  if (MODE != kWhole && pair_state < 0) return;
-  const int recorded_end = MODE == kWhole ? 0 : min(plan.phase_end, pair_state);
+  const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
+  if (MODE == kRecord && pair_state < 0) return;
+  const int recorded_end = MODE == kRecord ? min(plan.phase_end, pair_state) : 0;
   const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(blockIdx.x % plan.n_chunks) * plan.chunk_iters : 0;
   const int k_end = MODE == kRecord ? min(k_begin + plan.chunk_iters, recorded_end) : 0;
   if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, d));
   pmax = bcast_f(pmax, 0);
+  if (MODE == kRecord && lane == 0) plan.walk[pair].n_all = n_all;  // for replay_walk_kernel (every wave of the pair agrees)
 
   PH_MARK(1)
   // ------------------------------------------------------------------ RANSAC
@@ -1295,34 +1296,37 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         if (!occupied) break;
         refine_round();
       }
+    } else if (MODE == kReplay) {
+      // the in-order bookkeeping ran in replay_walk_kernel: adopt its outcome and the record of the best iteration
+      const WalkState ws = plan.walk[pair];
+      valid_iterations = ws.valid_iterations;
+      real_iterations = ws.real_iterations;
+      best_n = ws.best_n;
+      rmse = ws.rmse;
+      if (ws.best_idx >= 0 && lane == 0) {
+        const IterRec& r = rec_pair[ws.best_idx];
+        Hyp& b = lds.best;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) b.R[i] = r.rR[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b.t[i] = r.rt[i];
+#pragma unroll
+        for (int q = 0; q < kRounds; ++q) b.mask[q] = r.rmask[q];
+        b.n = r.rn;
+        b.nan = 0;
+        b.err = r.rerr;
+      }
+      __syncthreads();
     } else {
-    for (; !done && it < rc.ransac_iterations && n_all >= 4 &&
-           (MODE != kReplay || real_iterations < recorded_end);) {  // :1130
+    for (; !done && it < rc.ransac_iterations && n_all >= 4;) {  // :1130
       const int k0 = real_iterations;
       // The first iteration runs alone: an easy pair leaves the loop right after it (:1188) and must
       // not pay for a speculative window.
-      const int G = MODE == kReplay ? min(kSlots, recorded_end - k0) : ((k0 == 0) ? 1 : kSlots);
-      if (MODE == kReplay) {
-        // the outcomes of iterations k0 .. k0+G-1 come from the records written by the kRecord waves
-        if (lane < G) {
-          const IterRec& r = rec_pair[k0 + lane];
-          Slot& sl = lds.slot[lane];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) sl.rR[i] = r.rR[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) sl.rt[i] = r.rt[i];
-#pragma unroll
-          for (int q = 0; q < kRounds; ++q) sl.rmask[q] = r.rmask[q];
-          sl.rerr = r.rerr;
-          sl.rn = r.rn;
-        }
-        __syncthreads();
-      } else {
-        // ---- open the window: slot g <- iteration k0 + g; refine all of them to the end
-        for (int g = 0; g < G; ++g) open_slot(g, k0 + g);
-        __syncthreads();
-        while (refine_round()) {}
-      }
+      const int G = (k0 == 0) ? 1 : kSlots;
+      // ---- open the window: slot g <- iteration k0 + g; refine all of them to the end
+      for (int g = 0; g < G; ++g) open_slot(g, k0 + g);
+      __syncthreads();
+      while (refine_round()) {}
       // ---- replay the window in iteration order (:1171-1190)
       for (int g = 0; g < G; ++g) {
         if (!(it < rc.ransac_iterations)) { done = true; break; }
@@ -1357,12 +1361,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         ++it;
       }
     }
-    }  // MODE != kRecord
-    if (MODE == kReplay && !done && it < rc.ransac_iterations && n_all >= 4) {
-      // the records ran out before the loop ended: at most (ransac_iterations - it) more iterations can follow
-      if (lane == 0) plan.state[pair] = real_iterations + (rc.ransac_iterations - it);
-      return;
-    }
+    }  // kWhole
     if (MODE != kRecord && valid_iterations == 0) {  // :1192 identity hypothesis
       uint64_t inl_mask[kRounds];
       int n_inl;
@@ -1408,7 +1407,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) out->inlier_mask[r] = b.mask[r];
-    if (MODE == kReplay) plan.state[pair] = -1;  // finished: later phases skip this pair
 #ifdef RGBDFE_PROFILE_PHASES
     PH_MARK(5)
     uint64_t* dbg = reinterpret_cast<uint64_t*>(out->all_q);
@@ -1440,52 +1438,122 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, con
                      work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, plan);
 }
 
+// The reference's in-order bookkeeping (node.cpp:1130-1191: `it += 10 / 20`, the 80 % exit, best-so-far) over the records
+// of iterations [real_iterations, min(phase_end, state)): one wave per pair, 64 records fetched per step, the sequential
+// decisions on wave-uniform values.  Leaves either "finished" (state < 0) or a tighter bound on the iterations the pair
+// can still need; resumes where the previous phase stopped.
+__global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __restrict__ recs, WalkState* __restrict__ walk,
+                                                            uint32_t n_pairs, const RansacConst rc, int phase_begin,
+                                                            int phase_end) {
+  const uint32_t pair = blockIdx.x;
+  if (pair >= n_pairs) return;
+  const int lane = threadIdx.x;
+  WalkState ws = walk[pair];
+  const int I = rc.ransac_iterations;
+  if (phase_begin == 0) {
+    ws.state = I;
+    ws.it = 0; ws.real_iterations = 0; ws.valid_iterations = 0;
+    ws.best_idx = -1; ws.best_n = 0;
+    ws.rmse = 1e6f;  // :1112
+    if (I <= 0) ws.n_all = 0;  // nobody recorded anything: the loop below does not run
+  } else if (ws.state < 0) {
+    return;
+  }
+  const int n_all = ws.n_all;
+  const int recorded_end = min(phase_end, ws.state);
+  uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
+  if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
+  const IterRec* __restrict__ rec_pair = recs + (size_t)pair * (size_t)(I > 0 ? I : 0);
+  int it = ws.it, real_iterations = ws.real_iterations, valid_iterations = ws.valid_iterations;
+  int best_idx = ws.best_idx, best_n = ws.best_n;
+  float rmse = ws.rmse;
+  bool done = false;
+  const bool runs = n_all > rc.min_matches && n_all >= 4;  // :1087, :1130
+  while (runs && !done && it < I && real_iterations < recorded_end) {
+    const int k0 = real_iterations;
+    const int G = min(kWave, recorded_end - k0);
+    int rn_l = 0;
+    double rerr_l = 0.0;
+    if (lane < G) {
+      rn_l = rec_pair[k0 + lane].rn;
+      rerr_l = rec_pair[k0 + lane].rerr;
+    }
+    for (int g = 0; g < G; ++g) {
+      if (!(it < I)) { done = true; break; }
+      real_iterations++;  // :1139
+      const int refined_n = __builtin_amdgcn_readlane(rn_l, g);
+      const double refined_error = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rerr_l), g),
+                                                    __builtin_amdgcn_readlane(__double2loint(rerr_l), g));
+      if (refined_n > 0) {  // :1171
+        valid_iterations++;
+        if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
+          rmse = (float)refined_error;  // :1182
+          best_idx = k0 + g;
+          best_n = refined_n;
+          if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
+          if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
+          if ((double)refined_n > (double)n_all * 0.8) { done = true; break; }  // :1188
+        }
+      }
+      ++it;
+    }
+  }
+  if (lane == 0) {
+    // records ran out before the loop ended: at most (I - it) more iterations can follow
+    ws.state = (runs && !done && it < I) ? real_iterations + (I - it) : -1;
+    ws.it = it; ws.real_iterations = real_iterations; ws.valid_iterations = valid_iterations;
+    ws.best_idx = best_idx; ws.best_n = best_n; ws.rmse = rmse;
+    walk[pair] = ws;
+  }
+}
+
 // Record / replay schedule.  The iteration range is covered in `n_phases` phases ending at phase_ends[]: each phase
-// launches the recording waves (ceil(phase length / chunk_iters) per pair; waves of finished pairs and waves beyond
-// a pair's remaining need return at once) and then one replay wave per pair, which either finishes the pair (result
-// written, state < 0) or tightens the bound on the iterations it still needs.  One phase = full speculation (lowest
-// latency); several phases stop recording where the reference's bookkeeping stops iterating.
-// recs: n_pairs x rc.ransac_iterations records; state: n_pairs ints (set to rc.ransac_iterations here).
+// launches the recording waves (the phase in equal shares of at most chunk_iters iterations per wave; waves of finished
+// pairs and waves beyond a pair's remaining need return at once) and the walk (one small wave per pair), which either
+// ends the pair's loop or tightens the bound on the iterations it can still need.  One launch of result waves follows
+// the last phase.  One phase = full speculation (lowest latency); several phases stop recording where the reference's
+// bookkeeping stops iterating.  recs: n_pairs x rc.ransac_iterations records; walk: n_pairs states.
 template <bool SIFT>
 static void launch_record_replay(const float4* xyz_pool, const PairWork* work, const uint32_t* keys, uint32_t key_planes,
                                  const SiftMatchList& sm, rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                 const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool, int chunk_iters,
+                                 const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool, int chunk_iters,
                                  const int* phase_ends, int n_phases, hipStream_t stream) {
   if (n_pairs == 0) return;
-  (void)hipMemsetD32Async((hipDeviceptr_t)state, rc.ransac_iterations, n_pairs, stream);
   int begin = 0;
+  RecordPlan plan{};
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
     // the phase in ceil(length / chunk_iters) equal shares (a short last wave would be the launch's straggler)
     const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
     const int share = n_chunks > 0 ? (end - begin + n_chunks - 1) / n_chunks : chunk_iters;
-    RecordPlan plan{recs, state, (uint32_t)n_chunks, share, begin, end, ec_pool};
+    plan = RecordPlan{recs, walk, (uint32_t)n_chunks, share, begin, end, ec_pool};
     if (end > begin)
       hipLaunchKernelGGL((select_ransac_kernel<SIFT, kRecord>), dim3(n_pairs * plan.n_chunks), dim3(kWave), 0, stream,
                          xyz_pool, work, keys, key_planes, sm, results, max_kp, n_pairs, rc, plan);
-    plan.n_chunks = 1;
-    hipLaunchKernelGGL((select_ransac_kernel<SIFT, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys,
-                       key_planes, sm, results, max_kp, n_pairs, rc, plan);
+    hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, recs, walk, n_pairs, rc, begin, end);
     begin = end;
   }
+  plan.n_chunks = 1;
+  hipLaunchKernelGGL((select_ransac_kernel<SIFT, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys,
+                     key_planes, sm, results, max_kp, n_pairs, rc, plan);
 }
 
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
                                   int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream) {
   SiftMatchList none{};
-  launch_record_replay<false>(xyz_pool, work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, state,
+  launch_record_replay<false>(xyz_pool, work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, walk,
                               ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
                                        const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, int32_t* state, double* ec_pool,
+                                       const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
                                        int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream) {
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
-  launch_record_replay<true>(xyz_pool, work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, state,
+  launch_record_replay<true>(xyz_pool, work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, walk,
                              ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
