@@ -74,13 +74,14 @@ void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, 
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
                                   uint32_t n_pairs, const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
                                   int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
-void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
-                                       const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
+void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
+                                       uint16_t* sm_t, float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
                                        const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
                                        int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
-void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
-                               const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
+// (the SIFT launchers first sort each pair's match list in place: sift_sort_kernel)
+void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
+                               uint16_t* sm_t, float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
                                uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream);
 // SIFT matcher (sift_match.hip): u8-quantised descriptors as bf16, exact integer dot products

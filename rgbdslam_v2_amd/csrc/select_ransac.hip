@@ -856,6 +856,46 @@ struct SiftMatchList {
   float* all_dist;     // [pair][RGBDFE_MAX_MATCHES] output: distances of the selected matches
 };
 
+// keepStrongestMatches by the float L2 distance (node.cpp:674) with D2's tie-break, once per pair: the rank of a match
+// is the number of matches with a smaller (distance, queryIdx) key (distances are non-negative floats: their bit
+// patterns order like the values).  The max_matches best matches are written back, in rank order, over the head of the
+// pair's list; the count stays the original one.  One wave per pair.
+__global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__ sm_q, uint16_t* __restrict__ sm_t,
+                                                          float* __restrict__ sm_d, const int32_t* __restrict__ sm_n,
+                                                          uint32_t max_kp, uint32_t n_pairs, int max_matches) {
+  __shared__ uint32_t s_qt[RGBDFE_MAX_MATCHES], s_d[RGBDFE_MAX_MATCHES];
+  const uint32_t pair = blockIdx.x;
+  if (pair >= n_pairs) return;
+  const int lane = threadIdx.x;
+  uint16_t* __restrict__ sq = sm_q + (size_t)pair * max_kp;
+  uint16_t* __restrict__ st = sm_t + (size_t)pair * max_kp;
+  float* __restrict__ sd = sm_d + (size_t)pair * max_kp;
+  const int n = sm_n[pair];
+  const int n_all = min(n, max_matches);
+  for (int base = 0; base < n; base += kWave) {
+    const int i = base + lane;
+    const bool act = i < n;
+    const uint32_t di = act ? __float_as_uint(sd[i]) : 0u;
+    const uint32_t qi = act ? (uint32_t)sq[i] : 0u;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const uint32_t dj = __float_as_uint(sd[j]);
+      const uint32_t qj = (uint32_t)sq[j];
+      rank += (dj < di || (dj == di && qj < qi)) ? 1 : 0;
+    }
+    if (act && rank < max_matches) {
+      s_qt[rank] = qi | ((uint32_t)st[i] << 16);
+      s_d[rank] = di;
+    }
+  }
+  __syncthreads();  // every read of the unsorted list is done
+  for (int m = lane; m < n_all; m += kWave) {
+    sq[m] = (uint16_t)(s_qt[m] & 0xFFFFu);
+    st[m] = (uint16_t)(s_qt[m] >> 16);
+    sd[m] = __uint_as_float(s_d[m]);
+  }
+}
+
 // MODE selects what a wave does with a pair's RANSAC iterations ("record / replay"):
 //   kWhole   the whole pair: windows of iterations refined side by side, replayed in order (one wave per pair)
 //   kRecord  a share of the iterations of a phase: refine them (7 slots, refilled as iterations finish) and write each
@@ -968,28 +1008,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   __syncthreads();
   } else {
     // ------------------------------------------------------------- selection (SIFT)
-    // keepStrongestMatches by the float L2 distance (node.cpp:674) with D2's tie-break: the
-    // rank of a match is the number of matches with a smaller (distance, queryIdx) key.
-    // Distances are non-negative floats: their bit patterns order like the values.
+    // sift_sort_kernel has left the pair's matches in keepStrongestMatches order (node.cpp:674, D2) at the head of
+    // the list
     const uint16_t* __restrict__ sq = sm.q + (size_t)pair * max_kp;
     const uint16_t* __restrict__ st = sm.t + (size_t)pair * max_kp;
     const float* __restrict__ sd = sm.d + (size_t)pair * max_kp;
-    const int n = sm.n[pair];
-    n_all = min(n, max_matches);
-    for (int base = 0; base < n; base += kWave) {
-      const int i = base + lane;
-      const bool act = i < n;
-      const uint32_t di = act ? __float_as_uint(sd[i]) : 0u;
-      const uint32_t qi = act ? (uint32_t)sq[i] : 0u;
-      int rank = 0;
-      for (int j = 0; j < n; ++j) {
-        const uint32_t dj = __float_as_uint(sd[j]);
-        const uint32_t qj = (uint32_t)sq[j];
-        rank += (dj < di || (dj == di && qj < qi)) ? 1 : 0;
-      }
-      if (act && rank < max_matches) {
-        sel.mqt[rank] = qi | ((uint32_t)st[i] << 16);
-        sel.mhd[rank] = di;  // distance bits travel in the hd slot
+    n_all = min(sm.n[pair], max_matches);
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int m = r * kWave + lane;
+      if (m < n_all) {
+        sel.mqt[m] = (uint32_t)sq[m] | ((uint32_t)st[m] << 16);
+        sel.mhd[m] = __float_as_uint(sd[m]);  // distance bits travel in the hd slot
       }
     }
     __syncthreads();
@@ -1426,11 +1456,13 @@ void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const ui
                      work, keys, key_planes, none, results, max_kp, n_pairs, rc, plan);
 }
 
-void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
-                               const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n,
+void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
+                               uint16_t* sm_t, float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
                                uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream) {
   if (n_pairs == 0) return;
+  hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kWave), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
+                     rc.max_matches);
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
   RecordPlan plan{};
   plan.ec_pool = ec_pool;
@@ -1547,11 +1579,14 @@ void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, 
                               ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
-void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, const uint16_t* sm_q,
-                                       const uint16_t* sm_t, const float* sm_d, const int32_t* sm_n, float* all_dist,
+void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
+                                       uint16_t* sm_t, float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
                                        const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
                                        int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream) {
+  if (n_pairs == 0) return;
+  hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kWave), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
+                     rc.max_matches);
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
   launch_record_replay<true>(xyz_pool, work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, walk,
                              ec_pool, chunk_iters, phase_ends, n_phases, stream);

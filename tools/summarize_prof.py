@@ -22,6 +22,8 @@ def find(pattern):
 
 
 def short(name):
+    if "replay_walk_kernel" in name:  # part of the select+RANSAC stage of a batch (record / replay schedule)
+        return "select_ransac"
     for k in ("hamming_nn_kernel", "select_ransac_kernel", "project_to_3d_kernel"):
         if k in name:
             return k.replace("_kernel", "")
