@@ -195,7 +195,7 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
  *                         iterations the reference runs, but a pair takes ~4.6 ms however idle the chip is and a
  *                         launch lasts as long as its slowest pair.
  * Batches of at most max_pairs pairs (ORB and SIFT) take record / replay.  Defaults: max_pairs = INT32_MAX (every
- * batch), chunk_iterations = 0 (automatic: 7 up to 640 pairs, 14 up to 1280, 28 above; a phase is cut into equal
+ * batch), chunk_iterations = 0 (automatic: 4 up to 64 pairs, 7 up to 640, 14 up to 1280, 28 above; a phase is cut into equal
  * shares of at most that many iterations); max_pairs = 0 forces one wave per pair.
  * A negative chunk_iterations selects the four-phase plan for every batch size with |chunk_iterations| iterations
  * per recording wave (a testing aid: small batches are faster with the single phase). */

@@ -123,7 +123,7 @@ struct rgbdfe_ctx {
   // (uniform short waves fill the chip and have no straggler tail), the one-wave kernel above (it skips the
   // iterations the reference's early exits skip, and overlapped batches hide its tail).
   int32_t latency_pairs = INT32_MAX;  // record / replay for every batch size (rgbdfe_set_latency_mode)
-  int32_t latency_chunk_iters = 0;  // 0 = automatic: 7 iterations per wave up to 640 pairs, 14 up to 1280, 28 above
+  int32_t latency_chunk_iters = 0;  // 0 = automatic: 4 iterations per wave up to 64 pairs, 7 up to 640, 14 up to 1280, 28 above
   int64_t next_ticket = 1;
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   rgbdfe_match_result* h_results = nullptr;  // pinned staging of the synchronous host-output entry points
@@ -266,7 +266,7 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   const int chunk_cfg = force_phases ? -ctx->latency_chunk_iters : ctx->latency_chunk_iters;
   // automatic: small batches want many short waves (latency), large ones long waves (a wave refills its 7 slots from
   // its own share of iterations, so longer shares keep the batched rounds fuller); tools/bench_batch_sweep.py
-  int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 640 ? 7 : (n <= 1280 ? 14 : 28));
+  int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 64 ? 4 : (n <= 640 ? 7 : (n <= 1280 ? 14 : 28)));
   // every recording wave owns a region of the error pool: keep the largest grid (a phase is at most all iterations)
   // within kMaxEcRegions by recording more iterations per wave
   while ((size_t)n * (size_t)((ctx->rc.ransac_iterations + chunk - 1) / chunk) > kMaxEcRegions) ++chunk;
