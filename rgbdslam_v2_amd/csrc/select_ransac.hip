@@ -863,6 +863,8 @@ struct SiftMatchList {
 __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__ sm_q, uint16_t* __restrict__ sm_t,
                                                           float* __restrict__ sm_d, const int32_t* __restrict__ sm_n,
                                                           uint32_t max_kp, uint32_t n_pairs, int max_matches) {
+  constexpr int kTile = 2048;  // keys staged in LDS at a time (a longer list is staged again for every 64 ranks)
+  __shared__ uint64_t s_key[kTile];
   __shared__ uint32_t s_qt[RGBDFE_MAX_MATCHES], s_d[RGBDFE_MAX_MATCHES];
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
@@ -872,20 +874,34 @@ __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__
   float* __restrict__ sd = sm_d + (size_t)pair * max_kp;
   const int n = sm_n[pair];
   const int n_all = min(n, max_matches);
+  auto key_of = [&](int i) { return ((uint64_t)__float_as_uint(sd[i]) << 16) | (uint64_t)sq[i]; };  // (distance, queryIdx)
+  const bool single = n <= kTile;
+  if (single) {
+    for (int j = lane; j < n; j += kWave) s_key[j] = key_of(j);
+    __syncthreads();
+  }
   for (int base = 0; base < n; base += kWave) {
     const int i = base + lane;
     const bool act = i < n;
-    const uint32_t di = act ? __float_as_uint(sd[i]) : 0u;
-    const uint32_t qi = act ? (uint32_t)sq[i] : 0u;
+    const uint64_t ki = act ? key_of(i) : 0ull;
     int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const uint32_t dj = __float_as_uint(sd[j]);
-      const uint32_t qj = (uint32_t)sq[j];
-      rank += (dj < di || (dj == di && qj < qi)) ? 1 : 0;
+    for (int t0 = 0; t0 < n; t0 += kTile) {
+      const int tn = min(kTile, n - t0);
+      if (!single) {
+        __syncthreads();
+        for (int j = lane; j < tn; j += kWave) s_key[j] = key_of(t0 + j);
+        __syncthreads();
+      }
+      int j = 0;
+      for (; j + 8 <= tn; j += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += s_key[j + u] < ki ? 1 : 0;
+      }
+      for (; j < tn; ++j) rank += s_key[j] < ki ? 1 : 0;
     }
     if (act && rank < max_matches) {
-      s_qt[rank] = qi | ((uint32_t)st[i] << 16);
-      s_d[rank] = di;
+      s_qt[rank] = (uint32_t)sq[i] | ((uint32_t)st[i] << 16);
+      s_d[rank] = __float_as_uint(sd[i]);
     }
   }
   __syncthreads();  // every read of the unsorted list is done

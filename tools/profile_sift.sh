@@ -19,14 +19,14 @@ out = "$OUT"
 res = collections.defaultdict(dict)
 for f in glob.glob(out + "/trace/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        for k in ("sift_row_top2_kernel<false>", "sift_row_top2_kernel<true>", "sift_finish", "select_ransac_kernel<true>", "sift_quantise"):
+        for k in ("sift_row_top2_kernel<false>", "sift_row_top2_kernel<true>", "sift_finish", "select_ransac_kernel<true, 1>", "select_ransac_kernel<true, 2>", "replay_walk_kernel", "sift_sort_kernel", "sift_quantise"):
             if k in r["Name"]:
                 res[k]["calls"] = int(r["Calls"]); res[k]["avg_ns"] = float(r["AverageNs"]); res[k]["pct"] = float(r["Percentage"])
 for pat in ("pmc_mfma", "pmc_fetch", "pmc_write"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out + "/" + pat + "/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            for k in ("sift_row_top2_kernel<false>", "sift_row_top2_kernel<true>", "sift_finish", "select_ransac_kernel<true>"):
+            for k in ("sift_row_top2_kernel<false>", "sift_row_top2_kernel<true>", "sift_finish", "select_ransac_kernel<true, 1>", "select_ransac_kernel<true, 2>", "replay_walk_kernel", "sift_sort_kernel"):
                 if k in r["Kernel_Name"]:
                     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, c in acc.items():
