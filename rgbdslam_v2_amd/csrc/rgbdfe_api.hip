@@ -92,6 +92,7 @@ struct rgbdfe_ctx {
     IterRec* d_recs = nullptr;              // record / replay: per pair x RANSAC iteration outcome records
     size_t recs_capacity = 0;               // in records
     WalkState* d_walk = nullptr;            // record / replay: per pair progress (max_pairs)
+    PairPrep* d_prep = nullptr;             // selected matches of every pair of the batch (max_pairs)
     double* d_ec = nullptr;                 // error pool of select+RANSAC: one region per launched wave
     size_t ec_regions = 0;
     uint32_t* d_keys = nullptr;             // max_pairs x max_kp
@@ -374,10 +375,10 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
-                                     lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+                                     lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
       else
-        launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, lane.d_ec,
-                             stream);
+        launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, lane.d_prep,
+                             lane.d_ec, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
     } else {
       launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
@@ -393,11 +394,11 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       if (latency)
         launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
                                           d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
-                                          lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+                                          lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
       else
         launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
                                   lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
-                                  (uint32_t)n, ctx->rc, lane.d_ec, stream);
+                                  (uint32_t)n, ctx->rc, lane.d_prep, lane.d_ec, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.d, stream);
     }
     if (ctx->profiling) ctx->pending.push_back(pend);
@@ -484,6 +485,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
       return bail(RGBDFE_ERR_OUT_OF_MEMORY);
     if (hipMalloc((void**)&ln.d_results, np * sizeof(rgbdfe_match_result)) != hipSuccess)
       return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+    if (hipMalloc((void**)&ln.d_prep, np * sizeof(PairPrep)) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
   }
   ctx->emm_q_lo = erf_boundary(0.001);
   ctx->emm_q_hi = erf_boundary(0.999);
@@ -522,6 +524,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (ln.d_all_dist) (void)hipFree(ln.d_all_dist);
     if (ln.d_recs) (void)hipFree(ln.d_recs);
     if (ln.d_walk) (void)hipFree(ln.d_walk);
+    if (ln.d_prep) (void)hipFree(ln.d_prep);
     if (ln.d_ec) (void)hipFree(ln.d_ec);
     if (ln.d_keys) (void)hipFree(ln.d_keys);
     if (ln.d_results) (void)hipFree(ln.d_results);

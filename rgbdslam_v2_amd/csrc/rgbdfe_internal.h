@@ -40,7 +40,8 @@ uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint
                            uint32_t key_planes_capacity, hipStream_t stream);
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                          uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream);
+                          uint32_t n_pairs, const RansacConst& rc, struct PairPrep* prep, double* ec_pool,
+                          hipStream_t stream);
 // outcome of one RANSAC iteration's refinement loop (node.cpp:1140-1169): refined transform, inlier set, error
 struct IterRec {
   float rR[9], rt[3];
@@ -49,11 +50,20 @@ struct IterRec {
   int32_t rn;
   int32_t pad;
 };
+// what pair_prep_kernel leaves for every select+RANSAC wave of a pair: the selected matches' 3-D points as 7-word
+// records (from.xyz, to.xyz, 1/(from.z*to.z)) and the facts about them the waves need
+struct alignas(16) PairPrep {
+  float M[RGBDFE_MAX_MATCHES * 7];
+  uint64_t w_nonzero[RGBDFE_MASK_WORDS];  // matches with a non-zero weight
+  int32_t n_all;                          // selected matches
+  float pmax;                             // largest finite |coordinate| of their points
+  uint32_t fast_alpha;                    // every weight inside the window of the unscaled float division
+  uint32_t pad;
+};
 // per-pair progress of the record / replay schedule: the reference's in-order bookkeeping (node.cpp:1171-1190),
 // resumed phase by phase by replay_walk_kernel
 struct WalkState {
   int32_t state;             // >= 0: upper bound of the iterations that may still be needed; < 0: the loop has ended
-  int32_t n_all;             // selected matches of the pair (written by its recording waves)
   int32_t it, real_iterations, valid_iterations;
   int32_t best_idx;          // iteration whose record is the best hypothesis so far, -1 = none
   int32_t best_n;
@@ -66,24 +76,26 @@ struct RecordPlan {
   uint32_t n_chunks = 1;     // recording waves per pair in this phase
   int chunk_iters = 0;       // iterations per recording wave
   int phase_begin = 0, phase_end = 0;
+  const PairPrep* prep = nullptr;  // [pair], every mode
   double* ec_pool = nullptr;  // every mode: select_ransac_ec_region_bytes() per launched wave (the inlier errors of
                               // a refinement round's scorings, read back lane = slot by the sequential error sums)
 };
 size_t select_ransac_ec_region_bytes();
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
-                                  int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
+                                  uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, IterRec* recs, WalkState* walk,
+                                  double* ec_pool, int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
                                        uint16_t* sm_t, float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
-                                       int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
+                                       const RansacConst& rc, PairPrep* prep, IterRec* recs, WalkState* walk,
+                                       double* ec_pool, int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream);
 // (the SIFT launchers first sort each pair's match list in place: sift_sort_kernel)
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
                                uint16_t* sm_t, float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
-                               uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream);
+                               uint32_t n_pairs, const RansacConst& rc, struct PairPrep* prep, double* ec_pool,
+                               hipStream_t stream);
 // SIFT matcher (sift_match.hip): u8-quantised descriptors as bf16, exact integer dot products
 // on the bf16 MFMA, SiftMatchGPU row/column/mutual-best semantics.
 void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,

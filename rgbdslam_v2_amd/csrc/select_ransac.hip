@@ -76,7 +76,6 @@ struct SumStage {
   double v[kSlots][kStageRow];
 };
 union Scratch {  // the phases never overlap
-  SelBuf sel;
   ScoreBuf sc;
   FitBuf fit;
   SumStage sum;
@@ -111,7 +110,7 @@ struct __attribute__((aligned(16))) RansacLds {
   Scratch u;
   // match m: M[7m..7m+2] newer node's point ("from"), M[7m+3..7m+5] older node's point ("to"),
   // M[7m+6] = 1/(from.z*to.z) (transformation_estimation_euclidean.cpp:25)
-  float M[RGBDFE_MAX_MATCHES * kRec];
+  alignas(16) float M[RGBDFE_MAX_MATCHES * kRec];
   Slot slot[kSlots];
   Hyp best;
 };
@@ -922,31 +921,25 @@ __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__
 // its index, D1) with the refinement work of one pair spread over many waves.
 constexpr int kWhole = 0, kRecord = 1, kReplay = 2;
 
-template <bool SIFT, int MODE>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void select_ransac_kernel(
+// ---------------------------------------------------------------------------------
+// Once per pair, before any select+RANSAC wave: the <= max_matches strongest matches in the reference's order
+// (keepStrongestMatches + sort, node.cpp:674-676 / :1315) and their 3-D points as the 7-word records the RANSAC
+// waves keep in LDS.  Writes the pair's PairPrep and the match lists of its result POD.  One wave per pair.
+// ---------------------------------------------------------------------------------
+template <bool SIFT>
+__global__ __launch_bounds__(kWave) void pair_prep_kernel(
     const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
     const uint32_t* __restrict__ keys, uint32_t key_planes, const SiftMatchList sm,
     rgbdfe_match_result* __restrict__ results, uint32_t max_kp, uint32_t n_pairs,
-    const RansacConst rc, const RecordPlan plan) {
-  __shared__ RansacLds lds;
-  const uint32_t pair = MODE == kRecord ? blockIdx.x / plan.n_chunks : blockIdx.x;
+    const RansacConst rc, PairPrep* __restrict__ prep) {
+  __shared__ SelBuf sel;
+  const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
-  // record / replay bookkeeping: state[pair] >= 0 is an upper bound of the iterations the pair still needs recorded,
-  // < 0 means its result has been written
-  const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
-  if (MODE == kRecord && pair_state < 0) return;
-  const int recorded_end = MODE == kRecord ? min(plan.phase_end, pair_state) : 0;
-  const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(blockIdx.x % plan.n_chunks) * plan.chunk_iters : 0;
-  const int k_end = MODE == kRecord ? min(k_begin + plan.chunk_iters, recorded_end) : 0;
-  if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
-  IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : plan.recs + (size_t)pair * (size_t)rc.ransac_iterations;
   const int lane = threadIdx.x;
   const PairWork w = work[pair];
   rgbdfe_match_result* __restrict__ out = results + pair;
-  double* __restrict__ ec_region = plan.ec_pool + (size_t)blockIdx.x * kEcRegion;  // this wave's rows of the error pool
+  PairPrep* __restrict__ pp = prep + pair;
   const int max_matches = rc.max_matches;
-  SelBuf& sel = lds.u.sel;
-  PH_DECL
   int n_all;
 
   if (!SIFT) {
@@ -1041,11 +1034,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     __syncthreads();
   }
 
-  // ------------------------------------------------- matched 3-D points -> LDS
+  // ------------------------------------------------- matched 3-D points -> records
   const float4* __restrict__ qxyz = xyz_pool + (size_t)w.q_slot * max_kp;
   const float4* __restrict__ txyz = xyz_pool + (size_t)w.t_slot * max_kp;
   bool w_plain = false;  // a weight outside the window of fit_recurrence<true>
-  uint64_t w_nonzero[kRounds];
   float pmax = 0.0f;     // largest finite |coordinate| of the matched points (bounds the float prefilter's error)
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
@@ -1060,34 +1052,80 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
     pmax = fmaxf(pmax, fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)),
                              fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z))));  // fmaxf skips NaN
-    lds.M[m * kRec + 0] = p.x; lds.M[m * kRec + 1] = p.y; lds.M[m * kRec + 2] = p.z;
-    lds.M[m * kRec + 3] = q.x; lds.M[m * kRec + 4] = q.y; lds.M[m * kRec + 5] = q.z;
+    float* __restrict__ rec = pp->M + m * kRec;
+    rec[0] = p.x; rec[1] = p.y; rec[2] = p.z;
+    rec[3] = q.x; rec[4] = q.y; rec[5] = q.z;
     // weight = 1.0/(from(2)*to(2)) (transformation_estimation_euclidean.cpp:25): the double
     // divide rounded to float equals the float divide (53 >= 2*24+2)
     const float wgt = 1.0f / (p.z * q.z);
-    lds.M[m * kRec + 6] = wgt;
+    rec[6] = wgt;
     {
       const uint32_t ex = (__float_as_uint(wgt) >> 23) & 0xFFu;
       w_plain |= (m < n_all) && (wgt != 0.0f) && (ex < 127u - 40u || ex > 127u + 40u);
-      w_nonzero[r] = __ballot(wgt != 0.0f);
+      const uint64_t nz = __ballot(wgt != 0.0f);
+      if (lane == 0) pp->w_nonzero[r] = nz;
     }
-    if (MODE != kRecord) {
-      out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
-      out->all_t[m] = (uint16_t)(qt >> 16);
-      if (SIFT) {
-        out->all_hd[m] = 0;
-        sm.all_dist[(size_t)pair * RGBDFE_MAX_MATCHES + m] = __uint_as_float(hd);
-      } else {
-        out->all_hd[m] = (uint8_t)hd;
-      }
+    out->all_q[m] = (uint16_t)(qt & 0xFFFFu);
+    out->all_t[m] = (uint16_t)(qt >> 16);
+    if (SIFT) {
+      out->all_hd[m] = 0;
+      sm.all_dist[(size_t)pair * RGBDFE_MAX_MATCHES + m] = __uint_as_float(hd);
+    } else {
+      out->all_hd[m] = (uint8_t)hd;
     }
   }
-  __syncthreads();
   const bool fast_alpha = (__ballot(w_plain) == 0ull);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, d));
-  pmax = bcast_f(pmax, 0);
-  if (MODE == kRecord && lane == 0) plan.walk[pair].n_all = n_all;  // for replay_walk_kernel (every wave of the pair agrees)
+  if (lane == 0) {
+    pp->n_all = n_all;
+    pp->pmax = pmax;
+    pp->fast_alpha = fast_alpha ? 1u : 0u;
+    pp->pad = 0u;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void select_ransac_kernel(
+    const PairWork* __restrict__ work, rgbdfe_match_result* __restrict__ results, uint32_t n_pairs,
+    const RansacConst rc, const RecordPlan plan) {
+  __shared__ RansacLds lds;
+  const uint32_t pair = MODE == kRecord ? blockIdx.x / plan.n_chunks : blockIdx.x;
+  if (pair >= n_pairs) return;
+  // record / replay bookkeeping: walk[pair].state >= 0 is an upper bound of the iterations the pair can still need,
+  // < 0 means its loop has ended
+  const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
+  if (MODE == kRecord && pair_state < 0) return;
+  const int recorded_end = MODE == kRecord ? min(plan.phase_end, pair_state) : 0;
+  const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(blockIdx.x % plan.n_chunks) * plan.chunk_iters : 0;
+  const int k_end = MODE == kRecord ? min(k_begin + plan.chunk_iters, recorded_end) : 0;
+  if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
+  IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : plan.recs + (size_t)pair * (size_t)rc.ransac_iterations;
+  const int lane = threadIdx.x;
+  const PairWork w = work[pair];
+  rgbdfe_match_result* __restrict__ out = results + pair;
+  double* __restrict__ ec_region = plan.ec_pool + (size_t)blockIdx.x * kEcRegion;  // this wave's rows of the error pool
+  PH_DECL
+
+  // ------------------------------------------------- the pair's matches (pair_prep_kernel) -> LDS
+  const PairPrep* __restrict__ pp = plan.prep + pair;
+  const int n_all = pp->n_all;
+  const float pmax = pp->pmax;
+  const bool fast_alpha = pp->fast_alpha != 0u;
+  uint64_t w_nonzero[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) w_nonzero[r] = pp->w_nonzero[r];
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(pp->M);
+    float4* __restrict__ dst = reinterpret_cast<float4*>(lds.M);
+    constexpr int kVec = RGBDFE_MAX_MATCHES * kRec / 4;
+#pragma unroll
+    for (int i = 0; i < (kVec + kWave - 1) / kWave; ++i) {
+      const int v = i * kWave + lane;
+      if (v < kVec) dst[v] = src[v];
+    }
+  }
+  __syncthreads();
 
   PH_MARK(1)
   // ------------------------------------------------------------------ RANSAC
@@ -1463,27 +1501,42 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                          uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream) {
+                          uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, double* ec_pool, hipStream_t stream) {
   if (n_pairs == 0) return;
   SiftMatchList none{};
+  hipLaunchKernelGGL(pair_prep_kernel<false>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys, key_planes,
+                     none, results, max_kp, n_pairs, rc, prep);
   RecordPlan plan{};
+  plan.prep = prep;
   plan.ec_pool = ec_pool;
-  hipLaunchKernelGGL((select_ransac_kernel<false, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, keys, key_planes, none, results, max_kp, n_pairs, rc, plan);
+  hipLaunchKernelGGL(select_ransac_kernel<kWhole>, dim3(n_pairs), dim3(kWave), 0, stream, work, results, n_pairs, rc,
+                     plan);
+}
+
+// SIFT: sift_sort_kernel leaves each pair's match list in keepStrongestMatches order, pair_prep_kernel<true> takes
+// its head
+static void launch_sift_prep(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q, uint16_t* sm_t, float* sm_d,
+                             const int32_t* sm_n, float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
+                             uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, hipStream_t stream) {
+  hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kWave), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
+                     rc.max_matches);
+  SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
+  hipLaunchKernelGGL(pair_prep_kernel<true>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work,
+                     (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, prep);
 }
 
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
                                uint16_t* sm_t, float* sm_d, const int32_t* sm_n,
                                float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
-                               uint32_t n_pairs, const RansacConst& rc, double* ec_pool, hipStream_t stream) {
+                               uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, double* ec_pool,
+                               hipStream_t stream) {
   if (n_pairs == 0) return;
-  hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kWave), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
-                     rc.max_matches);
-  SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
+  launch_sift_prep(xyz_pool, work, sm_q, sm_t, sm_d, sm_n, all_dist, results, max_kp, n_pairs, rc, prep, stream);
   RecordPlan plan{};
+  plan.prep = prep;
   plan.ec_pool = ec_pool;
-  hipLaunchKernelGGL((select_ransac_kernel<true, kWhole>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool,
-                     work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, plan);
+  hipLaunchKernelGGL(select_ransac_kernel<kWhole>, dim3(n_pairs), dim3(kWave), 0, stream, work, results, n_pairs, rc,
+                     plan);
 }
 
 // The reference's in-order bookkeeping (node.cpp:1130-1191: `it += 10 / 20`, the 80 % exit, best-so-far) over the records
@@ -1491,8 +1544,8 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uin
 // decisions on wave-uniform values.  Leaves either "finished" (state < 0) or a tighter bound on the iterations the pair
 // can still need; resumes where the previous phase stopped.
 __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __restrict__ recs, WalkState* __restrict__ walk,
-                                                            uint32_t n_pairs, const RansacConst rc, int phase_begin,
-                                                            int phase_end) {
+                                                            const PairPrep* __restrict__ prep, uint32_t n_pairs,
+                                                            const RansacConst rc, int phase_begin, int phase_end) {
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x;
@@ -1503,11 +1556,10 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
     ws.it = 0; ws.real_iterations = 0; ws.valid_iterations = 0;
     ws.best_idx = -1; ws.best_n = 0;
     ws.rmse = 1e6f;  // :1112
-    if (I <= 0) ws.n_all = 0;  // nobody recorded anything: the loop below does not run
   } else if (ws.state < 0) {
     return;
   }
-  const int n_all = ws.n_all;
+  const int n_all = prep[pair].n_all;
   const int recorded_end = min(phase_end, ws.state);
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
@@ -1560,52 +1612,55 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
 // pairs and waves beyond a pair's remaining need return at once) and the walk (one small wave per pair), which either
 // ends the pair's loop or tightens the bound on the iterations it can still need.  One launch of result waves follows
 // the last phase.  One phase = full speculation (lowest latency); several phases stop recording where the reference's
-// bookkeeping stops iterating.  recs: n_pairs x rc.ransac_iterations records; walk: n_pairs states.
-template <bool SIFT>
-static void launch_record_replay(const float4* xyz_pool, const PairWork* work, const uint32_t* keys, uint32_t key_planes,
-                                 const SiftMatchList& sm, rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                 const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool, int chunk_iters,
-                                 const int* phase_ends, int n_phases, hipStream_t stream) {
-  if (n_pairs == 0) return;
+// bookkeeping stops iterating.  recs: n_pairs x rc.ransac_iterations records; walk: n_pairs states; prep: filled.
+static void launch_record_replay(const PairWork* work, rgbdfe_match_result* results, uint32_t n_pairs,
+                                 const RansacConst& rc, const PairPrep* prep, IterRec* recs, WalkState* walk,
+                                 double* ec_pool, int chunk_iters, const int* phase_ends, int n_phases,
+                                 hipStream_t stream) {
   int begin = 0;
   RecordPlan plan{};
+  plan.recs = recs; plan.walk = walk; plan.prep = prep; plan.ec_pool = ec_pool;
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
     // the phase in ceil(length / chunk_iters) equal shares (a short last wave would be the launch's straggler)
     const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
-    const int share = n_chunks > 0 ? (end - begin + n_chunks - 1) / n_chunks : chunk_iters;
-    plan = RecordPlan{recs, walk, (uint32_t)n_chunks, share, begin, end, ec_pool};
+    plan.n_chunks = (uint32_t)n_chunks;
+    plan.chunk_iters = n_chunks > 0 ? (end - begin + n_chunks - 1) / n_chunks : chunk_iters;
+    plan.phase_begin = begin;
+    plan.phase_end = end;
     if (end > begin)
-      hipLaunchKernelGGL((select_ransac_kernel<SIFT, kRecord>), dim3(n_pairs * plan.n_chunks), dim3(kWave), 0, stream,
-                         xyz_pool, work, keys, key_planes, sm, results, max_kp, n_pairs, rc, plan);
-    hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, recs, walk, n_pairs, rc, begin, end);
+      hipLaunchKernelGGL(select_ransac_kernel<kRecord>, dim3(n_pairs * plan.n_chunks), dim3(kWave), 0, stream, work,
+                         results, n_pairs, rc, plan);
+    hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, recs, walk, prep, n_pairs, rc, begin,
+                       end);
     begin = end;
   }
   plan.n_chunks = 1;
-  hipLaunchKernelGGL((select_ransac_kernel<SIFT, kReplay>), dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys,
-                     key_planes, sm, results, max_kp, n_pairs, rc, plan);
+  hipLaunchKernelGGL(select_ransac_kernel<kReplay>, dim3(n_pairs), dim3(kWave), 0, stream, work, results, n_pairs, rc,
+                     plan);
 }
 
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
-                                  uint32_t n_pairs, const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
-                                  int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream) {
+                                  uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, IterRec* recs, WalkState* walk,
+                                  double* ec_pool, int chunk_iters, const int* phase_ends, int n_phases,
+                                  hipStream_t stream) {
+  if (n_pairs == 0) return;
   SiftMatchList none{};
-  launch_record_replay<false>(xyz_pool, work, keys, key_planes, none, results, max_kp, n_pairs, rc, recs, walk,
-                              ec_pool, chunk_iters, phase_ends, n_phases, stream);
+  hipLaunchKernelGGL(pair_prep_kernel<false>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys, key_planes,
+                     none, results, max_kp, n_pairs, rc, prep);
+  launch_record_replay(work, results, n_pairs, rc, prep, recs, walk, ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
 void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
                                        uint16_t* sm_t, float* sm_d, const int32_t* sm_n, float* all_dist,
                                        rgbdfe_match_result* results, uint32_t max_kp, uint32_t n_pairs,
-                                       const RansacConst& rc, IterRec* recs, WalkState* walk, double* ec_pool,
-                                       int chunk_iters, const int* phase_ends, int n_phases, hipStream_t stream) {
+                                       const RansacConst& rc, PairPrep* prep, IterRec* recs, WalkState* walk,
+                                       double* ec_pool, int chunk_iters, const int* phase_ends, int n_phases,
+                                       hipStream_t stream) {
   if (n_pairs == 0) return;
-  hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kWave), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
-                     rc.max_matches);
-  SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
-  launch_record_replay<true>(xyz_pool, work, (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, recs, walk,
-                             ec_pool, chunk_iters, phase_ends, n_phases, stream);
+  launch_sift_prep(xyz_pool, work, sm_q, sm_t, sm_d, sm_n, all_dist, results, max_kp, n_pairs, rc, prep, stream);
+  launch_record_replay(work, results, n_pairs, rc, prep, recs, walk, ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
 size_t select_ransac_ec_region_bytes() { return sizeof(double) * (size_t)kEcRegion; }
