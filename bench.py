@@ -255,9 +255,9 @@ def main():
             "hamming_ms_per_launch": round(ham_avg_ms, 4),
             "ransac_ms_per_launch": round(rsc_ms / max(rsc_launches, 1), 4),
             "ransac_schedule": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
-                               "record/replay (a batch's select+RANSAC stage = 4 x (recording launch of "
-                               "select_ransac_kernel + replay_walk_kernel) + 1 result launch; avg_launch_ms spans the "
-                               "whole stage)",
+                               "record/replay (a batch's select+RANSAC stage = pair_prep_kernel + 4 x (recording "
+                               "launch of select_ransac_kernel + replay_walk_kernel) + 1 result launch; avg_launch_ms "
+                               "spans the whole stage)",
             "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
             "valu_laneops_per_s": round(valu_achieved, 1), "valu_peak": VALU_PEAK_LANEOPS,
             "valu_frac": round(valu_achieved / VALU_PEAK_LANEOPS, 4), **iso,

@@ -22,7 +22,7 @@ def find(pattern):
 
 
 def short(name):
-    if "replay_walk_kernel" in name:  # part of the select+RANSAC stage of a batch (record / replay schedule)
+    if "replay_walk_kernel" in name or "pair_prep_kernel" in name:  # parts of the select+RANSAC stage of a batch
         return "select_ransac"
     for k in ("hamming_nn_kernel", "select_ransac_kernel", "project_to_3d_kernel"):
         if k in name:
