@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   uint64_t w_nonzero[kRounds];
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) w_nonzero[r] = pp->w_nonzero[r];
-  {
+  auto load_points = [&]() {
     const float4* __restrict__ src = reinterpret_cast<const float4*>(pp->M);
     float4* __restrict__ dst = reinterpret_cast<float4*>(lds.M);
     constexpr int kVec = RGBDFE_MAX_MATCHES * kRec / 4;
@@ -1124,8 +1124,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       const int v = i * kWave + lane;
       if (v < kVec) dst[v] = src[v];
     }
-  }
-  __syncthreads();
+    __syncthreads();
+  };
+  if (MODE != kReplay) load_points();  // a result wave needs them for the identity fallback only
 
   PH_MARK(1)
   // ------------------------------------------------------------------ RANSAC
@@ -1447,6 +1448,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
     }  // kWhole
     if (MODE != kRecord && valid_iterations == 0) {  // :1192 identity hypothesis
+      if (MODE == kReplay) load_points();
       uint64_t inl_mask[kRounds];
       int n_inl;
       double inlier_error;
