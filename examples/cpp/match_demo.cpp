@@ -44,6 +44,15 @@ int main(int argc, char** argv) {
   }
   // the serial call site (graph_manager.cpp:466): one pair through Node::matchNodePair
   const rgbdslam::MatchingResult one = new_node->matchNodePair(graph.front().get());
+  // candidate selection for the next node (graph_manager.cpp:204-324): the earlier nodes as a chain of keyframes
+  for (int i = 0; i + 1 < n_nodes; ++i) {
+    gm.nodeAdded(graph[i].get(), /*vertex_id=*/i, /*keyframe=*/true);
+    if (i) gm.edgeAdded(i, i - 1);
+  }
+  const std::vector<int> targets = gm.getPotentialEdgeTargetsWithDijkstra(new_node, 2, 1, 1, -1, false, 3, nullptr, nullptr, 7u);
+  std::printf("{\"candidates\": [");
+  for (size_t i = 0; i < targets.size(); ++i) std::printf("%s%d", i ? ", " : "", targets[i]);
+  std::printf("]}\n");
   std::printf("{\"single_id1\": %d, \"single_n_inl\": %zu}\n", one.edge.id1, one.inlier_matches.size());
   return 0;
 }

@@ -236,6 +236,33 @@ int rgbdfe_observation_likelihood(rgbdfe_ctx* ctx, int32_t n, const int32_t* new
 int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32_t all,
                                      double observability_threshold, double* quality);
 
+/* ---- candidate selection for loop closure ----------------------------------
+ * rgbdfe_potential_edge_targets is GraphManager::getPotentialEdgeTargetsWithDijkstra (graph_manager.cpp:204-324): the
+ * ids of the earlier nodes a new node is to be compared with -- `sequential_targets` direct predecessors, then
+ * `geodesic_targets` drawn (weighted by their distance in time, :266) from the graph neighbourhood of the predecessor
+ * within `geodesic_depth` edges (g2o::HyperDijkstra with UniformCostFunction, :230-233), then `sampled_targets` drawn
+ * uniformly from the remaining matchable keyframes (:297-317).  Order as in the reference's QList: sampled ids first
+ * (latest draw first), sequential ones after, the predecessor last when include_predecessor != 0.  The list feeds
+ * rgbdfe_match_node_pairs.  Host code, no device work.
+ * The pose-graph object holds what the reference reads from graph_, camera_vertices, keyframe_ids_ and the optimizer's
+ * edges: rgbdfe_pose_graph_add_node per Node added to the graph (id_, vertex_id_, matchable_, and whether it became a
+ * keyframe, graph_manager.cpp:655), rgbdfe_pose_graph_add_edge per edge added to the optimizer (:811).
+ * rand_fn(rand_state) replaces rand() (pass a wrapper of rand() for the reference's stream); NULL selects a
+ * counter-based generator seeded with `seed`, which makes the selection reproducible.
+ * Returns RGBDFE_ERR_CAPACITY (with *n_out = the needed size) when ids_out is too small. */
+typedef struct rgbdfe_pose_graph rgbdfe_pose_graph;
+typedef int (*rgbdfe_rand_fn)(void* state);
+rgbdfe_pose_graph* rgbdfe_pose_graph_create(void);
+void rgbdfe_pose_graph_destroy(rgbdfe_pose_graph* g);
+int rgbdfe_pose_graph_add_node(rgbdfe_pose_graph* g, int32_t node_id, int32_t vertex_id, int32_t matchable,
+                               int32_t keyframe);
+int rgbdfe_pose_graph_add_edge(rgbdfe_pose_graph* g, int32_t node_id1, int32_t node_id2);
+int rgbdfe_pose_graph_set_matchable(rgbdfe_pose_graph* g, int32_t node_id, int32_t matchable);
+int rgbdfe_potential_edge_targets(const rgbdfe_pose_graph* g, int32_t sequential_targets, int32_t geodesic_targets,
+                                  int32_t sampled_targets, int32_t geodesic_depth, int32_t predecessor_id,
+                                  int32_t include_predecessor, rgbdfe_rand_fn rand_fn, void* rand_state, uint32_t seed,
+                                  int32_t* ids_out, int32_t capacity, int32_t* n_out);
+
 /* ---- per-frame feature path: detect + describe (Node::Node, node.cpp:139-210) -----------------
  * rgbdfe_detect_describe replaces, for one frame,
  *   detector->detect(gray, kps, mask)   the 3x3 grid of threshold-adaptive ORB detectors built by

@@ -9,6 +9,7 @@
 //   LoadedEdge3D / MatchingResult               rgbdslam::LoadedEdge3D / rgbdslam::MatchingResult
 //   Node::matchNodePair(const Node*)            rgbdslam::Node::matchNodePair(const Node*)
 //   QtConcurrent::blockingMapped(nodes, ...)    rgbdslam::GraphManager::nodeComparisons(new_node, nodes)
+//   GraphManager::getPotentialEdgeTargetsWithDijkstra   rgbdslam::GraphManager::getPotentialEdgeTargetsWithDijkstra
 // No exceptions are thrown on the pair path: like Node::matchNodePair (node.cpp:1424-1426) failures end
 // in a MatchingResult whose edge ids are -1.
 #ifndef RGBDFE_HPP
@@ -134,9 +135,33 @@ class Node {  // the slice of src/node.h the pair path touches
   friend class GraphManager;
 };
 
-class GraphManager {  // only the fan-out of GraphManager::nodeComparisons (graph_manager.cpp:531-583)
+class GraphManager {  // candidate selection (graph_manager.cpp:204-324) + the fan-out of nodeComparisons (:531-583)
  public:
-  explicit GraphManager(const FrontEnd& fe) : fe_(fe) {}
+  explicit GraphManager(const FrontEnd& fe)
+      : fe_(fe), topology_(rgbdfe_pose_graph_create(), &rgbdfe_pose_graph_destroy) {
+    if (!topology_) throw std::runtime_error("rgbdfe_pose_graph_create failed");
+  }
+  // what addNode / addEdgeToG2O tell the pose graph (graph_manager.cpp:681, :811); candidate selection reads it
+  void nodeAdded(const Node* n, int vertex_id, bool keyframe) {
+    rgbdfe_pose_graph_add_node(topology_.get(), n->id_, vertex_id, n->matchable_ ? 1 : 0, keyframe ? 1 : 0);
+  }
+  void edgeAdded(int id1, int id2) { rgbdfe_pose_graph_add_edge(topology_.get(), id1, id2); }
+  // QList<int> GraphManager::getPotentialEdgeTargetsWithDijkstra(new_node, sequential_targets, geodesic_targets,
+  // sampled_targets, predecessor_id, include_predecessor); geodesic_depth is the parameter server's "geodesic_depth".
+  // rand_fn == nullptr: reproducible draws from `seed` instead of rand().
+  std::vector<int> getPotentialEdgeTargetsWithDijkstra(const Node* /*new_node*/, int sequential_targets,
+                                                       int geodesic_targets, int sampled_targets,
+                                                       int predecessor_id = -1, bool include_predecessor = false,
+                                                       int geodesic_depth = 3, rgbdfe_rand_fn rand_fn = nullptr,
+                                                       void* rand_state = nullptr, uint32_t seed = 0) const {
+    std::vector<int32_t> ids((size_t)(sequential_targets + geodesic_targets + sampled_targets + 1));
+    int32_t n = 0;
+    if (rgbdfe_potential_edge_targets(topology_.get(), sequential_targets, geodesic_targets, sampled_targets,
+                                      geodesic_depth, predecessor_id, include_predecessor ? 1 : 0, rand_fn, rand_state,
+                                      seed, ids.data(), (int32_t)ids.size(), &n) != RGBDFE_OK)
+      return {};
+    return std::vector<int>(ids.begin(), ids.begin() + n);
+  }
   // 1:1 replacement of QtConcurrent::blockingMapped(nodes_to_comp, bind(&Node::matchNodePair, new_node, _1))
   std::vector<MatchingResult> nodeComparisons(const Node* new_node, const std::vector<const Node*>& nodes_to_comp) const {
     std::vector<int32_t> ids;
@@ -153,6 +178,7 @@ class GraphManager {  // only the fan-out of GraphManager::nodeComparisons (grap
 
  private:
   const FrontEnd& fe_;
+  std::unique_ptr<rgbdfe_pose_graph, void (*)(rgbdfe_pose_graph*)> topology_;
 };
 
 // 4x4 inverse of a column-major float matrix (the reference calls Eigen's Matrix4f::inverse(), node.cpp:1536):

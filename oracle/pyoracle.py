@@ -54,7 +54,7 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if force or not all(os.path.exists(os.path.join(_HERE, "_ref", f))
                         for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so", "libref_ransac.so",
-                                  "libref_frame.so", "libref_siftmatch.so")):
+                                  "libref_frame.so", "libref_siftmatch.so", "libref_graph.so")):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -566,3 +566,42 @@ def match_sift_node_pair(qdesc, qxyz1, qid, tdesc, txyz1, tid, params=None):
     r = result_to_dict(out)
     r["all_dist"] = dist[: r["n_all"]].copy()
     return r
+
+
+_ref_graph = None
+
+
+def ref_graph_lib():
+    """The reference's own GraphManager::getPotentialEdgeTargetsWithDijkstra (graph_manager.cpp:204-324), compiled
+    from /root/reference with Qt / g2o stand-ins (oracle/ref_stubs/graph_prelude.h), or None."""
+    global _ref_graph
+    if _ref_graph is None:
+        p = os.path.join(_HERE, "_ref", "libref_graph.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        i, vp = C.c_int, C.c_void_p
+        R.ref_potential_edge_targets.restype = i
+        R.ref_potential_edge_targets.argtypes = [i, vp, vp, vp, i, vp, i, vp, vp, i, i, i, i, i, i, C.c_uint, vp, i]
+        _ref_graph = R
+    return _ref_graph
+
+
+def ref_potential_edge_targets(node_ids, vertex_ids, matchable, keyframes, edges, sequential_targets, geodesic_targets,
+                               sampled_targets, geodesic_depth, predecessor_id, include_predecessor, srand_seed):
+    R = ref_graph_lib()
+    nid = np.ascontiguousarray(node_ids, np.int32)
+    vid = np.ascontiguousarray(vertex_ids, np.int32)
+    mt = np.ascontiguousarray(matchable, np.int32)
+    kf = np.ascontiguousarray(keyframes, np.int32)
+    ea = np.ascontiguousarray([e[0] for e in edges], np.int32)
+    eb = np.ascontiguousarray([e[1] for e in edges], np.int32)
+    cap = int(sequential_targets + geodesic_targets + sampled_targets + 2)
+    out = np.zeros(cap, np.int32)
+    n = R.ref_potential_edge_targets(len(nid), nid.ctypes.data, vid.ctypes.data, mt.ctypes.data, len(kf), kf.ctypes.data,
+                                     len(ea), ea.ctypes.data, eb.ctypes.data, int(sequential_targets),
+                                     int(geodesic_targets), int(sampled_targets), int(geodesic_depth), int(predecessor_id),
+                                     int(bool(include_predecessor)), int(srand_seed), out.ctypes.data, cap)
+    return out[:n].copy()

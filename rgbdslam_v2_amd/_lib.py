@@ -191,6 +191,21 @@ def load():
     if L.rgbdfe_sizeof_match_result() != C.sizeof(RgbdfeMatchResult) or \
             RESULT_DTYPE.itemsize != C.sizeof(RgbdfeMatchResult):
         raise RgbdfeError("rgbdfe_match_result layout mismatch between librgbdfe.so and the binding")
+    RAND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    L.rgbdfe_rand_fn = RAND_FN
+    L.rgbdfe_pose_graph_create.restype = vp
+    L.rgbdfe_pose_graph_create.argtypes = []
+    L.rgbdfe_pose_graph_destroy.restype = None
+    L.rgbdfe_pose_graph_destroy.argtypes = [vp]
+    L.rgbdfe_pose_graph_add_node.restype = C.c_int
+    L.rgbdfe_pose_graph_add_node.argtypes = [vp, i32, i32, i32, i32]
+    L.rgbdfe_pose_graph_add_edge.restype = C.c_int
+    L.rgbdfe_pose_graph_add_edge.argtypes = [vp, i32, i32]
+    L.rgbdfe_pose_graph_set_matchable.restype = C.c_int
+    L.rgbdfe_pose_graph_set_matchable.argtypes = [vp, i32, i32]
+    L.rgbdfe_potential_edge_targets.restype = C.c_int
+    L.rgbdfe_potential_edge_targets.argtypes = [vp, i32, i32, i32, i32, i32, i32, RAND_FN, vp, C.c_uint32, vp, i32,
+                                                C.POINTER(i32)]
     _lib = L
     return L
 
@@ -209,4 +224,6 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_upload_node_cloud", "rgbdfe_release_node_cloud", "rgbdfe_observation_likelihood",
     "rgbdfe_observation_criterion_met", "rgbdfe_set_latency_mode", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
     "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
+    "rgbdfe_pose_graph_create", "rgbdfe_pose_graph_destroy", "rgbdfe_pose_graph_add_node",
+    "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
 ]

@@ -30,9 +30,12 @@ def test_cpp_host_matches_oracle(tmp_path):
             f.write(seq["xyz1"][k].tobytes())
     out = subprocess.check_output([exe, str(path)], text=True, timeout=120)
     lines = [json.loads(l) for l in out.strip().splitlines()]
-    assert len(lines) == F
+    assert len(lines) == F + 1
+    # getPotentialEdgeTargetsWithDijkstra(2 sequential, 1 geodesic, 1 sampled) over the 4 earlier nodes: no more nodes
+    # than targets, so all of them, sequentially from the predecessor (graph_manager.cpp:212-227)
+    assert lines[-2]["candidates"] == [2, 1, 0]
     prm = po.default_params()
-    for t, rec in enumerate(lines[:-1]):
+    for t, rec in enumerate(lines[:-2]):
         ref = po.match_node_pair(seq["desc"][F - 1], seq["xyz1"][F - 1], F - 1, seq["desc"][t], seq["xyz1"][t], t, prm)
         assert (rec["id1"], rec["id2"]) == (ref["id1"], ref["id2"])
         assert rec["n_all"] == ref["n_all"] and rec["n_inl"] == ref["n_inl"]
