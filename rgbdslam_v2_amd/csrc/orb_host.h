@@ -1,5 +1,6 @@
 // orb_host.h -- per-context ORB workspace (device buffers + the detector's persistent state)
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -22,7 +23,10 @@ struct OrbWorkspace {
   int detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
                   std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err);
   int grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::string& err);
-  int compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err);
+  // enqueue_more (optional) is called after the descriptor work has been enqueued and before the one synchronisation,
+  // so that the caller's own launches on the stream ride on the same round trip
+  int compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
+              const std::function<int()>& enqueue_more = nullptr);
 
   // detector state (the reference's detector_ object, openni_listener.h:195)
   int grid = 3, adjuster_iters = 5, cell_min = 0, cell_max = 0, max_total = 0;
@@ -46,6 +50,13 @@ struct OrbWorkspace {
   RawKp* d_kps = nullptr; DescKp* d_desckp = nullptr; uint8_t* d_desc = nullptr;
   float* d_depth = nullptr; float* d_kpxy = nullptr; int32_t* d_kept = nullptr; float4* d_xyz = nullptr;
   int32_t* d_n = nullptr;
+  // pinned host staging for the small per-frame transfers (thresholds, counts, keypoints, descriptors, 3-D points):
+  // pageable copies of a few hundred bytes cost 10-20 us each and there are a dozen per frame
+  int last_n_total = 0;  // keypoints of the latest detection pass: sizes the next pass's speculative read-back
+  int pin_cap = 0;  // keypoints the staging buffers hold (larger transfers fall back to pageable vectors)
+  int* h_ctl = nullptr; int* h_totals = nullptr; int* h_base = nullptr;
+  RawKp* h_raw = nullptr; DescKp* h_desckp = nullptr; uint8_t* h_desc = nullptr;
+  float* h_xyz_in = nullptr; float* h_xyz_out = nullptr; int32_t* h_n = nullptr;
 };
 
 }  // namespace rgbdfe

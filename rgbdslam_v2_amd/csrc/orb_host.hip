@@ -80,9 +80,12 @@ OrbWorkspace::~OrbWorkspace() { release(); }
 
 void OrbWorkspace::release() {
   auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  fr(d_pool); fr(d_score); fr(d_blur); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr); fr(d_active);
+  fr(d_pool); fr(d_score); fr(d_blur); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr);
   fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_depth); fr(d_kpxy);
   fr(d_kept); fr(d_xyz); fr(d_n);
+  auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
+  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n);
+  d_active = nullptr;  // lives inside d_thr
   W = H = 0;
 }
 
@@ -189,8 +192,8 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMalloc((void**)&d_cell_imgs, sizeof(ImgDesc) * cell_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_frame_imgs, sizeof(ImgDesc) * frame_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_jobs, sizeof(ResizeJob) * jobs.size()));
-  ORB_HIP(hipMalloc((void**)&d_thr, sizeof(int) * 64));
-  ORB_HIP(hipMalloc((void**)&d_active, sizeof(int) * 64));
+  ORB_HIP(hipMalloc((void**)&d_thr, sizeof(int) * 128));  // thresholds and active flags travel in one copy
+  d_active = d_thr + 64;
   ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
   ORB_HIP(hipMalloc((void**)&d_img_total, sizeof(int) * cell_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_img_base, sizeof(int) * cell_imgs.size()));
@@ -198,10 +201,20 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMalloc((void**)&d_desckp, sizeof(DescKp) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_desc, (size_t)32 * kp_cap));
   ORB_HIP(hipMalloc((void**)&d_depth, sizeof(float) * (size_t)W * H));
-  ORB_HIP(hipMalloc((void**)&d_kpxy, sizeof(float) * 2 * (size_t)kp_cap));
+  ORB_HIP(hipMalloc((void**)&d_kpxy, sizeof(float) * 3 * (size_t)kp_cap));  // x, y and the looked-up depth per keypoint
   ORB_HIP(hipMalloc((void**)&d_kept, sizeof(int32_t) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_xyz, sizeof(float4) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_n, sizeof(int32_t)));
+  pin_cap = std::min(kp_cap, 16384);
+  ORB_HIP(hipHostMalloc((void**)&h_ctl, sizeof(int) * 128, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_totals, sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_base, sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_raw, sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_desckp, sizeof(DescKp) * (size_t)pin_cap, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_desc, (size_t)32 * pin_cap, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_xyz_in, sizeof(float) * 3 * (size_t)pin_cap, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_xyz_out, sizeof(float) * 4 * (size_t)pin_cap, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_n, sizeof(int32_t), hipHostMallocDefault));
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));
@@ -231,27 +244,40 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
 // per-level selection: retainBest(2*featuresNum) by FAST score, Harris responses, retainBest(featuresNum).
 int OrbWorkspace::detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
                               std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err) {
-  int h_thr[64] = {0}, h_act[64] = {0};
-  for (int c = 0; c < n_cells; ++c) { h_thr[c] = thr[c]; h_act[c] = active[c]; }
-  ORB_HIP(hipMemcpyAsync(d_thr, h_thr, sizeof(h_thr), hipMemcpyHostToDevice, s));
-  ORB_HIP(hipMemcpyAsync(d_active, h_act, sizeof(h_act), hipMemcpyHostToDevice, s));
+  for (int c = 0; c < 64; ++c) {
+    h_ctl[c] = c < n_cells ? thr[c] : 0;
+    h_ctl[64 + c] = c < n_cells ? active[c] : 0;
+  }
+  ORB_HIP(hipMemcpyAsync(d_thr, h_ctl, sizeof(int) * 128, hipMemcpyHostToDevice, s));
   const int n_imgs = n_cells * kLevels;
   launch_orb_fast_score(d_pool, d_cell_imgs, n_imgs, max_w, max_h, d_thr, d_active, d_score, s);
   launch_orb_nms_count(d_pool, d_cell_imgs, n_imgs, max_h, d_active, d_score, kDetectEdge, d_row_cnt, d_img_total, s);
-  std::vector<int> totals(n_imgs), base(n_imgs);
-  ORB_HIP(hipMemcpyAsync(totals.data(), d_img_total, sizeof(int) * n_imgs, hipMemcpyDeviceToHost, s));
-  ORB_HIP(hipStreamSynchronize(s));
-  int n_total = 0;
-  for (int i = 0; i < n_imgs; ++i) { base[i] = n_total; n_total += totals[i]; }
-  if (n_total > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
-  ORB_HIP(hipMemcpyAsync(d_img_base, base.data(), sizeof(int) * n_imgs, hipMemcpyHostToDevice, s));
-  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, d_active, d_score, kDetectEdge, d_row_cnt, d_img_base, d_kps,
-                  n_total, s);
+  // One round trip per pass: the device scans the per-image counts itself, emits and measures the keypoints, and the
+  // host reads counts and keypoints back together -- `bound` of them, a guess from the previous passes; a pass with
+  // more keypoints than that pays a second round trip for the rest.
+  const int bound = std::min(pin_cap, std::max(2048, 2 * last_n_total));
+  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, d_active, d_score, kDetectEdge, d_row_cnt, d_img_total, d_img_base,
+                  d_kps, d_n, bound, s);
   ORB_HIP(hipGetLastError());
-  std::vector<RawKp> raw((size_t)n_total);
-  if (n_total)
-    ORB_HIP(hipMemcpyAsync(raw.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipMemcpyAsync(h_totals, d_img_total, sizeof(int) * n_imgs, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipMemcpyAsync(h_raw, d_kps, sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
   ORB_HIP(hipStreamSynchronize(s));
+  const int* totals = h_totals;
+  const int* base = h_base;
+  int n_total = 0;
+  for (int i = 0; i < n_imgs; ++i) { h_base[i] = n_total; n_total += totals[i]; }
+  if (n_total > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
+  last_n_total = n_total;
+  std::vector<RawKp> raw_big;
+  const RawKp* raw = h_raw;
+  if (n_total > bound) {
+    launch_orb_measure_rest(d_pool, d_cell_imgs, d_kps, d_n, bound, n_total - bound, s);
+    ORB_HIP(hipGetLastError());
+    raw_big.resize((size_t)n_total);
+    ORB_HIP(hipMemcpyAsync(raw_big.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
+    ORB_HIP(hipStreamSynchronize(s));
+    raw = raw_big.data();
+  }
 
   // nfeaturesPerLevel (orb.cpp computeKeyPoints)
   int per_level[kLevels];
@@ -333,7 +359,8 @@ int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::strin
 }
 
 // cv::ORB::create()->compute (features.cpp:117-119): border filter, regroup by level, rBRIEF
-int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err) {
+int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
+                          const std::function<int()>& enqueue_more) {
   {  // KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31)
     size_t m = 0;
     for (const KpOut& k : kps)
@@ -355,7 +382,10 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
   desc.assign((size_t)n * 32, 0);
   if (n == 0) return RGBDFE_OK;
   if (n > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
-  std::vector<DescKp> dk((size_t)n);
+  std::vector<DescKp> dk_big;
+  DescKp* dk = h_desckp;
+  uint8_t* desc_stage = h_desc;
+  if (n > pin_cap) { dk_big.resize((size_t)n); dk = dk_big.data(); desc_stage = desc.data(); }
   for (int j = 0; j < n; ++j) {
     const KpOut& k = kps[j];
     const float sc = 1.f / scale[k.octave];
@@ -367,11 +397,16 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
     dk[j].cy = cv_round_f(k.y * sc);
     dk[j].level = k.octave;
   }
-  ORB_HIP(hipMemcpyAsync(d_desckp, dk.data(), sizeof(DescKp) * (size_t)n, hipMemcpyHostToDevice, s));
+  ORB_HIP(hipMemcpyAsync(d_desckp, dk, sizeof(DescKp) * (size_t)n, hipMemcpyHostToDevice, s));
   launch_orb_brief(d_pool, d_blur, d_frame_imgs, d_desckp, n, d_desc, s);
   ORB_HIP(hipGetLastError());
-  ORB_HIP(hipMemcpyAsync(desc.data(), d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipMemcpyAsync(desc_stage, d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+  if (enqueue_more) {
+    const int rc = enqueue_more();
+    if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(s); err = "enqueue after compute failed"; return rc; }
+  }
   ORB_HIP(hipStreamSynchronize(s));
+  if (desc_stage != desc.data()) memcpy(desc.data(), desc_stage, (size_t)n * 32);
   return RGBDFE_OK;
 }
 

@@ -46,8 +46,10 @@ void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs,
 void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
                           const uint8_t* score_pool, int edge, int* row_cnt, int* img_total, hipStream_t s);
 void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
-                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_base, RawKp* out,
-                     int n_total, hipStream_t s);
+                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, int* img_base,
+                     RawKp* out, int* n_total, int measure_bound, hipStream_t s);
+void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* n_total, int first,
+                             int count, hipStream_t s);
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
                      hipStream_t s);
 void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,

@@ -252,11 +252,13 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+// first..first+grid keypoints; n_ptr[0] = how many there are (on the device: the host has not seen the count yet)
 __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restrict__ pool,
                                                           const ImgDesc* __restrict__ imgs,
-                                                          RawKp* __restrict__ kps, int n) {
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= n) return;
+                                                          RawKp* __restrict__ kps, const int* __restrict__ n_ptr,
+                                                          int first) {
+  const int k = first + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= *n_ptr) return;
   const int lane = threadIdx.x & 63;
   RawKp kp = kps[k];
   const ImgDesc im = imgs[kp.img];
@@ -384,13 +386,34 @@ void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, 
                      row_cnt);
   hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, active, row_cnt, img_total);
 }
+// exclusive scan of the per-image keypoint counts -> where each image's keypoints start; total -> n_total[0]
+__global__ __launch_bounds__(64) void orb_base_scan_kernel(const int* __restrict__ img_total, int n_imgs,
+                                                           int* __restrict__ img_base, int* __restrict__ n_total) {
+  if (threadIdx.x != 0) return;
+  int run = 0;
+  for (int i = 0; i < n_imgs; ++i) {
+    img_base[i] = run;
+    run += img_total[i];
+  }
+  *n_total = run;
+}
+
+// Keypoints of every active image in raster order, then Harris response + orientation for the first `measure_bound` of
+// them -- all without the host knowing the count (it reads img_total and n_total back together with the keypoints; a
+// frame with more keypoints than the bound gets the rest measured by launch_orb_measure_rest).
 void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
-                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_base, RawKp* out,
-                     int n_total, hipStream_t s) {
+                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, int* img_base,
+                     RawKp* out, int* n_total, int measure_bound, hipStream_t s) {
+  hipLaunchKernelGGL(orb_base_scan_kernel, dim3(1), dim3(64), 0, s, img_total, n_imgs, img_base, n_total);
   hipLaunchKernelGGL(orb_emit_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, active, score_pool, edge,
                      row_off, img_base, out);
-  if (n_total > 0)
-    hipLaunchKernelGGL(orb_measure_kernel, dim3((n_total + 3) / 4), dim3(256), 0, s, pool, imgs, out, n_total);
+  if (measure_bound > 0)
+    hipLaunchKernelGGL(orb_measure_kernel, dim3((measure_bound + 3) / 4), dim3(256), 0, s, pool, imgs, out, n_total, 0);
+}
+void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* n_total, int first,
+                             int count, hipStream_t s) {
+  if (count > 0)
+    hipLaunchKernelGGL(orb_measure_kernel, dim3((count + 3) / 4), dim3(256), 0, s, pool, imgs, out, n_total, first);
 }
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
                      hipStream_t s) {

@@ -23,7 +23,8 @@ template <bool TRUNC>
 __global__ __launch_bounds__(256) void project_to_3d_kernel(
     const float2* __restrict__ kp, int n_kp, const float* __restrict__ depth, int rows, int cols,
     float fxinv, float fyinv, float cx, float cy, double depth_scaling, int max_keypoints,
-    int32_t* __restrict__ kept_idx, float4* __restrict__ xyz1, int32_t* __restrict__ n_out) {
+    int32_t* __restrict__ kept_idx, float4* __restrict__ xyz1, int32_t* __restrict__ n_out,
+    const float* __restrict__ z_gathered) {
   __shared__ uint32_t wave_cnt[4];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -52,7 +53,9 @@ __global__ __launch_bounds__(256) void project_to_3d_kernel(
         int r = (int)roundf(py), c = (int)roundf(px);
         r = r >= rows ? rows - 1 : r;
         c = c >= cols ? cols - 1 : c;
-        Z = (float)((double)depth[(size_t)r * (size_t)cols + (size_t)c] * depth_scaling);
+        // z_gathered: the caller has looked depth(round(y), round(x)) up already (the image stays on the host)
+        const float zraw = z_gathered ? z_gathered[i] : depth[(size_t)r * (size_t)cols + (size_t)c];
+        Z = (float)((double)zraw * depth_scaling);
         keep = !__builtin_isnan(Z);  // node.cpp:947
       }
     }
@@ -122,15 +125,15 @@ __global__ __launch_bounds__(256) void sift_pack_kernel(const float2* __restrict
 void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                           int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
-                          hipStream_t stream, bool truncate) {
+                          hipStream_t stream, bool truncate, const float* z_gathered) {
   if (truncate)
     hipLaunchKernelGGL(project_to_3d_kernel<true>, dim3(1), dim3(256), 0, stream,
                        reinterpret_cast<const float2*>(kp_xy), n_kp, depth, rows, cols, fxinv, fyinv,
-                       cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out);
+                       cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out, z_gathered);
   else
     hipLaunchKernelGGL(project_to_3d_kernel<false>, dim3(1), dim3(256), 0, stream,
                        reinterpret_cast<const float2*>(kp_xy), n_kp, depth, rows, cols, fxinv, fyinv,
-                       cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out);
+                       cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out, z_gathered);
 }
 
 void launch_sift_pack(const float* desc_in, const int32_t* kept_idx, const int32_t* n_ptr, int max_rows,

@@ -958,7 +958,7 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
       }
       orb.cell_mask_nonzero[c] = nz;
     }
-  HIP_TRY(ctx, hipMemcpyAsync(orb.d_depth, depth, sizeof(float) * (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream));
+  // the depth image stays on the host: removeDepthless and projectTo3D look at one pixel per keypoint
   rc = orb.upload_and_build(gray, mask, ctx->stream, err);
   std::vector<KpOut> kps;
   if (rc == RGBDFE_OK) rc = orb.grid_detect(kps, ctx->stream, err);  // node.cpp:160
@@ -986,23 +986,49 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
       if (keep[i]) kps[m++] = kps[i];
     kps.resize(m);
   }
+  // cv::ORB::compute (node.cpp:202) drops border keypoints and regroups the rest by octave, so projectTo3D (node.cpp:210)
+  // is enqueued from inside compute(), once the final keypoint list exists: both ride on one synchronisation.
+  // xy (2n floats) + depth.at<float>(round(y), round(x)) (n floats, node.cpp:942): 12 bytes per keypoint cross PCIe
+  // instead of the 1.2 MB image.
   std::vector<uint8_t> desc;
-  rc = orb.compute(kps, desc, ctx->stream, err);  // node.cpp:202
+  std::vector<float> xyz_in_big, xyz_out_big;
+  float* xyz_in = nullptr;
+  float* xyz_out = nullptr;
+  auto enqueue_project = [&]() -> int {
+    const int n = (int)kps.size();
+    if (n == 0) return RGBDFE_OK;
+    xyz_in = orb.h_xyz_in;
+    xyz_out = orb.h_xyz_out;
+    if (n > orb.pin_cap) {
+      xyz_in_big.resize((size_t)n * 3); xyz_out_big.resize((size_t)n * 4);
+      xyz_in = xyz_in_big.data(); xyz_out = xyz_out_big.data();
+    }
+    for (int i = 0; i < n; ++i) {
+      xyz_in[2 * i] = kps[i].x;
+      xyz_in[2 * i + 1] = kps[i].y;
+      int r = (int)roundf(kps[i].y), c = (int)roundf(kps[i].x);
+      r = r >= rows ? rows - 1 : r;
+      c = c >= cols ? cols - 1 : c;
+      xyz_in[(size_t)2 * n + i] = depth[(size_t)r * cols + c];
+    }
+    if (hipMemcpyAsync(orb.d_kpxy, xyz_in, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return RGBDFE_ERR_HIP;
+    launch_project_to_3d(orb.d_kpxy, n, nullptr, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
+                         (float)cy, depth_scaling, max_kp, orb.d_kept, orb.d_xyz, orb.d_n, ctx->stream, false,
+                         orb.d_kpxy + (size_t)2 * n);
+    if (hipGetLastError() != hipSuccess) return RGBDFE_ERR_HIP;
+    if (hipMemcpyAsync(orb.h_n, orb.d_n, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(xyz_out, orb.d_xyz, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      return RGBDFE_ERR_HIP;
+    return RGBDFE_OK;
+  };
+  rc = orb.compute(kps, desc, ctx->stream, err, enqueue_project);
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
   const int n = (int)kps.size();
   *n_out = 0;
-  if (n > 0) {  // projectTo3D (node.cpp:210)
-    std::vector<float> xy((size_t)n * 2);
-    for (int i = 0; i < n; ++i) { xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y; }
-    HIP_TRY(ctx, hipMemcpyAsync(orb.d_kpxy, xy.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    launch_project_to_3d(orb.d_kpxy, n, orb.d_depth, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
-                         (float)cy, depth_scaling, max_kp, orb.d_kept, orb.d_xyz, orb.d_n, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
-    int32_t n3 = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n3, orb.d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(xyz1, orb.d_xyz, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (n3 != n) return fail(ctx, RGBDFE_ERR_HIP, "projectTo3D dropped keypoints that removeDepthless kept");
+  if (n > 0) {
+    if (*orb.h_n != n) return fail(ctx, RGBDFE_ERR_HIP, "projectTo3D dropped keypoints that removeDepthless kept");
+    memcpy(xyz1, xyz_out, sizeof(float) * 4 * (size_t)n);
   }
   kp_to_abi(kps, keypoints);
   if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());

@@ -109,7 +109,7 @@ void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipS
 void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                           int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
-                          hipStream_t stream, bool truncate = false);
+                          hipStream_t stream, bool truncate = false, const float* z_gathered = nullptr);
 // one direction of one edge for the environment measurement model (emm.hip)
 struct EmmJob {
   const float4* new_samples;  // the sampled points (every skip-th row / column) of the frame that is projected
