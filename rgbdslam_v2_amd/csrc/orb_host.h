@@ -48,7 +48,7 @@ struct OrbWorkspace {
   int* d_thr = nullptr; int* d_active = nullptr; int* d_row_cnt = nullptr; int* d_img_total = nullptr;
   int* d_img_base = nullptr;
   RawKp* d_kps = nullptr; DescKp* d_desckp = nullptr; uint8_t* d_desc = nullptr;
-  float* d_depth = nullptr; float* d_kpxy = nullptr; int32_t* d_kept = nullptr; float4* d_xyz = nullptr;
+  float* d_kpxy = nullptr; int32_t* d_kept = nullptr; float4* d_xyz = nullptr;
   int32_t* d_n = nullptr;
   // pinned host staging for the small per-frame transfers (thresholds, counts, keypoints, descriptors, 3-D points):
   // pageable copies of a few hundred bytes cost 10-20 us each and there are a dozen per frame

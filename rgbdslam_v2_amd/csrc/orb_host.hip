@@ -81,7 +81,7 @@ OrbWorkspace::~OrbWorkspace() { release(); }
 void OrbWorkspace::release() {
   auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   fr(d_pool); fr(d_score); fr(d_blur); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr);
-  fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_depth); fr(d_kpxy);
+  fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_kpxy);
   fr(d_kept); fr(d_xyz); fr(d_n);
   auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
   frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n);
@@ -200,7 +200,6 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMalloc((void**)&d_kps, sizeof(RawKp) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_desckp, sizeof(DescKp) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_desc, (size_t)32 * kp_cap));
-  ORB_HIP(hipMalloc((void**)&d_depth, sizeof(float) * (size_t)W * H));
   ORB_HIP(hipMalloc((void**)&d_kpxy, sizeof(float) * 3 * (size_t)kp_cap));  // x, y and the looked-up depth per keypoint
   ORB_HIP(hipMalloc((void**)&d_kept, sizeof(int32_t) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_xyz, sizeof(float4) * (size_t)kp_cap));
