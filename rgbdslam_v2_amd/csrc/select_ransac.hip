@@ -8,25 +8,29 @@
 //   Node::computeInliersAndError + errorFunction2                       (node.cpp:968-1020, misc.cpp:697-770)
 //   Node::matchNodePair's result assembly                               (node.cpp:1305-1429)
 //
-// One wave64 per pair, no inter-wave synchronisation (13.4 KB LDS, 166 VGPRs: 12 waves per CU):
-//   * selection: counting sort of the (hd, queryIdx) keys in LDS -- histogram by hd, wave prefix scan, then a
-//     stable placement pass that ranks equal-hd lanes of a 64-query chunk with __ballot bit-matching; the
-//     matched points go to LDS as 7-word records (from.xyz, to.xyz, weight);
-//   * hypothesis generation: LANE = RANSAC ITERATION.  64 iterations' 4-point samples, weighted fits and 3x3
-//     Jacobi SVDs are computed at once (the counter-based generator makes iteration k's sample a pure function
-//     of k, D1);
-//   * windows: the refinement loops (node.cpp:1140-1169) of 7 consecutive iterations ("slots") run side by side,
-//     round by round, and are then replayed in iteration order with the reference's bookkeeping (`it += 10/20`,
-//     the 80 % exit), so the result is the sequential loop's;
-//   * scoring (per slot): LANE = MATCH, two passes -- transform + the reference's shortcut test + ballot
-//     compaction of the candidates, then (LANE = CANDIDATE) the double-precision covariance and Cholesky solve
-//     with the divisions / square roots spelled out as their unscaled gfx950 expansions behind an exponent guard;
-//   * refits (per round): the PCL weighted-mean recurrences of all active slots share one 63-lane loop (9 state
-//     elements per slot), followed by one batched SVD (LANE = SLOT);
-//   * the float/double operation order is the oracle's (oracle/rgbd_oracle.c), which restates the reference and
-//     is pinned on the reference's own compiled code (oracle/_ref/libref_ransac.so): sequential weighted-mean
-//     recurrence, sequential error sum.  Compiled with -ffp-contract=off the results are bit-identical to the
-//     CPU restatement, so every discrete RANSAC decision is too.
+// Kernels (one wave64 per workgroup throughout: barriers are free, LDS is private to the wave):
+//   pair_prep_kernel    once per pair.  Selection: counting sort of the (hd, queryIdx) keys in LDS -- histogram by
+//                       hd, wave prefix scan, then a stable placement pass that ranks equal-hd lanes of a 64-query
+//                       chunk with __ballot bit-matching (SIFT: the head of the list sift_sort_kernel ordered); the
+//                       matched points become 7-word records (from.xyz, to.xyz, weight) in the pair's PairPrep block.
+//   select_ransac_kernel<MODE>  the RANSAC work (12.9 KB LDS, 168 VGPRs: 12 waves per CU), see MODE below:
+//     * hypothesis generation: LANE = RANSAC ITERATION.  64 iterations' 4-point samples, weighted fits and 3x3
+//       Jacobi SVDs are computed at once (the counter-based generator makes iteration k's sample a pure function
+//       of k, D1);
+//     * slots: the refinement loops (node.cpp:1140-1169) of 7 iterations run side by side, round by round;
+//     * scoring (per slot): LANE = MATCH, two passes -- a float prefilter of the reference's shortcut test with a
+//       proven error band (exact double round when a lane is too close to call) + ballot compaction of the
+//       candidates, then (LANE = CANDIDATE) the double-precision covariance and Cholesky solve with the divisions /
+//       square roots spelled out as their unscaled gfx950 expansions behind an exponent guard;
+//     * error sums and the loop's bookkeeping (per round): LANE = SLOT, the sequential sums of the round's scorings
+//       side by side from the wave's rows of the error pool;
+//     * refits (per round): the PCL weighted-mean recurrences of all active slots share one 63-lane loop (9 state
+//       elements per slot), followed by one batched SVD (LANE = SLOT).
+//   replay_walk_kernel  the reference's in-order bookkeeping (`it += 10/20`, the 80 % exit) over recorded iterations.
+//   The float/double operation order is the oracle's (oracle/rgbd_oracle.c), which restates the reference and is
+//   pinned on the reference's own compiled code (oracle/_ref/libref_ransac.so): sequential weighted-mean recurrence,
+//   sequential error sum.  Compiled with -ffp-contract=off the results are bit-identical to the CPU restatement, so
+//   every discrete RANSAC decision is too.
 #include <float.h>
 
 #include <type_traits>
