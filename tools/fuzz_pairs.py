@@ -9,7 +9,8 @@ fe2 = FrontEnd(device_id=0, max_nodes=12, max_keypoints=1536, max_pairs_per_batc
 if len(sys.argv) > 1:  # one_wave | latency (single recording phase) | phased (four phases, forced for small batches)
     {"one_wave": lambda: fe2.set_latency_mode(0, 0), "latency": lambda: fe2.set_latency_mode(64, 7),
      "phased": lambda: fe2.set_latency_mode(64, -5)}[sys.argv[1]]()
-for master in range(40):
+first, count = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 40)  # fuzz_pairs.py <mode> <first> <count>
+for master in range(first, first + count):
     rng = np.random.default_rng(9000 + master)
     F = 8
     sizes = [int(rng.choice([0, 1, 2, 3, 4, 5, 20, 21, 22, 64, 65, 300, 301, 777, 1000, 1536])) for _ in range(F)]
