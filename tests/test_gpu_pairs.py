@@ -271,6 +271,12 @@ def test_randomised_nodes_and_parameters_match_oracle():
             for rec, q, t in zip(out, pq, pt):
                 ref = po.match_node_pair(nodes[q][0], nodes[q][1], int(q), nodes[t][0], nodes[t][1], int(t), prm)
                 check_against_oracle(rec, ref)
+            # the other schedules of the RANSAC work give the same bytes: four recording phases (forced onto this
+            # small batch), one wave per pair
+            for mode in ((1 << 30, -5), (0, 0)):
+                fe2.set_latency_mode(*mode)
+                assert fe2.match_pair_list(pq, pt).tobytes() == out.tobytes(), (trial, mode, kw)
+            fe2.set_latency_mode((1 << 31) - 1, 0)
             for f in range(F):
                 fe2.release_node(f)
     finally:
