@@ -331,3 +331,33 @@ def test_latency_path_equals_one_wave_path(fe):
         fe.set_latency_mode(fe.latency_default, 0)
         for k in nodes:
             fe.release_node(k)
+
+
+def test_whole_bench_step_matches_oracle():
+    """BASELINE configs[1] at its full size: every one of the 4000 pairs of a bench.py step (200 frames x 1000
+    keypoints, 20 candidates per frame, the bench's seed) equals the oracle bit for bit -- in the pipelined submission
+    the bench times, and through the synchronous host-buffer call."""
+    import torch
+    from rgbdslam_v2_amd.frontend import FrontEnd, RESULT_DTYPE
+    F, N = 200, 1000
+    seq = synth.make_sequence(n_frames=F, n_kp=N)
+    pq, pt = synth.candidate_pairs(F, 20)
+    assert len(pq) == 4000
+    big = FrontEnd(device_id=0, max_nodes=F, max_keypoints=1024, max_pairs_per_batch=4096)
+    try:
+        for f in range(F):
+            big.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+        bufs = [torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        tickets = [big.submit_pair_list(pq, pt, b.data_ptr()) for b in bufs]  # two batches in flight, as in bench.py
+        outs = []
+        for tk, b in zip(tickets, bufs):
+            big.wait_ticket(tk, None)
+            outs.append(np.frombuffer(b.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[: len(pq)])
+        assert outs[0].tobytes() == outs[1].tobytes() == big.match_pair_list(pq, pt).tobytes()
+        prm = po.default_params(seed=big.params.seed, depth_cov=big.params.depth_cov)
+        refs = po.match_pairs_mt(list(seq["desc"]), list(seq["xyz1"]), np.arange(F), pq, pt, prm)
+        for rec, r in zip(outs[0], refs):
+            check_against_oracle(rec, po.result_to_dict(r))
+        assert (outs[0]["id1"] >= 0).mean() > 0.95
+    finally:
+        big.close()
