@@ -307,7 +307,7 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
       begin = plan->ends[p];
     }
   }
-  return ensure_ec_pool(ctx, lane, regions, stream);
+  return ensure_ec_pool(ctx, lane, regions + 8, stream);  // recording grids are rounded up to a multiple of 8
 }
 
 // Build the PairWork list (host) and enqueue H2D + both kernels on the next lane.

@@ -1094,14 +1094,19 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     const PairWork* __restrict__ work, rgbdfe_match_result* __restrict__ results, uint32_t n_pairs,
     const RansacConst rc, const RecordPlan plan) {
   __shared__ RansacLds lds;
-  const uint32_t pair = MODE == kRecord ? blockIdx.x / plan.n_chunks : blockIdx.x;
+  // Recording waves: the workgroups of a launch go round-robin over the 8 XCDs, each with its own L2.  The grid is
+  // walked in 8 contiguous segments, segment = blockIdx % 8, so that the waves sharing a pair (its PairPrep block, its
+  // records) run on one XCD.
+  const uint32_t seg_len = (gridDim.x + 7u) / 8u;
+  const uint32_t unit = MODE == kRecord ? (blockIdx.x % 8u) * seg_len + blockIdx.x / 8u : blockIdx.x;
+  const uint32_t pair = MODE == kRecord ? unit / plan.n_chunks : unit;
   if (pair >= n_pairs) return;
   // record / replay bookkeeping: walk[pair].state >= 0 is an upper bound of the iterations the pair can still need,
   // < 0 means its loop has ended
   const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
   if (MODE == kRecord && pair_state < 0) return;
   const int recorded_end = MODE == kRecord ? min(plan.phase_end, pair_state) : 0;
-  const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(blockIdx.x % plan.n_chunks) * plan.chunk_iters : 0;
+  const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(unit % plan.n_chunks) * plan.chunk_iters : 0;
   const int k_end = MODE == kRecord ? min(k_begin + plan.chunk_iters, recorded_end) : 0;
   if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
   IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : plan.recs + (size_t)pair * (size_t)rc.ransac_iterations;
@@ -1635,8 +1640,8 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     plan.phase_begin = begin;
     plan.phase_end = end;
     if (end > begin)
-      hipLaunchKernelGGL(select_ransac_kernel<kRecord>, dim3(n_pairs * plan.n_chunks), dim3(kWave), 0, stream, work,
-                         results, n_pairs, rc, plan);
+      hipLaunchKernelGGL(select_ransac_kernel<kRecord>, dim3((n_pairs * plan.n_chunks + 7u) / 8u * 8u), dim3(kWave), 0,
+                         stream, work, results, n_pairs, rc, plan);  // a multiple of 8: see the XCD segments
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, recs, walk, prep, n_pairs, rc, begin,
                        end);
     begin = end;
