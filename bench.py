@@ -291,12 +291,35 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus(hardware_threads):
+    """Threads worth running: the hardware threads this process may use, capped by the container's CPU quota
+    (cgroup v2 cpu.max / v1 cfs quota) -- oversubscribing a 16-CPU quota with 256 threads more than halves the rate."""
+    n = hardware_threads
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(seq, pq, pt, fe, budget_s):
     """The oracle (CPU restatement of the reference pair path, kind='port') timed pair-parallel
     on this host's cores over a bounded sample of the same pair list."""
     from oracle import pyoracle as po
     prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov)
-    cores = po.num_cores()
+    cores = usable_cpus(po.num_cores())
     descs, xyzs = list(seq["desc"]), list(seq["xyz1"])
     ids = np.arange(len(descs))
     probe = min(len(pq), max(2 * cores, 16))
@@ -309,8 +332,9 @@ def cpu_baseline(seq, pq, pt, fe, budget_s):
     po.match_pairs_mt(descs, xyzs, ids, pq[sel], pt[sel], prm, cores)
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 2), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d pairs of one step, oracle/liboracle.so, OpenMP pair-parallel, %d threads"
-                      % (n, len(pq), cores)}
+            "sample": "%d of the %d pairs of one step, oracle/liboracle.so, OpenMP pair-parallel, %d threads "
+                      "(= the CPUs this container may use: %d hardware threads, cgroup quota applied)"
+                      % (n, len(pq), cores, po.num_cores())}
 
 
 def cpu_reference_code(seq, pq, pt, fe, budget_s):
