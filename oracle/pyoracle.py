@@ -436,10 +436,28 @@ def result_to_dict(r):
         inl_idx=np.array(r.inl_idx[:n_inl], np.int32))
 
 
+def usable_cpus():
+    """Hardware threads this process may use, capped by the container's cgroup CPU quota (oversubscribing the quota
+    makes the OpenMP run slower, not faster)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def match_pairs_mt(descs, xyzs, node_ids, pair_q, pair_t, params=None, n_threads=0):
     """Pair-parallel oracle run (the CPU baseline).  descs/xyzs: lists of per-node arrays;
-    pair_q/pair_t index into those lists."""
+    pair_q/pair_t index into those lists.  n_threads = 0: the CPUs this process may use."""
     params = params or default_params()
+    n_threads = n_threads or usable_cpus()
     n_nodes = len(descs)
     descs = [np.ascontiguousarray(d, np.uint8) for d in descs]
     xyzs = [np.ascontiguousarray(x, np.float32) for x in xyzs]
