@@ -389,13 +389,21 @@ void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, 
 // exclusive scan of the per-image keypoint counts -> where each image's keypoints start; total -> n_total[0]
 __global__ __launch_bounds__(64) void orb_base_scan_kernel(const int* __restrict__ img_total, int n_imgs,
                                                            int* __restrict__ img_base, int* __restrict__ n_total) {
-  if (threadIdx.x != 0) return;
-  int run = 0;
-  for (int i = 0; i < n_imgs; ++i) {
-    img_base[i] = run;
-    run += img_total[i];
+  const int lane = threadIdx.x;
+  int run = 0;  // keypoints of the images before this chunk of 64
+  for (int i0 = 0; i0 < n_imgs; i0 += 64) {
+    const int i = i0 + lane;
+    const int v = i < n_imgs ? img_total[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    if (i < n_imgs) img_base[i] = run + incl - v;
+    run += __shfl(incl, 63);
   }
-  *n_total = run;
+  if (lane == 0) *n_total = run;
 }
 
 // Keypoints of every active image in raster order, then Harris response + orientation for the first `measure_bound` of
