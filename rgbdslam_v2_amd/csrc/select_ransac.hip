@@ -1135,6 +1135,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
     __syncthreads();
   };
+  // no RANSAC for this pair (node.cpp:1087, :1130): a recording wave has nothing to record
+  if (MODE == kRecord && !(n_all > rc.min_matches && n_all >= 4)) return;
   if (MODE != kReplay) load_points();  // a result wave needs them for the identity fallback only
 
   PH_MARK(1)
