@@ -271,7 +271,7 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   // every recording wave owns a region of the error pool: keep the largest grid (a phase is at most all iterations)
   // within kMaxEcRegions by recording more iterations per wave
   while ((size_t)n * (size_t)((ctx->rc.ransac_iterations + chunk - 1) / chunk) > kMaxEcRegions) ++chunk;
-  bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * chunk && need_recs <= ((size_t)1 << 22);
+  bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * chunk && need_recs <= ((size_t)1 << 24);  // 1.7 GB of records per lane at most
   *chunk_out = chunk;
   if (latency && need_recs > lane.recs_capacity) {
     HIP_TRY(ctx, hipStreamSynchronize(stream));
