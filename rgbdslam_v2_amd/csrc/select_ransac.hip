@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         }
         __syncthreads();
         // ... then their sequential error sums side by side and the bookkeeping (:1154-1166), lane = slot
-        const double sum_mine = sum_rows(ec_region, lds, lane, cn_mine, n_sum_max);
+        const double sum_mine = n_sum_max > 0 ? sum_rows(ec_region, lds, lane, cn_mine, n_sum_max) : 0.0;  // wave-uniform
         const double err_mine = cn_mine > 0 ? sqrt(sum_mine / (double)cn_mine) : 1e9;  // :1016-1017
         PH_MARK(11)
         bool still = false;
