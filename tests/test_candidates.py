@@ -81,3 +81,35 @@ def test_counter_based_generator_is_reproducible_and_valid():
         small.add_node(i, keyframe=True)
     assert small.potential_edge_targets(2, 2, 2).tolist() == [2, 1, 0]
     assert small.potential_edge_targets(2, 2, 2, include_predecessor=True).tolist() == [2, 1, 0, 3]
+
+
+def test_argument_and_capacity_errors():
+    import ctypes as C
+    from rgbdslam_v2_amd import _lib
+    L = _lib.load()
+    g = PoseGraph()
+    for i in range(30):
+        g.add_node(i, keyframe=True)
+        if i:
+            g.add_edge(i, i - 1)
+    with pytest.raises(_lib.RgbdfeError):
+        g.add_edge(3, 3)              # an edge needs two different nodes
+    with pytest.raises(_lib.RgbdfeError):
+        g.add_edge(3, 99)             # ... that exist
+    with pytest.raises(_lib.RgbdfeError):
+        g.set_matchable(99, False)
+    with pytest.raises(_lib.RgbdfeError):
+        g.add_node(-1)
+    # a too small output buffer: RGBDFE_ERR_CAPACITY and the needed size
+    out = np.zeros(2, np.int32)
+    n = C.c_int32(0)
+    rc = L.rgbdfe_potential_edge_targets(g._g, 3, 2, 2, 3, -1, 0, L.rgbdfe_rand_fn(0), None, 5, out.ctypes.data, 2, C.byref(n))
+    assert rc != 0 and n.value == 7
+    assert L.rgbdfe_status_string(rc).decode().lower().find("capacity") >= 0
+    # unmatchable nodes are never drawn (geodesic :264, sampled :302) but stay sequential targets (:223-226)
+    for i in range(10, 25):
+        g.set_matchable(i, False)
+    ids = g.potential_edge_targets(2, 3, 4, geodesic_depth=30, seed=3).tolist()
+    assert ids[-2:] == [28, 27]
+    assert all(not (10 <= v < 25) for v in ids[:-2])
+    g.close()
