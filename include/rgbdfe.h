@@ -8,9 +8,10 @@
  * rgbdfe_status (0 = ok, <0 = error) unless noted.  INTEGRATION.md shows the
  * reference-side binding.
  *
- * Threading: a context owns one HIP stream and is internally locked; calls on
- * one context serialise (this replaces QtConcurrent::blockingMapped's barrier,
- * graph_manager.cpp:548, one call = one batch of pairs).
+ * Threading: a context owns its HIP streams and is internally locked; calls on
+ * one context from any number of threads serialise (this replaces
+ * QtConcurrent::blockingMapped's barrier, graph_manager.cpp:548, one call = one
+ * batch of pairs).  rgbdfe_last_error returns a per-thread copy of the message.
  */
 #ifndef RGBDFE_H
 #define RGBDFE_H
@@ -32,7 +33,8 @@ typedef enum {
   RGBDFE_ERR_HIP = -3,
   RGBDFE_ERR_UNKNOWN_NODE = -4,
   RGBDFE_ERR_CAPACITY = -5,
-  RGBDFE_ERR_OUT_OF_MEMORY = -6
+  RGBDFE_ERR_OUT_OF_MEMORY = -6,
+  RGBDFE_ERR_INTERNAL = -7      /* a C++ exception was caught at the ABI (none ever crosses it) */
 } rgbdfe_status;
 
 /* Snapshot of the ParameterServer values the pair path reads at call time
@@ -83,6 +85,30 @@ typedef struct rgbdfe_ctx rgbdfe_ctx;
 void rgbdfe_default_config(rgbdfe_config* cfg);
 int  rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out);
 void rgbdfe_destroy(rgbdfe_ctx* ctx);
+/* ---- several GPUs behind ONE handle --------------------------------------------------
+ * The reference's caller is one process (GraphManager::nodeComparisons, graph_manager.cpp:541-548), so the
+ * drop-in form of "shard the candidate pairs over the 8 GPUs of a node" is a context that owns one device
+ * context + one host thread per listed device (cfg->device_id is ignored).  With such a handle
+ *   - rgbdfe_upload_node / _sift_node / _node_cloud / release / set_* act on every device (node features are
+ *     replicated: 48 B per keypoint, trivial in 288 GB);
+ *   - rgbdfe_match_node_pairs / _pair_list / _sift_pair_list shard the list pair k -> device k mod G; each device
+ *     writes its results to the caller's out[k] directly and the call returns when all are done (the same
+ *     barrier semantics as the single-device call; results do not depend on G);
+ *   - rgbdfe_observation_likelihood shards its jobs the same way; frame-level calls (detect / describe /
+ *     project_to_3d ...) run on the first device;
+ *   - entry points that take device pointers are refused: use rgbdfe_device_context(ctx, i) for those.
+ * rgbdfe_match_pair_list_allgather is the device-resident form: d_out[i] is a buffer on device i holding
+ * G * per records, per = ceil(n_pairs / G) (returned in *records_per_device); afterwards EVERY buffer holds ALL
+ * results -- pair k at record (k mod G) * per + k / G, unused tail records filled with 0xFF bytes (ids -1) --
+ * exchanged with ONE ncclAllGather of the fixed-size PODs (RCCL over xGMI, loaded at run time), or with peer
+ * copies when RCCL cannot be used (a device listed twice, RGBDFE_GATHER=p2p); rgbdfe_gather_transport tells which.
+ * A device may be listed more than once (two shards on one GPU: how a 1-GPU box tests the sharding). */
+int  rgbdfe_create_multi(const rgbdfe_config* cfg, const int32_t* device_ids, int32_t n_devices, rgbdfe_ctx** out);
+int  rgbdfe_device_count(rgbdfe_ctx* ctx);                       /* 1 for rgbdfe_create handles */
+rgbdfe_ctx* rgbdfe_device_context(rgbdfe_ctx* ctx, int32_t i);   /* the i-th device's own context (owned by ctx) */
+int  rgbdfe_match_pair_list_allgather(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                      int32_t n_pairs, void* const* d_out, int32_t* records_per_device);
+const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx);            /* "rccl", "p2p" or "none" (last allgather) */
 int  rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p);
 const char* rgbdfe_status_string(int status);
 const char* rgbdfe_last_error(rgbdfe_ctx* ctx);
@@ -94,7 +120,11 @@ const char* rgbdfe_last_error(rgbdfe_ctx* ctx);
  * xyz1: n x 4 float, (x,y,z,1) as Node::projectTo3D writes them (node.cpp:955). */
 int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc,
                        const float* xyz1, int32_t n);
-/* same, sources already in device memory (device-to-device copy on `stream`, a hipStream_t) */
+/* same, sources already in device memory (device-to-device copy on `stream`, a hipStream_t).
+ * Ordering: stream == NULL copies on the context's stream and returns when the node is resident.  With a caller
+ * stream the copies are enqueued there and the call returns at once; every batch submitted to this context
+ * afterwards (any entry point) waits for them on the device, and the sources must stay valid until `stream` has
+ * passed the copies.  Overwriting a resident node first waits for the batches in flight. */
 int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_desc,
                               const void* d_xyz1, int32_t n, void* stream);
 int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id);
@@ -200,6 +230,14 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
  * A negative chunk_iterations selects the four-phase plan for every batch size with |chunk_iterations| iterations
  * per recording wave (a testing aid: small batches are faster with the single phase). */
 int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations);
+
+/* Which kernel computes the Hamming nearest neighbours of an ORB batch (identical keys, bit for bit):
+ *   1 (default)  the descriptor bits as fp4 (+-1) operands of v_mfma_f32_32x32x64_f8f6f4: hd = (256 + dot) / 2, exact
+ *                in the f32 accumulator, the row index folded into the accumulator's initial value (hamming_mfma.hip);
+ *   2            same, the row index added by the VALU instead of the matrix core's C operand;
+ *   0            xor + popcount on the VALU (hamming_nn.hip) -- also what nodes with max_keypoints > 32768 get.
+ * Environment variable RGBDFE_HAMMING_MODE sets the initial value. */
+int rgbdfe_set_hamming_mode(rgbdfe_ctx* ctx, int32_t mode);
 
 /* ---- frame-level data either side of the pair path ----------------
  * rgbdfe_depth_to_mono8: depthToCV8UC1 (misc.cpp:414-430), the detection mask the listener derives from

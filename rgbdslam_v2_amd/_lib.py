@@ -186,6 +186,18 @@ def load():
                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.rgbdfe_reset_kernel_time.restype = C.c_int
     L.rgbdfe_reset_kernel_time.argtypes = [ctx]
+    L.rgbdfe_create_multi.restype = C.c_int
+    L.rgbdfe_create_multi.argtypes = [C.POINTER(RgbdfeConfig), vp, i32, C.POINTER(vp)]
+    L.rgbdfe_device_count.restype = C.c_int
+    L.rgbdfe_device_count.argtypes = [ctx]
+    L.rgbdfe_device_context.restype = vp
+    L.rgbdfe_device_context.argtypes = [ctx, i32]
+    L.rgbdfe_match_pair_list_allgather.restype = C.c_int
+    L.rgbdfe_match_pair_list_allgather.argtypes = [ctx, vp, vp, i32, vp, C.POINTER(i32)]
+    L.rgbdfe_gather_transport.restype = C.c_char_p
+    L.rgbdfe_gather_transport.argtypes = [ctx]
+    L.rgbdfe_set_hamming_mode.restype = C.c_int
+    L.rgbdfe_set_hamming_mode.argtypes = [ctx, i32]
     L.rgbdfe_sizeof_match_result.restype = C.c_int
     L.rgbdfe_abi_version.restype = C.c_int
     if L.rgbdfe_sizeof_match_result() != C.sizeof(RgbdfeMatchResult) or \
@@ -226,4 +238,6 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_reset_kernel_time", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
     "rgbdfe_pose_graph_create", "rgbdfe_pose_graph_destroy", "rgbdfe_pose_graph_add_node",
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
+    "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",
+    "rgbdfe_gather_transport", "rgbdfe_set_hamming_mode",
 ]

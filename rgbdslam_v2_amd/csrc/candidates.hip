@@ -14,6 +14,7 @@
 #include <deque>
 #include <limits>
 #include <map>
+#include <new>
 #include <queue>
 #include <set>
 #include <utility>
@@ -86,36 +87,48 @@ rgbdfe_pose_graph* rgbdfe_pose_graph_create(void) { return new (std::nothrow) rg
 void rgbdfe_pose_graph_destroy(rgbdfe_pose_graph* g) { delete g; }
 
 int rgbdfe_pose_graph_add_node(rgbdfe_pose_graph* g, int32_t node_id, int32_t vertex_id, int32_t matchable,
-                               int32_t keyframe) {
+                               int32_t keyframe) try {
   if (!g || node_id < 0 || vertex_id < 0) return RGBDFE_ERR_INVALID_ARG;
   g->nodes[node_id] = rgbdfe_pose_graph::NodeInfo{vertex_id, matchable != 0};
   g->camera_vertices.insert(vertex_id);
   g->adjacency[vertex_id];
   if (keyframe) g->keyframes.push_back(node_id);
   return RGBDFE_OK;
+} catch (const std::bad_alloc&) {
+  return RGBDFE_ERR_OUT_OF_MEMORY;
+} catch (...) {
+  return RGBDFE_ERR_INTERNAL;  // no exception crosses the C ABI
 }
 
-int rgbdfe_pose_graph_add_edge(rgbdfe_pose_graph* g, int32_t node_id1, int32_t node_id2) {
+int rgbdfe_pose_graph_add_edge(rgbdfe_pose_graph* g, int32_t node_id1, int32_t node_id2) try {
   if (!g) return RGBDFE_ERR_INVALID_ARG;
   const auto a = g->nodes.find(node_id1), b = g->nodes.find(node_id2);
   if (a == g->nodes.end() || b == g->nodes.end() || node_id1 == node_id2) return RGBDFE_ERR_INVALID_ARG;
   g->adjacency[a->second.vertex_id].insert(b->second.vertex_id);
   g->adjacency[b->second.vertex_id].insert(a->second.vertex_id);
   return RGBDFE_OK;
+} catch (const std::bad_alloc&) {
+  return RGBDFE_ERR_OUT_OF_MEMORY;
+} catch (...) {
+  return RGBDFE_ERR_INTERNAL;  // no exception crosses the C ABI
 }
 
-int rgbdfe_pose_graph_set_matchable(rgbdfe_pose_graph* g, int32_t node_id, int32_t matchable) {
+int rgbdfe_pose_graph_set_matchable(rgbdfe_pose_graph* g, int32_t node_id, int32_t matchable) try {
   if (!g) return RGBDFE_ERR_INVALID_ARG;
   const auto a = g->nodes.find(node_id);
   if (a == g->nodes.end()) return RGBDFE_ERR_INVALID_ARG;
   a->second.matchable = matchable != 0;
   return RGBDFE_OK;
+} catch (const std::bad_alloc&) {
+  return RGBDFE_ERR_OUT_OF_MEMORY;
+} catch (...) {
+  return RGBDFE_ERR_INTERNAL;  // no exception crosses the C ABI
 }
 
 int rgbdfe_potential_edge_targets(const rgbdfe_pose_graph* g, int32_t sequential_targets, int32_t geodesic_targets,
                                   int32_t sampled_targets, int32_t geodesic_depth, int32_t predecessor_id,
                                   int32_t include_predecessor, rgbdfe_rand_fn rand_fn, void* rand_state, uint32_t seed,
-                                  int32_t* ids_out, int32_t capacity, int32_t* n_out) {
+                                  int32_t* ids_out, int32_t capacity, int32_t* n_out) try {
   if (!g || !ids_out || !n_out || capacity < 0) return RGBDFE_ERR_INVALID_ARG;
   CounterRand own{seed};
   auto draw = [&]() { return rand_fn ? rand_fn(rand_state) : own.next(); };
@@ -195,6 +208,10 @@ int rgbdfe_potential_edge_targets(const rgbdfe_pose_graph* g, int32_t sequential
   if ((int32_t)ids.size() > capacity) return RGBDFE_ERR_CAPACITY;
   for (size_t i = 0; i < ids.size(); ++i) ids_out[i] = ids[i];
   return RGBDFE_OK;
+} catch (const std::bad_alloc&) {
+  return RGBDFE_ERR_OUT_OF_MEMORY;
+} catch (...) {
+  return RGBDFE_ERR_INTERNAL;  // no exception crosses the C ABI
 }
 
 }  // extern "C"

@@ -1,0 +1,285 @@
+// hamming_mfma.hip -- the 256-bit Hamming distance matrix as an exact fp4 contraction on the gfx950 matrix cores.
+//
+// Same contract as hamming_nn.hip (the popcount kernel): for every query row of the newer node the nearest train row
+// of the older node under bruteForceSearchORB's rules (features.cpp:163-182: rows [0, nt-1) only, strict <, first
+// minimum wins), delivered as (hd << 16 | row) keys.  The arithmetic is different:
+//
+//   * every descriptor bit becomes one fp4 (E2M1) operand nibble: +1.0 (0x2) for a 0 bit, -1.0 (0xA) for a 1 bit
+//     (hamming_expand_kernel, once per node upload; 128 bytes per descriptor, stored in MFMA fragment order);
+//     the query side flips the sign bit of every nibble on load, so one product is -1 for equal bits and +1 for
+//     different bits and the 256-term dot product is  2*hd - 256  -- small integers, exact in the f32 accumulator;
+//   * v_mfma_f32_32x32x64_f8f6f4 (cbsz = blgp = 4: both operands fp4) does 32 train rows x 32 queries x 64 bits per
+//     instruction, four of them per 32x32 tile: 2*32*32*256 FLOP at the fp4 rate (4x the bf16 rate) instead of
+//     16 VALU instructions per 64 compares;
+//   * the accumulator is initialised with  row_in_tile / 2^14, so an accumulator element is the complete sort key
+//     (2*hd - 256) + row/2^14  (24 significant bits at most: exact in f32) and "first minimum wins" is v_min_f32;
+//     train rows run along the accumulator registers of a lane, queries along the lanes, so the running minimum is
+//     ONE register per 32-query tile and the epilogue is a min3 tree: 10 VALU instructions per 16 matrix elements;
+//   * a 256-thread block holds 256 queries (two 32-query operand tiles per wave) and streams the train tiles of the
+//     pair through LDS (16 KB stages, double buffered, one barrier per stage); the four waves share every tile.
+//
+// MODE 1 adds the row term inside the MFMA (C operand); MODE 2 starts from C = 0 and adds it with v_add_f32 (kept as
+// the conservative variant: it does not rely on the matrix core adding a 2^-14-granular C to the integer sum exactly).
+// Keys are identical to the popcount kernel's, bit for bit (tests/test_gpu_hamming.py runs every mode against the
+// golden vectors of the reference function).  Usable while max_keypoints <= 32768 (15 index bits next to 9 distance
+// bits in a 24-bit significand); the host falls back to the popcount kernel above that.
+#include "rgbdfe_internal.h"
+
+namespace rgbdfe {
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kQT = 2;                      // 32-query operand tiles per wave
+constexpr int kQueriesPerBlock = 4 * kQT * 32;  // 256
+constexpr int kStage = 4;                   // train tiles (of 32 rows, 4 KB each) per LDS stage
+constexpr float kNone = 3.0e38f;
+constexpr float kRowUnit = 1.0f / 16384.0f;  // 2^-14
+
+// 8 descriptor bits -> 8 fp4 nibbles (0x2 = +1.0 for a 0 bit, 0xA = -1.0 for a 1 bit)
+__device__ __forceinline__ uint32_t spread8(uint32_t x) {
+  uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+  t = (t | (t << 6)) & 0x03030303u;
+  t = (t | (t << 3)) & 0x11111111u;
+  return 0x22222222u | (t << 3);
+}
+
+// One thread per (row of a 32-row tile, descriptor dword): writes the 16 bytes lane (half*32 + row) feeds to k-step s,
+// with dword = 2*s + half.  Rows >= n of a touched tile are written as zeros (0.0 operands).
+__global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __restrict__ rows, uint4* __restrict__ tiles,
+                                                             uint32_t n) {
+  const uint32_t gid = blockIdx.x * 256u + threadIdx.x;  // tile*256 + s*64 + half*32 + row
+  const uint32_t tile = gid >> 8, s = (gid >> 6) & 3u, half = (gid >> 5) & 1u, r = gid & 31u;
+  const uint32_t row = tile * 32u + r;
+  if (tile * 32u >= n) return;
+  uint4 o = make_uint4(0u, 0u, 0u, 0u);
+  if (row < n) {
+    const uint32_t w = rows[(size_t)row * 8u + 2u * s + half];
+    o.x = spread8(w & 0xFFu);
+    o.y = spread8((w >> 8) & 0xFFu);
+    o.z = spread8((w >> 16) & 0xFFu);
+    o.w = spread8(w >> 24);
+  }
+  tiles[gid] = o;
+}
+
+__device__ __forceinline__ v8i as_operand(uint4 v) {
+  v8i o;
+  o[0] = (int)v.x; o[1] = (int)v.y; o[2] = (int)v.z; o[3] = (int)v.w;
+  o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0;
+  return o;
+}
+
+__device__ __forceinline__ float min16(const v16f& a) {
+  const float m0 = fminf(fminf(a[0], a[1]), a[2]);
+  const float m1 = fminf(fminf(a[3], a[4]), a[5]);
+  const float m2 = fminf(fminf(a[6], a[7]), a[8]);
+  const float m3 = fminf(fminf(a[9], a[10]), a[11]);
+  const float m4 = fminf(fminf(a[12], a[13]), a[14]);
+  const float m5 = fminf(fminf(m0, m1), a[15]);
+  const float m6 = fminf(fminf(m2, m3), m4);
+  return fminf(m5, m6);
+}
+
+template <int MODE, bool SPLIT>
+__global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __restrict__ slab,
+                                                                const PairWork* __restrict__ work,
+                                                                uint32_t* __restrict__ keys, uint32_t max_kp,
+                                                                uint32_t tiles_per_slot, uint32_t n_pairs,
+                                                                uint32_t qblocks, uint32_t tsplit) {
+  __shared__ uint4 lds[2][kStage * 256];
+  // whole pairs per XCD (block b runs on XCD b % 8), as in hamming_nn_kernel
+  const uint32_t L = blockIdx.x;
+  const uint32_t xcd = L & 7u;
+  const uint32_t j = L >> 3;
+  const uint32_t subs = qblocks * tsplit;
+  const uint32_t pair = (j / subs) * 8u + xcd;
+  if (pair >= n_pairs) return;
+  const uint32_t sub = j % subs;
+  const uint32_t qblock = sub / tsplit;
+  const uint32_t split = sub % tsplit;
+
+  const PairWork w = work[pair];
+  const uint32_t nq = w.nq;
+  if (qblock * kQueriesPerBlock >= nq) return;
+  const uint32_t nt_search = w.nt > 0 ? w.nt - 1u : 0u;  // features.cpp:174 (and D4)
+  const uint32_t n_ttiles = (nt_search + 31u) >> 5;
+  uint32_t tile0 = 0, tile1 = n_ttiles;
+  if (SPLIT) {
+    const uint32_t chunk = (n_ttiles + tsplit - 1u) / tsplit;
+    tile0 = min(split * chunk, n_ttiles);
+    tile1 = min(tile0 + chunk, n_ttiles);
+  }
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t half = lane >> 5;
+
+  // query operands: kQT tiles x 4 k-steps, sign-flipped
+  v8i bq[kQT][4];
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    uint32_t qt = qblock * (kQueriesPerBlock / 32) + wave * kQT + t;
+    qt = min(qt, tiles_per_slot - 1u);  // tiles beyond the node's rows: results are discarded
+    const uint4* __restrict__ qs = slab + ((size_t)w.q_slot * tiles_per_slot + qt) * 256u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 v = qs[s * 64 + lane];
+      v.x ^= 0x88888888u; v.y ^= 0x88888888u; v.z ^= 0x88888888u; v.w ^= 0x88888888u;
+      bq[t][s] = as_operand(v);
+    }
+  }
+
+  // accumulator register r of this lane belongs to train row (r & 3) + 8 * (r >> 2) + 4 * half of the tile
+  v16f crow;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) crow[r] = (float)((r & 3) + 8 * (r >> 2) + 4 * (int)half) * kRowUnit;
+  v16f czero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) czero[r] = 0.f;
+
+  float best[kQT];
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) best[t] = kNone;
+
+  const uint4* __restrict__ ts = slab + (size_t)w.t_slot * tiles_per_slot * 256u;
+  const uint32_t n_tiles = tile1 - tile0;
+  const uint32_t n_stages = (n_tiles + kStage - 1u) / kStage;
+  const uint32_t last_tile = tiles_per_slot - 1u;
+
+  // stage 0 -> LDS
+  {
+#pragma unroll
+    for (int i = 0; i < kStage; ++i) {
+      const uint32_t tl = min(tile0 + (uint32_t)i, last_tile);
+      lds[0][i * 256 + threadIdx.x] = ts[(size_t)tl * 256u + threadIdx.x];
+    }
+  }
+  __syncthreads();
+
+  for (uint32_t st = 0; st < n_stages; ++st) {
+    // the next stage's tiles travel through registers while this stage is computed (behind the last stage the
+    // clamped addresses are simply read again: no branch around the loads, nothing is done with them)
+    uint4 nxt[kStage];
+#pragma unroll
+    for (int i = 0; i < kStage; ++i) {
+      const uint32_t tl = min(tile0 + (st + 1u) * kStage + (uint32_t)i, last_tile);
+      nxt[i] = ts[(size_t)tl * 256u + threadIdx.x];
+    }
+    const uint4* __restrict__ buf = lds[st & 1u];
+#pragma unroll
+    for (int i = 0; i < kStage; ++i) {
+      const uint32_t tile = tile0 + st * kStage + (uint32_t)i;
+      if (tile < tile1) {  // block-uniform
+        v8i a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = as_operand(buf[i * 256 + s * 64 + lane]);
+        const uint32_t row0 = tile * 32u;
+        const float base = (float)row0 * kRowUnit;
+        const bool ragged = row0 + 32u > nt_search;  // rows >= nt_search of the pair's last tile do not take part
+        // both query tiles' MFMA chains are issued before the first epilogue: the matrix pipe works on tile 1 while
+        // the VALU reduces tile 0
+        v16f acc[kQT];
+#pragma unroll
+        for (int t = 0; t < kQT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], bq[t][0], MODE == 1 ? crow : czero, 4, 4, 0, 0,
+                                                                   0, 0);
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], bq[t][1], acc[t], 4, 4, 0, 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], bq[t][2], acc[t], 4, 4, 0, 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], bq[t][3], acc[t], 4, 4, 0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < kQT; ++t) {
+          if (MODE != 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += crow[r];
+          }
+          if (ragged) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
+              acc[t][r] = row < nt_search ? acc[t][r] : kNone;
+            }
+          }
+          const float m = min16(acc[t]);
+          best[t] = fminf(best[t], m + base);  // kNone + base stays huge
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kStage; ++i) lds[(st + 1u) & 1u][i * 256 + threadIdx.x] = nxt[i];
+    __syncthreads();
+  }
+
+  uint32_t* kout = keys + ((size_t)pair * tsplit + split) * max_kp;
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    float b = best[t];
+    b = fminf(b, __shfl_xor(b, 32));  // the two row halves of the tiles
+    const uint32_t qi = qblock * kQueriesPerBlock + (wave * kQT + (uint32_t)t) * 32u + (lane & 31u);
+    if (half == 0 && qi < nq) {
+      uint32_t key = kNoMatchKey;
+      if (b < 1.0e30f) {
+        // (2*hd - 256) + row / 2^14  ->  hd * 2^15 + row   (exact: < 2^24)
+        const uint32_t k = (uint32_t)(b * 16384.0f + 4194304.0f);
+        key = ((k >> 15) << 16) | (k & 32767u);
+      }
+      kout[qi] = key;
+    }
+  }
+}
+
+}  // namespace
+
+uint32_t hamming_mfma_tiles_per_slot(uint32_t max_kp) { return (max_kp + 31u) / 32u; }
+
+size_t hamming_mfma_slab_bytes(uint32_t max_nodes, uint32_t max_kp) {
+  return ((size_t)max_nodes * hamming_mfma_tiles_per_slot(max_kp) + 1u) * 4096u;
+}
+
+void launch_hamming_expand(const uint32_t* node_rows, uint32_t* slab, uint32_t slot, uint32_t max_kp, uint32_t n,
+                           hipStream_t stream) {
+  if (n == 0) return;
+  const uint32_t tiles = (n + 31u) / 32u;
+  uint4* dst = reinterpret_cast<uint4*>(slab) + (size_t)slot * hamming_mfma_tiles_per_slot(max_kp) * 256u;
+  hipLaunchKernelGGL(hamming_expand_kernel, dim3(tiles), dim3(256), 0, stream, node_rows, dst, n);
+}
+
+uint32_t launch_hamming_mfma(const uint32_t* slab, const PairWork* work, uint32_t* keys, uint32_t max_kp,
+                             uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity,
+                             int mode, hipStream_t stream) {
+  if (n_pairs == 0 || max_nq == 0) return 1;
+  const uint32_t qblocks = (max_nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
+  const uint32_t tiles_per_slot = hamming_mfma_tiles_per_slot(max_kp);
+  // small batches (live SLAM: ~20 pairs per frame) split the train tiles over several blocks, one key plane each
+  uint32_t tsplit = 1;
+  const uint32_t blocks1 = n_pairs * qblocks;
+  const uint32_t ttiles = (max_nt + 31u) / 32u;
+  if (blocks1 < 1024 && ttiles > kStage) {
+    tsplit = (1024 + blocks1 - 1) / blocks1;
+    const uint32_t max_split = (ttiles + kStage - 1) / kStage;  // at least one LDS stage per block
+    if (tsplit > max_split) tsplit = max_split;
+    if (tsplit > 32) tsplit = 32;
+    const uint32_t fit = key_planes_capacity / n_pairs;
+    if (tsplit > fit) tsplit = fit;
+    if (tsplit < 1) tsplit = 1;
+  }
+  const uint32_t pairs8 = (n_pairs + 7u) / 8u * 8u;
+  const uint32_t grid = pairs8 * qblocks * tsplit;
+  const uint4* s4 = reinterpret_cast<const uint4*>(slab);
+#define RGBDFE_LAUNCH_HM(M, S)                                                                                   \
+  hipLaunchKernelGGL((hamming_mfma_kernel<M, S>), dim3(grid), dim3(kThreads), 0, stream, s4, work, keys, max_kp, \
+                     tiles_per_slot, n_pairs, qblocks, tsplit)
+  if (mode == 2) {
+    if (tsplit > 1) RGBDFE_LAUNCH_HM(2, true); else RGBDFE_LAUNCH_HM(2, false);
+  } else {
+    if (tsplit > 1) RGBDFE_LAUNCH_HM(1, true); else RGBDFE_LAUNCH_HM(1, false);
+  }
+#undef RGBDFE_LAUNCH_HM
+  return tsplit;
+}
+
+}  // namespace rgbdfe

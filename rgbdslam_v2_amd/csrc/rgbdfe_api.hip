@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -76,11 +77,17 @@ inline uint32_t pair_uid(int32_t qid, int32_t tid) {
 struct rgbdfe_ctx {
   rgbdfe_config cfg{};
   std::mutex mu;
+  std::mutex err_mu;        // guards last_error only (fail() may run before `mu` is taken)
   std::string last_error;
+  // multi-device group handle (rgbdfe_create_multi): the per-device contexts and one host thread per device
+  struct Group* group = nullptr;
   hipStream_t stream = nullptr;
   // slabs
   uint32_t* d_desc = nullptr;  // max_nodes x max_kp x 8 dwords (+ pad rows)
   float4* d_xyz = nullptr;     // max_nodes x max_kp
+  uint32_t* d_desc4 = nullptr; // max_nodes x max_kp x 32 dwords: every descriptor bit as an fp4 (+-1) operand nibble, in
+                               // MFMA fragment order per tile of 32 rows (hamming_mfma.hip)
+  int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
   // Batches run on kLanes internal HIP streams ("lanes"), each with its own keys / results
   // staging, so that batch k+1's Hamming kernel fills the SIMDs that batch k's RANSAC tail
   // leaves idle.  The pair lists go through a ring of pinned buffers so the host can prepare
@@ -114,6 +121,7 @@ struct rgbdfe_ctx {
     PairWork* d_work = nullptr;
     hipEvent_t done = nullptr;
     bool pending = false;
+    bool failed = false;         // the batch with `ticket` did not launch completely
     int64_t ticket = 0;
   };
   Lane lanes[kLanes];
@@ -127,6 +135,8 @@ struct rgbdfe_ctx {
   int32_t latency_chunk_iters = 0;  // 0 = automatic: 4 iterations per wave up to 64 pairs, 7 up to 640, 14 up to 1280, 28 above
   int64_t next_ticket = 1;
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
+  hipEvent_t nodes_ready = nullptr;  // recorded behind the latest rgbdfe_upload_node_device copies; every batch waits for it
+  hipEvent_t nodes_ready_ev = nullptr;  // (storage; nodes_ready points here once the first such upload happened)
   rgbdfe_match_result* h_results = nullptr;  // pinned staging of the synchronous host-output entry points
   // scratch for single-pair helpers / project_to_3d
   void* d_scratch = nullptr;
@@ -153,7 +163,10 @@ struct rgbdfe_ctx {
 namespace {
 
 int fail(rgbdfe_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->last_error = msg;
+  if (ctx) {
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    ctx->last_error = msg;
+  }
   return code;
 }
 
@@ -270,8 +283,12 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 64 ? 4 : (n <= 640 ? 7 : (n <= 1280 ? 14 : 28)));
   // every recording wave owns a region of the error pool: keep the largest grid (a phase is at most all iterations)
   // within kMaxEcRegions by recording more iterations per wave
-  while ((size_t)n * (size_t)((ctx->rc.ransac_iterations + chunk - 1) / chunk) > kMaxEcRegions) ++chunk;
-  bool latency = n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * chunk && need_recs <= ((size_t)1 << 24);  // 1.7 GB of records per lane at most
+  // (a batch of more than kMaxEcRegions pairs cannot get below one region per pair: it takes the one-wave kernel)
+  const int I_all = ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 0;
+  const bool too_many_pairs = (size_t)n > kMaxEcRegions;
+  while (!too_many_pairs && chunk < I_all && (size_t)n * (size_t)((I_all + chunk - 1) / chunk) > kMaxEcRegions) ++chunk;
+  bool latency = !too_many_pairs && n <= ctx->latency_pairs && ctx->rc.ransac_iterations >= 2 * chunk &&
+                 need_recs <= ((size_t)1 << 24);  // 1.7 GB of records per lane at most
   *chunk_out = chunk;
   if (latency && need_recs > lane.recs_capacity) {
     HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -308,6 +325,17 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     }
   }
   return ensure_ec_pool(ctx, lane, regions + 8, stream);  // recording grids are rounded up to a multiple of 8
+}
+
+// The Hamming stage of an ORB batch: the fp4 MFMA kernel by default, the popcount kernel when asked for
+// (rgbdfe_set_hamming_mode) or when the row index does not fit the MFMA kernel's 15 key bits.  Same keys either way.
+uint32_t launch_hamming(rgbdfe_ctx* ctx, const PairWork* d_work, uint32_t* d_keys, uint32_t n, uint32_t max_nq,
+                        uint32_t max_nt, hipStream_t stream) {
+  const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
+  const uint32_t cap = (uint32_t)ctx->cfg.max_pairs_per_batch;
+  if (ctx->hamming_mode != 0 && mk <= 32768u)
+    return launch_hamming_mfma(ctx->d_desc4, d_work, d_keys, mk, n, max_nq, max_nt, cap, ctx->hamming_mode, stream);
+  return launch_hamming_nn(ctx->d_desc, d_work, d_keys, mk, n, max_nq, max_nt, cap, stream);
 }
 
 // Build the PairWork list (host) and enqueue H2D + both kernels on the next lane.
@@ -347,9 +375,19 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     if (w.nq > max_nq) max_nq = w.nq;
     if (w.nt > max_nt) max_nt = w.nt;
   }
-  ctx->next_ticket++;
-  slot.ticket = ticket;
+  if (sift && n > 65535) return fail(ctx, RGBDFE_ERR_CAPACITY, "a SIFT batch holds at most 65535 pairs");
+  // Everything that can fail without leaving work behind (scratch allocations, the schedule) comes first; the ticket
+  // is committed only once the batch is on its stream.
+  bool latency = false;
+  int chunk = 7;
+  PhasePlan pp{};
+  if (n > 0) {
+    int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp);
+    if (rcl != RGBDFE_OK) return rcl;
+  }
   if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(stream, wait_for, 0));
+  if (ctx->nodes_ready) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->nodes_ready, 0));  // rgbdfe_upload_node_device
+  hipError_t launch_err = hipSuccess;
   if (n > 0) {
     if (!d_out) d_out = lane.d_results;
     HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n,
@@ -366,13 +404,8 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     }
     const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
     if (!sift) {
-      const uint32_t planes = launch_hamming_nn(ctx->d_desc, slot.d_work, lane.d_keys, mk, (uint32_t)n, max_nq,
-                                                max_nt, (uint32_t)ctx->cfg.max_pairs_per_batch, stream);
+      const uint32_t planes = launch_hamming(ctx, slot.d_work, lane.d_keys, (uint32_t)n, max_nq, max_nt, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-      bool latency = false;
-      int chunk = 7;
-      PhasePlan pp{};
-      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
                                      lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
@@ -387,10 +420,6 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part,
                          lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
-      bool latency = false;
-      int chunk = 7;
-      PhasePlan pp{};
-      { int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp); if (rcl != RGBDFE_OK) return rcl; }
       if (latency)
         launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
                                           d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
@@ -401,11 +430,23 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
                                   (uint32_t)n, ctx->rc, lane.d_prep, lane.d_ec, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.d, stream);
     }
-    if (ctx->profiling) ctx->pending.push_back(pend);
-    HIP_TRY(ctx, hipGetLastError());
+    launch_err = hipGetLastError();
+    if (ctx->profiling) {
+      if (launch_err == hipSuccess) ctx->pending.push_back(pend);
+      else {  // a batch that did not launch has no timing record: the events go back to the pool
+        ctx->event_pool.push_back(pend.a); ctx->event_pool.push_back(pend.b); ctx->event_pool.push_back(pend.c);
+        if (sift) ctx->event_pool.push_back(pend.d);
+      }
+    }
   }
+  // whatever was enqueued is on `stream`: the slot's event covers it whether or not every launch succeeded
+  ctx->next_ticket++;
+  slot.ticket = ticket;
+  slot.failed = launch_err != hipSuccess;
   HIP_TRY(ctx, hipEventRecord(slot.done, stream));
   slot.pending = true;
+  if (launch_err != hipSuccess)
+    return fail(ctx, RGBDFE_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(launch_err));
   if (ticket_out) *ticket_out = ticket;
   if (lane_out) *lane_out = li;
   return RGBDFE_OK;
@@ -415,6 +456,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
 int wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, hipStream_t stream) {
   if (ticket <= 0 || ticket >= ctx->next_ticket) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "unknown ticket");
   rgbdfe_ctx::Slot& slot = ctx->ring[ticket % rgbdfe_ctx::kRing];
+  if (slot.ticket == ticket && slot.failed) return fail(ctx, RGBDFE_ERR_HIP, "the batch with this ticket failed to launch");
   if (slot.ticket != ticket || !slot.pending) return RGBDFE_OK;  // slot reused => that batch has completed
   if (stream) {
     HIP_TRY(ctx, hipStreamWaitEvent(stream, slot.done, 0));
@@ -427,7 +469,7 @@ int wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" {
+namespace impl {
 
 void rgbdfe_default_config(rgbdfe_config* cfg) {
   if (!cfg) return;
@@ -458,6 +500,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   int rc = validate_params(ctx, cfg->params);
   if (rc != RGBDFE_OK) { delete ctx; return rc; }
   fill_ransac_const(ctx);
+  if (const char* hm = getenv("RGBDFE_HAMMING_MODE")) ctx->hamming_mode = atoi(hm) < 0 || atoi(hm) > 2 ? 1 : atoi(hm);
   auto bail = [&](int code) { rgbdfe_destroy(ctx); return code; };
   if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
@@ -466,11 +509,16 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   const size_t rows = (size_t)cfg->max_nodes * (size_t)cfg->max_keypoints + 16;  // +pad: prefetch overrun
   if (hipMalloc((void**)&ctx->d_desc, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
   if (hipMalloc((void**)&ctx->d_xyz, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
+  // max_keypoints is rounded up to whole 32-row tiles per slot in the expanded slab
+  if (hipMalloc((void**)&ctx->d_desc4, hamming_mfma_slab_bytes((uint32_t)cfg->max_nodes, (uint32_t)cfg->max_keypoints)) != hipSuccess)
+    return bail(RGBDFE_ERR_OUT_OF_MEMORY);
   // hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which the
   // context's non-blocking streams do not wait for: a node upload issued right after create could be
   // overwritten by a late memset.  Wait for the device before returning.
   if (hipMemset(ctx->d_desc, 0, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_HIP);
   if (hipMemset(ctx->d_xyz, 0, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  if (hipMemset(ctx->d_desc4, 0, hamming_mfma_slab_bytes((uint32_t)cfg->max_nodes, (uint32_t)cfg->max_keypoints)) != hipSuccess)
+    return bail(RGBDFE_ERR_HIP);
   if (hipDeviceSynchronize() != hipSuccess) return bail(RGBDFE_ERR_HIP);
   const size_t np = (size_t)cfg->max_pairs_per_batch;
   for (auto& sl : ctx->ring) {
@@ -532,6 +580,8 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   }
   if (ctx->h_results) (void)hipHostFree(ctx->h_results);
   if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+  if (ctx->nodes_ready_ev) (void)hipEventDestroy(ctx->nodes_ready_ev);
+  if (ctx->d_desc4) (void)hipFree(ctx->d_desc4);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -555,7 +605,8 @@ const char* rgbdfe_status_string(int status) {
     case RGBDFE_ERR_HIP: return "HIP runtime error";
     case RGBDFE_ERR_UNKNOWN_NODE: return "unknown node id";
     case RGBDFE_ERR_CAPACITY: return "capacity exceeded";
-    case RGBDFE_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case RGBDFE_ERR_OUT_OF_MEMORY: return "out of memory";
+    case RGBDFE_ERR_INTERNAL: return "internal error (exception caught at the ABI)";
     default: return "unknown status";
   }
 }
@@ -583,7 +634,19 @@ static int upload_common(rgbdfe_ctx* ctx, int32_t node_id, const void* desc, con
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc + row0 * 8, desc, (size_t)n * 32, kind, stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, xyz1, (size_t)n * 16, kind, stream));
   }
+  if (n > 0) {
+    // the MFMA Hamming kernel reads the descriptors in their expanded (fp4 operand) form: built here, once per node
+    launch_hamming_expand(ctx->d_desc + row0 * 8, ctx->d_desc4, slot, (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, stream);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   if (sync) HIP_TRY(ctx, hipStreamSynchronize(stream));
+  else {
+    // Ordering contract of rgbdfe_upload_node_device with a caller stream: the copies are enqueued on that stream and
+    // every batch submitted afterwards (on the context's internal streams) waits for them through this event.
+    if (!ctx->nodes_ready_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->nodes_ready_ev, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->nodes_ready_ev, stream));
+    ctx->nodes_ready = ctx->nodes_ready_ev;
+  }
   ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 0u};
   return RGBDFE_OK;
 }
@@ -628,8 +691,9 @@ int rgbdfe_node_count(rgbdfe_ctx* ctx, int32_t node_id) {
   return (int)it->second.n;
 }
 
+// out_stride (in records): the multi-device group hands every device the interleaved positions of its shard
 int rgbdfe_match_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
-                           int32_t n_pairs, rgbdfe_match_result* out) {
+                           int32_t n_pairs, rgbdfe_match_result* out, int64_t out_stride = 1) {
   if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!query_ids || !train_ids || !out)))
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -660,7 +724,9 @@ int rgbdfe_match_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int3
                                   hipMemcpyDeviceToHost, ctx->lanes[li].stream));
     }
     for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
-    memcpy(out + super, ctx->h_results, sizeof(rgbdfe_match_result) * (size_t)m);
+    if (out_stride == 1) memcpy(out + super, ctx->h_results, sizeof(rgbdfe_match_result) * (size_t)m);
+    else
+      for (int32_t i = 0; i < m; ++i) out[(int64_t)(super + i) * out_stride] = ctx->h_results[i];
   }
   for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   if (ctx->profiling) drain_pending(ctx);
@@ -671,7 +737,7 @@ int rgbdfe_match_node_pairs(rgbdfe_ctx* ctx, int32_t new_node_id, const int32_t*
                             int32_t n_pairs, rgbdfe_match_result* out) {
   if (!ctx || n_pairs < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
   std::vector<int32_t> q((size_t)n_pairs, new_node_id);
-  return rgbdfe_match_pair_list(ctx, q.data(), candidate_ids, n_pairs, out);
+  return impl::rgbdfe_match_pair_list(ctx, q.data(), candidate_ids, n_pairs, out);
 }
 
 int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids,
@@ -775,7 +841,20 @@ int rgbdfe_upload_sift_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc1
 }
 
 int rgbdfe_match_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
-                                int32_t n_pairs, rgbdfe_match_result* out, float* out_dist) {
+                                int32_t n_pairs, rgbdfe_match_result* out, float* out_dist, int64_t out_stride = 1) {
+  if (out_stride != 1 && n_pairs > 0 && out) {  // multi-device shard: dense call, then the interleaved placement
+    std::vector<rgbdfe_match_result> tmp((size_t)n_pairs);
+    std::vector<float> tmpd(out_dist ? (size_t)n_pairs * RGBDFE_MAX_MATCHES : 0);
+    int rc = impl::rgbdfe_match_sift_pair_list(ctx, query_ids, train_ids, n_pairs, tmp.data(), out_dist ? tmpd.data() : nullptr, 1);
+    if (rc != RGBDFE_OK) return rc;
+    for (int32_t i = 0; i < n_pairs; ++i) {
+      out[(int64_t)i * out_stride] = tmp[(size_t)i];
+      if (out_dist)
+        memcpy(out_dist + (int64_t)i * out_stride * RGBDFE_MAX_MATCHES, tmpd.data() + (size_t)i * RGBDFE_MAX_MATCHES,
+               sizeof(float) * RGBDFE_MAX_MATCHES);
+    }
+    return RGBDFE_OK;
+  }
   if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!query_ids || !train_ids || !out)))
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -1069,6 +1148,8 @@ int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   auto t = ctx->nodes.find(train_id);
   if (q == ctx->nodes.end() || t == ctx->nodes.end())
     return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "node not resident");
+  if (q->second.kind != 0u || t->second.kind != 0u)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_hamming_nn_nodes needs ORB (binary descriptor) nodes");
   for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   for (auto& sl : ctx->ring) sl.pending = false;  // every lane is idle now
   rgbdfe_ctx::Slot& slot = ctx->ring[0];
@@ -1079,9 +1160,7 @@ int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id; w.pad = 0;
   if (w.nq == 0) return RGBDFE_OK;
   HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, st));
-  const uint32_t planes = launch_hamming_nn(ctx->d_desc, slot.d_work, ctx->lanes[0].d_keys,
-                                            (uint32_t)ctx->cfg.max_keypoints, 1u, w.nq, w.nt,
-                                            (uint32_t)ctx->cfg.max_pairs_per_batch, st);
+  const uint32_t planes = launch_hamming(ctx, slot.d_work, ctx->lanes[0].d_keys, 1u, w.nq, w.nt, st);
   HIP_TRY(ctx, hipGetLastError());
   return hamming_keys_to_host(ctx, w.nq, planes, out_hd, out_idx);
 }
@@ -1092,12 +1171,12 @@ int rgbdfe_hamming_nn_host(rgbdfe_ctx* ctx, const uint8_t* qdesc, int32_t nq, co
   // two temporary nodes with ids outside the int32 range a SLAM graph uses
   const int32_t qid = INT32_MIN + 1, tid = INT32_MIN + 2;
   std::vector<float> zq((size_t)(nq > 0 ? nq : 1) * 4, 0.f), zt((size_t)(nt > 0 ? nt : 1) * 4, 0.f);
-  int rc = rgbdfe_upload_node(ctx, qid, qdesc, zq.data(), nq);
+  int rc = impl::rgbdfe_upload_node(ctx, qid, qdesc, zq.data(), nq);
   if (rc != RGBDFE_OK) return rc;
-  rc = rgbdfe_upload_node(ctx, tid, tdesc, zt.data(), nt);
-  if (rc == RGBDFE_OK) rc = rgbdfe_hamming_nn_nodes(ctx, qid, tid, out_hd, out_idx);
-  (void)rgbdfe_release_node(ctx, qid);
-  (void)rgbdfe_release_node(ctx, tid);
+  rc = impl::rgbdfe_upload_node(ctx, tid, tdesc, zt.data(), nt);
+  if (rc == RGBDFE_OK) rc = impl::rgbdfe_hamming_nn_nodes(ctx, qid, tid, out_hd, out_idx);
+  (void)impl::rgbdfe_release_node(ctx, qid);
+  (void)impl::rgbdfe_release_node(ctx, tid);
   return rc;
 }
 
@@ -1376,6 +1455,13 @@ int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_it
   return RGBDFE_OK;
 }
 
+int rgbdfe_set_hamming_mode(rgbdfe_ctx* ctx, int32_t mode) {
+  if (!ctx || mode < 0 || mode > 2) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "hamming mode must be 0, 1 or 2");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->hamming_mode = mode;
+  return RGBDFE_OK;
+}
+
 int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -1406,6 +1492,688 @@ int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx) {
 }
 
 int rgbdfe_sizeof_match_result(void) { return (int)sizeof(rgbdfe_match_result); }
-int rgbdfe_abi_version(void) { return 1; }
+int rgbdfe_abi_version(void) { return 2; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL
+
+}  // namespace impl
+
+// =====================================================================================================================
+// Multi-device group (rgbdfe_create_multi) -- SURVEY.md 8(e), north_star "shard across the 8 GPUs of one node".
+//
+// The reference's caller is ONE process (GraphManager::nodeComparisons, graph_manager.cpp:541-548), so the drop-in
+// form of "8 GPUs" lives behind the same handle: a group owns one ordinary context per device and one host thread per
+// device.  Node features are replicated on every device (trivial in 288 GB), the pair list of a call is sharded
+// pair k -> device k mod G, every device writes its results straight to the caller's positions k, k+G, ... and the
+// call returns when all devices are done -- still the 1:1 replacement of blockingMapped's barrier.  For consumers on
+// the GPUs, rgbdfe_match_pair_list_allgather leaves ALL results on EVERY device: one ncclAllGather (RCCL over xGMI,
+// loaded with dlopen) of the fixed-size result PODs, or peer copies when RCCL cannot be used (the same device listed
+// twice -- how the single-GPU test box exercises two shards -- or RGBDFE_GATHER=p2p).
+// =====================================================================================================================
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <thread>
+
+namespace {
+
+// the handful of RCCL entry points the gather needs, resolved at run time (no link-time dependency for 1-GPU users)
+struct Rccl {
+  void* handle = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (handle) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (handle) break;
+    }
+    if (!handle) return false;
+    CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(handle, "ncclAllGather");
+    GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
+    GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+    return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
+  }
+};
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar (rccl.h: ncclDataType_t)
+
+struct Worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has_job = false, quit = false;
+  int rc = RGBDFE_OK;
+};
+
+}  // namespace
+
+struct Group {
+  std::vector<rgbdfe_ctx*> children;
+  std::vector<int> device_ids;
+  std::vector<std::unique_ptr<Worker>> workers;
+  Rccl rccl;
+  std::vector<void*> comms;      // one communicator per device once the RCCL path has been set up
+  bool rccl_tried = false, rccl_ok = false;
+  std::vector<hipStream_t> gather_streams;  // one per device
+  std::vector<hipEvent_t> gather_events;
+  std::string transport = "none";
+};
+
+namespace {
+
+void worker_main(Worker* w) {
+  std::unique_lock<std::mutex> lk(w->m);
+  for (;;) {
+    w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+    if (w->quit) return;
+    std::function<int()> job = std::move(w->job);
+    lk.unlock();
+    int rc;
+    try {
+      rc = job();
+    } catch (const std::bad_alloc&) {
+      rc = RGBDFE_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+      rc = RGBDFE_ERR_INTERNAL;
+    }
+    lk.lock();
+    w->rc = rc;
+    w->has_job = false;
+    w->cv.notify_all();
+  }
+}
+
+// run fn(i) for every device on that device's host thread; returns the first error
+int group_run(rgbdfe_ctx* gctx, const std::function<int(int)>& fn) {
+  Group& g = *gctx->group;
+  const int G = (int)g.children.size();
+  for (int i = 0; i < G; ++i) {
+    Worker& w = *g.workers[(size_t)i];
+    std::lock_guard<std::mutex> lk(w.m);
+    w.job = [&fn, i] { return fn(i); };
+    w.has_job = true;
+    w.cv.notify_all();
+  }
+  int first = RGBDFE_OK;
+  for (int i = 0; i < G; ++i) {
+    Worker& w = *g.workers[(size_t)i];
+    std::unique_lock<std::mutex> lk(w.m);
+    w.cv.wait(lk, [&] { return !w.has_job; });
+    if (w.rc != RGBDFE_OK && first == RGBDFE_OK) {
+      first = w.rc;
+      std::string msg;
+      {
+        std::lock_guard<std::mutex> e(g.children[(size_t)i]->err_mu);
+        msg = g.children[(size_t)i]->last_error;
+      }
+      fail(gctx, first, "device " + std::to_string(g.device_ids[(size_t)i]) + ": " + msg);
+    }
+  }
+  return first;
+}
+
+void group_destroy(rgbdfe_ctx* gctx) {
+  Group* g = gctx->group;
+  if (g) {
+    for (auto& w : g->workers) {
+      if (!w) continue;
+      {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->quit = true;
+        w->cv.notify_all();
+      }
+      if (w->th.joinable()) w->th.join();
+    }
+    if (g->rccl_ok)
+      for (void* c : g->comms)
+        if (c) (void)g->rccl.CommDestroy(c);
+    for (size_t i = 0; i < g->children.size(); ++i) {
+      if (g->children[i]) (void)hipSetDevice(g->device_ids[i]);
+      if (i < g->gather_streams.size() && g->gather_streams[i]) (void)hipStreamDestroy(g->gather_streams[i]);
+      if (i < g->gather_events.size() && g->gather_events[i]) (void)hipEventDestroy(g->gather_events[i]);
+      if (g->children[i]) impl::rgbdfe_destroy(g->children[i]);
+    }
+    delete g;
+  }
+  delete gctx;
+}
+
+int group_create(const rgbdfe_config* cfg, const int32_t* device_ids, int32_t n, rgbdfe_ctx** out) {
+  if (!cfg || !device_ids || !out || n < 1 || n > 64) return RGBDFE_ERR_INVALID_ARG;
+  *out = nullptr;
+  rgbdfe_ctx* gctx = new rgbdfe_ctx();
+  gctx->cfg = *cfg;
+  gctx->group = new Group();
+  Group& g = *gctx->group;
+  for (int32_t i = 0; i < n; ++i) {
+    rgbdfe_config c = *cfg;
+    c.device_id = device_ids[i];
+    rgbdfe_ctx* child = nullptr;
+    const int rc = impl::rgbdfe_create(&c, &child);
+    if (rc != RGBDFE_OK) {
+      group_destroy(gctx);
+      return rc;
+    }
+    g.children.push_back(child);
+    g.device_ids.push_back(device_ids[i]);
+  }
+  g.gather_streams.assign((size_t)n, nullptr);
+  g.gather_events.assign((size_t)n, nullptr);
+  for (int32_t i = 0; i < n; ++i) {
+    if (hipSetDevice(device_ids[i]) != hipSuccess ||
+        hipStreamCreateWithFlags(&g.gather_streams[(size_t)i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g.gather_events[(size_t)i], hipEventDisableTiming) != hipSuccess) {
+      group_destroy(gctx);
+      return RGBDFE_ERR_HIP;
+    }
+  }
+  for (int32_t i = 0; i < n; ++i) {
+    g.workers.emplace_back(new Worker());
+    Worker* w = g.workers.back().get();
+    w->th = std::thread(worker_main, w);
+  }
+  *out = gctx;
+  return RGBDFE_OK;
+}
+
+// sharded host-output match: device i computes pairs i, i+G, ... and writes them to out[i], out[i+G], ...
+int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, rgbdfe_match_result* out, bool sift,
+                float* out_dist) {
+  if (n < 0 || (n > 0 && (!q || !t || !out))) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
+  Group& g = *gctx->group;
+  const int G = (int)g.children.size();
+  return group_run(gctx, [&](int i) -> int {
+    std::vector<int32_t> qs, ts;
+    for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }
+    if (qs.empty()) return RGBDFE_OK;
+    if (sift)
+      return impl::rgbdfe_match_sift_pair_list(g.children[(size_t)i], qs.data(), ts.data(), (int32_t)qs.size(), out + i,
+                                               out_dist ? out_dist + (size_t)i * RGBDFE_MAX_MATCHES : nullptr, G);
+    return impl::rgbdfe_match_pair_list(g.children[(size_t)i], qs.data(), ts.data(), (int32_t)qs.size(), out + i, G);
+  });
+}
+
+bool group_setup_rccl(rgbdfe_ctx* gctx) {
+  Group& g = *gctx->group;
+  if (g.rccl_tried) return g.rccl_ok;
+  g.rccl_tried = true;
+  const char* force = getenv("RGBDFE_GATHER");
+  if (force && std::string(force) == "p2p") return false;
+  std::vector<int> sorted = g.device_ids;
+  std::sort(sorted.begin(), sorted.end());
+  if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return false;  // RCCL: one rank per device
+  if (!g.rccl.load()) return false;
+  g.comms.assign(g.device_ids.size(), nullptr);
+  if (g.rccl.CommInitAll(g.comms.data(), (int)g.device_ids.size(), g.device_ids.data()) != 0) {
+    g.comms.clear();
+    return false;
+  }
+  g.rccl_ok = true;
+  return true;
+}
+
+// Results of all pairs on every device.  d_out[i]: device-i buffer of G * per records, per = ceil(n / G);
+// pair k ends up at [(k % G) * per + k / G] of every buffer; unused tail records are filled with 0xFF (ids -1).
+int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, void* const* d_out,
+                          int32_t* records_per_device) {
+  if (n < 0 || !d_out || (n > 0 && (!q || !t))) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad allgather arguments");
+  Group& g = *gctx->group;
+  const int G = (int)g.children.size();
+  const int32_t per = (n + G - 1) / G;
+  if (records_per_device) *records_per_device = per;
+  if (per == 0) return RGBDFE_OK;
+  for (int i = 0; i < G; ++i)
+    if (!d_out[i]) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "allgather: a device buffer is NULL");
+  if (per > gctx->cfg.max_pairs_per_batch)
+    return fail(gctx, RGBDFE_ERR_CAPACITY, "allgather: the shard of a device exceeds max_pairs_per_batch");
+  const size_t rec = sizeof(rgbdfe_match_result);
+  // 1. every device computes its shard into its own segment of its own buffer
+  int rc = group_run(gctx, [&](int i) -> int {
+    rgbdfe_ctx* c = g.children[(size_t)i];
+    std::vector<int32_t> qs, ts;
+    for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }
+    rgbdfe_match_result* seg = (rgbdfe_match_result*)d_out[i] + (size_t)i * per;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+      HIP_TRY(c, hipMemsetAsync(seg, 0xFF, rec * (size_t)per, g.gather_streams[(size_t)i]));
+      HIP_TRY(c, hipEventRecord(g.gather_events[(size_t)i], g.gather_streams[(size_t)i]));
+    }
+    int64_t ticket = 0;
+    int r = RGBDFE_OK;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      r = enqueue_pairs(c, qs.data(), ts.data(), (int32_t)qs.size(), seg, g.gather_events[(size_t)i], &ticket, nullptr);
+      if (r == RGBDFE_OK) r = wait_ticket(c, ticket, g.gather_streams[(size_t)i]);
+    }
+    return r;
+  });
+  if (rc != RGBDFE_OK) return rc;
+  // 2. the exchange
+  if (G == 1 && !group_setup_rccl(gctx)) {
+    g.transport = "none (one device)";
+    HIP_TRY(gctx, hipSetDevice(g.device_ids[0]));
+    HIP_TRY(gctx, hipStreamSynchronize(g.gather_streams[0]));
+    return RGBDFE_OK;
+  }
+  if (group_setup_rccl(gctx)) {
+    g.transport = "rccl";
+    // one thread issues the grouped collective: ncclGroupStart/End makes the per-device calls one operation
+    if (g.rccl.GroupStart() != 0) return fail(gctx, RGBDFE_ERR_HIP, "ncclGroupStart failed");
+    int nrc = 0;
+    for (int i = 0; i < G && nrc == 0; ++i) {
+      const char* base = (const char*)d_out[i];
+      nrc = g.rccl.AllGather(base + (size_t)i * per * rec, d_out[i], (size_t)per * rec, kNcclChar, g.comms[(size_t)i],
+                             g.gather_streams[(size_t)i]);
+    }
+    const int erc = g.rccl.GroupEnd();
+    if (nrc != 0 || erc != 0)
+      return fail(gctx, RGBDFE_ERR_HIP, std::string("ncclAllGather: ") +
+                                            (g.rccl.GetErrorString ? g.rccl.GetErrorString(nrc ? nrc : erc) : "error"));
+  } else {
+    g.transport = "p2p";
+    // every device pushes its segment into every other buffer once its own batch has finished
+    for (int i = 0; i < G; ++i) {
+      HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+      const char* src = (const char*)d_out[i] + (size_t)i * per * rec;
+      for (int j = 0; j < G; ++j) {
+        if (j == i || d_out[j] == d_out[i]) continue;
+        char* dst = (char*)d_out[j] + (size_t)i * per * rec;
+        HIP_TRY(gctx, hipMemcpyPeerAsync(dst, g.device_ids[(size_t)j], src, g.device_ids[(size_t)i], (size_t)per * rec,
+                                         g.gather_streams[(size_t)i]));
+      }
+    }
+  }
+  for (int i = 0; i < G; ++i) {
+    HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+    HIP_TRY(gctx, hipStreamSynchronize(g.gather_streams[(size_t)i]));
+  }
+  return RGBDFE_OK;
+}
+
+// ---- the exception barrier: nothing thrown inside the library crosses the C ABI (node.cpp:1424 "never throws") ------
+template <class F>
+int guarded(rgbdfe_ctx* ctx, F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    try { return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "host allocation failed"); } catch (...) { return RGBDFE_ERR_OUT_OF_MEMORY; }
+  } catch (const std::exception& e) {
+    try { return fail(ctx, RGBDFE_ERR_INTERNAL, std::string("internal error: ") + e.what()); } catch (...) { return RGBDFE_ERR_INTERNAL; }
+  } catch (...) {
+    return RGBDFE_ERR_INTERNAL;
+  }
+}
+
+int group_only_single(rgbdfe_ctx* ctx, const char* what) {
+  return fail(ctx, RGBDFE_ERR_INVALID_ARG,
+              std::string(what) + " takes device pointers: call it on one device's context (rgbdfe_device_context)");
+}
+
+}  // namespace
+
+#define RGBDFE_IS_GROUP(ctx) ((ctx) && (ctx)->group)
+// broadcast to every device of a group, or the plain call
+#define RGBDFE_ALL(ctx, call_on_c)                                                          \
+  guarded(ctx, [&]() -> int {                                                               \
+    if (RGBDFE_IS_GROUP(ctx))                                                               \
+      return group_run(ctx, [&](int i_) -> int { rgbdfe_ctx* c = ctx->group->children[(size_t)i_]; return call_on_c; }); \
+    rgbdfe_ctx* c = ctx;                                                                    \
+    return call_on_c;                                                                       \
+  })
+// frame-level work of a group runs on its first device
+#define RGBDFE_FIRST(ctx, call_on_c)                                                        \
+  guarded(ctx, [&]() -> int {                                                               \
+    rgbdfe_ctx* c = RGBDFE_IS_GROUP(ctx) ? ctx->group->children[0] : ctx;                   \
+    const int rc_ = call_on_c;                                                              \
+    if (rc_ != RGBDFE_OK && RGBDFE_IS_GROUP(ctx)) {                                         \
+      std::string m_; { std::lock_guard<std::mutex> e_(c->err_mu); m_ = c->last_error; }    \
+      fail(ctx, rc_, m_);                                                                   \
+    }                                                                                       \
+    return rc_;                                                                             \
+  })
+
+extern "C" {
+
+void rgbdfe_default_config(rgbdfe_config* cfg) { impl::rgbdfe_default_config(cfg); }
+
+int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
+  return guarded(nullptr, [&]() -> int { return impl::rgbdfe_create(cfg, out); });
+}
+
+int rgbdfe_create_multi(const rgbdfe_config* cfg, const int32_t* device_ids, int32_t n_devices, rgbdfe_ctx** out) {
+  return guarded(nullptr, [&]() -> int { return group_create(cfg, device_ids, n_devices, out); });
+}
+
+void rgbdfe_destroy(rgbdfe_ctx* ctx) {
+  if (!ctx) return;
+  try {
+    if (ctx->group) group_destroy(ctx);
+    else impl::rgbdfe_destroy(ctx);
+  } catch (...) {
+  }
+}
+
+int rgbdfe_device_count(rgbdfe_ctx* ctx) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return ctx->group ? (int)ctx->group->children.size() : 1;
+}
+
+rgbdfe_ctx* rgbdfe_device_context(rgbdfe_ctx* ctx, int32_t i) {
+  if (!ctx) return nullptr;
+  if (!ctx->group) return i == 0 ? ctx : nullptr;
+  return i >= 0 && (size_t)i < ctx->group->children.size() ? ctx->group->children[(size_t)i] : nullptr;
+}
+
+const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx) {
+  static thread_local std::string buf;
+  buf = (ctx && ctx->group) ? ctx->group->transport : "none";
+  return buf.c_str();
+}
+
+int rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  if (RGBDFE_IS_GROUP(ctx) && p) ctx->cfg.params = *p;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_set_params(c, p));
+}
+
+const char* rgbdfe_status_string(int status) { return impl::rgbdfe_status_string(status); }
+
+// a copy per calling thread: the context's string may be rewritten by another thread at any time
+const char* rgbdfe_last_error(rgbdfe_ctx* ctx) {
+  static thread_local std::string buf;
+  try {
+    buf.clear();
+    if (ctx) {
+      std::lock_guard<std::mutex> g(ctx->err_mu);
+      buf = ctx->last_error;
+    }
+    return buf.c_str();
+  } catch (...) {
+    return "";
+  }
+}
+
+int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc, const float* xyz1, int32_t n) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_upload_node(c, node_id, desc, xyz1, n));
+}
+
+int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_desc, const void* d_xyz1, int32_t n,
+                              void* stream) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_upload_node_device");
+    return impl::rgbdfe_upload_node_device(ctx, node_id, d_desc, d_xyz1, n, stream);
+  });
+}
+
+int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_release_node(c, node_id));
+}
+
+int rgbdfe_node_count(rgbdfe_ctx* ctx, int32_t node_id) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    return impl::rgbdfe_node_count(RGBDFE_IS_GROUP(ctx) ? ctx->group->children[0] : ctx, node_id);
+  });
+}
+
+int rgbdfe_match_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                           rgbdfe_match_result* out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_match(ctx, query_ids, train_ids, n_pairs, out, false, nullptr);
+    return impl::rgbdfe_match_pair_list(ctx, query_ids, train_ids, n_pairs, out);
+  });
+}
+
+int rgbdfe_match_node_pairs(rgbdfe_ctx* ctx, int32_t new_node_id, const int32_t* candidate_ids, int32_t n_pairs,
+                            rgbdfe_match_result* out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (n_pairs < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
+    std::vector<int32_t> q((size_t)n_pairs, new_node_id);
+    if (RGBDFE_IS_GROUP(ctx)) return group_match(ctx, q.data(), candidate_ids, n_pairs, out, false, nullptr);
+    return impl::rgbdfe_match_pair_list(ctx, q.data(), candidate_ids, n_pairs, out);
+  });
+}
+
+int rgbdfe_match_pair_list_allgather(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                     int32_t n_pairs, void* const* d_out, int32_t* records_per_device) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!RGBDFE_IS_GROUP(ctx))
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_match_pair_list_allgather needs a context made by rgbdfe_create_multi");
+    return group_match_allgather(ctx, query_ids, train_ids, n_pairs, d_out, records_per_device);
+  });
+}
+
+int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                  void* d_out, void* stream) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_match_pair_list_device");
+    return impl::rgbdfe_match_pair_list_device(ctx, query_ids, train_ids, n_pairs, d_out, stream);
+  });
+}
+
+int rgbdfe_submit_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                            void* d_out, int64_t* ticket) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_submit_pair_list");
+    return impl::rgbdfe_submit_pair_list(ctx, query_ids, train_ids, n_pairs, d_out, ticket);
+  });
+}
+
+int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_wait_ticket");
+    return impl::rgbdfe_wait_ticket(ctx, ticket, stream);
+  });
+}
+
+int rgbdfe_synchronize(rgbdfe_ctx* ctx) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_synchronize(c));
+}
+
+int rgbdfe_upload_sift_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc128, const float* xyz1, int32_t n) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_upload_sift_node(c, node_id, desc128, xyz1, n));
+}
+
+int rgbdfe_match_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                rgbdfe_match_result* out, float* out_dist) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_match(ctx, query_ids, train_ids, n_pairs, out, true, out_dist);
+    return impl::rgbdfe_match_sift_pair_list(ctx, query_ids, train_ids, n_pairs, out, out_dist);
+  });
+}
+
+int rgbdfe_submit_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                 void* d_out, void* d_out_dist, int64_t* ticket) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_submit_sift_pair_list");
+    return impl::rgbdfe_submit_sift_pair_list(ctx, query_ids, train_ids, n_pairs, d_out, d_out_dist, ticket);
+  });
+}
+
+int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* match_q, int32_t* match_t,
+                            float* match_dist, int32_t* n_matches) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_match_nodes(c, query_id, train_id, match_q, match_t, match_dist, n_matches));
+}
+
+int rgbdfe_detector_configure(rgbdfe_ctx* ctx, int32_t max_keypoints, int32_t grid_resolution,
+                              int32_t adjuster_max_iterations) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_detector_configure(c, max_keypoints, grid_resolution, adjuster_max_iterations));
+}
+
+int rgbdfe_detector_thresholds(rgbdfe_ctx* ctx, double* thresholds, int32_t* n_cells) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_detector_thresholds(c, thresholds, n_cells));
+}
+
+int rgbdfe_orb_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,
+                      int32_t fast_threshold, rgbdfe_keypoint* keypoints, int32_t capacity, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_orb_detect(c, gray, mask, rows, cols, fast_threshold, keypoints, capacity, n_out));
+}
+
+int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32_t cols, rgbdfe_keypoint* keypoints,
+                       int32_t n, uint8_t* descriptors, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_orb_compute(c, gray, rows, cols, keypoints, n, descriptors, n_out));
+}
+
+int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth, int32_t rows,
+                           int32_t cols, double fx, double fy, double cx, double cy, double depth_scaling,
+                           rgbdfe_keypoint* keypoints, uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe(c, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling,
+                                                        keypoints, descriptors, xyz1, n_out));
+}
+
+int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* out_hd, int32_t* out_idx) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_hamming_nn_nodes(c, query_id, train_id, out_hd, out_idx));
+}
+
+int rgbdfe_hamming_nn_host(rgbdfe_ctx* ctx, const uint8_t* qdesc, int32_t nq, const uint8_t* tdesc, int32_t nt,
+                           int32_t* out_hd, int32_t* out_idx) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_hamming_nn_host(c, qdesc, nq, tdesc, nt, out_hd, out_idx));
+}
+
+int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* depth, int32_t rows,
+                         int32_t cols, double fx, double fy, double cx, double cy, double depth_scaling,
+                         int32_t max_keypoints, int32_t* kept_idx, float* xyz1, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_project_to_3d(c, kp_xy, n_kp, depth, rows, cols, fx, fy, cx, cy, depth_scaling,
+                                                      max_keypoints, kept_idx, xyz1, n_out));
+}
+
+int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* desc_in,
+                              const float* depth, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                              double depth_scaling, int32_t max_keypoints, int32_t use_root_sift, int32_t* kept_idx,
+                              float* xyz1, float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_node_features(c, kp_xy, n_kp, desc_in, depth, rows, cols, fx, fy, cx, cy,
+                                                           depth_scaling, max_keypoints, use_root_sift, kept_idx, xyz1,
+                                                           siftgpu_descriptors, feature_descriptors, n_out));
+}
+
+int rgbdfe_depth_to_mono8(rgbdfe_ctx* ctx, const void* depth, int32_t depth_is_u16, int32_t rows, int32_t cols,
+                          uint8_t* mono8, float* depth_m) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_depth_to_mono8(c, depth, depth_is_u16, rows, cols, mono8, depth_m));
+}
+
+int rgbdfe_upload_node_cloud(rgbdfe_ctx* ctx, int32_t node_id, const float* depth, int32_t rows, int32_t cols,
+                             const uint8_t* rgb, int32_t rgb_channels, int32_t encoding_bgr, double fx, double fy,
+                             double cx, double cy, double depth_scaling, double min_depth, int32_t cloud_skip,
+                             float* cloud_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  // replicated like the node features, so that the measurement-model jobs can be sharded; the copy comes from device 0
+  return RGBDFE_ALL(ctx, impl::rgbdfe_upload_node_cloud(c, node_id, depth, rows, cols, rgb, rgb_channels, encoding_bgr, fx,
+                                                        fy, cx, cy, depth_scaling, min_depth, cloud_skip,
+                                                        (!RGBDFE_IS_GROUP(ctx) || c == ctx->group->children[0]) ? cloud_out
+                                                                                                               : nullptr));
+}
+
+int rgbdfe_release_node_cloud(rgbdfe_ctx* ctx, int32_t node_id) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_release_node_cloud(c, node_id));
+}
+
+int rgbdfe_observation_likelihood(rgbdfe_ctx* ctx, int32_t n, const int32_t* new_ids, const int32_t* old_ids,
+                                  const float* transforms, int32_t emm_skip_step, rgbdfe_emm_counts* out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!RGBDFE_IS_GROUP(ctx))
+      return impl::rgbdfe_observation_likelihood(ctx, n, new_ids, old_ids, transforms, emm_skip_step, out);
+    if (n < 0 || (n > 0 && (!new_ids || !old_ids || !transforms || !out)))
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+    Group& g = *ctx->group;
+    const int G = (int)g.children.size();
+    return group_run(ctx, [&](int i) -> int {  // job k -> device k mod G
+      std::vector<int32_t> a, b;
+      std::vector<float> T;
+      for (int32_t k = i; k < n; k += G) {
+        a.push_back(new_ids[k]); b.push_back(old_ids[k]);
+        T.insert(T.end(), transforms + (size_t)k * 16, transforms + (size_t)k * 16 + 16);
+      }
+      if (a.empty()) return RGBDFE_OK;
+      std::vector<rgbdfe_emm_counts> o(a.size());
+      const int rc = impl::rgbdfe_observation_likelihood(g.children[(size_t)i], (int32_t)a.size(), a.data(), b.data(),
+                                                         T.data(), emm_skip_step, o.data());
+      if (rc != RGBDFE_OK) return rc;
+      for (size_t m = 0; m < o.size(); ++m) out[(size_t)i + m * (size_t)G] = o[m];
+      return RGBDFE_OK;
+    });
+  });
+}
+
+int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32_t all, double observability_threshold,
+                                     double* quality) {
+  return impl::rgbdfe_observation_criterion_met(inliers, outliers, all, observability_threshold, quality);
+}
+
+int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_set_latency_mode(c, max_pairs, chunk_iterations));
+}
+
+int rgbdfe_set_hamming_mode(rgbdfe_ctx* ctx, int32_t mode) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_set_hamming_mode(c, mode));
+}
+
+int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_set_profiling(c, enable));
+}
+
+// group: the sum over the devices
+int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t* launches, int64_t* pairs) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!RGBDFE_IS_GROUP(ctx)) return impl::rgbdfe_get_kernel_time(ctx, which, total_ms, launches, pairs);
+    double ms = 0; int64_t nl = 0, np = 0;
+    for (rgbdfe_ctx* c : ctx->group->children) {
+      double a = 0; int64_t b = 0, d = 0;
+      const int rc = impl::rgbdfe_get_kernel_time(c, which, &a, &b, &d);
+      if (rc != RGBDFE_OK) return rc;
+      ms += a; nl += b; np += d;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = nl;
+    if (pairs) *pairs = np;
+    return RGBDFE_OK;
+  });
+}
+
+int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_reset_kernel_time(c));
+}
+
+int rgbdfe_sizeof_match_result(void) { return impl::rgbdfe_sizeof_match_result(); }
+int rgbdfe_abi_version(void) { return impl::rgbdfe_abi_version(); }
 
 }  // extern "C"

@@ -38,6 +38,16 @@ struct RansacConst {
 uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
                            uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
                            uint32_t key_planes_capacity, hipStream_t stream);
+// fp4 MFMA form of the same search (hamming_mfma.hip): descriptors expanded to one fp4 operand nibble per bit, 128 B per
+// row in MFMA fragment order, tiles of 32 rows; same keys, bit for bit.  mode 1: row term added by the MFMA (C operand),
+// mode 2: by v_add_f32.  Valid for max_kp <= 32768.
+uint32_t hamming_mfma_tiles_per_slot(uint32_t max_kp);
+size_t hamming_mfma_slab_bytes(uint32_t max_nodes, uint32_t max_kp);
+void launch_hamming_expand(const uint32_t* node_rows, uint32_t* slab, uint32_t slot, uint32_t max_kp, uint32_t n,
+                           hipStream_t stream);
+uint32_t launch_hamming_mfma(const uint32_t* slab, const PairWork* work, uint32_t* keys, uint32_t max_kp,
+                             uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity,
+                             int mode, hipStream_t stream);
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
                           uint32_t n_pairs, const RansacConst& rc, struct PairPrep* prep, double* ec_pool,

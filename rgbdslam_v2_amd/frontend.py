@@ -77,7 +77,9 @@ class FrontEnd:
     """One rgbdfe context = one GPU: resident node features + the batched pair op."""
 
     def __init__(self, device_id: int = 0, max_nodes: int = 256, max_keypoints: int = 1024,
-                 max_pairs_per_batch: int = 4096, **params):
+                 max_pairs_per_batch: int = 4096, device_ids: Optional[Sequence[int]] = None, **params):
+        """device_ids: several GPUs behind this one handle (rgbdfe_create_multi): node features replicated,
+        pairs sharded pair k -> device k mod G, results gathered; a device may be listed twice."""
         self._L = _lib.load()
         cfg = RgbdfeConfig()
         self._L.rgbdfe_default_config(C.byref(cfg))
@@ -91,10 +93,36 @@ class FrontEnd:
             setattr(cfg.params, k, v)
         self.cfg = cfg
         self._ctx = C.c_void_p()
-        st = self._L.rgbdfe_create(C.byref(cfg), C.byref(self._ctx))
+        if device_ids is not None:
+            ids = np.ascontiguousarray(device_ids, np.int32)
+            st = self._L.rgbdfe_create_multi(C.byref(cfg), ids.ctypes.data, len(ids), C.byref(self._ctx))
+        else:
+            st = self._L.rgbdfe_create(C.byref(cfg), C.byref(self._ctx))
         if st != 0:
             self._ctx = C.c_void_p()
             raise RgbdfeError(f"rgbdfe_create failed: {self._L.rgbdfe_status_string(st).decode()}")
+
+    @property
+    def device_count(self) -> int:
+        return int(self._L.rgbdfe_device_count(self._ctx))
+
+    def set_hamming_mode(self, mode: int):
+        """0 = popcount kernel, 1 = fp4 MFMA kernel (default), 2 = MFMA kernel with the VALU row term."""
+        self._check(self._L.rgbdfe_set_hamming_mode(self._ctx, mode))
+
+    def gather_transport(self) -> str:
+        return self._L.rgbdfe_gather_transport(self._ctx).decode()
+
+    def match_pair_list_allgather(self, query_ids, train_ids, d_out_ptrs: Sequence[int]) -> int:
+        """All results on every device (ncclAllGather / peer copies).  d_out_ptrs: one device buffer per device,
+        each device_count * ceil(n / device_count) records.  Returns records per device."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        ptrs = (C.c_void_p * len(d_out_ptrs))(*[C.c_void_p(int(p)) for p in d_out_ptrs])
+        per = C.c_int32(0)
+        self._check(self._L.rgbdfe_match_pair_list_allgather(self._ctx, q.ctypes.data, t.ctypes.data, len(q),
+                                                             C.cast(ptrs, C.c_void_p), C.byref(per)))
+        return int(per.value)
 
     # -- plumbing --------------------------------------------------------------
     def _check(self, st):

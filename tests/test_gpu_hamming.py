@@ -11,10 +11,13 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "hamming_golden.npz")
 
 
-@pytest.fixture(scope="module")
-def fe():
+# every Hamming kernel of the library must return the reference's keys: 1 = fp4 MFMA contraction with the row term in
+# the accumulator's initial value (the default), 2 = the same with the row term added by the VALU, 0 = xor + popcount
+@pytest.fixture(scope="module", params=[1, 2, 0], ids=["mfma", "mfma_valu_row", "popcount"])
+def fe(request):
     from rgbdslam_v2_amd.frontend import FrontEnd
     f = FrontEnd(device_id=0, max_nodes=48, max_keypoints=4096, max_pairs_per_batch=1024)
+    f.set_hamming_mode(request.param)
     yield f
     f.close()
 
@@ -83,3 +86,43 @@ def test_resident_nodes_and_large_batch_path(fe):
     assert np.array_equal(hd, hd2) and np.array_equal(idx, idx2)
     for k in range(n_nodes):
         fe.release_node(100 + k)
+
+
+def test_all_hamming_kernels_agree_on_a_full_batch():
+    """4000-keypoint nodes, many pairs, ragged row counts: the three kernels write identical match lists."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    rng = np.random.default_rng(5)
+    n_nodes = 12
+    rows = [4000, 3999, 3969, 4001 - 64, 33, 32, 31, 1, 2, 2500, 1024, 1000]
+    descs = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in rows]
+    for k in range(1, n_nodes):  # related nodes, so that hd < 128 matches (and ties) exist
+        m = min(rows[k], rows[0])
+        take = rng.permutation(m)[: m // 2]
+        descs[k][take] = descs[0][take]
+        flips = rng.random((len(take), 256)) < 0.04
+        descs[k][take] ^= np.packbits(flips, axis=1, bitorder="little")
+    pq = np.array([a for a in range(n_nodes) for b in range(n_nodes) if a != b], np.int32)
+    pt = np.array([b for a in range(n_nodes) for b in range(n_nodes) if a != b], np.int32)
+    outs = []
+    for mode in (0, 1, 2):
+        fe = FrontEnd(device_id=0, max_nodes=16, max_keypoints=4032, max_pairs_per_batch=256)
+        fe.set_hamming_mode(mode)
+        for k in range(n_nodes):
+            xyz = np.concatenate([rng.uniform(-1, 1, (rows[k], 2)), rng.uniform(1, 3, (rows[k], 1)),
+                                  np.ones((rows[k], 1))], 1).astype(np.float32)
+            fe.upload_node(k, descs[k], xyz)
+        keys = []
+        for a, b in zip(pq[::7], pt[::7]):
+            hd, idx = fe.hamming_nn_nodes(int(a), int(b))
+            keys.append((hd, idx))
+        out = fe.match_pair_list(pq, pt)
+        outs.append((keys, out["n_all"].copy(), out["all_q"].copy(), out["all_t"].copy(), out["all_hd"].copy()))
+        fe.close()
+    for k, (a, b) in enumerate(zip(pq[::7], pt[::7])):
+        hd_ref, idx_ref = po.hamming_nn_batch(descs[a], descs[b])
+        for mode in range(3):
+            assert np.array_equal(outs[mode][0][k][0], hd_ref), (mode, a, b)
+            assert np.array_equal(outs[mode][0][k][1], idx_ref), (mode, a, b)
+    for mode in (1, 2):
+        for f in range(1, 5):
+            assert np.array_equal(outs[0][f], outs[mode][f])

@@ -1,0 +1,201 @@
+"""-m gpu: several devices behind one handle (rgbdfe_create_multi), the all-gather of the result
+PODs, and the ABI hardening (many threads on one context, batches beyond 65536 pairs, upload ordering).
+
+The GPU box has ONE device, so the group lists it twice: two device contexts, two host threads, two shards --
+real kernels on both shards, gathered bytes compared with the single-context result."""
+import threading
+
+import numpy as np
+import pytest
+
+from rgbdslam_v2_amd import synth
+from rgbdslam_v2_amd._lib import RESULT_DTYPE, RgbdfeError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data():
+    seq = synth.make_sequence(n_frames=14, n_kp=500, n_world=2000, seed=21)
+    pq, pt = synth.candidate_pairs(14, per_frame=7, seed=21)
+    return seq, pq, pt
+
+
+def _fe(seq, device_ids=None, cap=256, **kw):
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    fe = FrontEnd(device_id=0, max_nodes=16, max_keypoints=512, max_pairs_per_batch=cap, device_ids=device_ids, **kw)
+    for f in range(seq["desc"].shape[0]):
+        fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+    return fe
+
+
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0]])
+def test_sharded_match_equals_single_device(data, ids):
+    seq, pq, pt = data
+    one = _fe(seq)
+    ref = one.match_pair_list(pq, pt)
+    ref_np = one.match_node_pairs(13, np.arange(13))
+    one.close()
+    grp = _fe(seq, device_ids=ids)
+    assert grp.device_count == len(ids)
+    out = grp.match_pair_list(pq, pt)                 # pair k -> device k mod G, written to out[k]
+    assert out.tobytes() == ref.tobytes()
+    assert grp.match_node_pairs(13, np.arange(13)).tobytes() == ref_np.tobytes()   # the blockingMapped call shape
+    assert grp.match_pair_list(pq[:1], pt[:1]).tobytes() == ref[:1].tobytes()       # fewer pairs than devices
+    assert len(grp.match_pair_list(pq[:0], pt[:0])) == 0
+    # node lifetime is replicated too
+    grp.release_node(3)
+    with pytest.raises(RgbdfeError):
+        grp.match_pair_list([3], [1])
+    grp.upload_node(3, seq["desc"][3], seq["xyz1"][3])
+    assert grp.match_pair_list(pq, pt).tobytes() == ref.tobytes()
+    grp.close()
+
+
+@pytest.mark.parametrize("ids,transport", [([0, 0], "p2p"), ([0], None)])
+def test_allgather_leaves_all_results_on_every_device(data, ids, transport):
+    import torch
+    seq, pq, pt = data
+    one = _fe(seq)
+    ref = one.match_pair_list(pq, pt)
+    one.close()
+    grp = _fe(seq, device_ids=ids)
+    G, n = len(ids), len(pq)
+    per = (n + G - 1) // G
+    rec = RESULT_DTYPE.itemsize
+    bufs = [torch.zeros(G * per * rec, dtype=torch.uint8, device="cuda:0") for _ in ids]
+    torch.cuda.synchronize()
+    got_per = grp.match_pair_list_allgather(pq, pt, [b.data_ptr() for b in bufs])
+    assert got_per == per
+    if transport is not None:
+        assert grp.gather_transport() == transport
+    else:
+        assert grp.gather_transport() in ("rccl", "none (one device)")   # one rank: RCCL when librccl loads
+    for b in bufs:
+        allrec = np.frombuffer(b.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+        for k in range(n):
+            assert allrec[(k % G) * per + k // G].tobytes() == ref[k].tobytes()
+        for d in range(G):                             # unused tail records: ids -1
+            used = len(range(d, n, G))
+            assert np.all(allrec[d * per + used:(d + 1) * per]["id1"] == -1)
+    grp.close()
+
+
+def test_group_refuses_device_pointer_entry_points(data):
+    import torch
+    seq, pq, pt = data
+    grp = _fe(seq, device_ids=[0, 0])
+    buf = torch.zeros(4 * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RgbdfeError, match="device"):
+        grp.submit_pair_list(pq[:4], pt[:4], buf.data_ptr())
+    grp.close()
+
+
+def test_sift_pairs_shard_too(data):
+    seq, pq, pt = data
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    sd = synth.sift_descriptors_like(seq["desc"], seed=5)
+    outs = []
+    for ids in (None, [0, 0]):
+        fe = FrontEnd(device_id=0, max_nodes=16, max_keypoints=512, max_pairs_per_batch=128, device_ids=ids)
+        for f in range(sd.shape[0]):
+            fe.upload_sift_node(f, sd[f], seq["xyz1"][f])
+        outs.append(fe.match_sift_pair_list(pq, pt))
+        fe.close()
+    a, b = outs
+    if isinstance(a, tuple):
+        for x, y in zip(a, b):
+            assert np.asarray(x).tobytes() == np.asarray(y).tobytes()
+    else:
+        assert a.tobytes() == b.tobytes()
+
+
+def test_one_context_from_many_threads(data):
+    """rgbdfe.h: a context may be called from any thread; calls serialise, errors stay per thread."""
+    seq, pq, pt = data
+    fe = _fe(seq, cap=64)
+    ref = fe.match_pair_list(pq, pt)
+    errors, wrong = [], []
+
+    def worker(tid):
+        try:
+            for it in range(6):
+                lo = (tid * 7 + it * 3) % (len(pq) - 20)
+                out = fe.match_pair_list(pq[lo:lo + 20], pt[lo:lo + 20])
+                if out.tobytes() != ref[lo:lo + 20].tobytes():
+                    wrong.append((tid, it))
+                try:
+                    fe.match_pair_list([0], [1000 + tid])     # unknown node: this thread's own error text
+                    wrong.append((tid, it, "no error"))
+                except RgbdfeError as e:
+                    if "not resident" not in str(e):
+                        wrong.append((tid, it, str(e)))
+                if tid % 2 == 0:                              # uploads interleave with other threads' batches
+                    fe.upload_node(100 + tid, seq["desc"][tid % 14], seq["xyz1"][tid % 14])
+                    fe.release_node(100 + tid)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors and not wrong, (errors, wrong)
+    assert fe.match_pair_list(pq, pt).tobytes() == ref.tobytes()
+    fe.close()
+
+
+def test_batch_beyond_65536_pairs():
+    """more pairs than error-pool regions must fall back to the one-wave schedule, not spin."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    seq = synth.make_sequence(n_frames=6, n_kp=64, n_world=160, seed=3)
+    n = 66000
+    rng = np.random.default_rng(0)
+    pq = rng.integers(1, 6, n).astype(np.int32)
+    pt = (pq - 1 - rng.integers(0, 5, n) % pq).astype(np.int32)
+    fe = FrontEnd(device_id=0, max_nodes=8, max_keypoints=64, max_pairs_per_batch=n, min_matches=5, ransac_iterations=20)
+    for f in range(6):
+        fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+    # one submit = one batch (match_pair_list would cut the list in two halves for its two streams)
+    import torch
+    buf = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    fe.wait_ticket(fe.submit_pair_list(pq, pt, buf.data_ptr()), None)
+    out = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+    fe.close()
+    small = FrontEnd(device_id=0, max_nodes=8, max_keypoints=64, max_pairs_per_batch=512, min_matches=5,
+                     ransac_iterations=20)
+    for f in range(6):
+        small.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+    uniq = {}
+    for k in range(n):
+        uniq.setdefault((int(pq[k]), int(pt[k])), k)
+    keys = sorted(uniq)
+    ref = small.match_pair_list([a for a, _ in keys], [b for _, b in keys])
+    small.close()
+    lut = {kq: ref[i] for i, kq in enumerate(keys)}
+    for k in range(0, n, 97):
+        assert out[k].tobytes() == lut[(int(pq[k]), int(pt[k]))].tobytes()
+
+
+def test_upload_node_device_orders_before_later_batches(data):
+    """rgbdfe_upload_node_device on a caller stream returns at once; the next batch still sees the node."""
+    import torch
+    seq, pq, pt = data
+    fe = _fe(seq)
+    ref = fe.match_pair_list(pq, pt)
+    s = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for rep in range(3):
+        f = 5 + rep
+        d_desc = torch.from_numpy(seq["desc"][f].copy()).cuda()
+        d_xyz = torch.from_numpy(seq["xyz1"][f].copy()).cuda()
+        torch.cuda.synchronize()
+        fe.upload_node(f, np.zeros_like(seq["desc"][f]), np.zeros_like(seq["xyz1"][f]))   # wipe the slot
+        with torch.cuda.stream(s):
+            big.fill_(rep)                      # keeps the caller's stream busy ahead of the copies
+            fe.upload_node_device(f, d_desc.data_ptr(), d_xyz.data_ptr(), d_desc.shape[0], s.cuda_stream)
+        out = fe.match_pair_list(pq, pt)        # must wait for the copies on the device
+        assert out.tobytes() == ref.tobytes()
+        s.synchronize()
+    fe.close()
