@@ -12,7 +12,9 @@ torch.distributed.run) every rank holds all nodes, the global pair list (N x 400
 is sharded pair k -> rank k mod N, and each step ends with the RCCL all-gather of the
 MatchingResult PODs: weak scaling.
 
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Its `roofline` block is computed from times measured in THIS run: per-stage HIP-event
+times of steps that run one batch at a time (`serial`), next to the pipelined step time the metric uses; at N = 1 the
+line also carries `sift` (configs[3]) and `detect` (Level B frames/s) sub-records and the CPU baselines.
 """
 import argparse
 import json
@@ -61,6 +63,12 @@ def main():
                     help="which select+RANSAC schedule the library uses for the batches of this run: its default "
                          "(record / replay up to the library's batch limit, one wave per pair above it), or forced")
     ap.add_argument("--chunk-iterations", type=int, default=0, help="iterations per wave on the record / replay path")
+    ap.add_argument("--depth-noise", type=float, default=0.01,
+                    help="sigma of the synthetic depth noise as a multiple of z^2 (SURVEY.md 8(d): 0.01 = sigma_depth; "
+                         "round 1 measured with 0.002)")
+    ap.add_argument("--hamming-mode", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="-1 = the library's default (fp4 MFMA contraction), 0 = xor+popcount kernel, 2 = MFMA with VALU row term")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sift / detect sub-records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -87,7 +95,7 @@ def main():
     from rgbdslam_v2_amd.dist import shard_pairs
 
     F, N = args.frames, args.kp
-    seq = synth.make_sequence(n_frames=F, n_kp=N, seed=SEED)
+    seq = synth.make_sequence(n_frames=F, n_kp=N, seed=SEED, depth_noise=args.depth_noise)
     # global pair list: per frame 20*world candidates (weak scaling), sharded round-robin
     per_frame = min(args.pairs_per_frame * world, F - 1)
     pq_all, pt_all = synth.candidate_pairs(F, per_frame=per_frame, seed=SEED)
@@ -103,6 +111,8 @@ def main():
 
     fe = FrontEnd(device_id=local_rank, max_nodes=F, max_keypoints=((N + 63) // 64) * 64,
                   max_pairs_per_batch=max(n_pad, 1), seed=SEED)
+    if args.hamming_mode >= 0:
+        fe.set_hamming_mode(args.hamming_mode)
     if args.ransac_path == "one_wave":
         fe.set_latency_mode(0, 0)
     elif args.ransac_path == "record_replay":
@@ -171,24 +181,29 @@ def main():
     ham_ms, ham_launches, ham_pairs = fe.kernel_time(k_match)
     rsc_ms, rsc_launches, rsc_pairs = fe.kernel_time(KERNEL_RANSAC)
     fin_ms, fin_launches, _ = fe.kernel_time(KERNEL_SIFT_FINISH)
-    # Extra, clearly separate pass: three NON-overlapped steps (one batch in flight at a time), so that
-    # per-kernel durations are not inflated by the neighbouring batch sharing the CUs.  Reported as
-    # roofline["isolated_*_ms"] next to the official numbers.
+    # Second, clearly separate measurement: SERIAL steps (one batch in flight at a time), with their own wall clock.
+    # In the timed region two batches share the chip, so a stage's HIP-event span there is inflated by its neighbour
+    # and can exceed ms_per_step; the serial steps give stage times that add up to a step time measured the same way.
     iso = {}
     fe.reset_kernel_time()
     fe.set_profiling(True)
-    for _ in range(3):
+    n_serial = 5
+    torch.cuda.synchronize()
+    ts0 = time.perf_counter()
+    for _ in range(n_serial):
         if sift:
             tk = fe.submit_sift_pair_list(pq, pt, d_local[0].data_ptr())
         else:
             tk = fe.submit_pair_list(pq, pt, d_local[0].data_ptr())
         fe.wait_ticket(tk, None)
     fe.synchronize()
+    serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
     fe.set_profiling(False)
     for nme, kk in (("match", k_match), ("ransac", KERNEL_RANSAC), ("sift_finish", KERNEL_SIFT_FINISH)):
         ms, nl, _ = fe.kernel_time(kk)
         if nl:
-            iso["isolated_%s_ms" % nme] = round(ms / nl, 4)
+            iso["serial_%s_ms" % nme] = round(ms / nl, 4)
+    iso["serial_ms_per_step"] = round(serial_ms, 4)
 
     total_pairs = sum(counts) * args.steps
     value = total_pairs / elapsed
@@ -201,32 +216,35 @@ def main():
 
     if rank == 0:
         b_pair, b_ham, b_rsc = algorithmic_bytes(N, MAX_MATCHES)
-        dominant = "hamming_nn" if ham_ms >= rsc_ms else "select_ransac"
-        dom_ms, dom_launches, dom_bytes = ((ham_ms, ham_launches, b_ham) if dominant == "hamming_nn"
-                                           else (rsc_ms, rsc_launches, b_rsc))
-        avg_launch_ms = dom_ms / max(dom_launches, 1)
-        achieved = (dom_bytes * n_local) / (avg_launch_ms * 1e-3) / 1e9 if dom_launches else 0.0
-        ham_avg_ms = ham_ms / max(ham_launches, 1)
-        valu_achieved = (16.0 * N * (N - 1) * n_local) / (ham_avg_ms * 1e-3) if ham_launches else 0.0
-        traffic = valu_busy = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc_path) and args.ransac_path != "one_wave":  # collected on the default schedule
-            try:
-                pmc = json.load(open(pmc_path)).get(dominant, {})
-                traffic = pmc.get("hbm_bytes_per_launch")
-                valu_busy = pmc.get("valu_busy_frac")  # SQ_ACTIVE_INST_VALU over the SIMD time of the launch
-            except Exception:
-                traffic = valu_busy = None
+        ms_per_step = elapsed / args.steps * 1e3
+        # spans inside the timed region (two batches in flight: a span can exceed ms_per_step)
+        ham_ovl = ham_ms / max(ham_launches, 1)
+        rsc_ovl = rsc_ms / max(rsc_launches, 1)
+        fin_ovl = fin_ms / max(fin_launches, 1)
+        # serial stage times (one batch in flight): what `roofline` is computed from
+        ham_ser = iso.get("serial_match_ms", 0.0)
+        rsc_ser = iso.get("serial_ransac_ms", 0.0)
+        timing = {
+            "ms_per_step": round(ms_per_step, 4),
+            "serial_ms_per_step": iso.get("serial_ms_per_step"),
+            "serial_stage_ms": {"match": ham_ser, "sift_finish": iso.get("serial_sift_finish_ms"), "select_ransac": rsc_ser},
+            "overlapped_stage_span_ms": {"match": round(ham_ovl, 4), "sift_finish": round(fin_ovl, 4) if fin_launches else None,
+                                         "select_ransac": round(rsc_ovl, 4)},
+            "note": "value and ms_per_step come from the pipelined timed region (step k+1 is submitted while step k runs; "
+                    "a stage's HIP-event span there includes time it shares the CUs with the neighbouring batch and may "
+                    "exceed ms_per_step).  The serial figures are 5 extra steps with ONE batch in flight, timed in this "
+                    "run: serial stage times add up to (at most) serial_ms_per_step.  roofline uses the serial times.",
+        }
         if sift:
             # configs[3]: the dense contraction.  FLOP per pair = 2 * Nq * Nt * 128 on the bf16 MFMA
             # (dense peak 2.5 PFLOP/s, MI355X_MICROARCH.md); reported for the MFMA kernel itself.
             flop = 2.0 * N * N * 128 * n_local
-            tf = flop / (ham_avg_ms * 1e-3) / 1e12 if ham_launches else 0.0
+            tf = flop / (ham_ser * 1e-3) / 1e12 if ham_ser else 0.0
             out = {
                 "metric": "frame-pairs matched+RANSAC/sec, 640x480 SIFT-1000 (128-d float, bf16 MFMA)",
                 "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "ms_per_step": round(ms_per_step, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16 MFMA (exact u8 dot products) + f32/f64 (RANSAC)", "data": "synthetic",
                 "config": {"workload": "configs[3]: synthetic SIFT 128-d float descriptors, %d kp, %d candidate "
@@ -236,59 +254,205 @@ def main():
                 "roofline": {"bound": "mfma", "kernel": "sift_dot_top2", "achieved": round(tf, 3),
                              "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
                              "traffic": None, "flop_per_pair": 2.0 * N * N * 128,
-                             "pairs_per_launch": n_local, "avg_launch_ms": round(ham_avg_ms, 4),
-                             "finish_ms_per_launch": round(fin_ms / max(fin_launches, 1), 4),
-                             "ransac_ms_per_launch": round(rsc_ms / max(rsc_launches, 1), 4), **iso},
+                             "pairs_per_launch": n_local, "avg_launch_ms": ham_ser, "time_basis": "serial"},
+                "timing": timing,
             }
             print(json.dumps(out), flush=True)
             fe.close()
             if world > 1:
                 dist.destroy_process_group()
             return
+        dominant = "hamming_nn" if ham_ser >= rsc_ser else "select_ransac"
+        dom_ms, dom_bytes = (ham_ser, b_ham) if dominant == "hamming_nn" else (rsc_ser, b_rsc)
+        achieved = (dom_bytes * n_local) / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         roofline = {
-            "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3),
+            # the contract's block: ALGORITHMIC bytes of the dominant kernel / its launch time / HBM peak
+            "bound": "hbm", "limiter": "valu_issue", "kernel": dominant, "achieved": round(achieved, 3),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": traffic,
-            "valu_busy_frac_pmc": None if valu_busy is None else round(valu_busy, 3),
-            "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
-            "avg_launch_ms": round(avg_launch_ms, 4),
-            "hamming_ms_per_launch": round(ham_avg_ms, 4),
-            "ransac_ms_per_launch": round(rsc_ms / max(rsc_launches, 1), 4),
-            "ransac_schedule": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
-                               "record/replay (a batch's select+RANSAC stage = pair_prep_kernel + 4 x (recording "
-                               "launch of select_ransac_kernel + replay_walk_kernel) + 1 result launch; avg_launch_ms "
-                               "spans the whole stage)",
+            "traffic": None, "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
+            "avg_launch_ms": round(dom_ms, 4), "time_basis": "serial (one batch in flight), HIP events, this run",
+            "launches_per_stage": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
+                                  "pair_prep_kernel + 4 x (recording launch of select_ransac_kernel + replay_walk_kernel) + 1 "
+                                  "result launch; avg_launch_ms spans the whole stage",
             "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
-            "valu_laneops_per_s": round(valu_achieved, 1), "valu_peak": VALU_PEAK_LANEOPS,
-            "valu_frac": round(valu_achieved / VALU_PEAK_LANEOPS, 4), **iso,
-            "note": "neither kernel of the ORB pair path is HBM bound: the match is integer-VALU bound (xor+bcnt), "
-                    "select+RANSAC is VALU-issue/latency bound (valu_busy_frac_pmc = fraction of SIMD time with a VALU "
-                    "instruction active, rocprofv3 PMC pass); see DESIGN.md 4.1-4.2",
+            "note": "the HBM fraction is what the contract asks for and says only that this path is NOT memory bound "
+                    "(SURVEY.md 8(d)); the limiter is instruction issue: see issue_roofline",
         }
         out = {
             "metric": "frame-pairs matched+RANSAC/sec, 640x480 ORB-1000",
             "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 popcount (match) + f32/f64 (RANSAC)", "data": "synthetic",
+            "dtype": "fp4 MFMA, exact (match) + f32/f64 (RANSAC)" if fe.hamming_mode != 0 else
+                     "u32 popcount (match) + f32/f64 (RANSAC)", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 640x480 RGB-D, ORB %d kp, %d candidate pairs/frame, %d frames"
                                    % (N, args.pairs_per_frame, F),
                        "pairs_per_gpu_per_step": n_local, "max_matches": MAX_MATCHES,
                        "ransac_iterations": 200, "parallelism": "pair-sharded x%d" % world,
+                       "depth_noise_sigma_over_z2": args.depth_noise,
                        "edge_fraction": round(edge_frac, 4), "mean_ransac_iterations": round(mean_iters, 2)},
             "roofline": roofline,
+            "match_roofline": match_roofline(N, n_local, ham_ser, fe.hamming_mode),
+            "issue_roofline": issue_roofline(N, n_local, ham_ser, rsc_ser, fe.hamming_mode),
+            "timing": timing,
         }
+        if world == 1 and not args.no_extras:
+            fe.close()
+            fe = None
+            try:
+                out["sift"] = sift_subrecord(seq, local_rank)
+            except Exception as e:  # noqa: BLE001 -- a sub-record must not take the headline line down
+                out["sift"] = {"error": repr(e)}
+            try:
+                out["detect"] = detect_subrecord(local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["detect"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seq, pq, pt, fe, args.cpu_seconds)
-            ref = cpu_reference_code(seq, pq, pt, fe, 5.0)
+            out["cpu_baseline"] = cpu_baseline(seq, pq, pt, SEED, 1e-4, args.cpu_seconds)
+            ref = cpu_reference_code(seq, pq, pt, SEED, 1e-4, 5.0)
             if ref is not None:
                 out["cpu_baseline_reference_code"] = ref
         print(json.dumps(out), flush=True)
 
-    fe.close()
+    if fe is not None:
+        fe.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+# Measured issue cost per wave-instruction per SIMD on this chip (tools/ubench/valu_rate.hip, profiles/r01_ubench): the
+# classes the two ORB kernels are made of.  ns per wave-instruction per SIMD at 4 waves per SIMD, all 256 CUs busy.
+ISSUE_NS = {"f32_or_simple_int": 1.10, "vop3_int": 1.90, "f64": 2.20, "xor_sgpr_plus_bcnt_pair": 3.34}
+N_SIMD = 256 * 4
+
+
+def issue_roofline(n_kp, n_pairs, ham_ms, rsc_ms, hamming_mode):
+    """The instruction-issue roofline of the two ORB stages: wave-instructions per batch (counted by rocprofv3 PMC,
+    SQ_INSTS_VALU and friends, in the committed profile named in `source` -- a static figure of the same workload, not
+    collected in this run) x the measured issue cost of their instruction class / the stage time of THIS run.  frac =
+    the share of the stage time the SIMDs need just to issue the stage's VALU instructions."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    out = {"unit": "fraction of the stage time spent issuing its VALU instructions on %d SIMDs" % N_SIMD,
+           "issue_ns_per_wave_instruction": ISSUE_NS, "source": None, "stages": {}}
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return out
+    out["source"] = "profiles/r02_pmc_summary.json (static: %s)" % pmc.get("collected_with", "rocprofv3 --pmc")
+    for stage, ms in (("hamming", ham_ms), ("select_ransac", rsc_ms)):
+        rec = pmc.get(stage)
+        if not rec or not ms:
+            continue
+        if stage == "hamming" and int(rec.get("hamming_mode", -1)) != int(hamming_mode):
+            continue
+        scale = n_pairs / float(rec.get("pairs_per_batch", n_pairs))
+        insts = rec.get("valu_wave_instructions_per_batch", 0.0) * scale
+        ns = rec.get("mean_issue_ns", ISSUE_NS["f32_or_simple_int"])
+        t_issue_ms = insts * ns / N_SIMD * 1e-6
+        out["stages"][stage] = {"valu_wave_instructions": round(insts), "mean_issue_ns": ns,
+                                "issue_time_ms": round(t_issue_ms, 4), "stage_time_ms": round(ms, 4),
+                                "frac": round(t_issue_ms / ms, 4),
+                                "valu_busy_frac_pmc": rec.get("valu_busy_frac"),
+                                "hbm_bytes_per_batch_pmc": rec.get("hbm_bytes_per_launch")}
+    return out
+
+
+def match_roofline(n_kp, n_pairs, ham_ms, hamming_mode):
+    """The Hamming stage against the unit it actually runs on: the fp4 matrix cores (2 * N * N * 256 FLOP per pair,
+    dense fp4 peak 10 PFLOP/s, MI355X_MICROARCH.md) or, for the popcount kernel, the integer VALU lanes
+    (16 * N * (N - 1) lane-ops per pair: 8 xor + 8 bcnt per 256-bit compare)."""
+    if not ham_ms:
+        return None
+    if hamming_mode != 0:
+        tf = 2.0 * n_kp * n_kp * 256 * n_pairs / (ham_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "hamming_mfma_kernel (v_mfma_f32_32x32x64_f8f6f4, fp4 x fp4)",
+                "achieved": round(tf, 2), "peak": 10000.0, "unit": "TFLOP/s", "frac": round(tf / 10000.0, 5),
+                "flop_per_pair": 2.0 * n_kp * n_kp * 256, "avg_launch_ms": round(ham_ms, 4), "time_basis": "serial"}
+    ops = 16.0 * n_kp * (n_kp - 1) * n_pairs / (ham_ms * 1e-3)
+    return {"bound": "valu", "kernel": "hamming_nn_kernel (v_xor_b32 + v_bcnt_u32_b32)", "achieved": round(ops / 1e12, 3),
+            "peak": round(VALU_PEAK_LANEOPS / 1e12, 3), "unit": "T lane-ops/s", "frac": round(ops / VALU_PEAK_LANEOPS, 4),
+            "avg_launch_ms": round(ham_ms, 4), "time_basis": "serial"}
+
+
+def sift_subrecord(seq, device):
+    """configs[3] on a bounded workload (100 frames x 20 candidates = 2000 pairs per step): pairs/s and the MFMA
+    fraction of the dot-product kernel, serial stage times."""
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd._lib import KERNEL_RANSAC, KERNEL_SIFT_DOT, KERNEL_SIFT_FINISH, RESULT_DTYPE
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    import torch
+    F = 100
+    N = seq["desc"].shape[1]
+    sd = synth.sift_descriptors_like(seq["desc"][:F], seed=SEED)
+    pq, pt = synth.candidate_pairs(F, per_frame=20, seed=SEED)
+    fe = FrontEnd(device_id=device, max_nodes=F, max_keypoints=((N + 63) // 64) * 64, max_pairs_per_batch=len(pq), seed=SEED)
+    for f in range(F):
+        fe.upload_sift_node(f, sd[f], seq["xyz1"][f])
+    bufs = [torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    for k in range(2):
+        fe.submit_sift_pair_list(pq, pt, bufs[k % 4].data_ptr())
+    fe.synchronize()
+    steps = 8
+    t0 = time.perf_counter()
+    for k in range(steps):
+        fe.submit_sift_pair_list(pq, pt, bufs[k % 4].data_ptr())
+    fe.synchronize()
+    dt = time.perf_counter() - t0
+    fe.set_profiling(True)
+    fe.reset_kernel_time()
+    for k in range(3):
+        fe.wait_ticket(fe.submit_sift_pair_list(pq, pt, bufs[0].data_ptr()), None)
+    fe.synchronize()
+    fe.set_profiling(False)
+    dot_ms, nl, _ = fe.kernel_time(KERNEL_SIFT_DOT)
+    fin_ms, _, _ = fe.kernel_time(KERNEL_SIFT_FINISH)
+    rsc_ms, _, _ = fe.kernel_time(KERNEL_RANSAC)
+    dot_ms, fin_ms, rsc_ms = dot_ms / max(nl, 1), fin_ms / max(nl, 1), rsc_ms / max(nl, 1)
+    fe.close()
+    tf = 2.0 * N * N * 128 * len(pq) / (dot_ms * 1e-3) / 1e12 if dot_ms else 0.0
+    return {"metric": "frame-pairs matched+RANSAC/sec, SIFT 128-d float, %d kp (configs[3])" % N,
+            "value": round(steps * len(pq) / dt, 2), "unit": "frame-pairs/s", "pairs_per_step": len(pq),
+            "ms_per_step": round(dt / steps * 1e3, 4),
+            "roofline": {"bound": "mfma", "kernel": "sift dot-product + top-2", "achieved": round(tf, 3), "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5), "flop_per_pair": 2.0 * N * N * 128,
+                         "avg_launch_ms": round(dot_ms, 4), "time_basis": "serial", "traffic": None},
+            "serial_stage_ms": {"dot_top2": round(dot_ms, 4), "finish": round(fin_ms, 4), "select_ransac": round(rsc_ms, 4)}}
+
+
+def detect_subrecord(device):
+    """Level B: rgbdfe_detect_describe on synthetic frames, host buffers in and out (PCIe and the
+    adjuster's round trips included).  B_frame = 13.4 * W * H + 64 * N algorithmic bytes per frame."""
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    out = {}
+    for (w, h, n_kp, n_frames) in ((640, 480, 1000, 12), (1280, 960, 4000, 4)):
+        seq = synth.make_image_sequence(n_frames=n_frames, seed=1, width=w, height=h)
+        masks = [np.where(m > 0, 255, 0).astype(np.uint8) for m in seq["mask"]]
+        fe = FrontEnd(device_id=device, max_nodes=4, max_keypoints=((n_kp + 63) // 64) * 64, max_pairs_per_batch=8)
+        fe.detector_configure(max_keypoints=n_kp)
+        for f in range(min(3, n_frames)):
+            fe.detect_describe(seq["gray"][f], masks[f], seq["depth"][f], seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+        reps = 4
+        tot = 0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for f in range(n_frames):
+                kp, _, _ = fe.detect_describe(seq["gray"][f], masks[f], seq["depth"][f], seq["fx"], seq["fy"],
+                                              seq["cx"], seq["cy"])
+                tot += len(kp)
+        dt = time.perf_counter() - t0
+        fe.close()
+        frames = reps * n_frames
+        b_frame = 13.4 * w * h + 64 * n_kp
+        gbs = frames * b_frame / dt / 1e9
+        out["%dx%d_orb%d" % (w, h, n_kp)] = {
+            "value": round(frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),
+            "mean_keypoints": round(tot / frames, 1),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_frame": b_frame,
+                         "time_basis": "host wall clock per frame, PCIe and host round trips included", "traffic": None}}
+    return out
 
 
 def usable_cpus(hardware_threads):
@@ -314,11 +478,11 @@ def usable_cpus(hardware_threads):
     return max(1, n)
 
 
-def cpu_baseline(seq, pq, pt, fe, budget_s):
+def cpu_baseline(seq, pq, pt, seed, depth_cov, budget_s):
     """The oracle (CPU restatement of the reference pair path, kind='port') timed pair-parallel
     on this host's cores over a bounded sample of the same pair list."""
     from oracle import pyoracle as po
-    prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov)
+    prm = po.default_params(seed=seed, depth_cov=depth_cov)
     cores = usable_cpus(po.num_cores())
     descs, xyzs = list(seq["desc"]), list(seq["xyz1"])
     ids = np.arange(len(descs))
@@ -337,14 +501,14 @@ def cpu_baseline(seq, pq, pt, fe, budget_s):
                       % (n, len(pq), cores, po.num_cores())}
 
 
-def cpu_reference_code(seq, pq, pt, fe, budget_s):
+def cpu_reference_code(seq, pq, pt, seed, depth_cov, budget_s):
     """The reference's OWN pair op (Node::matchNodePair and everything below it, compiled from the reference
     sources into oracle/_ref/libref_ransac.so with Eigen / PCL stand-ins) timed on one host
     thread over a bounded sample.  Reported next to cpu_baseline; None when the prebuilt pin is absent."""
     from oracle import pyoracle as po
     if po.ref_ransac_lib() is None:
         return None
-    prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov)
+    prm = po.default_params(seed=seed, depth_cov=depth_cov)
     descs, xyzs = seq["desc"], seq["xyz1"]
     sel = np.linspace(0, len(pq) - 1, min(len(pq), 400)).astype(np.int64)
     n = 0

@@ -54,3 +54,41 @@ def all_gather_results(local_records, n_pairs: int, group=None):
     dist.all_gather_into_tensor(out, local, group=group)
     g = np.frombuffer(out.cpu().numpy().tobytes(), dtype=RESULT_DTYPE).reshape(world, n_pad)
     return unshard(g, n_pairs, world)
+
+
+def all_gather_edges(local_records, n_pairs: int, group=None):
+    """All-gather of the ACCEPTED edges only (for an all-pairs loop-closure sweep most pairs are
+    rejected, id1 == -1, and need not travel).  Every rank compacts its accepted records, the ranks exchange their
+    counts (one small all-gather), pad to the largest count and exchange the records plus their global pair indices.
+    local_records: this rank's RESULT_DTYPE records in shard order (numpy).  Returns (pair_index int64 [E], records [E])
+    in global pair order, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    local_records = np.asarray(local_records)
+    keep = np.flatnonzero(local_records["id1"] >= 0)
+    gidx = rank + world * keep.astype(np.int64)
+    assert len(local_records) == len(range(rank, n_pairs, world))
+    cnt = torch.tensor([len(keep)], dtype=torch.int64)
+    cnts = torch.zeros(world, dtype=torch.int64)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    n_pad = int(cnts.max().item())
+    rec = RESULT_DTYPE.itemsize
+    if n_pad == 0:
+        return np.zeros(0, np.int64), np.zeros(0, RESULT_DTYPE)
+    buf = np.zeros(n_pad, RESULT_DTYPE)
+    buf[: len(keep)] = local_records[keep]
+    ibuf = np.full(n_pad, -1, np.int64)
+    ibuf[: len(keep)] = gidx
+    t_rec = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy())
+    t_idx = torch.from_numpy(ibuf)
+    o_rec = torch.empty(world * n_pad * rec, dtype=torch.uint8)
+    o_idx = torch.empty(world * n_pad, dtype=torch.int64)
+    dist.all_gather_into_tensor(o_rec, t_rec, group=group)
+    dist.all_gather_into_tensor(o_idx, t_idx, group=group)
+    allrec = np.frombuffer(o_rec.numpy().tobytes(), dtype=RESULT_DTYPE)
+    allidx = o_idx.numpy()
+    sel = np.flatnonzero(allidx >= 0)
+    order = sel[np.argsort(allidx[sel], kind="stable")]
+    return allidx[order].copy(), allrec[order].copy()

@@ -109,6 +109,20 @@ class FrontEnd:
     def set_hamming_mode(self, mode: int):
         """0 = popcount kernel, 1 = fp4 MFMA kernel (default), 2 = MFMA kernel with the VALU row term."""
         self._check(self._L.rgbdfe_set_hamming_mode(self._ctx, mode))
+        self._hamming_mode = int(mode)
+
+    @property
+    def hamming_mode(self) -> int:
+        """The Hamming kernel in use (the library falls back to 0 above 32768 keypoints per node)."""
+        import os
+        m = getattr(self, "_hamming_mode", None)
+        if m is None:
+            try:
+                m = int(os.environ.get("RGBDFE_HAMMING_MODE", "1"))
+            except ValueError:
+                m = 1
+            m = m if 0 <= m <= 2 else 1
+        return 0 if self.cfg.max_keypoints > 32768 else m
 
     def gather_transport(self) -> str:
         return self._L.rgbdfe_gather_transport(self._ctx).decode()

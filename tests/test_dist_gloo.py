@@ -42,6 +42,14 @@ def _worker(rank, world, port, n_pairs, q):
     local = _fake_records(sq, st)
     allrec = rdist.all_gather_results(local, n_pairs)
     ok = allrec.tobytes() == _fake_records(pq, pt).tobytes()
+    # accepted edges only (all-pairs sweeps): rejected pairs (id1 == -1) do not travel
+    full = _fake_records(pq, pt)
+    rej = (pq + pt) % 3 != 0
+    full["id1"][rej] = -1
+    full["id2"][rej] = -1
+    idx, edges = rdist.all_gather_edges(full[rank::world], n_pairs)
+    want = np.flatnonzero(~rej)
+    ok = ok and np.array_equal(idx, want) and edges.tobytes() == full[want].tobytes()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
