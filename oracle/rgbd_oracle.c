@@ -163,6 +163,18 @@ int orc_sample4(uint32_t seed, uint32_t uid, uint32_t iter, uint32_t n, uint32_t
 }
 
 /* ------------------------------------------------------------------------- */
+/* Sensitivity harness (tests/test_oracle_sensitivity.py).       */
+/* The arithmetic INSIDE Eigen 3.2 / PCL 1.7 is restated here from the published */
+/* algorithms and cannot be pinned on this machine (the libraries are absent).  */
+/* Every place where a plausible implementation could round differently has a   */
+/* switchable alternative; the harness runs whole bench steps under each and    */
+/* measures what changes.  0 = the restatement the kernels follow.              */
+/* ------------------------------------------------------------------------- */
+static unsigned g_variant = 0u;
+void orc_set_variant(unsigned flags) { g_variant = flags; }
+unsigned orc_get_variant(void) { return g_variant; }
+
+/* ------------------------------------------------------------------------- */
 /* 3x3 float SVD (two-sided Jacobi, Eigen::JacobiSVD<Matrix3f> as published)   */
 /* Matrices are ROW-major here: A[i*3+j].                                      */
 /* ------------------------------------------------------------------------- */
@@ -174,6 +186,7 @@ void orc_svd3(const float C[9], float U[9], float S[3], float V[9]) {
     if (a > scale) scale = a;
   }
   if (scale == 0.0f) scale = 1.0f;
+  if (g_variant & ORC_VAR_SVD_NO_PRESCALE) scale = 1.0f;
   for (int i = 0; i < 9; ++i) W[i] = C[i] / scale;
   for (int i = 0; i < 9; ++i) U[i] = V[i] = (i % 4 == 0) ? 1.0f : 0.0f;
 
@@ -185,9 +198,17 @@ void orc_svd3(const float C[9], float U[9], float S[3], float V[9]) {
 
   for (int sweep = 0; sweep < 30; ++sweep) {
     int finished = 1;
-    for (int p = 1; p < 3; ++p) {
-      for (int q = 0; q < p; ++q) {
+    for (int pi = 0; pi < 3; ++pi) {
+      {
+        /* Eigen: for p = 1..2, for q = 0..p-1 -> (1,0) (2,0) (2,1); variant: (2,1) (2,0) (1,0) */
+        static const int kP[2][3] = {{1, 2, 2}, {2, 2, 1}}, kQ[2][3] = {{0, 0, 1}, {1, 0, 0}};
+        const int ord = (g_variant & ORC_VAR_SVD_SWEEP_ORDER) ? 1 : 0;
+        const int p = kP[ord][pi], q = kQ[ord][pi];
         float threshold = precision * max_diag;
+        if (g_variant & ORC_VAR_SVD_PAIR_THRESHOLD) { /* older Eigen: relative to the pair's own diagonal */
+          float dp = fabsf(W[p * 3 + p]), dq = fabsf(W[q * 3 + q]);
+          threshold = precision * (dp > dq ? dp : dq);
+        }
         if (consider_as_zero > threshold) threshold = consider_as_zero;
         if (!(fabsf(W[p * 3 + q]) > threshold || fabsf(W[q * 3 + p]) > threshold)) continue;
         finished = 0;
@@ -314,6 +335,10 @@ void orc_fit_transform(const float* qxyz1, const float* txyz1, const int32_t* mq
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) {
         float outer = d2[i] * d1[j];
+        if (g_variant & ORC_VAR_PCL_COV_ASSOC) { /* (1-a)*C + ((1-a)*a)*outer */
+          C[i * 3 + j] = oma * C[i * 3 + j] + (oma * alpha) * outer;
+          continue;
+        }
         float scaled = alpha * outer;
         float sum = C[i * 3 + j] + scaled;
         C[i * 3 + j] = oma * sum;
@@ -336,6 +361,9 @@ void orc_fit_transform(const float* qxyz1, const float* txyz1, const int32_t* mq
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
       float us2 = U[i * 3 + 2] * s22;
+      if (g_variant & ORC_VAR_ROT_ASSOC) /* U * (S * V^T), summed from the last term */
+        R[i * 3 + j] = U[i * 3 + 0] * V[j * 3 + 0] + (U[i * 3 + 1] * V[j * 3 + 1] + U[i * 3 + 2] * (s22 * V[j * 3 + 2]));
+      else
       R[i * 3 + j] = (U[i * 3 + 0] * V[j * 3 + 0] + U[i * 3 + 1] * V[j * 3 + 1]) + us2 * V[j * 3 + 2];
     }
   float t[3];
@@ -401,6 +429,11 @@ double orc_error_function2(const float x1[4], const float x2[4], const double T[
   double S[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
+      if (g_variant & ORC_VAR_COV_ASSOC) { /* R^T * (cov1 * R) */
+        S[i * 3 + j] = (T[i * 4 + 0] * (c1[0] * T[j * 4 + 0]) + T[i * 4 + 1] * (c1[1] * T[j * 4 + 1])) +
+                       T[i * 4 + 2] * (c1[2] * T[j * 4 + 2]);
+        continue;
+      }
       double a0 = T[i * 4 + 0] * c1[0]; /* (R^T cov1)(i,0) = R(0,i)*c1_0 */
       double a1 = T[i * 4 + 1] * c1[1];
       double a2 = T[i * 4 + 2] * c1[2];
@@ -413,22 +446,41 @@ double orc_error_function2(const float x1[4], const float x2[4], const double T[
   x = S[0];
   if (!(x > 0.0)) return DBL_MAX; /* D5 */
   l00 = sqrt(x);
-  l10 = S[3] / l00;
-  l20 = S[6] / l00;
+  if (g_variant & ORC_VAR_LLT_RECIPROCAL) { /* A21 *= 1/x instead of A21 /= x */
+    const double r = 1.0 / l00;
+    l10 = S[3] * r;
+    l20 = S[6] * r;
+  } else {
+    l10 = S[3] / l00;
+    l20 = S[6] / l00;
+  }
   x = S[4] - l10 * l10;
   if (!(x > 0.0)) return DBL_MAX;
   l11 = sqrt(x);
+  if (g_variant & ORC_VAR_LLT_RECIPROCAL) l21 = (S[7] - l20 * l10) * (1.0 / l11);
+  else
   l21 = (S[7] - l20 * l10) / l11;
   x = S[8] - (l20 * l20 + l21 * l21);
   if (!(x > 0.0)) return DBL_MAX;
   l22 = sqrt(x);
   /* forward: L y = d ; backward: L^T z = y */
-  double y0 = d[0] / l00;
-  double y1 = (d[1] - l10 * y0) / l11;
-  double y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
-  double z2 = y2 / l22;
-  double z1 = (y1 - l21 * z2) / l11;
-  double z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
+  double y0, y1, y2, z0, z1, z2;
+  if (g_variant & ORC_VAR_SOLVE_ORDER) { /* triangular solves that subtract term by term, reciprocal pivots */
+    const double r0 = 1.0 / l00, r1 = 1.0 / l11, r2 = 1.0 / l22;
+    y0 = d[0] * r0;
+    y1 = (d[1] - l10 * y0) * r1;
+    y2 = ((d[2] - l20 * y0) - l21 * y1) * r2;
+    z2 = y2 * r2;
+    z1 = (y1 - l21 * z2) * r1;
+    z0 = ((y0 - l20 * z2) - l10 * z1) * r0;
+  } else {
+  y0 = d[0] / l00;
+  y1 = (d[1] - l10 * y0) / l11;
+  y2 = (d[2] - (l20 * y0 + l21 * y1)) / l22;
+  z2 = y2 / l22;
+  z1 = (y1 - l21 * z2) / l11;
+  z0 = (y0 - (l10 * z1 + l20 * z2)) / l00;
+  }
   double e = (d[0] * z0 + d[1] * z1) + d[2] * z2;
   if (!(e >= 0.0)) return DBL_MAX; /* :765-768 */
   return e;
@@ -474,6 +526,17 @@ static int orc_has_nan16(const float* T) {
 /* A.3 getRelativeTransformationTo -- src/node.cpp:1074-1277                    */
 /* matches (mq,mt) must already be sorted ascending by distance (:1127, D2).    */
 /* ------------------------------------------------------------------------- */
+/* Sensitivity harness: which inlier set the adopted transform was FITTED from (the final inlier set is what that
+ * transform then scores; two runs can agree on the latter and still have fitted from different sets). */
+static _Thread_local uint64_t tl_fit_source = 0;
+static uint64_t* g_trace = NULL; /* orc_match_pairs_mt: one word per pair */
+void orc_set_trace(uint64_t* per_pair) { g_trace = per_pair; }
+static uint64_t orc_hash_set(const int32_t* v, int n) {
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+  for (int i = 0; i < n; ++i) h = (h ^ (uint64_t)(uint32_t)v[i]) * 0x100000001b3ull;
+  return h;
+}
+
 int orc_ransac(const float* qxyz1, const float* txyz1, const int32_t* mq,
                const int32_t* mt, int n, const orc_params* prm, uint32_t uid,
                float T[16], float* rmse_out, int32_t* matches, int* n_matches_out,
@@ -486,6 +549,7 @@ int orc_ransac(const float* qxyz1, const float* txyz1, const int32_t* mq,
   if (n <= prm->min_matches) { /* :1087 -- rmse is left untouched by the reference */
     return 0;
   }
+  tl_fit_source = 0;
   unsigned int min_inlier_threshold = (unsigned int)prm->min_matches; /* :1094 */
   if ((double)min_inlier_threshold > 0.75 * (double)n)                 /* :1095 */
     min_inlier_threshold = (unsigned int)(0.75 * (double)n);           /* :1098 */
@@ -510,8 +574,10 @@ int orc_ransac(const float* qxyz1, const float* txyz1, const int32_t* mq,
     int n_inl = orc_sample4(prm->seed, uid, (uint32_t)real_iterations, (uint32_t)n, ids); /* :1135 */
     for (int i = 0; i < n_inl; ++i) inlier[i] = (int32_t)ids[i];
     real_iterations++; /* :1139 */
+    uint64_t refined_src = 0;
     for (int refinements = 1; refinements < 20; refinements++) { /* :1140 */
       float Tn[16];
+      const uint64_t src = g_trace ? orc_hash_set(inlier, n_inl) : 0;
       orc_fit_transform(qxyz1, txyz1, mq, mt, inlier, n_inl, Tn); /* :1142 */
       if (orc_has_nan16(Tn)) break;                                /* :1144 */
       n_inl = orc_compute_inliers_and_error(qxyz1, txyz1, mq, mt, n, Tn, sq_max,
@@ -524,6 +590,7 @@ int orc_ransac(const float* qxyz1, const float* txyz1, const int32_t* mq,
         memcpy(refined, inlier, sizeof(int32_t) * (size_t)n_inl);
         n_refined = n_inl;
         refined_error = inlier_error;
+        refined_src = src;
         if (n_inl == prev) break; /* :1166 */
       } else
         break;
@@ -533,6 +600,7 @@ int orc_ransac(const float* qxyz1, const float* txyz1, const int32_t* mq,
       if (refined_error <= (double)rmse && n_refined >= n_matches &&
           (unsigned int)n_refined >= min_inlier_threshold) { /* :1177-1179 */
         rmse = (float)refined_error; /* :1182 double -> float */
+        tl_fit_source = refined_src;
         memcpy(T, refined_T, sizeof(refined_T));
         memcpy(matches, refined, sizeof(int32_t) * (size_t)n_refined);
         n_matches = n_refined;
@@ -608,8 +676,10 @@ void orc_match_pairs_mt(const uint8_t* const* desc, const float* const* xyz1,
 #endif
   for (int p = 0; p < n_pairs; ++p) {
     int q = pair_q[p], t = pair_t[p];
+    tl_fit_source = 0;
     orc_match_node_pair(desc[q], xyz1[q], counts[q], node_ids[q], desc[t], xyz1[t], counts[t],
                         node_ids[t], prm, &out[p]);
+    if (g_trace) g_trace[p] = tl_fit_source;
   }
 }
 

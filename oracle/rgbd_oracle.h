@@ -120,6 +120,23 @@ void orc_match_sift_node_pair(const float* qdesc, const float* qxyz1, int nq, in
                               const float* tdesc, const float* txyz1, int nt, int32_t tid,
                               const orc_params* prm, orc_result* out, float* all_dist);
 
+
+/* Sensitivity harness: alternative roundings of the third-party arithmetic (Eigen 3.2 JacobiSVD / LLT, PCL 1.7
+ * TransformationFromCorrespondences) that cannot be pinned here.  0 = the restatement the kernels follow. */
+#define ORC_VAR_LLT_RECIPROCAL     0x001u  /* LLT column scaling  A21 *= 1/x  instead of  A21 /= x  (misc.cpp:763) */
+#define ORC_VAR_SOLVE_ORDER        0x002u  /* triangular solves: term-by-term subtraction, reciprocal pivots */
+#define ORC_VAR_SVD_SWEEP_ORDER    0x004u  /* Jacobi sweeps visit (2,1) (2,0) (1,0) instead of (1,0) (2,0) (2,1) */
+#define ORC_VAR_SVD_PAIR_THRESHOLD 0x008u  /* rotation skipped relative to the pair's own diagonal (older Eigen) */
+#define ORC_VAR_SVD_NO_PRESCALE    0x010u  /* no division of the matrix by its largest coefficient */
+#define ORC_VAR_PCL_COV_ASSOC      0x020u  /* (1-a)*C + ((1-a)*a)*d2*d1^T  instead of  (1-a)*(C + a*d2*d1^T) */
+#define ORC_VAR_ROT_ASSOC          0x040u  /* R = U*(S*V^T), dot products summed from the last term */
+#define ORC_VAR_COV_ASSOC          0x080u  /* errorFunction2: R^T*(cov1*R) instead of (R^T*cov1)*R */
+#define ORC_VAR_ALL                0x0FFu
+void orc_set_variant(unsigned flags);
+unsigned orc_get_variant(void);
+/* per-pair trace of orc_match_pairs_mt: a hash of the inlier set the adopted transform was fitted from (0 = none) */
+void orc_set_trace(uint64_t* per_pair);
+
 #ifdef __cplusplus
 }
 #endif

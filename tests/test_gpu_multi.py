@@ -23,7 +23,7 @@ def data():
 
 def _fe(seq, device_ids=None, cap=256, **kw):
     from rgbdslam_v2_amd.frontend import FrontEnd
-    fe = FrontEnd(device_id=0, max_nodes=16, max_keypoints=512, max_pairs_per_batch=cap, device_ids=device_ids, **kw)
+    fe = FrontEnd(device_id=0, max_nodes=24, max_keypoints=512, max_pairs_per_batch=cap, device_ids=device_ids, **kw)
     for f in range(seq["desc"].shape[0]):
         fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
     return fe
