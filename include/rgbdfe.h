@@ -196,6 +196,18 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
                          double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
                          float* xyz1, int32_t* n_out);
 
+/* a22 (i), the Node constructor that receives the sensor's organised point cloud (node.cpp:252-369):
+ * rgbdfe_project_to_3d_cloud is Node::projectTo3D's point-cloud overload (node.cpp:855-898): lookup
+ * point_cloud->at((int)x, (int)y) -- truncation --, drop when z > maximum_depth ("maximum_depth") or a coordinate is NaN,
+ * the cloud's own (x, y, z, 1) is stored, cut at max_keypoints.  cloud: rows x cols x 4 float (x, y, z, rgb), host.
+ * rgbdfe_detect_describe_cloud is that constructor's feature path: detect (:293) -> projectTo3D(cloud) (:308) ->
+ * compute (:311), with the detector state / max_keypoints of rgbdfe_detector_configure; no removeDepthless, no
+ * retainBest.  The 3-D points stay with their keypoints through compute()'s border filter and regrouping (the
+ * reference leaves feature_locations_3d_ out of step there, its assert at :318). */
+int rgbdfe_project_to_3d_cloud(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* cloud, int32_t rows,
+                               int32_t cols, double maximum_depth, int32_t max_keypoints, int32_t* kept_idx, float* xyz1,
+                               int32_t* n_out);
+
 /* a20, SIFTGPU feature path: Node::projectTo3DSiftGPU (node.cpp:695-769) -- depth lookup with the
  * keypoint coordinates TRUNCATED to int (:733), no inside-the-image test (indices are clamped here
  * where the reference would read out of bounds), NaN depth drops the keypoint, stop at max_keypoints
@@ -328,6 +340,10 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
                            int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
                            double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
                            float* xyz1, int32_t* n_out);
+/* the point-cloud constructor's feature path (see rgbdfe_project_to_3d_cloud above) */
+int rgbdfe_detect_describe_cloud(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* cloud,
+                                 int32_t rows, int32_t cols, double maximum_depth, rgbdfe_keypoint* keypoints,
+                                 uint8_t* descriptors, float* xyz1, int32_t* n_out);
 /* pieces, for A/B against cv::ORB: detect() of one image with a fixed FAST threshold (no grid,
  * feature_adjuster.cpp:94) and compute() for given keypoints (may drop border keypoints and
  * regroups them by octave, like cv::ORB::compute). */

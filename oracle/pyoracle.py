@@ -102,6 +102,8 @@ def lib():
         L.orc_match_pairs_mt.restype = None
         L.orc_match_pairs_mt.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(OrcParams),
                                          vp, C.c_int]
+        L.orc_project_to_3d_cloud.restype = C.c_int
+        L.orc_project_to_3d_cloud.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp]
         L.orc_project_to_3d_sift.restype = C.c_int
         L.orc_project_to_3d_sift.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_double,
                                              C.c_double, C.c_double, C.c_double, C.c_int, vp, vp]
@@ -290,6 +292,8 @@ def ref_frame_lib():
         R.ref_remove_depthless.argtypes = [vp, i, vp, i, i, vp]
         R.ref_project_to_3d.restype = i
         R.ref_project_to_3d.argtypes = [vp, i, vp, i, i, d, d, d, d, d, i, vp, vp]
+        R.ref_project_to_3d_cloud.restype = i
+        R.ref_project_to_3d_cloud.argtypes = [vp, i, vp, i, i, d, i, vp, vp]
         R.ref_project_to_3d_sift.restype = i
         R.ref_project_to_3d_sift.argtypes = [vp, i, vp, vp, i, i, d, d, d, d, d, i, vp, vp, vp, vp]
         R.ref_root_sift.restype = None
@@ -481,6 +485,18 @@ def project_to_3d(kp_xy, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints
     xyz1 = np.empty((max(n, 1), 4), np.float32)
     k = lib().orc_project_to_3d(_p(kp_xy), n, _p(depth), depth.shape[0], depth.shape[1],
                                 fx, fy, cx, cy, depth_scaling, max_keypoints, _p(kept), _p(xyz1))
+    return kept[:k].copy(), xyz1[:k].copy()
+
+
+def project_to_3d_cloud(kp_xy, cloud, maximum_depth, max_keypoints=1000):
+    """Node::projectTo3D, point-cloud overload (node.cpp:855-898).  cloud: [rows, cols, 4] float32."""
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    n = kp_xy.shape[0]
+    kept = np.empty(max(n, 1), np.int32)
+    xyz1 = np.empty((max(n, 1), 4), np.float32)
+    k = lib().orc_project_to_3d_cloud(_p(kp_xy), n, _p(cloud), cloud.shape[0], cloud.shape[1], maximum_depth,
+                                      max_keypoints, _p(kept), _p(xyz1))
     return kept[:k].copy(), xyz1[:k].copy()
 
 

@@ -32,6 +32,22 @@ extern "C" int ref_project_to_3d(const float* kp_xy, int n, const float* depth, 
   for (size_t i = 0; i < p3.size(); ++i) { kept[i] = k[i].class_id; for (int c = 0; c < 4; ++c) xyz1[4 * i + c] = p3[i](c); }
   return (int)p3.size();
 }
+extern "C" int ref_project_to_3d_cloud(const float* kp_xy, int n, const float* cloud_xyzrgb, int rows, int cols,
+                                       double maximum_depth, int max_keypoints, int32_t* kept, float* xyz1) {
+  g_fp.maximum_depth = maximum_depth; g_fp.max_keypoints = max_keypoints;
+  std::vector<cv::KeyPoint> k = make_kps(kp_xy, n);
+  std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> > p3;
+  pointcloud_type* pc = new pointcloud_type();
+  pc->width = (uint32_t)cols; pc->height = (uint32_t)rows; pc->is_dense = false;
+  pc->points.resize((size_t)rows * cols);
+  for (size_t i = 0; i < pc->points.size(); ++i) {
+    pc->points[i].x = cloud_xyzrgb[4 * i]; pc->points[i].y = cloud_xyzrgb[4 * i + 1]; pc->points[i].z = cloud_xyzrgb[4 * i + 2];
+  }
+  Node node;
+  node.projectTo3D(k, p3, pointcloud_type::ConstPtr(pc));
+  for (size_t i = 0; i < p3.size(); ++i) { kept[i] = k[i].class_id; for (int c = 0; c < 4; ++c) xyz1[4 * i + c] = p3[i](c); }
+  return (int)p3.size();
+}
 extern "C" int ref_project_to_3d_sift(const float* kp_xy, int n, const float* desc_in, const float* depth, int rows, int cols,
                                       double fx, double fy, double cx, double cy, double depth_scaling, int max_keypoints,
                                       int32_t* kept, float* xyz1, float* desc_out, float* siftgpu_out) {

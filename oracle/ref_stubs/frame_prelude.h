@@ -3,7 +3,7 @@
 // so that these compile FROM WHERE THEY LIE in /root/reference into oracle/_ref/libref_frame.so:
 //   removeDepthless                 src/node.cpp:66-97
 //   Node::projectTo3DSiftGPU        src/node.cpp:695-769
-//   Node::projectTo3D               src/node.cpp:900-965
+//   Node::projectTo3D               src/node.cpp:900-965 (depth image) and :855-898 (point cloud)
 //   squareroot_descriptor_space     src/node.cpp:1557-1571
 //   backProject                     src/misc2.h:49-65
 //   getCameraIntrinsics*            src/misc.cpp:56-69
@@ -31,6 +31,7 @@
 #define ROS_WARN(...)
 #define ROS_ERROR(...)
 #define ROS_DEBUG(...)
+#define ROS_DEBUG_NAMED(...)
 #define ROS_INFO_STREAM(x)
 #define ROS_WARN_STREAM(x)
 #define ROS_ERROR_STREAM(x)
@@ -144,6 +145,7 @@ struct point_type {
 };
 struct pointcloud_type {
   typedef std::shared_ptr<pointcloud_type> Ptr;
+  typedef std::shared_ptr<const pointcloud_type> ConstPtr;
   typedef std::vector<point_type>::iterator iterator;
   std::vector<point_type> points;
   uint32_t width = 0, height = 0;
@@ -176,6 +178,9 @@ class Node {
   void projectTo3D(std::vector<cv::KeyPoint>& feature_locations_2d,
                    std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> >& feature_locations_3d,
                    const cv::Mat& depth, const sensor_msgs::CameraInfoConstPtr& cam_info);
+  void projectTo3D(std::vector<cv::KeyPoint>& feature_locations_2d,
+                   std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> >& feature_locations_3d,
+                   pointcloud_type::ConstPtr point_cloud);
   void projectTo3DSiftGPU(std::vector<cv::KeyPoint>& feature_locations_2d,
                           std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> >& feature_locations_3d,
                           const cv::Mat& depth, const sensor_msgs::CameraInfoConstPtr& cam_info,

@@ -727,6 +727,35 @@ int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows
 }
 
 /* ------------------------------------------------------------------------- */
+/* a22(i)  Node::projectTo3D, point-cloud overload -- node.cpp:855-898 (the ctor   */
+/* that receives the sensor's organised cloud, node.cpp:252-369: detect ->         */
+/* projectTo3D(cloud) -> compute, no retainBest).  The lookup truncates the        */
+/* coordinates, point_cloud->at((int)x, (int)y) (:877); a point is dropped when     */
+/* z > maximum_depth (float promoted to double) or any coordinate is NaN (:880);    */
+/* the stored point is the cloud's own (x, y, z, 1) (:887); cut at max_keypoints.   */
+/* cloud: rows x cols x 4 float (x, y, z, rgb).                                    */
+/* ------------------------------------------------------------------------- */
+int orc_project_to_3d_cloud(const float* kp_xy, int n_kp, const float* cloud, int rows, int cols,
+                            double maximum_depth, int max_keypoints, int32_t* kept_idx, float* xyz1) {
+  int n = 0;
+  for (int i = 0; i < n_kp; ++i) {
+    float px = kp_xy[2 * i], py = kp_xy[2 * i + 1];
+    if (px >= (float)cols || px < 0 || py >= (float)rows || py < 0 || isnan(px) || isnan(py))
+      continue; /* :868-875 (width/height are uint32: the comparison is done in float) */
+    const float* p3 = cloud + 4 * ((size_t)(int)py * (size_t)cols + (size_t)(int)px); /* :877 */
+    if (((double)p3[2] > maximum_depth) || isnan(p3[0]) || isnan(p3[1]) || isnan(p3[2])) continue; /* :880 */
+    xyz1[4 * n + 0] = p3[0];
+    xyz1[4 * n + 1] = p3[1];
+    xyz1[4 * n + 2] = p3[2];
+    xyz1[4 * n + 3] = 1.0f; /* :887 */
+    kept_idx[n] = i;
+    ++n;
+    if (n >= max_keypoints) break; /* :889 */
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------- */
 /* a20  Node::projectTo3DSiftGPU -- node.cpp:695-769 (SIFTGPU feature path)     */
 /* Differences to orc_project_to_3d: the depth lookup is depth.at<float>(p2d.y,  */
 /* p2d.x), i.e. the float coordinates are converted to int by TRUNCATION (:733),  */

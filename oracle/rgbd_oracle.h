@@ -109,6 +109,8 @@ void orc_emm_erf_boundaries(double* q_lo, double* q_hi);
 int orc_observation_criterion_met(unsigned int inliers, unsigned int outliers, unsigned int all,
                                   double obs_thresh, double* quality);
 /* a20: projectTo3DSiftGPU (node.cpp:695-769) and squareroot_descriptor_space (node.cpp:1557-1571) */
+int orc_project_to_3d_cloud(const float* kp_xy, int n_kp, const float* cloud, int rows, int cols,
+                            double maximum_depth, int max_keypoints, int32_t* kept_idx, float* xyz1);
 int orc_project_to_3d_sift(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                            double fx, double fy, double cx, double cy, double depth_scaling,
                            int max_keypoints, int32_t* kept_idx, float* xyz1);

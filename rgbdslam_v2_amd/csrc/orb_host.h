@@ -26,7 +26,9 @@ struct OrbWorkspace {
   // enqueue_more (optional) is called after the descriptor work has been enqueued and before the one synchronisation,
   // so that the caller's own launches on the stream ride on the same round trip
   int compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
-              const std::function<int()>& enqueue_more = nullptr);
+              const std::function<int()>& enqueue_more = nullptr, std::vector<int>* order_out = nullptr);
+  // (order_out: the positions, in the input list, of the keypoints that survive compute()'s border filter, in the
+  // level-grouped order of the output)
 
   // detector state (the reference's detector_ object, openni_listener.h:195)
   int grid = 3, adjuster_iters = 5, cell_min = 0, cell_max = 0, max_total = 0;

@@ -359,24 +359,30 @@ int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::strin
 
 // cv::ORB::create()->compute (features.cpp:117-119): border filter, regroup by level, rBRIEF
 int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
-                          const std::function<int()>& enqueue_more) {
-  {  // KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31)
-    size_t m = 0;
-    for (const KpOut& k : kps)
-      if (k.x >= kComputeEdge && k.x < W - kComputeEdge && k.y >= kComputeEdge && k.y < H - kComputeEdge) kps[m++] = k;
-    kps.resize(m);
-  }
+                          const std::function<int()>& enqueue_more, std::vector<int>* order_out) {
+  // KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31), then the stable regroup by level (orb.cpp:
+  // !sortedByLevel branch); `order` = the surviving input positions in output order
+  std::vector<int> order;
+  order.reserve(kps.size());
   int nlevels = 1;
-  for (const KpOut& k : kps) nlevels = std::max(nlevels, std::max(k.octave, 0) + 1);
+  auto inside = [&](const KpOut& k) {
+    return k.x >= kComputeEdge && k.x < W - kComputeEdge && k.y >= kComputeEdge && k.y < H - kComputeEdge;
+  };
+  for (const KpOut& k : kps)
+    if (inside(k)) nlevels = std::max(nlevels, std::max(k.octave, 0) + 1);
   if (nlevels > kLevels) { err = "keypoint octave beyond the 8-level pyramid"; return RGBDFE_ERR_INVALID_ARG; }
-  {  // stable regroup by level (orb.cpp: !sortedByLevel branch)
+  for (int l = 0; l < nlevels; ++l)
+    for (size_t i = 0; i < kps.size(); ++i) {
+      const KpOut& k = kps[i];
+      if (k.octave == l && inside(k)) order.push_back((int)i);
+    }
+  {
     std::vector<KpOut> t;
-    t.reserve(kps.size());
-    for (int l = 0; l < nlevels; ++l)
-      for (const KpOut& k : kps)
-        if (k.octave == l) t.push_back(k);
+    t.reserve(order.size());
+    for (int i : order) t.push_back(kps[(size_t)i]);
     kps.swap(t);
   }
+  if (order_out) *order_out = order;
   const int n = (int)kps.size();
   desc.assign((size_t)n * 32, 0);
   if (n == 0) return RGBDFE_OK;

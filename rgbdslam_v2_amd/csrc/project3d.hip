@@ -85,6 +85,52 @@ __global__ __launch_bounds__(256) void project_to_3d_kernel(
   if (tid == 0) *n_out = (int32_t)min(base, (uint32_t)max_keypoints);
 }
 
+// Node::projectTo3D, point-cloud overload (src/node.cpp:855-898; the ctor that is handed the sensor's organised cloud,
+// :252-369): lookup point_cloud->at((int)x, (int)y) -- truncation (:877) --, drop when z > maximum_depth or a coordinate
+// is NaN (:880), keep the cloud's own (x, y, z, 1) (:887), cut at max_keypoints (:889).  `pts` holds the looked-up cloud
+// point of every keypoint (gathered by the caller: 16 bytes per keypoint cross PCIe instead of the 4.9 MB cloud), or the
+// whole cloud when `gathered` is 0.  Same order-preserving compaction as project_to_3d_kernel.
+__global__ __launch_bounds__(256) void project_cloud_kernel(const float2* __restrict__ kp, int n_kp,
+                                                           const float4* __restrict__ pts, int gathered, int rows,
+                                                           int cols, double maximum_depth, int max_keypoints,
+                                                           int32_t* __restrict__ kept_idx, float4* __restrict__ xyz1,
+                                                           int32_t* __restrict__ n_out) {
+  __shared__ uint32_t wave_cnt[4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  uint32_t base = 0;
+  for (int c0 = 0; c0 < n_kp; c0 += 256) {
+    const int i = c0 + tid;
+    bool keep = false;
+    float4 p3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n_kp) {
+      const float2 p = kp[i];
+      const bool bad = p.x >= (float)cols || p.x < 0.f || p.y >= (float)rows || p.y < 0.f || __builtin_isnan(p.x) ||
+                       __builtin_isnan(p.y);  // :868-875
+      if (!bad) {
+        p3 = gathered ? pts[i] : pts[(size_t)(int)p.y * (size_t)cols + (size_t)(int)p.x];  // :877
+        keep = !(((double)p3.z > maximum_depth) || __builtin_isnan(p3.x) || __builtin_isnan(p3.y) || __builtin_isnan(p3.z));
+      }
+    }
+    const uint64_t m = __ballot(keep);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base;
+    for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+    const uint32_t chunk_total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    const uint32_t pos = off + rank;
+    if (keep && pos < (uint32_t)max_keypoints) {
+      xyz1[pos] = make_float4(p3.x, p3.y, p3.z, 1.0f);  // :887
+      kept_idx[pos] = i;
+    }
+    base += chunk_total;
+    __syncthreads();
+    if (base >= (uint32_t)max_keypoints) break;  // :889
+  }
+  if (tid == 0) *n_out = (int32_t)min(base, (uint32_t)max_keypoints);
+}
+
 // One wave per kept keypoint: row y of `raw` (siftgpu_descriptors) and of `feat`
 // (feature_descriptors_) <- descriptors_in[kept_idx[y]]; `feat` is RootSIFT-normalised when asked.
 // Lane l holds columns 2l, 2l+1.  The L1 norm follows cv::reduce's float accumulation order
@@ -134,6 +180,13 @@ void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int 
     hipLaunchKernelGGL(project_to_3d_kernel<false>, dim3(1), dim3(256), 0, stream,
                        reinterpret_cast<const float2*>(kp_xy), n_kp, depth, rows, cols, fxinv, fyinv,
                        cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out, z_gathered);
+}
+
+void launch_project_cloud(const float* kp_xy, int n_kp, const float4* pts, bool gathered, int rows, int cols,
+                          double maximum_depth, int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(project_cloud_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<const float2*>(kp_xy), n_kp,
+                     pts, gathered ? 1 : 0, rows, cols, maximum_depth, max_keypoints, kept_idx, xyz1, n_out);
 }
 
 void launch_sift_pack(const float* desc_in, const int32_t* kept_idx, const int32_t* n_ptr, int max_rows,

@@ -1221,6 +1221,115 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
   return RGBDFE_OK;
 }
 
+// Node::projectTo3D, point-cloud overload (node.cpp:855-898).  The organised cloud stays on the host: the point under
+// every keypoint, point_cloud->at((int)x, (int)y), is gathered here (16 bytes per keypoint cross PCIe instead of the
+// whole cloud); filter, compaction and the max_keypoints cut run on the device.
+static int project_cloud_common(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* cloud, int32_t rows,
+                                int32_t cols, double maximum_depth, int32_t max_keypoints, int32_t* kept_idx, float* xyz1,
+                                int32_t* n_out) {
+  *n_out = 0;
+  if (n_kp == 0 || max_keypoints == 0) return RGBDFE_OK;
+  const size_t b_kp = ((size_t)n_kp * 8 + 255) & ~(size_t)255;
+  const size_t b_pts = ((size_t)n_kp * 16 + 255) & ~(size_t)255;
+  const size_t b_idx = ((size_t)n_kp * 4 + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, b_kp + 2 * b_pts + b_idx + 256);
+  if (rc != RGBDFE_OK) return rc;
+  char* base = (char*)ctx->d_scratch;
+  float* d_kp = (float*)base;
+  float4* d_pts = (float4*)(base + b_kp);
+  int32_t* d_idx = (int32_t*)(base + b_kp + b_pts);
+  float4* d_xyz = (float4*)(base + b_kp + b_pts + b_idx);
+  int32_t* d_n = (int32_t*)(base + b_kp + 2 * b_pts + b_idx);
+  std::vector<float> pts((size_t)n_kp * 4, 0.f);
+  for (int32_t i = 0; i < n_kp; ++i) {
+    const float x = kp_xy[2 * i], y = kp_xy[2 * i + 1];
+    if (x >= (float)cols || x < 0.f || y >= (float)rows || y < 0.f || std::isnan(x) || std::isnan(y)) continue;
+    memcpy(&pts[(size_t)i * 4], cloud + 4 * ((size_t)(int)y * (size_t)cols + (size_t)(int)x), 16);  // :877
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp_xy, (size_t)n_kp * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_pts, pts.data(), (size_t)n_kp * 16, hipMemcpyHostToDevice, ctx->stream));
+  launch_project_cloud(d_kp, n_kp, d_pts, true, rows, cols, maximum_depth, max_keypoints, d_idx, d_xyz, d_n, ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(kept_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(xyz1, d_xyz, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *n_out = n;
+  return RGBDFE_OK;
+}
+
+int rgbdfe_project_to_3d_cloud(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* cloud, int32_t rows,
+                               int32_t cols, double maximum_depth, int32_t max_keypoints, int32_t* kept_idx, float* xyz1,
+                               int32_t* n_out) {
+  if (!ctx || n_kp < 0 || rows < 1 || cols < 1 || !cloud || !kept_idx || !xyz1 || !n_out || max_keypoints < 0 ||
+      (n_kp > 0 && !kp_xy))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  return project_cloud_common(ctx, kp_xy, n_kp, cloud, rows, cols, maximum_depth, max_keypoints, kept_idx, xyz1, n_out);
+}
+
+// The feature path of the Node constructor that is handed the sensor's organised point cloud (node.cpp:252-369):
+// detector->detect (:293) -> projectTo3D(cloud) (:308, with the maximum_depth test and the max_keypoints cut) ->
+// extractor->compute (:311).  No removeDepthless, no retainBest on this path.
+// Deviation D6: cv::ORB::compute drops keypoints within 31 px of the border and regroups the rest by octave, which in
+// the reference leaves feature_locations_3d_ (filled BEFORE compute) out of step with the keypoints and descriptors
+// (its assert at :318 fires in a debug build); here the 3-D points follow their keypoints.
+int rgbdfe_detect_describe_cloud(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* cloud,
+                                 int32_t rows, int32_t cols, double maximum_depth, rgbdfe_keypoint* keypoints,
+                                 uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+  if (!ctx || !gray || !cloud || rows < 1 || cols < 1 || !keypoints || !descriptors || !xyz1 || !n_out)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  ensure_detector(ctx);
+  OrbWorkspace& orb = ctx->orb;
+  const int max_kp = ctx->orb_max_keypoints;
+  std::string err;
+  int rc = orb.prepare(cols, rows, true, err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  orb.cell_mask_nonzero.assign((size_t)orb.n_cells, mask ? 0 : 1);
+  if (mask)
+    for (int c = 0; c < orb.n_cells; ++c) {
+      const OrbWorkspace::Cell& ce = orb.cells[c];
+      char nz = 0;
+      for (int y = 0; y < ce.h && !nz; ++y) {
+        const uint8_t* r = mask + (size_t)(ce.y0 + y) * cols + ce.x0;
+        for (int x = 0; x < ce.w; ++x)
+          if (r[x]) { nz = 1; break; }
+      }
+      orb.cell_mask_nonzero[c] = nz;
+    }
+  rc = orb.upload_and_build(gray, mask, ctx->stream, err);
+  std::vector<KpOut> kps;
+  if (rc == RGBDFE_OK) rc = orb.grid_detect(kps, ctx->stream, err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  *n_out = 0;
+  const int n_det = (int)kps.size();
+  std::vector<float> xy((size_t)n_det * 2), pxyz((size_t)n_det * 4);
+  std::vector<int32_t> kept((size_t)std::max(n_det, 1));
+  for (int i = 0; i < n_det; ++i) { xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y; }
+  int32_t n3 = 0;
+  rc = project_cloud_common(ctx, xy.data(), n_det, cloud, rows, cols, maximum_depth, max_kp, kept.data(), pxyz.data(), &n3);
+  if (rc != RGBDFE_OK) return rc;
+  std::vector<KpOut> k3((size_t)n3);
+  for (int i = 0; i < n3; ++i) k3[i] = kps[(size_t)kept[i]];  // feature_locations_2d after the erase / resize (:874-895)
+  std::vector<uint8_t> desc;
+  std::vector<int> order;
+  rc = orb.compute(k3, desc, ctx->stream, err, nullptr, &order);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  const int n = (int)k3.size();
+  for (int i = 0; i < n; ++i) memcpy(xyz1 + 4 * (size_t)i, &pxyz[(size_t)order[i] * 4], 16);
+  kp_to_abi(k3, keypoints);
+  if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());
+  *n_out = n;
+  return RGBDFE_OK;
+}
+
 int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* desc_in,
                               const float* depth, int32_t rows, int32_t cols, double fx, double fy,
                               double cx, double cy, double depth_scaling, int32_t max_keypoints,
@@ -2066,6 +2175,22 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_FIRST(ctx, impl::rgbdfe_project_to_3d(c, kp_xy, n_kp, depth, rows, cols, fx, fy, cx, cy, depth_scaling,
                                                       max_keypoints, kept_idx, xyz1, n_out));
+}
+
+int rgbdfe_project_to_3d_cloud(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* cloud, int32_t rows,
+                               int32_t cols, double maximum_depth, int32_t max_keypoints, int32_t* kept_idx, float* xyz1,
+                               int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_project_to_3d_cloud(c, kp_xy, n_kp, cloud, rows, cols, maximum_depth,
+                                                            max_keypoints, kept_idx, xyz1, n_out));
+}
+
+int rgbdfe_detect_describe_cloud(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* cloud,
+                                 int32_t rows, int32_t cols, double maximum_depth, rgbdfe_keypoint* keypoints,
+                                 uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe_cloud(c, gray, mask, cloud, rows, cols, maximum_depth, keypoints,
+                                                              descriptors, xyz1, n_out));
 }
 
 int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* desc_in,

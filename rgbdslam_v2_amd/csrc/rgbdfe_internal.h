@@ -120,6 +120,9 @@ void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int 
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                           int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
                           hipStream_t stream, bool truncate = false, const float* z_gathered = nullptr);
+void launch_project_cloud(const float* kp_xy, int n_kp, const float4* pts, bool gathered, int rows, int cols,
+                          double maximum_depth, int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
+                          hipStream_t stream);
 // one direction of one edge for the environment measurement model (emm.hip)
 struct EmmJob {
   const float4* new_samples;  // the sampled points (every skip-th row / column) of the frame that is projected

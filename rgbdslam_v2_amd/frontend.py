@@ -356,6 +356,34 @@ class FrontEnd:
             C.byref(n_out)))
         return kept[: n_out.value].copy(), xyz1[: n_out.value].copy()
 
+    def project_to_3d_cloud(self, kp_xy, cloud, maximum_depth, max_keypoints=1000):
+        """Node::projectTo3D, point-cloud overload (node.cpp:855-898).  cloud: [rows, cols, 4] float32."""
+        kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        n = kp_xy.shape[0]
+        kept = np.empty(max(n, 1), np.int32)
+        xyz1 = np.empty((max(n, 1), 4), np.float32)
+        n_out = C.c_int32(0)
+        self._check(self._L.rgbdfe_project_to_3d_cloud(self._ctx, kp_xy.ctypes.data, n, cloud.ctypes.data, cloud.shape[0],
+                                                       cloud.shape[1], maximum_depth, max_keypoints, kept.ctypes.data,
+                                                       xyz1.ctypes.data, C.byref(n_out)))
+        return kept[: n_out.value].copy(), xyz1[: n_out.value].copy()
+
+    def detect_describe_cloud(self, gray, mask, cloud, maximum_depth):
+        """The feature path of the Node constructor that is given the organised cloud (node.cpp:252-369)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        cap = int(1.5 * getattr(self, "_max_keypoints", 600)) + 64
+        kps = np.zeros(cap, _lib.KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        xyz = np.zeros((cap, 4), np.float32)
+        n = C.c_int32(0)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._check(self._L.rgbdfe_detect_describe_cloud(self._ctx, gray.ctypes.data, None if m is None else m.ctypes.data,
+                                                         cloud.ctypes.data, gray.shape[0], gray.shape[1], maximum_depth,
+                                                         kps.ctypes.data, desc.ctypes.data, xyz.ctypes.data, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy(), xyz[: n.value].copy()
+
     def sift_node_features(self, kp_xy, desc, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000,
                            use_root_sift=True):
         """projectTo3DSiftGPU (node.cpp:695-769) + squareroot_descriptor_space (node.cpp:1557-1571):

@@ -55,3 +55,69 @@ def test_sift_node_features_match_oracle():
         if n and root:
             assert not np.array_equal(got[2], got[3])
     fe.close()
+
+
+def _cloud(rng, rows, cols):
+    cloud = np.zeros((rows, cols, 4), np.float32)
+    cloud[..., 0] = rng.uniform(-2, 2, (rows, cols))
+    cloud[..., 1] = rng.uniform(-2, 2, (rows, cols))
+    cloud[..., 2] = rng.uniform(0.4, 5.0, (rows, cols))
+    for ch in range(3):
+        cloud[..., ch][rng.random((rows, cols)) < 0.05] = np.nan
+    return cloud
+
+
+@pytest.mark.parametrize("rows,cols,n,maxk,maxd", [(480, 640, 1500, 1000, 3.5), (48, 64, 700, 50, 2.0),
+                                                   (48, 64, 300, 1000, 1e9), (48, 64, 300, 1000, -1.0), (48, 64, 0, 10, 3.0)])
+def test_project_to_3d_cloud_matches_oracle(rows, cols, n, maxk, maxd):
+    """row a22 (i): Node::projectTo3D's point-cloud overload (node.cpp:855-898) on the device."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    rng = np.random.default_rng(rows * 31 + n)
+    cloud = _cloud(rng, rows, cols)
+    kp = np.stack([rng.uniform(-3, cols + 3, n), rng.uniform(-3, rows + 3, n)], 1).astype(np.float32)
+    if n > 5:
+        kp[3] = [np.nan, 5.0]
+        kp[5] = [10.9999959, 20.5]
+    fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=64, max_pairs_per_batch=2)
+    kept, xyz = fe.project_to_3d_cloud(kp, cloud, maxd, maxk)
+    okept, oxyz = po.project_to_3d_cloud(kp.reshape(-1, 2), cloud, maxd, maxk)
+    assert np.array_equal(kept, okept) and np.array_equal(xyz, oxyz)
+    fe.close()
+
+
+def test_point_cloud_constructor_feature_path():
+    """node.cpp:252-369: detect -> projectTo3D(cloud) -> compute (no removeDepthless, no retainBest); the 3-D points
+    follow their keypoints through compute()'s border filter and regrouping (deviation D6)."""
+    from oracle import pyorb
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    fr = synth.make_image_sequence(n_frames=2, seed=9)
+    fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=1024, max_pairs_per_batch=2)
+    fe.detector_configure(max_keypoints=800)
+    st = pyorb.grid_state(800)
+    rng = np.random.default_rng(2)
+    for f in range(2):
+        g, d = fr["gray"][f], fr["depth"][f]
+        m = np.where(fr["mask"][f] > 0, 255, 0).astype(np.uint8)
+        rows, cols = g.shape
+        u, v = np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32))
+        cloud = np.zeros((rows, cols, 4), np.float32)
+        cloud[..., 2] = d
+        cloud[..., 0] = (u - fr["cx"]) * d / fr["fx"]
+        cloud[..., 1] = (v - fr["cy"]) * d / fr["fy"]
+        cloud[..., 2][rng.random((rows, cols)) < 0.03] = np.nan
+        kp, desc, xyz = fe.detect_describe_cloud(g, m, cloud, 2.02)
+        det = pyorb.grid_detect(st, g, m)
+        kept, pxyz = po.project_to_3d_cloud(np.stack([det["x"], det["y"]], 1), cloud, 2.02, 800)
+        k3 = det[kept]
+        # compute(): border filter + stable regroup by octave; carry the positions along
+        inside = (k3["x"] >= 31) & (k3["x"] < cols - 31) & (k3["y"] >= 31) & (k3["y"] < rows - 31)
+        order = np.concatenate([np.flatnonzero(inside & (k3["octave"] == lv)) for lv in range(8)])
+        rk, rdesc = pyorb.compute(g, k3)
+        assert len(rk) == len(order) == len(kp) and 0 < len(kp) <= 800
+        for fld in ("x", "y", "octave", "size", "response", "angle"):
+            assert np.array_equal(kp[fld], rk[fld]), fld
+        assert np.array_equal(desc, rdesc)
+        assert np.array_equal(xyz, pxyz[order])
+        assert np.array_equal(fe.detector_thresholds(), np.array(st.thresh[:9]))
+    fe.close()

@@ -113,3 +113,27 @@ def test_observation_likelihood_on_reference_code():
         a = R.ref_observation_criterion_met(inl, outl, occ + inl + outl, th, C.byref(q1))
         b, q2 = po.observation_criterion_met(inl, outl, occ + inl + outl, th)
         assert bool(a) == b and (th < 0 or q1.value == q2)
+
+
+def test_project_to_3d_cloud_on_reference_code():
+    """row a22 (i): Node::projectTo3D, point-cloud overload (node.cpp:855-898): truncating lookup, maximum_depth,
+    NaN coordinates, the max_keypoints cut."""
+    rng = np.random.default_rng(41)
+    for rows, cols, n, maxk, maxd in ((480, 640, 1500, 1000, 3.5), (48, 64, 700, 50, 2.0), (48, 64, 300, 1000, 1e9),
+                                      (48, 64, 300, 1000, -1.0)):
+        cloud = np.zeros((rows, cols, 4), np.float32)
+        cloud[..., 0] = rng.uniform(-2, 2, (rows, cols))
+        cloud[..., 1] = rng.uniform(-2, 2, (rows, cols))
+        cloud[..., 2] = rng.uniform(0.4, 5.0, (rows, cols))
+        cloud[..., 3] = rng.uniform(0, 1, (rows, cols))
+        for ch in range(3):
+            cloud[..., ch][rng.random((rows, cols)) < 0.05] = np.nan
+        kp = np.stack([rng.uniform(-3, cols + 3, n), rng.uniform(-3, rows + 3, n)], 1).astype(np.float32)
+        kp[3] = [np.nan, 5.0]
+        kp[5] = [10.9999959, 20.5]  # the coordinates the reference's comment is about: truncation, not rounding
+        kept = np.zeros(n, np.int32)
+        xyz = np.zeros((n, 4), np.float32)
+        k = R.ref_project_to_3d_cloud(_p(kp), n, _p(cloud), rows, cols, maxd, maxk, _p(kept), _p(xyz))
+        okept, oxyz = po.project_to_3d_cloud(kp, cloud, maxd, maxk)
+        assert k == len(okept) and np.array_equal(kept[:k], okept) and np.array_equal(xyz[:k], oxyz)
+        assert maxd < 0 or k > 0
