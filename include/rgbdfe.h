@@ -300,6 +300,18 @@ int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32
  * rand_fn(rand_state) replaces rand() (pass a wrapper of rand() for the reference's stream); NULL selects a
  * counter-based generator seeded with `seed`, which makes the selection reproducible.
  * Returns RGBDFE_ERR_CAPACITY (with *n_out = the needed size) when ids_out is too small. */
+/* GPU prefilter in front of the pair path (second half): what loop_closing.cpp's
+ * GraphManager::getNeighbours (:190-277, behind DO_LOOP_CLOSING, never wired into nodeComparisons) sketched -- every
+ * descriptor of the new node votes `k_neighbours - rank` (:241) for the nodes holding its k nearest descriptors, a
+ * node's votes are divided by its descriptor count (:263), the nodes are ranked by that score (:269) -- with EXACT
+ * binary neighbours instead of an approximate kd-tree: a descriptor's k nearest nodes are the k candidates whose best
+ * match (the Hamming stage's keys) has the smallest distance, ties to the candidate listed first; matches with
+ * hd >= max_hd do not vote (128 = featureMatching's gate, node.cpp:572; 257 = every match votes).
+ * out_ids / out_scores: the at most max_out best candidates in descending score order (ties: listed first); candidates
+ * without a vote are not returned.  k_neighbours in [1, 8].  Feed out_ids to rgbdfe_match_node_pairs. */
+int rgbdfe_place_recognition(rgbdfe_ctx* ctx, int32_t query_id, const int32_t* candidate_ids, int32_t n_candidates,
+                             int32_t k_neighbours, int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
+                             int32_t* n_out);
 typedef struct rgbdfe_pose_graph rgbdfe_pose_graph;
 typedef int (*rgbdfe_rand_fn)(void* state);
 rgbdfe_pose_graph* rgbdfe_pose_graph_create(void);

@@ -639,3 +639,30 @@ def ref_potential_edge_targets(node_ids, vertex_ids, matchable, keyframes, edges
                                      int(geodesic_targets), int(sampled_targets), int(geodesic_depth), int(predecessor_id),
                                      int(bool(include_predecessor)), int(srand_seed), out.ctypes.data, cap)
     return out[:n].copy()
+
+
+def place_recognition(qdesc, cand_descs, k_neighbours=2, max_hd=128):
+    """Descriptor-vote ranking of loop-closure candidates: GraphManager::getNeighbours (loop_closing.cpp:190-277) with
+    exact binary neighbours.  Every query descriptor votes `k - rank` (:241) for the k candidate nodes whose best match
+    (bruteForceSearchORB's answer, features.cpp:163-182, incl. its last-row quirk) has the smallest Hamming distance
+    (ties: the candidate listed first; matches with hd >= max_hd do not vote); a node's votes are divided by its
+    descriptor count (:263); nodes are ranked by score, descending (:269; ties: listed first); nodes without votes are
+    absent (:243-248).  Returns (positions into cand_descs, float32 scores).  numpy: test infrastructure."""
+    nq = len(qdesc)
+    n = len(cand_descs)
+    hd = np.full((n, nq), 257, np.int64)
+    for c, t in enumerate(cand_descs):
+        if nq and len(t):
+            hd[c] = hamming_nn_batch(qdesc, t)[0]
+    votes = np.zeros(n, np.int64)
+    key = hd * 65536 + np.arange(n)[:, None]          # (hd, candidate position)
+    order = np.argsort(key, axis=0, kind="stable")    # per query descriptor: candidates by (hd, position)
+    for rank in range(min(k_neighbours, n)):
+        c = order[rank]
+        ok = hd[c, np.arange(nq)] < max_hd
+        np.add.at(votes, c[ok], k_neighbours - rank)
+    rows = np.array([len(t) for t in cand_descs], np.float32)
+    pos = np.flatnonzero(votes > 0)
+    score = votes[pos].astype(np.float32) / rows[pos]
+    o = np.argsort(-score, kind="stable")
+    return pos[o].astype(np.int32), score[o].astype(np.float32)

@@ -320,6 +320,19 @@ class FrontEnd:
                                                     mt.ctypes.data, md.ctypes.data, C.byref(k)))
         return mq[: k.value].copy(), mt[: k.value].copy(), md[: k.value].copy()
 
+    def place_recognition(self, query_id: int, candidate_ids, k_neighbours: int = 2, max_hd: int = 128,
+                          max_out: Optional[int] = None):
+        """Descriptor-vote ranking of loop-closure candidates (loop_closing.cpp:190-277 with exact neighbours).
+        Returns (ids, scores) in descending score order."""
+        c = np.ascontiguousarray(candidate_ids, np.int32)
+        max_out = len(c) if max_out is None else max_out
+        ids = np.zeros(max(max_out, 1), np.int32)
+        sc = np.zeros(max(max_out, 1), np.float32)
+        n = C.c_int32(0)
+        self._check(self._L.rgbdfe_place_recognition(self._ctx, query_id, c.ctypes.data, len(c), k_neighbours, max_hd,
+                                                     max_out, ids.ctypes.data, sc.ctypes.data, C.byref(n)))
+        return ids[: n.value].copy(), sc[: n.value].copy()
+
     # -- pieces -----------------------------------------------------------------------
     def hamming_nn_nodes(self, query_id: int, train_id: int):
         n = self.node_count(query_id)
