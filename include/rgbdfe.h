@@ -312,6 +312,14 @@ int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32
 int rgbdfe_place_recognition(rgbdfe_ctx* ctx, int32_t query_id, const int32_t* candidate_ids, int32_t n_candidates,
                              int32_t k_neighbours, int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
                              int32_t* n_out);
+/* Many query nodes at once (an offline loop-closure sweep: ONE Hamming launch + ONE vote launch for all of them).
+ * Query s has the candidates candidate_ids[candidate_offsets[s] .. candidate_offsets[s+1]-1] (offsets[0] = 0, at most
+ * 65535 per query, offsets[n_queries] <= max_pairs_per_batch); its ranked list goes to out_ids / out_scores
+ * [s * max_out ...], its length to out_counts[s]. */
+int rgbdfe_place_recognition_batch(rgbdfe_ctx* ctx, const int32_t* query_ids, int32_t n_queries,
+                                   const int32_t* candidate_offsets, const int32_t* candidate_ids, int32_t k_neighbours,
+                                   int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
+                                   int32_t* out_counts);
 typedef struct rgbdfe_pose_graph rgbdfe_pose_graph;
 typedef int (*rgbdfe_rand_fn)(void* state);
 rgbdfe_pose_graph* rgbdfe_pose_graph_create(void);

@@ -1165,72 +1165,102 @@ int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   return hamming_keys_to_host(ctx, w.nq, planes, out_hd, out_idx);
 }
 
-// Loop-closure prefilter (place_recognition.hip): ranks `candidate_ids` by how many of the new node's descriptors
-// find one of their k nearest matches in them.
-int rgbdfe_place_recognition(rgbdfe_ctx* ctx, int32_t query_id, const int32_t* candidate_ids, int32_t n_candidates,
-                             int32_t k_neighbours, int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
-                             int32_t* n_out) {
-  if (!ctx || n_candidates < 0 || k_neighbours < 1 || k_neighbours > 8 || max_hd < 1 || max_hd > 257 || max_out < 0 ||
-      !n_out || (n_candidates > 0 && !candidate_ids) || (max_out > 0 && (!out_ids || !out_scores)))
+// Loop-closure prefilter (place_recognition.hip): ranks the candidates of every query node by how many of the query's
+// descriptors find one of their k nearest matches in them.  One Hamming launch + one vote launch for the whole batch.
+int rgbdfe_place_recognition_batch(rgbdfe_ctx* ctx, const int32_t* query_ids, int32_t n_queries,
+                                   const int32_t* candidate_offsets, const int32_t* candidate_ids, int32_t k_neighbours,
+                                   int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
+                                   int32_t* out_counts) {
+  if (!ctx || n_queries < 0 || k_neighbours < 1 || k_neighbours > 8 || max_hd < 1 || max_hd > 257 || max_out < 0 ||
+      (n_queries > 0 && (!query_ids || !candidate_offsets || !out_counts)) ||
+      (n_queries > 0 && max_out > 0 && (!out_ids || !out_scores)))
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad place recognition arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
-  *n_out = 0;
-  if (n_candidates == 0 || max_out == 0) return RGBDFE_OK;
-  if (n_candidates > ctx->cfg.max_pairs_per_batch || n_candidates > 65535)
-    return fail(ctx, RGBDFE_ERR_CAPACITY, "more candidates than max_pairs_per_batch (or 65535)");
-  auto q = ctx->nodes.find(query_id);
-  if (q == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "query node not resident");
-  if (q->second.kind != 0u) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "place recognition needs ORB nodes");
+  for (int32_t s = 0; s < n_queries; ++s) out_counts[s] = 0;
+  if (n_queries == 0) return RGBDFE_OK;
+  const int32_t total = candidate_offsets[n_queries];
+  if (candidate_offsets[0] != 0 || total < 0 || (total > 0 && !candidate_ids))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "candidate_offsets must start at 0 and ascend");
+  if (total > ctx->cfg.max_pairs_per_batch)
+    return fail(ctx, RGBDFE_ERR_CAPACITY, "more (query, candidate) pairs than max_pairs_per_batch");
+  if (total == 0 || max_out == 0) return RGBDFE_OK;
   for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   for (auto& sl : ctx->ring) sl.pending = false;  // every lane is idle now
   rgbdfe_ctx::Slot& slot = ctx->ring[0];
   rgbdfe_ctx::Lane& lane = ctx->lanes[0];
   hipStream_t st = lane.stream;
-  std::vector<uint32_t> rows((size_t)n_candidates);
-  uint32_t max_nt = 0;
-  for (int32_t i = 0; i < n_candidates; ++i) {
-    auto t = ctx->nodes.find(candidate_ids[i]);
-    if (t == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "candidate node not resident");
-    if (t->second.kind != 0u) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "place recognition needs ORB nodes");
-    PairWork& w = slot.h_work[i];
-    w.q_slot = q->second.slot; w.t_slot = t->second.slot;
-    w.nq = q->second.n; w.nt = t->second.n;
-    w.uid = 0; w.qid = query_id; w.tid = candidate_ids[i]; w.pad = 0;
-    rows[(size_t)i] = t->second.n;
-    max_nt = std::max(max_nt, t->second.n);
+  std::vector<uint32_t> rows((size_t)total), seg((size_t)n_queries + 1);
+  uint32_t max_nt = 0, max_nq = 0;
+  for (int32_t s = 0; s < n_queries; ++s) {
+    const int32_t c0 = candidate_offsets[s], c1 = candidate_offsets[s + 1];
+    if (c1 < c0 || c1 - c0 > 65535) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "candidate_offsets must ascend (<= 65535 candidates per query)");
+    seg[(size_t)s] = (uint32_t)c0;
+    auto q = ctx->nodes.find(query_ids[s]);
+    if (q == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "query node not resident");
+    if (q->second.kind != 0u) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "place recognition needs ORB nodes");
+    if (c1 > c0) max_nq = std::max(max_nq, q->second.n);
+    for (int32_t i = c0; i < c1; ++i) {
+      auto t = ctx->nodes.find(candidate_ids[i]);
+      if (t == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "candidate node not resident");
+      if (t->second.kind != 0u) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "place recognition needs ORB nodes");
+      PairWork& w = slot.h_work[i];
+      w.q_slot = q->second.slot; w.t_slot = t->second.slot;
+      w.nq = q->second.n; w.nt = t->second.n;
+      w.uid = 0; w.qid = query_ids[s]; w.tid = candidate_ids[i]; w.pad = 0;
+      rows[(size_t)i] = t->second.n;
+      max_nt = std::max(max_nt, t->second.n);
+    }
   }
-  const uint32_t nq = q->second.n;
-  std::vector<uint32_t> votes((size_t)n_candidates, 0u);
-  if (nq > 0 && max_nt > 0) {
-    int rc = ensure_scratch(ctx, (size_t)n_candidates * 4 + 256);
+  seg[(size_t)n_queries] = (uint32_t)total;
+  std::vector<uint32_t> votes((size_t)total, 0u);
+  if (max_nq > 0 && max_nt > 0) {
+    const size_t b_votes = ((size_t)total * 4 + 255) & ~(size_t)255;
+    int rc = ensure_scratch(ctx, b_votes + ((size_t)n_queries + 1) * 4 + 256);
     if (rc != RGBDFE_OK) return rc;
     uint32_t* d_votes = (uint32_t*)ctx->d_scratch;
-    HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n_candidates, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(d_votes, 0, (size_t)n_candidates * 4, st));
-    const uint32_t planes = launch_hamming(ctx, slot.d_work, lane.d_keys, (uint32_t)n_candidates, nq, max_nt, st);
-    launch_place_votes(lane.d_keys, planes, (uint32_t)ctx->cfg.max_keypoints, nq, (uint32_t)n_candidates,
+    uint32_t* d_seg = (uint32_t*)((char*)ctx->d_scratch + b_votes);
+    HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)total, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_seg, seg.data(), ((size_t)n_queries + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_votes, 0, (size_t)total * 4, st));
+    const uint32_t planes = launch_hamming(ctx, slot.d_work, lane.d_keys, (uint32_t)total, max_nq, max_nt, st);
+    launch_place_votes(lane.d_keys, planes, (uint32_t)ctx->cfg.max_keypoints, slot.d_work, d_seg, (uint32_t)n_queries, max_nq,
                        (uint32_t)k_neighbours, (uint32_t)max_hd, d_votes, st);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(votes.data(), d_votes, (size_t)n_candidates * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(votes.data(), d_votes, (size_t)total * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
   }
   // score = votes / descriptor count of the candidate (loop_closing.cpp:263); rank by score, ties: listed first
   std::vector<int32_t> order;
-  std::vector<float> score((size_t)n_candidates, 0.f);
-  for (int32_t i = 0; i < n_candidates; ++i) {
-    if (votes[(size_t)i] == 0u) continue;  // nodes nobody voted for are not in the reference's score map either (:243-248)
-    score[(size_t)i] = (float)votes[(size_t)i] / (float)rows[(size_t)i];
-    order.push_back(i);
+  std::vector<float> score;
+  for (int32_t s = 0; s < n_queries; ++s) {
+    const int32_t c0 = candidate_offsets[s], c1 = candidate_offsets[s + 1];
+    order.clear();
+    score.assign((size_t)(c1 - c0), 0.f);
+    for (int32_t i = c0; i < c1; ++i) {
+      if (votes[(size_t)i] == 0u) continue;  // nodes nobody voted for are not in the reference's score map either (:243-248)
+      score[(size_t)(i - c0)] = (float)votes[(size_t)i] / (float)rows[(size_t)i];
+      order.push_back(i - c0);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return score[(size_t)a] > score[(size_t)b]; });
+    const int32_t n = std::min<int32_t>((int32_t)order.size(), max_out);
+    for (int32_t i = 0; i < n; ++i) {
+      out_ids[(size_t)s * max_out + i] = candidate_ids[c0 + order[(size_t)i]];
+      out_scores[(size_t)s * max_out + i] = score[(size_t)order[(size_t)i]];
+    }
+    out_counts[s] = n;
   }
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return score[(size_t)a] > score[(size_t)b]; });
-  const int32_t n = std::min<int32_t>((int32_t)order.size(), max_out);
-  for (int32_t i = 0; i < n; ++i) {
-    out_ids[i] = candidate_ids[order[(size_t)i]];
-    out_scores[i] = score[(size_t)order[(size_t)i]];
-  }
-  *n_out = n;
   return RGBDFE_OK;
+}
+
+int rgbdfe_place_recognition(rgbdfe_ctx* ctx, int32_t query_id, const int32_t* candidate_ids, int32_t n_candidates,
+                             int32_t k_neighbours, int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
+                             int32_t* n_out) {
+  if (!ctx || !n_out || n_candidates < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad place recognition arguments");
+  const int32_t offs[2] = {0, n_candidates};
+  *n_out = 0;
+  return impl::rgbdfe_place_recognition_batch(ctx, &query_id, 1, offs, candidate_ids, k_neighbours, max_hd, max_out, out_ids,
+                                              out_scores, n_out);
 }
 
 int rgbdfe_hamming_nn_host(rgbdfe_ctx* ctx, const uint8_t* qdesc, int32_t nq, const uint8_t* tdesc,
@@ -2237,6 +2267,16 @@ int rgbdfe_place_recognition(rgbdfe_ctx* ctx, int32_t query_id, const int32_t* c
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_FIRST(ctx, impl::rgbdfe_place_recognition(c, query_id, candidate_ids, n_candidates, k_neighbours, max_hd,
                                                           max_out, out_ids, out_scores, n_out));
+}
+
+int rgbdfe_place_recognition_batch(rgbdfe_ctx* ctx, const int32_t* query_ids, int32_t n_queries,
+                                   const int32_t* candidate_offsets, const int32_t* candidate_ids, int32_t k_neighbours,
+                                   int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
+                                   int32_t* out_counts) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_place_recognition_batch(c, query_ids, n_queries, candidate_offsets, candidate_ids,
+                                                                k_neighbours, max_hd, max_out, out_ids, out_scores,
+                                                                out_counts));
 }
 
 int rgbdfe_hamming_nn_host(rgbdfe_ctx* ctx, const uint8_t* qdesc, int32_t nq, const uint8_t* tdesc, int32_t nt,

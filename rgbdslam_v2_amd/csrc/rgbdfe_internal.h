@@ -50,8 +50,9 @@ uint32_t launch_hamming_mfma(const uint32_t* slab, const PairWork* work, uint32_
                              int mode, hipStream_t stream);
 // place_recognition.hip: every query descriptor votes k - rank for the k candidate nodes holding its nearest matches
 // (keys[candidate][plane][row] from the Hamming stage; k <= 8; candidates < 65536)
-void launch_place_votes(const uint32_t* keys, uint32_t planes, uint32_t max_kp, uint32_t nq, uint32_t n_cand,
-                        uint32_t k_neighbours, uint32_t max_hd, uint32_t* votes, hipStream_t stream);
+void launch_place_votes(const uint32_t* keys, uint32_t planes, uint32_t max_kp, const PairWork* work, const uint32_t* seg,
+                        uint32_t n_queries, uint32_t max_nq, uint32_t k_neighbours, uint32_t max_hd, uint32_t* votes,
+                        hipStream_t stream);
 void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                           uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
                           uint32_t n_pairs, const RansacConst& rc, struct PairPrep* prep, double* ec_pool,

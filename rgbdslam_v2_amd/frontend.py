@@ -333,6 +333,23 @@ class FrontEnd:
                                                      max_out, ids.ctypes.data, sc.ctypes.data, C.byref(n)))
         return ids[: n.value].copy(), sc[: n.value].copy()
 
+    def place_recognition_batch(self, query_ids, candidate_lists, k_neighbours: int = 2, max_hd: int = 128,
+                                max_out: int = 16):
+        """Many queries in one launch.  candidate_lists[s] = the candidate ids of query_ids[s].
+        Returns a list of (ids, scores) per query."""
+        qs = np.ascontiguousarray(query_ids, np.int32)
+        offs = np.zeros(len(qs) + 1, np.int32)
+        offs[1:] = np.cumsum([len(c) for c in candidate_lists])
+        cands = np.ascontiguousarray(np.concatenate([np.asarray(c, np.int32) for c in candidate_lists])
+                                     if len(candidate_lists) else np.zeros(0, np.int32), np.int32)
+        ids = np.zeros((max(len(qs), 1), max(max_out, 1)), np.int32)
+        sc = np.zeros((max(len(qs), 1), max(max_out, 1)), np.float32)
+        cnt = np.zeros(max(len(qs), 1), np.int32)
+        self._check(self._L.rgbdfe_place_recognition_batch(self._ctx, qs.ctypes.data, len(qs), offs.ctypes.data,
+                                                           cands.ctypes.data, k_neighbours, max_hd, max_out,
+                                                           ids.ctypes.data, sc.ctypes.data, cnt.ctypes.data))
+        return [(ids[s, : cnt[s]].copy(), sc[s, : cnt[s]].copy()) for s in range(len(qs))]
+
     # -- pieces -----------------------------------------------------------------------
     def hamming_nn_nodes(self, query_id: int, train_id: int):
         n = self.node_count(query_id)

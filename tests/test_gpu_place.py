@@ -40,6 +40,26 @@ def test_votes_and_ranking_match_oracle(world, k, max_hd):
     fe.close()
 
 
+def test_batch_of_queries_equals_single_calls(world):
+    """An offline sweep (every frame against all earlier frames) is one Hamming launch + one vote launch."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    desc, xyz = world
+    F = 24
+    fe = FrontEnd(device_id=0, max_nodes=32, max_keypoints=512, max_pairs_per_batch=F * F)
+    for f in range(F):
+        fe.upload_node(f, desc[f], xyz[f])
+    queries = list(range(1, F)) + [0]
+    lists = [np.arange(q) for q in range(1, F)] + [np.zeros(0, np.int32)]
+    ranked = fe.place_recognition_batch(queries, lists, k_neighbours=3, max_hd=128, max_out=6)
+    assert len(ranked) == len(queries)
+    for q, cands, (ids, sc) in zip(queries, lists, ranked):
+        ids1, sc1 = fe.place_recognition(q, cands, k_neighbours=3, max_hd=128, max_out=6)
+        assert np.array_equal(ids, ids1) and np.array_equal(sc, sc1)
+        pos, rsc = po.place_recognition(desc[q], [desc[c] for c in cands], 3, 128)
+        assert np.array_equal(ids, cands[pos][:6]) and np.array_equal(sc, rsc[:6])
+    fe.close()
+
+
 def test_edge_cases(world):
     from rgbdslam_v2_amd._lib import RgbdfeError
     from rgbdslam_v2_amd.frontend import FrontEnd

@@ -106,9 +106,10 @@ def test_point_cloud_constructor_feature_path():
         cloud[..., 0] = (u - fr["cx"]) * d / fr["fx"]
         cloud[..., 1] = (v - fr["cy"]) * d / fr["fy"]
         cloud[..., 2][rng.random((rows, cols)) < 0.03] = np.nan
-        kp, desc, xyz = fe.detect_describe_cloud(g, m, cloud, 2.02)
+        maxd = float(np.nanmedian(d)) + (1.0 if f == 0 else 0.0)   # frame 1: about half of the plane is too far away
+        kp, desc, xyz = fe.detect_describe_cloud(g, m, cloud, maxd)
         det = pyorb.grid_detect(st, g, m)
-        kept, pxyz = po.project_to_3d_cloud(np.stack([det["x"], det["y"]], 1), cloud, 2.02, 800)
+        kept, pxyz = po.project_to_3d_cloud(np.stack([det["x"], det["y"]], 1), cloud, maxd, 800)
         k3 = det[kept]
         # compute(): border filter + stable regroup by octave; carry the positions along
         inside = (k3["x"] >= 31) & (k3["x"] < cols - 31) & (k3["y"] >= 31) & (k3["y"] < rows - 31)

@@ -28,13 +28,13 @@ full = fe.match_pair_list(pq, pt)
 t_full = time.perf_counter() - t0
 edges_full = {(int(a), int(b)) for a, b, e in zip(pq, pt, full["id1"]) if e >= 0}
 
-fe.place_recognition(F - 1, np.arange(F - 1), k_neighbours=2, max_out=K)
+fe.place_recognition_batch([F - 1], [np.arange(F - 1)], k_neighbours=2, max_out=K)
 t0 = time.perf_counter()
-sel_q, sel_t, t_place = [], [], 0.0
-for q in range(1, F):
-    ta = time.perf_counter()
-    ids, sc = fe.place_recognition(q, np.arange(q), k_neighbours=2, max_hd=128, max_out=K)
-    t_place += time.perf_counter() - ta
+sel_q, sel_t = [], []
+ta = time.perf_counter()
+ranked = fe.place_recognition_batch(np.arange(1, F), [np.arange(q) for q in range(1, F)], k_neighbours=2, max_hd=128, max_out=K)
+t_place = time.perf_counter() - ta
+for q, (ids, sc) in zip(range(1, F), ranked):
     sel_q += [q] * len(ids)
     sel_t += list(ids)
 sel_q, sel_t = np.array(sel_q, np.int32), np.array(sel_t, np.int32)
