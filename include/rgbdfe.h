@@ -175,6 +175,21 @@ int rgbdfe_submit_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, cons
 int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* match_q,
                             int32_t* match_t, float* match_dist, int32_t* n_matches);
 
+/* ---- float-descriptor nodes on Node::featureMatching's FLANN branch (node.cpp:610-667; a11) -------------------------
+ * matcher_type == "FLANN" with a float extractor (SURF / SIFT / GFTT ...): knn-2 of every descriptor of the newer node
+ * in the older node, ratio = dists[2i] / dists[2i+1] over FLANN's squared-L2 distances (:645), accepted when
+ * nn_distance_ratio > ratio (:648), each train index once, first come first served in query order (:650-653),
+ * DMatch.distance = the ratio (:657); then keepStrongestMatches and RANSAC as for every matcher.  The reference's
+ * neighbours come from 4 randomised kd-trees searched with 16 checks (:493-505, :634) -- approximate and not
+ * reproducible; here they are the EXACT two nearest (squared distance accumulated in flann::L2<float>'s order,
+ * lowest row wins ties): the superset-quality replacement SURVEY.md 8(a) a11 names.
+ * desc: n x dim float (Node::feature_descriptors_), dim a multiple of 4, <= 128.  out_dist (may be NULL) receives
+ * the ratios of out[i].all_q/all_t (all_hd is 0 on this path). */
+int rgbdfe_upload_float_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc, int32_t dim, const float* xyz1,
+                             int32_t n);
+int rgbdfe_match_flann_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                 double nn_distance_ratio, rgbdfe_match_result* out, float* out_dist);
+
 /* ---- pieces of the pair op, exposed for A/B and parity ------------------- */
 /* Batched bruteForceSearchORB (features.h:14, features.cpp:168-182) of every row of
  * query node against train node: out_hd[i] in [0,257], out_idx[i] (or -1), including

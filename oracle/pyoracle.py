@@ -602,6 +602,41 @@ def match_sift_node_pair(qdesc, qxyz1, qid, tdesc, txyz1, tid, params=None):
     return r
 
 
+def flann_match(qdesc, tdesc, nn_distance_ratio=0.95):
+    """Node::featureMatching's FLANN branch (node.cpp:610-667) with exact neighbours: (queryIdx, trainIdx, ratio)."""
+    qdesc = np.ascontiguousarray(qdesc, np.float32)
+    tdesc = np.ascontiguousarray(tdesc, np.float32)
+    L = lib()
+    L.orc_flann_match.restype = C.c_int
+    L.orc_flann_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+    n = max(qdesc.shape[0], 1)
+    mq, mt, md = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+    k = L.orc_flann_match(_p(qdesc), qdesc.shape[0], _p(tdesc), tdesc.shape[0], qdesc.shape[1], nn_distance_ratio,
+                          _p(mq), _p(mt), _p(md))
+    return mq[:k].copy(), mt[:k].copy(), md[:k].copy()
+
+
+def match_float_node_pair(qdesc, qxyz1, qid, tdesc, txyz1, tid, nn_distance_ratio=0.95, params=None):
+    params = params or default_params()
+    qdesc = np.ascontiguousarray(qdesc, np.float32)
+    tdesc = np.ascontiguousarray(tdesc, np.float32)
+    qxyz1 = np.ascontiguousarray(qxyz1, np.float32)
+    txyz1 = np.ascontiguousarray(txyz1, np.float32)
+    out = OrcResult()
+    dist = np.zeros(ORC_MAX_MATCHES, np.float32)
+    L = lib()
+    L.orc_match_float_node_pair.restype = None
+    L.orc_match_float_node_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_int32, C.c_int, C.c_double, C.POINTER(OrcParams), C.POINTER(OrcResult),
+                                            C.c_void_p]
+    L.orc_match_float_node_pair(_p(qdesc), _p(qxyz1), qdesc.shape[0], qid, _p(tdesc), _p(txyz1), tdesc.shape[0], tid,
+                                qdesc.shape[1], nn_distance_ratio, C.byref(params), C.byref(out), _p(dist))
+    r = result_to_dict(out)
+    r["all_dist"] = dist[: r["n_all"]].copy()
+    return r
+
+
 _ref_graph = None
 
 

@@ -1133,6 +1133,65 @@ int orc_sift_match(const float* d1, int n1, const float* d2, int n2, int32_t* mq
 
 /* matchNodePair with matcher_type == SIFTGPU: SiftGPUWrapper::match, keepStrongestMatches by the
  * L2 distance (node.cpp:553-557, 674), then the same RANSAC. */
+/* ------------------------------------------------------------------------- */
+/* a11  Node::featureMatching, FLANN branch for float descriptors (node.cpp:610-667) with EXACT neighbours.  */
+/* The reference searches 4 randomised kd-trees with 16 checks (:493-505, :634): approximate, not reproducible.  */
+/* What it does with the neighbours is restated exactly: ratio of FLANN's squared-L2 distances (:645), accepted   */
+/* when nn_distance_ratio > ratio (:648), a train index is used once, first come first served in query order    */
+/* (:650-653), DMatch.distance = ratio (:657).  Squared distance in flann::L2<float>::operator()'s order (FLANN   */
+/* 1.8 dist.h, not in the tree): four differences per step, result += ((d0*d0 + d1*d1) + d2*d2) + d3*d3.           */
+/* desc rows are `dim` floats (dim % 4 == 0).  Returns the number of matches, in query order.                      */
+/* ------------------------------------------------------------------------- */
+int orc_flann_match(const float* qdesc, int nq, const float* tdesc, int nt, int dim, double nn_distance_ratio,
+                    int32_t* mq, int32_t* mt, float* md) {
+  if (nq <= 0 || nt < 2) return 0; /* knnSearch with k = 2 */
+  char* used = (char*)calloc((size_t)nt, 1);
+  int n = 0;
+  for (int i = 0; i < nq; ++i) {
+    const float* a = qdesc + (size_t)i * dim;
+    float b1 = INFINITY, b2 = INFINITY;
+    int i1 = -1;
+    for (int j = 0; j < nt; ++j) {
+      const float* b = tdesc + (size_t)j * dim;
+      float result = 0.0f;
+      for (int k = 0; k < dim; k += 4) {
+        const float d0 = a[k] - b[k], d1 = a[k + 1] - b[k + 1], d2 = a[k + 2] - b[k + 2], d3 = a[k + 3] - b[k + 3];
+        result += ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+      }
+      if (result < b1) { b2 = b1; b1 = result; i1 = j; }
+      else if (result < b2) b2 = result;
+    }
+    const float ratio = b1 / b2;                 /* :645 */
+    if (nn_distance_ratio > (double)ratio) {     /* :648 */
+      if (i1 < 0 || used[i1]) continue;          /* :650-651 */
+      used[i1] = 1;                              /* :653 */
+      mq[n] = i; mt[n] = i1; md[n] = ratio;      /* :654-657 */
+      ++n;
+    }
+  }
+  free(used);
+  return n;
+}
+
+static void orc_match_list_node_pair(int32_t* mq, int32_t* mt, float* md, int n, int cap, const float* qxyz1, int32_t qid,
+                                     const float* txyz1, int32_t tid, const orc_params* prm, orc_result* out,
+                                     float* all_dist);
+
+void orc_match_float_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid, const float* tdesc,
+                               const float* txyz1, int nt, int32_t tid, int dim, double nn_distance_ratio,
+                               const orc_params* prm, orc_result* out, float* all_dist) {
+  static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memset(out, 0, sizeof(*out));
+  out->id1 = out->id2 = -1;
+  memcpy(out->T, I16, sizeof(I16));
+  int cap = nq > 0 ? nq : 1;
+  int32_t* mq = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  int32_t* mt = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  float* md = (float*)malloc(sizeof(float) * (size_t)cap);
+  int n = orc_flann_match(qdesc, nq, tdesc, nt, dim, nn_distance_ratio, mq, mt, md);
+  orc_match_list_node_pair(mq, mt, md, n, cap, qxyz1, qid, txyz1, tid, prm, out, all_dist);
+}
+
 void orc_match_sift_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid,
                               const float* tdesc, const float* txyz1, int nt, int32_t tid,
                               const orc_params* prm, orc_result* out, float* all_dist) {
@@ -1145,6 +1204,13 @@ void orc_match_sift_node_pair(const float* qdesc, const float* qxyz1, int nq, in
   int32_t* mt = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
   float* md = (float*)malloc(sizeof(float) * (size_t)cap);
   int n = orc_sift_match(qdesc, nq, tdesc, nt, mq, mt, md);
+  orc_match_list_node_pair(mq, mt, md, n, cap, qxyz1, qid, txyz1, tid, prm, out, all_dist);
+}
+
+/* keepStrongestMatches + RANSAC + edge assembly over a (queryIdx, trainIdx, distance) list; frees the lists */
+static void orc_match_list_node_pair(int32_t* mq, int32_t* mt, float* md, int n, int cap, const float* qxyz1, int32_t qid,
+                                     const float* txyz1, int32_t tid, const orc_params* prm, orc_result* out,
+                                     float* all_dist) {
   int maxm = prm->max_matches > ORC_MAX_MATCHES ? ORC_MAX_MATCHES : prm->max_matches;
   /* keep the max_matches smallest by (distance, queryIdx) (D2), ascending */
   char* used = (char*)calloc((size_t)cap, 1);

@@ -118,6 +118,11 @@ void orc_gather_rows_f32(const float* in, const int32_t* kept_idx, int n, int di
 void orc_root_sift(float* desc, int n_rows, int dim);
 int orc_sift_match(const float* d1, int n1, const float* d2, int n2, int32_t* mq, int32_t* mt,
                    float* dist_out);
+int orc_flann_match(const float* qdesc, int nq, const float* tdesc, int nt, int dim, double nn_distance_ratio,
+                    int32_t* mq, int32_t* mt, float* md);
+void orc_match_float_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid, const float* tdesc,
+                               const float* txyz1, int nt, int32_t tid, int dim, double nn_distance_ratio,
+                               const orc_params* prm, orc_result* out, float* all_dist);
 void orc_match_sift_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid,
                               const float* tdesc, const float* txyz1, int nt, int32_t tid,
                               const orc_params* prm, orc_result* out, float* all_dist);

@@ -169,6 +169,10 @@ def load():
     L.rgbdfe_place_recognition.argtypes = [ctx, i32, vp, i32, i32, i32, i32, vp, vp, C.POINTER(i32)]
     L.rgbdfe_place_recognition_batch.restype = C.c_int
     L.rgbdfe_place_recognition_batch.argtypes = [ctx, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.rgbdfe_upload_float_node.restype = C.c_int
+    L.rgbdfe_upload_float_node.argtypes = [ctx, i32, vp, i32, vp, i32]
+    L.rgbdfe_match_flann_pair_list.restype = C.c_int
+    L.rgbdfe_match_flann_pair_list.argtypes = [ctx, vp, vp, i32, C.c_double, vp, vp]
     L.rgbdfe_sift_node_features.restype = C.c_int
     L.rgbdfe_sift_node_features.argtypes = [ctx, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
                                             C.c_double, C.c_double, C.c_double, i32, i32, vp, vp, vp, vp,
@@ -248,5 +252,6 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",
     "rgbdfe_gather_transport", "rgbdfe_set_hamming_mode", "rgbdfe_project_to_3d_cloud", "rgbdfe_detect_describe_cloud",
-    "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch",
+    "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",
+    "rgbdfe_match_flann_pair_list",
 ]

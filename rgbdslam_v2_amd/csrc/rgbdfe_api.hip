@@ -341,9 +341,11 @@ uint32_t launch_hamming(rgbdfe_ctx* ctx, const PairWork* d_work, uint32_t* d_key
 // Build the PairWork list (host) and enqueue H2D + both kernels on the next lane.
 // Results land in d_out (device memory; nullptr = the lane's own staging buffer).
 // Returns the batch's ticket.  Caller holds the lock.
+// matcher: 0 = ORB (Hamming), 1 = SIFTGPU (u8 dot products on the MFMA), 2 = FLANN branch (exact L2 knn-2 + ratio test)
 int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int32_t n,
                   rgbdfe_match_result* d_out, hipEvent_t wait_for, int64_t* ticket_out,
-                  int* lane_out, bool sift = false, float* d_out_dist = nullptr) {
+                  int* lane_out, int matcher = 0, float* d_out_dist = nullptr, double flann_ratio = 0.95) {
+  const bool sift = matcher != 0;  // both float matchers feed the (queryIdx, trainIdx, distance) list path
   if (n > ctx->cfg.max_pairs_per_batch)
     return fail(ctx, RGBDFE_ERR_CAPACITY, "n_pairs exceeds max_pairs_per_batch");
   const int64_t ticket = ctx->next_ticket;
@@ -361,7 +363,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     auto t = ctx->nodes.find(tids[i]);
     if (q == ctx->nodes.end() || t == ctx->nodes.end())
       return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "pair references a node that is not resident");
-    if (q->second.kind != (sift ? 1u : 0u) || t->second.kind != (sift ? 1u : 0u))
+    if (q->second.kind != (uint32_t)matcher || t->second.kind != (uint32_t)matcher)
       return fail(ctx, RGBDFE_ERR_INVALID_ARG, "node descriptor kind does not fit this matcher");
     PairWork& w = slot.h_work[i];
     w.q_slot = q->second.slot;
@@ -414,11 +416,18 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
                              lane.d_ec, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
     } else {
-      launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
-                      lane.d_col_part, stream);
-      if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-      launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part,
-                         lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+      if (matcher == 2) {
+        launch_l2_knn2(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, max_nq, lane.d_row_part, stream);
+        if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
+        launch_l2_ratio(slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part, flann_ratio, lane.d_sm_q,
+                        lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+      } else {
+        launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
+                        lane.d_col_part, stream);
+        if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
+        launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part,
+                           lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+      }
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
       if (latency)
         launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
@@ -840,12 +849,52 @@ int rgbdfe_upload_sift_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc1
   return RGBDFE_OK;
 }
 
+// Float descriptors as Node::feature_descriptors_ holds them for the FLANN branch (N x dim CV_32F, node.cpp:610-667;
+// SURF 64-d, SIFT 128-d, RootSIFT-normalised when use_root_sift): kind 2, rows zero-padded to 128 floats.
+int rgbdfe_upload_float_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc, int32_t dim, const float* xyz1,
+                             int32_t n) {
+  if (!ctx || n < 0 || dim < 4 || dim > 128 || dim % 4 != 0 || (n > 0 && (!desc || !xyz1)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad upload arguments (dim must be a multiple of 4 in [4, 128])");
+  if (n > ctx->cfg.max_keypoints) return fail(ctx, RGBDFE_ERR_CAPACITY, "node has more rows than max_keypoints");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  int rc = ensure_sift(ctx);
+  if (rc != RGBDFE_OK) return rc;
+  uint32_t slot;
+  auto it = ctx->nodes.find(node_id);
+  if (it != ctx->nodes.end()) {
+    slot = it->second.slot;
+    for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+  } else {
+    if (ctx->free_slots.empty()) return fail(ctx, RGBDFE_ERR_CAPACITY, "no free node slot (max_nodes)");
+    slot = ctx->free_slots.back();
+    ctx->free_slots.pop_back();
+  }
+  const size_t row0 = (size_t)slot * (size_t)ctx->cfg.max_keypoints;
+  if (n > 0) {
+    float* df = ctx->d_sift_f32 + row0 * 128;
+    if (dim == 128) {
+      HIP_TRY(ctx, hipMemcpyAsync(df, desc, (size_t)n * 128 * 4, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      HIP_TRY(ctx, hipMemsetAsync(df, 0, (size_t)n * 128 * 4, ctx->stream));
+      HIP_TRY(ctx, hipMemcpy2DAsync(df, 128 * 4, desc, (size_t)dim * 4, (size_t)dim * 4, (size_t)n, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, xyz1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 2u};
+  return RGBDFE_OK;
+}
+
 int rgbdfe_match_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
-                                int32_t n_pairs, rgbdfe_match_result* out, float* out_dist, int64_t out_stride = 1) {
+                                int32_t n_pairs, rgbdfe_match_result* out, float* out_dist, int64_t out_stride = 1,
+                                int matcher = 1, double flann_ratio = 0.95) {
   if (out_stride != 1 && n_pairs > 0 && out) {  // multi-device shard: dense call, then the interleaved placement
     std::vector<rgbdfe_match_result> tmp((size_t)n_pairs);
     std::vector<float> tmpd(out_dist ? (size_t)n_pairs * RGBDFE_MAX_MATCHES : 0);
-    int rc = impl::rgbdfe_match_sift_pair_list(ctx, query_ids, train_ids, n_pairs, tmp.data(), out_dist ? tmpd.data() : nullptr, 1);
+    int rc = impl::rgbdfe_match_sift_pair_list(ctx, query_ids, train_ids, n_pairs, tmp.data(), out_dist ? tmpd.data() : nullptr, 1,
+                                               matcher, flann_ratio);
     if (rc != RGBDFE_OK) return rc;
     for (int32_t i = 0; i < n_pairs; ++i) {
       out[(int64_t)i * out_stride] = tmp[(size_t)i];
@@ -867,7 +916,7 @@ int rgbdfe_match_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const
     const int li_next = (int)(ctx->next_ticket % rgbdfe_ctx::kLanes);
     if (chunk >= rgbdfe_ctx::kLanes) HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[li_next].stream));
     int li = 0;
-    int rc = enqueue_pairs(ctx, query_ids + off, train_ids + off, n, nullptr, nullptr, nullptr, &li, true);
+    int rc = enqueue_pairs(ctx, query_ids + off, train_ids + off, n, nullptr, nullptr, nullptr, &li, matcher, nullptr, flann_ratio);
     if (rc != RGBDFE_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out + off, ctx->lanes[li].d_results, sizeof(rgbdfe_match_result) * (size_t)n,
                                 hipMemcpyDeviceToHost, ctx->lanes[li].stream));
@@ -889,7 +938,7 @@ int rgbdfe_submit_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, cons
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   if (!ctx->sift_ready) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "no SIFT node has been uploaded");
   return enqueue_pairs(ctx, query_ids, train_ids, n_pairs, (rgbdfe_match_result*)d_out, nullptr, ticket,
-                       nullptr, true, (float*)d_out_dist);
+                       nullptr, 1, (float*)d_out_dist);
 }
 
 int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* match_q,
@@ -2207,6 +2256,35 @@ int rgbdfe_match_sift_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const
   return guarded(ctx, [&]() -> int {
     if (RGBDFE_IS_GROUP(ctx)) return group_match(ctx, query_ids, train_ids, n_pairs, out, true, out_dist);
     return impl::rgbdfe_match_sift_pair_list(ctx, query_ids, train_ids, n_pairs, out, out_dist);
+  });
+}
+
+int rgbdfe_upload_float_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc, int32_t dim, const float* xyz1,
+                             int32_t n) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_upload_float_node(c, node_id, desc, dim, xyz1, n));
+}
+
+int rgbdfe_match_flann_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                 double nn_distance_ratio, rgbdfe_match_result* out, float* out_dist) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!(nn_distance_ratio > 0.0)) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "nn_distance_ratio must be > 0");
+    if (RGBDFE_IS_GROUP(ctx)) {
+      if (n_pairs < 0 || (n_pairs > 0 && (!query_ids || !train_ids || !out)))
+        return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
+      Group& g = *ctx->group;
+      const int G = (int)g.children.size();
+      return group_run(ctx, [&](int i) -> int {
+        std::vector<int32_t> qs, ts;
+        for (int32_t k = i; k < n_pairs; k += G) { qs.push_back(query_ids[k]); ts.push_back(train_ids[k]); }
+        if (qs.empty()) return RGBDFE_OK;
+        return impl::rgbdfe_match_sift_pair_list(g.children[(size_t)i], qs.data(), ts.data(), (int32_t)qs.size(), out + i,
+                                                 out_dist ? out_dist + (size_t)i * RGBDFE_MAX_MATCHES : nullptr, G, 2,
+                                                 nn_distance_ratio);
+      });
+    }
+    return impl::rgbdfe_match_sift_pair_list(ctx, query_ids, train_ids, n_pairs, out, out_dist, 1, 2, nn_distance_ratio);
   });
 }
 

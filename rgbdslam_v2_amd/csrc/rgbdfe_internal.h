@@ -120,6 +120,12 @@ void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t ma
                         uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part,
                         uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n,
                         hipStream_t stream);
+// FLANN branch with exact neighbours (l2_knn.hip): knn[pair][row] = (d1 bits, d2 bits, nearest train row); then the
+// ratio test + train-unique rule -> (queryIdx, trainIdx, ratio) lists in query order
+void launch_l2_knn2(const float* f32_pool, const PairWork* work, uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq,
+                    uint32_t* knn, hipStream_t stream);
+void launch_l2_ratio(const PairWork* work, uint32_t max_kp, uint32_t n_pairs, const uint32_t* knn, uint32_t* claim,
+                     double max_ratio, uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n, hipStream_t stream);
 void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipStream_t stream);
 void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,

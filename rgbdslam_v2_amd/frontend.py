@@ -300,6 +300,26 @@ class FrontEnd:
                                                         q.shape[0], out.ctypes.data, dist.ctypes.data))
         return out, dist
 
+    def upload_float_node(self, node_id: int, desc: np.ndarray, xyz1: np.ndarray):
+        """Node::feature_descriptors_ (N x dim CV_32F) for the FLANN branch (node.cpp:610-667)."""
+        desc = np.ascontiguousarray(desc, np.float32)
+        xyz1 = np.ascontiguousarray(xyz1, np.float32)
+        n = desc.shape[0]
+        if desc.ndim != 2 or xyz1.shape != (n, 4):
+            raise ValueError("desc must be [n, dim] float32 and xyz1 [n, 4] float32")
+        self._check(self._L.rgbdfe_upload_float_node(self._ctx, node_id, desc.ctypes.data, desc.shape[1],
+                                                     xyz1.ctypes.data, n))
+
+    def match_flann_pair_list(self, query_ids, train_ids, nn_distance_ratio: float = 0.95):
+        """Batched matchNodePair on the FLANN branch with exact neighbours; returns (records, ratios [n, 320])."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        out = np.zeros(q.shape[0], RESULT_DTYPE)
+        dist = np.zeros((q.shape[0], _lib.RGBDFE_MAX_MATCHES), np.float32)
+        self._check(self._L.rgbdfe_match_flann_pair_list(self._ctx, q.ctypes.data, t.ctypes.data, q.shape[0],
+                                                         nn_distance_ratio, out.ctypes.data, dist.ctypes.data))
+        return out, dist
+
     def submit_sift_pair_list(self, query_ids, train_ids, d_out_ptr: int, d_dist_ptr: Optional[int] = None) -> int:
         q = np.ascontiguousarray(query_ids, np.int32)
         t = np.ascontiguousarray(train_ids, np.int32)
