@@ -47,7 +47,9 @@ typedef struct {
   double   depth_cov;             /* value depth_covariance() froze at its first call
                                      (misc2.h:30-35): (sigma_depth * z0^2)^2, default z0 = 1 m -> 1e-4 */
   uint32_t seed;                  /* replaces srand(clock()) (node.cpp:1102) */
-  uint32_t reserved;
+  uint32_t g2o_iterations;        /* "g2o_transformation_refinement" default 0 = off (parameter_server.cpp:103): Gauss-
+                                     Newton steps of the two-view refinement after RANSAC (node.cpp:1222-1268); needs the
+                                     nodes' 2-D keypoints, rgbdfe_upload_node_keypoints */
 } rgbdfe_params;
 
 typedef struct {
@@ -127,6 +129,9 @@ int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc,
  * passed the copies.  Overwriting a resident node first waits for the batches in flight. */
 int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_desc,
                               const void* d_xyz1, int32_t n, void* stream);
+/* Node::feature_locations_2d_ (KeyPoint.pt, n x 2 float) of a resident node: only the g2o refinement reads them
+ * (edgeToFeature, transformation_estimation.cpp:95-125).  n must equal the node's row count. */
+int rgbdfe_upload_node_keypoints(rgbdfe_ctx* ctx, int32_t node_id, const float* kp_xy, int32_t n);
 int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id);
 int rgbdfe_node_count(rgbdfe_ctx* ctx, int32_t node_id); /* rows of a resident node or <0 */
 

@@ -602,6 +602,22 @@ def match_sift_node_pair(qdesc, qxyz1, qid, tdesc, txyz1, tid, params=None):
     return r
 
 
+def match_node_pair_g2o(qdesc, qxyz1, qkp, qid, tdesc, txyz1, tkp, tid, g2o_iterations, params=None):
+    """matchNodePair with g2o_transformation_refinement = g2o_iterations (node.cpp:1222-1268)."""
+    params = params or default_params()
+    arrs = [np.ascontiguousarray(a, dt) for a, dt in ((qdesc, np.uint8), (qxyz1, np.float32), (qkp, np.float32),
+                                                      (tdesc, np.uint8), (txyz1, np.float32), (tkp, np.float32))]
+    out = OrcResult()
+    L = lib()
+    vp = C.c_void_p
+    L.orc_match_node_pair_g2o.restype = None
+    L.orc_match_node_pair_g2o.argtypes = [vp, vp, vp, C.c_uint32, C.c_int32, vp, vp, vp, C.c_uint32, C.c_int32,
+                                          C.POINTER(OrcParams), C.c_int, C.POINTER(OrcResult)]
+    L.orc_match_node_pair_g2o(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), arrs[0].shape[0], qid, _p(arrs[3]), _p(arrs[4]),
+                              _p(arrs[5]), arrs[3].shape[0], tid, C.byref(params), g2o_iterations, C.byref(out))
+    return result_to_dict(out)
+
+
 def flann_match(qdesc, tdesc, nn_distance_ratio=0.95):
     """Node::featureMatching's FLANN branch (node.cpp:610-667) with exact neighbours: (queryIdx, trainIdx, ratio)."""
     qdesc = np.ascontiguousarray(qdesc, np.float32)

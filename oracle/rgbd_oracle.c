@@ -526,6 +526,271 @@ static int orc_has_nan16(const float* T) {
 /* A.3 getRelativeTransformationTo -- src/node.cpp:1074-1277                    */
 /* matches (mq,mt) must already be sorted ascending by distance (:1127, D2).    */
 /* ------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------- */
+/* a21  getTransformFromMatchesG2O -- src/transformation_estimation.cpp:37-170                                  */
+/* Two-view bundle adjustment: camera 2 = the newer node, fixed at the identity (:70-81); camera 1 = the        */
+/* earlier node, free, initialised with the RANSAC estimate (:83-91); one free point vertex per match,           */
+/* initialised with the newer node's 3-D position (:95-125, the second edgeToFeature call overwrites the first);  */
+/* two EdgeSE3PointXYZDepth edges per match with measurement (u, v, depth) and information diag(1, 1,             */
+/* 1/depth_covariance) (misc2.h:37-47); camera K = (521, 521, 319.5, 239.5) hard-coded (:56); Gauss-Newton for     */
+/* `iterations` steps (:44, :164); result = float(estimate of camera 1).inverse() (:169).                          */
+/* g2o (felixendres/g2o, branch c++03) is NOT in the reference tree: the optimiser is restated from the published  */
+/* algorithm -- the normal equations of exactly this cost with the point blocks eliminated (Schur complement, as   */
+/* g2o's BlockSolver does), the 3x3 point blocks inverted by cofactors, the 6x6 reduced system solved by Cholesky, */
+/* VertexSE3's update estimate = estimate * (dt, quaternion(dq)) -- "parity unpinned" against a g2o build; the     */
+/* per-match partial sums are reduced in the order the kernel uses (64 lanes, xor butterfly) so that kernel and    */
+/* oracle agree to the bit.                                                                                        */
+/* sel: positions (into mq/mt) of the matches to use.  qkp/tkp: pixel coordinates (x, y) per keypoint.              */
+/* ------------------------------------------------------------------------- */
+static void gn_rot_from_matrix_via_quaternion(const double Rin[9], double Rout[9]) {
+  /* Eigen::Quaterniond(Matrix3d) (Shoemake), normalised by g2o::SE3Quat, back to a rotation matrix */
+  double q[4]; /* x y z w */
+  const double t = Rin[0] + Rin[4] + Rin[8];
+  if (t > 0.0) {
+    double tt = sqrt(t + 1.0);
+    q[3] = 0.5 * tt;
+    tt = 0.5 / tt;
+    q[0] = (Rin[7] - Rin[5]) * tt;
+    q[1] = (Rin[2] - Rin[6]) * tt;
+    q[2] = (Rin[3] - Rin[1]) * tt;
+  } else {
+    int i = 0;
+    if (Rin[4] > Rin[0]) i = 1;
+    if (Rin[8] > Rin[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double tt = sqrt(Rin[i * 3 + i] - Rin[j * 3 + j] - Rin[k * 3 + k] + 1.0);
+    q[i] = 0.5 * tt;
+    tt = 0.5 / tt;
+    q[3] = (Rin[k * 3 + j] - Rin[j * 3 + k]) * tt;
+    q[j] = (Rin[j * 3 + i] + Rin[i * 3 + j]) * tt;
+    q[k] = (Rin[k * 3 + i] + Rin[i * 3 + k]) * tt;
+  }
+  const double nrm = sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) q[i] = q[i] / nrm;
+  /* Quaternion::toRotationMatrix */
+  const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
+  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  Rout[0] = 1.0 - (tyy + tzz); Rout[1] = txy - twz;          Rout[2] = txz + twy;
+  Rout[3] = txy + twz;          Rout[4] = 1.0 - (txx + tzz); Rout[5] = tyz - twx;
+  Rout[6] = txz - twy;          Rout[7] = tyz + twx;          Rout[8] = 1.0 - (txx + tyy);
+}
+
+/* projection Jacobian d(u, v, depth)/dY at camera coordinates Y, K = (fx, fy) */
+static void gn_proj(const double Y[3], double fx, double fy, double cx, double cy, double e[3], double J[9]) {
+  const double iz = 1.0 / Y[2];
+  e[0] = fx * (Y[0] * iz) + cx;
+  e[1] = fy * (Y[1] * iz) + cy;
+  e[2] = Y[2];
+  J[0] = fx * iz; J[1] = 0.0;     J[2] = -(fx * (Y[0] * iz)) * iz;
+  J[3] = 0.0;     J[4] = fy * iz; J[5] = -(fy * (Y[1] * iz)) * iz;
+  J[6] = 0.0;     J[7] = 0.0;     J[8] = 1.0;
+}
+
+#define GN_LANES 64
+/* the 27 reduced quantities of one Gauss-Newton step: upper triangle of S (21) then g (6) */
+static void gn_match_terms(const double X[3], const double R1[9], const double t1[3], const double m1[3],
+                           const double m2[3], double wz, double acc[27], double Hpp_inv[9], double bp[3],
+                           double Hcp[18]) {
+  const double fx = 521.0, fy = 521.0, cx = 319.5, cy = 239.5; /* :56 */
+  double e2[3], J2[9], e1[3], Jp1[9];
+  gn_proj(X, fx, fy, cx, cy, e2, J2); /* camera 2 = identity */
+  for (int i = 0; i < 3; ++i) e2[i] = e2[i] - m2[i];
+  const double dX[3] = {X[0] - t1[0], X[1] - t1[1], X[2] - t1[2]};
+  double Y[3];
+  for (int i = 0; i < 3; ++i) Y[i] = (R1[0 * 3 + i] * dX[0] + R1[1 * 3 + i] * dX[1]) + R1[2 * 3 + i] * dX[2]; /* R1^T dX */
+  gn_proj(Y, fx, fy, cx, cy, e1, Jp1);
+  for (int i = 0; i < 3; ++i) e1[i] = e1[i] - m1[i];
+  /* J1p = Jp1 * R1^T (3x3) ; J1c = Jp1 * [ -I | 2 [Y]x ] (3x6) */
+  double J1p[9], J1c[18];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      J1p[r * 3 + c] = (Jp1[r * 3 + 0] * R1[c * 3 + 0] + Jp1[r * 3 + 1] * R1[c * 3 + 1]) + Jp1[r * 3 + 2] * R1[c * 3 + 2];
+  const double Yx[9] = {0.0, -Y[2], Y[1], Y[2], 0.0, -Y[0], -Y[1], Y[0], 0.0};
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) J1c[r * 6 + c] = -Jp1[r * 3 + c];
+    for (int c = 0; c < 3; ++c)
+      J1c[r * 6 + 3 + c] = 2.0 * ((Jp1[r * 3 + 0] * Yx[0 * 3 + c] + Jp1[r * 3 + 1] * Yx[1 * 3 + c]) + Jp1[r * 3 + 2] * Yx[2 * 3 + c]);
+  }
+  const double w[3] = {1.0, 1.0, wz};
+  double Hpp[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      double s2 = 0.0, s1 = 0.0;
+      for (int r = 0; r < 3; ++r) { s2 += (J2[r * 3 + a] * w[r]) * J2[r * 3 + b]; s1 += (J1p[r * 3 + a] * w[r]) * J1p[r * 3 + b]; }
+      Hpp[a * 3 + b] = s2 + s1;
+    }
+  for (int a = 0; a < 3; ++a) {
+    double s2 = 0.0, s1 = 0.0;
+    for (int r = 0; r < 3; ++r) { s2 += (J2[r * 3 + a] * w[r]) * e2[r]; s1 += (J1p[r * 3 + a] * w[r]) * e1[r]; }
+    bp[a] = s2 + s1;
+  }
+  double Hcc[36], bc[6];
+  for (int a = 0; a < 6; ++a) {
+    for (int b = 0; b < 6; ++b) {
+      double s = 0.0;
+      for (int r = 0; r < 3; ++r) s += (J1c[r * 6 + a] * w[r]) * J1c[r * 6 + b];
+      Hcc[a * 6 + b] = s;
+    }
+    for (int b = 0; b < 3; ++b) {
+      double s = 0.0;
+      for (int r = 0; r < 3; ++r) s += (J1c[r * 6 + a] * w[r]) * J1p[r * 3 + b];
+      Hcp[a * 3 + b] = s;
+    }
+    double s = 0.0;
+    for (int r = 0; r < 3; ++r) s += (J1c[r * 6 + a] * w[r]) * e1[r];
+    bc[a] = s;
+  }
+  /* Hpp^-1 by cofactors (Eigen's 3x3 inverse) */
+  {
+    const double c00 = Hpp[4] * Hpp[8] - Hpp[5] * Hpp[7], c01 = Hpp[5] * Hpp[6] - Hpp[3] * Hpp[8], c02 = Hpp[3] * Hpp[7] - Hpp[4] * Hpp[6];
+    const double det = (Hpp[0] * c00 + Hpp[1] * c01) + Hpp[2] * c02;
+    const double id = 1.0 / det;
+    Hpp_inv[0] = c00 * id; Hpp_inv[3] = c01 * id; Hpp_inv[6] = c02 * id;
+    Hpp_inv[1] = (Hpp[2] * Hpp[7] - Hpp[1] * Hpp[8]) * id;
+    Hpp_inv[4] = (Hpp[0] * Hpp[8] - Hpp[2] * Hpp[6]) * id;
+    Hpp_inv[7] = (Hpp[1] * Hpp[6] - Hpp[0] * Hpp[7]) * id;
+    Hpp_inv[2] = (Hpp[1] * Hpp[5] - Hpp[2] * Hpp[4]) * id;
+    Hpp_inv[5] = (Hpp[2] * Hpp[3] - Hpp[0] * Hpp[5]) * id;
+    Hpp_inv[8] = (Hpp[0] * Hpp[4] - Hpp[1] * Hpp[3]) * id;
+  }
+  /* W = Hcp * Hpp^-1 (6x3) ; S_i = Hcc - W Hcp^T ; g_i = bc - W bp */
+  double W[18];
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 3; ++b)
+      W[a * 3 + b] = (Hcp[a * 3 + 0] * Hpp_inv[0 * 3 + b] + Hcp[a * 3 + 1] * Hpp_inv[1 * 3 + b]) + Hcp[a * 3 + 2] * Hpp_inv[2 * 3 + b];
+  int k = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b)
+      acc[k++] += Hcc[a * 6 + b] - ((W[a * 3 + 0] * Hcp[b * 3 + 0] + W[a * 3 + 1] * Hcp[b * 3 + 1]) + W[a * 3 + 2] * Hcp[b * 3 + 2]);
+  for (int a = 0; a < 6; ++a) acc[21 + a] += bc[a] - ((W[a * 3 + 0] * bp[0] + W[a * 3 + 1] * bp[1]) + W[a * 3 + 2] * bp[2]);
+}
+
+/* returns 1 when every step solved (positive pivots), 0 when the solver stopped early */
+int orc_g2o_refine(const float* qxyz1, const float* txyz1, const float* qkp, const float* tkp, const int32_t* mq,
+                   const int32_t* mt, const int32_t* sel, int nsel, float T[16], int iterations, double depth_cov) {
+  if (nsel <= 0 || nsel > ORC_MAX_MATCHES) return 0;
+  const double wz = 1.0 / depth_cov; /* misc2.h:44 with the frozen depth_covariance (D3) */
+  double (*X)[3] = malloc(sizeof(double) * 3 * (size_t)nsel);
+  double (*M1)[3] = malloc(sizeof(double) * 3 * (size_t)nsel);
+  double (*M2)[3] = malloc(sizeof(double) * 3 * (size_t)nsel);
+  for (int s = 0; s < nsel; ++s) {
+    const int m = sel[s];
+    const float* pq = qxyz1 + 4 * mq[m]; /* newer node: camera 2 */
+    const float* pt = txyz1 + 4 * mt[m]; /* earlier node: camera 1 */
+    /* edgeToFeature(earlier_node, trainIdx, cam1, v) then edgeToFeature(newer_node, queryIdx, cam2, v) (:152-156) */
+    if (!isnan(pt[2])) { M1[s][0] = (double)tkp[2 * mt[m]]; M1[s][1] = (double)tkp[2 * mt[m] + 1]; M1[s][2] = (double)pt[2]; }
+    else { M1[s][0] = (double)tkp[2 * mt[m]]; M1[s][1] = (double)tkp[2 * mt[m] + 1]; M1[s][2] = 10.0; }
+    if (!isnan(pq[2])) {
+      M2[s][0] = (double)qkp[2 * mq[m]]; M2[s][1] = (double)qkp[2 * mq[m] + 1]; M2[s][2] = (double)pq[2];
+      X[s][0] = (double)pq[0]; X[s][1] = (double)pq[1]; X[s][2] = (double)pq[2];
+    } else {
+      M2[s][0] = (double)qkp[2 * mq[m]]; M2[s][1] = (double)qkp[2 * mq[m] + 1]; M2[s][2] = 10.0;
+      X[s][0] = (double)(pq[0] * 10); X[s][1] = (double)(pq[1] * 10); X[s][2] = 10.0; /* :118 (float products) */
+    }
+  }
+  double Rin[9], R1[9], t1[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Rin[r * 3 + c] = (double)T[c * 4 + r];
+    t1[r] = (double)T[12 + r];
+  }
+  gn_rot_from_matrix_via_quaternion(Rin, R1);
+  int ok = 1;
+  for (int it = 0; it < iterations; ++it) {
+    /* lane l accumulates its matches l, l+64, ...; then the xor butterfly */
+    double part[GN_LANES][27];
+    memset(part, 0, sizeof(part));
+    double Hinv[9], bp[3], Hcp[18];
+    for (int s = 0; s < nsel; ++s) gn_match_terms(X[s], R1, t1, M1[s], M2[s], wz, part[s % GN_LANES], Hinv, bp, Hcp);
+    for (int d = GN_LANES / 2; d >= 1; d >>= 1) {
+      double nxt[GN_LANES][27];
+      for (int l = 0; l < GN_LANES; ++l)
+        for (int k = 0; k < 27; ++k) nxt[l][k] = part[l][k] + part[l ^ d][k];
+      memcpy(part, nxt, sizeof(part));
+    }
+    /* S dc = -g by Cholesky (lower) */
+    double S[36], g[6], L[36], y[6], dc[6];
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) { S[a * 6 + b] = S[b * 6 + a] = part[0][k]; ++k; }
+    for (int a = 0; a < 6; ++a) g[a] = part[0][21 + a];
+    memset(L, 0, sizeof(L));
+    for (int j = 0; j < 6 && ok; ++j) {
+      double d = S[j * 6 + j];
+      for (int kk = 0; kk < j; ++kk) d -= L[j * 6 + kk] * L[j * 6 + kk];
+      if (!(d > 0.0)) { ok = 0; break; }
+      L[j * 6 + j] = sqrt(d);
+      for (int i = j + 1; i < 6; ++i) {
+        double v = S[i * 6 + j];
+        for (int kk = 0; kk < j; ++kk) v -= L[i * 6 + kk] * L[j * 6 + kk];
+        L[i * 6 + j] = v / L[j * 6 + j];
+      }
+    }
+    if (!ok) break; /* the linear solver failed: g2o stops optimising */
+    for (int i = 0; i < 6; ++i) {
+      double v = -g[i];
+      for (int kk = 0; kk < i; ++kk) v -= L[i * 6 + kk] * y[kk];
+      y[i] = v / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+      double v = y[i];
+      for (int kk = i + 1; kk < 6; ++kk) v -= L[kk * 6 + i] * dc[kk];
+      dc[i] = v / L[i * 6 + i];
+    }
+    /* points: dp = -Hpp^-1 (bp + Hcp^T dc), from the state BEFORE the update */
+    for (int s = 0; s < nsel; ++s) {
+      double dummy[27];
+      memset(dummy, 0, sizeof(dummy));
+      gn_match_terms(X[s], R1, t1, M1[s], M2[s], wz, dummy, Hinv, bp, Hcp);
+      double r[3];
+      for (int b = 0; b < 3; ++b) {
+        double v = bp[b];
+        for (int a = 0; a < 6; ++a) v += Hcp[a * 3 + b] * dc[a];
+        r[b] = v;
+      }
+      double dp[3];
+      for (int a = 0; a < 3; ++a) dp[a] = -((Hinv[a * 3 + 0] * r[0] + Hinv[a * 3 + 1] * r[1]) + Hinv[a * 3 + 2] * r[2]);
+      for (int a = 0; a < 3; ++a) X[s][a] = X[s][a] + dp[a];
+    }
+    /* pose: estimate = estimate * (dt, q(dq)) (VertexSE3::oplusImpl, fromVectorMQT / fromCompactQuaternion) */
+    {
+      double Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const double qx = dc[3], qy = dc[4], qz = dc[5];
+      double ww = 1.0 - ((qx * qx + qy * qy) + qz * qz);
+      if (!(ww < 0.0)) {
+        ww = sqrt(ww);
+        const double tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
+        const double twx = tx * ww, twy = ty * ww, twz = tz * ww;
+        const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+        const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+        Rd[0] = 1.0 - (tyy + tzz); Rd[1] = txy - twz;          Rd[2] = txz + twy;
+        Rd[3] = txy + twz;          Rd[4] = 1.0 - (txx + tzz); Rd[5] = tyz - twx;
+        Rd[6] = txz - twy;          Rd[7] = tyz + twx;          Rd[8] = 1.0 - (txx + tyy);
+      }
+      double tn[3], Rn[9];
+      for (int r = 0; r < 3; ++r) tn[r] = t1[r] + ((R1[r * 3 + 0] * dc[0] + R1[r * 3 + 1] * dc[1]) + R1[r * 3 + 2] * dc[2]);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rn[r * 3 + c] = (R1[r * 3 + 0] * Rd[0 * 3 + c] + R1[r * 3 + 1] * Rd[1 * 3 + c]) + R1[r * 3 + 2] * Rd[2 * 3 + c];
+      memcpy(R1, Rn, sizeof(Rn));
+      memcpy(t1, tn, sizeof(tn));
+    }
+  }
+  /* transformation_estimate = estimate.cast<float>().inverse().matrix() (:169): R^T, -(R^T t) in float */
+  float Rf[9], tf[3];
+  for (int i = 0; i < 9; ++i) Rf[i] = (float)R1[i];
+  for (int i = 0; i < 3; ++i) tf[i] = (float)t1[i];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T[c * 4 + r] = Rf[c * 3 + r];
+    const float v = (Rf[0 * 3 + r] * tf[0] + Rf[1 * 3 + r] * tf[1]) + Rf[2 * 3 + r] * tf[2];
+    T[12 + r] = -v;
+    T[r * 4 + 3] = 0.0f;
+  }
+  T[15] = 1.0f;
+  free(X); free(M1); free(M2);
+  return ok;
+}
+
 /* Sensitivity harness: which inlier set the adopted transform was FITTED from (the final inlier set is what that
  * transform then scores; two runs can agree on the latter and still have fitted from different sets). */
 static _Thread_local uint64_t tl_fit_source = 0;
@@ -627,6 +892,66 @@ int orc_ransac(const float* qxyz1, const float* txyz1, const int32_t* mq,
   *valid_iterations_out = (int)valid_iterations;
   *real_iterations_out = real_iterations;
   return (unsigned int)n_matches >= min_inlier_threshold; /* :1275 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* The "G2O Refinement" block of getRelativeTransformationTo (node.cpp:1222-1268), applied to what the RANSAC loop    */
+/* left (T, rmse, the inlier list `matches`): refine with the inliers, re-score ALL matches, keep the result when it    */
+/* is superior (:1239), refine once more when it gained inliers (:1241-1249), adopt when it has at least as many        */
+/* inliers as before (:1252-1260).  Runs only for g2o_iterations > 0 and more inliers than min_inlier_threshold (:1226). */
+/* Returns the new `found` (:1275).                                                                                      */
+/* ------------------------------------------------------------------------- */
+int orc_g2o_block(const float* qxyz1, const float* txyz1, const float* qkp, const float* tkp, const int32_t* mq,
+                  const int32_t* mt, int n, const orc_params* prm, int g2o_iterations, float T[16], float* rmse_io,
+                  int32_t* matches, int* n_matches_io, int* valid_iterations_io) {
+  unsigned int min_inlier_threshold = (unsigned int)prm->min_matches;
+  if ((double)min_inlier_threshold > 0.75 * (double)n) min_inlier_threshold = (unsigned int)(0.75 * (double)n);
+  const float max_dist_m = (float)(double)prm->max_dist_for_inliers;
+  const double sq_max = (double)(max_dist_m * max_dist_m); /* :1235 */
+  int n_matches = *n_matches_io;
+  float rmse = *rmse_io;
+  if (g2o_iterations > 0 && (unsigned int)n_matches > min_inlier_threshold) { /* :1226 */
+    float Tn[16];
+    memcpy(Tn, T, sizeof(Tn)); /* :1228 */
+    orc_g2o_refine(qxyz1, txyz1, qkp, tkp, mq, mt, matches, n_matches, Tn, g2o_iterations, prm->depth_cov); /* :1229 */
+    int32_t inlier[ORC_MAX_MATCHES];
+    double inlier_error;
+    int n_inl = orc_compute_inliers_and_error(qxyz1, txyz1, mq, mt, n, Tn, sq_max, prm->depth_cov, inlier, &inlier_error); /* :1233 */
+    if (n_inl >= n_matches || ((unsigned int)n_inl >= min_inlier_threshold && inlier_error < (double)rmse)) { /* :1239 */
+      if (n_inl > n_matches) { /* :1241 */
+        orc_g2o_refine(qxyz1, txyz1, qkp, tkp, mq, mt, inlier, n_inl, Tn, g2o_iterations, prm->depth_cov); /* :1243 */
+        n_inl = orc_compute_inliers_and_error(qxyz1, txyz1, mq, mt, n, Tn, sq_max, prm->depth_cov, inlier, &inlier_error); /* :1244 */
+      }
+      if (n_inl >= n_matches) { /* :1252 */
+        memcpy(T, Tn, sizeof(Tn));                                   /* :1256 */
+        memcpy(matches, inlier, sizeof(int32_t) * (size_t)n_inl);    /* :1257 */
+        n_matches = n_inl;
+        rmse = (float)inlier_error;                                  /* :1258 */
+        (*valid_iterations_io)++;                                    /* :1259 */
+      }
+    }
+  }
+  *n_matches_io = n_matches;
+  *rmse_io = rmse;
+  return (unsigned int)n_matches >= min_inlier_threshold; /* :1275 */
+}
+
+/* matchNodePair with g2o_transformation_refinement = g2o_iterations; qkp / tkp: KeyPoint.pt of the two nodes */
+void orc_match_node_pair_g2o(const uint8_t* qdesc, const float* qxyz1, const float* qkp, uint32_t nq, int32_t qid,
+                             const uint8_t* tdesc, const float* txyz1, const float* tkp, uint32_t nt, int32_t tid,
+                             const orc_params* prm, int g2o_iterations, orc_result* out) {
+  orc_match_node_pair(qdesc, qxyz1, nq, qid, tdesc, txyz1, nt, tid, prm, out);
+  if (g2o_iterations <= 0 || out->n_all < prm->min_matches || out->n_all <= prm->min_matches) return; /* no RANSAC ran (:1319, :1087) */
+  const int found = orc_g2o_block(qxyz1, txyz1, qkp, tkp, out->all_q, out->all_t, out->n_all, prm, g2o_iterations, out->T,
+                                  &out->rmse, out->inl_idx, &out->n_inl, &out->valid_iterations);
+  if (found) {
+    out->info_scale = (double)((float)out->n_inl / (out->rmse * out->rmse)); /* node.cpp:1335 */
+    out->id1 = tid;
+    out->id2 = qid;
+  } else {
+    out->id1 = out->id2 = -1;
+    out->info_scale = 0.0;
+  }
 }
 
 /* ------------------------------------------------------------------------- */

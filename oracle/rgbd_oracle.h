@@ -118,6 +118,14 @@ void orc_gather_rows_f32(const float* in, const int32_t* kept_idx, int n, int di
 void orc_root_sift(float* desc, int n_rows, int dim);
 int orc_sift_match(const float* d1, int n1, const float* d2, int n2, int32_t* mq, int32_t* mt,
                    float* dist_out);
+int orc_g2o_refine(const float* qxyz1, const float* txyz1, const float* qkp, const float* tkp, const int32_t* mq,
+                   const int32_t* mt, const int32_t* sel, int nsel, float T[16], int iterations, double depth_cov);
+int orc_g2o_block(const float* qxyz1, const float* txyz1, const float* qkp, const float* tkp, const int32_t* mq,
+                  const int32_t* mt, int n, const orc_params* prm, int g2o_iterations, float T[16], float* rmse_io,
+                  int32_t* matches, int* n_matches_io, int* valid_iterations_io);
+void orc_match_node_pair_g2o(const uint8_t* qdesc, const float* qxyz1, const float* qkp, uint32_t nq, int32_t qid,
+                             const uint8_t* tdesc, const float* txyz1, const float* tkp, uint32_t nt, int32_t tid,
+                             const orc_params* prm, int g2o_iterations, orc_result* out);
 int orc_flann_match(const float* qdesc, int nq, const float* tdesc, int nt, int dim, double nn_distance_ratio,
                     int32_t* mq, int32_t* mt, float* md);
 void orc_match_float_node_pair(const float* qdesc, const float* qxyz1, int nq, int32_t qid, const float* tdesc,

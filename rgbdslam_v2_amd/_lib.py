@@ -30,7 +30,7 @@ class RgbdfeParams(C.Structure):
         ("max_dist_for_inliers", C.c_float),
         ("depth_cov", C.c_double),
         ("seed", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("g2o_iterations", C.c_uint32),
     ]
 
 
@@ -173,6 +173,8 @@ def load():
     L.rgbdfe_upload_float_node.argtypes = [ctx, i32, vp, i32, vp, i32]
     L.rgbdfe_match_flann_pair_list.restype = C.c_int
     L.rgbdfe_match_flann_pair_list.argtypes = [ctx, vp, vp, i32, C.c_double, vp, vp]
+    L.rgbdfe_upload_node_keypoints.restype = C.c_int
+    L.rgbdfe_upload_node_keypoints.argtypes = [ctx, i32, vp, i32]
     L.rgbdfe_sift_node_features.restype = C.c_int
     L.rgbdfe_sift_node_features.argtypes = [ctx, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
                                             C.c_double, C.c_double, C.c_double, i32, i32, vp, vp, vp, vp,
@@ -253,5 +255,5 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",
     "rgbdfe_gather_transport", "rgbdfe_set_hamming_mode", "rgbdfe_project_to_3d_cloud", "rgbdfe_detect_describe_cloud",
     "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",
-    "rgbdfe_match_flann_pair_list",
+    "rgbdfe_match_flann_pair_list", "rgbdfe_upload_node_keypoints",
 ]

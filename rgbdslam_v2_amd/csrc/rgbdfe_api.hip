@@ -87,6 +87,7 @@ struct rgbdfe_ctx {
   float4* d_xyz = nullptr;     // max_nodes x max_kp
   uint32_t* d_desc4 = nullptr; // max_nodes x max_kp x 32 dwords: every descriptor bit as an fp4 (+-1) operand nibble, in
                                // MFMA fragment order per tile of 32 rows (hamming_mfma.hip)
+  float* d_kp2d = nullptr;     // max_nodes x max_kp x 2: KeyPoint.pt (allocated with the first rgbdfe_upload_node_keypoints)
   int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
   // Batches run on kLanes internal HIP streams ("lanes"), each with its own keys / results
   // staging, so that batch k+1's Hamming kernel fills the SIMDs that batch k's RANSAC tail
@@ -196,6 +197,7 @@ void fill_ransac_const(rgbdfe_ctx* ctx) {
   rc.raster_cov_x = sx * sx;
   rc.raster_cov_y = sy * sy;
   rc.seed = p.seed;
+  rc.g2o_iterations = (int32_t)p.g2o_iterations;
 }
 
 int validate_params(rgbdfe_ctx* ctx, const rgbdfe_params& p) {
@@ -205,6 +207,9 @@ int validate_params(rgbdfe_ctx* ctx, const rgbdfe_params& p) {
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "min_matches / ransac_iterations must be >= 0");
   if (!(p.max_dist_for_inliers > 0.f))
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "max_dist_for_inliers must be > 0");
+  if (p.g2o_iterations > 1000u) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "g2o_iterations must be <= 1000");
+  if (p.g2o_iterations > 0u && !(p.depth_cov > 0.0))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "the g2o refinement needs depth_cov > 0");
   return RGBDFE_OK;
 }
 
@@ -378,6 +383,8 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     if (w.nt > max_nt) max_nt = w.nt;
   }
   if (sift && n > 65535) return fail(ctx, RGBDFE_ERR_CAPACITY, "a SIFT batch holds at most 65535 pairs");
+  if (ctx->rc.g2o_iterations > 0 && !ctx->d_kp2d)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "g2o_iterations > 0 needs the nodes' keypoints (rgbdfe_upload_node_keypoints)");
   // Everything that can fail without leaving work behind (scratch allocations, the schedule) comes first; the ticket
   // is committed only once the batch is on its stream.
   bool latency = false;
@@ -414,6 +421,8 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       else
         launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, lane.d_prep,
                              lane.d_ec, stream);
+      if (ctx->rc.g2o_iterations > 0)
+        launch_g2o_refine(slot.d_work, d_out, (uint32_t)n, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
     } else {
       if (matcher == 2) {
@@ -437,6 +446,8 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
         launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
                                   lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
                                   (uint32_t)n, ctx->rc, lane.d_prep, lane.d_ec, stream);
+      if (ctx->rc.g2o_iterations > 0)
+        launch_g2o_refine(slot.d_work, d_out, (uint32_t)n, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
       if (ctx->profiling) (void)hipEventRecord(pend.d, stream);
     }
     launch_err = hipGetLastError();
@@ -591,6 +602,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
   if (ctx->nodes_ready_ev) (void)hipEventDestroy(ctx->nodes_ready_ev);
   if (ctx->d_desc4) (void)hipFree(ctx->d_desc4);
+  if (ctx->d_kp2d) (void)hipFree(ctx->d_kp2d);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -671,6 +683,26 @@ int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_de
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   return upload_common(ctx, node_id, d_desc, d_xyz1, n, hipMemcpyDeviceToDevice, s, stream == nullptr);
+}
+
+int rgbdfe_upload_node_keypoints(rgbdfe_ctx* ctx, int32_t node_id, const float* kp_xy, int32_t n) {
+  if (!ctx || n < 0 || (n > 0 && !kp_xy)) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad keypoint upload arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  auto it = ctx->nodes.find(node_id);
+  if (it == ctx->nodes.end()) return fail(ctx, RGBDFE_ERR_UNKNOWN_NODE, "keypoints of a node that is not resident");
+  if ((uint32_t)n != it->second.n) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "keypoint count differs from the node's rows");
+  if (!ctx->d_kp2d) {
+    const size_t rows = (size_t)ctx->cfg.max_nodes * (size_t)ctx->cfg.max_keypoints;
+    if (hipMalloc((void**)&ctx->d_kp2d, rows * 8) != hipSuccess) return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "keypoint slab");
+    HIP_TRY(ctx, hipMemset(ctx->d_kp2d, 0, rows * 8));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+  }
+  for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));  // batches in flight may read the slot
+  if (n > 0)
+    HIP_TRY(ctx, hipMemcpy(ctx->d_kp2d + (size_t)it->second.slot * (size_t)ctx->cfg.max_keypoints * 2, kp_xy,
+                           (size_t)n * 8, hipMemcpyHostToDevice));
+  return RGBDFE_OK;
 }
 
 int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id) {
@@ -2170,6 +2202,11 @@ int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_de
     if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_upload_node_device");
     return impl::rgbdfe_upload_node_device(ctx, node_id, d_desc, d_xyz1, n, stream);
   });
+}
+
+int rgbdfe_upload_node_keypoints(rgbdfe_ctx* ctx, int32_t node_id, const float* kp_xy, int32_t n) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_upload_node_keypoints(c, node_id, kp_xy, n));
 }
 
 int rgbdfe_release_node(rgbdfe_ctx* ctx, int32_t node_id) {

@@ -30,6 +30,7 @@ struct RansacConst {
   double raster_cov_x;  // misc.cpp:708
   double raster_cov_y;  // misc.cpp:709
   uint32_t seed;
+  int32_t g2o_iterations;  // "g2o_transformation_refinement" (parameter_server.cpp:103), 0 = off
 };
 
 // launchers (defined in the .hip files)
@@ -96,6 +97,10 @@ struct RecordPlan {
                               // a refinement round's scorings, read back lane = slot by the sequential error sums)
 };
 size_t select_ransac_ec_region_bytes();
+// node.cpp:1222-1268 after the RANSAC results exist (rc.g2o_iterations > 0): two-view Gauss-Newton refinement over the
+// inliers + re-scoring + the adopt rules.  kp_pool: KeyPoint.pt slab [slot][row] (float2).
+void launch_g2o_refine(const PairWork* work, rgbdfe_match_result* results, uint32_t n_pairs, const RansacConst& rc,
+                       const struct PairPrep* prep, const float* kp_pool, uint32_t max_kp, double* ec_pool, hipStream_t stream);
 void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, const uint32_t* keys,
                                   uint32_t key_planes, rgbdfe_match_result* results, uint32_t max_kp,
                                   uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, IterRec* recs, WalkState* walk,

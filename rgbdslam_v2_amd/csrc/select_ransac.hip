@@ -1676,6 +1676,423 @@ void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* w
   launch_record_replay(work, results, n_pairs, rc, prep, recs, walk, ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
+// =====================================================================================================================
+// "G2O Refinement" (node.cpp:1222-1268 + getTransformFromMatchesG2O, transformation_estimation.cpp:37-170), after the
+// RANSAC result of a pair exists: a two-view bundle adjustment over the inlier matches -- camera 2 = the newer node, fixed
+// at the identity; camera 1 = the earlier node, free, started at the RANSAC estimate; one free 3-D point per match started
+// at the newer node's position; two (u, v, depth) edges per match, information diag(1, 1, 1 / depth_covariance);
+// K = (521, 521, 319.5, 239.5) (:56); `g2o_transformation_refinement` Gauss-Newton steps -- then the re-scoring and the
+// accept / refine-again / adopt rules of :1233-1260.
+// g2o itself is not in the reference tree: the optimiser is the oracle's restatement (orc_g2o_refine: normal equations
+// with the 3x3 point blocks eliminated, the reduced 6x6 system by Cholesky, VertexSE3's multiplicative update), followed
+// operation by operation.  One wave per pair: LANE = MATCH for the per-match blocks (each lane owns matches l, l+64, ...),
+// the 27 reduced sums by an xor butterfly (the oracle adds in the same order), the 6x6 solve redundantly in every lane.
+// =====================================================================================================================
+struct GnShared {
+  double X[RGBDFE_MAX_MATCHES][3];     // the point vertices
+  float2 kq[RGBDFE_MAX_MATCHES];       // KeyPoint.pt of the selected matches in the newer / the earlier node
+  float2 kt[RGBDFE_MAX_MATCHES];
+  uint16_t sel[RGBDFE_MAX_MATCHES];    // k-th selected match
+};
+
+__device__ __forceinline__ void gn_proj(const double* Y, double* e, double* J) {
+  const double fx = 521.0, fy = 521.0, cx = 319.5, cy = 239.5;  // transformation_estimation.cpp:56
+  const double iz = 1.0 / Y[2];
+  e[0] = fx * (Y[0] * iz) + cx;
+  e[1] = fy * (Y[1] * iz) + cy;
+  e[2] = Y[2];
+  J[0] = fx * iz; J[1] = 0.0;     J[2] = -(fx * (Y[0] * iz)) * iz;
+  J[3] = 0.0;     J[4] = fy * iz; J[5] = -(fy * (Y[1] * iz)) * iz;
+  J[6] = 0.0;     J[7] = 0.0;     J[8] = 1.0;
+}
+
+// the blocks of one match: adds its Schur terms to acc[27] (upper triangle of S, then g); returns Hpp^-1, bp, Hcp
+__device__ __forceinline__ void gn_match_terms(const double* X, const double* R1, const double* t1, const double* m1,
+                                               const double* m2, double wz, double* acc, double* Hpp_inv, double* bp,
+                                               double* Hcp) {
+  double e2[3], J2[9], e1[3], Jp1[9];
+  gn_proj(X, e2, J2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e2[i] = e2[i] - m2[i];
+  const double dX[3] = {X[0] - t1[0], X[1] - t1[1], X[2] - t1[2]};
+  double Y[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Y[i] = (R1[0 * 3 + i] * dX[0] + R1[1 * 3 + i] * dX[1]) + R1[2 * 3 + i] * dX[2];
+  gn_proj(Y, e1, Jp1);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e1[i] = e1[i] - m1[i];
+  double J1p[9], J1c[18];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      J1p[r * 3 + c] = (Jp1[r * 3 + 0] * R1[c * 3 + 0] + Jp1[r * 3 + 1] * R1[c * 3 + 1]) + Jp1[r * 3 + 2] * R1[c * 3 + 2];
+  const double Yx[9] = {0.0, -Y[2], Y[1], Y[2], 0.0, -Y[0], -Y[1], Y[0], 0.0};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) J1c[r * 6 + c] = -Jp1[r * 3 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      J1c[r * 6 + 3 + c] = 2.0 * ((Jp1[r * 3 + 0] * Yx[0 * 3 + c] + Jp1[r * 3 + 1] * Yx[1 * 3 + c]) + Jp1[r * 3 + 2] * Yx[2 * 3 + c]);
+  }
+  const double w[3] = {1.0, 1.0, wz};
+  double Hpp[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      double s2 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { s2 += (J2[r * 3 + a] * w[r]) * J2[r * 3 + b]; s1 += (J1p[r * 3 + a] * w[r]) * J1p[r * 3 + b]; }
+      Hpp[a * 3 + b] = s2 + s1;
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double s2 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { s2 += (J2[r * 3 + a] * w[r]) * e2[r]; s1 += (J1p[r * 3 + a] * w[r]) * e1[r]; }
+    bp[a] = s2 + s1;
+  }
+  double Hcc[36], bc[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sacc += (J1c[r * 6 + a] * w[r]) * J1c[r * 6 + b];
+      Hcc[a * 6 + b] = sacc;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sacc += (J1c[r * 6 + a] * w[r]) * J1p[r * 3 + b];
+      Hcp[a * 3 + b] = sacc;
+    }
+    double sacc = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) sacc += (J1c[r * 6 + a] * w[r]) * e1[r];
+    bc[a] = sacc;
+  }
+  {
+    const double c00 = Hpp[4] * Hpp[8] - Hpp[5] * Hpp[7], c01 = Hpp[5] * Hpp[6] - Hpp[3] * Hpp[8], c02 = Hpp[3] * Hpp[7] - Hpp[4] * Hpp[6];
+    const double det = (Hpp[0] * c00 + Hpp[1] * c01) + Hpp[2] * c02;
+    const double id = 1.0 / det;
+    Hpp_inv[0] = c00 * id; Hpp_inv[3] = c01 * id; Hpp_inv[6] = c02 * id;
+    Hpp_inv[1] = (Hpp[2] * Hpp[7] - Hpp[1] * Hpp[8]) * id;
+    Hpp_inv[4] = (Hpp[0] * Hpp[8] - Hpp[2] * Hpp[6]) * id;
+    Hpp_inv[7] = (Hpp[1] * Hpp[6] - Hpp[0] * Hpp[7]) * id;
+    Hpp_inv[2] = (Hpp[1] * Hpp[5] - Hpp[2] * Hpp[4]) * id;
+    Hpp_inv[5] = (Hpp[2] * Hpp[3] - Hpp[0] * Hpp[5]) * id;
+    Hpp_inv[8] = (Hpp[0] * Hpp[4] - Hpp[1] * Hpp[3]) * id;
+  }
+  double W[18];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      W[a * 3 + b] = (Hcp[a * 3 + 0] * Hpp_inv[0 * 3 + b] + Hcp[a * 3 + 1] * Hpp_inv[1 * 3 + b]) + Hcp[a * 3 + 2] * Hpp_inv[2 * 3 + b];
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = a; b < 6; ++b)
+      acc[k++] += Hcc[a * 6 + b] - ((W[a * 3 + 0] * Hcp[b * 3 + 0] + W[a * 3 + 1] * Hcp[b * 3 + 1]) + W[a * 3 + 2] * Hcp[b * 3 + 2]);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) acc[21 + a] += bc[a] - ((W[a * 3 + 0] * bp[0] + W[a * 3 + 1] * bp[1]) + W[a * 3 + 2] * bp[2]);
+}
+
+// Eigen::Quaterniond(Matrix3d), normalised (g2o::SE3Quat), back to a rotation matrix: the start estimate of camera 1
+__device__ __forceinline__ void gn_rot_via_quaternion(const double* Rin, double* Rout) {
+  double q[4];
+  const double t = Rin[0] + Rin[4] + Rin[8];
+  if (t > 0.0) {
+    double tt = sqrt(t + 1.0);
+    q[3] = 0.5 * tt;
+    tt = 0.5 / tt;
+    q[0] = (Rin[7] - Rin[5]) * tt;
+    q[1] = (Rin[2] - Rin[6]) * tt;
+    q[2] = (Rin[3] - Rin[1]) * tt;
+  } else {
+    int i = 0;
+    if (Rin[4] > Rin[0]) i = 1;
+    if (Rin[8] > Rin[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double tt = sqrt(Rin[i * 3 + i] - Rin[j * 3 + j] - Rin[k * 3 + k] + 1.0);
+    q[i] = 0.5 * tt;
+    tt = 0.5 / tt;
+    q[3] = (Rin[k * 3 + j] - Rin[j * 3 + k]) * tt;
+    q[j] = (Rin[j * 3 + i] + Rin[i * 3 + j]) * tt;
+    q[k] = (Rin[k * 3 + i] + Rin[i * 3 + k]) * tt;
+  }
+  const double nrm = sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) q[i] = q[i] / nrm;
+  const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
+  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  Rout[0] = 1.0 - (tyy + tzz); Rout[1] = txy - twz;          Rout[2] = txz + twy;
+  Rout[3] = txy + twz;          Rout[4] = 1.0 - (txx + tzz); Rout[5] = tyz - twx;
+  Rout[6] = txz - twy;          Rout[7] = tyz + twx;          Rout[8] = 1.0 - (txx + tyy);
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int d) {
+  return __hiloint2double(__shfl_xor(__double2hiint(v), d), __shfl_xor(__double2loint(v), d));
+}
+
+// getTransformFromMatchesG2O over the matches whose bits are set in `mask`; R, t (float, newer -> earlier) in and out
+__device__ void gn_two_view(const uint64_t* mask, const RansacLds& lds, GnShared& gs, const rgbdfe_match_result* out,
+                            const float2* __restrict__ qkp, const float2* __restrict__ tkp, int iterations, double wz,
+                            float* R, float* tr) {
+  const int lane = threadIdx.x;
+  // the selected matches in match order
+  int nsel = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint64_t pm = mask[r];
+    if ((pm >> lane) & 1ull) gs.sel[nsel + (int)lane_rank(pm)] = (uint16_t)(r * kWave + lane);
+    nsel += __popcll(pm);
+  }
+  __syncthreads();
+  for (int s = lane; s < nsel; s += kWave) {
+    const int m = gs.sel[s];
+    gs.kq[s] = qkp[out->all_q[m]];
+    gs.kt[s] = tkp[out->all_t[m]];
+    const float px = lds.M[m * kRec + 0], py = lds.M[m * kRec + 1], pz = lds.M[m * kRec + 2];
+    if (!__builtin_isnan(pz)) {
+      gs.X[s][0] = (double)px; gs.X[s][1] = (double)py; gs.X[s][2] = (double)pz;
+    } else {  // :118
+      gs.X[s][0] = (double)(px * 10); gs.X[s][1] = (double)(py * 10); gs.X[s][2] = 10.0;
+    }
+  }
+  __syncthreads();
+  double R1[9], t1[3];
+  {
+    double Rin[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rin[i] = (double)R[i];
+    gn_rot_via_quaternion(Rin, R1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t1[i] = (double)tr[i];
+  }
+  auto measurements = [&](int s, double* m1, double* m2) {
+    const int m = gs.sel[s];
+    const float qz = lds.M[m * kRec + 2], tz = lds.M[m * kRec + 5];
+    m1[0] = (double)gs.kt[s].x; m1[1] = (double)gs.kt[s].y; m1[2] = __builtin_isnan(tz) ? 10.0 : (double)tz;
+    m2[0] = (double)gs.kq[s].x; m2[1] = (double)gs.kq[s].y; m2[2] = __builtin_isnan(qz) ? 10.0 : (double)qz;
+  };
+  bool ok = true;
+  for (int it = 0; it < iterations && ok; ++it) {
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    double Hinv[9], bp[3], Hcp[18];
+    for (int s = lane; s < nsel; s += kWave) {
+      double m1[3], m2[3];
+      measurements(s, m1, m2);
+      const double X[3] = {gs.X[s][0], gs.X[s][1], gs.X[s][2]};
+      gn_match_terms(X, R1, t1, m1, m2, wz, acc, Hinv, bp, Hcp);
+    }
+#pragma unroll
+    for (int d = kWave / 2; d >= 1; d >>= 1)
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc[k] = acc[k] + shfl_xor_f64(acc[k], d);
+    // S dc = -g by Cholesky, redundantly in every lane (all lanes hold the same sums)
+    double S[36], L[36], y[6], dc[6];
+    {
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) { S[a * 6 + b] = acc[k]; S[b * 6 + a] = acc[k]; ++k; }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = S[j * 6 + j];
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk)
+        if (kk < j) d -= L[j * 6 + kk] * L[j * 6 + kk];
+      if (!(d > 0.0)) ok = false;
+      L[j * 6 + j] = sqrt(d);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (i > j) {
+          double v = S[i * 6 + j];
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk)
+            if (kk < j) v -= L[i * 6 + kk] * L[j * 6 + kk];
+          L[i * 6 + j] = v / L[j * 6 + j];
+        }
+    }
+    if (!ok) break;  // the linear solver failed: the optimiser stops (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double v = -acc[21 + i];
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk)
+        if (kk < i) v -= L[i * 6 + kk] * y[kk];
+      y[i] = v / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double v = y[i];
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk)
+        if (kk > i) v -= L[kk * 6 + i] * dc[kk];
+      dc[i] = v / L[i * 6 + i];
+    }
+    // the points, from the state before the update
+    for (int s = lane; s < nsel; s += kWave) {
+      double m1[3], m2[3], dummy[27];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) dummy[k] = 0.0;
+      measurements(s, m1, m2);
+      const double X[3] = {gs.X[s][0], gs.X[s][1], gs.X[s][2]};
+      gn_match_terms(X, R1, t1, m1, m2, wz, dummy, Hinv, bp, Hcp);
+      double rr[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        double v = bp[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v += Hcp[a * 3 + b] * dc[a];
+        rr[b] = v;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double dp = -((Hinv[a * 3 + 0] * rr[0] + Hinv[a * 3 + 1] * rr[1]) + Hinv[a * 3 + 2] * rr[2]);
+        gs.X[s][a] = X[a] + dp;
+      }
+    }
+    // the pose: estimate = estimate * (dt, q(dq))
+    {
+      double Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const double qx = dc[3], qy = dc[4], qz = dc[5];
+      double ww = 1.0 - ((qx * qx + qy * qy) + qz * qz);
+      if (!(ww < 0.0)) {
+        ww = sqrt(ww);
+        const double tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
+        const double twx = tx * ww, twy = ty * ww, twz = tz * ww;
+        const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+        const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+        Rd[0] = 1.0 - (tyy + tzz); Rd[1] = txy - twz;          Rd[2] = txz + twy;
+        Rd[3] = txy + twz;          Rd[4] = 1.0 - (txx + tzz); Rd[5] = tyz - twx;
+        Rd[6] = txz - twy;          Rd[7] = tyz + twx;          Rd[8] = 1.0 - (txx + tyy);
+      }
+      double tn[3], Rn[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) tn[r] = t1[r] + ((R1[r * 3 + 0] * dc[0] + R1[r * 3 + 1] * dc[1]) + R1[r * 3 + 2] * dc[2]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          Rn[r * 3 + c] = (R1[r * 3 + 0] * Rd[0 * 3 + c] + R1[r * 3 + 1] * Rd[1 * 3 + c]) + R1[r * 3 + 2] * Rd[2 * 3 + c];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R1[i] = Rn[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t1[i] = tn[i];
+    }
+    __syncthreads();
+  }
+  // estimate.cast<float>().inverse() (:169)
+  float Rf[9], tf[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rf[i] = (float)R1[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tf[i] = (float)t1[i];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[r * 3 + c] = Rf[c * 3 + r];
+    const float v = (Rf[0 * 3 + r] * tf[0] + Rf[1 * 3 + r] * tf[1]) + Rf[2 * 3 + r] * tf[2];
+    tr[r] = -v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kWave) void g2o_refine_kernel(const PairWork* __restrict__ work,
+                                                           rgbdfe_match_result* __restrict__ results, uint32_t n_pairs,
+                                                           const RansacConst rc, const PairPrep* __restrict__ prep,
+                                                           const float2* __restrict__ kp_pool, uint32_t max_kp,
+                                                           double* __restrict__ ec_pool) {
+  __shared__ RansacLds lds;
+  __shared__ GnShared gs;
+  const uint32_t pair = blockIdx.x;
+  if (pair >= n_pairs) return;
+  const int lane = threadIdx.x;
+  const PairWork w = work[pair];
+  rgbdfe_match_result* __restrict__ out = results + pair;
+  const PairPrep* __restrict__ pp = prep + pair;
+  const int n_all = pp->n_all;
+  if (!(n_all > rc.min_matches)) return;  // getRelativeTransformationTo returned at :1087 (or was never called, :1319)
+  uint32_t thr = (uint32_t)rc.min_matches;
+  if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);
+  int n_matches = out->n_inl;
+  if (!((uint32_t)n_matches > thr)) return;  // :1226
+  double* __restrict__ ec_region = ec_pool + (size_t)blockIdx.x * kEcRegion;
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(pp->M);
+    float4* __restrict__ dst = reinterpret_cast<float4*>(lds.M);
+    constexpr int kVec = RGBDFE_MAX_MATCHES * kRec / 4;
+    for (int v = lane; v < kVec; v += kWave) dst[v] = src[v];
+    __syncthreads();
+  }
+  const float pmax = pp->pmax;
+  const float2* __restrict__ qkp = kp_pool + (size_t)w.q_slot * max_kp;
+  const float2* __restrict__ tkp = kp_pool + (size_t)w.t_slot * max_kp;
+  const double wz = 1.0 / rc.depth_cov;  // point_information_matrix (misc2.h:44), depth_covariance frozen (D3)
+  float R[9], tr[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = out->trafo[j * 4 + i];
+    tr[i] = out->trafo[12 + i];
+  }
+  uint64_t mask[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) mask[r] = out->inlier_mask[r];
+  float rmse = out->rmse;
+  gn_two_view(mask, lds, gs, out, qkp, tkp, rc.g2o_iterations, wz, R, tr);  // :1229
+  uint64_t inl[kRounds];
+  int n_inl;
+  double inlier_error;
+  score_hypothesis(R, tr, n_all, 0u, rc, lds, pmax, ec_region, inl, n_inl, inlier_error);  // :1233
+  bool adopt = false;
+  if (n_inl >= n_matches || ((uint32_t)n_inl >= thr && inlier_error < (double)rmse)) {  // :1239
+    if (n_inl > n_matches) {                                                             // :1241
+      gn_two_view(inl, lds, gs, out, qkp, tkp, rc.g2o_iterations, wz, R, tr);             // :1243
+      score_hypothesis(R, tr, n_all, 0u, rc, lds, pmax, ec_region, inl, n_inl, inlier_error);  // :1244
+    }
+    adopt = n_inl >= n_matches;  // :1252
+  }
+  if (adopt && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) out->trafo[j * 4 + i] = R[i * 3 + j];
+      out->trafo[12 + i] = tr[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) out->inlier_mask[r] = inl[r];
+    out->n_inl = n_inl;
+    const float new_rmse = (float)inlier_error;  // :1258
+    out->rmse = new_rmse;
+    out->valid_iterations = out->valid_iterations + 1;  // :1259
+    // found stays true (n_inl >= n_matches > thr); the edge's information follows the new numbers (node.cpp:1335)
+    out->info_scale = (double)((float)n_inl / (new_rmse * new_rmse));
+  }
+}
+
+void launch_g2o_refine(const PairWork* work, rgbdfe_match_result* results, uint32_t n_pairs, const RansacConst& rc,
+                       const PairPrep* prep, const float* kp_pool, uint32_t max_kp, double* ec_pool, hipStream_t stream) {
+  if (n_pairs == 0 || rc.g2o_iterations <= 0) return;
+  hipLaunchKernelGGL(g2o_refine_kernel, dim3(n_pairs), dim3(kWave), 0, stream, work, results, n_pairs, rc, prep,
+                     reinterpret_cast<const float2*>(kp_pool), max_kp, ec_pool);
+}
+
 size_t select_ransac_ec_region_bytes() { return sizeof(double) * (size_t)kEcRegion; }
 
 }  // namespace rgbdfe

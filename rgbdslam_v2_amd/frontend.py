@@ -179,6 +179,11 @@ class FrontEnd:
         self._check(self._L.rgbdfe_upload_node_device(self._ctx, node_id, d_desc_ptr, d_xyz1_ptr,
                                                       n, stream))
 
+    def upload_node_keypoints(self, node_id: int, kp_xy: np.ndarray):
+        """Node::feature_locations_2d_ (KeyPoint.pt) of a resident node, for the g2o refinement."""
+        kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+        self._check(self._L.rgbdfe_upload_node_keypoints(self._ctx, node_id, kp_xy.ctypes.data, kp_xy.shape[0]))
+
     def release_node(self, node_id: int):
         self._check(self._L.rgbdfe_release_node(self._ctx, node_id))
 
