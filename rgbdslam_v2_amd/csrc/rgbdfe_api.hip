@@ -285,7 +285,8 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   const int chunk_cfg = force_phases ? -ctx->latency_chunk_iters : ctx->latency_chunk_iters;
   // automatic: small batches want many short waves (latency), large ones long waves (a wave refills its 7 slots from
   // its own share of iterations, so longer shares keep the batched rounds fuller); tools/bench_batch_sweep.py
-  int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 64 ? 4 : (n <= 640 ? 7 : (n <= 1280 ? 14 : 28)));
+  // (above 1280 pairs: 64 = one full lane = hypothesis batch per recording wave, tools sweep r02g)
+  int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 64 ? 4 : (n <= 640 ? 7 : (n <= 1280 ? 14 : 64)));
   // every recording wave owns a region of the error pool: keep the largest grid (a phase is at most all iterations)
   // within kMaxEcRegions by recording more iterations per wave
   // (a batch of more than kMaxEcRegions pairs cannot get below one region per pair: it takes the one-wave kernel)
@@ -311,7 +312,9 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   // Up to 256 pairs one phase (full speculation, lowest latency); above, four phases so that recording stops
   // where the reference's bookkeeping stops iterating.
   const int I = ctx->rc.ransac_iterations;
-  if (n <= 256 && !force_phases) { plan->n_phases = 1; plan->ends[0] = I; }
+  static const int env_phases = getenv("RGBDFE_PHASES") ? atoi(getenv("RGBDFE_PHASES")) : 0;  // experiments only
+  if ((n <= 256 && !force_phases) || env_phases == 1) { plan->n_phases = 1; plan->ends[0] = I; }
+  else if (env_phases == 2) { plan->n_phases = 2; plan->ends[0] = ((I * 7 / 20) / 7) * 7 > 0 ? ((I * 7 / 20) / 7) * 7 : I; plan->ends[1] = I; if (plan->ends[0] >= I) plan->n_phases = 1; }
   else {
     const int cand[4] = {14, ((I * 7 / 20) / 7) * 7, ((I * 14 / 20) / 7) * 7, I};
     int k = 0, last = 0;
@@ -324,7 +327,8 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   if (latency) {
     int begin = 0;
     for (int p = 0; p < plan->n_phases; ++p) {
-      const size_t chunks = (size_t)((plan->ends[p] - begin + chunk - 1) / chunk);
+      const int cover = (plan->n_phases > 2 && p == 1) ? I : plan->ends[p];  // launch_record_replay: speculative cover
+      const size_t chunks = (size_t)((cover - begin + chunk - 1) / chunk);
       if ((size_t)n * chunks > regions) regions = (size_t)n * chunks;
       begin = plan->ends[p];
     }
@@ -382,16 +386,28 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     if (w.nq > max_nq) max_nq = w.nq;
     if (w.nt > max_nt) max_nt = w.nt;
   }
-  if (sift && n > 65535) return fail(ctx, RGBDFE_ERR_CAPACITY, "a SIFT batch holds at most 65535 pairs");
   if (ctx->rc.g2o_iterations > 0 && !ctx->d_kp2d)
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "g2o_iterations > 0 needs the nodes' keypoints (rgbdfe_upload_node_keypoints)");
   // Everything that can fail without leaving work behind (scratch allocations, the schedule) comes first; the ticket
   // is committed only once the batch is on its stream.
+  // A batch whose record / replay scratch would be too large (pairs x iterations records, one error-pool region per
+  // recording wave) is run as several pieces, one after the other on the same stream with the same scratch: every piece
+  // takes the record / replay schedule.  (The one-wave-per-pair kernel runs only when it is asked for,
+  // rgbdfe_set_latency_mode(ctx, 0, 0).)
+  int32_t piece = n;
+  if (n > 0 && ctx->latency_pairs != 0) {
+    const size_t I = (size_t)(ctx->rc.ransac_iterations > 0 ? ctx->rc.ransac_iterations : 1);
+    size_t fit = (((size_t)1 << 24) / I) < kMaxEcRegions ? (((size_t)1 << 24) / I) : kMaxEcRegions;
+    if (fit > 65535) fit = 65535;  // (also the limit of a grid's y extent, which the SIFT kernels index pairs with)
+    if (fit < 1) fit = 1;
+    if ((size_t)n > fit && (size_t)n <= (size_t)ctx->latency_pairs) piece = (int32_t)fit;
+  }
+  if (sift && piece > 65535) return fail(ctx, RGBDFE_ERR_CAPACITY, "a one-wave SIFT batch holds at most 65535 pairs");
   bool latency = false;
   int chunk = 7;
   PhasePlan pp{};
   if (n > 0) {
-    int rcl = want_latency_path(ctx, lane, n, stream, &latency, &chunk, &pp);
+    int rcl = want_latency_path(ctx, lane, piece, stream, &latency, &chunk, &pp);
     if (rcl != RGBDFE_OK) return rcl;
   }
   if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(stream, wait_for, 0));
@@ -412,45 +428,56 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       (void)hipEventRecord(pend.a, stream);
     }
     const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
-    if (!sift) {
-      const uint32_t planes = launch_hamming(ctx, slot.d_work, lane.d_keys, (uint32_t)n, max_nq, max_nt, stream);
-      if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-      if (latency)
-        launch_select_ransac_latency(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc,
-                                     lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
-      else
-        launch_select_ransac(ctx->d_xyz, slot.d_work, lane.d_keys, planes, d_out, mk, (uint32_t)n, ctx->rc, lane.d_prep,
-                             lane.d_ec, stream);
-      if (ctx->rc.g2o_iterations > 0)
-        launch_g2o_refine(slot.d_work, d_out, (uint32_t)n, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
-      if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
-    } else {
-      if (matcher == 2) {
-        launch_l2_knn2(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, max_nq, lane.d_row_part, stream);
-        if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-        launch_l2_ratio(slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part, flann_ratio, lane.d_sm_q,
-                        lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
-      } else {
-        launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, (uint32_t)n, max_nq, max_nt, lane.d_row_part,
-                        lane.d_col_part, stream);
-        if (ctx->profiling) (void)hipEventRecord(pend.b, stream);
-        launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, (uint32_t)n, lane.d_row_part, lane.d_col_part,
-                           lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+    for (int32_t off = 0; off < n; off += piece) {
+      const int32_t m = (n - off) < piece ? (n - off) : piece;
+      const bool first = off == 0, last = off + m >= n;
+      if (!first) {  // the schedule of a shorter last piece (its scratch needs are covered by the first one's)
+        int rcl = want_latency_path(ctx, lane, m, stream, &latency, &chunk, &pp);
+        if (rcl != RGBDFE_OK) { launch_err = hipErrorOutOfMemory; break; }
       }
-      if (ctx->profiling) (void)hipEventRecord(pend.c, stream);
-      if (latency)
-        launch_select_ransac_sift_latency(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
-                                          d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk, (uint32_t)n, ctx->rc,
-                                          lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
-      else
-        launch_select_ransac_sift(ctx->d_xyz, slot.d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
-                                  lane.d_sm_n, d_out_dist ? d_out_dist : lane.d_all_dist, d_out, mk,
-                                  (uint32_t)n, ctx->rc, lane.d_prep, lane.d_ec, stream);
-      if (ctx->rc.g2o_iterations > 0)
-        launch_g2o_refine(slot.d_work, d_out, (uint32_t)n, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
-      if (ctx->profiling) (void)hipEventRecord(pend.d, stream);
+      const PairWork* d_work = slot.d_work + off;
+      rgbdfe_match_result* d_res = d_out + off;
+      if (!sift) {
+        const uint32_t planes = launch_hamming(ctx, d_work, lane.d_keys, (uint32_t)m, max_nq, max_nt, stream);
+        if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
+        if (latency)
+          launch_select_ransac_latency(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc,
+                                       lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+        else
+          launch_select_ransac(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc, lane.d_prep,
+                               lane.d_ec, stream);
+        if (ctx->rc.g2o_iterations > 0)
+          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
+        if (ctx->profiling && last) (void)hipEventRecord(pend.c, stream);
+      } else {
+        float* d_dist = (d_out_dist ? d_out_dist : lane.d_all_dist) + (size_t)(d_out_dist ? off : 0) * RGBDFE_MAX_MATCHES;
+        if (matcher == 2) {
+          launch_l2_knn2(ctx->d_sift_f32, d_work, mk, (uint32_t)m, max_nq, lane.d_row_part, stream);
+          if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
+          launch_l2_ratio(d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part, flann_ratio, lane.d_sm_q,
+                          lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+        } else {
+          launch_sift_dot(ctx->d_sift_bf16, d_work, mk, (uint32_t)m, max_nq, max_nt, lane.d_row_part,
+                          lane.d_col_part, stream);
+          if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
+          launch_sift_finish(ctx->d_sift_f32, d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part,
+                             lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+        }
+        if (ctx->profiling && first) (void)hipEventRecord(pend.c, stream);
+        if (latency)
+          launch_select_ransac_sift_latency(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
+                                            d_dist, d_res, mk, (uint32_t)m, ctx->rc,
+                                            lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+        else
+          launch_select_ransac_sift(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
+                                    lane.d_sm_n, d_dist, d_res, mk,
+                                    (uint32_t)m, ctx->rc, lane.d_prep, lane.d_ec, stream);
+        if (ctx->rc.g2o_iterations > 0)
+          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
+        if (ctx->profiling && last) (void)hipEventRecord(pend.d, stream);
+      }
     }
-    launch_err = hipGetLastError();
+    if (launch_err == hipSuccess) launch_err = hipGetLastError();
     if (ctx->profiling) {
       if (launch_err == hipSuccess) ctx->pending.push_back(pend);
       else {  // a batch that did not launch has no timing record: the events go back to the pool

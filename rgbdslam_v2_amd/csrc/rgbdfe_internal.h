@@ -84,6 +84,9 @@ struct WalkState {
   int32_t best_idx;          // iteration whose record is the best hypothesis so far, -1 = none
   int32_t best_n;
   float rmse;
+  int32_t speculate;         // set by the walk of the first phase: nothing has advanced `it` yet (no hypothesis with more
+                             // than half of the matches as inliers): the pair will most likely run all its iterations,
+                             // so the next recording launch records ALL of them (full speculation for this pair only)
 };
 // parameters of one record / replay phase (select_ransac.hip)
 struct RecordPlan {
@@ -92,6 +95,8 @@ struct RecordPlan {
   uint32_t n_chunks = 1;     // recording waves per pair in this phase
   int chunk_iters = 0;       // iterations per recording wave
   int phase_begin = 0, phase_end = 0;
+  int spec_end = 0;          // iterations [phase_begin, spec_end) are covered by the launch's waves; a pair records beyond
+                             // phase_end only when its walk state says `speculate`
   const PairPrep* prep = nullptr;  // [pair], every mode
   double* ec_pool = nullptr;  // every mode: select_ransac_ec_region_bytes() per launched wave (the inlier errors of
                               // a refinement round's scorings, read back lane = slot by the sequential error sums)

@@ -1105,7 +1105,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   // < 0 means its loop has ended
   const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
   if (MODE == kRecord && pair_state < 0) return;
-  const int recorded_end = MODE == kRecord ? min(plan.phase_end, pair_state) : 0;
+  const bool speculate = MODE == kRecord && plan.phase_begin != 0 && plan.spec_end > plan.phase_end &&
+                         plan.walk[pair].speculate != 0;
+  const int recorded_end = MODE == kRecord ? min(speculate ? plan.spec_end : plan.phase_end, pair_state) : 0;
   const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(unit % plan.n_chunks) * plan.chunk_iters : 0;
   const int k_end = MODE == kRecord ? min(k_begin + plan.chunk_iters, recorded_end) : 0;
   if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
@@ -1160,6 +1162,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 
     float hypR[9], hypt[3];
     bool hyp_nan = true;
+    bool hyp_viable = false;     // this lane's hypothesis can reach `thr` candidates at all (pre-screen below)
+    uint64_t viable_mask = 0ull;  // ... of the 64 hypotheses of the batch
     int hyp_base = -kWave;  // iteration index of lane 0's hypothesis (none yet)
     bool done = false;
 
@@ -1203,18 +1207,56 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           if (s4 < cnt) acc.add(lds.M, (int)ids[s4]);
         tfc_get_transformation(acc, hypR, hypt);
         hyp_nan = has_nan12(hypR, hypt);
+        // ---- pre-screen, still LANE = HYPOTHESIS.  With inlier ratios of real loop-closure candidates almost every
+        // 4-point hypothesis is junk: its first scoring (:1148) finds fewer than `thr` inliers, the refinement loop
+        // breaks (:1154) and the iteration ends with refined_matches empty.  An iteration is certainly of that kind when
+        // fewer than `thr` matches can pass errorFunction2's shortcut test (misc.cpp:726-735): an upper bound of that
+        // count comes from the float evaluation of dsq with score_passes' error band (a match counts unless its dsq_f
+        // is provably above the threshold; NaN counts).  Every lane walks all matches for ITS hypothesis -- the match
+        // record is the same LDS address for all lanes (broadcast) -- which costs ~1/4 of a slot's pass-1 scoring per
+        // hypothesis and spares a junk iteration the whole slot machinery (open, score, bookkeeping round, close).
+        {
+          const float u4 = 4.0f * 5.9604645e-8f;
+          float es = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            es += u4 * (((fabsf(hypR[3 * i]) + fabsf(hypR[3 * i + 1])) + fabsf(hypR[3 * i + 2]) + 1.0f) * pmax + fabsf(hypt[i]));
+          const double smax = rc.raster_cov_x > rc.depth_cov ? rc.raster_cov_x : rc.depth_cov;
+          const float S = (float)(2.0 * (smax + smax));
+          const float E = 2.0f * ((2.0f * sqrtf(S) * 1.001f) * es + es * es + u4 * S) + 1e-30f;
+          const float hi_f = S * 1.000001f + E;
+          uint32_t may_pass = 0;
+          for (int m = 0; m < n_all; ++m) {
+            const float pxf = lds.M[m * kRec + 0], pyf = lds.M[m * kRec + 1], pzf = lds.M[m * kRec + 2];
+            const float qxf = lds.M[m * kRec + 3], qyf = lds.M[m * kRec + 4], qzf = lds.M[m * kRec + 5];
+            if ((pzf == 0.0f || qzf == 0.0f) || (__builtin_isnan(pzf) || __builtin_isnan(qzf))) continue;  // wave-uniform
+            const float f0 = __builtin_fmaf(hypR[0], pxf, __builtin_fmaf(hypR[1], pyf, __builtin_fmaf(hypR[2], pzf, hypt[0]))) - qxf;
+            const float f1 = __builtin_fmaf(hypR[3], pxf, __builtin_fmaf(hypR[4], pyf, __builtin_fmaf(hypR[5], pzf, hypt[1]))) - qyf;
+            const float f2 = __builtin_fmaf(hypR[6], pxf, __builtin_fmaf(hypR[7], pyf, __builtin_fmaf(hypR[8], pzf, hypt[2]))) - qzf;
+            const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
+            may_pass += (dsq_f > hi_f) ? 0u : 1u;
+          }
+          hyp_viable = !hyp_nan && may_pass >= thr;
+#ifdef RGBDFE_NO_PRESCREEN  // diagnostics build: every finite hypothesis takes a slot
+          hyp_viable = !hyp_nan;
+#endif
+          viable_mask = __ballot(hyp_viable);
+        }
         PH_MARK(2)
     };
     // slot g <- iteration k: first transform = its 4-point hypothesis
     auto open_slot = [&](int g, int k) {
-      if (hyp_base < 0 || k < hyp_base || k >= hyp_base + kWave) gen_hypotheses(k);
+      // (recording waves get here through next_viable(), which has generated the batch that holds k)
+      if (MODE != kRecord && (hyp_base < 0 || k < hyp_base || k >= hyp_base + kWave)) gen_hypotheses(k);
       const int hl = k - hyp_base;
       float R0[9], t0[3];
 #pragma unroll
       for (int i = 0; i < 9; ++i) R0[i] = bcast_f(hypR[i], hl);
 #pragma unroll
       for (int i = 0; i < 3; ++i) t0[i] = bcast_f(hypt[i], hl);
-      const bool nan0 = (__builtin_amdgcn_readlane((int)hyp_nan, hl) != 0);
+      // a NaN transform leaves the refinement loop at once (:1144); so does, after its first scoring, a hypothesis the
+      // pre-screen has shown to be junk (:1154) -- with the same outcome: refined_matches stays empty
+      const bool nan0 = ((viable_mask >> hl) & 1ull) == 0ull;
       if (lane == 0) {
         Slot& sl = lds.slot[g];
 #pragma unroll
@@ -1361,6 +1403,36 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       // so a slot whose iteration has left its refinement loop is written out and refilled with the next
       // iteration at once -- the batched rounds stay full instead of waiting for a window's slowest slot.
       int k_next = k_begin;
+      // next viable iteration of the chunk (or -1); generates hypothesis batches as needed and writes the (empty)
+      // records of their junk iterations, 64 at a time, lane = iteration
+      auto next_viable = [&]() -> int {
+        while (k_next < k_end) {
+          if (hyp_base < 0 || k_next < hyp_base || k_next >= hyp_base + kWave) {
+            gen_hypotheses(k_next);
+            const int k = hyp_base + lane;
+            if (k < k_end && !hyp_viable) {
+              IterRec& r = rec_pair[k];
+#pragma unroll
+              for (int i = 0; i < 9; ++i) r.rR[i] = IR[i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) r.rt[i] = 0.f;
+#pragma unroll
+              for (int q = 0; q < kRounds; ++q) r.rmask[q] = 0ull;
+              r.rerr = 1e6;
+              r.rn = 0;
+              r.pad = 0;
+            }
+          }
+          const int off0 = k_next - hyp_base;
+          const uint64_t rest = viable_mask >> off0;
+          if (rest == 0ull) { k_next = min(k_end, hyp_base + kWave); continue; }
+          const int k = k_next + (int)__builtin_ctzll(rest);
+          if (k >= k_end) { k_next = k_end; break; }
+          k_next = k + 1;
+          return k;
+        }
+        return -1;
+      };
       while (n_all >= 4) {
         if (lane < kSlots) {
           Slot& sl = lds.slot[lane];
@@ -1382,9 +1454,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         bool occupied = false;
         for (int g = 0; g < kSlots; ++g) {
           int it_g = __builtin_amdgcn_readfirstlane(lds.slot[g].iter);
-          if (it_g < 0 && k_next < k_end) {
-            open_slot(g, k_next);
-            it_g = k_next++;
+          if (it_g < 0) {
+            const int k = next_viable();
+            if (k >= 0) {
+              open_slot(g, k);
+              it_g = k;
+            }
           }
           occupied |= it_g >= 0;
         }
@@ -1558,7 +1633,8 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uin
 // can still need; resumes where the previous phase stopped.
 __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __restrict__ recs, WalkState* __restrict__ walk,
                                                             const PairPrep* __restrict__ prep, uint32_t n_pairs,
-                                                            const RansacConst rc, int phase_begin, int phase_end) {
+                                                            const RansacConst rc, int phase_begin, int phase_end,
+                                                            int spec_end, int may_speculate) {
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x;
@@ -1569,11 +1645,13 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
     ws.it = 0; ws.real_iterations = 0; ws.valid_iterations = 0;
     ws.best_idx = -1; ws.best_n = 0;
     ws.rmse = 1e6f;  // :1112
+    ws.speculate = 0;
   } else if (ws.state < 0) {
     return;
   }
   const int n_all = prep[pair].n_all;
-  const int recorded_end = min(phase_end, ws.state);
+  // the records of a speculating pair reach as far as its recording waves were allowed to go
+  const int recorded_end = min((ws.speculate && spec_end > phase_end) ? spec_end : phase_end, ws.state);
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
   const IterRec* __restrict__ rec_pair = recs + (size_t)pair * (size_t)(I > 0 ? I : 0);
@@ -1614,6 +1692,8 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
   if (lane == 0) {
     // records ran out before the loop ended: at most (I - it) more iterations can follow
     ws.state = (runs && !done && it < I) ? real_iterations + (I - it) : -1;
+    // after the first phase: nothing has jumped `it` ahead yet -> record the rest of this pair in one go
+    ws.speculate = (may_speculate && ws.state >= 0 && it == real_iterations) ? 1 : 0;
     ws.it = it; ws.real_iterations = real_iterations; ws.valid_iterations = valid_iterations;
     ws.best_idx = best_idx; ws.best_n = best_n; ws.rmse = rmse;
     walk[pair] = ws;
@@ -1633,19 +1713,25 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
   int begin = 0;
   RecordPlan plan{};
   plan.recs = recs; plan.walk = walk; plan.prep = prep; plan.ec_pool = ec_pool;
+  const int I = rc.ransac_iterations;
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
-    // the phase in ceil(length / chunk_iters) equal shares (a short last wave would be the launch's straggler)
-    const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
+    // The second phase's launch covers everything that is left: pairs whose first phase has not advanced `it` (no
+    // hypothesis with more than half of the matches as inliers -- the pair will most likely run all its iterations)
+    // record all of it at once, the others stop at the phase's nominal end.  Waves beyond a pair's range return at once.
+    const int cover = (n_phases > 2 && p == 1) ? I : end;
+    // the covered range in ceil(length / chunk_iters) equal shares (a short last wave would be the launch's straggler)
+    const int n_chunks = (cover - begin + chunk_iters - 1) / chunk_iters;
     plan.n_chunks = (uint32_t)n_chunks;
-    plan.chunk_iters = n_chunks > 0 ? (end - begin + n_chunks - 1) / n_chunks : chunk_iters;
+    plan.chunk_iters = n_chunks > 0 ? (cover - begin + n_chunks - 1) / n_chunks : chunk_iters;
     plan.phase_begin = begin;
     plan.phase_end = end;
-    if (end > begin)
+    plan.spec_end = cover;
+    if (cover > begin)
       hipLaunchKernelGGL(select_ransac_kernel<kRecord>, dim3((n_pairs * plan.n_chunks + 7u) / 8u * 8u), dim3(kWave), 0,
                          stream, work, results, n_pairs, rc, plan);  // a multiple of 8: see the XCD segments
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, recs, walk, prep, n_pairs, rc, begin,
-                       end);
+                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0);
     begin = end;
   }
   plan.n_chunks = 1;

@@ -147,7 +147,8 @@ def test_one_context_from_many_threads(data):
 
 
 def test_batch_beyond_65536_pairs():
-    """more pairs than error-pool regions must fall back to the one-wave schedule, not spin."""
+    """a batch with more pairs than error-pool regions (65536) must not spin: it runs as record / replay
+    pieces, with the results of the same pairs in bench-sized batches."""
     from rgbdslam_v2_amd.frontend import FrontEnd
     seq = synth.make_sequence(n_frames=6, n_kp=64, n_world=160, seed=3)
     n = 66000

@@ -1,5 +1,5 @@
-"""A batch too large for the record / replay scratch (pairs x iterations > 2^24 records) falls back to the one-wave
-schedule: its results must equal those of the same pairs submitted in bench-sized batches."""
+"""A batch too large for the record / replay scratch (pairs x iterations > 2^24 records) runs as several record / replay
+pieces: its results must equal those of the same pairs submitted in bench-sized batches."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ fe = FrontEnd(max_nodes=F, max_keypoints=1024, max_pairs_per_batch=n)
 for f in range(F):
     fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 big = fe.match_pair_list(pq, pt)            # 2 pieces of 12000 pairs x 200 iterations = 2.4M records each: record / replay
-fe.set_params(ransac_iterations=1500)       # ransac_iterations = 1500: 12000 x 1500 = 18M > 2^24 records: one wave per pair
+fe.set_params(ransac_iterations=1500)       # ransac_iterations = 1500: 12000 x 1500 = 18M > 2^24 records: pieces of 11184 pairs
 big400 = fe.match_pair_list(pq, pt)
 small400 = np.concatenate([fe.match_pair_list(pq[a:a + 4000], pt[a:a + 4000]) for a in range(0, n, 4000)])
 fe.set_params(ransac_iterations=200)

@@ -24,6 +24,8 @@ def find(pattern):
 def short(name):
     if "replay_walk_kernel" in name or "pair_prep_kernel" in name:  # parts of the select+RANSAC stage of a batch
         return "select_ransac"
+    if "hamming_mfma_kernel" in name:
+        return "hamming_nn"
     for k in ("hamming_nn_kernel", "select_ransac_kernel", "project_to_3d_kernel"):
         if k in name:
             return k.replace("_kernel", "")
