@@ -285,8 +285,7 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   const int chunk_cfg = force_phases ? -ctx->latency_chunk_iters : ctx->latency_chunk_iters;
   // automatic: small batches want many short waves (latency), large ones long waves (a wave refills its 7 slots from
   // its own share of iterations, so longer shares keep the batched rounds fuller); tools/bench_batch_sweep.py
-  // (above 1280 pairs: 64 = one full lane = hypothesis batch per recording wave, tools sweep r02g)
-  int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 64 ? 4 : (n <= 640 ? 7 : (n <= 1280 ? 14 : 64)));
+  int chunk = chunk_cfg > 0 ? chunk_cfg : (n <= 64 ? 4 : (n <= 640 ? 7 : (n <= 1280 ? 14 : 28)));
   // every recording wave owns a region of the error pool: keep the largest grid (a phase is at most all iterations)
   // within kMaxEcRegions by recording more iterations per wave
   // (a batch of more than kMaxEcRegions pairs cannot get below one region per pair: it takes the one-wave kernel)
@@ -327,13 +326,16 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
   if (latency) {
     int begin = 0;
     for (int p = 0; p < plan->n_phases; ++p) {
-      const int cover = (plan->n_phases > 2 && p == 1) ? I : plan->ends[p];  // launch_record_replay: speculative cover
-      const size_t chunks = (size_t)((cover - begin + chunk - 1) / chunk);
+      size_t chunks = (size_t)((plan->ends[p] - begin + chunk - 1) / chunk);
+      if (plan->n_phases > 2 && p == 1)  // launch_record_replay: the second phase covers all that is left, two sub-grids
+        chunks += (size_t)((I - begin + 63) / 64);
       if ((size_t)n * chunks > regions) regions = (size_t)n * chunks;
       begin = plan->ends[p];
     }
   }
-  return ensure_ec_pool(ctx, lane, regions + 8, stream);  // recording grids are rounded up to a multiple of 8
+  // recording grids: 8 segments x ceil(n / 8) pairs x shares per pair (one region per launched wave)
+  regions = regions / (size_t)(n > 0 ? n : 1) * (((size_t)n + 7) / 8 * 8);
+  return ensure_ec_pool(ctx, lane, regions + 8, stream);
 }
 
 // The Hamming stage of an ORB batch: the fp4 MFMA kernel by default, the popcount kernel when asked for

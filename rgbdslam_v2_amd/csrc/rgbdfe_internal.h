@@ -84,9 +84,10 @@ struct WalkState {
   int32_t best_idx;          // iteration whose record is the best hypothesis so far, -1 = none
   int32_t best_n;
   float rmse;
-  int32_t speculate;         // set by the walk of the first phase: nothing has advanced `it` yet (no hypothesis with more
-                             // than half of the matches as inliers): the pair will most likely run all its iterations,
-                             // so the next recording launch records ALL of them (full speculation for this pair only)
+  int32_t speculate;         // class of the pair, set by the walk of the first phase: 0 = `it` has jumped ahead (a hypothesis
+                             // with more than half of the matches as inliers: the loop may end early); 1 = no jump yet: the
+                             // pair will most likely run all its iterations, the next recording launch records ALL of them;
+                             // 2 = ... and at most 1/4 of the iterations produced a refined hypothesis ("junk-heavy")
 };
 // parameters of one record / replay phase (select_ransac.hip)
 struct RecordPlan {
@@ -95,8 +96,10 @@ struct RecordPlan {
   uint32_t n_chunks = 1;     // recording waves per pair in this phase
   int chunk_iters = 0;       // iterations per recording wave
   int phase_begin = 0, phase_end = 0;
-  int spec_end = 0;          // iterations [phase_begin, spec_end) are covered by the launch's waves; a pair records beyond
-                             // phase_end only when its walk state says `speculate`
+  int spec_end = 0;          // the launch's waves cover [phase_begin, spec_end); pairs of class 1 / 2 record beyond phase_end
+  uint32_t n_chunks_b = 0;   // sub-grid B (class-2 pairs): recording waves per pair, in shares of chunk_iters_b iterations
+  int chunk_iters_b = 0;
+  int n_phases_total = 0;    // phases of the whole plan
   const PairPrep* prep = nullptr;  // [pair], every mode
   double* ec_pool = nullptr;  // every mode: select_ransac_ec_region_bytes() per launched wave (the inlier errors of
                               // a refinement round's scorings, read back lane = slot by the sequential error sums)

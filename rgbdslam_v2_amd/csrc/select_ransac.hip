@@ -1089,27 +1089,85 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
   }
 }
 
+// Upper bound of the number of matches that can pass errorFunction2's shortcut test (misc.cpp:726-735) under THIS LANE's
+// hypothesis (lane = hypothesis): the float evaluation of dsq with score_passes' error band -- a match counts unless its
+// dsq_f is provably above the threshold, NaN counts.  Every lane walks all matches; the match record is the same LDS
+// address for all lanes (a broadcast read).
+__device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const float* hypt, const float* __restrict__ M,
+                                                    int n_all, float pmax, const RansacConst& rc) {
+  const float u4 = 4.0f * 5.9604645e-8f;
+  float es = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    es += u4 * (((fabsf(hypR[3 * i]) + fabsf(hypR[3 * i + 1])) + fabsf(hypR[3 * i + 2]) + 1.0f) * pmax + fabsf(hypt[i]));
+  const double smax = rc.raster_cov_x > rc.depth_cov ? rc.raster_cov_x : rc.depth_cov;
+  const float S = (float)(2.0 * (smax + smax));
+  const float E = 2.0f * ((2.0f * sqrtf(S) * 1.001f) * es + es * es + u4 * S) + 1e-30f;
+  const float hi_f = S * 1.000001f + E;
+  uint32_t may_pass = 0;
+  for (int m = 0; m < n_all; ++m) {
+    const float pxf = M[m * kRec + 0], pyf = M[m * kRec + 1], pzf = M[m * kRec + 2];
+    const float qxf = M[m * kRec + 3], qyf = M[m * kRec + 4], qzf = M[m * kRec + 5];
+    if ((pzf == 0.0f || qzf == 0.0f) || (__builtin_isnan(pzf) || __builtin_isnan(qzf))) continue;  // wave-uniform
+    const float f0 = __builtin_fmaf(hypR[0], pxf, __builtin_fmaf(hypR[1], pyf, __builtin_fmaf(hypR[2], pzf, hypt[0]))) - qxf;
+    const float f1 = __builtin_fmaf(hypR[3], pxf, __builtin_fmaf(hypR[4], pyf, __builtin_fmaf(hypR[5], pzf, hypt[1]))) - qyf;
+    const float f2 = __builtin_fmaf(hypR[6], pxf, __builtin_fmaf(hypR[7], pyf, __builtin_fmaf(hypR[8], pzf, hypt[2]))) - qzf;
+    const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
+    may_pass += (dsq_f > hi_f) ? 0u : 1u;
+  }
+  return may_pass;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void select_ransac_kernel(
     const PairWork* __restrict__ work, rgbdfe_match_result* __restrict__ results, uint32_t n_pairs,
     const RansacConst rc, const RecordPlan plan) {
   __shared__ RansacLds lds;
   // Recording waves: the workgroups of a launch go round-robin over the 8 XCDs, each with its own L2.  The grid is
-  // walked in 8 contiguous segments, segment = blockIdx % 8, so that the waves sharing a pair (its PairPrep block, its
-  // records) run on one XCD.
-  const uint32_t seg_len = (gridDim.x + 7u) / 8u;
-  const uint32_t unit = MODE == kRecord ? (blockIdx.x % 8u) * seg_len + blockIdx.x / 8u : blockIdx.x;
-  const uint32_t pair = MODE == kRecord ? unit / plan.n_chunks : unit;
+  // walked in 8 contiguous segments, segment = blockIdx % 8, and a segment owns a contiguous range of pairs, so that the
+  // waves sharing a pair (its PairPrep block, its records) run on one XCD.  The long shares of sub-grid B are ordered
+  // share-major inside a segment (share 0 of all its pairs, then share 1, ...): consecutive workgroups -- which the
+  // dispatcher spreads over the CUs -- then do the same kind of work instead of clustering a pair's long waves on a CU.
+  // A recording launch has two sub-grids per pair: n_chunks shares of chunk_iters iterations (sub-grid A) and n_chunks_b
+  // shares of a whole hypothesis batch (sub-grid B; only the second phase of a phased plan has one).  Which sub-grid
+  // works for a pair, and how far, is the pair's class:
+  //   WalkState::speculate 0  the first phase has moved `it` ahead (a hypothesis with > 50 % inliers): the loop may
+  //                           end early -> sub-grid A up to the phase's nominal end, phase by phase;
+  //                           (also: nearly every iteration gives a refined hypothesis, > 3/4 of them -- such a pair
+  //                           finds its > 50 % hypothesis soon: recording ahead of the walk would be wasted)
+  //                        2  no jump so far and at most 3/4 of the iterations gave a refined hypothesis: the pair will
+  //                           most likely run all its iterations -> sub-grid B records ALL that is left at once, in long
+  //                           shares and with the hypothesis pre-screen (no further phases, no launch tails for it).
+  //                        (a class "record all that is left, in short shares and without the pre-screen" was measured
+  //                           and is slower than class 0 for the pairs it would apply to)
+  const uint32_t per_pair = plan.n_chunks + plan.n_chunks_b;
+  const uint32_t pps = (n_pairs + 7u) / 8u;  // pairs per segment
+  const uint32_t seg = blockIdx.x % 8u, in_seg = blockIdx.x / 8u;
+  // sub-grid A first, pair-major (a pair's short shares next to each other: its PairPrep block is read once into L2 and
+  // the ordinary phases keep the locality they were tuned with); then sub-grid B, share-major
+  const uint32_t units_a = pps * plan.n_chunks;
+  const bool in_b = MODE == kRecord && in_seg >= units_a;
+  const uint32_t pair = MODE != kRecord ? blockIdx.x
+                        : seg * pps + (in_b ? (in_seg - units_a) % pps : (plan.n_chunks ? in_seg / plan.n_chunks : 0u));
+  const uint32_t in_pair = MODE != kRecord ? 0u
+                           : (in_b ? plan.n_chunks + (in_seg - units_a) / pps : (plan.n_chunks ? in_seg % plan.n_chunks : 0u));
+  if (MODE == kRecord && (in_pair >= per_pair || pair >= seg * pps + pps)) return;
+  const bool sub_b = MODE == kRecord && in_pair >= plan.n_chunks;
+  const uint32_t unit = sub_b ? in_pair - plan.n_chunks : in_pair;  // share index inside the pair's sub-grid
   if (pair >= n_pairs) return;
   // record / replay bookkeeping: walk[pair].state >= 0 is an upper bound of the iterations the pair can still need,
   // < 0 means its loop has ended
   const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
   if (MODE == kRecord && pair_state < 0) return;
-  const bool speculate = MODE == kRecord && plan.phase_begin != 0 && plan.spec_end > plan.phase_end &&
-                         plan.walk[pair].speculate != 0;
-  const int recorded_end = MODE == kRecord ? min(speculate ? plan.spec_end : plan.phase_end, pair_state) : 0;
-  const int k_begin = MODE == kRecord ? plan.phase_begin + (int)(unit % plan.n_chunks) * plan.chunk_iters : 0;
-  const int k_end = MODE == kRecord ? min(k_begin + plan.chunk_iters, recorded_end) : 0;
+  const int pair_class = (MODE == kRecord && plan.phase_begin != 0) ? plan.walk[pair].speculate : 0;
+  if (MODE == kRecord && (pair_class == 2) != sub_b) return;  // the other sub-grid works for this pair
+  const int my_chunk_iters = sub_b ? plan.chunk_iters_b : plan.chunk_iters;
+  const int recorded_end = MODE == kRecord ? min(sub_b ? plan.spec_end : plan.phase_end, pair_state) : 0;
+  // the pre-screen pays where many hypotheses are junk: for the pairs the first phase's walk has put into class 2 (the
+  // first phase itself, 14 of 200 iterations, runs without it: a pair of mostly valid hypotheses would only pay for it)
+  const bool prescreen = MODE != kRecord || pair_class == 2 || plan.n_phases_total == 1;
+  const int k_begin = MODE == kRecord ? plan.phase_begin + (int)unit * my_chunk_iters : 0;
+  const int k_end = MODE == kRecord ? min(k_begin + my_chunk_iters, recorded_end) : 0;
   if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
   IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : plan.recs + (size_t)pair * (size_t)rc.ransac_iterations;
   const int lane = threadIdx.x;
@@ -1215,33 +1273,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         // is provably above the threshold; NaN counts).  Every lane walks all matches for ITS hypothesis -- the match
         // record is the same LDS address for all lanes (broadcast) -- which costs ~1/4 of a slot's pass-1 scoring per
         // hypothesis and spares a junk iteration the whole slot machinery (open, score, bookkeeping round, close).
-        {
-          const float u4 = 4.0f * 5.9604645e-8f;
-          float es = 0.0f;
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-            es += u4 * (((fabsf(hypR[3 * i]) + fabsf(hypR[3 * i + 1])) + fabsf(hypR[3 * i + 2]) + 1.0f) * pmax + fabsf(hypt[i]));
-          const double smax = rc.raster_cov_x > rc.depth_cov ? rc.raster_cov_x : rc.depth_cov;
-          const float S = (float)(2.0 * (smax + smax));
-          const float E = 2.0f * ((2.0f * sqrtf(S) * 1.001f) * es + es * es + u4 * S) + 1e-30f;
-          const float hi_f = S * 1.000001f + E;
-          uint32_t may_pass = 0;
-          for (int m = 0; m < n_all; ++m) {
-            const float pxf = lds.M[m * kRec + 0], pyf = lds.M[m * kRec + 1], pzf = lds.M[m * kRec + 2];
-            const float qxf = lds.M[m * kRec + 3], qyf = lds.M[m * kRec + 4], qzf = lds.M[m * kRec + 5];
-            if ((pzf == 0.0f || qzf == 0.0f) || (__builtin_isnan(pzf) || __builtin_isnan(qzf))) continue;  // wave-uniform
-            const float f0 = __builtin_fmaf(hypR[0], pxf, __builtin_fmaf(hypR[1], pyf, __builtin_fmaf(hypR[2], pzf, hypt[0]))) - qxf;
-            const float f1 = __builtin_fmaf(hypR[3], pxf, __builtin_fmaf(hypR[4], pyf, __builtin_fmaf(hypR[5], pzf, hypt[1]))) - qyf;
-            const float f2 = __builtin_fmaf(hypR[6], pxf, __builtin_fmaf(hypR[7], pyf, __builtin_fmaf(hypR[8], pzf, hypt[2]))) - qzf;
-            const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
-            may_pass += (dsq_f > hi_f) ? 0u : 1u;
-          }
-          hyp_viable = !hyp_nan && may_pass >= thr;
-#ifdef RGBDFE_NO_PRESCREEN  // diagnostics build: every finite hypothesis takes a slot
+        if (!prescreen) {  // (wave-uniform) every finite hypothesis takes a slot
           hyp_viable = !hyp_nan;
-#endif
-          viable_mask = __ballot(hyp_viable);
+        } else {
+          hyp_viable = !hyp_nan && prescreen_may_pass(hypR, hypt, lds.M, n_all, pmax, rc) >= thr;
         }
+        viable_mask = __ballot(hyp_viable);
         PH_MARK(2)
     };
     // slot g <- iteration k: first transform = its 4-point hypothesis
@@ -1651,7 +1688,7 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
   }
   const int n_all = prep[pair].n_all;
   // the records of a speculating pair reach as far as its recording waves were allowed to go
-  const int recorded_end = min((ws.speculate && spec_end > phase_end) ? spec_end : phase_end, ws.state);
+  const int recorded_end = min((ws.speculate != 0 && spec_end > phase_end) ? spec_end : phase_end, ws.state);
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
   const IterRec* __restrict__ rec_pair = recs + (size_t)pair * (size_t)(I > 0 ? I : 0);
@@ -1693,7 +1730,9 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
     // records ran out before the loop ended: at most (I - it) more iterations can follow
     ws.state = (runs && !done && it < I) ? real_iterations + (I - it) : -1;
     // after the first phase: nothing has jumped `it` ahead yet -> record the rest of this pair in one go
-    ws.speculate = (may_speculate && ws.state >= 0 && it == real_iterations) ? 1 : 0;
+    // class of the pair for the rest of the plan (see select_ransac_kernel): 1 = no jump so far, 2 = ... and junk-heavy
+    if (may_speculate)
+      ws.speculate = (ws.state >= 0 && it == real_iterations && valid_iterations * 4 <= real_iterations * 3) ? 2 : 0;
     ws.it = it; ws.real_iterations = real_iterations; ws.valid_iterations = valid_iterations;
     ws.best_idx = best_idx; ws.best_n = best_n; ws.rmse = rmse;
     walk[pair] = ws;
@@ -1713,28 +1752,35 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
   int begin = 0;
   RecordPlan plan{};
   plan.recs = recs; plan.walk = walk; plan.prep = prep; plan.ec_pool = ec_pool;
+  plan.n_phases_total = n_phases;  // a single-phase plan (small batches: full speculation) always pre-screens
   const int I = rc.ransac_iterations;
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
-    // The second phase's launch covers everything that is left: pairs whose first phase has not advanced `it` (no
-    // hypothesis with more than half of the matches as inliers -- the pair will most likely run all its iterations)
-    // record all of it at once, the others stop at the phase's nominal end.  Waves beyond a pair's range return at once.
-    const int cover = (n_phases > 2 && p == 1) ? I : end;
-    // the covered range in ceil(length / chunk_iters) equal shares (a short last wave would be the launch's straggler)
-    const int n_chunks = (cover - begin + chunk_iters - 1) / chunk_iters;
+    // The second phase of a phased plan covers everything that is left (see the pair classes in select_ransac_kernel):
+    // sub-grid A in shares of chunk_iters, sub-grid B in shares of a whole hypothesis batch.  Waves that have nothing
+    // to do for their pair return at once.
+    const bool spec = n_phases > 2 && p == 1 && I > end;
+    const int cover = spec ? I : end;
+    // sub-grid A: the phase in ceil(length / chunk) equal shares (a short last wave would be the launch's straggler)
+    const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
     plan.n_chunks = (uint32_t)n_chunks;
-    plan.chunk_iters = n_chunks > 0 ? (cover - begin + n_chunks - 1) / n_chunks : chunk_iters;
+    plan.chunk_iters = n_chunks > 0 ? (end - begin + n_chunks - 1) / n_chunks : chunk_iters;
+    const int n_chunks_b = spec ? (cover - begin + kWave - 1) / kWave : 0;
+    plan.n_chunks_b = (uint32_t)n_chunks_b;
+    plan.chunk_iters_b = n_chunks_b > 0 ? (cover - begin + n_chunks_b - 1) / n_chunks_b : kWave;
     plan.phase_begin = begin;
     plan.phase_end = end;
     plan.spec_end = cover;
     if (cover > begin)
-      hipLaunchKernelGGL(select_ransac_kernel<kRecord>, dim3((n_pairs * plan.n_chunks + 7u) / 8u * 8u), dim3(kWave), 0,
-                         stream, work, results, n_pairs, rc, plan);  // a multiple of 8: see the XCD segments
+      hipLaunchKernelGGL(select_ransac_kernel<kRecord>,
+                         dim3(8u * ((n_pairs + 7u) / 8u) * (plan.n_chunks + plan.n_chunks_b)), dim3(kWave), 0, stream, work,
+                         results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, recs, walk, prep, n_pairs, rc, begin,
                        end, cover, (n_phases > 2 && p == 0) ? 1 : 0);
     begin = end;
   }
   plan.n_chunks = 1;
+  plan.n_chunks_b = 0;
   hipLaunchKernelGGL(select_ransac_kernel<kReplay>, dim3(n_pairs), dim3(kWave), 0, stream, work, results, n_pairs, rc,
                      plan);
 }
