@@ -85,7 +85,8 @@ def pmc(pattern):
 for name, pat in (("fetch", "pmc_fetch/**/*counter_collection.csv"),
                   ("write", "pmc_write/**/*counter_collection.csv"),
                   ("sq", "pmc_sq/**/*counter_collection.csv"),
-                  ("sq2", "pmc_sq2/**/*counter_collection.csv")):
+                  ("sq2", "pmc_sq2/**/*counter_collection.csv"),
+                  ("mfma", "pmc_mfma/**/*counter_collection.csv")):
     acc = pmc(pat)
     for k, ctrs in acc.items():
         for c, vals in ctrs.items():
