@@ -269,7 +269,9 @@ def main():
             # the contract's block: ALGORITHMIC bytes of the dominant kernel / its launch time / HBM peak
             "bound": "hbm", "limiter": "valu_issue", "kernel": dominant, "achieved": round(achieved, 3),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": None, "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
+            "traffic": static_traffic(dominant, n_local), "traffic_source": "profiles/r02_pmc_summary.json: FETCH_SIZE x 2 + "
+            "WRITE_SIZE of separate rocprofv3 --pmc passes over this workload (static figure, not collected in this run)",
+            "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
             "avg_launch_ms": round(dom_ms, 4), "time_basis": "serial (one batch in flight), HIP events, this run",
             "launches_per_stage": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
                                   "pair_prep_kernel + 4 x (recording launch of select_ransac_kernel + replay_walk_kernel) + 1 "
@@ -356,6 +358,16 @@ def issue_roofline(n_kp, n_pairs, ham_ms, rsc_ms, hamming_mode):
                                 "valu_busy_frac_pmc": rec.get("valu_busy_frac"),
                                 "hbm_bytes_per_batch_pmc": rec.get("hbm_bytes_per_launch")}
     return out
+
+
+def static_traffic(dominant, n_pairs):
+    """HBM bytes per launch of the dominant stage from the committed PMC profile (scaled to this run's pairs), or None."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        rec = pmc["hamming" if dominant == "hamming_nn" else "select_ransac"]
+        return round(rec["hbm_bytes_per_launch"] * n_pairs / float(rec["pairs_per_batch"]))
+    except Exception:
+        return None
 
 
 def match_roofline(n_kp, n_pairs, ham_ms, hamming_mode):

@@ -1105,15 +1105,25 @@ __device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const 
   const float E = 2.0f * ((2.0f * sqrtf(S) * 1.001f) * es + es * es + u4 * S) + 1e-30f;
   const float hi_f = S * 1.000001f + E;
   uint32_t may_pass = 0;
-  for (int m = 0; m < n_all; ++m) {
-    const float pxf = M[m * kRec + 0], pyf = M[m * kRec + 1], pzf = M[m * kRec + 2];
-    const float qxf = M[m * kRec + 3], qyf = M[m * kRec + 4], qzf = M[m * kRec + 5];
-    if ((pzf == 0.0f || qzf == 0.0f) || (__builtin_isnan(pzf) || __builtin_isnan(qzf))) continue;  // wave-uniform
-    const float f0 = __builtin_fmaf(hypR[0], pxf, __builtin_fmaf(hypR[1], pyf, __builtin_fmaf(hypR[2], pzf, hypt[0]))) - qxf;
-    const float f1 = __builtin_fmaf(hypR[3], pxf, __builtin_fmaf(hypR[4], pyf, __builtin_fmaf(hypR[5], pzf, hypt[1]))) - qyf;
-    const float f2 = __builtin_fmaf(hypR[6], pxf, __builtin_fmaf(hypR[7], pyf, __builtin_fmaf(hypR[8], pzf, hypt[2]))) - qzf;
-    const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
-    may_pass += (dsq_f > hi_f) ? 0u : 1u;
+  // four matches per trip: their 24 LDS reads are in flight together (the records behind n_all exist: PairPrep holds
+  // RGBDFE_MAX_MATCHES of them, a multiple of 4; what they contain does not count)
+#pragma unroll 1
+  for (int m0 = 0; m0 < n_all; m0 += 4) {
+    float rec[4][6];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) rec[u][c] = M[(m0 + u) * kRec + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float pxf = rec[u][0], pyf = rec[u][1], pzf = rec[u][2], qxf = rec[u][3], qyf = rec[u][4], qzf = rec[u][5];
+      const bool pre = (m0 + u < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
+      const float f0 = __builtin_fmaf(hypR[0], pxf, __builtin_fmaf(hypR[1], pyf, __builtin_fmaf(hypR[2], pzf, hypt[0]))) - qxf;
+      const float f1 = __builtin_fmaf(hypR[3], pxf, __builtin_fmaf(hypR[4], pyf, __builtin_fmaf(hypR[5], pzf, hypt[1]))) - qyf;
+      const float f2 = __builtin_fmaf(hypR[6], pxf, __builtin_fmaf(hypR[7], pyf, __builtin_fmaf(hypR[8], pzf, hypt[2]))) - qzf;
+      const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
+      may_pass += (pre && !(dsq_f > hi_f)) ? 1u : 0u;
+    }
   }
   return may_pass;
 }
@@ -1343,6 +1353,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           }
         }
         __syncthreads();
+#ifdef RGBDFE_FENCE_SUMS  // diagnostics build: drop this CU's L1 before the error rows are read back
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         // ... then their sequential error sums side by side and the bookkeeping (:1154-1166), lane = slot
         const double sum_mine = n_sum_max > 0 ? sum_rows(ec_region, lds, lane, cn_mine, n_sum_max) : 0.0;  // wave-uniform
         const double err_mine = cn_mine > 0 ? sqrt(sum_mine / (double)cn_mine) : 1e9;  // :1016-1017

@@ -4,7 +4,7 @@ tail -5 gpurun_out/r02h/tests.log
 timeout 300 python tools/fuzz_pairs.py phased 1 40 > gpurun_out/r02h/fuzz_phased.log 2>&1; tail -2 gpurun_out/r02h/fuzz_phased.log
 timeout 300 python tools/check_huge_batch.py > gpurun_out/r02h/huge.log 2>&1; tail -3 gpurun_out/r02h/huge.log
 for W in 0.01 0.002 0.005; do
- for CH in 0 28; do
+ for CH in 0; do
    timeout 120 python bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline --depth-noise $W --chunk-iterations $CH --ransac-path record_replay > gpurun_out/r02h/b_${W}_${CH}.json 2>/dev/null
    python - <<PY
 import json
