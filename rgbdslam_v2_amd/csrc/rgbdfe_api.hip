@@ -304,7 +304,7 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     else latency = false;
   }
   if (latency && !lane.d_walk &&
-      hipMalloc((void**)&lane.d_walk, sizeof(WalkState) * (size_t)ctx->cfg.max_pairs_per_batch) != hipSuccess) {
+      hipMalloc((void**)&lane.d_walk, sizeof(WalkState) * ((size_t)ctx->cfg.max_pairs_per_batch + 1)) != hipSuccess) {  // + the batch's counters
     lane.d_walk = nullptr;
     latency = false;
   }

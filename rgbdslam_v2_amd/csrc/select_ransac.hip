@@ -924,6 +924,13 @@ __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__
 // kRecord + replay_walk_kernel + kReplay give the same result as kWhole (an iteration's refinement is a pure function of
 // its index, D1) with the refinement work of one pair spread over many waves.
 constexpr int kWhole = 0, kRecord = 1, kReplay = 2;
+// a pair is "junk-heavy" (class 2 of the record / replay plan) when at most kClass2Num / kClass2Den of the first phase's
+// iterations produced a refined hypothesis
+#ifndef RGBDFE_CLASS2_NUM
+#define RGBDFE_CLASS2_NUM 9
+#define RGBDFE_CLASS2_DEN 14
+#endif
+constexpr int kClass2Num = RGBDFE_CLASS2_NUM, kClass2Den = RGBDFE_CLASS2_DEN;
 
 // ---------------------------------------------------------------------------------
 // Once per pair, before any select+RANSAC wave: the <= max_matches strongest matches in the reference's order
@@ -1089,6 +1096,14 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
   }
 }
 
+#ifdef RGBDFE_PADNOPS  // diagnostics: shifts the code that follows
+__global__ void rgbdfe_pad_kernel(int* p) {
+#pragma unroll
+  for (int i = 0; i < RGBDFE_PADNOPS; ++i) asm volatile("s_nop 0");
+  if (p) *p = 1;
+}
+#endif
+
 // Upper bound of the number of matches that can pass errorFunction2's shortcut test (misc.cpp:726-735) under THIS LANE's
 // hypothesis (lane = hypothesis): the float evaluation of dsq with score_passes' error band -- a match counts unless its
 // dsq_f is provably above the threshold, NaN counts.  Every lane walks all matches; the match record is the same LDS
@@ -1128,6 +1143,16 @@ __device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const 
   return may_pass;
 }
 
+// The class a pair is treated as from the second phase on.  WalkState::speculate: 0 = `it` has jumped ahead, 1 = no
+// jump and mostly valid hypotheses, 2 = no jump and junk-heavy.  Class 1 behaves like class 0 (phase by phase) unless the
+// batch has very few such pairs (walk[n_pairs].state counts them, < 1/64 of the batch): then keeping the third and fourth
+// phase's launches alive for a handful of long waves costs more than recording those pairs to the end like class 2.
+__device__ __forceinline__ int effective_class(const WalkState* __restrict__ walk, uint32_t pair, uint32_t n_pairs) {
+  const int c = walk[pair].speculate;
+  if (c != 1) return c;
+  return ((uint32_t)walk[n_pairs].state * 64u <= n_pairs) ? 2 : 0;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void select_ransac_kernel(
     const PairWork* __restrict__ work, rgbdfe_match_result* __restrict__ results, uint32_t n_pairs,
@@ -1143,9 +1168,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   // works for a pair, and how far, is the pair's class:
   //   WalkState::speculate 0  the first phase has moved `it` ahead (a hypothesis with > 50 % inliers): the loop may
   //                           end early -> sub-grid A up to the phase's nominal end, phase by phase;
-  //                           (also: nearly every iteration gives a refined hypothesis, > 3/4 of them -- such a pair
+  //                           (also: most iterations give a refined hypothesis, more than 9/14 of them -- such a pair
   //                           finds its > 50 % hypothesis soon: recording ahead of the walk would be wasted)
-  //                        2  no jump so far and at most 3/4 of the iterations gave a refined hypothesis: the pair will
+  //                        2  no jump so far and at most 9/14 of the iterations gave a refined hypothesis: the pair will
   //                           most likely run all its iterations -> sub-grid B records ALL that is left at once, in long
   //                           shares and with the hypothesis pre-screen (no further phases, no launch tails for it).
   //                        (a class "record all that is left, in short shares and without the pre-screen" was measured
@@ -1169,7 +1194,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   // < 0 means its loop has ended
   const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
   if (MODE == kRecord && pair_state < 0) return;
-  const int pair_class = (MODE == kRecord && plan.phase_begin != 0) ? plan.walk[pair].speculate : 0;
+  const int pair_class = (MODE == kRecord && plan.phase_begin != 0) ? effective_class(plan.walk, pair, n_pairs) : 0;
   if (MODE == kRecord && (pair_class == 2) != sub_b) return;  // the other sub-grid works for this pair
   const int my_chunk_iters = sub_b ? plan.chunk_iters_b : plan.chunk_iters;
   const int recorded_end = MODE == kRecord ? min(sub_b ? plan.spec_end : plan.phase_end, pair_state) : 0;
@@ -1616,6 +1641,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
     out->trafo[15] = 1.0f;
     out->pad0 = 0;
+#ifdef RGBDFE_DEBUG_CLASS  // diagnostics build: the pair's class of the record / replay plan
+    if (MODE == kReplay) out->pad0 = (uint32_t)plan.walk[pair].speculate;
+#endif
     out->valid_iterations = valid_iterations;
     out->real_iterations = real_iterations;
     if (found) {
@@ -1701,7 +1729,8 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
   }
   const int n_all = prep[pair].n_all;
   // the records of a speculating pair reach as far as its recording waves were allowed to go
-  const int recorded_end = min((ws.speculate != 0 && spec_end > phase_end) ? spec_end : phase_end, ws.state);
+  const int recorded_end =
+      min((phase_begin != 0 && spec_end > phase_end && effective_class(walk, pair, n_pairs) == 2) ? spec_end : phase_end, ws.state);
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
   const IterRec* __restrict__ rec_pair = recs + (size_t)pair * (size_t)(I > 0 ? I : 0);
@@ -1744,8 +1773,17 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
     ws.state = (runs && !done && it < I) ? real_iterations + (I - it) : -1;
     // after the first phase: nothing has jumped `it` ahead yet -> record the rest of this pair in one go
     // class of the pair for the rest of the plan (see select_ransac_kernel): 1 = no jump so far, 2 = ... and junk-heavy
-    if (may_speculate)
-      ws.speculate = (ws.state >= 0 && it == real_iterations && valid_iterations * 4 <= real_iterations * 3) ? 2 : 0;
+#ifdef RGBDFE_NO_CLASS2  // diagnostics build
+    may_speculate = 0;
+#endif
+    if (may_speculate) {
+      const bool no_jump = ws.state >= 0 && it == real_iterations;
+      const bool junk_heavy = valid_iterations * kClass2Den <= real_iterations * kClass2Num;
+      ws.speculate = no_jump ? (junk_heavy ? 2 : 1) : 0;
+      // class-1 pairs of the batch are counted: when there are only a few of them they are recorded like class 2
+      // (see effective_class) instead of keeping the later phases' launches alive for a handful of long waves
+      if (ws.speculate == 1) atomicAdd(&walk[n_pairs].state, 1);
+    }
     ws.it = it; ws.real_iterations = real_iterations; ws.valid_iterations = valid_iterations;
     ws.best_idx = best_idx; ws.best_n = best_n; ws.rmse = rmse;
     walk[pair] = ws;
@@ -1766,13 +1804,18 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
   RecordPlan plan{};
   plan.recs = recs; plan.walk = walk; plan.prep = prep; plan.ec_pool = ec_pool;
   plan.n_phases_total = n_phases;  // a single-phase plan (small batches: full speculation) always pre-screens
+  (void)hipMemsetAsync(walk + n_pairs, 0, sizeof(WalkState), stream);  // walk[n_pairs].state: the batch's class-1 pairs
   const int I = rc.ransac_iterations;
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
     // The second phase of a phased plan covers everything that is left (see the pair classes in select_ransac_kernel):
     // sub-grid A in shares of chunk_iters, sub-grid B in shares of a whole hypothesis batch.  Waves that have nothing
     // to do for their pair return at once.
+#ifdef RGBDFE_NO_SUBGRID_B  // diagnostics build
+    const bool spec = false;
+#else
     const bool spec = n_phases > 2 && p == 1 && I > end;
+#endif
     const int cover = spec ? I : end;
     // sub-grid A: the phase in ceil(length / chunk) equal shares (a short last wave would be the launch's straggler)
     const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;

@@ -10,7 +10,5 @@ for dn in (0.01, 0.005, 0.002):
     for f in range(200):
         fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
     r = fe.match_pair_list(pq, pt)
-    print(dn, "valid mean %.1f median %.0f max %d | real %.1f | n_inl mean %.1f | n_all %.1f" % (
-        r["valid_iterations"].mean(), np.median(r["valid_iterations"]), r["valid_iterations"].max(), r["real_iterations"].mean(),
-        r["n_inl"].mean(), r["n_all"].mean()))
+    print(dn, "valid mean %.1f | real %.1f | class histogram" % (r["valid_iterations"].mean(), r["real_iterations"].mean()), np.bincount(r["pad0"], minlength=3))
     fe.close()
