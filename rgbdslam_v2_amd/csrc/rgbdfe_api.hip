@@ -57,7 +57,8 @@ inline double division_boundary(double q, double denom) {
 struct NodeEntry {
   uint32_t slot;
   uint32_t n;
-  uint32_t kind;  // 0 = ORB (32-byte binary descriptors), 1 = SIFT (128 floats)
+  uint32_t kind;  // 0 = ORB (32-byte binary descriptors), 1 = SIFT (128 floats), 2 = float descriptors (FLANN branch)
+  uint32_t flags = 0;  // bit 0 (SIFT): every row's quantised squared norm is < 2^19 (sift_match.hip's fast keys)
 };
 
 inline uint32_t mix32_host(uint32_t x) {
@@ -88,6 +89,7 @@ struct rgbdfe_ctx {
   uint32_t* d_desc4 = nullptr; // max_nodes x max_kp x 32 dwords: every descriptor bit as an fp4 (+-1) operand nibble, in
                                // MFMA fragment order per tile of 32 rows (hamming_mfma.hip)
   float* d_kp2d = nullptr;     // max_nodes x max_kp x 2: KeyPoint.pt (allocated with the first rgbdfe_upload_node_keypoints)
+  bool sift_fast = true;       // sift_match.hip's float keys where a pair qualifies (RGBDFE_SIFT_FAST_KEYS=0: never)
   int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
   // Batches run on kLanes internal HIP streams ("lanes"), each with its own keys / results
   // staging, so that batch k+1's Hamming kernel fills the SIMDs that batch k's RANSAC tail
@@ -160,6 +162,15 @@ struct rgbdfe_ctx {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
 };
+
+namespace {
+// PairWork::pad bit 0 for a SIFT pair: dot products < 2^19 (Cauchy-Schwarz over the two nodes' squared norms) and at
+// most 32 column tiles of 32 on either side -- see sift_row_top2_kernel
+inline uint32_t sift_fast_keys(const rgbdfe_ctx* ctx, const NodeEntry& q, const NodeEntry& t) {
+  return (ctx->sift_fast && (q.flags & t.flags & 1u) && q.n <= 1024u && t.n <= 1024u) ? 1u : 0u;
+}
+}  // namespace
+
 
 namespace {
 
@@ -368,7 +379,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     HIP_TRY(ctx, hipEventSynchronize(slot.done));
     slot.pending = false;
   }
-  uint32_t max_nq = 0, max_nt = 0;
+  uint32_t max_nq = 0, max_nt = 0, sift_kinds = 0;
   for (int32_t i = 0; i < n; ++i) {
     auto q = ctx->nodes.find(qids[i]);
     auto t = ctx->nodes.find(tids[i]);
@@ -384,7 +395,9 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     w.uid = pair_uid(qids[i], tids[i]);
     w.qid = qids[i];
     w.tid = tids[i];
-    w.pad = 0;
+    // SIFT fast keys: dot products < 2^19 (Cauchy-Schwarz over the two nodes' norms) and at most 32 column tiles
+    w.pad = matcher == 1 ? sift_fast_keys(ctx, q->second, t->second) : 0u;
+    sift_kinds |= w.pad ? 1u : 2u;
     if (w.nq > max_nq) max_nq = w.nq;
     if (w.nt > max_nt) max_nt = w.nt;
   }
@@ -459,7 +472,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
           launch_l2_ratio(d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part, flann_ratio, lane.d_sm_q,
                           lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
         } else {
-          launch_sift_dot(ctx->d_sift_bf16, d_work, mk, (uint32_t)m, max_nq, max_nt, lane.d_row_part,
+          launch_sift_dot(ctx->d_sift_bf16, d_work, mk, (uint32_t)m, max_nq, max_nt, sift_kinds, lane.d_row_part,
                           lane.d_col_part, stream);
           if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
           launch_sift_finish(ctx->d_sift_f32, d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part,
@@ -549,6 +562,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   int rc = validate_params(ctx, cfg->params);
   if (rc != RGBDFE_OK) { delete ctx; return rc; }
   fill_ransac_const(ctx);
+  if (const char* sf = getenv("RGBDFE_SIFT_FAST_KEYS")) ctx->sift_fast = atoi(sf) != 0;
   if (const char* hm = getenv("RGBDFE_HAMMING_MODE")) ctx->hamming_mode = atoi(hm) < 0 || atoi(hm) > 2 ? 1 : atoi(hm);
   auto bail = [&](int code) { rgbdfe_destroy(ctx); return code; };
   if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
@@ -697,7 +711,7 @@ static int upload_common(rgbdfe_ctx* ctx, int32_t node_id, const void* desc, con
     HIP_TRY(ctx, hipEventRecord(ctx->nodes_ready_ev, stream));
     ctx->nodes_ready = ctx->nodes_ready_ev;
   }
-  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 0u};
+  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 0u, 0u};
   return RGBDFE_OK;
 }
 
@@ -859,10 +873,13 @@ static int ensure_sift(rgbdfe_ctx* ctx) {
   if (ctx->sift_ready) return RGBDFE_OK;
   const size_t rows = (size_t)ctx->cfg.max_nodes * (size_t)ctx->cfg.max_keypoints + 16;
   const size_t np = (size_t)ctx->cfg.max_pairs_per_batch, mk = (size_t)ctx->cfg.max_keypoints;
-  if (hipMalloc((void**)&ctx->d_sift_bf16, rows * 128 * 2) != hipSuccess ||
+  // + 384 rows: sift_top2_fast_kernel prefetches whole 128-row tiles without clamping the row (up to one tile past the
+  // node's last one); what lies beyond a node's rows is finite (zeros or older quantised values) and masked
+  const size_t bf16_rows = rows + 384;
+  if (hipMalloc((void**)&ctx->d_sift_bf16, bf16_rows * 128 * 2) != hipSuccess ||
       hipMalloc((void**)&ctx->d_sift_f32, rows * 128 * 4) != hipSuccess)
     return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "SIFT node slabs");
-  HIP_TRY(ctx, hipMemset(ctx->d_sift_bf16, 0, rows * 128 * 2));
+  HIP_TRY(ctx, hipMemset(ctx->d_sift_bf16, 0, bf16_rows * 128 * 2));
   HIP_TRY(ctx, hipMemset(ctx->d_sift_f32, 0, rows * 128 * 4));
   HIP_TRY(ctx, hipDeviceSynchronize());  // see rgbdfe_create: NULL-stream memsets vs non-blocking streams
   for (auto& ln : ctx->lanes) {
@@ -906,7 +923,19 @@ int rgbdfe_upload_sift_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc1
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 1u};
+  // quantised squared norms (SiftMatchCU.cpp:96-99's u8 values): decides whether pairs of this node may use the fast keys
+  uint32_t flags = 1u;
+  for (int32_t r = 0; r < n && flags; ++r) {
+    uint64_t sq = 0;
+    const float* d = desc128 + (size_t)r * 128;
+    for (int k = 0; k < 128; ++k) {
+      const float prod = 512 * d[k];
+      const unsigned char u = (unsigned char)(int)((double)prod + 0.5);
+      sq += (uint64_t)u * u;
+    }
+    if (sq >= (1ull << 19)) flags = 0u;  // strict: dot <= sqrt(sq1 * sq2) < 2^19
+  }
+  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 1u, flags};
   return RGBDFE_OK;
 }
 
@@ -944,7 +973,7 @@ int rgbdfe_upload_float_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, xyz1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 2u};
+  ctx->nodes[node_id] = NodeEntry{slot, (uint32_t)n, 2u, 0u};
   return RGBDFE_OK;
 }
 
@@ -1019,10 +1048,12 @@ int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   PairWork& w = slot.h_work[0];
   w.q_slot = q->second.slot; w.t_slot = t->second.slot;
   w.nq = q->second.n; w.nt = t->second.n;
-  w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id; w.pad = 0;
+  w.uid = pair_uid(query_id, train_id); w.qid = query_id; w.tid = train_id;
+  w.pad = sift_fast_keys(ctx, q->second, t->second);
   const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
   HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, lane.stream));
-  launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, 1u, w.nq, w.nt, lane.d_row_part, lane.d_col_part, lane.stream);
+  launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, 1u, w.nq, w.nt, w.pad ? 1u : 2u, lane.d_row_part, lane.d_col_part,
+                  lane.stream);
   launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, 1u, lane.d_row_part, lane.d_col_part, lane.d_sm_q,
                      lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, lane.stream);
   HIP_TRY(ctx, hipGetLastError());

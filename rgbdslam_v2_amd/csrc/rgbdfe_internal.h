@@ -127,8 +127,8 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uin
 // SIFT matcher (sift_match.hip): u8-quantised descriptors as bf16, exact integer dot products
 // on the bf16 MFMA, SiftMatchGPU row/column/mutual-best semantics.
 void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,
-                     uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t* row_part,
-                     uint32_t* col_part, hipStream_t stream);
+                     uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_kinds,
+                     uint32_t* row_part, uint32_t* col_part, hipStream_t stream);
 void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t max_kp,
                         uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part,
                         uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n,

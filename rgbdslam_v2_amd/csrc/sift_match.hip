@@ -19,19 +19,25 @@
 // ties).  The per-train-column result (ColMatch_Kernel, "lowest row wins") is a second pass of
 // the same kernel with the operands swapped: recomputing the products on the matrix cores is
 // cheaper than exchanging column partials through LDS and HBM.
+//
+// Two key formats.  INTEGER keys (sift_row_top2_kernel) hold for any input: dot < 2^23, up to 4096 rows.  FLOAT keys
+// (sift_top2_fast_kernel) apply when the host has checked (PairWork::pad bit 0) that both nodes hold at most 1024 rows
+// and that every descriptor's quantised squared norm is < 2^19 -- true for unit-length SIFT descriptors (512^2 = 2^18) --
+// so that every dot product is < 2^19 by Cauchy-Schwarz: a ninth k-step adds (31 - sequence) / 32 to every accumulator
+// element and the element IS the key (24 significant bits: exact in f32); non-negative floats order like their bit
+// patterns, so the running top-2 is v_med3_u32 + v_max_u32 on the raw accumulator: 2 VALU per element instead of 4.
 #include "rgbdfe_internal.h"
 
 namespace rgbdfe {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 constexpr int kSiftDim = 128;
 constexpr int kTile = 128;     // rows per block, columns per tile
 constexpr int kSiftThreads = 256;
 
-// running (best, second) with mx >= nx: the new second is the median of {mx, nx, key} (v_med3_u32), the new
-// best their maximum -- two VALU operations per accumulator element
 // running (best, second) with mx >= nx: the new second is the median of {mx, nx, key} (v_med3_u32), the new
 // best their maximum -- two VALU operations per accumulator element
 __device__ __forceinline__ void top2_insert(uint32_t& mx, uint32_t& nx, uint32_t key) {
@@ -83,18 +89,30 @@ void launch_sift_quantise(const float* f32, uint16_t* bf16, size_t n_elems, hipS
 // part: [pair][max_kp][3] = (best dot, second dot, best index or 0xFFFFFFFF)
 constexpr int kChunksPerRow = 16;  // 256 B / 16 B
 
+// Workgroup -> (pair, row block).  Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2; every
+// row block of a pair streams the WHOLE other node (256 KB at 1000 rows), so the row blocks of one pair must land on ONE
+// XCD -- one HBM / Infinity-Cache read, the rest L2 hits -- instead of one per XCD (measured: 7.5 GB fetched per launch of
+// 4000 pairs with the plain (row block, pair) grid, 8x the data).  XCD x takes pairs x, x + 8, ...; a pair's row blocks
+// are consecutive in its XCD's dispatch order.  Grid = n_rb * 8 * ceil(n_pairs / 8) workgroups.
+__device__ __forceinline__ void sift_block_to_tile(uint32_t n_rb, uint32_t& pair, uint32_t& rb) {
+  const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  pair = (j / n_rb) * 8u + xcd;
+  rb = j % n_rb;
+}
+
 template <bool SWAP>
 __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
     const uint16_t* __restrict__ bf16_pool, const PairWork* __restrict__ work, uint32_t max_kp,
-    uint32_t* __restrict__ part) {
+    uint32_t n_pairs, uint32_t n_rb, uint32_t* __restrict__ part) {
   __shared__ uint4 tileY[2][kTile * kChunksPerRow];
-  const uint32_t pair = blockIdx.y;
-  const uint32_t rb = blockIdx.x;
+  uint32_t pair, rb;
+  sift_block_to_tile(n_rb, pair, rb);
+  if (pair >= n_pairs) return;
   const PairWork w = work[pair];
   const int nq = (int)min(w.nq, 4096u), nt = (int)min(w.nt, 4096u);  // sift_gpu_wrapper.cpp:231
   const int nx = SWAP ? nt : nq, ny = SWAP ? nq : nt;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if ((int)(rb * kTile) >= nx) return;  // block-uniform
+  if ((int)(rb * kTile) >= nx || (w.pad & 1u)) return;  // block-uniform; pad bit 0: sift_top2_fast_kernel's pair
   const int r0 = rb * kTile + wv * 32;
 
   const uint16_t* __restrict__ xpool = bf16_pool + (size_t)(SWAP ? w.t_slot : w.q_slot) * max_kp * kSiftDim;
@@ -245,6 +263,228 @@ __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
   }
 }
 
+// ---- float keys -------------------------------------------------------------------------------------------------------
+// Same block shape and LDS tile as above.  The inner loop is software pipelined by hand over the column tiles (32 columns
+// = 8 B fragments = 9 MFMAs): while the matrix pipe works on column tile c, the VALU digests the accumulator of c - 1
+// (32 instructions: 4 per 32-cycle MFMA slot) and the LDS returns the B fragments of c + 1; the last accumulator of a
+// Y tile is digested beside the first MFMAs of the next one, across the barrier.  The ragged last Y tile (columns beyond
+// ny) runs unpipelined with a select per element.
+template <bool SWAP>
+__global__ __launch_bounds__(kSiftThreads) void sift_top2_fast_kernel(
+    const uint16_t* __restrict__ bf16_pool, const PairWork* __restrict__ work, uint32_t max_kp,
+    uint32_t n_pairs, uint32_t n_rb, uint32_t* __restrict__ part) {
+  __shared__ u32x4 tileY[2][kTile * kChunksPerRow];  // native vectors: the staging array is promoted to registers
+  uint32_t pair, rb;
+  sift_block_to_tile(n_rb, pair, rb);
+  if (pair >= n_pairs) return;
+  const PairWork w = work[pair];
+  const int nq = (int)w.nq, nt = (int)w.nt;  // <= 1024 (host)
+  const int nx = SWAP ? nt : nq, ny = SWAP ? nq : nt;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if ((int)(rb * kTile) >= nx || !(w.pad & 1u)) return;  // block-uniform
+  const int r0 = rb * kTile + wv * 32;
+
+  const uint16_t* __restrict__ xpool = bf16_pool + (size_t)(SWAP ? w.t_slot : w.q_slot) * max_kp * kSiftDim;
+  const uint16_t* __restrict__ ypool = bf16_pool + (size_t)(SWAP ? w.q_slot : w.t_slot) * max_kp * kSiftDim;
+
+  bf16x8 A[8];
+  {
+    int row = r0 + (lane & 31);
+    row = row < nx ? row : nx - 1;
+    row = row < 0 ? 0 : row;
+    const u32x4* src = reinterpret_cast<const u32x4*>(xpool + (size_t)row * kSiftDim + (lane >> 5) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) A[ks] = __builtin_bit_cast(bf16x8, src[ks * 2]);
+  }
+  // ninth k-step: A has 1.0 at k = 0 (lanes 0..31 hold k = 0..7), B the sequence term at k = 0
+  const uint32_t k0 = (lane < 32) ? 0xFFFFFFFFu : 0u;
+  const bf16x8 A9 = __builtin_bit_cast(bf16x8, u32x4{0x3F80u & k0, 0u, 0u, 0u});
+  auto seq_term = [&](int seq) {  // (31 - seq) / 32 as bf16 (at most 5 significant bits: exact)
+    const float term = (float)(31 - seq) * 0.03125f;
+    return __builtin_bit_cast(bf16x8, u32x4{(__float_as_uint(term) >> 16) & k0, 0u, 0u, 0u});
+  };
+
+  uint32_t rmx[16], rnx[16];  // float bit patterns of (dot + (31 - seq) / 32)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rmx[r] = rnx[r] = 0u;
+
+  const int n_tiles = (ny + kTile - 1) / kTile;
+  const int n_full = ny / kTile;
+  const u32x4* __restrict__ ysrc = reinterpret_cast<const u32x4*>(ypool);
+  // a tile is 2048 consecutive 16-byte chunks: thread tid moves chunks i * 256 + tid.  No row clamp: the pool is padded
+  // (ensure_sift) and rows beyond ny are masked in the ragged tile
+#define SIFT_LOAD_TILE_LINEAR(TILE, REGS) \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) REGS[i] = ysrc[(size_t)(TILE) * (kTile * kChunksPerRow) + i * kSiftThreads + tid];
+  {
+    u32x4 first[8];
+    SIFT_LOAD_TILE_LINEAR(0, first)
+    SIFT_STORE_TILE(0, first)
+  }
+  __syncthreads();
+
+  // B fragment slots of this lane inside a column tile: row = ct * 32 + (lane & 31), chunk (ks * 2 + hi) ^ (row & 15)
+  int boff[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    boff[ks] = (lane & 31) * kChunksPerRow + ((ks * 2 + (lane >> 5)) ^ (lane & 15));
+
+  f32x16 accX, accY;  // accY enters a tile holding the previous tile's last column tile (zeros: inert keys)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accX[r] = accY[r] = 0.0f;
+  bf16x8 Bc[8], Bn[8];
+
+#define SIFT_READ_B(DST, BUF, CT)                                                                   \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                   \
+      DST[ks] = __builtin_bit_cast(bf16x8, tileY[BUF][(CT) * 32 * kChunksPerRow + boff[ks]]);
+#define SIFT_MFMA9(ACC, B, SEQ)                                                                     \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[r] = 0.0f;                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                   \
+      ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], B[ks], ACC, 0, 0, 0);                     \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A9, seq_term(SEQ), ACC, 0, 0, 0);
+#define SIFT_DIGEST(ACC)                                                                            \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], __float_as_uint(ACC[r]));
+#if defined(RGBDFE_SIFT_ABL)  // timing ablations (wrong results): tools/sift_ablation.sh
+#if RGBDFE_SIFT_ABL == 1      // no digest (one element keeps the accumulator alive)
+#undef SIFT_DIGEST
+#define SIFT_DIGEST(ACC) top2_insert(rmx[0], rnx[0], __float_as_uint(ACC[0]));
+#elif RGBDFE_SIFT_ABL == 2    // no MFMA
+#undef SIFT_MFMA9
+#define SIFT_MFMA9(ACC, B, SEQ)                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(B[ks]));                    \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[r] = __uint_as_float((uint32_t)((SEQ) + r + lane));
+#elif RGBDFE_SIFT_ABL == 6 || RGBDFE_SIFT_ABL == 7   // no MFMA, no digest (7: no LDS reads either)
+#undef SIFT_MFMA9
+#define SIFT_MFMA9(ACC, B, SEQ)                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(B[ks]));                    \
+  ACC[0] = __uint_as_float((uint32_t)((SEQ) + lane));
+#undef SIFT_DIGEST
+#define SIFT_DIGEST(ACC) top2_insert(rmx[0], rnx[0], __float_as_uint(ACC[0]));
+#if RGBDFE_SIFT_ABL == 7
+#undef SIFT_READ_B
+#define SIFT_READ_B(DST, BUF, CT) _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) DST[ks] = A[(ks + (CT)) & 7];
+#endif
+#elif RGBDFE_SIFT_ABL == 5    // no LDS reads
+#undef SIFT_READ_B
+#define SIFT_READ_B(DST, BUF, CT) _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) DST[ks] = A[(ks + (CT)) & 7];
+#endif
+#endif
+  // one pipelined step: 9 x { 1 MFMA, 1 LDS read (the first 8), 4 VALU }, fenced so that nothing crosses into the next step
+#ifdef RGBDFE_SIFT_BURST
+#define SIFT_STEP_SCHED(N_READS)                                       \
+  __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);                   \
+  __builtin_amdgcn_sched_group_barrier(0x100, (N_READS), 0);           \
+  __builtin_amdgcn_sched_group_barrier(0x002, 36, 0);                  \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define SIFT_STEP_SCHED(N_READS)                                       \
+  _Pragma("unroll") for (int g = 0; g < 9; ++g) {                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+    if (g < (N_READS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                 \
+  }                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+
+  int tile = 0;
+  for (; tile < n_full; ++tile) {
+    const int buf = tile & 1;
+    u32x4 nxt[8];
+    SIFT_LOAD_TILE_LINEAR(tile + 1, nxt)
+    const int seq0 = tile * 4;
+    SIFT_READ_B(Bc, buf, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    // column tile 0 beside the digest of the previous tile's column tile 3
+    SIFT_MFMA9(accX, Bc, seq0)
+    SIFT_READ_B(Bn, buf, 1)
+    SIFT_DIGEST(accY)
+    SIFT_STEP_SCHED(8)
+    SIFT_MFMA9(accY, Bn, seq0 + 1)
+    SIFT_READ_B(Bc, buf, 2)
+    SIFT_DIGEST(accX)
+    SIFT_STEP_SCHED(8)
+    SIFT_MFMA9(accX, Bc, seq0 + 2)
+    SIFT_READ_B(Bn, buf, 3)
+    SIFT_DIGEST(accY)
+    SIFT_STEP_SCHED(8)
+    SIFT_MFMA9(accY, Bn, seq0 + 3)
+    SIFT_DIGEST(accX)
+    SIFT_STEP_SCHED(0)
+    // unconditional (after the last tile the other buffer is never read again): the loop body stays ONE basic block, so
+    // the digests cannot be sunk below the MFMAs into a latch block
+#if defined(RGBDFE_SIFT_ABL) && (RGBDFE_SIFT_ABL == 3 || RGBDFE_SIFT_ABL == 4)
+    asm volatile("" ::"v"(nxt[0]), "v"(nxt[7]));
+#else
+    SIFT_STORE_TILE(buf ^ 1, nxt)
+#endif
+#if !(defined(RGBDFE_SIFT_ABL) && RGBDFE_SIFT_ABL == 4)
+    __syncthreads();
+#endif
+  }
+  SIFT_DIGEST(accY)
+  if (tile < n_tiles) {  // ragged last tile: columns beyond ny carry key 0
+    const int buf = tile & 1;
+    const int t0 = tile * kTile;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      SIFT_READ_B(Bc, buf, ct)
+      SIFT_MFMA9(accX, Bc, tile * 4 + ct)
+      const bool ok = (t0 + ct * 32 + (lane & 31)) < ny;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) top2_insert(rmx[r], rnx[r], ok ? __float_as_uint(accX[r]) : 0u);
+    }
+  }
+#undef SIFT_READ_B
+#undef SIFT_LOAD_TILE_LINEAR
+#undef SIFT_MFMA9
+#undef SIFT_DIGEST
+#undef SIFT_STEP_SCHED
+  if (r0 >= nx) return;  // waves beyond the last row (after the last barrier)
+#if defined(RGBDFE_SIFT_ABL) && RGBDFE_SIFT_ABL == 8
+  if (rmx[0] != 0x12345u) return;
+#endif
+
+  // Float keys leave room for the lane in the key (dot < 2^19): the tie rules become ONE total order --
+  //   !SWAP: (dot, lower lane, lower sequence)   RowMatch_Kernel's butterfly prefers the lower slot at every step, so the
+  //                                              lowest lane among equal dots survives; inside a lane the first column
+  //    SWAP: (dot, lower sequence, lower lane)   = the lowest row index (ColMatch_Kernel)
+  // -- and the 32-lane merge is a plain max-reduction in any pairing: 4 DPP steps + one ds_bpermute, with
+  // second = max(loser's best, both seconds) per step (v_min, v_max3, v_max).
+  uint32_t* __restrict__ opart = part + (size_t)pair * max_kp * 3;
+  const uint32_t lrev = 31u - (uint32_t)(lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t k32 = (uint32_t)(__uint_as_float(rmx[r]) * 32.0f);  // dot << 5 | (31 - seq): exact, < 2^24
+    const uint32_t n32 = (uint32_t)(__uint_as_float(rnx[r]) * 32.0f);
+    uint32_t key = SWAP ? ((k32 << 5) | lrev) : (((k32 >> 5) << 10) | (lrev << 5) | (k32 & 31u));
+    uint32_t sec = (n32 >> 5) << 10;
+#define SIFT_MERGE_STEP(PK, PS)                          \
+  {                                                      \
+    const uint32_t pk = (PK), ps = (PS);                 \
+    sec = max(max(min(key, pk), sec), ps);               \
+    key = max(key, pk);                                  \
+  }
+    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0xB1, 0xF, 0xF, false),   // quad_perm [1,0,3,2]
+                    __builtin_amdgcn_update_dpp(0u, sec, 0xB1, 0xF, 0xF, false))
+    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0x4E, 0xF, 0xF, false),   // quad_perm [2,3,0,1]
+                    __builtin_amdgcn_update_dpp(0u, sec, 0x4E, 0xF, 0xF, false))
+    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0x141, 0xF, 0xF, false),  // row_half_mirror
+                    __builtin_amdgcn_update_dpp(0u, sec, 0x141, 0xF, 0xF, false))
+    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0x140, 0xF, 0xF, false),  // row_mirror
+                    __builtin_amdgcn_update_dpp(0u, sec, 0x140, 0xF, 0xF, false))
+    SIFT_MERGE_STEP(__shfl_xor(key, 16), __shfl_xor(sec, 16))
+#undef SIFT_MERGE_STEP
+    const uint32_t dmx = key >> 10, dnx = sec >> 10;
+    const uint32_t hi5 = 31u - ((key >> 5) & 31u), lo5 = 31u - (key & 31u);
+    const uint32_t idx = dmx ? (SWAP ? ((hi5 << 5) | lo5) : ((lo5 << 5) | hi5)) : 0xFFFFFFFFu;
+    const int row = r0 + row_of_reg(r, lane);
+    if ((lane & 31) == 0 && row < nx) {
+      opart[(size_t)row * 3 + 0] = dmx;
+      opart[(size_t)row * 3 + 1] = dnx;
+      opart[(size_t)row * 3 + 2] = idx;
+    }
+  }
+}
+
 __device__ __forceinline__ float sift_angle(uint32_t dot) {
   // ProgramCU.cu:1738: acos(min(dot * 0.000003814697265625f, 1.0)): float product, double min/acos
   const float prod = (float)(int)dot * 0.000003814697265625f;
@@ -349,16 +589,27 @@ __global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
 }
 
 void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,
-                     uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t* row_part,
-                     uint32_t* col_part, hipStream_t stream) {
+                     uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_kinds,
+                     uint32_t* row_part, uint32_t* col_part, hipStream_t stream) {
   if (n_pairs == 0) return;
   uint32_t rbq = (max_nq + kTile - 1) / kTile, rbt = (max_nt + kTile - 1) / kTile;
   if (rbq < 1) rbq = 1;
   if (rbt < 1) rbt = 1;
-  hipLaunchKernelGGL(sift_row_top2_kernel<false>, dim3(rbq, n_pairs), dim3(kSiftThreads), 0, stream,
-                     bf16_pool, work, max_kp, row_part);
-  hipLaunchKernelGGL(sift_row_top2_kernel<true>, dim3(rbt, n_pairs), dim3(kSiftThreads), 0, stream,
-                     bf16_pool, work, max_kp, col_part);
+  // key_kinds: bit 0 = some pair of the batch carries float keys (PairWork::pad bit 0), bit 1 = some pair integer keys;
+  // each kernel leaves the other kind's pairs at once
+  const uint32_t groups = (n_pairs + 7u) / 8u * 8u;
+  if (key_kinds & 1u) {
+    hipLaunchKernelGGL(sift_top2_fast_kernel<false>, dim3(rbq * groups), dim3(kSiftThreads), 0, stream,
+                       bf16_pool, work, max_kp, n_pairs, rbq, row_part);
+    hipLaunchKernelGGL(sift_top2_fast_kernel<true>, dim3(rbt * groups), dim3(kSiftThreads), 0, stream,
+                       bf16_pool, work, max_kp, n_pairs, rbt, col_part);
+  }
+  if (key_kinds & 2u) {
+    hipLaunchKernelGGL(sift_row_top2_kernel<false>, dim3(rbq * groups), dim3(kSiftThreads), 0, stream,
+                       bf16_pool, work, max_kp, n_pairs, rbq, row_part);
+    hipLaunchKernelGGL(sift_row_top2_kernel<true>, dim3(rbt * groups), dim3(kSiftThreads), 0, stream,
+                       bf16_pool, work, max_kp, n_pairs, rbt, col_part);
+  }
 }
 
 void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t max_kp,

@@ -56,6 +56,55 @@ def test_sift_match_nodes_vs_oracle(fe, n1, n2):
     fe.release_node(2)
 
 
+def _check_nodes(fe, d1, d2, rng):
+    fe.upload_sift_node(1, d1, _xyz(rng, len(d1)))
+    fe.upload_sift_node(2, d2, _xyz(rng, len(d2)))
+    mq, mt, md = fe.sift_match_nodes(1, 2)
+    oq, ot, od = po.sift_match(d1, d2)
+    assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od)
+    fe.release_node(1)
+    fe.release_node(2)
+    return len(mq)
+
+
+def test_sift_key_paths(fe):
+    """The dot-product kernel has two key formats (sift_match.hip): float keys  dot + (31 - seq) / 32  when both nodes
+    hold <= 1024 rows and every quantised squared norm is < 2^19, integer keys otherwise.  Same answers from both:
+    nodes above 1024 rows, descriptors that are not unit length (one node or both), norms right under the 2^19 limit
+    with duplicated rows (the tie-break bits sit 24 bits under the leading bit there), and saturated u8 values."""
+    rng = np.random.default_rng(77)
+    base = _rand_sift(rng, 1200)
+    noisy = np.abs(base + rng.normal(0, 0.01, base.shape).astype(np.float32))
+    noisy /= np.linalg.norm(noisy, axis=1, keepdims=True)
+    perm = rng.permutation(1200)
+    assert _check_nodes(fe, noisy[perm][:1000], base[:1000], rng) > 300      # float keys
+    assert _check_nodes(fe, noisy[perm][:1100], base[:900], rng) > 300       # > 1024 rows on one side: integer keys
+    assert _check_nodes(fe, noisy[perm][:900], base[:1100], rng) > 300
+    assert _check_nodes(fe, noisy[perm][:1000] * 1.6, base[:1000], rng) > 300   # |d|^2 = 2.56 * 2^18: integer keys
+    _check_nodes(fe, noisy[perm][:1000] * 1.6, base[:1000] * 1.7, rng)   # every angle is acos(1): no match survives
+    # squared norms just under 2^19 (float keys at their upper limit), many exact duplicates -> equal dot products
+    u = np.full((48, 128), 64, np.int32)
+    u[:, 0] = 63
+    for r in range(48):
+        k = rng.integers(1, 128, 6)
+        u[r, k] -= rng.integers(1, 20, 6)
+    assert ((u * u).sum(1) < (1 << 19)).all() and ((u * u).sum(1) > (1 << 19) - 40000).all()
+    f = (u / 512.0).astype(np.float32)
+    d2 = f[rng.integers(0, 48, 1024)]
+    d1 = f[rng.integers(0, 48, 1000)]
+    _check_nodes(fe, d1, d2, rng)
+    d2n = np.abs(d2 + rng.normal(0, 2e-3, d2.shape).astype(np.float32))
+    _check_nodes(fe, d1, np.minimum(d2n, 0.1249), rng)
+    # one row over the limit switches the whole node to integer keys
+    d1b = d1.copy()
+    d1b[500, :] = 0.126
+    _check_nodes(fe, d1b, d2, rng)
+    # saturated / wrapping u8 values (SiftMatchCU.cpp:96-99 stores an unsigned char): 0.6 * 512 = 307 -> 51
+    d1c = _rand_sift(rng, 300)
+    d1c[::7, 3] = 0.6
+    _check_nodes(fe, d1c, base[:400], rng)
+
+
 def test_sift_tie_rules(fe):
     """Exact duplicates force equal dot products: the row side must follow RowMatch_Kernel's
     32-thread butterfly (ProgramCU.cu:1715-1736), the column side "lowest row wins" (:1464-1467,
