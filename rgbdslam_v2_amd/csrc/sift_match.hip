@@ -447,41 +447,61 @@ __global__ __launch_bounds__(kSiftThreads) void sift_top2_fast_kernel(
   //   !SWAP: (dot, lower lane, lower sequence)   RowMatch_Kernel's butterfly prefers the lower slot at every step, so the
   //                                              lowest lane among equal dots survives; inside a lane the first column
   //    SWAP: (dot, lower sequence, lower lane)   = the lowest row index (ColMatch_Kernel)
-  // -- and the 32-lane merge is a plain max-reduction in any pairing: 4 DPP steps + one ds_bpermute, with
-  // second = max(loser's best, both seconds) per step (v_min, v_max3, v_max).
+  // -- so the 32 lanes that share a row merge by a plain max in any pairing, with second = max(loser's best, both
+  // seconds) per step (v_min, v_max3, v_max).  The merge is a reduce-scatter: at every step a lane keeps half of its
+  // rows and hands the other half to its partner (16 -> 8 -> 4 -> 2 -> 1 rows; xor 1 / 2 as DPP quad permutes, 4 / 8 /
+  // 16 through ds_bpermute), 31 merges per lane instead of 80, and ends holding ONE row, which it stores.
   uint32_t* __restrict__ opart = part + (size_t)pair * max_kp * 3;
   const uint32_t lrev = 31u - (uint32_t)(lane & 31);
+  uint32_t K[16], S[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const uint32_t k32 = (uint32_t)(__uint_as_float(rmx[r]) * 32.0f);  // dot << 5 | (31 - seq): exact, < 2^24
     const uint32_t n32 = (uint32_t)(__uint_as_float(rnx[r]) * 32.0f);
-    uint32_t key = SWAP ? ((k32 << 5) | lrev) : (((k32 >> 5) << 10) | (lrev << 5) | (k32 & 31u));
-    uint32_t sec = (n32 >> 5) << 10;
-#define SIFT_MERGE_STEP(PK, PS)                          \
+    K[r] = SWAP ? ((k32 << 5) | lrev) : (((k32 >> 5) << 10) | (lrev << 5) | (k32 & 31u));
+    S[r] = (n32 >> 5) << 10;
+  }
+#define SIFT_MERGE(KEY, SEC, PK, PS)                     \
   {                                                      \
     const uint32_t pk = (PK), ps = (PS);                 \
-    sec = max(max(min(key, pk), sec), ps);               \
-    key = max(key, pk);                                  \
+    SEC = max(max(min(KEY, pk), SEC), ps);               \
+    KEY = max(KEY, pk);                                  \
   }
-    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0xB1, 0xF, 0xF, false),   // quad_perm [1,0,3,2]
-                    __builtin_amdgcn_update_dpp(0u, sec, 0xB1, 0xF, 0xF, false))
-    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0x4E, 0xF, 0xF, false),   // quad_perm [2,3,0,1]
-                    __builtin_amdgcn_update_dpp(0u, sec, 0x4E, 0xF, 0xF, false))
-    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0x141, 0xF, 0xF, false),  // row_half_mirror
-                    __builtin_amdgcn_update_dpp(0u, sec, 0x141, 0xF, 0xF, false))
-    SIFT_MERGE_STEP(__builtin_amdgcn_update_dpp(0u, key, 0x140, 0xF, 0xF, false),  // row_mirror
-                    __builtin_amdgcn_update_dpp(0u, sec, 0x140, 0xF, 0xF, false))
-    SIFT_MERGE_STEP(__shfl_xor(key, 16), __shfl_xor(sec, 16))
-#undef SIFT_MERGE_STEP
-    const uint32_t dmx = key >> 10, dnx = sec >> 10;
-    const uint32_t hi5 = 31u - ((key >> 5) & 31u), lo5 = 31u - (key & 31u);
-    const uint32_t idx = dmx ? (SWAP ? ((hi5 << 5) | lo5) : ((lo5 << 5) | hi5)) : 0xFFFFFFFFu;
-    const int row = r0 + row_of_reg(r, lane);
-    if ((lane & 31) == 0 && row < nx) {
-      opart[(size_t)row * 3 + 0] = dmx;
-      opart[(size_t)row * 3 + 1] = dnx;
-      opart[(size_t)row * 3 + 2] = idx;
-    }
+  // STEP(N, bit, fetch): N rows -> N / 2; a lane with `bit` set keeps the upper half
+#define SIFT_SCATTER_STEP(N, BIT, FETCH)                                              \
+  _Pragma("unroll") for (int r = 0; r < (N) / 2; ++r) {                                \
+    const uint32_t sendK = (BIT) ? K[r] : K[r + (N) / 2], sendS = (BIT) ? S[r] : S[r + (N) / 2]; \
+    uint32_t keepK = (BIT) ? K[r + (N) / 2] : K[r], keepS = (BIT) ? S[r + (N) / 2] : S[r];       \
+    SIFT_MERGE(keepK, keepS, FETCH(sendK), FETCH(sendS))                               \
+    K[r] = keepK;                                                                      \
+    S[r] = keepS;                                                                      \
+  }
+#define SIFT_DPP_XOR1(V) __builtin_amdgcn_update_dpp(0u, (V), 0xB1, 0xF, 0xF, false)  // quad_perm [1,0,3,2]
+#define SIFT_DPP_XOR2(V) __builtin_amdgcn_update_dpp(0u, (V), 0x4E, 0xF, 0xF, false)  // quad_perm [2,3,0,1]
+#define SIFT_SHFL4(V) __shfl_xor((V), 4)
+#define SIFT_SHFL8(V) __shfl_xor((V), 8)
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+  SIFT_SCATTER_STEP(16, b0, SIFT_DPP_XOR1)
+  SIFT_SCATTER_STEP(8, b1, SIFT_DPP_XOR2)
+  SIFT_SCATTER_STEP(4, b2, SIFT_SHFL4)
+  SIFT_SCATTER_STEP(2, b3, SIFT_SHFL8)
+  uint32_t key = K[0], sec = S[0];
+  SIFT_MERGE(key, sec, __shfl_xor(key, 16), __shfl_xor(sec, 16))
+#undef SIFT_MERGE
+#undef SIFT_SCATTER_STEP
+#undef SIFT_DPP_XOR1
+#undef SIFT_DPP_XOR2
+#undef SIFT_SHFL4
+#undef SIFT_SHFL8
+  const int reg = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);  // the row this lane ended up with
+  const uint32_t dmx = key >> 10, dnx = sec >> 10;
+  const uint32_t hi5 = 31u - ((key >> 5) & 31u), lo5 = 31u - (key & 31u);
+  const uint32_t idx = dmx ? (SWAP ? ((hi5 << 5) | lo5) : ((lo5 << 5) | hi5)) : 0xFFFFFFFFu;
+  const int row = r0 + row_of_reg(reg, lane);
+  if ((lane & 16) == 0 && row < nx) {
+    opart[(size_t)row * 3 + 0] = dmx;
+    opart[(size_t)row * 3 + 1] = dnx;
+    opart[(size_t)row * 3 + 2] = idx;
   }
 }
 
