@@ -248,18 +248,22 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
  *   record / replay       (default) recording waves each refine chunk_iterations iterations of a pair and write the
  *                         outcomes, then one wave per pair replays the records in iteration order with the reference's
  *                         bookkeeping (node.cpp:1171-1190).  Up to 256 pairs all iterations are recorded in one phase
- *                         (full speculation: one node against 20 candidates returns in 0.44 ms instead of 5.7 ms);
- *                         larger batches run four phases ([0,14), [14,70), [70,140), [140,200) for 200 iterations)
- *                         and each replay tells the next phase which pairs are finished and how many iterations the
- *                         others can still need, so recording stops where the reference stops iterating.  The work
- *                         is spread over uniform short waves (no long tail of slow pairs);
+ *                         (full speculation: one node against 20 candidates returns in 0.41 ms instead of 5.7 ms);
+ *                         larger batches run up to four phases ([0,14), [14,70), [70,140), [140,200) for 200
+ *                         iterations): each replay tells the next phase which pairs are finished and how many
+ *                         iterations the others can still need, so recording stops where the reference stops
+ *                         iterating.  After the first phase a pair whose loop has not jumped ahead (it += 10 / 20) and
+ *                         whose hypotheses were mostly junk is recorded to the end in ONE launch (64-iteration shares,
+ *                         junk hypotheses screened out lane-parallel before they take a slot), the others go on
+ *                         phase by phase in short shares.  Batches beyond 2^24 / ransac_iterations (or 65535) pairs
+ *                         run as pieces of that size;
  *   one wave per pair     a wave runs a pair's whole loop (windows of 7 iterations, replayed in order): exactly the
  *                         iterations the reference runs, but a pair takes ~4.6 ms however idle the chip is and a
- *                         launch lasts as long as its slowest pair.
- * Batches of at most max_pairs pairs (ORB and SIFT) take record / replay.  Defaults: max_pairs = INT32_MAX (every
- * batch), chunk_iterations = 0 (automatic: 4 up to 64 pairs, 7 up to 640, 14 up to 1280, 28 above; a phase is cut into equal
- * shares of at most that many iterations); max_pairs = 0 forces one wave per pair.
- * A negative chunk_iterations selects the four-phase plan for every batch size with |chunk_iterations| iterations
+ *                         launch lasts as long as its slowest pair.  Kept for A/B runs; never chosen by the library.
+ * Batches of at most max_pairs pairs (ORB, SIFT, FLANN) take record / replay.  Defaults: max_pairs = INT32_MAX (every
+ * batch), chunk_iterations = 0 (automatic: 4 up to 64 pairs, 7 up to 640, 14 up to 1280, 28 above; a phase is cut into
+ * equal shares of at most that many iterations); max_pairs = 0 forces one wave per pair.
+ * A negative chunk_iterations selects the phased plan for every batch size with |chunk_iterations| iterations
  * per recording wave (a testing aid: small batches are faster with the single phase). */
 int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations);
 
