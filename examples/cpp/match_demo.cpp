@@ -1,11 +1,12 @@
 // match_demo.cpp -- C++ consumer of include/rgbdfe.hpp, written the way the reference's call site
 // (GraphManager::nodeComparisons, graph_manager.cpp:531-583) would use it.
-//   match_demo <nodes.bin>
+//   match_demo <nodes.bin> [multi]      "multi": two device contexts behind one handle (rgbdfe_create_multi, device 0 twice)
 // nodes.bin: int32 n_nodes, then per node: int32 n, n*32 bytes descriptors, n*4 floats xyz1.
 // Prints one JSON line per (last node, earlier node) pair.
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "rgbdfe.hpp"
@@ -20,7 +21,8 @@ int main(int argc, char** argv) {
   cfg.max_nodes = n_nodes + 2;
   cfg.max_keypoints = 2048;
   cfg.max_pairs_per_batch = 64;
-  rgbdslam::FrontEnd fe(cfg);
+  const bool multi = argc > 2 && std::string(argv[2]) == "multi";
+  rgbdslam::FrontEnd fe = multi ? rgbdslam::FrontEnd(cfg, std::vector<int32_t>{0, 0}) : rgbdslam::FrontEnd(cfg);
   std::vector<std::unique_ptr<rgbdslam::Node>> graph;
   for (int i = 0; i < n_nodes; ++i) {
     int32_t n = 0;
@@ -54,5 +56,10 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < targets.size(); ++i) std::printf("%s%d", i ? ", " : "", targets[i]);
   std::printf("]}\n");
   std::printf("{\"single_id1\": %d, \"single_n_inl\": %zu}\n", one.edge.id1, one.inlier_matches.size());
+  // place recognition (loop_closing.cpp:190-277): the earlier nodes ranked by descriptor votes
+  const std::vector<int> ranked = gm.getNeighbours(new_node, nodes_to_comp, /*neighbour_cnt=*/2, /*max_out=*/n_nodes);
+  std::printf("{\"devices\": %d, \"neighbours\": [", fe.deviceCount());
+  for (size_t i = 0; i < ranked.size(); ++i) std::printf("%s%d", i ? ", " : "", ranked[i]);
+  std::printf("]}\n");
   return 0;
 }

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <utility>
 #include <cstdint>
+#include <algorithm>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -79,6 +80,16 @@ class FrontEnd {
     if (st != RGBDFE_OK) throw std::runtime_error(std::string("rgbdfe_create: ") + rgbdfe_status_string(st));
     ctx_.reset(c, rgbdfe_destroy);
   }
+  // Several GPUs behind one handle (rgbdfe_create_multi): nodes are replicated, nodeComparisons shards its candidates
+  // (candidate k -> device k mod G) -- nothing else in this header changes.
+  FrontEnd(const rgbdfe_config& cfg, const std::vector<int32_t>& device_ids) {
+    rgbdfe_ctx* c = nullptr;
+    const int st = rgbdfe_create_multi(&cfg, device_ids.data(), (int32_t)device_ids.size(), &c);
+    if (st != RGBDFE_OK)
+      throw std::runtime_error(std::string("rgbdfe_create_multi: ") + rgbdfe_status_string(st) + ": " + rgbdfe_last_error(nullptr));
+    ctx_.reset(c, rgbdfe_destroy);
+  }
+  int deviceCount() const { return rgbdfe_device_count(ctx_.get()); }
   static rgbdfe_config defaultConfig() {
     rgbdfe_config c;
     rgbdfe_default_config(&c);
@@ -122,6 +133,9 @@ class Node {  // the slice of src/node.h the pair path touches
     return rgbdfe_upload_node_cloud(fe_.get(), id_, depth, rows, cols, rgb, rgb_channels, encoding_bgr ? 1 : 0, fx, fy,
                                     cx, cy, depth_scaling, minimum_depth, cloud_creation_skip_step, nullptr) == RGBDFE_OK;
   }
+  // feature_locations_2d_ (node.h:160): only the g2o pair refinement reads them (params.g2o_iterations > 0,
+  // node.cpp:1222-1268); kp_xy = n x (u, v)
+  bool setKeypoints(const float* kp_xy) { return rgbdfe_upload_node_keypoints(fe_.get(), id_, kp_xy, n_) == RGBDFE_OK; }
   void clearFeatureInformation() {  // src/node.cpp:1431-1443
     if (matchable_) rgbdfe_release_node(fe_.get(), id_);
     matchable_ = false;
@@ -161,6 +175,20 @@ class GraphManager {  // candidate selection (graph_manager.cpp:204-324) + the f
                                       seed, ids.data(), (int32_t)ids.size(), &n) != RGBDFE_OK)
       return {};
     return std::vector<int>(ids.begin(), ids.begin() + n);
+  }
+  // GraphManager::getNeighbours (loop_closing.cpp:190-277): candidates ranked by the votes of the new node's
+  // descriptors (exact Hamming neighbours); returns at most max_out node ids, best first
+  std::vector<int> getNeighbours(const Node* new_node, const std::vector<const Node*>& candidates, int neighbour_cnt,
+                                 int max_out, int max_hd = 256) const {
+    std::vector<int32_t> ids, out((size_t)std::max(max_out, 0));
+    std::vector<float> score(out.size());
+    for (const Node* n : candidates) ids.push_back(n->id_);
+    int32_t n_out = 0;
+    if (ids.empty() || out.empty() ||
+        rgbdfe_place_recognition(fe_.get(), new_node->id_, ids.data(), (int32_t)ids.size(), neighbour_cnt, max_hd,
+                                 (int32_t)out.size(), out.data(), score.data(), &n_out) != RGBDFE_OK)
+      return {};
+    return std::vector<int>(out.begin(), out.begin() + n_out);
   }
   // 1:1 replacement of QtConcurrent::blockingMapped(nodes_to_comp, bind(&Node::matchNodePair, new_node, _1))
   std::vector<MatchingResult> nodeComparisons(const Node* new_node, const std::vector<const Node*>& nodes_to_comp) const {

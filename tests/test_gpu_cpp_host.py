@@ -30,16 +30,24 @@ def test_cpp_host_matches_oracle(tmp_path):
             f.write(seq["xyz1"][k].tobytes())
     out = subprocess.check_output([exe, str(path)], text=True, timeout=120)
     lines = [json.loads(l) for l in out.strip().splitlines()]
-    assert len(lines) == F + 1
+    assert len(lines) == F + 2
     # getPotentialEdgeTargetsWithDijkstra(2 sequential, 1 geodesic, 1 sampled) over the 4 earlier nodes: no more nodes
     # than targets, so all of them, sequentially from the predecessor (graph_manager.cpp:212-227)
-    assert lines[-2]["candidates"] == [2, 1, 0]
+    assert lines[-3]["candidates"] == [2, 1, 0]
     prm = po.default_params()
-    for t, rec in enumerate(lines[:-2]):
+    for t, rec in enumerate(lines[:-3]):
         ref = po.match_node_pair(seq["desc"][F - 1], seq["xyz1"][F - 1], F - 1, seq["desc"][t], seq["xyz1"][t], t, prm)
         assert (rec["id1"], rec["id2"]) == (ref["id1"], ref["id2"])
         assert rec["n_all"] == ref["n_all"] and rec["n_inl"] == ref["n_inl"]
         T = np.array(rec["T"], np.float32).reshape(4, 4).T
         assert np.array_equal(T, ref["T"])
         assert np.float32(rec["rmse"]) == ref["rmse"] and rec["info"] == ref["info_scale"]
-    assert lines[-1]["single_id1"] == lines[0]["id1"] and lines[-1]["single_n_inl"] == lines[0]["n_inl"]
+    assert lines[-2]["single_id1"] == lines[0]["id1"] and lines[-2]["single_n_inl"] == lines[0]["n_inl"]
+    # GraphManager::getNeighbours through the C++ layer == the Python binding's ranking == the numpy oracle
+    ref_pos, _ = po.place_recognition(seq["desc"][F - 1], [seq["desc"][t] for t in range(F - 1)], 2, 256)
+    assert lines[-1]["devices"] == 1 and lines[-1]["neighbours"] == [int(i) for i in ref_pos]   # node id == position
+    # the same program over two device contexts behind one handle (rgbdfe_create_multi): same lines
+    out2 = subprocess.check_output([exe, str(path), "multi"], text=True, timeout=120)
+    lines2 = [json.loads(l) for l in out2.strip().splitlines()]
+    assert lines2[-1]["devices"] == 2
+    assert lines2[:-1] == lines[:-1] and lines2[-1]["neighbours"] == lines[-1]["neighbours"]
