@@ -20,6 +20,12 @@ struct OrbWorkspace {
   void reset_detector(int max_keypoints, int grid_res, int max_iters);
   int prepare(int cols, int rows, bool use_grid, std::string& err);
   int upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err);
+  // A detection pass = gpu_pass (FAST + NMS + Harris + angle for every corner at the cells' thresholds, one round trip)
+  // + select_pass (orb.cpp computeKeyPoints' per-level selections on the host).  select_pass may ask for HIGHER thresholds
+  // than the gpu_pass ran with: the corners at threshold t are exactly the corners at any floor f <= t whose FAST score
+  // is >= t (see select_pass), which lets grid_detect serve two adjuster iterations from one round trip.
+  int gpu_pass(const std::vector<int>& active, const std::vector<int>& thr, hipStream_t s, std::string& err);
+  void select_pass(const std::vector<int>& active, const std::vector<int>& thr, std::vector<std::vector<KpOut>>& out);
   int detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
                   std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err);
   int grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::string& err);
@@ -32,6 +38,7 @@ struct OrbWorkspace {
 
   // detector state (the reference's detector_ object, openni_listener.h:195)
   int grid = 3, adjuster_iters = 5, cell_min = 0, cell_max = 0, max_total = 0;
+  bool lookahead = true;  // grid_detect: one device pass per two adjuster iterations (RGBDFE_DETECT_LOOKAHEAD=0: off)
   double thresh[64];
   std::vector<char> cell_mask_nonzero;
   // geometry
@@ -59,6 +66,19 @@ struct OrbWorkspace {
   int* h_ctl = nullptr; int* h_totals = nullptr; int* h_base = nullptr;
   RawKp* h_raw = nullptr; DescKp* h_desckp = nullptr; uint8_t* h_desc = nullptr;
   float* h_xyz_in = nullptr; float* h_xyz_out = nullptr; int32_t* h_n = nullptr;
+  const RawKp* pass_raw = nullptr;   // the latest gpu_pass: its corners (h_raw or pass_raw_big) ...
+  std::vector<RawKp> pass_raw_big;
+  uint8_t* h_img = nullptr;  // gray + mask staging (2 x W x H): the caller's pageable images go through it in chunks
+  // RGBDFE_DETECT_TIMING=1: host wall clock per phase of rgbdfe_detect_describe, printed when the workspace is released
+  struct Timing {
+    bool on = false;
+    long frames = 0, passes = 0;
+    double us[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // 0 prepare + mask scan, 1 upload + pyramid enqueue, 2 pass enqueue, 3 pass wait, 4 pass host work,
+    // 5 adjuster + cell merge, 6 removeDepthless + retainBest, 7 compute host prep + enqueue, 8 compute wait, 9 copy-out
+  } timing;
 };
+
+double orb_now_us();
 
 }  // namespace rgbdfe

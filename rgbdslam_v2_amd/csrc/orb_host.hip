@@ -10,6 +10,9 @@
 #include <vector>
 
 #include "orb_host.h"
+
+#include <chrono>
+#include <cstdio>
 #include "orb_pattern.inc"
 
 namespace rgbdfe {
@@ -63,28 +66,49 @@ void retain_best(std::vector<KP>& v, int n_points, F key) {
 template <typename F>
 void keep_strongest(std::vector<KP>& v, int N, F key) {
   if ((int)v.size() <= N) return;
-  std::vector<int> idx(v.size());
-  for (size_t i = 0; i < v.size(); ++i) idx[i] = (int)i;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(v[a]) > key(v[b]); });
-  std::vector<char> keep(v.size(), 0);
-  for (int i = 0; i < N; ++i) keep[idx[i]] = 1;
+  if (N <= 0) { v.clear(); return; }
+  // the N-th element of the order (key descending, position ascending) is the cut: a selection, not a sort
+  std::vector<std::pair<float, int>> r(v.size());
+  for (size_t i = 0; i < v.size(); ++i) r[i] = std::make_pair(key(v[i]), (int)i);
+  auto before = [](const std::pair<float, int>& a, const std::pair<float, int>& b) {
+    return a.first > b.first || (a.first == b.first && a.second < b.second);
+  };
+  std::nth_element(r.begin(), r.begin() + (N - 1), r.end(), before);
+  const std::pair<float, int> cut = r[(size_t)N - 1];
   size_t m = 0;
-  for (size_t i = 0; i < v.size(); ++i)
-    if (keep[i]) v[m++] = v[i];
+  for (size_t i = 0; i < v.size(); ++i) {
+    const std::pair<float, int> me = std::make_pair(key(v[i]), (int)i);
+    if (!before(cut, me)) v[m++] = v[i];  // me is at or before the cut
+  }
   v.resize(m);
 }
 
 }  // namespace
 
+double orb_now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 OrbWorkspace::~OrbWorkspace() { release(); }
 
 void OrbWorkspace::release() {
+  if (timing.on && timing.frames) {
+    static const char* names[10] = {"prepare+mask scan", "upload+pyramid enqueue", "pass enqueue", "pass wait",
+                                    "pass host work", "adjuster+cell merge", "removeDepthless+retainBest",
+                                    "compute prep+enqueue", "compute wait", "copy-out"};
+    double sum = 0;
+    for (double u : timing.us) sum += u;
+    fprintf(stderr, "[rgbdfe detect timing] %ld frames, %.2f passes per frame, %.1f us per frame\n", timing.frames,
+            (double)timing.passes / timing.frames, sum / timing.frames);
+    for (int i = 0; i < 10; ++i) fprintf(stderr, "  %-28s %8.1f us\n", names[i], timing.us[i] / timing.frames);
+    timing.frames = 0;
+  }
   auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   fr(d_pool); fr(d_score); fr(d_blur); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr);
   fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_kpxy);
   fr(d_kept); fr(d_xyz); fr(d_n);
   auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n);
+  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n); frh(h_img);
   d_active = nullptr;  // lives inside d_thr
   W = H = 0;
 }
@@ -214,6 +238,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipHostMalloc((void**)&h_xyz_in, sizeof(float) * 3 * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_xyz_out, sizeof(float) * 4 * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_n, sizeof(int32_t), hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_img, (size_t)2 * W * H, hipHostMallocDefault));
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));
@@ -224,9 +249,26 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
 
 // uploads the frame and builds every pyramid (cells + whole frame) and the blurred frame levels
 int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err) {
-  ORB_HIP(hipMemcpyAsync(d_pool, gray, (size_t)W * H, hipMemcpyHostToDevice, s));
-  if (mask) ORB_HIP(hipMemcpyAsync(d_pool + (size_t)W * H, mask, (size_t)W * H, hipMemcpyHostToDevice, s));
-  else ORB_HIP(hipMemsetAsync(d_pool + (size_t)W * H, 255, (size_t)W * H, s));
+  // The caller's images are pageable: a plain hipMemcpyAsync of 0.6 MB stalls the host ~150 us while the runtime stages
+  // it.  Own staging instead: memcpy a chunk into pinned memory, start its DMA, memcpy the next chunk meanwhile.
+  {
+    const size_t img = (size_t)W * H;
+    const size_t total = mask ? 2 * img : img;
+    const size_t chunk = 128 << 10;
+    for (size_t off = 0; off < total; off += chunk) {
+      const size_t n = std::min(chunk, total - off);
+      // [0, img) = gray, [img, 2 img) = mask: contiguous in the staging buffer and in d_pool alike
+      if (off < img) {
+        const size_t n0 = std::min(n, img - off);
+        memcpy(h_img + off, gray + off, n0);
+        if (n0 < n) memcpy(h_img + img, mask, n - n0);
+      } else {
+        memcpy(h_img + off, mask + (off - img), n);
+      }
+      ORB_HIP(hipMemcpyAsync(d_pool + off, h_img + off, n, hipMemcpyHostToDevice, s));
+    }
+    if (!mask) ORB_HIP(hipMemsetAsync(d_pool + img, 255, img, s));
+  }
   for (int l = 1; l < kLevels; ++l) {
     const int b = level_job_begin[l], e = level_job_begin[l + 1];
     int mw = 0, mh = 0;
@@ -238,11 +280,11 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
   return RGBDFE_OK;
 }
 
-// One detection pass over the active cells with their current thresholds.  out[c] receives the cell's
-// keypoints (level coordinates scaled to the cell image, cell-local) after orb.cpp computeKeyPoints'
-// per-level selection: retainBest(2*featuresNum) by FAST score, Harris responses, retainBest(featuresNum).
-int OrbWorkspace::detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
-                              std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err) {
+// The device half of a detection pass over the active cells at the given FAST thresholds: every corner that survives
+// NMS, the mask and the border filters, in raster order per (cell, level) image, with its FAST score, Harris response
+// and orientation -- read back in one round trip (pass_raw, h_totals, h_base).
+int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int>& thr, hipStream_t s, std::string& err) {
+  const double tp0 = timing.on ? orb_now_us() : 0;
   for (int c = 0; c < 64; ++c) {
     h_ctl[c] = c < n_cells ? thr[c] : 0;
     h_ctl[64 + c] = c < n_cells ? active[c] : 0;
@@ -260,24 +302,46 @@ int OrbWorkspace::detect_pass(const std::vector<int>& active, const std::vector<
   ORB_HIP(hipGetLastError());
   ORB_HIP(hipMemcpyAsync(h_totals, d_img_total, sizeof(int) * n_imgs, hipMemcpyDeviceToHost, s));
   ORB_HIP(hipMemcpyAsync(h_raw, d_kps, sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
+  const double tp1 = timing.on ? orb_now_us() : 0;
   ORB_HIP(hipStreamSynchronize(s));
-  const int* totals = h_totals;
-  const int* base = h_base;
+  const double tp2 = timing.on ? orb_now_us() : 0;
   int n_total = 0;
-  for (int i = 0; i < n_imgs; ++i) { h_base[i] = n_total; n_total += totals[i]; }
+  for (int i = 0; i < n_imgs; ++i) { h_base[i] = n_total; n_total += h_totals[i]; }
   if (n_total > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
   last_n_total = n_total;
-  std::vector<RawKp> raw_big;
-  const RawKp* raw = h_raw;
+  pass_raw = h_raw;
   if (n_total > bound) {
     launch_orb_measure_rest(d_pool, d_cell_imgs, d_kps, d_n, bound, n_total - bound, s);
     ORB_HIP(hipGetLastError());
-    raw_big.resize((size_t)n_total);
-    ORB_HIP(hipMemcpyAsync(raw_big.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
+    pass_raw_big.resize((size_t)n_total);
+    ORB_HIP(hipMemcpyAsync(pass_raw_big.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
     ORB_HIP(hipStreamSynchronize(s));
-    raw = raw_big.data();
+    pass_raw = pass_raw_big.data();
   }
+  if (timing.on) {
+    timing.passes++;
+    timing.us[2] += tp1 - tp0;
+    timing.us[3] += tp2 - tp1;
+    timing.us[4] += orb_now_us() - tp2;
+  }
+  return RGBDFE_OK;
+}
 
+// The host half: out[c] receives the cell's keypoints (level coordinates scaled to the cell image, cell-local) after
+// orb.cpp computeKeyPoints' per-level selection: retainBest(2*featuresNum) by FAST score, Harris responses,
+// retainBest(featuresNum).  thr[c] may be HIGHER than the threshold the latest gpu_pass ran the cell with: cv::FAST at
+// threshold t keeps the pixels whose best arc has min |difference| m > t that are strict 3x3 maxima of the score
+// m - 1 (non-corners count as 0).  A corner kept at t therefore has score >= t and beats every neighbour whose own score
+// is < t whether that neighbour counts as a corner (floor f <= its score) or as 0; and a pixel that loses against a
+// neighbour at the floor loses against the same neighbour at t when its own score is >= t (the neighbour's is larger
+// still).  So { corners at t } = { corners at f with score >= t }, in the same raster order; Harris response and angle
+// do not depend on the threshold.
+void OrbWorkspace::select_pass(const std::vector<int>& active, const std::vector<int>& thr,
+                               std::vector<std::vector<KpOut>>& out) {
+  const double tp0 = timing.on ? orb_now_us() : 0;
+  const int* totals = h_totals;
+  const int* base = h_base;
+  const RawKp* raw = pass_raw;
   // nfeaturesPerLevel (orb.cpp computeKeyPoints)
   int per_level[kLevels];
   {
@@ -290,20 +354,32 @@ int OrbWorkspace::detect_pass(const std::vector<int>& active, const std::vector<
   for (int c = 0; c < n_cells; ++c) {
     if (!active[c]) continue;
     out[c].clear();
+    const int t = std::min(std::max(thr[c], 0), 255);  // the kernel's clamp
     float sc[kLevels]; int lw[kLevels], lh[kLevels];
     level_geometry(cells[c].w, cells[c].h, kLevels, sc, lw, lh);
     for (int l = 0; l < kLevels; ++l) {
       const int img = c * kLevels + l;
-      std::vector<KP> v((size_t)totals[img]);
+      std::vector<KP> v;
+      v.reserve((size_t)totals[img]);
       for (int k = 0; k < totals[img]; ++k) {
         const RawKp& r = raw[(size_t)base[img] + k];
-        v[k] = KP{(float)r.x, (float)r.y, 31 * sc[l], r.angle, r.harris, l, (float)r.score};
+        if ((int)r.score < t) continue;
+        v.push_back(KP{(float)r.x, (float)r.y, 31 * sc[l], r.angle, r.harris, l, (float)r.score});
       }
       retain_best(v, 2 * per_level[l], [](const KP& k) { return k.score; });
       retain_best(v, per_level[l], [](const KP& k) { return k.response; });
       for (const KP& k : v) out[c].push_back(KpOut{k.x * sc[l], k.y * sc[l], k.size, k.angle, k.response, l});
     }
   }
+  if (timing.on) timing.us[4] += orb_now_us() - tp0;
+}
+
+// One detection pass over the active cells with their current thresholds (cv::ORB::detect on one image).
+int OrbWorkspace::detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
+                              std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err) {
+  const int rc = gpu_pass(active, thr, s, err);
+  if (rc != RGBDFE_OK) return rc;
+  select_pass(active, thr, out);
   return RGBDFE_OK;
 }
 
@@ -313,11 +389,29 @@ int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::strin
   std::vector<int> active((size_t)n_cells, 1), iter_left((size_t)n_cells, adjuster_iters), thr((size_t)n_cells);
   std::vector<char> checked((size_t)n_cells, 0);
   // host copy of the mask is needed only for hasNonZero(): done lazily by the caller through mask_nonzero
+  // A device pass runs every active cell at the threshold its NEXT adjuster iteration would use (x0.7, below) and
+  // select_pass filters by score: the second iteration of a cell that finds too few keypoints -- the common case on
+  // frames the thresholds have not settled on -- needs no second round trip.  The corners are those of separate passes.
+  std::vector<int> floor_thr((size_t)n_cells, 0);
+  std::vector<char> covered((size_t)n_cells, 0);
   bool any = true;
   while (any) {
-    for (int c = 0; c < n_cells; ++c) thr[c] = (int)thresh[c];  // static_cast<int>(thresh_)
-    int rc = detect_pass(active, thr, cellkp, s, err);
-    if (rc != RGBDFE_OK) return rc;
+    bool need_gpu = false;
+    for (int c = 0; c < n_cells; ++c) {
+      thr[c] = (int)thresh[c];  // static_cast<int>(thresh_)
+      if (active[c] && (!covered[c] || thr[c] < floor_thr[c])) need_gpu = true;
+    }
+    if (need_gpu) {
+      for (int c = 0; c < n_cells; ++c) {
+        covered[c] = (char)active[c];
+        double next = thresh[c] * 0.7;  // tooFew (:131-136)
+        if (next < 2) next = 2;
+        floor_thr[c] = lookahead ? std::min(thr[c], (int)next) : thr[c];
+      }
+      const int rc = gpu_pass(active, floor_thr, s, err);
+      if (rc != RGBDFE_OK) return rc;
+    }
+    select_pass(active, thr, cellkp);
     any = false;
     for (int c = 0; c < n_cells; ++c) {
       if (!active[c]) continue;
@@ -362,6 +456,7 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
                           const std::function<int()>& enqueue_more, std::vector<int>* order_out) {
   // KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31), then the stable regroup by level (orb.cpp:
   // !sortedByLevel branch); `order` = the surviving input positions in output order
+  const double tc0 = timing.on ? orb_now_us() : 0;
   std::vector<int> order;
   order.reserve(kps.size());
   int nlevels = 1;
@@ -410,7 +505,12 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
     const int rc = enqueue_more();
     if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(s); err = "enqueue after compute failed"; return rc; }
   }
+  const double tc1 = timing.on ? orb_now_us() : 0;
   ORB_HIP(hipStreamSynchronize(s));
+  if (timing.on) {
+    timing.us[7] += tc1 - tc0;
+    timing.us[8] += orb_now_us() - tc1;
+  }
   if (desc_stage != desc.data()) memcpy(desc.data(), desc_stage, (size_t)n * 32);
   return RGBDFE_OK;
 }

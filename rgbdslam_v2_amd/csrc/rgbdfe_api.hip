@@ -1077,6 +1077,8 @@ int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
 // per-frame feature path
 // ---------------------------------------------------------------------------------------------
 static void ensure_detector(rgbdfe_ctx* ctx) {
+  static const bool lookahead_env = !(getenv("RGBDFE_DETECT_LOOKAHEAD") && atoi(getenv("RGBDFE_DETECT_LOOKAHEAD")) == 0);
+  ctx->orb.lookahead = lookahead_env;  // A/B switch: one device pass per adjuster iteration when 0
   if (ctx->orb_max_keypoints == 0) {
     ctx->orb_max_keypoints = 600;  // parameter_server.cpp:83
     ctx->orb.reset_detector(600, 3, 5);  // detector_grid_resolution 3, adjuster_max_iterations 5 (:87,:89)
@@ -1163,6 +1165,16 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   OrbWorkspace& orb = ctx->orb;
   const int max_kp = ctx->orb_max_keypoints;
   std::string err;
+  static const bool timing_env = getenv("RGBDFE_DETECT_TIMING") && atoi(getenv("RGBDFE_DETECT_TIMING")) != 0;
+  orb.timing.on = timing_env;
+  const bool tm = timing_env;
+  double tq = tm ? orb_now_us() : 0;
+  auto lap = [&](int slot) {
+    if (!tm) return;
+    const double now = orb_now_us();
+    orb.timing.us[slot] += now - tq;
+    tq = now;
+  };
   int rc = orb.prepare(cols, rows, true, err);
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
   // hasNonZero(sub_mask) per cell (feature_adjuster.cpp:175-183)
@@ -1179,11 +1191,28 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
       orb.cell_mask_nonzero[c] = nz;
     }
   // the depth image stays on the host: removeDepthless and projectTo3D look at one pixel per keypoint
+  lap(0);
   rc = orb.upload_and_build(gray, mask, ctx->stream, err);
+  lap(1);
   std::vector<KpOut> kps;
+  const double pass_before = tm ? orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] : 0;
   if (rc == RGBDFE_OK) rc = orb.grid_detect(kps, ctx->stream, err);  // node.cpp:160
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  if (tm) {  // grid_detect minus its detection passes = the adjuster logic + the per-cell merge
+    const double now = orb_now_us();
+    orb.timing.us[5] += (now - tq) - (orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] - pass_before);
+    tq = now;
+  }
   {  // removeDepthless (node.cpp:67-97, :186)
+    // one scattered read of the 1.2 MB depth image per keypoint: issue them all before the first is needed (the loop
+    // below otherwise pays a cache miss per keypoint, ~100 us per frame)
+    for (const KpOut& k : kps) {
+      if (!(k.x >= 0 && k.x < (float)cols && k.y >= 0 && k.y < (float)rows)) continue;
+      int r = (int)roundf(k.y), c = (int)roundf(k.x);
+      r = r >= rows ? rows - 1 : r;
+      c = c >= cols ? cols - 1 : c;
+      __builtin_prefetch(depth + (size_t)r * cols + c, 0, 1);
+    }
     size_t m = 0;
     for (const KpOut& k : kps) {
       if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
@@ -1196,14 +1225,17 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
     kps.resize(m);
   }
   if ((int)kps.size() > max_kp) {  // retainBest(max_keypoints) + resize (node.cpp:188-191)
-    std::vector<int> idx(kps.size());
-    for (size_t i = 0; i < kps.size(); ++i) idx[i] = (int)i;
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return kps[a].response > kps[b].response; });
-    std::vector<char> keep(kps.size(), 0);
-    for (int i = 0; i < max_kp; ++i) keep[idx[i]] = 1;
+    // the max_kp first of the order (response descending, position ascending), in their original order: a selection
+    std::vector<std::pair<float, int>> r(kps.size());
+    for (size_t i = 0; i < kps.size(); ++i) r[i] = std::make_pair(kps[i].response, (int)i);
+    auto before = [](const std::pair<float, int>& a, const std::pair<float, int>& b) {
+      return a.first > b.first || (a.first == b.first && a.second < b.second);
+    };
+    std::nth_element(r.begin(), r.begin() + (max_kp - 1), r.end(), before);
+    const std::pair<float, int> cut = r[(size_t)max_kp - 1];
     size_t m = 0;
     for (size_t i = 0; i < kps.size(); ++i)
-      if (keep[i]) kps[m++] = kps[i];
+      if (!before(cut, std::make_pair(kps[i].response, (int)i))) kps[m++] = kps[i];
     kps.resize(m);
   }
   // cv::ORB::compute (node.cpp:202) drops border keypoints and regroups the rest by octave, so projectTo3D (node.cpp:210)
@@ -1242,8 +1274,10 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
       return RGBDFE_ERR_HIP;
     return RGBDFE_OK;
   };
+  lap(6);
   rc = orb.compute(kps, desc, ctx->stream, err, enqueue_project);
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  if (tm) tq = orb_now_us();  // compute() books its own two slots
   const int n = (int)kps.size();
   *n_out = 0;
   if (n > 0) {
@@ -1253,6 +1287,8 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   kp_to_abi(kps, keypoints);
   if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());
   *n_out = n;
+  lap(9);
+  if (tm) orb.timing.frames++;
   return RGBDFE_OK;
 }
 
