@@ -140,6 +140,19 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
   v16f czero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) czero[r] = 0.f;
+  // The pair's last tile is ragged (rows >= nt_search do not take part: at least the node's last row, features.cpp:174):
+  // its row term is kNone for those rows, so their accumulator elements can never be a minimum -- the exclusion costs
+  // nothing in the epilogue, the ragged tile just starts from another C vector (3e38 + a dot product of at most 256 in
+  // magnitude stays 3e38).
+  v16f crow_ragged;
+  {
+    const uint32_t rag0 = (nt_search >> 5) << 5;  // first row of the ragged tile (no ragged tile when nt_search % 32 == 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t row = rag0 + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
+      crow_ragged[r] = row < nt_search ? crow[r] : kNone;
+    }
+  }
 
   float best[kQT];
 #pragma unroll
@@ -170,43 +183,38 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
       nxt[i] = ts[(size_t)tl * 256u + threadIdx.x];
     }
     const uint4* __restrict__ buf = lds[st & 1u];
+    // one train tile against this wave's query tiles; CROW = the row term (C operand in mode 1, added after in mode 2)
+    auto do_tile = [&](int i, uint32_t tile, const v16f& CROW) {
+      v8i a[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = as_operand(buf[i * 256 + s * 64 + lane]);
+      const float base = (float)(tile * 32u) * kRowUnit;
+      // both query tiles' MFMA chains are issued before the first epilogue: the matrix pipe works on tile 1 while
+      // the VALU reduces tile 0
+      v16f acc[kQT];
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], bq[t][0], MODE == 1 ? CROW : czero, 4, 4, 0, 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], bq[t][1], acc[t], 4, 4, 0, 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], bq[t][2], acc[t], 4, 4, 0, 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], bq[t][3], acc[t], 4, 4, 0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) {
+        if (MODE != 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += CROW[r];
+        }
+        const float m = min16(acc[t]);
+        best[t] = fminf(best[t], m + base);  // kNone + base stays huge
+      }
+    };
 #pragma unroll
     for (int i = 0; i < kStage; ++i) {
       const uint32_t tile = tile0 + st * kStage + (uint32_t)i;
       if (tile < tile1) {  // block-uniform
-        v8i a[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = as_operand(buf[i * 256 + s * 64 + lane]);
-        const uint32_t row0 = tile * 32u;
-        const float base = (float)row0 * kRowUnit;
-        const bool ragged = row0 + 32u > nt_search;  // rows >= nt_search of the pair's last tile do not take part
-        // both query tiles' MFMA chains are issued before the first epilogue: the matrix pipe works on tile 1 while
-        // the VALU reduces tile 0
-        v16f acc[kQT];
-#pragma unroll
-        for (int t = 0; t < kQT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], bq[t][0], MODE == 1 ? crow : czero, 4, 4, 0, 0,
-                                                                   0, 0);
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], bq[t][1], acc[t], 4, 4, 0, 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], bq[t][2], acc[t], 4, 4, 0, 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], bq[t][3], acc[t], 4, 4, 0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < kQT; ++t) {
-          if (MODE != 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] += crow[r];
-          }
-          if (ragged) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
-              acc[t][r] = row < nt_search ? acc[t][r] : kNone;
-            }
-          }
-          const float m = min16(acc[t]);
-          best[t] = fminf(best[t], m + base);  // kNone + base stays huge
-        }
+        if (tile * 32u + 32u > nt_search) do_tile(i, tile, crow_ragged);  // block-uniform: the pair's last tile only
+        else do_tile(i, tile, crow);
       }
     }
 #pragma unroll

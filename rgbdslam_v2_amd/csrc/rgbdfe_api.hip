@@ -95,8 +95,11 @@ struct rgbdfe_ctx {
   // staging, so that batch k+1's Hamming kernel fills the SIMDs that batch k's RANSAC tail
   // leaves idle.  The pair lists go through a ring of pinned buffers so the host can prepare
   // batch k+1 while batch k runs.
-  static constexpr int kLanes = 2;
-  static constexpr int kRing = 4;
+#ifndef RGBDFE_LANES
+#define RGBDFE_LANES 2  // measured on the bench: 2 lanes 1.50 ms per step, 3 lanes 1.71, 4 lanes 1.50
+#endif
+  static constexpr int kLanes = RGBDFE_LANES;
+  static constexpr int kRing = 2 * RGBDFE_LANES;
   struct Lane {
     hipStream_t stream = nullptr;
     IterRec* d_recs = nullptr;              // record / replay: per pair x RANSAC iteration outcome records
