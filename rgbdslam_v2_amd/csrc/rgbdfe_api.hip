@@ -314,7 +314,8 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     if (lane.d_recs) (void)hipFree(lane.d_recs);
     lane.d_recs = nullptr;
     lane.recs_capacity = 0;
-    if (hipMalloc((void**)&lane.d_recs, need_recs * sizeof(IterRec)) == hipSuccess) lane.recs_capacity = need_recs;
+    if (hipMalloc((void**)&lane.d_recs, need_recs * (sizeof(IterRec) + sizeof(IterSum))) == hipSuccess)  // records + summaries
+      lane.recs_capacity = need_recs;
     else latency = false;
   }
   if (latency && !lane.d_walk &&

@@ -66,6 +66,14 @@ struct IterRec {
   int32_t rn;
   int32_t pad;
 };
+// what the in-order walk needs of an iteration (refined_matches.size(), refined_error): a dense array next to the
+// records, so that the walk reads -- and a batch of junk iterations writes, lane = iteration -- whole cache lines instead
+// of one 104-byte record per lane (a junk iteration leaves only {1e6, 0} here and no IterRec at all)
+struct IterSum {
+  double rerr;
+  int32_t rn;
+  int32_t pad;
+};
 // what pair_prep_kernel leaves for every select+RANSAC wave of a pair: the selected matches' 3-D points as 7-word
 // records (from.xyz, to.xyz, 1/(from.z*to.z)) and the facts about them the waves need
 struct alignas(16) PairPrep {
@@ -92,6 +100,7 @@ struct WalkState {
 // parameters of one record / replay phase (select_ransac.hip)
 struct RecordPlan {
   IterRec* recs = nullptr;   // [pair][iteration]
+  IterSum* sums = nullptr;   // [pair][iteration], behind the records in the same allocation
   WalkState* walk = nullptr; // [pair]
   uint32_t n_chunks = 1;     // recording waves per pair in this phase
   int chunk_iters = 0;       // iterations per recording wave

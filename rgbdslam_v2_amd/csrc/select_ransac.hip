@@ -42,6 +42,26 @@ namespace rgbdfe {
 constexpr int kWave = 64;
 constexpr int kRounds = RGBDFE_MAX_MATCHES / kWave;  // 5
 
+// Every kernel of this file runs ONE wave per workgroup: a barrier orders the wave's own LDS traffic (lanes exchange data
+// through LDS).  __syncthreads() also drains the vector-memory queue (s_waitcnt vmcnt(0) before s_barrier); an LDS-only
+// variant (RGBDFE_LDS_ONLY_SYNC) was measured and changes nothing -- a wave's wall time is set by the SIMD's issue slots
+// it shares with two other waves, not by its own waits -- so the plain barrier stays.
+#ifdef RGBDFE_LDS_ONLY_SYNC
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wave_sync_global() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+#else
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+__device__ __forceinline__ void wave_sync_global() { __syncthreads(); }
+#endif
+
 // RANSAC iterations refined side by side: the refits of a round share ONE recurrence loop (9 lanes per
 // slot, 7 x 9 = 63 lanes) and ONE batched SVD (lane = slot).
 constexpr int kSlots = 7;
@@ -363,7 +383,9 @@ __device__ __forceinline__ bool has_nan12(const float* R, const float* t) {
 // Optional phase timers (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase are
 // written over the head of all_q of each result.  Never enabled in the product build.
 #ifdef RGBDFE_PROFILE_PHASES
-#define PH_DECL uint64_t ph_t0 = __builtin_readcyclecounter(); uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// totals over the recording waves of all launches since the last reset (slot 16 = waves); rgbdfe_debug_phase_totals
+__device__ unsigned long long g_phase_totals[24];
+#define PH_DECL uint64_t ph_t0 = __builtin_readcyclecounter(); uint64_t ph[22] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PH_MARK(i) { uint64_t ph_t1 = __builtin_readcyclecounter(); ph[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
 #define PH_COUNT(i) { ph[i] += 1; }
 #define PH_ADDX(i, v) { ph[i] += (uint64_t)(v); }
@@ -501,6 +523,8 @@ constexpr int kEcRegion = kSlots * kEcRow;      // doubles per wave
 // Passes 1 and 2 of computeInliersAndError: the inlier set (mask, n_inl) and the inliers' errors (ec_row).
 // n_inl == 0 when fewer than `need` candidates survive pass 1 (the caller rejects the hypothesis whatever the
 // exact numbers are).
+// (Summing the errors on the spot for short candidate lists -- a scalar v_readlane / v_add_f64 chain over the inlier
+// lanes -- was measured: slower on every workload, the chains of a round add up instead of running lane = slot.)
 __device__ __forceinline__ void score_passes(const float* R, const float* tr, int n_all, uint32_t need,
                                              const RansacConst& rc, RansacLds& lds, float pmax,
                                              double* __restrict__ ec_row, uint64_t* mask, int& n_inl PH_ARG) {
@@ -561,7 +585,7 @@ __device__ __forceinline__ void score_passes(const float* R, const float* tr, in
     n_cand += __popcll(cm);
   }
   if (lane < 2 * kRounds) sb.mbits[lane] = 0u;
-  __syncthreads();
+  wave_sync();
   n_inl = 0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) mask[r] = 0ull;
@@ -611,7 +635,7 @@ __device__ __forceinline__ void score_passes(const float* R, const float* tr, in
     }
     n_inl += __popcll(im);
   }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane(sb.mbits[2 * r]);
@@ -619,7 +643,7 @@ __device__ __forceinline__ void score_passes(const float* R, const float* tr, in
     mask[r] = ((uint64_t)hi << 32) | lo;
   }
   PH_ADD(14, n_inl)
-  __syncthreads();
+  wave_sync();
 }
 
 // mean_error += mahal_dist in match order (node.cpp:1006): a strictly sequential double sum per list.  Lane s
@@ -629,7 +653,7 @@ __device__ __forceinline__ void score_passes(const float* R, const float* tr, in
 // per lane (two blocks ahead of the chain: the rows sit in L2), entries behind a list's end are replaced by 0.0
 // (x + 0.0 == x for these non-negative sums), the block goes through LDS, and lane s reads row s back.
 __device__ __forceinline__ double sum_rows(const double* __restrict__ ec_region, RansacLds& lds, int lane, int n_mine,
-                                           int n_max) {
+                                           int n_max PH_ARG) {
   SumStage& st = lds.u.sum;
   // transport role of this lane: entries q = j * 64 + lane of a block, row = q / 32, column = q % 32
   const int col = lane & (kStageBlk - 1);
@@ -644,7 +668,17 @@ __device__ __forceinline__ double sum_rows(const double* __restrict__ ec_region,
   auto fetch = [&](double* g, int b) {
     const int idx = max(min(b, nb - 1), 0) * kStageBlk + col;  // reading ahead of the last block re-reads it
 #pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] = ec_region[min(row[j], kSlots - 1) * kEcRow + idx];
+    // only entries that exist are loaded: the rest of a region is memory nobody has written in this launch (other
+    // slots' rows, the tail of a row) -- touching it costs HBM and TLB misses on cold lines, measured at ~7 us per round
+    for (int j = 0; j < 4; ++j) {
+      g[j] = 0.0;
+      // the element offset is formed HERE (the asm keeps the compiler from hoisting four 64-bit lane addresses to the top
+      // of the kernel, where they were spilled: their reloads from scratch, each followed by s_waitcnt vmcnt(0), made the
+      // four loads of a block four dependent memory round trips -- ~9000 cycles per refinement round)
+      uint32_t off = (uint32_t)(((j * kWave + lane) / kStageBlk) * kEcRow + idx);
+      asm volatile("" : "+v"(off));
+      if (idx < n_row[j]) g[j] = ec_region[off];
+    }
   };
   const double* mine = st.v[min(lane, kSlots - 1)];
   double sum = 0.0;
@@ -653,7 +687,7 @@ __device__ __forceinline__ double sum_rows(const double* __restrict__ ec_region,
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (n_row[j] >= 0) st.v[row[j]][col] = idx < n_row[j] ? g[j] : 0.0;
-    __syncthreads();
+    wave_sync();
     asm volatile("" ::: "memory");  // g is dead: its registers take the block after next
     fetch(g, b + 2);
     asm volatile("" ::: "memory");
@@ -664,11 +698,18 @@ __device__ __forceinline__ double sum_rows(const double* __restrict__ ec_region,
       sum += v.y;
     }
     asm volatile("" : "+v"(sum) :: "memory");
-    __syncthreads();
+    wave_sync();
   };
   double g0[4], g1[4];
+  PH_MARK(20)
+  wave_sync_global();  // the rows were written by this wave's own stores (score_passes, pass 2)
+  PH_MARK(21)
   fetch(g0, 0);
   fetch(g1, 1);
+#ifdef RGBDFE_PROFILE_PHASES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the read-back latency on its own
+  PH_MARK(0)
+#endif
   for (int b = 0; b < nb; b += 2) {
     block(g0, b);
     if (b + 1 < nb) block(g1, b + 1);
@@ -689,7 +730,7 @@ __device__ __forceinline__ void score_hypothesis(const float* R, const float* tr
   score_passes(R, tr, n_all, need, rc, lds, pmax, ec_region, mask, n_inl PH_PASS);
   err = 1e9;
   if ((uint32_t)n_inl < need || n_inl < 3) return;  // err stays 1e9 (node.cpp:1012-1014); rejected anyway when < need
-  const double sum = uniform_f64(sum_rows(ec_region, lds, threadIdx.x, threadIdx.x == 0 ? n_inl : 0, n_inl));
+  const double sum = uniform_f64(sum_rows(ec_region, lds, threadIdx.x, threadIdx.x == 0 ? n_inl : 0, n_inl PH_PASS));
   err = sqrt(sum / (double)n_inl);  // node.cpp:1016-1017
 }
 
@@ -881,7 +922,7 @@ __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__
   const bool single = n <= kTile;
   if (single) {
     for (int j = lane; j < n; j += kWave) s_key[j] = key_of(j);
-    __syncthreads();
+    wave_sync();
   }
   for (int base = 0; base < n; base += kWave) {
     const int i = base + lane;
@@ -891,9 +932,9 @@ __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__
     for (int t0 = 0; t0 < n; t0 += kTile) {
       const int tn = min(kTile, n - t0);
       if (!single) {
-        __syncthreads();
+        wave_sync();
         for (int j = lane; j < tn; j += kWave) s_key[j] = key_of(t0 + j);
-        __syncthreads();
+        wave_sync();
       }
       int j = 0;
       for (; j + 8 <= tn; j += 8) {
@@ -907,7 +948,7 @@ __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__
       s_d[rank] = __float_as_uint(sd[i]);
     }
   }
-  __syncthreads();  // every read of the unsorted list is done
+  wave_sync();  // every read of the unsorted list is done
   for (int m = lane; m < n_all; m += kWave) {
     sq[m] = (uint16_t)(s_qt[m] & 0xFFFFu);
     st[m] = (uint16_t)(s_qt[m] >> 16);
@@ -965,7 +1006,7 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
   // ------------------------------------------------------------------ selection
   sel.cnt[lane] = 0;
   sel.cnt[lane + 64] = 0;
-  __syncthreads();
+  wave_sync();
   for (uint32_t base = 0; base < nq; base += kWave) {
     const uint32_t i = base + lane;
     if (i < nq) {
@@ -973,7 +1014,7 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
       if (hd < 128u) atomicAdd(&sel.cnt[hd], 1u);  // node.cpp:572
     }
   }
-  __syncthreads();
+  wave_sync();
   uint32_t total;
   uint32_t cut_hd;  // bins >= cut_hd start at or beyond max_matches: never selected
   {
@@ -993,11 +1034,11 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) c = min(c, (uint32_t)__shfl_xor(c, off));
     cut_hd = c;
-    __syncthreads();
+    wave_sync();
     sel.cnt[2 * lane] = s0;
     sel.cnt[2 * lane + 1] = s1;
   }
-  __syncthreads();
+  wave_sync();
   n_all = (int)min(total, (uint32_t)max_matches);
   // stable placement: (hd, queryIdx) order == D2's deterministic tie-break
   for (uint32_t base = 0; base < nq; base += kWave) {
@@ -1017,15 +1058,15 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
     const uint32_t cnt_same = __popcll(same);
     uint32_t pos = 0;
     if (valid) pos = sel.cnt[hd] + rank;
-    __syncthreads();
+    wave_sync();
     if (valid && rank == 0) sel.cnt[hd] = pos + cnt_same;
     if (valid && pos < (uint32_t)max_matches) {
       sel.mqt[pos] = i | ((key & 0xFFFFu) << 16);
       sel.mhd[pos] = hd;
     }
-    __syncthreads();
+    wave_sync();
   }
-  __syncthreads();
+  wave_sync();
   } else {
     // ------------------------------------------------------------- selection (SIFT)
     // sift_sort_kernel has left the pair's matches in keepStrongestMatches order (node.cpp:674, D2) at the head of
@@ -1042,7 +1083,7 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
         sel.mhd[m] = __float_as_uint(sd[m]);  // distance bits travel in the hd slot
       }
     }
-    __syncthreads();
+    wave_sync();
   }
 
   // ------------------------------------------------- matched 3-D points -> records
@@ -1205,6 +1246,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   const int k_end = MODE == kRecord ? min(k_begin + my_chunk_iters, recorded_end) : 0;
   if (MODE == kRecord && k_begin >= k_end) return;  // nothing of this chunk is needed (any more)
   IterRec* __restrict__ rec_pair = MODE == kWhole ? nullptr : plan.recs + (size_t)pair * (size_t)rc.ransac_iterations;
+  IterSum* __restrict__ sum_pair = MODE == kWhole ? nullptr : plan.sums + (size_t)pair * (size_t)rc.ransac_iterations;
   const int lane = threadIdx.x;
   const PairWork w = work[pair];
   rgbdfe_match_result* __restrict__ out = results + pair;
@@ -1228,7 +1270,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       const int v = i * kWave + lane;
       if (v < kVec) dst[v] = src[v];
     }
-    __syncthreads();
+    wave_sync();
   };
   // no RANSAC for this pair (node.cpp:1087, :1130): a recording wave has nothing to record
   if (MODE == kRecord && !(n_all > rc.min_matches && n_all >= 4)) return;
@@ -1377,12 +1419,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
             n_sum_max = max(n_sum_max, n_inl);
           }
         }
-        __syncthreads();
+        wave_sync();
+        PH_MARK(5)
+        PH_COUNT(18)
+        PH_ADDX(19, n_sum_max)
 #ifdef RGBDFE_FENCE_SUMS  // diagnostics build: drop this CU's L1 before the error rows are read back
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
         // ... then their sequential error sums side by side and the bookkeeping (:1154-1166), lane = slot
-        const double sum_mine = n_sum_max > 0 ? sum_rows(ec_region, lds, lane, cn_mine, n_sum_max) : 0.0;  // wave-uniform
+        const double sum_mine = n_sum_max > 0 ? sum_rows(ec_region, lds, lane, cn_mine, n_sum_max PH_PASS) : 0.0;  // wave-uniform
         const double err_mine = cn_mine > 0 ? sqrt(sum_mine / (double)cn_mine) : 1e9;  // :1016-1017
         PH_MARK(11)
         bool still = false;
@@ -1409,7 +1454,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           }
         }
         const bool any_active = __ballot(still) != 0ull;
-        __syncthreads();
+        wave_sync();
         if (!any_active) return false;
         // ---- refits (:1142): the weighted-mean recurrences of all active slots side by side, then
         // ONE batched 3x3 SVD with lane = slot
@@ -1428,7 +1473,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           n_min = min(n_min, n_g);
           PH_COUNT(7)
         }
-        __syncthreads();
+        wave_sync();
         PH_MARK(8)
         PH_COUNT(9)
         PH_ADD(10, n_max)
@@ -1448,7 +1493,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 #pragma unroll
           for (int i = 0; i < 3; ++i) mine.m2[i] = __shfl(m2, src + 3 * i);
         }
-        __syncthreads();
+        wave_sync();
         {
           float fR[9], ft[3];
           tfc_get_transformation(mine, fR, ft);
@@ -1465,12 +1510,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           }
           PH_MARK(12)
         }
-        __syncthreads();
+        wave_sync();
       return true;
     };
 
     if (lane < kSlots) { lds.slot[lane].active = 0; lds.slot[lane].iter = -1; }
-    __syncthreads();
+    wave_sync();
 
     int it = 0;
     if (MODE == kRecord) {
@@ -1485,18 +1530,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           if (hyp_base < 0 || k_next < hyp_base || k_next >= hyp_base + kWave) {
             gen_hypotheses(k_next);
             const int k = hyp_base + lane;
-            if (k < k_end && !hyp_viable) {
-              IterRec& r = rec_pair[k];
-#pragma unroll
-              for (int i = 0; i < 9; ++i) r.rR[i] = IR[i];
-#pragma unroll
-              for (int i = 0; i < 3; ++i) r.rt[i] = 0.f;
-#pragma unroll
-              for (int q = 0; q < kRounds; ++q) r.rmask[q] = 0ull;
-              r.rerr = 1e6;
-              r.rn = 0;
-              r.pad = 0;
-            }
+            if (k < k_end && !hyp_viable) sum_pair[k] = IterSum{1e6, 0, 0};  // refined_matches stays empty (:1133-1134)
           }
           const int off0 = k_next - hyp_base;
           const uint64_t rest = viable_mask >> off0;
@@ -1522,10 +1556,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
             r.rerr = sl.rerr;
             r.rn = sl.rn;
             r.pad = 0;
+            sum_pair[sl.iter] = IterSum{sl.rerr, sl.rn, 0};
             sl.iter = -1;
           }
         }
-        __syncthreads();
+        wave_sync();
         bool occupied = false;
         for (int g = 0; g < kSlots; ++g) {
           int it_g = __builtin_amdgcn_readfirstlane(lds.slot[g].iter);
@@ -1538,10 +1573,22 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           }
           occupied |= it_g >= 0;
         }
-        __syncthreads();
+        wave_sync();
         if (!occupied) break;
         refine_round();
       }
+#ifdef RGBDFE_PROFILE_PHASES
+      PH_MARK(5)
+      if (lane == 0) {
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_phase_totals[i], (unsigned long long)ph[i]);
+        atomicAdd(&g_phase_totals[16], 1ull);
+        atomicAdd(&g_phase_totals[17], (unsigned long long)(k_end - k_begin));
+        atomicAdd(&g_phase_totals[18], (unsigned long long)ph[18]);
+        atomicAdd(&g_phase_totals[19], (unsigned long long)ph[19]);
+        atomicAdd(&g_phase_totals[20], (unsigned long long)ph[20]);
+        atomicAdd(&g_phase_totals[21], (unsigned long long)ph[21]);
+      }
+#endif
     } else if (MODE == kReplay) {
       // the in-order bookkeeping ran in replay_walk_kernel: adopt its outcome and the record of the best iteration
       const WalkState ws = plan.walk[pair];
@@ -1562,7 +1609,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         b.nan = 0;
         b.err = r.rerr;
       }
-      __syncthreads();
+      wave_sync();
     } else {
     for (; !done && it < rc.ransac_iterations && n_all >= 4;) {  // :1130
       const int k0 = real_iterations;
@@ -1571,7 +1618,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       const int G = (k0 == 0) ? 1 : kSlots;
       // ---- open the window: slot g <- iteration k0 + g; refine all of them to the end
       for (int g = 0; g < G; ++g) open_slot(g, k0 + g);
-      __syncthreads();
+      wave_sync();
       while (refine_round()) {}
       // ---- replay the window in iteration order (:1171-1190)
       for (int g = 0; g < G; ++g) {
@@ -1584,7 +1631,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           valid_iterations++;
           if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
             rmse = (float)refined_error;  // :1182
-            __syncthreads();
+            wave_sync();
             if (lane == 0) {
               Hyp& b = lds.best;
 #pragma unroll
@@ -1597,7 +1644,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
               b.nan = 0;
               b.err = refined_error;
             }
-            __syncthreads();
+            wave_sync();
             best_n = refined_n;
             if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
             if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
@@ -1623,7 +1670,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
     found = (uint32_t)best_n >= thr;  // :1275
   }
-  __syncthreads();
+  wave_sync();
 
   // ------------------------------------------------------------------ result POD
   if (MODE != kRecord && lane == 0) {
@@ -1709,7 +1756,7 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uin
 // of iterations [real_iterations, min(phase_end, state)): one wave per pair, 64 records fetched per step, the sequential
 // decisions on wave-uniform values.  Leaves either "finished" (state < 0) or a tighter bound on the iterations the pair
 // can still need; resumes where the previous phase stopped.
-__global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __restrict__ recs, WalkState* __restrict__ walk,
+__global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __restrict__ sums, WalkState* __restrict__ walk,
                                                             const PairPrep* __restrict__ prep, uint32_t n_pairs,
                                                             const RansacConst rc, int phase_begin, int phase_end,
                                                             int spec_end, int may_speculate) {
@@ -1733,7 +1780,7 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
       min((phase_begin != 0 && spec_end > phase_end && effective_class(walk, pair, n_pairs) == 2) ? spec_end : phase_end, ws.state);
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
-  const IterRec* __restrict__ rec_pair = recs + (size_t)pair * (size_t)(I > 0 ? I : 0);
+  const IterSum* __restrict__ sum_pair = sums + (size_t)pair * (size_t)(I > 0 ? I : 0);
   int it = ws.it, real_iterations = ws.real_iterations, valid_iterations = ws.valid_iterations;
   int best_idx = ws.best_idx, best_n = ws.best_n;
   float rmse = ws.rmse;
@@ -1745,8 +1792,9 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterRec* __res
     int rn_l = 0;
     double rerr_l = 0.0;
     if (lane < G) {
-      rn_l = rec_pair[k0 + lane].rn;
-      rerr_l = rec_pair[k0 + lane].rerr;
+      const IterSum su = sum_pair[k0 + lane];
+      rn_l = su.rn;
+      rerr_l = su.rerr;
     }
     for (int g = 0; g < G; ++g) {
       if (!(it < I)) { done = true; break; }
@@ -1803,6 +1851,7 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
   int begin = 0;
   RecordPlan plan{};
   plan.recs = recs; plan.walk = walk; plan.prep = prep; plan.ec_pool = ec_pool;
+  plan.sums = reinterpret_cast<IterSum*>(recs + (size_t)n_pairs * (size_t)(rc.ransac_iterations > 0 ? rc.ransac_iterations : 0));
   plan.n_phases_total = n_phases;  // a single-phase plan (small batches: full speculation) always pre-screens
   (void)hipMemsetAsync(walk + n_pairs, 0, sizeof(WalkState), stream);  // walk[n_pairs].state: the batch's class-1 pairs
   const int I = rc.ransac_iterations;
@@ -1831,7 +1880,7 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
       hipLaunchKernelGGL(select_ransac_kernel<kRecord>,
                          dim3(8u * ((n_pairs + 7u) / 8u) * (plan.n_chunks + plan.n_chunks_b)), dim3(kWave), 0, stream, work,
                          results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
-    hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, recs, walk, prep, n_pairs, rc, begin,
+    hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, plan.sums, walk, prep, n_pairs, rc, begin,
                        end, cover, (n_phases > 2 && p == 0) ? 1 : 0);
     begin = end;
   }
@@ -2043,7 +2092,7 @@ __device__ void gn_two_view(const uint64_t* mask, const RansacLds& lds, GnShared
     if ((pm >> lane) & 1ull) gs.sel[nsel + (int)lane_rank(pm)] = (uint16_t)(r * kWave + lane);
     nsel += __popcll(pm);
   }
-  __syncthreads();
+  wave_sync();
   for (int s = lane; s < nsel; s += kWave) {
     const int m = gs.sel[s];
     gs.kq[s] = qkp[out->all_q[m]];
@@ -2055,7 +2104,7 @@ __device__ void gn_two_view(const uint64_t* mask, const RansacLds& lds, GnShared
       gs.X[s][0] = (double)(px * 10); gs.X[s][1] = (double)(py * 10); gs.X[s][2] = 10.0;
     }
   }
-  __syncthreads();
+  wave_sync();
   double R1[9], t1[3];
   {
     double Rin[9];
@@ -2183,7 +2232,7 @@ __device__ void gn_two_view(const uint64_t* mask, const RansacLds& lds, GnShared
 #pragma unroll
       for (int i = 0; i < 3; ++i) t1[i] = tn[i];
     }
-    __syncthreads();
+    wave_sync();
   }
   // estimate.cast<float>().inverse() (:169)
   float Rf[9], tf[3];
@@ -2198,7 +2247,7 @@ __device__ void gn_two_view(const uint64_t* mask, const RansacLds& lds, GnShared
     const float v = (Rf[0 * 3 + r] * tf[0] + Rf[1 * 3 + r] * tf[1]) + Rf[2 * 3 + r] * tf[2];
     tr[r] = -v;
   }
-  __syncthreads();
+  wave_sync();
 }
 
 __global__ __launch_bounds__(kWave) void g2o_refine_kernel(const PairWork* __restrict__ work,
@@ -2216,6 +2265,7 @@ __global__ __launch_bounds__(kWave) void g2o_refine_kernel(const PairWork* __res
   const PairPrep* __restrict__ pp = prep + pair;
   const int n_all = pp->n_all;
   if (!(n_all > rc.min_matches)) return;  // getRelativeTransformationTo returned at :1087 (or was never called, :1319)
+  PH_DECL
   uint32_t thr = (uint32_t)rc.min_matches;
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);
   int n_matches = out->n_inl;
@@ -2226,7 +2276,7 @@ __global__ __launch_bounds__(kWave) void g2o_refine_kernel(const PairWork* __res
     float4* __restrict__ dst = reinterpret_cast<float4*>(lds.M);
     constexpr int kVec = RGBDFE_MAX_MATCHES * kRec / 4;
     for (int v = lane; v < kVec; v += kWave) dst[v] = src[v];
-    __syncthreads();
+    wave_sync();
   }
   const float pmax = pp->pmax;
   const float2* __restrict__ qkp = kp_pool + (size_t)w.q_slot * max_kp;
@@ -2247,12 +2297,12 @@ __global__ __launch_bounds__(kWave) void g2o_refine_kernel(const PairWork* __res
   uint64_t inl[kRounds];
   int n_inl;
   double inlier_error;
-  score_hypothesis(R, tr, n_all, 0u, rc, lds, pmax, ec_region, inl, n_inl, inlier_error);  // :1233
+  score_hypothesis(R, tr, n_all, 0u, rc, lds, pmax, ec_region, inl, n_inl, inlier_error PH_PASS);  // :1233
   bool adopt = false;
   if (n_inl >= n_matches || ((uint32_t)n_inl >= thr && inlier_error < (double)rmse)) {  // :1239
     if (n_inl > n_matches) {                                                             // :1241
       gn_two_view(inl, lds, gs, out, qkp, tkp, rc.g2o_iterations, wz, R, tr);             // :1243
-      score_hypothesis(R, tr, n_all, 0u, rc, lds, pmax, ec_region, inl, n_inl, inlier_error);  // :1244
+      score_hypothesis(R, tr, n_all, 0u, rc, lds, pmax, ec_region, inl, n_inl, inlier_error PH_PASS);  // :1244
     }
     adopt = n_inl >= n_matches;  // :1252
   }
@@ -2284,3 +2334,13 @@ void launch_g2o_refine(const PairWork* work, rgbdfe_match_result* results, uint3
 size_t select_ransac_ec_region_bytes() { return sizeof(double) * (size_t)kEcRegion; }
 
 }  // namespace rgbdfe
+
+#ifdef RGBDFE_PROFILE_PHASES
+// diagnostics build only (librgbdfe_prof.so): wall cycles per phase summed over the recording waves
+extern "C" int rgbdfe_debug_phase_totals(unsigned long long* out20, int reset) {
+  unsigned long long zero[24] = {0};
+  if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(rgbdfe::g_phase_totals), sizeof(zero)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_phase_totals), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
