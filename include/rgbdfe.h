@@ -384,6 +384,16 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
                            int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
                            double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
                            float* xyz1, int32_t* n_out);
+/* A run of frames through the same detector state, in order: the same keypoints, descriptors and points as n_frames
+ * calls of rgbdfe_detect_describe (the per-cell thresholds carry over from frame to frame, feature_adjuster.cpp:185-224),
+ * with frame k+1's upload and pyramid overlapped with frame k's detection.  For offline runs (bag files, OpenNIListener
+ * in "batch_processing" mode).  mask may be NULL (no masks) or hold NULL entries; out_stride >= the configured
+ * max_keypoints: frame f's outputs start at row f * out_stride of keypoints / descriptors (32 B rows) / xyz1 (4 floats),
+ * n_out[f] of them. */
+int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray,
+                                 const uint8_t* const* mask, const float* const* depth, int32_t rows, int32_t cols,
+                                 double fx, double fy, double cx, double cy, double depth_scaling, int32_t out_stride,
+                                 rgbdfe_keypoint* keypoints, uint8_t* descriptors, float* xyz1, int32_t* n_out);
 /* the point-cloud constructor's feature path (see rgbdfe_project_to_3d_cloud above) */
 int rgbdfe_detect_describe_cloud(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* cloud,
                                  int32_t rows, int32_t cols, double maximum_depth, rgbdfe_keypoint* keypoints,

@@ -19,7 +19,15 @@ struct OrbWorkspace {
   void release();
   void reset_detector(int max_keypoints, int grid_res, int max_iters);
   int prepare(int cols, int rows, bool use_grid, std::string& err);
-  int upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err);
+  // set = 0 / 1: into that image / pyramid set (ensure_alt allocates set 1; use_set makes a set the current one, the one
+  // the detection and description kernels read); -1 = the current set.  rgbdfe_detect_describe_batch uploads frame k+1
+  // into the other set, from a helper thread on another stream, while frame k is being detected.  Reads only geometry
+  // that is constant between two prepare() calls: safe beside a detection running on the current set.
+  int upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set = -1);
+  int ensure_alt(std::string& err);
+  void use_set(int set);
+  // called once, by the next gpu_pass, after its work is enqueued and before the host waits for it
+  std::function<int()> before_wait;
   // A detection pass = gpu_pass (FAST + NMS + Harris + angle for every corner at the cells' thresholds, one round trip)
   // + select_pass (orb.cpp computeKeyPoints' per-level selections on the host).  select_pass may ask for HIGHER thresholds
   // than the gpu_pass ran with: the corners at threshold t are exactly the corners at any floor f <= t whose FAST score
@@ -68,6 +76,9 @@ struct OrbWorkspace {
   float* h_xyz_in = nullptr; float* h_xyz_out = nullptr; int32_t* h_n = nullptr;
   const RawKp* pass_raw = nullptr;   // the latest gpu_pass: its corners (h_raw or pass_raw_big) ...
   std::vector<RawKp> pass_raw_big;
+  uint8_t* pool_set[2] = {nullptr, nullptr}; uint8_t* blur_set[2] = {nullptr, nullptr};
+  uint8_t* himg_set[2] = {nullptr, nullptr};
+  size_t blur_bytes = 0;
   uint8_t* h_img = nullptr;  // gray + mask staging (2 x W x H): the caller's pageable images go through it in chunks
   // RGBDFE_DETECT_TIMING=1: host wall clock per phase of rgbdfe_detect_describe, printed when the workspace is released
   struct Timing {

@@ -104,11 +104,17 @@ void OrbWorkspace::release() {
     timing.frames = 0;
   }
   auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  fr(d_pool); fr(d_score); fr(d_blur); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr);
+  // d_pool / d_blur / h_img alias one of the two sets
+  for (int i = 0; i < 2; ++i) {
+    fr(pool_set[i]); fr(blur_set[i]);
+    if (himg_set[i]) { (void)hipHostFree(himg_set[i]); himg_set[i] = nullptr; }
+  }
+  d_pool = nullptr; d_blur = nullptr; h_img = nullptr;
+  fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr);
   fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_kpxy);
   fr(d_kept); fr(d_xyz); fr(d_n);
   auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n); frh(h_img);
+  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n);
   d_active = nullptr;  // lives inside d_thr
   W = H = 0;
 }
@@ -213,6 +219,9 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipDeviceSynchronize());  // NULL-stream memset vs the context's non-blocking stream
   ORB_HIP(hipMalloc((void**)&d_score, score_off + 256));
   ORB_HIP(hipMalloc((void**)&d_blur, blur_off + 256));
+  blur_bytes = blur_off + 256;
+  pool_set[0] = d_pool;
+  blur_set[0] = d_blur;
   ORB_HIP(hipMalloc((void**)&d_cell_imgs, sizeof(ImgDesc) * cell_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_frame_imgs, sizeof(ImgDesc) * frame_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_jobs, sizeof(ResizeJob) * jobs.size()));
@@ -239,6 +248,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipHostMalloc((void**)&h_xyz_out, sizeof(float) * 4 * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_n, sizeof(int32_t), hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_img, (size_t)2 * W * H, hipHostMallocDefault));
+  himg_set[0] = h_img;
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));
@@ -248,7 +258,26 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
 }
 
 // uploads the frame and builds every pyramid (cells + whole frame) and the blurred frame levels
-int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err) {
+int OrbWorkspace::ensure_alt(std::string& err) {
+  if (pool_set[1]) return RGBDFE_OK;
+  ORB_HIP(hipMalloc((void**)&pool_set[1], pool_bytes));
+  ORB_HIP(hipMemset(pool_set[1], 0, pool_bytes));
+  ORB_HIP(hipMalloc((void**)&blur_set[1], blur_bytes));
+  ORB_HIP(hipHostMalloc((void**)&himg_set[1], (size_t)2 * W * H, hipHostMallocDefault));
+  ORB_HIP(hipDeviceSynchronize());
+  return RGBDFE_OK;
+}
+
+void OrbWorkspace::use_set(int set) {
+  d_pool = pool_set[set];
+  d_blur = blur_set[set];
+  h_img = himg_set[set];
+}
+
+int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set) {
+  uint8_t* const d_pool = set < 0 ? this->d_pool : pool_set[set];  // shadow the members: the code below is set-agnostic
+  uint8_t* const d_blur = set < 0 ? this->d_blur : blur_set[set];
+  uint8_t* const h_img = set < 0 ? this->h_img : himg_set[set];
   // The caller's images are pageable: a plain hipMemcpyAsync of 0.6 MB stalls the host ~150 us while the runtime stages
   // it.  Own staging instead: memcpy a chunk into pinned memory, start its DMA, memcpy the next chunk meanwhile.
   {
@@ -302,6 +331,12 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
   ORB_HIP(hipGetLastError());
   ORB_HIP(hipMemcpyAsync(h_totals, d_img_total, sizeof(int) * n_imgs, hipMemcpyDeviceToHost, s));
   ORB_HIP(hipMemcpyAsync(h_raw, d_kps, sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
+  if (before_wait) {  // the caller's own host work (the next frame's upload) rides on this pass's device time
+    std::function<int()> f = std::move(before_wait);
+    before_wait = nullptr;
+    const int rc = f();
+    if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(s); err = "prefetch of the next frame failed"; return rc; }
+  }
   const double tp1 = timing.on ? orb_now_us() : 0;
   ORB_HIP(hipStreamSynchronize(s));
   const double tp2 = timing.on ? orb_now_us() : 0;

@@ -13,7 +13,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -89,6 +92,8 @@ struct rgbdfe_ctx {
   uint32_t* d_desc4 = nullptr; // max_nodes x max_kp x 32 dwords: every descriptor bit as an fp4 (+-1) operand nibble, in
                                // MFMA fragment order per tile of 32 rows (hamming_mfma.hip)
   float* d_kp2d = nullptr;     // max_nodes x max_kp x 2: KeyPoint.pt (allocated with the first rgbdfe_upload_node_keypoints)
+  hipStream_t orb_upload_stream = nullptr;  // rgbdfe_detect_describe_batch: uploads of frame k+1 beside frame k
+  hipEvent_t orb_upload_done[2] = {nullptr, nullptr};
   bool sift_fast = true;       // sift_match.hip's float keys where a pair qualifies (RGBDFE_SIFT_FAST_KEYS=0: never)
   int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
   // Batches run on kLanes internal HIP streams ("lanes"), each with its own keys / results
@@ -651,6 +656,8 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   if (ctx->d_desc4) (void)hipFree(ctx->d_desc4);
   if (ctx->d_kp2d) (void)hipFree(ctx->d_kp2d);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  for (hipEvent_t e : ctx->orb_upload_done) if (e) (void)hipEventDestroy(e);
+  if (ctx->orb_upload_stream) (void)hipStreamDestroy(ctx->orb_upload_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1157,15 +1164,13 @@ int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32
   return RGBDFE_OK;
 }
 
-int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
-                           int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
-                           double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
-                           float* xyz1, int32_t* n_out) {
-  if (!ctx || !gray || !depth || rows < 1 || cols < 1 || !keypoints || !descriptors || !xyz1 || !n_out)
-    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
-  std::lock_guard<std::mutex> g(ctx->mu);
-  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
-  ensure_detector(ctx);
+// One frame of Node::Node's feature path; the caller holds the lock.  uploaded: the frame's images and pyramid are already
+// in the workspace's current set (rgbdfe_detect_describe_batch); prefetch: host work to do while the first detection pass
+// of this frame runs on the device (the next frame's upload).
+static int detect_describe_frame(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
+                                 int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                                 double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
+                                 float* xyz1, int32_t* n_out, bool uploaded, const std::function<int()>& prefetch) {
   OrbWorkspace& orb = ctx->orb;
   const int max_kp = ctx->orb_max_keypoints;
   std::string err;
@@ -1196,11 +1201,18 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
     }
   // the depth image stays on the host: removeDepthless and projectTo3D look at one pixel per keypoint
   lap(0);
-  rc = orb.upload_and_build(gray, mask, ctx->stream, err);
+  if (!uploaded) rc = orb.upload_and_build(gray, mask, ctx->stream, err);
   lap(1);
+  orb.before_wait = prefetch;
   std::vector<KpOut> kps;
   const double pass_before = tm ? orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] : 0;
   if (rc == RGBDFE_OK) rc = orb.grid_detect(kps, ctx->stream, err);  // node.cpp:160
+  if (rc == RGBDFE_OK && orb.before_wait) {  // (cannot happen: a frame has at least one pass) -- never lose the prefetch
+    std::function<int()> f = std::move(orb.before_wait);
+    orb.before_wait = nullptr;
+    rc = f();
+  }
+  orb.before_wait = nullptr;
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
   if (tm) {  // grid_detect minus its detection passes = the adjuster logic + the per-cell merge
     const double now = orb_now_us();
@@ -1293,6 +1305,108 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   *n_out = n;
   lap(9);
   if (tm) orb.timing.frames++;
+  return RGBDFE_OK;
+}
+
+int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
+                           int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                           double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
+                           float* xyz1, int32_t* n_out) {
+  if (!ctx || !gray || !depth || rows < 1 || cols < 1 || !keypoints || !descriptors || !xyz1 || !n_out)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  ensure_detector(ctx);
+  return detect_describe_frame(ctx, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling, keypoints, descriptors,
+                               xyz1, n_out, false, nullptr);
+}
+
+// A run of frames through the same detector state, in order (the per-cell thresholds of frame k+1 start from frame k's,
+// as in a sequence of single calls -- same keypoints, bit for bit).  What the batch adds is overlap: frame k+1's images
+// are staged, uploaded and turned into their pyramid (a second image set, a second stream) while the device runs frame
+// k's detection pass and the host would otherwise sit in hipStreamSynchronize.  Outputs: frame f's keypoints /
+// descriptors / points at offset f * out_stride (rows), n_out[f] of them.
+int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
+                                 const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                 double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
+                                 uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+  if (!ctx || n_frames < 0 || (n_frames > 0 && (!gray || !depth || !keypoints || !descriptors || !xyz1 || !n_out)) ||
+      rows < 1 || cols < 1)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  ensure_detector(ctx);
+  if (n_frames > 0 && out_stride < ctx->orb_max_keypoints)
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "out_stride must be at least the configured max_keypoints");
+  for (int32_t f = 0; f < n_frames; ++f)
+    if (!gray[f] || !depth[f]) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "null frame");
+  if (n_frames == 0) return RGBDFE_OK;
+  OrbWorkspace& orb = ctx->orb;
+  std::string err;
+  int rc = orb.prepare(cols, rows, true, err);
+  if (rc == RGBDFE_OK) rc = orb.ensure_alt(err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  if (!ctx->orb_upload_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_upload_done[i], hipEventDisableTiming));
+  }
+  hipStream_t up = ctx->orb_upload_stream;
+  // Frame f lives in image set f & 1.  The helper thread stages, uploads and builds the pyramid of frame f as soon as
+  // the frame that used the set before (f - 2) is finished; the calling thread detects frame f once its upload has been
+  // enqueued (the stream waits for the event).  Host work of the two threads and device work of the two streams overlap.
+  std::mutex m;
+  std::condition_variable cv;
+  int uploaded = 0, finished = 0, up_rc = RGBDFE_OK;  // frames enqueued by the helper / completed by the caller
+  bool stop = false;
+  std::string up_err;
+  const int dev = ctx->cfg.device_id;
+  std::thread helper([&]() {
+    if (hipSetDevice(dev) != hipSuccess) {
+      std::lock_guard<std::mutex> l(m);
+      up_rc = RGBDFE_ERR_HIP; up_err = "hipSetDevice in the upload thread";
+      cv.notify_all();
+      return;
+    }
+    for (int32_t f = 0; f < n_frames; ++f) {
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return stop || finished >= f - 1; });  // frame f - 2 done: its set is free
+        if (stop) return;
+      }
+      std::string e2;
+      int r = orb.upload_and_build(gray[f], mask ? mask[f] : nullptr, up, e2, f & 1);
+      if (r == RGBDFE_OK && hipEventRecord(ctx->orb_upload_done[f & 1], up) != hipSuccess) { r = RGBDFE_ERR_HIP; e2 = "hipEventRecord"; }
+      std::lock_guard<std::mutex> l(m);
+      if (r != RGBDFE_OK) { up_rc = r; up_err = e2; cv.notify_all(); return; }
+      uploaded = f + 1;
+      cv.notify_all();
+    }
+  });
+  for (int32_t f = 0; f < n_frames && rc == RGBDFE_OK; ++f) {
+    {
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [&] { return up_rc != RGBDFE_OK || uploaded > f; });
+      if (up_rc != RGBDFE_OK) { rc = up_rc; err = up_err; break; }
+    }
+    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[f & 1], 0) != hipSuccess) { rc = RGBDFE_ERR_HIP; err = "hipStreamWaitEvent"; break; }
+    orb.use_set(f & 1);
+    rc = detect_describe_frame(ctx, gray[f], mask ? mask[f] : nullptr, depth[f], rows, cols, fx, fy, cx, cy, depth_scaling,
+                               keypoints + (size_t)f * out_stride, descriptors + (size_t)f * out_stride * 32,
+                               xyz1 + (size_t)f * out_stride * 4, n_out + f, true, nullptr);
+    if (rc != RGBDFE_OK) err.clear();  // detect_describe_frame has reported through fail()
+    std::lock_guard<std::mutex> l(m);
+    finished = f + 1;
+    cv.notify_all();
+  }
+  {
+    std::lock_guard<std::mutex> l(m);
+    stop = true;
+    cv.notify_all();
+  }
+  helper.join();
+  (void)hipStreamSynchronize(up);
+  orb.use_set(0);
+  if (rc != RGBDFE_OK) return err.empty() ? rc : fail(ctx, rc, err);
   return RGBDFE_OK;
 }
 
@@ -2469,6 +2583,16 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe(c, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling,
                                                         keypoints, descriptors, xyz1, n_out));
+}
+
+int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
+                                 const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                 double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
+                                 uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe_batch(c, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy,
+                                                              depth_scaling, out_stride, keypoints, descriptors, xyz1,
+                                                              n_out));
 }
 
 int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* out_hd, int32_t* out_idx) {

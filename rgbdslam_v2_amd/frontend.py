@@ -264,6 +264,34 @@ class FrontEnd:
             xyz.ctypes.data, C.byref(n)))
         return kp[: n.value].copy(), desc[: n.value].copy(), xyz[: n.value].copy()
 
+    def detect_describe_batch(self, grays, masks, depths, fx, fy, cx, cy, depth_scaling=1.0):
+        """A run of frames through the same detector state, in order (rgbdfe_detect_describe_batch): the results of
+        calling detect_describe frame by frame, with frame k+1's upload overlapped with frame k's detection.
+        Returns a list of (keypoints, descriptors, xyz1) per frame."""
+        n = len(grays)
+        if n == 0:
+            return []
+        g = [np.ascontiguousarray(x, np.uint8) for x in grays]
+        d = [np.ascontiguousarray(x, np.float32) for x in depths]
+        m = [None if (masks is None or masks[i] is None) else np.ascontiguousarray(masks[i], np.uint8) for i in range(n)]
+        rows, cols = g[0].shape
+        for a in g + d + [x for x in m if x is not None]:
+            if a.shape != (rows, cols):
+                raise ValueError("all frames of a batch share one size")
+        cap = getattr(self, "_max_keypoints", 600)
+        kp = np.zeros((n, cap), _lib.KEYPOINT_DTYPE)
+        desc = np.zeros((n, cap, 32), np.uint8)
+        xyz = np.zeros((n, cap, 4), np.float32)
+        cnt = np.zeros(n, np.int32)
+        vp = C.c_void_p * n
+        pg = vp(*[x.ctypes.data for x in g])
+        pd = vp(*[x.ctypes.data for x in d])
+        pm = vp(*[None if x is None else x.ctypes.data for x in m])
+        self._check(self._L.rgbdfe_detect_describe_batch(
+            self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
+            depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data))
+        return [(kp[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy(), xyz[f, : cnt[f]].copy()) for f in range(n)]
+
     def orb_detect(self, gray, mask, fast_threshold, capacity=60000):
         """cv::ORB::create(10000,1.2,8,15,0,2,HARRIS,31,thr)->detect(gray, kps, mask) (feature_adjuster.cpp:94)."""
         gray = np.ascontiguousarray(gray, np.uint8)

@@ -180,3 +180,38 @@ def test_orb_detect_full_resolution_levels():
     assert_kps_equal(k1, k2)
     assert np.array_equal(d1, d2)
     fe.close()
+
+
+def test_detect_describe_batch_equals_frame_by_frame(frames):
+    """rgbdfe_detect_describe_batch: frame k+1's upload and pyramid overlap frame k's detection (second image set, second
+    stream); the detector state carries over as in single calls -- identical keypoints, descriptors, points, thresholds.
+    The run includes a dark frame (several adjuster iterations), a frame without a mask, and a batch of one."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    K = (frames["fx"], frames["fy"], frames["cx"], frames["cy"])
+    grays = [frames["gray"][f] for f in range(4)]
+    grays.insert(2, (frames["gray"][0].astype(np.float32) * 0.3 + 80).astype(np.uint8))
+    depths = [frames["depth"][f] for f in (0, 1, 0, 2, 3)]
+    masks = [np.where(frames["mask"][f] > 0, 255, 0).astype(np.uint8) for f in (0, 1, 0, 2, 3)]
+    masks[3] = None
+    outs = []
+    for mode in ("single", "batch", "batch_then_single"):
+        fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=1024, max_pairs_per_batch=8)
+        fe.detector_configure(max_keypoints=1000)
+        if mode == "single":
+            res = [fe.detect_describe(g, m, d, *K) for g, m, d in zip(grays, masks, depths)]
+        elif mode == "batch":
+            res = fe.detect_describe_batch(grays, masks, depths, *K)
+        else:
+            res = fe.detect_describe_batch(grays[:1], masks[:1], depths[:1], *K)
+            res += fe.detect_describe_batch(grays[1:4], masks[1:4], depths[1:4], *K)
+            res.append(fe.detect_describe(grays[4], masks[4], depths[4], *K))
+        outs.append((res, fe.detector_thresholds().copy()))
+        assert fe.detect_describe_batch([], [], [], *K) == []
+        fe.close()
+    ref, ref_thr = outs[0]
+    assert min(len(r[0]) for r in ref) > 100
+    for res, thr in outs[1:]:
+        assert np.array_equal(thr, ref_thr)
+        for (k1, d1, x1), (k2, d2, x2) in zip(res, ref):
+            assert_kps_equal(k1, k2)
+            assert np.array_equal(d1, d2) and np.array_equal(x1, x2)

@@ -28,6 +28,15 @@ for rep in range(3):
 dt = time.perf_counter() - t0
 out = {"metric": "frames detected+described/sec, 640x480 ORB-1000 (Level B)", "value": round(3 * n_frames / dt, 2),
        "unit": "frames/s", "ms_per_frame": round(dt / (3 * n_frames) * 1e3, 3), "mean_keypoints": tot / (3 * n_frames)}
+K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+grays, depths = list(seq["gray"]), list(seq["depth"])
+fe.detect_describe_batch(grays, masks, depths, *K)
+t0 = time.perf_counter()
+for rep in range(3):
+    fe.detect_describe_batch(grays, masks, depths, *K)
+dtb = time.perf_counter() - t0
+out["batch_api_ms_per_frame"] = round(dtb / (3 * n_frames) * 1e3, 3)
+out["batch_api_frames_per_s"] = round(3 * n_frames / dtb, 2)
 try:
     from oracle import pyorb
     st = pyorb.grid_state(1000)
