@@ -26,6 +26,12 @@ def short(name):
         return "select_ransac"
     if "hamming_mfma_kernel" in name:
         return "hamming_nn"
+    if "sift_top2_fast_kernel" in name or "sift_row_top2_kernel" in name:  # both passes of the dot-product stage
+        return "sift_dot"
+    if "sift_finish_kernel" in name:
+        return "sift_finish"
+    if "sift_sort_kernel" in name:
+        return "sift_sort"
     for k in ("hamming_nn_kernel", "select_ransac_kernel", "project_to_3d_kernel"):
         if k in name:
             return k.replace("_kernel", "")
@@ -48,7 +54,7 @@ for f in find("trace/**/*kernel_stats.csv"):
 for k, e in summary.items():
     if "calls" in e:
         e["avg_ns"] = e["total_ns"] / e["calls"]
-batches = summary.get("hamming_nn", {}).get("calls")
+batches = summary.get("hamming_nn", {}).get("calls") or (summary.get("sift_dot", {}).get("calls", 0) // 2) or None
 if batches:
     for k, e in summary.items():
         if "total_ns" in e:
@@ -62,7 +68,7 @@ for f in find("trace/**/*kernel_trace.csv"):
         k = short(row.get("Kernel_Name", ""))
         if k:
             dur[k].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    nb = len(dur.get("hamming_nn", [])) or None
+    nb = len(dur.get("hamming_nn", [])) or (len(dur.get("sift_dot", [])) // 2) or None
     for k, v in dur.items():
         summary.setdefault(k, {})["trace_avg_ns"] = sum(v) / len(v)
         summary[k]["trace_min_ns"] = min(v)
@@ -90,7 +96,7 @@ for name, pat in (("fetch", "pmc_fetch/**/*counter_collection.csv"),
     acc = pmc(pat)
     for k, ctrs in acc.items():
         for c, vals in ctrs.items():
-            nb = len(acc.get("hamming_nn", {}).get(c, [])) or len(vals)
+            nb = len(acc.get("hamming_nn", {}).get(c, [])) or (len(acc.get("sift_dot", {}).get(c, [])) // 2) or len(vals)
             # per batch: a batch's RANSAC stage may be several dispatches
             summary.setdefault(k, {})[c + "_avg"] = sum(vals) / nb
             summary[k][c + "_n"] = len(vals)
