@@ -273,6 +273,7 @@ def main():
             "WRITE_SIZE of separate rocprofv3 --pmc passes over this workload (static figure, not collected in this run)",
             "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
             "avg_launch_ms": round(dom_ms, 4), "time_basis": "serial (one batch in flight), HIP events, this run",
+            "step_ms_same_basis": iso.get("serial_ms_per_step"),  # the stage time above is part of THIS step time
             "launches_per_stage": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
                                   "pair_prep_kernel + 4 x (recording launch of select_ransac_kernel + replay_walk_kernel) + 1 "
                                   "result launch; avg_launch_ms spans the whole stage",
@@ -310,6 +311,10 @@ def main():
                 out["detect"] = detect_subrecord(local_rank)
             except Exception as e:  # noqa: BLE001
                 out["detect"] = {"error": repr(e)}
+            try:
+                out["loop_closure"] = loop_closure_subrecord(local_rank, args.depth_noise)
+            except Exception as e:  # noqa: BLE001
+                out["loop_closure"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq, pq, pt, SEED, 1e-4, args.cpu_seconds)
             ref = cpu_reference_code(seq, pq, pt, SEED, 1e-4, 5.0)
@@ -430,6 +435,53 @@ def sift_subrecord(seq, device):
                          "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5), "flop_per_pair": 2.0 * N * N * 128,
                          "avg_launch_ms": round(dot_ms, 4), "time_basis": "serial", "traffic": None},
             "serial_stage_ms": {"dot_top2": round(dot_ms, 4), "finish": round(fin_ms, 4), "select_ransac": round(rsc_ms, 4)}}
+
+
+def loop_closure_subrecord(device, depth_noise):
+    """The reject path (every pair of the headline workload is a true edge): an all-pairs loop-closure search
+    over frames of unrelated places -- 180 frames in 18 places of 10, every frame against every earlier one (16 110
+    pairs per step, ~5 % true edges); the other pairs are chance matches that the min_matches gate or RANSAC rejects."""
+    import torch
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd._lib import RESULT_DTYPE
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    F, N = 180, 1000
+    places = [synth.make_sequence(n_frames=10, n_kp=N, seed=1000 + p, depth_noise=depth_noise) for p in range(F // 10)]
+    desc = [pl["desc"][i] for pl in places for i in range(10)]
+    xyz = [pl["xyz1"][i] for pl in places for i in range(10)]
+    pq = np.array([q for q in range(F) for t in range(q)], np.int32)
+    pt = np.array([t for q in range(F) for t in range(q)], np.int32)
+    fe = FrontEnd(device_id=device, max_nodes=F, max_keypoints=1024, max_pairs_per_batch=len(pq))
+    for f in range(F):
+        fe.upload_node(f, desc[f], xyz[f])
+    bufs = [torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:%d" % device) for _ in range(4)]
+
+    def run(steps):
+        tk = []
+        for st in range(steps):
+            if len(tk) >= 2:
+                fe.wait_ticket(tk.pop(0), None)
+            tk.append(fe.submit_pair_list(pq, pt, bufs[st % 4].data_ptr()))
+        for t in tk:
+            fe.wait_ticket(t, None)
+        fe.synchronize()
+
+    run(2)
+    steps = 6
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    res = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[: len(pq)]
+    same_place = (pq // 10) == (pt // 10)
+    edges = res["id1"] >= 0
+    fe.close()
+    return {"metric": "frame-pairs matched+RANSAC/sec, all-pairs loop-closure search, ORB-1000",
+            "value": round(len(pq) * steps / dt, 1), "unit": "frame-pairs/s", "pairs_per_step": int(len(pq)),
+            "ms_per_step": round(dt / steps * 1e3, 3), "frames": F,
+            "pairs_reaching_ransac": round(float((res["real_iterations"] > 0).mean()), 4),
+            "edge_fraction": round(float(edges.mean()), 4),
+            "true_pairs_found": round(float(edges[same_place].mean()), 4),
+            "false_edges": int(edges[~same_place].sum())}
 
 
 def detect_subrecord(device):
