@@ -110,6 +110,13 @@ int  rgbdfe_device_count(rgbdfe_ctx* ctx);                       /* 1 for rgbdfe
 rgbdfe_ctx* rgbdfe_device_context(rgbdfe_ctx* ctx, int32_t i);   /* the i-th device's own context (owned by ctx) */
 int  rgbdfe_match_pair_list_allgather(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
                                       int32_t n_pairs, void* const* d_out, int32_t* records_per_device);
+/* The same with only the ACCEPTED edges travelling (an all-pairs loop-closure sweep rejects most pairs: id1 == -1,
+ * node.cpp:1419): every device compacts its shard in shard order, `*stride` = the largest count of a device; on return
+ * d_out[j] holds device i's edges_per_device[i] records at [i * stride, ...), d_index[j] (optional, may be NULL) their
+ * positions in the caller's pair list.  Buffers as above (n_devices * ceil(n_pairs / n_devices) records / int32). */
+int  rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                            int32_t n_pairs, void* const* d_out, int32_t* const* d_index,
+                                            int32_t* edges_per_device, int32_t* stride);
 const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx);            /* "rccl", "p2p" or "none" (last allgather) */
 int  rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p);
 const char* rgbdfe_status_string(int status);

@@ -211,6 +211,8 @@ def load():
     L.rgbdfe_device_context.argtypes = [ctx, i32]
     L.rgbdfe_match_pair_list_allgather.restype = C.c_int
     L.rgbdfe_match_pair_list_allgather.argtypes = [ctx, vp, vp, i32, vp, C.POINTER(i32)]
+    L.rgbdfe_match_pair_list_allgather_edges.restype = C.c_int
+    L.rgbdfe_match_pair_list_allgather_edges.argtypes = [ctx, vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
     L.rgbdfe_gather_transport.restype = C.c_char_p
     L.rgbdfe_gather_transport.argtypes = [ctx]
     L.rgbdfe_set_hamming_mode.restype = C.c_int
@@ -257,7 +259,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",
     "rgbdfe_gather_transport", "rgbdfe_set_hamming_mode", "rgbdfe_project_to_3d_cloud", "rgbdfe_detect_describe_cloud",
-    "rgbdfe_detect_describe_batch",
+    "rgbdfe_detect_describe_batch", "rgbdfe_match_pair_list_allgather_edges",
     "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",
     "rgbdfe_match_flann_pair_list", "rgbdfe_upload_node_keypoints",
 ]

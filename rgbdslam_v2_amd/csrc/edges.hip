@@ -1,0 +1,69 @@
+// edges.hip -- stream compaction of the accepted edges of a shard (an all-pairs loop-closure sweep rejects
+// most pairs, id1 == -1 (node.cpp:1419), and those records need not cross xGMI).  Stable: the surviving records keep
+// their shard order, so every device -- and every run -- sees the same list.
+#include "rgbdfe_internal.h"
+
+namespace rgbdfe {
+
+namespace {
+
+// one block: flags -> exclusive positions (dst[k] = position of record k among the accepted ones, or -1), total -> *count
+__global__ __launch_bounds__(1024) void edge_scan_kernel(const rgbdfe_match_result* __restrict__ in, uint32_t n,
+                                                         int32_t* __restrict__ dst, int32_t* __restrict__ count) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < n; k0 += 1024u) {
+    const uint32_t k = k0 + tid;
+    const bool keep = k < n && in[k].id1 >= 0;
+    const uint64_t m = __ballot(keep);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) wave_tot[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base;
+    for (uint32_t w = 0; w < wv; ++w) off += wave_tot[w];
+    if (k < n) dst[k] = keep ? (int32_t)(off + rank) : -1;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_tot[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = (int32_t)base;
+}
+
+// one wave per record: 1744 bytes = 109 x 16 bytes
+__global__ __launch_bounds__(64) void edge_copy_kernel(const rgbdfe_match_result* __restrict__ in,
+                                                       const int32_t* __restrict__ dst, uint32_t n,
+                                                       rgbdfe_match_result* __restrict__ out,
+                                                       int32_t* __restrict__ out_index, int32_t index_scale,
+                                                       int32_t index_offset) {
+  const uint32_t k = blockIdx.x;
+  if (k >= n) return;
+  const int32_t d = dst[k];
+  if (d < 0) return;
+  static_assert(sizeof(rgbdfe_match_result) % 16 == 0, "records move as 16-byte chunks");
+  constexpr uint32_t chunks = sizeof(rgbdfe_match_result) / 16;
+  const uint4* __restrict__ s = reinterpret_cast<const uint4*>(in + k);
+  uint4* __restrict__ o = reinterpret_cast<uint4*>(out + d);
+  for (uint32_t c = threadIdx.x; c < chunks; c += 64u) o[c] = s[c];
+  if (out_index && threadIdx.x == 0) out_index[d] = index_offset + index_scale * (int32_t)k;  // position in the caller's list
+}
+
+}  // namespace
+
+// in[0..n) -> out[0..count): the records with id1 >= 0 in order; out_index[j] (optional) = index_offset + index_scale * k of
+// the j-th survivor (the caller's global pair index of a shard: offset = device, scale = devices).
+void launch_compact_edges(const rgbdfe_match_result* in, uint32_t n, rgbdfe_match_result* out, int32_t* out_index,
+                          int32_t index_scale, int32_t index_offset, int32_t* d_dst, int32_t* d_count, hipStream_t stream) {
+  hipLaunchKernelGGL(edge_scan_kernel, dim3(1), dim3(1024), 0, stream, in, n, d_dst, d_count);
+  if (n > 0)
+    hipLaunchKernelGGL(edge_copy_kernel, dim3(n), dim3(64), 0, stream, in, d_dst, n, out, out_index, index_scale,
+                       index_offset);
+}
+
+}  // namespace rgbdfe

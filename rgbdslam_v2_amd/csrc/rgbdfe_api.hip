@@ -2067,6 +2067,11 @@ struct Group {
   std::vector<hipStream_t> gather_streams;  // one per device
   std::vector<hipEvent_t> gather_events;
   std::string transport = "none";
+  // edges-only gather: per device a compacted copy of its shard, the survivors' global pair indices, scan scratch
+  std::vector<rgbdfe_match_result*> edge_recs;
+  std::vector<int32_t*> edge_idx, edge_dst, edge_cnt;
+  std::vector<int32_t*> edge_cnt_host;  // pinned
+  int32_t edge_cap = 0;                 // records per device the scratch holds
 };
 
 namespace {
@@ -2141,6 +2146,13 @@ void group_destroy(rgbdfe_ctx* gctx) {
       if (g->children[i]) (void)hipSetDevice(g->device_ids[i]);
       if (i < g->gather_streams.size() && g->gather_streams[i]) (void)hipStreamDestroy(g->gather_streams[i]);
       if (i < g->gather_events.size() && g->gather_events[i]) (void)hipEventDestroy(g->gather_events[i]);
+      if (i < g->edge_recs.size()) {
+        if (g->edge_recs[i]) (void)hipFree(g->edge_recs[i]);
+        if (g->edge_idx[i]) (void)hipFree(g->edge_idx[i]);
+        if (g->edge_dst[i]) (void)hipFree(g->edge_dst[i]);
+        if (g->edge_cnt[i]) (void)hipFree(g->edge_cnt[i]);
+        if (g->edge_cnt_host[i]) (void)hipHostFree(g->edge_cnt_host[i]);
+      }
       if (g->children[i]) impl::rgbdfe_destroy(g->children[i]);
     }
     delete g;
@@ -2291,6 +2303,112 @@ int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, 
         char* dst = (char*)d_out[j] + (size_t)i * per * rec;
         HIP_TRY(gctx, hipMemcpyPeerAsync(dst, g.device_ids[(size_t)j], src, g.device_ids[(size_t)i], (size_t)per * rec,
                                          g.gather_streams[(size_t)i]));
+      }
+    }
+  }
+  for (int i = 0; i < G; ++i) {
+    HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+    HIP_TRY(gctx, hipStreamSynchronize(g.gather_streams[(size_t)i]));
+  }
+  return RGBDFE_OK;
+}
+
+// All-gather of the ACCEPTED edges only (an all-pairs loop-closure sweep rejects most pairs and their
+// records need not travel): every device compacts its shard (stable: shard order), the host learns the counts, the
+// exchange moves `stride` = the largest count records per device instead of ceil(n / G).  On return d_out[j] holds, for
+// every device i, its counts[i] accepted records at [i * stride, i * stride + counts[i]) and d_index[j] (optional) their
+// positions in the caller's pair list.  Buffers are sized for the worst case: G * ceil(n / G) records / indices.
+int group_match_allgather_edges(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, void* const* d_out,
+                                int32_t* const* d_index, int32_t* counts, int32_t* stride_out) {
+  if (n < 0 || !d_out || !counts || !stride_out || (n > 0 && (!q || !t)))
+    return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad allgather arguments");
+  Group& g = *gctx->group;
+  const int G = (int)g.children.size();
+  const int32_t per = (n + G - 1) / G;
+  *stride_out = 0;
+  for (int i = 0; i < G; ++i) counts[i] = 0;
+  if (per == 0) return RGBDFE_OK;
+  for (int i = 0; i < G; ++i)
+    if (!d_out[i] || (d_index && !d_index[i])) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "allgather: a device buffer is NULL");
+  if (per > gctx->cfg.max_pairs_per_batch)
+    return fail(gctx, RGBDFE_ERR_CAPACITY, "allgather: the shard of a device exceeds max_pairs_per_batch");
+  const size_t rec = sizeof(rgbdfe_match_result);
+  if (g.edge_cap < per) {
+    g.edge_recs.resize((size_t)G, nullptr); g.edge_idx.resize((size_t)G, nullptr); g.edge_dst.resize((size_t)G, nullptr);
+    g.edge_cnt.resize((size_t)G, nullptr); g.edge_cnt_host.resize((size_t)G, nullptr);
+    for (int i = 0; i < G; ++i) {
+      HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+      if (g.edge_recs[(size_t)i]) { (void)hipFree(g.edge_recs[(size_t)i]); (void)hipFree(g.edge_idx[(size_t)i]); (void)hipFree(g.edge_dst[(size_t)i]); }
+      HIP_TRY(gctx, hipMalloc((void**)&g.edge_recs[(size_t)i], rec * (size_t)per));
+      HIP_TRY(gctx, hipMalloc((void**)&g.edge_idx[(size_t)i], sizeof(int32_t) * (size_t)per));
+      HIP_TRY(gctx, hipMalloc((void**)&g.edge_dst[(size_t)i], sizeof(int32_t) * (size_t)per));
+      if (!g.edge_cnt[(size_t)i]) {
+        HIP_TRY(gctx, hipMalloc((void**)&g.edge_cnt[(size_t)i], sizeof(int32_t)));
+        HIP_TRY(gctx, hipHostMalloc((void**)&g.edge_cnt_host[(size_t)i], sizeof(int32_t), hipHostMallocDefault));
+      }
+    }
+    g.edge_cap = per;
+  }
+  // 1. every device: its shard into its own segment of its own buffer, then the accepted records, compacted, into scratch
+  int rc = group_run(gctx, [&](int i) -> int {
+    rgbdfe_ctx* c = g.children[(size_t)i];
+    std::vector<int32_t> qs, ts;
+    for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }
+    rgbdfe_match_result* seg = (rgbdfe_match_result*)d_out[i] + (size_t)i * per;
+    hipStream_t gs = g.gather_streams[(size_t)i];
+    int64_t ticket = 0;
+    int r = RGBDFE_OK;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+      HIP_TRY(c, hipEventRecord(g.gather_events[(size_t)i], gs));
+      r = enqueue_pairs(c, qs.data(), ts.data(), (int32_t)qs.size(), seg, g.gather_events[(size_t)i], &ticket, nullptr);
+      if (r == RGBDFE_OK) r = wait_ticket(c, ticket, gs);
+    }
+    if (r != RGBDFE_OK) return r;
+    launch_compact_edges(seg, (uint32_t)qs.size(), g.edge_recs[(size_t)i], g.edge_idx[(size_t)i], G, i, g.edge_dst[(size_t)i],
+                         g.edge_cnt[(size_t)i], gs);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(g.edge_cnt_host[(size_t)i], g.edge_cnt[(size_t)i], sizeof(int32_t), hipMemcpyDeviceToHost, gs));
+    HIP_TRY(c, hipStreamSynchronize(gs));
+    return RGBDFE_OK;
+  });
+  if (rc != RGBDFE_OK) return rc;
+  int32_t stride = 0;
+  for (int i = 0; i < G; ++i) {
+    counts[i] = *g.edge_cnt_host[(size_t)i];
+    stride = std::max(stride, counts[i]);
+  }
+  *stride_out = stride;
+  if (stride == 0) { g.transport = "none (no edges)"; return RGBDFE_OK; }
+  // 2. the exchange: `stride` records (and indices) per device
+  if (group_setup_rccl(gctx)) {
+    g.transport = "rccl";
+    if (g.rccl.GroupStart() != 0) return fail(gctx, RGBDFE_ERR_HIP, "ncclGroupStart failed");
+    int nrc = 0;
+    for (int i = 0; i < G && nrc == 0; ++i) {
+      nrc = g.rccl.AllGather(g.edge_recs[(size_t)i], d_out[i], (size_t)stride * rec, kNcclChar, g.comms[(size_t)i],
+                             g.gather_streams[(size_t)i]);
+      if (nrc == 0 && d_index)
+        nrc = g.rccl.AllGather(g.edge_idx[(size_t)i], d_index[i], (size_t)stride * sizeof(int32_t), kNcclChar,
+                               g.comms[(size_t)i], g.gather_streams[(size_t)i]);
+    }
+    const int erc = g.rccl.GroupEnd();
+    if (nrc != 0 || erc != 0)
+      return fail(gctx, RGBDFE_ERR_HIP, std::string("ncclAllGather: ") +
+                                            (g.rccl.GetErrorString ? g.rccl.GetErrorString(nrc ? nrc : erc) : "error"));
+  } else {
+    g.transport = G == 1 ? "none (one device)" : "p2p";
+    for (int i = 0; i < G; ++i) {
+      HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+      for (int j = 0; j < G; ++j) {
+        char* dst = (char*)d_out[j] + (size_t)i * stride * rec;
+        HIP_TRY(gctx, hipMemcpyPeerAsync(dst, g.device_ids[(size_t)j], g.edge_recs[(size_t)i], g.device_ids[(size_t)i],
+                                         (size_t)counts[i] * rec, g.gather_streams[(size_t)i]));
+        if (d_index)
+          HIP_TRY(gctx, hipMemcpyPeerAsync(d_index[j] + (size_t)i * stride, g.device_ids[(size_t)j], g.edge_idx[(size_t)i],
+                                           g.device_ids[(size_t)i], (size_t)counts[i] * sizeof(int32_t),
+                                           g.gather_streams[(size_t)i]));
       }
     }
   }
@@ -2462,6 +2580,18 @@ int rgbdfe_match_pair_list_allgather(rgbdfe_ctx* ctx, const int32_t* query_ids, 
     if (!RGBDFE_IS_GROUP(ctx))
       return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_match_pair_list_allgather needs a context made by rgbdfe_create_multi");
     return group_match_allgather(ctx, query_ids, train_ids, n_pairs, d_out, records_per_device);
+  });
+}
+
+int rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                           int32_t n_pairs, void* const* d_out, int32_t* const* d_index,
+                                           int32_t* edges_per_device, int32_t* stride) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!RGBDFE_IS_GROUP(ctx))
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG,
+                  "rgbdfe_match_pair_list_allgather_edges needs a context made by rgbdfe_create_multi");
+    return group_match_allgather_edges(ctx, query_ids, train_ids, n_pairs, d_out, d_index, edges_per_device, stride);
   });
 }
 

@@ -138,6 +138,22 @@ class FrontEnd:
                                                              C.cast(ptrs, C.c_void_p), C.byref(per)))
         return int(per.value)
 
+    def match_pair_list_allgather_edges(self, query_ids, train_ids, d_out_ptrs: Sequence[int], d_index_ptrs=None):
+        """Only the accepted edges travel (rgbdfe_match_pair_list_allgather_edges).  Returns (counts per device, stride):
+        device i's edges sit at records [i * stride, i * stride + counts[i]) of every buffer, their positions in the pair
+        list at the same offsets of the index buffers."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        g = len(d_out_ptrs)
+        ptrs = (C.c_void_p * g)(*[C.c_void_p(int(p)) for p in d_out_ptrs])
+        iptrs = None if d_index_ptrs is None else (C.c_void_p * g)(*[C.c_void_p(int(p)) for p in d_index_ptrs])
+        counts = np.zeros(g, np.int32)
+        stride = C.c_int32(0)
+        self._check(self._L.rgbdfe_match_pair_list_allgather_edges(
+            self._ctx, q.ctypes.data, t.ctypes.data, len(q), C.cast(ptrs, C.c_void_p),
+            None if iptrs is None else C.cast(iptrs, C.c_void_p), counts.ctypes.data, C.byref(stride)))
+        return counts, int(stride.value)
+
     # -- plumbing --------------------------------------------------------------
     def _check(self, st):
         if st != 0:

@@ -81,6 +81,58 @@ def test_allgather_leaves_all_results_on_every_device(data, ids, transport):
     grp.close()
 
 
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0]])
+def test_allgather_of_accepted_edges_only(ids):
+    """in an all-pairs sweep most pairs are rejected and need not travel.  Two unrelated places: only pairs
+    inside a place become edges; every device ends up with exactly the accepted records, in shard order, plus their
+    positions in the pair list."""
+    import torch
+    a = synth.make_sequence(n_frames=6, n_kp=400, n_world=1500, seed=31)
+    b = synth.make_sequence(n_frames=6, n_kp=400, n_world=1500, seed=32)
+    desc = list(a["desc"]) + list(b["desc"])
+    xyz = list(a["xyz1"]) + list(b["xyz1"])
+    F = 12
+    pq = np.array([q for q in range(F) for t in range(q)], np.int32)
+    pt = np.array([t for q in range(F) for t in range(q)], np.int32)
+    from rgbdslam_v2_amd.frontend import FrontEnd
+
+    def make(device_ids):
+        fe = FrontEnd(device_id=0, max_nodes=16, max_keypoints=512, max_pairs_per_batch=128, device_ids=device_ids)
+        for f in range(F):
+            fe.upload_node(f, desc[f], xyz[f])
+        return fe
+
+    one = make(None)
+    ref = one.match_pair_list(pq, pt)
+    one.close()
+    is_edge = ref["id1"] >= 0
+    assert 10 <= is_edge.sum() <= 40 and not is_edge[(pq // 6) != (pt // 6)].any()
+    grp = make(ids)
+    G, n = len(ids), len(pq)
+    per = (n + G - 1) // G
+    rec = RESULT_DTYPE.itemsize
+    bufs = [torch.zeros(G * per * rec, dtype=torch.uint8, device="cuda:0") for _ in ids]
+    idxs = [torch.full((G * per,), -7, dtype=torch.int32, device="cuda:0") for _ in ids]
+    torch.cuda.synchronize()
+    counts, stride = grp.match_pair_list_allgather_edges(pq, pt, [b.data_ptr() for b in bufs], [i.data_ptr() for i in idxs])
+    assert counts.sum() == is_edge.sum() and stride == counts.max()
+    for d in range(G):
+        shard = np.arange(d, n, G)
+        want = shard[is_edge[shard]]
+        assert counts[d] == len(want)
+        for b, ix in zip(bufs, idxs):
+            got = np.frombuffer(b.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[d * stride: d * stride + counts[d]]
+            assert got.tobytes() == ref[want].tobytes()
+            assert np.array_equal(ix.cpu().numpy()[d * stride: d * stride + counts[d]], want)
+    # no index buffers, and a sweep without any edge
+    counts2, stride2 = grp.match_pair_list_allgather_edges(pq, pt, [b.data_ptr() for b in bufs])
+    assert np.array_equal(counts2, counts) and stride2 == stride
+    cross = (pq // 6) != (pt // 6)
+    counts3, stride3 = grp.match_pair_list_allgather_edges(pq[cross], pt[cross], [b.data_ptr() for b in bufs])
+    assert counts3.sum() == 0 and stride3 == 0
+    grp.close()
+
+
 def test_group_refuses_device_pointer_entry_points(data):
     import torch
     seq, pq, pt = data
