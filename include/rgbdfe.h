@@ -385,7 +385,17 @@ typedef struct {
   int32_t octave;   /* pyramid level */
 } rgbdfe_keypoint;
 int rgbdfe_detector_configure(rgbdfe_ctx* ctx, int32_t max_keypoints, int32_t grid_resolution,
-                              int32_t adjuster_max_iterations); /* parameter_server.cpp:83,87,89; resets thresholds */
+                              int32_t adjuster_max_iterations); /* "use_feature_min_depth" (parameter_server.cpp:90, default off): a keypoint's depth is the nearest valid depth in its
+ * neighbourhood (getMinDepthInNeighborhood, misc.cpp:774-793) instead of the pixel under it -- in removeDepthless
+ * (node.cpp:82) and projectTo3D (:940).  rgbdfe_set_feature_min_depth switches rgbdfe_detect_describe(_batch) over;
+ * rgbdfe_project_to_3d_min_depth is rgbdfe_project_to_3d in that mode (kp_size = cv::KeyPoint::size per keypoint).
+ * The SIFTGPU variant (node.cpp:730) is not built. */
+int rgbdfe_set_feature_min_depth(rgbdfe_ctx* ctx, int32_t on);
+int rgbdfe_project_to_3d_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, const float* kp_size, int32_t n_kp,
+                                   const float* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                   double cy, double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
+                                   float* xyz1, int32_t* n_out);
+/* parameter_server.cpp:83,87,89; resets thresholds */
 int rgbdfe_detector_thresholds(rgbdfe_ctx* ctx, double* thresholds, int32_t* n_cells);
 int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
                            int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,

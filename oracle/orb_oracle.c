@@ -646,10 +646,26 @@ static int remove_depthless(orb_keypoint* kp, int n, const float* depth, int row
   return m;
 }
 
+extern float orc_min_depth_in_neighborhood(const float* depth, int rows, int cols, float cx, float cy, float diameter);
+static int remove_depthless_min_depth(orb_keypoint* kp, int n, const float* depth, int rows, int cols) {
+  int m = 0;  /* node.cpp:82: Z = getMinDepthInNeighborhood(depth, p2d, size) */
+  for (int i = 0; i < n; ++i) {
+    const float px = kp[i].x, py = kp[i].y;
+    if (px >= (float)cols || px < 0 || py >= (float)rows || py < 0 || isnan(px) || isnan(py)) continue;
+    if (isnan(orc_min_depth_in_neighborhood(depth, rows, cols, px, py, kp[i].size))) continue;
+    kp[m++] = kp[i];
+  }
+  return m;
+}
+
+static int g_use_feature_min_depth = 0;
+void orb_set_use_feature_min_depth(int on) { g_use_feature_min_depth = on; }
+
 int orb_node_features(orb_grid_state* st, const uint8_t* gray, const uint8_t* mask, const float* depth,
                       int cols, int rows, int max_keypoints, orb_keypoint* kp, int cap, uint8_t* desc) {
   int n = orb_grid_detect(st, gray, mask, cols, rows, kp, cap);   /* node.cpp:160 */
-  n = remove_depthless(kp, n, depth, rows, cols);                  /* :186 */
+  n = g_use_feature_min_depth ? remove_depthless_min_depth(kp, n, depth, rows, cols)
+                              : remove_depthless(kp, n, depth, rows, cols);                  /* :186 */
   if (n > max_keypoints) {                                          /* :188-191 */
     /* retainBest keeps ties of the n-th response, resize() then cuts: the survivors are the
      * max_keypoints strongest, ties by order */

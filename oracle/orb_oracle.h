@@ -47,6 +47,7 @@ void orb_gaussian_blur7(const uint8_t* src, int w, int h, int stride, uint8_t* d
 int orb_compute(const uint8_t* img, int cols, int rows, orb_keypoint* kp, int n, uint8_t* desc);
 int orb_node_features(orb_grid_state* st, const uint8_t* gray, const uint8_t* mask, const float* depth,
                       int cols, int rows, int max_keypoints, orb_keypoint* kp, int cap, uint8_t* desc);
+void orb_set_use_feature_min_depth(int on);  /* parameter "use_feature_min_depth" for orb_node_features (node.cpp:82) */
 const int8_t* orb_pattern(void);
 
 #ifdef __cplusplus

@@ -488,6 +488,42 @@ def project_to_3d(kp_xy, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints
     return kept[:k].copy(), xyz1[:k].copy()
 
 
+def min_depth_in_neighborhood(depth, x, y, diameter):
+    """getMinDepthInNeighborhood (misc.cpp:774-793)."""
+    depth = np.ascontiguousarray(depth, np.float32)
+    L = lib()
+    L.orc_min_depth_in_neighborhood.restype = C.c_float
+    L.orc_min_depth_in_neighborhood.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    return float(L.orc_min_depth_in_neighborhood(_p(depth), depth.shape[0], depth.shape[1], x, y, diameter))
+
+
+def remove_depthless_min_depth(kp_xy, kp_size, depth):
+    """removeDepthless with use_feature_min_depth (node.cpp:66-97): kept input positions."""
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+    kp_size = np.ascontiguousarray(kp_size, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    n = kp_xy.shape[0]
+    kept = np.empty(max(n, 1), np.int32)
+    k = lib().orc_remove_depthless_min_depth(_p(kp_xy), _p(kp_size), n, _p(depth), depth.shape[0], depth.shape[1], _p(kept))
+    return kept[:k].copy()
+
+
+def project_to_3d_min_depth(kp_xy, kp_size, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000):
+    """projectTo3D with use_feature_min_depth (node.cpp:900-965, :940)."""
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+    kp_size = np.ascontiguousarray(kp_size, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    n = kp_xy.shape[0]
+    kept = np.empty(max(n, 1), np.int32)
+    xyz1 = np.empty((max(n, 1), 4), np.float32)
+    L = lib()
+    L.orc_project_to_3d_min_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                              C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    k = L.orc_project_to_3d_min_depth(_p(kp_xy), _p(kp_size), n, _p(depth), depth.shape[0], depth.shape[1], fx, fy, cx, cy,
+                                      depth_scaling, max_keypoints, _p(kept), _p(xyz1))
+    return kept[:k].copy(), xyz1[:k].copy()
+
+
 def project_to_3d_cloud(kp_xy, cloud, maximum_depth, max_keypoints=1000):
     """Node::projectTo3D, point-cloud overload (node.cpp:855-898).  cloud: [rows, cols, 4] float32."""
     kp_xy = np.ascontiguousarray(kp_xy, np.float32)

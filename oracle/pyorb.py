@@ -189,6 +189,11 @@ def node_features(st, gray, mask, depth, max_keypoints=1000, cap=60000):
     return kp[:n].copy(), desc[:n].copy()
 
 
+def set_use_feature_min_depth(on):
+    """Parameter "use_feature_min_depth" for node_features (node.cpp:82)."""
+    lib().orb_set_use_feature_min_depth(1 if on else 0)
+
+
 def pattern():
     return np.ctypeslib.as_array(lib().orb_pattern(), shape=(1024,)).copy()
 

@@ -14,6 +14,39 @@ static std::vector<cv::KeyPoint> make_kps(const float* kp_xy, int n) {
   return k;
 }
 
+// use_feature_min_depth (parameter_server.cpp:90): the same reference functions with the parameter switched on and the
+// keypoints' real sizes
+extern "C" float ref_min_depth_in_neighborhood(const float* depth, int rows, int cols, float x, float y, float diameter) {
+  cv::Mat d(rows, cols, CV_32FC1, (void*)depth);
+  cv::Point2f c; c.x = x; c.y = y;
+  return getMinDepthInNeighborhood(d, c, diameter);
+}
+extern "C" int ref_remove_depthless_min_depth(const float* kp_xy, const float* kp_size, int n, const float* depth, int rows,
+                                              int cols, int32_t* kept) {
+  std::vector<cv::KeyPoint> k = make_kps(kp_xy, n);
+  for (int i = 0; i < n; ++i) k[i].size = kp_size[i];
+  cv::Mat d(rows, cols, CV_32FC1, (void*)depth);
+  g_fp.use_feature_min_depth = true;
+  removeDepthless(k, d);
+  g_fp.use_feature_min_depth = false;
+  for (size_t i = 0; i < k.size(); ++i) kept[i] = k[i].class_id;
+  return (int)k.size();
+}
+extern "C" int ref_project_to_3d_min_depth(const float* kp_xy, const float* kp_size, int n, const float* depth, int rows,
+                                           int cols, double fx, double fy, double cx, double cy, double depth_scaling,
+                                           int max_keypoints, int32_t* kept, float* xyz1) {
+  g_fp.depth_scaling_factor = depth_scaling; g_fp.max_keypoints = max_keypoints;
+  std::vector<cv::KeyPoint> k = make_kps(kp_xy, n);
+  for (int i = 0; i < n; ++i) k[i].size = kp_size[i];
+  std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> > p3;
+  cv::Mat d(rows, cols, CV_32FC1, (void*)depth);
+  Node node;
+  g_fp.use_feature_min_depth = true;
+  node.projectTo3D(k, p3, d, make_cam(fx, fy, cx, cy));
+  g_fp.use_feature_min_depth = false;
+  for (size_t i = 0; i < p3.size(); ++i) { kept[i] = k[i].class_id; for (int c = 0; c < 4; ++c) xyz1[4 * i + c] = p3[i](c); }
+  return (int)p3.size();
+}
 extern "C" int ref_remove_depthless(const float* kp_xy, int n, const float* depth, int rows, int cols, int32_t* kept) {
   std::vector<cv::KeyPoint> k = make_kps(kp_xy, n);
   cv::Mat d(rows, cols, CV_32FC1, (void*)depth);

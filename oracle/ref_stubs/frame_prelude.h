@@ -28,6 +28,7 @@
 #include <vector>
 
 #define ROS_INFO(...)
+#define ROS_INFO_THROTTLE(...)
 #define ROS_WARN(...)
 #define ROS_ERROR(...)
 #define ROS_DEBUG(...)
@@ -44,6 +45,7 @@ struct FrameParams {
   double depth_cov = 1e-4;
   int max_keypoints = 1000, cloud_creation_skip_step = 2, emm__skip_step = 8;
   bool encoding_bgr = false;
+  bool use_feature_min_depth = false;
 };
 extern FrameParams g_fp;
 struct ParameterServer {
@@ -57,7 +59,8 @@ struct ParameterServer {
     if (n == "cloud_creation_skip_step") return (T)g_fp.cloud_creation_skip_step;
     if (n == "emm__skip_step") return (T)g_fp.emm__skip_step;
     if (n == "encoding_bgr") return (T)g_fp.encoding_bgr;
-    return T();  // depth_camera_fx.. = 0 (use CameraInfo), use_feature_min_depth / emm__mark_outliers = false, voxelfilter_size = 0
+    if (n == "use_feature_min_depth") return (T)g_fp.use_feature_min_depth;
+    return T();  // depth_camera_fx.. = 0 (use CameraInfo), emm__mark_outliers = false, voxelfilter_size = 0
   }
 };
 template <> inline std::string ParameterServer::get<std::string>(const std::string&) { return std::string(); }  // topic_points: empty
@@ -76,13 +79,21 @@ struct KeyPoint {
   int octave, class_id;
 };
 // row-major view / owner of an 8-bit or float image
+struct Range { int start, end; Range(int s, int e) : start(s), end(e) {} };
 struct Mat {
   int rows = 0, cols = 0, type_ = CV_8UC1;
+  int step_elems = 0;  // row stride in elements of a region-of-interest view (0: = cols)
   unsigned char* data = nullptr;
   std::shared_ptr<std::vector<unsigned char> > own;
   Mat() {}
   Mat(int r, int c, int t) : rows(r), cols(c), type_(t), own(new std::vector<unsigned char>((size_t)r * c * esz(t))) { data = own->data(); }
   Mat(int r, int c, int t, void* d) : rows(r), cols(c), type_(t), data((unsigned char*)d) {}
+  // region of interest (a view): rows [rr.start, rr.end) x cols [cr.start, cr.end)
+  Mat(const Mat& m, const Range& rr, const Range& cr)
+      : rows(rr.end > rr.start ? rr.end - rr.start : 0), cols(cr.end > cr.start ? cr.end - cr.start : 0), type_(m.type_),
+        step_elems(m.step_elems ? m.step_elems : m.cols),
+        data(m.data + ((size_t)rr.start * (m.step_elems ? m.step_elems : m.cols) + cr.start) * esz(m.type_)), own(m.own) {}
+  int stride() const { return step_elems ? step_elems : cols; }
   static size_t esz(int t) { return t == CV_32FC1 ? 4 : (t == CV_8UC3 ? 3 : 1); }
   int type() const { return type_; }
   size_t total() const { return (size_t)rows * cols; }
@@ -91,6 +102,18 @@ struct Mat {
   template <class T> T& at(int i) { return reinterpret_cast<T*>(data)[i]; }
   template <class T> const T& at(int i) const { return reinterpret_cast<const T*>(data)[i]; }
 };
+// cv::minMaxLoc(src, &minVal) on a CV_32F matrix: OpenCV 3.3 minMaxIdx_32f -- `if (val < minVal)` starting from FLT_MAX
+// (a NaN never compares less: skipped), and 0 when no element compared (minidx == 0).  Restated: OpenCV is absent.
+inline void minMaxLoc(const Mat& m, double* minVal) {
+  float mn = 3.402823466e+38f;
+  bool found = false;
+  for (int r = 0; r < m.rows; ++r)
+    for (int c = 0; c < m.cols; ++c) {
+      const float v = reinterpret_cast<const float*>(m.data)[(size_t)r * m.stride() + c];
+      if (v < mn) { mn = v; found = true; }
+    }
+  *minVal = found ? (double)mn : 0.0;
+}
 // cv::abs on a CV_32F matrix
 inline Mat abs(const Mat& m) {
   Mat r(m.rows, m.cols, CV_32FC1);
@@ -170,7 +193,7 @@ inline void transformPointCloud(const pointcloud_type& in, pointcloud_type& out,
 }
 }  // namespace pcl
 
-inline float getMinDepthInNeighborhood(const cv::Mat&, cv::Point2f, float) { return 0.f; }  // use_feature_min_depth = false
+float getMinDepthInNeighborhood(const cv::Mat& depth, cv::Point2f center, float diameter);  // misc.cpp:774-793, compiled from the source
 
 class Node {
  public:

@@ -1052,6 +1052,74 @@ int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows
 }
 
 /* ------------------------------------------------------------------------- */
+/* "use_feature_min_depth" (parameter_server.cpp:90, default false): the depth of   */
+/* a keypoint is the nearest valid depth in its neighbourhood,                       */
+/* getMinDepthInNeighborhood (misc.cpp:774-793), in removeDepthless (node.cpp:82),    */
+/* projectTo3D (:940) and projectTo3DSiftGPU (:730).                                  */
+/*   radius = (diameter - 1) / 2 in float, truncated; the window is                   */
+/*   rows [int(y - radius), int(y + radius)) x cols [int(x - radius), int(x + radius))*/
+/*   clamped to the image (cv::Range is half open: the last row / column of the       */
+/*   symmetric window is NOT part of it); cv::minMaxLoc skips NaN (its `val < min`     */
+/*   never holds for NaN) and reports 0 for a window without a comparable value       */
+/*   (OpenCV 3.3 minMaxIdx: minidx == 0 -> 0; "parity unpinned", OpenCV is absent);    */
+/*   a minimum of 0 becomes NaN (:786-789).                                            */
+/* ------------------------------------------------------------------------- */
+float orc_min_depth_in_neighborhood(const float* depth, int rows, int cols, float cx, float cy, float diameter) {
+  const int radius = (int)((diameter - 1) / 2);
+  int top = (int)(cy - (float)radius); top = top < 0 ? 0 : top;
+  int left = (int)(cx - (float)radius); left = left < 0 ? 0 : left;
+  int bot = (int)(cy + (float)radius); bot = bot > rows ? rows : bot;
+  int right = (int)(cx + (float)radius); right = right > cols ? cols : right;
+  float minv = FLT_MAX;
+  int found = 0;
+  for (int r = top; r < bot; ++r)
+    for (int c = left; c < right; ++c) {
+      const float v = depth[(size_t)r * (size_t)cols + (size_t)c];
+      if (v < minv) { minv = v; found = 1; }
+    }
+  double minZ = found ? (double)minv : 0.0;
+  if (minZ == 0.0) minZ = (double)NAN;
+  return (float)minZ;
+}
+
+/* removeDepthless with use_feature_min_depth (node.cpp:66-97): kept input positions */
+int orc_remove_depthless_min_depth(const float* kp_xy, const float* kp_size, int n_kp, const float* depth, int rows,
+                                   int cols, int32_t* kept_idx) {
+  int n = 0;
+  for (int i = 0; i < n_kp; ++i) {
+    const float px = kp_xy[2 * i], py = kp_xy[2 * i + 1];
+    if (px >= (float)cols || px < 0 || py >= (float)rows || py < 0 || isnan(px) || isnan(py)) continue;
+    const float Z = orc_min_depth_in_neighborhood(depth, rows, cols, px, py, kp_size[i]);
+    if (isnan(Z)) continue;
+    kept_idx[n++] = i;
+  }
+  return n;
+}
+
+/* projectTo3D with use_feature_min_depth (node.cpp:900-965, :940) */
+int orc_project_to_3d_min_depth(const float* kp_xy, const float* kp_size, int n_kp, const float* depth, int rows,
+                                int cols, double fx, double fy, double cx_d, double cy_d, double depth_scaling,
+                                int max_keypoints, int32_t* kept_idx, float* xyz1) {
+  const float fxinv = (float)(1. / fx), fyinv = (float)(1. / fy), cx = (float)cx_d, cy = (float)cy_d;
+  int n = 0;
+  for (int i = 0; i < n_kp; ++i) {
+    const float px = kp_xy[2 * i], py = kp_xy[2 * i + 1];
+    if (px >= (float)cols || px < 0 || py >= (float)rows || py < 0 || isnan(px) || isnan(py)) continue;
+    /* :941 getMinDepthInNeighborhood(...) * depth_scaling: float * double -> double -> float Z */
+    const float Z = (float)((double)orc_min_depth_in_neighborhood(depth, rows, cols, px, py, kp_size[i]) * depth_scaling);
+    if (isnan(Z)) continue;
+    xyz1[4 * n + 0] = (px - cx) * Z * fxinv;
+    xyz1[4 * n + 1] = (py - cy) * Z * fyinv;
+    xyz1[4 * n + 2] = Z;
+    xyz1[4 * n + 3] = 1.0f;
+    kept_idx[n] = i;
+    ++n;
+    if (n >= max_keypoints) break;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------- */
 /* a22(i)  Node::projectTo3D, point-cloud overload -- node.cpp:855-898 (the ctor   */
 /* that receives the sensor's organised cloud, node.cpp:252-369: detect ->         */
 /* projectTo3D(cloud) -> compute, no retainBest).  The lookup truncates the        */

@@ -94,6 +94,13 @@ void orc_match_pairs_mt(const uint8_t* const* desc, const float* const* xyz1,
 int orc_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int rows, int cols,
                       double fx, double fy, double cx, double cy, double depth_scaling,
                       int max_keypoints, int32_t* kept_idx, float* xyz1);
+/* "use_feature_min_depth" variants (misc.cpp:774-793, node.cpp:82, :940): kp_size = cv::KeyPoint::size per keypoint */
+float orc_min_depth_in_neighborhood(const float* depth, int rows, int cols, float cx, float cy, float diameter);
+int orc_remove_depthless_min_depth(const float* kp_xy, const float* kp_size, int n_kp, const float* depth, int rows,
+                                   int cols, int32_t* kept_idx);
+int orc_project_to_3d_min_depth(const float* kp_xy, const float* kp_size, int n_kp, const float* depth, int rows,
+                                int cols, double fx, double fy, double cx, double cy, double depth_scaling,
+                                int max_keypoints, int32_t* kept_idx, float* xyz1);
 int orc_num_cores(void);
 /* SiftGPUWrapper::match (sift_gpu_wrapper.cpp:169-227) over the CUDA SiftMatchGPU kernels */
 /* SURVEY 8(f) rows 3 + 2: depthToCV8UC1, createXYZRGBPointCloud, observationLikelihood (misc.cpp) */

@@ -182,6 +182,39 @@ void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int 
                        cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out, z_gathered);
 }
 
+// getMinDepthInNeighborhood (misc.cpp:774-793), the depth lookup of "use_feature_min_depth" (parameter_server.cpp:90):
+// the smallest non-NaN depth of the keypoint's neighbourhood -- rows [int(y - r), int(y + r)) x cols [int(x - r),
+// int(x + r)), r = int((size - 1) / 2), clamped to the image; no comparable value or a minimum of 0 gives NaN.
+// One wave per keypoint, lanes along the window's columns; a minimum is order independent: exact.
+__global__ __launch_bounds__(64) void min_depth_kernel(const float* __restrict__ kp, int n_kp, const float* __restrict__ depth,
+                                                       int rows, int cols, float* __restrict__ z_out) {
+  const int i = blockIdx.x;
+  if (i >= n_kp) return;
+  const float cx = kp[3 * i], cy = kp[3 * i + 1], diameter = kp[3 * i + 2];
+  const int radius = (int)((diameter - 1) / 2);
+  int top = (int)(cy - (float)radius); top = top < 0 ? 0 : top;
+  int left = (int)(cx - (float)radius); left = left < 0 ? 0 : left;
+  int bot = (int)(cy + (float)radius); bot = bot > rows ? rows : bot;
+  int right = (int)(cx + (float)radius); right = right > cols ? cols : right;
+  float mn = 3.402823466e+38f;
+  bool found = false;
+  for (int r = top; r < bot; ++r)
+    for (int c = left + (int)threadIdx.x; c < right; c += 64) {
+      const float v = depth[(size_t)r * (size_t)cols + (size_t)c];
+      if (v < mn) { mn = v; found = true; }  // NaN never compares less: skipped, as in cv::minMaxLoc
+    }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d));  // no NaN among the partial minima
+  found = __ballot(found) != 0ull;
+  if (threadIdx.x == 0) z_out[i] = (found && mn != 0.0f) ? mn : __builtin_nanf("");
+}
+
+// kp: n_kp x (x, y, size); z_out[i] = getMinDepthInNeighborhood(depth, (x, y), size)
+void launch_min_depth(const float* kp_xys, int n_kp, const float* depth, int rows, int cols, float* z_out,
+                      hipStream_t stream) {
+  if (n_kp > 0) hipLaunchKernelGGL(min_depth_kernel, dim3(n_kp), dim3(64), 0, stream, kp_xys, n_kp, depth, rows, cols, z_out);
+}
+
 void launch_project_cloud(const float* kp_xy, int n_kp, const float4* pts, bool gathered, int rows, int cols,
                           double maximum_depth, int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
                           hipStream_t stream) {

@@ -94,6 +94,7 @@ struct rgbdfe_ctx {
   float* d_kp2d = nullptr;     // max_nodes x max_kp x 2: KeyPoint.pt (allocated with the first rgbdfe_upload_node_keypoints)
   hipStream_t orb_upload_stream = nullptr;  // rgbdfe_detect_describe_batch: uploads of frame k+1 beside frame k
   hipEvent_t orb_upload_done[2] = {nullptr, nullptr};
+  bool feature_min_depth = false;  // "use_feature_min_depth" (parameter_server.cpp:90): rgbdfe_set_feature_min_depth
   bool sift_fast = true;       // sift_match.hip's float keys where a pair qualifies (RGBDFE_SIFT_FAST_KEYS=0: never)
   int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
   // Batches run on kLanes internal HIP streams ("lanes"), each with its own keys / results
@@ -1219,7 +1220,42 @@ static int detect_describe_frame(rgbdfe_ctx* ctx, const uint8_t* gray, const uin
     orb.timing.us[5] += (now - tq) - (orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] - pass_before);
     tq = now;
   }
-  {  // removeDepthless (node.cpp:67-97, :186)
+  // "use_feature_min_depth" (parameter_server.cpp:90, rgbdfe_set_feature_min_depth): a keypoint's depth is the nearest valid
+  // depth of its neighbourhood (getMinDepthInNeighborhood, misc.cpp:774-793) -- looked up on the device for all keypoints
+  // at once (the depth image is uploaded in this mode only) and carried along with the keypoints from here on.
+  std::vector<float> zmin;
+  const bool min_depth = ctx->feature_min_depth;
+  if (min_depth && !kps.empty()) {
+    const int n0 = (int)kps.size();
+    const size_t b_depth = ((size_t)rows * cols * 4 + 255) & ~(size_t)255;
+    const size_t b_kp = ((size_t)n0 * 12 + 255) & ~(size_t)255;
+    rc = ensure_scratch(ctx, b_depth + b_kp + (size_t)n0 * 4 + 256);
+    if (rc != RGBDFE_OK) return rc;
+    float* d_depth = (float*)ctx->d_scratch;
+    float* d_kps3 = (float*)((char*)ctx->d_scratch + b_depth);
+    float* d_z = (float*)((char*)ctx->d_scratch + b_depth + b_kp);
+    std::vector<float> h3((size_t)n0 * 3);
+    for (int i = 0; i < n0; ++i) { h3[3 * i] = kps[i].x; h3[3 * i + 1] = kps[i].y; h3[3 * i + 2] = kps[i].size; }
+    zmin.resize((size_t)n0);
+    HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_kps3, h3.data(), h3.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_min_depth(d_kps3, n0, d_depth, rows, cols, d_z, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(zmin.data(), d_z, (size_t)n0 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (min_depth) {  // removeDepthless with the neighbourhood depth (node.cpp:82)
+    size_t m = 0;
+    for (size_t i = 0; i < kps.size(); ++i) {
+      const KpOut& k = kps[i];
+      if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
+      if (std::isnan(zmin[i])) continue;
+      zmin[m] = zmin[i];
+      kps[m++] = k;
+    }
+    kps.resize(m);
+    zmin.resize(m);
+  } else {  // removeDepthless (node.cpp:67-97, :186)
     // one scattered read of the 1.2 MB depth image per keypoint: issue them all before the first is needed (the loop
     // below otherwise pays a cache miss per keypoint, ~100 us per frame)
     for (const KpOut& k : kps) {
@@ -1251,14 +1287,19 @@ static int detect_describe_frame(rgbdfe_ctx* ctx, const uint8_t* gray, const uin
     const std::pair<float, int> cut = r[(size_t)max_kp - 1];
     size_t m = 0;
     for (size_t i = 0; i < kps.size(); ++i)
-      if (!before(cut, std::make_pair(kps[i].response, (int)i))) kps[m++] = kps[i];
+      if (!before(cut, std::make_pair(kps[i].response, (int)i))) {
+        if (min_depth) zmin[m] = zmin[i];
+        kps[m++] = kps[i];
+      }
     kps.resize(m);
+    if (min_depth) zmin.resize(m);
   }
   // cv::ORB::compute (node.cpp:202) drops border keypoints and regroups the rest by octave, so projectTo3D (node.cpp:210)
   // is enqueued from inside compute(), once the final keypoint list exists: both ride on one synchronisation.
   // xy (2n floats) + depth.at<float>(round(y), round(x)) (n floats, node.cpp:942): 12 bytes per keypoint cross PCIe
   // instead of the 1.2 MB image.
   std::vector<uint8_t> desc;
+  std::vector<int> order;  // compute(): positions, in the list handed to it, of the keypoints it keeps, in output order
   std::vector<float> xyz_in_big, xyz_out_big;
   float* xyz_in = nullptr;
   float* xyz_out = nullptr;
@@ -1274,6 +1315,10 @@ static int detect_describe_frame(rgbdfe_ctx* ctx, const uint8_t* gray, const uin
     for (int i = 0; i < n; ++i) {
       xyz_in[2 * i] = kps[i].x;
       xyz_in[2 * i + 1] = kps[i].y;
+      if (min_depth) {  // node.cpp:940-941: the same neighbourhood depth as in removeDepthless
+        xyz_in[(size_t)2 * n + i] = zmin[(size_t)order[(size_t)i]];
+        continue;
+      }
       int r = (int)roundf(kps[i].y), c = (int)roundf(kps[i].x);
       r = r >= rows ? rows - 1 : r;
       c = c >= cols ? cols - 1 : c;
@@ -1291,7 +1336,7 @@ static int detect_describe_frame(rgbdfe_ctx* ctx, const uint8_t* gray, const uin
     return RGBDFE_OK;
   };
   lap(6);
-  rc = orb.compute(kps, desc, ctx->stream, err, enqueue_project);
+  rc = orb.compute(kps, desc, ctx->stream, err, enqueue_project, &order);
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
   if (tm) tq = orb_now_us();  // compute() books its own two slots
   const int n = (int)kps.size();
@@ -1601,6 +1646,62 @@ int rgbdfe_project_to_3d(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, cons
   // node.cpp:913-916: fxinv = float(1./fx) etc.
   launch_project_to_3d(d_kp, n_kp, d_depth, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
                        (float)cy, depth_scaling, max_keypoints, d_idx, d_xyz, d_n, ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(kept_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(xyz1, d_xyz, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *n_out = n;
+  return RGBDFE_OK;
+}
+
+int rgbdfe_set_feature_min_depth(rgbdfe_ctx* ctx, int32_t on) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->feature_min_depth = on != 0;
+  return RGBDFE_OK;
+}
+
+// removeDepthless / projectTo3D with "use_feature_min_depth" on (node.cpp:82, :940): the keypoint's depth is
+// getMinDepthInNeighborhood(depth, pt, size) (misc.cpp:774-793).  kp_size = cv::KeyPoint::size.
+int rgbdfe_project_to_3d_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, const float* kp_size, int32_t n_kp,
+                                   const float* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                   double cy, double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
+                                   float* xyz1, int32_t* n_out) {
+  if (!ctx || n_kp < 0 || rows < 1 || cols < 1 || !depth || !kept_idx || !xyz1 || !n_out || max_keypoints < 0 ||
+      (n_kp > 0 && (!kp_xy || !kp_size)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  *n_out = 0;
+  if (n_kp == 0 || max_keypoints == 0) return RGBDFE_OK;
+  const size_t b_kp = ((size_t)n_kp * 12 + 255) & ~(size_t)255;   // (x, y, size) for the neighbourhood kernel
+  const size_t b_xyz_in = ((size_t)n_kp * 12 + 255) & ~(size_t)255;  // x, y pairs followed by the n depths
+  const size_t b_depth = ((size_t)rows * cols * 4 + 255) & ~(size_t)255;
+  const size_t b_idx = ((size_t)n_kp * 4 + 255) & ~(size_t)255;
+  const size_t b_xyz = ((size_t)n_kp * 16 + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, b_kp + b_xyz_in + b_depth + b_idx + b_xyz + 256);
+  if (rc != RGBDFE_OK) return rc;
+  char* base = (char*)ctx->d_scratch;
+  float* d_kp3 = (float*)base;
+  float* d_in = (float*)(base + b_kp);
+  float* d_depth = (float*)(base + b_kp + b_xyz_in);
+  int32_t* d_idx = (int32_t*)(base + b_kp + b_xyz_in + b_depth);
+  float4* d_xyz = (float4*)(base + b_kp + b_xyz_in + b_depth + b_idx);
+  int32_t* d_n = (int32_t*)(base + b_kp + b_xyz_in + b_depth + b_idx + b_xyz);
+  std::vector<float> h3((size_t)n_kp * 3);
+  for (int32_t i = 0; i < n_kp; ++i) { h3[3 * i] = kp_xy[2 * i]; h3[3 * i + 1] = kp_xy[2 * i + 1]; h3[3 * i + 2] = kp_size[i]; }
+  HIP_TRY(ctx, hipMemcpyAsync(d_kp3, h3.data(), h3.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, kp_xy, (size_t)n_kp * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 4, hipMemcpyHostToDevice, ctx->stream));
+  launch_min_depth(d_kp3, n_kp, d_depth, rows, cols, d_in + (size_t)2 * n_kp, ctx->stream);
+  // projectTo3D proper, with the looked-up depths (its own gather is bypassed): node.cpp:913-916 for the intrinsics
+  launch_project_to_3d(d_in, n_kp, nullptr, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx, (float)cy,
+                       depth_scaling, max_keypoints, d_idx, d_xyz, d_n, ctx->stream, false, d_in + (size_t)2 * n_kp);
   HIP_TRY(ctx, hipGetLastError());
   int32_t n = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2713,6 +2814,20 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe(c, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling,
                                                         keypoints, descriptors, xyz1, n_out));
+}
+
+int rgbdfe_set_feature_min_depth(rgbdfe_ctx* ctx, int32_t on) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_set_feature_min_depth(c, on));
+}
+
+int rgbdfe_project_to_3d_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, const float* kp_size, int32_t n_kp,
+                                   const float* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                   double cy, double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
+                                   float* xyz1, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_project_to_3d_min_depth(c, kp_xy, kp_size, n_kp, depth, rows, cols, fx, fy, cx, cy,
+                                                                depth_scaling, max_keypoints, kept_idx, xyz1, n_out));
 }
 
 int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,

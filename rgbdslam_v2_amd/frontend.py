@@ -280,6 +280,24 @@ class FrontEnd:
             xyz.ctypes.data, C.byref(n)))
         return kp[: n.value].copy(), desc[: n.value].copy(), xyz[: n.value].copy()
 
+    def set_feature_min_depth(self, on: bool):
+        """Parameter "use_feature_min_depth" (parameter_server.cpp:90) for detect_describe(_batch)."""
+        self._check(self._L.rgbdfe_set_feature_min_depth(self._ctx, 1 if on else 0))
+
+    def project_to_3d_min_depth(self, kp_xy, kp_size, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000):
+        """projectTo3D with use_feature_min_depth (node.cpp:940): returns (kept_idx, xyz1)."""
+        kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+        kp_size = np.ascontiguousarray(kp_size, np.float32)
+        depth = np.ascontiguousarray(depth, np.float32)
+        n = kp_xy.shape[0]
+        kept = np.zeros(max(n, 1), np.int32)
+        xyz = np.zeros((max(n, 1), 4), np.float32)
+        k = C.c_int32(0)
+        self._check(self._L.rgbdfe_project_to_3d_min_depth(
+            self._ctx, kp_xy.ctypes.data, kp_size.ctypes.data, n, depth.ctypes.data, depth.shape[0], depth.shape[1],
+            fx, fy, cx, cy, depth_scaling, max_keypoints, kept.ctypes.data, xyz.ctypes.data, C.byref(k)))
+        return kept[: k.value].copy(), xyz[: k.value].copy()
+
     def detect_describe_batch(self, grays, masks, depths, fx, fy, cx, cy, depth_scaling=1.0):
         """A run of frames through the same detector state, in order (rgbdfe_detect_describe_batch): the results of
         calling detect_describe frame by frame, with frame k+1's upload overlapped with frame k's detection.

@@ -122,3 +122,54 @@ def test_point_cloud_constructor_feature_path():
         assert np.array_equal(xyz, pxyz[order])
         assert np.array_equal(fe.detector_thresholds(), np.array(st.thresh[:9]))
     fe.close()
+
+
+def test_use_feature_min_depth_mode():
+    """The default-off variant of rows a4 / a7 (parameter "use_feature_min_depth"): the neighbourhood minimum of
+    getMinDepthInNeighborhood (misc.cpp:774-793) on the device, in the A/B entry point and in the whole Node::Node feature
+    path (removeDepthless, retainBest, compute, projectTo3D with the keypoints' own sizes)."""
+    from oracle import pyorb
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    rng = np.random.default_rng(41)
+    fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=1024, max_pairs_per_batch=8)
+    for rows, cols, n, maxk, scale in ((480, 640, 1500, 1000, 1.0), (120, 160, 600, 1000, 0.5), (48, 64, 300, 40, 1.0)):
+        depth = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+        depth[rng.random((rows, cols)) < 0.3] = np.nan
+        depth[10:40, 20:50] = np.nan
+        depth[5, 7] = 0.0
+        kp = np.stack([rng.uniform(-3, cols + 3, n), rng.uniform(-3, rows + 3, n)], 1).astype(np.float32)
+        size = (31.0 * 1.2 ** rng.integers(0, 8, n)).astype(np.float32)
+        size[:10] = [1.0, 2.0, 2.9, 3.0, 0.5] * 2
+        f = 525.0 * cols / 640
+        K = (f, f * 1.01, (cols - 1) / 2, (rows - 1) / 2)
+        kept, xyz = fe.project_to_3d_min_depth(kp, size, depth, *K, scale, maxk)
+        okept, oxyz = po.project_to_3d_min_depth(kp, size, depth, *K, scale, maxk)
+        assert np.array_equal(kept, okept) and np.array_equal(xyz, oxyz) and 0 < len(kept) <= maxk
+    # the frame path: depth with holes, so that the two modes keep different keypoints
+    fr = synth.make_image_sequence(n_frames=3, seed=5)
+    K = (fr["fx"], fr["fy"], fr["cx"], fr["cy"])
+    fe.detector_configure(max_keypoints=1000)
+    fe.set_feature_min_depth(True)
+    pyorb.set_use_feature_min_depth(True)
+    try:
+        st = pyorb.grid_state(1000)
+        for f in range(3):
+            g = fr["gray"][f]
+            d = fr["depth"][f].copy()
+            d[rng.random(d.shape) < 0.2] = np.nan
+            m = np.full(g.shape, 255, np.uint8)
+            kp, desc, xyz = fe.detect_describe(g, m, d, *K)
+            rk, rdesc = pyorb.node_features(st, g, m, d, 1000)
+            assert len(kp) == len(rk) and np.array_equal(kp["x"], rk["x"]) and np.array_equal(kp["y"], rk["y"])
+            assert np.array_equal(desc, rdesc)
+            okept, oxyz = po.project_to_3d_min_depth(np.stack([rk["x"], rk["y"]], 1), rk["size"], d, *K, 1.0, 1000)
+            assert len(okept) == len(rk) and np.array_equal(xyz, oxyz)
+            plain, _ = po.project_to_3d(np.stack([rk["x"], rk["y"]], 1), d, *K, 1.0, 1000)
+            assert len(plain) < len(rk)          # the neighbourhood depth rescues keypoints on NaN pixels
+    finally:
+        pyorb.set_use_feature_min_depth(False)
+        fe.set_feature_min_depth(False)
+    kp2, _, _ = fe.detect_describe(fr["gray"][0], np.full(fr["gray"][0].shape, 255, np.uint8), fr["depth"][0], *K)
+    assert len(kp2) > 100
+    fe.close()

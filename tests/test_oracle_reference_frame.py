@@ -137,3 +137,40 @@ def test_project_to_3d_cloud_on_reference_code():
         okept, oxyz = po.project_to_3d_cloud(kp, cloud, maxd, maxk)
         assert k == len(okept) and np.array_equal(kept[:k], okept) and np.array_equal(xyz[:k], oxyz)
         assert maxd < 0 or k > 0
+
+
+def test_use_feature_min_depth_on_reference_code():
+    """The default-off variant of rows a4 / a7 ("use_feature_min_depth", parameter_server.cpp:90): getMinDepthInNeighborhood
+    (misc.cpp:774-793) compiled from the source, inside removeDepthless (node.cpp:82) and Node::projectTo3D (:940) with
+    the parameter switched on.  (cv::minMaxLoc is a stand-in: its NaN / empty-window behaviour is restated.)"""
+    rng = np.random.default_rng(33)
+    R.ref_min_depth_in_neighborhood.restype = C.c_float
+    R.ref_min_depth_in_neighborhood.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    for rows, cols, n, maxk, scale in ((120, 160, 600, 1000, 1.0), (48, 64, 300, 40, 0.5)):
+        depth = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+        depth[rng.random((rows, cols)) < 0.3] = np.nan
+        depth[10:40, 20:50] = np.nan            # windows without a single valid depth
+        depth[5, 7] = 0.0                       # a zero minimum becomes NaN (:786-789)
+        kp = np.stack([rng.uniform(-3, cols + 3, n), rng.uniform(-3, rows + 3, n)], 1).astype(np.float32)
+        size = (31.0 * 1.2 ** rng.integers(0, 8, n)).astype(np.float32)
+        size[:20] = [1.0, 2.0, 2.9, 3.0, 0.5] * 4   # radius 0: an empty window
+        kp[7] = [7.2, 5.4]
+        for i in range(0, n, 7):
+            a = R.ref_min_depth_in_neighborhood(_p(depth), rows, cols, float(kp[i, 0]), float(kp[i, 1]), float(size[i]))
+            b = po.min_depth_in_neighborhood(depth, float(kp[i, 0]), float(kp[i, 1]), float(size[i]))
+            assert (np.isnan(a) and np.isnan(b)) or np.float32(a) == np.float32(b)
+        f = 525.0 * cols / 640
+        K = (f, f * 1.01, (cols - 1) / 2, (rows - 1) / 2)
+        kept = np.zeros(n, np.int32)
+        xyz = np.zeros((n, 4), np.float32)
+        k = R.ref_project_to_3d_min_depth(_p(kp), _p(size), n, _p(depth), rows, cols, C.c_double(K[0]), C.c_double(K[1]),
+                                          C.c_double(K[2]), C.c_double(K[3]), C.c_double(scale), maxk, _p(kept), _p(xyz))
+        okept, oxyz = po.project_to_3d_min_depth(kp, size, depth, *K, scale, maxk)
+        assert k == len(okept) and np.array_equal(kept[:k], okept) and np.array_equal(xyz[:k], oxyz)
+        assert 0 < k <= maxk
+        k2 = R.ref_remove_depthless_min_depth(_p(kp), _p(size), n, _p(depth), rows, cols, _p(kept))
+        okept2 = po.remove_depthless_min_depth(kp, size, depth)
+        assert np.array_equal(kept[:k2], okept2)
+        # and it differs from the plain lookup (more keypoints survive: a NaN pixel has valid neighbours)
+        plain, _ = po.project_to_3d(kp, depth, *K, 1.0, 10 ** 9)
+        assert len(okept2) != len(plain)
