@@ -646,7 +646,24 @@ static int remove_depthless(orb_keypoint* kp, int n, const float* depth, int row
   return m;
 }
 
-extern float orc_min_depth_in_neighborhood(const float* depth, int rows, int cols, float cx, float cy, float diameter);
+/* getMinDepthInNeighborhood (misc.cpp:774-793); the same restatement as rgbd_oracle.c's orc_min_depth_in_neighborhood
+ * (which is the one pinned on the reference function) -- repeated here because this file is also linked on its own. */
+static float orc_min_depth_in_neighborhood(const float* depth, int rows, int cols, float cx, float cy, float diameter) {
+  const int radius = (int)((diameter - 1) / 2);
+  int top = (int)(cy - (float)radius); top = top < 0 ? 0 : top;
+  int left = (int)(cx - (float)radius); left = left < 0 ? 0 : left;
+  int bot = (int)(cy + (float)radius); bot = bot > rows ? rows : bot;
+  int right = (int)(cx + (float)radius); right = right > cols ? cols : right;
+  float minv = 3.402823466e+38f;
+  int found = 0;
+  for (int r = top; r < bot; ++r)
+    for (int c = left; c < right; ++c) {
+      const float v = depth[(size_t)r * (size_t)cols + (size_t)c];
+      if (v < minv) { minv = v; found = 1; }
+    }
+  if (!found || minv == 0.0f) return NAN;
+  return minv;
+}
 static int remove_depthless_min_depth(orb_keypoint* kp, int n, const float* depth, int rows, int cols) {
   int m = 0;  /* node.cpp:82: Z = getMinDepthInNeighborhood(depth, p2d, size) */
   for (int i = 0; i < n; ++i) {
