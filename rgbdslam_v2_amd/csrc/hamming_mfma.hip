@@ -33,9 +33,15 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int kQT = 2;                      // 32-query operand tiles per wave
+#ifndef RGBDFE_HAMMING_QT
+#define RGBDFE_HAMMING_QT 2
+#endif
+#ifndef RGBDFE_HAMMING_STAGE
+#define RGBDFE_HAMMING_STAGE 4
+#endif
+constexpr int kQT = RGBDFE_HAMMING_QT;          // 32-query operand tiles per wave
 constexpr int kQueriesPerBlock = 4 * kQT * 32;  // 256
-constexpr int kStage = 4;                   // train tiles (of 32 rows, 4 KB each) per LDS stage
+constexpr int kStage = RGBDFE_HAMMING_STAGE;    // train tiles (of 32 rows, 4 KB each) per LDS stage
 constexpr float kNone = 3.0e38f;
 constexpr float kRowUnit = 1.0f / 16384.0f;  // 2^-14
 
