@@ -41,6 +41,13 @@ struct OrbWorkspace {
   // so that the caller's own launches on the stream ride on the same round trip
   int compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
               const std::function<int()>& enqueue_more = nullptr, std::vector<int>* order_out = nullptr);
+  // the same in two halves (enqueue everything on s / wait and fill desc)
+  int compute_enqueue(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
+                      const std::function<int()>& enqueue_more = nullptr, std::vector<int>* order_out = nullptr);
+  int compute_finish(std::vector<uint8_t>& desc, hipStream_t s, std::string& err);
+  int cmp_n = 0;
+  uint8_t* cmp_stage = nullptr;
+  std::vector<DescKp> cmp_dk_big;
   // (order_out: the positions, in the input list, of the keypoints that survive compute()'s border filter, in the
   // level-grouped order of the output)
 
@@ -67,6 +74,7 @@ struct OrbWorkspace {
   RawKp* d_kps = nullptr; DescKp* d_desckp = nullptr; uint8_t* d_desc = nullptr;
   float* d_kpxy = nullptr; int32_t* d_kept = nullptr; float4* d_xyz = nullptr;
   int32_t* d_n = nullptr;
+  int32_t* d_n_proj = nullptr; int32_t* h_n_proj = nullptr;  // projectTo3D's count (its own: it may run beside a detection pass)
   // pinned host staging for the small per-frame transfers (thresholds, counts, keypoints, descriptors, 3-D points):
   // pageable copies of a few hundred bytes cost 10-20 us each and there are a dozen per frame
   int last_n_total = 0;  // keypoints of the latest detection pass: sizes the next pass's speculative read-back

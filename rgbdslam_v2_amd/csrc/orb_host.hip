@@ -112,9 +112,9 @@ void OrbWorkspace::release() {
   d_pool = nullptr; d_blur = nullptr; h_img = nullptr;
   fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr);
   fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_kpxy);
-  fr(d_kept); fr(d_xyz); fr(d_n);
+  fr(d_kept); fr(d_xyz); fr(d_n); fr(d_n_proj);
   auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n);
+  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n); frh(h_n_proj);
   d_active = nullptr;  // lives inside d_thr
   W = H = 0;
 }
@@ -237,6 +237,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMalloc((void**)&d_kept, sizeof(int32_t) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_xyz, sizeof(float4) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_n, sizeof(int32_t)));
+  ORB_HIP(hipMalloc((void**)&d_n_proj, sizeof(int32_t)));
   pin_cap = std::min(kp_cap, 16384);
   ORB_HIP(hipHostMalloc((void**)&h_ctl, sizeof(int) * 128, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_totals, sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
@@ -247,6 +248,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipHostMalloc((void**)&h_xyz_in, sizeof(float) * 3 * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_xyz_out, sizeof(float) * 4 * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_n, sizeof(int32_t), hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_n_proj, sizeof(int32_t), hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_img, (size_t)2 * W * H, hipHostMallocDefault));
   himg_set[0] = h_img;
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
@@ -487,8 +489,12 @@ int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::strin
 }
 
 // cv::ORB::create()->compute (features.cpp:117-119): border filter, regroup by level, rBRIEF
-int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
-                          const std::function<int()>& enqueue_more, std::vector<int>* order_out) {
+// compute() in two halves, so that a caller can do other work between the enqueue and the wait (the batch entry point
+// overlaps a frame's description with the next frame's detection): compute_enqueue filters and regroups the keypoints,
+// enqueues the descriptor kernel and the read-back on `s` (plus the caller's enqueue_more); compute_finish waits and
+// fills `desc` (sized by compute_enqueue).
+int OrbWorkspace::compute_enqueue(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
+                                  const std::function<int()>& enqueue_more, std::vector<int>* order_out) {
   // KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31), then the stable regroup by level (orb.cpp:
   // !sortedByLevel branch); `order` = the surviving input positions in output order
   const double tc0 = timing.on ? orb_now_us() : 0;
@@ -515,12 +521,14 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
   if (order_out) *order_out = order;
   const int n = (int)kps.size();
   desc.assign((size_t)n * 32, 0);
+  cmp_n = n;
+  cmp_stage = nullptr;
   if (n == 0) return RGBDFE_OK;
   if (n > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
-  std::vector<DescKp> dk_big;
   DescKp* dk = h_desckp;
   uint8_t* desc_stage = h_desc;
-  if (n > pin_cap) { dk_big.resize((size_t)n); dk = dk_big.data(); desc_stage = desc.data(); }
+  if (n > pin_cap) { cmp_dk_big.resize((size_t)n); dk = cmp_dk_big.data(); desc_stage = desc.data(); }
+  cmp_stage = desc_stage;
   for (int j = 0; j < n; ++j) {
     const KpOut& k = kps[j];
     const float sc = 1.f / scale[k.octave];
@@ -540,14 +548,24 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
     const int rc = enqueue_more();
     if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(s); err = "enqueue after compute failed"; return rc; }
   }
+  if (timing.on) timing.us[7] += orb_now_us() - tc0;
+  return RGBDFE_OK;
+}
+
+int OrbWorkspace::compute_finish(std::vector<uint8_t>& desc, hipStream_t s, std::string& err) {
+  if (cmp_n == 0) return RGBDFE_OK;
   const double tc1 = timing.on ? orb_now_us() : 0;
   ORB_HIP(hipStreamSynchronize(s));
-  if (timing.on) {
-    timing.us[7] += tc1 - tc0;
-    timing.us[8] += orb_now_us() - tc1;
-  }
-  if (desc_stage != desc.data()) memcpy(desc.data(), desc_stage, (size_t)n * 32);
+  if (timing.on) timing.us[8] += orb_now_us() - tc1;
+  if (cmp_stage && cmp_stage != desc.data()) memcpy(desc.data(), cmp_stage, (size_t)cmp_n * 32);
   return RGBDFE_OK;
+}
+
+int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,
+                          const std::function<int()>& enqueue_more, std::vector<int>* order_out) {
+  const int rc = compute_enqueue(kps, desc, s, err, enqueue_more, order_out);
+  if (rc != RGBDFE_OK) return rc;
+  return compute_finish(desc, s, err);
 }
 
 }  // namespace rgbdfe

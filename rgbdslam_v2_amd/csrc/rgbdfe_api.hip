@@ -93,6 +93,7 @@ struct rgbdfe_ctx {
                                // MFMA fragment order per tile of 32 rows (hamming_mfma.hip)
   float* d_kp2d = nullptr;     // max_nodes x max_kp x 2: KeyPoint.pt (allocated with the first rgbdfe_upload_node_keypoints)
   hipStream_t orb_upload_stream = nullptr;  // rgbdfe_detect_describe_batch: uploads of frame k+1 beside frame k
+  hipStream_t orb_compute_stream = nullptr; // ... and frame k's description beside frame k+1's detection
   hipEvent_t orb_upload_done[2] = {nullptr, nullptr};
   bool feature_min_depth = false;  // "use_feature_min_depth" (parameter_server.cpp:90): rgbdfe_set_feature_min_depth
   bool sift_fast = true;       // sift_match.hip's float keys where a pair qualifies (RGBDFE_SIFT_FAST_KEYS=0: never)
@@ -659,6 +660,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (hipEvent_t e : ctx->orb_upload_done) if (e) (void)hipEventDestroy(e);
   if (ctx->orb_upload_stream) (void)hipStreamDestroy(ctx->orb_upload_stream);
+  if (ctx->orb_compute_stream) (void)hipStreamDestroy(ctx->orb_compute_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1165,193 +1167,218 @@ int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32
   return RGBDFE_OK;
 }
 
-// One frame of Node::Node's feature path; the caller holds the lock.  uploaded: the frame's images and pyramid are already
-// in the workspace's current set (rgbdfe_detect_describe_batch); prefetch: host work to do while the first detection pass
-// of this frame runs on the device (the next frame's upload).
-static int detect_describe_frame(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
-                                 int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
-                                 double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
-                                 float* xyz1, int32_t* n_out, bool uploaded, const std::function<int()>& prefetch) {
-  OrbWorkspace& orb = ctx->orb;
-  const int max_kp = ctx->orb_max_keypoints;
-  std::string err;
-  static const bool timing_env = getenv("RGBDFE_DETECT_TIMING") && atoi(getenv("RGBDFE_DETECT_TIMING")) != 0;
-  orb.timing.on = timing_env;
-  const bool tm = timing_env;
-  double tq = tm ? orb_now_us() : 0;
-  auto lap = [&](int slot) {
-    if (!tm) return;
-    const double now = orb_now_us();
-    orb.timing.us[slot] += now - tq;
-    tq = now;
-  };
-  int rc = orb.prepare(cols, rows, true, err);
-  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
-  // hasNonZero(sub_mask) per cell (feature_adjuster.cpp:175-183)
-  orb.cell_mask_nonzero.assign((size_t)orb.n_cells, mask ? 0 : 1);
-  if (mask)
-    for (int c = 0; c < orb.n_cells; ++c) {
-      const OrbWorkspace::Cell& ce = orb.cells[c];
-      char nz = 0;
-      for (int y = 0; y < ce.h && !nz; ++y) {
-        const uint8_t* r = mask + (size_t)(ce.y0 + y) * cols + ce.x0;
-        for (int x = 0; x < ce.w; ++x)
-          if (r[x]) { nz = 1; break; }
-      }
-      orb.cell_mask_nonzero[c] = nz;
-    }
-  // the depth image stays on the host: removeDepthless and projectTo3D look at one pixel per keypoint
-  lap(0);
-  if (!uploaded) rc = orb.upload_and_build(gray, mask, ctx->stream, err);
-  lap(1);
-  orb.before_wait = prefetch;
+// One frame of Node::Node's feature path in three stages; the caller holds the lock.
+//   detect()            detector grid + threshold adaptation (node.cpp:160) on ctx->stream: the frame's keypoints
+//   describe_enqueue()  removeDepthless, retainBest, cv::ORB::compute and projectTo3D (:186-210) enqueued on a stream
+//   finish()            wait for that stream, hand the results out
+// A single call runs them back to back on one stream; rgbdfe_detect_describe_batch runs describe_enqueue of frame k while
+// the device executes the detection pass of frame k + 1 (another stream, the other image set).
+struct DetectFrame {
+  rgbdfe_ctx* ctx = nullptr;
+  const uint8_t* gray = nullptr; const uint8_t* mask = nullptr; const float* depth = nullptr;
+  int32_t rows = 0, cols = 0;
+  double fx = 0, fy = 0, cx = 0, cy = 0, depth_scaling = 1;
+  rgbdfe_keypoint* keypoints = nullptr; uint8_t* descriptors = nullptr; float* xyz1 = nullptr; int32_t* n_out = nullptr;
   std::vector<KpOut> kps;
-  const double pass_before = tm ? orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] : 0;
-  if (rc == RGBDFE_OK) rc = orb.grid_detect(kps, ctx->stream, err);  // node.cpp:160
-  if (rc == RGBDFE_OK && orb.before_wait) {  // (cannot happen: a frame has at least one pass) -- never lose the prefetch
-    std::function<int()> f = std::move(orb.before_wait);
-    orb.before_wait = nullptr;
-    rc = f();
-  }
-  orb.before_wait = nullptr;
-  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
-  if (tm) {  // grid_detect minus its detection passes = the adjuster logic + the per-cell merge
-    const double now = orb_now_us();
-    orb.timing.us[5] += (now - tq) - (orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] - pass_before);
-    tq = now;
-  }
-  // "use_feature_min_depth" (parameter_server.cpp:90, rgbdfe_set_feature_min_depth): a keypoint's depth is the nearest valid
-  // depth of its neighbourhood (getMinDepthInNeighborhood, misc.cpp:774-793) -- looked up on the device for all keypoints
-  // at once (the depth image is uploaded in this mode only) and carried along with the keypoints from here on.
   std::vector<float> zmin;
-  const bool min_depth = ctx->feature_min_depth;
-  if (min_depth && !kps.empty()) {
-    const int n0 = (int)kps.size();
-    const size_t b_depth = ((size_t)rows * cols * 4 + 255) & ~(size_t)255;
-    const size_t b_kp = ((size_t)n0 * 12 + 255) & ~(size_t)255;
-    rc = ensure_scratch(ctx, b_depth + b_kp + (size_t)n0 * 4 + 256);
-    if (rc != RGBDFE_OK) return rc;
-    float* d_depth = (float*)ctx->d_scratch;
-    float* d_kps3 = (float*)((char*)ctx->d_scratch + b_depth);
-    float* d_z = (float*)((char*)ctx->d_scratch + b_depth + b_kp);
-    std::vector<float> h3((size_t)n0 * 3);
-    for (int i = 0; i < n0; ++i) { h3[3 * i] = kps[i].x; h3[3 * i + 1] = kps[i].y; h3[3 * i + 2] = kps[i].size; }
-    zmin.resize((size_t)n0);
-    HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_kps3, h3.data(), h3.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    launch_min_depth(d_kps3, n0, d_depth, rows, cols, d_z, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(zmin.data(), d_z, (size_t)n0 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  if (min_depth) {  // removeDepthless with the neighbourhood depth (node.cpp:82)
-    size_t m = 0;
-    for (size_t i = 0; i < kps.size(); ++i) {
-      const KpOut& k = kps[i];
-      if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
-      if (std::isnan(zmin[i])) continue;
-      zmin[m] = zmin[i];
-      kps[m++] = k;
-    }
-    kps.resize(m);
-    zmin.resize(m);
-  } else {  // removeDepthless (node.cpp:67-97, :186)
-    // one scattered read of the 1.2 MB depth image per keypoint: issue them all before the first is needed (the loop
-    // below otherwise pays a cache miss per keypoint, ~100 us per frame)
-    for (const KpOut& k : kps) {
-      if (!(k.x >= 0 && k.x < (float)cols && k.y >= 0 && k.y < (float)rows)) continue;
-      int r = (int)roundf(k.y), c = (int)roundf(k.x);
-      r = r >= rows ? rows - 1 : r;
-      c = c >= cols ? cols - 1 : c;
-      __builtin_prefetch(depth + (size_t)r * cols + c, 0, 1);
-    }
-    size_t m = 0;
-    for (const KpOut& k : kps) {
-      if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
-      int r = (int)roundf(k.y), c = (int)roundf(k.x);
-      r = r >= rows ? rows - 1 : r;
-      c = c >= cols ? cols - 1 : c;
-      if (std::isnan(depth[(size_t)r * cols + c])) continue;
-      kps[m++] = k;
-    }
-    kps.resize(m);
-  }
-  if ((int)kps.size() > max_kp) {  // retainBest(max_keypoints) + resize (node.cpp:188-191)
-    // the max_kp first of the order (response descending, position ascending), in their original order: a selection
-    std::vector<std::pair<float, int>> r(kps.size());
-    for (size_t i = 0; i < kps.size(); ++i) r[i] = std::make_pair(kps[i].response, (int)i);
-    auto before = [](const std::pair<float, int>& a, const std::pair<float, int>& b) {
-      return a.first > b.first || (a.first == b.first && a.second < b.second);
-    };
-    std::nth_element(r.begin(), r.begin() + (max_kp - 1), r.end(), before);
-    const std::pair<float, int> cut = r[(size_t)max_kp - 1];
-    size_t m = 0;
-    for (size_t i = 0; i < kps.size(); ++i)
-      if (!before(cut, std::make_pair(kps[i].response, (int)i))) {
-        if (min_depth) zmin[m] = zmin[i];
-        kps[m++] = kps[i];
-      }
-    kps.resize(m);
-    if (min_depth) zmin.resize(m);
-  }
-  // cv::ORB::compute (node.cpp:202) drops border keypoints and regroups the rest by octave, so projectTo3D (node.cpp:210)
-  // is enqueued from inside compute(), once the final keypoint list exists: both ride on one synchronisation.
-  // xy (2n floats) + depth.at<float>(round(y), round(x)) (n floats, node.cpp:942): 12 bytes per keypoint cross PCIe
-  // instead of the 1.2 MB image.
   std::vector<uint8_t> desc;
   std::vector<int> order;  // compute(): positions, in the list handed to it, of the keypoints it keeps, in output order
   std::vector<float> xyz_in_big, xyz_out_big;
-  float* xyz_in = nullptr;
   float* xyz_out = nullptr;
-  auto enqueue_project = [&]() -> int {
-    const int n = (int)kps.size();
-    if (n == 0) return RGBDFE_OK;
-    xyz_in = orb.h_xyz_in;
-    xyz_out = orb.h_xyz_out;
-    if (n > orb.pin_cap) {
-      xyz_in_big.resize((size_t)n * 3); xyz_out_big.resize((size_t)n * 4);
-      xyz_in = xyz_in_big.data(); xyz_out = xyz_out_big.data();
-    }
-    for (int i = 0; i < n; ++i) {
-      xyz_in[2 * i] = kps[i].x;
-      xyz_in[2 * i + 1] = kps[i].y;
-      if (min_depth) {  // node.cpp:940-941: the same neighbourhood depth as in removeDepthless
-        xyz_in[(size_t)2 * n + i] = zmin[(size_t)order[(size_t)i]];
-        continue;
-      }
-      int r = (int)roundf(kps[i].y), c = (int)roundf(kps[i].x);
-      r = r >= rows ? rows - 1 : r;
-      c = c >= cols ? cols - 1 : c;
-      xyz_in[(size_t)2 * n + i] = depth[(size_t)r * cols + c];
-    }
-    if (hipMemcpyAsync(orb.d_kpxy, xyz_in, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-      return RGBDFE_ERR_HIP;
-    launch_project_to_3d(orb.d_kpxy, n, nullptr, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
-                         (float)cy, depth_scaling, max_kp, orb.d_kept, orb.d_xyz, orb.d_n, ctx->stream, false,
-                         orb.d_kpxy + (size_t)2 * n);
-    if (hipGetLastError() != hipSuccess) return RGBDFE_ERR_HIP;
-    if (hipMemcpyAsync(orb.h_n, orb.d_n, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(xyz_out, orb.d_xyz, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-      return RGBDFE_ERR_HIP;
-    return RGBDFE_OK;
-  };
-  lap(6);
-  rc = orb.compute(kps, desc, ctx->stream, err, enqueue_project, &order);
-  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
-  if (tm) tq = orb_now_us();  // compute() books its own two slots
-  const int n = (int)kps.size();
-  *n_out = 0;
-  if (n > 0) {
-    if (*orb.h_n != n) return fail(ctx, RGBDFE_ERR_HIP, "projectTo3D dropped keypoints that removeDepthless kept");
-    memcpy(xyz1, xyz_out, sizeof(float) * 4 * (size_t)n);
+  bool tm = false;
+  double tq = 0;
+  void lap(int slot) {
+    if (!tm) return;
+    const double now = orb_now_us();
+    ctx->orb.timing.us[slot] += now - tq;
+    tq = now;
   }
-  kp_to_abi(kps, keypoints);
-  if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());
-  *n_out = n;
-  lap(9);
-  if (tm) orb.timing.frames++;
-  return RGBDFE_OK;
-}
+
+  int detect(bool uploaded, const std::function<int()>& prefetch) {
+    OrbWorkspace& orb = ctx->orb;
+    std::string err;
+    static const bool timing_env = getenv("RGBDFE_DETECT_TIMING") && atoi(getenv("RGBDFE_DETECT_TIMING")) != 0;
+    orb.timing.on = timing_env;
+    tm = timing_env;
+    tq = tm ? orb_now_us() : 0;
+    int rc = orb.prepare(cols, rows, true, err);
+    if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+    // hasNonZero(sub_mask) per cell (feature_adjuster.cpp:175-183)
+    orb.cell_mask_nonzero.assign((size_t)orb.n_cells, mask ? 0 : 1);
+    if (mask)
+      for (int c = 0; c < orb.n_cells; ++c) {
+        const OrbWorkspace::Cell& ce = orb.cells[c];
+        char nz = 0;
+        for (int y = 0; y < ce.h && !nz; ++y) {
+          const uint8_t* r = mask + (size_t)(ce.y0 + y) * cols + ce.x0;
+          for (int x = 0; x < ce.w; ++x)
+            if (r[x]) { nz = 1; break; }
+        }
+        orb.cell_mask_nonzero[c] = nz;
+      }
+    // the depth image stays on the host: removeDepthless and projectTo3D look at one pixel per keypoint
+    lap(0);
+    if (!uploaded) rc = orb.upload_and_build(gray, mask, ctx->stream, err);
+    lap(1);
+    orb.before_wait = prefetch;
+    const double pass_before = tm ? orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] : 0;
+    if (rc == RGBDFE_OK) rc = orb.grid_detect(kps, ctx->stream, err);  // node.cpp:160
+    if (rc == RGBDFE_OK && orb.before_wait) {  // (cannot happen: a frame has at least one pass) -- never lose the hook
+      std::function<int()> f = std::move(orb.before_wait);
+      orb.before_wait = nullptr;
+      rc = f();
+    }
+    orb.before_wait = nullptr;
+    if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+    if (tm) {  // grid_detect minus its detection passes = the adjuster logic + the per-cell merge
+      const double now = orb_now_us();
+      orb.timing.us[5] += (now - tq) - (orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] - pass_before);
+      tq = now;
+    }
+    return RGBDFE_OK;
+  }
+
+  int describe_enqueue(hipStream_t st) {
+    OrbWorkspace& orb = ctx->orb;
+    const int max_kp = ctx->orb_max_keypoints;
+    std::string err;
+    int rc = RGBDFE_OK;
+    if (tm) tq = orb_now_us();
+    // "use_feature_min_depth" (parameter_server.cpp:90, rgbdfe_set_feature_min_depth): a keypoint's depth is the nearest
+    // valid depth of its neighbourhood (getMinDepthInNeighborhood, misc.cpp:774-793) -- looked up on the device for all
+    // keypoints at once (the depth image is uploaded in this mode only) and carried along with the keypoints from here on.
+    const bool min_depth = ctx->feature_min_depth;
+    if (min_depth && !kps.empty()) {
+      const int n0 = (int)kps.size();
+      const size_t b_depth = ((size_t)rows * cols * 4 + 255) & ~(size_t)255;
+      const size_t b_kp = ((size_t)n0 * 12 + 255) & ~(size_t)255;
+      rc = ensure_scratch(ctx, b_depth + b_kp + (size_t)n0 * 4 + 256);
+      if (rc != RGBDFE_OK) return rc;
+      float* d_depth = (float*)ctx->d_scratch;
+      float* d_kps3 = (float*)((char*)ctx->d_scratch + b_depth);
+      float* d_z = (float*)((char*)ctx->d_scratch + b_depth + b_kp);
+      std::vector<float> h3((size_t)n0 * 3);
+      for (int i = 0; i < n0; ++i) { h3[3 * i] = kps[i].x; h3[3 * i + 1] = kps[i].y; h3[3 * i + 2] = kps[i].size; }
+      zmin.resize((size_t)n0);
+      HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(d_kps3, h3.data(), h3.size() * 4, hipMemcpyHostToDevice, st));
+      launch_min_depth(d_kps3, n0, d_depth, rows, cols, d_z, st);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemcpyAsync(zmin.data(), d_z, (size_t)n0 * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    if (min_depth) {  // removeDepthless with the neighbourhood depth (node.cpp:82)
+      size_t m = 0;
+      for (size_t i = 0; i < kps.size(); ++i) {
+        const KpOut& k = kps[i];
+        if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
+        if (std::isnan(zmin[i])) continue;
+        zmin[m] = zmin[i];
+        kps[m++] = k;
+      }
+      kps.resize(m);
+      zmin.resize(m);
+    } else {  // removeDepthless (node.cpp:67-97, :186)
+      // one scattered read of the 1.2 MB depth image per keypoint: issue them all before the first is needed (the loop
+      // below otherwise pays a cache miss per keypoint, ~100 us per frame)
+      for (const KpOut& k : kps) {
+        if (!(k.x >= 0 && k.x < (float)cols && k.y >= 0 && k.y < (float)rows)) continue;
+        int r = (int)roundf(k.y), c = (int)roundf(k.x);
+        r = r >= rows ? rows - 1 : r;
+        c = c >= cols ? cols - 1 : c;
+        __builtin_prefetch(depth + (size_t)r * cols + c, 0, 1);
+      }
+      size_t m = 0;
+      for (const KpOut& k : kps) {
+        if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
+        int r = (int)roundf(k.y), c = (int)roundf(k.x);
+        r = r >= rows ? rows - 1 : r;
+        c = c >= cols ? cols - 1 : c;
+        if (std::isnan(depth[(size_t)r * cols + c])) continue;
+        kps[m++] = k;
+      }
+      kps.resize(m);
+    }
+    if ((int)kps.size() > max_kp) {  // retainBest(max_keypoints) + resize (node.cpp:188-191)
+      // the max_kp first of the order (response descending, position ascending), in their original order: a selection
+      std::vector<std::pair<float, int>> r(kps.size());
+      for (size_t i = 0; i < kps.size(); ++i) r[i] = std::make_pair(kps[i].response, (int)i);
+      auto before = [](const std::pair<float, int>& a, const std::pair<float, int>& b) {
+        return a.first > b.first || (a.first == b.first && a.second < b.second);
+      };
+      std::nth_element(r.begin(), r.begin() + (max_kp - 1), r.end(), before);
+      const std::pair<float, int> cut = r[(size_t)max_kp - 1];
+      size_t m = 0;
+      for (size_t i = 0; i < kps.size(); ++i)
+        if (!before(cut, std::make_pair(kps[i].response, (int)i))) {
+          if (min_depth) zmin[m] = zmin[i];
+          kps[m++] = kps[i];
+        }
+      kps.resize(m);
+      if (min_depth) zmin.resize(m);
+    }
+    // cv::ORB::compute (node.cpp:202) drops border keypoints and regroups the rest by octave, so projectTo3D
+    // (node.cpp:210) is enqueued from inside compute_enqueue(), once the final keypoint list exists: both ride on one
+    // synchronisation.  xy (2n floats) + depth.at<float>(round(y), round(x)) (n floats, node.cpp:942): 12 bytes per
+    // keypoint cross PCIe instead of the 1.2 MB image.
+    auto enqueue_project = [&]() -> int {
+      const int n = (int)kps.size();
+      if (n == 0) return RGBDFE_OK;
+      float* xyz_in = orb.h_xyz_in;
+      xyz_out = orb.h_xyz_out;
+      if (n > orb.pin_cap) {
+        xyz_in_big.resize((size_t)n * 3); xyz_out_big.resize((size_t)n * 4);
+        xyz_in = xyz_in_big.data(); xyz_out = xyz_out_big.data();
+      }
+      for (int i = 0; i < n; ++i) {
+        xyz_in[2 * i] = kps[i].x;
+        xyz_in[2 * i + 1] = kps[i].y;
+        if (min_depth) {  // node.cpp:940-941: the same neighbourhood depth as in removeDepthless
+          xyz_in[(size_t)2 * n + i] = zmin[(size_t)order[(size_t)i]];
+          continue;
+        }
+        int r = (int)roundf(kps[i].y), c = (int)roundf(kps[i].x);
+        r = r >= rows ? rows - 1 : r;
+        c = c >= cols ? cols - 1 : c;
+        xyz_in[(size_t)2 * n + i] = depth[(size_t)r * cols + c];
+      }
+      if (hipMemcpyAsync(orb.d_kpxy, xyz_in, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess)
+        return RGBDFE_ERR_HIP;
+      launch_project_to_3d(orb.d_kpxy, n, nullptr, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
+                           (float)cy, depth_scaling, max_kp, orb.d_kept, orb.d_xyz, orb.d_n_proj, st, false,
+                           orb.d_kpxy + (size_t)2 * n);
+      if (hipGetLastError() != hipSuccess) return RGBDFE_ERR_HIP;
+      if (hipMemcpyAsync(orb.h_n_proj, orb.d_n_proj, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipMemcpyAsync(xyz_out, orb.d_xyz, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return RGBDFE_ERR_HIP;
+      return RGBDFE_OK;
+    };
+    lap(6);
+    rc = orb.compute_enqueue(kps, desc, st, err, enqueue_project, &order);
+    if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+    return RGBDFE_OK;
+  }
+
+  int finish(hipStream_t st) {
+    OrbWorkspace& orb = ctx->orb;
+    std::string err;
+    const int rc = orb.compute_finish(desc, st, err);
+    if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+    if (tm) tq = orb_now_us();
+    const int n = (int)kps.size();
+    *n_out = 0;
+    if (n > 0) {
+      if (*orb.h_n_proj != n) return fail(ctx, RGBDFE_ERR_HIP, "projectTo3D dropped keypoints that removeDepthless kept");
+      memcpy(xyz1, xyz_out, sizeof(float) * 4 * (size_t)n);
+    }
+    kp_to_abi(kps, keypoints);
+    if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());
+    *n_out = n;
+    lap(9);
+    if (tm) orb.timing.frames++;
+    return RGBDFE_OK;
+  }
+};
 
 int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
                            int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
@@ -1362,14 +1389,21 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   ensure_detector(ctx);
-  return detect_describe_frame(ctx, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling, keypoints, descriptors,
-                               xyz1, n_out, false, nullptr);
+  DetectFrame fr;
+  fr.ctx = ctx; fr.gray = gray; fr.mask = mask; fr.depth = depth; fr.rows = rows; fr.cols = cols;
+  fr.fx = fx; fr.fy = fy; fr.cx = cx; fr.cy = cy; fr.depth_scaling = depth_scaling;
+  fr.keypoints = keypoints; fr.descriptors = descriptors; fr.xyz1 = xyz1; fr.n_out = n_out;
+  int rc = fr.detect(false, nullptr);
+  if (rc == RGBDFE_OK) rc = fr.describe_enqueue(ctx->stream);
+  if (rc == RGBDFE_OK) rc = fr.finish(ctx->stream);
+  return rc;
 }
 
 // A run of frames through the same detector state, in order (the per-cell thresholds of frame k+1 start from frame k's,
-// as in a sequence of single calls -- same keypoints, bit for bit).  What the batch adds is overlap: frame k+1's images
-// are staged, uploaded and turned into their pyramid (a second image set, a second stream) while the device runs frame
-// k's detection pass and the host would otherwise sit in hipStreamSynchronize.  Outputs: frame f's keypoints /
+// as in a sequence of single calls -- same keypoints, bit for bit).  What the batch adds is overlap, three deep: frame
+// k+2's images are staged, uploaded and turned into their pyramid by a helper thread (own stream, the free image set)
+// while frame k+1's detection pass runs on the device and the calling thread prepares and enqueues frame k's description
+// (third stream) instead of sitting in hipStreamSynchronize.  Outputs: frame f's keypoints /
 // descriptors / points at offset f * out_stride (rows), n_out[f] of them.
 int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
                                  const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
@@ -1393,6 +1427,7 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
   if (!ctx->orb_upload_stream) {
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_compute_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_upload_done[i], hipEventDisableTiming));
   }
   hipStream_t up = ctx->orb_upload_stream;
@@ -1427,22 +1462,68 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
       cv.notify_all();
     }
   });
-  for (int32_t f = 0; f < n_frames && rc == RGBDFE_OK; ++f) {
-    {
-      std::unique_lock<std::mutex> l(m);
-      cv.wait(l, [&] { return up_rc != RGBDFE_OK || uploaded > f; });
-      if (up_rc != RGBDFE_OK) { rc = up_rc; err = up_err; break; }
-    }
-    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[f & 1], 0) != hipSuccess) { rc = RGBDFE_ERR_HIP; err = "hipStreamWaitEvent"; break; }
+  // The calling thread: frame f + 1 is detected on ctx->stream (set (f + 1) & 1) while frame f is described on the second
+  // stream (set f & 1) -- describe_enqueue(f) runs as the `before_wait` hook of frame f + 1's first detection pass, i.e.
+  // its host work (removeDepthless, retainBest, the descriptor records) overlaps that pass's device time.
+  hipStream_t st2 = ctx->orb_compute_stream;
+  std::vector<DetectFrame> fr((size_t)2);
+  auto init = [&](DetectFrame& d, int32_t f) {
+    d = DetectFrame();
+    d.ctx = ctx; d.gray = gray[f]; d.mask = mask ? mask[f] : nullptr; d.depth = depth[f]; d.rows = rows; d.cols = cols;
+    d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy; d.depth_scaling = depth_scaling;
+    d.keypoints = keypoints + (size_t)f * out_stride; d.descriptors = descriptors + (size_t)f * out_stride * 32;
+    d.xyz1 = xyz1 + (size_t)f * out_stride * 4; d.n_out = n_out + f;
+  };
+  auto wait_upload = [&](int32_t f) -> int {  // frame f's images and pyramid are (being) built: order ctx->stream after them
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return up_rc != RGBDFE_OK || uploaded > f; });
+    if (up_rc != RGBDFE_OK) { err = up_err; return up_rc; }
+    l.unlock();
+    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[f & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
+    return RGBDFE_OK;
+  };
+  auto describe = [&](int32_t f) -> int {  // enqueue frame f's description on the second stream, from its own image set
     orb.use_set(f & 1);
-    rc = detect_describe_frame(ctx, gray[f], mask ? mask[f] : nullptr, depth[f], rows, cols, fx, fy, cx, cy, depth_scaling,
-                               keypoints + (size_t)f * out_stride, descriptors + (size_t)f * out_stride * 32,
-                               xyz1 + (size_t)f * out_stride * 4, n_out + f, true, nullptr);
-    if (rc != RGBDFE_OK) err.clear();  // detect_describe_frame has reported through fail()
+    if (hipStreamWaitEvent(st2, ctx->orb_upload_done[f & 1], 0) != hipSuccess) return RGBDFE_ERR_HIP;
+    return fr[(size_t)(f & 1)].describe_enqueue(st2);
+  };
+  rc = wait_upload(0);
+  if (rc == RGBDFE_OK) {
+    init(fr[0], 0);
+    orb.use_set(0);
+    rc = fr[0].detect(true, nullptr);
+    if (rc != RGBDFE_OK) err.clear();  // reported through fail()
+  }
+  for (int32_t f = 0; f < n_frames && rc == RGBDFE_OK; ++f) {
+    if (f + 1 < n_frames) {
+      rc = wait_upload(f + 1);
+      if (rc != RGBDFE_OK) break;
+      init(fr[(size_t)((f + 1) & 1)], f + 1);
+      orb.use_set((f + 1) & 1);
+      static const bool overlap = !(getenv("RGBDFE_DETECT_OVERLAP") && atoi(getenv("RGBDFE_DETECT_OVERLAP")) == 0);  // A/B switch
+      int rc_desc = RGBDFE_OK;
+      if (!overlap) {
+        rc = describe(f);
+        if (rc != RGBDFE_OK) { err.clear(); break; }
+        orb.use_set((f + 1) & 1);
+      }
+      rc = fr[(size_t)((f + 1) & 1)].detect(true, !overlap ? std::function<int()>() : [&, f]() -> int {
+        rc_desc = describe(f);
+        orb.use_set((f + 1) & 1);  // the rest of the pass (a second read-back of a crowded frame) is frame f + 1's
+        return rc_desc;
+      });
+      if (rc != RGBDFE_OK) { err.clear(); break; }
+    } else {
+      rc = describe(f);
+      if (rc != RGBDFE_OK) { err.clear(); break; }
+    }
+    rc = fr[(size_t)(f & 1)].finish(st2);
+    if (rc != RGBDFE_OK) { err.clear(); break; }
     std::lock_guard<std::mutex> l(m);
     finished = f + 1;
     cv.notify_all();
   }
+  (void)hipStreamSynchronize(st2);
   {
     std::lock_guard<std::mutex> l(m);
     stop = true;
