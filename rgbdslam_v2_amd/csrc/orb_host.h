@@ -69,8 +69,8 @@ struct OrbWorkspace {
   // device
   uint8_t* d_pool = nullptr; uint8_t* d_score = nullptr; uint8_t* d_blur = nullptr;
   ImgDesc* d_cell_imgs = nullptr; ImgDesc* d_frame_imgs = nullptr; ResizeJob* d_jobs = nullptr;
-  int* d_thr = nullptr; int* d_active = nullptr; int* d_row_cnt = nullptr; int* d_img_total = nullptr;
-  int* d_img_base = nullptr;
+  int* d_row_cnt = nullptr; int* d_img_total = nullptr;  // d_img_total and d_kps live inside d_passout
+  uint8_t* d_passout = nullptr; uint8_t* h_passout = nullptr; size_t passout_hdr = 0;  // [per-image counts | keypoints]
   RawKp* d_kps = nullptr; DescKp* d_desckp = nullptr; uint8_t* d_desc = nullptr;
   float* d_kpxy = nullptr; int32_t* d_kept = nullptr; float4* d_xyz = nullptr;
   int32_t* d_n = nullptr;
@@ -79,7 +79,7 @@ struct OrbWorkspace {
   // pageable copies of a few hundred bytes cost 10-20 us each and there are a dozen per frame
   int last_n_total = 0;  // keypoints of the latest detection pass: sizes the next pass's speculative read-back
   int pin_cap = 0;  // keypoints the staging buffers hold (larger transfers fall back to pageable vectors)
-  int* h_ctl = nullptr; int* h_totals = nullptr; int* h_base = nullptr;
+  int* h_totals = nullptr; int* h_base = nullptr;  // h_totals and h_raw live inside h_passout
   RawKp* h_raw = nullptr; DescKp* h_desckp = nullptr; uint8_t* h_desc = nullptr;
   float* h_xyz_in = nullptr; float* h_xyz_out = nullptr; int32_t* h_n = nullptr;
   const RawKp* pass_raw = nullptr;   // the latest gpu_pass: its corners (h_raw or pass_raw_big) ...

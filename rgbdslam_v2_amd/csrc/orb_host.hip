@@ -110,12 +110,13 @@ void OrbWorkspace::release() {
     if (himg_set[i]) { (void)hipHostFree(himg_set[i]); himg_set[i] = nullptr; }
   }
   d_pool = nullptr; d_blur = nullptr; h_img = nullptr;
-  fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_thr);
-  fr(d_row_cnt); fr(d_img_total); fr(d_img_base); fr(d_kps); fr(d_desckp); fr(d_desc); fr(d_kpxy);
+  fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs);
+  fr(d_row_cnt); fr(d_passout); fr(d_desckp); fr(d_desc); fr(d_kpxy);
+  d_img_total = nullptr; d_kps = nullptr;  // live inside d_passout
   fr(d_kept); fr(d_xyz); fr(d_n); fr(d_n_proj);
   auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-  frh(h_ctl); frh(h_totals); frh(h_base); frh(h_raw); frh(h_desckp); frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n); frh(h_n_proj);
-  d_active = nullptr;  // lives inside d_thr
+  frh(h_passout); frh(h_base); frh(h_desckp);
+  h_totals = nullptr; h_raw = nullptr;  // live inside h_passout frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n); frh(h_n_proj);
   W = H = 0;
 }
 
@@ -225,12 +226,12 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMalloc((void**)&d_cell_imgs, sizeof(ImgDesc) * cell_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_frame_imgs, sizeof(ImgDesc) * frame_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_jobs, sizeof(ResizeJob) * jobs.size()));
-  ORB_HIP(hipMalloc((void**)&d_thr, sizeof(int) * 128));  // thresholds and active flags travel in one copy
-  d_active = d_thr + 64;
   ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
-  ORB_HIP(hipMalloc((void**)&d_img_total, sizeof(int) * cell_imgs.size()));
-  ORB_HIP(hipMalloc((void**)&d_img_base, sizeof(int) * cell_imgs.size()));
-  ORB_HIP(hipMalloc((void**)&d_kps, sizeof(RawKp) * (size_t)kp_cap));
+  // a pass's outputs in ONE buffer -- [per-image counts | keypoints] -- so that they come back in one copy
+  passout_hdr = (sizeof(int) * cell_imgs.size() + 255) & ~(size_t)255;
+  ORB_HIP(hipMalloc((void**)&d_passout, passout_hdr + sizeof(RawKp) * (size_t)kp_cap));
+  d_img_total = reinterpret_cast<int*>(d_passout);
+  d_kps = reinterpret_cast<RawKp*>(d_passout + passout_hdr);
   ORB_HIP(hipMalloc((void**)&d_desckp, sizeof(DescKp) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_desc, (size_t)32 * kp_cap));
   ORB_HIP(hipMalloc((void**)&d_kpxy, sizeof(float) * 3 * (size_t)kp_cap));  // x, y and the looked-up depth per keypoint
@@ -239,10 +240,10 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMalloc((void**)&d_n, sizeof(int32_t)));
   ORB_HIP(hipMalloc((void**)&d_n_proj, sizeof(int32_t)));
   pin_cap = std::min(kp_cap, 16384);
-  ORB_HIP(hipHostMalloc((void**)&h_ctl, sizeof(int) * 128, hipHostMallocDefault));
-  ORB_HIP(hipHostMalloc((void**)&h_totals, sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_base, sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
-  ORB_HIP(hipHostMalloc((void**)&h_raw, sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_passout, passout_hdr + sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
+  h_totals = reinterpret_cast<int*>(h_passout);
+  h_raw = reinterpret_cast<RawKp*>(h_passout + passout_hdr);
   ORB_HIP(hipHostMalloc((void**)&h_desckp, sizeof(DescKp) * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_desc, (size_t)32 * pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_xyz_in, sizeof(float) * 3 * (size_t)pin_cap, hipHostMallocDefault));
@@ -316,23 +317,21 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
 // and orientation -- read back in one round trip (pass_raw, h_totals, h_base).
 int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int>& thr, hipStream_t s, std::string& err) {
   const double tp0 = timing.on ? orb_now_us() : 0;
+  OrbCtl ctl;  // thresholds and active flags are kernel arguments: no upload in front of the pass
   for (int c = 0; c < 64; ++c) {
-    h_ctl[c] = c < n_cells ? thr[c] : 0;
-    h_ctl[64 + c] = c < n_cells ? active[c] : 0;
+    ctl.thr[c] = c < n_cells ? thr[c] : 0;
+    ctl.active[c] = c < n_cells ? active[c] : 0;
   }
-  ORB_HIP(hipMemcpyAsync(d_thr, h_ctl, sizeof(int) * 128, hipMemcpyHostToDevice, s));
   const int n_imgs = n_cells * kLevels;
-  launch_orb_fast_score(d_pool, d_cell_imgs, n_imgs, max_w, max_h, d_thr, d_active, d_score, s);
-  launch_orb_nms_count(d_pool, d_cell_imgs, n_imgs, max_h, d_active, d_score, kDetectEdge, d_row_cnt, d_img_total, s);
+  launch_orb_fast_score(d_pool, d_cell_imgs, n_imgs, max_w, max_h, ctl, d_score, s);
+  launch_orb_nms_count(d_pool, d_cell_imgs, n_imgs, max_h, ctl, d_score, kDetectEdge, d_row_cnt, d_img_total, s);
   // One round trip per pass: the device scans the per-image counts itself, emits and measures the keypoints, and the
   // host reads counts and keypoints back together -- `bound` of them, a guess from the previous passes; a pass with
   // more keypoints than that pays a second round trip for the rest.
   const int bound = std::min(pin_cap, std::max(2048, 2 * last_n_total));
-  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, d_active, d_score, kDetectEdge, d_row_cnt, d_img_total, d_img_base,
-                  d_kps, d_n, bound, s);
+  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, ctl, d_score, kDetectEdge, d_row_cnt, d_img_total, d_kps, bound, s);
   ORB_HIP(hipGetLastError());
-  ORB_HIP(hipMemcpyAsync(h_totals, d_img_total, sizeof(int) * n_imgs, hipMemcpyDeviceToHost, s));
-  ORB_HIP(hipMemcpyAsync(h_raw, d_kps, sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipMemcpyAsync(h_passout, d_passout, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));  // counts + keypoints
   if (before_wait) {  // the caller's own host work (the next frame's upload) rides on this pass's device time
     std::function<int()> f = std::move(before_wait);
     before_wait = nullptr;
@@ -348,7 +347,7 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
   last_n_total = n_total;
   pass_raw = h_raw;
   if (n_total > bound) {
-    launch_orb_measure_rest(d_pool, d_cell_imgs, d_kps, d_n, bound, n_total - bound, s);
+    launch_orb_measure_rest(d_pool, d_cell_imgs, d_kps, d_img_total, n_imgs, bound, n_total - bound, s);
     ORB_HIP(hipGetLastError());
     pass_raw_big.resize((size_t)n_total);
     ORB_HIP(hipMemcpyAsync(pass_raw_big.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));

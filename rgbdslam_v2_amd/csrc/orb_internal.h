@@ -40,16 +40,24 @@ struct DescKp {
   float cos_a, sin_a;
 };
 
+// per-cell FAST thresholds and active flags of a detection pass: travel as a KERNEL ARGUMENT (no upload, one dependent
+// device operation fewer per pass)
+struct OrbCtl {
+  int32_t thr[64];
+  int32_t active[64];
+};
+
 void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max_w, int max_h, hipStream_t s);
-void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h,
-                           const int* cell_thr, const int* active, uint8_t* score_pool, hipStream_t s);
-void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
+void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, const OrbCtl& ctl,
+                           uint8_t* score_pool, hipStream_t s);
+void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
                           const uint8_t* score_pool, int edge, int* row_cnt, int* img_total, hipStream_t s);
-void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
-                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, int* img_base,
-                     RawKp* out, int* n_total, int measure_bound, hipStream_t s);
-void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* n_total, int first,
-                             int count, hipStream_t s);
+// img_total[n_imgs] (the per-image counts) doubles as the source of every prefix the later kernels need: no scan launch
+void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
+                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, RawKp* out,
+                     int measure_bound, hipStream_t s);
+void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* img_total, int n_imgs,
+                             int first, int count, hipStream_t s);
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
                      hipStream_t s);
 void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,

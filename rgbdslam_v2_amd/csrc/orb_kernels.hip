@@ -110,18 +110,16 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ ptr, int s
 }
 
 __global__ __launch_bounds__(256) void orb_fast_score_kernel(const uint8_t* __restrict__ pool,
-                                                             const ImgDesc* __restrict__ imgs,
-                                                             const int* __restrict__ cell_thr,
-                                                             const int* __restrict__ active,
+                                                             const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                              uint8_t* __restrict__ score_pool) {
   const ImgDesc im = imgs[blockIdx.z];
-  if (!active[im.cell]) return;
+  if (!ctl.active[im.cell]) return;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= im.w || y >= im.h) return;
   int s = 0;
   if (x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3) {
-    int thr = cell_thr[im.cell];
+    int thr = ctl.thr[im.cell];
     thr = min(max(thr, 0), 255);
     s = fast_score(pool + im.off + (size_t)y * im.stride + x, im.stride, thr);
     s = min(max(s, 0), 255);
@@ -147,13 +145,12 @@ __device__ __forceinline__ bool nms_keep(const uint8_t* __restrict__ sc, const u
 
 // one wave per image row: count the keypoints of the row
 __global__ __launch_bounds__(64) void orb_nms_count_kernel(const uint8_t* __restrict__ pool,
-                                                           const ImgDesc* __restrict__ imgs,
-                                                           const int* __restrict__ active,
+                                                           const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                            const uint8_t* __restrict__ score_pool, int edge,
                                                            int* __restrict__ row_cnt) {
   const ImgDesc im = imgs[blockIdx.y];
   const int y = blockIdx.x;
-  if (y >= im.h || !active[im.cell]) return;
+  if (y >= im.h || !ctl.active[im.cell]) return;
   const uint8_t* sc = score_pool + im.score_off;
   int cnt = 0;
   for (int x0 = 0; x0 < im.w; x0 += 64) {
@@ -165,12 +162,11 @@ __global__ __launch_bounds__(64) void orb_nms_count_kernel(const uint8_t* __rest
 }
 
 // one block per image: exclusive scan of the row counts, total per image
-__global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __restrict__ imgs,
-                                                           const int* __restrict__ active,
+__global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                            int* __restrict__ row_cnt, int* __restrict__ img_total) {
   __shared__ int part[256];
   const ImgDesc im = imgs[blockIdx.x];
-  if (!active[im.cell]) { if (threadIdx.x == 0) img_total[blockIdx.x] = 0; return; }
+  if (!ctl.active[im.cell]) { if (threadIdx.x == 0) img_total[blockIdx.x] = 0; return; }
   const int per = (im.h + 255) / 256;
   const int r0 = threadIdx.x * per;
   int sum = 0;
@@ -192,17 +188,26 @@ __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __rest
 }
 
 // one wave per image row: write the keypoints of the row at img_base + row_offset + rank (raster order)
+__device__ __forceinline__ int wave_sum(int v);
 __global__ __launch_bounds__(64) void orb_emit_kernel(const uint8_t* __restrict__ pool,
-                                                      const ImgDesc* __restrict__ imgs, const int* __restrict__ active,
+                                                      const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                       const uint8_t* __restrict__ score_pool, int edge,
-                                                      const int* __restrict__ row_off, const int* __restrict__ img_base,
+                                                      const int* __restrict__ row_off, const int* __restrict__ img_total,
                                                       RawKp* __restrict__ out) {
   const int img = blockIdx.y;
   const ImgDesc im = imgs[img];
   const int y = blockIdx.x;
-  if (y >= im.h || !active[im.cell]) return;
+  if (y >= im.h || !ctl.active[im.cell]) return;
   const uint8_t* sc = score_pool + im.score_off;
-  int base = img_base[img] + row_off[im.row_off + y];
+  // where this image's keypoints start = the keypoints of the images before it (at most 512 counts: a wave sums them,
+  // which is cheaper than a scan launch in front of this kernel)
+  int img_base = 0;
+  for (int j0 = 0; j0 < img; j0 += 64) {
+    const int j = j0 + (int)threadIdx.x;
+    img_base += j < img ? img_total[j] : 0;
+  }
+  img_base = wave_sum(img_base);
+  int base = img_base + row_off[im.row_off + y];
   for (int x0 = 0; x0 < im.w; x0 += 64) {
     int s = 0;
     const int x = x0 + (int)threadIdx.x;
@@ -252,14 +257,17 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-// first..first+grid keypoints; n_ptr[0] = how many there are (on the device: the host has not seen the count yet)
+// first..first+grid keypoints
 __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restrict__ pool,
                                                           const ImgDesc* __restrict__ imgs,
-                                                          RawKp* __restrict__ kps, const int* __restrict__ n_ptr,
-                                                          int first) {
+                                                          RawKp* __restrict__ kps, const int* __restrict__ img_total,
+                                                          int n_imgs, int first) {
   const int k = first + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= *n_ptr) return;
   const int lane = threadIdx.x & 63;
+  int n_total = 0;  // how many keypoints there are: the host has not seen the counts yet
+  for (int j0 = 0; j0 < n_imgs; j0 += 64) n_total += j0 + lane < n_imgs ? img_total[j0 + lane] : 0;
+  n_total = wave_sum(n_total);
+  if (k >= n_total) return;
   RawKp kp = kps[k];
   const ImgDesc im = imgs[kp.img];
   const int stride = im.stride;
@@ -375,53 +383,34 @@ void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max
   if (n_jobs == 0) return;
   hipLaunchKernelGGL(orb_resize_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_jobs), dim3(256), 0, s, pool, jobs);
 }
-void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h,
-                           const int* cell_thr, const int* active, uint8_t* score_pool, hipStream_t s) {
+void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, const OrbCtl& ctl,
+                           uint8_t* score_pool, hipStream_t s) {
   hipLaunchKernelGGL(orb_fast_score_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_imgs), dim3(256), 0, s, pool,
-                     imgs, cell_thr, active, score_pool);
+                     imgs, ctl, score_pool);
 }
-void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
+void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
                           const uint8_t* score_pool, int edge, int* row_cnt, int* img_total, hipStream_t s) {
-  hipLaunchKernelGGL(orb_nms_count_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, active, score_pool, edge,
+  hipLaunchKernelGGL(orb_nms_count_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, ctl, score_pool, edge,
                      row_cnt);
-  hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, active, row_cnt, img_total);
+  hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, ctl, row_cnt, img_total);
 }
-// exclusive scan of the per-image keypoint counts -> where each image's keypoints start; total -> n_total[0]
-__global__ __launch_bounds__(64) void orb_base_scan_kernel(const int* __restrict__ img_total, int n_imgs,
-                                                           int* __restrict__ img_base, int* __restrict__ n_total) {
-  const int lane = threadIdx.x;
-  int run = 0;  // keypoints of the images before this chunk of 64
-  for (int i0 = 0; i0 < n_imgs; i0 += 64) {
-    const int i = i0 + lane;
-    const int v = i < n_imgs ? img_total[i] : 0;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int up = __shfl_up(incl, off);
-      if (lane >= off) incl += up;
-    }
-    if (i < n_imgs) img_base[i] = run + incl - v;
-    run += __shfl(incl, 63);
-  }
-  if (lane == 0) *n_total = run;
-}
-
 // Keypoints of every active image in raster order, then Harris response + orientation for the first `measure_bound` of
-// them -- all without the host knowing the count (it reads img_total and n_total back together with the keypoints; a
-// frame with more keypoints than the bound gets the rest measured by launch_orb_measure_rest).
-void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const int* active,
-                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, int* img_base,
-                     RawKp* out, int* n_total, int measure_bound, hipStream_t s) {
-  hipLaunchKernelGGL(orb_base_scan_kernel, dim3(1), dim3(64), 0, s, img_total, n_imgs, img_base, n_total);
-  hipLaunchKernelGGL(orb_emit_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, active, score_pool, edge,
-                     row_off, img_base, out);
+// them -- all without the host knowing the count (it reads img_total back together with the keypoints; a frame with more
+// keypoints than the bound gets the rest measured by launch_orb_measure_rest).
+void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
+                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, RawKp* out,
+                     int measure_bound, hipStream_t s) {
+  hipLaunchKernelGGL(orb_emit_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, ctl, score_pool, edge, row_off,
+                     img_total, out);
   if (measure_bound > 0)
-    hipLaunchKernelGGL(orb_measure_kernel, dim3((measure_bound + 3) / 4), dim3(256), 0, s, pool, imgs, out, n_total, 0);
+    hipLaunchKernelGGL(orb_measure_kernel, dim3((measure_bound + 3) / 4), dim3(256), 0, s, pool, imgs, out, img_total,
+                       n_imgs, 0);
 }
-void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* n_total, int first,
-                             int count, hipStream_t s) {
+void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* img_total, int n_imgs,
+                             int first, int count, hipStream_t s) {
   if (count > 0)
-    hipLaunchKernelGGL(orb_measure_kernel, dim3((count + 3) / 4), dim3(256), 0, s, pool, imgs, out, n_total, first);
+    hipLaunchKernelGGL(orb_measure_kernel, dim3((count + 3) / 4), dim3(256), 0, s, pool, imgs, out, img_total, n_imgs,
+                       first);
 }
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
                      hipStream_t s) {
