@@ -1462,6 +1462,15 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
       cv.notify_all();
     }
   });
+  // whatever happens below (an exception on its way to the ABI barrier included): the helper is told to stop and joined
+  struct HelperJoin {
+    std::thread& th; std::mutex& m; std::condition_variable& cv; bool& stop;
+    ~HelperJoin() {
+      { std::lock_guard<std::mutex> l(m); stop = true; }
+      cv.notify_all();
+      if (th.joinable()) th.join();
+    }
+  } helper_join{helper, m, cv, stop};
   // The calling thread: frame f + 1 is detected on ctx->stream (set (f + 1) & 1) while frame f is described on the second
   // stream (set f & 1) -- describe_enqueue(f) runs as the `before_wait` hook of frame f + 1's first detection pass, i.e.
   // its host work (removeDepthless, retainBest, the descriptor records) overlaps that pass's device time.
@@ -1529,7 +1538,7 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
     stop = true;
     cv.notify_all();
   }
-  helper.join();
+  if (helper.joinable()) helper.join();
   (void)hipStreamSynchronize(up);
   orb.use_set(0);
   if (rc != RGBDFE_OK) return err.empty() ? rc : fail(ctx, rc, err);
