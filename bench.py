@@ -83,10 +83,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # RGBDFE_BENCH_BACKEND=gloo (tests only): several ranks on ONE GPU -- RCCL refuses two ranks on a device -- to exercise
+    # the sharding / gather / timing logic of the N > 1 path; collectives then go through host tensors.
+    backend = os.environ.get("RGBDFE_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    host_coll = world > 1 and backend != "nccl"
 
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd._lib import (KERNEL_HAMMING, KERNEL_RANSAC, KERNEL_SIFT_DOT,
@@ -103,7 +111,7 @@ def main():
     n_local = len(pq)
     counts = [n_local]
     if world > 1:
-        t_cnt = torch.tensor([n_local], device="cuda")
+        t_cnt = torch.tensor([n_local], device="cpu" if host_coll else "cuda")
         all_cnt = [torch.zeros_like(t_cnt) for _ in range(world)]
         dist.all_gather(all_cnt, t_cnt)
         counts = [int(c.item()) for c in all_cnt]
@@ -148,7 +156,12 @@ def main():
             ticket = fe.submit_pair_list(pq, pt, d_local[b].data_ptr())
         if world > 1:
             fe.wait_ticket(ticket, stream)  # torch's stream waits for this batch only
-            dist.all_gather_into_tensor(d_all, d_local[b])
+            if host_coll:
+                h_all = torch.empty(d_all.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(h_all, d_local[b].cpu())
+                d_all.copy_(h_all)
+            else:
+                dist.all_gather_into_tensor(d_all, d_local[b])
             consumed[b] = torch.cuda.Event()
             consumed[b].record()
 
@@ -172,7 +185,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        te = torch.tensor([elapsed], device="cpu" if host_coll else "cuda", dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     fe.set_profiling(False)

@@ -1,0 +1,35 @@
+"""-m gpu: bench.py's N > 1 path end to end -- two ranks under torch.distributed.run as the driver launches them, on the
+ONE GPU of the test box (RGBDFE_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device, so the collectives go through
+host tensors; everything else -- sharding, count exchange, padding, per-step gather, barriers, max-over-ranks timing, the
+one JSON line from rank 0 -- is the code the 8-GPU run executes)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RGBDFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+         "--frames", "60", "--pairs-per-frame", "10"],
+        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    # weak scaling: 10 candidates per frame and rank -> 20 per frame globally, sharded round robin
+    assert d["config"]["pairs_per_gpu_per_step"] > 0 and d["config"]["parallelism"] == "pair-sharded x2"
+    assert "sift" not in d and "cpu_baseline" not in d    # extras and the CPU leg belong to the N = 1 line
