@@ -105,7 +105,7 @@ class Node {  // the slice of src/node.h the pair path touches
  public:
   // feature_descriptors: n x 32 bytes (cv::Mat CV_8U, continuous); feature_locations_3d: n x (x,y,z,1)
   Node(const FrontEnd& fe, int id, const uint8_t* feature_descriptors, const float* feature_locations_3d, int n)
-      : fe_(fe), id_(id), n_(n) {
+      : id_(id), fe_(fe), n_(n) {
     matchable_ = rgbdfe_upload_node(fe_.get(), id_, feature_descriptors, feature_locations_3d, n) == RGBDFE_OK;
   }
   ~Node() { clearFeatureInformation(); }
