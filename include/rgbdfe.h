@@ -255,7 +255,7 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
  *   record / replay       (default) recording waves each refine chunk_iterations iterations of a pair and write the
  *                         outcomes, then one wave per pair replays the records in iteration order with the reference's
  *                         bookkeeping (node.cpp:1171-1190).  Up to 256 pairs all iterations are recorded in one phase
- *                         (full speculation: one node against 20 candidates returns in 0.41 ms instead of 5.7 ms);
+ *                         (full speculation: one node against 20 candidates returns in 0.24-0.41 ms instead of 5.7 ms);
  *                         larger batches run up to four phases ([0,14), [14,70), [70,140), [140,200) for 200
  *                         iterations): each replay tells the next phase which pairs are finished and how many
  *                         iterations the others can still need, so recording stops where the reference stops

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rgbdslam_v2_amd import synth
 from rgbdslam_v2_amd.frontend import FrontEnd
 F, N = 60, 1000
-seq = synth.make_sequence(n_frames=F, n_kp=N)
+NOISE = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01   # sigma_z = 0.01 z^2
+seq = synth.make_sequence(n_frames=F, n_kp=N, depth_noise=NOISE)
 fe = FrontEnd(max_nodes=F, max_keypoints=1024, max_pairs_per_batch=64)
 for f in range(F):
     fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
