@@ -263,6 +263,71 @@ __global__ __launch_bounds__(kSiftThreads) void sift_row_top2_kernel(
   }
 }
 
+// ---- merge of the 32 lanes that share a row (float keys) and the store of (best dot, second dot, best index)
+template <bool SWAP>
+__device__ __forceinline__ void sift_merge_store(const uint32_t (&rmx)[16], const uint32_t (&rnx)[16], int r0, int nx,
+                                                 int lane, uint32_t* __restrict__ opart) {
+  // Float keys leave room for the lane in the key (dot < 2^19): the tie rules become ONE total order --
+  //   !SWAP: (dot, lower lane, lower sequence)   RowMatch_Kernel's butterfly prefers the lower slot at every step, so the
+  //                                              lowest lane among equal dots survives; inside a lane the first column
+  //    SWAP: (dot, lower sequence, lower lane)   = the lowest row index (ColMatch_Kernel)
+  // -- so the 32 lanes that share a row merge by a plain max in any pairing, with second = max(loser's best, both
+  // seconds) per step (v_min, v_max3, v_max).  The merge is a reduce-scatter: at every step a lane keeps half of its
+  // rows and hands the other half to its partner (16 -> 8 -> 4 -> 2 -> 1 rows; xor 1 / 2 as DPP quad permutes, 4 / 8 /
+  // 16 through ds_bpermute), 31 merges per lane instead of 80, and ends holding ONE row, which it stores.
+  const uint32_t lrev = 31u - (uint32_t)(lane & 31);
+  uint32_t K[16], S[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t k32 = (uint32_t)(__uint_as_float(rmx[r]) * 32.0f);  // dot << 5 | (31 - seq): exact, < 2^24
+    const uint32_t n32 = (uint32_t)(__uint_as_float(rnx[r]) * 32.0f);
+    K[r] = SWAP ? ((k32 << 5) | lrev) : (((k32 >> 5) << 10) | (lrev << 5) | (k32 & 31u));
+    S[r] = (n32 >> 5) << 10;
+  }
+#define SIFT_MERGE(KEY, SEC, PK, PS)                     \
+  {                                                      \
+    const uint32_t pk = (PK), ps = (PS);                 \
+    SEC = max(max(min(KEY, pk), SEC), ps);               \
+    KEY = max(KEY, pk);                                  \
+  }
+  // STEP(N, bit, fetch): N rows -> N / 2; a lane with `bit` set keeps the upper half
+#define SIFT_SCATTER_STEP(N, BIT, FETCH)                                              \
+  _Pragma("unroll") for (int r = 0; r < (N) / 2; ++r) {                                \
+    const uint32_t sendK = (BIT) ? K[r] : K[r + (N) / 2], sendS = (BIT) ? S[r] : S[r + (N) / 2]; \
+    uint32_t keepK = (BIT) ? K[r + (N) / 2] : K[r], keepS = (BIT) ? S[r + (N) / 2] : S[r];       \
+    SIFT_MERGE(keepK, keepS, FETCH(sendK), FETCH(sendS))                               \
+    K[r] = keepK;                                                                      \
+    S[r] = keepS;                                                                      \
+  }
+#define SIFT_DPP_XOR1(V) __builtin_amdgcn_update_dpp(0u, (V), 0xB1, 0xF, 0xF, false)  // quad_perm [1,0,3,2]
+#define SIFT_DPP_XOR2(V) __builtin_amdgcn_update_dpp(0u, (V), 0x4E, 0xF, 0xF, false)  // quad_perm [2,3,0,1]
+#define SIFT_SHFL4(V) __shfl_xor((V), 4)
+#define SIFT_SHFL8(V) __shfl_xor((V), 8)
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+  SIFT_SCATTER_STEP(16, b0, SIFT_DPP_XOR1)
+  SIFT_SCATTER_STEP(8, b1, SIFT_DPP_XOR2)
+  SIFT_SCATTER_STEP(4, b2, SIFT_SHFL4)
+  SIFT_SCATTER_STEP(2, b3, SIFT_SHFL8)
+  uint32_t key = K[0], sec = S[0];
+  SIFT_MERGE(key, sec, __shfl_xor(key, 16), __shfl_xor(sec, 16))
+#undef SIFT_MERGE
+#undef SIFT_SCATTER_STEP
+#undef SIFT_DPP_XOR1
+#undef SIFT_DPP_XOR2
+#undef SIFT_SHFL4
+#undef SIFT_SHFL8
+  const int reg = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);  // the row this lane ended up with
+  const uint32_t dmx = key >> 10, dnx = sec >> 10;
+  const uint32_t hi5 = 31u - ((key >> 5) & 31u), lo5 = 31u - (key & 31u);
+  const uint32_t idx = dmx ? (SWAP ? ((hi5 << 5) | lo5) : ((lo5 << 5) | hi5)) : 0xFFFFFFFFu;
+  const int row = r0 + row_of_reg(reg, lane);
+  if ((lane & 16) == 0 && row < nx) {
+    opart[(size_t)row * 3 + 0] = dmx;
+    opart[(size_t)row * 3 + 1] = dnx;
+    opart[(size_t)row * 3 + 2] = idx;
+  }
+}
+
 // ---- float keys -------------------------------------------------------------------------------------------------------
 // Same block shape and LDS tile as above.  The inner loop is software pipelined by hand over the column tiles (32 columns
 // = 8 B fragments = 9 MFMAs): while the matrix pipe works on column tile c, the VALU digests the accumulator of c - 1
@@ -443,66 +508,195 @@ __global__ __launch_bounds__(kSiftThreads) void sift_top2_fast_kernel(
   if (rmx[0] != 0x12345u) return;
 #endif
 
-  // Float keys leave room for the lane in the key (dot < 2^19): the tie rules become ONE total order --
-  //   !SWAP: (dot, lower lane, lower sequence)   RowMatch_Kernel's butterfly prefers the lower slot at every step, so the
-  //                                              lowest lane among equal dots survives; inside a lane the first column
-  //    SWAP: (dot, lower sequence, lower lane)   = the lowest row index (ColMatch_Kernel)
-  // -- so the 32 lanes that share a row merge by a plain max in any pairing, with second = max(loser's best, both
-  // seconds) per step (v_min, v_max3, v_max).  The merge is a reduce-scatter: at every step a lane keeps half of its
-  // rows and hands the other half to its partner (16 -> 8 -> 4 -> 2 -> 1 rows; xor 1 / 2 as DPP quad permutes, 4 / 8 /
-  // 16 through ds_bpermute), 31 merges per lane instead of 80, and ends holding ONE row, which it stores.
-  uint32_t* __restrict__ opart = part + (size_t)pair * max_kp * 3;
-  const uint32_t lrev = 31u - (uint32_t)(lane & 31);
-  uint32_t K[16], S[16];
+  sift_merge_store<SWAP>(rmx, rnx, r0, nx, lane, part + (size_t)pair * max_kp * 3);
+}
+
+// ---- float keys, 64 rows per wave -----------------------------------------------------------------------------------------
+// The 32-row kernel above reads one 16-byte B fragment from LDS per MFMA: four SIMDs at the matrix pipe's rate ask for
+// exactly the LDS port's 128 B per clock, so neither unit gets past ~half busy.  Here a wave holds 64 rows of X (two A
+// fragment sets) and every B fragment feeds TWO MFMAs; block = 4 waves = 256 rows.  The registers for the second row group
+// come from the tile staging: the Y tile goes global -> LDS directly (global_load_lds_dwordx4: destination = wave-uniform
+// base + lane * 16, so the XOR swizzle of the 16-byte chunks is applied to the SOURCE address and to the ds_read side).
+// Pipelining: the 9 MFMAs of (row group 0, column tile c) run beside the digest of (group 1, c - 1); those of (group 1, c)
+// beside the digest of (group 0, c); the B fragments of c + 1 arrive during both.
+constexpr int kTile64 = 256;
+
+template <bool SWAP>
+__global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
+    const uint16_t* __restrict__ bf16_pool, const PairWork* __restrict__ work, uint32_t max_kp,
+    uint32_t n_pairs, uint32_t n_rb, uint32_t* __restrict__ part) {
+  __shared__ u32x4 tileY[2][kTile * kChunksPerRow];
+  uint32_t pair, rb;
+  sift_block_to_tile(n_rb, pair, rb);
+  if (pair >= n_pairs) return;
+  const PairWork w = work[pair];
+  const int nq = (int)w.nq, nt = (int)w.nt;  // <= 1024 (host)
+  const int nx = SWAP ? nt : nq, ny = SWAP ? nq : nt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)(rb * kTile64) >= nx || !(w.pad & 1u)) return;  // block-uniform
+  const int r0 = rb * kTile64 + wv * 64;
+
+  const uint16_t* __restrict__ xpool = bf16_pool + (size_t)(SWAP ? w.t_slot : w.q_slot) * max_kp * kSiftDim;
+  const uint16_t* __restrict__ ypool = bf16_pool + (size_t)(SWAP ? w.q_slot : w.t_slot) * max_kp * kSiftDim;
+
+  bf16x8 A0[8], A1[8];
+  {
+    int row = r0 + (lane & 31);
+    row = row < nx ? row : nx - 1;
+    row = row < 0 ? 0 : row;
+    const u32x4* src = reinterpret_cast<const u32x4*>(xpool + (size_t)row * kSiftDim + (lane >> 5) * 8);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const uint32_t k32 = (uint32_t)(__uint_as_float(rmx[r]) * 32.0f);  // dot << 5 | (31 - seq): exact, < 2^24
-    const uint32_t n32 = (uint32_t)(__uint_as_float(rnx[r]) * 32.0f);
-    K[r] = SWAP ? ((k32 << 5) | lrev) : (((k32 >> 5) << 10) | (lrev << 5) | (k32 & 31u));
-    S[r] = (n32 >> 5) << 10;
+    for (int ks = 0; ks < 8; ++ks) A0[ks] = __builtin_bit_cast(bf16x8, src[ks * 2]);
+    row = r0 + 32 + (lane & 31);
+    row = row < nx ? row : nx - 1;
+    row = row < 0 ? 0 : row;
+    src = reinterpret_cast<const u32x4*>(xpool + (size_t)row * kSiftDim + (lane >> 5) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) A1[ks] = __builtin_bit_cast(bf16x8, src[ks * 2]);
   }
-#define SIFT_MERGE(KEY, SEC, PK, PS)                     \
-  {                                                      \
-    const uint32_t pk = (PK), ps = (PS);                 \
-    SEC = max(max(min(KEY, pk), SEC), ps);               \
-    KEY = max(KEY, pk);                                  \
+  const uint32_t k0 = (lane < 32) ? 0xFFFFFFFFu : 0u;
+  const bf16x8 A9 = __builtin_bit_cast(bf16x8, u32x4{0x3F80u & k0, 0u, 0u, 0u});
+  auto seq_term = [&](int seq) {
+    const float term = (float)(31 - seq) * 0.03125f;
+    return __builtin_bit_cast(bf16x8, u32x4{(__float_as_uint(term) >> 16) & k0, 0u, 0u, 0u});
+  };
+
+  uint32_t mx0[16], sx0[16], mx1[16], sx1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx0[r] = sx0[r] = mx1[r] = sx1[r] = 0u;
+
+  const int n_tiles = (ny + kTile - 1) / kTile;
+  const int n_full = ny / kTile;
+  // Tile staging: wave wv owns LDS slots [wv * 512, wv * 512 + 512) of the 2048, 64 per instruction.  Slot p = row * 16 + c
+  // holds the row's chunk c ^ (row & 15); row & 15 = (i * 4 + lane / 16) & 15 for instruction i, i.e. the source chunk of a
+  // lane is ((lane & 15) ^ (lane >> 4)) ^ ((i & 3) * 4) in its row.  No row clamp: the pool is padded (ensure_sift).
+  // The instruction's immediate offset applies to BOTH addresses, so the 8 instructions of a tile share one LDS base (M0)
+  // and four 32-bit source offsets (13-bit signed immediate: both bases sit 4 KB into the wave's 8 KB).
+  const int sw_lane = (lane & ~15) | ((lane & 15) ^ (lane >> 4));
+  uint32_t voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) voff[j] = (uint32_t)((wv * 512 + (sw_lane ^ (j * 4))) * 16 + 4096);
+  // tile base as a scalar pair (the compiler would strength-reduce four 64-bit VGPR pointers otherwise: 8 registers)
+  const uint64_t ybase = reinterpret_cast<uint64_t>(ypool);
+  const uint32_t yb_lo = __builtin_amdgcn_readfirstlane((uint32_t)ybase);
+  const uint32_t yb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ybase >> 32));
+#define S64_GLDS(TB, BUF, I)                                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((TB) + voff[(I) & 3]),   \
+                                   (__attribute__((address_space(3))) void*)&tileY[BUF][wv * 512 + 256], 16, \
+                                   (I) * 1024 - 4096, 0);
+#define S64_STAGE_TILE(TILE, BUF)                                                                           \
+  {                                                                                                         \
+    const char* tb = reinterpret_cast<const char*>((((uint64_t)yb_hi << 32) | yb_lo) +                      \
+                                                   (uint64_t)(uint32_t)(TILE) * (kTile * kChunksPerRow * 16)); \
+    S64_GLDS(tb, BUF, 0) S64_GLDS(tb, BUF, 1) S64_GLDS(tb, BUF, 2) S64_GLDS(tb, BUF, 3)                     \
+    S64_GLDS(tb, BUF, 4) S64_GLDS(tb, BUF, 5) S64_GLDS(tb, BUF, 6) S64_GLDS(tb, BUF, 7)                     \
   }
-  // STEP(N, bit, fetch): N rows -> N / 2; a lane with `bit` set keeps the upper half
-#define SIFT_SCATTER_STEP(N, BIT, FETCH)                                              \
-  _Pragma("unroll") for (int r = 0; r < (N) / 2; ++r) {                                \
-    const uint32_t sendK = (BIT) ? K[r] : K[r + (N) / 2], sendS = (BIT) ? S[r] : S[r + (N) / 2]; \
-    uint32_t keepK = (BIT) ? K[r + (N) / 2] : K[r], keepS = (BIT) ? S[r + (N) / 2] : S[r];       \
-    SIFT_MERGE(keepK, keepS, FETCH(sendK), FETCH(sendS))                               \
-    K[r] = keepK;                                                                      \
-    S[r] = keepS;                                                                      \
+  S64_STAGE_TILE(0, 0)
+  __syncthreads();
+
+  // B fragment (ks, column tile ct, buffer) of this lane: row = ct * 32 + (lane & 31), chunk (ks * 2 + hi) ^ (row & 15), i.e.
+  // byte (row * 256 + ((hi ^ (lane & 15)) << 4)) ^ (ks << 5), + ct * 8192 + buffer * 32768 as the instruction's immediate.
+  // ONE address register; the XOR is redone per read (kept out of the loop-invariant hoisting, which would cost 8 registers)
+  const uint32_t abyte = (uint32_t)((lane & 31) * 256 + ((((lane >> 5) ^ lane) & 15) << 4));
+  const char* lds_bytes = reinterpret_cast<const char*>(&tileY[0][0]);
+
+  f32x16 acc0, acc1;  // acc1 enters a tile holding the previous tile's last column tile of row group 1 (zeros: inert keys)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+  bf16x8 Bf[8];
+
+#define S64_READ_ONE(BUF, CT, KS)                                                                   \
+  {                                                                                                 \
+    uint32_t a = abyte ^ ((KS) << 5);                                                               \
+    asm volatile("" : "+v"(a));                                                                     \
+    Bf[KS] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_bytes + a + ((BUF) * 32768 + (CT) * 8192))); \
   }
-#define SIFT_DPP_XOR1(V) __builtin_amdgcn_update_dpp(0u, (V), 0xB1, 0xF, 0xF, false)  // quad_perm [1,0,3,2]
-#define SIFT_DPP_XOR2(V) __builtin_amdgcn_update_dpp(0u, (V), 0x4E, 0xF, 0xF, false)  // quad_perm [2,3,0,1]
-#define SIFT_SHFL4(V) __shfl_xor((V), 4)
-#define SIFT_SHFL8(V) __shfl_xor((V), 8)
-  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
-  SIFT_SCATTER_STEP(16, b0, SIFT_DPP_XOR1)
-  SIFT_SCATTER_STEP(8, b1, SIFT_DPP_XOR2)
-  SIFT_SCATTER_STEP(4, b2, SIFT_SHFL4)
-  SIFT_SCATTER_STEP(2, b3, SIFT_SHFL8)
-  uint32_t key = K[0], sec = S[0];
-  SIFT_MERGE(key, sec, __shfl_xor(key, 16), __shfl_xor(sec, 16))
-#undef SIFT_MERGE
-#undef SIFT_SCATTER_STEP
-#undef SIFT_DPP_XOR1
-#undef SIFT_DPP_XOR2
-#undef SIFT_SHFL4
-#undef SIFT_SHFL8
-  const int reg = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);  // the row this lane ended up with
-  const uint32_t dmx = key >> 10, dnx = sec >> 10;
-  const uint32_t hi5 = 31u - ((key >> 5) & 31u), lo5 = 31u - (key & 31u);
-  const uint32_t idx = dmx ? (SWAP ? ((hi5 << 5) | lo5) : ((lo5 << 5) | hi5)) : 0xFFFFFFFFu;
-  const int row = r0 + row_of_reg(reg, lane);
-  if ((lane & 16) == 0 && row < nx) {
-    opart[(size_t)row * 3 + 0] = dmx;
-    opart[(size_t)row * 3 + 1] = dnx;
-    opart[(size_t)row * 3 + 2] = idx;
+#define S64_READ_B(BUF, CT)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) S64_READ_ONE(BUF, CT, ks)
+#define S64_MFMA9(ACC, AF, B, SEQ)                                                                  \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[r] = 0.0f;                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                   \
+      ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[ks], B[ks], ACC, 0, 0, 0);                    \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A9, seq_term(SEQ), ACC, 0, 0, 0);
+#define S64_DIGEST(ACC, MX, SX)                                                                     \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) top2_insert(MX[r], SX[r], __float_as_uint(ACC[r]));
+  // one pipelined half step: 9 x { 1 MFMA, 1 LDS read (the first N_READS), 4-5 VALU }
+#define S64_SCHED(N_READS)                                             \
+  _Pragma("unroll") for (int g = 0; g < 9; ++g) {                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+    if (g < (N_READS)) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); \
+    if (g < (N_READS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                 \
+  }                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+  // column tile CT: row group 0's MFMAs beside the digest of (group 1, CT - 1), then group 1's MFMAs beside the digest of
+  // (group 0, CT).  ONE set of B fragments: fragment ks of column tile CT + 1 is read right behind the group-1 MFMA that is
+  // the last user of fragment ks of CT (an MFMA reads its operands at issue), 9 MFMA slots before its own first use.
+#define S64_COLUMN_TILE(BUF, CT, SEQ, N_READS)                                                      \
+  S64_MFMA9(acc0, A0, Bf, SEQ)                                                                      \
+  S64_DIGEST(acc1, mx1, sx1)                                                                        \
+  S64_SCHED(0)                                                                                      \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                 \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[ks], Bf[ks], acc1, 0, 0, 0);                   \
+    if ((N_READS) > 0) S64_READ_ONE(BUF, (CT) + 1, ks)                                              \
+  }                                                                                                 \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A9, seq_term(SEQ), acc1, 0, 0, 0);                  \
+  S64_DIGEST(acc0, mx0, sx0)                                                                        \
+  S64_SCHED(N_READS)
+  // one full Y tile out of buffer BUF (a constant: the loop is unrolled by two so that every LDS offset is an immediate)
+#define S64_FULL_TILE(BUF)                                                                          \
+  {                                                                                                 \
+    S64_STAGE_TILE(tile + 1, (BUF) ^ 1)                                                             \
+    const int seq0 = tile * 4;                                                                      \
+    S64_READ_B(BUF, 0)                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    S64_COLUMN_TILE(BUF, 0, seq0, 8)                                                                \
+    S64_COLUMN_TILE(BUF, 1, seq0 + 1, 8)                                                            \
+    S64_COLUMN_TILE(BUF, 2, seq0 + 2, 8)                                                            \
+    S64_COLUMN_TILE(BUF, 3, seq0 + 3, 0)                                                            \
+    __syncthreads();                                                                                \
+    ++tile;                                                                                         \
   }
+
+  int tile = 0;
+  while (tile + 1 < n_full) {
+    S64_FULL_TILE(0)
+    S64_FULL_TILE(1)
+  }
+  if (tile < n_full) S64_FULL_TILE(0)   // n_full odd: `tile` is even here
+  S64_DIGEST(acc1, mx1, sx1)
+  if (tile < n_tiles) {  // ragged last tile: columns beyond ny carry key 0
+    const int t0 = tile * kTile;
+    const uint32_t bsel = (uint32_t)(tile & 1) * 32768u;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        Bf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_bytes + ((abyte ^ (ks << 5)) + bsel + ct * 8192)));
+      S64_MFMA9(acc0, A0, Bf, tile * 4 + ct)
+      S64_MFMA9(acc1, A1, Bf, tile * 4 + ct)
+      const bool ok = (t0 + ct * 32 + (lane & 31)) < ny;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) top2_insert(mx0[r], sx0[r], ok ? __float_as_uint(acc0[r]) : 0u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) top2_insert(mx1[r], sx1[r], ok ? __float_as_uint(acc1[r]) : 0u);
+    }
+  }
+#undef S64_FULL_TILE
+#undef S64_READ_ONE
+#undef S64_STAGE_TILE
+#undef S64_GLDS
+#undef S64_READ_B
+#undef S64_MFMA9
+#undef S64_DIGEST
+#undef S64_SCHED
+#undef S64_COLUMN_TILE
+  if (r0 >= nx) return;  // waves beyond the last row (after the last barrier)
+  uint32_t* __restrict__ opart = part + (size_t)pair * max_kp * 3;
+  sift_merge_store<SWAP>(mx0, sx0, r0, nx, lane, opart);
+  if (r0 + 32 < nx) sift_merge_store<SWAP>(mx1, sx1, r0 + 32, nx, lane, opart);
 }
 
 __device__ __forceinline__ float sift_angle(uint32_t dot) {
@@ -619,10 +813,19 @@ void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t m
   // each kernel leaves the other kind's pairs at once
   const uint32_t groups = (n_pairs + 7u) / 8u * 8u;
   if (key_kinds & 1u) {
-    hipLaunchKernelGGL(sift_top2_fast_kernel<false>, dim3(rbq * groups), dim3(kSiftThreads), 0, stream,
-                       bf16_pool, work, max_kp, n_pairs, rbq, row_part);
-    hipLaunchKernelGGL(sift_top2_fast_kernel<true>, dim3(rbt * groups), dim3(kSiftThreads), 0, stream,
-                       bf16_pool, work, max_kp, n_pairs, rbt, col_part);
+    static const int rows64 = [] { const char* e = getenv("RGBDFE_SIFT_ROWS64"); return e ? atoi(e) : 1; }();
+    if (rows64) {
+      const uint32_t rq = (max_nq + kTile64 - 1) / kTile64, rt = (max_nt + kTile64 - 1) / kTile64;
+      hipLaunchKernelGGL(sift_top2_fast64_kernel<false>, dim3((rq ? rq : 1u) * groups), dim3(kSiftThreads), 0, stream,
+                         bf16_pool, work, max_kp, n_pairs, rq ? rq : 1u, row_part);
+      hipLaunchKernelGGL(sift_top2_fast64_kernel<true>, dim3((rt ? rt : 1u) * groups), dim3(kSiftThreads), 0, stream,
+                         bf16_pool, work, max_kp, n_pairs, rt ? rt : 1u, col_part);
+    } else {
+      hipLaunchKernelGGL(sift_top2_fast_kernel<false>, dim3(rbq * groups), dim3(kSiftThreads), 0, stream,
+                         bf16_pool, work, max_kp, n_pairs, rbq, row_part);
+      hipLaunchKernelGGL(sift_top2_fast_kernel<true>, dim3(rbt * groups), dim3(kSiftThreads), 0, stream,
+                         bf16_pool, work, max_kp, n_pairs, rbt, col_part);
+    }
   }
   if (key_kinds & 2u) {
     hipLaunchKernelGGL(sift_row_top2_kernel<false>, dim3(rbq * groups), dim3(kSiftThreads), 0, stream,
