@@ -539,18 +539,58 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
 
   const uint16_t* __restrict__ xpool = bf16_pool + (size_t)(SWAP ? w.t_slot : w.q_slot) * max_kp * kSiftDim;
   const uint16_t* __restrict__ ypool = bf16_pool + (size_t)(SWAP ? w.q_slot : w.t_slot) * max_kp * kSiftDim;
+  const int n_tiles = (ny + kTile - 1) / kTile;
+  const int n_full = ny / kTile;
+
+  // Tile staging: wave wv owns LDS slots [wv * 512, wv * 512 + 512) of the 2048, 64 per instruction.  Slot p = row * 16 + c
+  // holds the row's chunk c ^ (row & 15); row & 15 = (i * 4 + lane / 16) & 15 for instruction i, i.e. the source chunk of a
+  // lane is ((lane & 15) ^ (lane >> 4)) ^ ((i & 3) * 4) in its row.  No row clamp: the pool is padded (ensure_sift).
+  // The instruction's immediate offset applies to BOTH addresses, so the 8 instructions of a tile share one LDS base (M0)
+  // and four 32-bit source offsets (13-bit signed immediate: both bases sit 4 KB into the wave's 8 KB).
+  const int sw_lane = (lane & ~15) | ((lane & 15) ^ (lane >> 4));
+  uint32_t voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) voff[j] = (uint32_t)((wv * 512 + (sw_lane ^ (j * 4))) * 16 + 4096);
+  const uint64_t ybase = reinterpret_cast<uint64_t>(ypool);
+  const uint32_t yb_lo = __builtin_amdgcn_readfirstlane((uint32_t)ybase);
+  const uint32_t yb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ybase >> 32));
+  // (the offset is made opaque where it is used: hoisted out of the loop as a zero-extended pair it would cost 16 registers
+  // and the scalar-base addressing mode)
+#define S64_GLDS(TB, BUF, I)                                                                                \
+  {                                                                                                         \
+    uint32_t vo = voff[(I) & 3];                                                                            \
+    asm volatile("" : "+v"(vo));                                                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((TB) + vo),            \
+                                     (__attribute__((address_space(3))) void*)&tileY[BUF][wv * 512 + 256], 16, \
+                                     (I) * 1024 - 4096, 0);                                                 \
+  }
+#define S64_STAGE_TILE(TILE, BUF)                                                                           \
+  {                                                                                                         \
+    const char* tb = reinterpret_cast<const char*>((((uint64_t)yb_hi << 32) | yb_lo) +                      \
+                                                   (uint64_t)(uint32_t)(TILE) * (kTile * kChunksPerRow * 16)); \
+    S64_GLDS(tb, BUF, 0) S64_GLDS(tb, BUF, 1) S64_GLDS(tb, BUF, 2) S64_GLDS(tb, BUF, 3)                     \
+    S64_GLDS(tb, BUF, 4) S64_GLDS(tb, BUF, 5) S64_GLDS(tb, BUF, 6) S64_GLDS(tb, BUF, 7)                     \
+  }
+  S64_STAGE_TILE(0, 0)
+
+  if (r0 >= nx) {  // a wave without rows only stages its share of the tiles (same barriers as the working waves)
+    __syncthreads();
+    for (int tile = 0; tile < n_full; ++tile) {
+      if (tile & 1) { S64_STAGE_TILE(tile + 1, 0) } else { S64_STAGE_TILE(tile + 1, 1) }
+      __syncthreads();
+    }
+    return;
+  }
 
   bf16x8 A0[8], A1[8];
   {
     int row = r0 + (lane & 31);
     row = row < nx ? row : nx - 1;
-    row = row < 0 ? 0 : row;
     const u32x4* src = reinterpret_cast<const u32x4*>(xpool + (size_t)row * kSiftDim + (lane >> 5) * 8);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) A0[ks] = __builtin_bit_cast(bf16x8, src[ks * 2]);
     row = r0 + 32 + (lane & 31);
     row = row < nx ? row : nx - 1;
-    row = row < 0 ? 0 : row;
     src = reinterpret_cast<const u32x4*>(xpool + (size_t)row * kSiftDim + (lane >> 5) * 8);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) A1[ks] = __builtin_bit_cast(bf16x8, src[ks * 2]);
@@ -565,39 +605,12 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
   uint32_t mx0[16], sx0[16], mx1[16], sx1[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) mx0[r] = sx0[r] = mx1[r] = sx1[r] = 0u;
-
-  const int n_tiles = (ny + kTile - 1) / kTile;
-  const int n_full = ny / kTile;
-  // Tile staging: wave wv owns LDS slots [wv * 512, wv * 512 + 512) of the 2048, 64 per instruction.  Slot p = row * 16 + c
-  // holds the row's chunk c ^ (row & 15); row & 15 = (i * 4 + lane / 16) & 15 for instruction i, i.e. the source chunk of a
-  // lane is ((lane & 15) ^ (lane >> 4)) ^ ((i & 3) * 4) in its row.  No row clamp: the pool is padded (ensure_sift).
-  // The instruction's immediate offset applies to BOTH addresses, so the 8 instructions of a tile share one LDS base (M0)
-  // and four 32-bit source offsets (13-bit signed immediate: both bases sit 4 KB into the wave's 8 KB).
-  const int sw_lane = (lane & ~15) | ((lane & 15) ^ (lane >> 4));
-  uint32_t voff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) voff[j] = (uint32_t)((wv * 512 + (sw_lane ^ (j * 4))) * 16 + 4096);
-  // tile base as a scalar pair (the compiler would strength-reduce four 64-bit VGPR pointers otherwise: 8 registers)
-  const uint64_t ybase = reinterpret_cast<uint64_t>(ypool);
-  const uint32_t yb_lo = __builtin_amdgcn_readfirstlane((uint32_t)ybase);
-  const uint32_t yb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ybase >> 32));
-#define S64_GLDS(TB, BUF, I)                                                                                \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((TB) + voff[(I) & 3]),   \
-                                   (__attribute__((address_space(3))) void*)&tileY[BUF][wv * 512 + 256], 16, \
-                                   (I) * 1024 - 4096, 0);
-#define S64_STAGE_TILE(TILE, BUF)                                                                           \
-  {                                                                                                         \
-    const char* tb = reinterpret_cast<const char*>((((uint64_t)yb_hi << 32) | yb_lo) +                      \
-                                                   (uint64_t)(uint32_t)(TILE) * (kTile * kChunksPerRow * 16)); \
-    S64_GLDS(tb, BUF, 0) S64_GLDS(tb, BUF, 1) S64_GLDS(tb, BUF, 2) S64_GLDS(tb, BUF, 3)                     \
-    S64_GLDS(tb, BUF, 4) S64_GLDS(tb, BUF, 5) S64_GLDS(tb, BUF, 6) S64_GLDS(tb, BUF, 7)                     \
-  }
-  S64_STAGE_TILE(0, 0)
   __syncthreads();
 
   // B fragment (ks, column tile ct, buffer) of this lane: row = ct * 32 + (lane & 31), chunk (ks * 2 + hi) ^ (row & 15), i.e.
-  // byte (row * 256 + ((hi ^ (lane & 15)) << 4)) ^ (ks << 5), + ct * 8192 + buffer * 32768 as the instruction's immediate.
-  // ONE address register; the XOR is redone per read (kept out of the loop-invariant hoisting, which would cost 8 registers)
+  // byte (row * 256 + ((hi ^ (lane & 15)) << 4)) ^ (ks << 5), + ct * 8192 + buffer * 32768 as the instruction's immediate
+  // (the full-tile loop is unrolled by two, so the buffer is a constant there).  ONE address register: the XOR is an asm
+  // statement per read, which keeps it from being hoisted out of the loop into 8 registers.
   const uint32_t abyte = (uint32_t)((lane & 31) * 256 + ((((lane >> 5) ^ lane) & 15) << 4));
   const char* lds_bytes = reinterpret_cast<const char*>(&tileY[0][0]);
 
@@ -606,57 +619,104 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
   bf16x8 Bf[8];
 
-#define S64_READ_ONE(BUF, CT, KS)                                                                   \
+  // BOFF: buffer offset in bytes, a constant (full tiles) or a register (the ragged tile)
+#define S64_READ_ONE(BOFF, CT, KS)                                                                  \
   {                                                                                                 \
-    uint32_t a = abyte ^ ((KS) << 5);                                                               \
-    asm volatile("" : "+v"(a));                                                                     \
-    Bf[KS] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_bytes + a + ((BUF) * 32768 + (CT) * 8192))); \
+    uint32_t a;                                                                                     \
+    asm volatile("v_xor_b32 %0, %2, %1" : "=v"(a) : "v"(abyte), "n"((KS) << 5));                     \
+    Bf[KS] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_bytes + (a + (BOFF)) + (CT) * 8192)); \
   }
-#define S64_READ_B(BUF, CT)                                                                         \
-  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) S64_READ_ONE(BUF, CT, ks)
-#define S64_MFMA9(ACC, AF, B, SEQ)                                                                  \
+#define S64_READ_B(BOFF, CT)                                                                        \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) S64_READ_ONE(BOFF, CT, ks)
+#define S64_MFMA9(ACC, AF, SEQ)                                                                     \
   _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[r] = 0.0f;                                      \
   _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                   \
-      ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[ks], B[ks], ACC, 0, 0, 0);                    \
+      ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[ks], Bf[ks], ACC, 0, 0, 0);                   \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A9, seq_term(SEQ), ACC, 0, 0, 0);
-#define S64_DIGEST(ACC, MX, SX)                                                                     \
-  _Pragma("unroll") for (int r = 0; r < 16; ++r) top2_insert(MX[r], SX[r], __float_as_uint(ACC[r]));
-  // one pipelined half step: 9 x { 1 MFMA, 1 LDS read (the first N_READS), 4-5 VALU }
-#define S64_SCHED(N_READS)                                             \
-  _Pragma("unroll") for (int g = 0; g < 9; ++g) {                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
-    if (g < (N_READS)) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); \
-    if (g < (N_READS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                 \
-  }                                                                    \
-  __builtin_amdgcn_sched_barrier(0);
+#if defined(RGBDFE_SIFT_ABL) && (RGBDFE_SIFT_ABL == 2 || RGBDFE_SIFT_ABL == 6)
+#define S64_MFMA_ONE(ACC, A, B) asm volatile("" : "+v"(ACC) : "v"(A), "v"(B));
+#else
+#define S64_MFMA_ONE(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0);
+#endif
+  // OK: true (full tiles) or the lane's "column exists" flag of the column tile the accumulator belongs to
+#define S64_DIGEST(ACC, MX, SX, OK)                                                                 \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) top2_insert(MX[r], SX[r], (OK) ? __float_as_uint(ACC[r]) : 0u);
+#if defined(RGBDFE_SIFT_ABL)  // timing ablations (wrong results): tools/sift_ablation.sh
+#if RGBDFE_SIFT_ABL == 1 || RGBDFE_SIFT_ABL == 6   // no digest (one element keeps the accumulator alive)
+#undef S64_DIGEST
+#define S64_DIGEST(ACC, MX, SX, OK) top2_insert(MX[0], SX[0], (OK) ? __float_as_uint(ACC[0]) : 0u);
+#endif
+#if RGBDFE_SIFT_ABL == 2 || RGBDFE_SIFT_ABL == 6   // no MFMA
+#undef S64_MFMA9
+#define S64_MFMA9(ACC, AF, SEQ)                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(Bf[ks]), "v"(AF[ks]));      \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[r] = __uint_as_float((uint32_t)((SEQ) + r + lane));
+#endif
+#endif
+  // One pipelined half step = the 9 MFMAs of one accumulator chain beside the digest of the OTHER chain's result.  That
+  // result comes from the MFMA issued last in the previous half step and a wave issues in order, so a digest instruction
+  // right behind it would hold the new chain back for the matrix pipe's latency: the first two MFMAs of a half step are
+  // fenced off in front (HEAD), the digest runs beside the other seven (TAIL: 7 x { 1 MFMA, [1 address + 1 LDS read], NV VALU }).
+#define S64_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define S64_TAIL_SCHED(WITH_READS, NV)                                  \
+  _Pragma("unroll") for (int g = 0; g < 7; ++g) {                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
+    if ((WITH_READS) && g < 6) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); \
+    if ((WITH_READS) && g < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);               \
+  }                                                                     \
+  S64_FENCE()
   // column tile CT: row group 0's MFMAs beside the digest of (group 1, CT - 1), then group 1's MFMAs beside the digest of
   // (group 0, CT).  ONE set of B fragments: fragment ks of column tile CT + 1 is read right behind the group-1 MFMA that is
   // the last user of fragment ks of CT (an MFMA reads its operands at issue), 9 MFMA slots before its own first use.
-#define S64_COLUMN_TILE(BUF, CT, SEQ, N_READS)                                                      \
-  S64_MFMA9(acc0, A0, Bf, SEQ)                                                                      \
-  S64_DIGEST(acc1, mx1, sx1)                                                                        \
-  S64_SCHED(0)                                                                                      \
+#define S64_PIN(ACC) asm volatile("" : "+v"(ACC));  // MFMAs and VALU are pure: only side effects keep them on their side of a fence
+#define S64_COLUMN_TILE(BOFF, CT, SEQ, WITH_READS, OK_PREV, OK_THIS, NV)                            \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;                                     \
+  S64_MFMA_ONE(acc0, A0[0], Bf[0])                                                                  \
+  S64_MFMA_ONE(acc0, A0[1], Bf[1])                                                                  \
+  S64_PIN(acc0)                                                                                     \
+  S64_FENCE()                                                                                       \
+  S64_PIN(acc1)                                                                                     \
+  _Pragma("unroll") for (int ks = 2; ks < 8; ++ks) S64_MFMA_ONE(acc0, A0[ks], Bf[ks])                \
+  S64_MFMA_ONE(acc0, A9, seq_term(SEQ))                                                             \
+  S64_PIN(acc0)                                                                                     \
+  S64_DIGEST(acc1, mx1, sx1, OK_PREV)                                                               \
+  S64_TAIL_SCHED(false, NV)                                                                         \
   _Pragma("unroll") for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;                                     \
-  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                 \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[ks], Bf[ks], acc1, 0, 0, 0);                   \
-    if ((N_READS) > 0) S64_READ_ONE(BUF, (CT) + 1, ks)                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                 \
+    S64_MFMA_ONE(acc1, A1[ks], Bf[ks])                                                              \
+    if (WITH_READS) S64_READ_ONE(BOFF, (CT) + 1, ks)                                                \
   }                                                                                                 \
-  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A9, seq_term(SEQ), acc1, 0, 0, 0);                  \
-  S64_DIGEST(acc0, mx0, sx0)                                                                        \
-  S64_SCHED(N_READS)
+  S64_PIN(acc1)                                                                                     \
+  S64_FENCE()                                                                                       \
+  S64_PIN(acc0)                                                                                     \
+  _Pragma("unroll") for (int ks = 2; ks < 8; ++ks) {                                                 \
+    S64_MFMA_ONE(acc1, A1[ks], Bf[ks])                                                              \
+    if (WITH_READS) S64_READ_ONE(BOFF, (CT) + 1, ks)                                                \
+  }                                                                                                 \
+  S64_MFMA_ONE(acc1, A9, seq_term(SEQ))                                                             \
+  S64_PIN(acc1)                                                                                     \
+  S64_DIGEST(acc0, mx0, sx0, OK_THIS)                                                               \
+  S64_TAIL_SCHED(WITH_READS, NV)
   // one full Y tile out of buffer BUF (a constant: the loop is unrolled by two so that every LDS offset is an immediate)
+#if defined(RGBDFE_SIFT_ABL) && RGBDFE_SIFT_ABL == 9   // no tile staging, no barriers in the loop
+#define S64_LOOP_STAGE(TILE, BUF)
+#define S64_LOOP_BARRIER()
+#else
+#define S64_LOOP_STAGE(TILE, BUF) S64_STAGE_TILE(TILE, BUF)
+#define S64_LOOP_BARRIER() __syncthreads();
+#endif
 #define S64_FULL_TILE(BUF)                                                                          \
   {                                                                                                 \
-    S64_STAGE_TILE(tile + 1, (BUF) ^ 1)                                                             \
+    S64_LOOP_STAGE(tile + 1, (BUF) ^ 1)                                                             \
     const int seq0 = tile * 4;                                                                      \
-    S64_READ_B(BUF, 0)                                                                              \
+    S64_READ_B((BUF) * 32768, 0)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                              \
-    S64_COLUMN_TILE(BUF, 0, seq0, 8)                                                                \
-    S64_COLUMN_TILE(BUF, 1, seq0 + 1, 8)                                                            \
-    S64_COLUMN_TILE(BUF, 2, seq0 + 2, 8)                                                            \
-    S64_COLUMN_TILE(BUF, 3, seq0 + 3, 0)                                                            \
-    __syncthreads();                                                                                \
+    S64_COLUMN_TILE((BUF) * 32768, 0, seq0, true, true, true, 6)                                       \
+    S64_COLUMN_TILE((BUF) * 32768, 1, seq0 + 1, true, true, true, 6)                                   \
+    S64_COLUMN_TILE((BUF) * 32768, 2, seq0 + 2, true, true, true, 6)                                   \
+    S64_COLUMN_TILE((BUF) * 32768, 3, seq0 + 3, false, true, true, 6)                                   \
+    S64_LOOP_BARRIER()                                                                              \
     ++tile;                                                                                         \
   }
 
@@ -666,34 +726,39 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
     S64_FULL_TILE(1)
   }
   if (tile < n_full) S64_FULL_TILE(0)   // n_full odd: `tile` is even here
-  S64_DIGEST(acc1, mx1, sx1)
-  if (tile < n_tiles) {  // ragged last tile: columns beyond ny carry key 0
-    const int t0 = tile * kTile;
-    const uint32_t bsel = (uint32_t)(tile & 1) * 32768u;
+  S64_DIGEST(acc1, mx1, sx1, true)
+  if (tile < n_tiles) {  // ragged last tile: the same pipeline, columns beyond ny carry key 0
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-        Bf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_bytes + ((abyte ^ (ks << 5)) + bsel + ct * 8192)));
-      S64_MFMA9(acc0, A0, Bf, tile * 4 + ct)
-      S64_MFMA9(acc1, A1, Bf, tile * 4 + ct)
-      const bool ok = (t0 + ct * 32 + (lane & 31)) < ny;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) top2_insert(mx0[r], sx0[r], ok ? __float_as_uint(acc0[r]) : 0u);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) top2_insert(mx1[r], sx1[r], ok ? __float_as_uint(acc1[r]) : 0u);
-    }
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+    const int c0 = tile * kTile + (lane & 31);
+    const bool ok0 = c0 < ny, ok1 = c0 + 32 < ny, ok2 = c0 + 64 < ny, ok3 = c0 + 96 < ny;
+    const uint32_t boff = (uint32_t)(tile & 1) * 32768u;
+    const int seq0 = tile * 4;
+    S64_READ_B(boff, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    S64_COLUMN_TILE(boff, 0, seq0, true, true, ok0, 8)
+    S64_COLUMN_TILE(boff, 1, seq0 + 1, true, ok0, ok1, 8)
+    S64_COLUMN_TILE(boff, 2, seq0 + 2, true, ok1, ok2, 8)
+    S64_COLUMN_TILE(boff, 3, seq0 + 3, false, ok2, ok3, 8)
+    S64_DIGEST(acc1, mx1, sx1, ok3)
   }
 #undef S64_FULL_TILE
+#undef S64_LOOP_STAGE
+#undef S64_LOOP_BARRIER
+#undef S64_MFMA_ONE
 #undef S64_READ_ONE
 #undef S64_STAGE_TILE
 #undef S64_GLDS
 #undef S64_READ_B
 #undef S64_MFMA9
 #undef S64_DIGEST
-#undef S64_SCHED
+#undef S64_TAIL_SCHED
+#undef S64_PIN
+#undef S64_FENCE
 #undef S64_COLUMN_TILE
-  if (r0 >= nx) return;  // waves beyond the last row (after the last barrier)
+#if defined(RGBDFE_SIFT_ABL) && RGBDFE_SIFT_ABL == 8
+  if (mx0[0] != 0x12345u && mx1[3] != 0x777u) return;
+#endif
   uint32_t* __restrict__ opart = part + (size_t)pair * max_kp * 3;
   sift_merge_store<SWAP>(mx0, sx0, r0, nx, lane, opart);
   if (r0 + 32 < nx) sift_merge_store<SWAP>(mx1, sx1, r0 + 32, nx, lane, opart);
@@ -813,19 +878,23 @@ void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t m
   // each kernel leaves the other kind's pairs at once
   const uint32_t groups = (n_pairs + 7u) / 8u * 8u;
   if (key_kinds & 1u) {
-    static const int rows64 = [] { const char* e = getenv("RGBDFE_SIFT_ROWS64"); return e ? atoi(e) : 1; }();
-    if (rows64) {
-      const uint32_t rq = (max_nq + kTile64 - 1) / kTile64, rt = (max_nt + kTile64 - 1) / kTile64;
-      hipLaunchKernelGGL(sift_top2_fast64_kernel<false>, dim3((rq ? rq : 1u) * groups), dim3(kSiftThreads), 0, stream,
-                         bf16_pool, work, max_kp, n_pairs, rq ? rq : 1u, row_part);
-      hipLaunchKernelGGL(sift_top2_fast64_kernel<true>, dim3((rt ? rt : 1u) * groups), dim3(kSiftThreads), 0, stream,
-                         bf16_pool, work, max_kp, n_pairs, rt ? rt : 1u, col_part);
-    } else {
-      hipLaunchKernelGGL(sift_top2_fast_kernel<false>, dim3(rbq * groups), dim3(kSiftThreads), 0, stream,
-                         bf16_pool, work, max_kp, n_pairs, rbq, row_part);
-      hipLaunchKernelGGL(sift_top2_fast_kernel<true>, dim3(rbt * groups), dim3(kSiftThreads), 0, stream,
-                         bf16_pool, work, max_kp, n_pairs, rbt, col_part);
-    }
+    // 64 rows per wave (256-row blocks) unless the batch's nodes fit one 128-row block; RGBDFE_SIFT_ROWS64=0/1 forces
+    // one kernel for A/B runs
+    static const int rows64_env = [] { const char* e = getenv("RGBDFE_SIFT_ROWS64"); return e ? atoi(e) : -1; }();
+    auto launch = [&](auto k32, auto k64, uint32_t max_n, uint32_t* out) {
+      const bool rows64 = rows64_env >= 0 ? rows64_env != 0 : max_n > (uint32_t)kTile;
+      if (rows64) {
+        uint32_t rb = (max_n + kTile64 - 1) / kTile64;
+        if (rb < 1) rb = 1;
+        hipLaunchKernelGGL(k64, dim3(rb * groups), dim3(kSiftThreads), 0, stream, bf16_pool, work, max_kp, n_pairs, rb, out);
+      } else {
+        uint32_t rb = (max_n + kTile - 1) / kTile;
+        if (rb < 1) rb = 1;
+        hipLaunchKernelGGL(k32, dim3(rb * groups), dim3(kSiftThreads), 0, stream, bf16_pool, work, max_kp, n_pairs, rb, out);
+      }
+    };
+    launch(sift_top2_fast_kernel<false>, sift_top2_fast64_kernel<false>, max_nq, row_part);
+    launch(sift_top2_fast_kernel<true>, sift_top2_fast64_kernel<true>, max_nt, col_part);
   }
   if (key_kinds & 2u) {
     hipLaunchKernelGGL(sift_row_top2_kernel<false>, dim3(rbq * groups), dim3(kSiftThreads), 0, stream,

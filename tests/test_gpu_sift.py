@@ -105,6 +105,23 @@ def test_sift_key_paths(fe):
     _check_nodes(fe, d1c, base[:400], rng)
 
 
+def test_sift_block_shapes(fe):
+    """Float keys run in two block shapes (sift_match.hip, launch_sift_dot): 128-row blocks (32 rows per wave) when the
+    larger side of the batch fits one block, 256-row blocks (64 rows per wave, tiles loaded straight into LDS)
+    otherwise.  Sizes around every boundary of both -- 32 / 64 rows per wave, 128 / 256 rows per block, 128-column tiles
+    (the ragged last tile runs the same pipeline under a column mask), waves without rows -- with duplicated rows so
+    that the tie rules are exercised in every shape."""
+    rng = np.random.default_rng(4242)
+    base = _rand_sift(rng, 1024)
+    base[1::5] = base[0::5][: len(base[1::5])]          # exact duplicates
+    noisy = np.abs(base + rng.normal(0, 0.01, base.shape).astype(np.float32))
+    noisy /= np.linalg.norm(noisy, axis=1, keepdims=True)
+    perm = rng.permutation(1024)
+    for n1, n2 in ((1, 1), (31, 128), (128, 33), (129, 64), (64, 129), (127, 255), (256, 256), (257, 129), (193, 385),
+                   (320, 511), (513, 640), (700, 1023), (1024, 767), (1024, 1024), (65, 1000)):
+        _check_nodes(fe, noisy[perm][:n1], base[:n2], rng)
+
+
 def test_sift_tie_rules(fe):
     """Exact duplicates force equal dot products: the row side must follow RowMatch_Kernel's
     32-thread butterfly (ProgramCU.cu:1715-1736), the column side "lowest row wins" (:1464-1467,

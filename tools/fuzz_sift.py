@@ -7,10 +7,10 @@ from rgbdslam_v2_amd import synth
 from rgbdslam_v2_amd.frontend import FrontEnd, inlier_indices
 bad = 0
 fe = FrontEnd(device_id=0, max_nodes=12, max_keypoints=1536, max_pairs_per_batch=64)
-for master in range(25):
+for master in range(int(sys.argv[1]) if len(sys.argv) > 1 else 25):
     rng = np.random.default_rng(7000 + master)
     F = 6
-    sizes = [int(rng.choice([0, 1, 2, 31, 32, 33, 127, 128, 129, 300, 1000, 1536])) for _ in range(F)]
+    sizes = [int(rng.choice([0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513, 640, 1000, 1023, 1024, 1536])) for _ in range(F)]
     seq = synth.make_sequence(n_frames=F, n_kp=1536, n_world=4000, seed=300 + master, nan_fraction=float(rng.choice([0.0, 0.1])))
     sd = synth.sift_descriptors_like(seq["desc"], seed=master)
     nodes = []

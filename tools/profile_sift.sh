@@ -14,21 +14,26 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $BE
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $BENCH > $OUT/bench_write.json 2> $OUT/write.err
 cd $REPO
 python - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 out = "$OUT"
 res = collections.defaultdict(dict)
+def short(name):
+    name = name.replace("rgbdfe::", "").replace("void ", "")
+    return re.sub(r"\\(.*$", "", name).strip()
+def wanted(k):
+    return any(t in k for t in ("sift", "select_ransac", "replay_walk"))
 for f in glob.glob(out + "/trace/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        for k in ("sift_row_top2_kernel<false>", "sift_row_top2_kernel<true>", "sift_finish", "select_ransac_kernel<true, 1>", "select_ransac_kernel<true, 2>", "replay_walk_kernel", "sift_sort_kernel", "sift_quantise"):
-            if k in r["Name"]:
-                res[k]["calls"] = int(r["Calls"]); res[k]["avg_ns"] = float(r["AverageNs"]); res[k]["pct"] = float(r["Percentage"])
+        k = short(r["Name"])
+        if wanted(k):
+            res[k]["calls"] = int(r["Calls"]); res[k]["avg_ns"] = float(r["AverageNs"]); res[k]["pct"] = float(r["Percentage"])
 for pat in ("pmc_mfma", "pmc_fetch", "pmc_write"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out + "/" + pat + "/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            for k in ("sift_row_top2_kernel<false>", "sift_row_top2_kernel<true>", "sift_finish", "select_ransac_kernel<true, 1>", "select_ransac_kernel<true, 2>", "replay_walk_kernel", "sift_sort_kernel"):
-                if k in r["Kernel_Name"]:
-                    acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            k = short(r["Kernel_Name"])
+            if wanted(k):
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, c in acc.items():
         for n, v in c.items():
             res[k][n + "_avg"] = sum(v) / len(v)
@@ -36,6 +41,8 @@ for k, d in res.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in d and "GRBM_GUI_ACTIVE_avg" in d:
         # MFMA busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE counts device cycles of the dispatch
         d["mfma_util_est"] = d["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (d["GRBM_GUI_ACTIVE_avg"] * 1024)
+    if "GRBM_GUI_ACTIVE_avg" in d and "avg_ns" in d:
+        d["clock_ghz_est"] = d["GRBM_GUI_ACTIVE_avg"] / d["avg_ns"]
 json.dump(res, open(out + "/summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
