@@ -26,7 +26,7 @@ def short(name):
         return "select_ransac"
     if "hamming_mfma_kernel" in name:
         return "hamming_nn"
-    if "sift_top2_fast_kernel" in name or "sift_row_top2_kernel" in name:  # both passes of the dot-product stage
+    if "sift_top2_fast" in name or "sift_row_top2_kernel" in name:  # both passes of the dot-product stage
         return "sift_dot"
     if "sift_finish_kernel" in name:
         return "sift_finish"
