@@ -904,38 +904,62 @@ struct SiftMatchList {
 // is the number of matches with a smaller (distance, queryIdx) key (distances are non-negative floats: their bit
 // patterns order like the values).  The max_matches best matches are written back, in rank order, over the head of the
 // pair's list; the count stays the original one.  One wave per pair.
-__global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__ sm_q, uint16_t* __restrict__ sm_t,
-                                                          float* __restrict__ sm_d, const int32_t* __restrict__ sm_n,
-                                                          uint32_t max_kp, uint32_t n_pairs, int max_matches) {
-  constexpr int kTile = 2048;  // keys staged in LDS at a time (a longer list is staged again for every 64 ranks)
+constexpr int kSortThreads = 256;
+__global__ __launch_bounds__(kSortThreads) void sift_sort_kernel(uint16_t* __restrict__ sm_q, uint16_t* __restrict__ sm_t,
+                                                                 float* __restrict__ sm_d, const int32_t* __restrict__ sm_n,
+                                                                 uint32_t max_kp, uint32_t n_pairs, int max_matches) {
+  constexpr int kTile = 2048;  // keys held in LDS at a time
   __shared__ uint64_t s_key[kTile];
   __shared__ uint32_t s_qt[RGBDFE_MAX_MATCHES], s_d[RGBDFE_MAX_MATCHES];
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   uint16_t* __restrict__ sq = sm_q + (size_t)pair * max_kp;
   uint16_t* __restrict__ st = sm_t + (size_t)pair * max_kp;
   float* __restrict__ sd = sm_d + (size_t)pair * max_kp;
   const int n = sm_n[pair];
   const int n_all = min(n, max_matches);
-  auto key_of = [&](int i) { return ((uint64_t)__float_as_uint(sd[i]) << 16) | (uint64_t)sq[i]; };  // (distance, queryIdx)
-  const bool single = n <= kTile;
-  if (single) {
-    for (int j = lane; j < n; j += kWave) s_key[j] = key_of(j);
-    wave_sync();
+  if (n <= kTile) {
+    // Bitonic sort of (distance, queryIdx, trainIdx) keys -- queryIdx is unique inside a list, so the order is the total
+    // order (distance, queryIdx) of the rank count below and the train index rides along in the low bits.
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    for (int j = tid; j < n_pad; j += kSortThreads)
+      s_key[j] = j < n ? (((uint64_t)__float_as_uint(sd[j]) << 32) | ((uint64_t)sq[j] << 16) | (uint64_t)st[j]) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= n_pad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < (n_pad >> 1); i += kSortThreads) {
+          const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+          const uint64_t a = s_key[lo], b = s_key[hi];
+          const bool up = (lo & k) == 0;
+          if ((a > b) == up) {
+            s_key[lo] = b;
+            s_key[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    for (int m = tid; m < n_all; m += kSortThreads) {
+      const uint64_t key = s_key[m];
+      sq[m] = (uint16_t)((key >> 16) & 0xFFFFu);
+      st[m] = (uint16_t)(key & 0xFFFFu);
+      sd[m] = __uint_as_float((uint32_t)(key >> 32));
+    }
+    return;
   }
-  for (int base = 0; base < n; base += kWave) {
-    const int i = base + lane;
+  // longer lists (nodes above 2048 keypoints): rank count, the keys staged again for every 256 ranks
+  auto key_of = [&](int i) { return ((uint64_t)__float_as_uint(sd[i]) << 16) | (uint64_t)sq[i]; };  // (distance, queryIdx)
+  for (int base = 0; base < n; base += kSortThreads) {
+    const int i = base + tid;
     const bool act = i < n;
     const uint64_t ki = act ? key_of(i) : 0ull;
     int rank = 0;
     for (int t0 = 0; t0 < n; t0 += kTile) {
       const int tn = min(kTile, n - t0);
-      if (!single) {
-        wave_sync();
-        for (int j = lane; j < tn; j += kWave) s_key[j] = key_of(t0 + j);
-        wave_sync();
-      }
+      __syncthreads();
+      for (int j = tid; j < tn; j += kSortThreads) s_key[j] = key_of(t0 + j);
+      __syncthreads();
       int j = 0;
       for (; j + 8 <= tn; j += 8) {
 #pragma unroll
@@ -948,8 +972,8 @@ __global__ __launch_bounds__(kWave) void sift_sort_kernel(uint16_t* __restrict__
       s_d[rank] = __float_as_uint(sd[i]);
     }
   }
-  wave_sync();  // every read of the unsorted list is done
-  for (int m = lane; m < n_all; m += kWave) {
+  __syncthreads();  // every read of the unsorted list is done
+  for (int m = tid; m < n_all; m += kSortThreads) {
     sq[m] = (uint16_t)(s_qt[m] & 0xFFFFu);
     st[m] = (uint16_t)(s_qt[m] >> 16);
     sd[m] = __uint_as_float(s_d[m]);
@@ -1731,7 +1755,7 @@ void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const ui
 static void launch_sift_prep(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q, uint16_t* sm_t, float* sm_d,
                              const int32_t* sm_n, float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
                              uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, hipStream_t stream) {
-  hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kWave), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
+  hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kSortThreads), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
                      rc.max_matches);
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
   hipLaunchKernelGGL(pair_prep_kernel<true>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work,

@@ -767,6 +767,9 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
 __device__ __forceinline__ float sift_angle(uint32_t dot) {
   // ProgramCU.cu:1738: acos(min(dot * 0.000003814697265625f, 1.0)): float product, double min/acos
   const float prod = (float)(int)dot * 0.000003814697265625f;
+#if defined(RGBDFE_SIFT_ABL) && RGBDFE_SIFT_ABL == 10
+  return 1.0f - prod;
+#endif
   const double v = (double)prod < 1.0 ? (double)prod : 1.0;
   return (float)acos(v);
 }
@@ -778,10 +781,14 @@ __global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
     const float* __restrict__ f32_pool, const PairWork* __restrict__ work, uint32_t max_kp,
     const uint32_t* __restrict__ row_part, uint32_t* __restrict__ col_part,
     uint16_t* __restrict__ sm_q, uint16_t* __restrict__ sm_t, float* __restrict__ sm_d,
-    int32_t* __restrict__ sm_n) {
+    int32_t* __restrict__ sm_n, uint32_t n_pairs) {
   __shared__ uint32_t wave_cnt[4];
   __shared__ int s_total;
-  const uint32_t pair = blockIdx.x;
+  // Workgroups go round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the pair list, so that pairs
+  // that share a node (a frame's candidate pairs are neighbours in the list) find its descriptors in ONE L2
+  const uint32_t per_xcd = (n_pairs + 7u) / 8u;
+  const uint32_t pair = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (pair >= n_pairs) return;
   const PairWork w = work[pair];
   const int nq = (int)min(w.nq, 4096u), nt = (int)min(w.nt, 4096u);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -851,19 +858,50 @@ __global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
   // ---- DMatch.distance: float L2 of the raw descriptors, sequential sum (:211-217)
   const float* __restrict__ qf = f32_pool + (size_t)w.q_slot * max_kp * kSiftDim;
   const float* __restrict__ tf = f32_pool + (size_t)w.t_slot * max_kp * kSiftDim;
-  for (int m = tid; m < number; m += kSiftThreads) {
-    const float4* a = reinterpret_cast<const float4*>(qf + (size_t)oq[m] * kSiftDim);
-    const float4* b = reinterpret_cast<const float4*>(tf + (size_t)ot[m] * kSiftDim);
+#if defined(RGBDFE_SIFT_ABL) && RGBDFE_SIFT_ABL == 11
+  for (int m = tid; m < number; m += kSiftThreads) od[m] = (float)(oq[m] + ot[m]);
+  return;
+#endif
+  // Lane = match, but a lane reading its own two 512-byte rows makes every load instruction touch 64 cache lines (the
+  // texture addresser, not the arithmetic, set the time: 0.30 of the kernel's 0.36 ms per 4000 pairs).  Each wave stages
+  // 16 floats of the 2 x 64 rows of its 64 matches at a time through LDS instead: 4 lanes fetch one 64-byte row piece
+  // (16 rows per instruction), rows padded to 20 floats (ds_read_b128 of 16 consecutive lanes hits 16 different bank
+  // groups), and every lane then adds its own row pair in the reference's order.  No block barrier: a wave's LDS
+  // operations execute in order and the four waves own disjoint staging areas.
+  constexpr int kPiece = 16, kStride = 20;
+  __shared__ float4 s_stage[4][2][64 * kStride / 4];
+  float4* sq4 = s_stage[wv][0];
+  float4* st4 = s_stage[wv][1];
+  for (int base = wv * 64; base < number; base += kSiftThreads) {
+    const int m = base + lane;
+    const bool act = m < number;
+    const uint32_t qi = act ? (uint32_t)oq[m] : 0u, ti = act ? (uint32_t)ot[m] : 0u;
     float sum = 0.0f;
-    for (int k = 0; k < kSiftDim / 4; ++k) {
-      const float4 x = a[k], y = b[k];
-      float d;
-      d = x.x - y.x; sum += d * d;
-      d = x.y - y.y; sum += d * d;
-      d = x.z - y.z; sum += d * d;
-      d = x.w - y.w; sum += d * d;
+    for (int c = 0; c < kSiftDim / kPiece; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = i * 16 + (lane >> 2);  // the match (lane of this wave) whose rows this lane helps to fetch
+        const uint32_t rq = (uint32_t)__shfl((int)qi, r), rt = (uint32_t)__shfl((int)ti, r);
+        const float4 vq = *reinterpret_cast<const float4*>(qf + (size_t)rq * kSiftDim + c * kPiece + (lane & 3) * 4);
+        const float4 vt = *reinterpret_cast<const float4*>(tf + (size_t)rt * kSiftDim + c * kPiece + (lane & 3) * 4);
+        sq4[r * (kStride / 4) + (lane & 3)] = vq;
+        st4[r * (kStride / 4) + (lane & 3)] = vt;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int k4 = 0; k4 < kPiece / 4; ++k4) {
+        const float4 x = sq4[lane * (kStride / 4) + k4], y = st4[lane * (kStride / 4) + k4];
+        float d;
+        d = x.x - y.x; sum += d * d;
+        d = x.y - y.y; sum += d * d;
+        d = x.z - y.z; sum += d * d;
+        d = x.w - y.w; sum += d * d;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    od[m] = sqrtf(sum);
+    if (act) od[m] = sqrtf(sum);
   }
 }
 
@@ -909,8 +947,8 @@ void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t ma
                         uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n,
                         hipStream_t stream) {
   if (n_pairs == 0) return;
-  hipLaunchKernelGGL(sift_finish_kernel, dim3(n_pairs), dim3(kSiftThreads), 0, stream, f32_pool, work,
-                     max_kp, row_part, col_part, sm_q, sm_t, sm_d, sm_n);
+  hipLaunchKernelGGL(sift_finish_kernel, dim3((n_pairs + 7u) / 8u * 8u), dim3(kSiftThreads), 0, stream, f32_pool, work,
+                     max_kp, row_part, col_part, sm_q, sm_t, sm_d, sm_n, n_pairs);
 }
 
 }  // namespace rgbdfe
