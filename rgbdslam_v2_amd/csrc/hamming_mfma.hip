@@ -11,10 +11,11 @@
 //   * v_mfma_f32_32x32x64_f8f6f4 (cbsz = blgp = 4: both operands fp4) does 32 train rows x 32 queries x 64 bits per
 //     instruction, four of them per 32x32 tile: 2*32*32*256 FLOP at the fp4 rate (4x the bf16 rate) instead of
 //     16 VALU instructions per 64 compares;
-//   * the accumulator is initialised with  row_in_tile / 2^14, so an accumulator element is the complete sort key
-//     (2*hd - 256) + row/2^14  (24 significant bits at most: exact in f32) and "first minimum wins" is v_min_f32;
-//     train rows run along the accumulator registers of a lane, queries along the lanes, so the running minimum is
-//     ONE register per 32-query tile and the epilogue is a min3 tree: 10 VALU instructions per 16 matrix elements;
+//   * the accumulator is initialised with  256 + row_in_tile / 2^14, so an accumulator element is the complete sort key
+//     2*hd + row/2^14  (24 significant bits at most: exact in f32), non-negative, hence ordered like its bit pattern:
+//     "first minimum wins" is an unsigned integer minimum; train rows run along the accumulator registers of a lane,
+//     queries along the lanes, so the running minimum is ONE register per 32-query tile and the epilogue is a
+//     v_min3_u32 tree: 10 VALU instructions per 16 matrix elements;
 //   * a 256-thread block holds 256 queries (two 32-query operand tiles per wave) and streams the train tiles of the
 //     pair through LDS (16 KB stages, double buffered, one barrier per stage); the four waves share every tile.
 //
@@ -44,6 +45,7 @@ constexpr int kQueriesPerBlock = 4 * kQT * 32;  // 256
 constexpr int kStage = RGBDFE_HAMMING_STAGE;    // train tiles (of 32 rows, 4 KB each) per LDS stage
 constexpr float kNone = 3.0e38f;
 constexpr float kRowUnit = 1.0f / 16384.0f;  // 2^-14
+constexpr float kBias = 256.0f;  // element = 2*hd + row / 2^14 >= 0 (24 significant bits at most: 2*hd <= 512, row < 2^15)
 
 // 8 descriptor bits -> 8 fp4 nibbles (0x2 = +1.0 for a 0 bit, 0xA = -1.0 for a 1 bit)
 __device__ __forceinline__ uint32_t spread8(uint32_t x) {
@@ -79,15 +81,21 @@ __device__ __forceinline__ v8i as_operand(uint4 v) {
   return o;
 }
 
-__device__ __forceinline__ float min16(const v16f& a) {
-  const float m0 = fminf(fminf(a[0], a[1]), a[2]);
-  const float m1 = fminf(fminf(a[3], a[4]), a[5]);
-  const float m2 = fminf(fminf(a[6], a[7]), a[8]);
-  const float m3 = fminf(fminf(a[9], a[10]), a[11]);
-  const float m4 = fminf(fminf(a[12], a[13]), a[14]);
-  const float m5 = fminf(fminf(m0, m1), a[15]);
-  const float m6 = fminf(fminf(m2, m3), m4);
-  return fminf(m5, m6);
+// Accumulator elements are non-negative (the C operand carries a +256 bias next to the row term), and non-negative
+// floats order like their bit patterns: the minimum is an INTEGER min3 tree -- fminf would add a canonicalising v_max
+// in front of every v_min3_f32 (44 of ~190 VALU instructions per four tiles).
+__device__ __forceinline__ uint32_t min16(const v16f& a) {
+  uint32_t x[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = __float_as_uint(a[r]);
+  const uint32_t m0 = min(min(x[0], x[1]), x[2]);
+  const uint32_t m1 = min(min(x[3], x[4]), x[5]);
+  const uint32_t m2 = min(min(x[6], x[7]), x[8]);
+  const uint32_t m3 = min(min(x[9], x[10]), x[11]);
+  const uint32_t m4 = min(min(x[12], x[13]), x[14]);
+  const uint32_t m5 = min(min(m0, m1), x[15]);
+  const uint32_t m6 = min(min(m2, m3), m4);
+  return min(m5, m6);
 }
 
 template <int MODE, bool SPLIT>
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
   // accumulator register r of this lane belongs to train row (r & 3) + 8 * (r >> 2) + 4 * half of the tile
   v16f crow;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) crow[r] = (float)((r & 3) + 8 * (r >> 2) + 4 * (int)half) * kRowUnit;
+  for (int r = 0; r < 16; ++r) crow[r] = kBias + (float)((r & 3) + 8 * (r >> 2) + 4 * (int)half) * kRowUnit;
   v16f czero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) czero[r] = 0.f;
@@ -160,9 +168,9 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
     }
   }
 
-  float best[kQT];
+  uint32_t best[kQT];  // float bit patterns
 #pragma unroll
-  for (int t = 0; t < kQT; ++t) best[t] = kNone;
+  for (int t = 0; t < kQT; ++t) best[t] = __float_as_uint(kNone);
 
   const uint4* __restrict__ ts = slab + (size_t)w.t_slot * tiles_per_slot * 256u;
   const uint32_t n_tiles = tile1 - tile0;
@@ -211,16 +219,24 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t][r] += CROW[r];
         }
-        const float m = min16(acc[t]);
-        best[t] = fminf(best[t], m + base);  // kNone + base stays huge
+        const float m = __uint_as_float(min16(acc[t]));
+        best[t] = min(best[t], __float_as_uint(m + base));  // kNone + base stays huge
       }
     };
+    const uint32_t stage_tile0 = tile0 + st * kStage;
+    if (stage_tile0 + kStage <= tile1 && (stage_tile0 + kStage) * 32u <= nt_search) {
+      // a full stage without the ragged tile: ONE basic block, so the LDS reads of tile i + 1 can be scheduled beside
+      // the MFMAs of tile i
 #pragma unroll
-    for (int i = 0; i < kStage; ++i) {
-      const uint32_t tile = tile0 + st * kStage + (uint32_t)i;
-      if (tile < tile1) {  // block-uniform
-        if (tile * 32u + 32u > nt_search) do_tile(i, tile, crow_ragged);  // block-uniform: the pair's last tile only
-        else do_tile(i, tile, crow);
+      for (int i = 0; i < kStage; ++i) do_tile(i, stage_tile0 + (uint32_t)i, crow);
+    } else {
+#pragma unroll
+      for (int i = 0; i < kStage; ++i) {
+        const uint32_t tile = stage_tile0 + (uint32_t)i;
+        if (tile < tile1) {  // block-uniform
+          if (tile * 32u + 32u > nt_search) do_tile(i, tile, crow_ragged);  // block-uniform: the pair's last tile only
+          else do_tile(i, tile, crow);
+        }
       }
     }
 #pragma unroll
@@ -231,14 +247,15 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
   uint32_t* kout = keys + ((size_t)pair * tsplit + split) * max_kp;
 #pragma unroll
   for (int t = 0; t < kQT; ++t) {
-    float b = best[t];
-    b = fminf(b, __shfl_xor(b, 32));  // the two row halves of the tiles
+    uint32_t bb = best[t];
+    bb = min(bb, (uint32_t)__shfl_xor((int)bb, 32));  // the two row halves of the tiles
+    const float b = __uint_as_float(bb);
     const uint32_t qi = qblock * kQueriesPerBlock + (wave * kQT + (uint32_t)t) * 32u + (lane & 31u);
     if (half == 0 && qi < nq) {
       uint32_t key = kNoMatchKey;
       if (b < 1.0e30f) {
-        // (2*hd - 256) + row / 2^14  ->  hd * 2^15 + row   (exact: < 2^24)
-        const uint32_t k = (uint32_t)(b * 16384.0f + 4194304.0f);
+        // 2*hd + row / 2^14  ->  hd * 2^15 + row   (exact: < 2^24)
+        const uint32_t k = (uint32_t)(b * 16384.0f);
         key = ((k >> 15) << 16) | (k & 32767u);
       }
       kout[qi] = key;
