@@ -1185,8 +1185,18 @@ __device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const 
   const float E = 2.0f * ((2.0f * sqrtf(S) * 1.001f) * es + es * es + u4 * S) + 1e-30f;
   const float hi_f = S * 1.000001f + E;
   uint32_t may_pass = 0;
-  // four matches per trip: their 24 LDS reads are in flight together (the records behind n_all exist: PairPrep holds
-  // RGBDFE_MAX_MATCHES of them, a multiple of 4; what they contain does not count)
+  // Four matches per trip (their 24 LDS reads are in flight together), evaluated two at a time with packed f32
+  // arithmetic (v_pk_fma_f32 / v_pk_add_f32: the hypothesis' coefficients feed both halves).  No validity test per
+  // match: the count is an UPPER bound, and a match without depth (zero or NaN z; none survive removeDepthless in
+  // practice) or one of the up to three records behind n_all can only add to it -- the outcome of the iteration is the
+  // scoring's either way, the pre-screen merely fails to skip it.  The records behind n_all exist: PairPrep holds
+  // RGBDFE_MAX_MATCHES of them, a multiple of 4.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f R2[9], t2[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R2[i] = v2f{hypR[i], hypR[i]};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t2[i] = v2f{hypt[i], hypt[i]};
 #pragma unroll 1
   for (int m0 = 0; m0 < n_all; m0 += 4) {
     float rec[4][6];
@@ -1195,14 +1205,15 @@ __device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const 
 #pragma unroll
       for (int c = 0; c < 6; ++c) rec[u][c] = M[(m0 + u) * kRec + c];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float pxf = rec[u][0], pyf = rec[u][1], pzf = rec[u][2], qxf = rec[u][3], qyf = rec[u][4], qzf = rec[u][5];
-      const bool pre = (m0 + u < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
-      const float f0 = __builtin_fmaf(hypR[0], pxf, __builtin_fmaf(hypR[1], pyf, __builtin_fmaf(hypR[2], pzf, hypt[0]))) - qxf;
-      const float f1 = __builtin_fmaf(hypR[3], pxf, __builtin_fmaf(hypR[4], pyf, __builtin_fmaf(hypR[5], pzf, hypt[1]))) - qyf;
-      const float f2 = __builtin_fmaf(hypR[6], pxf, __builtin_fmaf(hypR[7], pyf, __builtin_fmaf(hypR[8], pzf, hypt[2]))) - qzf;
-      const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
-      may_pass += (pre && !(dsq_f > hi_f)) ? 1u : 0u;
+    for (int u = 0; u < 4; u += 2) {
+      const v2f px = {rec[u][0], rec[u + 1][0]}, py = {rec[u][1], rec[u + 1][1]}, pz = {rec[u][2], rec[u + 1][2]};
+      const v2f qx = {rec[u][3], rec[u + 1][3]}, qy = {rec[u][4], rec[u + 1][4]}, qz = {rec[u][5], rec[u + 1][5]};
+      const v2f f0 = __builtin_elementwise_fma(R2[0], px, __builtin_elementwise_fma(R2[1], py, __builtin_elementwise_fma(R2[2], pz, t2[0]))) - qx;
+      const v2f f1 = __builtin_elementwise_fma(R2[3], px, __builtin_elementwise_fma(R2[4], py, __builtin_elementwise_fma(R2[5], pz, t2[1]))) - qy;
+      const v2f f2 = __builtin_elementwise_fma(R2[6], px, __builtin_elementwise_fma(R2[7], py, __builtin_elementwise_fma(R2[8], pz, t2[2]))) - qz;
+      const v2f dsq = __builtin_elementwise_fma(f0, f0, __builtin_elementwise_fma(f1, f1, f2 * f2));
+      may_pass += !(dsq.x > hi_f) ? 1u : 0u;
+      may_pass += !(dsq.y > hi_f) ? 1u : 0u;
     }
   }
   return may_pass;
