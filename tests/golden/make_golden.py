@@ -7,6 +7,10 @@ hamming_golden.npz  -- inputs + outputs of the REFERENCE's own bruteForceSearchO
                        (src/features.cpp:163-182 compiled into oracle/_ref/libref_bforb.so).
 pair_golden.npz     -- frozen outputs of the oracle's full pair path on a small seeded
                        sequence (guards the oracle against drift; "parity unpinned" parts).
+sift_golden.npz     -- REAL SIFT descriptors (the 677 features of external/SiftGPU/doc/evaluation/box.siftgpu, the only
+                       golden feature file in the reference tree) matched against derived sets by the REFERENCE's own
+                       matcher: MultiplyDescriptor / RowMatch / ColMatch kernels + SiftMatchCU + SiftGPUWrapper::match
+                       compiled from where they lie into oracle/_ref/libref_siftmatch.so (CUDA-on-CPU emulation).
 """
 import os
 import sys
@@ -50,8 +54,46 @@ def hamming_cases():
     return cases
 
 
+def read_siftgpu_ascii(path):
+    """Lowe's ASCII feature format: "n 128", then per feature  y x scale orientation  and 128 integers 0..255."""
+    tok = open(path).read().split()
+    n, dim = int(tok[0]), int(tok[1])
+    vals = np.array(tok[2:], dtype=np.float64).reshape(n, 4 + dim)
+    return vals[:, :4].astype(np.float32), vals[:, 4:].astype(np.uint8)
+
+
+def sift_cases():
+    """(name, d1, d2) float32 descriptor sets.  A descriptor byte b is stored as b / 512, which the matcher's
+    quantisation int(512 f + 0.5) turns back into b exactly (SiftMatchCU.cpp:96-99)."""
+    _, box = read_siftgpu_ascii("/root/reference/external/SiftGPU/doc/evaluation/box.siftgpu")
+    rng = np.random.Generator(np.random.PCG64(677))
+    f = box.astype(np.float32) / 512.0
+    cases = []
+    # the image against a "second view": a permuted subset with +-3 noise on a fifth of the bytes
+    perm = rng.permutation(len(box))[:520]
+    noisy = box[perm].astype(np.int32)
+    hit = rng.random(noisy.shape) < 0.2
+    noisy = np.clip(noisy + hit * rng.integers(-3, 4, noisy.shape), 0, 255).astype(np.float32) / 512.0
+    cases.append(("view", f, noisy.astype(np.float32)))
+    # the image against itself (every feature's best match is itself; near-duplicates in the image decide the ratio test)
+    cases.append(("self", f, f.copy()))
+    # a small query set with exact duplicates on the train side (tie rules on real descriptors), ragged sizes
+    d2 = f[rng.integers(0, len(box), 333)].copy()
+    cases.append(("dups", f[:97].copy(), d2))
+    return cases
+
+
 def main():
     assert po.ref_lib() is not None, "reference pin not built (needs /root/reference)"
+    assert po.ref_sift_lib() is not None, "oracle/_ref/libref_siftmatch.so not built"
+    g = {}
+    for name, d1, d2 in sift_cases():
+        q, t, d = po.ref_sift_match(d1, d2)
+        g[name + "_d1"], g[name + "_d2"] = (d1 * 512.0 + 0.5).astype(np.uint8), (d2 * 512.0 + 0.5).astype(np.uint8)
+        g[name + "_q"], g[name + "_t"], g[name + "_dist"] = np.asarray(q, np.int32), np.asarray(t, np.int32), np.asarray(d, np.float32)
+        assert np.array_equal(g[name + "_d1"].astype(np.float32) / 512.0, d1) and np.array_equal(g[name + "_d2"].astype(np.float32) / 512.0, d2)
+        print("sift golden", name, d1.shape, d2.shape, "matches", len(q))
+    np.savez_compressed(os.path.join(HERE, "sift_golden.npz"), **g)
     out = {}
     for name, (q, t) in hamming_cases().items():
         hd = np.empty(q.shape[0], np.int32)

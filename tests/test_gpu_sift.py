@@ -2,6 +2,8 @@
 the oracle.  The dot products are integers computed exactly on the matrix cores, so match lists
 are compared bit-exactly; distances and poses are float and asserted both within tolerance and
 bit-equal (same operation order)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -217,3 +219,20 @@ def test_sift_pair_op_ragged_and_empty_nodes(fe):
         fe.set_params(max_matches=300, min_matches=20, ransac_iterations=200)
         for f in range(F):
             fe.release_node(f)
+
+
+def test_sift_golden_vectors_from_the_reference_matcher(fe):
+    """The HIP matcher against tests/golden/sift_golden.npz: real SIFT descriptors (box.siftgpu of the reference tree)
+    matched by the reference's own matcher code (see tests/test_oracle_sift.py and tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sift_golden.npz"))
+    rng = np.random.default_rng(5)
+    for name in ("view", "self", "dups"):
+        d1 = g[name + "_d1"].astype(np.float32) / 512.0
+        d2 = g[name + "_d2"].astype(np.float32) / 512.0
+        fe.upload_sift_node(1, d1, _xyz(rng, len(d1)))
+        fe.upload_sift_node(2, d2, _xyz(rng, len(d2)))
+        mq, mt, md = fe.sift_match_nodes(1, 2)
+        assert np.array_equal(mq, g[name + "_q"]) and np.array_equal(mt, g[name + "_t"]), name
+        assert np.array_equal(md, g[name + "_dist"]), name
+        fe.release_node(1)
+        fe.release_node(2)

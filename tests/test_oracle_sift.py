@@ -1,5 +1,7 @@
 """CPU checks of the oracle's SiftGPUWrapper::match restatement against an independent numpy
 formulation (integer dot matrix + explicit tie rules)."""
+import os
+
 import numpy as np
 
 from oracle import pyoracle as po
@@ -165,3 +167,24 @@ def test_sift_match_matches_the_reference_trees_own_matcher():
         assert np.array_equal(md, rd)
         n_total += len(mq)
     assert n_total > 100
+
+
+GOLD_SIFT = os.path.join(os.path.dirname(__file__), "golden", "sift_golden.npz")
+
+
+def test_sift_golden_vectors_from_the_reference_matcher():
+    """tests/golden/sift_golden.npz (tests/golden/make_golden.py): the 677 real SIFT descriptors of the reference tree's
+    only golden feature file (external/SiftGPU/doc/evaluation/box.siftgpu) against a noisy permuted subset, against
+    themselves and against a set with exact duplicates, matched by the reference's OWN matcher code (SiftGPU's CUDA
+    kernels + SiftMatchCU + SiftGPUWrapper::match compiled into oracle/_ref/libref_siftmatch.so).  The oracle must
+    return the same (queryIdx, trainIdx) list and the same float distances."""
+    g = np.load(GOLD_SIFT)
+    total = 0
+    for name in ("view", "self", "dups"):
+        d1 = g[name + "_d1"].astype(np.float32) / 512.0
+        d2 = g[name + "_d2"].astype(np.float32) / 512.0
+        mq, mt, md = po.sift_match(d1, d2)
+        assert np.array_equal(mq, g[name + "_q"]) and np.array_equal(mt, g[name + "_t"]), name
+        assert np.array_equal(md, g[name + "_dist"]), name
+        total += len(mq)
+    assert total == 520 + 677 + 37
