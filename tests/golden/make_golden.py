@@ -6,7 +6,9 @@ for the executable reference pin):
 hamming_golden.npz  -- inputs + outputs of the REFERENCE's own bruteForceSearchORB
                        (src/features.cpp:163-182 compiled into oracle/_ref/libref_bforb.so).
 pair_golden.npz     -- frozen outputs of the oracle's full pair path on a small seeded
-                       sequence (guards the oracle against drift; "parity unpinned" parts).
+                       sequence (guards the oracle against drift; "parity unpinned" parts), and next to
+                       them (keys p<k>_ref_*) what the REFERENCE's own Node::matchNodePair returns for
+                       the same pairs (oracle/_ref/libref_ransac.so: src/node.cpp compiled in place).
 sift_golden.npz     -- REAL SIFT descriptors (the 677 features of external/SiftGPU/doc/evaluation/box.siftgpu, the only
                        golden feature file in the reference tree) matched against derived sets by the REFERENCE's own
                        matcher: MultiplyDescriptor / RowMatch / ColMatch kernels + SiftMatchCU + SiftGPUWrapper::match
@@ -86,6 +88,7 @@ def sift_cases():
 def main():
     assert po.ref_lib() is not None, "reference pin not built (needs /root/reference)"
     assert po.ref_sift_lib() is not None, "oracle/_ref/libref_siftmatch.so not built"
+    assert po.ref_ransac_lib() is not None, "oracle/_ref/libref_ransac.so not built"
     g = {}
     for name, d1, d2 in sift_cases():
         q, t, d = po.ref_sift_match(d1, d2)
@@ -113,6 +116,11 @@ def main():
         for key in ("id1", "id2", "n_all", "n_inl", "rmse", "T", "info_scale", "valid_iterations",
                     "real_iterations", "all_q", "all_t", "all_hd", "inl_idx"):
             g[f"p{k}_{key}"] = np.asarray(r[key])
+        # the same pair through the REFERENCE's own Node::matchNodePair (oracle/_ref/libref_ransac.so: first-party code
+        # compiled from /root/reference, third-party arithmetic from the stand-ins of DESIGN.md 3)
+        ref = po.ref_match_node_pair(seq["desc"][q], seq["xyz1"][q], q, seq["desc"][t], seq["xyz1"][t], t, prm)
+        for key in ("id1", "id2", "T", "rmse", "info_scale", "real_iterations", "all_q", "all_t", "inl_q", "inl_t", "accepted"):
+            g[f"p{k}_ref_{key}"] = np.asarray(ref[key])
     np.savez_compressed(os.path.join(HERE, "pair_golden.npz"), **g)
     print("golden fixtures written")
 

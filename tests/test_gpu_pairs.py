@@ -67,6 +67,15 @@ def test_frozen_golden_pairs(fe):
         T = np.array(rec["trafo"], np.float32).reshape(4, 4).T
         assert np.abs(T - g[f"p{k}_T"]).max() <= POSE_TOL
         assert np.array_equal(T, g[f"p{k}_T"])
+        # ... and against what the REFERENCE's own Node::matchNodePair returned for the pair when the fixture was made
+        # (keys p<k>_ref_*: src/node.cpp compiled in place, tests/golden/make_golden.py)
+        assert (rec["id1"], rec["id2"]) == (int(g[f"p{k}_ref_id1"]), int(g[f"p{k}_ref_id2"]))
+        assert np.array_equal(rec["all_q"][:n], g[f"p{k}_ref_all_q"]) and np.array_equal(rec["all_t"][:n], g[f"p{k}_ref_all_t"])
+        ii = inlier_indices(rec)
+        assert np.array_equal(rec["all_q"][:n][ii], g[f"p{k}_ref_inl_q"]) and np.array_equal(rec["all_t"][:n][ii], g[f"p{k}_ref_inl_t"])
+        assert np.array_equal(T, g[f"p{k}_ref_T"]) and np.float32(rec["rmse"]) == g[f"p{k}_ref_rmse"]
+        assert rec["info_scale"] == float(g[f"p{k}_ref_info_scale"])
+        assert rec["real_iterations"] == int(g[f"p{k}_ref_real_iterations"])
     for f in range(g["desc"].shape[0]):
         fe.release_node(f)
     fe.set_params(seed=20260923, depth_cov=1e-4)

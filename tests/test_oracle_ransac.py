@@ -329,6 +329,14 @@ def test_oracle_frozen_pair_outputs():
             assert r[key] == int(g[f"p{k}_{key}"]), key
         for key in ("all_q", "all_t", "all_hd", "inl_idx", "T", "rmse"):
             assert np.array_equal(np.asarray(r[key]), g[f"p{k}_{key}"]), key
+        # the reference's own Node::matchNodePair on the same pair, frozen in the fixture (keys p<k>_ref_*)
+        for key in ("id1", "id2", "real_iterations"):
+            assert r[key] == int(g[f"p{k}_ref_{key}"]), key
+        assert np.array_equal(r["all_q"], g[f"p{k}_ref_all_q"]) and np.array_equal(r["all_t"], g[f"p{k}_ref_all_t"])
+        assert np.array_equal(r["all_q"][r["inl_idx"]], g[f"p{k}_ref_inl_q"])
+        assert np.array_equal(r["all_t"][r["inl_idx"]], g[f"p{k}_ref_inl_t"])
+        assert np.array_equal(r["T"], g[f"p{k}_ref_T"]) and r["rmse"] == g[f"p{k}_ref_rmse"]
+        assert r["info_scale"] == float(g[f"p{k}_ref_info_scale"])
 
 
 def test_project_to_3d_oracle():
