@@ -9,6 +9,9 @@ pair_golden.npz     -- frozen outputs of the oracle's full pair path on a small 
                        sequence (guards the oracle against drift; "parity unpinned" parts), and next to
                        them (keys p<k>_ref_*) what the REFERENCE's own Node::matchNodePair returns for
                        the same pairs (oracle/_ref/libref_ransac.so: src/node.cpp compiled in place).
+frame_golden.npz    -- Node::projectTo3D / removeDepthless (src/node.cpp:66-97, 900-965), projectTo3DSiftGPU (:695-769) and
+                       squareroot_descriptor_space (:1557-1571) as compiled from the reference into
+                       oracle/_ref/libref_frame.so: inputs + the reference functions' outputs.
 sift_golden.npz     -- REAL SIFT descriptors (the 677 features of external/SiftGPU/doc/evaluation/box.siftgpu, the only
                        golden feature file in the reference tree) matched against derived sets by the REFERENCE's own
                        matcher: MultiplyDescriptor / RowMatch / ColMatch kernels + SiftMatchCU + SiftGPUWrapper::match
@@ -85,8 +88,58 @@ def sift_cases():
     return cases
 
 
+def frame_golden():
+    """Small frames through the reference's own frame-level functions (rows a4, a7, a20)."""
+    import ctypes as C
+    R = po.ref_frame_lib()
+    assert R is not None, "oracle/_ref/libref_frame.so not built"
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rng = np.random.Generator(np.random.PCG64(4096))
+    g = {}
+    for tag, rows, cols, n, maxk, scale in (("a", 48, 64, 700, 50, 0.5), ("b", 96, 128, 400, 1000, 1.0)):
+        depth = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+        depth[rng.random((rows, cols)) < 0.15] = np.nan
+        kp = np.stack([rng.uniform(-3, cols + 3, n), rng.uniform(-3, rows + 3, n)], 1).astype(np.float32)
+        kp[(kp[:, 0] >= cols - 0.5) & (kp[:, 0] < cols), 0] = 5.25   # the reference reads out of bounds there
+        kp[(kp[:, 1] >= rows - 0.5) & (kp[:, 1] < rows), 1] = 7.75
+        kp[3] = [np.nan, 5.0]
+        kp[5] = [10.5, 20.5]  # ties: round half away from zero
+        f = 525.0 * cols / 640
+        K = np.array([f, f * 1.01, (cols - 1) / 2, (rows - 1) / 2, scale], np.float64)
+        kept = np.zeros(n, np.int32)
+        xyz = np.zeros((n, 4), np.float32)
+        k = R.ref_project_to_3d(p(kp), n, p(depth), rows, cols, *[float(v) for v in K[:4]], float(scale), maxk, p(kept), p(xyz))
+        g[f"p3d_{tag}_kp"], g[f"p3d_{tag}_depth"], g[f"p3d_{tag}_K"], g[f"p3d_{tag}_maxk"] = kp, depth, K, np.int32(maxk)
+        g[f"p3d_{tag}_kept"], g[f"p3d_{tag}_xyz"] = kept[:k].copy(), xyz[:k].copy()
+        k2 = R.ref_remove_depthless(p(kp), n, p(depth), rows, cols, p(kept))
+        g[f"p3d_{tag}_depthless_kept"] = kept[:k2].copy()
+    # the SIFTGPU node path: truncating depth lookup, re-packed descriptors, RootSIFT
+    rows, cols, n, maxk = 48, 64, 300, 40
+    depth = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+    depth[rng.random((rows, cols)) < 0.15] = np.nan
+    kp = np.stack([rng.uniform(0, cols - 0.01, n), rng.uniform(0, rows - 0.01, n)], 1).astype(np.float32)
+    kp[5] = [10.9999959, 20.5]
+    desc = rng.gamma(0.6, 1.0, (n, 128)).astype(np.float32)
+    desc[6] = 0.0
+    desc[8] *= -1.0
+    K = np.array([525.0 * cols / 640, 520.0 * cols / 640, (cols - 1) / 2, (rows - 1) / 2, 1.0], np.float64)
+    kept = np.zeros(n, np.int32)
+    xyz = np.zeros((n, 4), np.float32)
+    dout = np.zeros((n, 128), np.float32)
+    sgpu = np.zeros((n, 128), np.float32)
+    k = R.ref_project_to_3d_sift(p(kp), n, p(desc), p(depth), rows, cols, *[float(v) for v in K[:4]], 1.0, maxk, p(kept), p(xyz),
+                                 p(dout), p(sgpu))
+    feat = dout[:k].copy()
+    R.ref_root_sift(p(feat), k, 128)
+    g["sift_kp"], g["sift_desc"], g["sift_depth"], g["sift_K"], g["sift_maxk"] = kp, desc, depth, K, np.int32(maxk)
+    g["sift_kept"], g["sift_xyz"], g["sift_raw"], g["sift_root"] = kept[:k].copy(), xyz[:k].copy(), dout[:k].copy(), feat
+    np.savez_compressed(os.path.join(HERE, "frame_golden.npz"), **g)
+    print("frame golden: kept", [len(g[f"p3d_{t}_kept"]) for t in "ab"], "sift", k)
+
+
 def main():
     assert po.ref_lib() is not None, "reference pin not built (needs /root/reference)"
+    frame_golden()
     assert po.ref_sift_lib() is not None, "oracle/_ref/libref_siftmatch.so not built"
     assert po.ref_ransac_lib() is not None, "oracle/_ref/libref_ransac.so not built"
     g = {}

@@ -173,3 +173,22 @@ def test_use_feature_min_depth_mode():
     kp2, _, _ = fe.detect_describe(fr["gray"][0], np.full(fr["gray"][0].shape, 255, np.uint8), fr["depth"][0], *K)
     assert len(kp2) > 100
     fe.close()
+
+
+def test_frame_golden_from_the_reference_functions():
+    """The HIP frame-level kernels against tests/golden/frame_golden.npz: the outputs of the reference's own
+    Node::projectTo3D / removeDepthless / projectTo3DSiftGPU / squareroot_descriptor_space on the same inputs
+    (tests/golden/make_golden.py; see tests/test_oracle_frame_golden.py)."""
+    import os
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_golden.npz"))
+    fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=1024, max_pairs_per_batch=4)
+    for tag in "ab":
+        kp, depth, K, maxk = g[f"p3d_{tag}_kp"], g[f"p3d_{tag}_depth"], g[f"p3d_{tag}_K"], int(g[f"p3d_{tag}_maxk"])
+        kept, xyz = fe.project_to_3d(kp, depth, *[float(v) for v in K[:4]], float(K[4]), maxk)
+        assert np.array_equal(kept, g[f"p3d_{tag}_kept"]) and np.array_equal(xyz, g[f"p3d_{tag}_xyz"])
+    K = g["sift_K"]
+    got = fe.sift_node_features(g["sift_kp"], g["sift_desc"], g["sift_depth"], *[float(v) for v in K[:4]], float(K[4]),
+                                int(g["sift_maxk"]), True)
+    assert np.array_equal(got[0], g["sift_kept"]) and np.array_equal(got[1], g["sift_xyz"])
+    assert np.array_equal(got[2], g["sift_raw"]) and np.array_equal(got[3], g["sift_root"])
