@@ -133,8 +133,72 @@ def frame_golden():
     R.ref_root_sift(p(feat), k, 128)
     g["sift_kp"], g["sift_desc"], g["sift_depth"], g["sift_K"], g["sift_maxk"] = kp, desc, depth, K, np.int32(maxk)
     g["sift_kept"], g["sift_xyz"], g["sift_raw"], g["sift_root"] = kept[:k].copy(), xyz[:k].copy(), dout[:k].copy(), feat
+    # createXYZRGBPointCloud (misc.cpp:467-556) + observationLikelihood (misc.cpp:814-969) on three small depth frames
+    seq = synth.make_depth_sequence(n_frames=3, width=160, height=120, nan_fraction=0.05)
+    Ke = (float(seq["fx"]), float(seq["fy"]), float(seq["cx"]), float(seq["cy"]))
+    g["emm_depth"] = np.asarray(seq["depth"], np.float32)
+    g["emm_K"] = np.array(Ke, np.float64)
+    clouds = []
+    for f in range(3):
+        d = np.ascontiguousarray(seq["depth"][f], np.float32)
+        rows, cols = d.shape
+        c = np.zeros((rows // 2, cols // 2, 4), np.float32)
+        gray = np.ascontiguousarray(rng.integers(0, 256, (rows, cols), dtype=np.uint8))
+        R.ref_create_point_cloud(p(d), rows, cols, p(gray), 1, 0, *Ke, 1.0, 0.1, 2, p(c))
+        clouds.append(c)
+        g.setdefault("emm_gray", []).append(gray)
+    g["emm_gray"] = np.stack(g["emm_gray"])
+    g["emm_clouds"] = np.stack(clouds)
+    jobs, counts = [], []
+    for n in range(3):
+        for o in range(3):
+            T = synth.relative_pose(seq["poses"], n, o).astype(np.float32)
+            Tp = T.copy()
+            Tp[:3, 3] += rng.normal(0, 0.08, 3).astype(np.float32)
+            for TT in (T, Tp):
+                TT = np.ascontiguousarray(TT, np.float32)
+                out = np.zeros(4, np.uint32)
+                R.ref_observation_likelihood(p(clouds[n]), p(clouds[o]), clouds[o].shape[0], clouds[o].shape[1], p(TT), *Ke, 2, 8,
+                                             1e-4, p(out))
+                jobs.append((n, o)); counts.append(out.copy())
+                g.setdefault("emm_T", [])
+                g["emm_T"].append(TT)
+    g["emm_T"] = np.stack(g["emm_T"])
+    g["emm_jobs"], g["emm_counts"] = np.array(jobs, np.int32), np.stack(counts)
+    # the point-cloud constructor's projection (node.cpp:855-898) and the use_feature_min_depth variant (misc.cpp:774-793)
+    rows, cols, n, maxk, maxd = 48, 64, 500, 60, 2.5
+    cloud = np.zeros((rows, cols, 4), np.float32)
+    cloud[..., 0] = rng.uniform(-2, 2, (rows, cols)); cloud[..., 1] = rng.uniform(-2, 2, (rows, cols))
+    cloud[..., 2] = rng.uniform(0.4, 5.0, (rows, cols)); cloud[..., 3] = rng.uniform(0, 1, (rows, cols))
+    for ch in range(3):
+        cloud[..., ch][rng.random((rows, cols)) < 0.05] = np.nan
+    kp = np.stack([rng.uniform(-3, cols + 3, n), rng.uniform(-3, rows + 3, n)], 1).astype(np.float32)
+    kp[3] = [np.nan, 5.0]
+    kp[5] = [10.9999959, 20.5]
+    kept = np.zeros(n, np.int32)
+    xyz = np.zeros((n, 4), np.float32)
+    k = R.ref_project_to_3d_cloud(p(kp), n, p(cloud), rows, cols, maxd, maxk, p(kept), p(xyz))
+    g["cloudp_kp"], g["cloudp_cloud"], g["cloudp_maxd"], g["cloudp_maxk"] = kp, cloud, np.float64(maxd), np.int32(maxk)
+    g["cloudp_kept"], g["cloudp_xyz"] = kept[:k].copy(), xyz[:k].copy()
+    rows, cols, n, maxk, scale = 60, 80, 300, 1000, 1.0
+    depth = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+    depth[rng.random((rows, cols)) < 0.3] = np.nan
+    depth[10:30, 20:50] = np.nan
+    depth[5, 7] = 0.0
+    kp = np.stack([rng.uniform(-3, cols + 3, n), rng.uniform(-3, rows + 3, n)], 1).astype(np.float32)
+    size = (31.0 * 1.2 ** rng.integers(0, 8, n)).astype(np.float32)
+    size[:20] = [1.0, 2.0, 2.9, 3.0, 0.5] * 4
+    f = 525.0 * cols / 640
+    Km = (f, f * 1.01, (cols - 1) / 2, (rows - 1) / 2)
+    kept = np.zeros(n, np.int32)
+    xyz = np.zeros((n, 4), np.float32)
+    k = R.ref_project_to_3d_min_depth(p(kp), p(size), n, p(depth), rows, cols, C.c_double(Km[0]), C.c_double(Km[1]),
+                                      C.c_double(Km[2]), C.c_double(Km[3]), C.c_double(scale), maxk, p(kept), p(xyz))
+    g["mind_kp"], g["mind_size"], g["mind_depth"], g["mind_K"] = kp, size, depth, np.array(Km + (scale,), np.float64)
+    g["mind_kept"], g["mind_xyz"] = kept[:k].copy(), xyz[:k].copy()
     np.savez_compressed(os.path.join(HERE, "frame_golden.npz"), **g)
-    print("frame golden: kept", [len(g[f"p3d_{t}_kept"]) for t in "ab"], "sift", k)
+    print("frame golden: emm counts", g["emm_counts"].sum(0), "cloud proj", len(g["cloudp_kept"]), "min depth", len(g["mind_kept"]))
+    print("frame golden: kept", [len(g[f"p3d_{t}_kept"]) for t in "ab"], "sift", len(g["sift_kept"]))
 
 
 def main():

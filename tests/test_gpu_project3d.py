@@ -192,3 +192,20 @@ def test_frame_golden_from_the_reference_functions():
                                 int(g["sift_maxk"]), True)
     assert np.array_equal(got[0], g["sift_kept"]) and np.array_equal(got[1], g["sift_xyz"])
     assert np.array_equal(got[2], g["sift_raw"]) and np.array_equal(got[3], g["sift_root"])
+    # point-cloud constructor's projection and the use_feature_min_depth variant
+    kept, xyz = fe.project_to_3d_cloud(g["cloudp_kp"], g["cloudp_cloud"], float(g["cloudp_maxd"]), int(g["cloudp_maxk"]))
+    assert np.array_equal(kept, g["cloudp_kept"]) and np.array_equal(xyz, g["cloudp_xyz"])
+    K = [float(v) for v in g["mind_K"]]
+    kept, xyz = fe.project_to_3d_min_depth(g["mind_kp"], g["mind_size"], g["mind_depth"], *K[:4], K[4], 1000)
+    assert np.array_equal(kept, g["mind_kept"]) and np.array_equal(xyz, g["mind_xyz"])
+    # createXYZRGBPointCloud + observationLikelihood
+    K = [float(v) for v in g["emm_K"]]
+    fe2 = FrontEnd(device_id=0, max_nodes=4, max_keypoints=64, max_pairs_per_batch=4)
+    for f in range(3):
+        c = fe2.upload_node_cloud(f, g["emm_depth"][f], *K, rgb=g["emm_gray"][f], encoding_bgr=False, depth_scaling=1.0,
+                                  min_depth=0.1, cloud_skip=2, return_cloud=True)
+        assert np.array_equal(c.view(np.uint32), g["emm_clouds"][f].view(np.uint32))
+    got = fe2.observation_likelihood(g["emm_jobs"][:, 0], g["emm_jobs"][:, 1], g["emm_T"], 8)
+    assert np.array_equal(got, g["emm_counts"])
+    fe2.close()
+    fe.close()
