@@ -312,6 +312,35 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
   return RGBDFE_OK;
 }
 
+// upload_and_build in two halves for the batch entry point.  Two host threads inside the HIP runtime at once serialise on
+// its locks (measured: the calling thread's five launches of a detection pass took 105 us instead of 16 while the helper
+// thread was issuing the next frame's copies and pyramid launches), so the helper only does the CPU half -- the copy of the
+// pageable images into the set's pinned staging buffer -- and the calling thread enqueues the device half while it would
+// otherwise wait for a pass.
+void OrbWorkspace::stage_images(const uint8_t* gray, const uint8_t* mask, int set) {
+  uint8_t* const h = himg_set[set];
+  const size_t img = (size_t)W * H;
+  memcpy(h, gray, img);
+  if (mask) memcpy(h + img, mask, img);
+}
+
+int OrbWorkspace::enqueue_staged(bool has_mask, hipStream_t s, std::string& err, int set) {
+  uint8_t* const d_pool = pool_set[set];
+  uint8_t* const d_blur = blur_set[set];
+  const size_t img = (size_t)W * H;
+  ORB_HIP(hipMemcpyAsync(d_pool, himg_set[set], has_mask ? 2 * img : img, hipMemcpyHostToDevice, s));
+  if (!has_mask) ORB_HIP(hipMemsetAsync(d_pool + img, 255, img, s));
+  for (int l = 1; l < kLevels; ++l) {
+    const int b = level_job_begin[l], e = level_job_begin[l + 1];
+    int mw = 0, mh = 0;
+    for (int k = b; k < e; ++k) { mw = std::max(mw, jobs[k].dw); mh = std::max(mh, jobs[k].dh); }
+    launch_orb_resize(d_pool, d_jobs + b, e - b, mw, mh, s);
+  }
+  launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+  ORB_HIP(hipGetLastError());
+  return RGBDFE_OK;
+}
+
 // The device half of a detection pass over the active cells at the given FAST thresholds: every corner that survives
 // NMS, the mask and the border filters, in raster order per (cell, level) image, with its FAST score, Harris response
 // and orientation -- read back in one round trip (pass_raw, h_totals, h_base).
@@ -332,13 +361,13 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
   launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, ctl, d_score, kDetectEdge, d_row_cnt, d_img_total, d_kps, bound, s);
   ORB_HIP(hipGetLastError());
   ORB_HIP(hipMemcpyAsync(h_passout, d_passout, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));  // counts + keypoints
+  const double tp1 = timing.on ? orb_now_us() : 0;  // the caller's hook below is its own time, not the pass's
   if (before_wait) {  // the caller's own host work (the next frame's upload) rides on this pass's device time
     std::function<int()> f = std::move(before_wait);
     before_wait = nullptr;
     const int rc = f();
     if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(s); err = "prefetch of the next frame failed"; return rc; }
   }
-  const double tp1 = timing.on ? orb_now_us() : 0;
   ORB_HIP(hipStreamSynchronize(s));
   const double tp2 = timing.on ? orb_now_us() : 0;
   int n_total = 0;

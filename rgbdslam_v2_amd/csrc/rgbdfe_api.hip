@@ -95,6 +95,7 @@ struct rgbdfe_ctx {
   hipStream_t orb_upload_stream = nullptr;  // rgbdfe_detect_describe_batch: uploads of frame k+1 beside frame k
   hipStream_t orb_compute_stream = nullptr; // ... and frame k's description beside frame k+1's detection
   hipEvent_t orb_upload_done[2] = {nullptr, nullptr};
+  hipEvent_t orb_describe_done[2] = {nullptr, nullptr};  // frame f's description has left image set f & 1
   bool feature_min_depth = false;  // "use_feature_min_depth" (parameter_server.cpp:90): rgbdfe_set_feature_min_depth
   bool sift_fast = true;       // sift_match.hip's float keys where a pair qualifies (RGBDFE_SIFT_FAST_KEYS=0: never)
   int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
@@ -659,6 +660,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   if (ctx->d_kp2d) (void)hipFree(ctx->d_kp2d);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   for (hipEvent_t e : ctx->orb_upload_done) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->orb_describe_done) if (e) (void)hipEventDestroy(e);
   if (ctx->orb_upload_stream) (void)hipStreamDestroy(ctx->orb_upload_stream);
   if (ctx->orb_compute_stream) (void)hipStreamDestroy(ctx->orb_compute_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1429,36 +1431,29 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_compute_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_upload_done[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_describe_done[i], hipEventDisableTiming));
   }
   hipStream_t up = ctx->orb_upload_stream;
-  // Frame f lives in image set f & 1.  The helper thread stages, uploads and builds the pyramid of frame f as soon as
-  // the frame that used the set before (f - 2) is finished; the calling thread detects frame f once its upload has been
-  // enqueued (the stream waits for the event).  Host work of the two threads and device work of the two streams overlap.
+  // Frame f lives in image set f & 1 (device pyramid + pinned staging buffer).  A helper thread copies the caller's
+  // pageable images of frame f into the set's staging buffer as soon as frame f - 2 has been detected (its upload from that
+  // buffer is complete then) -- CPU work only: two host threads inside the HIP runtime at once serialise on its locks, and
+  // the calling thread's launches are the critical path.  The calling thread enqueues the device half of frame f + 2's
+  // upload (one copy + the pyramid launches, on a second stream) from the hook of frame f + 1's detection pass, behind
+  // frame f's description, which reads the same set.
   std::mutex m;
   std::condition_variable cv;
-  int uploaded = 0, finished = 0, up_rc = RGBDFE_OK;  // frames enqueued by the helper / completed by the caller
+  int staged = 0, detected = 0;  // frames staged by the helper / detected by the caller
   bool stop = false;
-  std::string up_err;
-  const int dev = ctx->cfg.device_id;
   std::thread helper([&]() {
-    if (hipSetDevice(dev) != hipSuccess) {
-      std::lock_guard<std::mutex> l(m);
-      up_rc = RGBDFE_ERR_HIP; up_err = "hipSetDevice in the upload thread";
-      cv.notify_all();
-      return;
-    }
     for (int32_t f = 0; f < n_frames; ++f) {
       {
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return stop || finished >= f - 1; });  // frame f - 2 done: its set is free
+        cv.wait(l, [&] { return stop || detected >= f - 1; });
         if (stop) return;
       }
-      std::string e2;
-      int r = orb.upload_and_build(gray[f], mask ? mask[f] : nullptr, up, e2, f & 1);
-      if (r == RGBDFE_OK && hipEventRecord(ctx->orb_upload_done[f & 1], up) != hipSuccess) { r = RGBDFE_ERR_HIP; e2 = "hipEventRecord"; }
+      orb.stage_images(gray[f], mask ? mask[f] : nullptr, f & 1);
       std::lock_guard<std::mutex> l(m);
-      if (r != RGBDFE_OK) { up_rc = r; up_err = e2; cv.notify_all(); return; }
-      uploaded = f + 1;
+      staged = f + 1;
       cv.notify_all();
     }
   });
@@ -1483,25 +1478,44 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
     d.keypoints = keypoints + (size_t)f * out_stride; d.descriptors = descriptors + (size_t)f * out_stride * 32;
     d.xyz1 = xyz1 + (size_t)f * out_stride * 4; d.n_out = n_out + f;
   };
-  auto wait_upload = [&](int32_t f) -> int {  // frame f's images and pyramid are (being) built: order ctx->stream after them
-    std::unique_lock<std::mutex> l(m);
-    cv.wait(l, [&] { return up_rc != RGBDFE_OK || uploaded > f; });
-    if (up_rc != RGBDFE_OK) { err = up_err; return up_rc; }
-    l.unlock();
+  auto enqueue_upload = [&](int32_t f) -> int {  // the device half of frame f's upload, on `up`
+    {
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [&] { return staged > f; });
+    }
+    // the set was frame f - 2's: its description (second stream) reads the pyramid this upload overwrites
+    if (f >= 2 && hipStreamWaitEvent(up, ctx->orb_describe_done[f & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
+    const int r = orb.enqueue_staged(mask != nullptr && mask[f] != nullptr, up, err, f & 1);
+    if (r != RGBDFE_OK) return r;
+    if (hipEventRecord(ctx->orb_upload_done[f & 1], up) != hipSuccess) { err = "hipEventRecord"; return RGBDFE_ERR_HIP; }
+    return RGBDFE_OK;
+  };
+  auto wait_upload = [&](int32_t f) -> int {  // order ctx->stream behind frame f's upload and pyramid
     if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[f & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
     return RGBDFE_OK;
+  };
+  auto mark_detected = [&](int32_t f) {
+    std::lock_guard<std::mutex> l(m);
+    detected = f + 1;
+    cv.notify_all();
   };
   auto describe = [&](int32_t f) -> int {  // enqueue frame f's description on the second stream, from its own image set
     orb.use_set(f & 1);
     if (hipStreamWaitEvent(st2, ctx->orb_upload_done[f & 1], 0) != hipSuccess) return RGBDFE_ERR_HIP;
-    return fr[(size_t)(f & 1)].describe_enqueue(st2);
+    const int r = fr[(size_t)(f & 1)].describe_enqueue(st2);
+    if (r != RGBDFE_OK) return r;
+    return hipEventRecord(ctx->orb_describe_done[f & 1], st2) == hipSuccess ? RGBDFE_OK : RGBDFE_ERR_HIP;
   };
-  rc = wait_upload(0);
+  rc = enqueue_upload(0);
+  if (rc == RGBDFE_OK) rc = wait_upload(0);
   if (rc == RGBDFE_OK) {
     init(fr[0], 0);
     orb.use_set(0);
-    rc = fr[0].detect(true, nullptr);
-    if (rc != RGBDFE_OK) err.clear();  // reported through fail()
+    int rc_up = RGBDFE_OK;
+    rc = fr[0].detect(true, n_frames > 1 ? std::function<int()>([&]() -> int { rc_up = enqueue_upload(1); return rc_up; })
+                                         : std::function<int()>());
+    if (rc != RGBDFE_OK && rc_up == RGBDFE_OK) err.clear();  // reported through fail()
+    if (rc == RGBDFE_OK) mark_detected(0);
   }
   for (int32_t f = 0; f < n_frames && rc == RGBDFE_OK; ++f) {
     if (f + 1 < n_frames) {
@@ -1510,27 +1524,30 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
       init(fr[(size_t)((f + 1) & 1)], f + 1);
       orb.use_set((f + 1) & 1);
       static const bool overlap = !(getenv("RGBDFE_DETECT_OVERLAP") && atoi(getenv("RGBDFE_DETECT_OVERLAP")) == 0);  // A/B switch
-      int rc_desc = RGBDFE_OK;
       if (!overlap) {
         rc = describe(f);
         if (rc != RGBDFE_OK) { err.clear(); break; }
         orb.use_set((f + 1) & 1);
       }
-      rc = fr[(size_t)((f + 1) & 1)].detect(true, !overlap ? std::function<int()>() : [&, f]() -> int {
-        rc_desc = describe(f);
+      int rc_hook = RGBDFE_OK;
+      bool hook_err_is_mine = false;
+      rc = fr[(size_t)((f + 1) & 1)].detect(true, [&, f]() -> int {
+        if (overlap) rc_hook = describe(f);
+        if (rc_hook == RGBDFE_OK && f + 2 < n_frames) {
+          rc_hook = enqueue_upload(f + 2);
+          hook_err_is_mine = rc_hook != RGBDFE_OK;
+        }
         orb.use_set((f + 1) & 1);  // the rest of the pass (a second read-back of a crowded frame) is frame f + 1's
-        return rc_desc;
+        return rc_hook;
       });
-      if (rc != RGBDFE_OK) { err.clear(); break; }
+      if (rc != RGBDFE_OK) { if (!hook_err_is_mine) err.clear(); break; }
+      mark_detected(f + 1);
     } else {
       rc = describe(f);
       if (rc != RGBDFE_OK) { err.clear(); break; }
     }
     rc = fr[(size_t)(f & 1)].finish(st2);
     if (rc != RGBDFE_OK) { err.clear(); break; }
-    std::lock_guard<std::mutex> l(m);
-    finished = f + 1;
-    cv.notify_all();
   }
   (void)hipStreamSynchronize(st2);
   {
