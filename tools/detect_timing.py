@@ -1,3 +1,5 @@
+"""Per-phase host wall clock of the detect / describe path (RGBDFE_DETECT_TIMING=1 prints the table at context teardown):
+    RGBDFE_DETECT_TIMING=1 python tools/detect_timing.py single|batch"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.getcwd())
 from rgbdslam_v2_amd import synth
