@@ -16,6 +16,7 @@
 #ifndef RGBDFE_H
 #define RGBDFE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -401,6 +402,13 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
                            int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
                            double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,
                            float* xyz1, int32_t* n_out);
+/* Page-locks a range of the caller's host memory (hipHostRegister) / releases it.  rgbdfe_detect_describe copies image
+ * buffers that are page-locked straight to the device; pageable ones (cv::Mat data as cv_bridge hands it over,
+ * openni_listener.cpp) first go through the library's own pinned staging buffer, ~60 us per 640x480 frame.  An
+ * integration that owns its image buffers registers them once.  ptr / bytes: as malloc'ed or page-aligned; registering
+ * a range twice is an error. */
+int rgbdfe_host_register(rgbdfe_ctx* ctx, void* ptr, size_t bytes);
+int rgbdfe_host_unregister(rgbdfe_ctx* ctx, void* ptr);
 /* A run of frames through the same detector state, in order: the same keypoints, descriptors and points as n_frames
  * calls of rgbdfe_detect_describe (the per-cell thresholds carry over from frame to frame, feature_adjuster.cpp:185-224),
  * with frame k+1's upload and pyramid overlapped with frame k's detection.  For offline runs (bag files, OpenNIListener

@@ -283,8 +283,21 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
   uint8_t* const d_pool = set < 0 ? this->d_pool : pool_set[set];  // shadow the members: the code below is set-agnostic
   uint8_t* const d_blur = set < 0 ? this->d_blur : blur_set[set];
   uint8_t* const h_img = set < 0 ? this->h_img : himg_set[set];
-  // The caller's images are pageable: a plain hipMemcpyAsync of 0.6 MB stalls the host ~150 us while the runtime stages
-  // it.  Own staging instead: memcpy a chunk into pinned memory, start its DMA, memcpy the next chunk meanwhile.
+  // Page-locked caller images (hipHostMalloc / hipHostRegister, e.g. through rgbdfe_host_register) go to the device
+  // directly; the frame's results are waited for before the call returns, so the buffers are the caller's again then.
+  auto page_locked = [](const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+  };
+  if (page_locked(gray) && (!mask || page_locked(mask))) {
+    const size_t img = (size_t)W * H;
+    ORB_HIP(hipMemcpyAsync(d_pool, gray, img, hipMemcpyHostToDevice, s));
+    if (mask) ORB_HIP(hipMemcpyAsync(d_pool + img, mask, img, hipMemcpyHostToDevice, s));
+    else ORB_HIP(hipMemsetAsync(d_pool + img, 255, img, s));
+  } else
+  // Pageable images: a plain hipMemcpyAsync of 0.6 MB stalls the host ~150 us while the runtime stages it.  Own staging
+  // instead: memcpy a chunk into pinned memory, start its DMA, memcpy the next chunk meanwhile.
   {
     const size_t img = (size_t)W * H;
     const size_t total = mask ? 2 * img : img;

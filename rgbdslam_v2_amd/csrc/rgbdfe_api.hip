@@ -3010,6 +3010,30 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
                                                            siftgpu_descriptors, feature_descriptors, n_out));
 }
 
+int rgbdfe_host_register(rgbdfe_ctx* ctx, void* ptr, size_t bytes) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!ptr || bytes == 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, RGBDFE_ERR_HIP, "hipHostRegister failed (already registered, or not host memory)");
+    }
+    return RGBDFE_OK;
+  });
+}
+
+int rgbdfe_host_unregister(rgbdfe_ctx* ctx, void* ptr) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!ptr) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+    if (hipHostUnregister(ptr) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, RGBDFE_ERR_HIP, "hipHostUnregister failed (not a registered range)");
+    }
+    return RGBDFE_OK;
+  });
+}
+
 int rgbdfe_depth_to_mono8(rgbdfe_ctx* ctx, const void* depth, int32_t depth_is_u16, int32_t rows, int32_t cols,
                           uint8_t* mono8, float* depth_m) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;

@@ -263,6 +263,14 @@ class FrontEnd:
         self._check(self._L.rgbdfe_detector_thresholds(self._ctx, t.ctypes.data, C.byref(n)))
         return t[: n.value].copy()
 
+    def host_register(self, array):
+        """Page-locks a numpy array's memory (rgbdfe_host_register): detect_describe then copies it to the device directly
+        instead of through the library's staging buffer.  Keep the array alive and call host_unregister before freeing it."""
+        self._check(self._L.rgbdfe_host_register(self._ctx, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array):
+        self._check(self._L.rgbdfe_host_unregister(self._ctx, array.ctypes.data))
+
     def detect_describe(self, gray, mask, depth, fx, fy, cx, cy, depth_scaling=1.0):
         """detect -> removeDepthless -> retainBest -> compute -> projectTo3D for one frame.
         Returns (keypoints KEYPOINT_DTYPE, descriptors [n,32] uint8, xyz1 [n,4] float32)."""

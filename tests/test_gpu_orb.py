@@ -215,3 +215,32 @@ def test_detect_describe_batch_equals_frame_by_frame(frames):
         for (k1, d1, x1), (k2, d2, x2) in zip(res, ref):
             assert_kps_equal(k1, k2)
             assert np.array_equal(d1, d2) and np.array_equal(x1, x2)
+
+
+def test_detect_describe_with_page_locked_images(frames):
+    """rgbdfe_host_register: page-locked caller images are copied to the device directly (no staging copy); the outputs
+    are those of the pageable path, and the buffers can be unregistered and reused afterwards."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    K = (frames["fx"], frames["fy"], frames["cx"], frames["cy"])
+    outs = []
+    for pinned in (False, True):
+        fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=1024, max_pairs_per_batch=8)
+        fe.detector_configure(max_keypoints=1000)
+        res = []
+        for f in range(3):
+            gray = np.ascontiguousarray(frames["gray"][f]).copy()
+            mask = np.where(frames["mask"][f] > 0, 255, 0).astype(np.uint8)
+            if pinned:
+                fe.host_register(gray)
+                fe.host_register(mask)
+            res.append(fe.detect_describe(gray, mask if f != 1 else None, frames["depth"][f], *K))
+            if pinned:
+                fe.host_unregister(gray)
+                fe.host_unregister(mask)
+                with pytest.raises(Exception):
+                    fe.host_unregister(gray)   # not registered any more
+        outs.append(res)
+        fe.close()
+    for (k1, d1, x1), (k2, d2, x2) in zip(*outs):
+        assert_kps_equal(k1, k2)
+        assert np.array_equal(d1, d2) and np.array_equal(x1, x2)
