@@ -61,5 +61,30 @@ int main(int argc, char** argv) {
   std::printf("{\"devices\": %d, \"neighbours\": [", fe.deviceCount());
   for (size_t i = 0; i < ranked.size(); ++i) std::printf("%s%d", i ? ", " : "", ranked[i]);
   std::printf("]}\n");
+  // the depth-image Node constructor (node.cpp:139-210): two frames of a file written by the test, matched to each other
+  if (argc > 3) {
+    std::FILE* g = std::fopen(argv[3], "rb");
+    if (!g) { std::perror("open frames"); return 2; }
+    int32_t hdr[2];
+    double K[4];
+    if (std::fread(hdr, 4, 2, g) != 2 || std::fread(K, 8, 4, g) != 4) return 2;
+    const int rows = hdr[0], cols = hdr[1];
+    rgbdfe_detector_configure(fe.get(), 1000, 3, 5);
+    std::vector<std::unique_ptr<rgbdslam::Node>> fr;
+    for (int i = 0; i < 2; ++i) {
+      std::vector<uint8_t> gray((size_t)rows * cols), mask((size_t)rows * cols);
+      std::vector<float> depth((size_t)rows * cols);
+      if (std::fread(gray.data(), 1, gray.size(), g) != gray.size() || std::fread(mask.data(), 1, mask.size(), g) != mask.size() ||
+          std::fread(depth.data(), 4, depth.size(), g) != depth.size()) return 2;
+      fr.emplace_back(new rgbdslam::Node(fe, n_nodes + i, gray.data(), mask.data(), depth.data(), rows, cols, K[0], K[1], K[2],
+                                         K[3], 1.0, 1000));
+    }
+    std::fclose(g);
+    const rgbdslam::MatchingResult mr = fr[1]->matchNodePair(fr[0].get());
+    unsigned long long sum = 0;
+    for (uint8_t b : fr[1]->feature_descriptors_) sum = sum * 131 + b;
+    std::printf("{\"frame_features\": [%d, %d], \"frame_edge\": [%d, %d], \"frame_inliers\": %zu, \"desc_hash\": %llu}\n",
+                fr[0]->featureCount(), fr[1]->featureCount(), mr.edge.id1, mr.edge.id2, mr.inlier_matches.size(), sum);
+  }
   return 0;
 }

@@ -108,6 +108,27 @@ class Node {  // the slice of src/node.h the pair path touches
       : id_(id), fe_(fe), n_(n) {
     matchable_ = rgbdfe_upload_node(fe_.get(), id_, feature_descriptors, feature_locations_3d, n) == RGBDFE_OK;
   }
+  // The depth-image constructor (src/node.cpp:139-210): detect (grid of threshold-adaptive ORB detectors) ->
+  // removeDepthless -> retainBest(max_keypoints) -> cv::ORB::compute -> projectTo3D, then the node's features go to the
+  // device.  gray / mask: rows x cols uint8 (mask may be null), depth: rows x cols float metres.  The 2-D keypoints,
+  // descriptors and points stay available as in the reference (feature_locations_2d_, feature_descriptors_,
+  // feature_locations_3d_).  The detector's per-cell thresholds live in the FrontEnd and carry over from node to node.
+  Node(const FrontEnd& fe, int id, const uint8_t* gray, const uint8_t* mask, const float* depth, int rows, int cols,
+       double fx, double fy, double cx, double cy, double depth_scaling, int max_keypoints)
+      : id_(id), fe_(fe), n_(0) {
+    std::vector<rgbdfe_keypoint> kp((size_t)max_keypoints);
+    feature_descriptors_.resize((size_t)max_keypoints * 32);
+    feature_locations_3d_.resize((size_t)max_keypoints * 4);
+    int32_t n = 0;
+    if (rgbdfe_detect_describe(fe_.get(), gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling, kp.data(),
+                               feature_descriptors_.data(), feature_locations_3d_.data(), &n) != RGBDFE_OK)
+      n = 0;
+    n_ = n;
+    feature_descriptors_.resize((size_t)n * 32);
+    feature_locations_3d_.resize((size_t)n * 4);
+    feature_locations_2d_.assign(kp.begin(), kp.begin() + n);
+    matchable_ = n > 0 && rgbdfe_upload_node(fe_.get(), id_, feature_descriptors_.data(), feature_locations_3d_.data(), n) == RGBDFE_OK;
+  }
   ~Node() { clearFeatureInformation(); }
   Node(const Node&) = delete;
   Node& operator=(const Node&) = delete;
@@ -142,6 +163,11 @@ class Node {  // the slice of src/node.h the pair path touches
   }
   int id_;
   bool matchable_ = false;
+  // filled by the depth-image constructor only (node.h:160-170)
+  std::vector<rgbdfe_keypoint> feature_locations_2d_;
+  std::vector<uint8_t> feature_descriptors_;   // n x 32
+  std::vector<float> feature_locations_3d_;    // n x (x, y, z, 1)
+  int featureCount() const { return n_; }
 
  private:
   const FrontEnd& fe_;

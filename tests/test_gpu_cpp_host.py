@@ -51,3 +51,48 @@ def test_cpp_host_matches_oracle(tmp_path):
     lines2 = [json.loads(l) for l in out2.strip().splitlines()]
     assert lines2[-1]["devices"] == 2
     assert lines2[:-1] == lines[:-1] and lines2[-1]["neighbours"] == lines[-1]["neighbours"]
+
+
+def test_cpp_depth_image_node_constructor(tmp_path):
+    """include/rgbdfe.hpp's Node(gray, mask, depth, ...) -- the reference's depth-image constructor (node.cpp:139-210) --
+    from a plain g++ program: the same feature counts, descriptor bytes and edge as the Python binding's detect_describe
+    + upload + match on the same two frames."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    exe = os.path.join(ROOT, "examples", "cpp", "match_demo")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples", "cpp")], stdout=subprocess.DEVNULL)
+    seq = synth.make_sequence(n_frames=2, n_kp=300, n_world=1200, seed=6)
+    nodes = tmp_path / "nodes.bin"
+    with open(nodes, "wb") as f:
+        f.write(struct.pack("<i", 2))
+        for k in range(2):
+            f.write(struct.pack("<i", 300))
+            f.write(seq["desc"][k].tobytes())
+            f.write(seq["xyz1"][k].tobytes())
+    img = synth.make_image_sequence(n_frames=2, seed=1)
+    K = (float(img["fx"]), float(img["fy"]), float(img["cx"]), float(img["cy"]))
+    masks = [np.where(m > 0, 255, 0).astype(np.uint8) for m in img["mask"]]
+    frames = tmp_path / "frames.bin"
+    with open(frames, "wb") as f:
+        rows, cols = img["gray"][0].shape
+        f.write(struct.pack("<ii", rows, cols))
+        f.write(struct.pack("<dddd", *K))
+        for k in range(2):
+            f.write(np.ascontiguousarray(img["gray"][k], np.uint8).tobytes())
+            f.write(masks[k].tobytes())
+            f.write(np.ascontiguousarray(img["depth"][k], np.float32).tobytes())
+    out = subprocess.check_output([exe, str(nodes), "single", str(frames)], text=True, timeout=120)
+    rec = json.loads(out.strip().splitlines()[-1])
+    fe = FrontEnd(device_id=0, max_nodes=4, max_keypoints=2048, max_pairs_per_batch=8)
+    fe.detector_configure(max_keypoints=1000)
+    feats = [fe.detect_describe(img["gray"][k], masks[k], img["depth"][k], *K) for k in range(2)]
+    assert rec["frame_features"] == [len(feats[0][0]), len(feats[1][0])]
+    h = 0
+    for b in feats[1][1].reshape(-1).tolist():
+        h = (h * 131 + b) % (1 << 64)
+    assert rec["desc_hash"] == h
+    for k in range(2):   # the demo numbers its frame nodes behind the two file nodes: ids 2 and 3 (the draws depend on them)
+        fe.upload_node(2 + k, feats[k][1], feats[k][2])
+    r = fe.match_pair_list(np.array([3], np.int32), np.array([2], np.int32))[0]
+    assert rec["frame_edge"] == [int(r["id1"]), int(r["id2"])] and rec["frame_edge"] == [2, 3]
+    assert rec["frame_inliers"] == int(r["n_inl"]) and rec["frame_inliers"] > 20
+    fe.close()
