@@ -249,30 +249,30 @@ __device__ __forceinline__ bool jacobi_pair(float* W, float* U, float* V, float&
   }
   float cl = c1 * cr + s1 * sr;
   float sl = s1 * cr - c1 * sr;
+  // Each rotation updates a pair (x, y) from its own old values.  Written so that the results can land in the registers
+  // of x and y themselves (the lanes that skip this pair keep theirs): the four products first -- the last one into y --
+  // then the two sums; as two assignments of full expressions the compiler computed into temporaries and copied.
+  const float nsl = -sl;
+  auto rot_l = [&](float& x, float& y) {   // x' = cl x + sl y, y' = (-sl) x + cl y
+    const float a = cl * x, b = sl * y, c = nsl * x;
+    y = cl * y;
+    y = c + y;
+    x = a + b;
+  };
+  auto rot_r = [&](float& x, float& y) {   // x' = cr x - sr y, y' = sr x + cr y
+    const float a = cr * x, b = sr * y, c = sr * x;
+    y = cr * y;
+    y = c + y;
+    x = a - b;
+  };
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float x = W[p * 3 + k], y = W[q * 3 + k];
-    W[p * 3 + k] = cl * x + sl * y;
-    W[q * 3 + k] = (-sl) * x + cl * y;
-  }
+  for (int k = 0; k < 3; ++k) rot_l(W[p * 3 + k], W[q * 3 + k]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float x = U[k * 3 + p], y = U[k * 3 + q];
-    U[k * 3 + p] = cl * x + sl * y;
-    U[k * 3 + q] = (-sl) * x + cl * y;
-  }
+  for (int k = 0; k < 3; ++k) rot_l(U[k * 3 + p], U[k * 3 + q]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float x = W[k * 3 + p], y = W[k * 3 + q];
-    W[k * 3 + p] = cr * x - sr * y;
-    W[k * 3 + q] = sr * x + cr * y;
-  }
+  for (int k = 0; k < 3; ++k) rot_r(W[k * 3 + p], W[k * 3 + q]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float x = V[k * 3 + p], y = V[k * 3 + q];
-    V[k * 3 + p] = cr * x - sr * y;
-    V[k * 3 + q] = sr * x + cr * y;
-  }
+  for (int k = 0; k < 3; ++k) rot_r(V[k * 3 + p], V[k * 3 + q]);
   float a = fabsf(W[p * 3 + p]), b = fabsf(W[q * 3 + q]);
   if (b > a) a = b;
   if (a > max_diag) max_diag = a;
