@@ -24,6 +24,7 @@ struct OrbWorkspace {
   // into the other set, from a helper thread on another stream, while frame k is being detected.  Reads only geometry
   // that is constant between two prepare() calls: safe beside a detection running on the current set.
   int upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set = -1);
+  void build_pyramids(uint8_t* pool, hipStream_t s);
   void stage_images(const uint8_t* gray, const uint8_t* mask, int set);          // CPU half (any thread)
   int enqueue_staged(bool has_mask, hipStream_t s, std::string& err, int set);    // device half (the HIP thread)
   int ensure_alt(std::string& err);

@@ -215,6 +215,12 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
     add(frame_imgs[l - 1], frame_imgs[l], false);
   }
   level_job_begin[kLevels] = (int)jobs.size();
+  // Two pyramid levels per launch (build_pyramids): level l in {2, 4, 6} is written in the launch that writes level l - 1,
+  // its source pixels recomputed from level l - 2 (the jobs of a level come in the same order: cells x {image, mask}, frame)
+  for (ResizeJob& j : jobs) j.mid = -1;
+  for (int l = 2; l < kLevels; l += 2)
+    for (int k = level_job_begin[l]; k < level_job_begin[l + 1]; ++k)
+      jobs[(size_t)k].mid = level_job_begin[l - 1] + (k - level_job_begin[l]);
   n_rows_total = (int)row_off;
   kp_cap = (int)(score_off / 4) + 64 * n_cells * kLevels;
   ORB_HIP(hipMalloc((void**)&d_pool, pool_bytes));
@@ -279,6 +285,16 @@ void OrbWorkspace::use_set(int set) {
   h_img = himg_set[set];
 }
 
+// levels (1, 2), (3, 4), (5, 6), (7): four launches for the seven pyramid levels
+void OrbWorkspace::build_pyramids(uint8_t* pool, hipStream_t s) {
+  for (int l = 1; l < kLevels; l += 2) {
+    const int b = level_job_begin[l], e = level_job_begin[std::min(l + 2, kLevels)];
+    int mw = 0, mh = 0;
+    for (int k = b; k < e; ++k) { mw = std::max(mw, jobs[k].dw); mh = std::max(mh, jobs[k].dh); }
+    launch_orb_resize(pool, d_jobs, b, e - b, mw, mh, s);
+  }
+}
+
 int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set) {
   uint8_t* const d_pool = set < 0 ? this->d_pool : pool_set[set];  // shadow the members: the code below is set-agnostic
   uint8_t* const d_blur = set < 0 ? this->d_blur : blur_set[set];
@@ -316,12 +332,7 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
     }
     if (!mask) ORB_HIP(hipMemsetAsync(d_pool + img, 255, img, s));
   }
-  for (int l = 1; l < kLevels; ++l) {
-    const int b = level_job_begin[l], e = level_job_begin[l + 1];
-    int mw = 0, mh = 0;
-    for (int k = b; k < e; ++k) { mw = std::max(mw, jobs[k].dw); mh = std::max(mh, jobs[k].dh); }
-    launch_orb_resize(d_pool, d_jobs + b, e - b, mw, mh, s);
-  }
+  build_pyramids(d_pool, s);
   launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
   ORB_HIP(hipGetLastError());
   return RGBDFE_OK;
@@ -345,12 +356,7 @@ int OrbWorkspace::enqueue_staged(bool has_mask, hipStream_t s, std::string& err,
   const size_t img = (size_t)W * H;
   ORB_HIP(hipMemcpyAsync(d_pool, himg_set[set], has_mask ? 2 * img : img, hipMemcpyHostToDevice, s));
   if (!has_mask) ORB_HIP(hipMemsetAsync(d_pool + img, 255, img, s));
-  for (int l = 1; l < kLevels; ++l) {
-    const int b = level_job_begin[l], e = level_job_begin[l + 1];
-    int mw = 0, mh = 0;
-    for (int k = b; k < e; ++k) { mw = std::max(mw, jobs[k].dw); mh = std::max(mh, jobs[k].dh); }
-    launch_orb_resize(d_pool, d_jobs + b, e - b, mw, mh, s);
-  }
+  build_pyramids(d_pool, s);
   launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
   ORB_HIP(hipGetLastError());
   return RGBDFE_OK;
