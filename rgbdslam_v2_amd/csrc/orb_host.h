@@ -23,7 +23,8 @@ struct OrbWorkspace {
   // the detection and description kernels read); -1 = the current set.  rgbdfe_detect_describe_batch uploads frame k+1
   // into the other set, from a helper thread on another stream, while frame k is being detected.  Reads only geometry
   // that is constant between two prepare() calls: safe beside a detection running on the current set.
-  int upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set = -1);
+  int upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set = -1,
+                       bool defer_blur = false);
   void build_pyramids(uint8_t* pool, hipStream_t s);
   void stage_images(const uint8_t* gray, const uint8_t* mask, int set);          // CPU half (any thread)
   int enqueue_staged(bool has_mask, hipStream_t s, std::string& err, int set);    // device half (the HIP thread)
@@ -31,6 +32,8 @@ struct OrbWorkspace {
   void use_set(int set);
   // called once, by the next gpu_pass, after its work is enqueued and before the host waits for it
   std::function<int()> before_wait;
+  bool blur_pending = false;        // upload_and_build left the blur to the first detection pass (single-call path)
+  hipEvent_t ev_readback = nullptr;
   // A detection pass = gpu_pass (FAST + NMS + Harris + angle for every corner at the cells' thresholds, one round trip)
   // + select_pass (orb.cpp computeKeyPoints' per-level selections on the host).  select_pass may ask for HIGHER thresholds
   // than the gpu_pass ran with: the corners at threshold t are exactly the corners at any floor f <= t whose FAST score

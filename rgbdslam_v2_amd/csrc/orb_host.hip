@@ -105,6 +105,7 @@ void OrbWorkspace::release() {
     for (int i = 0; i < 10; ++i) fprintf(stderr, "  %-28s %8.1f us\n", names[i], timing.us[i] / timing.frames);
     timing.frames = 0;
   }
+  if (ev_readback) { (void)hipEventDestroy(ev_readback); ev_readback = nullptr; }
   auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   // d_pool / d_blur / h_img alias one of the two sets
   for (int i = 0; i < 2; ++i) {
@@ -295,7 +296,8 @@ void OrbWorkspace::build_pyramids(uint8_t* pool, hipStream_t s) {
   }
 }
 
-int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set) {
+int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hipStream_t s, std::string& err, int set,
+                                   bool defer_blur) {
   uint8_t* const d_pool = set < 0 ? this->d_pool : pool_set[set];  // shadow the members: the code below is set-agnostic
   uint8_t* const d_blur = set < 0 ? this->d_blur : blur_set[set];
   uint8_t* const h_img = set < 0 ? this->h_img : himg_set[set];
@@ -333,7 +335,10 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
     if (!mask) ORB_HIP(hipMemsetAsync(d_pool + img, 255, img, s));
   }
   build_pyramids(d_pool, s);
-  launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+  // The blurred levels are the descriptor kernel's input, not the detector's: on the single-call path (one stream) the blur
+  // is enqueued by the first detection pass BEHIND its read-back, so that the pass does not queue up behind it.
+  if (defer_blur) blur_pending = true;
+  else launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
   ORB_HIP(hipGetLastError());
   return RGBDFE_OK;
 }
@@ -382,6 +387,15 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
   launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, ctl, d_score, kDetectEdge, d_row_cnt, d_img_total, d_kps, bound, s);
   ORB_HIP(hipGetLastError());
   ORB_HIP(hipMemcpyAsync(h_passout, d_passout, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));  // counts + keypoints
+  bool wait_event = false;
+  if (blur_pending) {  // (see upload_and_build) the host waits for the read-back only, the blur runs behind it
+    blur_pending = false;
+    if (!ev_readback) ORB_HIP(hipEventCreateWithFlags(&ev_readback, hipEventDisableTiming));
+    ORB_HIP(hipEventRecord(ev_readback, s));
+    launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+    ORB_HIP(hipGetLastError());
+    wait_event = true;
+  }
   const double tp1 = timing.on ? orb_now_us() : 0;  // the caller's hook below is its own time, not the pass's
   if (before_wait) {  // the caller's own host work (the next frame's upload) rides on this pass's device time
     std::function<int()> f = std::move(before_wait);
@@ -389,7 +403,8 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
     const int rc = f();
     if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(s); err = "prefetch of the next frame failed"; return rc; }
   }
-  ORB_HIP(hipStreamSynchronize(s));
+  if (wait_event) ORB_HIP(hipEventSynchronize(ev_readback));
+  else ORB_HIP(hipStreamSynchronize(s));
   const double tp2 = timing.on ? orb_now_us() : 0;
   int n_total = 0;
   for (int i = 0; i < n_imgs; ++i) { h_base[i] = n_total; n_total += h_totals[i]; }
@@ -547,6 +562,10 @@ int OrbWorkspace::compute_enqueue(std::vector<KpOut>& kps, std::vector<uint8_t>&
                                   const std::function<int()>& enqueue_more, std::vector<int>* order_out) {
   // KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31), then the stable regroup by level (orb.cpp:
   // !sortedByLevel branch); `order` = the surviving input positions in output order
+  if (blur_pending) {  // no detection pass took it along (cannot happen on the paths that defer it)
+    blur_pending = false;
+    launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+  }
   const double tc0 = timing.on ? orb_now_us() : 0;
   std::vector<int> order;
   order.reserve(kps.size());

@@ -1220,7 +1220,7 @@ struct DetectFrame {
       }
     // the depth image stays on the host: removeDepthless and projectTo3D look at one pixel per keypoint
     lap(0);
-    if (!uploaded) rc = orb.upload_and_build(gray, mask, ctx->stream, err);
+    if (!uploaded) rc = orb.upload_and_build(gray, mask, ctx->stream, err, -1, /*defer_blur=*/true);
     lap(1);
     orb.before_wait = prefetch;
     const double pass_before = tm ? orb.timing.us[2] + orb.timing.us[3] + orb.timing.us[4] : 0;
