@@ -216,12 +216,6 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
     add(frame_imgs[l - 1], frame_imgs[l], false);
   }
   level_job_begin[kLevels] = (int)jobs.size();
-  // Two pyramid levels per launch (build_pyramids): level l in {2, 4, 6} is written in the launch that writes level l - 1,
-  // its source pixels recomputed from level l - 2 (the jobs of a level come in the same order: cells x {image, mask}, frame)
-  for (ResizeJob& j : jobs) j.mid = -1;
-  for (int l = 2; l < kLevels; l += 2)
-    for (int k = level_job_begin[l]; k < level_job_begin[l + 1]; ++k)
-      jobs[(size_t)k].mid = level_job_begin[l - 1] + (k - level_job_begin[l]);
   n_rows_total = (int)row_off;
   kp_cap = (int)(score_off / 4) + 64 * n_cells * kLevels;
   ORB_HIP(hipMalloc((void**)&d_pool, pool_bytes));
@@ -286,13 +280,16 @@ void OrbWorkspace::use_set(int set) {
   h_img = himg_set[set];
 }
 
-// levels (1, 2), (3, 4), (5, 6), (7): four launches for the seven pyramid levels
+// one launch per pyramid level (level l reads level l - 1).  Two levels per launch -- the second one's source pixels
+// recomputed from the level below -- was built and measured: 4 x 10.7 us instead of 7 x 6.1 us, the same chain; so were
+// host-side coefficient tables (cv::resize's xofs / alpha / yofs / beta) instead of the per-pixel double arithmetic:
+// 6.4 us per launch.  A level's launch is a chain of dependent memory round trips, not arithmetic; both were dropped.
 void OrbWorkspace::build_pyramids(uint8_t* pool, hipStream_t s) {
-  for (int l = 1; l < kLevels; l += 2) {
-    const int b = level_job_begin[l], e = level_job_begin[std::min(l + 2, kLevels)];
+  for (int l = 1; l < kLevels; ++l) {
+    const int b = level_job_begin[l], e = level_job_begin[l + 1];
     int mw = 0, mh = 0;
     for (int k = b; k < e; ++k) { mw = std::max(mw, jobs[k].dw); mh = std::max(mh, jobs[k].dh); }
-    launch_orb_resize(pool, d_jobs, b, e - b, mw, mh, s);
+    launch_orb_resize(pool, d_jobs + b, e - b, mw, mh, s);
   }
 }
 

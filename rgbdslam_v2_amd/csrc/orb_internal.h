@@ -26,8 +26,6 @@ struct ResizeJob {
   uint32_t src_off, dst_off;
   int32_t sw, sh, sstride, dw, dh, is_mask;
   double scale_x, scale_y;  // 1 / ((double)dw / sw), computed on the host exactly as cv::resize does
-  int32_t mid;              // >= 0: the job (absolute index) that writes this job's source level in the SAME launch
-  int32_t pad;
 };
 
 // a FAST keypoint as the device emits it (16 bytes)
@@ -49,7 +47,7 @@ struct OrbCtl {
   int32_t active[64];
 };
 
-void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int first_job, int n_jobs, int max_w, int max_h, hipStream_t s);
+void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max_w, int max_h, hipStream_t s);
 void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, const OrbCtl& ctl,
                            uint8_t* score_pool, hipStream_t s);
 void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,

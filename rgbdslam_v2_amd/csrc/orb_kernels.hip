@@ -29,11 +29,12 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // cv::resize(..., INTER_LINEAR) for 8-bit images (fixed point, INTER_RESIZE_COEF_BITS = 11), one
 // pyramid level for every job in the launch; the mask variant applies threshold(254, TOZERO).
 // ------------------------------------------------------------------------------------------------
-// One destination pixel of a job.  FETCH(x, y) returns the source pixel: a byte of the pool, or -- for a job whose source
-// level is produced in the SAME launch (ResizeJob::mid >= 0) -- that level's pixel recomputed from ITS source, so that two
-// pyramid levels leave one launch (the same arithmetic on the same operands as reading the stored level).
-template <typename Fetch>
-__device__ __forceinline__ int resize_pixel(const ResizeJob& j, int dx, int dy, Fetch fetch) {
+__global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs) {
+  const ResizeJob j = jobs[blockIdx.z];
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= j.dw || dy >= j.dh) return;
+  const uint8_t* __restrict__ src = pool + j.src_off;
   float fx = (float)((dx + 0.5) * j.scale_x - 0.5);
   int sx = (int)floorf(fx);
   fx -= sx;
@@ -48,37 +49,19 @@ __device__ __forceinline__ int resize_pixel(const ResizeJob& j, int dx, int dy, 
   const int b0 = max(min(__float2int_rn((1.f - fy) * 2048), 32767), -32768);
   const int b1 = max(min(__float2int_rn(fy * 2048), 32767), -32768);
   const int y0 = min(max(sy, 0), j.sh - 1), y1 = min(max(sy + 1, 0), j.sh - 1);
+  const uint8_t* r0 = src + (size_t)y0 * j.sstride;
+  const uint8_t* r1 = src + (size_t)y1 * j.sstride;
   int h0, h1;
   if (!edge) {
-    h0 = fetch(sx, y0) * a0 + fetch(sx + 1, y0) * a1;
-    h1 = fetch(sx, y1) * a0 + fetch(sx + 1, y1) * a1;
+    h0 = r0[sx] * a0 + r0[sx + 1] * a1;
+    h1 = r1[sx] * a0 + r1[sx + 1] * a1;
   } else {
-    h0 = fetch(sx, y0) * 2048;
-    h1 = fetch(sx, y1) * 2048;
+    h0 = r0[sx] * 2048;
+    h1 = r1[sx] * 2048;
   }
   int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
   v = min(max(v, 0), 255);
   if (j.is_mask && v <= 254) v = 0;
-  return v;
-}
-
-__global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
-                                                         int first_job) {
-  const ResizeJob j = jobs[first_job + blockIdx.z];
-  const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (dx >= j.dw || dy >= j.dh) return;
-  int v;
-  if (j.mid < 0) {
-    const uint8_t* __restrict__ src = pool + j.src_off;
-    v = resize_pixel(j, dx, dy, [&](int x, int y) { return (int)src[(size_t)y * j.sstride + x]; });
-  } else {
-    const ResizeJob m = jobs[j.mid];  // the job that writes this job's source level, in this launch
-    const uint8_t* __restrict__ src = pool + m.src_off;
-    v = resize_pixel(j, dx, dy, [&](int x, int y) {
-      return resize_pixel(m, x, y, [&](int x2, int y2) { return (int)src[(size_t)y2 * m.sstride + x2]; });
-    });
-  }
   pool[j.dst_off + (size_t)dy * j.dw + dx] = (uint8_t)v;
 }
 
@@ -396,10 +379,9 @@ __global__ __launch_bounds__(256) void orb_brief_kernel(const uint8_t* __restric
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int first_job, int n_jobs, int max_w, int max_h, hipStream_t s) {
+void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max_w, int max_h, hipStream_t s) {
   if (n_jobs == 0) return;
-  hipLaunchKernelGGL(orb_resize_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_jobs), dim3(256), 0, s, pool, jobs,
-                     first_job);
+  hipLaunchKernelGGL(orb_resize_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_jobs), dim3(256), 0, s, pool, jobs);
 }
 void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, const OrbCtl& ctl,
                            uint8_t* score_pool, hipStream_t s) {
