@@ -79,7 +79,24 @@ int main(int argc, char** argv) {
       fr.emplace_back(new rgbdslam::Node(fe, n_nodes + i, gray.data(), mask.data(), depth.data(), rows, cols, K[0], K[1], K[2],
                                          K[3], 1.0, 1000));
     }
+    // optionally one organised cloud for the second frame: the point-cloud constructor (node.cpp:218-369)
+    std::vector<float> cloud((size_t)rows * cols * 4);
+    const bool have_cloud = std::fread(cloud.data(), 4, cloud.size(), g) == cloud.size();
     std::fclose(g);
+    if (have_cloud) {
+      std::FILE* g2 = std::fopen(argv[3], "rb");
+      std::fseek(g2, 8 + 32 + (long)((size_t)rows * cols * 6), SEEK_SET);  // header, K, frame 0
+      std::vector<uint8_t> gray((size_t)rows * cols), mask((size_t)rows * cols);
+      if (std::fread(gray.data(), 1, gray.size(), g2) != gray.size() || std::fread(mask.data(), 1, mask.size(), g2) != mask.size()) return 2;
+      std::fclose(g2);
+      rgbdslam::Node pc(fe, n_nodes + 2, gray.data(), mask.data(), cloud.data(), rows, cols, 3.5, 1000,
+                        rgbdslam::Node::FromPointCloud());
+      unsigned long long s2 = 0;
+      for (uint8_t b : pc.feature_descriptors_) s2 = s2 * 131 + b;
+      float zsum = 0;
+      for (int i = 0; i < pc.featureCount(); ++i) zsum += pc.feature_locations_3d_[(size_t)i * 4 + 2];
+      std::printf("{\"cloud_features\": %d, \"cloud_desc_hash\": %llu, \"cloud_zsum\": %.9g}\n", pc.featureCount(), s2, zsum);
+    }
     const rgbdslam::MatchingResult mr = fr[1]->matchNodePair(fr[0].get());
     unsigned long long sum = 0;
     for (uint8_t b : fr[1]->feature_descriptors_) sum = sum * 131 + b;

@@ -129,6 +129,25 @@ class Node {  // the slice of src/node.h the pair path touches
     feature_locations_2d_.assign(kp.begin(), kp.begin() + n);
     matchable_ = n > 0 && rgbdfe_upload_node(fe_.get(), id_, feature_descriptors_.data(), feature_locations_3d_.data(), n) == RGBDFE_OK;
   }
+  // The point-cloud constructor (src/node.cpp:218-369): detect -> projectTo3D(cloud) (maximum_depth, truncating lookup,
+  // the max_keypoints cut, :855-898) -> cv::ORB::compute.  cloud: rows x cols x (x, y, z, rgb) floats, organised.
+  struct FromPointCloud {};
+  Node(const FrontEnd& fe, int id, const uint8_t* gray, const uint8_t* mask, const float* cloud, int rows, int cols,
+       double maximum_depth, int max_keypoints, FromPointCloud)
+      : id_(id), fe_(fe), n_(0) {
+    std::vector<rgbdfe_keypoint> kp((size_t)max_keypoints);
+    feature_descriptors_.resize((size_t)max_keypoints * 32);
+    feature_locations_3d_.resize((size_t)max_keypoints * 4);
+    int32_t n = 0;
+    if (rgbdfe_detect_describe_cloud(fe_.get(), gray, mask, cloud, rows, cols, maximum_depth, kp.data(),
+                                     feature_descriptors_.data(), feature_locations_3d_.data(), &n) != RGBDFE_OK)
+      n = 0;
+    n_ = n;
+    feature_descriptors_.resize((size_t)n * 32);
+    feature_locations_3d_.resize((size_t)n * 4);
+    feature_locations_2d_.assign(kp.begin(), kp.begin() + n);
+    matchable_ = n > 0 && rgbdfe_upload_node(fe_.get(), id_, feature_descriptors_.data(), feature_locations_3d_.data(), n) == RGBDFE_OK;
+  }
   ~Node() { clearFeatureInformation(); }
   Node(const Node&) = delete;
   Node& operator=(const Node&) = delete;

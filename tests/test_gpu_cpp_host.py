@@ -80,8 +80,13 @@ def test_cpp_depth_image_node_constructor(tmp_path):
             f.write(np.ascontiguousarray(img["gray"][k], np.uint8).tobytes())
             f.write(masks[k].tobytes())
             f.write(np.ascontiguousarray(img["depth"][k], np.float32).tobytes())
+        # an organised cloud of the second frame for the point-cloud constructor
+        cloud = po.create_point_cloud(np.ascontiguousarray(img["depth"][1], np.float32), *K, cloud_skip=1)
+        assert cloud.shape == (rows, cols, 4)
+        f.write(np.ascontiguousarray(cloud, np.float32).tobytes())
     out = subprocess.check_output([exe, str(nodes), "single", str(frames)], text=True, timeout=120)
     rec = json.loads(out.strip().splitlines()[-1])
+    rec_cloud = json.loads(out.strip().splitlines()[-2])
     fe = FrontEnd(device_id=0, max_nodes=4, max_keypoints=2048, max_pairs_per_batch=8)
     fe.detector_configure(max_keypoints=1000)
     feats = [fe.detect_describe(img["gray"][k], masks[k], img["depth"][k], *K) for k in range(2)]
@@ -90,6 +95,16 @@ def test_cpp_depth_image_node_constructor(tmp_path):
     for b in feats[1][1].reshape(-1).tolist():
         h = (h * 131 + b) % (1 << 64)
     assert rec["desc_hash"] == h
+    # the point-cloud constructor ran third on the demo's detector (its thresholds carry over): same call order here
+    ck, cd, cx3 = fe.detect_describe_cloud(img["gray"][1], masks[1], cloud, 3.5)
+    hc = 0
+    for b in cd.reshape(-1).tolist():
+        hc = (hc * 131 + b) % (1 << 64)
+    assert rec_cloud["cloud_features"] == len(ck) and rec_cloud["cloud_desc_hash"] == hc and len(ck) > 100
+    zs = np.float32(0)
+    for z in cx3[:, 2]:
+        zs = np.float32(zs + z)
+    assert np.float32(rec_cloud["cloud_zsum"]) == zs
     for k in range(2):   # the demo numbers its frame nodes behind the two file nodes: ids 2 and 3 (the draws depend on them)
         fe.upload_node(2 + k, feats[k][1], feats[k][2])
     r = fe.match_pair_list(np.array([3], np.int32), np.array([2], np.int32))[0]
