@@ -236,3 +236,47 @@ def test_sift_golden_vectors_from_the_reference_matcher(fe):
         assert np.array_equal(md, g[name + "_dist"]), name
         fe.release_node(1)
         fe.release_node(2)
+
+
+def test_sift_bench_step_properties():
+    """configs[3] at the bench's size (2000 pairs of 1000 x 1000 descriptors, bench.py's sift sub-record) through
+    properties that do not need the oracle on every pair: the records of a batch do not depend on its composition or order
+    (a permuted list gives the permuted records, two half batches give the same records as one), every match list is
+    mutual-best consistent and sorted by distance, and a sample of the pairs equals the oracle bit for bit."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    F = 100
+    seq = synth.make_sequence(n_frames=F, n_kp=1000, seed=20260923, depth_noise=0.01)
+    sd = synth.sift_descriptors_like(seq["desc"], seed=20260923)
+    fe = FrontEnd(device_id=0, max_nodes=F, max_keypoints=1024, max_pairs_per_batch=2048)
+    for f in range(F):
+        fe.upload_sift_node(f, sd[f], seq["xyz1"][f])
+    pq, pt = synth.candidate_pairs(F, per_frame=20, seed=20260923)
+    pq, pt = pq[:2000], pt[:2000]
+    out, dist = fe.match_sift_pair_list(pq, pt)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(len(pq))
+    out_p, dist_p = fe.match_sift_pair_list(pq[perm], pt[perm])
+    assert out_p.tobytes() == out[perm].tobytes() and np.array_equal(np.asarray(dist_p), np.asarray(dist)[perm])
+    h = len(pq) // 2
+    o1, d1 = fe.match_sift_pair_list(pq[:h], pt[:h])
+    o2, d2 = fe.match_sift_pair_list(pq[h:], pt[h:])
+    assert o1.tobytes() + o2.tobytes() == out.tobytes()
+    assert np.array_equal(np.concatenate([np.asarray(d1), np.asarray(d2)]), np.asarray(dist))
+    edges = 0
+    for rec, dd in zip(out, dist):
+        n = int(rec["n_all"])
+        assert np.all(np.diff(np.asarray(dd)[:n]) >= 0)                    # keepStrongestMatches order
+        assert len(set(rec["all_q"][:n].tolist())) == n and len(set(rec["all_t"][:n].tolist())) == n   # mutual best
+        edges += rec["id1"] >= 0
+    assert edges > 0.9 * len(pq)
+    prm = po.default_params(seed=fe.params.seed, depth_cov=fe.params.depth_cov)
+    for k in rng.choice(len(pq), 12, replace=False):
+        q, t = int(pq[k]), int(pt[k])
+        ref = po.match_sift_node_pair(sd[q], seq["xyz1"][q], q, sd[t], seq["xyz1"][t], t, prm)
+        rec = out[k]
+        n = ref["n_all"]
+        assert rec["n_all"] == n and np.array_equal(rec["all_q"][:n], ref["all_q"]) and np.array_equal(rec["all_t"][:n], ref["all_t"])
+        assert np.array_equal(np.asarray(dist[k])[:n], ref["all_dist"])
+        assert (rec["id1"], rec["id2"], rec["n_inl"]) == (ref["id1"], ref["id2"], ref["n_inl"])
+        assert np.array_equal(np.array(rec["trafo"], np.float32).reshape(4, 4).T, ref["T"])
+    fe.close()
