@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   int32_t n_nodes = 0;
   if (std::fread(&n_nodes, 4, 1, f) != 1) return 2;
   rgbdfe_config cfg = rgbdslam::FrontEnd::defaultConfig();
-  cfg.max_nodes = n_nodes + 2;
+  cfg.max_nodes = n_nodes + 12;  // + the frame nodes and the SIFT nodes of the optional sections
   cfg.max_keypoints = 2048;
   cfg.max_pairs_per_batch = 64;
   const bool multi = argc > 2 && std::string(argv[2]) == "multi";
@@ -61,8 +61,35 @@ int main(int argc, char** argv) {
   std::printf("{\"devices\": %d, \"neighbours\": [", fe.deviceCount());
   for (size_t i = 0; i < ranked.size(); ++i) std::printf("%s%d", i ? ", " : "", ranked[i]);
   std::printf("]}\n");
+  // SIFT nodes (matcher_type == "SIFTGPU"): a file of 128-d float descriptors, the last node against the others
+  if (argc > 4) {
+    std::FILE* s = std::fopen(argv[4], "rb");
+    if (!s) { std::perror("open sift"); return 2; }
+    int32_t ns = 0;
+    if (std::fread(&ns, 4, 1, s) != 1) return 2;
+    std::vector<std::unique_ptr<rgbdslam::Node>> sg;
+    for (int i = 0; i < ns; ++i) {
+      int32_t n = 0;
+      if (std::fread(&n, 4, 1, s) != 1) return 2;
+      std::vector<float> desc((size_t)n * 128), xyz((size_t)n * 4);
+      if (std::fread(desc.data(), 512, (size_t)n, s) != (size_t)n || std::fread(xyz.data(), 16, (size_t)n, s) != (size_t)n) return 2;
+      sg.emplace_back(new rgbdslam::Node(fe, 100 + i, desc.data(), xyz.data(), n, rgbdslam::Node::SiftDescriptors()));
+    }
+    std::fclose(s);
+    std::vector<const rgbdslam::Node*> older;
+    for (int i = 0; i + 1 < ns; ++i) older.push_back(sg[(size_t)i].get());
+    const std::vector<rgbdslam::MatchingResult> rs = gm.nodeComparisons(sg.back().get(), older);
+    const rgbdslam::MatchingResult one_s = sg.back()->matchNodePair(sg.front().get());
+    for (const rgbdslam::MatchingResult& mr : rs) {
+      double dsum = 0;
+      for (const rgbdslam::DMatch& m : mr.all_matches) dsum += m.distance;
+      std::printf("{\"sift_id1\": %d, \"sift_id2\": %d, \"sift_n_all\": %zu, \"sift_n_inl\": %zu, \"sift_dist_sum\": %.9g}\n", mr.edge.id1,
+                  mr.edge.id2, mr.all_matches.size(), mr.inlier_matches.size(), dsum);
+    }
+    std::printf("{\"sift_single_n_inl\": %zu}\n", one_s.inlier_matches.size());
+  }
   // the depth-image Node constructor (node.cpp:139-210): two frames of a file written by the test, matched to each other
-  if (argc > 3) {
+  if (argc > 3 && std::string(argv[3]) != "-") {
     std::FILE* g = std::fopen(argv[3], "rb");
     if (!g) { std::perror("open frames"); return 2; }
     int32_t hdr[2];

@@ -49,13 +49,14 @@ struct MatchingResult {  // src/matching_result.h:24-46
   unsigned int inlier_points = 0, outlier_points = 0, occluded_points = 0, all_points = 0;  // environment measurement model
 };
 
-inline MatchingResult toMatchingResult(const rgbdfe_match_result& r) {
+// float_dist: the DMatch.distance values of a SIFT / FLANN pair (float L2, rgbdfe_match_sift_pair_list's out_dist), or null
+inline MatchingResult toMatchingResult(const rgbdfe_match_result& r, const float* float_dist = nullptr) {
   MatchingResult mr;
   mr.all_matches.resize((size_t)r.n_all);
   for (int m = 0; m < r.n_all; ++m) {
     mr.all_matches[m].queryIdx = r.all_q[m];
     mr.all_matches[m].trainIdx = r.all_t[m];
-    mr.all_matches[m].distance = r.all_hd[m] / 256.0f;  // node.cpp:573 without the random jitter
+    mr.all_matches[m].distance = float_dist ? float_dist[m] : r.all_hd[m] / 256.0f;  // node.cpp:573 without the random jitter
   }
   for (int m = 0; m < r.n_all; ++m)
     if ((r.inlier_mask[m >> 6] >> (m & 63)) & 1ull) mr.inlier_matches.push_back(mr.all_matches[m]);
@@ -129,6 +130,13 @@ class Node {  // the slice of src/node.h the pair path touches
     feature_locations_2d_.assign(kp.begin(), kp.begin() + n);
     matchable_ = n > 0 && rgbdfe_upload_node(fe_.get(), id_, feature_descriptors_.data(), feature_locations_3d_.data(), n) == RGBDFE_OK;
   }
+  // A node of 128-d float descriptors for matcher_type == "SIFTGPU" (Node::siftgpu_descriptors, node.h:172;
+  // Node::featureMatching's SIFTGPU branch, node.cpp:553-557): desc128 = n x 128 floats
+  struct SiftDescriptors {};
+  Node(const FrontEnd& fe, int id, const float* desc128, const float* feature_locations_3d, int n, SiftDescriptors)
+      : id_(id), fe_(fe), n_(n), sift_(true) {
+    matchable_ = rgbdfe_upload_sift_node(fe_.get(), id_, desc128, feature_locations_3d, n) == RGBDFE_OK;
+  }
   // The point-cloud constructor (src/node.cpp:218-369): detect -> projectTo3D(cloud) (maximum_depth, truncating lookup,
   // the max_keypoints cut, :855-898) -> cv::ORB::compute.  cloud: rows x cols x (x, y, z, rgb) floats, organised.
   struct FromPointCloud {};
@@ -155,9 +163,14 @@ class Node {  // the slice of src/node.h the pair path touches
   // src/node.cpp:1305-1429.  Never throws; no edge <=> mr.edge.id1 == -1 && mr.edge.id2 == -1.
   MatchingResult matchNodePair(const Node* older_node) const {
     rgbdfe_match_result pod;
-    if (!matchable_ || !older_node || !older_node->matchable_ ||
-        rgbdfe_match_node_pairs(fe_.get(), id_, &older_node->id_, 1, &pod) != RGBDFE_OK)
-      return MatchingResult();
+    if (!matchable_ || !older_node || !older_node->matchable_) return MatchingResult();
+    if (sift_) {  // SiftGPUWrapper::match semantics; the distances are the float L2 of the raw descriptors
+      std::vector<float> dist((size_t)RGBDFE_MAX_MATCHES);
+      if (rgbdfe_match_sift_pair_list(fe_.get(), &id_, &older_node->id_, 1, &pod, dist.data()) != RGBDFE_OK)
+        return MatchingResult();
+      return toMatchingResult(pod, dist.data());
+    }
+    if (rgbdfe_match_node_pairs(fe_.get(), id_, &older_node->id_, 1, &pod) != RGBDFE_OK) return MatchingResult();
     return toMatchingResult(pod);
   }
   // src/node.cpp:535-690 (ORB branch): matches sorted by (hd, queryIdx), at most max_matches
@@ -191,6 +204,7 @@ class Node {  // the slice of src/node.h the pair path touches
  private:
   const FrontEnd& fe_;
   int n_;
+  bool sift_ = false;
   friend class GraphManager;
 };
 
@@ -242,8 +256,16 @@ class GraphManager {  // candidate selection (graph_manager.cpp:204-324) + the f
     for (const Node* n : nodes_to_comp) ids.push_back(n->id_);
     std::vector<rgbdfe_match_result> pods(ids.size());
     std::vector<MatchingResult> out(ids.size());
-    if (ids.empty() ||
-        rgbdfe_match_node_pairs(fe_.get(), new_node->id_, ids.data(), (int32_t)ids.size(), pods.data()) != RGBDFE_OK)
+    if (ids.empty()) return out;
+    if (new_node->sift_) {  // matcher_type == "SIFTGPU": the same fan-out over the SIFT pair op
+      std::vector<int32_t> q(ids.size(), new_node->id_);
+      std::vector<float> dist(ids.size() * (size_t)RGBDFE_MAX_MATCHES);
+      if (rgbdfe_match_sift_pair_list(fe_.get(), q.data(), ids.data(), (int32_t)ids.size(), pods.data(), dist.data()) != RGBDFE_OK)
+        return out;
+      for (size_t i = 0; i < pods.size(); ++i) out[i] = toMatchingResult(pods[i], dist.data() + i * (size_t)RGBDFE_MAX_MATCHES);
+      return out;
+    }
+    if (rgbdfe_match_node_pairs(fe_.get(), new_node->id_, ids.data(), (int32_t)ids.size(), pods.data()) != RGBDFE_OK)
       return out;
     for (size_t i = 0; i < pods.size(); ++i) out[i] = toMatchingResult(pods[i]);
     return out;

@@ -111,3 +111,37 @@ def test_cpp_depth_image_node_constructor(tmp_path):
     assert rec["frame_edge"] == [int(r["id1"]), int(r["id2"])] and rec["frame_edge"] == [2, 3]
     assert rec["frame_inliers"] == int(r["n_inl"]) and rec["frame_inliers"] > 20
     fe.close()
+
+
+def test_cpp_sift_nodes(tmp_path):
+    """include/rgbdfe.hpp with 128-d float descriptors (Node::SiftDescriptors: matcher_type == "SIFTGPU"): nodeComparisons and
+    matchNodePair from a plain g++ program give the oracle's match counts, inliers, edge ids and DMatch distances."""
+    exe = os.path.join(ROOT, "examples", "cpp", "match_demo")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples", "cpp")], stdout=subprocess.DEVNULL)
+    F = 4
+    seq = synth.make_sequence(n_frames=F, n_kp=500, n_world=2000, seed=8)
+    sd = synth.sift_descriptors_like(seq["desc"], seed=8)
+    nodes = tmp_path / "nodes.bin"
+    with open(nodes, "wb") as f:   # the ORB section of the demo needs its file too
+        f.write(struct.pack("<i", 2))
+        for k in range(2):
+            f.write(struct.pack("<i", 500))
+            f.write(seq["desc"][k].tobytes())
+            f.write(seq["xyz1"][k].tobytes())
+    sift = tmp_path / "sift.bin"
+    with open(sift, "wb") as f:
+        f.write(struct.pack("<i", F))
+        for k in range(F):
+            f.write(struct.pack("<i", 500))
+            f.write(np.ascontiguousarray(sd[k], np.float32).tobytes())
+            f.write(seq["xyz1"][k].tobytes())
+    out = subprocess.check_output([exe, str(nodes), "single", "-", str(sift)], text=True, timeout=120)
+    lines = [json.loads(l) for l in out.strip().splitlines() if "sift_" in l]
+    assert len(lines) == F   # F - 1 comparisons + the single call
+    prm = po.default_params()
+    for t, rec in enumerate(lines[:-1]):
+        ref = po.match_sift_node_pair(sd[F - 1], seq["xyz1"][F - 1], 100 + F - 1, sd[t], seq["xyz1"][t], 100 + t, prm)
+        assert (rec["sift_id1"], rec["sift_id2"]) == (ref["id1"], ref["id2"])
+        assert rec["sift_n_all"] == ref["n_all"] and rec["sift_n_inl"] == ref["n_inl"]
+        assert abs(rec["sift_dist_sum"] - float(np.sum(ref["all_dist"].astype(np.float64)))) < 1e-6 * max(1.0, rec["sift_dist_sum"])
+    assert lines[-1]["sift_single_n_inl"] == lines[0]["sift_n_inl"]
