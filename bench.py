@@ -12,9 +12,14 @@ torch.distributed.run) every rank holds all nodes, the global pair list (N x 400
 is sharded pair k -> rank k mod N, and each step ends with the RCCL all-gather of the
 MatchingResult PODs: weak scaling.
 
-Rank 0 prints ONE JSON line.  Its `roofline` block is computed from times measured in THIS run: per-stage HIP-event
-times of steps that run one batch at a time (`serial`), next to the pipelined step time the metric uses; at N = 1 the
-line also carries `sift` (configs[3]) and `detect` (Level B frames/s) sub-records and the CPU baselines.
+Rank 0 prints ONE JSON line.  The timed region (K steps between barrier + synchronize) is run REPEATS = 3 times in
+the invocation: `value` / `ms_per_step` are the median repetition, `repeats` lists all three.  Its `roofline` block is
+computed from times measured in THIS run: per-stage HIP-event times of steps that run one batch at a time (`serial`),
+next to the pipelined step time the metric uses (`frac_serial` / `frac_pipelined`); counter-derived figures (`traffic`,
+`issue_roofline`) are static and name the `profiles/` file they come from.  At N = 1 the line also carries the
+`ransac_heavy` (depth noise 0.002 z^2), `sift` (configs[3]), `sift_extract`, `detect` (Level B frames/s) and
+`loop_closure` sub-records and the CPU baselines, and the results of the last step are checked against aggregate figures
+the oracle produced for the same seeded workload (EXPECTED; tests/test_gpu_pairs.py re-derives them bit for bit).
 """
 import argparse
 import json
@@ -33,6 +38,17 @@ N_FRAMES = 200
 PAIRS_PER_FRAME = 20
 MAX_MATCHES = 300
 SEED = 20260923
+REPEATS = 3                                # repetitions of the timed region (median reported)
+PMC_SUMMARY = "profiles/r03_pmc_summary.json"   # static counter figures (tools/profile_r03.sh + tools/make_pmc_summary.py)
+PMC_FALLBACK = "profiles/r02_pmc_summary.json"
+# Aggregates of one step's results as the ORACLE computes them (oracle/liboracle.so over the same seeded workload;
+# tests/test_gpu_pairs.py::test_whole_bench_step_matches_oracle / test_loop_closure_subrecord_matches_oracle compare every
+# pair bit for bit and re-derive these sums).  bench.py refuses to print a number whose results differ.
+EXPECTED = {
+    ("orb", 0.01): {"edges": 3959, "real_iterations": 800000, "inliers": 156016},
+    ("orb", 0.002): {"edges": 4000, "real_iterations": 669765, "inliers": 666572},
+    ("loop_closure", 0.01): {"edges": 810, "real_iterations": 3222000, "inliers": 40190},
+}
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (int32 VALU lanes/s)
 
@@ -46,6 +62,29 @@ def algorithmic_bytes(n_kp, m):
     hamming = 2 * n_kp * 32 + 4 * n_kp
     ransac = 4 * n_kp + 2 * m * 16 + 1744
     return pair, hamming, ransac
+
+
+def parity_check(key, res):
+    """Sums over one step's records vs the oracle's (EXPECTED): raises when they differ."""
+    exp = EXPECTED.get(key)
+    got = {"edges": int((res["id1"] >= 0).sum()), "real_iterations": int(res["real_iterations"].astype(np.int64).sum()),
+           "inliers": int(res["n_inl"].astype(np.int64).sum())}
+    if exp is None:
+        return {"checked": False, "got": got, "note": "no oracle constants for this workload (non-default flags)"}
+    if got != exp:
+        raise SystemExit("bench.py: results of the timed workload differ from the oracle's aggregates: got %r, expected %r"
+                         % (got, exp))
+    return {"checked": True, "ok": True, "oracle_aggregates": exp,
+            "source": "oracle/liboracle.so on the same seeded workload; every pair bit for bit in tests/test_gpu_pairs.py"}
+
+
+def load_pmc():
+    for rel in (PMC_SUMMARY, PMC_FALLBACK):
+        try:
+            return json.load(open(os.path.join(ROOT, rel))), rel
+        except Exception:
+            continue
+    return {}, None
 
 
 def main():
@@ -68,7 +107,10 @@ def main():
                          "round 1 measured with 0.002)")
     ap.add_argument("--hamming-mode", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="-1 = the library's default (fp4 MFMA contraction), 0 = xor+popcount kernel, 2 = MFMA with VALU row term")
-    ap.add_argument("--no-extras", action="store_true", help="skip the sift / detect sub-records")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-records")
+    ap.add_argument("--gather", choices=["compact", "full"], default="compact",
+                    help="N > 1: payload of the per-step all-gather -- rgbdfe_compact_result (144 B per pair, default) or the "
+                         "whole 1744-byte record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -135,12 +177,22 @@ def main():
             fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 
     rec_bytes = RESULT_DTYPE.itemsize
+    from rgbdslam_v2_amd._lib import COMPACT_DTYPE
+    compact = world > 1 and args.gather == "compact"
+    gat_bytes = COMPACT_DTYPE.itemsize if compact else rec_bytes
+    rccl_ranks = None
+    if world > 1:
+        # what the collective library itself saw: every rank contributes 1 through the backend the steps use
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if host_coll else "cuda")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
     # Steps are pipelined: step k is submitted to one of the context's internal streams while
     # step k-1 still runs (its RANSAC tail overlaps step k's Hamming kernel).  A ring of result
     # buffers keeps every step's output alive until its all-gather has consumed it.
     NBUF = 4
     d_local = [torch.zeros(n_pad * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
-    d_all = torch.zeros(world * n_pad * rec_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    d_send = [torch.zeros(n_pad * gat_bytes, dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if compact else d_local
+    d_all = torch.zeros(world * n_pad * gat_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
     consumed = [None] * NBUF
     stream = torch.cuda.current_stream().cuda_stream
     state = {"k": 0}
@@ -156,12 +208,14 @@ def main():
             ticket = fe.submit_pair_list(pq, pt, d_local[b].data_ptr())
         if world > 1:
             fe.wait_ticket(ticket, stream)  # torch's stream waits for this batch only
+            if compact:  # header + inlier mask of every record (144 of 1744 B): compact_pack_kernel on torch's stream
+                fe.pack_compact(d_local[b].data_ptr(), n_local, d_send[b].data_ptr(), stream)
             if host_coll:
                 h_all = torch.empty(d_all.numel(), dtype=torch.uint8)
-                dist.all_gather_into_tensor(h_all, d_local[b].cpu())
+                dist.all_gather_into_tensor(h_all, d_send[b].cpu())
                 d_all.copy_(h_all)
             else:
-                dist.all_gather_into_tensor(d_all, d_local[b])
+                dist.all_gather_into_tensor(d_all, d_send[b])
             consumed[b] = torch.cuda.Event()
             consumed[b].record()
 
@@ -169,25 +223,31 @@ def main():
         step()
     fe.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    fe.synchronize()
     fe.set_profiling(True)
     fe.reset_kernel_time()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fe.synchronize()            # every internal stream of the context
-    torch.cuda.synchronize()    # device-wide
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        te = torch.tensor([elapsed], device="cpu" if host_coll else "cuda", dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    # The timed region -- exactly K steps between barrier + synchronize on both sides, max over ranks -- REPEATS times;
+    # the median repetition is the reported one (one region lasts a few tens of ms: single runs spread by several %).
+    rep_elapsed = []
+    for _rep in range(REPEATS):
+        if world > 1:
+            dist.barrier()
+        fe.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fe.synchronize()            # every internal stream of the context
+        torch.cuda.synchronize()    # device-wide
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        el = t1 - t0
+        if world > 1:
+            te = torch.tensor([el], device="cpu" if host_coll else "cuda", dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        rep_elapsed.append(el)
+    elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]
     fe.set_profiling(False)
     # Official per-kernel HIP-event times: measured inside the timed region (batches overlap there).
     k_match = KERNEL_SIFT_DOT if sift else KERNEL_HAMMING
@@ -226,6 +286,9 @@ def main():
     res = np.frombuffer(last.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[:n_local]
     edge_frac = float((res["id1"] >= 0).mean()) if n_local else 0.0
     mean_iters = float(res["real_iterations"].mean()) if n_local else 0.0
+    default_workload = (world == 1 and not sift and F == N_FRAMES and N == N_KP and args.pairs_per_frame == PAIRS_PER_FRAME)
+    parity = parity_check(("orb", args.depth_noise) if default_workload else None, res) if n_local else None
+    rep_values = [sum(counts) * args.steps / e for e in rep_elapsed]
 
     if rank == 0:
         b_pair, b_ham, b_rsc = algorithmic_bytes(N, MAX_MATCHES)
@@ -237,6 +300,8 @@ def main():
         # serial stage times (one batch in flight): what `roofline` is computed from
         ham_ser = iso.get("serial_match_ms", 0.0)
         rsc_ser = iso.get("serial_ransac_ms", 0.0)
+        repeats = {"values": [round(v, 2) for v in rep_values], "ms_per_step": [round(e / args.steps * 1e3, 4) for e in rep_elapsed],
+                   "reported": "median", "spread_pct": round((max(rep_values) - min(rep_values)) / value * 100.0, 2)}
         timing = {
             "ms_per_step": round(ms_per_step, 4),
             "serial_ms_per_step": iso.get("serial_ms_per_step"),
@@ -268,7 +333,7 @@ def main():
                              "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
                              "traffic": None, "flop_per_pair": 2.0 * N * N * 128,
                              "pairs_per_launch": n_local, "avg_launch_ms": ham_ser, "time_basis": "serial"},
-                "timing": timing,
+                "repeats": repeats, "timing": timing,
             }
             print(json.dumps(out), flush=True)
             fe.close()
@@ -278,17 +343,24 @@ def main():
         dominant = "hamming_nn" if ham_ser >= rsc_ser else "select_ransac"
         dom_ms, dom_bytes = (ham_ser, b_ham) if dominant == "hamming_nn" else (rsc_ser, b_rsc)
         achieved = (dom_bytes * n_local) / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+        achieved_pipe = (dom_bytes * n_local) / (ms_per_step * 1e-3) / 1e9
+        pmc, pmc_src = load_pmc()
         roofline = {
             # the contract's block: ALGORITHMIC bytes of the dominant kernel / its launch time / HBM peak
             "bound": "hbm", "limiter": "valu_issue", "kernel": dominant, "achieved": round(achieved, 3),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": static_traffic(dominant, n_local), "traffic_source": "profiles/r02_pmc_summary.json: FETCH_SIZE x 2 + "
-            "WRITE_SIZE of separate rocprofv3 --pmc passes over this workload (static figure, not collected in this run)",
+            # the same algorithmic bytes on both time bases of this run, spelled out
+            "frac_serial": round(achieved / HBM_PEAK_GBS, 6),            # / the stage's HIP-event time, one batch in flight
+            "frac_pipelined": round(achieved_pipe / HBM_PEAK_GBS, 6),    # / ms_per_step of the timed region (batches overlap)
+            "traffic": static_traffic(pmc, "orb" if args.depth_noise >= 0.005 else "ransac_heavy", dominant, n_local),
+            "traffic_source": "%s: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes over this workload "
+                              "(static figure of the committed profile, not collected in this run)" % pmc_src,
             "algorithmic_bytes_per_pair": dom_bytes, "pairs_per_launch": n_local,
             "avg_launch_ms": round(dom_ms, 4), "time_basis": "serial (one batch in flight), HIP events, this run",
-            "step_ms_same_basis": iso.get("serial_ms_per_step"),  # the stage time above is part of THIS step time
+            "step_ms_serial": iso.get("serial_ms_per_step"),   # the stage time above is part of THIS step time
+            "step_ms_pipelined": round(ms_per_step, 4),
             "launches_per_stage": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
-                                  "pair_prep_kernel + 4 x (recording launch of select_ransac_kernel + replay_walk_kernel) + 1 "
+                                  "pair_prep_kernel + recording launches of select_ransac_kernel + replay_walk_kernel + 1 "
                                   "result launch; avg_launch_ms spans the whole stage",
             "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
             "note": "the HBM fraction is what the contract asks for and says only that this path is NOT memory bound "
@@ -310,9 +382,17 @@ def main():
                        "edge_fraction": round(edge_frac, 4), "mean_ransac_iterations": round(mean_iters, 2)},
             "roofline": roofline,
             "match_roofline": match_roofline(N, n_local, ham_ser, fe.hamming_mode),
-            "issue_roofline": issue_roofline(N, n_local, ham_ser, rsc_ser, fe.hamming_mode),
+            "issue_roofline": issue_roofline(pmc, pmc_src, "orb" if args.depth_noise >= 0.005 else "ransac_heavy", N, n_local,
+                                             ham_ser, rsc_ser, fe.hamming_mode),
+            "repeats": repeats, "parity_check": parity,
             "timing": timing,
         }
+        if world > 1:
+            out["gather"] = {"payload": "rgbdfe_compact_result" if compact else "rgbdfe_match_result",
+                             "bytes_per_record": gat_bytes, "bytes_per_step_per_rank": world * n_pad * gat_bytes,
+                             "backend": backend, "rccl_ranks": rccl_ranks,
+                             "transport": "RCCL ncclAllGather via torch.distributed (nccl backend)" if backend == "nccl"
+                                          else "host tensors (%s; test mode)" % backend}
         if world == 1 and not args.no_extras:
             fe.close()
             fe = None
@@ -325,9 +405,22 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["detect"] = {"error": repr(e)}
             try:
+                out["sift_extract"] = sift_extract_subrecord(local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["sift_extract"] = {"error": repr(e)}
+            try:
                 out["loop_closure"] = loop_closure_subrecord(local_rank, args.depth_noise)
+            except SystemExit:
+                raise
             except Exception as e:  # noqa: BLE001
                 out["loop_closure"] = {"error": repr(e)}
+            if args.depth_noise >= 0.005:
+                try:
+                    out["ransac_heavy"] = ransac_heavy_subrecord(local_rank, N, F, args.pairs_per_frame)
+                except SystemExit:
+                    raise
+                except Exception as e:  # noqa: BLE001
+                    out["ransac_heavy"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq, pq, pt, SEED, 1e-4, args.cpu_seconds)
             ref = cpu_reference_code(seq, pq, pt, SEED, 1e-4, 5.0)
@@ -347,21 +440,20 @@ ISSUE_NS = {"f32_or_simple_int": 1.10, "vop3_int": 1.90, "f64": 2.20, "xor_sgpr_
 N_SIMD = 256 * 4
 
 
-def issue_roofline(n_kp, n_pairs, ham_ms, rsc_ms, hamming_mode):
+def issue_roofline(pmc, pmc_src, section, n_kp, n_pairs, ham_ms, rsc_ms, hamming_mode):
     """The instruction-issue roofline of the two ORB stages: wave-instructions per batch (counted by rocprofv3 PMC,
     SQ_INSTS_VALU and friends, in the committed profile named in `source` -- a static figure of the same workload, not
     collected in this run) x the measured issue cost of their instruction class / the stage time of THIS run.  frac =
-    the share of the stage time the SIMDs need just to issue the stage's VALU instructions."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    the share of the stage time the SIMDs need just to issue the stage's VALU instructions.  `section` picks the
+    workload of the summary ("orb": depth noise 0.01 z^2, "ransac_heavy": 0.002 z^2)."""
     out = {"unit": "fraction of the stage time spent issuing its VALU instructions on %d SIMDs" % N_SIMD,
            "issue_ns_per_wave_instruction": ISSUE_NS, "source": None, "stages": {}}
-    try:
-        pmc = json.load(open(path))
-    except Exception:
+    sec = pmc.get(section) if isinstance(pmc.get(section), dict) else (pmc if section == "orb" and "hamming" in pmc else None)
+    if not sec:
         return out
-    out["source"] = "profiles/r02_pmc_summary.json (static: %s)" % pmc.get("collected_with", "rocprofv3 --pmc")
+    out["source"] = "%s [%s] (static: %s)" % (pmc_src, section, pmc.get("collected_with", "rocprofv3 --pmc"))
     for stage, ms in (("hamming", ham_ms), ("select_ransac", rsc_ms)):
-        rec = pmc.get(stage)
+        rec = sec.get(stage)
         if not rec or not ms:
             continue
         if stage == "hamming" and int(rec.get("hamming_mode", -1)) != int(hamming_mode):
@@ -374,15 +466,16 @@ def issue_roofline(n_kp, n_pairs, ham_ms, rsc_ms, hamming_mode):
                                 "issue_time_ms": round(t_issue_ms, 4), "stage_time_ms": round(ms, 4),
                                 "frac": round(t_issue_ms / ms, 4),
                                 "valu_busy_frac_pmc": rec.get("valu_busy_frac"),
+                                "lds_bank_conflict_cycles_pmc": rec.get("lds_bank_conflict_cycles_per_batch"),
                                 "hbm_bytes_per_batch_pmc": rec.get("hbm_bytes_per_launch")}
     return out
 
 
-def static_traffic(dominant, n_pairs):
+def static_traffic(pmc, section, dominant, n_pairs):
     """HBM bytes per launch of the dominant stage from the committed PMC profile (scaled to this run's pairs), or None."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-        rec = pmc["hamming" if dominant == "hamming_nn" else "select_ransac"]
+        sec = pmc[section] if section in pmc else pmc
+        rec = sec["hamming" if dominant == "hamming_nn" else "select_ransac"]
         return round(rec["hbm_bytes_per_launch"] * n_pairs / float(rec["pairs_per_batch"]))
     except Exception:
         return None
@@ -441,12 +534,21 @@ def sift_subrecord(seq, device):
     dot_ms, fin_ms, rsc_ms = dot_ms / max(nl, 1), fin_ms / max(nl, 1), rsc_ms / max(nl, 1)
     fe.close()
     tf = 2.0 * N * N * 128 * len(pq) / (dot_ms * 1e-3) / 1e12 if dot_ms else 0.0
+    pmc, pmc_src = load_pmc()
+    traffic = None
+    try:
+        rec = pmc["sift"]["sift_dot"]
+        traffic = round(rec["hbm_bytes_per_launch"] * len(pq) / float(pmc["sift"]["pairs_per_batch"]))
+    except Exception:
+        pass
     return {"metric": "frame-pairs matched+RANSAC/sec, SIFT 128-d float, %d kp (configs[3])" % N,
             "value": round(steps * len(pq) / dt, 2), "unit": "frame-pairs/s", "pairs_per_step": len(pq),
             "ms_per_step": round(dt / steps * 1e3, 4),
             "roofline": {"bound": "mfma", "kernel": "sift dot-product + top-2", "achieved": round(tf, 3), "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5), "flop_per_pair": 2.0 * N * N * 128,
-                         "avg_launch_ms": round(dot_ms, 4), "time_basis": "serial", "traffic": None},
+                         "avg_launch_ms": round(dot_ms, 4), "time_basis": "serial", "traffic": traffic,
+                         "traffic_source": "%s [sift] (static: both passes of the dot-product stage, FETCH_SIZE x 2 + "
+                                           "WRITE_SIZE)" % pmc_src},
             "serial_stage_ms": {"dot_top2": round(dot_ms, 4), "finish": round(fin_ms, 4), "select_ransac": round(rsc_ms, 4)}}
 
 
@@ -458,12 +560,8 @@ def loop_closure_subrecord(device, depth_noise):
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd._lib import RESULT_DTYPE
     from rgbdslam_v2_amd.frontend import FrontEnd
-    F, N = 180, 1000
-    places = [synth.make_sequence(n_frames=10, n_kp=N, seed=1000 + p, depth_noise=depth_noise) for p in range(F // 10)]
-    desc = [pl["desc"][i] for pl in places for i in range(10)]
-    xyz = [pl["xyz1"][i] for pl in places for i in range(10)]
-    pq = np.array([q for q in range(F) for t in range(q)], np.int32)
-    pt = np.array([t for q in range(F) for t in range(q)], np.int32)
+    desc, xyz, pq, pt = synth.loop_closure_places(depth_noise=depth_noise)
+    F = len(desc)
     fe = FrontEnd(device_id=device, max_nodes=F, max_keypoints=1024, max_pairs_per_batch=len(pq))
     for f in range(F):
         fe.upload_node(f, desc[f], xyz[f])
@@ -488,13 +586,129 @@ def loop_closure_subrecord(device, depth_noise):
     same_place = (pq // 10) == (pt // 10)
     edges = res["id1"] >= 0
     fe.close()
-    return {"metric": "frame-pairs matched+RANSAC/sec, all-pairs loop-closure search, ORB-1000",
+    parity = parity_check(("loop_closure", depth_noise), res)
+    return {"metric": "frame-pairs matched+RANSAC/sec, all-pairs loop-closure search, ORB-1000", "parity_check": parity,
             "value": round(len(pq) * steps / dt, 1), "unit": "frame-pairs/s", "pairs_per_step": int(len(pq)),
             "ms_per_step": round(dt / steps * 1e3, 3), "frames": F,
             "pairs_reaching_ransac": round(float((res["real_iterations"] > 0).mean()), 4),
             "edge_fraction": round(float(edges.mean()), 4),
             "true_pairs_found": round(float(edges[same_place].mean()), 4),
             "false_edges": int(edges[~same_place].sum())}
+
+
+def ransac_heavy_subrecord(device, n_kp, n_frames, pairs_per_frame):
+    """The slower regime as a driver-visible figure: configs[1] with round 1's depth noise 0.002 z^2 -- 56 %
+    of the hypotheses are valid instead of 13 %, so the refinement rounds dominate the RANSAC stage.  Same 4000 pairs per
+    step, pipelined timing + serial stage times + its own issue roofline section; results checked against the oracle."""
+    import torch
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd._lib import KERNEL_HAMMING, KERNEL_RANSAC, RESULT_DTYPE
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    noise = synth.DEPTH_NOISE_R1
+    seq = synth.make_sequence(n_frames=n_frames, n_kp=n_kp, seed=SEED, depth_noise=noise)
+    pq, pt = synth.candidate_pairs(n_frames, per_frame=pairs_per_frame, seed=SEED)
+    fe = FrontEnd(device_id=device, max_nodes=n_frames, max_keypoints=((n_kp + 63) // 64) * 64, max_pairs_per_batch=len(pq), seed=SEED)
+    for f in range(n_frames):
+        fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+    bufs = [torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:%d" % device) for _ in range(4)]
+
+    def run(steps):
+        for st in range(steps):
+            fe.submit_pair_list(pq, pt, bufs[st % 4].data_ptr())
+        fe.synchronize()
+
+    run(2)
+    steps = 6
+    vals = []
+    for _ in range(REPEATS):
+        t0 = time.perf_counter()
+        run(steps)
+        vals.append(len(pq) * steps / (time.perf_counter() - t0))
+    value = sorted(vals)[len(vals) // 2]
+    fe.set_profiling(True)
+    fe.reset_kernel_time()
+    for _ in range(3):
+        fe.wait_ticket(fe.submit_pair_list(pq, pt, bufs[0].data_ptr()), None)
+    fe.synchronize()
+    fe.set_profiling(False)
+    ham_ms, nl, _ = fe.kernel_time(KERNEL_HAMMING)
+    rsc_ms, _, _ = fe.kernel_time(KERNEL_RANSAC)
+    ham_ms, rsc_ms = ham_ms / max(nl, 1), rsc_ms / max(nl, 1)
+    res = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[: len(pq)]
+    mode = fe.hamming_mode
+    fe.close()
+    default = n_kp == N_KP and n_frames == N_FRAMES and pairs_per_frame == PAIRS_PER_FRAME
+    parity = parity_check(("orb", noise) if default else None, res)
+    pmc, pmc_src = load_pmc()
+    _, _, b_rsc = algorithmic_bytes(n_kp, MAX_MATCHES)
+    gbs = b_rsc * len(pq) / (rsc_ms * 1e-3) / 1e9 if rsc_ms else 0.0
+    return {"metric": "frame-pairs matched+RANSAC/sec, 640x480 ORB-%d, depth noise 0.002 z^2 (round 1's regime)" % n_kp,
+            "value": round(value, 1), "unit": "frame-pairs/s", "pairs_per_step": int(len(pq)),
+            "ms_per_step": round(len(pq) / value * 1e3, 4),
+            "repeats": [round(v, 1) for v in vals],
+            "edge_fraction": round(float((res["id1"] >= 0).mean()), 4),
+            "mean_ransac_iterations": round(float(res["real_iterations"].mean()), 2),
+            "mean_valid_iterations": round(float(res["valid_iterations"].mean()), 2),
+            "serial_stage_ms": {"match": round(ham_ms, 4), "select_ransac": round(rsc_ms, 4)},
+            "roofline": {"bound": "hbm", "limiter": "valu_issue", "kernel": "select_ransac", "achieved": round(gbs, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
+                         "traffic": static_traffic(pmc, "ransac_heavy", "select_ransac", len(pq)),
+                         "traffic_source": "%s [ransac_heavy]" % pmc_src, "time_basis": "serial"},
+            "issue_roofline": issue_roofline(pmc, pmc_src, "ransac_heavy", n_kp, len(pq), ham_ms, rsc_ms, mode),
+            "parity_check": parity}
+
+
+def sift_extract_subrecord(device):
+    """SIFT extraction (SURVEY.md 8(f) rank 4, SiftGPUWrapper::detect): frames/s of rgbdfe_sift_detect on synthetic
+    640x480 frames, host buffers in and out; algorithmic bytes per frame stated in DESIGN.md 4.11."""
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    seq = synth.make_image_sequence(n_frames=8, seed=1)
+    fe = FrontEnd(device_id=device, max_nodes=4, max_keypoints=64, max_pairs_per_batch=8)
+    try:
+        for f in range(2):
+            fe.sift_detect(seq["gray"][f], None)
+        reps, tot = 3, 0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for f in range(len(seq["gray"])):
+                kp, _ = fe.sift_detect(seq["gray"][f], None)
+                tot += len(kp)
+        dt = time.perf_counter() - t0
+    finally:
+        fe.close()
+    frames = reps * len(seq["gray"])
+    w, h = seq["gray"][0].shape[1], seq["gray"][0].shape[0]
+    b_frame = sift_extract_bytes(w, h, tot / frames)
+    gbs = frames * b_frame / dt / 1e9
+    pmc, pmc_src = load_pmc()
+    prof = (pmc.get("sift_extract") or {}).get("%dx%d" % (w, h)) or {}
+    k_ns = prof.get("kernel_ns_per_frame")
+    return {"metric": "frames SIFT-detected+described/sec, %dx%d (SiftGPUWrapper::detect)" % (w, h),
+            "value": round(frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),
+            "mean_keypoints": round(tot / frames, 1),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_frame": b_frame,
+                         "time_basis": "host wall clock per frame, PCIe and host work included",
+                         "traffic": prof.get("hbm_bytes_per_frame"),
+                         "kernel_time_frac": round(b_frame / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 6) if k_ns else None,
+                         "kernel_us_per_frame": round(k_ns / 1e3, 2) if k_ns else None,
+                         "traffic_source": "%s [sift_extract]" % pmc_src}}
+
+
+def sift_extract_bytes(w, h, n_kp):
+    """Algorithmic bytes of one frame of SIFT extraction (f32 planes): the up-sampled first octave has
+    4 W H pixels, every octave o holds S + 3 = 6 Gaussian levels and S + 2 = 5 DoG levels of (4 W H) / 4^o pixels.
+    Per level: one separable blur = 2 reads + 2 writes of a plane (H pass, V pass), one DoG write + two reads, the
+    extrema scan reads 3 DoG planes once each, orientation + descriptor read a 16x16 neighbourhood's gradients per
+    keypoint.  Sum over octaves of 4^-o <= 4/3."""
+    px0 = 4.0 * w * h
+    planes = 4.0 / 3.0
+    blur = 6 * 4 * 4 * px0 * planes            # 6 levels x (2 reads + 2 writes) x 4 B
+    dog = 5 * 3 * 4 * px0 * planes             # 5 levels x (2 reads + 1 write) x 4 B
+    extrema = 5 * 4 * px0 * planes             # every DoG plane read once more
+    per_kp = n_kp * (2 * 16 * 16 * 4 * 2 + 128 * 4 + 16)
+    return w * h + blur + dog + extrema + per_kp
 
 
 def detect_subrecord(device):
@@ -531,15 +745,26 @@ def detect_subrecord(device):
         frames = reps * n_frames
         b_frame = 13.4 * w * h + 64 * n_kp
         gbs = frames * b_frame / dt / 1e9
-        out["%dx%d_orb%d" % (w, h, n_kp)] = {
+        gbs_batch = frames * b_frame / dt_batch / 1e9
+        key = "%dx%d_orb%d" % (w, h, n_kp)
+        pmc, pmc_src = load_pmc()
+        prof = (pmc.get("detect") or {}).get(key) or {}
+        k_ns = prof.get("kernel_ns_per_frame")
+        out[key] = {
             "value": round(frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),
             "batch_api": {"value": round(frames / dt_batch, 2), "unit": "frames/s",
                           "ms_per_frame": round(dt_batch / frames * 1e3, 4),
                           "note": "rgbdfe_detect_describe_batch over the same frames: identical outputs, uploads overlapped"},
             "mean_keypoints": round(tot / frames, 1),
-            "roofline": {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_frame": b_frame,
-                         "time_basis": "host wall clock per frame, PCIe and host round trips included", "traffic": None}}
+            "roofline": {"bound": "hbm", "achieved": round(gbs_batch, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs_batch / HBM_PEAK_GBS, 6), "frac_single_calls": round(gbs / HBM_PEAK_GBS, 6),
+                         "algorithmic_bytes_per_frame": b_frame,
+                         "time_basis": "host wall clock per frame of the batch entry point, PCIe and host work included",
+                         "traffic": prof.get("hbm_bytes_per_frame"),
+                         "kernel_time_frac": round(b_frame / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 6) if k_ns else None,
+                         "kernel_us_per_frame": round(k_ns / 1e3, 2) if k_ns else None,
+                         "traffic_source": "%s [detect] (static: all kernels of a frame summed, FETCH_SIZE x 2 + WRITE_SIZE; "
+                                           "kernel time from the kernel trace of the same run)" % pmc_src}}
     return out
 
 

@@ -82,6 +82,22 @@ typedef struct {
   uint64_t inlier_mask[RGBDFE_MASK_WORDS]; /* bit m set <=> all_*[m] is in inlier_matches */
 } rgbdfe_match_result;
 
+/* The same record without its all_matches lists: what GraphManager consumes of a MatchingResult besides GUI drawing
+ * (edge ids / transform / information scale, rmse, |inlier_matches|, graph_manager.cpp:554-606; all_matches only feeds
+ * graph_mgr_io.cpp:739-1107).  This is the default payload of the multi-GPU gather: 144 B instead of 1744 B per pair.
+ * Node features are replicated on every device, and a pair's result does not depend on the batch or the device it ran
+ * on, so the full record of a pair whose lists are wanted (updateInlierFeatures, :409-419; drawing) is
+ * rgbdfe_match_pair_list(ctx, &q, &t, 1, &full) on ANY device -- byte-identical to the owner's, no fetch needed. */
+typedef struct {
+  int32_t  id1, id2, n_all, n_inl;
+  float    rmse;
+  float    trafo[16];
+  uint32_t pad0;
+  double   info_scale;
+  int32_t  valid_iterations, real_iterations;
+  uint64_t inlier_mask[RGBDFE_MASK_WORDS];
+} rgbdfe_compact_result;
+
 typedef struct rgbdfe_ctx rgbdfe_ctx;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -119,6 +135,15 @@ int  rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* quer
                                             int32_t n_pairs, void* const* d_out, int32_t* const* d_index,
                                             int32_t* edges_per_device, int32_t* stride);
 const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx);            /* "rccl", "p2p" or "none" (last allgather) */
+/* The compact form of rgbdfe_match_pair_list_allgather: d_out[i] holds G * per rgbdfe_compact_result, same placement
+ * (pair k at (k mod G) * per + k / G, unused tail records 0xFF); 12x fewer bytes cross xGMI. */
+int  rgbdfe_match_pair_list_allgather_compact(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                              int32_t n_pairs, void* const* d_out, int32_t* records_per_device);
+/* d_records (n rgbdfe_match_result in HBM) -> d_compact (n rgbdfe_compact_result in HBM), enqueued on `stream`
+ * (hipStream_t; NULL = the context's stream): what a one-process-per-GPU caller runs between rgbdfe_wait_ticket and its
+ * own ncclAllGather (bench.py --gpus N).  Single-device contexts only. */
+int  rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void* d_compact, void* stream);
+int  rgbdfe_sizeof_compact_result(void);
 int  rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p);
 const char* rgbdfe_status_string(int status);
 const char* rgbdfe_last_error(rgbdfe_ctx* ctx);
@@ -332,6 +357,19 @@ int rgbdfe_observation_criterion_met(uint32_t inliers, uint32_t outliers, uint32
  * rand_fn(rand_state) replaces rand() (pass a wrapper of rand() for the reference's stream); NULL selects a
  * counter-based generator seeded with `seed`, which makes the selection reproducible.
  * Returns RGBDFE_ERR_CAPACITY (with *n_out = the needed size) when ids_out is too small. */
+typedef struct rgbdfe_pose_graph rgbdfe_pose_graph;
+typedef int (*rgbdfe_rand_fn)(void* state);
+rgbdfe_pose_graph* rgbdfe_pose_graph_create(void);
+void rgbdfe_pose_graph_destroy(rgbdfe_pose_graph* g);
+int rgbdfe_pose_graph_add_node(rgbdfe_pose_graph* g, int32_t node_id, int32_t vertex_id, int32_t matchable,
+                               int32_t keyframe);
+int rgbdfe_pose_graph_add_edge(rgbdfe_pose_graph* g, int32_t node_id1, int32_t node_id2);
+int rgbdfe_pose_graph_set_matchable(rgbdfe_pose_graph* g, int32_t node_id, int32_t matchable);
+int rgbdfe_potential_edge_targets(const rgbdfe_pose_graph* g, int32_t sequential_targets, int32_t geodesic_targets,
+                                  int32_t sampled_targets, int32_t geodesic_depth, int32_t predecessor_id,
+                                  int32_t include_predecessor, rgbdfe_rand_fn rand_fn, void* rand_state, uint32_t seed,
+                                  int32_t* ids_out, int32_t capacity, int32_t* n_out);
+
 /* GPU prefilter in front of the pair path (second half): what loop_closing.cpp's
  * GraphManager::getNeighbours (:190-277, behind DO_LOOP_CLOSING, never wired into nodeComparisons) sketched -- every
  * descriptor of the new node votes `k_neighbours - rank` (:241) for the nodes holding its k nearest descriptors, a
@@ -352,18 +390,6 @@ int rgbdfe_place_recognition_batch(rgbdfe_ctx* ctx, const int32_t* query_ids, in
                                    const int32_t* candidate_offsets, const int32_t* candidate_ids, int32_t k_neighbours,
                                    int32_t max_hd, int32_t max_out, int32_t* out_ids, float* out_scores,
                                    int32_t* out_counts);
-typedef struct rgbdfe_pose_graph rgbdfe_pose_graph;
-typedef int (*rgbdfe_rand_fn)(void* state);
-rgbdfe_pose_graph* rgbdfe_pose_graph_create(void);
-void rgbdfe_pose_graph_destroy(rgbdfe_pose_graph* g);
-int rgbdfe_pose_graph_add_node(rgbdfe_pose_graph* g, int32_t node_id, int32_t vertex_id, int32_t matchable,
-                               int32_t keyframe);
-int rgbdfe_pose_graph_add_edge(rgbdfe_pose_graph* g, int32_t node_id1, int32_t node_id2);
-int rgbdfe_pose_graph_set_matchable(rgbdfe_pose_graph* g, int32_t node_id, int32_t matchable);
-int rgbdfe_potential_edge_targets(const rgbdfe_pose_graph* g, int32_t sequential_targets, int32_t geodesic_targets,
-                                  int32_t sampled_targets, int32_t geodesic_depth, int32_t predecessor_id,
-                                  int32_t include_predecessor, rgbdfe_rand_fn rand_fn, void* rand_state, uint32_t seed,
-                                  int32_t* ids_out, int32_t capacity, int32_t* n_out);
 
 /* ---- per-frame feature path: detect + describe (Node::Node, node.cpp:139-210) -----------------
  * rgbdfe_detect_describe replaces, for one frame,
@@ -385,8 +411,12 @@ typedef struct {
   float response;   /* Harris response */
   int32_t octave;   /* pyramid level */
 } rgbdfe_keypoint;
+/* parameter_server.cpp:83,87,89; resets the per-cell thresholds */
 int rgbdfe_detector_configure(rgbdfe_ctx* ctx, int32_t max_keypoints, int32_t grid_resolution,
-                              int32_t adjuster_max_iterations); /* "use_feature_min_depth" (parameter_server.cpp:90, default off): a keypoint's depth is the nearest valid depth in its
+                              int32_t adjuster_max_iterations);
+/* the current per-cell FAST thresholds (grid_resolution^2 doubles) */
+int rgbdfe_detector_thresholds(rgbdfe_ctx* ctx, double* thresholds, int32_t* n_cells);
+/* "use_feature_min_depth" (parameter_server.cpp:90, default off): a keypoint's depth is the nearest valid depth in its
  * neighbourhood (getMinDepthInNeighborhood, misc.cpp:774-793) instead of the pixel under it -- in removeDepthless
  * (node.cpp:82) and projectTo3D (:940).  rgbdfe_set_feature_min_depth switches rgbdfe_detect_describe(_batch) over;
  * rgbdfe_project_to_3d_min_depth is rgbdfe_project_to_3d in that mode (kp_size = cv::KeyPoint::size per keypoint).
@@ -396,8 +426,6 @@ int rgbdfe_project_to_3d_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, const fl
                                    const float* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
                                    double cy, double depth_scaling, int32_t max_keypoints, int32_t* kept_idx,
                                    float* xyz1, int32_t* n_out);
-/* parameter_server.cpp:83,87,89; resets thresholds */
-int rgbdfe_detector_thresholds(rgbdfe_ctx* ctx, double* thresholds, int32_t* n_cells);
 int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* depth,
                            int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
                            double depth_scaling, rgbdfe_keypoint* keypoints, uint8_t* descriptors,

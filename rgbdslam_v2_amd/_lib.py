@@ -75,6 +75,23 @@ RESULT_DTYPE = np.dtype([
     ("all_hd", "u1", (RGBDFE_MAX_MATCHES,)), ("inlier_mask", "<u8", (RGBDFE_MASK_WORDS,)),
 ], align=True)
 
+# rgbdfe_compact_result: the record without its all_matches lists (the default multi-GPU gather payload, 144 B)
+COMPACT_DTYPE = np.dtype([
+    ("id1", "<i4"), ("id2", "<i4"), ("n_all", "<i4"), ("n_inl", "<i4"), ("rmse", "<f4"),
+    ("trafo", "<f4", (16,)), ("pad0", "<u4"), ("info_scale", "<f8"),
+    ("valid_iterations", "<i4"), ("real_iterations", "<i4"), ("inlier_mask", "<u8", (RGBDFE_MASK_WORDS,)),
+], align=True)
+COMPACT_FIELDS = [n for n in COMPACT_DTYPE.names]
+
+
+def compact_of(records: np.ndarray) -> np.ndarray:
+    """Host twin of compact_pack_kernel: RESULT_DTYPE records -> COMPACT_DTYPE records (tests)."""
+    out = np.zeros(len(records), COMPACT_DTYPE)
+    for f in COMPACT_FIELDS:
+        out[f] = records[f]
+    return out
+
+
 _lib = None
 
 
@@ -226,6 +243,13 @@ def load():
     L.rgbdfe_gather_transport.argtypes = [ctx]
     L.rgbdfe_set_hamming_mode.restype = C.c_int
     L.rgbdfe_set_hamming_mode.argtypes = [ctx, i32]
+    L.rgbdfe_match_pair_list_allgather_compact.restype = C.c_int
+    L.rgbdfe_match_pair_list_allgather_compact.argtypes = [ctx, vp, vp, i32, vp, C.POINTER(i32)]
+    L.rgbdfe_pack_compact.restype = C.c_int
+    L.rgbdfe_pack_compact.argtypes = [ctx, vp, i32, vp, vp]
+    L.rgbdfe_sizeof_compact_result.restype = C.c_int
+    if L.rgbdfe_sizeof_compact_result() != COMPACT_DTYPE.itemsize:
+        raise RgbdfeError("rgbdfe_compact_result layout mismatch between librgbdfe.so and the binding")
     L.rgbdfe_sizeof_match_result.restype = C.c_int
     L.rgbdfe_abi_version.restype = C.c_int
     if L.rgbdfe_sizeof_match_result() != C.sizeof(RgbdfeMatchResult) or \
@@ -273,4 +297,5 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_set_feature_min_depth", "rgbdfe_project_to_3d_min_depth",
     "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",
     "rgbdfe_match_flann_pair_list", "rgbdfe_upload_node_keypoints",
+    "rgbdfe_match_pair_list_allgather_compact", "rgbdfe_pack_compact", "rgbdfe_sizeof_compact_result",
 ]

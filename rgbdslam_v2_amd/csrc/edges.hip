@@ -1,6 +1,8 @@
 // edges.hip -- stream compaction of the accepted edges of a shard (an all-pairs loop-closure sweep rejects
 // most pairs, id1 == -1 (node.cpp:1419), and those records need not cross xGMI).  Stable: the surviving records keep
 // their shard order, so every device -- and every run -- sees the same list.
+#include <cstddef>
+
 #include "rgbdfe_internal.h"
 
 namespace rgbdfe {
@@ -54,7 +56,25 @@ __global__ __launch_bounds__(64) void edge_copy_kernel(const rgbdfe_match_result
   if (out_index && threadIdx.x == 0) out_index[d] = index_offset + index_scale * (int32_t)k;  // position in the caller's list
 }
 
+// rgbdfe_compact_result = a record without its all_q / all_t / all_hd lists: 13 + 5 words of 8 bytes out of 218
+__global__ __launch_bounds__(256) void compact_pack_kernel(const uint64_t* __restrict__ in, uint32_t n,
+                                                           uint64_t* __restrict__ out) {
+  static_assert(sizeof(rgbdfe_match_result) == 218 * 8 && sizeof(rgbdfe_compact_result) == 18 * 8, "compact record layout");
+  static_assert(offsetof(rgbdfe_match_result, all_q) == 13 * 8 && offsetof(rgbdfe_match_result, inlier_mask) == 213 * 8,
+                "compact record layout");
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n * 18u) return;
+  const uint32_t k = i / 18u, w = i - k * 18u;
+  out[i] = in[(size_t)k * 218u + (w < 13u ? w : 200u + w)];
+}
+
 }  // namespace
+
+void launch_compact_pack(const rgbdfe_match_result* in, uint32_t n, rgbdfe_compact_result* out, hipStream_t stream) {
+  if (n > 0)
+    hipLaunchKernelGGL(compact_pack_kernel, dim3((n * 18u + 255u) / 256u), dim3(256), 0, stream,
+                       reinterpret_cast<const uint64_t*>(in), n, reinterpret_cast<uint64_t*>(out));
+}
 
 // in[0..n) -> out[0..count): the records with id1 >= 0 in order; out_index[j] (optional) = index_offset + index_scale * k of
 // the j-th survivor (the caller's global pair index of a shard: offset = device, scale = devices).

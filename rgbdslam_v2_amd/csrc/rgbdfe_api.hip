@@ -62,7 +62,9 @@ struct NodeEntry {
   uint32_t n;
   uint32_t kind;  // 0 = ORB (32-byte binary descriptors), 1 = SIFT (128 floats), 2 = float descriptors (FLANN branch)
   uint32_t flags = 0;  // bit 0 (SIFT): every row's quantised squared norm is < 2^19 (sift_match.hip's fast keys)
+                       // bit 1: the slot holds THIS node's KeyPoint.pt (rgbdfe_upload_node_keypoints after the latest upload)
 };
+constexpr uint32_t kNodeHasKeypoints = 2u;
 
 inline uint32_t mix32_host(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du;
@@ -410,6 +412,10 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     // SIFT fast keys: dot products < 2^19 (Cauchy-Schwarz over the two nodes' norms) and at most 32 column tiles
     w.pad = matcher == 1 ? sift_fast_keys(ctx, q->second, t->second) : 0u;
     sift_kinds |= w.pad ? 1u : 2u;
+    // the g2o refinement reads the nodes' own feature_locations_2d_ (node.cpp:1222-1268): never a slot's previous occupant
+    if (ctx->rc.g2o_iterations > 0 && !(q->second.flags & t->second.flags & kNodeHasKeypoints))
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG,
+                  "g2o_iterations > 0: a node of the batch has no keypoints (rgbdfe_upload_node_keypoints after every upload of it)");
     if (w.nq > max_nq) max_nq = w.nq;
     if (w.nt > max_nt) max_nt = w.nt;
   }
@@ -477,7 +483,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
           launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
         if (ctx->profiling && last) (void)hipEventRecord(pend.c, stream);
       } else {
-        float* d_dist = (d_out_dist ? d_out_dist : lane.d_all_dist) + (size_t)(d_out_dist ? off : 0) * RGBDFE_MAX_MATCHES;
+        float* d_dist = (d_out_dist ? d_out_dist : lane.d_all_dist) + (size_t)off * RGBDFE_MAX_MATCHES;  // (the lane's buffer holds max_pairs rows)
         if (matcher == 2) {
           launch_l2_knn2(ctx->d_sift_f32, d_work, mk, (uint32_t)m, max_nq, lane.d_row_part, stream);
           if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
@@ -761,6 +767,7 @@ int rgbdfe_upload_node_keypoints(rgbdfe_ctx* ctx, int32_t node_id, const float* 
   if (n > 0)
     HIP_TRY(ctx, hipMemcpy(ctx->d_kp2d + (size_t)it->second.slot * (size_t)ctx->cfg.max_keypoints * 2, kp_xy,
                            (size_t)n * 8, hipMemcpyHostToDevice));
+  it->second.flags |= kNodeHasKeypoints;  // every upload into the slot builds a fresh NodeEntry, i.e. clears it
   return RGBDFE_OK;
 }
 
@@ -1631,6 +1638,14 @@ int rgbdfe_place_recognition_batch(rgbdfe_ctx* ctx, const int32_t* query_ids, in
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "candidate_offsets must start at 0 and ascend");
   if (total > ctx->cfg.max_pairs_per_batch)
     return fail(ctx, RGBDFE_ERR_CAPACITY, "more (query, candidate) pairs than max_pairs_per_batch");
+  // the whole offsets array is checked before anything indexed by it is written (h_work, rows); queries are the y
+  // extent of the vote grid
+  if (n_queries > 65535) return fail(ctx, RGBDFE_ERR_CAPACITY, "at most 65535 queries per place recognition batch");
+  for (int32_t s = 0; s < n_queries; ++s) {
+    const int32_t c0 = candidate_offsets[s], c1 = candidate_offsets[s + 1];
+    if (c0 < 0 || c1 < c0 || c1 > total || c1 - c0 > 65535)
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG, "candidate_offsets must ascend within [0, offsets[n_queries]] (<= 65535 candidates per query)");
+  }
   if (total == 0 || max_out == 0) return RGBDFE_OK;
   for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   for (auto& sl : ctx->ring) sl.pending = false;  // every lane is idle now
@@ -2202,7 +2217,17 @@ int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx) {
 }
 
 int rgbdfe_sizeof_match_result(void) { return (int)sizeof(rgbdfe_match_result); }
-int rgbdfe_abi_version(void) { return 2; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL
+int rgbdfe_sizeof_compact_result(void) { return (int)sizeof(rgbdfe_compact_result); }
+int rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void* d_compact, void* stream) {
+  if (!ctx || n < 0 || (n > 0 && (!d_records || !d_compact))) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad pack arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  launch_compact_pack((const rgbdfe_match_result*)d_records, (uint32_t)n, (rgbdfe_compact_result*)d_compact,
+                      stream ? (hipStream_t)stream : ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return RGBDFE_OK;
+}
+int rgbdfe_abi_version(void) { return 3; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect
 
 }  // namespace impl
 
@@ -2280,6 +2305,9 @@ struct Group {
   std::vector<int32_t*> edge_idx, edge_dst, edge_cnt;
   std::vector<int32_t*> edge_cnt_host;  // pinned
   int32_t edge_cap = 0;                 // records per device the scratch holds
+  // One call at a time on a group handle (rgbdfe.h: calls on one context serialise): covers the workers' job slots and
+  // transport / rccl_* / edge_* above.  Recursive: the gather entry points hold it around their group_run.
+  std::recursive_mutex mu;
 };
 
 namespace {
@@ -2309,6 +2337,7 @@ void worker_main(Worker* w) {
 // run fn(i) for every device on that device's host thread; returns the first error
 int group_run(rgbdfe_ctx* gctx, const std::function<int(int)>& fn) {
   Group& g = *gctx->group;
+  std::lock_guard<std::recursive_mutex> call_lock(g.mu);
   const int G = (int)g.children.size();
   for (int i = 0; i < G; ++i) {
     Worker& w = *g.workers[(size_t)i];
@@ -2442,12 +2471,40 @@ bool group_setup_rccl(rgbdfe_ctx* gctx) {
   return true;
 }
 
+// per-device scratch of `per` full records (+ index / scan buffers): the edges-only and the compact gathers stage there
+int group_ensure_edge_scratch(rgbdfe_ctx* gctx, int32_t per) {
+  Group& g = *gctx->group;
+  const int G = (int)g.children.size();
+  const size_t rec = sizeof(rgbdfe_match_result);
+  if (g.edge_cap >= per) return RGBDFE_OK;
+  g.edge_recs.resize((size_t)G, nullptr); g.edge_idx.resize((size_t)G, nullptr); g.edge_dst.resize((size_t)G, nullptr);
+  g.edge_cnt.resize((size_t)G, nullptr); g.edge_cnt_host.resize((size_t)G, nullptr);
+  for (int i = 0; i < G; ++i) {
+    HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+    if (g.edge_recs[(size_t)i]) { (void)hipFree(g.edge_recs[(size_t)i]); (void)hipFree(g.edge_idx[(size_t)i]); (void)hipFree(g.edge_dst[(size_t)i]); }
+    g.edge_recs[(size_t)i] = nullptr; g.edge_idx[(size_t)i] = nullptr; g.edge_dst[(size_t)i] = nullptr;
+    g.edge_cap = 0;
+    HIP_TRY(gctx, hipMalloc((void**)&g.edge_recs[(size_t)i], rec * (size_t)per));
+    HIP_TRY(gctx, hipMalloc((void**)&g.edge_idx[(size_t)i], sizeof(int32_t) * (size_t)per));
+    HIP_TRY(gctx, hipMalloc((void**)&g.edge_dst[(size_t)i], sizeof(int32_t) * (size_t)per));
+    if (!g.edge_cnt[(size_t)i]) {
+      HIP_TRY(gctx, hipMalloc((void**)&g.edge_cnt[(size_t)i], sizeof(int32_t)));
+      HIP_TRY(gctx, hipHostMalloc((void**)&g.edge_cnt_host[(size_t)i], sizeof(int32_t), hipHostMallocDefault));
+    }
+  }
+  g.edge_cap = per;
+  return RGBDFE_OK;
+}
+
 // Results of all pairs on every device.  d_out[i]: device-i buffer of G * per records, per = ceil(n / G);
 // pair k ends up at [(k % G) * per + k / G] of every buffer; unused tail records are filled with 0xFF (ids -1).
+// compact: d_out holds rgbdfe_compact_result (144 B) instead of full records; the shard is computed into the device's
+// record scratch and packed into its segment.
 int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, void* const* d_out,
-                          int32_t* records_per_device) {
+                          int32_t* records_per_device, bool compact = false) {
   if (n < 0 || !d_out || (n > 0 && (!q || !t))) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad allgather arguments");
   Group& g = *gctx->group;
+  std::lock_guard<std::recursive_mutex> call_lock(g.mu);
   const int G = (int)g.children.size();
   const int32_t per = (n + G - 1) / G;
   if (records_per_device) *records_per_device = per;
@@ -2456,17 +2513,19 @@ int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, 
     if (!d_out[i]) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "allgather: a device buffer is NULL");
   if (per > gctx->cfg.max_pairs_per_batch)
     return fail(gctx, RGBDFE_ERR_CAPACITY, "allgather: the shard of a device exceeds max_pairs_per_batch");
-  const size_t rec = sizeof(rgbdfe_match_result);
+  const size_t rec = compact ? sizeof(rgbdfe_compact_result) : sizeof(rgbdfe_match_result);
+  if (compact) { const int rce = group_ensure_edge_scratch(gctx, per); if (rce != RGBDFE_OK) return rce; }
   // 1. every device computes its shard into its own segment of its own buffer
   int rc = group_run(gctx, [&](int i) -> int {
     rgbdfe_ctx* c = g.children[(size_t)i];
     std::vector<int32_t> qs, ts;
     for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }
-    rgbdfe_match_result* seg = (rgbdfe_match_result*)d_out[i] + (size_t)i * per;
+    char* seg_bytes = (char*)d_out[i] + (size_t)i * per * rec;
+    rgbdfe_match_result* seg = compact ? g.edge_recs[(size_t)i] : (rgbdfe_match_result*)seg_bytes;
     {
       std::lock_guard<std::mutex> lk(c->mu);
       HIP_TRY(c, hipSetDevice(c->cfg.device_id));
-      HIP_TRY(c, hipMemsetAsync(seg, 0xFF, rec * (size_t)per, g.gather_streams[(size_t)i]));
+      HIP_TRY(c, hipMemsetAsync(seg_bytes, 0xFF, rec * (size_t)per, g.gather_streams[(size_t)i]));
       HIP_TRY(c, hipEventRecord(g.gather_events[(size_t)i], g.gather_streams[(size_t)i]));
     }
     int64_t ticket = 0;
@@ -2475,6 +2534,10 @@ int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, 
       std::lock_guard<std::mutex> lk(c->mu);
       r = enqueue_pairs(c, qs.data(), ts.data(), (int32_t)qs.size(), seg, g.gather_events[(size_t)i], &ticket, nullptr);
       if (r == RGBDFE_OK) r = wait_ticket(c, ticket, g.gather_streams[(size_t)i]);
+      if (r == RGBDFE_OK && compact) {
+        launch_compact_pack(seg, (uint32_t)qs.size(), (rgbdfe_compact_result*)seg_bytes, g.gather_streams[(size_t)i]);
+        if (hipGetLastError() != hipSuccess) r = fail(c, RGBDFE_ERR_HIP, "compact_pack_kernel launch");
+      }
     }
     return r;
   });
@@ -2531,6 +2594,7 @@ int group_match_allgather_edges(rgbdfe_ctx* gctx, const int32_t* q, const int32_
   if (n < 0 || !d_out || !counts || !stride_out || (n > 0 && (!q || !t)))
     return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad allgather arguments");
   Group& g = *gctx->group;
+  std::lock_guard<std::recursive_mutex> call_lock(g.mu);
   const int G = (int)g.children.size();
   const int32_t per = (n + G - 1) / G;
   *stride_out = 0;
@@ -2541,22 +2605,7 @@ int group_match_allgather_edges(rgbdfe_ctx* gctx, const int32_t* q, const int32_
   if (per > gctx->cfg.max_pairs_per_batch)
     return fail(gctx, RGBDFE_ERR_CAPACITY, "allgather: the shard of a device exceeds max_pairs_per_batch");
   const size_t rec = sizeof(rgbdfe_match_result);
-  if (g.edge_cap < per) {
-    g.edge_recs.resize((size_t)G, nullptr); g.edge_idx.resize((size_t)G, nullptr); g.edge_dst.resize((size_t)G, nullptr);
-    g.edge_cnt.resize((size_t)G, nullptr); g.edge_cnt_host.resize((size_t)G, nullptr);
-    for (int i = 0; i < G; ++i) {
-      HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
-      if (g.edge_recs[(size_t)i]) { (void)hipFree(g.edge_recs[(size_t)i]); (void)hipFree(g.edge_idx[(size_t)i]); (void)hipFree(g.edge_dst[(size_t)i]); }
-      HIP_TRY(gctx, hipMalloc((void**)&g.edge_recs[(size_t)i], rec * (size_t)per));
-      HIP_TRY(gctx, hipMalloc((void**)&g.edge_idx[(size_t)i], sizeof(int32_t) * (size_t)per));
-      HIP_TRY(gctx, hipMalloc((void**)&g.edge_dst[(size_t)i], sizeof(int32_t) * (size_t)per));
-      if (!g.edge_cnt[(size_t)i]) {
-        HIP_TRY(gctx, hipMalloc((void**)&g.edge_cnt[(size_t)i], sizeof(int32_t)));
-        HIP_TRY(gctx, hipHostMalloc((void**)&g.edge_cnt_host[(size_t)i], sizeof(int32_t), hipHostMallocDefault));
-      }
-    }
-    g.edge_cap = per;
-  }
+  { const int rce = group_ensure_edge_scratch(gctx, per); if (rce != RGBDFE_OK) return rce; }
   // 1. every device: its shard into its own segment of its own buffer, then the accepted records, compacted, into scratch
   int rc = group_run(gctx, [&](int i) -> int {
     rgbdfe_ctx* c = g.children[(size_t)i];
@@ -2703,13 +2752,20 @@ rgbdfe_ctx* rgbdfe_device_context(rgbdfe_ctx* ctx, int32_t i) {
 
 const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx) {
   static thread_local std::string buf;
-  buf = (ctx && ctx->group) ? ctx->group->transport : "none";
+  if (ctx && ctx->group) {
+    std::lock_guard<std::recursive_mutex> call_lock(ctx->group->mu);
+    buf = ctx->group->transport;
+  } else buf = "none";
   return buf.c_str();
 }
 
 int rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
-  if (RGBDFE_IS_GROUP(ctx) && p) ctx->cfg.params = *p;
+  if (RGBDFE_IS_GROUP(ctx) && p) {
+    std::lock_guard<std::recursive_mutex> call_lock(ctx->group->mu);
+    ctx->cfg.params = *p;
+    return RGBDFE_ALL(ctx, impl::rgbdfe_set_params(c, p));
+  }
   return RGBDFE_ALL(ctx, impl::rgbdfe_set_params(c, p));
 }
 
@@ -2788,6 +2844,24 @@ int rgbdfe_match_pair_list_allgather(rgbdfe_ctx* ctx, const int32_t* query_ids, 
     if (!RGBDFE_IS_GROUP(ctx))
       return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_match_pair_list_allgather needs a context made by rgbdfe_create_multi");
     return group_match_allgather(ctx, query_ids, train_ids, n_pairs, d_out, records_per_device);
+  });
+}
+
+int rgbdfe_match_pair_list_allgather_compact(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                             int32_t n_pairs, void* const* d_out, int32_t* records_per_device) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!RGBDFE_IS_GROUP(ctx))
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_match_pair_list_allgather_compact needs a context made by rgbdfe_create_multi");
+    return group_match_allgather(ctx, query_ids, train_ids, n_pairs, d_out, records_per_device, true);
+  });
+}
+
+int rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void* d_compact, void* stream) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_pack_compact");
+    return impl::rgbdfe_pack_compact(ctx, d_records, n, d_compact, stream);
   });
 }
 
@@ -3130,6 +3204,7 @@ int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx) {
 }
 
 int rgbdfe_sizeof_match_result(void) { return impl::rgbdfe_sizeof_match_result(); }
+int rgbdfe_sizeof_compact_result(void) { return impl::rgbdfe_sizeof_compact_result(); }
 int rgbdfe_abi_version(void) { return impl::rgbdfe_abi_version(); }
 
 }  // extern "C"

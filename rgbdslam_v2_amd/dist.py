@@ -6,7 +6,14 @@ No other collective exists on this path: pairs are independent
 (QtConcurrent::blockingMapped has no cross-task dependency, graph_manager.cpp:548)."""
 import numpy as np
 
-from ._lib import RESULT_DTYPE
+from ._lib import COMPACT_DTYPE, RESULT_DTYPE
+
+
+def collective_device(group=None):
+    """Where the tensors of a collective must live: the current GPU under the nccl (= RCCL) backend, the host otherwise."""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
 def shard_pairs(pair_q, pair_t, rank: int, world: int):
@@ -30,20 +37,20 @@ def unshard(gathered: np.ndarray, n_pairs: int, world: int) -> np.ndarray:
     return out
 
 
-def all_gather_results(local_records, n_pairs: int, group=None):
-    """All-gather of the per-rank result records.  local_records: numpy RESULT_DTYPE array (CPU,
-    gloo) or a uint8 torch tensor already in HBM (RCCL).  Returns all records in global order
-    (numpy)."""
+def all_gather_results(local_records, n_pairs: int, group=None, dtype=RESULT_DTYPE):
+    """All-gather of the per-rank result records.  local_records: numpy array of `dtype` (RESULT_DTYPE, or
+    COMPACT_DTYPE for the 144-byte payload) or a uint8 torch tensor already in HBM (RCCL).  Returns all
+    records in global order (numpy)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     sizes = shard_sizes(n_pairs, world)
     n_pad = max(sizes) if sizes else 0
-    rec = RESULT_DTYPE.itemsize
+    rec = dtype.itemsize
     if isinstance(local_records, np.ndarray):
-        buf = np.zeros(n_pad, RESULT_DTYPE)
+        buf = np.zeros(n_pad, dtype)
         buf[: len(local_records)] = local_records
-        local = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy())
+        local = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy()).to(collective_device(group))
     else:
         local = local_records.reshape(-1)
         if local.numel() != n_pad * rec:
@@ -52,8 +59,15 @@ def all_gather_results(local_records, n_pairs: int, group=None):
             local = pad
     out = torch.empty(world * n_pad * rec, dtype=torch.uint8, device=local.device)
     dist.all_gather_into_tensor(out, local, group=group)
-    g = np.frombuffer(out.cpu().numpy().tobytes(), dtype=RESULT_DTYPE).reshape(world, n_pad)
+    g = np.frombuffer(out.cpu().numpy().tobytes(), dtype=dtype).reshape(world, n_pad)
     return unshard(g, n_pairs, world)
+
+
+def all_gather_compact(local_records, n_pairs: int, group=None):
+    """The default payload of the multi-GPU gather: COMPACT_DTYPE records (header + inlier mask, 144 B instead of
+    1744 B per pair).  local_records: numpy COMPACT_DTYPE array, or a uint8 tensor in HBM as rgbdfe_pack_compact
+    wrote it."""
+    return all_gather_results(local_records, n_pairs, group, dtype=COMPACT_DTYPE)
 
 
 def all_gather_edges(local_records, n_pairs: int, group=None):
@@ -70,8 +84,9 @@ def all_gather_edges(local_records, n_pairs: int, group=None):
     keep = np.flatnonzero(local_records["id1"] >= 0)
     gidx = rank + world * keep.astype(np.int64)
     assert len(local_records) == len(range(rank, n_pairs, world))
-    cnt = torch.tensor([len(keep)], dtype=torch.int64)
-    cnts = torch.zeros(world, dtype=torch.int64)
+    dev = collective_device(group)  # RCCL moves device tensors only
+    cnt = torch.tensor([len(keep)], dtype=torch.int64, device=dev)
+    cnts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(cnts, cnt, group=group)
     n_pad = int(cnts.max().item())
     rec = RESULT_DTYPE.itemsize
@@ -81,14 +96,14 @@ def all_gather_edges(local_records, n_pairs: int, group=None):
     buf[: len(keep)] = local_records[keep]
     ibuf = np.full(n_pad, -1, np.int64)
     ibuf[: len(keep)] = gidx
-    t_rec = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy())
-    t_idx = torch.from_numpy(ibuf)
-    o_rec = torch.empty(world * n_pad * rec, dtype=torch.uint8)
-    o_idx = torch.empty(world * n_pad, dtype=torch.int64)
+    t_rec = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy()).to(dev)
+    t_idx = torch.from_numpy(ibuf).to(dev)
+    o_rec = torch.empty(world * n_pad * rec, dtype=torch.uint8, device=dev)
+    o_idx = torch.empty(world * n_pad, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(o_rec, t_rec, group=group)
     dist.all_gather_into_tensor(o_idx, t_idx, group=group)
-    allrec = np.frombuffer(o_rec.numpy().tobytes(), dtype=RESULT_DTYPE)
-    allidx = o_idx.numpy()
+    allrec = np.frombuffer(o_rec.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+    allidx = o_idx.cpu().numpy()
     sel = np.flatnonzero(allidx >= 0)
     order = sel[np.argsort(allidx[sel], kind="stable")]
     return allidx[order].copy(), allrec[order].copy()

@@ -138,6 +138,21 @@ class FrontEnd:
                                                              C.cast(ptrs, C.c_void_p), C.byref(per)))
         return int(per.value)
 
+    def match_pair_list_allgather_compact(self, query_ids, train_ids, d_out_ptrs: Sequence[int]) -> int:
+        """rgbdfe_match_pair_list_allgather with COMPACT_DTYPE records (144 B: no all_matches lists) as the payload."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        ptrs = (C.c_void_p * len(d_out_ptrs))(*[C.c_void_p(int(p)) for p in d_out_ptrs])
+        per = C.c_int32(0)
+        self._check(self._L.rgbdfe_match_pair_list_allgather_compact(self._ctx, q.ctypes.data, t.ctypes.data, len(q),
+                                                                     C.cast(ptrs, C.c_void_p), C.byref(per)))
+        return int(per.value)
+
+    def pack_compact(self, d_records_ptr: int, n: int, d_compact_ptr: int, stream: Optional[int] = None):
+        """n records in HBM -> n compact records in HBM on `stream` (rgbdfe_pack_compact)."""
+        self._check(self._L.rgbdfe_pack_compact(self._ctx, C.c_void_p(int(d_records_ptr)), int(n),
+                                                C.c_void_p(int(d_compact_ptr)), C.c_void_p(stream or 0)))
+
     def match_pair_list_allgather_edges(self, query_ids, train_ids, d_out_ptrs: Sequence[int], d_index_ptrs=None):
         """Only the accepted edges travel (rgbdfe_match_pair_list_allgather_edges).  Returns (counts per device, stride):
         device i's edges sit at records [i * stride, i * stride + counts[i]) of every buffer, their positions in the pair

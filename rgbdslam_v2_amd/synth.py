@@ -13,6 +13,8 @@ import numpy as np
 FX = FY = 525.0
 CX, CY = 319.5, 239.5
 WIDTH, HEIGHT = 640, 480
+DEPTH_NOISE = 0.01      # sigma = sigma_depth * z^2
+DEPTH_NOISE_R1 = 0.002   # round 1's regime, kept as a second test / bench parametrisation
 
 
 def _rot(rx, ry, rz):
@@ -26,10 +28,15 @@ def _rot(rx, ry, rz):
 
 
 def make_sequence(n_frames=200, n_kp=1000, n_world=4000, seed=20260923, bitflip=0.08,
-                  true_fraction=0.75, depth_noise=0.002, pixel_noise=0.3, nan_fraction=0.0,
+                  true_fraction=0.75, depth_noise=0.01, pixel_noise=0.3, nan_fraction=0.0,
                   width=WIDTH, height=HEIGHT, motion_scale=1.0):
     """Returns dict(desc uint8 [F,N,32], xyz1 float32 [F,N,4], poses float64 [F,4,4]
-    (camera-to-world), world_id int32 [F,N] (-1 = outlier))."""
+    (camera-to-world), world_id int32 [F,N] (-1 = outlier)).
+
+    depth_noise is the sigma of the depth error as a multiple of z^2: 0.01 = sigma_depth
+    (parameter_server.cpp:46), what SURVEY.md 8(d) specifies and bench.py measures; DEPTH_NOISE_R1
+    = 0.002 is the gentler regime round 1 measured (more valid hypotheses per pair, a slower
+    RANSAC stage) that the tests keep as a second parametrisation."""
     rng = np.random.Generator(np.random.PCG64(seed))
     fx, fy = FX * width / WIDTH, FY * height / HEIGHT
     cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
@@ -124,6 +131,21 @@ def candidate_pairs(n_frames, per_frame=20, seed=20260923, predecessors=3):
             pq.append(f)
             pt.append(c)
     return np.asarray(pq, np.int32), np.asarray(pt, np.int32)
+
+
+def loop_closure_places(n_frames=180, n_kp=1000, frames_per_place=10, depth_noise=DEPTH_NOISE, seed=1000):
+    """The reject-path workload of bench.py's `loop_closure` sub-record: `n_frames` frames in unrelated places of
+    `frames_per_place` frames each, every frame against every earlier one (180 frames -> 16 110 pairs, ~5 % of them
+    true edges; the others are chance matches that the min_matches gate or RANSAC rejects).
+    Returns (desc list, xyz1 list, pair_q, pair_t)."""
+    places = [make_sequence(n_frames=frames_per_place, n_kp=n_kp, seed=seed + p, depth_noise=depth_noise)
+              for p in range(n_frames // frames_per_place)]
+    desc = [pl["desc"][i] for pl in places for i in range(frames_per_place)]
+    xyz = [pl["xyz1"][i] for pl in places for i in range(frames_per_place)]
+    F = len(desc)
+    pq = np.array([q for q in range(F) for t in range(q)], np.int32)
+    pt = np.array([t for q in range(F) for t in range(q)], np.int32)
+    return desc, xyz, pq, pt
 
 
 def relative_pose(poses, q, t):

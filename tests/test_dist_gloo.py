@@ -8,7 +8,7 @@ import numpy as np
 import torch.multiprocessing as mp
 
 from rgbdslam_v2_amd import dist as rdist
-from rgbdslam_v2_amd._lib import RESULT_DTYPE
+from rgbdslam_v2_amd._lib import COMPACT_DTYPE, RESULT_DTYPE, compact_of
 
 
 def _free_port():
@@ -42,6 +42,10 @@ def _worker(rank, world, port, n_pairs, q):
     local = _fake_records(sq, st)
     allrec = rdist.all_gather_results(local, n_pairs)
     ok = allrec.tobytes() == _fake_records(pq, pt).tobytes()
+    # the default payload: compact records (header + inlier mask, 144 B)
+    allcmp = rdist.all_gather_compact(compact_of(local), n_pairs)
+    ok = ok and allcmp.dtype == COMPACT_DTYPE and allcmp.tobytes() == compact_of(_fake_records(pq, pt)).tobytes()
+    ok = ok and rdist.collective_device().type == "cpu"
     # accepted edges only (all-pairs sweeps): rejected pairs (id1 == -1) do not travel
     full = _fake_records(pq, pt)
     rej = (pq + pt) % 3 != 0
@@ -64,6 +68,15 @@ def test_shard_and_unshard_roundtrip():
         for r, s in enumerate(shards):
             g["id2"][r, : len(s)] = s
         assert np.array_equal(rdist.unshard(g, n, w)["id2"], pq)
+
+
+def test_compact_record_layout():
+    """rgbdfe_compact_result = the record's first 104 bytes + its inlier mask (include/rgbdfe.h)."""
+    assert COMPACT_DTYPE.itemsize == 144 and RESULT_DTYPE.itemsize == 1744
+    rec = _fake_records(np.arange(5, dtype=np.int32), np.arange(5, dtype=np.int32) + 1)
+    c = compact_of(rec)
+    raw, craw = rec.view(np.uint8).reshape(5, 1744), c.view(np.uint8).reshape(5, 144)
+    assert np.array_equal(craw[:, :104], raw[:, :104]) and np.array_equal(craw[:, 104:], raw[:, 1704:])
 
 
 def test_all_gather_world2_gloo():

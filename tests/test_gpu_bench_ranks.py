@@ -33,3 +33,7 @@ def test_bench_two_ranks_one_gpu():
     # weak scaling: 10 candidates per frame and rank -> 20 per frame globally, sharded round robin
     assert d["config"]["pairs_per_gpu_per_step"] > 0 and d["config"]["parallelism"] == "pair-sharded x2"
     assert "sift" not in d and "cpu_baseline" not in d    # extras and the CPU leg belong to the N = 1 line
+    # the per-step gather moves compact records by default, and the line says how many ranks the collective saw
+    assert d["gather"]["payload"] == "rgbdfe_compact_result" and d["gather"]["bytes_per_record"] == 144
+    assert d["gather"]["rccl_ranks"] == 2 and d["gather"]["backend"] == "gloo"
+    assert len(d["repeats"]["values"]) == 3 and d["value"] == sorted(d["repeats"]["values"])[1]

@@ -20,7 +20,7 @@ def _root_sift(rng, n, dim=128):
 
 @pytest.fixture(scope="module")
 def seq():
-    s = synth.make_sequence(n_frames=8, n_kp=700, n_world=2400, seed=77)
+    s = synth.make_sequence(n_frames=8, n_kp=700, n_world=2400, seed=77, depth_noise=synth.DEPTH_NOISE_R1)
     rng = np.random.default_rng(7)
     # float descriptors: one 128-d RootSIFT-like vector per world point, observed with a little noise; outliers random
     base = _root_sift(rng, 2400)

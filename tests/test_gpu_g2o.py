@@ -72,6 +72,25 @@ def test_g2o_needs_keypoints():
         fe.match_pair_list([1], [0])
     with pytest.raises(RgbdfeError):
         fe.upload_node_keypoints(0, np.zeros((5, 2), np.float32))     # wrong count
+    # keypoints belong to one upload of one node -- a re-upload, or a new node in a recycled slot, must not be
+    # refined against the slot's previous KeyPoint.pt
+    rng = np.random.default_rng(3)
+    kps = [keypoints_of(seq["xyz1"][f], rng) for f in range(3)]
+    for f in range(3):
+        fe.upload_node_keypoints(f, kps[f])
+    ok = fe.match_pair_list([1, 2], [0, 1])
+    fe.upload_node(1, seq["desc"][1], seq["xyz1"][1])                  # re-upload in place: keypoints gone
+    with pytest.raises(RgbdfeError, match="keypoints"):
+        fe.match_pair_list([1], [0])
+    fe.upload_node_keypoints(1, kps[1])
+    assert fe.match_pair_list([1, 2], [0, 1]).tobytes() == ok.tobytes()
+    fe.release_node(2)
+    fe.upload_node(7, seq["desc"][2], seq["xyz1"][2])                  # a new node takes the recycled slot
+    with pytest.raises(RgbdfeError, match="keypoints"):
+        fe.match_pair_list([7], [1])
+    fe.upload_node_keypoints(7, kps[2])
+    got = fe.match_pair_list([7], [1])
+    assert np.array_equal(got["trafo"][0], ok["trafo"][1]) and got["n_inl"][0] == ok["n_inl"][1]
     fe.set_params(g2o_iterations=0)
     assert fe.match_pair_list([1], [0])["n_all"][0] > 0
     fe.close()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from rgbdslam_v2_amd import synth
-from rgbdslam_v2_amd._lib import RESULT_DTYPE, RgbdfeError
+from rgbdslam_v2_amd._lib import COMPACT_DTYPE, RESULT_DTYPE, RgbdfeError, compact_of
 
 pytestmark = pytest.mark.gpu
 
@@ -196,6 +196,128 @@ def test_one_context_from_many_threads(data):
     assert not errors and not wrong, (errors, wrong)
     assert fe.match_pair_list(pq, pt).tobytes() == ref.tobytes()
     fe.close()
+
+
+def test_one_group_handle_from_many_threads(data):
+    """a rgbdfe_create_multi handle is one context -- calls from several threads (match / upload / release /
+    set_params / gathers) serialise on the group's own lock; no caller may lose its shard or see another caller's
+    status."""
+    import torch
+    seq, pq, pt = data
+    one = _fe(seq, cap=64)
+    ref = one.match_pair_list(pq, pt)
+    one.close()
+    grp = _fe(seq, device_ids=[0, 0], cap=64)
+    G, rec = 2, RESULT_DTYPE.itemsize
+    errors, wrong = [], []
+
+    def worker(tid):
+        try:
+            bufs = [torch.zeros(G * 10 * rec, dtype=torch.uint8, device="cuda:0") for _ in range(G)]
+            torch.cuda.synchronize()
+            for it in range(6):
+                lo = (tid * 5 + it * 3) % (len(pq) - 20)
+                out = grp.match_pair_list(pq[lo:lo + 19], pt[lo:lo + 19])      # odd count: uneven shards
+                if out.tobytes() != ref[lo:lo + 19].tobytes():
+                    wrong.append((tid, it, "match"))
+                try:
+                    grp.match_pair_list([0], [1000 + tid])
+                    wrong.append((tid, it, "no error"))
+                except RgbdfeError as e:
+                    if "not resident" not in str(e):
+                        wrong.append((tid, it, str(e)))
+                if tid % 3 == 0:
+                    grp.upload_node(100 + tid, seq["desc"][tid % 14], seq["xyz1"][tid % 14])
+                    grp.release_node(100 + tid)
+                if tid % 3 == 1:
+                    per = grp.match_pair_list_allgather(pq[lo:lo + 20], pt[lo:lo + 20], [b.data_ptr() for b in bufs])
+                    got = np.frombuffer(bufs[it % G].cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+                    for k in range(20):
+                        if got[(k % G) * per + k // G].tobytes() != ref[lo + k].tobytes():
+                            wrong.append((tid, it, "gather", k))
+                            break
+                if tid % 3 == 2:
+                    grp.set_params(seed=grp.params.seed)            # same values: results must not move
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors and not wrong, (errors, wrong)
+    assert grp.match_pair_list(pq, pt).tobytes() == ref.tobytes()
+    grp.close()
+
+
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0]])
+def test_compact_allgather_carries_everything_but_the_match_lists(data, ids):
+    """The default gather payload: rgbdfe_compact_result (144 B instead of 1744 B).  Every device ends up with every
+    pair's header + inlier mask; the full record of any pair is recomputed locally, byte-identical (no fetch)."""
+    import torch
+    seq, pq, pt = data
+    one = _fe(seq)
+    ref = one.match_pair_list(pq, pt)
+    # the single-context packer (what bench.py --gpus N runs before its own all-gather)
+    d_rec = torch.from_numpy(ref.view(np.uint8).reshape(-1).copy()).cuda()
+    d_cmp = torch.zeros(len(ref) * COMPACT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    one.pack_compact(d_rec.data_ptr(), len(ref), d_cmp.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d_cmp.cpu().numpy().tobytes() == compact_of(ref).tobytes()
+    one.close()
+    assert COMPACT_DTYPE.itemsize == 144
+    grp = _fe(seq, device_ids=ids)
+    G, n = len(ids), len(pq)
+    per = (n + G - 1) // G
+    bufs = [torch.zeros(G * per * COMPACT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0") for _ in ids]
+    torch.cuda.synchronize()
+    assert grp.match_pair_list_allgather_compact(pq, pt, [b.data_ptr() for b in bufs]) == per
+    want = compact_of(ref)
+    for b in bufs:
+        got = np.frombuffer(b.cpu().numpy().tobytes(), dtype=COMPACT_DTYPE)
+        for k in range(n):
+            assert got[(k % G) * per + k // G].tobytes() == want[k].tobytes()
+        for d in range(G):
+            used = len(range(d, n, G))
+            assert np.all(got[d * per + used:(d + 1) * per]["id1"] == -1)
+    # "lazy fetch": any device recomputes a pair's full record on its own
+    k = int(np.flatnonzero(ref["id1"] >= 0)[3])
+    assert grp.match_pair_list(pq[k:k + 1], pt[k:k + 1]).tobytes() == ref[k:k + 1].tobytes()
+    grp.close()
+
+
+def test_sift_and_flann_batches_split_into_pieces_keep_their_distance_rows():
+    """a SIFT / FLANN batch that runs as several record / replay pieces (pairs x ransac_iterations > 2^24)
+    with host outputs: every piece's DMatch.distance rows must land at the piece's offset, not on top of piece 0."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    seq = synth.make_sequence(n_frames=5, n_kp=96, n_world=260, seed=13)
+    sd = synth.sift_descriptors_like(seq["desc"], seed=2)
+    iters = 100000                       # pieces of 2^24 / 100000 = 167 pairs
+    n = 400
+    rng = np.random.default_rng(4)
+    pq = rng.integers(1, 5, n).astype(np.int32)
+    pt = (pq - 1 - rng.integers(0, 4, n) % pq).astype(np.int32)
+
+    def run(flann, pairs_q, pairs_t, cap):
+        fe = FrontEnd(device_id=0, max_nodes=8, max_keypoints=128, max_pairs_per_batch=cap, min_matches=5,
+                      ransac_iterations=iters)
+        for f in range(5):
+            (fe.upload_float_node if flann else fe.upload_sift_node)(f, sd[f], seq["xyz1"][f])
+        out = fe.match_flann_pair_list(pairs_q, pairs_t) if flann else fe.match_sift_pair_list(pairs_q, pairs_t)
+        fe.close()
+        return out
+
+    for flann in (False, True):
+        rec, dist = run(flann, pq, pt, n)                       # one batch of 400 pairs = three pieces
+        uniq = sorted({(int(a), int(b)) for a, b in zip(pq, pt)})
+        r1, d1 = run(flann, [a for a, _ in uniq], [b for _, b in uniq], 16)   # the same pairs, single-piece batches
+        lut = {kq: i for i, kq in enumerate(uniq)}
+        assert any(r1["n_all"] > 0)
+        for k in range(n):
+            i = lut[(int(pq[k]), int(pt[k]))]
+            assert rec[k].tobytes() == r1[i].tobytes(), (flann, k)
+            assert np.array_equal(dist[k][: rec[k]["n_all"]], d1[i][: r1[i]["n_all"]]), (flann, k)
 
 
 def test_batch_beyond_65536_pairs():

@@ -81,11 +81,16 @@ def test_frozen_golden_pairs(fe):
     fe.set_params(seed=20260923, depth_cov=1e-4)
 
 
+NOISES = [synth.DEPTH_NOISE, synth.DEPTH_NOISE_R1]   # 0.01 z^2 = SURVEY 8(d) / bench.py; 0.002 z^2 = round 1's regime
+NOISE_IDS = ["noise0.01", "noise0.002"]
+
+
+@pytest.mark.parametrize("depth_noise", NOISES, ids=NOISE_IDS)
 @pytest.mark.parametrize("n_kp,seed", [(1000, 1), (600, 2), (1500, 3)])
-def test_synthetic_sequence_matches_oracle(fe, n_kp, seed):
+def test_synthetic_sequence_matches_oracle(fe, n_kp, seed, depth_noise):
     # configs[1] (1000 kp), configs[0] (600 kp), configs[2] (1500 kp) at oracle-friendly pair counts
     F = 10
-    seq = synth.make_sequence(n_frames=F, n_kp=n_kp, n_world=4 * n_kp, seed=seed)
+    seq = synth.make_sequence(n_frames=F, n_kp=n_kp, n_world=4 * n_kp, seed=seed, depth_noise=depth_noise)
     for f in range(F):
         fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
     pq, pt = synth.candidate_pairs(F, per_frame=4, seed=seed)
@@ -212,12 +217,13 @@ def test_config5_4000_keypoints_all_pairs_match_oracle():
         fe5.close()
 
 
-def test_full_size_properties(fe):
+@pytest.mark.parametrize("depth_noise,pose_tol", [(synth.DEPTH_NOISE, 0.05), (synth.DEPTH_NOISE_R1, 0.03)], ids=NOISE_IDS)
+def test_full_size_properties(fe, depth_noise, pose_tol):
     """BASELINE configs[1] size (1000 kp, 20 candidates/frame) through size-independent properties:
     determinism, self-match identity, ground-truth pose recovery, inlier-set consistency."""
     from rgbdslam_v2_amd.frontend import inlier_indices
     F = 40
-    seq = synth.make_sequence(n_frames=F, n_kp=1000, seed=20260923)
+    seq = synth.make_sequence(n_frames=F, n_kp=1000, seed=20260923, depth_noise=depth_noise)
     for f in range(F):
         fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
     pq, pt = synth.candidate_pairs(F, per_frame=20)
@@ -228,7 +234,7 @@ def test_full_size_properties(fe):
     assert ok.mean() > 0.9
     for rec, q, t in zip(a[ok][::9], pq[ok][::9], pt[ok][::9]):
         T = np.array(rec["trafo"], np.float32).reshape(4, 4).T.astype(np.float64)
-        assert np.abs(T - synth.relative_pose(seq["poses"], q, t)).max() < 0.03
+        assert np.abs(T - synth.relative_pose(seq["poses"], q, t)).max() < pose_tol
         assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-4
         inl = inlier_indices(rec)
         assert len(inl) == rec["n_inl"] >= 20 and rec["rmse"] <= 3.0
@@ -255,7 +261,8 @@ def test_randomised_nodes_and_parameters_match_oracle():
             F = 8
             sizes = [int(rng.choice([0, 1, 3, 5, 21, 64, 300, 777, 1000, 1536])) for _ in range(F)]
             seq = synth.make_sequence(n_frames=F, n_kp=1536, n_world=4000, seed=100 + trial,
-                                      nan_fraction=float(rng.choice([0.0, 0.05, 0.3])))
+                                      nan_fraction=float(rng.choice([0.0, 0.05, 0.3])),
+                                      depth_noise=(0.002, 0.01, 0.03)[trial % 3])
             nodes = []
             for f in range(F):
                 d, x = seq["desc"][f][: sizes[f]].copy(), seq["xyz1"][f][: sizes[f]].copy()
@@ -342,14 +349,18 @@ def test_latency_path_equals_one_wave_path(fe):
             fe.release_node(k)
 
 
-def test_whole_bench_step_matches_oracle():
+@pytest.mark.parametrize("depth_noise", NOISES, ids=NOISE_IDS)
+def test_whole_bench_step_matches_oracle(depth_noise):
     """BASELINE configs[1] at its full size: every one of the 4000 pairs of a bench.py step (200 frames x 1000
-    keypoints, 20 candidates per frame, the bench's seed) equals the oracle bit for bit -- in the pipelined submission
-    the bench times, and through the synchronous host-buffer call."""
+    keypoints, 20 candidates per frame, the bench's seed and the bench's depth noise 0.01 z^2; second parametrisation:
+    round 1's 0.002 z^2 = bench.py's `ransac_heavy` sub-record) equals the oracle bit for bit -- in the pipelined
+    submission the bench times, and through the synchronous host-buffer call.  The aggregate figures bench.py asserts
+    on its own last step (bench.EXPECTED) are re-derived from the oracle here."""
     import torch
+    import bench
     from rgbdslam_v2_amd.frontend import FrontEnd, RESULT_DTYPE
     F, N = 200, 1000
-    seq = synth.make_sequence(n_frames=F, n_kp=N)
+    seq = synth.make_sequence(n_frames=F, n_kp=N, seed=bench.SEED, depth_noise=depth_noise)
     pq, pt = synth.candidate_pairs(F, 20)
     assert len(pq) == 4000
     big = FrontEnd(device_id=0, max_nodes=F, max_keypoints=1024, max_pairs_per_batch=4096)
@@ -365,8 +376,48 @@ def test_whole_bench_step_matches_oracle():
         assert outs[0].tobytes() == outs[1].tobytes() == big.match_pair_list(pq, pt).tobytes()
         prm = po.default_params(seed=big.params.seed, depth_cov=big.params.depth_cov)
         refs = po.match_pairs_mt(list(seq["desc"]), list(seq["xyz1"]), np.arange(F), pq, pt, prm)
+        n_edges = iters = inl = 0
         for rec, r in zip(outs[0], refs):
-            check_against_oracle(rec, po.result_to_dict(r))
-        assert (outs[0]["id1"] >= 0).mean() > 0.95
+            ref = po.result_to_dict(r)
+            check_against_oracle(rec, ref)
+            n_edges += ref["id1"] >= 0
+            iters += ref["real_iterations"]
+            inl += ref["n_inl"]
+        assert n_edges > 0.95 * len(pq)
+        # the constants bench.py checks its own results against are the oracle's
+        exp = bench.EXPECTED["orb", depth_noise]
+        assert (int(n_edges), int(iters), int(inl)) == (exp["edges"], exp["real_iterations"], exp["inliers"])
+    finally:
+        big.close()
+
+
+def test_loop_closure_subrecord_matches_oracle():
+    """The workload of bench.py's `loop_closure` sub-record at its full size -- 180 frames in 18 unrelated places, all
+    16 110 pairs, ~5 % true edges, the rest rejected by the min_matches gate or by RANSAC (the junk-hypothesis path:
+    prescreen, pair classes, one-launch recording) -- every pair against the oracle, bit for bit."""
+    import bench
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    desc, xyz, pq, pt = synth.loop_closure_places()
+    assert len(pq) == 16110
+    F = len(desc)
+    big = FrontEnd(device_id=0, max_nodes=F, max_keypoints=1024, max_pairs_per_batch=len(pq))
+    try:
+        for f in range(F):
+            big.upload_node(f, desc[f], xyz[f])
+        out = big.match_pair_list(pq, pt)
+        prm = po.default_params(seed=big.params.seed, depth_cov=big.params.depth_cov)
+        refs = po.match_pairs_mt(desc, xyz, np.arange(F), pq, pt, prm)
+        n_edges = iters = inl = ransac = 0
+        for rec, r in zip(out, refs):
+            ref = po.result_to_dict(r)
+            check_against_oracle(rec, ref)
+            n_edges += ref["id1"] >= 0
+            iters += ref["real_iterations"]
+            inl += ref["n_inl"]
+            ransac += ref["real_iterations"] > 0
+        same_place = (pq // 10) == (pt // 10)
+        assert n_edges >= 0.9 * same_place.sum() and ransac > n_edges   # true edges found, and junk pairs reached RANSAC
+        exp = bench.EXPECTED["loop_closure", synth.DEPTH_NOISE]
+        assert (int(n_edges), int(iters), int(inl)) == (exp["edges"], exp["real_iterations"], exp["inliers"])
     finally:
         big.close()

@@ -84,4 +84,15 @@ def test_edge_cases(world):
         fe.place_recognition(0, [1], k_neighbours=9)                  # k beyond 8
     with pytest.raises(RgbdfeError):
         fe.place_recognition(0, list(range(1, 6)) * 2, k_neighbours=2)  # more candidates than max_pairs_per_batch
+    # a malformed offsets array (an intermediate offset beyond the total that later descends) is refused
+    # before anything indexed by it is written
+    import ctypes as C
+    qs = np.array([0, 1, 2], np.int32)
+    cands = np.array([1, 2, 3, 4], np.int32)
+    ids = np.zeros((3, 4), np.int32); sc = np.zeros((3, 4), np.float32); cnt = np.zeros(3, np.int32)
+    for offs in ([0, 1 << 20, 2, 4], [0, 3, 2, 4], [0, -1, 2, 4], [1, 2, 3, 4]):
+        o = np.array(offs, np.int32)
+        st = fe._L.rgbdfe_place_recognition_batch(fe._ctx, qs.ctypes.data, 3, o.ctypes.data, cands.ctypes.data, 2, 128, 4,
+                                                  ids.ctypes.data, sc.ctypes.data, cnt.ctypes.data)
+        assert st == -1, offs                       # RGBDFE_ERR_INVALID_ARG
     fe.close()

@@ -150,7 +150,7 @@ def test_sift_tie_rules(fe):
 def test_sift_pair_op_vs_oracle(fe):
     from rgbdslam_v2_amd.frontend import inlier_indices
     F = 8
-    seq = synth.make_sequence(n_frames=F, n_kp=1000, seed=4)
+    seq = synth.make_sequence(n_frames=F, n_kp=1000, seed=4, depth_noise=synth.DEPTH_NOISE_R1)  # (0.01 z^2: the test below)
     sd = synth.sift_descriptors_like(seq["desc"], seed=4)
     for f in range(F):
         fe.upload_sift_node(f, sd[f], seq["xyz1"][f])

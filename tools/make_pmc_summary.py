@@ -1,38 +1,117 @@
-"""profiles/<tag>/summary.json (tools/summarize_prof.py: counters are already summed per batch) ->
-profiles/r02_pmc_summary.json, the per-batch figures bench.py
-reads for roofline.traffic and issue_roofline.  Usage: python tools/make_pmc_summary.py r02b [pairs_per_batch]"""
+"""<tag> profile directories -> profiles/<tag>_pmc_summary.json, the static counter figures bench.py quotes
+(roofline.traffic, issue_roofline, the sub-records' traffic / kernel time).
+
+    python tools/make_pmc_summary.py r03 [--from gpurun_out|profiles]
+
+Input: <from>/prof_<tag>/<workload>/ (gpurun_out) or profiles/<tag>/<workload>/ as tools/profile_r03.sh leaves them:
+orb / heavy / sift carry a summary.json of tools/summarize_prof.py (counters per batch); the frame-level workloads
+(detect_*, sift_extract_*) are summed here over ALL kernels of the run and divided by the frames the run processed.
+HBM bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md "HBM": KiB units, gfx950 FETCH_SIZE counts
+half of a wide coalesced read)."""
+import csv
+import glob
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
-d = json.load(open(os.path.join(ROOT, "profiles", tag, "summary.json")))
-h, r = d["hamming_nn"], d["select_ransac"]
+src = sys.argv[sys.argv.index("--from") + 1] if "--from" in sys.argv else "profiles"
+base = os.path.join(ROOT, "gpurun_out", "prof_" + tag) if src == "gpurun_out" else os.path.join(ROOT, "profiles", tag)
 ISSUE = {"hamming": 1.10, "select_ransac": 1.66}  # mean ns per wave-instruction per SIMD of each kernel's mix (r01_ubench)
-out = {
-    "collected_with": "tools/profile_gpu.sh %s (rocprofv3 --kernel-trace --stats, then separate --pmc passes), bench.py "
-                      "--steps 5 --warmup 1 --no-extras, configs[1] with depth noise 0.01 z^2" % tag,
-    "workload": "configs[1]: %d pairs per batch, 1000 keypoints, 200 RANSAC iterations, depth noise 0.01 z^2" % pairs,
-    "hamming": {
-        "hamming_mode": 1, "pairs_per_batch": pairs, "kernel": "hamming_mfma_kernel<1,false>",
-        "valu_wave_instructions_per_batch": h["SQ_INSTS_VALU_avg"],
-        "mfma_instructions_per_batch": h["SQ_INSTS_MFMA_avg"],
-        "mfma_busy_cycles_per_batch": h["SQ_VALU_MFMA_BUSY_CYCLES_avg"],
-        "lds_instructions_per_batch": h["SQ_INSTS_LDS_avg"],
-        "mean_issue_ns": ISSUE["hamming"], "valu_busy_frac": round(h["valu_busy_frac"], 4),
-        "hbm_bytes_per_launch": h["hbm_bytes_per_launch"], "kernel_ns_in_profile": h["per_batch_ns"]},
-    "select_ransac": {
-        "pairs_per_batch": pairs,
-        "kernels": "pair_prep_kernel + 4 x (select_ransac_kernel<1> + replay_walk_kernel) + select_ransac_kernel<2>",
-        "valu_wave_instructions_per_batch": r["SQ_INSTS_VALU_avg"],
-        "lds_instructions_per_batch": r["SQ_INSTS_LDS_avg"],
-        "lds_bank_conflict_cycles_per_batch": r["SQ_LDS_BANK_CONFLICT_avg"],
-        "mean_issue_ns": ISSUE["select_ransac"], "valu_busy_frac": round(r["valu_busy_frac"], 4),
-        "hbm_bytes_per_launch": r["hbm_bytes_per_launch"],
-        "stage_ns_in_profile": r["per_batch_ns"],
-        "note": "per batch = summed over the stage's %d launches" % int(r["launches_per_batch"])},
-}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+out = {"collected_with": "tools/profile_r03.sh %s: rocprofv3 --kernel-trace --stats, then separate --pmc passes "
+                         "(FETCH_SIZE / WRITE_SIZE / SQ_* / MFMA), one directory per workload under profiles/%s/" % (tag, tag)}
+
+
+def pairs_of(d):
+    try:
+        line = [l for l in open(os.path.join(d, "run_trace.json")) if l.startswith("{")][-1]
+        return int(json.loads(line)["config"]["pairs_per_gpu_per_step"])
+    except Exception:
+        return 4000
+
+
+def orb_section(d, noise):
+    s = json.load(open(os.path.join(d, "summary.json")))
+    h, r = s["hamming_nn"], s["select_ransac"]
+    pairs = pairs_of(d)
+    return {
+        "pairs_per_batch": pairs, "depth_noise": noise,
+        "hamming": {
+            "hamming_mode": 1, "pairs_per_batch": pairs, "kernel": "hamming_mfma_kernel",
+            "valu_wave_instructions_per_batch": h.get("SQ_INSTS_VALU_avg"),
+            "mfma_instructions_per_batch": h.get("SQ_INSTS_MFMA_avg"),
+            "mfma_busy_cycles_per_batch": h.get("SQ_VALU_MFMA_BUSY_CYCLES_avg"),
+            "lds_instructions_per_batch": h.get("SQ_INSTS_LDS_avg"),
+            "mean_issue_ns": ISSUE["hamming"], "valu_busy_frac": round(h.get("valu_busy_frac", 0.0), 4),
+            "hbm_bytes_per_launch": h.get("hbm_bytes_per_launch"), "kernel_ns_in_profile": h.get("per_batch_ns")},
+        "select_ransac": {
+            "pairs_per_batch": pairs, "kernels": sorted(r.get("instances", {}).keys()),
+            "valu_wave_instructions_per_batch": r.get("SQ_INSTS_VALU_avg"),
+            "lds_instructions_per_batch": r.get("SQ_INSTS_LDS_avg"),
+            "lds_bank_conflict_cycles_per_batch": r.get("SQ_LDS_BANK_CONFLICT_avg"),
+            "mean_issue_ns": ISSUE["select_ransac"], "valu_busy_frac": round(r.get("valu_busy_frac", 0.0), 4),
+            "hbm_bytes_per_launch": r.get("hbm_bytes_per_launch"), "stage_ns_in_profile": r.get("per_batch_ns"),
+            "note": "per batch = summed over the stage's %d launches" % int(r.get("launches_per_batch", 0))},
+    }
+
+
+def sift_section(d):
+    s = json.load(open(os.path.join(d, "summary.json")))
+    pairs = pairs_of(d)
+    sec = {"pairs_per_batch": pairs}
+    for k in ("sift_dot", "sift_finish", "sift_sort", "select_ransac"):
+        if k in s:
+            e = s[k]
+            sec[k] = {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "stage_ns_in_profile": e.get("per_batch_ns"),
+                      "mfma_instructions_per_batch": e.get("SQ_INSTS_MFMA_avg"),
+                      "mfma_busy_cycles_per_batch": e.get("SQ_VALU_MFMA_BUSY_CYCLES_avg"),
+                      "launches_per_batch": e.get("launches_per_batch")}
+    return sec
+
+
+def frame_section(d):
+    """all kernels of the run summed, per frame"""
+    meta = None
+    for f in ("run_trace.json", "run_fetch.json", "run_write.json"):
+        try:
+            meta = json.loads([l for l in open(os.path.join(d, f)) if l.startswith("{")][-1])
+            break
+        except Exception:
+            continue
+    frames = float(meta["frames"])
+    tot_ns, kernels = 0.0, {}
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            tot_ns += float(row["TotalDurationNs"])
+            name = row["Name"].split("(")[0].replace("void ", "").replace("rgbdfe::", "")
+            kernels[name] = {"calls_per_frame": round(int(row["Calls"]) / frames, 2), "avg_ns": float(row["AverageNs"]),
+                             "ns_per_frame": round(float(row["TotalDurationNs"]) / frames, 1)}
+    ctr = {}
+    for p in ("fetch", "write"):
+        tot = 0.0
+        for f in glob.glob(os.path.join(d, "pmc_" + p, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                tot += float(row["Counter_Value"])
+        ctr[p] = tot
+    return {"frames_in_profile": int(frames), "kernel_ns_per_frame": round(tot_ns / frames, 1),
+            "hbm_read_bytes_raw_per_frame": round(ctr["fetch"] * 1024 / frames),
+            "hbm_write_bytes_raw_per_frame": round(ctr["write"] * 1024 / frames),
+            "hbm_bytes_per_frame": round((2 * ctr["fetch"] + ctr["write"]) * 1024 / frames),
+            "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["ns_per_frame"]))}
+
+
+if os.path.isdir(os.path.join(base, "orb")):
+    out["orb"] = orb_section(os.path.join(base, "orb"), 0.01)
+if os.path.isdir(os.path.join(base, "heavy")):
+    out["ransac_heavy"] = orb_section(os.path.join(base, "heavy"), 0.002)
+if os.path.isdir(os.path.join(base, "sift")):
+    out["sift"] = sift_section(os.path.join(base, "sift"))
+for d in sorted(glob.glob(os.path.join(base, "detect_*"))):
+    out.setdefault("detect", {})[os.path.basename(d)[len("detect_"):]] = frame_section(d)
+for d in sorted(glob.glob(os.path.join(base, "sift_extract_*"))):
+    out.setdefault("sift_extract", {})[os.path.basename(d)[len("sift_extract_"):]] = frame_section(d)
+dst = os.path.join(ROOT, "gpurun_out" if src == "gpurun_out" else "profiles", "%s_pmc_summary.json" % tag)
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1)[:6000])
+print("wrote", dst)
