@@ -89,8 +89,13 @@ def test_g2o_needs_keypoints():
     with pytest.raises(RgbdfeError, match="keypoints"):
         fe.match_pair_list([7], [1])
     fe.upload_node_keypoints(7, kps[2])
-    got = fe.match_pair_list([7], [1])
-    assert np.array_equal(got["trafo"][0], ok["trafo"][1]) and got["n_inl"][0] == ok["n_inl"][1]
+    fe.match_pair_list([7], [1])                                       # (another node id = another RANSAC stream)
+    fe.release_node(7)
+    fe.upload_node(2, seq["desc"][2], seq["xyz1"][2])                  # node 2 again, into the slot node 7 just left
+    with pytest.raises(RgbdfeError, match="keypoints"):
+        fe.match_pair_list([2], [1])
+    fe.upload_node_keypoints(2, kps[2])
+    assert fe.match_pair_list([1, 2], [0, 1]).tobytes() == ok.tobytes()
     fe.set_params(g2o_iterations=0)
     assert fe.match_pair_list([1], [0])["n_all"][0] > 0
     fe.close()
