@@ -459,6 +459,29 @@ int rgbdfe_orb_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask,
 int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32_t cols,
                        rgbdfe_keypoint* keypoints, int32_t n, uint8_t* descriptors, int32_t* n_out);
 
+/* ---- SIFT extraction (feature_detector_type / feature_extractor_type == "SIFTGPU") ---------------------------------
+ * rgbdfe_sift_detect replaces SiftGPUWrapper::detect (sift_gpu_wrapper.h:49, sift_gpu_wrapper.cpp:113-167; called from
+ * Node::Node, node.cpp:149-152, 282-286) with an empty keypoint list: SiftGPU's scale-space extrema detection, orientation
+ * assignment and 4x4x8 descriptors with the options the wrapper's constructor sets (:29-88) -- first octave -1 (the image
+ * is up-sampled x2), 5 DoG levels per octave, edge threshold 10, sub-pixel localisation, two orientations per keypoint,
+ * UNNORMALISED descriptors ("-unn"), at most ~max_keypoints features chosen from the coarse octaves down ("-tc2",
+ * parameter "max_keypoints") -- on the pipeline of SiftGPU's CUDA back end (external/SiftGPU/src/SiftGPU/ProgramCU.cu,
+ * PyramidCU.cpp).  gray: rows x cols u8; mask is ignored, as the reference ignores it.  keypoints[i]: pt = SiftGPU's
+ * (x, y), size = 12 * scale, angle in degrees (the wrapper's conversion, :156-160), response = octave = 0; desc128: n x 128
+ * floats = what the wrapper returns as `descriptors` and Node::projectTo3DSiftGPU / rgbdfe_sift_node_features take.
+ * Returns RGBDFE_ERR_CAPACITY with *n_out = the number of features when `capacity` rows are too few.
+ * Not built: the wrapper's second mode (a caller-provided keypoint list, :132-142), which rgbdslam_v2's Node never uses. */
+int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,
+                       int32_t max_keypoints, rgbdfe_keypoint* keypoints, float* desc128, int32_t capacity, int32_t* n_out);
+/* stage access for parity tests: the pyramid geometry of the latest frame, one Gaussian plane (octave index from 0, level
+ * 0 .. levels-1; padded width x height floats), the keypoint candidates of one (octave, DoG level) as rows of
+ * (x, y, extremum sign, dx, dy, ds) in list order, before the feature-count limit */
+int rgbdfe_sift_geometry(rgbdfe_ctx* ctx, int32_t* octave_min, int32_t* octave_num, int32_t* levels, int32_t* dog_levels);
+int rgbdfe_sift_debug_plane(rgbdfe_ctx* ctx, int32_t octave, int32_t level, float* out, int32_t capacity_floats, int32_t* w,
+                            int32_t* h);
+int rgbdfe_sift_debug_candidates(rgbdfe_ctx* ctx, int32_t octave, int32_t dog_level, float* out, int32_t capacity_rows,
+                                 int32_t* n);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, every launch of the dominant kernels is bracketed by HIP events on the
  * stream it runs on; totals are read back with rgbdfe_get_kernel_time. */

@@ -54,7 +54,7 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if force or not all(os.path.exists(os.path.join(_HERE, "_ref", f))
                         for f in ("libref_bforb.so", "libref_node.so", "libref_adjuster.so", "libref_ransac.so",
-                                  "libref_frame.so", "libref_siftmatch.so", "libref_graph.so")):
+                                  "libref_frame.so", "libref_siftmatch.so", "libref_graph.so", "libref_siftgpu.so")):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -337,6 +337,87 @@ def ref_sift_match(d1, d2):
     md = np.empty(max(n1, 1), np.float32)
     n = ref_sift_lib().ref_sift_match(_p(d1), n1, _p(d2), d2.shape[0], _p(mq), _p(mt), _p(md))
     return mq[:n].copy(), mt[:n].copy(), md[:n].copy()
+
+
+_ref_siftgpu = None
+
+
+def ref_siftgpu_lib():
+    """SiftGPU's CUDA extraction pipeline as the reference vendors it (ProgramCU.cu kernels + launchers, PyramidCU.cpp,
+    SiftPyramid::RunSIFT), compiled from /root/reference on the fiber-based CUDA-on-CPU emulation of
+    oracle/ref_stubs/siftgpu_emu_prelude.h (or None when the pin is not built)."""
+    global _ref_siftgpu
+    if _ref_siftgpu is None:
+        p = os.path.join(_HERE, "_ref", "libref_siftgpu.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        vp, i = C.c_void_p, C.c_int
+        R.ref_siftgpu_run.restype = i
+        R.ref_siftgpu_run.argtypes = [vp, i, i, i, vp, vp, i]
+        R.ref_siftgpu_geometry.restype = i
+        R.ref_siftgpu_geometry.argtypes = [C.POINTER(i)] * 4
+        R.ref_siftgpu_level.restype = i
+        R.ref_siftgpu_level.argtypes = [i, i, i, vp, C.POINTER(i), C.POINTER(i)]
+        R.ref_siftgpu_level_counts.restype = i
+        R.ref_siftgpu_level_counts.argtypes = [vp, i]
+        R.ref_siftgpu_filter_kernel.restype = i
+        R.ref_siftgpu_filter_kernel.argtypes = [C.c_float, vp]
+        _ref_siftgpu = R
+    return _ref_siftgpu
+
+
+def ref_sift_detect(gray, max_features=1000):
+    """SiftGPUWrapper::detect's SiftGPU call on a mono8 image through the compiled reference: (keys [n, 4] = x, y, scale,
+    orientation; descriptors [n, 128]; features per (octave, dog level))."""
+    R = ref_siftgpu_lib()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    cap = 1 << 16
+    while True:
+        keys = np.zeros((cap, 4), np.float32)
+        desc = np.zeros((cap, 128), np.float32)
+        n = R.ref_siftgpu_run(_p(gray), gray.shape[1], gray.shape[0], int(max_features), _p(keys), _p(desc), cap)
+        if n >= 0:
+            break
+        cap = -n - 1 + 16
+    cnt = np.zeros(128, np.int32)
+    m = R.ref_siftgpu_level_counts(_p(cnt), 128)
+    return keys[:n].copy(), desc[:n].copy(), cnt[:m].copy()
+
+
+def ref_sift_geometry():
+    R = ref_siftgpu_lib()
+    a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    R.ref_siftgpu_geometry(C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+    return dict(octave_min=a.value, octave_num=b.value, levels=c.value, dog_levels=d.value)
+
+
+def ref_sift_level(octave, level, data=0):
+    """One plane of the latest ref_sift_detect pyramid.  data: 0 Gaussian, 1 DoG, 2 keypoint map (sign, dx, dy, ds),
+    3 gradient (magnitude, angle).  Returns [h, w] or [h, w, channels]."""
+    R = ref_siftgpu_lib()
+    ch = {0: 1, 1: 1, 2: 4, 3: 2}[data]
+    buf = np.zeros(4 * 4096 * 4096 // 4, np.float32) if False else np.zeros(1 << 25, np.float32)
+    w, h = C.c_int(), C.c_int()
+    n = R.ref_siftgpu_level(octave, level, data, _p(buf), C.byref(w), C.byref(h))
+    if n <= 0:
+        return None
+    out = buf[:n].reshape(h.value, w.value, ch) if ch > 1 else buf[:n].reshape(h.value, w.value)
+    return out.copy()
+
+
+def ref_sift_candidates(octave, dog_level):
+    """The keypoint candidates of one (octave, dog level) of the latest ref_sift_detect run, as InitHist / the list
+    generation enumerate them (ProgramCU.cu:665-688, PyramidCU.cpp:738-795): the non-zero entries of the keypoint map in
+    raster order, rows 1 .. h-2, columns 1 .. w-2.  Rows of (x, y, sign, dx, dy, ds)."""
+    key = ref_sift_level(octave, dog_level + 2, 2)
+    h, w = key.shape[:2]
+    inner = np.zeros((h, w), bool)
+    inner[1:h - 1, 1:w - 1] = True
+    ys, xs = np.nonzero((key[:, :, 0] != 0) & inner)
+    return np.concatenate([xs[:, None].astype(np.float32), ys[:, None].astype(np.float32), key[ys, xs]], axis=1)
 
 
 def _p(a):

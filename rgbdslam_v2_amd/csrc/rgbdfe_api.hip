@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "orb_host.h"
+#include "sift_extract.h"
 #include "rgbdfe_internal.h"
 
 using namespace rgbdfe;
@@ -158,6 +159,7 @@ struct rgbdfe_ctx {
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
   OrbWorkspace orb;
+  SiftExtractor sift;  // rgbdfe_sift_detect (sift_extract.hip)
   int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;
   std::unordered_map<int32_t, CloudEntry> clouds;
@@ -1173,6 +1175,74 @@ int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32
   kp_to_abi(kps, keypoints);
   if (!desc.empty()) memcpy(descriptors, desc.data(), desc.size());
   *n_out = (int32_t)kps.size();
+  return RGBDFE_OK;
+}
+
+// SiftGPUWrapper::detect (src/sift_gpu_wrapper.cpp:113-167): SIFT keypoints + 128-d descriptors of one mono8 image.  The
+// mask is accepted and ignored, as the reference ignores it.  Keypoints as the wrapper builds them (:156-160):
+// pt = SiftGPU's (x, y), size = 12 * scale, angle = orientation in degrees; response and octave stay 0.
+int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* /*mask*/, int32_t rows, int32_t cols,
+                       int32_t max_keypoints, rgbdfe_keypoint* keypoints, float* desc128, int32_t capacity, int32_t* n_out) {
+  if (!ctx || !gray || rows < 1 || cols < 1 || !n_out || capacity < 0 || (capacity > 0 && (!keypoints || !desc128)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  *n_out = 0;
+  std::vector<SiftKey> keys;
+  std::vector<float> desc;
+  std::string err;
+  const int rc = ctx->sift.run(gray, rows, cols, max_keypoints, keys, desc, ctx->stream, err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  *n_out = (int32_t)keys.size();
+  if ((int32_t)keys.size() > capacity) return fail(ctx, RGBDFE_ERR_CAPACITY, "more SIFT features than the output arrays hold");
+  for (size_t i = 0; i < keys.size(); ++i) {
+    keypoints[i].x = keys[i].x;
+    keypoints[i].y = keys[i].y;
+    keypoints[i].size = (float)(12.0 * keys[i].s);
+    keypoints[i].angle = (float)(keys[i].o * 180.0 / 3.1415927);
+    keypoints[i].response = 0.f;
+    keypoints[i].octave = 0;
+  }
+  if (!desc.empty()) memcpy(desc128, desc.data(), desc.size() * sizeof(float));
+  return RGBDFE_OK;
+}
+
+// stage access for the parity tests (tests/test_gpu_sift_extract.py): a Gaussian plane / the keypoint candidates of one
+// (octave, dog level) of the latest rgbdfe_sift_detect frame
+int rgbdfe_sift_debug_plane(rgbdfe_ctx* ctx, int32_t octave, int32_t level, float* out, int32_t capacity_floats, int32_t* w,
+                            int32_t* h) {
+  if (!ctx || !out || !w || !h) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  std::vector<float> v;
+  int ww = 0, hh = 0;
+  const int rc = ctx->sift.debug_plane(octave, level, v, &ww, &hh, ctx->stream);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, "no such SIFT pyramid plane");
+  *w = ww; *h = hh;
+  if ((int64_t)v.size() > (int64_t)capacity_floats) return fail(ctx, RGBDFE_ERR_CAPACITY, "plane larger than the output");
+  memcpy(out, v.data(), v.size() * sizeof(float));
+  return RGBDFE_OK;
+}
+
+int rgbdfe_sift_debug_candidates(rgbdfe_ctx* ctx, int32_t octave, int32_t dog_level, float* out, int32_t capacity_rows,
+                                 int32_t* n) {
+  if (!ctx || !n) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  std::vector<float> v;
+  const int rc = ctx->sift.debug_candidates(octave, dog_level, v);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, "no such SIFT level");
+  *n = (int32_t)(v.size() / 6);
+  if (*n > capacity_rows) return fail(ctx, RGBDFE_ERR_CAPACITY, "more candidates than the output holds");
+  if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(float));
+  return RGBDFE_OK;
+}
+
+int rgbdfe_sift_geometry(rgbdfe_ctx* ctx, int32_t* octave_min, int32_t* octave_num, int32_t* levels, int32_t* dog_levels) {
+  if (!ctx || !octave_min || !octave_num || !levels || !dog_levels) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  *octave_min = ctx->sift.octave_min; *octave_num = ctx->sift.octave_num;
+  *levels = SiftExtractor::kLevels; *dog_levels = SiftExtractor::kDogLevels;
   return RGBDFE_OK;
 }
 
@@ -3019,6 +3089,30 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
   return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe_batch(c, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy,
                                                               depth_scaling, out_stride, keypoints, descriptors, xyz1,
                                                               n_out));
+}
+
+int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,
+                       int32_t max_keypoints, rgbdfe_keypoint* keypoints, float* desc128, int32_t capacity, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_detect(c, gray, mask, rows, cols, max_keypoints, keypoints, desc128, capacity,
+                                                    n_out));
+}
+
+int rgbdfe_sift_debug_plane(rgbdfe_ctx* ctx, int32_t octave, int32_t level, float* out, int32_t capacity_floats, int32_t* w,
+                            int32_t* h) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_debug_plane(c, octave, level, out, capacity_floats, w, h));
+}
+
+int rgbdfe_sift_debug_candidates(rgbdfe_ctx* ctx, int32_t octave, int32_t dog_level, float* out, int32_t capacity_rows,
+                                 int32_t* n) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_debug_candidates(c, octave, dog_level, out, capacity_rows, n));
+}
+
+int rgbdfe_sift_geometry(rgbdfe_ctx* ctx, int32_t* octave_min, int32_t* octave_num, int32_t* levels, int32_t* dog_levels) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_geometry(c, octave_min, octave_num, levels, dog_levels));
 }
 
 int rgbdfe_hamming_nn_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id, int32_t* out_hd, int32_t* out_idx) {

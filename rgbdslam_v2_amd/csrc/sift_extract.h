@@ -1,0 +1,60 @@
+// sift_extract.h -- per-context workspace of the SIFT extraction path (sift_extract.hip): SiftGPUWrapper::detect
+// (src/sift_gpu_wrapper.cpp:113-167) = SiftGPU's pyramid / DoG / keypoint / orientation / descriptor pipeline
+// (external/SiftGPU/src/SiftGPU/ProgramCU.cu:113-1186, PyramidCU.cpp, SiftPyramid.cpp:49-168) with the options the
+// wrapper's constructor sets (:29-88): -s 1 -tc2 <max_keypoints> -fo -1 -unn -d 5 -e 10.0 -ofix-not.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace rgbdfe {
+
+struct SiftKey { float x, y, s, o; };  // SiftGPU::SiftKeypoint: level-0 pixel coordinates, scale, orientation (radians)
+
+struct SiftExtractor {
+  static constexpr int kDogLevels = 5;            // "-d 5"
+  static constexpr int kLevels = kDogLevels + 3;  // Gaussian levels per octave (level_min = -1 .. level_max = 6)
+  static constexpr int kMaxOctaves = 12;
+  struct Octave { int w, h; size_t plane; float* g[kLevels]; };  // w = the padded width (multiple of 4) every kernel uses
+  ~SiftExtractor();
+  void release();
+  // one frame: keys (n x 4) + descriptors (n x 128, unnormalised) in SiftGPU's output order
+  int run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys, std::vector<float>& desc,
+          hipStream_t s, std::string& err);
+  // stage access for the parity tests: a Gaussian plane of the latest frame / the keypoint candidates of one
+  // (octave, dog level) as (x, y, sign, dx, dy, ds) in list order, before the feature-count limits
+  int debug_plane(int octave, int level, std::vector<float>& out, int* w, int* h, hipStream_t s);
+  int debug_candidates(int octave, int dog_level, std::vector<float>& out);
+
+  // parameters (SiftParam::ParseSiftParam, SiftGPU.cpp:433-473)
+  float sigma0 = 0, sigmak = 0, dsigma0 = 0, sigma[kLevels - 1] = {}, dog_threshold = 0, edge_threshold = 0;
+  bool params_ready = false;
+  void init_params();
+  float initial_smooth_sigma(int octave_min) const;  // SiftParam::GetInitialSmoothSigma (SiftGPU.cpp:425-431)
+  float level_sigma(int lev) const;                  // SiftParam::GetLevelSigma (SiftGPU.cpp:1200-1203)
+
+  // geometry of the current image size
+  int W = 0, H = 0, w4 = 0, octave_min = 0, octave_num = 0;
+  Octave oct[kMaxOctaves];
+  // device
+  uint8_t* d_gray = nullptr; float* d_input = nullptr; float* d_up = nullptr;  // bytes, /255 floats, resampled base
+  float* d_planes = nullptr; size_t planes_floats = 0;
+  int8_t* d_flags = nullptr; size_t flags_bytes = 0;   // extremum sign per pixel of every (octave, dog level)
+  int* d_rowcnt = nullptr; int* d_rowoff = nullptr; int* d_lvltot = nullptr; int total_rows = 0;
+  struct LevelDesc { const float* g[4]; int8_t* flags; int w, h, row0; float pad; };
+  LevelDesc* d_levels = nullptr;
+  std::vector<LevelDesc> h_levels;
+  float* d_cand = nullptr; size_t cand_cap = 0;        // candidates: 6 floats each, per level at its offset
+  float4* d_feat = nullptr; size_t feat_cap = 0;       // feature list (x, y, scale, packed / final orientation)
+  float* d_desc = nullptr; size_t desc_cap = 0;
+  int* h_counts = nullptr;                             // pinned: per-level totals
+  float* h_stage = nullptr; size_t stage_floats = 0;   // pinned staging for lists
+  uint8_t* h_gray = nullptr; size_t gray_cap = 0;      // pinned staging of the caller's (pageable) image
+  std::vector<int> lvl_count, lvl_off;                 // candidates per (octave, dog level) of the latest frame
+  std::vector<float> last_cand;
+  int prepare(int rows, int cols, std::string& err);
+};
+
+}  // namespace rgbdfe

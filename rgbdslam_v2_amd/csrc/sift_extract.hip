@@ -1,0 +1,798 @@
+// sift_extract.hip -- SIFT extraction on CDNA4: SiftGPUWrapper::detect (src/sift_gpu_wrapper.cpp:113-167), i.e. the
+// pipeline of the SiftGPU the reference vendors (external/SiftGPU/src/SiftGPU/), CUDA flavour:
+//   PyramidCU::BuildPyramid (PyramidCU.cpp:946-998)          up-sample x2 ("-fo -1"), 8 Gaussian levels per octave
+//   PyramidCU::DetectKeypointsEX (:1000-1066)                 DoG, extrema + edge test + sub-pixel solve (ComputeKEY_Kernel,
+//                                                             ProgramCU.cu:524-640)
+//   PyramidCU::GenerateFeatureList (:738-850)                 raster-ordered lists, coarse octaves first, "-tc2" limit
+//   PyramidCU::GetFeatureOrientations (:1145-1172)            36-bin histograms, two orientations (ProgramCU.cu:774-935)
+//   PyramidCU::ReshapeFeatureListCPU (:501-585)               one feature per orientation, level -> image coordinates
+//   PyramidCU::GetFeatureDescriptors (:393-432)               4x4x8 histograms, unnormalised ("-unn", ProgramCU.cu:967-1046)
+// This is a new design, not a translation of those kernels:
+//   * a Gaussian level is ONE launch (horizontal + vertical pass fused through LDS) instead of two, with the same
+//     per-tap accumulation order, so every plane equals the reference's bit for bit;
+//   * no DoG, gradient or keypoint planes exist: the extremum test recomputes D = G[l] - G[l-1] from the Gaussian planes
+//     (the same subtraction), all octaves and levels in one launch that leaves one flag byte per pixel + per-row counts;
+//     an ordered ballot compaction (scan + emit) replaces the reference's 4-ary histogram pyramid and yields the same
+//     raster-ordered lists; the orientation and descriptor kernels take gradients from the Gaussian plane on the fly
+//     (same differences, sqrt, atan2) -- the 45 floats per pixel the reference keeps shrink to 8;
+//   * orientation / descriptor sample loops keep the reference's per-keypoint accumulation order.
+// Arithmetic without transcendental functions (pyramid, extrema, sub-pixel offsets, lists) is exact against the
+// reference's kernels compiled on the CPU emulation (oracle/_ref/libref_siftgpu.so); exp / atan2 / pow / sincos come
+// from the device's libm and differ from glibc's by ulps: tests/test_gpu_sift_extract.py states the tolerances.
+#include "sift_extract.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "rgbdfe_internal.h"
+
+namespace rgbdfe {
+
+namespace {
+
+constexpr int kMaxTaps = 33;  // KERNEL_MAX_WIDTH (ProgramCU.cu:40)
+struct Taps { float k[kMaxTaps]; int fw; };
+
+// ---- image in: bytes -> luminance / 255 (GLTexInput::DownSamplePixelDataI2F, GLTexImage.cpp:808-831), width cut to w4 ----
+__global__ __launch_bounds__(256) void sift_convert_kernel(const uint8_t* __restrict__ gray, int cols, int w4, int rows,
+                                                           float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w4 * rows) return;
+  const int y = i / w4, x = i - y * w4;
+  out[i] = (float)(int)gray[(size_t)y * cols + x] / 255.0f;
+}
+
+// UpsampleKernel<1> (ProgramCU.cu:221-265): src is w x h, dst 2w x 2h.  A fetch past the end of the source returns 0
+// (linear texture), a fetch past the end of a row continues in the next row -- both kept.
+__global__ __launch_bounds__(128) void sift_upsample2_kernel(const float* __restrict__ src, int w, int h,
+                                                             float* __restrict__ dst) {
+  const int col = blockIdx.x * 128 + threadIdx.x;
+  if (col >= w) return;
+  const int n = w * h;
+  auto fetch = [&](int i) -> float { return i < n ? src[i] : 0.0f; };
+  const int dst_row = blockIdx.y;
+  const int row = dst_row >> 1;
+  int index = row * w + col;
+  const int dst_idx = (w * dst_row + col) * 2;
+  const int helper = dst_row & 1;
+  if (helper) {
+    const float v11 = fetch(index), v12 = fetch(index + 1);
+    index += w;
+    const float v21 = fetch(index), v22 = fetch(index + 1);
+    const float w1 = 0.5f * helper, w2 = (float)(1.0 - (double)w1);
+    const float v1 = v21 * w1 + w2 * v11;
+    const float v2 = v22 * w1 + w2 * v12;
+    dst[dst_idx] = v1;
+    dst[dst_idx + 1] = v1 * 0.5f + v2 * 0.5f;
+  } else {
+    const float v1 = fetch(index), v2 = fetch(index + 1);
+    dst[dst_idx] = v1;
+    dst[dst_idx + 1] = v1 * 0.5f + v2 * 0.5f;
+  }
+}
+
+// DownsampleKernel<1> (ProgramCU.cu:283-294)
+__global__ __launch_bounds__(128) void sift_downsample2_kernel(const float* __restrict__ src, int src_w, int dst_w, int dst_h,
+                                                               float* __restrict__ dst) {
+  const int c = blockIdx.x * 128 + threadIdx.x;
+  if (c >= dst_w) return;
+  const int r = blockIdx.y;
+  const int sc = min(c << 1, src_w - 1);
+  dst[r * dst_w + c] = src[(size_t)(r << 1) * src_w + sc];
+}
+
+// One Gaussian level: FilterH then FilterV (ProgramCU.cu:113-218) in one launch.  A block owns a TW x TH output tile: it
+// stages the (TH + 2R) x (TW + 2R) source patch in LDS (rows / columns clamped to the image as the two reference kernels
+// clamp their fetches), filters it horizontally into a second LDS plane, then vertically into the output.  value starts
+// at 0 and the taps are added in ascending order, multiply and add unfused: the reference's sums, bit for bit.
+constexpr int TW = 64, TH = 16;
+__global__ __launch_bounds__(256) void sift_filter_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
+                                                          Taps taps) {
+  extern __shared__ float lds[];
+  const int fw = taps.fw, R = fw >> 1;
+  const int pw = TW + 2 * R, ph = TH + 2 * R;
+  float* patch = lds;              // ph x pw
+  float* hrow = lds + ph * pw;     // ph x TW
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ph * pw; i += 256) {
+    const int py = i / pw, px = i - py * pw;
+    int gy = y0 - R + py, gx = x0 - R + px;
+    gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+    patch[i] = src[(size_t)gy * w + gx];
+  }
+  __syncthreads();
+  for (int i = tid; i < ph * TW; i += 256) {
+    const int py = i / TW, px = i - py * TW;
+    const float* p = patch + py * pw + px;
+    float value = 0.f;
+    for (int t = 0; t < fw; ++t) value += p[t] * taps.k[t];
+    hrow[i] = value;
+  }
+  __syncthreads();
+  for (int i = tid; i < TH * TW; i += 256) {
+    const int ty = i / TW, tx = i - ty * TW;
+    const int gx = x0 + tx, gy = y0 + ty;
+    if (gx >= w || gy >= h) continue;
+    const float* p = hrow + ty * TW + tx;
+    float value = 0.f;
+    for (int t = 0; t < fw; ++t) value += p[t * TW] * taps.k[t];
+    dst[(size_t)gy * w + gx] = value;
+  }
+}
+
+// ---- extrema -----------------------------------------------------------------------------------------------------------
+struct KeyEval { float result, dx, dy, ds; };
+// ComputeKEY_Kernel (ProgramCU.cu:524-640) for one interior pixel; D[level] = G[level] - G[level - 1] taken from the
+// Gaussian planes g[0..3] = G[l-2], G[l-1], G[l], G[l+1] (ComputeDOG_Kernel's `v - vp`, :457-489).
+__device__ __forceinline__ KeyEval key_eval(const float* const g[4], int w, int index, float dog_threshold0, float dog_threshold,
+                                            float edge_threshold) {
+  KeyEval out{0.f, 0.f, 0.f, 0.f};
+  auto dogc = [&](int i) -> float { return g[2][i] - g[1][i]; };
+  auto dogp = [&](int i) -> float { return g[1][i] - g[0][i]; };
+  auto dogn = [&](int i) -> float { return g[3][i] - g[2][i]; };
+  float data[3][3], datap[3][3], datan[3][3];
+  const int idx[3] = {index - w, index, index + w};
+  float nmax, nmin;
+  const float v = dogc(idx[1]);
+  data[1][1] = v;
+  if (fabsf(v) <= dog_threshold0) return out;
+  data[1][0] = dogc(idx[1] - 1);
+  data[1][2] = dogc(idx[1] + 1);
+  nmax = fmaxf(data[1][0], data[1][2]);
+  nmin = fminf(data[1][0], data[1][2]);
+  if (v <= nmax && v >= nmin) return out;
+#define SIFT_READ_CMP(datai, F, ix)                 \
+  datai[0] = F((ix) - 1);                           \
+  datai[1] = F(ix);                                 \
+  datai[2] = F((ix) + 1);                           \
+  if (v > nmax) {                                   \
+    nmax = fmaxf(nmax, datai[0]);                   \
+    nmax = fmaxf(nmax, datai[1]);                   \
+    nmax = fmaxf(nmax, datai[2]);                   \
+    if (v < nmax) return out;                       \
+  } else {                                          \
+    nmin = fminf(nmin, datai[0]);                   \
+    nmin = fminf(nmin, datai[1]);                   \
+    nmin = fminf(nmin, datai[2]);                   \
+    if (v > nmin) return out;                       \
+  }
+  SIFT_READ_CMP(data[0], dogc, idx[0]);
+  SIFT_READ_CMP(data[2], dogc, idx[2]);
+  // edge suppression
+  const float vx2 = v * 2.0f;
+  const float fxx = data[1][0] + data[1][2] - vx2;
+  const float fyy = data[0][1] + data[2][1] - vx2;
+  const float fxy = 0.25f * (data[2][2] + data[0][0] - data[2][0] - data[0][2]);
+  const float temp1 = fxx * fyy - fxy * fxy;
+  const float temp2 = (fxx + fyy) * (fxx + fyy);
+  if (temp1 <= 0 || temp2 > edge_threshold * temp1) return out;
+  SIFT_READ_CMP(datap[0], dogp, idx[0]);
+  SIFT_READ_CMP(datap[1], dogp, idx[1]);
+  SIFT_READ_CMP(datap[2], dogp, idx[2]);
+  SIFT_READ_CMP(datan[0], dogn, idx[0]);
+  SIFT_READ_CMP(datan[1], dogn, idx[1]);
+  SIFT_READ_CMP(datan[2], dogn, idx[2]);
+#undef SIFT_READ_CMP
+  bool offset_test_passed = true;
+  float dx = 0, dy = 0, ds = 0;
+  {  // sub-pixel localisation ("-s 1"): Gaussian elimination with the reference's pivoting
+    const float fx = 0.5f * (data[1][2] - data[1][0]);
+    const float fy = 0.5f * (data[2][1] - data[0][1]);
+    const float fs = 0.5f * (datan[1][1] - datap[1][1]);
+    const float fss = (datan[1][1] + datap[1][1] - vx2);
+    const float fxs = 0.25f * (datan[1][2] + datap[1][0] - datan[1][0] - datap[1][2]);
+    const float fys = 0.25f * (datan[2][1] + datap[0][1] - datan[0][1] - datap[2][1]);
+    float4 A0 = fxx > 0 ? make_float4(fxx, fxy, fxs, -fx) : make_float4(-fxx, -fxy, -fxs, fx);
+    float4 A1 = fxy > 0 ? make_float4(fxy, fyy, fys, -fy) : make_float4(-fxy, -fyy, -fys, fy);
+    float4 A2 = fxs > 0 ? make_float4(fxs, fys, fss, -fs) : make_float4(-fxs, -fys, -fss, fs);
+    const float maxa = fmaxf(fmaxf(A0.x, A1.x), A2.x);
+    if (maxa >= 1e-10) {
+      if (maxa == A1.x) { const float4 t = A1; A1 = A0; A0 = t; }
+      else if (maxa == A2.x) { const float4 t = A2; A2 = A0; A0 = t; }
+      A0.y /= A0.x; A0.z /= A0.x; A0.w /= A0.x;
+      A1.y -= A1.x * A0.y; A1.z -= A1.x * A0.z; A1.w -= A1.x * A0.w;
+      A2.y -= A2.x * A0.y; A2.z -= A2.x * A0.z; A2.w -= A2.x * A0.w;
+      if (fabsf(A2.y) > fabsf(A1.y)) { const float4 t = A2; A2 = A1; A1 = t; }
+      if (fabsf(A1.y) >= 1e-10) {
+        A1.z /= A1.y; A1.w /= A1.y;
+        A2.z -= A2.y * A1.z; A2.w -= A2.y * A1.w;
+        if (fabsf(A2.z) >= 1e-10) {
+          ds = A2.w / A2.z;
+          dy = A1.w - ds * A1.z;
+          dx = A0.w - ds * A0.z - dy * A0.y;
+          offset_test_passed = fabsf(data[1][1] + 0.5f * (dx * fx + dy * fy + ds * fs)) > dog_threshold &&
+                               fabsf(ds) < 1.0f && fabsf(dx) < 1.0f && fabsf(dy) < 1.0f;
+        }
+      }
+    }
+  }
+  if (offset_test_passed) out.result = v > nmax ? 1.0f : -1.0f;
+  out.dx = dx; out.dy = dy; out.ds = ds;
+  return out;
+}
+
+// one wave per 64 consecutive columns of one row of one (octave, dog level): a flag byte per pixel + the row's count.
+// Counted = what InitHist_Kernel (ProgramCU.cu:665-688) counts: rows 1 .. h-2, columns 1 .. w-2 with a non-zero key.
+__global__ __launch_bounds__(64) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                           const int* __restrict__ row2lvl, int* __restrict__ rowcnt,
+                                                           float dog_threshold0, float dog_threshold, float edge_threshold) {
+  const int grow = blockIdx.y;
+  const int lvl = row2lvl[grow];
+  const SiftExtractor::LevelDesc L = levels[lvl];
+  const int row = grow - L.row0;
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (blockIdx.x * 64 >= L.w) return;
+  int8_t flag = 0;
+  if (col < L.w && row > 0 && col > 0 && row < L.h - 1 && col < L.w - 1) {
+    const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
+    flag = e.result > 0.f ? 1 : (e.result < 0.f ? -1 : 0);
+  }
+  if (col < L.w) L.flags[(size_t)row * L.w + col] = flag;
+  const uint64_t m = __ballot(flag != 0);
+  if (threadIdx.x == 0 && m) atomicAdd(&rowcnt[grow], (int)__popcll(m));
+}
+
+// per level: exclusive scan of its rows' counts, the level's total
+__global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                           const int* __restrict__ rowcnt, int* __restrict__ rowoff,
+                                                           int* __restrict__ lvltot) {
+  const SiftExtractor::LevelDesc L = levels[blockIdx.x];
+  int base = 0;
+  for (int r0 = 0; r0 < L.h; r0 += 64) {
+    const int r = r0 + (int)threadIdx.x;
+    const int c = r < L.h ? rowcnt[L.row0 + r] : 0;
+    int incl = c;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if ((int)threadIdx.x >= d) incl += o;
+    }
+    if (r < L.h) rowoff[L.row0 + r] = base + incl - c;
+    base += __shfl(incl, 63);
+  }
+  if (threadIdx.x == 0) lvltot[blockIdx.x] = base;
+}
+
+// one wave per row: the row's extrema in column order -> the level's candidate list (x, y, sign, dx, dy, ds)
+__global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                           const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
+                                                           const int* __restrict__ rowoff, const int* __restrict__ lvltot,
+                                                           float* __restrict__ cand, int cand_cap, float dog_threshold0,
+                                                           float dog_threshold, float edge_threshold) {
+  const int grow = blockIdx.x;
+  if (rowcnt[grow] == 0) return;
+  const int lvl = row2lvl[grow];
+  const SiftExtractor::LevelDesc L = levels[lvl];
+  const int row = grow - L.row0;
+  int base = rowoff[grow];
+  for (int l = 0; l < lvl; ++l) base += lvltot[l];
+  for (int c0 = 0; c0 < L.w; c0 += 64) {
+    const int col = c0 + (int)threadIdx.x;
+    const bool on = col < L.w && L.flags[(size_t)row * L.w + col] != 0;
+    const uint64_t m = __ballot(on);
+    if (on) {
+      const int rank = base + (int)__popcll(m & (((uint64_t)1 << threadIdx.x) - 1));
+      if (rank < cand_cap) {
+        const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
+        float* o = cand + (size_t)rank * 6;
+        o[0] = (float)col; o[1] = (float)row; o[2] = e.result; o[3] = e.dx; o[4] = e.dy; o[5] = e.ds;
+      }
+    }
+    base += (int)__popcll(m);
+  }
+}
+
+// ---- gradient of a Gaussian plane at an interior pixel (ComputeDOG_Kernel, ProgramCU.cu:466-473) -------------------------------
+__device__ __forceinline__ float2 grad_at(const float* __restrict__ G, int w, int px, int py) {
+  const int index = py * w + px;
+  const float vxn = G[index + 1], vxp = G[index - 1], vyp = G[index - w], vyn = G[index + w];
+  const float dx = vxn - vxp, dy = vyn - vyp;
+  const float grd = 0.5f * sqrtf(dx * dx + dy * dy);
+  const float rot = (grd == 0.0f ? 0.0f : atan2f(dy, dx));
+  return make_float2(grd, rot);
+}
+
+struct LevelJobs {  // the kept levels of a frame: consecutive segments of the work list
+  int n;
+  int begin[65];      // first work item of the segment (begin[n] = total); kMaxOctaves * kDogLevels = 60 segments at most
+  int src_off[64];    // candidate / feature offset of the segment's first item
+  const float* g[64]; // the Gaussian plane gradients are taken from (G[j + 1] of the level's octave)
+  int w[64], h[64];
+  float sigma[64];
+};
+
+// ComputeOrientation_Kernel (ProgramCU.cu:774-935), num_orientation = 2, sub-pixel on, no existing keypoints: one thread
+// per candidate, the sample loop in the reference's order.
+__global__ __launch_bounds__(64) void sift_orientation_kernel(LevelJobs jobs, const float* __restrict__ cand,
+                                                              float4* __restrict__ feat, float sigma_step,
+                                                              float gaussian_factor, float sample_factor) {
+  const float ten_degree_per_radius = 5.7295779513082320876798154814105;
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= jobs.begin[jobs.n]) return;
+  int s = 0;
+  while (s + 1 < jobs.n && idx >= jobs.begin[s + 1]) ++s;
+  const int k = idx - jobs.begin[s];
+  const float* c = cand + (size_t)(jobs.src_off[s] + k) * 6;
+  const int width = jobs.w[s], height = jobs.h[s];
+  const float* __restrict__ G = jobs.g[s];
+  float4 key;
+  key.x = c[0] + 0.5f;
+  key.y = c[1] + 0.5f;
+  key.z = jobs.sigma[s];
+  key.x += c[3];
+  key.y += c[4];
+  key.z *= powf(sigma_step, c[5]);
+  float vote[37];
+  const float gsigma = key.z * gaussian_factor;
+  const float win = fabsf(key.z) * sample_factor;
+  const float dist_threshold = (float)((double)(win * win) + 0.5);
+  const float factor = -0.5f / (gsigma * gsigma);
+  const float xmin = fmaxf(1.5f, floorf(key.x - win) + 0.5f);
+  const float ymin = fmaxf(1.5f, floorf(key.y - win) + 0.5f);
+  const float xmax = fminf(width - 1.5f, floorf(key.x + win) + 0.5f);
+  const float ymax = fminf(height - 1.5f, floorf(key.y + win) + 0.5f);
+  for (int i = 0; i < 36; ++i) vote[i] = 0.0f;
+  for (float y = ymin; y <= ymax; y += 1.0f) {
+    for (float x = xmin; x <= xmax; x += 1.0f) {
+      const float dx = x - key.x;
+      const float dy = y - key.y;
+      const float sq_dist = dx * dx + dy * dy;
+      if (sq_dist >= dist_threshold) continue;
+      const float2 got = grad_at(G, width, (int)floorf(x), (int)floorf(y));
+      const float weight = got.x * expf(sq_dist * factor);
+      const float fidx = floorf(got.y * ten_degree_per_radius);
+      int oidx = (int)fidx;
+      if (oidx < 0) oidx += 36;
+      vote[oidx] += weight;
+    }
+  }
+  const float one_third = 1.0 / 3.0;
+  for (int i = 0; i < 6; ++i) {
+    vote[36] = vote[0];
+    float pre = vote[35];
+    for (int j = 0; j < 36; ++j) {
+      const float temp = one_third * (pre + vote[j] + vote[j + 1]);
+      pre = vote[j];
+      vote[j] = temp;
+    }
+  }
+  vote[36] = vote[0];
+  float max_vote = vote[0];
+  for (int i = 1; i < 36; ++i) max_vote = fmaxf(max_vote, vote[i]);
+  const float vote_threshold = max_vote * 0.8f;
+  float pre = vote[35];
+  float max_rot[2] = {0.f, 0.f}, max_vot[2] = {0.f, 0.f};
+  int ocount = 0;
+  for (int i = 0; i < 36; ++i) {
+    const float next = vote[i + 1];
+    if (vote[i] > vote_threshold && vote[i] > pre && vote[i] > next) {
+      const float di = 0.5f * ((next - pre) / (vote[i] + vote[i] - next - pre));
+      const float rot = i + di + 0.5f;
+      const float weight = vote[i];
+      if (weight > max_vot[1]) {
+        if (weight > max_vot[0]) {
+          max_vot[1] = max_vot[0]; max_rot[1] = max_rot[0];
+          max_vot[0] = weight; max_rot[0] = rot;
+        } else {
+          max_vot[1] = weight; max_rot[1] = rot;
+        }
+        ocount++;
+      }
+    }
+    pre = vote[i];
+  }
+  float fr1 = max_rot[0] / 36.0f;
+  if (fr1 < 0) fr1 += 1.0f;
+  const unsigned short us1 = ocount == 0 ? 65535 : ((unsigned short)floorf(fr1 * 65535.0f));
+  unsigned short us2 = 65535;
+  if (ocount > 1) {
+    float fr2 = max_rot[1] / 36.0f;
+    if (fr2 < 0) fr2 += 1.0f;
+    us2 = (unsigned short)floorf(fr2 * 65535.0f);
+  }
+  const unsigned int uspack = ((unsigned int)us2 << 16) | us1;
+  key.w = __uint_as_float(uspack);
+  feat[idx] = key;
+}
+
+// ComputeDescriptor_Kernel<false> (ProgramCU.cu:967-1046): 16 threads per feature, one 4x4 cell each
+__global__ __launch_bounds__(64) void sift_descriptor_kernel(LevelJobs jobs, const float4* __restrict__ feat,
+                                                             float4* __restrict__ d_des, float window_factor) {
+  const float rpi = 4.0 / 3.14159265358979323846;
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  const int fidx = idx >> 4;
+  if (fidx >= jobs.begin[jobs.n]) return;
+  int s = 0;
+  while (s + 1 < jobs.n && fidx >= jobs.begin[s + 1]) ++s;
+  const int width = jobs.w[s], height = jobs.h[s];
+  const float* __restrict__ G = jobs.g[s];
+  const float4 key = feat[fidx];
+  const int bidx = idx & 0xf, ix = bidx & 0x3, iy = bidx >> 2;
+  const float spt = fabsf(key.z * window_factor);
+  float sn, cs;
+  sincosf(key.w, &sn, &cs);
+  const float anglef = key.w > 3.14159265358979323846 ? (float)((double)key.w - (2.0 * 3.14159265358979323846)) : key.w;
+  const float cspt = cs * spt, sspt = sn * spt;
+  const float crspt = cs / spt, srspt = sn / spt;
+  float2 offsetpt, pt;
+  offsetpt.x = ix - 1.5f;
+  offsetpt.y = iy - 1.5f;
+  pt.x = cspt * offsetpt.x - sspt * offsetpt.y + key.x;
+  pt.y = cspt * offsetpt.y + sspt * offsetpt.x + key.y;
+  const float bsz = fabsf(cspt) + fabsf(sspt);
+  const float xmin = fmaxf(1.5f, floorf(pt.x - bsz) + 0.5f);
+  const float ymin = fmaxf(1.5f, floorf(pt.y - bsz) + 0.5f);
+  const float xmax = fminf(width - 1.5f, floorf(pt.x + bsz) + 0.5f);
+  const float ymax = fminf(height - 1.5f, floorf(pt.y + bsz) + 0.5f);
+  float des[9];
+  for (int i = 0; i < 9; ++i) des[i] = 0.0f;
+  for (float y = ymin; y <= ymax; y += 1.0f) {
+    for (float x = xmin; x <= xmax; x += 1.0f) {
+      const float dx = x - pt.x;
+      const float dy = y - pt.y;
+      const float nx = crspt * dx + srspt * dy;
+      const float ny = crspt * dy - srspt * dx;
+      const float nxn = fabsf(nx);
+      const float nyn = fabsf(ny);
+      if (nxn < 1.0f && nyn < 1.0f) {
+        const float2 cc = grad_at(G, width, (int)floorf(x), (int)floorf(y));
+        const float dnx = nx + offsetpt.x;
+        const float dny = ny + offsetpt.y;
+        const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
+        const float wx = (float)(1.0 - (double)nxn);
+        const float wy = (float)(1.0 - (double)nyn);
+        const float weight = ww * wx * wy * cc.x;
+        float theta = (anglef - cc.y) * rpi;
+        if (theta < 0) theta += 8.0f;
+        const float fo = floorf(theta);
+        const int fi = (int)fo;
+        const float weight1 = fo + 1.0f - theta;
+        const float weight2 = theta - fo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (k == fi) {
+            des[k] += (weight1 * weight);
+            des[k + 1] += (weight2 * weight);
+          }
+        }
+      }
+    }
+  }
+  des[0] += des[8];
+  const int didx = idx << 1;
+  d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
+  d_des[didx + 1] = make_float4(des[4], des[5], des[6], des[7]);
+}
+
+#define SIFT_HIP(expr)                                                                    \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return RGBDFE_ERR_HIP; } \
+  } while (0)
+
+// ProgramCU::CreateFilterKernel (ProgramCU.cu:370-398), _FilterWidthFactor = 4
+Taps make_taps(float sigma) {
+  Taps t{};
+  int i, sz = int(ceil(4.0f * sigma - 0.5));
+  int width = 2 * sz + 1;
+  if (width > kMaxTaps) { sz = kMaxTaps >> 1; width = kMaxTaps; }
+  else if (width < 5) { sz = 5 >> 1; width = 5; }
+  float rv = 1.0f / (sigma * sigma), v, ksum = 0;
+  for (i = -sz; i <= sz; ++i) {
+    t.k[i + sz] = v = expf(-0.5f * i * i * rv);
+    ksum += v;
+  }
+  rv = 1.0f / ksum;
+  for (i = 0; i < width; i++) t.k[i] *= rv;
+  t.fw = width;
+  return t;
+}
+
+}  // namespace
+
+SiftExtractor::~SiftExtractor() { release(); }
+
+void SiftExtractor::release() {
+  if (d_gray) (void)hipFree(d_gray);
+  if (d_input) (void)hipFree(d_input);
+  if (d_up) (void)hipFree(d_up);
+  if (d_planes) (void)hipFree(d_planes);
+  if (d_flags) (void)hipFree(d_flags);
+  if (d_rowcnt) (void)hipFree(d_rowcnt);
+  if (d_levels) (void)hipFree(d_levels);
+  if (d_cand) (void)hipFree(d_cand);
+  if (d_feat) (void)hipFree(d_feat);
+  if (d_desc) (void)hipFree(d_desc);
+  if (h_counts) (void)hipHostFree(h_counts);
+  if (h_stage) (void)hipHostFree(h_stage);
+  if (h_gray) (void)hipHostFree(h_gray);
+  d_gray = nullptr; d_input = d_up = d_planes = nullptr; d_flags = nullptr; d_rowcnt = d_rowoff = d_lvltot = nullptr;
+  d_levels = nullptr; d_cand = nullptr; d_feat = nullptr; d_desc = nullptr; h_counts = nullptr; h_stage = nullptr;
+  h_gray = nullptr; gray_cap = 0; stage_floats = 0; cand_cap = feat_cap = desc_cap = 0; W = H = 0;
+}
+
+void SiftExtractor::init_params() {  // SiftParam::ParseSiftParam (SiftGPU.cpp:433-473) with "-d 5 -e 10.0"
+  if (params_ready) return;
+  const int dog_level_num = kDogLevels, level_min = -1, level_max = kDogLevels + 1;
+  sigma0 = 1.6f * powf(2.0f, 1.0f / dog_level_num);
+  sigmak = powf(2.0f, 1.0f / dog_level_num);
+  dsigma0 = sigma0 * sqrtf(1.0f - 1.0f / (sigmak * sigmak));
+  for (int i = level_min + 1; i <= level_max; i++) sigma[i - level_min - 1] = dsigma0 * powf(sigmak, float(i));
+  dog_threshold = 0.02f / dog_level_num;
+  edge_threshold = 10.0f;
+  params_ready = true;
+}
+
+float SiftExtractor::initial_smooth_sigma(int om) const {
+  const float sa = sigma0 * powf(2.0f, float(-1) / float(kDogLevels));
+  const float sb = 0.5f / powf(2.0f, float(om));
+  return sa > sb + 0.001 ? sqrtf(sa * sa - sb * sb) : 0.0f;
+}
+
+float SiftExtractor::level_sigma(int lev) const { return sigma0 * powf(2.0f, float(lev) / float(kDogLevels)); }
+
+// PyramidCU::InitPyramid / ResizePyramid / FitPyramid (PyramidCU.cpp:86-306): the geometry a frame of this size gets
+int SiftExtractor::prepare(int rows, int cols, std::string& err) {
+  init_params();
+  if (rows == H && cols == W && d_planes) return RGBDFE_OK;
+  const int tw = cols & 0xfffffffc;  // GLTexInput::TruncateWidthCU (GLTexImage.h:125)
+  if (tw < 16 || rows < 16) { err = "image too small for SIFT extraction"; return RGBDFE_ERR_INVALID_ARG; }
+  int om = -1;  // "-fo -1"
+  int wp = tw << 1, hp = rows << 1;
+  while (wp > 3200 || hp > 3200) { om++; wp >>= 1; hp >>= 1; }  // GlobalUtil::_texMaxDim (GlobalUtil.cpp:86)
+  if (om > 0) { err = "images beyond 3200 x 3200 pixels are not supported"; return RGBDFE_ERR_CAPACITY; }
+  int on = (int)floor(log(double(std::min(wp, hp))) / log(2.0)) - 3;
+  if (on < 1) on = 1;
+  if (on > kMaxOctaves) on = kMaxOctaves;
+  release();
+  W = cols; H = rows; w4 = tw; octave_min = om; octave_num = on;
+  size_t total = 0;
+  int w = wp, h = hp;
+  total_rows = 0;
+  for (int i = 0; i < on; ++i) {
+    oct[i].w = ((w + 3) / 4) * 4;
+    oct[i].h = h;
+    oct[i].plane = (size_t)oct[i].w * h;
+    total += oct[i].plane * kLevels;
+    total_rows += h * kDogLevels;
+    w >>= 1; h >>= 1;
+  }
+  planes_floats = total;
+  SIFT_HIP(hipMalloc((void**)&d_gray, (size_t)rows * cols));
+  SIFT_HIP(hipMalloc((void**)&d_input, (size_t)tw * rows * 4));
+  SIFT_HIP(hipMalloc((void**)&d_up, oct[0].plane * 4));
+  SIFT_HIP(hipMalloc((void**)&d_planes, total * 4));
+  size_t off = 0, foff = 0;
+  for (int i = 0; i < on; ++i)
+    for (int l = 0; l < kLevels; ++l) { oct[i].g[l] = d_planes + off; off += oct[i].plane; }
+  for (int i = 0; i < on; ++i) foff += oct[i].plane * kDogLevels;
+  flags_bytes = foff;
+  SIFT_HIP(hipMalloc((void**)&d_flags, flags_bytes));
+  // rowcnt | rowoff | row2lvl | lvltot
+  SIFT_HIP(hipMalloc((void**)&d_rowcnt, sizeof(int) * ((size_t)total_rows * 3 + 64)));
+  d_rowoff = d_rowcnt + total_rows;
+  d_lvltot = d_rowcnt + (size_t)total_rows * 3;
+  h_levels.assign((size_t)on * kDogLevels, LevelDesc{});
+  std::vector<int> row2lvl((size_t)total_rows);
+  int row0 = 0;
+  foff = 0;
+  for (int i = 0; i < on; ++i)
+    for (int j = 0; j < kDogLevels; ++j) {
+      LevelDesc& L = h_levels[(size_t)i * kDogLevels + j];
+      const int l = j + 2;  // key level: DoG l - 1, l, l + 1 = Gaussian l - 2 .. l + 1
+      for (int k = 0; k < 4; ++k) L.g[k] = oct[i].g[l - 2 + k];
+      L.flags = d_flags + foff;
+      L.w = oct[i].w; L.h = oct[i].h; L.row0 = row0;
+      for (int r = 0; r < oct[i].h; ++r) row2lvl[(size_t)row0 + r] = i * kDogLevels + j;
+      row0 += oct[i].h;
+      foff += oct[i].plane;
+    }
+  SIFT_HIP(hipMalloc((void**)&d_levels, sizeof(LevelDesc) * h_levels.size()));
+  SIFT_HIP(hipMemcpy(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice));
+  SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2, row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
+  cand_cap = std::max<size_t>((size_t)1 << 16, oct[0].plane / 16);
+  SIFT_HIP(hipMalloc((void**)&d_cand, cand_cap * 6 * 4));
+  feat_cap = cand_cap * 2;
+  SIFT_HIP(hipMalloc((void**)&d_feat, feat_cap * 16));
+  SIFT_HIP(hipHostMalloc((void**)&h_counts, sizeof(int) * 64, hipHostMallocDefault));
+  stage_floats = cand_cap * 8;
+  SIFT_HIP(hipHostMalloc((void**)&h_stage, stage_floats * 4, hipHostMallocDefault));
+  gray_cap = (size_t)rows * cols;
+  SIFT_HIP(hipHostMalloc((void**)&h_gray, gray_cap, hipHostMallocDefault));
+  return RGBDFE_OK;
+}
+
+int SiftExtractor::run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys,
+                       std::vector<float>& desc, hipStream_t s, std::string& err) {
+  keys.clear();
+  desc.clear();
+  int rc = prepare(rows, cols, err);
+  if (rc != RGBDFE_OK) return rc;
+  const int nlv = octave_num * kDogLevels;
+  // ---- image in (GLTexInput::SetImageData, CUDA branch, GLTexImage.cpp:971-1009) + BuildPyramid (PyramidCU.cpp:946-998) ----
+  memcpy(h_gray, gray, (size_t)rows * cols);
+  SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)rows * cols, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
+  auto filter = [&](const float* src, float* dst, int w, int h, float sg) {
+    const Taps t = make_taps(sg);
+    const int R = t.fw >> 1;
+    const size_t lds = sizeof(float) * ((size_t)(TH + 2 * R) * (TW + 2 * R) + (size_t)(TH + 2 * R) * TW);
+    hipLaunchKernelGGL(sift_filter_kernel, dim3((w + TW - 1) / TW, (h + TH - 1) / TH), dim3(256), lds, s, src, dst, w, h, t);
+  };
+  for (int i = 0; i < octave_num; ++i) {
+    const Octave& o = oct[i];
+    if (i == 0) {
+      const float sg = initial_smooth_sigma(octave_min);
+      if (octave_min < 0) {  // SampleImageU + FilterImage in place through the buffer plane
+        hipLaunchKernelGGL(sift_upsample2_kernel, dim3((w4 + 127) / 128, rows << 1), dim3(128), 0, s, d_input, w4, rows, d_up);
+        filter(d_up, o.g[0], o.w, o.h, sg);
+      } else {
+        filter(d_input, o.g[0], o.w, o.h, sg);
+      }
+    } else {  // SampleImageD from level_ds of the octave below (index level_ds - level_min = 5); sigma_skip1 = 0
+      const Octave& p = oct[i - 1];
+      hipLaunchKernelGGL(sift_downsample2_kernel, dim3((o.w + 127) / 128, o.h), dim3(128), 0, s, p.g[kDogLevels], p.w, o.w, o.h,
+                         o.g[0]);
+    }
+    for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], o.g[l], o.w, o.h, sigma[l - 1]);
+  }
+  // ---- DetectKeypointsEX + the list part of GenerateFeatureList: flags, row counts, scan, ordered emit ----------------------
+  const float tdog = dog_threshold, tdog1 = 0.8f * tdog;
+  const float tedge = (edge_threshold + 1) * (edge_threshold + 1) / edge_threshold;
+  int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2;
+  SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows, s));
+  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, total_rows), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt,
+                     tdog1, tdog, tedge);
+  hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot);
+  hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
+                     d_cand, (int)cand_cap, tdog1, tdog, tedge);
+  SIFT_HIP(hipGetLastError());
+  SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * (size_t)nlv, hipMemcpyDeviceToHost, s));
+  SIFT_HIP(hipStreamSynchronize(s));
+  lvl_count.assign(h_counts, h_counts + nlv);
+  lvl_off.assign((size_t)nlv + 1, 0);
+  for (int i = 0; i < nlv; ++i) lvl_off[(size_t)i + 1] = lvl_off[(size_t)i] + lvl_count[(size_t)i];
+  if ((size_t)lvl_off[(size_t)nlv] > cand_cap) { err = "more SIFT keypoint candidates than the candidate buffer holds"; return RGBDFE_ERR_CAPACITY; }
+  // ---- which levels run: GenerateFeatureList's "-tc2" order (coarse octaves first, PyramidCU.cpp:797-850) and
+  //      SiftPyramid::LimitFeatureCount(0) (SiftPyramid.cpp:170-210, _TruncateMethod = 1).  A skipped level contributes
+  //      nothing (the reference leaves the previous frame's list in it: DESIGN.md 4.11) ---------------------------------
+  std::vector<int> level_num((size_t)nlv, 0);
+  int feature_num = 0;
+  for (int i = octave_num - 1; i >= 0; --i)
+    for (int j = kDogLevels - 1; j >= 0; --j) {
+      if (max_features > 0 && feature_num > max_features) continue;
+      level_num[(size_t)i * kDogLevels + j] = lvl_count[(size_t)i * kDogLevels + j];
+      feature_num += lvl_count[(size_t)i * kDogLevels + j];
+    }
+  auto limit = [&]() {
+    if (max_features <= 0) return 0;
+    int i = 0, erased = 0;
+    while (i < nlv && feature_num - level_num[(size_t)i] > max_features) {
+      erased += level_num[(size_t)i];
+      feature_num -= level_num[(size_t)i];
+      level_num[(size_t)i++] = 0;
+    }
+    return erased;
+  };
+  limit();
+  if (feature_num == 0) return RGBDFE_OK;
+  // ---- GetFeatureOrientations (PyramidCU.cpp:1145-1172) --------------------------------------------------------------------
+  LevelJobs jobs{};
+  int total = 0;
+  for (int idx = 0; idx < nlv; ++idx) {
+    if (level_num[(size_t)idx] <= 0) continue;
+    const int i = idx / kDogLevels, j = idx % kDogLevels;
+    const int n = jobs.n++;
+    jobs.begin[n] = total;
+    jobs.src_off[n] = lvl_off[(size_t)idx];
+    jobs.g[n] = oct[i].g[j + 1];
+    jobs.w[n] = oct[i].w; jobs.h[n] = oct[i].h;
+    jobs.sigma[n] = level_sigma(j);  // GetLevelSigma(j + level_min + 1)
+    total += level_num[(size_t)idx];
+  }
+  jobs.begin[jobs.n] = total;
+  const float sigma_step = powf(2.0f, 1.0f / kDogLevels);
+  hipLaunchKernelGGL(sift_orientation_kernel, dim3((total + 63) / 64), dim3(64), 0, s, jobs, d_cand, d_feat, sigma_step, 1.5f,
+                     1.5f * 2.0f);
+  SIFT_HIP(hipGetLastError());
+  if ((size_t)total * 4 > stage_floats) { err = "SIFT staging buffer too small"; return RGBDFE_ERR_CAPACITY; }
+  SIFT_HIP(hipMemcpyAsync(h_stage, d_feat, (size_t)total * 16, hipMemcpyDeviceToHost, s));
+  SIFT_HIP(hipStreamSynchronize(s));
+  // ---- ReshapeFeatureListCPU (PyramidCU.cpp:501-585, NO_DUPLICATE_DOWNLOAD) + LimitFeatureCount(1) -----------------------------
+  const double twopi = 2.0 * 3.14159265358979323846;
+  const double factor = 2.0 * 3.14159265358979323846 / 65535.0;
+  const float os = octave_min >= 0 ? float(1 << octave_min) : 1.0f / (1 << (-octave_min));
+  std::vector<float> list;            // final feature list in level coordinates (x, y, scale, orientation)
+  std::vector<float> keybuf;          // image coordinates
+  list.reserve((size_t)total * 8);
+  keybuf.reserve((size_t)total * 8);
+  feature_num = 0;
+  {
+    int seg = 0;
+    for (int idx = 0; idx < nlv; ++idx) {
+      if (level_num[(size_t)idx] <= 0) continue;
+      const float* src = h_stage + (size_t)jobs.begin[seg] * 4;
+      const int cnt = level_num[(size_t)idx];
+      int fcount = 0;
+      const float oss = os * (1 << (idx / kDogLevels));
+      for (int k = 0; k < cnt; ++k, src += 4) {
+        unsigned short orientations[2];
+        memcpy(orientations, &src[3], 4);
+        auto push = [&](unsigned short o) {
+          const float fo = float(factor * o);
+          list.push_back(src[0]); list.push_back(src[1]); list.push_back(src[2]); list.push_back(fo);
+          keybuf.push_back(oss * (src[0] - 0.5f) + 0.5f);
+          keybuf.push_back(oss * (src[1] - 0.5f) + 0.5f);
+          keybuf.push_back(oss * src[2]);
+          keybuf.push_back((float)fmod(twopi - fo, twopi));
+          fcount++;
+        };
+        if (orientations[0] != 65535) {
+          push(orientations[0]);
+          if (orientations[1] != 65535 && orientations[1] != orientations[0]) push(orientations[1]);
+        }
+      }
+      level_num[(size_t)idx] = fcount;
+      feature_num += fcount;
+      ++seg;
+    }
+  }
+  const int erased = limit();
+  if (feature_num == 0) return RGBDFE_OK;
+  // ---- GetFeatureDescriptors (PyramidCU.cpp:393-432) ---------------------------------------------------------------------------
+  LevelJobs dj{};
+  total = 0;
+  for (int idx = 0; idx < nlv; ++idx) {
+    if (level_num[(size_t)idx] <= 0) continue;
+    const int i = idx / kDogLevels, j = idx % kDogLevels;
+    const int n = dj.n++;
+    dj.begin[n] = total;
+    dj.g[n] = oct[i].g[j + 1];
+    dj.w[n] = oct[i].w; dj.h[n] = oct[i].h;
+    total += level_num[(size_t)idx];
+  }
+  dj.begin[dj.n] = total;
+  if ((size_t)total > feat_cap) { err = "more SIFT features than the feature buffer holds"; return RGBDFE_ERR_CAPACITY; }
+  if ((size_t)total * 128 > desc_cap) {
+    if (d_desc) (void)hipFree(d_desc);
+    d_desc = nullptr; desc_cap = 0;
+    SIFT_HIP(hipMalloc((void**)&d_desc, (size_t)total * 128 * 4 * 2));
+    desc_cap = (size_t)total * 128 * 2;
+  }
+  memcpy(h_stage, list.data() + (size_t)erased * 4, (size_t)total * 16);
+  SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)total * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(sift_descriptor_kernel, dim3((total * 16 + 63) / 64), dim3(64), 0, s, dj, d_feat, (float4*)d_desc, 3.0f);
+  SIFT_HIP(hipGetLastError());
+  desc.resize((size_t)total * 128);
+  SIFT_HIP(hipMemcpyAsync(desc.data(), d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));
+  SIFT_HIP(hipStreamSynchronize(s));
+  keys.resize((size_t)total);
+  memcpy(keys.data(), keybuf.data() + (size_t)erased * 4, (size_t)total * 16);
+  return RGBDFE_OK;
+}
+
+int SiftExtractor::debug_plane(int octave, int level, std::vector<float>& out, int* w, int* h, hipStream_t s) {
+  if (octave < 0 || octave >= octave_num || level < 0 || level >= kLevels || !d_planes) return RGBDFE_ERR_INVALID_ARG;
+  out.resize(oct[octave].plane);
+  *w = oct[octave].w; *h = oct[octave].h;
+  if (hipMemcpyAsync(out.data(), oct[octave].g[level], oct[octave].plane * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return RGBDFE_ERR_HIP;
+  return RGBDFE_OK;
+}
+
+int SiftExtractor::debug_candidates(int octave, int dog_level, std::vector<float>& out) {
+  if (octave < 0 || octave >= octave_num || dog_level < 0 || dog_level >= kDogLevels || lvl_count.empty())
+    return RGBDFE_ERR_INVALID_ARG;
+  const int idx = octave * kDogLevels + dog_level;
+  out.resize((size_t)lvl_count[(size_t)idx] * 6);
+  if (!out.empty() &&
+      hipMemcpy(out.data(), d_cand + (size_t)lvl_off[(size_t)idx] * 6, out.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return RGBDFE_ERR_HIP;
+  return RGBDFE_OK;
+}
+
+}  // namespace rgbdfe

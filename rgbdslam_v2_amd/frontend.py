@@ -371,6 +371,45 @@ class FrontEnd:
         return kp[: n.value].copy(), desc[: n.value].copy()
 
     # -- SIFT (128-d float descriptors, matcher_type == SIFTGPU) ---------------------------
+    def sift_detect(self, gray, mask=None, max_keypoints: int = 1000):
+        """SiftGPUWrapper::detect (sift_gpu_wrapper.cpp:113-167): (keypoints KEYPOINT_DTYPE [n], descriptors [n, 128] f32,
+        unnormalised) of a mono8 image.  `mask` is ignored, as in the reference."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        rows, cols = gray.shape
+        cap = max(2 * max_keypoints + 4096, 8192)
+        while True:
+            kp = np.zeros(cap, _lib.KEYPOINT_DTYPE)
+            desc = np.zeros((cap, 128), np.float32)
+            n = C.c_int32(0)
+            st = self._L.rgbdfe_sift_detect(self._ctx, gray.ctypes.data, None, rows, cols, int(max_keypoints), kp.ctypes.data,
+                                            desc.ctypes.data, cap, C.byref(n))
+            if st == -5 and n.value > cap:        # RGBDFE_ERR_CAPACITY: *n_out = the number of features
+                cap = n.value + 64
+                continue
+            self._check(st)
+            return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def sift_geometry(self):
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.rgbdfe_sift_geometry(self._ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(octave_min=a.value, octave_num=b.value, levels=c.value, dog_levels=d.value)
+
+    def sift_debug_plane(self, octave: int, level: int) -> np.ndarray:
+        """A Gaussian plane [h, w] of the latest sift_detect frame (tests)."""
+        buf = np.zeros(1 << 25, np.float32)
+        w, h = C.c_int32(), C.c_int32()
+        self._check(self._L.rgbdfe_sift_debug_plane(self._ctx, octave, level, buf.ctypes.data, buf.size, C.byref(w),
+                                                    C.byref(h)))
+        return buf[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def sift_debug_candidates(self, octave: int, dog_level: int) -> np.ndarray:
+        """The keypoint candidates [n, 6] = (x, y, sign, dx, dy, ds) of one (octave, dog level), list order (tests)."""
+        buf = np.zeros((1 << 20, 6), np.float32)
+        n = C.c_int32()
+        self._check(self._L.rgbdfe_sift_debug_candidates(self._ctx, octave, dog_level, buf.ctypes.data, buf.shape[0],
+                                                         C.byref(n)))
+        return buf[: n.value].copy()
+
     def upload_sift_node(self, node_id: int, desc128: np.ndarray, xyz1: np.ndarray):
         desc128 = np.ascontiguousarray(desc128, np.float32)
         xyz1 = np.ascontiguousarray(xyz1, np.float32)
