@@ -376,7 +376,8 @@ class FrontEnd:
         unnormalised) of a mono8 image.  `mask` is ignored, as in the reference."""
         gray = np.ascontiguousarray(gray, np.uint8)
         rows, cols = gray.shape
-        cap = max(2 * max_keypoints + 4096, 8192)
+        cap = min(max(2 * int(max_keypoints) + 4096, 8192), 1 << 16)
+        max_keypoints = min(int(max_keypoints), (1 << 31) - 1)
         while True:
             kp = np.zeros(cap, _lib.KEYPOINT_DTYPE)
             desc = np.zeros((cap, 128), np.float32)
