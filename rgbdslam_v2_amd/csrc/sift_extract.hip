@@ -15,7 +15,8 @@
 //     an ordered ballot compaction (scan + emit) replaces the reference's 4-ary histogram pyramid and yields the same
 //     raster-ordered lists; the orientation and descriptor kernels take gradients from the Gaussian plane on the fly
 //     (same differences, sqrt, atan2) -- the 45 floats per pixel the reference keeps shrink to 8;
-//   * orientation / descriptor sample loops keep the reference's per-keypoint accumulation order.
+//   * a keypoint's orientation histogram and each of its 16 descriptor cells are wave-wide jobs (the reference gives each
+//     one thread); per-sample arithmetic is the reference's, the sums run lane-parallel in a fixed order.
 // Arithmetic without transcendental functions (pyramid, extrema, sub-pixel offsets, lists) is exact against the
 // reference's kernels compiled on the CPU emulation (oracle/_ref/libref_siftgpu.so); exp / atan2 / pow / sincos come
 // from the device's libm and differ from glibc's by ulps: tests/test_gpu_sift_extract.py states the tolerances.
@@ -87,14 +88,16 @@ __global__ __launch_bounds__(128) void sift_downsample2_kernel(const float* __re
 // stages the (TH + 2R) x (TW + 2R) source patch in LDS (rows / columns clamped to the image as the two reference kernels
 // clamp their fetches), filters it horizontally into a second LDS plane, then vertically into the output.  value starts
 // at 0 and the taps are added in ascending order, multiply and add unfused: the reference's sums, bit for bit.
-constexpr int TW = 64, TH = 16;
+// Two tile shapes: 64 x 16 outputs per block for the large planes, 16 x 16 for planes of a few thousand pixels, where the
+// level-after-level dependency makes the latency of one block the cost of the launch.  FW is a template parameter so
+// that the tap loops unroll.
+template <int FW, int TW, int TH>
 __global__ __launch_bounds__(256) void sift_filter_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
                                                           Taps taps) {
-  extern __shared__ float lds[];
-  const int fw = taps.fw, R = fw >> 1;
-  const int pw = TW + 2 * R, ph = TH + 2 * R;
-  float* patch = lds;              // ph x pw
-  float* hrow = lds + ph * pw;     // ph x TW
+  constexpr int R = FW >> 1;
+  constexpr int pw = TW + 2 * R, ph = TH + 2 * R;
+  __shared__ float patch[ph * pw];   // source rows / columns clamped to the image
+  __shared__ float hrow[ph * TW];    // horizontally filtered
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tid = threadIdx.x;
   for (int i = tid; i < ph * pw; i += 256) {
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void sift_filter_kernel(const float* __restric
     const int py = i / TW, px = i - py * TW;
     const float* p = patch + py * pw + px;
     float value = 0.f;
-    for (int t = 0; t < fw; ++t) value += p[t] * taps.k[t];
+#pragma unroll
+    for (int t = 0; t < FW; ++t) value += p[t] * taps.k[t];
     hrow[i] = value;
   }
   __syncthreads();
@@ -119,8 +123,37 @@ __global__ __launch_bounds__(256) void sift_filter_kernel(const float* __restric
     if (gx >= w || gy >= h) continue;
     const float* p = hrow + ty * TW + tx;
     float value = 0.f;
-    for (int t = 0; t < fw; ++t) value += p[t * TW] * taps.k[t];
+#pragma unroll
+    for (int t = 0; t < FW; ++t) value += p[t * TW] * taps.k[t];
     dst[(size_t)gy * w + gx] = value;
+  }
+}
+
+template <int FW>
+void launch_filter(const float* src, float* dst, int w, int h, const Taps& t, hipStream_t s) {
+  if ((size_t)w * h <= (size_t)160 * 120)
+    hipLaunchKernelGGL((sift_filter_kernel<FW, 16, 16>), dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, s, src, dst, w, h, t);
+  else
+    hipLaunchKernelGGL((sift_filter_kernel<FW, 64, 16>), dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, s, src, dst, w, h, t);
+}
+
+void launch_filter_any(const float* src, float* dst, int w, int h, const Taps& t, hipStream_t s) {
+  switch (t.fw) {   // ProgramCU::FilterImage's switch over the odd widths 5 .. 33 (ProgramCU.cu:430-448)
+    case 5: launch_filter<5>(src, dst, w, h, t, s); break;
+    case 7: launch_filter<7>(src, dst, w, h, t, s); break;
+    case 9: launch_filter<9>(src, dst, w, h, t, s); break;
+    case 11: launch_filter<11>(src, dst, w, h, t, s); break;
+    case 13: launch_filter<13>(src, dst, w, h, t, s); break;
+    case 15: launch_filter<15>(src, dst, w, h, t, s); break;
+    case 17: launch_filter<17>(src, dst, w, h, t, s); break;
+    case 19: launch_filter<19>(src, dst, w, h, t, s); break;
+    case 21: launch_filter<21>(src, dst, w, h, t, s); break;
+    case 23: launch_filter<23>(src, dst, w, h, t, s); break;
+    case 25: launch_filter<25>(src, dst, w, h, t, s); break;
+    case 27: launch_filter<27>(src, dst, w, h, t, s); break;
+    case 29: launch_filter<29>(src, dst, w, h, t, s); break;
+    case 31: launch_filter<31>(src, dst, w, h, t, s); break;
+    default: launch_filter<33>(src, dst, w, h, t, s); break;
   }
 }
 
@@ -304,14 +337,21 @@ struct LevelJobs {  // the kept levels of a frame: consecutive segments of the w
   float sigma[64];
 };
 
-// ComputeOrientation_Kernel (ProgramCU.cu:774-935), num_orientation = 2, sub-pixel on, no existing keypoints: one thread
-// per candidate, the sample loop in the reference's order.
+// ComputeOrientation_Kernel (ProgramCU.cu:774-935), num_orientation = 2, sub-pixel on, no existing keypoints.
+// The reference runs one THREAD per keypoint through a few hundred samples (gradient + atan2 + exp each): a few dozen
+// long waves on a 256-CU chip.  Here a WAVE owns a keypoint: the samples of its window go round-robin (raster order) over
+// the 64 lanes, each lane adds into its own column of a [36 bins][64 lanes] LDS histogram (no atomics: deterministic), 36
+// lanes then sum their bin's 64 partials in lane order, the 6 smoothing passes are circular 3-tap filters across lanes
+// (the reference's in-place loop reads only old values: `one_third * ((pre + v) + next)`, same association), and the
+// two-peak selection is the reference's sequential scan on wave-uniform scalars.  Only the ORDER of the weight sums
+// differs from the reference (per-lane partial sums): ~1e-7 relative, far inside the libm tolerance of this stage.
 __global__ __launch_bounds__(64) void sift_orientation_kernel(LevelJobs jobs, const float* __restrict__ cand,
                                                               float4* __restrict__ feat, float sigma_step,
                                                               float gaussian_factor, float sample_factor) {
+  __shared__ float hist[36][64];
   const float ten_degree_per_radius = 5.7295779513082320876798154814105;
-  const int idx = blockIdx.x * 64 + threadIdx.x;
-  if (idx >= jobs.begin[jobs.n]) return;
+  const int idx = blockIdx.x;
+  const int lane = threadIdx.x;
   int s = 0;
   while (s + 1 < jobs.n && idx >= jobs.begin[s + 1]) ++s;
   const int k = idx - jobs.begin[s];
@@ -325,7 +365,6 @@ __global__ __launch_bounds__(64) void sift_orientation_kernel(LevelJobs jobs, co
   key.x += c[3];
   key.y += c[4];
   key.z *= powf(sigma_step, c[5]);
-  float vote[37];
   const float gsigma = key.z * gaussian_factor;
   const float win = fabsf(key.z) * sample_factor;
   const float dist_threshold = (float)((double)(win * win) + 0.5);
@@ -334,56 +373,61 @@ __global__ __launch_bounds__(64) void sift_orientation_kernel(LevelJobs jobs, co
   const float ymin = fmaxf(1.5f, floorf(key.y - win) + 0.5f);
   const float xmax = fminf(width - 1.5f, floorf(key.x + win) + 0.5f);
   const float ymax = fminf(height - 1.5f, floorf(key.y + win) + 0.5f);
-  for (int i = 0; i < 36; ++i) vote[i] = 0.0f;
-  for (float y = ymin; y <= ymax; y += 1.0f) {
-    for (float x = xmin; x <= xmax; x += 1.0f) {
-      const float dx = x - key.x;
-      const float dy = y - key.y;
-      const float sq_dist = dx * dx + dy * dy;
-      if (sq_dist >= dist_threshold) continue;
-      const float2 got = grad_at(G, width, (int)floorf(x), (int)floorf(y));
-      const float weight = got.x * expf(sq_dist * factor);
-      const float fidx = floorf(got.y * ten_degree_per_radius);
-      int oidx = (int)fidx;
-      if (oidx < 0) oidx += 36;
-      vote[oidx] += weight;
-    }
+  const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;   // iterations of `for (x = xmin; x <= xmax; x += 1.0f)`
+  const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
+#pragma unroll
+  for (int b = 0; b < 36; ++b) hist[b][lane] = 0.0f;
+  const int total = nx * ny;
+  for (int t = lane; t < total; t += 64) {
+    const int iy = t / nx, ix = t - iy * nx;
+    const float x = xmin + (float)ix, y = ymin + (float)iy;
+    const float dx = x - key.x;
+    const float dy = y - key.y;
+    const float sq_dist = dx * dx + dy * dy;
+    if (sq_dist >= dist_threshold) continue;
+    const float2 got = grad_at(G, width, (int)floorf(x), (int)floorf(y));
+    const float weight = got.x * expf(sq_dist * factor);
+    const float fidx = floorf(got.y * ten_degree_per_radius);
+    int oidx = (int)fidx;
+    if (oidx < 0) oidx += 36;
+    hist[oidx][lane] += weight;
   }
+  __syncthreads();
+  float v = 0.0f;
+  if (lane < 36)
+    for (int l = 0; l < 64; ++l) v += hist[lane][l];
+  const int lp = lane < 36 ? (lane + 35) % 36 : lane, ln = lane < 36 ? (lane + 1) % 36 : lane;
   const float one_third = 1.0 / 3.0;
   for (int i = 0; i < 6; ++i) {
-    vote[36] = vote[0];
-    float pre = vote[35];
-    for (int j = 0; j < 36; ++j) {
-      const float temp = one_third * (pre + vote[j] + vote[j + 1]);
-      pre = vote[j];
-      vote[j] = temp;
-    }
+    const float pre = __shfl(v, lp), next = __shfl(v, ln);
+    v = one_third * (pre + v + next);
   }
-  vote[36] = vote[0];
-  float max_vote = vote[0];
-  for (int i = 1; i < 36; ++i) max_vote = fmaxf(max_vote, vote[i]);
+  float max_vote = lane < 36 ? v : -1.0f;
+  for (int d = 32; d >= 1; d >>= 1) max_vote = fmaxf(max_vote, __shfl_xor(max_vote, d));
   const float vote_threshold = max_vote * 0.8f;
-  float pre = vote[35];
+  const float pre = __shfl(v, lp), next = __shfl(v, ln);
+  const bool peak = lane < 36 && v > vote_threshold && v > pre && v > next;
+  const float di = 0.5f * ((next - pre) / (v + v - next - pre));
+  const float rot = lane + di + 0.5f;
+  const uint64_t peaks = __ballot(peak);
   float max_rot[2] = {0.f, 0.f}, max_vot[2] = {0.f, 0.f};
   int ocount = 0;
-  for (int i = 0; i < 36; ++i) {
-    const float next = vote[i + 1];
-    if (vote[i] > vote_threshold && vote[i] > pre && vote[i] > next) {
-      const float di = 0.5f * ((next - pre) / (vote[i] + vote[i] - next - pre));
-      const float rot = i + di + 0.5f;
-      const float weight = vote[i];
-      if (weight > max_vot[1]) {
-        if (weight > max_vot[0]) {
-          max_vot[1] = max_vot[0]; max_rot[1] = max_rot[0];
-          max_vot[0] = weight; max_rot[0] = rot;
-        } else {
-          max_vot[1] = weight; max_rot[1] = rot;
-        }
-        ocount++;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) {   // the reference's scan, on wave-uniform values
+    if (!((peaks >> i) & 1)) continue;
+    const float weight = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+    const float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rot), i));
+    if (weight > max_vot[1]) {
+      if (weight > max_vot[0]) {
+        max_vot[1] = max_vot[0]; max_rot[1] = max_rot[0];
+        max_vot[0] = weight; max_rot[0] = r;
+      } else {
+        max_vot[1] = weight; max_rot[1] = r;
       }
+      ocount++;
     }
-    pre = vote[i];
   }
+  if (lane != 0) return;
   float fr1 = max_rot[0] / 36.0f;
   if (fr1 < 0) fr1 += 1.0f;
   const unsigned short us1 = ocount == 0 ? 65535 : ((unsigned short)floorf(fr1 * 65535.0f));
@@ -398,13 +442,16 @@ __global__ __launch_bounds__(64) void sift_orientation_kernel(LevelJobs jobs, co
   feat[idx] = key;
 }
 
-// ComputeDescriptor_Kernel<false> (ProgramCU.cu:967-1046): 16 threads per feature, one 4x4 cell each
+// ComputeDescriptor_Kernel<false> (ProgramCU.cu:967-1046).  The reference gives each of a feature's 16 cells one thread;
+// here a cell gets a WAVE: the samples of the cell's bounding box go round-robin over the lanes, every lane keeps its own
+// 8 + 1 bins in registers (the reference's compare-and-add over k, so no dynamic indexing), a fixed butterfly sums the
+// lanes.  Per-sample arithmetic is the reference's; only the order of the sums differs (see the orientation kernel).
 __global__ __launch_bounds__(64) void sift_descriptor_kernel(LevelJobs jobs, const float4* __restrict__ feat,
                                                              float4* __restrict__ d_des, float window_factor) {
   const float rpi = 4.0 / 3.14159265358979323846;
-  const int idx = blockIdx.x * 64 + threadIdx.x;
+  const int idx = blockIdx.x;      // feature * 16 + cell
+  const int lane = threadIdx.x;
   const int fidx = idx >> 4;
-  if (fidx >= jobs.begin[jobs.n]) return;
   int s = 0;
   while (s + 1 < jobs.n && fidx >= jobs.begin[s + 1]) ++s;
   const int width = jobs.w[s], height = jobs.h[s];
@@ -427,40 +474,48 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(LevelJobs jobs, con
   const float ymin = fmaxf(1.5f, floorf(pt.y - bsz) + 0.5f);
   const float xmax = fminf(width - 1.5f, floorf(pt.x + bsz) + 0.5f);
   const float ymax = fminf(height - 1.5f, floorf(pt.y + bsz) + 0.5f);
+  const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;
+  const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
   float des[9];
-  for (int i = 0; i < 9; ++i) des[i] = 0.0f;
-  for (float y = ymin; y <= ymax; y += 1.0f) {
-    for (float x = xmin; x <= xmax; x += 1.0f) {
-      const float dx = x - pt.x;
-      const float dy = y - pt.y;
-      const float nx = crspt * dx + srspt * dy;
-      const float ny = crspt * dy - srspt * dx;
-      const float nxn = fabsf(nx);
-      const float nyn = fabsf(ny);
-      if (nxn < 1.0f && nyn < 1.0f) {
-        const float2 cc = grad_at(G, width, (int)floorf(x), (int)floorf(y));
-        const float dnx = nx + offsetpt.x;
-        const float dny = ny + offsetpt.y;
-        const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
-        const float wx = (float)(1.0 - (double)nxn);
-        const float wy = (float)(1.0 - (double)nyn);
-        const float weight = ww * wx * wy * cc.x;
-        float theta = (anglef - cc.y) * rpi;
-        if (theta < 0) theta += 8.0f;
-        const float fo = floorf(theta);
-        const int fi = (int)fo;
-        const float weight1 = fo + 1.0f - theta;
-        const float weight2 = theta - fo;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (k == fi) {
-            des[k] += (weight1 * weight);
-            des[k + 1] += (weight2 * weight);
-          }
+  for (int i = 0; i < 9; ++i) des[i] = 0.0f;
+  const int total = nx * ny;
+  for (int t = lane; t < total; t += 64) {
+    const int jy = t / nx, jx = t - jy * nx;
+    const float x = xmin + (float)jx, y = ymin + (float)jy;
+    const float dx = x - pt.x;
+    const float dy = y - pt.y;
+    const float nxf = crspt * dx + srspt * dy;
+    const float nyf = crspt * dy - srspt * dx;
+    const float nxn = fabsf(nxf);
+    const float nyn = fabsf(nyf);
+    if (nxn < 1.0f && nyn < 1.0f) {
+      const float2 cc = grad_at(G, width, (int)floorf(x), (int)floorf(y));
+      const float dnx = nxf + offsetpt.x;
+      const float dny = nyf + offsetpt.y;
+      const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
+      const float wx = (float)(1.0 - (double)nxn);
+      const float wy = (float)(1.0 - (double)nyn);
+      const float weight = ww * wx * wy * cc.x;
+      float theta = (anglef - cc.y) * rpi;
+      if (theta < 0) theta += 8.0f;
+      const float fo = floorf(theta);
+      const int fi = (int)fo;
+      const float weight1 = fo + 1.0f - theta;
+      const float weight2 = theta - fo;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k == fi) {
+          des[k] += (weight1 * weight);
+          des[k + 1] += (weight2 * weight);
         }
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    for (int d = 32; d >= 1; d >>= 1) des[i] += __shfl_xor(des[i], d);
+  if (lane != 0) return;
   des[0] += des[8];
   const int didx = idx << 1;
   d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
@@ -616,12 +671,7 @@ int SiftExtractor::run(const uint8_t* gray, int rows, int cols, int max_features
   memcpy(h_gray, gray, (size_t)rows * cols);
   SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)rows * cols, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
-  auto filter = [&](const float* src, float* dst, int w, int h, float sg) {
-    const Taps t = make_taps(sg);
-    const int R = t.fw >> 1;
-    const size_t lds = sizeof(float) * ((size_t)(TH + 2 * R) * (TW + 2 * R) + (size_t)(TH + 2 * R) * TW);
-    hipLaunchKernelGGL(sift_filter_kernel, dim3((w + TW - 1) / TW, (h + TH - 1) / TH), dim3(256), lds, s, src, dst, w, h, t);
-  };
+  auto filter = [&](const float* src, float* dst, int w, int h, float sg) { launch_filter_any(src, dst, w, h, make_taps(sg), s); };
   for (int i = 0; i < octave_num; ++i) {
     const Octave& o = oct[i];
     if (i == 0) {
@@ -695,7 +745,7 @@ int SiftExtractor::run(const uint8_t* gray, int rows, int cols, int max_features
   }
   jobs.begin[jobs.n] = total;
   const float sigma_step = powf(2.0f, 1.0f / kDogLevels);
-  hipLaunchKernelGGL(sift_orientation_kernel, dim3((total + 63) / 64), dim3(64), 0, s, jobs, d_cand, d_feat, sigma_step, 1.5f,
+  hipLaunchKernelGGL(sift_orientation_kernel, dim3(total), dim3(64), 0, s, jobs, d_cand, d_feat, sigma_step, 1.5f,
                      1.5f * 2.0f);
   SIFT_HIP(hipGetLastError());
   if ((size_t)total * 4 > stage_floats) { err = "SIFT staging buffer too small"; return RGBDFE_ERR_CAPACITY; }
@@ -764,7 +814,7 @@ int SiftExtractor::run(const uint8_t* gray, int rows, int cols, int max_features
   }
   memcpy(h_stage, list.data() + (size_t)erased * 4, (size_t)total * 16);
   SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)total * 16, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_descriptor_kernel, dim3((total * 16 + 63) / 64), dim3(64), 0, s, dj, d_feat, (float4*)d_desc, 3.0f);
+  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(total * 16), dim3(64), 0, s, dj, d_feat, (float4*)d_desc, 3.0f);
   SIFT_HIP(hipGetLastError());
   desc.resize((size_t)total * 128);
   SIFT_HIP(hipMemcpyAsync(desc.data(), d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));

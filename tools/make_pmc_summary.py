@@ -84,7 +84,7 @@ def frame_section(d):
     for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             tot_ns += float(row["TotalDurationNs"])
-            name = row["Name"].split("(")[0].replace("void ", "").replace("rgbdfe::", "")
+            name = row["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rgbdfe::", "")
             kernels[name] = {"calls_per_frame": round(int(row["Calls"]) / frames, 2), "avg_ns": float(row["AverageNs"]),
                              "ns_per_frame": round(float(row["TotalDurationNs"]) / frames, 1)}
     ctr = {}
