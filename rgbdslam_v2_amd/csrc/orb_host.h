@@ -18,7 +18,8 @@ struct OrbWorkspace {
   ~OrbWorkspace();
   void release();
   void reset_detector(int max_keypoints, int grid_res, int max_iters);
-  int prepare(int cols, int rows, bool use_grid, std::string& err);
+  int prepare(int cols, int rows, bool use_grid, std::string& err, int n_frames = 1);
+  int frames = 1;  // frames per super-frame this workspace holds (1: the single-frame paths)
   // set = 0 / 1: into that image / pyramid set (ensure_alt allocates set 1; use_set makes a set the current one, the one
   // the detection and description kernels read); -1 = the current set.  rgbdfe_detect_describe_batch uploads frame k+1
   // into the other set, from a helper thread on another stream, while frame k is being detected.  Reads only geometry
@@ -27,6 +28,8 @@ struct OrbWorkspace {
                        bool defer_blur = false);
   void build_pyramids(uint8_t* pool, hipStream_t s);
   void stage_images(const uint8_t* gray, const uint8_t* mask, int set);          // CPU half (any thread)
+  void stage_image_at(const uint8_t* gray, const uint8_t* mask, int set, int k);  // super-frame: frame k of the set
+  int enqueue_staged_super(int nf, hipStream_t s, std::string& err, int set);
   int enqueue_staged(bool has_mask, hipStream_t s, std::string& err, int set);    // device half (the HIP thread)
   int ensure_alt(std::string& err);
   void use_set(int set);
@@ -43,6 +46,11 @@ struct OrbWorkspace {
   int detect_pass(const std::vector<int>& active, const std::vector<int>& thr,
                   std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err);
   int grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::string& err);
+  // super-frame workspace: the frames [0, nf) of the current image set in order (cell_mask_nonzero holds nf * grid^2 flags)
+  int super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err);
+  void compute_prepare(std::vector<KpOut>& kps, int frame, std::vector<int>& order, std::vector<DescKp>& dk) const;
+  double super_floor_factor = 0.49;  // floor of a super-frame pass = threshold x this (two x0.7 steps)
+  long super_passes = 0;             // device passes run by super_detect (diagnostics)
   // enqueue_more (optional) is called after the descriptor work has been enqueued and before the one synchronisation,
   // so that the caller's own launches on the stream ride on the same round trip
   int compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, hipStream_t s, std::string& err,

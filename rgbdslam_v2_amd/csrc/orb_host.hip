@@ -137,30 +137,35 @@ void OrbWorkspace::reset_detector(int max_keypoints, int grid_res, int max_iters
 }
 
 // (re)build the geometry for a frame size / cell layout
-int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
-  const int want_cells = use_grid ? grid * grid : 1;
-  if (cols == W && rows == H && n_cells == want_cells && d_pool) return RGBDFE_OK;
+int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, int n_frames) {
+  // n_frames > 1: a SUPER-FRAME workspace (rgbdfe_detect_describe_batch): the images of up to n_frames frames live in one
+  // pool and every stage's ONE launch covers all of them -- frame f's grid cell c is "cell" f * grid^2 + c of the kernels'
+  // ImgDesc / OrbCtl tables (64 entries: 7 frames of a 3 x 3 grid), its pyramid levels are frame images f * 8 + l.
+  const int per_frame_cells = use_grid ? grid * grid : 1;
+  const int want_cells = per_frame_cells * n_frames;
+  if (want_cells > 64) { err = "super-frame: more than 64 (frame, cell) detectors"; return RGBDFE_ERR_CAPACITY; }
+  if (cols == W && rows == H && n_cells == want_cells && frames == n_frames && d_pool) return RGBDFE_OK;
   release();
   W = cols; H = rows;
   n_cells = want_cells;
+  frames = n_frames;
   const int G = use_grid ? grid : 1;
   const int edge = use_grid ? 31 : 0;  // VideoGridAdaptedFeatureDetector edgeThreshold (feature_adjuster.h)
   cells.clear();
-  for (int i = 0; i < G; ++i) {
-    const int rowstart = std::max((i * rows) / G - edge, 0);
-    const int rowend = std::min(rows, ((i + 1) * rows) / G + edge);
-    for (int j = 0; j < G; ++j) {
-      const int colstart = std::max((j * cols) / G - edge, 0);
-      const int colend = std::min(cols, ((j + 1) * cols) / G + edge);
-      cells.push_back(Cell{colstart, rowstart, colend - colstart, rowend - rowstart});
+  for (int f = 0; f < n_frames; ++f)
+    for (int i = 0; i < G; ++i) {
+      const int rowstart = std::max((i * rows) / G - edge, 0);
+      const int rowend = std::min(rows, ((i + 1) * rows) / G + edge);
+      for (int j = 0; j < G; ++j) {
+        const int colstart = std::max((j * cols) / G - edge, 0);
+        const int colend = std::min(cols, ((j + 1) * cols) / G + edge);
+        cells.push_back(Cell{colstart, rowstart, colend - colstart, rowend - rowstart});
+      }
     }
-  }
-  // pool layout
-  size_t off = 0;
-  const uint32_t gray_off = 0; off += (size_t)W * H;
-  const uint32_t mask_off = (uint32_t)off; off += (size_t)W * H;
+  // pool layout: [frame 0 gray | frame 0 mask | frame 1 gray | ...] first (one upload), the pyramid levels behind
+  size_t off = (size_t)2 * W * H * n_frames;
   cell_imgs.assign((size_t)n_cells * kLevels, ImgDesc{});
-  frame_imgs.assign(kLevels, ImgDesc{});
+  frame_imgs.assign((size_t)kLevels * n_frames, ImgDesc{});
   jobs.clear();
   level_job_begin.assign(kLevels + 1, 0);
   size_t score_off = 0, row_off = 0;
@@ -177,6 +182,8 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
       ImgDesc& d = cell_imgs[(size_t)c * kLevels + l];
       d.w = lw[(size_t)c * kLevels + l]; d.h = lh[(size_t)c * kLevels + l];
       d.cell = c; d.level = l; d.has_mask = 1;
+      const uint32_t gray_off = (uint32_t)((size_t)2 * W * H * (c / per_frame_cells));
+      const uint32_t mask_off = gray_off + (uint32_t)((size_t)W * H);
       if (l == 0) {
         d.off = gray_off + (uint32_t)((size_t)cells[c].y0 * W + cells[c].x0); d.stride = W;
         d.mask_off = mask_off + (uint32_t)((size_t)cells[c].y0 * W + cells[c].x0); d.mask_stride = W;
@@ -189,13 +196,14 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
   size_t blur_off = 0;
-  for (int l = 0; l < kLevels; ++l) {
-    ImgDesc& d = frame_imgs[l];
-    d.w = flw[l]; d.h = flh[l]; d.cell = 0; d.level = l; d.has_mask = 0;
-    if (l == 0) { d.off = gray_off; d.stride = W; }
-    else { d.off = (uint32_t)off; off += (size_t)d.w * d.h; d.stride = d.w; }
-    d.score_off = (uint32_t)blur_off; blur_off += (size_t)d.w * d.h;
-  }
+  for (int f = 0; f < n_frames; ++f)
+    for (int l = 0; l < kLevels; ++l) {
+      ImgDesc& d = frame_imgs[(size_t)f * kLevels + l];
+      d.w = flw[l]; d.h = flh[l]; d.cell = 0; d.level = l; d.has_mask = 0;
+      if (l == 0) { d.off = (uint32_t)((size_t)2 * W * H * f); d.stride = W; }
+      else { d.off = (uint32_t)off; off += (size_t)d.w * d.h; d.stride = d.w; }
+      d.score_off = (uint32_t)blur_off; blur_off += (size_t)d.w * d.h;
+    }
   pool_bytes = off + 256;
   // resize jobs, level by level (level l reads level l-1)
   for (int l = 1; l < kLevels; ++l) {
@@ -213,7 +221,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
       add(cell_imgs[(size_t)c * kLevels + l - 1], cell_imgs[(size_t)c * kLevels + l], false);
       add(cell_imgs[(size_t)c * kLevels + l - 1], cell_imgs[(size_t)c * kLevels + l], true);
     }
-    add(frame_imgs[l - 1], frame_imgs[l], false);
+    for (int f = 0; f < n_frames; ++f) add(frame_imgs[(size_t)f * kLevels + l - 1], frame_imgs[(size_t)f * kLevels + l], false);
   }
   level_job_begin[kLevels] = (int)jobs.size();
   n_rows_total = (int)row_off;
@@ -241,8 +249,8 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipMalloc((void**)&d_kept, sizeof(int32_t) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_xyz, sizeof(float4) * (size_t)kp_cap));
   ORB_HIP(hipMalloc((void**)&d_n, sizeof(int32_t)));
-  ORB_HIP(hipMalloc((void**)&d_n_proj, sizeof(int32_t)));
-  pin_cap = std::min(kp_cap, 16384);
+  ORB_HIP(hipMalloc((void**)&d_n_proj, sizeof(int32_t) * 64));
+  pin_cap = std::min(kp_cap, n_frames > 1 ? 16384 * 8 : 16384);
   ORB_HIP(hipHostMalloc((void**)&h_base, sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_passout, passout_hdr + sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
   h_totals = reinterpret_cast<int*>(h_passout);
@@ -252,8 +260,8 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err) {
   ORB_HIP(hipHostMalloc((void**)&h_xyz_in, sizeof(float) * 3 * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_xyz_out, sizeof(float) * 4 * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_n, sizeof(int32_t), hipHostMallocDefault));
-  ORB_HIP(hipHostMalloc((void**)&h_n_proj, sizeof(int32_t), hipHostMallocDefault));
-  ORB_HIP(hipHostMalloc((void**)&h_img, (size_t)2 * W * H, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_n_proj, sizeof(int32_t) * 64, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_img, (size_t)2 * W * H * n_frames, hipHostMallocDefault));
   himg_set[0] = h_img;
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
@@ -269,7 +277,7 @@ int OrbWorkspace::ensure_alt(std::string& err) {
   ORB_HIP(hipMalloc((void**)&pool_set[1], pool_bytes));
   ORB_HIP(hipMemset(pool_set[1], 0, pool_bytes));
   ORB_HIP(hipMalloc((void**)&blur_set[1], blur_bytes));
-  ORB_HIP(hipHostMalloc((void**)&himg_set[1], (size_t)2 * W * H, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&himg_set[1], (size_t)2 * W * H * frames, hipHostMallocDefault));
   ORB_HIP(hipDeviceSynchronize());
   return RGBDFE_OK;
 }
@@ -350,6 +358,25 @@ void OrbWorkspace::stage_images(const uint8_t* gray, const uint8_t* mask, int se
   const size_t img = (size_t)W * H;
   memcpy(h, gray, img);
   if (mask) memcpy(h + img, mask, img);
+}
+
+// super-frame variants: frame k of the super-frame at [k * 2WH, ...) of the staging buffer / pool, a missing mask as 255s
+void OrbWorkspace::stage_image_at(const uint8_t* gray, const uint8_t* mask, int set, int k) {
+  uint8_t* const h = himg_set[set] + (size_t)2 * W * H * k;
+  const size_t img = (size_t)W * H;
+  memcpy(h, gray, img);
+  if (mask) memcpy(h + img, mask, img);
+  else memset(h + img, 255, img);
+}
+
+int OrbWorkspace::enqueue_staged_super(int nf, hipStream_t s, std::string& err, int set) {
+  uint8_t* const d_pool = pool_set[set];
+  uint8_t* const d_blur = blur_set[set];
+  ORB_HIP(hipMemcpyAsync(d_pool, himg_set[set], (size_t)2 * W * H * nf, hipMemcpyHostToDevice, s));
+  build_pyramids(d_pool, s);
+  launch_orb_blur(d_pool, d_frame_imgs, kLevels * frames, W, H, d_blur, s);
+  ORB_HIP(hipGetLastError());
+  return RGBDFE_OK;
 }
 
 int OrbWorkspace::enqueue_staged(bool has_mask, hipStream_t s, std::string& err, int set) {
@@ -548,6 +575,127 @@ int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::strin
       kps.push_back(KpOut{k.x + cells[c].x0, k.y + cells[c].y0, k.size, k.angle, k.response, k.octave});
   }
   return RGBDFE_OK;
+}
+
+// VideoGridAdaptedFeatureDetector::detect for the frames [0, nf) of a super-frame, IN ORDER: frame f + 1 starts from the
+// per-cell thresholds frame f leaves behind (feature_adjuster.cpp:185-224), exactly as nf calls of grid_detect would.
+// What makes one device pass serve all of them: the corners at threshold t are the corners at any floor f <= t whose
+// score is >= t (select_pass), so the pass runs every (frame, cell) at a floor below the threshold it is expected to
+// end up with, and the adjuster is replayed on the host over the scored corners, frame by frame.  A cell whose threshold
+// drops below its floor (rare: two x0.7 steps inside one super-frame) triggers another pass over the frames from there
+// on, with floors taken from the thresholds of that moment -- results do not depend on the floors.
+int OrbWorkspace::super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err) {
+  const int pc = grid * grid;
+  std::vector<std::vector<KpOut>> cellkp((size_t)n_cells);
+  std::vector<int> act((size_t)n_cells, 0), thr((size_t)n_cells, 0), floor_thr((size_t)n_cells, 0);
+  std::vector<char> covered((size_t)n_cells, 0);
+  kps_per_frame.assign((size_t)nf, std::vector<KpOut>());
+  auto run_pass = [&](int f_from) -> int {
+    std::vector<int> pa((size_t)n_cells, 0);
+    for (int c = 0; c < n_cells; ++c) {
+      const int f = c / pc;
+      covered[c] = 0;
+      if (f < f_from || f >= nf) continue;
+      pa[c] = 1;
+      covered[c] = 1;
+      double next = thresh[c % pc] * super_floor_factor;
+      if (next < 2) next = 2;
+      floor_thr[c] = std::min((int)thresh[c % pc], (int)next);
+    }
+    super_passes++;
+    return gpu_pass(pa, floor_thr, s, err);
+  };
+  for (int f = 0; f < nf; ++f) {
+    std::vector<int> iter_left((size_t)pc, adjuster_iters);
+    std::vector<char> checked((size_t)pc, 0), active((size_t)pc, 1);
+    bool any = true;
+    while (any) {
+      bool need_gpu = false;
+      std::fill(act.begin(), act.end(), 0);
+      for (int c9 = 0; c9 < pc; ++c9) {
+        const int c = f * pc + c9;
+        thr[c] = (int)thresh[c9];  // static_cast<int>(thresh_)
+        act[c] = active[c9];
+        if (active[c9] && (!covered[c] || thr[c] < floor_thr[c])) need_gpu = true;
+      }
+      if (need_gpu) {
+        const int rc = run_pass(f);
+        if (rc != RGBDFE_OK) return rc;
+      }
+      select_pass(act, thr, cellkp);
+      any = false;
+      for (int c9 = 0; c9 < pc; ++c9) {
+        if (!active[c9]) continue;
+        const int c = f * pc + c9;
+        const int found = (int)cellkp[c].size();
+        bool again = false;
+        // VideoDynamicAdaptedFeatureDetector::detect (feature_adjuster.cpp:185-224)
+        if (found < cell_min) {
+          thresh[c9] *= 0.7;                       // tooFew (:131-136)
+          if (thresh[c9] < 2) thresh[c9] = 2;
+          bool brk = false;
+          if (found == 0 && !checked[c9]) {
+            checked[c9] = 1;
+            if (!cell_mask_nonzero[c]) brk = true;  // hasNonZero(mask) (:205-209)
+          }
+          if (!brk) {
+            iter_left[c9]--;
+            again = iter_left[c9] > 0 && (thresh[c9] > 2 && thresh[c9] < 10000);  // good() (:147-150)
+          }
+        } else if (found > cell_max) {
+          thresh[c9] *= 1.3;                       // tooMany (:138-143)
+          if (thresh[c9] > 10000) thresh[c9] = 10000;
+        }
+        active[c9] = again ? 1 : 0;
+        any |= again;
+      }
+    }
+    const int maxPerCell = max_total / pc;  // :292
+    std::vector<KpOut>& kps = kps_per_frame[(size_t)f];
+    for (int c9 = 0; c9 < pc; ++c9) {
+      const int c = f * pc + c9;
+      std::vector<KP> v;
+      v.reserve(cellkp[c].size());
+      for (const KpOut& k : cellkp[c]) v.push_back(KP{k.x, k.y, k.size, k.angle, k.response, k.octave, 0.f});
+      keep_strongest(v, maxPerCell, [](const KP& k) { return std::fabs(k.response); });  // :247-255
+      for (const KP& k : v)  // aggregateKeypointsPerGridCell (:259-282)
+        kps.push_back(KpOut{k.x + cells[c].x0, k.y + cells[c].y0, k.size, k.angle, k.response, k.octave});
+    }
+  }
+  return RGBDFE_OK;
+}
+
+// The CPU half of cv::ORB::compute for one frame of a super-frame (see compute_enqueue): border filter, regroup by level,
+// descriptor records with the frame's pyramid images (frame_imgs[frame * 8 + octave]).  Pure host code: runs on any thread.
+void OrbWorkspace::compute_prepare(std::vector<KpOut>& kps, int frame, std::vector<int>& order, std::vector<DescKp>& dk) const {
+  order.clear();
+  order.reserve(kps.size());
+  auto inside = [&](const KpOut& k) {
+    return k.x >= kComputeEdge && k.x < W - kComputeEdge && k.y >= kComputeEdge && k.y < H - kComputeEdge;
+  };
+  for (int l = 0; l < kLevels; ++l)
+    for (size_t i = 0; i < kps.size(); ++i) {
+      const KpOut& k = kps[i];
+      if (k.octave == l && inside(k)) order.push_back((int)i);
+    }
+  {
+    std::vector<KpOut> t;
+    t.reserve(order.size());
+    for (int i : order) t.push_back(kps[(size_t)i]);
+    kps.swap(t);
+  }
+  dk.resize(kps.size());
+  for (size_t j = 0; j < kps.size(); ++j) {
+    const KpOut& k = kps[j];
+    const float sc = 1.f / scale[k.octave];
+    float angle = k.angle;
+    angle *= (float)(M_PI / 180.f);
+    dk[j].cos_a = (float)std::cos((double)angle);
+    dk[j].sin_a = (float)std::sin((double)angle);
+    dk[j].cx = cv_round_f(k.x * sc);
+    dk[j].cy = cv_round_f(k.y * sc);
+    dk[j].level = frame * kLevels + k.octave;
+  }
 }
 
 // cv::ORB::create()->compute (features.cpp:117-119): border filter, regroup by level, rBRIEF

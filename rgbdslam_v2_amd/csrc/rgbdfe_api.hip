@@ -159,6 +159,7 @@ struct rgbdfe_ctx {
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
   OrbWorkspace orb;
+  OrbWorkspace orb_super;  // rgbdfe_detect_describe_batch: up to 7 frames per launch chain (its own image sets)
   SiftExtractor sift;  // rgbdfe_sift_detect (sift_extract.hip)
   int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;
@@ -1478,6 +1479,316 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
   return rc;
 }
 
+// ---- rgbdfe_detect_describe_batch, super-frame form -----------------------------------------------------------------
+// B = 64 / grid^2 (7 for the 3 x 3 grid) frames share every launch: one upload, one pyramid chain (7 launches), one blur,
+// one detection pass (FAST score -> NMS count -> scan -> emit -> measure) over 7 x 72 images, one rBRIEF launch -- a frame
+// alone is 1.7 M pixels and cannot fill 256 CUs, and its 27 dependent device operations cost 5-15 us each whatever their
+// size.  Frames stay sequentially dependent through the per-cell FAST thresholds: OrbWorkspace::super_detect runs the
+// device pass at a floor threshold and replays the reference's adjuster over the scored corners frame by frame (identical
+// keypoints: see select_pass).  The per-frame CPU work that does not touch the HIP runtime (removeDepthless, retainBest,
+// cv::ORB::compute's border filter / regroup / descriptor records, the depth look-ups) runs on worker threads while the
+// calling thread drives the next super-frame's pass.
+namespace {
+
+class TaskPool {  // a few persistent worker threads for pure-CPU jobs
+ public:
+  explicit TaskPool(int n) {
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+  }
+  ~TaskPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) if (t.joinable()) t.join();
+  }
+  void submit(std::function<void()> f) {
+    { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); ++pending_; }
+    cv_.notify_one();
+  }
+  void wait_all() {
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [&] { return pending_ == 0; });
+  }
+ private:
+  void run() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+        if (stop_ && q_.empty()) return;
+        f = std::move(q_.front());
+        q_.erase(q_.begin());
+      }
+      try { f(); } catch (...) { failed_ = true; }
+      { std::lock_guard<std::mutex> l(m_); --pending_; }
+      done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::vector<std::function<void()>> q_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  int pending_ = 0;
+  bool stop_ = false;
+ public:
+  bool failed_ = false;
+};
+
+struct SuperFrameJob {  // one frame of a super-frame, between detection and copy-out
+  std::vector<KpOut> kps;
+  std::vector<int> order;
+  std::vector<DescKp> dk;
+  std::vector<float> xyz_in;  // 2n (x, y) then n depths
+  int off = 0;                // first row of this frame in the super-frame's concatenated buffers
+};
+
+// removeDepthless (node.cpp:67-97, :186) + retainBest(max_keypoints) (:188-191) + the CPU half of cv::ORB::compute +
+// projectTo3D's depth look-ups (node.cpp:942) for one frame: DetectFrame::describe_enqueue's host work, no HIP calls
+void super_describe_prepare(const OrbWorkspace& orb, SuperFrameJob& j, int frame_in_super, const float* depth, int rows,
+                            int cols, int max_kp) {
+  std::vector<KpOut>& kps = j.kps;
+  size_t m = 0;
+  for (const KpOut& k : kps) {
+    if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
+    int r = (int)roundf(k.y), c = (int)roundf(k.x);
+    r = r >= rows ? rows - 1 : r;
+    c = c >= cols ? cols - 1 : c;
+    if (std::isnan(depth[(size_t)r * cols + c])) continue;
+    kps[m++] = k;
+  }
+  kps.resize(m);
+  if ((int)kps.size() > max_kp) {  // the max_kp first of the order (response descending, position ascending), in place
+    std::vector<std::pair<float, int>> r(kps.size());
+    for (size_t i = 0; i < kps.size(); ++i) r[i] = std::make_pair(kps[i].response, (int)i);
+    auto before = [](const std::pair<float, int>& a, const std::pair<float, int>& b) {
+      return a.first > b.first || (a.first == b.first && a.second < b.second);
+    };
+    std::nth_element(r.begin(), r.begin() + (max_kp - 1), r.end(), before);
+    const std::pair<float, int> cut = r[(size_t)max_kp - 1];
+    m = 0;
+    for (size_t i = 0; i < kps.size(); ++i)
+      if (!before(cut, std::make_pair(kps[i].response, (int)i))) kps[m++] = kps[i];
+    kps.resize(m);
+  }
+  orb.compute_prepare(kps, frame_in_super, j.order, j.dk);
+  const int n = (int)kps.size();
+  j.xyz_in.resize((size_t)n * 3);
+  for (int i = 0; i < n; ++i) {
+    j.xyz_in[(size_t)2 * i] = kps[i].x;
+    j.xyz_in[(size_t)2 * i + 1] = kps[i].y;
+    int r = (int)roundf(kps[i].y), c = (int)roundf(kps[i].x);
+    r = r >= rows ? rows - 1 : r;
+    c = c >= cols ? cols - 1 : c;
+    j.xyz_in[(size_t)2 * n + i] = depth[(size_t)r * cols + c];
+  }
+}
+
+int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
+                                const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
+                                uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+  OrbWorkspace& orb = ctx->orb_super;
+  const OrbWorkspace& one = ctx->orb;
+  const int pc = one.grid * one.grid;
+  const int B = std::min(64 / pc, 7);
+  // the detector object is one: its configuration and thresholds move into the super-frame workspace and back
+  orb.grid = one.grid; orb.adjuster_iters = one.adjuster_iters; orb.cell_min = one.cell_min; orb.cell_max = one.cell_max;
+  orb.max_total = one.max_total; orb.lookahead = one.lookahead;
+  for (int i = 0; i < 64; ++i) orb.thresh[i] = one.thresh[i];
+  if (const char* e = getenv("RGBDFE_SUPER_FLOOR")) orb.super_floor_factor = atof(e);  // experiments
+  std::string err;
+  int rc = orb.prepare(cols, rows, true, err, B);
+  if (rc == RGBDFE_OK) rc = orb.ensure_alt(err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  if (!ctx->orb_upload_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_compute_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_upload_done[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_describe_done[i], hipEventDisableTiming));
+  }
+  hipStream_t up = ctx->orb_upload_stream, st2 = ctx->orb_compute_stream;
+  const int max_kp = ctx->orb_max_keypoints;
+  const int S = (n_frames + B - 1) / B;
+  auto first_of = [&](int s) { return s * B; };
+  auto count_of = [&](int s) { return std::min(B, n_frames - s * B); };
+  // helper thread: the caller's pageable images of super-frame s -> the pinned staging buffer of set s & 1, as soon as
+  // super-frame s - 2 (the set's previous user) has been detected (its upload from that buffer is complete then)
+  std::mutex m;
+  std::condition_variable cv;
+  int staged = 0, detected = 0;
+  bool stop = false;
+  std::thread helper([&]() {
+    for (int s = 0; s < S; ++s) {
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return stop || detected >= s - 1; });
+        if (stop) return;
+      }
+      for (int k = 0; k < count_of(s); ++k) {
+        const int f = first_of(s) + k;
+        orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s & 1, k);
+      }
+      std::lock_guard<std::mutex> l(m);
+      staged = s + 1;
+      cv.notify_all();
+    }
+  });
+  struct HelperJoin {
+    std::thread& th; std::mutex& m; std::condition_variable& cv; bool& stop;
+    ~HelperJoin() {
+      { std::lock_guard<std::mutex> l(m); stop = true; }
+      cv.notify_all();
+      if (th.joinable()) th.join();
+    }
+  } helper_join{helper, m, cv, stop};
+  TaskPool pool(std::min(B, 6));
+  std::vector<SuperFrameJob> jobs[2];
+  jobs[0].resize((size_t)B); jobs[1].resize((size_t)B);
+  int n_tot[2] = {0, 0};
+  auto enqueue_upload = [&](int s) -> int {
+    {
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [&] { return staged > s; });
+    }
+    if (s >= 2 && hipStreamWaitEvent(up, ctx->orb_describe_done[s & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
+    const int r = orb.enqueue_staged_super(count_of(s), up, err, s & 1);
+    if (r != RGBDFE_OK) return r;
+    if (hipEventRecord(ctx->orb_upload_done[s & 1], up) != hipSuccess) { err = "hipEventRecord"; return RGBDFE_ERR_HIP; }
+    return RGBDFE_OK;
+  };
+  // the CPU halves of super-frame s's descriptions: worker threads, no HIP calls
+  auto start_prepare = [&](int s) {
+    std::vector<SuperFrameJob>& J = jobs[s & 1];
+    for (int k = 0; k < count_of(s); ++k) {
+      const float* dp = depth[first_of(s) + k];
+      SuperFrameJob* j = &J[(size_t)k];
+      pool.submit([&orb, j, k, dp, rows, cols, max_kp] { super_describe_prepare(orb, *j, k, dp, rows, cols, max_kp); });
+    }
+  };
+  // device half: one descriptor-record upload, one rBRIEF launch, one projectTo3D launch per frame, three read-backs
+  auto enqueue_describe = [&](int s) -> int {
+    pool.wait_all();
+    if (pool.failed_) { err = "describe preparation failed"; return RGBDFE_ERR_INTERNAL; }
+    std::vector<SuperFrameJob>& J = jobs[s & 1];
+    const int nf = count_of(s);
+    int tot = 0;
+    for (int k = 0; k < nf; ++k) { J[(size_t)k].off = tot; tot += (int)J[(size_t)k].kps.size(); }
+    n_tot[s & 1] = tot;
+    if (hipStreamWaitEvent(st2, ctx->orb_upload_done[s & 1], 0) != hipSuccess) return RGBDFE_ERR_HIP;
+    if (tot > orb.pin_cap || tot > orb.kp_cap) { err = "super-frame: more keypoints than the staging buffers hold"; return RGBDFE_ERR_CAPACITY; }
+    if (tot > 0) {
+      for (int k = 0; k < nf; ++k) {
+        const SuperFrameJob& j = J[(size_t)k];
+        const size_t n = j.kps.size();
+        if (n == 0) continue;
+        memcpy(orb.h_desckp + j.off, j.dk.data(), sizeof(DescKp) * n);
+        memcpy(orb.h_xyz_in + (size_t)3 * j.off, j.xyz_in.data(), sizeof(float) * 3 * n);
+      }
+      uint8_t* const pool_dev = orb.pool_set[s & 1];
+      uint8_t* const blur_dev = orb.blur_set[s & 1];
+      if (hipMemcpyAsync(orb.d_desckp, orb.h_desckp, sizeof(DescKp) * (size_t)tot, hipMemcpyHostToDevice, st2) != hipSuccess ||
+          hipMemcpyAsync(orb.d_kpxy, orb.h_xyz_in, sizeof(float) * 3 * (size_t)tot, hipMemcpyHostToDevice, st2) != hipSuccess)
+        return RGBDFE_ERR_HIP;
+      launch_orb_brief(pool_dev, blur_dev, orb.d_frame_imgs, orb.d_desckp, tot, orb.d_desc, st2);
+      for (int k = 0; k < nf; ++k) {
+        const SuperFrameJob& j = J[(size_t)k];
+        const int n = (int)j.kps.size();
+        if (n == 0) continue;
+        launch_project_to_3d(orb.d_kpxy + (size_t)3 * j.off, n, nullptr, rows, cols, (float)(1. / fx), (float)(1. / fy),
+                             (float)cx, (float)cy, depth_scaling, max_kp, orb.d_kept + j.off, orb.d_xyz + j.off,
+                             orb.d_n_proj + k, st2, false, orb.d_kpxy + (size_t)3 * j.off + (size_t)2 * n);
+      }
+      if (hipGetLastError() != hipSuccess) return RGBDFE_ERR_HIP;
+      if (hipMemcpyAsync(orb.h_desc, orb.d_desc, (size_t)32 * tot, hipMemcpyDeviceToHost, st2) != hipSuccess ||
+          hipMemcpyAsync(orb.h_xyz_out, orb.d_xyz, sizeof(float) * 4 * (size_t)tot, hipMemcpyDeviceToHost, st2) != hipSuccess ||
+          hipMemcpyAsync(orb.h_n_proj, orb.d_n_proj, sizeof(int32_t) * (size_t)nf, hipMemcpyDeviceToHost, st2) != hipSuccess)
+        return RGBDFE_ERR_HIP;
+    }
+    return hipEventRecord(ctx->orb_describe_done[s & 1], st2) == hipSuccess ? RGBDFE_OK : RGBDFE_ERR_HIP;
+  };
+  auto finish = [&](int s) -> int {
+    if (hipStreamSynchronize(st2) != hipSuccess) return RGBDFE_ERR_HIP;
+    std::vector<SuperFrameJob>& J = jobs[s & 1];
+    for (int k = 0; k < count_of(s); ++k) {
+      const SuperFrameJob& j = J[(size_t)k];
+      const int f = first_of(s) + k;
+      const int n = (int)j.kps.size();
+      n_out[f] = 0;
+      if (n > 0) {
+        if (orb.h_n_proj[k] != n) { err = "projectTo3D dropped keypoints that removeDepthless kept"; return RGBDFE_ERR_HIP; }
+        memcpy(xyz1 + (size_t)f * out_stride * 4, orb.h_xyz_out + (size_t)4 * j.off, sizeof(float) * 4 * (size_t)n);
+        memcpy(descriptors + (size_t)f * out_stride * 32, orb.h_desc + (size_t)32 * j.off, (size_t)32 * n);
+      }
+      kp_to_abi(j.kps, keypoints + (size_t)f * out_stride);
+      n_out[f] = n;
+    }
+    return RGBDFE_OK;
+  };
+  rc = enqueue_upload(0);
+  for (int s = 0; s < S && rc == RGBDFE_OK; ++s) {
+    const int nf = count_of(s);
+    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[s & 1], 0) != hipSuccess) { rc = RGBDFE_ERR_HIP; err = "hipStreamWaitEvent"; break; }
+    orb.use_set(s & 1);
+    // hasNonZero(sub_mask) per (frame, cell) (feature_adjuster.cpp:175-183)
+    orb.cell_mask_nonzero.assign((size_t)orb.n_cells, 1);
+    for (int k = 0; k < nf; ++k) {
+      const uint8_t* mk = mask ? mask[first_of(s) + k] : nullptr;
+      if (!mk) continue;
+      for (int c9 = 0; c9 < pc; ++c9) {
+        const OrbWorkspace::Cell& ce = orb.cells[(size_t)k * pc + c9];
+        char nz = 0;
+        for (int y = 0; y < ce.h && !nz; ++y) {
+          const uint8_t* r = mk + (size_t)(ce.y0 + y) * cols + ce.x0;
+          for (int x = 0; x < ce.w; ++x)
+            if (r[x]) { nz = 1; break; }
+        }
+        orb.cell_mask_nonzero[(size_t)k * pc + c9] = nz;
+      }
+    }
+    int rc_hook = RGBDFE_OK;
+    orb.before_wait = [&, s]() -> int {   // rides on the device time of this super-frame's first pass
+      if (s > 0) rc_hook = enqueue_describe(s - 1);
+      if (rc_hook == RGBDFE_OK && s + 1 < S) rc_hook = enqueue_upload(s + 1);
+      return rc_hook;
+    };
+    std::vector<std::vector<KpOut>> kps;
+    rc = orb.super_detect(nf, kps, ctx->stream, err);
+    if (rc == RGBDFE_OK && orb.before_wait) {  // (a super-frame always runs a pass; never lose the hook)
+      std::function<int()> f = std::move(orb.before_wait);
+      orb.before_wait = nullptr;
+      rc = f();
+    }
+    orb.before_wait = nullptr;
+    if (rc != RGBDFE_OK) break;
+    {
+      std::lock_guard<std::mutex> l(m);
+      detected = s + 1;
+    }
+    cv.notify_all();
+    if (s > 0) { rc = finish(s - 1); if (rc != RGBDFE_OK) break; }
+    for (int k = 0; k < nf; ++k) jobs[s & 1][(size_t)k].kps.swap(kps[(size_t)k]);
+    start_prepare(s);
+  }
+  if (rc == RGBDFE_OK) rc = enqueue_describe(S - 1);
+  if (rc == RGBDFE_OK) rc = finish(S - 1);
+  pool.wait_all();
+  (void)hipStreamSynchronize(st2);
+  {
+    std::lock_guard<std::mutex> l(m);
+    stop = true;
+    cv.notify_all();
+  }
+  if (helper.joinable()) helper.join();
+  (void)hipStreamSynchronize(up);
+  (void)hipStreamSynchronize(ctx->stream);
+  orb.use_set(0);
+  for (int i = 0; i < 64; ++i) ctx->orb.thresh[i] = orb.thresh[i];   // the detector's state goes back
+  if (rc != RGBDFE_OK) return err.empty() ? rc : fail(ctx, rc, err);
+  return RGBDFE_OK;
+}
+
+}  // namespace
+
 // A run of frames through the same detector state, in order (the per-cell thresholds of frame k+1 start from frame k's,
 // as in a sequence of single calls -- same keypoints, bit for bit).  What the batch adds is overlap, three deep: frame
 // k+2's images are staged, uploaded and turned into their pyramid by a helper thread (own stream, the free image set)
@@ -1499,6 +1810,12 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
   for (int32_t f = 0; f < n_frames; ++f)
     if (!gray[f] || !depth[f]) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "null frame");
   if (n_frames == 0) return RGBDFE_OK;
+  {  // several frames per launch chain (above) unless switched off or the detector is in a mode only the frame path has
+    static const bool super_env = !(getenv("RGBDFE_DETECT_SUPER") && atoi(getenv("RGBDFE_DETECT_SUPER")) == 0);
+    if (super_env && n_frames >= 2 && !ctx->feature_min_depth && ctx->orb.grid * ctx->orb.grid * 2 <= 64)
+      return detect_describe_batch_super(ctx, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling, out_stride,
+                                         keypoints, descriptors, xyz1, n_out);
+  }
   OrbWorkspace& orb = ctx->orb;
   std::string err;
   int rc = orb.prepare(cols, rows, true, err);

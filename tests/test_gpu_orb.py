@@ -194,11 +194,18 @@ def test_detect_describe_batch_equals_frame_by_frame(frames):
     masks = [np.where(frames["mask"][f] > 0, 255, 0).astype(np.uint8) for f in (0, 1, 0, 2, 3)]
     masks[3] = None
     outs = []
-    for mode in ("single", "batch", "batch_then_single"):
+    # (a run longer than two super-frames of 7: the super-frame pipeline's double buffering, a partial last super-frame)
+    long_idx = [i % 5 for i in range(17)]
+    for mode in ("single", "batch", "batch_then_single", "single_long", "batch_long"):
         fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=1024, max_pairs_per_batch=8)
         fe.detector_configure(max_keypoints=1000)
         if mode == "single":
             res = [fe.detect_describe(g, m, d, *K) for g, m, d in zip(grays, masks, depths)]
+        elif mode == "single_long":
+            res = [fe.detect_describe(grays[i], masks[i], depths[i], *K) for i in long_idx]
+        elif mode == "batch_long":
+            res = fe.detect_describe_batch([grays[i] for i in long_idx], [masks[i] for i in long_idx],
+                                           [depths[i] for i in long_idx], *K)
         elif mode == "batch":
             res = fe.detect_describe_batch(grays, masks, depths, *K)
         else:
@@ -208,10 +215,10 @@ def test_detect_describe_batch_equals_frame_by_frame(frames):
         outs.append((res, fe.detector_thresholds().copy()))
         assert fe.detect_describe_batch([], [], [], *K) == []
         fe.close()
-    ref, ref_thr = outs[0]
-    assert min(len(r[0]) for r in ref) > 100
-    for res, thr in outs[1:]:
-        assert np.array_equal(thr, ref_thr)
+    assert min(len(r[0]) for r in outs[0][0]) > 100
+    for got, want in ((outs[1], outs[0]), (outs[2], outs[0]), (outs[4], outs[3])):
+        (res, thr), (ref, ref_thr) = got, want
+        assert len(res) == len(ref) and np.array_equal(thr, ref_thr)
         for (k1, d1, x1), (k2, d2, x2) in zip(res, ref):
             assert_kps_equal(k1, k2)
             assert np.array_equal(d1, d2) and np.array_equal(x1, x2)
