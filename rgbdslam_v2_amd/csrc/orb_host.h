@@ -28,8 +28,8 @@ struct OrbWorkspace {
                        bool defer_blur = false);
   void build_pyramids(uint8_t* pool, hipStream_t s);
   void stage_images(const uint8_t* gray, const uint8_t* mask, int set);          // CPU half (any thread)
-  void stage_image_at(const uint8_t* gray, const uint8_t* mask, int set, int k);  // super-frame: frame k of the set
-  int enqueue_staged_super(int nf, hipStream_t s, std::string& err, int set);
+  void stage_image_at(const uint8_t* gray, const uint8_t* mask, int stage, int k);  // super-frame: frame k of staging buffer `stage`
+  int enqueue_staged_super(int nf, hipStream_t s, std::string& err, int set, int stage);
   int enqueue_staged(bool has_mask, hipStream_t s, std::string& err, int set);    // device half (the HIP thread)
   int ensure_alt(std::string& err);
   void use_set(int set);
@@ -47,8 +47,20 @@ struct OrbWorkspace {
                   std::vector<std::vector<KpOut>>& out, hipStream_t s, std::string& err);
   int grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::string& err);
   // super-frame workspace: the frames [0, nf) of the current image set in order (cell_mask_nonzero holds nf * grid^2 flags)
-  int super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err);
+  int super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err,
+                   const std::vector<int>* covered_floors = nullptr);
   void compute_prepare(std::vector<KpOut>& kps, int frame, std::vector<int>& order, std::vector<DescKp>& dk) const;
+  // software pipeline of the batch entry point: the device pass of super-frame s + 1 runs while the host replays the
+  // adjuster over super-frame s -- a pass's outputs (counts + keypoints, device and pinned host side) exist twice
+  int super_pass_enqueue(int nf, int set, int slot, hipStream_t s, std::string& err);
+  int super_replay(int nf, int set, int slot, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err);
+  void use_slot(int slot);
+  uint8_t* d_passout_slot[2] = {nullptr, nullptr}; uint8_t* h_passout_slot[2] = {nullptr, nullptr};
+  int* h_base_slot[2] = {nullptr, nullptr};
+  hipEvent_t ev_pass[2] = {nullptr, nullptr};
+  int slot_bound[2] = {0, 0};
+  std::vector<int> slot_floor[2];
+  uint8_t* himg_stage[3] = {nullptr, nullptr, nullptr};  // super-frame staging, three deep (pinned)
   double super_floor_factor = 0.49;  // floor of a super-frame pass = threshold x this (two x0.7 steps)
   long super_passes = 0;             // device passes run by super_detect (diagnostics)
   // enqueue_more (optional) is called after the descriptor work has been enqueued and before the one synchronisation,
@@ -83,6 +95,10 @@ struct OrbWorkspace {
   // device
   uint8_t* d_pool = nullptr; uint8_t* d_score = nullptr; uint8_t* d_blur = nullptr;
   ImgDesc* d_cell_imgs = nullptr; ImgDesc* d_frame_imgs = nullptr; ResizeJob* d_jobs = nullptr;
+  TileUnit* d_units = nullptr;  // workgroup lists: FAST tiles | blur tiles | cell-image rows | resize tiles per level
+  int units_fast_off = 0, units_fast_n = 0, units_blur_off = 0, units_blur_n = 0, units_rows_off = 0, units_rows_n = 0;
+  int units_resize_off[8] = {}, units_resize_n[8] = {};
+  uint64_t* d_keep = nullptr;  // NMS survivors, one bit per pixel of every (cell, level) image
   int* d_row_cnt = nullptr; int* d_img_total = nullptr;  // d_img_total and d_kps live inside d_passout
   uint8_t* d_passout = nullptr; uint8_t* h_passout = nullptr; size_t passout_hdr = 0;  // [per-image counts | keypoints]
   RawKp* d_kps = nullptr; DescKp* d_desckp = nullptr; uint8_t* d_desc = nullptr;

@@ -106,6 +106,13 @@ void OrbWorkspace::release() {
     timing.frames = 0;
   }
   if (ev_readback) { (void)hipEventDestroy(ev_readback); ev_readback = nullptr; }
+  if (d_passout_slot[0]) use_slot(0);  // the member pointers the frees below go through
+  if (d_passout_slot[1]) { (void)hipFree(d_passout_slot[1]); d_passout_slot[1] = nullptr; }
+  if (h_passout_slot[1]) { (void)hipHostFree(h_passout_slot[1]); h_passout_slot[1] = nullptr; }
+  if (h_base_slot[1]) { (void)hipHostFree(h_base_slot[1]); h_base_slot[1] = nullptr; }
+  d_passout_slot[0] = nullptr; h_passout_slot[0] = nullptr; h_base_slot[0] = nullptr;
+  for (int i = 0; i < 2; ++i) if (ev_pass[i]) { (void)hipEventDestroy(ev_pass[i]); ev_pass[i] = nullptr; }
+  for (int i = 0; i < 3; ++i) if (himg_stage[i]) { (void)hipHostFree(himg_stage[i]); himg_stage[i] = nullptr; }
   auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   // d_pool / d_blur / h_img alias one of the two sets
   for (int i = 0; i < 2; ++i) {
@@ -113,8 +120,8 @@ void OrbWorkspace::release() {
     if (himg_set[i]) { (void)hipHostFree(himg_set[i]); himg_set[i] = nullptr; }
   }
   d_pool = nullptr; d_blur = nullptr; h_img = nullptr;
-  fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs);
-  fr(d_row_cnt); fr(d_passout); fr(d_desckp); fr(d_desc); fr(d_kpxy);
+  fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_units);
+  fr(d_row_cnt); fr(d_keep); fr(d_passout); fr(d_desckp); fr(d_desc); fr(d_kpxy);
   d_img_total = nullptr; d_kps = nullptr;  // live inside d_passout
   fr(d_kept); fr(d_xyz); fr(d_n); fr(d_n_proj);
   auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
@@ -168,7 +175,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   frame_imgs.assign((size_t)kLevels * n_frames, ImgDesc{});
   jobs.clear();
   level_job_begin.assign(kLevels + 1, 0);
-  size_t score_off = 0, row_off = 0;
+  size_t score_off = 0, row_off = 0, keep_words = 0;
   max_w = max_h = 0;
   // geometry first
   std::vector<int> lw((size_t)n_cells * kLevels), lh((size_t)n_cells * kLevels);
@@ -193,6 +200,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
       }
       d.score_off = (uint32_t)score_off; score_off += (size_t)d.w * d.h;
       d.row_off = (int32_t)row_off; row_off += (size_t)d.h;
+      d.keep_off = (uint32_t)keep_words; keep_words += (size_t)d.h * (size_t)((d.w + 63) / 64);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
   size_t blur_off = 0;
@@ -224,6 +232,27 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
     for (int f = 0; f < n_frames; ++f) add(frame_imgs[(size_t)f * kLevels + l - 1], frame_imgs[(size_t)f * kLevels + l], false);
   }
   level_job_begin[kLevels] = (int)jobs.size();
+  // workgroup lists of the 2-D stages (orb_internal.h TileUnit): no empty workgroups for the small images of a step
+  std::vector<TileUnit> units;
+  auto add_tiles = [&](int img, int w, int h) {
+    for (int by = 0; by < (h + 3) / 4; ++by)
+      for (int bx = 0; bx < (w + 63) / 64; ++bx) units.push_back(TileUnit{(uint16_t)img, (uint16_t)bx, (uint16_t)by, 0});
+  };
+  units_fast_off = (int)units.size();
+  for (size_t i = 0; i < cell_imgs.size(); ++i) add_tiles((int)i, cell_imgs[i].w, cell_imgs[i].h);
+  units_fast_n = (int)units.size() - units_fast_off;
+  units_blur_off = (int)units.size();
+  for (size_t i = 0; i < frame_imgs.size(); ++i) add_tiles((int)i, frame_imgs[i].w, frame_imgs[i].h);
+  units_blur_n = (int)units.size() - units_blur_off;
+  units_rows_off = (int)units.size();
+  for (size_t i = 0; i < cell_imgs.size(); ++i)
+    for (int y = 0; y < cell_imgs[i].h; ++y) units.push_back(TileUnit{(uint16_t)i, 0, (uint16_t)y, 0});
+  units_rows_n = (int)units.size() - units_rows_off;
+  for (int l = 1; l < kLevels; ++l) {
+    units_resize_off[l] = (int)units.size();
+    for (int k = level_job_begin[l]; k < level_job_begin[l + 1]; ++k) add_tiles(k - level_job_begin[l], jobs[k].dw, jobs[k].dh);
+    units_resize_n[l] = (int)units.size() - units_resize_off[l];
+  }
   n_rows_total = (int)row_off;
   kp_cap = (int)(score_off / 4) + 64 * n_cells * kLevels;
   ORB_HIP(hipMalloc((void**)&d_pool, pool_bytes));
@@ -237,7 +266,10 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipMalloc((void**)&d_cell_imgs, sizeof(ImgDesc) * cell_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_frame_imgs, sizeof(ImgDesc) * frame_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_jobs, sizeof(ResizeJob) * jobs.size()));
+  ORB_HIP(hipMalloc((void**)&d_units, sizeof(TileUnit) * units.size()));
+  ORB_HIP(hipMemcpy(d_units, units.data(), sizeof(TileUnit) * units.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
+  ORB_HIP(hipMalloc((void**)&d_keep, sizeof(uint64_t) * (keep_words + 16)));
   // a pass's outputs in ONE buffer -- [per-image counts | keypoints] -- so that they come back in one copy
   passout_hdr = (sizeof(int) * cell_imgs.size() + 255) & ~(size_t)255;
   ORB_HIP(hipMalloc((void**)&d_passout, passout_hdr + sizeof(RawKp) * (size_t)kp_cap));
@@ -255,6 +287,14 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipHostMalloc((void**)&h_passout, passout_hdr + sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
   h_totals = reinterpret_cast<int*>(h_passout);
   h_raw = reinterpret_cast<RawKp*>(h_passout + passout_hdr);
+  d_passout_slot[0] = d_passout; h_passout_slot[0] = h_passout; h_base_slot[0] = h_base;
+  if (n_frames > 1) {
+    ORB_HIP(hipMalloc((void**)&d_passout_slot[1], passout_hdr + sizeof(RawKp) * (size_t)kp_cap));
+    ORB_HIP(hipHostMalloc((void**)&h_passout_slot[1], passout_hdr + sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
+    ORB_HIP(hipHostMalloc((void**)&h_base_slot[1], sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) ORB_HIP(hipEventCreateWithFlags(&ev_pass[i], hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) ORB_HIP(hipHostMalloc((void**)&himg_stage[i], (size_t)2 * W * H * n_frames, hipHostMallocDefault));
+  }
   ORB_HIP(hipHostMalloc((void**)&h_desckp, sizeof(DescKp) * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_desc, (size_t)32 * pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_xyz_in, sizeof(float) * 3 * (size_t)pin_cap, hipHostMallocDefault));
@@ -294,10 +334,7 @@ void OrbWorkspace::use_set(int set) {
 // 6.4 us per launch.  A level's launch is a chain of dependent memory round trips, not arithmetic; both were dropped.
 void OrbWorkspace::build_pyramids(uint8_t* pool, hipStream_t s) {
   for (int l = 1; l < kLevels; ++l) {
-    const int b = level_job_begin[l], e = level_job_begin[l + 1];
-    int mw = 0, mh = 0;
-    for (int k = b; k < e; ++k) { mw = std::max(mw, jobs[k].dw); mh = std::max(mh, jobs[k].dh); }
-    launch_orb_resize(pool, d_jobs + b, e - b, mw, mh, s);
+    launch_orb_resize(pool, d_jobs + level_job_begin[l], d_units + units_resize_off[l], units_resize_n[l], s);
   }
 }
 
@@ -343,7 +380,7 @@ int OrbWorkspace::upload_and_build(const uint8_t* gray, const uint8_t* mask, hip
   // The blurred levels are the descriptor kernel's input, not the detector's: on the single-call path (one stream) the blur
   // is enqueued by the first detection pass BEHIND its read-back, so that the pass does not queue up behind it.
   if (defer_blur) blur_pending = true;
-  else launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+  else launch_orb_blur(d_pool, d_frame_imgs, d_units + units_blur_off, units_blur_n, d_blur, s);
   ORB_HIP(hipGetLastError());
   return RGBDFE_OK;
 }
@@ -361,20 +398,30 @@ void OrbWorkspace::stage_images(const uint8_t* gray, const uint8_t* mask, int se
 }
 
 // super-frame variants: frame k of the super-frame at [k * 2WH, ...) of the staging buffer / pool, a missing mask as 255s
-void OrbWorkspace::stage_image_at(const uint8_t* gray, const uint8_t* mask, int set, int k) {
-  uint8_t* const h = himg_set[set] + (size_t)2 * W * H * k;
+void OrbWorkspace::use_slot(int slot) {
+  d_passout = d_passout_slot[slot];
+  d_img_total = reinterpret_cast<int*>(d_passout);
+  d_kps = reinterpret_cast<RawKp*>(d_passout + passout_hdr);
+  h_passout = h_passout_slot[slot];
+  h_totals = reinterpret_cast<int*>(h_passout);
+  h_raw = reinterpret_cast<RawKp*>(h_passout + passout_hdr);
+  h_base = h_base_slot[slot];
+}
+
+void OrbWorkspace::stage_image_at(const uint8_t* gray, const uint8_t* mask, int stage, int k) {
+  uint8_t* const h = himg_stage[stage] + (size_t)2 * W * H * k;
   const size_t img = (size_t)W * H;
   memcpy(h, gray, img);
   if (mask) memcpy(h + img, mask, img);
   else memset(h + img, 255, img);
 }
 
-int OrbWorkspace::enqueue_staged_super(int nf, hipStream_t s, std::string& err, int set) {
+int OrbWorkspace::enqueue_staged_super(int nf, hipStream_t s, std::string& err, int set, int stage) {
   uint8_t* const d_pool = pool_set[set];
   uint8_t* const d_blur = blur_set[set];
-  ORB_HIP(hipMemcpyAsync(d_pool, himg_set[set], (size_t)2 * W * H * nf, hipMemcpyHostToDevice, s));
+  ORB_HIP(hipMemcpyAsync(d_pool, himg_stage[stage], (size_t)2 * W * H * nf, hipMemcpyHostToDevice, s));
   build_pyramids(d_pool, s);
-  launch_orb_blur(d_pool, d_frame_imgs, kLevels * frames, W, H, d_blur, s);
+  launch_orb_blur(d_pool, d_frame_imgs, d_units + units_blur_off, units_blur_n, d_blur, s);
   ORB_HIP(hipGetLastError());
   return RGBDFE_OK;
 }
@@ -386,7 +433,7 @@ int OrbWorkspace::enqueue_staged(bool has_mask, hipStream_t s, std::string& err,
   ORB_HIP(hipMemcpyAsync(d_pool, himg_set[set], has_mask ? 2 * img : img, hipMemcpyHostToDevice, s));
   if (!has_mask) ORB_HIP(hipMemsetAsync(d_pool + img, 255, img, s));
   build_pyramids(d_pool, s);
-  launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+  launch_orb_blur(d_pool, d_frame_imgs, d_units + units_blur_off, units_blur_n, d_blur, s);
   ORB_HIP(hipGetLastError());
   return RGBDFE_OK;
 }
@@ -402,13 +449,15 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
     ctl.active[c] = c < n_cells ? active[c] : 0;
   }
   const int n_imgs = n_cells * kLevels;
-  launch_orb_fast_score(d_pool, d_cell_imgs, n_imgs, max_w, max_h, ctl, d_score, s);
-  launch_orb_nms_count(d_pool, d_cell_imgs, n_imgs, max_h, ctl, d_score, kDetectEdge, d_row_cnt, d_img_total, s);
+  launch_orb_fast_score(d_pool, d_cell_imgs, d_units + units_fast_off, units_fast_n, ctl, d_score, s);
+  launch_orb_nms_count(d_pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, kDetectEdge, d_row_cnt,
+                       d_img_total, d_keep, s);
   // One round trip per pass: the device scans the per-image counts itself, emits and measures the keypoints, and the
   // host reads counts and keypoints back together -- `bound` of them, a guess from the previous passes; a pass with
   // more keypoints than that pays a second round trip for the rest.
   const int bound = std::min(pin_cap, std::max(2048, 2 * last_n_total));
-  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, max_h, ctl, d_score, kDetectEdge, d_row_cnt, d_img_total, d_kps, bound, s);
+  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_cnt,
+                  d_img_total, d_kps, bound, s);
   ORB_HIP(hipGetLastError());
   ORB_HIP(hipMemcpyAsync(h_passout, d_passout, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));  // counts + keypoints
   bool wait_event = false;
@@ -416,7 +465,7 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
     blur_pending = false;
     if (!ev_readback) ORB_HIP(hipEventCreateWithFlags(&ev_readback, hipEventDisableTiming));
     ORB_HIP(hipEventRecord(ev_readback, s));
-    launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+    launch_orb_blur(d_pool, d_frame_imgs, d_units + units_blur_off, units_blur_n, d_blur, s);
     ORB_HIP(hipGetLastError());
     wait_event = true;
   }
@@ -577,6 +626,66 @@ int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::strin
   return RGBDFE_OK;
 }
 
+// The device half of a super-frame's detection pass, enqueued only (no wait): the frames [0, nf) of image set `set` at floor
+// thresholds derived from the detector's thresholds OF THIS MOMENT -- the replay of the previous super-frame may still
+// move them; a cell that ends up below its floor is re-run by super_replay.  Outputs go to pass slot `slot`.
+int OrbWorkspace::super_pass_enqueue(int nf, int set, int slot, hipStream_t s, std::string& err) {
+  const int pc = grid * grid;
+  OrbCtl ctl;
+  std::vector<int>& fl = slot_floor[slot];
+  fl.assign((size_t)n_cells, 0);
+  for (int c = 0; c < 64; ++c) {
+    ctl.thr[c] = 0; ctl.active[c] = 0;
+    if (c >= n_cells || c / pc >= nf) continue;
+    double next = thresh[c % pc] * super_floor_factor;
+    if (next < 2) next = 2;
+    fl[(size_t)c] = std::min((int)thresh[c % pc], (int)next);
+    ctl.thr[c] = fl[(size_t)c];
+    ctl.active[c] = 1;
+  }
+  uint8_t* const pool = pool_set[set];
+  uint8_t* const dpo = d_passout_slot[slot];
+  int* const img_total = reinterpret_cast<int*>(dpo);
+  RawKp* const kps = reinterpret_cast<RawKp*>(dpo + passout_hdr);
+  const int n_imgs = n_cells * kLevels;
+  launch_orb_fast_score(pool, d_cell_imgs, d_units + units_fast_off, units_fast_n, ctl, d_score, s);
+  launch_orb_nms_count(pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, kDetectEdge, d_row_cnt,
+                       img_total, d_keep, s);
+  const int bound = std::min(pin_cap, std::max(2048 * frames, 2 * last_n_total));
+  slot_bound[slot] = bound;
+  launch_orb_emit(pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_cnt,
+                  img_total, kps, bound, s);
+  ORB_HIP(hipGetLastError());
+  ORB_HIP(hipMemcpyAsync(h_passout_slot[slot], dpo, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
+  ORB_HIP(hipEventRecord(ev_pass[slot], s));
+  super_passes++;
+  return RGBDFE_OK;
+}
+
+// The host half: waits for the slot's pass, then replays the adjuster frame by frame exactly as super_detect does (see
+// there); re-passes (a threshold fell below its floor) run synchronously behind whatever the stream already holds.
+int OrbWorkspace::super_replay(int nf, int set, int slot, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s,
+                               std::string& err) {
+  ORB_HIP(hipEventSynchronize(ev_pass[slot]));
+  use_slot(slot);
+  use_set(set);
+  const int n_imgs = n_cells * kLevels;
+  int n_total = 0;
+  for (int i = 0; i < n_imgs; ++i) { h_base[i] = n_total; n_total += h_totals[i]; }
+  if (n_total > kp_cap) { err = "keypoint capacity exceeded"; return RGBDFE_ERR_CAPACITY; }
+  last_n_total = n_total;
+  pass_raw = h_raw;
+  if (n_total > slot_bound[slot]) {  // more corners than the speculative read-back: the rest in a second trip
+    launch_orb_measure_rest(d_pool, d_cell_imgs, d_kps, d_img_total, n_imgs, slot_bound[slot], n_total - slot_bound[slot], s);
+    ORB_HIP(hipGetLastError());
+    pass_raw_big.resize((size_t)n_total);
+    ORB_HIP(hipMemcpyAsync(pass_raw_big.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
+    ORB_HIP(hipStreamSynchronize(s));
+    pass_raw = pass_raw_big.data();
+  }
+  return super_detect(nf, kps_per_frame, s, err, &slot_floor[slot]);
+}
+
 // VideoGridAdaptedFeatureDetector::detect for the frames [0, nf) of a super-frame, IN ORDER: frame f + 1 starts from the
 // per-cell thresholds frame f leaves behind (feature_adjuster.cpp:185-224), exactly as nf calls of grid_detect would.
 // What makes one device pass serve all of them: the corners at threshold t are the corners at any floor f <= t whose
@@ -584,11 +693,14 @@ int OrbWorkspace::grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::strin
 // end up with, and the adjuster is replayed on the host over the scored corners, frame by frame.  A cell whose threshold
 // drops below its floor (rare: two x0.7 steps inside one super-frame) triggers another pass over the frames from there
 // on, with floors taken from the thresholds of that moment -- results do not depend on the floors.
-int OrbWorkspace::super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err) {
+int OrbWorkspace::super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err,
+                               const std::vector<int>* covered_floors) {
   const int pc = grid * grid;
   std::vector<std::vector<KpOut>> cellkp((size_t)n_cells);
   std::vector<int> act((size_t)n_cells, 0), thr((size_t)n_cells, 0), floor_thr((size_t)n_cells, 0);
   std::vector<char> covered((size_t)n_cells, 0);
+  if (covered_floors)  // a pass over all nf frames at these floors has already been read back (super_replay)
+    for (int c = 0; c < n_cells && c / pc < nf; ++c) { covered[c] = 1; floor_thr[c] = (*covered_floors)[(size_t)c]; }
   kps_per_frame.assign((size_t)nf, std::vector<KpOut>());
   auto run_pass = [&](int f_from) -> int {
     std::vector<int> pa((size_t)n_cells, 0);
@@ -709,7 +821,7 @@ int OrbWorkspace::compute_enqueue(std::vector<KpOut>& kps, std::vector<uint8_t>&
   // !sortedByLevel branch); `order` = the surviving input positions in output order
   if (blur_pending) {  // no detection pass took it along (cannot happen on the paths that defer it)
     blur_pending = false;
-    launch_orb_blur(d_pool, d_frame_imgs, kLevels, W, H, d_blur, s);
+    launch_orb_blur(d_pool, d_frame_imgs, d_units + units_blur_off, units_blur_n, d_blur, s);
   }
   const double tc0 = timing.on ? orb_now_us() : 0;
   std::vector<int> order;

@@ -20,6 +20,7 @@ struct ImgDesc {
   int32_t cell;        // grid cell (index into thresholds / active flags)
   int32_t level;
   int32_t row_off;     // first entry of this image in the row-count array
+  uint32_t keep_off;   // first 64-bit word of this image in the keep-mask array (ceil(w / 64) words per row)
 };
 
 struct ResizeJob {
@@ -47,18 +48,25 @@ struct OrbCtl {
   int32_t active[64];
 };
 
-void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max_w, int max_h, hipStream_t s);
-void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, const OrbCtl& ctl,
+// one workgroup of a 2-D stage: tile (bx, by) of 64 x 4 pixels of image / resize job `img`; for the row stages (one wave per
+// image row) by is the row
+struct TileUnit {
+  uint16_t img, bx, by, pad;
+};
+
+void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, const TileUnit* units, int n_units, hipStream_t s);
+void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, const OrbCtl& ctl,
                            uint8_t* score_pool, hipStream_t s);
-void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
-                          const uint8_t* score_pool, int edge, int* row_cnt, int* img_total, hipStream_t s);
+void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
+                          const OrbCtl& ctl, const uint8_t* score_pool, int edge, int* row_cnt, int* img_total,
+                          uint64_t* keep_mask, hipStream_t s);
 // img_total[n_imgs] (the per-image counts) doubles as the source of every prefix the later kernels need: no scan launch
-void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
-                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, RawKp* out,
-                     int measure_bound, hipStream_t s);
+void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
+                     const OrbCtl& ctl, const uint8_t* score_pool, const uint64_t* keep_mask, const int* row_off,
+                     const int* img_total, RawKp* out, int measure_bound, hipStream_t s);
 void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* img_total, int n_imgs,
                              int first, int count, hipStream_t s);
-void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
+void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,
                      hipStream_t s);
 void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,
                       uint8_t* desc, hipStream_t s);

@@ -29,10 +29,14 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // cv::resize(..., INTER_LINEAR) for 8-bit images (fixed point, INTER_RESIZE_COEF_BITS = 11), one
 // pyramid level for every job in the launch; the mask variant applies threshold(254, TOZERO).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs) {
-  const ResizeJob j = jobs[blockIdx.z];
-  const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+// (every 2-D stage walks a host-built list of (image, tile) units: the images of a step differ in size by a factor of 13,
+// a grid sized for the largest one would be mostly empty workgroups)
+__global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
+                                                         const TileUnit* __restrict__ units) {
+  const TileUnit u = units[blockIdx.x];
+  const ResizeJob j = jobs[u.img];
+  const int dx = u.bx * 64 + (threadIdx.x & 63);
+  const int dy = u.by * 4 + (threadIdx.x >> 6);
   if (dx >= j.dw || dy >= j.dh) return;
   const uint8_t* __restrict__ src = pool + j.src_off;
   float fx = (float)((dx + 0.5) * j.scale_x - 0.5);
@@ -111,11 +115,13 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ ptr, int s
 
 __global__ __launch_bounds__(256) void orb_fast_score_kernel(const uint8_t* __restrict__ pool,
                                                              const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
-                                                             uint8_t* __restrict__ score_pool) {
-  const ImgDesc im = imgs[blockIdx.z];
+                                                             uint8_t* __restrict__ score_pool,
+                                                             const TileUnit* __restrict__ units) {
+  const TileUnit u = units[blockIdx.x];
+  const ImgDesc im = imgs[u.img];
   if (!ctl.active[im.cell]) return;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int x = u.bx * 64 + (threadIdx.x & 63);
+  const int y = u.by * 4 + (threadIdx.x >> 6);
   if (x >= im.w || y >= im.h) return;
   int s = 0;
   if (x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3) {
@@ -143,20 +149,28 @@ __device__ __forceinline__ bool nms_keep(const uint8_t* __restrict__ sc, const u
   return x >= edge && x < im.w - edge && y >= edge && y < im.h - edge;
 }
 
-// one wave per image row: count the keypoints of the row
+// one wave per image row: count the keypoints of the row and leave their positions as one bit per pixel (64 pixels per
+// word), so that the emit stage does not evaluate the 3x3 test a second time
 __global__ __launch_bounds__(64) void orb_nms_count_kernel(const uint8_t* __restrict__ pool,
                                                            const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                            const uint8_t* __restrict__ score_pool, int edge,
-                                                           int* __restrict__ row_cnt) {
-  const ImgDesc im = imgs[blockIdx.y];
-  const int y = blockIdx.x;
+                                                           int* __restrict__ row_cnt,
+                                                           const TileUnit* __restrict__ rows,
+                                                           uint64_t* __restrict__ keep_mask) {
+  const TileUnit u = rows[blockIdx.x];   // one wave per image row
+  const ImgDesc im = imgs[u.img];
+  const int y = u.by;
   if (y >= im.h || !ctl.active[im.cell]) return;
   const uint8_t* sc = score_pool + im.score_off;
+  const int words = (im.w + 63) >> 6;
+  uint64_t* __restrict__ km = keep_mask + im.keep_off + (size_t)y * words;
   int cnt = 0;
   for (int x0 = 0; x0 < im.w; x0 += 64) {
     int s;
     const bool keep = nms_keep(sc, pool, im, x0 + (int)threadIdx.x, y, edge, s);
-    cnt += __popcll(__ballot(keep));
+    const uint64_t m = __ballot(keep);
+    if (threadIdx.x == 0) km[x0 >> 6] = m;
+    cnt += __popcll(m);
   }
   if (threadIdx.x == 0) row_cnt[im.row_off + y] = cnt;
 }
@@ -189,15 +203,22 @@ __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __rest
 
 // one wave per image row: write the keypoints of the row at img_base + row_offset + rank (raster order)
 __device__ __forceinline__ int wave_sum(int v);
-__global__ __launch_bounds__(64) void orb_emit_kernel(const uint8_t* __restrict__ pool,
-                                                      const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
-                                                      const uint8_t* __restrict__ score_pool, int edge,
+__global__ __launch_bounds__(64) void orb_emit_kernel(const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
+                                                      const uint8_t* __restrict__ score_pool,
+                                                      const uint64_t* __restrict__ keep_mask,
                                                       const int* __restrict__ row_off, const int* __restrict__ img_total,
-                                                      RawKp* __restrict__ out) {
-  const int img = blockIdx.y;
+                                                      RawKp* __restrict__ out, const TileUnit* __restrict__ rows) {
+  const TileUnit u = rows[blockIdx.x];
+  const int img = u.img;
   const ImgDesc im = imgs[img];
-  const int y = blockIdx.x;
+  const int y = u.by;
   if (y >= im.h || !ctl.active[im.cell]) return;
+  const int words = (im.w + 63) >> 6;
+  const uint64_t* __restrict__ km = keep_mask + im.keep_off + (size_t)y * words;
+  // a row without keypoints (most rows) costs its mask words only
+  uint64_t any = 0;
+  for (int wd = (int)threadIdx.x; wd < words; wd += 64) any |= km[wd];
+  if (__ballot(any != 0) == 0) return;
   const uint8_t* sc = score_pool + im.score_off;
   // where this image's keypoints start = the keypoints of the images before it (at most 512 counts: a wave sums them,
   // which is cheaper than a scan launch in front of this kernel)
@@ -208,15 +229,14 @@ __global__ __launch_bounds__(64) void orb_emit_kernel(const uint8_t* __restrict_
   }
   img_base = wave_sum(img_base);
   int base = img_base + row_off[im.row_off + y];
-  for (int x0 = 0; x0 < im.w; x0 += 64) {
-    int s = 0;
-    const int x = x0 + (int)threadIdx.x;
-    const bool keep = nms_keep(sc, pool, im, x, y, edge, s);
-    const uint64_t m = __ballot(keep);
-    if (keep) {
+  for (int wd = 0; wd < words; ++wd) {
+    const uint64_t m = km[wd];
+    if (!m) continue;
+    const int x = wd * 64 + (int)threadIdx.x;
+    if ((m >> threadIdx.x) & 1) {
       const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       RawKp k;
-      k.x = (uint16_t)x; k.y = (uint16_t)y; k.img = (uint16_t)img; k.score = (uint16_t)s;
+      k.x = (uint16_t)x; k.y = (uint16_t)y; k.img = (uint16_t)img; k.score = (uint16_t)sc[(size_t)y * im.w + x];
       k.harris = 0.f; k.angle = 0.f;
       out[base + rank] = k;
     }
@@ -309,10 +329,11 @@ __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restr
 __constant__ int c_gauss[7] = {18, 34, 49, 55, 49, 34, 18};
 
 __global__ __launch_bounds__(256) void orb_blur_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
-                                                       uint8_t* __restrict__ blur_pool) {
-  const ImgDesc im = imgs[blockIdx.z];
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+                                                       uint8_t* __restrict__ blur_pool, const TileUnit* __restrict__ units) {
+  const TileUnit u = units[blockIdx.x];
+  const ImgDesc im = imgs[u.img];
+  const int x = u.bx * 64 + (threadIdx.x & 63);
+  const int y = u.by * 4 + (threadIdx.x >> 6);
   if (x >= im.w || y >= im.h) return;
   const uint8_t* __restrict__ src = pool + im.off;
   int xs[7];
@@ -379,29 +400,29 @@ __global__ __launch_bounds__(256) void orb_brief_kernel(const uint8_t* __restric
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, int n_jobs, int max_w, int max_h, hipStream_t s) {
-  if (n_jobs == 0) return;
-  hipLaunchKernelGGL(orb_resize_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_jobs), dim3(256), 0, s, pool, jobs);
+void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, const TileUnit* units, int n_units, hipStream_t s) {
+  if (n_units == 0) return;
+  hipLaunchKernelGGL(orb_resize_kernel, dim3(n_units), dim3(256), 0, s, pool, jobs, units);
 }
-void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, const OrbCtl& ctl,
+void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, const OrbCtl& ctl,
                            uint8_t* score_pool, hipStream_t s) {
-  hipLaunchKernelGGL(orb_fast_score_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_imgs), dim3(256), 0, s, pool,
-                     imgs, ctl, score_pool);
+  hipLaunchKernelGGL(orb_fast_score_kernel, dim3(n_units), dim3(256), 0, s, pool, imgs, ctl, score_pool, units);
 }
-void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
-                          const uint8_t* score_pool, int edge, int* row_cnt, int* img_total, hipStream_t s) {
-  hipLaunchKernelGGL(orb_nms_count_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, ctl, score_pool, edge,
-                     row_cnt);
+void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
+                          const OrbCtl& ctl, const uint8_t* score_pool, int edge, int* row_cnt, int* img_total,
+                          uint64_t* keep_mask, hipStream_t s) {
+  hipLaunchKernelGGL(orb_nms_count_kernel, dim3(n_rows), dim3(64), 0, s, pool, imgs, ctl, score_pool, edge, row_cnt, rows,
+                     keep_mask);
   hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, ctl, row_cnt, img_total);
 }
 // Keypoints of every active image in raster order, then Harris response + orientation for the first `measure_bound` of
 // them -- all without the host knowing the count (it reads img_total back together with the keypoints; a frame with more
 // keypoints than the bound gets the rest measured by launch_orb_measure_rest).
-void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_h, const OrbCtl& ctl,
-                     const uint8_t* score_pool, int edge, const int* row_off, const int* img_total, RawKp* out,
-                     int measure_bound, hipStream_t s) {
-  hipLaunchKernelGGL(orb_emit_kernel, dim3(max_h, n_imgs), dim3(64), 0, s, pool, imgs, ctl, score_pool, edge, row_off,
-                     img_total, out);
+void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
+                     const OrbCtl& ctl, const uint8_t* score_pool, const uint64_t* keep_mask, const int* row_off,
+                     const int* img_total, RawKp* out, int measure_bound, hipStream_t s) {
+  hipLaunchKernelGGL(orb_emit_kernel, dim3(n_rows), dim3(64), 0, s, imgs, ctl, score_pool, keep_mask, row_off, img_total,
+                     out, rows);
   if (measure_bound > 0)
     hipLaunchKernelGGL(orb_measure_kernel, dim3((measure_bound + 3) / 4), dim3(256), 0, s, pool, imgs, out, img_total,
                        n_imgs, 0);
@@ -412,10 +433,9 @@ void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* ou
     hipLaunchKernelGGL(orb_measure_kernel, dim3((count + 3) / 4), dim3(256), 0, s, pool, imgs, out, img_total, n_imgs,
                        first);
 }
-void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, int max_w, int max_h, uint8_t* blur_pool,
+void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,
                      hipStream_t s) {
-  hipLaunchKernelGGL(orb_blur_kernel, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_imgs), dim3(256), 0, s, pool, imgs,
-                     blur_pool);
+  hipLaunchKernelGGL(orb_blur_kernel, dim3(n_units), dim3(256), 0, s, pool, imgs, blur_pool, units);
 }
 void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,
                       uint8_t* desc, hipStream_t s) {

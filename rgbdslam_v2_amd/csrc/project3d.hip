@@ -182,6 +182,70 @@ void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int 
                        cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out, z_gathered);
 }
 
+// Several frames in one launch (the super-frame batch path of rgbdfe_detect_describe_batch): block f projects the keypoints
+// [off[f], off[f] + n[f]) of the concatenated buffers -- a frame's input block holds 2 n (x, y) floats followed by its n
+// depths depth.at<float>(round(y), round(x)), looked up by the caller.  project_to_3d_kernel<false>'s arithmetic and
+// order-preserving compaction (node.cpp:931-957, misc2.h:62-64).
+__global__ __launch_bounds__(256) void project_to_3d_frames_kernel(ProjectFrames fr, const float* __restrict__ kpxy, int rows,
+                                                                   int cols, float fxinv, float fyinv, float cx, float cy,
+                                                                   double depth_scaling, int max_keypoints,
+                                                                   int32_t* __restrict__ kept_all, float4* __restrict__ xyz_all,
+                                                                   int32_t* __restrict__ n_out) {
+  __shared__ uint32_t wave_cnt[4];
+  const int f = blockIdx.x;
+  const int n_kp = fr.n[f];
+  const float* __restrict__ in = kpxy + (size_t)3 * fr.off[f];
+  const float* __restrict__ zg = in + (size_t)2 * n_kp;
+  int32_t* __restrict__ kept_idx = kept_all + fr.off[f];
+  float4* __restrict__ xyz1 = xyz_all + fr.off[f];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  uint32_t base = 0;
+  for (int c0 = 0; c0 < n_kp; c0 += 256) {
+    const int i = c0 + tid;
+    bool keep = false;
+    float px = 0.f, py = 0.f, Z = 0.f;
+    if (i < n_kp) {
+      px = in[2 * i]; py = in[2 * i + 1];
+      const bool bad = px >= (float)cols || px < 0.f || py >= (float)rows || py < 0.f || __builtin_isnan(px) ||
+                       __builtin_isnan(py);
+      if (!bad) {
+        Z = (float)((double)zg[i] * depth_scaling);
+        keep = !__builtin_isnan(Z);
+      }
+    }
+    const uint64_t m = __ballot(keep);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base;
+    for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+    const uint32_t chunk_total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    const uint32_t pos = off + rank;
+    if (keep && pos < (uint32_t)max_keypoints) {
+      float4 o;
+      o.x = (px - cx) * Z * fxinv;
+      o.y = (py - cy) * Z * fyinv;
+      o.z = Z;
+      o.w = 1.0f;
+      xyz1[pos] = o;
+      kept_idx[pos] = i;
+    }
+    base += chunk_total;
+    __syncthreads();
+    if (base >= (uint32_t)max_keypoints) break;
+  }
+  if (tid == 0) n_out[f] = (int32_t)min(base, (uint32_t)max_keypoints);
+}
+
+void launch_project_to_3d_frames(const ProjectFrames& fr, const float* kpxy, int rows, int cols, float fxinv, float fyinv,
+                                 float cx, float cy, double depth_scaling, int max_keypoints, int32_t* kept_idx, float4* xyz1,
+                                 int32_t* n_out, hipStream_t stream) {
+  if (fr.n_frames > 0)
+    hipLaunchKernelGGL(project_to_3d_frames_kernel, dim3(fr.n_frames), dim3(256), 0, stream, fr, kpxy, rows, cols, fxinv,
+                       fyinv, cx, cy, depth_scaling, max_keypoints, kept_idx, xyz1, n_out);
+}
+
 // getMinDepthInNeighborhood (misc.cpp:774-793), the depth lookup of "use_feature_min_depth" (parameter_server.cpp:90):
 // the smallest non-NaN depth of the keypoint's neighbourhood -- rows [int(y - r), int(y + r)) x cols [int(x - r),
 // int(x + r)), r = int((size - 1) / 2), clamped to the image; no comparable value or a minimum of 0 gives NaN.

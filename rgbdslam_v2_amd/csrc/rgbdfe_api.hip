@@ -1611,8 +1611,8 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   const int S = (n_frames + B - 1) / B;
   auto first_of = [&](int s) { return s * B; };
   auto count_of = [&](int s) { return std::min(B, n_frames - s * B); };
-  // helper thread: the caller's pageable images of super-frame s -> the pinned staging buffer of set s & 1, as soon as
-  // super-frame s - 2 (the set's previous user) has been detected (its upload from that buffer is complete then)
+  // helper thread: the caller's pageable images of super-frame s -> pinned staging buffer s % 3, as soon as super-frame
+  // s - 3 (the buffer's previous user) has been detected (its upload from that buffer is complete then)
   std::mutex m;
   std::condition_variable cv;
   int staged = 0, detected = 0;
@@ -1621,12 +1621,12 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     for (int s = 0; s < S; ++s) {
       {
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return stop || detected >= s - 1; });
+        cv.wait(l, [&] { return stop || detected >= s - 2; });
         if (stop) return;
       }
       for (int k = 0; k < count_of(s); ++k) {
         const int f = first_of(s) + k;
-        orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s & 1, k);
+        orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s % 3, k);
       }
       std::lock_guard<std::mutex> l(m);
       staged = s + 1;
@@ -1651,7 +1651,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
       cv.wait(l, [&] { return staged > s; });
     }
     if (s >= 2 && hipStreamWaitEvent(up, ctx->orb_describe_done[s & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
-    const int r = orb.enqueue_staged_super(count_of(s), up, err, s & 1);
+    const int r = orb.enqueue_staged_super(count_of(s), up, err, s & 1, s % 3);
     if (r != RGBDFE_OK) return r;
     if (hipEventRecord(ctx->orb_upload_done[s & 1], up) != hipSuccess) { err = "hipEventRecord"; return RGBDFE_ERR_HIP; }
     return RGBDFE_OK;
@@ -1690,14 +1690,11 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
           hipMemcpyAsync(orb.d_kpxy, orb.h_xyz_in, sizeof(float) * 3 * (size_t)tot, hipMemcpyHostToDevice, st2) != hipSuccess)
         return RGBDFE_ERR_HIP;
       launch_orb_brief(pool_dev, blur_dev, orb.d_frame_imgs, orb.d_desckp, tot, orb.d_desc, st2);
-      for (int k = 0; k < nf; ++k) {
-        const SuperFrameJob& j = J[(size_t)k];
-        const int n = (int)j.kps.size();
-        if (n == 0) continue;
-        launch_project_to_3d(orb.d_kpxy + (size_t)3 * j.off, n, nullptr, rows, cols, (float)(1. / fx), (float)(1. / fy),
-                             (float)cx, (float)cy, depth_scaling, max_kp, orb.d_kept + j.off, orb.d_xyz + j.off,
-                             orb.d_n_proj + k, st2, false, orb.d_kpxy + (size_t)3 * j.off + (size_t)2 * n);
-      }
+      ProjectFrames pf{};
+      pf.n_frames = nf;
+      for (int k = 0; k < nf; ++k) { pf.off[k] = J[(size_t)k].off; pf.n[k] = (int)J[(size_t)k].kps.size(); }
+      launch_project_to_3d_frames(pf, orb.d_kpxy, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx, (float)cy,
+                                  depth_scaling, max_kp, orb.d_kept, orb.d_xyz, orb.d_n_proj, st2);
       if (hipGetLastError() != hipSuccess) return RGBDFE_ERR_HIP;
       if (hipMemcpyAsync(orb.h_desc, orb.d_desc, (size_t)32 * tot, hipMemcpyDeviceToHost, st2) != hipSuccess ||
           hipMemcpyAsync(orb.h_xyz_out, orb.d_xyz, sizeof(float) * 4 * (size_t)tot, hipMemcpyDeviceToHost, st2) != hipSuccess ||
@@ -1724,11 +1721,33 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     }
     return RGBDFE_OK;
   };
+  static const bool tm = getenv("RGBDFE_DETECT_TIMING") && atoi(getenv("RGBDFE_DETECT_TIMING")) != 0;
+  double t_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // mask scan, super_detect, hook: describe enqueue, hook: upload enqueue, finish, prepare start, pool wait
+  double tq = tm ? orb_now_us() : 0;
+  auto lap = [&](int i) { if (tm) { const double now = orb_now_us(); t_us[i] += now - tq; tq = now; } };
+  orb.timing.on = tm;
+  const long passes0 = orb.super_passes;
+  // Software pipeline: the device pass of super-frame s + 1 is enqueued BEFORE the host replays the adjuster over
+  // super-frame s (its floors come from the thresholds of that moment; a cell that falls below its floor is re-run by
+  // super_replay), so the device works on s + 1 while the host selects keypoints of s; description of s - 1 and the
+  // upload of s + 1 are enqueued in between, the CPU halves of the descriptions run on the worker threads.
+  auto pass_enqueue = [&](int s) -> int {
+    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[s & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
+    return orb.super_pass_enqueue(count_of(s), s & 1, s & 1, ctx->stream, err);
+  };
   rc = enqueue_upload(0);
+  if (rc == RGBDFE_OK) rc = pass_enqueue(0);
   for (int s = 0; s < S && rc == RGBDFE_OK; ++s) {
     const int nf = count_of(s);
-    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[s & 1], 0) != hipSuccess) { rc = RGBDFE_ERR_HIP; err = "hipStreamWaitEvent"; break; }
-    orb.use_set(s & 1);
+    if (tm) tq = orb_now_us();
+    if (s > 0) { rc = enqueue_describe(s - 1); if (rc != RGBDFE_OK) break; }
+    lap(2);
+    if (s + 1 < S) {
+      rc = enqueue_upload(s + 1);
+      if (rc == RGBDFE_OK) rc = pass_enqueue(s + 1);
+      if (rc != RGBDFE_OK) break;
+    }
+    lap(3);
     // hasNonZero(sub_mask) per (frame, cell) (feature_adjuster.cpp:175-183)
     orb.cell_mask_nonzero.assign((size_t)orb.n_cells, 1);
     for (int k = 0; k < nf; ++k) {
@@ -1745,29 +1764,30 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
         orb.cell_mask_nonzero[(size_t)k * pc + c9] = nz;
       }
     }
-    int rc_hook = RGBDFE_OK;
-    orb.before_wait = [&, s]() -> int {   // rides on the device time of this super-frame's first pass
-      if (s > 0) rc_hook = enqueue_describe(s - 1);
-      if (rc_hook == RGBDFE_OK && s + 1 < S) rc_hook = enqueue_upload(s + 1);
-      return rc_hook;
-    };
+    lap(0);
     std::vector<std::vector<KpOut>> kps;
-    rc = orb.super_detect(nf, kps, ctx->stream, err);
-    if (rc == RGBDFE_OK && orb.before_wait) {  // (a super-frame always runs a pass; never lose the hook)
-      std::function<int()> f = std::move(orb.before_wait);
-      orb.before_wait = nullptr;
-      rc = f();
-    }
-    orb.before_wait = nullptr;
+    rc = orb.super_replay(nf, s & 1, s & 1, kps, ctx->stream, err);
     if (rc != RGBDFE_OK) break;
     {
       std::lock_guard<std::mutex> l(m);
       detected = s + 1;
     }
     cv.notify_all();
+    lap(1);
     if (s > 0) { rc = finish(s - 1); if (rc != RGBDFE_OK) break; }
+    lap(4);
     for (int k = 0; k < nf; ++k) jobs[s & 1][(size_t)k].kps.swap(kps[(size_t)k]);
     start_prepare(s);
+    lap(5);
+  }
+  if (tm) {
+    fprintf(stderr, "[rgbdfe super-frame timing] %d frames in %d super-frames, %ld device passes; per frame (us): mask scan %.1f, "
+            "replay incl. wait for its pass %.1f, describe enqueue %.1f, upload + next pass enqueue %.1f (re-passes: enqueue %.1f, "
+            "wait %.1f; selections %.1f), finish %.1f, prepare start %.1f\n", (int)n_frames, S, orb.super_passes - passes0,
+            t_us[0] / n_frames, t_us[1] / n_frames, t_us[2] / n_frames, t_us[3] / n_frames, orb.timing.us[2] / n_frames,
+            orb.timing.us[3] / n_frames, orb.timing.us[4] / n_frames, t_us[4] / n_frames, t_us[5] / n_frames);
+    for (double& u : orb.timing.us) u = 0;
+    orb.timing.frames = 0; orb.timing.passes = 0;
   }
   if (rc == RGBDFE_OK) rc = enqueue_describe(S - 1);
   if (rc == RGBDFE_OK) rc = finish(S - 1);
