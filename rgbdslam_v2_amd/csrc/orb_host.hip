@@ -234,15 +234,15 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   level_job_begin[kLevels] = (int)jobs.size();
   // workgroup lists of the 2-D stages (orb_internal.h TileUnit): no empty workgroups for the small images of a step
   std::vector<TileUnit> units;
-  auto add_tiles = [&](int img, int w, int h) {
-    for (int by = 0; by < (h + 3) / 4; ++by)
+  auto add_tiles = [&](int img, int w, int h, int th = 4) {
+    for (int by = 0; by < (h + th - 1) / th; ++by)
       for (int bx = 0; bx < (w + 63) / 64; ++bx) units.push_back(TileUnit{(uint16_t)img, (uint16_t)bx, (uint16_t)by, 0});
   };
   units_fast_off = (int)units.size();
   for (size_t i = 0; i < cell_imgs.size(); ++i) add_tiles((int)i, cell_imgs[i].w, cell_imgs[i].h);
   units_fast_n = (int)units.size() - units_fast_off;
   units_blur_off = (int)units.size();
-  for (size_t i = 0; i < frame_imgs.size(); ++i) add_tiles((int)i, frame_imgs[i].w, frame_imgs[i].h);
+  for (size_t i = 0; i < frame_imgs.size(); ++i) add_tiles((int)i, frame_imgs[i].w, frame_imgs[i].h, 16);  // orb_blur_kernel: 64 x 16
   units_blur_n = (int)units.size() - units_blur_off;
   units_rows_off = (int)units.size();
   for (size_t i = 0; i < cell_imgs.size(); ++i)
@@ -271,7 +271,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
   ORB_HIP(hipMalloc((void**)&d_keep, sizeof(uint64_t) * (keep_words + 16)));
   // a pass's outputs in ONE buffer -- [per-image counts | keypoints] -- so that they come back in one copy
-  passout_hdr = (sizeof(int) * cell_imgs.size() + 255) & ~(size_t)255;
+  passout_hdr = (sizeof(int) * (cell_imgs.size() + 1) + 255) & ~(size_t)255;  // per-image counts + their sum
   ORB_HIP(hipMalloc((void**)&d_passout, passout_hdr + sizeof(RawKp) * (size_t)kp_cap));
   d_img_total = reinterpret_cast<int*>(d_passout);
   d_kps = reinterpret_cast<RawKp*>(d_passout + passout_hdr);

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(64) void orb_nms_count_kernel(const uint8_t* __rest
                                                            const uint8_t* __restrict__ score_pool, int edge,
                                                            int* __restrict__ row_cnt,
                                                            const TileUnit* __restrict__ rows,
-                                                           uint64_t* __restrict__ keep_mask) {
+                                                           uint64_t* __restrict__ keep_mask,
+                                                           int* __restrict__ grand_total) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *grand_total = 0;   // the row scan (next launch) adds the per-image totals
   const TileUnit u = rows[blockIdx.x];   // one wave per image row
   const ImgDesc im = imgs[u.img];
   const int y = u.by;
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(64) void orb_nms_count_kernel(const uint8_t* __rest
 
 // one block per image: exclusive scan of the row counts, total per image
 __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
-                                                           int* __restrict__ row_cnt, int* __restrict__ img_total) {
+                                                           int* __restrict__ row_cnt, int* __restrict__ img_total,
+                                                           int* __restrict__ grand_total) {
   __shared__ int part[256];
   const ImgDesc im = imgs[blockIdx.x];
   if (!ctl.active[im.cell]) { if (threadIdx.x == 0) img_total[blockIdx.x] = 0; return; }
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __rest
     int acc = 0;
     for (int i = 0; i < 256; ++i) { const int t = part[i]; part[i] = acc; acc += t; }
     img_total[blockIdx.x] = acc;
+    if (acc) atomicAdd(grand_total, acc);   // (zeroed by the NMS launch's memset) the measure waves read one word
   }
   __syncthreads();
   int acc = part[threadIdx.x];
@@ -284,9 +288,8 @@ __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restr
                                                           int n_imgs, int first) {
   const int k = first + blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  int n_total = 0;  // how many keypoints there are: the host has not seen the counts yet
-  for (int j0 = 0; j0 < n_imgs; j0 += 64) n_total += j0 + lane < n_imgs ? img_total[j0 + lane] : 0;
-  n_total = wave_sum(n_total);
+  // how many keypoints there are (the host has not seen the counts yet): the scan left the sum behind the per-image counts
+  const int n_total = img_total[n_imgs];
   if (k >= n_total) return;
   RawKp kp = kps[k];
   const ImgDesc im = imgs[kp.img];
@@ -328,29 +331,45 @@ __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restr
 // ------------------------------------------------------------------------------------------------
 __constant__ int c_gauss[7] = {18, 34, 49, 55, 49, 34, 18};
 
+// Separable through LDS: the reference sums c[j] * (sum_i c[i] * p[y+j][x+i]) -- the inner sums h are shared by the 7
+// output rows that use them (integer arithmetic: the same numbers whatever the order of evaluation).  A block owns 64 x 16
+// output pixels: 22 x 70 source bytes (reflect-101 coordinates) -> 22 x 64 row sums -> 16 x 64 outputs.
+constexpr int kBlurTH = 16;
 __global__ __launch_bounds__(256) void orb_blur_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
                                                        uint8_t* __restrict__ blur_pool, const TileUnit* __restrict__ units) {
+  __shared__ uint8_t patch[(kBlurTH + 6) * 72];
+  __shared__ int hsum[(kBlurTH + 6) * 64];
   const TileUnit u = units[blockIdx.x];
   const ImgDesc im = imgs[u.img];
-  const int x = u.bx * 64 + (threadIdx.x & 63);
-  const int y = u.by * 4 + (threadIdx.x >> 6);
-  if (x >= im.w || y >= im.h) return;
+  const int x0 = u.bx * 64, y0 = u.by * kBlurTH;
   const uint8_t* __restrict__ src = pool + im.off;
-  int xs[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) xs[i] = reflect101(x + i - 3, im.w);
-  int s = 0;
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const uint8_t* row = src + (size_t)reflect101(y + j - 3, im.h) * im.stride;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (kBlurTH + 6) * 70; i += 256) {
+    const int py = i / 70, px = i - py * 70;
+    const int gy = reflect101(min(y0 + py - 3, im.h + 2), im.h), gx = reflect101(min(x0 + px - 3, im.w + 2), im.w);
+    patch[py * 72 + px] = src[(size_t)gy * im.stride + gx];
+  }
+  __syncthreads();
+  for (int i = tid; i < (kBlurTH + 6) * 64; i += 256) {
+    const int py = i >> 6, px = i & 63;
+    const uint8_t* p = patch + py * 72 + px;
     int h = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) h += c_gauss[i] * row[xs[i]];
-    s += c_gauss[j] * h;
+    for (int k = 0; k < 7; ++k) h += c_gauss[k] * p[k];
+    hsum[i] = h;
   }
-  int v = (s + (1 << 15)) >> 16;
-  v = min(max(v, 0), 255);
-  blur_pool[im.score_off + (size_t)y * im.w + x] = (uint8_t)v;
+  __syncthreads();
+  for (int i = tid; i < kBlurTH * 64; i += 256) {
+    const int ty = i >> 6, tx = i & 63;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= im.w || y >= im.h) continue;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s += c_gauss[j] * hsum[(ty + j) * 64 + tx];
+    int v = (s + (1 << 15)) >> 16;
+    v = min(max(v, 0), 255);
+    blur_pool[im.score_off + (size_t)y * im.w + x] = (uint8_t)v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,8 +431,8 @@ void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, 
                           const OrbCtl& ctl, const uint8_t* score_pool, int edge, int* row_cnt, int* img_total,
                           uint64_t* keep_mask, hipStream_t s) {
   hipLaunchKernelGGL(orb_nms_count_kernel, dim3(n_rows), dim3(64), 0, s, pool, imgs, ctl, score_pool, edge, row_cnt, rows,
-                     keep_mask);
-  hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, ctl, row_cnt, img_total);
+                     keep_mask, img_total + n_imgs);
+  hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, ctl, row_cnt, img_total, img_total + n_imgs);
 }
 // Keypoints of every active image in raster order, then Harris response + orientation for the first `measure_bound` of
 // them -- all without the host knowing the count (it reads img_total back together with the keypoints; a frame with more
