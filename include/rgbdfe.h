@@ -135,6 +135,10 @@ int  rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* quer
                                             int32_t n_pairs, void* const* d_out, int32_t* const* d_index,
                                             int32_t* edges_per_device, int32_t* stride);
 const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx);            /* "rccl", "p2p" or "none" (last allgather) */
+/* Host time (microseconds) the calling thread spent enqueueing the latest sharded batch on all devices of a multi handle:
+ * the shards are submitted by ONE thread, device after device -- the batch's launch chain is a cached hipGraph per device,
+ * so this is one hipGraphLaunch (+ a read-back or pack enqueue) per device.  0 for single-device contexts. */
+int  rgbdfe_group_submit_us(rgbdfe_ctx* ctx, double* us);
 /* The compact form of rgbdfe_match_pair_list_allgather: d_out[i] holds G * per rgbdfe_compact_result, same placement
  * (pair k at (k mod G) * per + k / G, unused tail records 0xFF); 12x fewer bytes cross xGMI. */
 int  rgbdfe_match_pair_list_allgather_compact(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,

@@ -239,6 +239,8 @@ def load():
     L.rgbdfe_match_pair_list_allgather.argtypes = [ctx, vp, vp, i32, vp, C.POINTER(i32)]
     L.rgbdfe_match_pair_list_allgather_edges.restype = C.c_int
     L.rgbdfe_match_pair_list_allgather_edges.argtypes = [ctx, vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
+    L.rgbdfe_group_submit_us.restype = C.c_int
+    L.rgbdfe_group_submit_us.argtypes = [ctx, C.POINTER(C.c_double)]
     L.rgbdfe_gather_transport.restype = C.c_char_p
     L.rgbdfe_gather_transport.argtypes = [ctx]
     L.rgbdfe_set_hamming_mode.restype = C.c_int
@@ -306,5 +308,5 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",
     "rgbdfe_match_flann_pair_list", "rgbdfe_upload_node_keypoints",
     "rgbdfe_match_pair_list_allgather_compact", "rgbdfe_pack_compact", "rgbdfe_sizeof_compact_result",
-    "rgbdfe_sift_detect", "rgbdfe_sift_geometry", "rgbdfe_sift_debug_plane", "rgbdfe_sift_debug_candidates",
+    "rgbdfe_group_submit_us", "rgbdfe_sift_detect", "rgbdfe_sift_geometry", "rgbdfe_sift_debug_plane", "rgbdfe_sift_debug_candidates",
 ]

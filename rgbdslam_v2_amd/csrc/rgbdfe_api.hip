@@ -151,6 +151,20 @@ struct rgbdfe_ctx {
   int32_t latency_pairs = INT32_MAX;  // record / replay for every batch size (rgbdfe_set_latency_mode)
   int32_t latency_chunk_iters = 0;  // 0 = automatic: 4 iterations per wave up to 64 pairs, 7 up to 640, 14 up to 1280, 28 above
   int64_t next_ticket = 1;
+  // The launch chain of an ORB batch (pair-list upload, Hamming, pair_prep, recording / walk launches, result launch:
+  // ~12 enqueues) as a hipGraph: captured once per distinct batch shape, then ONE hipGraphLaunch per batch -- what keeps
+  // a single submitting thread ahead of several devices (rgbdfe_create_multi) and shortens the live-SLAM call.
+  // Everything a kernel argument depends on is part of the key.
+  struct GraphKey {
+    int32_t n; uint32_t max_nq, max_nt; int32_t slot, latency, chunk, hamming_mode, n_phases; int32_t ends[4];
+    RansacConst rc;
+    void* d_out; void* d_recs; void* d_ec; void* d_walk; void* d_keys;
+  };
+  struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; uint64_t used; };
+  std::vector<GraphEntry> graphs;
+  uint64_t graph_clock = 0;
+  int64_t graph_launches = 0, graph_captures = 0;
+  bool use_graphs = true;  // RGBDFE_GRAPHS=0: plain stream launches
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   hipEvent_t nodes_ready = nullptr;  // recorded behind the latest rgbdfe_upload_node_device copies; every batch waits for it
   hipEvent_t nodes_ready_ev = nullptr;  // (storage; nodes_ready points here once the first such upload happened)
@@ -451,8 +465,41 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
   hipError_t launch_err = hipSuccess;
   if (n > 0) {
     if (!d_out) d_out = lane.d_results;
+    // hipGraph form of the whole chain: ORB batches that run as one piece, no per-stage timing events, no refinement
+    const bool graphable = ctx->use_graphs && !sift && !ctx->profiling && piece >= n && ctx->rc.g2o_iterations == 0;
+    rgbdfe_ctx::GraphEntry* ge = nullptr;
+    bool capturing = false;
+    if (graphable) {
+      rgbdfe_ctx::GraphKey key;
+      memset(&key, 0, sizeof(key));
+      key.n = n; key.max_nq = max_nq; key.max_nt = max_nt; key.slot = (int32_t)(ticket % rgbdfe_ctx::kRing);
+      key.latency = latency ? 1 : 0; key.chunk = chunk; key.hamming_mode = ctx->hamming_mode; key.n_phases = pp.n_phases;
+      for (int i = 0; i < 4; ++i) key.ends[i] = i < pp.n_phases ? pp.ends[i] : 0;
+      memcpy(&key.rc, &ctx->rc, sizeof(RansacConst));
+      key.d_out = d_out; key.d_recs = lane.d_recs; key.d_ec = lane.d_ec; key.d_walk = lane.d_walk; key.d_keys = lane.d_keys;
+      for (auto& e : ctx->graphs)
+        if (memcmp(&e.key, &key, sizeof(key)) == 0) { ge = &e; break; }
+      if (ge) {
+        ge->used = ++ctx->graph_clock;
+        if (hipGraphLaunch(ge->exec, stream) != hipSuccess) launch_err = hipGetLastError();
+        ctx->graph_launches++;
+      } else if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        capturing = true;
+        if (ctx->graphs.size() >= 48) {  // drop the least recently used shape
+          size_t lru = 0;
+          for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].used < ctx->graphs[lru].used) lru = i;
+          (void)hipGraphExecDestroy(ctx->graphs[lru].exec); (void)hipGraphDestroy(ctx->graphs[lru].graph);
+          ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
+        }
+        ctx->graphs.push_back(rgbdfe_ctx::GraphEntry{key, nullptr, nullptr, ++ctx->graph_clock});
+      } else {
+        (void)hipGetLastError();  // capture unavailable: plain launches
+      }
+    }
+    if (!ge) {
     HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n,
                                 hipMemcpyHostToDevice, stream));
+    }
     rgbdfe_ctx::Pending pend{};
     pend.sift = sift;
     if (ctx->profiling) {
@@ -464,7 +511,7 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       (void)hipEventRecord(pend.a, stream);
     }
     const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
-    for (int32_t off = 0; off < n; off += piece) {
+    for (int32_t off = 0; off < n && !ge; off += piece) {
       const int32_t m = (n - off) < piece ? (n - off) : piece;
       const bool first = off == 0, last = off + m >= n;
       if (!first) {  // the schedule of a shorter last piece (its scratch needs are covered by the first one's)
@@ -512,6 +559,20 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
           launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
         if (ctx->profiling && last) (void)hipEventRecord(pend.d, stream);
       }
+    }
+    if (capturing) {  // close the capture, keep the executable graph, run it
+      rgbdfe_ctx::GraphEntry& e = ctx->graphs.back();
+      hipError_t ce = hipStreamEndCapture(stream, &e.graph);
+      if (ce == hipSuccess) ce = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+      if (ce == hipSuccess) {
+        ctx->graph_captures++;
+        ce = hipGraphLaunch(e.exec, stream);
+        ctx->graph_launches++;
+      } else {
+        if (e.graph) (void)hipGraphDestroy(e.graph);
+        ctx->graphs.pop_back();
+      }
+      if (ce != hipSuccess && launch_err == hipSuccess) launch_err = ce;
     }
     if (launch_err == hipSuccess) launch_err = hipGetLastError();
     if (ctx->profiling) {
@@ -585,6 +646,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   fill_ransac_const(ctx);
   if (const char* sf = getenv("RGBDFE_SIFT_FAST_KEYS")) ctx->sift_fast = atoi(sf) != 0;
   if (const char* hm = getenv("RGBDFE_HAMMING_MODE")) ctx->hamming_mode = atoi(hm) < 0 || atoi(hm) > 2 ? 1 : atoi(hm);
+  if (const char* gr = getenv("RGBDFE_GRAPHS")) ctx->use_graphs = atoi(gr) != 0;
   auto bail = [&](int code) { rgbdfe_destroy(ctx); return code; };
   if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
@@ -633,6 +695,8 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   (void)hipDeviceSynchronize();
   drain_pending(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
+  ctx->graphs.clear();
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
   if (ctx->d_xyz) (void)hipFree(ctx->d_xyz);
   for (auto& sl : ctx->ring) {
@@ -2712,6 +2776,7 @@ struct Group {
   std::vector<int32_t*> edge_idx, edge_dst, edge_cnt;
   std::vector<int32_t*> edge_cnt_host;  // pinned
   int32_t edge_cap = 0;                 // records per device the scratch holds
+  double last_submit_us = 0.0;          // host time the calling thread spent enqueueing the latest sharded batch on all devices
   // One call at a time on a group handle (rgbdfe.h: calls on one context serialise): covers the workers' job slots and
   // transport / rccl_* / edge_* above.  Recursive: the gather entry points hold it around their group_run.
   std::recursive_mutex mu;
@@ -2843,11 +2908,61 @@ int group_create(const rgbdfe_config* cfg, const int32_t* device_ids, int32_t n,
 }
 
 // sharded host-output match: device i computes pairs i, i+G, ... and writes them to out[i], out[i+G], ...
+// ORB shards that fit one batch are SUBMITTED BY THE CALLING THREAD, device after device (one hipGraphLaunch + one
+// read-back enqueue each once the batch shape has been seen: host threads inside the HIP runtime at the same time
+// serialise on its locks), then collected; everything else goes through the per-device worker threads.
 int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, rgbdfe_match_result* out, bool sift,
                 float* out_dist) {
   if (n < 0 || (n > 0 && (!q || !t || !out))) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
   Group& g = *gctx->group;
+  std::lock_guard<std::recursive_mutex> call_lock(g.mu);
   const int G = (int)g.children.size();
+  const int32_t per = (n + G - 1) / G;
+  if (!sift && n > 0 && per <= gctx->cfg.max_pairs_per_batch) {
+    std::vector<std::vector<int32_t>> qs((size_t)G), ts((size_t)G);
+    for (int32_t k = 0; k < n; ++k) { qs[(size_t)(k % G)].push_back(q[k]); ts[(size_t)(k % G)].push_back(t[k]); }
+    std::vector<int> lane((size_t)G, -1);
+    int first = RGBDFE_OK;
+    const double t0 = orb_now_us();
+    for (int i = 0; i < G; ++i) {
+      rgbdfe_ctx* c = g.children[(size_t)i];
+      const int32_t ni = (int32_t)qs[(size_t)i].size();
+      if (ni == 0) continue;
+      std::lock_guard<std::mutex> lk(c->mu);
+      int r = RGBDFE_OK;
+      if (hipSetDevice(c->cfg.device_id) != hipSuccess) r = fail(c, RGBDFE_ERR_HIP, "hipSetDevice");
+      if (r == RGBDFE_OK && !c->h_results &&
+          hipHostMalloc((void**)&c->h_results, sizeof(rgbdfe_match_result) * (size_t)c->cfg.max_pairs_per_batch,
+                        hipHostMallocDefault) != hipSuccess)
+        r = fail(c, RGBDFE_ERR_OUT_OF_MEMORY, "pinned result staging allocation failed");
+      int li = 0;
+      if (r == RGBDFE_OK) r = enqueue_pairs(c, qs[(size_t)i].data(), ts[(size_t)i].data(), ni, nullptr, nullptr, nullptr, &li);
+      if (r == RGBDFE_OK &&
+          hipMemcpyAsync(c->h_results, c->lanes[li].d_results, sizeof(rgbdfe_match_result) * (size_t)ni, hipMemcpyDeviceToHost,
+                         c->lanes[li].stream) != hipSuccess)
+        r = fail(c, RGBDFE_ERR_HIP, "result read-back");
+      if (r == RGBDFE_OK) lane[(size_t)i] = li;
+      else if (first == RGBDFE_OK) {
+        first = r;
+        std::string msg; { std::lock_guard<std::mutex> e(c->err_mu); msg = c->last_error; }
+        fail(gctx, first, "device " + std::to_string(g.device_ids[(size_t)i]) + ": " + msg);
+      }
+    }
+    g.last_submit_us = orb_now_us() - t0;
+    for (int i = 0; i < G; ++i) {   // collect (also after an error: nothing may stay in flight behind the caller's back)
+      if (lane[(size_t)i] < 0) continue;
+      rgbdfe_ctx* c = g.children[(size_t)i];
+      std::lock_guard<std::mutex> lk(c->mu);
+      (void)hipSetDevice(c->cfg.device_id);
+      if (hipStreamSynchronize(c->lanes[lane[(size_t)i]].stream) != hipSuccess) {
+        if (first == RGBDFE_OK) first = fail(gctx, RGBDFE_ERR_HIP, "device " + std::to_string(g.device_ids[(size_t)i]) + ": synchronize");
+        continue;
+      }
+      const int32_t ni = (int32_t)qs[(size_t)i].size();
+      for (int32_t m = 0; m < ni; ++m) out[(size_t)i + (size_t)m * (size_t)G] = c->h_results[m];
+    }
+    return first;
+  }
   return group_run(gctx, [&](int i) -> int {
     std::vector<int32_t> qs, ts;
     for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }
@@ -2857,6 +2972,21 @@ int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n,
                                                out_dist ? out_dist + (size_t)i * RGBDFE_MAX_MATCHES : nullptr, G);
     return impl::rgbdfe_match_pair_list(g.children[(size_t)i], qs.data(), ts.data(), (int32_t)qs.size(), out + i, G);
   });
+}
+
+// run fn(i) for every device on THIS thread, device after device: for work that only enqueues (returns the first error)
+int group_each(rgbdfe_ctx* gctx, const std::function<int(int)>& fn) {
+  Group& g = *gctx->group;
+  int first = RGBDFE_OK;
+  for (int i = 0; i < (int)g.children.size(); ++i) {
+    const int r = fn(i);
+    if (r != RGBDFE_OK && first == RGBDFE_OK) {
+      first = r;
+      std::string msg; { std::lock_guard<std::mutex> e(g.children[(size_t)i]->err_mu); msg = g.children[(size_t)i]->last_error; }
+      fail(gctx, first, "device " + std::to_string(g.device_ids[(size_t)i]) + ": " + msg);
+    }
+  }
+  return first;
 }
 
 bool group_setup_rccl(rgbdfe_ctx* gctx) {
@@ -2922,8 +3052,9 @@ int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, 
     return fail(gctx, RGBDFE_ERR_CAPACITY, "allgather: the shard of a device exceeds max_pairs_per_batch");
   const size_t rec = compact ? sizeof(rgbdfe_compact_result) : sizeof(rgbdfe_match_result);
   if (compact) { const int rce = group_ensure_edge_scratch(gctx, per); if (rce != RGBDFE_OK) return rce; }
-  // 1. every device computes its shard into its own segment of its own buffer
-  int rc = group_run(gctx, [&](int i) -> int {
+  // 1. every device computes its shard into its own segment of its own buffer: enqueued by this thread, device after device
+  const double t_sub0 = orb_now_us();
+  int rc = group_each(gctx, [&](int i) -> int {
     rgbdfe_ctx* c = g.children[(size_t)i];
     std::vector<int32_t> qs, ts;
     for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }
@@ -2948,7 +3079,11 @@ int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, 
     }
     return r;
   });
-  if (rc != RGBDFE_OK) return rc;
+  g.last_submit_us = orb_now_us() - t_sub0;
+  if (rc != RGBDFE_OK) {   // nothing may stay in flight behind the caller's back
+    for (int i = 0; i < G; ++i) { (void)hipSetDevice(g.device_ids[(size_t)i]); (void)hipStreamSynchronize(g.gather_streams[(size_t)i]); }
+    return rc;
+  }
   // 2. the exchange
   if (G == 1 && !group_setup_rccl(gctx)) {
     g.transport = "none (one device)";
@@ -3155,6 +3290,16 @@ rgbdfe_ctx* rgbdfe_device_context(rgbdfe_ctx* ctx, int32_t i) {
   if (!ctx) return nullptr;
   if (!ctx->group) return i == 0 ? ctx : nullptr;
   return i >= 0 && (size_t)i < ctx->group->children.size() ? ctx->group->children[(size_t)i] : nullptr;
+}
+
+int rgbdfe_group_submit_us(rgbdfe_ctx* ctx, double* us) {
+  if (!ctx || !us) return RGBDFE_ERR_INVALID_ARG;
+  *us = 0.0;
+  if (ctx->group) {
+    std::lock_guard<std::recursive_mutex> call_lock(ctx->group->mu);
+    *us = ctx->group->last_submit_us;
+  }
+  return RGBDFE_OK;
 }
 
 const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx) {

@@ -124,6 +124,12 @@ class FrontEnd:
             m = m if 0 <= m <= 2 else 1
         return 0 if self.cfg.max_keypoints > 32768 else m
 
+    def group_submit_us(self) -> float:
+        """Host microseconds the calling thread spent enqueueing the latest sharded batch on all devices."""
+        v = C.c_double(0.0)
+        self._check(self._L.rgbdfe_group_submit_us(self._ctx, C.byref(v)))
+        return float(v.value)
+
     def gather_transport(self) -> str:
         return self._L.rgbdfe_gather_transport(self._ctx).decode()
 

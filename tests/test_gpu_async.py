@@ -104,3 +104,39 @@ def test_small_batches_repeat_bytes(data):
             b = fe.match_pair_list(pq[j:j + 4], pt[j:j + 4])
             assert b.tobytes() == ref[j:j + 4].tobytes()
         fe.close()
+
+
+def test_graph_replay_equals_plain_launches(data, monkeypatch):
+    """The launch chain of an ORB batch is captured into a hipGraph once per batch shape and replayed afterwards
+    (rgbdfe_api.hip enqueue_pairs): first use (capture), replays, another shape, new pair lists through the same graph, a
+    parameter change (new key), the device-output entry points -- every result equals the plain stream launches of a
+    context created with RGBDFE_GRAPHS=0."""
+    import torch
+    seq, pq, pt = data
+    monkeypatch.setenv("RGBDFE_GRAPHS", "0")
+    plain = _fe(128, seq)
+    monkeypatch.setenv("RGBDFE_GRAPHS", "1")
+    graph = _fe(128, seq)
+    try:
+        for lists in ((pq, pt), (pq, pt), (pq[::-1].copy(), pt[::-1].copy()), (pq[:31], pt[:31]), (pq, pt), (pq[:31], pt[:31])):
+            assert graph.match_pair_list(*lists).tobytes() == plain.match_pair_list(*lists).tobytes()
+        for kw in (dict(ransac_iterations=50), dict(max_matches=128, min_matches=10), dict(ransac_iterations=200)):
+            plain.set_params(**kw)
+            graph.set_params(**kw)
+            for _ in range(2):
+                assert graph.match_pair_list(pq, pt).tobytes() == plain.match_pair_list(pq, pt).tobytes()
+        plain.set_params(max_matches=300, min_matches=20)
+        graph.set_params(max_matches=300, min_matches=20)
+        ref = plain.match_pair_list(pq, pt)
+        bufs = [torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        for rep in range(3):                      # pipelined submissions: ring slots x output buffers = several keys
+            tks = [graph.submit_pair_list(pq, pt, b.data_ptr()) for b in bufs]
+            for tk, b in zip(tks, bufs):
+                graph.wait_ticket(tk, None)
+                assert b.cpu().numpy().tobytes() == ref.tobytes()
+        graph.set_latency_mode(0, 0)              # the one-wave schedule: its own shape
+        plain.set_latency_mode(0, 0)
+        assert graph.match_pair_list(pq, pt).tobytes() == plain.match_pair_list(pq, pt).tobytes()
+    finally:
+        plain.close()
+        graph.close()
