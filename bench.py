@@ -697,18 +697,14 @@ def sift_extract_subrecord(device):
 
 
 def sift_extract_bytes(w, h, n_kp):
-    """Algorithmic bytes of one frame of SIFT extraction (f32 planes): the up-sampled first octave has
-    4 W H pixels, every octave o holds S + 3 = 6 Gaussian levels and S + 2 = 5 DoG levels of (4 W H) / 4^o pixels.
-    Per level: one separable blur = 2 reads + 2 writes of a plane (H pass, V pass), one DoG write + two reads, the
-    extrema scan reads 3 DoG planes once each, orientation + descriptor read a 16x16 neighbourhood's gradients per
-    keypoint.  Sum over octaves of 4^-o <= 4/3."""
-    px0 = 4.0 * w * h
-    planes = 4.0 / 3.0
-    blur = 6 * 4 * 4 * px0 * planes            # 6 levels x (2 reads + 2 writes) x 4 B
-    dog = 5 * 3 * 4 * px0 * planes             # 5 levels x (2 reads + 1 write) x 4 B
-    extrema = 5 * 4 * px0 * planes             # every DoG plane read once more
-    per_kp = n_kp * (2 * 16 * 16 * 4 * 2 + 128 * 4 + 16)
-    return w * h + blur + dog + extrema + per_kp
+    """Algorithmic bytes of one frame of SIFT extraction.  "-fo -1": the first octave is the 2x up-sampled
+    image, 4 W H pixels; octave o has (4 W H) / 4^o pixels (sum <= 4/3) and "-d 5" gives 8 Gaussian levels per octave,
+    f32.  Every level is written once, read once by the filter that produces the next level and once by the keypoint
+    scan (the DoG planes are differences formed in registers, never stored): 24 plane passes x 4 B = 96 B per pixel; the
+    extremum flags add one byte written + one read for each of the 5 scanned levels.  Per keypoint: 24 B candidate,
+    16 B key, 512 B descriptor out (their gradient windows re-read planes already counted)."""
+    px = 4.0 * w * h * (4.0 / 3.0)
+    return w * h + px * (24 * 4 + 5 * 2) + n_kp * (24 + 16 + 512)
 
 
 def detect_subrecord(device):
