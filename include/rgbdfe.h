@@ -280,6 +280,14 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
                               double cx, double cy, double depth_scaling, int32_t max_keypoints,
                               int32_t use_root_sift, int32_t* kept_idx, float* xyz1,
                               float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out);
+/* The same with "use_feature_min_depth" on (parameter_server.cpp:90, node.cpp:727-731): a keypoint's depth is
+ * getMinDepthInNeighborhood(depth, pt, size) (misc.cpp:774-793); kp_size = cv::KeyPoint::size per keypoint (for SiftGPU
+ * keypoints 12 * scale, what rgbdfe_sift_detect returns). */
+int rgbdfe_sift_node_features_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, const float* kp_size, int32_t n_kp,
+                                        const float* desc_in, const float* depth, int32_t rows, int32_t cols, double fx,
+                                        double fy, double cx, double cy, double depth_scaling, int32_t max_keypoints,
+                                        int32_t use_root_sift, int32_t* kept_idx, float* xyz1, float* siftgpu_descriptors,
+                                        float* feature_descriptors, int32_t* n_out);
 
 /* Two schedules of a batch's RANSAC work give byte-identical results:
  *   record / replay       (default) recording waves each refine chunk_iterations iterations of a pair and write the
@@ -424,7 +432,7 @@ int rgbdfe_detector_thresholds(rgbdfe_ctx* ctx, double* thresholds, int32_t* n_c
  * neighbourhood (getMinDepthInNeighborhood, misc.cpp:774-793) instead of the pixel under it -- in removeDepthless
  * (node.cpp:82) and projectTo3D (:940).  rgbdfe_set_feature_min_depth switches rgbdfe_detect_describe(_batch) over;
  * rgbdfe_project_to_3d_min_depth is rgbdfe_project_to_3d in that mode (kp_size = cv::KeyPoint::size per keypoint).
- * The SIFTGPU variant (node.cpp:730) is not built. */
+ * The SIFTGPU call site (node.cpp:730) is rgbdfe_sift_node_features_min_depth. */
 int rgbdfe_set_feature_min_depth(rgbdfe_ctx* ctx, int32_t on);
 int rgbdfe_project_to_3d_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, const float* kp_size, int32_t n_kp,
                                    const float* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,

@@ -296,6 +296,9 @@ def ref_frame_lib():
         R.ref_project_to_3d_cloud.argtypes = [vp, i, vp, i, i, d, i, vp, vp]
         R.ref_project_to_3d_sift.restype = i
         R.ref_project_to_3d_sift.argtypes = [vp, i, vp, vp, i, i, d, d, d, d, d, i, vp, vp, vp, vp]
+        if hasattr(R, "ref_project_to_3d_sift_min_depth"):
+            R.ref_project_to_3d_sift_min_depth.restype = i
+            R.ref_project_to_3d_sift_min_depth.argtypes = [vp, vp, i, vp, vp, i, i, d, d, d, d, d, i, vp, vp]
         R.ref_root_sift.restype = None
         R.ref_root_sift.argtypes = [vp, i, i]
         R.ref_create_point_cloud.restype = None
@@ -618,17 +621,25 @@ def project_to_3d_cloud(kp_xy, cloud, maximum_depth, max_keypoints=1000):
 
 
 def sift_node_features(kp_xy, desc, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000,
-                       use_root_sift=True):
+                       use_root_sift=True, kp_size=None):
     """projectTo3DSiftGPU + squareroot_descriptor_space: (kept_idx, xyz1, siftgpu_descriptors,
-    feature_descriptors)."""
+    feature_descriptors).  kp_size (cv::KeyPoint::size per keypoint): the use_feature_min_depth variant (node.cpp:730)."""
     kp_xy = np.ascontiguousarray(kp_xy, np.float32)
     desc = np.ascontiguousarray(desc, np.float32)
     depth = np.ascontiguousarray(depth, np.float32)
     n = kp_xy.shape[0]
     kept = np.empty(max(n, 1), np.int32)
     xyz1 = np.empty((max(n, 1), 4), np.float32)
-    k = lib().orc_project_to_3d_sift(_p(kp_xy), n, _p(depth), depth.shape[0], depth.shape[1],
-                                     fx, fy, cx, cy, depth_scaling, max_keypoints, _p(kept), _p(xyz1))
+    if kp_size is not None:
+        kp_size = np.ascontiguousarray(kp_size, np.float32)
+        f = lib().orc_project_to_3d_sift_min_depth
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
+        k = f(_p(kp_xy), _p(kp_size), n, _p(depth), depth.shape[0], depth.shape[1], fx, fy, cx, cy, depth_scaling,
+              max_keypoints, _p(kept), _p(xyz1))
+    else:
+        k = lib().orc_project_to_3d_sift(_p(kp_xy), n, _p(depth), depth.shape[0], depth.shape[1],
+                                         fx, fy, cx, cy, depth_scaling, max_keypoints, _p(kept), _p(xyz1))
     raw = np.empty((max(k, 1), desc.shape[1]), np.float32)
     lib().orc_gather_rows_f32(_p(desc), _p(kept), k, desc.shape[1], _p(raw))
     raw = raw[:k].copy()

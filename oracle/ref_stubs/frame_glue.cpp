@@ -99,6 +99,23 @@ extern "C" int ref_project_to_3d_sift(const float* kp_xy, int n, const float* de
   }
   return (int)p3.size();
 }
+extern "C" int ref_project_to_3d_sift_min_depth(const float* kp_xy, const float* kp_size, int n, const float* desc_in,
+                                                const float* depth, int rows, int cols, double fx, double fy, double cx,
+                                                double cy, double depth_scaling, int max_keypoints, int32_t* kept, float* xyz1) {
+  g_fp.depth_scaling_factor = depth_scaling; g_fp.max_keypoints = max_keypoints;
+  std::vector<cv::KeyPoint> k = make_kps(kp_xy, n);
+  for (int i = 0; i < n; ++i) k[i].size = kp_size[i];
+  std::vector<Eigen::Vector4f, Eigen::aligned_allocator<Eigen::Vector4f> > p3;
+  cv::Mat d(rows, cols, CV_32FC1, (void*)depth);
+  std::vector<float> din(desc_in, desc_in + (size_t)n * 128);
+  cv::Mat dout;
+  Node node;
+  g_fp.use_feature_min_depth = true;
+  node.projectTo3DSiftGPU(k, p3, d, make_cam(fx, fy, cx, cy), din, dout);
+  g_fp.use_feature_min_depth = false;
+  for (size_t i = 0; i < p3.size(); ++i) { kept[i] = k[i].class_id; for (int c = 0; c < 4; ++c) xyz1[4 * i + c] = p3[i](c); }
+  return (int)p3.size();
+}
 extern "C" void ref_root_sift(float* desc, int n_rows, int dim) {
   cv::Mat m(n_rows, dim, CV_32FC1, desc);
   squareroot_descriptor_space(m);  // `descriptors = cv::abs(descriptors)` re-seats the Mat: copy the result back

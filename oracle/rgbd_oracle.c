@@ -1185,6 +1185,27 @@ int orc_project_to_3d_sift(const float* kp_xy, int n_kp, const float* depth, int
   return n;
 }
 
+/* projectTo3DSiftGPU with use_feature_min_depth (node.cpp:727-731): Z = getMinDepthInNeighborhood(depth, p2d, size) *
+ * depth_scaling, everything else as above (no inside-the-image test either: the neighbourhood is clamped, :781-784) */
+int orc_project_to_3d_sift_min_depth(const float* kp_xy, const float* kp_size, int n_kp, const float* depth, int rows,
+                                     int cols, double fx, double fy, double cx_d, double cy_d, double depth_scaling,
+                                     int max_keypoints, int32_t* kept_idx, float* xyz1) {
+  const float fxinv = (float)(1. / fx), fyinv = (float)(1. / fy), cx = (float)cx_d, cy = (float)cy_d;
+  int n = 0;
+  for (int i = 0; i < n_kp && n < max_keypoints; ++i) {
+    const float px = kp_xy[2 * i], py = kp_xy[2 * i + 1];
+    const float Z = (float)((double)orc_min_depth_in_neighborhood(depth, rows, cols, px, py, kp_size[i]) * depth_scaling); /* :731 */
+    if (isnan(Z)) continue;
+    xyz1[4 * n + 0] = (px - cx) * Z * fxinv;
+    xyz1[4 * n + 1] = (py - cy) * Z * fyinv;
+    xyz1[4 * n + 2] = Z;
+    xyz1[4 * n + 3] = 1.0f;
+    kept_idx[n] = i;
+    ++n;
+  }
+  return n;
+}
+
 /* descriptors_out / siftgpu_descriptors (:752-766): row y <- descriptors_in[featuresUsed[y]] */
 void orc_gather_rows_f32(const float* in, const int32_t* kept_idx, int n, int dim, float* out) {
   for (int y = 0; y < n; ++y)

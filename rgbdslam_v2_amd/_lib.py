@@ -204,6 +204,10 @@ def load():
     L.rgbdfe_sift_node_features.argtypes = [ctx, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
                                             C.c_double, C.c_double, C.c_double, i32, i32, vp, vp, vp, vp,
                                             C.POINTER(i32)]
+    L.rgbdfe_sift_node_features_min_depth.restype = C.c_int
+    L.rgbdfe_sift_node_features_min_depth.argtypes = [ctx, vp, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
+                                                      C.c_double, C.c_double, C.c_double, i32, i32, vp, vp, vp, vp,
+                                                      C.POINTER(i32)]
     L.rgbdfe_host_register.restype = C.c_int
     L.rgbdfe_host_register.argtypes = [ctx, vp, C.c_size_t]
     L.rgbdfe_host_unregister.restype = C.c_int
@@ -294,7 +298,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket", "rgbdfe_upload_sift_node",
     "rgbdfe_match_sift_pair_list", "rgbdfe_submit_sift_pair_list", "rgbdfe_sift_match_nodes",
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
-    "rgbdfe_project_to_3d", "rgbdfe_sift_node_features", "rgbdfe_depth_to_mono8",
+    "rgbdfe_project_to_3d", "rgbdfe_sift_node_features", "rgbdfe_sift_node_features_min_depth", "rgbdfe_depth_to_mono8",
     "rgbdfe_host_register", "rgbdfe_host_unregister",
     "rgbdfe_upload_node_cloud", "rgbdfe_release_node_cloud", "rgbdfe_observation_likelihood",
     "rgbdfe_observation_criterion_met", "rgbdfe_set_latency_mode", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",

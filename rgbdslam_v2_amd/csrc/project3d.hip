@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void project_to_3d_kernel(
         int r = (int)py, c = (int)px;
         r = min(max(r, 0), rows - 1);
         c = min(max(c, 0), cols - 1);
-        Z = (float)((double)depth[(size_t)r * (size_t)cols + (size_t)c] * depth_scaling);  // :733
+        // z_gathered: getMinDepthInNeighborhood's value under "use_feature_min_depth" (:731) instead of the pixel (:733)
+        const float zraw = z_gathered ? z_gathered[i] : depth[(size_t)r * (size_t)cols + (size_t)c];
+        Z = (float)((double)zraw * depth_scaling);
         keep = !__builtin_isnan(Z);  // :736
       } else if (!bad) {
         // depth.at<float>(round(y), round(x)): std::round = half away from zero (node.cpp:942).

@@ -2417,7 +2417,9 @@ int rgbdfe_detect_describe_cloud(rgbdfe_ctx* ctx, const uint8_t* gray, const uin
   return RGBDFE_OK;
 }
 
-int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp, const float* desc_in,
+// kp_size != nullptr: "use_feature_min_depth" (node.cpp:727-731) -- the depth of a keypoint is
+// getMinDepthInNeighborhood(depth, pt, size) (misc.cpp:774-793) instead of the pixel under it
+int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, const float* kp_size, int32_t n_kp, const float* desc_in,
                               const float* depth, int32_t rows, int32_t cols, double fx, double fy,
                               double cx, double cy, double depth_scaling, int32_t max_keypoints,
                               int32_t use_root_sift, int32_t* kept_idx, float* xyz1,
@@ -2433,9 +2435,12 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
   const int cap = n_kp < max_keypoints ? n_kp : max_keypoints;
   const size_t b_kp = up((size_t)n_kp * 8), b_depth = up((size_t)rows * cols * 4), b_idx = up((size_t)n_kp * 4);
   const size_t b_xyz = up((size_t)n_kp * 16), b_in = up((size_t)n_kp * 512), b_out = up((size_t)cap * 512);
-  int rc = ensure_scratch(ctx, b_kp + b_depth + b_idx + b_xyz + b_in + 2 * b_out + 256);
+  const size_t b_kp3 = kp_size ? up((size_t)n_kp * 12) : 0, b_z = kp_size ? up((size_t)n_kp * 4) : 0;
+  int rc = ensure_scratch(ctx, b_kp + b_depth + b_idx + b_xyz + b_in + 2 * b_out + b_kp3 + b_z + 256);
   if (rc != RGBDFE_OK) return rc;
   char* p = (char*)ctx->d_scratch;
+  float* d_kp3 = (float*)p;         p += b_kp3;
+  float* d_z = (float*)p;           p += b_z;
   float* d_kp = (float*)p;          p += b_kp;
   float* d_depth = (float*)p;       p += b_depth;
   int32_t* d_idx = (int32_t*)p;     p += b_idx;
@@ -2447,8 +2452,15 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
   HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp_xy, (size_t)n_kp * 8, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_in, desc_in, (size_t)n_kp * 512, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<float> h3;
+  if (kp_size) {
+    h3.resize((size_t)n_kp * 3);
+    for (int32_t i = 0; i < n_kp; ++i) { h3[3 * i] = kp_xy[2 * i]; h3[3 * i + 1] = kp_xy[2 * i + 1]; h3[3 * i + 2] = kp_size[i]; }
+    HIP_TRY(ctx, hipMemcpyAsync(d_kp3, h3.data(), h3.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_min_depth(d_kp3, n_kp, d_depth, rows, cols, d_z, ctx->stream);
+  }
   launch_project_to_3d(d_kp, n_kp, d_depth, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx,
-                       (float)cy, depth_scaling, max_keypoints, d_idx, d_xyz, d_n, ctx->stream, true);
+                       (float)cy, depth_scaling, max_keypoints, d_idx, d_xyz, d_n, ctx->stream, true, kp_size ? d_z : nullptr);
   launch_sift_pack(d_in, d_idx, d_n, cap, use_root_sift != 0, d_raw, feature_descriptors ? d_feat : nullptr,
                    ctx->stream);
   HIP_TRY(ctx, hipGetLastError());
@@ -3655,8 +3667,20 @@ int rgbdfe_sift_node_features(rgbdfe_ctx* ctx, const float* kp_xy, int32_t n_kp,
                               double depth_scaling, int32_t max_keypoints, int32_t use_root_sift, int32_t* kept_idx,
                               float* xyz1, float* siftgpu_descriptors, float* feature_descriptors, int32_t* n_out) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
-  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_node_features(c, kp_xy, n_kp, desc_in, depth, rows, cols, fx, fy, cx, cy,
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_node_features(c, kp_xy, nullptr, n_kp, desc_in, depth, rows, cols, fx, fy, cx, cy,
                                                            depth_scaling, max_keypoints, use_root_sift, kept_idx, xyz1,
+                                                           siftgpu_descriptors, feature_descriptors, n_out));
+}
+
+int rgbdfe_sift_node_features_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, const float* kp_size, int32_t n_kp,
+                                        const float* desc_in, const float* depth, int32_t rows, int32_t cols, double fx,
+                                        double fy, double cx, double cy, double depth_scaling, int32_t max_keypoints,
+                                        int32_t use_root_sift, int32_t* kept_idx, float* xyz1, float* siftgpu_descriptors,
+                                        float* feature_descriptors, int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  if (n_kp > 0 && !kp_size) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "kp_size is required");
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_node_features(c, kp_xy, kp_size, n_kp, desc_in, depth, rows, cols, fx, fy, cx,
+                                                           cy, depth_scaling, max_keypoints, use_root_sift, kept_idx, xyz1,
                                                            siftgpu_descriptors, feature_descriptors, n_out));
 }
 

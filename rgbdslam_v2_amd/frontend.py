@@ -571,9 +571,10 @@ class FrontEnd:
         return kps[: n.value].copy(), desc[: n.value].copy(), xyz[: n.value].copy()
 
     def sift_node_features(self, kp_xy, desc, depth, fx, fy, cx, cy, depth_scaling=1.0, max_keypoints=1000,
-                           use_root_sift=True):
+                           use_root_sift=True, kp_size=None):
         """projectTo3DSiftGPU (node.cpp:695-769) + squareroot_descriptor_space (node.cpp:1557-1571):
-        returns (kept_idx, xyz1, siftgpu_descriptors, feature_descriptors)."""
+        returns (kept_idx, xyz1, siftgpu_descriptors, feature_descriptors).  kp_size (cv::KeyPoint::size per keypoint)
+        selects the use_feature_min_depth variant (node.cpp:727-731)."""
         kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
         desc = np.ascontiguousarray(desc, np.float32)
         depth = np.ascontiguousarray(depth, np.float32)
@@ -586,10 +587,19 @@ class FrontEnd:
         raw = np.empty((cap, 128), np.float32)
         feat = np.empty((cap, 128), np.float32)
         n_out = C.c_int32(0)
-        self._check(self._L.rgbdfe_sift_node_features(
-            self._ctx, kp_xy.ctypes.data, n, desc.ctypes.data, depth.ctypes.data, depth.shape[0],
-            depth.shape[1], fx, fy, cx, cy, depth_scaling, max_keypoints, int(bool(use_root_sift)),
-            kept.ctypes.data, xyz1.ctypes.data, raw.ctypes.data, feat.ctypes.data, C.byref(n_out)))
+        if kp_size is not None:
+            kp_size = np.ascontiguousarray(kp_size, np.float32).reshape(-1)
+            if kp_size.shape[0] != n:
+                raise ValueError("kp_size must hold one size per keypoint")
+            self._check(self._L.rgbdfe_sift_node_features_min_depth(
+                self._ctx, kp_xy.ctypes.data, kp_size.ctypes.data, n, desc.ctypes.data, depth.ctypes.data, depth.shape[0],
+                depth.shape[1], fx, fy, cx, cy, depth_scaling, max_keypoints, int(bool(use_root_sift)),
+                kept.ctypes.data, xyz1.ctypes.data, raw.ctypes.data, feat.ctypes.data, C.byref(n_out)))
+        else:
+            self._check(self._L.rgbdfe_sift_node_features(
+                self._ctx, kp_xy.ctypes.data, n, desc.ctypes.data, depth.ctypes.data, depth.shape[0],
+                depth.shape[1], fx, fy, cx, cy, depth_scaling, max_keypoints, int(bool(use_root_sift)),
+                kept.ctypes.data, xyz1.ctypes.data, raw.ctypes.data, feat.ctypes.data, C.byref(n_out)))
         k = n_out.value
         return kept[:k].copy(), xyz1[:k].copy(), raw[:k].copy(), feat[:k].copy()
 

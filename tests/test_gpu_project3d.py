@@ -57,6 +57,31 @@ def test_sift_node_features_match_oracle():
     fe.close()
 
 
+def test_sift_node_features_min_depth_match_oracle():
+    """node.cpp:727-731: projectTo3DSiftGPU with use_feature_min_depth (rgbdfe_sift_node_features_min_depth): exact."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=64, max_pairs_per_batch=2)
+    rng = np.random.default_rng(15)
+    for (rows, cols, n, maxk, scale, nanf) in [(480, 640, 1500, 1000, 1.0, 0.3), (960, 1280, 3000, 4000, 1.0, 0.5),
+                                               (48, 64, 700, 50, 0.5, 0.6), (48, 64, 200, 1000, 1.0, 0.97),
+                                               (48, 64, 0, 10, 1.0, 0.1)]:
+        depth = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+        depth[rng.random((rows, cols)) < nanf] = np.nan
+        depth[rng.random((rows, cols)) < 0.02] = 0.0
+        kp = np.stack([rng.uniform(0, cols - 0.01, n), rng.uniform(0, rows - 0.01, n)], 1).astype(np.float32)
+        size = (12.0 * rng.uniform(0.8, 12.0, n)).astype(np.float32)
+        desc = rng.gamma(0.6, 1.0, (n, 128)).astype(np.float32)
+        if n > 10:
+            kp[:4] = [[0.2, 0.3], [cols - 0.5, rows - 0.5], [cols / 2, 0.1], [0.4, rows / 2]]
+            size[7] = 1.0
+        fx = 525.0 * cols / 640
+        got = fe.sift_node_features(kp, desc, depth, fx, fx, (cols - 1) / 2, (rows - 1) / 2, scale, maxk, True, kp_size=size)
+        ref = po.sift_node_features(kp, desc, depth, fx, fx, (cols - 1) / 2, (rows - 1) / 2, scale, maxk, True, kp_size=size)
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+    fe.close()
+
+
 def _cloud(rng, rows, cols):
     cloud = np.zeros((rows, cols, 4), np.float32)
     cloud[..., 0] = rng.uniform(-2, 2, (rows, cols))

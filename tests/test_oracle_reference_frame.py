@@ -68,6 +68,33 @@ def test_sift_node_features_on_reference_code():
         assert np.array_equal(feat, ofeat)
 
 
+def test_sift_node_features_min_depth_on_reference_code():
+    """node.cpp:727-731: projectTo3DSiftGPU with use_feature_min_depth -- the reference function with the parameter switched
+    on (sizes = 12 * scale as SiftGPUWrapper::detect sets them) against the oracle's restatement."""
+    if not hasattr(R, "ref_project_to_3d_sift_min_depth"):
+        pytest.skip("oracle/_ref/libref_frame.so predates this entry point")
+    rng = np.random.default_rng(35)
+    for rows, cols, n, maxk, nanf in ((480, 640, 900, 1000, 0.3), (48, 64, 300, 40, 0.6), (48, 64, 200, 1000, 0.97)):
+        depth = rng.uniform(0.4, 5.0, (rows, cols)).astype(np.float32)
+        depth[rng.random((rows, cols)) < nanf] = np.nan
+        depth[rng.random((rows, cols)) < 0.02] = 0.0           # a minimum of 0 counts as "no depth" (misc.cpp:790)
+        kp = np.stack([rng.uniform(0, cols - 0.01, n), rng.uniform(0, rows - 0.01, n)], 1).astype(np.float32)
+        kp[:4] = [[0.2, 0.3], [cols - 0.5, rows - 0.5], [cols / 2, 0.1], [0.4, rows / 2]]   # windows clipped by the image
+        size = (12.0 * rng.uniform(0.8, 12.0, n)).astype(np.float32)
+        size[7] = 1.0                                             # radius 0: an empty window
+        desc = rng.gamma(0.6, 1.0, (n, 128)).astype(np.float32)
+        K = (525.0 * cols / 640, 520.0 * cols / 640, (cols - 1) / 2, (rows - 1) / 2)
+        kept = np.zeros(n, np.int32)
+        xyz = np.zeros((n, 4), np.float32)
+        k = R.ref_project_to_3d_sift_min_depth(_p(kp), _p(size), n, _p(desc), _p(depth), rows, cols, *K, 1.0, maxk, _p(kept),
+                                               _p(xyz))
+        okept, oxyz, oraw, _ = po.sift_node_features(kp, desc, depth, *K, 1.0, maxk, use_root_sift=False, kp_size=size)
+        assert k == len(okept) and np.array_equal(kept[:k], okept) and np.array_equal(xyz[:k], oxyz)
+        assert np.array_equal(oraw, desc[okept])
+        plain = po.sift_node_features(kp, desc, depth, *K, 1.0, maxk, use_root_sift=False)
+        assert len(plain[0]) != k or not np.array_equal(plain[1], oxyz)   # the variant matters on this input
+
+
 def test_point_cloud_on_reference_code():
     """createXYZRGBPointCloud (misc.cpp:467-556)."""
     rng = np.random.default_rng(33)

@@ -29,6 +29,17 @@ def test_pin_reproduces_its_golden_outputs():
 
 
 @needs_pin
+def test_pin_reproduces_the_photo_fixture():
+    """Case d: a window of external/SiftGPU/data/800-2.jpg, luminance stored in the fixture (no JPEG decoder, no
+    reference tree needed)."""
+    g = np.load(GOLD)
+    w, h, maxf, seed, omin, onum = [int(v) for v in g["d_meta"]]
+    keys, desc, cnt = po.ref_sift_detect(g["d_img"], maxf)
+    assert np.array_equal(keys, g["d_keys"]) and np.array_equal(desc, g["d_desc"]) and np.array_equal(cnt, g["d_counts"])
+    assert len(keys) > 300 and np.all(desc >= 0)
+
+
+@needs_pin
 def test_pin_finds_a_blob_at_its_place_and_scale():
     """A Gaussian blob of standard deviation s is a DoG extremum at scale ~ s * sqrt(2) ... within the sampling of 5 levels
     per octave: the strongest feature sits on the blob, its scale within a factor 1.5 of s."""
