@@ -55,12 +55,19 @@ struct OrbWorkspace {
   int super_pass_enqueue(int nf, int set, int slot, hipStream_t s, std::string& err);
   int super_replay(int nf, int set, int slot, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err);
   void use_slot(int slot);
-  uint8_t* d_passout_slot[2] = {nullptr, nullptr}; uint8_t* h_passout_slot[2] = {nullptr, nullptr};
-  int* h_base_slot[2] = {nullptr, nullptr};
-  hipEvent_t ev_pass[2] = {nullptr, nullptr};
-  int slot_bound[2] = {0, 0};
-  std::vector<int> slot_floor[2];
-  uint8_t* himg_stage[3] = {nullptr, nullptr, nullptr};  // super-frame staging, three deep (pinned)
+  static constexpr int kSets = 3;  // image sets / pass slots of the super-frame pipeline (kSets - 1 passes ahead of the replay)
+  uint8_t* d_passout_slot[kSets] = {}; uint8_t* h_passout_slot[kSets] = {};
+  int* h_base_slot[kSets] = {};
+  hipEvent_t ev_pass[kSets] = {};
+  int slot_bound[kSets] = {};
+  std::vector<int> slot_floor[kSets];
+  uint8_t* himg_stage[kSets + 1] = {};  // super-frame staging (pinned), one deeper than the image sets
+  // optional: runs fn(0) .. fn(n - 1) on several threads and returns when all are done (the batch entry point's worker
+  // pool); the replay then runs the per-cell adjuster chains and the per-frame merges through it -- pure host code
+  std::function<void(int, const std::function<void(int)>&)> parallel_for;
+  void select_cell(int c, int t, std::vector<KpOut>& out) const;   // select_pass for one cell at threshold t
+  int replay_chains(int nf, const std::vector<int>& floors, std::vector<std::vector<KpOut>>& kps_per_frame);
+  long replay_fallbacks = 0;  // super-frames whose replay needed another device pass (diagnostics)
   double super_floor_factor = 0.49;  // floor of a super-frame pass = threshold x this (two x0.7 steps)
   long super_passes = 0;             // device passes run by super_detect (diagnostics)
   // enqueue_more (optional) is called after the descriptor work has been enqueued and before the one synchronisation,
@@ -99,7 +106,7 @@ struct OrbWorkspace {
   int units_fast_off = 0, units_fast_n = 0, units_blur_off = 0, units_blur_n = 0, units_rows_off = 0, units_rows_n = 0;
   int units_resize_off[8] = {}, units_resize_n[8] = {};
   uint64_t* d_keep = nullptr;  // NMS survivors, one bit per pixel of every (cell, level) image
-  int* d_row_cnt = nullptr; int* d_img_total = nullptr;  // d_img_total and d_kps live inside d_passout
+  int* d_row_cnt = nullptr; int* d_row_off = nullptr; int* d_img_total = nullptr;  // d_img_total and d_kps live inside d_passout
   uint8_t* d_passout = nullptr; uint8_t* h_passout = nullptr; size_t passout_hdr = 0;  // [per-image counts | keypoints]
   RawKp* d_kps = nullptr; DescKp* d_desckp = nullptr; uint8_t* d_desc = nullptr;
   float* d_kpxy = nullptr; int32_t* d_kept = nullptr; float4* d_xyz = nullptr;
@@ -108,13 +115,14 @@ struct OrbWorkspace {
   // pinned host staging for the small per-frame transfers (thresholds, counts, keypoints, descriptors, 3-D points):
   // pageable copies of a few hundred bytes cost 10-20 us each and there are a dozen per frame
   int last_n_total = 0;  // keypoints of the latest detection pass: sizes the next pass's speculative read-back
+  int raw_cap = 0;  // scored corners a pass's pinned read-back buffer holds
   int pin_cap = 0;  // keypoints the staging buffers hold (larger transfers fall back to pageable vectors)
   int* h_totals = nullptr; int* h_base = nullptr;  // h_totals and h_raw live inside h_passout
   RawKp* h_raw = nullptr; DescKp* h_desckp = nullptr; uint8_t* h_desc = nullptr;
   float* h_xyz_in = nullptr; float* h_xyz_out = nullptr; int32_t* h_n = nullptr;
   const RawKp* pass_raw = nullptr;   // the latest gpu_pass: its corners (h_raw or pass_raw_big) ...
   std::vector<RawKp> pass_raw_big;
-  uint8_t* pool_set[2] = {nullptr, nullptr}; uint8_t* blur_set[2] = {nullptr, nullptr};
+  uint8_t* pool_set[kSets] = {}; uint8_t* blur_set[kSets] = {};
   uint8_t* himg_set[2] = {nullptr, nullptr};
   size_t blur_bytes = 0;
   uint8_t* h_img = nullptr;  // gray + mask staging (2 x W x H): the caller's pageable images go through it in chunks

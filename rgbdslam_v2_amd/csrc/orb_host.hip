@@ -107,26 +107,28 @@ void OrbWorkspace::release() {
   }
   if (ev_readback) { (void)hipEventDestroy(ev_readback); ev_readback = nullptr; }
   if (d_passout_slot[0]) use_slot(0);  // the member pointers the frees below go through
-  if (d_passout_slot[1]) { (void)hipFree(d_passout_slot[1]); d_passout_slot[1] = nullptr; }
-  if (h_passout_slot[1]) { (void)hipHostFree(h_passout_slot[1]); h_passout_slot[1] = nullptr; }
-  if (h_base_slot[1]) { (void)hipHostFree(h_base_slot[1]); h_base_slot[1] = nullptr; }
-  d_passout_slot[0] = nullptr; h_passout_slot[0] = nullptr; h_base_slot[0] = nullptr;
-  for (int i = 0; i < 2; ++i) if (ev_pass[i]) { (void)hipEventDestroy(ev_pass[i]); ev_pass[i] = nullptr; }
-  for (int i = 0; i < 3; ++i) if (himg_stage[i]) { (void)hipHostFree(himg_stage[i]); himg_stage[i] = nullptr; }
-  auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  // d_pool / d_blur / h_img alias one of the two sets
-  for (int i = 0; i < 2; ++i) {
-    fr(pool_set[i]); fr(blur_set[i]);
-    if (himg_set[i]) { (void)hipHostFree(himg_set[i]); himg_set[i] = nullptr; }
+  for (int i = 1; i < kSets; ++i) {
+    if (d_passout_slot[i]) { (void)hipFree(d_passout_slot[i]); d_passout_slot[i] = nullptr; }
+    if (h_passout_slot[i]) { (void)hipHostFree(h_passout_slot[i]); h_passout_slot[i] = nullptr; }
+    if (h_base_slot[i]) { (void)hipHostFree(h_base_slot[i]); h_base_slot[i] = nullptr; }
   }
+  d_passout_slot[0] = nullptr; h_passout_slot[0] = nullptr; h_base_slot[0] = nullptr;
+  for (int i = 0; i < kSets; ++i) if (ev_pass[i]) { (void)hipEventDestroy(ev_pass[i]); ev_pass[i] = nullptr; }
+  for (int i = 0; i < kSets + 1; ++i) if (himg_stage[i]) { (void)hipHostFree(himg_stage[i]); himg_stage[i] = nullptr; }
+  auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  // d_pool / d_blur / h_img alias one of the sets
+  for (int i = 0; i < kSets; ++i) { fr(pool_set[i]); fr(blur_set[i]); }
+  for (int i = 0; i < 2; ++i)
+    if (himg_set[i]) { (void)hipHostFree(himg_set[i]); himg_set[i] = nullptr; }
   d_pool = nullptr; d_blur = nullptr; h_img = nullptr;
   fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_units);
-  fr(d_row_cnt); fr(d_keep); fr(d_passout); fr(d_desckp); fr(d_desc); fr(d_kpxy);
+  fr(d_row_cnt); fr(d_row_off); fr(d_keep); fr(d_passout); fr(d_desckp); fr(d_desc); fr(d_kpxy);
   d_img_total = nullptr; d_kps = nullptr;  // live inside d_passout
   fr(d_kept); fr(d_xyz); fr(d_n); fr(d_n_proj);
   auto frh = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
   frh(h_passout); frh(h_base); frh(h_desckp);
-  h_totals = nullptr; h_raw = nullptr;  // live inside h_passout frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n); frh(h_n_proj);
+  h_totals = nullptr; h_raw = nullptr;  // live inside h_passout
+  frh(h_desc); frh(h_xyz_in); frh(h_xyz_out); frh(h_n); frh(h_n_proj);
   W = H = 0;
 }
 
@@ -239,7 +241,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
       for (int bx = 0; bx < (w + 63) / 64; ++bx) units.push_back(TileUnit{(uint16_t)img, (uint16_t)bx, (uint16_t)by, 0});
   };
   units_fast_off = (int)units.size();
-  for (size_t i = 0; i < cell_imgs.size(); ++i) add_tiles((int)i, cell_imgs[i].w, cell_imgs[i].h);
+  for (size_t i = 0; i < cell_imgs.size(); ++i) add_tiles((int)i, cell_imgs[i].w, cell_imgs[i].h, 16);  // orb_fast_nms_kernel: 64 x 16
   units_fast_n = (int)units.size() - units_fast_off;
   units_blur_off = (int)units.size();
   for (size_t i = 0; i < frame_imgs.size(); ++i) add_tiles((int)i, frame_imgs[i].w, frame_imgs[i].h, 16);  // orb_blur_kernel: 64 x 16
@@ -269,6 +271,8 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipMalloc((void**)&d_units, sizeof(TileUnit) * units.size()));
   ORB_HIP(hipMemcpy(d_units, units.data(), sizeof(TileUnit) * units.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
+  ORB_HIP(hipMemset(d_row_cnt, 0, sizeof(int) * (row_off + 16)));   // accumulated by atomics, re-zeroed by the row scan
+  ORB_HIP(hipMalloc((void**)&d_row_off, sizeof(int) * (row_off + 16)));
   ORB_HIP(hipMalloc((void**)&d_keep, sizeof(uint64_t) * (keep_words + 16)));
   // a pass's outputs in ONE buffer -- [per-image counts | keypoints] -- so that they come back in one copy
   passout_hdr = (sizeof(int) * (cell_imgs.size() + 1) + 255) & ~(size_t)255;  // per-image counts + their sum
@@ -283,17 +287,21 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipMalloc((void**)&d_n, sizeof(int32_t)));
   ORB_HIP(hipMalloc((void**)&d_n_proj, sizeof(int32_t) * 64));
   pin_cap = std::min(kp_cap, n_frames > 1 ? 16384 * 8 : 16384);
+  raw_cap = std::min(kp_cap, n_frames > 1 ? 65536 * 8 : 16384);   // a pass's scored corners (16 bytes each)
   ORB_HIP(hipHostMalloc((void**)&h_base, sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
-  ORB_HIP(hipHostMalloc((void**)&h_passout, passout_hdr + sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
+  ORB_HIP(hipHostMalloc((void**)&h_passout, passout_hdr + sizeof(RawKp) * (size_t)raw_cap, hipHostMallocDefault));
   h_totals = reinterpret_cast<int*>(h_passout);
   h_raw = reinterpret_cast<RawKp*>(h_passout + passout_hdr);
   d_passout_slot[0] = d_passout; h_passout_slot[0] = h_passout; h_base_slot[0] = h_base;
   if (n_frames > 1) {
-    ORB_HIP(hipMalloc((void**)&d_passout_slot[1], passout_hdr + sizeof(RawKp) * (size_t)kp_cap));
-    ORB_HIP(hipHostMalloc((void**)&h_passout_slot[1], passout_hdr + sizeof(RawKp) * (size_t)pin_cap, hipHostMallocDefault));
-    ORB_HIP(hipHostMalloc((void**)&h_base_slot[1], sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
-    for (int i = 0; i < 2; ++i) ORB_HIP(hipEventCreateWithFlags(&ev_pass[i], hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) ORB_HIP(hipHostMalloc((void**)&himg_stage[i], (size_t)2 * W * H * n_frames, hipHostMallocDefault));
+    for (int i = 1; i < kSets; ++i) {
+      ORB_HIP(hipMalloc((void**)&d_passout_slot[i], passout_hdr + sizeof(RawKp) * (size_t)kp_cap));
+      ORB_HIP(hipHostMalloc((void**)&h_passout_slot[i], passout_hdr + sizeof(RawKp) * (size_t)raw_cap, hipHostMallocDefault));
+      ORB_HIP(hipHostMalloc((void**)&h_base_slot[i], sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
+    }
+    for (int i = 0; i < kSets; ++i) ORB_HIP(hipEventCreateWithFlags(&ev_pass[i], hipEventDisableTiming));
+    for (int i = 0; i < kSets + 1; ++i)
+      ORB_HIP(hipHostMalloc((void**)&himg_stage[i], (size_t)2 * W * H * n_frames, hipHostMallocDefault));
   }
   ORB_HIP(hipHostMalloc((void**)&h_desckp, sizeof(DescKp) * (size_t)pin_cap, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_desc, (size_t)32 * pin_cap, hipHostMallocDefault));
@@ -314,9 +322,11 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
 // uploads the frame and builds every pyramid (cells + whole frame) and the blurred frame levels
 int OrbWorkspace::ensure_alt(std::string& err) {
   if (pool_set[1]) return RGBDFE_OK;
-  ORB_HIP(hipMalloc((void**)&pool_set[1], pool_bytes));
-  ORB_HIP(hipMemset(pool_set[1], 0, pool_bytes));
-  ORB_HIP(hipMalloc((void**)&blur_set[1], blur_bytes));
+  for (int i = 1; i < (frames > 1 ? kSets : 2); ++i) {  // the super-frame pipeline is kSets deep, the frame pipeline two
+    ORB_HIP(hipMalloc((void**)&pool_set[i], pool_bytes));
+    ORB_HIP(hipMemset(pool_set[i], 0, pool_bytes));
+    ORB_HIP(hipMalloc((void**)&blur_set[i], blur_bytes));
+  }
   ORB_HIP(hipHostMalloc((void**)&himg_set[1], (size_t)2 * W * H * frames, hipHostMallocDefault));
   ORB_HIP(hipDeviceSynchronize());
   return RGBDFE_OK;
@@ -449,14 +459,13 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
     ctl.active[c] = c < n_cells ? active[c] : 0;
   }
   const int n_imgs = n_cells * kLevels;
-  launch_orb_fast_score(d_pool, d_cell_imgs, d_units + units_fast_off, units_fast_n, ctl, d_score, s);
-  launch_orb_nms_count(d_pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, kDetectEdge, d_row_cnt,
-                       d_img_total, d_keep, s);
+  launch_orb_fast_nms(d_pool, d_cell_imgs, n_imgs, d_units + units_fast_off, units_fast_n, ctl, d_score, kDetectEdge, d_row_cnt,
+                      d_row_off, d_img_total, d_keep, s);
   // One round trip per pass: the device scans the per-image counts itself, emits and measures the keypoints, and the
   // host reads counts and keypoints back together -- `bound` of them, a guess from the previous passes; a pass with
   // more keypoints than that pays a second round trip for the rest.
-  const int bound = std::min(pin_cap, std::max(2048, 2 * last_n_total));
-  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_cnt,
+  const int bound = std::min(raw_cap, std::max(2048, 2 * last_n_total));
+  launch_orb_emit(d_pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_off,
                   d_img_total, d_kps, bound, s);
   ORB_HIP(hipGetLastError());
   ORB_HIP(hipMemcpyAsync(h_passout, d_passout, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));  // counts + keypoints
@@ -510,12 +519,7 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
 // neighbour at the floor loses against the same neighbour at t when its own score is >= t (the neighbour's is larger
 // still).  So { corners at t } = { corners at f with score >= t }, in the same raster order; Harris response and angle
 // do not depend on the threshold.
-void OrbWorkspace::select_pass(const std::vector<int>& active, const std::vector<int>& thr,
-                               std::vector<std::vector<KpOut>>& out) {
-  const double tp0 = timing.on ? orb_now_us() : 0;
-  const int* totals = h_totals;
-  const int* base = h_base;
-  const RawKp* raw = pass_raw;
+void OrbWorkspace::select_cell(int c, int thr_c, std::vector<KpOut>& out) const {
   // nfeaturesPerLevel (orb.cpp computeKeyPoints)
   int per_level[kLevels];
   {
@@ -525,27 +529,34 @@ void OrbWorkspace::select_pass(const std::vector<int>& active, const std::vector
     for (int l = 0; l < kLevels - 1; ++l) { per_level[l] = cv_round_f(nd); sum += per_level[l]; nd *= factor; }
     per_level[kLevels - 1] = std::max(kDetectFeatures - sum, 0);
   }
-  for (int c = 0; c < n_cells; ++c) {
-    if (!active[c]) continue;
-    out[c].clear();
-    const int t = std::min(std::max(thr[c], 0), 255);  // the kernel's clamp
-    float sc[kLevels]; int lw[kLevels], lh[kLevels];
-    level_geometry(cells[c].w, cells[c].h, kLevels, sc, lw, lh);
-    for (int l = 0; l < kLevels; ++l) {
-      const int img = c * kLevels + l;
-      static thread_local std::vector<KP> v;  // scratch: 72 (cell, level) images per pass
-      v.clear();
-      v.reserve((size_t)totals[img]);
-      for (int k = 0; k < totals[img]; ++k) {
-        const RawKp& r = raw[(size_t)base[img] + k];
-        if ((int)r.score < t) continue;
-        v.push_back(KP{(float)r.x, (float)r.y, 31 * sc[l], r.angle, r.harris, l, (float)r.score});
-      }
-      retain_best(v, 2 * per_level[l], [](const KP& k) { return k.score; });
-      retain_best(v, per_level[l], [](const KP& k) { return k.response; });
-      for (const KP& k : v) out[c].push_back(KpOut{k.x * sc[l], k.y * sc[l], k.size, k.angle, k.response, l});
+  const int* totals = h_totals;
+  const int* base = h_base;
+  const RawKp* raw = pass_raw;
+  out.clear();
+  const int t = std::min(std::max(thr_c, 0), 255);  // the kernel's clamp
+  float sc[kLevels]; int lw[kLevels], lh[kLevels];
+  level_geometry(cells[c].w, cells[c].h, kLevels, sc, lw, lh);
+  for (int l = 0; l < kLevels; ++l) {
+    const int img = c * kLevels + l;
+    static thread_local std::vector<KP> v;  // scratch: 72 (cell, level) images per pass
+    v.clear();
+    v.reserve((size_t)totals[img]);
+    for (int k = 0; k < totals[img]; ++k) {
+      const RawKp& r = raw[(size_t)base[img] + k];
+      if ((int)r.score < t) continue;
+      v.push_back(KP{(float)r.x, (float)r.y, 31 * sc[l], r.angle, r.harris, l, (float)r.score});
     }
+    retain_best(v, 2 * per_level[l], [](const KP& k) { return k.score; });
+    retain_best(v, per_level[l], [](const KP& k) { return k.response; });
+    for (const KP& k : v) out.push_back(KpOut{k.x * sc[l], k.y * sc[l], k.size, k.angle, k.response, l});
   }
+}
+
+void OrbWorkspace::select_pass(const std::vector<int>& active, const std::vector<int>& thr,
+                               std::vector<std::vector<KpOut>>& out) {
+  const double tp0 = timing.on ? orb_now_us() : 0;
+  for (int c = 0; c < n_cells; ++c)
+    if (active[c]) select_cell(c, thr[c], out[c]);
   if (timing.on) timing.us[4] += orb_now_us() - tp0;
 }
 
@@ -648,12 +659,11 @@ int OrbWorkspace::super_pass_enqueue(int nf, int set, int slot, hipStream_t s, s
   int* const img_total = reinterpret_cast<int*>(dpo);
   RawKp* const kps = reinterpret_cast<RawKp*>(dpo + passout_hdr);
   const int n_imgs = n_cells * kLevels;
-  launch_orb_fast_score(pool, d_cell_imgs, d_units + units_fast_off, units_fast_n, ctl, d_score, s);
-  launch_orb_nms_count(pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, kDetectEdge, d_row_cnt,
-                       img_total, d_keep, s);
-  const int bound = std::min(pin_cap, std::max(2048 * frames, 2 * last_n_total));
+  launch_orb_fast_nms(pool, d_cell_imgs, n_imgs, d_units + units_fast_off, units_fast_n, ctl, d_score, kDetectEdge, d_row_cnt,
+                      d_row_off, img_total, d_keep, s);
+  const int bound = std::min(raw_cap, std::max(2048 * frames, 2 * last_n_total));
   slot_bound[slot] = bound;
-  launch_orb_emit(pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_cnt,
+  launch_orb_emit(pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_off,
                   img_total, kps, bound, s);
   ORB_HIP(hipGetLastError());
   ORB_HIP(hipMemcpyAsync(h_passout_slot[slot], dpo, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
@@ -693,9 +703,81 @@ int OrbWorkspace::super_replay(int nf, int set, int slot, std::vector<std::vecto
 // end up with, and the adjuster is replayed on the host over the scored corners, frame by frame.  A cell whose threshold
 // drops below its floor (rare: two x0.7 steps inside one super-frame) triggers another pass over the frames from there
 // on, with floors taken from the thresholds of that moment -- results do not depend on the floors.
+// The replay of super_detect when one pass at `floors` covers every frame -- the common case -- as independent work items:
+// the adjuster of a grid cell only ever looks at its own cell (feature_adjuster.cpp:185-224 runs inside one cell's
+// detector object), so the grid^2 chains "cell c9 over frames 0 .. nf - 1" do not interact, and neither do the nf per-frame
+// merges (keepStrongest per cell + aggregate, :247-282) that follow.  Both run through parallel_for.  Returns 0 when a chain
+// met a threshold below its floor: nothing has been committed then, and super_detect's sequential loop (which owns the
+// re-pass logic) starts from the same state.  Same selections in the same order as that loop: identical keypoints.
+int OrbWorkspace::replay_chains(int nf, const std::vector<int>& floors, std::vector<std::vector<KpOut>>& kps_per_frame) {
+  const int pc = grid * grid;
+  std::vector<std::vector<KpOut>> cellkp((size_t)nf * pc);
+  std::vector<double> th_end((size_t)pc);
+  std::vector<char> failed((size_t)pc, 0);
+  parallel_for(pc, [&](int c9) {
+    double th = thresh[c9];
+    for (int f = 0; f < nf && !failed[c9]; ++f) {
+      const int c = f * pc + c9;
+      int iter_left = adjuster_iters;
+      bool checked = false, active = true;
+      while (active) {
+        const int t = (int)th;  // static_cast<int>(thresh_)
+        if (t < floors[(size_t)c]) { failed[c9] = 1; break; }
+        select_cell(c, t, cellkp[(size_t)c]);
+        const int found = (int)cellkp[(size_t)c].size();
+        bool again = false;
+        if (found < cell_min) {
+          th *= 0.7;                                 // tooFew (:131-136)
+          if (th < 2) th = 2;
+          bool brk = false;
+          if (found == 0 && !checked) {
+            checked = true;
+            if (!cell_mask_nonzero[(size_t)c]) brk = true;  // hasNonZero(mask) (:205-209)
+          }
+          if (!brk) {
+            iter_left--;
+            again = iter_left > 0 && (th > 2 && th < 10000);  // good() (:147-150)
+          }
+        } else if (found > cell_max) {
+          th *= 1.3;                                 // tooMany (:138-143)
+          if (th > 10000) th = 10000;
+        }
+        active = again;
+      }
+    }
+    th_end[(size_t)c9] = th;
+  });
+  for (int c9 = 0; c9 < pc; ++c9)
+    if (failed[c9]) return 0;
+  for (int c9 = 0; c9 < pc; ++c9) thresh[c9] = th_end[(size_t)c9];
+  kps_per_frame.assign((size_t)nf, std::vector<KpOut>());
+  const int maxPerCell = max_total / pc;  // :292
+  parallel_for(nf, [&](int f) {
+    std::vector<KpOut>& kps = kps_per_frame[(size_t)f];
+    std::vector<KP> v;
+    for (int c9 = 0; c9 < pc; ++c9) {
+      const int c = f * pc + c9;
+      v.clear();
+      v.reserve(cellkp[(size_t)c].size());
+      for (const KpOut& k : cellkp[(size_t)c]) v.push_back(KP{k.x, k.y, k.size, k.angle, k.response, k.octave, 0.f});
+      keep_strongest(v, maxPerCell, [](const KP& k) { return std::fabs(k.response); });  // :247-255
+      for (const KP& k : v)  // aggregateKeypointsPerGridCell (:259-282)
+        kps.push_back(KpOut{k.x + cells[c].x0, k.y + cells[c].y0, k.size, k.angle, k.response, k.octave});
+    }
+  });
+  return 1;
+}
+
 int OrbWorkspace::super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err,
                                const std::vector<int>* covered_floors) {
   const int pc = grid * grid;
+  if (covered_floors && parallel_for) {
+    const double tp0 = timing.on ? orb_now_us() : 0;
+    const int done = replay_chains(nf, *covered_floors, kps_per_frame);
+    if (timing.on) timing.us[4] += orb_now_us() - tp0;
+    if (done) return RGBDFE_OK;
+    replay_fallbacks++;
+  }
   std::vector<std::vector<KpOut>> cellkp((size_t)n_cells);
   std::vector<int> act((size_t)n_cells, 0), thr((size_t)n_cells, 0), floor_thr((size_t)n_cells, 0);
   std::vector<char> covered((size_t)n_cells, 0);

@@ -48,18 +48,16 @@ struct OrbCtl {
   int32_t active[64];
 };
 
-// one workgroup of a 2-D stage: tile (bx, by) of 64 x 4 pixels of image / resize job `img`; for the row stages (one wave per
-// image row) by is the row
+// one workgroup of a 2-D stage: tile (bx, by) of 64 x 4 (resize) or 64 x 16 (FAST, blur) pixels of image / resize job `img`;
+// for the row stages (one wave per image row) by is the row
 struct TileUnit {
   uint16_t img, bx, by, pad;
 };
 
 void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, const TileUnit* units, int n_units, hipStream_t s);
-void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, const OrbCtl& ctl,
-                           uint8_t* score_pool, hipStream_t s);
-void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
-                          const OrbCtl& ctl, const uint8_t* score_pool, int edge, int* row_cnt, int* img_total,
-                          uint64_t* keep_mask, hipStream_t s);
+void launch_orb_fast_nms(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* units, int n_units,
+                         const OrbCtl& ctl, uint8_t* score_pool, int edge, int* row_cnt, int* row_off, int* img_total,
+                         uint64_t* keep_mask, hipStream_t s);
 // img_total[n_imgs] (the per-image counts) doubles as the source of every prefix the later kernels need: no scan launch
 void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
                      const OrbCtl& ctl, const uint8_t* score_pool, const uint64_t* keep_mask, const int* row_off,

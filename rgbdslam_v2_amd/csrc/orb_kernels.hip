@@ -70,117 +70,125 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
-// cv::FAST TYPE_9_16 corner test + cornerScore<16> for every pixel of every image of the launch.
+// cv::FAST TYPE_9_16 corner test + cornerScore<16> + 3x3 non-maximum suppression for every pixel of every image of the
+// launch, one kernel.
+//
+// cv::FAST keeps a pixel when 9 contiguous ring pixels are all brighter than v + t or all darker than v - t, and scores it
+// with cornerScore<16> = (the largest t' for which that still holds) = max over the 16 arcs of 9 of min |difference| over
+// the arc, taken over both polarities, minus 1 (fast_score.cpp: a0 starts at the threshold and only grows, b0 starts at
+// -a0).  So with  P = max_arcs min_{k in arc} d[k]  and  N = max_arcs min_{k in arc} -d[k]  (d = centre - ring):
+//   corner  <=>  max(P, N) > t,      score = max(P, N) - 1.
+// An arc minimum is min3 over three min3's (9 = 3 x 3, v_min3_i32), the maximum over the 16 arcs eight max3's: ~100 integer
+// operations per pixel, no branches, the same integers as the reference's loops.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ ptr, int stride, int threshold) {
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// ptr -> the centre pixel inside an LDS tile of row stride `stride`
+__device__ __forceinline__ int fast_arc_score(const uint8_t* __restrict__ ptr, int stride) {
   const int v = ptr[0];
-  int d[25];
+  int d[16];
   d[0] = v - ptr[3 * stride];       d[1] = v - ptr[1 + 3 * stride];   d[2] = v - ptr[2 + 2 * stride];
   d[3] = v - ptr[3 + stride];       d[4] = v - ptr[3];                d[5] = v - ptr[3 - stride];
   d[6] = v - ptr[2 - 2 * stride];   d[7] = v - ptr[1 - 3 * stride];   d[8] = v - ptr[-3 * stride];
   d[9] = v - ptr[-1 - 3 * stride];  d[10] = v - ptr[-2 - 2 * stride]; d[11] = v - ptr[-3 - stride];
   d[12] = v - ptr[-3];              d[13] = v - ptr[-3 + stride];     d[14] = v - ptr[-2 + 2 * stride];
   d[15] = v - ptr[-1 + 3 * stride];
+  int lo3[16], hi3[16];
 #pragma unroll
-  for (int k = 16; k < 25; ++k) d[k] = d[k - 16];
-  bool corner = false;
-  int cd = 0, cb = 0;
-#pragma unroll
-  for (int k = 0; k < 25; ++k) {
-    cd = d[k] > threshold ? cd + 1 : 0;
-    cb = d[k] < -threshold ? cb + 1 : 0;
-    corner |= (cd > 8) | (cb > 8);
+  for (int k = 0; k < 16; ++k) {
+    lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
   }
-  if (!corner) return 0;
-  int a0 = threshold;
+  int P = -256, N = 256;
 #pragma unroll
   for (int k = 0; k < 16; k += 2) {
-    int a = min(min(d[k + 1], d[k + 2]), d[k + 3]);
-    if (a <= a0) continue;
-    a = min(a, min(min(d[k + 4], d[k + 5]), min(d[k + 6], min(d[k + 7], d[k + 8]))));
-    a0 = max(a0, min(a, d[k]));
-    a0 = max(a0, min(a, d[k + 9]));
+    const int p0 = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    const int p1 = min3i(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]);
+    P = max3i(P, p0, p1);
+    const int n0 = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+    const int n1 = max3i(hi3[k + 1], hi3[(k + 4) & 15], hi3[(k + 7) & 15]);
+    N = min3i(N, n0, n1);
   }
-  int b0 = -a0;
-#pragma unroll
-  for (int k = 0; k < 16; k += 2) {
-    int b = max(max(d[k + 1], d[k + 2]), max(d[k + 3], max(d[k + 4], d[k + 5])));
-    if (b >= b0) continue;
-    b = max(b, max(d[k + 6], max(d[k + 7], d[k + 8])));
-    b0 = min(b0, max(b, d[k]));
-    b0 = min(b0, max(b, d[k + 9]));
-  }
-  return -b0 - 1;
+  return max(P, -N);
 }
 
-__global__ __launch_bounds__(256) void orb_fast_score_kernel(const uint8_t* __restrict__ pool,
-                                                             const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
-                                                             uint8_t* __restrict__ score_pool,
-                                                             const TileUnit* __restrict__ units) {
+// A workgroup owns 64 x 16 pixels of one (cell, level) image: the source tile with a halo of 4 goes through LDS (unaligned
+// dword loads), the scores of the 66 x 18 pixels around the tile are computed into LDS, and the 3x3 test + mask + border
+// filters run from there -- the score plane is written once (the emit stage reads the scores of the survivors) and never
+// read back for the suppression.  Survivors leave as one bit per pixel (64 pixels per word) plus per-row counts (atomics:
+// an image row can span several tiles; the row scan that consumes the counts zeroes them again).
+constexpr int kFastTW = 64, kFastTH = 16, kFastSrcStride = 76, kFastScStride = 68;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__global__ __launch_bounds__(256) void orb_fast_nms_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
+                                                           const OrbCtl ctl, uint8_t* __restrict__ score_pool, int edge,
+                                                           int* __restrict__ row_cnt, uint64_t* __restrict__ keep_mask,
+                                                           int* __restrict__ grand_total,
+                                                           const TileUnit* __restrict__ units) {
+  __shared__ __attribute__((aligned(4))) uint8_t src[(kFastTH + 8) * kFastSrcStride];
+  __shared__ uint8_t sc[(kFastTH + 2) * kFastScStride];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *grand_total = 0;   // the row scan (next launch) adds the per-image totals
   const TileUnit u = units[blockIdx.x];
   const ImgDesc im = imgs[u.img];
   if (!ctl.active[im.cell]) return;
-  const int x = u.bx * 64 + (threadIdx.x & 63);
-  const int y = u.by * 4 + (threadIdx.x >> 6);
-  if (x >= im.w || y >= im.h) return;
-  int s = 0;
-  if (x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3) {
-    int thr = ctl.thr[im.cell];
-    thr = min(max(thr, 0), 255);
-    s = fast_score(pool + im.off + (size_t)y * im.stride + x, im.stride, thr);
-    s = min(max(s, 0), 255);
+  const int tid = threadIdx.x;
+  const int x0 = u.bx * kFastTW, y0 = u.by * kFastTH;
+  const uint8_t* __restrict__ img = pool + im.off;
+  // source rows y0 - 4 .. y0 + 19, columns x0 - 4 .. x0 + 67 (18 dwords per row).  Rows are clamped into the image and a
+  // dword left of column 0 is not loaded: such bytes only feed pixels whose score is 0 by definition (3-pixel border);
+  // a dword may run over the right end of a row (into the next row / the pool's slack) for the same reason.
+  for (int i = tid; i < (kFastTH + 8) * 18; i += 256) {
+    const int r = (i * 3641) >> 16, j = i - r * 18;   // i / 18 for i < 432
+    const int gy = min(max(y0 - 4 + r, 0), im.h - 1), gx = x0 - 4 + 4 * j;
+    uint32_t v = 0;
+    if (gx >= 0 && gx < im.w) v = *reinterpret_cast<const u32_unaligned*>(img + (size_t)gy * im.stride + gx);
+    *reinterpret_cast<uint32_t*>(src + r * kFastSrcStride + 4 * j) = v;
   }
-  score_pool[im.score_off + (size_t)y * im.w + x] = (uint8_t)s;
-}
-
-// keep = 3x3 non-maximum suppression (strict >) && runByPixelsMask && runByImageBorder(edge)
-__device__ __forceinline__ bool nms_keep(const uint8_t* __restrict__ sc, const uint8_t* __restrict__ pool,
-                                         const ImgDesc& im, int x, int y, int edge, int& s_out) {
-  if (!(x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3)) return false;
-  const uint8_t* p = sc + (size_t)y * im.w + x;
-  const int s = p[0];
-  s_out = s;
-  if (!s) return false;
-  const int w = im.w;
-  if (!(s > p[1] && s > p[-1] && s > p[-w - 1] && s > p[-w] && s > p[-w + 1] && s > p[w - 1] && s > p[w] &&
-        s > p[w + 1]))
-    return false;
-  if (im.has_mask && pool[im.mask_off + (size_t)y * im.mask_stride + x] == 0) return false;
-  return x >= edge && x < im.w - edge && y >= edge && y < im.h - edge;
-}
-
-// one wave per image row: count the keypoints of the row and leave their positions as one bit per pixel (64 pixels per
-// word), so that the emit stage does not evaluate the 3x3 test a second time
-__global__ __launch_bounds__(64) void orb_nms_count_kernel(const uint8_t* __restrict__ pool,
-                                                           const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
-                                                           const uint8_t* __restrict__ score_pool, int edge,
-                                                           int* __restrict__ row_cnt,
-                                                           const TileUnit* __restrict__ rows,
-                                                           uint64_t* __restrict__ keep_mask,
-                                                           int* __restrict__ grand_total) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *grand_total = 0;   // the row scan (next launch) adds the per-image totals
-  const TileUnit u = rows[blockIdx.x];   // one wave per image row
-  const ImgDesc im = imgs[u.img];
-  const int y = u.by;
-  if (y >= im.h || !ctl.active[im.cell]) return;
-  const uint8_t* sc = score_pool + im.score_off;
+  __syncthreads();
+  int thr = ctl.thr[im.cell];
+  thr = min(max(thr, 0), 255);
+  uint8_t* __restrict__ score_img = score_pool + im.score_off;
+  for (int i = tid; i < (kFastTH + 2) * 66; i += 256) {
+    const int ty = (i * 993) >> 16, tx = i - ty * 66;   // i / 66 for i < 1188
+    const int x = x0 - 1 + tx, y = y0 - 1 + ty;
+    int s = 0;
+    if (x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3) {
+      const int m = fast_arc_score(src + (ty + 3) * kFastSrcStride + (tx + 3), kFastSrcStride);
+      s = m > thr ? m - 1 : 0;
+    }
+    sc[ty * kFastScStride + tx] = (uint8_t)s;
+    if (tx >= 1 && tx <= kFastTW && ty >= 1 && ty <= kFastTH && x < im.w && y < im.h) score_img[(size_t)y * im.w + x] = (uint8_t)s;
+  }
+  __syncthreads();
+  // wave w: rows 4w .. 4w + 3 of the tile, lane = column
+  const int lane = tid & 63, w = tid >> 6;
   const int words = (im.w + 63) >> 6;
-  uint64_t* __restrict__ km = keep_mask + im.keep_off + (size_t)y * words;
-  int cnt = 0;
-  for (int x0 = 0; x0 < im.w; x0 += 64) {
-    int s;
-    const bool keep = nms_keep(sc, pool, im, x0 + (int)threadIdx.x, y, edge, s);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int ty = w * 4 + rr, y = y0 + ty, x = x0 + lane;
+    if (y >= im.h) break;
+    const uint8_t* p = sc + (ty + 1) * kFastScStride + (lane + 1);
+    const int s = p[0];
+    bool keep = false;
+    if (s && x < im.w) {
+      keep = s > p[1] && s > p[-1] && s > p[-kFastScStride - 1] && s > p[-kFastScStride] && s > p[-kFastScStride + 1] &&
+             s > p[kFastScStride - 1] && s > p[kFastScStride] && s > p[kFastScStride + 1];
+      if (keep && im.has_mask && pool[im.mask_off + (size_t)y * im.mask_stride + x] == 0) keep = false;   // runByPixelsMask
+      keep = keep && x >= edge && x < im.w - edge && y >= edge && y < im.h - edge;                          // runByImageBorder
+    }
     const uint64_t m = __ballot(keep);
-    if (threadIdx.x == 0) km[x0 >> 6] = m;
-    cnt += __popcll(m);
+    if (lane == 0) {
+      keep_mask[im.keep_off + (size_t)y * words + u.bx] = m;
+      if (m) atomicAdd(&row_cnt[im.row_off + y], __popcll(m));
+    }
   }
-  if (threadIdx.x == 0) row_cnt[im.row_off + y] = cnt;
 }
 
-// one block per image: exclusive scan of the row counts, total per image
+// one block per image: exclusive scan of the row counts (-> row_off), total per image; the counts are zeroed for the next
+// pass (orb_fast_nms_kernel accumulates them with atomics)
 __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
-                                                           int* __restrict__ row_cnt, int* __restrict__ img_total,
-                                                           int* __restrict__ grand_total) {
+                                                           int* __restrict__ row_cnt, int* __restrict__ row_off,
+                                                           int* __restrict__ img_total, int* __restrict__ grand_total) {
   __shared__ int part[256];
   const ImgDesc im = imgs[blockIdx.x];
   if (!ctl.active[im.cell]) { if (threadIdx.x == 0) img_total[blockIdx.x] = 0; return; }
@@ -194,13 +202,14 @@ __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __rest
     int acc = 0;
     for (int i = 0; i < 256; ++i) { const int t = part[i]; part[i] = acc; acc += t; }
     img_total[blockIdx.x] = acc;
-    if (acc) atomicAdd(grand_total, acc);   // (zeroed by the NMS launch's memset) the measure waves read one word
+    if (acc) atomicAdd(grand_total, acc);   // (zeroed by the FAST launch) the measure waves read one word
   }
   __syncthreads();
   int acc = part[threadIdx.x];
   for (int r = r0; r < min(r0 + per, im.h); ++r) {
     const int t = row_cnt[im.row_off + r];
-    row_cnt[im.row_off + r] = acc;
+    row_off[im.row_off + r] = acc;
+    row_cnt[im.row_off + r] = 0;
     acc += t;
   }
 }
@@ -333,42 +342,75 @@ __constant__ int c_gauss[7] = {18, 34, 49, 55, 49, 34, 18};
 
 // Separable through LDS: the reference sums c[j] * (sum_i c[i] * p[y+j][x+i]) -- the inner sums h are shared by the 7
 // output rows that use them (integer arithmetic: the same numbers whatever the order of evaluation).  A block owns 64 x 16
-// output pixels: 22 x 70 source bytes (reflect-101 coordinates) -> 22 x 64 row sums -> 16 x 64 outputs.
-constexpr int kBlurTH = 16;
+// output pixels: 22 x 72 source bytes (reflect-101 coordinates; dword loads wherever four bytes lie inside the row) ->
+// 22 x 64 row sums (<= 255 * 257: 16 bits; a thread forms four neighbouring sums from three LDS dwords) -> 16 x 64 outputs
+// (a thread forms four rows of a column from ten row sums).
+constexpr int kBlurTH = 16, kBlurStride = 76;
 __global__ __launch_bounds__(256) void orb_blur_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
                                                        uint8_t* __restrict__ blur_pool, const TileUnit* __restrict__ units) {
-  __shared__ uint8_t patch[(kBlurTH + 6) * 72];
-  __shared__ int hsum[(kBlurTH + 6) * 64];
+  __shared__ __attribute__((aligned(8))) uint8_t patch[(kBlurTH + 6) * kBlurStride];   // columns x0 - 4 .. x0 + 67
+  __shared__ __attribute__((aligned(8))) uint16_t hsum[(kBlurTH + 6) * 64];
   const TileUnit u = units[blockIdx.x];
   const ImgDesc im = imgs[u.img];
   const int x0 = u.bx * 64, y0 = u.by * kBlurTH;
   const uint8_t* __restrict__ src = pool + im.off;
   const int tid = threadIdx.x;
-  for (int i = tid; i < (kBlurTH + 6) * 70; i += 256) {
-    const int py = i / 70, px = i - py * 70;
-    const int gy = reflect101(min(y0 + py - 3, im.h + 2), im.h), gx = reflect101(min(x0 + px - 3, im.w + 2), im.w);
-    patch[py * 72 + px] = src[(size_t)gy * im.stride + gx];
+  for (int i = tid; i < (kBlurTH + 6) * 18; i += 256) {
+    const int r = (i * 3641) >> 16, j = i - r * 18;   // i / 18 for i < 396
+    const int gy = reflect101(min(y0 + r - 3, im.h + 2), im.h);
+    const uint8_t* __restrict__ row = src + (size_t)gy * im.stride;
+    const int gx = x0 - 4 + 4 * j;
+    uint32_t v;
+    if (gx >= 0 && gx + 3 < im.w) {
+      v = *reinterpret_cast<const u32_unaligned*>(row + gx);
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v |= (uint32_t)row[reflect101(min(max(gx + k, -3), im.w + 2), im.w)] << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(patch + r * kBlurStride + 4 * j) = v;
   }
   __syncthreads();
-  for (int i = tid; i < (kBlurTH + 6) * 64; i += 256) {
-    const int py = i >> 6, px = i & 63;
-    const uint8_t* p = patch + py * 72 + px;
-    int h = 0;
+  for (int i = tid; i < (kBlurTH + 6) * 16; i += 256) {
+    const int r = i >> 4, g = i & 15;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(patch + r * kBlurStride + 4 * g);
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    int b[12];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) h += c_gauss[k] * p[k];
-    hsum[i] = h;
+    for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 255; b[4 + k] = (w1 >> (8 * k)) & 255; b[8 + k] = (w2 >> (8 * k)) & 255; }
+    uint32_t h[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int acc = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc += c_gauss[k] * b[t + k + 1];   // output column 4g + t reads patch columns 4g + t + 1 ..
+      h[t] = (uint32_t)acc;
+    }
+    uint2 o;
+    o.x = h[0] | (h[1] << 16);
+    o.y = h[2] | (h[3] << 16);
+    *reinterpret_cast<uint2*>(hsum + r * 64 + 4 * g) = o;
   }
   __syncthreads();
-  for (int i = tid; i < kBlurTH * 64; i += 256) {
-    const int ty = i >> 6, tx = i & 63;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= im.w || y >= im.h) continue;
-    int s = 0;
+  {
+    const int tx = tid & 63, ty0 = (tid >> 6) * 4;
+    const int x = x0 + tx;
+    int hv[10];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) s += c_gauss[j] * hsum[(ty + j) * 64 + tx];
-    int v = (s + (1 << 15)) >> 16;
-    v = min(max(v, 0), 255);
-    blur_pool[im.score_off + (size_t)y * im.w + x] = (uint8_t)v;
+    for (int j = 0; j < 10; ++j) hv[j] = hsum[(ty0 + j) * 64 + tx];
+    if (x < im.w) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int y = y0 + ty0 + t;
+        if (y >= im.h) break;
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) sum += c_gauss[j] * hv[t + j];
+        int v = (sum + (1 << 15)) >> 16;
+        v = min(max(v, 0), 255);
+        blur_pool[im.score_off + (size_t)y * im.w + x] = (uint8_t)v;
+      }
+    }
   }
 }
 
@@ -423,16 +465,14 @@ void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, const TileUnit* uni
   if (n_units == 0) return;
   hipLaunchKernelGGL(orb_resize_kernel, dim3(n_units), dim3(256), 0, s, pool, jobs, units);
 }
-void launch_orb_fast_score(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, const OrbCtl& ctl,
-                           uint8_t* score_pool, hipStream_t s) {
-  hipLaunchKernelGGL(orb_fast_score_kernel, dim3(n_units), dim3(256), 0, s, pool, imgs, ctl, score_pool, units);
-}
-void launch_orb_nms_count(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
-                          const OrbCtl& ctl, const uint8_t* score_pool, int edge, int* row_cnt, int* img_total,
-                          uint64_t* keep_mask, hipStream_t s) {
-  hipLaunchKernelGGL(orb_nms_count_kernel, dim3(n_rows), dim3(64), 0, s, pool, imgs, ctl, score_pool, edge, row_cnt, rows,
-                     keep_mask, img_total + n_imgs);
-  hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, ctl, row_cnt, img_total, img_total + n_imgs);
+// FAST-9/16 scores + 3x3 NMS + mask + border filters (keep bits, per-row counts), then the per-image scan of the row counts
+void launch_orb_fast_nms(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* units, int n_units,
+                         const OrbCtl& ctl, uint8_t* score_pool, int edge, int* row_cnt, int* row_off, int* img_total,
+                         uint64_t* keep_mask, hipStream_t s) {
+  hipLaunchKernelGGL(orb_fast_nms_kernel, dim3(n_units), dim3(256), 0, s, pool, imgs, ctl, score_pool, edge, row_cnt,
+                     keep_mask, img_total + n_imgs, units);
+  hipLaunchKernelGGL(orb_row_scan_kernel, dim3(n_imgs), dim3(256), 0, s, imgs, ctl, row_cnt, row_off, img_total,
+                     img_total + n_imgs);
 }
 // Keypoints of every active image in raster order, then Harris response + orientation for the first `measure_bound` of
 // them -- all without the host knowing the count (it reads img_total back together with the keypoints; a frame with more

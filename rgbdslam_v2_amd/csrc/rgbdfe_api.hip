@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -97,8 +98,8 @@ struct rgbdfe_ctx {
   float* d_kp2d = nullptr;     // max_nodes x max_kp x 2: KeyPoint.pt (allocated with the first rgbdfe_upload_node_keypoints)
   hipStream_t orb_upload_stream = nullptr;  // rgbdfe_detect_describe_batch: uploads of frame k+1 beside frame k
   hipStream_t orb_compute_stream = nullptr; // ... and frame k's description beside frame k+1's detection
-  hipEvent_t orb_upload_done[2] = {nullptr, nullptr};
-  hipEvent_t orb_describe_done[2] = {nullptr, nullptr};  // frame f's description has left image set f & 1
+  hipEvent_t orb_upload_done[OrbWorkspace::kSets] = {};
+  hipEvent_t orb_describe_done[OrbWorkspace::kSets] = {};  // frame f's description has left its image set
   bool feature_min_depth = false;  // "use_feature_min_depth" (parameter_server.cpp:90): rgbdfe_set_feature_min_depth
   bool sift_fast = true;       // sift_match.hip's float keys where a pair qualifies (RGBDFE_SIFT_FAST_KEYS=0: never)
   int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
@@ -1572,6 +1573,16 @@ class TaskPool {  // a few persistent worker threads for pure-CPU jobs
     std::unique_lock<std::mutex> l(m_);
     done_.wait(l, [&] { return pending_ == 0; });
   }
+  int size() const { return (int)th_.size(); }
+  // fn(0) .. fn(n - 1), the caller working too; returns when all are done (and everything else in the queue)
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    std::atomic<int> next{0};
+    auto body = [&next, &fn, n] { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i); } };
+    const int helpers = std::min(n - 1, size());
+    for (int h = 0; h < helpers; ++h) submit(body);
+    body();
+    wait_all();
+  }
  private:
   void run() {
     for (;;) {
@@ -1667,16 +1678,21 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   if (!ctx->orb_upload_stream) {
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_compute_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_upload_done[i], hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_describe_done[i], hipEventDisableTiming));
+    for (hipEvent_t& e : ctx->orb_upload_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : ctx->orb_describe_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   hipStream_t up = ctx->orb_upload_stream, st2 = ctx->orb_compute_stream;
   const int max_kp = ctx->orb_max_keypoints;
   const int S = (n_frames + B - 1) / B;
+  // D - 1 device passes are in flight ahead of the super-frame the host is replaying: D image sets / pass slots, D + 1
+  // staging buffers.  A pass is a chain of ~25 dependent device operations (~1 ms from enqueue to read-back although its
+  // kernels take < 0.5 ms), so one pass ahead leaves the host waiting; two hide the chain.  RGBDFE_SUPER_DEPTH=2: one ahead.
+  int D = OrbWorkspace::kSets;
+  if (const char* e = getenv("RGBDFE_SUPER_DEPTH")) D = std::min(std::max(atoi(e), 2), (int)OrbWorkspace::kSets);
   auto first_of = [&](int s) { return s * B; };
   auto count_of = [&](int s) { return std::min(B, n_frames - s * B); };
-  // helper thread: the caller's pageable images of super-frame s -> pinned staging buffer s % 3, as soon as super-frame
-  // s - 3 (the buffer's previous user) has been detected (its upload from that buffer is complete then)
+  // helper thread: the caller's pageable images of super-frame s -> pinned staging buffer s % (D + 1), as soon as super-frame
+  // s - (D + 1) (the buffer's previous user) has been detected (its upload from that buffer is complete then)
   std::mutex m;
   std::condition_variable cv;
   int staged = 0, detected = 0;
@@ -1685,12 +1701,12 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     for (int s = 0; s < S; ++s) {
       {
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return stop || detected >= s - 2; });
+        cv.wait(l, [&] { return stop || detected >= s - D; });
         if (stop) return;
       }
       for (int k = 0; k < count_of(s); ++k) {
         const int f = first_of(s) + k;
-        orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s % 3, k);
+        orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s % (D + 1), k);
       }
       std::lock_guard<std::mutex> l(m);
       staged = s + 1;
@@ -1706,6 +1722,13 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     }
   } helper_join{helper, m, cv, stop};
   TaskPool pool(std::min(B, 6));
+  static const bool par_replay = !(getenv("RGBDFE_SUPER_PARALLEL_REPLAY") && atoi(getenv("RGBDFE_SUPER_PARALLEL_REPLAY")) == 0);
+  struct ParallelForGuard {  // the workspace outlives the pool
+    OrbWorkspace& o;
+    ~ParallelForGuard() { o.parallel_for = nullptr; }
+  } pf_guard{orb};
+  if (par_replay) orb.parallel_for = [&pool](int n, const std::function<void(int)>& fn) { pool.parallel_for(n, fn); };
+  else orb.parallel_for = nullptr;
   std::vector<SuperFrameJob> jobs[2];
   jobs[0].resize((size_t)B); jobs[1].resize((size_t)B);
   int n_tot[2] = {0, 0};
@@ -1714,10 +1737,10 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
       std::unique_lock<std::mutex> l(m);
       cv.wait(l, [&] { return staged > s; });
     }
-    if (s >= 2 && hipStreamWaitEvent(up, ctx->orb_describe_done[s & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
-    const int r = orb.enqueue_staged_super(count_of(s), up, err, s & 1, s % 3);
+    if (s >= D && hipStreamWaitEvent(up, ctx->orb_describe_done[s % D], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
+    const int r = orb.enqueue_staged_super(count_of(s), up, err, s % D, s % (D + 1));
     if (r != RGBDFE_OK) return r;
-    if (hipEventRecord(ctx->orb_upload_done[s & 1], up) != hipSuccess) { err = "hipEventRecord"; return RGBDFE_ERR_HIP; }
+    if (hipEventRecord(ctx->orb_upload_done[s % D], up) != hipSuccess) { err = "hipEventRecord"; return RGBDFE_ERR_HIP; }
     return RGBDFE_OK;
   };
   // the CPU halves of super-frame s's descriptions: worker threads, no HIP calls
@@ -1738,7 +1761,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     int tot = 0;
     for (int k = 0; k < nf; ++k) { J[(size_t)k].off = tot; tot += (int)J[(size_t)k].kps.size(); }
     n_tot[s & 1] = tot;
-    if (hipStreamWaitEvent(st2, ctx->orb_upload_done[s & 1], 0) != hipSuccess) return RGBDFE_ERR_HIP;
+    if (hipStreamWaitEvent(st2, ctx->orb_upload_done[s % D], 0) != hipSuccess) return RGBDFE_ERR_HIP;
     if (tot > orb.pin_cap || tot > orb.kp_cap) { err = "super-frame: more keypoints than the staging buffers hold"; return RGBDFE_ERR_CAPACITY; }
     if (tot > 0) {
       for (int k = 0; k < nf; ++k) {
@@ -1748,8 +1771,8 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
         memcpy(orb.h_desckp + j.off, j.dk.data(), sizeof(DescKp) * n);
         memcpy(orb.h_xyz_in + (size_t)3 * j.off, j.xyz_in.data(), sizeof(float) * 3 * n);
       }
-      uint8_t* const pool_dev = orb.pool_set[s & 1];
-      uint8_t* const blur_dev = orb.blur_set[s & 1];
+      uint8_t* const pool_dev = orb.pool_set[s % D];
+      uint8_t* const blur_dev = orb.blur_set[s % D];
       if (hipMemcpyAsync(orb.d_desckp, orb.h_desckp, sizeof(DescKp) * (size_t)tot, hipMemcpyHostToDevice, st2) != hipSuccess ||
           hipMemcpyAsync(orb.d_kpxy, orb.h_xyz_in, sizeof(float) * 3 * (size_t)tot, hipMemcpyHostToDevice, st2) != hipSuccess)
         return RGBDFE_ERR_HIP;
@@ -1765,7 +1788,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
           hipMemcpyAsync(orb.h_n_proj, orb.d_n_proj, sizeof(int32_t) * (size_t)nf, hipMemcpyDeviceToHost, st2) != hipSuccess)
         return RGBDFE_ERR_HIP;
     }
-    return hipEventRecord(ctx->orb_describe_done[s & 1], st2) == hipSuccess ? RGBDFE_OK : RGBDFE_ERR_HIP;
+    return hipEventRecord(ctx->orb_describe_done[s % D], st2) == hipSuccess ? RGBDFE_OK : RGBDFE_ERR_HIP;
   };
   auto finish = [&](int s) -> int {
     if (hipStreamSynchronize(st2) != hipSuccess) return RGBDFE_ERR_HIP;
@@ -1796,19 +1819,21 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   // super_replay), so the device works on s + 1 while the host selects keypoints of s; description of s - 1 and the
   // upload of s + 1 are enqueued in between, the CPU halves of the descriptions run on the worker threads.
   auto pass_enqueue = [&](int s) -> int {
-    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[s & 1], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
-    return orb.super_pass_enqueue(count_of(s), s & 1, s & 1, ctx->stream, err);
+    if (hipStreamWaitEvent(ctx->stream, ctx->orb_upload_done[s % D], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
+    return orb.super_pass_enqueue(count_of(s), s % D, s % D, ctx->stream, err);
   };
-  rc = enqueue_upload(0);
-  if (rc == RGBDFE_OK) rc = pass_enqueue(0);
+  for (int s = 0; s < D - 1 && s < S && rc == RGBDFE_OK; ++s) {
+    rc = enqueue_upload(s);
+    if (rc == RGBDFE_OK) rc = pass_enqueue(s);
+  }
   for (int s = 0; s < S && rc == RGBDFE_OK; ++s) {
     const int nf = count_of(s);
     if (tm) tq = orb_now_us();
     if (s > 0) { rc = enqueue_describe(s - 1); if (rc != RGBDFE_OK) break; }
     lap(2);
-    if (s + 1 < S) {
-      rc = enqueue_upload(s + 1);
-      if (rc == RGBDFE_OK) rc = pass_enqueue(s + 1);
+    if (s + D - 1 < S) {
+      rc = enqueue_upload(s + D - 1);
+      if (rc == RGBDFE_OK) rc = pass_enqueue(s + D - 1);
       if (rc != RGBDFE_OK) break;
     }
     lap(3);
@@ -1830,7 +1855,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     }
     lap(0);
     std::vector<std::vector<KpOut>> kps;
-    rc = orb.super_replay(nf, s & 1, s & 1, kps, ctx->stream, err);
+    rc = orb.super_replay(nf, s % D, s % D, kps, ctx->stream, err);
     if (rc != RGBDFE_OK) break;
     {
       std::lock_guard<std::mutex> l(m);
@@ -1845,6 +1870,8 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     lap(5);
   }
   if (tm) {
+    fprintf(stderr, "[rgbdfe super-frame timing] depth %d, parallel replay %d (sequential fallbacks: %ld); ", D, par_replay ? 1 : 0,
+            orb.replay_fallbacks);
     fprintf(stderr, "[rgbdfe super-frame timing] %d frames in %d super-frames, %ld device passes; per frame (us): mask scan %.1f, "
             "replay incl. wait for its pass %.1f, describe enqueue %.1f, upload + next pass enqueue %.1f (re-passes: enqueue %.1f, "
             "wait %.1f; selections %.1f), finish %.1f, prepare start %.1f\n", (int)n_frames, S, orb.super_passes - passes0,
@@ -1908,8 +1935,8 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
   if (!ctx->orb_upload_stream) {
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_compute_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_upload_done[i], hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orb_describe_done[i], hipEventDisableTiming));
+    for (hipEvent_t& e : ctx->orb_upload_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : ctx->orb_describe_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   hipStream_t up = ctx->orb_upload_stream;
   // Frame f lives in image set f & 1 (device pyramid + pinned staging buffer).  A helper thread copies the caller's
