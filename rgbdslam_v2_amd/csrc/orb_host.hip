@@ -252,7 +252,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   units_rows_n = (int)units.size() - units_rows_off;
   for (int l = 1; l < kLevels; ++l) {
     units_resize_off[l] = (int)units.size();
-    for (int k = level_job_begin[l]; k < level_job_begin[l + 1]; ++k) add_tiles(k - level_job_begin[l], jobs[k].dw, jobs[k].dh);
+    for (int k = level_job_begin[l]; k < level_job_begin[l + 1]; ++k) add_tiles(k - level_job_begin[l], jobs[k].dw, jobs[k].dh, 16);  // orb_resize_kernel: 64 x 16
     units_resize_n[l] = (int)units.size() - units_resize_off[l];
   }
   n_rows_total = (int)row_off;

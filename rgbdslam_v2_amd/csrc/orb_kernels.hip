@@ -31,13 +31,15 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // ------------------------------------------------------------------------------------------------
 // (every 2-D stage walks a host-built list of (image, tile) units: the images of a step differ in size by a factor of 13,
 // a grid sized for the largest one would be mostly empty workgroups)
+// A workgroup owns 64 x 16 destination pixels; a thread a column of four rows (the horizontal coefficients are formed once).
+constexpr int kResizeTH = 16;
 __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
                                                          const TileUnit* __restrict__ units) {
   const TileUnit u = units[blockIdx.x];
   const ResizeJob j = jobs[u.img];
   const int dx = u.bx * 64 + (threadIdx.x & 63);
-  const int dy = u.by * 4 + (threadIdx.x >> 6);
-  if (dx >= j.dw || dy >= j.dh) return;
+  const int dy0 = u.by * kResizeTH + (threadIdx.x >> 6) * 4;
+  if (dx >= j.dw || dy0 >= j.dh) return;
   const uint8_t* __restrict__ src = pool + j.src_off;
   float fx = (float)((dx + 0.5) * j.scale_x - 0.5);
   int sx = (int)floorf(fx);
@@ -47,26 +49,27 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
   if (sx >= j.sw - 1) { fx = 0; sx = j.sw - 1; }
   const int a0 = max(min(__float2int_rn((1.f - fx) * 2048), 32767), -32768);
   const int a1 = max(min(__float2int_rn(fx * 2048), 32767), -32768);
-  float fy = (float)((dy + 0.5) * j.scale_y - 0.5);
-  int sy = (int)floorf(fy);
-  fy -= sy;
-  const int b0 = max(min(__float2int_rn((1.f - fy) * 2048), 32767), -32768);
-  const int b1 = max(min(__float2int_rn(fy * 2048), 32767), -32768);
-  const int y0 = min(max(sy, 0), j.sh - 1), y1 = min(max(sy + 1, 0), j.sh - 1);
-  const uint8_t* r0 = src + (size_t)y0 * j.sstride;
-  const uint8_t* r1 = src + (size_t)y1 * j.sstride;
-  int h0, h1;
-  if (!edge) {
-    h0 = r0[sx] * a0 + r0[sx + 1] * a1;
-    h1 = r1[sx] * a0 + r1[sx + 1] * a1;
-  } else {
-    h0 = r0[sx] * 2048;
-    h1 = r1[sx] * 2048;
+  const int sx1 = edge ? sx : sx + 1;          // at the right edge the second tap is not read: a0 = 2048, a1 = 0 there
+  const int c1 = edge ? 0 : a1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int dy = dy0 + t;
+    if (dy >= j.dh) break;
+    float fy = (float)((dy + 0.5) * j.scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    const int b0 = max(min(__float2int_rn((1.f - fy) * 2048), 32767), -32768);
+    const int b1 = max(min(__float2int_rn(fy * 2048), 32767), -32768);
+    const int y0 = min(max(sy, 0), j.sh - 1), y1 = min(max(sy + 1, 0), j.sh - 1);
+    const uint8_t* r0 = src + (size_t)y0 * j.sstride;
+    const uint8_t* r1 = src + (size_t)y1 * j.sstride;
+    const int h0 = r0[sx] * (edge ? 2048 : a0) + r0[sx1] * c1;
+    const int h1 = r1[sx] * (edge ? 2048 : a0) + r1[sx1] * c1;
+    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    if (j.is_mask && v <= 254) v = 0;
+    pool[j.dst_off + (size_t)dy * j.dw + dx] = (uint8_t)v;
   }
-  int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-  v = min(max(v, 0), 255);
-  if (j.is_mask && v <= 254) v = 0;
-  pool[j.dst_off + (size_t)dy * j.dw + dx] = (uint8_t)v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -290,11 +293,14 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-// first..first+grid keypoints
+// first..first+grid keypoints.  The 31 x 31 patch around the keypoint (it lies >= 31 pixels inside the image: runByImageBorder)
+// goes through LDS -- four unaligned dword loads per lane instead of 23 dependent byte gathers -- and both measurements read it
+// from there.
 __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restrict__ pool,
                                                           const ImgDesc* __restrict__ imgs,
                                                           RawKp* __restrict__ kps, const int* __restrict__ img_total,
                                                           int n_imgs, int first) {
+  __shared__ __attribute__((aligned(4))) uint8_t patch_all[4][31 * 32];
   const int k = first + blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // how many keypoints there are (the host has not seen the counts yet): the scan left the sum behind the per-image counts
@@ -303,26 +309,40 @@ __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restr
   RawKp kp = kps[k];
   const ImgDesc im = imgs[kp.img];
   const int stride = im.stride;
-  const uint8_t* __restrict__ center = pool + im.off + (size_t)kp.y * stride + kp.x;
+  uint8_t* __restrict__ patch = patch_all[threadIdx.x >> 6];
+  const uint8_t* __restrict__ corner = pool + im.off + (size_t)(kp.y - 15) * stride + (kp.x - 15);
+#pragma unroll
+  for (int i0 = 0; i0 < 256; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < 31 * 8) {
+      const int r = i >> 3, j = i & 7;
+      *reinterpret_cast<uint32_t*>(patch + r * 32 + 4 * j) = *reinterpret_cast<const u32_unaligned*>(corner + (size_t)r * stride + 4 * j);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // one wave: its LDS writes precede its LDS reads in program order
+  const uint8_t* __restrict__ center = patch + 15 * 32 + 15;
   // Harris: 49 positions, one per lane
   int a = 0, b = 0, c = 0;
   if (lane < 49) {
-    const uint8_t* ptr = center + (lane / 7 - 3) * stride + (lane % 7 - 3);
-    const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-stride + 1] - ptr[-stride - 1]) + (ptr[stride + 1] - ptr[stride - 1]);
-    const int Iy = (ptr[stride] - ptr[-stride]) * 2 + (ptr[stride - 1] - ptr[-stride - 1]) + (ptr[stride + 1] - ptr[-stride + 1]);
+    const uint8_t* ptr = center + (lane / 7 - 3) * 32 + (lane % 7 - 3);
+    const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-32 + 1] - ptr[-32 - 1]) + (ptr[32 + 1] - ptr[32 - 1]);
+    const int Iy = (ptr[32] - ptr[-32]) * 2 + (ptr[32 - 1] - ptr[-32 - 1]) + (ptr[32 + 1] - ptr[-32 + 1]);
     a = Ix * Ix; b = Iy * Iy; c = Ix * Iy;
   }
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
   const float scale = 1.f / ((1 << 2) * 7 * 255.f);
   const float scale_sq_sq = scale * scale * scale * scale;
   const float harris = ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
-  // IC angle: integer moments are order-independent -> any lane assignment is exact
+  // IC angle: integer moments are order-independent -> any lane assignment is exact.  Two patch rows per step: lanes 0-31
+  // row 2i, lanes 32-63 row 2i + 1.
   int m01 = 0, m10 = 0;
-  for (int r = lane; r < 31 * 31; r += 64) {
-    const int v = r / 31 - 15, u = r % 31 - 15;
+  const int u = (lane & 31) - 15, half = lane >> 5;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int v = 2 * it + half - 15;
     const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-    if (au <= c_umax[av]) {
-      const int val = center[u + v * stride];
+    if (v <= 15 && au <= c_umax[av & 15]) {
+      const int val = center[u + v * 32];
       m10 += u * val;
       m01 += v * val;
     }

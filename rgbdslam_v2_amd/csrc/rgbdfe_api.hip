@@ -166,6 +166,7 @@ struct rgbdfe_ctx {
   uint64_t graph_clock = 0;
   int64_t graph_launches = 0, graph_captures = 0;
   bool use_graphs = true;  // RGBDFE_GRAPHS=0: plain stream launches
+  hipStream_t capture_stream = nullptr;  // graphs are captured here, never on a stream other threads may wait on
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   hipEvent_t nodes_ready = nullptr;  // recorded behind the latest rgbdfe_upload_node_device copies; every batch waits for it
   hipEvent_t nodes_ready_ev = nullptr;  // (storage; nodes_ready points here once the first such upload happened)
@@ -396,6 +397,12 @@ uint32_t launch_hamming(rgbdfe_ctx* ctx, const PairWork* d_work, uint32_t* d_key
 // Results land in d_out (device memory; nullptr = the lane's own staging buffer).
 // Returns the batch's ticket.  Caller holds the lock.
 // matcher: 0 = ORB (Hamming), 1 = SIFTGPU (u8 dot products on the MFMA), 2 = FLANN branch (exact L2 knn-2 + ratio test)
+bool capture_stream_ready(rgbdfe_ctx* ctx) {
+  if (ctx->capture_stream) return true;
+  if (hipStreamCreateWithFlags(&ctx->capture_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->capture_stream = nullptr; }
+  return ctx->capture_stream != nullptr;
+}
+
 int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int32_t n,
                   rgbdfe_match_result* d_out, hipEvent_t wait_for, int64_t* ticket_out,
                   int* lane_out, int matcher = 0, float* d_out_dist = nullptr, double flann_ratio = 0.95) {
@@ -484,7 +491,10 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
         ge->used = ++ctx->graph_clock;
         if (hipGraphLaunch(ge->exec, stream) != hipSuccess) launch_err = hipGetLastError();
         ctx->graph_launches++;
-      } else if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      } else if (capture_stream_ready(ctx) && hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        // Captured on a stream of its own, in relaxed mode: other host threads may be waiting on `stream` for an earlier
+        // batch (hipStreamSynchronize on a capturing stream is an error) or be inside the HIP runtime for unrelated work
+        // (any capture that is not relaxed makes their hipMalloc / synchronous copies fail for its duration).
         capturing = true;
         if (ctx->graphs.size() >= 48) {  // drop the least recently used shape
           size_t lru = 0;
@@ -497,9 +507,10 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
         (void)hipGetLastError();  // capture unavailable: plain launches
       }
     }
+    hipStream_t const ls = capturing ? ctx->capture_stream : stream;   // where this batch's operations are issued
     if (!ge) {
-    HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n,
-                                hipMemcpyHostToDevice, stream));
+      const hipError_t me = hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n, hipMemcpyHostToDevice, ls);
+      if (me != hipSuccess && launch_err == hipSuccess) launch_err = me;
     }
     rgbdfe_ctx::Pending pend{};
     pend.sift = sift;
@@ -509,61 +520,61 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       pend.c = get_event(ctx);
       if (sift) pend.d = get_event(ctx);
       pend.pairs = n;
-      (void)hipEventRecord(pend.a, stream);
+      (void)hipEventRecord(pend.a, ls);
     }
     const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
     for (int32_t off = 0; off < n && !ge; off += piece) {
       const int32_t m = (n - off) < piece ? (n - off) : piece;
       const bool first = off == 0, last = off + m >= n;
       if (!first) {  // the schedule of a shorter last piece (its scratch needs are covered by the first one's)
-        int rcl = want_latency_path(ctx, lane, m, stream, &latency, &chunk, &pp);
+        int rcl = want_latency_path(ctx, lane, m, ls, &latency, &chunk, &pp);
         if (rcl != RGBDFE_OK) { launch_err = hipErrorOutOfMemory; break; }
       }
       const PairWork* d_work = slot.d_work + off;
       rgbdfe_match_result* d_res = d_out + off;
       if (!sift) {
-        const uint32_t planes = launch_hamming(ctx, d_work, lane.d_keys, (uint32_t)m, max_nq, max_nt, stream);
-        if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
+        const uint32_t planes = launch_hamming(ctx, d_work, lane.d_keys, (uint32_t)m, max_nq, max_nt, ls);
+        if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
         if (latency)
           launch_select_ransac_latency(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc,
-                                       lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+                                       lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, ls);
         else
           launch_select_ransac(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc, lane.d_prep,
-                               lane.d_ec, stream);
+                               lane.d_ec, ls);
         if (ctx->rc.g2o_iterations > 0)
-          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
-        if (ctx->profiling && last) (void)hipEventRecord(pend.c, stream);
+          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, ls);
+        if (ctx->profiling && last) (void)hipEventRecord(pend.c, ls);
       } else {
         float* d_dist = (d_out_dist ? d_out_dist : lane.d_all_dist) + (size_t)off * RGBDFE_MAX_MATCHES;  // (the lane's buffer holds max_pairs rows)
         if (matcher == 2) {
-          launch_l2_knn2(ctx->d_sift_f32, d_work, mk, (uint32_t)m, max_nq, lane.d_row_part, stream);
-          if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
+          launch_l2_knn2(ctx->d_sift_f32, d_work, mk, (uint32_t)m, max_nq, lane.d_row_part, ls);
+          if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
           launch_l2_ratio(d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part, flann_ratio, lane.d_sm_q,
-                          lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+                          lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
         } else {
           launch_sift_dot(ctx->d_sift_bf16, d_work, mk, (uint32_t)m, max_nq, max_nt, sift_kinds, lane.d_row_part,
-                          lane.d_col_part, stream);
-          if (ctx->profiling && first) (void)hipEventRecord(pend.b, stream);
+                          lane.d_col_part, ls);
+          if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
           launch_sift_finish(ctx->d_sift_f32, d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part,
-                             lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, stream);
+                             lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
         }
-        if (ctx->profiling && first) (void)hipEventRecord(pend.c, stream);
+        if (ctx->profiling && first) (void)hipEventRecord(pend.c, ls);
         if (latency)
           launch_select_ransac_sift_latency(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
                                             d_dist, d_res, mk, (uint32_t)m, ctx->rc,
-                                            lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, stream);
+                                            lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, ls);
         else
           launch_select_ransac_sift(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
                                     lane.d_sm_n, d_dist, d_res, mk,
-                                    (uint32_t)m, ctx->rc, lane.d_prep, lane.d_ec, stream);
+                                    (uint32_t)m, ctx->rc, lane.d_prep, lane.d_ec, ls);
         if (ctx->rc.g2o_iterations > 0)
-          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, stream);
-        if (ctx->profiling && last) (void)hipEventRecord(pend.d, stream);
+          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, ls);
+        if (ctx->profiling && last) (void)hipEventRecord(pend.d, ls);
       }
     }
     if (capturing) {  // close the capture, keep the executable graph, run it
       rgbdfe_ctx::GraphEntry& e = ctx->graphs.back();
-      hipError_t ce = hipStreamEndCapture(stream, &e.graph);
+      hipError_t ce = hipStreamEndCapture(ctx->capture_stream, &e.graph);
       if (ce == hipSuccess) ce = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
       if (ce == hipSuccess) {
         ctx->graph_captures++;
@@ -697,6 +708,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   drain_pending(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
+  if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
   ctx->graphs.clear();
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
   if (ctx->d_xyz) (void)hipFree(ctx->d_xyz);
@@ -1697,6 +1709,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   std::condition_variable cv;
   int staged = 0, detected = 0;
   bool stop = false;
+  TaskPool stage_pool(4);   // declared before the helper thread that feeds it: destroyed after the helper has been joined
   std::thread helper([&]() {
     for (int s = 0; s < S; ++s) {
       {
@@ -1704,10 +1717,12 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
         cv.wait(l, [&] { return stop || detected >= s - D; });
         if (stop) return;
       }
+      // (2 W H bytes per frame through one core's memcpy would bound the whole pipeline: 75 us per 640 x 480 frame)
       for (int k = 0; k < count_of(s); ++k) {
         const int f = first_of(s) + k;
-        orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s % (D + 1), k);
+        stage_pool.submit([&orb, &gray, &mask, f, s, k, D] { orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s % (D + 1), k); });
       }
+      stage_pool.wait_all();
       std::lock_guard<std::mutex> l(m);
       staged = s + 1;
       cv.notify_all();
@@ -1721,7 +1736,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
       if (th.joinable()) th.join();
     }
   } helper_join{helper, m, cv, stop};
-  TaskPool pool(std::min(B, 6));
+  TaskPool pool(B);   // one worker per frame of a super-frame: the description halves of a super-frame run in one round
   static const bool par_replay = !(getenv("RGBDFE_SUPER_PARALLEL_REPLAY") && atoi(getenv("RGBDFE_SUPER_PARALLEL_REPLAY")) == 0);
   struct ParallelForGuard {  // the workspace outlives the pool
     OrbWorkspace& o;

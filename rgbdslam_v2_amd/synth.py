@@ -169,6 +169,12 @@ def sift_descriptors_like(desc_bits: np.ndarray, seed: int = 0, noise: float = 0
     return v.astype(np.float32)
 
 
+def forth_and_back(n_frames, base_len):
+    """Indices into a generated sequence of base_len frames that walk it forth and back: a continuous camera path of any
+    length (long batches for rgbdfe_detect_describe_batch without generating every frame)."""
+    return [i % base_len if (i // base_len) % 2 == 0 else base_len - 1 - i % base_len for i in range(n_frames)]
+
+
 def make_image_sequence(n_frames=4, width=WIDTH, height=HEIGHT, seed=20260923, plane_depth=2.0,
                         nan_fraction=0.03):
     """SURVEY.md 8(d) "Level B": textured gray images of a fronto-parallel plane seen from a moving

@@ -15,8 +15,7 @@ from rgbdslam_v2_amd.frontend import FrontEnd
 
 w, h, n_kp, n_frames, reps = [int(v) for v in (sys.argv[1:6] + ["640", "480", "1000", "56", "5"][len(sys.argv) - 1:])]
 base = synth.make_image_sequence(n_frames=min(n_frames, 28), seed=1, width=w, height=h)
-idx = [i % len(base["gray"]) if (i // len(base["gray"])) % 2 == 0 else len(base["gray"]) - 1 - i % len(base["gray"])
-       for i in range(n_frames)]                        # forth and back: a continuous camera path of any length
+idx = synth.forth_and_back(n_frames, len(base["gray"]))   # a continuous camera path of any length
 gray = [base["gray"][i] for i in idx]
 depth = [base["depth"][i] for i in idx]
 masks = [np.where(base["mask"][i] > 0, 255, 0).astype(np.uint8) for i in idx]

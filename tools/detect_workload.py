@@ -15,8 +15,11 @@ from rgbdslam_v2_amd.frontend import FrontEnd
 kind, w, h, n_kp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 n_frames = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
-seq = synth.make_image_sequence(n_frames=n_frames, seed=1, width=w, height=h)
-masks = [np.where(m > 0, 255, 0).astype(np.uint8) for m in seq["mask"]]
+n_base = min(n_frames, 28 if w <= 640 else 14)      # bench.py's detect sub-record: the generated frames forth and back
+seq = synth.make_image_sequence(n_frames=n_base, seed=1, width=w, height=h)
+idx = synth.forth_and_back(n_frames, n_base)
+seq["gray"], seq["depth"] = [seq["gray"][i] for i in idx], [seq["depth"][i] for i in idx]
+masks = [np.where(seq["mask"][i] > 0, 255, 0).astype(np.uint8) for i in idx]
 fe = FrontEnd(max_nodes=4, max_keypoints=max(64, ((n_kp + 63) // 64) * 64), max_pairs_per_batch=8)
 total = 0
 if kind == "orb":

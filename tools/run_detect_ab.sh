@@ -3,7 +3,7 @@ mkdir -p gpurun_out/r03f; export TMPDIR=/tmp; R=$PWD
 python -m pytest tests/test_gpu_orb.py tests/test_gpu_cpp_host.py -x -q > gpurun_out/r03f/tests.log 2>&1; tail -3 gpurun_out/r03f/tests.log
 python tools/bench_detect_batch.py 640 480 1000 56 5 2>/dev/null | tee gpurun_out/r03f/b640_56.json
 python tools/bench_detect_batch.py 640 480 1000 112 5 2>/dev/null | tee gpurun_out/r03f/b640_112.json
-RGBDFE_DETECT_TIMING=1 python tools/bench_detect_batch.py 1280 960 4000 28 4 2> gpurun_out/r03f/b1280.err | tee gpurun_out/r03f/b1280_28.json
+RGBDFE_DETECT_TIMING=1 python tools/bench_detect_batch.py 1280 960 4000 56 4 2> gpurun_out/r03f/b1280.err | tee gpurun_out/r03f/b1280_28.json
 tail -2 gpurun_out/r03f/b1280.err | cut -c1-500
 cd /tmp
 for cfg in "640 480 1000 56" "1280 960 4000 28"; do set -- $cfg
