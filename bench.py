@@ -713,9 +713,9 @@ def detect_subrecord(device):
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd.frontend import FrontEnd
     out = {}
-    # single calls over the generated frames; the batch entry point over a run of 8 super-frames of 7 (a recorded sequence:
+    # single calls over the generated frames; the batch entry point over a run of 16 / 8 super-frames of 7 (a recorded sequence:
     # the generated frames forth and back) -- its pipeline is three super-frames deep, a short run would time fill and drain
-    for (w, h, n_kp, n_base, n_run) in ((640, 480, 1000, 28, 56), (1280, 960, 4000, 14, 56)):
+    for (w, h, n_kp, n_base, n_run) in ((640, 480, 1000, 28, 112), (1280, 960, 4000, 14, 56)):
         seq = synth.make_image_sequence(n_frames=n_base, seed=1, width=w, height=h)
         masks = [np.where(m > 0, 255, 0).astype(np.uint8) for m in seq["mask"]]
         fe = FrontEnd(device_id=device, max_nodes=4, max_keypoints=((n_kp + 63) // 64) * 64, max_pairs_per_batch=8)

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -79,6 +80,64 @@ inline uint32_t mix32_host(uint32_t x) {
 inline uint32_t pair_uid(int32_t qid, int32_t tid) {
   return mix32_host((uint32_t)qid * 0x9E3779B1u ^ ((uint32_t)tid + 0x7F4A7C15u));
 }
+
+}  // namespace
+
+namespace {
+
+class TaskPool {  // a few persistent worker threads for pure-CPU jobs
+ public:
+  explicit TaskPool(int n) {
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+  }
+  ~TaskPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) if (t.joinable()) t.join();
+  }
+  void submit(std::function<void()> f) {
+    { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); ++pending_; }
+    cv_.notify_one();
+  }
+  void wait_all() {
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [&] { return pending_ == 0; });
+  }
+  int size() const { return (int)th_.size(); }
+  // fn(0) .. fn(n - 1), the caller working too; returns when all are done (and everything else in the queue)
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    std::atomic<int> next{0};
+    auto body = [&next, &fn, n] { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i); } };
+    const int helpers = std::min(n - 1, size());
+    for (int h = 0; h < helpers; ++h) submit(body);
+    body();
+    wait_all();
+  }
+ private:
+  void run() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+        if (stop_ && q_.empty()) return;
+        f = std::move(q_.front());
+        q_.erase(q_.begin());
+      }
+      try { f(); } catch (...) { failed_ = true; }
+      { std::lock_guard<std::mutex> l(m_); --pending_; }
+      done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::vector<std::function<void()>> q_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  int pending_ = 0;
+  bool stop_ = false;
+ public:
+  bool failed_ = false;
+};
 
 }  // namespace
 
@@ -176,6 +235,7 @@ struct rgbdfe_ctx {
   size_t scratch_bytes = 0;
   OrbWorkspace orb;
   OrbWorkspace orb_super;  // rgbdfe_detect_describe_batch: up to 7 frames per launch chain (its own image sets)
+  std::unique_ptr<TaskPool> detect_pool, stage_pool;  // its worker threads (created by the first batch call, kept)
   SiftExtractor sift;  // rgbdfe_sift_detect (sift_extract.hip)
   int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;
@@ -1567,60 +1627,6 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
 // calling thread drives the next super-frame's pass.
 namespace {
 
-class TaskPool {  // a few persistent worker threads for pure-CPU jobs
- public:
-  explicit TaskPool(int n) {
-    for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
-  }
-  ~TaskPool() {
-    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& t : th_) if (t.joinable()) t.join();
-  }
-  void submit(std::function<void()> f) {
-    { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); ++pending_; }
-    cv_.notify_one();
-  }
-  void wait_all() {
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [&] { return pending_ == 0; });
-  }
-  int size() const { return (int)th_.size(); }
-  // fn(0) .. fn(n - 1), the caller working too; returns when all are done (and everything else in the queue)
-  void parallel_for(int n, const std::function<void(int)>& fn) {
-    std::atomic<int> next{0};
-    auto body = [&next, &fn, n] { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i); } };
-    const int helpers = std::min(n - 1, size());
-    for (int h = 0; h < helpers; ++h) submit(body);
-    body();
-    wait_all();
-  }
- private:
-  void run() {
-    for (;;) {
-      std::function<void()> f;
-      {
-        std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return stop_ || !q_.empty(); });
-        if (stop_ && q_.empty()) return;
-        f = std::move(q_.front());
-        q_.erase(q_.begin());
-      }
-      try { f(); } catch (...) { failed_ = true; }
-      { std::lock_guard<std::mutex> l(m_); --pending_; }
-      done_.notify_all();
-    }
-  }
-  std::vector<std::thread> th_;
-  std::vector<std::function<void()>> q_;
-  std::mutex m_;
-  std::condition_variable cv_, done_;
-  int pending_ = 0;
-  bool stop_ = false;
- public:
-  bool failed_ = false;
-};
-
 struct SuperFrameJob {  // one frame of a super-frame, between detection and copy-out
   std::vector<KpOut> kps;
   std::vector<int> order;
@@ -1709,7 +1715,11 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   std::condition_variable cv;
   int staged = 0, detected = 0;
   bool stop = false;
-  TaskPool stage_pool(4);   // declared before the helper thread that feeds it: destroyed after the helper has been joined
+  if (!ctx->stage_pool) ctx->stage_pool.reset(new TaskPool(4));
+  if (!ctx->detect_pool || ctx->detect_pool->size() != B) ctx->detect_pool.reset(new TaskPool(B));  // one worker per frame of a super-frame
+  TaskPool& stage_pool = *ctx->stage_pool;
+  TaskPool& pool = *ctx->detect_pool;
+  pool.failed_ = false;
   std::thread helper([&]() {
     for (int s = 0; s < S; ++s) {
       {
@@ -1736,7 +1746,6 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
       if (th.joinable()) th.join();
     }
   } helper_join{helper, m, cv, stop};
-  TaskPool pool(B);   // one worker per frame of a super-frame: the description halves of a super-frame run in one round
   static const bool par_replay = !(getenv("RGBDFE_SUPER_PARALLEL_REPLAY") && atoi(getenv("RGBDFE_SUPER_PARALLEL_REPLAY")) == 0);
   struct ParallelForGuard {  // the workspace outlives the pool
     OrbWorkspace& o;
