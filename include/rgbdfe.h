@@ -485,6 +485,14 @@ int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32
  * Not built: the wrapper's second mode (a caller-provided keypoint list, :132-142), which rgbdslam_v2's Node never uses. */
 int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,
                        int32_t max_keypoints, rgbdfe_keypoint* keypoints, float* desc128, int32_t capacity, int32_t* n_out);
+/* A run of frames of one size (offline processing of a recorded sequence): the results of n_frames single calls -- the
+ * pipeline keeps no state between images -- with up to 8 frames sharing every launch (a frame alone is ~70 dependent
+ * launches over planes of a few thousand pixels to 1.2 Mpixel and cannot fill the chip).  Frame f's keypoints / descriptors
+ * go to row f * out_stride of keypoints / desc128 (128 floats per row), its count to n_out[f]; RGBDFE_ERR_CAPACITY when a
+ * frame has more than out_stride features (n_out is complete, the rows of the other frames are valid). */
+int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, int32_t rows, int32_t cols,
+                             int32_t max_keypoints, int32_t out_stride, rgbdfe_keypoint* keypoints, float* desc128,
+                             int32_t* n_out);
 /* stage access for parity tests: the pyramid geometry of the latest frame, one Gaussian plane (octave index from 0, level
  * 0 .. levels-1; padded width x height floats), the keypoint candidates of one (octave, DoG level) as rows of
  * (x, y, extremum sign, dx, dy, ds) in list order, before the feature-count limit */

@@ -1327,7 +1327,7 @@ int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* /*ma
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   *n_out = 0;
   std::vector<SiftKey> keys;
-  std::vector<float> desc;
+  const float* desc = nullptr;
   std::string err;
   const int rc = ctx->sift.run(gray, rows, cols, max_keypoints, keys, desc, ctx->stream, err);
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
@@ -1341,7 +1341,48 @@ int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* /*ma
     keypoints[i].response = 0.f;
     keypoints[i].octave = 0;
   }
-  if (!desc.empty()) memcpy(desc128, desc.data(), desc.size() * sizeof(float));
+  if (!keys.empty()) memcpy(desc128, desc, keys.size() * 128 * sizeof(float));
+  return RGBDFE_OK;
+}
+
+// A run of frames (a recorded sequence): SiftExtractor::kMaxBatch of them share every launch of the pipeline -- the
+// images are independent (SiftGPU keeps no state between them), so frame f's outputs are those of a single call.
+int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, int32_t rows, int32_t cols,
+                             int32_t max_keypoints, int32_t out_stride, rgbdfe_keypoint* keypoints, float* desc128,
+                             int32_t* n_out) {
+  if (!ctx || n_frames < 0 || rows < 1 || cols < 1 || out_stride < 0 ||
+      (n_frames > 0 && (!gray || !n_out || (out_stride > 0 && (!keypoints || !desc128)))))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  for (int32_t f = 0; f < n_frames; ++f)
+    if (!gray[f]) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "null frame");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  for (int32_t f = 0; f < n_frames; ++f) n_out[f] = 0;
+  bool overflow = false;
+  std::vector<SiftKey> keys[SiftExtractor::kMaxBatch];
+  const float* desc[SiftExtractor::kMaxBatch];
+  std::string err;
+  for (int32_t f0 = 0; f0 < n_frames; f0 += SiftExtractor::kMaxBatch) {
+    const int nf = std::min<int32_t>(SiftExtractor::kMaxBatch, n_frames - f0);
+    const int rc = ctx->sift.run_batch(gray + f0, nf, rows, cols, max_keypoints, keys, desc, ctx->stream, err);
+    if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+    for (int k = 0; k < nf; ++k) {
+      const int32_t f = f0 + k;
+      n_out[f] = (int32_t)keys[k].size();
+      if ((int32_t)keys[k].size() > out_stride) { overflow = true; continue; }
+      rgbdfe_keypoint* kp = keypoints + (size_t)f * out_stride;
+      for (size_t i = 0; i < keys[k].size(); ++i) {
+        kp[i].x = keys[k][i].x;
+        kp[i].y = keys[k][i].y;
+        kp[i].size = (float)(12.0 * keys[k][i].s);
+        kp[i].angle = (float)(keys[k][i].o * 180.0 / 3.1415927);
+        kp[i].response = 0.f;
+        kp[i].octave = 0;
+      }
+      if (!keys[k].empty()) memcpy(desc128 + (size_t)f * out_stride * 128, desc[k], keys[k].size() * 128 * sizeof(float));
+    }
+  }
+  if (overflow) return fail(ctx, RGBDFE_ERR_CAPACITY, "more SIFT features in a frame than out_stride rows");
   return RGBDFE_OK;
 }
 
@@ -3641,6 +3682,14 @@ int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_detect(c, gray, mask, rows, cols, max_keypoints, keypoints, desc128, capacity,
                                                     n_out));
+}
+
+int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, int32_t rows, int32_t cols,
+                             int32_t max_keypoints, int32_t out_stride, rgbdfe_keypoint* keypoints, float* desc128,
+                             int32_t* n_out) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_detect_batch(c, n_frames, gray, rows, cols, max_keypoints, out_stride, keypoints,
+                                                          desc128, n_out));
 }
 
 int rgbdfe_sift_debug_plane(rgbdfe_ctx* ctx, int32_t octave, int32_t level, float* out, int32_t capacity_floats, int32_t* w,

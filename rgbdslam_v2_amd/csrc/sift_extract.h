@@ -20,11 +20,18 @@ struct SiftExtractor {
   struct Octave { int w, h; size_t plane; float* g[kLevels]; };  // w = the padded width (multiple of 4) every kernel uses
   ~SiftExtractor();
   void release();
-  // one frame: keys (n x 4) + descriptors (n x 128, unnormalised) in SiftGPU's output order
-  int run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys, std::vector<float>& desc,
-          hipStream_t s, std::string& err);
-  // stage access for the parity tests: a Gaussian plane of the latest frame / the keypoint candidates of one
-  // (octave, dog level) as (x, y, sign, dx, dy, ds) in list order, before the feature-count limits
+  static constexpr int kMaxBatch = 8;   // frames per launch chain of run_batch
+  // nf <= kMaxBatch frames of one size through ONE launch chain: keys[f] (n x 4) + desc[f] (n x 128, unnormalised) in SiftGPU's
+  // output order.  Frames are independent (the pipeline keeps no state between images): the batch only shares launches.
+  // desc[f] points into a pinned buffer of this object (valid until the next call): the caller copies from there once
+  int run_batch(const uint8_t* const* gray, int nf, int rows, int cols, int max_features, std::vector<SiftKey>* keys,
+                const float** desc, hipStream_t s, std::string& err);
+  int run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys, const float*& desc,
+          hipStream_t s, std::string& err) {
+    return run_batch(&gray, 1, rows, cols, max_features, &keys, &desc, s, err);
+  }
+  // stage access for the parity tests: a Gaussian plane of the latest call's FIRST frame / the keypoint candidates of one
+  // (octave, dog level) of that frame as (x, y, sign, dx, dy, ds) in list order, before the feature-count limits
   int debug_plane(int octave, int level, std::vector<float>& out, int* w, int* h, hipStream_t s);
   int debug_candidates(int octave, int dog_level, std::vector<float>& out);
 
@@ -49,12 +56,15 @@ struct SiftExtractor {
   float* d_cand = nullptr; size_t cand_cap = 0;        // candidates: 6 floats each, per level at its offset
   float4* d_feat = nullptr; size_t feat_cap = 0;       // feature list (x, y, scale, packed / final orientation)
   float* d_desc = nullptr; size_t desc_cap = 0;
-  int* h_counts = nullptr;                             // pinned: per-level totals
-  float* h_stage = nullptr; size_t stage_floats = 0;   // pinned staging for lists
-  uint8_t* h_gray = nullptr; size_t gray_cap = 0;      // pinned staging of the caller's (pageable) image
-  std::vector<int> lvl_count, lvl_off;                 // candidates per (octave, dog level) of the latest frame
-  std::vector<float> last_cand;
-  int prepare(int rows, int cols, std::string& err);
+  float* h_desc = nullptr; size_t h_desc_cap = 0;      // pinned: the descriptors of the latest call (128 floats per feature)
+  int* h_counts = nullptr;                             // pinned: per-level totals, 64 per frame
+  float* h_stage = nullptr; size_t stage_floats = 0;   // pinned staging for lists (all frames of a batch)
+  uint8_t* h_gray = nullptr; size_t gray_cap = 0;      // pinned staging of the caller's (pageable) images
+  void* d_jobs = nullptr; void* h_jobs = nullptr;      // the per-frame segment tables of the orientation / descriptor launches
+  std::vector<int> lvl_count, lvl_off;                 // candidates per (octave, dog level) of the latest call's first frame
+  int frames_cap = 0;                                  // frames the buffers hold (every device buffer is [frames_cap][...])
+  size_t input_floats = 0;                             // per-frame strides: d_input; d_up = oct[0].plane; d_planes = planes_floats
+  int prepare(int rows, int cols, int nf, std::string& err);
 };
 
 }  // namespace rgbdfe

@@ -37,10 +37,13 @@ constexpr int kMaxTaps = 33;  // KERNEL_MAX_WIDTH (ProgramCU.cu:40)
 struct Taps { float k[kMaxTaps]; int fw; };
 
 // ---- image in: bytes -> luminance / 255 (GLTexInput::DownSamplePixelDataI2F, GLTexImage.cpp:808-831), width cut to w4 ----
+// (every kernel of this file serves a BATCH of frames: one grid dimension is the frame, each buffer has a per-frame stride)
 __global__ __launch_bounds__(256) void sift_convert_kernel(const uint8_t* __restrict__ gray, int cols, int w4, int rows,
                                                            float* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= w4 * rows) return;
+  gray += (size_t)blockIdx.y * rows * cols;
+  out += (size_t)blockIdx.y * w4 * rows;
   const int y = i / w4, x = i - y * w4;
   out[i] = (float)(int)gray[(size_t)y * cols + x] / 255.0f;
 }
@@ -48,10 +51,12 @@ __global__ __launch_bounds__(256) void sift_convert_kernel(const uint8_t* __rest
 // UpsampleKernel<1> (ProgramCU.cu:221-265): src is w x h, dst 2w x 2h.  A fetch past the end of the source returns 0
 // (linear texture), a fetch past the end of a row continues in the next row -- both kept.
 __global__ __launch_bounds__(128) void sift_upsample2_kernel(const float* __restrict__ src, int w, int h,
-                                                             float* __restrict__ dst) {
+                                                             float* __restrict__ dst, size_t dst_stride) {
   const int col = blockIdx.x * 128 + threadIdx.x;
   if (col >= w) return;
   const int n = w * h;
+  src += (size_t)blockIdx.z * n;
+  dst += (size_t)blockIdx.z * dst_stride;
   auto fetch = [&](int i) -> float { return i < n ? src[i] : 0.0f; };
   const int dst_row = blockIdx.y;
   const int row = dst_row >> 1;
@@ -76,9 +81,11 @@ __global__ __launch_bounds__(128) void sift_upsample2_kernel(const float* __rest
 
 // DownsampleKernel<1> (ProgramCU.cu:283-294)
 __global__ __launch_bounds__(128) void sift_downsample2_kernel(const float* __restrict__ src, int src_w, int dst_w, int dst_h,
-                                                               float* __restrict__ dst) {
+                                                               float* __restrict__ dst, size_t frame_stride) {
   const int c = blockIdx.x * 128 + threadIdx.x;
   if (c >= dst_w) return;
+  src += (size_t)blockIdx.z * frame_stride;
+  dst += (size_t)blockIdx.z * frame_stride;
   const int r = blockIdx.y;
   const int sc = min(c << 1, src_w - 1);
   dst[r * dst_w + c] = src[(size_t)(r << 1) * src_w + sc];
@@ -93,8 +100,10 @@ __global__ __launch_bounds__(128) void sift_downsample2_kernel(const float* __re
 // that the tap loops unroll.
 template <int FW, int TW, int TH>
 __global__ __launch_bounds__(256) void sift_filter_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
-                                                          Taps taps) {
+                                                          Taps taps, size_t src_stride, size_t dst_stride) {
   constexpr int R = FW >> 1;
+  src += (size_t)blockIdx.z * src_stride;
+  dst += (size_t)blockIdx.z * dst_stride;
   constexpr int pw = TW + 2 * R, ph = TH + 2 * R;
   __shared__ float patch[ph * pw];   // source rows / columns clamped to the image
   __shared__ float hrow[ph * TW];    // horizontally filtered
@@ -129,31 +138,34 @@ __global__ __launch_bounds__(256) void sift_filter_kernel(const float* __restric
   }
 }
 
+struct FilterArgs { const float* src; float* dst; int w, h, nf; size_t src_stride, dst_stride; };
 template <int FW>
-void launch_filter(const float* src, float* dst, int w, int h, const Taps& t, hipStream_t s) {
-  if ((size_t)w * h <= (size_t)160 * 120)
-    hipLaunchKernelGGL((sift_filter_kernel<FW, 16, 16>), dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, s, src, dst, w, h, t);
+void launch_filter(const FilterArgs& a, const Taps& t, hipStream_t s) {
+  if ((size_t)a.w * a.h * a.nf <= (size_t)160 * 120)   // few thousand pixels in the whole launch: small tiles, more workgroups
+    hipLaunchKernelGGL((sift_filter_kernel<FW, 16, 16>), dim3((a.w + 15) / 16, (a.h + 15) / 16, a.nf), dim3(256), 0, s, a.src, a.dst,
+                       a.w, a.h, t, a.src_stride, a.dst_stride);
   else
-    hipLaunchKernelGGL((sift_filter_kernel<FW, 64, 16>), dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, s, src, dst, w, h, t);
+    hipLaunchKernelGGL((sift_filter_kernel<FW, 64, 16>), dim3((a.w + 63) / 64, (a.h + 15) / 16, a.nf), dim3(256), 0, s, a.src, a.dst,
+                       a.w, a.h, t, a.src_stride, a.dst_stride);
 }
 
-void launch_filter_any(const float* src, float* dst, int w, int h, const Taps& t, hipStream_t s) {
+void launch_filter_any(const FilterArgs& a, const Taps& t, hipStream_t s) {
   switch (t.fw) {   // ProgramCU::FilterImage's switch over the odd widths 5 .. 33 (ProgramCU.cu:430-448)
-    case 5: launch_filter<5>(src, dst, w, h, t, s); break;
-    case 7: launch_filter<7>(src, dst, w, h, t, s); break;
-    case 9: launch_filter<9>(src, dst, w, h, t, s); break;
-    case 11: launch_filter<11>(src, dst, w, h, t, s); break;
-    case 13: launch_filter<13>(src, dst, w, h, t, s); break;
-    case 15: launch_filter<15>(src, dst, w, h, t, s); break;
-    case 17: launch_filter<17>(src, dst, w, h, t, s); break;
-    case 19: launch_filter<19>(src, dst, w, h, t, s); break;
-    case 21: launch_filter<21>(src, dst, w, h, t, s); break;
-    case 23: launch_filter<23>(src, dst, w, h, t, s); break;
-    case 25: launch_filter<25>(src, dst, w, h, t, s); break;
-    case 27: launch_filter<27>(src, dst, w, h, t, s); break;
-    case 29: launch_filter<29>(src, dst, w, h, t, s); break;
-    case 31: launch_filter<31>(src, dst, w, h, t, s); break;
-    default: launch_filter<33>(src, dst, w, h, t, s); break;
+    case 5: launch_filter<5>(a, t, s); break;
+    case 7: launch_filter<7>(a, t, s); break;
+    case 9: launch_filter<9>(a, t, s); break;
+    case 11: launch_filter<11>(a, t, s); break;
+    case 13: launch_filter<13>(a, t, s); break;
+    case 15: launch_filter<15>(a, t, s); break;
+    case 17: launch_filter<17>(a, t, s); break;
+    case 19: launch_filter<19>(a, t, s); break;
+    case 21: launch_filter<21>(a, t, s); break;
+    case 23: launch_filter<23>(a, t, s); break;
+    case 25: launch_filter<25>(a, t, s); break;
+    case 27: launch_filter<27>(a, t, s); break;
+    case 29: launch_filter<29>(a, t, s); break;
+    case 31: launch_filter<31>(a, t, s); break;
+    default: launch_filter<33>(a, t, s); break;
   }
 }
 
@@ -248,17 +260,33 @@ __device__ __forceinline__ KeyEval key_eval(const float* const g[4], int w, int 
   return out;
 }
 
-// one wave per 64 consecutive columns of one row of one (octave, dog level): a flag byte per pixel + the row's count.
+// per-frame strides of the batch: frame f's planes / flags / row counters / level totals / candidates start f strides
+// behind frame 0's, which is what the LevelDesc records point at
+struct FrameStrides { size_t planes, flags, cand; int rows, lvltot; };
+__device__ __forceinline__ SiftExtractor::LevelDesc level_of_frame(SiftExtractor::LevelDesc L, const FrameStrides& st, int f) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) L.g[k] += (size_t)f * st.planes;
+  L.flags += (size_t)f * st.flags;
+  return L;
+}
+
+// one wave per 64 consecutive columns of one row of the stacked (octave, dog level) planes, four rows per workgroup: a flag
+// byte per pixel + the row's count.  (Measured: a wave that walks 8 rows instead of one is 50 % slower -- most pixels leave
+// key_eval after one dependent load, the launch lives on the number of waves in flight.)
 // Counted = what InitHist_Kernel (ProgramCU.cu:665-688) counts: rows 1 .. h-2, columns 1 .. w-2 with a non-zero key.
-__global__ __launch_bounds__(64) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                           const int* __restrict__ row2lvl, int* __restrict__ rowcnt,
-                                                           float dog_threshold0, float dog_threshold, float edge_threshold) {
-  const int grow = blockIdx.y;
+__global__ __launch_bounds__(256) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                            const int* __restrict__ row2lvl, int* __restrict__ rowcnt,
+                                                            float dog_threshold0, float dog_threshold, float edge_threshold,
+                                                            FrameStrides st) {
+  const int lane = threadIdx.x & 63;
+  const int grow = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (grow >= st.rows) return;
+  rowcnt += (size_t)blockIdx.z * st.rows;
   const int lvl = row2lvl[grow];
-  const SiftExtractor::LevelDesc L = levels[lvl];
+  const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.z);
+  if ((int)blockIdx.x * 64 >= L.w) return;
   const int row = grow - L.row0;
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (blockIdx.x * 64 >= L.w) return;
+  const int col = blockIdx.x * 64 + lane;
   int8_t flag = 0;
   if (col < L.w && row > 0 && col > 0 && row < L.h - 1 && col < L.w - 1) {
     const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
@@ -266,14 +294,17 @@ __global__ __launch_bounds__(64) void sift_key_flag_kernel(const SiftExtractor::
   }
   if (col < L.w) L.flags[(size_t)row * L.w + col] = flag;
   const uint64_t m = __ballot(flag != 0);
-  if (threadIdx.x == 0 && m) atomicAdd(&rowcnt[grow], (int)__popcll(m));
+  if (lane == 0 && m) atomicAdd(&rowcnt[grow], (int)__popcll(m));
 }
 
 // per level: exclusive scan of its rows' counts, the level's total
 __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
                                                            const int* __restrict__ rowcnt, int* __restrict__ rowoff,
-                                                           int* __restrict__ lvltot) {
+                                                           int* __restrict__ lvltot, FrameStrides st) {
   const SiftExtractor::LevelDesc L = levels[blockIdx.x];
+  rowcnt += (size_t)blockIdx.y * st.rows;
+  rowoff += (size_t)blockIdx.y * st.rows;
+  lvltot += (size_t)blockIdx.y * st.lvltot;
   int base = 0;
   for (int r0 = 0; r0 < L.h; r0 += 64) {
     const int r = r0 + (int)threadIdx.x;
@@ -294,11 +325,15 @@ __global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::
                                                            const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
                                                            const int* __restrict__ rowoff, const int* __restrict__ lvltot,
                                                            float* __restrict__ cand, int cand_cap, float dog_threshold0,
-                                                           float dog_threshold, float edge_threshold) {
+                                                           float dog_threshold, float edge_threshold, FrameStrides st) {
   const int grow = blockIdx.x;
+  rowcnt += (size_t)blockIdx.y * st.rows;
+  rowoff += (size_t)blockIdx.y * st.rows;
+  lvltot += (size_t)blockIdx.y * st.lvltot;
+  cand += (size_t)blockIdx.y * st.cand;
   if (rowcnt[grow] == 0) return;
   const int lvl = row2lvl[grow];
-  const SiftExtractor::LevelDesc L = levels[lvl];
+  const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.y);
   const int row = grow - L.row0;
   int base = rowoff[grow];
   for (int l = 0; l < lvl; ++l) base += lvltot[l];
@@ -330,6 +365,7 @@ __device__ __forceinline__ float2 grad_at(const float* __restrict__ G, int w, in
 
 struct LevelJobs {  // the kept levels of a frame: consecutive segments of the work list
   int n;
+  int base;           // the frame's first item in the batch-wide feature list (outputs) / candidate offsets are absolute
   int begin[65];      // first work item of the segment (begin[n] = total); kMaxOctaves * kDogLevels = 60 segments at most
   int src_off[64];    // candidate / feature offset of the segment's first item
   const float* g[64]; // the Gaussian plane gradients are taken from (G[j + 1] of the level's octave)
@@ -345,12 +381,14 @@ struct LevelJobs {  // the kept levels of a frame: consecutive segments of the w
 // (the reference's in-place loop reads only old values: `one_third * ((pre + v) + next)`, same association), and the
 // two-peak selection is the reference's sequential scan on wave-uniform scalars.  Only the ORDER of the weight sums
 // differs from the reference (per-lane partial sums): ~1e-7 relative, far inside the libm tolerance of this stage.
-__global__ __launch_bounds__(64) void sift_orientation_kernel(LevelJobs jobs, const float* __restrict__ cand,
-                                                              float4* __restrict__ feat, float sigma_step,
-                                                              float gaussian_factor, float sample_factor) {
+__global__ __launch_bounds__(64) void sift_orientation_kernel(const LevelJobs* __restrict__ jobs_of_frame,
+                                                              const float* __restrict__ cand, float4* __restrict__ feat,
+                                                              float sigma_step, float gaussian_factor, float sample_factor) {
   __shared__ float hist[36][64];
   const float ten_degree_per_radius = 5.7295779513082320876798154814105;
+  const LevelJobs& jobs = jobs_of_frame[blockIdx.y];
   const int idx = blockIdx.x;
+  if (idx >= jobs.begin[jobs.n]) return;   // the grid is sized for the batch's largest frame
   const int lane = threadIdx.x;
   int s = 0;
   while (s + 1 < jobs.n && idx >= jobs.begin[s + 1]) ++s;
@@ -439,24 +477,27 @@ __global__ __launch_bounds__(64) void sift_orientation_kernel(LevelJobs jobs, co
   }
   const unsigned int uspack = ((unsigned int)us2 << 16) | us1;
   key.w = __uint_as_float(uspack);
-  feat[idx] = key;
+  feat[jobs.base + idx] = key;
 }
 
 // ComputeDescriptor_Kernel<false> (ProgramCU.cu:967-1046).  The reference gives each of a feature's 16 cells one thread;
 // here a cell gets a WAVE: the samples of the cell's bounding box go round-robin over the lanes, every lane keeps its own
 // 8 + 1 bins in registers (the reference's compare-and-add over k, so no dynamic indexing), a fixed butterfly sums the
 // lanes.  Per-sample arithmetic is the reference's; only the order of the sums differs (see the orientation kernel).
-__global__ __launch_bounds__(64) void sift_descriptor_kernel(LevelJobs jobs, const float4* __restrict__ feat,
-                                                             float4* __restrict__ d_des, float window_factor) {
+__global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* __restrict__ jobs_of_frame,
+                                                              const float4* __restrict__ feat, float4* __restrict__ d_des,
+                                                              float window_factor) {
   const float rpi = 4.0 / 3.14159265358979323846;
-  const int idx = blockIdx.x;      // feature * 16 + cell
-  const int lane = threadIdx.x;
+  const LevelJobs& jobs = jobs_of_frame[blockIdx.y];
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // feature * 16 + cell: four cells (waves) per workgroup
+  const int lane = threadIdx.x & 63;
   const int fidx = idx >> 4;
+  if (fidx >= jobs.begin[jobs.n]) return;
   int s = 0;
   while (s + 1 < jobs.n && fidx >= jobs.begin[s + 1]) ++s;
   const int width = jobs.w[s], height = jobs.h[s];
   const float* __restrict__ G = jobs.g[s];
-  const float4 key = feat[fidx];
+  const float4 key = feat[jobs.base + fidx];
   const int bidx = idx & 0xf, ix = bidx & 0x3, iy = bidx >> 2;
   const float spt = fabsf(key.z * window_factor);
   float sn, cs;
@@ -517,7 +558,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(LevelJobs jobs, con
     for (int d = 32; d >= 1; d >>= 1) des[i] += __shfl_xor(des[i], d);
   if (lane != 0) return;
   des[0] += des[8];
-  const int didx = idx << 1;
+  const int didx = (jobs.base * 16 + idx) << 1;
   d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
   d_des[didx + 1] = make_float4(des[4], des[5], des[6], des[7]);
 }
@@ -561,12 +602,17 @@ void SiftExtractor::release() {
   if (d_cand) (void)hipFree(d_cand);
   if (d_feat) (void)hipFree(d_feat);
   if (d_desc) (void)hipFree(d_desc);
+  if (d_jobs) (void)hipFree(d_jobs);
   if (h_counts) (void)hipHostFree(h_counts);
   if (h_stage) (void)hipHostFree(h_stage);
   if (h_gray) (void)hipHostFree(h_gray);
+  if (h_jobs) (void)hipHostFree(h_jobs);
+  if (h_desc) (void)hipHostFree(h_desc);
+  h_desc = nullptr; h_desc_cap = 0;
   d_gray = nullptr; d_input = d_up = d_planes = nullptr; d_flags = nullptr; d_rowcnt = d_rowoff = d_lvltot = nullptr;
   d_levels = nullptr; d_cand = nullptr; d_feat = nullptr; d_desc = nullptr; h_counts = nullptr; h_stage = nullptr;
-  h_gray = nullptr; gray_cap = 0; stage_floats = 0; cand_cap = feat_cap = desc_cap = 0; W = H = 0;
+  d_jobs = nullptr; h_jobs = nullptr;
+  h_gray = nullptr; gray_cap = 0; stage_floats = 0; cand_cap = feat_cap = desc_cap = 0; W = H = 0; frames_cap = 0;
 }
 
 void SiftExtractor::init_params() {  // SiftParam::ParseSiftParam (SiftGPU.cpp:433-473) with "-d 5 -e 10.0"
@@ -589,10 +635,11 @@ float SiftExtractor::initial_smooth_sigma(int om) const {
 
 float SiftExtractor::level_sigma(int lev) const { return sigma0 * powf(2.0f, float(lev) / float(kDogLevels)); }
 
-// PyramidCU::InitPyramid / ResizePyramid / FitPyramid (PyramidCU.cpp:86-306): the geometry a frame of this size gets
-int SiftExtractor::prepare(int rows, int cols, std::string& err) {
+// PyramidCU::InitPyramid / ResizePyramid / FitPyramid (PyramidCU.cpp:86-306): the geometry a frame of this size gets;
+// every buffer holds nf frames side by side
+int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
   init_params();
-  if (rows == H && cols == W && d_planes) return RGBDFE_OK;
+  if (rows == H && cols == W && d_planes && nf <= frames_cap) return RGBDFE_OK;
   const int tw = cols & 0xfffffffc;  // GLTexInput::TruncateWidthCU (GLTexImage.h:125)
   if (tw < 16 || rows < 16) { err = "image too small for SIFT extraction"; return RGBDFE_ERR_INVALID_ARG; }
   int om = -1;  // "-fo -1"
@@ -602,6 +649,7 @@ int SiftExtractor::prepare(int rows, int cols, std::string& err) {
   int on = (int)floor(log(double(std::min(wp, hp))) / log(2.0)) - 3;
   if (on < 1) on = 1;
   if (on > kMaxOctaves) on = kMaxOctaves;
+  if (rows == H && cols == W && nf < frames_cap) nf = frames_cap;
   release();
   W = cols; H = rows; w4 = tw; octave_min = om; octave_num = on;
   size_t total = 0;
@@ -616,20 +664,22 @@ int SiftExtractor::prepare(int rows, int cols, std::string& err) {
     w >>= 1; h >>= 1;
   }
   planes_floats = total;
-  SIFT_HIP(hipMalloc((void**)&d_gray, (size_t)rows * cols));
-  SIFT_HIP(hipMalloc((void**)&d_input, (size_t)tw * rows * 4));
-  SIFT_HIP(hipMalloc((void**)&d_up, oct[0].plane * 4));
-  SIFT_HIP(hipMalloc((void**)&d_planes, total * 4));
+  input_floats = (size_t)tw * rows;
+  const size_t F = (size_t)nf;
+  SIFT_HIP(hipMalloc((void**)&d_gray, F * rows * cols));
+  SIFT_HIP(hipMalloc((void**)&d_input, F * input_floats * 4));
+  SIFT_HIP(hipMalloc((void**)&d_up, F * oct[0].plane * 4));
+  SIFT_HIP(hipMalloc((void**)&d_planes, F * total * 4));
   size_t off = 0, foff = 0;
   for (int i = 0; i < on; ++i)
-    for (int l = 0; l < kLevels; ++l) { oct[i].g[l] = d_planes + off; off += oct[i].plane; }
+    for (int l = 0; l < kLevels; ++l) { oct[i].g[l] = d_planes + off; off += oct[i].plane; }   // frame 0's planes
   for (int i = 0; i < on; ++i) foff += oct[i].plane * kDogLevels;
   flags_bytes = foff;
-  SIFT_HIP(hipMalloc((void**)&d_flags, flags_bytes));
-  // rowcnt | rowoff | row2lvl | lvltot
-  SIFT_HIP(hipMalloc((void**)&d_rowcnt, sizeof(int) * ((size_t)total_rows * 3 + 64)));
-  d_rowoff = d_rowcnt + total_rows;
-  d_lvltot = d_rowcnt + (size_t)total_rows * 3;
+  SIFT_HIP(hipMalloc((void**)&d_flags, F * flags_bytes));
+  // rowcnt [nf][total_rows] | rowoff [nf][total_rows] | row2lvl [total_rows] | lvltot [nf][64]
+  SIFT_HIP(hipMalloc((void**)&d_rowcnt, sizeof(int) * ((size_t)total_rows * (2 * F + 1) + 64 * F)));
+  d_rowoff = d_rowcnt + (size_t)total_rows * F;
+  d_lvltot = d_rowcnt + (size_t)total_rows * (2 * F + 1);
   h_levels.assign((size_t)on * kDogLevels, LevelDesc{});
   std::vector<int> row2lvl((size_t)total_rows);
   int row0 = 0;
@@ -647,125 +697,154 @@ int SiftExtractor::prepare(int rows, int cols, std::string& err) {
     }
   SIFT_HIP(hipMalloc((void**)&d_levels, sizeof(LevelDesc) * h_levels.size()));
   SIFT_HIP(hipMemcpy(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice));
-  SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2, row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
+  SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2 * F, row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
   cand_cap = std::max<size_t>((size_t)1 << 16, oct[0].plane / 16);
-  SIFT_HIP(hipMalloc((void**)&d_cand, cand_cap * 6 * 4));
-  feat_cap = cand_cap * 2;
-  SIFT_HIP(hipMalloc((void**)&d_feat, feat_cap * 16));
-  SIFT_HIP(hipHostMalloc((void**)&h_counts, sizeof(int) * 64, hipHostMallocDefault));
-  stage_floats = cand_cap * 8;
+  SIFT_HIP(hipMalloc((void**)&d_cand, F * cand_cap * 6 * 4));
+  feat_cap = cand_cap * 2;                      // per frame; the batch-wide lists are packed: F * feat_cap entries at most
+  SIFT_HIP(hipMalloc((void**)&d_feat, F * feat_cap * 16));
+  SIFT_HIP(hipHostMalloc((void**)&h_counts, sizeof(int) * 64 * F, hipHostMallocDefault));
+  stage_floats = F * cand_cap * 8;
   SIFT_HIP(hipHostMalloc((void**)&h_stage, stage_floats * 4, hipHostMallocDefault));
   gray_cap = (size_t)rows * cols;
-  SIFT_HIP(hipHostMalloc((void**)&h_gray, gray_cap, hipHostMallocDefault));
+  SIFT_HIP(hipHostMalloc((void**)&h_gray, F * gray_cap, hipHostMallocDefault));
+  SIFT_HIP(hipMalloc((void**)&d_jobs, sizeof(LevelJobs) * F));
+  SIFT_HIP(hipHostMalloc((void**)&h_jobs, sizeof(LevelJobs) * F, hipHostMallocDefault));
+  frames_cap = nf;
   return RGBDFE_OK;
 }
 
-int SiftExtractor::run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys,
-                       std::vector<float>& desc, hipStream_t s, std::string& err) {
-  keys.clear();
-  desc.clear();
-  int rc = prepare(rows, cols, err);
+int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int cols, int max_features, std::vector<SiftKey>* keys,
+                             const float** desc, hipStream_t s, std::string& err) {
+  if (nf < 1 || nf > kMaxBatch) { err = "SIFT batch size out of range"; return RGBDFE_ERR_INVALID_ARG; }
+  for (int f = 0; f < nf; ++f) { keys[f].clear(); desc[f] = nullptr; }
+  int rc = prepare(rows, cols, nf, err);
   if (rc != RGBDFE_OK) return rc;
   const int nlv = octave_num * kDogLevels;
-  // ---- image in (GLTexInput::SetImageData, CUDA branch, GLTexImage.cpp:971-1009) + BuildPyramid (PyramidCU.cpp:946-998) ----
-  memcpy(h_gray, gray, (size_t)rows * cols);
-  SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)rows * cols, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
-  auto filter = [&](const float* src, float* dst, int w, int h, float sg) { launch_filter_any(src, dst, w, h, make_taps(sg), s); };
+  const unsigned NF = (unsigned)nf;
+  FrameStrides st{};
+  st.planes = planes_floats; st.flags = flags_bytes; st.cand = cand_cap * 6; st.rows = total_rows; st.lvltot = 64;
+  // ---- images in (GLTexInput::SetImageData, CUDA branch, GLTexImage.cpp:971-1009) + BuildPyramid (PyramidCU.cpp:946-998) ----
+  for (int f = 0; f < nf; ++f) memcpy(h_gray + (size_t)f * gray_cap, gray[f], gray_cap);
+  SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)nf * gray_cap, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256, NF), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
+  auto filter = [&](const float* src, size_t src_stride, float* dst, int w, int h, float sg) {
+    launch_filter_any(FilterArgs{src, dst, w, h, nf, src_stride, planes_floats}, make_taps(sg), s);
+  };
   for (int i = 0; i < octave_num; ++i) {
     const Octave& o = oct[i];
     if (i == 0) {
       const float sg = initial_smooth_sigma(octave_min);
       if (octave_min < 0) {  // SampleImageU + FilterImage in place through the buffer plane
-        hipLaunchKernelGGL(sift_upsample2_kernel, dim3((w4 + 127) / 128, rows << 1), dim3(128), 0, s, d_input, w4, rows, d_up);
-        filter(d_up, o.g[0], o.w, o.h, sg);
+        hipLaunchKernelGGL(sift_upsample2_kernel, dim3((w4 + 127) / 128, rows << 1, NF), dim3(128), 0, s, d_input, w4, rows, d_up,
+                           o.plane);
+        filter(d_up, o.plane, o.g[0], o.w, o.h, sg);
       } else {
-        filter(d_input, o.g[0], o.w, o.h, sg);
+        filter(d_input, input_floats, o.g[0], o.w, o.h, sg);
       }
     } else {  // SampleImageD from level_ds of the octave below (index level_ds - level_min = 5); sigma_skip1 = 0
       const Octave& p = oct[i - 1];
-      hipLaunchKernelGGL(sift_downsample2_kernel, dim3((o.w + 127) / 128, o.h), dim3(128), 0, s, p.g[kDogLevels], p.w, o.w, o.h,
-                         o.g[0]);
+      hipLaunchKernelGGL(sift_downsample2_kernel, dim3((o.w + 127) / 128, o.h, NF), dim3(128), 0, s, p.g[kDogLevels], p.w, o.w, o.h,
+                         o.g[0], planes_floats);
     }
-    for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], o.g[l], o.w, o.h, sigma[l - 1]);
+    for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, sigma[l - 1]);
   }
   // ---- DetectKeypointsEX + the list part of GenerateFeatureList: flags, row counts, scan, ordered emit ----------------------
   const float tdog = dog_threshold, tdog1 = 0.8f * tdog;
   const float tedge = (edge_threshold + 1) * (edge_threshold + 1) / edge_threshold;
-  int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2;
-  SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows, s));
-  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, total_rows), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt,
-                     tdog1, tdog, tedge);
-  hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot);
-  hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
-                     d_cand, (int)cand_cap, tdog1, tdog, tedge);
+  int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2 * frames_cap;
+  st.rows = total_rows;
+  SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
+  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, (total_rows + 3) / 4, NF), dim3(256),
+                     0, s, d_levels, d_row2lvl, d_rowcnt, tdog1, tdog, tedge, st);
+  hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
+  hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows, NF), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
+                     d_cand, (int)cand_cap, tdog1, tdog, tedge, st);
   SIFT_HIP(hipGetLastError());
-  SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * (size_t)nlv, hipMemcpyDeviceToHost, s));
+  SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * 64 * (size_t)nf, hipMemcpyDeviceToHost, s));
   SIFT_HIP(hipStreamSynchronize(s));
-  lvl_count.assign(h_counts, h_counts + nlv);
-  lvl_off.assign((size_t)nlv + 1, 0);
-  for (int i = 0; i < nlv; ++i) lvl_off[(size_t)i + 1] = lvl_off[(size_t)i] + lvl_count[(size_t)i];
-  if ((size_t)lvl_off[(size_t)nlv] > cand_cap) { err = "more SIFT keypoint candidates than the candidate buffer holds"; return RGBDFE_ERR_CAPACITY; }
-  // ---- which levels run: GenerateFeatureList's "-tc2" order (coarse octaves first, PyramidCU.cpp:797-850) and
+  // ---- per frame: which levels run -- GenerateFeatureList's "-tc2" order (coarse octaves first, PyramidCU.cpp:797-850) and
   //      SiftPyramid::LimitFeatureCount(0) (SiftPyramid.cpp:170-210, _TruncateMethod = 1).  A skipped level contributes
   //      nothing (the reference leaves the previous frame's list in it: DESIGN.md 4.11) ---------------------------------
-  std::vector<int> level_num((size_t)nlv, 0);
-  int feature_num = 0;
-  for (int i = octave_num - 1; i >= 0; --i)
-    for (int j = kDogLevels - 1; j >= 0; --j) {
-      if (max_features > 0 && feature_num > max_features) continue;
-      level_num[(size_t)i * kDogLevels + j] = lvl_count[(size_t)i * kDogLevels + j];
-      feature_num += lvl_count[(size_t)i * kDogLevels + j];
-    }
-  auto limit = [&]() {
+  struct FrameState {
+    std::vector<int> cnt, off, level_num;
+    int feature_num = 0, total = 0, base = 0, erased = 0;
+    std::vector<float> list, keybuf;
+  };
+  std::vector<FrameState> fs((size_t)nf);
+  auto limit = [&](FrameState& F) {
     if (max_features <= 0) return 0;
     int i = 0, erased = 0;
-    while (i < nlv && feature_num - level_num[(size_t)i] > max_features) {
-      erased += level_num[(size_t)i];
-      feature_num -= level_num[(size_t)i];
-      level_num[(size_t)i++] = 0;
+    while (i < nlv && F.feature_num - F.level_num[(size_t)i] > max_features) {
+      erased += F.level_num[(size_t)i];
+      F.feature_num -= F.level_num[(size_t)i];
+      F.level_num[(size_t)i++] = 0;
     }
     return erased;
   };
-  limit();
-  if (feature_num == 0) return RGBDFE_OK;
-  // ---- GetFeatureOrientations (PyramidCU.cpp:1145-1172) --------------------------------------------------------------------
-  LevelJobs jobs{};
-  int total = 0;
-  for (int idx = 0; idx < nlv; ++idx) {
-    if (level_num[(size_t)idx] <= 0) continue;
-    const int i = idx / kDogLevels, j = idx % kDogLevels;
-    const int n = jobs.n++;
-    jobs.begin[n] = total;
-    jobs.src_off[n] = lvl_off[(size_t)idx];
-    jobs.g[n] = oct[i].g[j + 1];
-    jobs.w[n] = oct[i].w; jobs.h[n] = oct[i].h;
-    jobs.sigma[n] = level_sigma(j);  // GetLevelSigma(j + level_min + 1)
-    total += level_num[(size_t)idx];
+  LevelJobs* hj = static_cast<LevelJobs*>(h_jobs);
+  int grand = 0, max_total = 0;
+  for (int f = 0; f < nf; ++f) {
+    FrameState& F = fs[(size_t)f];
+    F.cnt.assign(h_counts + (size_t)f * 64, h_counts + (size_t)f * 64 + nlv);
+    F.off.assign((size_t)nlv + 1, 0);
+    for (int i = 0; i < nlv; ++i) F.off[(size_t)i + 1] = F.off[(size_t)i] + F.cnt[(size_t)i];
+    if ((size_t)F.off[(size_t)nlv] > cand_cap) { err = "more SIFT keypoint candidates than the candidate buffer holds"; return RGBDFE_ERR_CAPACITY; }
+    F.level_num.assign((size_t)nlv, 0);
+    for (int i = octave_num - 1; i >= 0; --i)
+      for (int j = kDogLevels - 1; j >= 0; --j) {
+        if (max_features > 0 && F.feature_num > max_features) continue;
+        F.level_num[(size_t)i * kDogLevels + j] = F.cnt[(size_t)i * kDogLevels + j];
+        F.feature_num += F.cnt[(size_t)i * kDogLevels + j];
+      }
+    limit(F);
+    // ---- GetFeatureOrientations (PyramidCU.cpp:1145-1172): the frame's segment table --------------------------------------
+    LevelJobs& jobs = hj[f];
+    memset(&jobs, 0, sizeof(jobs));
+    int total = 0;
+    for (int idx = 0; idx < nlv; ++idx) {
+      if (F.level_num[(size_t)idx] <= 0) continue;
+      const int i = idx / kDogLevels, j = idx % kDogLevels;
+      const int n = jobs.n++;
+      jobs.begin[n] = total;
+      jobs.src_off[n] = (int)((size_t)f * cand_cap) + F.off[(size_t)idx];
+      jobs.g[n] = oct[i].g[j + 1] + (size_t)f * planes_floats;
+      jobs.w[n] = oct[i].w; jobs.h[n] = oct[i].h;
+      jobs.sigma[n] = level_sigma(j);  // GetLevelSigma(j + level_min + 1)
+      total += F.level_num[(size_t)idx];
+    }
+    jobs.begin[jobs.n] = total;
+    jobs.base = grand;
+    F.total = total; F.base = grand;
+    grand += total;
+    max_total = std::max(max_total, total);
   }
-  jobs.begin[jobs.n] = total;
+  lvl_count = fs[0].cnt;
+  lvl_off = fs[0].off;
+  if (grand == 0) return RGBDFE_OK;
+  if ((size_t)grand * 4 > stage_floats) { err = "SIFT staging buffer too small"; return RGBDFE_ERR_CAPACITY; }
   const float sigma_step = powf(2.0f, 1.0f / kDogLevels);
-  hipLaunchKernelGGL(sift_orientation_kernel, dim3(total), dim3(64), 0, s, jobs, d_cand, d_feat, sigma_step, 1.5f,
-                     1.5f * 2.0f);
+  SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(sift_orientation_kernel, dim3(max_total, NF), dim3(64), 0, s, static_cast<const LevelJobs*>(d_jobs), d_cand, d_feat,
+                     sigma_step, 1.5f, 1.5f * 2.0f);
   SIFT_HIP(hipGetLastError());
-  if ((size_t)total * 4 > stage_floats) { err = "SIFT staging buffer too small"; return RGBDFE_ERR_CAPACITY; }
-  SIFT_HIP(hipMemcpyAsync(h_stage, d_feat, (size_t)total * 16, hipMemcpyDeviceToHost, s));
+  SIFT_HIP(hipMemcpyAsync(h_stage, d_feat, (size_t)grand * 16, hipMemcpyDeviceToHost, s));
   SIFT_HIP(hipStreamSynchronize(s));
-  // ---- ReshapeFeatureListCPU (PyramidCU.cpp:501-585, NO_DUPLICATE_DOWNLOAD) + LimitFeatureCount(1) -----------------------------
+  // ---- ReshapeFeatureListCPU (PyramidCU.cpp:501-585, NO_DUPLICATE_DOWNLOAD) + LimitFeatureCount(1), per frame ------------------
   const double twopi = 2.0 * 3.14159265358979323846;
   const double factor = 2.0 * 3.14159265358979323846 / 65535.0;
   const float os = octave_min >= 0 ? float(1 << octave_min) : 1.0f / (1 << (-octave_min));
-  std::vector<float> list;            // final feature list in level coordinates (x, y, scale, orientation)
-  std::vector<float> keybuf;          // image coordinates
-  list.reserve((size_t)total * 8);
-  keybuf.reserve((size_t)total * 8);
-  feature_num = 0;
-  {
+  int grand2 = 0, max_total2 = 0;
+  for (int f = 0; f < nf; ++f) {
+    FrameState& F = fs[(size_t)f];
+    const LevelJobs& jobs = hj[f];
+    F.list.reserve((size_t)F.total * 8);     // final feature list in level coordinates (x, y, scale, orientation)
+    F.keybuf.reserve((size_t)F.total * 8);   // image coordinates
+    F.feature_num = 0;
     int seg = 0;
     for (int idx = 0; idx < nlv; ++idx) {
-      if (level_num[(size_t)idx] <= 0) continue;
-      const float* src = h_stage + (size_t)jobs.begin[seg] * 4;
-      const int cnt = level_num[(size_t)idx];
+      if (F.level_num[(size_t)idx] <= 0) continue;
+      const float* src = h_stage + ((size_t)F.base + jobs.begin[seg]) * 4;
+      const int cnt = F.level_num[(size_t)idx];
       int fcount = 0;
       const float oss = os * (1 << (idx / kDogLevels));
       for (int k = 0; k < cnt; ++k, src += 4) {
@@ -773,11 +852,11 @@ int SiftExtractor::run(const uint8_t* gray, int rows, int cols, int max_features
         memcpy(orientations, &src[3], 4);
         auto push = [&](unsigned short o) {
           const float fo = float(factor * o);
-          list.push_back(src[0]); list.push_back(src[1]); list.push_back(src[2]); list.push_back(fo);
-          keybuf.push_back(oss * (src[0] - 0.5f) + 0.5f);
-          keybuf.push_back(oss * (src[1] - 0.5f) + 0.5f);
-          keybuf.push_back(oss * src[2]);
-          keybuf.push_back((float)fmod(twopi - fo, twopi));
+          F.list.push_back(src[0]); F.list.push_back(src[1]); F.list.push_back(src[2]); F.list.push_back(fo);
+          F.keybuf.push_back(oss * (src[0] - 0.5f) + 0.5f);
+          F.keybuf.push_back(oss * (src[1] - 0.5f) + 0.5f);
+          F.keybuf.push_back(oss * src[2]);
+          F.keybuf.push_back((float)fmod(twopi - fo, twopi));
           fcount++;
         };
         if (orientations[0] != 65535) {
@@ -785,42 +864,65 @@ int SiftExtractor::run(const uint8_t* gray, int rows, int cols, int max_features
           if (orientations[1] != 65535 && orientations[1] != orientations[0]) push(orientations[1]);
         }
       }
-      level_num[(size_t)idx] = fcount;
-      feature_num += fcount;
+      F.level_num[(size_t)idx] = fcount;
+      F.feature_num += fcount;
       ++seg;
     }
+    F.erased = limit(F);
   }
-  const int erased = limit();
-  if (feature_num == 0) return RGBDFE_OK;
   // ---- GetFeatureDescriptors (PyramidCU.cpp:393-432) ---------------------------------------------------------------------------
-  LevelJobs dj{};
-  total = 0;
-  for (int idx = 0; idx < nlv; ++idx) {
-    if (level_num[(size_t)idx] <= 0) continue;
-    const int i = idx / kDogLevels, j = idx % kDogLevels;
-    const int n = dj.n++;
-    dj.begin[n] = total;
-    dj.g[n] = oct[i].g[j + 1];
-    dj.w[n] = oct[i].w; dj.h[n] = oct[i].h;
-    total += level_num[(size_t)idx];
+  for (int f = 0; f < nf; ++f) {
+    FrameState& F = fs[(size_t)f];
+    LevelJobs& dj = hj[f];
+    memset(&dj, 0, sizeof(dj));
+    int total = 0;
+    for (int idx = 0; idx < nlv; ++idx) {
+      if (F.level_num[(size_t)idx] <= 0) continue;
+      const int i = idx / kDogLevels, j = idx % kDogLevels;
+      const int n = dj.n++;
+      dj.begin[n] = total;
+      dj.g[n] = oct[i].g[j + 1] + (size_t)f * planes_floats;
+      dj.w[n] = oct[i].w; dj.h[n] = oct[i].h;
+      total += F.level_num[(size_t)idx];
+    }
+    dj.begin[dj.n] = total;
+    dj.base = grand2;
+    F.total = total; F.base = grand2;
+    grand2 += total;
+    max_total2 = std::max(max_total2, total);
   }
-  dj.begin[dj.n] = total;
-  if ((size_t)total > feat_cap) { err = "more SIFT features than the feature buffer holds"; return RGBDFE_ERR_CAPACITY; }
-  if ((size_t)total * 128 > desc_cap) {
+  if (grand2 == 0) return RGBDFE_OK;
+  if ((size_t)grand2 > feat_cap * (size_t)frames_cap) { err = "more SIFT features than the feature buffer holds"; return RGBDFE_ERR_CAPACITY; }
+  if ((size_t)grand2 * 4 > stage_floats) { err = "SIFT staging buffer too small"; return RGBDFE_ERR_CAPACITY; }
+  if ((size_t)grand2 * 128 > desc_cap) {
     if (d_desc) (void)hipFree(d_desc);
     d_desc = nullptr; desc_cap = 0;
-    SIFT_HIP(hipMalloc((void**)&d_desc, (size_t)total * 128 * 4 * 2));
-    desc_cap = (size_t)total * 128 * 2;
+    SIFT_HIP(hipMalloc((void**)&d_desc, (size_t)grand2 * 128 * 4 * 2));
+    desc_cap = (size_t)grand2 * 128 * 2;
   }
-  memcpy(h_stage, list.data() + (size_t)erased * 4, (size_t)total * 16);
-  SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)total * 16, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(total * 16), dim3(64), 0, s, dj, d_feat, (float4*)d_desc, 3.0f);
+  for (int f = 0; f < nf; ++f) {
+    const FrameState& F = fs[(size_t)f];
+    if (F.total > 0) memcpy(h_stage + (size_t)F.base * 4, F.list.data() + (size_t)F.erased * 4, (size_t)F.total * 16);
+  }
+  SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)grand2 * 16, hipMemcpyHostToDevice, s));
+  SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(max_total2 * 4, NF), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
+                     (float4*)d_desc, 3.0f);
   SIFT_HIP(hipGetLastError());
-  desc.resize((size_t)total * 128);
-  SIFT_HIP(hipMemcpyAsync(desc.data(), d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));
+  if ((size_t)grand2 * 128 > h_desc_cap) {
+    if (h_desc) (void)hipHostFree(h_desc);
+    h_desc = nullptr; h_desc_cap = 0;
+    SIFT_HIP(hipHostMalloc((void**)&h_desc, (size_t)grand2 * 128 * 4 * 2, hipHostMallocDefault));
+    h_desc_cap = (size_t)grand2 * 128 * 2;
+  }
+  SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)grand2 * 128 * 4, hipMemcpyDeviceToHost, s));
   SIFT_HIP(hipStreamSynchronize(s));
-  keys.resize((size_t)total);
-  memcpy(keys.data(), keybuf.data() + (size_t)erased * 4, (size_t)total * 16);
+  for (int f = 0; f < nf; ++f) {
+    const FrameState& F = fs[(size_t)f];
+    desc[f] = h_desc + (size_t)F.base * 128;
+    keys[f].resize((size_t)F.total);
+    if (F.total > 0) memcpy(keys[f].data(), F.keybuf.data() + (size_t)F.erased * 4, (size_t)F.total * 16);
+  }
   return RGBDFE_OK;
 }
 

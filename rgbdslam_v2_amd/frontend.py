@@ -396,6 +396,41 @@ class FrontEnd:
             self._check(st)
             return kp[: n.value].copy(), desc[: n.value].copy()
 
+    def sift_detect_batch(self, grays, max_keypoints: int = 1000, out_stride=None, copy=True):
+        """rgbdfe_sift_detect_batch: sift_detect over a run of frames of one size, up to 8 frames per launch chain.
+        Returns a list of (keypoints, descriptors) per frame.  copy=False returns views of output arrays this object keeps
+        and reuses for the next call of the same shape (what an integration with its own buffers does)."""
+        n = len(grays)
+        if n == 0:
+            return []
+        g = [np.ascontiguousarray(x, np.uint8) for x in grays]
+        rows, cols = g[0].shape
+        for a in g:
+            if a.shape != (rows, cols):
+                raise ValueError("all frames of a batch share one size")
+        max_keypoints = min(int(max_keypoints), (1 << 31) - 1)
+        stride = int(out_stride) if out_stride else min(2 * max_keypoints + 1024, 1 << 16)
+        while True:
+            cache = getattr(self, "_sift_out", None)
+            if copy or cache is None or cache[0] != (n, stride):
+                kp = np.zeros((n, stride), _lib.KEYPOINT_DTYPE)
+                desc = np.zeros((n, stride, 128), np.float32)
+                if not copy:
+                    self._sift_out = ((n, stride), kp, desc)
+            else:
+                kp, desc = cache[1], cache[2]
+            cnt = np.zeros(n, np.int32)
+            pg = (C.c_void_p * n)(*[x.ctypes.data for x in g])
+            rc = self._L.rgbdfe_sift_detect_batch(self._ctx, n, C.cast(pg, C.c_void_p), rows, cols, max_keypoints, stride,
+                                                  kp.ctypes.data, desc.ctypes.data, cnt.ctypes.data)
+            if rc == -5 and int(cnt.max()) > stride and not out_stride:   # RGBDFE_ERR_CAPACITY: cnt holds the counts
+                stride = int(cnt.max())
+                continue
+            self._check(rc)
+            if not copy:
+                return [(kp[f, : cnt[f]], desc[f, : cnt[f]]) for f in range(n)]
+            return [(kp[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy()) for f in range(n)]
+
     def sift_geometry(self):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         self._check(self._L.rgbdfe_sift_geometry(self._ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

@@ -120,6 +120,26 @@ def test_full_size_properties(fe):
     assert 0 < len(small) < len(kp) and kp[len(kp) - len(small):].tobytes() == small.tobytes()
 
 
+def test_batch_equals_single_calls(fe):
+    """rgbdfe_sift_detect_batch: 8 frames per launch chain (11 frames = one full chain + a ragged one), every frame's
+    output identical to its single call -- textured frames, a featureless one in the middle, with and without the limit."""
+    frames = [image(320, 240, 20 + k) for k in range(11)]
+    frames[4] = np.full((240, 320), 90, np.uint8)
+    for maxf in (300, 1 << 20):
+        single = [fe.sift_detect(g, None, maxf) for g in frames]
+        batch = fe.sift_detect_batch(frames, maxf)
+        assert len(batch) == len(frames) and len(batch[4][0]) == 0
+        for (ka, da), (kb, db) in zip(single, batch):
+            assert ka.tobytes() == kb.tobytes() and da.tobytes() == db.tobytes()
+    # a single call after a batch sees the first frame's stage data again (debug accessors) and the same result
+    again = fe.sift_detect(frames[0], None, 300)
+    assert again[0].tobytes() == fe.sift_detect_batch(frames[:1], 300)[0][0].tobytes()
+    # a stride that is too small: the counts come back, the error is raised
+    from rgbdslam_v2_amd.frontend import RgbdfeError
+    with pytest.raises(RgbdfeError):
+        fe.sift_detect_batch(frames[:3], 300, out_stride=8)
+
+
 def test_extraction_feeds_the_sift_pair_path(fe):
     """detect -> projectTo3DSiftGPU (rgbdfe_sift_node_features) -> upload -> SiftGPU matcher + RANSAC: two views of the same
     textured plane give an edge."""

@@ -1,7 +1,8 @@
 """Profiling workload for the frame-level paths (tools/profile_r03.sh): runs N frames through one entry point and prints
 {"frames": total frames processed in this process} so that per-frame counter sums can be formed.
     python tools/detect_workload.py orb 640 480 1000 [frames] [reps]      rgbdfe_detect_describe_batch
-    python tools/detect_workload.py sift 640 480 0 [frames] [reps]        rgbdfe_sift_detect"""
+    python tools/detect_workload.py sift 640 480 0 [frames] [reps]        rgbdfe_sift_detect
+    python tools/detect_workload.py sift_batch 640 480 0 [frames] [reps]  rgbdfe_sift_detect_batch"""
 import json
 import os
 import sys
@@ -27,6 +28,10 @@ if kind == "orb":
     K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
     for _ in range(reps):
         fe.detect_describe_batch(list(seq["gray"]), masks, list(seq["depth"]), *K)
+        total += n_frames
+elif kind == "sift_batch":
+    for _ in range(reps):
+        fe.sift_detect_batch(list(seq["gray"]))
         total += n_frames
 else:
     for _ in range(reps):
