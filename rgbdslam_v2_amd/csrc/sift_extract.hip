@@ -270,23 +270,22 @@ __device__ __forceinline__ SiftExtractor::LevelDesc level_of_frame(SiftExtractor
   return L;
 }
 
-// one wave per 64 consecutive columns of one row of the stacked (octave, dog level) planes, four rows per workgroup: a flag
-// byte per pixel + the row's count.  (Measured: a wave that walks 8 rows instead of one is 50 % slower -- most pixels leave
-// key_eval after one dependent load, the launch lives on the number of waves in flight.)
+// one wave (= one workgroup) per 64 consecutive columns of one row of the stacked (octave, dog level) planes: a flag byte
+// per pixel + the row's count.  Most pixels leave key_eval after one dependent load, so the launch lives on the number of
+// independent waves in flight -- measured: four rows per 256-thread workgroup +50 % (a wave that runs the whole test holds
+// the slots of its three finished neighbours), a wave walking 8 rows +50 %.
 // Counted = what InitHist_Kernel (ProgramCU.cu:665-688) counts: rows 1 .. h-2, columns 1 .. w-2 with a non-zero key.
-__global__ __launch_bounds__(256) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                            const int* __restrict__ row2lvl, int* __restrict__ rowcnt,
-                                                            float dog_threshold0, float dog_threshold, float edge_threshold,
-                                                            FrameStrides st) {
-  const int lane = threadIdx.x & 63;
-  const int grow = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (grow >= st.rows) return;
+__global__ __launch_bounds__(64) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                           const int* __restrict__ row2lvl, int* __restrict__ rowcnt,
+                                                           float dog_threshold0, float dog_threshold, float edge_threshold,
+                                                           FrameStrides st) {
+  const int grow = blockIdx.y;
   rowcnt += (size_t)blockIdx.z * st.rows;
   const int lvl = row2lvl[grow];
   const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.z);
   if ((int)blockIdx.x * 64 >= L.w) return;
   const int row = grow - L.row0;
-  const int col = blockIdx.x * 64 + lane;
+  const int col = blockIdx.x * 64 + threadIdx.x;
   int8_t flag = 0;
   if (col < L.w && row > 0 && col > 0 && row < L.h - 1 && col < L.w - 1) {
     const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(256) void sift_key_flag_kernel(const SiftExtractor:
   }
   if (col < L.w) L.flags[(size_t)row * L.w + col] = flag;
   const uint64_t m = __ballot(flag != 0);
-  if (lane == 0 && m) atomicAdd(&rowcnt[grow], (int)__popcll(m));
+  if (threadIdx.x == 0 && m) atomicAdd(&rowcnt[grow], (int)__popcll(m));
 }
 
 // per level: exclusive scan of its rows' counts, the level's total
@@ -754,7 +753,7 @@ int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int c
   int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2 * frames_cap;
   st.rows = total_rows;
   SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
-  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, (total_rows + 3) / 4, NF), dim3(256),
+  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, total_rows, NF), dim3(64),
                      0, s, d_levels, d_row2lvl, d_rowcnt, tdog1, tdog, tedge, st);
   hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
   hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows, NF), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
