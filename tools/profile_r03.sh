@@ -4,7 +4,7 @@
 #   heavy    bench.py --depth-noise 0.002                     trace + FETCH/WRITE + SQ passes
 #   sift     bench.py --config sift --frames 100              trace + FETCH/WRITE + MFMA pass
 #   detect_640x480_orb1000, detect_1280x960_orb4000           trace + FETCH/WRITE   (tools/detect_workload.py orb)
-#   sift_extract_640x480                                      trace + FETCH/WRITE   (tools/detect_workload.py sift)
+#   sift_extract_640x480                                      trace + FETCH/WRITE   (tools/detect_workload.py sift_batch)
 # Counters are collected in their own runs (never together with a trace domain).  tools/make_pmc_summary.py <tag> turns the
 # result into profiles/<tag>_pmc_summary.json.   Usage: tools/profile_r03.sh <tag> [workloads...]
 set -u
@@ -38,7 +38,7 @@ for W in $WL; do
     sift)  run_passes sift "python $REPO/bench.py --config sift --frames 100 --steps 5 --warmup 1" fetch write mfma; python tools/summarize_prof.py $ROOT/sift > $ROOT/sift/summary.txt 2>&1;;
     detect_640x480_orb1000)  run_passes $W "python $REPO/tools/detect_workload.py orb 640 480 1000 56 3" fetch write;;
     detect_1280x960_orb4000) run_passes $W "python $REPO/tools/detect_workload.py orb 1280 960 4000 56 2" fetch write;;
-    sift_extract_640x480)    run_passes $W "python $REPO/tools/detect_workload.py sift 640 480 0 8 3" fetch write;;
+    sift_extract_640x480)    run_passes $W "python $REPO/tools/detect_workload.py sift_batch 640 480 0 32 3" fetch write;;
   esac
 done
 python tools/make_pmc_summary.py $TAG --from gpurun_out > $ROOT/pmc_summary.txt 2>&1
