@@ -677,9 +677,10 @@ def sift_extract_subrecord(device):
         dt = time.perf_counter() - t0
         # the same frames as a run through the batch entry point (8 frames per launch chain), 32 frames per call
         run = [seq["gray"][i] for i in synth.forth_and_back(32, len(seq["gray"]))]
-        fe.sift_detect_batch(run, copy=False)
+        for _ in range(2):
+            fe.sift_detect_batch(run, copy=False)
         per_frame = []
-        for _ in range(REPEATS):
+        for _ in range(REPEATS + 2):
             t0 = time.perf_counter()
             fe.sift_detect_batch(run, copy=False)          # output arrays reused, as an integration's buffers are
             per_frame.append((time.perf_counter() - t0) / len(run))
@@ -747,9 +748,10 @@ def detect_subrecord(device):
         K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
         idx = synth.forth_and_back(n_run, n_base)
         grays, depths, mks = [seq["gray"][i] for i in idx], [seq["depth"][i] for i in idx], [masks[i] for i in idx]
-        fe.detect_describe_batch(grays[:14], mks[:14], depths[:14], *K)
+        for _ in range(2):                      # the first calls of a run length pay page faults and thread wake-ups
+            fe.detect_describe_batch(grays, mks, depths, *K)
         per_frame = []
-        for _ in range(REPEATS):
+        for _ in range(REPEATS + 2):
             t0 = time.perf_counter()
             fe.detect_describe_batch(grays, mks, depths, *K)
             per_frame.append((time.perf_counter() - t0) / n_run)
@@ -770,7 +772,7 @@ def detect_subrecord(device):
                           "ms_per_frame_repeats": [round(v * 1e3, 4) for v in per_frame],
                           "note": "rgbdfe_detect_describe_batch over a run of %d frames (7 frames per launch chain, three "
                                   "chains in flight, adjuster replayed on worker threads): the outputs of single calls; "
-                                  "median of %d repetitions" % (n_run, REPEATS)},
+                                  "median of %d repetitions after two warm-up calls" % (n_run, REPEATS + 2)},
             "mean_keypoints": round(tot / n_base, 1),
             "roofline": {"bound": "hbm", "achieved": round(gbs_batch, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs_batch / HBM_PEAK_GBS, 6), "frac_single_calls": round(gbs / HBM_PEAK_GBS, 6),
