@@ -129,6 +129,27 @@ int main(int argc, char** argv) {
     for (uint8_t b : fr[1]->feature_descriptors_) sum = sum * 131 + b;
     std::printf("{\"frame_features\": [%d, %d], \"frame_edge\": [%d, %d], \"frame_inliers\": %zu, \"desc_hash\": %llu}\n",
                 fr[0]->featureCount(), fr[1]->featureCount(), mr.edge.id1, mr.edge.id2, mr.inlier_matches.size(), sum);
+    // the same two frames as SiftGPU nodes (feature_detector_type == "SIFTGPU": SiftGPUWrapper::detect -> projectTo3DSiftGPU),
+    // matched with the SIFTGPU matcher branch
+    {
+      std::FILE* g3 = std::fopen(argv[3], "rb");
+      std::fseek(g3, 8 + 32, SEEK_SET);
+      std::vector<std::unique_ptr<rgbdslam::Node>> sn;
+      for (int i = 0; i < 2; ++i) {
+        std::vector<uint8_t> gray((size_t)rows * cols), mask((size_t)rows * cols);
+        std::vector<float> depth((size_t)rows * cols);
+        if (std::fread(gray.data(), 1, gray.size(), g3) != gray.size() || std::fread(mask.data(), 1, mask.size(), g3) != mask.size() ||
+            std::fread(depth.data(), 4, depth.size(), g3) != depth.size()) return 2;
+        sn.emplace_back(new rgbdslam::Node(fe, 200 + i, gray.data(), depth.data(), rows, cols, K[0], K[1], K[2], K[3], 1.0, 1000,
+                                           rgbdslam::Node::SiftGPU()));
+      }
+      std::fclose(g3);
+      const rgbdslam::MatchingResult ms = sn[1]->matchNodePair(sn[0].get());
+      double dsum = 0;
+      for (float v : sn[1]->siftgpu_descriptors_) dsum += v;
+      std::printf("{\"siftgpu_features\": [%d, %d], \"siftgpu_edge\": [%d, %d], \"siftgpu_inliers\": %zu, \"siftgpu_desc_sum\": %.9g}\n",
+                  sn[0]->featureCount(), sn[1]->featureCount(), ms.edge.id1, ms.edge.id2, ms.inlier_matches.size(), dsum);
+    }
   }
   return 0;
 }

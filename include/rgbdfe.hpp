@@ -102,6 +102,32 @@ class FrontEnd {
   std::shared_ptr<rgbdfe_ctx> ctx_;
 };
 
+// src/sift_gpu_wrapper.h:49 -- SiftGPUWrapper::detect(image, keypoints, descriptors, mask): SiftGPU's extraction with the
+// options the reference's constructor sets (sift_gpu_wrapper.cpp:29-88).  keypoints: pt, size = 12 * scale, angle in
+// degrees; descriptors: n x 128 floats, unnormalised.  `mask` does not exist here: the reference ignores it.
+class SiftGPUWrapper {
+ public:
+  explicit SiftGPUWrapper(const FrontEnd& fe, int max_keypoints) : fe_(fe), max_keypoints_(max_keypoints) {}
+  void detect(const uint8_t* image, int rows, int cols, std::vector<rgbdfe_keypoint>& keypoints,
+              std::vector<float>& descriptors) const {
+    int32_t cap = 2 * max_keypoints_ + 1024, n = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      keypoints.resize((size_t)cap);
+      descriptors.resize((size_t)cap * 128);
+      const int rc = rgbdfe_sift_detect(fe_.get(), image, nullptr, rows, cols, max_keypoints_, keypoints.data(),
+                                        descriptors.data(), cap, &n);
+      if (rc == RGBDFE_OK) break;
+      if (rc != RGBDFE_ERR_CAPACITY) { n = 0; break; }   // "SIFTGPU->RunSIFT() failed!" (:158): no features
+      cap = n;                                            // n = the number of features: once more with room for them
+    }
+    keypoints.resize((size_t)n);
+    descriptors.resize((size_t)n * 128);
+  }
+ private:
+  FrontEnd fe_;
+  int max_keypoints_;
+};
+
 class Node {  // the slice of src/node.h the pair path touches
  public:
   // feature_descriptors: n x 32 bytes (cv::Mat CV_8U, continuous); feature_locations_3d: n x (x,y,z,1)
@@ -136,6 +162,33 @@ class Node {  // the slice of src/node.h the pair path touches
   Node(const FrontEnd& fe, int id, const float* desc128, const float* feature_locations_3d, int n, SiftDescriptors)
       : id_(id), fe_(fe), n_(n), sift_(true) {
     matchable_ = rgbdfe_upload_sift_node(fe_.get(), id_, desc128, feature_locations_3d, n) == RGBDFE_OK;
+  }
+  // The depth-image constructor with feature_detector_type == "SIFTGPU" (node.cpp:147-152, 195-200): SiftGPUWrapper::detect ->
+  // projectTo3DSiftGPU (:695-769: truncating depth lookup, NaN depth drops the keypoint, max_keypoints cut, descriptors
+  // re-packed) -> the node's siftgpu_descriptors go to the device for the SIFTGPU matcher branch.
+  struct SiftGPU {};
+  Node(const FrontEnd& fe, int id, const uint8_t* gray, const float* depth, int rows, int cols, double fx, double fy, double cx,
+       double cy, double depth_scaling, int max_keypoints, SiftGPU)
+      : id_(id), fe_(fe), n_(0), sift_(true) {
+    std::vector<rgbdfe_keypoint> kp;
+    std::vector<float> desc;
+    SiftGPUWrapper(fe, max_keypoints).detect(gray, rows, cols, kp, desc);
+    const int m = (int)kp.size();
+    std::vector<float> xy((size_t)m * 2);
+    for (int i = 0; i < m; ++i) { xy[(size_t)2 * i] = kp[(size_t)i].x; xy[(size_t)2 * i + 1] = kp[(size_t)i].y; }
+    std::vector<int32_t> kept((size_t)(m > 0 ? m : 1));
+    feature_locations_3d_.resize((size_t)(m > 0 ? m : 1) * 4);
+    siftgpu_descriptors_.resize((size_t)(m > 0 ? m : 1) * 128);
+    int32_t n = 0;
+    if (m > 0 && rgbdfe_sift_node_features(fe_.get(), xy.data(), m, desc.data(), depth, rows, cols, fx, fy, cx, cy, depth_scaling,
+                                           max_keypoints, 0, kept.data(), feature_locations_3d_.data(),
+                                           siftgpu_descriptors_.data(), nullptr, &n) != RGBDFE_OK)
+      n = 0;
+    n_ = n;
+    feature_locations_3d_.resize((size_t)n * 4);
+    siftgpu_descriptors_.resize((size_t)n * 128);
+    for (int i = 0; i < n; ++i) feature_locations_2d_.push_back(kp[(size_t)kept[(size_t)i]]);
+    matchable_ = n > 0 && rgbdfe_upload_sift_node(fe_.get(), id_, siftgpu_descriptors_.data(), feature_locations_3d_.data(), n) == RGBDFE_OK;
   }
   // The point-cloud constructor (src/node.cpp:218-369): detect -> projectTo3D(cloud) (maximum_depth, truncating lookup,
   // the max_keypoints cut, :855-898) -> cv::ORB::compute.  cloud: rows x cols x (x, y, z, rgb) floats, organised.
@@ -199,6 +252,7 @@ class Node {  // the slice of src/node.h the pair path touches
   std::vector<rgbdfe_keypoint> feature_locations_2d_;
   std::vector<uint8_t> feature_descriptors_;   // n x 32
   std::vector<float> feature_locations_3d_;    // n x (x, y, z, 1)
+  std::vector<float> siftgpu_descriptors_;     // n x 128 (node.h:172; SiftGPU nodes built from an image)
   int featureCount() const { return n_; }
 
  private:

@@ -85,8 +85,9 @@ def test_cpp_depth_image_node_constructor(tmp_path):
         assert cloud.shape == (rows, cols, 4)
         f.write(np.ascontiguousarray(cloud, np.float32).tobytes())
     out = subprocess.check_output([exe, str(nodes), "single", str(frames)], text=True, timeout=120)
-    rec = json.loads(out.strip().splitlines()[-1])
-    rec_cloud = json.loads(out.strip().splitlines()[-2])
+    rec_sift = json.loads(out.strip().splitlines()[-1])
+    rec = json.loads(out.strip().splitlines()[-2])
+    rec_cloud = json.loads(out.strip().splitlines()[-3])
     fe = FrontEnd(device_id=0, max_nodes=4, max_keypoints=2048, max_pairs_per_batch=8)
     fe.detector_configure(max_keypoints=1000)
     feats = [fe.detect_describe(img["gray"][k], masks[k], img["depth"][k], *K) for k in range(2)]
@@ -110,6 +111,22 @@ def test_cpp_depth_image_node_constructor(tmp_path):
     r = fe.match_pair_list(np.array([3], np.int32), np.array([2], np.int32))[0]
     assert rec["frame_edge"] == [int(r["id1"]), int(r["id2"])] and rec["frame_edge"] == [2, 3]
     assert rec["frame_inliers"] == int(r["n_inl"]) and rec["frame_inliers"] > 20
+    # the SiftGPU node constructor (SiftGPUWrapper::detect -> projectTo3DSiftGPU -> upload) and the SIFTGPU matcher branch
+    sn = []
+    for k in range(2):
+        kp, d = fe.sift_detect(img["gray"][k], None, 1000)
+        xy = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+        kept, xyz1, raw, _ = fe.sift_node_features(xy, d, img["depth"][k], *K, 1.0, 1000, False)
+        fe.upload_sift_node(200 + k, raw, xyz1)
+        sn.append(raw)
+    rs = fe.match_sift_pair_list(np.array([201], np.int32), np.array([200], np.int32))[0][0]
+    assert rec_sift["siftgpu_features"] == [len(sn[0]), len(sn[1])] and len(sn[1]) > 200
+    # (whether this pair yields an edge is not the point: the reference extracts with "-unn" and its matcher quantises
+    # 512 * d to bytes, so the unnormalised descriptors saturate -- reproduced as found; the C++ layer and
+    # the Python mirror must agree on whatever comes out)
+    assert rec_sift["siftgpu_edge"] == [int(rs["id1"]), int(rs["id2"])]
+    assert rec_sift["siftgpu_inliers"] == int(rs["n_inl"])
+    assert abs(rec_sift["siftgpu_desc_sum"] - float(sn[1].astype(np.float64).sum())) < 1e-6 * rec_sift["siftgpu_desc_sum"]
     fe.close()
 
 
