@@ -80,6 +80,37 @@ def test_fast_corner_test_and_score(img, t):
         assert not fast_numpy(sub, s + 1)[y, x]
 
 
+def _closed_form_scores(a, t):
+    """orb_fast_nms_kernel's formulation (csrc/orb_kernels.hip): with d = centre - ring, P = max over the 16 arcs of 9 of
+    min d, N = the same for -d:  corner <=> max(P, N) > t,  score = max(P, N) - 1."""
+    h, w = a.shape
+    circle = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0),
+              (-3, 1), (-2, 2), (-1, 3)]
+    c = a[3:h - 3, 3:w - 3].astype(np.int32)
+    d = np.stack([c - a[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx].astype(np.int32) for dx, dy in circle])
+    P = np.max([np.min([d[(i + j) & 15] for j in range(9)], 0) for i in range(16)], 0)
+    N = np.max([np.min([-d[(i + j) & 15] for j in range(9)], 0) for i in range(16)], 0)
+    m = np.maximum(P, N)
+    out = np.zeros((h, w), np.uint8)
+    out[3:h - 3, 3:w - 3] = np.where(m > t, np.clip(m - 1, 0, 255), 0)
+    return out
+
+
+def test_fast_closed_form_equals_the_reference_loops(img):
+    """The kernel does not run cv::FAST's counting loop and cornerScore<16>'s two pruned loops (fast.cpp, fast_score.cpp; restated
+    in orb_fast_score_at) but their closed form: same integers for every pixel and threshold -- textured, flat, saturated
+    and random images, thresholds from 0 to 255."""
+    rng = np.random.default_rng(5)
+    images = [np.ascontiguousarray(img[60:180, 100:260]),
+              rng.integers(0, 256, (64, 96), dtype=np.uint8),                               # noise: many arcs, both polarities
+              rng.integers(100, 104, (48, 64), dtype=np.uint8),                             # nearly flat
+              (rng.integers(0, 2, (48, 64), dtype=np.uint8) * 255),                         # saturated differences (+-255)
+              np.tile(np.arange(64, dtype=np.uint8) * 4, (48, 1))]                          # a ramp: long monotone arcs
+    for a in images:
+        for t in (0, 1, 2, 7, 20, 60, 127, 254, 255):
+            assert np.array_equal(pyorb.fast_score_map(a, t), _closed_form_scores(a, t)), t
+
+
 def test_nms_mask_border(img):
     sub = np.ascontiguousarray(img[:200, :300])
     score = pyorb.fast_score_map(sub, 15)
