@@ -3,6 +3,8 @@ Keypoint coordinates, octaves, FAST/NMS decisions and descriptor bytes are integ
 Harris responses and angles are float, computed in the same operation order: asserted within 1e-6
 relative AND bit-equal.  (The oracle itself restates OpenCV 3.3 from the published algorithm:
 "parity unpinned" against a real OpenCV build.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -222,6 +224,51 @@ def test_detect_describe_batch_equals_frame_by_frame(frames):
         for (k1, d1, x1), (k2, d2, x2) in zip(res, ref):
             assert_kps_equal(k1, k2)
             assert np.array_equal(d1, d2) and np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("grid,n_frames,shape,depth", [(3, 37, (480, 640), "3"), (3, 30, (480, 640), "2"), (2, 23, (240, 320), "3"),
+                                                       (4, 11, (240, 320), "3"), (1, 16, (120, 160), "3")])
+def test_detect_describe_batch_long_runs_and_grids(grid, n_frames, shape, depth):
+    """The super-frame pipeline in its steady state -- more super-frames than image sets / pass slots / staging buffers, so
+    every ring wraps around (37 frames = 6 super-frames of 7 with three in flight) --, with both pipeline depths, other
+    grid resolutions (a super-frame holds floor(64 / grid^2) frames: 7, 7, 4, 7) and image sizes, a dark stretch that makes
+    the adjuster iterate and thresholds fall below the floors of passes already in flight (re-passes), and a frame without
+    a mask: the outputs and the thresholds left behind are those of single calls."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    h, w = shape
+    seq = synth.make_image_sequence(n_frames=min(n_frames, 12), seed=31 + grid, width=w, height=h)
+    idx = synth.forth_and_back(n_frames, len(seq["gray"]))
+    grays = [seq["gray"][i] for i in idx]
+    depths = [seq["depth"][i] for i in idx]
+    masks = [np.where(seq["mask"][i] > 0, 255, 0).astype(np.uint8) for i in idx]
+    for f in range(n_frames // 3, n_frames // 3 + 5):          # a dark, low-contrast stretch
+        grays[f] = (grays[f].astype(np.float32) * 0.25 + 70).astype(np.uint8)
+    masks[n_frames // 2] = None
+    K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    outs = []
+    old = os.environ.get("RGBDFE_SUPER_DEPTH")
+    os.environ["RGBDFE_SUPER_DEPTH"] = depth
+    try:
+        for mode in ("single", "batch"):
+            fe = FrontEnd(device_id=0, max_nodes=2, max_keypoints=512, max_pairs_per_batch=8)
+            fe.detector_configure(max_keypoints=400, grid_resolution=grid, adjuster_max_iterations=5)
+            if mode == "single":
+                res = [fe.detect_describe(g, m, d, *K) for g, m, d in zip(grays, masks, depths)]
+            else:
+                res = fe.detect_describe_batch(grays, masks, depths, *K)
+            outs.append((res, fe.detector_thresholds().copy()))
+            fe.close()
+    finally:
+        if old is None:
+            os.environ.pop("RGBDFE_SUPER_DEPTH", None)
+        else:
+            os.environ["RGBDFE_SUPER_DEPTH"] = old
+    (res, thr), (ref, ref_thr) = outs[1], outs[0]
+    assert len(res) == len(ref) == n_frames and np.array_equal(thr, ref_thr)
+    assert sum(len(r[0]) for r in ref) > 20 * n_frames
+    for (k1, d1, x1), (k2, d2, x2) in zip(res, ref):
+        assert_kps_equal(k1, k2)
+        assert np.array_equal(d1, d2) and np.array_equal(x1, x2)
 
 
 def test_detect_describe_with_page_locked_images(frames):
