@@ -451,8 +451,12 @@ int rgbdfe_host_register(rgbdfe_ctx* ctx, void* ptr, size_t bytes);
 int rgbdfe_host_unregister(rgbdfe_ctx* ctx, void* ptr);
 /* A run of frames through the same detector state, in order: the same keypoints, descriptors and points as n_frames
  * calls of rgbdfe_detect_describe (the per-cell thresholds carry over from frame to frame, feature_adjuster.cpp:185-224),
- * with frame k+1's upload and pyramid overlapped with frame k's detection.  For offline runs (bag files, OpenNIListener
- * in "batch_processing" mode).  mask may be NULL (no masks) or hold NULL entries; out_stride >= the configured
+ * with up to 7 frames sharing every kernel launch (64 / grid_resolution^2 frames per launch chain: the device pass runs at
+ * floor thresholds and the adjuster is replayed over the scored corners on the host) and three launch chains
+ * in flight.  For offline runs (bag files, OpenNIListener in "batch_processing" mode): 10-14 k frames/s at 640 x 480 for runs
+ * of >= 56 frames.  Threads: the first call creates 11 worker threads inside the context (7 for the CPU halves of the
+ * descriptions and the replay, 4 for staging copies; pure CPU work, they never enter the HIP runtime) that live until
+ * rgbdfe_destroy, plus one helper thread per call.  mask may be NULL (no masks) or hold NULL entries; out_stride >= the configured
  * max_keypoints: frame f's outputs start at row f * out_stride of keypoints / descriptors (32 B rows) / xyz1 (4 floats),
  * n_out[f] of them. */
 int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray,
