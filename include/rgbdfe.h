@@ -486,9 +486,16 @@ int rgbdfe_orb_compute(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32
  * (x, y), size = 12 * scale, angle in degrees (the wrapper's conversion, :156-160), response = octave = 0; desc128: n x 128
  * floats = what the wrapper returns as `descriptors` and Node::projectTo3DSiftGPU / rgbdfe_sift_node_features take.
  * Returns RGBDFE_ERR_CAPACITY with *n_out = the number of features when `capacity` rows are too few.
- * Not built: the wrapper's second mode (a caller-provided keypoint list, :132-142), which rgbdslam_v2's Node never uses. */
+ * The wrapper's second mode (a caller-provided keypoint list, :132-142) is rgbdfe_sift_describe below. */
 int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,
                        int32_t max_keypoints, rgbdfe_keypoint* keypoints, float* desc128, int32_t capacity, int32_t* n_out);
+/* SiftGPUWrapper::detect with a non-empty keypoint list (sift_gpu_wrapper.cpp:132-142): feature_extractor_type == "SIFTGPU"
+ * behind another detector (node.cpp:166-171) -- SiftGPU::SetKeypointList with its default "keys have orientation"
+ * (SiftGPU.h:150), i.e. descriptors at the given positions, scales (size / 12) and orientations (angle, degrees), no
+ * detection, no orientation assignment.  keypoints[n] are rewritten as the wrapper rebuilds them (size and angle through its
+ * float conversions, response = octave = 0); desc128: n x 128 floats, unnormalised, row i for keypoint i. */
+int rgbdfe_sift_describe(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32_t cols, rgbdfe_keypoint* keypoints, int32_t n,
+                         float* desc128);
 /* A run of frames of one size (offline processing of a recorded sequence): the results of n_frames single calls -- the
  * pipeline keeps no state between images -- with up to 8 frames sharing every launch (a frame alone is ~70 dependent
  * launches over planes of a few thousand pixels to 1.2 Mpixel and cannot fill the chip).  Frame f's keypoints / descriptors

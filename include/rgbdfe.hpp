@@ -110,6 +110,15 @@ class SiftGPUWrapper {
   explicit SiftGPUWrapper(const FrontEnd& fe, int max_keypoints) : fe_(fe), max_keypoints_(max_keypoints) {}
   void detect(const uint8_t* image, int rows, int cols, std::vector<rgbdfe_keypoint>& keypoints,
               std::vector<float>& descriptors) const {
+    if (!keypoints.empty()) {   // "Use Keypoints if provided" (:132-142): descriptors for the caller's keypoints
+      descriptors.assign(keypoints.size() * 128, 0.f);
+      if (rgbdfe_sift_describe(fe_.get(), image, rows, cols, keypoints.data(), (int32_t)keypoints.size(), descriptors.data()) !=
+          RGBDFE_OK) {
+        keypoints.clear();
+        descriptors.clear();
+      }
+      return;
+    }
     int32_t cap = 2 * max_keypoints_ + 1024, n = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
       keypoints.resize((size_t)cap);

@@ -390,6 +390,22 @@ def ref_sift_detect(gray, max_features=1000):
     return keys[:n].copy(), desc[:n].copy(), cnt[:m].copy()
 
 
+def ref_sift_describe(gray, keys):
+    """The reference's SiftGPU pipeline with a caller-provided keypoint list (SiftGPUWrapper::detect's second mode):
+    keys [n, 4] = (x, y, scale, orientation in radians) -> descriptors [n, 128]."""
+    L = ref_siftgpu_lib()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    keys = np.ascontiguousarray(keys, np.float32)
+    n = keys.shape[0]
+    desc = np.zeros((max(n, 1), 128), np.float32)
+    L.ref_siftgpu_describe.restype = C.c_int
+    L.ref_siftgpu_describe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rc = L.ref_siftgpu_describe(_p(gray), gray.shape[1], gray.shape[0], _p(keys), n, _p(desc))
+    if rc != n:
+        raise RuntimeError("ref_siftgpu_describe failed")
+    return desc[:n]
+
+
 def ref_sift_geometry():
     R = ref_siftgpu_lib()
     a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -233,6 +233,34 @@ int ref_siftgpu_run(const unsigned char* gray, int width, int height, int max_fe
   return n;
 }
 
+// SiftGPUWrapper::detect with a keypoint list (src/sift_gpu_wrapper.cpp:132-142): SiftGPU::SetKeypointList(num, keys) --
+// keys_have_orientation defaults to 1 (SiftGPU.h:150) -> SiftPyramid::SetKeypointList(num, keys, 0, 1) (SiftGPU.cpp:365-368) --
+// then RunSIFT and GetFeatureVector(NULL, descriptors).  keys: n x 4 (x, y, scale, orientation).  desc: n x 128.
+int ref_siftgpu_describe(const unsigned char* gray, int width, int height, const float* keys, int n, float* desc) {
+  configure(1000);
+  if (g_sift) { delete g_sift->pyramid; delete[] g_sift->param._sigma; delete g_sift; g_sift = nullptr; }
+  g_sift = new RefSift();
+  g_sift->param._dog_level_num = 5;
+  g_sift->param._edge_threshold = 10.0f;
+  g_sift->param.ParseSiftParam();
+  g_sift->pyramid = new PyramidCU(g_sift->param);
+  RefSift& s = *g_sift;
+  const int tw = GLTexInput::TruncateWidthCU(width);
+  s.pixels.resize((size_t)tw * height);
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < tw; ++x) s.pixels[(size_t)y * tw + x] = gray[(size_t)y * width + x] / 255.0f;
+  s.input._pixel_data = s.pixels.data();
+  s.input._imgWidth = tw;
+  s.input._imgHeight = height;
+  s.input._down_sampled = 0;
+  s.pyramid->SetKeypointList(n, keys, 0, 1);
+  s.pyramid->InitPyramid(width, height, 0);
+  s.pyramid->RunSIFT(&s.input);
+  if (s.pyramid->GetFeatureNum() != n) return -1;
+  s.pyramid->CopyFeatureVector(nullptr, desc);
+  return n;
+}
+
 // pyramid geometry of the last run + one level's planes, for stage-by-stage checks.  data: 0 Gaussian (1 float), 1 DoG
 // (1), 2 keypoint map (4: extremum sign, dx, dy, ds), 3 gradient (2: magnitude, angle).  level: 0 .. level_num-1
 // (= SiftParam level _level_min + level).  Returns the number of floats written (w x h x channels) or 0.

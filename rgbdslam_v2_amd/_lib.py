@@ -258,6 +258,8 @@ def load():
         raise RgbdfeError("rgbdfe_compact_result layout mismatch between librgbdfe.so and the binding")
     L.rgbdfe_sift_detect.restype = C.c_int
     L.rgbdfe_sift_detect.argtypes = [ctx, vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
+    L.rgbdfe_sift_describe.restype = C.c_int
+    L.rgbdfe_sift_describe.argtypes = [ctx, vp, i32, i32, vp, i32, vp]
     L.rgbdfe_sift_detect_batch.restype = C.c_int
     L.rgbdfe_sift_detect_batch.argtypes = [ctx, i32, vp, i32, i32, i32, i32, vp, vp, vp]
     L.rgbdfe_sift_geometry.restype = C.c_int
@@ -314,5 +316,5 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",
     "rgbdfe_match_flann_pair_list", "rgbdfe_upload_node_keypoints",
     "rgbdfe_match_pair_list_allgather_compact", "rgbdfe_pack_compact", "rgbdfe_sizeof_compact_result",
-    "rgbdfe_group_submit_us", "rgbdfe_sift_detect", "rgbdfe_sift_detect_batch", "rgbdfe_sift_geometry", "rgbdfe_sift_debug_plane", "rgbdfe_sift_debug_candidates",
+    "rgbdfe_group_submit_us", "rgbdfe_sift_detect", "rgbdfe_sift_detect_batch", "rgbdfe_sift_describe", "rgbdfe_sift_geometry", "rgbdfe_sift_debug_plane", "rgbdfe_sift_debug_candidates",
 ]

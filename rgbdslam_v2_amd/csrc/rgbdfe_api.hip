@@ -1345,6 +1345,38 @@ int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* /*ma
   return RGBDFE_OK;
 }
 
+// SiftGPUWrapper::detect with a non-empty keypoint list (sift_gpu_wrapper.cpp:132-142, 161-165): feature_extractor_type ==
+// "SIFTGPU" behind another detector (node.cpp:166-171).  The keypoints' positions, sizes and angles go through the wrapper's
+// conversions (o = angle / 180 * 3.1415927, s = size / 12) and come back as the wrapper rebuilds them (12 * s, o * 180 /
+// 3.1415927, response = octave = 0); desc128 gets one row per keypoint, in the callers' order.
+int rgbdfe_sift_describe(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32_t cols, rgbdfe_keypoint* keypoints, int32_t n,
+                         float* desc128) {
+  if (!ctx || !gray || rows < 1 || cols < 1 || n < 0 || (n > 0 && (!keypoints || !desc128)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  if (n == 0) return RGBDFE_OK;
+  std::vector<SiftKey> keys((size_t)n);
+  for (int32_t i = 0; i < n; ++i) {
+    keys[(size_t)i].x = keypoints[i].x;
+    keys[(size_t)i].y = keypoints[i].y;
+    keys[(size_t)i].o = (float)(keypoints[i].angle / 180.0 * 3.1415927);
+    keys[(size_t)i].s = (float)(keypoints[i].size / 12.0);
+  }
+  const float* desc = nullptr;
+  std::string err;
+  const int rc = ctx->sift.describe(gray, rows, cols, keys.data(), n, &desc, ctx->stream, err);
+  if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  memcpy(desc128, desc, (size_t)n * 128 * sizeof(float));
+  for (int32_t i = 0; i < n; ++i) {
+    keypoints[i].size = (float)(12.0 * keys[(size_t)i].s);
+    keypoints[i].angle = (float)(keys[(size_t)i].o * 180.0 / 3.1415927);
+    keypoints[i].response = 0.f;
+    keypoints[i].octave = 0;
+  }
+  return RGBDFE_OK;
+}
+
 // A run of frames (a recorded sequence): SiftExtractor::kMaxBatch of them share every launch of the pipeline -- the
 // images are independent (SiftGPU keeps no state between them), so frame f's outputs are those of a single call.
 int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, int32_t rows, int32_t cols,
@@ -3682,6 +3714,12 @@ int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_detect(c, gray, mask, rows, cols, max_keypoints, keypoints, desc128, capacity,
                                                     n_out));
+}
+
+int rgbdfe_sift_describe(rgbdfe_ctx* ctx, const uint8_t* gray, int32_t rows, int32_t cols, rgbdfe_keypoint* keypoints, int32_t n,
+                         float* desc128) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_FIRST(ctx, impl::rgbdfe_sift_describe(c, gray, rows, cols, keypoints, n, desc128));
 }
 
 int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, int32_t rows, int32_t cols,

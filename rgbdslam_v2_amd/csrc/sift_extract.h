@@ -30,6 +30,10 @@ struct SiftExtractor {
           hipStream_t s, std::string& err) {
     return run_batch(&gray, 1, rows, cols, max_features, &keys, &desc, s, err);
   }
+  // descriptors for the caller's keypoints (x, y, scale, orientation): SiftGPUWrapper::detect's second mode
+  int describe(const uint8_t* gray, int rows, int cols, const SiftKey* keys_in, int n, const float** desc, hipStream_t s,
+               std::string& err);
+  int enqueue_pyramid(const uint8_t* const* gray, int nf, hipStream_t s, std::string& err);
   // stage access for the parity tests: a Gaussian plane of the latest call's FIRST frame / the keypoint candidates of one
   // (octave, dog level) of that frame as (x, y, sign, dx, dy, ds) in list order, before the feature-count limits
   int debug_plane(int octave, int level, std::vector<float>& out, int* w, int* h, hipStream_t s);

@@ -712,17 +712,10 @@ int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
   return RGBDFE_OK;
 }
 
-int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int cols, int max_features, std::vector<SiftKey>* keys,
-                             const float** desc, hipStream_t s, std::string& err) {
-  if (nf < 1 || nf > kMaxBatch) { err = "SIFT batch size out of range"; return RGBDFE_ERR_INVALID_ARG; }
-  for (int f = 0; f < nf; ++f) { keys[f].clear(); desc[f] = nullptr; }
-  int rc = prepare(rows, cols, nf, err);
-  if (rc != RGBDFE_OK) return rc;
-  const int nlv = octave_num * kDogLevels;
+// images in (GLTexInput::SetImageData, CUDA branch, GLTexImage.cpp:971-1009) + BuildPyramid (PyramidCU.cpp:946-998) for nf frames
+int SiftExtractor::enqueue_pyramid(const uint8_t* const* gray, int nf, hipStream_t s, std::string& err) {
+  const int rows = H, cols = W;
   const unsigned NF = (unsigned)nf;
-  FrameStrides st{};
-  st.planes = planes_floats; st.flags = flags_bytes; st.cand = cand_cap * 6; st.rows = total_rows; st.lvltot = 64;
-  // ---- images in (GLTexInput::SetImageData, CUDA branch, GLTexImage.cpp:971-1009) + BuildPyramid (PyramidCU.cpp:946-998) ----
   for (int f = 0; f < nf; ++f) memcpy(h_gray + (size_t)f * gray_cap, gray[f], gray_cap);
   SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)nf * gray_cap, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256, NF), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
@@ -747,6 +740,22 @@ int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int c
     }
     for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, sigma[l - 1]);
   }
+  SIFT_HIP(hipGetLastError());
+  return RGBDFE_OK;
+}
+
+int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int cols, int max_features, std::vector<SiftKey>* keys,
+                             const float** desc, hipStream_t s, std::string& err) {
+  if (nf < 1 || nf > kMaxBatch) { err = "SIFT batch size out of range"; return RGBDFE_ERR_INVALID_ARG; }
+  for (int f = 0; f < nf; ++f) { keys[f].clear(); desc[f] = nullptr; }
+  int rc = prepare(rows, cols, nf, err);
+  if (rc != RGBDFE_OK) return rc;
+  const int nlv = octave_num * kDogLevels;
+  const unsigned NF = (unsigned)nf;
+  FrameStrides st{};
+  st.planes = planes_floats; st.flags = flags_bytes; st.cand = cand_cap * 6; st.rows = total_rows; st.lvltot = 64;
+  rc = enqueue_pyramid(gray, nf, s, err);
+  if (rc != RGBDFE_OK) return rc;
   // ---- DetectKeypointsEX + the list part of GenerateFeatureList: flags, row counts, scan, ordered emit ----------------------
   const float tdog = dog_threshold, tdog1 = 0.8f * tdog;
   const float tedge = (edge_threshold + 1) * (edge_threshold + 1) / edge_threshold;
@@ -922,6 +931,91 @@ int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int c
     keys[f].resize((size_t)F.total);
     if (F.total > 0) memcpy(keys[f].data(), F.keybuf.data() + (size_t)F.erased * 4, (size_t)F.total * 16);
   }
+  return RGBDFE_OK;
+}
+
+// SiftGPUWrapper::detect with a caller-provided keypoint list (sift_gpu_wrapper.cpp:132-142): SiftGPU::SetKeypointList(num,
+// keys) with its default keys_have_orientation = 1 (SiftGPU.h:150) = SIFT_SKIP_DETECTION | SIFT_SKIP_ORIENTATION
+// (SiftPyramid.cpp:244-261): the pyramid is built, every keypoint is assigned to the (octave, level) whose scale band holds its
+// scale (PyramidCU::GenerateFeatureListTex, :434-498: level coordinates, orientation mirrored), descriptors are computed
+// at the given positions / scales / orientations and put back into the callers' order (GetFeatureDescriptors, :393-432).
+// keys_in: n x (x, y, scale, orientation in radians); desc: n x 128 in a pinned buffer of this object.
+int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftKey* keys_in, int n, const float** desc, hipStream_t s,
+                            std::string& err) {
+  *desc = nullptr;
+  int rc = prepare(rows, cols, 1, err);
+  if (rc != RGBDFE_OK) return rc;
+  if (n <= 0) return RGBDFE_OK;
+  rc = enqueue_pyramid(&gray, 1, s, err);
+  if (rc != RGBDFE_OK) return rc;
+  const int nlv = octave_num * kDogLevels;
+  const double twopi = 2.0 * 3.14159265358979323846;
+  const float sigma_half_step = powf(2.0f, 0.5f / kDogLevels);
+  float octave_sigma = octave_min >= 0 ? float(1 << octave_min) : 1.0f / (1 << (-octave_min));
+  const float offset = 0.5f;   // GlobalUtil::_LoweOrigin = 0
+  std::vector<float> list;     // level coordinates, level by level
+  std::vector<int> index;      // _keypoint_index: the input position of every list entry
+  LevelJobs* dj = static_cast<LevelJobs*>(h_jobs);
+  memset(dj, 0, sizeof(LevelJobs));
+  int total = 0;
+  for (int i = 0; i < octave_num; ++i, octave_sigma *= 2.0f)
+    for (int j = 0; j < kDogLevels; ++j) {
+      const float level_sg = level_sigma(j) * octave_sigma;   // GetLevelSigma(j + level_min + 1)
+      const float sigma_min = level_sg / sigma_half_step, sigma_max = level_sg * sigma_half_step;
+      int fcount = 0;
+      for (int k = 0; k < n; ++k) {
+        const float sigmak = keys_in[k].s;
+        if ((sigmak >= sigma_min && sigmak < sigma_max) || (sigmak < sigma_min && i == 0 && j == 0) ||
+            (sigmak > sigma_max && i == octave_num - 1 && j == kDogLevels - 1)) {
+          list.push_back((keys_in[k].x - offset) / octave_sigma + 0.5f);
+          list.push_back((keys_in[k].y - offset) / octave_sigma + 0.5f);
+          list.push_back(keys_in[k].s / octave_sigma);
+          list.push_back((float)fmod(twopi - keys_in[k].o, twopi));
+          index.push_back(k);
+          ++fcount;
+        }
+      }
+      if (fcount == 0) continue;
+      const int m = dj->n++;
+      dj->begin[m] = total;
+      dj->g[m] = oct[i].g[j + 1];
+      dj->w[m] = oct[i].w; dj->h[m] = oct[i].h;
+      total += fcount;
+    }
+  (void)nlv;
+  dj->begin[dj->n] = total;
+  dj->base = 0;
+  // (a scale exactly on a band's edge can satisfy two bands or none in float arithmetic: the reference then lists the keypoint
+  // twice -- and overruns its buffers -- or not at all; here a keypoint keeps the LAST band that took it, one without a band a
+  // zero descriptor)
+  if ((size_t)total > feat_cap || (size_t)total * 4 > stage_floats) { err = "more SIFT keypoints than the feature buffer holds"; return RGBDFE_ERR_CAPACITY; }
+  const size_t rows_out = (size_t)std::max(total, n);
+  if (rows_out * 128 > desc_cap) {
+    if (d_desc) (void)hipFree(d_desc);
+    d_desc = nullptr; desc_cap = 0;
+    SIFT_HIP(hipMalloc((void**)&d_desc, rows_out * 128 * 4 * 2));
+    desc_cap = rows_out * 128 * 2;
+  }
+  if ((rows_out + (size_t)n) * 128 > h_desc_cap) {
+    if (h_desc) (void)hipHostFree(h_desc);
+    h_desc = nullptr; h_desc_cap = 0;
+    SIFT_HIP(hipHostMalloc((void**)&h_desc, (rows_out + (size_t)n) * 128 * 4 * 2, hipHostMallocDefault));
+    h_desc_cap = (rows_out + (size_t)n) * 128 * 2;
+  }
+  float* ordered = h_desc + rows_out * 128;   // the second half of the pinned buffer: the callers' order
+  memset(ordered, 0, (size_t)n * 128 * 4);
+  if (total > 0) {
+    memcpy(h_stage, list.data(), (size_t)total * 16);
+    SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)total * 16, hipMemcpyHostToDevice, s));
+    SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(sift_descriptor_kernel, dim3(total * 4, 1), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
+                       (float4*)d_desc, 3.0f);
+    SIFT_HIP(hipGetLastError());
+    SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));
+    SIFT_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < total; ++i) memcpy(ordered + (size_t)index[(size_t)i] * 128, h_desc + (size_t)i * 128, 128 * 4);
+  }
+  *desc = ordered;
   return RGBDFE_OK;
 }
 

@@ -396,6 +396,17 @@ class FrontEnd:
             self._check(st)
             return kp[: n.value].copy(), desc[: n.value].copy()
 
+    def sift_describe(self, gray, keypoints):
+        """SiftGPUWrapper::detect with a given keypoint list (sift_gpu_wrapper.cpp:132-142): descriptors at the keypoints'
+        positions, sizes and angles.  Returns (keypoints as the wrapper rebuilds them, descriptors [n, 128])."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        kp = np.ascontiguousarray(keypoints.copy())
+        n = len(kp)
+        desc = np.zeros((max(n, 1), 128), np.float32)
+        self._check(self._L.rgbdfe_sift_describe(self._ctx, gray.ctypes.data, gray.shape[0], gray.shape[1], kp.ctypes.data, n,
+                                                 desc.ctypes.data))
+        return kp, desc[:n]
+
     def sift_detect_batch(self, grays, max_keypoints: int = 1000, out_stride=None, copy=True):
         """rgbdfe_sift_detect_batch: sift_detect over a run of frames of one size, up to 8 frames per launch chain.
         Returns a list of (keypoints, descriptors) per frame.  copy=False returns views of output arrays this object keeps

@@ -62,6 +62,16 @@ def main():
         out[name + "_plane_crc"] = np.array(crcs, np.uint32)
         out[name + "_cand_crc"], out[name + "_cand_n"] = np.array(ccrc, np.uint32), np.array(ccnt, np.int32)
         print(name, w, h, "features", len(keys), "levels", cnt)
+    # the wrapper's second mode (a caller-provided keypoint list, sift_gpu_wrapper.cpp:132-142): descriptors of the reference
+    # pipeline for given (x, y, scale, orientation) -- scales across all bands, below the first and above the last one
+    g = image(322, 241, 5)
+    rng = np.random.default_rng(12)
+    n = 300
+    keys = np.stack([rng.uniform(8, 314, n), rng.uniform(8, 233, n), np.exp(rng.uniform(np.log(0.6), np.log(40.0), n)),
+                     rng.uniform(0, 2 * np.pi, n)], 1).astype(np.float32)
+    out["k_keys"] = keys
+    out["k_desc"] = po.ref_sift_describe(g, keys)
+    print("keypoint-list mode:", n, "keypoints, descriptor norms", float(np.linalg.norm(out["k_desc"], axis=1).mean()))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "sift_extract_golden.npz"), **out)
 
 

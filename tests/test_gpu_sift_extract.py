@@ -140,6 +140,49 @@ def test_batch_equals_single_calls(fe):
         fe.sift_detect_batch(frames[:3], 300, out_stride=8)
 
 
+def _check_descriptors(desc, rdesc):
+    rel = np.linalg.norm(desc - rdesc, axis=1) / np.maximum(np.linalg.norm(rdesc, axis=1), 1e-12)
+    nz = np.linalg.norm(rdesc, axis=1) > 0
+    assert np.array_equal(np.linalg.norm(desc, axis=1) > 0, nz)
+    assert rel[nz].max() <= DESC_RTOL_ALL and (rel[nz] <= DESC_RTOL).mean() >= TIGHT_FRACTION, (rel[nz].max(), (rel[nz] <= DESC_RTOL).mean())
+
+
+def test_describe_given_keypoints(fe):
+    """rgbdfe_sift_describe = SiftGPUWrapper::detect with a keypoint list (sift_gpu_wrapper.cpp:132-142; extractor SIFTGPU behind
+    another detector, node.cpp:166-171): descriptors at given positions / sizes / angles, in the callers' order, against the
+    frozen outputs of the reference pipeline and -- where the pin library travelled -- against the pin itself on ORB
+    keypoints."""
+    g = np.load(GOLD)
+    img = image(322, 241, 5)
+    keys = g["k_keys"]
+    kp = np.zeros(len(keys), fe.sift_detect(img, None, 10)[0].dtype)
+    kp["x"], kp["y"] = keys[:, 0], keys[:, 1]
+    # the ABI takes cv::KeyPoint fields: size = 12 * scale, angle in degrees; the fixture's floats survive the wrapper's
+    # two conversions only approximately, so the comparison keys are those the library reports back
+    kp["size"] = (12.0 * keys[:, 2].astype(np.float64)).astype(np.float32)
+    kp["angle"] = (keys[:, 3].astype(np.float64) * 180.0 / 3.1415927).astype(np.float32)
+    out_kp, desc = fe.sift_describe(img, kp)
+    assert np.array_equal(out_kp["x"], kp["x"]) and np.all(out_kp["response"] == 0) and np.all(out_kp["octave"] == 0)
+    back = np.stack([out_kp["x"], out_kp["y"], out_kp["size"] / 12.0, out_kp["angle"] * 3.1415927 / 180.0], 1)
+    assert np.abs(back[:, 2] - keys[:, 2]).max() <= 2e-6 * keys[:, 2].max() and np.abs(back[:, 3] - keys[:, 3]).max() < 2e-6
+    if po.ref_siftgpu_lib() is not None:
+        s = (out_kp["size"].astype(np.float64) / 12.0).astype(np.float32)
+        o = (out_kp["angle"].astype(np.float64) / 180.0 * 3.1415927).astype(np.float32)
+        _check_descriptors(desc, po.ref_sift_describe(img, np.stack([out_kp["x"], out_kp["y"], s, o], 1)))
+    else:
+        _check_descriptors(desc, g["k_desc"])
+    # ORB keypoints of a frame (the mixed configuration): the order is the detector's, nothing is dropped
+    seq = synth.make_image_sequence(n_frames=1, seed=2)
+    okp = fe.orb_detect(seq["gray"][0], None, 20)[:400]
+    k2, d2 = fe.sift_describe(seq["gray"][0], okp)
+    assert len(k2) == len(okp) == len(d2) and np.array_equal(k2["x"], okp["x"]) and np.all(np.linalg.norm(d2, axis=1) > 0)
+    if po.ref_siftgpu_lib() is not None:
+        s = (okp["size"].astype(np.float64) / 12.0).astype(np.float32)
+        o = (okp["angle"].astype(np.float64) / 180.0 * 3.1415927).astype(np.float32)
+        _check_descriptors(d2, po.ref_sift_describe(seq["gray"][0], np.stack([okp["x"], okp["y"], s, o], 1)))
+    assert fe.sift_describe(img, kp[:0])[1].shape == (0, 128)
+
+
 def test_extraction_feeds_the_sift_pair_path(fe):
     """detect -> projectTo3DSiftGPU (rgbdfe_sift_node_features) -> upload -> SiftGPU matcher + RANSAC: two views of the same
     textured plane give an edge."""
