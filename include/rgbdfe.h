@@ -159,6 +159,12 @@ const char* rgbdfe_last_error(rgbdfe_ctx* ctx);
  * xyz1: n x 4 float, (x,y,z,1) as Node::projectTo3D writes them (node.cpp:955). */
 int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc,
                        const float* xyz1, int32_t n);
+/* Many nodes in one call (offline runs: the nodes of a stretch of frames): the same residency as n_nodes calls of
+ * rgbdfe_upload_node, with one pinned staging pass, back-to-back copies and expansion launches and ONE wait -- ~10 us per
+ * node instead of ~65.  desc[i]: counts[i] x 32 bytes, xyz1[i]: counts[i] x 4 floats.  Nothing is uploaded when an argument
+ * is bad, a node has more than max_keypoints rows, an id appears twice or the free slots do not suffice. */
+int rgbdfe_upload_nodes(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* node_ids, const uint8_t* const* desc,
+                        const float* const* xyz1, const int32_t* counts);
 /* same, sources already in device memory (device-to-device copy on `stream`, a hipStream_t).
  * Ordering: stream == NULL copies on the context's stream and returns when the node is resident.  With a caller
  * stream the copies are enqueued there and the call returns at once; every batch submitted to this context

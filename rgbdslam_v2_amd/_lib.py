@@ -133,6 +133,8 @@ def load():
     L.rgbdfe_last_error.argtypes = [ctx]
     L.rgbdfe_upload_node.restype = C.c_int
     L.rgbdfe_upload_node.argtypes = [ctx, i32, vp, vp, i32]
+    L.rgbdfe_upload_nodes.restype = C.c_int
+    L.rgbdfe_upload_nodes.argtypes = [ctx, i32, vp, vp, vp, vp]
     L.rgbdfe_upload_node_device.restype = C.c_int
     L.rgbdfe_upload_node_device.argtypes = [ctx, i32, vp, vp, i32, vp]
     L.rgbdfe_release_node.restype = C.c_int
@@ -294,7 +296,7 @@ def load():
 
 EXPORTED_SYMBOLS = [
     "rgbdfe_default_config", "rgbdfe_create", "rgbdfe_destroy", "rgbdfe_set_params",
-    "rgbdfe_status_string", "rgbdfe_last_error", "rgbdfe_upload_node",
+    "rgbdfe_status_string", "rgbdfe_last_error", "rgbdfe_upload_node", "rgbdfe_upload_nodes",
     "rgbdfe_upload_node_device", "rgbdfe_release_node", "rgbdfe_node_count",
     "rgbdfe_match_node_pairs", "rgbdfe_match_pair_list", "rgbdfe_match_pair_list_device",
     "rgbdfe_detector_configure", "rgbdfe_detector_thresholds", "rgbdfe_detect_describe",

@@ -226,6 +226,7 @@ struct rgbdfe_ctx {
   int64_t graph_launches = 0, graph_captures = 0;
   bool use_graphs = true;  // RGBDFE_GRAPHS=0: plain stream launches
   hipStream_t capture_stream = nullptr;  // graphs are captured here, never on a stream other threads may wait on
+  uint8_t* upload_stage = nullptr; size_t upload_stage_bytes = 0;  // pinned staging of rgbdfe_upload_nodes
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   hipEvent_t nodes_ready = nullptr;  // recorded behind the latest rgbdfe_upload_node_device copies; every batch waits for it
   hipEvent_t nodes_ready_ev = nullptr;  // (storage; nodes_ready points here once the first such upload happened)
@@ -769,6 +770,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
   if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
+  if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
   ctx->graphs.clear();
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
   if (ctx->d_xyz) (void)hipFree(ctx->d_xyz);
@@ -881,6 +883,58 @@ int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc, co
                        int32_t n) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return upload_common(ctx, node_id, desc, xyz1, n, hipMemcpyHostToDevice, ctx->stream, true);
+}
+
+// Many nodes in one call (an offline run hands over the nodes of a stretch of frames): every node's rows go through one
+// pinned staging buffer, the copies and expansion kernels of all nodes are enqueued back to back and the host waits once --
+// a single rgbdfe_upload_node is two pageable copies, a launch and a synchronisation (~65 us), here a node costs its
+// three enqueues.  All-or-nothing on argument / capacity errors (checked before anything is copied).
+int rgbdfe_upload_nodes(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* node_ids, const uint8_t* const* desc,
+                        const float* const* xyz1, const int32_t* counts) {
+  if (!ctx || n_nodes < 0 || (n_nodes > 0 && (!node_ids || !desc || !xyz1 || !counts)))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad upload arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  size_t rows = 0, fresh = 0;
+  bool overwrite = false;
+  for (int32_t i = 0; i < n_nodes; ++i) {
+    if (counts[i] < 0 || (counts[i] > 0 && (!desc[i] || !xyz1[i]))) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad upload arguments");
+    if (counts[i] > ctx->cfg.max_keypoints) return fail(ctx, RGBDFE_ERR_CAPACITY, "node has more rows than max_keypoints");
+    for (int32_t j = 0; j < i; ++j)
+      if (node_ids[j] == node_ids[i]) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "a node id appears twice in one upload");
+    if (ctx->nodes.count(node_ids[i])) overwrite = true; else ++fresh;
+    rows += (size_t)counts[i];
+  }
+  if (fresh > ctx->free_slots.size()) return fail(ctx, RGBDFE_ERR_CAPACITY, "no free node slot (max_nodes)");
+  if (overwrite)  // nodes rewritten in place: wait for batches that may still read them
+    for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+  if (rows * 48 > ctx->upload_stage_bytes) {
+    if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
+    ctx->upload_stage = nullptr; ctx->upload_stage_bytes = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->upload_stage, rows * 48 * 2, hipHostMallocDefault));
+    ctx->upload_stage_bytes = rows * 48 * 2;
+  }
+  uint8_t* stage = ctx->upload_stage;
+  for (int32_t i = 0; i < n_nodes; ++i) {
+    const int32_t n = counts[i];
+    uint32_t slot;
+    auto it = ctx->nodes.find(node_ids[i]);
+    if (it != ctx->nodes.end()) slot = it->second.slot;
+    else { slot = ctx->free_slots.back(); ctx->free_slots.pop_back(); }
+    const size_t row0 = (size_t)slot * (size_t)ctx->cfg.max_keypoints;
+    if (n > 0) {
+      memcpy(stage, desc[i], (size_t)n * 32);
+      memcpy(stage + (size_t)n * 32, xyz1[i], (size_t)n * 16);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc + row0 * 8, stage, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, stage + (size_t)n * 32, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+      launch_hamming_expand(ctx->d_desc + row0 * 8, ctx->d_desc4, slot, (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->stream);
+      stage += (size_t)n * 48;
+    }
+    ctx->nodes[node_ids[i]] = NodeEntry{slot, (uint32_t)n, 0u, 0u};
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RGBDFE_OK;
 }
 
 int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_desc,
@@ -3477,6 +3531,12 @@ const char* rgbdfe_last_error(rgbdfe_ctx* ctx) {
 int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc, const float* xyz1, int32_t n) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_ALL(ctx, impl::rgbdfe_upload_node(c, node_id, desc, xyz1, n));
+}
+
+int rgbdfe_upload_nodes(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* node_ids, const uint8_t* const* desc,
+                        const float* const* xyz1, const int32_t* counts) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_upload_nodes(c, n_nodes, node_ids, desc, xyz1, counts));
 }
 
 int rgbdfe_upload_node_device(rgbdfe_ctx* ctx, int32_t node_id, const void* d_desc, const void* d_xyz1, int32_t n,

@@ -463,6 +463,22 @@ class FrontEnd:
                                                          C.byref(n)))
         return buf[: n.value].copy()
 
+    def upload_nodes(self, node_ids, descs, xyz1s):
+        """rgbdfe_upload_nodes: upload_node for a list of nodes in one call (one wait, pinned staging)."""
+        n = len(node_ids)
+        d = [np.ascontiguousarray(x, np.uint8) for x in descs]
+        p = [np.ascontiguousarray(x, np.float32) for x in xyz1s]
+        for a, b in zip(d, p):
+            if a.ndim != 2 or a.shape[1] != 32 or b.shape != (a.shape[0], 4):
+                raise ValueError("desc must be [n,32] uint8 and xyz1 [n,4] float32")
+        ids = np.ascontiguousarray(node_ids, np.int32)
+        cnt = np.array([a.shape[0] for a in d], np.int32)
+        vp = C.c_void_p * max(n, 1)
+        pd = vp(*[a.ctypes.data for a in d])
+        pp = vp(*[b.ctypes.data for b in p])
+        self._check(self._L.rgbdfe_upload_nodes(self._ctx, n, ids.ctypes.data, C.cast(pd, C.c_void_p), C.cast(pp, C.c_void_p),
+                                                cnt.ctypes.data))
+
     def upload_sift_node(self, node_id: int, desc128: np.ndarray, xyz1: np.ndarray):
         desc128 = np.ascontiguousarray(desc128, np.float32)
         xyz1 = np.ascontiguousarray(xyz1, np.float32)

@@ -444,3 +444,44 @@ def test_one_wave_schedule_is_deterministic_at_many_iterations():
         for _ in range(3):
             assert fe.match_pair_list(pq, pt).tobytes() == ref
         fe.close()
+
+
+def test_upload_nodes_equals_single_uploads():
+    """rgbdfe_upload_nodes: the residency of n single uploads (fresh ids, ids rewritten in place, empty nodes), all-or-nothing
+    on errors, through a multi-device handle too; prints what a node costs either way."""
+    import time
+    from rgbdslam_v2_amd.frontend import FrontEnd, RgbdfeError
+    F = 40
+    seq = synth.make_sequence(n_frames=F, n_kp=700, n_world=2800, seed=4)
+    pq, pt = synth.candidate_pairs(F, per_frame=6, seed=4)
+    descs = [seq["desc"][f] for f in range(F)]
+    xyzs = [seq["xyz1"][f] for f in range(F)]
+    for devs in (None, [0, 0]):
+        a = FrontEnd(device_id=0, max_nodes=F + 2, max_keypoints=1024, max_pairs_per_batch=len(pq), device_ids=devs)
+        t0 = time.perf_counter()
+        for f in range(F):
+            a.upload_node(f, descs[f], xyzs[f])
+        t_single = (time.perf_counter() - t0) / F
+        ref = a.match_pair_list(pq, pt)
+        b = FrontEnd(device_id=0, max_nodes=F + 2, max_keypoints=1024, max_pairs_per_batch=len(pq), device_ids=devs)
+        b.upload_nodes(list(range(F)), descs, xyzs)                       # warm-up: allocates the staging buffer
+        for f in range(F):
+            b.release_node(f)
+        t0 = time.perf_counter()
+        b.upload_nodes(list(range(F)), descs, xyzs)
+        t_batch = (time.perf_counter() - t0) / F
+        print("upload per node: single %.1f us, batched %.1f us (devices %s)" % (t_single * 1e6, t_batch * 1e6, devs))
+        assert b.match_pair_list(pq, pt).tobytes() == ref.tobytes()
+        # rewrite some nodes in place with other content + an empty node + a new id, then back
+        b.upload_nodes([3, 5, F], [descs[7], descs[9][:0], descs[1]], [xyzs[7], xyzs[9][:0], xyzs[1]])
+        a.upload_node(3, descs[7], xyzs[7]); a.upload_node(5, descs[9][:0], xyzs[9][:0]); a.upload_node(F, descs[1], xyzs[1])
+        assert b.match_pair_list(pq, pt).tobytes() == a.match_pair_list(pq, pt).tobytes()
+        # errors leave everything as it was
+        with pytest.raises(RgbdfeError):
+            b.upload_nodes([1, 1], [descs[0], descs[2]], [xyzs[0], xyzs[2]])          # an id twice
+        with pytest.raises(RgbdfeError):
+            b.upload_nodes([F + 1, F + 2], [descs[0], descs[2]], [xyzs[0], xyzs[2]])  # one slot too few
+        with pytest.raises(RgbdfeError):
+            b.upload_nodes([2], [np.zeros((2000, 32), np.uint8)], [np.zeros((2000, 4), np.float32)])   # > max_keypoints
+        assert b.match_pair_list(pq, pt).tobytes() == a.match_pair_list(pq, pt).tobytes()
+        a.close(); b.close()
