@@ -409,6 +409,10 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["sift_extract"] = {"error": repr(e)}
             try:
+                out["front_end"] = front_end_subrecord(local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["front_end"] = {"error": repr(e)}
+            try:
                 out["loop_closure"] = loop_closure_subrecord(local_rank, args.depth_noise)
             except SystemExit:
                 raise
@@ -721,6 +725,51 @@ def sift_extract_bytes(w, h, n_kp):
     16 B key, 512 B descriptor out (their gradient windows re-read planes already counted)."""
     px = 4.0 * w * h * (4.0 / 3.0)
     return w * h + px * (24 * 4 + 5 * 2) + n_kp * (24 + 16 + 512)
+
+
+def front_end_subrecord(device):
+    """Level C: a recorded sequence through the whole front end, the way an offline run (OpenNIListener reading a bag file)
+    would drive it -- rgbdfe_detect_describe_batch over a stretch of frames, rgbdfe_upload_nodes for their features,
+    rgbdfe_match_pair_list for every new node against its 20 predecessors -- with host buffers in and out at every step."""
+    from rgbdslam_v2_amd import synth
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    n_base, n_run, cand, n_kp = 28, 112, 20, 1000
+    seq = synth.make_image_sequence(n_frames=n_base, seed=1)
+    idx = synth.forth_and_back(n_run, n_base)
+    grays, depths = [seq["gray"][i] for i in idx], [seq["depth"][i] for i in idx]
+    masks = [np.where(seq["mask"][i] > 0, 255, 0).astype(np.uint8) for i in idx]
+    K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    pq = np.array([f for f in range(1, n_run) for c in range(1, min(cand, f) + 1)], np.int32)
+    pt = np.array([f - c for f in range(1, n_run) for c in range(1, min(cand, f) + 1)], np.int32)
+    fe = FrontEnd(device_id=device, max_nodes=n_run, max_keypoints=1024, max_pairs_per_batch=len(pq))
+    fe.detector_configure(max_keypoints=n_kp)
+    per, parts, edges = [], None, 0
+    try:
+        for rep in range(REPEATS + 1):
+            for f in range(n_run):
+                if rep:
+                    fe.release_node(f)
+            t0 = time.perf_counter()
+            feats = fe.detect_describe_batch(grays, masks, depths, *K)
+            t1 = time.perf_counter()
+            fe.upload_nodes(list(range(n_run)), [ft[1] for ft in feats], [ft[2] for ft in feats])
+            t2 = time.perf_counter()
+            res = fe.match_pair_list(pq, pt)
+            t3 = time.perf_counter()
+            if rep:                                  # the first pass warms buffers and threads up
+                per.append((t3 - t0) / n_run)
+                parts = ((t1 - t0) / n_run, (t2 - t1) / n_run, (t3 - t2) / n_run)
+            edges = int((res["id1"] >= 0).sum())
+    finally:
+        fe.close()
+    per.sort()
+    dt = per[len(per) // 2]
+    return {"metric": "frames through detect + describe + node upload + 20 candidate pairs each, per second (640x480, ORB-1000)",
+            "value": round(1.0 / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt * 1e3, 4), "frames_per_run": n_run,
+            "pairs_per_run": int(len(pq)), "edges_found": edges,
+            "ms_per_frame_parts_last_run": {"detect_describe_batch": round(parts[0] * 1e3, 4), "upload_nodes": round(parts[1] * 1e3, 4),
+                                            "match_pair_list": round(parts[2] * 1e3, 4)},
+            "note": "host wall clock, host buffers between the three calls (no device-resident hand-over), median of %d runs" % REPEATS}
 
 
 def detect_subrecord(device):
