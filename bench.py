@@ -729,8 +729,8 @@ def sift_extract_bytes(w, h, n_kp):
 
 def front_end_subrecord(device):
     """Level C: a recorded sequence through the whole front end, the way an offline run (OpenNIListener reading a bag file)
-    would drive it -- rgbdfe_detect_describe_batch over a stretch of frames, rgbdfe_upload_nodes for their features,
-    rgbdfe_match_pair_list for every new node against its 20 predecessors -- with host buffers in and out at every step."""
+    would drive it -- rgbdfe_detect_describe_batch_nodes over a stretch of frames (features to the host, nodes resident),
+    rgbdfe_match_pair_list for every new node against its 20 predecessors -- host buffers in and out."""
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd.frontend import FrontEnd
     n_base, n_run, cand, n_kp = 28, 112, 20, 1000
@@ -744,21 +744,20 @@ def front_end_subrecord(device):
     fe = FrontEnd(device_id=device, max_nodes=n_run, max_keypoints=1024, max_pairs_per_batch=len(pq))
     fe.detector_configure(max_keypoints=n_kp)
     per, parts, edges = [], None, 0
+    ids = np.arange(n_run, dtype=np.int32)
     try:
         for rep in range(REPEATS + 1):
             for f in range(n_run):
                 if rep:
                     fe.release_node(f)
             t0 = time.perf_counter()
-            feats = fe.detect_describe_batch(grays, masks, depths, *K)
+            fe.detect_describe_batch(grays, masks, depths, *K, node_ids=ids)     # features to the host AND resident nodes
             t1 = time.perf_counter()
-            fe.upload_nodes(list(range(n_run)), [ft[1] for ft in feats], [ft[2] for ft in feats])
-            t2 = time.perf_counter()
             res = fe.match_pair_list(pq, pt)
             t3 = time.perf_counter()
             if rep:                                  # the first pass warms buffers and threads up
                 per.append((t3 - t0) / n_run)
-                parts = ((t1 - t0) / n_run, (t2 - t1) / n_run, (t3 - t2) / n_run)
+                parts = ((t1 - t0) / n_run, (t3 - t1) / n_run)
             edges = int((res["id1"] >= 0).sum())
     finally:
         fe.close()
@@ -767,9 +766,10 @@ def front_end_subrecord(device):
     return {"metric": "frames through detect + describe + node upload + 20 candidate pairs each, per second (640x480, ORB-1000)",
             "value": round(1.0 / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt * 1e3, 4), "frames_per_run": n_run,
             "pairs_per_run": int(len(pq)), "edges_found": edges,
-            "ms_per_frame_parts_last_run": {"detect_describe_batch": round(parts[0] * 1e3, 4), "upload_nodes": round(parts[1] * 1e3, 4),
-                                            "match_pair_list": round(parts[2] * 1e3, 4)},
-            "note": "host wall clock, host buffers between the three calls (no device-resident hand-over), median of %d runs" % REPEATS}
+            "ms_per_frame_parts_last_run": {"detect_describe_batch_nodes": round(parts[0] * 1e3, 4),
+                                            "match_pair_list": round(parts[1] * 1e3, 4)},
+            "note": "host wall clock; rgbdfe_detect_describe_batch_nodes returns the features to the host and leaves them resident "
+                    "as nodes (device-to-device), rgbdfe_match_pair_list returns the result records; median of %d runs" % REPEATS}
 
 
 def detect_subrecord(device):

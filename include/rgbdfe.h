@@ -469,6 +469,15 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
                                  const uint8_t* const* mask, const float* const* depth, int32_t rows, int32_t cols,
                                  double fx, double fy, double cx, double cy, double depth_scaling, int32_t out_stride,
                                  rgbdfe_keypoint* keypoints, uint8_t* descriptors, float* xyz1, int32_t* n_out);
+/* The same, and frame f's features also become the resident node node_ids[f] (>= 0; negative: no node for that frame) --
+ * what Node::Node + GraphManager::addNode + rgbdfe_upload_node do, without the features' trip to the host and back: the
+ * descriptors and points are copied into the node slabs from the description's device buffers (the host outputs are filled
+ * as before).  A frame without features leaves an empty node.  An id that exists is rewritten in place. */
+int rgbdfe_detect_describe_batch_nodes(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray,
+                                       const uint8_t* const* mask, const float* const* depth, int32_t rows, int32_t cols,
+                                       double fx, double fy, double cx, double cy, double depth_scaling, int32_t out_stride,
+                                       rgbdfe_keypoint* keypoints, uint8_t* descriptors, float* xyz1, int32_t* n_out,
+                                       const int32_t* node_ids);
 /* the point-cloud constructor's feature path (see rgbdfe_project_to_3d_cloud above) */
 int rgbdfe_detect_describe_cloud(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, const float* cloud,
                                  int32_t rows, int32_t cols, double maximum_depth, rgbdfe_keypoint* keypoints,

@@ -190,6 +190,9 @@ def load():
     L.rgbdfe_detect_describe_batch.restype = C.c_int
     L.rgbdfe_detect_describe_batch.argtypes = [ctx, i32, vp, vp, vp, i32, i32, C.c_double, C.c_double, C.c_double,
                                                C.c_double, C.c_double, i32, vp, vp, vp, vp]
+    L.rgbdfe_detect_describe_batch_nodes.restype = C.c_int
+    L.rgbdfe_detect_describe_batch_nodes.argtypes = [ctx, i32, vp, vp, vp, i32, i32, C.c_double, C.c_double, C.c_double,
+                                                     C.c_double, C.c_double, i32, vp, vp, vp, vp, vp]
     L.rgbdfe_detect_describe_cloud.restype = C.c_int
     L.rgbdfe_detect_describe_cloud.argtypes = [ctx, vp, vp, vp, i32, i32, C.c_double, vp, vp, vp, C.POINTER(i32)]
     L.rgbdfe_place_recognition.restype = C.c_int
@@ -313,7 +316,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",
     "rgbdfe_gather_transport", "rgbdfe_set_hamming_mode", "rgbdfe_project_to_3d_cloud", "rgbdfe_detect_describe_cloud",
-    "rgbdfe_detect_describe_batch", "rgbdfe_match_pair_list_allgather_edges",
+    "rgbdfe_detect_describe_batch", "rgbdfe_detect_describe_batch_nodes", "rgbdfe_match_pair_list_allgather_edges",
     "rgbdfe_set_feature_min_depth", "rgbdfe_project_to_3d_min_depth",
     "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",
     "rgbdfe_match_flann_pair_list", "rgbdfe_upload_node_keypoints",

@@ -889,12 +889,19 @@ int rgbdfe_upload_node(rgbdfe_ctx* ctx, int32_t node_id, const uint8_t* desc, co
 // pinned staging buffer, the copies and expansion kernels of all nodes are enqueued back to back and the host waits once --
 // a single rgbdfe_upload_node is two pageable copies, a launch and a synchronisation (~65 us), here a node costs its
 // three enqueues.  All-or-nothing on argument / capacity errors (checked before anything is copied).
+static int upload_nodes_locked(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* node_ids, const uint8_t* const* desc,
+                               const float* const* xyz1, const int32_t* counts);
 int rgbdfe_upload_nodes(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* node_ids, const uint8_t* const* desc,
                         const float* const* xyz1, const int32_t* counts) {
   if (!ctx || n_nodes < 0 || (n_nodes > 0 && (!node_ids || !desc || !xyz1 || !counts)))
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad upload arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  return upload_nodes_locked(ctx, n_nodes, node_ids, desc, xyz1, counts);
+}
+
+static int upload_nodes_locked(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* node_ids, const uint8_t* const* desc,
+                               const float* const* xyz1, const int32_t* counts) {
   size_t rows = 0, fresh = 0;
   bool overwrite = false;
   for (int32_t i = 0; i < n_nodes; ++i) {
@@ -1806,7 +1813,7 @@ void super_describe_prepare(const OrbWorkspace& orb, SuperFrameJob& j, int frame
 int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
                                 const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
                                 double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
-                                uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+                                uint8_t* descriptors, float* xyz1, int32_t* n_out, const int32_t* node_ids) {
   OrbWorkspace& orb = ctx->orb_super;
   const OrbWorkspace& one = ctx->orb;
   const int pc = one.grid * one.grid;
@@ -1828,6 +1835,12 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   }
   hipStream_t up = ctx->orb_upload_stream, st2 = ctx->orb_compute_stream;
   const int max_kp = ctx->orb_max_keypoints;
+  if (node_ids) {
+    bool overwrite = false;
+    for (int32_t f = 0; f < n_frames; ++f) overwrite |= node_ids[f] >= 0 && ctx->nodes.count(node_ids[f]) != 0;
+    if (overwrite)  // nodes rewritten in place: wait for pair batches that may still read them
+      for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
+  }
   const int S = (n_frames + B - 1) / B;
   // D - 1 device passes are in flight ahead of the super-frame the host is replaying: D image sets / pass slots, D + 1
   // staging buffers.  A pass is a chain of ~25 dependent device operations (~1 ms from enqueue to read-back although its
@@ -1934,6 +1947,30 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
       launch_project_to_3d_frames(pf, orb.d_kpxy, rows, cols, (float)(1. / fx), (float)(1. / fy), (float)cx, (float)cy,
                                   depth_scaling, max_kp, orb.d_kept, orb.d_xyz, orb.d_n_proj, st2);
       if (hipGetLastError() != hipSuccess) return RGBDFE_ERR_HIP;
+      // node_ids: the frames' features become resident nodes straight from the description's device buffers (no trip
+      // through the host and back: what Node::Node + GraphManager::addNode + rgbdfe_upload_node would do)
+      if (node_ids)
+        for (int k = 0; k < nf; ++k) {
+          const int32_t id = node_ids[first_of(s) + k];
+          const int n = (int)J[(size_t)k].kps.size();
+          if (id < 0 || n == 0) continue;
+          uint32_t slot;
+          auto it = ctx->nodes.find(id);
+          if (it != ctx->nodes.end()) slot = it->second.slot;
+          else {
+            if (ctx->free_slots.empty()) { err = "no free node slot (max_nodes)"; return RGBDFE_ERR_CAPACITY; }
+            slot = ctx->free_slots.back();
+            ctx->free_slots.pop_back();
+          }
+          if (n > ctx->cfg.max_keypoints) { err = "node has more rows than max_keypoints"; return RGBDFE_ERR_CAPACITY; }
+          const size_t row0 = (size_t)slot * (size_t)ctx->cfg.max_keypoints;
+          const size_t off = (size_t)J[(size_t)k].off;
+          if (hipMemcpyAsync(ctx->d_desc + row0 * 8, orb.d_desc + off * 32, (size_t)n * 32, hipMemcpyDeviceToDevice, st2) != hipSuccess ||
+              hipMemcpyAsync(ctx->d_xyz + row0, orb.d_xyz + off, (size_t)n * 16, hipMemcpyDeviceToDevice, st2) != hipSuccess)
+            return RGBDFE_ERR_HIP;
+          launch_hamming_expand(ctx->d_desc + row0 * 8, ctx->d_desc4, slot, (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, st2);
+          ctx->nodes[id] = NodeEntry{slot, (uint32_t)n, 0u, 0u};
+        }
       if (hipMemcpyAsync(orb.h_desc, orb.d_desc, (size_t)32 * tot, hipMemcpyDeviceToHost, st2) != hipSuccess ||
           hipMemcpyAsync(orb.h_xyz_out, orb.d_xyz, sizeof(float) * 4 * (size_t)tot, hipMemcpyDeviceToHost, st2) != hipSuccess ||
           hipMemcpyAsync(orb.h_n_proj, orb.d_n_proj, sizeof(int32_t) * (size_t)nf, hipMemcpyDeviceToHost, st2) != hipSuccess)
@@ -2046,6 +2083,17 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   orb.use_set(0);
   for (int i = 0; i < 64; ++i) ctx->orb.thresh[i] = orb.thresh[i];   // the detector's state goes back
   if (rc != RGBDFE_OK) return err.empty() ? rc : fail(ctx, rc, err);
+  if (node_ids)   // frames without features: empty nodes (n = 0), as rgbdfe_upload_node(id, ..., 0) would leave them
+    for (int32_t f = 0; f < n_frames; ++f)
+      if (node_ids[f] >= 0 && n_out[f] == 0) {
+        auto it = ctx->nodes.find(node_ids[f]);
+        if (it != ctx->nodes.end()) it->second.n = 0;
+        else {
+          if (ctx->free_slots.empty()) return fail(ctx, RGBDFE_ERR_CAPACITY, "no free node slot (max_nodes)");
+          ctx->nodes[node_ids[f]] = NodeEntry{ctx->free_slots.back(), 0u, 0u, 0u};
+          ctx->free_slots.pop_back();
+        }
+      }
   return RGBDFE_OK;
 }
 
@@ -2057,13 +2105,23 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
 // while frame k+1's detection pass runs on the device and the calling thread prepares and enqueues frame k's description
 // (third stream) instead of sitting in hipStreamSynchronize.  Outputs: frame f's keypoints /
 // descriptors / points at offset f * out_stride (rows), n_out[f] of them.
+static int detect_describe_batch_frames(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
+                                        const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                        double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
+                                        uint8_t* descriptors, float* xyz1, int32_t* n_out);
+// node_ids (may be NULL): frame f's features also become the resident node node_ids[f] (>= 0), see
+// rgbdfe_detect_describe_batch_nodes
 int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
                                  const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
                                  double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
-                                 uint8_t* descriptors, float* xyz1, int32_t* n_out) {
+                                 uint8_t* descriptors, float* xyz1, int32_t* n_out, const int32_t* node_ids = nullptr) {
   if (!ctx || n_frames < 0 || (n_frames > 0 && (!gray || !depth || !keypoints || !descriptors || !xyz1 || !n_out)) ||
       rows < 1 || cols < 1)
     return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad arguments");
+  if (node_ids)
+    for (int32_t f = 0; f < n_frames; ++f)
+      for (int32_t j = 0; j < f; ++j)
+        if (node_ids[f] >= 0 && node_ids[j] == node_ids[f]) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "a node id appears twice");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   ensure_detector(ctx);
@@ -2076,8 +2134,27 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
     static const bool super_env = !(getenv("RGBDFE_DETECT_SUPER") && atoi(getenv("RGBDFE_DETECT_SUPER")) == 0);
     if (super_env && n_frames >= 2 && !ctx->feature_min_depth && ctx->orb.grid * ctx->orb.grid * 2 <= 64)
       return detect_describe_batch_super(ctx, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling, out_stride,
-                                         keypoints, descriptors, xyz1, n_out);
+                                         keypoints, descriptors, xyz1, n_out, node_ids);
   }
+  const int rc_frames = detect_describe_batch_frames(ctx, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy, depth_scaling,
+                                                    out_stride, keypoints, descriptors, xyz1, n_out);
+  if (rc_frames != RGBDFE_OK || !node_ids) return rc_frames;
+  // the frame-by-frame pipeline hands its nodes over from the host outputs
+  std::vector<int32_t> ids, cnt;
+  std::vector<const uint8_t*> dp;
+  std::vector<const float*> xp;
+  for (int32_t f = 0; f < n_frames; ++f)
+    if (node_ids[f] >= 0) {
+      ids.push_back(node_ids[f]); cnt.push_back(n_out[f]);
+      dp.push_back(descriptors + (size_t)f * out_stride * 32); xp.push_back(xyz1 + (size_t)f * out_stride * 4);
+    }
+  return upload_nodes_locked(ctx, (int32_t)ids.size(), ids.data(), dp.data(), xp.data(), cnt.data());
+}
+
+static int detect_describe_batch_frames(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
+                                        const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                        double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
+                                        uint8_t* descriptors, float* xyz1, int32_t* n_out) {
   OrbWorkspace& orb = ctx->orb;
   std::string err;
   int rc = orb.prepare(cols, rows, true, err);
@@ -3767,6 +3844,32 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
   return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe_batch(c, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy,
                                                               depth_scaling, out_stride, keypoints, descriptors, xyz1,
                                                               n_out));
+}
+
+int rgbdfe_detect_describe_batch_nodes(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray, const uint8_t* const* mask,
+                                       const float* const* depth, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                       double cy, double depth_scaling, int32_t out_stride, rgbdfe_keypoint* keypoints,
+                                       uint8_t* descriptors, float* xyz1, int32_t* n_out, const int32_t* node_ids) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  if (!node_ids) return guarded(ctx, [&]() -> int { return fail(ctx, RGBDFE_ERR_INVALID_ARG, "node_ids is required"); });
+  if (!RGBDFE_IS_GROUP(ctx))
+    return RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe_batch(c, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy,
+                                                                depth_scaling, out_stride, keypoints, descriptors, xyz1, n_out,
+                                                                node_ids));
+  // several devices behind the handle: the frames are processed on the first one, the nodes go to all of them from the host
+  // outputs (every device holds every node)
+  int rc = RGBDFE_FIRST(ctx, impl::rgbdfe_detect_describe_batch(c, n_frames, gray, mask, depth, rows, cols, fx, fy, cx, cy,
+                                                                depth_scaling, out_stride, keypoints, descriptors, xyz1, n_out));
+  if (rc != RGBDFE_OK) return rc;
+  std::vector<int32_t> ids, cnt;
+  std::vector<const uint8_t*> dp;
+  std::vector<const float*> xp;
+  for (int32_t f = 0; f < n_frames; ++f)
+    if (node_ids[f] >= 0) {
+      ids.push_back(node_ids[f]); cnt.push_back(n_out[f]);
+      dp.push_back(descriptors + (size_t)f * out_stride * 32); xp.push_back(xyz1 + (size_t)f * out_stride * 4);
+    }
+  return RGBDFE_ALL(ctx, impl::rgbdfe_upload_nodes(c, (int32_t)ids.size(), ids.data(), dp.data(), xp.data(), cnt.data()));
 }
 
 int rgbdfe_sift_detect(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* mask, int32_t rows, int32_t cols,

@@ -327,10 +327,11 @@ class FrontEnd:
             fx, fy, cx, cy, depth_scaling, max_keypoints, kept.ctypes.data, xyz.ctypes.data, C.byref(k)))
         return kept[: k.value].copy(), xyz[: k.value].copy()
 
-    def detect_describe_batch(self, grays, masks, depths, fx, fy, cx, cy, depth_scaling=1.0):
+    def detect_describe_batch(self, grays, masks, depths, fx, fy, cx, cy, depth_scaling=1.0, node_ids=None):
         """A run of frames through the same detector state, in order (rgbdfe_detect_describe_batch): the results of
         calling detect_describe frame by frame, with frame k+1's upload overlapped with frame k's detection.
-        Returns a list of (keypoints, descriptors, xyz1) per frame."""
+        Returns a list of (keypoints, descriptors, xyz1) per frame.  node_ids: frame f's features also become the resident
+        node node_ids[f] (rgbdfe_detect_describe_batch_nodes; a negative id: no node)."""
         n = len(grays)
         if n == 0:
             return []
@@ -350,9 +351,17 @@ class FrontEnd:
         pg = vp(*[x.ctypes.data for x in g])
         pd = vp(*[x.ctypes.data for x in d])
         pm = vp(*[None if x is None else x.ctypes.data for x in m])
-        self._check(self._L.rgbdfe_detect_describe_batch(
-            self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
-            depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data))
+        if node_ids is not None:
+            ids = np.ascontiguousarray(node_ids, np.int32)
+            if ids.shape != (n,):
+                raise ValueError("node_ids must hold one id per frame")
+            self._check(self._L.rgbdfe_detect_describe_batch_nodes(
+                self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
+                depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data, ids.ctypes.data))
+        else:
+            self._check(self._L.rgbdfe_detect_describe_batch(
+                self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
+                depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data))
         return [(kp[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy(), xyz[f, : cnt[f]].copy()) for f in range(n)]
 
     def orb_detect(self, gray, mask, fast_threshold, capacity=60000):

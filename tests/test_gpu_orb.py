@@ -271,6 +271,48 @@ def test_detect_describe_batch_long_runs_and_grids(grid, n_frames, shape, depth)
         assert np.array_equal(d1, d2) and np.array_equal(x1, x2)
 
 
+@pytest.mark.parametrize("devs,grid", [(None, 3), (None, 6), ([0, 0], 3)], ids=["super_frames", "frame_pipeline", "two_device_handle"])
+def test_detect_describe_batch_nodes(devs, grid):
+    """rgbdfe_detect_describe_batch_nodes: the frames' features become resident nodes inside the call (device-to-device from
+    the description's buffers on the super-frame path; from the host outputs on the frame-by-frame path -- grid 6 -- and on a
+    multi-device handle) -- pair results are those of upload_node + match on the returned features; an empty frame gives an
+    empty node, a negative id none, an existing id is rewritten."""
+    from rgbdslam_v2_amd.frontend import FrontEnd, RgbdfeError
+    n = 16
+    seq = synth.make_image_sequence(n_frames=8, seed=41)
+    idx = synth.forth_and_back(n, 8)
+    grays = [seq["gray"][i] for i in idx]
+    depths = [seq["depth"][i].copy() for i in idx]
+    masks = [np.where(seq["mask"][i] > 0, 255, 0).astype(np.uint8) for i in idx]
+    depths[5][:] = np.nan                                   # no depth anywhere: no features, an empty node
+    K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    ids = np.arange(100, 100 + n, dtype=np.int32)
+    ids[9] = -1                                             # no node for frame 9
+    pq = np.array([100 + f for f in range(1, n) for c in (1, 2, 3) if f - c >= 0 and f != 9 and f - c != 9], np.int32)
+    pt = np.array([100 + f - c for f in range(1, n) for c in (1, 2, 3) if f - c >= 0 and f != 9 and f - c != 9], np.int32)
+    a = FrontEnd(device_id=0, max_nodes=n + 2, max_keypoints=1024, max_pairs_per_batch=64, device_ids=devs)
+    a.detector_configure(max_keypoints=600, grid_resolution=grid)
+    feats = a.detect_describe_batch(grays, masks, depths, *K)
+    for f in range(n):
+        if ids[f] >= 0:
+            a.upload_node(int(ids[f]), feats[f][1], feats[f][2])
+    ref = a.match_pair_list(pq, pt)
+    b = FrontEnd(device_id=0, max_nodes=n + 2, max_keypoints=1024, max_pairs_per_batch=64, device_ids=devs)
+    b.detector_configure(max_keypoints=600, grid_resolution=grid)
+    b.upload_node(103, feats[0][1][:50], feats[0][2][:50])  # id 103 exists already: rewritten by the call
+    got = b.detect_describe_batch(grays, masks, depths, *K, node_ids=ids)
+    for (k1, d1, x1), (k2, d2, x2) in zip(got, feats):
+        assert_kps_equal(k1, k2)
+        assert np.array_equal(d1, d2) and np.array_equal(x1, x2)
+    assert len(got[5][0]) == 0 and (ref["id1"] >= 0).sum() > 10
+    assert b.match_pair_list(pq, pt).tobytes() == ref.tobytes()
+    with pytest.raises(RgbdfeError):
+        b.match_pair_list([100], [109])                     # frame 9 got no node
+    with pytest.raises(RgbdfeError):
+        b.detect_describe_batch(grays[:2], masks[:2], depths[:2], *K, node_ids=[7, 7])
+    a.close(); b.close()
+
+
 def test_detect_describe_with_page_locked_images(frames):
     """rgbdfe_host_register: page-locked caller images are copied to the device directly (no staging copy); the outputs
     are those of the pageable path, and the buffers can be unregistered and reused afterwards."""
