@@ -43,6 +43,7 @@ def orb_section(d, noise):
             "mfma_instructions_per_batch": h.get("SQ_INSTS_MFMA_avg"),
             "mfma_busy_cycles_per_batch": h.get("SQ_VALU_MFMA_BUSY_CYCLES_avg"),
             "lds_instructions_per_batch": h.get("SQ_INSTS_LDS_avg"),
+            "lds_bank_conflict_cycles_per_batch": h.get("SQ_LDS_BANK_CONFLICT_avg"),
             "mean_issue_ns": ISSUE["hamming"], "valu_busy_frac": round(h.get("valu_busy_frac", 0.0), 4),
             "hbm_bytes_per_launch": h.get("hbm_bytes_per_launch"), "kernel_ns_in_profile": h.get("per_batch_ns")},
         "select_ransac": {
