@@ -237,6 +237,8 @@ struct rgbdfe_ctx {
   OrbWorkspace orb;
   OrbWorkspace orb_super;  // rgbdfe_detect_describe_batch: up to 7 frames per launch chain (its own image sets)
   std::unique_ptr<TaskPool> detect_pool, stage_pool;  // its worker threads (created by the first batch call, kept)
+  SiftExtractor sift2;          // rgbdfe_sift_detect_batch alternates between two extractors (two chunks in flight)
+  hipStream_t sift_stream2 = nullptr;
   SiftExtractor sift;  // rgbdfe_sift_detect (sift_extract.hip)
   int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;
@@ -771,6 +773,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
   if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
   if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
+  if (ctx->sift_stream2) (void)hipStreamDestroy(ctx->sift_stream2);
   ctx->graphs.clear();
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
   if (ctx->d_xyz) (void)hipFree(ctx->d_xyz);
@@ -1455,10 +1458,28 @@ int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* c
   std::vector<SiftKey> keys[SiftExtractor::kMaxBatch];
   const float* desc[SiftExtractor::kMaxBatch];
   std::string err;
-  for (int32_t f0 = 0; f0 < n_frames; f0 += SiftExtractor::kMaxBatch) {
-    const int nf = std::min<int32_t>(SiftExtractor::kMaxBatch, n_frames - f0);
-    const int rc = ctx->sift.run_batch(gray + f0, nf, rows, cols, max_keypoints, keys, desc, ctx->stream, err);
+  // Two extractors, two streams: the shape-static first half of chunk c + 1 (pyramids, extremum flags, candidate lists) is
+  // enqueued before the host collects chunk c, so it runs on the device beside chunk c's orientation / descriptor launches and
+  // behind the host's waits and list work.
+  constexpr int B = SiftExtractor::kMaxBatch;
+  const int32_t n_chunks = (n_frames + B - 1) / B;
+  SiftExtractor* ex[2] = {&ctx->sift, &ctx->sift2};
+  if (n_chunks > 1 && !ctx->sift_stream2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->sift_stream2, hipStreamNonBlocking));
+  hipStream_t st[2] = {ctx->stream, ctx->sift_stream2 ? ctx->sift_stream2 : ctx->stream};
+  auto count_of = [&](int32_t c) { return std::min<int32_t>(B, n_frames - c * B); };
+  if (n_chunks > 0) {
+    const int rc = ex[0]->begin_batch(gray, count_of(0), rows, cols, st[0], err);
     if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  }
+  for (int32_t c = 0; c < n_chunks; ++c) {
+    const int32_t f0 = c * B;
+    const int nf = count_of(c);
+    if (c + 1 < n_chunks) {
+      const int rcb = ex[(c + 1) & 1]->begin_batch(gray + (size_t)(c + 1) * B, count_of(c + 1), rows, cols, st[(c + 1) & 1], err);
+      if (rcb != RGBDFE_OK) { (void)hipStreamSynchronize(st[c & 1]); return fail(ctx, rcb, err); }
+    }
+    const int rc = ex[c & 1]->finish_batch(max_keypoints, keys, desc, st[c & 1], err);
+    if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(st[(c + 1) & 1]); return fail(ctx, rc, err); }
     for (int k = 0; k < nf; ++k) {
       const int32_t f = f0 + k;
       n_out[f] = (int32_t)keys[k].size();

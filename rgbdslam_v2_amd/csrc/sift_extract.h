@@ -26,6 +26,9 @@ struct SiftExtractor {
   // desc[f] points into a pinned buffer of this object (valid until the next call): the caller copies from there once
   int run_batch(const uint8_t* const* gray, int nf, int rows, int cols, int max_features, std::vector<SiftKey>* keys,
                 const float** desc, hipStream_t s, std::string& err);
+  int begin_batch(const uint8_t* const* gray, int nf, int rows, int cols, hipStream_t s, std::string& err);
+  int finish_batch(int max_features, std::vector<SiftKey>* keys, const float** desc, hipStream_t s, std::string& err);
+  int pending_nf = 0;   // frames of the batch begin_batch enqueued and finish_batch has not collected yet
   int run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys, const float*& desc,
           hipStream_t s, std::string& err) {
     return run_batch(&gray, 1, rows, cols, max_features, &keys, &desc, s, err);

@@ -746,8 +746,17 @@ int SiftExtractor::enqueue_pyramid(const uint8_t* const* gray, int nf, hipStream
 
 int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int cols, int max_features, std::vector<SiftKey>* keys,
                              const float** desc, hipStream_t s, std::string& err) {
+  const int rc = begin_batch(gray, nf, rows, cols, s, err);
+  return rc != RGBDFE_OK ? rc : finish_batch(max_features, keys, desc, s, err);
+}
+
+// The first, shape-static half of a batch -- images in, pyramids, extremum flags, ordered candidate lists, the per-level
+// counts on their way to the host -- is only ENQUEUED here; finish_batch waits for it.  The batch entry point runs two
+// extractors alternately, each on its own stream, so that this half of chunk k + 1 executes while the host works through the
+// second half of chunk k (its three waits, the feature-count limits, the list reshaping).
+int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int cols, hipStream_t s, std::string& err) {
   if (nf < 1 || nf > kMaxBatch) { err = "SIFT batch size out of range"; return RGBDFE_ERR_INVALID_ARG; }
-  for (int f = 0; f < nf; ++f) { keys[f].clear(); desc[f] = nullptr; }
+  pending_nf = 0;
   int rc = prepare(rows, cols, nf, err);
   if (rc != RGBDFE_OK) return rc;
   const int nlv = octave_num * kDogLevels;
@@ -769,6 +778,17 @@ int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int c
                      d_cand, (int)cand_cap, tdog1, tdog, tedge, st);
   SIFT_HIP(hipGetLastError());
   SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * 64 * (size_t)nf, hipMemcpyDeviceToHost, s));
+  pending_nf = nf;
+  return RGBDFE_OK;
+}
+
+int SiftExtractor::finish_batch(int max_features, std::vector<SiftKey>* keys, const float** desc, hipStream_t s, std::string& err) {
+  const int nf = pending_nf;
+  if (nf < 1) { err = "finish_batch without begin_batch"; return RGBDFE_ERR_INVALID_ARG; }
+  pending_nf = 0;
+  for (int f = 0; f < nf; ++f) { keys[f].clear(); desc[f] = nullptr; }
+  const int nlv = octave_num * kDogLevels;
+  const unsigned NF = (unsigned)nf;
   SIFT_HIP(hipStreamSynchronize(s));
   // ---- per frame: which levels run -- GenerateFeatureList's "-tc2" order (coarse octaves first, PyramidCU.cpp:797-850) and
   //      SiftPyramid::LimitFeatureCount(0) (SiftPyramid.cpp:170-210, _TruncateMethod = 1).  A skipped level contributes
