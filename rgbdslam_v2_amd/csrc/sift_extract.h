@@ -67,6 +67,7 @@ struct SiftExtractor {
   int* h_counts = nullptr;                             // pinned: per-level totals, 64 per frame
   float* h_stage = nullptr; size_t stage_floats = 0;   // pinned staging for lists (all frames of a batch)
   uint8_t* h_gray = nullptr; size_t gray_cap = 0;      // pinned staging of the caller's (pageable) images
+  int* d_orow2oct = nullptr;                           // (octave, row) pairs of the stacked octaves
   void* d_jobs = nullptr; void* h_jobs = nullptr;      // the per-frame segment tables of the orientation / descriptor launches
   std::vector<int> lvl_count, lvl_off;                 // candidates per (octave, dog level) of the latest call's first frame
   int frames_cap = 0;                                  // frames the buffers hold (every device buffer is [frames_cap][...])

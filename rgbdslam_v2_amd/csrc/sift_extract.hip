@@ -270,30 +270,45 @@ __device__ __forceinline__ SiftExtractor::LevelDesc level_of_frame(SiftExtractor
   return L;
 }
 
-// one wave (= one workgroup) per 64 consecutive columns of one row of the stacked (octave, dog level) planes: a flag byte
-// per pixel + the row's count.  Most pixels leave key_eval after one dependent load, so the launch lives on the number of
-// independent waves in flight -- measured: four rows per 256-thread workgroup +50 % (a wave that runs the whole test holds
+// one wave (= one workgroup) per 64 consecutive columns of one row of an OCTAVE, for all its kDogLevels key levels at once:
+// the six Gaussian planes the five centre DoG values need are read once per pixel (10 reads when every level had its own
+// wave), the common early exit -- |D| <= 0.8 * threshold, which most pixels take -- is decided from those registers, and only a
+// level that passes it runs the full test (key_eval: neighbours, edge ratio, sub-pixel solve).  A flag byte per pixel and
+// level + the rows' counts.  Most waves end after the six loads, so the launch lives on the number of independent waves in
+// flight -- measured on the per-level form: four rows per 256-thread workgroup +50 % (a wave that runs the whole test holds
 // the slots of its three finished neighbours), a wave walking 8 rows +50 %.
 // Counted = what InitHist_Kernel (ProgramCU.cu:665-688) counts: rows 1 .. h-2, columns 1 .. w-2 with a non-zero key.
 __global__ __launch_bounds__(64) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                           const int* __restrict__ row2lvl, int* __restrict__ rowcnt,
+                                                           const int* __restrict__ orow2oct, int* __restrict__ rowcnt,
                                                            float dog_threshold0, float dog_threshold, float edge_threshold,
                                                            FrameStrides st) {
-  const int grow = blockIdx.y;
+  const int oct = orow2oct[2 * blockIdx.y], row = orow2oct[2 * blockIdx.y + 1];
   rowcnt += (size_t)blockIdx.z * st.rows;
-  const int lvl = row2lvl[grow];
-  const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.z);
-  if ((int)blockIdx.x * 64 >= L.w) return;
-  const int row = grow - L.row0;
+  const SiftExtractor::LevelDesc* __restrict__ lv = levels + oct * SiftExtractor::kDogLevels;
+  const SiftExtractor::LevelDesc L0 = level_of_frame(lv[0], st, blockIdx.z);
+  const int w = L0.w, h = L0.h;
+  if ((int)blockIdx.x * 64 >= w) return;
   const int col = blockIdx.x * 64 + threadIdx.x;
-  int8_t flag = 0;
-  if (col < L.w && row > 0 && col > 0 && row < L.h - 1 && col < L.w - 1) {
-    const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
-    flag = e.result > 0.f ? 1 : (e.result < 0.f ? -1 : 0);
+  const bool interior = col < w && row > 0 && col > 0 && row < h - 1 && col < w - 1;
+  const int index = row * w + col;
+  // G[1] .. G[6] at the pixel: level j's centre value is G[j + 2] - G[j + 1]
+  float c[SiftExtractor::kDogLevels + 1];
+#pragma unroll
+  for (int j = 0; j < SiftExtractor::kDogLevels; ++j) c[j] = interior ? (lv[j].g[1] + (size_t)blockIdx.z * st.planes)[index] : 0.f;
+  c[SiftExtractor::kDogLevels] =
+      interior ? (lv[SiftExtractor::kDogLevels - 1].g[2] + (size_t)blockIdx.z * st.planes)[index] : 0.f;
+#pragma unroll
+  for (int j = 0; j < SiftExtractor::kDogLevels; ++j) {
+    const SiftExtractor::LevelDesc L = level_of_frame(lv[j], st, blockIdx.z);
+    int8_t flag = 0;
+    if (interior && fabsf(c[j + 1] - c[j]) > dog_threshold0) {
+      const KeyEval e = key_eval(L.g, w, index, dog_threshold0, dog_threshold, edge_threshold);
+      flag = e.result > 0.f ? 1 : (e.result < 0.f ? -1 : 0);
+    }
+    if (col < w) L.flags[(size_t)row * w + col] = flag;
+    const uint64_t m = __ballot(flag != 0);
+    if (threadIdx.x == 0 && m) atomicAdd(&rowcnt[L.row0 + row], (int)__popcll(m));
   }
-  if (col < L.w) L.flags[(size_t)row * L.w + col] = flag;
-  const uint64_t m = __ballot(flag != 0);
-  if (threadIdx.x == 0 && m) atomicAdd(&rowcnt[grow], (int)__popcll(m));
 }
 
 // per level: exclusive scan of its rows' counts, the level's total
@@ -602,6 +617,8 @@ void SiftExtractor::release() {
   if (d_feat) (void)hipFree(d_feat);
   if (d_desc) (void)hipFree(d_desc);
   if (d_jobs) (void)hipFree(d_jobs);
+  if (d_orow2oct) (void)hipFree(d_orow2oct);
+  d_orow2oct = nullptr;
   if (h_counts) (void)hipHostFree(h_counts);
   if (h_stage) (void)hipHostFree(h_stage);
   if (h_gray) (void)hipHostFree(h_gray);
@@ -697,6 +714,14 @@ int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
   SIFT_HIP(hipMalloc((void**)&d_levels, sizeof(LevelDesc) * h_levels.size()));
   SIFT_HIP(hipMemcpy(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice));
   SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2 * F, row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
+  {  // (octave, row) of every row of the stacked octaves: the keypoint scan's launch walks it
+    std::vector<int> o2((size_t)total_rows / kDogLevels * 2);
+    size_t k = 0;
+    for (int i = 0; i < on; ++i)
+      for (int r = 0; r < oct[i].h; ++r) { o2[k++] = i; o2[k++] = r; }
+    SIFT_HIP(hipMalloc((void**)&d_orow2oct, sizeof(int) * o2.size()));
+    SIFT_HIP(hipMemcpy(d_orow2oct, o2.data(), sizeof(int) * o2.size(), hipMemcpyHostToDevice));
+  }
   cand_cap = std::max<size_t>((size_t)1 << 16, oct[0].plane / 16);
   SIFT_HIP(hipMalloc((void**)&d_cand, F * cand_cap * 6 * 4));
   feat_cap = cand_cap * 2;                      // per frame; the batch-wide lists are packed: F * feat_cap entries at most
@@ -771,8 +796,8 @@ int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int
   int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2 * frames_cap;
   st.rows = total_rows;
   SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
-  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, total_rows, NF), dim3(64),
-                     0, s, d_levels, d_row2lvl, d_rowcnt, tdog1, tdog, tedge, st);
+  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, total_rows / kDogLevels, NF), dim3(64),
+                     0, s, d_levels, d_orow2oct, d_rowcnt, tdog1, tdog, tedge, st);
   hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
   hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows, NF), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
                      d_cand, (int)cand_cap, tdog1, tdog, tedge, st);
