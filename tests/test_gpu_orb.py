@@ -313,6 +313,32 @@ def test_detect_describe_batch_nodes(devs, grid):
     a.close(); b.close()
 
 
+def test_detect_describe_batch_nodes_out_of_slots_leaves_a_usable_context():
+    """More frames with node ids than free node slots: the call fails with RGBDFE_ERR_CAPACITY part of the way through; the
+    context keeps working -- the nodes that were made can be matched and released, a later batch that fits succeeds."""
+    from rgbdslam_v2_amd.frontend import FrontEnd, RgbdfeError
+    seq = synth.make_image_sequence(n_frames=8, seed=43)
+    idx = synth.forth_and_back(16, 8)
+    grays = [seq["gray"][i] for i in idx]
+    depths = [seq["depth"][i] for i in idx]
+    masks = [np.where(seq["mask"][i] > 0, 255, 0).astype(np.uint8) for i in idx]
+    K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    fe = FrontEnd(device_id=0, max_nodes=10, max_keypoints=1024, max_pairs_per_batch=16)
+    fe.detector_configure(max_keypoints=600)
+    with pytest.raises(RgbdfeError):
+        fe.detect_describe_batch(grays, masks, depths, *K, node_ids=np.arange(16, dtype=np.int32))
+    made = [i for i in range(16) if fe.node_count(i) >= 0]      # rgbdfe_node_count: rows of a resident node, < 0 otherwise
+    assert len(made) <= 10
+    for i in made:
+        fe.release_node(i)
+    assert all(fe.node_count(i) < 0 for i in range(16))
+    out = fe.detect_describe_batch(grays[:8], masks[:8], depths[:8], *K, node_ids=np.arange(8, dtype=np.int32))
+    assert all(fe.node_count(i) == len(out[i][0]) for i in range(8)) and min(len(o[0]) for o in out) > 100
+    r = fe.match_pair_list([1, 2, 3], [0, 1, 2])
+    assert (r["id1"] >= 0).sum() >= 2
+    fe.close()
+
+
 def test_detect_describe_with_page_locked_images(frames):
     """rgbdfe_host_register: page-locked caller images are copied to the device directly (no staging copy); the outputs
     are those of the pageable path, and the buffers can be unregistered and reused afterwards."""
