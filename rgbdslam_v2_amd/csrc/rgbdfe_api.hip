@@ -238,7 +238,7 @@ struct rgbdfe_ctx {
   OrbWorkspace orb_super;  // rgbdfe_detect_describe_batch: up to 7 frames per launch chain (its own image sets)
   std::unique_ptr<TaskPool> detect_pool, stage_pool;  // its worker threads (created by the first batch call, kept)
   SiftExtractor sift2;          // rgbdfe_sift_detect_batch alternates between two extractors (two chunks in flight)
-  hipStream_t sift_stream2 = nullptr;
+  hipStream_t sift_stream1 = nullptr, sift_stream2 = nullptr;
   SiftExtractor sift;  // rgbdfe_sift_detect (sift_extract.hip)
   int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;
@@ -460,6 +460,17 @@ uint32_t launch_hamming(rgbdfe_ctx* ctx, const PairWork* d_work, uint32_t* d_key
 // Results land in d_out (device memory; nullptr = the lane's own staging buffer).
 // Returns the batch's ticket.  Caller holds the lock.
 // matcher: 0 = ORB (Hamming), 1 = SIFTGPU (u8 dot products on the MFMA), 2 = FLANN branch (exact L2 knn-2 + ratio test)
+// A stream that must run BESIDE the context's main stream gets another priority class: the runtime maps the streams of one
+// priority onto a small pool of hardware queues (4 by default), and two streams that land on the same queue execute one
+// after the other -- which two do depends on every stream the process created before (measured: the SIFT batch's second chunk
+// stream shared the main stream's queue in a process that had run the ORB batch before, 0.24 instead of 0.18 ms per frame).
+// Priority classes have their own queues.  which: -1 = the lowest, +1 = the highest priority the device offers.
+hipError_t create_side_stream(hipStream_t* s, int which) {
+  int lo = 0, hi = 0;   // hipDeviceGetStreamPriorityRange: numerically lower = higher priority
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, which > 0 ? hi : lo);
+}
+
 bool capture_stream_ready(rgbdfe_ctx* ctx) {
   if (ctx->capture_stream) return true;
   if (hipStreamCreateWithFlags(&ctx->capture_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->capture_stream = nullptr; }
@@ -773,6 +784,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
   if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
   if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
+  if (ctx->sift_stream1) (void)hipStreamDestroy(ctx->sift_stream1);
   if (ctx->sift_stream2) (void)hipStreamDestroy(ctx->sift_stream2);
   ctx->graphs.clear();
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
@@ -1464,8 +1476,13 @@ int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* c
   constexpr int B = SiftExtractor::kMaxBatch;
   const int32_t n_chunks = (n_frames + B - 1) / B;
   SiftExtractor* ex[2] = {&ctx->sift, &ctx->sift2};
-  if (n_chunks > 1 && !ctx->sift_stream2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->sift_stream2, hipStreamNonBlocking));
-  hipStream_t st[2] = {ctx->stream, ctx->sift_stream2 ? ctx->sift_stream2 : ctx->stream};
+  // (both chunk streams come from the high-priority class, created back to back: two queues of a pool nothing else in the
+  // process is likely to use -- see create_side_stream; equal priority, so neither chunk starves the other)
+  if (n_chunks > 1 && !ctx->sift_stream2) {
+    HIP_TRY(ctx, create_side_stream(&ctx->sift_stream1, +1));
+    HIP_TRY(ctx, create_side_stream(&ctx->sift_stream2, +1));
+  }
+  hipStream_t st[2] = {ctx->sift_stream1 ? ctx->sift_stream1 : ctx->stream, ctx->sift_stream2 ? ctx->sift_stream2 : ctx->stream};
   auto count_of = [&](int32_t c) { return std::min<int32_t>(B, n_frames - c * B); };
   if (n_chunks > 0) {
     const int rc = ex[0]->begin_batch(gray, count_of(0), rows, cols, st[0], err);
@@ -1849,8 +1866,8 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   if (rc == RGBDFE_OK) rc = orb.ensure_alt(err);
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
   if (!ctx->orb_upload_stream) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_compute_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, create_side_stream(&ctx->orb_upload_stream, -1));   // uploads + pyramids: behind everything else
+    HIP_TRY(ctx, create_side_stream(&ctx->orb_compute_stream, +1));  // descriptions: short, the host waits for them
     for (hipEvent_t& e : ctx->orb_upload_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : ctx->orb_describe_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -2182,8 +2199,8 @@ static int detect_describe_batch_frames(rgbdfe_ctx* ctx, int32_t n_frames, const
   if (rc == RGBDFE_OK) rc = orb.ensure_alt(err);
   if (rc != RGBDFE_OK) return fail(ctx, rc, err);
   if (!ctx->orb_upload_stream) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_upload_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->orb_compute_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, create_side_stream(&ctx->orb_upload_stream, -1));   // uploads + pyramids: behind everything else
+    HIP_TRY(ctx, create_side_stream(&ctx->orb_compute_stream, +1));  // descriptions: short, the host waits for them
     for (hipEvent_t& e : ctx->orb_upload_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : ctx->orb_describe_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
