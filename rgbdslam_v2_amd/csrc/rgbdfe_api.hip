@@ -141,6 +141,17 @@ class TaskPool {  // a few persistent worker threads for pure-CPU jobs
 
 }  // namespace
 
+// A stream that must run BESIDE the context's main stream gets another priority class: the runtime maps the streams of one
+// priority onto a small pool of hardware queues (4 by default), and two streams that land on the same queue execute one
+// after the other -- which two do depends on every stream the process created before (measured: the SIFT batch's second chunk
+// stream shared the main stream's queue in a process that had run the ORB batch before, 0.24 instead of 0.18 ms per frame).
+// Priority classes have their own queues.  which: -1 = the lowest, +1 = the highest priority the device offers.
+static hipError_t create_side_stream(hipStream_t* s, int which) {
+  int lo = 0, hi = 0;   // hipDeviceGetStreamPriorityRange: numerically lower = higher priority
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, which > 0 ? hi : lo);
+}
+
 struct rgbdfe_ctx {
   rgbdfe_config cfg{};
   std::mutex mu;
@@ -460,17 +471,6 @@ uint32_t launch_hamming(rgbdfe_ctx* ctx, const PairWork* d_work, uint32_t* d_key
 // Results land in d_out (device memory; nullptr = the lane's own staging buffer).
 // Returns the batch's ticket.  Caller holds the lock.
 // matcher: 0 = ORB (Hamming), 1 = SIFTGPU (u8 dot products on the MFMA), 2 = FLANN branch (exact L2 knn-2 + ratio test)
-// A stream that must run BESIDE the context's main stream gets another priority class: the runtime maps the streams of one
-// priority onto a small pool of hardware queues (4 by default), and two streams that land on the same queue execute one
-// after the other -- which two do depends on every stream the process created before (measured: the SIFT batch's second chunk
-// stream shared the main stream's queue in a process that had run the ORB batch before, 0.24 instead of 0.18 ms per frame).
-// Priority classes have their own queues.  which: -1 = the lowest, +1 = the highest priority the device offers.
-hipError_t create_side_stream(hipStream_t* s, int which) {
-  int lo = 0, hi = 0;   // hipDeviceGetStreamPriorityRange: numerically lower = higher priority
-  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, which > 0 ? hi : lo);
-}
-
 bool capture_stream_ready(rgbdfe_ctx* ctx) {
   if (ctx->capture_stream) return true;
   if (hipStreamCreateWithFlags(&ctx->capture_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->capture_stream = nullptr; }
