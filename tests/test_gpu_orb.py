@@ -54,6 +54,36 @@ def test_orb_detect_matches_oracle(fe, frames, thr, mask_kind):
         assert np.all(kp["octave"] == 0)
 
 
+@pytest.mark.parametrize("kind,thr", [("noise", 1), ("noise", 40), ("binary", 0), ("binary", 254), ("ramp", 2), ("flat", 0),
+                                      ("checker", 10)])
+def test_orb_detect_on_adversarial_images(fe, kind, thr):
+    """The fused FAST + NMS kernel and the LDS-patch measure kernel on images a camera never delivers: pure noise (a corner on
+    almost every pixel: tens of thousands of scored corners, the second read-back of a crowded pass), saturated 0 / 255
+    patterns (differences of +-255, thresholds at both ends of the range), ramps (long monotone arcs, score ties for the strict
+    3x3 maximum), a flat image (nothing), a checkerboard (corners exactly on the 64 x 16 tile seams of several levels)."""
+    rng = np.random.default_rng(9)
+    h, w = 240, 330                                       # not a multiple of the tile sizes
+    if kind == "noise":
+        g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "binary":
+        g = (rng.integers(0, 2, (h, w), dtype=np.uint8) * 255)
+    elif kind == "ramp":
+        g = ((np.arange(w)[None, :] * 3 + np.arange(h)[:, None] * 2) % 256).astype(np.uint8)
+    elif kind == "flat":
+        g = np.full((h, w), 77, np.uint8)
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        g = np.where(((xx // 16) + (yy // 16)) % 2 == 0, 40, 200).astype(np.uint8)
+    mask = np.where(rng.random((h, w)) < 0.9, 255, 0).astype(np.uint8) if kind in ("noise", "checker") else None
+    kp = fe.orb_detect(np.ascontiguousarray(g), mask, thr, capacity=200000)
+    ref = pyorb.detect(np.ascontiguousarray(g), mask, thr, cap=200000)
+    assert_kps_equal(kp, ref)
+    if kind == "flat":
+        assert len(kp) == 0
+    if kind == "noise" and thr == 1:
+        assert len(kp) > 2000
+
+
 @pytest.mark.parametrize("shape", [(480, 640), (231, 309), (64, 80)])
 def test_orb_detect_other_sizes(fe, frames, shape):
     g = np.ascontiguousarray(frames["gray"][1][: shape[0], : shape[1]])
