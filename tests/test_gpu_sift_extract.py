@@ -100,6 +100,44 @@ def test_against_the_compiled_reference(fe, w, h, maxf, seed):
     check_features(kp, desc, rkeys, rdesc)
 
 
+@pytest.mark.parametrize("kind", ["noise", "flat", "steps", "binary"])
+def test_adversarial_images_against_the_compiled_reference(fe, kind):
+    """Images a camera never delivers: pure noise (candidates everywhere: tens of thousands per level, the truncation by the
+    feature limit cuts whole octaves), a flat image (nothing anywhere), intensity steps (extrema on straight edges: the edge
+    ratio test), a 0 / 255 pattern (the largest gradients) -- planes and candidates bit for bit, features within the stated
+    tolerances."""
+    if po.ref_siftgpu_lib() is None:
+        pytest.skip("oracle/_ref/libref_siftgpu.so was not built (no reference tree when the snapshot was made)")
+    rng = np.random.default_rng(17)
+    h, w = 120, 164
+    if kind == "noise":
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "flat":
+        img = np.full((h, w), 131, np.uint8)
+    elif kind == "steps":
+        img = (((np.arange(w)[None, :] // 23) * 60 + (np.arange(h)[:, None] // 31) * 35) % 256).astype(np.uint8)
+    else:
+        img = (rng.integers(0, 2, (h // 4, w // 4), dtype=np.uint8).repeat(4, 0).repeat(4, 1) * 255)
+    img = np.ascontiguousarray(img)
+    maxf = 600
+    kp, desc = fe.sift_detect(img, None, maxf)
+    rkeys, rdesc, rcnt = po.ref_sift_detect(img, maxf)
+    geo = fe.sift_geometry()
+    assert geo == po.ref_sift_geometry()
+    for o in range(geo["octave_num"]):
+        for l in range(geo["levels"]):
+            a, b = fe.sift_debug_plane(o, l), po.ref_sift_level(o, l, 0)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), ("plane", o, l)
+        for j in range(geo["dog_levels"]):
+            a, b = fe.sift_debug_candidates(o, j), po.ref_sift_candidates(o, j)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), ("candidates", o, j)
+    check_features(kp, desc, rkeys, rdesc)
+    if kind == "flat":
+        assert len(kp) == 0
+    if kind == "noise":
+        assert len(kp) > 50          # the limit keeps the coarse octaves only (whole fine levels are dropped)
+
+
 def test_full_size_properties(fe):
     """BASELINE configs[3]'s frame size through size-independent properties: determinism, the feature-count limit's
     semantics (coarse octaves first, whole levels), keypoints inside the image, histogram descriptors non-negative."""
