@@ -15,6 +15,10 @@ struct KpOut {  // cv::KeyPoint fields in use
 
 struct OrbWorkspace {
   struct Cell { int x0, y0, w, h; };
+  // the read-back of one detection pass: per-image counts, their prefix, the scored corners
+  struct PassView { const int* totals = nullptr; const int* base = nullptr; const RawKp* raw = nullptr; };
+  // (see replay_counts)
+  struct Deferred { bool valid = false; PassView pv; std::vector<int> thr_final; };
   ~OrbWorkspace();
   void release();
   void reset_detector(int max_keypoints, int grid_res, int max_iters);
@@ -48,12 +52,13 @@ struct OrbWorkspace {
   int grid_detect(std::vector<KpOut>& kps, hipStream_t s, std::string& err);
   // super-frame workspace: the frames [0, nf) of the current image set in order (cell_mask_nonzero holds nf * grid^2 flags)
   int super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err,
-                   const std::vector<int>* covered_floors = nullptr);
+                   const std::vector<int>* covered_floors = nullptr, Deferred* deferred = nullptr);
   void compute_prepare(std::vector<KpOut>& kps, int frame, std::vector<int>& order, std::vector<DescKp>& dk) const;
   // software pipeline of the batch entry point: the device pass of super-frame s + 1 runs while the host replays the
   // adjuster over super-frame s -- a pass's outputs (counts + keypoints, device and pinned host side) exist twice
   int super_pass_enqueue(int nf, int set, int slot, hipStream_t s, std::string& err);
-  int super_replay(int nf, int set, int slot, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err);
+  int super_replay(int nf, int set, int slot, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err,
+                   Deferred* deferred = nullptr);
   void use_slot(int slot);
   static constexpr int kSets = 3;  // image sets / pass slots of the super-frame pipeline (kSets - 1 passes ahead of the replay)
   uint8_t* d_passout_slot[kSets] = {}; uint8_t* h_passout_slot[kSets] = {};
@@ -65,7 +70,14 @@ struct OrbWorkspace {
   // optional: runs fn(0) .. fn(n - 1) on several threads and returns when all are done (the batch entry point's worker
   // pool); the replay then runs the per-cell adjuster chains and the per-frame merges through it -- pure host code
   std::function<void(int, const std::function<void(int)>&)> parallel_for;
-  void select_cell(int c, int t, std::vector<KpOut>& out) const;   // select_pass for one cell at threshold t
+  PassView current_pass() const { PassView v; v.totals = h_totals; v.base = h_base; v.raw = pass_raw; return v; }
+  void select_cell(const PassView& pv, int c, int t, std::vector<KpOut>& out) const;   // select_pass for one cell at threshold t
+  // A super-frame whose one pass covers every frame is replayed from COUNTS: the adjuster only needs how many keypoints a
+  // cell would return at a threshold (replay_counts); the selections themselves -- select_cell at each cell's final
+  // threshold, keepStrongest, the aggregate -- are left to whoever prepares the frame's description (select_frame, any thread).
+  int replay_counts(int nf, const std::vector<int>& floors, const PassView& pv, std::vector<int>& thr_final);
+  void select_frame(const PassView& pv, int frame, const int* thr_final, std::vector<KpOut>& kps) const;
+  int count_cell(const PassView& pv, int c, int t, bool* capped) const;
   int replay_chains(int nf, const std::vector<int>& floors, std::vector<std::vector<KpOut>>& kps_per_frame);
   long replay_fallbacks = 0;  // super-frames whose replay needed another device pass (diagnostics)
   double super_floor_factor = 0.49;  // floor of a super-frame pass = threshold x this (two x0.7 steps)
@@ -122,6 +134,7 @@ struct OrbWorkspace {
   float* h_xyz_in = nullptr; float* h_xyz_out = nullptr; int32_t* h_n = nullptr;
   const RawKp* pass_raw = nullptr;   // the latest gpu_pass: its corners (h_raw or pass_raw_big) ...
   std::vector<RawKp> pass_raw_big;
+  std::vector<RawKp> pass_raw_big_slot[kSets];   // (per pass slot: a slot's corners are read until its frames are described)
   uint8_t* pool_set[kSets] = {}; uint8_t* blur_set[kSets] = {};
   uint8_t* himg_set[2] = {nullptr, nullptr};
   size_t blur_bytes = 0;

@@ -519,7 +519,34 @@ int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int
 // neighbour at the floor loses against the same neighbour at t when its own score is >= t (the neighbour's is larger
 // still).  So { corners at t } = { corners at f with score >= t }, in the same raster order; Harris response and angle
 // do not depend on the threshold.
-void OrbWorkspace::select_cell(int c, int thr_c, std::vector<KpOut>& out) const {
+static void per_level_caps(int* per_level) {  // nfeaturesPerLevel (orb.cpp computeKeyPoints)
+  const float factor = (float)(1.0 / (double)1.2f);
+  float nd = kDetectFeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)kLevels));
+  int sum = 0;
+  for (int l = 0; l < kLevels - 1; ++l) { per_level[l] = cv_round_f(nd); sum += per_level[l]; nd *= factor; }
+  per_level[kLevels - 1] = std::max(kDetectFeatures - sum, 0);
+}
+
+// How many keypoints select_cell(c, t) would return, without building them: per level the corners with score >= t -- exact as
+// long as no level reaches its retainBest cap (n <= nfeaturesPerLevel: neither retainBest(2n) nor retainBest(n) cuts, ties
+// included); *capped is set otherwise and the caller runs the selection itself.
+int OrbWorkspace::count_cell(const PassView& pv, int c, int thr_c, bool* capped) const {
+  int per_level[kLevels];
+  per_level_caps(per_level);
+  const int t = std::min(std::max(thr_c, 0), 255);
+  int found = 0;
+  for (int l = 0; l < kLevels; ++l) {
+    const int img = c * kLevels + l;
+    const RawKp* r = pv.raw + pv.base[img];
+    int n = 0;
+    for (int k = 0; k < pv.totals[img]; ++k) n += (int)r[k].score >= t ? 1 : 0;
+    if (n > per_level[l]) { *capped = true; return 0; }
+    found += n;
+  }
+  return found;
+}
+
+void OrbWorkspace::select_cell(const PassView& pv, int c, int thr_c, std::vector<KpOut>& out) const {
   // nfeaturesPerLevel (orb.cpp computeKeyPoints)
   int per_level[kLevels];
   {
@@ -529,9 +556,9 @@ void OrbWorkspace::select_cell(int c, int thr_c, std::vector<KpOut>& out) const 
     for (int l = 0; l < kLevels - 1; ++l) { per_level[l] = cv_round_f(nd); sum += per_level[l]; nd *= factor; }
     per_level[kLevels - 1] = std::max(kDetectFeatures - sum, 0);
   }
-  const int* totals = h_totals;
-  const int* base = h_base;
-  const RawKp* raw = pass_raw;
+  const int* totals = pv.totals;
+  const int* base = pv.base;
+  const RawKp* raw = pv.raw;
   out.clear();
   const int t = std::min(std::max(thr_c, 0), 255);  // the kernel's clamp
   float sc[kLevels]; int lw[kLevels], lh[kLevels];
@@ -555,8 +582,9 @@ void OrbWorkspace::select_cell(int c, int thr_c, std::vector<KpOut>& out) const 
 void OrbWorkspace::select_pass(const std::vector<int>& active, const std::vector<int>& thr,
                                std::vector<std::vector<KpOut>>& out) {
   const double tp0 = timing.on ? orb_now_us() : 0;
+  const PassView pv = current_pass();
   for (int c = 0; c < n_cells; ++c)
-    if (active[c]) select_cell(c, thr[c], out[c]);
+    if (active[c]) select_cell(pv, c, thr[c], out[c]);
   if (timing.on) timing.us[4] += orb_now_us() - tp0;
 }
 
@@ -675,7 +703,7 @@ int OrbWorkspace::super_pass_enqueue(int nf, int set, int slot, hipStream_t s, s
 // The host half: waits for the slot's pass, then replays the adjuster frame by frame exactly as super_detect does (see
 // there); re-passes (a threshold fell below its floor) run synchronously behind whatever the stream already holds.
 int OrbWorkspace::super_replay(int nf, int set, int slot, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s,
-                               std::string& err) {
+                               std::string& err, Deferred* deferred) {
   ORB_HIP(hipEventSynchronize(ev_pass[slot]));
   use_slot(slot);
   use_set(set);
@@ -688,12 +716,13 @@ int OrbWorkspace::super_replay(int nf, int set, int slot, std::vector<std::vecto
   if (n_total > slot_bound[slot]) {  // more corners than the speculative read-back: the rest in a second trip
     launch_orb_measure_rest(d_pool, d_cell_imgs, d_kps, d_img_total, n_imgs, slot_bound[slot], n_total - slot_bound[slot], s);
     ORB_HIP(hipGetLastError());
-    pass_raw_big.resize((size_t)n_total);
-    ORB_HIP(hipMemcpyAsync(pass_raw_big.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
+    std::vector<RawKp>& big = pass_raw_big_slot[slot];
+    big.resize((size_t)n_total);
+    ORB_HIP(hipMemcpyAsync(big.data(), d_kps, sizeof(RawKp) * (size_t)n_total, hipMemcpyDeviceToHost, s));
     ORB_HIP(hipStreamSynchronize(s));
-    pass_raw = pass_raw_big.data();
+    pass_raw = big.data();
   }
-  return super_detect(nf, kps_per_frame, s, err, &slot_floor[slot]);
+  return super_detect(nf, kps_per_frame, s, err, &slot_floor[slot], deferred);
 }
 
 // VideoGridAdaptedFeatureDetector::detect for the frames [0, nf) of a super-frame, IN ORDER: frame f + 1 starts from the
@@ -714,6 +743,7 @@ int OrbWorkspace::replay_chains(int nf, const std::vector<int>& floors, std::vec
   std::vector<std::vector<KpOut>> cellkp((size_t)nf * pc);
   std::vector<double> th_end((size_t)pc);
   std::vector<char> failed((size_t)pc, 0);
+  const PassView pv = current_pass();
   parallel_for(pc, [&](int c9) {
     double th = thresh[c9];
     for (int f = 0; f < nf && !failed[c9]; ++f) {
@@ -723,7 +753,7 @@ int OrbWorkspace::replay_chains(int nf, const std::vector<int>& floors, std::vec
       while (active) {
         const int t = (int)th;  // static_cast<int>(thresh_)
         if (t < floors[(size_t)c]) { failed[c9] = 1; break; }
-        select_cell(c, t, cellkp[(size_t)c]);
+        select_cell(pv, c, t, cellkp[(size_t)c]);
         const int found = (int)cellkp[(size_t)c].size();
         bool again = false;
         if (found < cell_min) {
@@ -768,10 +798,91 @@ int OrbWorkspace::replay_chains(int nf, const std::vector<int>& floors, std::vec
   return 1;
 }
 
-int OrbWorkspace::super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err,
-                               const std::vector<int>* covered_floors) {
+// The adjuster over the frames of a covered super-frame from counts alone (see orb_host.h): per grid cell the chain
+// "threshold -> keypoints found -> too few: x0.7 and again / too many: x1.3 for the next frame" (feature_adjuster.cpp:185-224)
+// needs `found` only, and found = the corners of the cell's 8 levels whose score is >= the threshold (count_cell; a level at
+// its retainBest cap falls back to the real selection).  thr_final[c] = the threshold of the LAST detection of (frame, cell)
+// c, the one whose keypoints the reference keeps.  Returns 0 -- nothing committed -- when a threshold falls below its floor.
+int OrbWorkspace::replay_counts(int nf, const std::vector<int>& floors, const PassView& pv, std::vector<int>& thr_final) {
   const int pc = grid * grid;
-  if (covered_floors && parallel_for) {
+  thr_final.assign((size_t)n_cells, 0);
+  std::vector<double> th_end((size_t)pc);
+  std::vector<KpOut> scratch;
+  for (int c9 = 0; c9 < pc; ++c9) {
+    double th = thresh[c9];
+    for (int f = 0; f < nf; ++f) {
+      const int c = f * pc + c9;
+      int iter_left = adjuster_iters;
+      bool checked = false, active = true;
+      while (active) {
+        const int t = (int)th;  // static_cast<int>(thresh_)
+        if (t < floors[(size_t)c]) return 0;
+        thr_final[(size_t)c] = t;
+        bool capped = false;
+        int found = count_cell(pv, c, t, &capped);
+        if (capped) { select_cell(pv, c, t, scratch); found = (int)scratch.size(); }
+        bool again = false;
+        if (found < cell_min) {
+          th *= 0.7;                                 // tooFew (:131-136)
+          if (th < 2) th = 2;
+          bool brk = false;
+          if (found == 0 && !checked) {
+            checked = true;
+            if (!cell_mask_nonzero[(size_t)c]) brk = true;  // hasNonZero(mask) (:205-209)
+          }
+          if (!brk) {
+            iter_left--;
+            again = iter_left > 0 && (th > 2 && th < 10000);  // good() (:147-150)
+          }
+        } else if (found > cell_max) {
+          th *= 1.3;                                 // tooMany (:138-143)
+          if (th > 10000) th = 10000;
+        }
+        active = again;
+      }
+    }
+    th_end[(size_t)c9] = th;
+  }
+  for (int c9 = 0; c9 < pc; ++c9) thresh[c9] = th_end[(size_t)c9];
+  return 1;
+}
+
+// VideoGridAdaptedFeatureDetector::detect's output for one frame of a super-frame, given each cell's final threshold:
+// the cell's keypoints at that threshold (select_cell), keepStrongest(maxPerCell) (:247-255), cell offsets added and the cells
+// appended in order (aggregateKeypointsPerGridCell, :259-282).  Reads the pass view only: runs on any thread.
+void OrbWorkspace::select_frame(const PassView& pv, int frame, const int* thr_final, std::vector<KpOut>& kps) const {
+  const int pc = grid * grid;
+  const int maxPerCell = max_total / pc;  // :292
+  kps.clear();
+  std::vector<KpOut> cell;
+  std::vector<KP> v;
+  for (int c9 = 0; c9 < pc; ++c9) {
+    const int c = frame * pc + c9;
+    select_cell(pv, c, thr_final[c], cell);
+    v.clear();
+    v.reserve(cell.size());
+    for (const KpOut& k : cell) v.push_back(KP{k.x, k.y, k.size, k.angle, k.response, k.octave, 0.f});
+    keep_strongest(v, maxPerCell, [](const KP& k) { return std::fabs(k.response); });
+    for (const KP& k : v) kps.push_back(KpOut{k.x + cells[c].x0, k.y + cells[c].y0, k.size, k.angle, k.response, k.octave});
+  }
+}
+
+int OrbWorkspace::super_detect(int nf, std::vector<std::vector<KpOut>>& kps_per_frame, hipStream_t s, std::string& err,
+                               const std::vector<int>* covered_floors, Deferred* deferred) {
+  const int pc = grid * grid;
+  if (deferred) deferred->valid = false;
+  if (covered_floors && deferred) {
+    const double tp0 = timing.on ? orb_now_us() : 0;
+    deferred->pv = current_pass();
+    const int done = replay_counts(nf, *covered_floors, deferred->pv, deferred->thr_final);
+    if (timing.on) timing.us[4] += orb_now_us() - tp0;
+    if (done) {
+      deferred->valid = true;
+      kps_per_frame.assign((size_t)nf, std::vector<KpOut>());
+      return RGBDFE_OK;
+    }
+    replay_fallbacks++;
+  } else if (covered_floors && parallel_for) {
     const double tp0 = timing.on ? orb_now_us() : 0;
     const int done = replay_chains(nf, *covered_floors, kps_per_frame);
     if (timing.on) timing.us[4] += orb_now_us() - tp0;

@@ -1800,6 +1800,9 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
 namespace {
 
 struct SuperFrameJob {  // one frame of a super-frame, between detection and copy-out
+  bool deferred = false;              // the frame's keypoints are still to be selected from the pass's corners (select_frame)
+  OrbWorkspace::PassView pv;
+  std::vector<int> thr;               // every (frame, cell)'s final threshold of the super-frame
   std::vector<KpOut> kps;
   std::vector<int> order;
   std::vector<DescKp> dk;
@@ -1812,6 +1815,7 @@ struct SuperFrameJob {  // one frame of a super-frame, between detection and cop
 void super_describe_prepare(const OrbWorkspace& orb, SuperFrameJob& j, int frame_in_super, const float* depth, int rows,
                             int cols, int max_kp) {
   std::vector<KpOut>& kps = j.kps;
+  if (j.deferred) orb.select_frame(j.pv, frame_in_super, j.thr.data(), kps);
   size_t m = 0;
   for (const KpOut& k : kps) {
     if (k.x >= (float)cols || k.x < 0 || k.y >= (float)rows || k.y < 0 || std::isnan(k.x) || std::isnan(k.y)) continue;
@@ -1924,7 +1928,11 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
       if (th.joinable()) th.join();
     }
   } helper_join{helper, m, cv, stop};
-  static const bool par_replay = !(getenv("RGBDFE_SUPER_PARALLEL_REPLAY") && atoi(getenv("RGBDFE_SUPER_PARALLEL_REPLAY")) == 0);
+  // how the host replays the adjuster over a super-frame's scored corners: 1 (default) from counts on the calling thread, the
+  // selections themselves inside the frames' description jobs; 2 = per-cell chains + per-frame merges on the worker pool
+  // while the calling thread waits; 0 = the sequential loop
+  static const int replay_mode = getenv("RGBDFE_SUPER_PARALLEL_REPLAY") ? atoi(getenv("RGBDFE_SUPER_PARALLEL_REPLAY")) : 1;
+  static const bool par_replay = replay_mode == 2;
   struct ParallelForGuard {  // the workspace outlives the pool
     OrbWorkspace& o;
     ~ParallelForGuard() { o.parallel_for = nullptr; }
@@ -2081,7 +2089,8 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     }
     lap(0);
     std::vector<std::vector<KpOut>> kps;
-    rc = orb.super_replay(nf, s % D, s % D, kps, ctx->stream, err);
+    OrbWorkspace::Deferred def;
+    rc = orb.super_replay(nf, s % D, s % D, kps, ctx->stream, err, replay_mode == 1 ? &def : nullptr);
     if (rc != RGBDFE_OK) break;
     {
       std::lock_guard<std::mutex> l(m);
@@ -2091,12 +2100,17 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     lap(1);
     if (s > 0) { rc = finish(s - 1); if (rc != RGBDFE_OK) break; }
     lap(4);
-    for (int k = 0; k < nf; ++k) jobs[s & 1][(size_t)k].kps.swap(kps[(size_t)k]);
+    for (int k = 0; k < nf; ++k) {
+      SuperFrameJob& j = jobs[s & 1][(size_t)k];
+      j.deferred = def.valid;
+      if (def.valid) { j.pv = def.pv; j.thr = def.thr_final; j.kps.clear(); }
+      else j.kps.swap(kps[(size_t)k]);
+    }
     start_prepare(s);
     lap(5);
   }
   if (tm) {
-    fprintf(stderr, "[rgbdfe super-frame timing] depth %d, parallel replay %d (sequential fallbacks: %ld); ", D, par_replay ? 1 : 0,
+    fprintf(stderr, "[rgbdfe super-frame timing] depth %d, replay mode %d (sequential fallbacks: %ld); ", D, replay_mode,
             orb.replay_fallbacks);
     fprintf(stderr, "[rgbdfe super-frame timing] %d frames in %d super-frames, %ld device passes; per frame (us): mask scan %.1f, "
             "replay incl. wait for its pass %.1f, describe enqueue %.1f, upload + next pass enqueue %.1f (re-passes: enqueue %.1f, "
