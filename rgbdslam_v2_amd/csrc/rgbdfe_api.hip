@@ -237,6 +237,7 @@ struct rgbdfe_ctx {
   int64_t graph_launches = 0, graph_captures = 0;
   bool use_graphs = true;  // RGBDFE_GRAPHS=0: plain stream launches
   hipStream_t capture_stream = nullptr;  // graphs are captured here, never on a stream other threads may wait on
+  long graph_capture_failures = 0;       // captures another thread's HIP call invalidated (the batch then ran as plain launches)
   uint8_t* upload_stage = nullptr; size_t upload_stage_bytes = 0;  // pinned staging of rgbdfe_upload_nodes
   hipEvent_t ev_in = nullptr;  // orders a caller's stream before a lane
   hipEvent_t nodes_ready = nullptr;  // recorded behind the latest rgbdfe_upload_node_device copies; every batch waits for it
@@ -581,13 +582,16 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
         (void)hipGetLastError();  // capture unavailable: plain launches
       }
     }
+    // (at most twice: a capture that another thread's HIP call invalidated -- relaxed mode keeps THEM from failing, but a
+    // device-wide synchronisation elsewhere in the process still breaks the capture -- is dropped and the batch issued plainly)
+    rgbdfe_ctx::Pending pend{};
+    pend.sift = sift;
+    for (int attempt = 0; attempt < 2; ++attempt) {
     hipStream_t const ls = capturing ? ctx->capture_stream : stream;   // where this batch's operations are issued
     if (!ge) {
       const hipError_t me = hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n, hipMemcpyHostToDevice, ls);
       if (me != hipSuccess && launch_err == hipSuccess) launch_err = me;
     }
-    rgbdfe_ctx::Pending pend{};
-    pend.sift = sift;
     if (ctx->profiling) {
       pend.a = get_event(ctx);
       pend.b = get_event(ctx);
@@ -650,15 +654,23 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
       rgbdfe_ctx::GraphEntry& e = ctx->graphs.back();
       hipError_t ce = hipStreamEndCapture(ctx->capture_stream, &e.graph);
       if (ce == hipSuccess) ce = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
-      if (ce == hipSuccess) {
+      if (ce == hipSuccess && launch_err == hipSuccess) {
         ctx->graph_captures++;
         ce = hipGraphLaunch(e.exec, stream);
         ctx->graph_launches++;
+        if (ce != hipSuccess) launch_err = ce;
       } else {
+        if (e.exec) (void)hipGraphExecDestroy(e.exec);
         if (e.graph) (void)hipGraphDestroy(e.graph);
         ctx->graphs.pop_back();
+        (void)hipGetLastError();
+        capturing = false;
+        launch_err = hipSuccess;
+        ctx->graph_capture_failures++;
+        continue;   // once more, plain launches on `stream`
       }
-      if (ce != hipSuccess && launch_err == hipSuccess) launch_err = ce;
+    }
+    break;
     }
     if (launch_err == hipSuccess) launch_err = hipGetLastError();
     if (ctx->profiling) {
