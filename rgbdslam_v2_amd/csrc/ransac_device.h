@@ -4,6 +4,7 @@
 // the reference's own compiled code): with -ffp-contract=off the results are bit-identical to the CPU restatement.
 #pragma once
 #include <float.h>
+#include <stddef.h>
 
 #include <type_traits>
 
@@ -399,7 +400,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, const uint64_t* w_nonzero, FitBuf& fit,
                                            int& n_below_256) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);  // (workgroups of several waves: ransac_split.hip)
   uint32_t base = 0;
   n_below_256 = 0;
 #pragma unroll
@@ -434,7 +435,7 @@ template <bool FAST_DIV>
 __device__ __forceinline__ void fit_recurrence(int n_mine, int k256_mine, int n_min, int n_max, const FitBuf& fit,
                                                const float* __restrict__ M, float& C, float& m1, float& m2) {
   constexpr int U = kFitUnroll;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);  // (workgroups of several waves: ransac_split.hip)
   const int sl = min(lane / 9, kSlots - 1);
   const int l9 = lane % 9;
   const int ci = l9 / 3, cj = l9 % 3;
@@ -569,6 +570,16 @@ __device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const 
     }
   }
   return may_pass;
+}
+
+// The class a pair is treated as from the second phase on.  WalkState::speculate: 0 = `it` has jumped ahead, 1 = no
+// jump and mostly valid hypotheses, 2 = no jump and junk-heavy.  Class 1 behaves like class 0 (phase by phase) unless the
+// batch has very few such pairs (walk[n_pairs].state counts them, < 1/64 of the batch): then keeping the third and fourth
+// phase's launches alive for a handful of long waves costs more than recording those pairs to the end like class 2.
+__device__ __forceinline__ int effective_class(const WalkState* __restrict__ walk, uint32_t pair, uint32_t n_pairs) {
+  const int c = walk[pair].speculate;
+  if (c != 1) return c;
+  return ((uint32_t)walk[n_pairs].state * 64u <= n_pairs) ? 2 : 0;
 }
 
 }  // namespace rgbdfe

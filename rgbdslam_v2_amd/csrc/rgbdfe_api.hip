@@ -418,7 +418,8 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     if (lane.d_recs) (void)hipFree(lane.d_recs);
     lane.d_recs = nullptr;
     lane.recs_capacity = 0;
-    if (hipMalloc((void**)&lane.d_recs, need_recs * (sizeof(IterRec) + sizeof(IterSum))) == hipSuccess)  // records + summaries
+    if (hipMalloc((void**)&lane.d_recs, need_recs * (sizeof(IterRec) + sizeof(IterSum)) +  // records + summaries
+                                            ransac_split_mask_bytes(need_recs, (size_t)ctx->cfg.max_pairs_per_batch)) == hipSuccess)  // + viable-iteration masks
       lane.recs_capacity = need_recs;
     else latency = false;
   }

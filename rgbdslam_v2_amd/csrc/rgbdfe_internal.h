@@ -114,6 +114,28 @@ struct RecordPlan {
                               // a refinement round's scorings, read back lane = slot by the sequential error sums)
 };
 size_t select_ransac_ec_region_bytes();
+// ransac_split.hip: the recording stage as a hypothesis kernel (lane = iteration) + a refinement kernel over the viable
+// iterations.  One plan per launch.
+struct SplitPlan {
+  IterRec* recs = nullptr;     // [pair][iteration]: the hypothesis kernel leaves a viable iteration's transform in rR / rt,
+                               // the refinement kernel the iteration's outcome
+  IterSum* sums = nullptr;     // [pair][iteration]
+  uint64_t* vmask = nullptr;   // [pair][vmask_words]: bit k of a pair = iteration k passed the pre-screen
+  WalkState* walk = nullptr;   // [pair] (+ the batch's class-1 counter)
+  const PairPrep* prep = nullptr;
+  int vmask_words = 0;
+  int phase_begin = 0, phase_end = 0;
+  int spec_end = 0;            // class-2 pairs record [phase_begin, spec_end), the others [phase_begin, phase_end)
+  int n_shares = 1;            // workgroup units per pair: the range in shares of share_iters iterations
+  int share_iters = 0;
+  int debug_flags = 0;         // bisecting aid: 1 = a wave serves only its own SVD requests, 2 = one wave per unit does all the work
+};
+void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
+void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
+int ransac_split_words_per_pair(int ransac_iterations);
+int ransac_split_waves_per_unit();
+// bytes of the per-pair iteration masks behind the records + summaries of a record buffer of `rec_capacity` records
+inline size_t ransac_split_mask_bytes(size_t rec_capacity, size_t max_pairs) { return (rec_capacity / 64 + 4 * max_pairs + 64) * 8; }
 // edges.hip: stable compaction of the accepted edges (id1 >= 0) of a shard
 void launch_compact_edges(const rgbdfe_match_result* in, uint32_t n, rgbdfe_match_result* out, int32_t* out_index,
                           int32_t index_scale, int32_t index_offset, int32_t* d_dst, int32_t* d_count, hipStream_t stream);

@@ -664,15 +664,6 @@ __global__ void rgbdfe_pad_kernel(int* p) {
 #endif
 
 
-// The class a pair is treated as from the second phase on.  WalkState::speculate: 0 = `it` has jumped ahead, 1 = no
-// jump and mostly valid hypotheses, 2 = no jump and junk-heavy.  Class 1 behaves like class 0 (phase by phase) unless the
-// batch has very few such pairs (walk[n_pairs].state counts them, < 1/64 of the batch): then keeping the third and fourth
-// phase's launches alive for a handful of long waves costs more than recording those pairs to the end like class 2.
-__device__ __forceinline__ int effective_class(const WalkState* __restrict__ walk, uint32_t pair, uint32_t n_pairs) {
-  const int c = walk[pair].speculate;
-  if (c != 1) return c;
-  return ((uint32_t)walk[n_pairs].state * 64u <= n_pairs) ? 2 : 0;
-}
 
 template <int MODE>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void select_ransac_kernel(
@@ -1276,24 +1267,37 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
       rn_l = su.rn;
       rerr_l = su.rerr;
     }
-    for (int g = 0; g < G; ++g) {
+    // Iterations whose refinement left refined_matches empty (:1171 fails) only count: `if (!(it < I)) break;
+    // real_iterations++; ++it` -- a run of them is taken in one step; only the others are looked at one by one.
+    const uint64_t with_matches = __ballot(lane < G && rn_l > 0);
+    for (int g = 0; g < G;) {
+      const uint64_t rest = with_matches >> g;
+      const int run = rest != 0ull ? (int)__builtin_ctzll(rest) : G - g;  // empty iterations before the next one with matches
+      if (run > 0) {
+        const int can = min(run, max(I - it, 0));  // (`it` may have jumped beyond ransac_iterations, :1186-1187)
+        real_iterations += can;            // :1139
+        it += can;
+        if (can < run) { done = true; break; }  // the next check of `it < ransac_iterations` fails (:1130)
+        g += run;
+        if (g >= G) break;
+      }
       if (!(it < I)) { done = true; break; }
       real_iterations++;  // :1139
       const int refined_n = __builtin_amdgcn_readlane(rn_l, g);
       const double refined_error = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rerr_l), g),
                                                     __builtin_amdgcn_readlane(__double2loint(rerr_l), g));
-      if (refined_n > 0) {  // :1171
-        valid_iterations++;
-        if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
-          rmse = (float)refined_error;  // :1182
-          best_idx = k0 + g;
-          best_n = refined_n;
-          if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
-          if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
-          if ((double)refined_n > (double)n_all * 0.8) { done = true; break; }  // :1188
-        }
+      // refined_n > 0 (:1171)
+      valid_iterations++;
+      if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
+        rmse = (float)refined_error;  // :1182
+        best_idx = k0 + g;
+        best_n = refined_n;
+        if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
+        if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
+        if ((double)refined_n > (double)n_all * 0.8) { done = true; break; }  // :1188
       }
       ++it;
+      ++g;
     }
   }
   if (lane == 0) {
@@ -1318,6 +1322,13 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
   }
 }
 
+// RGBDFE_RANSAC_SPLIT=0: the recording stage as one kernel (select_ransac_kernel<kRecord>: hypotheses, scoring, refits and
+// a per-wave SVD in one wave program) instead of ransac_split.hip's hypothesis + refinement kernels -- A/B runs only.
+static bool ransac_split_enabled() {
+  static const bool on = !(getenv("RGBDFE_RANSAC_SPLIT") && atoi(getenv("RGBDFE_RANSAC_SPLIT")) == 0);
+  return on;
+}
+
 // Record / replay schedule.  The iteration range is covered in `n_phases` phases ending at phase_ends[]: each phase
 // launches the recording waves (the phase in equal shares of at most chunk_iters iterations per wave; waves of finished
 // pairs and waves beyond a pair's remaining need return at once) and the walk (one small wave per pair), which either
@@ -1331,21 +1342,42 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
   int begin = 0;
   RecordPlan plan{};
   plan.recs = recs; plan.walk = walk; plan.prep = prep; plan.ec_pool = ec_pool;
-  plan.sums = reinterpret_cast<IterSum*>(recs + (size_t)n_pairs * (size_t)(rc.ransac_iterations > 0 ? rc.ransac_iterations : 0));
+  const size_t n_recs = (size_t)n_pairs * (size_t)(rc.ransac_iterations > 0 ? rc.ransac_iterations : 0);
+  plan.sums = reinterpret_cast<IterSum*>(recs + n_recs);
   plan.n_phases_total = n_phases;  // a single-phase plan (small batches: full speculation) always pre-screens
   (void)hipMemsetAsync(walk + n_pairs, 0, sizeof(WalkState), stream);  // walk[n_pairs].state: the batch's class-1 pairs
   const int I = rc.ransac_iterations;
+  const bool split = ransac_split_enabled();
+  SplitPlan sp{};
+  if (split) {
+    // every iteration's hypothesis + pre-screen, all pairs, one launch (lane = iteration); the phases below refine the
+    // viable ones
+    sp.recs = recs; sp.sums = plan.sums; sp.walk = walk; sp.prep = prep;
+    sp.vmask = reinterpret_cast<uint64_t*>(plan.sums + n_recs);
+    sp.vmask_words = ransac_split_words_per_pair(I);
+    static const int dbg = getenv("RGBDFE_SPLIT_DEBUG") ? atoi(getenv("RGBDFE_SPLIT_DEBUG")) : 0;  // bisecting aid
+    sp.debug_flags = dbg;
+    launch_ransac_hyp(work, n_pairs, rc, sp, stream);
+  }
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
-    // The second phase of a phased plan covers everything that is left (see the pair classes in select_ransac_kernel):
-    // sub-grid A in shares of chunk_iters, sub-grid B in shares of a whole hypothesis batch.  Waves that have nothing
-    // to do for their pair return at once.
+    // The second phase of a phased plan covers everything that is left for the pairs of class 2 (see replay_walk_kernel);
+    // units / waves that have nothing to do for their pair return at once.
 #ifdef RGBDFE_NO_SUBGRID_B  // diagnostics build
     const bool spec = false;
 #else
     const bool spec = n_phases > 2 && p == 1 && I > end;
 #endif
     const int cover = spec ? I : end;
+    if (split) {
+      // a unit (half a workgroup: 4 waves sharing the pair's match records) per share of 4 x chunk_iters iterations;
+      // throughput batches (chunk_iters >= 28: more than 1280 pairs) keep a pair's range in one unit
+      const int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * ransac_split_waves_per_unit();
+      sp.phase_begin = begin; sp.phase_end = end; sp.spec_end = cover;
+      sp.n_shares = cover > begin ? (cover - begin + share - 1) / share : 1;
+      sp.share_iters = cover > begin ? (cover - begin + sp.n_shares - 1) / sp.n_shares : share;
+      if (cover > begin) launch_ransac_refine(n_pairs, rc, sp, stream);
+    } else {
     // sub-grid A: the phase in ceil(length / chunk) equal shares (a short last wave would be the launch's straggler)
     const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
     plan.n_chunks = (uint32_t)n_chunks;
@@ -1360,6 +1392,7 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
       hipLaunchKernelGGL(select_ransac_kernel<kRecord>,
                          dim3(8u * ((n_pairs + 7u) / 8u) * (plan.n_chunks + plan.n_chunks_b)), dim3(kWave), 0, stream, work,
                          results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
+    }
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, plan.sums, walk, prep, n_pairs, rc, begin,
                        end, cover, (n_phases > 2 && p == 0) ? 1 : 0);
     begin = end;
