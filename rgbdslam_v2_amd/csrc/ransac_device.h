@@ -572,6 +572,14 @@ __device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const 
   return may_pass;
 }
 
+// a pair is "junk-heavy" (class 2 of the record / replay plan) when at most kClass2Num / kClass2Den of the first phase's
+// iterations produced a refined hypothesis
+#ifndef RGBDFE_CLASS2_NUM
+#define RGBDFE_CLASS2_NUM 9
+#define RGBDFE_CLASS2_DEN 14
+#endif
+constexpr int kClass2Num = RGBDFE_CLASS2_NUM, kClass2Den = RGBDFE_CLASS2_DEN;
+
 // The class a pair is treated as from the second phase on.  WalkState::speculate: 0 = `it` has jumped ahead, 1 = no
 // jump and mostly valid hypotheses, 2 = no jump and junk-heavy.  Class 1 behaves like class 0 (phase by phase) unless the
 // batch has very few such pairs (walk[n_pairs].state counts them, < 1/64 of the batch): then keeping the third and fourth

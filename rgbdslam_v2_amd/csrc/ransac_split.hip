@@ -36,6 +36,8 @@
 //                         operations in order).
 // Same bytes as the one-wave kernel (select_ransac_kernel<kWhole>): every float / double operation is the one
 // oracle/rgbd_oracle.c performs, in the same order (-ffp-contract=off), so every discrete RANSAC decision is the same.
+#include <vector>
+
 #include "ransac_device.h"
 
 namespace rgbdfe {
@@ -57,8 +59,30 @@ __device__ __forceinline__ void flag_store(int* p, int v) { __hip_atomic_store(p
 
 constexpr int kHypThreads = 256;
 
-constexpr int kUnitsPerWg = 2;    // (pair, share) units per workgroup
-constexpr int kWavesPerUnit = 4;  // waves that share a unit's match records
+// Optional phase timers of the refinement kernel (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase
+// summed over the waves of all launches since the last reset.  Never enabled in the product build.
+#ifdef RGBDFE_PROFILE_PHASES
+// one row per wave (26 atomics per wave on shared counters clog the memory pipeline of the very waves being measured)
+constexpr unsigned kSplitLogWaves = 1u << 18;
+__device__ unsigned long long g_split_log[kSplitLogWaves][26];
+__device__ unsigned int g_split_count;
+#define SP_DECL uint64_t sp_t0 = __builtin_readcyclecounter(); uint64_t sp[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SP_MARK(i) { const uint64_t sp_t1 = __builtin_readcyclecounter(); sp[i] += sp_t1 - sp_t0; sp_t0 = sp_t1; }
+#define SP_COUNT(i, v) { sp[i] += (uint64_t)(v); }
+#else
+#define SP_DECL
+#define SP_MARK(i)
+#define SP_COUNT(i, v)
+#endif
+
+#ifndef RGBDFE_SPLIT_UNITS
+#define RGBDFE_SPLIT_UNITS 2
+#endif
+#ifndef RGBDFE_SPLIT_WAVES
+#define RGBDFE_SPLIT_WAVES 4
+#endif
+constexpr int kUnitsPerWg = RGBDFE_SPLIT_UNITS;    // (pair, share) units per workgroup
+constexpr int kWavesPerUnit = RGBDFE_SPLIT_WAVES;  // waves that share a unit's match records
 constexpr int kSplitWaves = kUnitsPerWg * kWavesPerUnit;
 constexpr int kSplitThreads = kSplitWaves * kWave;
 constexpr int kSplitSlots = kSplitWaves * kSlots;  // slots of a workgroup: one lane each in the combined SVD
@@ -310,9 +334,22 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
     tfc_get_transformation(acc, hypR, hypt);
     // a NaN transform leaves the refinement loop at once (:1144); so does, after its first scoring, a hypothesis that
     // cannot reach `thr` candidates (:1154) -- with the same outcome: refined_matches stays empty (:1133-1134)
-    const bool viable = in_range && !has_nan12(hypR, hypt) && prescreen_may_pass(hypR, hypt, M, n_all, pmax, rc) >= thr;
+    const uint32_t may_pass = prescreen_may_pass(hypR, hypt, M, n_all, pmax, rc);
+    const bool viable = in_range && !has_nan12(hypR, hypt) && may_pass >= thr;
     const uint64_t vm = __ballot(viable);
     if (lane == 0) vm_pair[k >> 6] = vm;  // (k0 and the wave's first lane are multiples of 64)
+    if (k0 == 0 && tid < kWave && plan.preclass_iters > 0) {  // the first wave: the pair's class by the pre-screen alone
+      // junk-heavy for certain (at most 9 of the first 14 iterations can give a refined hypothesis) AND no sign of a
+      // hypothesis with more than half of the matches as inliers among them (the loop's early exits, :1186-1188): the
+      // largest candidate bound stays below 30 % of the matches.  Only a scheduling hint: the walk decides the outcome.
+      const int n14 = min(plan.preclass_iters, min(I, kWave));
+      uint32_t best = (lane < n14 && viable) ? may_pass : 0u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, d));
+      const int viable14 = __popcll(vm & (n14 >= 64 ? ~0ull : ((1ull << n14) - 1ull)));
+      if (lane == 0)
+        plan.preclass[pair] = (viable14 * kClass2Den <= n14 * kClass2Num && best * 10u <= (uint32_t)n_all * 3u) ? 2 : 0;
+    }
     if (viable) {
       IterRec& r = rec_pair[k];
 #pragma unroll
@@ -331,62 +368,80 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_refine_kernel(
     uint32_t n_pairs, const RansacConst rc, const SplitPlan plan) {
   __shared__ SplitLds lds;
+  SP_DECL
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int u = wave / kWavesPerUnit, wu = wave % kWavesPerUnit;
   WaveLds& wl = lds.w[wave];
   const int I = rc.ransac_iterations;
 
-  // ---- this wave's unit: a pair and a share of the launch's iteration range
+  // ---- this wave's unit: a pair and a share of the launch's iteration range.  Everything here is wave-uniform and kept
+  // in scalar registers (readfirstlane); the loads that only need the pair index are issued together.
   const uint32_t unit = blockIdx.x * (uint32_t)kUnitsPerWg + (uint32_t)u;
-  bool have = unit < n_pairs * (uint32_t)plan.n_shares;
-  const uint32_t pair = have ? unit / (uint32_t)plan.n_shares : 0u;
-  const int share = have ? (int)(unit % (uint32_t)plan.n_shares) : 0;
-  int k_begin = 0, k_end = 0;
-  if (have) {
-    // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
-    const int pair_state = plan.phase_begin == 0 ? I : plan.walk[pair].state;
-    if (pair_state < 0) {
-      have = false;
-    } else {
-      // class 2 (no jump of `it` so far, junk-heavy): everything that is left is recorded in this launch
-      const int cls = plan.phase_begin != 0 ? effective_class(plan.walk, pair, n_pairs) : 0;
-      const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, pair_state);
-      k_begin = plan.phase_begin + share * plan.share_iters;
-      k_end = min(k_begin + plan.share_iters, end);
-      have = k_begin < k_end;
-    }
-  }
+  const bool in_grid = unit < n_pairs * (uint32_t)plan.n_shares;
+  const uint32_t pair = in_grid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(unit / (uint32_t)plan.n_shares)) : 0u;
+  const int share = (int)(unit - pair * (uint32_t)plan.n_shares);
   const PairPrep* __restrict__ pp = plan.prep + pair;
-  const int n_all = have ? pp->n_all : 0;
+  const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
+  // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
+  const WalkState ws = plan.walk[pair];
+  const int batch_class1 = plan.walk[n_pairs].state;
+  const int n_all_ld = pp->n_all;
+  const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pp->pmax)));
+  const bool fast_alpha = __builtin_amdgcn_readfirstlane((int)pp->fast_alpha) != 0;
+  uint64_t w_nonzero[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) w_nonzero[r] = uniform_u64(pp->w_nonzero[r]);
+  // the first four words of the pair's viable-iteration mask from the range's first block on (256 iterations: the whole
+  // range of the default 200); later blocks are fetched when the scan reaches them
+  const int blk0 = (plan.phase_begin + share * plan.share_iters) >> 6;
+  uint64_t vw0 = 0ull, vw1 = 0ull, vw2 = 0ull, vw3 = 0ull;
+  if (blk0 + 0 < plan.vmask_words) vw0 = uniform_u64(vm_pair[blk0 + 0]);
+  if (blk0 + 1 < plan.vmask_words) vw1 = uniform_u64(vm_pair[blk0 + 1]);
+  if (blk0 + 2 < plan.vmask_words) vw2 = uniform_u64(vm_pair[blk0 + 2]);
+  if (blk0 + 3 < plan.vmask_words) vw3 = uniform_u64(vm_pair[blk0 + 3]);
+  bool have = in_grid;
+  int k_begin = 0, k_end = 0;
+  {
+    const int pair_state = plan.phase_begin == 0 ? I : __builtin_amdgcn_readfirstlane(ws.state);
+    // class 2 (no jump of `it` so far, junk-heavy; class 1 when the batch has few such pairs: effective_class): everything
+    // that is left is recorded in this launch
+    int cls = plan.phase_begin != 0 ? __builtin_amdgcn_readfirstlane(ws.speculate)
+                                    : (plan.first_spec ? __builtin_amdgcn_readfirstlane((int)plan.preclass[pair]) : 0);
+    if (cls == 1) cls = ((uint32_t)__builtin_amdgcn_readfirstlane(batch_class1) * 64u <= n_pairs) ? 2 : 0;
+    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, pair_state);
+    k_begin = plan.phase_begin + share * plan.share_iters;
+    k_end = min(k_begin + plan.share_iters, end);
+    have = have && pair_state >= 0 && k_begin < k_end;
+  }
+  const int n_all = have ? __builtin_amdgcn_readfirstlane(n_all_ld) : 0;
+  SP_MARK(17)
   have = have && (n_all > rc.min_matches && n_all >= 4);  // no RANSAC for this pair (node.cpp:1087, :1130)
 
-  // ---- prologue: the units' match records -> LDS, slot / mailbox state
-  if (have) {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(pp->M);
-    float4* __restrict__ dst = reinterpret_cast<float4*>(lds.M[u]);
-    for (int v = wu * kWave + lane; v < kMVec; v += kWavesPerUnit * kWave) dst[v] = src[v];
+  // ---- prologue: the unit's match records (into registers first: the loads fly while the first iterations are picked)
+  // ---- prologue: the unit's match records go global -> LDS directly (global_load_lds_dwordx4: 64 x 16 bytes per wave
+  // instruction, LDS destination = wave-uniform base + lane * 16); the loads fly while the first iterations are picked.
+  // (A unit without work reads its pair's records all the same: the loads do not wait for the pair's state.)
+  if (in_grid) {
+    const char* __restrict__ src = reinterpret_cast<const char*>(pp->M);
+    for (int i = wu; i < (kMVec + kWave - 1) / kWave; i += kWavesPerUnit) {
+      const int v = i * kWave + lane;
+      if (v < kMVec)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)v * 16),
+                                         (__attribute__((address_space(3))) void*)(lds.M[u] + i * (kWave * 4)), 16, 0, 0);
+    }
   }
   if (lane < kSlots) { wl.slot[lane].active = 0; wl.slot[lane].iter = -1; }
   if (wave == 0) {
     lds.req[lane] = 0;
     if (lane == 0) lds.lock = 0;
   }
-  __syncthreads();  // the only workgroup barrier: from here on the waves run on their own
-  if (!have) return;
-
   const float* __restrict__ M = lds.M[u];
-  const float pmax = pp->pmax;
-  const bool fast_alpha = pp->fast_alpha != 0u;
-  uint64_t w_nonzero[kRounds];
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) w_nonzero[r] = uniform_u64(pp->w_nonzero[r]);
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
-  const double max_dist_d = (double)rc.max_dist_m;
+  thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr);
   IterRec* __restrict__ rec_pair = plan.recs + (size_t)pair * (size_t)I;
   IterSum* __restrict__ sum_pair = plan.sums + (size_t)pair * (size_t)I;
-  const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
 
   // ---- the unit's viable iterations, in order; the k-th one belongs to wave k mod kWavesPerUnit
   int blk = (k_begin >> 6) - 1;
@@ -398,7 +453,8 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
         ++blk;
         const int lo = blk << 6;
         if (lo >= k_end) return -1;
-        uint64_t wv = uniform_u64(vm_pair[blk]);
+        const int rel = blk - blk0;
+        uint64_t wv = rel == 0 ? vw0 : (rel == 1 ? vw1 : (rel == 2 ? vw2 : (rel == 3 ? vw3 : uniform_u64(vm_pair[blk]))));
         if (k_begin > lo) wv &= ~0ull << (k_begin - lo);
         if (k_end - lo < 64) wv &= (1ull << (k_end - lo)) - 1ull;
         word = wv;
@@ -412,8 +468,8 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
     }
   };
 
-  for (;;) {
-    // ---- iterations that have left their refinement loop: the outcome record, the slot is free again
+  // iterations that have left their refinement loop: the outcome record, the slot is free again
+  auto close_finished = [&]() {
     if (lane < kSlots) {
       SlotB& sl = wl.slot[lane];
       if (sl.iter >= 0 && !sl.active) {
@@ -432,7 +488,11 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
       }
     }
     lsync();
-    // ---- free slots take the next viable iterations; their hypotheses are fetched together, 6 lanes (float2) each
+    SP_MARK(1)
+  };
+  // free slots take the next viable iterations; their hypotheses are fetched together, 6 lanes (float2) each.
+  // Returns whether any slot holds an iteration.
+  auto refill = [&]() -> bool {
     bool occupied = false;
     int n_open = 0, my_g = -1, my_k = 0;
     for (int g = 0; g < kSlots; ++g) {
@@ -447,9 +507,12 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
       }
       occupied |= it_g >= 0;
     }
-    if (!occupied) break;
+    SP_MARK(2)
+    SP_COUNT(12, n_open)
     if (my_g >= 0) {
-      const int e2 = lane % 6;
+      int lane_here = lane;
+      asm volatile("" : "+v"(lane_here));  // the load address is formed here, not carried through the rounds
+      const int e2 = lane_here % 6;
       SlotB& sl = wl.slot[my_g];
       const float2 v = reinterpret_cast<const float2*>(rec_pair[my_k].rR)[e2];  // rR[9], rt[3] are contiguous
       reinterpret_cast<float2*>(sl.R)[e2] = v;                                   // ... and so are R[9], t[3]
@@ -468,7 +531,24 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
         sl.iter = my_k;
       }
     }
+    return occupied;
+  };
+
+  lsync();
+  SP_MARK(18)
+  bool occupied = have ? refill() : false;
+  SP_MARK(19)
+  // the match records are in LDS behind the first hypotheses' loads; then the only workgroup barrier: from here on the
+  // waves run on their own
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SP_MARK(20)
+  __syncthreads();
+  SP_MARK(0)
+
+  for (; occupied; close_finished(), occupied = refill()) {
     lsync();
+    SP_MARK(3)
+    SP_COUNT(13, 1)
 
     // ================================ one pass of the refinement loop (:1140) for every active slot
     // ---- scorings (:1148), one after the other (lane = match), each followed by its error sum
@@ -493,8 +573,10 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
         sl.cn = n_inl;
         sl.csum = sum;
       }
+      SP_COUNT(14, 1)
     }
     lsync();
+    SP_MARK(4)
     // ---- the loop's bookkeeping (:1154-1166), lane = slot
     bool still = false;
     if (lane < kSlots) {
@@ -504,7 +586,9 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
         const uint32_t need = max(thr, (uint32_t)rn);
         // mean_error = 1e9 below 3 inliers (:1012-1014); a count below `need` is rejected by the count
         const double err_mine = !((uint32_t)n_inl < need || n_inl < 3) ? sqrt(sl.csum / (double)n_inl) : 1e9;  // :1016-1017
-        if (!((uint32_t)n_inl < thr || err_mine > max_dist_d)) {  // :1154
+        float max_dist_f = rc.max_dist_m;
+        asm volatile("" : "+v"(max_dist_f));  // (kept out of the loop-invariant registers: they are scarce)
+        if (!((uint32_t)n_inl < thr || err_mine > (double)max_dist_f)) {  // :1154
           if (n_inl >= rn && err_mine <= sl.rerr) {               // :1160
             still = (n_inl != rn);                                // :1166
 #pragma unroll
@@ -524,6 +608,7 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
     }
     const bool any_active = __ballot(still) != 0ull;
     lsync();
+    SP_MARK(5)
     if (!any_active) continue;
     // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side ...
     int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
@@ -540,13 +625,16 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
       n_min = min(n_min, n_g);
     }
     lsync();
+    SP_MARK(6)
     {
       float C, m1, m2;
       if (fast_alpha) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2);
       else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2);
       // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox
-      const int s = min(lane / 9, kSlots - 1), x = lane % 9;
-      if (lane < 9 * kSlots && wl.slot[s].active) {
+      int lane_here = lane;
+      asm volatile("" : "+v"(lane_here));  // the mailbox address is formed here, not carried through the round
+      const int s = min(lane_here / 9, kSlots - 1), x = lane_here % 9;
+      if (lane_here < 9 * kSlots && wl.slot[s].active) {
         float* __restrict__ in = lds.svd_in[wave * kSlots + s];
         in[x] = C;
         if (x < 3) in[9 + x] = m1;
@@ -554,6 +642,7 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
       }
     }
     lsync();
+    SP_MARK(7)
     // ---- ... then their 3x3 SVDs, combined over the workgroup: post the requests, then serve whatever is pending
     // (every wave's, this one's included) if no other wave is serving, else wait for the server
     const int my_req = wave * kSlots + min(lane, kSlots - 1);
@@ -566,6 +655,7 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
       if (lane == 0) got = atomicCAS(&lds.lock, 0, 1) == 0 ? 1 : 0;
       got = __builtin_amdgcn_readfirstlane(got);
       if (got) {
+        SP_MARK(8)
         asm volatile("" ::: "memory");
         const bool p = lane < kSplitSlots && flag_load(&lds.req[lane]) == 1 && (!(plan.debug_flags & 1) || lane / kSlots == wave);
         if (__ballot(p) != 0ull) {
@@ -591,15 +681,28 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
           }
           lsync();  // the transforms are in LDS before the flags say so
           if (p) flag_store(&lds.req[lane], 0);
+          SP_COUNT(11, __popcll(__ballot(p)))
         }
         lsync();
         if (lane == 0) atomicExch(&lds.lock, 0);
+        SP_COUNT(15, 1)
+        SP_MARK(9)
       } else {
         __builtin_amdgcn_s_sleep(2);
       }
     }
     asm volatile("" ::: "memory");
+    SP_MARK(8)
   }
+#ifdef RGBDFE_PROFILE_PHASES
+  SP_MARK(10)
+  if (lane == 0) {
+    const unsigned row = atomicAdd(&g_split_count, 1u) % kSplitLogWaves;
+    for (int i = 0; i < 24; ++i) g_split_log[row][i] = sp[i];
+    g_split_log[row][24] = 1ull;
+    g_split_log[row][25] = have ? 1ull : 0ull;
+  }
+#endif
 }
 
 void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan,
@@ -622,3 +725,24 @@ int ransac_split_words_per_pair(int ransac_iterations) {
 int ransac_split_waves_per_unit() { return kWavesPerUnit; }
 
 }  // namespace rgbdfe
+
+#ifdef RGBDFE_PROFILE_PHASES
+// diagnostics build only (librgbdfe_prof.so): wall cycles per phase summed over the refinement kernel's waves
+extern "C" int rgbdfe_debug_split_totals(unsigned long long* out32, int reset) {
+  if (out32) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_split_count), sizeof(n)) != hipSuccess) return -1;
+    if (n > rgbdfe::kSplitLogWaves) n = rgbdfe::kSplitLogWaves;
+    std::vector<unsigned long long> rows((size_t)n * 26);
+    if (n && hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(rgbdfe::g_split_log), rows.size() * 8) != hipSuccess) return -1;
+    for (int i = 0; i < 32; ++i) out32[i] = 0;
+    for (unsigned r = 0; r < n; ++r)
+      for (int i = 0; i < 26; ++i) out32[i] += rows[(size_t)r * 26 + i];
+  }
+  if (reset) {
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_count), &zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

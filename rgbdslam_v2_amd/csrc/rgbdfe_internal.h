@@ -128,6 +128,12 @@ struct SplitPlan {
   int spec_end = 0;            // class-2 pairs record [phase_begin, spec_end), the others [phase_begin, phase_end)
   int n_shares = 1;            // workgroup units per pair: the range in shares of share_iters iterations
   int share_iters = 0;
+  uint8_t* preclass = nullptr; // [pair]: 2 = at most 9 of the first 14 iterations passed the pre-screen ("junk-heavy" whatever
+                               // their refinement gives: such a pair will most likely run all its iterations) -- written by the
+                               // hypothesis kernel when preclass_iters > 0; the first refinement launch of a phased plan then
+                               // records ALL iterations of these pairs (first_spec) instead of the first phase only
+  int preclass_iters = 0;      // the first phase's length (14), 0 = no pre-classification
+  int first_spec = 0;          // this launch is the first phase of a phased plan: preclass-2 pairs record [0, spec_end)
   int debug_flags = 0;         // bisecting aid: 1 = a wave serves only its own SVD requests, 2 = one wave per unit does all the work
 };
 void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
@@ -135,7 +141,7 @@ void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPl
 int ransac_split_words_per_pair(int ransac_iterations);
 int ransac_split_waves_per_unit();
 // bytes of the per-pair iteration masks behind the records + summaries of a record buffer of `rec_capacity` records
-inline size_t ransac_split_mask_bytes(size_t rec_capacity, size_t max_pairs) { return (rec_capacity / 64 + 4 * max_pairs + 64) * 8; }
+inline size_t ransac_split_mask_bytes(size_t rec_capacity, size_t max_pairs) { return (rec_capacity / 64 + 5 * max_pairs + 64) * 8; }  // + 8 bytes per pair: preclass
 // edges.hip: stable compaction of the accepted edges (id1 >= 0) of a shard
 void launch_compact_edges(const rgbdfe_match_result* in, uint32_t n, rgbdfe_match_result* out, int32_t* out_index,
                           int32_t index_scale, int32_t index_offset, int32_t* d_dst, int32_t* d_count, hipStream_t stream);

@@ -483,13 +483,6 @@ __global__ __launch_bounds__(kSortThreads) void sift_sort_kernel(uint16_t* __res
 // kRecord + replay_walk_kernel + kReplay give the same result as kWhole (an iteration's refinement is a pure function of
 // its index, D1) with the refinement work of one pair spread over many waves.
 constexpr int kWhole = 0, kRecord = 1, kReplay = 2;
-// a pair is "junk-heavy" (class 2 of the record / replay plan) when at most kClass2Num / kClass2Den of the first phase's
-// iterations produced a refined hypothesis
-#ifndef RGBDFE_CLASS2_NUM
-#define RGBDFE_CLASS2_NUM 9
-#define RGBDFE_CLASS2_DEN 14
-#endif
-constexpr int kClass2Num = RGBDFE_CLASS2_NUM, kClass2Den = RGBDFE_CLASS2_DEN;
 
 // ---------------------------------------------------------------------------------
 // Once per pair, before any select+RANSAC wave: the <= max_matches strongest matches in the reference's order
@@ -1230,7 +1223,8 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uin
 __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __restrict__ sums, WalkState* __restrict__ walk,
                                                             const PairPrep* __restrict__ prep, uint32_t n_pairs,
                                                             const RansacConst rc, int phase_begin, int phase_end,
-                                                            int spec_end, int may_speculate) {
+                                                            int spec_end, int may_speculate,
+                                                            const uint8_t* __restrict__ preclass) {
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x;
@@ -1247,8 +1241,10 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
   }
   const int n_all = prep[pair].n_all;
   // the records of a speculating pair reach as far as its recording waves were allowed to go
-  const int recorded_end =
-      min((phase_begin != 0 && spec_end > phase_end && effective_class(walk, pair, n_pairs) == 2) ? spec_end : phase_end, ws.state);
+  // (first phase of a split plan: the pairs the hypothesis kernel has pre-classified junk-heavy were recorded to the end)
+  const bool to_spec_end = spec_end > phase_end && (phase_begin != 0 ? effective_class(walk, pair, n_pairs) == 2
+                                                                     : (preclass != nullptr && preclass[pair] == 2));
+  const int recorded_end = min(to_spec_end ? spec_end : phase_end, ws.state);
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
   const IterSum* __restrict__ sum_pair = sums + (size_t)pair * (size_t)(I > 0 ? I : 0);
@@ -1355,6 +1351,11 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     sp.recs = recs; sp.sums = plan.sums; sp.walk = walk; sp.prep = prep;
     sp.vmask = reinterpret_cast<uint64_t*>(plan.sums + n_recs);
     sp.vmask_words = ransac_split_words_per_pair(I);
+    sp.preclass = reinterpret_cast<uint8_t*>(sp.vmask + (size_t)n_pairs * (size_t)sp.vmask_words);
+    // phased plans: pairs the pre-screen alone shows to be junk-heavy skip the first phase's launch + walk and record
+    // everything at once (the classes only schedule the recording: the walk decides the outcome either way)
+    static const bool no_pre = getenv("RGBDFE_NO_PRECLASS") && atoi(getenv("RGBDFE_NO_PRECLASS")) != 0;  // A/B runs
+    sp.preclass_iters = (n_phases > 2 && !no_pre) ? phase_ends[0] : 0;
     static const int dbg = getenv("RGBDFE_SPLIT_DEBUG") ? atoi(getenv("RGBDFE_SPLIT_DEBUG")) : 0;  // bisecting aid
     sp.debug_flags = dbg;
     launch_ransac_hyp(work, n_pairs, rc, sp, stream);
@@ -1368,12 +1369,13 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
 #else
     const bool spec = n_phases > 2 && p == 1 && I > end;
 #endif
-    const int cover = spec ? I : end;
+    const bool first_spec = split && sp.preclass_iters > 0 && p == 0 && I > end;
+    const int cover = (spec || first_spec) ? I : end;
     if (split) {
       // a unit (half a workgroup: 4 waves sharing the pair's match records) per share of 4 x chunk_iters iterations;
       // throughput batches (chunk_iters >= 28: more than 1280 pairs) keep a pair's range in one unit
       const int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * ransac_split_waves_per_unit();
-      sp.phase_begin = begin; sp.phase_end = end; sp.spec_end = cover;
+      sp.phase_begin = begin; sp.phase_end = end; sp.spec_end = cover; sp.first_spec = first_spec ? 1 : 0;
       sp.n_shares = cover > begin ? (cover - begin + share - 1) / share : 1;
       sp.share_iters = cover > begin ? (cover - begin + sp.n_shares - 1) / sp.n_shares : share;
       if (cover > begin) launch_ransac_refine(n_pairs, rc, sp, stream);
@@ -1394,7 +1396,7 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
                          results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
     }
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, plan.sums, walk, prep, n_pairs, rc, begin,
-                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0);
+                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0, first_spec ? sp.preclass : (const uint8_t*)nullptr);
     begin = end;
   }
   plan.n_chunks = 1;
