@@ -399,8 +399,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 // operands: bit-identical to Tfc::add over the same matches.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int fit_compact(int s, const uint64_t* mask, const uint64_t* w_nonzero, FitBuf& fit,
-                                           int& n_below_256) {
-  const int lane = threadIdx.x & (kWave - 1);  // (workgroups of several waves: ransac_split.hip)
+                                           int& n_below_256, int lane) {
   uint32_t base = 0;
   n_below_256 = 0;
 #pragma unroll
@@ -433,9 +432,8 @@ __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 // most 320 of them).
 template <bool FAST_DIV>
 __device__ __forceinline__ void fit_recurrence(int n_mine, int k256_mine, int n_min, int n_max, const FitBuf& fit,
-                                               const float* __restrict__ M, float& C, float& m1, float& m2) {
+                                               const float* __restrict__ M, float& C, float& m1, float& m2, int lane) {
   constexpr int U = kFitUnroll;
-  const int lane = threadIdx.x & (kWave - 1);  // (workgroups of several waves: ransac_split.hip)
   const int sl = min(lane / 9, kSlots - 1);
   const int l9 = lane % 9;
   const int ci = l9 / 3, cj = l9 % 3;

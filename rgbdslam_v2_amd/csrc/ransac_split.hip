@@ -36,6 +36,9 @@
 //                         operations in order).
 // Same bytes as the one-wave kernel (select_ransac_kernel<kWhole>): every float / double operation is the one
 // oracle/rgbd_oracle.c performs, in the same order (-ffp-contract=off), so every discrete RANSAC decision is the same.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <vector>
 
 #include "ransac_device.h"
@@ -54,6 +57,12 @@ __device__ __forceinline__ void lsync() {
 
 // flags other waves of the workgroup poll: relaxed atomics on LDS (a plain ds_read / ds_write the compiler neither hoists
 // out of a polling loop nor drops); ordering against the data they guard comes from lsync()
+// a lane index (or anything derived from it) the compiler may not carry across this point: addresses formed from it are
+// recomputed where they are used instead of being hoisted to the top of the kernel and spilled
+__device__ __forceinline__ int fresh(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ int flag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void flag_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -66,7 +75,8 @@ constexpr int kHypThreads = 256;
 constexpr unsigned kSplitLogWaves = 1u << 18;
 __device__ unsigned long long g_split_log[kSplitLogWaves][26];
 __device__ unsigned int g_split_count;
-#define SP_DECL uint64_t sp_t0 = __builtin_readcyclecounter(); uint64_t sp[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned int g_dbg_reopened;  // iterations opened whose record was not a fresh hypothesis
+#define SP_DECL const uint64_t sp_rt0 = __builtin_amdgcn_s_memrealtime(); uint64_t sp_t0 = __builtin_readcyclecounter(); uint64_t sp[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define SP_MARK(i) { const uint64_t sp_t1 = __builtin_readcyclecounter(); sp[i] += sp_t1 - sp_t0; sp_t0 = sp_t1; }
 #define SP_COUNT(i, v) { sp[i] += (uint64_t)(v); }
 #else
@@ -75,26 +85,25 @@ __device__ unsigned int g_split_count;
 #define SP_COUNT(i, v)
 #endif
 
-#ifndef RGBDFE_SPLIT_UNITS
-#define RGBDFE_SPLIT_UNITS 2
-#endif
-#ifndef RGBDFE_SPLIT_WAVES
-#define RGBDFE_SPLIT_WAVES 4
-#endif
-constexpr int kUnitsPerWg = RGBDFE_SPLIT_UNITS;    // (pair, share) units per workgroup
-constexpr int kWavesPerUnit = RGBDFE_SPLIT_WAVES;  // waves that share a unit's match records
-constexpr int kSplitWaves = kUnitsPerWg * kWavesPerUnit;
-constexpr int kSplitThreads = kSplitWaves * kWave;
-constexpr int kSplitSlots = kSplitWaves * kSlots;  // slots of a workgroup: one lane each in the combined SVD
-static_assert(kSplitSlots <= kWave, "the combined SVD is lane = slot of the workgroup");
+constexpr int kStreamWaves = 8;                       // waves of a refinement workgroup
+constexpr int kStreamThreads = kStreamWaves * kWave;
+constexpr int kStreamSlots = kStreamWaves * kSlots;   // slots of a workgroup: one lane each in the combined SVD
+static_assert(kStreamSlots <= kWave, "the combined SVD is lane = slot of the workgroup");
+constexpr int kBufs = 3;                              // units (pair, iteration range) resident in a workgroup's LDS
+constexpr int kMaxShare = 512;                        // iterations of a unit at most (the host cuts longer ranges)
 constexpr int kMVec = RGBDFE_MAX_MATCHES * kRec / 4;  // float4s of a pair's match records
 
-// one RANSAC iteration in flight (see select_ransac.hip: Slot)
-struct SlotB {
+// one RANSAC iteration in flight (see select_ransac.hip: Slot), with the facts of its unit the scoring needs
+struct SlotS {
   float R[9], t[3];          // transform to score next (first the 4-point hypothesis, then the refits')
+  int n_all;                 // the unit's pair: selected matches,
+  uint32_t thr;              // inlier threshold (:1094-1098),
+  float pmax;                // largest |coordinate| of its points,
+  int fast;                  // every weight inside the window of the unscaled float division
   float rR[9], rt[3];        // refined_transformation (node.cpp:1137,1163)
-  uint64_t rmask[kRounds];   // refined_matches = the input of the next refit while the slot is active
+  uint64_t rmask[kRounds];   // refined_matches
   uint64_t cmask[kRounds];   // inlier set of the scoring of the current round
+  uint64_t fmask[kRounds];   // refined_matches without zero weights = the input of the next refit while the slot is active
   double rerr;               // refined_error
   double csum;               // sequential sum of the current scoring's inlier errors (node.cpp:1006)
   int rn;                    // refined_matches.size()
@@ -102,6 +111,8 @@ struct SlotB {
   int active;                // still inside the refinement loop (:1140-1169)
   int round;                 // refinement passes done
   int iter;                  // RANSAC iteration held by the slot, -1 = free
+  int buf;                   // LDS buffer of the slot's unit
+  uint32_t pair;             // the unit's pair
   int pad;
 };
 // scoring phase of a wave: candidates of pass 1, inlier bits, the inliers' errors in match order
@@ -117,16 +128,36 @@ struct alignas(16) WaveLds {
     ScoreB sc;
     FitBuf fit;
   } u;
-  SlotB slot[kSlots];
+  SlotS slot[kSlots];
 };
-struct alignas(16) SplitLds {
-  float M[kUnitsPerWg][RGBDFE_MAX_MATCHES * kRec];  // the units' match records (see PairPrep)
-  WaveLds w[kSplitWaves];
-  float svd_in[kSplitSlots][16];  // mailbox of the combined SVD: C[9], mean1[3], mean2[3] of a slot's refit
-  int req[kWave];                 // 1 = the slot's SVD is pending (accessed with relaxed workgroup atomics)
-  int lock;                       // 1 = a wave is serving the pending requests
+// a unit resident in LDS: its pair's facts and the viable iterations of its range, handed out in order
+constexpr int kUnitFree = 0, kUnitLoading = 1, kUnitReady = 2;
+struct UnitCtx {
+  int state;                 // kUnitFree / kUnitLoading (one wave is filling the buffer) / kUnitReady
+  int next;                  // iterations handed out so far (may run past n_items)
+  int done;                  // iterations whose refinement has ended; == n_items => the buffer is free again
+  int n_items;
+  uint32_t pair;
+  int n_all;
+  uint32_t thr;
+  float pmax;
+  int fast;
+  int pad[3];
+  uint64_t w_nonzero[kRounds];
+  uint16_t klist[kMaxShare];  // the viable iterations of the unit's range, ascending
 };
-static_assert(sizeof(SplitLds) <= 80 * 1024, "two workgroups per CU");
+struct alignas(16) StreamLds {
+  float M[kBufs][RGBDFE_MAX_MATCHES * kRec];  // the resident units' match records (see PairPrep)
+  WaveLds w[kStreamWaves];
+  float svd_in[kStreamSlots][16];  // mailbox of the combined SVD: C[9], mean1[3], mean2[3] of a slot's refit
+  UnitCtx ctx[kBufs];
+  int req[kWave];                  // 1 = the slot's SVD is pending (relaxed workgroup atomics)
+  int lock;                        // 1 = a wave is serving the pending requests
+  int qlock;                       // 1 = a wave is taking iterations / choosing a buffer to fill
+  int no_more_units;               // the launch's unit counter has run past the last unit
+  int pad;
+};
+static_assert(sizeof(StreamLds) <= 80 * 1024, "two workgroups per CU");
 
 // ---------------------------------------------------------------------------------
 // computeInliersAndError (node.cpp:968-1020) with errorFunction2 (misc.cpp:697-770) for one wave-uniform transform:
@@ -274,6 +305,10 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
   __shared__ __attribute__((aligned(16))) float M[RGBDFE_MAX_MATCHES * kRec];
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
+  // the batch's counters (walk[n_pairs]: class-1 pairs, the refinement launches' unit counters, "still running" flag)
+  // start at zero: done here, ahead of every kernel that uses them (a memset node captured into the batch's hipGraph
+  // was not reliably in effect when the graph was replayed)
+  if (pair == 0 && threadIdx.x < sizeof(WalkState) / 4) reinterpret_cast<uint32_t*>(plan.walk + n_pairs)[threadIdx.x] = 0u;
   const PairPrep* __restrict__ pp = plan.prep + pair;
   const int n_all = pp->n_all;
   // no RANSAC for this pair (node.cpp:1087, :1130)
@@ -356,6 +391,9 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
       for (int i = 0; i < 9; ++i) r.rR[i] = hypR[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) r.rt[i] = hypt[i];
+#ifdef RGBDFE_PROFILE_PHASES
+      r.rn = -77;  // diagnostics: "a hypothesis, not yet refined"
+#endif
     } else if (in_range) {
       sum_pair[k] = IterSum{1e6, 0, 0};
     }
@@ -363,117 +401,123 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 }
 
 // ---------------------------------------------------------------------------------
-// The refinement loops (node.cpp:1140-1169) of the viable iterations of [phase_begin, phase_end / spec_end).
+// The refinement loops (node.cpp:1140-1169) of the viable iterations of [phase_begin, phase_end / spec_end), streamed:
+// a workgroup takes units (pair, iteration range) off the launch's counter, keeps up to three of them resident in LDS and
+// its 8 waves take whatever viable iteration is next, of any resident unit.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_refine_kernel(
-    uint32_t n_pairs, const RansacConst rc, const SplitPlan plan) {
-  __shared__ SplitLds lds;
+__global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_refine_kernel(
+    uint32_t n_pairs, const RansacConst rc, const SplitPlan plan, uint32_t n_units) {
+  // a later phase of a batch whose pairs have all ended (the walk of the phase before found nobody still running)
+  if (plan.phase_index > 0 && plan.walk[n_pairs].best_n != plan.phase_index) return;
+  extern __shared__ __attribute__((aligned(16))) char stream_smem[];
+  StreamLds& lds = *reinterpret_cast<StreamLds*>(stream_smem);
   SP_DECL
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int u = wave / kWavesPerUnit, wu = wave % kWavesPerUnit;
   WaveLds& wl = lds.w[wave];
   const int I = rc.ransac_iterations;
 
-  // ---- this wave's unit: a pair and a share of the launch's iteration range.  Everything here is wave-uniform and kept
-  // in scalar registers (readfirstlane); the loads that only need the pair index are issued together.
-  const uint32_t unit = blockIdx.x * (uint32_t)kUnitsPerWg + (uint32_t)u;
-  const bool in_grid = unit < n_pairs * (uint32_t)plan.n_shares;
-  const uint32_t pair = in_grid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(unit / (uint32_t)plan.n_shares)) : 0u;
-  const int share = (int)(unit - pair * (uint32_t)plan.n_shares);
-  const PairPrep* __restrict__ pp = plan.prep + pair;
-  const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
-  // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
-  const WalkState ws = plan.walk[pair];
-  const int batch_class1 = plan.walk[n_pairs].state;
-  const int n_all_ld = pp->n_all;
-  const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pp->pmax)));
-  const bool fast_alpha = __builtin_amdgcn_readfirstlane((int)pp->fast_alpha) != 0;
-  uint64_t w_nonzero[kRounds];
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) w_nonzero[r] = uniform_u64(pp->w_nonzero[r]);
-  // the first four words of the pair's viable-iteration mask from the range's first block on (256 iterations: the whole
-  // range of the default 200); later blocks are fetched when the scan reaches them
-  const int blk0 = (plan.phase_begin + share * plan.share_iters) >> 6;
-  uint64_t vw0 = 0ull, vw1 = 0ull, vw2 = 0ull, vw3 = 0ull;
-  if (blk0 + 0 < plan.vmask_words) vw0 = uniform_u64(vm_pair[blk0 + 0]);
-  if (blk0 + 1 < plan.vmask_words) vw1 = uniform_u64(vm_pair[blk0 + 1]);
-  if (blk0 + 2 < plan.vmask_words) vw2 = uniform_u64(vm_pair[blk0 + 2]);
-  if (blk0 + 3 < plan.vmask_words) vw3 = uniform_u64(vm_pair[blk0 + 3]);
-  bool have = in_grid;
-  int k_begin = 0, k_end = 0;
-  {
-    const int pair_state = plan.phase_begin == 0 ? I : __builtin_amdgcn_readfirstlane(ws.state);
-    // class 2 (no jump of `it` so far, junk-heavy; class 1 when the batch has few such pairs: effective_class): everything
-    // that is left is recorded in this launch
-    int cls = plan.phase_begin != 0 ? __builtin_amdgcn_readfirstlane(ws.speculate)
-                                    : (plan.first_spec ? __builtin_amdgcn_readfirstlane((int)plan.preclass[pair]) : 0);
-    if (cls == 1) cls = ((uint32_t)__builtin_amdgcn_readfirstlane(batch_class1) * 64u <= n_pairs) ? 2 : 0;
-    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, pair_state);
-    k_begin = plan.phase_begin + share * plan.share_iters;
-    k_end = min(k_begin + plan.share_iters, end);
-    have = have && pair_state >= 0 && k_begin < k_end;
-  }
-  const int n_all = have ? __builtin_amdgcn_readfirstlane(n_all_ld) : 0;
-  SP_MARK(17)
-  have = have && (n_all > rc.min_matches && n_all >= 4);  // no RANSAC for this pair (node.cpp:1087, :1130)
-
-  // ---- prologue: the unit's match records (into registers first: the loads fly while the first iterations are picked)
-  // ---- prologue: the unit's match records go global -> LDS directly (global_load_lds_dwordx4: 64 x 16 bytes per wave
-  // instruction, LDS destination = wave-uniform base + lane * 16); the loads fly while the first iterations are picked.
-  // (A unit without work reads its pair's records all the same: the loads do not wait for the pair's state.)
-  if (in_grid) {
-    const char* __restrict__ src = reinterpret_cast<const char*>(pp->M);
-    for (int i = wu; i < (kMVec + kWave - 1) / kWave; i += kWavesPerUnit) {
-      const int v = i * kWave + lane;
-      if (v < kMVec)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)v * 16),
-                                         (__attribute__((address_space(3))) void*)(lds.M[u] + i * (kWave * 4)), 16, 0, 0);
-    }
-  }
   if (lane < kSlots) { wl.slot[lane].active = 0; wl.slot[lane].iter = -1; }
   if (wave == 0) {
     lds.req[lane] = 0;
-    if (lane == 0) lds.lock = 0;
-  }
-  const float* __restrict__ M = lds.M[u];
-  uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
-  if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
-  thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr);
-  IterRec* __restrict__ rec_pair = plan.recs + (size_t)pair * (size_t)I;
-  IterSum* __restrict__ sum_pair = plan.sums + (size_t)pair * (size_t)I;
-
-  // ---- the unit's viable iterations, in order; the k-th one belongs to wave k mod kWavesPerUnit
-  int blk = (k_begin >> 6) - 1;
-  uint64_t word = 0ull;
-  uint32_t rank = 0u;
-  auto next_item = [&]() -> int {
-    for (;;) {
-      if (word == 0ull) {
-        ++blk;
-        const int lo = blk << 6;
-        if (lo >= k_end) return -1;
-        const int rel = blk - blk0;
-        uint64_t wv = rel == 0 ? vw0 : (rel == 1 ? vw1 : (rel == 2 ? vw2 : (rel == 3 ? vw3 : uniform_u64(vm_pair[blk]))));
-        if (k_begin > lo) wv &= ~0ull << (k_begin - lo);
-        if (k_end - lo < 64) wv &= (1ull << (k_end - lo)) - 1ull;
-        word = wv;
-        continue;
-      }
-      const int b = (int)__builtin_ctzll(word);
-      word &= word - 1ull;
-      const bool mine = (plan.debug_flags & 2) ? wu == 0 : (rank % (uint32_t)kWavesPerUnit) == (uint32_t)wu;
-      ++rank;
-      if (mine) return (blk << 6) + b;
+    if (lane < kBufs) { lds.ctx[lane].state = kUnitFree; lds.ctx[lane].next = 0; lds.ctx[lane].done = 0; lds.ctx[lane].n_items = 0; }
+    if (lane == 0) {
+      lds.lock = 0;
+      lds.qlock = 0;
+      lds.no_more_units = 0;
     }
+  }
+  __syncthreads();  // the only workgroup barrier: from here on the waves run on their own
+  SP_MARK(0)
+
+  // ---- a unit -> LDS buffer b (one wave): the pair's facts, its match records (global -> LDS directly:
+  // global_load_lds_dwordx4, 64 x 16 bytes per instruction), the viable iterations of the unit's range as a list.
+  // Leaves the buffer ready, or free again when the unit has nothing to do in this launch.
+  auto load_unit = [&](int b, uint32_t unit) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    const uint32_t pair = unit / (uint32_t)plan.n_shares;
+    const int share = (int)(unit - pair * (uint32_t)plan.n_shares);
+    const PairPrep* __restrict__ pp = plan.prep + pair;
+    const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
+    UnitCtx& cx = lds.ctx[b];
+    auto load_records = [&]() {
+      const char* __restrict__ src = reinterpret_cast<const char*>(pp->M);
+      for (int i = 0; i < (kMVec + kWave - 1) / kWave; ++i) {
+        const int v = i * kWave + lane;
+        if (v < kMVec)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)v * 16),
+                                           (__attribute__((address_space(3))) void*)(lds.M[b] + i * (kWave * 4)), 16, 0, 0);
+      }
+    };
+    // the first launch of a batch: every pair is still running, the records need not wait for the pair's state
+    if (plan.phase_begin == 0) load_records();
+    // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
+    const WalkState ws = plan.walk[pair];
+    const int batch_class1 = plan.walk[n_pairs].state;
+    const int pre = plan.first_spec ? (int)plan.preclass[pair] : 0;
+    const int n_all = __builtin_amdgcn_readfirstlane(pp->n_all);
+    const float pmax = pp->pmax;
+    const uint32_t fast = pp->fast_alpha;
+    const uint64_t wnz = lane < kRounds ? pp->w_nonzero[lane] : 0ull;
+    const int k_first = plan.phase_begin + share * plan.share_iters;
+    const int blk0 = k_first >> 6;
+    const uint64_t wv_ld = (blk0 + lane < plan.vmask_words && lane <= kMaxShare / kWave) ? vm_pair[blk0 + lane] : 0ull;
+    const int pair_state = plan.phase_begin == 0 ? I : __builtin_amdgcn_readfirstlane(ws.state);
+    // class 2 (no jump of `it` so far, junk-heavy; class 1 when the batch has few such pairs: effective_class): everything
+    // that is left is recorded in this launch
+    int cls = plan.phase_begin != 0 ? __builtin_amdgcn_readfirstlane(ws.speculate) : __builtin_amdgcn_readfirstlane(pre);
+    if (cls == 1) cls = ((uint32_t)__builtin_amdgcn_readfirstlane(batch_class1) * 64u <= n_pairs) ? 2 : 0;
+    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, pair_state);
+    const int k_begin = k_first;
+    const int k_end = min(k_begin + plan.share_iters, end);
+    // no RANSAC for this pair (node.cpp:1087, :1130), or nothing of this range is needed (any more)
+    const bool have = pair_state >= 0 && k_begin < k_end && n_all > rc.min_matches && n_all >= 4;
+    int total = 0;
+    if (have) {
+      if (plan.phase_begin != 0) load_records();
+      // lane w holds word blk0 + w of the pair's mask, cut to the range; lane = iteration builds the list
+      uint64_t wv = wv_ld;
+      {
+        const int lo = (blk0 + lane) << 6;
+        if (k_begin > lo) wv &= (k_begin - lo >= 64) ? 0ull : (~0ull << (k_begin - lo));
+        if (k_end - lo < 64) wv &= (k_end - lo <= 0) ? 0ull : ((1ull << (k_end - lo)) - 1ull);
+      }
+      const int n_words = ((k_end - 1) >> 6) - blk0 + 1;  // <= kMaxShare / 64 + 1
+      for (int c = 0; c < n_words; ++c) {
+        const uint64_t wc = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), c) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wv, c);
+        if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)(((blk0 + c) << 6) + lane);
+        total += __popcll(wc);
+      }
+      uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
+      if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
+      if (lane < kRounds) cx.w_nonzero[lane] = wnz;
+      if (lane == 0) {
+        cx.pair = pair;
+        cx.n_all = n_all;
+        cx.thr = thr;
+        cx.pmax = pmax;
+        cx.fast = (int)fast;
+        cx.n_items = total;
+        cx.next = 0;
+        cx.done = 0;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the match records are in LDS
+    lsync();
+    if (lane == 0) flag_store(&cx.state, total > 0 ? kUnitReady : kUnitFree);
+    SP_COUNT(21, 1)
   };
 
-  // iterations that have left their refinement loop: the outcome record, the slot is free again
+  // ---- iterations that have left their refinement loop: the outcome record; the slot is free again, and so is the
+  // unit's buffer once all its iterations have ended
   auto close_finished = [&]() {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
     if (lane < kSlots) {
-      SlotB& sl = wl.slot[lane];
+      SlotS& sl = wl.slot[lane];
       if (sl.iter >= 0 && !sl.active) {
-        IterRec& r = rec_pair[sl.iter];
+        const size_t at = (size_t)sl.pair * (size_t)I + (size_t)sl.iter;
+        IterRec& r = plan.recs[at];
 #pragma unroll
         for (int i = 0; i < 9; ++i) r.rR[i] = sl.rR[i];
 #pragma unroll
@@ -483,39 +527,102 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
         r.rerr = sl.rerr;
         r.rn = sl.rn;
         r.pad = 0;
-        sum_pair[sl.iter] = IterSum{sl.rerr, sl.rn, 0};
+        plan.sums[at] = IterSum{sl.rerr, sl.rn, 0};
         sl.iter = -1;
+        UnitCtx& cx = lds.ctx[sl.buf];
+        const int n_items = cx.n_items;  // (read before the count: once the last iteration is counted the buffer may be refilled)
+        if (atomicAdd(&cx.done, 1) + 1 == n_items) flag_store(&cx.state, kUnitFree);
       }
     }
     lsync();
     SP_MARK(1)
   };
-  // free slots take the next viable iterations; their hypotheses are fetched together, 6 lanes (float2) each.
-  // Returns whether any slot holds an iteration.
+
+  // ---- free slots take the next viable iterations of the resident units (any unit: a slot carries its unit's facts);
+  // a wave that finds nothing to take brings the workgroup's next unit in.  Returns false when the wave holds no
+  // iteration and none will come.
   auto refill = [&]() -> bool {
-    bool occupied = false;
-    int n_open = 0, my_g = -1, my_k = 0;
-    for (int g = 0; g < kSlots; ++g) {
-      int it_g = __builtin_amdgcn_readfirstlane(wl.slot[g].iter);
-      if (it_g < 0) {
-        const int k = next_item();
-        if (k >= 0) {
-          if (lane / 6 == n_open) { my_g = g; my_k = k; }
-          ++n_open;
-          it_g = k;
-        }
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    uint64_t free_slots = __ballot(lane < kSlots && wl.slot[min(lane, kSlots - 1)].iter < 0);
+    const int n_free = __popcll(free_slots);
+    const bool had = n_free < kSlots;
+    int got = 0;
+    int my_g = -1, my_at = 0, my_b = 0;  // lanes 6j .. 6j+5: the j-th slot opened by this call
+    while (got < n_free) {
+      // The hand-out of iterations and the choice of a buffer to fill happen under the workgroup's queue lock: a unit
+      // with iterations left cannot be recycled, so what a wave sees inside the lock is what it takes.  (Lock-free
+      // claims on `next` could land on a buffer that had been drained, freed and refilled in between.)
+      int locked = 0;
+      do {
+        if (lane == 0) locked = atomicCAS(&lds.qlock, 0, 1) == 0 ? 1 : 0;
+        locked = __builtin_amdgcn_readfirstlane(locked);
+        if (!locked) __builtin_amdgcn_s_sleep(1);
+      } while (!locked);
+      asm volatile("" ::: "memory");
+      int st = kUnitLoading, nx = 0, ni = 0;
+      if (lane < kBufs) {
+        st = flag_load(&lds.ctx[lane].state);
+        nx = flag_load(&lds.ctx[lane].next);
+        ni = flag_load(&lds.ctx[lane].n_items);
       }
-      occupied |= it_g >= 0;
+      const uint64_t avail = __ballot(lane < kBufs && st == kUnitReady && nx < ni);
+      const bool units_left = flag_load(&lds.no_more_units) == 0;
+      const uint64_t free_bufs = __ballot(lane < kBufs && st == kUnitFree);
+      const uint64_t loading = __ballot(lane < kBufs && st == kUnitLoading);
+      int b = -1, idx = 0, cnt = 0;
+      bool fill = false;
+      if (avail != 0ull) {
+        b = (int)__builtin_ctzll(avail);
+        idx = __builtin_amdgcn_readlane(nx, b);
+        cnt = min(n_free - got, __builtin_amdgcn_readlane(ni, b) - idx);
+        if (lane == 0) flag_store(&lds.ctx[b].next, idx + cnt);
+      } else if (units_left && free_bufs != 0ull) {
+        b = (int)__builtin_ctzll(free_bufs);
+        fill = true;
+        if (lane == 0) flag_store(&lds.ctx[b].state, kUnitLoading);
+      }
+      lsync();
+      if (lane == 0) atomicExch(&lds.qlock, 0);
+      if (cnt > 0) {
+        for (int j = 0; j < cnt; ++j) {
+          const int g = (int)__builtin_ctzll(free_slots);
+          free_slots &= free_slots - 1ull;
+          if (lane / 6 == got + j) { my_g = g; my_at = idx + j; my_b = b; }
+        }
+        got += cnt;
+        continue;
+      }
+      if (fill) {
+        // the launch's units are handed out one by one, to whichever workgroup has a buffer free (pairs differ a lot in
+        // their work, neighbours alike: equal shares of the pair list would leave half the chip waiting for the rest)
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(plan.unit_counter, 1u);
+        unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+        if (unit < n_units) {
+          load_unit(b, unit);
+        } else if (lane == 0) {
+          flag_store(&lds.no_more_units, 1);
+          flag_store(&lds.ctx[b].state, kUnitFree);
+        }
+        continue;
+      }
+      if (!units_left && loading == 0ull) break;  // nothing more will come
+      if (had || got > 0) break;                  // this wave has work: it looks again after the round
+      __builtin_amdgcn_s_sleep(4);                // idle: a loader is at work, or every buffer is still in use
     }
     SP_MARK(2)
-    SP_COUNT(12, n_open)
+    SP_COUNT(12, got)
     if (my_g >= 0) {
-      int lane_here = lane;
-      asm volatile("" : "+v"(lane_here));  // the load address is formed here, not carried through the rounds
-      const int e2 = lane_here % 6;
-      SlotB& sl = wl.slot[my_g];
-      const float2 v = reinterpret_cast<const float2*>(rec_pair[my_k].rR)[e2];  // rR[9], rt[3] are contiguous
-      reinterpret_cast<float2*>(sl.R)[e2] = v;                                   // ... and so are R[9], t[3]
+      const int e2 = lane % 6;
+      const UnitCtx& cx = lds.ctx[my_b];
+      SlotS& sl = wl.slot[my_g];
+      const int k = (int)cx.klist[my_at];
+      const uint32_t pair = cx.pair;
+      const float2 v = reinterpret_cast<const float2*>(plan.recs[(size_t)pair * (size_t)I + (size_t)k].rR)[e2];  // rR[9], rt[3]
+      reinterpret_cast<float2*>(sl.R)[e2] = v;                                                                  // -> R[9], t[3]
+#ifdef RGBDFE_PROFILE_PHASES
+      if (e2 == 0 && plan.recs[(size_t)pair * (size_t)I + (size_t)k].rn != -77) atomicAdd(&g_dbg_reopened, 1u);
+#endif
       if (e2 == 0) {
         const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 #pragma unroll
@@ -523,43 +630,43 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int i = 0; i < 3; ++i) sl.rt[i] = 0.f;
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) sl.rmask[r] = 0ull;
+        for (int r = 0; r < kRounds; ++r) { sl.rmask[r] = 0ull; sl.fmask[r] = 0ull; }
         sl.rerr = 1e6;  // :1133
         sl.rn = 0;      // :1134
         sl.active = 1;
         sl.round = 0;
-        sl.iter = my_k;
+        sl.iter = k;
+        sl.buf = my_b;
+        sl.pair = pair;
+        sl.n_all = cx.n_all;
+        sl.thr = cx.thr;
+        sl.pmax = cx.pmax;
+        sl.fast = cx.fast;
       }
     }
-    return occupied;
-  };
-
-  lsync();
-  SP_MARK(18)
-  bool occupied = have ? refill() : false;
-  SP_MARK(19)
-  // the match records are in LDS behind the first hypotheses' loads; then the only workgroup barrier: from here on the
-  // waves run on their own
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  SP_MARK(20)
-  __syncthreads();
-  SP_MARK(0)
-
-  for (; occupied; close_finished(), occupied = refill()) {
     lsync();
     SP_MARK(3)
-    SP_COUNT(13, 1)
+    return had || got > 0;
+  };
 
+  for (bool occupied = refill(); occupied; close_finished(), occupied = refill()) {
+    SP_COUNT(13, 1)
     // ================================ one pass of the refinement loop (:1140) for every active slot
     // ---- scorings (:1148), one after the other (lane = match), each followed by its error sum
-    for (int g = 0; g < kSlots; ++g) {
-      SlotB& sl = wl.slot[g];
-      if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
+    uint64_t act = __ballot(lane < kSlots && wl.slot[min(lane, kSlots - 1)].active != 0);
+    while (act != 0ull) {
+      const int g = (int)__builtin_ctzll(act);
+      act &= act - 1ull;
+      SlotS& sl = wl.slot[g];
       float curR[9], curt[3];
 #pragma unroll
       for (int i = 0; i < 9; ++i) curR[i] = sl.R[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) curt[i] = sl.t[i];
+      const int n_all = __builtin_amdgcn_readfirstlane(sl.n_all);
+      const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.thr);
+      const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.pmax)));
+      const float* __restrict__ M = lds.M[__builtin_amdgcn_readfirstlane(sl.buf)];
       // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever its error
       // is (:1154, :1160): the scorer may stop counting as soon as that is certain
       const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
@@ -579,10 +686,11 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
     SP_MARK(4)
     // ---- the loop's bookkeeping (:1154-1166), lane = slot
     bool still = false;
-    if (lane < kSlots) {
-      SlotB& sl = wl.slot[lane];
+    if (fresh(lane) < kSlots) {
+      SlotS& sl = wl.slot[fresh(lane)];
       if (sl.active) {
         const int n_inl = sl.cn, rn = sl.rn;
+        const uint32_t thr = sl.thr;
         const uint32_t need = max(thr, (uint32_t)rn);
         // mean_error = 1e9 below 3 inliers (:1012-1014); a count below `need` is rejected by the count
         const double err_mine = !((uint32_t)n_inl < need || n_inl < 3) ? sqrt(sl.csum / (double)n_inl) : 1e9;  // :1016-1017
@@ -591,12 +699,18 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
         if (!((uint32_t)n_inl < thr || err_mine > (double)max_dist_f)) {  // :1154
           if (n_inl >= rn && err_mine <= sl.rerr) {               // :1160
             still = (n_inl != rn);                                // :1166
+            const UnitCtx& cx = lds.ctx[sl.buf];
 #pragma unroll
             for (int i = 0; i < 9; ++i) sl.rR[i] = sl.R[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) sl.rt[i] = sl.t[i];
 #pragma unroll
-            for (int r = 0; r < kRounds; ++r) sl.rmask[r] = sl.cmask[r];
+            for (int r = 0; r < kRounds; ++r) {
+              const uint64_t m = sl.cmask[r];
+              sl.rmask[r] = m;
+              // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
+              sl.fmask[r] = m & cx.w_nonzero[r];
+            }
             sl.rn = n_inl;
             sl.rerr = err_mine;
           }
@@ -606,35 +720,42 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
         sl.active = still ? 1 : 0;
       }
     }
-    const bool any_active = __ballot(still) != 0ull;
+    uint64_t refit = __ballot(still);
     lsync();
     SP_MARK(5)
-    if (!any_active) continue;
+    if (refit == 0ull) continue;
     // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side ...
+    // (the unscaled division of the recurrence needs every slot's pair inside its window)
+    const bool all_fast = __ballot(still && wl.slot[min(lane, kSlots - 1)].fast == 0) == 0ull;
     int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
-    for (int g = 0; g < kSlots; ++g) {
-      SlotB& sl = wl.slot[g];
-      if (__builtin_amdgcn_readfirstlane(sl.active) == 0) continue;
-      uint64_t m5[kRounds];
+    {
+      const uint64_t ones[kRounds] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+      uint64_t todo = refit;
+      while (todo != 0ull) {
+        const int g = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        SlotS& sl = wl.slot[g];
+        uint64_t m5[kRounds];
 #pragma unroll
-      for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.rmask[r]);
-      int k256_g;
-      const int n_g = fit_compact(g, m5, w_nonzero, wl.u.fit, k256_g);
-      if (lane / 9 == g) { n_mine = n_g; k256_mine = k256_g; }
-      n_max = max(n_max, n_g);
-      n_min = min(n_min, n_g);
+        for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.fmask[r]);
+        int k256_g;
+        const int n_g = fit_compact(g, m5, ones, wl.u.fit, k256_g, fresh(lane));
+        if (lane / 9 == g) { n_mine = n_g; k256_mine = k256_g; }
+        n_max = max(n_max, n_g);
+        n_min = min(n_min, n_g);
+      }
     }
     lsync();
     SP_MARK(6)
     {
-      float C, m1, m2;
-      if (fast_alpha) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2);
-      else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2);
-      // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox
-      int lane_here = lane;
-      asm volatile("" : "+v"(lane_here));  // the mailbox address is formed here, not carried through the round
+      const int lane_here = fresh(lane);
       const int s = min(lane_here / 9, kSlots - 1), x = lane_here % 9;
-      if (lane_here < 9 * kSlots && wl.slot[s].active) {
+      const float* __restrict__ M = lds.M[wl.slot[s].buf];  // (per lane: the records of the lane's slot's unit)
+      float C, m1, m2;
+      if (all_fast) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
+      else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
+      // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox
+      if (lane_here < 9 * kSlots && ((refit >> s) & 1ull)) {
         float* __restrict__ in = lds.svd_in[wave * kSlots + s];
         in[x] = C;
         if (x < 3) in[9 + x] = m1;
@@ -646,7 +767,7 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
     // ---- ... then their 3x3 SVDs, combined over the workgroup: post the requests, then serve whatever is pending
     // (every wave's, this one's included) if no other wave is serving, else wait for the server
     const int my_req = wave * kSlots + min(lane, kSlots - 1);
-    if (lane < kSlots && wl.slot[lane].active) flag_store(&lds.req[my_req], 1);
+    if (lane < kSlots && ((refit >> lane) & 1ull)) flag_store(&lds.req[my_req], 1);
     lsync();
     for (;;) {
       const bool pending = lane < kSlots && flag_load(&lds.req[my_req]) != 0;
@@ -657,7 +778,7 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
       if (got) {
         SP_MARK(8)
         asm volatile("" ::: "memory");
-        const bool p = lane < kSplitSlots && flag_load(&lds.req[lane]) == 1 && (!(plan.debug_flags & 1) || lane / kSlots == wave);
+        const bool p = lane < kStreamSlots && flag_load(&lds.req[lane]) == 1;
         if (__ballot(p) != 0ull) {
           Tfc mine;
           mine.reset();  // lanes without a request: the zero matrix (no rotation, one sweep)
@@ -672,7 +793,7 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
           tfc_get_transformation(mine, fR, ft);
           const bool fnan = has_nan12(fR, ft);
           if (p) {
-            SlotB& sl = lds.w[lane / kSlots].slot[lane % kSlots];
+            SlotS& sl = lds.w[lane / kSlots].slot[lane % kSlots];
 #pragma unroll
             for (int i = 0; i < 9; ++i) sl.R[i] = fR[i];
 #pragma unroll
@@ -698,9 +819,11 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_waves_per_eu(4
   SP_MARK(10)
   if (lane == 0) {
     const unsigned row = atomicAdd(&g_split_count, 1u) % kSplitLogWaves;
-    for (int i = 0; i < 24; ++i) g_split_log[row][i] = sp[i];
-    g_split_log[row][24] = 1ull;
-    g_split_log[row][25] = have ? 1ull : 0ull;
+    for (int i = 0; i < 22; ++i) g_split_log[row][i] = sp[i];
+    g_split_log[row][22] = sp_rt0;
+    g_split_log[row][23] = __builtin_amdgcn_s_memrealtime();
+    g_split_log[row][24] = (unsigned long long)blockIdx.x * 8ull + (unsigned long long)wave;
+    g_split_log[row][25] = sp[13] != 0 ? 1ull : 0ull;
   }
 #endif
 }
@@ -711,23 +834,59 @@ void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst
   hipLaunchKernelGGL(ransac_hyp_kernel, dim3(n_pairs), dim3(kHypThreads), 0, stream, work, n_pairs, rc, plan);
 }
 
+// Once per process, outside any stream capture (rgbdfe_create): the refinement kernel's dynamic LDS exceeds the 64 KB a
+// kernel gets by default.  Returns the device's CU count.
+int ransac_split_init() {
+  static int n_cus = 0;
+  if (n_cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(StreamLds));
+    if (getenv("RGBDFE_SPLIT_VERBOSE")) {  // diagnostics: what the runtime makes of the kernel's resources
+      int nb = -1;
+      const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(ransac_refine_kernel), kStreamThreads, sizeof(StreamLds));
+      fprintf(stderr, "ransac_refine_kernel: %zu B LDS per workgroup, %d workgroups per CU (%s), %d CUs\n", sizeof(StreamLds), nb, hipGetErrorString(e), v);
+    }
+    n_cus = v;
+  }
+  return n_cus;
+}
+
 void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream) {
   const uint32_t units = n_pairs * (uint32_t)plan.n_shares;
   if (units == 0) return;
-  hipLaunchKernelGGL(ransac_refine_kernel, dim3((units + kUnitsPerWg - 1) / kUnitsPerWg), dim3(kSplitThreads), 0, stream,
-                     n_pairs, rc, plan);
+  // persistent workgroups: two per CU (LDS), each streaming units through its three LDS buffers; the units are handed out
+  // through plan.unit_counter (zero at launch)
+  const int n_cus = ransac_split_init();
+  const uint32_t max_wgs = 2u * (uint32_t)n_cus;
+  hipLaunchKernelGGL(ransac_refine_kernel, dim3(units < max_wgs ? units : max_wgs), dim3(kStreamThreads), sizeof(StreamLds), stream,
+                     n_pairs, rc, plan, units);
 }
 
 int ransac_split_words_per_pair(int ransac_iterations) {
   const int I = ransac_iterations > 0 ? ransac_iterations : 0;
   return 4 * ((I + kHypThreads - 1) / kHypThreads);  // a workgroup of the hypothesis kernel writes 4 words per pass
 }
-int ransac_split_waves_per_unit() { return kWavesPerUnit; }
+int ransac_split_max_share() { return kMaxShare; }
 
 }  // namespace rgbdfe
 
 #ifdef RGBDFE_PROFILE_PHASES
 // diagnostics build only (librgbdfe_prof.so): wall cycles per phase summed over the refinement kernel's waves
+extern "C" int rgbdfe_debug_reopened() {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_dbg_reopened), sizeof(n)) != hipSuccess) return -1;
+  return (int)n;
+}
+extern "C" int rgbdfe_debug_split_rows(unsigned long long* out, unsigned max_rows) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_split_count), sizeof(n)) != hipSuccess) return -1;
+  if (n > rgbdfe::kSplitLogWaves) n = rgbdfe::kSplitLogWaves;
+  if (n > max_rows) n = max_rows;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(rgbdfe::g_split_log), (size_t)n * 26 * 8) != hipSuccess) return -1;
+  return (int)n;
+}
 extern "C" int rgbdfe_debug_split_totals(unsigned long long* out32, int reset) {
   if (out32) {
     unsigned n = 0;

@@ -748,6 +748,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   if (const char* gr = getenv("RGBDFE_GRAPHS")) ctx->use_graphs = atoi(gr) != 0;
   auto bail = [&](int code) { rgbdfe_destroy(ctx); return code; };
   if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
+  (void)ransac_split_init();  // kernel attributes of the RANSAC refinement kernel: once, outside any stream capture
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(RGBDFE_ERR_HIP);
   if (hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) return bail(RGBDFE_ERR_HIP);

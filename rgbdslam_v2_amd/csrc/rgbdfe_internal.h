@@ -133,13 +133,15 @@ struct SplitPlan {
                                // hypothesis kernel when preclass_iters > 0; the first refinement launch of a phased plan then
                                // records ALL iterations of these pairs (first_spec) instead of the first phase only
   int preclass_iters = 0;      // the first phase's length (14), 0 = no pre-classification
+  uint32_t* unit_counter = nullptr;  // zero at launch: the refinement kernel's workgroups take their units off it
+  int phase_index = 0;         // > 0: the launch has work only when walk[n_pairs].best_n == phase_index (set by the walk of the phase before)
   int first_spec = 0;          // this launch is the first phase of a phased plan: preclass-2 pairs record [0, spec_end)
-  int debug_flags = 0;         // bisecting aid: 1 = a wave serves only its own SVD requests, 2 = one wave per unit does all the work
 };
 void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
 void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
 int ransac_split_words_per_pair(int ransac_iterations);
-int ransac_split_waves_per_unit();
+int ransac_split_max_share();
+int ransac_split_init();  // once per process before the first batch (not inside a stream capture); returns the CU count
 // bytes of the per-pair iteration masks behind the records + summaries of a record buffer of `rec_capacity` records
 inline size_t ransac_split_mask_bytes(size_t rec_capacity, size_t max_pairs) { return (rec_capacity / 64 + 5 * max_pairs + 64) * 8; }  // + 8 bytes per pair: preclass
 // edges.hip: stable compaction of the accepted edges (id1 >= 0) of a shard

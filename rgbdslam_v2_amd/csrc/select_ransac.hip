@@ -931,7 +931,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 #pragma unroll
           for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.rmask[r]);
           int k256_g;
-          const int n_g = fit_compact(g, m5, w_nonzero, lds.u.fit, k256_g);
+          const int n_g = fit_compact(g, m5, w_nonzero, lds.u.fit, k256_g, lane);
           if (lane / 9 == g) { n_mine = n_g; k256_mine = k256_g; }
           n_max = max(n_max, n_g);
           n_min = min(n_min, n_g);
@@ -945,8 +945,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         mine.reset();
         {
           float C, m1, m2;
-          if (fast_alpha) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, lds.u.fit, lds.M, C, m1, m2);
-          else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, lds.u.fit, lds.M, C, m1, m2);
+          if (fast_alpha) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, lds.u.fit, lds.M, C, m1, m2, lane);
+          else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, lds.u.fit, lds.M, C, m1, m2, lane);
           PH_MARK(4)
           // lane s (< G) collects the state of slot s
           const int src = min(lane, kSlots - 1) * 9;
@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
                                                             const PairPrep* __restrict__ prep, uint32_t n_pairs,
                                                             const RansacConst rc, int phase_begin, int phase_end,
                                                             int spec_end, int may_speculate,
-                                                            const uint8_t* __restrict__ preclass) {
+                                                            const uint8_t* __restrict__ preclass, int phase_index) {
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x;
@@ -1315,6 +1315,8 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
     ws.it = it; ws.real_iterations = real_iterations; ws.valid_iterations = valid_iterations;
     ws.best_idx = best_idx; ws.best_n = best_n; ws.rmse = rmse;
     walk[pair] = ws;
+    // "a pair is still running after phase phase_index": the next refinement launch ends at once when nobody says so
+    if (ws.state >= 0) walk[n_pairs].best_n = phase_index + 1;
   }
 }
 
@@ -1341,9 +1343,11 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
   const size_t n_recs = (size_t)n_pairs * (size_t)(rc.ransac_iterations > 0 ? rc.ransac_iterations : 0);
   plan.sums = reinterpret_cast<IterSum*>(recs + n_recs);
   plan.n_phases_total = n_phases;  // a single-phase plan (small batches: full speculation) always pre-screens
-  (void)hipMemsetAsync(walk + n_pairs, 0, sizeof(WalkState), stream);  // walk[n_pairs].state: the batch's class-1 pairs
   const int I = rc.ransac_iterations;
   const bool split = ransac_split_enabled();
+  // walk[n_pairs]: the batch's counters (class-1 pairs; split path: unit counters, "still running" flag), zero at the start
+  // (the split path's hypothesis kernel does it itself)
+  if (!split) (void)hipMemsetAsync(walk + n_pairs, 0, sizeof(WalkState), stream);
   SplitPlan sp{};
   if (split) {
     // every iteration's hypothesis + pre-screen, all pairs, one launch (lane = iteration); the phases below refine the
@@ -1356,8 +1360,6 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     // everything at once (the classes only schedule the recording: the walk decides the outcome either way)
     static const bool no_pre = getenv("RGBDFE_NO_PRECLASS") && atoi(getenv("RGBDFE_NO_PRECLASS")) != 0;  // A/B runs
     sp.preclass_iters = (n_phases > 2 && !no_pre) ? phase_ends[0] : 0;
-    static const int dbg = getenv("RGBDFE_SPLIT_DEBUG") ? atoi(getenv("RGBDFE_SPLIT_DEBUG")) : 0;  // bisecting aid
-    sp.debug_flags = dbg;
     launch_ransac_hyp(work, n_pairs, rc, sp, stream);
   }
   for (int p = 0; p < n_phases; ++p) {
@@ -1372,12 +1374,17 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     const bool first_spec = split && sp.preclass_iters > 0 && p == 0 && I > end;
     const int cover = (spec || first_spec) ? I : end;
     if (split) {
-      // a unit (half a workgroup: 4 waves sharing the pair's match records) per share of 4 x chunk_iters iterations;
-      // throughput batches (chunk_iters >= 28: more than 1280 pairs) keep a pair's range in one unit
-      const int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * ransac_split_waves_per_unit();
+      // units = (pair, share of the range): latency batches cut a pair's range into shares of 4 x chunk_iters iterations
+      // so that a handful of pairs still fills the chip; throughput batches (chunk_iters >= 28: more than 1280 pairs)
+      // keep a pair's range together, up to the 512 iterations a unit's list holds
+      int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * 4;
+      if (share > ransac_split_max_share()) share = ransac_split_max_share();
       sp.phase_begin = begin; sp.phase_end = end; sp.spec_end = cover; sp.first_spec = first_spec ? 1 : 0;
       sp.n_shares = cover > begin ? (cover - begin + share - 1) / share : 1;
       sp.share_iters = cover > begin ? (cover - begin + sp.n_shares - 1) / sp.n_shares : share;
+      // (the launch's unit counter: a spare word of walk[n_pairs], zeroed with it above; a plan has at most 4 phases)
+      sp.unit_counter = reinterpret_cast<uint32_t*>(&walk[n_pairs].it) + p;
+      sp.phase_index = p;
       if (cover > begin) launch_ransac_refine(n_pairs, rc, sp, stream);
     } else {
     // sub-grid A: the phase in ceil(length / chunk) equal shares (a short last wave would be the launch's straggler)
@@ -1396,7 +1403,7 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
                          results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
     }
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, plan.sums, walk, prep, n_pairs, rc, begin,
-                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0, first_spec ? sp.preclass : (const uint8_t*)nullptr);
+                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0, first_spec ? sp.preclass : (const uint8_t*)nullptr, p);
     begin = end;
   }
   plan.n_chunks = 1;

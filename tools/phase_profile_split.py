@@ -19,23 +19,48 @@ for f in range(F):
     fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 L = C.CDLL(_lib.LIB_PATH)
 tot = (C.c_ulonglong * 32)()
-fe.match_pair_list(pq, pt)
+import torch
+from rgbdslam_v2_amd._lib import RESULT_DTYPE
+buf = torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+def one_batch():
+    fe.wait_ticket(fe.submit_pair_list(pq, pt, buf.data_ptr()), None)
+    fe.synchronize()
+one_batch()
 L.rgbdfe_debug_split_totals(tot, 1)
-reps = 3
-for _ in range(reps):
-    fe.match_pair_list(pq, pt)
-L.rgbdfe_debug_split_totals(tot, 0)
-t = np.array(list(tot), np.float64)
-names = ["prologue: barrier", "close (record writes)", "item fetch (vmask scan)", "open (hypothesis load)", "scoring + error sums",
+reps = 1
+one_batch()
+rows = np.zeros((1 << 18, 26), np.uint64)
+nrows = L.rgbdfe_debug_split_rows(rows.ctypes.data_as(C.c_void_p), C.c_uint(1 << 18))
+rows = rows[:nrows]
+t = rows.sum(axis=0).astype(np.float64)
+t[24] = nrows
+t[25] = rows[:, 25].sum()
+work = rows[rows[:, 25] != 0]
+life = (work[:, 23] - work[:, 22]).astype(np.float64) / 100.0  # us (100 MHz)
+# the launches with work: cluster by start time
+st = np.sort(work[:, 22].astype(np.float64)) / 100.0
+print("working waves: %d; lifetime us: mean %.1f  p50 %.1f  p90 %.1f  max %.1f" % (len(work), life.mean(), np.percentile(life, 50), np.percentile(life, 90), life.max()))
+gaps = np.where(np.diff(st) > 3.0)[0]
+starts = np.concatenate([[0], gaps + 1]); ends = np.concatenate([gaps + 1, [len(st)]])
+order = np.argsort(work[:, 22])
+for a, b in list(zip(starts, ends))[:8]:
+    w = work[order[a:b]]
+    if len(w) < 64: continue
+    s0 = w[:, 22].min() / 100.0
+    e = w[:, 23].astype(np.float64) / 100.0 - s0
+    wg = (w[:, 24] // 8)
+    print("  launch: %d working waves in %d workgroups, start spread %.1f us, ends: p10 %.1f p50 %.1f p90 %.1f max %.1f us" % (
+        len(w), len(np.unique(wg)), (w[:, 22].max() / 100.0 - s0), np.percentile(e, 10), np.percentile(e, 50), np.percentile(e, 90), e.max()))
+
+names = ["init + barrier", "close (record writes)", "refill: claim items / load units / wait", "refill: hypothesis load", "scoring + error sums",
          "bookkeeping", "compaction", "recurrence + mailbox", "SVD: waiting / polling", "SVD: serving", "exit"]
-wall = t[:11].sum() + t[17:21].sum()
+wall = t[:11].sum()
 pairs = len(pq) * reps
 waves = t[24]
 print("noise %.3f: %.0f working waves per batch, %.3g wall cycles per wave (100 MHz counter => %.1f us)" % (noise, waves / reps, wall / waves, wall / waves / 100.0))
 for i, nm in enumerate(names):
     print("  %-32s %5.1f %%   %9.0f cycles per wave" % (nm, 100 * t[i] / wall, t[i] / waves))
-for i, nm in ((17, "prologue: unit parameters (loads)"), (18, "prologue: M loads issued, slot init"), (19, "prologue: first refill"), (20, "prologue: vmcnt(0)")):
-    print("  %-32s %5.1f %%   %9.0f cycles per wave" % (nm, 100 * t[i] / wall, t[i] / waves))
+print("  units loaded: %.0f per batch" % (t[21] / reps))
 print("  waves with work: %.0f of %.0f per batch" % (t[25] / reps, waves / reps))
 print("  per wave: %.2f rounds, %.2f items, %.2f scorings, %.2f services of %.2f requests each" % (
     t[13] / waves, t[12] / waves, t[14] / waves, t[15] / waves, t[11] / max(t[15], 1)))
