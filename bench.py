@@ -360,8 +360,9 @@ def main():
             "step_ms_serial": iso.get("serial_ms_per_step"),   # the stage time above is part of THIS step time
             "step_ms_pipelined": round(ms_per_step, 4),
             "launches_per_stage": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
-                                  "pair_prep_kernel + recording launches of select_ransac_kernel + replay_walk_kernel + 1 "
-                                  "result launch; avg_launch_ms spans the whole stage",
+                                  "pair_prep_kernel + ransac_hyp_kernel (all iterations' hypotheses + pre-screen) + per phase "
+                                  "ransac_refine_kernel (streaming refinement) and replay_walk_kernel + 1 result launch; "
+                                  "avg_launch_ms spans the whole stage",
             "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
             "note": "the HBM fraction is what the contract asks for and says only that this path is NOT memory bound "
                     "(SURVEY.md 8(d)); the limiter is instruction issue: see issue_roofline",

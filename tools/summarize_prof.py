@@ -22,7 +22,8 @@ def find(pattern):
 
 
 def short(name):
-    if "replay_walk_kernel" in name or "pair_prep_kernel" in name:  # parts of the select+RANSAC stage of a batch
+    if ("replay_walk_kernel" in name or "pair_prep_kernel" in name or "ransac_hyp_kernel" in name or
+            "ransac_refine_kernel" in name):  # parts of the select+RANSAC stage of a batch
         return "select_ransac"
     if "hamming_mfma_kernel" in name:
         return "hamming_nn"
