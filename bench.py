@@ -39,8 +39,8 @@ PAIRS_PER_FRAME = 20
 MAX_MATCHES = 300
 SEED = 20260923
 REPEATS = 3                                # repetitions of the timed region (median reported)
-PMC_SUMMARY = "profiles/r03_pmc_summary.json"   # static counter figures (tools/profile_r03.sh + tools/make_pmc_summary.py)
-PMC_FALLBACK = "profiles/r02_pmc_summary.json"
+PMC_SUMMARY = "profiles/r04_pmc_summary.json"   # static counter figures (tools/profile_r03.sh + tools/make_pmc_summary.py)
+PMC_FALLBACK = "profiles/r03_pmc_summary.json"
 # Aggregates of one step's results as the ORACLE computes them (oracle/liboracle.so over the same seeded workload;
 # tests/test_gpu_pairs.py::test_whole_bench_step_matches_oracle / test_loop_closure_subrecord_matches_oracle compare every
 # pair bit for bit and re-derive these sums).  bench.py refuses to print a number whose results differ.

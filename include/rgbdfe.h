@@ -537,6 +537,13 @@ int rgbdfe_set_profiling(rgbdfe_ctx* ctx, int enable);
 int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t* launches,
                            int64_t* pairs);
 int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx);
+/* The hipGraph cache of the ORB pair path (one executable graph per distinct batch shape: pair count, Hamming launch
+ * geometry, output buffer): out[0..n_out) = { captures, graph launches, misses (graphable batches whose shape was not
+ * cached), batches issued as plain launches because the shapes kept missing, captures another thread invalidated,
+ * cached graphs that failed to launch, graphs cached now, graphs enabled (RGBDFE_GRAPHS) }; summed over the devices
+ * of a multi handle. */
+#define RGBDFE_GRAPH_STATS 8
+int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out);
 
 /* ABI self-description (lets bindings verify struct layout) */
 int rgbdfe_sizeof_match_result(void);

@@ -279,25 +279,31 @@ void launch_hamming_expand(const uint32_t* node_rows, uint32_t* slab, uint32_t s
   hipLaunchKernelGGL(hamming_expand_kernel, dim3(tiles), dim3(256), 0, stream, node_rows, dst, n);
 }
 
-uint32_t launch_hamming_mfma(const uint32_t* slab, const PairWork* work, uint32_t* keys, uint32_t max_kp,
-                             uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity,
-                             int mode, hipStream_t stream) {
-  if (n_pairs == 0 || max_nq == 0) return 1;
-  const uint32_t qblocks = (max_nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
-  const uint32_t tiles_per_slot = hamming_mfma_tiles_per_slot(max_kp);
+HammingGeometry hamming_mfma_geometry(uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity) {
+  HammingGeometry g{0, 1};
+  if (n_pairs == 0 || max_nq == 0) return g;
+  g.qblocks = (max_nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
   // small batches (live SLAM: ~20 pairs per frame) split the train tiles over several blocks, one key plane each
-  uint32_t tsplit = 1;
-  const uint32_t blocks1 = n_pairs * qblocks;
+  const uint32_t blocks1 = n_pairs * g.qblocks;
   const uint32_t ttiles = (max_nt + 31u) / 32u;
   if (blocks1 < 1024 && ttiles > kStage) {
-    tsplit = (1024 + blocks1 - 1) / blocks1;
+    uint32_t tsplit = (1024 + blocks1 - 1) / blocks1;
     const uint32_t max_split = (ttiles + kStage - 1) / kStage;  // at least one LDS stage per block
     if (tsplit > max_split) tsplit = max_split;
     if (tsplit > 32) tsplit = 32;
     const uint32_t fit = key_planes_capacity / n_pairs;
     if (tsplit > fit) tsplit = fit;
     if (tsplit < 1) tsplit = 1;
+    g.tsplit = tsplit;
   }
+  return g;
+}
+
+uint32_t launch_hamming_mfma(const uint32_t* slab, const PairWork* work, uint32_t* keys, uint32_t max_kp,
+                             uint32_t n_pairs, HammingGeometry geom, int mode, hipStream_t stream) {
+  if (n_pairs == 0 || geom.qblocks == 0) return 1;
+  const uint32_t qblocks = geom.qblocks, tsplit = geom.tsplit;
+  const uint32_t tiles_per_slot = hamming_mfma_tiles_per_slot(max_kp);
   const uint32_t pairs8 = (n_pairs + 7u) / 8u * 8u;
   const uint32_t grid = pairs8 * qblocks * tsplit;
   const uint4* s4 = reinterpret_cast<const uint4*>(slab);

@@ -130,24 +130,30 @@ __global__ __launch_bounds__(kHamThreads) void hamming_nn_kernel(
   }
 }
 
-uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
-                           uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
-                           uint32_t key_planes_capacity, hipStream_t stream) {
-  if (n_pairs == 0 || max_nq == 0) return 1;
-  const uint32_t tiles = (max_nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
+HammingGeometry hamming_nn_geometry(uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity) {
+  HammingGeometry g{0, 1};
+  if (n_pairs == 0 || max_nq == 0) return g;
+  g.qblocks = (max_nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
   // Enough blocks to fill 256 CUs several times over; split the train rows when the
   // batch is small (live SLAM: ~20 pairs per frame).  Every split owns a key plane.
-  uint32_t tsplit = 1;
-  const uint32_t blocks1 = n_pairs * tiles;
+  const uint32_t blocks1 = n_pairs * g.qblocks;
   if (blocks1 < 2048 && max_nt > 64) {
-    tsplit = (2048 + blocks1 - 1) / blocks1;
+    uint32_t tsplit = (2048 + blocks1 - 1) / blocks1;
     const uint32_t max_split = (max_nt + 63) / 64;  // at least 64 rows per block
     if (tsplit > max_split) tsplit = max_split;
     if (tsplit > 32) tsplit = 32;
     const uint32_t fit = key_planes_capacity / n_pairs;  // planes the keys buffer can hold
     if (tsplit > fit) tsplit = fit;
     if (tsplit < 1) tsplit = 1;
+    g.tsplit = tsplit;
   }
+  return g;
+}
+
+uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
+                           uint32_t max_kp, uint32_t n_pairs, HammingGeometry geom, hipStream_t stream) {
+  if (n_pairs == 0 || geom.qblocks == 0) return 1;
+  const uint32_t tiles = geom.qblocks, tsplit = geom.tsplit;
   const uint32_t pairs8 = (n_pairs + 7u) / 8u * 8u;
   const uint32_t grid = pairs8 * tiles * tsplit;
   if (tsplit > 1)

@@ -142,9 +142,10 @@ struct UnitCtx {
   uint32_t thr;
   float pmax;
   int fast;
-  int pad[3];
+  int base;                  // iteration index of bit 0 of the first mask word of the unit's range
+  int pad[2];
   uint64_t w_nonzero[kRounds];
-  uint16_t klist[kMaxShare];  // the viable iterations of the unit's range, ascending
+  uint16_t klist[kMaxShare];  // the viable iterations of the unit's range, ascending, relative to `base` (< kMaxShare + 64)
 };
 struct alignas(16) StreamLds {
   float M[kBufs][RGBDFE_MAX_MATCHES * kRec];  // the resident units' match records (see PairPrep)
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       for (int c = 0; c < n_words; ++c) {
         const uint64_t wc = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), c) << 32) |
                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wv, c);
-        if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)(((blk0 + c) << 6) + lane);
+        if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)((c << 6) + lane);
         total += __popcll(wc);
       }
       uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         cx.thr = thr;
         cx.pmax = pmax;
         cx.fast = (int)fast;
+        cx.base = blk0 << 6;
         cx.n_items = total;
         cx.next = 0;
         cx.done = 0;
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       const int e2 = lane % 6;
       const UnitCtx& cx = lds.ctx[my_b];
       SlotS& sl = wl.slot[my_g];
-      const int k = (int)cx.klist[my_at];
+      const int k = cx.base + (int)cx.klist[my_at];
       const uint32_t pair = cx.pair;
       const float2 v = reinterpret_cast<const float2*>(plan.recs[(size_t)pair * (size_t)I + (size_t)k].rR)[e2];  // rR[9], rt[3]
       reinterpret_cast<float2*>(sl.R)[e2] = v;                                                                  // -> R[9], t[3]

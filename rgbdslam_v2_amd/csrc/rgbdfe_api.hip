@@ -21,6 +21,7 @@
 #include <thread>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "orb_host.h"
@@ -225,9 +226,10 @@ struct rgbdfe_ctx {
   // The launch chain of an ORB batch (pair-list upload, Hamming, pair_prep, recording / walk launches, result launch:
   // ~12 enqueues) as a hipGraph: captured once per distinct batch shape, then ONE hipGraphLaunch per batch -- what keeps
   // a single submitting thread ahead of several devices (rgbdfe_create_multi) and shortens the live-SLAM call.
-  // Everything a kernel argument depends on is part of the key.
+  // Everything a kernel argument or a grid depends on is part of the key -- and nothing else: node sizes count only
+  // through the Hamming stage's launch geometry (HammingGeometry), so frames with different keypoint counts share graphs.
   struct GraphKey {
-    int32_t n; uint32_t max_nq, max_nt; int32_t slot, latency, chunk, hamming_mode, n_phases; int32_t ends[4];
+    int32_t n; uint32_t qblocks, tsplit; int32_t slot, latency, chunk, hamming_mode, n_phases; int32_t ends[4];
     RansacConst rc;
     void* d_out; void* d_recs; void* d_ec; void* d_walk; void* d_keys;
   };
@@ -235,6 +237,11 @@ struct rgbdfe_ctx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   int64_t graph_launches = 0, graph_captures = 0;
+  int64_t graph_misses = 0;          // graphable batches whose shape was not cached
+  int64_t graph_plain_batches = 0;   // of those: issued as plain launches without a capture attempt
+  int64_t graph_launch_failures = 0; // cached executable graphs that failed to launch (dropped)
+  int32_t graph_miss_run = 0;        // misses since the last hit
+  static constexpr int32_t kGraphMissRun = 8, kGraphRetry = 16;
   bool use_graphs = true;  // RGBDFE_GRAPHS=0: plain stream launches
   hipStream_t capture_stream = nullptr;  // graphs are captured here, never on a stream other threads may wait on
   long graph_capture_failures = 0;       // captures another thread's HIP call invalidated (the batch then ran as plain launches)
@@ -460,13 +467,24 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
 
 // The Hamming stage of an ORB batch: the fp4 MFMA kernel by default, the popcount kernel when asked for
 // (rgbdfe_set_hamming_mode) or when the row index does not fit the MFMA kernel's 15 key bits.  Same keys either way.
+bool hamming_on_mfma(const rgbdfe_ctx* ctx) { return ctx->hamming_mode != 0 && (uint32_t)ctx->cfg.max_keypoints <= 32768u; }
+
+HammingGeometry hamming_geometry(const rgbdfe_ctx* ctx, uint32_t n, uint32_t max_nq, uint32_t max_nt) {
+  const uint32_t cap = (uint32_t)ctx->cfg.max_pairs_per_batch;
+  return hamming_on_mfma(ctx) ? hamming_mfma_geometry(n, max_nq, max_nt, cap) : hamming_nn_geometry(n, max_nq, max_nt, cap);
+}
+
+uint32_t launch_hamming(rgbdfe_ctx* ctx, const PairWork* d_work, uint32_t* d_keys, uint32_t n, HammingGeometry geom,
+                        hipStream_t stream) {
+  const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
+  if (hamming_on_mfma(ctx))
+    return launch_hamming_mfma(ctx->d_desc4, d_work, d_keys, mk, n, geom, ctx->hamming_mode, stream);
+  return launch_hamming_nn(ctx->d_desc, d_work, d_keys, mk, n, geom, stream);
+}
+
 uint32_t launch_hamming(rgbdfe_ctx* ctx, const PairWork* d_work, uint32_t* d_keys, uint32_t n, uint32_t max_nq,
                         uint32_t max_nt, hipStream_t stream) {
-  const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
-  const uint32_t cap = (uint32_t)ctx->cfg.max_pairs_per_batch;
-  if (ctx->hamming_mode != 0 && mk <= 32768u)
-    return launch_hamming_mfma(ctx->d_desc4, d_work, d_keys, mk, n, max_nq, max_nt, cap, ctx->hamming_mode, stream);
-  return launch_hamming_nn(ctx->d_desc, d_work, d_keys, mk, n, max_nq, max_nt, cap, stream);
+  return launch_hamming(ctx, d_work, d_keys, n, hamming_geometry(ctx, n, max_nq, max_nt), stream);
 }
 
 // Build the PairWork list (host) and enqueue H2D + both kernels on the next lane.
@@ -551,36 +569,60 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     if (!d_out) d_out = lane.d_results;
     // hipGraph form of the whole chain: ORB batches that run as one piece, no per-stage timing events, no refinement
     const bool graphable = ctx->use_graphs && !sift && !ctx->profiling && piece >= n && ctx->rc.g2o_iterations == 0;
+    // node sizes enter the launches only through the Hamming stage's geometry (query blocks and train splits per pair)
+    const HammingGeometry geom = sift ? HammingGeometry{0, 1}
+                                      : hamming_geometry(ctx, (uint32_t)(piece < n ? piece : n), max_nq, max_nt);
     rgbdfe_ctx::GraphEntry* ge = nullptr;
     bool capturing = false;
     if (graphable) {
       rgbdfe_ctx::GraphKey key;
       memset(&key, 0, sizeof(key));
-      key.n = n; key.max_nq = max_nq; key.max_nt = max_nt; key.slot = (int32_t)(ticket % rgbdfe_ctx::kRing);
+      key.n = n; key.qblocks = geom.qblocks; key.tsplit = geom.tsplit; key.slot = (int32_t)(ticket % rgbdfe_ctx::kRing);
       key.latency = latency ? 1 : 0; key.chunk = chunk; key.hamming_mode = ctx->hamming_mode; key.n_phases = pp.n_phases;
       for (int i = 0; i < 4; ++i) key.ends[i] = i < pp.n_phases ? pp.ends[i] : 0;
       memcpy(&key.rc, &ctx->rc, sizeof(RansacConst));
       key.d_out = d_out; key.d_recs = lane.d_recs; key.d_ec = lane.d_ec; key.d_walk = lane.d_walk; key.d_keys = lane.d_keys;
-      for (auto& e : ctx->graphs)
-        if (memcmp(&e.key, &key, sizeof(key)) == 0) { ge = &e; break; }
+      size_t gi = 0;
+      for (; gi < ctx->graphs.size(); ++gi)
+        if (memcmp(&ctx->graphs[gi].key, &key, sizeof(key)) == 0) { ge = &ctx->graphs[gi]; break; }
       if (ge) {
         ge->used = ++ctx->graph_clock;
-        if (hipGraphLaunch(ge->exec, stream) != hipSuccess) launch_err = hipGetLastError();
-        ctx->graph_launches++;
-      } else if (capture_stream_ready(ctx) && hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
-        // Captured on a stream of its own, in relaxed mode: other host threads may be waiting on `stream` for an earlier
-        // batch (hipStreamSynchronize on a capturing stream is an error) or be inside the HIP runtime for unrelated work
-        // (any capture that is not relaxed makes their hipMalloc / synchronous copies fail for its duration).
-        capturing = true;
-        if (ctx->graphs.size() >= 48) {  // drop the least recently used shape
-          size_t lru = 0;
-          for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].used < ctx->graphs[lru].used) lru = i;
-          (void)hipGraphExecDestroy(ctx->graphs[lru].exec); (void)hipGraphDestroy(ctx->graphs[lru].graph);
-          ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
+        const hipError_t le = hipGraphLaunch(ge->exec, stream);
+        if (le == hipSuccess) {
+          ctx->graph_launches++;
+          ctx->graph_miss_run = 0;
+        } else {  // an executable graph that does not launch is dropped; this batch goes out as plain launches
+          (void)hipGetLastError();
+          (void)hipGraphExecDestroy(ge->exec); (void)hipGraphDestroy(ge->graph);
+          ctx->graphs.erase(ctx->graphs.begin() + (long)gi);
+          ctx->graph_launch_failures++;
+          ge = nullptr;
         }
-        ctx->graphs.push_back(rgbdfe_ctx::GraphEntry{key, nullptr, nullptr, ++ctx->graph_clock});
       } else {
-        (void)hipGetLastError();  // capture unavailable: plain launches
+        // A capture costs more than the ~12 enqueues it replaces: it pays only for shapes that come back.  After
+        // kGraphMissRun misses in a row (a caller whose batch shape or output buffer changes every time) batches go out
+        // as plain launches, and only every kGraphRetry-th miss is captured, until a shape hits again.
+        ctx->graph_misses++;
+        const bool try_capture = ctx->graph_miss_run < rgbdfe_ctx::kGraphMissRun ||
+                                 ctx->graph_miss_run % rgbdfe_ctx::kGraphRetry == 0;
+        ctx->graph_miss_run++;
+        if (try_capture && capture_stream_ready(ctx) &&
+            hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+          // Captured on a stream of its own, in relaxed mode: other host threads may be waiting on `stream` for an earlier
+          // batch (hipStreamSynchronize on a capturing stream is an error) or be inside the HIP runtime for unrelated work
+          // (any capture that is not relaxed makes their hipMalloc / synchronous copies fail for its duration).
+          capturing = true;
+          if (ctx->graphs.size() >= 48) {  // drop the least recently used shape
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].used < ctx->graphs[lru].used) lru = i;
+            (void)hipGraphExecDestroy(ctx->graphs[lru].exec); (void)hipGraphDestroy(ctx->graphs[lru].graph);
+            ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
+          }
+          ctx->graphs.push_back(rgbdfe_ctx::GraphEntry{key, nullptr, nullptr, ++ctx->graph_clock});
+        } else {
+          (void)hipGetLastError();  // no capture: plain launches
+          ctx->graph_plain_batches++;
+        }
       }
     }
     // (at most twice: a capture that another thread's HIP call invalidated -- relaxed mode keeps THEM from failing, but a
@@ -588,90 +630,90 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
     rgbdfe_ctx::Pending pend{};
     pend.sift = sift;
     for (int attempt = 0; attempt < 2; ++attempt) {
-    hipStream_t const ls = capturing ? ctx->capture_stream : stream;   // where this batch's operations are issued
-    if (!ge) {
-      const hipError_t me = hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n, hipMemcpyHostToDevice, ls);
-      if (me != hipSuccess && launch_err == hipSuccess) launch_err = me;
-    }
-    if (ctx->profiling) {
-      pend.a = get_event(ctx);
-      pend.b = get_event(ctx);
-      pend.c = get_event(ctx);
-      if (sift) pend.d = get_event(ctx);
-      pend.pairs = n;
-      (void)hipEventRecord(pend.a, ls);
-    }
-    const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
-    for (int32_t off = 0; off < n && !ge; off += piece) {
-      const int32_t m = (n - off) < piece ? (n - off) : piece;
-      const bool first = off == 0, last = off + m >= n;
-      if (!first) {  // the schedule of a shorter last piece (its scratch needs are covered by the first one's)
-        int rcl = want_latency_path(ctx, lane, m, ls, &latency, &chunk, &pp);
-        if (rcl != RGBDFE_OK) { launch_err = hipErrorOutOfMemory; break; }
+      hipStream_t const ls = capturing ? ctx->capture_stream : stream;   // where this batch's operations are issued
+      if (!ge) {
+        const hipError_t me = hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork) * (size_t)n, hipMemcpyHostToDevice, ls);
+        if (me != hipSuccess && launch_err == hipSuccess) launch_err = me;
       }
-      const PairWork* d_work = slot.d_work + off;
-      rgbdfe_match_result* d_res = d_out + off;
-      if (!sift) {
-        const uint32_t planes = launch_hamming(ctx, d_work, lane.d_keys, (uint32_t)m, max_nq, max_nt, ls);
-        if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
-        if (latency)
-          launch_select_ransac_latency(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc,
-                                       lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, ls);
-        else
-          launch_select_ransac(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc, lane.d_prep,
-                               lane.d_ec, ls);
-        if (ctx->rc.g2o_iterations > 0)
-          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, ls);
-        if (ctx->profiling && last) (void)hipEventRecord(pend.c, ls);
-      } else {
-        float* d_dist = (d_out_dist ? d_out_dist : lane.d_all_dist) + (size_t)off * RGBDFE_MAX_MATCHES;  // (the lane's buffer holds max_pairs rows)
-        if (matcher == 2) {
-          launch_l2_knn2(ctx->d_sift_f32, d_work, mk, (uint32_t)m, max_nq, lane.d_row_part, ls);
-          if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
-          launch_l2_ratio(d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part, flann_ratio, lane.d_sm_q,
-                          lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
-        } else {
-          launch_sift_dot(ctx->d_sift_bf16, d_work, mk, (uint32_t)m, max_nq, max_nt, sift_kinds, lane.d_row_part,
-                          lane.d_col_part, ls);
-          if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
-          launch_sift_finish(ctx->d_sift_f32, d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part,
-                             lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
+      if (ctx->profiling) {
+        pend.a = get_event(ctx);
+        pend.b = get_event(ctx);
+        pend.c = get_event(ctx);
+        if (sift) pend.d = get_event(ctx);
+        pend.pairs = n;
+        (void)hipEventRecord(pend.a, ls);
+      }
+      const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
+      for (int32_t off = 0; off < n && !ge; off += piece) {
+        const int32_t m = (n - off) < piece ? (n - off) : piece;
+        const bool first = off == 0, last = off + m >= n;
+        if (!first) {  // the schedule of a shorter last piece (its scratch needs are covered by the first one's)
+          int rcl = want_latency_path(ctx, lane, m, ls, &latency, &chunk, &pp);
+          if (rcl != RGBDFE_OK) { launch_err = hipErrorOutOfMemory; break; }
         }
-        if (ctx->profiling && first) (void)hipEventRecord(pend.c, ls);
-        if (latency)
-          launch_select_ransac_sift_latency(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
-                                            d_dist, d_res, mk, (uint32_t)m, ctx->rc,
-                                            lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, ls);
-        else
-          launch_select_ransac_sift(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
-                                    lane.d_sm_n, d_dist, d_res, mk,
-                                    (uint32_t)m, ctx->rc, lane.d_prep, lane.d_ec, ls);
-        if (ctx->rc.g2o_iterations > 0)
-          launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, ls);
-        if (ctx->profiling && last) (void)hipEventRecord(pend.d, ls);
+        const PairWork* d_work = slot.d_work + off;
+        rgbdfe_match_result* d_res = d_out + off;
+        if (!sift) {
+          const uint32_t planes = launch_hamming(ctx, d_work, lane.d_keys, (uint32_t)m, first ? geom : hamming_geometry(ctx, (uint32_t)m, max_nq, max_nt), ls);
+          if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
+          if (latency)
+            launch_select_ransac_latency(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc,
+                                         lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, ls);
+          else
+            launch_select_ransac(ctx->d_xyz, d_work, lane.d_keys, planes, d_res, mk, (uint32_t)m, ctx->rc, lane.d_prep,
+                                 lane.d_ec, ls);
+          if (ctx->rc.g2o_iterations > 0)
+            launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, ls);
+          if (ctx->profiling && last) (void)hipEventRecord(pend.c, ls);
+        } else {
+          float* d_dist = (d_out_dist ? d_out_dist : lane.d_all_dist) + (size_t)off * RGBDFE_MAX_MATCHES;  // (the lane's buffer holds max_pairs rows)
+          if (matcher == 2) {
+            launch_l2_knn2(ctx->d_sift_f32, d_work, mk, (uint32_t)m, max_nq, lane.d_row_part, ls);
+            if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
+            launch_l2_ratio(d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part, flann_ratio, lane.d_sm_q,
+                            lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
+          } else {
+            launch_sift_dot(ctx->d_sift_bf16, d_work, mk, (uint32_t)m, max_nq, max_nt, sift_kinds, lane.d_row_part,
+                            lane.d_col_part, ls);
+            if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
+            launch_sift_finish(ctx->d_sift_f32, d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part,
+                               lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
+          }
+          if (ctx->profiling && first) (void)hipEventRecord(pend.c, ls);
+          if (latency)
+            launch_select_ransac_sift_latency(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n,
+                                              d_dist, d_res, mk, (uint32_t)m, ctx->rc,
+                                              lane.d_prep, lane.d_recs, lane.d_walk, lane.d_ec, chunk, pp.ends, pp.n_phases, ls);
+          else
+            launch_select_ransac_sift(ctx->d_xyz, d_work, lane.d_sm_q, lane.d_sm_t, lane.d_sm_d,
+                                      lane.d_sm_n, d_dist, d_res, mk,
+                                      (uint32_t)m, ctx->rc, lane.d_prep, lane.d_ec, ls);
+          if (ctx->rc.g2o_iterations > 0)
+            launch_g2o_refine(d_work, d_res, (uint32_t)m, ctx->rc, lane.d_prep, ctx->d_kp2d, mk, lane.d_ec, ls);
+          if (ctx->profiling && last) (void)hipEventRecord(pend.d, ls);
+        }
       }
-    }
-    if (capturing) {  // close the capture, keep the executable graph, run it
-      rgbdfe_ctx::GraphEntry& e = ctx->graphs.back();
-      hipError_t ce = hipStreamEndCapture(ctx->capture_stream, &e.graph);
-      if (ce == hipSuccess) ce = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
-      if (ce == hipSuccess && launch_err == hipSuccess) {
-        ctx->graph_captures++;
-        ce = hipGraphLaunch(e.exec, stream);
-        ctx->graph_launches++;
-        if (ce != hipSuccess) launch_err = ce;
-      } else {
-        if (e.exec) (void)hipGraphExecDestroy(e.exec);
-        if (e.graph) (void)hipGraphDestroy(e.graph);
-        ctx->graphs.pop_back();
-        (void)hipGetLastError();
-        capturing = false;
-        launch_err = hipSuccess;
-        ctx->graph_capture_failures++;
-        continue;   // once more, plain launches on `stream`
+      if (capturing) {  // close the capture, keep the executable graph, run it
+        rgbdfe_ctx::GraphEntry& e = ctx->graphs.back();
+        hipError_t ce = hipStreamEndCapture(ctx->capture_stream, &e.graph);
+        if (ce == hipSuccess) ce = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+        if (ce == hipSuccess && launch_err == hipSuccess) {
+          ctx->graph_captures++;
+          ce = hipGraphLaunch(e.exec, stream);
+          ctx->graph_launches++;
+          if (ce != hipSuccess) launch_err = ce;
+        } else {
+          if (e.exec) (void)hipGraphExecDestroy(e.exec);
+          if (e.graph) (void)hipGraphDestroy(e.graph);
+          ctx->graphs.pop_back();
+          (void)hipGetLastError();
+          capturing = false;
+          launch_err = hipSuccess;
+          ctx->graph_capture_failures++;
+          continue;   // once more, plain launches on `stream`
+        }
       }
-    }
-    break;
+      break;
     }
     if (launch_err == hipSuccess) launch_err = hipGetLastError();
     if (ctx->profiling) {
@@ -933,11 +975,12 @@ static int upload_nodes_locked(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* 
                                const float* const* xyz1, const int32_t* counts) {
   size_t rows = 0, fresh = 0;
   bool overwrite = false;
+  std::unordered_set<int32_t> seen;
+  seen.reserve((size_t)n_nodes * 2);
   for (int32_t i = 0; i < n_nodes; ++i) {
     if (counts[i] < 0 || (counts[i] > 0 && (!desc[i] || !xyz1[i]))) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad upload arguments");
     if (counts[i] > ctx->cfg.max_keypoints) return fail(ctx, RGBDFE_ERR_CAPACITY, "node has more rows than max_keypoints");
-    for (int32_t j = 0; j < i; ++j)
-      if (node_ids[j] == node_ids[i]) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "a node id appears twice in one upload");
+    if (!seen.insert(node_ids[i]).second) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "a node id appears twice in one upload");
     if (ctx->nodes.count(node_ids[i])) overwrite = true; else ++fresh;
     rows += (size_t)counts[i];
   }
@@ -951,25 +994,34 @@ static int upload_nodes_locked(rgbdfe_ctx* ctx, int32_t n_nodes, const int32_t* 
     ctx->upload_stage_bytes = rows * 48 * 2;
   }
   uint8_t* stage = ctx->upload_stage;
-  for (int32_t i = 0; i < n_nodes; ++i) {
+  // A node is registered BEFORE its copies are enqueued, so a failing enqueue leaves no slot unaccounted for: the node is
+  // resident with whatever reached it (the caller gets the error and uploads it again or releases it).  Whatever the
+  // outcome, the copies out of the pinned stage have ended when this returns -- the next call overwrites the stage.
+  hipError_t err = hipSuccess;
+  for (int32_t i = 0; i < n_nodes && err == hipSuccess; ++i) {
     const int32_t n = counts[i];
     uint32_t slot;
     auto it = ctx->nodes.find(node_ids[i]);
     if (it != ctx->nodes.end()) slot = it->second.slot;
     else { slot = ctx->free_slots.back(); ctx->free_slots.pop_back(); }
+    ctx->nodes[node_ids[i]] = NodeEntry{slot, (uint32_t)n, 0u, 0u};
     const size_t row0 = (size_t)slot * (size_t)ctx->cfg.max_keypoints;
     if (n > 0) {
       memcpy(stage, desc[i], (size_t)n * 32);
       memcpy(stage + (size_t)n * 32, xyz1[i], (size_t)n * 16);
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc + row0 * 8, stage, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xyz + row0, stage + (size_t)n * 32, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-      launch_hamming_expand(ctx->d_desc + row0 * 8, ctx->d_desc4, slot, (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->stream);
+      err = hipMemcpyAsync(ctx->d_desc + row0 * 8, stage, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream);
+      if (err == hipSuccess)
+        err = hipMemcpyAsync(ctx->d_xyz + row0, stage + (size_t)n * 32, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+      if (err == hipSuccess) {
+        launch_hamming_expand(ctx->d_desc + row0 * 8, ctx->d_desc4, slot, (uint32_t)ctx->cfg.max_keypoints, (uint32_t)n, ctx->stream);
+        err = hipGetLastError();
+      }
       stage += (size_t)n * 48;
     }
-    ctx->nodes[node_ids[i]] = NodeEntry{slot, (uint32_t)n, 0u, 0u};
   }
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const hipError_t sync_err = hipStreamSynchronize(ctx->stream);
+  if (err == hipSuccess) err = sync_err;
+  if (err != hipSuccess) return fail(ctx, RGBDFE_ERR_HIP, std::string("rgbdfe_upload_nodes: ") + hipGetErrorString(err));
   return RGBDFE_OK;
 }
 
@@ -1892,8 +1944,18 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   hipStream_t up = ctx->orb_upload_stream, st2 = ctx->orb_compute_stream;
   const int max_kp = ctx->orb_max_keypoints;
   if (node_ids) {
+    // all-or-nothing on capacity, like rgbdfe_upload_nodes: everything that can be refused is refused before the first
+    // frame is detected (every frame may need a slot: a frame without features still becomes an empty node)
+    if (max_kp > ctx->cfg.max_keypoints)
+      return fail(ctx, RGBDFE_ERR_CAPACITY, "the detector's max_keypoints exceeds the context's max_keypoints (node rows)");
     bool overwrite = false;
-    for (int32_t f = 0; f < n_frames; ++f) overwrite |= node_ids[f] >= 0 && ctx->nodes.count(node_ids[f]) != 0;
+    std::unordered_set<int32_t> fresh_ids;
+    for (int32_t f = 0; f < n_frames; ++f) {
+      if (node_ids[f] < 0) continue;
+      if (ctx->nodes.count(node_ids[f]) != 0) overwrite = true;
+      else fresh_ids.insert(node_ids[f]);
+    }
+    if (fresh_ids.size() > ctx->free_slots.size()) return fail(ctx, RGBDFE_ERR_CAPACITY, "no free node slot (max_nodes)");
     if (overwrite)  // nodes rewritten in place: wait for pair batches that may still read them
       for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));
   }
@@ -2014,6 +2076,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
           const int32_t id = node_ids[first_of(s) + k];
           const int n = (int)J[(size_t)k].kps.size();
           if (id < 0 || n == 0) continue;
+          if (n > ctx->cfg.max_keypoints) { err = "node has more rows than max_keypoints"; return RGBDFE_ERR_CAPACITY; }
           uint32_t slot;
           auto it = ctx->nodes.find(id);
           if (it != ctx->nodes.end()) slot = it->second.slot;
@@ -2021,8 +2084,8 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
             if (ctx->free_slots.empty()) { err = "no free node slot (max_nodes)"; return RGBDFE_ERR_CAPACITY; }
             slot = ctx->free_slots.back();
             ctx->free_slots.pop_back();
+            ctx->nodes[id] = NodeEntry{slot, 0u, 0u, 0u};   // registered before anything can fail: no slot goes missing
           }
-          if (n > ctx->cfg.max_keypoints) { err = "node has more rows than max_keypoints"; return RGBDFE_ERR_CAPACITY; }
           const size_t row0 = (size_t)slot * (size_t)ctx->cfg.max_keypoints;
           const size_t off = (size_t)J[(size_t)k].off;
           if (hipMemcpyAsync(ctx->d_desc + row0 * 8, orb.d_desc + off * 32, (size_t)n * 32, hipMemcpyDeviceToDevice, st2) != hipSuccess ||
@@ -3031,7 +3094,17 @@ int rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void*
   HIP_TRY(ctx, hipGetLastError());
   return RGBDFE_OK;
 }
-int rgbdfe_abi_version(void) { return 3; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect
+int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
+  if (!ctx || !out || n_out < 0) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  const int64_t v[RGBDFE_GRAPH_STATS] = {ctx->graph_captures, ctx->graph_launches, ctx->graph_misses, ctx->graph_plain_batches,
+                                         (int64_t)ctx->graph_capture_failures, ctx->graph_launch_failures,
+                                         (int64_t)ctx->graphs.size(), ctx->use_graphs ? 1 : 0};
+  for (int32_t i = 0; i < n_out && i < RGBDFE_GRAPH_STATS; ++i) out[i] += v[i];
+  return RGBDFE_OK;
+}
+
+int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats
 
 }  // namespace impl
 
@@ -4168,6 +4241,20 @@ int rgbdfe_get_kernel_time(rgbdfe_ctx* ctx, int which, double* total_ms, int64_t
 int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   return RGBDFE_ALL(ctx, impl::rgbdfe_reset_kernel_time(c));
+}
+
+// group: the sum over the devices
+int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
+  if (!ctx || !out || n_out < 0) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    for (int32_t i = 0; i < n_out; ++i) out[i] = 0;
+    if (!RGBDFE_IS_GROUP(ctx)) return impl::rgbdfe_graph_stats(ctx, out, n_out);
+    for (rgbdfe_ctx* c : ctx->group->children) {
+      const int rc = impl::rgbdfe_graph_stats(c, out, n_out);
+      if (rc != RGBDFE_OK) return rc;
+    }
+    return RGBDFE_OK;
+  });
 }
 
 int rgbdfe_sizeof_match_result(void) { return impl::rgbdfe_sizeof_match_result(); }

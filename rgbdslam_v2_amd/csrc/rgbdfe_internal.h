@@ -36,9 +36,13 @@ struct RansacConst {
 // launchers (defined in the .hip files)
 // returns the number of key planes written per pair (keys[pair][plane][row]); the consumer
 // takes the min over planes.  key_planes_capacity = planes the keys buffer can hold in total.
+// HammingGeometry = everything of a Hamming launch that depends on the batch's node sizes: query blocks per pair and
+// train-row splits (key planes) per pair.  Batches with equal (n_pairs, geometry) are the same launch -- what the
+// hipGraph cache of rgbdfe_api.hip keys on.
+struct HammingGeometry { uint32_t qblocks, tsplit; };
+HammingGeometry hamming_nn_geometry(uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity);
 uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,
-                           uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt,
-                           uint32_t key_planes_capacity, hipStream_t stream);
+                           uint32_t max_kp, uint32_t n_pairs, HammingGeometry geom, hipStream_t stream);
 // fp4 MFMA form of the same search (hamming_mfma.hip): descriptors expanded to one fp4 operand nibble per bit, 128 B per
 // row in MFMA fragment order, tiles of 32 rows; same keys, bit for bit.  mode 1: row term added by the MFMA (C operand),
 // mode 2: by v_add_f32.  Valid for max_kp <= 32768.
@@ -46,9 +50,9 @@ uint32_t hamming_mfma_tiles_per_slot(uint32_t max_kp);
 size_t hamming_mfma_slab_bytes(uint32_t max_nodes, uint32_t max_kp);
 void launch_hamming_expand(const uint32_t* node_rows, uint32_t* slab, uint32_t slot, uint32_t max_kp, uint32_t n,
                            hipStream_t stream);
+HammingGeometry hamming_mfma_geometry(uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity);
 uint32_t launch_hamming_mfma(const uint32_t* slab, const PairWork* work, uint32_t* keys, uint32_t max_kp,
-                             uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity,
-                             int mode, hipStream_t stream);
+                             uint32_t n_pairs, HammingGeometry geom, int mode, hipStream_t stream);
 // place_recognition.hip: every query descriptor votes k - rank for the k candidate nodes holding its nearest matches
 // (keys[candidate][plane][row] from the Hamming stage; k <= 8; candidates < 65536)
 void launch_place_votes(const uint32_t* keys, uint32_t planes, uint32_t max_kp, const PairWork* work, const uint32_t* seg,

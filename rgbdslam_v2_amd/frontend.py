@@ -754,6 +754,13 @@ class FrontEnd:
     def reset_kernel_time(self):
         self._check(self._L.rgbdfe_reset_kernel_time(self._ctx))
 
+    def graph_stats(self):
+        """The hipGraph cache of the ORB pair path (rgbdfe_graph_stats)."""
+        v = (C.c_int64 * 8)()
+        self._check(self._L.rgbdfe_graph_stats(self._ctx, v, 8))
+        names = ("captures", "launches", "misses", "plain_batches", "capture_failures", "launch_failures", "cached", "enabled")
+        return dict(zip(names, (int(x) for x in v)))
+
     def kernel_time(self, which: int):
         ms, n, p = C.c_double(0), C.c_int64(0), C.c_int64(0)
         self._check(self._L.rgbdfe_get_kernel_time(self._ctx, which, C.byref(ms), C.byref(n),

@@ -344,8 +344,9 @@ def test_detect_describe_batch_nodes(devs, grid):
 
 
 def test_detect_describe_batch_nodes_out_of_slots_leaves_a_usable_context():
-    """More frames with node ids than free node slots: the call fails with RGBDFE_ERR_CAPACITY part of the way through; the
-    context keeps working -- the nodes that were made can be matched and released, a later batch that fits succeeds."""
+    """More frames with node ids than free node slots: the call is refused with RGBDFE_ERR_CAPACITY before anything is
+    detected (all-or-nothing, like rgbdfe_upload_nodes: ADVICE r3); no node was made, no slot is lost -- a later batch that
+    needs every slot of the context succeeds."""
     from rgbdslam_v2_amd.frontend import FrontEnd, RgbdfeError
     seq = synth.make_image_sequence(n_frames=8, seed=43)
     idx = synth.forth_and_back(16, 8)
@@ -358,12 +359,9 @@ def test_detect_describe_batch_nodes_out_of_slots_leaves_a_usable_context():
     with pytest.raises(RgbdfeError):
         fe.detect_describe_batch(grays, masks, depths, *K, node_ids=np.arange(16, dtype=np.int32))
     made = [i for i in range(16) if fe.node_count(i) >= 0]      # rgbdfe_node_count: rows of a resident node, < 0 otherwise
-    assert len(made) <= 10
-    for i in made:
-        fe.release_node(i)
-    assert all(fe.node_count(i) < 0 for i in range(16))
-    out = fe.detect_describe_batch(grays[:8], masks[:8], depths[:8], *K, node_ids=np.arange(8, dtype=np.int32))
-    assert all(fe.node_count(i) == len(out[i][0]) for i in range(8)) and min(len(o[0]) for o in out) > 100
+    assert made == []
+    out = fe.detect_describe_batch(grays[:10], masks[:10], depths[:10], *K, node_ids=np.arange(10, dtype=np.int32))   # all 10 slots
+    assert all(fe.node_count(i) == len(out[i][0]) for i in range(10)) and min(len(o[0]) for o in out) > 100
     r = fe.match_pair_list([1, 2, 3], [0, 1, 2])
     assert (r["id1"] >= 0).sum() >= 2
     fe.close()

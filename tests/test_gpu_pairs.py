@@ -485,3 +485,46 @@ def test_upload_nodes_equals_single_uploads():
             b.upload_nodes([2], [np.zeros((2000, 32), np.uint8)], [np.zeros((2000, 4), np.float32)])   # > max_keypoints
         assert b.match_pair_list(pq, pt).tobytes() == a.match_pair_list(pq, pt).tobytes()
         a.close(); b.close()
+
+
+def test_graph_cache_keys_on_launch_geometry(monkeypatch):
+    """the hipGraph cache of the ORB pair path is keyed on what the launches depend on (pair count, the Hamming
+    stage's query blocks / train splits), not on the raw keypoint counts -- frames with different feature counts share
+    the captured graphs -- and a caller whose shapes never repeat stops paying for captures.  Same bytes as plain launches."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    F = 24
+    seq = synth.make_sequence(n_frames=F, n_kp=1000, n_world=3200, seed=21)
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(780, 1001, F)          # every node its own keypoint count, all with 4 query blocks of 256
+    batches = []
+    for _ in range(30):
+        q = rng.integers(1, F, 20).astype(np.int32)
+        t = (q - 1 - rng.integers(0, 6, 20) % q).astype(np.int32)
+        batches.append((q, t))
+
+    def run(graphs):
+        monkeypatch.setenv("RGBDFE_GRAPHS", "1" if graphs else "0")
+        fe = FrontEnd(device_id=0, max_nodes=F, max_keypoints=1024, max_pairs_per_batch=64)
+        for f in range(F):
+            fe.upload_node(f, seq["desc"][f][:sizes[f]], seq["xyz1"][f][:sizes[f]])
+        out = [fe.match_pair_list(q, t).tobytes() for q, t in batches]
+        st = fe.graph_stats()
+        # shapes that never repeat: 21, 22, 23, ... pairs per batch
+        for n in range(21, 61):
+            fe.match_pair_list(np.resize(batches[0][0], n), np.resize(batches[0][1], n))
+        st2 = fe.graph_stats()
+        fe.close()
+        return out, st, st2
+
+    plain, st_off, _ = run(False)
+    graphed, st, st2 = run(True)
+    assert graphed == plain
+    assert st_off["enabled"] == 0 and st_off["launches"] == 0 and st_off["captures"] == 0
+    assert st["enabled"] == 1
+    # 30 batches of 20 pairs over nodes of 24 different sizes: one capture per ring slot (4) and geometry -- the train
+    # split count can take two values around a tile boundary -- and every batch went out as a graph launch
+    assert st["launches"] == 30 and st["captures"] <= 8 and st["captures"] == st["misses"], st
+    assert st["plain_batches"] == 0 and st["capture_failures"] == 0 and st["launch_failures"] == 0, st
+    # 40 batches with 40 different pair counts: the first 8 misses in a row are captured, then only every 16th
+    new_caps = st2["captures"] - st["captures"]
+    assert st2["misses"] - st["misses"] == 40 and new_caps <= 8 + 3 and st2["plain_batches"] == 40 - new_caps, st2
