@@ -17,8 +17,8 @@ the invocation: `value` / `ms_per_step` are the median repetition, `repeats` lis
 computed from times measured in THIS run: per-stage HIP-event times of steps that run one batch at a time (`serial`),
 next to the pipelined step time the metric uses (`frac_serial` / `frac_pipelined`); counter-derived figures (`traffic`,
 `issue_roofline`) are static and name the `profiles/` file they come from.  At N = 1 the line also carries the
-`ransac_heavy` (depth noise 0.002 z^2), `sift` (configs[3]), `sift_extract`, `detect` (Level B frames/s) and
-`loop_closure` sub-records and the CPU baselines, and the results of the last step are checked against aggregate figures
+`ransac_heavy` (depth noise 0.002 z^2), `sift` (configs[3]), `sift_extract`, `detect` (Level B frames/s), `front_end`,
+`host_io` and `loop_closure` sub-records and the CPU baselines, and the results of the last step are checked against aggregate figures
 the oracle produced for the same seeded workload (EXPECTED; tests/test_gpu_pairs.py re-derives them bit for bit).
 """
 import argparse
@@ -41,14 +41,17 @@ SEED = 20260923
 REPEATS = 3                                # repetitions of the timed region (median reported)
 PMC_SUMMARY = "profiles/r04_pmc_summary.json"   # static counter figures (tools/profile_r03.sh + tools/make_pmc_summary.py)
 PMC_FALLBACK = "profiles/r03_pmc_summary.json"
-# Aggregates of one step's results as the ORACLE computes them (oracle/liboracle.so over the same seeded workload;
-# tests/test_gpu_pairs.py::test_whole_bench_step_matches_oracle / test_loop_closure_subrecord_matches_oracle compare every
-# pair bit for bit and re-derive these sums).  bench.py refuses to print a number whose results differ.
-EXPECTED = {
-    ("orb", 0.01): {"edges": 3959, "real_iterations": 800000, "inliers": 156016},
-    ("orb", 0.002): {"edges": 4000, "real_iterations": 669765, "inliers": 666572},
-    ("loop_closure", 0.01): {"edges": 810, "real_iterations": 3222000, "inliers": 40190},
-}
+# Aggregates of every workload this file prints a number for, as the ORACLE computes them (tools/make_bench_expected.py:
+# oracle/liboracle.so, oracle/orb_oracle.c and the compiled reference SiftGPU pipeline over the same seeded workloads,
+# offline on the CPU; committed as tests/golden/bench_expected.json).  The -m gpu tests compare the same workloads record by
+# record (tests/test_gpu_pairs.py::test_whole_bench_step_matches_oracle, test_loop_closure_subrecord_matches_oracle,
+# tests/test_gpu_bench_parity.py).  bench.py refuses to print a number whose results differ.
+EXPECTED_FILE = "tests/golden/bench_expected.json"
+try:
+    EXPECTED = json.load(open(os.path.join(ROOT, EXPECTED_FILE)))
+except Exception:  # noqa: BLE001
+    EXPECTED = {}
+SIFT_DESC_RTOL = 2e-3   # sift_extract: sum of |descriptor elements| per frame vs the reference's (libm differences)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (int32 VALU lanes/s)
 
@@ -64,18 +67,122 @@ def algorithmic_bytes(n_kp, m):
     return pair, hamming, ransac
 
 
-def parity_check(key, res):
-    """Sums over one step's records vs the oracle's (EXPECTED): raises when they differ."""
-    exp = EXPECTED.get(key)
-    got = {"edges": int((res["id1"] >= 0).sum()), "real_iterations": int(res["real_iterations"].astype(np.int64).sum()),
-           "inliers": int(res["n_inl"].astype(np.int64).sum())}
+def expected(*path):
+    """EXPECTED[path[0]][path[1]]... (keys as strings), or None."""
+    d = EXPECTED
+    for k in path:
+        if not isinstance(d, dict) or str(k) not in d:
+            return None
+        d = d[str(k)]
+    return d
+
+
+def pair_aggregates(res):
+    """Sums over result records (RESULT_DTYPE or COMPACT_DTYPE): what the oracle constants of the pair workloads are."""
+    return {"edges": int((res["id1"] >= 0).sum()), "real_iterations": int(res["real_iterations"].astype(np.int64).sum()),
+            "inliers": int(res["n_inl"].astype(np.int64).sum())}
+
+
+def features_checksum(frames):
+    """(keypoints, descriptors, points) of a run of frames -> {"keypoints": total, "crc32": of every keypoint field,
+    descriptor byte and point coordinate in frame order}: the constants of the detect / front_end sub-records."""
+    import zlib
+    crc, n = 0, 0
+    for kp, desc, xyz in frames:
+        n += len(kp)
+        for f in ("x", "y", "size", "angle", "response", "octave"):
+            crc = zlib.crc32(np.ascontiguousarray(kp[f]).tobytes(), crc)
+        crc = zlib.crc32(np.ascontiguousarray(desc, np.uint8).tobytes(), crc)
+        crc = zlib.crc32(np.ascontiguousarray(xyz, np.float32).tobytes(), crc)
+    return {"keypoints": int(n), "crc32": int(crc)}
+
+
+def sift_features_checksum(frames):
+    """SIFT extraction outputs of a run of frames: feature counts and positions are bit-exact against the reference
+    (crc32 over x, y), descriptors within a libm tolerance (sum of |elements| per run, compared with SIFT_DESC_RTOL)."""
+    import zlib
+    crc, counts, dsum = 0, [], 0.0
+    for kp, desc in frames:
+        counts.append(int(len(kp)))
+        crc = zlib.crc32(np.ascontiguousarray(kp["x"], np.float32).tobytes(), crc)
+        crc = zlib.crc32(np.ascontiguousarray(kp["y"], np.float32).tobytes(), crc)
+        dsum += float(np.abs(np.asarray(desc, np.float64)).sum())
+    return {"features_per_frame": counts, "xy_crc32": int(crc), "descriptor_abs_sum": dsum}
+
+
+def check_against(exp, got, what, source, approx=()):
+    """parity_check block of a (sub-)record: raises when `got` differs from the oracle constants `exp`."""
     if exp is None:
         return {"checked": False, "got": got, "note": "no oracle constants for this workload (non-default flags)"}
-    if got != exp:
-        raise SystemExit("bench.py: results of the timed workload differ from the oracle's aggregates: got %r, expected %r"
-                         % (got, exp))
-    return {"checked": True, "ok": True, "oracle_aggregates": exp,
-            "source": "oracle/liboracle.so on the same seeded workload; every pair bit for bit in tests/test_gpu_pairs.py"}
+    bad = []
+    for k, v in exp.items():
+        if k in approx:
+            if abs(got[k] - v) > SIFT_DESC_RTOL * abs(v):
+                bad.append(k)
+        elif got.get(k) != v:
+            bad.append(k)
+    if bad:
+        raise SystemExit("bench.py: results of %s differ from the oracle's constants in %s: got %r, expected %r" % (what, bad, got, exp))
+    out = {"checked": True, "ok": True, "oracle_aggregates": exp, "source": source}
+    if approx:
+        out["tolerance"] = {k: SIFT_DESC_RTOL for k in approx}
+    return out
+
+
+def parity_check(path, res):
+    """Sums over one step's records vs the oracle's (EXPECTED[path...]): raises when they differ."""
+    return check_against(expected(*path) if path else None, pair_aggregates(res), "the timed workload %r" % (path,),
+                         "oracle/liboracle.so on the same seeded workload (%s); every pair bit for bit in tests/test_gpu_pairs.py, "
+                         "tests/test_gpu_bench_parity.py" % EXPECTED_FILE)
+
+
+# ---- the workloads of the sub-records (tools/make_bench_expected.py builds the same ones for the oracle) ------------------
+def orb_workload(world, frames=N_FRAMES, n_kp=N_KP, pairs_per_frame=PAIRS_PER_FRAME, depth_noise=0.01):
+    """configs[1] at `world` ranks (weak scaling): the nodes and the GLOBAL pair list (world x 4000 pairs; rank r owns pairs r::world)."""
+    from rgbdslam_v2_amd import synth
+    seq = synth.make_sequence(n_frames=frames, n_kp=n_kp, seed=SEED, depth_noise=depth_noise)
+    per_frame = min(pairs_per_frame * world, frames - 1)
+    pq, pt = synth.candidate_pairs(frames, per_frame=per_frame, seed=SEED)
+    return seq, pq, pt
+
+
+SIFT_FRAMES = 100
+
+
+def sift_workload(seq):
+    """configs[3]: the first 100 nodes of configs[1] with 128-d float descriptors, 20 candidates each = 2000 pairs."""
+    from rgbdslam_v2_amd import synth
+    sd = synth.sift_descriptors_like(seq["desc"][:SIFT_FRAMES], seed=SEED)
+    pq, pt = synth.candidate_pairs(SIFT_FRAMES, per_frame=20, seed=SEED)
+    return sd, pq, pt
+
+
+DETECT_WORKLOADS = ((640, 480, 1000, 28, 112), (1280, 960, 4000, 14, 56))   # w, h, keypoints, generated frames, frames per run
+
+
+def detect_workload(w, h, n_base, n_run):
+    """A recorded sequence for the detect sub-records: n_base generated frames walked forth and back for n_run frames."""
+    from rgbdslam_v2_amd import synth
+    seq = synth.make_image_sequence(n_frames=n_base, seed=1, width=w, height=h)
+    masks = [np.where(m > 0, 255, 0).astype(np.uint8) for m in seq["mask"]]
+    idx = synth.forth_and_back(n_run, n_base)
+    K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    return seq, masks, [seq["gray"][i] for i in idx], [masks[i] for i in idx], [seq["depth"][i] for i in idx], K
+
+
+FRONT_END = dict(n_base=28, n_run=112, cand=20, n_kp=1000)
+
+
+def front_end_pairs(n_run, cand):
+    pq = np.array([f for f in range(1, n_run) for c in range(1, min(cand, f) + 1)], np.int32)
+    pt = np.array([f - c for f in range(1, n_run) for c in range(1, min(cand, f) + 1)], np.int32)
+    return pq, pt
+
+
+def sift_extract_workload():
+    from rgbdslam_v2_amd import synth
+    seq = synth.make_image_sequence(n_frames=8, seed=1)
+    return seq, [seq["gray"][i] for i in synth.forth_and_back(32, len(seq["gray"]))]
 
 
 def load_pmc():
@@ -108,9 +215,10 @@ def main():
     ap.add_argument("--hamming-mode", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="-1 = the library's default (fp4 MFMA contraction), 0 = xor+popcount kernel, 2 = MFMA with VALU row term")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records")
-    ap.add_argument("--gather", choices=["compact", "full"], default="compact",
-                    help="N > 1: payload of the per-step all-gather -- rgbdfe_compact_result (144 B per pair, default) or the "
-                         "whole 1744-byte record")
+    ap.add_argument("--gather", choices=["inliers", "compact", "full"], default="inliers",
+                    help="N > 1: payload of the per-step all-gather -- the inlier stream (default: 104-byte header + 4 bytes per "
+                         "inlier match, what GraphManager reads of a MatchingResult), rgbdfe_compact_result (144 B per pair: "
+                         "header + inlier mask, the lists stay behind) or the whole 1744-byte record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -145,10 +253,8 @@ def main():
     from rgbdslam_v2_amd.dist import shard_pairs
 
     F, N = args.frames, args.kp
-    seq = synth.make_sequence(n_frames=F, n_kp=N, seed=SEED, depth_noise=args.depth_noise)
     # global pair list: per frame 20*world candidates (weak scaling), sharded round-robin
-    per_frame = min(args.pairs_per_frame * world, F - 1)
-    pq_all, pt_all = synth.candidate_pairs(F, per_frame=per_frame, seed=SEED)
+    seq, pq_all, pt_all = orb_workload(world, F, N, args.pairs_per_frame, args.depth_noise)
     pq, pt = shard_pairs(pq_all, pt_all, rank, world)
     n_local = len(pq)
     counts = [n_local]
@@ -177,13 +283,17 @@ def main():
             fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
 
     rec_bytes = RESULT_DTYPE.itemsize
-    from rgbdslam_v2_amd._lib import COMPACT_DTYPE
+    from rgbdslam_v2_amd._lib import COMPACT_DTYPE, INLIER_HEADER_DTYPE, RGBDFE_MAX_MATCHES
     compact = world > 1 and args.gather == "compact"
-    gat_bytes = COMPACT_DTYPE.itemsize if compact else rec_bytes
+    inliers = world > 1 and args.gather == "inliers"
+    hdr_bytes = INLIER_HEADER_DTYPE.itemsize
+    stream_cap = n_pad * (hdr_bytes + 4 * RGBDFE_MAX_MATCHES)      # a shard's inlier stream at its largest
+    gat_bytes = COMPACT_DTYPE.itemsize if compact else rec_bytes    # (fixed-size payloads)
     rccl_ranks = None
+    cdev = "cpu" if host_coll else "cuda"
     if world > 1:
         # what the collective library itself saw: every rank contributes 1 through the backend the steps use
-        ones = torch.ones(1, dtype=torch.int32, device="cpu" if host_coll else "cuda")
+        ones = torch.ones(1, dtype=torch.int32, device=cdev)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
     # Steps are pipelined: step k is submitted to one of the context's internal streams while
@@ -191,11 +301,45 @@ def main():
     # buffers keeps every step's output alive until its all-gather has consumed it.
     NBUF = 4
     d_local = [torch.zeros(n_pad * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
-    d_send = [torch.zeros(n_pad * gat_bytes, dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if compact else d_local
-    d_all = torch.zeros(world * n_pad * gat_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    if inliers:
+        d_send = [torch.zeros(stream_cap, dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
+        d_tot = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(NBUF)]
+        h_tot = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(NBUF)]
+        ev_tot = [torch.cuda.Event() for _ in range(NBUF)]
+        d_all = torch.zeros(world * stream_cap, dtype=torch.uint8, device="cuda")
+        d_tots = torch.zeros(world, dtype=torch.int64, device=cdev)
+    else:
+        d_send = [torch.zeros(n_pad * gat_bytes, dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if compact else d_local
+        d_all = torch.zeros(world * n_pad * gat_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
     consumed = [None] * NBUF
     stream = torch.cuda.current_stream().cuda_stream
-    state = {"k": 0}
+    state = {"k": 0, "open": None, "bytes": 0, "gathers": 0, "last": None}
+
+    def gather_inliers(b):
+        """The two collectives of step b's inlier streams: the list lengths (one int64 per rank), then the streams padded to the
+        longest.  The lengths come through the host -- which is why a step's gather is issued one step late (step())."""
+        ev_tot[b].synchronize()
+        mine = torch.tensor([int(h_tot[b].item())], dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(d_tots, mine)
+        totals = [int(v) for v in d_tots.cpu().tolist()]
+        nbytes = n_pad * hdr_bytes + 4 * max(totals)
+        out = d_all[: world * nbytes]
+        if host_coll:
+            h_all = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(h_all, d_send[b][:nbytes].cpu())
+            out.copy_(h_all)
+        else:
+            dist.all_gather_into_tensor(out, d_send[b][:nbytes])
+        consumed[b] = torch.cuda.Event()
+        consumed[b].record()
+        state["bytes"] += world * nbytes
+        state["gathers"] += 1
+        state["last"] = (nbytes, totals)
+
+    def flush():
+        if state["open"] is not None:
+            gather_inliers(state["open"])
+            state["open"] = None
 
     def step():
         b = state["k"] % NBUF
@@ -208,6 +352,17 @@ def main():
             ticket = fe.submit_pair_list(pq, pt, d_local[b].data_ptr())
         if world > 1:
             fe.wait_ticket(ticket, stream)  # torch's stream waits for this batch only
+            if inliers:
+                # headers + (query row, train row) of every inlier match: inlier_scan_kernel + inlier_list_kernel on torch's
+                # stream; the length of the list block goes to the host (pinned).  The gather itself needs that length, so it is
+                # issued while the NEXT step computes: the host never waits for the step it has just submitted.
+                fe.pack_inliers(d_local[b].data_ptr(), n_local, n_pad, d_send[b].data_ptr(), d_tot[b].data_ptr(), stream)
+                h_tot[b].copy_(d_tot[b], non_blocking=True)
+                ev_tot[b].record()
+                prev, state["open"] = state["open"], b
+                if prev is not None:
+                    gather_inliers(prev)
+                return
             if compact:  # header + inlier mask of every record (144 of 1744 B): compact_pack_kernel on torch's stream
                 fe.pack_compact(d_local[b].data_ptr(), n_local, d_send[b].data_ptr(), stream)
             if host_coll:
@@ -218,11 +373,16 @@ def main():
                 dist.all_gather_into_tensor(d_all, d_send[b])
             consumed[b] = torch.cuda.Event()
             consumed[b].record()
+            state["bytes"] += d_all.numel()
+            state["gathers"] += 1
 
     for _ in range(args.warmup):
         step()
+    if inliers:
+        flush()
     fe.synchronize()
     torch.cuda.synchronize()
+    state["bytes"] = state["gathers"] = 0
     fe.set_profiling(True)
     fe.reset_kernel_time()
     # The timed region -- exactly K steps between barrier + synchronize on both sides, max over ranks -- REPEATS times;
@@ -236,6 +396,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        if inliers:
+            flush()                 # the last step's gather (K steps = K gathers inside the timed region)
         fe.synchronize()            # every internal stream of the context
         torch.cuda.synchronize()    # device-wide
         if world > 1:
@@ -286,8 +448,37 @@ def main():
     res = np.frombuffer(last.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[:n_local]
     edge_frac = float((res["id1"] >= 0).mean()) if n_local else 0.0
     mean_iters = float(res["real_iterations"].mean()) if n_local else 0.0
-    default_workload = (world == 1 and not sift and F == N_FRAMES and N == N_KP and args.pairs_per_frame == PAIRS_PER_FRAME)
-    parity = parity_check(("orb", args.depth_noise) if default_workload else None, res) if n_local else None
+    default_workload = (not sift and F == N_FRAMES and N == N_KP and args.pairs_per_frame == PAIRS_PER_FRAME)
+    # N = 1: this rank's records; N > 1: what the all-gather of the last step left on rank 0 -- every rank's records, as the
+    # consumer of the gather sees them -- against the oracle's sums over the world x 4000 pairs of the global list
+    list_entries = None
+    if world > 1:
+        torch.cuda.synchronize()
+        if inliers:
+            from rgbdslam_v2_amd._lib import parse_inlier_stream
+            nbytes, totals = state["last"]
+            g = d_all[: world * nbytes].cpu().numpy().reshape(world, nbytes)
+            parsed = [parse_inlier_stream(g[r], n_pad, totals[r]) for r in range(world)]
+            res_all = np.concatenate([parsed[r][0][:counts[r]] for r in range(world)])
+            list_entries = int(sum(totals))
+            # every header's list lies inside its rank's list block, lists follow each other without gaps
+            for r in range(world):
+                h = parsed[r][0][:counts[r]]
+                assert np.array_equal(h["first_inlier"], np.concatenate([[0], np.cumsum(h["n_inl"])[:-1]])) and \
+                    int(h["n_inl"].sum()) == totals[r], "inlier stream of rank %d is inconsistent" % r
+        else:
+            g = np.frombuffer(d_all.cpu().numpy().tobytes(), dtype=COMPACT_DTYPE if compact else RESULT_DTYPE).reshape(world, n_pad)
+            res_all = np.concatenate([g[r, :counts[r]] for r in range(world)])
+    else:
+        res_all = res
+    parity = parity_check(("orb", args.depth_noise, world) if default_workload else None, res_all) if len(res_all) else None
+    if parity is not None and world > 1:
+        parity["records"] = "gathered on rank 0: %d records of %d ranks" % (len(res_all), world)
+        if list_entries is not None:
+            parity["inlier_list_entries"] = list_entries
+            if parity.get("checked") and list_entries != parity["oracle_aggregates"]["inliers"]:
+                raise SystemExit("bench.py: the gathered inlier lists hold %d matches, the oracle counts %d"
+                                 % (list_entries, parity["oracle_aggregates"]["inliers"]))
     rep_values = [sum(counts) * args.steps / e for e in rep_elapsed]
 
     if rank == 0:
@@ -389,8 +580,17 @@ def main():
             "timing": timing,
         }
         if world > 1:
-            out["gather"] = {"payload": "rgbdfe_compact_result" if compact else "rgbdfe_match_result",
-                             "bytes_per_record": gat_bytes, "bytes_per_step_per_rank": world * n_pad * gat_bytes,
+            per_step = state["bytes"] / max(state["gathers"], 1)
+            out["gather"] = {"payload_option": args.gather,
+                             "payload": "inlier stream: rgbdfe_inlier_header (104 B) + 4 B per inlier match" if inliers else
+                                        ("rgbdfe_compact_result" if compact else "rgbdfe_match_result"),
+                             "bytes_per_record": round(per_step / world / max(n_pad, 1), 1) if inliers else gat_bytes,
+                             "bytes_per_step_per_rank": round(per_step),
+                             "bytes_per_step_per_rank_by_payload": {
+                                 "inliers": round(per_step) if inliers else None,
+                                 "compact": world * n_pad * COMPACT_DTYPE.itemsize, "full": world * n_pad * rec_bytes},
+                             "gathers_in_timed_regions": state["gathers"],
+                             "collectives_per_step": 2 if inliers else 1,
                              "backend": backend, "rccl_ranks": rccl_ranks,
                              "transport": "RCCL ncclAllGather via torch.distributed (nccl backend)" if backend == "nccl"
                                           else "host tensors (%s; test mode)" % backend}
@@ -398,7 +598,7 @@ def main():
             fe.close()
             fe = None
             try:
-                out["sift"] = sift_subrecord(seq, local_rank)
+                out["sift"] = sift_subrecord(seq, local_rank, default_workload and args.depth_noise == 0.01)
             except Exception as e:  # noqa: BLE001 -- a sub-record must not take the headline line down
                 out["sift"] = {"error": repr(e)}
             try:
@@ -413,6 +613,12 @@ def main():
                 out["front_end"] = front_end_subrecord(local_rank)
             except Exception as e:  # noqa: BLE001
                 out["front_end"] = {"error": repr(e)}
+            try:
+                out["host_io"] = host_io_subrecord(seq, pq, pt, local_rank, default_workload and args.depth_noise == 0.01)
+            except SystemExit:
+                raise
+            except Exception as e:  # noqa: BLE001
+                out["host_io"] = {"error": repr(e)}
             try:
                 out["loop_closure"] = loop_closure_subrecord(local_rank, args.depth_noise)
             except SystemExit:
@@ -503,17 +709,16 @@ def match_roofline(n_kp, n_pairs, ham_ms, hamming_mode):
             "avg_launch_ms": round(ham_ms, 4), "time_basis": "serial"}
 
 
-def sift_subrecord(seq, device):
+def sift_subrecord(seq, device, default=True):
     """configs[3] on a bounded workload (100 frames x 20 candidates = 2000 pairs per step): pairs/s and the MFMA
     fraction of the dot-product kernel, serial stage times."""
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd._lib import KERNEL_RANSAC, KERNEL_SIFT_DOT, KERNEL_SIFT_FINISH, RESULT_DTYPE
     from rgbdslam_v2_amd.frontend import FrontEnd
     import torch
-    F = 100
+    F = SIFT_FRAMES
     N = seq["desc"].shape[1]
-    sd = synth.sift_descriptors_like(seq["desc"][:F], seed=SEED)
-    pq, pt = synth.candidate_pairs(F, per_frame=20, seed=SEED)
+    sd, pq, pt = sift_workload(seq)
     fe = FrontEnd(device_id=device, max_nodes=F, max_keypoints=((N + 63) // 64) * 64, max_pairs_per_batch=len(pq), seed=SEED)
     for f in range(F):
         fe.upload_sift_node(f, sd[f], seq["xyz1"][f])
@@ -537,7 +742,9 @@ def sift_subrecord(seq, device):
     fin_ms, _, _ = fe.kernel_time(KERNEL_SIFT_FINISH)
     rsc_ms, _, _ = fe.kernel_time(KERNEL_RANSAC)
     dot_ms, fin_ms, rsc_ms = dot_ms / max(nl, 1), fin_ms / max(nl, 1), rsc_ms / max(nl, 1)
+    res = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=RESULT_DTYPE)[: len(pq)]
     fe.close()
+    parity = parity_check(("sift", "0.01") if default else None, res)
     tf = 2.0 * N * N * 128 * len(pq) / (dot_ms * 1e-3) / 1e12 if dot_ms else 0.0
     pmc, pmc_src = load_pmc()
     traffic = None
@@ -554,7 +761,38 @@ def sift_subrecord(seq, device):
                          "avg_launch_ms": round(dot_ms, 4), "time_basis": "serial", "traffic": traffic,
                          "traffic_source": "%s [sift] (static: both passes of the dot-product stage, FETCH_SIZE x 2 + "
                                            "WRITE_SIZE)" % pmc_src},
-            "serial_stage_ms": {"dot_top2": round(dot_ms, 4), "finish": round(fin_ms, 4), "select_ransac": round(rsc_ms, 4)}}
+            "serial_stage_ms": {"dot_top2": round(dot_ms, 4), "finish": round(fin_ms, 4), "select_ransac": round(rsc_ms, 4)},
+            "parity_check": parity}
+
+
+def host_io_subrecord(seq, pq, pt, device, default=True):
+    """The headline workload through the synchronous host-buffer entry point (the timed region of the
+    headline leaves its results in HBM): rgbdfe_match_pair_list -- pair ids in, the 1744-byte result records of all 4000
+    pairs back in the caller's memory over PCIe -- and the cost of making a node resident from host arrays."""
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    F, N = seq["desc"].shape[0], seq["desc"].shape[1]
+    fe = FrontEnd(device_id=device, max_nodes=F, max_keypoints=((N + 63) // 64) * 64, max_pairs_per_batch=len(pq), seed=SEED)
+    try:
+        t0 = time.perf_counter()
+        for f in range(F):
+            fe.upload_node(f, seq["desc"][f], seq["xyz1"][f])
+        t_up = (time.perf_counter() - t0) / F
+        fe.match_pair_list(pq, pt)
+        per = []
+        for _ in range(REPEATS + 2):
+            t0 = time.perf_counter()
+            out = fe.match_pair_list(pq, pt)
+            per.append(time.perf_counter() - t0)
+    finally:
+        fe.close()
+    per.sort()
+    dt = per[len(per) // 2]
+    return {"metric": "frame-pairs matched+RANSAC/sec, results returned to host memory (rgbdfe_match_pair_list)",
+            "value": round(len(pq) / dt, 1), "unit": "frame-pairs/s", "pairs_per_call": int(len(pq)),
+            "ms_per_call": round(dt * 1e3, 4), "ms_per_call_repeats": [round(v * 1e3, 4) for v in per],
+            "result_bytes_per_call": int(out.nbytes), "node_upload_us": round(t_up * 1e6, 1),
+            "note": "host wall clock, PCIe both ways and the library's pinned staging included; never the headline `value`",
+            "parity_check": parity_check(("orb", "0.01", 1) if default else None, out)}
 
 
 def loop_closure_subrecord(device, depth_noise):
@@ -643,7 +881,7 @@ def ransac_heavy_subrecord(device, n_kp, n_frames, pairs_per_frame):
     mode = fe.hamming_mode
     fe.close()
     default = n_kp == N_KP and n_frames == N_FRAMES and pairs_per_frame == PAIRS_PER_FRAME
-    parity = parity_check(("orb", noise) if default else None, res)
+    parity = parity_check(("orb", noise, 1) if default else None, res)
     pmc, pmc_src = load_pmc()
     _, _, b_rsc = algorithmic_bytes(n_kp, MAX_MATCHES)
     gbs = b_rsc * len(pq) / (rsc_ms * 1e-3) / 1e9 if rsc_ms else 0.0
@@ -668,7 +906,7 @@ def sift_extract_subrecord(device):
     640x480 frames, host buffers in and out; algorithmic bytes per frame stated in DESIGN.md 4.11."""
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd.frontend import FrontEnd
-    seq = synth.make_image_sequence(n_frames=8, seed=1)
+    seq, run = sift_extract_workload()
     fe = FrontEnd(device_id=device, max_nodes=4, max_keypoints=64, max_pairs_per_batch=8)
     try:
         for f in range(2):
@@ -681,7 +919,6 @@ def sift_extract_subrecord(device):
                 tot += len(kp)
         dt = time.perf_counter() - t0
         # the same frames as a run through the batch entry point (8 frames per launch chain), 32 frames per call
-        run = [seq["gray"][i] for i in synth.forth_and_back(32, len(seq["gray"]))]
         for _ in range(2):
             fe.sift_detect_batch(run, copy=False)
         per_frame = []
@@ -691,8 +928,14 @@ def sift_extract_subrecord(device):
             per_frame.append((time.perf_counter() - t0) / len(run))
         per_frame.sort()
         dt_batch = per_frame[len(per_frame) // 2]
+        # the outputs of the batch entry point over the generated frames against the compiled reference's (constants)
+        got = sift_features_checksum(fe.sift_detect_batch(list(seq["gray"])))
     finally:
         fe.close()
+    parity = check_against(expected("sift_extract", "640x480"), got, "the sift_extract sub-record",
+                           "SiftGPU's own kernels + host code compiled on a CPU emulation (oracle/_ref/libref_siftgpu.so) over the "
+                           "same frames (%s); planes / candidates / descriptors per feature in tests/test_gpu_sift_extract.py" % EXPECTED_FILE,
+                           approx=("descriptor_abs_sum",))
     frames = reps * len(seq["gray"])
     w, h = seq["gray"][0].shape[1], seq["gray"][0].shape[0]
     b_frame = sift_extract_bytes(w, h, tot / frames)
@@ -714,7 +957,8 @@ def sift_extract_subrecord(device):
                          "traffic": prof.get("hbm_bytes_per_frame"),
                          "kernel_time_frac": round(b_frame / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 6) if k_ns else None,
                          "kernel_us_per_frame": round(k_ns / 1e3, 2) if k_ns else None,
-                         "traffic_source": "%s [sift_extract]" % pmc_src}}
+                         "traffic_source": "%s [sift_extract]" % pmc_src},
+            "parity_check": parity}
 
 
 def sift_extract_bytes(w, h, n_kp):
@@ -734,16 +978,10 @@ def front_end_subrecord(device):
     rgbdfe_match_pair_list for every new node against its 20 predecessors -- host buffers in and out."""
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd.frontend import FrontEnd
-    n_base, n_run, cand, n_kp = 28, 112, 20, 1000
-    seq = synth.make_image_sequence(n_frames=n_base, seed=1)
-    idx = synth.forth_and_back(n_run, n_base)
-    grays, depths = [seq["gray"][i] for i in idx], [seq["depth"][i] for i in idx]
-    masks = [np.where(seq["mask"][i] > 0, 255, 0).astype(np.uint8) for i in idx]
-    K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
-    pq = np.array([f for f in range(1, n_run) for c in range(1, min(cand, f) + 1)], np.int32)
-    pt = np.array([f - c for f in range(1, n_run) for c in range(1, min(cand, f) + 1)], np.int32)
-    fe = FrontEnd(device_id=device, max_nodes=n_run, max_keypoints=1024, max_pairs_per_batch=len(pq))
-    fe.detector_configure(max_keypoints=n_kp)
+    n_base, n_run, cand, n_kp = FRONT_END["n_base"], FRONT_END["n_run"], FRONT_END["cand"], FRONT_END["n_kp"]
+    _, _, grays, masks, depths, K = detect_workload(640, 480, n_base, n_run)
+    pq, pt = front_end_pairs(n_run, cand)
+    fe = FrontEnd(device_id=device, max_nodes=n_run, max_keypoints=1024, max_pairs_per_batch=len(pq), seed=SEED)
     per, parts, edges = [], None, 0
     ids = np.arange(n_run, dtype=np.int32)
     try:
@@ -751,8 +989,11 @@ def front_end_subrecord(device):
             for f in range(n_run):
                 if rep:
                     fe.release_node(f)
+            # every pass starts from createDetector's state (the per-cell thresholds adapt over a run): the passes are the same
+            # work, and their outputs the ones the oracle constants were made from
+            fe.detector_configure(max_keypoints=n_kp)
             t0 = time.perf_counter()
-            fe.detect_describe_batch(grays, masks, depths, *K, node_ids=ids)     # features to the host AND resident nodes
+            feats = fe.detect_describe_batch(grays, masks, depths, *K, node_ids=ids)     # features to the host AND resident nodes
             t1 = time.perf_counter()
             res = fe.match_pair_list(pq, pt)
             t3 = time.perf_counter()
@@ -762,6 +1003,10 @@ def front_end_subrecord(device):
             edges = int((res["id1"] >= 0).sum())
     finally:
         fe.close()
+    got = dict(features_checksum(feats), **pair_aggregates(res))
+    parity = check_against(expected("front_end", "640x480_orb1000"), got, "the front_end sub-record",
+                           "oracle/orb_oracle.c (detect + describe + projectTo3D, frame after frame) and oracle/liboracle.so (the "
+                           "pairs over the oracle's features) on the same frames (%s)" % EXPECTED_FILE)
     per.sort()
     dt = per[len(per) // 2]
     return {"metric": "frames through detect + describe + node upload + 20 candidate pairs each, per second (640x480, ORB-1000)",
@@ -770,7 +1015,8 @@ def front_end_subrecord(device):
             "ms_per_frame_parts_last_run": {"detect_describe_batch_nodes": round(parts[0] * 1e3, 4),
                                             "match_pair_list": round(parts[1] * 1e3, 4)},
             "note": "host wall clock; rgbdfe_detect_describe_batch_nodes returns the features to the host and leaves them resident "
-                    "as nodes (device-to-device), rgbdfe_match_pair_list returns the result records; median of %d runs" % REPEATS}
+                    "as nodes (device-to-device), rgbdfe_match_pair_list returns the result records; median of %d runs" % REPEATS,
+            "parity_check": parity}
 
 
 def detect_subrecord(device):
@@ -781,9 +1027,8 @@ def detect_subrecord(device):
     out = {}
     # single calls over the generated frames; the batch entry point over a run of 16 / 8 super-frames of 7 (a recorded sequence:
     # the generated frames forth and back) -- its pipeline is three super-frames deep, a short run would time fill and drain
-    for (w, h, n_kp, n_base, n_run) in ((640, 480, 1000, 28, 112), (1280, 960, 4000, 14, 56)):
-        seq = synth.make_image_sequence(n_frames=n_base, seed=1, width=w, height=h)
-        masks = [np.where(m > 0, 255, 0).astype(np.uint8) for m in seq["mask"]]
+    for (w, h, n_kp, n_base, n_run) in DETECT_WORKLOADS:
+        seq, masks, grays, mks, depths, K = detect_workload(w, h, n_base, n_run)
         fe = FrontEnd(device_id=device, max_nodes=4, max_keypoints=((n_kp + 63) // 64) * 64, max_pairs_per_batch=8)
         fe.detector_configure(max_keypoints=n_kp)
         for f in range(min(3, n_base)):
@@ -795,9 +1040,6 @@ def detect_subrecord(device):
                                           seq["cx"], seq["cy"])
             tot += len(kp)
         dt = (time.perf_counter() - t0) / n_base
-        K = (seq["fx"], seq["fy"], seq["cx"], seq["cy"])
-        idx = synth.forth_and_back(n_run, n_base)
-        grays, depths, mks = [seq["gray"][i] for i in idx], [seq["depth"][i] for i in idx], [masks[i] for i in idx]
         for _ in range(2):                      # the first calls of a run length pay page faults and thread wake-ups
             fe.detect_describe_batch(grays, mks, depths, *K)
         per_frame = []
@@ -807,11 +1049,18 @@ def detect_subrecord(device):
             per_frame.append((time.perf_counter() - t0) / n_run)
         per_frame.sort()
         dt_batch = per_frame[len(per_frame) // 2]
+        # one more run from createDetector's state (the thresholds adapt from call to call): the outputs the oracle constants
+        # were made from
+        fe.detector_configure(max_keypoints=n_kp)
+        got = features_checksum(fe.detect_describe_batch(grays, mks, depths, *K))
         fe.close()
+        key = "%dx%d_orb%d" % (w, h, n_kp)
+        parity = check_against(expected("detect", key), got, "the detect sub-record %s" % key,
+                               "oracle/orb_oracle.c (detect + describe + projectTo3D, frame after frame from a fresh detector) on the "
+                               "same frames (%s); every field per frame in tests/test_gpu_orb.py" % EXPECTED_FILE)
         b_frame = 13.4 * w * h + 64 * n_kp
         gbs = b_frame / dt / 1e9
         gbs_batch = b_frame / dt_batch / 1e9
-        key = "%dx%d_orb%d" % (w, h, n_kp)
         pmc, pmc_src = load_pmc()
         prof = (pmc.get("detect") or {}).get(key) or {}
         k_ns = prof.get("kernel_ns_per_frame")
@@ -832,7 +1081,8 @@ def detect_subrecord(device):
                          "kernel_time_frac": round(b_frame / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 6) if k_ns else None,
                          "kernel_us_per_frame": round(k_ns / 1e3, 2) if k_ns else None,
                          "traffic_source": "%s [detect] (static: all kernels of a frame summed, FETCH_SIZE x 2 + WRITE_SIZE; "
-                                           "kernel time from the kernel trace of the same run)" % pmc_src}}
+                                           "kernel time from the kernel trace of the same run)" % pmc_src},
+            "parity_check": parity}
     return out
 
 

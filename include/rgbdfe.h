@@ -98,6 +98,25 @@ typedef struct {
   uint64_t inlier_mask[RGBDFE_MASK_WORDS];
 } rgbdfe_compact_result;
 
+/* The inlier form of a shard's results: what the consumer of the multi-GPU gather reads of a MatchingResult -- the edge
+ * (ids, transform, information scale), rmse and counts as above, and the inlier matches' (queryIdx, trainIdx)
+ * (GraphManager::updateInlierFeatures, graph_manager.cpp:409-419) -- without the all_matches lists and without a second
+ * pair op on the receiving device.  A shard of n pairs is ONE byte stream:
+ *   n_headers x rgbdfe_inlier_header   (the leading 104 bytes of rgbdfe_match_result; `first_inlier` = position of the pair's
+ *                                       first inlier in the list block; headers n .. n_headers-1 are padding: ids -1, no inliers)
+ *   total x uint32                     (the list block: query row | train row << 16 of every inlier, pair after pair, inliers
+ *                                       in match order = ascending bit of inlier_mask)
+ * total = sum of n_inl: 104 + 4 * n_inl bytes per pair instead of 1744 (configs[1]: ~260).  The default payload of
+ * bench.py --gpus N. */
+typedef struct {
+  int32_t  id1, id2, n_all, n_inl;
+  float    rmse;
+  float    trafo[16];
+  uint32_t first_inlier;
+  double   info_scale;
+  int32_t  valid_iterations, real_iterations;
+} rgbdfe_inlier_header;
+
 typedef struct rgbdfe_ctx rgbdfe_ctx;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -148,6 +167,13 @@ int  rgbdfe_match_pair_list_allgather_compact(rgbdfe_ctx* ctx, const int32_t* qu
  * own ncclAllGather (bench.py --gpus N).  Single-device contexts only. */
 int  rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void* d_compact, void* stream);
 int  rgbdfe_sizeof_compact_result(void);
+/* d_records (n rgbdfe_match_result in HBM) -> the inlier stream of the shard at d_stream (see rgbdfe_inlier_header; capacity
+ * n_headers * 104 + 4 * sum of n_inl bytes, at most n_headers * 104 + n * 4 * RGBDFE_MAX_MATCHES), *d_total (device int32) =
+ * entries of the list block; enqueued on `stream` (hipStream_t; NULL = the context's stream).  n_headers >= n: the
+ * header count every rank of a gather pads its shard to.  Single-device contexts only. */
+int  rgbdfe_pack_inliers(rgbdfe_ctx* ctx, const void* d_records, int32_t n, int32_t n_headers, void* d_stream,
+                         int32_t* d_total, void* stream);
+int  rgbdfe_sizeof_inlier_header(void);
 int  rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p);
 const char* rgbdfe_status_string(int status);
 const char* rgbdfe_last_error(rgbdfe_ctx* ctx);

@@ -82,6 +82,12 @@ COMPACT_DTYPE = np.dtype([
     ("valid_iterations", "<i4"), ("real_iterations", "<i4"), ("inlier_mask", "<u8", (RGBDFE_MASK_WORDS,)),
 ], align=True)
 COMPACT_FIELDS = [n for n in COMPACT_DTYPE.names]
+# rgbdfe_inlier_header: the leading 104 bytes of a record, pad0 = first_inlier
+INLIER_HEADER_DTYPE = np.dtype([
+    ("id1", "<i4"), ("id2", "<i4"), ("n_all", "<i4"), ("n_inl", "<i4"), ("rmse", "<f4"),
+    ("trafo", "<f4", (16,)), ("first_inlier", "<u4"), ("info_scale", "<f8"),
+    ("valid_iterations", "<i4"), ("real_iterations", "<i4"),
+], align=True)
 
 
 def compact_of(records: np.ndarray) -> np.ndarray:
@@ -90,6 +96,42 @@ def compact_of(records: np.ndarray) -> np.ndarray:
     for f in COMPACT_FIELDS:
         out[f] = records[f]
     return out
+
+
+def inlier_stream_of(records: np.ndarray, n_headers: int):
+    """Host twin of rgbdfe_pack_inliers: RESULT_DTYPE records -> (headers INLIER_HEADER_DTYPE [n_headers], list uint32 [total])."""
+    n = len(records)
+    hdr = np.zeros(n_headers, INLIER_HEADER_DTYPE)
+    hdr["id1"][n:] = -1
+    hdr["id2"][n:] = -1
+    for f in INLIER_HEADER_DTYPE.names:
+        if f != "first_inlier":
+            hdr[f][:n] = records[f]
+    bits = np.unpackbits(np.ascontiguousarray(records["inlier_mask"]).view(np.uint8).reshape(n, -1), axis=1, bitorder="little") \
+        if n else np.zeros((0, 64 * RGBDFE_MASK_WORDS), np.uint8)
+    counts = bits.sum(1).astype(np.int64)
+    first = np.concatenate([[0], np.cumsum(counts)])
+    hdr["first_inlier"][:n] = first[:n]
+    hdr["first_inlier"][n:] = first[n]
+    lst = np.zeros(int(first[n]), np.uint32)
+    for k in range(n):
+        m = np.nonzero(bits[k])[0]
+        lst[first[k]:first[k + 1]] = records["all_q"][k][m].astype(np.uint32) | (records["all_t"][k][m].astype(np.uint32) << 16)
+    return hdr, lst
+
+
+def parse_inlier_stream(buf: np.ndarray, n_headers: int, total: int):
+    """A shard's inlier stream (uint8) -> (headers, list uint32 [total])."""
+    b = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    hb = n_headers * INLIER_HEADER_DTYPE.itemsize
+    return b[:hb].view(INLIER_HEADER_DTYPE), b[hb:hb + 4 * total].view(np.uint32)
+
+
+def inlier_pairs(hdr, lst, k):
+    """(query rows, train rows) of pair k's inlier matches from a parsed inlier stream."""
+    a = int(hdr["first_inlier"][k])
+    e = lst[a:a + int(hdr["n_inl"][k])]
+    return (e & 0xFFFF).astype(np.int32), (e >> 16).astype(np.int32)
 
 
 _lib = None
@@ -261,6 +303,11 @@ def load():
     L.rgbdfe_pack_compact.restype = C.c_int
     L.rgbdfe_pack_compact.argtypes = [ctx, vp, i32, vp, vp]
     L.rgbdfe_sizeof_compact_result.restype = C.c_int
+    L.rgbdfe_pack_inliers.restype = C.c_int
+    L.rgbdfe_pack_inliers.argtypes = [ctx, vp, i32, i32, vp, vp, vp]
+    L.rgbdfe_sizeof_inlier_header.restype = C.c_int
+    if L.rgbdfe_sizeof_inlier_header() != INLIER_HEADER_DTYPE.itemsize:
+        raise RgbdfeError("rgbdfe_inlier_header layout mismatch between librgbdfe.so and the binding")
     if L.rgbdfe_sizeof_compact_result() != COMPACT_DTYPE.itemsize:
         raise RgbdfeError("rgbdfe_compact_result layout mismatch between librgbdfe.so and the binding")
     L.rgbdfe_sift_detect.restype = C.c_int
@@ -313,7 +360,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_host_register", "rgbdfe_host_unregister",
     "rgbdfe_upload_node_cloud", "rgbdfe_release_node_cloud", "rgbdfe_observation_likelihood",
     "rgbdfe_observation_criterion_met", "rgbdfe_set_latency_mode", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
-    "rgbdfe_reset_kernel_time", "rgbdfe_graph_stats", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
+    "rgbdfe_reset_kernel_time", "rgbdfe_graph_stats", "rgbdfe_pack_inliers", "rgbdfe_sizeof_inlier_header", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
     "rgbdfe_pose_graph_create", "rgbdfe_pose_graph_destroy", "rgbdfe_pose_graph_add_node",
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",

@@ -68,7 +68,83 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const uint64_t* __res
   out[i] = in[(size_t)k * 218u + (w < 13u ? w : 200u + w)];
 }
 
+// ---- the inlier stream of a shard (rgbdfe_inlier_header): headers + one list of (query row, train row) per pair ----------
+constexpr uint32_t kHeaderWords = sizeof(rgbdfe_inlier_header) / 4;                      // 26
+constexpr uint32_t kFirstInlierWord = offsetof(rgbdfe_inlier_header, first_inlier) / 4;  // 21
+static_assert(sizeof(rgbdfe_inlier_header) == offsetof(rgbdfe_match_result, all_q), "an inlier header = a record's leading fields");
+static_assert(offsetof(rgbdfe_inlier_header, first_inlier) == offsetof(rgbdfe_match_result, pad0), "first_inlier sits in pad0");
+
+// one block: inlier counts -> exclusive positions (headers' first_inlier), the padding headers, the total
+__global__ __launch_bounds__(1024) void inlier_scan_kernel(const rgbdfe_match_result* __restrict__ in, uint32_t n,
+                                                           uint32_t n_headers, rgbdfe_inlier_header* __restrict__ hdr,
+                                                           int32_t* __restrict__ total) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < n; k0 += 1024u) {
+    const uint32_t k = k0 + tid;
+    uint32_t c = 0;
+    if (k < n)
+      for (int w = 0; w < RGBDFE_MASK_WORDS; ++w) c += (uint32_t)__popcll(in[k].inlier_mask[w]);
+    uint32_t incl = c;  // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t off = base;
+    for (uint32_t w = 0; w < wv; ++w) off += wave_tot[w];
+    if (k < n) hdr[k].first_inlier = off + incl - c;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_tot[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  for (uint32_t k = n + tid; k < n_headers; k += 1024u) {   // padding headers: "no edge", no inliers
+    uint32_t* __restrict__ h = reinterpret_cast<uint32_t*>(hdr + k);
+    for (uint32_t w = 0; w < kHeaderWords; ++w) h[w] = 0u;
+    hdr[k].id1 = -1; hdr[k].id2 = -1; hdr[k].first_inlier = base;
+  }
+  if (tid == 0) *total = (int32_t)base;
+}
+
+// one wave per pair: the header (its first_inlier is already there) and the pair's list
+__global__ __launch_bounds__(64) void inlier_list_kernel(const rgbdfe_match_result* __restrict__ in, uint32_t n,
+                                                         rgbdfe_inlier_header* __restrict__ hdr, uint32_t* __restrict__ list) {
+  const uint32_t k = blockIdx.x, lane = threadIdx.x;
+  if (k >= n) return;
+  const rgbdfe_match_result& r = in[k];
+  if (lane < kHeaderWords && lane != kFirstInlierWord)
+    reinterpret_cast<uint32_t*>(hdr + k)[lane] = reinterpret_cast<const uint32_t*>(&r)[lane];
+  uint32_t at = hdr[k].first_inlier;
+#pragma unroll
+  for (int w = 0; w < RGBDFE_MASK_WORDS; ++w) {
+    const uint64_t m = r.inlier_mask[w];
+    if ((m >> lane) & 1ull) {
+      const uint32_t i = (uint32_t)w * 64u + lane;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      list[at + rank] = (uint32_t)r.all_q[i] | ((uint32_t)r.all_t[i] << 16);
+    }
+    at += (uint32_t)__popcll(m);
+  }
+}
+
 }  // namespace
+
+void launch_pack_inliers(const rgbdfe_match_result* in, uint32_t n, uint32_t n_headers, void* stream_out, int32_t* d_total,
+                         hipStream_t stream) {
+  rgbdfe_inlier_header* hdr = reinterpret_cast<rgbdfe_inlier_header*>(stream_out);
+  uint32_t* list = reinterpret_cast<uint32_t*>(hdr + n_headers);
+  hipLaunchKernelGGL(inlier_scan_kernel, dim3(1), dim3(1024), 0, stream, in, n, n_headers, hdr, d_total);
+  if (n > 0) hipLaunchKernelGGL(inlier_list_kernel, dim3(n), dim3(64), 0, stream, in, n, hdr, list);
+}
 
 void launch_compact_pack(const rgbdfe_match_result* in, uint32_t n, rgbdfe_compact_result* out, hipStream_t stream) {
   if (n > 0)

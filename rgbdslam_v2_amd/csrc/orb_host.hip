@@ -93,6 +93,24 @@ double orb_now_us() {
 
 OrbWorkspace::~OrbWorkspace() { release(); }
 
+// Zero-fills of freshly allocated device memory go through a stream of the workspace's own and wait for THAT stream: a
+// NULL-stream hipMemset would need a device-wide synchronisation to be ordered before the context's non-blocking streams,
+// and hipDeviceSynchronize() invalidates a hipGraph capture another thread of the process may have open (rgbdfe_api.hip).
+static hipError_t zero_fill_and_wait(void* p, size_t bytes) {
+  static thread_local hipStream_t s = nullptr;
+  static thread_local int s_dev = -1;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (!s || s_dev != dev) {
+    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { s = nullptr; return e; }
+    s_dev = dev;
+  }
+  e = hipMemsetAsync(p, 0, bytes, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+
 void OrbWorkspace::release() {
   if (timing.on && timing.frames) {
     static const char* names[10] = {"prepare+mask scan", "upload+pyramid enqueue", "pass enqueue", "pass wait",
@@ -258,8 +276,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   n_rows_total = (int)row_off;
   kp_cap = (int)(score_off / 4) + 64 * n_cells * kLevels;
   ORB_HIP(hipMalloc((void**)&d_pool, pool_bytes));
-  ORB_HIP(hipMemset(d_pool, 0, pool_bytes));
-  ORB_HIP(hipDeviceSynchronize());  // NULL-stream memset vs the context's non-blocking stream
+  ORB_HIP(zero_fill_and_wait(d_pool, pool_bytes));
   ORB_HIP(hipMalloc((void**)&d_score, score_off + 256));
   ORB_HIP(hipMalloc((void**)&d_blur, blur_off + 256));
   blur_bytes = blur_off + 256;
@@ -271,7 +288,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipMalloc((void**)&d_units, sizeof(TileUnit) * units.size()));
   ORB_HIP(hipMemcpy(d_units, units.data(), sizeof(TileUnit) * units.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
-  ORB_HIP(hipMemset(d_row_cnt, 0, sizeof(int) * (row_off + 16)));   // accumulated by atomics, re-zeroed by the row scan
+  ORB_HIP(zero_fill_and_wait(d_row_cnt, sizeof(int) * (row_off + 16)));   // accumulated by atomics, re-zeroed by the row scan
   ORB_HIP(hipMalloc((void**)&d_row_off, sizeof(int) * (row_off + 16)));
   ORB_HIP(hipMalloc((void**)&d_keep, sizeof(uint64_t) * (keep_words + 16)));
   // a pass's outputs in ONE buffer -- [per-image counts | keypoints] -- so that they come back in one copy
@@ -313,8 +330,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   himg_set[0] = h_img;
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
-  ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));
-  ORB_HIP(hipDeviceSynchronize());
+  ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));   // (synchronous: pageable source)
   if (!pattern_uploaded) { orb_upload_pattern(kOrbBitPattern31); pattern_uploaded = true; }
   return RGBDFE_OK;
 }
@@ -324,11 +340,10 @@ int OrbWorkspace::ensure_alt(std::string& err) {
   if (pool_set[1]) return RGBDFE_OK;
   for (int i = 1; i < (frames > 1 ? kSets : 2); ++i) {  // the super-frame pipeline is kSets deep, the frame pipeline two
     ORB_HIP(hipMalloc((void**)&pool_set[i], pool_bytes));
-    ORB_HIP(hipMemset(pool_set[i], 0, pool_bytes));
+    ORB_HIP(zero_fill_and_wait(pool_set[i], pool_bytes));
     ORB_HIP(hipMalloc((void**)&blur_set[i], blur_bytes));
   }
   ORB_HIP(hipHostMalloc((void**)&himg_set[1], (size_t)2 * W * H * frames, hipHostMallocDefault));
-  ORB_HIP(hipDeviceSynchronize());
   return RGBDFE_OK;
 }
 

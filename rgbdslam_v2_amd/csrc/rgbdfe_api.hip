@@ -800,14 +800,14 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   // max_keypoints is rounded up to whole 32-row tiles per slot in the expanded slab
   if (hipMalloc((void**)&ctx->d_desc4, hamming_mfma_slab_bytes((uint32_t)cfg->max_nodes, (uint32_t)cfg->max_keypoints)) != hipSuccess)
     return bail(RGBDFE_ERR_OUT_OF_MEMORY);
-  // hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which the
-  // context's non-blocking streams do not wait for: a node upload issued right after create could be
-  // overwritten by a late memset.  Wait for the device before returning.
-  if (hipMemset(ctx->d_desc, 0, rows * 32) != hipSuccess) return bail(RGBDFE_ERR_HIP);
-  if (hipMemset(ctx->d_xyz, 0, rows * 16) != hipSuccess) return bail(RGBDFE_ERR_HIP);
-  if (hipMemset(ctx->d_desc4, 0, hamming_mfma_slab_bytes((uint32_t)cfg->max_nodes, (uint32_t)cfg->max_keypoints)) != hipSuccess)
+  // The zero-fills run on the context's own stream and the call waits for THAT stream (a NULL-stream hipMemset is not
+  // ordered before the context's non-blocking streams without a device-wide synchronisation -- and hipDeviceSynchronize()
+  // invalidates a hipGraph capture another context's thread may have open).
+  if (hipMemsetAsync(ctx->d_desc, 0, rows * 32, ctx->stream) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  if (hipMemsetAsync(ctx->d_xyz, 0, rows * 16, ctx->stream) != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  if (hipMemsetAsync(ctx->d_desc4, 0, hamming_mfma_slab_bytes((uint32_t)cfg->max_nodes, (uint32_t)cfg->max_keypoints), ctx->stream) != hipSuccess)
     return bail(RGBDFE_ERR_HIP);
-  if (hipDeviceSynchronize() != hipSuccess) return bail(RGBDFE_ERR_HIP);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(RGBDFE_ERR_HIP);
   const size_t np = (size_t)cfg->max_pairs_per_batch;
   for (auto& sl : ctx->ring) {
     if (hipMalloc((void**)&sl.d_work, np * sizeof(PairWork)) != hipSuccess) return bail(RGBDFE_ERR_OUT_OF_MEMORY);
@@ -833,8 +833,11 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
 
 void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   if (!ctx) return;
+  // every stream this context has work on -- not the device: another context's thread may be capturing a hipGraph
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipDeviceSynchronize();
+  for (auto& ln : ctx->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+  for (hipStream_t st : {ctx->orb_upload_stream, ctx->orb_compute_stream, ctx->sift_stream1, ctx->sift_stream2})
+    if (st) (void)hipStreamSynchronize(st);
   drain_pending(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
@@ -1042,8 +1045,8 @@ int rgbdfe_upload_node_keypoints(rgbdfe_ctx* ctx, int32_t node_id, const float* 
   if (!ctx->d_kp2d) {
     const size_t rows = (size_t)ctx->cfg.max_nodes * (size_t)ctx->cfg.max_keypoints;
     if (hipMalloc((void**)&ctx->d_kp2d, rows * 8) != hipSuccess) return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "keypoint slab");
-    HIP_TRY(ctx, hipMemset(ctx->d_kp2d, 0, rows * 8));
-    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_kp2d, 0, rows * 8, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (this stream only: see rgbdfe_create)
   }
   for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));  // batches in flight may read the slot
   if (n > 0)
@@ -1184,9 +1187,9 @@ static int ensure_sift(rgbdfe_ctx* ctx) {
   if (hipMalloc((void**)&ctx->d_sift_bf16, bf16_rows * 128 * 2) != hipSuccess ||
       hipMalloc((void**)&ctx->d_sift_f32, rows * 128 * 4) != hipSuccess)
     return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "SIFT node slabs");
-  HIP_TRY(ctx, hipMemset(ctx->d_sift_bf16, 0, bf16_rows * 128 * 2));
-  HIP_TRY(ctx, hipMemset(ctx->d_sift_f32, 0, rows * 128 * 4));
-  HIP_TRY(ctx, hipDeviceSynchronize());  // see rgbdfe_create: NULL-stream memsets vs non-blocking streams
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_sift_bf16, 0, bf16_rows * 128 * 2, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_sift_f32, 0, rows * 128 * 4, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (this stream only: see rgbdfe_create)
   for (auto& ln : ctx->lanes) {
     if (hipMalloc((void**)&ln.d_row_part, np * mk * 3 * 4) != hipSuccess ||
         hipMalloc((void**)&ln.d_col_part, np * mk * 3 * 4) != hipSuccess ||
@@ -3094,6 +3097,18 @@ int rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void*
   HIP_TRY(ctx, hipGetLastError());
   return RGBDFE_OK;
 }
+int rgbdfe_pack_inliers(rgbdfe_ctx* ctx, const void* d_records, int32_t n, int32_t n_headers, void* d_stream, int32_t* d_total,
+                        void* stream) {
+  if (!ctx || n < 0 || n_headers < n || !d_stream || !d_total || (n > 0 && !d_records))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad pack arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  launch_pack_inliers((const rgbdfe_match_result*)d_records, (uint32_t)n, (uint32_t)n_headers, d_stream, d_total,
+                      stream ? (hipStream_t)stream : ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return RGBDFE_OK;
+}
+int rgbdfe_sizeof_inlier_header(void) { return (int)sizeof(rgbdfe_inlier_header); }
 int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
   if (!ctx || !out || n_out < 0) return RGBDFE_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -3104,7 +3119,7 @@ int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
   return RGBDFE_OK;
 }
 
-int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats
+int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_pack_inliers
 
 }  // namespace impl
 
@@ -3828,6 +3843,16 @@ int rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void*
     return impl::rgbdfe_pack_compact(ctx, d_records, n, d_compact, stream);
   });
 }
+
+int rgbdfe_pack_inliers(rgbdfe_ctx* ctx, const void* d_records, int32_t n, int32_t n_headers, void* d_stream, int32_t* d_total,
+                        void* stream) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_pack_inliers");
+    return impl::rgbdfe_pack_inliers(ctx, d_records, n, n_headers, d_stream, d_total, stream);
+  });
+}
+int rgbdfe_sizeof_inlier_header(void) { return impl::rgbdfe_sizeof_inlier_header(); }
 
 int rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
                                            int32_t n_pairs, void* const* d_out, int32_t* const* d_index,

@@ -153,6 +153,9 @@ void launch_compact_edges(const rgbdfe_match_result* in, uint32_t n, rgbdfe_matc
                           int32_t index_scale, int32_t index_offset, int32_t* d_dst, int32_t* d_count, hipStream_t stream);
 // edges.hip: records -> rgbdfe_compact_result (header + inlier mask, 144 of the 1744 bytes)
 void launch_compact_pack(const rgbdfe_match_result* in, uint32_t n, rgbdfe_compact_result* out, hipStream_t stream);
+// the inlier stream of a shard (include/rgbdfe.h: rgbdfe_inlier_header): n_headers headers, then the list block; *d_total = its entries
+void launch_pack_inliers(const rgbdfe_match_result* in, uint32_t n, uint32_t n_headers, void* stream_out, int32_t* d_total,
+                         hipStream_t stream);
 // node.cpp:1222-1268 after the RANSAC results exist (rc.g2o_iterations > 0): two-view Gauss-Newton refinement over the
 // inliers + re-scoring + the adopt rules.  kp_pool: KeyPoint.pt slab [slot][row] (float2).
 void launch_g2o_refine(const PairWork* work, rgbdfe_match_result* results, uint32_t n_pairs, const RansacConst& rc,

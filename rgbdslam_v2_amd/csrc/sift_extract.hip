@@ -48,35 +48,29 @@ __global__ __launch_bounds__(256) void sift_convert_kernel(const uint8_t* __rest
   out[i] = (float)(int)gray[(size_t)y * cols + x] / 255.0f;
 }
 
-// UpsampleKernel<1> (ProgramCU.cu:221-265): src is w x h, dst 2w x 2h.  A fetch past the end of the source returns 0
-// (linear texture), a fetch past the end of a row continues in the next row -- both kept.
+// The "-fo -1" first octave: the input at twice its size (behaviour of UpsampleKernel<1>, ProgramCU.cu:221-265).  One thread
+// makes the two output pixels above source pixel (x, y2 / 2): even output rows repeat the source row, odd ones are the mean of
+// the rows above and below; even output columns take that value, odd ones the mean with the right-hand neighbour.  The
+// source is addressed as ONE linear array, as the reference's linear texture is: the neighbour of a row's last pixel is the
+// first pixel of the next row, and anything past the last pixel reads as 0.
 __global__ __launch_bounds__(128) void sift_upsample2_kernel(const float* __restrict__ src, int w, int h,
                                                              float* __restrict__ dst, size_t dst_stride) {
-  const int col = blockIdx.x * 128 + threadIdx.x;
-  if (col >= w) return;
-  const int n = w * h;
-  src += (size_t)blockIdx.z * n;
+  const int x = blockIdx.x * 128 + threadIdx.x;
+  if (x >= w) return;
+  const int pixels = w * h;
+  src += (size_t)blockIdx.z * pixels;
   dst += (size_t)blockIdx.z * dst_stride;
-  auto fetch = [&](int i) -> float { return i < n ? src[i] : 0.0f; };
-  const int dst_row = blockIdx.y;
-  const int row = dst_row >> 1;
-  int index = row * w + col;
-  const int dst_idx = (w * dst_row + col) * 2;
-  const int helper = dst_row & 1;
-  if (helper) {
-    const float v11 = fetch(index), v12 = fetch(index + 1);
-    index += w;
-    const float v21 = fetch(index), v22 = fetch(index + 1);
-    const float w1 = 0.5f * helper, w2 = (float)(1.0 - (double)w1);
-    const float v1 = v21 * w1 + w2 * v11;
-    const float v2 = v22 * w1 + w2 * v12;
-    dst[dst_idx] = v1;
-    dst[dst_idx + 1] = v1 * 0.5f + v2 * 0.5f;
-  } else {
-    const float v1 = fetch(index), v2 = fetch(index + 1);
-    dst[dst_idx] = v1;
-    dst[dst_idx + 1] = v1 * 0.5f + v2 * 0.5f;
+  auto px = [&](int i) -> float { return i < pixels ? src[i] : 0.0f; };
+  const int y2 = blockIdx.y;               // output row
+  const int at = (y2 >> 1) * w + x;        // the source pixel above-left of the output pair
+  float here = px(at), right = px(at + 1);
+  if (y2 & 1) {                            // between two source rows: half of each
+    here = px(at + w) * 0.5f + 0.5f * here;
+    right = px(at + w + 1) * 0.5f + 0.5f * right;
   }
+  float* __restrict__ out = dst + (size_t)(w * y2 + x) * 2;
+  out[0] = here;
+  out[1] = here * 0.5f + right * 0.5f;
 }
 
 // DownsampleKernel<1> (ProgramCU.cu:283-294)
@@ -171,92 +165,116 @@ void launch_filter_any(const FilterArgs& a, const Taps& t, hipStream_t s) {
 
 // ---- extrema -----------------------------------------------------------------------------------------------------------
 struct KeyEval { float result, dx, dy, ds; };
-// ComputeKEY_Kernel (ProgramCU.cu:524-640) for one interior pixel; D[level] = G[level] - G[level - 1] taken from the
-// Gaussian planes g[0..3] = G[l-2], G[l-1], G[l], G[l+1] (ComputeDOG_Kernel's `v - vp`, :457-489).
-__device__ __forceinline__ KeyEval key_eval(const float* const g[4], int w, int index, float dog_threshold0, float dog_threshold,
-                                            float edge_threshold) {
-  KeyEval out{0.f, 0.f, 0.f, 0.f};
-  auto dogc = [&](int i) -> float { return g[2][i] - g[1][i]; };
-  auto dogp = [&](int i) -> float { return g[1][i] - g[0][i]; };
-  auto dogn = [&](int i) -> float { return g[3][i] - g[2][i]; };
-  float data[3][3], datap[3][3], datan[3][3];
-  const int idx[3] = {index - w, index, index + w};
-  float nmax, nmin;
-  const float v = dogc(idx[1]);
-  data[1][1] = v;
-  if (fabsf(v) <= dog_threshold0) return out;
-  data[1][0] = dogc(idx[1] - 1);
-  data[1][2] = dogc(idx[1] + 1);
-  nmax = fmaxf(data[1][0], data[1][2]);
-  nmin = fminf(data[1][0], data[1][2]);
-  if (v <= nmax && v >= nmin) return out;
-#define SIFT_READ_CMP(datai, F, ix)                 \
-  datai[0] = F((ix) - 1);                           \
-  datai[1] = F(ix);                                 \
-  datai[2] = F((ix) + 1);                           \
-  if (v > nmax) {                                   \
-    nmax = fmaxf(nmax, datai[0]);                   \
-    nmax = fmaxf(nmax, datai[1]);                   \
-    nmax = fmaxf(nmax, datai[2]);                   \
-    if (v < nmax) return out;                       \
-  } else {                                          \
-    nmin = fminf(nmin, datai[0]);                   \
-    nmin = fminf(nmin, datai[1]);                   \
-    nmin = fminf(nmin, datai[2]);                   \
-    if (v > nmin) return out;                       \
+
+// one row [c0 c1 c2 | rhs] of the 3 x 3 system of the sub-pixel fit
+struct FitRow {
+  float c0, c1, c2, rhs;
+  // the row with a non-negative leading coefficient
+  static __device__ __forceinline__ FitRow oriented(float c0, float c1, float c2, float rhs) {
+    return c0 > 0 ? FitRow{c0, c1, c2, rhs} : FitRow{-c0, -c1, -c2, -rhs};
   }
-  SIFT_READ_CMP(data[0], dogc, idx[0]);
-  SIFT_READ_CMP(data[2], dogc, idx[2]);
-  // edge suppression
-  const float vx2 = v * 2.0f;
-  const float fxx = data[1][0] + data[1][2] - vx2;
-  const float fyy = data[0][1] + data[2][1] - vx2;
-  const float fxy = 0.25f * (data[2][2] + data[0][0] - data[2][0] - data[0][2]);
-  const float temp1 = fxx * fyy - fxy * fxy;
-  const float temp2 = (fxx + fyy) * (fxx + fyy);
-  if (temp1 <= 0 || temp2 > edge_threshold * temp1) return out;
-  SIFT_READ_CMP(datap[0], dogp, idx[0]);
-  SIFT_READ_CMP(datap[1], dogp, idx[1]);
-  SIFT_READ_CMP(datap[2], dogp, idx[2]);
-  SIFT_READ_CMP(datan[0], dogn, idx[0]);
-  SIFT_READ_CMP(datan[1], dogn, idx[1]);
-  SIFT_READ_CMP(datan[2], dogn, idx[2]);
-#undef SIFT_READ_CMP
-  bool offset_test_passed = true;
-  float dx = 0, dy = 0, ds = 0;
-  {  // sub-pixel localisation ("-s 1"): Gaussian elimination with the reference's pivoting
-    const float fx = 0.5f * (data[1][2] - data[1][0]);
-    const float fy = 0.5f * (data[2][1] - data[0][1]);
-    const float fs = 0.5f * (datan[1][1] - datap[1][1]);
-    const float fss = (datan[1][1] + datap[1][1] - vx2);
-    const float fxs = 0.25f * (datan[1][2] + datap[1][0] - datan[1][0] - datap[1][2]);
-    const float fys = 0.25f * (datan[2][1] + datap[0][1] - datan[0][1] - datap[2][1]);
-    float4 A0 = fxx > 0 ? make_float4(fxx, fxy, fxs, -fx) : make_float4(-fxx, -fxy, -fxs, fx);
-    float4 A1 = fxy > 0 ? make_float4(fxy, fyy, fys, -fy) : make_float4(-fxy, -fyy, -fys, fy);
-    float4 A2 = fxs > 0 ? make_float4(fxs, fys, fss, -fs) : make_float4(-fxs, -fys, -fss, fs);
-    const float maxa = fmaxf(fmaxf(A0.x, A1.x), A2.x);
-    if (maxa >= 1e-10) {
-      if (maxa == A1.x) { const float4 t = A1; A1 = A0; A0 = t; }
-      else if (maxa == A2.x) { const float4 t = A2; A2 = A0; A0 = t; }
-      A0.y /= A0.x; A0.z /= A0.x; A0.w /= A0.x;
-      A1.y -= A1.x * A0.y; A1.z -= A1.x * A0.z; A1.w -= A1.x * A0.w;
-      A2.y -= A2.x * A0.y; A2.z -= A2.x * A0.z; A2.w -= A2.x * A0.w;
-      if (fabsf(A2.y) > fabsf(A1.y)) { const float4 t = A2; A2 = A1; A1 = t; }
-      if (fabsf(A1.y) >= 1e-10) {
-        A1.z /= A1.y; A1.w /= A1.y;
-        A2.z -= A2.y * A1.z; A2.w -= A2.y * A1.w;
-        if (fabsf(A2.z) >= 1e-10) {
-          ds = A2.w / A2.z;
-          dy = A1.w - ds * A1.z;
-          dx = A0.w - ds * A0.z - dy * A0.y;
-          offset_test_passed = fabsf(data[1][1] + 0.5f * (dx * fx + dy * fy + ds * fs)) > dog_threshold &&
-                               fabsf(ds) < 1.0f && fabsf(dx) < 1.0f && fabsf(dy) < 1.0f;
+};
+__device__ __forceinline__ void exchange(FitRow& a, FitRow& b) { const FitRow t = a; a = b; b = t; }
+
+// Is the pixel `at` of D[l] = G[l] - G[l-1] a keypoint candidate, and where does the fitted extremum lie?  (Behaviour of
+// ComputeKEY_Kernel, ProgramCU.cu:524-640, for an interior pixel.)  g[0..3] = the Gaussian planes G[l-2] .. G[l+1]: the three
+// DoG levels involved are differences of neighbouring planes, formed here instead of being stored (ComputeDOG_Kernel's
+// `v - vp`, :457-489).  The tests, cheapest first -- each one only ever rejects:
+//   contrast gate      |D| above 0.8 * threshold;
+//   extremum           strictly above (below) its two row neighbours, not below (above) any of the other 24 neighbours in
+//                      scale space (ties: see `holds`); `rim` follows the neighbour closest to the centre value on the side
+//                      that matters;
+//   edge response      principal-curvature ratio of the 2 x 2 spatial Hessian;
+//   sub-pixel fit      Newton step (dx, dy, ds) from the 3 x 3 Hessian system, solved by elimination with the reference's
+//                      pivot choices; rejected when the step leaves the pixel / level or the fitted contrast is too low.
+// result = +1 for a maximum that is strictly above all 26 neighbours, -1 for every other candidate, 0 = no candidate.
+__device__ __forceinline__ KeyEval key_eval(const float* const g[4], int w, int at, float gate, float contrast_threshold,
+                                            float edge_threshold) {
+  const KeyEval none{0.f, 0.f, 0.f, 0.f};
+  auto same = [&](int i) -> float { return g[2][i] - g[1][i]; };    // D[l]
+  auto below = [&](int i) -> float { return g[1][i] - g[0][i]; };   // D[l-1]
+  auto above = [&](int i) -> float { return g[3][i] - g[2][i]; };   // D[l+1]
+  const float v = same(at);
+  if (fabsf(v) <= gate) return none;
+  const float west = same(at - 1), east = same(at + 1);
+  const bool peak = v > fmaxf(west, east);
+  if (!peak && !(v < fminf(west, east))) return none;   // between its row neighbours (or level with one of them)
+  float rim = peak ? fmaxf(west, east) : fminf(west, east);
+  // three more neighbours: does the centre still stand out?  A valley may be level with any neighbour; a peak may only be
+  // level with one of the LAST three looked at (it is then reported as -1): a peak found level with an earlier neighbour
+  // is dropped when the next three are looked at -- the reference's behaviour, kept.
+  auto holds = [&](float a, float b, float c) -> bool {
+    if (peak) {
+      if (!(v > rim)) return false;
+      rim = fmaxf(fmaxf(fmaxf(rim, a), b), c);
+      return !(v < rim);
+    }
+    rim = fminf(fminf(fminf(rim, a), b), c);
+    return !(v > rim);
+  };
+  const int up = at - w, down = at + w;
+  const float nw = same(up - 1), north = same(up), ne = same(up + 1);
+  if (!holds(nw, north, ne)) return none;
+  const float sw = same(down - 1), south = same(down), se = same(down + 1);
+  if (!holds(sw, south, se)) return none;
+  // edge response: det(H) > 0 and trace(H)^2 / det(H) within the threshold
+  const float twice = v * 2.0f;
+  const float hxx = west + east - twice;
+  const float hyy = north + south - twice;
+  const float hxy = 0.25f * (se + nw - sw - ne);
+  const float det = hxx * hyy - hxy * hxy;
+  const float trace_sq = (hxx + hyy) * (hxx + hyy);
+  if (det <= 0 || trace_sq > edge_threshold * det) return none;
+  // the 9 + 9 neighbours in the levels below and above
+  const float b_nw = below(up - 1), b_n = below(up), b_ne = below(up + 1);
+  if (!holds(b_nw, b_n, b_ne)) return none;
+  const float b_w = below(at - 1), b_c = below(at), b_e = below(at + 1);
+  if (!holds(b_w, b_c, b_e)) return none;
+  const float b_sw = below(down - 1), b_s = below(down), b_se = below(down + 1);
+  if (!holds(b_sw, b_s, b_se)) return none;
+  const float a_nw = above(up - 1), a_n = above(up), a_ne = above(up + 1);
+  if (!holds(a_nw, a_n, a_ne)) return none;
+  const float a_w = above(at - 1), a_c = above(at), a_e = above(at + 1);
+  if (!holds(a_w, a_c, a_e)) return none;
+  const float a_sw = above(down - 1), a_s = above(down), a_se = above(down + 1);
+  if (!holds(a_sw, a_s, a_se)) return none;
+  (void)b_nw; (void)b_ne; (void)b_sw; (void)b_se; (void)a_nw; (void)a_ne; (void)a_sw; (void)a_se;
+  // sub-pixel fit ("-s 1"): H * step = -gradient by central differences over (x, y, scale)
+  KeyEval out{0.f, 0.f, 0.f, 0.f};
+  bool keep = true;
+  {
+    const float gx = 0.5f * (east - west);
+    const float gy = 0.5f * (south - north);
+    const float gs = 0.5f * (a_c - b_c);
+    const float hss = (a_c + b_c - twice);
+    const float hxs = 0.25f * (a_e + b_w - a_w - b_e);
+    const float hys = 0.25f * (a_s + b_n - a_n - b_s);
+    FitRow r0 = FitRow::oriented(hxx, hxy, hxs, -gx);
+    FitRow r1 = FitRow::oriented(hxy, hyy, hys, -gy);
+    FitRow r2 = FitRow::oriented(hxs, hys, hss, -gs);
+    const float lead = fmaxf(fmaxf(r0.c0, r1.c0), r2.c0);
+    if (lead >= 1e-10) {
+      // first pivot: the row with the largest leading coefficient (the second row wins a tie, then the third)
+      if (lead == r1.c0) exchange(r0, r1);
+      else if (lead == r2.c0) exchange(r0, r2);
+      r0.c1 /= r0.c0; r0.c2 /= r0.c0; r0.rhs /= r0.c0;
+      r1.c1 -= r1.c0 * r0.c1; r1.c2 -= r1.c0 * r0.c2; r1.rhs -= r1.c0 * r0.rhs;
+      r2.c1 -= r2.c0 * r0.c1; r2.c2 -= r2.c0 * r0.c2; r2.rhs -= r2.c0 * r0.rhs;
+      if (fabsf(r2.c1) > fabsf(r1.c1)) exchange(r1, r2);   // second pivot
+      if (fabsf(r1.c1) >= 1e-10) {
+        r1.c2 /= r1.c1; r1.rhs /= r1.c1;
+        r2.c2 -= r2.c1 * r1.c2; r2.rhs -= r2.c1 * r1.rhs;
+        if (fabsf(r2.c2) >= 1e-10) {   // back substitution
+          out.ds = r2.rhs / r2.c2;
+          out.dy = r1.rhs - out.ds * r1.c2;
+          out.dx = r0.rhs - out.ds * r0.c2 - out.dy * r0.c1;
+          keep = fabsf(v + 0.5f * (out.dx * gx + out.dy * gy + out.ds * gs)) > contrast_threshold &&
+                 fabsf(out.ds) < 1.0f && fabsf(out.dx) < 1.0f && fabsf(out.dy) < 1.0f;
         }
       }
     }
   }
-  if (offset_test_passed) out.result = v > nmax ? 1.0f : -1.0f;
-  out.dx = dx; out.dy = dy; out.ds = ds;
+  if (keep) out.result = (peak && v > rim) ? 1.0f : -1.0f;
   return out;
 }
 
@@ -583,21 +601,23 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* _
     if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return RGBDFE_ERR_HIP; } \
   } while (0)
 
-// ProgramCU::CreateFilterKernel (ProgramCU.cu:370-398), _FilterWidthFactor = 4
+// The taps of a Gaussian level: exp(-d^2 / 2 sigma^2) for d = -half .. half, normalised to sum 1 (f32 throughout, summed
+// left to right -- the values of ProgramCU::CreateFilterKernel, ProgramCU.cu:370-398, with its width factor 4): half =
+// ceil(4 sigma - 1/2) taps either side, kept between 2 and 16 (widths 5 .. 33).
 Taps make_taps(float sigma) {
   Taps t{};
-  int i, sz = int(ceil(4.0f * sigma - 0.5));
-  int width = 2 * sz + 1;
-  if (width > kMaxTaps) { sz = kMaxTaps >> 1; width = kMaxTaps; }
-  else if (width < 5) { sz = 5 >> 1; width = 5; }
-  float rv = 1.0f / (sigma * sigma), v, ksum = 0;
-  for (i = -sz; i <= sz; ++i) {
-    t.k[i + sz] = v = expf(-0.5f * i * i * rv);
-    ksum += v;
+  const int half = std::min(std::max((int)ceil(4.0f * sigma - 0.5), 2), kMaxTaps / 2);
+  const float inv_var = 1.0f / (sigma * sigma);
+  t.fw = 2 * half + 1;
+  float sum = 0.f;
+  for (int j = 0; j < t.fw; ++j) {
+    const int d = j - half;
+    const float gd = expf(-0.5f * d * d * inv_var);
+    t.k[j] = gd;
+    sum += gd;
   }
-  rv = 1.0f / ksum;
-  for (i = 0; i < width; i++) t.k[i] *= rv;
-  t.fw = width;
+  const float norm = 1.0f / sum;
+  for (int j = 0; j < t.fw; ++j) t.k[j] *= norm;
   return t;
 }
 

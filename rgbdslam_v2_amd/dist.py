@@ -6,7 +6,7 @@ No other collective exists on this path: pairs are independent
 (QtConcurrent::blockingMapped has no cross-task dependency, graph_manager.cpp:548)."""
 import numpy as np
 
-from ._lib import COMPACT_DTYPE, RESULT_DTYPE
+from ._lib import COMPACT_DTYPE, INLIER_HEADER_DTYPE, RESULT_DTYPE, inlier_stream_of, parse_inlier_stream
 
 
 def collective_device(group=None):
@@ -68,6 +68,59 @@ def all_gather_compact(local_records, n_pairs: int, group=None):
     1744 B per pair).  local_records: numpy COMPACT_DTYPE array, or a uint8 tensor in HBM as rgbdfe_pack_compact
     wrote it."""
     return all_gather_results(local_records, n_pairs, group, dtype=COMPACT_DTYPE)
+
+
+def gather_inlier_streams(local_stream, local_total: int, n_pad: int, group=None):
+    """The two collectives of the inlier-stream gather (include/rgbdfe.h: rgbdfe_inlier_header): the ranks exchange the
+    lengths of their list blocks (one tiny all-gather), then their streams padded to the longest.  local_stream: uint8 tensor
+    holding at least n_pad * 104 + 4 * local_total bytes (HBM under RCCL, host under gloo).  Returns (the gathered uint8
+    tensor [world, n_pad * 104 + 4 * max_total], the list of totals)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = local_stream.device
+    t = torch.tensor([int(local_total)], dtype=torch.int64, device=dev)
+    tots = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(tots, t, group=group)
+    totals = [int(v) for v in tots.cpu().tolist()]
+    nbytes = n_pad * INLIER_HEADER_DTYPE.itemsize + 4 * max(totals)
+    if local_stream.numel() < nbytes:
+        pad = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        pad[: local_stream.numel()] = local_stream.reshape(-1)
+        local_stream = pad
+    out = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, local_stream.reshape(-1)[:nbytes], group=group)
+    return out.reshape(world, nbytes), totals
+
+
+def unshard_inlier_streams(gathered: np.ndarray, totals, n_pairs: int, world: int):
+    """gathered [world, bytes] (numpy uint8) -> (headers in global pair order [n_pairs], list of (query rows, train rows) per
+    pair): what updateInlierFeatures (graph_manager.cpp:409-419) reads, for every pair of the global list."""
+    sizes = shard_sizes(n_pairs, world)
+    n_pad = max(sizes) if sizes else 0
+    hdr_all = np.zeros(n_pairs, INLIER_HEADER_DTYPE)
+    pairs = [None] * n_pairs
+    for r in range(world):
+        hdr, lst = parse_inlier_stream(gathered[r], n_pad, totals[r])
+        for j in range(sizes[r]):
+            k = r + j * world
+            hdr_all[k] = hdr[j]
+            e = lst[int(hdr["first_inlier"][j]): int(hdr["first_inlier"][j]) + int(hdr["n_inl"][j])]
+            pairs[k] = ((e & 0xFFFF).astype(np.int32), (e >> 16).astype(np.int32))
+    return hdr_all, pairs
+
+
+def all_gather_inliers(local_records: np.ndarray, n_pairs: int, group=None):
+    """All-gather of the inlier form of the per-rank results (host records in, global order out): see gather_inlier_streams /
+    unshard_inlier_streams.  local_records: this rank's RESULT_DTYPE records in shard order (numpy)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n_pad = max(shard_sizes(n_pairs, world))
+    hdr, lst = inlier_stream_of(local_records, n_pad)
+    buf = np.concatenate([hdr.view(np.uint8).reshape(-1), lst.view(np.uint8).reshape(-1)])
+    g, totals = gather_inlier_streams(torch.from_numpy(buf.copy()).to(collective_device(group)), len(lst), n_pad, group)
+    return unshard_inlier_streams(g.cpu().numpy(), totals, n_pairs, world)
 
 
 def all_gather_edges(local_records, n_pairs: int, group=None):

@@ -159,6 +159,14 @@ class FrontEnd:
         self._check(self._L.rgbdfe_pack_compact(self._ctx, C.c_void_p(int(d_records_ptr)), int(n),
                                                 C.c_void_p(int(d_compact_ptr)), C.c_void_p(stream or 0)))
 
+    def pack_inliers(self, d_records_ptr: int, n: int, n_headers: int, d_stream_ptr: int, d_total_ptr: int,
+                     stream: Optional[int] = None):
+        """n records in HBM -> the shard's inlier stream in HBM on `stream` (rgbdfe_pack_inliers: n_headers headers of 104
+        bytes, then query | train << 16 of every inlier; the entry count goes to the device int32 at d_total_ptr)."""
+        self._check(self._L.rgbdfe_pack_inliers(self._ctx, C.c_void_p(int(d_records_ptr)), int(n), int(n_headers),
+                                                C.c_void_p(int(d_stream_ptr)), C.c_void_p(int(d_total_ptr)),
+                                                C.c_void_p(stream or 0)))
+
     def match_pair_list_allgather_edges(self, query_ids, train_ids, d_out_ptrs: Sequence[int], d_index_ptrs=None):
         """Only the accepted edges travel (rgbdfe_match_pair_list_allgather_edges).  Returns (counts per device, stride):
         device i's edges sit at records [i * stride, i * stride + counts[i]) of every buffer, their positions in the pair

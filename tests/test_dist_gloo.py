@@ -8,7 +8,8 @@ import numpy as np
 import torch.multiprocessing as mp
 
 from rgbdslam_v2_amd import dist as rdist
-from rgbdslam_v2_amd._lib import COMPACT_DTYPE, RESULT_DTYPE, compact_of
+from rgbdslam_v2_amd._lib import (COMPACT_DTYPE, INLIER_HEADER_DTYPE, RESULT_DTYPE, compact_of, inlier_pairs, inlier_stream_of,
+                                  parse_inlier_stream)
 
 
 def _free_port():
@@ -27,7 +28,19 @@ def _fake_records(pq, pt):
     out["rmse"] = (pq + 0.5 * pt).astype(np.float32)
     out["trafo"][:, 0] = pq
     out["inlier_mask"][:, 0] = pq.astype(np.uint64) << np.uint64(7)
+    out["inlier_mask"][:, 3] = (pt.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(20)
+    out["n_inl"] = np.unpackbits(out["inlier_mask"].view(np.uint8).reshape(len(pq), -1), axis=1).sum(1)
+    m = np.arange(320, dtype=np.uint16)
+    out["all_q"] = (m[None, :] * 3 + pq[:, None].astype(np.uint16)) % 1000
+    out["all_t"] = (m[None, :] * 5 + pt[:, None].astype(np.uint16)) % 1000
     return out
+
+
+def _inliers_of(rec):
+    """(query rows, train rows) of a record's inlier matches, straight from its mask and lists."""
+    bits = np.unpackbits(np.ascontiguousarray(rec["inlier_mask"]).view(np.uint8), bitorder="little")
+    m = np.nonzero(bits)[0]
+    return rec["all_q"][m].astype(np.int32), rec["all_t"][m].astype(np.int32)
 
 
 def _worker(rank, world, port, n_pairs, q):
@@ -54,6 +67,15 @@ def _worker(rank, world, port, n_pairs, q):
     idx, edges = rdist.all_gather_edges(full[rank::world], n_pairs)
     want = np.flatnonzero(~rej)
     ok = ok and np.array_equal(idx, want) and edges.tobytes() == full[want].tobytes()
+    # the inlier form (bench.py's default payload): headers + (query row, train row) of every inlier, two collectives
+    hdr, pairs = rdist.all_gather_inliers(local, n_pairs)
+    want_all = _fake_records(pq, pt)
+    for f in INLIER_HEADER_DTYPE.names:
+        if f != "first_inlier":
+            ok = ok and np.array_equal(hdr[f], want_all[f])
+    for k in range(n_pairs):
+        a, b = _inliers_of(want_all[k])
+        ok = ok and np.array_equal(pairs[k][0], a) and np.array_equal(pairs[k][1], b)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -77,6 +99,27 @@ def test_compact_record_layout():
     c = compact_of(rec)
     raw, craw = rec.view(np.uint8).reshape(5, 1744), c.view(np.uint8).reshape(5, 144)
     assert np.array_equal(craw[:, :104], raw[:, :104]) and np.array_equal(craw[:, 104:], raw[:, 1704:])
+
+
+def test_inlier_stream_layout():
+    """rgbdfe_inlier_header = the record's first 104 bytes with pad0 = first_inlier; the list block holds
+    query | train << 16 of every set bit of inlier_mask in ascending order; padding headers carry ids -1."""
+    assert INLIER_HEADER_DTYPE.itemsize == 104
+    rec = _fake_records(np.arange(6, dtype=np.int32) * 9 + 1, np.arange(6, dtype=np.int32) + 2)
+    hdr, lst = inlier_stream_of(rec, 8)
+    raw, hraw = rec.view(np.uint8).reshape(6, 1744), hdr.view(np.uint8).reshape(8, 104)
+    keep = np.r_[0:84, 88:104]
+    assert np.array_equal(hraw[:6][:, keep], raw[:, :104][:, keep])
+    assert np.array_equal(hdr["first_inlier"][:6], np.concatenate([[0], np.cumsum(rec["n_inl"])[:-1]]))
+    assert np.all(hdr["id1"][6:] == -1) and np.all(hdr["n_inl"][6:] == 0) and len(lst) == rec["n_inl"].sum() > 20
+    buf = np.concatenate([hdr.view(np.uint8).reshape(-1), lst.view(np.uint8).reshape(-1), np.zeros(40, np.uint8)])
+    h2, l2 = parse_inlier_stream(buf, 8, len(lst))
+    for k in range(6):
+        a, b = inlier_pairs(h2, l2, k)
+        wa, wb = _inliers_of(rec[k])
+        assert np.array_equal(a, wa) and np.array_equal(b, wb)
+    e, _ = inlier_stream_of(rec[:0], 3)
+    assert np.all(e["id1"] == -1) and np.all(e["first_inlier"] == 0)
 
 
 def test_all_gather_world2_gloo():

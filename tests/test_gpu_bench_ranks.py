@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_one_gpu():
+def _run_two_ranks(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -22,18 +22,36 @@ def test_bench_two_ranks_one_gpu():
     env = dict(os.environ, RGBDFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-         "--frames", "60", "--pairs-per-frame", "10"],
-        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra,
+        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                      # rank 0 only
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_one_gpu():
+    d = _run_two_ranks(["--steps", "4", "--warmup", "1", "--frames", "60", "--pairs-per-frame", "10", "--gather", "compact"])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     # weak scaling: 10 candidates per frame and rank -> 20 per frame globally, sharded round robin
     assert d["config"]["pairs_per_gpu_per_step"] > 0 and d["config"]["parallelism"] == "pair-sharded x2"
     assert "sift" not in d and "cpu_baseline" not in d    # extras and the CPU leg belong to the N = 1 line
-    # the per-step gather moves compact records by default, and the line says how many ranks the collective saw
+    # the per-step gather moves compact records here (--gather compact), and the line says how many ranks the collective saw
     assert d["gather"]["payload"] == "rgbdfe_compact_result" and d["gather"]["bytes_per_record"] == 144
     assert d["gather"]["rccl_ranks"] == 2 and d["gather"]["backend"] == "gloo"
     assert len(d["repeats"]["values"]) == 3 and d["value"] == sorted(d["repeats"]["values"])[1]
+    assert d["parity_check"]["checked"] is False            # a reduced workload has no oracle constants
+
+
+@pytest.mark.parametrize("gather", ["inliers", "compact", "full"])
+def test_bench_two_ranks_full_workload_is_checked_against_the_oracle(gather):
+    """The N > 1 line of the driver's scaling run: configs[1] at world 2 = 2 x 4000 pairs; rank 0 checks the
+    records the all-gather left behind -- both ranks' -- against the oracle's sums over the global pair list
+    (tests/golden/bench_expected.json, orb / 0.01 / 2), for every gather payload."""
+    d = _run_two_ranks(["--steps", "3", "--warmup", "1", "--gather", gather])
+    assert d["config"]["pairs_per_gpu_per_step"] == 4000 and d["n_gpus"] == 2
+    pc = d["parity_check"]
+    assert pc["checked"] and pc["ok"] and "8000 records of 2 ranks" in pc["records"]
+    import bench
+    assert pc["oracle_aggregates"] == bench.expected("orb", 0.01, 2)
+    assert d["gather"]["payload_option"] == gather

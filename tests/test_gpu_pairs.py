@@ -385,7 +385,7 @@ def test_whole_bench_step_matches_oracle(depth_noise):
             inl += ref["n_inl"]
         assert n_edges > 0.95 * len(pq)
         # the constants bench.py checks its own results against are the oracle's
-        exp = bench.EXPECTED["orb", depth_noise]
+        exp = bench.expected("orb", depth_noise, 1)
         assert (int(n_edges), int(iters), int(inl)) == (exp["edges"], exp["real_iterations"], exp["inliers"])
     finally:
         big.close()
@@ -417,7 +417,7 @@ def test_loop_closure_subrecord_matches_oracle():
             ransac += ref["real_iterations"] > 0
         same_place = (pq // 10) == (pt // 10)
         assert n_edges >= 0.9 * same_place.sum() and ransac > n_edges   # true edges found, and junk pairs reached RANSAC
-        exp = bench.EXPECTED["loop_closure", synth.DEPTH_NOISE]
+        exp = bench.expected("loop_closure", synth.DEPTH_NOISE)
         assert (int(n_edges), int(iters), int(inl)) == (exp["edges"], exp["real_iterations"], exp["inliers"])
     finally:
         big.close()
