@@ -196,6 +196,7 @@ struct rgbdfe_ctx {
     // SIFT scratch (allocated with the first SIFT node)
     uint32_t* d_row_part = nullptr;   // max_pairs x max_kp x 3
     uint32_t* d_col_part = nullptr;   // max_pairs x max_kp x 3 (per train row)
+    uint2* d_col_blocks = nullptr;    // max_pairs x sift_col_block_bytes_per_pair() (one-pass matcher: per-row-block column partials)
     uint16_t* d_sm_q = nullptr;       // max_pairs x max_kp
     uint16_t* d_sm_t = nullptr;
     float* d_sm_d = nullptr;
@@ -674,9 +675,9 @@ int enqueue_pairs(rgbdfe_ctx* ctx, const int32_t* qids, const int32_t* tids, int
                             lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
           } else {
             launch_sift_dot(ctx->d_sift_bf16, d_work, mk, (uint32_t)m, max_nq, max_nt, sift_kinds, lane.d_row_part,
-                            lane.d_col_part, ls);
+                            lane.d_col_part, lane.d_col_blocks, ls);
             if (ctx->profiling && first) (void)hipEventRecord(pend.b, ls);
-            launch_sift_finish(ctx->d_sift_f32, d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part,
+            launch_sift_finish(ctx->d_sift_f32, d_work, mk, (uint32_t)m, lane.d_row_part, lane.d_col_part, lane.d_col_blocks,
                                lane.d_sm_q, lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, ls);
           }
           if (ctx->profiling && first) (void)hipEventRecord(pend.c, ls);
@@ -862,6 +863,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   for (auto& ln : ctx->lanes) {
     if (ln.d_row_part) (void)hipFree(ln.d_row_part);
     if (ln.d_col_part) (void)hipFree(ln.d_col_part);
+    if (ln.d_col_blocks) (void)hipFree(ln.d_col_blocks);
     if (ln.d_sm_q) (void)hipFree(ln.d_sm_q);
     if (ln.d_sm_t) (void)hipFree(ln.d_sm_t);
     if (ln.d_sm_d) (void)hipFree(ln.d_sm_d);
@@ -1193,6 +1195,7 @@ static int ensure_sift(rgbdfe_ctx* ctx) {
   for (auto& ln : ctx->lanes) {
     if (hipMalloc((void**)&ln.d_row_part, np * mk * 3 * 4) != hipSuccess ||
         hipMalloc((void**)&ln.d_col_part, np * mk * 3 * 4) != hipSuccess ||
+        hipMalloc((void**)&ln.d_col_blocks, np * sift_col_block_bytes_per_pair()) != hipSuccess ||
         hipMalloc((void**)&ln.d_sm_q, np * mk * 2) != hipSuccess ||
         hipMalloc((void**)&ln.d_sm_t, np * mk * 2) != hipSuccess ||
         hipMalloc((void**)&ln.d_sm_d, np * mk * 4) != hipSuccess ||
@@ -1361,8 +1364,8 @@ int rgbdfe_sift_match_nodes(rgbdfe_ctx* ctx, int32_t query_id, int32_t train_id,
   const uint32_t mk = (uint32_t)ctx->cfg.max_keypoints;
   HIP_TRY(ctx, hipMemcpyAsync(slot.d_work, slot.h_work, sizeof(PairWork), hipMemcpyHostToDevice, lane.stream));
   launch_sift_dot(ctx->d_sift_bf16, slot.d_work, mk, 1u, w.nq, w.nt, w.pad ? 1u : 2u, lane.d_row_part, lane.d_col_part,
-                  lane.stream);
-  launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, 1u, lane.d_row_part, lane.d_col_part, lane.d_sm_q,
+                  lane.d_col_blocks, lane.stream);
+  launch_sift_finish(ctx->d_sift_f32, slot.d_work, mk, 1u, lane.d_row_part, lane.d_col_part, lane.d_col_blocks, lane.d_sm_q,
                      lane.d_sm_t, lane.d_sm_d, lane.d_sm_n, lane.stream);
   HIP_TRY(ctx, hipGetLastError());
   int32_t n = 0;

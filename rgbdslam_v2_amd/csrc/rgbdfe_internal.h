@@ -179,11 +179,14 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uin
 // on the bf16 MFMA, SiftMatchGPU row/column/mutual-best semantics.
 void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,
                      uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_kinds,
-                     uint32_t* row_part, uint32_t* col_part, hipStream_t stream);
+                     uint32_t* row_part, uint32_t* col_part, uint2* col_blocks, hipStream_t stream);
 void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t max_kp,
-                        uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part,
+                        uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part, const uint2* col_blocks,
                         uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n,
                         hipStream_t stream);
+// col_blocks (one-pass float-key path): per pair and 256-row block of the query node, the two largest dot products of every
+// train column (float key bits); sift_col_block_bytes_per_pair() bytes per pair.  nullptr = the two-pass form.
+size_t sift_col_block_bytes_per_pair();
 // FLANN branch with exact neighbours (l2_knn.hip): knn[pair][row] = (d1 bits, d2 bits, nearest train row); then the
 // ratio test + train-unique rule -> (queryIdx, trainIdx, ratio) lists in query order
 void launch_l2_knn2(const float* f32_pool, const PairWork* work, uint32_t max_kp, uint32_t n_pairs, uint32_t max_nq,

@@ -764,6 +764,287 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
   if (r0 + 32 < nx) sift_merge_store<SWAP>(mx1, sx1, r0 + 32, nx, lane, opart);
 }
 
+// ---- float keys, ONE pass ---------------------------------------------------------------------------------------------
+// sift_top2_fast64_kernel<false> with the per-train-column result taken from the SAME sweep (the second
+// pass with swapped operands ran every dot product twice).  What the column side needs is less than what the row side needs:
+// ColMatch_Kernel (ProgramCU.cu:1764-1782) accepts column j only when dist(best) < 0.9 * dist(second); dist is a
+// non-increasing function of the dot product, so an accepted column's best dot is STRICTLY above its second -- its
+// argmax row is unique -- and "col_match[j] == i" for the row i whose best column is j (GetBestMatch, SiftMatchCU.cpp:165)
+// is the same statement as "column j is accepted and dot(i, j) == best dot of column j".  So a column keeps only its two
+// largest dot products, no row index, and the accumulator element itself is the key once more: within one column every
+// element carries the same sequence term, i.e. the float bit patterns of a column order like its dot products.
+//   in the sweep   a lane owns column (lane & 31) of the column tile and sees 16 rows of each of the wave's two row groups:
+//                  2 more VALU per accumulator element (v_med3_u32 + v_max_u32 into one running pair per lane), one
+//                  cross-half exchange and one 8-byte LDS store per column tile and wave;
+//   per Y tile     the four waves' column partials (4 column tiles x 32 columns x 8 bytes each, double buffered by tile
+//                  parity) are merged behind the tile's barrier -- wave w takes column tile w -- and leave as ONE record
+//                  per column and 256-row block: col_blocks[pair][row block][slot][column in tile] = (best, second)
+//                  float bits, slot = column tile + 1 (slot 0 takes the pipeline's empty first digest);
+//   sift_finish    merges the <= 4 row blocks of a column, applies ColMatch's acceptance and the identity above.
+// Rows beyond the node's last one enter as ZERO rows (dot 0: inert for the columns; their own results are never stored).
+constexpr int kColSlots = 36;   // 32 column tiles of a 1024-row node + slot 0 + the merge steps' overrun past the last tile
+
+__global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_onepass_kernel(
+    const uint16_t* __restrict__ bf16_pool, const PairWork* __restrict__ work, uint32_t max_kp,
+    uint32_t n_pairs, uint32_t n_rb, uint32_t* __restrict__ part, uint2* __restrict__ col_blocks) {
+  __shared__ u32x4 tileY[2][kTile * kChunksPerRow];
+  __shared__ uint2 colp[2][4][4][32];   // [tile parity][wave][column tile of the group][column]
+  __shared__ uint2 colp_last[4][32];    // [wave][column]: the ragged tile's last column tile
+  uint32_t pair, rb;
+  sift_block_to_tile(n_rb, pair, rb);
+  if (pair >= n_pairs) return;
+  const PairWork w = work[pair];
+  const int nx = (int)w.nq, ny = (int)w.nt;  // <= 1024 (host)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)(rb * kTile64) >= nx || !(w.pad & 1u)) return;  // block-uniform
+  const int r0 = rb * kTile64 + wv * 64;
+  const int n_active = min(4, (nx - (int)(rb * kTile64) + 63) / 64);   // waves of this block that hold rows
+
+  const uint16_t* __restrict__ xpool = bf16_pool + (size_t)w.q_slot * max_kp * kSiftDim;
+  const uint16_t* __restrict__ ypool = bf16_pool + (size_t)w.t_slot * max_kp * kSiftDim;
+  const int n_tiles = (ny + kTile - 1) / kTile;
+  const int n_full = ny / kTile;
+  uint2* __restrict__ cblk = col_blocks + ((size_t)pair * 4 + rb) * (kColSlots * 32);
+
+  // tile staging: see sift_top2_fast64_kernel
+  const int sw_lane = (lane & ~15) | ((lane & 15) ^ (lane >> 4));
+  uint32_t voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) voff[j] = (uint32_t)((wv * 512 + (sw_lane ^ (j * 4))) * 16 + 4096);
+  const uint64_t ybase = reinterpret_cast<uint64_t>(ypool);
+  const uint32_t yb_lo = __builtin_amdgcn_readfirstlane((uint32_t)ybase);
+  const uint32_t yb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ybase >> 32));
+#define S1_GLDS(TB, BUF, I)                                                                                 \
+  {                                                                                                         \
+    uint32_t vo = voff[(I) & 3];                                                                            \
+    asm volatile("" : "+v"(vo));                                                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((TB) + vo),            \
+                                     (__attribute__((address_space(3))) void*)&tileY[BUF][wv * 512 + 256], 16, \
+                                     (I) * 1024 - 4096, 0);                                                 \
+  }
+#define S1_STAGE_TILE(TILE, BUF)                                                                            \
+  {                                                                                                         \
+    const char* tb = reinterpret_cast<const char*>((((uint64_t)yb_hi << 32) | yb_lo) +                      \
+                                                   (uint64_t)(uint32_t)(TILE) * (kTile * kChunksPerRow * 16)); \
+    S1_GLDS(tb, BUF, 0) S1_GLDS(tb, BUF, 1) S1_GLDS(tb, BUF, 2) S1_GLDS(tb, BUF, 3)                         \
+    S1_GLDS(tb, BUF, 4) S1_GLDS(tb, BUF, 5) S1_GLDS(tb, BUF, 6) S1_GLDS(tb, BUF, 7)                         \
+  }
+  // The column partials of group G (the column tiles whose digests ended between barrier G - 1 and barrier G: column tiles
+  // 4 G - 1 .. 4 G + 2, slots 4 G .. 4 G + 3) -> col_blocks: wave wv merges slot 4 G + wv over the block's active waves.
+  // Straight-line code for every lane: lanes 32 .. 63 repeat the work of lanes 0 .. 31 (same value to the same address),
+  // slot 0 and slots past the node's last column tile receive whatever the buffer held -- nobody reads them.
+#define S1_MERGE_GROUP(G)                                                                                   \
+  {                                                                                                         \
+    const int g_ = (G);                                                                                     \
+    uint32_t m_ = 0u, n_ = 0u;                                                                              \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                         \
+      const uint2 p = colp[g_ & 1][a][wv][lane & 31];                                                       \
+      const uint32_t pm = a < n_active ? p.x : 0u, pn = a < n_active ? p.y : 0u;                            \
+      n_ = max(max(min(m_, pm), n_), pn);                                                                   \
+      m_ = max(m_, pm);                                                                                     \
+    }                                                                                                       \
+    const int slot = max(4 * g_ + wv, 0);                                                                   \
+    cblk[slot * 32 + (lane & 31)] = make_uint2(m_, n_);                                                     \
+  }
+  S1_STAGE_TILE(0, 0)
+
+  if (r0 >= nx) {  // a wave without rows: its share of the staging and of the column merges, the same barriers
+    __syncthreads();
+    for (int tile = 0; tile < n_full; ++tile) {
+      S1_MERGE_GROUP(tile - 1)
+      if (tile & 1) { S1_STAGE_TILE(tile + 1, 0) } else { S1_STAGE_TILE(tile + 1, 1) }
+      __syncthreads();
+    }
+    S1_MERGE_GROUP(n_full - 1)
+    __syncthreads();
+    S1_MERGE_GROUP(n_full)   // (the slot behind a ragged tile is wave 0's, and wave 0 holds rows whenever the block runs)
+    return;
+  }
+
+  bf16x8 A0[8], A1[8];
+  {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    int row = r0 + (lane & 31);
+    const u32x4* src = reinterpret_cast<const u32x4*>(xpool + (size_t)min(row, nx - 1) * kSiftDim + (lane >> 5) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) A0[ks] = __builtin_bit_cast(bf16x8, row < nx ? src[ks * 2] : zero);
+    row = r0 + 32 + (lane & 31);
+    src = reinterpret_cast<const u32x4*>(xpool + (size_t)min(row, nx - 1) * kSiftDim + (lane >> 5) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) A1[ks] = __builtin_bit_cast(bf16x8, row < nx ? src[ks * 2] : zero);
+  }
+  const uint32_t k0 = (lane < 32) ? 0xFFFFFFFFu : 0u;
+  const bf16x8 A9 = __builtin_bit_cast(bf16x8, u32x4{0x3F80u & k0, 0u, 0u, 0u});
+  auto seq_term = [&](int seq) {
+    const float term = (float)(31 - seq) * 0.03125f;
+    return __builtin_bit_cast(bf16x8, u32x4{(__float_as_uint(term) >> 16) & k0, 0u, 0u, 0u});
+  };
+
+  uint32_t mx0[16], sx0[16], mx1[16], sx1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx0[r] = sx0[r] = mx1[r] = sx1[r] = 0u;
+  uint32_t cm = 0u, cn = 0u;   // this lane's column of the column tile in flight: best / second over the wave's rows so far
+  __syncthreads();
+
+  const uint32_t abyte = (uint32_t)((lane & 31) * 256 + ((((lane >> 5) ^ lane) & 15) << 4));
+  const char* lds_bytes = reinterpret_cast<const char*>(&tileY[0][0]);
+  uint2* const my_colp = &colp[0][wv][0][lane & 31];   // + parity * 512 + column tile * 32 (in uint2)
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+  bf16x8 Bf[8];
+
+#define S1_READ_ONE(BOFF, CT, KS)                                                                   \
+  {                                                                                                 \
+    uint32_t a;                                                                                     \
+    asm volatile("v_xor_b32 %0, %2, %1" : "=v"(a) : "v"(abyte), "n"((KS) << 5));                     \
+    Bf[KS] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_bytes + (a + (BOFF)) + (CT) * 8192)); \
+  }
+#define S1_READ_B(BOFF, CT)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) S1_READ_ONE(BOFF, CT, ks)
+#define S1_MFMA_ONE(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0);
+  // row side (OK: the lane's "column exists" flag, or true) and column side of one accumulator
+#define S1_DIGEST(ACC, MX, SX, OK)                                                                  \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+    const uint32_t key = __float_as_uint(ACC[r]);                                                   \
+    top2_insert(MX[r], SX[r], (OK) ? key : 0u);                                                     \
+    top2_insert(cm, cn, key);                                                                       \
+  }
+  // the column tile whose second accumulator has just been digested is complete: both lane halves hold the same 32
+  // columns (rows +0 / +4) -> one pair per column into the wave's slot PSLOT of the tile parity PBUF; start the next one
+#define S1_COLUMN_DONE(PBUF_OFF, PSLOT)                                                             \
+  {                                                                                                 \
+    const uint32_t pm = (uint32_t)__shfl_xor((int)cm, 32), pn = (uint32_t)__shfl_xor((int)cn, 32);   \
+    cn = max(max(min(cm, pm), cn), pn);                                                             \
+    cm = max(cm, pm);                                                                               \
+    my_colp[(PBUF_OFF) + (PSLOT) * 32] = make_uint2(cm, cn);                                        \
+    cm = 0u;                                                                                        \
+    cn = 0u;                                                                                        \
+  }
+#define S1_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define S1_TAIL_SCHED(WITH_READS, NV)                                   \
+  _Pragma("unroll") for (int g = 0; g < 7; ++g) {                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
+    if ((WITH_READS) && g < 6) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); \
+    if ((WITH_READS) && g < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);               \
+  }                                                                     \
+  S1_FENCE()
+#define S1_PIN(ACC) asm volatile("" : "+v"(ACC));
+  // column tile CT of the Y tile in buffer offset BOFF; PBUF_OFF: the tile parity's offset into colp (in uint2)
+#define S1_COLUMN_TILE(BOFF, PBUF_OFF, CT, SEQ, WITH_READS, OK_PREV, OK_THIS, NV)                   \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;                                     \
+  S1_MFMA_ONE(acc0, A0[0], Bf[0])                                                                   \
+  S1_MFMA_ONE(acc0, A0[1], Bf[1])                                                                   \
+  S1_PIN(acc0)                                                                                      \
+  S1_FENCE()                                                                                        \
+  S1_PIN(acc1)                                                                                      \
+  _Pragma("unroll") for (int ks = 2; ks < 8; ++ks) S1_MFMA_ONE(acc0, A0[ks], Bf[ks])                 \
+  S1_MFMA_ONE(acc0, A9, seq_term(SEQ))                                                              \
+  S1_PIN(acc0)                                                                                      \
+  S1_DIGEST(acc1, mx1, sx1, OK_PREV)                                                                \
+  S1_TAIL_SCHED(false, NV)                                                                          \
+  S1_COLUMN_DONE(PBUF_OFF, CT)                                                                      \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                 \
+    S1_MFMA_ONE(acc1, A1[ks], Bf[ks])                                                               \
+    if (WITH_READS) S1_READ_ONE(BOFF, (CT) + 1, ks)                                                 \
+  }                                                                                                 \
+  S1_PIN(acc1)                                                                                      \
+  S1_FENCE()                                                                                        \
+  S1_PIN(acc0)                                                                                      \
+  _Pragma("unroll") for (int ks = 2; ks < 8; ++ks) {                                                 \
+    S1_MFMA_ONE(acc1, A1[ks], Bf[ks])                                                               \
+    if (WITH_READS) S1_READ_ONE(BOFF, (CT) + 1, ks)                                                 \
+  }                                                                                                 \
+  S1_MFMA_ONE(acc1, A9, seq_term(SEQ))                                                              \
+  S1_PIN(acc1)                                                                                      \
+  S1_DIGEST(acc0, mx0, sx0, OK_THIS)                                                                \
+  S1_TAIL_SCHED(WITH_READS, NV)
+  // one full Y tile out of buffer BUF (a constant: the loop is unrolled by two); the column partials the previous tile's
+  // waves left behind its barrier go out first
+#define S1_FULL_TILE(BUF)                                                                           \
+  {                                                                                                 \
+    S1_MERGE_GROUP(tile - 1)                                                                        \
+    S1_STAGE_TILE(tile + 1, (BUF) ^ 1)                                                              \
+    const int seq0 = tile * 4;                                                                      \
+    S1_READ_B((BUF) * 32768, 0)                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 0, seq0, true, true, true, 11)                       \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 1, seq0 + 1, true, true, true, 11)                   \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 2, seq0 + 2, true, true, true, 11)                   \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 3, seq0 + 3, false, true, true, 11)                  \
+    __syncthreads();                                                                                \
+    ++tile;                                                                                         \
+  }
+
+  int tile = 0;
+  while (tile + 1 < n_full) {
+    S1_FULL_TILE(0)
+    S1_FULL_TILE(1)
+  }
+  if (tile < n_full) S1_FULL_TILE(0)   // n_full odd: `tile` is even here
+  // Behind the last full tile's barrier: its group goes out; acc1 still holds the last column tile of that tile (or the
+  // pipeline's empty start) = slot 0 of group `tile`.
+  S1_MERGE_GROUP(tile - 1)
+  {
+    const int pb = (tile & 1) * 512;
+    if (tile < n_tiles) {  // ragged last tile: the same pipeline, columns beyond ny carry key 0 on the row side
+      const int c0 = tile * kTile + (lane & 31);
+      const bool ok0 = c0 < ny, ok1 = c0 + 32 < ny, ok2 = c0 + 64 < ny, ok3 = c0 + 96 < ny;
+      const uint32_t boff = (uint32_t)(tile & 1) * 32768u;
+      const int seq0 = tile * 4;
+      S1_READ_B(boff, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      S1_COLUMN_TILE(boff, pb, 0, seq0, true, true, ok0, 13)       // (its first half digests the column tile in flight)
+      S1_COLUMN_TILE(boff, pb, 1, seq0 + 1, true, ok0, ok1, 13)
+      S1_COLUMN_TILE(boff, pb, 2, seq0 + 2, true, ok1, ok2, 13)
+      S1_COLUMN_TILE(boff, pb, 3, seq0 + 3, false, ok2, ok3, 13)
+      // the ragged tile's last column tile = slot 0 of the group after this one: a buffer of its own (the other parity may
+      // still be read by a wave that has not merged the last full tile's group yet)
+      S1_DIGEST(acc1, mx1, sx1, ok3)
+      {
+        const uint32_t pm = (uint32_t)__shfl_xor((int)cm, 32), pn = (uint32_t)__shfl_xor((int)cn, 32);
+        colp_last[wv][lane & 31] = make_uint2(max(cm, pm), max(max(min(cm, pm), cn), pn));
+      }
+    } else {
+      S1_DIGEST(acc1, mx1, sx1, true)
+      S1_COLUMN_DONE(pb, 0)
+    }
+  }
+  __syncthreads();
+  S1_MERGE_GROUP(tile)
+  if (tile < n_tiles && wv == 0) {   // slot 0 of the group after the ragged tile's
+    uint32_t m_ = 0u, n_ = 0u;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const uint2 p = colp_last[a][lane & 31];
+      const uint32_t pm = a < n_active ? p.x : 0u, pn = a < n_active ? p.y : 0u;
+      n_ = max(max(min(m_, pm), n_), pn);
+      m_ = max(m_, pm);
+    }
+    cblk[(4 * tile + 4) * 32 + (lane & 31)] = make_uint2(m_, n_);
+  }
+#undef S1_FULL_TILE
+#undef S1_MFMA_ONE
+#undef S1_READ_ONE
+#undef S1_STAGE_TILE
+#undef S1_GLDS
+#undef S1_READ_B
+#undef S1_DIGEST
+#undef S1_COLUMN_DONE
+#undef S1_TAIL_SCHED
+#undef S1_PIN
+#undef S1_FENCE
+#undef S1_COLUMN_TILE
+#undef S1_MERGE_GROUP
+  uint32_t* __restrict__ opart = part + (size_t)pair * max_kp * 3;
+  sift_merge_store<false>(mx0, sx0, r0, nx, lane, opart);
+  if (r0 + 32 < nx) sift_merge_store<false>(mx1, sx1, r0 + 32, nx, lane, opart);
+}
+
 __device__ __forceinline__ float sift_angle(uint32_t dot) {
   // ProgramCU.cu:1738: acos(min(dot * 0.000003814697265625f, 1.0)): float product, double min/acos
   const float prod = (float)(int)dot * 0.000003814697265625f;
@@ -779,7 +1060,7 @@ __device__ __forceinline__ float sift_angle(uint32_t dot) {
 // descriptors (sift_gpu_wrapper.cpp:211-217).
 __global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
     const float* __restrict__ f32_pool, const PairWork* __restrict__ work, uint32_t max_kp,
-    const uint32_t* __restrict__ row_part, uint32_t* __restrict__ col_part,
+    const uint32_t* __restrict__ row_part, uint32_t* __restrict__ col_part, const uint2* __restrict__ col_blocks,
     uint16_t* __restrict__ sm_q, uint16_t* __restrict__ sm_t, float* __restrict__ sm_d,
     int32_t* __restrict__ sm_n, uint32_t n_pairs) {
   __shared__ uint32_t wave_cnt[4];
@@ -801,13 +1082,33 @@ __global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
     return;
   }
   uint32_t* __restrict__ cbase = col_part + (size_t)pair * max_kp * 3;
-  // ---- ColMatch_Kernel acceptance: col_match[j] replaces the best-dot slot
-  for (int j = tid; j < nt; j += kSiftThreads) {
-    const uint32_t dot = cbase[(size_t)j * 3], dotn = cbase[(size_t)j * 3 + 1];
-    const int row = (int)cbase[(size_t)j * 3 + 2];
-    const float dist = sift_angle(dot), distn = sift_angle(dotn);
-    const int cm = (dist < distmax) && (dist < distn * ratiomax) ? row : -1;  // :1781
-    cbase[(size_t)j * 3] = (uint32_t)cm;
+  // one-pass pairs (sift_top2_onepass_kernel): a column's two largest dot products per 256-row block instead of
+  // (best, second, argmax row); the mutual-best test below compares dot products instead of row indices
+  const bool onepass = col_blocks != nullptr && (w.pad & 1u);
+  if (onepass) {
+    const uint2* __restrict__ cb = col_blocks + (size_t)pair * 4 * (kColSlots * 32);
+    const int n_blk = (nq + kTile64 - 1) / kTile64;
+    for (int j = tid; j < nt; j += kSiftThreads) {
+      uint32_t m = 0u, n = 0u;
+      for (int b = 0; b < n_blk; ++b) {
+        const uint2 p = cb[(size_t)b * (kColSlots * 32) + 32 + j];   // slot = column tile + 1
+        n = max(max(min(m, p.x), n), p.y);
+        m = max(m, p.x);
+      }
+      const uint32_t dot = (uint32_t)__uint_as_float(m), dotn = (uint32_t)__uint_as_float(n);   // dot + (31 - seq) / 32
+      const float dist = sift_angle(dot), distn = sift_angle(dotn);
+      // accepted (:1781) => best > second strictly => the argmax row is the one row whose dot equals `dot`
+      cbase[(size_t)j * 3] = (dist < distmax) && (dist < distn * ratiomax) ? dot : 0xFFFFFFFFu;
+    }
+  } else {
+    // ---- ColMatch_Kernel acceptance: col_match[j] replaces the best-dot slot
+    for (int j = tid; j < nt; j += kSiftThreads) {
+      const uint32_t dot = cbase[(size_t)j * 3], dotn = cbase[(size_t)j * 3 + 1];
+      const int row = (int)cbase[(size_t)j * 3 + 2];
+      const float dist = sift_angle(dot), distn = sift_angle(dotn);
+      const int cm = (dist < distmax) && (dist < distn * ratiomax) ? row : -1;  // :1781
+      cbase[(size_t)j * 3] = (uint32_t)cm;
+    }
   }
   __syncthreads();
   // ---- RowMatch acceptance (:1738-1742) + mutual best in ascending query order
@@ -822,7 +1123,7 @@ __global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
       const int idx = (int)rpart[(size_t)i * 3 + 2];
       const float dist = sift_angle(dot), distn = sift_angle(dotn);
       j = (dist < distmax) && (dist < distn * ratiomax) ? idx : -1;
-      keep = j >= 0 && (int)cbase[(size_t)j * 3] == i;  // SiftMatchCU.cpp:165
+      keep = j >= 0 && cbase[(size_t)j * 3] == (onepass ? dot : (uint32_t)i);  // SiftMatchCU.cpp:165
     }
     const uint64_t m = __ballot(keep);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
@@ -905,9 +1206,16 @@ __global__ __launch_bounds__(kSiftThreads) void sift_finish_kernel(
   }
 }
 
+// RGBDFE_SIFT_ONEPASS=0: the two-pass form of the float-key path (A/B runs)
+static bool sift_onepass_enabled() {
+  static const bool on = !(getenv("RGBDFE_SIFT_ONEPASS") && atoi(getenv("RGBDFE_SIFT_ONEPASS")) == 0);
+  return on;
+}
+size_t sift_col_block_bytes_per_pair() { return (size_t)4 * kColSlots * 32 * sizeof(uint2); }
+
 void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t max_kp,
                      uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_kinds,
-                     uint32_t* row_part, uint32_t* col_part, hipStream_t stream) {
+                     uint32_t* row_part, uint32_t* col_part, uint2* col_blocks, hipStream_t stream) {
   if (n_pairs == 0) return;
   uint32_t rbq = (max_nq + kTile - 1) / kTile, rbt = (max_nt + kTile - 1) / kTile;
   if (rbq < 1) rbq = 1;
@@ -915,7 +1223,13 @@ void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t m
   // key_kinds: bit 0 = some pair of the batch carries float keys (PairWork::pad bit 0), bit 1 = some pair integer keys;
   // each kernel leaves the other kind's pairs at once
   const uint32_t groups = (n_pairs + 7u) / 8u * 8u;
-  if (key_kinds & 1u) {
+  if ((key_kinds & 1u) && col_blocks && sift_onepass_enabled()) {
+    // one sweep: row results + per-block column partials (fast pairs hold at most 1024 rows: at most 4 row blocks)
+    uint32_t rb = (max_nq + kTile64 - 1) / kTile64;
+    if (rb < 1) rb = 1;
+    hipLaunchKernelGGL(sift_top2_onepass_kernel, dim3(rb * groups), dim3(kSiftThreads), 0, stream, bf16_pool, work, max_kp,
+                       n_pairs, rb, row_part, col_blocks);
+  } else if (key_kinds & 1u) {
     // 64 rows per wave (256-row blocks) unless the batch's nodes fit one 128-row block; RGBDFE_SIFT_ROWS64=0/1 forces
     // one kernel for A/B runs
     static const int rows64_env = [] { const char* e = getenv("RGBDFE_SIFT_ROWS64"); return e ? atoi(e) : -1; }();
@@ -943,12 +1257,13 @@ void launch_sift_dot(const uint16_t* bf16_pool, const PairWork* work, uint32_t m
 }
 
 void launch_sift_finish(const float* f32_pool, const PairWork* work, uint32_t max_kp,
-                        uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part,
+                        uint32_t n_pairs, const uint32_t* row_part, uint32_t* col_part, const uint2* col_blocks,
                         uint16_t* sm_q, uint16_t* sm_t, float* sm_d, int32_t* sm_n,
                         hipStream_t stream) {
   if (n_pairs == 0) return;
   hipLaunchKernelGGL(sift_finish_kernel, dim3((n_pairs + 7u) / 8u * 8u), dim3(kSiftThreads), 0, stream, f32_pool, work,
-                     max_kp, row_part, col_part, sm_q, sm_t, sm_d, sm_n, n_pairs);
+                     max_kp, row_part, col_part, sift_onepass_enabled() ? col_blocks : (const uint2*)nullptr, sm_q, sm_t, sm_d,
+                     sm_n, n_pairs);
 }
 
 }  // namespace rgbdfe

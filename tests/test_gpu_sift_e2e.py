@@ -18,8 +18,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-POSE_TOL = 1e-4          # north_star: RANSAC pose for float descriptors
-BYTE_FLIP_FRACTION = 0.02
+POSE_TOL = 1e-4              # north_star: RANSAC pose for float descriptors
+BYTE_FLIP_FRACTION = 1e-3    # measured: 1 .. 29 of 3e5 .. 4e5 quantised bytes (profiles/r04/sift_e2e.json)
+REORDERED_POSE_TOL = 3e-2    # a pair whose match ORDER differs takes another RANSAC trajectory (see the second test)
 
 
 @pytest.fixture(scope="module")
@@ -38,33 +39,43 @@ def report():
 
 
 def test_extraction_hands_the_matcher_the_same_features(report):
-    """Feature lists (count, order, positions, the 3-D points projectTo3DSiftGPU makes of them) are identical; the bytes the
-    SiftGPU matcher quantises the descriptors to differ in a small fraction of positions, by one step."""
+    """Feature lists (count, order, positions, the 3-D points projectTo3DSiftGPU makes of them) are identical; of the bytes
+    the SiftGPU matcher quantises the descriptors to, at most one in a thousand differs (measured: 1e-5 .. 1e-4), by a few
+    steps at most (a feature whose orientation histogram peak moved by a fraction of a bin)."""
     for name, r in report.items():
         assert r["feature_lists_identical"] and r["position_or_point_differences"] == 0, name
         assert r["features_a"][0] == r["features_a"][1] > 300 and r["features_b"][0] == r["features_b"][1] > 300, name
         assert r["quantised_bytes_that_differ"] <= BYTE_FLIP_FRACTION * r["quantised_bytes"], name
-        assert r["largest_byte_step"] <= 2, name
+        assert r["largest_byte_step"] <= 8 and r["largest_descriptor_relative_l2_difference"] <= 5e-2, name
 
 
 @pytest.mark.parametrize("variant", ["siftgpu_matcher_normalised", "flann_rootsift"])
 def test_edges_and_poses_agree_with_reference_features(report, variant):
-    """Same edge decision on every pair; where the match lists are identical the inlier sets are too and the pose agrees
-    within north_star's 1e-4; where a handful of matches differ the inlier counts stay within 2 % and the pose within 5e-3."""
+    """The same edge decision and the same SET of matches on every pair.  Where the match lists are identical in order too,
+    everything downstream is identical: inlier sets, and the pose to the bit (<= north_star's 1e-4).  DMatch.distance is an
+    f32 L2 norm of the raw descriptors (sift_gpu_wrapper.cpp:211-217) and keepStrongestMatches sorts by it, so descriptors
+    that differ in the 4th digit can swap two neighbours of the sorted list: the sampler then draws other matches for the
+    same random numbers, RANSAC takes another trajectory and ends at another -- equally valid -- consensus set.  For those
+    pairs: inlier counts within 2 %, pose within the spread RANSAC itself has between two seeds on these views."""
+    identical = 0
     for name, r in report.items():
         v = r[variant]
         assert v["edge"] == [True, True], (name, v)
-        assert min(v["matches"]) >= 100 and v["matches_only_on_one_side"] <= 0.05 * max(v["matches"]), (name, v)
+        assert min(v["matches"]) >= 100 and v["matches_only_on_one_side"] <= 0.02 * max(v["matches"]), (name, v)
         if v["match_lists_identical"]:
+            identical += 1
             assert v["inliers_only_on_one_side"] == 0 and v["pose_max_abs_diff"] <= POSE_TOL, (name, v)
+            assert v["pose_max_abs_diff"] == 0.0 and v["rmse"][0] == v["rmse"][1], (name, v)
         else:
             assert abs(v["inliers"][0] - v["inliers"][1]) <= 0.02 * max(v["inliers"]) + 2, (name, v)
-            assert v["pose_max_abs_diff"] <= 5e-3, (name, v)
+            assert v["pose_max_abs_diff"] <= REORDERED_POSE_TOL, (name, v)
+    assert identical >= len(report) // 2, identical    # (measured: 3 of 4 views per matcher)
 
 
 def test_the_wrapper_as_written_matches_nothing_on_either_side(report):
     """matcher_type SIFTGPU with the wrapper's "-unn" descriptors (norm ~2) and SiftMatchGPU's byte quantisation
-    (SiftMatchCU.cpp:96-99): the bytes wrap around; both sides see the same (near-)empty outcome -- recorded, not fixed."""
+    (SiftMatchCU.cpp:96-99): the bytes wrap around and no mutual-best pair passes the tests -- on both sides alike.
+    Recorded as a property of the reference, not fixed."""
     for name, r in report.items():
         v = r["siftgpu_matcher_unn"]
-        assert v["edge"][0] == v["edge"][1] and abs(v["matches"][0] - v["matches"][1]) <= 5, (name, v)
+        assert v["edge"] == [False, False] and v["matches"][0] == v["matches"][1] and v["matches"][0] <= 5, (name, v)

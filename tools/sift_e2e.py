@@ -93,7 +93,6 @@ VARIANTS = (
 def evaluate(fe, po, only=None):
     from rgbdslam_v2_amd.frontend import inlier_indices
     report = {}
-    node_id = 0
     for name, ga, da, gb, db in views():
         if only and name not in only:
             continue
@@ -126,8 +125,7 @@ def evaluate(fe, po, only=None):
         for vname, kind, pick in VARIANTS:
             out = {}
             for side in ("reference", "product"):
-                ia, ib = node_id, node_id + 1
-                node_id += 2
+                ia, ib = 1, 0   # the same node ids on both sides: the pair's RANSAC draws are a function of them
                 up = fe.upload_sift_node if kind == "sift" else fe.upload_float_node
                 up(ia, pick(nodes[side, "a"]), nodes[side, "a"]["xyz1"])
                 up(ib, pick(nodes[side, "b"]), nodes[side, "b"]["xyz1"])

@@ -4,7 +4,7 @@ context's own streams and wait for those only).  Besides the tests' own assertio
 captures another thread invalidated (`capture_failures`) must stay 0 while a second context is created, SIFT slabs and
 keypoint slabs are first used and detectors are prepared on other threads.
 
-    python tools/stress_threads.py [rounds=50]
+    python tools/stress_threads.py [rounds=20]
 """
 import os
 import sys
@@ -20,7 +20,7 @@ from rgbdslam_v2_amd import synth  # noqa: E402
 from rgbdslam_v2_amd.frontend import FrontEnd  # noqa: E402
 import test_gpu_multi as tm  # noqa: E402
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seq = synth.make_sequence(n_frames=14, n_kp=500, n_world=2000, seed=21)
 pq, pt = synth.candidate_pairs(14, per_frame=7, seed=21)
 data = (seq, pq, pt)
@@ -33,6 +33,8 @@ for r in range(rounds):
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("round %d %s: %r" % (r, fn.__name__, e), flush=True)
+    if r % 5 == 4:
+        print("  %d rounds, %d failures, %.1f s" % (r + 1, fails, time.time() - t0), flush=True)
 print("many-threads tests: %d rounds x 2, %d failures, %.1f s" % (rounds, fails, time.time() - t0), flush=True)
 
 # captures of one context while other threads create contexts / first-use allocations
