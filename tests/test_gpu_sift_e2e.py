@@ -20,7 +20,6 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 POSE_TOL = 1e-4              # north_star: RANSAC pose for float descriptors
 BYTE_FLIP_FRACTION = 1e-3    # measured: 1 .. 29 of 3e5 .. 4e5 quantised bytes (profiles/r04/sift_e2e.json)
-REORDERED_POSE_TOL = 3e-2    # a pair whose match ORDER differs takes another RANSAC trajectory (see the second test)
 
 
 @pytest.fixture(scope="module")
@@ -51,25 +50,23 @@ def test_extraction_hands_the_matcher_the_same_features(report):
 
 @pytest.mark.parametrize("variant", ["siftgpu_matcher_normalised", "flann_rootsift"])
 def test_edges_and_poses_agree_with_reference_features(report, variant):
-    """The same edge decision and the same SET of matches on every pair.  Where the match lists are identical in order too,
-    everything downstream is identical: inlier sets, and the pose to the bit (<= north_star's 1e-4).  DMatch.distance is an
-    f32 L2 norm of the raw descriptors (sift_gpu_wrapper.cpp:211-217) and keepStrongestMatches sorts by it, so descriptors
-    that differ in the 4th digit can swap two neighbours of the sorted list: the sampler then draws other matches for the
-    same random numbers, RANSAC takes another trajectory and ends at another -- equally valid -- consensus set.  For those
-    pairs: inlier counts within 2 %, pose within the spread RANSAC itself has between two seeds on these views."""
+    """The same edge decision, the same SET of matches, the same inlier set and a pose within north_star's 1e-4 on every
+    pair (measured: 0 .. 2.4e-7, profiles/r04/sift_e2e.json).  Where the match lists are identical in order too -- 6 of the
+    8 (view, matcher) cases -- the pose is identical to the bit.  In the other two, descriptors that differ in the 4th digit
+    swap neighbours of the distance-sorted list (DMatch.distance is an f32 L2 norm of the raw descriptors,
+    sift_gpu_wrapper.cpp:211-217): the same matches in another order, the same consensus set, the final fit summed in
+    another order."""
     identical = 0
     for name, r in report.items():
         v = r[variant]
         assert v["edge"] == [True, True], (name, v)
-        assert min(v["matches"]) >= 100 and v["matches_only_on_one_side"] <= 0.02 * max(v["matches"]), (name, v)
+        assert min(v["matches"]) >= 100 and v["matches_only_on_one_side"] == 0, (name, v)
+        assert v["inliers"][0] == v["inliers"][1] and v["inliers_only_on_one_side"] == 0, (name, v)
+        assert v["pose_max_abs_diff"] <= POSE_TOL, (name, v)
         if v["match_lists_identical"]:
             identical += 1
-            assert v["inliers_only_on_one_side"] == 0 and v["pose_max_abs_diff"] <= POSE_TOL, (name, v)
             assert v["pose_max_abs_diff"] == 0.0 and v["rmse"][0] == v["rmse"][1], (name, v)
-        else:
-            assert abs(v["inliers"][0] - v["inliers"][1]) <= 0.02 * max(v["inliers"]) + 2, (name, v)
-            assert v["pose_max_abs_diff"] <= REORDERED_POSE_TOL, (name, v)
-    assert identical >= len(report) // 2, identical    # (measured: 3 of 4 views per matcher)
+    assert identical >= len(report) // 2, identical
 
 
 def test_the_wrapper_as_written_matches_nothing_on_either_side(report):

@@ -18,24 +18,23 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from rgbdslam_v2_amd import synth  # noqa: E402
 from rgbdslam_v2_amd.frontend import FrontEnd  # noqa: E402
-import test_gpu_multi as tm  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seq = synth.make_sequence(n_frames=14, n_kp=500, n_world=2000, seed=21)
 pq, pt = synth.candidate_pairs(14, per_frame=7, seed=21)
-data = (seq, pq, pt)
 t0 = time.time()
 fails = 0
+# the two tests as pytest runs them, `rounds` processes one after the other (a fresh HIP runtime each time)
+import subprocess  # noqa: E402
 for r in range(rounds):
-    for fn in (tm.test_one_context_from_many_threads, tm.test_one_group_handle_from_many_threads):
-        try:
-            fn(data)
-        except Exception as e:  # noqa: BLE001
-            fails += 1
-            print("round %d %s: %r" % (r, fn.__name__, e), flush=True)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_multi.py"), "-q", "-x", "-p",
+                          "no:cacheprovider", "-k", "many_threads", "--timeout", "120"], cwd=ROOT, capture_output=True, text=True)
+    if out.returncode != 0:
+        fails += 1
+        print("round %d failed:\n%s" % (r, out.stdout[-1500:]), flush=True)
     if r % 5 == 4:
         print("  %d rounds, %d failures, %.1f s" % (r + 1, fails, time.time() - t0), flush=True)
-print("many-threads tests: %d rounds x 2, %d failures, %.1f s" % (rounds, fails, time.time() - t0), flush=True)
+print("many-threads tests: %d rounds x 2 tests, %d failures, %.1f s" % (rounds, fails, time.time() - t0), flush=True)
 
 # captures of one context while other threads create contexts / first-use allocations
 main = FrontEnd(device_id=0, max_nodes=24, max_keypoints=512, max_pairs_per_batch=64)
@@ -61,13 +60,14 @@ def churn():
         side_errors.append(repr(e))
 
 
+print("captures beside context churn ...", flush=True)
 th = [threading.Thread(target=churn) for _ in range(2)]
 for t in th:
     t.start()
 wrong = 0
 n_batches = 0
 t1 = time.time()
-while time.time() - t1 < 20.0:
+while time.time() - t1 < 15.0:
     n = 5 + n_batches % 40                      # a new batch shape (= a capture) most of the time
     if main.match_pair_list(pq[:n], pt[:n]).tobytes() != ref[: n * 1744]:
         wrong += 1
