@@ -783,6 +783,35 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_fast64_kernel(
 //   sift_finish    merges the <= 4 row blocks of a column, applies ColMatch's acceptance and the identity above.
 // Rows beyond the node's last one enter as ZERO rows (dot 0: inert for the columns; their own results are never stored).
 constexpr int kColSlots = 36;   // 32 column tiles of a 1024-row node + slot 0 + the merge steps' overrun past the last tile
+// build-time variants of the one-pass kernel (tools/sweep_sift_onepass.sh): VALU slots per MFMA in the scheduling hint, the
+// cross-half exchange as v_permlane32_swap instead of ds_bpermute, the column side as a tree over the accumulator
+#ifndef RGBDFE_SIFT1_NV
+#define RGBDFE_SIFT1_NV 11
+#endif
+#ifndef RGBDFE_SIFT1_SWAP
+#define RGBDFE_SIFT1_SWAP 1
+#endif
+#ifndef RGBDFE_SIFT1_TREE
+#define RGBDFE_SIFT1_TREE 0
+#endif
+// upper 32 lanes' value in the lower 32 lanes (and vice versa)
+__device__ __forceinline__ uint32_t other_half(uint32_t v) {
+#if RGBDFE_SIFT1_SWAP
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // lanes 32..63 of the first <-> lanes 0..31 of the second
+  return (threadIdx.x & 32u) ? r[0] : r[1];
+#else
+  return (uint32_t)__shfl_xor((int)v, 32);
+#endif
+}
+// (best, second) of three keys: 2 VALU; merge of two such pairs: 3 VALU
+__device__ __forceinline__ void top2_of3(uint32_t a, uint32_t b, uint32_t c, uint32_t& m, uint32_t& n) {
+  m = max(max(a, b), c);
+  n = max(min(a, b), min(max(a, b), c));   // median of three (v_med3_u32)
+}
+__device__ __forceinline__ void top2_merge(uint32_t& m, uint32_t& n, uint32_t pm, uint32_t pn) {
+  n = max(max(min(m, pm), n), pn);
+  m = max(m, pm);
+}
 
 __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_onepass_kernel(
     const uint16_t* __restrict__ bf16_pool, const PairWork* __restrict__ work, uint32_t max_kp,
@@ -906,17 +935,40 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_onepass_kernel(
   _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) S1_READ_ONE(BOFF, CT, ks)
 #define S1_MFMA_ONE(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0);
   // row side (OK: the lane's "column exists" flag, or true) and column side of one accumulator
+#if RGBDFE_SIFT1_TREE
+#define S1_DIGEST(ACC, MX, SX, OK)                                                                  \
+  {                                                                                                 \
+    uint32_t k_[16];                                                                                \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+      k_[r] = __float_as_uint(ACC[r]);                                                              \
+      top2_insert(MX[r], SX[r], (OK) ? k_[r] : 0u);                                                 \
+    }                                                                                               \
+    uint32_t m0, n0, m1, n1, m2, n2, m3, n3, m4, n4;                                                \
+    top2_of3(k_[0], k_[1], k_[2], m0, n0);                                                          \
+    top2_of3(k_[3], k_[4], k_[5], m1, n1);                                                          \
+    top2_of3(k_[6], k_[7], k_[8], m2, n2);                                                          \
+    top2_of3(k_[9], k_[10], k_[11], m3, n3);                                                        \
+    top2_of3(k_[12], k_[13], k_[14], m4, n4);                                                       \
+    top2_insert(m4, n4, k_[15]);                                                                    \
+    top2_merge(m0, n0, m1, n1);                                                                     \
+    top2_merge(m2, n2, m3, n3);                                                                     \
+    top2_merge(m0, n0, m2, n2);                                                                     \
+    top2_merge(m0, n0, m4, n4);                                                                     \
+    top2_merge(cm, cn, m0, n0);                                                                     \
+  }
+#else
 #define S1_DIGEST(ACC, MX, SX, OK)                                                                  \
   _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
     const uint32_t key = __float_as_uint(ACC[r]);                                                   \
     top2_insert(MX[r], SX[r], (OK) ? key : 0u);                                                     \
     top2_insert(cm, cn, key);                                                                       \
   }
+#endif
   // the column tile whose second accumulator has just been digested is complete: both lane halves hold the same 32
   // columns (rows +0 / +4) -> one pair per column into the wave's slot PSLOT of the tile parity PBUF; start the next one
 #define S1_COLUMN_DONE(PBUF_OFF, PSLOT)                                                             \
   {                                                                                                 \
-    const uint32_t pm = (uint32_t)__shfl_xor((int)cm, 32), pn = (uint32_t)__shfl_xor((int)cn, 32);   \
+    const uint32_t pm = other_half(cm), pn = other_half(cn);                                        \
     cn = max(max(min(cm, pm), cn), pn);                                                             \
     cm = max(cm, pm);                                                                               \
     my_colp[(PBUF_OFF) + (PSLOT) * 32] = make_uint2(cm, cn);                                        \
@@ -972,10 +1024,10 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_onepass_kernel(
     const int seq0 = tile * 4;                                                                      \
     S1_READ_B((BUF) * 32768, 0)                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                              \
-    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 0, seq0, true, true, true, 11)                       \
-    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 1, seq0 + 1, true, true, true, 11)                   \
-    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 2, seq0 + 2, true, true, true, 11)                   \
-    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 3, seq0 + 3, false, true, true, 11)                  \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 0, seq0, true, true, true, RGBDFE_SIFT1_NV)                       \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 1, seq0 + 1, true, true, true, RGBDFE_SIFT1_NV)                   \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 2, seq0 + 2, true, true, true, RGBDFE_SIFT1_NV)                   \
+    S1_COLUMN_TILE((BUF) * 32768, (BUF) * 512, 3, seq0 + 3, false, true, true, RGBDFE_SIFT1_NV)                  \
     __syncthreads();                                                                                \
     ++tile;                                                                                         \
   }
@@ -1006,7 +1058,7 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_onepass_kernel(
       // still be read by a wave that has not merged the last full tile's group yet)
       S1_DIGEST(acc1, mx1, sx1, ok3)
       {
-        const uint32_t pm = (uint32_t)__shfl_xor((int)cm, 32), pn = (uint32_t)__shfl_xor((int)cn, 32);
+        const uint32_t pm = other_half(cm), pn = other_half(cn);
         colp_last[wv][lane & 31] = make_uint2(max(cm, pm), max(max(min(cm, pm), cn), pn));
       }
     } else {
