@@ -222,6 +222,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    # The launch chain of an ORB pair batch as a cached hipGraph (rgbdfe_set_graph_capture): off by default in the library --
+    # an open capture makes device-wide synchronisations on OTHER threads of the process fail -- on here, where every HIP
+    # call of the process comes from this thread (the line's config says so).
+    os.environ.setdefault("RGBDFE_GRAPHS", "1")
 
     import torch
     import torch.distributed as dist
@@ -552,8 +556,9 @@ def main():
             "step_ms_pipelined": round(ms_per_step, 4),
             "launches_per_stage": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
                                   "pair_prep_kernel + ransac_hyp_kernel (all iterations' hypotheses + pre-screen) + per phase "
-                                  "ransac_refine_kernel (streaming refinement) and replay_walk_kernel + 1 result launch; "
-                                  "avg_launch_ms spans the whole stage",
+                                  "ransac_refine_kernel (streaming refinement; bounded waits), its guarded fallback launch "
+                                  "(select_ransac_kernel<1>: returns at once unless the refinement gave up) and "
+                                  "replay_walk_kernel + 1 result launch; avg_launch_ms spans the whole stage",
             "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
             "note": "the HBM fraction is what the contract asks for and says only that this path is NOT memory bound "
                     "(SURVEY.md 8(d)); the limiter is instruction issue: see issue_roofline",
@@ -570,6 +575,7 @@ def main():
                                    % (N, args.pairs_per_frame, F),
                        "pairs_per_gpu_per_step": n_local, "max_matches": MAX_MATCHES,
                        "ransac_iterations": 200, "parallelism": "pair-sharded x%d" % world,
+                       "graph_capture": os.environ.get("RGBDFE_GRAPHS") != "0",
                        "depth_noise_sigma_over_z2": args.depth_noise,
                        "edge_fraction": round(edge_frac, 4), "mean_ransac_iterations": round(mean_iters, 2)},
             "roofline": roofline,

@@ -570,6 +570,13 @@ int rgbdfe_reset_kernel_time(rgbdfe_ctx* ctx);
  * of a multi handle. */
 #define RGBDFE_GRAPH_STATS 8
 int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out);
+/* Cached hipGraphs for the launch chain of ORB pair batches (one hipGraphLaunch instead of ~12 enqueues per batch: 2-3 %
+ * on the 4000-pair headline, 20 % of the submission cost of a multi-device handle).  OFF by default: while a capture is
+ * open, hipDeviceSynchronize() (torch.cuda.synchronize(), a synchronous hipMemcpy on the NULL stream ...) on any OTHER
+ * thread of the process fails with hipErrorStreamCaptureUnsupported, and the library cannot know what the host
+ * application's threads do.  Turn it on when every thread that calls HIP is yours (bench.py does).  RGBDFE_GRAPHS=1 / 0 in
+ * the environment sets the initial value of new contexts. */
+int rgbdfe_set_graph_capture(rgbdfe_ctx* ctx, int enable);
 
 /* ABI self-description (lets bindings verify struct layout) */
 int rgbdfe_sizeof_match_result(void);

@@ -280,6 +280,8 @@ def load():
                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.rgbdfe_reset_kernel_time.restype = C.c_int
     L.rgbdfe_reset_kernel_time.argtypes = [ctx]
+    L.rgbdfe_set_graph_capture.restype = C.c_int
+    L.rgbdfe_set_graph_capture.argtypes = [ctx, C.c_int]
     L.rgbdfe_graph_stats.restype = C.c_int
     L.rgbdfe_graph_stats.argtypes = [ctx, C.POINTER(C.c_int64), C.c_int32]
     L.rgbdfe_create_multi.restype = C.c_int
@@ -360,7 +362,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_host_register", "rgbdfe_host_unregister",
     "rgbdfe_upload_node_cloud", "rgbdfe_release_node_cloud", "rgbdfe_observation_likelihood",
     "rgbdfe_observation_criterion_met", "rgbdfe_set_latency_mode", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
-    "rgbdfe_reset_kernel_time", "rgbdfe_graph_stats", "rgbdfe_pack_inliers", "rgbdfe_sizeof_inlier_header", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
+    "rgbdfe_reset_kernel_time", "rgbdfe_graph_stats", "rgbdfe_set_graph_capture", "rgbdfe_pack_inliers", "rgbdfe_sizeof_inlier_header", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
     "rgbdfe_pose_graph_create", "rgbdfe_pose_graph_destroy", "rgbdfe_pose_graph_add_node",
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",

@@ -39,6 +39,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "ransac_device.h"
@@ -84,6 +85,54 @@ __device__ unsigned int g_dbg_reopened;  // iterations opened whose record was n
 #define SP_MARK(i)
 #define SP_COUNT(i, v)
 #endif
+
+// Every spin wait of the refinement kernel is BOUNDED (round 4, after intermittent hangs: about one launch in 10^4 never
+// ended -- a wave that had just taken or released the queue lock stopped making progress and its workgroup waited for it
+// forever; see DESIGN.md 4.2b for the evidence and for what was ruled out).  A wave whose wait exceeds kSpinBound turns
+// (milliseconds; normal waits are microseconds) raises plan.gave_up and ends; the waves that depend on it follow, the
+// launch terminates, and the guarded select_ransac_kernel<kRecord> behind it (select_ransac.hip) records the phase
+// instead -- same bytes.  The diagnostics build (-DRGBDFE_SPLIT_WATCHDOG, librgbdfe_wd.so) also records where the first
+// wave stood and what the workgroup's shared state looked like (rgbdfe_debug_watchdog).
+constexpr unsigned kSpinBound = 1u << 15;
+__device__ unsigned int g_split_gave_up;   // launches' waves that gave up since the process started (rgbdfe_debug_split_gave_up)
+#define WD_DECL unsigned wd_n = 0;
+#define WD_RESET wd_n = 0;
+#ifdef RGBDFE_SPLIT_WATCHDOG
+__device__ unsigned int g_wd[64];
+#define WD_SNAPSHOT(SITE)                                                                                 \
+    if ((threadIdx.x & 63) == 0 && atomicCAS(&g_wd[0], 0u, (unsigned)(SITE)) == 0u) {                     \
+      g_wd[1] = blockIdx.x; g_wd[2] = threadIdx.x >> 6; g_wd[3] = gridDim.x; g_wd[4] = n_units;           \
+      g_wd[5] = (unsigned)lds.qlock; g_wd[6] = (unsigned)lds.lock; g_wd[7] = (unsigned)lds.no_more_units; \
+      for (int b_ = 0; b_ < kBufs; ++b_) {                                                                \
+        g_wd[8 + 4 * b_] = (unsigned)lds.ctx[b_].state; g_wd[9 + 4 * b_] = (unsigned)lds.ctx[b_].next;    \
+        g_wd[10 + 4 * b_] = (unsigned)lds.ctx[b_].done; g_wd[11 + 4 * b_] = (unsigned)lds.ctx[b_].n_items; \
+      }                                                                                                   \
+      unsigned rq = 0, rq2 = 0;                                                                           \
+      for (int q_ = 0; q_ < 32; ++q_) { rq |= lds.req[q_] ? 1u << q_ : 0u; rq2 |= lds.req[32 + q_] ? 1u << q_ : 0u; } \
+      g_wd[20] = rq; g_wd[21] = rq2; g_wd[22] = *plan.unit_counter; g_wd[23] = (unsigned)plan.phase_index;   \
+      for (int w_ = 0; w_ < kStreamWaves; ++w_) {                                                          \
+        unsigned act = 0, held = 0;                                                                       \
+        for (int s_ = 0; s_ < kSlots; ++s_) { act |= lds.w[w_].slot[s_].active ? 1u << s_ : 0u; held |= lds.w[w_].slot[s_].iter >= 0 ? 1u << s_ : 0u; } \
+        g_wd[24 + w_] = act | (held << 8) | ((unsigned)lds.dbg[w_] << 16);                                \
+      }                                                                                                   \
+      g_wd[32] = n_pairs; g_wd[33] = (unsigned)plan.n_shares; g_wd[34] = (unsigned)plan.share_iters;      \
+    }
+#define WD_MARK(CODE) if ((threadIdx.x & 63) == 0) lds.dbg[threadIdx.x >> 6] = (CODE);
+#define WD_OWNER (int)(threadIdx.x >> 6) + 1
+#else
+#define WD_SNAPSHOT(SITE)
+#define WD_MARK(CODE)
+#define WD_OWNER 1
+#endif
+#define WD_TICK(SITE)                                                                                     \
+  if (++wd_n > kSpinBound) {                                                                              \
+    WD_SNAPSHOT(SITE)                                                                                     \
+    if ((threadIdx.x & 63) == 0) {                                                                        \
+      atomicExch(plan.gave_up, 1);                                                                        \
+      atomicAdd(&g_split_gave_up, 1u);                                                                    \
+    }                                                                                                     \
+    __builtin_amdgcn_endpgm();                                                                            \
+  }
 
 constexpr int kStreamWaves = 8;                       // waves of a refinement workgroup
 constexpr int kStreamThreads = kStreamWaves * kWave;
@@ -157,6 +206,9 @@ struct alignas(16) StreamLds {
   int qlock;                       // 1 = a wave is taking iterations / choosing a buffer to fill
   int no_more_units;               // the launch's unit counter has run past the last unit
   int pad;
+#ifdef RGBDFE_SPLIT_WATCHDOG
+  int dbg[kStreamWaves];           // where each wave is (progress codes)
+#endif
 };
 static_assert(sizeof(StreamLds) <= 80 * 1024, "two workgroups per CU");
 
@@ -413,6 +465,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   extern __shared__ __attribute__((aligned(16))) char stream_smem[];
   StreamLds& lds = *reinterpret_cast<StreamLds*>(stream_smem);
   SP_DECL
+  WD_DECL
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   WaveLds& wl = lds.w[wave];
@@ -427,6 +480,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       lds.qlock = 0;
       lds.no_more_units = 0;
     }
+#ifdef RGBDFE_SPLIT_WATCHDOG
+    if (lane < kStreamWaves) lds.dbg[lane] = 1;
+#endif
   }
   __syncthreads();  // the only workgroup barrier: from here on the waves run on their own
   SP_MARK(0)
@@ -442,6 +498,14 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
     UnitCtx& cx = lds.ctx[b];
     auto load_records = [&]() {
+#ifdef RGBDFE_SPLIT_NO_LDSDMA   // diagnostics variant: the records through registers
+      const float4* __restrict__ src4 = reinterpret_cast<const float4*>(pp->M);
+      float4* __restrict__ dst4 = reinterpret_cast<float4*>(lds.M[b]);
+      for (int i = 0; i < (kMVec + kWave - 1) / kWave; ++i) {
+        const int v = i * kWave + lane;
+        if (v < kMVec) dst4[v] = src4[v];
+      }
+#else
       const char* __restrict__ src = reinterpret_cast<const char*>(pp->M);
       for (int i = 0; i < (kMVec + kWave - 1) / kWave; ++i) {
         const int v = i * kWave + lane;
@@ -449,6 +513,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)v * 16),
                                            (__attribute__((address_space(3))) void*)(lds.M[b] + i * (kWave * 4)), 16, 0, 0);
       }
+#endif
     };
     // the first launch of a batch: every pair is still running, the records need not wait for the pair's state
     if (plan.phase_begin == 0) load_records();
@@ -514,6 +579,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   // ---- iterations that have left their refinement loop: the outcome record; the slot is free again, and so is the
   // unit's buffer once all its iterations have ended
   auto close_finished = [&]() {
+    WD_MARK(50)
     const int lane = fresh(threadIdx.x & (kWave - 1));
     if (lane < kSlots) {
       SlotS& sl = wl.slot[lane];
@@ -544,6 +610,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   // a wave that finds nothing to take brings the workgroup's next unit in.  Returns false when the wave holds no
   // iteration and none will come.
   auto refill = [&]() -> bool {
+    WD_RESET
     const int lane = fresh(threadIdx.x & (kWave - 1));
     uint64_t free_slots = __ballot(lane < kSlots && wl.slot[min(lane, kSlots - 1)].iter < 0);
     const int n_free = __popcll(free_slots);
@@ -556,10 +623,16 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       // claims on `next` could land on a buffer that had been drained, freed and refilled in between.)
       int locked = 0;
       do {
-        if (lane == 0) locked = atomicCAS(&lds.qlock, 0, 1) == 0 ? 1 : 0;
+#ifdef RGBDFE_SPLIT_TTAS   // test-and-test-and-set: a plain read first, the returning atomic only when the lock looks free
+        if (lane == 0) locked = flag_load(&lds.qlock) == 0 ? (atomicCAS(&lds.qlock, 0, WD_OWNER) == 0 ? 1 : 0) : 0;
+#else
+        if (lane == 0) locked = atomicCAS(&lds.qlock, 0, WD_OWNER) == 0 ? 1 : 0;
+#endif
         locked = __builtin_amdgcn_readfirstlane(locked);
         if (!locked) __builtin_amdgcn_s_sleep(1);
+        WD_TICK(1)
       } while (!locked);
+      WD_MARK(10)
       asm volatile("" ::: "memory");
       int st = kUnitLoading, nx = 0, ni = 0;
       if (lane < kBufs) {
@@ -584,7 +657,12 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         if (lane == 0) flag_store(&lds.ctx[b].state, kUnitLoading);
       }
       lsync();
+#ifdef RGBDFE_SPLIT_PLAIN_UNLOCK
+      if (lane == 0) flag_store(&lds.qlock, 0);
+#else
       if (lane == 0) atomicExch(&lds.qlock, 0);
+#endif
+      WD_MARK(11)
       if (cnt > 0) {
         for (int j = 0; j < cnt; ++j) {
           const int g = (int)__builtin_ctzll(free_slots);
@@ -601,7 +679,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         if (lane == 0) unit = atomicAdd(plan.unit_counter, 1u);
         unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
         if (unit < n_units) {
+          WD_MARK(20)
           load_unit(b, unit);
+          WD_MARK(21)
         } else if (lane == 0) {
           flag_store(&lds.no_more_units, 1);
           flag_store(&lds.ctx[b].state, kUnitFree);
@@ -611,9 +691,11 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       if (!units_left && loading == 0ull) break;  // nothing more will come
       if (had || got > 0) break;                  // this wave has work: it looks again after the round
       __builtin_amdgcn_s_sleep(4);                // idle: a loader is at work, or every buffer is still in use
+      WD_TICK(2)
     }
     SP_MARK(2)
     SP_COUNT(12, got)
+    WD_MARK(12)
     if (my_g >= 0) {
       const int e2 = lane % 6;
       const UnitCtx& cx = lds.ctx[my_b];
@@ -651,10 +733,13 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     return had || got > 0;
   };
 
+  unsigned wd_rounds = 0;
   for (bool occupied = refill(); occupied; close_finished(), occupied = refill()) {
     SP_COUNT(13, 1)
+    if (++wd_rounds > (1u << 16)) { wd_n = kSpinBound; WD_TICK(4) }   // (a wave holds at most a few thousand iterations' rounds)
     // ================================ one pass of the refinement loop (:1140) for every active slot
     // ---- scorings (:1148), one after the other (lane = match), each followed by its error sum
+    WD_MARK(30)
     uint64_t act = __ballot(lane < kSlots && wl.slot[min(lane, kSlots - 1)].active != 0);
     while (act != 0ull) {
       const int g = (int)__builtin_ctzll(act);
@@ -771,6 +856,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const int my_req = wave * kSlots + min(lane, kSlots - 1);
     if (lane < kSlots && ((refit >> lane) & 1ull)) flag_store(&lds.req[my_req], 1);
     lsync();
+    WD_MARK(40)
     for (;;) {
       const bool pending = lane < kSlots && flag_load(&lds.req[my_req]) != 0;
       if (__ballot(pending) == 0ull) break;
@@ -807,16 +893,23 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           SP_COUNT(11, __popcll(__ballot(p)))
         }
         lsync();
+#ifdef RGBDFE_SPLIT_PLAIN_UNLOCK
+        if (lane == 0) flag_store(&lds.lock, 0);
+#else
         if (lane == 0) atomicExch(&lds.lock, 0);
+#endif
         SP_COUNT(15, 1)
         SP_MARK(9)
       } else {
         __builtin_amdgcn_s_sleep(2);
       }
+      WD_TICK(3)
     }
+    WD_RESET
     asm volatile("" ::: "memory");
     SP_MARK(8)
   }
+  WD_MARK(99)
 #ifdef RGBDFE_PROFILE_PHASES
   SP_MARK(10)
   if (lane == 0) {
@@ -836,23 +929,28 @@ void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst
   hipLaunchKernelGGL(ransac_hyp_kernel, dim3(n_pairs), dim3(kHypThreads), 0, stream, work, n_pairs, rc, plan);
 }
 
-// Once per process, outside any stream capture (rgbdfe_create): the refinement kernel's dynamic LDS exceeds the 64 KB a
-// kernel gets by default.  Returns the device's CU count.
+// Once per DEVICE, outside any stream capture (rgbdfe_create runs it with the context's device current): the refinement
+// kernel's dynamic LDS exceeds the 64 KB a kernel gets by default, and that attribute belongs to the device's code object.
+// Returns the device's CU count.
 int ransac_split_init() {
-  static int n_cus = 0;
-  if (n_cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  static int n_cus[64] = {};   // per device ordinal (a multi-device handle creates one context per device)
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> g(mu);
+  if (n_cus[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)sizeof(StreamLds));
     if (getenv("RGBDFE_SPLIT_VERBOSE")) {  // diagnostics: what the runtime makes of the kernel's resources
       int nb = -1;
       const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(ransac_refine_kernel), kStreamThreads, sizeof(StreamLds));
-      fprintf(stderr, "ransac_refine_kernel: %zu B LDS per workgroup, %d workgroups per CU (%s), %d CUs\n", sizeof(StreamLds), nb, hipGetErrorString(e), v);
+      fprintf(stderr, "ransac_refine_kernel: %zu B LDS per workgroup, %d workgroups per CU (%s), %d CUs (device %d)\n", sizeof(StreamLds), nb, hipGetErrorString(e), v, dev);
     }
-    n_cus = v;
+    n_cus[dev] = v;
   }
-  return n_cus;
+  return n_cus[dev];
 }
 
 void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream) {
@@ -903,6 +1001,26 @@ extern "C" int rgbdfe_debug_split_totals(unsigned long long* out32, int reset) {
   if (reset) {
     const unsigned zero = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_count), &zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
+// waves of refinement launches that gave up on a spin wait since the process started (the phases concerned were recorded
+// by the fallback launch); -1 = could not be read
+extern "C" int rgbdfe_debug_split_gave_up() {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_split_gave_up), sizeof(n)) != hipSuccess) return -1;
+  return (int)n;
+}
+
+#ifdef RGBDFE_SPLIT_WATCHDOG
+// diagnostics build only: the watchdog record (word 0 = the site of the wait that never ended, 0 = none), optionally cleared
+extern "C" int rgbdfe_debug_watchdog(unsigned int* out64, int reset) {
+  if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(rgbdfe::g_wd), 64 * sizeof(unsigned int)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned int z[64] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_wd), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
 }

@@ -243,7 +243,11 @@ struct rgbdfe_ctx {
   int64_t graph_launch_failures = 0; // cached executable graphs that failed to launch (dropped)
   int32_t graph_miss_run = 0;        // misses since the last hit
   static constexpr int32_t kGraphMissRun = 8, kGraphRetry = 16;
-  bool use_graphs = true;  // RGBDFE_GRAPHS=0: plain stream launches
+  // Off by default (round 4): while a capture is open, a device-wide synchronisation on ANY thread of the process fails with
+  // hipErrorStreamCaptureUnsupported -- relaxed mode spares other threads' allocations and copies, not that -- and a
+  // drop-in library may not make its host application's unrelated HIP calls fail (rgbdslam is a multi-threaded Qt / ROS
+  // process).  A caller that owns every thread touching HIP turns it on: rgbdfe_set_graph_capture / RGBDFE_GRAPHS=1.
+  bool use_graphs = false;
   hipStream_t capture_stream = nullptr;  // graphs are captured here, never on a stream other threads may wait on
   long graph_capture_failures = 0;       // captures another thread's HIP call invalidated (the batch then ran as plain launches)
   uint8_t* upload_stage = nullptr; size_t upload_stage_bytes = 0;  // pinned staging of rgbdfe_upload_nodes
@@ -788,7 +792,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   fill_ransac_const(ctx);
   if (const char* sf = getenv("RGBDFE_SIFT_FAST_KEYS")) ctx->sift_fast = atoi(sf) != 0;
   if (const char* hm = getenv("RGBDFE_HAMMING_MODE")) ctx->hamming_mode = atoi(hm) < 0 || atoi(hm) > 2 ? 1 : atoi(hm);
-  if (const char* gr = getenv("RGBDFE_GRAPHS")) ctx->use_graphs = atoi(gr) != 0;
+  if (const char* gr = getenv("RGBDFE_GRAPHS")) ctx->use_graphs = atoi(gr) != 0;   // (rgbdfe_set_graph_capture overrides)
   auto bail = [&](int code) { rgbdfe_destroy(ctx); return code; };
   if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
   (void)ransac_split_init();  // kernel attributes of the RANSAC refinement kernel: once, outside any stream capture
@@ -3100,6 +3104,13 @@ int rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void*
   HIP_TRY(ctx, hipGetLastError());
   return RGBDFE_OK;
 }
+int rgbdfe_set_graph_capture(rgbdfe_ctx* ctx, int enable) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->use_graphs = enable != 0;
+  return RGBDFE_OK;
+}
+
 int rgbdfe_pack_inliers(rgbdfe_ctx* ctx, const void* d_records, int32_t n, int32_t n_headers, void* d_stream, int32_t* d_total,
                         void* stream) {
   if (!ctx || n < 0 || n_headers < n || !d_stream || !d_total || (n > 0 && !d_records))
@@ -3122,7 +3133,7 @@ int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
   return RGBDFE_OK;
 }
 
-int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_pack_inliers
+int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_set_graph_capture, rgbdfe_pack_inliers
 
 }  // namespace impl
 
@@ -3845,6 +3856,11 @@ int rgbdfe_pack_compact(rgbdfe_ctx* ctx, const void* d_records, int32_t n, void*
     if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_pack_compact");
     return impl::rgbdfe_pack_compact(ctx, d_records, n, d_compact, stream);
   });
+}
+
+int rgbdfe_set_graph_capture(rgbdfe_ctx* ctx, int enable) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return RGBDFE_ALL(ctx, impl::rgbdfe_set_graph_capture(c, enable));
 }
 
 int rgbdfe_pack_inliers(rgbdfe_ctx* ctx, const void* d_records, int32_t n, int32_t n_headers, void* d_stream, int32_t* d_total,

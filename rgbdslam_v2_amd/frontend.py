@@ -762,6 +762,11 @@ class FrontEnd:
     def reset_kernel_time(self):
         self._check(self._L.rgbdfe_reset_kernel_time(self._ctx))
 
+    def set_graph_capture(self, enable: bool):
+        """Cached hipGraphs for ORB pair batches (rgbdfe_set_graph_capture): off by default -- an open capture makes
+        device-wide synchronisations on other threads of the process fail; for callers that own every HIP-calling thread."""
+        self._check(self._L.rgbdfe_set_graph_capture(self._ctx, int(bool(enable))))
+
     def graph_stats(self):
         """The hipGraph cache of the ORB pair path (rgbdfe_graph_stats)."""
         v = (C.c_int64 * 8)()

@@ -516,6 +516,13 @@ def test_graph_cache_keys_on_launch_geometry(monkeypatch):
         fe.close()
         return out, st, st2
 
+    # off unless asked for: an open capture would make other threads' device-wide synchronisations fail (rgbdfe.h)
+    monkeypatch.delenv("RGBDFE_GRAPHS", raising=False)
+    fe0 = FrontEnd(device_id=0, max_nodes=4, max_keypoints=64, max_pairs_per_batch=8)
+    assert fe0.graph_stats()["enabled"] == 0
+    fe0.set_graph_capture(True)
+    assert fe0.graph_stats()["enabled"] == 1
+    fe0.close()
     plain, st_off, _ = run(False)
     graphed, st, st2 = run(True)
     assert graphed == plain

@@ -2,6 +2,8 @@
 submitting thread, and the batch's wall time, for G = 1, 2, 4, 8 (VERDICT r2 #6a).  Weak scaling: 4000 pairs per listed
 device.  With G devices on G real GPUs the wall time is that of one shard; here the shards share one chip, so only the
 submission figures carry over."""
+import os
+os.environ.setdefault("RGBDFE_GRAPHS", "1")   # the cached launch chains are what this tool measures (off by default in the library)
 import json
 import os
 import sys

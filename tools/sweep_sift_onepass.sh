@@ -7,7 +7,7 @@
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-V="base:-DRGBDFE_SIFT1_NV=11 nv9:-DRGBDFE_SIFT1_NV=9 nv13:-DRGBDFE_SIFT1_NV=13 nv16:-DRGBDFE_SIFT1_NV=16 shfl:-DRGBDFE_SIFT1_SWAP=0 tree:-DRGBDFE_SIFT1_TREE=1 tree13:-DRGBDFE_SIFT1_TREE=1_-DRGBDFE_SIFT1_NV=13"
+V=${SIFT1_VARIANTS:-"base:-DRGBDFE_SIFT1_NV=11 burst:-DRGBDFE_SIFT1_BURST=1 bursttree:-DRGBDFE_SIFT1_BURST=1_-DRGBDFE_SIFT1_TREE=1"}
 if [ "${1:-build}" = build ]; then
   cd rgbdslam_v2_amd/csrc && make -s
   REST=$(ls *.o | grep -v '^sift_match' | grep -v '_prof.o' | grep -v '^sift_match_')
