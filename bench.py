@@ -765,8 +765,11 @@ def sift_subrecord(seq, device, default=True):
             "roofline": {"bound": "mfma", "kernel": "sift dot-product + top-2", "achieved": round(tf, 3), "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5), "flop_per_pair": 2.0 * N * N * 128,
                          "avg_launch_ms": round(dot_ms, 4), "time_basis": "serial", "traffic": traffic,
-                         "traffic_source": "%s [sift] (static: both passes of the dot-product stage, FETCH_SIZE x 2 + "
-                                           "WRITE_SIZE)" % pmc_src},
+                         "traffic_source": "%s [sift] (static: the dot-product stage -- one launch per batch since round 4 -- "
+                                           "FETCH_SIZE x 2 + WRITE_SIZE)" % pmc_src,
+                         "executed_over_algorithmic_flop": round(float(pmc["sift"]["sift_dot"]["mfma_instructions_per_batch"]) * 32768.0 /
+                                                                 (2.0 * N * N * 128 * float(pmc["sift"]["pairs_per_batch"])), 3)
+                         if isinstance((pmc.get("sift") or {}).get("sift_dot"), dict) and pmc["sift"]["sift_dot"].get("mfma_instructions_per_batch") else None},
             "serial_stage_ms": {"dot_top2": round(dot_ms, 4), "finish": round(fin_ms, 4), "select_ransac": round(rsc_ms, 4)},
             "parity_check": parity}
 

@@ -27,7 +27,7 @@ def short(name):
         return "select_ransac"
     if "hamming_mfma_kernel" in name:
         return "hamming_nn"
-    if "sift_top2_fast" in name or "sift_row_top2_kernel" in name:  # both passes of the dot-product stage
+    if "sift_top2_fast" in name or "sift_row_top2_kernel" in name or "sift_top2_onepass" in name:  # the dot-product stage (one or two passes)
         return "sift_dot"
     if "sift_finish_kernel" in name:
         return "sift_finish"
@@ -55,7 +55,8 @@ for f in find("trace/**/*kernel_stats.csv"):
 for k, e in summary.items():
     if "calls" in e:
         e["avg_ns"] = e["total_ns"] / e["calls"]
-batches = summary.get("hamming_nn", {}).get("calls") or (summary.get("sift_dot", {}).get("calls", 0) // 2) or None
+# batches of the run: one Hamming launch per ORB batch, one sift_finish launch per SIFT batch
+batches = summary.get("hamming_nn", {}).get("calls") or summary.get("sift_finish", {}).get("calls") or None
 if batches:
     for k, e in summary.items():
         if "total_ns" in e:
@@ -69,7 +70,7 @@ for f in find("trace/**/*kernel_trace.csv"):
         k = short(row.get("Kernel_Name", ""))
         if k:
             dur[k].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    nb = len(dur.get("hamming_nn", [])) or (len(dur.get("sift_dot", [])) // 2) or None
+    nb = len(dur.get("hamming_nn", [])) or len(dur.get("sift_finish", [])) or None
     for k, v in dur.items():
         summary.setdefault(k, {})["trace_avg_ns"] = sum(v) / len(v)
         summary[k]["trace_min_ns"] = min(v)
@@ -97,7 +98,7 @@ for name, pat in (("fetch", "pmc_fetch/**/*counter_collection.csv"),
     acc = pmc(pat)
     for k, ctrs in acc.items():
         for c, vals in ctrs.items():
-            nb = len(acc.get("hamming_nn", {}).get(c, [])) or (len(acc.get("sift_dot", {}).get(c, [])) // 2) or len(vals)
+            nb = len(acc.get("hamming_nn", {}).get(c, [])) or len(acc.get("sift_finish", {}).get(c, [])) or len(vals)
             # per batch: a batch's RANSAC stage may be several dispatches
             summary.setdefault(k, {})[c + "_avg"] = sum(vals) / nb
             summary[k][c + "_n"] = len(vals)
