@@ -95,6 +95,7 @@ __device__ unsigned int g_dbg_reopened;  // iterations opened whose record was n
 // wave stood and what the workgroup's shared state looked like (rgbdfe_debug_watchdog).
 constexpr unsigned kSpinBound = 1u << 15;
 __device__ unsigned int g_split_gave_up;   // launches' waves that gave up since the process started (rgbdfe_debug_split_gave_up)
+__device__ int g_split_sabotage;           // tests: the next n refinement launches give up at once (rgbdfe_debug_split_sabotage)
 #define WD_DECL unsigned wd_n = 0;
 #define WD_RESET wd_n = 0;
 #ifdef RGBDFE_SPLIT_WATCHDOG
@@ -486,6 +487,16 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   }
   __syncthreads();  // the only workgroup barrier: from here on the waves run on their own
   SP_MARK(0)
+  // Test hook (rgbdfe_debug_split_sabotage): the first wave of the launch gives up before doing anything, as a wave whose
+  // wait reached its bound would -- the launch's records are void and the guarded fallback launch has to produce them.
+  if (blockIdx.x == 0 && wave == 0 && g_split_sabotage > 0) {
+    if (lane == 0) {
+      atomicSub(&g_split_sabotage, 1);
+      atomicExch(plan.gave_up, 1);
+      atomicAdd(&g_split_gave_up, 1u);
+    }
+    __builtin_amdgcn_endpgm();
+  }
 
   // ---- a unit -> LDS buffer b (one wave): the pair's facts, its match records (global -> LDS directly:
   // global_load_lds_dwordx4, 64 x 16 bytes per instruction), the viable iterations of the unit's range as a list.
@@ -1012,6 +1023,11 @@ extern "C" int rgbdfe_debug_split_gave_up() {
   unsigned n = 0;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_split_gave_up), sizeof(n)) != hipSuccess) return -1;
   return (int)n;
+}
+
+// tests: make the next n refinement launches of this device give up at once (their phases then come from the fallback launch)
+extern "C" int rgbdfe_debug_split_sabotage(int n) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_sabotage), &n, sizeof(n)) == hipSuccess ? 0 : -1;
 }
 
 #ifdef RGBDFE_SPLIT_WATCHDOG
