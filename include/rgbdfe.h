@@ -162,6 +162,16 @@ int  rgbdfe_group_submit_us(rgbdfe_ctx* ctx, double* us);
  * (pair k at (k mod G) * per + k / G, unused tail records 0xFF); 12x fewer bytes cross xGMI. */
 int  rgbdfe_match_pair_list_allgather_compact(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
                                               int32_t n_pairs, void* const* d_out, int32_t* records_per_device);
+/* The inlier form of the all-gather (rgbdfe_inlier_header below the result structs): every device packs its shard into an
+ * inlier stream -- per = ceil(n_pairs / G) headers of 104 bytes, then (queryIdx | trainIdx << 16) of every inlier match --
+ * and on return d_out[j] holds device i's stream at byte offset i * (*stride_bytes); list_entries[i] = entries of device
+ * i's list block (*stride_bytes = per * 104 + 4 * the largest of them).  Pair k of the caller's list = header k / G of
+ * device k mod G.  What GraphManager reads of a MatchingResult (edge, rmse, counts, inlier_matches for
+ * updateInlierFeatures, graph_manager.cpp:409-419) at ~260 bytes per pair instead of 1744.  Buffers: G * per *
+ * (104 + 4 * RGBDFE_MAX_MATCHES) bytes each (the worst case). */
+int  rgbdfe_match_pair_list_allgather_inliers(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                              int32_t n_pairs, void* const* d_out, int32_t* records_per_device,
+                                              int32_t* list_entries, int64_t* stride_bytes);
 /* d_records (n rgbdfe_match_result in HBM) -> d_compact (n rgbdfe_compact_result in HBM), enqueued on `stream`
  * (hipStream_t; NULL = the context's stream): what a one-process-per-GPU caller runs between rgbdfe_wait_ticket and its
  * own ncclAllGather (bench.py --gpus N).  Single-device contexts only. */

@@ -305,6 +305,8 @@ def load():
     L.rgbdfe_pack_compact.restype = C.c_int
     L.rgbdfe_pack_compact.argtypes = [ctx, vp, i32, vp, vp]
     L.rgbdfe_sizeof_compact_result.restype = C.c_int
+    L.rgbdfe_match_pair_list_allgather_inliers.restype = C.c_int
+    L.rgbdfe_match_pair_list_allgather_inliers.argtypes = [ctx, vp, vp, i32, vp, C.POINTER(i32), vp, C.POINTER(C.c_int64)]
     L.rgbdfe_pack_inliers.restype = C.c_int
     L.rgbdfe_pack_inliers.argtypes = [ctx, vp, i32, i32, vp, vp, vp]
     L.rgbdfe_sizeof_inlier_header.restype = C.c_int
@@ -362,7 +364,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_host_register", "rgbdfe_host_unregister",
     "rgbdfe_upload_node_cloud", "rgbdfe_release_node_cloud", "rgbdfe_observation_likelihood",
     "rgbdfe_observation_criterion_met", "rgbdfe_set_latency_mode", "rgbdfe_set_profiling", "rgbdfe_get_kernel_time",
-    "rgbdfe_reset_kernel_time", "rgbdfe_graph_stats", "rgbdfe_set_graph_capture", "rgbdfe_pack_inliers", "rgbdfe_sizeof_inlier_header", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
+    "rgbdfe_reset_kernel_time", "rgbdfe_graph_stats", "rgbdfe_set_graph_capture", "rgbdfe_match_pair_list_allgather_inliers", "rgbdfe_pack_inliers", "rgbdfe_sizeof_inlier_header", "rgbdfe_sizeof_match_result", "rgbdfe_abi_version",
     "rgbdfe_pose_graph_create", "rgbdfe_pose_graph_destroy", "rgbdfe_pose_graph_add_node",
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",

@@ -3133,7 +3133,7 @@ int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
   return RGBDFE_OK;
 }
 
-int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_set_graph_capture, rgbdfe_pack_inliers
+int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_set_graph_capture, rgbdfe_pack_inliers, rgbdfe_match_pair_list_allgather_inliers
 
 }  // namespace impl
 
@@ -3210,6 +3210,7 @@ struct Group {
   std::vector<rgbdfe_match_result*> edge_recs;
   std::vector<int32_t*> edge_idx, edge_dst, edge_cnt;
   std::vector<int32_t*> edge_cnt_host;  // pinned
+  std::vector<char*> inl_stream;        // inlier gather: per device the shard's inlier stream (rgbdfe_inlier_header), worst case
   int32_t edge_cap = 0;                 // records per device the scratch holds
   double last_submit_us = 0.0;          // host time the calling thread spent enqueueing the latest sharded batch on all devices
   // One call at a time on a group handle (rgbdfe.h: calls on one context serialise): covers the workers' job slots and
@@ -3291,7 +3292,8 @@ void group_destroy(rgbdfe_ctx* gctx) {
       if (i < g->gather_streams.size() && g->gather_streams[i]) (void)hipStreamDestroy(g->gather_streams[i]);
       if (i < g->gather_events.size() && g->gather_events[i]) (void)hipEventDestroy(g->gather_events[i]);
       if (i < g->edge_recs.size()) {
-        if (g->edge_recs[i]) (void)hipFree(g->edge_recs[i]);
+        if (i < g->inl_stream.size() && g->inl_stream[i]) (void)hipFree(g->inl_stream[i]);
+      if (g->edge_recs[i]) (void)hipFree(g->edge_recs[i]);
         if (g->edge_idx[i]) (void)hipFree(g->edge_idx[i]);
         if (g->edge_dst[i]) (void)hipFree(g->edge_dst[i]);
         if (g->edge_cnt[i]) (void)hipFree(g->edge_cnt[i]);
@@ -3459,6 +3461,8 @@ int group_ensure_edge_scratch(rgbdfe_ctx* gctx, int32_t per) {
     HIP_TRY(gctx, hipMalloc((void**)&g.edge_recs[(size_t)i], rec * (size_t)per));
     HIP_TRY(gctx, hipMalloc((void**)&g.edge_idx[(size_t)i], sizeof(int32_t) * (size_t)per));
     HIP_TRY(gctx, hipMalloc((void**)&g.edge_dst[(size_t)i], sizeof(int32_t) * (size_t)per));
+    if (g.inl_stream.size() < (size_t)G) g.inl_stream.resize((size_t)G, nullptr);
+    if (g.inl_stream[(size_t)i]) { (void)hipFree(g.inl_stream[(size_t)i]); g.inl_stream[(size_t)i] = nullptr; }   // (allocated on first use)
     if (!g.edge_cnt[(size_t)i]) {
       HIP_TRY(gctx, hipMalloc((void**)&g.edge_cnt[(size_t)i], sizeof(int32_t)));
       HIP_TRY(gctx, hipHostMalloc((void**)&g.edge_cnt_host[(size_t)i], sizeof(int32_t), hipHostMallocDefault));
@@ -3644,6 +3648,92 @@ int group_match_allgather_edges(rgbdfe_ctx* gctx, const int32_t* q, const int32_
                                            g.device_ids[(size_t)i], (size_t)counts[i] * sizeof(int32_t),
                                            g.gather_streams[(size_t)i]));
       }
+    }
+  }
+  for (int i = 0; i < G; ++i) {
+    HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+    HIP_TRY(gctx, hipStreamSynchronize(g.gather_streams[(size_t)i]));
+  }
+  return RGBDFE_OK;
+}
+
+// All-gather of the INLIER FORM of the results (include/rgbdfe.h: rgbdfe_inlier_header): what GraphManager reads of a
+// MatchingResult -- edge, rmse, counts and the inlier matches' (queryIdx, trainIdx) -- ~260 bytes per pair at configs[1] instead
+// of 1744.  Every device packs its shard (per headers + its lists) into scratch, the host learns the list lengths, and the
+// exchange moves stride = per * 104 + 4 * max(length) bytes per device.  On return d_out[j] holds device i's stream at byte
+// offset i * stride: pair k of the caller's list = header k / G of device k mod G.
+int group_match_allgather_inliers(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, void* const* d_out,
+                                  int32_t* records_per_device, int32_t* totals, int64_t* stride_bytes) {
+  if (n < 0 || !d_out || !totals || !stride_bytes || (n > 0 && (!q || !t)))
+    return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad allgather arguments");
+  Group& g = *gctx->group;
+  std::lock_guard<std::recursive_mutex> call_lock(g.mu);
+  const int G = (int)g.children.size();
+  const int32_t per = (n + G - 1) / G;
+  if (records_per_device) *records_per_device = per;
+  *stride_bytes = 0;
+  for (int i = 0; i < G; ++i) totals[i] = 0;
+  if (per == 0) return RGBDFE_OK;
+  for (int i = 0; i < G; ++i)
+    if (!d_out[i]) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "allgather: a device buffer is NULL");
+  if (per > gctx->cfg.max_pairs_per_batch)
+    return fail(gctx, RGBDFE_ERR_CAPACITY, "allgather: the shard of a device exceeds max_pairs_per_batch");
+  { const int rce = group_ensure_edge_scratch(gctx, per); if (rce != RGBDFE_OK) return rce; }
+  const size_t hdr_bytes = (size_t)per * sizeof(rgbdfe_inlier_header);
+  if (g.inl_stream.size() < (size_t)G) g.inl_stream.resize((size_t)G, nullptr);
+  for (int i = 0; i < G; ++i)
+    if (!g.inl_stream[(size_t)i]) {
+      HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+      HIP_TRY(gctx, hipMalloc((void**)&g.inl_stream[(size_t)i], (size_t)g.edge_cap * (sizeof(rgbdfe_inlier_header) + 4 * RGBDFE_MAX_MATCHES)));
+    }
+  // 1. every device: its shard into scratch records, then the inlier stream
+  int rc = group_run(gctx, [&](int i) -> int {
+    rgbdfe_ctx* c = g.children[(size_t)i];
+    std::vector<int32_t> qs, ts;
+    for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }
+    rgbdfe_match_result* seg = g.edge_recs[(size_t)i];
+    hipStream_t gs = g.gather_streams[(size_t)i];
+    int64_t ticket = 0;
+    int r = RGBDFE_OK;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+      HIP_TRY(c, hipEventRecord(g.gather_events[(size_t)i], gs));
+      if (!qs.empty()) {
+        r = enqueue_pairs(c, qs.data(), ts.data(), (int32_t)qs.size(), seg, g.gather_events[(size_t)i], &ticket, nullptr);
+        if (r == RGBDFE_OK) r = wait_ticket(c, ticket, gs);
+      }
+    }
+    if (r != RGBDFE_OK) return r;
+    launch_pack_inliers(seg, (uint32_t)qs.size(), (uint32_t)per, g.inl_stream[(size_t)i], g.edge_cnt[(size_t)i], gs);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(g.edge_cnt_host[(size_t)i], g.edge_cnt[(size_t)i], sizeof(int32_t), hipMemcpyDeviceToHost, gs));
+    HIP_TRY(c, hipStreamSynchronize(gs));
+    return RGBDFE_OK;
+  });
+  if (rc != RGBDFE_OK) return rc;
+  int32_t longest = 0;
+  for (int i = 0; i < G; ++i) { totals[i] = *g.edge_cnt_host[(size_t)i]; longest = std::max(longest, totals[i]); }
+  const size_t stride = hdr_bytes + (size_t)longest * 4;
+  *stride_bytes = (int64_t)stride;
+  // 2. the exchange
+  if (group_setup_rccl(gctx)) {
+    g.transport = "rccl";
+    if (g.rccl.GroupStart() != 0) return fail(gctx, RGBDFE_ERR_HIP, "ncclGroupStart failed");
+    int nrc = 0;
+    for (int i = 0; i < G && nrc == 0; ++i)
+      nrc = g.rccl.AllGather(g.inl_stream[(size_t)i], d_out[i], stride, kNcclChar, g.comms[(size_t)i], g.gather_streams[(size_t)i]);
+    const int erc = g.rccl.GroupEnd();
+    if (nrc != 0 || erc != 0)
+      return fail(gctx, RGBDFE_ERR_HIP, std::string("ncclAllGather: ") +
+                                            (g.rccl.GetErrorString ? g.rccl.GetErrorString(nrc ? nrc : erc) : "error"));
+  } else {
+    g.transport = G == 1 ? "none (one device)" : "p2p";
+    for (int i = 0; i < G; ++i) {
+      HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+      for (int j = 0; j < G; ++j)
+        HIP_TRY(gctx, hipMemcpyPeerAsync((char*)d_out[j] + (size_t)i * stride, g.device_ids[(size_t)j], g.inl_stream[(size_t)i],
+                                         g.device_ids[(size_t)i], hdr_bytes + (size_t)totals[i] * 4, g.gather_streams[(size_t)i]));
     }
   }
   for (int i = 0; i < G; ++i) {
@@ -3882,6 +3972,18 @@ int rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* query
       return fail(ctx, RGBDFE_ERR_INVALID_ARG,
                   "rgbdfe_match_pair_list_allgather_edges needs a context made by rgbdfe_create_multi");
     return group_match_allgather_edges(ctx, query_ids, train_ids, n_pairs, d_out, d_index, edges_per_device, stride);
+  });
+}
+
+int rgbdfe_match_pair_list_allgather_inliers(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
+                                             int32_t n_pairs, void* const* d_out, int32_t* records_per_device,
+                                             int32_t* list_entries, int64_t* stride_bytes) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (!RGBDFE_IS_GROUP(ctx))
+      return fail(ctx, RGBDFE_ERR_INVALID_ARG,
+                  "rgbdfe_match_pair_list_allgather_inliers needs a context made by rgbdfe_create_multi");
+    return group_match_allgather_inliers(ctx, query_ids, train_ids, n_pairs, d_out, records_per_device, list_entries, stride_bytes);
   });
 }
 

@@ -154,6 +154,20 @@ class FrontEnd:
                                                                      C.cast(ptrs, C.c_void_p), C.byref(per)))
         return int(per.value)
 
+    def match_pair_list_allgather_inliers(self, query_ids, train_ids, d_out_ptrs: Sequence[int]):
+        """rgbdfe_match_pair_list_allgather_inliers: every device buffer ends up with every device's inlier stream.
+        Returns (records per device, list entries per device, stride in bytes)."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        g = len(d_out_ptrs)
+        ptrs = (C.c_void_p * g)(*[C.c_void_p(int(p)) for p in d_out_ptrs])
+        per, stride = C.c_int32(0), C.c_int64(0)
+        totals = np.zeros(g, np.int32)
+        self._check(self._L.rgbdfe_match_pair_list_allgather_inliers(self._ctx, q.ctypes.data, t.ctypes.data, len(q),
+                                                                     C.cast(ptrs, C.c_void_p), C.byref(per), totals.ctypes.data,
+                                                                     C.byref(stride)))
+        return int(per.value), totals, int(stride.value)
+
     def pack_compact(self, d_records_ptr: int, n: int, d_compact_ptr: int, stream: Optional[int] = None):
         """n records in HBM -> n compact records in HBM on `stream` (rgbdfe_pack_compact)."""
         self._check(self._L.rgbdfe_pack_compact(self._ctx, C.c_void_p(int(d_records_ptr)), int(n),

@@ -374,3 +374,50 @@ def test_upload_node_device_orders_before_later_batches(data):
         assert out.tobytes() == ref.tobytes()
         s.synchronize()
     fe.close()
+
+
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0]])
+def test_allgather_of_the_inlier_form(data, ids):
+    """rgbdfe_match_pair_list_allgather_inliers: every device ends up with every device's inlier stream -- the 104-byte
+    headers of its shard in shard order and the (query row, train row) of every inlier match -- equal to the host twin of
+    the format applied to the single-context records; pair k of the list = header k // G of device k % G."""
+    import torch
+    from rgbdslam_v2_amd._lib import INLIER_HEADER_DTYPE, inlier_pairs, inlier_stream_of, parse_inlier_stream
+    from rgbdslam_v2_amd.frontend import inlier_indices
+    seq, pq, pt = data
+    one = _fe(seq)
+    ref = one.match_pair_list(pq, pt)
+    one.close()
+    grp = _fe(seq, device_ids=ids)
+    G, n = len(ids), len(pq)
+    per = (n + G - 1) // G
+    cap = G * per * (INLIER_HEADER_DTYPE.itemsize + 4 * 320)
+    bufs = [torch.full((cap,), 0xCD, dtype=torch.uint8, device="cuda:0") for _ in ids]
+    torch.cuda.synchronize()
+    got_per, totals, stride = grp.match_pair_list_allgather_inliers(pq, pt, [b.data_ptr() for b in bufs])
+    assert got_per == per and stride == per * 104 + 4 * int(totals.max())
+    assert int(totals.sum()) == int(ref["n_inl"].sum()) > 20 * n // 2
+    for b in bufs:
+        raw = b.cpu().numpy()
+        for d in range(G):
+            shard = ref[d::G]
+            hdr_want, lst_want = inlier_stream_of(shard, per)
+            hdr, lst = parse_inlier_stream(raw[d * stride:(d + 1) * stride], per, int(totals[d]))
+            assert hdr.tobytes() == hdr_want.tobytes() and np.array_equal(lst, lst_want), d
+        for k in (0, 1, n // 2, n - 1):                 # what GraphManager::updateInlierFeatures reads, pair k of the list
+            d, j = k % G, k // G
+            hdr, lst = parse_inlier_stream(raw[d * stride:(d + 1) * stride], per, int(totals[d]))
+            q_rows, t_rows = inlier_pairs(hdr, lst, j)
+            ii = inlier_indices(ref[k])
+            assert np.array_equal(q_rows, ref[k]["all_q"][ii]) and np.array_equal(t_rows, ref[k]["all_t"][ii])
+            assert hdr["id1"][j] == ref[k]["id1"] and np.array_equal(hdr["trafo"][j], ref[k]["trafo"])
+    # a list shorter than the device count, and an empty one
+    p1, t1, s1 = grp.match_pair_list_allgather_inliers(pq[:1], pt[:1], [b.data_ptr() for b in bufs])
+    assert p1 == 1 and int(t1.sum()) == int(ref["n_inl"][0]) and s1 == 104 + 4 * int(t1.max())
+    p0, t0, s0 = grp.match_pair_list_allgather_inliers(pq[:0], pt[:0], [b.data_ptr() for b in bufs])
+    assert p0 == 0 and s0 == 0
+    one = _fe(seq)
+    with pytest.raises(RgbdfeError):
+        one.match_pair_list_allgather_inliers(pq, pt, [bufs[0].data_ptr()])       # needs a multi-device handle
+    one.close()
+    grp.close()
