@@ -1,5 +1,6 @@
-"""GPU box, diagnostics build (librgbdfe_wd.so via RGBDFE_LIB): the many-threads tests in a loop until the refinement kernel's
-watchdog reports a spin loop that never ended.  python tools/r04_wd_probe.py <seconds> <group|single|both>"""
+"""GPU box, diagnostics build of the refinement kernel (csrc: hipcc ... -DRGBDFE_SPLIT_WATCHDOG -c ransac_split.hip, linked with the
+other objects into librgbdfe_wd.so; picked with RGBDFE_LIB; RGBDFE_RANSAC_SPLIT=1 so that small batches take the split path): the many-threads tests in a loop until the refinement kernel's
+watchdog reports a spin loop that never ended.  python tools/refine_watchdog_probe.py <seconds> <group|single|both>"""
 import ctypes as C
 import faulthandler
 import os
