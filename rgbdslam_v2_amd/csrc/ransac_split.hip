@@ -459,7 +459,12 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 // a workgroup takes units (pair, iteration range) off the launch's counter, keeps up to three of them resident in LDS and
 // its 8 waves take whatever viable iteration is next, of any resident unit.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_refine_kernel(
+#ifdef RGBDFE_SPLIT_NO_WAVES_ATTR
+#define RGBDFE_REFINE_ATTR
+#else
+#define RGBDFE_REFINE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+__global__ __launch_bounds__(kStreamThreads) RGBDFE_REFINE_ATTR void ransac_refine_kernel(
     uint32_t n_pairs, const RansacConst rc, const SplitPlan plan, uint32_t n_units) {
   // a later phase of a batch whose pairs have all ended (the walk of the phase before found nobody still running)
   if (plan.phase_index > 0 && plan.walk[n_pairs].best_n != plan.phase_index) return;
@@ -668,8 +673,12 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         if (lane == 0) flag_store(&lds.ctx[b].state, kUnitLoading);
       }
       lsync();
-#ifdef RGBDFE_SPLIT_PLAIN_UNLOCK
-      if (lane == 0) flag_store(&lds.qlock, 0);
+      // (Diagnostics variant -DRGBDFE_SPLIT_UNLOCK_ALL_LANES: the release as a store of the same word by every lane.  In the
+      // watchdog build it ran 4447 iterations of the stress loop without a stall where the single-lane forms stalled within
+      // 30 .. 886; in the product build it made stalls ~10x rarer, not impossible -- the effect is one of timing, the cause
+      // of the stall is still open -- and the 64-lane same-address store is not free, so it is not the default.)
+#if defined(RGBDFE_SPLIT_UNLOCK_ALL_LANES)
+      flag_store(&lds.qlock, 0);
 #else
       if (lane == 0) atomicExch(&lds.qlock, 0);
 #endif
@@ -701,6 +710,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       }
       if (!units_left && loading == 0ull) break;  // nothing more will come
       if (had || got > 0) break;                  // this wave has work: it looks again after the round
+#ifdef RGBDFE_SPLIT_IDLE_EXIT   // diagnostics variant: a wave without work does not poll, it leaves (while somebody else loads or works)
+      if (loading != 0ull || free_bufs == 0ull) break;
+#endif
       __builtin_amdgcn_s_sleep(4);                // idle: a loader is at work, or every buffer is still in use
       WD_TICK(2)
     }
@@ -904,8 +916,8 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           SP_COUNT(11, __popcll(__ballot(p)))
         }
         lsync();
-#ifdef RGBDFE_SPLIT_PLAIN_UNLOCK
-        if (lane == 0) flag_store(&lds.lock, 0);
+#if defined(RGBDFE_SPLIT_UNLOCK_ALL_LANES)
+        flag_store(&lds.lock, 0);
 #else
         if (lane == 0) atomicExch(&lds.lock, 0);
 #endif
@@ -952,8 +964,12 @@ int ransac_split_init() {
   if (n_cus[dev] == 0) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+#ifdef RGBDFE_SPLIT_ONE_WG_PER_CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+#else
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)sizeof(StreamLds));
+#endif
     if (getenv("RGBDFE_SPLIT_VERBOSE")) {  // diagnostics: what the runtime makes of the kernel's resources
       int nb = -1;
       const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(ransac_refine_kernel), kStreamThreads, sizeof(StreamLds));
@@ -971,7 +987,12 @@ void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPl
   // through plan.unit_counter (zero at launch)
   const int n_cus = ransac_split_init();
   const uint32_t max_wgs = 2u * (uint32_t)n_cus;
-  hipLaunchKernelGGL(ransac_refine_kernel, dim3(units < max_wgs ? units : max_wgs), dim3(kStreamThreads), sizeof(StreamLds), stream,
+#ifdef RGBDFE_SPLIT_ONE_WG_PER_CU   // diagnostics variant: more LDS than two workgroups of a CU can get
+  const size_t lds_bytes = 100 * 1024;
+#else
+  const size_t lds_bytes = sizeof(StreamLds);
+#endif
+  hipLaunchKernelGGL(ransac_refine_kernel, dim3(units < max_wgs ? units : max_wgs), dim3(kStreamThreads), lds_bytes, stream,
                      n_pairs, rc, plan, units);
 }
 
