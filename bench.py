@@ -240,15 +240,19 @@ def main():
     # RGBDFE_BENCH_BACKEND=gloo (tests only): several ranks on ONE GPU -- RCCL refuses two ranks on a device -- to exercise
     # the sharding / gather / timing logic of the N > 1 path; collectives then go through host tensors.
     backend = os.environ.get("RGBDFE_BENCH_BACKEND", "nccl")
+    # RGBDFE_BENCH_FORCE_GATHER=1 (tests only): the N > 1 gather code with ONE rank -- the only way to run its RCCL branch
+    # (process group, pack kernels, two-collective inlier gather, parity check on the gathered records) on a one-GPU box
+    force_gather = os.environ.get("RGBDFE_BENCH_FORCE_GATHER") == "1"
+    gather_on = world > 1 or force_gather
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or force_gather:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    host_coll = world > 1 and backend != "nccl"
+    host_coll = (world > 1 or force_gather) and backend != "nccl"
 
     from rgbdslam_v2_amd import synth
     from rgbdslam_v2_amd._lib import (KERNEL_HAMMING, KERNEL_RANSAC, KERNEL_SIFT_DOT,
@@ -262,7 +266,7 @@ def main():
     pq, pt = shard_pairs(pq_all, pt_all, rank, world)
     n_local = len(pq)
     counts = [n_local]
-    if world > 1:
+    if world > 1 or force_gather:
         t_cnt = torch.tensor([n_local], device="cpu" if host_coll else "cuda")
         all_cnt = [torch.zeros_like(t_cnt) for _ in range(world)]
         dist.all_gather(all_cnt, t_cnt)
@@ -288,14 +292,14 @@ def main():
 
     rec_bytes = RESULT_DTYPE.itemsize
     from rgbdslam_v2_amd._lib import COMPACT_DTYPE, INLIER_HEADER_DTYPE, RGBDFE_MAX_MATCHES
-    compact = world > 1 and args.gather == "compact"
-    inliers = world > 1 and args.gather == "inliers"
+    compact = gather_on and args.gather == "compact"
+    inliers = gather_on and args.gather == "inliers"
     hdr_bytes = INLIER_HEADER_DTYPE.itemsize
     stream_cap = n_pad * (hdr_bytes + 4 * RGBDFE_MAX_MATCHES)      # a shard's inlier stream at its largest
     gat_bytes = COMPACT_DTYPE.itemsize if compact else rec_bytes    # (fixed-size payloads)
     rccl_ranks = None
     cdev = "cpu" if host_coll else "cuda"
-    if world > 1:
+    if gather_on:
         # what the collective library itself saw: every rank contributes 1 through the backend the steps use
         ones = torch.ones(1, dtype=torch.int32, device=cdev)
         dist.all_reduce(ones)
@@ -314,7 +318,7 @@ def main():
         d_tots = torch.zeros(world, dtype=torch.int64, device=cdev)
     else:
         d_send = [torch.zeros(n_pad * gat_bytes, dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if compact else d_local
-        d_all = torch.zeros(world * n_pad * gat_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+        d_all = torch.zeros(world * n_pad * gat_bytes, dtype=torch.uint8, device="cuda") if gather_on else None
     consumed = [None] * NBUF
     stream = torch.cuda.current_stream().cuda_stream
     state = {"k": 0, "open": None, "bytes": 0, "gathers": 0, "last": None}
@@ -354,7 +358,7 @@ def main():
             ticket = fe.submit_sift_pair_list(pq, pt, d_local[b].data_ptr())
         else:
             ticket = fe.submit_pair_list(pq, pt, d_local[b].data_ptr())
-        if world > 1:
+        if gather_on:
             fe.wait_ticket(ticket, stream)  # torch's stream waits for this batch only
             if inliers:
                 # headers + (query row, train row) of every inlier match: inlier_scan_kernel + inlier_list_kernel on torch's
@@ -456,7 +460,7 @@ def main():
     # N = 1: this rank's records; N > 1: what the all-gather of the last step left on rank 0 -- every rank's records, as the
     # consumer of the gather sees them -- against the oracle's sums over the world x 4000 pairs of the global list
     list_entries = None
-    if world > 1:
+    if gather_on:
         torch.cuda.synchronize()
         if inliers:
             from rgbdslam_v2_amd._lib import parse_inlier_stream
@@ -476,7 +480,7 @@ def main():
     else:
         res_all = res
     parity = parity_check(("orb", args.depth_noise, world) if default_workload else None, res_all) if len(res_all) else None
-    if parity is not None and world > 1:
+    if parity is not None and gather_on:
         parity["records"] = "gathered on rank 0: %d records of %d ranks" % (len(res_all), world)
         if list_entries is not None:
             parity["inlier_list_entries"] = list_entries
@@ -532,7 +536,7 @@ def main():
             }
             print(json.dumps(out), flush=True)
             fe.close()
-            if world > 1:
+            if gather_on:
                 dist.destroy_process_group()
             return
         dominant = "hamming_nn" if ham_ser >= rsc_ser else "select_ransac"
@@ -585,7 +589,7 @@ def main():
             "repeats": repeats, "parity_check": parity,
             "timing": timing,
         }
-        if world > 1:
+        if gather_on:
             per_step = state["bytes"] / max(state["gathers"], 1)
             out["gather"] = {"payload_option": args.gather,
                              "payload": "inlier stream: rgbdfe_inlier_header (104 B) + 4 B per inlier match" if inliers else
@@ -647,7 +651,7 @@ def main():
 
     if fe is not None:
         fe.close()
-    if world > 1:
+    if world > 1 or force_gather:
         dist.destroy_process_group()
 
 

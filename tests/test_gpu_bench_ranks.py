@@ -55,3 +55,30 @@ def test_bench_two_ranks_full_workload_is_checked_against_the_oracle(gather):
     import bench
     assert pc["oracle_aggregates"] == bench.expected("orb", 0.01, 2)
     assert d["gather"]["payload_option"] == gather
+
+
+@pytest.mark.parametrize("gather", ["inliers", "compact", "full"])
+def test_bench_gather_path_over_rccl_with_one_rank(gather):
+    """The RCCL branch of the N > 1 code (nccl process group, pack kernels on torch's stream, ncclAllGather of device
+    buffers -- two collectives for the inlier payload --, the parity check on the gathered records) cannot run with two
+    ranks on a one-GPU box; RGBDFE_BENCH_FORCE_GATHER=1 runs it with ONE rank under torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RGBDFE_BENCH_FORCE_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RGBDFE_BENCH_BACKEND", None)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+         "--no-extras", "--no-cpu-baseline", "--gather", gather],
+        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["gather"]["backend"] == "nccl" and d["gather"]["rccl_ranks"] == 1
+    assert d["gather"]["payload_option"] == gather and d["gather"]["gathers_in_timed_regions"] == 3 * 4
+    pc = d["parity_check"]
+    assert pc["checked"] and pc["ok"] and "4000 records of 1 ranks" in pc["records"]
+    if gather == "inliers":
+        assert pc["inlier_list_entries"] == pc["oracle_aggregates"]["inliers"]
+        assert d["gather"]["collectives_per_step"] == 2 and 200 < d["gather"]["bytes_per_record"] < 400
