@@ -355,11 +355,15 @@ int rgbdfe_sift_node_features_min_depth(rgbdfe_ctx* ctx, const float* kp_xy, con
 int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_iterations);
 
 /* Which kernel computes the Hamming nearest neighbours of an ORB batch (identical keys, bit for bit):
- *   1 (default)  the descriptor bits as fp4 (+-1) operands of v_mfma_f32_32x32x64_f8f6f4: hd = (256 + dot) / 2, exact
+ *   1            the descriptor bits as fp4 (+-1) operands of v_mfma_f32_32x32x64_f8f6f4: hd = (256 + dot) / 2, exact
  *                in the f32 accumulator, the row index folded into the accumulator's initial value (hamming_mfma.hip);
- *   2            same, the row index added by the VALU instead of the matrix core's C operand;
+ *   3            the same contraction as a software pipeline inside every wave (the reduction of one accumulator and the
+ *                LDS reads of the next train tile sit between the MFMAs of the other accumulator; train tiles arrive by
+ *                global_load_lds through three LDS buffers);
+ *   2            as 1, the row index added by the VALU instead of the matrix core's C operand;
  *   0            xor + popcount on the VALU (hamming_nn.hip) -- also what nodes with max_keypoints > 32768 get.
- * Environment variable RGBDFE_HAMMING_MODE sets the initial value. */
+ * RGBDFE_HAMMING_MODE_DEFAULT is the mode of a new context; environment variable RGBDFE_HAMMING_MODE overrides it. */
+#define RGBDFE_HAMMING_MODE_DEFAULT 1
 int rgbdfe_set_hamming_mode(rgbdfe_ctx* ctx, int32_t mode);
 
 /* ---- frame-level data either side of the pair path ----------------

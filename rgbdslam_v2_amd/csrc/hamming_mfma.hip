@@ -263,6 +263,242 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MODE 3: the same contraction as a software pipeline inside every wave (round 4).
+//
+// In the kernel above a wave issues the eight MFMAs of a train tile in one burst and reduces the two accumulators
+// afterwards: the matrix pipe only stays busy while ANOTHER wave of the SIMD happens to be in its burst, and bursts of
+// co-resident waves drift into step (measured: matrix pipe 0.61 + VALU 0.40 of the kernel time, i.e. no overlap).  Here the
+// overlap is built into the instruction stream of each wave:
+//   * the unit of work is one chain of four MFMAs (one train tile x one of the wave's two query tiles); the v_min3 tree of
+//     unit u - 1 and the LDS reads of the next train tile are placed in the gaps between the MFMAs of unit u
+//     (sched_group_barrier pins the order): ~3.3 single-issue instructions per 32-cycle MFMA;
+//   * the two accumulators alternate (unit u writes acc[u & 1] while acc[(u - 1) & 1] is reduced): no more registers than
+//     the burst form;
+//   * train tiles come in stages of four through THREE LDS buffers filled by global_load_lds (no staging registers, no
+//     ds_write); the one barrier per stage sits in the MIDDLE of the stage's instruction stream -- it publishes the NEXT
+//     stage (loaded a whole stage ago) and frees the buffer of the previous one -- so the stream of MFMAs does not drain at
+//     a stage boundary;
+//   * every stage is the same straight-line code: the pair's ragged tile is moved to the last slot of the last stage
+//     (the minimum does not care about the order of the tiles) where the C operand is `c3` (= the row term with 3e38 for
+//     the excluded rows in that one stage), missing tiles are phantoms: they read some valid tile and add a base of
+//     2^22, which no real key reaches (real keys are < 1024).
+// Keys are those of the other kernels, bit for bit (tests/test_gpu_hamming.py runs all four).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPipeStage = 4;  // train tiles per stage (the unrolled stream below is written for four)
+constexpr uint32_t kPhantomTile = 0x7FFFFFFFu;
+constexpr float kRowUnitPerTile = 32.0f / 16384.0f;  // the tile's first row, in key units
+
+#define HP_MFMA(ACC, A, B, C) ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, C, 4, 4, 0, 0, 0, 0);
+#define HP_SGB(MASK, N) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+#define HP_FENCE() __builtin_amdgcn_sched_barrier(0);
+
+template <bool SPLIT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
+                                                                     const PairWork* __restrict__ work,
+                                                                     uint32_t* __restrict__ keys, uint32_t max_kp,
+                                                                     uint32_t tiles_per_slot, uint32_t n_pairs,
+                                                                     uint32_t qblocks, uint32_t tsplit) {
+  // three stage buffers [slot][fragment order of a tile] as three VARIABLES: the compiler tells LDS objects apart by
+  // variable, and only then does it let the LDS reads of one buffer pass the global_load_lds towards another
+  __shared__ uint4 lds0[kPipeStage][256], lds1[kPipeStage][256], lds2[kPipeStage][256];
+  const uint32_t L = blockIdx.x;
+  const uint32_t xcd = L & 7u;
+  const uint32_t j = L >> 3;
+  const uint32_t subs = qblocks * tsplit;
+  const uint32_t pair = (j / subs) * 8u + xcd;
+  if (pair >= n_pairs) return;
+  const uint32_t sub = j % subs;
+  const uint32_t qblock = sub / tsplit;
+  const uint32_t split = sub % tsplit;
+
+  const PairWork w = work[pair];
+  const uint32_t nq = w.nq;
+  if (qblock * kQueriesPerBlock >= nq) return;
+  const uint32_t nt_search = w.nt > 0 ? w.nt - 1u : 0u;  // features.cpp:174 (and D4)
+  const uint32_t n_ttiles = (nt_search + 31u) >> 5;
+  uint32_t tile0 = 0, tile1 = n_ttiles;
+  if (SPLIT) {
+    const uint32_t chunk = (n_ttiles + tsplit - 1u) / tsplit;
+    tile0 = min(split * chunk, n_ttiles);
+    tile1 = min(tile0 + chunk, n_ttiles);
+  }
+  // this block's tiles as slots: the full tiles first, phantoms, the ragged tile (if it is this block's) in the last slot
+  const uint32_t fend = min(tile1, nt_search >> 5);
+  const uint32_t n_full = fend > tile0 ? fend - tile0 : 0u;
+  const bool has_ragged = (nt_search & 31u) != 0u && tile1 == n_ttiles && tile1 > tile0;
+  const uint32_t n_stages = (n_full + (has_ragged ? 1u : 0u) + kPipeStage - 1u) / kPipeStage;
+  const uint32_t last_slot = n_stages * kPipeStage - 1u;
+  const uint32_t ragged_tile = n_ttiles - 1u;
+  auto slot_tile = [&](uint32_t s) -> uint32_t {  // block-uniform
+    return s < n_full ? tile0 + s : (has_ragged && s == last_slot ? ragged_tile : kPhantomTile);
+  };
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t half = lane >> 5;
+
+  v8i bq[kQT][4];
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    uint32_t qt = qblock * (kQueriesPerBlock / 32) + wave * kQT + t;
+    qt = min(qt, tiles_per_slot - 1u);
+    const uint4* __restrict__ qs = slab + ((size_t)w.q_slot * tiles_per_slot + qt) * 256u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 v = qs[s * 64 + lane];
+      v.x ^= 0x88888888u; v.y ^= 0x88888888u; v.z ^= 0x88888888u; v.w ^= 0x88888888u;
+      bq[t][s] = as_operand(v);
+    }
+  }
+
+  v16f crow, c3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) crow[r] = kBias + (float)((r & 3) + 8 * (r >> 2) + 4 * (int)half) * kRowUnit;
+  c3 = crow;
+  auto set_c3_ragged = [&]() {
+    uint32_t nts = nt_search;
+    asm volatile("" : "+v"(nts));  // formed where it is needed (once per block), not kept in 16 registers from the start
+    const uint32_t rag0 = (nts >> 5) << 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t row = rag0 + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
+      c3[r] = row < nts ? crow[r] : kNone;
+    }
+  };
+
+  uint32_t best0 = __float_as_uint(kNone), best1 = __float_as_uint(kNone);
+
+  const uint32_t last_tile = tiles_per_slot - 1u;
+  const char* __restrict__ ts = reinterpret_cast<const char*>(slab + (size_t)w.t_slot * tiles_per_slot * 256u);
+  const uint64_t ts_u = reinterpret_cast<uint64_t>(ts);
+  const uint32_t ts_lo = __builtin_amdgcn_readfirstlane((uint32_t)ts_u);
+  const uint32_t ts_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ts_u >> 32));
+  const uint32_t vo16 = threadIdx.x * 16u;
+
+  // stage `st` of this block -> LDS buffer `b` (this wave's quarter of each of the four tiles)
+  auto load_stage = [&](uint32_t st, uint4 (*buf)[256]) {
+#pragma unroll
+    for (int i = 0; i < kPipeStage; ++i) {
+      const uint32_t tl = min(slot_tile(st * kPipeStage + (uint32_t)i), last_tile);
+      const char* tb = reinterpret_cast<const char*>((((uint64_t)ts_hi << 32) | ts_lo) + (uint64_t)tl * 4096u);
+      uint32_t vo = vo16;
+      asm volatile("" : "+v"(vo));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + vo),
+                                       (__attribute__((address_space(3))) void*)&buf[i][wave * 64],
+                                       16, 0, 0);
+    }
+  };
+
+  if (n_stages > 0) {
+    static_assert(kQT == 2 && kPipeStage == 4, "the unrolled stream is written for two query tiles and four-tile stages");
+    load_stage(0, lds0);
+    if (n_stages > 1) load_stage(1, lds1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+
+    v8i aA[4], aB[4];  // A operands of the even / odd slots of a stage
+    // (BUF = 0, 1, 2 is a literal everywhere: the compiler must SEE that a stage's LDS reads and the global_load_lds of the
+    // stage after the next one touch different buffers, or it waits for the loads in front of the next LDS read)
+#define HP_READ(DST, BUF, SLOT, S) DST[S] = as_operand(lds##BUF[SLOT][(S) * 64 + lane]);
+#define HP_BASE(SLOT) ((float)slot_tile(st * kPipeStage + (SLOT)) * kRowUnitPerTile)
+    // reduction of one accumulator into the running minimum of its query tile
+#define HP_EPI(ACC, BEST, BASE)                                                 \
+    BEST = min(BEST, __float_as_uint(__uint_as_float(min16(ACC)) + (BASE))); \
+    asm volatile("" : "+v"(BEST));   /* the reduction is finished HERE, not merged into a later one */
+    // one unit: four MFMAs with the previous unit's reduction (10 VALU) and two LDS reads in their gaps
+#define HP_UNIT(ACC, A, Q, C, PACC, PBEST, PBASE, R0, R1)                                           \
+    HP_MFMA(ACC, A[0], bq[Q][0], C)                                                                 \
+    R0 R1                                                                                           \
+    HP_MFMA(ACC, A[1], bq[Q][1], ACC)                                                               \
+    HP_EPI(PACC, PBEST, PBASE)                                                                      \
+    HP_MFMA(ACC, A[2], bq[Q][2], ACC)                                                               \
+    HP_MFMA(ACC, A[3], bq[Q][3], ACC)                                                               \
+    HP_SGB(0x008, 1) HP_SGB(0x100, 2)                                                               \
+    HP_SGB(0x008, 1) HP_SGB(0x002, 4)                                                               \
+    HP_SGB(0x008, 1) HP_SGB(0x002, 4)                                                               \
+    HP_SGB(0x008, 1) HP_SGB(0x002, 4)                                                               \
+    HP_FENCE()
+    // A stage out of buffer CUR in two halves; the barrier between them publishes the NEXT stage (this wave's
+    // global_load_lds of it was issued a whole stage ago) and frees the buffer of the PREVIOUS one for the stage after the
+    // next.  The loop below turns at that barrier, where nothing is in flight (the compiler's bookkeeping of what an LDS
+    // read may have to wait for is exact in straight-line code only).
+#define HP_HALF_A(CUR)                                                                                               \
+    {                                                                                                                \
+      b0 = HP_BASE(0); b1 = HP_BASE(1);                                                                              \
+      HP_FENCE()                                                                                                     \
+      HP_UNIT(acc0, aA, 0, crow, acc1, best1, pend, HP_READ(aB, CUR, 1, 0), HP_READ(aB, CUR, 1, 1))                  \
+      HP_UNIT(acc1, aA, 1, crow, acc0, best0, b0, HP_READ(aB, CUR, 1, 2), HP_READ(aB, CUR, 1, 3))                    \
+      HP_UNIT(acc0, aB, 0, crow, acc1, best1, b0, HP_READ(aA, CUR, 2, 0), HP_READ(aA, CUR, 2, 1))                    \
+      HP_UNIT(acc1, aB, 1, crow, acc0, best0, b1, HP_READ(aA, CUR, 2, 2), HP_READ(aA, CUR, 2, 3))                    \
+      __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): this wave's share of the next stage has landed */            \
+      __syncthreads();                                                                                               \
+    }
+#define HP_HALF_B(CUR, NXT, NN)                                                                                      \
+    {                                                                                                                \
+      if (st + 2u < n_stages) load_stage(st + 2u, lds##NN); /* (nothing may be in flight towards LDS at the end) */  \
+      const float b2 = HP_BASE(2), b3 = HP_BASE(3);                                                                  \
+      if (has_ragged && st + 1u == n_stages) {                                                                       \
+        set_c3_ragged();                                                                                             \
+        asm volatile("" : "+v"(c3)); /* a real (block-uniform) branch: not sixteen selects in every stage */        \
+      }                                                                                                              \
+      HP_FENCE()                                                                                                     \
+      HP_UNIT(acc0, aA, 0, crow, acc1, best1, b1, HP_READ(aB, CUR, 3, 0), HP_READ(aB, CUR, 3, 1))                    \
+      HP_UNIT(acc1, aA, 1, crow, acc0, best0, b2, HP_READ(aB, CUR, 3, 2), HP_READ(aB, CUR, 3, 3))                    \
+      HP_UNIT(acc0, aB, 0, c3, acc1, best1, b2, HP_READ(aA, NXT, 0, 0), HP_READ(aA, NXT, 0, 1))                      \
+      HP_UNIT(acc1, aB, 1, c3, acc0, best0, b3, HP_READ(aA, NXT, 0, 2), HP_READ(aA, NXT, 0, 3))                      \
+      pend = b3;                                                                                                     \
+    }
+
+    HP_READ(aA, 0, 0, 0) HP_READ(aA, 0, 0, 1) HP_READ(aA, 0, 0, 2) HP_READ(aA, 0, 0, 3)
+    v16f acc0, acc1 = crow;
+    float pend = 4.0e6f;  // acc1 = the row terms (>= 256), + 4e6: a phantom for the first unit's reduction slot
+    float b0, b1;
+    uint32_t st = 0;
+    HP_HALF_A(0)
+    for (;;) {
+      HP_HALF_B(0, 1, 2)
+      if (++st == n_stages) break;
+      HP_HALF_A(1)
+      HP_HALF_B(1, 2, 0)
+      if (++st == n_stages) break;
+      HP_HALF_A(2)
+      HP_HALF_B(2, 0, 1)
+      if (++st == n_stages) break;
+      HP_HALF_A(0)
+    }
+    HP_EPI(acc1, best1, pend)
+#undef HP_HALF_A
+#undef HP_HALF_B
+#undef HP_UNIT
+#undef HP_EPI
+#undef HP_BASE
+#undef HP_READ
+  }
+
+  uint32_t* kout = keys + ((size_t)pair * tsplit + split) * max_kp;
+  const uint32_t bests[2] = {best0, best1};
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    uint32_t bb = bests[t];
+    bb = min(bb, (uint32_t)__shfl_xor((int)bb, 32));
+    const float b = __uint_as_float(bb);
+    const uint32_t qi = qblock * kQueriesPerBlock + (wave * kQT + (uint32_t)t) * 32u + (lane & 31u);
+    if (half == 0 && qi < nq) {
+      uint32_t key = kNoMatchKey;
+      if (b < 1024.0f) {  // real keys: 2*hd + row / 2^14 < 514; phantoms and excluded rows are >= 2^22
+        const uint32_t k = (uint32_t)(b * 16384.0f);
+        key = ((k >> 15) << 16) | (k & 32767u);
+      }
+      kout[qi] = key;
+    }
+  }
+}
+#undef HP_MFMA
+#undef HP_SGB
+#undef HP_FENCE
+
 }  // namespace
 
 uint32_t hamming_mfma_tiles_per_slot(uint32_t max_kp) { return (max_kp + 31u) / 32u; }
@@ -310,7 +546,14 @@ uint32_t launch_hamming_mfma(const uint32_t* slab, const PairWork* work, uint32_
 #define RGBDFE_LAUNCH_HM(M, S)                                                                                   \
   hipLaunchKernelGGL((hamming_mfma_kernel<M, S>), dim3(grid), dim3(kThreads), 0, stream, s4, work, keys, max_kp, \
                      tiles_per_slot, n_pairs, qblocks, tsplit)
-  if (mode == 2) {
+  if (mode == 3) {
+    if (tsplit > 1)
+      hipLaunchKernelGGL((hamming_mfma_pipe_kernel<true>), dim3(grid), dim3(kThreads), 0, stream, s4, work, keys, max_kp,
+                         tiles_per_slot, n_pairs, qblocks, tsplit);
+    else
+      hipLaunchKernelGGL((hamming_mfma_pipe_kernel<false>), dim3(grid), dim3(kThreads), 0, stream, s4, work, keys, max_kp,
+                         tiles_per_slot, n_pairs, qblocks, tsplit);
+  } else if (mode == 2) {
     if (tsplit > 1) RGBDFE_LAUNCH_HM(2, true); else RGBDFE_LAUNCH_HM(2, false);
   } else {
     if (tsplit > 1) RGBDFE_LAUNCH_HM(1, true); else RGBDFE_LAUNCH_HM(1, false);

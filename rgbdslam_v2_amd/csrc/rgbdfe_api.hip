@@ -173,7 +173,7 @@ struct rgbdfe_ctx {
   hipEvent_t orb_describe_done[OrbWorkspace::kSets] = {};  // frame f's description has left its image set
   bool feature_min_depth = false;  // "use_feature_min_depth" (parameter_server.cpp:90): rgbdfe_set_feature_min_depth
   bool sift_fast = true;       // sift_match.hip's float keys where a pair qualifies (RGBDFE_SIFT_FAST_KEYS=0: never)
-  int hamming_mode = 1;        // 0 = popcount kernel (hamming_nn.hip), 1 = fp4 MFMA kernel (hamming_mfma.hip)
+  int hamming_mode = RGBDFE_HAMMING_MODE_DEFAULT;   // rgbdfe.h: 0 = popcount kernel (hamming_nn.hip), 1 / 2 / 3 = fp4 MFMA kernels (hamming_mfma.hip)
   // Batches run on kLanes internal HIP streams ("lanes"), each with its own keys / results
   // staging, so that batch k+1's Hamming kernel fills the SIMDs that batch k's RANSAC tail
   // leaves idle.  The pair lists go through a ring of pinned buffers so the host can prepare
@@ -791,7 +791,7 @@ int rgbdfe_create(const rgbdfe_config* cfg, rgbdfe_ctx** out) {
   if (rc != RGBDFE_OK) { delete ctx; return rc; }
   fill_ransac_const(ctx);
   if (const char* sf = getenv("RGBDFE_SIFT_FAST_KEYS")) ctx->sift_fast = atoi(sf) != 0;
-  if (const char* hm = getenv("RGBDFE_HAMMING_MODE")) ctx->hamming_mode = atoi(hm) < 0 || atoi(hm) > 2 ? 1 : atoi(hm);
+  if (const char* hm = getenv("RGBDFE_HAMMING_MODE")) ctx->hamming_mode = atoi(hm) < 0 || atoi(hm) > 3 ? RGBDFE_HAMMING_MODE_DEFAULT : atoi(hm);
   if (const char* gr = getenv("RGBDFE_GRAPHS")) ctx->use_graphs = atoi(gr) != 0;   // (rgbdfe_set_graph_capture overrides)
   auto bail = [&](int code) { rgbdfe_destroy(ctx); return code; };
   if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(RGBDFE_ERR_NO_DEVICE);
@@ -3058,7 +3058,7 @@ int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_it
 }
 
 int rgbdfe_set_hamming_mode(rgbdfe_ctx* ctx, int32_t mode) {
-  if (!ctx || mode < 0 || mode > 2) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "hamming mode must be 0, 1 or 2");
+  if (!ctx || mode < 0 || mode > 3) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "hamming mode must be 0, 1, 2 or 3");
   std::lock_guard<std::mutex> g(ctx->mu);
   ctx->hamming_mode = mode;
   return RGBDFE_OK;

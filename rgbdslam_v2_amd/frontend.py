@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import RESULT_DTYPE, RgbdfeConfig, RgbdfeError, RgbdfeParams
+from ._lib import DEFAULT_HAMMING_MODE, RESULT_DTYPE, RgbdfeConfig, RgbdfeError, RgbdfeParams
 
 
 @dataclass
@@ -107,7 +107,8 @@ class FrontEnd:
         return int(self._L.rgbdfe_device_count(self._ctx))
 
     def set_hamming_mode(self, mode: int):
-        """0 = popcount kernel, 1 = fp4 MFMA kernel (default), 2 = MFMA kernel with the VALU row term."""
+        """0 = popcount kernel, 1 = fp4 MFMA kernel, 2 = MFMA kernel with the VALU row term, 3 = the MFMA kernel as a
+        software pipeline inside every wave (include/rgbdfe.h; _lib.DEFAULT_HAMMING_MODE is what a new context uses)."""
         self._check(self._L.rgbdfe_set_hamming_mode(self._ctx, mode))
         self._hamming_mode = int(mode)
 
@@ -118,10 +119,10 @@ class FrontEnd:
         m = getattr(self, "_hamming_mode", None)
         if m is None:
             try:
-                m = int(os.environ.get("RGBDFE_HAMMING_MODE", "1"))
+                m = int(os.environ.get("RGBDFE_HAMMING_MODE", str(DEFAULT_HAMMING_MODE)))
             except ValueError:
-                m = 1
-            m = m if 0 <= m <= 2 else 1
+                m = DEFAULT_HAMMING_MODE
+            m = m if 0 <= m <= 3 else DEFAULT_HAMMING_MODE
         return 0 if self.cfg.max_keypoints > 32768 else m
 
     def group_submit_us(self) -> float:

@@ -55,3 +55,10 @@ def test_no_cpu_fallback_without_device(frontend_lib):
     from rgbdslam_v2_amd.frontend import FrontEnd
     with pytest.raises(_lib.RgbdfeError):
         FrontEnd()
+
+
+def test_default_hamming_mode_is_the_headers():
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rgbdfe.h")).read()
+    m = re.search(r"#define\s+RGBDFE_HAMMING_MODE_DEFAULT\s+(\d+)", hdr)
+    assert m and int(m.group(1)) == _lib.DEFAULT_HAMMING_MODE

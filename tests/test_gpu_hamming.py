@@ -13,7 +13,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "hamming_golden.npz")
 
 # every Hamming kernel of the library must return the reference's keys: 1 = fp4 MFMA contraction with the row term in
 # the accumulator's initial value (the default), 2 = the same with the row term added by the VALU, 0 = xor + popcount
-@pytest.fixture(scope="module", params=[1, 2, 0], ids=["mfma", "mfma_valu_row", "popcount"])
+# 3 = the MFMA contraction as a software pipeline inside every wave
+@pytest.fixture(scope="module", params=[1, 3, 2, 0], ids=["mfma", "mfma_pipelined", "mfma_valu_row", "popcount"])
 def fe(request):
     from rgbdslam_v2_amd.frontend import FrontEnd
     f = FrontEnd(device_id=0, max_nodes=48, max_keypoints=4096, max_pairs_per_batch=1024)
@@ -104,7 +105,7 @@ def test_all_hamming_kernels_agree_on_a_full_batch():
     pq = np.array([a for a in range(n_nodes) for b in range(n_nodes) if a != b], np.int32)
     pt = np.array([b for a in range(n_nodes) for b in range(n_nodes) if a != b], np.int32)
     outs = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         fe = FrontEnd(device_id=0, max_nodes=16, max_keypoints=4032, max_pairs_per_batch=256)
         fe.set_hamming_mode(mode)
         for k in range(n_nodes):
@@ -120,9 +121,9 @@ def test_all_hamming_kernels_agree_on_a_full_batch():
         fe.close()
     for k, (a, b) in enumerate(zip(pq[::7], pt[::7])):
         hd_ref, idx_ref = po.hamming_nn_batch(descs[a], descs[b])
-        for mode in range(3):
+        for mode in range(4):
             assert np.array_equal(outs[mode][0][k][0], hd_ref), (mode, a, b)
             assert np.array_equal(outs[mode][0][k][1], idx_ref), (mode, a, b)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         for f in range(1, 5):
             assert np.array_equal(outs[0][f], outs[mode][f])

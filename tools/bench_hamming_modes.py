@@ -1,4 +1,4 @@
-"""The three Hamming kernels of the library side by side (rgbdfe_set_hamming_mode): serial stage time per batch
+"""The Hamming kernels of the library side by side (rgbdfe_set_hamming_mode): serial stage time per batch
 (HIP events, one batch in flight) at 1000 and 4000 keypoints, and a byte comparison of the batch results."""
 import json
 import os
@@ -13,12 +13,13 @@ from rgbdslam_v2_amd.frontend import FrontEnd
 
 import torch
 
+MODES = [int(m) for m in os.environ.get("RGBDFE_BENCH_HAMMING_MODES", "0,1,2,3").split(",")]   # the first one is the byte reference
 out = {}
 for n_kp, frames, per in ((1000, 200, 20), (4000, 100, 10)):
     seq = synth.make_sequence(n_frames=frames, n_kp=n_kp, n_world=4 * n_kp, seed=20260923, depth_noise=0.01)
     pq, pt = synth.candidate_pairs(frames, per_frame=per, seed=20260923)
     ref = None
-    for mode in (0, 1, 2):
+    for mode in MODES:
         fe = FrontEnd(device_id=0, max_nodes=frames, max_keypoints=((n_kp + 63) // 64) * 64, max_pairs_per_batch=len(pq))
         fe.set_hamming_mode(mode)
         for f in range(frames):
