@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--depth-noise", type=float, default=0.01,
                     help="sigma of the synthetic depth noise as a multiple of z^2 (SURVEY.md 8(d): 0.01 = sigma_depth; "
                          "round 1 measured with 0.002)")
-    ap.add_argument("--hamming-mode", type=int, default=-1, choices=[-1, 0, 1, 2],
+    ap.add_argument("--hamming-mode", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="-1 = the library's default (fp4 MFMA contraction), 0 = xor+popcount kernel, 2 = MFMA with VALU row term")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records")
     ap.add_argument("--gather", choices=["inliers", "compact", "full"], default="inliers",
@@ -710,7 +710,8 @@ def match_roofline(n_kp, n_pairs, ham_ms, hamming_mode):
         return None
     if hamming_mode != 0:
         tf = 2.0 * n_kp * n_kp * 256 * n_pairs / (ham_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "hamming_mfma_kernel (v_mfma_f32_32x32x64_f8f6f4, fp4 x fp4)",
+        return {"bound": "mfma", "kernel": "%s (v_mfma_f32_32x32x64_f8f6f4, fp4 x fp4)"
+                                           % ("hamming_mfma_pipe_kernel" if hamming_mode == 3 else "hamming_mfma_kernel"),
                 "achieved": round(tf, 2), "peak": 10000.0, "unit": "TFLOP/s", "frac": round(tf / 10000.0, 5),
                 "flop_per_pair": 2.0 * n_kp * n_kp * 256, "avg_launch_ms": round(ham_ms, 4), "time_basis": "serial"}
     ops = 16.0 * n_kp * (n_kp - 1) * n_pairs / (ham_ms * 1e-3)

@@ -363,7 +363,7 @@ int rgbdfe_set_latency_mode(rgbdfe_ctx* ctx, int32_t max_pairs, int32_t chunk_it
  *   2            as 1, the row index added by the VALU instead of the matrix core's C operand;
  *   0            xor + popcount on the VALU (hamming_nn.hip) -- also what nodes with max_keypoints > 32768 get.
  * RGBDFE_HAMMING_MODE_DEFAULT is the mode of a new context; environment variable RGBDFE_HAMMING_MODE overrides it. */
-#define RGBDFE_HAMMING_MODE_DEFAULT 1
+#define RGBDFE_HAMMING_MODE_DEFAULT 3
 int rgbdfe_set_hamming_mode(rgbdfe_ctx* ctx, int32_t mode);
 
 /* ---- frame-level data either side of the pair path ----------------

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RGBDFE_LIB", os.path.join(_HERE, "librgbdfe.so"))  # 
 RGBDFE_MAX_MATCHES = 320
 RGBDFE_MASK_WORDS = 5
 
-DEFAULT_HAMMING_MODE = 1   # RGBDFE_HAMMING_MODE_DEFAULT of include/rgbdfe.h (tests/test_abi.py keeps the two equal)
+DEFAULT_HAMMING_MODE = 3   # RGBDFE_HAMMING_MODE_DEFAULT of include/rgbdfe.h (tests/test_abi.py keeps the two equal)
 KERNEL_HAMMING = 0
 KERNEL_RANSAC = 1
 KERNEL_SIFT_DOT = 2

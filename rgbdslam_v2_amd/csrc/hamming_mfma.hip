@@ -286,6 +286,15 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
 //     2^22, which no real key reaches (real keys are < 1024).
 // Keys are those of the other kernels, bit for bit (tests/test_gpu_hamming.py runs all four).
 // ------------------------------------------------------------------------------------------------
+#ifndef RGBDFE_HAMMING_PIPE_WAVES
+#define RGBDFE_HAMMING_PIPE_WAVES 3          // waves per SIMD the register allocation aims at (48 KB of LDS: three blocks per CU)
+#endif
+#ifndef RGBDFE_HAMMING_PIPE_VALU_GROUPS
+#define RGBDFE_HAMMING_PIPE_VALU_GROUPS 334  // reduction instructions behind the 2nd / 3rd / 4th MFMA of a unit (diagnostics)
+#endif
+#ifndef RGBDFE_HAMMING_PIPE_DIAG
+#define RGBDFE_HAMMING_PIPE_DIAG 0   // TIMING-ONLY builds (keys are forced to "no match"): 1 no reductions, 2 no LDS reads in the
+#endif                               // loop, 4 no global_load_lds / barriers in the loop; tools/build_hamming_pipe_variants.sh
 constexpr int kPipeStage = 4;  // train tiles per stage (the unrolled stream below is written for four)
 constexpr uint32_t kPhantomTile = 0x7FFFFFFFu;
 constexpr float kRowUnitPerTile = 32.0f / 16384.0f;  // the tile's first row, in key units
@@ -295,7 +304,8 @@ constexpr float kRowUnitPerTile = 32.0f / 16384.0f;  // the tile's first row, in
 #define HP_FENCE() __builtin_amdgcn_sched_barrier(0);
 
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(RGBDFE_HAMMING_PIPE_WAVES, RGBDFE_HAMMING_PIPE_WAVES)))
+void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
                                                                      const PairWork* __restrict__ work,
                                                                      uint32_t* __restrict__ keys, uint32_t max_kp,
                                                                      uint32_t tiles_per_slot, uint32_t n_pairs,
@@ -401,12 +411,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
     v8i aA[4], aB[4];  // A operands of the even / odd slots of a stage
     // (BUF = 0, 1, 2 is a literal everywhere: the compiler must SEE that a stage's LDS reads and the global_load_lds of the
     // stage after the next one touch different buffers, or it waits for the loads in front of the next LDS read)
+#if RGBDFE_HAMMING_PIPE_DIAG & 2
+#define HP_READ(DST, BUF, SLOT, S) asm volatile("" : "+v"(DST[S]));
+#else
 #define HP_READ(DST, BUF, SLOT, S) DST[S] = as_operand(lds##BUF[SLOT][(S) * 64 + lane]);
+#endif
 #define HP_BASE(SLOT) ((float)slot_tile(st * kPipeStage + (SLOT)) * kRowUnitPerTile)
     // reduction of one accumulator into the running minimum of its query tile
+#if RGBDFE_HAMMING_PIPE_DIAG & 1
+#define HP_EPI(ACC, BEST, BASE) asm volatile("" : : "v"(ACC));
+#else
 #define HP_EPI(ACC, BEST, BASE)                                                 \
     BEST = min(BEST, __float_as_uint(__uint_as_float(min16(ACC)) + (BASE))); \
     asm volatile("" : "+v"(BEST));   /* the reduction is finished HERE, not merged into a later one */
+#endif
     // one unit: four MFMAs with the previous unit's reduction (10 VALU) and two LDS reads in their gaps
 #define HP_UNIT(ACC, A, Q, C, PACC, PBEST, PBASE, R0, R1)                                           \
     HP_MFMA(ACC, A[0], bq[Q][0], C)                                                                 \
@@ -416,14 +434,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
     HP_MFMA(ACC, A[2], bq[Q][2], ACC)                                                               \
     HP_MFMA(ACC, A[3], bq[Q][3], ACC)                                                               \
     HP_SGB(0x008, 1) HP_SGB(0x100, 2)                                                               \
-    HP_SGB(0x008, 1) HP_SGB(0x002, 4)                                                               \
-    HP_SGB(0x008, 1) HP_SGB(0x002, 4)                                                               \
-    HP_SGB(0x008, 1) HP_SGB(0x002, 4)                                                               \
+    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS / 100)                            \
+    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS / 10 % 10)                        \
+    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS % 10)                             \
     HP_FENCE()
     // A stage out of buffer CUR in two halves; the barrier between them publishes the NEXT stage (this wave's
     // global_load_lds of it was issued a whole stage ago) and frees the buffer of the PREVIOUS one for the stage after the
     // next.  The loop below turns at that barrier, where nothing is in flight (the compiler's bookkeeping of what an LDS
     // read may have to wait for is exact in straight-line code only).
+#if RGBDFE_HAMMING_PIPE_DIAG & 4
+#define HP_TURN()
+#define HP_LOADS false
+#else
+    /* vmcnt(0): this wave's share of the next stage has landed */
+#define HP_TURN() __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+#define HP_LOADS true
+#endif
 #define HP_HALF_A(CUR)                                                                                               \
     {                                                                                                                \
       b0 = HP_BASE(0); b1 = HP_BASE(1);                                                                              \
@@ -432,12 +458,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
       HP_UNIT(acc1, aA, 1, crow, acc0, best0, b0, HP_READ(aB, CUR, 1, 2), HP_READ(aB, CUR, 1, 3))                    \
       HP_UNIT(acc0, aB, 0, crow, acc1, best1, b0, HP_READ(aA, CUR, 2, 0), HP_READ(aA, CUR, 2, 1))                    \
       HP_UNIT(acc1, aB, 1, crow, acc0, best0, b1, HP_READ(aA, CUR, 2, 2), HP_READ(aA, CUR, 2, 3))                    \
-      __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): this wave's share of the next stage has landed */            \
-      __syncthreads();                                                                                               \
+      HP_TURN()                                                                                                      \
     }
 #define HP_HALF_B(CUR, NXT, NN)                                                                                      \
     {                                                                                                                \
-      if (st + 2u < n_stages) load_stage(st + 2u, lds##NN); /* (nothing may be in flight towards LDS at the end) */  \
+      if (HP_LOADS && st + 2u < n_stages) load_stage(st + 2u, lds##NN); /* (nothing may be in flight at the end) */   \
       const float b2 = HP_BASE(2), b3 = HP_BASE(3);                                                                  \
       if (has_ragged && st + 1u == n_stages) {                                                                       \
         set_c3_ragged();                                                                                             \
@@ -471,6 +496,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
     HP_EPI(acc1, best1, pend)
 #undef HP_HALF_A
 #undef HP_HALF_B
+#undef HP_TURN
+#undef HP_LOADS
 #undef HP_UNIT
 #undef HP_EPI
 #undef HP_BASE
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
     const uint32_t qi = qblock * kQueriesPerBlock + (wave * kQT + (uint32_t)t) * 32u + (lane & 31u);
     if (half == 0 && qi < nq) {
       uint32_t key = kNoMatchKey;
-      if (b < 1024.0f) {  // real keys: 2*hd + row / 2^14 < 514; phantoms and excluded rows are >= 2^22
+      if (RGBDFE_HAMMING_PIPE_DIAG ? b < -1.0f : b < 1024.0f) {  // real keys: 2*hd + row / 2^14 < 514; phantoms and excluded rows are >= 2^22
         const uint32_t k = (uint32_t)(b * 16384.0f);
         key = ((k >> 15) << 16) | (k & 32767u);
       }

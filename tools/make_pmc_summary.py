@@ -35,10 +35,12 @@ def orb_section(d, noise):
     s = json.load(open(os.path.join(d, "summary.json")))
     h, r = s["hamming_nn"], s["select_ransac"]
     pairs = pairs_of(d)
+    piped = any("hamming_mfma_pipe_kernel" in k for k in h.get("instances", {}))   # mode 3 (the default since round 4)
     return {
         "pairs_per_batch": pairs, "depth_noise": noise,
         "hamming": {
-            "hamming_mode": 1, "pairs_per_batch": pairs, "kernel": "hamming_mfma_kernel",
+            "hamming_mode": 3 if piped else 1, "pairs_per_batch": pairs,
+            "kernel": "hamming_mfma_pipe_kernel" if piped else "hamming_mfma_kernel",
             "valu_wave_instructions_per_batch": h.get("SQ_INSTS_VALU_avg"),
             "mfma_instructions_per_batch": h.get("SQ_INSTS_MFMA_avg"),
             "mfma_busy_cycles_per_batch": h.get("SQ_VALU_MFMA_BUSY_CYCLES_avg"),

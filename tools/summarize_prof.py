@@ -25,7 +25,7 @@ def short(name):
     if ("replay_walk_kernel" in name or "pair_prep_kernel" in name or "ransac_hyp_kernel" in name or
             "ransac_refine_kernel" in name):  # parts of the select+RANSAC stage of a batch
         return "select_ransac"
-    if "hamming_mfma_kernel" in name:
+    if "hamming_mfma_kernel" in name or "hamming_mfma_pipe_kernel" in name:
         return "hamming_nn"
     if "sift_top2_fast" in name or "sift_row_top2_kernel" in name or "sift_top2_onepass" in name:  # the dot-product stage (one or two passes)
         return "sift_dot"
@@ -50,7 +50,7 @@ for f in find("trace/**/*kernel_stats.csv"):
             e["calls"] = e.get("calls", 0) + int(row["Calls"])
             e["total_ns"] = e.get("total_ns", 0.0) + float(row["TotalDurationNs"])
             e["pct"] = e.get("pct", 0.0) + float(row["Percentage"])
-            e.setdefault("instances", {})[re.sub(r"\(.*", "", row["Name"]).replace("void rgbdfe::", "")] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
+            e.setdefault("instances", {})[re.sub(r"\(.*", "", row["Name"].replace("(anonymous namespace)::", "")).replace("void rgbdfe::", "")] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
     print("kernel stats:", f)
 for k, e in summary.items():
     if "calls" in e:
