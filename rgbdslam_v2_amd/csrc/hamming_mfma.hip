@@ -286,6 +286,12 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
 //     2^22, which no real key reaches (real keys are < 1024).
 // Keys are those of the other kernels, bit for bit (tests/test_gpu_hamming.py runs all four).
 // ------------------------------------------------------------------------------------------------
+#ifndef RGBDFE_HAMMING_PIPE_BURST
+#define RGBDFE_HAMMING_PIPE_BURST 0
+#endif
+#ifndef RGBDFE_HAMMING_PIPE_ALT4
+#define RGBDFE_HAMMING_PIPE_ALT4 0
+#endif
 #ifndef RGBDFE_HAMMING_PIPE_WAVES
 #define RGBDFE_HAMMING_PIPE_WAVES 3          // waves per SIMD the register allocation aims at (48 KB of LDS: three blocks per CU)
 #endif
@@ -426,6 +432,15 @@ void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
     asm volatile("" : "+v"(BEST));   /* the reduction is finished HERE, not merged into a later one */
 #endif
     // one unit: four MFMAs with the previous unit's reduction (10 VALU) and two LDS reads in their gaps
+#if RGBDFE_HAMMING_PIPE_BURST   /* diagnostics: the chain back to back, everything else behind it */
+#define HP_UNIT_SCHED() HP_SGB(0x008, 4) HP_SGB(0x100, 2) HP_SGB(0x002, 12)
+#else
+#define HP_UNIT_SCHED()                                                                             \
+    HP_SGB(0x008, 1) HP_SGB(0x100, 2)                                                               \
+    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS / 100)                            \
+    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS / 10 % 10)                        \
+    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS % 10)
+#endif
 #define HP_UNIT(ACC, A, Q, C, PACC, PBEST, PBASE, R0, R1)                                           \
     HP_MFMA(ACC, A[0], bq[Q][0], C)                                                                 \
     R0 R1                                                                                           \
@@ -433,10 +448,7 @@ void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
     HP_EPI(PACC, PBEST, PBASE)                                                                      \
     HP_MFMA(ACC, A[2], bq[Q][2], ACC)                                                               \
     HP_MFMA(ACC, A[3], bq[Q][3], ACC)                                                               \
-    HP_SGB(0x008, 1) HP_SGB(0x100, 2)                                                               \
-    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS / 100)                            \
-    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS / 10 % 10)                        \
-    HP_SGB(0x008, 1) HP_SGB(0x002, RGBDFE_HAMMING_PIPE_VALU_GROUPS % 10)                             \
+    HP_UNIT_SCHED()                                                                                 \
     HP_FENCE()
     // A stage out of buffer CUR in two halves; the barrier between them publishes the NEXT stage (this wave's
     // global_load_lds of it was issued a whole stage ago) and frees the buffer of the PREVIOUS one for the stage after the
@@ -450,6 +462,49 @@ void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
 #define HP_TURN() __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
 #define HP_LOADS true
 #endif
+#if RGBDFE_HAMMING_PIPE_ALT4
+    // Diagnostics (2 waves per SIMD: four accumulators): a unit is a whole train tile, the chains of the two query tiles
+    // ALTERNATE (no instruction ever sits between two MFMAs on the same accumulator without an MFMA on another one), the
+    // previous tile's two reductions fill the gaps.
+#define HP_TILE(X0, X1, A, C, P0, P1, PBASE, R0, R1, R2, R3)                                         \
+    HP_MFMA(X0, A[0], bq[0][0], C) HP_MFMA(X1, A[0], bq[1][0], C)                                    \
+    R0 R1 R2 R3                                                                                      \
+    HP_MFMA(X0, A[1], bq[0][1], X0) HP_MFMA(X1, A[1], bq[1][1], X1)                                  \
+    HP_EPI(P0, best0, PBASE)                                                                         \
+    HP_MFMA(X0, A[2], bq[0][2], X0) HP_MFMA(X1, A[2], bq[1][2], X1)                                  \
+    HP_EPI(P1, best1, PBASE)                                                                         \
+    HP_MFMA(X0, A[3], bq[0][3], X0) HP_MFMA(X1, A[3], bq[1][3], X1)                                  \
+    HP_SGB(0x008, 1) HP_SGB(0x100, 1) HP_SGB(0x008, 1) HP_SGB(0x100, 1)                              \
+    HP_SGB(0x008, 1) HP_SGB(0x100, 1) HP_SGB(0x002, 2) HP_SGB(0x008, 1) HP_SGB(0x100, 1) HP_SGB(0x002, 3) \
+    HP_SGB(0x008, 1) HP_SGB(0x002, 4) HP_SGB(0x008, 1) HP_SGB(0x002, 4)                              \
+    HP_SGB(0x008, 1) HP_SGB(0x002, 4) HP_SGB(0x008, 1) HP_SGB(0x002, 4)                              \
+    HP_FENCE()
+#define HP_HALF_A(CUR)                                                                                               \
+    {                                                                                                                \
+      b0 = HP_BASE(0); b1 = HP_BASE(1);                                                                              \
+      HP_FENCE()                                                                                                     \
+      HP_TILE(acc0, acc1, aA, crow, acc2, acc3, pend, HP_READ(aB, CUR, 1, 0), HP_READ(aB, CUR, 1, 1),                \
+              HP_READ(aB, CUR, 1, 2), HP_READ(aB, CUR, 1, 3))                                                        \
+      HP_TILE(acc2, acc3, aB, crow, acc0, acc1, b0, HP_READ(aA, CUR, 2, 0), HP_READ(aA, CUR, 2, 1),                  \
+              HP_READ(aA, CUR, 2, 2), HP_READ(aA, CUR, 2, 3))                                                        \
+      HP_TURN()                                                                                                      \
+    }
+#define HP_HALF_B(CUR, NXT, NN)                                                                                      \
+    {                                                                                                                \
+      if (HP_LOADS && st + 2u < n_stages) load_stage(st + 2u, lds##NN);                                              \
+      const float b2 = HP_BASE(2), b3 = HP_BASE(3);                                                                  \
+      if (has_ragged && st + 1u == n_stages) {                                                                       \
+        set_c3_ragged();                                                                                             \
+        asm volatile("" : "+v"(c3));                                                                                 \
+      }                                                                                                              \
+      HP_FENCE()                                                                                                     \
+      HP_TILE(acc0, acc1, aA, crow, acc2, acc3, b1, HP_READ(aB, CUR, 3, 0), HP_READ(aB, CUR, 3, 1),                  \
+              HP_READ(aB, CUR, 3, 2), HP_READ(aB, CUR, 3, 3))                                                        \
+      HP_TILE(acc2, acc3, aB, c3, acc0, acc1, b2, HP_READ(aA, NXT, 0, 0), HP_READ(aA, NXT, 0, 1),                    \
+              HP_READ(aA, NXT, 0, 2), HP_READ(aA, NXT, 0, 3))                                                        \
+      pend = b3;                                                                                                     \
+    }
+#else
 #define HP_HALF_A(CUR)                                                                                               \
     {                                                                                                                \
       b0 = HP_BASE(0); b1 = HP_BASE(1);                                                                              \
@@ -476,8 +531,13 @@ void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
       pend = b3;                                                                                                     \
     }
 
+#endif
     HP_READ(aA, 0, 0, 0) HP_READ(aA, 0, 0, 1) HP_READ(aA, 0, 0, 2) HP_READ(aA, 0, 0, 3)
+#if RGBDFE_HAMMING_PIPE_ALT4
+    v16f acc0, acc1, acc2 = crow, acc3 = crow;
+#else
     v16f acc0, acc1 = crow;
+#endif
     float pend = 4.0e6f;  // acc1 = the row terms (>= 256), + 4e6: a phantom for the first unit's reduction slot
     float b0, b1;
     uint32_t st = 0;
@@ -493,7 +553,12 @@ void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
       if (++st == n_stages) break;
       HP_HALF_A(0)
     }
+#if RGBDFE_HAMMING_PIPE_ALT4
+    HP_EPI(acc2, best0, pend)
+    HP_EPI(acc3, best1, pend)
+#else
     HP_EPI(acc1, best1, pend)
+#endif
 #undef HP_HALF_A
 #undef HP_HALF_B
 #undef HP_TURN

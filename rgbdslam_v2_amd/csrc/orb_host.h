@@ -117,6 +117,10 @@ struct OrbWorkspace {
   TileUnit* d_units = nullptr;  // workgroup lists: FAST tiles | blur tiles | cell-image rows | resize tiles per level
   int units_fast_off = 0, units_fast_n = 0, units_blur_off = 0, units_blur_n = 0, units_rows_off = 0, units_rows_n = 0;
   int units_resize_off[8] = {}, units_resize_n[8] = {};
+  // the fused pyramid kernel's workgroups (orb_internal.h PyrTile) and its LDS plan; RGBDFE_ORB_PYRAMID=levels: one launch
+  // per level instead (orb_resize_kernel)
+  PyrTile* d_pyr_tiles = nullptr; int n_pyr_tiles = 0; PyrPlan pyr_plan{}; bool fused_pyramid = true;
+  int plan_pyramid(std::vector<PyrTile>& tiles, std::string& err);
   uint64_t* d_keep = nullptr;  // NMS survivors, one bit per pixel of every (cell, level) image
   int* d_row_cnt = nullptr; int* d_row_off = nullptr; int* d_img_total = nullptr;  // d_img_total and d_kps live inside d_passout
   uint8_t* d_passout = nullptr; uint8_t* h_passout = nullptr; size_t passout_hdr = 0;  // [per-image counts | keypoints]

@@ -139,7 +139,7 @@ void OrbWorkspace::release() {
   for (int i = 0; i < 2; ++i)
     if (himg_set[i]) { (void)hipHostFree(himg_set[i]); himg_set[i] = nullptr; }
   d_pool = nullptr; d_blur = nullptr; h_img = nullptr;
-  fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_units);
+  fr(d_score); fr(d_cell_imgs); fr(d_frame_imgs); fr(d_jobs); fr(d_units); fr(d_pyr_tiles);
   fr(d_row_cnt); fr(d_row_off); fr(d_keep); fr(d_passout); fr(d_desckp); fr(d_desc); fr(d_kpxy);
   d_img_total = nullptr; d_kps = nullptr;  // live inside d_passout
   fr(d_kept); fr(d_xyz); fr(d_n); fr(d_n_proj);
@@ -331,7 +331,78 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
   ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));   // (synchronous: pageable source)
+  {
+    const char* pm = getenv("RGBDFE_ORB_PYRAMID");
+    fused_pyramid = !(pm && std::string(pm) == "levels");
+    std::vector<PyrTile> tiles;
+    if (fused_pyramid) {
+      const int rc = plan_pyramid(tiles, err);
+      if (rc != RGBDFE_OK) return rc;
+    }
+    n_pyr_tiles = (int)tiles.size();
+    if (n_pyr_tiles) {
+      ORB_HIP(hipMalloc((void**)&d_pyr_tiles, sizeof(PyrTile) * tiles.size()));
+      ORB_HIP(hipMemcpy(d_pyr_tiles, tiles.data(), sizeof(PyrTile) * tiles.size(), hipMemcpyHostToDevice));
+    }
+  }
   if (!pattern_uploaded) { orb_upload_pattern(kOrbBitPattern31); pattern_uploaded = true; }
+  return RGBDFE_OK;
+}
+
+// The workgroups of orb_pyramid_kernel.  A chain (the levels of one cell's gray image, of its mask, or of a frame) is cut
+// into gx x gy tiles; tile (i, j) OWNS columns [i w_l / gx, (i + 1) w_l / gx) and the rows alike of every level l, and
+// COMPUTES at level l the bounding box of what it owns and of the source pixels of what it computes at level l + 1
+// (resize_tap_x / resize_tap_y: the taps the kernel will read).  LDS holds two consecutive levels of a tile.
+int OrbWorkspace::plan_pyramid(std::vector<PyrTile>& tiles, std::string& err) {
+  const int n_chains = level_job_begin[2] - level_job_begin[1];
+  PyrPlan plan{};
+  for (int l = 0; l < kLevels; ++l) plan.level_job_begin[l] = level_job_begin[l];
+  int buf[2] = {0, 0}, max_rw = 0, max_rh = 0;
+  for (int c = 0; c < n_chains; ++c) {
+    const ResizeJob& j1 = jobs[(size_t)level_job_begin[1] + c];
+    const int gx = std::max(1, (j1.dw + 127) / 128), gy = std::max(1, (j1.dh + 95) / 96);
+    for (int ty = 0; ty < gy; ++ty)
+      for (int tx = 0; tx < gx; ++tx) {
+        PyrTile t{};
+        t.chain = (uint16_t)c;
+        int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;   // what the level below the current one has to provide
+        for (int l = kLevels - 1; l >= 1; --l) {
+          const ResizeJob& j = jobs[(size_t)level_job_begin[l] + c];
+          const int ox0 = tx * j.dw / gx, ox1 = (tx + 1) * j.dw / gx, oy0 = ty * j.dh / gy, oy1 = (ty + 1) * j.dh / gy;
+          const bool owns = ox1 > ox0 && oy1 > oy0, needed = nx1 > nx0 && ny1 > ny0;
+          int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+          if (owns && needed) { x0 = std::min(ox0, nx0); x1 = std::max(ox1, nx1); y0 = std::min(oy0, ny0); y1 = std::max(oy1, ny1); }
+          else if (owns) { x0 = ox0; x1 = ox1; y0 = oy0; y1 = oy1; }
+          else if (needed) { x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1; }
+          if (x1 > j.dw || y1 > j.dh) { err = "pyramid plan: a region leaves its level"; return RGBDFE_ERR_INTERNAL; }
+          t.nx0[l] = (uint16_t)x0; t.nx1[l] = (uint16_t)x1; t.ny0[l] = (uint16_t)y0; t.ny1[l] = (uint16_t)y1;
+          t.ox0[l] = (uint16_t)(owns ? ox0 : 0); t.ox1[l] = (uint16_t)(owns ? ox1 : 0);
+          t.oy0[l] = (uint16_t)(owns ? oy0 : 0); t.oy1[l] = (uint16_t)(owns ? oy1 : 0);
+          if (x1 > x0 && y1 > y0) {
+            // the source pixels of the region (taps are monotone in the destination coordinate)
+            nx0 = resize_tap_x(x0, j.scale_x, j.sw).s0; nx1 = resize_tap_x(x1 - 1, j.scale_x, j.sw).s1 + 1;
+            ny0 = resize_tap_y(y0, j.scale_y, j.sh).r0; ny1 = resize_tap_y(y1 - 1, j.scale_y, j.sh).r1 + 1;
+            const int bytes = ((x1 - x0) * (y1 - y0) + 15) & ~15;
+            buf[(l - 1) & 1] = std::max(buf[(l - 1) & 1], bytes);
+            max_rw = std::max(max_rw, x1 - x0); max_rh = std::max(max_rh, y1 - y0);
+          } else {
+            nx0 = nx1 = ny0 = ny1 = 0;
+          }
+        }
+        // a tile that computes nothing at level 1 computes nothing at all (the kernel stops at the first empty level)
+        bool any = false, gap = false;
+        for (int l = 1; l < kLevels; ++l) {
+          const bool e = !(t.nx1[l] > t.nx0[l] && t.ny1[l] > t.ny0[l]);
+          if (e) any = true; else if (any) gap = true;
+        }
+        if (gap) { err = "pyramid plan: an empty level above a non-empty one"; return RGBDFE_ERR_INTERNAL; }
+        if (t.nx1[1] > t.nx0[1] && t.ny1[1] > t.ny0[1]) tiles.push_back(t);
+      }
+  }
+  plan.buf_bytes[0] = buf[0]; plan.buf_bytes[1] = buf[1];
+  plan.max_rw = max_rw; plan.max_rh = max_rh;
+  if ((size_t)buf[0] + buf[1] + 8u * (size_t)(max_rw + max_rh) > 64u * 1024u) { err = "pyramid plan: LDS"; return RGBDFE_ERR_INTERNAL; }
+  pyr_plan = plan;
   return RGBDFE_OK;
 }
 
@@ -358,6 +429,10 @@ void OrbWorkspace::use_set(int set) {
 // host-side coefficient tables (cv::resize's xofs / alpha / yofs / beta) instead of the per-pixel double arithmetic:
 // 6.4 us per launch.  A level's launch is a chain of dependent memory round trips, not arithmetic; both were dropped.
 void OrbWorkspace::build_pyramids(uint8_t* pool, hipStream_t s) {
+  if (fused_pyramid) {  // round 4: every level of every chain in one launch (orb_pyramid_kernel)
+    launch_orb_pyramid(pool, d_jobs, d_pyr_tiles, n_pyr_tiles, pyr_plan, s);
+    return;
+  }
   for (int l = 1; l < kLevels; ++l) {
     launch_orb_resize(pool, d_jobs + level_job_begin[l], d_units + units_resize_off[l], units_resize_n[l], s);
   }

@@ -54,7 +54,56 @@ struct TileUnit {
   uint16_t img, bx, by, pad;
 };
 
+// One workgroup of the fused pyramid kernel: a tile of ONE chain of images (a cell's gray levels, a cell's mask levels or a
+// frame's gray levels) followed through levels 1..7.  n*: the region of level l the workgroup COMPUTES (into LDS: what it owns
+// plus what its regions of the deeper levels read), o*: the part of it the workgroup STORES (the tiles of a chain partition
+// every level).  Index 0 is unused (level 0 is the uploaded image).
+struct PyrTile {
+  uint16_t chain, pad;
+  uint16_t nx0[8], nx1[8], ny0[8], ny1[8];
+  uint16_t ox0[8], ox1[8], oy0[8], oy1[8];
+};
+struct PyrPlan {
+  int32_t level_job_begin[8];   // jobs[level_job_begin[l] + chain]: the resize of the chain's level l - 1 into level l
+  int32_t buf_bytes[2];         // LDS: regions of the odd / even levels
+  int32_t max_rw, max_rh;       // LDS: coefficient tables (8 bytes per column / row of a region)
+};
+
 void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, const TileUnit* units, int n_units, hipStream_t s);
+void launch_orb_pyramid(uint8_t* pool, const ResizeJob* jobs, const PyrTile* tiles, int n_tiles, const PyrPlan& plan,
+                        hipStream_t s);
+// cv::resize's horizontal / vertical taps of destination column / row d (host and device: the fused kernel's regions are
+// planned on the host with the arithmetic the kernels use)
+struct ResizeTapX { int s0, s1, w0, w1; };
+struct ResizeTapY { int r0, r1, b0, b1; };
+__host__ __device__ inline int resize_coef(float f) {
+  const int v = (int)rintf(f * 2048.f);
+  return v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+}
+__host__ __device__ inline ResizeTapX resize_tap_x(int dx, double scale_x, int sw) {
+  float fx = (float)((dx + 0.5) * scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= sx;
+  if (sx < 0) { fx = 0; sx = 0; }
+  const bool edge = (sx + 1 >= sw);   // at the right edge the second tap is not read: weights 2048 / 0 there
+  if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+  ResizeTapX t;
+  t.s0 = sx; t.s1 = edge ? sx : sx + 1;
+  t.w0 = edge ? 2048 : resize_coef(1.f - fx);
+  t.w1 = edge ? 0 : resize_coef(fx);
+  return t;
+}
+__host__ __device__ inline ResizeTapY resize_tap_y(int dy, double scale_y, int sh) {
+  float fy = (float)((dy + 0.5) * scale_y - 0.5);
+  int sy = (int)floorf(fy);
+  fy -= sy;
+  ResizeTapY t;
+  t.b0 = resize_coef(1.f - fy);
+  t.b1 = resize_coef(fy);
+  t.r0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+  t.r1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+  return t;
+}
 void launch_orb_fast_nms(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* units, int n_units,
                          const OrbCtl& ctl, uint8_t* score_pool, int edge, int* row_cnt, int* row_off, int* img_total,
                          uint64_t* keep_mask, hipStream_t s);

@@ -73,6 +73,81 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
+// The seven resize steps of every image chain of a step in ONE launch (round 4, VERDICT r3 #5a).  A level is the bilinear
+// resize of the level below it, so seven launches form a chain of dependent round trips through memory (a quarter of the
+// kernel time of a super-frame).  Here a workgroup follows ONE tile of one chain through all seven levels: level l of the
+// tile is computed from level l - 1 held in LDS (level 1 from the uploaded image), stored to the pool where the tile owns
+// it, and kept in LDS -- with the rim the deeper levels of the tile read, which neighbouring workgroups compute again
+// (a pixel of level l is the same integer expression of the same four pixels of level l - 1 wherever it is evaluated).
+// The regions are planned on the host (OrbWorkspace::plan_pyramid) with resize_tap_x / resize_tap_y, the functions the
+// coefficient tables below are filled with: per region one table entry per column and per row instead of the double
+// arithmetic per pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
+                                                          const PyrTile* __restrict__ tiles, const PyrPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
+  uint8_t* const buf[2] = {pyr_lds, pyr_lds + plan.buf_bytes[0]};   // level l lives in buf[(l - 1) & 1]
+  ushort4* const xtab = reinterpret_cast<ushort4*>(pyr_lds + plan.buf_bytes[0] + plan.buf_bytes[1]);
+  ushort4* const ytab = xtab + plan.max_rw;
+  const PyrTile* __restrict__ tl = tiles + blockIdx.x;
+  const int chain = tl->chain;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  int px0 = 0, py0 = 0, prw = 0;   // the region of the level below, as it lies in LDS
+  for (int l = 1; l < 8; ++l) {
+    const int x0 = tl->nx0[l], x1 = tl->nx1[l], y0 = tl->ny0[l], y1 = tl->ny1[l];
+    const int rw = x1 - x0, rh = y1 - y0;
+    if (rw <= 0 || rh <= 0) break;   // (block-uniform; a tile without pixels at level l has none below it either)
+    const ResizeJob j = jobs[plan.level_job_begin[l] + chain];
+    // taps and weights of the region's columns and rows; source coordinates relative to the level below as it lies in LDS
+    // (level 1: absolute, the source is the uploaded image)
+    for (int i = tid; i < rw + rh; i += 256) {
+      if (i < rw) {
+        const ResizeTapX t = resize_tap_x(x0 + i, j.scale_x, j.sw);
+        xtab[i] = make_ushort4((unsigned short)(t.s0 - px0), (unsigned short)(t.s1 - px0), (unsigned short)t.w0,
+                               (unsigned short)t.w1);
+      } else {
+        const ResizeTapY t = resize_tap_y(y0 + (i - rw), j.scale_y, j.sh);
+        ytab[i - rw] = make_ushort4((unsigned short)(t.r0 - py0), (unsigned short)(t.r1 - py0), (unsigned short)t.b0,
+                                    (unsigned short)t.b1);
+      }
+    }
+    __syncthreads();
+    uint8_t* __restrict__ cur = buf[(l - 1) & 1];
+    const uint8_t* __restrict__ prev = buf[l & 1];
+    const uint8_t* __restrict__ src0 = pool + j.src_off;
+    const int ox0 = tl->ox0[l], ox1 = tl->ox1[l], oy0 = tl->oy0[l], oy1 = tl->oy1[l];
+    uint8_t* __restrict__ dst = pool + j.dst_off;
+    for (int x = tx; x < rw; x += 64) {
+      const ushort4 cx = xtab[x];
+      const int w0 = (short)cx.z, w1 = (short)cx.w;
+      const bool own_x = x0 + x >= ox0 && x0 + x < ox1;
+      for (int y = ty; y < rh; y += 4) {
+        const ushort4 cy = ytab[y];
+        int p00, p01, p10, p11;
+        if (l == 1) {
+          const uint8_t* r0 = src0 + (size_t)cy.x * j.sstride;
+          const uint8_t* r1 = src0 + (size_t)cy.y * j.sstride;
+          p00 = r0[cx.x]; p01 = r0[cx.y]; p10 = r1[cx.x]; p11 = r1[cx.y];
+        } else {
+          const uint8_t* r0 = prev + cy.x * prw;
+          const uint8_t* r1 = prev + cy.y * prw;
+          p00 = r0[cx.x]; p01 = r0[cx.y]; p10 = r1[cx.x]; p11 = r1[cx.y];
+        }
+        const int h0 = p00 * w0 + p01 * w1;
+        const int h1 = p10 * w0 + p11 * w1;
+        int v = ((((int)(short)cy.z * (h0 >> 4)) >> 16) + (((int)(short)cy.w * (h1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        if (j.is_mask && v <= 254) v = 0;
+        cur[y * rw + x] = (uint8_t)v;
+        if (own_x && y0 + y >= oy0 && y0 + y < oy1) dst[(size_t)(y0 + y) * j.dw + (x0 + x)] = (uint8_t)v;
+      }
+    }
+    px0 = x0; py0 = y0; prw = rw;
+    __syncthreads();   // the level is complete in LDS; the tables may be overwritten
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // cv::FAST TYPE_9_16 corner test + cornerScore<16> + 3x3 non-maximum suppression for every pixel of every image of the
 // launch, one kernel.
 //
@@ -486,6 +561,12 @@ __global__ __launch_bounds__(256) void orb_brief_kernel(const uint8_t* __restric
 void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, const TileUnit* units, int n_units, hipStream_t s) {
   if (n_units == 0) return;
   hipLaunchKernelGGL(orb_resize_kernel, dim3(n_units), dim3(256), 0, s, pool, jobs, units);
+}
+void launch_orb_pyramid(uint8_t* pool, const ResizeJob* jobs, const PyrTile* tiles, int n_tiles, const PyrPlan& plan,
+                        hipStream_t s) {
+  if (n_tiles == 0) return;
+  const size_t lds = (size_t)plan.buf_bytes[0] + plan.buf_bytes[1] + sizeof(ushort4) * (size_t)(plan.max_rw + plan.max_rh);
+  hipLaunchKernelGGL(orb_pyramid_kernel, dim3(n_tiles), dim3(256), lds, s, pool, jobs, tiles, plan);
 }
 // FAST-9/16 scores + 3x3 NMS + mask + border filters (keep bits, per-row counts), then the per-image scan of the row counts
 void launch_orb_fast_nms(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* units, int n_units,

@@ -7,11 +7,11 @@ build() {  # name, extra flags
   OBJS=$(ls *.o | grep -v "^hamming_mfma.o$" | grep -v prof | grep -v _wd | tr '\n' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librgbdfe_hp_$1.so $OBJS /tmp/hp_$1.o
 }
-build v334 "-DRGBDFE_HAMMING_PIPE_VALU_GROUPS=334"
-# timing-only builds (keys forced to "no match"): what the stream costs without its reductions / LDS reads / loads + barriers
+build w2 "-DRGBDFE_HAMMING_PIPE_WAVES=2"
+build burst "-DRGBDFE_HAMMING_PIPE_BURST=1"
+build alt4 "-DRGBDFE_HAMMING_PIPE_ALT4=1 -DRGBDFE_HAMMING_PIPE_WAVES=2"
+# timing-only builds (keys forced to "no match"): what the stream costs without its reductions / loads + barriers
 build d1 "-DRGBDFE_HAMMING_PIPE_DIAG=1"
-build d2 "-DRGBDFE_HAMMING_PIPE_DIAG=2"
-build d3 "-DRGBDFE_HAMMING_PIPE_DIAG=3"
-build d7 "-DRGBDFE_HAMMING_PIPE_DIAG=7"
 build d4 "-DRGBDFE_HAMMING_PIPE_DIAG=4"
+build alt4d1 "-DRGBDFE_HAMMING_PIPE_ALT4=1 -DRGBDFE_HAMMING_PIPE_WAVES=2 -DRGBDFE_HAMMING_PIPE_DIAG=1"
 ls -la ../librgbdfe_hp_*.so
