@@ -383,11 +383,18 @@ int OrbWorkspace::plan_pyramid(std::vector<PyrTile>& tiles, std::string& err) {
             nx0 = resize_tap_x(x0, j.scale_x, j.sw).s0; nx1 = resize_tap_x(x1 - 1, j.scale_x, j.sw).s1 + 1;
             ny0 = resize_tap_y(y0, j.scale_y, j.sh).r0; ny1 = resize_tap_y(y1 - 1, j.scale_y, j.sh).r1 + 1;
             const int bytes = ((x1 - x0) * (y1 - y0) + 15) & ~15;
-            buf[(l - 1) & 1] = std::max(buf[(l - 1) & 1], bytes);
+            buf[(l + 1) & 1] = std::max(buf[(l + 1) & 1], bytes);
             max_rw = std::max(max_rw, x1 - x0); max_rh = std::max(max_rh, y1 - y0);
           } else {
             nx0 = nx1 = ny0 = ny1 = 0;
           }
+        }
+        // level 0: the part of the uploaded image the tile's level 1 reads, from a multiple of four columns on (the kernel
+        // copies it to LDS in dwords); it shares the LDS buffer of the even levels
+        if (nx1 > nx0 && ny1 > ny0) {
+          nx0 &= ~3;
+          t.nx0[0] = (uint16_t)nx0; t.nx1[0] = (uint16_t)nx1; t.ny0[0] = (uint16_t)ny0; t.ny1[0] = (uint16_t)ny1;
+          buf[1] = std::max(buf[1], (((nx1 - nx0 + 3) & ~3) * (ny1 - ny0) + 15) & ~15);
         }
         // a tile that computes nothing at level 1 computes nothing at all (the kernel stops at the first empty level)
         bool any = false, gap = false;

@@ -19,6 +19,8 @@
 
 namespace rgbdfe {
 
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   if (len == 1) return 0;
   while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
 // The seven resize steps of every image chain of a step in ONE launch (round 4, VERDICT r3 #5a).  A level is the bilinear
 // resize of the level below it, so seven launches form a chain of dependent round trips through memory (a quarter of the
 // kernel time of a super-frame).  Here a workgroup follows ONE tile of one chain through all seven levels: level l of the
-// tile is computed from level l - 1 held in LDS (level 1 from the uploaded image), stored to the pool where the tile owns
+// tile is computed from level l - 1 held in LDS (the tile's part of the uploaded image is copied there first, whole dwords,
+// every load in flight at once), stored to the pool where the tile owns
 // it, and kept in LDS -- with the rim the deeper levels of the tile read, which neighbouring workgroups compute again
 // (a pixel of level l is the same integer expression of the same four pixels of level l - 1 wherever it is evaluated).
 // The regions are planned on the host (OrbWorkspace::plan_pyramid) with resize_tap_x / resize_tap_y, the functions the
@@ -86,20 +89,31 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
 __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
                                                           const PyrTile* __restrict__ tiles, const PyrPlan plan) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
-  uint8_t* const buf[2] = {pyr_lds, pyr_lds + plan.buf_bytes[0]};   // level l lives in buf[(l - 1) & 1]
+  uint8_t* const buf[2] = {pyr_lds, pyr_lds + plan.buf_bytes[0]};   // level l lives in buf[(l + 1) & 1]
   ushort4* const xtab = reinterpret_cast<ushort4*>(pyr_lds + plan.buf_bytes[0] + plan.buf_bytes[1]);
   ushort4* const ytab = xtab + plan.max_rw;
   const PyrTile* __restrict__ tl = tiles + blockIdx.x;
   const int chain = tl->chain;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  int px0 = 0, py0 = 0, prw = 0;   // the region of the level below, as it lies in LDS
+  // the tile's part of the uploaded image -> LDS, whole dwords (the region starts at a multiple of four columns of the
+  // image and its LDS rows are a multiple of four bytes long; the last dword of a row may reach past the region: the pool
+  // has slack behind its last image)
+  int px0 = tl->nx0[0], py0 = tl->ny0[0], prw = (tl->nx1[0] - tl->nx0[0] + 3) & ~3;   // the level below, as it lies in LDS
+  {
+    const ResizeJob j = jobs[plan.level_job_begin[1] + chain];
+    const uint8_t* __restrict__ src = pool + j.src_off + (size_t)py0 * j.sstride + px0;
+    const int dwords = prw >> 2, rows = tl->ny1[0] - py0;
+    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(buf[1]);
+    for (int r = ty; r < rows; r += 4)
+      for (int d = tx; d < dwords; d += 64)
+        dst[r * dwords + d] = *reinterpret_cast<const u32_unaligned*>(src + (size_t)r * j.sstride + 4 * d);
+  }
   for (int l = 1; l < 8; ++l) {
     const int x0 = tl->nx0[l], x1 = tl->nx1[l], y0 = tl->ny0[l], y1 = tl->ny1[l];
     const int rw = x1 - x0, rh = y1 - y0;
     if (rw <= 0 || rh <= 0) break;   // (block-uniform; a tile without pixels at level l has none below it either)
     const ResizeJob j = jobs[plan.level_job_begin[l] + chain];
     // taps and weights of the region's columns and rows; source coordinates relative to the level below as it lies in LDS
-    // (level 1: absolute, the source is the uploaded image)
     for (int i = tid; i < rw + rh; i += 256) {
       if (i < rw) {
         const ResizeTapX t = resize_tap_x(x0 + i, j.scale_x, j.sw);
@@ -107,37 +121,30 @@ __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ 
                                (unsigned short)t.w1);
       } else {
         const ResizeTapY t = resize_tap_y(y0 + (i - rw), j.scale_y, j.sh);
-        ytab[i - rw] = make_ushort4((unsigned short)(t.r0 - py0), (unsigned short)(t.r1 - py0), (unsigned short)t.b0,
-                                    (unsigned short)t.b1);
+        ytab[i - rw] = make_ushort4((unsigned short)((t.r0 - py0) * prw), (unsigned short)((t.r1 - py0) * prw),
+                                    (unsigned short)t.b0, (unsigned short)t.b1);
       }
     }
-    __syncthreads();
-    uint8_t* __restrict__ cur = buf[(l - 1) & 1];
+    __syncthreads();   // the level below and the tables are complete
+    uint8_t* __restrict__ cur = buf[(l + 1) & 1];
     const uint8_t* __restrict__ prev = buf[l & 1];
-    const uint8_t* __restrict__ src0 = pool + j.src_off;
     const int ox0 = tl->ox0[l], ox1 = tl->ox1[l], oy0 = tl->oy0[l], oy1 = tl->oy1[l];
     uint8_t* __restrict__ dst = pool + j.dst_off;
+    const bool is_mask = j.is_mask != 0;
     for (int x = tx; x < rw; x += 64) {
       const ushort4 cx = xtab[x];
       const int w0 = (short)cx.z, w1 = (short)cx.w;
       const bool own_x = x0 + x >= ox0 && x0 + x < ox1;
+      const uint8_t* __restrict__ c0 = prev + cx.x;
+      const uint8_t* __restrict__ c1 = prev + cx.y;
+#pragma unroll 4
       for (int y = ty; y < rh; y += 4) {
         const ushort4 cy = ytab[y];
-        int p00, p01, p10, p11;
-        if (l == 1) {
-          const uint8_t* r0 = src0 + (size_t)cy.x * j.sstride;
-          const uint8_t* r1 = src0 + (size_t)cy.y * j.sstride;
-          p00 = r0[cx.x]; p01 = r0[cx.y]; p10 = r1[cx.x]; p11 = r1[cx.y];
-        } else {
-          const uint8_t* r0 = prev + cy.x * prw;
-          const uint8_t* r1 = prev + cy.y * prw;
-          p00 = r0[cx.x]; p01 = r0[cx.y]; p10 = r1[cx.x]; p11 = r1[cx.y];
-        }
-        const int h0 = p00 * w0 + p01 * w1;
-        const int h1 = p10 * w0 + p11 * w1;
+        const int h0 = c0[cy.x] * w0 + c1[cy.x] * w1;
+        const int h1 = c0[cy.y] * w0 + c1[cy.y] * w1;
         int v = ((((int)(short)cy.z * (h0 >> 4)) >> 16) + (((int)(short)cy.w * (h1 >> 4)) >> 16) + 2) >> 2;
         v = min(max(v, 0), 255);
-        if (j.is_mask && v <= 254) v = 0;
+        if (is_mask && v <= 254) v = 0;
         cur[y * rw + x] = (uint8_t)v;
         if (own_x && y0 + y >= oy0 && y0 + y < oy1) dst[(size_t)(y0 + y) * j.dw + (x0 + x)] = (uint8_t)v;
       }
@@ -197,7 +204,6 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t* __restrict__ ptr, i
 // buffer, read by the emit stage).  Survivors leave as one bit per pixel (64 pixels per word) plus per-row counts (atomics:
 // an image row can span several tiles; the row scan that consumes the counts zeroes them again).
 constexpr int kFastTW = 64, kFastTH = 16, kFastSrcStride = 76, kFastScStride = 68;
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __global__ __launch_bounds__(256) void orb_fast_nms_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
                                                            const OrbCtl ctl, uint8_t* __restrict__ score_pool, int edge,
                                                            int* __restrict__ row_cnt, uint64_t* __restrict__ keep_mask,
@@ -269,23 +275,35 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(const uint8_t* __rest
 __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                            int* __restrict__ row_cnt, int* __restrict__ row_off,
                                                            int* __restrict__ img_total, int* __restrict__ grand_total) {
-  __shared__ int part[256];
+  __shared__ int wave_total[4];
   const ImgDesc im = imgs[blockIdx.x];
   if (!ctl.active[im.cell]) { if (threadIdx.x == 0) img_total[blockIdx.x] = 0; return; }
   const int per = (im.h + 255) / 256;
   const int r0 = threadIdx.x * per;
   int sum = 0;
   for (int r = r0; r < min(r0 + per, im.h); ++r) sum += row_cnt[im.row_off + r];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int i = 0; i < 256; ++i) { const int t = part[i]; part[i] = acc; acc += t; }
-    img_total[blockIdx.x] = acc;
-    if (acc) atomicAdd(grand_total, acc);   // (zeroed by the FAST launch) the measure waves read one word
+  // exclusive prefix of the 256 partial sums: shuffles inside a wave, four wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
   }
+  if (lane == 63) wave_total[wave] = incl;
   __syncthreads();
-  int acc = part[threadIdx.x];
+  int acc = incl - sum;
+  int total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int t = wave_total[w];
+    if (w < wave) acc += t;
+    total += t;
+  }
+  if (threadIdx.x == 0) {
+    img_total[blockIdx.x] = total;
+    if (total) atomicAdd(grand_total, total);   // (zeroed by the FAST launch) the measure waves read one word
+  }
   for (int r = r0; r < min(r0 + per, im.h); ++r) {
     const int t = row_cnt[im.row_off + r];
     row_off[im.row_off + r] = acc;
@@ -296,11 +314,14 @@ __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __rest
 
 // one wave per image row: write the keypoints of the row at img_base + row_offset + rank (raster order)
 __device__ __forceinline__ int wave_sum(int v);
+// (one-wave workgroups: four rows per 256-thread workgroup was measured and is slower, 44 -> 66 us per step in the same
+// trace -- the kernel's time is the chain rows[] -> imgs[] -> mask words of ~55 000 waves, most of which end there)
 __global__ __launch_bounds__(64) void orb_emit_kernel(const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                       const uint8_t* __restrict__ score_pool,
                                                       const uint64_t* __restrict__ keep_mask,
                                                       const int* __restrict__ row_off, const int* __restrict__ img_total,
                                                       RawKp* __restrict__ out, const TileUnit* __restrict__ rows) {
+  const int lane_id = threadIdx.x;
   const TileUnit u = rows[blockIdx.x];
   const int img = u.img;
   const ImgDesc im = imgs[img];
@@ -310,14 +331,14 @@ __global__ __launch_bounds__(64) void orb_emit_kernel(const ImgDesc* __restrict_
   const uint64_t* __restrict__ km = keep_mask + im.keep_off + (size_t)y * words;
   // a row without keypoints (most rows) costs its mask words only
   uint64_t any = 0;
-  for (int wd = (int)threadIdx.x; wd < words; wd += 64) any |= km[wd];
+  for (int wd = lane_id; wd < words; wd += 64) any |= km[wd];
   if (__ballot(any != 0) == 0) return;
   const uint8_t* sc = score_pool + im.score_off;
   // where this image's keypoints start = the keypoints of the images before it (at most 512 counts: a wave sums them,
   // which is cheaper than a scan launch in front of this kernel)
   int img_base = 0;
   for (int j0 = 0; j0 < img; j0 += 64) {
-    const int j = j0 + (int)threadIdx.x;
+    const int j = j0 + lane_id;
     img_base += j < img ? img_total[j] : 0;
   }
   img_base = wave_sum(img_base);
@@ -325,8 +346,8 @@ __global__ __launch_bounds__(64) void orb_emit_kernel(const ImgDesc* __restrict_
   for (int wd = 0; wd < words; ++wd) {
     const uint64_t m = km[wd];
     if (!m) continue;
-    const int x = wd * 64 + (int)threadIdx.x;
-    if ((m >> threadIdx.x) & 1) {
+    const int x = wd * 64 + lane_id;
+    if ((m >> lane_id) & 1) {
       const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       RawKp k;
       k.x = (uint16_t)x; k.y = (uint16_t)y; k.img = (uint16_t)img; k.score = (uint16_t)sc[(size_t)y * im.w + x];
@@ -367,6 +388,18 @@ __device__ __forceinline__ int wave_sum(int v) {
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+// the sum over the wave as a wave-uniform value, on the DPP path (row shifts by 1, 2, 4, 8: lane 15 of every row of 16 holds
+// its row; row_bcast 15 / 31: lane 63 holds everything): six VALU instructions and one readlane instead of six
+// ds_bpermute round trips
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restr
     const int Iy = (ptr[32] - ptr[-32]) * 2 + (ptr[32 - 1] - ptr[-32 - 1]) + (ptr[32 + 1] - ptr[-32 + 1]);
     a = Ix * Ix; b = Iy * Iy; c = Ix * Iy;
   }
-  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  a = wave_sum_dpp(a); b = wave_sum_dpp(b); c = wave_sum_dpp(c);
   const float scale = 1.f / ((1 << 2) * 7 * 255.f);
   const float scale_sq_sq = scale * scale * scale * scale;
   const float harris = ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
@@ -424,7 +457,7 @@ __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restr
       m01 += v * val;
     }
   }
-  m01 = wave_sum(m01); m10 = wave_sum(m10);
+  m01 = wave_sum_dpp(m01); m10 = wave_sum_dpp(m10);
   if (lane == 0) {
     kp.harris = harris;
     kp.angle = fast_atan2_deg((float)m01, (float)m10);
