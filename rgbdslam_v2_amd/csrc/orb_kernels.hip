@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
                                                           const PyrTile* __restrict__ tiles, const PyrPlan plan) {
+  // (every LDS access below indexes pyr_lds itself with an integer offset: pointers picked from an array of two buffer
+  // pointers made the compiler fall back to flat loads and stores, each with its own wait)
   extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
-  uint8_t* const buf[2] = {pyr_lds, pyr_lds + plan.buf_bytes[0]};   // level l lives in buf[(l + 1) & 1]
-  ushort4* const xtab = reinterpret_cast<ushort4*>(pyr_lds + plan.buf_bytes[0] + plan.buf_bytes[1]);
-  ushort4* const ytab = xtab + plan.max_rw;
+  const int buf_off[2] = {0, plan.buf_bytes[0]};   // level l lives at buf_off[(l + 1) & 1]
+  const int xtab_off = plan.buf_bytes[0] + plan.buf_bytes[1], ytab_off = xtab_off + 8 * plan.max_rw;
   const PyrTile* __restrict__ tl = tiles + blockIdx.x;
   const int chain = tl->chain;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
@@ -103,10 +104,10 @@ __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ 
     const ResizeJob j = jobs[plan.level_job_begin[1] + chain];
     const uint8_t* __restrict__ src = pool + j.src_off + (size_t)py0 * j.sstride + px0;
     const int dwords = prw >> 2, rows = tl->ny1[0] - py0;
-    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(buf[1]);
     for (int r = ty; r < rows; r += 4)
       for (int d = tx; d < dwords; d += 64)
-        dst[r * dwords + d] = *reinterpret_cast<const u32_unaligned*>(src + (size_t)r * j.sstride + 4 * d);
+        *reinterpret_cast<uint32_t*>(&pyr_lds[buf_off[1] + 4 * (r * dwords + d)]) =
+            *reinterpret_cast<const u32_unaligned*>(src + (size_t)r * j.sstride + 4 * d);
   }
   for (int l = 1; l < 8; ++l) {
     const int x0 = tl->nx0[l], x1 = tl->nx1[l], y0 = tl->ny0[l], y1 = tl->ny1[l];
@@ -117,36 +118,47 @@ __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ 
     for (int i = tid; i < rw + rh; i += 256) {
       if (i < rw) {
         const ResizeTapX t = resize_tap_x(x0 + i, j.scale_x, j.sw);
-        xtab[i] = make_ushort4((unsigned short)(t.s0 - px0), (unsigned short)(t.s1 - px0), (unsigned short)t.w0,
-                               (unsigned short)t.w1);
+        *reinterpret_cast<ushort4*>(&pyr_lds[xtab_off + 8 * i]) =
+            make_ushort4((unsigned short)(t.s0 - px0), (unsigned short)(t.s1 - px0), (unsigned short)t.w0, (unsigned short)t.w1);
       } else {
         const ResizeTapY t = resize_tap_y(y0 + (i - rw), j.scale_y, j.sh);
-        ytab[i - rw] = make_ushort4((unsigned short)((t.r0 - py0) * prw), (unsigned short)((t.r1 - py0) * prw),
-                                    (unsigned short)t.b0, (unsigned short)t.b1);
+        *reinterpret_cast<ushort4*>(&pyr_lds[ytab_off + 8 * (i - rw)]) =
+            make_ushort4((unsigned short)((t.r0 - py0) * prw), (unsigned short)((t.r1 - py0) * prw), (unsigned short)t.b0,
+                         (unsigned short)t.b1);
       }
     }
     __syncthreads();   // the level below and the tables are complete
-    uint8_t* __restrict__ cur = buf[(l + 1) & 1];
-    const uint8_t* __restrict__ prev = buf[l & 1];
+    const int cur = buf_off[(l + 1) & 1], prev = buf_off[l & 1];
     const int ox0 = tl->ox0[l], ox1 = tl->ox1[l], oy0 = tl->oy0[l], oy1 = tl->oy1[l];
     uint8_t* __restrict__ dst = pool + j.dst_off;
     const bool is_mask = j.is_mask != 0;
     for (int x = tx; x < rw; x += 64) {
-      const ushort4 cx = xtab[x];
+      const ushort4 cx = *reinterpret_cast<const ushort4*>(&pyr_lds[xtab_off + 8 * x]);
       const int w0 = (short)cx.z, w1 = (short)cx.w;
       const bool own_x = x0 + x >= ox0 && x0 + x < ox1;
-      const uint8_t* __restrict__ c0 = prev + cx.x;
-      const uint8_t* __restrict__ c1 = prev + cx.y;
-#pragma unroll 4
-      for (int y = ty; y < rh; y += 4) {
-        const ushort4 cy = ytab[y];
-        const int h0 = c0[cy.x] * w0 + c1[cy.x] * w1;
-        const int h1 = c0[cy.y] * w0 + c1[cy.y] * w1;
-        int v = ((((int)(short)cy.z * (h0 >> 4)) >> 16) + (((int)(short)cy.w * (h1 >> 4)) >> 16) + 2) >> 2;
-        v = min(max(v, 0), 255);
-        if (is_mask && v <= 254) v = 0;
-        cur[y * rw + x] = (uint8_t)v;
-        if (own_x && y0 + y >= oy0 && y0 + y < oy1) dst[(size_t)(y0 + y) * j.dw + (x0 + x)] = (uint8_t)v;
+      const int c0 = prev + cx.x, c1 = prev + cx.y;
+      // four rows per step: all their taps are read before the first result is formed
+      for (int yb = ty; yb < rh; yb += 16) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int y = min(yb + 4 * u, rh - 1);   // (rows past the region repeat its last row and are not stored)
+          const ushort4 cy = *reinterpret_cast<const ushort4*>(&pyr_lds[ytab_off + 8 * y]);
+          const int h0 = pyr_lds[c0 + cy.x] * w0 + pyr_lds[c1 + cy.x] * w1;
+          const int h1 = pyr_lds[c0 + cy.y] * w0 + pyr_lds[c1 + cy.y] * w1;
+          int t = ((((int)(short)cy.z * (h0 >> 4)) >> 16) + (((int)(short)cy.w * (h1 >> 4)) >> 16) + 2) >> 2;
+          t = min(max(t, 0), 255);
+          if (is_mask && t <= 254) t = 0;
+          v[u] = t;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int y = yb + 4 * u;
+          if (y < rh) {
+            pyr_lds[cur + y * rw + x] = (uint8_t)v[u];
+            if (own_x && y0 + y >= oy0 && y0 + y < oy1) dst[(size_t)(y0 + y) * j.dw + (x0 + x)] = (uint8_t)v[u];
+          }
+        }
       }
     }
     px0 = x0; py0 = y0; prw = rw;
