@@ -216,6 +216,9 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t* __restrict__ ptr, i
 // buffer, read by the emit stage).  Survivors leave as one bit per pixel (64 pixels per word) plus per-row counts (atomics:
 // an image row can span several tiles; the row scan that consumes the counts zeroes them again).
 constexpr int kFastTW = 64, kFastTH = 16, kFastSrcStride = 76, kFastScStride = 68;
+#ifndef RGBDFE_FAST_PRESCREEN
+#define RGBDFE_FAST_PRESCREEN 1   // 0: the arc score for every pixel (rounds 1-3)
+#endif
 __global__ __launch_bounds__(256) void orb_fast_nms_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
                                                            const OrbCtl ctl, uint8_t* __restrict__ score_pool, int edge,
                                                            int* __restrict__ row_cnt, uint64_t* __restrict__ keep_mask,
@@ -223,6 +226,8 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(const uint8_t* __rest
                                                            const TileUnit* __restrict__ units) {
   __shared__ __attribute__((aligned(4))) uint8_t src[(kFastTH + 8) * kFastSrcStride];
   __shared__ uint8_t sc[(kFastTH + 2) * kFastScStride];
+  __shared__ uint16_t cand[(kFastTH + 2) * 66];   // the tile's pixels that pass the four-pixel screen
+  __shared__ int n_cand;
   if (blockIdx.x == 0 && threadIdx.x == 0) *grand_total = 0;   // the row scan (next launch) adds the per-image totals
   const TileUnit u = units[blockIdx.x];
   const ImgDesc im = imgs[u.img];
@@ -240,10 +245,49 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(const uint8_t* __rest
     if (gx >= 0 && gx < im.w) v = *reinterpret_cast<const u32_unaligned*>(img + (size_t)gy * im.stride + gx);
     *reinterpret_cast<uint32_t*>(src + r * kFastSrcStride + 4 * j) = v;
   }
+  if (tid == 0) n_cand = 0;
   __syncthreads();
   int thr = ctl.thr[im.cell];
   thr = min(max(thr, 0), 255);
   uint8_t* __restrict__ score_img = score_pool + im.score_off;
+#if RGBDFE_FAST_PRESCREEN
+  // Round 4: the ~100-operation arc score only for the pixels that can be corners at all.  An arc of 9 of the 16 ring pixels
+  // contains one pixel of every antipodal pair, so "all nine brighter than v + t" needs max(d[k], d[k + 8]) > t for every k
+  // (d = centre - ring), "all nine darker" min(d[k], d[k + 8]) < -t: testing the pairs (0, 8) and (4, 12) -- four ring pixels --
+  // is a NECESSARY condition for a score above the threshold, exact whatever it lets through.  Pixels that pass are queued
+  // in LDS (ballot + one atomic per wave) and scored densely afterwards; everything else scores 0 as before.
+  for (int i0 = 0; i0 < (kFastTH + 2) * 66; i0 += 256) {
+    const int i = i0 + tid;
+    bool pass = false;
+    if (i < (kFastTH + 2) * 66) {
+      const int ty = (i * 993) >> 16, tx = i - ty * 66;   // i / 66 for i < 1188
+      const int x = x0 - 1 + tx, y = y0 - 1 + ty;
+      sc[ty * kFastScStride + tx] = 0;
+      if (x >= 3 && x < im.w - 3 && y >= 3 && y < im.h - 3) {
+        const uint8_t* ptr = src + (ty + 3) * kFastSrcStride + (tx + 3);
+        const int v = ptr[0];
+        const int d0 = v - ptr[3 * kFastSrcStride], d8 = v - ptr[-3 * kFastSrcStride], d4 = v - ptr[3], d12 = v - ptr[-3];
+        pass = (max(d0, d8) > thr && max(d4, d12) > thr) || (min(d0, d8) < -thr && min(d4, d12) < -thr);
+      }
+    }
+    const uint64_t m = __ballot(pass);
+    if (m) {
+      const int lane = tid & 63;
+      int base = 0;
+      if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&n_cand, (int)__popcll(m));
+      base = __shfl(base, (int)__builtin_ctzll(m));
+      if (pass) cand[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < n_cand; q += 256) {
+    const int i = cand[q];
+    const int ty = (i * 993) >> 16, tx = i - ty * 66;
+    const int mm = fast_arc_score(src + (ty + 3) * kFastSrcStride + (tx + 3), kFastSrcStride);
+    if (mm > thr) sc[ty * kFastScStride + tx] = (uint8_t)(mm - 1);
+  }
+  __syncthreads();
+#else
   for (int i = tid; i < (kFastTH + 2) * 66; i += 256) {
     const int ty = (i * 993) >> 16, tx = i - ty * 66;   // i / 66 for i < 1188
     const int x = x0 - 1 + tx, y = y0 - 1 + ty;
@@ -255,6 +299,7 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(const uint8_t* __rest
     sc[ty * kFastScStride + tx] = (uint8_t)s;
   }
   __syncthreads();
+#endif
   // wave w: rows 4w .. 4w + 3 of the tile, lane = column
   const int lane = tid & 63, w = tid >> 6;
   const int words = (im.w + 63) >> 6;
