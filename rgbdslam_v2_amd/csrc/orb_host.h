@@ -22,7 +22,9 @@ struct OrbWorkspace {
   ~OrbWorkspace();
   void release();
   void reset_detector(int max_keypoints, int grid_res, int max_iters);
-  int prepare(int cols, int rows, bool use_grid, std::string& err, int n_frames = 1);
+  // geometry_only: the host-side tables only (images, resize jobs, workgroup lists), no device call -- the pyramid plan's
+  // host check (rgbdfe_debug_pyramid_plan_check) runs on machines without a GPU
+  int prepare(int cols, int rows, bool use_grid, std::string& err, int n_frames = 1, bool geometry_only = false);
   int frames = 1;  // frames per super-frame this workspace holds (1: the single-frame paths)
   // set = 0 / 1: into that image / pyramid set (ensure_alt allocates set 1; use_set makes a set the current one, the one
   // the detection and description kernels read); -1 = the current set.  rgbdfe_detect_describe_batch uploads frame k+1

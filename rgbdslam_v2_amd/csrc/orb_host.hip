@@ -164,14 +164,14 @@ void OrbWorkspace::reset_detector(int max_keypoints, int grid_res, int max_iters
 }
 
 // (re)build the geometry for a frame size / cell layout
-int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, int n_frames) {
+int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, int n_frames, bool geometry_only) {
   // n_frames > 1: a SUPER-FRAME workspace (rgbdfe_detect_describe_batch): the images of up to n_frames frames live in one
   // pool and every stage's ONE launch covers all of them -- frame f's grid cell c is "cell" f * grid^2 + c of the kernels'
   // ImgDesc / OrbCtl tables (64 entries: 7 frames of a 3 x 3 grid), its pyramid levels are frame images f * 8 + l.
   const int per_frame_cells = use_grid ? grid * grid : 1;
   const int want_cells = per_frame_cells * n_frames;
   if (want_cells > 64) { err = "super-frame: more than 64 (frame, cell) detectors"; return RGBDFE_ERR_CAPACITY; }
-  if (cols == W && rows == H && n_cells == want_cells && frames == n_frames && d_pool) return RGBDFE_OK;
+  if (!geometry_only && cols == W && rows == H && n_cells == want_cells && frames == n_frames && d_pool) return RGBDFE_OK;
   release();
   W = cols; H = rows;
   n_cells = want_cells;
@@ -275,6 +275,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   }
   n_rows_total = (int)row_off;
   kp_cap = (int)(score_off / 4) + 64 * n_cells * kLevels;
+  if (geometry_only) return RGBDFE_OK;
   ORB_HIP(hipMalloc((void**)&d_pool, pool_bytes));
   ORB_HIP(zero_fill_and_wait(d_pool, pool_bytes));
   ORB_HIP(hipMalloc((void**)&d_score, score_off + 256));
@@ -1185,3 +1186,113 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
 }
 
 }  // namespace rgbdfe
+
+// ------------------------------------------------------------------------------------------------
+// Host check of the fused pyramid kernel's plan (tests/test_pyramid_plan.py, no GPU): the geometry and the plan of a workspace
+// of the given shape, a pool filled with pseudo-random level-0 images, then (A) one resize per level and image with
+// resize_tap_x / resize_tap_y and (B) an emulation of orb_pyramid_kernel tile by tile -- the same regions, the same 16-bit
+// table entries, the same LDS offsets, every LDS index checked against the buffer sizes of the plan.  Returns the number of
+// pool bytes that differ (0 = every pixel of every level was written, with the value the per-level resize gives), or a
+// negative number: -1 geometry, -2 plan, -3 an LDS index left its buffer.
+// ------------------------------------------------------------------------------------------------
+extern "C" int rgbdfe_debug_pyramid_plan_check(int cols, int rows, int use_grid, int n_frames, unsigned seed, int* n_tiles_out,
+                                               int* lds_bytes_out) {
+  using namespace rgbdfe;
+  OrbWorkspace ws;
+  std::string err;
+  if (ws.prepare(cols, rows, use_grid != 0, err, n_frames, true) != RGBDFE_OK) return -1;
+  std::vector<PyrTile> tiles;
+  if (ws.plan_pyramid(tiles, err) != RGBDFE_OK) return -2;
+  const PyrPlan plan = ws.pyr_plan;
+  if (n_tiles_out) *n_tiles_out = (int)tiles.size();
+  if (lds_bytes_out) *lds_bytes_out = plan.buf_bytes[0] + plan.buf_bytes[1] + 8 * (plan.max_rw + plan.max_rh);
+  const size_t level0 = (size_t)2 * cols * rows * n_frames;
+  std::vector<uint8_t> a(ws.pool_bytes, 0x55), b(ws.pool_bytes, 0xAA);
+  uint32_t x = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < level0; ++i) {
+    x = x * 1664525u + 1013904223u;
+    const bool is_mask = (i / ((size_t)cols * rows)) & 1;
+    const uint8_t v = (uint8_t)(x >> 24);
+    a[i] = is_mask ? (v < 40 ? 0 : (v < 60 ? v : 255)) : v;   // masks: mostly 255, holes, a few grey values
+    b[i] = a[i];
+  }
+  auto pixel = [](int p00, int p01, int p10, int p11, const ResizeTapX& tx, const ResizeTapY& ty, bool is_mask) {
+    const int h0 = p00 * tx.w0 + p01 * tx.w1, h1 = p10 * tx.w0 + p11 * tx.w1;
+    int v = (((ty.b0 * (h0 >> 4)) >> 16) + ((ty.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = std::min(std::max(v, 0), 255);
+    if (is_mask && v <= 254) v = 0;
+    return (uint8_t)v;
+  };
+  // (A) level by level
+  for (int l = 1; l < kLevels; ++l)
+    for (int k = ws.level_job_begin[l]; k < ws.level_job_begin[l + 1]; ++k) {
+      const ResizeJob& j = ws.jobs[k];
+      for (int dy = 0; dy < j.dh; ++dy) {
+        const ResizeTapY ty = resize_tap_y(dy, j.scale_y, j.sh);
+        for (int dx = 0; dx < j.dw; ++dx) {
+          const ResizeTapX tx = resize_tap_x(dx, j.scale_x, j.sw);
+          const uint8_t* r0 = a.data() + j.src_off + (size_t)ty.r0 * j.sstride;
+          const uint8_t* r1 = a.data() + j.src_off + (size_t)ty.r1 * j.sstride;
+          a[j.dst_off + (size_t)dy * j.dw + dx] = pixel(r0[tx.s0], r0[tx.s1], r1[tx.s0], r1[tx.s1], tx, ty, j.is_mask != 0);
+        }
+      }
+    }
+  // (B) the kernel, tile by tile
+  std::vector<uint8_t> lds((size_t)plan.buf_bytes[0] + plan.buf_bytes[1]);
+  struct Tab { uint16_t a, b; int16_t w0, w1; };
+  std::vector<Tab> xtab(plan.max_rw), ytab(plan.max_rh);
+  const int buf_off[2] = {0, plan.buf_bytes[0]};
+  const int buf_end[2] = {plan.buf_bytes[0], plan.buf_bytes[0] + plan.buf_bytes[1]};
+  for (const PyrTile& t : tiles) {
+    int px0 = t.nx0[0], py0 = t.ny0[0], prw = (t.nx1[0] - t.nx0[0] + 3) & ~3;
+    {
+      const ResizeJob& j = ws.jobs[(size_t)plan.level_job_begin[1] + t.chain];
+      const int rows0 = t.ny1[0] - py0;
+      if (prw * rows0 > plan.buf_bytes[1]) return -3;
+      for (int r = 0; r < rows0; ++r)
+        for (int c = 0; c < prw; ++c) {
+          const size_t src = j.src_off + (size_t)(py0 + r) * j.sstride + px0 + c;
+          lds[buf_off[1] + r * prw + c] = src < b.size() ? b[src] : 0;   // (dwords may reach past the region: the pool's slack)
+        }
+    }
+    for (int l = 1; l < kLevels; ++l) {
+      const int x0 = t.nx0[l], x1 = t.nx1[l], y0 = t.ny0[l], y1 = t.ny1[l];
+      const int rw = x1 - x0, rh = y1 - y0;
+      if (rw <= 0 || rh <= 0) break;
+      if (rw > plan.max_rw || rh > plan.max_rh) return -3;
+      const ResizeJob& j = ws.jobs[(size_t)plan.level_job_begin[l] + t.chain];
+      for (int i = 0; i < rw; ++i) {
+        const ResizeTapX tx = resize_tap_x(x0 + i, j.scale_x, j.sw);
+        xtab[i] = Tab{(uint16_t)(tx.s0 - px0), (uint16_t)(tx.s1 - px0), (int16_t)tx.w0, (int16_t)tx.w1};
+      }
+      for (int i = 0; i < rh; ++i) {
+        const ResizeTapY ty = resize_tap_y(y0 + i, j.scale_y, j.sh);
+        ytab[i] = Tab{(uint16_t)((ty.r0 - py0) * prw), (uint16_t)((ty.r1 - py0) * prw), (int16_t)ty.b0, (int16_t)ty.b1};
+      }
+      const int cur = buf_off[(l + 1) & 1], cur_end = buf_end[(l + 1) & 1], prev = buf_off[l & 1], prev_end = buf_end[l & 1];
+      if (cur + rw * rh > cur_end) return -3;
+      for (int y = 0; y < rh; ++y)
+        for (int xx = 0; xx < rw; ++xx) {
+          const Tab cx = xtab[xx], cy = ytab[y];
+          const int i00 = prev + cx.a + cy.a, i01 = prev + cx.b + cy.a, i10 = prev + cx.a + cy.b, i11 = prev + cx.b + cy.b;
+          if (std::max(std::max(i00, i01), std::max(i10, i11)) >= prev_end) return -3;
+          ResizeTapX tx{}; tx.w0 = cx.w0; tx.w1 = cx.w1;
+          ResizeTapY ty{}; ty.b0 = cy.w0; ty.b1 = cy.w1;
+          const uint8_t v = pixel(lds[i00], lds[i01], lds[i10], lds[i11], tx, ty, j.is_mask != 0);
+          lds[cur + y * rw + xx] = v;
+          if (x0 + xx >= t.ox0[l] && x0 + xx < t.ox1[l] && y0 + y >= t.oy0[l] && y0 + y < t.oy1[l])
+            b[j.dst_off + (size_t)(y0 + y) * j.dw + (x0 + xx)] = v;
+        }
+      px0 = x0; py0 = y0; prw = rw;
+    }
+  }
+  // every byte behind the level-0 images that belongs to a level >= 1 must agree (A pre-filled 0x55, B 0xAA: a pixel nobody
+  // wrote differs); bytes between images (none) or the slack are not compared
+  int diff = 0;
+  for (int l = 1; l < kLevels; ++l)
+    for (int k = ws.level_job_begin[l]; k < ws.level_job_begin[l + 1]; ++k) {
+      const ResizeJob& j = ws.jobs[k];
+      for (size_t i = 0; i < (size_t)j.dw * j.dh; ++i) diff += a[j.dst_off + i] != b[j.dst_off + i];
+    }
+  return diff;
+}
