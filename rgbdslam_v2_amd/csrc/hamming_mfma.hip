@@ -28,6 +28,37 @@
 
 namespace rgbdfe {
 
+// The train tiles of ONE block of hamming_mfma_pipe_kernel (mode 3) as slots of four-tile stages: the block's full tiles
+// first, then phantoms, the pair's ragged tile -- if it is this block's -- in the LAST slot of the last stage.  Host and
+// device (rgbdfe_debug_hamming_slots, tests/test_hamming_slots.py check the enumeration without a GPU).
+constexpr uint32_t kHammingPhantomTile = 0x7FFFFFFFu;
+struct HammingSlots {
+  uint32_t nt_search, n_ttiles, tile0, tile1, n_full, n_stages, last_slot;
+  bool has_ragged;
+  __host__ __device__ static HammingSlots make(uint32_t nt, uint32_t tsplit, uint32_t split, uint32_t tiles_per_stage) {
+    HammingSlots s;
+    s.nt_search = nt > 0 ? nt - 1u : 0u;   // features.cpp:174 (and D4): the node's last row is never a candidate
+    s.n_ttiles = (s.nt_search + 31u) >> 5;
+    s.tile0 = 0; s.tile1 = s.n_ttiles;
+    if (tsplit > 1u) {
+      const uint32_t chunk = (s.n_ttiles + tsplit - 1u) / tsplit;
+      s.tile0 = split * chunk < s.n_ttiles ? split * chunk : s.n_ttiles;
+      s.tile1 = s.tile0 + chunk < s.n_ttiles ? s.tile0 + chunk : s.n_ttiles;
+    }
+    const uint32_t full_tiles = s.nt_search >> 5;
+    const uint32_t fend = s.tile1 < full_tiles ? s.tile1 : full_tiles;
+    s.n_full = fend > s.tile0 ? fend - s.tile0 : 0u;
+    s.has_ragged = (s.nt_search & 31u) != 0u && s.tile1 == s.n_ttiles && s.tile1 > s.tile0;
+    s.n_stages = (s.n_full + (s.has_ragged ? 1u : 0u) + tiles_per_stage - 1u) / tiles_per_stage;
+    s.last_slot = s.n_stages * tiles_per_stage - 1u;
+    return s;
+  }
+  __host__ __device__ uint32_t tile(uint32_t slot) const {
+    const uint32_t behind = (has_ragged & (slot == last_slot)) ? n_ttiles - 1u : kHammingPhantomTile;   // (selects, no branches)
+    return slot < n_full ? tile0 + slot : behind;
+  }
+};
+
 namespace {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -302,7 +333,6 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(const uint4* __r
 #define RGBDFE_HAMMING_PIPE_DIAG 0   // TIMING-ONLY builds (keys are forced to "no match"): 1 no reductions, 2 no LDS reads in the
 #endif                               // loop, 4 no global_load_lds / barriers in the loop; tools/build_hamming_pipe_variants.sh
 constexpr int kPipeStage = 4;  // train tiles per stage (the unrolled stream below is written for four)
-constexpr uint32_t kPhantomTile = 0x7FFFFFFFu;
 constexpr float kRowUnitPerTile = 32.0f / 16384.0f;  // the tile's first row, in key units
 
 #define HP_MFMA(ACC, A, B, C) ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, C, 4, 4, 0, 0, 0, 0);
@@ -332,24 +362,11 @@ void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
   const PairWork w = work[pair];
   const uint32_t nq = w.nq;
   if (qblock * kQueriesPerBlock >= nq) return;
-  const uint32_t nt_search = w.nt > 0 ? w.nt - 1u : 0u;  // features.cpp:174 (and D4)
-  const uint32_t n_ttiles = (nt_search + 31u) >> 5;
-  uint32_t tile0 = 0, tile1 = n_ttiles;
-  if (SPLIT) {
-    const uint32_t chunk = (n_ttiles + tsplit - 1u) / tsplit;
-    tile0 = min(split * chunk, n_ttiles);
-    tile1 = min(tile0 + chunk, n_ttiles);
-  }
   // this block's tiles as slots: the full tiles first, phantoms, the ragged tile (if it is this block's) in the last slot
-  const uint32_t fend = min(tile1, nt_search >> 5);
-  const uint32_t n_full = fend > tile0 ? fend - tile0 : 0u;
-  const bool has_ragged = (nt_search & 31u) != 0u && tile1 == n_ttiles && tile1 > tile0;
-  const uint32_t n_stages = (n_full + (has_ragged ? 1u : 0u) + kPipeStage - 1u) / kPipeStage;
-  const uint32_t last_slot = n_stages * kPipeStage - 1u;
-  const uint32_t ragged_tile = n_ttiles - 1u;
-  auto slot_tile = [&](uint32_t s) -> uint32_t {  // block-uniform
-    return s < n_full ? tile0 + s : (has_ragged && s == last_slot ? ragged_tile : kPhantomTile);
-  };
+  const HammingSlots slots = HammingSlots::make(w.nt, SPLIT ? tsplit : 1u, SPLIT ? split : 0u, kPipeStage);
+  const uint32_t nt_search = slots.nt_search, n_stages = slots.n_stages;
+  const bool has_ragged = slots.has_ragged;
+  auto slot_tile = [&](uint32_t s) -> uint32_t { return slots.tile(s); };  // block-uniform
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -592,6 +609,23 @@ void hamming_mfma_pipe_kernel(const uint4* __restrict__ slab,
 #undef HP_FENCE
 
 }  // namespace
+
+}  // namespace rgbdfe
+
+// tests: the slot enumeration of one block of the pipelined kernel (host only; tiles_out[s] = train tile of slot s or
+// 0x7FFFFFFF for a phantom); returns the number of slots (4 x stages) or -1 when they do not fit
+extern "C" int rgbdfe_debug_hamming_slots(uint32_t nt, uint32_t tsplit, uint32_t split, uint32_t* tiles_out, int capacity,
+                                          int* has_ragged, uint32_t* n_ttiles) {
+  const rgbdfe::HammingSlots s = rgbdfe::HammingSlots::make(nt, tsplit, split, 4u);
+  if (has_ragged) *has_ragged = s.has_ragged ? 1 : 0;
+  if (n_ttiles) *n_ttiles = s.n_ttiles;
+  const int n = (int)(s.n_stages * 4u);
+  if (n > capacity) return -1;
+  for (int i = 0; i < n; ++i) tiles_out[i] = s.tile((uint32_t)i);
+  return n;
+}
+
+namespace rgbdfe {
 
 uint32_t hamming_mfma_tiles_per_slot(uint32_t max_kp) { return (max_kp + 31u) / 32u; }
 
