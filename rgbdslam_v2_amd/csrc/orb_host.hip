@@ -336,9 +336,11 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
     const char* pm = getenv("RGBDFE_ORB_PYRAMID");
     fused_pyramid = !(pm && std::string(pm) == "levels");
     std::vector<PyrTile> tiles;
-    if (fused_pyramid) {
-      const int rc = plan_pyramid(tiles, err);
-      if (rc != RGBDFE_OK) return rc;
+    if (fused_pyramid && plan_pyramid(tiles, err) != RGBDFE_OK) {
+      // a shape the plan does not cover (it says why in err): one launch per level, the path of rounds 1-3
+      fused_pyramid = false;
+      tiles.clear();
+      err.clear();
     }
     n_pyr_tiles = (int)tiles.size();
     if (n_pyr_tiles) {
