@@ -791,6 +791,9 @@ constexpr int kColSlots = 36;   // 32 column tiles of a 1024-row node + slot 0 +
 #ifndef RGBDFE_SIFT1_SWAP
 #define RGBDFE_SIFT1_SWAP 1
 #endif
+#ifndef RGBDFE_SIFT1_DIAG
+#define RGBDFE_SIFT1_DIAG 0   // TIMING-ONLY builds (results are void): 1 no digest at all, 2 row side only, 4 column side only --
+#endif                        // what the MFMA + LDS + barrier stream costs without (part of) its VALU work (tools/sweep_sift_onepass.sh diag)
 #ifndef RGBDFE_SIFT1_TREE
 #define RGBDFE_SIFT1_TREE 0
 #endif
@@ -958,6 +961,14 @@ __global__ __launch_bounds__(kSiftThreads, 2) void sift_top2_onepass_kernel(
     top2_merge(m0, n0, m2, n2);                                                                     \
     top2_merge(m0, n0, m4, n4);                                                                     \
     top2_merge(cm, cn, m0, n0);                                                                     \
+  }
+#elif RGBDFE_SIFT1_DIAG
+#define S1_DIGEST(ACC, MX, SX, OK)                                                                  \
+  if (RGBDFE_SIFT1_DIAG == 1) { asm volatile("" : : "v"(ACC)); }                                     \
+  else _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+    const uint32_t key = __float_as_uint(ACC[r]);                                                   \
+    if (RGBDFE_SIFT1_DIAG == 2) top2_insert(MX[r], SX[r], (OK) ? key : 0u);                         \
+    if (RGBDFE_SIFT1_DIAG == 4) top2_insert(cm, cn, key);                                           \
   }
 #else
 #define S1_DIGEST(ACC, MX, SX, OK)                                                                  \

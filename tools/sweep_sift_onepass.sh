@@ -4,6 +4,10 @@
 # library; every variant passes the sub-record's oracle-constant check or aborts).
 #   tools/sweep_sift_onepass.sh build        (here)
 #   tools/sweep_sift_onepass.sh run          (GPU box, via gpurun)
+# Timing-only decomposition (results void, no parity check): SIFT1_VARIANTS="base:-DRGBDFE_SIFT1_NV=11 d1:-DRGBDFE_SIFT1_DIAG=1
+# d2:-DRGBDFE_SIFT1_DIAG=2 d4:-DRGBDFE_SIFT1_DIAG=4" SIFT1_NO_PARITY=1 -- no digest / row side only / column side only: what the
+# MFMA + LDS + barrier stream of the one-pass kernel costs without (part of) its VALU work (prepared at the end of round 4,
+# not yet run: DESIGN.md section 7).
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
@@ -25,8 +29,8 @@ import json, sys, os
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import bench
 seq, _, _ = bench.orb_workload(1)
-r = bench.sift_subrecord(seq, 0)
-print(json.dumps({"value": r["value"], "ms_per_step": r["ms_per_step"], "serial_stage_ms": r["serial_stage_ms"], "frac": r["roofline"]["frac"], "parity": r["parity_check"]["ok"]}))
+r = bench.sift_subrecord(seq, 0, os.environ.get("SIFT1_NO_PARITY") != "1")
+print(json.dumps({"value": r["value"], "ms_per_step": r["ms_per_step"], "serial_stage_ms": r["serial_stage_ms"], "frac": r["roofline"]["frac"], "parity": (r.get("parity_check") or {}).get("ok")}))
 PY
   for v in $V; do
     tag=${v%%:*}
