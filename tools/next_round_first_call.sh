@@ -27,7 +27,6 @@ def rows(pat):
         out += list(csv.DictReader(open(f)))
     return out
 cc = rows("hamming_clock/**/*counter_collection.csv")
-kt = {r["Kernel_Name"][:60]: r for r in rows("hamming_clock/**/*kernel_trace.csv")} if False else None
 ham = [r for r in cc if "hamming_mfma_pipe" in r.get("Kernel_Name", "")]
 by = {}
 for r in ham:
