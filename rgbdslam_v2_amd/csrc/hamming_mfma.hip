@@ -20,7 +20,9 @@
 //     pair through LDS (16 KB stages, double buffered, one barrier per stage); the four waves share every tile.
 //
 // MODE 1 adds the row term inside the MFMA (C operand); MODE 2 starts from C = 0 and adds it with v_add_f32 (kept as
-// the conservative variant: it does not rely on the matrix core adding a 2^-14-granular C to the integer sum exactly).
+// the conservative variant: it does not rely on the matrix core adding a 2^-14-granular C to the integer sum exactly);
+// MODE 3 (hamming_mfma_pipe_kernel below, the default since round 4) is mode 1's arithmetic as a software pipeline inside
+// every wave: reductions and LDS reads between the MFMAs, train tiles by global_load_lds through three LDS buffers.
 // Keys are identical to the popcount kernel's, bit for bit (tests/test_gpu_hamming.py runs every mode against the
 // golden vectors of the reference function).  Usable while max_keypoints <= 32768 (15 index bits next to 9 distance
 // bits in a 24-bit significand); the host falls back to the popcount kernel above that.
