@@ -1197,8 +1197,19 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
 // pool bytes that differ (0 = every pixel of every level was written, with the value the per-level resize gives), or a
 // negative number: -1 geometry, -2 plan, -3 an LDS index left its buffer.
 // ------------------------------------------------------------------------------------------------
+// runner (optional): called for the fused side instead of the built-in emulation -- tests/test_emu_orb_pyramid.py passes the
+// product's own kernel source compiled for the host (tests/emu/), so the KERNEL is checked against the per-level resize,
+// not a restatement of it.
+typedef void (*rgbdfe_pyramid_runner)(uint8_t* pool, const rgbdfe::ResizeJob* jobs, const rgbdfe::PyrTile* tiles, int n_tiles,
+                                      const rgbdfe::PyrPlan* plan);
+extern "C" int rgbdfe_debug_pyramid_plan_check2(int cols, int rows, int use_grid, int n_frames, unsigned seed, int* n_tiles_out,
+                                                int* lds_bytes_out, rgbdfe_pyramid_runner runner);
 extern "C" int rgbdfe_debug_pyramid_plan_check(int cols, int rows, int use_grid, int n_frames, unsigned seed, int* n_tiles_out,
                                                int* lds_bytes_out) {
+  return rgbdfe_debug_pyramid_plan_check2(cols, rows, use_grid, n_frames, seed, n_tiles_out, lds_bytes_out, nullptr);
+}
+extern "C" int rgbdfe_debug_pyramid_plan_check2(int cols, int rows, int use_grid, int n_frames, unsigned seed, int* n_tiles_out,
+                                                int* lds_bytes_out, rgbdfe_pyramid_runner runner) {
   using namespace rgbdfe;
   OrbWorkspace ws;
   std::string err;
@@ -1245,7 +1256,9 @@ extern "C" int rgbdfe_debug_pyramid_plan_check(int cols, int rows, int use_grid,
   std::vector<Tab> xtab(plan.max_rw), ytab(plan.max_rh);
   const int buf_off[2] = {0, plan.buf_bytes[0]};
   const int buf_end[2] = {plan.buf_bytes[0], plan.buf_bytes[0] + plan.buf_bytes[1]};
+  if (runner) runner(b.data(), ws.jobs.data(), tiles.data(), (int)tiles.size(), &plan);
   for (const PyrTile& t : tiles) {
+    if (runner) break;
     int px0 = t.nx0[0], py0 = t.ny0[0], prw = (t.nx1[0] - t.nx0[0] + 3) & ~3;
     {
       const ResizeJob& j = ws.jobs[(size_t)plan.level_job_begin[1] + t.chain];
@@ -1297,4 +1310,27 @@ extern "C" int rgbdfe_debug_pyramid_plan_check(int cols, int rows, int use_grid,
       for (size_t i = 0; i < (size_t)j.dw * j.dh; ++i) diff += a[j.dst_off + i] != b[j.dst_off + i];
     }
   return diff;
+}
+
+// tests (host only): the pool of a workspace of the given shape after `runner` (the fused pyramid kernel, see above) has run
+// over the caller's level-0 images ([frame f gray | frame f mask] x n_frames, cols x rows bytes each), and the resize jobs
+// that describe where every level of every image lies in it.  Returns the pool size in bytes (the caller's capacity must
+// cover it), or a negative number.
+extern "C" long rgbdfe_debug_pyramid_run(int cols, int rows, int use_grid, int n_frames, const uint8_t* level0,
+                                         rgbdfe_pyramid_runner runner, uint8_t* pool_out, long pool_capacity,
+                                         rgbdfe::ResizeJob* jobs_out, int jobs_capacity, int* n_jobs_out) {
+  using namespace rgbdfe;
+  OrbWorkspace ws;
+  std::string err;
+  if (!runner || ws.prepare(cols, rows, use_grid != 0, err, n_frames, true) != RGBDFE_OK) return -1;
+  std::vector<PyrTile> tiles;
+  if (ws.plan_pyramid(tiles, err) != RGBDFE_OK) return -2;
+  if ((long)ws.pool_bytes > pool_capacity || (int)ws.jobs.size() > jobs_capacity) return -3;
+  std::vector<uint8_t> pool(ws.pool_bytes, 0x5A);
+  memcpy(pool.data(), level0, (size_t)2 * cols * rows * n_frames);
+  runner(pool.data(), ws.jobs.data(), tiles.data(), (int)tiles.size(), &ws.pyr_plan);
+  memcpy(pool_out, pool.data(), ws.pool_bytes);
+  memcpy(jobs_out, ws.jobs.data(), sizeof(ResizeJob) * ws.jobs.size());
+  if (n_jobs_out) *n_jobs_out = (int)ws.jobs.size();
+  return (long)ws.pool_bytes;
 }
