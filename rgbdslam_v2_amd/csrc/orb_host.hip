@@ -1197,7 +1197,7 @@ int OrbWorkspace::compute(std::vector<KpOut>& kps, std::vector<uint8_t>& desc, h
 // pool bytes that differ (0 = every pixel of every level was written, with the value the per-level resize gives), or a
 // negative number: -1 geometry, -2 plan, -3 an LDS index left its buffer.
 // ------------------------------------------------------------------------------------------------
-// runner (optional): called for the fused side instead of the built-in emulation -- tests/test_emu_orb_pyramid.py passes the
+// runner (optional): called for the fused side instead of the built-in emulation -- tests/test_emu_orb_kernels.py passes the
 // product's own kernel source compiled for the host (tests/emu/), so the KERNEL is checked against the per-level resize,
 // not a restatement of it.
 typedef void (*rgbdfe_pyramid_runner)(uint8_t* pool, const rgbdfe::ResizeJob* jobs, const rgbdfe::PyrTile* tiles, int n_tiles,

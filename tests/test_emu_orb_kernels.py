@@ -1,10 +1,14 @@
-"""CPU: orb_pyramid_kernel ITSELF -- the kernel source of csrc/orb_kernels.hip compiled for the host over a small HIP-on-CPU
-vocabulary (tests/emu/: one OS thread per HIP thread, __shared__ = static storage, __syncthreads() = a barrier) -- against one
-bilinear resize per level.  rgbdfe_debug_pyramid_plan_check2 builds the geometry and the plan of a workspace, fills a pool
-with pseudo-random images and masks, runs the per-level resize on one copy and hands the other copy, with the product's
-job / tile / plan tables, to the runner passed in: here the product's launcher over the product's kernel.  0 differing bytes =
-the kernel computes every pyramid pixel the per-level path computes, with the same value.  (The GPU runs of the same kernel are
-tests/test_gpu_orb.py; tests/test_pyramid_plan.py checks the plan with a restatement of the kernel.)"""
+"""CPU: the SOURCE of three kernels of csrc/orb_kernels.hip -- orb_pyramid_kernel, orb_resize_kernel, orb_blur_kernel -- run on
+the host: the file compiled with g++ over a small HIP-on-CPU vocabulary (tests/emu/: one OS thread per HIP thread of a workgroup,
+__shared__ = static storage, __syncthreads() = a barrier; wave-level operations abort, so only kernels without them run).
+
+orb_pyramid_kernel: rgbdfe_debug_pyramid_plan_check2 builds the geometry and the plan of a workspace, fills a pool with
+pseudo-random images and masks, runs one bilinear resize per level on one copy and hands the other copy, with the product's
+job / tile / plan tables, to the runner passed in -- here the product's launcher over the product's kernel.  0 differing bytes
+= the kernel computes every pyramid pixel the per-level path computes, with the same value.  A second test compares every level
+the kernel wrote with oracle/orb_oracle.c's own cv::resize restatement of the level below; two more run the per-level resize
+kernel and the 7x7 blur kernel against the oracle.  (The GPU runs of the same kernels: tests/test_gpu_orb.py;
+tests/test_pyramid_plan.py checks the plan with a restatement of the kernel.)"""
 import ctypes
 import os
 import shutil
@@ -91,3 +95,46 @@ def test_the_kernel_source_against_the_oracles_resize(emu, cols, rows, grid):
         assert np.array_equal(got, want), "job %d (%dx%d -> %dx%d, mask %d)" % (k, j.sw, j.sh, j.dw, j.dh, j.is_mask)
         checked += 1
     assert checked == n_jobs.value
+
+
+def _oracle():
+    from oracle import pyoracle as po
+    po.build()
+    O = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    O.orb_resize_linear_u8.restype = None
+    O.orb_resize_linear_u8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int]
+    O.orb_gaussian_blur7.restype = None
+    O.orb_gaussian_blur7.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    return O
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(320, 240, 267, 200), (275, 222, 229, 185), (77, 62, 64, 52), (130, 97, 108, 81)])
+def test_resize_kernel_source_against_the_oracle(emu, sw, sh, dw, dh):
+    """orb_resize_kernel (one launch per level: RGBDFE_ORB_PYRAMID=levels) on the host = the oracle's cv::resize, gray and mask."""
+    import numpy as np
+    O = _oracle()
+    rng = np.random.default_rng(sw + dh)
+    src = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+    for is_mask in (0, 1):
+        got = np.zeros((dh, dw), np.uint8)
+        want = np.zeros((dh, dw), np.uint8)
+        emu.emu_orb_resize(src.ctypes.data_as(ctypes.c_void_p), sw, sh, got.ctypes.data_as(ctypes.c_void_p), dw, dh, is_mask)
+        O.orb_resize_linear_u8(src.ctypes.data, sw, sh, sw, want.ctypes.data, dw, dh, dw)
+        if is_mask:
+            want[want <= 254] = 0
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (131, 97), (64, 16), (70, 33)])
+def test_blur_kernel_source_against_the_oracle(emu, w, h):
+    """orb_blur_kernel on the host = the oracle's GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) in 8-bit fixed point."""
+    import numpy as np
+    O = _oracle()
+    rng = np.random.default_rng(w * 5 + h)
+    src = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    got = np.zeros((h, w), np.uint8)
+    want = np.zeros((h, w), np.uint8)
+    emu.emu_orb_blur(src.ctypes.data_as(ctypes.c_void_p), w, h, got.ctypes.data_as(ctypes.c_void_p))
+    O.orb_gaussian_blur7(src.ctypes.data, w, h, w, want.ctypes.data)
+    assert np.array_equal(got, want)
