@@ -227,14 +227,32 @@ def main():
     # call of the process comes from this thread (the line's config says so).
     os.environ.setdefault("RGBDFE_GRAPHS", "1")
 
+    # `python bench.py --gpus N` creates its N ranks itself: without WORLD_SIZE in the environment and with
+    # N > 1 the process re-executes under torch.distributed.run exactly as the driver would launch it (one rank per GPU,
+    # rendezvous on 127.0.0.1, a free port).  A WORLD_SIZE that disagrees with --gpus -- in EITHER direction -- is an error:
+    # eight "N = 1" lines must never pass for a scaling curve.  (GraphManager's pair fan-out this replaces:
+    # graph_manager.cpp:541-560.)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+                 + sys.argv[1:])
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or leave WORLD_SIZE unset and "
+                         f"let bench.py start them)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # RGBDFE_BENCH_BACKEND=gloo (tests only): several ranks on ONE GPU -- RCCL refuses two ranks on a device -- to exercise
@@ -298,12 +316,18 @@ def main():
     stream_cap = n_pad * (hdr_bytes + 4 * RGBDFE_MAX_MATCHES)      # a shard's inlier stream at its largest
     gat_bytes = COMPACT_DTYPE.itemsize if compact else rec_bytes    # (fixed-size payloads)
     rccl_ranks = None
+    rank_devices = None
     cdev = "cpu" if host_coll else "cuda"
     if gather_on:
         # what the collective library itself saw: every rank contributes 1 through the backend the steps use
         ones = torch.ones(1, dtype=torch.int32, device=cdev)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
+        # ... and which device every rank really sits on (N ranks on N distinct devices is what a scaling line claims)
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = "rank %d: cuda:%d %s" % (rank, local_rank, getattr(prop, "uuid", None) or getattr(prop, "pci_bus_id", "?"))
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
     # Steps are pipelined: step k is submitted to one of the context's internal streams while
     # step k-1 still runs (its RANSAC tail overlaps step k's Hamming kernel).  A ring of result
     # buffers keeps every step's output alive until its all-gather has consumed it.
@@ -601,7 +625,8 @@ def main():
                                  "compact": world * n_pad * COMPACT_DTYPE.itemsize, "full": world * n_pad * rec_bytes},
                              "gathers_in_timed_regions": state["gathers"],
                              "collectives_per_step": 2 if inliers else 1,
-                             "backend": backend, "rccl_ranks": rccl_ranks,
+                             "backend": backend, "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+                             "distinct_devices": len({d.split(" ", 2)[2] for d in rank_devices}) if rank_devices else None,
                              "transport": "RCCL ncclAllGather via torch.distributed (nccl backend)" if backend == "nccl"
                                           else "host tensors (%s; test mode)" % backend}
         if world == 1 and not args.no_extras:

@@ -14,26 +14,33 @@
 //                         iteration certainly ends with refined_matches empty, node.cpp:1148-1154).  Leaves, per pair, a
 //                         bit mask of the viable iterations, their transforms (in the rR / rt fields of the iteration's
 //                         record) and the empty summaries of the others.  No slot machinery, no scoring state.
-//   ransac_refine_kernel  the refinement loops of the viable iterations only.  A workgroup = 8 waves = 2 pairs x 4
-//                         waves: the 4 waves of a pair share ONE LDS copy of the pair's match records (PairPrep, 8.9 KB)
-//                         and take the pair's viable iterations in turn (the k-th viable iteration goes to wave k mod 4).
-//                         Every wave refines 7 iterations side by side (slots, refilled as iterations finish):
+//   ransac_refine_kernel  the refinement loops of the viable iterations only.  Persistent workgroups of 8 waves =
+//                         7 WORKERS + 1 SERVER; up to three units (pair, iteration range) are resident in LDS (their match
+//                         records, PairPrep, 8.4 KB each) and their viable iterations occupy SLOTS.  The slots form two
+//                         groups that take turns: in a half-round the workers run one pass of the refinement loop
+//                         (node.cpp:1140) for their slots of group g
 //                           scoring          LANE = MATCH; the inliers' errors stay in LDS and the reference's strictly
-//                                            sequential error sum (node.cpp:1006) runs right behind the scoring from
-//                                            broadcast LDS reads -- no error pool in global memory, no read-back;
-//                           bookkeeping      LANE = SLOT (node.cpp:1154-1166);
-//                           refit            the PCL weighted-mean recurrences of the wave's active slots share one
-//                                            63-lane loop (9 state elements per slot);
-//                           3x3 Jacobi SVD   LANE = SLOT OF THE WORKGROUP: a wave posts its slots' covariance / means in an
-//                                            LDS mailbox and whichever wave finds the server lock free runs ONE SVD for
-//                                            every request pending in the workgroup (56 slots), its own included.  At 7
-//                                            lanes per wave the SVDs were 40 % of the recording stage's instructions;
-//                                            requests that arrive while a server is busy ride with the next one, so the
-//                                            batches grow with the load.
-//                         LDS: 60 KB per workgroup => 16 waves per CU at <= 128 VGPRs (4 per SIMD).  Nothing but the
-//                         hypothesis read and the record write touches global memory inside the loop, and the waves of a
-//                         workgroup never meet at a barrier after the prologue (wave-local ordering: LDS executes a wave's
-//                         operations in order).
+//                                            sequential error sum (node.cpp:1006) runs right behind the scoring,
+//                           bookkeeping      LANE = SLOT (node.cpp:1154-1166),
+//                           refit            the PCL weighted-mean recurrences of the wave's slots side by side
+//                                            (9 state elements per slot),
+//                         while the server does for the OTHER group everything that concerns more than one wave:
+//                           3x3 Jacobi SVD   LANE = SLOT OF THE GROUP: one SVD for every refit the workers left in the
+//                                            group's mailbox in the half-round before (at 7 lanes per wave the SVDs were
+//                                            40 % of the recording stage's instructions),
+//                           recycling        finished iterations' slots and drained units' buffers,
+//                           hand-out         the next viable iterations of the resident units to the free slots, to the
+//                                            least occupied workers first,
+//                           unit loading     the launch's units come off a global counter (a block at a time, lane = unit:
+//                                            units whose pair has ended or whose range holds no viable iteration cost
+//                                            nothing); the records go global -> LDS directly (global_load_lds_dwordx4),
+//                                            issued in one half-round and awaited in the next.
+//                         ONE s_barrier per half-round is the only synchronisation between the waves of a workgroup:
+//                         the queue state is touched by the server alone, a slot by one wave at a time.  There is no spin
+//                         wait, no lock and no atomic on LDS anywhere in the kernel (round 4's streaming version handed
+//                         work out through LDS spin locks and stalled about once in 10^4 small launches; see DESIGN.md
+//                         4.2b) -- a launch cannot wait for anything but its own waves' arrival at the barrier.
+//                         LDS: 70 KB per workgroup => 2 workgroups = 16 waves per CU at <= 128 VGPRs (4 per SIMD).
 // Same bytes as the one-wave kernel (select_ransac_kernel<kWhole>): every float / double operation is the one
 // oracle/rgbd_oracle.c performs, in the same order (-ffp-contract=off), so every discrete RANSAC decision is the same.
 #include <stdio.h>
@@ -56,94 +63,37 @@ __device__ __forceinline__ void lsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// flags other waves of the workgroup poll: relaxed atomics on LDS (a plain ds_read / ds_write the compiler neither hoists
-// out of a polling loop nor drops); ordering against the data they guard comes from lsync()
+// The workgroup barrier of the refinement kernel: this wave's LDS operations have been performed, then s_barrier.  Vector
+// memory is NOT drained (the server's unit loads and everybody's record stores stay in flight across it) -- which is why
+// this is not __syncthreads(), in front of which the compiler waits for every counter.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // a lane index (or anything derived from it) the compiler may not carry across this point: addresses formed from it are
 // recomputed where they are used instead of being hoisted to the top of the kernel and spilled
 __device__ __forceinline__ int fresh(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
-__device__ __forceinline__ int flag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void flag_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 constexpr int kHypThreads = 256;
 
-// Optional phase timers of the refinement kernel (librgbdfe_prof.so, -DRGBDFE_PROFILE_PHASES): wall cycles per phase
-// summed over the waves of all launches since the last reset.  Never enabled in the product build.
-#ifdef RGBDFE_PROFILE_PHASES
-// one row per wave (26 atomics per wave on shared counters clog the memory pipeline of the very waves being measured)
-constexpr unsigned kSplitLogWaves = 1u << 18;
-__device__ unsigned long long g_split_log[kSplitLogWaves][26];
-__device__ unsigned int g_split_count;
-__device__ unsigned int g_dbg_reopened;  // iterations opened whose record was not a fresh hypothesis
-#define SP_DECL const uint64_t sp_rt0 = __builtin_amdgcn_s_memrealtime(); uint64_t sp_t0 = __builtin_readcyclecounter(); uint64_t sp[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define SP_MARK(i) { const uint64_t sp_t1 = __builtin_readcyclecounter(); sp[i] += sp_t1 - sp_t0; sp_t0 = sp_t1; }
-#define SP_COUNT(i, v) { sp[i] += (uint64_t)(v); }
-#else
-#define SP_DECL
-#define SP_MARK(i)
-#define SP_COUNT(i, v)
-#endif
-
-// Every spin wait of the refinement kernel is BOUNDED (round 4, after intermittent hangs: about one launch in 10^4 never
-// ended -- a wave that had just taken or released the queue lock stopped making progress and its workgroup waited for it
-// forever; see DESIGN.md 4.2b for the evidence and for what was ruled out).  A wave whose wait exceeds kSpinBound turns
-// (milliseconds; normal waits are microseconds) raises plan.gave_up and ends; the waves that depend on it follow, the
-// launch terminates, and the guarded select_ransac_kernel<kRecord> behind it (select_ransac.hip) records the phase
-// instead -- same bytes.  The diagnostics build (-DRGBDFE_SPLIT_WATCHDOG, librgbdfe_wd.so) also records where the first
-// wave stood and what the workgroup's shared state looked like (rgbdfe_debug_watchdog).
-constexpr unsigned kSpinBound = 1u << 15;
-__device__ unsigned int g_split_gave_up;   // launches' waves that gave up since the process started (rgbdfe_debug_split_gave_up)
-__device__ int g_split_sabotage;           // tests: the next n refinement launches give up at once (rgbdfe_debug_split_sabotage)
-#define WD_DECL unsigned wd_n = 0;
-#define WD_RESET wd_n = 0;
-#ifdef RGBDFE_SPLIT_WATCHDOG
-__device__ unsigned int g_wd[64];
-#define WD_SNAPSHOT(SITE)                                                                                 \
-    if ((threadIdx.x & 63) == 0 && atomicCAS(&g_wd[0], 0u, (unsigned)(SITE)) == 0u) {                     \
-      g_wd[1] = blockIdx.x; g_wd[2] = threadIdx.x >> 6; g_wd[3] = gridDim.x; g_wd[4] = n_units;           \
-      g_wd[5] = (unsigned)lds.qlock; g_wd[6] = (unsigned)lds.lock; g_wd[7] = (unsigned)lds.no_more_units; \
-      for (int b_ = 0; b_ < kBufs; ++b_) {                                                                \
-        g_wd[8 + 4 * b_] = (unsigned)lds.ctx[b_].state; g_wd[9 + 4 * b_] = (unsigned)lds.ctx[b_].next;    \
-        g_wd[10 + 4 * b_] = (unsigned)lds.ctx[b_].done; g_wd[11 + 4 * b_] = (unsigned)lds.ctx[b_].n_items; \
-      }                                                                                                   \
-      unsigned rq = 0, rq2 = 0;                                                                           \
-      for (int q_ = 0; q_ < 32; ++q_) { rq |= lds.req[q_] ? 1u << q_ : 0u; rq2 |= lds.req[32 + q_] ? 1u << q_ : 0u; } \
-      g_wd[20] = rq; g_wd[21] = rq2; g_wd[22] = *plan.unit_counter; g_wd[23] = (unsigned)plan.phase_index;   \
-      for (int w_ = 0; w_ < kStreamWaves; ++w_) {                                                          \
-        unsigned act = 0, held = 0;                                                                       \
-        for (int s_ = 0; s_ < kSlots; ++s_) { act |= lds.w[w_].slot[s_].active ? 1u << s_ : 0u; held |= lds.w[w_].slot[s_].iter >= 0 ? 1u << s_ : 0u; } \
-        g_wd[24 + w_] = act | (held << 8) | ((unsigned)lds.dbg[w_] << 16);                                \
-      }                                                                                                   \
-      g_wd[32] = n_pairs; g_wd[33] = (unsigned)plan.n_shares; g_wd[34] = (unsigned)plan.share_iters;      \
-    }
-#define WD_MARK(CODE) if ((threadIdx.x & 63) == 0) lds.dbg[threadIdx.x >> 6] = (CODE);
-#define WD_OWNER (int)(threadIdx.x >> 6) + 1
-#else
-#define WD_SNAPSHOT(SITE)
-#define WD_MARK(CODE)
-#define WD_OWNER 1
-#endif
-#define WD_TICK(SITE)                                                                                     \
-  if (++wd_n > kSpinBound) {                                                                              \
-    WD_SNAPSHOT(SITE)                                                                                     \
-    if ((threadIdx.x & 63) == 0) {                                                                        \
-      atomicExch(plan.gave_up, 1);                                                                        \
-      atomicAdd(&g_split_gave_up, 1u);                                                                    \
-    }                                                                                                     \
-    __builtin_amdgcn_endpgm();                                                                            \
-  }
-
-constexpr int kStreamWaves = 8;                       // waves of a refinement workgroup
+constexpr int kStreamWaves = 8;                        // waves of a refinement workgroup: 7 workers + the server
+constexpr int kWorkers = kStreamWaves - 1;
 constexpr int kStreamThreads = kStreamWaves * kWave;
-constexpr int kStreamSlots = kStreamWaves * kSlots;   // slots of a workgroup: one lane each in the combined SVD
-static_assert(kStreamSlots <= kWave, "the combined SVD is lane = slot of the workgroup");
+constexpr int kWaveSlots = 4;                          // iterations a worker refines side by side, per group
+constexpr int kGroupSlots = kWorkers * kWaveSlots;     // slots of a group: one lane each in the server's SVD
+constexpr int kStreamSlots = 2 * kGroupSlots;
+static_assert(kWaveSlots <= kSlots, "the refit phase (fit_compact / fit_recurrence) holds kSlots lists per wave");
+static_assert(kStreamSlots <= kWave, "the server looks at all slots with one lane each");
 constexpr int kBufs = 3;                              // units (pair, iteration range) resident in a workgroup's LDS
 constexpr int kMaxShare = 512;                        // iterations of a unit at most (the host cuts longer ranges)
+constexpr int kMaskLanes = kMaxShare / kWave + 1;     // words of a pair's viable mask that can overlap a unit's range
 constexpr int kMVec = RGBDFE_MAX_MATCHES * kRec / 4;  // float4s of a pair's match records
 
 // one RANSAC iteration in flight (see select_ransac.hip: Slot), with the facts of its unit the scoring needs
+constexpr int kSlotDone = 0, kSlotActive = 1, kSlotRecorded = 2;
 struct SlotS {
   float R[9], t[3];          // transform to score next (first the 4-point hypothesis, then the refits')
   int n_all;                 // the unit's pair: selected matches,
@@ -158,9 +108,10 @@ struct SlotS {
   double csum;               // sequential sum of the current scoring's inlier errors (node.cpp:1006)
   int rn;                    // refined_matches.size()
   int cn;                    // inliers of the current scoring
-  int active;                // still inside the refinement loop (:1140-1169)
+  int active;                // kSlotActive: inside the refinement loop (:1140-1169); kSlotDone: it has left the loop;
+                             // kSlotRecorded: ... and its worker has written the outcome record
   int round;                 // refinement passes done
-  int iter;                  // RANSAC iteration held by the slot, -1 = free
+  int iter;                  // RANSAC iteration held by the slot, -1 = free (written by the server only)
   int buf;                   // LDS buffer of the slot's unit
   uint32_t pair;             // the unit's pair
   int pad;
@@ -174,17 +125,16 @@ struct ScoreB {
 };
 static_assert(offsetof(ScoreB, err) % 16 == 0, "16-byte reads of the error list");
 struct alignas(16) WaveLds {
-  union {  // the phases of a round never overlap
+  union {  // the phases of a half-round never overlap
     ScoreB sc;
     FitBuf fit;
   } u;
-  SlotS slot[kSlots];
 };
-// a unit resident in LDS: its pair's facts and the viable iterations of its range, handed out in order
+// a unit resident in LDS: its pair's facts and the viable iterations of its range, handed out in order.  Server only.
 constexpr int kUnitFree = 0, kUnitLoading = 1, kUnitReady = 2;
 struct UnitCtx {
-  int state;                 // kUnitFree / kUnitLoading (one wave is filling the buffer) / kUnitReady
-  int next;                  // iterations handed out so far (may run past n_items)
+  int state;                 // kUnitFree / kUnitLoading (the records are on their way) / kUnitReady
+  int next;                  // iterations handed out so far
   int done;                  // iterations whose refinement has ended; == n_items => the buffer is free again
   int n_items;
   uint32_t pair;
@@ -199,17 +149,12 @@ struct UnitCtx {
 };
 struct alignas(16) StreamLds {
   float M[kBufs][RGBDFE_MAX_MATCHES * kRec];  // the resident units' match records (see PairPrep)
-  WaveLds w[kStreamWaves];
-  float svd_in[kStreamSlots][16];  // mailbox of the combined SVD: C[9], mean1[3], mean2[3] of a slot's refit
+  WaveLds w[kWorkers];
+  SlotS slot[kStreamSlots];        // group g: slots g * kGroupSlots + worker * kWaveSlots + j
+  float svd_in[kStreamSlots][16];  // mailbox of the server's SVD: C[9], mean1[3], mean2[3] of a slot's refit
   UnitCtx ctx[kBufs];
-  int req[kWave];                  // 1 = the slot's SVD is pending (relaxed workgroup atomics)
-  int lock;                        // 1 = a wave is serving the pending requests
-  int qlock;                       // 1 = a wave is taking iterations / choosing a buffer to fill
-  int no_more_units;               // the launch's unit counter has run past the last unit
-  int pad;
-#ifdef RGBDFE_SPLIT_WATCHDOG
-  int dbg[kStreamWaves];           // where each wave is (progress codes)
-#endif
+  int quit;                        // set by the server: every unit of the launch has been refined
+  int pad[3];
 };
 static_assert(sizeof(StreamLds) <= 80 * 1024, "two workgroups per CU");
 
@@ -455,495 +400,466 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 }
 
 // ---------------------------------------------------------------------------------
-// The refinement loops (node.cpp:1140-1169) of the viable iterations of [phase_begin, phase_end / spec_end), streamed:
-// a workgroup takes units (pair, iteration range) off the launch's counter, keeps up to three of them resident in LDS and
-// its 8 waves take whatever viable iteration is next, of any resident unit.
+// The refinement loops (node.cpp:1140-1169) of the viable iterations of [phase_begin, phase_end / spec_end): persistent
+// workgroups of 7 workers + 1 server, two slot groups taking turns, one s_barrier per half-round (see the file header).
 // ---------------------------------------------------------------------------------
-#ifdef RGBDFE_SPLIT_NO_WAVES_ATTR
-#define RGBDFE_REFINE_ATTR
-#else
-#define RGBDFE_REFINE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
-__global__ __launch_bounds__(kStreamThreads) RGBDFE_REFINE_ATTR void ransac_refine_kernel(
+__global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_refine_kernel(
     uint32_t n_pairs, const RansacConst rc, const SplitPlan plan, uint32_t n_units) {
   // a later phase of a batch whose pairs have all ended (the walk of the phase before found nobody still running)
   if (plan.phase_index > 0 && plan.walk[n_pairs].best_n != plan.phase_index) return;
   extern __shared__ __attribute__((aligned(16))) char stream_smem[];
   StreamLds& lds = *reinterpret_cast<StreamLds*>(stream_smem);
-  SP_DECL
-  WD_DECL
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  WaveLds& wl = lds.w[wave];
   const int I = rc.ransac_iterations;
 
-  if (lane < kSlots) { wl.slot[lane].active = 0; wl.slot[lane].iter = -1; }
   if (wave == 0) {
-    lds.req[lane] = 0;
+    if (lane < kStreamSlots) { lds.slot[lane].active = kSlotDone; lds.slot[lane].iter = -1; lds.slot[lane].buf = 0; }
     if (lane < kBufs) { lds.ctx[lane].state = kUnitFree; lds.ctx[lane].next = 0; lds.ctx[lane].done = 0; lds.ctx[lane].n_items = 0; }
-    if (lane == 0) {
-      lds.lock = 0;
-      lds.qlock = 0;
-      lds.no_more_units = 0;
-    }
-#ifdef RGBDFE_SPLIT_WATCHDOG
-    if (lane < kStreamWaves) lds.dbg[lane] = 1;
-#endif
+    if (lane == 0) lds.quit = 0;
   }
-  __syncthreads();  // the only workgroup barrier: from here on the waves run on their own
-  SP_MARK(0)
-  // Test hook (rgbdfe_debug_split_sabotage): the first wave of the launch gives up before doing anything, as a wave whose
-  // wait reached its bound would -- the launch's records are void and the guarded fallback launch has to produce them.
-  if (blockIdx.x == 0 && wave == 0 && g_split_sabotage > 0) {
-    if (lane == 0) {
-      atomicSub(&g_split_sabotage, 1);
-      atomicExch(plan.gave_up, 1);
-      atomicAdd(&g_split_gave_up, 1u);
-    }
-    __builtin_amdgcn_endpgm();
-  }
+  lds_barrier();
 
-  // ---- a unit -> LDS buffer b (one wave): the pair's facts, its match records (global -> LDS directly:
-  // global_load_lds_dwordx4, 64 x 16 bytes per instruction), the viable iterations of the unit's range as a list.
-  // Leaves the buffer ready, or free again when the unit has nothing to do in this launch.
-  auto load_unit = [&](int b, uint32_t unit) {
-    const int lane = fresh(threadIdx.x & (kWave - 1));
-    const uint32_t pair = unit / (uint32_t)plan.n_shares;
-    const int share = (int)(unit - pair * (uint32_t)plan.n_shares);
-    const PairPrep* __restrict__ pp = plan.prep + pair;
-    const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
-    UnitCtx& cx = lds.ctx[b];
-    auto load_records = [&]() {
-#ifdef RGBDFE_SPLIT_NO_LDSDMA   // diagnostics variant: the records through registers
-      const float4* __restrict__ src4 = reinterpret_cast<const float4*>(pp->M);
-      float4* __restrict__ dst4 = reinterpret_cast<float4*>(lds.M[b]);
-      for (int i = 0; i < (kMVec + kWave - 1) / kWave; ++i) {
-        const int v = i * kWave + lane;
-        if (v < kMVec) dst4[v] = src4[v];
-      }
-#else
-      const char* __restrict__ src = reinterpret_cast<const char*>(pp->M);
-      for (int i = 0; i < (kMVec + kWave - 1) / kWave; ++i) {
-        const int v = i * kWave + lane;
-        if (v < kMVec)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)v * 16),
-                                           (__attribute__((address_space(3))) void*)(lds.M[b] + i * (kWave * 4)), 16, 0, 0);
-      }
-#endif
-    };
-    // the first launch of a batch: every pair is still running, the records need not wait for the pair's state
-    if (plan.phase_begin == 0) load_records();
-    // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
-    const WalkState ws = plan.walk[pair];
-    const int batch_class1 = plan.walk[n_pairs].state;
-    const int pre = plan.first_spec ? (int)plan.preclass[pair] : 0;
-    const int n_all = __builtin_amdgcn_readfirstlane(pp->n_all);
-    const float pmax = pp->pmax;
-    const uint32_t fast = pp->fast_alpha;
-    const uint64_t wnz = lane < kRounds ? pp->w_nonzero[lane] : 0ull;
-    const int k_first = plan.phase_begin + share * plan.share_iters;
-    const int blk0 = k_first >> 6;
-    const uint64_t wv_ld = (blk0 + lane < plan.vmask_words && lane <= kMaxShare / kWave) ? vm_pair[blk0 + lane] : 0ull;
-    const int pair_state = plan.phase_begin == 0 ? I : __builtin_amdgcn_readfirstlane(ws.state);
-    // class 2 (no jump of `it` so far, junk-heavy; class 1 when the batch has few such pairs: effective_class): everything
-    // that is left is recorded in this launch
-    int cls = plan.phase_begin != 0 ? __builtin_amdgcn_readfirstlane(ws.speculate) : __builtin_amdgcn_readfirstlane(pre);
-    if (cls == 1) cls = ((uint32_t)__builtin_amdgcn_readfirstlane(batch_class1) * 64u <= n_pairs) ? 2 : 0;
-    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, pair_state);
-    const int k_begin = k_first;
-    const int k_end = min(k_begin + plan.share_iters, end);
-    // no RANSAC for this pair (node.cpp:1087, :1130), or nothing of this range is needed (any more)
-    const bool have = pair_state >= 0 && k_begin < k_end && n_all > rc.min_matches && n_all >= 4;
-    int total = 0;
-    if (have) {
-      if (plan.phase_begin != 0) load_records();
-      // lane w holds word blk0 + w of the pair's mask, cut to the range; lane = iteration builds the list
-      uint64_t wv = wv_ld;
-      {
-        const int lo = (blk0 + lane) << 6;
-        if (k_begin > lo) wv &= (k_begin - lo >= 64) ? 0ull : (~0ull << (k_begin - lo));
-        if (k_end - lo < 64) wv &= (k_end - lo <= 0) ? 0ull : ((1ull << (k_end - lo)) - 1ull);
-      }
-      const int n_words = ((k_end - 1) >> 6) - blk0 + 1;  // <= kMaxShare / 64 + 1
-      for (int c = 0; c < n_words; ++c) {
-        const uint64_t wc = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), c) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wv, c);
-        if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)((c << 6) + lane);
-        total += __popcll(wc);
-      }
-      uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
-      if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
-      if (lane < kRounds) cx.w_nonzero[lane] = wnz;
-      if (lane == 0) {
-        cx.pair = pair;
-        cx.n_all = n_all;
-        cx.thr = thr;
-        cx.pmax = pmax;
-        cx.fast = (int)fast;
-        cx.base = blk0 << 6;
-        cx.n_items = total;
-        cx.next = 0;
-        cx.done = 0;
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the match records are in LDS
-    lsync();
-    if (lane == 0) flag_store(&cx.state, total > 0 ? kUnitReady : kUnitFree);
-    SP_COUNT(21, 1)
+  // the outcome record of an iteration that has left its refinement loop (its worker's lane, or the server's)
+  auto write_record = [&](const SlotS& sl) {
+    const size_t at = (size_t)sl.pair * (size_t)I + (size_t)sl.iter;
+    IterRec& r = plan.recs[at];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.rR[i] = sl.rR[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r.rt[i] = sl.rt[i];
+#pragma unroll
+    for (int q = 0; q < kRounds; ++q) r.rmask[q] = sl.rmask[q];
+    r.rerr = sl.rerr;
+    r.rn = sl.rn;
+    r.pad = 0;
+    plan.sums[at] = IterSum{sl.rerr, sl.rn, 0};
   };
 
-  // ---- iterations that have left their refinement loop: the outcome record; the slot is free again, and so is the
-  // unit's buffer once all its iterations have ended
-  auto close_finished = [&]() {
-    WD_MARK(50)
-    const int lane = fresh(threadIdx.x & (kWave - 1));
-    if (lane < kSlots) {
-      SlotS& sl = wl.slot[lane];
-      if (sl.iter >= 0 && !sl.active) {
-        const size_t at = (size_t)sl.pair * (size_t)I + (size_t)sl.iter;
-        IterRec& r = plan.recs[at];
+  if (wave < kWorkers) {
+    // =========================================================================================== a worker
+    WaveLds& wl = lds.w[wave];
+    lds_barrier();   // (the server's prologue: the first unit's iterations are in group 0's slots)
+    for (int h = 0;; ++h) {
+      const int lane = fresh(threadIdx.x & (kWave - 1));
+      SlotS* const mine = &lds.slot[(h & 1) * kGroupSlots + wave * kWaveSlots];   // this half-round's slots of this wave
+      // ================================ one pass of the refinement loop (:1140) for every active slot
+      // ---- scorings (:1148), one after the other (lane = match), each followed by its error sum
+      uint64_t act = __ballot(lane < kWaveSlots && mine[min(lane, kWaveSlots - 1)].active == kSlotActive);
+      if (act != 0ull) {
+        while (act != 0ull) {
+          const int j = (int)__builtin_ctzll(act);
+          act &= act - 1ull;
+          SlotS& sl = mine[j];
+          float curR[9], curt[3];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) r.rR[i] = sl.rR[i];
+          for (int i = 0; i < 9; ++i) curR[i] = sl.R[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) r.rt[i] = sl.rt[i];
+          for (int i = 0; i < 3; ++i) curt[i] = sl.t[i];
+          const int n_all = __builtin_amdgcn_readfirstlane(sl.n_all);
+          const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.thr);
+          const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.pmax)));
+          const float* __restrict__ M = lds.M[__builtin_amdgcn_readfirstlane(sl.buf)];
+          // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever its error
+          // is (:1154, :1160): the scorer may stop counting as soon as that is certain
+          const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
+          uint64_t inl_mask[kRounds];
+          int n_inl;
+          double sum;
+          score_b(curR, curt, M, n_all, need, rc, wl.u.sc, pmax, inl_mask, n_inl, sum);
+          if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < kRounds; ++q) r.rmask[q] = sl.rmask[q];
-        r.rerr = sl.rerr;
-        r.rn = sl.rn;
-        r.pad = 0;
-        plan.sums[at] = IterSum{sl.rerr, sl.rn, 0};
-        sl.iter = -1;
-        UnitCtx& cx = lds.ctx[sl.buf];
-        const int n_items = cx.n_items;  // (read before the count: once the last iteration is counted the buffer may be refilled)
-        if (atomicAdd(&cx.done, 1) + 1 == n_items) flag_store(&cx.state, kUnitFree);
-      }
-    }
-    lsync();
-    SP_MARK(1)
-  };
-
-  // ---- free slots take the next viable iterations of the resident units (any unit: a slot carries its unit's facts);
-  // a wave that finds nothing to take brings the workgroup's next unit in.  Returns false when the wave holds no
-  // iteration and none will come.
-  auto refill = [&]() -> bool {
-    WD_RESET
-    const int lane = fresh(threadIdx.x & (kWave - 1));
-    uint64_t free_slots = __ballot(lane < kSlots && wl.slot[min(lane, kSlots - 1)].iter < 0);
-    const int n_free = __popcll(free_slots);
-    const bool had = n_free < kSlots;
-    int got = 0;
-    int my_g = -1, my_at = 0, my_b = 0;  // lanes 6j .. 6j+5: the j-th slot opened by this call
-    while (got < n_free) {
-      // The hand-out of iterations and the choice of a buffer to fill happen under the workgroup's queue lock: a unit
-      // with iterations left cannot be recycled, so what a wave sees inside the lock is what it takes.  (Lock-free
-      // claims on `next` could land on a buffer that had been drained, freed and refilled in between.)
-      int locked = 0;
-      do {
-#ifdef RGBDFE_SPLIT_TTAS   // test-and-test-and-set: a plain read first, the returning atomic only when the lock looks free
-        if (lane == 0) locked = flag_load(&lds.qlock) == 0 ? (atomicCAS(&lds.qlock, 0, WD_OWNER) == 0 ? 1 : 0) : 0;
-#else
-        if (lane == 0) locked = atomicCAS(&lds.qlock, 0, WD_OWNER) == 0 ? 1 : 0;
-#endif
-        locked = __builtin_amdgcn_readfirstlane(locked);
-        if (!locked) __builtin_amdgcn_s_sleep(1);
-        WD_TICK(1)
-      } while (!locked);
-      WD_MARK(10)
-      asm volatile("" ::: "memory");
-      int st = kUnitLoading, nx = 0, ni = 0;
-      if (lane < kBufs) {
-        st = flag_load(&lds.ctx[lane].state);
-        nx = flag_load(&lds.ctx[lane].next);
-        ni = flag_load(&lds.ctx[lane].n_items);
-      }
-      const uint64_t avail = __ballot(lane < kBufs && st == kUnitReady && nx < ni);
-      const bool units_left = flag_load(&lds.no_more_units) == 0;
-      const uint64_t free_bufs = __ballot(lane < kBufs && st == kUnitFree);
-      const uint64_t loading = __ballot(lane < kBufs && st == kUnitLoading);
-      int b = -1, idx = 0, cnt = 0;
-      bool fill = false;
-      if (avail != 0ull) {
-        b = (int)__builtin_ctzll(avail);
-        idx = __builtin_amdgcn_readlane(nx, b);
-        cnt = min(n_free - got, __builtin_amdgcn_readlane(ni, b) - idx);
-        if (lane == 0) flag_store(&lds.ctx[b].next, idx + cnt);
-      } else if (units_left && free_bufs != 0ull) {
-        b = (int)__builtin_ctzll(free_bufs);
-        fill = true;
-        if (lane == 0) flag_store(&lds.ctx[b].state, kUnitLoading);
-      }
-      lsync();
-      // (Diagnostics variant -DRGBDFE_SPLIT_UNLOCK_ALL_LANES: the release as a store of the same word by every lane.  In the
-      // watchdog build it ran 4447 iterations of the stress loop without a stall where the single-lane forms stalled within
-      // 30 .. 886; in the product build it made stalls ~10x rarer, not impossible -- the effect is one of timing, the cause
-      // of the stall is still open -- and the 64-lane same-address store is not free, so it is not the default.)
-#if defined(RGBDFE_SPLIT_UNLOCK_ALL_LANES)
-      flag_store(&lds.qlock, 0);
-#else
-      if (lane == 0) atomicExch(&lds.qlock, 0);
-#endif
-      WD_MARK(11)
-      if (cnt > 0) {
-        for (int j = 0; j < cnt; ++j) {
-          const int g = (int)__builtin_ctzll(free_slots);
-          free_slots &= free_slots - 1ull;
-          if (lane / 6 == got + j) { my_g = g; my_at = idx + j; my_b = b; }
-        }
-        got += cnt;
-        continue;
-      }
-      if (fill) {
-        // the launch's units are handed out one by one, to whichever workgroup has a buffer free (pairs differ a lot in
-        // their work, neighbours alike: equal shares of the pair list would leave half the chip waiting for the rest)
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(plan.unit_counter, 1u);
-        unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-        if (unit < n_units) {
-          WD_MARK(20)
-          load_unit(b, unit);
-          WD_MARK(21)
-        } else if (lane == 0) {
-          flag_store(&lds.no_more_units, 1);
-          flag_store(&lds.ctx[b].state, kUnitFree);
-        }
-        continue;
-      }
-      if (!units_left && loading == 0ull) break;  // nothing more will come
-      if (had || got > 0) break;                  // this wave has work: it looks again after the round
-#ifdef RGBDFE_SPLIT_IDLE_EXIT   // diagnostics variant: a wave without work does not poll, it leaves (while somebody else loads or works)
-      if (loading != 0ull || free_bufs == 0ull) break;
-#endif
-      __builtin_amdgcn_s_sleep(4);                // idle: a loader is at work, or every buffer is still in use
-      WD_TICK(2)
-    }
-    SP_MARK(2)
-    SP_COUNT(12, got)
-    WD_MARK(12)
-    if (my_g >= 0) {
-      const int e2 = lane % 6;
-      const UnitCtx& cx = lds.ctx[my_b];
-      SlotS& sl = wl.slot[my_g];
-      const int k = cx.base + (int)cx.klist[my_at];
-      const uint32_t pair = cx.pair;
-      const float2 v = reinterpret_cast<const float2*>(plan.recs[(size_t)pair * (size_t)I + (size_t)k].rR)[e2];  // rR[9], rt[3]
-      reinterpret_cast<float2*>(sl.R)[e2] = v;                                                                  // -> R[9], t[3]
-#ifdef RGBDFE_PROFILE_PHASES
-      if (e2 == 0 && plan.recs[(size_t)pair * (size_t)I + (size_t)k].rn != -77) atomicAdd(&g_dbg_reopened, 1u);
-#endif
-      if (e2 == 0) {
-        const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-#pragma unroll
-        for (int i = 0; i < 9; ++i) sl.rR[i] = IR[i];  // :1137 refined = Identity
-#pragma unroll
-        for (int i = 0; i < 3; ++i) sl.rt[i] = 0.f;
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) { sl.rmask[r] = 0ull; sl.fmask[r] = 0ull; }
-        sl.rerr = 1e6;  // :1133
-        sl.rn = 0;      // :1134
-        sl.active = 1;
-        sl.round = 0;
-        sl.iter = k;
-        sl.buf = my_b;
-        sl.pair = pair;
-        sl.n_all = cx.n_all;
-        sl.thr = cx.thr;
-        sl.pmax = cx.pmax;
-        sl.fast = cx.fast;
-      }
-    }
-    lsync();
-    SP_MARK(3)
-    return had || got > 0;
-  };
-
-  unsigned wd_rounds = 0;
-  for (bool occupied = refill(); occupied; close_finished(), occupied = refill()) {
-    SP_COUNT(13, 1)
-    if (++wd_rounds > (1u << 16)) { wd_n = kSpinBound; WD_TICK(4) }   // (a wave holds at most a few thousand iterations' rounds)
-    // ================================ one pass of the refinement loop (:1140) for every active slot
-    // ---- scorings (:1148), one after the other (lane = match), each followed by its error sum
-    WD_MARK(30)
-    uint64_t act = __ballot(lane < kSlots && wl.slot[min(lane, kSlots - 1)].active != 0);
-    while (act != 0ull) {
-      const int g = (int)__builtin_ctzll(act);
-      act &= act - 1ull;
-      SlotS& sl = wl.slot[g];
-      float curR[9], curt[3];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) curR[i] = sl.R[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) curt[i] = sl.t[i];
-      const int n_all = __builtin_amdgcn_readfirstlane(sl.n_all);
-      const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.thr);
-      const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.pmax)));
-      const float* __restrict__ M = lds.M[__builtin_amdgcn_readfirstlane(sl.buf)];
-      // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever its error
-      // is (:1154, :1160): the scorer may stop counting as soon as that is certain
-      const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
-      uint64_t inl_mask[kRounds];
-      int n_inl;
-      double sum;
-      score_b(curR, curt, M, n_all, need, rc, wl.u.sc, pmax, inl_mask, n_inl, sum);
-      if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) sl.cmask[r] = inl_mask[r];
-        sl.cn = n_inl;
-        sl.csum = sum;
-      }
-      SP_COUNT(14, 1)
-    }
-    lsync();
-    SP_MARK(4)
-    // ---- the loop's bookkeeping (:1154-1166), lane = slot
-    bool still = false;
-    if (fresh(lane) < kSlots) {
-      SlotS& sl = wl.slot[fresh(lane)];
-      if (sl.active) {
-        const int n_inl = sl.cn, rn = sl.rn;
-        const uint32_t thr = sl.thr;
-        const uint32_t need = max(thr, (uint32_t)rn);
-        // mean_error = 1e9 below 3 inliers (:1012-1014); a count below `need` is rejected by the count
-        const double err_mine = !((uint32_t)n_inl < need || n_inl < 3) ? sqrt(sl.csum / (double)n_inl) : 1e9;  // :1016-1017
-        float max_dist_f = rc.max_dist_m;
-        asm volatile("" : "+v"(max_dist_f));  // (kept out of the loop-invariant registers: they are scarce)
-        if (!((uint32_t)n_inl < thr || err_mine > (double)max_dist_f)) {  // :1154
-          if (n_inl >= rn && err_mine <= sl.rerr) {               // :1160
-            still = (n_inl != rn);                                // :1166
-            const UnitCtx& cx = lds.ctx[sl.buf];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sl.rR[i] = sl.R[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) sl.rt[i] = sl.t[i];
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) {
-              const uint64_t m = sl.cmask[r];
-              sl.rmask[r] = m;
-              // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
-              sl.fmask[r] = m & cx.w_nonzero[r];
-            }
-            sl.rn = n_inl;
-            sl.rerr = err_mine;
+            for (int r = 0; r < kRounds; ++r) sl.cmask[r] = inl_mask[r];
+            sl.cn = n_inl;
+            sl.csum = sum;
           }
-        }
-        if (sl.round == 18) still = false;  // the 19th pass was the last one (:1140)
-        sl.round++;
-        sl.active = still ? 1 : 0;
-      }
-    }
-    uint64_t refit = __ballot(still);
-    lsync();
-    SP_MARK(5)
-    if (refit == 0ull) continue;
-    // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side ...
-    // (the unscaled division of the recurrence needs every slot's pair inside its window)
-    const bool all_fast = __ballot(still && wl.slot[min(lane, kSlots - 1)].fast == 0) == 0ull;
-    int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
-    {
-      const uint64_t ones[kRounds] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
-      uint64_t todo = refit;
-      while (todo != 0ull) {
-        const int g = (int)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        SlotS& sl = wl.slot[g];
-        uint64_t m5[kRounds];
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.fmask[r]);
-        int k256_g;
-        const int n_g = fit_compact(g, m5, ones, wl.u.fit, k256_g, fresh(lane));
-        if (lane / 9 == g) { n_mine = n_g; k256_mine = k256_g; }
-        n_max = max(n_max, n_g);
-        n_min = min(n_min, n_g);
-      }
-    }
-    lsync();
-    SP_MARK(6)
-    {
-      const int lane_here = fresh(lane);
-      const int s = min(lane_here / 9, kSlots - 1), x = lane_here % 9;
-      const float* __restrict__ M = lds.M[wl.slot[s].buf];  // (per lane: the records of the lane's slot's unit)
-      float C, m1, m2;
-      if (all_fast) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
-      else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
-      // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox
-      if (lane_here < 9 * kSlots && ((refit >> s) & 1ull)) {
-        float* __restrict__ in = lds.svd_in[wave * kSlots + s];
-        in[x] = C;
-        if (x < 3) in[9 + x] = m1;
-        if (x % 3 == 0) in[12 + x / 3] = m2;
-      }
-    }
-    lsync();
-    SP_MARK(7)
-    // ---- ... then their 3x3 SVDs, combined over the workgroup: post the requests, then serve whatever is pending
-    // (every wave's, this one's included) if no other wave is serving, else wait for the server
-    const int my_req = wave * kSlots + min(lane, kSlots - 1);
-    if (lane < kSlots && ((refit >> lane) & 1ull)) flag_store(&lds.req[my_req], 1);
-    lsync();
-    WD_MARK(40)
-    for (;;) {
-      const bool pending = lane < kSlots && flag_load(&lds.req[my_req]) != 0;
-      if (__ballot(pending) == 0ull) break;
-      int got = 0;
-      if (lane == 0) got = atomicCAS(&lds.lock, 0, 1) == 0 ? 1 : 0;
-      got = __builtin_amdgcn_readfirstlane(got);
-      if (got) {
-        SP_MARK(8)
-        asm volatile("" ::: "memory");
-        const bool p = lane < kStreamSlots && flag_load(&lds.req[lane]) == 1;
-        if (__ballot(p) != 0ull) {
-          Tfc mine;
-          mine.reset();  // lanes without a request: the zero matrix (no rotation, one sweep)
-          if (p) {
-            const float* __restrict__ in = lds.svd_in[lane];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) mine.C[i] = in[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { mine.m1[i] = in[9 + i]; mine.m2[i] = in[12 + i]; }
-          }
-          float fR[9], ft[3];
-          tfc_get_transformation(mine, fR, ft);
-          const bool fnan = has_nan12(fR, ft);
-          if (p) {
-            SlotS& sl = lds.w[lane / kSlots].slot[lane % kSlots];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sl.R[i] = fR[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) sl.t[i] = ft[i];
-            if (fnan) sl.active = 0;  // :1144
-          }
-          lsync();  // the transforms are in LDS before the flags say so
-          if (p) flag_store(&lds.req[lane], 0);
-          SP_COUNT(11, __popcll(__ballot(p)))
         }
         lsync();
-#if defined(RGBDFE_SPLIT_UNLOCK_ALL_LANES)
-        flag_store(&lds.lock, 0);
-#else
-        if (lane == 0) atomicExch(&lds.lock, 0);
-#endif
-        SP_COUNT(15, 1)
-        SP_MARK(9)
-      } else {
-        __builtin_amdgcn_s_sleep(2);
+        // ---- the loop's bookkeeping (:1154-1166), lane = slot
+        bool still = false;
+        if (fresh(lane) < kWaveSlots) {
+          SlotS& sl = mine[fresh(lane)];
+          if (sl.active == kSlotActive) {
+            const int n_inl = sl.cn, rn = sl.rn;
+            const uint32_t thr = sl.thr;
+            const uint32_t need = max(thr, (uint32_t)rn);
+            // mean_error = 1e9 below 3 inliers (:1012-1014); a count below `need` is rejected by the count
+            const double err_mine = !((uint32_t)n_inl < need || n_inl < 3) ? sqrt(sl.csum / (double)n_inl) : 1e9;  // :1016-1017
+            float max_dist_f = rc.max_dist_m;
+            asm volatile("" : "+v"(max_dist_f));  // (kept out of the loop-invariant registers: they are scarce)
+            if (!((uint32_t)n_inl < thr || err_mine > (double)max_dist_f)) {  // :1154
+              if (n_inl >= rn && err_mine <= sl.rerr) {               // :1160
+                still = (n_inl != rn);                                // :1166
+                const UnitCtx& cx = lds.ctx[sl.buf];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sl.rR[i] = sl.R[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sl.rt[i] = sl.t[i];
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) {
+                  const uint64_t m = sl.cmask[r];
+                  sl.rmask[r] = m;
+                  // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
+                  sl.fmask[r] = m & cx.w_nonzero[r];
+                }
+                sl.rn = n_inl;
+                sl.rerr = err_mine;
+              }
+            }
+            if (sl.round == 18) still = false;  // the 19th pass was the last one (:1140)
+            sl.round++;
+            if (still) {
+              sl.active = kSlotActive;
+            } else {  // the iteration has left its loop: the outcome record, from the lane that holds the slot
+              write_record(sl);
+              sl.active = kSlotRecorded;
+            }
+          }
+        }
+        const uint64_t refit = __ballot(still);
+        lsync();
+        if (refit != 0ull) {
+          // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side; their SVDs are
+          // the server's, next half-round
+          // (the unscaled division of the recurrence needs every slot's pair inside its window)
+          const bool all_fast = __ballot(still && mine[min(lane, kWaveSlots - 1)].fast == 0) == 0ull;
+          int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
+          {
+            const uint64_t ones[kRounds] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+            uint64_t todo = refit;
+            while (todo != 0ull) {
+              const int j = (int)__builtin_ctzll(todo);
+              todo &= todo - 1ull;
+              SlotS& sl = mine[j];
+              uint64_t m5[kRounds];
+#pragma unroll
+              for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.fmask[r]);
+              int k256_j;
+              const int n_j = fit_compact(j, m5, ones, wl.u.fit, k256_j, fresh(lane));
+              if (lane / 9 == j) { n_mine = n_j; k256_mine = k256_j; }
+              n_max = max(n_max, n_j);
+              n_min = min(n_min, n_j);
+            }
+          }
+          lsync();
+          {
+            const int lane_here = fresh(lane);
+            const int s = min(lane_here / 9, kWaveSlots - 1), x = lane_here % 9;
+            const float* __restrict__ M = lds.M[mine[s].buf];  // (per lane: the records of the lane's slot's unit)
+            float C, m1, m2;
+            if (all_fast) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
+            else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
+            // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox
+            if (lane_here < 9 * kWaveSlots && ((refit >> s) & 1ull)) {
+              float* __restrict__ in = lds.svd_in[(int)(&mine[s] - lds.slot)];
+              in[x] = C;
+              if (x < 3) in[9 + x] = m1;
+              if (x % 3 == 0) in[12 + x / 3] = m2;
+            }
+          }
+        }
       }
-      WD_TICK(3)
+      lds_barrier();
+      if (__builtin_amdgcn_readfirstlane(lds.quit) != 0) break;
     }
-    WD_RESET
-    asm volatile("" ::: "memory");
-    SP_MARK(8)
+    return;
   }
-  WD_MARK(99)
-#ifdef RGBDFE_PROFILE_PHASES
-  SP_MARK(10)
-  if (lane == 0) {
-    const unsigned row = atomicAdd(&g_split_count, 1u) % kSplitLogWaves;
-    for (int i = 0; i < 22; ++i) g_split_log[row][i] = sp[i];
-    g_split_log[row][22] = sp_rt0;
-    g_split_log[row][23] = __builtin_amdgcn_s_memrealtime();
-    g_split_log[row][24] = (unsigned long long)blockIdx.x * 8ull + (unsigned long long)wave;
-    g_split_log[row][25] = sp[13] != 0 ? 1ull : 0ull;
+
+  // ============================================================================================= the server
+  // units come off the launch's counter a block at a time; lane = unit of the block holds the unit's facts
+  uint64_t live = 0ull;        // units of the claimed block that have work and are not loaded yet
+  bool units_left = true;      // the counter has not run past the last unit yet
+  uint32_t u_pair = 0;
+  int u_kb = 0, u_ke = 0, u_nall = 0;
+  // the load in flight (issued in one half-round, awaited in the next)
+  int ld_b = -1;
+  uint32_t ld_pair = 0, ld_fast = 0;
+  int ld_kb = 0, ld_ke = 0, ld_nall = 0;
+  float ld_pmax = 0.f;
+  uint64_t ld_wnz = 0ull, ld_wv = 0ull;
+  const int batch_class1 = plan.phase_begin != 0 ? __builtin_amdgcn_readfirstlane(plan.walk[n_pairs].state) : 0;
+  const int blk = max(1, min(plan.unit_block, kWave));
+
+  // ---- the next block of units: which of them have anything to do in this launch (lane = unit)
+  auto claim_block = [&]() {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(plan.unit_counter, (uint32_t)blk);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= n_units) { units_left = false; live = 0ull; return; }
+    const int n = (int)min((uint32_t)blk, n_units - base);
+    const uint32_t unit = base + (uint32_t)min(lane, n - 1);
+    const uint32_t pair = unit / (uint32_t)plan.n_shares;
+    const int share = (int)(unit - pair * (uint32_t)plan.n_shares);
+    const int n_all = plan.prep[pair].n_all;
+    // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
+    // (the first launch of a batch: every pair is still running)
+    int pair_state = I, cls = 0;
+    if (plan.phase_begin != 0) {
+      const WalkState ws = plan.walk[pair];
+      pair_state = ws.state;
+      cls = ws.speculate;
+    } else if (plan.first_spec) {
+      cls = (int)plan.preclass[pair];
+    }
+    // class 2 (no jump of `it` so far, junk-heavy; class 1 when the batch has few such pairs: effective_class): everything
+    // that is left is recorded in this launch
+    if (cls == 1) cls = ((uint32_t)batch_class1 * 64u <= n_pairs) ? 2 : 0;
+    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, pair_state);
+    const int k_begin = plan.phase_begin + share * plan.share_iters;
+    const int k_end = min(k_begin + plan.share_iters, end);
+    // no RANSAC for this pair (node.cpp:1087, :1130), or nothing of this range is needed (any more)
+    bool have = lane < n && pair_state >= 0 && k_begin < k_end && n_all > rc.min_matches && n_all >= 4;
+    if (have) {  // ... or none of its iterations passed the pre-screen
+      const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
+      int items = 0;
+      for (int w = k_begin >> 6; w <= (k_end - 1) >> 6; ++w) {
+        uint64_t wv = vm_pair[w];
+        const int lo = w << 6;
+        if (k_begin > lo) wv &= ~0ull << (k_begin - lo);
+        if (k_end - lo < 64) wv &= (1ull << (k_end - lo)) - 1ull;
+        items += __popcll(wv);
+      }
+      have = items > 0;
+    }
+    live = __ballot(have);
+    u_pair = pair; u_kb = k_begin; u_ke = k_end; u_nall = n_all;
+  };
+
+  // ---- the next unit with work -> a free buffer: its match records global -> LDS directly (global_load_lds_dwordx4,
+  // 64 x 16 bytes per instruction), its facts and the words of the viable mask into registers.  Nothing is awaited here.
+  auto issue_load = [&]() {
+    if (ld_b >= 0) return;
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    const uint64_t free_bufs = __ballot(lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitFree);
+    if (free_bufs == 0ull) return;
+    while (live == 0ull && units_left) claim_block();
+    if (live == 0ull) return;
+    const int src = (int)__builtin_ctzll(live);
+    live &= live - 1ull;
+    const int b = (int)__builtin_ctzll(free_bufs);
+    const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)u_pair, src);
+    ld_kb = __builtin_amdgcn_readlane(u_kb, src);
+    ld_ke = __builtin_amdgcn_readlane(u_ke, src);
+    ld_nall = __builtin_amdgcn_readlane(u_nall, src);
+    ld_pair = pair;
+    ld_b = b;
+    const PairPrep* __restrict__ pp = plan.prep + pair;
+    const char* __restrict__ srcp = reinterpret_cast<const char*>(pp->M);
+    for (int i = 0; i < (kMVec + kWave - 1) / kWave; ++i) {
+      const int v = i * kWave + lane;
+      if (v < kMVec)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcp + (size_t)v * 16),
+                                         (__attribute__((address_space(3))) void*)(lds.M[b] + i * (kWave * 4)), 16, 0, 0);
+    }
+    ld_pmax = pp->pmax;
+    ld_fast = pp->fast_alpha;
+    ld_wnz = lane < kRounds ? pp->w_nonzero[lane] : 0ull;
+    const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
+    const int blk0 = ld_kb >> 6;
+    ld_wv = (blk0 + lane < plan.vmask_words && lane < kMaskLanes) ? vm_pair[blk0 + lane] : 0ull;
+    if (lane == 0) lds.ctx[b].state = kUnitLoading;
+  };
+
+  // ---- the load issued a half-round ago has arrived: the list of the unit's viable iterations, the buffer is ready
+  auto complete_load = [&]() {
+    if (ld_b < 0) return;
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the match records are in LDS, the facts in registers
+    UnitCtx& cx = lds.ctx[ld_b];
+    const int blk0 = ld_kb >> 6;
+    // lane w holds word blk0 + w of the pair's mask, cut to the range; lane = iteration builds the list
+    uint64_t wv = ld_wv;
+    {
+      const int lo = (blk0 + lane) << 6;
+      if (ld_kb > lo) wv &= (ld_kb - lo >= 64) ? 0ull : (~0ull << (ld_kb - lo));
+      if (ld_ke - lo < 64) wv &= (ld_ke - lo <= 0) ? 0ull : ((1ull << (ld_ke - lo)) - 1ull);
+    }
+    const int n_words = ((ld_ke - 1) >> 6) - blk0 + 1;  // <= kMaskLanes
+    int total = 0;
+    for (int c = 0; c < n_words; ++c) {
+      const uint64_t wc = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), c) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wv, c);
+      if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)((c << 6) + lane);
+      total += __popcll(wc);
+    }
+    uint32_t thr = (uint32_t)rc.min_matches;                                             // :1094
+    if ((double)thr > 0.75 * (double)ld_nall) thr = (uint32_t)(0.75 * (double)ld_nall);  // :1095-1098
+    if (lane < kRounds) cx.w_nonzero[lane] = ld_wnz;
+    if (lane == 0) {
+      cx.pair = ld_pair;
+      cx.n_all = ld_nall;
+      cx.thr = thr;
+      cx.pmax = ld_pmax;
+      cx.fast = (int)ld_fast;
+      cx.base = blk0 << 6;
+      cx.n_items = total;
+      cx.next = 0;
+      cx.done = 0;
+      cx.state = total > 0 ? kUnitReady : kUnitFree;
+    }
+    ld_b = -1;
+    lsync();
+  };
+
+  // ---- the 3x3 SVDs of the refits the workers left in group gs' mailbox (lane = slot): the transforms to score next
+  auto serve_svd = [&](int gs) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    const int s = gs * kGroupSlots + min(lane, kGroupSlots - 1);
+    SlotS& sl = lds.slot[s];
+    const bool p = lane < kGroupSlots && sl.iter >= 0 && sl.active == kSlotActive;
+    if (__ballot(p) == 0ull) return;
+    Tfc mine;
+    mine.reset();  // lanes without a request: the zero matrix (no rotation, one sweep)
+    if (p) {
+      const float* __restrict__ in = lds.svd_in[s];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) mine.C[i] = in[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { mine.m1[i] = in[9 + i]; mine.m2[i] = in[12 + i]; }
+    }
+    float fR[9], ft[3];
+    tfc_get_transformation(mine, fR, ft);
+    if (p) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sl.R[i] = fR[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sl.t[i] = ft[i];
+      if (has_nan12(fR, ft)) sl.active = kSlotDone;  // :1144: the iteration ends with what it has refined so far
+    }
+    lsync();
+  };
+
+  // ---- iterations of group gs that have left their refinement loop: the slot is free again, and so is the unit's
+  // buffer once all its iterations have ended
+  auto recycle = [&](int gs) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    SlotS& sl = lds.slot[gs * kGroupSlots + min(lane, kGroupSlots - 1)];
+    const bool fin = lane < kGroupSlots && sl.iter >= 0 && sl.active != kSlotActive;
+    if (__ballot(fin) == 0ull) return;
+    const int b = fin ? sl.buf : -1;
+    if (fin) {
+      if (sl.active == kSlotDone) write_record(sl);  // (ended by a NaN refit: nobody has written its record yet)
+      sl.iter = -1;
+      sl.active = kSlotDone;
+    }
+#pragma unroll
+    for (int q = 0; q < kBufs; ++q) {
+      const int c = __popcll(__ballot(b == q));
+      if (c > 0 && lane == 0) {
+        UnitCtx& cx = lds.ctx[q];
+        cx.done += c;
+        if (cx.done == cx.n_items) cx.state = kUnitFree;
+      }
+    }
+    lsync();
+  };
+
+  // ---- free slots of group gs take the next viable iterations of the resident units (any unit: a slot carries its
+  // unit's facts), the least occupied workers first; the two groups are kept level
+  auto hand_out = [&](int gs) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    int av = 0, nx = 0;
+    if (lane < kBufs) {
+      const UnitCtx& cx = lds.ctx[lane];
+      nx = cx.next;
+      av = cx.state == kUnitReady ? cx.n_items - nx : 0;
+    }
+    const int a0 = __builtin_amdgcn_readlane(av, 0), a1 = __builtin_amdgcn_readlane(av, 1), a2 = __builtin_amdgcn_readlane(av, 2);
+    const int total = a0 + a1 + a2;
+    if (total == 0) return;
+    const bool in_g = lane < kGroupSlots;
+    const bool held = in_g && lds.slot[gs * kGroupSlots + min(lane, kGroupSlots - 1)].iter >= 0;
+    const bool held_o = in_g && lds.slot[(1 - gs) * kGroupSlots + min(lane, kGroupSlots - 1)].iter >= 0;
+    const uint64_t held_m = __ballot(held), free_m = __ballot(in_g && !held);
+    const int n_held = __popcll(held_m), n_free = kGroupSlots - n_held, n_held_o = __popcll(__ballot(held_o));
+    // the share of this group: what levels the two groups (the other one takes its share in the next half-round),
+    // everything when the other group is full
+    int n_take = n_held_o == kGroupSlots ? total : (total + n_held_o - n_held + 1) / 2;
+    n_take = max(0, min(n_take, min(n_free, total)));
+    if (n_take == 0) return;
+    // order of the free slots: the one that would become its worker's (k+1)-th occupied slot comes before every (k+2)-th
+    const int w = min(lane, kGroupSlots - 1) / kWaveSlots;
+    const uint64_t wbits = ((1ull << kWaveSlots) - 1ull) << (w * kWaveSlots);
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int key = __popcll(held_m & wbits) + __popcll(free_m & wbits & below);
+    const bool is_free = in_g && !held;
+    int ord = 0;
+#pragma unroll
+    for (int L = 0; L < kWaveSlots; ++L) {
+      const uint64_t mL = __ballot(is_free && key == L);
+      if (key > L) ord += __popcll(mL);
+      if (key == L) ord += __popcll(mL & below);
+    }
+    const bool take = is_free && ord < n_take;
+    int b = 0, at = 0;
+    if (take) {
+      const int n0 = __builtin_amdgcn_readlane(nx, 0), n1 = __builtin_amdgcn_readlane(nx, 1), n2 = __builtin_amdgcn_readlane(nx, 2);
+      if (ord < a0) { b = 0; at = n0 + ord; }
+      else if (ord < a0 + a1) { b = 1; at = n1 + (ord - a0); }
+      else { b = 2; at = n2 + (ord - a0 - a1); }
+    }
+    if (lane < kBufs) {  // items taken from buffer `lane`
+      const int before = lane == 0 ? 0 : (lane == 1 ? a0 : a0 + a1);
+      lds.ctx[lane].next = nx + max(0, min(av, n_take - before));
+    }
+    if (take) {
+      const UnitCtx& cx = lds.ctx[b];
+      SlotS& sl = lds.slot[gs * kGroupSlots + lane];
+      const int k = cx.base + (int)cx.klist[at];
+      const uint32_t pair = cx.pair;
+      const float2* __restrict__ hyp = reinterpret_cast<const float2*>(plan.recs[(size_t)pair * (size_t)I + (size_t)k].rR);  // rR[9], rt[3]
+      float2 v[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) v[e] = hyp[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) reinterpret_cast<float2*>(sl.R)[e] = v[e];  // -> R[9], t[3]
+      const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sl.rR[i] = IR[i];  // :1137 refined = Identity
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sl.rt[i] = 0.f;
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) { sl.rmask[r] = 0ull; sl.fmask[r] = 0ull; }
+      sl.rerr = 1e6;  // :1133
+      sl.rn = 0;      // :1134
+      sl.active = kSlotActive;
+      sl.round = 0;
+      sl.iter = k;
+      sl.buf = b;
+      sl.pair = pair;
+      sl.n_all = cx.n_all;
+      sl.thr = cx.thr;
+      sl.pmax = cx.pmax;
+      sl.fast = cx.fast;
+    }
+    lsync();
+  };
+
+  // the first unit before the first half-round (the workers start with group 0)
+  issue_load();
+  complete_load();
+  hand_out(0);
+  issue_load();
+  lds_barrier();
+  for (int h = 0;; ++h) {
+    const int gs = 1 - (h & 1);   // the group the workers do NOT touch in this half-round
+    serve_svd(gs);
+    recycle(gs);
+    complete_load();
+    hand_out(gs);
+    issue_load();
+    {
+      const int lane = fresh(threadIdx.x & (kWave - 1));
+      const bool held = lane < kStreamSlots && lds.slot[min(lane, kStreamSlots - 1)].iter >= 0;
+      const bool items = lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitReady &&
+                         lds.ctx[min(lane, kBufs - 1)].next < lds.ctx[min(lane, kBufs - 1)].n_items;
+      const bool more = __ballot(held || items) != 0ull || ld_b >= 0 || live != 0ull || units_left;
+      if (!more && lane == 0) lds.quit = 1;
+      lds_barrier();
+      if (!more) break;
+    }
   }
-#endif
 }
 
 void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan,
@@ -1003,62 +919,3 @@ int ransac_split_words_per_pair(int ransac_iterations) {
 int ransac_split_max_share() { return kMaxShare; }
 
 }  // namespace rgbdfe
-
-#ifdef RGBDFE_PROFILE_PHASES
-// diagnostics build only (librgbdfe_prof.so): wall cycles per phase summed over the refinement kernel's waves
-extern "C" int rgbdfe_debug_reopened() {
-  unsigned n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_dbg_reopened), sizeof(n)) != hipSuccess) return -1;
-  return (int)n;
-}
-extern "C" int rgbdfe_debug_split_rows(unsigned long long* out, unsigned max_rows) {
-  unsigned n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_split_count), sizeof(n)) != hipSuccess) return -1;
-  if (n > rgbdfe::kSplitLogWaves) n = rgbdfe::kSplitLogWaves;
-  if (n > max_rows) n = max_rows;
-  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(rgbdfe::g_split_log), (size_t)n * 26 * 8) != hipSuccess) return -1;
-  return (int)n;
-}
-extern "C" int rgbdfe_debug_split_totals(unsigned long long* out32, int reset) {
-  if (out32) {
-    unsigned n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_split_count), sizeof(n)) != hipSuccess) return -1;
-    if (n > rgbdfe::kSplitLogWaves) n = rgbdfe::kSplitLogWaves;
-    std::vector<unsigned long long> rows((size_t)n * 26);
-    if (n && hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(rgbdfe::g_split_log), rows.size() * 8) != hipSuccess) return -1;
-    for (int i = 0; i < 32; ++i) out32[i] = 0;
-    for (unsigned r = 0; r < n; ++r)
-      for (int i = 0; i < 26; ++i) out32[i] += rows[(size_t)r * 26 + i];
-  }
-  if (reset) {
-    const unsigned zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_count), &zero, sizeof(zero)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif
-
-// waves of refinement launches that gave up on a spin wait since the process started (the phases concerned were recorded
-// by the fallback launch); -1 = could not be read
-extern "C" int rgbdfe_debug_split_gave_up() {
-  unsigned n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(rgbdfe::g_split_gave_up), sizeof(n)) != hipSuccess) return -1;
-  return (int)n;
-}
-
-// tests: make the next n refinement launches of this device give up at once (their phases then come from the fallback launch)
-extern "C" int rgbdfe_debug_split_sabotage(int n) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_sabotage), &n, sizeof(n)) == hipSuccess ? 0 : -1;
-}
-
-#ifdef RGBDFE_SPLIT_WATCHDOG
-// diagnostics build only: the watchdog record (word 0 = the site of the wait that never ended, 0 = none), optionally cleared
-extern "C" int rgbdfe_debug_watchdog(unsigned int* out64, int reset) {
-  if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(rgbdfe::g_wd), 64 * sizeof(unsigned int)) != hipSuccess) return -1;
-  if (reset) {
-    unsigned int z[64] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_wd), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif

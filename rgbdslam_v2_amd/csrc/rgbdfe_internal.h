@@ -116,11 +116,6 @@ struct RecordPlan {
   const PairPrep* prep = nullptr;  // [pair], every mode
   double* ec_pool = nullptr;  // every mode: select_ransac_ec_region_bytes() per launched wave (the inlier errors of
                               // a refinement round's scorings, read back lane = slot by the sequential error sums)
-  // kRecord as the FALLBACK behind a split-path refinement launch (RGBDFE_RANSAC_SPLIT=1): the launch does its phase only
-  // when *only_if != 0 (the refinement kernel gave up: a spin wait reached its bound), and then takes the pairs'
-  // pre-classification back (the walk that follows must not expect more iterations than this kernel records)
-  const int32_t* only_if = nullptr;
-  uint8_t* clear_preclass = nullptr;
 };
 size_t select_ransac_ec_region_bytes();
 // ransac_split.hip: the recording stage as a hypothesis kernel (lane = iteration) + a refinement kernel over the viable
@@ -143,8 +138,8 @@ struct SplitPlan {
                                // records ALL iterations of these pairs (first_spec) instead of the first phase only
   int preclass_iters = 0;      // the first phase's length (14), 0 = no pre-classification
   uint32_t* unit_counter = nullptr;  // zero at launch: the refinement kernel's workgroups take their units off it
-  int32_t* gave_up = nullptr;        // set by a wave whose spin wait reached its bound (the wave ends): the launch's results are
-                                     // void, the guarded select_ransac_kernel<kRecord> behind it records the phase instead
+  int unit_block = 1;          // units a workgroup's server takes off the counter at a time (lane = unit: units without work
+                               // cost nothing); 1 while every unit has work, larger for the later phases of a plan
   int phase_index = 0;         // > 0: the launch has work only when walk[n_pairs].best_n == phase_index (set by the walk of the phase before)
   int first_spec = 0;          // this launch is the first phase of a phased plan: preclass-2 pairs record [0, spec_end)
 };

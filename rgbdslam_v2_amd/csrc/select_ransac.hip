@@ -695,10 +695,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   const bool sub_b = MODE == kRecord && in_pair >= plan.n_chunks;
   const uint32_t unit = sub_b ? in_pair - plan.n_chunks : in_pair;  // share index inside the pair's sub-grid
   if (pair >= n_pairs) return;
-  if (MODE == kRecord && plan.only_if != nullptr) {   // fallback launch behind the split path's refinement kernel
-    if (__builtin_amdgcn_readfirstlane(*plan.only_if) == 0) return;
-    if (plan.clear_preclass != nullptr && threadIdx.x == 0) plan.clear_preclass[pair] = 0;
-  }
   // record / replay bookkeeping: walk[pair].state >= 0 is an upper bound of the iterations the pair can still need,
   // < 0 means its loop has ended
   const int pair_state = MODE != kRecord ? 0 : (plan.phase_begin == 0 ? rc.ransac_iterations : plan.walk[pair].state);
@@ -1324,16 +1320,11 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
   }
 }
 
-// Which recording stage a batch takes.  ransac_split.hip's hypothesis + streaming refinement kernels are 1.5x faster on
-// configs[1] and bit-identical, but their persistent workgroups hand work out through LDS spin locks, and in the LATENCY
-// regime (single-phase plans: at most 256 pairs per batch, many idle waves polling the queue) about one launch in 10^4
-// stalled: a wave that had just taken or released the queue lock stopped making progress (watchdog
-// evidence, what was ruled out).  Two consequences: (1) every spin wait of that kernel is bounded, a wave that reaches the
-// bound raises a flag and ends, and a guarded launch of the one-kernel stage (select_ransac_kernel<kRecord>) behind it
-// records the phase instead -- a launch can be slow, never wrong, never endless; (2) by default only PHASED plans (more
-// than 256 pairs per batch) take the split path -- 37 000 consecutive 4000-pair batches (150 M pairs) ran without a single
-// wave giving up -- and small batches keep the one-kernel stage, which has no waits at all.
-//   RGBDFE_RANSAC_SPLIT unset: as above; = 1: the split path for every batch; = 0: never.
+// Which recording stage a batch takes.  ransac_split.hip's hypothesis + refinement kernels (bit-identical to the
+// one-kernel stage select_ransac_kernel<kRecord>) are the default for every record / replay plan; the refinement kernel's
+// waves synchronise through one hardware barrier per half-round and nothing else, so there is no batch shape it has to be
+// kept away from (round 4's streaming version, with LDS spin locks, stalled on small batches and was gated to phased plans).
+//   RGBDFE_RANSAC_SPLIT unset or = 1: the split path; = 0: the one-kernel stage (A/B runs).
 static int ransac_split_mode() {
   static const int mode = getenv("RGBDFE_RANSAC_SPLIT") ? (atoi(getenv("RGBDFE_RANSAC_SPLIT")) != 0 ? 1 : 0) : -1;
   return mode;
@@ -1357,7 +1348,7 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
   plan.n_phases_total = n_phases;  // a single-phase plan (small batches: full speculation) always pre-screens
   const int I = rc.ransac_iterations;
   const int split_mode = ransac_split_mode();
-  const bool split = split_mode == 1 || (split_mode < 0 && n_phases > 2);
+  const bool split = split_mode != 0;
   // walk[n_pairs]: the batch's counters (class-1 pairs; split path: unit counters, "still running" flag), zero at the start
   // (the split path's hypothesis kernel does it itself)
   if (!split) (void)hipMemsetAsync(walk + n_pairs, 0, sizeof(WalkState), stream);
@@ -1386,9 +1377,30 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
 #endif
     const bool first_spec = split && sp.preclass_iters > 0 && p == 0 && I > end;
     const int cover = (spec || first_spec) ? I : end;
-    // the one-kernel recording launch of this phase (the default path; behind the split path's refinement kernel: the
-    // guarded fallback)
-    auto launch_record_phase = [&](const int32_t* only_if, uint8_t* clear_preclass) {
+    if (split) {
+      // units = (pair, share of the range): latency batches cut a pair's range into shares of 4 x chunk_iters iterations
+      // so that a handful of pairs still fills the chip; throughput batches (chunk_iters >= 28: more than 1280 pairs)
+      // keep a pair's range together, up to the 512 iterations a unit's list holds
+      int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * 4;
+      if (share > ransac_split_max_share()) share = ransac_split_max_share();
+      sp.phase_begin = begin; sp.phase_end = end; sp.spec_end = cover; sp.first_spec = first_spec ? 1 : 0;
+      sp.n_shares = cover > begin ? (cover - begin + share - 1) / share : 1;
+      sp.share_iters = cover > begin ? (cover - begin + sp.n_shares - 1) / sp.n_shares : share;
+      // (the launch's unit counter: a spare word of walk[n_pairs], zeroed by the hypothesis kernel; a plan has at most 4 phases)
+      sp.unit_counter = reinterpret_cast<uint32_t*>(&walk[n_pairs].it) + p;
+      sp.phase_index = p;
+      // the first launch of a batch: every unit has work, the workgroups take them one by one (pairs differ a lot in their
+      // work).  Later phases: most pairs have ended -- a workgroup looks at a block of units at once (lane = unit) and
+      // loads the few that still run
+      {
+        const uint32_t units = n_pairs * (uint32_t)sp.n_shares;
+        const uint32_t wgs = 2u * (uint32_t)ransac_split_init();
+        const uint32_t per_wg = units / (wgs > 0 ? wgs : 1u);
+        sp.unit_block = p == 0 ? 1 : (int)(per_wg < 2u ? 1u : (per_wg > 32u ? 16u : per_wg / 2u));
+      }
+      if (cover > begin) launch_ransac_refine(n_pairs, rc, sp, stream);
+    } else {
+      // the one-kernel recording launch of this phase
       // sub-grid A: the phase in ceil(length / chunk) equal shares (a short last wave would be the launch's straggler)
       const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
       plan.n_chunks = (uint32_t)n_chunks;
@@ -1400,38 +1412,10 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
       plan.phase_begin = begin;
       plan.phase_end = end;
       plan.spec_end = cover_rec;
-      plan.only_if = only_if;
-      plan.clear_preclass = clear_preclass;
       if (cover_rec > begin)
         hipLaunchKernelGGL(select_ransac_kernel<kRecord>,
                            dim3(8u * ((n_pairs + 7u) / 8u) * (plan.n_chunks + plan.n_chunks_b)), dim3(kWave), 0, stream, work,
                            results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
-      plan.only_if = nullptr;
-      plan.clear_preclass = nullptr;
-    };
-    if (split) {
-      // units = (pair, share of the range): latency batches cut a pair's range into shares of 4 x chunk_iters iterations
-      // so that a handful of pairs still fills the chip; throughput batches (chunk_iters >= 28: more than 1280 pairs)
-      // keep a pair's range together, up to the 512 iterations a unit's list holds
-      int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * 4;
-      if (share > ransac_split_max_share()) share = ransac_split_max_share();
-      sp.phase_begin = begin; sp.phase_end = end; sp.spec_end = cover; sp.first_spec = first_spec ? 1 : 0;
-      sp.n_shares = cover > begin ? (cover - begin + share - 1) / share : 1;
-      sp.share_iters = cover > begin ? (cover - begin + sp.n_shares - 1) / sp.n_shares : share;
-      // (the launch's unit counter: a spare word of walk[n_pairs], zeroed with it above; a plan has at most 4 phases)
-      sp.unit_counter = reinterpret_cast<uint32_t*>(&walk[n_pairs].it) + p;
-      sp.phase_index = p;
-      // a spare word of the batch's counters (zeroed by the hypothesis kernel): "the refinement kernel gave up"
-      sp.gave_up = &walk[n_pairs].speculate;
-      if (cover > begin) {
-        launch_ransac_refine(n_pairs, rc, sp, stream);
-        // Every spin wait of the refinement kernel is bounded; a wave that reaches the bound raises gave_up and ends.  Behind
-        // it, the one-kernel recording launch of the same phase: its waves return at once unless gave_up is set, and then
-        // record the phase as the default path would (same bytes: an iteration's outcome is a pure function of its index).
-        launch_record_phase(sp.gave_up, first_spec ? sp.preclass : (uint8_t*)nullptr);
-      }
-    } else {
-      launch_record_phase(nullptr, nullptr);
     }
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, plan.sums, walk, prep, n_pairs, rc, begin,
                        end, cover, (n_phases > 2 && p == 0) ? 1 : 0, first_spec ? sp.preclass : (const uint8_t*)nullptr, p);

@@ -69,3 +69,18 @@ def test_a_sample_of_the_constants_is_rederived_by_the_oracle():
     from rgbdslam_v2_amd.dist import shard_pairs
     q0, t0 = shard_pairs(pq, pt, 0, 2)
     assert np.array_equal(q0, pq[0::2]) and len(q0) == 4000
+
+
+@pytest.mark.parametrize("gpus,world", [(8, 1), (1, 2), (2, 4)])
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus(gpus, world):
+    """a WORLD_SIZE that differs from --gpus in EITHER direction ends the run before anything is measured (with
+    WORLD_SIZE unset and --gpus N > 1 bench.py starts its N ranks itself: tests/test_gpu_bench_ranks.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE=str(world), RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "1"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and ("--gpus %d but WORLD_SIZE=%d" % (gpus, world)) in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

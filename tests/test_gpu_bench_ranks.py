@@ -82,3 +82,22 @@ def test_bench_gather_path_over_rccl_with_one_rank(gather):
     if gather == "inliers":
         assert pc["inlier_list_entries"] == pc["oracle_aggregates"]["inliers"]
         assert d["gather"]["collectives_per_step"] == 2 and 200 < d["gather"]["bytes_per_record"] < 400
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run must create the two ranks itself (it re-executes
+    under torch.distributed.run) -- invoked the way the driver invokes the N = 1 line it used to run ONE rank and print
+    n_gpus 1.  Full configs[1] workload, so the line carries the oracle check of both ranks' records."""
+    env = dict(os.environ, RGBDFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gather"]["rccl_ranks"] == 2
+    assert d["parity_check"]["checked"] and d["parity_check"]["ok"]
+    assert len(d["gather"]["rank_devices"]) == 2 and d["gather"]["rank_devices"][1].startswith("rank 1: cuda:")
+    assert d["gather"]["distinct_devices"] == 1      # (two ranks on the one GPU of the test box: the line says so)
