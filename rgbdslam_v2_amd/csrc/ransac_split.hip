@@ -15,32 +15,38 @@
 //                         bit mask of the viable iterations, their transforms (in the rR / rt fields of the iteration's
 //                         record) and the empty summaries of the others.  No slot machinery, no scoring state.
 //   ransac_refine_kernel  the refinement loops of the viable iterations only.  Persistent workgroups of 8 waves =
-//                         7 WORKERS + 1 SERVER; up to three units (pair, iteration range) are resident in LDS (their match
-//                         records, PairPrep, 8.4 KB each) and their viable iterations occupy SLOTS.  The slots form two
-//                         groups that take turns: in a half-round the workers run one pass of the refinement loop
-//                         (node.cpp:1140) for their slots of group g
+//                         7 WORKERS + 1 SERVER; up to three units (pair, iteration range) are resident in LDS (the pair's
+//                         PairPrep: match records + facts, 9 KB each) and their viable iterations occupy SLOTS (7 per
+//                         worker and group).  The slots form two groups that take turns: in a half-round the workers run
+//                         one pass of the refinement loop (node.cpp:1140) for the slots of group g
 //                           scoring          LANE = MATCH; the inliers' errors stay in LDS and the reference's strictly
-//                                            sequential error sum (node.cpp:1006) runs right behind the scoring,
+//                                            sequential error sum (node.cpp:1006) runs right behind the scoring.  Cheap
+//                                            passes (junk hypotheses end after the float prefilter): every worker scores
+//                                            its own slots.  Expensive passes (>= 24 slots with a refined set: ~140
+//                                            Cholesky solves per scoring): all 8 waves take the group's scorings one by
+//                                            one off a ticket counter (ds_add_rtn) and meet at a barrier behind them --
+//                                            fixed shares left most waves waiting for the one with the good hypotheses,
 //                           bookkeeping      LANE = SLOT (node.cpp:1154-1166),
 //                           refit            the PCL weighted-mean recurrences of the wave's slots side by side
-//                                            (9 state elements per slot),
+//                                            (9 state elements per slot, 63 lanes),
 //                         while the server does for the OTHER group everything that concerns more than one wave:
 //                           3x3 Jacobi SVD   LANE = SLOT OF THE GROUP: one SVD for every refit the workers left in the
-//                                            group's mailbox in the half-round before (at 7 lanes per wave the SVDs were
+//                                            slots' mailboxes in the half-round before (at 7 lanes per wave the SVDs were
 //                                            40 % of the recording stage's instructions),
 //                           recycling        finished iterations' slots and drained units' buffers,
-//                           hand-out         the next viable iterations of the resident units to the free slots, to the
-//                                            least occupied workers first,
-//                           unit loading     the launch's units come off a global counter (a block at a time, lane = unit:
-//                                            units whose pair has ended or whose range holds no viable iteration cost
-//                                            nothing); the records go global -> LDS directly (global_load_lds_dwordx4),
+//                           hand-out         the next viable iterations of the resident units (with their 4-point
+//                                            hypotheses) to the free slots, to the least occupied workers first,
+//                           unit loading     the launch's units come off a global counter a block at a time (lane = unit:
+//                                            units whose pair has ended cost nothing); PairPrep, the words of the viable
+//                                            mask and the next block's facts go global -> LDS directly (global_load_lds),
 //                                            issued in one half-round and awaited in the next.
-//                         ONE s_barrier per half-round is the only synchronisation between the waves of a workgroup:
-//                         the queue state is touched by the server alone, a slot by one wave at a time.  There is no spin
-//                         wait, no lock and no atomic on LDS anywhere in the kernel (round 4's streaming version handed
-//                         work out through LDS spin locks and stalled about once in 10^4 small launches; see DESIGN.md
-//                         4.2b) -- a launch cannot wait for anything but its own waves' arrival at the barrier.
-//                         LDS: 70 KB per workgroup => 2 workgroups = 16 waves per CU at <= 128 VGPRs (4 per SIMD).
+//                         s_barrier -- one per half-round, two when the scorings go out by ticket -- is the ONLY way a
+//                         wave of this kernel ever waits for another: the queue state is touched by the server alone, a
+//                         slot by one wave at a time, the ticket is a single returning add.  No spin wait, no lock, no
+//                         polling (round 4's streaming version handed work out through LDS spin locks and stalled about
+//                         twice in 10^4 small launches beside context churn): a launch cannot wait for
+//                         anything but its own waves' arrival at a hardware barrier.
+//                         LDS: 79.6 KB per workgroup => 2 workgroups = 16 waves per CU at <= 128 VGPRs (4 per SIMD).
 // Same bytes as the one-wave kernel (select_ransac_kernel<kWhole>): every float / double operation is the one
 // oracle/rgbd_oracle.c performs, in the same order (-ffp-contract=off), so every discrete RANSAC decision is the same.
 #include <stdio.h>
@@ -82,28 +88,39 @@ constexpr int kHypThreads = 256;
 constexpr int kStreamWaves = 8;                        // waves of a refinement workgroup: 7 workers + the server
 constexpr int kWorkers = kStreamWaves - 1;
 constexpr int kStreamThreads = kStreamWaves * kWave;
-constexpr int kWaveSlots = 4;                          // iterations a worker refines side by side, per group
-constexpr int kGroupSlots = kWorkers * kWaveSlots;     // slots of a group: one lane each in the server's SVD
-constexpr int kStreamSlots = 2 * kGroupSlots;
+#ifndef RGBDFE_SPLIT_WAVE_SLOTS
+#define RGBDFE_SPLIT_WAVE_SLOTS 7
+#endif
+#ifndef RGBDFE_SPLIT_BUFS
+#define RGBDFE_SPLIT_BUFS 3
+#endif
+constexpr int kWaveSlots = RGBDFE_SPLIT_WAVE_SLOTS;    // iterations a worker refines side by side, per group (7 x 9 = 63 lanes of the refit)
 static_assert(kWaveSlots <= kSlots, "the refit phase (fit_compact / fit_recurrence) holds kSlots lists per wave");
-static_assert(kStreamSlots <= kWave, "the server looks at all slots with one lane each");
-constexpr int kBufs = 3;                              // units (pair, iteration range) resident in a workgroup's LDS
+constexpr int kGroupSlots = kWorkers * kWaveSlots;     // 49 slots of a group: one lane each in the server's SVD
+constexpr int kStreamSlots = 2 * kGroupSlots;
+static_assert(kGroupSlots <= kWave, "the server looks at a group's slots with one lane each");
+static_assert(kStreamSlots <= 2 * kWave, "the server's end-of-work test looks at two slots per lane");
+#ifndef RGBDFE_SPLIT_TICKETS_FROM
+#define RGBDFE_SPLIT_TICKETS_FROM 24
+#endif
+constexpr int kTicketsFrom = RGBDFE_SPLIT_TICKETS_FROM;  // expensive scorings in a group's pass from which they go out by ticket
+constexpr int kBufs = RGBDFE_SPLIT_BUFS;              // units (pair, iteration range) resident in a workgroup's LDS
 constexpr int kMaxShare = 512;                        // iterations of a unit at most (the host cuts longer ranges)
 constexpr int kMaskLanes = kMaxShare / kWave + 1;     // words of a pair's viable mask that can overlap a unit's range
 constexpr int kMVec = RGBDFE_MAX_MATCHES * kRec / 4;  // float4s of a pair's match records
+constexpr int kPrepVec = (int)(sizeof(PairPrep) / 16);  // a pair's match records + facts as 16-byte pieces
+static_assert(sizeof(PairPrep) % 16 == 0, "PairPrep goes global -> LDS in 16-byte pieces");
 
-// one RANSAC iteration in flight (see select_ransac.hip: Slot), with the facts of its unit the scoring needs
+// one RANSAC iteration in flight (see select_ransac.hip: Slot); the facts of its unit are in the unit's buffer
 constexpr int kSlotDone = 0, kSlotActive = 1, kSlotRecorded = 2;
 struct SlotS {
-  float R[9], t[3];          // transform to score next (first the 4-point hypothesis, then the refits')
-  int n_all;                 // the unit's pair: selected matches,
-  uint32_t thr;              // inlier threshold (:1094-1098),
-  float pmax;                // largest |coordinate| of its points,
-  int fast;                  // every weight inside the window of the unscaled float division
+  union {
+    struct { float R[9], t[3]; } x;  // transform to score next (first the 4-point hypothesis, then the refits')
+    float svd_in[15];                // ... or, between a refit's recurrences and its SVD: C[9], mean1[3], mean2[3]
+  } u;
   float rR[9], rt[3];        // refined_transformation (node.cpp:1137,1163)
   uint64_t rmask[kRounds];   // refined_matches
-  uint64_t cmask[kRounds];   // inlier set of the scoring of the current round
-  uint64_t fmask[kRounds];   // refined_matches without zero weights = the input of the next refit while the slot is active
+  uint64_t cmask[kRounds];   // inlier set of the scoring of the current pass
   double rerr;               // refined_error
   double csum;               // sequential sum of the current scoring's inlier errors (node.cpp:1006)
   int rn;                    // refined_matches.size()
@@ -130,29 +147,37 @@ struct alignas(16) WaveLds {
     FitBuf fit;
   } u;
 };
-// a unit resident in LDS: its pair's facts and the viable iterations of its range, handed out in order.  Server only.
+// a unit resident in LDS: the viable iterations of its range, handed out in order.  Server only.
 constexpr int kUnitFree = 0, kUnitLoading = 1, kUnitReady = 2;
-struct UnitCtx {
+struct alignas(16) UnitCtx {
+  uint64_t mw[kMaskLanes + 1];  // the words of the pair's viable mask that overlap the range (global -> LDS with the records)
   int state;                 // kUnitFree / kUnitLoading (the records are on their way) / kUnitReady
   int next;                  // iterations handed out so far
   int done;                  // iterations whose refinement has ended; == n_items => the buffer is free again
   int n_items;
   uint32_t pair;
-  int n_all;
-  uint32_t thr;
-  float pmax;
-  int fast;
-  int base;                  // iteration index of bit 0 of the first mask word of the unit's range
-  int pad[2];
-  uint64_t w_nonzero[kRounds];
+  int kb, ke;                // the unit's iteration range
+  uint32_t thr;              // inlier threshold of the pair (:1094-1098)
+  int base;                  // iteration index of bit 0 of mw[0]
+  int pad[3];
   uint16_t klist[kMaxShare];  // the viable iterations of the unit's range, ascending, relative to `base` (< kMaxShare + 64)
 };
 struct alignas(16) StreamLds {
-  float M[kBufs][RGBDFE_MAX_MATCHES * kRec];  // the resident units' match records (see PairPrep)
-  WaveLds w[kWorkers];
+  PairPrep prep[kBufs];            // the resident units' pairs: match records + facts, as pair_prep_kernel left them
+  WaveLds w[kStreamWaves];
   SlotS slot[kStreamSlots];        // group g: slots g * kGroupSlots + worker * kWaveSlots + j
-  float svd_in[kStreamSlots][16];  // mailbox of the server's SVD: C[9], mean1[3], mean2[3] of a slot's refit
   UnitCtx ctx[kBufs];
+  // facts of the units of the block the server has taken off the counter last (lane = unit), global -> LDS like the records
+  // (a load into registers that stays in flight across the server's loop makes the compiler wait before every reuse of
+  // any register such a load might be pending on -- between the pieces of a unit's record load, for one)
+  int claim_nall[kWave];           // PairPrep::n_all
+  int claim_state[kWave];          // WalkState::state (later phases)
+  int claim_cls[kWave];            // WalkState::speculate (later phases) / the pre-classification byte (first launch)
+  // the scorings of a half-round: the group's active slots as a list, taken one by one by whichever wave is free
+  uint8_t act_list[2][kWave];
+  int n_act[2];
+  int task[2];                     // next entry of act_list[g] to score (ds_add_rtn: a ticket, nobody waits for anybody)
+  int tickets[2];                  // the group's next pass hands its scorings out by ticket (many expensive ones) / by owner
   int quit;                        // set by the server: every unit of the launch has been refined
   int pad[3];
 };
@@ -413,10 +438,11 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int I = rc.ransac_iterations;
 
-  if (wave == 0) {
-    if (lane < kStreamSlots) { lds.slot[lane].active = kSlotDone; lds.slot[lane].iter = -1; lds.slot[lane].buf = 0; }
-    if (lane < kBufs) { lds.ctx[lane].state = kUnitFree; lds.ctx[lane].next = 0; lds.ctx[lane].done = 0; lds.ctx[lane].n_items = 0; }
-    if (lane == 0) lds.quit = 0;
+  if (wave < 2) {
+    const int s = wave * kWave + lane;
+    if (s < kStreamSlots) { lds.slot[s].active = kSlotDone; lds.slot[s].iter = -1; lds.slot[s].buf = 0; }
+    if (wave == 0 && lane < kBufs) { lds.ctx[lane].state = kUnitFree; lds.ctx[lane].next = 0; lds.ctx[lane].done = 0; lds.ctx[lane].n_items = 0; }
+    if (wave == 0 && lane == 0) lds.quit = 0;
   }
   lds_barrier();
 
@@ -436,126 +462,151 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     plan.sums[at] = IterSum{sl.rerr, sl.rn, 0};
   };
 
+  // ---- the scorings (:1148) of group g's pass: every wave takes the next active slot off the group's list until there is
+  // none left (a ticket per scoring: scorings differ a lot in their cost -- a junk hypothesis ends after the float
+  // prefilter, a good one runs ~140 Cholesky solves -- so fixed shares would leave most waves waiting at the barrier)
+  // ---- one scoring (:1148) of slot sl by this wave (lane = match): the inlier set, its size and error sum into the slot
+  auto score_slot = [&](SlotS& sl) {
+    WaveLds& wl = lds.w[wave];
+    float curR[9], curt[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) curR[i] = sl.u.x.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) curt[i] = sl.u.x.t[i];
+    const int b = __builtin_amdgcn_readfirstlane(sl.buf);
+    const PairPrep& pp = lds.prep[b];
+    const int n_all = __builtin_amdgcn_readfirstlane(pp.n_all);
+    const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.ctx[b].thr);
+    const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pp.pmax)));
+    // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever its error
+    // is (:1154, :1160): the scorer may stop counting as soon as that is certain
+    const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
+    uint64_t inl_mask[kRounds];
+    int n_inl;
+    double sum;
+    score_b(curR, curt, pp.M, n_all, need, rc, wl.u.sc, pmax, inl_mask, n_inl, sum);
+    // (the lane tests inside loops are opaque to the compiler, each on its own: seeing the same `lane == 0` twice in a
+    // loop body it threads the first branch into the second and splits the loop by lane -- in the ticket loop below lane 0
+    // left with its ticket and the other 63 lanes stayed behind in a copy whose readfirstlane never saw a new ticket: an
+    // endless loop, found on the GPU)
+    if (fresh(threadIdx.x & (kWave - 1)) == 0) {
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) sl.cmask[r] = inl_mask[r];
+      sl.cn = n_inl;
+      sl.csum = sum;
+    }
+  };
+  // ---- the scorings of group g's pass when they are expensive (good hypotheses: ~140 Cholesky solves each, against a
+  // junk hypothesis that ends after the float prefilter): every wave takes the next active slot off the group's list
+  // until there is none left -- a ticket per scoring, nobody waits for anybody; fixed shares would leave most waves
+  // waiting at the barrier for the one with the most good hypotheses
+  auto score_tickets = [&](int g) {
+    const int n_act = __builtin_amdgcn_readfirstlane(lds.n_act[g]);
+    for (;;) {
+      int t = 0;
+      if (fresh(threadIdx.x & (kWave - 1)) == 0) t = atomicAdd(&lds.task[g], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= n_act) break;
+      score_slot(lds.slot[g * kGroupSlots + (int)lds.act_list[g][t]]);
+    }
+  };
+
   if (wave < kWorkers) {
     // =========================================================================================== a worker
     WaveLds& wl = lds.w[wave];
     lds_barrier();   // (the server's prologue: the first unit's iterations are in group 0's slots)
     for (int h = 0;; ++h) {
+      const int g = h & 1;
       const int lane = fresh(threadIdx.x & (kWave - 1));
-      SlotS* const mine = &lds.slot[(h & 1) * kGroupSlots + wave * kWaveSlots];   // this half-round's slots of this wave
-      // ================================ one pass of the refinement loop (:1140) for every active slot
-      // ---- scorings (:1148), one after the other (lane = match), each followed by its error sum
-      uint64_t act = __ballot(lane < kWaveSlots && mine[min(lane, kWaveSlots - 1)].active == kSlotActive);
-      if (act != 0ull) {
+      SlotS* const mine = &lds.slot[g * kGroupSlots + wave * kWaveSlots];   // bookkeeping and refits: this wave's slots
+      // ================================ one pass of the refinement loop (:1140) for every active slot of group g
+      if (__builtin_amdgcn_readfirstlane(lds.tickets[g]) != 0) {
+        score_tickets(g);
+        lds_barrier();   // every scoring of the pass is done
+      } else {           // cheap scorings: every worker scores its own slots and goes on without meeting the others
+        uint64_t act = __ballot(lane < kWaveSlots && mine[min(lane, kWaveSlots - 1)].active == kSlotActive);
         while (act != 0ull) {
           const int j = (int)__builtin_ctzll(act);
           act &= act - 1ull;
-          SlotS& sl = mine[j];
-          float curR[9], curt[3];
+          score_slot(mine[j]);
+        }
+        lsync();
+      }
+      // ---- the loop's bookkeeping (:1154-1166), lane = slot
+      bool still = false;
+      if (fresh(lane) < kWaveSlots) {
+        SlotS& sl = mine[fresh(lane)];
+        if (sl.active == kSlotActive) {
+          const int n_inl = sl.cn, rn = sl.rn;
+          const uint32_t thr = lds.ctx[sl.buf].thr;
+          const uint32_t need = max(thr, (uint32_t)rn);
+          // mean_error = 1e9 below 3 inliers (:1012-1014); a count below `need` is rejected by the count
+          const double err_mine = !((uint32_t)n_inl < need || n_inl < 3) ? sqrt(sl.csum / (double)n_inl) : 1e9;  // :1016-1017
+          float max_dist_f = rc.max_dist_m;
+          asm volatile("" : "+v"(max_dist_f));  // (kept out of the loop-invariant registers: they are scarce)
+          if (!((uint32_t)n_inl < thr || err_mine > (double)max_dist_f)) {  // :1154
+            if (n_inl >= rn && err_mine <= sl.rerr) {               // :1160
+              still = (n_inl != rn);                                // :1166
 #pragma unroll
-          for (int i = 0; i < 9; ++i) curR[i] = sl.R[i];
+              for (int i = 0; i < 9; ++i) sl.rR[i] = sl.u.x.R[i];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) curt[i] = sl.t[i];
-          const int n_all = __builtin_amdgcn_readfirstlane(sl.n_all);
-          const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.thr);
-          const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.pmax)));
-          const float* __restrict__ M = lds.M[__builtin_amdgcn_readfirstlane(sl.buf)];
-          // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever its error
-          // is (:1154, :1160): the scorer may stop counting as soon as that is certain
-          const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
-          uint64_t inl_mask[kRounds];
-          int n_inl;
-          double sum;
-          score_b(curR, curt, M, n_all, need, rc, wl.u.sc, pmax, inl_mask, n_inl, sum);
-          if (lane == 0) {
+              for (int i = 0; i < 3; ++i) sl.rt[i] = sl.u.x.t[i];
 #pragma unroll
-            for (int r = 0; r < kRounds; ++r) sl.cmask[r] = inl_mask[r];
-            sl.cn = n_inl;
-            sl.csum = sum;
+              for (int r = 0; r < kRounds; ++r) sl.rmask[r] = sl.cmask[r];
+              sl.rn = n_inl;
+              sl.rerr = err_mine;
+            }
+          }
+          if (sl.round == 18) still = false;  // the 19th pass was the last one (:1140)
+          sl.round++;
+          if (!still) {  // the iteration has left its loop: the outcome record, from the lane that holds the slot
+            write_record(sl);
+            sl.active = kSlotRecorded;
+          }
+        }
+      }
+      const uint64_t refit = __ballot(still);
+      if (refit != 0ull) {
+        lsync();
+        // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side; their SVDs are
+        // the server's, next half-round
+        // (the unscaled division of the recurrence needs every slot's pair inside its window)
+        const bool all_fast = __ballot(still && lds.prep[mine[min(lane, kWaveSlots - 1)].buf].fast_alpha == 0u) == 0ull;
+        int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
+        {
+          uint64_t todo = refit;
+          while (todo != 0ull) {
+            const int j = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const SlotS& sl = mine[j];
+            const PairPrep& pp = lds.prep[__builtin_amdgcn_readfirstlane(sl.buf)];
+            // refined_matches without zero weights: tfc.add skips weight == 0; NaN depths never reach an inlier set
+            // (misc.cpp:712-717)
+            uint64_t m5[kRounds], nz[kRounds];
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) { m5[r] = uniform_u64(sl.rmask[r]); nz[r] = uniform_u64(pp.w_nonzero[r]); }
+            int k256_j;
+            const int n_j = fit_compact(j, m5, nz, wl.u.fit, k256_j, fresh(lane));
+            if (lane / 9 == j) { n_mine = n_j; k256_mine = k256_j; }
+            n_max = max(n_max, n_j);
+            n_min = min(n_min, n_j);
           }
         }
         lsync();
-        // ---- the loop's bookkeeping (:1154-1166), lane = slot
-        bool still = false;
-        if (fresh(lane) < kWaveSlots) {
-          SlotS& sl = mine[fresh(lane)];
-          if (sl.active == kSlotActive) {
-            const int n_inl = sl.cn, rn = sl.rn;
-            const uint32_t thr = sl.thr;
-            const uint32_t need = max(thr, (uint32_t)rn);
-            // mean_error = 1e9 below 3 inliers (:1012-1014); a count below `need` is rejected by the count
-            const double err_mine = !((uint32_t)n_inl < need || n_inl < 3) ? sqrt(sl.csum / (double)n_inl) : 1e9;  // :1016-1017
-            float max_dist_f = rc.max_dist_m;
-            asm volatile("" : "+v"(max_dist_f));  // (kept out of the loop-invariant registers: they are scarce)
-            if (!((uint32_t)n_inl < thr || err_mine > (double)max_dist_f)) {  // :1154
-              if (n_inl >= rn && err_mine <= sl.rerr) {               // :1160
-                still = (n_inl != rn);                                // :1166
-                const UnitCtx& cx = lds.ctx[sl.buf];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) sl.rR[i] = sl.R[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) sl.rt[i] = sl.t[i];
-#pragma unroll
-                for (int r = 0; r < kRounds; ++r) {
-                  const uint64_t m = sl.cmask[r];
-                  sl.rmask[r] = m;
-                  // tfc.add skips weight == 0; NaN depths never reach an inlier set (misc.cpp:712-717)
-                  sl.fmask[r] = m & cx.w_nonzero[r];
-                }
-                sl.rn = n_inl;
-                sl.rerr = err_mine;
-              }
-            }
-            if (sl.round == 18) still = false;  // the 19th pass was the last one (:1140)
-            sl.round++;
-            if (still) {
-              sl.active = kSlotActive;
-            } else {  // the iteration has left its loop: the outcome record, from the lane that holds the slot
-              write_record(sl);
-              sl.active = kSlotRecorded;
-            }
-          }
-        }
-        const uint64_t refit = __ballot(still);
-        lsync();
-        if (refit != 0ull) {
-          // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side; their SVDs are
-          // the server's, next half-round
-          // (the unscaled division of the recurrence needs every slot's pair inside its window)
-          const bool all_fast = __ballot(still && mine[min(lane, kWaveSlots - 1)].fast == 0) == 0ull;
-          int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
-          {
-            const uint64_t ones[kRounds] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
-            uint64_t todo = refit;
-            while (todo != 0ull) {
-              const int j = (int)__builtin_ctzll(todo);
-              todo &= todo - 1ull;
-              SlotS& sl = mine[j];
-              uint64_t m5[kRounds];
-#pragma unroll
-              for (int r = 0; r < kRounds; ++r) m5[r] = uniform_u64(sl.fmask[r]);
-              int k256_j;
-              const int n_j = fit_compact(j, m5, ones, wl.u.fit, k256_j, fresh(lane));
-              if (lane / 9 == j) { n_mine = n_j; k256_mine = k256_j; }
-              n_max = max(n_max, n_j);
-              n_min = min(n_min, n_j);
-            }
-          }
-          lsync();
-          {
-            const int lane_here = fresh(lane);
-            const int s = min(lane_here / 9, kWaveSlots - 1), x = lane_here % 9;
-            const float* __restrict__ M = lds.M[mine[s].buf];  // (per lane: the records of the lane's slot's unit)
-            float C, m1, m2;
-            if (all_fast) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
-            else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
-            // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox
-            if (lane_here < 9 * kWaveSlots && ((refit >> s) & 1ull)) {
-              float* __restrict__ in = lds.svd_in[(int)(&mine[s] - lds.slot)];
-              in[x] = C;
-              if (x < 3) in[9 + x] = m1;
-              if (x % 3 == 0) in[12 + x / 3] = m2;
-            }
+        {
+          const int lane_here = fresh(lane);
+          const int s = min(lane_here / 9, kWaveSlots - 1), x = lane_here % 9;
+          const float* __restrict__ M = lds.prep[mine[s].buf].M;  // (per lane: the records of the lane's slot's unit)
+          float C, m1, m2;
+          if (all_fast) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
+          else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
+          // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox (the
+          // transform it was scored with is history: the same bytes)
+          if (lane_here < 9 * kWaveSlots && ((refit >> s) & 1ull)) {
+            float* __restrict__ in = mine[s].u.svd_in;
+            in[x] = C;
+            if (x < 3) in[9 + x] = m1;
+            if (x % 3 == 0) in[12 + x / 3] = m2;
           }
         }
       }
@@ -566,139 +617,141 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   }
 
   // ============================================================================================= the server
-  // units come off the launch's counter a block at a time; lane = unit of the block holds the unit's facts
-  uint64_t live = 0ull;        // units of the claimed block that have work and are not loaded yet
+  // Units come off the launch's counter a block at a time, lane = unit.  `nx_*`: the block taken last, its facts still on
+  // their way (the loads are not awaited until the block is needed); `live` / `u_*`: the block in use.
+  uint64_t live = 0ull;        // units of the block in use that have work and are not loaded yet
   bool units_left = true;      // the counter has not run past the last unit yet
   uint32_t u_pair = 0;
-  int u_kb = 0, u_ke = 0, u_nall = 0;
-  // the load in flight (issued in one half-round, awaited in the next)
-  int ld_b = -1;
-  uint32_t ld_pair = 0, ld_fast = 0;
-  int ld_kb = 0, ld_ke = 0, ld_nall = 0;
-  float ld_pmax = 0.f;
-  uint64_t ld_wnz = 0ull, ld_wv = 0ull;
+  int u_kb = 0, u_ke = 0;
+  int nx_n = 0;                // units of the prefetched block (0 = none)
+  uint32_t nx_pair = 0;
+  int nx_share = 0;
   const int batch_class1 = plan.phase_begin != 0 ? __builtin_amdgcn_readfirstlane(plan.walk[n_pairs].state) : 0;
   const int blk = max(1, min(plan.unit_block, kWave));
 
-  // ---- the next block of units: which of them have anything to do in this launch (lane = unit)
-  auto claim_block = [&]() {
+  // ---- the next block of units off the counter; the facts that decide which of them have work are requested (global ->
+  // LDS), not awaited
+  auto prefetch_block = [&]() {
+    nx_n = 0;
+    if (!units_left) return;
     const int lane = fresh(threadIdx.x & (kWave - 1));
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(plan.unit_counter, (uint32_t)blk);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (base >= n_units) { units_left = false; live = 0ull; return; }
-    const int n = (int)min((uint32_t)blk, n_units - base);
-    const uint32_t unit = base + (uint32_t)min(lane, n - 1);
-    const uint32_t pair = unit / (uint32_t)plan.n_shares;
-    const int share = (int)(unit - pair * (uint32_t)plan.n_shares);
-    const int n_all = plan.prep[pair].n_all;
-    // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
-    // (the first launch of a batch: every pair is still running)
-    int pair_state = I, cls = 0;
-    if (plan.phase_begin != 0) {
-      const WalkState ws = plan.walk[pair];
-      pair_state = ws.state;
-      cls = ws.speculate;
-    } else if (plan.first_spec) {
-      cls = (int)plan.preclass[pair];
+    if (base >= n_units) { units_left = false; return; }
+    nx_n = (int)min((uint32_t)blk, n_units - base);
+    const uint32_t unit = base + (uint32_t)min(lane, nx_n - 1);
+    nx_pair = unit / (uint32_t)plan.n_shares;
+    nx_share = (int)(unit - nx_pair * (uint32_t)plan.n_shares);
+    if (lane < nx_n) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&plan.prep[nx_pair].n_all,
+                                       (__attribute__((address_space(3))) void*)lds.claim_nall, 4, 0, 0);
+      // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
+      // (the first launch of a batch: every pair is still running)
+      if (plan.phase_begin != 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&plan.walk[nx_pair].state,
+                                         (__attribute__((address_space(3))) void*)lds.claim_state, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&plan.walk[nx_pair].speculate,
+                                         (__attribute__((address_space(3))) void*)lds.claim_cls, 4, 0, 0);
+      } else if (plan.first_spec) {  // (one byte per pair, read as the low byte of a dword: the array has slack behind it)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plan.preclass + nx_pair),
+                                         (__attribute__((address_space(3))) void*)lds.claim_cls, 4, 0, 0);
+      }
     }
+  };
+  // ---- the prefetched block becomes the block in use: which of its units have anything to do in this launch
+  auto adopt_block = [&]() {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requested at least one pass of the server's loop ago)
+    const int n_all = lds.claim_nall[lane];
+    const int state = plan.phase_begin != 0 ? lds.claim_state[lane] : I;
     // class 2 (no jump of `it` so far, junk-heavy; class 1 when the batch has few such pairs: effective_class): everything
     // that is left is recorded in this launch
+    int cls = plan.phase_begin != 0 ? lds.claim_cls[lane] : (plan.first_spec ? (lds.claim_cls[lane] & 0xFF) : 0);
     if (cls == 1) cls = ((uint32_t)batch_class1 * 64u <= n_pairs) ? 2 : 0;
-    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, pair_state);
-    const int k_begin = plan.phase_begin + share * plan.share_iters;
+    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, state);
+    const int k_begin = plan.phase_begin + nx_share * plan.share_iters;
     const int k_end = min(k_begin + plan.share_iters, end);
     // no RANSAC for this pair (node.cpp:1087, :1130), or nothing of this range is needed (any more)
-    bool have = lane < n && pair_state >= 0 && k_begin < k_end && n_all > rc.min_matches && n_all >= 4;
-    if (have) {  // ... or none of its iterations passed the pre-screen
-      const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
-      int items = 0;
-      for (int w = k_begin >> 6; w <= (k_end - 1) >> 6; ++w) {
-        uint64_t wv = vm_pair[w];
-        const int lo = w << 6;
-        if (k_begin > lo) wv &= ~0ull << (k_begin - lo);
-        if (k_end - lo < 64) wv &= (1ull << (k_end - lo)) - 1ull;
-        items += __popcll(wv);
-      }
-      have = items > 0;
-    }
+    const bool have = lane < nx_n && state >= 0 && k_begin < k_end && n_all > rc.min_matches && n_all >= 4;
     live = __ballot(have);
-    u_pair = pair; u_kb = k_begin; u_ke = k_end; u_nall = n_all;
+    u_pair = nx_pair; u_kb = k_begin; u_ke = k_end;
+    lsync();   // (the staging arrays have been read before the next block's facts land in them)
+    prefetch_block();
   };
 
-  // ---- the next unit with work -> a free buffer: its match records global -> LDS directly (global_load_lds_dwordx4,
-  // 64 x 16 bytes per instruction), its facts and the words of the viable mask into registers.  Nothing is awaited here.
-  auto issue_load = [&]() {
-    if (ld_b >= 0) return;
+  // ---- units with work -> the free buffers: the pair's match records and facts (PairPrep, 8.4 KB) and the words of its
+  // viable mask go global -> LDS directly (global_load_lds: no registers, nothing awaited here)
+  auto issue_loads = [&]() {
     const int lane = fresh(threadIdx.x & (kWave - 1));
-    const uint64_t free_bufs = __ballot(lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitFree);
-    if (free_bufs == 0ull) return;
-    while (live == 0ull && units_left) claim_block();
-    if (live == 0ull) return;
-    const int src = (int)__builtin_ctzll(live);
-    live &= live - 1ull;
-    const int b = (int)__builtin_ctzll(free_bufs);
-    const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)u_pair, src);
-    ld_kb = __builtin_amdgcn_readlane(u_kb, src);
-    ld_ke = __builtin_amdgcn_readlane(u_ke, src);
-    ld_nall = __builtin_amdgcn_readlane(u_nall, src);
-    ld_pair = pair;
-    ld_b = b;
-    const PairPrep* __restrict__ pp = plan.prep + pair;
-    const char* __restrict__ srcp = reinterpret_cast<const char*>(pp->M);
-    for (int i = 0; i < (kMVec + kWave - 1) / kWave; ++i) {
-      const int v = i * kWave + lane;
-      if (v < kMVec)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcp + (size_t)v * 16),
-                                         (__attribute__((address_space(3))) void*)(lds.M[b] + i * (kWave * 4)), 16, 0, 0);
+    uint64_t free_bufs = __ballot(lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitFree);
+    while (free_bufs != 0ull) {
+      while (live == 0ull && nx_n != 0) adopt_block();
+      if (live == 0ull) return;
+      const int src = (int)__builtin_ctzll(live);
+      live &= live - 1ull;
+      const int b = (int)__builtin_ctzll(free_bufs);
+      free_bufs &= free_bufs - 1ull;
+      const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)u_pair, src);
+      const int kb = __builtin_amdgcn_readlane(u_kb, src), ke = __builtin_amdgcn_readlane(u_ke, src);
+      UnitCtx& cx = lds.ctx[b];
+      const char* __restrict__ srcp = reinterpret_cast<const char*>(plan.prep + pair);
+      char* const dst = reinterpret_cast<char*>(&lds.prep[b]);
+      for (int i = 0; i < (kPrepVec + kWave - 1) / kWave; ++i) {
+        const int v = i * kWave + lane;
+        if (v < kPrepVec)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcp + (size_t)v * 16),
+                                           (__attribute__((address_space(3))) void*)(dst + i * (kWave * 16)), 16, 0, 0);
+      }
+      const int blk0 = kb >> 6;
+      const int n_dw = 2 * min(kMaskLanes, plan.vmask_words - blk0);
+      const char* __restrict__ srcm = reinterpret_cast<const char*>(plan.vmask + (size_t)pair * (size_t)plan.vmask_words + blk0);
+      if (lane < n_dw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcm + lane * 4),
+                                         (__attribute__((address_space(3))) void*)cx.mw, 4, 0, 0);
+      if (lane == 0) {
+        cx.pair = pair;
+        cx.kb = kb;
+        cx.ke = ke;
+        cx.state = kUnitLoading;
+      }
     }
-    ld_pmax = pp->pmax;
-    ld_fast = pp->fast_alpha;
-    ld_wnz = lane < kRounds ? pp->w_nonzero[lane] : 0ull;
-    const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
-    const int blk0 = ld_kb >> 6;
-    ld_wv = (blk0 + lane < plan.vmask_words && lane < kMaskLanes) ? vm_pair[blk0 + lane] : 0ull;
-    if (lane == 0) lds.ctx[b].state = kUnitLoading;
   };
 
-  // ---- the load issued a half-round ago has arrived: the list of the unit's viable iterations, the buffer is ready
-  auto complete_load = [&]() {
-    if (ld_b < 0) return;
+  // ---- the loads issued a half-round ago have arrived: the lists of the units' viable iterations, the buffers are ready
+  auto complete_loads = [&]() {
     const int lane = fresh(threadIdx.x & (kWave - 1));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the match records are in LDS, the facts in registers
-    UnitCtx& cx = lds.ctx[ld_b];
-    const int blk0 = ld_kb >> 6;
-    // lane w holds word blk0 + w of the pair's mask, cut to the range; lane = iteration builds the list
-    uint64_t wv = ld_wv;
-    {
-      const int lo = (blk0 + lane) << 6;
-      if (ld_kb > lo) wv &= (ld_kb - lo >= 64) ? 0ull : (~0ull << (ld_kb - lo));
-      if (ld_ke - lo < 64) wv &= (ld_ke - lo <= 0) ? 0ull : ((1ull << (ld_ke - lo)) - 1ull);
+    uint64_t loading = __ballot(lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitLoading);
+    if (loading == 0ull) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the match records, facts and mask words are in LDS
+    while (loading != 0ull) {
+      const int b = (int)__builtin_ctzll(loading);
+      loading &= loading - 1ull;
+      UnitCtx& cx = lds.ctx[b];
+      const int kb = __builtin_amdgcn_readfirstlane(cx.kb), ke = __builtin_amdgcn_readfirstlane(cx.ke);
+      const int blk0 = kb >> 6;
+      const int n_words = ((ke - 1) >> 6) - blk0 + 1;  // <= kMaskLanes
+      int total = 0;
+      for (int c = 0; c < n_words; ++c) {  // lane = iteration of word c builds the list
+        uint64_t wc = uniform_u64(cx.mw[c]);
+        const int lo = (blk0 + c) << 6;
+        if (kb > lo) wc &= ~0ull << (kb - lo);
+        if (ke - lo < 64) wc &= (1ull << (ke - lo)) - 1ull;
+        if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)((c << 6) + lane);
+        total += __popcll(wc);
+      }
+      const int n_all = lds.prep[b].n_all;
+      uint32_t thr = (uint32_t)rc.min_matches;                                       // :1094
+      if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
+      if (lane == 0) {
+        cx.thr = thr;
+        cx.base = blk0 << 6;
+        cx.n_items = total;
+        cx.next = 0;
+        cx.done = 0;
+        cx.state = total > 0 ? kUnitReady : kUnitFree;   // (no iteration of the range passed the pre-screen: nothing to refine)
+      }
     }
-    const int n_words = ((ld_ke - 1) >> 6) - blk0 + 1;  // <= kMaskLanes
-    int total = 0;
-    for (int c = 0; c < n_words; ++c) {
-      const uint64_t wc = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), c) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wv, c);
-      if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)((c << 6) + lane);
-      total += __popcll(wc);
-    }
-    uint32_t thr = (uint32_t)rc.min_matches;                                             // :1094
-    if ((double)thr > 0.75 * (double)ld_nall) thr = (uint32_t)(0.75 * (double)ld_nall);  // :1095-1098
-    if (lane < kRounds) cx.w_nonzero[lane] = ld_wnz;
-    if (lane == 0) {
-      cx.pair = ld_pair;
-      cx.n_all = ld_nall;
-      cx.thr = thr;
-      cx.pmax = ld_pmax;
-      cx.fast = (int)ld_fast;
-      cx.base = blk0 << 6;
-      cx.n_items = total;
-      cx.next = 0;
-      cx.done = 0;
-      cx.state = total > 0 ? kUnitReady : kUnitFree;
-    }
-    ld_b = -1;
     lsync();
   };
 
@@ -712,7 +765,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     Tfc mine;
     mine.reset();  // lanes without a request: the zero matrix (no rotation, one sweep)
     if (p) {
-      const float* __restrict__ in = lds.svd_in[s];
+      const float* __restrict__ in = sl.u.svd_in;
 #pragma unroll
       for (int i = 0; i < 9; ++i) mine.C[i] = in[i];
 #pragma unroll
@@ -722,9 +775,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     tfc_get_transformation(mine, fR, ft);
     if (p) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) sl.R[i] = fR[i];
+      for (int i = 0; i < 9; ++i) sl.u.x.R[i] = fR[i];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) sl.t[i] = ft[i];
+      for (int i = 0; i < 3; ++i) sl.u.x.t[i] = ft[i];
       if (has_nan12(fR, ft)) sl.active = kSlotDone;  // :1144: the iteration ends with what it has refined so far
     }
     lsync();
@@ -755,8 +808,8 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     lsync();
   };
 
-  // ---- free slots of group gs take the next viable iterations of the resident units (any unit: a slot carries its
-  // unit's facts), the least occupied workers first; the two groups are kept level
+  // ---- free slots of group gs take the next viable iterations of the resident units (any unit: a slot names its unit's
+  // buffer), the least occupied workers first; the two groups are kept level
   auto hand_out = [&](int gs) {
     const int lane = fresh(threadIdx.x & (kWave - 1));
     int av = 0, nx = 0;
@@ -765,8 +818,13 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       nx = cx.next;
       av = cx.state == kUnitReady ? cx.n_items - nx : 0;
     }
-    const int a0 = __builtin_amdgcn_readlane(av, 0), a1 = __builtin_amdgcn_readlane(av, 1), a2 = __builtin_amdgcn_readlane(av, 2);
-    const int total = a0 + a1 + a2;
+    int avs[kBufs], nxs[kBufs], total = 0;
+#pragma unroll
+    for (int q = 0; q < kBufs; ++q) {
+      avs[q] = __builtin_amdgcn_readlane(av, q);
+      nxs[q] = __builtin_amdgcn_readlane(nx, q);
+      total += avs[q];
+    }
     if (total == 0) return;
     const bool in_g = lane < kGroupSlots;
     const bool held = in_g && lds.slot[gs * kGroupSlots + min(lane, kGroupSlots - 1)].iter >= 0;
@@ -793,72 +851,91 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     }
     const bool take = is_free && ord < n_take;
     int b = 0, at = 0;
-    if (take) {
-      const int n0 = __builtin_amdgcn_readlane(nx, 0), n1 = __builtin_amdgcn_readlane(nx, 1), n2 = __builtin_amdgcn_readlane(nx, 2);
-      if (ord < a0) { b = 0; at = n0 + ord; }
-      else if (ord < a0 + a1) { b = 1; at = n1 + (ord - a0); }
-      else { b = 2; at = n2 + (ord - a0 - a1); }
-    }
-    if (lane < kBufs) {  // items taken from buffer `lane`
-      const int before = lane == 0 ? 0 : (lane == 1 ? a0 : a0 + a1);
-      lds.ctx[lane].next = nx + max(0, min(av, n_take - before));
+    {
+      int before = 0;   // items of the buffers in front of buffer q
+#pragma unroll
+      for (int q = 0; q < kBufs; ++q) {
+        if (take && ord >= before && ord < before + avs[q]) { b = q; at = nxs[q] + (ord - before); }
+        if (lane == q) lds.ctx[q].next = nxs[q] + max(0, min(avs[q], n_take - before));   // items taken from buffer q
+        before += avs[q];
+      }
     }
     if (take) {
       const UnitCtx& cx = lds.ctx[b];
       SlotS& sl = lds.slot[gs * kGroupSlots + lane];
+      // the 4-point hypothesis ransac_hyp_kernel left in the iteration's record: the first transform to score
       const int k = cx.base + (int)cx.klist[at];
-      const uint32_t pair = cx.pair;
-      const float2* __restrict__ hyp = reinterpret_cast<const float2*>(plan.recs[(size_t)pair * (size_t)I + (size_t)k].rR);  // rR[9], rt[3]
+      const float2* __restrict__ hyp = reinterpret_cast<const float2*>(plan.recs[(size_t)cx.pair * (size_t)I + (size_t)k].rR);  // rR[9], rt[3]
       float2 v[6];
 #pragma unroll
       for (int e = 0; e < 6; ++e) v[e] = hyp[e];
 #pragma unroll
-      for (int e = 0; e < 6; ++e) reinterpret_cast<float2*>(sl.R)[e] = v[e];  // -> R[9], t[3]
+      for (int e = 0; e < 6; ++e) reinterpret_cast<float2*>(sl.u.x.R)[e] = v[e];  // -> R[9], t[3]
       const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 #pragma unroll
       for (int i = 0; i < 9; ++i) sl.rR[i] = IR[i];  // :1137 refined = Identity
 #pragma unroll
       for (int i = 0; i < 3; ++i) sl.rt[i] = 0.f;
 #pragma unroll
-      for (int r = 0; r < kRounds; ++r) { sl.rmask[r] = 0ull; sl.fmask[r] = 0ull; }
+      for (int r = 0; r < kRounds; ++r) sl.rmask[r] = 0ull;
       sl.rerr = 1e6;  // :1133
       sl.rn = 0;      // :1134
       sl.active = kSlotActive;
       sl.round = 0;
       sl.iter = k;
       sl.buf = b;
-      sl.pair = pair;
-      sl.n_all = cx.n_all;
-      sl.thr = cx.thr;
-      sl.pmax = cx.pmax;
-      sl.fast = cx.fast;
+      sl.pair = cx.pair;
     }
     lsync();
   };
 
-  // the first unit before the first half-round (the workers start with group 0)
-  issue_load();
-  complete_load();
+  // ---- the list of group gs' active slots for its next pass: the scorings are taken off it one by one
+  auto list_active = [&](int gs) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    const SlotS& sl = lds.slot[gs * kGroupSlots + min(lane, kGroupSlots - 1)];
+    const bool a = lane < kGroupSlots && sl.iter >= 0 && sl.active == kSlotActive;
+    const uint64_t m = __ballot(a);
+    if (a) lds.act_list[gs][lane_rank(m)] = (uint8_t)lane;
+    // expensive scorings ahead: iterations that already hold a refined set (their transform will pass the prefilter again)
+    const int n_dear = __popcll(__ballot(a && sl.rn > 0));
+    if (lane == 0) {
+      lds.n_act[gs] = __popcll(m);
+      lds.task[gs] = 0;
+      lds.tickets[gs] = n_dear >= kTicketsFrom ? 1 : 0;
+    }
+  };
+
+  // the first units before the first half-round (the workers start with group 0)
+  if (lane < 2) { lds.n_act[lane] = 0; lds.task[lane] = 0; lds.tickets[lane] = 0; }
+  prefetch_block();
+  adopt_block();
+  issue_loads();
+  complete_loads();
   hand_out(0);
-  issue_load();
+  list_active(0);
+  issue_loads();
   lds_barrier();
   for (int h = 0;; ++h) {
-    const int gs = 1 - (h & 1);   // the group the workers do NOT touch in this half-round
+    const int g = h & 1, gs = 1 - g;   // gs: the group nobody scores in this half-round
+    const int by_ticket = __builtin_amdgcn_readfirstlane(lds.tickets[g]);
     serve_svd(gs);
     recycle(gs);
-    complete_load();
+    complete_loads();
     hand_out(gs);
-    issue_load();
-    {
-      const int lane = fresh(threadIdx.x & (kWave - 1));
-      const bool held = lane < kStreamSlots && lds.slot[min(lane, kStreamSlots - 1)].iter >= 0;
-      const bool items = lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitReady &&
-                         lds.ctx[min(lane, kBufs - 1)].next < lds.ctx[min(lane, kBufs - 1)].n_items;
-      const bool more = __ballot(held || items) != 0ull || ld_b >= 0 || live != 0ull || units_left;
-      if (!more && lane == 0) lds.quit = 1;
+    list_active(gs);
+    issue_loads();
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    bool busy = lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state != kUnitFree;   // items to hand out, in flight, or a load
+    busy = busy || (lane < kStreamSlots && lds.slot[min(lane, kStreamSlots - 1)].iter >= 0) ||
+           (lane + kWave < kStreamSlots && lds.slot[min(lane + kWave, kStreamSlots - 1)].iter >= 0);
+    const bool more = __ballot(busy) != 0ull || live != 0ull || nx_n != 0 || units_left;
+    if (!more && lane == 0) lds.quit = 1;
+    if (by_ticket) {
+      score_tickets(g);   // its own duties done, the server scores like everybody else
       lds_barrier();
-      if (!more) break;
     }
+    lds_barrier();        // (the workers' bookkeeping and refits of group g)
+    if (!more) break;
   }
 }
 
@@ -919,3 +996,4 @@ int ransac_split_words_per_pair(int ransac_iterations) {
 int ransac_split_max_share() { return kMaxShare; }
 
 }  // namespace rgbdfe
+
