@@ -155,8 +155,9 @@ int  rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* quer
                                             int32_t* edges_per_device, int32_t* stride);
 const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx);            /* "rccl", "p2p" or "none" (last allgather) */
 /* Host time (microseconds) the calling thread spent enqueueing the latest sharded batch on all devices of a multi handle:
- * the shards are submitted by ONE thread, device after device -- the batch's launch chain is a cached hipGraph per device,
- * so this is one hipGraphLaunch (+ a read-back or pack enqueue) per device.  0 for single-device contexts. */
+ * the shards are submitted by ONE thread, device after device.  With graph capture on (rgbdfe_set_graph_capture; OFF by
+ * default) a batch's launch chain is a cached hipGraph per device -- one hipGraphLaunch (+ a read-back or pack enqueue) per
+ * device; with the default it is the chain's ~10 kernel launches per device.  0 for single-device contexts. */
 int  rgbdfe_group_submit_us(rgbdfe_ctx* ctx, double* us);
 /* The compact form of rgbdfe_match_pair_list_allgather: d_out[i] holds G * per rgbdfe_compact_result, same placement
  * (pair k at (k mod G) * per + k / G, unused tail records 0xFF); 12x fewer bytes cross xGMI. */
@@ -238,6 +239,21 @@ int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids,
 int rgbdfe_submit_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,
                             int32_t n_pairs, void* d_out, int64_t* ticket);
 int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream);
+/* The asynchronous form with results in HOST memory -- what GraphManager consumes (graph_manager.cpp:409-419, 554-560) at
+ * the rate the device produces it: batch k's results travel device -> host behind batch k on its internal stream while
+ * batch k+1 (submitted before the wait) computes on the other one.  payload RGBDFE_HOST_RECORDS: n_pairs
+ * rgbdfe_match_result; RGBDFE_HOST_INLIERS: the inlier stream of the batch (rgbdfe_inlier_header above: n_pairs headers,
+ * then the list block -- ~260 instead of 1744 bytes per pair on configs[1]); out_bytes = capacity of `out` (the worst case
+ * of the inlier stream is n_pairs * (104 + 4 * RGBDFE_MAX_MATCHES)).  `out` stays the library's until rgbdfe_wait_host
+ * (ticket) returns; *bytes_written (may be NULL) = the payload's size.  When `out` is pinned (hipHostMalloc /
+ * rgbdfe_host_register) the download goes straight into it, otherwise through a pinned stage and one memcpy inside
+ * rgbdfe_wait_host.  At most two jobs in flight per context (one per internal stream): a third submit before a wait is
+ * refused with RGBDFE_ERR_CAPACITY.  Same results as rgbdfe_match_pair_list.  Single-device contexts only. */
+#define RGBDFE_HOST_RECORDS 0
+#define RGBDFE_HOST_INLIERS 1
+int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                 void* out, size_t out_bytes, int payload, int64_t* ticket);
+int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written);
 int rgbdfe_synchronize(rgbdfe_ctx* ctx);
 
 /* ---- SIFT (128-d float descriptor) nodes: matcher_type == "SIFTGPU" ------------------------
@@ -512,7 +528,10 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
 /* The same, and frame f's features also become the resident node node_ids[f] (>= 0; negative: no node for that frame) --
  * what Node::Node + GraphManager::addNode + rgbdfe_upload_node do, without the features' trip to the host and back: the
  * descriptors and points are copied into the node slabs from the description's device buffers (the host outputs are filled
- * as before).  A frame without features leaves an empty node.  An id that exists is rewritten in place. */
+ * as before).  A frame WITHOUT features registers nothing: a fresh id stays unknown (matching against it reports "not
+ * resident", as for a node GraphManager never added), an id that exists keeps its old features.  An id that exists and gets
+ * features is rewritten in place.  Capacity is checked for the whole batch before the first frame is detected, counting
+ * every fresh id as one slot. */
 int rgbdfe_detect_describe_batch_nodes(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray,
                                        const uint8_t* const* mask, const float* const* depth, int32_t rows, int32_t cols,
                                        double fx, double fy, double cx, double cy, double depth_scaling, int32_t out_stride,

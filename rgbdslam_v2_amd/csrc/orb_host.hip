@@ -12,6 +12,7 @@
 #include "orb_host.h"
 
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include "orb_pattern.inc"
 
@@ -96,19 +97,22 @@ OrbWorkspace::~OrbWorkspace() { release(); }
 // Zero-fills of freshly allocated device memory go through a stream of the workspace's own and wait for THAT stream: a
 // NULL-stream hipMemset would need a device-wide synchronisation to be ordered before the context's non-blocking streams,
 // and hipDeviceSynchronize() invalidates a hipGraph capture another thread of the process may have open (rgbdfe_api.hip).
+// One stream per device for the whole process (a caller that alternates devices -- the multi-device handle's thread, tests
+// with contexts on several devices -- used to get a new thread-local stream on every switch and leak the old one).
 static hipError_t zero_fill_and_wait(void* p, size_t bytes) {
-  static thread_local hipStream_t s = nullptr;
-  static thread_local int s_dev = -1;
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (!s || s_dev != dev) {
-    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e != hipSuccess) { s = nullptr; return e; }
-    s_dev = dev;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> g(mu);   // (allocation-time work: first use of a workspace, a grown buffer)
+  if (!streams[dev]) {
+    e = hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
+    if (e != hipSuccess) { streams[dev] = nullptr; return e; }
   }
-  e = hipMemsetAsync(p, 0, bytes, s);
-  return e != hipSuccess ? e : hipStreamSynchronize(s);
+  e = hipMemsetAsync(p, 0, bytes, streams[dev]);
+  return e != hipSuccess ? e : hipStreamSynchronize(streams[dev]);
 }
 
 void OrbWorkspace::release() {

@@ -255,6 +255,24 @@ struct rgbdfe_ctx {
   hipEvent_t nodes_ready = nullptr;  // recorded behind the latest rgbdfe_upload_node_device copies; every batch waits for it
   hipEvent_t nodes_ready_ev = nullptr;  // (storage; nodes_ready points here once the first such upload happened)
   rgbdfe_match_result* h_results = nullptr;  // pinned staging of the synchronous host-output entry points
+  // rgbdfe_submit_pair_list_host / rgbdfe_wait_host: one job per lane -- the results of the batch on lane li go device ->
+  // pinned stage li (or straight into the caller's buffer when that is pinned) behind the batch, on the lane's stream, while
+  // the other lane computes the next batch; the copy-out to pageable caller memory happens in rgbdfe_wait_host
+  struct HostJob {
+    bool pending = false;
+    bool direct = false;          // the download went straight into the caller's (pinned / registered) buffer
+    int payload = 0;              // RGBDFE_HOST_RECORDS / RGBDFE_HOST_INLIERS
+    int64_t ticket = 0;
+    int32_t n = 0;
+    void* out = nullptr;
+    size_t out_bytes = 0;
+    hipEvent_t copied = nullptr;  // the download has ended (inlier payload: headers + the list block's length)
+  };
+  HostJob host_jobs[kLanes];
+  uint8_t* h_stage[kLanes] = {};    // pinned: max_pairs records, or the largest inlier stream of max_pairs pairs
+  uint8_t* d_inl_stream[kLanes] = {};  // inlier payload: the packed stream in HBM
+  int32_t* d_inl_total[kLanes] = {};
+  int32_t* h_inl_total[kLanes] = {};   // pinned
   // scratch for single-pair helpers / project_to_3d
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -882,6 +900,13 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
   if (ctx->h_results) (void)hipHostFree(ctx->h_results);
+  for (int li = 0; li < rgbdfe_ctx::kLanes; ++li) {
+    if (ctx->host_jobs[li].copied) (void)hipEventDestroy(ctx->host_jobs[li].copied);
+    if (ctx->h_stage[li]) (void)hipHostFree(ctx->h_stage[li]);
+    if (ctx->d_inl_stream[li]) (void)hipFree(ctx->d_inl_stream[li]);
+    if (ctx->d_inl_total[li]) (void)hipFree(ctx->d_inl_total[li]);
+    if (ctx->h_inl_total[li]) (void)hipHostFree(ctx->h_inl_total[li]);
+  }
   if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
   if (ctx->nodes_ready_ev) (void)hipEventDestroy(ctx->nodes_ready_ev);
   if (ctx->d_desc4) (void)hipFree(ctx->d_desc4);
@@ -1171,6 +1196,117 @@ int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream) {
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   return wait_ticket(ctx, ticket, (hipStream_t)stream);
+}
+
+// is `p` host memory the device can copy into asynchronously (hipHostMalloc / hipHostRegister)?
+static bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+// The asynchronous form of rgbdfe_match_pair_list: results in HOST memory, the download of batch k behind batch k on its lane
+// while batch k+1 computes on the other lane (the reference's consumer reads the results on the host:
+// graph_manager.cpp:409-419, 554-560).
+int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                 void* out, size_t out_bytes, int payload, int64_t* ticket) {
+  if (!ctx || n_pairs < 0 || !ticket || (n_pairs > 0 && (!query_ids || !train_ids || !out)) ||
+      (payload != RGBDFE_HOST_RECORDS && payload != RGBDFE_HOST_INLIERS))
+    return fail(ctx, RGBDFE_ERR_INVALID_ARG, "bad host submit arguments");
+  const size_t rec = sizeof(rgbdfe_match_result), hdr = sizeof(rgbdfe_inlier_header);
+  const size_t need = payload == RGBDFE_HOST_RECORDS ? rec * (size_t)n_pairs : hdr * (size_t)n_pairs;  // (+ the list block)
+  if (out_bytes < need) return fail(ctx, RGBDFE_ERR_CAPACITY, "host output buffer too small");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
+  const int li = (int)(ctx->next_ticket % rgbdfe_ctx::kLanes);   // the lane enqueue_pairs will take
+  rgbdfe_ctx::HostJob& job = ctx->host_jobs[li];
+  if (job.pending) return fail(ctx, RGBDFE_ERR_CAPACITY, "rgbdfe_submit_pair_list_host: wait for an earlier ticket first (one job per lane)");
+  const size_t cap = (size_t)ctx->cfg.max_pairs_per_batch;
+  const size_t stream_cap = cap * (hdr + 4 * (size_t)RGBDFE_MAX_MATCHES);
+  if (!job.copied) HIP_TRY(ctx, hipEventCreateWithFlags(&job.copied, hipEventDisableTiming));
+  if (!ctx->h_stage[li] &&
+      hipHostMalloc((void**)&ctx->h_stage[li], stream_cap > rec * cap ? stream_cap : rec * cap, hipHostMallocDefault) != hipSuccess)
+    return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "pinned result staging allocation failed");
+  if (payload == RGBDFE_HOST_INLIERS && !ctx->d_inl_stream[li]) {
+    if (hipMalloc((void**)&ctx->d_inl_stream[li], stream_cap) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_inl_total[li], sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_inl_total[li], sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+      return fail(ctx, RGBDFE_ERR_OUT_OF_MEMORY, "inlier stream buffers");
+  }
+  int lane_used = 0;
+  const int rc = enqueue_pairs(ctx, query_ids, train_ids, n_pairs, nullptr, nullptr, ticket, &lane_used);
+  if (rc != RGBDFE_OK) return rc;
+  if (lane_used != li) return fail(ctx, RGBDFE_ERR_INTERNAL, "host submit: lane bookkeeping out of step");
+  hipStream_t st = ctx->lanes[li].stream;
+  job.direct = n_pairs > 0 && is_pinned_host(out);
+  if (payload == RGBDFE_HOST_RECORDS) {
+    if (n_pairs > 0)
+      HIP_TRY(ctx, hipMemcpyAsync(job.direct ? out : (void*)ctx->h_stage[li], ctx->lanes[li].d_results, rec * (size_t)n_pairs,
+                                  hipMemcpyDeviceToHost, st));
+  } else if (n_pairs > 0) {
+    launch_pack_inliers(ctx->lanes[li].d_results, (uint32_t)n_pairs, (uint32_t)n_pairs, ctx->d_inl_stream[li],
+                        ctx->d_inl_total[li], st);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_inl_total[li], ctx->d_inl_total[li], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(job.direct ? out : (void*)ctx->h_stage[li], ctx->d_inl_stream[li], hdr * (size_t)n_pairs,
+                                hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(ctx, hipEventRecord(job.copied, st));
+  job.pending = true;
+  job.payload = payload;
+  job.ticket = *ticket;
+  job.n = n_pairs;
+  job.out = out;
+  job.out_bytes = out_bytes;
+  return RGBDFE_OK;
+}
+
+int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  rgbdfe_ctx::HostJob job;
+  int li = -1;
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (int k = 0; k < rgbdfe_ctx::kLanes; ++k)
+      if (ctx->host_jobs[k].pending && ctx->host_jobs[k].ticket == ticket) li = k;
+    if (li < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_wait_host: no host job with this ticket");
+    job = ctx->host_jobs[li];
+  }
+  // (the context is not locked while this thread waits and copies: another thread may submit the next batch meanwhile)
+  hipError_t e = hipSetDevice(ctx->cfg.device_id);
+  if (e == hipSuccess) e = hipEventSynchronize(job.copied);
+  const size_t rec = sizeof(rgbdfe_match_result), hdr = sizeof(rgbdfe_inlier_header);
+  size_t written = 0;
+  int rc = RGBDFE_OK;
+  if (e == hipSuccess && job.n > 0) {
+    if (job.payload == RGBDFE_HOST_RECORDS) {
+      written = rec * (size_t)job.n;
+      if (!job.direct) memcpy(job.out, ctx->h_stage[li], written);
+    } else {
+      const size_t list_bytes = 4 * (size_t)(*ctx->h_inl_total[li] > 0 ? *ctx->h_inl_total[li] : 0);
+      written = hdr * (size_t)job.n + list_bytes;
+      if (written > job.out_bytes) {
+        rc = RGBDFE_ERR_CAPACITY;
+      } else {
+        if (!job.direct) memcpy(job.out, ctx->h_stage[li], hdr * (size_t)job.n);
+        // the list block: its length is known only now (a second, short download on the lane's stream)
+        if (list_bytes > 0) {
+          uint8_t* dst = job.direct ? (uint8_t*)job.out + hdr * (size_t)job.n : ctx->h_stage[li] + hdr * (size_t)job.n;
+          e = hipMemcpyAsync(dst, ctx->d_inl_stream[li] + hdr * (size_t)job.n, list_bytes, hipMemcpyDeviceToHost, ctx->lanes[li].stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->lanes[li].stream);
+          if (e == hipSuccess && !job.direct) memcpy((uint8_t*)job.out + hdr * (size_t)job.n, dst, list_bytes);
+        }
+      }
+    }
+  }
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->host_jobs[li].pending = false;
+  }
+  if (bytes_written) *bytes_written = (int64_t)written;
+  if (e != hipSuccess) return fail(ctx, RGBDFE_ERR_HIP, std::string("rgbdfe_wait_host: ") + hipGetErrorString(e));
+  if (rc != RGBDFE_OK) return fail(ctx, rc, "rgbdfe_wait_host: the inlier stream does not fit the caller's buffer");
+  return RGBDFE_OK;
 }
 
 int rgbdfe_synchronize(rgbdfe_ctx* ctx) {
@@ -1955,7 +2091,9 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   const int max_kp = ctx->orb_max_keypoints;
   if (node_ids) {
     // all-or-nothing on capacity, like rgbdfe_upload_nodes: everything that can be refused is refused before the first
-    // frame is detected (every frame may need a slot: a frame without features still becomes an empty node)
+    // frame is detected.  Every fresh id is counted as needing a slot -- how many features a frame has is not known before
+    // it is detected; a frame that ends up WITHOUT features registers nothing (a fresh id stays unknown, an existing node
+    // keeps its features), so the check can refuse a batch that would have fitted by exactly that many slots.
     if (max_kp > ctx->cfg.max_keypoints)
       return fail(ctx, RGBDFE_ERR_CAPACITY, "the detector's max_keypoints exceeds the context's max_keypoints (node rows)");
     bool overwrite = false;
@@ -3133,7 +3271,7 @@ int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
   return RGBDFE_OK;
 }
 
-int rgbdfe_abi_version(void) { return 4; }  // 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_set_graph_capture, rgbdfe_pack_inliers, rgbdfe_match_pair_list_allgather_inliers
+int rgbdfe_abi_version(void) { return 5; }  // 5: rgbdfe_submit_pair_list_host / rgbdfe_wait_host (the refinement kernel's round-4 debug hooks are gone); 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_set_graph_capture, rgbdfe_pack_inliers, rgbdfe_match_pair_list_allgather_inliers
 
 }  // namespace impl
 
@@ -3984,6 +4122,22 @@ int rgbdfe_match_pair_list_allgather_inliers(rgbdfe_ctx* ctx, const int32_t* que
       return fail(ctx, RGBDFE_ERR_INVALID_ARG,
                   "rgbdfe_match_pair_list_allgather_inliers needs a context made by rgbdfe_create_multi");
     return group_match_allgather_inliers(ctx, query_ids, train_ids, n_pairs, d_out, records_per_device, list_entries, stride_bytes);
+  });
+}
+
+int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
+                                 void* out, size_t out_bytes, int payload, int64_t* ticket) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_submit_pair_list_host");
+    return impl::rgbdfe_submit_pair_list_host(ctx, query_ids, train_ids, n_pairs, out, out_bytes, payload, ticket);
+  });
+}
+int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_wait_host");
+    return impl::rgbdfe_wait_host(ctx, ticket, bytes_written);
   });
 }
 

@@ -291,6 +291,25 @@ class FrontEnd:
         """Make `stream` (hipStream_t as int) wait for the batch, or block the host if None."""
         self._check(self._L.rgbdfe_wait_ticket(self._ctx, ticket, stream))
 
+    def submit_pair_list_host(self, query_ids, train_ids, out: np.ndarray, inliers: bool = False) -> int:
+        """rgbdfe_submit_pair_list_host: results into the HOST array `out` (RESULT_DTYPE records, or -- inliers=True -- a
+        uint8 buffer for the batch's inlier stream); returns the ticket for wait_host.  `out` must stay alive and untouched
+        until then; pinned arrays (host_register) are written by the download itself."""
+        q = np.ascontiguousarray(query_ids, np.int32)
+        t = np.ascontiguousarray(train_ids, np.int32)
+        if not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be contiguous")
+        ticket = C.c_int64(0)
+        self._check(self._L.rgbdfe_submit_pair_list_host(self._ctx, q.ctypes.data, t.ctypes.data, q.shape[0], out.ctypes.data,
+                                                         out.nbytes, 1 if inliers else 0, C.byref(ticket)))
+        return ticket.value
+
+    def wait_host(self, ticket: int) -> int:
+        """rgbdfe_wait_host: block until the job's results are in its `out`; returns the payload's size in bytes."""
+        nb = C.c_int64(0)
+        self._check(self._L.rgbdfe_wait_host(self._ctx, ticket, C.byref(nb)))
+        return nb.value
+
     def synchronize(self):
         self._check(self._L.rgbdfe_synchronize(self._ctx))
 

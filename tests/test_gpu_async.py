@@ -140,3 +140,46 @@ def test_graph_replay_equals_plain_launches(data, monkeypatch):
     finally:
         plain.close()
         graph.close()
+
+
+def test_host_output_jobs_pipeline_and_equal_the_synchronous_call(data):
+    """rgbdfe_submit_pair_list_host / rgbdfe_wait_host (round 5): results in HOST memory with the download of
+    batch k behind batch k while batch k+1 computes.  Same bytes as rgbdfe_match_pair_list -- into pageable and into pinned
+    caller memory, two jobs in flight, waited in either order; a third submit before a wait is refused; the inlier payload is
+    the stream the host twin of rgbdfe_pack_inliers makes of the same records."""
+    import torch
+    from rgbdslam_v2_amd._lib import INLIER_HEADER_DTYPE, RGBDFE_MAX_MATCHES, inlier_stream_of
+    from rgbdslam_v2_amd.frontend import RgbdfeError
+    seq, pq, pt = data
+    fe = _fe(64, seq)
+    try:
+        ref_a = fe.match_pair_list(pq[:40], pt[:40])
+        ref_b = fe.match_pair_list(pq[40:], pt[40:])
+        out_a = np.zeros(40, RESULT_DTYPE)                                           # pageable
+        pinned = torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+        out_b = pinned.numpy()[: len(ref_b) * RESULT_DTYPE.itemsize].view(RESULT_DTYPE)  # pinned: the download writes it
+        for order in ((0, 1), (1, 0)):
+            out_a[:] = 0
+            out_b.view(np.uint8)[:] = 0
+            ta = fe.submit_pair_list_host(pq[:40], pt[:40], out_a)
+            tb = fe.submit_pair_list_host(pq[40:], pt[40:], out_b)
+            with pytest.raises(RgbdfeError, match="wait for an earlier ticket"):
+                fe.submit_pair_list_host(pq[:5], pt[:5], np.zeros(5, RESULT_DTYPE))
+            sizes = [fe.wait_host((ta, tb)[k]) for k in order]
+            assert sorted(sizes) == sorted([ref_a.nbytes, ref_b.nbytes])
+            assert out_a.tobytes() == ref_a.tobytes() and out_b.tobytes() == ref_b.tobytes()
+        with pytest.raises(RgbdfeError, match="no host job"):
+            fe.wait_host(ta)
+        # the inlier payload (~104 + 4 * inliers bytes per pair instead of 1744)
+        buf = np.zeros(40 * (INLIER_HEADER_DTYPE.itemsize + 4 * RGBDFE_MAX_MATCHES), np.uint8)
+        nb = fe.wait_host(fe.submit_pair_list_host(pq[:40], pt[:40], buf, inliers=True))
+        hdr, lst = inlier_stream_of(ref_a, 40)
+        assert nb == hdr.nbytes + lst.nbytes and nb < ref_a.nbytes // 3
+        assert buf[: hdr.nbytes].tobytes() == hdr.tobytes() and buf[hdr.nbytes: nb].tobytes() == lst.tobytes()
+        small = np.zeros(40 * INLIER_HEADER_DTYPE.itemsize + 8, np.uint8)            # headers fit, the list does not
+        t = fe.submit_pair_list_host(pq[:40], pt[:40], small, inliers=True)
+        with pytest.raises(RgbdfeError, match="does not fit"):
+            fe.wait_host(t)
+        assert fe.match_pair_list(pq[:40], pt[:40]).tobytes() == ref_a.tobytes()     # the context is still usable
+    finally:
+        fe.close()
