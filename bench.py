@@ -39,8 +39,8 @@ PAIRS_PER_FRAME = 20
 MAX_MATCHES = 300
 SEED = 20260923
 REPEATS = 3                                # repetitions of the timed region (median reported)
-PMC_SUMMARY = "profiles/r04_pmc_summary.json"   # static counter figures (tools/profile_r03.sh + tools/make_pmc_summary.py)
-PMC_FALLBACK = "profiles/r03_pmc_summary.json"
+PMC_SUMMARY = "profiles/r05_pmc_summary.json"   # static counter figures (tools/profile_round.sh + tools/make_pmc_summary.py)
+PMC_FALLBACK = "profiles/r04_pmc_summary.json"
 # Aggregates of every workload this file prints a number for, as the ORACLE computes them (tools/make_bench_expected.py:
 # oracle/liboracle.so, oracle/orb_oracle.c and the compiled reference SiftGPU pipeline over the same seeded workloads,
 # offline on the CPU; committed as tests/golden/bench_expected.json).  The -m gpu tests compare the same workloads record by
@@ -188,7 +188,9 @@ def sift_extract_workload():
 def load_pmc():
     for rel in (PMC_SUMMARY, PMC_FALLBACK):
         try:
-            return json.load(open(os.path.join(ROOT, rel))), rel
+            d = json.load(open(os.path.join(ROOT, rel)))
+            # (every section of the summary carries the tree it was collected on: tools/make_pmc_summary.py)
+            return d, rel + (" @ commit " + ", ".join(c[:12] for c in d["commits"]) if d.get("commits") else "")
         except Exception:
             continue
     return {}, None

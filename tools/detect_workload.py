@@ -1,4 +1,4 @@
-"""Profiling workload for the frame-level paths (tools/profile_r03.sh): runs N frames through one entry point and prints
+"""Profiling workload for the frame-level paths (tools/profile_round.sh): runs N frames through one entry point and prints
 {"frames": total frames processed in this process} so that per-frame counter sums can be formed.
     python tools/detect_workload.py orb 640 480 1000 [frames] [reps]      rgbdfe_detect_describe_batch
     python tools/detect_workload.py sift 640 480 0 [frames] [reps]        rgbdfe_sift_detect

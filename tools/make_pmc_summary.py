@@ -3,7 +3,7 @@
 
     python tools/make_pmc_summary.py r03 [--from gpurun_out|profiles]
 
-Input: <from>/prof_<tag>/<workload>/ (gpurun_out) or profiles/<tag>/<workload>/ as tools/profile_r03.sh leaves them:
+Input: <from>/prof_<tag>/<workload>/ (gpurun_out) or profiles/<tag>/<workload>/ as tools/profile_round.sh leaves them:
 orb / heavy / sift carry a summary.json of tools/summarize_prof.py (counters per batch); the frame-level workloads
 (detect_*, sift_extract_*) are summed here over ALL kernels of the run and divided by the frames the run processed.
 HBM bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md "HBM": KiB units, gfx950 FETCH_SIZE counts
@@ -19,7 +19,7 @@ tag = sys.argv[1]
 src = sys.argv[sys.argv.index("--from") + 1] if "--from" in sys.argv else "profiles"
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag) if src == "gpurun_out" else os.path.join(ROOT, "profiles", tag)
 ISSUE = {"hamming": 1.10, "select_ransac": 1.66}  # mean ns per wave-instruction per SIMD of each kernel's mix (r01_ubench)
-out = {"collected_with": "tools/profile_r03.sh %s: rocprofv3 --kernel-trace --stats, then separate --pmc passes "
+out = {"collected_with": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --stats, then separate --pmc passes "
                          "(FETCH_SIZE / WRITE_SIZE / SQ_* / MFMA), one directory per workload under profiles/%s/" % (tag, tag)}
 
 
@@ -104,6 +104,31 @@ def frame_section(d):
             "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["ns_per_frame"]))}
 
 
+def commit_of(d):
+    try:
+        return open(os.path.join(d, "commit")).read().strip()
+    except Exception:
+        return "unknown"
+
+
+def serial_section(d):
+    """kernel trace with ONE batch in flight: per-kernel averages and the stage sums of the last traced batches"""
+    kern, n_batches = {}, 0
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rgbdfe::", "")
+            kern[name] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "total_ns": float(row["TotalDurationNs"])}
+            if "hamming_mfma" in name and "expand" not in name:
+                n_batches = int(row["Calls"])
+    nb = max(n_batches, 1)
+    stage = sum(v["total_ns"] for k, v in kern.items() if any(t in k for t in ("pair_prep", "ransac_hyp", "ransac_refine", "replay_walk", "select_ransac")))
+    ham = sum(v["total_ns"] for k, v in kern.items() if "hamming_mfma" in k and "expand" not in k)
+    return {"batches_in_trace": n_batches, "hamming_ms_per_batch": round(ham / nb / 1e6, 4),
+            "select_ransac_stage_ms_per_batch": round(stage / nb / 1e6, 4),
+            "note": "one batch in flight; kernel durations under the tracer are a few percent longer than HIP-event spans",
+            "kernels": {k: {"calls_per_batch": round(v["calls"] / nb, 2), "avg_ns": v["avg_ns"]} for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ns"]) if v["calls"] >= nb}}
+
+
 if os.path.isdir(os.path.join(base, "orb")):
     out["orb"] = orb_section(os.path.join(base, "orb"), 0.01)
 if os.path.isdir(os.path.join(base, "heavy")):
@@ -114,6 +139,20 @@ for d in sorted(glob.glob(os.path.join(base, "detect_*"))):
     out.setdefault("detect", {})[os.path.basename(d)[len("detect_"):]] = frame_section(d)
 for d in sorted(glob.glob(os.path.join(base, "sift_extract_*"))):
     out.setdefault("sift_extract", {})[os.path.basename(d)[len("sift_extract_"):]] = frame_section(d)
+for w in ("orb_serial", "heavy_serial"):
+    if os.path.isdir(os.path.join(base, w)):
+        out[w] = serial_section(os.path.join(base, w))
+# every section says which tree it was collected on; a summary is built from ONE tree unless --allow-mixed
+stamps = {}
+for name, d in [("orb", "orb"), ("ransac_heavy", "heavy"), ("sift", "sift"), ("orb_serial", "orb_serial"), ("heavy_serial", "heavy_serial")]:
+    if name in out:
+        out[name]["commit"] = stamps[name] = commit_of(os.path.join(base, d))
+for grp, prefix in (("detect", "detect_"), ("sift_extract", "sift_extract_")):
+    for key in out.get(grp, {}):
+        out[grp][key]["commit"] = stamps[grp + "." + key] = commit_of(os.path.join(base, prefix + key))
+out["commits"] = sorted(set(stamps.values()))
+if len(out["commits"]) > 1 and "--allow-mixed" not in sys.argv:
+    sys.exit("sections were collected on different trees: %s (pass --allow-mixed to build the summary anyway)" % stamps)
 dst = os.path.join(ROOT, "gpurun_out" if src == "gpurun_out" else "profiles", "%s_pmc_summary.json" % tag)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])

@@ -23,7 +23,7 @@ for i in range(4):
     fe.wait_ticket(fe.submit_pair_list(pq, pt, buf.data_ptr()), None)
     fe.synchronize()
 PY
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python /tmp/serial_run.py > $O/run.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O -o t -- python /tmp/serial_run.py > $O/run.log 2>&1)
 python - <<'PY'
 import csv, glob, os
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/trace_serial/**/*kernel_trace.csv", recursive=True)[0]
