@@ -85,6 +85,18 @@ __device__ __forceinline__ int fresh(int v) {
 
 constexpr int kHypThreads = 256;
 
+// Diagnostics build only (-DRGBDFE_SPLIT_STATS): what the refinement kernel's servers saw, summed over workgroups and launches
+// [0] half-rounds, [1] workgroups, [2] half-rounds scored by ticket, [3] scorings, [4] SVD requests, [5] units loaded,
+// [6] hand-outs, [7] longest run of half-rounds of a workgroup
+#ifdef RGBDFE_SPLIT_STATS
+__device__ unsigned long long g_split_stats[8];
+#define ST_ADD(I, V) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_split_stats[I], (unsigned long long)(V)); }
+#define ST_MAX(I, V) { if ((threadIdx.x & 63) == 0) atomicMax(&g_split_stats[I], (unsigned long long)(V)); }
+#else
+#define ST_ADD(I, V)
+#define ST_MAX(I, V)
+#endif
+
 constexpr int kStreamWaves = 8;                        // waves of a refinement workgroup: 7 workers + the server
 constexpr int kWorkers = kStreamWaves - 1;
 constexpr int kStreamThreads = kStreamWaves * kWave;
@@ -715,6 +727,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         cx.ke = ke;
         cx.state = kUnitLoading;
       }
+      ST_ADD(5, 1)
     }
   };
 
@@ -762,6 +775,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     SlotS& sl = lds.slot[s];
     const bool p = lane < kGroupSlots && sl.iter >= 0 && sl.active == kSlotActive;
     if (__ballot(p) == 0ull) return;
+    ST_ADD(4, __popcll(__ballot(p)))
     Tfc mine;
     mine.reset();  // lanes without a request: the zero matrix (no rotation, one sweep)
     if (p) {
@@ -850,6 +864,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       if (key == L) ord += __popcll(mL & below);
     }
     const bool take = is_free && ord < n_take;
+    ST_ADD(6, n_take)
     int b = 0, at = 0;
     {
       int before = 0;   // items of the buffers in front of buffer q
@@ -918,6 +933,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   for (int h = 0;; ++h) {
     const int g = h & 1, gs = 1 - g;   // gs: the group nobody scores in this half-round
     const int by_ticket = __builtin_amdgcn_readfirstlane(lds.tickets[g]);
+    ST_ADD(0, 1) ST_ADD(2, by_ticket) ST_ADD(3, lds.n_act[g])
     serve_svd(gs);
     recycle(gs);
     complete_loads();
@@ -935,7 +951,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       lds_barrier();
     }
     lds_barrier();        // (the workers' bookkeeping and refits of group g)
-    if (!more) break;
+    if (!more) { ST_ADD(1, 1) ST_MAX(7, h + 1) break; }
   }
 }
 
@@ -996,4 +1012,15 @@ int ransac_split_words_per_pair(int ransac_iterations) {
 int ransac_split_max_share() { return kMaxShare; }
 
 }  // namespace rgbdfe
+
+#ifdef RGBDFE_SPLIT_STATS
+extern "C" int rgbdfe_debug_split_stats(unsigned long long* out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(rgbdfe::g_split_stats), 64) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_stats), z, 64) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
