@@ -269,8 +269,8 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   for (size_t i = 0; i < frame_imgs.size(); ++i) add_tiles((int)i, frame_imgs[i].w, frame_imgs[i].h, 16);  // orb_blur_kernel: 64 x 16
   units_blur_n = (int)units.size() - units_blur_off;
   units_rows_off = (int)units.size();
-  for (size_t i = 0; i < cell_imgs.size(); ++i)
-    for (int y = 0; y < cell_imgs[i].h; ++y) units.push_back(TileUnit{(uint16_t)i, 0, (uint16_t)y, 0});
+  for (size_t i = 0; i < cell_imgs.size(); ++i)   // orb_emit_kernel: one wave per 64 rows of an image
+    for (int y = 0; y < cell_imgs[i].h; y += 64) units.push_back(TileUnit{(uint16_t)i, 0, (uint16_t)y, 0});
   units_rows_n = (int)units.size() - units_rows_off;
   for (int l = 1; l < kLevels; ++l) {
     units_resize_off[l] = (int)units.size();

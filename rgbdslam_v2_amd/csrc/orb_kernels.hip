@@ -369,10 +369,13 @@ __global__ __launch_bounds__(256) void orb_row_scan_kernel(const ImgDesc* __rest
   }
 }
 
-// one wave per image row: write the keypoints of the row at img_base + row_offset + rank (raster order)
+// one wave per 64 rows of an image, LANE = ROW: the lane writes the keypoints of its row at img_base + row_offset + rank
+// (raster order).  The row scan's offsets say which rows have keypoints at all (most have none) and where they go; a lane
+// with keypoints loads its row's keep words (four at a time, all lanes' loads in flight together) and walks their set bits.
+// (Rounds 1-4: one wave per row, ~55 000 waves per super-frame, most of them ending after the chain rows[] -> imgs[] -> mask
+// words of an empty row.  A wave per 64 rows that walked its non-empty rows one after the other took as long: the chain of
+// dependent loads per row had only moved inside the wave.)
 __device__ __forceinline__ int wave_sum(int v);
-// (one-wave workgroups: four rows per 256-thread workgroup was measured and is slower, 44 -> 66 us per step in the same
-// trace -- the kernel's time is the chain rows[] -> imgs[] -> mask words of ~55 000 waves, most of which end there)
 __global__ __launch_bounds__(64) void orb_emit_kernel(const ImgDesc* __restrict__ imgs, const OrbCtl ctl,
                                                       const uint8_t* __restrict__ score_pool,
                                                       const uint64_t* __restrict__ keep_mask,
@@ -382,15 +385,16 @@ __global__ __launch_bounds__(64) void orb_emit_kernel(const ImgDesc* __restrict_
   const TileUnit u = rows[blockIdx.x];
   const int img = u.img;
   const ImgDesc im = imgs[img];
-  const int y = u.by;
-  if (y >= im.h || !ctl.active[im.cell]) return;
+  if (!ctl.active[im.cell]) return;
+  const int y = u.by + lane_id;
+  // keypoints of the lane's row = the next row's offset (the image's total behind the last row) minus its own
+  int off_mine = 0, cnt_mine = 0;
+  if (y < im.h) {
+    off_mine = row_off[im.row_off + y];
+    cnt_mine = (y + 1 < im.h ? row_off[im.row_off + y + 1] : img_total[img]) - off_mine;
+  }
+  if (__ballot(cnt_mine > 0) == 0ull) return;
   const int words = (im.w + 63) >> 6;
-  const uint64_t* __restrict__ km = keep_mask + im.keep_off + (size_t)y * words;
-  // a row without keypoints (most rows) costs its mask words only
-  uint64_t any = 0;
-  for (int wd = lane_id; wd < words; wd += 64) any |= km[wd];
-  if (__ballot(any != 0) == 0) return;
-  const uint8_t* sc = score_pool + im.score_off;
   // where this image's keypoints start = the keypoints of the images before it (at most 512 counts: a wave sums them,
   // which is cheaper than a scan launch in front of this kernel)
   int img_base = 0;
@@ -399,19 +403,26 @@ __global__ __launch_bounds__(64) void orb_emit_kernel(const ImgDesc* __restrict_
     img_base += j < img ? img_total[j] : 0;
   }
   img_base = wave_sum(img_base);
-  int base = img_base + row_off[im.row_off + y];
-  for (int wd = 0; wd < words; ++wd) {
-    const uint64_t m = km[wd];
-    if (!m) continue;
-    const int x = wd * 64 + lane_id;
-    if ((m >> lane_id) & 1) {
-      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      RawKp k;
-      k.x = (uint16_t)x; k.y = (uint16_t)y; k.img = (uint16_t)img; k.score = (uint16_t)sc[(size_t)y * im.w + x];
-      k.harris = 0.f; k.angle = 0.f;
-      out[base + rank] = k;
+  const bool mine = cnt_mine > 0;
+  const uint64_t* __restrict__ km = keep_mask + im.keep_off + (size_t)(mine ? y : 0) * words;
+  const uint8_t* __restrict__ sc = score_pool + im.score_off + (size_t)(mine ? y : 0) * im.w;
+  RawKp* __restrict__ dst = out + img_base + off_mine;
+  for (int wd0 = 0; wd0 < words; wd0 += 4) {
+    uint64_t m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = (mine && wd0 + q < words) ? km[wd0 + q] : 0ull;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint64_t mm = m[q];
+      while (mm != 0ull) {
+        const int x = (wd0 + q) * 64 + (int)__builtin_ctzll(mm);
+        mm &= mm - 1ull;
+        RawKp k;
+        k.x = (uint16_t)x; k.y = (uint16_t)y; k.img = (uint16_t)img; k.score = (uint16_t)sc[x];
+        k.harris = 0.f; k.angle = 0.f;
+        *dst++ = k;
+      }
     }
-    base += __popcll(m);
   }
 }
 

@@ -1,8 +1,16 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/ -q -m gpu --timeout 200 -x 2>&1 | grep -E "passed|failed|error|Timeout|Error" | tail -6
-for lib in librgbdfe.so librgbdfe_v_l3.so; do
-  echo -n "$lib: "
-  RGBDFE_LIB=$GRAFT_REPO_ROOT/rgbdslam_v2_amd/$lib timeout 100 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(json.dumps({'value':d['value'],'ms':d['ms_per_step'],'serial':d['timing']['serial_stage_ms']['select_ransac'],'parity':d['parity_check']['ok']}))"
-done
+timeout 300 python -m pytest tests/test_gpu_orb.py -x -q -m gpu --timeout 150 2>&1 | grep -E "passed|failed|error" | tail -3
+cd /tmp && export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r05/emit_lane_row; rm -rf $O; mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o trace -- python $GRAFT_REPO_ROOT/tools/detect_workload.py orb 640 480 1000 7 24 > $O/run.log 2>&1
+find $O -name "*.db" -delete
+python - <<P
+import csv, glob
+f = glob.glob("$O/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("  kernels total %.1f us per frame" % (tot / (7 * 24) / 1e3))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:9]:
+    print("  %-40s %7.2f us/frame (%s calls)" % (r["Name"].replace("rgbdfe::", "").split("(")[0][:40], float(r["TotalDurationNs"]) / (7 * 24) / 1e3, r["Calls"]))
+P
+cd $GRAFT_REPO_ROOT; timeout 100 python tools/bench_detect_batch.py 640 480 1000 112 5 2>&1 | tail -1 | cut -c1-220
