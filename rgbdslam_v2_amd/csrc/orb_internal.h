@@ -115,6 +115,8 @@ void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* ou
                              int first, int count, hipStream_t s);
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,
                      hipStream_t s);
+void launch_orb_blur_always(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,
+                            hipStream_t s);
 void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,
                       uint8_t* desc, hipStream_t s);
 void orb_upload_pattern(const int8_t* host_pattern);

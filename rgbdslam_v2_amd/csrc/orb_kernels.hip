@@ -15,6 +15,9 @@
 // order with __ballot / mbcnt prefixes (row counts -> block scan -> emit), so the order of keypoints is
 // the one cv::FAST produces; per-keypoint measurements (Harris response, intensity-centroid angle, rBRIEF)
 // use one wave per keypoint with shuffle reductions.
+#include <stdlib.h>
+#include <string.h>
+
 #include "orb_internal.h"
 
 namespace rgbdfe {
@@ -657,6 +660,90 @@ __global__ __launch_bounds__(256) void orb_brief_kernel(const uint8_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// rBRIEF with the Gaussian computed where it is read (round 5; RGBDFE_ORB_BRIEF=patch, NOT the default): a keypoint's 256
+// tests read 512 pixels of the BLURRED level within 18 pixels of it, and blurring the whole pyramid (orb_blur_kernel: a read
+// and a write of 3.1 x W x H bytes per frame) to read ~1000 x 512 of its pixels is a second full pass over the pyramid.
+// Here a wave copies the 45 x 45 raw pixels around its keypoint (the samples' reach + the 7 x 7 kernel's halo, reflect-101
+// coordinates) into LDS and every lane forms the blurred value of its 8 samples from there:
+// (sum_j c[j] * sum_i c[i] * p[y + j][x + i] + 2^15) >> 16, the integer the separable pass computes (the row sums fit 16
+// bits, nothing is rounded in between).  Samples outside the level read the raw reflected pixel, as before.
+// Same bytes (tests/test_gpu_orb.py passes in both modes) -- and measured SLOWER at the bench's density: 49 byte reads and
+// multiply-adds per sample are 13.1 us per 640x480 frame of ~920 keypoints against 7.1 (blur) + 1.7 (brief) through the pool
+// (profiles/r05/brief_patch_ab.log); it pays below ~500 keypoints per frame, which no caller of the batch pipeline has.
+// Kept as the switch for sparse callers and as the record of the attempt (VERDICT r4 #4a asked for the blur pass to go).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBriefReach = 19;                       // |rotated pattern point| <= 18.39 (the table's largest radius), rounded
+constexpr int kBriefR = kBriefReach + 3, kBriefW = 2 * kBriefR + 1, kBriefStride = 48;
+static_assert(kBriefStride >= kBriefW && kBriefStride % 4 == 0, "rows of whole dwords");
+__global__ __launch_bounds__(256) void orb_brief_patch_kernel(const uint8_t* __restrict__ pool, const ImgDesc* __restrict__ imgs,
+                                                              const DescKp* __restrict__ kps, int n, uint8_t* __restrict__ desc) {
+  __shared__ __attribute__((aligned(4))) uint8_t region_all[4][kBriefW * kBriefStride];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= n) return;   // (no workgroup barrier below: a wave's region is its own)
+  uint8_t* __restrict__ region = region_all[wave];
+  const DescKp kp = kps[k];
+  const ImgDesc im = imgs[kp.level];
+  const uint8_t* __restrict__ raw = pool + im.off;
+  const int gx0 = kp.cx - kBriefR, gy0 = kp.cy - kBriefR;
+  const bool rows_inside = gx0 >= 0 && gx0 + kBriefStride - 1 < im.w;   // whole dwords of every row lie inside the level
+  for (int i = lane; i < kBriefW * (kBriefStride / 4); i += 64) {
+    const int r = i / (kBriefStride / 4), j = i - r * (kBriefStride / 4);
+    const uint8_t* __restrict__ row = raw + (size_t)reflect101(gy0 + r, im.h) * im.stride;
+    uint32_t v;
+    if (rows_inside) {
+      v = *reinterpret_cast<const u32_unaligned*>(row + gx0 + 4 * j);
+    } else {
+      v = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v |= (uint32_t)row[reflect101(gx0 + 4 * j + b, im.w)] << (8 * b);
+    }
+    *reinterpret_cast<uint32_t*>(region + r * kBriefStride + 4 * j) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const float a = kp.cos_a, b = kp.sin_a;
+  const int byte = lane >> 1, half = lane & 1;
+  int bits = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int test = byte * 8 + half * 4 + t;
+    int v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float px = (float)c_pattern[(test * 2 + e) * 2], py = (float)c_pattern[(test * 2 + e) * 2 + 1];
+      const float x = px * a - py * b;
+      const float y = px * b + py * a;
+      const int dx = __float2int_rn(x), dy = __float2int_rn(y);
+      const int ix = kp.cx + dx, iy = kp.cy + dy;
+      const uint8_t* __restrict__ p = region + (dy + kBriefR) * kBriefStride + (dx + kBriefR);
+      if (ix >= 0 && ix < im.w && iy >= 0 && iy < im.h) {
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          int h = 0;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) h += c_gauss[i] * (int)p[(j - 3) * kBriefStride + (i - 3)];
+          acc += c_gauss[j] * h;
+        }
+        v[e] = min(max((acc + (1 << 15)) >> 16, 0), 255);
+      } else {  // the unblurred reflect-101 border copyMakeBorder wrote before the in-place blur
+        v[e] = p[0];
+      }
+    }
+    bits |= (v[0] < v[1]) << (half * 4 + t);
+  }
+  bits |= __shfl_xor(bits, 1);
+  if (half == 0) desc[(size_t)k * 32 + byte] = (uint8_t)bits;
+}
+
+static bool orb_brief_from_pool() {
+  static const bool patch = getenv("RGBDFE_ORB_BRIEF") && strcmp(getenv("RGBDFE_ORB_BRIEF"), "patch") == 0;
+  return !patch;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 void launch_orb_resize(uint8_t* pool, const ResizeJob* jobs, const TileUnit* units, int n_units, hipStream_t s) {
@@ -696,14 +783,24 @@ void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* ou
     hipLaunchKernelGGL(orb_measure_kernel, dim3((count + 3) / 4), dim3(256), 0, s, pool, imgs, out, img_total, n_imgs,
                        first);
 }
+// (no blurred pyramid with RGBDFE_ORB_BRIEF=patch: that descriptor kernel blurs what it reads)
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,
                      hipStream_t s) {
+  if (!orb_brief_from_pool()) return;
+  hipLaunchKernelGGL(orb_blur_kernel, dim3(n_units), dim3(256), 0, s, pool, imgs, blur_pool, units);
+}
+// the blur kernel whatever the mode (tests/test_emu_orb_kernels.py, A/B runs)
+void launch_orb_blur_always(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,
+                            hipStream_t s) {
   hipLaunchKernelGGL(orb_blur_kernel, dim3(n_units), dim3(256), 0, s, pool, imgs, blur_pool, units);
 }
 void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,
                       uint8_t* desc, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(orb_brief_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pool, blur_pool, imgs, kps, n, desc);
+  if (orb_brief_from_pool())
+    hipLaunchKernelGGL(orb_brief_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pool, blur_pool, imgs, kps, n, desc);
+  else
+    hipLaunchKernelGGL(orb_brief_patch_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pool, imgs, kps, n, desc);
 }
 
 }  // namespace rgbdfe

@@ -77,6 +77,6 @@ extern "C" void emu_orb_blur(const uint8_t* src, int w, int h, uint8_t* dst) {
   std::vector<rgbdfe::TileUnit> units;
   for (int by = 0; by < (h + 15) / 16; ++by)
     for (int bx = 0; bx < (w + 63) / 64; ++bx) units.push_back(rgbdfe::TileUnit{0, (uint16_t)bx, (uint16_t)by, 0});
-  rgbdfe::launch_orb_blur(pool.data(), &im, units.data(), (int)units.size(), blur.data(), nullptr);
+  rgbdfe::launch_orb_blur_always(pool.data(), &im, units.data(), (int)units.size(), blur.data(), nullptr);
   memcpy(dst, blur.data(), (size_t)w * h);
 }
