@@ -89,7 +89,14 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
 // coefficient tables below are filled with: per region one table entry per column and per row instead of the double
 // arithmetic per pixel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
+// kPyrWaves waves share a tile's pixels level by level.  Measured in one call (640x480, 7 frames per launch, us per frame:
+// profiles/r05/pyr_waves_ab*.log): 1 wave 24.7, 2 waves 17.2, 4 waves 9.4-9.8, 8 waves 13.8, 16 waves 19.0 -- fewer waves leave
+// the chain of seven dependent levels too long, more waves spend their time in the level loops' bookkeeping and barriers.
+#ifndef RGBDFE_PYR_WAVES
+#define RGBDFE_PYR_WAVES 4
+#endif
+constexpr int kPyrWaves = RGBDFE_PYR_WAVES, kPyrThreads = 64 * kPyrWaves;
+__global__ __launch_bounds__(kPyrThreads) void orb_pyramid_kernel(uint8_t* __restrict__ pool, const ResizeJob* __restrict__ jobs,
                                                           const PyrTile* __restrict__ tiles, const PyrPlan plan) {
   // (every LDS access below indexes pyr_lds itself with an integer offset: pointers picked from an array of two buffer
   // pointers made the compiler fall back to flat loads and stores, each with its own wait)
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ 
     const ResizeJob j = jobs[plan.level_job_begin[1] + chain];
     const uint8_t* __restrict__ src = pool + j.src_off + (size_t)py0 * j.sstride + px0;
     const int dwords = prw >> 2, rows = tl->ny1[0] - py0;
-    for (int r = ty; r < rows; r += 4)
+    for (int r = ty; r < rows; r += kPyrWaves)
       for (int d = tx; d < dwords; d += 64)
         *reinterpret_cast<uint32_t*>(&pyr_lds[buf_off[1] + 4 * (r * dwords + d)]) =
             *reinterpret_cast<const u32_unaligned*>(src + (size_t)r * j.sstride + 4 * d);
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ 
     if (rw <= 0 || rh <= 0) break;   // (block-uniform; a tile without pixels at level l has none below it either)
     const ResizeJob j = jobs[plan.level_job_begin[l] + chain];
     // taps and weights of the region's columns and rows; source coordinates relative to the level below as it lies in LDS
-    for (int i = tid; i < rw + rh; i += 256) {
+    for (int i = tid; i < rw + rh; i += kPyrThreads) {
       if (i < rw) {
         const ResizeTapX t = resize_tap_x(x0 + i, j.scale_x, j.sw);
         *reinterpret_cast<ushort4*>(&pyr_lds[xtab_off + 8 * i]) =
@@ -141,11 +148,11 @@ __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ 
       const bool own_x = x0 + x >= ox0 && x0 + x < ox1;
       const int c0 = prev + cx.x, c1 = prev + cx.y;
       // four rows per step: all their taps are read before the first result is formed
-      for (int yb = ty; yb < rh; yb += 16) {
+      for (int yb = ty; yb < rh; yb += 4 * kPyrWaves) {
         int v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int y = min(yb + 4 * u, rh - 1);   // (rows past the region repeat its last row and are not stored)
+          const int y = min(yb + kPyrWaves * u, rh - 1);   // (rows past the region repeat its last row and are not stored)
           const ushort4 cy = *reinterpret_cast<const ushort4*>(&pyr_lds[ytab_off + 8 * y]);
           const int h0 = pyr_lds[c0 + cy.x] * w0 + pyr_lds[c1 + cy.x] * w1;
           const int h1 = pyr_lds[c0 + cy.y] * w0 + pyr_lds[c1 + cy.y] * w1;
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void orb_pyramid_kernel(uint8_t* __restrict__ 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int y = yb + 4 * u;
+          const int y = yb + kPyrWaves * u;
           if (y < rh) {
             pyr_lds[cur + y * rw + x] = (uint8_t)v[u];
             if (own_x && y0 + y >= oy0 && y0 + y < oy1) dst[(size_t)(y0 + y) * j.dw + (x0 + x)] = (uint8_t)v[u];
@@ -754,7 +761,7 @@ void launch_orb_pyramid(uint8_t* pool, const ResizeJob* jobs, const PyrTile* til
                         hipStream_t s) {
   if (n_tiles == 0) return;
   const size_t lds = (size_t)plan.buf_bytes[0] + plan.buf_bytes[1] + sizeof(ushort4) * (size_t)(plan.max_rw + plan.max_rh);
-  hipLaunchKernelGGL(orb_pyramid_kernel, dim3(n_tiles), dim3(256), lds, s, pool, jobs, tiles, plan);
+  hipLaunchKernelGGL(orb_pyramid_kernel, dim3(n_tiles), dim3(kPyrThreads), lds, s, pool, jobs, tiles, plan);
 }
 // FAST-9/16 scores + 3x3 NMS + mask + border filters (keep bits, per-row counts), then the per-image scan of the row counts
 void launch_orb_fast_nms(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* units, int n_units,
