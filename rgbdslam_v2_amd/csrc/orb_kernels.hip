@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(uint8_t* __restrict__ p
 // arithmetic per pixel.
 // ------------------------------------------------------------------------------------------------
 // kPyrWaves waves share a tile's pixels level by level.  Measured in one call (640x480, 7 frames per launch, us per frame:
-// profiles/r05/pyr_waves_ab*.log): 1 wave 24.7, 2 waves 17.2, 4 waves 9.4-9.8, 8 waves 13.8, 16 waves 19.0 -- fewer waves leave
+// profiles/r05_logs/pyr_waves_ab*.log): 1 wave 24.7, 2 waves 17.2, 4 waves 9.4-9.8, 8 waves 13.8, 16 waves 19.0 -- fewer waves leave
 // the chain of seven dependent levels too long, more waves spend their time in the level loops' bookkeeping and barriers.
 #ifndef RGBDFE_PYR_WAVES
 #define RGBDFE_PYR_WAVES 4
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void orb_brief_kernel(const uint8_t* __restric
 // bits, nothing is rounded in between).  Samples outside the level read the raw reflected pixel, as before.
 // Same bytes (tests/test_gpu_orb.py passes in both modes) -- and measured SLOWER at the bench's density: 49 byte reads and
 // multiply-adds per sample are 13.1 us per 640x480 frame of ~920 keypoints against 7.1 (blur) + 1.7 (brief) through the pool
-// (profiles/r05/brief_patch_ab.log); it pays below ~500 keypoints per frame, which no caller of the batch pipeline has.
+// (profiles/r05_logs/brief_patch_ab.log); it pays below ~500 keypoints per frame, which no caller of the batch pipeline has.
 // Kept as the switch for sparse callers and as the record of the attempt (VERDICT r4 #4a asked for the blur pass to go).
 // ------------------------------------------------------------------------------------------------
 constexpr int kBriefReach = 19;                       // |rotated pattern point| <= 18.39 (the table's largest radius), rounded
