@@ -586,9 +586,9 @@ def main():
             "step_ms_pipelined": round(ms_per_step, 4),
             "launches_per_stage": "one wave per pair (1 kernel per batch)" if args.ransac_path == "one_wave" else
                                   "pair_prep_kernel + ransac_hyp_kernel (all iterations' hypotheses + pre-screen) + per phase "
-                                  "ransac_refine_kernel (streaming refinement; bounded waits), its guarded fallback launch "
-                                  "(select_ransac_kernel<1>: returns at once unless the refinement gave up) and "
-                                  "replay_walk_kernel + 1 result launch; avg_launch_ms spans the whole stage",
+                                  "ransac_refine_kernel (7 workers + 1 server per workgroup, hardware barriers only: no spin "
+                                  "wait, no fallback launch) and replay_walk_kernel + 1 result launch; avg_launch_ms spans the "
+                                  "whole stage",
             "pair_path_GBs": round(value / world * b_pair / 1e9, 3),
             "note": "the HBM fraction is what the contract asks for and says only that this path is NOT memory bound "
                     "(SURVEY.md 8(d)); the limiter is instruction issue: see issue_roofline",
