@@ -88,13 +88,21 @@ constexpr int kHypThreads = 256;
 // Diagnostics build only (-DRGBDFE_SPLIT_STATS): what the refinement kernel's servers saw, summed over workgroups and launches
 // [0] half-rounds, [1] workgroups, [2] half-rounds scored by ticket, [3] scorings, [4] SVD requests, [5] units loaded,
 // [6] hand-outs, [7] longest run of half-rounds of a workgroup
+// [8..15] the server's time (100 MHz ticks): SVD, recycle, load completion, hand-out, active list, load issue, scoring by
+// ticket, waiting at the barriers; [16..19] a worker's (wave 0): scoring, bookkeeping + refits, waiting at the barriers, -
 #ifdef RGBDFE_SPLIT_STATS
-__device__ unsigned long long g_split_stats[8];
+__device__ unsigned long long g_split_stats[24];
 #define ST_ADD(I, V) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_split_stats[I], (unsigned long long)(V)); }
 #define ST_MAX(I, V) { if ((threadIdx.x & 63) == 0) atomicMax(&g_split_stats[I], (unsigned long long)(V)); }
+#define ST_T0 unsigned long long st_t = __builtin_amdgcn_s_memrealtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ST_LAP(I) { const unsigned long long st_n = __builtin_amdgcn_s_memrealtime(); st_acc[I] += st_n - st_t; st_t = st_n; }
+#define ST_FLUSH(BASE, N) { for (int st_i = 0; st_i < (N); ++st_i) ST_ADD((BASE) + st_i, st_acc[st_i]) }
 #else
 #define ST_ADD(I, V)
 #define ST_MAX(I, V)
+#define ST_T0
+#define ST_LAP(I)
+#define ST_FLUSH(BASE, N)
 #endif
 
 constexpr int kStreamWaves = 8;                        // waves of a refinement workgroup: 7 workers + the server
@@ -527,6 +535,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     // =========================================================================================== a worker
     WaveLds& wl = lds.w[wave];
     lds_barrier();   // (the server's prologue: the first unit's iterations are in group 0's slots)
+    ST_T0
     for (int h = 0;; ++h) {
       const int g = h & 1;
       const int lane = fresh(threadIdx.x & (kWave - 1));
@@ -534,7 +543,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       // ================================ one pass of the refinement loop (:1140) for every active slot of group g
       if (__builtin_amdgcn_readfirstlane(lds.tickets[g]) != 0) {
         score_tickets(g);
+        ST_LAP(0)
         lds_barrier();   // every scoring of the pass is done
+        ST_LAP(2)
       } else {           // cheap scorings: every worker scores its own slots and goes on without meeting the others
         uint64_t act = __ballot(lane < kWaveSlots && mine[min(lane, kWaveSlots - 1)].active == kSlotActive);
         while (act != 0ull) {
@@ -543,6 +554,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           score_slot(mine[j]);
         }
         lsync();
+        ST_LAP(0)
       }
       // ---- the loop's bookkeeping (:1154-1166), lane = slot
       bool still = false;
@@ -622,13 +634,22 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           }
         }
       }
+      ST_LAP(1)
       lds_barrier();
+      ST_LAP(2)
       if (__builtin_amdgcn_readfirstlane(lds.quit) != 0) break;
     }
+#ifdef RGBDFE_SPLIT_STATS
+    if (wave == 0) ST_FLUSH(16, 3)
+#endif
     return;
   }
 
   // ============================================================================================= the server
+  // (s_setprio 3 for this wave -- its SVD is ~1500 dependent instructions on a SIMD it shares with three other waves -- was
+  // measured: 1.068 -> 1.048 ms serial stage, 1.117 -> 1.133 ms per pipelined step, i.e. nothing.  The per-phase clocks of
+  // the counter build (make stats, tools/refine_stats.py) say why: server and workers are each busy ~60 % of a half-round at
+  // 0.01 z^2 (75 % at 0.002 z^2) and wait the rest at the barrier for the slowest worker of that half-round.)
   // Units come off the launch's counter a block at a time, lane = unit.  `nx_*`: the block taken last, its facts still on
   // their way (the loads are not awaited until the block is needed); `live` / `u_*`: the block in use.
   uint64_t live = 0ull;        // units of the block in use that have work and are not loaded yet
@@ -930,16 +951,24 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   list_active(0);
   issue_loads();
   lds_barrier();
+  ST_T0
   for (int h = 0;; ++h) {
     const int g = h & 1, gs = 1 - g;   // gs: the group nobody scores in this half-round
     const int by_ticket = __builtin_amdgcn_readfirstlane(lds.tickets[g]);
     ST_ADD(0, 1) ST_ADD(2, by_ticket) ST_ADD(3, lds.n_act[g])
+    ST_LAP(7)
     serve_svd(gs);
+    ST_LAP(0)
     recycle(gs);
+    ST_LAP(1)
     complete_loads();
+    ST_LAP(2)
     hand_out(gs);
+    ST_LAP(3)
     list_active(gs);
+    ST_LAP(4)
     issue_loads();
+    ST_LAP(5)
     const int lane = fresh(threadIdx.x & (kWave - 1));
     bool busy = lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state != kUnitFree;   // items to hand out, in flight, or a load
     busy = busy || (lane < kStreamSlots && lds.slot[min(lane, kStreamSlots - 1)].iter >= 0) ||
@@ -948,10 +977,12 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     if (!more && lane == 0) lds.quit = 1;
     if (by_ticket) {
       score_tickets(g);   // its own duties done, the server scores like everybody else
+      ST_LAP(6)
       lds_barrier();
     }
     lds_barrier();        // (the workers' bookkeeping and refits of group g)
-    if (!more) { ST_ADD(1, 1) ST_MAX(7, h + 1) break; }
+    ST_LAP(7)
+    if (!more) { ST_ADD(1, 1) ST_MAX(7, h + 1) ST_FLUSH(8, 8) break; }
   }
 }
 
@@ -1014,11 +1045,11 @@ int ransac_split_max_share() { return kMaxShare; }
 }  // namespace rgbdfe
 
 #ifdef RGBDFE_SPLIT_STATS
-extern "C" int rgbdfe_debug_split_stats(unsigned long long* out8, int reset) {
-  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(rgbdfe::g_split_stats), 64) != hipSuccess) return -1;
+extern "C" int rgbdfe_debug_split_stats(unsigned long long* out24, int reset) {
+  if (out24 && hipMemcpyFromSymbol(out24, HIP_SYMBOL(rgbdfe::g_split_stats), 192) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[8] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_stats), z, 64) != hipSuccess) return -1;
+    unsigned long long z[24] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_stats), z, 192) != hipSuccess) return -1;
   }
   return 0;
 }

@@ -27,7 +27,7 @@ buf = torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cu
 for i in range(2):
     fe.wait_ticket(fe.submit_pair_list(pq, pt, buf.data_ptr()), None)
 fe.synchronize()
-st = (C.c_ulonglong * 8)()
+st = (C.c_ulonglong * 24)()
 L.rgbdfe_debug_split_stats(st, 1)
 fe.reset_kernel_time()
 fe.set_profiling(True)
@@ -44,4 +44,8 @@ print(json.dumps({"depth_noise": noise, "batches": B, "stage_ms_per_batch": roun
                   "workgroup_launches_with_work_per_batch": v[1] / B, "half_rounds_per_workgroup": round(v[0] / wgs, 1),
                   "longest_workgroup_half_rounds": v[7], "ticket_half_round_fraction": round(v[2] / max(v[0], 1), 3),
                   "scorings_per_batch": v[3] / B, "scorings_per_half_round": round(v[3] / max(v[0], 1), 2),
-                  "svd_requests_per_batch": v[4] / B, "units_loaded_per_batch": v[5] / B, "items_per_batch": v[6] / B}))
+                  "svd_requests_per_batch": v[4] / B, "units_loaded_per_batch": v[5] / B, "items_per_batch": v[6] / B,
+                  "server_us_per_half_round": dict(zip(("svd", "recycle", "complete_loads", "hand_out", "list_active", "issue_loads",
+                                                        "ticket_scoring", "barrier_wait"), [round(x / 100.0 / max(v[0], 1), 2) for x in v[8:16]])),
+                  "worker0_us_per_half_round": dict(zip(("scoring", "bookkeeping_refit", "barrier_wait"),
+                                                        [round(x / 100.0 / max(v[0], 1), 2) for x in v[16:19]]))}))
