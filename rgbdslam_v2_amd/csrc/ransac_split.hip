@@ -125,7 +125,10 @@ static_assert(kStreamSlots <= 2 * kWave, "the server's end-of-work test looks at
 #endif
 constexpr int kTicketsFrom = RGBDFE_SPLIT_TICKETS_FROM;  // expensive scorings in a group's pass from which they go out by ticket
 constexpr int kBufs = RGBDFE_SPLIT_BUFS;              // units (pair, iteration range) resident in a workgroup's LDS
-constexpr int kMaxShare = 512;                        // iterations of a unit at most (the host cuts longer ranges)
+#ifndef RGBDFE_SPLIT_MAX_SHARE
+#define RGBDFE_SPLIT_MAX_SHARE 512
+#endif
+constexpr int kMaxShare = RGBDFE_SPLIT_MAX_SHARE;      // iterations of a unit at most (the host cuts longer ranges)
 constexpr int kMaskLanes = kMaxShare / kWave + 1;     // words of a pair's viable mask that can overlap a unit's range
 constexpr int kMVec = RGBDFE_MAX_MATCHES * kRec / 4;  // float4s of a pair's match records
 constexpr int kPrepVec = (int)(sizeof(PairPrep) / 16);  // a pair's match records + facts as 16-byte pieces
