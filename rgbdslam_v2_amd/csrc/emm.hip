@@ -10,7 +10,7 @@
 // float / double operation order is the oracle's (oracle/rgbd_oracle.c), compiled with -ffp-contract=off:
 // results are bit-identical.  The EMM's two cdf tests compare the depth difference against boundaries found
 // on the host (bisection with the host's libm erf, then the exact pre-image under the IEEE division by
-// sigma * SQRT_2; rgbdfe_api.hip), so neither a device erf nor a division enters the decision.
+// sigma * SQRT_2; api_frame.hip), so neither a device erf nor a division enters the decision.
 #include "rgbdfe_internal.h"
 
 namespace rgbdfe {

@@ -96,7 +96,7 @@ OrbWorkspace::~OrbWorkspace() { release(); }
 
 // Zero-fills of freshly allocated device memory go through a stream of the workspace's own and wait for THAT stream: a
 // NULL-stream hipMemset would need a device-wide synchronisation to be ordered before the context's non-blocking streams,
-// and hipDeviceSynchronize() invalidates a hipGraph capture another thread of the process may have open (rgbdfe_api.hip).
+// and hipDeviceSynchronize() invalidates a hipGraph capture another thread of the process may have open (api_batches.hip).
 // One stream per device for the whole process (a caller that alternates devices -- the multi-device handle's thread, tests
 // with contexts on several devices -- used to get a new thread-local stream on every switch and leak the old one).
 static hipError_t zero_fill_and_wait(void* p, size_t bytes) {

@@ -38,7 +38,7 @@ struct RansacConst {
 // takes the min over planes.  key_planes_capacity = planes the keys buffer can hold in total.
 // HammingGeometry = everything of a Hamming launch that depends on the batch's node sizes: query blocks per pair and
 // train-row splits (key planes) per pair.  Batches with equal (n_pairs, geometry) are the same launch -- what the
-// hipGraph cache of rgbdfe_api.hip keys on.
+// hipGraph cache of api_batches.hip keys on.
 struct HammingGeometry { uint32_t qblocks, tsplit; };
 HammingGeometry hamming_nn_geometry(uint32_t n_pairs, uint32_t max_nq, uint32_t max_nt, uint32_t key_planes_capacity);
 uint32_t launch_hamming_nn(const uint32_t* desc_pool, const PairWork* work, uint32_t* keys,

@@ -108,7 +108,7 @@ def test_small_batches_repeat_bytes(data):
 
 def test_graph_replay_equals_plain_launches(data, monkeypatch):
     """The launch chain of an ORB batch is captured into a hipGraph once per batch shape and replayed afterwards
-    (rgbdfe_api.hip enqueue_pairs): first use (capture), replays, another shape, new pair lists through the same graph, a
+    (api_batches.hip enqueue_pairs): first use (capture), replays, another shape, new pair lists through the same graph, a
     parameter change (new key), the device-output entry points -- every result equals the plain stream launches of a
     context created with RGBDFE_GRAPHS=0."""
     import torch

@@ -2,7 +2,7 @@
 # CPU (cross-compile): registers, LDS, scratch and occupancy of every kernel of librgbdfe.so as the compiler reports them
 # (-Rpass-analysis=kernel-resource-usage), with the flags of csrc/Makefile.   Usage: tools/kernel_resources.sh > profiles/<tag>/kernel_resources.txt
 cd "$(dirname "$0")/../rgbdslam_v2_amd/csrc"
-for f in hamming_nn hamming_mfma place_recognition l2_knn edges select_ransac ransac_split sift_match project3d emm orb_kernels orb_host sift_extract rgbdfe_api; do
+for f in hamming_nn hamming_mfma place_recognition l2_knn edges select_ransac ransac_split sift_match project3d emm orb_kernels orb_host sift_extract api_batches api_context api_pairs api_detect api_frame api_group rgbdfe_api; do
   extra=""
   case $f in
     sift_match) extra="-mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize";;
