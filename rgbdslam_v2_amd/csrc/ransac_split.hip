@@ -22,7 +22,7 @@
 //                           scoring          LANE = MATCH; the inliers' errors stay in LDS and the reference's strictly
 //                                            sequential error sum (node.cpp:1006) runs right behind the scoring.  Cheap
 //                                            passes (junk hypotheses end after the float prefilter): every worker scores
-//                                            its own slots.  Expensive passes (>= 24 slots with a refined set: ~140
+//                                            the slots the server dealt it.  Expensive passes (>= 24 slots with a refined set: ~140
 //                                            Cholesky solves per scoring): all 8 waves take the group's scorings one by
 //                                            one off a ticket counter (ds_add_rtn) and meet at a barrier behind them --
 //                                            fixed shares left most waves waiting for the one with the good hypotheses,
@@ -35,7 +35,11 @@
 //                                            40 % of the recording stage's instructions),
 //                           recycling        finished iterations' slots and drained units' buffers,
 //                           hand-out         the next viable iterations of the resident units (with their 4-point
-//                                            hypotheses) to the free slots, to the least occupied workers first,
+//                                            hypotheses) to the free slots,
+//                           the deal         which worker scores, books and refits which slots of the group's next pass
+//                                            (a slot belongs to nobody): the slots that already hold a refined set -- a
+//                                            scoring ~4x that of a junk hypothesis -- go round the workers first, the
+//                                            cheap ones level the rest; closed form, lane = slot,
 //                           unit loading     the launch's units come off a global counter a block at a time (lane = unit:
 //                                            units whose pair has ended cost nothing); PairPrep, the words of the viable
 //                                            mask and the next block's facts go global -> LDS directly (global_load_lds),
@@ -123,6 +127,7 @@ static_assert(kStreamSlots <= 2 * kWave, "the server's end-of-work test looks at
 #ifndef RGBDFE_SPLIT_TICKETS_FROM
 #define RGBDFE_SPLIT_TICKETS_FROM 24
 #endif
+constexpr int kCostDear = 4;                           // a scoring that runs pass 2, in scorings of a junk hypothesis (the deal's weight)
 constexpr int kTicketsFrom = RGBDFE_SPLIT_TICKETS_FROM;  // expensive scorings in a group's pass from which they go out by ticket
 constexpr int kBufs = RGBDFE_SPLIT_BUFS;              // units (pair, iteration range) resident in a workgroup's LDS
 #ifndef RGBDFE_SPLIT_MAX_SHARE
@@ -188,7 +193,7 @@ struct alignas(16) UnitCtx {
 struct alignas(16) StreamLds {
   PairPrep prep[kBufs];            // the resident units' pairs: match records + facts, as pair_prep_kernel left them
   WaveLds w[kStreamWaves];
-  SlotS slot[kStreamSlots];        // group g: slots g * kGroupSlots + worker * kWaveSlots + j
+  SlotS slot[kStreamSlots];        // group g: slots g * kGroupSlots + 0 .. kGroupSlots - 1
   UnitCtx ctx[kBufs];
   // facts of the units of the block the server has taken off the counter last (lane = unit), global -> LDS like the records
   // (a load into registers that stays in flight across the server's loop makes the compiler wait before every reuse of
@@ -200,7 +205,10 @@ struct alignas(16) StreamLds {
   uint8_t act_list[2][kWave];
   int n_act[2];
   int task[2];                     // next entry of act_list[g] to score (ds_add_rtn: a ticket, nobody waits for anybody)
-  int tickets[2];                  // the group's next pass hands its scorings out by ticket (many expensive ones) / by owner
+  int tickets[2];                  // the group's next pass hands its scorings out by ticket (many expensive ones) / by list
+  // the work of a pass: which slots of the group each worker scores (unless the pass goes by ticket), keeps the books of and
+  // refits -- at most kWaveSlots each, dealt by the server so that the workers' loads are level (a slot belongs to nobody)
+  uint8_t wlist[2][kWorkers][8];   // [..][7] = entries
   int quit;                        // set by the server: every unit of the launch has been refined
   int pad[3];
 };
@@ -542,7 +550,10 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     for (int h = 0;; ++h) {
       const int g = h & 1;
       const int lane = fresh(threadIdx.x & (kWave - 1));
-      SlotS* const mine = &lds.slot[g * kGroupSlots + wave * kWaveSlots];   // bookkeeping and refits: this wave's slots
+      // this pass's slots of this wave (the server's deal): lane j < n_mine_slots holds the j-th
+      const int n_mine_slots = __builtin_amdgcn_readfirstlane((int)lds.wlist[g][wave][7]);
+      const int my_slot = g * kGroupSlots + (lane < n_mine_slots ? (int)lds.wlist[g][wave][min(lane, kWaveSlots - 1)] : 0);
+      auto slot_at = [&](int j) -> SlotS& { return lds.slot[__builtin_amdgcn_readlane(my_slot, j)]; };
       // ================================ one pass of the refinement loop (:1140) for every active slot of group g
       if (__builtin_amdgcn_readfirstlane(lds.tickets[g]) != 0) {
         score_tickets(g);
@@ -550,19 +561,14 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         lds_barrier();   // every scoring of the pass is done
         ST_LAP(2)
       } else {           // cheap scorings: every worker scores its own slots and goes on without meeting the others
-        uint64_t act = __ballot(lane < kWaveSlots && mine[min(lane, kWaveSlots - 1)].active == kSlotActive);
-        while (act != 0ull) {
-          const int j = (int)__builtin_ctzll(act);
-          act &= act - 1ull;
-          score_slot(mine[j]);
-        }
+        for (int j = 0; j < n_mine_slots; ++j) score_slot(slot_at(j));
         lsync();
         ST_LAP(0)
       }
       // ---- the loop's bookkeeping (:1154-1166), lane = slot
       bool still = false;
-      if (fresh(lane) < kWaveSlots) {
-        SlotS& sl = mine[fresh(lane)];
+      if (fresh(lane) < n_mine_slots) {
+        SlotS& sl = lds.slot[my_slot];
         if (sl.active == kSlotActive) {
           const int n_inl = sl.cn, rn = sl.rn;
           const uint32_t thr = lds.ctx[sl.buf].thr;
@@ -598,14 +604,16 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side; their SVDs are
         // the server's, next half-round
         // (the unscaled division of the recurrence needs every slot's pair inside its window)
-        const bool all_fast = __ballot(still && lds.prep[mine[min(lane, kWaveSlots - 1)].buf].fast_alpha == 0u) == 0ull;
+        bool slow_div = false;
+        if (still) slow_div = lds.prep[lds.slot[my_slot].buf].fast_alpha == 0u;
+        const bool all_fast = __ballot(slow_div) == 0ull;
         int n_mine = 0, k256_mine = 0, n_max = 0, n_min = RGBDFE_MAX_MATCHES;
         {
           uint64_t todo = refit;
           while (todo != 0ull) {
             const int j = (int)__builtin_ctzll(todo);
             todo &= todo - 1ull;
-            const SlotS& sl = mine[j];
+            const SlotS& sl = slot_at(j);
             const PairPrep& pp = lds.prep[__builtin_amdgcn_readfirstlane(sl.buf)];
             // refined_matches without zero weights: tfc.add skips weight == 0; NaN depths never reach an inlier set
             // (misc.cpp:712-717)
@@ -623,14 +631,16 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         {
           const int lane_here = fresh(lane);
           const int s = min(lane_here / 9, kWaveSlots - 1), x = lane_here % 9;
-          const float* __restrict__ M = lds.prep[mine[s].buf].M;  // (per lane: the records of the lane's slot's unit)
+          // (per lane: the records of the lane's slot's unit; lanes of positions without a refit read some valid slot)
+          const int slot_s = __shfl(my_slot, min(s, max(n_mine_slots - 1, 0)));
+          const float* __restrict__ M = lds.prep[lds.slot[slot_s].buf].M;
           float C, m1, m2;
           if (all_fast) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
           else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
           // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox (the
           // transform it was scored with is history: the same bytes)
           if (lane_here < 9 * kWaveSlots && ((refit >> s) & 1ull)) {
-            float* __restrict__ in = mine[s].u.svd_in;
+            float* __restrict__ in = lds.slot[slot_s].u.svd_in;
             in[x] = C;
             if (x < 3) in[9 + x] = m1;
             if (x % 3 == 0) in[12 + x / 3] = m2;
@@ -874,19 +884,8 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     int n_take = n_held_o == kGroupSlots ? total : (total + n_held_o - n_held + 1) / 2;
     n_take = max(0, min(n_take, min(n_free, total)));
     if (n_take == 0) return;
-    // order of the free slots: the one that would become its worker's (k+1)-th occupied slot comes before every (k+2)-th
-    const int w = min(lane, kGroupSlots - 1) / kWaveSlots;
-    const uint64_t wbits = ((1ull << kWaveSlots) - 1ull) << (w * kWaveSlots);
-    const uint64_t below = (1ull << lane) - 1ull;
-    const int key = __popcll(held_m & wbits) + __popcll(free_m & wbits & below);
     const bool is_free = in_g && !held;
-    int ord = 0;
-#pragma unroll
-    for (int L = 0; L < kWaveSlots; ++L) {
-      const uint64_t mL = __ballot(is_free && key == L);
-      if (key > L) ord += __popcll(mL);
-      if (key == L) ord += __popcll(mL & below);
-    }
+    const int ord = (int)lane_rank(free_m);   // (a slot belongs to no worker: the work lists are dealt pass by pass)
     const bool take = is_free && ord < n_take;
     ST_ADD(6, n_take)
     int b = 0, at = 0;
@@ -928,20 +927,60 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     lsync();
   };
 
-  // ---- the list of group gs' active slots for its next pass: the scorings are taken off it one by one
-  auto list_active = [&](int gs) {
+  // ---- the work of group gs' next pass: the list of its active slots (scorings by ticket are taken off it one by one) and
+  // the DEAL -- every worker's slots of the pass.  A slot that already holds a refined set will pass the float prefilter
+  // again (a scoring ~4x that of a junk hypothesis) and most likely be refitted: the dear slots go round the workers first,
+  // the cheap ones then fill up the workers that got one dear slot less before they go round as well.  Closed form, lane =
+  // slot (no step-by-step deal: that was measured and put the server on the critical path); a deal that would overflow a
+  // worker's list (never with <= 28 active slots) is replaced by the plain round.
+  auto deal_work = [&](int gs) {
     const int lane = fresh(threadIdx.x & (kWave - 1));
     const SlotS& sl = lds.slot[gs * kGroupSlots + min(lane, kGroupSlots - 1)];
     const bool a = lane < kGroupSlots && sl.iter >= 0 && sl.active == kSlotActive;
-    const uint64_t m = __ballot(a);
+    const bool dear = a && sl.rn > 0;
+    const uint64_t m = __ballot(a), dm = __ballot(dear), cm = m & ~dm;
     if (a) lds.act_list[gs][lane_rank(m)] = (uint8_t)lane;
-    // expensive scorings ahead: iterations that already hold a refined set (their transform will pass the prefilter again)
-    const int n_dear = __popcll(__ballot(a && sl.rn > 0));
+    const int D = __popcll(dm), Cn = __popcll(cm);
     if (lane == 0) {
-      lds.n_act[gs] = __popcll(m);
+      lds.n_act[gs] = D + Cn;
       lds.task[gs] = 0;
-      lds.tickets[gs] = n_dear >= kTicketsFrom ? 1 : 0;
+      lds.tickets[gs] = D >= kTicketsFrom ? 1 : 0;
     }
+    const int q = D / kWorkers, r = D - q * kWorkers;   // workers 0 .. r-1 hold q + 1 dear slots, the others q
+    const int L = r > 0 ? kWorkers - r : 0;             // workers that are one dear slot short
+    const int fill = kCostDear * L;                     // cheap slots that level them
+    int w = 0, pos = 0;
+    if (dear) {
+      const int d = (int)lane_rank(dm);
+      w = d % kWorkers;
+      pos = d / kWorkers;
+    } else if (a) {
+      const int c = (int)lane_rank(cm);
+      if (c < fill) {
+        w = r + c % L;
+        pos = q + c / L;
+      } else {
+        const int c2 = c - fill, n1 = min(fill, Cn);   // (n1: cheap slots dealt in the first stage)
+        w = c2 % kWorkers;
+        // entries of worker w before this one: its dear slots, its share of the first stage, the rounds before
+        const int first = (w >= r && L > 0) ? (n1 / L + ((w - r) < n1 % L ? 1 : 0)) : 0;
+        pos = (w < r ? q + 1 : q) + first + c2 / kWorkers;
+      }
+    }
+    if (__ballot(a && pos >= kWaveSlots) != 0ull) {     // the plain round: position p of the list -> worker p mod 7
+      const int p = (int)lane_rank(m);
+      w = p % kWorkers;
+      pos = p / kWorkers;
+    }
+    if (a) lds.wlist[gs][w][pos] = (uint8_t)lane;
+    // entries per worker
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kWorkers; ++k) {
+      const int ck = __popcll(__ballot(a && w == k));
+      if (lane == k) cnt = ck;
+    }
+    if (lane < kWorkers) lds.wlist[gs][lane][7] = (uint8_t)cnt;
   };
 
   // the first units before the first half-round (the workers start with group 0)
@@ -951,7 +990,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   issue_loads();
   complete_loads();
   hand_out(0);
-  list_active(0);
+  deal_work(0);
   issue_loads();
   lds_barrier();
   ST_T0
@@ -968,7 +1007,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     ST_LAP(2)
     hand_out(gs);
     ST_LAP(3)
-    list_active(gs);
+    deal_work(gs);
     ST_LAP(4)
     issue_loads();
     ST_LAP(5)
