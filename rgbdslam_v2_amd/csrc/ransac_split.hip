@@ -381,7 +381,6 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
   const uint32_t seed_uid = mix32(mix32(rc.seed ^ 0x9E3779B9u) + work[pair].uid * 0x85EBCA6Bu);
   const int I = rc.ransac_iterations;
   IterRec* __restrict__ rec_pair = plan.recs + (size_t)pair * (size_t)I;
-  IterSum* __restrict__ sum_pair = plan.sums + (size_t)pair * (size_t)I;
   uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
   for (int k0 = 0; k0 < I; k0 += kHypThreads) {
     const int k = k0 + tid;
@@ -449,9 +448,8 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 #ifdef RGBDFE_PROFILE_PHASES
       r.rn = -77;  // diagnostics: "a hypothesis, not yet refined"
 #endif
-    } else if (in_range) {
-      sum_pair[k] = IterSum{1e6, 0, 0};
     }
+    // (an iteration that is not viable leaves nothing behind: the walk reads its cleared bit of the mask as {1e6, 0})
   }
 }
 

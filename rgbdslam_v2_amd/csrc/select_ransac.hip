@@ -1224,7 +1224,8 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
                                                             const PairPrep* __restrict__ prep, uint32_t n_pairs,
                                                             const RansacConst rc, int phase_begin, int phase_end,
                                                             int spec_end, int may_speculate,
-                                                            const uint8_t* __restrict__ preclass, int phase_index) {
+                                                            const uint8_t* __restrict__ preclass, int phase_index,
+                                                            const uint64_t* __restrict__ vmask, int vmask_words) {
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x;
@@ -1258,7 +1259,15 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
     const int G = min(kWave, recorded_end - k0);
     int rn_l = 0;
     double rerr_l = 0.0;
-    if (lane < G) {
+    // split path: an iteration the pre-screen rejected has no summary at all -- the pair's viable mask says so (its bit is
+    // clear) and it counts as {1e6, 0} (the hypothesis kernel used to write 16 bytes for every one of them: 12.8 MB per batch
+    // of configs[1] written and read back up to four times)
+    bool listed = lane < G;
+    if (listed && vmask != nullptr) {
+      const int k = k0 + lane;
+      listed = ((vmask[(size_t)pair * (size_t)vmask_words + (size_t)(k >> 6)] >> (k & 63)) & 1ull) != 0ull;
+    }
+    if (listed) {
       const IterSum su = sum_pair[k0 + lane];
       rn_l = su.rn;
       rerr_l = su.rerr;
@@ -1418,7 +1427,8 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
                            results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
     }
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, plan.sums, walk, prep, n_pairs, rc, begin,
-                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0, first_spec ? sp.preclass : (const uint8_t*)nullptr, p);
+                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0, first_spec ? sp.preclass : (const uint8_t*)nullptr, p,
+                       split ? sp.vmask : (const uint64_t*)nullptr, sp.vmask_words);
     begin = end;
   }
   plan.n_chunks = 1;
