@@ -60,6 +60,10 @@ struct SiftExtractor {
   struct LevelDesc { const float* g[4]; int8_t* flags; int w, h, row0; float pad; };
   LevelDesc* d_levels = nullptr;
   std::vector<LevelDesc> h_levels;
+  std::vector<int> h_row2lvl;                          // level (octave * kDogLevels + dog level) of every stacked row
+  static constexpr int kKeyTileH = 16;
+  struct KeyTile { int oct, x0, y0; };                 // a 64 x kKeyTileH pixel tile of an octave
+  std::vector<KeyTile> h_key_tiles;
   float* d_cand = nullptr; size_t cand_cap = 0;        // candidates: 6 floats each, per level at its offset
   float4* d_feat = nullptr; size_t feat_cap = 0;       // feature list (x, y, scale, packed / final orientation)
   float* d_desc = nullptr; size_t desc_cap = 0;
@@ -67,12 +71,14 @@ struct SiftExtractor {
   int* h_counts = nullptr;                             // pinned: per-level totals, 64 per frame
   float* h_stage = nullptr; size_t stage_floats = 0;   // pinned staging for lists (all frames of a batch)
   uint8_t* h_gray = nullptr; size_t gray_cap = 0;      // pinned staging of the caller's (pageable) images
-  int* d_orow2oct = nullptr;                           // (octave, row) pairs of the stacked octaves
+  void* d_key_tiles = nullptr; int n_key_tiles = 0;    // the (octave, x0, y0) tiles of the extremum launch
   void* d_jobs = nullptr; void* h_jobs = nullptr;      // the per-frame segment tables of the orientation / descriptor launches
   std::vector<int> lvl_count, lvl_off;                 // candidates per (octave, dog level) of the latest call's first frame
   int frames_cap = 0;                                  // frames the buffers hold (every device buffer is [frames_cap][...])
   size_t input_floats = 0;                             // per-frame strides: d_input; d_up = oct[0].plane; d_planes = planes_floats
   int prepare(int rows, int cols, int nf, std::string& err);
+  int plan_geometry(int rows, int cols, std::string& err);   // sizes only (defined in sift_pyramid_kernels.h, as bind_levels)
+  void bind_levels();
 };
 
 }  // namespace rgbdfe

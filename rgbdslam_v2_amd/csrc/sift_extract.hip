@@ -28,306 +28,11 @@
 #include <algorithm>
 
 #include "rgbdfe_internal.h"
+#include "sift_pyramid_kernels.h"
 
 namespace rgbdfe {
 
 namespace {
-
-constexpr int kMaxTaps = 33;  // KERNEL_MAX_WIDTH (ProgramCU.cu:40)
-struct Taps { float k[kMaxTaps]; int fw; };
-
-// ---- image in: bytes -> luminance / 255 (GLTexInput::DownSamplePixelDataI2F, GLTexImage.cpp:808-831), width cut to w4 ----
-// (every kernel of this file serves a BATCH of frames: one grid dimension is the frame, each buffer has a per-frame stride)
-__global__ __launch_bounds__(256) void sift_convert_kernel(const uint8_t* __restrict__ gray, int cols, int w4, int rows,
-                                                           float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= w4 * rows) return;
-  gray += (size_t)blockIdx.y * rows * cols;
-  out += (size_t)blockIdx.y * w4 * rows;
-  const int y = i / w4, x = i - y * w4;
-  out[i] = (float)(int)gray[(size_t)y * cols + x] / 255.0f;
-}
-
-// The "-fo -1" first octave: the input at twice its size (behaviour of UpsampleKernel<1>, ProgramCU.cu:221-265).  One thread
-// makes the two output pixels above source pixel (x, y2 / 2): even output rows repeat the source row, odd ones are the mean of
-// the rows above and below; even output columns take that value, odd ones the mean with the right-hand neighbour.  The
-// source is addressed as ONE linear array, as the reference's linear texture is: the neighbour of a row's last pixel is the
-// first pixel of the next row, and anything past the last pixel reads as 0.
-__global__ __launch_bounds__(128) void sift_upsample2_kernel(const float* __restrict__ src, int w, int h,
-                                                             float* __restrict__ dst, size_t dst_stride) {
-  const int x = blockIdx.x * 128 + threadIdx.x;
-  if (x >= w) return;
-  const int pixels = w * h;
-  src += (size_t)blockIdx.z * pixels;
-  dst += (size_t)blockIdx.z * dst_stride;
-  auto px = [&](int i) -> float { return i < pixels ? src[i] : 0.0f; };
-  const int y2 = blockIdx.y;               // output row
-  const int at = (y2 >> 1) * w + x;        // the source pixel above-left of the output pair
-  float here = px(at), right = px(at + 1);
-  if (y2 & 1) {                            // between two source rows: half of each
-    here = px(at + w) * 0.5f + 0.5f * here;
-    right = px(at + w + 1) * 0.5f + 0.5f * right;
-  }
-  float* __restrict__ out = dst + (size_t)(w * y2 + x) * 2;
-  out[0] = here;
-  out[1] = here * 0.5f + right * 0.5f;
-}
-
-// DownsampleKernel<1> (ProgramCU.cu:283-294)
-__global__ __launch_bounds__(128) void sift_downsample2_kernel(const float* __restrict__ src, int src_w, int dst_w, int dst_h,
-                                                               float* __restrict__ dst, size_t frame_stride) {
-  const int c = blockIdx.x * 128 + threadIdx.x;
-  if (c >= dst_w) return;
-  src += (size_t)blockIdx.z * frame_stride;
-  dst += (size_t)blockIdx.z * frame_stride;
-  const int r = blockIdx.y;
-  const int sc = min(c << 1, src_w - 1);
-  dst[r * dst_w + c] = src[(size_t)(r << 1) * src_w + sc];
-}
-
-// One Gaussian level: FilterH then FilterV (ProgramCU.cu:113-218) in one launch.  A block owns a TW x TH output tile: it
-// stages the (TH + 2R) x (TW + 2R) source patch in LDS (rows / columns clamped to the image as the two reference kernels
-// clamp their fetches), filters it horizontally into a second LDS plane, then vertically into the output.  value starts
-// at 0 and the taps are added in ascending order, multiply and add unfused: the reference's sums, bit for bit.
-// Two tile shapes: 64 x 16 outputs per block for the large planes, 16 x 16 for planes of a few thousand pixels, where the
-// level-after-level dependency makes the latency of one block the cost of the launch.  FW is a template parameter so
-// that the tap loops unroll.
-template <int FW, int TW, int TH>
-__global__ __launch_bounds__(256) void sift_filter_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
-                                                          Taps taps, size_t src_stride, size_t dst_stride) {
-  constexpr int R = FW >> 1;
-  src += (size_t)blockIdx.z * src_stride;
-  dst += (size_t)blockIdx.z * dst_stride;
-  constexpr int pw = TW + 2 * R, ph = TH + 2 * R;
-  __shared__ float patch[ph * pw];   // source rows / columns clamped to the image
-  __shared__ float hrow[ph * TW];    // horizontally filtered
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < ph * pw; i += 256) {
-    const int py = i / pw, px = i - py * pw;
-    int gy = y0 - R + py, gx = x0 - R + px;
-    gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-    gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-    patch[i] = src[(size_t)gy * w + gx];
-  }
-  __syncthreads();
-  for (int i = tid; i < ph * TW; i += 256) {
-    const int py = i / TW, px = i - py * TW;
-    const float* p = patch + py * pw + px;
-    float value = 0.f;
-#pragma unroll
-    for (int t = 0; t < FW; ++t) value += p[t] * taps.k[t];
-    hrow[i] = value;
-  }
-  __syncthreads();
-  for (int i = tid; i < TH * TW; i += 256) {
-    const int ty = i / TW, tx = i - ty * TW;
-    const int gx = x0 + tx, gy = y0 + ty;
-    if (gx >= w || gy >= h) continue;
-    const float* p = hrow + ty * TW + tx;
-    float value = 0.f;
-#pragma unroll
-    for (int t = 0; t < FW; ++t) value += p[t * TW] * taps.k[t];
-    dst[(size_t)gy * w + gx] = value;
-  }
-}
-
-struct FilterArgs { const float* src; float* dst; int w, h, nf; size_t src_stride, dst_stride; };
-template <int FW>
-void launch_filter(const FilterArgs& a, const Taps& t, hipStream_t s) {
-  if ((size_t)a.w * a.h * a.nf <= (size_t)160 * 120)   // few thousand pixels in the whole launch: small tiles, more workgroups
-    hipLaunchKernelGGL((sift_filter_kernel<FW, 16, 16>), dim3((a.w + 15) / 16, (a.h + 15) / 16, a.nf), dim3(256), 0, s, a.src, a.dst,
-                       a.w, a.h, t, a.src_stride, a.dst_stride);
-  else
-    hipLaunchKernelGGL((sift_filter_kernel<FW, 64, 16>), dim3((a.w + 63) / 64, (a.h + 15) / 16, a.nf), dim3(256), 0, s, a.src, a.dst,
-                       a.w, a.h, t, a.src_stride, a.dst_stride);
-}
-
-void launch_filter_any(const FilterArgs& a, const Taps& t, hipStream_t s) {
-  switch (t.fw) {   // ProgramCU::FilterImage's switch over the odd widths 5 .. 33 (ProgramCU.cu:430-448)
-    case 5: launch_filter<5>(a, t, s); break;
-    case 7: launch_filter<7>(a, t, s); break;
-    case 9: launch_filter<9>(a, t, s); break;
-    case 11: launch_filter<11>(a, t, s); break;
-    case 13: launch_filter<13>(a, t, s); break;
-    case 15: launch_filter<15>(a, t, s); break;
-    case 17: launch_filter<17>(a, t, s); break;
-    case 19: launch_filter<19>(a, t, s); break;
-    case 21: launch_filter<21>(a, t, s); break;
-    case 23: launch_filter<23>(a, t, s); break;
-    case 25: launch_filter<25>(a, t, s); break;
-    case 27: launch_filter<27>(a, t, s); break;
-    case 29: launch_filter<29>(a, t, s); break;
-    case 31: launch_filter<31>(a, t, s); break;
-    default: launch_filter<33>(a, t, s); break;
-  }
-}
-
-// ---- extrema -----------------------------------------------------------------------------------------------------------
-struct KeyEval { float result, dx, dy, ds; };
-
-// one row [c0 c1 c2 | rhs] of the 3 x 3 system of the sub-pixel fit
-struct FitRow {
-  float c0, c1, c2, rhs;
-  // the row with a non-negative leading coefficient
-  static __device__ __forceinline__ FitRow oriented(float c0, float c1, float c2, float rhs) {
-    return c0 > 0 ? FitRow{c0, c1, c2, rhs} : FitRow{-c0, -c1, -c2, -rhs};
-  }
-};
-__device__ __forceinline__ void exchange(FitRow& a, FitRow& b) { const FitRow t = a; a = b; b = t; }
-
-// Is the pixel `at` of D[l] = G[l] - G[l-1] a keypoint candidate, and where does the fitted extremum lie?  (Behaviour of
-// ComputeKEY_Kernel, ProgramCU.cu:524-640, for an interior pixel.)  g[0..3] = the Gaussian planes G[l-2] .. G[l+1]: the three
-// DoG levels involved are differences of neighbouring planes, formed here instead of being stored (ComputeDOG_Kernel's
-// `v - vp`, :457-489).  The tests, cheapest first -- each one only ever rejects:
-//   contrast gate      |D| above 0.8 * threshold;
-//   extremum           strictly above (below) its two row neighbours, not below (above) any of the other 24 neighbours in
-//                      scale space (ties: see `holds`); `rim` follows the neighbour closest to the centre value on the side
-//                      that matters;
-//   edge response      principal-curvature ratio of the 2 x 2 spatial Hessian;
-//   sub-pixel fit      Newton step (dx, dy, ds) from the 3 x 3 Hessian system, solved by elimination with the reference's
-//                      pivot choices; rejected when the step leaves the pixel / level or the fitted contrast is too low.
-// result = +1 for a maximum that is strictly above all 26 neighbours, -1 for every other candidate, 0 = no candidate.
-__device__ __forceinline__ KeyEval key_eval(const float* const g[4], int w, int at, float gate, float contrast_threshold,
-                                            float edge_threshold) {
-  const KeyEval none{0.f, 0.f, 0.f, 0.f};
-  auto same = [&](int i) -> float { return g[2][i] - g[1][i]; };    // D[l]
-  auto below = [&](int i) -> float { return g[1][i] - g[0][i]; };   // D[l-1]
-  auto above = [&](int i) -> float { return g[3][i] - g[2][i]; };   // D[l+1]
-  const float v = same(at);
-  if (fabsf(v) <= gate) return none;
-  const float west = same(at - 1), east = same(at + 1);
-  const bool peak = v > fmaxf(west, east);
-  if (!peak && !(v < fminf(west, east))) return none;   // between its row neighbours (or level with one of them)
-  float rim = peak ? fmaxf(west, east) : fminf(west, east);
-  // three more neighbours: does the centre still stand out?  A valley may be level with any neighbour; a peak may only be
-  // level with one of the LAST three looked at (it is then reported as -1): a peak found level with an earlier neighbour
-  // is dropped when the next three are looked at -- the reference's behaviour, kept.
-  auto holds = [&](float a, float b, float c) -> bool {
-    if (peak) {
-      if (!(v > rim)) return false;
-      rim = fmaxf(fmaxf(fmaxf(rim, a), b), c);
-      return !(v < rim);
-    }
-    rim = fminf(fminf(fminf(rim, a), b), c);
-    return !(v > rim);
-  };
-  const int up = at - w, down = at + w;
-  const float nw = same(up - 1), north = same(up), ne = same(up + 1);
-  if (!holds(nw, north, ne)) return none;
-  const float sw = same(down - 1), south = same(down), se = same(down + 1);
-  if (!holds(sw, south, se)) return none;
-  // edge response: det(H) > 0 and trace(H)^2 / det(H) within the threshold
-  const float twice = v * 2.0f;
-  const float hxx = west + east - twice;
-  const float hyy = north + south - twice;
-  const float hxy = 0.25f * (se + nw - sw - ne);
-  const float det = hxx * hyy - hxy * hxy;
-  const float trace_sq = (hxx + hyy) * (hxx + hyy);
-  if (det <= 0 || trace_sq > edge_threshold * det) return none;
-  // the 9 + 9 neighbours in the levels below and above
-  const float b_nw = below(up - 1), b_n = below(up), b_ne = below(up + 1);
-  if (!holds(b_nw, b_n, b_ne)) return none;
-  const float b_w = below(at - 1), b_c = below(at), b_e = below(at + 1);
-  if (!holds(b_w, b_c, b_e)) return none;
-  const float b_sw = below(down - 1), b_s = below(down), b_se = below(down + 1);
-  if (!holds(b_sw, b_s, b_se)) return none;
-  const float a_nw = above(up - 1), a_n = above(up), a_ne = above(up + 1);
-  if (!holds(a_nw, a_n, a_ne)) return none;
-  const float a_w = above(at - 1), a_c = above(at), a_e = above(at + 1);
-  if (!holds(a_w, a_c, a_e)) return none;
-  const float a_sw = above(down - 1), a_s = above(down), a_se = above(down + 1);
-  if (!holds(a_sw, a_s, a_se)) return none;
-  (void)b_nw; (void)b_ne; (void)b_sw; (void)b_se; (void)a_nw; (void)a_ne; (void)a_sw; (void)a_se;
-  // sub-pixel fit ("-s 1"): H * step = -gradient by central differences over (x, y, scale)
-  KeyEval out{0.f, 0.f, 0.f, 0.f};
-  bool keep = true;
-  {
-    const float gx = 0.5f * (east - west);
-    const float gy = 0.5f * (south - north);
-    const float gs = 0.5f * (a_c - b_c);
-    const float hss = (a_c + b_c - twice);
-    const float hxs = 0.25f * (a_e + b_w - a_w - b_e);
-    const float hys = 0.25f * (a_s + b_n - a_n - b_s);
-    FitRow r0 = FitRow::oriented(hxx, hxy, hxs, -gx);
-    FitRow r1 = FitRow::oriented(hxy, hyy, hys, -gy);
-    FitRow r2 = FitRow::oriented(hxs, hys, hss, -gs);
-    const float lead = fmaxf(fmaxf(r0.c0, r1.c0), r2.c0);
-    if (lead >= 1e-10) {
-      // first pivot: the row with the largest leading coefficient (the second row wins a tie, then the third)
-      if (lead == r1.c0) exchange(r0, r1);
-      else if (lead == r2.c0) exchange(r0, r2);
-      r0.c1 /= r0.c0; r0.c2 /= r0.c0; r0.rhs /= r0.c0;
-      r1.c1 -= r1.c0 * r0.c1; r1.c2 -= r1.c0 * r0.c2; r1.rhs -= r1.c0 * r0.rhs;
-      r2.c1 -= r2.c0 * r0.c1; r2.c2 -= r2.c0 * r0.c2; r2.rhs -= r2.c0 * r0.rhs;
-      if (fabsf(r2.c1) > fabsf(r1.c1)) exchange(r1, r2);   // second pivot
-      if (fabsf(r1.c1) >= 1e-10) {
-        r1.c2 /= r1.c1; r1.rhs /= r1.c1;
-        r2.c2 -= r2.c1 * r1.c2; r2.rhs -= r2.c1 * r1.rhs;
-        if (fabsf(r2.c2) >= 1e-10) {   // back substitution
-          out.ds = r2.rhs / r2.c2;
-          out.dy = r1.rhs - out.ds * r1.c2;
-          out.dx = r0.rhs - out.ds * r0.c2 - out.dy * r0.c1;
-          keep = fabsf(v + 0.5f * (out.dx * gx + out.dy * gy + out.ds * gs)) > contrast_threshold &&
-                 fabsf(out.ds) < 1.0f && fabsf(out.dx) < 1.0f && fabsf(out.dy) < 1.0f;
-        }
-      }
-    }
-  }
-  if (keep) out.result = (peak && v > rim) ? 1.0f : -1.0f;
-  return out;
-}
-
-// per-frame strides of the batch: frame f's planes / flags / row counters / level totals / candidates start f strides
-// behind frame 0's, which is what the LevelDesc records point at
-struct FrameStrides { size_t planes, flags, cand; int rows, lvltot; };
-__device__ __forceinline__ SiftExtractor::LevelDesc level_of_frame(SiftExtractor::LevelDesc L, const FrameStrides& st, int f) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) L.g[k] += (size_t)f * st.planes;
-  L.flags += (size_t)f * st.flags;
-  return L;
-}
-
-// one wave (= one workgroup) per 64 consecutive columns of one row of an OCTAVE, for all its kDogLevels key levels at once:
-// the six Gaussian planes the five centre DoG values need are read once per pixel (10 reads when every level had its own
-// wave), the common early exit -- |D| <= 0.8 * threshold, which most pixels take -- is decided from those registers, and only a
-// level that passes it runs the full test (key_eval: neighbours, edge ratio, sub-pixel solve).  A flag byte per pixel and
-// level + the rows' counts.  Most waves end after the six loads, so the launch lives on the number of independent waves in
-// flight -- measured on the per-level form: four rows per 256-thread workgroup +50 % (a wave that runs the whole test holds
-// the slots of its three finished neighbours), a wave walking 8 rows +50 %.
-// Counted = what InitHist_Kernel (ProgramCU.cu:665-688) counts: rows 1 .. h-2, columns 1 .. w-2 with a non-zero key.
-__global__ __launch_bounds__(64) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                           const int* __restrict__ orow2oct, int* __restrict__ rowcnt,
-                                                           float dog_threshold0, float dog_threshold, float edge_threshold,
-                                                           FrameStrides st) {
-  const int oct = orow2oct[2 * blockIdx.y], row = orow2oct[2 * blockIdx.y + 1];
-  rowcnt += (size_t)blockIdx.z * st.rows;
-  const SiftExtractor::LevelDesc* __restrict__ lv = levels + oct * SiftExtractor::kDogLevels;
-  const SiftExtractor::LevelDesc L0 = level_of_frame(lv[0], st, blockIdx.z);
-  const int w = L0.w, h = L0.h;
-  if ((int)blockIdx.x * 64 >= w) return;
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  const bool interior = col < w && row > 0 && col > 0 && row < h - 1 && col < w - 1;
-  const int index = row * w + col;
-  // G[1] .. G[6] at the pixel: level j's centre value is G[j + 2] - G[j + 1]
-  float c[SiftExtractor::kDogLevels + 1];
-#pragma unroll
-  for (int j = 0; j < SiftExtractor::kDogLevels; ++j) c[j] = interior ? (lv[j].g[1] + (size_t)blockIdx.z * st.planes)[index] : 0.f;
-  c[SiftExtractor::kDogLevels] =
-      interior ? (lv[SiftExtractor::kDogLevels - 1].g[2] + (size_t)blockIdx.z * st.planes)[index] : 0.f;
-#pragma unroll
-  for (int j = 0; j < SiftExtractor::kDogLevels; ++j) {
-    const SiftExtractor::LevelDesc L = level_of_frame(lv[j], st, blockIdx.z);
-    int8_t flag = 0;
-    if (interior && fabsf(c[j + 1] - c[j]) > dog_threshold0) {
-      const KeyEval e = key_eval(L.g, w, index, dog_threshold0, dog_threshold, edge_threshold);
-      flag = e.result > 0.f ? 1 : (e.result < 0.f ? -1 : 0);
-    }
-    if (col < w) L.flags[(size_t)row * w + col] = flag;
-    const uint64_t m = __ballot(flag != 0);
-    if (threadIdx.x == 0 && m) atomicAdd(&rowcnt[L.row0 + row], (int)__popcll(m));
-  }
-}
 
 // per level: exclusive scan of its rows' counts, the level's total
 __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
@@ -601,26 +306,6 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* _
     if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return RGBDFE_ERR_HIP; } \
   } while (0)
 
-// The taps of a Gaussian level: exp(-d^2 / 2 sigma^2) for d = -half .. half, normalised to sum 1 (f32 throughout, summed
-// left to right -- the values of ProgramCU::CreateFilterKernel, ProgramCU.cu:370-398, with its width factor 4): half =
-// ceil(4 sigma - 1/2) taps either side, kept between 2 and 16 (widths 5 .. 33).
-Taps make_taps(float sigma) {
-  Taps t{};
-  const int half = std::min(std::max((int)ceil(4.0f * sigma - 0.5), 2), kMaxTaps / 2);
-  const float inv_var = 1.0f / (sigma * sigma);
-  t.fw = 2 * half + 1;
-  float sum = 0.f;
-  for (int j = 0; j < t.fw; ++j) {
-    const int d = j - half;
-    const float gd = expf(-0.5f * d * d * inv_var);
-    t.k[j] = gd;
-    sum += gd;
-  }
-  const float norm = 1.0f / sum;
-  for (int j = 0; j < t.fw; ++j) t.k[j] *= norm;
-  return t;
-}
-
 }  // namespace
 
 SiftExtractor::~SiftExtractor() { release(); }
@@ -637,8 +322,8 @@ void SiftExtractor::release() {
   if (d_feat) (void)hipFree(d_feat);
   if (d_desc) (void)hipFree(d_desc);
   if (d_jobs) (void)hipFree(d_jobs);
-  if (d_orow2oct) (void)hipFree(d_orow2oct);
-  d_orow2oct = nullptr;
+  if (d_key_tiles) (void)hipFree(d_key_tiles);
+  d_key_tiles = nullptr; n_key_tiles = 0;
   if (h_counts) (void)hipHostFree(h_counts);
   if (h_stage) (void)hipHostFree(h_stage);
   if (h_gray) (void)hipHostFree(h_gray);
@@ -651,97 +336,31 @@ void SiftExtractor::release() {
   h_gray = nullptr; gray_cap = 0; stage_floats = 0; cand_cap = feat_cap = desc_cap = 0; W = H = 0; frames_cap = 0;
 }
 
-void SiftExtractor::init_params() {  // SiftParam::ParseSiftParam (SiftGPU.cpp:433-473) with "-d 5 -e 10.0"
-  if (params_ready) return;
-  const int dog_level_num = kDogLevels, level_min = -1, level_max = kDogLevels + 1;
-  sigma0 = 1.6f * powf(2.0f, 1.0f / dog_level_num);
-  sigmak = powf(2.0f, 1.0f / dog_level_num);
-  dsigma0 = sigma0 * sqrtf(1.0f - 1.0f / (sigmak * sigmak));
-  for (int i = level_min + 1; i <= level_max; i++) sigma[i - level_min - 1] = dsigma0 * powf(sigmak, float(i));
-  dog_threshold = 0.02f / dog_level_num;
-  edge_threshold = 10.0f;
-  params_ready = true;
-}
-
-float SiftExtractor::initial_smooth_sigma(int om) const {
-  const float sa = sigma0 * powf(2.0f, float(-1) / float(kDogLevels));
-  const float sb = 0.5f / powf(2.0f, float(om));
-  return sa > sb + 0.001 ? sqrtf(sa * sa - sb * sb) : 0.0f;
-}
-
-float SiftExtractor::level_sigma(int lev) const { return sigma0 * powf(2.0f, float(lev) / float(kDogLevels)); }
-
-// PyramidCU::InitPyramid / ResizePyramid / FitPyramid (PyramidCU.cpp:86-306): the geometry a frame of this size gets;
-// every buffer holds nf frames side by side
+// the buffers of nf frames of this size, side by side (geometry: plan_geometry / bind_levels, sift_pyramid_kernels.h)
 int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
   init_params();
   if (rows == H && cols == W && d_planes && nf <= frames_cap) return RGBDFE_OK;
-  const int tw = cols & 0xfffffffc;  // GLTexInput::TruncateWidthCU (GLTexImage.h:125)
-  if (tw < 16 || rows < 16) { err = "image too small for SIFT extraction"; return RGBDFE_ERR_INVALID_ARG; }
-  int om = -1;  // "-fo -1"
-  int wp = tw << 1, hp = rows << 1;
-  while (wp > 3200 || hp > 3200) { om++; wp >>= 1; hp >>= 1; }  // GlobalUtil::_texMaxDim (GlobalUtil.cpp:86)
-  if (om > 0) { err = "images beyond 3200 x 3200 pixels are not supported"; return RGBDFE_ERR_CAPACITY; }
-  int on = (int)floor(log(double(std::min(wp, hp))) / log(2.0)) - 3;
-  if (on < 1) on = 1;
-  if (on > kMaxOctaves) on = kMaxOctaves;
   if (rows == H && cols == W && nf < frames_cap) nf = frames_cap;
   release();
-  W = cols; H = rows; w4 = tw; octave_min = om; octave_num = on;
-  size_t total = 0;
-  int w = wp, h = hp;
-  total_rows = 0;
-  for (int i = 0; i < on; ++i) {
-    oct[i].w = ((w + 3) / 4) * 4;
-    oct[i].h = h;
-    oct[i].plane = (size_t)oct[i].w * h;
-    total += oct[i].plane * kLevels;
-    total_rows += h * kDogLevels;
-    w >>= 1; h >>= 1;
-  }
-  planes_floats = total;
-  input_floats = (size_t)tw * rows;
+  const int rc = plan_geometry(rows, cols, err);
+  if (rc != RGBDFE_OK) return rc;
   const size_t F = (size_t)nf;
   SIFT_HIP(hipMalloc((void**)&d_gray, F * rows * cols));
   SIFT_HIP(hipMalloc((void**)&d_input, F * input_floats * 4));
   SIFT_HIP(hipMalloc((void**)&d_up, F * oct[0].plane * 4));
-  SIFT_HIP(hipMalloc((void**)&d_planes, F * total * 4));
-  size_t off = 0, foff = 0;
-  for (int i = 0; i < on; ++i)
-    for (int l = 0; l < kLevels; ++l) { oct[i].g[l] = d_planes + off; off += oct[i].plane; }   // frame 0's planes
-  for (int i = 0; i < on; ++i) foff += oct[i].plane * kDogLevels;
-  flags_bytes = foff;
+  SIFT_HIP(hipMalloc((void**)&d_planes, F * planes_floats * 4));
   SIFT_HIP(hipMalloc((void**)&d_flags, F * flags_bytes));
   // rowcnt [nf][total_rows] | rowoff [nf][total_rows] | row2lvl [total_rows] | lvltot [nf][64]
   SIFT_HIP(hipMalloc((void**)&d_rowcnt, sizeof(int) * ((size_t)total_rows * (2 * F + 1) + 64 * F)));
   d_rowoff = d_rowcnt + (size_t)total_rows * F;
   d_lvltot = d_rowcnt + (size_t)total_rows * (2 * F + 1);
-  h_levels.assign((size_t)on * kDogLevels, LevelDesc{});
-  std::vector<int> row2lvl((size_t)total_rows);
-  int row0 = 0;
-  foff = 0;
-  for (int i = 0; i < on; ++i)
-    for (int j = 0; j < kDogLevels; ++j) {
-      LevelDesc& L = h_levels[(size_t)i * kDogLevels + j];
-      const int l = j + 2;  // key level: DoG l - 1, l, l + 1 = Gaussian l - 2 .. l + 1
-      for (int k = 0; k < 4; ++k) L.g[k] = oct[i].g[l - 2 + k];
-      L.flags = d_flags + foff;
-      L.w = oct[i].w; L.h = oct[i].h; L.row0 = row0;
-      for (int r = 0; r < oct[i].h; ++r) row2lvl[(size_t)row0 + r] = i * kDogLevels + j;
-      row0 += oct[i].h;
-      foff += oct[i].plane;
-    }
+  bind_levels();
   SIFT_HIP(hipMalloc((void**)&d_levels, sizeof(LevelDesc) * h_levels.size()));
   SIFT_HIP(hipMemcpy(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice));
-  SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2 * F, row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
-  {  // (octave, row) of every row of the stacked octaves: the keypoint scan's launch walks it
-    std::vector<int> o2((size_t)total_rows / kDogLevels * 2);
-    size_t k = 0;
-    for (int i = 0; i < on; ++i)
-      for (int r = 0; r < oct[i].h; ++r) { o2[k++] = i; o2[k++] = r; }
-    SIFT_HIP(hipMalloc((void**)&d_orow2oct, sizeof(int) * o2.size()));
-    SIFT_HIP(hipMemcpy(d_orow2oct, o2.data(), sizeof(int) * o2.size(), hipMemcpyHostToDevice));
-  }
+  SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2 * F, h_row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
+  n_key_tiles = (int)h_key_tiles.size();
+  SIFT_HIP(hipMalloc((void**)&d_key_tiles, sizeof(KeyTile) * h_key_tiles.size()));
+  SIFT_HIP(hipMemcpy(d_key_tiles, h_key_tiles.data(), sizeof(KeyTile) * h_key_tiles.size(), hipMemcpyHostToDevice));
   cand_cap = std::max<size_t>((size_t)1 << 16, oct[0].plane / 16);
   SIFT_HIP(hipMalloc((void**)&d_cand, F * cand_cap * 6 * 4));
   feat_cap = cand_cap * 2;                      // per frame; the batch-wide lists are packed: F * feat_cap entries at most
@@ -759,32 +378,9 @@ int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
 
 // images in (GLTexInput::SetImageData, CUDA branch, GLTexImage.cpp:971-1009) + BuildPyramid (PyramidCU.cpp:946-998) for nf frames
 int SiftExtractor::enqueue_pyramid(const uint8_t* const* gray, int nf, hipStream_t s, std::string& err) {
-  const int rows = H, cols = W;
-  const unsigned NF = (unsigned)nf;
   for (int f = 0; f < nf; ++f) memcpy(h_gray + (size_t)f * gray_cap, gray[f], gray_cap);
   SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)nf * gray_cap, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256, NF), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
-  auto filter = [&](const float* src, size_t src_stride, float* dst, int w, int h, float sg) {
-    launch_filter_any(FilterArgs{src, dst, w, h, nf, src_stride, planes_floats}, make_taps(sg), s);
-  };
-  for (int i = 0; i < octave_num; ++i) {
-    const Octave& o = oct[i];
-    if (i == 0) {
-      const float sg = initial_smooth_sigma(octave_min);
-      if (octave_min < 0) {  // SampleImageU + FilterImage in place through the buffer plane
-        hipLaunchKernelGGL(sift_upsample2_kernel, dim3((w4 + 127) / 128, rows << 1, NF), dim3(128), 0, s, d_input, w4, rows, d_up,
-                           o.plane);
-        filter(d_up, o.plane, o.g[0], o.w, o.h, sg);
-      } else {
-        filter(d_input, input_floats, o.g[0], o.w, o.h, sg);
-      }
-    } else {  // SampleImageD from level_ds of the octave below (index level_ds - level_min = 5); sigma_skip1 = 0
-      const Octave& p = oct[i - 1];
-      hipLaunchKernelGGL(sift_downsample2_kernel, dim3((o.w + 127) / 128, o.h, NF), dim3(128), 0, s, p.g[kDogLevels], p.w, o.w, o.h,
-                         o.g[0], planes_floats);
-    }
-    for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, sigma[l - 1]);
-  }
+  launch_pyramid(*this, nf, s);
   SIFT_HIP(hipGetLastError());
   return RGBDFE_OK;
 }
@@ -816,8 +412,7 @@ int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int
   int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2 * frames_cap;
   st.rows = total_rows;
   SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
-  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((oct[0].w + 63) / 64, total_rows / kDogLevels, NF), dim3(64),
-                     0, s, d_levels, d_orow2oct, d_rowcnt, tdog1, tdog, tedge, st);
+  launch_key_flags(*this, nf, st, s);
   hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
   hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows, NF), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
                      d_cand, (int)cand_cap, tdog1, tdog, tedge, st);

@@ -1,0 +1,81 @@
+// tests/emu/emu_sift.cpp -- TEST INFRASTRUCTURE ONLY: csrc/sift_pyramid_kernels.h (the product's SIFT pyramid and extremum
+// kernels, their launch chains and the extractor's geometry) compiled as host C++ over tests/emu/hip/hip_runtime.h.
+// tests/test_emu_sift_kernels.py builds it and holds the kernel SOURCES against SiftGPU's own kernels
+// (oracle/_ref/libref_siftgpu.so): one OS thread per HIP thread, workgroups one after the other.
+#include "hip/hip_runtime.h"
+
+#include "hipemu_runtime.inc"
+
+#include "sift_pyramid_kernels.h"
+
+namespace rgbdfe {
+// the extractor's device-buffer management lives in sift_extract.hip, which is not part of this library: the emulation
+// owns the (host) buffers it binds below
+SiftExtractor::~SiftExtractor() {}
+void SiftExtractor::release() {}
+}  // namespace rgbdfe
+
+using rgbdfe::SiftExtractor;
+
+namespace {
+struct Run {
+  SiftExtractor E;
+  std::vector<uint8_t> gray;
+  std::vector<float> input, up, planes;
+  std::vector<int8_t> flags;
+  std::vector<int> rowcnt;
+};
+Run* g_run = nullptr;
+}  // namespace
+
+// The shape-static half of SiftExtractor::begin_batch for ONE frame: plan_geometry + bind_levels (the product's), then
+// launch_pyramid and launch_key_flags (the product's launch chains over the product's kernels).  filter_choice: the tile shape
+// of every Gaussian level's launch (filter_tile_choice's codes: 0 = 16 x 16, 1 = 64 x 16, 2 = 64 x 32, 3 = 64 x 64), -1 = the
+// product's choice by plane size.  Returns the number of octaves (< 0: the geometry was refused).
+extern "C" int emu_sift_run(const uint8_t* gray, int cols, int rows, int filter_choice) {
+  delete g_run;
+  g_run = new Run();
+  Run& R = *g_run;
+  SiftExtractor& E = R.E;
+  E.init_params();
+  std::string err;
+  const int rc = E.plan_geometry(rows, cols, err);
+  if (rc != 0) return rc;
+  R.gray.assign(gray, gray + (size_t)rows * cols);
+  R.input.assign(E.input_floats, 0.f);
+  R.up.assign(E.oct[0].plane, 0.f);
+  R.planes.assign(E.planes_floats, 0.f);
+  R.flags.assign(E.flags_bytes, 0);
+  R.rowcnt.assign((size_t)E.total_rows, 0);
+  E.d_gray = R.gray.data(); E.d_input = R.input.data(); E.d_up = R.up.data(); E.d_planes = R.planes.data();
+  E.d_flags = R.flags.data(); E.d_rowcnt = R.rowcnt.data();
+  E.bind_levels();
+  E.d_levels = E.h_levels.data();
+  E.d_key_tiles = E.h_key_tiles.data();
+  E.n_key_tiles = (int)E.h_key_tiles.size();
+  rgbdfe::launch_pyramid(E, 1, nullptr, filter_choice);
+  rgbdfe::FrameStrides st{};
+  st.planes = E.planes_floats; st.flags = E.flags_bytes; st.rows = E.total_rows; st.lvltot = 64;
+  rgbdfe::launch_key_flags(E, 1, st, nullptr);
+  return E.octave_num;
+}
+
+extern "C" int emu_sift_octave_size(int octave, int* w, int* h) {
+  if (!g_run || octave < 0 || octave >= g_run->E.octave_num) return -1;
+  *w = g_run->E.oct[octave].w; *h = g_run->E.oct[octave].h;
+  return 0;
+}
+extern "C" const float* emu_sift_plane(int octave, int level) { return g_run->E.oct[octave].g[level]; }
+extern "C" const int8_t* emu_sift_flags(int octave, int dog_level) {
+  return g_run->E.h_levels[(size_t)octave * SiftExtractor::kDogLevels + dog_level].flags;
+}
+extern "C" const int* emu_sift_rowcnt(int octave, int dog_level) {
+  return g_run->rowcnt.data() + g_run->E.h_levels[(size_t)octave * SiftExtractor::kDogLevels + dog_level].row0;
+}
+
+// one Gaussian level of one plane through the product's launcher (any size, any tile shape)
+extern "C" int emu_sift_filter(const float* src, int w, int h, float sigma, float* dst, int choice) {
+  const rgbdfe::Taps t = rgbdfe::make_taps(sigma);
+  rgbdfe::launch_filter_any(rgbdfe::FilterArgs{src, dst, w, h, 1, 0, 0}, t, nullptr, choice);
+  return t.fw;
+}

@@ -1,8 +1,8 @@
 // tests/emu/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY (found before the real header through -I tests/emu).
-// A HIP-on-CPU vocabulary just large enough to compile csrc/orb_kernels.hip with g++ and RUN those of its kernels that use
-// no wave-level operation (orb_pyramid_kernel, orb_resize_kernel, orb_blur_kernel) on the host: one OS thread per HIP thread
+// A HIP-on-CPU vocabulary just large enough to compile csrc/orb_kernels.hip and csrc/sift_pyramid_kernels.h with g++ and RUN those of their kernels that use
+// no wave-level operation (orb_pyramid_kernel, orb_resize_kernel, orb_blur_kernel; the SIFT pyramid and extremum kernels) on the host: one OS thread per HIP thread
 // of a workgroup, workgroups one after the other, __shared__ = static storage, __syncthreads() = a barrier over the
-// workgroup's threads.  Wave intrinsics (ballot, shuffles, DPP, mbcnt, LDS / global atomics) compile to calls that abort:
+// workgroup's threads.  Wave intrinsics (ballot, shuffles, DPP, mbcnt) compile to calls that abort:
 // the kernels built on them are not run here.  Nothing under rgbdslam_v2_amd/ includes this file.
 #pragma once
 #include <float.h>
@@ -62,7 +62,8 @@ void hipemu_barrier();
 void hipemu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hipemu_launch(grid, block, [&] { kernel(__VA_ARGS__); })
 
-// wave-level operations: kernels that use them are compiled but must not run on this emulation
+// wave-level operations (atomics and readfirstlane of a uniform value aside): kernels that use them are compiled but must
+// not run on this emulation
 [[noreturn]] static inline void hipemu_no_wave_ops(const char* what) {
   fprintf(stderr, "hip emulation: %s is a wave-level operation (this kernel cannot run here)\n", what);
   abort();
@@ -71,7 +72,8 @@ static inline unsigned long long __ballot(int) { hipemu_no_wave_ops("__ballot");
 static inline int __shfl(int, int) { hipemu_no_wave_ops("__shfl"); }
 static inline int __shfl_xor(int, int) { hipemu_no_wave_ops("__shfl_xor"); }
 static inline int __shfl_up(int, int) { hipemu_no_wave_ops("__shfl_up"); }
-static inline int atomicAdd(int*, int) { hipemu_no_wave_ops("atomicAdd"); }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }   // LDS or global: one address space here
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned, unsigned) { hipemu_no_wave_ops("mbcnt"); }
 static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned, unsigned) { hipemu_no_wave_ops("mbcnt"); }
 static inline int __builtin_amdgcn_update_dpp(int, int, int, int, int, bool) { hipemu_no_wave_ops("update_dpp"); }

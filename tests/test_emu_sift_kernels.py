@@ -1,0 +1,98 @@
+"""CPU: the SOURCE of the SIFT pyramid and extremum kernels of the product (csrc/sift_pyramid_kernels.h: sift_convert_kernel,
+sift_upsample2_kernel, sift_filter_kernel, sift_filter_tile_kernel, sift_downsample2_kernel, sift_key_flag_kernel), their launch
+chains (launch_pyramid, launch_key_flags) and the extractor's geometry (SiftExtractor::plan_geometry / bind_levels) run on the
+host -- the header compiled with g++ over the HIP-on-CPU vocabulary of tests/emu/ (one OS thread per HIP thread, __shared__ =
+static storage, __syncthreads() = a barrier, atomicAdd = a host atomic) -- against SiftGPU's own CUDA kernels and host code
+compiled on the CUDA-on-CPU emulation of oracle/ref_stubs (oracle/_ref/libref_siftgpu.so):
+
+  * every Gaussian plane of every octave: equal bit for bit (the f32 sums of FilterH / FilterV, ProgramCU.cu:113-218, keep
+    their order in the register-window kernel of round 5);
+  * every extremum flag of every (octave, dog level) and the per-row counts: the reference's keypoint map (ComputeKEY_Kernel,
+    ProgramCU.cu:524-640) as InitHist_Kernel enumerates it (:665-688).
+
+The tile shape of the Gaussian levels is forced (64 x 64 and 64 x 32 register-window tiles on EVERY octave, down to planes
+smaller than one tile: the clamped borders) or left to the product's choice.  The GPU runs of the same kernels:
+tests/test_gpu_sift_extract.py."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rgbdslam_v2_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    if po.ref_siftgpu_lib() is None:
+        pytest.skip("oracle/_ref/libref_siftgpu.so was not built (no reference tree when the snapshot was made)")
+    d = tmp_path_factory.mktemp("emu_sift")
+    lib = os.path.join(d, "libemu_sift.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas",
+                    "-I", os.path.join(ROOT, "tests", "emu"), "-I", os.path.join(ROOT, "rgbdslam_v2_amd", "csrc"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "emu", "emu_sift.cpp"), "-o", lib],
+                   check=True, capture_output=True, timeout=300)
+    L = C.CDLL(lib)
+    L.emu_sift_run.restype = C.c_int
+    L.emu_sift_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    for f in (L.emu_sift_plane, L.emu_sift_flags, L.emu_sift_rowcnt):
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_int, C.c_int]
+    L.emu_sift_filter.restype = C.c_int
+    L.emu_sift_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+    return L
+
+
+def _array(ptr, ctype, shape):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=shape)
+
+
+@pytest.mark.parametrize("w,h,seed,choice", [(172, 116, 7, 2), (128, 96, 5, 3), (96, 72, 11, -1)])
+def test_pyramid_planes_and_extremum_flags_equal_siftgpus(emu, w, h, seed, choice):
+    img = synth.make_image_sequence(n_frames=1, seed=seed, width=w, height=h)["gray"][0]
+    po.ref_sift_detect(img, 0)
+    geo = po.ref_sift_geometry()
+    on = emu.emu_sift_run(img.ctypes.data_as(C.c_void_p), w, h, choice)
+    assert on == geo["octave_num"] and geo["levels"] == 8 and geo["dog_levels"] == 5
+    n_flags = 0
+    for o in range(on):
+        ww, hh = C.c_int(), C.c_int()
+        assert emu.emu_sift_octave_size(o, C.byref(ww), C.byref(hh)) == 0
+        ww, hh = ww.value, hh.value
+        for l in range(geo["levels"]):
+            got, ref = _array(emu.emu_sift_plane(o, l), C.c_float, (hh, ww)), po.ref_sift_level(o, l, 0)
+            assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (o, l)
+        for j in range(geo["dog_levels"]):
+            flags = _array(emu.emu_sift_flags(o, j), C.c_int8, (hh, ww))
+            rowcnt = _array(emu.emu_sift_rowcnt(o, j), C.c_int, (hh,))
+            cand = po.ref_sift_candidates(o, j)
+            want = np.zeros((hh, ww), np.int8)
+            want[cand[:, 1].astype(int), cand[:, 0].astype(int)] = np.where(cand[:, 2] > 0, 1, -1)
+            assert np.array_equal(flags, want), (o, j)
+            assert np.array_equal(rowcnt, (want != 0).sum(1)), (o, j)
+            n_flags += len(cand)
+    assert n_flags > 50   # the comparison is not vacuous
+
+
+@pytest.mark.parametrize("fw_sigma", [0.6, 2.6, 3.9])   # 5, 21 and 33 taps: widths the pyramid's own sigmas never take
+def test_every_tile_shape_computes_the_same_level(emu, fw_sigma):
+    """Tap widths outside the pyramid's 9 .. 17 (the launcher's switch covers 5 .. 33): the four tile shapes agree bit for bit
+    on a plane with partial tiles on both axes -- the 16 x 16 kernel is the form rounds 3 - 4 pinned on the reference."""
+    rng = np.random.default_rng(int(fw_sigma * 10))
+    w, h = 140, 75
+    src = rng.random((h, w), dtype=np.float32)
+    out = []
+    for choice in range(4):
+        dst = np.zeros((h, w), np.float32)
+        fw = emu.emu_sift_filter(src.ctypes.data_as(C.c_void_p), w, h, fw_sigma, dst.ctypes.data_as(C.c_void_p), choice)
+        out.append(dst)
+    assert fw == {0.6: 5, 2.6: 21, 3.9: 33}[fw_sigma]
+    for choice in (1, 2, 3):
+        assert np.array_equal(out[0].view(np.uint32), out[choice].view(np.uint32)), choice
