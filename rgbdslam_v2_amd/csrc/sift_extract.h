@@ -64,6 +64,9 @@ struct SiftExtractor {
   static constexpr int kKeyTileH = 16;
   struct KeyTile { int oct, x0, y0; };                 // a 64 x kKeyTileH pixel tile of an octave
   std::vector<KeyTile> h_key_tiles;
+  struct OctDesc { size_t plane_off, flag_off; int w, h, row0, pad; };   // an octave inside a frame's planes / flags / rows
+  std::vector<OctDesc> h_octs;
+  void* d_octs = nullptr;
   float* d_cand = nullptr; size_t cand_cap = 0;        // candidates: 6 floats each, per level at its offset
   float4* d_feat = nullptr; size_t feat_cap = 0;       // feature list (x, y, scale, packed / final orientation)
   float* d_desc = nullptr; size_t desc_cap = 0;

@@ -324,6 +324,8 @@ void SiftExtractor::release() {
   if (d_jobs) (void)hipFree(d_jobs);
   if (d_key_tiles) (void)hipFree(d_key_tiles);
   d_key_tiles = nullptr; n_key_tiles = 0;
+  if (d_octs) (void)hipFree(d_octs);
+  d_octs = nullptr;
   if (h_counts) (void)hipHostFree(h_counts);
   if (h_stage) (void)hipHostFree(h_stage);
   if (h_gray) (void)hipHostFree(h_gray);
@@ -358,6 +360,8 @@ int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
   SIFT_HIP(hipMalloc((void**)&d_levels, sizeof(LevelDesc) * h_levels.size()));
   SIFT_HIP(hipMemcpy(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice));
   SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2 * F, h_row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
+  SIFT_HIP(hipMalloc((void**)&d_octs, sizeof(OctDesc) * h_octs.size()));
+  SIFT_HIP(hipMemcpy(d_octs, h_octs.data(), sizeof(OctDesc) * h_octs.size(), hipMemcpyHostToDevice));
   n_key_tiles = (int)h_key_tiles.size();
   SIFT_HIP(hipMalloc((void**)&d_key_tiles, sizeof(KeyTile) * h_key_tiles.size()));
   SIFT_HIP(hipMemcpy(d_key_tiles, h_key_tiles.data(), sizeof(KeyTile) * h_key_tiles.size(), hipMemcpyHostToDevice));

@@ -144,20 +144,35 @@ __global__ __launch_bounds__(256) void sift_filter_tile_kernel(const float* __re
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  {  // ---- the source patch, rows and columns clamped to the image (FilterH / FilterV clamp their fetches) ----------------
+  {  // ---- the source patch, rows and columns clamped to the image (FilterH / FilterV clamp their fetches).  Fixed trip
+     //      counts, loads first, LDS writes after: all of a thread's loads are in flight together ------------------------
+    constexpr int KM = (PH + 3) / 4, KT = (PH * 2 * R + 255) / 256;
+    float vm[KM], vt[KT];
     int gx = x0 - R + lane;
     gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-    for (int py = wave; py < PH; py += 4) {
-      int gy = y0 - R + py;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      int gy = y0 - R + wave + 4 * k;      // (a row past the patch re-reads the image's last row: loaded, not stored)
       gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-      patch[py * PW + lane] = src[(size_t)gy * w + gx];
+      vm[k] = src[(size_t)gy * w + gx];
     }
-    for (int i = tid; i < PH * 2 * R; i += 256) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int i = tid + 256 * k;
       const int py = i / (2 * R), px = 64 + (i - py * (2 * R));
       int gy = y0 - R + py, tx = x0 - R + px;
       gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
       tx = tx > w - 1 ? w - 1 : tx;
-      patch[py * PW + px] = src[(size_t)gy * w + tx];
+      vt[k] = src[(size_t)gy * w + tx];
+    }
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (wave + 4 * k < PH) patch[(wave + 4 * k) * PW + lane] = vm[k];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int i = tid + 256 * k;
+      const int py = i / (2 * R), px = 64 + (i - py * (2 * R));
+      if (i < PH * 2 * R) patch[py * PW + px] = vt[k];
     }
   }
   __syncthreads();
@@ -391,7 +406,8 @@ __device__ __forceinline__ SiftExtractor::LevelDesc level_of_frame(SiftExtractor
 // Counted = what InitHist_Kernel (ProgramCU.cu:665-688) counts: rows 1 .. h-2, columns 1 .. w-2 with a non-zero key.
 using KeyTile = SiftExtractor::KeyTile;
 constexpr int kKeyTileH = SiftExtractor::kKeyTileH, kKeyPW = 68;   // LDS row: 66 columns, padded to a multiple of 4
-__global__ __launch_bounds__(256) void sift_key_flag_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+__global__ __launch_bounds__(256) void sift_key_flag_kernel(const float* __restrict__ planes, int8_t* __restrict__ flags,
+                                                            const SiftExtractor::OctDesc* __restrict__ octs,
                                                             const KeyTile* __restrict__ tiles, int* __restrict__ rowcnt,
                                                             float dog_threshold0, float dog_threshold, float edge_threshold,
                                                             FrameStrides st) {
@@ -400,31 +416,50 @@ __global__ __launch_bounds__(256) void sift_key_flag_kernel(const SiftExtractor:
   __shared__ float G[kLv][PH * kKeyPW];
   __shared__ int cnt[kDog * kKeyTileH];
   const KeyTile T = tiles[blockIdx.x];
-  const SiftExtractor::LevelDesc* __restrict__ lv = levels + T.oct * kDog;
-  rowcnt += (size_t)blockIdx.y * st.rows;
-  const int w = lv[0].w, h = lv[0].h;
+  const SiftExtractor::OctDesc O = octs[T.oct];
+  // (planes and flags are addressed from the kernel's own pointer arguments, not through pointers kept in a table: the
+  //  compiler then knows the loads are global, which lets it issue all of a thread's 36 loads before the first LDS write --
+  //  through table pointers they were flat loads, each ordered behind the LDS write before it: 90 us per frame instead of 49)
+  planes += (size_t)blockIdx.y * st.planes + O.plane_off;
+  flags += (size_t)blockIdx.y * st.flags + O.flag_off;
+  rowcnt += (size_t)blockIdx.y * st.rows + O.row0;
+  const int w = O.w, h = O.h;
+  const size_t plane = (size_t)w * h;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < kDog * kKeyTileH) cnt[tid] = 0;
-  {  // the planes G[0] .. G[7] of the octave: level 0's four, then the top plane of each further level
+  {  // the planes G[0] .. G[7] of the octave: every load of the thread first, the LDS writes after
+    constexpr int KM = (PH + 3) / 4, KT = (kLv * PH * 2 + 255) / 256;
+    float vm[kLv][KM], vt[KT];
     int gx = T.x0 - 1 + lane;
     gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
 #pragma unroll
-    for (int p = 0; p < kLv; ++p) {
-      const float* __restrict__ src = (p < 4 ? lv[0].g[p] : lv[p - 3].g[3]) + (size_t)blockIdx.y * st.planes;
-      for (int r = wave; r < PH; r += 4) {
-        int gy = T.y0 - 1 + r;
-        gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-        G[p][r * kKeyPW + lane] = src[(size_t)gy * w + gx];
-      }
+    for (int k = 0; k < KM; ++k) {
+      int gy = T.y0 - 1 + wave + 4 * k;    // (a row past the tile re-reads the image's last row: loaded, not stored)
+      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+#pragma unroll
+      for (int p = 0; p < kLv; ++p) vm[p][k] = planes[plane * p + (size_t)gy * w + gx];
     }
-    for (int i = tid; i < kLv * PH * 2; i += 256) {   // columns 64, 65 of every row
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {          // columns 64, 65 of every row
+      const int i = tid + 256 * k;
       const int p = i / (PH * 2), q = i - p * (PH * 2), r = q >> 1, c = 64 + (q & 1);
-      const float* __restrict__ src = (p < 4 ? lv[0].g[p] : lv[p - 3].g[3]) + (size_t)blockIdx.y * st.planes;
       int gy = T.y0 - 1 + r, tx = T.x0 - 1 + c;
       gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
       tx = tx > w - 1 ? w - 1 : tx;
-      G[p][r * kKeyPW + c] = src[(size_t)gy * w + tx];
+      vt[k] = i < kLv * PH * 2 ? planes[plane * p + (size_t)gy * w + tx] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (wave + 4 * k < PH) {
+#pragma unroll
+        for (int p = 0; p < kLv; ++p) G[p][(wave + 4 * k) * kKeyPW + lane] = vm[p][k];
+      }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int i = tid + 256 * k;
+      const int p = i / (PH * 2), q = i - p * (PH * 2), r = q >> 1, c = 64 + (q & 1);
+      if (i < kLv * PH * 2) G[p][r * kKeyPW + c] = vt[k];
     }
   }
   __syncthreads();
@@ -447,13 +482,13 @@ __global__ __launch_bounds__(256) void sift_key_flag_kernel(const SiftExtractor:
         flag = e.result > 0.f ? 1 : (e.result < 0.f ? -1 : 0);
         if (flag) atomicAdd(&cnt[j * kKeyTileH + lr], 1);
       }
-      if (col < w) (lv[j].flags + (size_t)blockIdx.y * st.flags)[(size_t)row * w + col] = flag;
+      if (col < w) flags[plane * j + (size_t)row * w + col] = flag;
     }
   }
   __syncthreads();
   if (tid < kDog * kKeyTileH) {
     const int j = tid / kKeyTileH, lr = tid - j * kKeyTileH;
-    if (cnt[tid]) atomicAdd(&rowcnt[lv[j].row0 + T.y0 + lr], cnt[tid]);
+    if (cnt[tid]) atomicAdd(&rowcnt[j * h + T.y0 + lr], cnt[tid]);
   }
 }
 
@@ -517,8 +552,9 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
 inline void launch_key_flags(const SiftExtractor& E, int nf, const FrameStrides& st, hipStream_t s) {
   const float tdog = E.dog_threshold, tdog1 = 0.8f * tdog;
   const float tedge = (E.edge_threshold + 1) * (E.edge_threshold + 1) / E.edge_threshold;
-  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((unsigned)E.n_key_tiles, (unsigned)nf), dim3(256), 0, s, E.d_levels,
-                     static_cast<const KeyTile*>(E.d_key_tiles), E.d_rowcnt, tdog1, tdog, tedge, st);
+  hipLaunchKernelGGL(sift_key_flag_kernel, dim3((unsigned)E.n_key_tiles, (unsigned)nf), dim3(256), 0, s, E.d_planes, E.d_flags,
+                     static_cast<const SiftExtractor::OctDesc*>(E.d_octs), static_cast<const KeyTile*>(E.d_key_tiles),
+                     E.d_rowcnt, tdog1, tdog, tedge, st);
 }
 
 }  // namespace
@@ -595,6 +631,11 @@ inline void SiftExtractor::bind_levels() {
       row0 += oct[i].h;
       foff += oct[i].plane;
     }
+  h_octs.assign((size_t)on, OctDesc{});
+  for (int i = 0; i < on; ++i) {   // the same facts per OCTAVE, as offsets: what the extremum kernel addresses with
+    const LevelDesc& L0 = h_levels[(size_t)i * kDogLevels];
+    h_octs[(size_t)i] = OctDesc{(size_t)(oct[i].g[0] - d_planes), (size_t)(L0.flags - d_flags), oct[i].w, oct[i].h, L0.row0, 0};
+  }
   h_key_tiles.clear();
   for (int i = 0; i < on; ++i)
     for (int y0 = 0; y0 < oct[i].h; y0 += kKeyTileH)

@@ -52,6 +52,7 @@ extern "C" int emu_sift_run(const uint8_t* gray, int cols, int rows, int filter_
   E.bind_levels();
   E.d_levels = E.h_levels.data();
   E.d_key_tiles = E.h_key_tiles.data();
+  E.d_octs = E.h_octs.data();
   E.n_key_tiles = (int)E.h_key_tiles.size();
   rgbdfe::launch_pyramid(E, 1, nullptr, filter_choice);
   rgbdfe::FrameStrides st{};
