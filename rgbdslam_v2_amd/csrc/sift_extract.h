@@ -29,6 +29,10 @@ struct SiftExtractor {
   int begin_batch(const uint8_t* const* gray, int nf, int rows, int cols, hipStream_t s, std::string& err);
   int finish_batch(int max_features, std::vector<SiftKey>* keys, const float** desc, hipStream_t s, std::string& err);
   int pending_nf = 0;   // frames of the batch begin_batch enqueued and finish_batch has not collected yet
+  int enqueue_begin(int nf, hipStream_t s, std::string& err);
+  hipGraph_t begin_graph[kMaxBatch + 1] = {};          // begin_batch's launch chain per batch size, captured on first use
+  hipGraphExec_t begin_exec[kMaxBatch + 1] = {};
+  bool begin_capture_failed = false;
   int run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys, const float*& desc,
           hipStream_t s, std::string& err) {
     return run_batch(&gray, 1, rows, cols, max_features, &keys, &desc, s, err);

@@ -218,86 +218,140 @@ __global__ __launch_bounds__(64) void sift_orientation_kernel(const LevelJobs* _
 }
 
 // ComputeDescriptor_Kernel<false> (ProgramCU.cu:967-1046).  The reference gives each of a feature's 16 cells one thread;
-// here a cell gets a WAVE: the samples of the cell's bounding box go round-robin over the lanes, every lane keeps its own
-// 8 + 1 bins in registers (the reference's compare-and-add over k, so no dynamic indexing), a fixed butterfly sums the
-// lanes.  Per-sample arithmetic is the reference's; only the order of the sums differs (see the orientation kernel).
+// here a FEATURE gets a workgroup and a cell a wave (four cells per wave, one after the other): the samples of the cell's
+// bounding box go round-robin over the lanes, every lane keeps its own 8 + 1 bins in registers (the reference's
+// compare-and-add over k, so no dynamic indexing), a fixed butterfly sums the lanes.  Per-sample arithmetic is the
+// reference's; only the order of the sums differs (see the orientation kernel).
+// A pixel of the feature's window lies in up to four cells' supports, and its gradient -- four loads, a sqrt, an atan2: most
+// of a sample's cost -- was computed once per cell in rounds 3 - 4.  Now the workgroup first evaluates grad_at over the
+// bounding box of all sixteen cells into LDS (256 threads, each pixel once: <= 80 x 80 for any feature the detector
+// produces), and the cells' loops read (magnitude, angle) from there.  Same values, same sample order per cell, same
+// butterfly: the descriptors are the earlier kernel's bit for bit (tests/test_gpu_sift_extract.py compares the two forms;
+// kStaged = false is that earlier form -- RGBDFE_SIFT_DESC=cells -- and what a feature whose window exceeds the LDS patch
+// falls back to: a caller's keypoint of arbitrary scale in describe()).
+constexpr int kDescPatchCap = 6400;   // float2 entries: 51.2 KB, three workgroups per CU
+template <bool kStaged>
 __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* __restrict__ jobs_of_frame,
                                                               const float4* __restrict__ feat, float4* __restrict__ d_des,
                                                               float window_factor) {
+  __shared__ float2 patch[kStaged ? kDescPatchCap : 1];
   const float rpi = 4.0 / 3.14159265358979323846;
   const LevelJobs& jobs = jobs_of_frame[blockIdx.y];
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // feature * 16 + cell: four cells (waves) per workgroup
-  const int lane = threadIdx.x & 63;
-  const int fidx = idx >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fidx = blockIdx.x;
   if (fidx >= jobs.begin[jobs.n]) return;
   int s = 0;
   while (s + 1 < jobs.n && fidx >= jobs.begin[s + 1]) ++s;
   const int width = jobs.w[s], height = jobs.h[s];
   const float* __restrict__ G = jobs.g[s];
   const float4 key = feat[jobs.base + fidx];
-  const int bidx = idx & 0xf, ix = bidx & 0x3, iy = bidx >> 2;
   const float spt = fabsf(key.z * window_factor);
   float sn, cs;
   sincosf(key.w, &sn, &cs);
   const float anglef = key.w > 3.14159265358979323846 ? (float)((double)key.w - (2.0 * 3.14159265358979323846)) : key.w;
   const float cspt = cs * spt, sspt = sn * spt;
   const float crspt = cs / spt, srspt = sn / spt;
-  float2 offsetpt, pt;
-  offsetpt.x = ix - 1.5f;
-  offsetpt.y = iy - 1.5f;
-  pt.x = cspt * offsetpt.x - sspt * offsetpt.y + key.x;
-  pt.y = cspt * offsetpt.y + sspt * offsetpt.x + key.y;
   const float bsz = fabsf(cspt) + fabsf(sspt);
-  const float xmin = fmaxf(1.5f, floorf(pt.x - bsz) + 0.5f);
-  const float ymin = fmaxf(1.5f, floorf(pt.y - bsz) + 0.5f);
-  const float xmax = fminf(width - 1.5f, floorf(pt.x + bsz) + 0.5f);
-  const float ymax = fminf(height - 1.5f, floorf(pt.y + bsz) + 0.5f);
-  const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;
-  const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
-  float des[9];
+  struct Box { float2 offsetpt, pt; float xmin, ymin, xmax, ymax; };
+  auto cell_box = [&](int bidx) -> Box {
+    Box b;
+    const int ix = bidx & 0x3, iy = bidx >> 2;
+    b.offsetpt.x = ix - 1.5f;
+    b.offsetpt.y = iy - 1.5f;
+    b.pt.x = cspt * b.offsetpt.x - sspt * b.offsetpt.y + key.x;
+    b.pt.y = cspt * b.offsetpt.y + sspt * b.offsetpt.x + key.y;
+    b.xmin = fmaxf(1.5f, floorf(b.pt.x - bsz) + 0.5f);
+    b.ymin = fmaxf(1.5f, floorf(b.pt.y - bsz) + 0.5f);
+    b.xmax = fminf(width - 1.5f, floorf(b.pt.x + bsz) + 0.5f);
+    b.ymax = fminf(height - 1.5f, floorf(b.pt.y + bsz) + 0.5f);
+    return b;
+  };
+  // ---- the gradients of the feature's window, once per pixel ----------------------------------------------------------------
+  int bx0 = 0, by0 = 0, bw = 0;
+  bool staged = false;
+  if (kStaged) {
+    float fx0 = 1e30f, fy0 = 1e30f, fx1 = -1e30f, fy1 = -1e30f;
+    for (int c = 0; c < 16; ++c) {
+      const Box b = cell_box(c);
+      if (b.xmax >= b.xmin && b.ymax >= b.ymin) {
+        fx0 = fminf(fx0, b.xmin); fy0 = fminf(fy0, b.ymin); fx1 = fmaxf(fx1, b.xmax); fy1 = fmaxf(fy1, b.ymax);
+      }
+    }
+    if (fx1 >= fx0) {
+      bx0 = (int)floorf(fx0); by0 = (int)floorf(fy0);
+      bw = (int)floorf(fx1) - bx0 + 1;
+      const int bh = (int)floorf(fy1) - by0 + 1;
+      staged = bw * bh <= kDescPatchCap;
+      if (staged)
+        for (int t = threadIdx.x; t < bw * bh; t += 256) {
+          const int jy = t / bw, jx = t - jy * bw;
+          patch[t] = grad_at(G, width, bx0 + jx, by0 + jy);
+        }
+    }
+    __syncthreads();
+  }
+  // ---- the cells --------------------------------------------------------------------------------------------------------------
+  for (int bidx = wave; bidx < 16; bidx += 4) {
+    const Box B = cell_box(bidx);
+    const float2 offsetpt = B.offsetpt, pt = B.pt;
+    const float xmin = B.xmin, ymin = B.ymin, xmax = B.xmax, ymax = B.ymax;
+    const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;
+    const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
+    float des[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) des[i] = 0.0f;
-  const int total = nx * ny;
-  for (int t = lane; t < total; t += 64) {
-    const int jy = t / nx, jx = t - jy * nx;
-    const float x = xmin + (float)jx, y = ymin + (float)jy;
-    const float dx = x - pt.x;
-    const float dy = y - pt.y;
-    const float nxf = crspt * dx + srspt * dy;
-    const float nyf = crspt * dy - srspt * dx;
-    const float nxn = fabsf(nxf);
-    const float nyn = fabsf(nyf);
-    if (nxn < 1.0f && nyn < 1.0f) {
-      const float2 cc = grad_at(G, width, (int)floorf(x), (int)floorf(y));
-      const float dnx = nxf + offsetpt.x;
-      const float dny = nyf + offsetpt.y;
-      const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
-      const float wx = (float)(1.0 - (double)nxn);
-      const float wy = (float)(1.0 - (double)nyn);
-      const float weight = ww * wx * wy * cc.x;
-      float theta = (anglef - cc.y) * rpi;
-      if (theta < 0) theta += 8.0f;
-      const float fo = floorf(theta);
-      const int fi = (int)fo;
-      const float weight1 = fo + 1.0f - theta;
-      const float weight2 = theta - fo;
+    for (int i = 0; i < 9; ++i) des[i] = 0.0f;
+    const int total = nx * ny;
+    for (int t = lane; t < total; t += 64) {
+      const int jy = t / nx, jx = t - jy * nx;
+      const float x = xmin + (float)jx, y = ymin + (float)jy;
+      const float dx = x - pt.x;
+      const float dy = y - pt.y;
+      const float nxf = crspt * dx + srspt * dy;
+      const float nyf = crspt * dy - srspt * dx;
+      const float nxn = fabsf(nxf);
+      const float nyn = fabsf(nyf);
+      if (nxn < 1.0f && nyn < 1.0f) {
+        const int px = (int)floorf(x), py = (int)floorf(y);
+        const float2 cc = (kStaged && staged) ? patch[(py - by0) * bw + (px - bx0)] : grad_at(G, width, px, py);
+        const float dnx = nxf + offsetpt.x;
+        const float dny = nyf + offsetpt.y;
+        const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
+        const float wx = (float)(1.0 - (double)nxn);
+        const float wy = (float)(1.0 - (double)nyn);
+        const float weight = ww * wx * wy * cc.x;
+        float theta = (anglef - cc.y) * rpi;
+        if (theta < 0) theta += 8.0f;
+        const float fo = floorf(theta);
+        const int fi = (int)fo;
+        const float weight1 = fo + 1.0f - theta;
+        const float weight2 = theta - fo;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k == fi) {
-          des[k] += (weight1 * weight);
-          des[k + 1] += (weight2 * weight);
+        for (int k = 0; k < 8; ++k) {
+          if (k == fi) {
+            des[k] += (weight1 * weight);
+            des[k + 1] += (weight2 * weight);
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
-    for (int d = 32; d >= 1; d >>= 1) des[i] += __shfl_xor(des[i], d);
-  if (lane != 0) return;
-  des[0] += des[8];
-  const int didx = (jobs.base * 16 + idx) << 1;
-  d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
-  d_des[didx + 1] = make_float4(des[4], des[5], des[6], des[7]);
+    for (int i = 0; i < 9; ++i)
+      for (int d = 32; d >= 1; d >>= 1) des[i] += __shfl_xor(des[i], d);
+    if (lane == 0) {
+      des[0] += des[8];
+      const int didx = (jobs.base * 16 + fidx * 16 + bidx) << 1;
+      d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
+      d_des[didx + 1] = make_float4(des[4], des[5], des[6], des[7]);
+    }
+  }
+}
+
+void launch_descriptors(int max_features_per_frame, int nf, const LevelJobs* jobs, const float4* feat, float4* des, hipStream_t s) {
+  const char* e = getenv("RGBDFE_SIFT_DESC");   // read per call: the parity test switches forms inside one process
+  if (e && strcmp(e, "cells") == 0)
+    hipLaunchKernelGGL(sift_descriptor_kernel<false>, dim3(max_features_per_frame, nf), dim3(256), 0, s, jobs, feat, des, 3.0f);
+  else
+    hipLaunchKernelGGL(sift_descriptor_kernel<true>, dim3(max_features_per_frame, nf), dim3(256), 0, s, jobs, feat, des, 3.0f);
 }
 
 #define SIFT_HIP(expr)                                                                    \
@@ -311,6 +365,12 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* _
 SiftExtractor::~SiftExtractor() { release(); }
 
 void SiftExtractor::release() {
+  for (int i = 0; i <= kMaxBatch; ++i) {   // the captured launch chains hold the buffers' addresses
+    if (begin_exec[i]) (void)hipGraphExecDestroy(begin_exec[i]);
+    if (begin_graph[i]) (void)hipGraphDestroy(begin_graph[i]);
+    begin_exec[i] = nullptr; begin_graph[i] = nullptr;
+  }
+  begin_capture_failed = false;
   if (d_gray) (void)hipFree(d_gray);
   if (d_input) (void)hipFree(d_input);
   if (d_up) (void)hipFree(d_up);
@@ -404,17 +464,61 @@ int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int
   pending_nf = 0;
   int rc = prepare(rows, cols, nf, err);
   if (rc != RGBDFE_OK) return rc;
+  for (int f = 0; f < nf; ++f) memcpy(h_gray + (size_t)f * gray_cap, gray[f], gray_cap);
+  // Everything this half enqueues -- the frames' upload from the pinned stage, ~55 pyramid launches, the extremum flags, the
+  // scan, the ordered emit, the counts' download -- has the same arguments for every batch of nf frames of this size: it is
+  // captured ONCE per nf as a hipGraph and replayed with one hipGraphLaunch.  The calling thread spent ~0.3 ms per chunk on
+  // those enqueues, time the other chunk's stream sat idle for; a single call's ~60 dependent launches also
+  // start closer together inside a graph.  RGBDFE_SIFT_GRAPH=0: plain launches (the A/B switch; also what a failed capture
+  // falls back to).
+  static const bool graph_env = !(getenv("RGBDFE_SIFT_GRAPH") && atoi(getenv("RGBDFE_SIFT_GRAPH")) == 0);
+  bool launched = false;
+  if (graph_env) {
+    if (!begin_exec[nf] && !begin_capture_failed) {
+      hipGraph_t g = nullptr;
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        std::string cap_err;
+        const int crc = enqueue_begin(nf, s, cap_err);
+        hipError_t ce = hipStreamEndCapture(s, &g);
+        if (crc == RGBDFE_OK && ce == hipSuccess) ce = hipGraphInstantiate(&begin_exec[nf], g, nullptr, nullptr, 0);
+        if (crc != RGBDFE_OK || ce != hipSuccess) {
+          if (begin_exec[nf]) (void)hipGraphExecDestroy(begin_exec[nf]);
+          begin_exec[nf] = nullptr;
+          if (g) (void)hipGraphDestroy(g);
+          g = nullptr;
+          begin_capture_failed = true;
+        }
+        begin_graph[nf] = g;
+      } else {
+        begin_capture_failed = true;
+      }
+      (void)hipGetLastError();
+    }
+    if (begin_exec[nf]) {
+      SIFT_HIP(hipGraphLaunch(begin_exec[nf], s));
+      launched = true;
+    }
+  }
+  if (!launched) {
+    rc = enqueue_begin(nf, s, err);
+    if (rc != RGBDFE_OK) return rc;
+  }
+  pending_nf = nf;
+  return RGBDFE_OK;
+}
+
+// the enqueues of begin_batch (frames staged in h_gray): directly, or under stream capture
+int SiftExtractor::enqueue_begin(int nf, hipStream_t s, std::string& err) {
   const int nlv = octave_num * kDogLevels;
   const unsigned NF = (unsigned)nf;
   FrameStrides st{};
   st.planes = planes_floats; st.flags = flags_bytes; st.cand = cand_cap * 6; st.rows = total_rows; st.lvltot = 64;
-  rc = enqueue_pyramid(gray, nf, s, err);
-  if (rc != RGBDFE_OK) return rc;
+  SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)nf * gray_cap, hipMemcpyHostToDevice, s));
+  launch_pyramid(*this, nf, s);
   // ---- DetectKeypointsEX + the list part of GenerateFeatureList: flags, row counts, scan, ordered emit ----------------------
   const float tdog = dog_threshold, tdog1 = 0.8f * tdog;
   const float tedge = (edge_threshold + 1) * (edge_threshold + 1) / edge_threshold;
   int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2 * frames_cap;
-  st.rows = total_rows;
   SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
   launch_key_flags(*this, nf, st, s);
   hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
@@ -422,7 +526,6 @@ int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int
                      d_cand, (int)cand_cap, tdog1, tdog, tedge, st);
   SIFT_HIP(hipGetLastError());
   SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * 64 * (size_t)nf, hipMemcpyDeviceToHost, s));
-  pending_nf = nf;
   return RGBDFE_OK;
 }
 
@@ -578,8 +681,7 @@ int SiftExtractor::finish_batch(int max_features, std::vector<SiftKey>* keys, co
   }
   SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)grand2 * 16, hipMemcpyHostToDevice, s));
   SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(max_total2 * 4, NF), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
-                     (float4*)d_desc, 3.0f);
+  launch_descriptors(max_total2, nf, static_cast<const LevelJobs*>(d_jobs), d_feat, (float4*)d_desc, s);
   SIFT_HIP(hipGetLastError());
   if ((size_t)grand2 * 128 > h_desc_cap) {
     if (h_desc) (void)hipHostFree(h_desc);
@@ -672,8 +774,7 @@ int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftK
     memcpy(h_stage, list.data(), (size_t)total * 16);
     SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)total * 16, hipMemcpyHostToDevice, s));
     SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(sift_descriptor_kernel, dim3(total * 4, 1), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
-                       (float4*)d_desc, 3.0f);
+    launch_descriptors(total, 1, static_cast<const LevelJobs*>(d_jobs), d_feat, (float4*)d_desc, s);
     SIFT_HIP(hipGetLastError());
     SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));
     SIFT_HIP(hipStreamSynchronize(s));

@@ -32,6 +32,8 @@ static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
 
