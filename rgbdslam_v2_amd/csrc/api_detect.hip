@@ -162,9 +162,11 @@ int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* c
   std::vector<SiftKey> keys[SiftExtractor::kMaxBatch];
   const float* desc[SiftExtractor::kMaxBatch];
   std::string err;
-  // Two extractors, two streams: the shape-static first half of chunk c + 1 (pyramids, extremum flags, candidate lists) is
-  // enqueued before the host collects chunk c, so it runs on the device beside chunk c's orientation / descriptor launches and
-  // behind the host's waits and list work.
+  // Two extractors, two streams, two chunks ahead: the shape-static first half of a chunk (upload, pyramids, extremum flags,
+  // candidate lists -- one hipGraphLaunch) needs nothing of its extractor but the device buffers and the pinned image stage,
+  // and those are free the moment finish_batch of the chunk two back has returned.  So chunk c + 2 is enqueued right THERE,
+  // before the host copies chunk c's keypoints and descriptors out (~0.6 ms per chunk during which, with only chunk c + 1
+  // enqueued -- and long finished -- the device sat idle in rounds 3 - 4: profiles/r05_logs/sift_pipeline.txt).
   constexpr int B = SiftExtractor::kMaxBatch;
   const int32_t n_chunks = (n_frames + B - 1) / B;
   SiftExtractor* ex[2] = {&ctx->sift, &ctx->sift2};
@@ -176,19 +178,22 @@ int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* c
   }
   hipStream_t st[2] = {ctx->sift_stream1 ? ctx->sift_stream1 : ctx->stream, ctx->sift_stream2 ? ctx->sift_stream2 : ctx->stream};
   auto count_of = [&](int32_t c) { return std::min<int32_t>(B, n_frames - c * B); };
-  if (n_chunks > 0) {
-    const int rc = ex[0]->begin_batch(gray, count_of(0), rows, cols, st[0], err);
-    if (rc != RGBDFE_OK) return fail(ctx, rc, err);
+  auto begin = [&](int32_t c) {
+    return ex[c & 1]->begin_batch(gray + (size_t)c * B, count_of(c), rows, cols, st[c & 1], err);
+  };
+  for (int32_t c = 0; c < std::min<int32_t>(2, n_chunks); ++c) {
+    const int rc = begin(c);
+    if (rc != RGBDFE_OK) { if (c) (void)hipStreamSynchronize(st[0]); return fail(ctx, rc, err); }
   }
   for (int32_t c = 0; c < n_chunks; ++c) {
     const int32_t f0 = c * B;
     const int nf = count_of(c);
-    if (c + 1 < n_chunks) {
-      const int rcb = ex[(c + 1) & 1]->begin_batch(gray + (size_t)(c + 1) * B, count_of(c + 1), rows, cols, st[(c + 1) & 1], err);
-      if (rcb != RGBDFE_OK) { (void)hipStreamSynchronize(st[c & 1]); return fail(ctx, rcb, err); }
-    }
     const int rc = ex[c & 1]->finish_batch(max_keypoints, keys, desc, st[c & 1], err);
     if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(st[(c + 1) & 1]); return fail(ctx, rc, err); }
+    if (c + 2 < n_chunks) {   // (keys / desc of chunk c live in host memory begin_batch does not touch)
+      const int rcb = begin(c + 2);
+      if (rcb != RGBDFE_OK) { (void)hipStreamSynchronize(st[(c + 1) & 1]); return fail(ctx, rcb, err); }
+    }
     for (int k = 0; k < nf; ++k) {
       const int32_t f = f0 + k;
       n_out[f] = (int32_t)keys[k].size();

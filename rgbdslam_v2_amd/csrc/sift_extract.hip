@@ -218,140 +218,90 @@ __global__ __launch_bounds__(64) void sift_orientation_kernel(const LevelJobs* _
 }
 
 // ComputeDescriptor_Kernel<false> (ProgramCU.cu:967-1046).  The reference gives each of a feature's 16 cells one thread;
-// here a FEATURE gets a workgroup and a cell a wave (four cells per wave, one after the other): the samples of the cell's
-// bounding box go round-robin over the lanes, every lane keeps its own 8 + 1 bins in registers (the reference's
-// compare-and-add over k, so no dynamic indexing), a fixed butterfly sums the lanes.  Per-sample arithmetic is the
-// reference's; only the order of the sums differs (see the orientation kernel).
-// A pixel of the feature's window lies in up to four cells' supports, and its gradient -- four loads, a sqrt, an atan2: most
-// of a sample's cost -- was computed once per cell in rounds 3 - 4.  Now the workgroup first evaluates grad_at over the
-// bounding box of all sixteen cells into LDS (256 threads, each pixel once: <= 80 x 80 for any feature the detector
-// produces), and the cells' loops read (magnitude, angle) from there.  Same values, same sample order per cell, same
-// butterfly: the descriptors are the earlier kernel's bit for bit (tests/test_gpu_sift_extract.py compares the two forms;
-// kStaged = false is that earlier form -- RGBDFE_SIFT_DESC=cells -- and what a feature whose window exceeds the LDS patch
-// falls back to: a caller's keypoint of arbitrary scale in describe()).
-constexpr int kDescPatchCap = 6400;   // float2 entries: 51.2 KB, three workgroups per CU
-template <bool kStaged>
+// here a cell gets a WAVE: the samples of the cell's bounding box go round-robin over the lanes, every lane keeps its own
+// 8 + 1 bins in registers (the reference's compare-and-add over k, so no dynamic indexing), a fixed butterfly sums the
+// lanes.  Per-sample arithmetic is the reference's; only the order of the sums differs (see the orientation kernel).
+// (Round 5 tried a workgroup per feature that evaluates the gradients of the whole 4 x 4 window once into LDS -- a pixel
+// lies in up to four cells' supports -- and lets the cells read them: bit-identical output, but 43 instead of 37 us per VGA
+// frame.  The window's bounding box holds 1.6 x the pixels the cells' rotated supports cover, and 51 KB of LDS left 12
+// waves per CU for a loop that lives on latency hiding: profiles/r05_logs/sift_descriptor_staged.txt.)
 __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* __restrict__ jobs_of_frame,
                                                               const float4* __restrict__ feat, float4* __restrict__ d_des,
                                                               float window_factor) {
-  __shared__ float2 patch[kStaged ? kDescPatchCap : 1];
   const float rpi = 4.0 / 3.14159265358979323846;
   const LevelJobs& jobs = jobs_of_frame[blockIdx.y];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int fidx = blockIdx.x;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // feature * 16 + cell: four cells (waves) per workgroup
+  const int lane = threadIdx.x & 63;
+  const int fidx = idx >> 4;
   if (fidx >= jobs.begin[jobs.n]) return;
   int s = 0;
   while (s + 1 < jobs.n && fidx >= jobs.begin[s + 1]) ++s;
   const int width = jobs.w[s], height = jobs.h[s];
   const float* __restrict__ G = jobs.g[s];
   const float4 key = feat[jobs.base + fidx];
+  const int bidx = idx & 0xf, ix = bidx & 0x3, iy = bidx >> 2;
   const float spt = fabsf(key.z * window_factor);
   float sn, cs;
   sincosf(key.w, &sn, &cs);
   const float anglef = key.w > 3.14159265358979323846 ? (float)((double)key.w - (2.0 * 3.14159265358979323846)) : key.w;
   const float cspt = cs * spt, sspt = sn * spt;
   const float crspt = cs / spt, srspt = sn / spt;
+  float2 offsetpt, pt;
+  offsetpt.x = ix - 1.5f;
+  offsetpt.y = iy - 1.5f;
+  pt.x = cspt * offsetpt.x - sspt * offsetpt.y + key.x;
+  pt.y = cspt * offsetpt.y + sspt * offsetpt.x + key.y;
   const float bsz = fabsf(cspt) + fabsf(sspt);
-  struct Box { float2 offsetpt, pt; float xmin, ymin, xmax, ymax; };
-  auto cell_box = [&](int bidx) -> Box {
-    Box b;
-    const int ix = bidx & 0x3, iy = bidx >> 2;
-    b.offsetpt.x = ix - 1.5f;
-    b.offsetpt.y = iy - 1.5f;
-    b.pt.x = cspt * b.offsetpt.x - sspt * b.offsetpt.y + key.x;
-    b.pt.y = cspt * b.offsetpt.y + sspt * b.offsetpt.x + key.y;
-    b.xmin = fmaxf(1.5f, floorf(b.pt.x - bsz) + 0.5f);
-    b.ymin = fmaxf(1.5f, floorf(b.pt.y - bsz) + 0.5f);
-    b.xmax = fminf(width - 1.5f, floorf(b.pt.x + bsz) + 0.5f);
-    b.ymax = fminf(height - 1.5f, floorf(b.pt.y + bsz) + 0.5f);
-    return b;
-  };
-  // ---- the gradients of the feature's window, once per pixel ----------------------------------------------------------------
-  int bx0 = 0, by0 = 0, bw = 0;
-  bool staged = false;
-  if (kStaged) {
-    float fx0 = 1e30f, fy0 = 1e30f, fx1 = -1e30f, fy1 = -1e30f;
-    for (int c = 0; c < 16; ++c) {
-      const Box b = cell_box(c);
-      if (b.xmax >= b.xmin && b.ymax >= b.ymin) {
-        fx0 = fminf(fx0, b.xmin); fy0 = fminf(fy0, b.ymin); fx1 = fmaxf(fx1, b.xmax); fy1 = fmaxf(fy1, b.ymax);
-      }
-    }
-    if (fx1 >= fx0) {
-      bx0 = (int)floorf(fx0); by0 = (int)floorf(fy0);
-      bw = (int)floorf(fx1) - bx0 + 1;
-      const int bh = (int)floorf(fy1) - by0 + 1;
-      staged = bw * bh <= kDescPatchCap;
-      if (staged)
-        for (int t = threadIdx.x; t < bw * bh; t += 256) {
-          const int jy = t / bw, jx = t - jy * bw;
-          patch[t] = grad_at(G, width, bx0 + jx, by0 + jy);
-        }
-    }
-    __syncthreads();
-  }
-  // ---- the cells --------------------------------------------------------------------------------------------------------------
-  for (int bidx = wave; bidx < 16; bidx += 4) {
-    const Box B = cell_box(bidx);
-    const float2 offsetpt = B.offsetpt, pt = B.pt;
-    const float xmin = B.xmin, ymin = B.ymin, xmax = B.xmax, ymax = B.ymax;
-    const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;
-    const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
-    float des[9];
+  const float xmin = fmaxf(1.5f, floorf(pt.x - bsz) + 0.5f);
+  const float ymin = fmaxf(1.5f, floorf(pt.y - bsz) + 0.5f);
+  const float xmax = fminf(width - 1.5f, floorf(pt.x + bsz) + 0.5f);
+  const float ymax = fminf(height - 1.5f, floorf(pt.y + bsz) + 0.5f);
+  const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;
+  const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
+  float des[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) des[i] = 0.0f;
-    const int total = nx * ny;
-    for (int t = lane; t < total; t += 64) {
-      const int jy = t / nx, jx = t - jy * nx;
-      const float x = xmin + (float)jx, y = ymin + (float)jy;
-      const float dx = x - pt.x;
-      const float dy = y - pt.y;
-      const float nxf = crspt * dx + srspt * dy;
-      const float nyf = crspt * dy - srspt * dx;
-      const float nxn = fabsf(nxf);
-      const float nyn = fabsf(nyf);
-      if (nxn < 1.0f && nyn < 1.0f) {
-        const int px = (int)floorf(x), py = (int)floorf(y);
-        const float2 cc = (kStaged && staged) ? patch[(py - by0) * bw + (px - bx0)] : grad_at(G, width, px, py);
-        const float dnx = nxf + offsetpt.x;
-        const float dny = nyf + offsetpt.y;
-        const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
-        const float wx = (float)(1.0 - (double)nxn);
-        const float wy = (float)(1.0 - (double)nyn);
-        const float weight = ww * wx * wy * cc.x;
-        float theta = (anglef - cc.y) * rpi;
-        if (theta < 0) theta += 8.0f;
-        const float fo = floorf(theta);
-        const int fi = (int)fo;
-        const float weight1 = fo + 1.0f - theta;
-        const float weight2 = theta - fo;
+  for (int i = 0; i < 9; ++i) des[i] = 0.0f;
+  const int total = nx * ny;
+  for (int t = lane; t < total; t += 64) {
+    const int jy = t / nx, jx = t - jy * nx;
+    const float x = xmin + (float)jx, y = ymin + (float)jy;
+    const float dx = x - pt.x;
+    const float dy = y - pt.y;
+    const float nxf = crspt * dx + srspt * dy;
+    const float nyf = crspt * dy - srspt * dx;
+    const float nxn = fabsf(nxf);
+    const float nyn = fabsf(nyf);
+    if (nxn < 1.0f && nyn < 1.0f) {
+      const float2 cc = grad_at(G, width, (int)floorf(x), (int)floorf(y));
+      const float dnx = nxf + offsetpt.x;
+      const float dny = nyf + offsetpt.y;
+      const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
+      const float wx = (float)(1.0 - (double)nxn);
+      const float wy = (float)(1.0 - (double)nyn);
+      const float weight = ww * wx * wy * cc.x;
+      float theta = (anglef - cc.y) * rpi;
+      if (theta < 0) theta += 8.0f;
+      const float fo = floorf(theta);
+      const int fi = (int)fo;
+      const float weight1 = fo + 1.0f - theta;
+      const float weight2 = theta - fo;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (k == fi) {
-            des[k] += (weight1 * weight);
-            des[k + 1] += (weight2 * weight);
-          }
+      for (int k = 0; k < 8; ++k) {
+        if (k == fi) {
+          des[k] += (weight1 * weight);
+          des[k + 1] += (weight2 * weight);
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-      for (int d = 32; d >= 1; d >>= 1) des[i] += __shfl_xor(des[i], d);
-    if (lane == 0) {
-      des[0] += des[8];
-      const int didx = (jobs.base * 16 + fidx * 16 + bidx) << 1;
-      d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
-      d_des[didx + 1] = make_float4(des[4], des[5], des[6], des[7]);
-    }
   }
-}
-
-void launch_descriptors(int max_features_per_frame, int nf, const LevelJobs* jobs, const float4* feat, float4* des, hipStream_t s) {
-  const char* e = getenv("RGBDFE_SIFT_DESC");   // read per call: the parity test switches forms inside one process
-  if (e && strcmp(e, "cells") == 0)
-    hipLaunchKernelGGL(sift_descriptor_kernel<false>, dim3(max_features_per_frame, nf), dim3(256), 0, s, jobs, feat, des, 3.0f);
-  else
-    hipLaunchKernelGGL(sift_descriptor_kernel<true>, dim3(max_features_per_frame, nf), dim3(256), 0, s, jobs, feat, des, 3.0f);
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    for (int d = 32; d >= 1; d >>= 1) des[i] += __shfl_xor(des[i], d);
+  if (lane != 0) return;
+  des[0] += des[8];
+  const int didx = (jobs.base * 16 + idx) << 1;
+  d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
+  d_des[didx + 1] = make_float4(des[4], des[5], des[6], des[7]);
 }
 
 #define SIFT_HIP(expr)                                                                    \
@@ -681,7 +631,8 @@ int SiftExtractor::finish_batch(int max_features, std::vector<SiftKey>* keys, co
   }
   SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)grand2 * 16, hipMemcpyHostToDevice, s));
   SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
-  launch_descriptors(max_total2, nf, static_cast<const LevelJobs*>(d_jobs), d_feat, (float4*)d_desc, s);
+  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(max_total2 * 4, NF), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
+                     (float4*)d_desc, 3.0f);
   SIFT_HIP(hipGetLastError());
   if ((size_t)grand2 * 128 > h_desc_cap) {
     if (h_desc) (void)hipHostFree(h_desc);
@@ -774,7 +725,8 @@ int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftK
     memcpy(h_stage, list.data(), (size_t)total * 16);
     SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)total * 16, hipMemcpyHostToDevice, s));
     SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs), hipMemcpyHostToDevice, s));
-    launch_descriptors(total, 1, static_cast<const LevelJobs*>(d_jobs), d_feat, (float4*)d_desc, s);
+    hipLaunchKernelGGL(sift_descriptor_kernel, dim3(total * 4, 1), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
+                       (float4*)d_desc, 3.0f);
     SIFT_HIP(hipGetLastError());
     SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));
     SIFT_HIP(hipStreamSynchronize(s));

@@ -158,31 +158,6 @@ def test_full_size_properties(fe):
     assert 0 < len(small) < len(kp) and kp[len(kp) - len(small):].tobytes() == small.tobytes()
 
 
-def test_the_staged_descriptor_kernel_equals_the_per_cell_form(fe):
-    """Round 5's descriptor kernel evaluates the gradients of a feature's window once into LDS; RGBDFE_SIFT_DESC=cells is
-    the form of rounds 3 - 4 (every cell its own grad_at calls).  Same samples, same order, same butterfly: the same bytes,
-    over single calls (640 x 480 and a small frame whose windows meet the image border) and a batch."""
-    import os
-    frames = [image(640, 480, 31), image(320, 240, 32), image(96, 80, 33)]
-    got = {}
-    for form in ("cells", None):
-        if form:
-            os.environ["RGBDFE_SIFT_DESC"] = form
-        else:
-            os.environ.pop("RGBDFE_SIFT_DESC", None)
-        try:
-            got[form] = [fe.sift_detect(g, None, 1 << 20) for g in frames] + fe.sift_detect_batch([frames[1]] * 3, 700)
-            # caller-given keypoints eight times larger: windows beyond the LDS patch take the kernel's direct-gradient path
-            big = fe.sift_detect(frames[0], None, 200)[0].copy()
-            big["size"] *= 8
-            got[form].append(fe.sift_describe(frames[0], big))
-        finally:
-            os.environ.pop("RGBDFE_SIFT_DESC", None)
-    assert sum(len(k) for k, _ in got[None]) > 2000
-    for (ka, da), (kb, db) in zip(got["cells"], got[None]):
-        assert ka.tobytes() == kb.tobytes() and da.tobytes() == db.tobytes()
-
-
 def test_batch_equals_single_calls(fe):
     """rgbdfe_sift_detect_batch: 8 frames per launch chain (11 frames = one full chain + a ragged one), every frame's
     output identical to its single call -- textured frames, a featureless one in the middle, with and without the limit."""
