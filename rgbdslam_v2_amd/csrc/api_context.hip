@@ -85,7 +85,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   // every stream this context has work on -- not the device: another context's thread may be capturing a hipGraph
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& ln : ctx->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
-  for (hipStream_t st : {ctx->orb_upload_stream, ctx->orb_compute_stream, ctx->sift_stream1, ctx->sift_stream2})
+  for (hipStream_t st : {ctx->orb_upload_stream, ctx->orb_compute_stream, ctx->sift_stream1, ctx->sift_stream2, ctx->sift_stream3})
     if (st) (void)hipStreamSynchronize(st);
   drain_pending(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -94,6 +94,7 @@ void rgbdfe_destroy(rgbdfe_ctx* ctx) {
   if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
   if (ctx->sift_stream1) (void)hipStreamDestroy(ctx->sift_stream1);
   if (ctx->sift_stream2) (void)hipStreamDestroy(ctx->sift_stream2);
+  if (ctx->sift_stream3) (void)hipStreamDestroy(ctx->sift_stream3);
   ctx->graphs.clear();
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
   if (ctx->d_xyz) (void)hipFree(ctx->d_xyz);

@@ -159,57 +159,74 @@ int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* c
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   for (int32_t f = 0; f < n_frames; ++f) n_out[f] = 0;
   bool overflow = false;
-  std::vector<SiftKey> keys[SiftExtractor::kMaxBatch];
-  const float* desc[SiftExtractor::kMaxBatch];
   std::string err;
-  // Two extractors, two streams, two chunks ahead: the shape-static first half of a chunk (upload, pyramids, extremum flags,
-  // candidate lists -- one hipGraphLaunch) needs nothing of its extractor but the device buffers and the pinned image stage,
-  // and those are free the moment finish_batch of the chunk two back has returned.  So chunk c + 2 is enqueued right THERE,
-  // before the host copies chunk c's keypoints and descriptors out (~0.6 ms per chunk during which, with only chunk c + 1
-  // enqueued -- and long finished -- the device sat idle in rounds 3 - 4: profiles/r05_logs/sift_pipeline.txt).
-  constexpr int B = SiftExtractor::kMaxBatch;
+  // Three extractors, three streams, a software pipeline over chunks of up to 8 frames.  A chunk passes four steps, each of
+  // which waits for the launches of the one before, does the host's part and enqueues the next launches (sift_extract.hip):
+  //   begin_batch           images staged + uploaded, pyramids, extremum flags, candidate lists     ~1.0 ms of device time
+  //   finish_orientations   feature-count limits -> the orientation launch                          ~0.06 ms
+  //   finish_descriptors    one feature per orientation -> the descriptor launch + 6 MB download    ~0.45 ms
+  //   finish_outputs        keys / descriptor pointers; then the copy into the caller's arrays      host only, ~0.35 ms
+  // One host thread drives all of it, so the ORDER of the steps decides what the device has to do while the host works or
+  // waits: within an iteration the descriptor launch of chunk c goes out first, then chunk c + 2 is begun (its extractor's
+  // device buffers were released by chunk c - 1's last wait; the results of c - 1 sit in host memory begin_batch does not
+  // touch), then chunk c - 1 is copied out -- with two launch chains and a descriptor launch enqueued behind the host's
+  // back -- and only then the host waits: for chunk c + 1's first half (begun a whole iteration ago) and chunk c's
+  // descriptors.  Rounds 3 - 4 ran begin(c + 1) | all of finish(c) | copy-out(c) with two extractors: the device idled
+  // through every copy-out and most waits (profiles/r05_logs/sift_pipeline.txt).
+  constexpr int B = SiftExtractor::kMaxBatch, D = 3;
   const int32_t n_chunks = (n_frames + B - 1) / B;
-  SiftExtractor* ex[2] = {&ctx->sift, &ctx->sift2};
-  // (both chunk streams come from the high-priority class, created back to back: two queues of a pool nothing else in the
-  // process is likely to use -- see create_side_stream; equal priority, so neither chunk starves the other)
-  if (n_chunks > 1 && !ctx->sift_stream2) {
-    HIP_TRY(ctx, create_side_stream(&ctx->sift_stream1, +1));
-    HIP_TRY(ctx, create_side_stream(&ctx->sift_stream2, +1));
+  SiftExtractor* ex[D] = {&ctx->sift, &ctx->sift2, &ctx->sift3};
+  // (the chunk streams come from the high-priority class, created back to back: queues of a pool nothing else in the
+  // process is likely to use -- see create_side_stream; equal priority, so no chunk starves another)
+  if (n_chunks > 1 && !ctx->sift_stream3) {
+    if (!ctx->sift_stream1) HIP_TRY(ctx, create_side_stream(&ctx->sift_stream1, +1));
+    if (!ctx->sift_stream2) HIP_TRY(ctx, create_side_stream(&ctx->sift_stream2, +1));
+    HIP_TRY(ctx, create_side_stream(&ctx->sift_stream3, +1));
   }
-  hipStream_t st[2] = {ctx->sift_stream1 ? ctx->sift_stream1 : ctx->stream, ctx->sift_stream2 ? ctx->sift_stream2 : ctx->stream};
+  hipStream_t st[D] = {ctx->sift_stream1 ? ctx->sift_stream1 : ctx->stream, ctx->sift_stream2 ? ctx->sift_stream2 : ctx->stream,
+                       ctx->sift_stream3 ? ctx->sift_stream3 : ctx->stream};
+  std::vector<SiftKey> keys[D][SiftExtractor::kMaxBatch];
+  const float* desc[D][SiftExtractor::kMaxBatch];
   auto count_of = [&](int32_t c) { return std::min<int32_t>(B, n_frames - c * B); };
-  auto begin = [&](int32_t c) {
-    return ex[c & 1]->begin_batch(gray + (size_t)c * B, count_of(c), rows, cols, st[c & 1], err);
-  };
-  for (int32_t c = 0; c < std::min<int32_t>(2, n_chunks); ++c) {
-    const int rc = begin(c);
-    if (rc != RGBDFE_OK) { if (c) (void)hipStreamSynchronize(st[0]); return fail(ctx, rc, err); }
-  }
-  for (int32_t c = 0; c < n_chunks; ++c) {
+  auto drain = [&]() { for (int i = 0; i < D; ++i) (void)hipStreamSynchronize(st[i]); };
+  auto copy_out = [&](int32_t c) {
     const int32_t f0 = c * B;
     const int nf = count_of(c);
-    const int rc = ex[c & 1]->finish_batch(max_keypoints, keys, desc, st[c & 1], err);
-    if (rc != RGBDFE_OK) { (void)hipStreamSynchronize(st[(c + 1) & 1]); return fail(ctx, rc, err); }
-    if (c + 2 < n_chunks) {   // (keys / desc of chunk c live in host memory begin_batch does not touch)
-      const int rcb = begin(c + 2);
-      if (rcb != RGBDFE_OK) { (void)hipStreamSynchronize(st[(c + 1) & 1]); return fail(ctx, rcb, err); }
-    }
     for (int k = 0; k < nf; ++k) {
+      const std::vector<SiftKey>& K = keys[c % D][k];
       const int32_t f = f0 + k;
-      n_out[f] = (int32_t)keys[k].size();
-      if ((int32_t)keys[k].size() > out_stride) { overflow = true; continue; }
+      n_out[f] = (int32_t)K.size();
+      if ((int32_t)K.size() > out_stride) { overflow = true; continue; }
       rgbdfe_keypoint* kp = keypoints + (size_t)f * out_stride;
-      for (size_t i = 0; i < keys[k].size(); ++i) {
-        kp[i].x = keys[k][i].x;
-        kp[i].y = keys[k][i].y;
-        kp[i].size = (float)(12.0 * keys[k][i].s);
-        kp[i].angle = (float)(keys[k][i].o * 180.0 / 3.1415927);
+      for (size_t i = 0; i < K.size(); ++i) {
+        kp[i].x = K[i].x;
+        kp[i].y = K[i].y;
+        kp[i].size = (float)(12.0 * K[i].s);
+        kp[i].angle = (float)(K[i].o * 180.0 / 3.1415927);
         kp[i].response = 0.f;
         kp[i].octave = 0;
       }
-      if (!keys[k].empty()) memcpy(desc128 + (size_t)f * out_stride * 128, desc[k], keys[k].size() * 128 * sizeof(float));
+      if (!K.empty()) memcpy(desc128 + (size_t)f * out_stride * 128, desc[c % D][k], K.size() * 128 * sizeof(float));
     }
+  };
+#define SIFT_STEP(expr)                                       \
+  do {                                                        \
+    const int rc_ = (expr);                                   \
+    if (rc_ != RGBDFE_OK) { drain(); return fail(ctx, rc_, err); } \
+  } while (0)
+  for (int32_t c = 0; c < std::min<int32_t>(2, n_chunks); ++c)
+    SIFT_STEP(ex[c % D]->begin_batch(gray + (size_t)c * B, count_of(c), rows, cols, st[c % D], err));
+  if (n_chunks > 0) SIFT_STEP(ex[0]->finish_orientations(max_keypoints, st[0], err));
+  for (int32_t c = 0; c < n_chunks; ++c) {
+    SIFT_STEP(ex[c % D]->finish_descriptors(st[c % D], err));
+    if (c + 2 < n_chunks)
+      SIFT_STEP(ex[(c + 2) % D]->begin_batch(gray + (size_t)(c + 2) * B, count_of(c + 2), rows, cols, st[(c + 2) % D], err));
+    if (c >= 1) copy_out(c - 1);
+    if (c + 1 < n_chunks) SIFT_STEP(ex[(c + 1) % D]->finish_orientations(max_keypoints, st[(c + 1) % D], err));
+    SIFT_STEP(ex[c % D]->finish_outputs(keys[c % D], desc[c % D], st[c % D], err));
   }
+  if (n_chunks > 0) copy_out(n_chunks - 1);
+#undef SIFT_STEP
   if (overflow) return fail(ctx, RGBDFE_ERR_CAPACITY, "more SIFT features in a frame than out_stride rows");
   return RGBDFE_OK;
 }

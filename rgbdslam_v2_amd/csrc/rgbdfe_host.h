@@ -280,8 +280,8 @@ struct rgbdfe_ctx {
   OrbWorkspace orb;
   OrbWorkspace orb_super;  // rgbdfe_detect_describe_batch: up to 7 frames per launch chain (its own image sets)
   std::unique_ptr<TaskPool> detect_pool, stage_pool;  // its worker threads (created by the first batch call, kept)
-  SiftExtractor sift2;          // rgbdfe_sift_detect_batch alternates between two extractors (two chunks in flight)
-  hipStream_t sift_stream1 = nullptr, sift_stream2 = nullptr;
+  SiftExtractor sift2, sift3;   // rgbdfe_sift_detect_batch rotates over three extractors (three chunks in flight)
+  hipStream_t sift_stream1 = nullptr, sift_stream2 = nullptr, sift_stream3 = nullptr;
   SiftExtractor sift;  // rgbdfe_sift_detect (sift_extract.hip)
   int orb_max_keypoints = 0;  // 0 = detector not configured yet
   std::unordered_map<int32_t, NodeEntry> nodes;

@@ -28,6 +28,17 @@ struct SiftExtractor {
                 const float** desc, hipStream_t s, std::string& err);
   int begin_batch(const uint8_t* const* gray, int nf, int rows, int cols, hipStream_t s, std::string& err);
   int finish_batch(int max_features, std::vector<SiftKey>* keys, const float** desc, hipStream_t s, std::string& err);
+  // finish_batch in its three wait-work-enqueue steps (sift_extract.hip)
+  int finish_orientations(int max_features, hipStream_t s, std::string& err);
+  int finish_descriptors(hipStream_t s, std::string& err);
+  int finish_outputs(std::vector<SiftKey>* keys, const float** desc, hipStream_t s, std::string& err);
+  struct FrameState {   // a frame of the batch between those steps
+    std::vector<int> cnt, off, level_num;
+    int feature_num = 0, total = 0, base = 0, erased = 0;
+    std::vector<float> list, keybuf;
+  };
+  std::vector<FrameState> fs;
+  int fin_nf = 0, fin_stage = 0, fin_max_features = 0, fin_grand = 0, fin_grand2 = 0;
   int pending_nf = 0;   // frames of the batch begin_batch enqueued and finish_batch has not collected yet
   int enqueue_begin(int nf, hipStream_t s, std::string& err);
   hipGraph_t begin_graph[kMaxBatch + 1] = {};          // begin_batch's launch chain per batch size, captured on first use

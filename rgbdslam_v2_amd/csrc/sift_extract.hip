@@ -480,22 +480,31 @@ int SiftExtractor::enqueue_begin(int nf, hipStream_t s, std::string& err) {
 }
 
 int SiftExtractor::finish_batch(int max_features, std::vector<SiftKey>* keys, const float** desc, hipStream_t s, std::string& err) {
+  int rc = finish_orientations(max_features, s, err);
+  if (rc == RGBDFE_OK) rc = finish_descriptors(s, err);
+  return rc == RGBDFE_OK ? finish_outputs(keys, desc, s, err) : rc;
+}
+
+// The data-dependent half of a batch in three steps, each of which WAITS for what the step before enqueued, works on the
+// host and enqueues the next launch -- so that a caller with two batches in flight can put the other batch's host work
+// (and the copy of finished results) between them instead of sitting in a wait (rgbdfe_sift_detect_batch, api_detect.hip):
+//   finish_orientations  waits for begin_batch's half; feature-count limits; enqueues the orientation launch + its download
+//   finish_descriptors   waits for that; one feature per orientation, limits again; enqueues the descriptor launch + download
+//   finish_outputs       waits for that; keys[f] / desc[f] of every frame
+int SiftExtractor::finish_orientations(int max_features_in, hipStream_t s, std::string& err) {
   const int nf = pending_nf;
   if (nf < 1) { err = "finish_batch without begin_batch"; return RGBDFE_ERR_INVALID_ARG; }
   pending_nf = 0;
-  for (int f = 0; f < nf; ++f) { keys[f].clear(); desc[f] = nullptr; }
+  fin_nf = nf; fin_stage = 1; fin_max_features = max_features_in;
+  fin_grand = fin_grand2 = 0;
+  const int max_features = max_features_in;
   const int nlv = octave_num * kDogLevels;
   const unsigned NF = (unsigned)nf;
   SIFT_HIP(hipStreamSynchronize(s));
   // ---- per frame: which levels run -- GenerateFeatureList's "-tc2" order (coarse octaves first, PyramidCU.cpp:797-850) and
   //      SiftPyramid::LimitFeatureCount(0) (SiftPyramid.cpp:170-210, _TruncateMethod = 1).  A skipped level contributes
   //      nothing (the reference leaves the previous frame's list in it: DESIGN.md 4.11) ---------------------------------
-  struct FrameState {
-    std::vector<int> cnt, off, level_num;
-    int feature_num = 0, total = 0, base = 0, erased = 0;
-    std::vector<float> list, keybuf;
-  };
-  std::vector<FrameState> fs((size_t)nf);
+  fs.assign((size_t)nf, FrameState{});
   auto limit = [&](FrameState& F) {
     if (max_features <= 0) return 0;
     int i = 0, erased = 0;
@@ -545,7 +554,7 @@ int SiftExtractor::finish_batch(int max_features, std::vector<SiftKey>* keys, co
   }
   lvl_count = fs[0].cnt;
   lvl_off = fs[0].off;
-  if (grand == 0) return RGBDFE_OK;
+  if (grand == 0) return RGBDFE_OK;   // (fin_grand stays 0: the later steps have nothing to wait for)
   if ((size_t)grand * 4 > stage_floats) { err = "SIFT staging buffer too small"; return RGBDFE_ERR_CAPACITY; }
   const float sigma_step = powf(2.0f, 1.0f / kDogLevels);
   SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
@@ -553,6 +562,28 @@ int SiftExtractor::finish_batch(int max_features, std::vector<SiftKey>* keys, co
                      sigma_step, 1.5f, 1.5f * 2.0f);
   SIFT_HIP(hipGetLastError());
   SIFT_HIP(hipMemcpyAsync(h_stage, d_feat, (size_t)grand * 16, hipMemcpyDeviceToHost, s));
+  fin_grand = grand;
+  return RGBDFE_OK;
+}
+
+int SiftExtractor::finish_descriptors(hipStream_t s, std::string& err) {
+  if (fin_stage != 1) { err = "finish_descriptors out of order"; return RGBDFE_ERR_INVALID_ARG; }
+  fin_stage = 2;
+  if (fin_grand == 0) return RGBDFE_OK;
+  const int nf = fin_nf, max_features = fin_max_features;
+  const int nlv = octave_num * kDogLevels;
+  const unsigned NF = (unsigned)nf;
+  LevelJobs* hj = static_cast<LevelJobs*>(h_jobs);
+  auto limit = [&](FrameState& F) {
+    if (max_features <= 0) return 0;
+    int i = 0, erased = 0;
+    while (i < nlv && F.feature_num - F.level_num[(size_t)i] > max_features) {
+      erased += F.level_num[(size_t)i];
+      F.feature_num -= F.level_num[(size_t)i];
+      F.level_num[(size_t)i++] = 0;
+    }
+    return erased;
+  };
   SIFT_HIP(hipStreamSynchronize(s));
   // ---- ReshapeFeatureListCPU (PyramidCU.cpp:501-585, NO_DUPLICATE_DOWNLOAD) + LimitFeatureCount(1), per frame ------------------
   const double twopi = 2.0 * 3.14159265358979323846;
@@ -641,6 +672,16 @@ int SiftExtractor::finish_batch(int max_features, std::vector<SiftKey>* keys, co
     h_desc_cap = (size_t)grand2 * 128 * 2;
   }
   SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)grand2 * 128 * 4, hipMemcpyDeviceToHost, s));
+  fin_grand2 = grand2;
+  return RGBDFE_OK;
+}
+
+int SiftExtractor::finish_outputs(std::vector<SiftKey>* keys, const float** desc, hipStream_t s, std::string& err) {
+  if (fin_stage != 2) { err = "finish_outputs out of order"; return RGBDFE_ERR_INVALID_ARG; }
+  fin_stage = 0;
+  const int nf = fin_nf;
+  for (int f = 0; f < nf; ++f) { keys[f].clear(); desc[f] = nullptr; }
+  if (fin_grand2 == 0) return RGBDFE_OK;
   SIFT_HIP(hipStreamSynchronize(s));
   for (int f = 0; f < nf; ++f) {
     const FrameState& F = fs[(size_t)f];
