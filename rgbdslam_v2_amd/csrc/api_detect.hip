@@ -1,5 +1,7 @@
 // api_detect.hip -- the feature path: ORB detect / describe (single calls, super-frames), SIFT extraction
 // (one of the host-side translation units of librgbdfe.so; shared declarations: rgbdfe_host.h)
+#include <chrono>
+
 #include "rgbdfe_host.h"
 
 namespace impl {
@@ -209,24 +211,36 @@ int rgbdfe_sift_detect_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* c
       if (!K.empty()) memcpy(desc128 + (size_t)f * out_stride * 128, desc[c % D][k], K.size() * 128 * sizeof(float));
     }
   };
-#define SIFT_STEP(expr)                                       \
+  // RGBDFE_SIFT_TIMING=1: the calling thread's time per step, summed over the call, on stderr (how the order above was found)
+  static const bool timing = getenv("RGBDFE_SIFT_TIMING") && atoi(getenv("RGBDFE_SIFT_TIMING")) != 0;
+  double t_step[5] = {0, 0, 0, 0, 0};   // begin, orientations, descriptors, outputs, copy-out
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_call = timing ? now() : 0;
+  const double stage0 = ctx->sift.stage_us + ctx->sift2.stage_us + ctx->sift3.stage_us;
+#define SIFT_STEP(slot, expr)                                 \
   do {                                                        \
+    const double t0_ = timing ? now() : 0;                    \
     const int rc_ = (expr);                                   \
+    if (timing) t_step[slot] += now() - t0_;                  \
     if (rc_ != RGBDFE_OK) { drain(); return fail(ctx, rc_, err); } \
   } while (0)
   for (int32_t c = 0; c < std::min<int32_t>(2, n_chunks); ++c)
-    SIFT_STEP(ex[c % D]->begin_batch(gray + (size_t)c * B, count_of(c), rows, cols, st[c % D], err));
-  if (n_chunks > 0) SIFT_STEP(ex[0]->finish_orientations(max_keypoints, st[0], err));
+    SIFT_STEP(0, ex[c % D]->begin_batch(gray + (size_t)c * B, count_of(c), rows, cols, st[c % D], err));
+  if (n_chunks > 0) SIFT_STEP(1, ex[0]->finish_orientations(max_keypoints, st[0], err));
   for (int32_t c = 0; c < n_chunks; ++c) {
-    SIFT_STEP(ex[c % D]->finish_descriptors(st[c % D], err));
+    SIFT_STEP(2, ex[c % D]->finish_descriptors(st[c % D], err));
     if (c + 2 < n_chunks)
-      SIFT_STEP(ex[(c + 2) % D]->begin_batch(gray + (size_t)(c + 2) * B, count_of(c + 2), rows, cols, st[(c + 2) % D], err));
-    if (c >= 1) copy_out(c - 1);
-    if (c + 1 < n_chunks) SIFT_STEP(ex[(c + 1) % D]->finish_orientations(max_keypoints, st[(c + 1) % D], err));
-    SIFT_STEP(ex[c % D]->finish_outputs(keys[c % D], desc[c % D], st[c % D], err));
+      SIFT_STEP(0, ex[(c + 2) % D]->begin_batch(gray + (size_t)(c + 2) * B, count_of(c + 2), rows, cols, st[(c + 2) % D], err));
+    if (c >= 1) { const double t0 = timing ? now() : 0; copy_out(c - 1); if (timing) t_step[4] += now() - t0; }
+    if (c + 1 < n_chunks) SIFT_STEP(1, ex[(c + 1) % D]->finish_orientations(max_keypoints, st[(c + 1) % D], err));
+    SIFT_STEP(3, ex[c % D]->finish_outputs(keys[c % D], desc[c % D], st[c % D], err));
   }
-  if (n_chunks > 0) copy_out(n_chunks - 1);
+  if (n_chunks > 0) { const double t0 = timing ? now() : 0; copy_out(n_chunks - 1); if (timing) t_step[4] += now() - t0; }
 #undef SIFT_STEP
+  if (timing)
+    fprintf(stderr, "sift_detect_batch %d frames: %.0f us; host us in begin %.0f orientations %.0f descriptors %.0f outputs %.0f copy-out %.0f; of begin, image staging %.0f\n",
+            (int)n_frames, now() - t_call, t_step[0], t_step[1], t_step[2], t_step[3], t_step[4],
+            ctx->sift.stage_us + ctx->sift2.stage_us + ctx->sift3.stage_us - stage0);
   if (overflow) return fail(ctx, RGBDFE_ERR_CAPACITY, "more SIFT features in a frame than out_stride rows");
   return RGBDFE_OK;
 }

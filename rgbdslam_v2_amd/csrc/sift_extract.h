@@ -39,6 +39,7 @@ struct SiftExtractor {
   };
   std::vector<FrameState> fs;
   int fin_nf = 0, fin_stage = 0, fin_max_features = 0, fin_grand = 0, fin_grand2 = 0;
+  double stage_us = 0;  // host time spent copying callers' images into the pinned stage (RGBDFE_SIFT_TIMING reports it)
   int pending_nf = 0;   // frames of the batch begin_batch enqueued and finish_batch has not collected yet
   int enqueue_begin(int nf, hipStream_t s, std::string& err);
   hipGraph_t begin_graph[kMaxBatch + 1] = {};          // begin_batch's launch chain per batch size, captured on first use

@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "rgbdfe_internal.h"
 #include "sift_pyramid_kernels.h"
@@ -57,7 +58,10 @@ __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::
   if (threadIdx.x == 0) lvltot[blockIdx.x] = base;
 }
 
-// one wave per row: the row's extrema in column order -> the level's candidate list (x, y, sign, dx, dy, ds)
+// one wave per row: the row's extrema in column order -> the level's candidate list (x, y, sign, dx, dy, ds).  A lane takes
+// EIGHT neighbouring flag bytes per step (512 columns per step: three steps for the widest plane of a VGA frame, where the
+// byte-per-lane form of rounds 3 - 4 took twenty dependent load + ballot rounds), counts its non-zero bytes, an exclusive
+// wave scan of the counts gives every flagged pixel its rank in the row, and the few lanes that hold one evaluate it.
 __global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
                                                            const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
                                                            const int* __restrict__ rowoff, const int* __restrict__ lvltot,
@@ -72,21 +76,40 @@ __global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::
   const int lvl = row2lvl[grow];
   const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.y);
   const int row = grow - L.row0;
+  const int lane = threadIdx.x;
   int base = rowoff[grow];
   for (int l = 0; l < lvl; ++l) base += lvltot[l];
-  for (int c0 = 0; c0 < L.w; c0 += 64) {
-    const int col = c0 + (int)threadIdx.x;
-    const bool on = col < L.w && L.flags[(size_t)row * L.w + col] != 0;
-    const uint64_t m = __ballot(on);
-    if (on) {
-      const int rank = base + (int)__popcll(m & (((uint64_t)1 << threadIdx.x) - 1));
+  const int8_t* __restrict__ frow = L.flags + (size_t)row * L.w;   // (w is a multiple of 4: the row starts dword-aligned)
+  for (int c0 = 0; c0 < L.w; c0 += 512) {
+    const int col0 = c0 + lane * 8;
+    uint32_t lo = 0, hi = 0;
+    if (col0 < L.w) lo = *reinterpret_cast<const uint32_t*>(frow + col0);
+    if (col0 + 4 < L.w) hi = *reinterpret_cast<const uint32_t*>(frow + col0 + 4);
+    if (__ballot((lo | hi) != 0) == 0) continue;
+    // non-zero bytes of the eight: bit 8 i + 7 of `nz` set for byte i
+    const uint64_t bytes = ((uint64_t)hi << 32) | lo;
+    const uint64_t nz = (((bytes & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | bytes) & 0x8080808080808080ull;
+    const int mine = (int)__popcll(nz);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    int rank = base + incl - mine;
+    uint64_t todo = nz;
+    while (todo) {
+      const int i = (__ffsll((long long)todo) - 1) >> 3;
+      todo &= todo - 1;
+      const int col = col0 + i;
       if (rank < cand_cap) {
         const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
         float* o = cand + (size_t)rank * 6;
         o[0] = (float)col; o[1] = (float)row; o[2] = e.result; o[3] = e.dx; o[4] = e.dy; o[5] = e.ds;
       }
+      ++rank;
     }
-    base += (int)__popcll(m);
+    base += __shfl(incl, 63);
   }
 }
 
@@ -414,7 +437,9 @@ int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int
   pending_nf = 0;
   int rc = prepare(rows, cols, nf, err);
   if (rc != RGBDFE_OK) return rc;
+  const auto t_in = std::chrono::steady_clock::now();
   for (int f = 0; f < nf; ++f) memcpy(h_gray + (size_t)f * gray_cap, gray[f], gray_cap);
+  stage_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count();
   // Everything this half enqueues -- the frames' upload from the pinned stage, ~55 pyramid launches, the extremum flags, the
   // scan, the ordered emit, the counts' download -- has the same arguments for every batch of nf frames of this size: it is
   // captured ONCE per nf as a hipGraph and replayed with one hipGraphLaunch.  The calling thread spent ~0.3 ms per chunk on
