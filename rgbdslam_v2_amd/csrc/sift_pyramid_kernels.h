@@ -218,122 +218,6 @@ __global__ __launch_bounds__(256) void sift_filter_tile_kernel(const float* __re
   }
 }
 
-// The octaves whose planes FIT LDS (<= kTailPlane floats: 160 x 120 and below -- octaves 3, 4, 5 of a VGA frame), all of them
-// and all their levels in ONE launch: a workgroup of 1024 threads per frame decimates the parent octave's level kDogLevels
-// (SampleImageD), then runs the seven Gaussian levels back to back out of two LDS planes -- A holds the level, the horizontal
-// pass writes B, the vertical pass writes the next level back into A and out to HBM -- and goes on to the next octave.  These
-// planes were 24 launches of 5 us each per chunk, every one waiting for the one before with a few dozen workgroups on 256
-// CUs: 127 us of a chunk's ~1000 us first half and 40 % of its launches; the frames' workgroups now overlap with the
-// large octaves of the other chunks in flight.  Sums as everywhere: taps ascending from 0, products and sums rounded
-// separately, fetches clamped to the plane.
-constexpr int kTailPlane = 19200;
-struct TailTaps { float k[SiftExtractor::kLevels - 1][kMaxTaps]; int fw[SiftExtractor::kLevels - 1]; };
-
-// one level of an LDS-resident plane: A (w x h) -> B horizontally, B -> A and `dst` vertically.  Horizontal: a thread keeps a
-// column and walks down the rows (lanes along the row: conflict-free reads, one per tap); vertical: a work item is a run of 8
-// rows of one column, its 8 + 2R inputs streaming through one register.  FW is a template parameter so that the tap loops
-// unroll and the level's taps sit in scalar registers.
-template <int FW>
-__device__ __forceinline__ void tail_level(float* __restrict__ A, float* __restrict__ B, float* dst, int w, int h, const float* k,
-                                           int tid) {
-  constexpr int R = FW >> 1, RV = 8;
-  float kk[FW];
-#pragma unroll
-  for (int t = 0; t < FW; ++t) kk[t] = k[t];
-  const int rows_per_pass = 1024 / w;
-  const int r0 = tid / w, c = tid - r0 * w;
-  if (r0 < rows_per_pass) {
-    int xs[FW];
-#pragma unroll
-    for (int t = 0; t < FW; ++t) {
-      const int x = c - R + t;
-      xs[t] = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-    }
-    for (int r = r0; r < h; r += rows_per_pass) {
-      const float* __restrict__ row = A + r * w;
-      float value = 0.f;
-#pragma unroll
-      for (int t = 0; t < FW; ++t) value += row[xs[t]] * kk[t];
-      B[r * w + c] = value;
-    }
-  }
-  __syncthreads();
-  const int runs = (h + RV - 1) / RV;
-  for (int it = tid; it < runs * w; it += 1024) {
-    const int run = it / w, cc = it - run * w, y0 = run * RV;
-    float acc[RV];
-#pragma unroll
-    for (int o = 0; o < RV; ++o) acc[o] = 0.f;
-#pragma unroll
-    for (int j = 0; j < RV + 2 * R; ++j) {
-      int y = y0 - R + j;
-      y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-      const float v = B[y * w + cc];
-#pragma unroll
-      for (int o = 0; o < RV; ++o)
-        if (j - o >= 0 && j - o < FW) acc[o] += v * kk[j - o];
-    }
-#pragma unroll
-    for (int o = 0; o < RV; ++o)
-      if (y0 + o < h) {
-        A[(y0 + o) * w + cc] = acc[o];
-        dst[(y0 + o) * w + cc] = acc[o];
-      }
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(1024) void sift_octave_tail_kernel(float* __restrict__ planes,
-                                                                const SiftExtractor::OctDesc* __restrict__ octs, int first_oct,
-                                                                int n_oct, TailTaps taps, size_t frame_stride) {
-  HIP_DYNAMIC_SHARED(float, tail_lds)   // A | B: 2 x kTailPlane floats
-  float* __restrict__ A = tail_lds;
-  float* __restrict__ B = tail_lds + kTailPlane;
-  planes += (size_t)blockIdx.x * frame_stride;
-  const int tid = threadIdx.x;
-  for (int o = first_oct; o < first_oct + n_oct; ++o) {
-    const SiftExtractor::OctDesc O = octs[o], P = octs[o - 1];
-    const int w = O.w, h = O.h;
-    const size_t plane = (size_t)w * h;
-    float* g = planes + O.plane_off;
-    {  // level 0 = every second pixel of every second row of the parent's level kDogLevels (this workgroup wrote it, if the
-       // parent is a tail octave too: the barrier at the end of its last level ordered those stores)
-      const float* src = planes + P.plane_off + (size_t)P.w * P.h * SiftExtractor::kDogLevels;
-      const int rows_per_pass = 1024 / w;
-      const int r0 = tid / w, c = tid - r0 * w;
-      const int sc = min(c << 1, P.w - 1);
-      if (r0 < rows_per_pass)
-        for (int r = r0; r < h; r += rows_per_pass) {
-          const float v = src[(size_t)(r << 1) * P.w + sc];
-          A[r * w + c] = v;
-          g[r * w + c] = v;
-        }
-    }
-    __syncthreads();
-    for (int l = 1; l < SiftExtractor::kLevels; ++l) {
-      float* dst = g + plane * l;
-      const float* k = taps.k[l - 1];
-      switch (taps.fw[l - 1]) {   // the widths ProgramCU::FilterImage serves (ProgramCU.cu:430-448)
-        case 5: tail_level<5>(A, B, dst, w, h, k, tid); break;
-        case 7: tail_level<7>(A, B, dst, w, h, k, tid); break;
-        case 9: tail_level<9>(A, B, dst, w, h, k, tid); break;
-        case 11: tail_level<11>(A, B, dst, w, h, k, tid); break;
-        case 13: tail_level<13>(A, B, dst, w, h, k, tid); break;
-        case 15: tail_level<15>(A, B, dst, w, h, k, tid); break;
-        case 17: tail_level<17>(A, B, dst, w, h, k, tid); break;
-        case 19: tail_level<19>(A, B, dst, w, h, k, tid); break;
-        case 21: tail_level<21>(A, B, dst, w, h, k, tid); break;
-        case 23: tail_level<23>(A, B, dst, w, h, k, tid); break;
-        case 25: tail_level<25>(A, B, dst, w, h, k, tid); break;
-        case 27: tail_level<27>(A, B, dst, w, h, k, tid); break;
-        case 29: tail_level<29>(A, B, dst, w, h, k, tid); break;
-        case 31: tail_level<31>(A, B, dst, w, h, k, tid); break;
-        default: tail_level<33>(A, B, dst, w, h, k, tid); break;
-      }
-    }
-  }
-}
-
 struct FilterArgs { const float* src; float* dst; int w, h, nf; size_t src_stride, dst_stride; };
 // which kernel a level's launch takes: 0 = 16 x 16 tiles, 1 = 64 x 16, 2 = 64 x 32 (register-window kernel), 3 = 64 x 64
 inline int filter_tile_choice(int w, int h, int nf) {
@@ -644,13 +528,7 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
   auto filter = [&](const float* src, size_t src_stride, float* dst, int w, int h, float sg) {
     launch_filter_any(FilterArgs{src, dst, w, h, nf, src_stride, planes_floats}, make_taps(sg), s, filter_choice);
   };
-  // the octaves from `tail` on fit LDS: one launch for all of them (sift_octave_tail_kernel); RGBDFE_SIFT_TAIL=0: per-level
-  // launches everywhere (the A/B switch)
-  static const bool tail_env = !(getenv("RGBDFE_SIFT_TAIL") && atoi(getenv("RGBDFE_SIFT_TAIL")) == 0);
-  int tail = E.octave_num;
-  if (tail_env)
-    while (tail > 1 && E.oct[tail - 1].plane <= (size_t)kTailPlane && E.oct[tail - 1].w <= 1024) --tail;
-  for (int i = 0; i < tail; ++i) {
+  for (int i = 0; i < E.octave_num; ++i) {
     const SiftExtractor::Octave& o = E.oct[i];
     if (i == 0) {
       const float sg = E.initial_smooth_sigma(E.octave_min);
@@ -667,20 +545,6 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
                          o.g[0], planes_floats);
     }
     for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, E.sigma[l - 1]);
-  }
-  if (tail < E.octave_num) {
-    TailTaps tt{};
-    for (int l = 1; l < kLevels; ++l) {
-      const Taps t = make_taps(E.sigma[l - 1]);
-      tt.fw[l - 1] = t.fw;
-      for (int j = 0; j < kMaxTaps; ++j) tt.k[l - 1][j] = t.k[j];
-    }
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sift_octave_tail_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   2 * kTailPlane * (int)sizeof(float)) == hipSuccess;
-    (void)lds_ok;
-    hipLaunchKernelGGL(sift_octave_tail_kernel, dim3(NF), dim3(1024), 2 * kTailPlane * sizeof(float), s, E.d_planes,
-                       static_cast<const SiftExtractor::OctDesc*>(E.d_octs), tail, E.octave_num - tail, tt, planes_floats);
   }
 }
 

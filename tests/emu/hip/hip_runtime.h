@@ -47,11 +47,6 @@ extern dim3 blockDim, gridDim;
 #define __shared__ static
 #define __launch_bounds__(...)
 #define HIP_SYMBOL(x) (&(x))
-// dynamic LDS: one buffer for the library (workgroups run one after the other); the launch macro ignores its size argument
-extern float hipemu_dynamic_lds[];
-#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu_dynamic_lds);
-enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipMemcpyToSymbol(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return hipSuccess; }
 
 // the overloads device code gets from the HIP headers
