@@ -45,6 +45,9 @@ struct SiftExtractor {
   hipGraph_t begin_graph[kMaxBatch + 1] = {};          // begin_batch's launch chain per batch size, captured on first use
   hipGraphExec_t begin_exec[kMaxBatch + 1] = {};
   bool begin_capture_failed = false;
+  // levels 6, 7 of an octave (needed by the extremum launch only) run on a side stream beside the next octave's chain
+  hipStream_t side_stream = nullptr;
+  hipEvent_t fork_event[kMaxOctaves] = {}, join_event = nullptr;
   int run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys, const float*& desc,
           hipStream_t s, std::string& err) {
     return run_batch(&gray, 1, rows, cols, max_features, &keys, &desc, s, err);
@@ -77,7 +80,10 @@ struct SiftExtractor {
   LevelDesc* d_levels = nullptr;
   std::vector<LevelDesc> h_levels;
   std::vector<int> h_row2lvl;                          // level (octave * kDogLevels + dog level) of every stacked row
-  static constexpr int kKeyTileH = 16;
+#ifndef RGBDFE_KEY_TILE_H
+#define RGBDFE_KEY_TILE_H 8    // rows per extremum tile, a multiple of 4 (measured: 4 -> 224, 8 -> 193, 12 -> 205, 16 -> 236 us per 8 VGA frames)
+#endif
+  static constexpr int kKeyTileH = RGBDFE_KEY_TILE_H;
   struct KeyTile { int oct, x0, y0; };                 // a 64 x kKeyTileH pixel tile of an octave
   std::vector<KeyTile> h_key_tiles;
   struct OctDesc { size_t plane_off, flag_off; int w, h, row0, pad; };   // an octave inside a frame's planes / flags / rows

@@ -525,9 +525,11 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
   float* d_up = E.d_up;
   const size_t planes_floats = E.planes_floats, input_floats = E.input_floats;
   hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256, NF), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
+  hipStream_t cur = s;
   auto filter = [&](const float* src, size_t src_stride, float* dst, int w, int h, float sg) {
-    launch_filter_any(FilterArgs{src, dst, w, h, nf, src_stride, planes_floats}, make_taps(sg), s, filter_choice);
+    launch_filter_any(FilterArgs{src, dst, w, h, nf, src_stride, planes_floats}, make_taps(sg), cur, filter_choice);
   };
+  const bool fork = E.side_stream != nullptr && E.octave_num > 1;
   for (int i = 0; i < E.octave_num; ++i) {
     const SiftExtractor::Octave& o = E.oct[i];
     if (i == 0) {
@@ -544,7 +546,18 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
       hipLaunchKernelGGL(sift_downsample2_kernel, dim3((o.w + 127) / 128, o.h, NF), dim3(128), 0, s, p.g[kDogLevels], p.w, o.w, o.h,
                          o.g[0], planes_floats);
     }
-    for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, E.sigma[l - 1]);
+    for (int l = 1; l <= kDogLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, E.sigma[l - 1]);
+    if (fork && i + 1 < E.octave_num) {   // (the last octave has nothing to run beside: it stays on the caller's stream)
+      (void)hipEventRecord(E.fork_event[i], s);
+      (void)hipStreamWaitEvent(E.side_stream, E.fork_event[i], 0);
+      cur = E.side_stream;
+    }
+    for (int l = kDogLevels + 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, E.sigma[l - 1]);
+    cur = s;
+  }
+  if (fork) {
+    (void)hipEventRecord(E.join_event, E.side_stream);
+    (void)hipStreamWaitEvent(s, E.join_event, 0);
   }
 }
 
