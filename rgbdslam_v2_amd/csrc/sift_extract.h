@@ -45,9 +45,6 @@ struct SiftExtractor {
   hipGraph_t begin_graph[kMaxBatch + 1] = {};          // begin_batch's launch chain per batch size, captured on first use
   hipGraphExec_t begin_exec[kMaxBatch + 1] = {};
   bool begin_capture_failed = false;
-  // levels 6, 7 of an octave (needed by the extremum launch only) run on a side stream beside the next octave's chain
-  hipStream_t side_stream = nullptr;
-  hipEvent_t fork_event[kMaxOctaves] = {}, join_event = nullptr;
   int run(const uint8_t* gray, int rows, int cols, int max_features, std::vector<SiftKey>& keys, const float*& desc,
           hipStream_t s, std::string& err) {
     return run_batch(&gray, 1, rows, cols, max_features, &keys, &desc, s, err);

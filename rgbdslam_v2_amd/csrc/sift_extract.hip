@@ -344,11 +344,6 @@ void SiftExtractor::release() {
     begin_exec[i] = nullptr; begin_graph[i] = nullptr;
   }
   begin_capture_failed = false;
-  if (side_stream) (void)hipStreamDestroy(side_stream);
-  side_stream = nullptr;
-  for (int i = 0; i < kMaxOctaves; ++i) { if (fork_event[i]) (void)hipEventDestroy(fork_event[i]); fork_event[i] = nullptr; }
-  if (join_event) (void)hipEventDestroy(join_event);
-  join_event = nullptr;
   if (d_gray) (void)hipFree(d_gray);
   if (d_input) (void)hipFree(d_input);
   if (d_up) (void)hipFree(d_up);
@@ -394,12 +389,6 @@ int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
   SIFT_HIP(hipMalloc((void**)&d_rowcnt, sizeof(int) * ((size_t)total_rows * (2 * F + 1) + 64 * F)));
   d_rowoff = d_rowcnt + (size_t)total_rows * F;
   d_lvltot = d_rowcnt + (size_t)total_rows * (2 * F + 1);
-  static const bool fork_env = !(getenv("RGBDFE_SIFT_FORK") && atoi(getenv("RGBDFE_SIFT_FORK")) == 0);   // A/B switch
-  if (fork_env) {
-    SIFT_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-    for (int i = 0; i < octave_num; ++i) SIFT_HIP(hipEventCreateWithFlags(&fork_event[i], hipEventDisableTiming));
-    SIFT_HIP(hipEventCreateWithFlags(&join_event, hipEventDisableTiming));
-  }
   bind_levels();
   SIFT_HIP(hipMalloc((void**)&d_levels, sizeof(LevelDesc) * h_levels.size()));
   SIFT_HIP(hipMemcpy(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice));

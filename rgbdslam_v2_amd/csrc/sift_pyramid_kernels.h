@@ -516,6 +516,13 @@ Taps make_taps(float sigma) {
 // BuildPyramid (PyramidCU.cpp:946-998) for the nf frames whose bytes lie in E.d_gray: the launch chain, nothing else (the
 // extractor's enqueue_pyramid and the CPU emulation of tests/emu/emu_sift.cpp both run THIS).  filter_choice: the tile shape
 // of every level's launch (filter_tile_choice's codes), -1 = by plane size.
+// Two ways to shorten this chain of 56 dependent launches were built and measured in round 5, and dropped:
+//   * the octaves that fit LDS (3, 4, 5 of a VGA frame) whole in one launch, a 1024-thread workgroup per frame: 33 launches
+//     and the same planes, but 133 us against the 127 us of the 24 launches it replaced, single calls 10 % slower
+//     (profiles/r05_logs/sift_octave_tail.txt);
+//   * levels 6, 7 of each octave -- only the extremum launch reads them -- on a side stream beside the next octave's chain,
+//     40 dependent launches: as plain launches no change (6989 vs 7132 frames/s through the batch entry point), as a captured
+//     graph with those edges 4850 -- multi-branch graphs replay slowly on this runtime.
 inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int filter_choice = -1) {
   constexpr int kLevels = SiftExtractor::kLevels, kDogLevels = SiftExtractor::kDogLevels;
   const int rows = E.H, cols = E.W, w4 = E.w4;
@@ -525,11 +532,9 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
   float* d_up = E.d_up;
   const size_t planes_floats = E.planes_floats, input_floats = E.input_floats;
   hipLaunchKernelGGL(sift_convert_kernel, dim3((w4 * rows + 255) / 256, NF), dim3(256), 0, s, d_gray, cols, w4, rows, d_input);
-  hipStream_t cur = s;
   auto filter = [&](const float* src, size_t src_stride, float* dst, int w, int h, float sg) {
-    launch_filter_any(FilterArgs{src, dst, w, h, nf, src_stride, planes_floats}, make_taps(sg), cur, filter_choice);
+    launch_filter_any(FilterArgs{src, dst, w, h, nf, src_stride, planes_floats}, make_taps(sg), s, filter_choice);
   };
-  const bool fork = E.side_stream != nullptr && E.octave_num > 1;
   for (int i = 0; i < E.octave_num; ++i) {
     const SiftExtractor::Octave& o = E.oct[i];
     if (i == 0) {
@@ -546,18 +551,7 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
       hipLaunchKernelGGL(sift_downsample2_kernel, dim3((o.w + 127) / 128, o.h, NF), dim3(128), 0, s, p.g[kDogLevels], p.w, o.w, o.h,
                          o.g[0], planes_floats);
     }
-    for (int l = 1; l <= kDogLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, E.sigma[l - 1]);
-    if (fork && i + 1 < E.octave_num) {   // (the last octave has nothing to run beside: it stays on the caller's stream)
-      (void)hipEventRecord(E.fork_event[i], s);
-      (void)hipStreamWaitEvent(E.side_stream, E.fork_event[i], 0);
-      cur = E.side_stream;
-    }
-    for (int l = kDogLevels + 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, E.sigma[l - 1]);
-    cur = s;
-  }
-  if (fork) {
-    (void)hipEventRecord(E.join_event, E.side_stream);
-    (void)hipStreamWaitEvent(s, E.join_event, 0);
+    for (int l = 1; l < kLevels; ++l) filter(o.g[l - 1], planes_floats, o.g[l], o.w, o.h, E.sigma[l - 1]);
   }
 }
 

@@ -47,8 +47,6 @@ extern dim3 blockDim, gridDim;
 #define __shared__ static
 #define __launch_bounds__(...)
 #define HIP_SYMBOL(x) (&(x))
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipMemcpyToSymbol(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return hipSuccess; }
 
 // the overloads device code gets from the HIP headers
