@@ -1,0 +1,75 @@
+"""GPU: the SIFT batch entry point beside itself.  rgbdfe_sift_detect_batch captures the first half of a chunk as a hipGraph
+on first use (relaxed capture on the chunk's own stream) and keeps three chunks in flight on three streams; here two host
+threads drive two contexts at once -- one of them capturing its graphs while the other is already replaying, allocating and
+waiting -- and a third thread runs ORB pair batches on a third context.  Every result must equal the one the same context
+type produces alone (frames are independent: the pipeline keeps no state between images)."""
+import threading
+
+import numpy as np
+import pytest
+
+from rgbdslam_v2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(seed, n, w=320, h=240):
+    return list(synth.make_image_sequence(n_frames=n, seed=seed, width=w, height=h)["gray"])
+
+
+def test_two_contexts_extract_concurrently_and_equal_their_serial_results():
+    from rgbdslam_v2_amd.frontend import FrontEnd
+    sets = [_frames(101, 19), _frames(202, 27)]
+    ref = []
+    fe = FrontEnd(device_id=0, max_nodes=8, max_keypoints=2048, max_pairs_per_batch=8)
+    try:
+        for fr in sets:
+            ref.append([(k.copy(), d.copy()) for k, d in fe.sift_detect_batch(fr, 700)])
+    finally:
+        fe.close()
+    assert sum(len(k) for k, _ in ref[0]) > 1000
+    errors, got = [], [None, None]
+
+    def extract(i):
+        try:
+            f = FrontEnd(device_id=0, max_nodes=8, max_keypoints=2048, max_pairs_per_batch=8)
+            try:
+                out = None
+                for _ in range(4):   # the first call captures this context's graphs while the other thread is mid-flight
+                    out = [(k.copy(), d.copy()) for k, d in f.sift_detect_batch(sets[i], 700)]
+                    one = f.sift_detect(sets[i][3], None, 700)   # single calls in between: the one-chunk path on ctx->stream
+                    assert one[0].tobytes() == out[3][0].tobytes() and one[1].tobytes() == out[3][1].tobytes()
+                got[i] = out
+            finally:
+                f.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    def pairs():
+        try:
+            seq = synth.make_sequence(n_frames=12, n_kp=600, n_world=2400, seed=5)
+            f = FrontEnd(device_id=0, max_nodes=16, max_keypoints=1024, max_pairs_per_batch=64)
+            try:
+                for i in range(12):
+                    f.upload_node(i, seq["desc"][i], seq["xyz1"][i])
+                q = np.arange(1, 12, dtype=np.int32)
+                t = np.arange(0, 11, dtype=np.int32)
+                first = f.match_pair_list(q, t).tobytes()
+                for _ in range(20):
+                    assert f.match_pair_list(q, t).tobytes() == first
+            finally:
+                f.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(("pairs", repr(e)))
+
+    th = [threading.Thread(target=extract, args=(0,)), threading.Thread(target=extract, args=(1,)), threading.Thread(target=pairs)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=200)
+    assert not any(x.is_alive() for x in th), "a thread did not finish"
+    assert not errors, errors
+    for i in range(2):
+        assert len(got[i]) == len(ref[i])
+        for (ka, da), (kb, db) in zip(got[i], ref[i]):
+            assert ka.tobytes() == kb.tobytes() and da.tobytes() == db.tobytes()
