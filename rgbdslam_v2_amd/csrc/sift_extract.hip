@@ -248,6 +248,19 @@ __global__ __launch_bounds__(64) void sift_orientation_kernel(const LevelJobs* _
 // lies in up to four cells' supports -- and lets the cells read them: bit-identical output, but 43 instead of 37 us per VGA
 // frame.  The window's bounding box holds 1.6 x the pixels the cells' rotated supports cover, and 51 KB of LDS left 12
 // waves per CU for a loop that lives on latency hiding: profiles/r05_logs/sift_descriptor_staged.txt.)
+// the wave's sum of v, valid in lane 63 (rows of 16 by row_shr 1, 2, 4, 8; then row 0 -> 1, 2 -> 3 and 1 -> 2, 3)
+#define SIFT_DPP_F32(x, ctrl, rows, bound) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rows, 0xF, bound))
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += SIFT_DPP_F32(v, 0x111, 0xF, true);    // row_shr:1
+  v += SIFT_DPP_F32(v, 0x112, 0xF, true);    // row_shr:2
+  v += SIFT_DPP_F32(v, 0x114, 0xF, true);    // row_shr:4
+  v += SIFT_DPP_F32(v, 0x118, 0xF, true);    // row_shr:8
+  v += SIFT_DPP_F32(v, 0x142, 0xA, false);   // row_bcast:15 into rows 1 and 3
+  v += SIFT_DPP_F32(v, 0x143, 0xC, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+#undef SIFT_DPP_F32
+
 __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* __restrict__ jobs_of_frame,
                                                               const float4* __restrict__ feat, float4* __restrict__ d_des,
                                                               float window_factor) {
@@ -285,8 +298,10 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* _
 #pragma unroll
   for (int i = 0; i < 9; ++i) des[i] = 0.0f;
   const int total = nx * ny;
+  const float rnx = 1.0f / (float)nx;   // jy = t / nx through the reciprocal: (t + 0.5) / nx is at least 0.5 / nx away from
+                                        // an integer and t, nx < 2^12 here, so the rounding of the product cannot cross one
   for (int t = lane; t < total; t += 64) {
-    const int jy = t / nx, jx = t - jy * nx;
+    const int jy = (int)(((float)t + 0.5f) * rnx), jx = t - jy * nx;
     const float x = xmin + (float)jx, y = ymin + (float)jy;
     const float dx = x - pt.x;
     const float dy = y - pt.y;
@@ -317,10 +332,11 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* _
       }
     }
   }
+  // the lanes' bins -> lane 63: four row_shr steps inside the rows of 16, then the rows' totals across (DPP adds: no LDS
+  // round trip per step, as the xor butterfly of rounds 3 - 4 had -- a fifth of the kernel's instructions).  A fixed order.
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
-    for (int d = 32; d >= 1; d >>= 1) des[i] += __shfl_xor(des[i], d);
-  if (lane != 0) return;
+  for (int i = 0; i < 9; ++i) des[i] = wave_sum_to_lane63(des[i]);
+  if (lane != 63) return;
   des[0] += des[8];
   const int didx = (jobs.base * 16 + idx) << 1;
   d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
