@@ -306,8 +306,11 @@ int rgbdfe_upload_node_keypoints(rgbdfe_ctx* ctx, int32_t node_id, const float* 
   }
   for (auto& ln : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(ln.stream));  // batches in flight may read the slot
   if (n > 0)
-    HIP_TRY(ctx, hipMemcpy(ctx->d_kp2d + (size_t)it->second.slot * (size_t)ctx->cfg.max_keypoints * 2, kp_xy,
-                           (size_t)n * 8, hipMemcpyHostToDevice));
+  {   // (not a NULL-stream copy: refused while another thread of the process has a stream capture open, see orb_host.hip)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_kp2d + (size_t)it->second.slot * (size_t)ctx->cfg.max_keypoints * 2, kp_xy,
+                                (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   it->second.flags |= kNodeHasKeypoints;  // every upload into the slot builds a fresh NodeEntry, i.e. clears it
   return RGBDFE_OK;
 }

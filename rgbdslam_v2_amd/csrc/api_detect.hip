@@ -268,7 +268,7 @@ int rgbdfe_sift_debug_candidates(rgbdfe_ctx* ctx, int32_t octave, int32_t dog_le
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device_id));
   std::vector<float> v;
-  const int rc = ctx->sift.debug_candidates(octave, dog_level, v);
+  const int rc = ctx->sift.debug_candidates(octave, dog_level, v, ctx->stream);
   if (rc != RGBDFE_OK) return fail(ctx, rc, "no such SIFT level");
   *n = (int32_t)(v.size() / 6);
   if (*n > capacity_rows) return fail(ctx, RGBDFE_ERR_CAPACITY, "more candidates than the output holds");

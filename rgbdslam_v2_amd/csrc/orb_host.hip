@@ -12,6 +12,7 @@
 #include "orb_host.h"
 
 #include <chrono>
+#include <functional>
 #include <mutex>
 #include <cstdio>
 #include "orb_pattern.inc"
@@ -94,12 +95,15 @@ double orb_now_us() {
 
 OrbWorkspace::~OrbWorkspace() { release(); }
 
-// Zero-fills of freshly allocated device memory go through a stream of the workspace's own and wait for THAT stream: a
-// NULL-stream hipMemset would need a device-wide synchronisation to be ordered before the context's non-blocking streams,
-// and hipDeviceSynchronize() invalidates a hipGraph capture another thread of the process may have open (api_batches.hip).
-// One stream per device for the whole process (a caller that alternates devices -- the multi-device handle's thread, tests
-// with contexts on several devices -- used to get a new thread-local stream on every switch and leak the old one).
-static hipError_t zero_fill_and_wait(void* p, size_t bytes) {
+// Allocation-time zero-fills and table uploads go through a SETUP STREAM and wait for THAT stream.  Neither may use the NULL
+// stream: a NULL-stream hipMemset would need a device-wide synchronisation to be ordered before the context's non-blocking
+// streams, hipDeviceSynchronize() invalidates a hipGraph capture another thread of the process may have open
+// (api_batches.hip), and a synchronous hipMemcpy / hipMemcpyToSymbol is itself refused with "operation would make the legacy
+// stream depend on a capturing blocking stream" while any other thread is capturing -- which the SIFT batch path now does by
+// default (tests/test_gpu_sift_threads.py found it).  One stream per device for the whole process (a caller that alternates
+// devices -- the multi-device handle's thread, tests with contexts on several devices -- used to get a new thread-local
+// stream on every switch and leak the old one).
+static hipError_t on_setup_stream(const std::function<hipError_t(hipStream_t)>& op) {
   static std::mutex mu;
   static hipStream_t streams[64] = {};
   int dev = 0;
@@ -111,9 +115,16 @@ static hipError_t zero_fill_and_wait(void* p, size_t bytes) {
     e = hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
     if (e != hipSuccess) { streams[dev] = nullptr; return e; }
   }
-  e = hipMemsetAsync(p, 0, bytes, streams[dev]);
+  e = op(streams[dev]);
   return e != hipSuccess ? e : hipStreamSynchronize(streams[dev]);
 }
+static hipError_t zero_fill_and_wait(void* p, size_t bytes) {
+  return on_setup_stream([&](hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); });
+}
+static hipError_t upload_and_wait(void* dst, const void* src, size_t bytes) {
+  return on_setup_stream([&](hipStream_t s) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s); });
+}
+hipError_t orb_setup_stream_run(const std::function<hipError_t(hipStream_t)>& op) { return on_setup_stream(op); }
 
 void OrbWorkspace::release() {
   if (timing.on && timing.frames) {
@@ -291,7 +302,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipMalloc((void**)&d_frame_imgs, sizeof(ImgDesc) * frame_imgs.size()));
   ORB_HIP(hipMalloc((void**)&d_jobs, sizeof(ResizeJob) * jobs.size()));
   ORB_HIP(hipMalloc((void**)&d_units, sizeof(TileUnit) * units.size()));
-  ORB_HIP(hipMemcpy(d_units, units.data(), sizeof(TileUnit) * units.size(), hipMemcpyHostToDevice));
+  ORB_HIP(upload_and_wait(d_units, units.data(), sizeof(TileUnit) * units.size()));
   ORB_HIP(hipMalloc((void**)&d_row_cnt, sizeof(int) * (row_off + 16)));
   ORB_HIP(zero_fill_and_wait(d_row_cnt, sizeof(int) * (row_off + 16)));   // accumulated by atomics, re-zeroed by the row scan
   ORB_HIP(hipMalloc((void**)&d_row_off, sizeof(int) * (row_off + 16)));
@@ -333,9 +344,9 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
   ORB_HIP(hipHostMalloc((void**)&h_n_proj, sizeof(int32_t) * 64, hipHostMallocDefault));
   ORB_HIP(hipHostMalloc((void**)&h_img, (size_t)2 * W * H * n_frames, hipHostMallocDefault));
   himg_set[0] = h_img;
-  ORB_HIP(hipMemcpy(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size(), hipMemcpyHostToDevice));
-  ORB_HIP(hipMemcpy(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size(), hipMemcpyHostToDevice));
-  ORB_HIP(hipMemcpy(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size(), hipMemcpyHostToDevice));   // (synchronous: pageable source)
+  ORB_HIP(upload_and_wait(d_cell_imgs, cell_imgs.data(), sizeof(ImgDesc) * cell_imgs.size()));
+  ORB_HIP(upload_and_wait(d_frame_imgs, frame_imgs.data(), sizeof(ImgDesc) * frame_imgs.size()));
+  ORB_HIP(upload_and_wait(d_jobs, jobs.data(), sizeof(ResizeJob) * jobs.size()));
   {
     const char* pm = getenv("RGBDFE_ORB_PYRAMID");
     fused_pyramid = !(pm && std::string(pm) == "levels");
@@ -349,7 +360,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
     n_pyr_tiles = (int)tiles.size();
     if (n_pyr_tiles) {
       ORB_HIP(hipMalloc((void**)&d_pyr_tiles, sizeof(PyrTile) * tiles.size()));
-      ORB_HIP(hipMemcpy(d_pyr_tiles, tiles.data(), sizeof(PyrTile) * tiles.size(), hipMemcpyHostToDevice));
+      ORB_HIP(upload_and_wait(d_pyr_tiles, tiles.data(), sizeof(PyrTile) * tiles.size()));
     }
   }
   if (!pattern_uploaded) { orb_upload_pattern(kOrbBitPattern31); pattern_uploaded = true; }

@@ -5,6 +5,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <functional>
+
 #include "rgbdfe_internal.h"
 
 namespace rgbdfe {
@@ -120,5 +122,6 @@ void launch_orb_blur_always(const uint8_t* pool, const ImgDesc* imgs, const Tile
 void launch_orb_brief(const uint8_t* pool, const uint8_t* blur_pool, const ImgDesc* imgs, const DescKp* kps, int n,
                       uint8_t* desc, hipStream_t s);
 void orb_upload_pattern(const int8_t* host_pattern);
+hipError_t orb_setup_stream_run(const std::function<hipError_t(hipStream_t)>& op);   // orb_host.hip: op on the setup stream, then wait
 
 }  // namespace rgbdfe

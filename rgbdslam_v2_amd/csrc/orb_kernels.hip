@@ -628,8 +628,10 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------------------
 __constant__ int8_t c_pattern[1024];
 
-void orb_upload_pattern(const int8_t* host_pattern) {
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), host_pattern, 1024);
+void orb_upload_pattern(const int8_t* host_pattern) {   // (on the setup stream: see on_setup_stream, orb_host.hip)
+  (void)orb_setup_stream_run([&](hipStream_t s) {
+    return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pattern), host_pattern, 1024, 0, hipMemcpyHostToDevice, s);
+  });
 }
 
 __global__ __launch_bounds__(256) void orb_brief_kernel(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ blur_pool,

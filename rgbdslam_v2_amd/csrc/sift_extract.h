@@ -56,7 +56,7 @@ struct SiftExtractor {
   // stage access for the parity tests: a Gaussian plane of the latest call's FIRST frame / the keypoint candidates of one
   // (octave, dog level) of that frame as (x, y, sign, dx, dy, ds) in list order, before the feature-count limits
   int debug_plane(int octave, int level, std::vector<float>& out, int* w, int* h, hipStream_t s);
-  int debug_candidates(int octave, int dog_level, std::vector<float>& out);
+  int debug_candidates(int octave, int dog_level, std::vector<float>& out, hipStream_t s);
 
   // parameters (SiftParam::ParseSiftParam, SiftGPU.cpp:433-473)
   float sigma0 = 0, sigmak = 0, dsigma0 = 0, sigma[kLevels - 1] = {}, dog_threshold = 0, edge_threshold = 0;
@@ -98,7 +98,7 @@ struct SiftExtractor {
   std::vector<int> lvl_count, lvl_off;                 // candidates per (octave, dog level) of the latest call's first frame
   int frames_cap = 0;                                  // frames the buffers hold (every device buffer is [frames_cap][...])
   size_t input_floats = 0;                             // per-frame strides: d_input; d_up = oct[0].plane; d_planes = planes_floats
-  int prepare(int rows, int cols, int nf, std::string& err);
+  int prepare(int rows, int cols, int nf, hipStream_t s, std::string& err);
   int plan_geometry(int rows, int cols, std::string& err);   // sizes only (defined in sift_pyramid_kernels.h, as bind_levels)
   void bind_levels();
 };

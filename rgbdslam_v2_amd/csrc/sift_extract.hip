@@ -388,7 +388,11 @@ void SiftExtractor::release() {
 }
 
 // the buffers of nf frames of this size, side by side (geometry: plan_geometry / bind_levels, sift_pyramid_kernels.h)
-int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
+// (the tables go up on the caller's stream, followed by a wait: a synchronous hipMemcpy is an operation of the legacy stream,
+// and the runtime refuses those -- "would make the legacy stream depend on a capturing blocking stream" -- while ANOTHER
+// thread of the process has a stream capture open, e.g. another context recording its own launch chain:
+// tests/test_gpu_sift_threads.py)
+int SiftExtractor::prepare(int rows, int cols, int nf, hipStream_t s, std::string& err) {
   init_params();
   if (rows == H && cols == W && d_planes && nf <= frames_cap) return RGBDFE_OK;
   if (rows == H && cols == W && nf < frames_cap) nf = frames_cap;
@@ -407,13 +411,14 @@ int SiftExtractor::prepare(int rows, int cols, int nf, std::string& err) {
   d_lvltot = d_rowcnt + (size_t)total_rows * (2 * F + 1);
   bind_levels();
   SIFT_HIP(hipMalloc((void**)&d_levels, sizeof(LevelDesc) * h_levels.size()));
-  SIFT_HIP(hipMemcpy(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice));
-  SIFT_HIP(hipMemcpy(d_rowcnt + (size_t)total_rows * 2 * F, h_row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice));
+  SIFT_HIP(hipMemcpyAsync(d_levels, h_levels.data(), sizeof(LevelDesc) * h_levels.size(), hipMemcpyHostToDevice, s));
+  SIFT_HIP(hipMemcpyAsync(d_rowcnt + (size_t)total_rows * 2 * F, h_row2lvl.data(), sizeof(int) * (size_t)total_rows, hipMemcpyHostToDevice, s));
   SIFT_HIP(hipMalloc((void**)&d_octs, sizeof(OctDesc) * h_octs.size()));
-  SIFT_HIP(hipMemcpy(d_octs, h_octs.data(), sizeof(OctDesc) * h_octs.size(), hipMemcpyHostToDevice));
+  SIFT_HIP(hipMemcpyAsync(d_octs, h_octs.data(), sizeof(OctDesc) * h_octs.size(), hipMemcpyHostToDevice, s));
   n_key_tiles = (int)h_key_tiles.size();
   SIFT_HIP(hipMalloc((void**)&d_key_tiles, sizeof(KeyTile) * h_key_tiles.size()));
-  SIFT_HIP(hipMemcpy(d_key_tiles, h_key_tiles.data(), sizeof(KeyTile) * h_key_tiles.size(), hipMemcpyHostToDevice));
+  SIFT_HIP(hipMemcpyAsync(d_key_tiles, h_key_tiles.data(), sizeof(KeyTile) * h_key_tiles.size(), hipMemcpyHostToDevice, s));
+  SIFT_HIP(hipStreamSynchronize(s));   // the host vectors may change before the copies would otherwise have run
   cand_cap = std::max<size_t>((size_t)1 << 16, oct[0].plane / 16);
   SIFT_HIP(hipMalloc((void**)&d_cand, F * cand_cap * 6 * 4));
   feat_cap = cand_cap * 2;                      // per frame; the batch-wide lists are packed: F * feat_cap entries at most
@@ -451,7 +456,7 @@ int SiftExtractor::run_batch(const uint8_t* const* gray, int nf, int rows, int c
 int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int cols, hipStream_t s, std::string& err) {
   if (nf < 1 || nf > kMaxBatch) { err = "SIFT batch size out of range"; return RGBDFE_ERR_INVALID_ARG; }
   pending_nf = 0;
-  int rc = prepare(rows, cols, nf, err);
+  int rc = prepare(rows, cols, nf, s, err);
   if (rc != RGBDFE_OK) return rc;
   const auto t_in = std::chrono::steady_clock::now();
   for (int f = 0; f < nf; ++f) memcpy(h_gray + (size_t)f * gray_cap, gray[f], gray_cap);
@@ -742,7 +747,7 @@ int SiftExtractor::finish_outputs(std::vector<SiftKey>* keys, const float** desc
 int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftKey* keys_in, int n, const float** desc, hipStream_t s,
                             std::string& err) {
   *desc = nullptr;
-  int rc = prepare(rows, cols, 1, err);
+  int rc = prepare(rows, cols, 1, s, err);
   if (rc != RGBDFE_OK) return rc;
   if (n <= 0) return RGBDFE_OK;
   rc = enqueue_pyramid(&gray, 1, s, err);
@@ -828,13 +833,14 @@ int SiftExtractor::debug_plane(int octave, int level, std::vector<float>& out, i
   return RGBDFE_OK;
 }
 
-int SiftExtractor::debug_candidates(int octave, int dog_level, std::vector<float>& out) {
+int SiftExtractor::debug_candidates(int octave, int dog_level, std::vector<float>& out, hipStream_t s) {
   if (octave < 0 || octave >= octave_num || dog_level < 0 || dog_level >= kDogLevels || lvl_count.empty())
     return RGBDFE_ERR_INVALID_ARG;
   const int idx = octave * kDogLevels + dog_level;
   out.resize((size_t)lvl_count[(size_t)idx] * 6);
   if (!out.empty() &&
-      hipMemcpy(out.data(), d_cand + (size_t)lvl_off[(size_t)idx] * 6, out.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+      (hipMemcpyAsync(out.data(), d_cand + (size_t)lvl_off[(size_t)idx] * 6, out.size() * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+       hipStreamSynchronize(s) != hipSuccess))
     return RGBDFE_ERR_HIP;
   return RGBDFE_OK;
 }

@@ -6,6 +6,10 @@
 
 namespace rgbdfe { alignas(16) uint8_t pyr_lds[64 * 1024]; }   // the kernel's `extern __shared__` array
 
+#include "orb_internal.h"
+// the setup stream lives in orb_host.hip, which is not part of this library: run the operation in place
+namespace rgbdfe { hipError_t orb_setup_stream_run(const std::function<hipError_t(hipStream_t)>& op) { return op(nullptr); } }
+
 #include "orb_kernels_emu.inc"   // csrc/orb_kernels.hip with its one `extern __shared__` declaration made a plain extern
 
 // what rgbdfe_debug_pyramid_plan_check2 calls for the fused side: the product's launcher over the product's kernel

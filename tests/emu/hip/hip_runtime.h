@@ -48,6 +48,11 @@ extern dim3 blockDim, gridDim;
 #define __launch_bounds__(...)
 #define HIP_SYMBOL(x) (&(x))
 static inline hipError_t hipMemcpyToSymbol(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return hipSuccess; }
+enum { hipMemcpyHostToDevice = 1 };
+static inline hipError_t hipMemcpyToSymbolAsync(void* dst, const void* src, size_t n, size_t off, int, hipStream_t) {
+  memcpy((char*)dst + off, src, n);
+  return hipSuccess;
+}
 
 // the overloads device code gets from the HIP headers
 static inline int min(int a, int b) { return a < b ? a : b; }

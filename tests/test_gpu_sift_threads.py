@@ -1,7 +1,8 @@
 """GPU: the SIFT batch entry point beside itself.  rgbdfe_sift_detect_batch captures the first half of a chunk as a hipGraph
 on first use (relaxed capture on the chunk's own stream) and keeps three chunks in flight on three streams; here two host
 threads drive two contexts at once -- one of them capturing its graphs while the other is already replaying, allocating and
-waiting -- and a third thread runs ORB pair batches on a third context.  Every result must equal the one the same context
+waiting -- and a third thread sets up an ORB detector workspace and runs ORB pair batches on a third context (its allocation-time table
+uploads must not be NULL-stream copies: the runtime refuses those while another thread has a capture open).  Every result must equal the one the same context
 type produces alone (frames are independent: the pipeline keeps no state between images)."""
 import threading
 
@@ -52,6 +53,12 @@ def test_two_contexts_extract_concurrently_and_equal_their_serial_results():
             try:
                 for i in range(12):
                     f.upload_node(i, seq["desc"][i], seq["xyz1"][i])
+                f.upload_node_keypoints(3, np.zeros((len(seq["desc"][3]), 2), np.float32))   # allocation-time fills and copies
+                img = synth.make_image_sequence(n_frames=3, seed=9, width=320, height=240)    # ... and a first ORB workspace
+                masks = [np.where(m > 0, 255, 0).astype(np.uint8) for m in img["mask"]]
+                f.detector_configure(max_keypoints=300)
+                det = f.detect_describe_batch(list(img["gray"]), masks, list(img["depth"]), img["fx"], img["fy"], img["cx"], img["cy"])
+                assert len(det) == 3
                 q = np.arange(1, 12, dtype=np.int32)
                 t = np.arange(0, 11, dtype=np.int32)
                 first = f.match_pair_list(q, t).tobytes()
