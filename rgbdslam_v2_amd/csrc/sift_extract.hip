@@ -461,13 +461,15 @@ int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int
   const auto t_in = std::chrono::steady_clock::now();
   for (int f = 0; f < nf; ++f) memcpy(h_gray + (size_t)f * gray_cap, gray[f], gray_cap);
   stage_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count();
-  // Everything this half enqueues -- the frames' upload from the pinned stage, ~55 pyramid launches, the extremum flags, the
-  // scan, the ordered emit, the counts' download -- has the same arguments for every batch of nf frames of this size: it is
-  // captured ONCE per nf as a hipGraph and replayed with one hipGraphLaunch.  The calling thread spent ~0.3 ms per chunk on
-  // those enqueues, time the other chunk's stream sat idle for; a single call's ~60 dependent launches also
-  // start closer together inside a graph.  RGBDFE_SIFT_GRAPH=0: plain launches (the A/B switch; also what a failed capture
-  // falls back to).
-  static const bool graph_env = !(getenv("RGBDFE_SIFT_GRAPH") && atoi(getenv("RGBDFE_SIFT_GRAPH")) == 0);
+  // Everything this half enqueues -- the frames' upload from the pinned stage, 50 pyramid launches, the extremum flags, the
+  // scan, the ordered emit, the counts' download -- has the same arguments for every batch of nf frames of this size, so it
+  // CAN be captured once per nf as a hipGraph and replayed with one hipGraphLaunch: RGBDFE_SIFT_GRAPH=1.  Measured: the
+  // calling thread's time in this function falls from 0.86 to 0.27 ms per 32-frame call, the wall clock does not move (the
+  // device is the bound: profiles/r05_logs/sift_host_steps.txt).  It is therefore NOT the default: while a capture is open --
+  // even a relaxed one on a non-blocking stream -- the runtime refuses NULL-stream operations of every other thread of the
+  // process ("operation would make the legacy stream depend on a capturing blocking stream"; tests/test_gpu_sift_threads.py
+  // met it in this library's own allocation-time copies, which no longer use the NULL stream -- a caller's own code may).
+  static const bool graph_env = getenv("RGBDFE_SIFT_GRAPH") && atoi(getenv("RGBDFE_SIFT_GRAPH")) != 0;
   bool launched = false;
   if (graph_env) {
     if (!begin_exec[nf] && !begin_capture_failed) {

@@ -1,15 +1,19 @@
-"""GPU: the SIFT batch entry point beside itself.  rgbdfe_sift_detect_batch captures the first half of a chunk as a hipGraph
-on first use (relaxed capture on the chunk's own stream) and keeps three chunks in flight on three streams; here two host
-threads drive two contexts at once -- one of them capturing its graphs while the other is already replaying, allocating and
-waiting -- and a third thread sets up an ORB detector workspace and runs ORB pair batches on a third context (its allocation-time table
+"""GPU: the SIFT batch entry point beside itself.  rgbdfe_sift_detect_batch keeps three chunks in flight on three streams and,
+with RGBDFE_SIFT_GRAPH=1, captures the first half of a chunk as a hipGraph on first use (relaxed capture on the chunk's own
+stream); here two host threads drive two contexts at once -- with the switch on, one of them capturing its graphs while the
+other is already replaying, allocating and waiting -- and a third thread sets up an ORB detector workspace and runs ORB pair batches on a third context (its allocation-time table
 uploads must not be NULL-stream copies: the runtime refuses those while another thread has a capture open).  Every result must equal the one the same context
 type produces alone (frames are independent: the pipeline keeps no state between images)."""
+import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
 import pytest
 
-from rgbdslam_v2_amd import synth
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rgbdslam_v2_amd import synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +22,15 @@ def _frames(seed, n, w=320, h=240):
     return list(synth.make_image_sequence(n_frames=n, seed=seed, width=w, height=h)["gray"])
 
 
-def test_two_contexts_extract_concurrently_and_equal_their_serial_results():
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_two_contexts_extract_concurrently_and_equal_their_serial_results(graph):
+    """(a process of its own: the switch is read once per process)"""
+    env = dict(os.environ, RGBDFE_SIFT_GRAPH=graph)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "scenario ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def scenario():
     from rgbdslam_v2_amd.frontend import FrontEnd
     sets = [_frames(101, 19), _frames(202, 27)]
     ref = []
@@ -80,3 +92,8 @@ def test_two_contexts_extract_concurrently_and_equal_their_serial_results():
         assert len(got[i]) == len(ref[i])
         for (ka, da), (kb, db) in zip(got[i], ref[i]):
             assert ka.tobytes() == kb.tobytes() and da.tobytes() == db.tobytes()
+
+
+if __name__ == "__main__":
+    scenario()
+    print("scenario ok")
