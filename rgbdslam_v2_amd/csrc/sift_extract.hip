@@ -58,44 +58,25 @@ __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::
   if (threadIdx.x == 0) lvltot[blockIdx.x] = base;
 }
 
-// A wave per row, sixteen rows per workgroup: the row's extrema in column order -> the level's candidate list (x, y, sign, dx,
-// dy, ds).  (Most rows hold no extremum and end after one load: as one-wave workgroups -- 75 000 of them per chunk of 8 VGA
-// frames -- the launch was bound by workgroup dispatch.)  A lane takes EIGHT neighbouring flag bytes per step (512 columns
-// per step: three steps for the widest plane of a VGA frame, where the byte-per-lane form of rounds 3 - 4 took twenty
-// dependent load + ballot rounds), counts its non-zero bytes, an exclusive wave scan of the counts gives every flagged pixel
-// its rank in the row, and the few lanes that hold one evaluate it.
-constexpr int kEmitRowsPerWave = 4, kEmitRowsPerGroup = 4 * kEmitRowsPerWave;
-__device__ __forceinline__ void emit_row(const SiftExtractor::LevelDesc* __restrict__ levels, const int* __restrict__ row2lvl,
-                                         const int* __restrict__ rowcnt, const int* __restrict__ rowoff,
-                                         const int* __restrict__ lvltot, float* __restrict__ cand, int cand_cap,
-                                         float dog_threshold0, float dog_threshold, float edge_threshold, const FrameStrides& st,
-                                         int grow, int frame, int lane);
-__global__ __launch_bounds__(256) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                            const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
-                                                            const int* __restrict__ rowoff, const int* __restrict__ lvltot,
-                                                            float* __restrict__ cand, int cand_cap, float dog_threshold0,
-                                                            float dog_threshold, float edge_threshold, FrameStrides st) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// one wave per row: the row's extrema in column order -> the level's candidate list (x, y, sign, dx, dy, ds).  A lane takes
+// EIGHT neighbouring flag bytes per step (512 columns per step: three steps for the widest plane of a VGA frame, where the
+// byte-per-lane form of rounds 3 - 4 took twenty dependent load + ballot rounds), counts its non-zero bytes, an exclusive
+// wave scan of the counts gives every flagged pixel its rank in the row, and the few lanes that hold one evaluate it.
+__global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                           const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
+                                                           const int* __restrict__ rowoff, const int* __restrict__ lvltot,
+                                                           float* __restrict__ cand, int cand_cap, float dog_threshold0,
+                                                           float dog_threshold, float edge_threshold, FrameStrides st) {
+  const int grow = blockIdx.x;
   rowcnt += (size_t)blockIdx.y * st.rows;
   rowoff += (size_t)blockIdx.y * st.rows;
   lvltot += (size_t)blockIdx.y * st.lvltot;
   cand += (size_t)blockIdx.y * st.cand;
-  for (int k = 0; k < kEmitRowsPerWave; ++k) {
-    const int grow = blockIdx.x * kEmitRowsPerGroup + wave * kEmitRowsPerWave + k;
-    if (grow >= st.rows) return;
-    if (rowcnt[grow] == 0) continue;
-    emit_row(levels, row2lvl, rowcnt, rowoff, lvltot, cand, cand_cap, dog_threshold0, dog_threshold, edge_threshold, st, grow,
-             (int)blockIdx.y, lane);
-  }
-}
-__device__ __forceinline__ void emit_row(const SiftExtractor::LevelDesc* __restrict__ levels, const int* __restrict__ row2lvl,
-                                         const int* __restrict__ rowcnt, const int* __restrict__ rowoff,
-                                         const int* __restrict__ lvltot, float* __restrict__ cand, int cand_cap,
-                                         float dog_threshold0, float dog_threshold, float edge_threshold, const FrameStrides& st,
-                                         int grow, int frame, int lane) {
+  if (rowcnt[grow] == 0) return;
   const int lvl = row2lvl[grow];
-  const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, frame);
+  const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.y);
   const int row = grow - L.row0;
+  const int lane = threadIdx.x;
   int base = rowoff[grow];
   for (int l = 0; l < lvl; ++l) base += lvltot[l];
   const int8_t* __restrict__ frow = L.flags + (size_t)row * L.w;   // (w is a multiple of 4: the row starts dword-aligned)
@@ -539,7 +520,7 @@ int SiftExtractor::enqueue_begin(int nf, hipStream_t s, std::string& err) {
   SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
   launch_key_flags(*this, nf, st, s);
   hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
-  hipLaunchKernelGGL(sift_key_emit_kernel, dim3((total_rows + kEmitRowsPerGroup - 1) / kEmitRowsPerGroup, NF), dim3(256), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
+  hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows, NF), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
                      d_cand, (int)cand_cap, tdog1, tdog, tedge, st);
   SIFT_HIP(hipGetLastError());
   SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * 64 * (size_t)nf, hipMemcpyDeviceToHost, s));
