@@ -62,6 +62,8 @@ __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::
 // EIGHT neighbouring flag bytes per step (512 columns per step: three steps for the widest plane of a VGA frame, where the
 // byte-per-lane form of rounds 3 - 4 took twenty dependent load + ballot rounds), counts its non-zero bytes, an exclusive
 // wave scan of the counts gives every flagged pixel its rank in the row, and the few lanes that hold one evaluate it.
+// (Sixteen rows per workgroup, a wave walking four of them, was measured too: 77 instead of 44 us per 8 frames -- a row with
+// extrema is a chain of dependent loads, and the launch lives on rows in flight, not on workgroup dispatch.)
 __global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
                                                            const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
                                                            const int* __restrict__ rowoff, const int* __restrict__ lvltot,
