@@ -519,6 +519,8 @@ int SiftExtractor::enqueue_begin(int nf, hipStream_t s, std::string& err) {
   const float tdog = dog_threshold, tdog1 = 0.8f * tdog;
   const float tedge = (edge_threshold + 1) * (edge_threshold + 1) / edge_threshold;
   int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2 * frames_cap;
+  // (under RGBDFE_SIFT_GRAPH=1 this becomes a memset NODE; the pair path once saw such a node not in effect on replay
+  //  (ransac_split.hip, ransac_hyp_kernel) and zeroes its counters in a kernel since -- one more reason the graph is opt-in)
   SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
   launch_key_flags(*this, nf, st, s);
   hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
