@@ -35,86 +35,6 @@ namespace rgbdfe {
 
 namespace {
 
-// per level: exclusive scan of its rows' counts, the level's total
-__global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                           const int* __restrict__ rowcnt, int* __restrict__ rowoff,
-                                                           int* __restrict__ lvltot, FrameStrides st) {
-  const SiftExtractor::LevelDesc L = levels[blockIdx.x];
-  rowcnt += (size_t)blockIdx.y * st.rows;
-  rowoff += (size_t)blockIdx.y * st.rows;
-  lvltot += (size_t)blockIdx.y * st.lvltot;
-  int base = 0;
-  for (int r0 = 0; r0 < L.h; r0 += 64) {
-    const int r = r0 + (int)threadIdx.x;
-    const int c = r < L.h ? rowcnt[L.row0 + r] : 0;
-    int incl = c;
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d);
-      if ((int)threadIdx.x >= d) incl += o;
-    }
-    if (r < L.h) rowoff[L.row0 + r] = base + incl - c;
-    base += __shfl(incl, 63);
-  }
-  if (threadIdx.x == 0) lvltot[blockIdx.x] = base;
-}
-
-// one wave per row: the row's extrema in column order -> the level's candidate list (x, y, sign, dx, dy, ds).  A lane takes
-// EIGHT neighbouring flag bytes per step (512 columns per step: three steps for the widest plane of a VGA frame, where the
-// byte-per-lane form of rounds 3 - 4 took twenty dependent load + ballot rounds), counts its non-zero bytes, an exclusive
-// wave scan of the counts gives every flagged pixel its rank in the row, and the few lanes that hold one evaluate it.
-// (Sixteen rows per workgroup, a wave walking four of them, was measured too: 77 instead of 44 us per 8 frames -- a row with
-// extrema is a chain of dependent loads, and the launch lives on rows in flight, not on workgroup dispatch.)
-__global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                           const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
-                                                           const int* __restrict__ rowoff, const int* __restrict__ lvltot,
-                                                           float* __restrict__ cand, int cand_cap, float dog_threshold0,
-                                                           float dog_threshold, float edge_threshold, FrameStrides st) {
-  const int grow = blockIdx.x;
-  rowcnt += (size_t)blockIdx.y * st.rows;
-  rowoff += (size_t)blockIdx.y * st.rows;
-  lvltot += (size_t)blockIdx.y * st.lvltot;
-  cand += (size_t)blockIdx.y * st.cand;
-  if (rowcnt[grow] == 0) return;
-  const int lvl = row2lvl[grow];
-  const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.y);
-  const int row = grow - L.row0;
-  const int lane = threadIdx.x;
-  int base = rowoff[grow];
-  for (int l = 0; l < lvl; ++l) base += lvltot[l];
-  const int8_t* __restrict__ frow = L.flags + (size_t)row * L.w;   // (w is a multiple of 4: the row starts dword-aligned)
-  for (int c0 = 0; c0 < L.w; c0 += 512) {
-    const int col0 = c0 + lane * 8;
-    uint32_t lo = 0, hi = 0;
-    if (col0 < L.w) lo = *reinterpret_cast<const uint32_t*>(frow + col0);
-    if (col0 + 4 < L.w) hi = *reinterpret_cast<const uint32_t*>(frow + col0 + 4);
-    if (__ballot((lo | hi) != 0) == 0) continue;
-    // non-zero bytes of the eight: bit 8 i + 7 of `nz` set for byte i
-    const uint64_t bytes = ((uint64_t)hi << 32) | lo;
-    const uint64_t nz = (((bytes & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | bytes) & 0x8080808080808080ull;
-    const int mine = (int)__popcll(nz);
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
-    int rank = base + incl - mine;
-    uint64_t todo = nz;
-    while (todo) {
-      const int i = (__ffsll((long long)todo) - 1) >> 3;
-      todo &= todo - 1;
-      const int col = col0 + i;
-      if (rank < cand_cap) {
-        const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
-        float* o = cand + (size_t)rank * 6;
-        o[0] = (float)col; o[1] = (float)row; o[2] = e.result; o[3] = e.dx; o[4] = e.dy; o[5] = e.ds;
-      }
-      ++rank;
-    }
-    base += __shfl(incl, 63);
-  }
-}
-
 // ---- gradient of a Gaussian plane at an interior pixel (ComputeDOG_Kernel, ProgramCU.cu:466-473) -------------------------------
 __device__ __forceinline__ float2 grad_at(const float* __restrict__ G, int w, int px, int py) {
   const int index = py * w + px;
@@ -509,23 +429,16 @@ int SiftExtractor::begin_batch(const uint8_t* const* gray, int nf, int rows, int
 
 // the enqueues of begin_batch (frames staged in h_gray): directly, or under stream capture
 int SiftExtractor::enqueue_begin(int nf, hipStream_t s, std::string& err) {
-  const int nlv = octave_num * kDogLevels;
-  const unsigned NF = (unsigned)nf;
   FrameStrides st{};
   st.planes = planes_floats; st.flags = flags_bytes; st.cand = cand_cap * 6; st.rows = total_rows; st.lvltot = 64;
   SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)nf * gray_cap, hipMemcpyHostToDevice, s));
   launch_pyramid(*this, nf, s);
   // ---- DetectKeypointsEX + the list part of GenerateFeatureList: flags, row counts, scan, ordered emit ----------------------
-  const float tdog = dog_threshold, tdog1 = 0.8f * tdog;
-  const float tedge = (edge_threshold + 1) * (edge_threshold + 1) / edge_threshold;
-  int* d_row2lvl = d_rowcnt + (size_t)total_rows * 2 * frames_cap;
   // (under RGBDFE_SIFT_GRAPH=1 this becomes a memset NODE; the pair path once saw such a node not in effect on replay
   //  (ransac_split.hip, ransac_hyp_kernel) and zeroes its counters in a kernel since -- one more reason the graph is opt-in)
   SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
   launch_key_flags(*this, nf, st, s);
-  hipLaunchKernelGGL(sift_row_scan_kernel, dim3(nlv, NF), dim3(64), 0, s, d_levels, d_rowcnt, d_rowoff, d_lvltot, st);
-  hipLaunchKernelGGL(sift_key_emit_kernel, dim3(total_rows, NF), dim3(64), 0, s, d_levels, d_row2lvl, d_rowcnt, d_rowoff, d_lvltot,
-                     d_cand, (int)cand_cap, tdog1, tdog, tedge, st);
+  launch_key_lists(*this, nf, st, s);
   SIFT_HIP(hipGetLastError());
   SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * 64 * (size_t)nf, hipMemcpyDeviceToHost, s));
   return RGBDFE_OK;

@@ -492,6 +492,86 @@ __global__ __launch_bounds__(256) void sift_key_flag_kernel(const float* __restr
   }
 }
 
+// per level: exclusive scan of its rows' counts, the level's total
+__global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                           const int* __restrict__ rowcnt, int* __restrict__ rowoff,
+                                                           int* __restrict__ lvltot, FrameStrides st) {
+  const SiftExtractor::LevelDesc L = levels[blockIdx.x];
+  rowcnt += (size_t)blockIdx.y * st.rows;
+  rowoff += (size_t)blockIdx.y * st.rows;
+  lvltot += (size_t)blockIdx.y * st.lvltot;
+  int base = 0;
+  for (int r0 = 0; r0 < L.h; r0 += 64) {
+    const int r = r0 + (int)threadIdx.x;
+    const int c = r < L.h ? rowcnt[L.row0 + r] : 0;
+    int incl = c;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if ((int)threadIdx.x >= d) incl += o;
+    }
+    if (r < L.h) rowoff[L.row0 + r] = base + incl - c;
+    base += __shfl(incl, 63);
+  }
+  if (threadIdx.x == 0) lvltot[blockIdx.x] = base;
+}
+
+// one wave per row: the row's extrema in column order -> the level's candidate list (x, y, sign, dx, dy, ds).  A lane takes
+// EIGHT neighbouring flag bytes per step (512 columns per step: three steps for the widest plane of a VGA frame, where the
+// byte-per-lane form of rounds 3 - 4 took twenty dependent load + ballot rounds), counts its non-zero bytes, an exclusive
+// wave scan of the counts gives every flagged pixel its rank in the row, and the few lanes that hold one evaluate it.
+// (Sixteen rows per workgroup, a wave walking four of them, was measured too: 77 instead of 44 us per 8 frames -- a row with
+// extrema is a chain of dependent loads, and the launch lives on rows in flight, not on workgroup dispatch.)
+__global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
+                                                           const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
+                                                           const int* __restrict__ rowoff, const int* __restrict__ lvltot,
+                                                           float* __restrict__ cand, int cand_cap, float dog_threshold0,
+                                                           float dog_threshold, float edge_threshold, FrameStrides st) {
+  const int grow = blockIdx.x;
+  rowcnt += (size_t)blockIdx.y * st.rows;
+  rowoff += (size_t)blockIdx.y * st.rows;
+  lvltot += (size_t)blockIdx.y * st.lvltot;
+  cand += (size_t)blockIdx.y * st.cand;
+  if (rowcnt[grow] == 0) return;
+  const int lvl = row2lvl[grow];
+  const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.y);
+  const int row = grow - L.row0;
+  const int lane = threadIdx.x;
+  int base = rowoff[grow];
+  for (int l = 0; l < lvl; ++l) base += lvltot[l];
+  const int8_t* __restrict__ frow = L.flags + (size_t)row * L.w;   // (w is a multiple of 4: the row starts dword-aligned)
+  for (int c0 = 0; c0 < L.w; c0 += 512) {
+    const int col0 = c0 + lane * 8;
+    uint32_t lo = 0, hi = 0;
+    if (col0 < L.w) lo = *reinterpret_cast<const uint32_t*>(frow + col0);
+    if (col0 + 4 < L.w) hi = *reinterpret_cast<const uint32_t*>(frow + col0 + 4);
+    if (__ballot((lo | hi) != 0) == 0) continue;
+    // non-zero bytes of the eight: bit 8 i + 7 of `nz` set for byte i
+    const uint64_t bytes = ((uint64_t)hi << 32) | lo;
+    const uint64_t nz = (((bytes & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | bytes) & 0x8080808080808080ull;
+    const int mine = (int)__popcll(nz);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    int rank = base + incl - mine;
+    uint64_t todo = nz;
+    while (todo) {
+      const int i = (__ffsll((long long)todo) - 1) >> 3;
+      todo &= todo - 1;
+      const int col = col0 + i;
+      if (rank < cand_cap) {
+        const KeyEval e = key_eval(L.g, L.w, row * L.w + col, dog_threshold0, dog_threshold, edge_threshold);
+        float* o = cand + (size_t)rank * 6;
+        o[0] = (float)col; o[1] = (float)row; o[2] = e.result; o[3] = e.dx; o[4] = e.dy; o[5] = e.ds;
+      }
+      ++rank;
+    }
+    base += __shfl(incl, 63);
+  }
+}
+
 // The taps of a Gaussian level: exp(-d^2 / 2 sigma^2) for d = -half .. half, normalised to sum 1 (f32 throughout, summed
 // left to right -- the values of ProgramCU::CreateFilterKernel, ProgramCU.cu:370-398, with its width factor 4): half =
 // ceil(4 sigma - 1/2) taps either side, kept between 2 and 16 (widths 5 .. 33).
@@ -562,6 +642,18 @@ inline void launch_key_flags(const SiftExtractor& E, int nf, const FrameStrides&
   hipLaunchKernelGGL(sift_key_flag_kernel, dim3((unsigned)E.n_key_tiles, (unsigned)nf), dim3(256), 0, s, E.d_planes, E.d_flags,
                      static_cast<const SiftExtractor::OctDesc*>(E.d_octs), static_cast<const KeyTile*>(E.d_key_tiles),
                      E.d_rowcnt, tdog1, tdog, tedge, st);
+}
+
+// the list part of GenerateFeatureList: per-level scan of the row counts, then the ordered emit into the candidate lists
+inline void launch_key_lists(const SiftExtractor& E, int nf, const FrameStrides& st, hipStream_t s) {
+  const float tdog = E.dog_threshold, tdog1 = 0.8f * tdog;
+  const float tedge = (E.edge_threshold + 1) * (E.edge_threshold + 1) / E.edge_threshold;
+  const int nlv = E.octave_num * SiftExtractor::kDogLevels;
+  const int* d_row2lvl = E.d_rowcnt + (size_t)E.total_rows * 2 * E.frames_cap;
+  hipLaunchKernelGGL(sift_row_scan_kernel, dim3((unsigned)nlv, (unsigned)nf), dim3(64), 0, s, E.d_levels, E.d_rowcnt, E.d_rowoff,
+                     E.d_lvltot, st);
+  hipLaunchKernelGGL(sift_key_emit_kernel, dim3((unsigned)E.total_rows, (unsigned)nf), dim3(64), 0, s, E.d_levels, d_row2lvl,
+                     E.d_rowcnt, E.d_rowoff, E.d_lvltot, E.d_cand, (int)E.cand_cap, tdog1, tdog, tedge, st);
 }
 
 }  // namespace

@@ -2,7 +2,8 @@
 // A HIP-on-CPU vocabulary just large enough to compile csrc/orb_kernels.hip and csrc/sift_pyramid_kernels.h with g++ and RUN those of their kernels that use
 // no wave-level operation (orb_pyramid_kernel, orb_resize_kernel, orb_blur_kernel; the SIFT pyramid and extremum kernels) on the host: one OS thread per HIP thread
 // of a workgroup, workgroups one after the other, __shared__ = static storage, __syncthreads() = a barrier over the
-// workgroup's threads.  Wave intrinsics (ballot, shuffles, DPP, mbcnt) compile to calls that abort:
+// workgroup's threads.  Ballot and shuffles are served for one-wave workgroups (through that barrier); DPP, mbcnt, readlane and
+// wave intrinsics in larger workgroups compile to calls that abort:
 // the kernels built on them are not run here.  Nothing under rgbdslam_v2_amd/ includes this file.
 #pragma once
 #include <float.h>
@@ -69,16 +70,42 @@ void hipemu_barrier();
 void hipemu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hipemu_launch(grid, block, [&] { kernel(__VA_ARGS__); })
 
-// wave-level operations (atomics and readfirstlane of a uniform value aside): kernels that use them are compiled but must
-// not run on this emulation
+// wave-level operations: atomics, readfirstlane of a uniform value and -- for one-wave workgroups -- ballot / shuffles are
+// served; kernels that use anything else are compiled but must not run on this emulation
 [[noreturn]] static inline void hipemu_no_wave_ops(const char* what) {
   fprintf(stderr, "hip emulation: %s is a wave-level operation (this kernel cannot run here)\n", what);
   abort();
 }
-static inline unsigned long long __ballot(int) { hipemu_no_wave_ops("__ballot"); }
-static inline int __shfl(int, int) { hipemu_no_wave_ops("__shfl"); }
+// __ballot / __shfl / __shfl_up: served for workgroups that are ONE wave (64 threads) whose lanes all take part -- the
+// workgroup barrier is then the wave's rendezvous: every lane deposits its value, all wait, every lane reads its source.
+// (sift_row_scan_kernel, sift_key_emit_kernel.)  Any other workgroup shape aborts as before.
+extern int hipemu_wave_slot[64];
+static inline void hipemu_need_one_wave(const char* what) {
+  if (blockDim.x * blockDim.y * blockDim.z != 64) hipemu_no_wave_ops(what);
+}
+static inline int hipemu_wave_fetch(int v, int src_lane, const char* what) {
+  hipemu_need_one_wave(what);
+  const int lane = (int)threadIdx.x;
+  hipemu_wave_slot[lane] = v;
+  hipemu_barrier();
+  const int r = hipemu_wave_slot[(src_lane >= 0 && src_lane < 64) ? src_lane : lane];
+  hipemu_barrier();
+  return r;
+}
+static inline unsigned long long __ballot(int pred) {
+  unsigned long long m = 0;
+  hipemu_need_one_wave("__ballot");
+  const int lane = (int)threadIdx.x;
+  hipemu_wave_slot[lane] = pred ? 1 : 0;
+  hipemu_barrier();
+  for (int i = 0; i < 64; ++i) m |= (unsigned long long)(hipemu_wave_slot[i] & 1) << i;
+  hipemu_barrier();
+  return m;
+}
+static inline int __shfl(int v, int src_lane) { return hipemu_wave_fetch(v, src_lane, "__shfl"); }
+static inline int __shfl_up(int v, int delta) { return hipemu_wave_fetch(v, (int)threadIdx.x - delta, "__shfl_up"); }
 static inline int __shfl_xor(int, int) { hipemu_no_wave_ops("__shfl_xor"); }
-static inline int __shfl_up(int, int) { hipemu_no_wave_ops("__shfl_up"); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }   // LDS or global: one address space here
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned, unsigned) { hipemu_no_wave_ops("mbcnt"); }

@@ -1,6 +1,6 @@
 """CPU: the SOURCE of the SIFT pyramid and extremum kernels of the product (csrc/sift_pyramid_kernels.h: sift_convert_kernel,
-sift_upsample2_kernel, sift_filter_kernel, sift_filter_tile_kernel, sift_downsample2_kernel, sift_key_flag_kernel), their launch
-chains (launch_pyramid, launch_key_flags) and the extractor's geometry (SiftExtractor::plan_geometry / bind_levels) run on the
+sift_upsample2_kernel, sift_filter_kernel, sift_filter_tile_kernel, sift_downsample2_kernel, sift_key_flag_kernel,
+sift_row_scan_kernel, sift_key_emit_kernel), their launch chains (launch_pyramid, launch_key_flags, launch_key_lists) and the extractor's geometry (SiftExtractor::plan_geometry / bind_levels) run on the
 host -- the header compiled with g++ over the HIP-on-CPU vocabulary of tests/emu/ (one OS thread per HIP thread, __shared__ =
 static storage, __syncthreads() = a barrier, atomicAdd = a host atomic) -- against SiftGPU's own CUDA kernels and host code
 compiled on the CUDA-on-CPU emulation of oracle/ref_stubs (oracle/_ref/libref_siftgpu.so):
@@ -8,7 +8,9 @@ compiled on the CUDA-on-CPU emulation of oracle/ref_stubs (oracle/_ref/libref_si
   * every Gaussian plane of every octave: equal bit for bit (the f32 sums of FilterH / FilterV, ProgramCU.cu:113-218, keep
     their order in the register-window kernel of round 5);
   * every extremum flag of every (octave, dog level) and the per-row counts: the reference's keypoint map (ComputeKEY_Kernel,
-    ProgramCU.cu:524-640) as InitHist_Kernel enumerates it (:665-688).
+    ProgramCU.cu:524-640) as InitHist_Kernel enumerates it (:665-688);
+  * the candidate lists sift_row_scan_kernel + sift_key_emit_kernel make of them (one-wave workgroups: the emulation serves
+    their ballot / shuffles through the workgroup barrier): count, raster order, (x, y, sign, dx, dy, ds) bit for bit.
 
 The tile shape of the Gaussian levels is forced (64 x 64 and 64 x 32 register-window tiles on EVERY octave, down to planes
 smaller than one tile: the clamped borders) or left to the product's choice.  The GPU runs of the same kernels:
@@ -42,6 +44,8 @@ def emu(tmp_path_factory):
     L = C.CDLL(lib)
     L.emu_sift_run.restype = C.c_int
     L.emu_sift_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.emu_sift_candidates.restype = C.c_int
+    L.emu_sift_candidates.argtypes = [C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float))]
     for f in (L.emu_sift_plane, L.emu_sift_flags, L.emu_sift_rowcnt):
         f.restype = C.c_void_p
         f.argtypes = [C.c_int, C.c_int]
@@ -77,6 +81,14 @@ def test_pyramid_planes_and_extremum_flags_equal_siftgpus(emu, w, h, seed, choic
             want[cand[:, 1].astype(int), cand[:, 0].astype(int)] = np.where(cand[:, 2] > 0, 1, -1)
             assert np.array_equal(flags, want), (o, j)
             assert np.array_equal(rowcnt, (want != 0).sum(1)), (o, j)
+            # the ordered list sift_row_scan_kernel + sift_key_emit_kernel make of the flags: the reference's raster order,
+            # sign and sub-pixel offsets bit for bit
+            rows = C.POINTER(C.c_float)()
+            n = emu.emu_sift_candidates(o, j, C.byref(rows))
+            assert n == len(cand), (o, j)
+            if n:
+                got_list = np.ctypeslib.as_array(rows, shape=(n, 6))
+                assert np.array_equal(got_list.view(np.uint32), np.ascontiguousarray(cand, np.float32).view(np.uint32)), (o, j)
             n_flags += len(cand)
     assert n_flags > 50   # the comparison is not vacuous
 
