@@ -1,7 +1,9 @@
 // sift_pyramid_kernels.h -- the shape-static device half of the SIFT extraction (sift_extract.hip includes it; so does the
 // CPU emulation of tests/emu/emu_sift.cpp, which runs these kernel SOURCES on the host against SiftGPU's own kernels):
-// image in, the x2 base, one Gaussian level per launch, the 2:1 decimation between octaves, the extremum flags.
-// Reference: external/SiftGPU/src/SiftGPU/ProgramCU.cu:113-640, PyramidCU.cpp:946-1066.
+// image in, the x2 base, one Gaussian level per launch, the 2:1 decimation between octaves, the extremum flags, the per-level
+// scan of the row counts and the ordered emit into the candidate lists -- with their launch chains (launch_pyramid,
+// launch_key_flags, launch_key_lists) and the extractor's geometry (SiftExtractor::plan_geometry / bind_levels / init_params).
+// Reference: external/SiftGPU/src/SiftGPU/ProgramCU.cu:113-688, PyramidCU.cpp:86-306, 738-850, 946-1066.
 #pragma once
 #include <math.h>
 #include <stdlib.h>
