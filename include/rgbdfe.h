@@ -528,10 +528,11 @@ int rgbdfe_detect_describe_batch(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_
 /* The same, and frame f's features also become the resident node node_ids[f] (>= 0; negative: no node for that frame) --
  * what Node::Node + GraphManager::addNode + rgbdfe_upload_node do, without the features' trip to the host and back: the
  * descriptors and points are copied into the node slabs from the description's device buffers (the host outputs are filled
- * as before).  A frame WITHOUT features registers nothing: a fresh id stays unknown (matching against it reports "not
- * resident", as for a node GraphManager never added), an id that exists keeps its old features.  An id that exists and gets
- * features is rewritten in place.  Capacity is checked for the whole batch before the first frame is detected, counting
- * every fresh id as one slot. */
+ * as before).  A frame WITHOUT features becomes an EMPTY node (n = 0), exactly what rgbdfe_upload_node(id, ..., 0)
+ * leaves: a fresh id takes a slot and is resident (a pair against it is matched and comes back without an edge), an id that
+ * exists is rewritten to n = 0 -- its old features are gone.  An id that exists and gets features is rewritten in place.
+ * Capacity is checked for the whole batch before the first frame is detected, counting every fresh id as one slot (empty
+ * frames consume theirs, so the count is exact). */
 int rgbdfe_detect_describe_batch_nodes(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t* const* gray,
                                        const uint8_t* const* mask, const float* const* depth, int32_t rows, int32_t cols,
                                        double fx, double fy, double cx, double cy, double depth_scaling, int32_t out_stride,

@@ -607,9 +607,9 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   const int max_kp = ctx->orb_max_keypoints;
   if (node_ids) {
     // all-or-nothing on capacity, like rgbdfe_upload_nodes: everything that can be refused is refused before the first
-    // frame is detected.  Every fresh id is counted as needing a slot -- how many features a frame has is not known before
-    // it is detected; a frame that ends up WITHOUT features registers nothing (a fresh id stays unknown, an existing node
-    // keeps its features), so the check can refuse a batch that would have fitted by exactly that many slots.
+    // frame is detected.  Every fresh id is counted as needing a slot: a frame that ends up WITHOUT features still becomes an
+    // (empty, n = 0) node -- a fresh id takes its slot, an existing node is rewritten to n = 0 (the end of this function) -- so
+    // the count is exact.
     if (max_kp > ctx->cfg.max_keypoints)
       return fail(ctx, RGBDFE_ERR_CAPACITY, "the detector's max_keypoints exceeds the context's max_keypoints (node rows)");
     bool overwrite = false;

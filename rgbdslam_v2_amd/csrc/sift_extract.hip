@@ -35,14 +35,50 @@ namespace rgbdfe {
 
 namespace {
 
-// ---- gradient of a Gaussian plane at an interior pixel (ComputeDOG_Kernel, ProgramCU.cu:466-473) -------------------------------
-__device__ __forceinline__ float2 grad_at(const float* __restrict__ G, int w, int px, int py) {
-  const int index = py * w + px;
-  const float vxn = G[index + 1], vxp = G[index - 1], vyp = G[index - w], vyn = G[index + w];
-  const float dx = vxn - vxp, dy = vyn - vyp;
-  const float grd = 0.5f * sqrtf(dx * dx + dy * dy);
-  const float rot = (grd == 0.0f ? 0.0f : atan2f(dy, dx));
-  return make_float2(grd, rot);
+constexpr float kPi = 3.14159265358979323846f;
+
+// ---- what the orientation and descriptor stages see of the image: central differences of a Gaussian plane ---------------------
+// (the reference keeps a gradient-magnitude and an angle plane per level, written by its DoG kernel, ProgramCU.cu:466-473;
+// here they are recomputed where they are read: half the difference vector's length, atan2 of it, 0 for a flat spot)
+struct PolarGradient { float len, dir; };
+__device__ __forceinline__ PolarGradient polar_gradient(const float* __restrict__ plane, int stride, int col, int row) {
+  const float* p = plane + (size_t)row * stride + col;
+  const float gh = p[1] - p[-1], gv = p[stride] - p[-stride];
+  PolarGradient r;
+  r.len = 0.5f * sqrtf(gh * gh + gv * gv);
+  r.dir = r.len == 0.0f ? 0.0f : atan2f(gv, gh);
+  return r;
+}
+
+// The same for the descriptor stage, whose outputs are continuous in the direction (a vote is SPLIT between the two nearest
+// direction bins, none is moved whole): hardware square root (1 ulp) and an arctangent of |error| < 3e-7 rad -- one
+// reciprocal, the octant folded to |t| <= tan(pi / 8) by (mn - mx) / (mn + mx), a four-term odd polynomial (the classic
+// single-precision minimax set for that interval) -- in a quarter of libm's instructions.  3e-7 rad is 4e-7 of a
+// direction bin; tests/test_gpu_sift_extract.py allows descriptors 1e-3.
+#ifndef RGBDFE_SIFT_DESC_LIBM
+#define RGBDFE_SIFT_DESC_LIBM 0   // 1: libm's sqrtf / atan2f / expf in the descriptor kernel (A/B: tools/sift_extract_ab.sh)
+#endif
+__device__ __forceinline__ PolarGradient polar_gradient_quick(const float* __restrict__ plane, int stride, int col, int row) {
+#if RGBDFE_SIFT_DESC_LIBM
+  return polar_gradient(plane, stride, col, row);
+#else
+  const float* p = plane + (size_t)row * stride + col;
+  const float gh = p[1] - p[-1], gv = p[stride] - p[-stride];
+  PolarGradient r;
+  r.len = 0.5f * __builtin_amdgcn_sqrtf(gh * gh + gv * gv);
+  const float ah = fabsf(gh), av = fabsf(gv);
+  const float mn = fminf(ah, av), mx = fmaxf(ah, av);
+  const bool upper = mn > 0.41421356f * mx;               // beyond pi / 8: measure from the diagonal instead
+  const float t = (upper ? mn - mx : mn) * __builtin_amdgcn_rcpf(upper ? mn + mx : mx);
+  const float t2 = t * t;
+  float ang = ((((8.05374449538e-2f * t2 - 1.38776856032e-1f) * t2 + 1.99777106478e-1f) * t2 - 3.33329491539e-1f) * t2) * t + t;
+  ang += upper ? 0.25f * kPi : 0.0f;
+  ang = av > ah ? 0.5f * kPi - ang : ang;                 // first octant pair -> first quadrant
+  ang = gh < 0.0f ? kPi - ang : ang;
+  ang = gv < 0.0f ? -ang : ang;
+  r.dir = mx == 0.0f ? 0.0f : ang;
+  return r;
+#endif
 }
 
 struct LevelJobs {  // the kept levels of a frame: consecutive segments of the work list
@@ -55,214 +91,210 @@ struct LevelJobs {  // the kept levels of a frame: consecutive segments of the w
   float sigma[64];
 };
 
-// ComputeOrientation_Kernel (ProgramCU.cu:774-935), num_orientation = 2, sub-pixel on, no existing keypoints.
-// The reference runs one THREAD per keypoint through a few hundred samples (gradient + atan2 + exp each): a few dozen
-// long waves on a 256-CU chip.  Here a WAVE owns a keypoint: the samples of its window go round-robin (raster order) over
-// the 64 lanes, each lane adds into its own column of a [36 bins][64 lanes] LDS histogram (no atomics: deterministic), 36
-// lanes then sum their bin's 64 partials in lane order, the 6 smoothing passes are circular 3-tap filters across lanes
-// (the reference's in-place loop reads only old values: `one_third * ((pre + v) + next)`, same association), and the
-// two-peak selection is the reference's sequential scan on wave-uniform scalars.  Only the ORDER of the weight sums
-// differs from the reference (per-lane partial sums): ~1e-7 relative, far inside the libm tolerance of this stage.
+// the segment an item lies in: lane l holds begin[l + 1]; the segments at or before the item are a ballot's popcount
+__device__ __forceinline__ int segment_of(const LevelJobs& jobs, int item, int lane) {
+  const bool before = lane + 1 < jobs.n && item >= jobs.begin[lane + 1];
+  return __popcll(__ballot(before));
+}
+
+// The pixel-centre window both stages scan around a point: every pixel whose centre (index + 0.5) lies within `reach` of the
+// point (by the floor of the window's edges, as the reference's loops run), kept one pixel off the plane's border so that
+// the central differences exist.
+struct Window { int c0, r0, cols, rows; };
+__device__ __forceinline__ Window window_around(float cx, float cy, float reach, int width, int height) {
+  Window wd;
+  wd.c0 = max(1, (int)floorf(cx - reach));
+  wd.r0 = max(1, (int)floorf(cy - reach));
+  wd.cols = max(0, min(width - 2, (int)floorf(cx + reach)) - wd.c0 + 1);
+  wd.rows = max(0, min(height - 2, (int)floorf(cy + reach)) - wd.r0 + 1);
+  return wd;
+}
+
+__device__ __forceinline__ float lane_value(float v, int src) { return __shfl(v, src); }
+
+// The descriptor stage sums its votes in FIXED POINT: a non-negative vote becomes round(vote * 2^k) and goes into a 32-bit LDS
+// counter by ds_add_u32.  Two reasons.  Integer sums do not depend on the order of the additions, so every histogram is the
+// same bit pattern on every run and for every dealing of pixels to lanes, by construction.  And the LDS adds integers at the
+// rate it writes, whereas ds_add_f32 was measured at ~35 cycles per wave instruction whatever the collisions (descriptor kernel
+// 52 us per VGA frame with float adds, 18 with integer ones: profiles/r06_logs/sift_descriptor_forms.txt).  k is chosen per
+// feature from a bound of the largest possible sum (gradient length <= 0.7072 for planes in [0, 1], weights <= 1): the
+// counters cannot wrap, the grid is 2^-31 of that bound (~1e-7 absolute for a typical feature, where votes are 1e-3 .. 1).
+// (The ORIENTATION stage keeps float sums: its peak tests are strict comparisons of neighbouring bins, and on mirror-symmetric
+// patterns exact sums produce exact ties -- no peak at all -- where the reference's float rounding leaves one bin ahead:
+// tests/test_gpu_sift_extract.py, the 0 / 255 block pattern, lost 0.7 % of its orientations to that.)
+__device__ __forceinline__ float fixed_point_scale(float sum_bound) {   // the power of two with sum_bound * scale < 2^31
+  int e;
+  (void)frexpf(sum_bound, &e);                                          // sum_bound < 2^e
+  return ldexpf(1.0f, 31 - e);
+}
+__device__ __forceinline__ void vote(unsigned* counter, float v) { atomicAdd(counter, (unsigned)rintf(v)); }
+
+// ---- orientation assignment: what SiftGPU's ComputeOrientation_Kernel computes (ProgramCU.cu:774-935 with num_orientation = 2,
+//      sub-pixel positions, detected keypoints), organised for a 64-wide wave ------------------------------------------------------
+// One wave per keypoint candidate.
+//   votes   the window's pixels are dealt to the lanes in raster order; a pixel inside the disc adds its gradient length, damped
+//           by a Gaussian of the distance, to one of 36 direction bins -- each lane into its own column of a [36][64 + 1] LDS
+//           array (plain read-add-write, no atomics); lane b < 36 then adds bin b's 64 partial sums in lane order: one fixed
+//           order of float additions whatever the hardware does
+//   smooth  lanes 0 .. 35 hold a bin each; six circular box filters are lane rotations
+//   peaks   a ballot of the local maxima above 0.8 of the largest bin; the strongest and the runner-up by two wave-wide
+//           arg-max reductions (the lower bin wins a tie, as a first-come scan would have it); each peak's position is refined
+//           by the parabola through its neighbours and leaves as a 16-bit fraction of a turn, 0xFFFF = no such peak
+constexpr int kDirBins = 36;
 __global__ __launch_bounds__(64) void sift_orientation_kernel(const LevelJobs* __restrict__ jobs_of_frame,
                                                               const float* __restrict__ cand, float4* __restrict__ feat,
-                                                              float sigma_step, float gaussian_factor, float sample_factor) {
-  __shared__ float hist[36][64];
-  const float ten_degree_per_radius = 5.7295779513082320876798154814105;
+                                                              float level_ratio, float damping_scales, float disc_scales) {
+  __shared__ float column[kDirBins][64 + 1];   // + 1: bin b's row starts in bank b, the final sums read 36 banks at a time
   const LevelJobs& jobs = jobs_of_frame[blockIdx.y];
-  const int idx = blockIdx.x;
-  if (idx >= jobs.begin[jobs.n]) return;   // the grid is sized for the batch's largest frame
+  const int item = blockIdx.x;
+  if (item >= jobs.begin[jobs.n]) return;   // the grid is sized for the batch's largest frame
   const int lane = threadIdx.x;
-  int s = 0;
-  while (s + 1 < jobs.n && idx >= jobs.begin[s + 1]) ++s;
-  const int k = idx - jobs.begin[s];
-  const float* c = cand + (size_t)(jobs.src_off[s] + k) * 6;
-  const int width = jobs.w[s], height = jobs.h[s];
-  const float* __restrict__ G = jobs.g[s];
-  float4 key;
-  key.x = c[0] + 0.5f;
-  key.y = c[1] + 0.5f;
-  key.z = jobs.sigma[s];
-  key.x += c[3];
-  key.y += c[4];
-  key.z *= powf(sigma_step, c[5]);
-  const float gsigma = key.z * gaussian_factor;
-  const float win = fabsf(key.z) * sample_factor;
-  const float dist_threshold = (float)((double)(win * win) + 0.5);
-  const float factor = -0.5f / (gsigma * gsigma);
-  const float xmin = fmaxf(1.5f, floorf(key.x - win) + 0.5f);
-  const float ymin = fmaxf(1.5f, floorf(key.y - win) + 0.5f);
-  const float xmax = fminf(width - 1.5f, floorf(key.x + win) + 0.5f);
-  const float ymax = fminf(height - 1.5f, floorf(key.y + win) + 0.5f);
-  const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;   // iterations of `for (x = xmin; x <= xmax; x += 1.0f)`
-  const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
+  const int seg = segment_of(jobs, item, lane);
+  const float* rec = cand + (size_t)(jobs.src_off[seg] + item - jobs.begin[seg]) * 6;   // column, row, sign, d_col, d_row, d_level
+  const float* __restrict__ plane = jobs.g[seg];
+  const int stride = jobs.w[seg];
+  // the refined keypoint in pixel-centre coordinates and its scale between the levels
+  const float cx = (rec[0] + 0.5f) + rec[3], cy = (rec[1] + 0.5f) + rec[4];
+  const float scale = jobs.sigma[seg] * powf(level_ratio, rec[5]);
+  const float disc = fabsf(scale) * disc_scales;
+  const float disc2 = disc * disc + 0.5f;
+  const float spread = scale * damping_scales;
+  const float damp = -0.5f / (spread * spread);
+  const Window wd = window_around(cx, cy, disc, stride, jobs.h[seg]);
 #pragma unroll
-  for (int b = 0; b < 36; ++b) hist[b][lane] = 0.0f;
-  const int total = nx * ny;
-  for (int t = lane; t < total; t += 64) {
-    const int iy = t / nx, ix = t - iy * nx;
-    const float x = xmin + (float)ix, y = ymin + (float)iy;
-    const float dx = x - key.x;
-    const float dy = y - key.y;
-    const float sq_dist = dx * dx + dy * dy;
-    if (sq_dist >= dist_threshold) continue;
-    const float2 got = grad_at(G, width, (int)floorf(x), (int)floorf(y));
-    const float weight = got.x * expf(sq_dist * factor);
-    const float fidx = floorf(got.y * ten_degree_per_radius);
-    int oidx = (int)fidx;
-    if (oidx < 0) oidx += 36;
-    hist[oidx][lane] += weight;
+  for (int b = 0; b < kDirBins; ++b) column[b][lane] = 0.0f;
+  const int pixels = wd.cols * wd.rows;
+  const float per_col = 1.0f / (float)max(wd.cols, 1);
+  for (int t = lane; t < pixels; t += 64) {
+    // row = t / cols through the reciprocal: (t + 0.5) / cols is at least 0.5 / cols away from an integer and t, cols < 2^12
+    // here, so the rounding of the product cannot cross one
+    const int r = (int)(((float)t + 0.5f) * per_col), c = t - r * wd.cols;
+    const float ox = ((float)(wd.c0 + c) + 0.5f) - cx, oy = ((float)(wd.r0 + r) + 0.5f) - cy;
+    const float d2 = ox * ox + oy * oy;
+    if (d2 >= disc2) continue;
+    const PolarGradient g = polar_gradient(plane, stride, wd.c0 + c, wd.r0 + r);
+    int bin = (int)floorf(g.dir * (18.0f / kPi));   // ten degrees per bin, -pi .. pi -> -18 .. 18
+    bin += bin < 0 ? kDirBins : 0;
+    column[bin][lane] += g.len * expf(d2 * damp);
   }
   __syncthreads();
+  const bool owner = lane < kDirBins;
   float v = 0.0f;
-  if (lane < 36)
-    for (int l = 0; l < 64; ++l) v += hist[lane][l];
-  const int lp = lane < 36 ? (lane + 35) % 36 : lane, ln = lane < 36 ? (lane + 1) % 36 : lane;
-  const float one_third = 1.0 / 3.0;
-  for (int i = 0; i < 6; ++i) {
-    const float pre = __shfl(v, lp), next = __shfl(v, ln);
-    v = one_third * (pre + v + next);
-  }
-  float max_vote = lane < 36 ? v : -1.0f;
-  for (int d = 32; d >= 1; d >>= 1) max_vote = fmaxf(max_vote, __shfl_xor(max_vote, d));
-  const float vote_threshold = max_vote * 0.8f;
-  const float pre = __shfl(v, lp), next = __shfl(v, ln);
-  const bool peak = lane < 36 && v > vote_threshold && v > pre && v > next;
-  const float di = 0.5f * ((next - pre) / (v + v - next - pre));
-  const float rot = lane + di + 0.5f;
-  const uint64_t peaks = __ballot(peak);
-  float max_rot[2] = {0.f, 0.f}, max_vot[2] = {0.f, 0.f};
-  int ocount = 0;
+  if (owner)
+    for (int l = 0; l < 64; ++l) v += column[lane][l];
+  const int left = owner ? (lane == 0 ? kDirBins - 1 : lane - 1) : lane;
+  const int right = owner ? (lane == kDirBins - 1 ? 0 : lane + 1) : lane;
+  const float third = 1.0 / 3.0;
+  for (int pass = 0; pass < 6; ++pass) v = third * ((lane_value(v, left) + v) + lane_value(v, right));
+  float top = owner ? v : -1.0f;
+  for (int d = 32; d >= 1; d >>= 1) top = fmaxf(top, __shfl_xor(top, d));
+  const float vl = lane_value(v, left), vr = lane_value(v, right);
+  uint64_t peaks = __ballot(owner && v > 0.8f * top && v > vl && v > vr);
+  // this bin's refined direction as a fraction of a turn, quantised (only read from peak lanes)
+  float turn = ((float)lane + 0.5f * ((vr - vl) / (v + v - vr - vl)) + 0.5f) / (float)kDirBins;
+  turn += turn < 0.0f ? 1.0f : 0.0f;
+  const float quantised = floorf(turn * 65535.0f);
+  unsigned code[2] = {0xFFFFu, 0xFFFFu};
 #pragma unroll
-  for (int i = 0; i < 36; ++i) {   // the reference's scan, on wave-uniform values
-    if (!((peaks >> i) & 1)) continue;
-    const float weight = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
-    const float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rot), i));
-    if (weight > max_vot[1]) {
-      if (weight > max_vot[0]) {
-        max_vot[1] = max_vot[0]; max_rot[1] = max_rot[0];
-        max_vot[0] = weight; max_rot[0] = r;
-      } else {
-        max_vot[1] = weight; max_rot[1] = r;
-      }
-      ocount++;
-    }
+  for (int rank = 0; rank < 2; ++rank) {
+    if (peaks == 0) break;
+    const bool in = (peaks >> lane) & 1;
+    float best = in ? v : -1.0f;
+    for (int d = 32; d >= 1; d >>= 1) best = fmaxf(best, __shfl_xor(best, d));
+    const int who = __builtin_ctzll(__ballot(in && v == best));
+    code[rank] = (unsigned)lane_value(quantised, who) & 0xFFFFu;
+    peaks &= ~(1ull << who);
   }
-  if (lane != 0) return;
-  float fr1 = max_rot[0] / 36.0f;
-  if (fr1 < 0) fr1 += 1.0f;
-  const unsigned short us1 = ocount == 0 ? 65535 : ((unsigned short)floorf(fr1 * 65535.0f));
-  unsigned short us2 = 65535;
-  if (ocount > 1) {
-    float fr2 = max_rot[1] / 36.0f;
-    if (fr2 < 0) fr2 += 1.0f;
-    us2 = (unsigned short)floorf(fr2 * 65535.0f);
-  }
-  const unsigned int uspack = ((unsigned int)us2 << 16) | us1;
-  key.w = __uint_as_float(uspack);
-  feat[jobs.base + idx] = key;
+  if (lane == 0) feat[jobs.base + item] = make_float4(cx, cy, scale, __uint_as_float(code[0] | (code[1] << 16)));
 }
 
-// ComputeDescriptor_Kernel<false> (ProgramCU.cu:967-1046).  The reference gives each of a feature's 16 cells one thread;
-// here a cell gets a WAVE: the samples of the cell's bounding box go round-robin over the lanes, every lane keeps its own
-// 8 + 1 bins in registers (the reference's compare-and-add over k, so no dynamic indexing), a fixed butterfly sums the
-// lanes.  Per-sample arithmetic is the reference's; only the order of the sums differs (see the orientation kernel).
-// (Round 5 tried a workgroup per feature that evaluates the gradients of the whole 4 x 4 window once into LDS -- a pixel
-// lies in up to four cells' supports -- and lets the cells read them: bit-identical output, but 43 instead of 37 us per VGA
-// frame.  The window's bounding box holds 1.6 x the pixels the cells' rotated supports cover, and 51 KB of LDS left 12
-// waves per CU for a loop that lives on latency hiding: profiles/r05_logs/sift_descriptor_staged.txt.)
-// the wave's sum of v, valid in lane 63 (rows of 16 by row_shr 1, 2, 4, 8; then row 0 -> 1, 2 -> 3 and 1 -> 2, 3)
-#define SIFT_DPP_F32(x, ctrl, rows, bound) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rows, 0xF, bound))
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v += SIFT_DPP_F32(v, 0x111, 0xF, true);    // row_shr:1
-  v += SIFT_DPP_F32(v, 0x112, 0xF, true);    // row_shr:2
-  v += SIFT_DPP_F32(v, 0x114, 0xF, true);    // row_shr:4
-  v += SIFT_DPP_F32(v, 0x118, 0xF, true);    // row_shr:8
-  v += SIFT_DPP_F32(v, 0x142, 0xA, false);   // row_bcast:15 into rows 1 and 3
-  v += SIFT_DPP_F32(v, 0x143, 0xC, false);   // row_bcast:31 into rows 2 and 3
-  return v;
-}
-#undef SIFT_DPP_F32
-
-__global__ __launch_bounds__(256) void sift_descriptor_kernel(const LevelJobs* __restrict__ jobs_of_frame,
-                                                              const float4* __restrict__ feat, float4* __restrict__ d_des,
-                                                              float window_factor) {
-  const float rpi = 4.0 / 3.14159265358979323846;
+// ---- descriptors: what SiftGPU's ComputeDescriptor_Kernel<false> computes (ProgramCU.cu:967-1046, "-unn": raw histograms),
+//      turned inside out ---------------------------------------------------------------------------------------------------------------
+// The reference runs a thread per (feature, cell): each of the 16 cells walks the pixels of its own rotated 2 x 2-cell
+// support, so a pixel's gradient (4 loads, a square root, an atan2) is evaluated by up to four cells, and the cell keeps 8 bins.
+// Here a WAVE owns a feature and walks the feature's whole 5 x 5-cell support ONCE: a pixel is taken into the feature's
+// frame -- (a, b) = M (pixel - feature) with the 2 x 2 matrix M = rotation / cell size, direction o relative to the
+// feature's in units of 45 degrees -- and its vote, gradient length x Gaussian of the frame distance, is split trilinearly:
+// (1 - fa, fa) x (1 - fb, fb) over the four cells around (a, b) that exist, (1 - fo, fo) over the two directions around o:
+// eight ds_add_u32 into this wave's LDS histogram (fixed point, see above).  That is the same sum as the reference's:
+// cell (i, j) there collects exactly the pixels with |a - i| < 1 and |b - j| < 1, weighted (1 - |a - i|)(1 - |b - j|).
+// The wave then writes its 512 bytes of histogram in one coalesced store.  Per feature 25 instead of 64 cell areas of
+// gradient evaluations, one wave prologue instead of 16.  Measured per VGA frame (~1550 features): 35 us for round 5's
+// wave-per-cell kernel -> 18 us (libm) -> see profiles/r06_logs/sift_descriptor_forms.txt for the quick-math figure.
+constexpr int kDescBins = 128;   // 4 x 4 cells x 8 directions
+#ifndef RGBDFE_SIFT_DESC_COPIES
+#define RGBDFE_SIFT_DESC_COPIES 4
+#endif
+// Neighbouring pixels mostly vote for the same (cell, direction).  The wave keeps kCopies interleaved histograms, lane l
+// adding to copy l mod kCopies at [bin][copy]: fewer lanes of one instruction meet in a counter (measured 20.3 us with one
+// copy, 18.2 with four, per VGA frame).
+constexpr int kCopies = RGBDFE_SIFT_DESC_COPIES;
+__global__ __launch_bounds__(64) void sift_descriptor_kernel(const LevelJobs* __restrict__ jobs_of_frame,
+                                                             const float4* __restrict__ feat, float2* __restrict__ out,
+                                                             float cell_scales) {
+  __shared__ unsigned hist[kDescBins * kCopies];
   const LevelJobs& jobs = jobs_of_frame[blockIdx.y];
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // feature * 16 + cell: four cells (waves) per workgroup
-  const int lane = threadIdx.x & 63;
-  const int fidx = idx >> 4;
-  if (fidx >= jobs.begin[jobs.n]) return;
-  int s = 0;
-  while (s + 1 < jobs.n && fidx >= jobs.begin[s + 1]) ++s;
-  const int width = jobs.w[s], height = jobs.h[s];
-  const float* __restrict__ G = jobs.g[s];
-  const float4 key = feat[jobs.base + fidx];
-  const int bidx = idx & 0xf, ix = bidx & 0x3, iy = bidx >> 2;
-  const float spt = fabsf(key.z * window_factor);
+  const int item = blockIdx.x;
+  if (item >= jobs.begin[jobs.n]) return;
+  const int lane = threadIdx.x;
+  const int seg = segment_of(jobs, item, lane);
+  const float* __restrict__ plane = jobs.g[seg];
+  const int stride = jobs.w[seg];
+  const float4 f = feat[jobs.base + item];          // column, row, scale, direction in [0, 2 pi)
+  const float cell = fabsf(f.z * cell_scales);      // a cell's side in pixels of this level
   float sn, cs;
-  sincosf(key.w, &sn, &cs);
-  const float anglef = key.w > 3.14159265358979323846 ? (float)((double)key.w - (2.0 * 3.14159265358979323846)) : key.w;
-  const float cspt = cs * spt, sspt = sn * spt;
-  const float crspt = cs / spt, srspt = sn / spt;
-  float2 offsetpt, pt;
-  offsetpt.x = ix - 1.5f;
-  offsetpt.y = iy - 1.5f;
-  pt.x = cspt * offsetpt.x - sspt * offsetpt.y + key.x;
-  pt.y = cspt * offsetpt.y + sspt * offsetpt.x + key.y;
-  const float bsz = fabsf(cspt) + fabsf(sspt);
-  const float xmin = fmaxf(1.5f, floorf(pt.x - bsz) + 0.5f);
-  const float ymin = fmaxf(1.5f, floorf(pt.y - bsz) + 0.5f);
-  const float xmax = fminf(width - 1.5f, floorf(pt.x + bsz) + 0.5f);
-  const float ymax = fminf(height - 1.5f, floorf(pt.y + bsz) + 0.5f);
-  const int nx = xmax >= xmin ? (int)(xmax - xmin) + 1 : 0;
-  const int ny = ymax >= ymin ? (int)(ymax - ymin) + 1 : 0;
-  float des[9];
+  sincosf(f.w, &sn, &cs);
+  const float facing = f.w > kPi ? f.w - 2.0f * kPi : f.w;
+  const float m_c = cs / cell, m_s = sn / cell;     // M = [m_c m_s; -m_s m_c]
+  // the support |a|, |b| < 2.5 is a rotated square; its bounding box in the image
+  const Window wd = window_around(f.x, f.y, 2.5f * cell * (fabsf(cs) + fabsf(sn)), stride, jobs.h[seg]);
+  // a bin's sum: at most 0.7072 x the lattice sum of a cell's tent weights, which is about cell^2 and below (cell + 1)^2
+  const float to_fixed = fixed_point_scale((cell + 2.0f) * (cell + 2.0f));
 #pragma unroll
-  for (int i = 0; i < 9; ++i) des[i] = 0.0f;
-  const int total = nx * ny;
-  const float rnx = 1.0f / (float)nx;   // jy = t / nx through the reciprocal: (t + 0.5) / nx is at least 0.5 / nx away from
-                                        // an integer and t, nx < 2^12 here, so the rounding of the product cannot cross one
-  for (int t = lane; t < total; t += 64) {
-    const int jy = (int)(((float)t + 0.5f) * rnx), jx = t - jy * nx;
-    const float x = xmin + (float)jx, y = ymin + (float)jy;
-    const float dx = x - pt.x;
-    const float dy = y - pt.y;
-    const float nxf = crspt * dx + srspt * dy;
-    const float nyf = crspt * dy - srspt * dx;
-    const float nxn = fabsf(nxf);
-    const float nyn = fabsf(nyf);
-    if (nxn < 1.0f && nyn < 1.0f) {
-      const float2 cc = grad_at(G, width, (int)floorf(x), (int)floorf(y));
-      const float dnx = nxf + offsetpt.x;
-      const float dny = nyf + offsetpt.y;
-      const float ww = expf(-0.125f * (dnx * dnx + dny * dny));
-      const float wx = (float)(1.0 - (double)nxn);
-      const float wy = (float)(1.0 - (double)nyn);
-      const float weight = ww * wx * wy * cc.x;
-      float theta = (anglef - cc.y) * rpi;
-      if (theta < 0) theta += 8.0f;
-      const float fo = floorf(theta);
-      const int fi = (int)fo;
-      const float weight1 = fo + 1.0f - theta;
-      const float weight2 = theta - fo;
+  for (int i = 0; i < kDescBins * kCopies / 64; ++i) hist[i * 64 + lane] = 0u;
+  __syncthreads();
+  unsigned* mine = hist + (lane & (kCopies - 1));
+  const int pixels = wd.cols * wd.rows;
+  const float per_col = 1.0f / (float)max(wd.cols, 1);
+  for (int t = lane; t < pixels; t += 64) {
+    const int r = (int)(((float)t + 0.5f) * per_col), c = t - r * wd.cols;   // see the orientation kernel
+    const float ox = ((float)(wd.c0 + c) + 0.5f) - f.x, oy = ((float)(wd.r0 + r) + 0.5f) - f.y;
+    const float a = m_c * ox + m_s * oy, b = m_c * oy - m_s * ox;
+    if (!(fabsf(a) < 2.5f && fabsf(b) < 2.5f)) continue;
+    const PolarGradient g = polar_gradient_quick(plane, stride, wd.c0 + c, wd.r0 + r);
+#if RGBDFE_SIFT_DESC_LIBM
+    const float weight = g.len * expf(-0.125f * (a * a + b * b)) * to_fixed;
+#else
+    const float weight = g.len * __builtin_amdgcn_exp2f((-0.125f * 1.44269504f) * (a * a + b * b)) * to_fixed;
+#endif
+    // cells sit at -1.5, -0.5, 0.5, 1.5: the lower neighbour's index and the distance past it
+    const float ai = floorf(a + 1.5f), bi = floorf(b + 1.5f);
+    const float fa = (a + 1.5f) - ai, fb = (b + 1.5f) - bi;
+    const int ia = (int)ai, ib = (int)bi;            // -1 .. 3
+    float o = (facing - g.dir) * (4.0f / kPi);
+    o += o < 0.0f ? 8.0f : 0.0f;
+    const float oi = floorf(o);
+    const float fo = o - oi;
+    const int d0 = (int)oi & 7, d1 = ((int)oi + 1) & 7;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k == fi) {
-          des[k] += (weight1 * weight);
-          des[k + 1] += (weight2 * weight);
-        }
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int ja = ia + (q & 1), jb = ib + (q >> 1);
+      if ((unsigned)ja > 3u || (unsigned)jb > 3u) continue;
+      const float share = weight * ((q & 1) ? fa : 1.0f - fa) * ((q >> 1) ? fb : 1.0f - fb);
+      unsigned* cell_bins = mine + (jb * 4 + ja) * 8 * kCopies;
+      vote(cell_bins + d0 * kCopies, share * (1.0f - fo));
+      vote(cell_bins + d1 * kCopies, share * fo);
     }
   }
-  // the lanes' bins -> lane 63: four row_shr steps inside the rows of 16, then the rows' totals across (DPP adds: no LDS
-  // round trip per step, as the xor butterfly of rounds 3 - 4 had -- a fifth of the kernel's instructions).  A fixed order.
+  __syncthreads();
+  // the copies of a bin added up (integers: any order), back to float; the wave's 512 bytes leave in one store
+  unsigned even = 0u, odd = 0u;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) des[i] = wave_sum_to_lane63(des[i]);
-  if (lane != 63) return;
-  des[0] += des[8];
-  const int didx = (jobs.base * 16 + idx) << 1;
-  d_des[didx] = make_float4(des[0], des[1], des[2], des[3]);
-  d_des[didx + 1] = make_float4(des[4], des[5], des[6], des[7]);
+  for (int k = 0; k < kCopies; ++k) {
+    even += hist[(2 * lane) * kCopies + k];
+    odd += hist[(2 * lane + 1) * kCopies + k];
+  }
+  out[(size_t)(jobs.base + item) * (kDescBins / 2) + lane] = make_float2((float)even / to_fixed, (float)odd / to_fixed);
 }
 
 #define SIFT_HIP(expr)                                                                    \
@@ -627,8 +659,8 @@ int SiftExtractor::finish_descriptors(hipStream_t s, std::string& err) {
   }
   SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)grand2 * 16, hipMemcpyHostToDevice, s));
   SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(max_total2 * 4, NF), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
-                     (float4*)d_desc, 3.0f);
+  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(max_total2, NF), dim3(64), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
+                     (float2*)d_desc, 3.0f);
   SIFT_HIP(hipGetLastError());
   if ((size_t)grand2 * 128 > h_desc_cap) {
     if (h_desc) (void)hipHostFree(h_desc);
@@ -731,8 +763,8 @@ int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftK
     memcpy(h_stage, list.data(), (size_t)total * 16);
     SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)total * 16, hipMemcpyHostToDevice, s));
     SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(sift_descriptor_kernel, dim3(total * 4, 1), dim3(256), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
-                       (float4*)d_desc, 3.0f);
+    hipLaunchKernelGGL(sift_descriptor_kernel, dim3(total, 1), dim3(64), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
+                       (float2*)d_desc, 3.0f);
     SIFT_HIP(hipGetLastError());
     SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));
     SIFT_HIP(hipStreamSynchronize(s));
