@@ -15,11 +15,12 @@
 //     an ordered ballot compaction (scan + emit) replaces the reference's 4-ary histogram pyramid and yields the same
 //     raster-ordered lists; the orientation and descriptor kernels take gradients from the Gaussian plane on the fly
 //     (same differences, sqrt, atan2) -- the 45 floats per pixel the reference keeps shrink to 8;
-//   * a keypoint's orientation histogram and each of its 16 descriptor cells are wave-wide jobs (the reference gives each
-//     one thread); per-sample arithmetic is the reference's, the sums run lane-parallel in a fixed order.
+//   * a keypoint's orientation histogram is a wave-wide job (the reference gives it one thread), and so is a whole
+//     DESCRIPTOR: the wave walks the feature's 5 x 5-cell support once and splits each pixel's vote over the cells and
+//     directions around it (the reference walks every cell's own support, a pixel up to four times) -- see the two kernels.
 // Arithmetic without transcendental functions (pyramid, extrema, sub-pixel offsets, lists) is exact against the
-// reference's kernels compiled on the CPU emulation (oracle/_ref/libref_siftgpu.so); exp / atan2 / pow / sincos come
-// from the device's libm and differ from glibc's by ulps: tests/test_gpu_sift_extract.py states the tolerances.
+// reference's kernels compiled on the CPU emulation (oracle/_ref/libref_siftgpu.so); orientations and descriptors involve
+// exp / atan2 / pow / sincos and a different order of summation: tests/test_gpu_sift_extract.py states the tolerances.
 #include "sift_extract.h"
 
 #include <math.h>
@@ -97,7 +98,7 @@ __device__ __forceinline__ int segment_of(const LevelJobs& jobs, int item, int l
   return __popcll(__ballot(before));
 }
 
-// The pixel-centre window both stages scan around a point: every pixel whose centre (index + 0.5) lies within `reach` of the
+// The pixel-centre window both stages scan around a point: every pixel whose centre (caller_row + 0.5) lies within `reach` of the
 // point (by the floor of the window's edges, as the reference's loops run), kept one pixel off the plane's border so that
 // the central differences exist.
 struct Window { int c0, r0, cols, rows; };
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const LevelJobs* __
 #else
     const float weight = g.len * __builtin_amdgcn_exp2f((-0.125f * 1.44269504f) * (a * a + b * b)) * to_fixed;
 #endif
-    // cells sit at -1.5, -0.5, 0.5, 1.5: the lower neighbour's index and the distance past it
+    // cells sit at -1.5, -0.5, 0.5, 1.5: the lower neighbour's caller_row and the distance past it
     const float ai = floorf(a + 1.5f), bi = floorf(b + 1.5f);
     const float fa = (a + 1.5f) - ai, fb = (b + 1.5f) - bi;
     const int ia = (int)ai, ib = (int)bi;            // -1 .. 3
@@ -583,8 +584,8 @@ int SiftExtractor::finish_descriptors(hipStream_t s, std::string& err) {
   };
   SIFT_HIP(hipStreamSynchronize(s));
   // ---- ReshapeFeatureListCPU (PyramidCU.cpp:501-585, NO_DUPLICATE_DOWNLOAD) + LimitFeatureCount(1), per frame ------------------
-  const double twopi = 2.0 * 3.14159265358979323846;
-  const double factor = 2.0 * 3.14159265358979323846 / 65535.0;
+  const double full_turn = 2.0 * 3.14159265358979323846;
+  const double rad_per_code = 2.0 * 3.14159265358979323846 / 65535.0;
   const float os = octave_min >= 0 ? float(1 << octave_min) : 1.0f / (1 << (-octave_min));
   int grand2 = 0, max_total2 = 0;
   for (int f = 0; f < nf; ++f) {
@@ -598,27 +599,27 @@ int SiftExtractor::finish_descriptors(hipStream_t s, std::string& err) {
       if (F.level_num[(size_t)idx] <= 0) continue;
       const float* src = h_stage + ((size_t)F.base + jobs.begin[seg]) * 4;
       const int cnt = F.level_num[(size_t)idx];
-      int fcount = 0;
+      int kept = 0;
       const float oss = os * (1 << (idx / kDogLevels));
       for (int k = 0; k < cnt; ++k, src += 4) {
         unsigned short orientations[2];
         memcpy(orientations, &src[3], 4);
         auto push = [&](unsigned short o) {
-          const float fo = float(factor * o);
+          const float fo = float(rad_per_code * o);
           F.list.push_back(src[0]); F.list.push_back(src[1]); F.list.push_back(src[2]); F.list.push_back(fo);
           F.keybuf.push_back(oss * (src[0] - 0.5f) + 0.5f);
           F.keybuf.push_back(oss * (src[1] - 0.5f) + 0.5f);
           F.keybuf.push_back(oss * src[2]);
-          F.keybuf.push_back((float)fmod(twopi - fo, twopi));
-          fcount++;
+          F.keybuf.push_back((float)fmod(full_turn - fo, full_turn));
+          kept++;
         };
         if (orientations[0] != 65535) {
           push(orientations[0]);
           if (orientations[1] != 65535 && orientations[1] != orientations[0]) push(orientations[1]);
         }
       }
-      F.level_num[(size_t)idx] = fcount;
-      F.feature_num += fcount;
+      F.level_num[(size_t)idx] = kept;
+      F.feature_num += kept;
       ++seg;
     }
     F.erased = limit(F);
@@ -704,12 +705,12 @@ int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftK
   rc = enqueue_pyramid(&gray, 1, s, err);
   if (rc != RGBDFE_OK) return rc;
   const int nlv = octave_num * kDogLevels;
-  const double twopi = 2.0 * 3.14159265358979323846;
+  const double full_turn = 2.0 * 3.14159265358979323846;
   const float sigma_half_step = powf(2.0f, 0.5f / kDogLevels);
   float octave_sigma = octave_min >= 0 ? float(1 << octave_min) : 1.0f / (1 << (-octave_min));
   const float offset = 0.5f;   // GlobalUtil::_LoweOrigin = 0
   std::vector<float> list;     // level coordinates, level by level
-  std::vector<int> index;      // _keypoint_index: the input position of every list entry
+  std::vector<int> caller_row;      // _keypoint_index: the input position of every list entry
   LevelJobs* dj = static_cast<LevelJobs*>(h_jobs);
   memset(dj, 0, sizeof(LevelJobs));
   int total = 0;
@@ -717,7 +718,7 @@ int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftK
     for (int j = 0; j < kDogLevels; ++j) {
       const float level_sg = level_sigma(j) * octave_sigma;   // GetLevelSigma(j + level_min + 1)
       const float sigma_min = level_sg / sigma_half_step, sigma_max = level_sg * sigma_half_step;
-      int fcount = 0;
+      int kept = 0;
       for (int k = 0; k < n; ++k) {
         const float sigmak = keys_in[k].s;
         if ((sigmak >= sigma_min && sigmak < sigma_max) || (sigmak < sigma_min && i == 0 && j == 0) ||
@@ -725,17 +726,17 @@ int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftK
           list.push_back((keys_in[k].x - offset) / octave_sigma + 0.5f);
           list.push_back((keys_in[k].y - offset) / octave_sigma + 0.5f);
           list.push_back(keys_in[k].s / octave_sigma);
-          list.push_back((float)fmod(twopi - keys_in[k].o, twopi));
-          index.push_back(k);
-          ++fcount;
+          list.push_back((float)fmod(full_turn - keys_in[k].o, full_turn));
+          caller_row.push_back(k);
+          ++kept;
         }
       }
-      if (fcount == 0) continue;
+      if (kept == 0) continue;
       const int m = dj->n++;
       dj->begin[m] = total;
       dj->g[m] = oct[i].g[j + 1];
       dj->w[m] = oct[i].w; dj->h[m] = oct[i].h;
-      total += fcount;
+      total += kept;
     }
   (void)nlv;
   dj->begin[dj->n] = total;
@@ -768,7 +769,7 @@ int SiftExtractor::describe(const uint8_t* gray, int rows, int cols, const SiftK
     SIFT_HIP(hipGetLastError());
     SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)total * 128 * 4, hipMemcpyDeviceToHost, s));
     SIFT_HIP(hipStreamSynchronize(s));
-    for (int i = 0; i < total; ++i) memcpy(ordered + (size_t)index[(size_t)i] * 128, h_desc + (size_t)i * 128, 128 * 4);
+    for (int i = 0; i < total; ++i) memcpy(ordered + (size_t)caller_row[(size_t)i] * 128, h_desc + (size_t)i * 128, 128 * 4);
   }
   *desc = ordered;
   return RGBDFE_OK;
