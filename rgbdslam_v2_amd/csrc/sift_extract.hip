@@ -98,7 +98,7 @@ __device__ __forceinline__ int segment_of(const LevelJobs& jobs, int item, int l
   return __popcll(__ballot(before));
 }
 
-// The pixel-centre window both stages scan around a point: every pixel whose centre (caller_row + 0.5) lies within `reach` of the
+// The pixel-centre window both stages scan around a point: every pixel whose centre (index + 0.5) lies within `reach` of the
 // point (by the floor of the window's edges, as the reference's loops run), kept one pixel off the plane's border so that
 // the central differences exist.
 struct Window { int c0, r0, cols, rows; };
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const LevelJobs* __
 #else
     const float weight = g.len * __builtin_amdgcn_exp2f((-0.125f * 1.44269504f) * (a * a + b * b)) * to_fixed;
 #endif
-    // cells sit at -1.5, -0.5, 0.5, 1.5: the lower neighbour's caller_row and the distance past it
+    // cells sit at -1.5, -0.5, 0.5, 1.5: the lower neighbour's index and the distance past it
     const float ai = floorf(a + 1.5f), bi = floorf(b + 1.5f);
     const float fa = (a + 1.5f) - ai, fb = (b + 1.5f) - bi;
     const int ia = (int)ai, ib = (int)bi;            // -1 .. 3
