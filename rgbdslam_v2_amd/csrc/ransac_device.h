@@ -570,6 +570,56 @@ __device__ __forceinline__ uint32_t prescreen_may_pass(const float* hypR, const 
   return may_pass;
 }
 
+// The same count from a transposed copy of the records: blocks of four matches, component-major -- S4[block][component 0..5]
+// [match 0..3] -- so that one 16-byte LDS read (the same address in every lane: a broadcast) brings one component of four
+// matches, and the halves of its four registers ARE the operand pairs of the packed arithmetic: 6 reads and no register
+// shuffling per four matches, against 24 reads and 19 moves from the 7-word records.  Same pairs, same operations, same
+// count.  (The copy costs a workgroup 7 LDS writes per thread once.)
+constexpr int kS4Block = 24;   // floats of a block of four matches
+__device__ __forceinline__ void transpose_records(const float* __restrict__ M, float* __restrict__ S4, int tid, int n_threads) {
+  for (int v = tid; v < (RGBDFE_MAX_MATCHES / 4) * kS4Block; v += n_threads) {
+    const int blk = v / kS4Block, r = v - blk * kS4Block;
+    S4[v] = M[(blk * 4 + (r & 3)) * kRec + (r >> 2)];
+  }
+}
+__device__ __forceinline__ uint32_t prescreen_may_pass_s4(const float* hypR, const float* hypt, const float* __restrict__ S4,
+                                                       int n_all, float pmax, const RansacConst& rc) {
+  const float u4 = 4.0f * 5.9604645e-8f;
+  float es = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    es += u4 * (((fabsf(hypR[3 * i]) + fabsf(hypR[3 * i + 1])) + fabsf(hypR[3 * i + 2]) + 1.0f) * pmax + fabsf(hypt[i]));
+  const double smax = rc.raster_cov_x > rc.depth_cov ? rc.raster_cov_x : rc.depth_cov;
+  const float S = (float)(2.0 * (smax + smax));
+  const float E = 2.0f * ((2.0f * sqrtf(S) * 1.001f) * es + es * es + u4 * S) + 1e-30f;
+  const float hi_f = S * 1.000001f + E;
+  uint32_t may_pass = 0;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v2f R2[9], t2[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R2[i] = v2f{hypR[i], hypR[i]};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t2[i] = v2f{hypt[i], hypt[i]};
+  const v4f* __restrict__ blocks = reinterpret_cast<const v4f*>(S4);
+#pragma unroll 1
+  for (int m0 = 0; m0 < n_all; m0 += 4) {
+    const v4f* __restrict__ b = blocks + (m0 >> 2) * 6;
+    const v4f px = b[0], py = b[1], pz = b[2], qx = b[3], qy = b[4], qz = b[5];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const v2f x = h ? px.zw : px.xy, y = h ? py.zw : py.xy, z = h ? pz.zw : pz.xy;
+      const v2f f0 = __builtin_elementwise_fma(R2[0], x, __builtin_elementwise_fma(R2[1], y, __builtin_elementwise_fma(R2[2], z, t2[0]))) - (h ? qx.zw : qx.xy);
+      const v2f f1 = __builtin_elementwise_fma(R2[3], x, __builtin_elementwise_fma(R2[4], y, __builtin_elementwise_fma(R2[5], z, t2[1]))) - (h ? qy.zw : qy.xy);
+      const v2f f2 = __builtin_elementwise_fma(R2[6], x, __builtin_elementwise_fma(R2[7], y, __builtin_elementwise_fma(R2[8], z, t2[2]))) - (h ? qz.zw : qz.xy);
+      const v2f dsq = __builtin_elementwise_fma(f0, f0, __builtin_elementwise_fma(f1, f1, f2 * f2));
+      may_pass += !(dsq.x > hi_f) ? 1u : 0u;
+      may_pass += !(dsq.y > hi_f) ? 1u : 0u;
+    }
+  }
+  return may_pass;
+}
+
 // a pair is "junk-heavy" (class 2 of the record / replay plan) when at most kClass2Num / kClass2Den of the first phase's
 // iterations produced a refined hypothesis
 #ifndef RGBDFE_CLASS2_NUM

@@ -92,6 +92,7 @@ constexpr int kHypThreads = 256;
 // Diagnostics build only (-DRGBDFE_SPLIT_STATS): what the refinement kernel's servers saw, summed over workgroups and launches
 // [0] half-rounds, [1] workgroups, [2] half-rounds scored by ticket, [3] scorings, [4] SVD requests, [5] units loaded,
 // [6] hand-outs, [7] longest run of half-rounds of a workgroup
+// [20] iterations ended, [21] ... after their first scoring, [22] ... with refined_matches empty
 // [8..15] the server's time (100 MHz ticks): SVD, recycle, load completion, hand-out, active list, load issue, scoring by
 // ticket, waiting at the barriers; [16..19] a worker's (wave 0): scoring, bookkeeping + refits, waiting at the barriers, -
 #ifdef RGBDFE_SPLIT_STATS
@@ -358,6 +359,7 @@ __device__ __forceinline__ void score_b(const float* R, const float* tr, const f
 __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork* __restrict__ work, uint32_t n_pairs,
                                                                 const RansacConst rc, const SplitPlan plan) {
   __shared__ __attribute__((aligned(16))) float M[RGBDFE_MAX_MATCHES * kRec];
+  __shared__ __attribute__((aligned(16))) float S4[(RGBDFE_MAX_MATCHES / 4) * kS4Block];   // the pre-screen's copy (ransac_device.h)
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   // the batch's counters (walk[n_pairs]: class-1 pairs, the refinement launches' unit counters, "still running" flag)
@@ -374,6 +376,8 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
     float4* __restrict__ dst = reinterpret_cast<float4*>(M);
     for (int v = tid; v < kMVec; v += kHypThreads) dst[v] = src[v];
   }
+  __syncthreads();
+  transpose_records(M, S4, tid, kHypThreads);
   __syncthreads();
   const float pmax = pp->pmax;
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
     tfc_get_transformation(acc, hypR, hypt);
     // a NaN transform leaves the refinement loop at once (:1144); so does, after its first scoring, a hypothesis that
     // cannot reach `thr` candidates (:1154) -- with the same outcome: refined_matches stays empty (:1133-1134)
-    const uint32_t may_pass = prescreen_may_pass(hypR, hypt, M, n_all, pmax, rc);
+    const uint32_t may_pass = prescreen_may_pass_s4(hypR, hypt, S4, n_all, pmax, rc);
     const bool viable = in_range && !has_nan12(hypR, hypt) && may_pass >= thr;
     const uint64_t vm = __ballot(viable);
     if (lane == 0) vm_pair[k >> 6] = vm;  // (k0 and the wave's first lane are multiples of 64)
@@ -597,6 +601,19 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         }
       }
       const uint64_t refit = __ballot(still);
+#ifdef RGBDFE_SPLIT_STATS
+      {  // [20] iterations that left their loop in this pass, [21] ... after their first scoring, [22] ... without a refined set
+        bool ended = false, first = false, empty = false;
+        if (fresh(lane) < n_mine_slots) {
+          const SlotS& sl = lds.slot[my_slot];
+          ended = sl.active == kSlotRecorded && !still;
+          first = ended && sl.round == 1;
+          empty = ended && sl.rn == 0;
+        }
+        const int st_e = __popcll(__ballot(ended)), st_f = __popcll(__ballot(first)), st_z = __popcll(__ballot(empty));
+        ST_ADD(20, st_e) ST_ADD(21, st_f) ST_ADD(22, st_z)
+      }
+#endif
       if (refit != 0ull) {
         lsync();
         // ---- refits (:1142): the weighted-mean recurrences of the wave's active slots side by side; their SVDs are
@@ -807,7 +824,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     SlotS& sl = lds.slot[s];
     const bool p = lane < kGroupSlots && sl.iter >= 0 && sl.active == kSlotActive;
     if (__ballot(p) == 0ull) return;
-    ST_ADD(4, __popcll(__ballot(p)))
+#ifdef RGBDFE_SPLIT_STATS
+    { const int st_n = __popcll(__ballot(p)); ST_ADD(4, st_n) }   // (the ballot outside the macro's lane-0 branch)
+#endif
     Tfc mine;
     mine.reset();  // lanes without a request: the zero matrix (no rotation, one sweep)
     if (p) {

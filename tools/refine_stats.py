@@ -44,7 +44,8 @@ print(json.dumps({"depth_noise": noise, "batches": B, "stage_ms_per_batch": roun
                   "workgroup_launches_with_work_per_batch": v[1] / B, "half_rounds_per_workgroup": round(v[0] / wgs, 1),
                   "longest_workgroup_half_rounds": v[7], "ticket_half_round_fraction": round(v[2] / max(v[0], 1), 3),
                   "scorings_per_batch": v[3] / B, "scorings_per_half_round": round(v[3] / max(v[0], 1), 2),
-                  "svd_requests_per_batch": v[4] / B, "units_loaded_per_batch": v[5] / B, "items_per_batch": v[6] / B,
+                  "svd_requests_per_batch": v[4] / B, "iterations_ended_per_batch": v[20] / B,
+                  "ended_after_first_scoring_per_batch": v[21] / B, "ended_without_refined_set_per_batch": v[22] / B, "units_loaded_per_batch": v[5] / B, "items_per_batch": v[6] / B,
                   "server_us_per_half_round": dict(zip(("svd", "recycle", "complete_loads", "hand_out", "list_active", "issue_loads",
                                                         "ticket_scoring", "barrier_wait"), [round(x / 100.0 / max(v[0], 1), 2) for x in v[8:16]])),
                   "worker0_us_per_half_round": dict(zip(("scoring", "bookkeeping_refit", "barrier_wait"),
