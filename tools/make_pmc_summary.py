@@ -118,12 +118,14 @@ def serial_section(d):
         for row in csv.DictReader(open(f)):
             name = row["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rgbdfe::", "")
             kern[name] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "total_ns": float(row["TotalDurationNs"])}
-            if "hamming_mfma" in name and "expand" not in name:
+            if ("hamming_mfma" in name and "expand" not in name) or "sift_top2" in name or "sift_row_top2" in name:
                 n_batches = int(row["Calls"])
     nb = max(n_batches, 1)
     stage = sum(v["total_ns"] for k, v in kern.items() if any(t in k for t in ("pair_prep", "ransac_hyp", "ransac_refine", "replay_walk", "select_ransac")))
     ham = sum(v["total_ns"] for k, v in kern.items() if "hamming_mfma" in k and "expand" not in k)
+    dot = sum(v["total_ns"] for k, v in kern.items() if "sift_top2" in k or "sift_row_top2" in k)
     return {"batches_in_trace": n_batches, "hamming_ms_per_batch": round(ham / nb / 1e6, 4),
+            "sift_dot_ms_per_batch": round(dot / nb / 1e6, 4),
             "select_ransac_stage_ms_per_batch": round(stage / nb / 1e6, 4),
             "note": "one batch in flight; kernel durations under the tracer are a few percent longer than HIP-event spans",
             "kernels": {k: {"calls_per_batch": round(v["calls"] / nb, 2), "avg_ns": v["avg_ns"]} for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ns"]) if v["calls"] >= nb}}
@@ -139,12 +141,12 @@ for d in sorted(glob.glob(os.path.join(base, "detect_*"))):
     out.setdefault("detect", {})[os.path.basename(d)[len("detect_"):]] = frame_section(d)
 for d in sorted(glob.glob(os.path.join(base, "sift_extract_*"))):
     out.setdefault("sift_extract", {})[os.path.basename(d)[len("sift_extract_"):]] = frame_section(d)
-for w in ("orb_serial", "heavy_serial"):
+for w in ("orb_serial", "heavy_serial", "sift_serial"):
     if os.path.isdir(os.path.join(base, w)):
         out[w] = serial_section(os.path.join(base, w))
 # every section says which tree it was collected on; a summary is built from ONE tree unless --allow-mixed
 stamps = {}
-for name, d in [("orb", "orb"), ("ransac_heavy", "heavy"), ("sift", "sift"), ("orb_serial", "orb_serial"), ("heavy_serial", "heavy_serial")]:
+for name, d in [("orb", "orb"), ("ransac_heavy", "heavy"), ("sift", "sift"), ("orb_serial", "orb_serial"), ("heavy_serial", "heavy_serial"), ("sift_serial", "sift_serial")]:
     if name in out:
         out[name]["commit"] = stamps[name] = commit_of(os.path.join(base, d))
 for grp, prefix in (("detect", "detect_"), ("sift_extract", "sift_extract_")):

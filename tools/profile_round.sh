@@ -5,7 +5,7 @@
 #   sift     bench.py --config sift --frames 100              trace + FETCH/WRITE + MFMA pass
 #   detect_640x480_orb1000, detect_1280x960_orb4000           trace + FETCH/WRITE   (tools/detect_workload.py orb)
 #   sift_extract_640x480                                      trace + FETCH/WRITE   (tools/detect_workload.py sift_batch)
-#   orb_serial, heavy_serial                                  kernel trace with ONE batch in flight (tools/trace_serial.sh's
+#   orb_serial, heavy_serial, sift_serial                     kernel trace with ONE batch in flight (tools/trace_serial.sh's
 #                                                             run): the stage times bench.py's serial figures must agree with
 # Counters are collected in their own runs (never together with a trace domain).  tools/make_pmc_summary.py <tag> turns the
 # result into profiles/<tag>_pmc_summary.json.   Usage: tools/profile_round.sh <tag> [workloads...]
@@ -15,7 +15,7 @@
 set -u
 TAG=${1:-r03}
 shift || true
-WL=${*:-orb orb_serial heavy heavy_serial sift detect_640x480_orb1000 detect_1280x960_orb4000 sift_extract_640x480}
+WL=${*:-orb orb_serial heavy heavy_serial sift sift_serial detect_640x480_orb1000 detect_1280x960_orb4000 sift_extract_640x480}
 REPO=$PWD
 ROOT=$REPO/gpurun_out/prof_$TAG
 export TMPDIR=/tmp
@@ -40,11 +40,11 @@ run_passes() {  # <workload dir> <command> <passes...>
 for W in $WL; do
   case $W in
     orb)   run_passes orb "$B" fetch write sq sq2 mfma; python tools/summarize_prof.py $ROOT/orb > $ROOT/orb/summary.txt 2>&1;;
-    orb_serial|heavy_serial)
+    orb_serial|heavy_serial|sift_serial)
       mkdir -p $ROOT/$W; cp $REPO/tools/_commit.txt $ROOT/$W/commit 2>/dev/null || echo unknown > $ROOT/$W/commit
-      NOISE=$([ $W = orb_serial ] && echo 0.01 || echo 0.002) GRAFT_REPO_ROOT=$REPO bash tools/trace_serial.sh > $ROOT/$W/last_batch.txt 2>&1
+      CONFIG=$([ $W = sift_serial ] && echo sift || echo orb) NOISE=$([ $W = heavy_serial ] && echo 0.002 || echo 0.01) GRAFT_REPO_ROOT=$REPO bash tools/trace_serial.sh > $ROOT/$W/last_batch.txt 2>&1
       rm -rf $ROOT/$W/trace; mkdir -p $ROOT/$W/trace; cp -r $REPO/gpurun_out/trace_serial/* $ROOT/$W/trace/ 2>/dev/null;;
-    heavy) run_passes heavy "$B --depth-noise 0.002" fetch write sq sq2; python tools/summarize_prof.py $ROOT/heavy > $ROOT/heavy/summary.txt 2>&1;;
+    heavy) run_passes heavy "$B --depth-noise 0.002" fetch write sq sq2 mfma; python tools/summarize_prof.py $ROOT/heavy > $ROOT/heavy/summary.txt 2>&1;;
     sift)  run_passes sift "python $REPO/bench.py --config sift --frames 100 --steps 5 --warmup 1" fetch write mfma; python tools/summarize_prof.py $ROOT/sift > $ROOT/sift/summary.txt 2>&1;;
     detect_640x480_orb1000)  run_passes $W "python $REPO/tools/detect_workload.py orb 640 480 1000 56 3" fetch write;;
     detect_1280x960_orb4000) run_passes $W "python $REPO/tools/detect_workload.py orb 1280 960 4000 56 2" fetch write;;
