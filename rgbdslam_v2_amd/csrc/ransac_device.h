@@ -620,6 +620,75 @@ __device__ __forceinline__ uint32_t prescreen_may_pass_s4(const float* hypR, con
   return may_pass;
 }
 
+// ---------------------------------------------------------------------------------
+// The reference's in-order bookkeeping (node.cpp:1130-1191: `it += 10 / 20`, the 80 % exit, best-so-far) over the recorded
+// outcomes of iterations [w.real_iterations, recorded_end): one wave, 64 summaries fetched per step, the sequential decisions
+// on wave-uniform values.  Stops when the loop ends (w.done) or the records run out.  listed(k): iteration k passed the
+// pre-screen and has a summary (an iteration that did not counts as {1e6, 0} and leaves nothing in memory).
+// COHERENT: the summaries were written by other waves of the SAME launch (the refinement kernel's walk between two windows
+// of a pair): agent-scope loads that do not stop at this CU's vector cache.
+// ---------------------------------------------------------------------------------
+struct WalkRegs {
+  int it, real_iterations, valid_iterations, best_idx, best_n;
+  float rmse;
+  bool done;
+};
+template <bool COHERENT, class Listed>
+__device__ __forceinline__ void walk_records(WalkRegs& w, int recorded_end, int I, int n_all, uint32_t thr,
+                                             const IterSum* __restrict__ sum_pair, Listed listed, int lane) {
+  while (!w.done && w.it < I && w.real_iterations < recorded_end) {
+    const int k0 = w.real_iterations;
+    const int G = min(kWave, recorded_end - k0);
+    int rn_l = 0;
+    double rerr_l = 0.0;
+    if (lane < G && listed(k0 + lane)) {
+      if (COHERENT) {
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(sum_pair + (k0 + lane));
+        const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rerr_l = __longlong_as_double((long long)a);
+        rn_l = (int)(uint32_t)b;
+      } else {
+        const IterSum su = sum_pair[k0 + lane];
+        rn_l = su.rn;
+        rerr_l = su.rerr;
+      }
+    }
+    // Iterations whose refinement left refined_matches empty (:1171 fails) only count: `if (!(it < I)) break;
+    // real_iterations++; ++it` -- a run of them is taken in one step; only the others are looked at one by one.
+    const uint64_t with_matches = __ballot(lane < G && rn_l > 0);
+    for (int g = 0; g < G;) {
+      const uint64_t rest = with_matches >> g;
+      const int run = rest != 0ull ? (int)__builtin_ctzll(rest) : G - g;  // empty iterations before the next one with matches
+      if (run > 0) {
+        const int can = min(run, max(I - w.it, 0));  // (`it` may have jumped beyond ransac_iterations, :1186-1187)
+        w.real_iterations += can;          // :1139
+        w.it += can;
+        if (can < run) { w.done = true; break; }  // the next check of `it < ransac_iterations` fails (:1130)
+        g += run;
+        if (g >= G) break;
+      }
+      if (!(w.it < I)) { w.done = true; break; }
+      w.real_iterations++;  // :1139
+      const int refined_n = __builtin_amdgcn_readlane(rn_l, g);
+      const double refined_error = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rerr_l), g),
+                                                    __builtin_amdgcn_readlane(__double2loint(rerr_l), g));
+      // refined_n > 0 (:1171)
+      w.valid_iterations++;
+      if (refined_error <= (double)w.rmse && refined_n >= w.best_n && (uint32_t)refined_n >= thr) {  // :1177
+        w.rmse = (float)refined_error;  // :1182
+        w.best_idx = k0 + g;
+        w.best_n = refined_n;
+        if ((double)refined_n > (double)n_all * 0.5) w.it += 10;   // :1186
+        if ((double)refined_n > (double)n_all * 0.75) w.it += 10;  // :1187
+        if ((double)refined_n > (double)n_all * 0.8) { w.done = true; break; }  // :1188
+      }
+      ++w.it;
+      ++g;
+    }
+  }
+}
+
 // a pair is "junk-heavy" (class 2 of the record / replay plan) when at most kClass2Num / kClass2Den of the first phase's
 // iterations produced a refined hypothesis
 #ifndef RGBDFE_CLASS2_NUM

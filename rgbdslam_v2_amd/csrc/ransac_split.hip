@@ -93,31 +93,47 @@ constexpr int kHypThreads = 256;
 // [0] half-rounds, [1] workgroups, [2] half-rounds scored by ticket, [3] scorings, [4] SVD requests, [5] units loaded,
 // [6] hand-outs, [7] longest run of half-rounds of a workgroup
 // [20] iterations ended, [21] ... after their first scoring, [22] ... with refined_matches empty
+// [23] recurrence passes (a worker's refits of a half-round), [24] their steps (longest list), [25] their refits,
+// [26] scorings that ran pass 2, [27] pass-2 rounds of 64 candidates, [28] error-sum additions, [29] candidates of pass 1
 // [8..15] the server's time (100 MHz ticks): SVD, recycle, load completion, hand-out, active list, load issue, scoring by
 // ticket, waiting at the barriers; [16..19] a worker's (wave 0): scoring, bookkeeping + refits, waiting at the barriers, -
 #ifdef RGBDFE_SPLIT_STATS
-__device__ unsigned long long g_split_stats[24];
-#define ST_ADD(I, V) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_split_stats[I], (unsigned long long)(V)); }
-#define ST_MAX(I, V) { if ((threadIdx.x & 63) == 0) atomicMax(&g_split_stats[I], (unsigned long long)(V)); }
-#define ST_T0 unsigned long long st_t = __builtin_amdgcn_s_memrealtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define ST_LAP(I) { const unsigned long long st_n = __builtin_amdgcn_s_memrealtime(); st_acc[I] += st_n - st_t; st_t = st_n; }
-#define ST_FLUSH(BASE, N) { for (int st_i = 0; st_i < (N); ++st_i) ST_ADD((BASE) + st_i, st_acc[st_i]) }
+// (a wave counts in registers and adds to the global array once, when it leaves the kernel: per-event atomics on 24 words
+// shared by 4096 waves serialised the launch they were meant to describe -- 4.8 instead of 1.0 ms per batch)
+__device__ unsigned long long g_split_stats[32];
+#define ST_DECL unsigned long long st_c[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_mx = 0;
+#define ST_ADD(I, V) { st_c[I] += (unsigned long long)(V); }
+#define ST_MAX(I, V) { st_mx = (unsigned long long)(V) > st_mx ? (unsigned long long)(V) : st_mx; }
+#define ST_T0 unsigned long long st_t = __builtin_amdgcn_s_memrealtime();
+#define ST_LAP(I) { const unsigned long long st_n = __builtin_amdgcn_s_memrealtime(); st_c[I] += st_n - st_t; st_t = st_n; }
+#define ST_OUT { if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 32; ++st_i) if (st_c[st_i] != 0ull) atomicAdd(&g_split_stats[st_i], st_c[st_i]); \
+                 if (st_mx != 0ull) atomicMax(&g_split_stats[7], st_mx); } }
 #else
+#define ST_DECL
 #define ST_ADD(I, V)
 #define ST_MAX(I, V)
 #define ST_T0
 #define ST_LAP(I)
-#define ST_FLUSH(BASE, N)
+#define ST_OUT
 #endif
 
-constexpr int kStreamWaves = 8;                        // waves of a refinement workgroup: 7 workers + the server
+#ifndef RGBDFE_SPLIT_WAVES
+#define RGBDFE_SPLIT_WAVES 8
+#endif
+constexpr int kStreamWaves = RGBDFE_SPLIT_WAVES;       // waves of a refinement workgroup: the workers + the server
+static_assert(kStreamWaves >= 3 && 16 % kStreamWaves == 0, "16 waves per CU (4 per SIMD at <= 128 VGPRs) in whole workgroups");
+constexpr int kWgsPerCu = 16 / kStreamWaves;
 constexpr int kWorkers = kStreamWaves - 1;
+#ifndef RGBDFE_SPLIT_SERVER_SCORES
+#define RGBDFE_SPLIT_SERVER_SCORES (RGBDFE_SPLIT_WAVES >= 8)
+#endif
+constexpr bool kServerScores = RGBDFE_SPLIT_SERVER_SCORES;   // the server takes tickets too (and owns a scoring scratch)
 constexpr int kStreamThreads = kStreamWaves * kWave;
 #ifndef RGBDFE_SPLIT_WAVE_SLOTS
 #define RGBDFE_SPLIT_WAVE_SLOTS 7
 #endif
 #ifndef RGBDFE_SPLIT_BUFS
-#define RGBDFE_SPLIT_BUFS 3
+#define RGBDFE_SPLIT_BUFS (RGBDFE_SPLIT_WAVES >= 8 ? 4 : 2)
 #endif
 constexpr int kWaveSlots = RGBDFE_SPLIT_WAVE_SLOTS;    // iterations a worker refines side by side, per group (7 x 9 = 63 lanes of the refit)
 static_assert(kWaveSlots <= kSlots, "the refit phase (fit_compact / fit_recurrence) holds kSlots lists per wave");
@@ -126,13 +142,13 @@ constexpr int kStreamSlots = 2 * kGroupSlots;
 static_assert(kGroupSlots <= kWave, "the server looks at a group's slots with one lane each");
 static_assert(kStreamSlots <= 2 * kWave, "the server's end-of-work test looks at two slots per lane");
 #ifndef RGBDFE_SPLIT_TICKETS_FROM
-#define RGBDFE_SPLIT_TICKETS_FROM 24
+#define RGBDFE_SPLIT_TICKETS_FROM (24 * (RGBDFE_SPLIT_WAVES - 1) * RGBDFE_SPLIT_WAVE_SLOTS / 49)
 #endif
 constexpr int kCostDear = 4;                           // a scoring that runs pass 2, in scorings of a junk hypothesis (the deal's weight)
 constexpr int kTicketsFrom = RGBDFE_SPLIT_TICKETS_FROM;  // expensive scorings in a group's pass from which they go out by ticket
 constexpr int kBufs = RGBDFE_SPLIT_BUFS;              // units (pair, iteration range) resident in a workgroup's LDS
 #ifndef RGBDFE_SPLIT_MAX_SHARE
-#define RGBDFE_SPLIT_MAX_SHARE 512
+#define RGBDFE_SPLIT_MAX_SHARE 256
 #endif
 constexpr int kMaxShare = RGBDFE_SPLIT_MAX_SHARE;      // iterations of a unit at most (the host cuts longer ranges)
 constexpr int kMaskLanes = kMaxShare / kWave + 1;     // words of a pair's viable mask that can overlap a unit's range
@@ -147,8 +163,9 @@ struct SlotS {
     struct { float R[9], t[3]; } x;  // transform to score next (first the 4-point hypothesis, then the refits')
     float svd_in[15];                // ... or, between a refit's recurrences and its SVD: C[9], mean1[3], mean2[3]
   } u;
-  float rR[9], rt[3];        // refined_transformation (node.cpp:1137,1163)
-  uint64_t rmask[kRounds];   // refined_matches
+  // (refined_transformation and refined_matches, node.cpp:1137 / :1163, are not kept here: whenever a pass's scoring is
+  // accepted they go straight into the iteration's outcome record in memory -- the last acceptance is the outcome -- and the
+  // refit that follows an acceptance reads the set it has just accepted, cmask.  88 bytes per slot: a fourth resident unit.)
   uint64_t cmask[kRounds];   // inlier set of the scoring of the current pass
   double rerr;               // refined_error
   double csum;               // sequential sum of the current scoring's inlier errors (node.cpp:1006)
@@ -177,31 +194,36 @@ struct alignas(16) WaveLds {
   } u;
 };
 // a unit resident in LDS: the viable iterations of its range, handed out in order.  Server only.
-constexpr int kUnitFree = 0, kUnitLoading = 1, kUnitReady = 2;
+constexpr int kUnitFree = 0, kUnitLoading = 1, kUnitReady = 2, kUnitDrained = 3;
 struct alignas(16) UnitCtx {
-  uint64_t mw[kMaskLanes + 1];  // the words of the pair's viable mask that overlap the range (global -> LDS with the records)
-  int state;                 // kUnitFree / kUnitLoading (the records are on their way) / kUnitReady
+  uint64_t mw[kMaskLanes + 1];  // the words of the pair's viable mask that overlap the window (global -> LDS with the records)
+  int state;                 // kUnitFree / kUnitLoading (the records are on their way) / kUnitReady / kUnitDrained (every
+                             // iteration of the window has ended: the next window, or the buffer is free again)
   int next;                  // iterations handed out so far
-  int done;                  // iterations whose refinement has ended; == n_items => the buffer is free again
+  int done;                  // iterations whose refinement has ended; == n_items => the window has drained
   int n_items;
   uint32_t pair;
-  int kb, ke;                // the unit's iteration range
+  int kb, ke;                // the window: the unit's iteration range / the part of the pair's range that is recorded now
   uint32_t thr;              // inlier threshold of the pair (:1094-1098)
   int base;                  // iteration index of bit 0 of mw[0]
+  int cls;                   // phased plans: 2 = junk-heavy and no jump of `it` (everything that is left is one window), 0 / 1 =
+                             // phase by phase, -1 = not decided yet (the first walk does)
+  // the pair's in-order bookkeeping up to the windows walked so far (node.cpp:1171-1190), phased plans
+  int w_it, w_real, w_valid, w_best_idx, w_best_n, w_state;
+  float w_rmse;
   int pad[3];
   uint16_t klist[kMaxShare];  // the viable iterations of the unit's range, ascending, relative to `base` (< kMaxShare + 64)
 };
 struct alignas(16) StreamLds {
   PairPrep prep[kBufs];            // the resident units' pairs: match records + facts, as pair_prep_kernel left them
-  WaveLds w[kStreamWaves];
+  WaveLds w[kServerScores ? kStreamWaves : kWorkers];
   SlotS slot[kStreamSlots];        // group g: slots g * kGroupSlots + 0 .. kGroupSlots - 1
   UnitCtx ctx[kBufs];
   // facts of the units of the block the server has taken off the counter last (lane = unit), global -> LDS like the records
   // (a load into registers that stays in flight across the server's loop makes the compiler wait before every reuse of
   // any register such a load might be pending on -- between the pieces of a unit's record load, for one)
   int claim_nall[kWave];           // PairPrep::n_all
-  int claim_state[kWave];          // WalkState::state (later phases)
-  int claim_cls[kWave];            // WalkState::speculate (later phases) / the pre-classification byte (first launch)
+  int claim_cls[kWave];            // the hypothesis kernel's pre-classification byte (phased plans)
   // the scorings of a half-round: the group's active slots as a list, taken one by one by whichever wave is free
   uint8_t act_list[2][kWave];
   int n_act[2];
@@ -213,7 +235,7 @@ struct alignas(16) StreamLds {
   int quit;                        // set by the server: every unit of the launch has been refined
   int pad[3];
 };
-static_assert(sizeof(StreamLds) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(StreamLds) <= 160 * 1024 / kWgsPerCu, "kWgsPerCu workgroups per CU");
 
 // ---------------------------------------------------------------------------------
 // computeInliersAndError (node.cpp:968-1020) with errorFunction2 (misc.cpp:697-770) for one wave-uniform transform:
@@ -228,7 +250,7 @@ static_assert(sizeof(StreamLds) <= 80 * 1024, "two workgroups per CU");
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void score_b(const float* R, const float* tr, const float* __restrict__ M, int n_all,
                                         uint32_t need, const RansacConst& rc, ScoreB& sb, float pmax, uint64_t* mask,
-                                        int& n_inl, double& sum) {
+                                        int& n_inl, double& sum, int& n_cand_out) {
   const int lane = threadIdx.x & (kWave - 1);
   double Rd[9], td[3];
 #pragma unroll
@@ -282,6 +304,7 @@ __device__ __forceinline__ void score_b(const float* R, const float* tr, const f
   sum = 0.0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) mask[r] = 0ull;
+  n_cand_out = n_cand;
   if ((uint32_t)n_cand < need) return;  // hopeless: nobody looks at the exact numbers
   // ---- pass 2
   for (int k0 = 0; k0 < n_cand; k0 += kWave) {
@@ -368,6 +391,17 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
   if (pair == 0 && threadIdx.x < sizeof(WalkState) / 4) reinterpret_cast<uint32_t*>(plan.walk + n_pairs)[threadIdx.x] = 0u;
   const PairPrep* __restrict__ pp = plan.prep + pair;
   const int n_all = pp->n_all;
+  // the pair's in-order bookkeeping starts here (:1112, :1130); WalkState::speculate = end of the pair's recorded range:
+  // everything when the batch is recorded with full speculation, else whatever the refinement kernel leaves behind
+  if (threadIdx.x == 0) {
+    WalkState ws;
+    ws.state = rc.ransac_iterations;
+    ws.it = 0; ws.real_iterations = 0; ws.valid_iterations = 0;
+    ws.best_idx = -1; ws.best_n = 0;
+    ws.rmse = 1e6f;
+    ws.speculate = plan.phased ? 0 : rc.ransac_iterations;
+    plan.walk[pair] = ws;
+  }
   // no RANSAC for this pair (node.cpp:1087, :1130)
   if (!(n_all > rc.min_matches && n_all >= 4)) return;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -463,13 +497,12 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_refine_kernel(
     uint32_t n_pairs, const RansacConst rc, const SplitPlan plan, uint32_t n_units) {
-  // a later phase of a batch whose pairs have all ended (the walk of the phase before found nobody still running)
-  if (plan.phase_index > 0 && plan.walk[n_pairs].best_n != plan.phase_index) return;
   extern __shared__ __attribute__((aligned(16))) char stream_smem[];
   StreamLds& lds = *reinterpret_cast<StreamLds*>(stream_smem);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int I = rc.ransac_iterations;
+  ST_DECL
 
   if (wave < 2) {
     const int s = wave * kWave + lane;
@@ -479,20 +512,24 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   }
   lds_barrier();
 
-  // the outcome record of an iteration that has left its refinement loop (its worker's lane, or the server's)
-  auto write_record = [&](const SlotS& sl) {
-    const size_t at = (size_t)sl.pair * (size_t)I + (size_t)sl.iter;
-    IterRec& r = plan.recs[at];
+  // an iteration has left its refinement loop (its worker's lane, or the server's): what the in-order walk needs of it.  The
+  // outcome record itself was written when the pass that set refined_matches was accepted (accept_record); an iteration whose
+  // refined_matches stayed empty has none -- the walk never adopts it (:1171).
+  auto write_summary = [&](const SlotS& sl) {
+    plan.sums[(size_t)sl.pair * (size_t)I + (size_t)sl.iter] = IterSum{sl.rerr, sl.rn, 0};
+  };
+  // :1160-1165: the pass's transform, inlier set and error become the iteration's outcome so far
+  auto accept_record = [&](const SlotS& sl, int n_inl, double err) {
+    IterRec& r = plan.recs[(size_t)sl.pair * (size_t)I + (size_t)sl.iter];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.rR[i] = sl.rR[i];
+    for (int i = 0; i < 9; ++i) r.rR[i] = sl.u.x.R[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) r.rt[i] = sl.rt[i];
+    for (int i = 0; i < 3; ++i) r.rt[i] = sl.u.x.t[i];
 #pragma unroll
-    for (int q = 0; q < kRounds; ++q) r.rmask[q] = sl.rmask[q];
-    r.rerr = sl.rerr;
-    r.rn = sl.rn;
+    for (int q = 0; q < kRounds; ++q) r.rmask[q] = sl.cmask[q];
+    r.rerr = err;
+    r.rn = n_inl;
     r.pad = 0;
-    plan.sums[at] = IterSum{sl.rerr, sl.rn, 0};
   };
 
   // ---- the scorings (:1148) of group g's pass: every wave takes the next active slot off the group's list until there is
@@ -517,7 +554,15 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     uint64_t inl_mask[kRounds];
     int n_inl;
     double sum;
-    score_b(curR, curt, pp.M, n_all, need, rc, wl.u.sc, pmax, inl_mask, n_inl, sum);
+    int n_cand;
+    score_b(curR, curt, pp.M, n_all, need, rc, wl.u.sc, pmax, inl_mask, n_inl, sum, n_cand);
+#ifdef RGBDFE_SPLIT_STATS
+    ST_ADD(29, n_cand)
+    if ((uint32_t)n_cand >= need) {
+      ST_ADD(26, 1) ST_ADD(27, (n_cand + 63) / 64)
+      if (!((uint32_t)n_inl < need || n_inl < 3)) ST_ADD(28, n_inl)
+    }
+#endif
     // (the lane tests inside loops are opaque to the compiler, each on its own: seeing the same `lane == 0` twice in a
     // loop body it threads the first branch into the second and splits the loop by lane -- in the ticket loop below lane 0
     // left with its ticket and the other 63 lanes stayed behind in a copy whose readfirstlane never saw a new ticket: an
@@ -559,13 +604,13 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       // ================================ one pass of the refinement loop (:1140) for every active slot of group g
       if (__builtin_amdgcn_readfirstlane(lds.tickets[g]) != 0) {
         score_tickets(g);
-        ST_LAP(0)
+        ST_LAP(16)
         lds_barrier();   // every scoring of the pass is done
-        ST_LAP(2)
+        ST_LAP(18)
       } else {           // cheap scorings: every worker scores its own slots and goes on without meeting the others
         for (int j = 0; j < n_mine_slots; ++j) score_slot(slot_at(j));
         lsync();
-        ST_LAP(0)
+        ST_LAP(16)
       }
       // ---- the loop's bookkeeping (:1154-1166), lane = slot
       bool still = false;
@@ -582,12 +627,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           if (!((uint32_t)n_inl < thr || err_mine > (double)max_dist_f)) {  // :1154
             if (n_inl >= rn && err_mine <= sl.rerr) {               // :1160
               still = (n_inl != rn);                                // :1166
-#pragma unroll
-              for (int i = 0; i < 9; ++i) sl.rR[i] = sl.u.x.R[i];
-#pragma unroll
-              for (int i = 0; i < 3; ++i) sl.rt[i] = sl.u.x.t[i];
-#pragma unroll
-              for (int r = 0; r < kRounds; ++r) sl.rmask[r] = sl.cmask[r];
+              accept_record(sl, n_inl, err_mine);
               sl.rn = n_inl;
               sl.rerr = err_mine;
             }
@@ -595,7 +635,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           if (sl.round == 18) still = false;  // the 19th pass was the last one (:1140)
           sl.round++;
           if (!still) {  // the iteration has left its loop: the outcome record, from the lane that holds the slot
-            write_record(sl);
+            write_summary(sl);
             sl.active = kSlotRecorded;
           }
         }
@@ -634,7 +674,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
             // (misc.cpp:712-717)
             uint64_t m5[kRounds], nz[kRounds];
 #pragma unroll
-            for (int r = 0; r < kRounds; ++r) { m5[r] = uniform_u64(sl.rmask[r]); nz[r] = uniform_u64(pp.w_nonzero[r]); }
+            for (int r = 0; r < kRounds; ++r) { m5[r] = uniform_u64(sl.cmask[r]); nz[r] = uniform_u64(pp.w_nonzero[r]); }
             int k256_j;
             const int n_j = fit_compact(j, m5, nz, wl.u.fit, k256_j, fresh(lane));
             if (lane / 9 == j) { n_mine = n_j; k256_mine = k256_j; }
@@ -650,6 +690,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           const int slot_s = __shfl(my_slot, min(s, max(n_mine_slots - 1, 0)));
           const float* __restrict__ M = lds.prep[lds.slot[slot_s].buf].M;
           float C, m1, m2;
+          ST_ADD(23, 1) ST_ADD(24, n_max) ST_ADD(25, __popcll(refit))
           if (all_fast) fit_recurrence<true>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
           else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, wl.u.fit, M, C, m1, m2, lane_here);
           // lane 9s+x holds C[x], lane 9s+j mean1[j], lane 9s+3i mean2[i] of slot s: into the slot's mailbox (the
@@ -662,33 +703,36 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
           }
         }
       }
-      ST_LAP(1)
+      ST_LAP(17)
+      // (the outcome records written in this pass are in memory before the server learns that their iterations have ended:
+      // its walk between two windows of a pair reads them back)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
-      ST_LAP(2)
+      ST_LAP(18)
       if (__builtin_amdgcn_readfirstlane(lds.quit) != 0) break;
     }
 #ifdef RGBDFE_SPLIT_STATS
-    if (wave == 0) ST_FLUSH(16, 3)
+    if (wave != 0) { st_c[16] = st_c[17] = st_c[18] = 0ull; }
+    ST_OUT
 #endif
     return;
   }
 
   // ============================================================================================= the server
   // (s_setprio 3 for this wave -- its SVD is ~1500 dependent instructions on a SIMD it shares with three other waves -- was
-  // measured: 1.068 -> 1.048 ms serial stage, 1.117 -> 1.133 ms per pipelined step, i.e. nothing.  The per-phase clocks of
-  // the counter build (make stats, tools/refine_stats.py) say why: server and workers are each busy ~60 % of a half-round at
-  // 0.01 z^2 (75 % at 0.002 z^2) and wait the rest at the barrier for the slowest worker of that half-round.)
+  // measured: 1.068 -> 1.048 ms serial stage, 1.117 -> 1.133 ms per pipelined step, i.e. nothing.)
   // Units come off the launch's counter a block at a time, lane = unit.  `nx_*`: the block taken last, its facts still on
   // their way (the loads are not awaited until the block is needed); `live` / `u_*`: the block in use.
   uint64_t live = 0ull;        // units of the block in use that have work and are not loaded yet
   bool units_left = true;      // the counter has not run past the last unit yet
   uint32_t u_pair = 0;
-  int u_kb = 0, u_ke = 0;
+  int u_kb = 0, u_ke = 0, u_cls = 0;
   int nx_n = 0;                // units of the prefetched block (0 = none)
   uint32_t nx_pair = 0;
   int nx_share = 0;
-  const int batch_class1 = plan.phase_begin != 0 ? __builtin_amdgcn_readfirstlane(plan.walk[n_pairs].state) : 0;
-  const int blk = max(1, min(plan.unit_block, kWave));
+  const int blk = 1;           // (every unit of the launch has work: the workgroups take them one by one -- pairs differ a lot)
+  const bool phased = plan.phased != 0;
+  const bool use_preclass = phased && plan.preclass_iters > 0;
 
   // ---- the next block of units off the counter; the facts that decide which of them have work are requested (global ->
   // LDS), not awaited
@@ -707,17 +751,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     if (lane < nx_n) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&plan.prep[nx_pair].n_all,
                                        (__attribute__((address_space(3))) void*)lds.claim_nall, 4, 0, 0);
-      // walk[pair].state >= 0: upper bound of the iterations the pair can still need; < 0: its loop has ended
-      // (the first launch of a batch: every pair is still running)
-      if (plan.phase_begin != 0) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&plan.walk[nx_pair].state,
-                                         (__attribute__((address_space(3))) void*)lds.claim_state, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&plan.walk[nx_pair].speculate,
-                                         (__attribute__((address_space(3))) void*)lds.claim_cls, 4, 0, 0);
-      } else if (plan.first_spec) {  // (one byte per pair, read as the low byte of a dword: the array has slack behind it)
+      if (use_preclass)  // (one byte per pair, read as the low byte of a dword: the array has slack behind it)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plan.preclass + nx_pair),
                                          (__attribute__((address_space(3))) void*)lds.claim_cls, 4, 0, 0);
-      }
     }
   };
   // ---- the prefetched block becomes the block in use: which of its units have anything to do in this launch
@@ -725,18 +761,15 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const int lane = fresh(threadIdx.x & (kWave - 1));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requested at least one pass of the server's loop ago)
     const int n_all = lds.claim_nall[lane];
-    const int state = plan.phase_begin != 0 ? lds.claim_state[lane] : I;
-    // class 2 (no jump of `it` so far, junk-heavy; class 1 when the batch has few such pairs: effective_class): everything
-    // that is left is recorded in this launch
-    int cls = plan.phase_begin != 0 ? lds.claim_cls[lane] : (plan.first_spec ? (lds.claim_cls[lane] & 0xFF) : 0);
-    if (cls == 1) cls = ((uint32_t)batch_class1 * 64u <= n_pairs) ? 2 : 0;
-    const int end = min(cls == 2 ? plan.spec_end : plan.phase_end, state);
-    const int k_begin = plan.phase_begin + nx_share * plan.share_iters;
-    const int k_end = min(k_begin + plan.share_iters, end);
-    // no RANSAC for this pair (node.cpp:1087, :1130), or nothing of this range is needed (any more)
-    const bool have = lane < nx_n && state >= 0 && k_begin < k_end && n_all > rc.min_matches && n_all >= 4;
+    // phased plans: a pair the hypothesis kernel has found junk-heavy (class 2) is recorded in one window, the others start
+    // with the first phase; full speculation: the unit's share of the range
+    const int cls = use_preclass ? (((lds.claim_cls[lane] & 0xFF) == 2) ? 2 : -1) : -1;
+    const int k_begin = phased ? 0 : nx_share * plan.share_iters;
+    const int k_end = phased ? min(cls == 2 ? I : plan.phase_ends[0], kMaxShare) : min(k_begin + plan.share_iters, I);
+    // no RANSAC for this pair (node.cpp:1087, :1130), or an empty share
+    const bool have = lane < nx_n && k_begin < k_end && n_all > rc.min_matches && n_all >= 4;
     live = __ballot(have);
-    u_pair = nx_pair; u_kb = k_begin; u_ke = k_end;
+    u_pair = nx_pair; u_kb = k_begin; u_ke = k_end; u_cls = cls;
     lsync();   // (the staging arrays have been read before the next block's facts land in them)
     prefetch_block();
   };
@@ -755,6 +788,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       free_bufs &= free_bufs - 1ull;
       const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)u_pair, src);
       const int kb = __builtin_amdgcn_readlane(u_kb, src), ke = __builtin_amdgcn_readlane(u_ke, src);
+      const int cls = __builtin_amdgcn_readlane(u_cls, src);
       UnitCtx& cx = lds.ctx[b];
       const char* __restrict__ srcp = reinterpret_cast<const char*>(plan.prep + pair);
       char* const dst = reinterpret_cast<char*>(&lds.prep[b]);
@@ -774,13 +808,40 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         cx.pair = pair;
         cx.kb = kb;
         cx.ke = ke;
+        cx.cls = cls;
         cx.state = kUnitLoading;
       }
       ST_ADD(5, 1)
     }
   };
 
-  // ---- the loads issued a half-round ago have arrived: the lists of the units' viable iterations, the buffers are ready
+  // ---- the list of the viable iterations of unit b's window [kb, ke) from the mask words in cx.mw (lane = iteration of a
+  // word); the window is ready to be handed out, or has drained already when nothing of it passed the pre-screen
+  auto build_list = [&](int b) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    UnitCtx& cx = lds.ctx[b];
+    const int kb = __builtin_amdgcn_readfirstlane(cx.kb), ke = __builtin_amdgcn_readfirstlane(cx.ke);
+    const int blk0 = kb >> 6;
+    const int n_words = ((ke - 1) >> 6) - blk0 + 1;  // <= kMaskLanes
+    int total = 0;
+    for (int c = 0; c < n_words; ++c) {
+      uint64_t wc = uniform_u64(cx.mw[c]);
+      const int lo = (blk0 + c) << 6;
+      if (kb > lo) wc &= ~0ull << (kb - lo);
+      if (ke - lo < 64) wc &= (1ull << (ke - lo)) - 1ull;
+      if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)((c << 6) + lane);
+      total += __popcll(wc);
+    }
+    if (lane == 0) {
+      cx.base = blk0 << 6;
+      cx.n_items = total;
+      cx.next = 0;
+      cx.done = 0;
+      cx.state = total > 0 ? kUnitReady : kUnitDrained;
+    }
+  };
+
+  // ---- the loads issued a half-round ago have arrived: the first window of each unit
   auto complete_loads = [&]() {
     const int lane = fresh(threadIdx.x & (kWave - 1));
     uint64_t loading = __ballot(lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitLoading);
@@ -790,28 +851,97 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       const int b = (int)__builtin_ctzll(loading);
       loading &= loading - 1ull;
       UnitCtx& cx = lds.ctx[b];
-      const int kb = __builtin_amdgcn_readfirstlane(cx.kb), ke = __builtin_amdgcn_readfirstlane(cx.ke);
-      const int blk0 = kb >> 6;
-      const int n_words = ((ke - 1) >> 6) - blk0 + 1;  // <= kMaskLanes
-      int total = 0;
-      for (int c = 0; c < n_words; ++c) {  // lane = iteration of word c builds the list
-        uint64_t wc = uniform_u64(cx.mw[c]);
-        const int lo = (blk0 + c) << 6;
-        if (kb > lo) wc &= ~0ull << (kb - lo);
-        if (ke - lo < 64) wc &= (1ull << (ke - lo)) - 1ull;
-        if ((wc >> lane) & 1ull) cx.klist[total + (int)lane_rank(wc)] = (uint16_t)((c << 6) + lane);
-        total += __popcll(wc);
-      }
       const int n_all = lds.prep[b].n_all;
       uint32_t thr = (uint32_t)rc.min_matches;                                       // :1094
       if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
       if (lane == 0) {
         cx.thr = thr;
-        cx.base = blk0 << 6;
-        cx.n_items = total;
-        cx.next = 0;
-        cx.done = 0;
-        cx.state = total > 0 ? kUnitReady : kUnitFree;   // (no iteration of the range passed the pre-screen: nothing to refine)
+        cx.w_it = 0; cx.w_real = 0; cx.w_valid = 0; cx.w_best_idx = -1; cx.w_best_n = 0;
+        cx.w_rmse = 1e6f;   // :1112
+        cx.w_state = I;
+      }
+      build_list(b);
+    }
+    lsync();
+  };
+
+  // ---- units whose window has drained.  Full speculation: the buffer is free.  Phased plans: the reference's in-order
+  // bookkeeping (node.cpp:1171-1190) over what the pair has recorded so far -- unless nothing can follow the window anyway
+  // -- and then either the pair's loop has ended / everything it can still need is recorded (the walk state goes to memory
+  // for the result wave, WalkState::speculate = end of the recorded range), or the next window.
+  auto advance_units = [&]() {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    uint64_t drained = __ballot(lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state == kUnitDrained);
+    if (drained == 0ull) return;
+    while (drained != 0ull) {
+      const int b = (int)__builtin_ctzll(drained);
+      drained &= drained - 1ull;
+      UnitCtx& cx = lds.ctx[b];
+      if (!phased) {
+        if (lane == 0) cx.state = kUnitFree;
+        continue;
+      }
+      const uint32_t pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)cx.pair);
+      const int n_all = __builtin_amdgcn_readfirstlane(lds.prep[b].n_all);
+      const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)cx.thr);
+      int cls = __builtin_amdgcn_readfirstlane(cx.cls);
+      WalkRegs wr{__builtin_amdgcn_readfirstlane(cx.w_it), __builtin_amdgcn_readfirstlane(cx.w_real),
+                  __builtin_amdgcn_readfirstlane(cx.w_valid), __builtin_amdgcn_readfirstlane(cx.w_best_idx),
+                  __builtin_amdgcn_readfirstlane(cx.w_best_n),
+                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx.w_rmse))), false};
+      int state = __builtin_amdgcn_readfirstlane(cx.w_state);
+      int ke = __builtin_amdgcn_readfirstlane(cx.ke);
+      bool finished = false;
+      for (;;) {   // (a window without a viable iteration drains at once: the loop goes on to the next one)
+        if (ke >= min(I, state)) { finished = true; break; }   // nothing can follow this window: the result wave walks
+        // every record of the window is in memory: the workers wait for their stores before the barrier behind which the
+        // server sees `done`; the server's own (iterations ended by a NaN refit) are awaited here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const IterSum* __restrict__ sum_pair = plan.sums + (size_t)pair * (size_t)I;
+        const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
+        walk_records<true>(wr, ke, I, n_all, thr, sum_pair,
+                           [&](int k) { return ((vm_pair[k >> 6] >> (k & 63)) & 1ull) != 0ull; }, lane);
+        state = (!wr.done && wr.it < I) ? wr.real_iterations + (I - wr.it) : -1;
+        if (state < 0) { finished = true; break; }
+        if (cls < 0) {   // the first walk: 2 = nothing has jumped `it` ahead and at most 9 of 14 iterations were valid
+          const bool no_jump = wr.it == wr.real_iterations;
+          const bool junk_heavy = wr.valid_iterations * kClass2Den <= wr.real_iterations * kClass2Num;
+          cls = no_jump ? (junk_heavy ? 2 : 1) : 0;
+        }
+        int target = I;
+        if (cls != 2)
+          for (int ph = plan.n_phases - 1; ph >= 0; --ph)
+            if (plan.phase_ends[ph] > ke) target = plan.phase_ends[ph];
+        const int end = min(min(target, state), I);
+        if (ke >= end) { finished = true; break; }
+        const int kb = ke;
+        ke = min(end, kb + kMaxShare);
+        // the window's words of the viable mask (written by the hypothesis kernel, a launch ago)
+        const int blk0 = kb >> 6;
+        const int n_w = min(kMaskLanes, plan.vmask_words - blk0);
+        {   // (lane tests inside this loop: each opaque to the compiler on its own, see score_slot)
+          const int ln = fresh(threadIdx.x & (kWave - 1));
+          if (ln < n_w) cx.mw[ln] = vm_pair[blk0 + ln];
+        }
+        if (fresh(threadIdx.x & (kWave - 1)) == 0) { cx.kb = kb; cx.ke = ke; }
+        lsync();
+        build_list(b);
+        lsync();
+        if (__builtin_amdgcn_readfirstlane(cx.state) == kUnitReady) break;
+      }
+      if (lane == 0) {
+        if (finished) {
+          WalkState ws;
+          ws.state = state; ws.it = wr.it; ws.real_iterations = wr.real_iterations; ws.valid_iterations = wr.valid_iterations;
+          ws.best_idx = wr.best_idx; ws.best_n = wr.best_n; ws.rmse = wr.rmse;
+          ws.speculate = ke;
+          plan.walk[pair] = ws;
+          cx.state = kUnitFree;
+        } else {
+          cx.cls = cls;
+          cx.w_it = wr.it; cx.w_real = wr.real_iterations; cx.w_valid = wr.valid_iterations;
+          cx.w_best_idx = wr.best_idx; cx.w_best_n = wr.best_n; cx.w_rmse = wr.rmse; cx.w_state = state;
+        }
       }
     }
     lsync();
@@ -848,8 +978,8 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     lsync();
   };
 
-  // ---- iterations of group gs that have left their refinement loop: the slot is free again, and so is the unit's
-  // buffer once all its iterations have ended
+  // ---- iterations of group gs that have left their refinement loop: the slot is free again, and the unit's window has
+  // drained once all its iterations have ended
   auto recycle = [&](int gs) {
     const int lane = fresh(threadIdx.x & (kWave - 1));
     SlotS& sl = lds.slot[gs * kGroupSlots + min(lane, kGroupSlots - 1)];
@@ -857,7 +987,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     if (__ballot(fin) == 0ull) return;
     const int b = fin ? sl.buf : -1;
     if (fin) {
-      if (sl.active == kSlotDone) write_record(sl);  // (ended by a NaN refit: nobody has written its record yet)
+      if (sl.active == kSlotDone) write_summary(sl);  // (ended by a NaN refit: nobody has written its summary yet)
       sl.iter = -1;
       sl.active = kSlotDone;
     }
@@ -867,7 +997,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       if (c > 0 && lane == 0) {
         UnitCtx& cx = lds.ctx[q];
         cx.done += c;
-        if (cx.done == cx.n_items) cx.state = kUnitFree;
+        if (cx.done == cx.n_items) cx.state = kUnitDrained;
       }
     }
     lsync();
@@ -926,13 +1056,6 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       for (int e = 0; e < 6; ++e) v[e] = hyp[e];
 #pragma unroll
       for (int e = 0; e < 6; ++e) reinterpret_cast<float2*>(sl.u.x.R)[e] = v[e];  // -> R[9], t[3]
-      const float IR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-#pragma unroll
-      for (int i = 0; i < 9; ++i) sl.rR[i] = IR[i];  // :1137 refined = Identity
-#pragma unroll
-      for (int i = 0; i < 3; ++i) sl.rt[i] = 0.f;
-#pragma unroll
-      for (int r = 0; r < kRounds; ++r) sl.rmask[r] = 0ull;
       sl.rerr = 1e6;  // :1133
       sl.rn = 0;      // :1134
       sl.active = kSlotActive;
@@ -1006,6 +1129,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   adopt_block();
   issue_loads();
   complete_loads();
+  advance_units();
   hand_out(0);
   deal_work(0);
   issue_loads();
@@ -1015,19 +1139,20 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const int g = h & 1, gs = 1 - g;   // gs: the group nobody scores in this half-round
     const int by_ticket = __builtin_amdgcn_readfirstlane(lds.tickets[g]);
     ST_ADD(0, 1) ST_ADD(2, by_ticket) ST_ADD(3, lds.n_act[g])
-    ST_LAP(7)
+    ST_LAP(15)
     serve_svd(gs);
-    ST_LAP(0)
+    ST_LAP(8)
     recycle(gs);
-    ST_LAP(1)
+    ST_LAP(9)
     complete_loads();
-    ST_LAP(2)
+    advance_units();
+    ST_LAP(10)
     hand_out(gs);
-    ST_LAP(3)
+    ST_LAP(11)
     deal_work(gs);
-    ST_LAP(4)
+    ST_LAP(12)
     issue_loads();
-    ST_LAP(5)
+    ST_LAP(13)
     const int lane = fresh(threadIdx.x & (kWave - 1));
     bool busy = lane < kBufs && lds.ctx[min(lane, kBufs - 1)].state != kUnitFree;   // items to hand out, in flight, or a load
     busy = busy || (lane < kStreamSlots && lds.slot[min(lane, kStreamSlots - 1)].iter >= 0) ||
@@ -1035,19 +1160,19 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const bool more = __ballot(busy) != 0ull || live != 0ull || nx_n != 0 || units_left;
     if (!more && lane == 0) lds.quit = 1;
     if (by_ticket) {
-      score_tickets(g);   // its own duties done, the server scores like everybody else
-      ST_LAP(6)
+      if (kServerScores) score_tickets(g);   // its own duties done, the server scores like everybody else
+      ST_LAP(14)
       lds_barrier();
     }
     lds_barrier();        // (the workers' bookkeeping and refits of group g)
-    ST_LAP(7)
-    if (!more) { ST_ADD(1, 1) ST_MAX(7, h + 1) ST_FLUSH(8, 8) break; }
+    ST_LAP(15)
+    if (!more) { ST_ADD(1, 1) ST_MAX(7, h + 1) ST_OUT break; }
   }
 }
 
 void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan,
                        hipStream_t stream) {
-  if (n_pairs == 0 || rc.ransac_iterations <= 0) return;
+  if (n_pairs == 0) return;   // (no iterations: the pairs' walk states are still initialised)
   hipLaunchKernelGGL(ransac_hyp_kernel, dim3(n_pairs), dim3(kHypThreads), 0, stream, work, n_pairs, rc, plan);
 }
 
@@ -1084,8 +1209,7 @@ void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPl
   if (units == 0) return;
   // persistent workgroups: two per CU (LDS), each streaming units through its three LDS buffers; the units are handed out
   // through plan.unit_counter (zero at launch)
-  const int n_cus = ransac_split_init();
-  const uint32_t max_wgs = 2u * (uint32_t)n_cus;
+  const uint32_t max_wgs = (uint32_t)ransac_split_wgs();
 #ifdef RGBDFE_SPLIT_ONE_WG_PER_CU   // diagnostics variant: more LDS than two workgroups of a CU can get
   const size_t lds_bytes = 100 * 1024;
 #else
@@ -1100,15 +1224,16 @@ int ransac_split_words_per_pair(int ransac_iterations) {
   return 4 * ((I + kHypThreads - 1) / kHypThreads);  // a workgroup of the hypothesis kernel writes 4 words per pass
 }
 int ransac_split_max_share() { return kMaxShare; }
+int ransac_split_wgs() { return kWgsPerCu * ransac_split_init(); }
 
 }  // namespace rgbdfe
 
 #ifdef RGBDFE_SPLIT_STATS
-extern "C" int rgbdfe_debug_split_stats(unsigned long long* out24, int reset) {
-  if (out24 && hipMemcpyFromSymbol(out24, HIP_SYMBOL(rgbdfe::g_split_stats), 192) != hipSuccess) return -1;
+extern "C" int rgbdfe_debug_split_stats(unsigned long long* out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(rgbdfe::g_split_stats), 256) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[24] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_stats), z, 192) != hipSuccess) return -1;
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_stats), z, 256) != hipSuccess) return -1;
   }
   return 0;
 }

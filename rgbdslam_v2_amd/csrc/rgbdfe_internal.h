@@ -116,37 +116,45 @@ struct RecordPlan {
   const PairPrep* prep = nullptr;  // [pair], every mode
   double* ec_pool = nullptr;  // every mode: select_ransac_ec_region_bytes() per launched wave (the inlier errors of
                               // a refinement round's scorings, read back lane = slot by the sequential error sums)
+  // result waves of the split path: the walk over [WalkState::real_iterations, WalkState::speculate) is theirs
+  int final_walk = 0;
+  const uint64_t* vmask = nullptr;  // [pair][vmask_words]: SplitPlan::vmask
+  int vmask_words = 0;
 };
 size_t select_ransac_ec_region_bytes();
-// ransac_split.hip: the recording stage as a hypothesis kernel (lane = iteration) + a refinement kernel over the viable
-// iterations.  One plan per launch.
+// ransac_split.hip: the recording stage as a hypothesis kernel (lane = iteration) + ONE refinement launch over the viable
+// iterations of the whole batch.
 struct SplitPlan {
   IterRec* recs = nullptr;     // [pair][iteration]: the hypothesis kernel leaves a viable iteration's transform in rR / rt,
                                // the refinement kernel the iteration's outcome
   IterSum* sums = nullptr;     // [pair][iteration]
   uint64_t* vmask = nullptr;   // [pair][vmask_words]: bit k of a pair = iteration k passed the pre-screen
-  WalkState* walk = nullptr;   // [pair] (+ the batch's class-1 counter)
+  WalkState* walk = nullptr;   // [pair] (+ the batch's counters in walk[n_pairs])
   const PairPrep* prep = nullptr;
   int vmask_words = 0;
-  int phase_begin = 0, phase_end = 0;
-  int spec_end = 0;            // class-2 pairs record [phase_begin, spec_end), the others [phase_begin, phase_end)
-  int n_shares = 1;            // workgroup units per pair: the range in shares of share_iters iterations
+  // phased = 0 (small batches, full speculation): a workgroup unit is (pair, share of share_iters iterations); everything is
+  //          recorded, the result waves walk.
+  // phased = 1: a unit is a pair.  Its range is recorded in WINDOWS inside the kernel -- [0, phase_ends[0]) first, or
+  //          [0, I) at once for a pair the pre-screen shows to be junk-heavy -- and between two windows the workgroup's
+  //          server runs the reference's in-order bookkeeping over what has been recorded: the loop has ended, or the next
+  //          window (the next phase; everything that is left for a junk-heavy pair without a jump of `it`; never beyond
+  //          the iterations the pair can still need).  The pair's match records stay in LDS across its windows.
+  int phased = 0;
+  int n_phases = 1;
+  int phase_ends[4] = {0, 0, 0, 0};
+  int n_shares = 1;            // phased = 0: units per pair
   int share_iters = 0;
   uint8_t* preclass = nullptr; // [pair]: 2 = at most 9 of the first 14 iterations passed the pre-screen ("junk-heavy" whatever
                                // their refinement gives: such a pair will most likely run all its iterations) -- written by the
-                               // hypothesis kernel when preclass_iters > 0; the first refinement launch of a phased plan then
-                               // records ALL iterations of these pairs (first_spec) instead of the first phase only
+                               // hypothesis kernel when preclass_iters > 0
   int preclass_iters = 0;      // the first phase's length (14), 0 = no pre-classification
   uint32_t* unit_counter = nullptr;  // zero at launch: the refinement kernel's workgroups take their units off it
-  int unit_block = 1;          // units a workgroup's server takes off the counter at a time (lane = unit: units without work
-                               // cost nothing); 1 while every unit has work, larger for the later phases of a plan
-  int phase_index = 0;         // > 0: the launch has work only when walk[n_pairs].best_n == phase_index (set by the walk of the phase before)
-  int first_spec = 0;          // this launch is the first phase of a phased plan: preclass-2 pairs record [0, spec_end)
 };
 void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
 void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
 int ransac_split_words_per_pair(int ransac_iterations);
 int ransac_split_max_share();
+int ransac_split_wgs();   // persistent workgroups of a refinement launch on this device
 int ransac_split_init();  // once per process before the first batch (not inside a stream capture); returns the CU count
 // bytes of the per-pair iteration masks behind the records + summaries of a record buffer of `rec_capacity` records
 inline size_t ransac_split_mask_bytes(size_t rec_capacity, size_t max_pairs) { return (rec_capacity / 64 + 5 * max_pairs + 64) * 8; }  // + 8 bytes per pair: preclass

@@ -1054,14 +1054,23 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       }
 #endif
     } else if (MODE == kReplay) {
-      // the in-order bookkeeping ran in replay_walk_kernel: adopt its outcome and the record of the best iteration
+      // the in-order bookkeeping: adopt its outcome and the record of the best iteration.  One-kernel recording stage: it
+      // ran in replay_walk_kernel, phase by phase.  Split path (plan.final_walk): the refinement kernel has walked what it
+      // had to know between a pair's windows (nothing at all for a pair recorded in one window) and left the end of the
+      // pair's recorded range in WalkState::speculate; the rest of the walk is this wave's.
       const WalkState ws = plan.walk[pair];
-      valid_iterations = ws.valid_iterations;
-      real_iterations = ws.real_iterations;
-      best_n = ws.best_n;
-      rmse = ws.rmse;
-      if (ws.best_idx >= 0 && lane == 0) {
-        const IterRec& r = rec_pair[ws.best_idx];
+      WalkRegs wr{ws.it, ws.real_iterations, ws.valid_iterations, ws.best_idx, ws.best_n, ws.rmse, ws.state < 0};
+      if (plan.final_walk && n_all >= 4) {
+        const uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
+        walk_records<false>(wr, min(ws.speculate, rc.ransac_iterations), rc.ransac_iterations, n_all, thr, sum_pair,
+                            [&](int k) { return ((vm_pair[k >> 6] >> (k & 63)) & 1ull) != 0ull; }, lane);
+      }
+      valid_iterations = wr.valid_iterations;
+      real_iterations = wr.real_iterations;
+      best_n = wr.best_n;
+      rmse = wr.rmse;
+      if (wr.best_idx >= 0 && lane == 0) {
+        const IterRec& r = rec_pair[wr.best_idx];
         Hyp& b = lds.best;
 #pragma unroll
         for (int i = 0; i < 9; ++i) b.R[i] = r.rR[i];
@@ -1249,62 +1258,19 @@ __global__ __launch_bounds__(kWave) void replay_walk_kernel(const IterSum* __res
   uint32_t thr = (uint32_t)rc.min_matches;                                         // :1094
   if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
   const IterSum* __restrict__ sum_pair = sums + (size_t)pair * (size_t)(I > 0 ? I : 0);
-  int it = ws.it, real_iterations = ws.real_iterations, valid_iterations = ws.valid_iterations;
-  int best_idx = ws.best_idx, best_n = ws.best_n;
-  float rmse = ws.rmse;
-  bool done = false;
+  WalkRegs wr{ws.it, ws.real_iterations, ws.valid_iterations, ws.best_idx, ws.best_n, ws.rmse, false};
   const bool runs = n_all > rc.min_matches && n_all >= 4;  // :1087, :1130
-  while (runs && !done && it < I && real_iterations < recorded_end) {
-    const int k0 = real_iterations;
-    const int G = min(kWave, recorded_end - k0);
-    int rn_l = 0;
-    double rerr_l = 0.0;
-    // split path: an iteration the pre-screen rejected has no summary at all -- the pair's viable mask says so (its bit is
-    // clear) and it counts as {1e6, 0} (the hypothesis kernel used to write 16 bytes for every one of them: 12.8 MB per batch
-    // of configs[1] written and read back up to four times)
-    bool listed = lane < G;
-    if (listed && vmask != nullptr) {
-      const int k = k0 + lane;
-      listed = ((vmask[(size_t)pair * (size_t)vmask_words + (size_t)(k >> 6)] >> (k & 63)) & 1ull) != 0ull;
-    }
-    if (listed) {
-      const IterSum su = sum_pair[k0 + lane];
-      rn_l = su.rn;
-      rerr_l = su.rerr;
-    }
-    // Iterations whose refinement left refined_matches empty (:1171 fails) only count: `if (!(it < I)) break;
-    // real_iterations++; ++it` -- a run of them is taken in one step; only the others are looked at one by one.
-    const uint64_t with_matches = __ballot(lane < G && rn_l > 0);
-    for (int g = 0; g < G;) {
-      const uint64_t rest = with_matches >> g;
-      const int run = rest != 0ull ? (int)__builtin_ctzll(rest) : G - g;  // empty iterations before the next one with matches
-      if (run > 0) {
-        const int can = min(run, max(I - it, 0));  // (`it` may have jumped beyond ransac_iterations, :1186-1187)
-        real_iterations += can;            // :1139
-        it += can;
-        if (can < run) { done = true; break; }  // the next check of `it < ransac_iterations` fails (:1130)
-        g += run;
-        if (g >= G) break;
-      }
-      if (!(it < I)) { done = true; break; }
-      real_iterations++;  // :1139
-      const int refined_n = __builtin_amdgcn_readlane(rn_l, g);
-      const double refined_error = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rerr_l), g),
-                                                    __builtin_amdgcn_readlane(__double2loint(rerr_l), g));
-      // refined_n > 0 (:1171)
-      valid_iterations++;
-      if (refined_error <= (double)rmse && refined_n >= best_n && (uint32_t)refined_n >= thr) {  // :1177
-        rmse = (float)refined_error;  // :1182
-        best_idx = k0 + g;
-        best_n = refined_n;
-        if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
-        if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
-        if ((double)refined_n > (double)n_all * 0.8) { done = true; break; }  // :1188
-      }
-      ++it;
-      ++g;
-    }
-  }
+  // split path: an iteration the pre-screen rejected has no summary at all -- the pair's viable mask says so (its bit is
+  // clear) and it counts as {1e6, 0} (the hypothesis kernel used to write 16 bytes for every one of them: 12.8 MB per batch
+  // of configs[1] written and read back up to four times)
+  const uint64_t* __restrict__ vm_pair = vmask != nullptr ? vmask + (size_t)pair * (size_t)vmask_words : nullptr;
+  if (runs)
+    walk_records<false>(wr, recorded_end, I, n_all, thr, sum_pair,
+                        [&](int k) { return vm_pair == nullptr || ((vm_pair[k >> 6] >> (k & 63)) & 1ull) != 0ull; }, lane);
+  const int it = wr.it, real_iterations = wr.real_iterations, valid_iterations = wr.valid_iterations;
+  const int best_idx = wr.best_idx, best_n = wr.best_n;
+  const float rmse = wr.rmse;
+  const bool done = wr.done;
   if (lane == 0) {
     // records ran out before the loop ended: at most (I - it) more iterations can follow
     ws.state = (runs && !done && it < I) ? real_iterations + (I - it) : -1;
@@ -1373,42 +1339,36 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     // everything at once (the classes only schedule the recording: the walk decides the outcome either way)
     static const bool no_pre = getenv("RGBDFE_NO_PRECLASS") && atoi(getenv("RGBDFE_NO_PRECLASS")) != 0;  // A/B runs
     sp.preclass_iters = (n_phases > 2 && !no_pre) ? phase_ends[0] : 0;
+    // ONE refinement launch for the whole batch.  Phased plans: a unit is a pair, whose range the kernel records in windows
+    // with the in-order walk between them (SplitPlan); latency batches (one phase, full speculation): a pair's range in
+    // shares of 4 x chunk_iters iterations so that a handful of pairs still fills the chip.  The result waves below finish
+    // the walk.
+    sp.phased = n_phases > 1 ? 1 : 0;
+    sp.n_phases = n_phases < 4 ? n_phases : 4;
+    for (int p = 0; p < 4; ++p) sp.phase_ends[p] = p < sp.n_phases ? (p == sp.n_phases - 1 ? I : phase_ends[p]) : I;
+    int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * 4;
+    if (share > ransac_split_max_share()) share = ransac_split_max_share();
+    sp.n_shares = sp.phased ? 1 : (I > 0 ? (I + share - 1) / share : 1);
+    sp.share_iters = sp.phased ? I : (I > 0 ? (I + sp.n_shares - 1) / sp.n_shares : share);
+    // (the launch's unit counter: a spare word of walk[n_pairs], zeroed by the hypothesis kernel)
+    sp.unit_counter = reinterpret_cast<uint32_t*>(&walk[n_pairs].it);
     launch_ransac_hyp(work, n_pairs, rc, sp, stream);
-  }
+    if (I > 0) launch_ransac_refine(n_pairs, rc, sp, stream);
+    plan.final_walk = 1;
+    plan.vmask = sp.vmask;
+    plan.vmask_words = sp.vmask_words;
+  } else {
   for (int p = 0; p < n_phases; ++p) {
     const int end = phase_ends[p];
     // The second phase of a phased plan covers everything that is left for the pairs of class 2 (see replay_walk_kernel);
-    // units / waves that have nothing to do for their pair return at once.
+    // waves that have nothing to do for their pair return at once.
 #ifdef RGBDFE_NO_SUBGRID_B  // diagnostics build
     const bool spec = false;
 #else
     const bool spec = n_phases > 2 && p == 1 && I > end;
 #endif
-    const bool first_spec = split && sp.preclass_iters > 0 && p == 0 && I > end;
-    const int cover = (spec || first_spec) ? I : end;
-    if (split) {
-      // units = (pair, share of the range): latency batches cut a pair's range into shares of 4 x chunk_iters iterations
-      // so that a handful of pairs still fills the chip; throughput batches (chunk_iters >= 28: more than 1280 pairs)
-      // keep a pair's range together, up to the 512 iterations a unit's list holds
-      int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * 4;
-      if (share > ransac_split_max_share()) share = ransac_split_max_share();
-      sp.phase_begin = begin; sp.phase_end = end; sp.spec_end = cover; sp.first_spec = first_spec ? 1 : 0;
-      sp.n_shares = cover > begin ? (cover - begin + share - 1) / share : 1;
-      sp.share_iters = cover > begin ? (cover - begin + sp.n_shares - 1) / sp.n_shares : share;
-      // (the launch's unit counter: a spare word of walk[n_pairs], zeroed by the hypothesis kernel; a plan has at most 4 phases)
-      sp.unit_counter = reinterpret_cast<uint32_t*>(&walk[n_pairs].it) + p;
-      sp.phase_index = p;
-      // the first launch of a batch: every unit has work, the workgroups take them one by one (pairs differ a lot in their
-      // work).  Later phases: most pairs have ended -- a workgroup looks at a block of units at once (lane = unit) and
-      // loads the few that still run
-      {
-        const uint32_t units = n_pairs * (uint32_t)sp.n_shares;
-        const uint32_t wgs = 2u * (uint32_t)ransac_split_init();
-        const uint32_t per_wg = units / (wgs > 0 ? wgs : 1u);
-        sp.unit_block = p == 0 ? 1 : (int)(per_wg < 2u ? 1u : (per_wg > 32u ? 16u : per_wg / 2u));
-      }
-      if (cover > begin) launch_ransac_refine(n_pairs, rc, sp, stream);
-    } else {
+    const int cover = spec ? I : end;
+    {
       // the one-kernel recording launch of this phase
       // sub-grid A: the phase in ceil(length / chunk) equal shares (a short last wave would be the launch's straggler)
       const int n_chunks = (end - begin + chunk_iters - 1) / chunk_iters;
@@ -1427,9 +1387,10 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
                            results, n_pairs, rc, plan);  // 8 XCD segments x pairs per segment x shares per pair
     }
     hipLaunchKernelGGL(replay_walk_kernel, dim3(n_pairs), dim3(kWave), 0, stream, plan.sums, walk, prep, n_pairs, rc, begin,
-                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0, first_spec ? sp.preclass : (const uint8_t*)nullptr, p,
-                       split ? sp.vmask : (const uint64_t*)nullptr, sp.vmask_words);
+                       end, cover, (n_phases > 2 && p == 0) ? 1 : 0, (const uint8_t*)nullptr, p,
+                       (const uint64_t*)nullptr, 0);
     begin = end;
+  }
   }
   plan.n_chunks = 1;
   plan.n_chunks_b = 0;

@@ -27,7 +27,7 @@ buf = torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cu
 for i in range(2):
     fe.wait_ticket(fe.submit_pair_list(pq, pt, buf.data_ptr()), None)
 fe.synchronize()
-st = (C.c_ulonglong * 24)()
+st = (C.c_ulonglong * 32)()
 L.rgbdfe_debug_split_stats(st, 1)
 fe.reset_kernel_time()
 fe.set_profiling(True)
@@ -45,7 +45,11 @@ print(json.dumps({"depth_noise": noise, "batches": B, "stage_ms_per_batch": roun
                   "longest_workgroup_half_rounds": v[7], "ticket_half_round_fraction": round(v[2] / max(v[0], 1), 3),
                   "scorings_per_batch": v[3] / B, "scorings_per_half_round": round(v[3] / max(v[0], 1), 2),
                   "svd_requests_per_batch": v[4] / B, "iterations_ended_per_batch": v[20] / B,
-                  "ended_after_first_scoring_per_batch": v[21] / B, "ended_without_refined_set_per_batch": v[22] / B, "units_loaded_per_batch": v[5] / B, "items_per_batch": v[6] / B,
+                  "ended_after_first_scoring_per_batch": v[21] / B, "ended_without_refined_set_per_batch": v[22] / B,
+                  "recurrence_passes_per_batch": v[23] / B, "recurrence_steps_per_pass": round(v[24] / max(v[23], 1), 1),
+                  "refits_per_recurrence_pass": round(v[25] / max(v[23], 1), 2), "scorings_with_pass2_per_batch": v[26] / B,
+                  "pass2_rounds_per_batch": v[27] / B, "error_sum_additions_per_batch": v[28] / B,
+                  "pass1_candidates_per_scoring": round(v[29] / max(v[3], 1), 1), "units_loaded_per_batch": v[5] / B, "items_per_batch": v[6] / B,
                   "server_us_per_half_round": dict(zip(("svd", "recycle", "complete_loads", "hand_out", "list_active", "issue_loads",
                                                         "ticket_scoring", "barrier_wait"), [round(x / 100.0 / max(v[0], 1), 2) for x in v[8:16]])),
                   "worker0_us_per_half_round": dict(zip(("scoring", "bookkeeping_refit", "barrier_wait"),
