@@ -121,8 +121,12 @@ __device__ unsigned long long g_split_stats[32];
 #define RGBDFE_SPLIT_WAVES 8
 #endif
 constexpr int kStreamWaves = RGBDFE_SPLIT_WAVES;       // waves of a refinement workgroup: the workers + the server
-static_assert(kStreamWaves >= 3 && 16 % kStreamWaves == 0, "16 waves per CU (4 per SIMD at <= 128 VGPRs) in whole workgroups");
-constexpr int kWgsPerCu = 16 / kStreamWaves;
+#ifndef RGBDFE_SPLIT_WGS_PER_CU
+#define RGBDFE_SPLIT_WGS_PER_CU (16 / RGBDFE_SPLIT_WAVES)
+#endif
+constexpr int kWgsPerCu = RGBDFE_SPLIT_WGS_PER_CU;     // (default: 16 waves per CU = 4 per SIMD at <= 128 VGPRs)
+static_assert(kStreamWaves >= 3 && (kStreamWaves * kWgsPerCu) % 4 == 0, "whole waves per SIMD");
+#define RGBDFE_SPLIT_EU_WAVES (RGBDFE_SPLIT_WAVES * RGBDFE_SPLIT_WGS_PER_CU / 4)
 constexpr int kWorkers = kStreamWaves - 1;
 #ifndef RGBDFE_SPLIT_SERVER_SCORES
 #define RGBDFE_SPLIT_SERVER_SCORES (RGBDFE_SPLIT_WAVES >= 8)
@@ -142,7 +146,7 @@ constexpr int kStreamSlots = 2 * kGroupSlots;
 static_assert(kGroupSlots <= kWave, "the server looks at a group's slots with one lane each");
 static_assert(kStreamSlots <= 2 * kWave, "the server's end-of-work test looks at two slots per lane");
 #ifndef RGBDFE_SPLIT_TICKETS_FROM
-#define RGBDFE_SPLIT_TICKETS_FROM (24 * (RGBDFE_SPLIT_WAVES - 1) * RGBDFE_SPLIT_WAVE_SLOTS / 49)
+#define RGBDFE_SPLIT_TICKETS_FROM (24 * (RGBDFE_SPLIT_WAVES - 1) * RGBDFE_SPLIT_WAVE_SLOTS / 49)   // (half of a group's slots)
 #endif
 constexpr int kCostDear = 4;                           // a scoring that runs pass 2, in scorings of a junk hypothesis (the deal's weight)
 constexpr int kTicketsFrom = RGBDFE_SPLIT_TICKETS_FROM;  // expensive scorings in a group's pass from which they go out by ticket
@@ -177,7 +181,11 @@ struct SlotS {
   int iter;                  // RANSAC iteration held by the slot, -1 = free (written by the server only)
   int buf;                   // LDS buffer of the slot's unit
   uint32_t pair;             // the unit's pair
-  int pad;
+  // facts of the unit, copied at the hand-out: a scoring finds them with the slot's transform in one LDS round trip instead
+  // of chasing buf -> PairPrep / UnitCtx
+  int n_all;                 // PairPrep::n_all
+  uint32_t thr;              // UnitCtx::thr
+  float pmax;                // PairPrep::pmax
 };
 // scoring phase of a wave: candidates of pass 1, inlier bits, the inliers' errors in match order
 struct ScoreB {
@@ -272,30 +280,51 @@ __device__ __forceinline__ void score_b(const float* R, const float* tr, const f
     lo_f = S * 0.999999f - E;
     hi_f = S * 1.000001f + E;
   }
+  // (three steps over all five rounds -- every record first, then the float arithmetic, then the compaction -- instead of
+  // five rounds one after the other: a round that waits for its own LDS reads and ends in branches cost a wave five exposed
+  // LDS round trips per scoring, and these waves are bound by their own latencies, not by issue slots)
   int n_cand = 0;
+  float rec[kRounds][6];
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int m = r * kWave + lane;
-    const float pxf = M[m * kRec + 0], pyf = M[m * kRec + 1], pzf = M[m * kRec + 2];
-    const float qxf = M[m * kRec + 3], qyf = M[m * kRec + 4], qzf = M[m * kRec + 5];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rec[r][c] = M[m * kRec + c];
+  }
+  bool pre[kRounds], cand[kRounds];
+  bool unsure = false;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int m = r * kWave + lane;
+    const float pxf = rec[r][0], pyf = rec[r][1], pzf = rec[r][2];
+    const float qxf = rec[r][3], qyf = rec[r][4], qzf = rec[r][5];
     // node.cpp:994 (z == 0 skip) ; misc.cpp:712-717 (NaN -> DBL_MAX)
-    const bool pre = (m < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
+    pre[r] = (m < n_all) && !(pzf == 0.0f || qzf == 0.0f) && !(__builtin_isnan(pzf) || __builtin_isnan(qzf));
     const float f0 = __builtin_fmaf(R[0], pxf, __builtin_fmaf(R[1], pyf, __builtin_fmaf(R[2], pzf, tr[0]))) - qxf;
     const float f1 = __builtin_fmaf(R[3], pxf, __builtin_fmaf(R[4], pyf, __builtin_fmaf(R[5], pzf, tr[1]))) - qyf;
     const float f2 = __builtin_fmaf(R[6], pxf, __builtin_fmaf(R[7], pyf, __builtin_fmaf(R[8], pzf, tr[2]))) - qzf;
     const float dsq_f = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, f2 * f2));
     const bool sure_in = dsq_f < lo_f, sure_out = dsq_f > hi_f;
-    bool cand = pre && sure_in;
-    if (__ballot(pre && !(sure_in || sure_out)) != 0ull) {  // a lane too close to call: the round in double
+    cand[r] = pre[r] && sure_in;
+    unsure = unsure || (pre[r] && !(sure_in || sure_out));
+  }
+  if (__ballot(unsure) != 0ull) {  // a lane too close to call in some round: those rounds in double
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const float pxf = rec[r][0], pyf = rec[r][1], pzf = rec[r][2];
+      const float qxf = rec[r][3], qyf = rec[r][4], qzf = rec[r][5];
       const double a0 = (double)pxf, a1 = (double)pyf, a2 = (double)pzf;
       const double d0 = (((Rd[0] * a0 + Rd[1] * a1) + Rd[2] * a2) + td[0]) - (double)qxf;
       const double d1 = (((Rd[3] * a0 + Rd[4] * a1) + Rd[5] * a2) + td[1]) - (double)qyf;
       const double d2 = (((Rd[6] * a0 + Rd[7] * a1) + Rd[8] * a2) + td[2]) - (double)qzf;
       const double dsq = (d0 * d0 + d1 * d1) + d2 * d2;
-      cand = pre && !(dsq > shortcut) && !__builtin_isnan(d2);  // misc.cpp:731, 755
+      cand[r] = pre[r] && !(dsq > shortcut) && !__builtin_isnan(d2);  // misc.cpp:731, 755
     }
-    const uint64_t cm = __ballot(cand);
-    if (cand) sb.cand[n_cand + (int)lane_rank(cm)] = (uint16_t)m;
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint64_t cm = __ballot(cand[r]);
+    if (cand[r]) sb.cand[n_cand + (int)lane_rank(cm)] = (uint16_t)(r * kWave + lane);
     n_cand += __popcll(cm);
   }
   if (lane < 2 * kRounds) sb.mbits[lane] = 0u;
@@ -495,7 +524,7 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 // The refinement loops (node.cpp:1140-1169) of the viable iterations of [phase_begin, phase_end / spec_end): persistent
 // workgroups of 7 workers + 1 server, two slot groups taking turns, one s_barrier per half-round (see the file header).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_refine_kernel(
+__global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(RGBDFE_SPLIT_EU_WAVES, RGBDFE_SPLIT_EU_WAVES))) void ransac_refine_kernel(
     uint32_t n_pairs, const RansacConst rc, const SplitPlan plan, uint32_t n_units) {
   extern __shared__ __attribute__((aligned(16))) char stream_smem[];
   StreamLds& lds = *reinterpret_cast<StreamLds*>(stream_smem);
@@ -545,9 +574,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     for (int i = 0; i < 3; ++i) curt[i] = sl.u.x.t[i];
     const int b = __builtin_amdgcn_readfirstlane(sl.buf);
     const PairPrep& pp = lds.prep[b];
-    const int n_all = __builtin_amdgcn_readfirstlane(pp.n_all);
-    const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds.ctx[b].thr);
-    const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pp.pmax)));
+    const int n_all = __builtin_amdgcn_readfirstlane(sl.n_all);
+    const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.thr);
+    const float pmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.pmax)));
     // a scoring with fewer inliers than max(threshold, refined_matches.size()) is rejected whatever its error
     // is (:1154, :1160): the scorer may stop counting as soon as that is certain
     const uint32_t need = max(thr, (uint32_t)__builtin_amdgcn_readfirstlane(sl.rn));
@@ -618,7 +647,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         SlotS& sl = lds.slot[my_slot];
         if (sl.active == kSlotActive) {
           const int n_inl = sl.cn, rn = sl.rn;
-          const uint32_t thr = lds.ctx[sl.buf].thr;
+          const uint32_t thr = sl.thr;
           const uint32_t need = max(thr, (uint32_t)rn);
           // mean_error = 1e9 below 3 inliers (:1012-1014); a count below `need` is rejected by the count
           const double err_mine = !((uint32_t)n_inl < need || n_inl < 3) ? sqrt(sl.csum / (double)n_inl) : 1e9;  // :1016-1017
@@ -1063,6 +1092,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       sl.iter = k;
       sl.buf = b;
       sl.pair = cx.pair;
+      sl.n_all = lds.prep[b].n_all;
+      sl.thr = cx.thr;
+      sl.pmax = lds.prep[b].pmax;
     }
     lsync();
   };
