@@ -439,6 +439,8 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
     float4* __restrict__ dst = reinterpret_cast<float4*>(M);
     for (int v = tid; v < kMVec; v += kHypThreads) dst[v] = src[v];
   }
+  __shared__ int n_viable_sh;   // viable iterations of the pair, summed over the waves at the end
+  if (tid == 0) n_viable_sh = 0;
   __syncthreads();
   transpose_records(M, S4, tid, kHypThreads);
   __syncthreads();
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
   const int I = rc.ransac_iterations;
   IterRec* __restrict__ rec_pair = plan.recs + (size_t)pair * (size_t)I;
   uint64_t* __restrict__ vm_pair = plan.vmask + (size_t)pair * (size_t)plan.vmask_words;
+  int n_viable_wave = 0;
   for (int k0 = 0; k0 < I; k0 += kHypThreads) {
     const int k = k0 + tid;
     const bool in_range = k < I;
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
     const bool viable = in_range && !has_nan12(hypR, hypt) && may_pass >= thr;
     const uint64_t vm = __ballot(viable);
     if (lane == 0) vm_pair[k >> 6] = vm;  // (k0 and the wave's first lane are multiples of 64)
+    n_viable_wave += __popcll(vm);
     if (k0 == 0 && tid < kWave && plan.preclass_iters > 0) {  // the first wave: the pair's class by the pre-screen alone
       // junk-heavy for certain (at most 9 of the first 14 iterations can give a refined hypothesis) AND no sign of a
       // hypothesis with more than half of the matches as inliers among them (the loop's early exits, :1186-1188): the
@@ -517,6 +521,16 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
 #endif
     }
     // (an iteration that is not viable leaves nothing behind: the walk reads its cleared bit of the mask as {1e6, 0})
+  }
+  // phased plans: the pair joins the order bucket of its number of viable iterations (SplitPlan::order)
+  if (plan.phased) {
+    if (lane == 0) atomicAdd(&n_viable_sh, n_viable_wave);
+    __syncthreads();
+    if (tid == 0) {
+      const int b = order_bucket(n_viable_sh);
+      const uint32_t at = atomicAdd(plan.order_cnt + b, 1u);
+      plan.order[(size_t)b * (size_t)n_pairs + at] = pair;
+    }
   }
 }
 
@@ -762,6 +776,21 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   const int blk = 1;           // (every unit of the launch has work: the workgroups take them one by one -- pairs differ a lot)
   const bool phased = plan.phased != 0;
   const bool use_preclass = phased && plan.preclass_iters > 0;
+  // phased plans: the launch's units are the pairs of the order buckets, fullest bucket first (lane b: bucket 63 - b)
+  int ord_cnt = 0, ord_start = 0;
+  uint32_t n_units_here = n_units;
+  if (phased) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    ord_cnt = (int)plan.order_cnt[kOrderBuckets - 1 - lane];
+    int incl = ord_cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    ord_start = incl - ord_cnt;
+    n_units_here = (uint32_t)__builtin_amdgcn_readlane(incl, kWave - 1);
+  }
 
   // ---- the next block of units off the counter; the facts that decide which of them have work are requested (global ->
   // LDS), not awaited
@@ -772,11 +801,20 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(plan.unit_counter, (uint32_t)blk);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (base >= n_units) { units_left = false; return; }
-    nx_n = (int)min((uint32_t)blk, n_units - base);
+    if (base >= n_units_here) { units_left = false; return; }
+    nx_n = (int)min((uint32_t)blk, n_units_here - base);
     const uint32_t unit = base + (uint32_t)min(lane, nx_n - 1);
-    nx_pair = unit / (uint32_t)plan.n_shares;
-    nx_share = (int)(unit - nx_pair * (uint32_t)plan.n_shares);
+    if (phased) {   // unit `base` of the launch = entry (base - start) of the bucket whose range holds it
+      const uint64_t holds = __ballot((int)base >= ord_start && (int)base < ord_start + ord_cnt);
+      const int bl = (int)__builtin_ctzll(holds);
+      const uint32_t idx = base - (uint32_t)__builtin_amdgcn_readlane(ord_start, bl);
+      const uint32_t pr = plan.order[(size_t)(kOrderBuckets - 1 - bl) * (size_t)n_pairs + idx];
+      nx_pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr);
+      nx_share = 0;
+    } else {
+      nx_pair = unit / (uint32_t)plan.n_shares;
+      nx_share = (int)(unit - nx_pair * (uint32_t)plan.n_shares);
+    }
     if (lane < nx_n) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&plan.prep[nx_pair].n_all,
                                        (__attribute__((address_space(3))) void*)lds.claim_nall, 4, 0, 0);

@@ -149,7 +149,16 @@ struct SplitPlan {
                                // hypothesis kernel when preclass_iters > 0
   int preclass_iters = 0;      // the first phase's length (14), 0 = no pre-classification
   uint32_t* unit_counter = nullptr;  // zero at launch: the refinement kernel's workgroups take their units off it
+  // phased plans: the pairs that run RANSAC, bucketed by the number of their viable iterations (the hypothesis kernel
+  // appends; kOrderBuckets counters, zeroed by pair_prep_kernel, + [bucket][n_pairs] pair indices).  The refinement kernel
+  // takes the buckets from the top: a launch is about two generations of resident units per workgroup, and the pairs that
+  // keep a workgroup longest should not be the ones it picks up last.
+  uint32_t* order_cnt = nullptr;
+  uint32_t* order = nullptr;
 };
+constexpr int kOrderBuckets = 64;
+// bucket of a pair with n viable iterations: one per count below 32, then steps of 8
+__host__ __device__ inline int order_bucket(int n) { return n < 32 ? n : (32 + (n - 32) / 8 < kOrderBuckets ? 32 + (n - 32) / 8 : kOrderBuckets - 1); }
 void launch_ransac_hyp(const PairWork* work, uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
 void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream);
 int ransac_split_words_per_pair(int ransac_iterations);
@@ -157,7 +166,16 @@ int ransac_split_max_share();
 int ransac_split_wgs();   // persistent workgroups of a refinement launch on this device
 int ransac_split_init();  // once per process before the first batch (not inside a stream capture); returns the CU count
 // bytes of the per-pair iteration masks behind the records + summaries of a record buffer of `rec_capacity` records
-inline size_t ransac_split_mask_bytes(size_t rec_capacity, size_t max_pairs) { return (rec_capacity / 64 + 5 * max_pairs + 64) * 8; }  // + 8 bytes per pair: preclass
+// (+ 8 bytes per pair: preclass; + the order buckets: kOrderBuckets counters and kOrderBuckets x max_pairs indices)
+inline size_t ransac_split_mask_bytes(size_t rec_capacity, size_t max_pairs) { return (rec_capacity / 64 + (5 + 32) * max_pairs + 64 + 64) * 8; }
+// where the order buckets of a batch of n_pairs live behind its records (the same for pair_prep_kernel, which zeroes the
+// counters, and the plan of the kernels that use them)
+inline uint32_t* ransac_split_order_cnt(IterRec* recs, size_t n_pairs, int ransac_iterations) {
+  const size_t I = ransac_iterations > 0 ? (size_t)ransac_iterations : 0, n_recs = n_pairs * I;
+  uint64_t* vmask = reinterpret_cast<uint64_t*>(reinterpret_cast<IterSum*>(recs + n_recs) + n_recs);
+  uint8_t* preclass = reinterpret_cast<uint8_t*>(vmask + n_pairs * (size_t)ransac_split_words_per_pair(ransac_iterations));
+  return reinterpret_cast<uint32_t*>(preclass + ((n_pairs + 8 + 7) & ~(size_t)7));
+}
 // edges.hip: stable compaction of the accepted edges (id1 >= 0) of a shard
 void launch_compact_edges(const rgbdfe_match_result* in, uint32_t n, rgbdfe_match_result* out, int32_t* out_index,
                           int32_t index_scale, int32_t index_offset, int32_t* d_dst, int32_t* d_count, hipStream_t stream);

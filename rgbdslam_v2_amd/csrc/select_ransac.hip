@@ -494,11 +494,13 @@ __global__ __launch_bounds__(kWave) void pair_prep_kernel(
     const float4* __restrict__ xyz_pool, const PairWork* __restrict__ work,
     const uint32_t* __restrict__ keys, uint32_t key_planes, const SiftMatchList sm,
     rgbdfe_match_result* __restrict__ results, uint32_t max_kp, uint32_t n_pairs,
-    const RansacConst rc, PairPrep* __restrict__ prep) {
+    const RansacConst rc, PairPrep* __restrict__ prep, uint32_t* __restrict__ zero64) {
   __shared__ SelBuf sel;
   const uint32_t pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x;
+  // (the batch's order-bucket counters, SplitPlan::order_cnt: the hypothesis kernel's workgroups add to them)
+  if (pair == 0 && zero64 != nullptr) zero64[lane] = 0u;
   const PairWork w = work[pair];
   rgbdfe_match_result* __restrict__ out = results + pair;
   PairPrep* __restrict__ pp = prep + pair;
@@ -1191,7 +1193,7 @@ void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const ui
   if (n_pairs == 0) return;
   SiftMatchList none{};
   hipLaunchKernelGGL(pair_prep_kernel<false>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys, key_planes,
-                     none, results, max_kp, n_pairs, rc, prep);
+                     none, results, max_kp, n_pairs, rc, prep, (uint32_t*)nullptr);
   RecordPlan plan{};
   plan.prep = prep;
   plan.ec_pool = ec_pool;
@@ -1203,12 +1205,12 @@ void launch_select_ransac(const float4* xyz_pool, const PairWork* work, const ui
 // its head
 static void launch_sift_prep(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q, uint16_t* sm_t, float* sm_d,
                              const int32_t* sm_n, float* all_dist, rgbdfe_match_result* results, uint32_t max_kp,
-                             uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, hipStream_t stream) {
+                             uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, uint32_t* zero64, hipStream_t stream) {
   hipLaunchKernelGGL(sift_sort_kernel, dim3(n_pairs), dim3(kSortThreads), 0, stream, sm_q, sm_t, sm_d, sm_n, max_kp, n_pairs,
                      rc.max_matches);
   SiftMatchList sm{sm_q, sm_t, sm_d, sm_n, all_dist};
   hipLaunchKernelGGL(pair_prep_kernel<true>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work,
-                     (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, prep);
+                     (const uint32_t*)nullptr, 1u, sm, results, max_kp, n_pairs, rc, prep, zero64);
 }
 
 void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uint16_t* sm_q,
@@ -1217,7 +1219,7 @@ void launch_select_ransac_sift(const float4* xyz_pool, const PairWork* work, uin
                                uint32_t n_pairs, const RansacConst& rc, PairPrep* prep, double* ec_pool,
                                hipStream_t stream) {
   if (n_pairs == 0) return;
-  launch_sift_prep(xyz_pool, work, sm_q, sm_t, sm_d, sm_n, all_dist, results, max_kp, n_pairs, rc, prep, stream);
+  launch_sift_prep(xyz_pool, work, sm_q, sm_t, sm_d, sm_n, all_dist, results, max_kp, n_pairs, rc, prep, nullptr, stream);
   RecordPlan plan{};
   plan.prep = prep;
   plan.ec_pool = ec_pool;
@@ -1335,6 +1337,8 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     sp.vmask = reinterpret_cast<uint64_t*>(plan.sums + n_recs);
     sp.vmask_words = ransac_split_words_per_pair(I);
     sp.preclass = reinterpret_cast<uint8_t*>(sp.vmask + (size_t)n_pairs * (size_t)sp.vmask_words);
+    sp.order_cnt = ransac_split_order_cnt(recs, n_pairs, I);
+    sp.order = sp.order_cnt + kOrderBuckets;
     // phased plans: pairs the pre-screen alone shows to be junk-heavy skip the first phase's launch + walk and record
     // everything at once (the classes only schedule the recording: the walk decides the outcome either way)
     static const bool no_pre = getenv("RGBDFE_NO_PRECLASS") && atoi(getenv("RGBDFE_NO_PRECLASS")) != 0;  // A/B runs
@@ -1406,7 +1410,7 @@ void launch_select_ransac_latency(const float4* xyz_pool, const PairWork* work, 
   if (n_pairs == 0) return;
   SiftMatchList none{};
   hipLaunchKernelGGL(pair_prep_kernel<false>, dim3(n_pairs), dim3(kWave), 0, stream, xyz_pool, work, keys, key_planes,
-                     none, results, max_kp, n_pairs, rc, prep);
+                     none, results, max_kp, n_pairs, rc, prep, ransac_split_order_cnt(recs, n_pairs, rc.ransac_iterations));
   launch_record_replay(work, results, n_pairs, rc, prep, recs, walk, ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
@@ -1417,7 +1421,8 @@ void launch_select_ransac_sift_latency(const float4* xyz_pool, const PairWork* w
                                        double* ec_pool, int chunk_iters, const int* phase_ends, int n_phases,
                                        hipStream_t stream) {
   if (n_pairs == 0) return;
-  launch_sift_prep(xyz_pool, work, sm_q, sm_t, sm_d, sm_n, all_dist, results, max_kp, n_pairs, rc, prep, stream);
+  launch_sift_prep(xyz_pool, work, sm_q, sm_t, sm_d, sm_n, all_dist, results, max_kp, n_pairs, rc, prep,
+                   ransac_split_order_cnt(recs, n_pairs, rc.ransac_iterations), stream);
   launch_record_replay(work, results, n_pairs, rc, prep, recs, walk, ec_pool, chunk_iters, phase_ends, n_phases, stream);
 }
 
