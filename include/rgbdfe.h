@@ -248,12 +248,17 @@ int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream);
  * (ticket) returns; *bytes_written (may be NULL) = the payload's size.  When `out` is pinned (hipHostMalloc /
  * rgbdfe_host_register) the download goes straight into it, otherwise through a pinned stage and one memcpy inside
  * rgbdfe_wait_host.  At most two jobs in flight per context (one per internal stream): a third submit before a wait is
- * refused with RGBDFE_ERR_CAPACITY.  Same results as rgbdfe_match_pair_list.  Single-device contexts only. */
+ * refused with RGBDFE_ERR_CAPACITY.  Same results as rgbdfe_match_pair_list.  Single-device contexts only.
+ * One waiter per ticket (a second concurrent rgbdfe_wait_host of the same ticket is refused).  When the payload does not
+ * fit `out` (the inlier stream's list block is sized by the results), rgbdfe_wait_host returns RGBDFE_ERR_CAPACITY with
+ * *bytes_written = the size the payload needs and the job STAYS pending: rgbdfe_wait_host_into(ticket, out2, bytes2)
+ * collects it into a larger buffer (pageable or pinned; through the library's pinned stage), out2 == NULL drops it. */
 #define RGBDFE_HOST_RECORDS 0
 #define RGBDFE_HOST_INLIERS 1
 int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
                                  void* out, size_t out_bytes, int payload, int64_t* ticket);
 int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written);
+int rgbdfe_wait_host_into(rgbdfe_ctx* ctx, int64_t ticket, void* out, size_t out_bytes, int64_t* bytes_written);
 int rgbdfe_synchronize(rgbdfe_ctx* ctx);
 
 /* ---- SIFT (128-d float descriptor) nodes: matcher_type == "SIFTGPU" ------------------------

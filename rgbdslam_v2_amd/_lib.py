@@ -198,6 +198,8 @@ def load():
     L.rgbdfe_submit_pair_list_host.argtypes = [ctx, vp, vp, i32, vp, C.c_size_t, C.c_int, C.POINTER(C.c_int64)]
     L.rgbdfe_wait_host.restype = C.c_int
     L.rgbdfe_wait_host.argtypes = [ctx, C.c_int64, C.POINTER(C.c_int64)]
+    L.rgbdfe_wait_host_into.restype = C.c_int
+    L.rgbdfe_wait_host_into.argtypes = [ctx, C.c_int64, vp, C.c_size_t, C.POINTER(C.c_int64)]
     L.rgbdfe_upload_sift_node.restype = C.c_int
     L.rgbdfe_upload_sift_node.argtypes = [ctx, i32, vp, vp, i32]
     L.rgbdfe_match_sift_pair_list.restype = C.c_int
@@ -362,7 +364,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_match_node_pairs", "rgbdfe_match_pair_list", "rgbdfe_match_pair_list_device",
     "rgbdfe_detector_configure", "rgbdfe_detector_thresholds", "rgbdfe_detect_describe",
     "rgbdfe_orb_detect", "rgbdfe_orb_compute",
-    "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket", "rgbdfe_submit_pair_list_host", "rgbdfe_wait_host", "rgbdfe_upload_sift_node",
+    "rgbdfe_submit_pair_list", "rgbdfe_wait_ticket", "rgbdfe_submit_pair_list_host", "rgbdfe_wait_host", "rgbdfe_wait_host_into", "rgbdfe_upload_sift_node",
     "rgbdfe_match_sift_pair_list", "rgbdfe_submit_sift_pair_list", "rgbdfe_sift_match_nodes",
     "rgbdfe_synchronize", "rgbdfe_hamming_nn_nodes", "rgbdfe_hamming_nn_host",
     "rgbdfe_project_to_3d", "rgbdfe_sift_node_features", "rgbdfe_sift_node_features_min_depth", "rgbdfe_depth_to_mono8",

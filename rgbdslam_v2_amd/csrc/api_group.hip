@@ -130,9 +130,9 @@ int group_create(const rgbdfe_config* cfg, const int32_t* device_ids, int32_t n,
 }
 
 // sharded host-output match: device i computes pairs i, i+G, ... and writes them to out[i], out[i+G], ...
-// ORB shards that fit one batch are SUBMITTED BY THE CALLING THREAD, device after device (one hipGraphLaunch + one
-// read-back enqueue each once the batch shape has been seen: host threads inside the HIP runtime at the same time
-// serialise on its locks), then collected; everything else goes through the per-device worker threads.
+// ORB shards that fit one batch are ENQUEUED first (group_submit: by the calling thread device after device up to two
+// devices, by the devices' host threads all at once from three on), then collected; everything else goes through the
+// per-device worker threads.
 int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, rgbdfe_match_result* out, bool sift,
                 float* out_dist) {
   if (n < 0 || (n > 0 && (!q || !t || !out))) return fail(gctx, RGBDFE_ERR_INVALID_ARG, "bad match arguments");
@@ -144,12 +144,11 @@ int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n,
     std::vector<std::vector<int32_t>> qs((size_t)G), ts((size_t)G);
     for (int32_t k = 0; k < n; ++k) { qs[(size_t)(k % G)].push_back(q[k]); ts[(size_t)(k % G)].push_back(t[k]); }
     std::vector<int> lane((size_t)G, -1);
-    int first = RGBDFE_OK;
     const double t0 = orb_now_us();
-    for (int i = 0; i < G; ++i) {
+    int first = group_submit(gctx, [&](int i) -> int {
       rgbdfe_ctx* c = g.children[(size_t)i];
       const int32_t ni = (int32_t)qs[(size_t)i].size();
-      if (ni == 0) continue;
+      if (ni == 0) return RGBDFE_OK;
       std::lock_guard<std::mutex> lk(c->mu);
       int r = RGBDFE_OK;
       if (hipSetDevice(c->cfg.device_id) != hipSuccess) r = fail(c, RGBDFE_ERR_HIP, "hipSetDevice");
@@ -164,12 +163,8 @@ int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n,
                          c->lanes[li].stream) != hipSuccess)
         r = fail(c, RGBDFE_ERR_HIP, "result read-back");
       if (r == RGBDFE_OK) lane[(size_t)i] = li;
-      else if (first == RGBDFE_OK) {
-        first = r;
-        std::string msg; { std::lock_guard<std::mutex> e(c->err_mu); msg = c->last_error; }
-        fail(gctx, first, "device " + std::to_string(g.device_ids[(size_t)i]) + ": " + msg);
-      }
-    }
+      return r;
+    });
     g.last_submit_us = orb_now_us() - t0;
     for (int i = 0; i < G; ++i) {   // collect (also after an error: nothing may stay in flight behind the caller's back)
       if (lane[(size_t)i] < 0) continue;
@@ -194,6 +189,17 @@ int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n,
                                                out_dist ? out_dist + (size_t)i * RGBDFE_MAX_MATCHES : nullptr, G);
     return impl::rgbdfe_match_pair_list(g.children[(size_t)i], qs.data(), ts.data(), (int32_t)qs.size(), out + i, G);
   });
+}
+
+// The enqueues of a sharded batch, fn(i) per device.  From three devices on every device's enqueues run on that device's own
+// host thread, all at once: measured with one GPU listed eight times (tools/bench_group_submit.py, ROCm 7.0) the calling
+// thread alone takes 48 - 57 us per device, 380 - 450 us for eight, the eight threads together 142 - 146 us (round 2's runtime
+// serialised concurrent enqueues on its locks; this one does not).  One or two devices: the calling thread (the hand-off to
+// a thread costs what a device's enqueues cost).  RGBDFE_GROUP_SUBMIT=serial / threads forces one or the other.
+int group_submit(rgbdfe_ctx* gctx, const std::function<int(int)>& fn) {
+  static const char* mode = getenv("RGBDFE_GROUP_SUBMIT");
+  const bool threads = mode ? std::string(mode) == "threads" : gctx->group->children.size() >= 3;
+  return threads ? group_run(gctx, fn) : group_each(gctx, fn);
 }
 
 // run fn(i) for every device on THIS thread, device after device: for work that only enqueues (returns the first error)
@@ -276,9 +282,9 @@ int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, 
     return fail(gctx, RGBDFE_ERR_CAPACITY, "allgather: the shard of a device exceeds max_pairs_per_batch");
   const size_t rec = compact ? sizeof(rgbdfe_compact_result) : sizeof(rgbdfe_match_result);
   if (compact) { const int rce = group_ensure_edge_scratch(gctx, per); if (rce != RGBDFE_OK) return rce; }
-  // 1. every device computes its shard into its own segment of its own buffer: enqueued by this thread, device after device
+  // 1. every device computes its shard into its own segment of its own buffer (group_submit)
   const double t_sub0 = orb_now_us();
-  int rc = group_each(gctx, [&](int i) -> int {
+  int rc = group_submit(gctx, [&](int i) -> int {
     rgbdfe_ctx* c = g.children[(size_t)i];
     std::vector<int32_t> qs, ts;
     for (int32_t k = i; k < n; k += G) { qs.push_back(q[k]); ts.push_back(t[k]); }

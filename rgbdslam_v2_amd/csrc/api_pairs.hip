@@ -88,11 +88,16 @@ int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream) {
   return wait_ticket(ctx, ticket, (hipStream_t)stream);
 }
 
-// is `p` host memory the device can copy into asynchronously (hipHostMalloc / hipHostRegister)?
-static bool is_pinned_host(const void* p) {
-  hipPointerAttribute_t a{};
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return a.type == hipMemoryTypeHost;
+// is [p, p + bytes) host memory the device can copy into asynchronously (hipHostMalloc / hipHostRegister)?  Both ends of
+// the range are asked about: a registration shorter than the buffer must not make an async DMA write pageable memory.
+static bool is_pinned_host(const void* p, size_t bytes) {
+  if (bytes == 0) return false;
+  for (const void* q : {p, (const void*)((const uint8_t*)p + bytes - 1)}) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost) return false;
+  }
+  return true;
 }
 
 // The asynchronous form of rgbdfe_match_pair_list: results in HOST memory, the download of batch k behind batch k on its lane
@@ -128,7 +133,8 @@ int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, cons
   if (rc != RGBDFE_OK) return rc;
   if (lane_used != li) return fail(ctx, RGBDFE_ERR_INTERNAL, "host submit: lane bookkeeping out of step");
   hipStream_t st = ctx->lanes[li].stream;
-  job.direct = n_pairs > 0 && is_pinned_host(out);
+  // (the whole caller buffer: the inlier stream's list block lands behind the headers, its length is known only later)
+  job.direct = n_pairs > 0 && is_pinned_host(out, out_bytes);
   if (payload == RGBDFE_HOST_RECORDS) {
     if (n_pairs > 0)
       HIP_TRY(ctx, hipMemcpyAsync(job.direct ? out : (void*)ctx->h_stage[li], ctx->lanes[li].d_results, rec * (size_t)n_pairs,
@@ -143,6 +149,7 @@ int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, cons
   }
   HIP_TRY(ctx, hipEventRecord(job.copied, st));
   job.pending = true;
+  job.waiting = false;
   job.payload = payload;
   job.ticket = *ticket;
   job.n = n_pairs;
@@ -151,7 +158,9 @@ int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, cons
   return RGBDFE_OK;
 }
 
-int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
+// replace: collect the job into [new_out, new_out + new_bytes) instead of the buffer named at submit (new_out == nullptr:
+// drop the job).  The headers of a job that went straight into a pinned buffer are fetched again, through the stage.
+static int wait_host_impl(rgbdfe_ctx* ctx, int64_t ticket, bool replace, void* new_out, size_t new_bytes, int64_t* bytes_written) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   rgbdfe_ctx::HostJob job;
   int li = -1;
@@ -160,7 +169,22 @@ int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
     for (int k = 0; k < rgbdfe_ctx::kLanes; ++k)
       if (ctx->host_jobs[k].pending && ctx->host_jobs[k].ticket == ticket) li = k;
     if (li < 0) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_wait_host: no host job with this ticket");
+    // one waiter per job: a second one would copy out of a staging buffer the lane's next job may already be filling
+    if (ctx->host_jobs[li].waiting) return fail(ctx, RGBDFE_ERR_INVALID_ARG, "rgbdfe_wait_host: another thread is waiting for this ticket");
+    if (replace && new_out == nullptr) {   // the caller gives the job up
+      ctx->host_jobs[li].pending = false;
+      if (bytes_written) *bytes_written = 0;
+      return RGBDFE_OK;
+    }
+    ctx->host_jobs[li].waiting = true;
     job = ctx->host_jobs[li];
+  }
+  bool refetch = false;
+  if (replace) {
+    refetch = job.direct;
+    job.direct = false;
+    job.out = new_out;
+    job.out_bytes = new_bytes;
   }
   // (the context is not locked while this thread waits and copies: another thread may submit the next batch meanwhile)
   hipError_t e = hipSetDevice(ctx->cfg.device_id);
@@ -168,10 +192,16 @@ int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
   const size_t rec = sizeof(rgbdfe_match_result), hdr = sizeof(rgbdfe_inlier_header);
   size_t written = 0;
   int rc = RGBDFE_OK;
+  if (e == hipSuccess && job.n > 0 && refetch) {   // (the first download went into the buffer that is being replaced)
+    e = hipMemcpyAsync(ctx->h_stage[li], job.payload == RGBDFE_HOST_RECORDS ? (const void*)ctx->lanes[li].d_results : (const void*)ctx->d_inl_stream[li],
+                       (job.payload == RGBDFE_HOST_RECORDS ? rec : hdr) * (size_t)job.n, hipMemcpyDeviceToHost, ctx->lanes[li].stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->lanes[li].stream);
+  }
   if (e == hipSuccess && job.n > 0) {
     if (job.payload == RGBDFE_HOST_RECORDS) {
       written = rec * (size_t)job.n;
-      if (!job.direct) memcpy(job.out, ctx->h_stage[li], written);
+      if (written > job.out_bytes) rc = RGBDFE_ERR_CAPACITY;
+      else if (!job.direct) memcpy(job.out, ctx->h_stage[li], written);
     } else {
       const size_t list_bytes = 4 * (size_t)(*ctx->h_inl_total[li] > 0 ? *ctx->h_inl_total[li] : 0);
       written = hdr * (size_t)job.n + list_bytes;
@@ -191,12 +221,22 @@ int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
   }
   {
     std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->host_jobs[li].pending = false;
+    ctx->host_jobs[li].waiting = false;
+    // a payload that did not fit: the job stays (its results are still on the device) -- *bytes_written is what the buffer
+    // has to hold; rgbdfe_wait_host_into() collects it with a larger one, or drops it
+    if (!(rc == RGBDFE_ERR_CAPACITY && e == hipSuccess)) ctx->host_jobs[li].pending = false;
   }
   if (bytes_written) *bytes_written = (int64_t)written;
   if (e != hipSuccess) return fail(ctx, RGBDFE_ERR_HIP, std::string("rgbdfe_wait_host: ") + hipGetErrorString(e));
-  if (rc != RGBDFE_OK) return fail(ctx, rc, "rgbdfe_wait_host: the inlier stream does not fit the caller's buffer");
+  if (rc != RGBDFE_OK) return fail(ctx, rc, "rgbdfe_wait_host: the payload does not fit the caller's buffer (the job stays: rgbdfe_wait_host_into)");
   return RGBDFE_OK;
+}
+
+int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
+  return wait_host_impl(ctx, ticket, false, nullptr, 0, bytes_written);
+}
+int rgbdfe_wait_host_into(rgbdfe_ctx* ctx, int64_t ticket, void* out, size_t out_bytes, int64_t* bytes_written) {
+  return wait_host_impl(ctx, ticket, true, out, out_bytes, bytes_written);
 }
 
 int rgbdfe_synchronize(rgbdfe_ctx* ctx) {

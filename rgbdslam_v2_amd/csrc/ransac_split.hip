@@ -240,8 +240,12 @@ struct alignas(16) StreamLds {
   // the work of a pass: which slots of the group each worker scores (unless the pass goes by ticket), keeps the books of and
   // refits -- at most kWaveSlots each, dealt by the server so that the workers' loads are level (a slot belongs to nobody)
   uint8_t wlist[2][kWorkers][8];   // [..][7] = entries
-  int quit;                        // set by the server: every unit of the launch has been refined
-  int pad[3];
+  // set by the server in half-round h: every unit of the launch has been refined.  One word per half-round parity: the
+  // workers read quit[h & 1] behind the barrier that ends half-round h, and the server -- which may be well into h + 1 by
+  // then -- writes only quit[(h + 1) & 1] there; quit[h & 1] is written again in h + 2, behind a barrier every worker has
+  // passed after its read
+  int quit[2];
+  int pad[2];
 };
 static_assert(sizeof(StreamLds) <= 160 * 1024 / kWgsPerCu, "kWgsPerCu workgroups per CU");
 
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const int s = wave * kWave + lane;
     if (s < kStreamSlots) { lds.slot[s].active = kSlotDone; lds.slot[s].iter = -1; lds.slot[s].buf = 0; }
     if (wave == 0 && lane < kBufs) { lds.ctx[lane].state = kUnitFree; lds.ctx[lane].next = 0; lds.ctx[lane].done = 0; lds.ctx[lane].n_items = 0; }
-    if (wave == 0 && lane == 0) lds.quit = 0;
+    if (wave == 0 && lane < 2) lds.quit[lane] = 0;
   }
   lds_barrier();
 
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       ST_LAP(18)
-      if (__builtin_amdgcn_readfirstlane(lds.quit) != 0) break;
+      if (__builtin_amdgcn_readfirstlane(lds.quit[g]) != 0) break;
     }
 #ifdef RGBDFE_SPLIT_STATS
     if (wave != 0) { st_c[16] = st_c[17] = st_c[18] = 0ull; }
@@ -1228,7 +1232,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     busy = busy || (lane < kStreamSlots && lds.slot[min(lane, kStreamSlots - 1)].iter >= 0) ||
            (lane + kWave < kStreamSlots && lds.slot[min(lane + kWave, kStreamSlots - 1)].iter >= 0);
     const bool more = __ballot(busy) != 0ull || live != 0ull || nx_n != 0 || units_left;
-    if (!more && lane == 0) lds.quit = 1;
+    if (!more && lane == 0) lds.quit[g] = 1;
     if (by_ticket) {
       if (kServerScores) score_tickets(g);   // its own duties done, the server scores like everybody else
       ST_LAP(14)

@@ -221,6 +221,14 @@ int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written) {
   });
 }
 
+int rgbdfe_wait_host_into(rgbdfe_ctx* ctx, int64_t ticket, void* out, size_t out_bytes, int64_t* bytes_written) {
+  if (!ctx) return RGBDFE_ERR_INVALID_ARG;
+  return guarded(ctx, [&]() -> int {
+    if (RGBDFE_IS_GROUP(ctx)) return group_only_single(ctx, "rgbdfe_wait_host_into");
+    return impl::rgbdfe_wait_host_into(ctx, ticket, out, out_bytes, bytes_written);
+  });
+}
+
 int rgbdfe_match_pair_list_device(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs,
                                   void* d_out, void* stream) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;

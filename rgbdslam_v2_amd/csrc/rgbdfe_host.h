@@ -261,6 +261,7 @@ struct rgbdfe_ctx {
   // the other lane computes the next batch; the copy-out to pageable caller memory happens in rgbdfe_wait_host
   struct HostJob {
     bool pending = false;
+    bool waiting = false;         // a thread is inside rgbdfe_wait_host for this job (one waiter per job)
     bool direct = false;          // the download went straight into the caller's (pinned / registered) buffer
     int payload = 0;              // RGBDFE_HOST_RECORDS / RGBDFE_HOST_INLIERS
     int64_t ticket = 0;
@@ -365,6 +366,7 @@ int rgbdfe_submit_pair_list(rgbdfe_ctx* ctx, const int32_t* query_ids, const int
 int rgbdfe_wait_ticket(rgbdfe_ctx* ctx, int64_t ticket, void* stream);
 int rgbdfe_submit_pair_list_host(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids, int32_t n_pairs, void* out, size_t out_bytes, int payload, int64_t* ticket);
 int rgbdfe_wait_host(rgbdfe_ctx* ctx, int64_t ticket, int64_t* bytes_written);
+int rgbdfe_wait_host_into(rgbdfe_ctx* ctx, int64_t ticket, void* out, size_t out_bytes, int64_t* bytes_written);
 int rgbdfe_synchronize(rgbdfe_ctx* ctx);
 int rgbdfe_upload_sift_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc128, const float* xyz1, int32_t n);
 int rgbdfe_upload_float_node(rgbdfe_ctx* ctx, int32_t node_id, const float* desc, int32_t dim, const float* xyz1, int32_t n);
@@ -483,6 +485,7 @@ void group_destroy(rgbdfe_ctx* gctx);
 int group_create(const rgbdfe_config* cfg, const int32_t* device_ids, int32_t n, rgbdfe_ctx** out);
 int group_match(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, rgbdfe_match_result* out, bool sift, float* out_dist);
 int group_each(rgbdfe_ctx* gctx, const std::function<int(int)>& fn);
+int group_submit(rgbdfe_ctx* gctx, const std::function<int(int)>& fn);
 bool group_setup_rccl(rgbdfe_ctx* gctx);
 int group_ensure_edge_scratch(rgbdfe_ctx* gctx, int32_t per);
 int group_match_allgather(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, void* const* d_out, int32_t* records_per_device, bool compact = false);

@@ -362,6 +362,7 @@ int SiftExtractor::prepare(int rows, int cols, int nf, hipStream_t s, std::strin
   SIFT_HIP(hipMalloc((void**)&d_flags, F * flags_bytes));
   // rowcnt [nf][total_rows] | rowoff [nf][total_rows] | row2lvl [total_rows] | lvltot [nf][64]
   SIFT_HIP(hipMalloc((void**)&d_rowcnt, sizeof(int) * ((size_t)total_rows * (2 * F + 1) + 64 * F)));
+  SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * F, s));
   d_rowoff = d_rowcnt + (size_t)total_rows * F;
   d_lvltot = d_rowcnt + (size_t)total_rows * (2 * F + 1);
   bind_levels();
@@ -467,9 +468,8 @@ int SiftExtractor::enqueue_begin(int nf, hipStream_t s, std::string& err) {
   SIFT_HIP(hipMemcpyAsync(d_gray, h_gray, (size_t)nf * gray_cap, hipMemcpyHostToDevice, s));
   launch_pyramid(*this, nf, s);
   // ---- DetectKeypointsEX + the list part of GenerateFeatureList: flags, row counts, scan, ordered emit ----------------------
-  // (under RGBDFE_SIFT_GRAPH=1 this becomes a memset NODE; the pair path once saw such a node not in effect on replay
-  //  (ransac_split.hip, ransac_hyp_kernel) and zeroes its counters in a kernel since -- one more reason the graph is opt-in)
-  SIFT_HIP(hipMemsetAsync(d_rowcnt, 0, sizeof(int) * (size_t)total_rows * nf, s));
+  // (the row counts are zero here: zeroed once at allocation, and the emit kernel -- their last reader -- resets every count it
+  //  has used; no memset between batches, hence no memset node in the RGBDFE_SIFT_GRAPH=1 capture)
   launch_key_flags(*this, nf, st, s);
   launch_key_lists(*this, nf, st, s);
   SIFT_HIP(hipGetLastError());

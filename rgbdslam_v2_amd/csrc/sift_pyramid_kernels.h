@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::
 // (Sixteen rows per workgroup, a wave walking four of them, was measured too: 77 instead of 44 us per 8 frames -- a row with
 // extrema is a chain of dependent loads, and the launch lives on rows in flight, not on workgroup dispatch.)
 __global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
-                                                           const int* __restrict__ row2lvl, const int* __restrict__ rowcnt,
+                                                           const int* __restrict__ row2lvl, int* __restrict__ rowcnt,
                                                            const int* __restrict__ rowoff, const int* __restrict__ lvltot,
                                                            float* __restrict__ cand, int cand_cap, float dog_threshold0,
                                                            float dog_threshold, float edge_threshold, FrameStrides st) {
@@ -534,6 +534,9 @@ __global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::
   lvltot += (size_t)blockIdx.y * st.lvltot;
   cand += (size_t)blockIdx.y * st.cand;
   if (rowcnt[grow] == 0) return;
+  // the row's count is zero again for the next batch's flag kernel (atomicAdd): this wave is its last reader -- no memset
+  // between batches, in particular no memset NODE when the chain is captured into a hipGraph
+  if (threadIdx.x == 0) rowcnt[grow] = 0;
   const int lvl = row2lvl[grow];
   const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.y);
   const int row = grow - L.row0;
@@ -637,7 +640,7 @@ inline void launch_pyramid(const SiftExtractor& E, int nf, hipStream_t s, int fi
   }
 }
 
-// DetectKeypointsEX: the extremum flags + row counts of every octave and level of the nf frames (rowcnt zeroed by the caller)
+// DetectKeypointsEX: the extremum flags + row counts of every octave and level of the nf frames (rowcnt is zero: at allocation, and sift_key_emit_kernel leaves it so)
 inline void launch_key_flags(const SiftExtractor& E, int nf, const FrameStrides& st, hipStream_t s) {
   const float tdog = E.dog_threshold, tdog1 = 0.8f * tdog;
   const float tedge = (E.edge_threshold + 1) * (E.edge_threshold + 1) / E.edge_threshold;

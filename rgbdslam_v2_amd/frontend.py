@@ -310,6 +310,17 @@ class FrontEnd:
         self._check(self._L.rgbdfe_wait_host(self._ctx, ticket, C.byref(nb)))
         return nb.value
 
+    def wait_host_into(self, ticket: int, out) -> int:
+        """rgbdfe_wait_host_into: collect a job whose payload did not fit its buffer into `out` (None: drop the job)."""
+        nb = C.c_int64(0)
+        if out is None:
+            self._check(self._L.rgbdfe_wait_host_into(self._ctx, ticket, None, 0, C.byref(nb)))
+            return 0
+        if not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be contiguous")
+        self._check(self._L.rgbdfe_wait_host_into(self._ctx, ticket, out.ctypes.data, out.nbytes, C.byref(nb)))
+        return nb.value
+
     def synchronize(self):
         self._check(self._L.rgbdfe_synchronize(self._ctx))
 

@@ -24,6 +24,7 @@ struct Run {
   std::vector<float> input, up, planes;
   std::vector<int8_t> flags;
   std::vector<int> rowcnt;   // rowcnt [rows] | rowoff [rows] | row2lvl [rows] | lvltot [64]: the extractor's layout for one frame
+  std::vector<int> rowcnt_after_flags;   // (the emit kernel resets the counts it has used)
   std::vector<float> cand;
   std::vector<int> level_offset;   // first candidate of every (octave, dog level), and the total
 };
@@ -68,6 +69,7 @@ extern "C" int emu_sift_run(const uint8_t* gray, int cols, int rows, int filter_
   st.cand = E.cand_cap * 6;
   rgbdfe::launch_key_flags(E, 1, st, nullptr);
   memcpy(E.d_rowcnt + (size_t)E.total_rows * 2, E.h_row2lvl.data(), sizeof(int) * (size_t)E.total_rows);
+  R.rowcnt_after_flags.assign(R.rowcnt.begin(), R.rowcnt.begin() + E.total_rows);
   rgbdfe::launch_key_lists(E, 1, st, nullptr);   // the scan + the ordered emit: one-wave workgroups, ballot / shuffles served
   const int nlv = E.octave_num * SiftExtractor::kDogLevels;
   R.level_offset.assign((size_t)nlv + 1, 0);
@@ -85,7 +87,7 @@ extern "C" const int8_t* emu_sift_flags(int octave, int dog_level) {
   return g_run->E.h_levels[(size_t)octave * SiftExtractor::kDogLevels + dog_level].flags;
 }
 extern "C" const int* emu_sift_rowcnt(int octave, int dog_level) {
-  return g_run->rowcnt.data() + g_run->E.h_levels[(size_t)octave * SiftExtractor::kDogLevels + dog_level].row0;
+  return g_run->rowcnt_after_flags.data() + g_run->E.h_levels[(size_t)octave * SiftExtractor::kDogLevels + dog_level].row0;
 }
 
 // the candidate list of one (octave, dog level): rows of (x, y, sign, dx, dy, ds) in list order; returns the count

@@ -180,6 +180,16 @@ def test_host_output_jobs_pipeline_and_equal_the_synchronous_call(data):
         t = fe.submit_pair_list_host(pq[:40], pt[:40], small, inliers=True)
         with pytest.raises(RgbdfeError, match="does not fit"):
             fe.wait_host(t)
+        # ... and the job stays: the same ticket into a buffer that is large enough, then the ticket is gone
+        buf[:] = 0
+        assert fe.wait_host_into(t, buf) == nb
+        assert buf[: hdr.nbytes].tobytes() == hdr.tobytes() and buf[hdr.nbytes: nb].tobytes() == lst.tobytes()
+        with pytest.raises(RgbdfeError, match="no host job"):
+            fe.wait_host(t)
+        t = fe.submit_pair_list_host(pq[:40], pt[:40], small, inliers=True)          # ... or the job is dropped
+        with pytest.raises(RgbdfeError, match="does not fit"):
+            fe.wait_host(t)
+        assert fe.wait_host_into(t, None) == 0
         assert fe.match_pair_list(pq[:40], pt[:40]).tobytes() == ref_a.tobytes()     # the context is still usable
     finally:
         fe.close()
