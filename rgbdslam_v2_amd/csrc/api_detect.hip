@@ -517,6 +517,7 @@ int rgbdfe_detect_describe(rgbdfe_ctx* ctx, const uint8_t* gray, const uint8_t* 
 }
 
 // ---- rgbdfe_detect_describe_batch, super-frame form -----------------------------------------------------------------
+constexpr int kSuperFrames = 7;   // frames per super-frame at least (large frames)
 // B = 64 / grid^2 (7 for the 3 x 3 grid) frames share every launch: one upload, one pyramid chain (7 launches), one blur,
 // one detection pass (FAST score -> NMS count -> scan -> emit -> measure) over 7 x 72 images, one rBRIEF launch -- a frame
 // alone is 1.7 M pixels and cannot fill 256 CUs, and its 27 dependent device operations cost 5-15 us each whatever their
@@ -587,7 +588,12 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   OrbWorkspace& orb = ctx->orb_super;
   const OrbWorkspace& one = ctx->orb;
   const int pc = one.grid * one.grid;
-  const int B = std::min(64 / pc, 7);
+  // frames per super-frame: as many as the launches' tables hold, at most kSuperFrames (RGBDFE_SUPER_FRAMES: A/B runs)
+  static const int super_frames_env = getenv("RGBDFE_SUPER_FRAMES") ? atoi(getenv("RGBDFE_SUPER_FRAMES")) : 0;
+  // default: about 4.3 Mpixel of frames per launch, 7 to 28 frames -- 14 at 640 x 480 (measured 7 / 14 / 28 frames: 13.4 / 16.3 /
+  // 16.6 k frames/s), 7 at 1280 x 960 (4.7 / 4.7 / 1.9 k: a 112-frame run is only four super-frames of 28)
+  const int by_size = std::max(kSuperFrames, std::min(28, (int)(4300000.0 / ((double)rows * (double)cols) + 0.5)));
+  const int B = std::max(1, std::min(std::min(kOrbCtlMax / pc, kProjectFramesMax), super_frames_env > 0 ? super_frames_env : by_size));
   // the detector object is one: its configuration and thresholds move into the super-frame workspace and back
   orb.grid = one.grid; orb.adjuster_iters = one.adjuster_iters; orb.cell_min = one.cell_min; orb.cell_max = one.cell_max;
   orb.max_total = one.max_total; orb.lookahead = one.lookahead;
@@ -638,7 +644,10 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   int staged = 0, detected = 0;
   bool stop = false;
   if (!ctx->stage_pool) ctx->stage_pool.reset(new TaskPool(4));
-  if (!ctx->detect_pool || ctx->detect_pool->size() != B) ctx->detect_pool.reset(new TaskPool(B));  // one worker per frame of a super-frame
+  // (the frames' CPU halves: a worker per frame up to RGBDFE_DETECT_WORKERS workers, the frames queue behind them)
+  static const int max_workers = getenv("RGBDFE_DETECT_WORKERS") ? std::max(1, atoi(getenv("RGBDFE_DETECT_WORKERS"))) : 12;   // (7 / 8 / 10 / 12 / 14 workers: 14.4 / 14.2 / 15.7 / 16.4 / 15.4 k frames/s in one call)
+  const int n_workers = std::min(B, max_workers);
+  if (!ctx->detect_pool || ctx->detect_pool->size() != n_workers) ctx->detect_pool.reset(new TaskPool(n_workers));
   TaskPool& stage_pool = *ctx->stage_pool;
   TaskPool& pool = *ctx->detect_pool;
   pool.failed_ = false;

@@ -182,10 +182,10 @@ void OrbWorkspace::reset_detector(int max_keypoints, int grid_res, int max_iters
 int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, int n_frames, bool geometry_only) {
   // n_frames > 1: a SUPER-FRAME workspace (rgbdfe_detect_describe_batch): the images of up to n_frames frames live in one
   // pool and every stage's ONE launch covers all of them -- frame f's grid cell c is "cell" f * grid^2 + c of the kernels'
-  // ImgDesc / OrbCtl tables (64 entries: 7 frames of a 3 x 3 grid), its pyramid levels are frame images f * 8 + l.
+  // ImgDesc / OrbCtl tables (kOrbCtlMax entries: 28 frames of a 3 x 3 grid), its pyramid levels are frame images f * 8 + l.
   const int per_frame_cells = use_grid ? grid * grid : 1;
   const int want_cells = per_frame_cells * n_frames;
-  if (want_cells > 64) { err = "super-frame: more than 64 (frame, cell) detectors"; return RGBDFE_ERR_CAPACITY; }
+  if (want_cells > kOrbCtlMax || n_frames > kProjectFramesMax) { err = "super-frame: more (frame, cell) detectors than a launch's tables hold"; return RGBDFE_ERR_CAPACITY; }
   if (!geometry_only && cols == W && rows == H && n_cells == want_cells && frames == n_frames && d_pool) return RGBDFE_OK;
   release();
   W = cols; H = rows;
@@ -569,7 +569,7 @@ int OrbWorkspace::enqueue_staged(bool has_mask, hipStream_t s, std::string& err,
 int OrbWorkspace::gpu_pass(const std::vector<int>& active, const std::vector<int>& thr, hipStream_t s, std::string& err) {
   const double tp0 = timing.on ? orb_now_us() : 0;
   OrbCtl ctl;  // thresholds and active flags are kernel arguments: no upload in front of the pass
-  for (int c = 0; c < 64; ++c) {
+  for (int c = 0; c < kOrbCtlMax; ++c) {
     ctl.thr[c] = c < n_cells ? thr[c] : 0;
     ctl.active[c] = c < n_cells ? active[c] : 0;
   }
@@ -788,7 +788,7 @@ int OrbWorkspace::super_pass_enqueue(int nf, int set, int slot, hipStream_t s, s
   OrbCtl ctl;
   std::vector<int>& fl = slot_floor[slot];
   fl.assign((size_t)n_cells, 0);
-  for (int c = 0; c < 64; ++c) {
+  for (int c = 0; c < kOrbCtlMax; ++c) {
     ctl.thr[c] = 0; ctl.active[c] = 0;
     if (c >= n_cells || c / pc >= nf) continue;
     double next = thresh[c % pc] * super_floor_factor;

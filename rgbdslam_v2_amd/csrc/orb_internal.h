@@ -45,9 +45,10 @@ struct DescKp {
 
 // per-cell FAST thresholds and active flags of a detection pass: travel as a KERNEL ARGUMENT (no upload, one dependent
 // device operation fewer per pass)
+constexpr int kOrbCtlMax = 256;   // (frame, cell) detectors of a launch: 28 frames of a 3 x 3 grid
 struct OrbCtl {
-  int32_t thr[64];
-  int32_t active[64];
+  int32_t thr[kOrbCtlMax];
+  int32_t active[kOrbCtlMax];
 };
 
 // one workgroup of a 2-D stage: tile (bx, by) of 64 x 4 (resize) or 64 x 16 (FAST, blur) pixels of image / resize job `img`;

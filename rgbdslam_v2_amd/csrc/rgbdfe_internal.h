@@ -226,7 +226,8 @@ void launch_project_to_3d(const float* kp_xy, int n_kp, const float* depth, int 
                           float fxinv, float fyinv, float cx, float cy, double depth_scaling,
                           int max_keypoints, int32_t* kept_idx, float4* xyz1, int32_t* n_out,
                           hipStream_t stream, bool truncate = false, const float* z_gathered = nullptr);
-struct ProjectFrames { int n_frames; int off[8]; int n[8]; };
+constexpr int kProjectFramesMax = 32;   // frames of a super-frame (api_detect.hip)
+struct ProjectFrames { int n_frames; int off[kProjectFramesMax]; int n[kProjectFramesMax]; };
 void launch_project_to_3d_frames(const ProjectFrames& fr, const float* kpxy, int rows, int cols, float fxinv, float fyinv,
                                  float cx, float cy, double depth_scaling, int max_keypoints, int32_t* kept_idx, float4* xyz1,
                                  int32_t* n_out, hipStream_t stream);

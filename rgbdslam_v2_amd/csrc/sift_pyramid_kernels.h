@@ -535,7 +535,9 @@ __global__ __launch_bounds__(64) void sift_key_emit_kernel(const SiftExtractor::
   cand += (size_t)blockIdx.y * st.cand;
   if (rowcnt[grow] == 0) return;
   // the row's count is zero again for the next batch's flag kernel (atomicAdd): this wave is its last reader -- no memset
-  // between batches, in particular no memset NODE when the chain is captured into a hipGraph
+  // between batches, in particular no memset NODE when the chain is captured into a hipGraph.  (The barrier: every thread has
+  // read the count before one of them resets it -- a wave does that in lockstep anyway, the CPU emulation of tests/emu does not.)
+  __syncthreads();
   if (threadIdx.x == 0) rowcnt[grow] = 0;
   const int lvl = row2lvl[grow];
   const SiftExtractor::LevelDesc L = level_of_frame(levels[lvl], st, blockIdx.y);
