@@ -450,6 +450,7 @@ def main():
             el = float(te.item())
         rep_elapsed.append(el)
     elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]
+    gathers_timed, gather_bytes_timed = state["gathers"], state["bytes"]   # (the default-path leg below gathers too)
     fe.set_profiling(False)
     # Official per-kernel HIP-event times: measured inside the timed region (batches overlap there).
     k_match = KERNEL_SIFT_DOT if sift else KERNEL_HAMMING
@@ -660,7 +661,7 @@ def main():
         if world != 1 or args.no_cpu_baseline:
             del out["cpu_baseline"]
         if gather_on:
-            per_step = state["bytes"] / max(state["gathers"], 1)
+            per_step = gather_bytes_timed / max(gathers_timed, 1)
             out["gather"] = {"payload_option": args.gather,
                              "payload": "inlier stream: rgbdfe_inlier_header (104 B) + 4 B per inlier match" if inliers else
                                         ("rgbdfe_compact_result" if compact else "rgbdfe_match_result"),
@@ -669,7 +670,7 @@ def main():
                              "bytes_per_step_per_rank_by_payload": {
                                  "inliers": round(per_step) if inliers else None,
                                  "compact": world * n_pad * COMPACT_DTYPE.itemsize, "full": world * n_pad * rec_bytes},
-                             "gathers_in_timed_regions": state["gathers"],
+                             "gathers_in_timed_regions": gathers_timed,
                              "collectives_per_step": 2 if inliers else 1,
                              "backend": backend, "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
                              "distinct_devices": len({d.split(" ", 2)[2] for d in rank_devices}) if rank_devices else None,
