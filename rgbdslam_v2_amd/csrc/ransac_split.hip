@@ -150,6 +150,10 @@ static_assert(kStreamSlots <= 2 * kWave, "the server's end-of-work test looks at
 #endif
 constexpr int kCostDear = 4;                           // a scoring that runs pass 2, in scorings of a junk hypothesis (the deal's weight)
 constexpr int kTicketsFrom = RGBDFE_SPLIT_TICKETS_FROM;  // expensive scorings in a group's pass from which they go out by ticket
+#ifndef RGBDFE_SPLIT_PACK_FROM
+#define RGBDFE_SPLIT_PACK_FROM 1000
+#endif
+constexpr int kPackFrom = RGBDFE_SPLIT_PACK_FROM;     // refined matches of a pass's dear slots from which its refits are packed (-1: never)
 constexpr int kBufs = RGBDFE_SPLIT_BUFS;              // units (pair, iteration range) resident in a workgroup's LDS
 #ifndef RGBDFE_SPLIT_MAX_SHARE
 #define RGBDFE_SPLIT_MAX_SHARE 256
@@ -1155,10 +1159,15 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const uint64_t m = __ballot(a), dm = __ballot(dear), cm = m & ~dm;
     if (a) lds.act_list[gs][lane_rank(m)] = (uint8_t)lane;
     const int D = __popcll(dm), Cn = __popcll(cm);
+    // what the pass's refits will cost: the sizes of the refined sets the dear slots hold (a recurrence walks its set)
+    int sum_rn = dear ? sl.rn : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum_rn += __shfl_xor(sum_rn, d);
+    const bool packed = kPackFrom >= 0 && D >= 4 && sum_rn >= kPackFrom;
     if (lane == 0) {
       lds.n_act[gs] = D + Cn;
       lds.task[gs] = 0;
-      lds.tickets[gs] = D >= kTicketsFrom ? 1 : 0;
+      lds.tickets[gs] = (packed || D >= kTicketsFrom) ? 1 : 0;
     }
     const int q = D / kWorkers, r = D - q * kWorkers;   // workers 0 .. r-1 hold q + 1 dear slots, the others q
     const int L = r > 0 ? kWorkers - r : 0;             // workers that are one dear slot short
@@ -1180,6 +1189,17 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         const int first = (w >= r && L > 0) ? (n1 / L + ((w - r) < n1 % L ? 1 : 0)) : 0;
         pos = (w < r ? q + 1 : q) + first + c2 / kWorkers;
       }
+    }
+    // A pass with much to refit (`packed`: the dear slots' refined sets add up to kPackFrom matches) has its bookkeeping and
+    // refits PACKED -- the dear slots, the ones that will most likely be refitted, seven to a worker, the cheap ones behind
+    // them -- and its scorings go out by ticket.  A worker's recurrence pass costs the same for one refit or seven (9 lanes
+    // each; three refits per pass on average when they are dealt round), so the fewer workers run one the fewer instructions
+    // the pass costs; the price is the second barrier of a ticket pass, which short recurrences (0.01 z^2: 41 steps) do not
+    // repay and long ones (0.002 z^2: 164 steps) do.
+    if (packed) {
+      const int idx = dear ? (int)lane_rank(dm) : D + (int)lane_rank(cm);
+      w = idx / kWaveSlots;
+      pos = idx - w * kWaveSlots;
     }
     if (__ballot(a && pos >= kWaveSlots) != 0ull) {     // the plain round: position p of the list -> worker p mod 7
       const int p = (int)lane_rank(m);
