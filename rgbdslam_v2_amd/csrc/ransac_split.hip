@@ -95,18 +95,20 @@ constexpr int kHypThreads = 256;
 // [20] iterations ended, [21] ... after their first scoring, [22] ... with refined_matches empty
 // [23] recurrence passes (a worker's refits of a half-round), [24] their steps (longest list), [25] their refits,
 // [26] scorings that ran pass 2, [27] pass-2 rounds of 64 candidates, [28] error-sum additions, [29] candidates of pass 1
+// per half-round over the workgroup's workers (ticks): [30] longest scoring phase, [31] mean scoring phase, [32] longest
+// bookkeeping + refit phase, [33] its mean, [34] longest busy time (both), [35] mean busy time
 // [8..15] the server's time (100 MHz ticks): SVD, recycle, load completion, hand-out, active list, load issue, scoring by
 // ticket, waiting at the barriers; [16..19] a worker's (wave 0): scoring, bookkeeping + refits, waiting at the barriers, -
 #ifdef RGBDFE_SPLIT_STATS
 // (a wave counts in registers and adds to the global array once, when it leaves the kernel: per-event atomics on 24 words
 // shared by 4096 waves serialised the launch they were meant to describe -- 4.8 instead of 1.0 ms per batch)
-__device__ unsigned long long g_split_stats[32];
-#define ST_DECL unsigned long long st_c[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_mx = 0;
+__device__ unsigned long long g_split_stats[40];
+#define ST_DECL unsigned long long st_c[40] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_mx = 0;
 #define ST_ADD(I, V) { st_c[I] += (unsigned long long)(V); }
 #define ST_MAX(I, V) { st_mx = (unsigned long long)(V) > st_mx ? (unsigned long long)(V) : st_mx; }
 #define ST_T0 unsigned long long st_t = __builtin_amdgcn_s_memrealtime();
 #define ST_LAP(I) { const unsigned long long st_n = __builtin_amdgcn_s_memrealtime(); st_c[I] += st_n - st_t; st_t = st_n; }
-#define ST_OUT { if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 32; ++st_i) if (st_c[st_i] != 0ull) atomicAdd(&g_split_stats[st_i], st_c[st_i]); \
+#define ST_OUT { if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 40; ++st_i) if (st_c[st_i] != 0ull) atomicAdd(&g_split_stats[st_i], st_c[st_i]); \
                  if (st_mx != 0ull) atomicMax(&g_split_stats[7], st_mx); } }
 #else
 #define ST_DECL
@@ -250,6 +252,9 @@ struct alignas(16) StreamLds {
   // passed after its read
   int quit[2];
   int pad[2];
+#ifdef RGBDFE_SPLIT_STATS
+  unsigned int st_w[2][8][2];     // [half-round parity][worker][scoring, bookkeeping + refit] ticks of the half-round
+#endif
 };
 static_assert(sizeof(StreamLds) <= 160 * 1024 / kWgsPerCu, "kWgsPerCu workgroups per CU");
 
@@ -648,6 +653,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     for (int h = 0;; ++h) {
       const int g = h & 1;
       const int lane = fresh(threadIdx.x & (kWave - 1));
+#ifdef RGBDFE_SPLIT_STATS
+      const unsigned long long st_s0 = st_c[16], st_f0 = st_c[17];
+#endif
       // this pass's slots of this wave (the server's deal): lane j < n_mine_slots holds the j-th
       const int n_mine_slots = __builtin_amdgcn_readfirstlane((int)lds.wlist[g][wave][7]);
       const int my_slot = g * kGroupSlots + (lane < n_mine_slots ? (int)lds.wlist[g][wave][min(lane, kWaveSlots - 1)] : 0);
@@ -755,6 +763,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
         }
       }
       ST_LAP(17)
+#ifdef RGBDFE_SPLIT_STATS
+      if ((threadIdx.x & 63) == 0) { lds.st_w[g][wave][0] = (unsigned int)(st_c[16] - st_s0); lds.st_w[g][wave][1] = (unsigned int)(st_c[17] - st_f0); }
+#endif
       // (the outcome records written in this pass are in memory before the server learns that their iterations have ended:
       // its walk between two windows of a pair reads them back)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1260,6 +1271,16 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     }
     lds_barrier();        // (the workers' bookkeeping and refits of group g)
     ST_LAP(15)
+#ifdef RGBDFE_SPLIT_STATS
+    {
+      unsigned int ms = 0, mf = 0, mb = 0, ss = 0, sf = 0;
+      for (int wk = 0; wk < kWorkers; ++wk) {
+        const unsigned int a = lds.st_w[g][wk][0], b = lds.st_w[g][wk][1];
+        ms = a > ms ? a : ms; mf = b > mf ? b : mf; mb = a + b > mb ? a + b : mb; ss += a; sf += b;
+      }
+      ST_ADD(30, ms) ST_ADD(31, ss / kWorkers) ST_ADD(32, mf) ST_ADD(33, sf / kWorkers) ST_ADD(34, mb) ST_ADD(35, (ss + sf) / kWorkers)
+    }
+#endif
     if (!more) { ST_ADD(1, 1) ST_MAX(7, h + 1) ST_OUT break; }
   }
 }
@@ -1323,11 +1344,11 @@ int ransac_split_wgs() { return kWgsPerCu * ransac_split_init(); }
 }  // namespace rgbdfe
 
 #ifdef RGBDFE_SPLIT_STATS
-extern "C" int rgbdfe_debug_split_stats(unsigned long long* out32, int reset) {
-  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(rgbdfe::g_split_stats), 256) != hipSuccess) return -1;
+extern "C" int rgbdfe_debug_split_stats(unsigned long long* out40, int reset) {
+  if (out40 && hipMemcpyFromSymbol(out40, HIP_SYMBOL(rgbdfe::g_split_stats), 320) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[32] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_stats), z, 256) != hipSuccess) return -1;
+    unsigned long long z[40] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rgbdfe::g_split_stats), z, 320) != hipSuccess) return -1;
   }
   return 0;
 }

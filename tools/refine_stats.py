@@ -27,7 +27,7 @@ buf = torch.zeros(len(pq) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cu
 for i in range(2):
     fe.wait_ticket(fe.submit_pair_list(pq, pt, buf.data_ptr()), None)
 fe.synchronize()
-st = (C.c_ulonglong * 32)()
+st = (C.c_ulonglong * 40)()
 L.rgbdfe_debug_split_stats(st, 1)
 fe.reset_kernel_time()
 fe.set_profiling(True)
@@ -53,4 +53,6 @@ print(json.dumps({"depth_noise": noise, "batches": B, "stage_ms_per_batch": roun
                   "server_us_per_half_round": dict(zip(("svd", "recycle", "complete_loads", "hand_out", "list_active", "issue_loads",
                                                         "ticket_scoring", "barrier_wait"), [round(x / 100.0 / max(v[0], 1), 2) for x in v[8:16]])),
                   "worker0_us_per_half_round": dict(zip(("scoring", "bookkeeping_refit", "barrier_wait"),
-                                                        [round(x / 100.0 / max(v[0], 1), 2) for x in v[16:19]]))}))
+                                                        [round(x / 100.0 / max(v[0], 1), 2) for x in v[16:19]])),
+                  "workers_us_per_half_round": dict(zip(("scoring_longest", "scoring_mean", "bookkeeping_refit_longest", "bookkeeping_refit_mean",
+                                                         "busy_longest", "busy_mean"), [round(x / 100.0 / max(v[0], 1), 2) for x in v[30:36]]))}))
