@@ -1319,7 +1319,15 @@ int ransac_split_init() {
   return n_cus[dev];
 }
 
-void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan, hipStream_t stream) {
+void launch_ransac_refine(uint32_t n_pairs, const RansacConst& rc, const SplitPlan& plan_in, hipStream_t stream) {
+  SplitPlan plan = plan_in;
+  // a unit's list of viable iterations holds kMaxShare entries: whatever the caller's plan says, no share is longer (the kernel
+  // would write past the list -- found as a hang when a policy change dropped the caller's own clamp)
+  if (!plan.phased && plan.share_iters > kMaxShare) {
+    const int I = rc.ransac_iterations > 0 ? rc.ransac_iterations : 0;
+    plan.n_shares = I > 0 ? (I + kMaxShare - 1) / kMaxShare : 1;
+    plan.share_iters = I > 0 ? (I + plan.n_shares - 1) / plan.n_shares : kMaxShare;
+  }
   const uint32_t units = n_pairs * (uint32_t)plan.n_shares;
   if (units == 0) return;
   // persistent workgroups: two per CU (LDS), each streaming units through its three LDS buffers; the units are handed out

@@ -1350,8 +1350,18 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     sp.phased = n_phases > 1 ? 1 : 0;
     sp.n_phases = n_phases < 4 ? n_phases : 4;
     for (int p = 0; p < 4; ++p) sp.phase_ends[p] = p < sp.n_phases ? (p == sp.n_phases - 1 ? I : phase_ends[p]) : I;
+    // Full speculation: a pair's range in shares of 4 x chunk_iters iterations so that a handful of pairs still fills the chip
+    // -- but no more shares than it takes to give every unit buffer of the launch (workgroups x resident units) a unit: a
+    // pair cut into shares is loaded once per share, a pair in one piece is one workgroup's chain of passes (0.002 z^2, 512
+    // pairs: whole pairs 2.66 ms, shares of 28 1.83 ms; 0.01 z^2: 0.397 / 0.427 ms).
     int share = chunk_iters >= 28 ? (I > 0 ? I : 1) : chunk_iters * 4;
-    if (share > ransac_split_max_share()) share = ransac_split_max_share();
+    {
+      const int buffers = ransac_split_wgs() * 4;
+      const int want = (int)((buffers + (int)n_pairs - 1) / (int)(n_pairs > 0 ? n_pairs : 1));   // shares per pair that fill them
+      const int by_want = I > 0 ? (I + want - 1) / (want > 0 ? want : 1) : 1;
+      if (by_want > share) share = by_want;
+    }
+    if (share > ransac_split_max_share()) share = ransac_split_max_share();   // (a unit's list of viable iterations)
     sp.n_shares = sp.phased ? 1 : (I > 0 ? (I + share - 1) / share : 1);
     sp.share_iters = sp.phased ? I : (I > 0 ? (I + sp.n_shares - 1) / sp.n_shares : share);
     // (the launch's unit counter: a spare word of walk[n_pairs], zeroed by the hypothesis kernel)
