@@ -144,16 +144,21 @@ int want_latency_path(rgbdfe_ctx* ctx, rgbdfe_ctx::Lane& lane, int32_t n, hipStr
     lane.d_walk = nullptr;
     latency = false;
   }
-  // Up to 1280 pairs one phase (full speculation, lowest latency); above, four phases so that recording stops
+  // Up to 256 pairs one phase (full speculation, lowest latency); above, four phases so that recording stops
   // where the reference's bookkeeping stops iterating.
   const int I = ctx->rc.ransac_iterations;
   static const int env_phases = getenv("RGBDFE_PHASES") ? atoi(getenv("RGBDFE_PHASES")) : 0;  // experiments only
-  // (round 6: a phased plan's unit is a whole pair whose windows follow each other inside one workgroup -- with fewer pairs than the
-  // launch has unit buffers, 512 workgroups x 4, that is a chain of drains per pair on a chip that has room for everything at
-  // once: up to 1280 pairs are recorded with full speculation.  0.002 z^2, 512 / 1024 pairs: 2.72 / 3.72 ms phased, 1.85 /
-  // 2.72 ms speculated; from 1536 pairs on the phased plan wins.)
-  static const int phased_from = getenv("RGBDFE_PHASED_FROM") ? atoi(getenv("RGBDFE_PHASED_FROM")) : 1281;
-  if ((n < phased_from && !force_phases) || env_phases == 1) { plan->n_phases = 1; plan->ends[0] = I; }
+  // (round 6, measured and kept as a switch only -- RGBDFE_MID_PLAN: a phased plan's unit is a whole pair whose windows follow each
+  // other inside one workgroup; with 257 .. 1280 pairs, fewer than the launch has unit buffers, a HARD pair -- one that needs
+  // nearly all of its iterations and passes the pre-screen with most of them, 0.002 z^2 -- is one workgroup's chain of 160
+  // refinements while others idle: 512 such pairs take 2.7 ms phased and 1.8 ms with full speculation in shares (= 1).  But an
+  // EASY pair, the usual case between neighbouring frames, ends its loop inside the first 14 iterations and speculation records
+  // all 200: the front-end sub-record's 2030 pairs, matched as two halves, take 6.3 ms instead of 3.3.  Two windows, [0, 14) and
+  // the rest (= 2), help neither.  Default 0: phased from 257 pairs on, as before.)
+  static const int mid_plan = getenv("RGBDFE_MID_PLAN") ? atoi(getenv("RGBDFE_MID_PLAN")) : 0;
+  const bool mid = n > 256 && n <= 1280 && !force_phases && env_phases == 0;
+  if ((n <= 256 && !force_phases) || env_phases == 1 || (mid && mid_plan == 1)) { plan->n_phases = 1; plan->ends[0] = I; }
+  else if (mid && mid_plan == 2 && I > 14) { plan->n_phases = 2; plan->ends[0] = 14; plan->ends[1] = I; }
   else if (env_phases == 2) { plan->n_phases = 2; plan->ends[0] = ((I * 7 / 20) / 7) * 7 > 0 ? ((I * 7 / 20) / 7) * 7 : I; plan->ends[1] = I; if (plan->ends[0] >= I) plan->n_phases = 1; }
   else {
     const int cand[4] = {14, ((I * 7 / 20) / 7) * 7, ((I * 14 / 20) / 7) * 7, I};

@@ -1342,7 +1342,7 @@ static void launch_record_replay(const PairWork* work, rgbdfe_match_result* resu
     // phased plans: pairs the pre-screen alone shows to be junk-heavy skip the first phase's launch + walk and record
     // everything at once (the classes only schedule the recording: the walk decides the outcome either way)
     static const bool no_pre = getenv("RGBDFE_NO_PRECLASS") && atoi(getenv("RGBDFE_NO_PRECLASS")) != 0;  // A/B runs
-    sp.preclass_iters = (n_phases > 2 && !no_pre) ? phase_ends[0] : 0;
+    sp.preclass_iters = (n_phases > 1 && !no_pre) ? phase_ends[0] : 0;
     // ONE refinement launch for the whole batch.  Phased plans: a unit is a pair, whose range the kernel records in windows
     // with the in-order walk between them (SplitPlan); latency batches (one phase, full speculation): a pair's range in
     // shares of 4 x chunk_iters iterations so that a handful of pairs still fills the chip.  The result waves below finish
