@@ -1247,6 +1247,18 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     ST_LAP(15)
     serve_svd(gs);
     ST_LAP(8)
+#ifndef RGBDFE_SPLIT_NO_EARLY_MID
+    // A pass whose scorings go out by ticket has a barrier in its middle (every scoring done) -- and that barrier waits for this
+    // wave too.  With all of the server's duties in front of it (13 us at 0.01 z^2) the workers, done with their tickets after
+    // 8 us, stood there for the difference in every such half-round (a fifth of them at 0.01 z^2, more than half at 0.002 z^2).
+    // So: the SVDs (which the other group's next scorings need, and which take as long as the tickets) and whatever tickets are
+    // left in front of the barrier, everything else behind it, beside the workers' bookkeeping and refits.
+    if (by_ticket) {
+      if (kServerScores) score_tickets(g);
+      ST_LAP(14)
+      lds_barrier();
+    }
+#endif
     recycle(gs);
     ST_LAP(9)
     complete_loads();
@@ -1264,11 +1276,13 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
            (lane + kWave < kStreamSlots && lds.slot[min(lane + kWave, kStreamSlots - 1)].iter >= 0);
     const bool more = __ballot(busy) != 0ull || live != 0ull || nx_n != 0 || units_left;
     if (!more && lane == 0) lds.quit[g] = 1;
+#ifdef RGBDFE_SPLIT_NO_EARLY_MID
     if (by_ticket) {
       if (kServerScores) score_tickets(g);   // its own duties done, the server scores like everybody else
       ST_LAP(14)
       lds_barrier();
     }
+#endif
     lds_barrier();        // (the workers' bookkeeping and refits of group g)
     ST_LAP(15)
 #ifdef RGBDFE_SPLIT_STATS
