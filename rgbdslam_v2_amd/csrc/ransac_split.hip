@@ -251,7 +251,7 @@ struct alignas(16) StreamLds {
   // then -- writes only quit[(h + 1) & 1] there; quit[h & 1] is written again in h + 2, behind a barrier every worker has
   // passed after its read
   int quit[2];
-  int pad[2];
+  int sum_rn[2];                   // refined matches held by the group's active slots (hand_out -> deal_work: the packed deal)
 #ifdef RGBDFE_SPLIT_STATS
   unsigned int st_w[2][8][2];     // [half-round parity][worker][scoring, bookkeeping + refit] ticks of the half-round
 #endif
@@ -1142,7 +1142,13 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       for (int e = 0; e < 6; ++e) v[e] = hyp[e];
 #pragma unroll
       for (int e = 0; e < 6; ++e) reinterpret_cast<float2*>(sl.u.x.R)[e] = v[e];  // -> R[9], t[3]
-      sl.rerr = 1e6;  // :1133
+      // refined_error = 1e6 (:1133), written as its two words: as a double the constant was hoisted out of the server's loop into
+      // a register PAIR, which the allocator cannot rematerialise -- the one value of the kernel that went to scratch
+      // (... and the halves kept apart, or the compiler fuses them back into the pair)
+      uint32_t rerr_hi = 0x412E8480u;
+      asm volatile("" : "+v"(rerr_hi));
+      reinterpret_cast<uint32_t*>(&sl.rerr)[0] = 0u;
+      reinterpret_cast<uint32_t*>(&sl.rerr)[1] = rerr_hi;
       sl.rn = 0;      // :1134
       sl.active = kSlotActive;
       sl.round = 0;
@@ -1153,6 +1159,17 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
       sl.thr = cx.thr;
       sl.pmax = lds.prep[b].pmax;
     }
+    lsync();
+  };
+
+  // ---- the refined matches the active slots of group gs hold (deal_work: whether the pass's refits are packed)
+  auto sum_refined = [&](int gs) {
+    const int lane = fresh(threadIdx.x & (kWave - 1));
+    const SlotS& sl = lds.slot[gs * kGroupSlots + min(lane, kGroupSlots - 1)];
+    int v = (lane < kGroupSlots && sl.iter >= 0 && sl.active == kSlotActive) ? sl.rn : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) lds.sum_rn[gs] = v;
     lsync();
   };
 
@@ -1170,11 +1187,9 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     const uint64_t m = __ballot(a), dm = __ballot(dear), cm = m & ~dm;
     if (a) lds.act_list[gs][lane_rank(m)] = (uint8_t)lane;
     const int D = __popcll(dm), Cn = __popcll(cm);
-    // what the pass's refits will cost: the sizes of the refined sets the dear slots hold (a recurrence walks its set)
-    int sum_rn = dear ? sl.rn : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum_rn += __shfl_xor(sum_rn, d);
-    const bool packed = kPackFrom >= 0 && D >= 4 && sum_rn >= kPackFrom;
+    // what the pass's refits will cost: the sizes of the refined sets the dear slots hold (a recurrence walks its set) --
+    // summed by the hand-out, which comes just before and has the registers for it (in here the reduction cost a spill)
+    const bool packed = kPackFrom >= 0 && D >= 4 && __builtin_amdgcn_readfirstlane(lds.sum_rn[gs]) >= kPackFrom;
     if (lane == 0) {
       lds.n_act[gs] = D + Cn;
       lds.task[gs] = 0;
@@ -1236,6 +1251,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   complete_loads();
   advance_units();
   hand_out(0);
+  sum_refined(0);
   deal_work(0);
   issue_loads();
   lds_barrier();
@@ -1266,6 +1282,7 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     ST_LAP(10)
     hand_out(gs);
     ST_LAP(11)
+    sum_refined(gs);
     deal_work(gs);
     ST_LAP(12)
     issue_loads();
