@@ -252,6 +252,9 @@ struct alignas(16) StreamLds {
   // passed after its read
   int quit[2];
   int sum_rn[2];                   // refined matches held by the group's active slots (hand_out -> deal_work: the packed deal)
+  uint16_t ord_cnt[kWave], ord_start[kWave];   // phased plans: pairs per order bucket (lane b: bucket 63 - b) and their exclusive prefix
+                                               // sums (a batch has at most 65 535 pairs) -- kept here, not in registers of the server:
+                                               // it has none to spare
 #ifdef RGBDFE_SPLIT_STATS
   unsigned int st_w[2][8][2];     // [half-round parity][worker][scoring, bookkeeping + refit] ticks of the half-round
 #endif
@@ -542,7 +545,8 @@ __global__ __launch_bounds__(kHypThreads) void ransac_hyp_kernel(const PairWork*
     if (tid == 0) {
       const int b = order_bucket(n_viable_sh);
       const uint32_t at = atomicAdd(plan.order_cnt + b, 1u);
-      plan.order[(size_t)b * (size_t)n_pairs + at] = pair;
+      if (at < n_pairs) plan.order[(size_t)b * (size_t)n_pairs + at] = pair;   // (a bucket holds every pair at most once: the
+                                                                               // counters were zeroed by pair_prep_kernel)
     }
   }
 }
@@ -796,19 +800,20 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
   const bool phased = plan.phased != 0;
   const bool use_preclass = phased && plan.preclass_iters > 0;
   // phased plans: the launch's units are the pairs of the order buckets, fullest bucket first (lane b: bucket 63 - b)
-  int ord_cnt = 0, ord_start = 0;
   uint32_t n_units_here = n_units;
   if (phased) {
     const int lane = fresh(threadIdx.x & (kWave - 1));
-    ord_cnt = (int)plan.order_cnt[kOrderBuckets - 1 - lane];
-    int incl = ord_cnt;
+    const int cnt = (int)min(plan.order_cnt[kOrderBuckets - 1 - lane], n_pairs);
+    int incl = cnt;
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
       const int t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
     }
-    ord_start = incl - ord_cnt;
+    lds.ord_cnt[lane] = (uint16_t)cnt;
+    lds.ord_start[lane] = (uint16_t)(incl - cnt);
     n_units_here = (uint32_t)__builtin_amdgcn_readlane(incl, kWave - 1);
+    lsync();
   }
 
   // ---- the next block of units off the counter; the facts that decide which of them have work are requested (global ->
@@ -824,11 +829,12 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
     nx_n = (int)min((uint32_t)blk, n_units_here - base);
     const uint32_t unit = base + (uint32_t)min(lane, nx_n - 1);
     if (phased) {   // unit `base` of the launch = entry (base - start) of the bucket whose range holds it
+      const int ord_start = (int)lds.ord_start[lane], ord_cnt = (int)lds.ord_cnt[lane];
       const uint64_t holds = __ballot((int)base >= ord_start && (int)base < ord_start + ord_cnt);
       const int bl = (int)__builtin_ctzll(holds);
       const uint32_t idx = base - (uint32_t)__builtin_amdgcn_readlane(ord_start, bl);
       const uint32_t pr = plan.order[(size_t)(kOrderBuckets - 1 - bl) * (size_t)n_pairs + idx];
-      nx_pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr);
+      nx_pair = min((uint32_t)__builtin_amdgcn_readfirstlane((int)pr), n_pairs - 1u);   // (an index of this batch, whatever the memory held)
       nx_share = 0;
     } else {
       nx_pair = unit / (uint32_t)plan.n_shares;
