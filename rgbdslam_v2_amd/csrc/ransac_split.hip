@@ -3,8 +3,10 @@
 // Replaces, per (newer node, older node) pair, the body of the RANSAC loop of Node::getRelativeTransformationTo
 // (node.cpp:1130-1169): sample_matches_prefer_by_distance (node.cpp:1024-1047), getTransformFromMatches
 // (transformation_estimation_euclidean.cpp:7-61), computeInliersAndError + errorFunction2 (node.cpp:968-1020,
-// misc.cpp:697-770) and the refinement loop (node.cpp:1140-1169).  The in-order bookkeeping (node.cpp:1171-1190) stays with
-// replay_walk_kernel, the result with select_ransac_kernel<kReplay> (select_ransac.hip).
+// misc.cpp:697-770) and the refinement loop (node.cpp:1140-1169).  The in-order bookkeeping (node.cpp:1171-1190, walk_records
+// in ransac_device.h) runs between a pair's WINDOWS inside the refinement kernel -- a phased plan records a pair's iteration
+// range window by window in ONE launch and stops where the reference's loop stops -- and is finished by the result waves,
+// select_ransac_kernel<kReplay> (select_ransac.hip).  Five launches per batch: Hamming, pair_prep, the two kernels here, result.
 //
 // An iteration's outcome is a pure function of its index (counter-based sampling, D1), so the work of a batch is cut by
 // WHAT IS DONE, not by pair:
@@ -12,10 +14,11 @@
 //                         4-point sample, the weighted fit, the 3x3 Jacobi SVD and the pre-screen (an upper bound of the
 //                         matches that can pass errorFunction2's shortcut test; fewer than the inlier threshold => the
 //                         iteration certainly ends with refined_matches empty, node.cpp:1148-1154).  Leaves, per pair, a
-//                         bit mask of the viable iterations, their transforms (in the rR / rt fields of the iteration's
-//                         record) and the empty summaries of the others.  No slot machinery, no scoring state.
+//                         bit mask of the viable iterations and their transforms (in the rR / rt fields of the iteration's
+//                         record), the pair's initial walk state, and its place in the ORDER BUCKETS (pairs by their number of
+//                         viable iterations: the refinement launch takes the fullest first).  No slot machinery, no scoring state.
 //   ransac_refine_kernel  the refinement loops of the viable iterations only.  Persistent workgroups of 8 waves =
-//                         7 WORKERS + 1 SERVER; up to three units (pair, iteration range) are resident in LDS (the pair's
+//                         7 WORKERS + 1 SERVER; up to four units (a pair, or a share of its range) are resident in LDS (the pair's
 //                         PairPrep: match records + facts, 9 KB each) and their viable iterations occupy SLOTS (7 per
 //                         worker and group).  The slots form two groups that take turns: in a half-round the workers run
 //                         one pass of the refinement loop (node.cpp:1140) for the slots of group g
@@ -50,7 +53,8 @@
 //                         polling (round 4's streaming version handed work out through LDS spin locks and stalled about
 //                         twice in 10^4 small launches beside context churn): a launch cannot wait for
 //                         anything but its own waves' arrival at a hardware barrier.
-//                         LDS: 79.6 KB per workgroup => 2 workgroups = 16 waves per CU at <= 128 VGPRs (4 per SIMD).
+//                         LDS: 80 KB per workgroup (four resident units) => 2 workgroups = 16 waves per CU at <= 128 VGPRs
+//                         (4 per SIMD).
 // Same bytes as the one-wave kernel (select_ransac_kernel<kWhole>): every float / double operation is the one
 // oracle/rgbd_oracle.c performs, in the same order (-ffp-contract=off), so every discrete RANSAC decision is the same.
 #include <stdio.h>
