@@ -757,7 +757,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   if (n_all > rc.min_matches) {
     uint32_t thr = (uint32_t)rc.min_matches;                                  // :1094
     if ((double)thr > 0.75 * (double)n_all) thr = (uint32_t)(0.75 * (double)n_all);  // :1095-1098
-    const double max_dist_d = (double)rc.max_dist_m;
+    // (the double of max_dist_m is formed where it is compared: as a loop-invariant value it sat in a register PAIR for the length
+    // of the kernel -- one of the values the allocator sent to scratch)
+    auto max_dist_d = [&]() { float f = rc.max_dist_m; asm volatile("" : "+v"(f)); return (double)f; };
     rmse = 1e6f;  // :1112
     const uint32_t seed_uid = mix32(mix32(rc.seed ^ 0x9E3779B9u) + w.uid * 0x85EBCA6Bu);
 
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           Slot& sl = lds.slot[lane];
           if (sl.active) {
             const int n_inl = sl.cn, rn = sl.rn;
-            if (!((uint32_t)n_inl < thr || err_mine > max_dist_d)) {   // :1154
+            if (!((uint32_t)n_inl < thr || err_mine > max_dist_d())) {   // :1154
               if (n_inl >= rn && err_mine <= sl.rerr) {                 // :1160
                 still = (n_inl != rn);                                 // :1166
 #pragma unroll
@@ -951,7 +953,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
           else fit_recurrence<false>(n_mine, k256_mine, n_min, n_max, lds.u.fit, lds.M, C, m1, m2, lane);
           PH_MARK(4)
           // lane s (< G) collects the state of slot s
-          const int src = min(lane, kSlots - 1) * 9;
+          // (the lane made opaque here: derived from the kernel's `lane` the shuffle addresses were formed at the top of the
+          // kernel, kept for its whole length and spilled)
+          int lane_here = lane;
+          asm volatile("" : "+v"(lane_here));
+          const int src = min(lane_here, kSlots - 1) * 9;
 #pragma unroll
           for (int x = 0; x < 9; ++x) mine.C[x] = __shfl(C, src + x);
 #pragma unroll
@@ -1121,9 +1127,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
             }
             wave_sync();
             best_n = refined_n;
-            if ((double)refined_n > (double)n_all * 0.5) it += 10;   // :1186
-            if ((double)refined_n > (double)n_all * 0.75) it += 10;  // :1187
-            if ((double)refined_n > (double)n_all * 0.8) { done = true; break; }  // :1188
+            // (n_all's double formed here, from a value the compiler cannot see through: as three loop-invariant products they sat
+            // in register pairs for the length of the kernel -- the values the allocator sent to scratch)
+            int n_all_here = n_all;
+            asm volatile("" : "+v"(n_all_here));
+            const double n_all_d = (double)n_all_here;
+            if ((double)refined_n > n_all_d * 0.5) it += 10;   // :1186
+            if ((double)refined_n > n_all_d * 0.75) it += 10;  // :1187
+            if ((double)refined_n > n_all_d * 0.8) { done = true; break; }  // :1188
           }
         }
         ++it;
@@ -1136,7 +1147,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
       int n_inl;
       double inlier_error;
       score_hypothesis(IR, It, n_all, thr + 1u, rc, lds, pmax, ec_region, inl_mask, n_inl, inlier_error PH_PASS);  // needs > thr (:1206)
-      if ((uint32_t)n_inl > thr && inlier_error < max_dist_d) {  // :1206
+      if ((uint32_t)n_inl > thr && inlier_error < max_dist_d()) {  // :1206
         hyp_store(lds.best, IR, It, inl_mask, n_inl, 0, inlier_error);
         best_n = n_inl;
         rmse = (float)inlier_error;
