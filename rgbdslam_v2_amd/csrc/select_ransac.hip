@@ -1587,16 +1587,23 @@ __device__ __forceinline__ void gn_rot_via_quaternion(const double* Rin, double*
     q[1] = (Rin[2] - Rin[6]) * tt;
     q[2] = (Rin[3] - Rin[1]) * tt;
   } else {
-    int i = 0;
-    if (Rin[4] > Rin[0]) i = 1;
-    if (Rin[8] > Rin[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double tt = sqrt(Rin[i * 3 + i] - Rin[j * 3 + j] - Rin[k * 3 + k] + 1.0);
-    q[i] = 0.5 * tt;
-    tt = 0.5 / tt;
-    q[3] = (Rin[k * 3 + j] - Rin[j * 3 + k]) * tt;
-    q[j] = (Rin[j * 3 + i] + Rin[i * 3 + j]) * tt;
-    q[k] = (Rin[k * 3 + i] + Rin[i * 3 + k]) * tt;
+    // the largest diagonal element picks (i, j, k); each case is written out with constant indices -- indexed by a run-time i
+    // the nine doubles of Rin (and q) lived in an 80-byte private array in scratch
+    const bool i1 = Rin[4] > Rin[0];
+    const bool i2 = Rin[8] > (i1 ? Rin[4] : Rin[0]);
+    auto pick = [&](auto I, auto J, auto K) {
+      constexpr int i = decltype(I)::value, j = decltype(J)::value, k = decltype(K)::value;
+      double tt = sqrt(Rin[i * 3 + i] - Rin[j * 3 + j] - Rin[k * 3 + k] + 1.0);
+      q[i] = 0.5 * tt;
+      tt = 0.5 / tt;
+      q[3] = (Rin[k * 3 + j] - Rin[j * 3 + k]) * tt;
+      q[j] = (Rin[j * 3 + i] + Rin[i * 3 + j]) * tt;
+      q[k] = (Rin[k * 3 + i] + Rin[i * 3 + k]) * tt;
+    };
+    using std::integral_constant;
+    if (i2) pick(integral_constant<int, 2>(), integral_constant<int, 0>(), integral_constant<int, 1>());
+    else if (i1) pick(integral_constant<int, 1>(), integral_constant<int, 2>(), integral_constant<int, 0>());
+    else pick(integral_constant<int, 0>(), integral_constant<int, 1>(), integral_constant<int, 2>());
   }
   const double nrm = sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
   for (int i = 0; i < 4; ++i) q[i] = q[i] / nrm;
