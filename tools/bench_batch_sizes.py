@@ -1,6 +1,8 @@
+"""GPU box: one synchronous pair batch of n pairs, results left in HBM, n = 64 ... 4000 (ms per batch, 20 repetitions each).
+    python tools/bench_batch_sizes.py [depth_noise=0.01]"""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rgbdslam_v2_amd import synth
 from rgbdslam_v2_amd.frontend import FrontEnd
 noise = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
