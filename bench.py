@@ -267,7 +267,7 @@ def main():
     # the sharding / gather / timing logic of the N > 1 path; collectives then go through host tensors.
     backend = os.environ.get("RGBDFE_BENCH_BACKEND", "nccl")
     # RGBDFE_BENCH_FORCE_GATHER=1 (tests only): the N > 1 gather code with ONE rank -- the only way to run its RCCL branch
-    # (process group, pack kernels, two-collective inlier gather, parity check on the gathered records) on a one-GPU box
+    # (process group, pack kernels, the inlier gather, parity check on the gathered records) on a one-GPU box
     force_gather = os.environ.get("RGBDFE_BENCH_FORCE_GATHER") == "1"
     gather_on = world > 1 or force_gather
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
@@ -344,8 +344,6 @@ def main():
     if inliers:
         d_send = [torch.zeros(stream_cap, dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
         d_tot = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(NBUF)]
-        h_tot = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(NBUF)]
-        ev_tot = [torch.cuda.Event() for _ in range(NBUF)]
         d_all = torch.zeros(world * stream_cap, dtype=torch.uint8, device="cuda")
         d_tots = torch.zeros(world, dtype=torch.int64, device=cdev)
     else:
@@ -353,16 +351,25 @@ def main():
         d_all = torch.zeros(world * n_pad * gat_bytes, dtype=torch.uint8, device="cuda") if gather_on else None
     consumed = [None] * NBUF
     stream = torch.cuda.current_stream().cuda_stream
-    state = {"k": 0, "open": None, "bytes": 0, "gathers": 0, "last": None}
+    state = {"k": 0, "bytes": 0, "gathers": 0, "gathers_all": 0, "last": None}
 
-    def gather_inliers(b):
-        """The two collectives of step b's inlier streams: the list lengths (one int64 per rank), then the streams padded to the
-        longest.  The lengths come through the host -- which is why a step's gather is issued one step late (step())."""
-        ev_tot[b].synchronize()
-        mine = torch.tensor([int(h_tot[b].item())], dtype=torch.int64, device=cdev)
-        dist.all_gather_into_tensor(d_tots, mine)
-        totals = [int(v) for v in d_tots.cpu().tolist()]
-        nbytes = n_pad * hdr_bytes + 4 * max(totals)
+    # The inlier streams' gather: ONE collective per step and no host read in front of it.  The collective is
+    # sized BEFORE the ranks have counted their lists: n_pad headers + `cap` list entries per rank, cap = the longest list of
+    # the first (warm-up) gather plus a quarter -- the only gather that exchanges the lengths first.  Every stream carries
+    # its own length (its last header: first_inlier + n_inl), so what every rank got is checked on the device from the
+    # gathered headers; the check's result reaches the host behind the NEXT step's submission (an event that has long
+    # fired by then), and a list that has outgrown `cap` -- every rank sees the same gathered headers and decides alike --
+    # repeats that step's gather at the exact size from the ring buffer that still holds its stream.
+    hdr_dt = INLIER_HEADER_DTYPE
+    off_first, off_ninl = hdr_dt.fields["first_inlier"][1], hdr_dt.fields["n_inl"][1]
+    # (RGBDFE_BENCH_INLIER_CAP: tests only -- a capacity to start from instead of the learned one, e.g. one that is too small)
+    inl = {"cap": int(os.environ.get("RGBDFE_BENCH_INLIER_CAP", "0")), "pending": [], "collectives": 0, "regathers": 0, "idx": None}
+    if inliers:
+        h_chk = [torch.zeros(world, dtype=torch.int32).pin_memory() for _ in range(NBUF)]
+        ev_chk = [torch.cuda.Event() for _ in range(NBUF)]
+
+    def exchange_streams(b, entries):
+        nbytes = n_pad * hdr_bytes + 4 * entries
         out = d_all[: world * nbytes]
         if host_coll:
             h_all = torch.empty(world * nbytes, dtype=torch.uint8)
@@ -370,16 +377,64 @@ def main():
             out.copy_(h_all)
         else:
             dist.all_gather_into_tensor(out, d_send[b][:nbytes])
-        consumed[b] = torch.cuda.Event()
-        consumed[b].record()
+        inl["collectives"] += 1
         state["bytes"] += world * nbytes
-        state["gathers"] += 1
+        return nbytes, out
+
+    def learn_capacity(b):
+        """The first gather: the list lengths (one int64 per rank) through the host, then the streams at the longest."""
+        torch.cuda.current_stream().synchronize()
+        mine = torch.tensor([int(d_tot[b].item())], dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(d_tots, mine)
+        inl["collectives"] += 1
+        totals = [int(v) for v in d_tots.cpu().tolist()]
+        nbytes, _ = exchange_streams(b, max(totals))
+        inl["cap"] = min(max(totals) + max(totals) // 4 + 64, n_pad * RGBDFE_MAX_MATCHES)
+        inl["idx"] = None
         state["last"] = (nbytes, totals)
 
+    def gather_inliers(b):
+        if inl["cap"] == 0:
+            learn_capacity(b)
+        else:
+            nbytes, out = exchange_streams(b, inl["cap"])
+            if inl["idx"] is None:   # word positions of every rank's last header's (first_inlier, n_inl) in the gathered buffer
+                base = [(r * nbytes + (n_pad - 1) * hdr_bytes) // 4 for r in range(world)]
+                inl["idx"] = (torch.tensor([x + off_first // 4 for x in base], device="cuda"),
+                              torch.tensor([x + off_ninl // 4 for x in base], device="cuda"))
+            w32 = out.view(torch.int32)
+            h_chk[b].copy_(w32[inl["idx"][0]] + w32[inl["idx"][1]], non_blocking=True)
+            ev_chk[b].record()
+            inl["pending"].append((b, nbytes, inl["cap"]))
+        consumed[b] = torch.cuda.Event()
+        consumed[b].record()
+        state["gathers"] += 1
+        state["gathers_all"] += 1
+
+    def check_gathers(block):
+        """The length checks of the gathers issued so far (those whose event has fired; all of them when `block`)."""
+        redo = False   # behind a repeated gather every later one is repeated too: d_all ends up holding the LAST step's streams
+        while inl["pending"]:
+            b, nbytes, cap_used = inl["pending"][0]
+            if block or redo:
+                ev_chk[b].synchronize()
+            elif not ev_chk[b].query():
+                return
+            inl["pending"].pop(0)
+            totals = [int(v) for v in h_chk[b].tolist()]
+            if max(totals) > cap_used or redo:   # (the same on every rank: all of them read the same gathered headers)
+                redo = True
+                inl["regathers"] += 1
+                if max(totals) > inl["cap"]:
+                    inl["cap"] = min(max(totals) + max(totals) // 4 + 64, n_pad * RGBDFE_MAX_MATCHES)
+                    inl["idx"] = None
+                nbytes, _ = exchange_streams(b, inl["cap"])
+                consumed[b] = torch.cuda.Event()
+                consumed[b].record()
+            state["last"] = (nbytes, totals)
+
     def flush():
-        if state["open"] is not None:
-            gather_inliers(state["open"])
-            state["open"] = None
+        check_gathers(True)
 
     def step():
         b = state["k"] % NBUF
@@ -394,14 +449,10 @@ def main():
             fe.wait_ticket(ticket, stream)  # torch's stream waits for this batch only
             if inliers:
                 # headers + (query row, train row) of every inlier match: inlier_scan_kernel + inlier_list_kernel on torch's
-                # stream; the length of the list block goes to the host (pinned).  The gather itself needs that length, so it is
-                # issued while the NEXT step computes: the host never waits for the step it has just submitted.
+                # stream, and behind them -- stream ordered, no host read -- the step's one collective (gather_inliers)
                 fe.pack_inliers(d_local[b].data_ptr(), n_local, n_pad, d_send[b].data_ptr(), d_tot[b].data_ptr(), stream)
-                h_tot[b].copy_(d_tot[b], non_blocking=True)
-                ev_tot[b].record()
-                prev, state["open"] = state["open"], b
-                if prev is not None:
-                    gather_inliers(prev)
+                check_gathers(False)    # earlier steps' length checks (host side: reads of pinned words whose events have fired)
+                gather_inliers(b)
                 return
             if compact:  # header + inlier mask of every record (144 of 1744 B): compact_pack_kernel on torch's stream
                 fe.pack_compact(d_local[b].data_ptr(), n_local, d_send[b].data_ptr(), stream)
@@ -671,7 +722,11 @@ def main():
                                  "inliers": round(per_step) if inliers else None,
                                  "compact": world * n_pad * COMPACT_DTYPE.itemsize, "full": world * n_pad * rec_bytes},
                              "gathers_in_timed_regions": gathers_timed,
-                             "collectives_per_step": 2 if inliers else 1,
+                             "collectives_per_step": 1,
+                             "inlier_gather": {"list_capacity_entries": inl["cap"], "collectives_issued": inl["collectives"],
+                                               "gathers_issued": state["gathers_all"], "regathers": inl["regathers"],
+                                               "host_reads_before_a_collective": "the first (warm-up) gather only"}
+                                              if inliers else None,
                              "backend": backend, "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
                              "distinct_devices": len({d.split(" ", 2)[2] for d in rank_devices}) if rank_devices else None,
                              "transport": "RCCL ncclAllGather via torch.distributed (nccl backend)" if backend == "nccl"

@@ -154,6 +154,10 @@ int  rgbdfe_match_pair_list_allgather_edges(rgbdfe_ctx* ctx, const int32_t* quer
                                             int32_t n_pairs, void* const* d_out, int32_t* const* d_index,
                                             int32_t* edges_per_device, int32_t* stride);
 const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx);            /* "rccl", "p2p" or "none" (last allgather) */
+/* Exchanges the latest rgbdfe_match_pair_list_allgather_inliers call issued: 1 = the one collective sized before the
+ * devices had counted their lists, 2 = a list had outgrown that size (and the group's first call: 1, after reading the
+ * counts); 0 for other handles / before the first call. */
+int  rgbdfe_gather_exchanges(rgbdfe_ctx* ctx);
 /* Host time (microseconds) the calling thread spent enqueueing the latest sharded batch on all devices of a multi handle:
  * the shards are submitted by ONE thread, device after device.  With graph capture on (rgbdfe_set_graph_capture; OFF by
  * default) a batch's launch chain is a cached hipGraph per device -- one hipGraphLaunch (+ a read-back or pack enqueue) per
@@ -166,8 +170,10 @@ int  rgbdfe_match_pair_list_allgather_compact(rgbdfe_ctx* ctx, const int32_t* qu
 /* The inlier form of the all-gather (rgbdfe_inlier_header below the result structs): every device packs its shard into an
  * inlier stream -- per = ceil(n_pairs / G) headers of 104 bytes, then (queryIdx | trainIdx << 16) of every inlier match --
  * and on return d_out[j] holds device i's stream at byte offset i * (*stride_bytes); list_entries[i] = entries of device
- * i's list block (*stride_bytes = per * 104 + 4 * the largest of them).  Pair k of the caller's list = header k / G of
- * device k mod G.  What GraphManager reads of a MatchingResult (edge, rmse, counts, inlier_matches for
+ * i's list block (*stride_bytes = per * 104 + 4 * C with C >= the largest of them: the exchange is sized from the lists of
+ * the group's earlier calls, so that packing and the ONE collective are enqueued without a host read between them; C is the
+ * largest list itself on a group's first call and whenever a list has outgrown the earlier ones by more than a quarter --
+ * rgbdfe_gather_exchanges).  Pair k of the caller's list = header k / G of device k mod G.  What GraphManager reads of a MatchingResult (edge, rmse, counts, inlier_matches for
  * updateInlierFeatures, graph_manager.cpp:409-419) at ~260 bytes per pair instead of 1744.  Buffers: G * per *
  * (104 + 4 * RGBDFE_MAX_MATCHES) bytes each (the worst case). */
 int  rgbdfe_match_pair_list_allgather_inliers(rgbdfe_ctx* ctx, const int32_t* query_ids, const int32_t* train_ids,

@@ -305,6 +305,8 @@ def load():
     L.rgbdfe_group_submit_us.argtypes = [ctx, C.POINTER(C.c_double)]
     L.rgbdfe_gather_transport.restype = C.c_char_p
     L.rgbdfe_gather_transport.argtypes = [ctx]
+    L.rgbdfe_gather_exchanges.restype = C.c_int
+    L.rgbdfe_gather_exchanges.argtypes = [ctx]
     L.rgbdfe_set_hamming_mode.restype = C.c_int
     L.rgbdfe_set_hamming_mode.argtypes = [ctx, i32]
     L.rgbdfe_match_pair_list_allgather_compact.restype = C.c_int
@@ -375,7 +377,7 @@ EXPORTED_SYMBOLS = [
     "rgbdfe_pose_graph_create", "rgbdfe_pose_graph_destroy", "rgbdfe_pose_graph_add_node",
     "rgbdfe_pose_graph_add_edge", "rgbdfe_pose_graph_set_matchable", "rgbdfe_potential_edge_targets",
     "rgbdfe_create_multi", "rgbdfe_device_count", "rgbdfe_device_context", "rgbdfe_match_pair_list_allgather",
-    "rgbdfe_gather_transport", "rgbdfe_set_hamming_mode", "rgbdfe_project_to_3d_cloud", "rgbdfe_detect_describe_cloud",
+    "rgbdfe_gather_transport", "rgbdfe_gather_exchanges", "rgbdfe_set_hamming_mode", "rgbdfe_project_to_3d_cloud", "rgbdfe_detect_describe_cloud",
     "rgbdfe_detect_describe_batch", "rgbdfe_detect_describe_batch_nodes", "rgbdfe_match_pair_list_allgather_edges",
     "rgbdfe_set_feature_min_depth", "rgbdfe_project_to_3d_min_depth",
     "rgbdfe_place_recognition", "rgbdfe_place_recognition_batch", "rgbdfe_upload_float_node",

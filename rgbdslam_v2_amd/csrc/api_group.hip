@@ -450,9 +450,16 @@ int group_match_allgather_edges(rgbdfe_ctx* gctx, const int32_t* q, const int32_
 
 // All-gather of the INLIER FORM of the results (include/rgbdfe.h: rgbdfe_inlier_header): what GraphManager reads of a
 // MatchingResult -- edge, rmse, counts and the inlier matches' (queryIdx, trainIdx) -- ~260 bytes per pair at configs[1] instead
-// of 1744.  Every device packs its shard (per headers + its lists) into scratch, the host learns the list lengths, and the
-// exchange moves stride = per * 104 + 4 * max(length) bytes per device.  On return d_out[j] holds device i's stream at byte
-// offset i * stride: pair k of the caller's list = header k / G of device k mod G.
+// of 1744.  Every device packs its shard (per headers + its lists) into scratch and the streams are exchanged at a stride of
+// per * 104 + 4 * C bytes per device, C >= the longest list.  On return d_out[j] holds device i's stream at byte offset
+// i * stride: pair k of the caller's list = header k / G of device k mod G.
+//
+// ONE exchange, no host read in front of it: C is fixed BEFORE the devices have counted their lists -- the
+// longest list the group has seen so far plus a quarter -- so matching, packing and the collective go onto every device's
+// stream back to back, and the host reads the counts once, behind all of it (they are what the call returns).  Only the
+// first call of a group, and a call whose lists outgrow what was seen (more than a quarter longer than any before), pay a
+// second exchange -- of the streams that are still in scratch -- at the exact size; `inl_exchanges` says which it was
+// (rgbdfe_gather_exchanges).
 int group_match_allgather_inliers(rgbdfe_ctx* gctx, const int32_t* q, const int32_t* t, int32_t n, void* const* d_out,
                                   int32_t* records_per_device, int32_t* totals, int64_t* stride_bytes) {
   if (n < 0 || !d_out || !totals || !stride_bytes || (n > 0 && (!q || !t)))
@@ -463,6 +470,7 @@ int group_match_allgather_inliers(rgbdfe_ctx* gctx, const int32_t* q, const int3
   const int32_t per = (n + G - 1) / G;
   if (records_per_device) *records_per_device = per;
   *stride_bytes = 0;
+  g.inl_exchanges = 0;
   for (int i = 0; i < G; ++i) totals[i] = 0;
   if (per == 0) return RGBDFE_OK;
   for (int i = 0; i < G; ++i)
@@ -477,7 +485,9 @@ int group_match_allgather_inliers(rgbdfe_ctx* gctx, const int32_t* q, const int3
       HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
       HIP_TRY(gctx, hipMalloc((void**)&g.inl_stream[(size_t)i], (size_t)g.edge_cap * (sizeof(rgbdfe_inlier_header) + 4 * RGBDFE_MAX_MATCHES)));
     }
-  // 1. every device: its shard into scratch records, then the inlier stream
+  const size_t worst = (size_t)per * RGBDFE_MAX_MATCHES;          // (the caller's buffers and the scratch hold this much)
+  const size_t cap_known = std::min(g.inl_cap_entries, worst);    // 0: nothing seen yet -- the counts are read first
+  // 1. every device: its shard into scratch records, then the inlier stream and its length (to pinned memory)
   int rc = group_run(gctx, [&](int i) -> int {
     rgbdfe_ctx* c = g.children[(size_t)i];
     std::vector<int32_t> qs, ts;
@@ -499,38 +509,59 @@ int group_match_allgather_inliers(rgbdfe_ctx* gctx, const int32_t* q, const int3
     launch_pack_inliers(seg, (uint32_t)qs.size(), (uint32_t)per, g.inl_stream[(size_t)i], g.edge_cnt[(size_t)i], gs);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(g.edge_cnt_host[(size_t)i], g.edge_cnt[(size_t)i], sizeof(int32_t), hipMemcpyDeviceToHost, gs));
-    HIP_TRY(c, hipStreamSynchronize(gs));
+    if (cap_known == 0) HIP_TRY(c, hipStreamSynchronize(gs));
     return RGBDFE_OK;
   });
   if (rc != RGBDFE_OK) return rc;
-  int32_t longest = 0;
-  for (int i = 0; i < G; ++i) { totals[i] = *g.edge_cnt_host[(size_t)i]; longest = std::max(longest, totals[i]); }
-  const size_t stride = hdr_bytes + (size_t)longest * 4;
-  *stride_bytes = (int64_t)stride;
-  // 2. the exchange
-  if (group_setup_rccl(gctx)) {
-    g.transport = "rccl";
-    if (g.rccl.GroupStart() != 0) return fail(gctx, RGBDFE_ERR_HIP, "ncclGroupStart failed");
-    int nrc = 0;
-    for (int i = 0; i < G && nrc == 0; ++i)
-      nrc = g.rccl.AllGather(g.inl_stream[(size_t)i], d_out[i], stride, kNcclChar, g.comms[(size_t)i], g.gather_streams[(size_t)i]);
-    const int erc = g.rccl.GroupEnd();
-    if (nrc != 0 || erc != 0)
-      return fail(gctx, RGBDFE_ERR_HIP, std::string("ncclAllGather: ") +
-                                            (g.rccl.GetErrorString ? g.rccl.GetErrorString(nrc ? nrc : erc) : "error"));
-  } else {
-    g.transport = G == 1 ? "none (one device)" : "p2p";
+  // the exchange at `entries` list entries per device, enqueued behind the packing on every device's gather stream
+  auto exchange = [&](size_t entries) -> int {
+    const size_t stride = hdr_bytes + entries * 4;
+    ++g.inl_exchanges;
+    if (group_setup_rccl(gctx)) {
+      g.transport = "rccl";
+      if (g.rccl.GroupStart() != 0) return fail(gctx, RGBDFE_ERR_HIP, "ncclGroupStart failed");
+      int nrc = 0;
+      for (int i = 0; i < G && nrc == 0; ++i)
+        nrc = g.rccl.AllGather(g.inl_stream[(size_t)i], d_out[i], stride, kNcclChar, g.comms[(size_t)i], g.gather_streams[(size_t)i]);
+      const int erc = g.rccl.GroupEnd();
+      if (nrc != 0 || erc != 0)
+        return fail(gctx, RGBDFE_ERR_HIP, std::string("ncclAllGather: ") +
+                                              (g.rccl.GetErrorString ? g.rccl.GetErrorString(nrc ? nrc : erc) : "error"));
+    } else {
+      g.transport = G == 1 ? "none (one device)" : "p2p";
+      for (int i = 0; i < G; ++i) {
+        HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
+        for (int j = 0; j < G; ++j)
+          HIP_TRY(gctx, hipMemcpyPeerAsync((char*)d_out[j] + (size_t)i * stride, g.device_ids[(size_t)j], g.inl_stream[(size_t)i],
+                                           g.device_ids[(size_t)i], stride, g.gather_streams[(size_t)i]));
+      }
+    }
     for (int i = 0; i < G; ++i) {
       HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
-      for (int j = 0; j < G; ++j)
-        HIP_TRY(gctx, hipMemcpyPeerAsync((char*)d_out[j] + (size_t)i * stride, g.device_ids[(size_t)j], g.inl_stream[(size_t)i],
-                                         g.device_ids[(size_t)i], hdr_bytes + (size_t)totals[i] * 4, g.gather_streams[(size_t)i]));
+      HIP_TRY(gctx, hipStreamSynchronize(g.gather_streams[(size_t)i]));
     }
+    return RGBDFE_OK;
+  };
+  auto read_totals = [&]() -> size_t {
+    int32_t longest = 0;
+    for (int i = 0; i < G; ++i) { totals[i] = *g.edge_cnt_host[(size_t)i]; longest = std::max(longest, totals[i]); }
+    return (size_t)longest;
+  };
+  // 2. the exchange: at the capacity known from earlier calls (the counts arrive behind it), or -- nothing known, or a list
+  //    has outgrown it -- at the longest list of this call
+  size_t entries = cap_known;
+  if (cap_known != 0) {
+    rc = exchange(cap_known);
+    if (rc != RGBDFE_OK) return rc;
   }
-  for (int i = 0; i < G; ++i) {
-    HIP_TRY(gctx, hipSetDevice(g.device_ids[(size_t)i]));
-    HIP_TRY(gctx, hipStreamSynchronize(g.gather_streams[(size_t)i]));
+  const size_t longest = read_totals();
+  if (cap_known == 0 || longest > cap_known) {
+    entries = longest;
+    rc = exchange(longest);
+    if (rc != RGBDFE_OK) return rc;
   }
+  *stride_bytes = (int64_t)(hdr_bytes + entries * 4);
+  g.inl_cap_entries = std::max(g.inl_cap_entries, longest + longest / 4 + 64);
   return RGBDFE_OK;
 }
 

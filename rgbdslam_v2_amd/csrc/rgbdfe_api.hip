@@ -54,6 +54,12 @@ const char* rgbdfe_gather_transport(rgbdfe_ctx* ctx) {
   return buf.c_str();
 }
 
+int rgbdfe_gather_exchanges(rgbdfe_ctx* ctx) {
+  if (!ctx || !ctx->group) return 0;
+  std::lock_guard<std::recursive_mutex> call_lock(ctx->group->mu);
+  return ctx->group->inl_exchanges;
+}
+
 int rgbdfe_set_params(rgbdfe_ctx* ctx, const rgbdfe_params* p) {
   if (!ctx) return RGBDFE_ERR_INVALID_ARG;
   if (RGBDFE_IS_GROUP(ctx) && p) {

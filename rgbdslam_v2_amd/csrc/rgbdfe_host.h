@@ -473,6 +473,10 @@ struct Group {
   std::vector<int32_t*> edge_cnt_host;  // pinned
   std::vector<char*> inl_stream;        // inlier gather: per device the shard's inlier stream (rgbdfe_inlier_header), worst case
   int32_t edge_cap = 0;                 // records per device the scratch holds
+  // inlier gather: entries of a device's list block the exchange is sized for BEFORE the devices have counted their lists
+  // (the longest list of the earlier calls + a quarter; 0: nothing seen yet), and how many exchanges the latest call issued
+  size_t inl_cap_entries = 0;
+  int inl_exchanges = 0;
   double last_submit_us = 0.0;          // host time the calling thread spent enqueueing the latest sharded batch on all devices
   // One call at a time on a group handle (rgbdfe.h: calls on one context serialise): covers the workers' job slots and
   // transport / rccl_* / edge_* above.  Recursive: the gather entry points hold it around their group_run.

@@ -93,6 +93,40 @@ def gather_inlier_streams(local_stream, local_total: int, n_pad: int, group=None
     return out.reshape(world, nbytes), totals
 
 
+def inlier_stream_totals(gathered, n_pad: int):
+    """Lengths of the list blocks of gathered inlier streams ([world, bytes] uint8 tensor), read from the streams themselves: a
+    stream's last header holds first_inlier + n_inl = the length of its list block (padding headers carry first_inlier = the
+    length and n_inl = 0).  An int32 tensor [world] on the streams' device -- no host read."""
+    import torch
+    hb = INLIER_HEADER_DTYPE.itemsize
+    w32 = gathered.reshape(gathered.shape[0], -1).view(torch.int32)
+    last = (n_pad - 1) * hb // 4
+    return w32[:, last + INLIER_HEADER_DTYPE.fields["first_inlier"][1] // 4] + w32[:, last + INLIER_HEADER_DTYPE.fields["n_inl"][1] // 4]
+
+
+def gather_inlier_streams_sized(local_stream, n_pad: int, cap_entries: int, group=None):
+    """The inlier-stream gather as ONE collective sized before the ranks have counted their lists: every rank sends n_pad
+    headers + cap_entries list entries (cap_entries: agreed beforehand, e.g. the longest list of an earlier gather plus a
+    quarter -- bench.py).  The lengths travel inside the streams (inlier_stream_totals), so the receiver needs no second
+    collective and the sender no host read.  Returns (gathered [world, n_pad * 104 + 4 * cap_entries], the totals as a
+    device tensor [world]); a total above cap_entries means that rank's list was cut: gather again with a larger capacity
+    (every rank sees the same totals and decides alike)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = local_stream.device
+    nbytes = n_pad * INLIER_HEADER_DTYPE.itemsize + 4 * int(cap_entries)
+    flat = local_stream.reshape(-1)
+    if flat.numel() < nbytes:
+        pad = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        pad[: flat.numel()] = flat
+        flat = pad
+    out = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, flat[:nbytes], group=group)
+    out = out.reshape(world, nbytes)
+    return out, inlier_stream_totals(out, n_pad)
+
+
 def unshard_inlier_streams(gathered: np.ndarray, totals, n_pairs: int, world: int):
     """gathered [world, bytes] (numpy uint8) -> (headers in global pair order [n_pairs], list of (query rows, train rows) per
     pair): what updateInlierFeatures (graph_manager.cpp:409-419) reads, for every pair of the global list."""

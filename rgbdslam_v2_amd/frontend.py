@@ -134,6 +134,10 @@ class FrontEnd:
     def gather_transport(self) -> str:
         return self._L.rgbdfe_gather_transport(self._ctx).decode()
 
+    def gather_exchanges(self) -> int:
+        """Exchanges the latest match_pair_list_allgather_inliers issued (1: one collective, no host read in front of it)."""
+        return int(self._L.rgbdfe_gather_exchanges(self._ctx))
+
     def match_pair_list_allgather(self, query_ids, train_ids, d_out_ptrs: Sequence[int]) -> int:
         """All results on every device (ncclAllGather / peer copies).  d_out_ptrs: one device buffer per device,
         each device_count * ceil(n / device_count) records.  Returns records per device."""

@@ -67,7 +67,7 @@ def _worker(rank, world, port, n_pairs, q):
     idx, edges = rdist.all_gather_edges(full[rank::world], n_pairs)
     want = np.flatnonzero(~rej)
     ok = ok and np.array_equal(idx, want) and edges.tobytes() == full[want].tobytes()
-    # the inlier form (bench.py's default payload): headers + (query row, train row) of every inlier, two collectives
+    # the inlier form (bench.py's default payload): headers + (query row, train row) of every inlier
     hdr, pairs = rdist.all_gather_inliers(local, n_pairs)
     want_all = _fake_records(pq, pt)
     for f in INLIER_HEADER_DTYPE.names:
@@ -76,6 +76,20 @@ def _worker(rank, world, port, n_pairs, q):
     for k in range(n_pairs):
         a, b = _inliers_of(want_all[k])
         ok = ok and np.array_equal(pairs[k][0], a) and np.array_equal(pairs[k][1], b)
+    # the same gather as ONE collective sized in advance: the lengths are read from the gathered streams' own headers
+    import torch
+    n_pad = max(rdist.shard_sizes(n_pairs, world))
+    h_loc, l_loc = inlier_stream_of(local, n_pad)
+    buf = torch.from_numpy(np.concatenate([h_loc.view(np.uint8).reshape(-1), l_loc.view(np.uint8).reshape(-1)]).copy())
+    g2, tot2 = rdist.gather_inlier_streams(buf, len(l_loc), n_pad)                    # (the two-collective form: exact size)
+    g1, tot1 = rdist.gather_inlier_streams_sized(buf, n_pad, max(tot2) + max(tot2) // 4 + 64)
+    ok = ok and tot1.tolist() == tot2 and g1.shape[1] > g2.shape[1]
+    h1, p1 = rdist.unshard_inlier_streams(g1.numpy(), tot1.tolist(), n_pairs, world)
+    ok = ok and h1.tobytes() == hdr.tobytes() and all(np.array_equal(p1[k][0], pairs[k][0]) and
+                                                     np.array_equal(p1[k][1], pairs[k][1]) for k in range(n_pairs))
+    # a capacity that is too small: the headers still arrive whole, the totals say which lists were cut
+    g0, tot0 = rdist.gather_inlier_streams_sized(buf, n_pad, 3)
+    ok = ok and tot0.tolist() == tot2 and min(tot2) > 3 and g0.shape[1] == n_pad * INLIER_HEADER_DTYPE.itemsize + 12
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

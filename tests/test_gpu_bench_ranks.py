@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_two_ranks(extra):
+def _run_two_ranks(extra, **more_env):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, RGBDFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, RGBDFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **more_env)
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra,
@@ -57,10 +57,21 @@ def test_bench_two_ranks_full_workload_is_checked_against_the_oracle(gather):
     assert d["gather"]["payload_option"] == gather
 
 
+def test_inlier_lists_that_outgrow_the_collective_are_gathered_again():
+    """The inlier gather is ONE collective sized before the ranks have counted their lists; a capacity that turns out too small
+    (forced here: 1000 entries per rank against ~10^5) is noticed on every rank from the gathered headers and that step's
+    gather is repeated at a size that fits -- the records rank 0 ends up with are the oracle's."""
+    d = _run_two_ranks(["--steps", "3", "--warmup", "1", "--gather", "inliers"], RGBDFE_BENCH_INLIER_CAP="1000")
+    pc, ig = d["parity_check"], d["gather"]["inlier_gather"]
+    assert pc["checked"] and pc["ok"] and pc["inlier_list_entries"] == pc["oracle_aggregates"]["inliers"]
+    assert ig["regathers"] >= 1 and ig["list_capacity_entries"] > 1000
+    assert ig["collectives_issued"] == ig["gathers_issued"] + ig["regathers"]     # no exchange of lengths anywhere
+
+
 @pytest.mark.parametrize("gather", ["inliers", "compact", "full"])
 def test_bench_gather_path_over_rccl_with_one_rank(gather):
     """The RCCL branch of the N > 1 code (nccl process group, pack kernels on torch's stream, ncclAllGather of device
-    buffers -- two collectives for the inlier payload --, the parity check on the gathered records) cannot run with two
+    buffers -- one collective per step for every payload --, the parity check on the gathered records) cannot run with two
     ranks on a one-GPU box; RGBDFE_BENCH_FORCE_GATHER=1 runs it with ONE rank under torch.distributed.run."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -81,7 +92,10 @@ def test_bench_gather_path_over_rccl_with_one_rank(gather):
     assert pc["checked"] and pc["ok"] and "4000 records of 1 ranks" in pc["records"]
     if gather == "inliers":
         assert pc["inlier_list_entries"] == pc["oracle_aggregates"]["inliers"]
-        assert d["gather"]["collectives_per_step"] == 2 and 200 < d["gather"]["bytes_per_record"] < 400
+        assert d["gather"]["collectives_per_step"] == 1 and 200 < d["gather"]["bytes_per_record"] < 400
+        ig = d["gather"]["inlier_gather"]    # one collective per gather; the first (warm-up) one exchanged the lengths before it
+        assert ig["collectives_issued"] == ig["gathers_issued"] + 1 and ig["regathers"] == 0
+        assert pc["inlier_list_entries"] < ig["list_capacity_entries"] <= pc["inlier_list_entries"] * 5 // 4 + 64
 
 
 def test_bench_gpus_2_starts_its_own_ranks():

@@ -394,8 +394,17 @@ def test_allgather_of_the_inlier_form(data, ids):
     cap = G * per * (INLIER_HEADER_DTYPE.itemsize + 4 * 320)
     bufs = [torch.full((cap,), 0xCD, dtype=torch.uint8, device="cuda:0") for _ in ids]
     torch.cuda.synchronize()
+    # The group's first call sizes the exchange after reading the counts (stride = the longest list exactly); from then on
+    # the exchange is sized BEFORE the counts are known -- the longest list seen + a quarter -- and is the call's only one.
+    first = grp.match_pair_list_allgather_inliers(pq, pt, [b.data_ptr() for b in bufs])
+    assert first[0] == per and first[2] == per * 104 + 4 * int(first[1].max()) and grp.gather_exchanges() == 1
+    for b in bufs:
+        b.fill_(0xCD)
+    torch.cuda.synchronize()
     got_per, totals, stride = grp.match_pair_list_allgather_inliers(pq, pt, [b.data_ptr() for b in bufs])
-    assert got_per == per and stride == per * 104 + 4 * int(totals.max())
+    longest = int(totals.max())
+    assert got_per == per and np.array_equal(totals, first[1]) and grp.gather_exchanges() == 1
+    assert stride == per * 104 + 4 * min(longest + longest // 4 + 64, per * 320)
     assert int(totals.sum()) == int(ref["n_inl"].sum()) > 20 * n // 2
     for b in bufs:
         raw = b.cpu().numpy()
@@ -413,11 +422,24 @@ def test_allgather_of_the_inlier_form(data, ids):
             assert hdr["id1"][j] == ref[k]["id1"] and np.array_equal(hdr["trafo"][j], ref[k]["trafo"])
     # a list shorter than the device count, and an empty one
     p1, t1, s1 = grp.match_pair_list_allgather_inliers(pq[:1], pt[:1], [b.data_ptr() for b in bufs])
-    assert p1 == 1 and int(t1.sum()) == int(ref["n_inl"][0]) and s1 == 104 + 4 * int(t1.max())
+    assert p1 == 1 and int(t1.sum()) == int(ref["n_inl"][0]) and s1 == 104 + 4 * 320   # (the known capacity, cut to the worst case)
+    assert grp.gather_exchanges() == 1
     p0, t0, s0 = grp.match_pair_list_allgather_inliers(pq[:0], pt[:0], [b.data_ptr() for b in bufs])
     assert p0 == 0 and s0 == 0
     one = _fe(seq)
     with pytest.raises(RgbdfeError):
         one.match_pair_list_allgather_inliers(pq, pt, [bufs[0].data_ptr()])       # needs a multi-device handle
     one.close()
+    grp.close()
+    # lists that outgrow what the group has seen: the exchange sized from the one-pair call is too small for the whole list --
+    # a second exchange at the exact size, the same streams
+    grp = _fe(seq, device_ids=ids)
+    grp.match_pair_list_allgather_inliers(pq[:1], pt[:1], [b.data_ptr() for b in bufs])
+    _, totals2, stride2 = grp.match_pair_list_allgather_inliers(pq, pt, [b.data_ptr() for b in bufs])
+    assert grp.gather_exchanges() == 2 and np.array_equal(totals2, totals) and stride2 == per * 104 + 4 * int(totals.max())
+    raw = bufs[-1].cpu().numpy()
+    for d in range(G):
+        hdr_want, lst_want = inlier_stream_of(ref[d::G], per)
+        hdr, lst = parse_inlier_stream(raw[d * stride2:(d + 1) * stride2], per, int(totals2[d]))
+        assert hdr.tobytes() == hdr_want.tobytes() and np.array_equal(lst, lst_want), d
     grp.close()
