@@ -637,13 +637,16 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   if (const char* e = getenv("RGBDFE_SUPER_DEPTH")) D = std::min(std::max(atoi(e), 2), (int)OrbWorkspace::kSets);
   auto first_of = [&](int s) { return s * B; };
   auto count_of = [&](int s) { return std::min(B, n_frames - s * B); };
-  // helper thread: the caller's pageable images of super-frame s -> pinned staging buffer s % (D + 1), as soon as super-frame
-  // s - (D + 1) (the buffer's previous user) has been detected (its upload from that buffer is complete then)
+  // helper thread: the caller's pageable images of super-frame s -> pinned staging buffer s % NS, as soon as super-frame
+  // s - NS (the buffer's previous user) has been detected (its upload from that buffer is complete then)
+  const int NS = std::max(D + 1, std::min((int)OrbWorkspace::kStages,
+                                          getenv("RGBDFE_SUPER_STAGES") ? atoi(getenv("RGBDFE_SUPER_STAGES")) : (int)OrbWorkspace::kStages));
   std::mutex m;
   std::condition_variable cv;
   int staged = 0, detected = 0;
   bool stop = false;
-  if (!ctx->stage_pool) ctx->stage_pool.reset(new TaskPool(4));
+  static const int stage_threads = getenv("RGBDFE_STAGE_THREADS") ? std::max(1, atoi(getenv("RGBDFE_STAGE_THREADS"))) : 4;
+  if (!ctx->stage_pool) ctx->stage_pool.reset(new TaskPool(stage_threads));
   // (the frames' CPU halves: a worker per frame up to RGBDFE_DETECT_WORKERS workers, the frames queue behind them)
   static const int max_workers = getenv("RGBDFE_DETECT_WORKERS") ? std::max(1, atoi(getenv("RGBDFE_DETECT_WORKERS"))) : 12;   // (7 / 8 / 10 / 12 / 14 workers: 14.4 / 14.2 / 15.7 / 16.4 / 15.4 k frames/s in one call)
   const int n_workers = std::min(B, max_workers);
@@ -655,13 +658,13 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     for (int s = 0; s < S; ++s) {
       {
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return stop || detected >= s - D; });
+        cv.wait(l, [&] { return stop || detected >= s - NS + 1; });
         if (stop) return;
       }
       // (2 W H bytes per frame through one core's memcpy would bound the whole pipeline: 75 us per 640 x 480 frame)
       for (int k = 0; k < count_of(s); ++k) {
         const int f = first_of(s) + k;
-        stage_pool.submit([&orb, &gray, &mask, f, s, k, D] { orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s % (D + 1), k); });
+        stage_pool.submit([&orb, &gray, &mask, f, s, k, NS] { orb.stage_image_at(gray[f], mask ? mask[f] : nullptr, s % NS, k); });
       }
       stage_pool.wait_all();
       std::lock_guard<std::mutex> l(m);
@@ -697,7 +700,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
       cv.wait(l, [&] { return staged > s; });
     }
     if (s >= D && hipStreamWaitEvent(up, ctx->orb_describe_done[s % D], 0) != hipSuccess) { err = "hipStreamWaitEvent"; return RGBDFE_ERR_HIP; }
-    const int r = orb.enqueue_staged_super(count_of(s), up, err, s % D, s % (D + 1));
+    const int r = orb.enqueue_staged_super(count_of(s), up, err, s % D, s % NS);
     if (r != RGBDFE_OK) return r;
     if (hipEventRecord(ctx->orb_upload_done[s % D], up) != hipSuccess) { err = "hipEventRecord"; return RGBDFE_ERR_HIP; }
     return RGBDFE_OK;
@@ -810,6 +813,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
     rc = enqueue_upload(s);
     if (rc == RGBDFE_OK) rc = pass_enqueue(s);
   }
+  lap(6);
   for (int s = 0; s < S && rc == RGBDFE_OK; ++s) {
     const int nf = count_of(s);
     if (tm) tq = orb_now_us();
@@ -869,11 +873,15 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
             orb.timing.us[3] / n_frames, orb.timing.us[4] / n_frames, t_us[4] / n_frames, t_us[5] / n_frames);
     for (double& u : orb.timing.us) u = 0;
     orb.timing.frames = 0; orb.timing.passes = 0;
+    tq = orb_now_us();
   }
   if (rc == RGBDFE_OK) rc = enqueue_describe(S - 1);
   if (rc == RGBDFE_OK) rc = finish(S - 1);
   pool.wait_all();
   (void)hipStreamSynchronize(st2);
+  lap(7);
+  if (tm) fprintf(stderr, "[rgbdfe super-frame timing] whole call (us): filling the pipeline (staging + upload + pass enqueue of the first "
+                          "%d super-frames) %.0f, draining it (the last super-frame's description) %.0f\n", D - 1, t_us[6], t_us[7]);
   {
     std::lock_guard<std::mutex> l(m);
     stop = true;

@@ -68,7 +68,12 @@ struct OrbWorkspace {
   hipEvent_t ev_pass[kSets] = {};
   int slot_bound[kSets] = {};
   std::vector<int> slot_floor[kSets];
-  uint8_t* himg_stage[kSets + 1] = {};  // super-frame staging (pinned), one deeper than the image sets
+  // super-frame staging (pinned): a ring deeper than the image sets, so that the helper thread's copies of the caller's
+  // pageable images run several super-frames ahead of the uploads (with kSets + 1 buffers the copy of super-frame s + 2 could
+  // only start once s - 1 had been replayed and was waited for right behind that: 0 - 60 us per frame, depending on where the
+  // copy threads ran)
+  static constexpr int kStages = kSets + 3;
+  uint8_t* himg_stage[kStages] = {};
   // optional: runs fn(0) .. fn(n - 1) on several threads and returns when all are done (the batch entry point's worker
   // pool); the replay then runs the per-cell adjuster chains and the per-frame merges through it -- pure host code
   std::function<void(int, const std::function<void(int)>&)> parallel_for;

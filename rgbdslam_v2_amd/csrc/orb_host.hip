@@ -147,7 +147,7 @@ void OrbWorkspace::release() {
   }
   d_passout_slot[0] = nullptr; h_passout_slot[0] = nullptr; h_base_slot[0] = nullptr;
   for (int i = 0; i < kSets; ++i) if (ev_pass[i]) { (void)hipEventDestroy(ev_pass[i]); ev_pass[i] = nullptr; }
-  for (int i = 0; i < kSets + 1; ++i) if (himg_stage[i]) { (void)hipHostFree(himg_stage[i]); himg_stage[i] = nullptr; }
+  for (int i = 0; i < kStages; ++i) if (himg_stage[i]) { (void)hipHostFree(himg_stage[i]); himg_stage[i] = nullptr; }
   auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   // d_pool / d_blur / h_img alias one of the sets
   for (int i = 0; i < kSets; ++i) { fr(pool_set[i]); fr(blur_set[i]); }
@@ -333,7 +333,7 @@ int OrbWorkspace::prepare(int cols, int rows, bool use_grid, std::string& err, i
       ORB_HIP(hipHostMalloc((void**)&h_base_slot[i], sizeof(int) * cell_imgs.size(), hipHostMallocDefault));
     }
     for (int i = 0; i < kSets; ++i) ORB_HIP(hipEventCreateWithFlags(&ev_pass[i], hipEventDisableTiming));
-    for (int i = 0; i < kSets + 1; ++i)
+    for (int i = 0; i < kStages; ++i)
       ORB_HIP(hipHostMalloc((void**)&himg_stage[i], (size_t)2 * W * H * n_frames, hipHostMallocDefault));
   }
   ORB_HIP(hipHostMalloc((void**)&h_desckp, sizeof(DescKp) * (size_t)pin_cap, hipHostMallocDefault));
@@ -806,10 +806,16 @@ int OrbWorkspace::super_pass_enqueue(int nf, int set, int slot, hipStream_t s, s
                       d_row_off, img_total, d_keep, s);
   const int bound = std::min(raw_cap, std::max(2048 * frames, 2 * last_n_total));
   slot_bound[slot] = bound;
+  // the read-back: written by the measure kernel itself into the slot's page-locked buffer (RGBDFE_DETECT_HOSTWRITE=0: a copy
+  // of the counts and `bound` records behind the kernels, the form of rounds 2-5)
+  static const bool host_write = !(getenv("RGBDFE_DETECT_HOSTWRITE") && atoi(getenv("RGBDFE_DETECT_HOSTWRITE")) == 0);
+  uint8_t* const hpo = h_passout_slot[slot];
   launch_orb_emit(pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_off,
-                  img_total, kps, bound, s);
+                  img_total, kps, bound, s, host_write ? reinterpret_cast<int*>(hpo) : nullptr,
+                  host_write ? reinterpret_cast<RawKp*>(hpo + passout_hdr) : nullptr);
   ORB_HIP(hipGetLastError());
-  ORB_HIP(hipMemcpyAsync(h_passout_slot[slot], dpo, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
+  if (!host_write)
+    ORB_HIP(hipMemcpyAsync(hpo, dpo, passout_hdr + sizeof(RawKp) * (size_t)bound, hipMemcpyDeviceToHost, s));
   ORB_HIP(hipEventRecord(ev_pass[slot], s));
   super_passes++;
   return RGBDFE_OK;

@@ -113,7 +113,8 @@ void launch_orb_fast_nms(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, c
 // img_total[n_imgs] (the per-image counts) doubles as the source of every prefix the later kernels need: no scan launch
 void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
                      const OrbCtl& ctl, const uint8_t* score_pool, const uint64_t* keep_mask, const int* row_off,
-                     const int* img_total, RawKp* out, int measure_bound, hipStream_t s);
+                     const int* img_total, RawKp* out, int measure_bound, hipStream_t s, int* host_totals = nullptr,
+                     RawKp* host_kps = nullptr);   // (page-locked host memory: the measure kernel writes the read-back itself)
 void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* img_total, int n_imgs,
                              int first, int count, hipStream_t s);
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,

@@ -484,13 +484,20 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // first..first+grid keypoints.  The 31 x 31 patch around the keypoint (it lies >= 31 pixels inside the image: runByImageBorder)
 // goes through LDS -- four unaligned dword loads per lane instead of 23 dependent byte gathers -- and both measurements read it
 // from there.
+// host_totals / host_kps (may be nullptr): the pass's read-back buffer in page-locked HOST memory -- [per-image counts + their
+// sum | keypoints] -- written by this kernel itself: every wave stores its finished 16-byte record there as well, the first
+// workgroup copies the counts.  Posted writes over PCIe that ride along with the kernel; the detection pass needs no copy
+// (a 50-100 us blit kernel on the pass's stream at 14 frames of 640x480) behind it.
 __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restrict__ pool,
                                                           const ImgDesc* __restrict__ imgs,
                                                           RawKp* __restrict__ kps, const int* __restrict__ img_total,
-                                                          int n_imgs, int first) {
+                                                          int n_imgs, int first, int* __restrict__ host_totals,
+                                                          RawKp* __restrict__ host_kps) {
   __shared__ __attribute__((aligned(4))) uint8_t patch_all[4][31 * 32];
   const int k = first + blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  if (host_totals != nullptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i <= n_imgs; i += 256) host_totals[i] = img_total[i];
   // how many keypoints there are (the host has not seen the counts yet): the scan left the sum behind the per-image counts
   const int n_total = img_total[n_imgs];
   if (k >= n_total) return;
@@ -540,6 +547,7 @@ __global__ __launch_bounds__(256) void orb_measure_kernel(const uint8_t* __restr
     kp.harris = harris;
     kp.angle = fast_atan2_deg((float)m01, (float)m10);
     kps[k] = kp;
+    if (host_kps != nullptr) host_kps[k] = kp;
   }
 }
 
@@ -779,18 +787,18 @@ void launch_orb_fast_nms(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, c
 // keypoints than the bound gets the rest measured by launch_orb_measure_rest).
 void launch_orb_emit(const uint8_t* pool, const ImgDesc* imgs, int n_imgs, const TileUnit* rows, int n_rows,
                      const OrbCtl& ctl, const uint8_t* score_pool, const uint64_t* keep_mask, const int* row_off,
-                     const int* img_total, RawKp* out, int measure_bound, hipStream_t s) {
+                     const int* img_total, RawKp* out, int measure_bound, hipStream_t s, int* host_totals, RawKp* host_kps) {
   hipLaunchKernelGGL(orb_emit_kernel, dim3(n_rows), dim3(64), 0, s, imgs, ctl, score_pool, keep_mask, row_off, img_total,
                      out, rows);
   if (measure_bound > 0)
     hipLaunchKernelGGL(orb_measure_kernel, dim3((measure_bound + 3) / 4), dim3(256), 0, s, pool, imgs, out, img_total,
-                       n_imgs, 0);
+                       n_imgs, 0, host_totals, host_kps);
 }
 void launch_orb_measure_rest(const uint8_t* pool, const ImgDesc* imgs, RawKp* out, const int* img_total, int n_imgs,
                              int first, int count, hipStream_t s) {
   if (count > 0)
     hipLaunchKernelGGL(orb_measure_kernel, dim3((count + 3) / 4), dim3(256), 0, s, pool, imgs, out, img_total, n_imgs,
-                       first);
+                       first, (int*)nullptr, (RawKp*)nullptr);
 }
 // (no blurred pyramid with RGBDFE_ORB_BRIEF=patch: that descriptor kernel blurs what it reads)
 void launch_orb_blur(const uint8_t* pool, const ImgDesc* imgs, const TileUnit* units, int n_units, uint8_t* blur_pool,

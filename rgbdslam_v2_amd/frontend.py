@@ -9,6 +9,7 @@ This module keeps those names and argument meanings so the parity tests read
 like tests of the reference; all arithmetic happens in librgbdfe.so on the GPU.
 """
 import ctypes as C
+import threading
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -81,6 +82,7 @@ class FrontEnd:
         """device_ids: several GPUs behind this one handle (rgbdfe_create_multi): node features replicated,
         pairs sharded pair k -> device k mod G, results gathered; a device may be listed twice."""
         self._L = _lib.load()
+        self._batch_lock = threading.Lock()
         cfg = RgbdfeConfig()
         self._L.rgbdfe_default_config(C.byref(cfg))
         cfg.device_id = device_id
@@ -400,26 +402,34 @@ class FrontEnd:
             if a.shape != (rows, cols):
                 raise ValueError("all frames of a batch share one size")
         cap = getattr(self, "_max_keypoints", 600)
-        kp = np.zeros((n, cap), _lib.KEYPOINT_DTYPE)
-        desc = np.zeros((n, cap, 32), np.uint8)
-        xyz = np.zeros((n, cap, 4), np.float32)
-        cnt = np.zeros(n, np.int32)
-        vp = C.c_void_p * n
-        pg = vp(*[x.ctypes.data for x in g])
-        pd = vp(*[x.ctypes.data for x in d])
-        pm = vp(*[None if x is None else x.ctypes.data for x in m])
-        if node_ids is not None:
-            ids = np.ascontiguousarray(node_ids, np.int32)
-            if ids.shape != (n,):
-                raise ValueError("node_ids must hold one id per frame")
-            self._check(self._L.rgbdfe_detect_describe_batch_nodes(
-                self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
-                depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data, ids.ctypes.data))
-        else:
-            self._check(self._L.rgbdfe_detect_describe_batch(
-                self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
-                depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data))
-        return [(kp[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy(), xyz[f, : cnt[f]].copy()) for f in range(n)]
+        # the ABI's output arrays (n * cap rows each: 8.7 MB for 112 frames of 1024) are scratch of this object, kept between
+        # calls of the same shape: fresh np.zeros arrays of that size are fresh mmap'ed pages every call, i.e. ~2000 page
+        # faults inside the library's result copies (10 us per frame of a 640 x 480 run); what is returned are copies of the
+        # rows in use
+        with self._batch_lock:   # (the scratch is one per object)
+            key = (n, cap)
+            if getattr(self, "_batch_out_key", None) != key:
+                self._batch_out = (np.zeros((n, cap), _lib.KEYPOINT_DTYPE), np.zeros((n, cap, 32), np.uint8),
+                                   np.zeros((n, cap, 4), np.float32), np.zeros(n, np.int32))
+                self._batch_out_key = key
+            kp, desc, xyz, cnt = self._batch_out
+            cnt[:] = 0
+            vp = C.c_void_p * n
+            pg = vp(*[x.ctypes.data for x in g])
+            pd = vp(*[x.ctypes.data for x in d])
+            pm = vp(*[None if x is None else x.ctypes.data for x in m])
+            if node_ids is not None:
+                ids = np.ascontiguousarray(node_ids, np.int32)
+                if ids.shape != (n,):
+                    raise ValueError("node_ids must hold one id per frame")
+                self._check(self._L.rgbdfe_detect_describe_batch_nodes(
+                    self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
+                    depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data, ids.ctypes.data))
+            else:
+                self._check(self._L.rgbdfe_detect_describe_batch(
+                    self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
+                    depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data))
+            return [(kp[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy(), xyz[f, : cnt[f]].copy()) for f in range(n)]
 
     def orb_detect(self, gray, mask, fast_threshold, capacity=60000):
         """cv::ORB::create(10000,1.2,8,15,0,2,HARRIS,31,thr)->detect(gray, kps, mask) (feature_adjuster.cpp:94)."""
