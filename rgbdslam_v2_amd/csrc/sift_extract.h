@@ -92,6 +92,10 @@ struct SiftExtractor {
   float* h_desc = nullptr; size_t h_desc_cap = 0;      // pinned: the descriptors of the latest call (128 floats per feature)
   int* h_counts = nullptr;                             // pinned: per-level totals, 64 per frame
   float* h_stage = nullptr; size_t stage_floats = 0;   // pinned staging for lists (all frames of a batch)
+  // The three read-backs of a batch -- the levels' candidate counts, the oriented features, the descriptors -- are stored into
+  // the pinned buffers by the kernels that produce them (posted PCIe writes beside the kernel) instead of being copied behind
+  // them (a blit kernel each on the batch's stream: 16 % of a chunk's kernel time).  RGBDFE_SIFT_HOSTWRITE=0: the copies.
+  bool host_write = true;
   uint8_t* h_gray = nullptr; size_t gray_cap = 0;      // pinned staging of the caller's (pageable) images
   void* d_key_tiles = nullptr; int n_key_tiles = 0;    // the (octave, x0, y0) tiles of the extremum launch
   void* d_jobs = nullptr; void* h_jobs = nullptr;      // the per-frame segment tables of the orientation / descriptor launches

@@ -348,6 +348,8 @@ void SiftExtractor::release() {
 // thread of the process has a stream capture open, e.g. another context recording its own launch chain:
 // tests/test_gpu_sift_threads.py)
 int SiftExtractor::prepare(int rows, int cols, int nf, hipStream_t s, std::string& err) {
+  static const bool host_write_env = !(getenv("RGBDFE_SIFT_HOSTWRITE") && atoi(getenv("RGBDFE_SIFT_HOSTWRITE")) == 0);
+  host_write = host_write_env;
   init_params();
   if (rows == H && cols == W && d_planes && nf <= frames_cap) return RGBDFE_OK;
   if (rows == H && cols == W && nf < frames_cap) nf = frames_cap;
@@ -473,7 +475,7 @@ int SiftExtractor::enqueue_begin(int nf, hipStream_t s, std::string& err) {
   launch_key_flags(*this, nf, st, s);
   launch_key_lists(*this, nf, st, s);
   SIFT_HIP(hipGetLastError());
-  SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * 64 * (size_t)nf, hipMemcpyDeviceToHost, s));
+  if (!host_write) SIFT_HIP(hipMemcpyAsync(h_counts, d_lvltot, sizeof(int) * 64 * (size_t)nf, hipMemcpyDeviceToHost, s));
   return RGBDFE_OK;
 }
 
@@ -556,10 +558,10 @@ int SiftExtractor::finish_orientations(int max_features_in, hipStream_t s, std::
   if ((size_t)grand * 4 > stage_floats) { err = "SIFT staging buffer too small"; return RGBDFE_ERR_CAPACITY; }
   const float sigma_step = powf(2.0f, 1.0f / kDogLevels);
   SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_orientation_kernel, dim3(max_total, NF), dim3(64), 0, s, static_cast<const LevelJobs*>(d_jobs), d_cand, d_feat,
-                     sigma_step, 1.5f, 1.5f * 2.0f);
+  hipLaunchKernelGGL(sift_orientation_kernel, dim3(max_total, NF), dim3(64), 0, s, static_cast<const LevelJobs*>(d_jobs), d_cand,
+                     host_write ? reinterpret_cast<float4*>(h_stage) : d_feat, sigma_step, 1.5f, 1.5f * 2.0f);
   SIFT_HIP(hipGetLastError());
-  SIFT_HIP(hipMemcpyAsync(h_stage, d_feat, (size_t)grand * 16, hipMemcpyDeviceToHost, s));
+  if (!host_write) SIFT_HIP(hipMemcpyAsync(h_stage, d_feat, (size_t)grand * 16, hipMemcpyDeviceToHost, s));
   fin_grand = grand;
   return RGBDFE_OK;
 }
@@ -660,16 +662,16 @@ int SiftExtractor::finish_descriptors(hipStream_t s, std::string& err) {
   }
   SIFT_HIP(hipMemcpyAsync(d_feat, h_stage, (size_t)grand2 * 16, hipMemcpyHostToDevice, s));
   SIFT_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(LevelJobs) * (size_t)nf, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(max_total2, NF), dim3(64), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
-                     (float2*)d_desc, 3.0f);
-  SIFT_HIP(hipGetLastError());
   if ((size_t)grand2 * 128 > h_desc_cap) {
     if (h_desc) (void)hipHostFree(h_desc);
     h_desc = nullptr; h_desc_cap = 0;
     SIFT_HIP(hipHostMalloc((void**)&h_desc, (size_t)grand2 * 128 * 4 * 2, hipHostMallocDefault));
     h_desc_cap = (size_t)grand2 * 128 * 2;
   }
-  SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)grand2 * 128 * 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(sift_descriptor_kernel, dim3(max_total2, NF), dim3(64), 0, s, static_cast<const LevelJobs*>(d_jobs), d_feat,
+                     (float2*)(host_write ? h_desc : d_desc), 3.0f);
+  SIFT_HIP(hipGetLastError());
+  if (!host_write) SIFT_HIP(hipMemcpyAsync(h_desc, d_desc, (size_t)grand2 * 128 * 4, hipMemcpyDeviceToHost, s));
   fin_grand2 = grand2;
   return RGBDFE_OK;
 }

@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void sift_key_flag_kernel(const float* __restr
 // per level: exclusive scan of its rows' counts, the level's total
 __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::LevelDesc* __restrict__ levels,
                                                            const int* __restrict__ rowcnt, int* __restrict__ rowoff,
-                                                           int* __restrict__ lvltot, FrameStrides st) {
+                                                           int* __restrict__ lvltot, FrameStrides st,
+                                                           int* __restrict__ host_lvltot) {   // (pinned host copy of lvltot, or nullptr)
   const SiftExtractor::LevelDesc L = levels[blockIdx.x];
   rowcnt += (size_t)blockIdx.y * st.rows;
   rowoff += (size_t)blockIdx.y * st.rows;
@@ -514,7 +515,10 @@ __global__ __launch_bounds__(64) void sift_row_scan_kernel(const SiftExtractor::
     if (r < L.h) rowoff[L.row0 + r] = base + incl - c;
     base += __shfl(incl, 63);
   }
-  if (threadIdx.x == 0) lvltot[blockIdx.x] = base;
+  if (threadIdx.x == 0) {
+    lvltot[blockIdx.x] = base;
+    if (host_lvltot != nullptr) host_lvltot[(size_t)blockIdx.y * st.lvltot + blockIdx.x] = base;
+  }
 }
 
 // one wave per row: the row's extrema in column order -> the level's candidate list (x, y, sign, dx, dy, ds).  A lane takes
@@ -658,7 +662,7 @@ inline void launch_key_lists(const SiftExtractor& E, int nf, const FrameStrides&
   const int nlv = E.octave_num * SiftExtractor::kDogLevels;
   const int* d_row2lvl = E.d_rowcnt + (size_t)E.total_rows * 2 * E.frames_cap;
   hipLaunchKernelGGL(sift_row_scan_kernel, dim3((unsigned)nlv, (unsigned)nf), dim3(64), 0, s, E.d_levels, E.d_rowcnt, E.d_rowoff,
-                     E.d_lvltot, st);
+                     E.d_lvltot, st, E.host_write ? E.h_counts : (int*)nullptr);
   hipLaunchKernelGGL(sift_key_emit_kernel, dim3((unsigned)E.total_rows, (unsigned)nf), dim3(64), 0, s, E.d_levels, d_row2lvl,
                      E.d_rowcnt, E.d_rowoff, E.d_lvltot, E.d_cand, (int)E.cand_cap, tdog1, tdog, tedge, st);
 }
