@@ -1233,11 +1233,11 @@ def detect_subrecord(device):
             tot += len(kp)
         dt = (time.perf_counter() - t0) / n_base
         for _ in range(2):                      # the first calls of a run length pay page faults and thread wake-ups
-            fe.detect_describe_batch(grays, mks, depths, *K)
+            fe.detect_describe_batch(grays, mks, depths, *K, copy=False)
         per_frame = []
         for _ in range(REPEATS + 2):
             t0 = time.perf_counter()
-            fe.detect_describe_batch(grays, mks, depths, *K)
+            fe.detect_describe_batch(grays, mks, depths, *K, copy=False)   # output arrays reused, as an integration's buffers are
             per_frame.append((time.perf_counter() - t0) / n_run)
         per_frame.sort()
         dt_batch = per_frame[len(per_frame) // 2]
@@ -1261,7 +1261,8 @@ def detect_subrecord(device):
             "batch_api": {"value": round(1.0 / dt_batch, 2), "unit": "frames/s",
                           "ms_per_frame": round(dt_batch * 1e3, 4), "frames_per_call": n_run,
                           "ms_per_frame_repeats": [round(v * 1e3, 4) for v in per_frame],
-                          "note": "rgbdfe_detect_describe_batch, run of %d frames; median of %d" % (n_run, REPEATS + 2)},
+                          "note": "rgbdfe_detect_describe_batch, run of %d frames into reused output arrays; median of %d"
+                                  % (n_run, REPEATS + 2)},
             "mean_keypoints": round(tot / n_base, 1),
             "roofline": {"bound": "hbm", "achieved": round(gbs_batch, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs_batch / HBM_PEAK_GBS, 6), "frac_single_calls": round(gbs / HBM_PEAK_GBS, 6),

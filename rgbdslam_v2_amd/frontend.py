@@ -386,11 +386,13 @@ class FrontEnd:
             fx, fy, cx, cy, depth_scaling, max_keypoints, kept.ctypes.data, xyz.ctypes.data, C.byref(k)))
         return kept[: k.value].copy(), xyz[: k.value].copy()
 
-    def detect_describe_batch(self, grays, masks, depths, fx, fy, cx, cy, depth_scaling=1.0, node_ids=None):
+    def detect_describe_batch(self, grays, masks, depths, fx, fy, cx, cy, depth_scaling=1.0, node_ids=None, copy=True):
         """A run of frames through the same detector state, in order (rgbdfe_detect_describe_batch): the results of
         calling detect_describe frame by frame, with frame k+1's upload overlapped with frame k's detection.
         Returns a list of (keypoints, descriptors, xyz1) per frame.  node_ids: frame f's features also become the resident
-        node node_ids[f] (rgbdfe_detect_describe_batch_nodes; a negative id: no node)."""
+        node node_ids[f] (rgbdfe_detect_describe_batch_nodes; a negative id: no node).  copy=False returns views of the
+        output arrays this object keeps and reuses for its next call (what an integration with its own buffers does;
+        sift_detect_batch has the same switch): valid until then."""
         n = len(grays)
         if n == 0:
             return []
@@ -429,6 +431,8 @@ class FrontEnd:
                 self._check(self._L.rgbdfe_detect_describe_batch(
                     self._ctx, n, C.cast(pg, C.c_void_p), C.cast(pm, C.c_void_p), C.cast(pd, C.c_void_p), rows, cols, fx, fy, cx, cy,
                     depth_scaling, cap, kp.ctypes.data, desc.ctypes.data, xyz.ctypes.data, cnt.ctypes.data))
+            if not copy:
+                return [(kp[f, : cnt[f]], desc[f, : cnt[f]], xyz[f, : cnt[f]]) for f in range(n)]
             return [(kp[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy(), xyz[f, : cnt[f]].copy()) for f in range(n)]
 
     def orb_detect(self, gray, mask, fast_threshold, capacity=60000):

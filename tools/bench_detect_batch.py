@@ -26,7 +26,7 @@ fe.detect_describe_batch(gray[:14], masks[:14], depth[:14], *K)     # warm-up: a
 ms, tot = [], 0
 for _ in range(reps):
     t0 = time.perf_counter()
-    out = fe.detect_describe_batch(gray, masks, depth, *K)
+    out = fe.detect_describe_batch(gray, masks, depth, *K, copy=os.environ.get("BENCH_COPY", "0") == "1")   # (bench.py: reused output arrays)
     ms.append((time.perf_counter() - t0) * 1e3 / n_frames)
     tot = sum(len(o[0]) for o in out)
 fe.close()
