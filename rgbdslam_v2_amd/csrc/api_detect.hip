@@ -648,7 +648,7 @@ int detect_describe_batch_super(rgbdfe_ctx* ctx, int32_t n_frames, const uint8_t
   static const int stage_threads = getenv("RGBDFE_STAGE_THREADS") ? std::max(1, atoi(getenv("RGBDFE_STAGE_THREADS"))) : 4;
   if (!ctx->stage_pool) ctx->stage_pool.reset(new TaskPool(stage_threads));
   // (the frames' CPU halves: a worker per frame up to RGBDFE_DETECT_WORKERS workers, the frames queue behind them)
-  static const int max_workers = getenv("RGBDFE_DETECT_WORKERS") ? std::max(1, atoi(getenv("RGBDFE_DETECT_WORKERS"))) : 12;   // (7 / 8 / 10 / 12 / 14 workers: 14.4 / 14.2 / 15.7 / 16.4 / 15.4 k frames/s in one call)
+  static const int max_workers = getenv("RGBDFE_DETECT_WORKERS") ? std::max(1, atoi(getenv("RGBDFE_DETECT_WORKERS"))) : 14;   // (a worker per frame of a 14-frame super-frame; 7 / 12 / 14 workers: 20.6 / 20.3 / 21.2 k frames/s, four alternating runs each)
   const int n_workers = std::min(B, max_workers);
   if (!ctx->detect_pool || ctx->detect_pool->size() != n_workers) ctx->detect_pool.reset(new TaskPool(n_workers));
   TaskPool& stage_pool = *ctx->stage_pool;
