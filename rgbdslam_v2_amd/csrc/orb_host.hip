@@ -808,7 +808,8 @@ int OrbWorkspace::super_pass_enqueue(int nf, int set, int slot, hipStream_t s, s
   slot_bound[slot] = bound;
   // the read-back: written by the measure kernel itself into the slot's page-locked buffer (RGBDFE_DETECT_HOSTWRITE=0: a copy
   // of the counts and `bound` records behind the kernels, the form of rounds 2-5)
-  static const bool host_write = !(getenv("RGBDFE_DETECT_HOSTWRITE") && atoi(getenv("RGBDFE_DETECT_HOSTWRITE")) == 0);
+  const char* const hw_env = getenv("RGBDFE_DETECT_HOSTWRITE");   // (read per pass: the tests switch it inside one process)
+  const bool host_write = !(hw_env && atoi(hw_env) == 0);
   uint8_t* const hpo = h_passout_slot[slot];
   launch_orb_emit(pool, d_cell_imgs, n_imgs, d_units + units_rows_off, units_rows_n, ctl, d_score, d_keep, d_row_off,
                   img_total, kps, bound, s, host_write ? reinterpret_cast<int*>(hpo) : nullptr,

@@ -348,8 +348,8 @@ void SiftExtractor::release() {
 // thread of the process has a stream capture open, e.g. another context recording its own launch chain:
 // tests/test_gpu_sift_threads.py)
 int SiftExtractor::prepare(int rows, int cols, int nf, hipStream_t s, std::string& err) {
-  static const bool host_write_env = !(getenv("RGBDFE_SIFT_HOSTWRITE") && atoi(getenv("RGBDFE_SIFT_HOSTWRITE")) == 0);
-  host_write = host_write_env;
+  const char* const hw_env = getenv("RGBDFE_SIFT_HOSTWRITE");   // (read per call: the tests switch it inside one process)
+  host_write = !(hw_env && atoi(hw_env) == 0);
   init_params();
   if (rows == H && cols == W && d_planes && nf <= frames_cap) return RGBDFE_OK;
   if (rows == H && cols == W && nf < frames_cap) nf = frames_cap;
