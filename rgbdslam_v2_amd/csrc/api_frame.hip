@@ -703,7 +703,7 @@ int rgbdfe_graph_stats(rgbdfe_ctx* ctx, int64_t* out, int32_t n_out) {
   return RGBDFE_OK;
 }
 
-int rgbdfe_abi_version(void) { return 5; }  // 5: rgbdfe_submit_pair_list_host / rgbdfe_wait_host (the refinement kernel's round-4 debug hooks are gone); 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_set_graph_capture, rgbdfe_pack_inliers, rgbdfe_match_pair_list_allgather_inliers
+int rgbdfe_abi_version(void) { return 6; }  // 6: rgbdfe_wait_host_into, rgbdfe_gather_exchanges, the inlier all-gather's stride is a capacity (>= the longest list); 5: rgbdfe_submit_pair_list_host / rgbdfe_wait_host (the refinement kernel's round-4 debug hooks are gone); 2: multi-device handles, rgbdfe_set_hamming_mode, RGBDFE_ERR_INTERNAL; 3: compact gather records, rgbdfe_sift_detect; 4: rgbdfe_graph_stats, rgbdfe_set_graph_capture, rgbdfe_pack_inliers, rgbdfe_match_pair_list_allgather_inliers
 
 
 }  // namespace impl

@@ -31,7 +31,7 @@ def test_result_pod_layout(frontend_lib):
     assert _lib.RESULT_DTYPE.itemsize == 1744
     assert _lib.RESULT_DTYPE.fields["inlier_mask"][1] == _lib.RgbdfeMatchResult.inlier_mask.offset
     assert _lib.RESULT_DTYPE.fields["info_scale"][1] == _lib.RgbdfeMatchResult.info_scale.offset
-    assert frontend_lib.rgbdfe_abi_version() == 5
+    assert frontend_lib.rgbdfe_abi_version() == 6
 
 
 def test_default_config_matches_reference_defaults(frontend_lib):
