@@ -1185,7 +1185,7 @@ def front_end_subrecord(device):
             # work, and their outputs the ones the oracle constants were made from
             fe.detector_configure(max_keypoints=n_kp)
             t0 = time.perf_counter()
-            feats = fe.detect_describe_batch(grays, masks, depths, *K, node_ids=ids)     # features to the host AND resident nodes
+            feats = fe.detect_describe_batch(grays, masks, depths, *K, node_ids=ids, copy=False)   # features to the host (reused output arrays) AND resident nodes
             t1 = time.perf_counter()
             res = fe.match_pair_list(pq, pt)
             t3 = time.perf_counter()
