@@ -46,7 +46,7 @@ for W in $WL; do
       rm -rf $ROOT/$W/trace; mkdir -p $ROOT/$W/trace; cp -r $REPO/gpurun_out/trace_serial/* $ROOT/$W/trace/ 2>/dev/null;;
     heavy) run_passes heavy "$B --depth-noise 0.002" fetch write sq sq2 mfma; python tools/summarize_prof.py $ROOT/heavy > $ROOT/heavy/summary.txt 2>&1;;
     sift)  run_passes sift "python $REPO/bench.py --config sift --frames 100 --steps 5 --warmup 1" fetch write mfma; python tools/summarize_prof.py $ROOT/sift > $ROOT/sift/summary.txt 2>&1;;
-    detect_640x480_orb1000)  run_passes $W "python $REPO/tools/detect_workload.py orb 640 480 1000 56 3" fetch write;;
+    detect_640x480_orb1000)  run_passes $W "python $REPO/tools/detect_workload.py orb 640 480 1000 112 2" fetch write;;
     detect_1280x960_orb4000) run_passes $W "python $REPO/tools/detect_workload.py orb 1280 960 4000 56 2" fetch write;;
     sift_extract_640x480)    run_passes $W "python $REPO/tools/detect_workload.py sift_batch 640 480 0 32 3" fetch write;;
   esac
