@@ -405,22 +405,20 @@ def main():
             w32 = out.view(torch.int32)
             h_chk[b].copy_(w32[inl["idx"][0]] + w32[inl["idx"][1]], non_blocking=True)
             ev_chk[b].record()
-            inl["pending"].append((b, nbytes, inl["cap"]))
+            inl["pending"].append((b, nbytes, inl["cap"], state["k"]))
         consumed[b] = torch.cuda.Event()
         consumed[b].record()
         state["gathers"] += 1
         state["gathers_all"] += 1
 
-    def check_gathers(block):
-        """The length checks of the gathers issued so far (those whose event has fired; all of them when `block`)."""
+    def check_gathers(upto):
+        """The length checks of the gathers of steps <= upto (None: all of them).  Which gathers are checked at which step is
+        a function of the step count alone -- never of whether an event happens to have fired -- so that every rank issues a
+        repeated gather at the same position of its sequence of collectives; the events of steps two behind have long fired."""
         redo = False   # behind a repeated gather every later one is repeated too: d_all ends up holding the LAST step's streams
-        while inl["pending"]:
-            b, nbytes, cap_used = inl["pending"][0]
-            if block or redo:
-                ev_chk[b].synchronize()
-            elif not ev_chk[b].query():
-                return
-            inl["pending"].pop(0)
+        while inl["pending"] and (upto is None or inl["pending"][0][3] <= upto or redo):
+            b, nbytes, cap_used, _ = inl["pending"].pop(0)
+            ev_chk[b].synchronize()
             totals = [int(v) for v in h_chk[b].tolist()]
             if max(totals) > cap_used or redo:   # (the same on every rank: all of them read the same gathered headers)
                 redo = True
@@ -434,7 +432,7 @@ def main():
             state["last"] = (nbytes, totals)
 
     def flush():
-        check_gathers(True)
+        check_gathers(None)
 
     def step():
         b = state["k"] % NBUF
@@ -451,7 +449,7 @@ def main():
                 # headers + (query row, train row) of every inlier match: inlier_scan_kernel + inlier_list_kernel on torch's
                 # stream, and behind them -- stream ordered, no host read -- the step's one collective (gather_inliers)
                 fe.pack_inliers(d_local[b].data_ptr(), n_local, n_pad, d_send[b].data_ptr(), d_tot[b].data_ptr(), stream)
-                check_gathers(False)    # earlier steps' length checks (host side: reads of pinned words whose events have fired)
+                check_gathers(state["k"] - 2)   # the length checks of the steps two and more behind this one (state["k"]: this step, from 1)
                 gather_inliers(b)
                 return
             if compact:  # header + inlier mask of every record (144 of 1744 B): compact_pack_kernel on torch's stream
