@@ -357,9 +357,9 @@ def main():
     # sized BEFORE the ranks have counted their lists: n_pad headers + `cap` list entries per rank, cap = the longest list of
     # the first (warm-up) gather plus a quarter -- the only gather that exchanges the lengths first.  Every stream carries
     # its own length (its last header: first_inlier + n_inl), so what every rank got is checked on the device from the
-    # gathered headers; the check's result reaches the host behind the NEXT step's submission (an event that has long
-    # fired by then), and a list that has outgrown `cap` -- every rank sees the same gathered headers and decides alike --
-    # repeats that step's gather at the exact size from the ring buffer that still holds its stream.
+    # gathered headers; the check's result is read by the host two steps later (an event that has long fired by then), and
+    # a list that has outgrown `cap` -- every rank sees the same gathered headers and decides alike, at the same step --
+    # repeats that step's gather at a size that fits from the ring buffer that still holds its stream.
     hdr_dt = INLIER_HEADER_DTYPE
     off_first, off_ninl = hdr_dt.fields["first_inlier"][1], hdr_dt.fields["n_inl"][1]
     # (RGBDFE_BENCH_INLIER_CAP: tests only -- a capacity to start from instead of the learned one, e.g. one that is too small)
